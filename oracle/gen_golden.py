@@ -1,0 +1,108 @@
+#!/usr/bin/env python
+"""Generate tests/golden/*.pt by running the REFERENCE's own hot-path files.
+
+TEST INFRASTRUCTURE (see oracle/gps_oracle.py header).  Run in the build container only:
+it needs /root/reference, which does not exist on the GPU box.
+
+    python oracle/gen_golden.py            # rewrites tests/golden/*.pt
+
+What executes: ``/root/reference/graphgps/layer/{gps_layer,gatedgcn_layer,gine_conv_layer,
+performer_layer}.py`` imported unmodified from where they lie, hosted on the stand-in modules
+in ``oracle/ref_stubs`` for the third-party packages that are absent here.  So the in-tree
+arithmetic of the fixtures is the reference's; PyG / torch_scatter semantics are the stubs'
+restatement (see oracle/ref_stubs/README.md).
+
+Each fixture holds: ctor kwargs, state_dict (before the step), inputs, loss weights, the
+train-mode outputs, input/parameter gradients, the state_dict after the step (BN running
+stats) and an eval-mode forward taken afterwards.
+"""
+import os
+import sys
+import types
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.environ.get("GPS_REFERENCE_ROOT", "/root/reference")
+sys.path.insert(0, ROOT)
+
+import graphgps_amd.graphgym.register  # noqa: E402,F401  (before the stubs go on sys.path)
+from graphgps_amd.graphgym.config import cfg, set_cfg  # noqa: E402
+from graphgps_amd.synthetic import make_structure  # noqa: E402
+
+sys.path.insert(0, os.path.join(ROOT, "oracle", "ref_stubs"))
+_pkg = types.ModuleType("graphgps")
+_pkg.__path__ = [os.path.join(REF, "graphgps")]   # skip graphgps/__init__.py (imports ogb, wandb, ...)
+sys.modules["graphgps"] = _pkg
+set_cfg(cfg)
+from graphgps.layer.gps_layer import GPSLayer as RefGPSLayer  # noqa: E402
+from torch_geometric.data import Batch as StubBatch  # noqa: E402
+
+CASES = {
+    # name: (ctor kwargs, profile, num_graphs, seed)
+    "gatedgcn_transformer_d32h4": (dict(dim_h=32, local_gnn_type="CustomGatedGCN",
+                                        global_model_type="Transformer", num_heads=4), "P14", 6, 11),
+    "gatedgcn_transformer_d48h2": (dict(dim_h=48, local_gnn_type="CustomGatedGCN",
+                                        global_model_type="Transformer", num_heads=2), "P30", 5, 12),
+    "gine_transformer_d32h2": (dict(dim_h=32, local_gnn_type="GINE",
+                                    global_model_type="Transformer", num_heads=2), "ZINC", 4, 13),
+    "gatedgcn_performer_d32h2": (dict(dim_h=32, local_gnn_type="CustomGatedGCN",
+                                      global_model_type="Performer", num_heads=2), "P30", 4, 14),
+    "gatedgcn_only_d16": (dict(dim_h=16, local_gnn_type="CustomGatedGCN",
+                               global_model_type="None", num_heads=1), "P14", 5, 15),
+}
+
+
+def run_case(name, kw, profile, num_graphs, seed):
+    torch.manual_seed(seed)
+    layer = RefGPSLayer(**kw, act="relu", dropout=0.0, attn_dropout=0.0,
+                        layer_norm=False, batch_norm=True)
+    layer.train()
+    # non-trivial BN affine parameters so that their gradients are exercised
+    with torch.no_grad():
+        for mod in layer.modules():
+            if isinstance(mod, torch.nn.BatchNorm1d):
+                mod.weight.uniform_(0.5, 1.5)
+                mod.bias.uniform_(-0.3, 0.3)
+    sd0 = {k: v.clone() for k, v in layer.state_dict().items()}
+    sizes, edge_index, bvec, ptr, gen, _ = make_structure(profile, num_graphs, seed)
+    N, E, d = int(ptr[-1]), edge_index.shape[1], kw["dim_h"]
+    x = torch.randn(N, d, generator=gen, requires_grad=True)
+    e = torch.randn(E, d, generator=gen, requires_grad=True)
+    wx = torch.randn(N, d, generator=gen)
+    we = torch.randn(E, d, generator=gen)
+    batch = StubBatch(x=x, edge_index=edge_index, edge_attr=e, batch=bvec)
+    out = layer(batch)
+    loss = (out.x * wx).sum() + (out.edge_attr * we).sum()
+    loss.backward()
+    fix = dict(
+        name=name, ctor=dict(kw, act="relu", dropout=0.0, attn_dropout=0.0,
+                             layer_norm=False, batch_norm=True),
+        state_dict=sd0, x=x.detach().clone(), edge_attr=e.detach().clone(),
+        edge_index=edge_index, batch=bvec, ptr=ptr, wx=wx, we=we,
+        out_x=out.x.detach().clone(), out_edge_attr=out.edge_attr.detach().clone(),
+        grad_x=x.grad.clone(), grad_edge_attr=e.grad.clone(),
+        param_grads={k: p.grad.clone() for k, p in layer.named_parameters() if p.grad is not None},
+        state_dict_after=({k: v.clone() for k, v in layer.state_dict().items()}),
+    )
+    layer.eval()
+    with torch.no_grad():
+        ob = layer(StubBatch(x=x.detach(), edge_index=edge_index, edge_attr=e.detach(), batch=bvec))
+    fix["eval_out_x"] = ob.x.clone()
+    fix["eval_out_edge_attr"] = ob.edge_attr.clone()
+    return fix
+
+
+def main():
+    outdir = os.path.join(ROOT, "tests", "golden")
+    os.makedirs(outdir, exist_ok=True)
+    for name, (kw, profile, nb, seed) in CASES.items():
+        fix = run_case(name, kw, profile, nb, seed)
+        path = os.path.join(outdir, f"{name}.pt")
+        torch.save(fix, path)
+        print(f"{name}: N={fix['x'].shape[0]} E={fix['edge_index'].shape[1]} "
+              f"|out_x|max={fix['out_x'].abs().max():.4f} -> {os.path.getsize(path)/1024:.0f} KiB")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,20 @@
+"""Stub of torch_geometric.nn: ``Linear`` (== torch.nn.Linear for fixed in_channels: weight
+[out,in], bias, kaiming-uniform(a=sqrt(5)) init) and the conv classes."""
+import torch
+from . import conv  # noqa: F401
+from .conv import (MessagePassing, GINEConv, GCNConv, GINConv, GENConv, GATConv,  # noqa: F401
+                   PNAConv)
+
+
+class Linear(torch.nn.Linear):
+    def __init__(self, in_channels, out_channels, bias=True, **kwargs):
+        super().__init__(in_channels, out_channels, bias=bias)
+
+
+class _Norm:
+    class LayerNorm(torch.nn.Module):
+        def __init__(self, *a, **k):
+            raise NotImplementedError
+
+
+norm = _Norm
