@@ -1,0 +1,280 @@
+#!/usr/bin/env python
+"""bench.py -- PCQM4M GPS-medium training step on N MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A "step" is one pass of the hot path over one batch of synthetic PCQM4M-shaped input
+(profile P30, 256 graphs per GPU, inputs resident in HBM): per-batch graph index build ->
+GPSModel forward (encoders, 10 x GPSLayer on the HIP kernels, head) -> L1 loss -> backward ->
+gradient all-reduce (N > 1) -> grad-clip + AdamW step, i.e. the whole of the reference's
+train_epoch body (graphgps/train/custom_train.py:22-39) minus logging.  Dropout is ON
+(0.1 / 0.1 as in configs/GPS/pcqm4m-GPSmedium+RWSE.yaml).  Weak scaling: per-GPU work is fixed.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  roofline      the GatedGCN gather-gate-segment-reduce forward kernel (HBM-bound): algorithmic
+                bytes (8*E*d + 20*N*d + CSR index bytes) / mean launch
+                duration measured with HIP events on the launching stream
+  kernels       the same measurement for every hand-written kernel (HBM GB/s or MFMA TFLOP/s)
+  cpu_baseline  the CPU oracle (pure-torch restatement of the reference path) timed on the
+                host cores of the same box, same batch, same step definition (rank 0, N = 1)
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
+MFMA_F32_PEAK_TF = 157.3     # v_mfma_f32_16x16x4_f32 dense peak
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=30)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--graphs-per-gpu", type=int, default=256)
+    ap.add_argument("--profile", default="P30", help="synthetic size profile (P30 | P14)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-roofline", action="store_true")
+    ap.add_argument("--cpu-steps", type=int, default=2)
+    return ap.parse_args()
+
+
+def make_step(model, opt, reducer, batch_dev, compute_loss, clip_value):
+    params = [p for p in model.parameters() if p.requires_grad]
+
+    def step():
+        b = batch_dev.clone()            # fresh batch object -> the graph index is rebuilt
+        reducer.zero_grad()
+        pred, true = model(b)
+        loss, _ = compute_loss(pred, true)
+        loss.backward()
+        reducer.finish()
+        torch.nn.utils.clip_grad_norm_(params, clip_value, foreach=True)
+        opt.step()
+        return loss
+    return step
+
+
+def time_kernel(fn, iters=50, warm=5):
+    """Mean duration (ms) of ``fn`` (enqueues on torch's current stream, the stream the C-ABI
+    launches on) measured with HIP events."""
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    t0.record()
+    for _ in range(iters):
+        fn()
+    t1.record()
+    torch.cuda.synchronize()
+    return t0.elapsed_time(t1) / iters
+
+
+def kernel_rooflines(dev, profile, nb, d=384, H=16):
+    """Layer-shaped micro-measurements of each hand-written kernel at the benchmark's sizes."""
+    from graphgps_amd import lib as L_
+    from graphgps_amd.lib import check, current_stream, ptr
+    from graphgps_amd.ops import build_graph_index
+    from graphgps_amd.synthetic import layer_batch
+    L = L_.load()
+    b = layer_batch(profile, nb, d, seed=1234).to(dev)
+    N, E = b.x.shape[0], b.edge_index.shape[1]
+    gi = build_graph_index(b.edge_index, N, nb, ptr_vec=b.ptr)
+    st = current_stream(dev)
+    f = lambda *s: torch.randn(*s, device=dev)
+    proj, ce = f(N, 4 * d), f(E, d)
+    xt, eh, ag, dn = f(N, d), f(E, d), f(N, d), f(N, d)
+    gx, ge, gproj, gce = f(N, d), f(E, d), f(N, 4 * d), f(E, d)
+    P, G, fs = proj.data_ptr(), gproj.data_ptr(), d * 4
+
+    def gg_fwd():
+        check(L.gps_gatedgcn_fwd(P, P + fs, P + 2 * fs, P + 3 * fs, 4 * d, ptr(ce), ptr(gi.rowptr_dst),
+                                 ptr(gi.src_by_dst), ptr(gi.eid_by_dst), N, E, d, ptr(xt), ptr(eh),
+                                 ptr(ag), ptr(dn), st))
+
+    def gg_bwd():
+        check(L.gps_gatedgcn_bwd(ptr(gx), ptr(ge), ptr(eh), P + fs, 4 * d, ptr(ag), ptr(dn),
+                                 ptr(gi.rowptr_dst), ptr(gi.src_by_dst), ptr(gi.eid_by_dst),
+                                 ptr(gi.rowptr_src), ptr(gi.dst_by_src), ptr(gi.eid_by_src), N, E, d,
+                                 ptr(gce), G, G + fs, G + 2 * fs, G + 3 * fs, 4 * d, st))
+
+    dh = d // H
+    qkv, out, lse = f(N, 3 * d), f(N, d), f(H, N)
+    dout, delta, dqkv = f(N, d), f(H, N), f(N, 3 * d)
+    scale = dh ** -0.5
+
+    def at_fwd(p=0.1):
+        check(L.gps_seg_attn_fwd(ptr(qkv), 3 * d, ptr(gi.ptr), ptr(gi.tile_graph), ptr(gi.tile_row0),
+                                 gi.max_tiles, N, H, dh, scale, p, 1234, ptr(out), ptr(lse), st))
+
+    def at_bwd(p=0.1):
+        check(L.gps_seg_attn_bwd(ptr(dout), ptr(qkv), 3 * d, ptr(out), ptr(lse), ptr(gi.ptr),
+                                 ptr(gi.tile_graph), ptr(gi.tile_row0), gi.max_tiles, N, H, dh, scale,
+                                 p, 1234, ptr(delta), ptr(dqkv), 3 * d, st))
+
+    gg_fwd(); at_fwd()                     # produce valid saved tensors for the backward kernels
+    sizes = (b.ptr[1:] - b.ptr[:-1]).double()
+    s2 = float((sizes * sizes).sum())
+    idx = 4 * (N + 1) + 8 * E
+    res = {}
+    t = time_kernel(gg_fwd)
+    bytes_f = 8 * E * d + 20 * N * d + idx
+    res["gatedgcn_fwd"] = dict(bound="hbm", ms=t, bytes=bytes_f, achieved=bytes_f / t / 1e6,
+                               peak=HBM_PEAK_GBS, unit="GB/s")
+    t = time_kernel(gg_bwd)
+    bytes_b = 12 * E * d + 28 * N * d + 2 * idx
+    res["gatedgcn_bwd"] = dict(bound="hbm", ms=t, bytes=bytes_b, achieved=bytes_b / t / 1e6,
+                               peak=HBM_PEAK_GBS, unit="GB/s", launches=2)
+    t = time_kernel(at_fwd)
+    fl = 4 * s2 * d
+    res["seg_attn_fwd"] = dict(bound="mfma", ms=t, flops=fl, achieved=fl / t / 1e9,
+                               peak=MFMA_F32_PEAK_TF, unit="TFLOP/s")
+    t = time_kernel(at_bwd)
+    flb = 8 * s2 * d
+    res["seg_attn_bwd"] = dict(bound="mfma", ms=t, flops=flb, achieved=flb / t / 1e9,
+                               peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", launches=3)
+    for v in res.values():
+        v["frac"] = v["achieved"] / v["peak"]
+    return res, dict(N=N, E=E, d=d, H=H, sum_n2=s2)
+
+
+def cpu_baseline(model, batch_cpu, compute_loss, clip_value, steps):
+    """CPU oracle (kind='port'): same batch, same step definition, all host cores."""
+    from oracle.gps_oracle import to_oracle_model
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    oracle = to_oracle_model(model).train()
+    opt = torch.optim.AdamW(oracle.parameters(), lr=2e-4, weight_decay=0.0)
+    params = list(oracle.parameters())
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        pred, true = oracle(batch_cpu.clone())
+        loss, _ = compute_loss(pred, true)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(params, clip_value)
+        opt.step()
+
+    step()                                   # warm-up (allocator, thread pool)
+    t0 = time.perf_counter()
+    done = 0
+    while done < steps and (done == 0 or time.perf_counter() - t0 < 30.0):
+        step()
+        done += 1
+    dt = (time.perf_counter() - t0) / done
+    nb = int(batch_cpu.num_graphs)
+    return dict(value=nb / dt, unit="graphs/s", cores=cores, kind="port", ms_per_step=dt * 1e3,
+                sample=f"{done} full training step(s) of the same {nb}-graph batch after 1 warm-up, "
+                       f"pure-torch CPU oracle of the reference path, torch threads={cores}")
+
+
+def main():
+    args = parse_args()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X: the GPS hot path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    import graphgps_amd as g
+    from graphgps_amd.dp import GradBucketReducer
+    from graphgps_amd.loss.losses import compute_loss
+    from graphgps_amd.synthetic import model_batch
+
+    torch.manual_seed(0)                       # identical initial weights on every rank
+    model = g.create_model(os.path.join(g.CONFIG_DIR, "pcqm4m_gpsmedium_rwse.yaml"), None, 9, 1)
+    cfg = g.cfg
+    model.train()
+    nb = args.graphs_per_gpu
+    batch_cpu = model_batch("pcqm4m", nb, seed=1234 + rank, profile=args.profile)
+    cpu_ref_model = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        import copy
+        cpu_ref_model = copy.deepcopy(model)
+    model.to(dev)
+    batch_dev = batch_cpu.clone().to(dev)
+    reducer = GradBucketReducer(model)
+    opt = torch.optim.AdamW(model.parameters(), lr=cfg.optim.base_lr,
+                            weight_decay=cfg.optim.weight_decay, fused=True)
+    step = make_step(model, opt, reducer, batch_dev, compute_loss, cfg.optim.clip_grad_norm_value)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    torch.manual_seed(1000 + rank)             # dropout streams differ per rank
+    for _ in range(args.warmup):
+        loss = step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms = elapsed / args.steps * 1e3
+    final_loss = float(loss.item())
+
+    if rank == 0:
+        N, E = batch_dev.x.shape[0], batch_dev.edge_index.shape[1]
+        out = {
+            "metric": "graphs/sec, PCQM4M GPS-medium training step (fwd+bwd+optimizer)",
+            "value": world * nb / (ms / 1e3), "unit": "graphs/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": f"pcqm4m-GPSmedium+RWSE (CustomGatedGCN+Transformer, 10L x 384d, "
+                                   f"16 heads, dropout 0.1/0.1), synthetic profile {args.profile}, "
+                                   f"{nb} graphs/GPU ({N} nodes, {E} directed edges on rank 0)",
+                       "global_batch": world * nb, "parallelism": f"dp{world}",
+                       "timed_region": "graph-index build + forward + L1 loss + backward + "
+                                       "grad all-reduce + clip + AdamW"},
+            "final_loss": final_loss,
+            "grad_allreduce_bytes": reducer.num_bytes if world > 1 else 0,
+        }
+        if not args.no_kernel_roofline:
+            kr, shape = kernel_rooflines(dev, args.profile, nb)
+            k = kr["gatedgcn_fwd"]
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "pmc_gatedgcn_fwd.json")
+            if os.path.exists(pmc):           # HBM bytes per launch from a rocprofv3 --pmc pass
+                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+            out["roofline"] = {"kernel": "k_gatedgcn_fwd", "bound": "hbm", "achieved": k["achieved"],
+                               "peak": k["peak"], "unit": "GB/s", "frac": k["frac"],
+                               "traffic": traffic, "algorithmic_bytes": k["bytes"],
+                               "launch_ms": k["ms"]}
+            out["kernels"] = kr
+            out["kernel_shape"] = shape
+        if cpu_ref_model is not None:
+            out["cpu_baseline"] = cpu_baseline(cpu_ref_model, batch_cpu, compute_loss,
+                                               cfg.optim.clip_grad_norm_value, args.cpu_steps)
+            out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

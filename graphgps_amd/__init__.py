@@ -1,0 +1,32 @@
+"""graphgps_amd -- the GPSLayer hot path of rampasek/GraphGPS, built MI355X-first.
+
+Importing the package registers the HIP-backed implementations under the reference's own
+GraphGym plugin names (``network_dict['GPSModel']``, ``layer_dict['gatedgcnconv']``,
+``layer_dict['gineconv']``, heads, encoders, losses).  Scope and boundary: DESIGN.md.
+"""
+__version__ = "0.1.0"
+
+from .graphgym import register  # noqa: F401
+from .graphgym.config import cfg, load_cfg, set_cfg  # noqa: F401
+from .data import Batch  # noqa: F401
+from .layer.gps_layer import GPSLayer  # noqa: F401
+from .layer.gatedgcn_layer import GatedGCNLayer, GatedGCNGraphGymLayer  # noqa: F401
+from .layer.gine_conv_layer import GINEConv, GINEConvLayer, GINEConvGraphGymLayer  # noqa: F401
+from .network.gps_model import GPSModel  # noqa: F401
+from .loss import losses as _losses  # noqa: F401
+
+import os as _os
+
+CONFIG_DIR = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "configs")
+
+
+def create_model(cfg_file=None, opts=None, dim_in=None, dim_out=None):
+    """``set_cfg`` + ``load_cfg`` + ``network_dict[cfg.model.type](dim_in, dim_out)``: the
+    GraphGym ``create_model`` path (reference main.py:118-121,144) without the dataset."""
+    set_cfg(cfg)
+    load_cfg(cfg, cfg_file, opts)
+    if dim_in is not None:
+        cfg.share.dim_in = dim_in
+    if dim_out is not None:
+        cfg.share.dim_out = dim_out
+    return register.network_dict[cfg.model.type](cfg.share.dim_in, cfg.share.dim_out)

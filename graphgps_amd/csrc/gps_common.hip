@@ -1,0 +1,29 @@
+// Error plumbing of the C ABI (include/gps_hip.h).
+#include "gps_common.hpp"
+
+namespace gps {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+int launch_status(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) {
+    set_error("%s: %s", what, hipGetErrorString(e));
+    return GPS_ELAUNCH;
+  }
+  return GPS_OK;
+}
+
+}  // namespace gps
+
+extern "C" {
+int gps_abi_version(void) { return 1; }
+const char* gps_last_error(void) { return gps::g_err; }
+}

@@ -1,0 +1,32 @@
+// Shared host/device helpers for libgps_hip.so (gfx950 only; no multi-backend paths).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+
+#include "gps_hip.h"
+
+namespace gps {
+
+void set_error(const char* fmt, ...);
+int launch_status(const char* what);  // hipGetLastError -> GPS_OK / GPS_ELAUNCH (+ message)
+
+static inline hipStream_t as_stream(gps_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+static inline unsigned grid_for(int64_t work, int block) {
+  return static_cast<unsigned>((work + block - 1) / block);
+}
+
+}  // namespace gps
+
+#define GPS_REQUIRE(cond, ...)        \
+  do {                                \
+    if (!(cond)) {                    \
+      gps::set_error(__VA_ARGS__);    \
+      return GPS_EINVAL;              \
+    }                                 \
+  } while (0)
+
+constexpr int kWave = 64;  // CDNA wavefront

@@ -1,0 +1,226 @@
+"""Input encoders used by the measured configs (run once per step, before the layers; plain
+PyTorch embedding lookups -- SURVEY.md section 2a marks them out of the HIP scope).
+
+Mirrors, with identical parameter names:
+  * ``Atom`` / ``Bond``: GraphGym ``AtomEncoder`` / ``BondEncoder`` (PyG 2.2
+    graphgym/models/encoder.py, third-party): one xavier-initialised ``nn.Embedding`` per OGB
+    feature column (``atom_embedding_list`` / ``bond_embedding_list``), summed.
+  * ``TypeDictNode`` / ``TypeDictEdge``: /root/reference/graphgps/encoder/type_dict_encoder.py:81-116
+  * ``ASTNode`` / ``ASTEdge``: graphgps/encoder/ast_encoder.py:34-85
+  * ``RWSE`` (+ ``HKdiagSE``, ``ElstaticSE``): graphgps/encoder/kernel_pos_encoder.py:8-110
+  * ``X+RWSE`` compositions: graphgps/encoder/composed_encoders.py:19-58
+  * ``BatchNorm1dNode``: GraphGym layer used for ``dataset.{node,edge}_encoder_bn``
+    (graphgps/network/gps_model.py:27-46) -- note the reference applies it to ``batch.x`` for the
+    edge case as well; kept.
+"""
+import torch
+import torch.nn as nn
+
+from ..graphgym.config import cfg
+from ..graphgym.register import (node_encoder_dict, register_edge_encoder,
+                                 register_node_encoder)
+from ..synthetic import ATOM_FEATURE_DIMS, BOND_FEATURE_DIMS
+
+
+class _OGBFeatureEncoder(nn.Module):
+    _attr = None
+    _dims = None
+
+    def __init__(self, emb_dim, *args, **kwargs):
+        super().__init__()
+        embs = nn.ModuleList()
+        for dim in self._dims:
+            emb = nn.Embedding(dim, emb_dim)
+            nn.init.xavier_uniform_(emb.weight.data)
+            embs.append(emb)
+        setattr(self, self._attr, embs)
+
+    def _encode(self, feats):
+        embs = getattr(self, self._attr)
+        out = 0
+        for i in range(feats.shape[1]):
+            out = out + embs[i](feats[:, i])
+        return out
+
+
+@register_node_encoder('Atom', overwrite=True)
+class AtomEncoder(_OGBFeatureEncoder):
+    _attr, _dims = 'atom_embedding_list', ATOM_FEATURE_DIMS
+
+    def forward(self, batch):
+        batch.x = self._encode(batch.x)
+        return batch
+
+
+@register_edge_encoder('Bond', overwrite=True)
+class BondEncoder(_OGBFeatureEncoder):
+    _attr, _dims = 'bond_embedding_list', BOND_FEATURE_DIMS
+
+    def forward(self, batch):
+        batch.edge_attr = self._encode(batch.edge_attr)
+        return batch
+
+
+@register_node_encoder('TypeDictNode', overwrite=True)
+class TypeDictNodeEncoder(nn.Module):
+    def __init__(self, emb_dim):
+        super().__init__()
+        num_types = cfg.dataset.node_encoder_num_types
+        if num_types < 1:
+            raise ValueError(f"Invalid 'node_encoder_num_types': {num_types}")
+        self.encoder = nn.Embedding(num_embeddings=num_types, embedding_dim=emb_dim)
+
+    def forward(self, batch):
+        batch.x = self.encoder(batch.x[:, 0])  # only the first column
+        return batch
+
+
+@register_edge_encoder('TypeDictEdge', overwrite=True)
+class TypeDictEdgeEncoder(nn.Module):
+    def __init__(self, emb_dim):
+        super().__init__()
+        num_types = cfg.dataset.edge_encoder_num_types
+        if num_types < 1:
+            raise ValueError(f"Invalid 'edge_encoder_num_types': {num_types}")
+        self.encoder = nn.Embedding(num_embeddings=num_types, embedding_dim=emb_dim)
+
+    def forward(self, batch):
+        batch.edge_attr = self.encoder(batch.edge_attr)
+        return batch
+
+
+@register_node_encoder('ASTNode', overwrite=True)
+class ASTNodeEncoder(nn.Module):
+    def __init__(self, emb_dim):
+        super().__init__()
+        self.max_depth = 20
+        self.type_encoder = nn.Embedding(98, emb_dim)
+        self.attribute_encoder = nn.Embedding(10030, emb_dim)
+        self.depth_encoder = nn.Embedding(self.max_depth + 1, emb_dim)
+
+    def forward(self, batch):
+        x = batch.x
+        depth = batch.node_depth.view(-1).clamp(max=self.max_depth)
+        batch.x = (self.type_encoder(x[:, 0]) + self.attribute_encoder(x[:, 1])
+                   + self.depth_encoder(depth))
+        return batch
+
+
+@register_edge_encoder('ASTEdge', overwrite=True)
+class ASTEdgeEncoder(nn.Module):
+    def __init__(self, emb_dim):
+        super().__init__()
+        self.embedding_type = nn.Embedding(2, emb_dim)
+        self.embedding_direction = nn.Embedding(2, emb_dim)
+
+    def forward(self, batch):
+        batch.edge_attr = (self.embedding_type(batch.edge_attr[:, 0])
+                           + self.embedding_direction(batch.edge_attr[:, 1]))
+        return batch
+
+
+class KernelPENodeEncoder(nn.Module):
+    """Kernel-statistics PE encoder (RWSE etc.): raw-norm -> Linear/MLP -> concat to x."""
+    kernel_type = None
+
+    def __init__(self, dim_emb, expand_x=True):
+        super().__init__()
+        if self.kernel_type is None:
+            raise ValueError(f"{self.__class__.__name__} has to be preconfigured by setting "
+                             f"'kernel_type' class variable before calling the constructor.")
+        dim_in = cfg.share.dim_in
+        pecfg = getattr(cfg, f"posenc_{self.kernel_type}")
+        dim_pe = pecfg.dim_pe
+        num_rw_steps = len(pecfg.kernel.times)
+        model_type = pecfg.model.lower()
+        n_layers = pecfg.layers
+        norm_type = pecfg.raw_norm_type.lower()
+        self.pass_as_var = pecfg.pass_as_var
+        if dim_emb - dim_pe < 0:
+            raise ValueError(f"PE dim size {dim_pe} is too large for desired embedding size of "
+                             f"{dim_emb}.")
+        if expand_x and dim_emb - dim_pe > 0:
+            self.linear_x = nn.Linear(dim_in, dim_emb - dim_pe)
+        self.expand_x = expand_x and dim_emb - dim_pe > 0
+        self.raw_norm = nn.BatchNorm1d(num_rw_steps) if norm_type == 'batchnorm' else None
+        if model_type == 'mlp':
+            layers = []
+            if n_layers == 1:
+                layers += [nn.Linear(num_rw_steps, dim_pe), nn.ReLU()]
+            else:
+                layers += [nn.Linear(num_rw_steps, 2 * dim_pe), nn.ReLU()]
+                for _ in range(n_layers - 2):
+                    layers += [nn.Linear(2 * dim_pe, 2 * dim_pe), nn.ReLU()]
+                layers += [nn.Linear(2 * dim_pe, dim_pe), nn.ReLU()]
+            self.pe_encoder = nn.Sequential(*layers)
+        elif model_type == 'linear':
+            self.pe_encoder = nn.Linear(num_rw_steps, dim_pe)
+        else:
+            raise ValueError(f"{self.__class__.__name__}: Does not support '{model_type}' "
+                             f"encoder model.")
+
+    def forward(self, batch):
+        pestat_var = f"pestat_{self.kernel_type}"
+        if not hasattr(batch, pestat_var):
+            raise ValueError(f"Precomputed '{pestat_var}' variable is required for "
+                             f"{self.__class__.__name__}; set config "
+                             f"'posenc_{self.kernel_type}.enable' to True, and also set "
+                             f"'posenc.kernel.times' values")
+        pos_enc = getattr(batch, pestat_var)
+        if self.raw_norm:
+            pos_enc = self.raw_norm(pos_enc)
+        pos_enc = self.pe_encoder(pos_enc)
+        h = self.linear_x(batch.x) if self.expand_x else batch.x
+        batch.x = torch.cat((h, pos_enc), 1)
+        if self.pass_as_var:
+            setattr(batch, f'pe_{self.kernel_type}', pos_enc)
+        return batch
+
+
+def _kernel_encoder(name):
+    cls = type(f"{name}NodeEncoder", (KernelPENodeEncoder,), {"kernel_type": name})
+    register_node_encoder(name, cls, overwrite=True)
+    return cls
+
+
+RWSENodeEncoder = _kernel_encoder('RWSE')
+HKdiagSENodeEncoder = _kernel_encoder('HKdiagSE')
+ElstaticSENodeEncoder = _kernel_encoder('ElstaticSE')
+
+
+def concat_node_encoders(enc1_cls, enc2_cls, enc2_name):
+    """Dataset encoder to (dim_emb - dim_pe) then PE encoder appending dim_pe
+    (composed_encoders.py:36-58, non-EquivStable branch)."""
+
+    class Concat2NodeEncoder(nn.Module):
+        def __init__(self, dim_emb):
+            super().__init__()
+            enc2_dim_pe = getattr(cfg, f"posenc_{enc2_name}").dim_pe
+            self.encoder1 = enc1_cls(dim_emb - enc2_dim_pe)
+            self.encoder2 = enc2_cls(dim_emb, expand_x=False)
+
+        def forward(self, batch):
+            return self.encoder2(self.encoder1(batch))
+
+    Concat2NodeEncoder.__name__ = f"{enc1_cls.__name__}+{enc2_cls.__name__}"
+    return Concat2NodeEncoder
+
+
+for _ds_name, _ds_cls in (('Atom', AtomEncoder), ('ASTNode', ASTNodeEncoder),
+                          ('TypeDictNode', TypeDictNodeEncoder)):
+    for _pe_name, _pe_cls in (('RWSE', RWSENodeEncoder), ('HKdiagSE', HKdiagSENodeEncoder),
+                              ('ElstaticSE', ElstaticSENodeEncoder)):
+        register_node_encoder(f"{_ds_name}+{_pe_name}",
+                              concat_node_encoders(_ds_cls, _pe_cls, _pe_name), overwrite=True)
+
+
+class BatchNorm1dNode(nn.Module):
+    """GraphGym ``BatchNorm1dNode``: BN over ``batch.x`` (parameter prefix ``bn``)."""
+
+    def __init__(self, dim_in, eps=1e-5, momentum=0.1):
+        super().__init__()
+        self.bn = nn.BatchNorm1d(dim_in, eps=eps, momentum=momentum)
+
+    def forward(self, batch):
+        batch.x = self.bn(batch.x)
+        return batch

@@ -1,0 +1,188 @@
+"""GPSLayer: local MPNN || global attention -> sum -> FFN, on MI355X HIP kernels.
+
+Drop-in for ``/root/reference/graphgps/layer/gps_layer.py:15-264``: identical constructor
+signature (:20-24), ``forward(batch) -> batch`` contract (reads ``batch.x``, ``edge_index``,
+``edge_attr``, ``batch``/``ptr``; assigns ``batch.x`` and, for GatedGCN, ``batch.edge_attr``),
+identical parameter/buffer names so ``state_dict``s interchange with reference checkpoints
+(SURVEY.md section 8b).
+
+What runs where:
+  * sparse local half  -> csrc/gatedgcn.hip / csrc/gine.hip (CSR segment reductions)
+  * global half        -> csrc/seg_attention.hip (varlen MFMA attention off ``ptr``; the
+                          reference's to_dense_batch padding, key-padding mask and [mask]
+                          un-pad -- 3 host syncs per layer -- do not exist here)
+                          or csrc/favor.hip (Performer FAVOR+)
+  * dense projections / FFN / BatchNorm -> rocBLAS + MIOpen through torch
+There is no CPU fallback: on a CPU tensor the ops raise.
+"""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..graphgym import register
+from ..graphgym import act as _act  # noqa: F401
+from ..ops import graph_index_of, segment_attention
+from .gatedgcn_layer import GatedGCNLayer
+from .gine_conv_layer import GINEConv
+
+_NEEDS_PYG = {"GCN", "GIN", "GENConv", "GAT", "PNA"}
+
+
+class GPSLayer(nn.Module):
+    """Local MPNN + full graph attention x-former layer."""
+
+    def __init__(self, dim_h,
+                 local_gnn_type, global_model_type, num_heads, act='relu',
+                 pna_degrees=None, equivstable_pe=False, dropout=0.0,
+                 attn_dropout=0.0, layer_norm=False, batch_norm=True,
+                 bigbird_cfg=None, log_attn_weights=False):
+        super().__init__()
+        self.ctor_kwargs = dict(dim_h=dim_h, local_gnn_type=local_gnn_type,
+                                global_model_type=global_model_type, num_heads=num_heads,
+                                act=act, dropout=dropout, attn_dropout=attn_dropout,
+                                layer_norm=layer_norm, batch_norm=batch_norm)
+        self.dim_h = dim_h
+        self.num_heads = num_heads
+        self.attn_dropout = attn_dropout
+        self.layer_norm = layer_norm
+        self.batch_norm = batch_norm
+        self.equivstable_pe = equivstable_pe
+        self.activation = register.act_dict[act]
+
+        self.log_attn_weights = log_attn_weights
+        if log_attn_weights and global_model_type not in ['Transformer', 'BiasedTransformer']:
+            raise NotImplementedError(
+                f"Logging of attention weights is not supported "
+                f"for '{global_model_type}' global attention model.")
+        if log_attn_weights:
+            raise NotImplementedError(
+                "log_attn_weights materialises [B,H,n,n]; the varlen kernel never forms it")
+        if equivstable_pe:
+            raise NotImplementedError("equivstable_pe (posenc_EquivStableLapPE) is outside the "
+                                      "HIP hot path; no BASELINE.json config enables it")
+
+        # Local message-passing model (reference :43-98).
+        self.local_gnn_with_edge_attr = True
+        if local_gnn_type == 'None':
+            self.local_model = None
+        elif local_gnn_type == 'GINE':
+            gin_nn = nn.Sequential(nn.Linear(dim_h, dim_h), self.activation(),
+                                   nn.Linear(dim_h, dim_h))
+            self.local_model = GINEConv(gin_nn)
+        elif local_gnn_type == 'CustomGatedGCN':
+            self.local_model = GatedGCNLayer(dim_h, dim_h, dropout=dropout, residual=True,
+                                             act=act, equivstable_pe=equivstable_pe)
+        elif local_gnn_type in _NEEDS_PYG:
+            raise NotImplementedError(
+                f"local_gnn_type={local_gnn_type!r} is a PyG-native conv outside the HIP hot path "
+                f"(SURVEY.md section 8b item 4); supported: 'None', 'GINE', 'CustomGatedGCN'")
+        else:
+            raise ValueError(f"Unsupported local GNN model: {local_gnn_type}")
+        self.local_gnn_type = local_gnn_type
+
+        # Global attention transformer-style model (reference :100-123).
+        if global_model_type == 'None':
+            self.self_attn = None
+        elif global_model_type == 'Transformer':
+            if dim_h % num_heads != 0:
+                raise AssertionError("embed_dim must be divisible by num_heads")
+            # parameter container only (same names/init as the reference's module, :104-106);
+            # its dense forward is never called
+            self.self_attn = torch.nn.MultiheadAttention(
+                dim_h, num_heads, dropout=self.attn_dropout, batch_first=True)
+        elif global_model_type == 'Performer':
+            try:
+                from .performer_layer import SelfAttention
+            except ImportError as e:
+                raise NotImplementedError(
+                    "global_model_type='Performer': the FAVOR+ HIP path (csrc/favor.hip) is not "
+                    "built in this tree") from e
+            self.self_attn = SelfAttention(dim=dim_h, heads=num_heads,
+                                           dropout=self.attn_dropout, causal=False)
+        elif global_model_type in ('BiasedTransformer', 'BigBird'):
+            raise NotImplementedError(
+                f"global_model_type={global_model_type!r} is outside the HIP hot path "
+                f"(SURVEY.md section 8f rank 3); supported: 'None', 'Transformer', 'Performer'")
+        else:
+            raise ValueError(f"Unsupported global x-former model: {global_model_type}")
+        self.global_model_type = global_model_type
+
+        if self.layer_norm and self.batch_norm:
+            raise ValueError("Cannot apply two types of normalization together")
+        if self.layer_norm:
+            raise NotImplementedError("gt.layer_norm=True (PyG graph LayerNorm) is not built; "
+                                      "every configs/GPS/*.yaml uses batch_norm")
+        if self.batch_norm:
+            self.norm1_local = nn.BatchNorm1d(dim_h)
+            self.norm1_attn = nn.BatchNorm1d(dim_h)
+        self.dropout_local = nn.Dropout(dropout)
+        self.dropout_attn = nn.Dropout(dropout)
+
+        # Feed Forward block (reference :142-153).
+        self.ff_linear1 = nn.Linear(dim_h, dim_h * 2)
+        self.ff_linear2 = nn.Linear(dim_h * 2, dim_h)
+        self.act_fn_ff = self.activation()
+        if self.batch_norm:
+            self.norm2 = nn.BatchNorm1d(dim_h)
+        self.ff_dropout1 = nn.Dropout(dropout)
+        self.ff_dropout2 = nn.Dropout(dropout)
+
+    def forward(self, batch):
+        h = batch.x
+        h_in1 = h  # for first residual connection
+        gi = graph_index_of(batch)
+
+        h_out_list = []
+        if self.local_model is not None:
+            if self.local_gnn_type == 'CustomGatedGCN':
+                # GatedGCN does residual connection and dropout internally (reference :164-174)
+                h_local, e_new = self.local_model.forward_tensors(h, batch.edge_attr, gi)
+                batch.edge_attr = e_new
+            else:
+                h_local = self.local_model.forward_tensors(h, batch.edge_attr, gi)
+                h_local = self.dropout_local(h_local)
+                h_local = h_in1 + h_local  # Residual connection.
+            if self.batch_norm:
+                h_local = self.norm1_local(h_local)
+            h_out_list.append(h_local)
+
+        if self.self_attn is not None:
+            # the global branch attends over the PRE-layer h (reference :156,199)
+            if self.global_model_type == 'Transformer':
+                h_attn = self._sa_block(h, gi)
+            elif self.global_model_type == 'Performer':
+                h_attn = self.self_attn.forward_segments(h, gi)
+            else:
+                raise RuntimeError(f"Unexpected {self.global_model_type}")
+            h_attn = self.dropout_attn(h_attn)
+            h_attn = h_in1 + h_attn  # Residual connection.
+            if self.batch_norm:
+                h_attn = self.norm1_attn(h_attn)
+            h_out_list.append(h_attn)
+
+        h = sum(h_out_list)
+
+        h = h + self._ff_block(h)
+        if self.batch_norm:
+            h = self.norm2(h)
+
+        batch.x = h
+        return batch
+
+    def _sa_block(self, x, gi):
+        """Self-attention block: packed in-proj GEMM -> varlen MFMA attention -> out-proj GEMM.
+        Same arithmetic as nn.MultiheadAttention(x, x, x, key_padding_mask=~mask)[mask]
+        (reference :199-201,234-241) without the dense padding."""
+        sa = self.self_attn
+        qkv = F.linear(x, sa.in_proj_weight, sa.in_proj_bias)
+        p = self.attn_dropout if self.training else 0.0
+        o = segment_attention(qkv, gi, self.num_heads, p)
+        return F.linear(o, sa.out_proj.weight, sa.out_proj.bias)
+
+    def _ff_block(self, x):
+        x = self.ff_dropout1(self.act_fn_ff(self.ff_linear1(x)))
+        return self.ff_dropout2(self.ff_linear2(x))
+
+    def extra_repr(self):
+        return (f'summary: dim_h={self.dim_h}, local_gnn_type={self.local_gnn_type}, '
+                f'global_model_type={self.global_model_type}, heads={self.num_heads}')

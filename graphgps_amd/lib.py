@@ -1,0 +1,108 @@
+"""ctypes binding of ``libgps_hip.so`` (C ABI declared in ``include/gps_hip.h``).
+
+The product path has NO fallback: if the shared library is missing, stale or bound to a
+different HIP runtime than PyTorch's, importing/using the ops raises immediately.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
+from typing import Optional
+
+import torch  # noqa: F401  -- must be imported first: it maps the HIP runtime our .so binds to
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libgps_hip.so")
+ABI_VERSION = 1
+
+_lib: Optional[ctypes.CDLL] = None
+
+_P = c_void_p
+_SIGNATURES = {
+    # name: (restype, argtypes)
+    "gps_abi_version": (c_int, []),
+    "gps_last_error": (c_char_p, []),
+    "gps_graph_index_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "gps_graph_index_build": (c_int, [_P, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
+    "gps_segment_ptr_from_batch": (c_int, [_P, c_int64, c_int64, _P, _P]),
+    "gps_attn_tile_map": (c_int, [_P, c_int64, c_int64, _P, _P, _P]),
+    "gps_gatedgcn_fwd": (c_int, [_P, _P, _P, _P, c_int64, _P, _P, _P, _P, c_int64, c_int64, c_int,
+                                 _P, _P, _P, _P, _P]),
+    "gps_gatedgcn_bwd": (c_int, [_P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, c_int64,
+                                 c_int64, c_int, _P, _P, _P, _P, _P, c_int64, _P]),
+    "gps_gine_fwd": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int64, c_int, c_float, _P, _P]),
+    "gps_gine_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int64, c_int, c_float, _P,
+                             _P, _P]),
+    "gps_node_graph_from_ptr": (c_int, [_P, c_int64, _P, _P]),
+    "gps_segment_pool_fwd": (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P]),
+    "gps_segment_pool_bwd": (c_int, [_P, _P, _P, c_int64, c_int, c_int, _P, _P]),
+    "gps_attn_supported_head_dim": (c_int, [c_int]),
+    "gps_seg_attn_fwd": (c_int, [_P, c_int64, _P, _P, _P, c_int64, c_int64, c_int, c_int, c_float,
+                                 c_float, c_uint64, _P, _P, _P]),
+    "gps_seg_attn_bwd": (c_int, [_P, _P, c_int64, _P, _P, _P, _P, _P, c_int64, c_int64, c_int, c_int,
+                                 c_float, c_float, c_uint64, _P, _P, c_int64, _P]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+class GpsHipError(RuntimeError):
+    pass
+
+
+def _hip_runtimes_mapped():
+    try:
+        with open("/proc/self/maps") as f:
+            return sorted({line.split()[-1] for line in f if "libamdhip64" in line})
+    except OSError:
+        return []
+
+
+def load() -> ctypes.CDLL:
+    """Load (once) and type the library.  Raises ``GpsHipError`` when it cannot."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise GpsHipError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+            f"g.build()'` or `make -C graphgps_amd/csrc -j`. There is no CPU/PyTorch fallback "
+            f"for the GPS hot path.")
+    try:
+        lib = ctypes.CDLL(LIB_PATH, mode=ctypes.RTLD_LOCAL)
+    except OSError as e:
+        raise GpsHipError(f"cannot dlopen {LIB_PATH}: {e}") from e
+    for name, (res, args) in _SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise GpsHipError(f"{LIB_PATH} does not export {name} (stale build?)") from e
+        fn.restype, fn.argtypes = res, args
+    if lib.gps_abi_version() != ABI_VERSION:
+        raise GpsHipError(f"ABI mismatch: library {lib.gps_abi_version()} vs binding {ABI_VERSION}")
+    rts = _hip_runtimes_mapped()
+    if len(rts) > 1:
+        raise GpsHipError(
+            "two HIP runtimes are mapped in this process (" + ", ".join(rts) + "): kernels would "
+            "be launched on a runtime PyTorch does not own. Import torch before graphgps_amd.lib.")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().gps_last_error()
+        raise GpsHipError(f"{what or 'libgps_hip'} failed (code {rc}): "
+                          f"{msg.decode() if msg else 'no message'}")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    """Device pointer of a tensor as a ``c_void_p`` argument (None -> NULL)."""
+    if t is None:
+        return None
+    return t.data_ptr()
+
+
+def current_stream(device: torch.device) -> Optional[int]:
+    return torch.cuda.current_stream(device).cuda_stream

@@ -1,0 +1,45 @@
+"""Losses on the measured configs: L1 / smooth-L1 (``/root/reference/graphgps/loss/l1.py:6-15``)
+and the code2 sub-token cross-entropy
+(``graphgps/loss/subtoken_prediction_loss.py:6-20``: mean over the 5 positions of
+CE(pred_list[i], y_arr[:, i])).  ``compute_loss`` is GraphGym's dispatcher restricted to them."""
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..graphgym.config import cfg
+from ..graphgym.register import loss_dict, register_loss
+
+
+@register_loss('l1_losses', overwrite=True)
+def l1_losses(pred, true):
+    if cfg.model.loss_fun == 'l1':
+        return nn.L1Loss()(pred, true), pred
+    if cfg.model.loss_fun == 'smoothl1':
+        return nn.SmoothL1Loss()(pred, true), pred
+
+
+@register_loss('subtoken_cross_entropy', overwrite=True)
+def subtoken_cross_entropy(pred_list, true):
+    if cfg.dataset.task_type == 'subtoken_prediction':
+        if cfg.model.loss_fun != 'cross_entropy':
+            raise ValueError("Only 'cross_entropy' loss_fun supported with 'subtoken_prediction' "
+                             "task_type.")
+        loss = 0
+        for i in range(len(pred_list)):
+            loss = loss + F.cross_entropy(pred_list[i].to(torch.float32), true['y_arr'][:, i])
+        return loss / len(pred_list), pred_list
+
+
+def compute_loss(pred, true):
+    """GraphGym ``compute_loss`` (third-party), as called at graphgps/train/custom_train.py:29:
+    squeeze the trailing dim of pred/true, try every registered loss, then the built-ins.
+    (ogbg-code2 bypasses it and calls ``subtoken_cross_entropy`` directly, custom_train.py:24-25.)"""
+    pred = pred.squeeze(-1) if pred.ndim > 1 else pred
+    true = true.squeeze(-1) if true.ndim > 1 else true
+    for fn in loss_dict.values():
+        out = fn(pred, true)
+        if out is not None:
+            return out
+    if cfg.model.loss_fun == 'mse':
+        return F.mse_loss(pred, true), pred
+    raise ValueError(f"Loss function '{cfg.model.loss_fun}' not supported")

@@ -1,0 +1,362 @@
+"""Autograd front-ends of the HIP kernels (the operators ``GPSLayer`` is written in).
+
+Every function here enqueues kernels from ``libgps_hip.so`` on PyTorch's current stream and
+does nothing else: no device synchronisation, no host read-back, no fallback.  Tensors are
+allocated by torch's caching allocator and kept alive by the autograd context.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Optional, Tuple
+
+import torch
+
+from . import lib as _lib
+from .lib import check, current_stream, ptr
+
+
+def _require_cuda(*tensors: torch.Tensor) -> torch.device:
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise _lib.GpsHipError(
+                "graphgps_amd ops run on an MI355X only (got a CPU tensor); there is no CPU "
+                "fallback in the product path -- the CPU oracle lives in oracle/ and is test-only")
+        dev = t.device if dev is None else dev
+        if t.device != dev:
+            raise _lib.GpsHipError(f"tensors on different devices: {dev} vs {t.device}")
+    return dev
+
+
+def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        raise _lib.GpsHipError(f"{name}: expected float32, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# -------------------------------------------------------------------------------------------
+# per-batch graph index
+# -------------------------------------------------------------------------------------------
+@dataclass
+class GraphIndex:
+    """Device-side index of one batch; built once, shared by all layers (fwd and bwd)."""
+    N: int
+    E: int
+    B: int
+    rowptr_dst: torch.Tensor
+    src_by_dst: torch.Tensor
+    eid_by_dst: torch.Tensor
+    rowptr_src: torch.Tensor
+    dst_by_src: torch.Tensor
+    eid_by_src: torch.Tensor
+    ptr: torch.Tensor          # int32 [B+1]
+    tile_graph: torch.Tensor   # int32 [max_tiles]
+    tile_row0: torch.Tensor    # int32 [max_tiles]
+    max_tiles: int
+    key: tuple = ()
+
+
+def build_graph_index(edge_index: torch.Tensor, num_nodes: int, num_graphs: int,
+                      batch_vec: Optional[torch.Tensor] = None,
+                      ptr_vec: Optional[torch.Tensor] = None) -> GraphIndex:
+    """CSR-by-target + CSC-by-source + int32 ``ptr`` + attention tile map for one batch.
+
+    ``edge_index`` is the reference's int64 ``[2, E]`` (row 0 = source, row 1 = target;
+    graphgps/layer/gps_layer.py:169).  ``ptr_vec`` (PyG ``batch.ptr``) is used when present,
+    otherwise ``ptr`` is derived on the device from the sorted ``batch_vec``
+    (graphgps/layer/gps_layer.py:199 reads only ``batch.batch``)."""
+    L = _lib.load()
+    dev = _require_cuda(edge_index, batch_vec, ptr_vec)
+    if edge_index.dtype != torch.int64 or edge_index.dim() != 2 or edge_index.shape[0] != 2:
+        raise _lib.GpsHipError(f"edge_index must be int64 [2, E], got {edge_index.dtype} "
+                               f"{tuple(edge_index.shape)}")
+    edge_index = edge_index.contiguous()
+    N, E, B = int(num_nodes), int(edge_index.shape[1]), int(num_graphs)
+    i32 = dict(dtype=torch.int32, device=dev)
+    stream = current_stream(dev)
+    rowptr_dst = torch.empty(N + 1, **i32)
+    rowptr_src = torch.empty(N + 1, **i32)
+    src_by_dst = torch.empty(E, **i32)
+    eid_by_dst = torch.empty(E, **i32)
+    dst_by_src = torch.empty(E, **i32)
+    eid_by_src = torch.empty(E, **i32)
+    ws_bytes = L.gps_graph_index_workspace_bytes(N, E)
+    ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=dev)
+    check(L.gps_graph_index_build(ptr(edge_index), N, E, ptr(rowptr_dst), ptr(src_by_dst),
+                                  ptr(eid_by_dst), ptr(rowptr_src), ptr(dst_by_src),
+                                  ptr(eid_by_src), ptr(ws), ws_bytes, stream),
+          "gps_graph_index_build")
+    if ptr_vec is not None:
+        p32 = ptr_vec.to(torch.int32).contiguous()
+        if p32.numel() != B + 1:
+            raise _lib.GpsHipError(f"ptr has {p32.numel()} entries, expected {B + 1}")
+    else:
+        if batch_vec is None:
+            raise _lib.GpsHipError("need batch.batch or batch.ptr")
+        if batch_vec.dtype != torch.int64:
+            batch_vec = batch_vec.long()
+        batch_vec = batch_vec.contiguous()
+        p32 = torch.empty(B + 1, **i32)
+        check(L.gps_segment_ptr_from_batch(ptr(batch_vec), N, B, ptr(p32), stream),
+              "gps_segment_ptr_from_batch")
+    max_tiles = N // 16 + B
+    tile_graph = torch.empty(max(max_tiles, 1), **i32)
+    tile_row0 = torch.empty(max(max_tiles, 1), **i32)
+    check(L.gps_attn_tile_map(ptr(p32), B, max_tiles, ptr(tile_graph), ptr(tile_row0), stream),
+          "gps_attn_tile_map")
+    return GraphIndex(N, E, B, rowptr_dst, src_by_dst, eid_by_dst, rowptr_src, dst_by_src,
+                      eid_by_src, p32, tile_graph, tile_row0, max_tiles)
+
+
+def graph_index_of(batch) -> GraphIndex:
+    """Index cached on the batch object (one build per batch, not per layer)."""
+    ei = batch.edge_index
+    N = int(batch.x.shape[0])
+    key = (ei.data_ptr(), int(ei.shape[1]), N, str(ei.device))
+    cached = batch.__dict__.get("_gps_index") if hasattr(batch, "__dict__") else None
+    if cached is not None and cached.key == key:
+        return cached
+    B = int(batch.num_graphs)
+    gi = build_graph_index(ei, N, B, batch_vec=getattr(batch, "batch", None),
+                           ptr_vec=getattr(batch, "ptr", None))
+    gi.key = key
+    try:
+        batch.__dict__["_gps_index"] = gi
+    except Exception:
+        pass
+    return gi
+
+
+# -------------------------------------------------------------------------------------------
+# GatedGCN sparse core
+# -------------------------------------------------------------------------------------------
+class _GatedGCNAggregate(torch.autograd.Function):
+    """(proj [N,4d] = Ax|Bx|Dx|Ex, Ce [E,d]) -> (x_tilde [N,d], e_hat [E,d]).
+
+    graphgps/layer/gatedgcn_layer.py:67-70,90-136."""
+
+    @staticmethod
+    def forward(ctx, proj: torch.Tensor, ce: torch.Tensor, gi: GraphIndex):
+        L = _lib.load()
+        dev = _require_cuda(proj, ce)
+        proj, ce = _f32c(proj, "proj"), _f32c(ce, "Ce")
+        N, E = gi.N, gi.E
+        d = proj.shape[1] // 4
+        if proj.shape != (N, 4 * d) or ce.shape != (E, d):
+            raise _lib.GpsHipError(f"gatedgcn: proj {tuple(proj.shape)} / Ce {tuple(ce.shape)} do "
+                                   f"not match N={N} E={E}")
+        need_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        x_tilde = torch.empty(N, d, dtype=torch.float32, device=dev)
+        e_hat = torch.empty(E, d, dtype=torch.float32, device=dev)
+        aggr = torch.empty(N, d, dtype=torch.float32, device=dev) if need_grad else None
+        den = torch.empty(N, d, dtype=torch.float32, device=dev) if need_grad else None
+        base, fs = proj.data_ptr(), d * 4  # fs = byte offset between the Ax|Bx|Dx|Ex column blocks
+        check(L.gps_gatedgcn_fwd(base, base + fs, base + 2 * fs, base + 3 * fs, 4 * d, ptr(ce),
+                                 ptr(gi.rowptr_dst), ptr(gi.src_by_dst), ptr(gi.eid_by_dst), N, E,
+                                 d, ptr(x_tilde), ptr(e_hat), ptr(aggr), ptr(den),
+                                 current_stream(dev)), "gps_gatedgcn_fwd")
+        if need_grad:
+            ctx.save_for_backward(proj, e_hat, aggr, den)
+            ctx.gi = gi
+        return x_tilde, e_hat
+
+    @staticmethod
+    def backward(ctx, g_x: torch.Tensor, g_e: torch.Tensor):
+        L = _lib.load()
+        proj, e_hat, aggr, den = ctx.saved_tensors
+        gi: GraphIndex = ctx.gi
+        dev = proj.device
+        N, E = gi.N, gi.E
+        d = proj.shape[1] // 4
+        g_x = _f32c(g_x, "g_x") if g_x is not None else torch.zeros(N, d, device=dev)
+        g_e = _f32c(g_e, "g_e") if g_e is not None else torch.zeros(E, d, device=dev)
+        g_proj = torch.empty(N, 4 * d, dtype=torch.float32, device=dev)
+        g_ce = torch.empty(E, d, dtype=torch.float32, device=dev)
+        gb, fs = g_proj.data_ptr(), d * 4
+        check(L.gps_gatedgcn_bwd(ptr(g_x), ptr(g_e), ptr(e_hat), proj.data_ptr() + fs, 4 * d,
+                                 ptr(aggr), ptr(den), ptr(gi.rowptr_dst), ptr(gi.src_by_dst),
+                                 ptr(gi.eid_by_dst), ptr(gi.rowptr_src), ptr(gi.dst_by_src),
+                                 ptr(gi.eid_by_src), N, E, d, ptr(g_ce), gb, gb + fs, gb + 2 * fs,
+                                 gb + 3 * fs, 4 * d, current_stream(dev)), "gps_gatedgcn_bwd")
+        return g_proj, g_ce, None
+
+
+def gatedgcn_aggregate(proj: torch.Tensor, ce: torch.Tensor, gi: GraphIndex):
+    return _GatedGCNAggregate.apply(proj, ce, gi)
+
+
+# -------------------------------------------------------------------------------------------
+# GINE sparse core
+# -------------------------------------------------------------------------------------------
+class _GINEAggregate(torch.autograd.Function):
+    """out_i = (1+eps) x_i + sum_{j->i} relu(x_j + e_ji)  (PyG GINEConv, pre-MLP)."""
+
+    @staticmethod
+    def forward(ctx, x: torch.Tensor, e: torch.Tensor, gi: GraphIndex, eps: float):
+        L = _lib.load()
+        dev = _require_cuda(x, e)
+        x, e = _f32c(x, "x"), _f32c(e, "edge_attr")
+        N, E, d = gi.N, gi.E, x.shape[1]
+        if x.shape[0] != N or e.shape != (E, d):
+            raise ValueError("Node and edge feature dimensionalities do not match. Consider "
+                             "setting the 'edge_dim' attribute of 'GINEConv'")
+        out = torch.empty_like(x)
+        check(L.gps_gine_fwd(ptr(x), ptr(e), ptr(gi.rowptr_dst), ptr(gi.src_by_dst),
+                             ptr(gi.eid_by_dst), N, E, d, float(eps), ptr(out),
+                             current_stream(dev)), "gps_gine_fwd")
+        ctx.save_for_backward(x, e)
+        ctx.gi, ctx.eps = gi, float(eps)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out: torch.Tensor):
+        L = _lib.load()
+        x, e = ctx.saved_tensors
+        gi: GraphIndex = ctx.gi
+        g_out = _f32c(g_out, "g_out")
+        g_x, g_e = torch.empty_like(x), torch.empty_like(e)
+        check(L.gps_gine_bwd(ptr(g_out), ptr(x), ptr(e), ptr(gi.rowptr_dst), ptr(gi.src_by_dst),
+                             ptr(gi.eid_by_dst), ptr(gi.rowptr_src), ptr(gi.eid_by_src), gi.N,
+                             gi.E, x.shape[1], ctx.eps, ptr(g_x), ptr(g_e),
+                             current_stream(x.device)), "gps_gine_bwd")
+        return g_x, g_e, None, None
+
+
+def gine_aggregate(x: torch.Tensor, e: torch.Tensor, gi: GraphIndex, eps: float = 0.0):
+    return _GINEAggregate.apply(x, e, gi, eps)
+
+
+# -------------------------------------------------------------------------------------------
+# segment attention
+# -------------------------------------------------------------------------------------------
+def draw_dropout_seed() -> int:
+    """64-bit seed from torch's CPU generator: reproducible under torch.manual_seed, no
+    device sync."""
+    return int(torch.empty((), dtype=torch.int64).random_().item()) & 0xFFFFFFFFFFFFFFFF
+
+
+class _SegmentAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv: torch.Tensor, gi: GraphIndex, num_heads: int, p_drop: float, seed: int):
+        L = _lib.load()
+        dev = _require_cuda(qkv)
+        qkv = _f32c(qkv, "qkv")
+        N, H = gi.N, int(num_heads)
+        d = qkv.shape[1] // 3
+        dh = d // H
+        if qkv.shape != (N, 3 * d) or dh * H != d:
+            raise _lib.GpsHipError(f"segment_attention: qkv {tuple(qkv.shape)} vs N={N} H={H}")
+        out = torch.empty(N, d, dtype=torch.float32, device=dev)
+        lse = torch.empty(H, N, dtype=torch.float32, device=dev)
+        scale = float(dh) ** -0.5
+        check(L.gps_seg_attn_fwd(ptr(qkv), 3 * d, ptr(gi.ptr), ptr(gi.tile_graph),
+                                 ptr(gi.tile_row0), gi.max_tiles, N, H, dh, scale, float(p_drop),
+                                 seed, ptr(out), ptr(lse), current_stream(dev)),
+              "gps_seg_attn_fwd")
+        ctx.save_for_backward(qkv, out, lse)
+        ctx.gi, ctx.H, ctx.dh, ctx.scale, ctx.p_drop, ctx.seed = gi, H, dh, scale, float(p_drop), seed
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out: torch.Tensor):
+        L = _lib.load()
+        qkv, out, lse = ctx.saved_tensors
+        gi: GraphIndex = ctx.gi
+        dev = qkv.device
+        d_out = _f32c(d_out, "d_out")
+        N, H, dh = gi.N, ctx.H, ctx.dh
+        d_qkv = torch.empty_like(qkv)
+        delta = torch.empty(H, N, dtype=torch.float32, device=dev)
+        check(L.gps_seg_attn_bwd(ptr(d_out), ptr(qkv), qkv.shape[1], ptr(out), ptr(lse), ptr(gi.ptr),
+                                 ptr(gi.tile_graph), ptr(gi.tile_row0), gi.max_tiles, N, H, dh,
+                                 ctx.scale, ctx.p_drop, ctx.seed, ptr(delta), ptr(d_qkv),
+                                 d_qkv.shape[1], current_stream(dev)), "gps_seg_attn_bwd")
+        return d_qkv, None, None, None, None
+
+
+def segment_attention(qkv: torch.Tensor, gi: GraphIndex, num_heads: int, p_drop: float = 0.0,
+                      seed: Optional[int] = None) -> torch.Tensor:
+    """softmax(q k^T / sqrt(dh)) (dropout) v per graph and head, straight off ``ptr``.
+
+    ``qkv`` is the packed in-projection output [N, 3d] (``torch.nn.MultiheadAttention``'s
+    ``in_proj_weight`` layout).  Replaces graphgps/layer/gps_layer.py:199-201 + the core of
+    ``nn.MultiheadAttention``."""
+    if p_drop > 0.0 and seed is None:
+        seed = draw_dropout_seed()
+    return _SegmentAttention.apply(qkv, gi, num_heads, float(p_drop), int(seed or 0))
+
+
+def attn_dropout_keep_mask(seed: int, q_global: torch.Tensor, head: int, num_heads: int,
+                           key_local: torch.Tensor, p_drop: float) -> torch.Tensor:
+    """Bit-exact host model of the kernel's counter-based dropout mask
+    (csrc/seg_attention.hip: row_hash/keep_elem).  ``q_global`` [Q] and ``key_local`` [K] are
+    integer tensors; returns bool [Q, K].  Used by the parity tests to inject the SAME mask
+    into the oracle."""
+    M = 0xFFFFFFFF
+
+    def mix(x):
+        x = x & M
+        x = x ^ (x >> 16)
+        x = (x * 0x7FEB352D) & M
+        x = x ^ (x >> 15)
+        x = (x * 0x846CA68B) & M
+        x = x ^ (x >> 16)
+        return x
+
+    q = q_global.to(torch.int64).cpu()
+    k = key_local.to(torch.int64).cpu()
+    rowid = (q * num_heads + head) & M
+    rh = (mix(rowid ^ (seed & M)) + ((seed >> 32) & M)) & M
+    r = mix((rh[:, None] + (k[None, :] * 0x9E3779B9)) & M)
+    u = (r >> 8).to(torch.float32) * (1.0 / 16777216.0)
+    return u >= torch.tensor(p_drop, dtype=torch.float32)
+
+
+# -------------------------------------------------------------------------------------------
+# graph pooling over ptr segments
+# -------------------------------------------------------------------------------------------
+def _node_graph(gi: GraphIndex) -> torch.Tensor:
+    ng = getattr(gi, "_node_graph", None)
+    if ng is None:
+        L = _lib.load()
+        dev = gi.ptr.device
+        ng = torch.empty(max(gi.N, 1), dtype=torch.int32, device=dev)
+        check(L.gps_node_graph_from_ptr(ptr(gi.ptr), gi.B, ptr(ng), current_stream(dev)),
+              "gps_node_graph_from_ptr")
+        gi._node_graph = ng
+    return ng
+
+
+class _SegmentPool(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: torch.Tensor, gi: GraphIndex, mean: bool):
+        L = _lib.load()
+        dev = _require_cuda(x)
+        x = _f32c(x, "x")
+        d = x.shape[1]
+        out = torch.empty(gi.B, d, dtype=torch.float32, device=dev)
+        check(L.gps_segment_pool_fwd(ptr(x), ptr(gi.ptr), gi.B, d, int(mean), ptr(out),
+                                     current_stream(dev)), "gps_segment_pool_fwd")
+        ctx.gi, ctx.mean, ctx.d = gi, bool(mean), d
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out: torch.Tensor):
+        L = _lib.load()
+        gi: GraphIndex = ctx.gi
+        g_out = _f32c(g_out, "g_out")
+        dev = g_out.device
+        g_x = torch.empty(gi.N, ctx.d, dtype=torch.float32, device=dev)
+        check(L.gps_segment_pool_bwd(ptr(g_out), ptr(gi.ptr), ptr(_node_graph(gi)), gi.N, ctx.d,
+                                     int(ctx.mean), ptr(g_x), current_stream(dev)),
+              "gps_segment_pool_bwd")
+        return g_x, None, None
+
+
+def segment_pool(x: torch.Tensor, gi: GraphIndex, mode: str = "mean") -> torch.Tensor:
+    """``global_add_pool`` / ``global_mean_pool`` over ``ptr`` segments (deterministic)."""
+    if mode not in ("add", "sum", "mean"):
+        raise ValueError(f"segment_pool: unsupported mode {mode!r}")
+    return _SegmentPool.apply(x, gi, mode == "mean")

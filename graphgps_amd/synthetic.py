@@ -25,7 +25,7 @@ import torch
 from .data import Batch
 
 # OGB feature vocabulary sizes (ogb.utils.features.get_{atom,bond}_feature_dims; third-party)
-ATOM_FEATURE_DIMS = [119, 5, 12, 12, 10, 6, 6, 2, 2]
+ATOM_FEATURE_DIMS = [119, 4, 12, 12, 10, 6, 6, 2, 2]
 BOND_FEATURE_DIMS = [5, 6, 2]
 
 

@@ -1,0 +1,146 @@
+/* gps_hip.h -- C ABI of libgps_hip.so: the MI355X (gfx950) kernels behind GPSLayer.
+ *
+ * This is the drop-in boundary of the port.  The reference has no
+ * native code of its own; every entry point below replaces a *third-party* native op that the
+ * reference reaches from Python.  Citations are relative to /root/reference.
+ *
+ * Conventions (all entry points):
+ *   - plain C, no C++/torch types; device pointers are raw `void*`/typed pointers into memory
+ *     owned by the caller (torch's caching allocator).  The library never allocates, frees or
+ *     synchronises; it only enqueues kernels on `stream` (a hipStream_t passed as void*;
+ *     NULL = the legacy default stream), so every call is hipGraph-capturable.
+ *   - activations are contiguous row-major fp32; "ld" arguments are row strides in floats.
+ *   - indices are int32 on the device (N, E < 2^31 is validated); `edge_index` is accepted in
+ *     the reference's own layout, int64 [2, E] (row 0 = source j, row 1 = target i).
+ *   - return 0 on success, a negative GPS_E* code otherwise; gps_last_error() returns a
+ *     thread-local message.  No C++ exception crosses the boundary.  Re-entrant/thread-safe
+ *     (called from the Python main thread in forward and the autograd thread in backward).
+ */
+#ifndef GPS_HIP_H
+#define GPS_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define GPS_OK 0
+#define GPS_EINVAL (-1)   /* bad argument (null pointer, negative size, unsupported dim) */
+#define GPS_ELAUNCH (-2)  /* hipLaunchKernel / hipMemsetAsync reported an error */
+#define GPS_EUNSUPPORTED (-3)
+
+typedef void* gps_stream_t; /* hipStream_t */
+
+int gps_abi_version(void);
+const char* gps_last_error(void);
+
+/* ---------------------------------------------------------------------------------------
+ * Per-batch graph index.  Replaces PyG's per-layer `MessagePassing._collect` index_select
+ * bookkeeping (graphgps/layer/gatedgcn_layer.py:67-70) and `to_dense_batch`'s cumsum
+ * (graphgps/layer/gps_layer.py:199) with structures built ONCE per batch:
+ *   CSR by target : rowptr_dst[N+1], src_by_dst[E], eid_by_dst[E]   (edges of target i, in
+ *                   ascending original edge id == the order torch_scatter's CPU scatter adds)
+ *   CSC by source : rowptr_src[N+1], dst_by_src[E], eid_by_src[E]   (for the backward)
+ * Deterministic (stable counting sort); bit-exact vs numpy stable argsort.
+ * `ws` needs gps_graph_index_workspace_bytes(N, E) bytes.
+ * ------------------------------------------------------------------------------------- */
+size_t gps_graph_index_workspace_bytes(int64_t N, int64_t E);
+int gps_graph_index_build(const int64_t* edge_index, int64_t N, int64_t E,
+                          int32_t* rowptr_dst, int32_t* src_by_dst, int32_t* eid_by_dst,
+                          int32_t* rowptr_src, int32_t* dst_by_src, int32_t* eid_by_src,
+                          void* ws, size_t ws_bytes, gps_stream_t stream);
+
+/* ptr[B+1] (cumulative node counts, int32) from the sorted int64 `batch` vector
+ * (graphgps/layer/gps_layer.py:199 reads only `batch.batch`; PyG loader batches carry `ptr`). */
+int gps_segment_ptr_from_batch(const int64_t* batch, int64_t N, int64_t B, int32_t* ptr,
+                               gps_stream_t stream);
+
+/* 16-row tile map for the segment-attention kernels: slot t of `tile_graph`/`tile_row0`
+ * (both int32[max_tiles], max_tiles >= N/16 + B) holds (graph id, first global row) of one
+ * 16-row tile, or -1.  Lets a fixed-size grid walk ragged graphs with no host sync. */
+int gps_attn_tile_map(const int32_t* ptr, int64_t B, int64_t max_tiles, int32_t* tile_graph,
+                      int32_t* tile_row0, gps_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * GatedGCN sparse core.  Replaces propagate()'s 3 index_select gathers, the sigmoid gate and
+ * the 2 torch_scatter.scatter sums + the node update (graphgps/layer/gatedgcn_layer.py:67-70,
+ * 90-136) with ONE gather-gate-segment-reduce kernel (forward) and TWO (backward).
+ *   e_hat[eid] = Dx[i] + Ex[j] + Ce[eid]                      (edge order, pre-BN edge output)
+ *   x_tilde[i] = Ax[i] + (sum_j sig*Bx[j]) / (sum_j sig + 1e-6)
+ * Ax/Bx/Dx/Ex are [N, d] views with row stride ld_node (a fused [N,4d] projection passes
+ * ld_node = 4d).  `aggr`/`den` ([N,d]) are saved for the backward (may be NULL in inference).
+ * ------------------------------------------------------------------------------------- */
+int gps_gatedgcn_fwd(const float* Ax, const float* Bx, const float* Dx, const float* Ex,
+                     int64_t ld_node, const float* Ce, const int32_t* rowptr_dst,
+                     const int32_t* src_by_dst, const int32_t* eid_by_dst, int64_t N, int64_t E,
+                     int d, float* x_tilde, float* e_hat, float* aggr, float* den,
+                     gps_stream_t stream);
+
+/* Backward.  Inputs: g_x [N,d] (grad wrt x_tilde), g_e [E,d] (grad wrt e_hat), saved e_hat,
+ * Bx (ld_node), aggr, den.  Outputs: g_Ce [E,d]; g_Ax/g_Bx/g_Dx/g_Ex [N,d] views with row stride
+ * ld_gnode (all four written; g_Ax = g_x).  Two launches: a target-keyed pass (delta, g_Ce,
+ * g_Dx) and a source-keyed pass (g_Ex, g_Bx).  Deterministic, no atomics. */
+int gps_gatedgcn_bwd(const float* g_x, const float* g_e, const float* e_hat, const float* Bx,
+                     int64_t ld_node, const float* aggr, const float* den,
+                     const int32_t* rowptr_dst, const int32_t* src_by_dst,
+                     const int32_t* eid_by_dst, const int32_t* rowptr_src,
+                     const int32_t* dst_by_src, const int32_t* eid_by_src, int64_t N, int64_t E,
+                     int d, float* g_Ce, float* g_Ax, float* g_Bx, float* g_Dx, float* g_Ex,
+                     int64_t ld_gnode, gps_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * GINE sparse core.  Replaces PyG GINEConv's gather + relu + scatter-add + (1+eps)*x
+ * (constructed graphgps/layer/gps_layer.py:62-69, called :183-185):
+ *   out[i] = (1+eps) * x[i] + sum_{j->i} relu(x[j] + e[eid])
+ * Backward: g_e[eid] = g_out[i] * [x[j]+e[eid] > 0];  g_x[j] = (1+eps)*g_out[j] + sum_{j->.} g_e.
+ * ------------------------------------------------------------------------------------- */
+int gps_gine_fwd(const float* x, const float* e, const int32_t* rowptr_dst,
+                 const int32_t* src_by_dst, const int32_t* eid_by_dst, int64_t N, int64_t E, int d,
+                 float eps, float* out, gps_stream_t stream);
+int gps_gine_bwd(const float* g_out, const float* x, const float* e, const int32_t* rowptr_dst,
+                 const int32_t* src_by_dst, const int32_t* eid_by_dst, const int32_t* rowptr_src,
+                 const int32_t* eid_by_src, int64_t N, int64_t E, int d, float eps, float* g_x,
+                 float* g_e, gps_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Segment (per-graph, varlen) multi-head attention core on fp32 MFMA (v_mfma_f32_16x16x4_f32).
+ * Replaces to_dense_batch + the softmax(QK^T/sqrt(dh) + key-padding mask) -> dropout -> .V core
+ * of torch.nn.MultiheadAttention + the [mask] un-pad (graphgps/layer/gps_layer.py:199-201,
+ * 234-241).  No padding, no mask tensor: graphs are walked through `ptr`.
+ *   qkv  [N, 3d] packed in-proj output (q | k | v, head h at columns h*dh..), row stride ld_qkv
+ *   out  [N, d]   heads merged;   lse [H, N] log-sum-exp per (head, query), saved for backward
+ * Attention dropout (p_drop in [0,1)) uses a counter-based hash of (seed, query, head, key) so
+ * that forward and backward regenerate the same mask; p_drop == 0 disables it.
+ * Supported head dims: 4..128 (any), see gps_attn_supported_head_dim().
+ * ------------------------------------------------------------------------------------- */
+int gps_attn_supported_head_dim(int dh);
+int gps_seg_attn_fwd(const float* qkv, int64_t ld_qkv, const int32_t* ptr,
+                     const int32_t* tile_graph, const int32_t* tile_row0, int64_t max_tiles,
+                     int64_t N, int H, int dh, float scale, float p_drop, uint64_t seed, float* out,
+                     float* lse, gps_stream_t stream);
+/* d_qkv [N,3d] (row stride ld_dqkv) receives dq | dk | dv.  `delta` is an [H,N] scratch buffer
+ * (rowsum(dO*O)).  Three launches: delta, dQ (query-tile keyed), dK+dV (key-tile keyed). */
+int gps_seg_attn_bwd(const float* d_out, const float* qkv, int64_t ld_qkv, const float* out,
+                     const float* lse, const int32_t* ptr, const int32_t* tile_graph,
+                     const int32_t* tile_row0, int64_t max_tiles, int64_t N, int H, int dh,
+                     float scale, float p_drop, uint64_t seed, float* delta, float* d_qkv,
+                     int64_t ld_dqkv, gps_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * Graph pooling over `ptr` segments (sum: mean = 0, mean: mean = 1) and its backward.
+ * Replaces GraphGym pooling_dict['add'|'mean'] (torch_scatter atomics), called from
+ * graphgps/head/san_graph.py:35 and graphgps/head/ogb_code_graph.py:37.
+ * `node_graph` int32 [N] (graph id per node) comes from gps_node_graph_from_ptr.
+ * ------------------------------------------------------------------------------------- */
+int gps_node_graph_from_ptr(const int32_t* ptr, int64_t B, int32_t* node_graph, gps_stream_t stream);
+int gps_segment_pool_fwd(const float* x, const int32_t* ptr, int64_t B, int d, int mean, float* out,
+                         gps_stream_t stream);
+int gps_segment_pool_bwd(const float* g_out, const int32_t* ptr, const int32_t* node_graph,
+                         int64_t N, int d, int mean, float* g_x, gps_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPS_HIP_H */

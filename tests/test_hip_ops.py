@@ -1,0 +1,243 @@
+"""GPU parity tests of the individual HIP operators, through the C ABI (ctypes), against CPU
+restatements.  Tolerances: bit-exact for indices; 1e-5 absolute on O(1) activations and 1e-5
+relative-to-max on gradients (BASELINE.json north_star: 'within 1e-5 fp32')."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import Tol, assert_close
+from helpers import gatedgcn_core_ref, gine_core_ref, segment_attention_ref
+
+pytestmark = pytest.mark.gpu
+
+
+def _structure(profile, nb, seed):
+    from graphgps_amd.synthetic import make_structure
+    sizes, ei, bvec, ptr, gen, _ = make_structure(profile, nb, seed)
+    return sizes, ei, bvec, ptr, gen
+
+
+def _index(ei, bvec, ptr, use_ptr=True):
+    from graphgps_amd.ops import build_graph_index
+    dev = torch.device("cuda:0")
+    return build_graph_index(ei.to(dev), int(ptr[-1]), len(ptr) - 1,
+                             batch_vec=bvec.to(dev), ptr_vec=ptr.to(dev) if use_ptr else None)
+
+
+@pytest.mark.parametrize("profile,nb,seed", [("P30", 64, 1), ("P14", 256, 2), ("CODE2_REAL", 8, 3)])
+def test_graph_index_bit_exact(profile, nb, seed):
+    sizes, ei, bvec, ptr, _ = _structure(profile, nb, seed)
+    gi = _index(ei, bvec, ptr, use_ptr=False)
+    N, E = int(ptr[-1]), ei.shape[1]
+    src, dst = ei[0].numpy(), ei[1].numpy()
+    for key, other, rowptr, oth_sorted, eid in (
+            (dst, src, gi.rowptr_dst, gi.src_by_dst, gi.eid_by_dst),
+            (src, dst, gi.rowptr_src, gi.dst_by_src, gi.eid_by_src)):
+        perm = np.argsort(key, kind="stable")
+        rp = np.concatenate([[0], np.cumsum(np.bincount(key, minlength=N))])
+        assert np.array_equal(rowptr.cpu().numpy(), rp.astype(np.int32))
+        assert np.array_equal(eid.cpu().numpy(), perm.astype(np.int32))
+        assert np.array_equal(oth_sorted.cpu().numpy(), other[perm].astype(np.int32))
+    assert torch.equal(gi.ptr.cpu(), ptr.to(torch.int32))  # derived from batch.batch on device
+    # tile map: every 16-row tile of every graph exactly once
+    tg, tr = gi.tile_graph.cpu().numpy()[:gi.max_tiles], gi.tile_row0.cpu().numpy()[:gi.max_tiles]
+    got = sorted((int(g), int(r)) for g, r in zip(tg, tr) if g >= 0)
+    want = sorted((g, r) for g in range(nb) for r in range(int(ptr[g]), int(ptr[g + 1]), 16))
+    assert got == want
+
+
+def test_graph_index_hub_and_isolated_nodes():
+    # star graph (hub degree 300 -> heapsort path) + isolated nodes + empty graph in the middle
+    n = 301
+    hub_edges = torch.stack([torch.arange(1, n), torch.zeros(n - 1, dtype=torch.long)])
+    ei = torch.cat([hub_edges, hub_edges.flip(0)], 1)
+    ei = ei[:, torch.randperm(ei.shape[1], generator=torch.Generator().manual_seed(0))]
+    N = n + 5
+    bvec = torch.cat([torch.zeros(n, dtype=torch.long), torch.full((5,), 2, dtype=torch.long)])
+    ptr = torch.tensor([0, n, n, N])
+    gi = _index(ei, bvec, ptr, use_ptr=False)
+    perm = np.argsort(ei[1].numpy(), kind="stable")
+    assert np.array_equal(gi.eid_by_dst.cpu().numpy(), perm.astype(np.int32))
+    assert torch.equal(gi.ptr.cpu(), ptr.to(torch.int32))
+
+
+@pytest.mark.parametrize("d", [16, 52, 384])
+def test_gatedgcn_core(d):
+    from graphgps_amd.ops import gatedgcn_aggregate
+    sizes, ei, bvec, ptr, gen = _structure("P30", 48, 5)
+    N, E = int(ptr[-1]), ei.shape[1]
+    proj = torch.randn(N, 4 * d, generator=gen)
+    ce = torch.randn(E, d, generator=gen)
+    wx, we = torch.randn(N, d, generator=gen), torch.randn(E, d, generator=gen)
+    pr, cr = proj.clone().requires_grad_(True), ce.clone().requires_grad_(True)
+    xr, er = gatedgcn_core_ref(pr, cr, ei)
+    ((xr * wx).sum() + (er * we).sum()).backward()
+    dev = torch.device("cuda:0")
+    gi = _index(ei, bvec, ptr)
+    pg, cg = proj.to(dev).requires_grad_(True), ce.to(dev).requires_grad_(True)
+    xg, eg = gatedgcn_aggregate(pg, cg, gi)
+    ((xg * wx.to(dev)).sum() + (eg * we.to(dev)).sum()).backward()
+    assert_close(xg, xr, Tol.ACT, "x_tilde")
+    assert_close(eg, er, Tol.ACT, "e_hat")
+    assert_close(pg.grad, pr.grad, Tol.GRAD_REL, "g_proj", rel_to_max=True)
+    assert_close(cg.grad, cr.grad, Tol.GRAD_REL, "g_Ce", rel_to_max=True)
+    # determinism: bitwise identical on a second run
+    xg2, eg2 = gatedgcn_aggregate(pg.detach(), cg.detach(), gi)
+    assert torch.equal(xg2, xg.detach()) and torch.equal(eg2, eg.detach())
+
+
+def test_gatedgcn_no_edges_and_odd_dim():
+    from graphgps_amd.ops import build_graph_index, gatedgcn_aggregate
+    dev = torch.device("cuda:0")
+    N, d = 7, 6  # d % 4 != 0 -> float2 path; no edges -> x_tilde = Ax
+    ei = torch.zeros(2, 0, dtype=torch.long, device=dev)
+    gi = build_graph_index(ei, N, 1, ptr_vec=torch.tensor([0, N], device=dev))
+    proj = torch.randn(N, 4 * d, device=dev)
+    x, e = gatedgcn_aggregate(proj, torch.zeros(0, d, device=dev), gi)
+    assert torch.equal(x, proj[:, :d]) and e.shape == (0, d)
+
+
+@pytest.mark.parametrize("d", [64, 50])
+def test_gine_core(d):
+    from graphgps_amd.ops import gine_aggregate
+    sizes, ei, bvec, ptr, gen = _structure("ZINC", 32, 6)
+    N, E = int(ptr[-1]), ei.shape[1]
+    x, e = torch.randn(N, d, generator=gen), torch.randn(E, d, generator=gen)
+    w = torch.randn(N, d, generator=gen)
+    xr, er = x.clone().requires_grad_(True), e.clone().requires_grad_(True)
+    (gine_core_ref(xr, er, ei) * w).sum().backward()
+    dev = torch.device("cuda:0")
+    gi = _index(ei, bvec, ptr)
+    xg, eg = x.to(dev).requires_grad_(True), e.to(dev).requires_grad_(True)
+    out = gine_aggregate(xg, eg, gi, 0.0)
+    (out * w.to(dev)).sum().backward()
+    assert_close(out, gine_core_ref(x, e, ei), Tol.ACT, "gine out")
+    assert_close(xg.grad, xr.grad, Tol.GRAD_REL, "g_x", rel_to_max=True)
+    assert_close(eg.grad, er.grad, Tol.GRAD_REL, "g_e", rel_to_max=True)
+
+
+ATTN_CASES = [  # (H, dh, graph sizes)
+    (4, 16, [23, 9, 37, 16, 1, 17]),
+    (16, 24, [30, 45, 4, 64, 29]),
+    (4, 13, [12, 33, 20]),
+    (8, 6, [14, 14, 7]),
+    (4, 76, [40, 18]),
+    (2, 32, [150, 70, 129]),      # > 64 keys: several online-softmax blocks
+    (4, 96, [31, 66]),
+]
+
+
+def _attn_inputs(H, dh, sizes, seed=0):
+    gen = torch.Generator().manual_seed(seed)
+    N, d = sum(sizes), H * dh
+    ptr = torch.tensor([0] + list(np.cumsum(sizes)))
+    qkv = torch.randn(N, 3 * d, generator=gen)
+    w = torch.randn(N, d, generator=gen)
+    ei = torch.zeros(2, 0, dtype=torch.long)
+    bvec = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
+    return qkv, w, ptr, ei, bvec
+
+
+@pytest.mark.parametrize("H,dh,sizes", ATTN_CASES)
+def test_segment_attention_fwd_bwd(H, dh, sizes):
+    from graphgps_amd.ops import segment_attention
+    qkv, w, ptr, ei, bvec = _attn_inputs(H, dh, sizes)
+    qr = qkv.clone().double().requires_grad_(True)
+    ref = segment_attention_ref(qr, ptr, H)
+    (ref * w.double()).sum().backward()
+    dev = torch.device("cuda:0")
+    gi = _index(ei, bvec, ptr)
+    qg = qkv.to(dev).requires_grad_(True)
+    out = segment_attention(qg, gi, H, 0.0)
+    (out * w.to(dev)).sum().backward()
+    assert_close(out, ref, Tol.ACT, "attn out")
+    assert_close(qg.grad, qr.grad, Tol.GRAD_REL, "d_qkv", rel_to_max=True)
+
+
+def test_segment_attention_spiked_scores():
+    """Online-softmax rescale path: a key block whose max jumps far above the previous ones."""
+    from graphgps_amd.ops import segment_attention
+    H, dh, sizes = 2, 16, [200]
+    qkv, w, ptr, ei, bvec = _attn_inputs(H, dh, sizes, seed=3)
+    d = H * dh
+    qkv[5, :d] *= 6.0
+    qkv[170, d:2 * d] = qkv[5, :d] * 1.5      # huge q.k in the last key block
+    qkv[70, d:2 * d] = -qkv[5, :d]
+    ref = segment_attention_ref(qkv.double(), ptr, H)
+    gi = _index(ei, bvec, ptr)
+    out = segment_attention(qkv.cuda(), gi, H, 0.0)
+    assert torch.isfinite(out).all()
+    assert_close(out, ref, Tol.ACT, "attn out (spiked)")
+
+
+@pytest.mark.parametrize("H,dh,sizes", [(4, 16, [23, 9, 37]), (16, 24, [30, 45, 70])])
+def test_segment_attention_dropout_shared_mask(H, dh, sizes):
+    """Dropout parity by injecting the kernel's own counter-based mask into the reference."""
+    from graphgps_amd.ops import attn_dropout_keep_mask, segment_attention
+    p, seed = 0.3, 0x1234_5678_9ABC_DEF1
+    qkv, w, ptr, ei, bvec = _attn_inputs(H, dh, sizes, seed=1)
+    keep = []
+    for g in range(len(sizes)):
+        a, b = int(ptr[g]), int(ptr[g + 1])
+        keep.append(torch.stack([attn_dropout_keep_mask(seed, torch.arange(a, b), h, H,
+                                                        torch.arange(b - a), p) for h in range(H)]))
+    rate = torch.cat([k.flatten() for k in keep]).float().mean().item()
+    assert abs(rate - (1 - p)) < 0.02, rate
+    qr = qkv.clone().double().requires_grad_(True)
+    ref = segment_attention_ref(qr, ptr, H, keep=keep, p_drop=p)
+    (ref * w.double()).sum().backward()
+    gi = _index(ei, bvec, ptr)
+    qg = qkv.cuda().requires_grad_(True)
+    out = segment_attention(qg, gi, H, p, seed=seed)
+    (out * w.cuda()).sum().backward()
+    assert_close(out, ref, Tol.ACT, "attn out (dropout)")
+    assert_close(qg.grad, qr.grad, Tol.GRAD_REL, "d_qkv (dropout)", rel_to_max=True)
+
+
+def test_segment_attention_padding_invariance():
+    """A graph's output must not depend on which other graphs share the batch."""
+    from graphgps_amd.ops import segment_attention
+    H, dh = 16, 24
+    qkv, w, ptr, ei, bvec = _attn_inputs(H, dh, [30, 61, 12])
+    gi = _index(ei, bvec, ptr)
+    full = segment_attention(qkv.cuda(), gi, H, 0.0)
+    a, b = int(ptr[1]), int(ptr[2])
+    solo_ptr = torch.tensor([0, b - a])
+    gi1 = _index(ei, torch.zeros(b - a, dtype=torch.long), solo_ptr)
+    solo = segment_attention(qkv[a:b].cuda(), gi1, H, 0.0)
+    assert torch.equal(full[a:b], solo)
+
+
+def test_unsupported_head_dim_fails_loudly():
+    from graphgps_amd.lib import GpsHipError
+    from graphgps_amd.ops import segment_attention
+    qkv, w, ptr, ei, bvec = _attn_inputs(2, 7, [5])
+    gi = _index(ei, bvec, ptr)
+    with pytest.raises(GpsHipError):
+        segment_attention(qkv.cuda(), gi, 2, 0.0)
+
+
+@pytest.mark.parametrize("mode", ["mean", "add"])
+def test_segment_pool(mode):
+    from graphgps_amd.ops import segment_pool
+    sizes, ei, bvec, ptr, gen = _structure("P30", 40, 9)
+    N, d = int(ptr[-1]), 384
+    x, w = torch.randn(N, d, generator=gen), torch.randn(40, d, generator=gen)
+    xr = x.clone().requires_grad_(True)
+    ref = torch.zeros(40, d).index_add_(0, bvec, xr)
+    if mode == "mean":
+        ref = ref / torch.bincount(bvec, minlength=40).clamp(min=1)[:, None]
+    (ref * w).sum().backward()
+    gi = _index(ei, bvec, ptr)
+    xg = x.cuda().requires_grad_(True)
+    out = segment_pool(xg, gi, mode)
+    (out * w.cuda()).sum().backward()
+    assert_close(out, ref, Tol.ACT, "pool")
+    assert_close(xg.grad, xr.grad, Tol.GRAD_REL, "pool grad", rel_to_max=True)
+
+
+def test_cpu_tensor_is_rejected():
+    from graphgps_amd.lib import GpsHipError
+    from graphgps_amd.ops import build_graph_index
+    with pytest.raises(GpsHipError):
+        build_graph_index(torch.zeros(2, 3, dtype=torch.long), 4, 1, ptr_vec=torch.tensor([0, 4]))
