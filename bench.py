@@ -35,6 +35,25 @@ HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/
 MFMA_F32_PEAK_TF = 157.3     # v_mfma_f32_16x16x4_f32 dense peak
 
 
+_T0 = time.time()
+
+
+def log(msg):
+    print(f"[bench +{time.time() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
+def usable_cores():
+    """Host cores this process may actually use (affinity mask and cgroup CPU quota)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -45,6 +64,8 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-roofline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-threads", type=int, default=0,
+                    help="torch threads for the CPU baseline (0 = min(usable cores, 32))")
     return ap.parse_args()
 
 
@@ -147,11 +168,14 @@ def kernel_rooflines(dev, profile, nb, d=384, H=16):
     return res, dict(N=N, E=E, d=d, H=H, sum_n2=s2)
 
 
-def cpu_baseline(model, batch_cpu, compute_loss, clip_value, steps):
-    """CPU oracle (kind='port'): same batch, same step definition, all host cores."""
+def cpu_baseline(model, batch_cpu, compute_loss, clip_value, steps, threads=0):
+    """CPU oracle (kind='port'): same batch, same step definition, on the host cores.  The op
+    granularity of the reference path ([7.7k,384] GEMMs, gathers, elementwise) stops scaling
+    well before 32 threads, so more threads than that only add barrier cost."""
     from oracle.gps_oracle import to_oracle_model
-    cores = os.cpu_count() or 1
+    cores = threads or min(usable_cores(), 32)
     torch.set_num_threads(cores)
+    log(f"cpu baseline: {cores} torch threads of {usable_cores()} usable cores")
     oracle = to_oracle_model(model).train()
     opt = torch.optim.AdamW(oracle.parameters(), lr=2e-4, weight_decay=0.0)
     params = list(oracle.parameters())
@@ -164,7 +188,9 @@ def cpu_baseline(model, batch_cpu, compute_loss, clip_value, steps):
         torch.nn.utils.clip_grad_norm_(params, clip_value)
         opt.step()
 
+    tw = time.perf_counter()
     step()                                   # warm-up (allocator, thread pool)
+    log(f"cpu baseline: warm-up step {time.perf_counter() - tw:.2f}s")
     t0 = time.perf_counter()
     done = 0
     while done < steps and (done == 0 or time.perf_counter() - t0 < 30.0):
@@ -222,9 +248,14 @@ def main():
         torch.cuda.synchronize()
 
     torch.manual_seed(1000 + rank)             # dropout streams differ per rank
-    for _ in range(args.warmup):
+    log("model on device, starting warm-up")
+    for i in range(args.warmup):
         loss = step()
+        if i == 0:
+            torch.cuda.synchronize()
+            log("first step done")
     barrier()
+    log("warm-up done")
     t0 = time.perf_counter()
     for _ in range(args.steps):
         loss = step()
@@ -236,6 +267,7 @@ def main():
         elapsed = float(t.item())
     ms = elapsed / args.steps * 1e3
     final_loss = float(loss.item())
+    log(f"timed region done: {ms:.2f} ms/step")
 
     if rank == 0:
         N, E = batch_dev.x.shape[0], batch_dev.edge_index.shape[1]
@@ -256,6 +288,7 @@ def main():
         }
         if not args.no_kernel_roofline:
             kr, shape = kernel_rooflines(dev, args.profile, nb)
+            log("kernel rooflines done")
             k = kr["gatedgcn_fwd"]
             traffic = None
             pmc = os.path.join(ROOT, "profiles", "pmc_gatedgcn_fwd.json")
@@ -269,7 +302,8 @@ def main():
             out["kernel_shape"] = shape
         if cpu_ref_model is not None:
             out["cpu_baseline"] = cpu_baseline(cpu_ref_model, batch_cpu, compute_loss,
-                                               cfg.optim.clip_grad_norm_value, args.cpu_steps)
+                                               cfg.optim.clip_grad_norm_value, args.cpu_steps,
+                                               args.cpu_threads)
             out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
     if world > 1:

