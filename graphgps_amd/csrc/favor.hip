@@ -1,0 +1,678 @@
+// FAVOR+ (Performer softmax-kernel linear attention) over ptr segments, on fp32 MFMA.
+//
+// Reference arithmetic: graphgps/layer/performer_layer.py:119-144 (softmax_kernel),
+// :200-205 (linear_attention), :467-503 (Attention.forward), as called through
+// performer_pytorch.SelfAttention at graphgps/layer/gps_layer.py:111-114,206 on the
+// to_dense_batch-padded tensor.  Per graph g (n rows; Nmax = longest graph of the batch) and head:
+//     dd_q = (c q) P^T,  phi_q = r (exp(dd_q - |cq|^2/2 - rowmax(dd_q)) + 1e-4)
+//     dd_k = (c k) P^T,  phi_k = r (exp(dd_k - |ck|^2/2 - M) + 1e-4),  M = max over ALL rows and features
+//     ksum = sum_n phi_k (+ padded rows),  ctx = phi_k^T v,  out = (phi_q ctx) / (phi_q . ksum)
+// with c = dh^-1/4, r = m^-1/2.  The reference masks only V, so each of the (Nmax - n) zero-padded
+// key rows still contributes r (exp(-M) + 1e-4) to ksum and a 0 logit to M;
+// this varlen kernel never builds padded rows and adds that closed form instead.
+//
+// Machine mapping: dim_head = 64, m <= 272 (17 feature tiles of 16; the package default
+// m = int(64 ln 64) = 266).  All contractions are v_mfma_f32_16x16x4_f32 built from two operand
+// patterns (same order-free-contraction trick as seg_attention.hip, no LDS, no cross-lane moves):
+//   rows x rows^T : C[4g+r][l&15] = sum_k A_row(l&15)[k] * B_row(l&15)[k], each lane loading 16
+//                   contiguous floats of its row                               (mm_rows)
+//   chain         : acc[4g+r'][l&15] += sum_{4g+r} X[row 4g+r][col l&15] * Cprev[4g+r][l&15]
+//                   i.e. a previous accumulator is consumed directly as the B operand  (mm_chain)
+// Forward: k-max (atomicMax, order-free) -> ctx/ksum per (graph, head, feature tile) -> output per
+// (16-query tile, head).  Backward: 4 passes (query side, context side, key side, key-max fix-up),
+// every cross-row reduction keyed so that it is summed in a fixed order: deterministic.
+#include "gps_common.hpp"
+
+namespace {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+constexpr int DH = 64;    // dim_head of performer_pytorch.SelfAttention (performer_layer.py:427)
+constexpr int MT = 17;    // feature tiles of 16 -> m <= 272
+constexpr int KPL = 16;   // contiguous floats per lane when contracting over a 64-wide dim
+constexpr float FEPS = 1e-4f;
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
+  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x4 zero4() { return (f32x4){0.f, 0.f, 0.f, 0.f}; }
+__device__ __forceinline__ float group_max(float v) {
+  v = fmaxf(v, __shfl_xor(v, 16));
+  return fmaxf(v, __shfl_xor(v, 32));
+}
+__device__ __forceinline__ float group_sum(float v) {
+  v += __shfl_xor(v, 16);
+  return v + __shfl_xor(v, 32);
+}
+__device__ __forceinline__ float wave_sum(float v) {
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// 16 contiguous floats of `row` starting at column 16*grp (zero if !ok), scaled.
+__device__ __forceinline__ void load_row16(const float* __restrict__ p, bool ok, float scale,
+                                           float (&dst)[KPL]) {
+  if (ok) {
+    const float4* q = reinterpret_cast<const float4*>(p);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const float4 v = q[s];
+      dst[4 * s + 0] = v.x * scale; dst[4 * s + 1] = v.y * scale;
+      dst[4 * s + 2] = v.z * scale; dst[4 * s + 3] = v.w * scale;
+    }
+  } else {
+#pragma unroll
+    for (int s = 0; s < KPL; ++s) dst[s] = 0.0f;
+  }
+}
+__device__ __forceinline__ f32x4 mm_rows(const float (&a)[KPL], const float (&b)[KPL], f32x4 c) {
+#pragma unroll
+  for (int s = 0; s < KPL; ++s) c = mfma16(a[s], b[s], c);
+  return c;
+}
+__device__ __forceinline__ float sumsq16(const float (&a)[KPL]) {
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < KPL; ++i) s += a[i] * a[i];
+  return s;
+}
+
+// ordered encoding so that unsigned atomicMax == float max (memset 0 is below every float)
+__device__ __forceinline__ uint32_t enc_f32(float f) {
+  const uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+__device__ __forceinline__ float dec_f32(uint32_t e) {
+  return __uint_as_float((e & 0x80000000u) ? (e & 0x7FFFFFFFu) : ~e);
+}
+
+struct Seg {
+  int g, h, row0, n0, n1, i, grp;
+  bool valid;
+};
+__device__ __forceinline__ Seg tile_work(const int32_t* ptr, const int32_t* tile_graph,
+                                         const int32_t* tile_row0, int64_t n_work, int H) {
+  Seg s;
+  s.valid = false;
+  const int lane = threadIdx.x & 63;
+  const int64_t w = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  s.i = lane & 15;
+  s.grp = lane >> 4;
+  if (w >= n_work) return s;
+  const int64_t tile = w / H;
+  s.h = (int)(w - tile * H);
+  s.g = tile_graph[tile];
+  if (s.g < 0) return s;
+  s.row0 = tile_row0[tile];
+  s.n0 = ptr[s.g];
+  s.n1 = ptr[s.g + 1];
+  s.valid = true;
+  return s;
+}
+
+// global key max incl. the zero logits of padded rows (only when the graph is shorter than Nmax)
+__device__ __forceinline__ float key_max_M(const unsigned long long* kmax, int gh, int pad) {
+  const float mr = dec_f32((uint32_t)(kmax[gh] >> 32));
+  return pad > 0 ? fmaxf(mr, 0.0f) : mr;
+}
+
+// ---------------------------------------------------------------------------------------------
+// F1: per (key tile, head): max over (key, feature) of dd_k, with its position, via atomicMax.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_favor_kmax(
+    const float* __restrict__ qkv, int64_t ld, const float* __restrict__ P, int m, float c,
+    const int32_t* __restrict__ ptr, const int32_t* __restrict__ tile_graph,
+    const int32_t* __restrict__ tile_row0, int64_t n_work, int H,
+    unsigned long long* __restrict__ kmax) {
+  const Seg s = tile_work(ptr, tile_graph, tile_row0, n_work, H);
+  if (!s.valid) return;
+  const int inner = H * DH;
+  const int krow = s.row0 + s.i;
+  float kv[KPL];
+  load_row16(qkv + (int64_t)krow * ld + inner + s.h * DH + 16 * s.grp, krow < s.n1, c, kv);
+  float best = -INFINITY;
+  uint32_t best_idx = 0;
+  for (int mt = 0; mt < MT; ++mt) {
+    const int prow = mt * 16 + s.i;
+    float pv[KPL];
+    load_row16(P + (int64_t)prow * DH + 16 * s.grp, prow < m, 1.0f, pv);
+    const f32x4 dd = mm_rows(pv, kv, zero4());  // [feature 4g+r][key l&15]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int f = mt * 16 + 4 * s.grp + r;
+      if (f < m && krow < s.n1 && dd[r] > best) {
+        best = dd[r];
+        best_idx = (uint32_t)(krow - s.n0) * 272u + (uint32_t)f;
+      }
+    }
+  }
+  // wave arg-max (ties -> smallest index), then one 64-bit atomicMax per wave
+  unsigned long long key = ((unsigned long long)enc_f32(best) << 32) | (0xFFFFFFFFu - best_idx);
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long other = __shfl_xor(key, o);
+    key = other > key ? other : key;
+  }
+  if ((threadIdx.x & 63) == 0) atomicMax(&kmax[s.g * H + s.h], key);
+}
+
+// ---------------------------------------------------------------------------------------------
+// F2: per (graph, head, feature tile): ctx[m][64] = phi_k^T v and ksum[m] over all keys.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_favor_ctx(
+    const float* __restrict__ qkv, int64_t ld, const float* __restrict__ P, int m, float c,
+    float ratio, const int32_t* __restrict__ ptr, const int32_t* __restrict__ nmax_dev, int64_t B,
+    int H, const unsigned long long* __restrict__ kmax, float* __restrict__ ctx,
+    float* __restrict__ ksum) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (w >= B * H * MT) return;
+  const int mt = (int)(w % MT);
+  const int gh = (int)(w / MT);
+  const int g = gh / H, h = gh - g * H;
+  const int n0 = ptr[g], n1 = ptr[g + 1];
+  const int i = lane & 15, grp = lane >> 4;
+  const int inner = H * DH;
+  const int pad = nmax_dev[0] - (n1 - n0);
+  const float M = key_max_M(kmax, gh, pad);
+  const int f = mt * 16 + i;  // this lane's feature column
+  float pv[KPL];
+  load_row16(P + (int64_t)f * DH + 16 * grp, f < m, 1.0f, pv);
+  f32x4 acc[4];
+#pragma unroll
+  for (int et = 0; et < 4; ++et) acc[et] = zero4();
+  float ks = 0.0f;
+  for (int kb = n0; kb < n1; kb += 16) {
+    const int krow = kb + i;
+    float kv[KPL];
+    load_row16(qkv + (int64_t)krow * ld + inner + h * DH + 16 * grp, krow < n1, c, kv);
+    const float nrm = group_sum(sumsq16(kv));       // |c k|^2 of row (l&15)
+    f32x4 dd = mm_rows(kv, pv, zero4());            // [key 4g+r][feature l&15]
+    f32x4 phi;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = kb + 4 * grp + r;
+      const float dg = 0.5f * __shfl(nrm, 4 * grp + r);
+      const bool ok = key < n1 && f < m;
+      phi[r] = ok ? ratio * (expf(dd[r] - dg - M) + FEPS) : 0.0f;
+      ks += phi[r];
+    }
+#pragma unroll
+    for (int et = 0; et < 4; ++et)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kb + 4 * grp + r;
+        const float vv = key < n1 ? qkv[(int64_t)key * ld + 2 * inner + h * DH + et * 16 + i] : 0.0f;
+        acc[et] = mfma16(vv, phi[r], acc[et]);      // ctx^T[e 4g+r'][feature l&15]
+      }
+  }
+  ks = group_sum(ks);
+  if (f < m) {
+    float* cp = ctx + ((int64_t)gh * 272 + f) * DH;
+#pragma unroll
+    for (int et = 0; et < 4; ++et)
+      *reinterpret_cast<float4*>(cp + et * 16 + 4 * grp) =
+          make_float4(acc[et][0], acc[et][1], acc[et][2], acc[et][3]);
+    if (grp == 0) ksum[(int64_t)gh * 272 + f] = ks + (float)pad * (ratio * (expf(-M) + FEPS));
+  }
+}
+
+// dd_q^T tiles [feature 4g+r + 16mt][query l&15] and phi_q for one 16-query tile
+__device__ __forceinline__ void query_features(const float (&qv)[KPL], const float* __restrict__ P,
+                                               int m, int i, int grp, float (&dd)[MT][4], float& mq,
+                                               bool have_mq) {
+  float mx = -INFINITY;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int prow = mt * 16 + i;
+    float pv[KPL];
+    load_row16(P + (int64_t)prow * DH + 16 * grp, prow < m, 1.0f, pv);
+    const f32x4 t = mm_rows(pv, qv, zero4());
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      dd[mt][r] = t[r];
+      if (mt * 16 + 4 * grp + r < m) mx = fmaxf(mx, t[r]);
+    }
+  }
+  if (!have_mq) mq = group_max(mx);
+}
+
+// ---------------------------------------------------------------------------------------------
+// F3: per (query tile, head): out = (phi_q ctx) / (phi_q . ksum); saves mq (row max) and D.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_favor_out(
+    const float* __restrict__ qkv, int64_t ld, const float* __restrict__ P, int m, float c,
+    float ratio, const int32_t* __restrict__ ptr, const int32_t* __restrict__ tile_graph,
+    const int32_t* __restrict__ tile_row0, int64_t n_work, int64_t N, int H,
+    const float* __restrict__ ctx, const float* __restrict__ ksum, float* __restrict__ out,
+    float* __restrict__ mq_out, float* __restrict__ D_out) {
+  const Seg s = tile_work(ptr, tile_graph, tile_row0, n_work, H);
+  if (!s.valid) return;
+  const int inner = H * DH;
+  const int gh = s.g * H + s.h;
+  const int qrow = s.row0 + s.i;
+  const bool q_ok = qrow < s.n1;
+  float qv[KPL];
+  load_row16(qkv + (int64_t)qrow * ld + s.h * DH + 16 * s.grp, q_ok, c, qv);
+  const float half_nrm = 0.5f * group_sum(sumsq16(qv));
+  float dd[MT][4];
+  float mq;
+  query_features(qv, P, m, s.i, s.grp, dd, mq, false);
+  float dpart = 0.0f;
+  f32x4 acc[4];
+#pragma unroll
+  for (int et = 0; et < 4; ++et) acc[et] = zero4();
+  const float* cbase = ctx + (int64_t)gh * 272 * DH;
+  const float* kbase = ksum + (int64_t)gh * 272;
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int f = mt * 16 + 4 * s.grp + r;
+      const float phi = f < m ? ratio * (expf(dd[mt][r] - half_nrm - mq) + FEPS) : 0.0f;
+      dd[mt][r] = phi;
+      dpart += f < m ? phi * kbase[f] : 0.0f;
+    }
+#pragma unroll
+    for (int et = 0; et < 4; ++et)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int f = mt * 16 + 4 * s.grp + r;
+        const float cv = f < m ? cbase[(int64_t)f * DH + et * 16 + s.i] : 0.0f;
+        acc[et] = mfma16(cv, dd[mt][r], acc[et]);   // num^T[e 4g+r'][query l&15]
+      }
+  }
+  const float D = group_sum(dpart);
+  if (q_ok) {
+    const float inv = 1.0f / D;
+    float* o = out + (int64_t)qrow * inner + s.h * DH;
+#pragma unroll
+    for (int et = 0; et < 4; ++et)
+      *reinterpret_cast<float4*>(o + et * 16 + 4 * s.grp) =
+          make_float4(acc[et][0] * inv, acc[et][1] * inv, acc[et][2] * inv, acc[et][3] * inv);
+    if (s.grp == 0) {
+      mq_out[(int64_t)s.h * N + qrow] = mq;
+      D_out[(int64_t)s.h * N + qrow] = D;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// B0: gD[h][q] = -sum_e g_out*out / D  (16 lanes per (q, h), float4 each)
+// ---------------------------------------------------------------------------------------------
+__global__ void k_favor_bwd_gd(const float* __restrict__ g_out, const float* __restrict__ out,
+                               const float* __restrict__ D, int64_t N, int H,
+                               float* __restrict__ gD) {
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t item = t >> 4;
+  const int sub = (int)(t & 15);
+  float acc = 0.0f;
+  const bool ok = item < N * H;
+  int64_t q = 0;
+  int h = 0;
+  if (ok) {
+    q = item / H;
+    h = (int)(item - q * H);
+    const float4 a = *reinterpret_cast<const float4*>(g_out + q * (int64_t)(H * DH) + h * DH + 4 * sub);
+    const float4 b = *reinterpret_cast<const float4*>(out + q * (int64_t)(H * DH) + h * DH + 4 * sub);
+    acc = a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w;
+  }
+  for (int o = 8; o > 0; o >>= 1) acc += __shfl_xor(acc, o);
+  if (ok && sub == 0) gD[(int64_t)h * N + q] = -acc / D[(int64_t)h * N + q];
+}
+
+// ---------------------------------------------------------------------------------------------
+// B1: per (query tile, head): g_q
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_favor_bwd_q(
+    const float* __restrict__ g_out, const float* __restrict__ qkv, int64_t ld,
+    const float* __restrict__ P, int m, float c, float ratio, const int32_t* __restrict__ ptr,
+    const int32_t* __restrict__ tile_graph, const int32_t* __restrict__ tile_row0, int64_t n_work,
+    int64_t N, int H, const float* __restrict__ ctx, const float* __restrict__ ksum,
+    const float* __restrict__ mq_in, const float* __restrict__ D_in, const float* __restrict__ gD_in,
+    float* __restrict__ d_qkv, int64_t ldg) {
+  const Seg s = tile_work(ptr, tile_graph, tile_row0, n_work, H);
+  if (!s.valid) return;
+  const int inner = H * DH;
+  const int gh = s.g * H + s.h;
+  const int qrow = s.row0 + s.i;
+  const bool q_ok = qrow < s.n1;
+  float qv[KPL], gn[KPL];
+  load_row16(qkv + (int64_t)qrow * ld + s.h * DH + 16 * s.grp, q_ok, c, qv);
+  const float half_nrm = 0.5f * group_sum(sumsq16(qv));
+  float mq = q_ok ? mq_in[(int64_t)s.h * N + qrow] : 0.0f;
+  const float Dq = q_ok ? D_in[(int64_t)s.h * N + qrow] : 1.0f;
+  const float gDq = q_ok ? gD_in[(int64_t)s.h * N + qrow] : 0.0f;
+  load_row16(g_out + (int64_t)qrow * inner + s.h * DH + 16 * s.grp, q_ok, 1.0f / Dq, gn);  // g_num
+  float dd[MT][4];
+  query_features(qv, P, m, s.i, s.grp, dd, mq, true);
+  const float* cbase = ctx + (int64_t)gh * 272 * DH;
+  const float* kbase = ksum + (int64_t)gh * 272;
+  float s1 = 0.0f;
+  float gA[MT][4];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int crow = mt * 16 + s.i;
+    float cv[KPL];
+    load_row16(cbase + (int64_t)crow * DH + 16 * s.grp, crow < m, 1.0f, cv);
+    const f32x4 gphi = mm_rows(cv, gn, zero4());   // [feature 4g+r][query]: sum_e ctx[f][e] g_num[q][e]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int f = mt * 16 + 4 * s.grp + r;
+      float ga = 0.0f;
+      if (f < m) {
+        const float ex = ratio * expf(dd[mt][r] - half_nrm - mq);   // = phi - r*eps
+        ga = (gphi[r] + kbase[f] * gDq) * ex;
+      }
+      gA[mt][r] = ga;
+      s1 += ga;
+    }
+  }
+  s1 = group_sum(s1);                                 // sum_m g_A of this query
+  f32x4 acc[4];
+#pragma unroll
+  for (int dt = 0; dt < 4; ++dt) acc[dt] = zero4();
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int f = mt * 16 + 4 * s.grp + r;
+      // the row max is subtracted inside the exponent: its gradient (-s1) lands on the arg-max
+      if (f < m && dd[mt][r] == mq) gA[mt][r] -= s1;
+    }
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int f = mt * 16 + 4 * s.grp + r;
+        const float pv = f < m ? P[(int64_t)f * DH + dt * 16 + s.i] : 0.0f;
+        acc[dt] = mfma16(pv, gA[mt][r], acc[dt]);   // g_q^T[dh 4g+r'][query]
+      }
+  }
+  if (q_ok) {
+    const float* qsrc = qkv + (int64_t)qrow * ld + s.h * DH;
+    float* o = d_qkv + (int64_t)qrow * ldg + s.h * DH;
+    const float k2 = -s1 * c * c;                     // d(diag)/dq = c^2 q, g_diag = -s1
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) {
+      const int col = dt * 16 + 4 * s.grp;
+      const float4 qq = *reinterpret_cast<const float4*>(qsrc + col);
+      *reinterpret_cast<float4*>(o + col) =
+          make_float4(c * acc[dt][0] + k2 * qq.x, c * acc[dt][1] + k2 * qq.y,
+                      c * acc[dt][2] + k2 * qq.z, c * acc[dt][3] + k2 * qq.w);
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// B2: per (graph, head, feature tile): g_ctx[m][64] = sum_q phi_q g_num, g_ksum[m] = sum_q gD phi_q
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_favor_bwd_ctx(
+    const float* __restrict__ g_out, const float* __restrict__ qkv, int64_t ld,
+    const float* __restrict__ P, int m, float c, float ratio, const int32_t* __restrict__ ptr,
+    int64_t B, int64_t N, int H, const float* __restrict__ mq_in, const float* __restrict__ D_in,
+    const float* __restrict__ gD_in, float* __restrict__ g_ctx, float* __restrict__ g_ksum) {
+  const int lane = threadIdx.x & 63;
+  const int64_t w = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (w >= B * H * MT) return;
+  const int mt = (int)(w % MT);
+  const int gh = (int)(w / MT);
+  const int g = gh / H, h = gh - g * H;
+  const int n0 = ptr[g], n1 = ptr[g + 1];
+  const int i = lane & 15, grp = lane >> 4;
+  const int inner = H * DH;
+  const int f = mt * 16 + i;
+  float pv[KPL];
+  load_row16(P + (int64_t)f * DH + 16 * grp, f < m, 1.0f, pv);
+  f32x4 acc[4];
+#pragma unroll
+  for (int et = 0; et < 4; ++et) acc[et] = zero4();
+  float gks = 0.0f;
+  for (int qb = n0; qb < n1; qb += 16) {
+    const int qrow = qb + i;
+    float qv[KPL];
+    load_row16(qkv + (int64_t)qrow * ld + h * DH + 16 * grp, qrow < n1, c, qv);
+    const float nrm = group_sum(sumsq16(qv));
+    const f32x4 dd = mm_rows(qv, pv, zero4());     // [query 4g+r][feature l&15]
+    f32x4 phi;
+    float invD[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qq = qb + 4 * grp + r;
+      const bool ok = qq < n1 && f < m;
+      const float dg = 0.5f * __shfl(nrm, 4 * grp + r);
+      const float mqv = qq < n1 ? mq_in[(int64_t)h * N + qq] : 0.0f;
+      phi[r] = ok ? ratio * (expf(dd[r] - dg - mqv) + FEPS) : 0.0f;
+      invD[r] = qq < n1 ? 1.0f / D_in[(int64_t)h * N + qq] : 0.0f;
+      gks += qq < n1 ? gD_in[(int64_t)h * N + qq] * phi[r] : 0.0f;
+    }
+#pragma unroll
+    for (int et = 0; et < 4; ++et)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int qq = qb + 4 * grp + r;
+        const float gv = qq < n1 ? g_out[(int64_t)qq * inner + h * DH + et * 16 + i] * invD[r] : 0.0f;
+        acc[et] = mfma16(gv, phi[r], acc[et]);     // g_ctx^T[e 4g+r'][feature l&15]
+      }
+  }
+  gks = group_sum(gks);
+  if (f < m) {
+    float* cp = g_ctx + ((int64_t)gh * 272 + f) * DH;
+#pragma unroll
+    for (int et = 0; et < 4; ++et)
+      *reinterpret_cast<float4*>(cp + et * 16 + 4 * grp) =
+          make_float4(acc[et][0], acc[et][1], acc[et][2], acc[et][3]);
+    if (grp == 0) g_ksum[(int64_t)gh * 272 + f] = gks;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// B3: per (key tile, head): g_k (without the key-max term), g_v, and this tile's share of g_M
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_favor_bwd_k(
+    const float* __restrict__ qkv, int64_t ld, const float* __restrict__ P, int m, float c,
+    float ratio, const int32_t* __restrict__ ptr, const int32_t* __restrict__ tile_graph,
+    const int32_t* __restrict__ tile_row0, int64_t n_work, const int32_t* __restrict__ nmax_dev,
+    int H, const unsigned long long* __restrict__ kmax, const float* __restrict__ g_ctx,
+    const float* __restrict__ g_ksum, float* __restrict__ d_qkv, int64_t ldg,
+    float* __restrict__ gM_part) {
+  const Seg s = tile_work(ptr, tile_graph, tile_row0, n_work, H);
+  const int64_t w = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (!s.valid) {
+    if (w < n_work && (threadIdx.x & 63) == 0) gM_part[w] = 0.0f;
+    return;
+  }
+  const int inner = H * DH;
+  const int gh = s.g * H + s.h;
+  const int krow = s.row0 + s.i;
+  const bool k_ok = krow < s.n1;
+  const int pad = nmax_dev[0] - (s.n1 - s.n0);
+  const float M = key_max_M(kmax, gh, pad);
+  float kv[KPL], vv[KPL];
+  load_row16(qkv + (int64_t)krow * ld + inner + s.h * DH + 16 * s.grp, k_ok, c, kv);
+  load_row16(qkv + (int64_t)krow * ld + 2 * inner + s.h * DH + 16 * s.grp, k_ok, 1.0f, vv);
+  const float half_nrm = 0.5f * group_sum(sumsq16(kv));
+  const float* gcb = g_ctx + (int64_t)gh * 272 * DH;
+  const float* gkb = g_ksum + (int64_t)gh * 272;
+  float sk = 0.0f;
+  f32x4 accK[4], accV[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) { accK[t] = zero4(); accV[t] = zero4(); }
+  for (int mt = 0; mt < MT; ++mt) {
+    const int prow = mt * 16 + s.i;
+    float pv[KPL], gc[KPL];
+    load_row16(P + (int64_t)prow * DH + 16 * s.grp, prow < m, 1.0f, pv);
+    load_row16(gcb + (int64_t)prow * DH + 16 * s.grp, prow < m, 1.0f, gc);
+    const f32x4 dd = mm_rows(pv, kv, zero4());     // [feature 4g+r][key l&15]
+    const f32x4 gphi = mm_rows(gc, vv, zero4());   // sum_e g_ctx[f][e] v[key][e]
+    f32x4 phi, gB;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int f = mt * 16 + 4 * s.grp + r;
+      const bool ok = f < m && k_ok;
+      const float ex = ok ? ratio * expf(dd[r] - half_nrm - M) : 0.0f;
+      phi[r] = ok ? ex + ratio * FEPS : 0.0f;
+      gB[r] = ok ? (gphi[r] + gkb[f]) * ex : 0.0f;
+      sk += gB[r];
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int f = mt * 16 + 4 * s.grp + r;
+        const float pe = f < m ? P[(int64_t)f * DH + t * 16 + s.i] : 0.0f;
+        const float ge = f < m ? gcb[(int64_t)f * DH + t * 16 + s.i] : 0.0f;
+        accK[t] = mfma16(pe, gB[r], accK[t]);      // g_k^T[dh][key] += P^T[dh][f] g_B[f][key]
+        accV[t] = mfma16(ge, phi[r], accV[t]);     // g_v^T[e][key]  += g_ctx^T[e][f] phi_k^T[f][key]
+      }
+  }
+  sk = group_sum(sk);                                // sum_f g_B for key (l&15)
+  if (k_ok) {
+    const float* ksrc = qkv + (int64_t)krow * ld + inner + s.h * DH;
+    float* ok_ = d_qkv + (int64_t)krow * ldg + inner + s.h * DH;
+    float* ov_ = d_qkv + (int64_t)krow * ldg + 2 * inner + s.h * DH;
+    const float k2 = -sk * c * c;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int col = t * 16 + 4 * s.grp;
+      const float4 kk = *reinterpret_cast<const float4*>(ksrc + col);
+      *reinterpret_cast<float4*>(ok_ + col) =
+          make_float4(c * accK[t][0] + k2 * kk.x, c * accK[t][1] + k2 * kk.y,
+                      c * accK[t][2] + k2 * kk.z, c * accK[t][3] + k2 * kk.w);
+      *reinterpret_cast<float4*>(ov_ + col) =
+          make_float4(accV[t][0], accV[t][1], accV[t][2], accV[t][3]);
+    }
+  }
+  // this tile's contribution to -g_M: sum over its valid keys of sk (each key counted once: group 0)
+  const float part = wave_sum((s.grp == 0 && k_ok) ? sk : 0.0f);
+  if ((threadIdx.x & 63) == 0) gM_part[w] = part;
+}
+
+// ---------------------------------------------------------------------------------------------
+// B4: per (graph, head): g_M = -(sum of tile parts) - pad * sum_f g_ksum[f] * r exp(-M); it lands on
+// the arg-max element of dd_k when that element (not a padded row's 0 logit) is the global max.
+// ---------------------------------------------------------------------------------------------
+__global__ void k_favor_bwd_kmax_fix(const float* __restrict__ P, int m, float c, float ratio,
+                                     const int32_t* __restrict__ ptr,
+                                     const int32_t* __restrict__ nmax_dev, int64_t B, int H,
+                                     const unsigned long long* __restrict__ kmax,
+                                     const float* __restrict__ g_ksum,
+                                     const float* __restrict__ gM_part, float* __restrict__ d_qkv,
+                                     int64_t ldg) {
+  const int gh = blockIdx.x;
+  if (gh >= B * H) return;
+  const int lane = threadIdx.x;  // 64 threads
+  const int g = gh / H, h = gh - g * H;
+  const int n0 = ptr[g], n1 = ptr[g + 1];
+  if (n1 <= n0) return;
+  const int pad = nmax_dev[0] - (n1 - n0);
+  const unsigned long long km = kmax[gh];
+  const float m_real = dec_f32((uint32_t)(km >> 32));
+  if (pad > 0 && !(m_real > 0.0f)) return;   // the max is a padded row's zero logit: constant
+  const uint32_t idx = 0xFFFFFFFFu - (uint32_t)(km & 0xFFFFFFFFu);
+  const int key = n0 + (int)(idx / 272u), f = (int)(idx % 272u);
+  // tile slots of this graph: (n0>>4)+g .. , same map as gps_attn_tile_map; parts are indexed tile*H+h
+  float acc = 0.0f;
+  const int t0 = (n0 >> 4) + g;
+  const int nt = (n1 - n0 + 15) >> 4;
+  for (int t = lane; t < nt; t += 64) acc += gM_part[(int64_t)(t0 + t) * H + h];
+  float gM = -wave_sum(acc);
+  if (pad > 0) {
+    float ks = 0.0f;
+    for (int j = lane; j < m; j += 64) ks += g_ksum[(int64_t)gh * 272 + j];
+    gM -= (float)pad * wave_sum(ks) * ratio * expf(-m_real);
+  }
+  d_qkv[(int64_t)key * ldg + H * DH + h * DH + lane] += c * gM * P[(int64_t)f * DH + lane];
+}
+
+__global__ void k_segment_max_len(const int32_t* __restrict__ ptr, int64_t B, int32_t* __restrict__ out) {
+  int best = 0;
+  for (int64_t g = threadIdx.x; g < B; g += blockDim.x) best = max(best, ptr[g + 1] - ptr[g]);
+  for (int o = 32; o > 0; o >>= 1) best = max(best, __shfl_xor(best, o));
+  __shared__ int sm[16];
+  if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = best;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < (int)(blockDim.x >> 6); ++w) best = max(best, sm[w]);
+    out[0] = best;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int gps_segment_max_len(const int32_t* ptr, int64_t B, int32_t* nmax, gps_stream_t stream) {
+  GPS_REQUIRE(ptr && nmax && B >= 0, "gps_segment_max_len: bad arguments");
+  k_segment_max_len<<<1, 1024, 0, gps::as_stream(stream)>>>(ptr, B, nmax);
+  return gps::launch_status("gps_segment_max_len");
+}
+
+size_t gps_favor_workspace_floats(int64_t B, int H) { return (size_t)B * H * 272 * (DH + 1); }
+
+int gps_favor_fwd(const float* qkv, int64_t ld_qkv, const float* proj, int m, const int32_t* ptr,
+                  const int32_t* nmax, const int32_t* tile_graph, const int32_t* tile_row0,
+                  int64_t max_tiles, int64_t N, int64_t B, int H, int dh, float* out, float* ctx,
+                  float* ksum, uint64_t* kmax, float* mq, float* D, gps_stream_t stream) {
+  GPS_REQUIRE(N >= 0 && B >= 0 && H > 0 && max_tiles >= 0, "gps_favor_fwd: bad sizes");
+  if (dh != DH || m <= 0 || m > 16 * MT) {
+    gps::set_error("gps_favor_fwd: only dim_head=64 with nb_features<=272 is compiled (got dh=%d m=%d)", dh, m);
+    return GPS_EUNSUPPORTED;
+  }
+  GPS_REQUIRE(ld_qkv >= 3LL * H * DH && ld_qkv % 4 == 0, "gps_favor_fwd: bad ld_qkv");
+  if (N == 0 || B == 0) return GPS_OK;
+  GPS_REQUIRE(qkv && proj && ptr && nmax && tile_graph && tile_row0 && out && ctx && ksum && kmax && mq && D,
+              "gps_favor_fwd: null buffer");
+  hipStream_t s = gps::as_stream(stream);
+  const float c = powf((float)DH, -0.25f), ratio = 1.0f / sqrtf((float)m);
+  if (hipMemsetAsync(kmax, 0, sizeof(uint64_t) * B * H, s) != hipSuccess)
+    return gps::launch_status("gps_favor_fwd/memset");
+  const int64_t n_work = max_tiles * H;
+  k_favor_kmax<<<gps::grid_for(n_work, 4), 256, 0, s>>>(qkv, ld_qkv, proj, m, c, ptr, tile_graph, tile_row0,
+                                                        n_work, H, (unsigned long long*)kmax);
+  k_favor_ctx<<<gps::grid_for(B * H * MT, 4), 256, 0, s>>>(qkv, ld_qkv, proj, m, c, ratio, ptr, nmax, B, H,
+                                                           (const unsigned long long*)kmax, ctx, ksum);
+  k_favor_out<<<gps::grid_for(n_work, 4), 256, 0, s>>>(qkv, ld_qkv, proj, m, c, ratio, ptr, tile_graph,
+                                                       tile_row0, n_work, N, H, ctx, ksum, out, mq, D);
+  return gps::launch_status("gps_favor_fwd");
+}
+
+int gps_favor_bwd(const float* g_out, const float* qkv, int64_t ld_qkv, const float* proj, int m,
+                  const float* out, const int32_t* ptr, const int32_t* nmax, const int32_t* tile_graph,
+                  const int32_t* tile_row0, int64_t max_tiles, int64_t N, int64_t B, int H, int dh,
+                  const float* ctx, const float* ksum, const uint64_t* kmax, const float* mq,
+                  const float* D, float* gD, float* g_ctx, float* g_ksum, float* gM_part,
+                  float* d_qkv, int64_t ld_dqkv, gps_stream_t stream) {
+  GPS_REQUIRE(N >= 0 && B >= 0 && H > 0 && max_tiles >= 0, "gps_favor_bwd: bad sizes");
+  if (dh != DH || m <= 0 || m > 16 * MT) {
+    gps::set_error("gps_favor_bwd: only dim_head=64 with nb_features<=272 is compiled (got dh=%d m=%d)", dh, m);
+    return GPS_EUNSUPPORTED;
+  }
+  GPS_REQUIRE(ld_qkv >= 3LL * H * DH && ld_dqkv >= 3LL * H * DH && ld_qkv % 4 == 0 && ld_dqkv % 4 == 0,
+              "gps_favor_bwd: bad leading dims");
+  if (N == 0 || B == 0) return GPS_OK;
+  GPS_REQUIRE(g_out && qkv && proj && out && ptr && nmax && tile_graph && tile_row0 && ctx && ksum && kmax &&
+                  mq && D && gD && g_ctx && g_ksum && gM_part && d_qkv,
+              "gps_favor_bwd: null buffer");
+  hipStream_t s = gps::as_stream(stream);
+  const float c = powf((float)DH, -0.25f), ratio = 1.0f / sqrtf((float)m);
+  const int64_t n_work = max_tiles * H;
+  k_favor_bwd_gd<<<gps::grid_for(N * H * 16, 256), 256, 0, s>>>(g_out, out, D, N, H, gD);
+  k_favor_bwd_q<<<gps::grid_for(n_work, 4), 256, 0, s>>>(g_out, qkv, ld_qkv, proj, m, c, ratio, ptr, tile_graph,
+                                                         tile_row0, n_work, N, H, ctx, ksum, mq, D, gD, d_qkv,
+                                                         ld_dqkv);
+  k_favor_bwd_ctx<<<gps::grid_for(B * H * MT, 4), 256, 0, s>>>(g_out, qkv, ld_qkv, proj, m, c, ratio, ptr, B, N,
+                                                               H, mq, D, gD, g_ctx, g_ksum);
+  k_favor_bwd_k<<<gps::grid_for(n_work, 4), 256, 0, s>>>(qkv, ld_qkv, proj, m, c, ratio, ptr, tile_graph,
+                                                         tile_row0, n_work, nmax, H,
+                                                         (const unsigned long long*)kmax, g_ctx, g_ksum, d_qkv,
+                                                         ld_dqkv, gM_part);
+  k_favor_bwd_kmax_fix<<<(unsigned)(B * H), 64, 0, s>>>(proj, m, c, ratio, ptr, nmax, B, H,
+                                                        (const unsigned long long*)kmax, g_ksum, gM_part,
+                                                        d_qkv, ld_dqkv);
+  return gps::launch_status("gps_favor_bwd");
+}
+
+}  // extern "C"

@@ -43,3 +43,11 @@ def compute_loss(pred, true):
     if cfg.model.loss_fun == 'mse':
         return F.mse_loss(pred, true), pred
     raise ValueError(f"Loss function '{cfg.model.loss_fun}' not supported")
+
+
+def train_loss(pred, true):
+    """The loss dispatch of the reference's train_epoch (graphgps/train/custom_train.py:24-29):
+    ogbg-code2 calls the sub-token CE directly, everything else goes through compute_loss."""
+    if cfg.dataset.name == 'ogbg-code2':
+        return subtoken_cross_entropy(pred, true)
+    return compute_loss(pred, true)

@@ -360,3 +360,81 @@ def segment_pool(x: torch.Tensor, gi: GraphIndex, mode: str = "mean") -> torch.T
     if mode not in ("add", "sum", "mean"):
         raise ValueError(f"segment_pool: unsupported mode {mode!r}")
     return _SegmentPool.apply(x, gi, mode == "mean")
+
+
+# -------------------------------------------------------------------------------------------
+# FAVOR+ (Performer) linear attention over ptr segments
+# -------------------------------------------------------------------------------------------
+def _nmax_dev(gi: GraphIndex) -> torch.Tensor:
+    """Longest graph of the batch as a device scalar (the reference's to_dense_batch Nmax)."""
+    nm = getattr(gi, "_nmax", None)
+    if nm is None:
+        L = _lib.load()
+        dev = gi.ptr.device
+        nm = torch.zeros(1, dtype=torch.int32, device=dev)
+        check(L.gps_segment_max_len(ptr(gi.ptr), gi.B, ptr(nm), current_stream(dev)),
+              "gps_segment_max_len")
+        gi._nmax = nm
+    return nm
+
+
+class _FavorAttention(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv: torch.Tensor, proj: torch.Tensor, gi: GraphIndex, num_heads: int):
+        L = _lib.load()
+        dev = _require_cuda(qkv, proj)
+        qkv, proj = _f32c(qkv, "qkv"), _f32c(proj, "projection_matrix")
+        N, B, H = gi.N, gi.B, int(num_heads)
+        inner = qkv.shape[1] // 3
+        dh = inner // H
+        m = proj.shape[0]
+        if qkv.shape != (N, 3 * inner) or dh * H != inner or proj.shape[1] != dh:
+            raise _lib.GpsHipError(f"favor_attention: qkv {tuple(qkv.shape)} / proj "
+                                   f"{tuple(proj.shape)} vs N={N} H={H}")
+        f32 = dict(dtype=torch.float32, device=dev)
+        out = torch.empty(N, inner, **f32)
+        cbuf = torch.empty(B * H, 272, dh, **f32)
+        ksum = torch.empty(B * H, 272, **f32)
+        kmax = torch.empty(B * H, dtype=torch.int64, device=dev)
+        mq = torch.empty(H, N, **f32)
+        D = torch.empty(H, N, **f32)
+        nmax = _nmax_dev(gi)
+        check(L.gps_favor_fwd(ptr(qkv), qkv.shape[1], ptr(proj), m, ptr(gi.ptr), ptr(nmax),
+                              ptr(gi.tile_graph), ptr(gi.tile_row0), gi.max_tiles, N, B, H, dh,
+                              ptr(out), ptr(cbuf), ptr(ksum), ptr(kmax), ptr(mq), ptr(D),
+                              current_stream(dev)), "gps_favor_fwd")
+        ctx.save_for_backward(qkv, proj, out, cbuf, ksum, kmax, mq, D)
+        ctx.gi, ctx.H, ctx.dh = gi, H, dh
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out: torch.Tensor):
+        L = _lib.load()
+        qkv, proj, out, cbuf, ksum, kmax, mq, D = ctx.saved_tensors
+        gi: GraphIndex = ctx.gi
+        dev = qkv.device
+        g_out = _f32c(g_out, "g_out")
+        N, B, H, dh = gi.N, gi.B, ctx.H, ctx.dh
+        f32 = dict(dtype=torch.float32, device=dev)
+        gD = torch.empty(H, N, **f32)
+        g_ctx = torch.empty_like(cbuf)
+        g_ksum = torch.empty_like(ksum)
+        gm_part = torch.empty(max(gi.max_tiles * H, 1), **f32)
+        d_qkv = torch.empty_like(qkv)
+        check(L.gps_favor_bwd(ptr(g_out), ptr(qkv), qkv.shape[1], ptr(proj), proj.shape[0], ptr(out),
+                              ptr(gi.ptr), ptr(_nmax_dev(gi)), ptr(gi.tile_graph), ptr(gi.tile_row0),
+                              gi.max_tiles, N, B, H, dh, ptr(cbuf), ptr(ksum), ptr(kmax), ptr(mq),
+                              ptr(D), ptr(gD), ptr(g_ctx), ptr(g_ksum), ptr(gm_part), ptr(d_qkv),
+                              d_qkv.shape[1], current_stream(dev)), "gps_favor_bwd")
+        return d_qkv, None, None, None
+
+
+def favor_attention(qkv: torch.Tensor, proj: torch.Tensor, gi: GraphIndex,
+                    num_heads: int) -> torch.Tensor:
+    """Performer FAVOR+ attention per graph and head, straight off ``ptr`` (no padding).
+
+    ``qkv`` = [N, 3*64H] (to_q | to_k | to_v outputs), ``proj`` = the fixed
+    ``fast_attention.projection_matrix`` buffer [m, 64].  Reproduces the reference's result ON
+    THE PADDED BATCH, including the padded-key contribution to the normaliser
+    (graphgps/layer/performer_layer.py:485-487)."""
+    return _FavorAttention.apply(qkv, proj, gi, num_heads)

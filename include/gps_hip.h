@@ -129,6 +129,33 @@ int gps_seg_attn_bwd(const float* d_out, const float* qkv, int64_t ld_qkv, const
                      int64_t ld_dqkv, gps_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * FAVOR+ (Performer softmax-kernel linear attention) over `ptr` segments on fp32 MFMA.
+ * Replaces to_dense_batch + performer_pytorch.SelfAttention's core (graphgps/layer/gps_layer.py:
+ * 111-114,206; arithmetic graphgps/layer/performer_layer.py:119-144,200-205,485-492): feature maps
+ * phi_q/phi_k through the [m, 64] projection `proj`, ksum, ctx = phi_k^T v, out = phi_q ctx / (phi_q ksum).
+ * The reference runs on the PADDED batch and masks only V, so every graph's normaliser also sees
+ * (Nmax - n_g) zero key rows; `nmax` (device int32[1], from gps_segment_max_len) supplies Nmax and
+ * the kernels add that term in closed form.  dim_head must be 64 and m <= 272.
+ *   qkv [N, 3*64H] (q | k | v, no bias), out [N, 64H]
+ *   saved for backward: ctx [B*H,272,64], ksum [B*H,272], kmax uint64[B*H] (key max + arg-max),
+ *   mq [H,N] (query row max), D [H,N] (normaliser)
+ * Backward additionally needs scratch gD [H,N], g_ctx [B*H,272,64], g_ksum [B*H,272],
+ * gM_part [max_tiles*H]; d_qkv [N, 3*64H] receives dq | dk | dv.
+ * ------------------------------------------------------------------------------------- */
+int gps_segment_max_len(const int32_t* ptr, int64_t B, int32_t* nmax, gps_stream_t stream);
+size_t gps_favor_workspace_floats(int64_t B, int H);
+int gps_favor_fwd(const float* qkv, int64_t ld_qkv, const float* proj, int m, const int32_t* ptr,
+                  const int32_t* nmax, const int32_t* tile_graph, const int32_t* tile_row0,
+                  int64_t max_tiles, int64_t N, int64_t B, int H, int dh, float* out, float* ctx,
+                  float* ksum, uint64_t* kmax, float* mq, float* D, gps_stream_t stream);
+int gps_favor_bwd(const float* g_out, const float* qkv, int64_t ld_qkv, const float* proj, int m,
+                  const float* out, const int32_t* ptr, const int32_t* nmax, const int32_t* tile_graph,
+                  const int32_t* tile_row0, int64_t max_tiles, int64_t N, int64_t B, int H, int dh,
+                  const float* ctx, const float* ksum, const uint64_t* kmax, const float* mq,
+                  const float* D, float* gD, float* g_ctx, float* g_ksum, float* gM_part,
+                  float* d_qkv, int64_t ld_dqkv, gps_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * Graph pooling over `ptr` segments (sum: mean = 0, mean: mean = 1) and its backward.
  * Replaces GraphGym pooling_dict['add'|'mean'] (torch_scatter atomics), called from
  * graphgps/head/san_graph.py:35 and graphgps/head/ogb_code_graph.py:37.

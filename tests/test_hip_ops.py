@@ -241,3 +241,49 @@ def test_cpu_tensor_is_rejected():
     from graphgps_amd.ops import build_graph_index
     with pytest.raises(GpsHipError):
         build_graph_index(torch.zeros(2, 3, dtype=torch.long), 4, 1, ptr_vec=torch.tensor([0, 4]))
+
+
+def _favor_ref(qkv, proj, ptr, H):
+    """The reference's padded path: to_dense_batch -> mask V -> softmax_kernel -> linear_attention
+    -> [mask] (oracle restatement of performer_layer.py, itself pinned by the golden fixture)."""
+    from oracle.gps_oracle import linear_attention, softmax_kernel, to_dense_batch
+    N, inner3 = qkv.shape
+    inner = inner3 // 3
+    B = len(ptr) - 1
+    bvec = torch.repeat_interleave(torch.arange(B), ptr[1:] - ptr[:-1])
+    dense, mask = to_dense_batch(qkv, bvec, B)
+    b, n = mask.shape
+    q, k, v = (dense[..., j * inner:(j + 1) * inner].view(b, n, H, -1).permute(0, 2, 1, 3)
+               for j in range(3))
+    v = v.masked_fill(~mask[:, None, :, None], 0.0)
+    out = linear_attention(softmax_kernel(q, proj, True), softmax_kernel(k, proj, False), v)
+    return out.permute(0, 2, 1, 3).reshape(b, n, inner)[mask]
+
+
+@pytest.mark.parametrize("H,sizes", [(2, [40, 7, 64, 33]), (4, [25, 25, 25]), (1, [130]),
+                                     (2, [3, 300, 17, 1])])
+def test_favor_attention_fwd_bwd(H, sizes):
+    from graphgps_amd.ops import favor_attention
+    from oracle.gps_oracle import gaussian_orthogonal_random_matrix
+    gen = torch.Generator().manual_seed(11)
+    torch.manual_seed(11)
+    dh, m = 64, 266
+    proj = gaussian_orthogonal_random_matrix(m, dh)
+    N, inner = sum(sizes), H * dh
+    ptr = torch.tensor([0] + list(np.cumsum(sizes)))
+    qkv = torch.randn(N, 3 * inner, generator=gen) * 0.7
+    if len(sizes) > 1:
+        qkv[int(ptr[1]):int(ptr[2]), inner:2 * inner] *= 0.02   # a graph whose real key max < 0 is possible
+    w = torch.randn(N, inner, generator=gen)
+    qr = qkv.clone().double().requires_grad_(True)
+    ref = _favor_ref(qr, proj.double(), ptr, H)
+    (ref * w.double()).sum().backward()
+    bvec = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
+    gi = _index(torch.zeros(2, 0, dtype=torch.long), bvec, ptr)
+    qg = qkv.cuda().requires_grad_(True)
+    out = favor_attention(qg, proj.cuda(), gi, H)
+    (out * w.cuda()).sum().backward()
+    assert_close(out, ref, Tol.ACT, "favor out")
+    assert_close(qg.grad, qr.grad, Tol.GRAD_REL, "favor d_qkv", rel_to_max=True)
+    out2 = favor_attention(qg.detach(), proj.cuda(), gi, H)
+    assert torch.equal(out2, out.detach())
