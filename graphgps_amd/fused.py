@@ -1,0 +1,132 @@
+"""Fused BatchNorm / ReLU / dropout / residual operators (csrc/bn_fused.hip).
+
+``bn_act``       y = res + dropout(relu(BatchNorm1d(z)))   -- every stage optional
+``add_dropout``  out = a + dropout(b)
+``relu_dropout`` out = dropout(relu(x))
+
+They stand in for the module chains of the reference (``gatedgcn_layer.py:72-83``,
+``gps_layer.py:191-194,212-217,225-229,253-257``) in TRAINING mode on the GPU; semantics are
+``torch.nn.BatchNorm1d`` / ``F.dropout`` / ``relu`` exactly, except that dropout masks come from
+the library's counter hash (seeded from torch's CPU generator) instead of ATen's Philox stream.
+Evaluation mode, non-ReLU activations and BatchNorm configurations the kernels do not cover
+(``affine=False``, ``momentum=None``) take the equivalent torch ops.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import lib as _lib
+from .lib import check, current_stream, ptr
+from .ops import _f32c, _require_cuda, draw_dropout_seed
+
+
+class _BNAct(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, z, gamma, beta, res, running_mean, running_var, eps, momentum, relu, p_drop,
+                seed):
+        L = _lib.load()
+        dev = _require_cuda(z, gamma, beta, res)
+        z = _f32c(z, "z")
+        R, d = z.shape
+        res_c = _f32c(res, "res") if res is not None else None
+        f32 = dict(dtype=torch.float32, device=dev)
+        mean, rstd = torch.empty(d, **f32), torch.empty(d, **f32)
+        ws = torch.empty(max(L.gps_bn_workspace_floats(R, d), 1), **f32)
+        st = current_stream(dev)
+        check(L.gps_bn_stats(ptr(z), R, d, eps, momentum, ptr(mean), ptr(rstd), ptr(running_mean),
+                             ptr(running_var), ptr(ws), st), "gps_bn_stats")
+        y = torch.empty_like(z)
+        check(L.gps_bn_apply(ptr(z), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), ptr(res_c), R, d,
+                             int(relu), p_drop, seed, ptr(y), st), "gps_bn_apply")
+        ctx.save_for_backward(z, gamma, beta, mean, rstd)
+        ctx.cfg = (bool(relu), float(p_drop), int(seed), res is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g_y):
+        L = _lib.load()
+        z, gamma, beta, mean, rstd = ctx.saved_tensors
+        relu, p_drop, seed, has_res = ctx.cfg
+        g_y = _f32c(g_y, "g_y")
+        R, d = z.shape
+        dev = z.device
+        f32 = dict(dtype=torch.float32, device=dev)
+        g_z = torch.empty_like(z)
+        g_gamma, g_beta = torch.empty(d, **f32), torch.empty(d, **f32)
+        ws = torch.empty(max(L.gps_bn_workspace_floats(R, d), 1), **f32)
+        check(L.gps_bn_bwd(ptr(z), ptr(g_y), ptr(mean), ptr(rstd), ptr(gamma), ptr(beta), R, d,
+                           int(relu), p_drop, seed, ptr(g_z), ptr(g_gamma), ptr(g_beta), ptr(ws),
+                           current_stream(dev)), "gps_bn_bwd")
+        return (g_z, g_gamma, g_beta, g_y if has_res else None, None, None, None, None, None, None,
+                None)
+
+
+def _fusable(bn: nn.BatchNorm1d, z: torch.Tensor) -> bool:
+    return (bn.training and z.is_cuda and bn.affine and bn.track_running_stats
+            and bn.momentum is not None and z.dim() == 2 and z.shape[0] >= 2
+            and z.dtype == torch.float32)
+
+
+def bn_act(z: torch.Tensor, bn: nn.BatchNorm1d, relu: bool = False, p_drop: float = 0.0,
+           res: Optional[torch.Tensor] = None, seed: Optional[int] = None) -> torch.Tensor:
+    """``res + dropout(relu(bn(z)))`` with train-mode batch statistics, one stats pass + one
+    apply pass; updates ``running_mean/var`` and ``num_batches_tracked`` like the module."""
+    if not _fusable(bn, z):
+        y = bn(z)
+        if relu:
+            y = F.relu(y)
+        y = F.dropout(y, p_drop, training=bn.training)
+        return y if res is None else res + y
+    if p_drop > 0.0 and seed is None:
+        seed = draw_dropout_seed()
+    bn.num_batches_tracked.add_(1)
+    return _BNAct.apply(z, bn.weight, bn.bias, res, bn.running_mean, bn.running_var, float(bn.eps),
+                        float(bn.momentum), bool(relu), float(p_drop), int(seed or 0))
+
+
+class _ActDropAdd(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a, b, relu, p_drop, seed):
+        L = _lib.load()
+        dev = _require_cuda(a, b)
+        b = _f32c(b, "b")
+        a_c = _f32c(a, "a") if a is not None else None
+        R, d = b.shape
+        out = torch.empty_like(b)
+        check(L.gps_act_drop_add(ptr(a_c), ptr(b), R, d, int(relu), p_drop, seed, ptr(out),
+                                 current_stream(dev)), "gps_act_drop_add")
+        if relu:
+            ctx.save_for_backward(b)
+        ctx.cfg = (bool(relu), float(p_drop), int(seed), a is not None, R, d)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.load()
+        relu, p_drop, seed, has_a, R, d = ctx.cfg
+        g = _f32c(g, "g")
+        pre = ctx.saved_tensors[0] if relu else None
+        g_b = torch.empty_like(g)
+        check(L.gps_act_drop_bwd(ptr(g), ptr(pre), R, d, int(relu), p_drop, seed, ptr(g_b),
+                                 current_stream(g.device)), "gps_act_drop_bwd")
+        return (g if has_a else None), g_b, None, None, None
+
+
+def add_dropout(a: torch.Tensor, b: torch.Tensor, p_drop: float, training: bool,
+                seed: Optional[int] = None) -> torch.Tensor:
+    """``a + dropout(b)`` (residual connections of gps_layer.py:188-189,212-213,225)."""
+    if not (training and p_drop > 0.0 and b.is_cuda and b.dim() == 2 and b.dtype == torch.float32):
+        return a + F.dropout(b, p_drop, training=training)
+    return _ActDropAdd.apply(a, b, False, float(p_drop), int(seed or draw_dropout_seed()))
+
+
+def relu_dropout(x: torch.Tensor, p_drop: float, training: bool,
+                 seed: Optional[int] = None) -> torch.Tensor:
+    """``dropout(relu(x))`` (FFN, gps_layer.py:256)."""
+    if not (training and p_drop > 0.0 and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32):
+        return F.dropout(F.relu(x), p_drop, training=training)
+    return _ActDropAdd.apply(None, x, True, float(p_drop), int(seed or draw_dropout_seed()))

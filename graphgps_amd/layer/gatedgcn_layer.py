@@ -14,6 +14,7 @@ import torch.nn.functional as F
 from ..graphgym import register
 from ..graphgym import act as _act  # noqa: F401  (fills act_dict)
 from ..graphgym.register import register_layer
+from ..fused import bn_act
 from ..ops import gatedgcn_aggregate, graph_index_of
 
 
@@ -51,6 +52,12 @@ class GatedGCNLayer(nn.Module):
         proj = F.linear(x, w, b)
         ce = self.C(e)
         x, e = gatedgcn_aggregate(proj, ce, gi)
+        if isinstance(self.act_fn_x, nn.ReLU) and isinstance(self.act_fn_e, nn.ReLU):
+            # lines :72-83 as two fused passes per stream (csrc/bn_fused.hip)
+            p = self.dropout if self.training else 0.0
+            x = bn_act(x, self.bn_node_x, relu=True, p_drop=p, res=x_in if self.residual else None)
+            e = bn_act(e, self.bn_edge_e, relu=True, p_drop=p, res=e_in if self.residual else None)
+            return x, e
         x = self.bn_node_x(x)
         e = self.bn_edge_e(e)
         x = self.act_fn_x(x)

@@ -21,6 +21,7 @@ import torch.nn.functional as F
 
 from ..graphgym import register
 from ..graphgym import act as _act  # noqa: F401
+from ..fused import add_dropout, bn_act, relu_dropout
 from ..ops import graph_index_of, segment_attention
 from .gatedgcn_layer import GatedGCNLayer
 from .gine_conv_layer import GINEConv
@@ -132,7 +133,7 @@ class GPSLayer(nn.Module):
         h_in1 = h  # for first residual connection
         gi = graph_index_of(batch)
 
-        h_out_list = []
+        h_local = h_attn = None
         if self.local_model is not None:
             if self.local_gnn_type == 'CustomGatedGCN':
                 # GatedGCN does residual connection and dropout internally (reference :164-174)
@@ -140,11 +141,10 @@ class GPSLayer(nn.Module):
                 batch.edge_attr = e_new
             else:
                 h_local = self.local_model.forward_tensors(h, batch.edge_attr, gi)
-                h_local = self.dropout_local(h_local)
-                h_local = h_in1 + h_local  # Residual connection.
+                # dropout_local + residual (reference :188-189)
+                h_local = add_dropout(h_in1, h_local, self.dropout_local.p, self.training)
             if self.batch_norm:
-                h_local = self.norm1_local(h_local)
-            h_out_list.append(h_local)
+                h_local = bn_act(h_local, self.norm1_local)                  # :193-194
 
         if self.self_attn is not None:
             # the global branch attends over the PRE-layer h (reference :156,199)
@@ -154,17 +154,22 @@ class GPSLayer(nn.Module):
                 h_attn = self.self_attn.forward_segments(h, gi)
             else:
                 raise RuntimeError(f"Unexpected {self.global_model_type}")
-            h_attn = self.dropout_attn(h_attn)
-            h_attn = h_in1 + h_attn  # Residual connection.
+            h_attn = add_dropout(h_in1, h_attn, self.dropout_attn.p, self.training)  # :212-213
             if self.batch_norm:
-                h_attn = self.norm1_attn(h_attn)
-            h_out_list.append(h_attn)
+                # norm1_attn, with the branch sum h_local + h_attn (:222) folded into the
+                # BN epilogue as its residual operand
+                h_attn = bn_act(h_attn, self.norm1_attn, res=h_local)
+                h_local = None
 
-        h = sum(h_out_list)
+        # Combine local and global outputs (reference :222: sum of the branch outputs).
+        parts = [t for t in (h_local, h_attn) if t is not None]
+        h = parts[0] if len(parts) == 1 else sum(parts)
 
-        h = h + self._ff_block(h)
+        # Feed Forward block + norm2 (reference :225-229).
+        ff = self._ff_block(h)
+        h = add_dropout(h, ff, self.ff_dropout2.p, self.training)
         if self.batch_norm:
-            h = self.norm2(h)
+            h = bn_act(h, self.norm2)
 
         batch.x = h
         return batch
@@ -180,8 +185,14 @@ class GPSLayer(nn.Module):
         return F.linear(o, sa.out_proj.weight, sa.out_proj.bias)
 
     def _ff_block(self, x):
-        x = self.ff_dropout1(self.act_fn_ff(self.ff_linear1(x)))
-        return self.ff_dropout2(self.ff_linear2(x))
+        """ff_linear2(ff_dropout1(act(ff_linear1(x)))); ff_dropout2 is applied by the caller
+        together with the residual add (reference :253-257)."""
+        x = self.ff_linear1(x)
+        if isinstance(self.act_fn_ff, nn.ReLU):
+            x = relu_dropout(x, self.ff_dropout1.p, self.training)
+        else:
+            x = self.ff_dropout1(self.act_fn_ff(x))
+        return self.ff_linear2(x)
 
     def extra_repr(self):
         return (f'summary: dim_h={self.dim_h}, local_gnn_type={self.local_gnn_type}, '

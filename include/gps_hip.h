@@ -156,6 +156,37 @@ int gps_favor_bwd(const float* g_out, const float* qkv, int64_t ld_qkv, const fl
                   float* d_qkv, int64_t ld_dqkv, gps_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Fused BatchNorm1d epilogues for [R, d] activation streams (training mode, batch statistics).
+ * Replace the module chains around every BatchNorm1d of the path:
+ *   x_in + dropout(relu(bn(x)))                    graphgps/layer/gatedgcn_layer.py:72-83
+ *   norm(h_in + dropout(branch)), norm2(h + ffn)   graphgps/layer/gps_layer.py:191-194,212-217,225-229
+ *   dropout(relu(ff_linear1(h)))                   graphgps/layer/gps_layer.py:253-257
+ * i.e. ATen batch_norm (collect_statistics/transform/backward_reduce/backward_elemt), relu, dropout
+ * (Philox) and add kernels.  torch.nn.BatchNorm1d semantics: biased variance for normalisation,
+ * unbiased for running_var, eps inside the sqrt, running = (1-momentum)*running + momentum*batch.
+ * Dropout masks come from the same counter hash as the attention kernel, keyed (seed, row, column),
+ * so the backward recomputes them (and the ReLU mask) instead of storing them.
+ *   gps_bn_stats : mean[d], rstd[d] (+ running stats update when non-NULL); ws >= gps_bn_workspace_floats
+ *   gps_bn_apply : y = res + drop(relu((z-mean)*rstd*gamma+beta)); relu / p_drop==0 / res==NULL switch stages off
+ *   gps_bn_bwd   : g_z, g_gamma, g_beta from g_y (grad wrt y; the residual's grad is g_y itself)
+ *   gps_act_drop_add / _bwd : out = a + drop(relu?(b)) (a may be NULL) and g_b
+ * ------------------------------------------------------------------------------------- */
+size_t gps_bn_workspace_floats(int64_t R, int d);
+int gps_bn_stats(const float* z, int64_t R, int d, float eps, float momentum, float* mean, float* rstd,
+                 float* running_mean, float* running_var, float* ws, gps_stream_t stream);
+int gps_bn_apply(const float* z, const float* mean, const float* rstd, const float* gamma,
+                 const float* beta, const float* res, int64_t R, int d, int relu, float p_drop,
+                 uint64_t seed, float* y, gps_stream_t stream);
+int gps_bn_bwd(const float* z, const float* g_y, const float* mean, const float* rstd,
+               const float* gamma, const float* beta, int64_t R, int d, int relu, float p_drop,
+               uint64_t seed, float* g_z, float* g_gamma, float* g_beta, float* ws,
+               gps_stream_t stream);
+int gps_act_drop_add(const float* a, const float* b, int64_t R, int d, int relu, float p_drop,
+                     uint64_t seed, float* out, gps_stream_t stream);
+int gps_act_drop_bwd(const float* g, const float* pre, int64_t R, int d, int relu, float p_drop,
+                     uint64_t seed, float* g_b, gps_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * Graph pooling over `ptr` segments (sum: mean = 0, mean: mean = 1) and its backward.
  * Replaces GraphGym pooling_dict['add'|'mean'] (torch_scatter atomics), called from
  * graphgps/head/san_graph.py:35 and graphgps/head/ogb_code_graph.py:37.

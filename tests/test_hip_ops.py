@@ -287,3 +287,88 @@ def test_favor_attention_fwd_bwd(H, sizes):
     assert_close(qg.grad, qr.grad, Tol.GRAD_REL, "favor d_qkv", rel_to_max=True)
     out2 = favor_attention(qg.detach(), proj.cuda(), gi, H)
     assert torch.equal(out2, out.detach())
+
+
+def _drop_mask(seed, R, d, p):
+    from graphgps_amd.ops import attn_dropout_keep_mask
+    # the BN/elementwise kernels key the same hash by (row, column)
+    return attn_dropout_keep_mask(seed, torch.arange(R), 0, 1, torch.arange(d), p)
+
+
+@pytest.mark.parametrize("R,d,relu,p,with_res", [
+    (7569, 384, True, 0.1, True),      # GatedGCN node stream at P30
+    (15348, 384, True, 0.0, True),     # edge stream, dropout off
+    (3001, 64, False, 0.0, False),     # plain norm (ZINC width)
+    (257, 52, True, 0.25, False),      # d % 4 == 0 but odd sizes, one partial row block
+    (130, 6, False, 0.5, True),        # float2 path
+])
+def test_bn_act_fused(R, d, relu, p, with_res):
+    """res + dropout(relu(BatchNorm1d(z))) fwd/bwd, batch statistics and running stats, against
+    torch.nn.BatchNorm1d in fp64 with the kernel's own dropout mask injected."""
+    from graphgps_amd.fused import bn_act
+    gen = torch.Generator().manual_seed(R + d)
+    z = torch.randn(R, d, generator=gen) * 1.7 + 0.6
+    res = torch.randn(R, d, generator=gen) if with_res else None
+    w = torch.randn(R, d, generator=gen)
+    seed = 0xABCDEF0123456789
+    bn_ref = torch.nn.BatchNorm1d(d).double().train()
+    with torch.no_grad():
+        bn_ref.weight.uniform_(0.5, 1.5, generator=gen)
+        bn_ref.bias.uniform_(-0.5, 0.5, generator=gen)
+    bn_gpu = torch.nn.BatchNorm1d(d)
+    bn_gpu.load_state_dict({k: v.float() if v.is_floating_point() else v
+                            for k, v in bn_ref.state_dict().items()})
+    bn_gpu.cuda().train()
+    zr = z.double().requires_grad_(True)
+    y = bn_ref(zr)
+    if relu:
+        y = y.relu()
+    if p > 0:
+        y = y * _drop_mask(seed, R, d, p).double() / (1 - p)
+    rr = res.double().requires_grad_(True) if with_res else None
+    if with_res:
+        y = rr + y
+    (y * w.double()).sum().backward()
+    zg = z.cuda().requires_grad_(True)
+    rg = res.cuda().requires_grad_(True) if with_res else None
+    yg = bn_act(zg, bn_gpu, relu=relu, p_drop=p, res=rg, seed=seed)
+    (yg * w.cuda()).sum().backward()
+    assert_close(yg, y, Tol.ACT, "bn_act out")
+    assert_close(zg.grad, zr.grad, Tol.GRAD_REL, "bn_act g_z", rel_to_max=True)
+    assert_close(bn_gpu.weight.grad, bn_ref.weight.grad, 1e-4, "g_gamma", rel_to_max=True)
+    assert_close(bn_gpu.bias.grad, bn_ref.bias.grad, 1e-4, "g_beta", rel_to_max=True)
+    if with_res:
+        assert_close(rg.grad, rr.grad, Tol.GRAD_REL, "g_res", rel_to_max=True)
+    assert_close(bn_gpu.running_mean, bn_ref.running_mean, 1e-6, "running_mean")
+    assert_close(bn_gpu.running_var, bn_ref.running_var, 1e-5, "running_var")
+    assert int(bn_gpu.num_batches_tracked) == 1
+
+
+def test_bn_stats_large_mean_is_accurate():
+    """Shifted/Chan-merged statistics: a column with |mean| >> std must not lose the variance."""
+    from graphgps_amd.fused import bn_act
+    gen = torch.Generator().manual_seed(0)
+    z = torch.randn(20000, 64, generator=gen) * 0.01 + 100.0
+    bn = torch.nn.BatchNorm1d(64).cuda().train()
+    y = bn_act(z.cuda(), bn)
+    ref = torch.nn.functional.batch_norm(z.double(), None, None, training=True)
+    assert_close(y, ref, 2e-3, "normalised output at mean/std = 1e4")  # fp32 input quantum is 7.6e-6 = 7.6e-4 std
+
+
+@pytest.mark.parametrize("relu,with_a", [(False, True), (True, False)])
+def test_act_drop_add(relu, with_a):
+    from graphgps_amd.fused import add_dropout, relu_dropout
+    gen = torch.Generator().manual_seed(4)
+    R, d, p, seed = 7569, 768 if relu else 384, 0.1, 77
+    a, b, w = (torch.randn(R, d, generator=gen) for _ in range(3))
+    keep = _drop_mask(seed, R, d, p).double()
+    br = b.double().requires_grad_(True)
+    ref = (br.relu() if relu else br) * keep / (1 - p)
+    if with_a:
+        ref = a.double() + ref
+    (ref * w.double()).sum().backward()
+    bg = b.cuda().requires_grad_(True)
+    out = relu_dropout(bg, p, True, seed=seed) if relu else add_dropout(a.cuda(), bg, p, True, seed=seed)
+    (out * w.cuda()).sum().backward()
+    assert_close(out, ref, Tol.ACT, "act_drop_add out")
+    assert_close(bg.grad, br.grad, Tol.GRAD_REL, "act_drop_add g_b", rel_to_max=True)
