@@ -61,6 +61,8 @@ def assert_close_kink_tolerant(a, b, tol, what, max_outlier_row_frac=1e-3):
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
     scale = max(b.abs().max().item(), 1.0)
+    if a.dim() == 1:            # vectors: every element is its own "row"
+        a, b = a.view(-1, 1), b.view(-1, 1)
     err = ((a - b).abs() / scale).view(a.shape[0], -1)
     bad_rows = (err > tol).any(dim=1)
     rows = int(bad_rows.sum())

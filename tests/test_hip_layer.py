@@ -109,9 +109,12 @@ def test_gpslayer_vs_oracle_baseline_sizes(local, glob, d, H, profile, nb):
         if op[k].grad is None:
             continue
         # parameter gradients are sums over ~8k rows / ~16k edges of fp32 products: reduction
-        # order differs between rocBLAS and the CPU BLAS, and a ReLU-kink flip (see
-        # assert_close_kink_tolerant) perturbs one summand: the bar is 1e-4 of max|g|
-        assert_close(p.grad, op[k].grad, 1e-4, f"grad {k}", rel_to_max=True)
+        # order differs between rocBLAS and the CPU BLAS (bar 1e-4 of max|g|), and a ReLU-kink
+        # flip at (row r, channel c) lands undamped in row c of a weight gradient, so a few
+        # outlier rows per parameter are allowed (see assert_close_kink_tolerant)
+        r = assert_close_kink_tolerant(p.grad, op[k].grad, 1e-4, f"grad {k}")
+        if r[2]:
+            print(f"grad {k}: {r[2]} kink rows, max rel {r[0]:.2e} outside them")
 
 
 def test_gpslayer_edge_permutation_and_determinism():

