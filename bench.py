@@ -74,11 +74,15 @@ def make_step(model, opt, reducer, batch_dev, compute_loss, clip_value):
 
     def step():
         b = batch_dev.clone()            # fresh batch object -> the graph index is rebuilt
-        reducer.zero_grad()
+        if reducer is None:              # single GPU: nothing to exchange, autograd owns .grad
+            opt.zero_grad(set_to_none=True)
+        else:
+            reducer.zero_grad()
         pred, true = model(b)
         loss, _ = compute_loss(pred, true)
         loss.backward()
-        reducer.finish()
+        if reducer is not None:
+            reducer.finish()
         torch.nn.utils.clip_grad_norm_(params, clip_value, foreach=True)
         opt.step()
         return loss
@@ -237,7 +241,7 @@ def main():
         cpu_ref_model = copy.deepcopy(model)
     model.to(dev)
     batch_dev = batch_cpu.clone().to(dev)
-    reducer = GradBucketReducer(model)
+    reducer = GradBucketReducer(model) if world > 1 else None
     opt = torch.optim.AdamW(model.parameters(), lr=cfg.optim.base_lr,
                             weight_decay=cfg.optim.weight_decay, fused=True)
     step = make_step(model, opt, reducer, batch_dev, compute_loss, cfg.optim.clip_grad_norm_value)
@@ -284,7 +288,7 @@ def main():
                        "timed_region": "graph-index build + forward + L1 loss + backward + "
                                        "grad all-reduce + clip + AdamW"},
             "final_loss": final_loss,
-            "grad_allreduce_bytes": reducer.num_bytes if world > 1 else 0,
+            "grad_allreduce_bytes": reducer.num_bytes if reducer is not None else 0,
         }
         if not args.no_kernel_roofline:
             kr, shape = kernel_rooflines(dev, args.profile, nb)

@@ -15,12 +15,15 @@
 // HBM-bound row kernels, same lane-owns-4-channels mapping as gatedgcn.hip.  Training-mode batch
 // statistics follow torch.nn.BatchNorm1d: biased variance for normalisation, unbiased for the running
 // estimate, eps inside the sqrt.
+#include <algorithm>
+
 #include "gps_common.hpp"
 #include "vec.hpp"
 
 namespace {
 
-constexpr int ROWS_PER_BLOCK = 128;
+constexpr int TARGET_BLOCKS = 1024;  // stage-1 partial blocks: ~4 per CU so the reduction fills the chip
+constexpr int FCOLS = 16, FCHUNKS = 16;  // stage-2 block = 16 columns x 16 partial-list chunks
 
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
@@ -39,14 +42,14 @@ __device__ __forceinline__ bool keep_elem(uint32_t rh, uint32_t col, float p_dro
 // ws layout: [nblocks][3][d] = (count, mean, M2) per block and column.
 template <int VEC>
 __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ z, int64_t R, int d,
-                                                    float* __restrict__ ws) {
+                                                    int rpb, float* __restrict__ ws) {
   extern __shared__ __attribute__((aligned(16))) float lds[];  // [RS][2][d]
   const int L = d / VEC;            // lanes per row
   const int RS = 256 / L;           // row sub-groups in the block
   const int rsub = threadIdx.x / L;
   const int c = (threadIdx.x - rsub * L) * VEC;
-  const int64_t row0 = (int64_t)blockIdx.x * ROWS_PER_BLOCK;
-  const int64_t row1 = min(R, row0 + ROWS_PER_BLOCK);
+  const int64_t row0 = (int64_t)blockIdx.x * rpb;
+  const int64_t row1 = min(R, row0 + rpb);
   const bool active = rsub < RS;
   Vec<VEC> k = Vec<VEC>::zero(), s1 = Vec<VEC>::zero(), s2 = Vec<VEC>::zero();
   if (active) {
@@ -86,29 +89,49 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ z,
   }
 }
 
-__global__ void k_bn_finalize(const float* __restrict__ ws, int nblocks, int d, float eps,
-                              float momentum, float* __restrict__ mean_out,
-                              float* __restrict__ rstd_out, float* __restrict__ running_mean,
-                              float* __restrict__ running_var) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= d) return;
+// Stage 2: block = FCOLS columns x FCHUNKS chunks of the partial list.  Each thread Chan-merges its
+// contiguous chunk in order, then chunk 0 merges the FCHUNKS results in order: fixed tree shape ->
+// deterministic; sequential depth nblocks/16 + 16 instead of nblocks.
+__device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, float nb, float mb,
+                                           float qb) {
+  if (nb <= 0.0f) return;
+  const float nn = n + nb;
+  const float delta = mb - mean;
+  mean += delta * (nb / nn);
+  m2 += qb + delta * delta * (n * nb / nn);
+  n = nn;
+}
+
+__global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ ws, int nblocks, int d,
+                                                     float eps, float momentum,
+                                                     float* __restrict__ mean_out,
+                                                     float* __restrict__ rstd_out,
+                                                     float* __restrict__ running_mean,
+                                                     float* __restrict__ running_var) {
+  __shared__ float sh[FCHUNKS][FCOLS][3];
+  const int col = threadIdx.x % FCOLS, chunk = threadIdx.x / FCOLS;
+  const int c = blockIdx.x * FCOLS + col;
+  const int per = (nblocks + FCHUNKS - 1) / FCHUNKS;
+  const int b0 = chunk * per, b1 = min(nblocks, b0 + per);
   float n = 0.f, mean = 0.f, m2 = 0.f;
-  for (int b = 0; b < nblocks; ++b) {   // Chan et al. pairwise merge, in block order
-    const float nb = ws[(int64_t)b * 3 * d + c];
-    const float mb = ws[(int64_t)b * 3 * d + d + c];
-    const float qb = ws[(int64_t)b * 3 * d + 2 * d + c];
-    const float nn = n + nb;
-    const float delta = mb - mean;
-    mean += delta * (nb / nn);
-    m2 += qb + delta * delta * (n * nb / nn);
-    n = nn;
+  if (c < d) {
+#pragma unroll 4
+    for (int b = b0; b < b1; ++b) {
+      const float* w = ws + (int64_t)b * 3 * d + c;
+      chan_merge(n, mean, m2, w[0], w[d], w[2 * d]);
+    }
   }
-  const float var = m2 / n;
-  mean_out[c] = mean;
-  rstd_out[c] = 1.0f / sqrtf(var + eps);
-  if (running_mean) {
-    running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mean;
-    running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (m2 / fmaxf(n - 1.0f, 1.0f));
+  sh[chunk][col][0] = n; sh[chunk][col][1] = mean; sh[chunk][col][2] = m2;
+  __syncthreads();
+  if (chunk == 0 && c < d) {
+    for (int q = 1; q < FCHUNKS; ++q) chan_merge(n, mean, m2, sh[q][col][0], sh[q][col][1], sh[q][col][2]);
+    const float var = m2 / n;
+    mean_out[c] = mean;
+    rstd_out[c] = 1.0f / sqrtf(var + eps);
+    if (running_mean) {
+      running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mean;
+      running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (m2 / fmaxf(n - 1.0f, 1.0f));
+    }
   }
 }
 
@@ -169,14 +192,14 @@ template <int VEC, bool RELU, bool DROP>
 __global__ __launch_bounds__(256) void k_bn_bwd_partial(
     const float* __restrict__ z, const float* __restrict__ g_y, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
-    int64_t R, int d, float p_drop, uint64_t seed, float* __restrict__ ws) {
+    int64_t R, int d, int rpb, float p_drop, uint64_t seed, float* __restrict__ ws) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int L = d / VEC;
   const int RS = 256 / L;
   const int rsub = threadIdx.x / L;
   const int c = (threadIdx.x - rsub * L) * VEC;
-  const int64_t row0 = (int64_t)blockIdx.x * ROWS_PER_BLOCK;
-  const int64_t row1 = min(R, row0 + ROWS_PER_BLOCK);
+  const int64_t row0 = (int64_t)blockIdx.x * rpb;
+  const int64_t row1 = min(R, row0 + rpb);
   const bool active = rsub < RS;
   Vec<VEC> sg = Vec<VEC>::zero(), sgz = Vec<VEC>::zero();
   if (active) {
@@ -218,17 +241,29 @@ __global__ __launch_bounds__(256) void k_bn_bwd_partial(
   }
 }
 
-__global__ void k_bn_bwd_finalize(const float* __restrict__ ws, int nblocks, int d,
-                                  float* __restrict__ g_beta, float* __restrict__ g_gamma) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= d) return;
+__global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float* __restrict__ ws, int nblocks,
+                                                         int d, float* __restrict__ g_beta,
+                                                         float* __restrict__ g_gamma) {
+  __shared__ float sh[FCHUNKS][FCOLS][2];
+  const int col = threadIdx.x % FCOLS, chunk = threadIdx.x / FCOLS;
+  const int c = blockIdx.x * FCOLS + col;
+  const int per = (nblocks + FCHUNKS - 1) / FCHUNKS;
+  const int b0 = chunk * per, b1 = min(nblocks, b0 + per);
   float a = 0.f, b = 0.f;
-  for (int k = 0; k < nblocks; ++k) {
-    a += ws[(int64_t)k * 2 * d + c];
-    b += ws[(int64_t)k * 2 * d + d + c];
+  if (c < d) {
+#pragma unroll 4
+    for (int k = b0; k < b1; ++k) {
+      a += ws[(int64_t)k * 2 * d + c];
+      b += ws[(int64_t)k * 2 * d + d + c];
+    }
   }
-  g_beta[c] = a;
-  g_gamma[c] = b;
+  sh[chunk][col][0] = a; sh[chunk][col][1] = b;
+  __syncthreads();
+  if (chunk == 0 && c < d) {
+    for (int q = 1; q < FCHUNKS; ++q) { a += sh[q][col][0]; b += sh[q][col][1]; }
+    g_beta[c] = a;
+    g_gamma[c] = b;
+  }
 }
 
 template <int VEC, bool RELU, bool DROP>
@@ -317,8 +352,67 @@ __global__ __launch_bounds__(256) void k_act_drop_bwd(const float* __restrict__ 
   o.store(g_b + row * d + c);
 }
 
+// ---- plain column sum (bias gradients of the dense projections) ------------------------------------
+template <int VEC>
+__global__ __launch_bounds__(256) void k_colsum_partial(const float* __restrict__ x, int64_t R, int d,
+                                                        int rpb, float* __restrict__ ws) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];  // [RS][Lb*VEC]
+  const int L = d / VEC;                       // lanes per full row
+  const int Lb = L < 256 ? L : 256;            // lanes of this block's column slab (blockIdx.y)
+  const int RS = 256 / Lb;
+  const int rsub = threadIdx.x / Lb;
+  const int lane = threadIdx.x - rsub * Lb;
+  const int c = (blockIdx.y * Lb + lane) * VEC;
+  const int64_t row0 = (int64_t)blockIdx.x * rpb;
+  const int64_t row1 = min(R, row0 + rpb);
+  const bool active = rsub < RS && c < d;
+  Vec<VEC> acc = Vec<VEC>::zero();
+  if (active) {
+    for (int64_t r = row0 + rsub; r < row1; r += RS) {
+      const Vec<VEC> v = Vec<VEC>::load(x + r * d + c);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[j] += v[j];
+    }
+    if (rsub > 0) {
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) lds[(rsub * Lb + lane) * VEC + j] = acc[j];
+    }
+  }
+  __syncthreads();
+  if (active && rsub == 0) {
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      float a = acc[j];
+      for (int q = 1; q < RS; ++q) a += lds[(q * Lb + lane) * VEC + j];
+      ws[(int64_t)blockIdx.x * d + c + j] = a;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void k_colsum_finalize(const float* __restrict__ ws, int nblocks,
+                                                         int d, float* __restrict__ out) {
+  __shared__ float sh[FCHUNKS][FCOLS];
+  const int col = threadIdx.x % FCOLS, chunk = threadIdx.x / FCOLS;
+  const int c = blockIdx.x * FCOLS + col;
+  const int per = (nblocks + FCHUNKS - 1) / FCHUNKS;
+  const int b0 = chunk * per, b1 = min(nblocks, b0 + per);
+  float a = 0.f;
+  if (c < d) {
+#pragma unroll 4
+    for (int k = b0; k < b1; ++k) a += ws[(int64_t)k * d + c];
+  }
+  sh[chunk][col] = a;
+  __syncthreads();
+  if (chunk == 0 && c < d) {
+    for (int q = 1; q < FCHUNKS; ++q) a += sh[q][col];
+    out[c] = a;
+  }
+}
+
 inline bool al(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
-inline int nblocks_for(int64_t R) { return (int)((R + ROWS_PER_BLOCK - 1) / ROWS_PER_BLOCK); }
+// rows per stage-1 block (a multiple of the block's row sub-groups is not required) and block count
+inline int rows_per_block(int64_t R) { return (int)std::max<int64_t>(8, (R + TARGET_BLOCKS - 1) / TARGET_BLOCKS); }
+inline int nblocks_for(int64_t R) { const int rpb = rows_per_block(R); return (int)((R + rpb - 1) / rpb); }
 
 }  // namespace
 
@@ -354,10 +448,10 @@ int gps_bn_stats(const float* z, int64_t R, int d, float eps, float momentum, fl
   GPS_DISPATCH_VEC(d, al(z, 16) && d / 4 <= 256, al(z, 8) && d / 2 <= 256, {
     GPS_REQUIRE(d / VEC <= 256, "gps_bn_stats: d=%d too wide for this vector width", d);
     const int RS = 256 / (d / VEC);
-    k_bn_partial<VEC><<<nb, 256, sizeof(float) * 2 * RS * d, s>>>(z, R, d, ws);
+    k_bn_partial<VEC><<<nb, 256, sizeof(float) * 2 * RS * d, s>>>(z, R, d, rows_per_block(R), ws);
   });
-  k_bn_finalize<<<gps::grid_for(d, 128), 128, 0, s>>>(ws, nb, d, eps, momentum, mean, rstd, running_mean,
-                                                      running_var);
+  k_bn_finalize<<<gps::grid_for(d, FCOLS), 256, 0, s>>>(ws, nb, d, eps, momentum, mean, rstd, running_mean,
+                                                        running_var);
   return gps::launch_status("gps_bn_stats");
 }
 
@@ -400,13 +494,26 @@ int gps_bn_bwd(const float* z, const float* g_y, const float* mean, const float*
     GPS_BOOL3(relu != 0, p_drop > 0.f, false, {
       (void)kC;
       k_bn_bwd_partial<VEC, kA, kB><<<nb, 256, sizeof(float) * 2 * RS * d, s>>>(
-          z, g_y, mean, rstd, gamma, beta, R, d, p_drop, seed, ws);
-      k_bn_bwd_finalize<<<gps::grid_for(d, 128), 128, 0, s>>>(ws, nb, d, g_beta, g_gamma);
+          z, g_y, mean, rstd, gamma, beta, R, d, rows_per_block(R), p_drop, seed, ws);
+      k_bn_bwd_finalize<<<gps::grid_for(d, FCOLS), 256, 0, s>>>(ws, nb, d, g_beta, g_gamma);
       k_bn_bwd_apply<VEC, kA, kB><<<grid, 256, 0, s>>>(z, g_y, mean, rstd, gamma, beta, g_beta, g_gamma,
                                                        R, d, p_drop, seed, g_z);
     });
   });
   return gps::launch_status("gps_bn_bwd");
+}
+
+int gps_colsum(const float* x, int64_t R, int d, float* out, float* ws, gps_stream_t stream) {
+  GPS_REQUIRE(R >= 1 && d > 0 && x && out && ws, "gps_colsum: bad arguments");
+  hipStream_t s = gps::as_stream(stream);
+  const int nb = nblocks_for(R);
+  GPS_DISPATCH_VEC(d, al(x, 16), al(x, 8), {
+    const int L = d / VEC, Lb = L < 256 ? L : 256;
+    const dim3 grid(nb, (L + Lb - 1) / Lb);
+    k_colsum_partial<VEC><<<grid, 256, sizeof(float) * (256 / Lb) * Lb * VEC, s>>>(x, R, d, rows_per_block(R), ws);
+  });
+  k_colsum_finalize<<<gps::grid_for(d, FCOLS), 256, 0, s>>>(ws, nb, d, out);
+  return gps::launch_status("gps_colsum");
 }
 
 int gps_act_drop_add(const float* a, const float* b, int64_t R, int d, int relu, float p_drop,

@@ -191,7 +191,16 @@ __global__ void k_attn_delta(const float* __restrict__ d_out, const float* __res
   const float* a = d_out + q * (int64_t)(H * DH) + h * DH;
   const float* b = out + q * (int64_t)(H * DH) + h * DH;
   float acc = 0.0f;
-  for (int c = 0; c < DH; ++c) acc += a[c] * b[c];
+  if ((DH & 3) == 0) {  // rows are 16-byte aligned when d % 4 == 0 (checked on the host side)
+    const float4* a4 = reinterpret_cast<const float4*>(a);
+    const float4* b4 = reinterpret_cast<const float4*>(b);
+    for (int c = 0; c < DH / 4; ++c) {
+      const float4 u = a4[c], v = b4[c];
+      acc += u.x * v.x + u.y * v.y + u.z * v.z + u.w * v.w;
+    }
+  } else {
+    for (int c = 0; c < DH; ++c) acc += a[c] * b[c];
+  }
   delta[(int64_t)h * N + q] = acc;
 }
 

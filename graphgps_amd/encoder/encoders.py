@@ -37,10 +37,27 @@ class _OGBFeatureEncoder(nn.Module):
 
     def _encode(self, feats):
         embs = getattr(self, self._attr)
+        if feats.is_cuda and feats.shape[1] == len(embs):
+            return self._encode_onehot(feats, embs)
         out = 0
         for i in range(feats.shape[1]):
             out = out + embs[i](feats[:, i])
         return out
+
+    def _encode_onehot(self, feats, embs):
+        """Same sum of per-column embedding rows, as ONE [R, sum(vocab)] x [sum(vocab), emb] GEMM
+        over a multi-hot matrix (vocabularies are tiny: 173 atom / 13 bond entries).  The point
+        is the backward: grad_W = multihot^T @ g is a deterministic GEMM instead of 9 (3)
+        sort-based ``embedding_dense_backward`` pipelines (~1.3 ms per step on MI355X)."""
+        offs = getattr(self, "_offsets", None)
+        if offs is None or offs.device != feats.device:
+            sizes = [e.num_embeddings for e in embs]
+            offs = torch.tensor([sum(sizes[:i]) for i in range(len(sizes))], device=feats.device)
+            self._offsets, self._vocab = offs, sum(sizes)
+        multihot = torch.zeros(feats.shape[0], self._vocab, dtype=embs[0].weight.dtype,
+                               device=feats.device)
+        multihot.scatter_(1, feats + offs, 1.0)
+        return multihot @ torch.cat([e.weight for e in embs], dim=0)
 
 
 @register_node_encoder('Atom', overwrite=True)

@@ -124,6 +124,42 @@ def add_dropout(a: torch.Tensor, b: torch.Tensor, p_drop: float, training: bool,
     return _ActDropAdd.apply(a, b, False, float(p_drop), int(seed or draw_dropout_seed()))
 
 
+class _Linear(torch.autograd.Function):
+    """y = x W^T + b with rocBLAS/hipBLASLt GEMMs (through torch) and the bias gradient taken by
+    the library's deterministic two-stage column sum instead of ATen's reduce_kernel."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, weight = ctx.saved_tensors
+        g = _f32c(g, "g")
+        g_x = g.mm(weight) if ctx.needs_input_grad[0] else None
+        g_w = g.t().mm(x) if ctx.needs_input_grad[1] else None
+        g_b = None
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            L = _lib.load()
+            R, d = g.shape
+            g_b = torch.empty(d, dtype=torch.float32, device=g.device)
+            ws = torch.empty(max(L.gps_bn_workspace_floats(R, d), 1), dtype=torch.float32,
+                             device=g.device)
+            check(L.gps_colsum(ptr(g), R, d, ptr(g_b), ptr(ws), current_stream(g.device)),
+                  "gps_colsum")
+        return g_x, g_w, g_b
+
+
+def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """``F.linear`` for the [N,d] / [E,d] projections of the layer (A..E, in/out-proj, FFN)."""
+    if not (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and x.shape[0] >= 1
+            and torch.is_grad_enabled()):
+        return F.linear(x, weight, bias)
+    return _Linear.apply(x, weight, bias)
+
+
 def relu_dropout(x: torch.Tensor, p_drop: float, training: bool,
                  seed: Optional[int] = None) -> torch.Tensor:
     """``dropout(relu(x))`` (FFN, gps_layer.py:256)."""

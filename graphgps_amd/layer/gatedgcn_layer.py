@@ -14,7 +14,7 @@ import torch.nn.functional as F
 from ..graphgym import register
 from ..graphgym import act as _act  # noqa: F401  (fills act_dict)
 from ..graphgym.register import register_layer
-from ..fused import bn_act
+from ..fused import bn_act, linear
 from ..ops import gatedgcn_aggregate, graph_index_of
 
 
@@ -49,8 +49,8 @@ class GatedGCNLayer(nn.Module):
         # Ax|Bx|Dx|Ex in one GEMM; column block order is what csrc/gatedgcn.hip expects
         w = torch.cat([self.A.weight, self.B.weight, self.D.weight, self.E.weight], dim=0)
         b = torch.cat([self.A.bias, self.B.bias, self.D.bias, self.E.bias], dim=0)
-        proj = F.linear(x, w, b)
-        ce = self.C(e)
+        proj = linear(x, w, b)
+        ce = linear(e, self.C.weight, self.C.bias)
         x, e = gatedgcn_aggregate(proj, ce, gi)
         if isinstance(self.act_fn_x, nn.ReLU) and isinstance(self.act_fn_e, nn.ReLU):
             # lines :72-83 as two fused passes per stream (csrc/bn_fused.hip)

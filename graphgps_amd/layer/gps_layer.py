@@ -21,7 +21,7 @@ import torch.nn.functional as F
 
 from ..graphgym import register
 from ..graphgym import act as _act  # noqa: F401
-from ..fused import add_dropout, bn_act, relu_dropout
+from ..fused import add_dropout, bn_act, linear, relu_dropout
 from ..ops import graph_index_of, segment_attention
 from .gatedgcn_layer import GatedGCNLayer
 from .gine_conv_layer import GINEConv
@@ -179,20 +179,20 @@ class GPSLayer(nn.Module):
         Same arithmetic as nn.MultiheadAttention(x, x, x, key_padding_mask=~mask)[mask]
         (reference :199-201,234-241) without the dense padding."""
         sa = self.self_attn
-        qkv = F.linear(x, sa.in_proj_weight, sa.in_proj_bias)
+        qkv = linear(x, sa.in_proj_weight, sa.in_proj_bias)
         p = self.attn_dropout if self.training else 0.0
         o = segment_attention(qkv, gi, self.num_heads, p)
-        return F.linear(o, sa.out_proj.weight, sa.out_proj.bias)
+        return linear(o, sa.out_proj.weight, sa.out_proj.bias)
 
     def _ff_block(self, x):
         """ff_linear2(ff_dropout1(act(ff_linear1(x)))); ff_dropout2 is applied by the caller
         together with the residual add (reference :253-257)."""
-        x = self.ff_linear1(x)
+        x = linear(x, self.ff_linear1.weight, self.ff_linear1.bias)
         if isinstance(self.act_fn_ff, nn.ReLU):
             x = relu_dropout(x, self.ff_dropout1.p, self.training)
         else:
             x = self.ff_dropout1(self.act_fn_ff(x))
-        return self.ff_linear2(x)
+        return linear(x, self.ff_linear2.weight, self.ff_linear2.bias)
 
     def extra_repr(self):
         return (f'summary: dim_h={self.dim_h}, local_gnn_type={self.local_gnn_type}, '

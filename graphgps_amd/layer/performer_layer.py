@@ -18,6 +18,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from ..fused import linear
 from ..ops import favor_attention
 
 
@@ -93,9 +94,9 @@ class SelfAttention(nn.Module):
         b = None
         if self.to_q.bias is not None:
             b = torch.cat([self.to_q.bias, self.to_k.bias, self.to_v.bias], dim=0)
-        qkv = F.linear(x, w, b)
+        qkv = linear(x, w, b)
         out = favor_attention(qkv, self.fast_attention.projection_matrix, gi, self.heads)
-        return self.dropout(self.to_out(out))
+        return self.dropout(linear(out, self.to_out.weight, self.to_out.bias))
 
     def forward(self, x, mask=None, **kwargs):
         raise NotImplementedError(

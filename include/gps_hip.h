@@ -185,6 +185,10 @@ int gps_act_drop_add(const float* a, const float* b, int64_t R, int d, int relu,
                      uint64_t seed, float* out, gps_stream_t stream);
 int gps_act_drop_bwd(const float* g, const float* pre, int64_t R, int d, int relu, float p_drop,
                      uint64_t seed, float* g_b, gps_stream_t stream);
+/* out[d] = column sums of x[R,d] (deterministic two-stage reduction; ws >= gps_bn_workspace_floats).
+ * Replaces ATen's reduce_kernel for the bias gradients of the dense projections (autograd of
+ * nn.Linear at graphgps/layer/gatedgcn_layer.py:57-61, graphgps/layer/gps_layer.py:143-144). */
+int gps_colsum(const float* x, int64_t R, int d, float* out, float* ws, gps_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Graph pooling over `ptr` segments (sum: mean = 0, mean: mean = 1) and its backward.
