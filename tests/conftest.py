@@ -50,7 +50,7 @@ def assert_close(a, b, tol, what, rel_to_max=False):
     return err / scale
 
 
-def assert_close_kink_tolerant(a, b, tol, what, max_outlier_row_frac=1e-3):
+def assert_close_kink_tolerant(a, b, tol, what, max_outlier_row_frac=1e-3, min_scale=1.0):
     """Gradient parity at full BASELINE sizes.  With ~2e7 ReLU pre-activations per layer, a
     handful lie within fp32 rounding of 0 and land on different sides of the kink on the GPU
     and on the CPU; each such flip changes the gradient of ONE row (all its channels) by
@@ -60,7 +60,7 @@ def assert_close_kink_tolerant(a, b, tol, what, max_outlier_row_frac=1e-3):
     says how many did not.  Forward outputs never use this helper."""
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     assert a.shape == b.shape, f"{what}: shape {tuple(a.shape)} vs {tuple(b.shape)}"
-    scale = max(b.abs().max().item(), 1.0)
+    scale = max(b.abs().max().item(), min_scale)
     if a.dim() == 1:            # vectors: every element is its own "row"
         a, b = a.view(-1, 1), b.view(-1, 1)
     err = ((a - b).abs() / scale).view(a.shape[0], -1)

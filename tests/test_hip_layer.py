@@ -105,6 +105,7 @@ def test_gpslayer_vs_oracle_baseline_sizes(local, glob, d, H, profile, nb):
     print(f"grad x: max rel {rx[0]:.2e} outside {rx[2]} kink rows; "
           f"grad e: max rel {re_[0]:.2e} outside {re_[2]} kink rows")
     op = dict(oracle.named_parameters())
+    gscale = max(float(q.grad.abs().max()) for q in op.values() if q.grad is not None)
     for k, p in layer.named_parameters():
         if op[k].grad is None:
             continue
@@ -112,7 +113,11 @@ def test_gpslayer_vs_oracle_baseline_sizes(local, glob, d, H, profile, nb):
         # order differs between rocBLAS and the CPU BLAS (bar 1e-4 of max|g|), and a ReLU-kink
         # flip at (row r, channel c) lands undamped in row c of a weight gradient, so a few
         # outlier rows per parameter are allowed (see assert_close_kink_tolerant)
-        r = assert_close_kink_tolerant(p.grad, op[k].grad, 1e-4, f"grad {k}")
+        # biases that feed a BatchNorm have a mathematically zero gradient: what both sides hold
+        # is the rounding residue of a 7.5k-term cancelling sum, so the scale floor is 1 % of the
+        # layer's largest parameter gradient rather than the parameter's own (noise) magnitude
+        r = assert_close_kink_tolerant(p.grad, op[k].grad, 1e-4, f"grad {k}",
+                                       min_scale=max(1.0, 0.01 * gscale))
         if r[2]:
             print(f"grad {k}: {r[2]} kink rows, max rel {r[0]:.2e} outside them")
 
