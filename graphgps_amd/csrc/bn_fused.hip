@@ -6,8 +6,9 @@
 //   relu -> dropout inside the FFN                 graphgps/layer/gps_layer.py:253-257
 // (ATen: collect_statistics + transform + relu + dropout + add forward, reduce + elemt + masked_scale +
 // threshold backward; the [E,384] reductions alone ran ~60 us each on MI355X) with:
-//   stats   : per-column (count, mean, M2) per 128-row block (shifted sums) + an in-order Chan merge
-//             -> batch mean / biased var, running-stat update.  Deterministic, Welford-grade accuracy.
+//   stats   : per-column shifted sums (x - x[0]) over ~512 row blocks + an in-order two-level sum
+//             -> batch mean / biased var, running-stat update.  Deterministic; the shift removes the
+//             E[x^2]-E[x]^2 cancellation (tests/test_hip_ops.py::test_bn_stats_large_mean_is_accurate).
 //   apply   : y = res + drop(relu((z - mean) * rstd * gamma + beta))     (each stage optional)
 //   bwd     : column sums of g and g*zhat (g = dL/d(bn output), ReLU and dropout masks RECOMPUTED from
 //             z and the counter hash -> nothing but z is saved), then
@@ -22,7 +23,7 @@
 
 namespace {
 
-constexpr int TARGET_BLOCKS = 1024;  // stage-1 partial blocks: ~4 per CU so the reduction fills the chip
+constexpr int TARGET_BLOCKS = 512;   // stage-1 partial blocks: ~2 per CU so the reduction fills the chip
 constexpr int FCOLS = 16, FCHUNKS = 16;  // stage-2 block = 16 columns x 16 partial-list chunks
 
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
@@ -53,7 +54,10 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ z,
   const bool active = rsub < RS;
   Vec<VEC> k = Vec<VEC>::zero(), s1 = Vec<VEC>::zero(), s2 = Vec<VEC>::zero();
   if (active) {
-    k = Vec<VEC>::load(z + row0 * d + c);  // shift = the block's first row (kills cancellation)
+    // shift = row 0 of the WHOLE tensor (a sample of the column's distribution): kills the
+    // E[x^2]-E[x]^2 cancellation like a per-block shift would, and because it is the same for every
+    // block the partial sums simply add in stage 2 (no Chan merge, no divisions, pipelinable loads)
+    k = Vec<VEC>::load(z + c);
     for (int64_t r = row0 + rsub; r < row1; r += RS) {
       const Vec<VEC> v = Vec<VEC>::load(z + r * d + c);
 #pragma unroll
@@ -73,7 +77,6 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ z,
   }
   __syncthreads();
   if (active && rsub == 0) {
-    const float n = (float)(row1 - row0);
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       float a = s1[j], b = s2[j];
@@ -81,56 +84,48 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ z,
         a += lds[(q * 2 + 0) * d + c + j];
         b += lds[(q * 2 + 1) * d + c + j];
       }
-      float* o = ws + (int64_t)blockIdx.x * 3 * d;
-      o[c + j] = n;
-      o[d + c + j] = k[j] + a / n;
-      o[2 * d + c + j] = b - a * a / n;
+      float* o = ws + (int64_t)blockIdx.x * 2 * d;   // [nblocks][2][d] = (sum(x-k), sum((x-k)^2))
+      o[c + j] = a;
+      o[d + c + j] = b;
     }
   }
 }
 
-// Stage 2: block = FCOLS columns x FCHUNKS chunks of the partial list.  Each thread Chan-merges its
-// contiguous chunk in order, then chunk 0 merges the FCHUNKS results in order: fixed tree shape ->
-// deterministic; sequential depth nblocks/16 + 16 instead of nblocks.
-__device__ __forceinline__ void chan_merge(float& n, float& mean, float& m2, float nb, float mb,
-                                           float qb) {
-  if (nb <= 0.0f) return;
-  const float nn = n + nb;
-  const float delta = mb - mean;
-  mean += delta * (nb / nn);
-  m2 += qb + delta * delta * (n * nb / nn);
-  n = nn;
-}
-
+// Stage 2: block = FCOLS columns x FCHUNKS chunks of the partial list.  Each thread sums its
+// contiguous chunk in order, chunk 0 then adds the FCHUNKS results in order (fixed tree shape ->
+// deterministic; sequential depth nblocks/16 + 16, branch-free so the loads pipeline).
 __global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ ws, int nblocks, int d,
+                                                     const float* __restrict__ z, float count,
                                                      float eps, float momentum,
                                                      float* __restrict__ mean_out,
                                                      float* __restrict__ rstd_out,
                                                      float* __restrict__ running_mean,
                                                      float* __restrict__ running_var) {
-  __shared__ float sh[FCHUNKS][FCOLS][3];
+  __shared__ float sh[FCHUNKS][FCOLS][2];
   const int col = threadIdx.x % FCOLS, chunk = threadIdx.x / FCOLS;
   const int c = blockIdx.x * FCOLS + col;
   const int per = (nblocks + FCHUNKS - 1) / FCHUNKS;
   const int b0 = chunk * per, b1 = min(nblocks, b0 + per);
-  float n = 0.f, mean = 0.f, m2 = 0.f;
+  float a = 0.f, b = 0.f;
   if (c < d) {
-#pragma unroll 4
-    for (int b = b0; b < b1; ++b) {
-      const float* w = ws + (int64_t)b * 3 * d + c;
-      chan_merge(n, mean, m2, w[0], w[d], w[2 * d]);
+#pragma unroll 8
+    for (int k = b0; k < b1; ++k) {
+      a += ws[(int64_t)k * 2 * d + c];
+      b += ws[(int64_t)k * 2 * d + d + c];
     }
   }
-  sh[chunk][col][0] = n; sh[chunk][col][1] = mean; sh[chunk][col][2] = m2;
+  sh[chunk][col][0] = a; sh[chunk][col][1] = b;
   __syncthreads();
   if (chunk == 0 && c < d) {
-    for (int q = 1; q < FCHUNKS; ++q) chan_merge(n, mean, m2, sh[q][col][0], sh[q][col][1], sh[q][col][2]);
-    const float var = m2 / n;
+    for (int q = 1; q < FCHUNKS; ++q) { a += sh[q][col][0]; b += sh[q][col][1]; }
+    const float s1 = a / count;                 // mean of (x - k)
+    const float mean = z[c] + s1;               // k = row 0 of the tensor
+    const float m2 = fmaxf(b - a * s1, 0.0f);   // sum (x - mean)^2
     mean_out[c] = mean;
-    rstd_out[c] = 1.0f / sqrtf(var + eps);
+    rstd_out[c] = 1.0f / sqrtf(m2 / count + eps);
     if (running_mean) {
       running_mean[c] = (1.0f - momentum) * running_mean[c] + momentum * mean;
-      running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (m2 / fmaxf(n - 1.0f, 1.0f));
+      running_var[c] = (1.0f - momentum) * running_var[c] + momentum * (m2 / fmaxf(count - 1.0f, 1.0f));
     }
   }
 }
@@ -251,7 +246,7 @@ __global__ __launch_bounds__(256) void k_bn_bwd_finalize(const float* __restrict
   const int b0 = chunk * per, b1 = min(nblocks, b0 + per);
   float a = 0.f, b = 0.f;
   if (c < d) {
-#pragma unroll 4
+#pragma unroll 8
     for (int k = b0; k < b1; ++k) {
       a += ws[(int64_t)k * 2 * d + c];
       b += ws[(int64_t)k * 2 * d + d + c];
@@ -398,7 +393,7 @@ __global__ __launch_bounds__(256) void k_colsum_finalize(const float* __restrict
   const int b0 = chunk * per, b1 = min(nblocks, b0 + per);
   float a = 0.f;
   if (c < d) {
-#pragma unroll 4
+#pragma unroll 8
     for (int k = b0; k < b1; ++k) a += ws[(int64_t)k * d + c];
   }
   sh[chunk][col] = a;
@@ -450,8 +445,8 @@ int gps_bn_stats(const float* z, int64_t R, int d, float eps, float momentum, fl
     const int RS = 256 / (d / VEC);
     k_bn_partial<VEC><<<nb, 256, sizeof(float) * 2 * RS * d, s>>>(z, R, d, rows_per_block(R), ws);
   });
-  k_bn_finalize<<<gps::grid_for(d, FCOLS), 256, 0, s>>>(ws, nb, d, eps, momentum, mean, rstd, running_mean,
-                                                        running_var);
+  k_bn_finalize<<<gps::grid_for(d, FCOLS), 256, 0, s>>>(ws, nb, d, z, (float)R, eps, momentum, mean, rstd,
+                                                        running_mean, running_var);
   return gps::launch_status("gps_bn_stats");
 }
 

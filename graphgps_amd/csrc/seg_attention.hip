@@ -79,6 +79,78 @@ __device__ __forceinline__ float group_sum(float v) {
 // =============================================================================================
 // forward
 // =============================================================================================
+// One 64-key block with NT (1..4) live 16-key tiles.  Branch-free and fully unrolled on purpose:
+// every K and V operand load of the block is issued before the first MFMA, so a wave pays ONE
+// memory round trip per block instead of one per tile (the kernel is latency-bound at molecule
+// sizes: ~30 x 30 x 24 per (graph, head)).  Rows past the graph end are clamped to its last row
+// (finite data) and their scores masked to -inf, so they contribute exactly 0.
+template <int DH, bool DROP, int NT>
+__device__ __forceinline__ void attn_fwd_block(
+    const float* __restrict__ qkv, int64_t ld, int kb, int n0, int n1, int h, int d, int i, int grp,
+    const float (&qv)[Geo<DH>::KPL], uint32_t rh, float p_drop, float inv_keep, float& m, float& lsum,
+    f32x4 (&oacc)[Geo<DH>::DT]) {
+  constexpr int KPL = Geo<DH>::KPL, DT = Geo<DH>::DT;
+  float kv[NT][KPL];
+  float vv[DT][NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int krow = min(kb + 16 * t + i, n1 - 1);
+    load_kslice<DH>(qkv, ld, krow, true, d + h * DH, grp, 1.0f, kv[t]);
+  }
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = min(kb + 16 * t + 4 * grp + r, n1 - 1);
+        const int col = dt * 16 + i;
+        vv[dt][t][r] = col < DH ? qkv[(int64_t)key * ld + 2 * d + h * DH + col] : 0.0f;
+      }
+  f32x4 s[NT];
+  float mloc = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < NT; ++t) s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int c = 0; c < KPL; ++c)          // tiles interleaved: NT independent accumulator chains
+#pragma unroll
+    for (int t = 0; t < NT; ++t) s[t] = mfma16(kv[t][c], qv[c], s[t]);
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = kb + 16 * t + 4 * grp + r;
+      s[t][r] = key < n1 ? s[t][r] : -INFINITY;
+      mloc = fmaxf(mloc, s[t][r]);
+    }
+  const float mnew = fmaxf(m, group_max(mloc));
+  const float alpha = expf(m - mnew);  // m = -inf on the first block -> 0
+  m = mnew;
+  float psum = 0.0f;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      float p = expf(s[t][r] - mnew);  // masked keys: exp(-inf) = 0
+      psum += p;
+      if (DROP) {
+        const uint32_t key_local = (uint32_t)(kb + 16 * t + 4 * grp + r - n0);
+        p = keep_elem(rh, key_local, p_drop) ? p * inv_keep : 0.0f;
+      }
+      s[t][r] = p;
+    }
+  lsum = lsum * alpha + psum;
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt) oacc[dt] *= alpha;
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)    // DT independent accumulator chains interleaved
+        oacc[dt] = mfma16(vv[dt][t][r], s[t][r], oacc[dt]);
+}
+
 template <int DH, bool DROP>
 __global__ __launch_bounds__(256) void k_attn_fwd(
     const float* __restrict__ qkv, int64_t ld, const int32_t* __restrict__ ptr,
@@ -111,59 +183,12 @@ __global__ __launch_bounds__(256) void k_attn_fwd(
   for (int dt = 0; dt < DT; ++dt) oacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   for (int kb = n0; kb < n1; kb += 16 * KT) {
-    f32x4 s[KT];
-    float mloc = -INFINITY;
-#pragma unroll
-    for (int t = 0; t < KT; ++t) {
-      s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-      const int k_tile0 = kb + 16 * t;
-      if (k_tile0 < n1) {  // wave-uniform
-        float kv[KPL];
-        const int krow = k_tile0 + i;
-        load_kslice<DH>(qkv, ld, krow, krow < n1, d + h * DH, grp, 1.0f, kv);
-#pragma unroll
-        for (int c = 0; c < KPL; ++c) s[t] = mfma16(kv[c], qv[c], s[t]);
-      }
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = k_tile0 + 4 * grp + r;
-        s[t][r] = key < n1 ? s[t][r] : -INFINITY;
-        mloc = fmaxf(mloc, s[t][r]);
-      }
-    }
-    const float mnew = fmaxf(m, group_max(mloc));
-    const float alpha = expf(m - mnew);  // m = -inf on the first block -> 0
-    m = mnew;
-    float psum = 0.0f;
-#pragma unroll
-    for (int t = 0; t < KT; ++t)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        float p = expf(s[t][r] - mnew);  // masked keys: exp(-inf) = 0
-        psum += p;
-        if (DROP) {
-          const uint32_t key_local = (uint32_t)(kb + 16 * t + 4 * grp + r - n0);
-          p = keep_elem(rh, key_local, p_drop) ? p * inv_keep : 0.0f;
-        }
-        s[t][r] = p;
-      }
-    lsum = lsum * alpha + psum;
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) {
-      oacc[dt] *= alpha;
-#pragma unroll
-      for (int t = 0; t < KT; ++t) {
-        if (kb + 16 * t < n1) {  // wave-uniform
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int key = kb + 16 * t + 4 * grp + r;
-            const int col = dt * 16 + i;
-            const bool ok = key < n1 && col < DH;
-            const float vv = ok ? qkv[(int64_t)key * ld + 2 * d + h * DH + col] : 0.0f;
-            oacc[dt] = mfma16(vv, s[t][r], oacc[dt]);
-          }
-        }
-      }
+    const int nt = min(KT, (n1 - kb + 15) >> 4);  // wave-uniform
+    switch (nt) {
+      case 1: attn_fwd_block<DH, DROP, 1>(qkv, ld, kb, n0, n1, h, d, i, grp, qv, rh, p_drop, inv_keep, m, lsum, oacc); break;
+      case 2: attn_fwd_block<DH, DROP, 2>(qkv, ld, kb, n0, n1, h, d, i, grp, qv, rh, p_drop, inv_keep, m, lsum, oacc); break;
+      case 3: attn_fwd_block<DH, DROP, 3>(qkv, ld, kb, n0, n1, h, d, i, grp, qv, rh, p_drop, inv_keep, m, lsum, oacc); break;
+      default: attn_fwd_block<DH, DROP, 4>(qkv, ld, kb, n0, n1, h, d, i, grp, qv, rh, p_drop, inv_keep, m, lsum, oacc); break;
     }
   }
   const float ltot = group_sum(lsum);
@@ -241,6 +266,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) acc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+#pragma unroll 2
   for (int kb = n0; kb < n1; kb += 16) {
     const int krow = kb + i;
     float kv[KPL], vv[KPL];
@@ -321,6 +347,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(
     dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
 
+#pragma unroll 2
   for (int qb = n0; qb < n1; qb += 16) {
     const int qrow = qb + i;
     float qa[KPL], da[KPL];
