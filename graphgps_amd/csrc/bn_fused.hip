@@ -6,9 +6,10 @@
 //   relu -> dropout inside the FFN                 graphgps/layer/gps_layer.py:253-257
 // (ATen: collect_statistics + transform + relu + dropout + add forward, reduce + elemt + masked_scale +
 // threshold backward; the [E,384] reductions alone ran ~60 us each on MI355X) with:
-//   stats   : per-column shifted sums (x - x[0]) over ~512 row blocks + an in-order two-level sum
-//             -> batch mean / biased var, running-stat update.  Deterministic; the shift removes the
-//             E[x^2]-E[x]^2 cancellation (tests/test_hip_ops.py::test_bn_stats_large_mean_is_accurate).
+//   stats   : per-column (mean_b, M2_b) of ~512 row blocks (block-local shifted sums) combined by a
+//             two-pass stage 2 (global mean, then sum of M2_b + n_b (mean_b - mean)^2) -> batch mean /
+//             biased var, running-stat update.  Deterministic, Welford-grade accuracy
+//             (tests/test_hip_ops.py::test_bn_stats_large_mean_is_accurate).
 //   apply   : y = res + drop(relu((z - mean) * rstd * gamma + beta))     (each stage optional)
 //   bwd     : column sums of g and g*zhat (g = dL/d(bn output), ReLU and dropout masks RECOMPUTED from
 //             z and the counter hash -> nothing but z is saved), then
@@ -40,7 +41,7 @@ __device__ __forceinline__ bool keep_elem(uint32_t rh, uint32_t col, float p_dro
 }
 
 // ---- statistics ---------------------------------------------------------------------------------
-// ws layout: [nblocks][3][d] = (count, mean, M2) per block and column.
+// ws layout: [nblocks][2][d] = (mean_b, M2_b) per block and column.
 template <int VEC>
 __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ z, int64_t R, int d,
                                                     int rpb, float* __restrict__ ws) {
@@ -54,10 +55,9 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ z,
   const bool active = rsub < RS;
   Vec<VEC> k = Vec<VEC>::zero(), s1 = Vec<VEC>::zero(), s2 = Vec<VEC>::zero();
   if (active) {
-    // shift = row 0 of the WHOLE tensor (a sample of the column's distribution): kills the
-    // E[x^2]-E[x]^2 cancellation like a per-block shift would, and because it is the same for every
-    // block the partial sums simply add in stage 2 (no Chan merge, no divisions, pipelinable loads)
-    k = Vec<VEC>::load(z + c);
+    // shift = the block's own first row: inside a ~15-row block the shifted sums have no
+    // E[x^2]-E[x]^2 cancellation to speak of, so (mean_b, M2_b) are accurate to ~1 ulp
+    k = Vec<VEC>::load(z + row0 * d + c);
     for (int64_t r = row0 + rsub; r < row1; r += RS) {
       const Vec<VEC> v = Vec<VEC>::load(z + r * d + c);
 #pragma unroll
@@ -84,43 +84,64 @@ __global__ __launch_bounds__(256) void k_bn_partial(const float* __restrict__ z,
         a += lds[(q * 2 + 0) * d + c + j];
         b += lds[(q * 2 + 1) * d + c + j];
       }
-      float* o = ws + (int64_t)blockIdx.x * 2 * d;   // [nblocks][2][d] = (sum(x-k), sum((x-k)^2))
-      o[c + j] = a;
-      o[d + c + j] = b;
+      const float n = (float)(row1 - row0);
+      float* o = ws + (int64_t)blockIdx.x * 2 * d;   // [nblocks][2][d] = (mean_b, M2_b)
+      o[c + j] = k[j] + a / n;
+      o[d + c + j] = fmaxf(b - a * a / n, 0.0f);
     }
   }
 }
 
-// Stage 2: block = FCOLS columns x FCHUNKS chunks of the partial list.  Each thread sums its
-// contiguous chunk in order, chunk 0 then adds the FCHUNKS results in order (fixed tree shape ->
-// deterministic; sequential depth nblocks/16 + 16, branch-free so the loads pipeline).
+// Stage 2: block = FCOLS columns x FCHUNKS chunks of the partial list; every thread keeps its chunk
+// of (mean_b, M2_b) in registers.  Pass 1: global mean = sum n_b mean_b / n.  Pass 2: M2 = sum
+// [M2_b + n_b (mean_b - mean)^2] -- a sum of non-negative terms, no cancellation, no sequential
+// Chan chain, loads issued once and pipelined.  Fixed summation tree -> deterministic.
+constexpr int FPER = (TARGET_BLOCKS + FCHUNKS - 1) / FCHUNKS;   // partials per thread (32)
+
 __global__ __launch_bounds__(256) void k_bn_finalize(const float* __restrict__ ws, int nblocks, int d,
-                                                     const float* __restrict__ z, float count,
-                                                     float eps, float momentum,
+                                                     int rpb, float count, float eps, float momentum,
                                                      float* __restrict__ mean_out,
                                                      float* __restrict__ rstd_out,
                                                      float* __restrict__ running_mean,
                                                      float* __restrict__ running_var) {
-  __shared__ float sh[FCHUNKS][FCOLS][2];
+  __shared__ float sh[FCHUNKS][FCOLS];
+  __shared__ float sh_mean[FCOLS];
   const int col = threadIdx.x % FCOLS, chunk = threadIdx.x / FCOLS;
   const int c = blockIdx.x * FCOLS + col;
-  const int per = (nblocks + FCHUNKS - 1) / FCHUNKS;
-  const int b0 = chunk * per, b1 = min(nblocks, b0 + per);
-  float a = 0.f, b = 0.f;
-  if (c < d) {
-#pragma unroll 8
-    for (int k = b0; k < b1; ++k) {
-      a += ws[(int64_t)k * 2 * d + c];
-      b += ws[(int64_t)k * 2 * d + d + c];
-    }
+  const int per = (nblocks + FCHUNKS - 1) / FCHUNKS;   // <= FPER
+  const int b0 = chunk * per;
+  float mb[FPER], qb[FPER], nbv[FPER];
+  float a = 0.f;
+#pragma unroll
+  for (int j = 0; j < FPER; ++j) {
+    const int b = b0 + j;
+    const bool ok = c < d && j < per && b < nblocks;
+    mb[j] = ok ? ws[(int64_t)b * 2 * d + c] : 0.f;
+    qb[j] = ok ? ws[(int64_t)b * 2 * d + d + c] : 0.f;
+    // rows in block b: rpb, except the last block
+    nbv[j] = ok ? fminf((float)rpb, count - (float)b * (float)rpb) : 0.f;
   }
-  sh[chunk][col][0] = a; sh[chunk][col][1] = b;
+#pragma unroll
+  for (int j = 0; j < FPER; ++j) a += nbv[j] * mb[j];
+  sh[chunk][col] = a;
+  __syncthreads();
+  if (chunk == 0) {
+    for (int q = 1; q < FCHUNKS; ++q) a += sh[q][col];
+    sh_mean[col] = a / count;
+  }
+  __syncthreads();
+  const float mean = sh_mean[col];
+  float m2 = 0.f;
+#pragma unroll
+  for (int j = 0; j < FPER; ++j) {
+    const float dl = mb[j] - mean;
+    m2 += qb[j] + nbv[j] * dl * dl;
+  }
+  __syncthreads();
+  sh[chunk][col] = m2;
   __syncthreads();
   if (chunk == 0 && c < d) {
-    for (int q = 1; q < FCHUNKS; ++q) { a += sh[q][col][0]; b += sh[q][col][1]; }
-    const float s1 = a / count;                 // mean of (x - k)
-    const float mean = z[c] + s1;               // k = row 0 of the tensor
-    const float m2 = fmaxf(b - a * s1, 0.0f);   // sum (x - mean)^2
+    for (int q = 1; q < FCHUNKS; ++q) m2 += sh[q][col];
     mean_out[c] = mean;
     rstd_out[c] = 1.0f / sqrtf(m2 / count + eps);
     if (running_mean) {
@@ -445,8 +466,8 @@ int gps_bn_stats(const float* z, int64_t R, int d, float eps, float momentum, fl
     const int RS = 256 / (d / VEC);
     k_bn_partial<VEC><<<nb, 256, sizeof(float) * 2 * RS * d, s>>>(z, R, d, rows_per_block(R), ws);
   });
-  k_bn_finalize<<<gps::grid_for(d, FCOLS), 256, 0, s>>>(ws, nb, d, z, (float)R, eps, momentum, mean, rstd,
-                                                        running_mean, running_var);
+  k_bn_finalize<<<gps::grid_for(d, FCOLS), 256, 0, s>>>(ws, nb, d, rows_per_block(R), (float)R, eps, momentum,
+                                                        mean, rstd, running_mean, running_var);
   return gps::launch_status("gps_bn_stats");
 }
 

@@ -319,26 +319,35 @@ def test_bn_act_fused(R, d, relu, p, with_res):
     bn_gpu.load_state_dict({k: v.float() if v.is_floating_point() else v
                             for k, v in bn_ref.state_dict().items()})
     bn_gpu.cuda().train()
-    zr = z.double().requires_grad_(True)
-    y = bn_ref(zr)
-    if relu:
-        y = y.relu()
-    if p > 0:
-        y = y * _drop_mask(seed, R, d, p).double() / (1 - p)
-    rr = res.double().requires_grad_(True) if with_res else None
-    if with_res:
-        y = rr + y
-    (y * w.double()).sum().backward()
+    import copy
+    bn_probe = copy.deepcopy(bn_gpu)
     zg = z.cuda().requires_grad_(True)
     rg = res.cuda().requires_grad_(True) if with_res else None
     yg = bn_act(zg, bn_gpu, relu=relu, p_drop=p, res=rg, seed=seed)
     (yg * w.cuda()).sum().backward()
-    assert_close(yg, y, Tol.ACT, "bn_act out")
-    if relu:   # ~3e6 pre-activations: one or two sit within rounding of the ReLU kink (fp32 vs fp64 side)
-        from conftest import assert_close_kink_tolerant
-        assert_close_kink_tolerant(zg.grad, zr.grad, Tol.GRAD_REL, "bn_act g_z", outlier_cap=1.0)
+    with torch.no_grad():   # same op without the residual: its zeros ARE the ReLU/dropout decisions
+        branch = bn_act(z.cuda(), bn_probe, relu=relu, p_drop=p, res=None, seed=seed).cpu().double()
+    # fp64 reference.  The forward is checked against the true ReLU; for the BACKWARD the ReLU
+    # decision the GPU actually took is injected (read off its output), because of ~3e6
+    # pre-activations one or two sit within fp32 rounding of the kink, and a single flipped
+    # element shifts a whole column of g_z through BatchNorm's mean terms by ~1/R.
+    zr = z.double().requires_grad_(True)
+    rr = res.double().requires_grad_(True) if with_res else None
+    pre = bn_ref(zr)
+    keep = _drop_mask(seed, R, d, p).double() / (1 - p) if p > 0 else 1.0
+    y_true = (pre.relu() if relu else pre) * keep
+    if with_res:
+        y_true = rr + y_true
+    assert_close(yg, y_true, Tol.ACT, "bn_act out")
+    if relu:
+        gate = (branch != 0).double() if p == 0 else ((branch != 0) | (keep == 0)).double()
+        y = pre * gate * keep
+        if with_res:
+            y = rr + y
     else:
-        assert_close(zg.grad, zr.grad, Tol.GRAD_REL, "bn_act g_z", rel_to_max=True)
+        y = y_true
+    (y * w.double()).sum().backward()
+    assert_close(zg.grad, zr.grad, Tol.GRAD_REL, "bn_act g_z", rel_to_max=True)
     assert_close(bn_gpu.weight.grad, bn_ref.weight.grad, 1e-4, "g_gamma", rel_to_max=True)
     assert_close(bn_gpu.bias.grad, bn_ref.bias.grad, 1e-4, "g_beta", rel_to_max=True)
     if with_res:
