@@ -241,7 +241,14 @@ def main():
         cpu_ref_model = copy.deepcopy(model)
     model.to(dev)
     batch_dev = batch_cpu.clone().to(dev)
-    reducer = GradBucketReducer(model) if world > 1 else None
+    # GPS_BENCH_FORCE_REDUCER=1 exercises the bucketed all-reduce path on a single rank too
+    # (used to validate the RCCL plumbing on the 1-GPU box; not the default measurement)
+    use_reducer = world > 1 or os.environ.get("GPS_BENCH_FORCE_REDUCER") == "1"
+    if use_reducer and world == 1 and not torch.distributed.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        torch.distributed.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+    reducer = GradBucketReducer(model, force_collective=True) if use_reducer else None
     opt = torch.optim.AdamW(model.parameters(), lr=cfg.optim.base_lr,
                             weight_decay=cfg.optim.weight_decay, fused=True)
     step = make_step(model, opt, reducer, batch_dev, compute_loss, cfg.optim.clip_grad_norm_value)

@@ -62,9 +62,12 @@ class GradBucketReducer:
     """
 
     def __init__(self, model: nn.Module, process_group=None,
-                 buckets: Optional[Dict[str, List[nn.Parameter]]] = None):
+                 buckets: Optional[Dict[str, List[nn.Parameter]]] = None,
+                 force_collective: bool = False):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        # force_collective: issue the all-reduces even on a single rank (plumbing validation)
+        self.active = self.world > 1 or (force_collective and dist.is_initialized())
         self.buckets = [_Bucket(k, v) for k, v in (buckets or default_buckets(model)).items()]
         self._owner = {}
         for b in self.buckets:
@@ -77,7 +80,7 @@ class GradBucketReducer:
         return sum(b.flat.numel() * b.flat.element_size() for b in self.buckets)
 
     def _launch(self, b: _Bucket) -> None:
-        if self.world > 1 and b.work is None:
+        if self.active and b.work is None:
             b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
     def _hook(self, p: nn.Parameter) -> None:
@@ -98,7 +101,7 @@ class GradBucketReducer:
                 off += p.numel()
 
     def finish(self) -> None:
-        if self.world == 1:
+        if not self.active:
             return
         for b in self.buckets:
             self._launch(b)      # buckets with parameters that received no gradient this step
