@@ -1,17 +1,19 @@
 """Data-parallel gradient exchange for the GPS step: one process per GPU, RCCL over xGMI.
 
 The reference has no distributed code at all; graphs are independent
-units, so the batch shards across ranks with ONE exchange per step: a sum-all-reduce of the
-gradients (19.4 M fp32 = 77.7 MB for GPS-medium), here bucketed per GPS layer (~7.7 MB at
+units, so the batch shards across ranks with ONE exchange per step: an averaging all-reduce of
+the gradients (19.4 M fp32 = 77.7 MB for GPS-medium), here bucketed per GPS layer (~7.7 MB at
 d = 384) and launched from autograd hooks as soon as a bucket's last gradient has been
 accumulated, so the collective of layer l overlaps the backward of layers < l.
 
 Design points (MI355X: 8 GPUs, xGMI point-to-point, 7 links x ~153 GB/s per GPU):
-  * gradients live IN the flat bucket buffers (each ``p.grad`` is a view), so no pack/unpack
-    copies and exactly one collective per bucket;
   * buckets are per layer, not fixed-size chunks: 7.7 MB is already past the latency knee of a
     direct reduce-scatter + all-gather over 7 links, and layer granularity is what gives
     backward overlap;
+  * a bucket is packed by ONE multi-tensor copy when it completes (autograd keeps producing
+    ordinary per-parameter gradients: no per-parameter accumulate kernels), reduced in place,
+    and after ``finish()`` every ``p.grad`` IS a view of the reduced flat buffer (no unpack);
+  * the average uses RCCL's native AVG reduction (one pass); gloo falls back to SUM + scale;
   * BatchNorm statistics stay per rank (standard DDP semantics; the reference has no SyncBN).
 Works with ``backend='nccl'`` (= RCCL on ROCm) and with ``gloo`` (CPU tests).
 """
@@ -25,15 +27,15 @@ import torch.nn as nn
 
 
 class _Bucket:
-    __slots__ = ("name", "params", "flat", "pending", "work")
+    __slots__ = ("name", "params", "flat", "views", "pending", "work")
 
     def __init__(self, name: str, params: List[nn.Parameter]):
         self.name, self.params = name, params
         n = sum(p.numel() for p in params)
         self.flat = torch.zeros(n, dtype=params[0].dtype, device=params[0].device)
-        off = 0
+        self.views, off = [], 0
         for p in params:
-            p.grad = self.flat[off:off + p.numel()].view_as(p)
+            self.views.append(self.flat[off:off + p.numel()].view_as(p))
             off += p.numel()
         self.pending = len(params)
         self.work = None
@@ -56,9 +58,9 @@ class GradBucketReducer:
 
     Usage per step::
 
-        reducer.zero_grad()          # memset of the flat buffers
-        loss.backward()              # hooks launch all-reduces as buckets complete
-        reducer.finish()             # wait + 1/world scaling; grads are now rank-averaged
+        reducer.zero_grad()          # p.grad = None (no memsets)
+        loss.backward()              # hooks pack + launch all-reduces as buckets complete
+        reducer.finish()             # wait; p.grad now views the rank-averaged flat buffers
     """
 
     def __init__(self, model: nn.Module, process_group=None,
@@ -68,6 +70,8 @@ class GradBucketReducer:
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         # force_collective: issue the all-reduces even on a single rank (plumbing validation)
         self.active = self.world > 1 or (force_collective and dist.is_initialized())
+        backend = dist.get_backend(process_group) if dist.is_initialized() else ""
+        self.native_avg = backend == "nccl"
         self.buckets = [_Bucket(k, v) for k, v in (buckets or default_buckets(model)).items()]
         self._owner = {}
         for b in self.buckets:
@@ -80,8 +84,17 @@ class GradBucketReducer:
         return sum(b.flat.numel() * b.flat.element_size() for b in self.buckets)
 
     def _launch(self, b: _Bucket) -> None:
-        if self.active and b.work is None:
-            b.work = dist.all_reduce(b.flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        if b.work is not None:
+            return
+        # pack: one multi-tensor copy (parameters that got no gradient contribute zeros)
+        srcs = [p.grad if p.grad is not None else torch.zeros_like(v)
+                for p, v in zip(b.params, b.views)]
+        torch._foreach_copy_(b.views, srcs)
+        if self.active:
+            op = dist.ReduceOp.AVG if self.native_avg else dist.ReduceOp.SUM
+            b.work = dist.all_reduce(b.flat, op=op, group=self.group, async_op=True)
+        else:
+            b.work = True
 
     def _hook(self, p: nn.Parameter) -> None:
         b = self._owner[p]
@@ -91,21 +104,18 @@ class GradBucketReducer:
 
     def zero_grad(self) -> None:
         for b in self.buckets:
-            b.flat.zero_()
             b.pending = len(b.params)
             b.work = None
-            off = 0
-            for p in b.params:   # re-point in case an optimizer replaced .grad
-                if p.grad is None or p.grad.data_ptr() != b.flat.data_ptr() + off * b.flat.element_size():
-                    p.grad = b.flat[off:off + p.numel()].view_as(p)
-                off += p.numel()
+            for p in b.params:
+                p.grad = None
 
     def finish(self) -> None:
-        if not self.active:
-            return
         for b in self.buckets:
             self._launch(b)      # buckets with parameters that received no gradient this step
-        inv = 1.0 / self.world
         for b in self.buckets:
-            b.work.wait()
-            b.flat.mul_(inv)
+            if self.active:
+                b.work.wait()
+                if not self.native_avg and self.world > 1:
+                    b.flat.mul_(1.0 / self.world)
+            for p, v in zip(b.params, b.views):
+                p.grad = v

@@ -160,6 +160,94 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) 
     return _Linear.apply(x, weight, bias)
 
 
+class _GroupLinear(torch.autograd.Function):
+    """y = x [W_1; ...; W_k]^T + [b_1; ...; b_k] where the stacked weight is a zero-copy view of
+    the k parameters' shared storage; the backward hands each parameter its row-slice of the
+    stacked weight gradient (views, no split kernels)."""
+
+    @staticmethod
+    def forward(ctx, x, wcat, bcat, sizes, *params):
+        ctx.save_for_backward(x, wcat)
+        ctx.sizes, ctx.has_bias = sizes, bcat is not None
+        return F.linear(x, wcat, bcat)
+
+    @staticmethod
+    def backward(ctx, g):
+        x, wcat = ctx.saved_tensors
+        g = _f32c(g, "g")
+        g_x = g.mm(wcat) if ctx.needs_input_grad[0] else None
+        g_w = g.t().mm(x)
+        outs, off = [], 0
+        for n in ctx.sizes:
+            outs.append(g_w[off:off + n])
+            off += n
+        if ctx.has_bias:
+            L = _lib.load()
+            R, d = g.shape
+            g_b = torch.empty(d, dtype=torch.float32, device=g.device)
+            ws = torch.empty(max(L.gps_bn_workspace_floats(R, d), 1), dtype=torch.float32,
+                             device=g.device)
+            check(L.gps_colsum(ptr(g), R, d, ptr(g_b), ptr(ws), current_stream(g.device)),
+                  "gps_colsum")
+            off = 0
+            for n in ctx.sizes:
+                outs.append(g_b[off:off + n])
+                off += n
+        return (g_x, None, None, None, *outs)
+
+
+class LinearGroup:
+    """Several ``nn.Linear`` modules that consume the same input (A, B, D, E of GatedGCN --
+    gatedgcn_layer.py:57-61; to_q/to_k/to_v of the Performer) evaluated as ONE GEMM.
+
+    The parameters stay separate leaves with their reference names (state_dict contract) but
+    their storage is re-pointed into one flat buffer, so the stacked [sum(out), in] weight
+    exists without a per-step ``torch.cat`` and its gradient needs no per-step split."""
+
+    def __init__(self, linears):
+        self.linears = list(linears)
+        self._w = self._b = None
+
+    def _stacked(self):
+        ls = self.linears
+        w0 = ls[0].weight
+        ok = self._w is not None and self._w.device == w0.device
+        if ok:
+            off = 0
+            for l in ls:   # still views of the flat buffer?  (.to(), load of a new tensor, ...)
+                if l.weight.data_ptr() != self._w.data_ptr() + off * self._w.shape[1] * 4:
+                    ok = False
+                    break
+                off += l.weight.shape[0]
+        if not ok:
+            with torch.no_grad():
+                self._w = torch.cat([l.weight.data for l in ls], dim=0).contiguous()
+                off = 0
+                for l in ls:
+                    l.weight.data = self._w[off:off + l.weight.shape[0]]
+                    off += l.weight.shape[0]
+                if ls[0].bias is not None:
+                    self._b = torch.cat([l.bias.data for l in ls], dim=0).contiguous()
+                    off = 0
+                    for l in ls:
+                        l.bias.data = self._b[off:off + l.bias.shape[0]]
+                        off += l.bias.shape[0]
+                else:
+                    self._b = None
+        return self._w, self._b
+
+    def __call__(self, x: torch.Tensor) -> torch.Tensor:
+        ls = self.linears
+        if not (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and torch.is_grad_enabled()):
+            w = torch.cat([l.weight for l in ls], dim=0)
+            b = torch.cat([l.bias for l in ls], dim=0) if ls[0].bias is not None else None
+            return F.linear(x, w, b)
+        w, b = self._stacked()
+        sizes = tuple(l.weight.shape[0] for l in ls)
+        params = [l.weight for l in ls] + ([l.bias for l in ls] if b is not None else [])
+        return _GroupLinear.apply(x, w, b, sizes, *params)
+
+
 def relu_dropout(x: torch.Tensor, p_drop: float, training: bool,
                  seed: Optional[int] = None) -> torch.Tensor:
     """``dropout(relu(x))`` (FFN, gps_layer.py:256)."""

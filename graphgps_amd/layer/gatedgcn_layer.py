@@ -14,7 +14,7 @@ import torch.nn.functional as F
 from ..graphgym import register
 from ..graphgym import act as _act  # noqa: F401  (fills act_dict)
 from ..graphgym.register import register_layer
-from ..fused import bn_act, linear
+from ..fused import LinearGroup, bn_act, linear
 from ..ops import gatedgcn_aggregate, graph_index_of
 
 
@@ -43,13 +43,15 @@ class GatedGCNLayer(nn.Module):
         self.act_fn_e = self.activation()
         self.dropout = dropout
         self.residual = residual
+        self._abde = None
 
     def forward_tensors(self, x, e, gi):
         x_in, e_in = x, e
-        # Ax|Bx|Dx|Ex in one GEMM; column block order is what csrc/gatedgcn.hip expects
-        w = torch.cat([self.A.weight, self.B.weight, self.D.weight, self.E.weight], dim=0)
-        b = torch.cat([self.A.bias, self.B.bias, self.D.bias, self.E.bias], dim=0)
-        proj = linear(x, w, b)
+        # Ax|Bx|Dx|Ex in one GEMM over a zero-copy stacked view of the four weights; column
+        # block order is what csrc/gatedgcn.hip expects
+        if self._abde is None:
+            self._abde = LinearGroup([self.A, self.B, self.D, self.E])
+        proj = self._abde(x)
         ce = linear(e, self.C.weight, self.C.bias)
         x, e = gatedgcn_aggregate(proj, ce, gi)
         if isinstance(self.act_fn_x, nn.ReLU) and isinstance(self.act_fn_e, nn.ReLU):

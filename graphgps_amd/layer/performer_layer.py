@@ -18,7 +18,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from ..fused import linear
+from ..fused import LinearGroup, linear
 from ..ops import favor_attention
 
 
@@ -86,15 +86,14 @@ class SelfAttention(nn.Module):
         self.to_v = nn.Linear(dim, inner_dim, bias=qkv_bias)
         self.to_out = nn.Linear(inner_dim, dim, bias=attn_out_bias)
         self.dropout = nn.Dropout(dropout)
+        self._qkv = None
 
     def forward_segments(self, x, gi):
         """[N, dim] node features + graph index -> [N, dim]; equals
         ``SelfAttention(to_dense_batch(x), mask=mask)[mask]`` of the reference (gps_layer.py:199,206)."""
-        w = torch.cat([self.to_q.weight, self.to_k.weight, self.to_v.weight], dim=0)
-        b = None
-        if self.to_q.bias is not None:
-            b = torch.cat([self.to_q.bias, self.to_k.bias, self.to_v.bias], dim=0)
-        qkv = linear(x, w, b)
+        if self._qkv is None:
+            self._qkv = LinearGroup([self.to_q, self.to_k, self.to_v])
+        qkv = self._qkv(x)
         out = favor_attention(qkv, self.fast_attention.projection_matrix, gi, self.heads)
         return self.dropout(linear(out, self.to_out.weight, self.to_out.bias))
 
