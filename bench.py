@@ -209,6 +209,11 @@ def cpu_baseline(model, batch_cpu, compute_loss, clip_value, steps, threads=0):
 
 def main():
     args = parse_args()
+    # RCCL prints a version banner on STDOUT when its first communicator comes up; the contract
+    # is ONE JSON line on stdout, so everything before the final print goes to stderr.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -316,8 +321,10 @@ def main():
                                                cfg.optim.clip_grad_norm_value, args.cpu_steps,
                                                args.cpu_threads)
             out["speedup_vs_cpu"] = out["value"] / out["cpu_baseline"]["value"]
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
         torch.distributed.destroy_process_group()
 
 
