@@ -87,6 +87,9 @@ class GradBucketReducer:
         if b.work is not None:
             return
         # pack: one multi-tensor copy (parameters that got no gradient contribute zeros)
+        if b.flat.is_cuda:   # weight gradients are produced on the side stream (fused.py)
+            from .fused import join_side_stream
+            join_side_stream(b.flat.device)
         srcs = [p.grad if p.grad is not None else torch.zeros_like(v)
                 for p, v in zip(b.params, b.views)]
         torch._foreach_copy_(b.views, srcs)

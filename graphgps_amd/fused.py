@@ -124,6 +124,77 @@ def add_dropout(a: torch.Tensor, b: torch.Tensor, p_drop: float, training: bool,
     return _ActDropAdd.apply(a, b, False, float(p_drop), int(seed or draw_dropout_seed()))
 
 
+# -------------------------------------------------------------------------------------------
+# weight / bias gradients on a second HIP stream
+# -------------------------------------------------------------------------------------------
+# The weight-gradient GEMMs (long K = N or E rows, small [out, in] result) are off the critical
+# path of the backward chain: nothing needs them before the optimizer.  They are issued on a side
+# stream so they overlap the small latency-bound kernels of the chain (BN passes, attention,
+# sparse kernels) instead of serialising with them.  The main stream re-joins the side stream
+# (a) at the end of every backward pass (autograd engine callback) and (b) wherever dp.py packs
+# gradients.  GPS_WGRAD_SIDE_STREAM=0 disables it.
+import os as _os
+
+_SIDE_ENABLED = _os.environ.get("GPS_WGRAD_SIDE_STREAM", "1") != "0"
+_side_streams = {}
+_join_pending = set()
+
+
+def _side_stream(dev: torch.device) -> "torch.cuda.Stream":
+    st = _side_streams.get(dev.index)
+    if st is None:
+        st = _side_streams[dev.index] = torch.cuda.Stream(device=dev)
+    return st
+
+
+def join_side_stream(dev: Optional[torch.device] = None) -> None:
+    """Make the current stream wait for the weight-gradient stream(s)."""
+    for idx, st in _side_streams.items():
+        if dev is None or dev.index == idx:
+            torch.cuda.current_stream(torch.device("cuda", idx)).wait_stream(st)
+    _join_pending.clear()
+
+
+def _queue_join(dev: torch.device) -> None:
+    if dev.index in _join_pending:
+        return
+    _join_pending.add(dev.index)
+    try:   # runs once, when the backward pass that is executing right now has finished
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: join_side_stream(dev))
+    except RuntimeError:   # not inside a backward pass (e.g. torch.autograd.grad on a sub-graph)
+        join_side_stream(dev)
+
+
+def _param_grads(g: torch.Tensor, x: torch.Tensor, need_w: bool, need_b: bool, params=()):
+    """(g^T x, column sums of g): rocBLAS GEMM + the library's two-stage colsum.  ``params`` are
+    the leaf parameters the results go to: if any already holds a ``.grad`` autograd will
+    accumulate into it on the main stream right after this function returns, so the side stream
+    is only used when they are all empty (the zero_grad(set_to_none=True) regime)."""
+    dev = g.device
+
+    def compute():
+        g_w = g.t().mm(x) if need_w else None
+        g_b = None
+        if need_b:
+            L = _lib.load()
+            R, d = g.shape
+            g_b = torch.empty(d, dtype=torch.float32, device=dev)
+            ws = torch.empty(max(L.gps_bn_workspace_floats(R, d), 1), dtype=torch.float32, device=dev)
+            check(L.gps_colsum(ptr(g), R, d, ptr(g_b), ptr(ws), current_stream(dev)), "gps_colsum")
+        return g_w, g_b
+
+    if not _SIDE_ENABLED or any(p is not None and p.grad is not None for p in params):
+        return compute()
+    cur, side = torch.cuda.current_stream(dev), _side_stream(dev)
+    side.wait_stream(cur)                 # g and x are complete
+    with torch.cuda.stream(side):
+        g_w, g_b = compute()
+    g.record_stream(side)                 # keep the caching allocator from recycling them early
+    x.record_stream(side)
+    _queue_join(dev)
+    return g_w, g_b
+
+
 class _Linear(torch.autograd.Function):
     """y = x W^T + b with rocBLAS/hipBLASLt GEMMs (through torch) and the bias gradient taken by
     the library's deterministic two-stage column sum instead of ATen's reduce_kernel."""
@@ -132,23 +203,16 @@ class _Linear(torch.autograd.Function):
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
+        ctx.params = (weight, bias)
         return F.linear(x, weight, bias)
 
     @staticmethod
     def backward(ctx, g):
         x, weight = ctx.saved_tensors
         g = _f32c(g, "g")
+        g_w, g_b = _param_grads(g, x, ctx.needs_input_grad[1],
+                                ctx.has_bias and ctx.needs_input_grad[2], ctx.params)
         g_x = g.mm(weight) if ctx.needs_input_grad[0] else None
-        g_w = g.t().mm(x) if ctx.needs_input_grad[1] else None
-        g_b = None
-        if ctx.has_bias and ctx.needs_input_grad[2]:
-            L = _lib.load()
-            R, d = g.shape
-            g_b = torch.empty(d, dtype=torch.float32, device=g.device)
-            ws = torch.empty(max(L.gps_bn_workspace_floats(R, d), 1), dtype=torch.float32,
-                             device=g.device)
-            check(L.gps_colsum(ptr(g), R, d, ptr(g_b), ptr(ws), current_stream(g.device)),
-                  "gps_colsum")
         return g_x, g_w, g_b
 
 
@@ -169,26 +233,20 @@ class _GroupLinear(torch.autograd.Function):
     def forward(ctx, x, wcat, bcat, sizes, *params):
         ctx.save_for_backward(x, wcat)
         ctx.sizes, ctx.has_bias = sizes, bcat is not None
+        ctx.params = params
         return F.linear(x, wcat, bcat)
 
     @staticmethod
     def backward(ctx, g):
         x, wcat = ctx.saved_tensors
         g = _f32c(g, "g")
+        g_w, g_b = _param_grads(g, x, True, ctx.has_bias, ctx.params)
         g_x = g.mm(wcat) if ctx.needs_input_grad[0] else None
-        g_w = g.t().mm(x)
         outs, off = [], 0
         for n in ctx.sizes:
             outs.append(g_w[off:off + n])
             off += n
         if ctx.has_bias:
-            L = _lib.load()
-            R, d = g.shape
-            g_b = torch.empty(d, dtype=torch.float32, device=g.device)
-            ws = torch.empty(max(L.gps_bn_workspace_floats(R, d), 1), dtype=torch.float32,
-                             device=g.device)
-            check(L.gps_colsum(ptr(g), R, d, ptr(g_b), ptr(ws), current_stream(g.device)),
-                  "gps_colsum")
             off = 0
             for n in ctx.sizes:
                 outs.append(g_b[off:off + n])
