@@ -283,6 +283,16 @@ def main():
         elapsed = float(t.item())
     ms = elapsed / args.steps * 1e3
     final_loss = float(loss.item())
+    # host-side cost of enqueueing one step (GPU queue drained first): if this is close to
+    # ms_per_step the step is launch-bound, not GPU-bound
+    host_ms = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        th = time.perf_counter()
+        step()
+        host_ms.append((time.perf_counter() - th) * 1e3)
+    torch.cuda.synchronize()
+    host_enqueue_ms = min(host_ms)
     log(f"timed region done: {ms:.2f} ms/step")
 
     if rank == 0:
@@ -300,6 +310,7 @@ def main():
                        "timed_region": "graph-index build + forward + L1 loss + backward + "
                                        "grad all-reduce + clip + AdamW"},
             "final_loss": final_loss,
+            "host_enqueue_ms_per_step": host_enqueue_ms,
             "grad_allreduce_bytes": reducer.num_bytes if reducer is not None else 0,
         }
         if not args.no_kernel_roofline:
