@@ -1,0 +1,268 @@
+"""One autograd node for a whole ``CustomGatedGCN+Transformer`` GPS block (training mode).
+
+Same arithmetic, same kernels and same kernel order as the operator-by-operator path in
+``gps_layer.py`` / ``gatedgcn_layer.py`` (which stays the general path: evaluation, GINE,
+Performer, non-ReLU activations, ``batch_norm=False``).  What this buys is host time: the
+modular path spends ~18 us of Python/autograd bookkeeping per launch (~100 launches per layer),
+which is as long as the GPU work itself at PCQM4M sizes; here a layer's forward and backward are
+two straight-line Python functions that call the C ABI and rocBLAS directly, with hand-written
+backward formulas (the ones SURVEY.md section 8a lists and the per-operator tests pin).
+
+Reference lines: graphgps/layer/gps_layer.py:155-232, graphgps/layer/gatedgcn_layer.py:45-88.
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn.functional as F
+
+from .. import lib as _lib
+from ..fused import _SIDE_ENABLED, _queue_join, _side_stream
+from ..lib import check, current_stream, ptr
+from ..ops import GraphIndex, draw_dropout_seed
+
+_E = torch.empty
+
+
+class _K:
+    """Raw (non-autograd) launch helpers; every call enqueues on torch's current stream."""
+
+    @staticmethod
+    def bn_stats(L, z, bn, st):
+        R, d = z.shape
+        mean, rstd = _E(d, dtype=z.dtype, device=z.device), _E(d, dtype=z.dtype, device=z.device)
+        ws = _E(max(L.gps_bn_workspace_floats(R, d), 1), dtype=z.dtype, device=z.device)
+        check(L.gps_bn_stats(ptr(z), R, d, float(bn.eps), float(bn.momentum), ptr(mean), ptr(rstd),
+                             ptr(bn.running_mean), ptr(bn.running_var), ptr(ws), st), "gps_bn_stats")
+        return mean, rstd
+
+    @staticmethod
+    def bn_apply(L, z, mean, rstd, bn, res, relu, p, seed, st):
+        R, d = z.shape
+        y = torch.empty_like(z)
+        check(L.gps_bn_apply(ptr(z), ptr(mean), ptr(rstd), ptr(bn.weight), ptr(bn.bias), ptr(res), R, d,
+                             int(relu), p, seed, ptr(y), st), "gps_bn_apply")
+        return y
+
+    @staticmethod
+    def bn_bwd(L, z, g_y, mean, rstd, bn, relu, p, seed, st):
+        R, d = z.shape
+        g_z = torch.empty_like(z)
+        g_gamma = _E(d, dtype=z.dtype, device=z.device)
+        g_beta = _E(d, dtype=z.dtype, device=z.device)
+        ws = _E(max(L.gps_bn_workspace_floats(R, d), 1), dtype=z.dtype, device=z.device)
+        check(L.gps_bn_bwd(ptr(z), ptr(g_y), ptr(mean), ptr(rstd), ptr(bn.weight), ptr(bn.bias), R, d,
+                           int(relu), p, seed, ptr(g_z), ptr(g_gamma), ptr(g_beta), ptr(ws), st),
+              "gps_bn_bwd")
+        return g_z, g_gamma, g_beta
+
+    @staticmethod
+    def act_drop_add(L, a, b, relu, p, seed, st):
+        R, d = b.shape
+        out = torch.empty_like(b)
+        check(L.gps_act_drop_add(ptr(a), ptr(b), R, d, int(relu), p, seed, ptr(out), st),
+              "gps_act_drop_add")
+        return out
+
+    @staticmethod
+    def act_drop_bwd(L, g, pre, relu, p, seed, st):
+        R, d = g.shape
+        out = torch.empty_like(g)
+        check(L.gps_act_drop_bwd(ptr(g), ptr(pre), R, d, int(relu), p, seed, ptr(out), st),
+              "gps_act_drop_bwd")
+        return out
+
+    @staticmethod
+    def param_grads(L, g, x):
+        """(g^T x, colsum(g)) on the side stream (see fused.py)."""
+        dev = g.device
+
+        def compute():
+            g_w = g.t().mm(x)
+            R, d = g.shape
+            g_b = _E(d, dtype=g.dtype, device=dev)
+            ws = _E(max(L.gps_bn_workspace_floats(R, d), 1), dtype=g.dtype, device=dev)
+            check(L.gps_colsum(ptr(g), R, d, ptr(g_b), ptr(ws), current_stream(dev)), "gps_colsum")
+            return g_w, g_b
+
+        if not _SIDE_ENABLED:
+            return compute()
+        cur, side = torch.cuda.current_stream(dev), _side_stream(dev)
+        side.wait_stream(cur)
+        with torch.cuda.stream(side):
+            out = compute()
+        g.record_stream(side)
+        x.record_stream(side)
+        _queue_join(dev)
+        return out
+
+
+class _GPSBlock(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, e, layer, gi: GraphIndex, seed: int, *params):
+        # ``params`` (the layer's leaf parameters, fixed order below) are inputs only so that
+        # autograd routes the returned gradients to them; the values are read off the modules.
+        L = _lib.load()
+        dev = x.device
+        st = current_stream(dev)
+        lm, sa = layer.local_model, layer.self_attn
+        N, d = x.shape
+        E = e.shape[0]
+        H = layer.num_heads
+        dh = d // H
+        p = float(lm.dropout)
+        p_l = float(layer.dropout_attn.p)
+        p_f1, p_f2 = float(layer.ff_dropout1.p), float(layer.ff_dropout2.p)
+        p_at = float(layer.attn_dropout)
+        s = [(seed + 0x9E3779B97F4A7C15 * (i + 1)) & 0xFFFFFFFFFFFFFFFF for i in range(7)]
+        f32 = dict(dtype=torch.float32, device=dev)
+
+        # -- local branch: GatedGCN (gatedgcn_layer.py:57-83) ---------------------------------
+        wabde, babde = lm._abde._stacked()
+        proj = torch.addmm(babde, x, wabde.t())
+        ce = torch.addmm(lm.C.bias, e, lm.C.weight.t())
+        xt, eh = _E(N, d, **f32), _E(E, d, **f32)
+        aggr, den = _E(N, d, **f32), _E(N, d, **f32)
+        P, fs = proj.data_ptr(), d * 4
+        check(L.gps_gatedgcn_fwd(P, P + fs, P + 2 * fs, P + 3 * fs, 4 * d, ptr(ce), ptr(gi.rowptr_dst),
+                                 ptr(gi.src_by_dst), ptr(gi.eid_by_dst), N, E, d, ptr(xt), ptr(eh),
+                                 ptr(aggr), ptr(den), st), "gps_gatedgcn_fwd")
+        mx, rx = _K.bn_stats(L, xt, lm.bn_node_x, st)
+        x1 = _K.bn_apply(L, xt, mx, rx, lm.bn_node_x, x, True, p, s[0], st)
+        me, re_ = _K.bn_stats(L, eh, lm.bn_edge_e, st)
+        e1 = _K.bn_apply(L, eh, me, re_, lm.bn_edge_e, e, True, p, s[1], st)
+        ml, rl = _K.bn_stats(L, x1, layer.norm1_local, st)
+        hl = _K.bn_apply(L, x1, ml, rl, layer.norm1_local, None, False, 0.0, 0, st)
+
+        # -- global branch: varlen attention over the PRE-layer x (gps_layer.py:199-217) -------
+        qkv = torch.addmm(sa.in_proj_bias, x, sa.in_proj_weight.t())
+        o, lse = _E(N, d, **f32), _E(H, N, **f32)
+        scale = float(dh) ** -0.5
+        check(L.gps_seg_attn_fwd(ptr(qkv), 3 * d, ptr(gi.ptr), ptr(gi.tile_graph), ptr(gi.tile_row0),
+                                 gi.max_tiles, N, H, dh, scale, p_at, s[2], ptr(o), ptr(lse), st),
+              "gps_seg_attn_fwd")
+        ao = torch.addmm(sa.out_proj.bias, o, sa.out_proj.weight.t())
+        za = _K.act_drop_add(L, x, ao, False, p_l, s[3], st)
+        ma, ra = _K.bn_stats(L, za, layer.norm1_attn, st)
+        h = _K.bn_apply(L, za, ma, ra, layer.norm1_attn, hl, False, 0.0, 0, st)   # hl + BN(za)
+
+        # -- FFN + norm2 (gps_layer.py:225-229,253-257) ----------------------------------------
+        f1 = torch.addmm(layer.ff_linear1.bias, h, layer.ff_linear1.weight.t())
+        t = _K.act_drop_add(L, None, f1, True, p_f1, s[4], st)
+        f2 = torch.addmm(layer.ff_linear2.bias, t, layer.ff_linear2.weight.t())
+        z2 = _K.act_drop_add(L, h, f2, False, p_f2, s[5], st)
+        m2, r2 = _K.bn_stats(L, z2, layer.norm2, st)
+        out = _K.bn_apply(L, z2, m2, r2, layer.norm2, None, False, 0.0, 0, st)
+        torch._foreach_add_([lm.bn_node_x.num_batches_tracked, lm.bn_edge_e.num_batches_tracked,
+                             layer.norm1_local.num_batches_tracked,
+                             layer.norm1_attn.num_batches_tracked,
+                             layer.norm2.num_batches_tracked], 1)
+
+        ctx.save_for_backward(x, e, proj, eh, aggr, den, xt, mx, rx, me, re_, x1, ml, rl, qkv, o, lse,
+                              za, ma, ra, h, f1, t, z2, m2, r2)
+        ctx.layer, ctx.gi, ctx.seeds = layer, gi, s
+        ctx.cfg = (p, p_l, p_f1, p_f2, p_at, H, dh, scale)
+        return out, e1
+
+    @staticmethod
+    def backward(ctx, g_out, g_e1):
+        L = _lib.load()
+        (x, e, proj, eh, aggr, den, xt, mx, rx, me, re_, x1, ml, rl, qkv, o, lse, za, ma, ra, h, f1, t,
+         z2, m2, r2) = ctx.saved_tensors
+        layer, gi, s = ctx.layer, ctx.gi, ctx.seeds
+        p, p_l, p_f1, p_f2, p_at, H, dh, scale = ctx.cfg
+        lm, sa = layer.local_model, layer.self_attn
+        dev = x.device
+        st = current_stream(dev)
+        N, d = x.shape
+        E = e.shape[0]
+        f32 = dict(dtype=torch.float32, device=dev)
+        g_out = g_out.contiguous()
+        g_e1 = g_e1.contiguous() if g_e1 is not None else torch.zeros(E, d, **f32)
+
+        # norm2 <- z2 = h + drop(f2);  f2 = ff2(t);  t = drop(relu(f1));  f1 = ff1(h)
+        g_z2, g_n2w, g_n2b = _K.bn_bwd(L, z2, g_out, m2, r2, layer.norm2, False, 0.0, 0, st)
+        g_f2 = _K.act_drop_bwd(L, g_z2, None, False, p_f2, s[5], st)
+        g_w2, g_b2 = _K.param_grads(L, g_f2, t)
+        g_t = g_f2.mm(layer.ff_linear2.weight)
+        g_f1 = _K.act_drop_bwd(L, g_t, f1, True, p_f1, s[4], st)
+        g_w1, g_b1 = _K.param_grads(L, g_f1, h)
+        g_h = torch.addmm(g_z2, g_f1, layer.ff_linear1.weight)            # residual + FFN input
+
+        # h = hl + BN_a(za);  za = x + drop(ao);  ao = out_proj(o)
+        g_za, g_naw, g_nab = _K.bn_bwd(L, za, g_h, ma, ra, layer.norm1_attn, False, 0.0, 0, st)
+        g_ao = _K.act_drop_bwd(L, g_za, None, False, p_l, s[3], st)
+        g_wo, g_bo = _K.param_grads(L, g_ao, o)
+        g_o = g_ao.mm(sa.out_proj.weight)
+        d_qkv, delta = torch.empty_like(qkv), _E(H, N, **f32)
+        check(L.gps_seg_attn_bwd(ptr(g_o), ptr(qkv), 3 * d, ptr(o), ptr(lse), ptr(gi.ptr),
+                                 ptr(gi.tile_graph), ptr(gi.tile_row0), gi.max_tiles, N, H, dh, scale,
+                                 p_at, s[2], ptr(delta), ptr(d_qkv), 3 * d, st), "gps_seg_attn_bwd")
+        g_wi, g_bi = _K.param_grads(L, d_qkv, x)
+        g_x = torch.addmm(g_za, d_qkv, sa.in_proj_weight)                 # residual + in-proj input
+
+        # hl = BN_l(x1);  x1 = x + drop(relu(BN_x(xt)));  e1 = e + drop(relu(BN_e(eh)))
+        g_x1, g_nlw, g_nlb = _K.bn_bwd(L, x1, g_h, ml, rl, layer.norm1_local, False, 0.0, 0, st)
+        g_xt, g_bxw, g_bxb = _K.bn_bwd(L, xt, g_x1, mx, rx, lm.bn_node_x, True, p, s[0], st)
+        g_eh, g_bew, g_beb = _K.bn_bwd(L, eh, g_e1, me, re_, lm.bn_edge_e, True, p, s[1], st)
+        g_proj, g_ce = _E(N, 4 * d, **f32), _E(E, d, **f32)
+        G, fs = g_proj.data_ptr(), d * 4
+        check(L.gps_gatedgcn_bwd(ptr(g_xt), ptr(g_eh), ptr(eh), proj.data_ptr() + fs, 4 * d, ptr(aggr),
+                                 ptr(den), ptr(gi.rowptr_dst), ptr(gi.src_by_dst), ptr(gi.eid_by_dst),
+                                 ptr(gi.rowptr_src), ptr(gi.dst_by_src), ptr(gi.eid_by_src), N, E, d,
+                                 ptr(g_ce), G, G + fs, G + 2 * fs, G + 3 * fs, 4 * d, st),
+              "gps_gatedgcn_bwd")
+        wabde, _ = lm._abde._stacked()
+        g_wabde, g_babde = _K.param_grads(L, g_proj, x)
+        g_wc, g_bc = _K.param_grads(L, g_ce, e)
+        g_x.add_(g_x1)                                                     # residual of x1
+        g_x = torch.addmm(g_x, g_proj, wabde)
+        g_e = torch.addmm(g_e1, g_ce, lm.C.weight)                         # residual of e1 + C input
+
+        abde = [g_wabde[i * d:(i + 1) * d] for i in range(4)] + [g_babde[i * d:(i + 1) * d] for i in range(4)]
+        # order must match GPSBlockRunner.params
+        return (g_x, g_e, None, None, None,
+                *abde, g_wc, g_bc, g_bxw, g_bxb, g_bew, g_beb, g_nlw, g_nlb,
+                g_wi, g_bi, g_wo, g_bo, g_naw, g_nab, g_w1, g_b1, g_w2, g_b2, g_n2w, g_n2b)
+
+
+def block_params(layer):
+    lm, sa = layer.local_model, layer.self_attn
+    return [lm.A.weight, lm.B.weight, lm.D.weight, lm.E.weight,
+            lm.A.bias, lm.B.bias, lm.D.bias, lm.E.bias,
+            lm.C.weight, lm.C.bias,
+            lm.bn_node_x.weight, lm.bn_node_x.bias, lm.bn_edge_e.weight, lm.bn_edge_e.bias,
+            layer.norm1_local.weight, layer.norm1_local.bias,
+            sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight, sa.out_proj.bias,
+            layer.norm1_attn.weight, layer.norm1_attn.bias,
+            layer.ff_linear1.weight, layer.ff_linear1.bias,
+            layer.ff_linear2.weight, layer.ff_linear2.bias,
+            layer.norm2.weight, layer.norm2.bias]
+
+
+def block_supported(layer, x) -> bool:
+    """The single-node path covers the measured configuration: CustomGatedGCN + Transformer,
+    BatchNorm, ReLU, training mode with gradients, fp32 on the GPU."""
+    import torch.nn as nn
+    lm = layer.local_model
+    if not (layer.training and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32):
+        return False
+    if layer.local_gnn_type != 'CustomGatedGCN' or layer.global_model_type != 'Transformer':
+        return False
+    if not layer.batch_norm or not lm.residual:
+        return False
+    if not (isinstance(lm.act_fn_x, nn.ReLU) and isinstance(lm.act_fn_e, nn.ReLU)
+            and isinstance(layer.act_fn_ff, nn.ReLU)):
+        return False
+    for bn in (lm.bn_node_x, lm.bn_edge_e, layer.norm1_local, layer.norm1_attn, layer.norm2):
+        if not (bn.affine and bn.track_running_stats and bn.momentum is not None):
+            return False
+    return x.shape[0] >= 2
+
+
+def gps_block(layer, x, e, gi):
+    from ..fused import LinearGroup
+    lm = layer.local_model
+    if lm._abde is None:
+        lm._abde = LinearGroup([lm.A, lm.B, lm.D, lm.E])
+    lm._abde._stacked()
+    return _GPSBlock.apply(x, e, layer, gi, draw_dropout_seed(), *block_params(layer))

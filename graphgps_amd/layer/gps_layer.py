@@ -25,6 +25,10 @@ from ..fused import add_dropout, bn_act, linear, relu_dropout
 from ..ops import graph_index_of, segment_attention
 from .gatedgcn_layer import GatedGCNLayer
 from .gine_conv_layer import GINEConv
+from .gps_block import block_supported, gps_block
+
+import os as _os
+_BLOCK_ENABLED = _os.environ.get("GPS_FUSED_BLOCK", "1") != "0"
 
 _NEEDS_PYG = {"GCN", "GIN", "GENConv", "GAT", "PNA"}
 
@@ -132,6 +136,14 @@ class GPSLayer(nn.Module):
         h = batch.x
         h_in1 = h  # for first residual connection
         gi = graph_index_of(batch)
+
+        if _BLOCK_ENABLED and block_supported(self, h):
+            # measured configuration (CustomGatedGCN+Transformer, BN, ReLU, training): the whole
+            # block as ONE autograd node -- same kernels, ~4x less host time (layer/gps_block.py)
+            h, e_new = gps_block(self, h, batch.edge_attr, gi)
+            batch.x = h
+            batch.edge_attr = e_new
+            return batch
 
         h_local = h_attn = None
         if self.local_model is not None:
