@@ -173,14 +173,25 @@ def _param_grads(g: torch.Tensor, x: torch.Tensor, need_w: bool, need_b: bool, p
     dev = g.device
 
     def compute():
+        L = _lib.load()
+        R, d = g.shape
+        k = x.shape[1]
+        st = current_stream(dev)
+        if need_w and d % 4 == 0 and k % 4 == 0 and g.stride(0) % 4 == 0 and x.stride(0) % 4 == 0:
+            # split-K MFMA kernel: weight AND bias gradient in one pass (csrc/wgrad.hip)
+            g_w = torch.empty(d, k, dtype=torch.float32, device=dev)
+            g_b = torch.empty(d, dtype=torch.float32, device=dev) if need_b else None
+            ws = torch.empty(max(L.gps_wgrad_workspace_floats(R, d, k), 4), dtype=torch.float32,
+                             device=dev)
+            check(L.gps_wgrad(ptr(g), g.stride(0), ptr(x), x.stride(0), R, d, k, ptr(g_w), ptr(g_b),
+                              ptr(ws), st), "gps_wgrad")
+            return g_w, g_b
         g_w = g.t().mm(x) if need_w else None
         g_b = None
         if need_b:
-            L = _lib.load()
-            R, d = g.shape
             g_b = torch.empty(d, dtype=torch.float32, device=dev)
             ws = torch.empty(max(L.gps_bn_workspace_floats(R, d), 1), dtype=torch.float32, device=dev)
-            check(L.gps_colsum(ptr(g), R, d, ptr(g_b), ptr(ws), current_stream(dev)), "gps_colsum")
+            check(L.gps_colsum(ptr(g), R, d, ptr(g_b), ptr(ws), st), "gps_colsum")
         return g_w, g_b
 
     if not _SIDE_ENABLED or any(p is not None and p.grad is not None for p in params):

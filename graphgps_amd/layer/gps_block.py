@@ -77,11 +77,13 @@ class _K:
         dev = g.device
 
         def compute():
-            g_w = g.t().mm(x)
             R, d = g.shape
+            k = x.shape[1]
+            g_w = _E(d, k, dtype=g.dtype, device=dev)
             g_b = _E(d, dtype=g.dtype, device=dev)
-            ws = _E(max(L.gps_bn_workspace_floats(R, d), 1), dtype=g.dtype, device=dev)
-            check(L.gps_colsum(ptr(g), R, d, ptr(g_b), ptr(ws), current_stream(dev)), "gps_colsum")
+            ws = _E(max(L.gps_wgrad_workspace_floats(R, d, k), 4), dtype=g.dtype, device=dev)
+            check(L.gps_wgrad(ptr(g), g.stride(0), ptr(x), x.stride(0), R, d, k, ptr(g_w), ptr(g_b),
+                              ptr(ws), current_stream(dev)), "gps_wgrad")
             return g_w, g_b
 
         if not _SIDE_ENABLED:

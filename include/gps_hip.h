@@ -190,6 +190,16 @@ int gps_act_drop_bwd(const float* g, const float* pre, int64_t R, int d, int rel
  * nn.Linear at graphgps/layer/gatedgcn_layer.py:57-61, graphgps/layer/gps_layer.py:143-144). */
 int gps_colsum(const float* x, int64_t R, int d, float* out, float* ws, gps_stream_t stream);
 
+/* Weight and bias gradient of y = x W^T + b in one pass on fp32 MFMA (split-K, deterministic):
+ *   gw[M, Nn] = g^T x   with g [R, M] (row stride ldg), x [R, Nn] (row stride ldx);   gb[M] = colsum(g)
+ * (gb may be NULL).  Replaces the long-K/small-output GEMMs autograd issues through rocBLAS for the
+ * nn.Linear modules of the block (graphgps/layer/gatedgcn_layer.py:57-61, gps_layer.py:143-144) and
+ * the separate bias-gradient reductions.  M, Nn, ldg, ldx multiples of 4; ws >=
+ * gps_wgrad_workspace_floats(R, M, Nn) floats. */
+size_t gps_wgrad_workspace_floats(int64_t R, int M, int Nn);
+int gps_wgrad(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t R, int M, int Nn,
+              float* gw, float* gb, float* ws, gps_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * Graph pooling over `ptr` segments (sum: mean = 0, mean: mean = 1) and its backward.
  * Replaces GraphGym pooling_dict['add'|'mean'] (torch_scatter atomics), called from

@@ -213,3 +213,16 @@ def test_full_model_train_step_with_dropout_runs():
         p1, _ = model(b.clone())
         p2, _ = model(b.clone())
     assert torch.equal(p1, p2)
+
+
+def test_single_node_block_path_matches_fixture(monkeypatch):
+    """The opt-in one-autograd-node GPS block (layer/gps_block.py, GPS_FUSED_BLOCK=1) runs the same
+    kernels with hand-written backward formulas: it must meet the reference fixtures too."""
+    import graphgps_amd.layer.gps_layer as gl
+    monkeypatch.setattr(gl, "_BLOCK_ENABLED", True)
+    calls = []
+    orig = gl.gps_block
+    monkeypatch.setattr(gl, "gps_block", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    for name in ("gatedgcn_transformer_d32h4", "gatedgcn_transformer_d48h2"):
+        _check_against_fixture(name)
+    assert calls, "the block path was not taken"

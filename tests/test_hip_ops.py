@@ -387,3 +387,24 @@ def test_act_drop_add(relu, with_a):
     (out * w.cuda()).sum().backward()
     assert_close(out, ref, Tol.ACT, "act_drop_add out")
     assert_close(bg.grad, br.grad, Tol.GRAD_REL, "act_drop_add g_b", rel_to_max=True)
+
+
+@pytest.mark.parametrize("R,M,Nn", [(7569, 384, 384), (15348, 384, 384), (7569, 1536, 384),
+                                    (7569, 384, 768), (738, 64, 64), (1000, 100, 52), (3, 8, 4)])
+def test_wgrad_split_k(R, M, Nn):
+    """gW = g^T x and gb = colsum(g) from the split-K MFMA kernel vs fp64 (1e-5 of max|gW|)."""
+    from graphgps_amd import lib as L_
+    from graphgps_amd.lib import check, current_stream, ptr
+    L = L_.load()
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(R + M)
+    g, x = torch.randn(R, M, generator=gen), torch.randn(R, Nn, generator=gen)
+    gd, xd = g.to(dev), x.to(dev)
+    gw, gb = torch.empty(M, Nn, device=dev), torch.empty(M, device=dev)
+    ws = torch.empty(max(L.gps_wgrad_workspace_floats(R, M, Nn), 4), device=dev)
+    check(L.gps_wgrad(ptr(gd), M, ptr(xd), Nn, R, M, Nn, ptr(gw), ptr(gb), ptr(ws), current_stream(dev)))
+    assert_close(gw, g.double().t() @ x.double(), Tol.GRAD_REL, "gW", rel_to_max=True)
+    assert_close(gb, g.double().sum(0), Tol.GRAD_REL, "gb", rel_to_max=True)
+    gw2 = torch.empty_like(gw)
+    check(L.gps_wgrad(ptr(gd), M, ptr(xd), Nn, R, M, Nn, ptr(gw2), None, ptr(ws), current_stream(dev)))
+    assert torch.equal(gw, gw2)     # deterministic, and the bias output is optional
