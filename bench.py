@@ -62,6 +62,8 @@ def parse_args():
     ap.add_argument("--graphs-per-gpu", type=int, default=256)
     ap.add_argument("--profile", default="P30", help="synthetic size profile (P30 | P14)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true",
+                    help="run the step eagerly instead of replaying it from a hipGraph")
     ap.add_argument("--no-kernel-roofline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=0,
@@ -69,10 +71,12 @@ def parse_args():
     return ap.parse_args()
 
 
-def make_step(model, opt, reducer, batch_dev, compute_loss, clip_value):
+def make_step(model, opt, reducer, batch_dev, compute_loss, clip_value, salt=None):
     params = [p for p in model.parameters() if p.requires_grad]
 
     def step():
+        if salt is not None:
+            salt.add_(1)                 # device-side: every hipGraph replay draws new dropout masks
         b = batch_dev.clone()            # fresh batch object -> the graph index is rebuilt
         if reducer is None:              # single GPU: nothing to exchange, autograd owns .grad
             opt.zero_grad(set_to_none=True)
@@ -254,9 +258,17 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         torch.distributed.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
     reducer = GradBucketReducer(model, force_collective=True) if use_reducer else None
+    # hipGraph capture of the whole step (the synthetic batch has a fixed shape, which is what a
+    # capture needs; a real loader would keep one graph per shape bucket).  Single-GPU only: the
+    # RCCL collectives of the N > 1 path are issued from autograd hooks and stay eager.
+    use_graph = (not args.no_graph) and reducer is None
     opt = torch.optim.AdamW(model.parameters(), lr=cfg.optim.base_lr,
-                            weight_decay=cfg.optim.weight_decay, fused=True)
-    step = make_step(model, opt, reducer, batch_dev, compute_loss, cfg.optim.clip_grad_norm_value)
+                            weight_decay=cfg.optim.weight_decay, fused=True, capturable=use_graph)
+    from graphgps_amd.ops import enable_dropout_salt
+    salt = enable_dropout_salt(dev) if use_graph else None
+    eager_step = make_step(model, opt, reducer, batch_dev, compute_loss,
+                           cfg.optim.clip_grad_norm_value, salt)
+    step = eager_step
 
     def barrier():
         if world > 1:
@@ -264,6 +276,30 @@ def main():
         torch.cuda.synchronize()
 
     torch.manual_seed(1000 + rank)             # dropout streams differ per rank
+    graph_mode = "eager"
+    if use_graph:
+        try:
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(3):           # allocator / autotuner warm-up before capture
+                    eager_step()
+            torch.cuda.current_stream().wait_stream(side)
+            torch.cuda.synchronize()
+            opt.zero_grad(set_to_none=True)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_loss = eager_step()
+            torch.cuda.synchronize()
+
+            def step():
+                graph.replay()
+                return static_loss
+            graph_mode = "hipGraph replay of the whole step"
+            log("step captured in a hipGraph")
+        except Exception as exc:             # capture is an optimisation, never a requirement
+            log(f"hipGraph capture failed ({type(exc).__name__}: {exc}); running eagerly")
+            step = eager_step
     log("model on device, starting warm-up")
     for i in range(args.warmup):
         loss = step()
@@ -311,6 +347,7 @@ def main():
                                        "grad all-reduce + clip + AdamW"},
             "final_loss": final_loss,
             "host_enqueue_ms_per_step": host_enqueue_ms,
+            "launch_mode": graph_mode,
             "grad_allreduce_bytes": reducer.num_bytes if reducer is not None else 0,
         }
         if not args.no_kernel_roofline:

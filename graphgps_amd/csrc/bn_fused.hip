@@ -159,7 +159,8 @@ __global__ __launch_bounds__(256) void k_bn_apply(const float* __restrict__ z,
                                                   const float* __restrict__ gamma,
                                                   const float* __restrict__ beta,
                                                   const float* __restrict__ res, int64_t R, int d,
-                                                  float p_drop, uint64_t seed, float* __restrict__ y) {
+                                                  float p_drop, uint64_t seed, const uint64_t* __restrict__ salt, float* __restrict__ y) {
+  seed = gps::salted_seed(seed, salt);
   const int L = d / VEC;
   const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   const int64_t row = t / L;
@@ -208,7 +209,8 @@ template <int VEC, bool RELU, bool DROP>
 __global__ __launch_bounds__(256) void k_bn_bwd_partial(
     const float* __restrict__ z, const float* __restrict__ g_y, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
-    int64_t R, int d, int rpb, float p_drop, uint64_t seed, float* __restrict__ ws) {
+    int64_t R, int d, int rpb, float p_drop, uint64_t seed, const uint64_t* __restrict__ salt, float* __restrict__ ws) {
+  seed = gps::salted_seed(seed, salt);
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int L = d / VEC;
   const int RS = 256 / L;
@@ -287,7 +289,8 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(
     const float* __restrict__ z, const float* __restrict__ g_y, const float* __restrict__ mean,
     const float* __restrict__ rstd, const float* __restrict__ gamma, const float* __restrict__ beta,
     const float* __restrict__ sum_g, const float* __restrict__ sum_gz, int64_t R, int d, float p_drop,
-    uint64_t seed, float* __restrict__ g_z) {
+    uint64_t seed, const uint64_t* __restrict__ salt, float* __restrict__ g_z) {
+  seed = gps::salted_seed(seed, salt);
   const int L = d / VEC;
   const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   const int64_t row = t / L;
@@ -315,8 +318,9 @@ __global__ __launch_bounds__(256) void k_bn_bwd_apply(
 template <int VEC, bool RELU, bool DROP, bool ADD>
 __global__ __launch_bounds__(256) void k_act_drop_add(const float* __restrict__ a,
                                                       const float* __restrict__ b, int64_t R, int d,
-                                                      float p_drop, uint64_t seed,
+                                                      float p_drop, uint64_t seed, const uint64_t* __restrict__ salt,
                                                       float* __restrict__ out) {
+  seed = gps::salted_seed(seed, salt);
   const int L = d / VEC;
   const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   const int64_t row = t / L;
@@ -345,8 +349,9 @@ __global__ __launch_bounds__(256) void k_act_drop_add(const float* __restrict__ 
 template <int VEC, bool RELU, bool DROP>
 __global__ __launch_bounds__(256) void k_act_drop_bwd(const float* __restrict__ g,
                                                       const float* __restrict__ pre, int64_t R, int d,
-                                                      float p_drop, uint64_t seed,
+                                                      float p_drop, uint64_t seed, const uint64_t* __restrict__ salt,
                                                       float* __restrict__ g_b) {
+  seed = gps::salted_seed(seed, salt);
   const int L = d / VEC;
   const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   const int64_t row = t / L;
@@ -485,7 +490,7 @@ int gps_bn_apply(const float* z, const float* mean, const float* rstd, const flo
     const unsigned grid = gps::grid_for(R * (int64_t)(d / VEC), 256);
     GPS_BOOL3(relu != 0, p_drop > 0.f, res != nullptr,
               (k_bn_apply<VEC, kA, kB, kC><<<grid, 256, 0, s>>>(z, mean, rstd, gamma, beta, res, R, d,
-                                                                p_drop, seed, y)));
+                                                                p_drop, seed, gps::dropout_salt(), y)));
   });
   return gps::launch_status("gps_bn_apply");
 }
@@ -510,10 +515,10 @@ int gps_bn_bwd(const float* z, const float* g_y, const float* mean, const float*
     GPS_BOOL3(relu != 0, p_drop > 0.f, false, {
       (void)kC;
       k_bn_bwd_partial<VEC, kA, kB><<<nb, 256, sizeof(float) * 2 * RS * d, s>>>(
-          z, g_y, mean, rstd, gamma, beta, R, d, rows_per_block(R), p_drop, seed, ws);
+          z, g_y, mean, rstd, gamma, beta, R, d, rows_per_block(R), p_drop, seed, gps::dropout_salt(), ws);
       k_bn_bwd_finalize<<<gps::grid_for(d, FCOLS), 256, 0, s>>>(ws, nb, d, g_beta, g_gamma);
       k_bn_bwd_apply<VEC, kA, kB><<<grid, 256, 0, s>>>(z, g_y, mean, rstd, gamma, beta, g_beta, g_gamma,
-                                                       R, d, p_drop, seed, g_z);
+                                                       R, d, p_drop, seed, gps::dropout_salt(), g_z);
     });
   });
   return gps::launch_status("gps_bn_bwd");
@@ -541,7 +546,7 @@ int gps_act_drop_add(const float* a, const float* b, int64_t R, int d, int relu,
   GPS_DISPATCH_VEC(d, al(a, 16) && al(b, 16) && al(out, 16), al(a, 8) && al(b, 8) && al(out, 8), {
     const unsigned grid = gps::grid_for(R * (int64_t)(d / VEC), 256);
     GPS_BOOL3(relu != 0, p_drop > 0.f, a != nullptr,
-              (k_act_drop_add<VEC, kA, kB, kC><<<grid, 256, 0, s>>>(a, b, R, d, p_drop, seed, out)));
+              (k_act_drop_add<VEC, kA, kB, kC><<<grid, 256, 0, s>>>(a, b, R, d, p_drop, seed, gps::dropout_salt(), out)));
   });
   return gps::launch_status("gps_act_drop_add");
 }
@@ -556,7 +561,7 @@ int gps_act_drop_bwd(const float* g, const float* pre, int64_t R, int d, int rel
     const unsigned grid = gps::grid_for(R * (int64_t)(d / VEC), 256);
     GPS_BOOL3(relu != 0, p_drop > 0.f, false, {
       (void)kC;
-      k_act_drop_bwd<VEC, kA, kB><<<grid, 256, 0, s>>>(g, pre, R, d, p_drop, seed, g_b);
+      k_act_drop_bwd<VEC, kA, kB><<<grid, 256, 0, s>>>(g, pre, R, d, p_drop, seed, gps::dropout_salt(), g_b);
     });
   });
   return gps::launch_status("gps_act_drop_bwd");

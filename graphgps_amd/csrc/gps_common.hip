@@ -4,6 +4,9 @@
 namespace gps {
 
 static thread_local char g_err[512] = "";
+static const uint64_t* g_dropout_salt = nullptr;
+
+const uint64_t* dropout_salt() { return g_dropout_salt; }
 
 void set_error(const char* fmt, ...) {
   va_list ap;
@@ -26,4 +29,8 @@ int launch_status(const char* what) {
 extern "C" {
 int gps_abi_version(void) { return 1; }
 const char* gps_last_error(void) { return gps::g_err; }
+int gps_set_dropout_salt(const uint64_t* device_salt) {
+  gps::g_dropout_salt = device_salt;
+  return GPS_OK;
+}
 }

@@ -15,6 +15,14 @@ int launch_status(const char* what);  // hipGetLastError -> GPS_OK / GPS_ELAUNCH
 
 static inline hipStream_t as_stream(gps_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// Device-resident dropout "salt" (one uint64, owned by the caller, NULL = none).  Every dropout
+// kernel adds salt[0] * golden-ratio to its by-value seed, so a step captured in a hipGraph draws
+// fresh masks on every replay when the captured step increments the salt (graphgps_amd/ops.py).
+const uint64_t* dropout_salt();
+__device__ __forceinline__ uint64_t salted_seed(uint64_t seed, const uint64_t* salt) {
+  return salt ? seed + salt[0] * 0x9E3779B97F4A7C15ULL : seed;
+}
+
 static inline unsigned grid_for(int64_t work, int block) {
   return static_cast<unsigned>((work + block - 1) / block);
 }

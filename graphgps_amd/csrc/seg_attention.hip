@@ -155,8 +155,9 @@ template <int DH, bool DROP>
 __global__ __launch_bounds__(256) void k_attn_fwd(
     const float* __restrict__ qkv, int64_t ld, const int32_t* __restrict__ ptr,
     const int32_t* __restrict__ tile_graph, const int32_t* __restrict__ tile_row0,
-    int64_t n_work, int64_t N, int H, float scale, float p_drop, uint64_t seed,
+    int64_t n_work, int64_t N, int H, float scale, float p_drop, uint64_t seed, const uint64_t* __restrict__ salt,
     float* __restrict__ out, float* __restrict__ lse) {
+  seed = gps::salted_seed(seed, salt);
   constexpr int KPL = Geo<DH>::KPL, DT = Geo<DH>::DT, KT = 4;
   const int lane = threadIdx.x & 63;
   const int64_t w = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -238,7 +239,8 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(
     const float* __restrict__ lse, const float* __restrict__ delta,
     const int32_t* __restrict__ ptr, const int32_t* __restrict__ tile_graph,
     const int32_t* __restrict__ tile_row0, int64_t n_work, int64_t N, int H, float scale,
-    float p_drop, uint64_t seed, float* __restrict__ d_qkv, int64_t ldg) {
+    float p_drop, uint64_t seed, const uint64_t* __restrict__ salt, float* __restrict__ d_qkv, int64_t ldg) {
+  seed = gps::salted_seed(seed, salt);
   constexpr int KPL = Geo<DH>::KPL, DT = Geo<DH>::DT;
   const int lane = threadIdx.x & 63;
   const int64_t w = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -319,7 +321,8 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(
     const float* __restrict__ lse, const float* __restrict__ delta,
     const int32_t* __restrict__ ptr, const int32_t* __restrict__ tile_graph,
     const int32_t* __restrict__ tile_row0, int64_t n_work, int64_t N, int H, float scale,
-    float p_drop, uint64_t seed, float* __restrict__ d_qkv, int64_t ldg) {
+    float p_drop, uint64_t seed, const uint64_t* __restrict__ salt, float* __restrict__ d_qkv, int64_t ldg) {
+  seed = gps::salted_seed(seed, salt);
   constexpr int KPL = Geo<DH>::KPL, DT = Geo<DH>::DT;
   const int lane = threadIdx.x & 63;
   const int64_t w = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
@@ -446,10 +449,10 @@ int gps_seg_attn_fwd(const float* qkv, int64_t ld_qkv, const int32_t* ptr,
   case D:                                                                                         \
     if (p_drop > 0.0f)                                                                            \
       k_attn_fwd<D, true><<<grid, 256, 0, s>>>(qkv, ld_qkv, ptr, tile_graph, tile_row0, n_work, N, \
-                                               H, scale, p_drop, seed, out, lse);                 \
+                                               H, scale, p_drop, seed, gps::dropout_salt(), out, lse);                 \
     else                                                                                          \
       k_attn_fwd<D, false><<<grid, 256, 0, s>>>(qkv, ld_qkv, ptr, tile_graph, tile_row0, n_work,  \
-                                                N, H, scale, p_drop, seed, out, lse);             \
+                                                N, H, scale, p_drop, seed, gps::dropout_salt(), out, lse);             \
     break;
     GPS_FOR_EACH_DH(X)
 #undef X
@@ -483,18 +486,18 @@ int gps_seg_attn_bwd(const float* d_out, const float* qkv, int64_t ld_qkv, const
   case D:                                                                                          \
     if (p_drop > 0.0f) {                                                                           \
       k_attn_bwd_dq<D, true><<<grid, 256, 0, s>>>(d_out, qkv, ld_qkv, lse, delta, ptr, tile_graph, \
-                                                  tile_row0, n_work, N, H, scale, p_drop, seed,    \
+                                                  tile_row0, n_work, N, H, scale, p_drop, seed, gps::dropout_salt(),    \
                                                   d_qkv, ld_dqkv);                                 \
       k_attn_bwd_dkv<D, true><<<grid, 256, 0, s>>>(d_out, qkv, ld_qkv, lse, delta, ptr,            \
                                                    tile_graph, tile_row0, n_work, N, H, scale,     \
-                                                   p_drop, seed, d_qkv, ld_dqkv);                  \
+                                                   p_drop, seed, gps::dropout_salt(), d_qkv, ld_dqkv);                  \
     } else {                                                                                       \
       k_attn_bwd_dq<D, false><<<grid, 256, 0, s>>>(d_out, qkv, ld_qkv, lse, delta, ptr,            \
                                                    tile_graph, tile_row0, n_work, N, H, scale,     \
-                                                   p_drop, seed, d_qkv, ld_dqkv);                  \
+                                                   p_drop, seed, gps::dropout_salt(), d_qkv, ld_dqkv);                  \
       k_attn_bwd_dkv<D, false><<<grid, 256, 0, s>>>(d_out, qkv, ld_qkv, lse, delta, ptr,           \
                                                     tile_graph, tile_row0, n_work, N, H, scale,    \
-                                                    p_drop, seed, d_qkv, ld_dqkv);                 \
+                                                    p_drop, seed, gps::dropout_salt(), d_qkv, ld_dqkv);                 \
     }                                                                                              \
     break;
     GPS_FOR_EACH_DH(X)

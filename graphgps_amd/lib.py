@@ -23,6 +23,7 @@ _SIGNATURES = {
     # name: (restype, argtypes)
     "gps_abi_version": (c_int, []),
     "gps_last_error": (c_char_p, []),
+    "gps_set_dropout_salt": (c_int, [_P]),
     "gps_graph_index_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "gps_graph_index_build": (c_int, [_P, c_int64, c_int64, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),
     "gps_segment_ptr_from_batch": (c_int, [_P, c_int64, c_int64, _P, _P]),

@@ -237,6 +237,22 @@ def draw_dropout_seed() -> int:
     return int(torch.empty((), dtype=torch.int64).random_().item()) & 0xFFFFFFFFFFFFFFFF
 
 
+_dropout_salt = None
+
+
+def enable_dropout_salt(device) -> torch.Tensor:
+    """Install (once) the device-resident dropout salt and return it (int64[1]).  A training step
+    that is going to be captured in a hipGraph must do ``salt.add_(1)`` inside the step: replays
+    reuse the captured by-value seeds, the salt is what makes their masks differ (the kernels add
+    ``salt * 0x9E3779B97F4A7C15`` to every seed; include/gps_hip.h: gps_set_dropout_salt)."""
+    global _dropout_salt
+    dev = torch.device(device)
+    if _dropout_salt is None or _dropout_salt.device != dev:
+        _dropout_salt = torch.zeros(1, dtype=torch.int64, device=dev)
+        check(_lib.load().gps_set_dropout_salt(ptr(_dropout_salt)), "gps_set_dropout_salt")
+    return _dropout_salt
+
+
 class _SegmentAttention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qkv: torch.Tensor, gi: GraphIndex, num_heads: int, p_drop: float, seed: int):

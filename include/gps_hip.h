@@ -36,6 +36,14 @@ typedef void* gps_stream_t; /* hipStream_t */
 int gps_abi_version(void);
 const char* gps_last_error(void);
 
+/* Optional device-resident dropout salt: one uint64 in device memory owned by the caller (NULL
+ * turns it off, the default).  Every dropout-drawing kernel (segment attention, fused BN/act
+ * epilogues) adds salt[0] * 0x9E3779B97F4A7C15 to its by-value seed.  Purpose: a training step
+ * captured in a hipGraph replays the SAME by-value seeds; incrementing the salt inside the captured
+ * step gives every replay fresh masks, with forward and backward of one replay still agreeing.
+ * Process-global; set once before capture. */
+int gps_set_dropout_salt(const uint64_t* device_salt);
+
 /* ---------------------------------------------------------------------------------------
  * Per-batch graph index.  Replaces PyG's per-layer `MessagePassing._collect` index_select
  * bookkeeping (graphgps/layer/gatedgcn_layer.py:67-70) and `to_dense_batch`'s cumsum
