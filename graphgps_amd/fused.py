@@ -273,48 +273,56 @@ class LinearGroup:
     their storage is re-pointed into one flat buffer, so the stacked [sum(out), in] weight
     exists without a per-step ``torch.cat`` and its gradient needs no per-step split."""
 
-    def __init__(self, linears):
-        self.linears = list(linears)
+    def __init__(self, linears=None, weights=None, biases=None):
+        """Either ``linears`` (nn.Linear modules) or explicit ``weights`` / ``biases`` parameter
+        lists (e.g. A..E plus MultiheadAttention.in_proj_weight / in_proj_bias)."""
+        if linears is not None:
+            linears = list(linears)
+            weights = [l.weight for l in linears]
+            biases = [l.bias for l in linears] if linears[0].bias is not None else None
+        self.ws = list(weights)
+        self.bs = list(biases) if biases is not None else None
         self._w = self._b = None
 
+    @property
+    def sizes(self):
+        return tuple(w.shape[0] for w in self.ws)
+
     def _stacked(self):
-        ls = self.linears
-        w0 = ls[0].weight
-        ok = self._w is not None and self._w.device == w0.device
+        ws = self.ws
+        ok = self._w is not None and self._w.device == ws[0].device
         if ok:
             off = 0
-            for l in ls:   # still views of the flat buffer?  (.to(), load of a new tensor, ...)
-                if l.weight.data_ptr() != self._w.data_ptr() + off * self._w.shape[1] * 4:
+            for w in ws:   # still views of the flat buffer?  (.to(), load of a new tensor, ...)
+                if w.data_ptr() != self._w.data_ptr() + off * self._w.shape[1] * 4:
                     ok = False
                     break
-                off += l.weight.shape[0]
+                off += w.shape[0]
         if not ok:
             with torch.no_grad():
-                self._w = torch.cat([l.weight.data for l in ls], dim=0).contiguous()
+                self._w = torch.cat([w.data for w in ws], dim=0).contiguous()
                 off = 0
-                for l in ls:
-                    l.weight.data = self._w[off:off + l.weight.shape[0]]
-                    off += l.weight.shape[0]
-                if ls[0].bias is not None:
-                    self._b = torch.cat([l.bias.data for l in ls], dim=0).contiguous()
+                for w in ws:
+                    w.data = self._w[off:off + w.shape[0]]
+                    off += w.shape[0]
+                if self.bs is not None:
+                    self._b = torch.cat([b.data for b in self.bs], dim=0).contiguous()
                     off = 0
-                    for l in ls:
-                        l.bias.data = self._b[off:off + l.bias.shape[0]]
-                        off += l.bias.shape[0]
+                    for b in self.bs:
+                        b.data = self._b[off:off + b.shape[0]]
+                        off += b.shape[0]
                 else:
                     self._b = None
         return self._w, self._b
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:
-        ls = self.linears
         if not (x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and torch.is_grad_enabled()):
-            w = torch.cat([l.weight for l in ls], dim=0)
-            b = torch.cat([l.bias for l in ls], dim=0) if ls[0].bias is not None else None
+            w = torch.cat(self.ws, dim=0)
+            b = torch.cat(self.bs, dim=0) if self.bs is not None else None
             return F.linear(x, w, b)
         w, b = self._stacked()
-        sizes = tuple(l.weight.shape[0] for l in ls)
-        params = [l.weight for l in ls] + ([l.bias for l in ls] if b is not None else [])
-        return _GroupLinear.apply(x, w, b, sizes, *params)
+        params = self.ws + (self.bs if b is not None else [])
+        return _GroupLinear.apply(x, w, b, self.sizes, *params)
 
 
 def relu_dropout(x: torch.Tensor, p_drop: float, training: bool,
