@@ -215,14 +215,16 @@ def test_full_model_train_step_with_dropout_runs():
     assert torch.equal(p1, p2)
 
 
-def test_single_node_block_path_matches_fixture(monkeypatch):
-    """The opt-in one-autograd-node GPS block (layer/gps_block.py, GPS_FUSED_BLOCK=1) runs the same
-    kernels with hand-written backward formulas: it must meet the reference fixtures too."""
+@pytest.mark.parametrize("block", [True, False])
+def test_block_and_operator_paths_match_fixture(monkeypatch, block):
+    """Two host-side implementations of the same block: the one-autograd-node path
+    (layer/gps_block.py: merged [N,d]x[d,7d] projection GEMM, hand-written backward; default) and
+    the operator-by-operator path (GPS_FUSED_BLOCK=0).  Both must meet the reference fixtures."""
     import graphgps_amd.layer.gps_layer as gl
-    monkeypatch.setattr(gl, "_BLOCK_ENABLED", True)
+    monkeypatch.setattr(gl, "_BLOCK_ENABLED", block)
     calls = []
     orig = gl.gps_block
     monkeypatch.setattr(gl, "gps_block", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
     for name in ("gatedgcn_transformer_d32h4", "gatedgcn_transformer_d48h2"):
         _check_against_fixture(name)
-    assert calls, "the block path was not taken"
+    assert bool(calls) == block
