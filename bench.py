@@ -64,6 +64,9 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true",
                     help="run the step eagerly instead of replaying it from a hipGraph")
+    ap.add_argument("--exchange", choices=("flat", "bucketed"), default="flat",
+                    help="N>1 gradient exchange: one all-reduce of the flat gradient arena between "
+                         "two hipGraphs (default), or eager per-layer buckets from autograd hooks")
     ap.add_argument("--no-kernel-roofline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=0,
@@ -250,25 +253,13 @@ def main():
         cpu_ref_model = copy.deepcopy(model)
     model.to(dev)
     batch_dev = batch_cpu.clone().to(dev)
-    # GPS_BENCH_FORCE_REDUCER=1 exercises the bucketed all-reduce path on a single rank too
-    # (used to validate the RCCL plumbing on the 1-GPU box; not the default measurement)
-    use_reducer = world > 1 or os.environ.get("GPS_BENCH_FORCE_REDUCER") == "1"
-    if use_reducer and world == 1 and not torch.distributed.is_initialized():
+    # GPS_BENCH_FORCE_REDUCER=1 exercises the RCCL exchange on a single rank too (validates the
+    # plumbing on the 1-GPU box; not the default measurement)
+    use_exchange = world > 1 or os.environ.get("GPS_BENCH_FORCE_REDUCER") == "1"
+    if use_exchange and world == 1 and not torch.distributed.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         torch.distributed.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
-    reducer = GradBucketReducer(model, force_collective=True) if use_reducer else None
-    # hipGraph capture of the whole step (the synthetic batch has a fixed shape, which is what a
-    # capture needs; a real loader would keep one graph per shape bucket).  Single-GPU only: the
-    # RCCL collectives of the N > 1 path are issued from autograd hooks and stay eager.
-    use_graph = (not args.no_graph) and reducer is None
-    opt = torch.optim.AdamW(model.parameters(), lr=cfg.optim.base_lr,
-                            weight_decay=cfg.optim.weight_decay, fused=True, capturable=use_graph)
-    from graphgps_amd.ops import enable_dropout_salt
-    salt = enable_dropout_salt(dev) if use_graph else None
-    eager_step = make_step(model, opt, reducer, batch_dev, compute_loss,
-                           cfg.optim.clip_grad_norm_value, salt)
-    step = eager_step
 
     def barrier():
         if world > 1:
@@ -276,30 +267,46 @@ def main():
         torch.cuda.synchronize()
 
     torch.manual_seed(1000 + rank)             # dropout streams differ per rank
-    graph_mode = "eager"
-    if use_graph:
-        try:
-            side = torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(3):           # allocator / autotuner warm-up before capture
-                    eager_step()
-            torch.cuda.current_stream().wait_stream(side)
-            torch.cuda.synchronize()
-            opt.zero_grad(set_to_none=True)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                static_loss = eager_step()
-            torch.cuda.synchronize()
+    make_batch = batch_dev.clone               # fresh batch object -> the graph index is rebuilt
+    reducer = exchange = None
+    if args.exchange == "bucketed" and use_exchange:
+        # hook-driven per-layer buckets overlapped with backward (dp.GradBucketReducer), eager
+        reducer = GradBucketReducer(model, force_collective=True)
+        opt = torch.optim.AdamW(model.parameters(), lr=cfg.optim.base_lr,
+                                weight_decay=cfg.optim.weight_decay, fused=True)
+        step = make_step(model, opt, reducer, batch_dev, compute_loss,
+                         cfg.optim.clip_grad_norm_value)
+        graph_mode = "eager (bucketed all-reduce from autograd hooks)"
+        allreduce_bytes = reducer.num_bytes
+    else:
+        # the product step (graphgps_amd/train.py): flat-arena clip+AdamW, one all-reduce of the
+        # flat gradient, hipGraph replay of the compute on either side of it (the synthetic
+        # batch has a fixed shape, which is what a capture needs; a loader would keep one graph
+        # per shape bucket)
+        from graphgps_amd.dp import FlatGradExchange
+        from graphgps_amd.ops import enable_dropout_salt
+        from graphgps_amd.optim import FlatAdamW
+        from graphgps_amd.train import TrainStep
+        opt = FlatAdamW(model.parameters(), lr=cfg.optim.base_lr,
+                        weight_decay=cfg.optim.weight_decay,
+                        max_grad_norm=cfg.optim.clip_grad_norm_value
+                        if cfg.optim.clip_grad_norm else None)
+        if use_exchange:
+            exchange = FlatGradExchange(opt.arena, force_collective=True)
+        salt = None if args.no_graph else enable_dropout_salt(dev)
+        ts = TrainStep(model, opt, loss_fn=compute_loss, exchange=exchange, salt=salt)
+        if not args.no_graph:
+            try:
+                ts.capture(make_batch)
+                log("step captured: " + ts.mode)
+            except Exception as exc:         # capture is an optimisation, never a requirement
+                log(f"hipGraph capture failed ({type(exc).__name__}: {exc}); running eagerly")
+                ts = TrainStep(model, opt, loss_fn=compute_loss, exchange=exchange, salt=salt)
 
-            def step():
-                graph.replay()
-                return static_loss
-            graph_mode = "hipGraph replay of the whole step"
-            log("step captured in a hipGraph")
-        except Exception as exc:             # capture is an optimisation, never a requirement
-            log(f"hipGraph capture failed ({type(exc).__name__}: {exc}); running eagerly")
-            step = eager_step
+        def step():
+            return ts(make_batch())
+        graph_mode = ts.mode
+        allreduce_bytes = exchange.num_bytes if exchange is not None else 0
     log("model on device, starting warm-up")
     for i in range(args.warmup):
         loss = step()
@@ -348,7 +355,8 @@ def main():
             "final_loss": final_loss,
             "host_enqueue_ms_per_step": host_enqueue_ms,
             "launch_mode": graph_mode,
-            "grad_allreduce_bytes": reducer.num_bytes if reducer is not None else 0,
+            "grad_allreduce_bytes": allreduce_bytes,
+            "optimizer": type(opt).__name__,
         }
         if not args.no_kernel_roofline:
             kr, shape = kernel_rooflines(dev, args.profile, nb)

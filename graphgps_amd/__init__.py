@@ -14,6 +14,7 @@ from .layer.gatedgcn_layer import GatedGCNLayer, GatedGCNGraphGymLayer  # noqa: 
 from .layer.gine_conv_layer import GINEConv, GINEConvLayer, GINEConvGraphGymLayer  # noqa: F401
 from .network.gps_model import GPSModel  # noqa: F401
 from .loss import losses as _losses  # noqa: F401
+from .optim import FlatAdamW, ParamArena  # noqa: F401
 
 import os as _os
 

@@ -122,3 +122,39 @@ class GradBucketReducer:
                     b.flat.mul_(1.0 / self.world)
             for p, v in zip(b.params, b.views):
                 p.grad = v
+
+
+class FlatGradExchange:
+    """The data-parallel exchange on a flat gradient arena (optim.ParamArena): ONE averaging
+    all-reduce of the whole gradient (77.7 MB for GPS-medium) per step.
+
+    Why one unbucketed collective: on 8 MI355X a 78 MB all-reduce over xGMI costs ~0.5 ms against
+    a ~16 ms step, so overlapping it with backward buys < 3 %, while keeping every collective
+    OUT of autograd hooks lets the compute on either side of it (forward + backward + pack |
+    clip + AdamW) be replayed from two hipGraphs -- host work per step is then two graph launches
+    and one RCCL call, which matters more than the overlap when 8 ranks share the host's cores.
+    ``GradBucketReducer`` (above) remains the hook-driven, overlapped variant for eager steps."""
+
+    def __init__(self, arena, process_group=None, force_collective: bool = False):
+        self.arena = arena
+        self.group = process_group
+        self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.active = self.world > 1 or (force_collective and dist.is_initialized())
+        backend = dist.get_backend(process_group) if dist.is_initialized() else ""
+        self.native_avg = backend == "nccl"
+
+    @property
+    def num_bytes(self) -> int:
+        return self.arena.num_bytes if self.active else 0
+
+    def all_reduce(self) -> None:
+        """Average ``arena.flat_g`` over the ranks, in place, on the current stream."""
+        if not self.active:
+            return
+        flat = self.arena.flat_g
+        if self.native_avg:
+            dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
+        else:
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+            if self.world > 1:
+                flat.mul_(1.0 / self.world)

@@ -282,37 +282,56 @@ class LinearGroup:
             biases = [l.bias for l in linears] if linears[0].bias is not None else None
         self.ws = list(weights)
         self.bs = list(biases) if biases is not None else None
-        self._w = self._b = None
+        self._w = self._b = self._key = None
 
     @property
     def sizes(self):
         return tuple(w.shape[0] for w in self.ws)
 
+    @staticmethod
+    def _adjacent(ts):
+        """The tensors sit back to back, in order, in one storage (so their row-stack is a view)."""
+        st = ts[0].data.untyped_storage().data_ptr()
+        nxt = ts[0].data_ptr()
+        for t in ts:
+            if not t.data.is_contiguous() or t.data_ptr() != nxt \
+                    or t.data.untyped_storage().data_ptr() != st:
+                return False
+            nxt += t.numel() * t.element_size()
+        return True
+
+    @staticmethod
+    def _view_over(ts, shape):
+        base = ts[0].data
+        return base.new_empty(0).set_(base.untyped_storage(), base.storage_offset(), shape)
+
     def _stacked(self):
-        ws = self.ws
-        ok = self._w is not None and self._w.device == ws[0].device
-        if ok:
-            off = 0
-            for w in ws:   # still views of the flat buffer?  (.to(), load of a new tensor, ...)
-                if w.data_ptr() != self._w.data_ptr() + off * self._w.shape[1] * 4:
-                    ok = False
-                    break
-                off += w.shape[0]
-        if not ok:
-            with torch.no_grad():
-                self._w = torch.cat([w.data for w in ws], dim=0).contiguous()
+        """(stacked weight [sum(out), in], stacked bias) as VIEWS of the parameters' storage.
+        Whoever owns that storage may move it (``.to()``, a parameter arena -- optim.py) as long as
+        the members stay adjacent; otherwise they are re-stacked here once."""
+        ws, bs = self.ws, self.bs
+        key = tuple(t.data_ptr() for t in (ws + bs if bs is not None else ws))
+        if self._w is not None and self._key == key:
+            return self._w, self._b
+        with torch.no_grad():
+            if not self._adjacent(ws):
+                flat = torch.cat([w.data for w in ws], dim=0).contiguous()
                 off = 0
                 for w in ws:
-                    w.data = self._w[off:off + w.shape[0]]
+                    w.data = flat[off:off + w.shape[0]]
                     off += w.shape[0]
-                if self.bs is not None:
-                    self._b = torch.cat([b.data for b in self.bs], dim=0).contiguous()
+            self._w = self._view_over(ws, (sum(w.shape[0] for w in ws), ws[0].shape[1]))
+            if bs is not None:
+                if not self._adjacent(bs):
+                    flat = torch.cat([b.data for b in bs], dim=0).contiguous()
                     off = 0
-                    for b in self.bs:
-                        b.data = self._b[off:off + b.shape[0]]
+                    for b in bs:
+                        b.data = flat[off:off + b.shape[0]]
                         off += b.shape[0]
-                else:
-                    self._b = None
+                self._b = self._view_over(bs, (sum(b.shape[0] for b in bs),))
+            else:
+                self._b = None
+        self._key = tuple(t.data_ptr() for t in (ws + bs if bs is not None else ws))
         return self._w, self._b
 
     def __call__(self, x: torch.Tensor) -> torch.Tensor:

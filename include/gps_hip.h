@@ -220,6 +220,25 @@ int gps_segment_pool_fwd(const float* x, const int32_t* ptr, int64_t B, int d, i
 int gps_segment_pool_bwd(const float* g_out, const int32_t* ptr, const int32_t* node_graph,
                          int64_t N, int d, int mean, float* g_x, gps_stream_t stream);
 
+/* ---------------------------------------------------------------------------------------
+ * Optimizer side of the step: gradient-norm clip + AdamW over a flat fp32 parameter arena.
+ * Replaces torch.nn.utils.clip_grad_norm_(model.parameters(), cfg.optim.clip_grad_norm_value)
+ * followed by optimizer.step() (graphgps/train/custom_train.py:33-37) for the optimizer
+ * register_optimizer('adamW') builds (graphgps/optimizer/extra_optimizers.py:21-24).
+ *   p, g, m, v     float arenas of identical layout (parameters, gradients, exp_avg, exp_avg_sq)
+ *   chunk_off[c]   int64 element offset of chunk c; chunk_len[c] <= gps_optim_chunk();
+ *   chunk_param[c] index of the parameter the chunk belongs to (chunks never straddle one)
+ *   active[param]  0 = the parameter got no gradient this step: skipped (no decay, no moments),
+ *                  and excluded from the norm, like torch skips p.grad is None
+ *   hyper          DEVICE float[8]: lr, beta1, beta2, eps, weight_decay, max_norm (<= 0: no clip),
+ *                  step (incremented by the call), total_norm (written by the call)
+ *   ws             >= n_chunks floats
+ * Deterministic (fixed-order reductions), no host sync: replayable from a hipGraph. */
+int gps_optim_chunk(void);
+int gps_adamw_step(float* p, const float* g, float* m, float* v, const int64_t* chunk_off,
+                   const int32_t* chunk_len, const int32_t* chunk_param, const uint8_t* active,
+                   int64_t n_chunks, float* hyper, float* ws, gps_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

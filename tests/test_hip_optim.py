@@ -1,0 +1,151 @@
+"""GPU parity of the optimizer side of the step (csrc/optim.hip, graphgps_amd/optim.py, train.py).
+
+Checker: torch.optim.AdamW + torch.nn.utils.clip_grad_norm_ on the CPU -- exactly what the
+reference's train_epoch runs (graphgps/train/custom_train.py:33-37 with the optimizer of
+graphgps/optimizer/extra_optimizers.py:21-24)."""
+import os
+
+import pytest
+import torch
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _clone_params(shapes, seed):
+    g = torch.Generator().manual_seed(seed)
+    return [torch.nn.Parameter(torch.randn(*s, generator=g)) for s in shapes]
+
+
+@pytest.mark.parametrize("wd,max_norm", [(0.0, 1.0), (0.01, 0.5), (0.01, None)])
+def test_flat_adamw_matches_torch_adamw_with_clip(wd, max_norm):
+    from graphgps_amd.optim import FlatAdamW
+    dev = torch.device("cuda:0")
+    # ragged sizes: scalars, non-multiples of 4, > one chunk, an exact chunk multiple
+    shapes = [(1,), (7,), (3, 5), (4096,), (5000,), (384, 384), (2, 4097), (384,)]
+    ref = _clone_params(shapes, 0)
+    got = [torch.nn.Parameter(p.detach().clone().to(dev)) for p in ref]
+    o_ref = torch.optim.AdamW(ref, lr=3e-3, weight_decay=wd)
+    o_got = FlatAdamW(got, lr=3e-3, weight_decay=wd, max_grad_norm=max_norm)
+    gen = torch.Generator().manual_seed(1)
+    for step in range(6):
+        if step == 3:                            # an LR scheduler writes the param group
+            o_ref.param_groups[0]["lr"] = 1e-3
+            o_got.param_groups[0]["lr"] = 1e-3
+        skip = 2 if step in (1, 2) else None     # parameter 2 gets no gradient on steps 1, 2
+        scale = 10.0 if step % 2 == 0 else 0.01  # clip active / inactive
+        o_ref.zero_grad(set_to_none=True)
+        o_got.zero_grad()
+        for i, (pr, pg) in enumerate(zip(ref, got)):
+            if i == skip:
+                continue
+            g = torch.randn(pr.shape, generator=gen) * scale
+            pr.grad = g.clone()
+            pg.grad = g.to(dev)
+        norm = None
+        if max_norm is not None:
+            norm = torch.nn.utils.clip_grad_norm_(ref, max_norm)
+        o_ref.step()
+        o_got.step()
+        if norm is not None:
+            assert abs(float(o_got.total_norm) - float(norm)) <= 2e-6 * float(norm)
+        assert float(o_got.step_count) == step + 1
+        for i, (pr, pg) in enumerate(zip(ref, got)):
+            assert_close(pg.detach().cpu(), pr.detach(), 2e-6, f"step {step} param {i}")
+    # checkpoint layout is torch.optim.AdamW's: state round-trips into the reference optimizer
+    sd = o_got.state_dict()
+    o_ref2 = torch.optim.AdamW(_clone_params(shapes, 0), lr=1e-3, weight_decay=wd)
+    cpu_sd = {"state": {k: {n: t.cpu() for n, t in v.items()} for k, v in sd["state"].items()},
+              "param_groups": [{k: v for k, v in sd["param_groups"][0].items()
+                                if k != "max_grad_norm"}]}
+    ref_sd = o_ref.state_dict()
+    cpu_sd["param_groups"][0] = dict(ref_sd["param_groups"][0])
+    o_ref2.load_state_dict(cpu_sd)
+    for i in range(len(shapes)):
+        assert_close(o_ref2.state_dict()["state"][i]["exp_avg"], ref_sd["state"][i]["exp_avg"], 2e-6,
+                     f"exp_avg {i}")
+        assert_close(o_ref2.state_dict()["state"][i]["exp_avg_sq"], ref_sd["state"][i]["exp_avg_sq"],
+                     2e-6, f"exp_avg_sq {i}")
+    # ... and back
+    o_new = FlatAdamW([torch.nn.Parameter(p.detach().clone()) for p in got], lr=1.0)
+    o_new.load_state_dict(sd)
+    assert torch.equal(o_new.exp_avg[:1], o_got.exp_avg[:1]) and float(o_new.step_count) == 6
+    assert o_new.param_groups[0]["lr"] == 1e-3
+
+
+def test_flat_adamw_refuses_cpu_parameters():
+    from graphgps_amd.lib import GpsHipError
+    from graphgps_amd.optim import FlatAdamW
+    p = torch.nn.Parameter(torch.ones(4))
+    opt = FlatAdamW([p])
+    p.grad = torch.ones(4)
+    with pytest.raises(GpsHipError):
+        opt.step()
+
+
+def _zinc_model(dev, opts=()):
+    import graphgps_amd as g
+    torch.manual_seed(0)
+    m = g.create_model(os.path.join(g.CONFIG_DIR, "zinc_gps_rwse.yaml"),
+                       ["gt.layers", 3, "gt.layer_type", "CustomGatedGCN+Transformer",
+                        "gt.dropout", 0.0, "gt.attn_dropout", 0.0] + list(opts), 1, 1)
+    return m.to(dev).train()
+
+
+def test_train_step_matches_oracle_training():
+    """Three optimisation steps (fwd, L1, bwd, clip 1.0, AdamW) on the HIP path vs the CPU oracle
+    model driven by torch's clip_grad_norm_ + AdamW, dropout off: the loss trajectory agrees."""
+    from graphgps_amd.loss.losses import compute_loss
+    from graphgps_amd.optim import FlatAdamW
+    from graphgps_amd.synthetic import model_batch
+    from graphgps_amd.train import TrainStep
+    from oracle.gps_oracle import to_oracle_model
+    dev = torch.device("cuda:0")
+    model = _zinc_model(torch.device("cpu"))
+    oracle = to_oracle_model(model).train()
+    model.to(dev)
+    o_ref = torch.optim.AdamW(oracle.parameters(), lr=1e-3, weight_decay=1e-5)
+    opt = FlatAdamW(model.parameters(), lr=1e-3, weight_decay=1e-5, max_grad_norm=1.0)
+    ts = TrainStep(model, opt, loss_fn=compute_loss)
+    for step in range(3):
+        b = model_batch("zinc", 16, seed=40 + step)
+        o_ref.zero_grad(set_to_none=True)
+        lo, _ = compute_loss(*oracle(b.clone()))
+        lo.backward()
+        torch.nn.utils.clip_grad_norm_(oracle.parameters(), 1.0)
+        o_ref.step()
+        lg = ts(b.clone().to(dev))
+        assert_close(lg.detach().cpu(), lo.detach(), 2e-4 * (step + 1), f"loss at step {step}")
+    assert opt.arena.intact()
+
+
+def test_train_step_hipgraph_replay_equals_eager():
+    """The captured step (one hipGraph) replays the same arithmetic as the eager step."""
+    from graphgps_amd.loss.losses import compute_loss
+    from graphgps_amd.optim import FlatAdamW
+    from graphgps_amd.synthetic import model_batch
+    from graphgps_amd.train import TrainStep
+    dev = torch.device("cuda:0")
+    b = model_batch("zinc", 16, seed=7).to(dev)
+    runs = []
+    for captured in (False, True):
+        model = _zinc_model(dev)
+        opt = FlatAdamW(model.parameters(), lr=1e-3, weight_decay=0.0, max_grad_norm=1.0)
+        ts = TrainStep(model, opt, loss_fn=compute_loss)
+        losses = []
+        if captured:
+            snap = {k: v.detach().clone() for k, v in model.state_dict().items()}
+            ts.capture(b.clone, warmup=2)
+            # the warm-up steps trained the model: rewind weights, BN buffers and moments
+            with torch.no_grad():
+                for k, v in model.state_dict().items():
+                    v.copy_(snap[k])
+                opt.exp_avg.zero_(), opt.exp_avg_sq.zero_(), opt.hyper[6].zero_()
+            assert "hipGraph" in ts.mode
+        for _ in range(4):
+            losses.append(float(ts(b.clone())))
+        runs.append(losses)
+    assert runs[0][0] > runs[0][-1]                       # it trains
+    for a, c in zip(*runs):
+        assert abs(a - c) <= 1e-6 * max(abs(a), 1.0), runs

@@ -9,6 +9,7 @@ import sqlite3
 
 CATS = [
     ("dense GEMM (rocBLAS/hipBLASLt)", r"^Cijk_|gemm|Gemm"),
+    ("weight-gradient split-K MFMA (HIP)", r"k_wgrad"),
     ("segment attention (HIP)", r"k_attn_"),
     ("GatedGCN / GINE sparse (HIP)", r"k_gatedgcn|k_gine"),
     ("FAVOR+ (HIP)", r"k_favor"),
