@@ -13,7 +13,7 @@
 // torch skips `p.grad is None`.  HBM-bound: 4 reads + 3 writes per element = 28 B/param.
 //
 //   K1 k_sqnorm : per-chunk sum of g^2 (deterministic in-block tree)        -> ws[chunk]
-//                 (+ one thread advances the device-resident step counter)
+//                 (+ advances the device-resident global and per-parameter step counters)
 //   K2 k_adamw  : every block re-reduces ws[] in the same fixed order (fp64) -> clip coefficient,
 //                 then updates its chunk.  No host sync, no atomics, replayable from a hipGraph.
 #include "gps_common.hpp"
@@ -24,7 +24,8 @@ namespace {
 constexpr int kChunk = 4096;   // floats per block (256 threads x 4 float4)
 constexpr int kThreads = 256;
 
-// hyper[] slots (device floats owned by the caller)
+// hyper[] slots (device DOUBLES owned by the caller: torch derives step_size and the bias
+// corrections in Python doubles, and 1 - 0.999f is already off by 1.3e-5 relative)
 enum { H_LR = 0, H_B1, H_B2, H_EPS, H_WD, H_MAXNORM, H_STEP, H_NORM, H_COUNT };
 
 __device__ __forceinline__ float block_sum(float v, float* sh) {
@@ -43,13 +44,21 @@ __global__ __launch_bounds__(kThreads) void k_sqnorm(const float* __restrict__ g
                                                      const int32_t* __restrict__ chunk_len,
                                                      const int32_t* __restrict__ chunk_param,
                                                      const uint8_t* __restrict__ active,
-                                                     float* __restrict__ hyper,
+                                                     double* __restrict__ hyper,
+                                                     float* __restrict__ pstep,
                                                      float* __restrict__ ws) {
   __shared__ float sh[kThreads / 64];
   const int c = blockIdx.x;
-  if (c == 0 && threadIdx.x == 0) hyper[H_STEP] += 1.0f;
+  const int prm = chunk_param[c];
+  const bool on = active[prm] != 0;
+  if (threadIdx.x == 0) {
+    if (c == 0) hyper[H_STEP] += 1.0;
+    // torch keeps one step counter PER PARAMETER (a parameter without a gradient does not
+    // advance): the first chunk of every active parameter advances it
+    if (on && (c == 0 || chunk_param[c - 1] != prm)) pstep[prm] += 1.0f;
+  }
   float acc = 0.f;
-  if (active[chunk_param[c]]) {
+  if (on) {
     const float* gp = g + chunk_off[c];
     const int len = chunk_len[c];
     if ((reinterpret_cast<uintptr_t>(gp) & 15) == 0) {
@@ -87,7 +96,8 @@ __global__ __launch_bounds__(kThreads) void k_adamw(float* __restrict__ p, const
                                                     const int32_t* __restrict__ chunk_len,
                                                     const int32_t* __restrict__ chunk_param,
                                                     const uint8_t* __restrict__ active,
-                                                    int64_t n_chunks, float* __restrict__ hyper,
+                                                    int64_t n_chunks, double* __restrict__ hyper,
+                                                    const float* __restrict__ pstep,
                                                     const float* __restrict__ ws) {
   __shared__ double shd[kThreads / 64];
   __shared__ AdamCoef shk;
@@ -104,23 +114,23 @@ __global__ __launch_bounds__(kThreads) void k_adamw(float* __restrict__ p, const
     double tot = 0.0;
     for (int i = 0; i < kThreads / 64; ++i) tot += shd[i];
     const float norm = static_cast<float>(sqrt(tot));
-    const float lr = hyper[H_LR], b1 = hyper[H_B1], b2 = hyper[H_B2];
-    const float maxn = hyper[H_MAXNORM];
-    const double step = static_cast<double>(hyper[H_STEP]);
-    const double bc1 = 1.0 - pow(static_cast<double>(b1), step);
-    const double bc2 = 1.0 - pow(static_cast<double>(b2), step);
+    const double lr = hyper[H_LR], b1 = hyper[H_B1], b2 = hyper[H_B2];
+    const float maxn = static_cast<float>(hyper[H_MAXNORM]);
+    const double step = static_cast<double>(pstep[chunk_param[c]]);
+    const double bc1 = 1.0 - pow(b1, step);
+    const double bc2 = 1.0 - pow(b2, step);
     AdamCoef k;
-    k.decay = 1.0f - lr * hyper[H_WD];
-    k.one_m_b1 = 1.0f - b1;
-    k.b2 = b2;
-    k.one_m_b2 = 1.0f - b2;
-    k.step_size = static_cast<float>(static_cast<double>(lr) / bc1);
+    k.decay = static_cast<float>(1.0 - lr * hyper[H_WD]);
+    k.one_m_b1 = static_cast<float>(1.0 - b1);
+    k.b2 = static_cast<float>(b2);
+    k.one_m_b2 = static_cast<float>(1.0 - b2);
+    k.step_size = static_cast<float>(lr / bc1);
     k.inv_bc2_sqrt = static_cast<float>(1.0 / sqrt(bc2));
-    k.eps = hyper[H_EPS];
+    k.eps = static_cast<float>(hyper[H_EPS]);
     // torch.nn.utils.clip_grad_norm_: coef = max_norm / (total_norm + 1e-6), clamped to <= 1
     k.clip = maxn > 0.f ? fminf(1.0f, maxn / (norm + 1e-6f)) : 1.0f;
     shk = k;
-    if (c == 0) hyper[H_NORM] = norm;
+    if (c == 0) hyper[H_NORM] = static_cast<double>(norm);
   }
   __syncthreads();
   if (!on) return;
@@ -166,18 +176,18 @@ int gps_optim_chunk(void) { return kChunk; }
 
 int gps_adamw_step(float* p, const float* g, float* m, float* v, const int64_t* chunk_off,
                    const int32_t* chunk_len, const int32_t* chunk_param, const uint8_t* active,
-                   int64_t n_chunks, float* hyper, float* ws, gps_stream_t stream) {
+                   int64_t n_chunks, double* hyper, float* pstep, float* ws, gps_stream_t stream) {
   GPS_REQUIRE(n_chunks >= 0 && n_chunks < (int64_t(1) << 31), "gps_adamw_step: n_chunks=%lld",
               static_cast<long long>(n_chunks));
   if (n_chunks == 0) return GPS_OK;
-  GPS_REQUIRE(p && g && m && v && chunk_off && chunk_len && chunk_param && active && hyper && ws,
+  GPS_REQUIRE(p && g && m && v && chunk_off && chunk_len && chunk_param && active && hyper && pstep && ws,
               "gps_adamw_step: null pointer argument");
   hipStream_t s = gps::as_stream(stream);
   k_sqnorm<<<static_cast<unsigned>(n_chunks), kThreads, 0, s>>>(g, chunk_off, chunk_len, chunk_param,
-                                                                 active, hyper, ws);
+                                                                 active, hyper, pstep, ws);
   k_adamw<<<static_cast<unsigned>(n_chunks), kThreads, 0, s>>>(p, g, m, v, chunk_off, chunk_len,
                                                                 chunk_param, active, n_chunks, hyper,
-                                                                ws);
+                                                                pstep, ws);
   return gps::launch_status("gps_adamw_step");
 }
 

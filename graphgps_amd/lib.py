@@ -49,7 +49,7 @@ _SIGNATURES = {
     "gps_wgrad_workspace_floats": (c_size_t, [c_int64, c_int, c_int]),
     "gps_wgrad": (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int, c_int, _P, _P, _P, _P]),
     "gps_optim_chunk": (c_int, []),
-    "gps_adamw_step": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P]),
+    "gps_adamw_step": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P]),
     "gps_segment_max_len": (c_int, [_P, c_int64, _P, _P]),
     "gps_favor_workspace_floats": (c_size_t, [c_int64, c_int]),
     "gps_favor_fwd": (c_int, [_P, c_int64, _P, c_int, _P, _P, _P, _P, c_int64, c_int64, c_int64, c_int,

@@ -171,7 +171,8 @@ class FlatAdamW(torch.optim.Optimizer):
         n = self.arena.flat_p.numel()
         self.exp_avg = torch.zeros(n, dtype=torch.float32, device=dev)
         self.exp_avg_sq = torch.zeros(n, dtype=torch.float32, device=dev)
-        self.hyper = torch.zeros(8, dtype=torch.float32, device=dev)
+        self.hyper = torch.zeros(8, dtype=torch.float64, device=dev)
+        self.param_step = torch.zeros(len(self.arena.params), dtype=torch.float32, device=dev)
         self._ws = torch.empty(max(self.arena.n_chunks, 1), dtype=torch.float32, device=dev)
         self._hyper_host = None
         self._packed = False
@@ -189,7 +190,7 @@ class FlatAdamW(torch.optim.Optimizer):
         scheduler does once per epoch).  Call it OUTSIDE a captured region."""
         h = self._hyper_tuple()
         if h != self._hyper_host:
-            self.hyper[:6].copy_(torch.tensor(h, dtype=torch.float32))
+            self.hyper[:6].copy_(torch.tensor(h, dtype=torch.float64))
             self._hyper_host = h
 
     @property
@@ -242,7 +243,8 @@ class FlatAdamW(torch.optim.Optimizer):
         check(_lib.load().gps_adamw_step(ptr(a.flat_p), ptr(a.flat_g), ptr(self.exp_avg),
                                          ptr(self.exp_avg_sq), ptr(a.chunk_off), ptr(a.chunk_len),
                                          ptr(a.chunk_param), ptr(a.active), a.n_chunks,
-                                         ptr(self.hyper), ptr(self._ws), current_stream(a.device)),
+                                         ptr(self.hyper), ptr(self.param_step), ptr(self._ws),
+                                         current_stream(a.device)),
               "gps_adamw_step")
         self._packed = False
         return loss
@@ -259,11 +261,13 @@ class FlatAdamW(torch.optim.Optimizer):
         checkpoints interchange with the reference's optimizer (custom_train.py:130-131 saves
         ``optimizer.state_dict()`` through GraphGym's save_ckpt)."""
         a = self.arena
-        step = self.hyper[6].detach().cpu().clone()
+        steps = self.param_step.detach().cpu()
         state = {}
         for i, (o, p) in enumerate(zip(a.offsets, a.params)):
             k = p.numel()
-            state[i] = dict(step=step.clone(),
+            if float(steps[i]) == 0.0:        # torch creates state lazily, at the first gradient
+                continue
+            state[i] = dict(step=steps[i].clone(),
                             exp_avg=self.exp_avg[o:o + k].view(p.shape).clone(),
                             exp_avg_sq=self.exp_avg_sq[o:o + k].view(p.shape).clone())
         g = {k: v for k, v in self.param_groups[0].items() if k != "params"}
@@ -277,8 +281,10 @@ class FlatAdamW(torch.optim.Optimizer):
             if k != "params":
                 self.param_groups[0][k] = v
         self.param_groups[0].setdefault("max_grad_norm", None)
-        step = 0.0
+        steps = [0.0] * len(a.params)
         with torch.no_grad():
+            self.exp_avg.zero_()
+            self.exp_avg_sq.zero_()
             for i, (o, p) in enumerate(zip(a.offsets, a.params)):
                 st = sd["state"].get(i)
                 if st is None:
@@ -286,8 +292,9 @@ class FlatAdamW(torch.optim.Optimizer):
                 k = p.numel()
                 self.exp_avg[o:o + k].copy_(st["exp_avg"].reshape(-1))
                 self.exp_avg_sq[o:o + k].copy_(st["exp_avg_sq"].reshape(-1))
-                step = max(step, float(st["step"]))
-            self.hyper[6] = step
+                steps[i] = float(st["step"])
+            self.param_step.copy_(torch.tensor(steps, dtype=torch.float32))
+            self.hyper[6] = max(steps)
         self._hyper_host = None
         self.sync_hyper()
 

@@ -230,14 +230,16 @@ int gps_segment_pool_bwd(const float* g_out, const int32_t* ptr, const int32_t* 
  *   chunk_param[c] index of the parameter the chunk belongs to (chunks never straddle one)
  *   active[param]  0 = the parameter got no gradient this step: skipped (no decay, no moments),
  *                  and excluded from the norm, like torch skips p.grad is None
- *   hyper          DEVICE float[8]: lr, beta1, beta2, eps, weight_decay, max_norm (<= 0: no clip),
- *                  step (incremented by the call), total_norm (written by the call)
+ *   hyper          DEVICE double[8]: lr, beta1, beta2, eps, weight_decay, max_norm (<= 0: no clip),
+ *                  step (optimizer steps taken; incremented by the call), total_norm (written)
+ *   pstep          DEVICE float[n_params]: torch's per-parameter `step` (advances only for active
+ *                  parameters; drives the bias corrections)
  *   ws             >= n_chunks floats
  * Deterministic (fixed-order reductions), no host sync: replayable from a hipGraph. */
 int gps_optim_chunk(void);
 int gps_adamw_step(float* p, const float* g, float* m, float* v, const int64_t* chunk_off,
                    const int32_t* chunk_len, const int32_t* chunk_param, const uint8_t* active,
-                   int64_t n_chunks, float* hyper, float* ws, gps_stream_t stream);
+                   int64_t n_chunks, double* hyper, float* pstep, float* ws, gps_stream_t stream);
 
 #ifdef __cplusplus
 }

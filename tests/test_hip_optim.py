@@ -141,7 +141,7 @@ def test_train_step_hipgraph_replay_equals_eager():
             with torch.no_grad():
                 for k, v in model.state_dict().items():
                     v.copy_(snap[k])
-                opt.exp_avg.zero_(), opt.exp_avg_sq.zero_(), opt.hyper[6].zero_()
+                opt.exp_avg.zero_(), opt.exp_avg_sq.zero_(), opt.hyper[6].zero_(), opt.param_step.zero_()
             assert "hipGraph" in ts.mode
         for _ in range(4):
             losses.append(float(ts(b.clone())))
