@@ -22,6 +22,23 @@ from ..ops import GraphIndex, draw_dropout_seed
 
 _E = torch.empty
 
+import contextlib as _ctx
+import os as _os
+
+# The local (GatedGCN) and global (attention) halves of a block only meet at their sum: run the
+# attention half on its own HIP stream so its latency-bound kernels fill the gaps of the local
+# half's HBM-bound ones (forward and backward).  Under hipGraph replay this is just a fork/join in
+# the graph.  GPS_BRANCH_STREAM=0 keeps everything on one stream.
+_BRANCH_ENABLED = _os.environ.get("GPS_BRANCH_STREAM", "1") != "0"
+_branch_streams = {}
+
+
+def _branch_stream(dev):
+    st = _branch_streams.get(dev.index)
+    if st is None:
+        st = _branch_streams[dev.index] = torch.cuda.Stream(device=dev)
+    return st
+
 
 class _K:
     """Raw (non-autograd) launch helpers; every call enqueues on torch's current stream."""
@@ -124,10 +141,28 @@ class _GPSBlock(torch.autograd.Function):
         wcat, bcat = layer._xgroup._stacked()
         pq = torch.addmm(bcat, x, wcat.t())                     # [N, 4d + 3d]
         ldp = 7 * d
-        ce = torch.addmm(lm.C.bias, e, lm.C.weight.t())
         xt, eh = _E(N, d, **f32), _E(E, d, **f32)
         aggr, den = _E(N, d, **f32), _E(N, d, **f32)
         P, fs = pq.data_ptr(), d * 4
+        # -- global branch (own stream): varlen attention over the PRE-layer x (gps_layer.py:199-217)
+        cur = torch.cuda.current_stream(dev)
+        br = _branch_stream(dev) if _BRANCH_ENABLED else None
+        if br is not None:
+            br.wait_stream(cur)                                  # pq is complete
+        with (torch.cuda.stream(br) if br is not None else _ctx.nullcontext()):
+            sb = current_stream(dev)
+            o, lse = _E(N, d, **f32), _E(H, N, **f32)
+            scale = float(dh) ** -0.5
+            check(L.gps_seg_attn_fwd(P + 4 * fs, ldp, ptr(gi.ptr), ptr(gi.tile_graph),
+                                     ptr(gi.tile_row0), gi.max_tiles, N, H, dh, scale, p_at, s[2],
+                                     ptr(o), ptr(lse), sb), "gps_seg_attn_fwd")
+            ao = torch.addmm(sa.out_proj.bias, o, sa.out_proj.weight.t())
+            za = _K.act_drop_add(L, x, ao, False, p_l, s[3], sb)
+            ma, ra = _K.bn_stats(L, za, layer.norm1_attn, sb)
+            del ao
+
+        # -- local branch: GatedGCN core + its two BatchNorms + norm1_local ---------------------
+        ce = torch.addmm(lm.C.bias, e, lm.C.weight.t())
         check(L.gps_gatedgcn_fwd(P, P + fs, P + 2 * fs, P + 3 * fs, ldp, ptr(ce), ptr(gi.rowptr_dst),
                                  ptr(gi.src_by_dst), ptr(gi.eid_by_dst), N, E, d, ptr(xt), ptr(eh),
                                  ptr(aggr), ptr(den), st), "gps_gatedgcn_fwd")
@@ -137,16 +172,10 @@ class _GPSBlock(torch.autograd.Function):
         e1 = _K.bn_apply(L, eh, me, re_, lm.bn_edge_e, e, True, p, s[1], st)
         ml, rl = _K.bn_stats(L, x1, layer.norm1_local, st)
         hl = _K.bn_apply(L, x1, ml, rl, layer.norm1_local, None, False, 0.0, 0, st)
-
-        # -- global branch: varlen attention over the PRE-layer x (gps_layer.py:199-217) -------
-        o, lse = _E(N, d, **f32), _E(H, N, **f32)
-        scale = float(dh) ** -0.5
-        check(L.gps_seg_attn_fwd(P + 4 * fs, ldp, ptr(gi.ptr), ptr(gi.tile_graph), ptr(gi.tile_row0),
-                                 gi.max_tiles, N, H, dh, scale, p_at, s[2], ptr(o), ptr(lse), st),
-              "gps_seg_attn_fwd")
-        ao = torch.addmm(sa.out_proj.bias, o, sa.out_proj.weight.t())
-        za = _K.act_drop_add(L, x, ao, False, p_l, s[3], st)
-        ma, ra = _K.bn_stats(L, za, layer.norm1_attn, st)
+        if br is not None:
+            cur.wait_stream(br)
+            for t_ in (o, lse, za, ma, ra):                      # allocated on the branch stream
+                t_.record_stream(cur)
         h = _K.bn_apply(L, za, ma, ra, layer.norm1_attn, hl, False, 0.0, 0, st)   # hl + BN(za)
 
         # -- FFN + norm2 (gps_layer.py:225-229,253-257) ----------------------------------------
@@ -190,24 +219,32 @@ class _GPSBlock(torch.autograd.Function):
         g_t = g_f2.mm(layer.ff_linear2.weight)
         g_f1 = _K.act_drop_bwd(L, g_t, f1, True, p_f1, s[4], st)
         g_w1, g_b1 = _K.param_grads(L, g_f1, h)
-        g_h = torch.addmm(g_z2, g_f1, layer.ff_linear1.weight)            # residual + FFN input
+        g_h = g_z2.addmm_(g_f1, layer.ff_linear1.weight)                  # residual + FFN input
 
-        # h = hl + BN_a(za);  za = x + drop(ao);  ao = out_proj(o)
-        g_za, g_naw, g_nab = _K.bn_bwd(L, za, g_h, ma, ra, layer.norm1_attn, False, 0.0, 0, st)
-        g_ao = _K.act_drop_bwd(L, g_za, None, False, p_l, s[3], st)
-        g_wo, g_bo = _K.param_grads(L, g_ao, o)
-        g_o = g_ao.mm(sa.out_proj.weight)
         # gradient of the merged projection: attention writes dq|dk|dv into columns 4d.., GatedGCN
         # writes g_Ax|g_Bx|g_Dx|g_Ex into columns 0..4d of ONE [N,7d] buffer -> one dgrad, one wgrad
         ldp = 7 * d
         fs = d * 4
-        g_pq, delta = _E(N, ldp, **f32), _E(H, N, **f32)
+        g_pq = _E(N, ldp, **f32)
         G, P = g_pq.data_ptr(), pq.data_ptr()
-        check(L.gps_seg_attn_bwd(ptr(g_o), P + 4 * fs, ldp, ptr(o), ptr(lse), ptr(gi.ptr),
-                                 ptr(gi.tile_graph), ptr(gi.tile_row0), gi.max_tiles, N, H, dh, scale,
-                                 p_at, s[2], ptr(delta), G + 4 * fs, ldp, st), "gps_seg_attn_bwd")
+        cur = torch.cuda.current_stream(dev)
+        br = _branch_stream(dev) if _BRANCH_ENABLED else None
+        if br is not None:
+            br.wait_stream(cur)                                  # g_h is complete
+        with (torch.cuda.stream(br) if br is not None else _ctx.nullcontext()):
+            # h = hl + BN_a(za);  za = x + drop(ao);  ao = out_proj(o)      (attention half)
+            sb = current_stream(dev)
+            g_za, g_naw, g_nab = _K.bn_bwd(L, za, g_h, ma, ra, layer.norm1_attn, False, 0.0, 0, sb)
+            g_ao = _K.act_drop_bwd(L, g_za, None, False, p_l, s[3], sb)
+            g_wo, g_bo = _K.param_grads(L, g_ao, o)
+            g_o = g_ao.mm(sa.out_proj.weight)
+            delta = _E(H, N, **f32)
+            check(L.gps_seg_attn_bwd(ptr(g_o), P + 4 * fs, ldp, ptr(o), ptr(lse), ptr(gi.ptr),
+                                     ptr(gi.tile_graph), ptr(gi.tile_row0), gi.max_tiles, N, H, dh,
+                                     scale, p_at, s[2], ptr(delta), G + 4 * fs, ldp, sb),
+                  "gps_seg_attn_bwd")
 
-        # hl = BN_l(x1);  x1 = x + drop(relu(BN_x(xt)));  e1 = e + drop(relu(BN_e(eh)))
+        # hl = BN_l(x1);  x1 = x + drop(relu(BN_x(xt)));  e1 = e + drop(relu(BN_e(eh)))   (local half)
         g_x1, g_nlw, g_nlb = _K.bn_bwd(L, x1, g_h, ml, rl, layer.norm1_local, False, 0.0, 0, st)
         g_xt, g_bxw, g_bxb = _K.bn_bwd(L, xt, g_x1, mx, rx, lm.bn_node_x, True, p, s[0], st)
         g_eh, g_bew, g_beb = _K.bn_bwd(L, eh, g_e1, me, re_, lm.bn_edge_e, True, p, s[1], st)
@@ -217,10 +254,14 @@ class _GPSBlock(torch.autograd.Function):
                                  ptr(gi.rowptr_src), ptr(gi.dst_by_src), ptr(gi.eid_by_src), N, E, d,
                                  ptr(g_ce), G, G + fs, G + 2 * fs, G + 3 * fs, ldp, st),
               "gps_gatedgcn_bwd")
+        if br is not None:
+            cur.wait_stream(br)
+            for t_ in (g_za, g_naw, g_nab, g_wo, g_bo):
+                t_.record_stream(cur)
         wcat, _ = layer._xgroup._stacked()
         g_wcat, g_bcat = _K.param_grads(L, g_pq, x)
         g_wc, g_bc = _K.param_grads(L, g_ce, e)
-        g_x = torch.addmm(g_za, g_pq, wcat)                               # residual(za) + A..E + in-proj
+        g_x = g_za.addmm_(g_pq, wcat)                                     # residual(za) + A..E + in-proj
         g_x.add_(g_x1)                                                     # residual of x1
         g_e = torch.addmm(g_e1, g_ce, lm.C.weight)                         # residual of e1 + C input
         g_wabde, g_babde = g_wcat, g_bcat
