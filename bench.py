@@ -62,8 +62,12 @@ def parse_args():
     ap.add_argument("--graphs-per-gpu", type=int, default=256)
     ap.add_argument("--profile", default="P30", help="synthetic size profile (P30 | P14)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-graph", action="store_true",
-                    help="run the step eagerly instead of replaying it from a hipGraph")
+    ap.add_argument("--launch", choices=("auto", "graph", "eager"), default="auto",
+                    help="how the step is launched: replayed from hipGraph(s), eagerly, or (auto) "
+                         "whichever of the two measures faster on a few untimed trial steps -- "
+                         "replay removes the host cost, eager keeps the weight-gradient stream "
+                         "overlapped, which one wins depends on the host")
+    ap.add_argument("--no-graph", action="store_true", help="alias for --launch eager")
     ap.add_argument("--exchange", choices=("flat", "bucketed"), default="flat",
                     help="N>1 gradient exchange: one all-reduce of the flat gradient arena between "
                          "two hipGraphs (default), or eager per-layer buckets from autograd hooks")
@@ -269,6 +273,7 @@ def main():
     torch.manual_seed(1000 + rank)             # dropout streams differ per rank
     make_batch = batch_dev.clone               # fresh batch object -> the graph index is rebuilt
     reducer = exchange = None
+    trial = {}
     if args.exchange == "bucketed" and use_exchange:
         # hook-driven per-layer buckets overlapped with backward (dp.GradBucketReducer), eager
         reducer = GradBucketReducer(model, force_collective=True)
@@ -293,19 +298,40 @@ def main():
                         if cfg.optim.clip_grad_norm else None)
         if use_exchange:
             exchange = FlatGradExchange(opt.arena, force_collective=True)
-        salt = None if args.no_graph else enable_dropout_salt(dev)
+        launch = "eager" if args.no_graph else args.launch
+        salt = None if launch == "eager" else enable_dropout_salt(dev)
         ts = TrainStep(model, opt, loss_fn=compute_loss, exchange=exchange, salt=salt)
-        if not args.no_graph:
+        if launch != "eager":
             try:
                 ts.capture(make_batch)
                 log("step captured: " + ts.mode)
             except Exception as exc:         # capture is an optimisation, never a requirement
                 log(f"hipGraph capture failed ({type(exc).__name__}: {exc}); running eagerly")
                 ts = TrainStep(model, opt, loss_fn=compute_loss, exchange=exchange, salt=salt)
+                launch = "eager"
 
         def step():
             return ts(make_batch())
-        graph_mode = ts.mode
+        if launch == "auto":                 # untimed trial: 6 steps each way, keep the faster
+            for mode in ("eager", "graph"):
+                ts.use_replay = mode == "graph"
+                for _ in range(2):
+                    step()
+                barrier()
+                tt = time.perf_counter()
+                for _ in range(6):
+                    step()
+                barrier()
+                trial[mode] = (time.perf_counter() - tt) / 6 * 1e3
+            if world > 1:                    # every rank must take the same decision
+                tv = torch.tensor([trial["eager"], trial["graph"]], device=dev, dtype=torch.float64)
+                torch.distributed.all_reduce(tv, op=torch.distributed.ReduceOp.MAX)
+                trial = {"eager": float(tv[0]), "graph": float(tv[1])}
+            launch = min(trial, key=trial.get)
+            log(f"launch-mode trial: eager {trial['eager']:.2f} ms, graph {trial['graph']:.2f} ms "
+                f"-> {launch}")
+        ts.use_replay = launch == "graph"
+        graph_mode = ts.mode if launch == "graph" else "eager (3 HIP streams: main, weight-gradient)"
         allreduce_bytes = exchange.num_bytes if exchange is not None else 0
     log("model on device, starting warm-up")
     for i in range(args.warmup):
@@ -355,6 +381,7 @@ def main():
             "final_loss": final_loss,
             "host_enqueue_ms_per_step": host_enqueue_ms,
             "launch_mode": graph_mode,
+            "launch_trial_ms": trial or None,
             "grad_allreduce_bytes": allreduce_bytes,
             "optimizer": type(opt).__name__,
         }

@@ -25,11 +25,11 @@ _E = torch.empty
 import contextlib as _ctx
 import os as _os
 
-# The local (GatedGCN) and global (attention) halves of a block only meet at their sum: run the
-# attention half on its own HIP stream so its latency-bound kernels fill the gaps of the local
-# half's HBM-bound ones (forward and backward).  Under hipGraph replay this is just a fork/join in
-# the graph.  GPS_BRANCH_STREAM=0 keeps everything on one stream.
-_BRANCH_ENABLED = _os.environ.get("GPS_BRANCH_STREAM", "1") != "0"
+# The local (GatedGCN) and global (attention) halves of a block only meet at their sum, so the
+# attention half CAN run on its own HIP stream (GPS_BRANCH_STREAM=1).  Measured on MI355X at the
+# PCQM4M size it does not pay: eager 14.4 -> 16.6 ms/step (the stream switches make the step
+# host-bound), hipGraph replay 15.55 -> 15.71 ms.  Off by default; kept for larger graphs.
+_BRANCH_ENABLED = _os.environ.get("GPS_BRANCH_STREAM", "0") == "1"
 _branch_streams = {}
 
 

@@ -43,6 +43,7 @@ class TrainStep:
         self.salt = salt
         self._g_fb = self._g_up = None
         self._static_loss = None
+        self.use_replay = True           # once captured: replay (True) or keep launching eagerly
         self.mode = "eager"
 
     # -- the three pieces ------------------------------------------------------------------
@@ -66,8 +67,11 @@ class TrainStep:
         self.opt.step()
 
     def __call__(self, batch):
-        if self._g_fb is not None:
+        if self._g_fb is not None and self.use_replay:
             return self.replay()
+        return self.run_eager(batch)
+
+    def run_eager(self, batch):
         loss, _, _ = self.forward_backward(batch)
         self.reduce()
         self.update()
