@@ -3,7 +3,7 @@
 //     gW[m][n] = sum_r g[r][m] * x[r][n]        gb[m] = sum_r g[r][m]
 //
 // with r over N nodes or E edges (7.5k-15k at PCQM4M sizes) and a small [M, Nn] result
-// (384..1536 x 384..768).  This is what autograd derives for the nn.Linear modules of the block
+// (384..2688 x 384..768).  This is what autograd derives for the nn.Linear modules of the block
 // (graphgps/layer/gatedgcn_layer.py:57-61, graphgps/layer/gps_layer.py:143-144,234-241); through
 // rocBLAS/hipBLASLt these long-K / small-output GEMMs run at 45-85 TFLOP/s (profiles/), and the bias
 // gradients were separate column-sum launches.
@@ -15,33 +15,54 @@
 // flight while the current one is multiplied.  The row range is split S ways so that tiles * S ~ one
 // workgroup per CU; slices write partial tiles that a second kernel sums in slice order (no atomics).
 // The bias gradient falls out of the staged g chunk for free.
+//
+// Grouped form (gps_wgrad_grouped): the five weight gradients of one GPS block (merged A|B|D|E|in_proj,
+// C, out_proj, ff1, ff2) in ONE launch + ONE reduce launch.  Separately they cost ~390 us per block of
+// which only ~250 us is MFMA time: each launch pays its own prologue (first chunk from HBM), partial-
+// tile epilogue, tail and reduce pass, and the small ones split K 28 ways just to fill the chip.
+// Grouped, every workgroup gets an equal share (~R*tiles/256 chunk-tiles) of the whole list, so slices
+// are long (S = 2..4) and the partial traffic drops 4x.
 #include "gps_common.hpp"
+
+#include <algorithm>
+#include <cstdlib>
 
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int NLD = BK / 8;   // float4 loads per thread per operand per chunk (256 threads x 4 floats = 8 rows)
+constexpr int kMaxGroup = 8;
 
-__global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ g, int64_t ldg,
-                                               const float* __restrict__ x, int64_t ldx, int64_t R,
-                                               int M, int Nn, int tiles_m, int tiles_n, int n_slices,
-                                               int rows_per_slice, int want_bias,
-                                               float* __restrict__ part,
-                                               float* __restrict__ bias_part) {
-  __shared__ __attribute__((aligned(16))) float As[2][BK][BM];
-  __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
-  // plain map: consecutive blocks = the tiles of one row slice.  (An XCD-grouped map -- all tiles
-  // of a slice on one XCD for L2 reuse -- was measured 25-50 % SLOWER here: with ~250 workgroups
-  // the uneven tiles-per-XCD split costs a second dispatch round on some XCDs.)
-  const int tiles = tiles_m * tiles_n;
-  const int slice = blockIdx.x / tiles;
-  const int tile = blockIdx.x - slice * tiles;
-  if (slice >= n_slices) return;
-  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+struct Problem {
+  const float* g;
+  const float* x;
+  float* part;        // [S][M][Nn] partial tiles
+  float* bias_part;   // [S][M] partial column sums (nullptr: no bias gradient)
+  float* gw;          // [M][Nn]
+  float* gb;          // [M] or nullptr
+  int64_t ldg, ldx, R;
+  int M, Nn, tiles_m, tiles_n, S, rows_per_slice;
+  int block_begin;    // first workgroup of this problem (grouped launch)
+  int64_t out_begin;  // first reduce-thread index of this problem (grouped reduce)
+};
+
+struct Group {
+  Problem p[kMaxGroup];
+  int n;
+};
+
+// One (tile, slice) work item of problem P.
+__device__ __forceinline__ void wgrad_tile(const Problem& P, int tile, int slice, float (*As)[BK][BM],
+                                           float (*Bs)[BK][BN]) {
+  const float* __restrict__ g = P.g;
+  const float* __restrict__ x = P.x;
+  const int64_t ldg = P.ldg, ldx = P.ldx;
+  const int M = P.M, Nn = P.Nn;
+  const int tm = tile / P.tiles_n, tn = tile - tm * P.tiles_n;
   const int m0 = tm * BM, n0 = tn * BN;
-  const int64_t r_begin = (int64_t)slice * rows_per_slice;
-  const int64_t r_end = min(R, r_begin + rows_per_slice);
+  const int64_t r_begin = (int64_t)slice * P.rows_per_slice;
+  const int64_t r_end = min(P.R, r_begin + P.rows_per_slice);
   const int t = threadIdx.x;
   const int lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -59,53 +80,70 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ g, int6
   float4 bsum = make_float4(0.f, 0.f, 0.f, 0.f);
 
   float4 ra[NLD], rb[NLD];
+  // branch-free staging loads: out-of-range rows / column quads are clamped to a valid address and
+  // zeroed by a select at store time (exec-masked branches around every load serialise their issue,
+  // and a select placed right after the load would make the MFMAs wait for it)
+  const float* ga = g + m0 + (a_col_ok ? scol : 0);
+  const float* xb = x + n0 + (b_col_ok ? scol : 0);
+  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
   auto load_chunk = [&](int64_t r0) {
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
       const int64_t r = r0 + srow + 8 * j;
-      const bool ok = r < r_end;
-      ra[j] = (ok && a_col_ok) ? *reinterpret_cast<const float4*>(g + r * ldg + m0 + scol)
-                               : make_float4(0.f, 0.f, 0.f, 0.f);
-      rb[j] = (ok && b_col_ok) ? *reinterpret_cast<const float4*>(x + r * ldx + n0 + scol)
-                               : make_float4(0.f, 0.f, 0.f, 0.f);
+      const int64_t rc = r < r_end ? r : r_end - 1;
+      ra[j] = *reinterpret_cast<const float4*>(ga + rc * ldg);
+      rb[j] = *reinterpret_cast<const float4*>(xb + rc * ldx);
     }
   };
-  auto store_chunk = [&](int buf) {
+  auto store_chunk = [&](int buf, int64_t r0) {
 #pragma unroll
     for (int j = 0; j < NLD; ++j) {
-      *reinterpret_cast<float4*>(&As[buf][srow + 8 * j][scol]) = ra[j];
-      *reinterpret_cast<float4*>(&Bs[buf][srow + 8 * j][scol]) = rb[j];
-      bsum.x += ra[j].x; bsum.y += ra[j].y; bsum.z += ra[j].z; bsum.w += ra[j].w;
+      const bool ok = r0 + srow + 8 * j < r_end;
+      const float4 va = (ok && a_col_ok) ? ra[j] : zero4;
+      const float4 vb = (ok && b_col_ok) ? rb[j] : zero4;
+      *reinterpret_cast<float4*>(&As[buf][srow + 8 * j][scol]) = va;
+      *reinterpret_cast<float4*>(&Bs[buf][srow + 8 * j][scol]) = vb;
+      bsum.x += va.x; bsum.y += va.y; bsum.z += va.z; bsum.w += va.w;
     }
   };
 
   load_chunk(r_begin);
-  store_chunk(0);
+  store_chunk(0, r_begin);
   __syncthreads();
   int buf = 0;
+  const int kh = lane >> 5, li = lane & 31;
   for (int64_t r0 = r_begin; r0 < r_end; r0 += BK) {
     const bool more = r0 + BK < r_end;
     if (more) load_chunk(r0 + BK);     // global loads in flight during the MFMAs below
-    const int kh = lane >> 5, li = lane & 31;
+    // operands of step ks+1 are fetched from LDS into their own registers BEFORE the MFMAs of
+    // step ks issue (sched_barrier: the scheduler sinks the prefetch next to its use otherwise)
+    const float* ap = &As[buf][kh][wm * 64 + li];
+    const float* bp = &Bs[buf][kh][wn * 64 + li];
+    float a0 = ap[0], a1 = ap[32], b0 = bp[0], b1 = bp[32];
 #pragma unroll
     for (int ks = 0; ks < BK / 2; ++ks) {
-      const int kk = 2 * ks + kh;
-      const float a0 = As[buf][kk][wm * 64 + li];
-      const float a1 = As[buf][kk][wm * 64 + 32 + li];
-      const float b0 = Bs[buf][kk][wn * 64 + li];
-      const float b1 = Bs[buf][kk][wn * 64 + 32 + li];
+      float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+      if (ks + 1 < BK / 2) {
+        na0 = ap[(2 * ks + 2) * BM];
+        na1 = ap[(2 * ks + 2) * BM + 32];
+        nb0 = bp[(2 * ks + 2) * BN];
+        nb1 = bp[(2 * ks + 2) * BN + 32];
+      }
+      __builtin_amdgcn_sched_barrier(0);
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
       acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
       acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
       acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+      a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
     }
-    if (more) store_chunk(buf ^ 1);
+    if (more) store_chunk(buf ^ 1, r0 + BK);
     __syncthreads();
     buf ^= 1;
   }
 
   // partial tile: D[row = (q&3) + 8*(q>>2) + 4*(lane>>5)][col = lane&31]
-  float* po = part + (int64_t)slice * M * Nn;
+  float* po = P.part + (int64_t)slice * M * Nn;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -117,7 +155,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ g, int6
         if (row < M && col < Nn) po[(int64_t)row * Nn + col] = acc[i][j][q];
       }
     }
-  if (want_bias && tn == 0) {
+  if (P.bias_part && tn == 0) {
     // 8 threads (srow = 0..7) share a column quad: reduce through LDS in fixed order
     float* scratch = &As[0][0][0];   // all MFMA reads are done (barrier at loop end)
     *reinterpret_cast<float4*>(&scratch[srow * BM + scol]) = bsum;
@@ -126,49 +164,129 @@ __global__ __launch_bounds__(256) void k_wgrad(const float* __restrict__ g, int6
       float s = 0.f;
 #pragma unroll
       for (int q = 0; q < 8; ++q) s += scratch[q * BM + t];
-      bias_part[(int64_t)slice * M + m0 + t] = s;
+      P.bias_part[(int64_t)slice * M + m0 + t] = s;
     }
   }
 }
 
+// plain map: consecutive blocks = the tiles of one row slice.  (An XCD-grouped map -- all tiles
+// of a slice on one XCD for L2 reuse -- was measured 25-50 % SLOWER here: with ~250 workgroups
+// the uneven tiles-per-XCD split costs a second dispatch round on some XCDs.)
+__global__ __launch_bounds__(256) void k_wgrad(const Group G) {
+  __shared__ __attribute__((aligned(16))) float As[2][BK][BM];
+  __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < kMaxGroup; ++i)
+    if (i < G.n && (int)blockIdx.x >= G.p[i].block_begin) pi = i;
+  const Problem& P = G.p[pi];
+  const int local = blockIdx.x - P.block_begin;
+  const int tiles = P.tiles_m * P.tiles_n;
+  const int slice = local / tiles;
+  if (slice >= P.S) return;
+  wgrad_tile(P, local - slice * tiles, slice, As, Bs);
+}
+
 // out[i] = sum_s part[s][i] in slice order (one float per thread: enough threads to pull the
-// S x M x Nn partials at bandwidth); bias likewise, by the first blocks
-__global__ __launch_bounds__(256) void k_wgrad_reduce(const float* __restrict__ part, int S, int64_t total,
-                                                      float* __restrict__ out,
-                                                      const float* __restrict__ bias_part, int M,
-                                                      float* __restrict__ bias_out) {
-  const int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+// S x M x Nn partials at bandwidth); bias likewise, by the first threads of each problem
+__global__ __launch_bounds__(256) void k_wgrad_reduce(const Group G) {
+  const int64_t gi = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < kMaxGroup; ++i)
+    if (i < G.n && gi >= G.p[i].out_begin) pi = i;
+  const Problem& P = G.p[pi];
+  const int64_t i = gi - P.out_begin;
+  const int64_t total = (int64_t)P.M * P.Nn;
   if (i < total) {
     float a = 0.f;
-#pragma unroll 8
-    for (int s = 0; s < S; ++s) a += part[(int64_t)s * total + i];
-    out[i] = a;
+#pragma unroll 4
+    for (int s = 0; s < P.S; ++s) a += P.part[(int64_t)s * total + i];
+    P.gw[i] = a;
   }
-  if (bias_out && i < M) {
+  if (P.gb && i < P.M) {
     float a = 0.f;
-#pragma unroll 8
-    for (int s = 0; s < S; ++s) a += bias_part[(int64_t)s * M + i];
-    bias_out[i] = a;
+#pragma unroll 4
+    for (int s = 0; s < P.S; ++s) a += P.bias_part[(int64_t)s * P.M + i];
+    P.gb[i] = a;
   }
 }
 
-struct Plan {
-  int tiles_m, tiles_n, S, rows_per_slice;
-};
-inline Plan make_plan(int64_t R, int M, int Nn) {
-  Plan p;
-  p.tiles_m = (M + BM - 1) / BM;
-  p.tiles_n = (Nn + BN - 1) / BN;
-  const int tiles = p.tiles_m * p.tiles_n;
-  int S = 256 / tiles;                               // ~one workgroup per CU
-  const int64_t max_s = (R + 4 * BK - 1) / (4 * BK); // at least 4 chunks per slice
-  if (S > max_s) S = (int)max_s;
+// Slices for a problem so that one workgroup owns about `chunks_per_block` 32-row chunks.
+inline void plan_slices(Problem& p, int64_t chunks_per_block) {
+  p.tiles_m = (p.M + BM - 1) / BM;
+  p.tiles_n = (p.Nn + BN - 1) / BN;
+  const int64_t chunks = (p.R + BK - 1) / BK;
+  int64_t S = (chunks + chunks_per_block - 1) / chunks_per_block;
+  const int64_t max_s = (chunks + 3) / 4;            // at least 4 chunks per slice
+  if (S > max_s) S = max_s;
   if (S < 1) S = 1;
-  int64_t rps = (R + S - 1) / S;
+  int64_t rps = (p.R + S - 1) / S;
   rps = (rps + BK - 1) / BK * BK;
   p.rows_per_slice = (int)rps;
-  p.S = (int)((R + rps - 1) / rps);
-  return p;
+  p.S = (int)((p.R + rps - 1) / rps);
+}
+
+// Smallest chunks-per-workgroup for which the whole list fits in ONE dispatch round: kTargetBlocks =
+// 2 workgroups per CU (64 KB LDS and 140 registers each -> two are co-resident, and one's MFMAs fill
+// the other's chunk-boundary bubble: measured 93 -> 107 TFLOP/s on the grouped block list vs one per
+// CU); one workgroup more would cost a second round.  GPS_WGRAD_TARGET_BLOCKS overrides (tuning).
+static const int kTargetBlocks = [] { const char* e = getenv("GPS_WGRAD_TARGET_BLOCKS"); return e ? atoi(e) : 512; }();
+inline int64_t balanced_chunks(const int64_t* R, const int* M, const int* Nn, int n) {
+  int64_t work = 0, tiles_total = 0;
+  for (int i = 0; i < n; ++i) {
+    const int64_t tiles = (int64_t)((M[i] + BM - 1) / BM) * ((Nn[i] + BN - 1) / BN);
+    work += ((R[i] + BK - 1) / BK) * tiles;
+    tiles_total += tiles;
+  }
+  int64_t cpb = std::max<int64_t>(4, (work + kTargetBlocks - 1) / kTargetBlocks);
+  if (tiles_total >= kTargetBlocks) return INT64_MAX / 4;   // no split-K at all
+  for (;; ++cpb) {
+    int64_t blocks = 0;
+    for (int i = 0; i < n; ++i) {
+      const int64_t tiles = (int64_t)((M[i] + BM - 1) / BM) * ((Nn[i] + BN - 1) / BN);
+      const int64_t chunks = (R[i] + BK - 1) / BK;
+      int64_t S = std::min((chunks + cpb - 1) / cpb, (chunks + 3) / 4);
+      if (S < 1) S = 1;
+      const int64_t rps = ((R[i] + S - 1) / S + BK - 1) / BK * BK;
+      blocks += tiles * ((R[i] + rps - 1) / rps);
+    }
+    if (blocks <= kTargetBlocks) return cpb;
+  }
+}
+
+inline size_t problem_ws_floats(const Problem& p) {
+  return ((size_t)p.S * ((size_t)p.M * p.Nn + p.M) + 3) / 4 * 4;   // keeps the next one 16-B aligned
+}
+
+int check_problem(const char* who, const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t R,
+                  int M, int Nn, const float* gw) {
+  GPS_REQUIRE(R >= 1 && M > 0 && Nn > 0 && ldg >= M && ldx >= Nn, "%s: bad sizes", who);
+  GPS_REQUIRE(g && x && gw, "%s: null buffer", who);
+  GPS_REQUIRE(M % 4 == 0 && Nn % 4 == 0 && ldg % 4 == 0 && ldx % 4 == 0 &&
+                  (reinterpret_cast<uintptr_t>(g) % 16 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0) &&
+                  (reinterpret_cast<uintptr_t>(gw) % 16 == 0),
+              "%s: dimensions must be multiples of 4 and buffers 16-byte aligned", who);
+  return GPS_OK;
+}
+
+int launch_group(Group& G, float* ws, hipStream_t s, const char* who) {
+  int blocks = 0;
+  int64_t outs = 0;
+  for (int i = 0; i < G.n; ++i) {
+    Problem& p = G.p[i];
+    p.part = ws;
+    float* bias_part = ws + (size_t)p.S * p.M * p.Nn;
+    p.bias_part = p.gb ? bias_part : nullptr;
+    ws += problem_ws_floats(p);
+    p.block_begin = blocks;
+    blocks += p.S * p.tiles_m * p.tiles_n;
+    p.out_begin = outs;
+    outs += ((int64_t)p.M * p.Nn + 255) / 256 * 256;   // whole reduce blocks per problem
+  }
+  k_wgrad<<<(unsigned)blocks, 256, 0, s>>>(G);
+  k_wgrad_reduce<<<gps::grid_for(outs, 256), 256, 0, s>>>(G);
+  return gps::launch_status(who);
 }
 
 }  // namespace
@@ -177,29 +295,64 @@ extern "C" {
 
 size_t gps_wgrad_workspace_floats(int64_t R, int M, int Nn) {
   if (R <= 0 || M <= 0 || Nn <= 0) return 0;
-  const Plan p = make_plan(R, M, Nn);
-  return (size_t)p.S * ((size_t)M * Nn + M);
+  Problem p{};
+  p.R = R; p.M = M; p.Nn = Nn;
+  plan_slices(p, balanced_chunks(&R, &M, &Nn, 1));
+  return problem_ws_floats(p);
 }
 
 int gps_wgrad(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t R, int M, int Nn,
               float* gw, float* gb, float* ws, gps_stream_t stream) {
-  GPS_REQUIRE(R >= 1 && M > 0 && Nn > 0 && ldg >= M && ldx >= Nn, "gps_wgrad: bad sizes");
-  GPS_REQUIRE(g && x && gw && ws, "gps_wgrad: null buffer");
-  GPS_REQUIRE(M % 4 == 0 && Nn % 4 == 0 && ldg % 4 == 0 && ldx % 4 == 0 &&
-                  (reinterpret_cast<uintptr_t>(g) % 16 == 0) && (reinterpret_cast<uintptr_t>(x) % 16 == 0) &&
-                  (reinterpret_cast<uintptr_t>(gw) % 16 == 0) && (reinterpret_cast<uintptr_t>(ws) % 16 == 0),
-              "gps_wgrad: dimensions must be multiples of 4 and buffers 16-byte aligned");
-  const Plan p = make_plan(R, M, Nn);
-  float* part = ws;
-  float* bias_part = ws + (size_t)p.S * M * Nn;
-  hipStream_t s = gps::as_stream(stream);
-  const int tiles = p.tiles_m * p.tiles_n;
-  const unsigned grid = (unsigned)(p.S * tiles);
-  k_wgrad<<<grid, 256, 0, s>>>(g, ldg, x, ldx, R, M, Nn, p.tiles_m, p.tiles_n, p.S, p.rows_per_slice,
-                               gb != nullptr, part, bias_part);
-  const int64_t total = (int64_t)M * Nn;
-  k_wgrad_reduce<<<gps::grid_for(total, 256), 256, 0, s>>>(part, p.S, total, gw, bias_part, M, gb);
-  return gps::launch_status("gps_wgrad");
+  if (int rc = check_problem("gps_wgrad", g, ldg, x, ldx, R, M, Nn, gw)) return rc;
+  GPS_REQUIRE(ws && reinterpret_cast<uintptr_t>(ws) % 16 == 0, "gps_wgrad: workspace null/misaligned");
+  Group G{};
+  G.n = 1;
+  Problem& p = G.p[0];
+  p.g = g; p.x = x; p.gw = gw; p.gb = gb; p.ldg = ldg; p.ldx = ldx; p.R = R; p.M = M; p.Nn = Nn;
+  plan_slices(p, balanced_chunks(&R, &M, &Nn, 1));
+  return launch_group(G, ws, gps::as_stream(stream), "gps_wgrad");
+}
+
+size_t gps_wgrad_grouped_workspace_floats(int n, const gps_wgrad_problem* probs) {
+  if (n <= 0 || n > kMaxGroup || !probs) return 0;
+  int64_t R[kMaxGroup];
+  int M[kMaxGroup], Nn[kMaxGroup];
+  for (int i = 0; i < n; ++i) { R[i] = probs[i].R; M[i] = probs[i].M; Nn[i] = probs[i].Nn; }
+  const int64_t cpb = balanced_chunks(R, M, Nn, n);
+  size_t total = 0;
+  for (int i = 0; i < n; ++i) {
+    if (R[i] <= 0 || M[i] <= 0 || Nn[i] <= 0) return 0;
+    Problem p{};
+    p.R = R[i]; p.M = M[i]; p.Nn = Nn[i];
+    plan_slices(p, cpb);
+    total += problem_ws_floats(p);
+  }
+  return total;
+}
+
+int gps_wgrad_grouped(int n, const gps_wgrad_problem* probs, float* ws, gps_stream_t stream) {
+  GPS_REQUIRE(n >= 1 && n <= kMaxGroup && probs, "gps_wgrad_grouped: n=%d (1..%d)", n, kMaxGroup);
+  GPS_REQUIRE(ws && reinterpret_cast<uintptr_t>(ws) % 16 == 0,
+              "gps_wgrad_grouped: workspace null/misaligned");
+  Group G{};
+  G.n = n;
+  int64_t R[kMaxGroup];
+  int M[kMaxGroup], Nn[kMaxGroup];
+  for (int i = 0; i < n; ++i) {
+    const gps_wgrad_problem& q = probs[i];
+    if (int rc = check_problem("gps_wgrad_grouped", q.g, q.ldg, q.x, q.ldx, q.R, q.M, q.Nn, q.gw))
+      return rc;
+    R[i] = q.R; M[i] = q.M; Nn[i] = q.Nn;
+  }
+  const int64_t cpb = balanced_chunks(R, M, Nn, n);
+  for (int i = 0; i < n; ++i) {
+    const gps_wgrad_problem& q = probs[i];
+    Problem& p = G.p[i];
+    p.g = q.g; p.x = q.x; p.gw = q.gw; p.gb = q.gb; p.ldg = q.ldg; p.ldx = q.ldx;
+    p.R = q.R; p.M = q.M; p.Nn = q.Nn;
+    plan_slices(p, cpb);
+  }
+  return launch_group(G, ws, gps::as_stream(stream), "gps_wgrad_grouped");
 }
 
 }  // extern "C"

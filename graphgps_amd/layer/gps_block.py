@@ -115,6 +115,43 @@ class _K:
         return out
 
 
+def _grouped_param_grads(L, pairs):
+    """[(g, x), ...] -> [(g^T x, colsum(g)), ...]: all weight/bias gradients of the block in ONE
+    split-K MFMA launch + one reduce launch (csrc/wgrad.hip grouped form) on the side stream."""
+    dev = pairs[0][0].device
+    n = len(pairs)
+
+    def compute():
+        probs = (_lib.WgradProblem * n)()
+        outs = []
+        for q, (g, x) in zip(probs, pairs):
+            R, M = g.shape
+            Nn = x.shape[1]
+            g_w = _E(M, Nn, dtype=g.dtype, device=dev)
+            g_b = _E(M, dtype=g.dtype, device=dev)
+            q.g, q.x, q.gw, q.gb = g.data_ptr(), x.data_ptr(), g_w.data_ptr(), g_b.data_ptr()
+            q.ldg, q.ldx, q.R, q.M, q.Nn = g.stride(0), x.stride(0), R, M, Nn
+            outs.append((g_w, g_b))
+        ws = _E(max(L.gps_wgrad_grouped_workspace_floats(n, probs), 4), dtype=torch.float32, device=dev)
+        check(L.gps_wgrad_grouped(n, probs, ptr(ws), current_stream(dev)), "gps_wgrad_grouped")
+        return outs
+
+    if not _SIDE_ENABLED:
+        return compute()
+    cur, side = torch.cuda.current_stream(dev), _side_stream(dev)
+    side.wait_stream(cur)
+    with torch.cuda.stream(side):
+        outs = compute()
+    for g, x in pairs:
+        g.record_stream(side)
+        x.record_stream(side)
+    _queue_join(dev)
+    return outs
+
+
+_GROUPED_WGRAD = _os.environ.get("GPS_WGRAD_GROUPED", "1") != "0"
+
+
 class _GPSBlock(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, e, layer, gi: GraphIndex, seed: int, *params):
@@ -215,10 +252,12 @@ class _GPSBlock(torch.autograd.Function):
         # norm2 <- z2 = h + drop(f2);  f2 = ff2(t);  t = drop(relu(f1));  f1 = ff1(h)
         g_z2, g_n2w, g_n2b = _K.bn_bwd(L, z2, g_out, m2, r2, layer.norm2, False, 0.0, 0, st)
         g_f2 = _K.act_drop_bwd(L, g_z2, None, False, p_f2, s[5], st)
-        g_w2, g_b2 = _K.param_grads(L, g_f2, t)
+        if not _GROUPED_WGRAD:
+            g_w2, g_b2 = _K.param_grads(L, g_f2, t)
         g_t = g_f2.mm(layer.ff_linear2.weight)
         g_f1 = _K.act_drop_bwd(L, g_t, f1, True, p_f1, s[4], st)
-        g_w1, g_b1 = _K.param_grads(L, g_f1, h)
+        if not _GROUPED_WGRAD:
+            g_w1, g_b1 = _K.param_grads(L, g_f1, h)
         g_h = g_z2.addmm_(g_f1, layer.ff_linear1.weight)                  # residual + FFN input
 
         # gradient of the merged projection: attention writes dq|dk|dv into columns 4d.., GatedGCN
@@ -236,7 +275,8 @@ class _GPSBlock(torch.autograd.Function):
             sb = current_stream(dev)
             g_za, g_naw, g_nab = _K.bn_bwd(L, za, g_h, ma, ra, layer.norm1_attn, False, 0.0, 0, sb)
             g_ao = _K.act_drop_bwd(L, g_za, None, False, p_l, s[3], sb)
-            g_wo, g_bo = _K.param_grads(L, g_ao, o)
+            if not _GROUPED_WGRAD:
+                g_wo, g_bo = _K.param_grads(L, g_ao, o)
             g_o = g_ao.mm(sa.out_proj.weight)
             delta = _E(H, N, **f32)
             check(L.gps_seg_attn_bwd(ptr(g_o), P + 4 * fs, ldp, ptr(o), ptr(lse), ptr(gi.ptr),
@@ -256,11 +296,15 @@ class _GPSBlock(torch.autograd.Function):
               "gps_gatedgcn_bwd")
         if br is not None:
             cur.wait_stream(br)
-            for t_ in (g_za, g_naw, g_nab, g_wo, g_bo):
+            for t_ in (g_za, g_naw, g_nab, g_ao) + (() if _GROUPED_WGRAD else (g_wo, g_bo)):
                 t_.record_stream(cur)
         wcat, _ = layer._xgroup._stacked()
-        g_wcat, g_bcat = _K.param_grads(L, g_pq, x)
-        g_wc, g_bc = _K.param_grads(L, g_ce, e)
+        if _GROUPED_WGRAD:
+            ((g_wcat, g_bcat), (g_wc, g_bc), (g_wo, g_bo), (g_w1, g_b1), (g_w2, g_b2)) = \
+                _grouped_param_grads(L, [(g_pq, x), (g_ce, e), (g_ao, o), (g_f1, h), (g_f2, t)])
+        else:
+            g_wcat, g_bcat = _K.param_grads(L, g_pq, x)
+            g_wc, g_bc = _K.param_grads(L, g_ce, e)
         g_x = g_za.addmm_(g_pq, wcat)                                     # residual(za) + A..E + in-proj
         g_x.add_(g_x1)                                                     # residual of x1
         g_e = torch.addmm(g_e1, g_ce, lm.C.weight)                         # residual of e1 + C input

@@ -50,6 +50,8 @@ _SIGNATURES = {
     "gps_wgrad": (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int, c_int, _P, _P, _P, _P]),
     "gps_optim_chunk": (c_int, []),
     "gps_adamw_step": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P]),
+    "gps_wgrad_grouped_workspace_floats": (c_size_t, [c_int, _P]),
+    "gps_wgrad_grouped": (c_int, [c_int, _P, _P, _P]),
     "gps_segment_max_len": (c_int, [_P, c_int64, _P, _P]),
     "gps_favor_workspace_floats": (c_size_t, [c_int64, c_int]),
     "gps_favor_fwd": (c_int, [_P, c_int64, _P, c_int, _P, _P, _P, _P, c_int64, c_int64, c_int64, c_int,
@@ -64,6 +66,13 @@ _SIGNATURES = {
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+class WgradProblem(ctypes.Structure):
+    """``gps_wgrad_problem`` (include/gps_hip.h)."""
+    _fields_ = [("g", c_void_p), ("x", c_void_p), ("gw", c_void_p), ("gb", c_void_p),
+                ("ldg", c_int64), ("ldx", c_int64), ("R", c_int64), ("M", ctypes.c_int32),
+                ("Nn", ctypes.c_int32)]
 
 
 class GpsHipError(RuntimeError):

@@ -207,6 +207,20 @@ int gps_colsum(const float* x, int64_t R, int d, float* out, float* ws, gps_stre
 size_t gps_wgrad_workspace_floats(int64_t R, int M, int Nn);
 int gps_wgrad(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t R, int M, int Nn,
               float* gw, float* gb, float* ws, gps_stream_t stream);
+/* Grouped form: up to 8 independent weight(+bias)-gradient problems -- the five of one GPS block:
+ * merged A|B|D|E|in_proj, C, out_proj, ff_linear1, ff_linear2 -- in ONE launch + ONE reduce launch,
+ * the row ranges split so that every workgroup gets an equal share of the whole list.
+ * Same arithmetic per problem as gps_wgrad; ws >= gps_wgrad_grouped_workspace_floats(n, probs). */
+typedef struct gps_wgrad_problem {
+  const float* g;   /* [R, M] upstream gradient, row stride ldg */
+  const float* x;   /* [R, Nn] layer input, row stride ldx */
+  float* gw;        /* [M, Nn] out */
+  float* gb;        /* [M] out, or NULL */
+  int64_t ldg, ldx, R;
+  int32_t M, Nn;
+} gps_wgrad_problem;
+size_t gps_wgrad_grouped_workspace_floats(int n, const gps_wgrad_problem* probs);
+int gps_wgrad_grouped(int n, const gps_wgrad_problem* probs, float* ws, gps_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Graph pooling over `ptr` segments (sum: mean = 0, mean: mean = 1) and its backward.
