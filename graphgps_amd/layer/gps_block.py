@@ -21,23 +21,9 @@ from ..lib import check, current_stream, ptr
 from ..ops import GraphIndex, draw_dropout_seed
 
 _E = torch.empty
+_BY_REF = __import__("ctypes").byref
 
-import contextlib as _ctx
 import os as _os
-
-# The local (GatedGCN) and global (attention) halves of a block only meet at their sum, so the
-# attention half CAN run on its own HIP stream (GPS_BRANCH_STREAM=1).  Measured on MI355X at the
-# PCQM4M size it does not pay: eager 14.4 -> 16.6 ms/step (the stream switches make the step
-# host-bound), hipGraph replay 15.55 -> 15.71 ms.  Off by default; kept for larger graphs.
-_BRANCH_ENABLED = _os.environ.get("GPS_BRANCH_STREAM", "0") == "1"
-_branch_streams = {}
-
-
-def _branch_stream(dev):
-    st = _branch_streams.get(dev.index)
-    if st is None:
-        st = _branch_streams[dev.index] = torch.cuda.Stream(device=dev)
-    return st
 
 
 class _K:
@@ -152,7 +138,17 @@ def _grouped_param_grads(L, pairs):
 _GROUPED_WGRAD = _os.environ.get("GPS_WGRAD_GROUPED", "1") != "0"
 
 
+def _bn_desc(bn, mean, rstd):
+    """``gps_bn`` descriptor of a BatchNorm1d + the [d] buffers holding its batch statistics."""
+    return _lib.BnDesc(ptr(bn.weight), ptr(bn.bias), ptr(mean), ptr(rstd), ptr(bn.running_mean),
+                       ptr(bn.running_var), float(bn.eps), float(bn.momentum))
+
+
 class _GPSBlock(torch.autograd.Function):
+    """Kernel sequence of one block (launch counts for d = 384): 5 GEMMs + GatedGCN + attention + 10
+    norm/residual/dropout launches forward; 5 dgrad GEMMs + 1 grouped wgrad (+ reduce) + GatedGCN (2) +
+    attention (3) + 10 norm launches backward.  csrc/block_norm.hip documents the merged stages."""
+
     @staticmethod
     def forward(ctx, x, e, layer, gi: GraphIndex, seed: int, *params):
         # ``params`` (the layer's leaf parameters, fixed order below) are inputs only so that
@@ -173,62 +169,60 @@ class _GPSBlock(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
 
         # -- one GEMM for everything that consumes the layer input x: Ax|Bx|Dx|Ex (gatedgcn_layer.py:
-        # 57-61) and the attention in-projection q|k|v (gps_layer.py:238).  [N,d] x [d,7d]: hipBLASLt
-        # runs the wide GEMM at ~125 TF/s vs 100 + 65 TF/s for the two separate ones.
+        # 57-61) and the attention in-projection q|k|v (gps_layer.py:238): [N,d] x [d,7d]
         wcat, bcat = layer._xgroup._stacked()
         pq = torch.addmm(bcat, x, wcat.t())                     # [N, 4d + 3d]
         ldp = 7 * d
+        P, fs = pq.data_ptr(), d * 4
+        ce = torch.addmm(lm.C.bias, e, lm.C.weight.t())
         xt, eh = _E(N, d, **f32), _E(E, d, **f32)
         aggr, den = _E(N, d, **f32), _E(N, d, **f32)
-        P, fs = pq.data_ptr(), d * 4
-        # -- global branch (own stream): varlen attention over the PRE-layer x (gps_layer.py:199-217)
-        cur = torch.cuda.current_stream(dev)
-        br = _branch_stream(dev) if _BRANCH_ENABLED else None
-        if br is not None:
-            br.wait_stream(cur)                                  # pq is complete
-        with (torch.cuda.stream(br) if br is not None else _ctx.nullcontext()):
-            sb = current_stream(dev)
-            o, lse = _E(N, d, **f32), _E(H, N, **f32)
-            scale = float(dh) ** -0.5
-            check(L.gps_seg_attn_fwd(P + 4 * fs, ldp, ptr(gi.ptr), ptr(gi.tile_graph),
-                                     ptr(gi.tile_row0), gi.max_tiles, N, H, dh, scale, p_at, s[2],
-                                     ptr(o), ptr(lse), sb), "gps_seg_attn_fwd")
-            ao = torch.addmm(sa.out_proj.bias, o, sa.out_proj.weight.t())
-            za = _K.act_drop_add(L, x, ao, False, p_l, s[3], sb)
-            ma, ra = _K.bn_stats(L, za, layer.norm1_attn, sb)
-            del ao
-
-        # -- local branch: GatedGCN core + its two BatchNorms + norm1_local ---------------------
-        ce = torch.addmm(lm.C.bias, e, lm.C.weight.t())
         check(L.gps_gatedgcn_fwd(P, P + fs, P + 2 * fs, P + 3 * fs, ldp, ptr(ce), ptr(gi.rowptr_dst),
                                  ptr(gi.src_by_dst), ptr(gi.eid_by_dst), N, E, d, ptr(xt), ptr(eh),
                                  ptr(aggr), ptr(den), st), "gps_gatedgcn_fwd")
-        mx, rx = _K.bn_stats(L, xt, lm.bn_node_x, st)
-        x1 = _K.bn_apply(L, xt, mx, rx, lm.bn_node_x, x, True, p, s[0], st)
-        me, re_ = _K.bn_stats(L, eh, lm.bn_edge_e, st)
-        e1 = _K.bn_apply(L, eh, me, re_, lm.bn_edge_e, e, True, p, s[1], st)
-        ml, rl = _K.bn_stats(L, x1, layer.norm1_local, st)
-        hl = _K.bn_apply(L, x1, ml, rl, layer.norm1_local, None, False, 0.0, 0, st)
-        if br is not None:
-            cur.wait_stream(br)
-            for t_ in (o, lse, za, ma, ra):                      # allocated on the branch stream
-                t_.record_stream(cur)
-        h = _K.bn_apply(L, za, ma, ra, layer.norm1_attn, hl, False, 0.0, 0, st)   # hl + BN(za)
+        # -- global branch: varlen attention over the PRE-layer x (gps_layer.py:199-201,234-241)
+        o, lse = _E(N, d, **f32), _E(H, N, **f32)
+        scale = float(dh) ** -0.5
+        check(L.gps_seg_attn_fwd(P + 4 * fs, ldp, ptr(gi.ptr), ptr(gi.tile_graph), ptr(gi.tile_row0),
+                                 gi.max_tiles, N, H, dh, scale, p_at, s[2], ptr(o), ptr(lse), st),
+              "gps_seg_attn_fwd")
+        ao = torch.addmm(sa.out_proj.bias, o, sa.out_proj.weight.t())
+
+        # -- the five BatchNorms, residuals and dropouts as task lists (csrc/block_norm.hip) -------
+        stats = _E(10, d, **f32)                                # (mean, rstd) x 5
+        ws = _E(L.gps_block_norm_workspace_floats(N, E, d), **f32)
+        bnx = _bn_desc(lm.bn_node_x, stats[0], stats[1])
+        bne = _bn_desc(lm.bn_edge_e, stats[2], stats[3])
+        bnl = _bn_desc(layer.norm1_local, stats[4], stats[5])
+        bna = _bn_desc(layer.norm1_attn, stats[6], stats[7])
+        bn2 = _bn_desc(layer.norm2, stats[8], stats[9])
+        ref = _BY_REF
+        check(L.gps_bn_stats_pair(ptr(xt), N, ref(bnx), ptr(eh), E, ref(bne), d, ptr(ws), st),
+              "gps_bn_stats_pair")
+        x1, e1, za = _E(N, d, **f32), _E(E, d, **f32), _E(N, d, **f32)
+        # x1 = x + drop(relu(BN_x(xt))), e1 = e + drop(relu(BN_e(eh))), za = x + drop(ao)
+        # (+ statistics of x1 and za for norm1_local / norm1_attn)
+        check(L.gps_block_mid_fwd(ptr(xt), ptr(x), ref(bnx), p, s[0], ptr(x1), ptr(eh), ptr(e), ref(bne),
+                                  s[1], ptr(e1), ptr(ao), p_l, s[3], ptr(za), ref(bnl), ref(bna), N, E,
+                                  d, ptr(ws), st), "gps_block_mid_fwd")
+        h = _E(N, d, **f32)                                     # BN_l(x1) + BN_a(za)  (gps_layer.py:222)
+        check(L.gps_bn_dual_apply(ptr(x1), ref(bnl), ptr(za), ref(bna), N, d, ptr(h), st),
+              "gps_bn_dual_apply")
 
         # -- FFN + norm2 (gps_layer.py:225-229,253-257) ----------------------------------------
         f1 = torch.addmm(layer.ff_linear1.bias, h, layer.ff_linear1.weight.t())
         t = _K.act_drop_add(L, None, f1, True, p_f1, s[4], st)
         f2 = torch.addmm(layer.ff_linear2.bias, t, layer.ff_linear2.weight.t())
-        z2 = _K.act_drop_add(L, h, f2, False, p_f2, s[5], st)
-        m2, r2 = _K.bn_stats(L, z2, layer.norm2, st)
-        out = _K.bn_apply(L, z2, m2, r2, layer.norm2, None, False, 0.0, 0, st)
+        z2 = _E(N, d, **f32)                                    # h + drop(f2) and its statistics
+        check(L.gps_add_drop_stats(ptr(h), ptr(f2), N, d, p_f2, s[5], ptr(z2), ref(bn2), ptr(ws), st),
+              "gps_add_drop_stats")
+        out = _K.bn_apply(L, z2, stats[8], stats[9], layer.norm2, None, False, 0.0, 0, st)
         torch._foreach_add_([lm.bn_node_x.num_batches_tracked, lm.bn_edge_e.num_batches_tracked,
                              layer.norm1_local.num_batches_tracked,
                              layer.norm1_attn.num_batches_tracked,
                              layer.norm2.num_batches_tracked], 1)
 
-        ctx.save_for_backward(x, e, pq, eh, aggr, den, xt, mx, rx, me, re_, x1, ml, rl, o, lse,
-                              za, ma, ra, h, f1, t, z2, m2, r2)
+        ctx.save_for_backward(x, e, pq, eh, aggr, den, xt, x1, o, lse, za, h, f1, t, z2, stats)
         ctx.layer, ctx.gi, ctx.seeds = layer, gi, s
         ctx.cfg = (p, p_l, p_f1, p_f2, p_at, H, dh, scale)
         return out, e1
@@ -236,8 +230,7 @@ class _GPSBlock(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_out, g_e1):
         L = _lib.load()
-        (x, e, pq, eh, aggr, den, xt, mx, rx, me, re_, x1, ml, rl, o, lse, za, ma, ra, h, f1, t,
-         z2, m2, r2) = ctx.saved_tensors
+        x, e, pq, eh, aggr, den, xt, x1, o, lse, za, h, f1, t, z2, stats = ctx.saved_tensors
         layer, gi, s = ctx.layer, ctx.gi, ctx.seeds
         p, p_l, p_f1, p_f2, p_at, H, dh, scale = ctx.cfg
         lm, sa = layer.local_model, layer.self_attn
@@ -248,71 +241,66 @@ class _GPSBlock(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         g_out = g_out.contiguous()
         g_e1 = g_e1.contiguous() if g_e1 is not None else torch.zeros(E, d, **f32)
+        ws = _E(L.gps_block_norm_workspace_floats(N, E, d), **f32)
+        bnx = _bn_desc(lm.bn_node_x, stats[0], stats[1])
+        bne = _bn_desc(lm.bn_edge_e, stats[2], stats[3])
+        bnl = _bn_desc(layer.norm1_local, stats[4], stats[5])
+        bna = _bn_desc(layer.norm1_attn, stats[6], stats[7])
+        bn2 = _bn_desc(layer.norm2, stats[8], stats[9])
+        ref = _BY_REF
+        gpar = _E(10, d, **f32)              # (g_gamma, g_beta) of the five norms
+        g_bxw, g_bxb, g_bew, g_beb, g_nlw, g_nlb, g_naw, g_nab, g_n2w, g_n2b = gpar.unbind(0)
 
-        # norm2 <- z2 = h + drop(f2);  f2 = ff2(t);  t = drop(relu(f1));  f1 = ff1(h)
-        g_z2, g_n2w, g_n2b = _K.bn_bwd(L, z2, g_out, m2, r2, layer.norm2, False, 0.0, 0, st)
-        g_f2 = _K.act_drop_bwd(L, g_z2, None, False, p_f2, s[5], st)
-        if not _GROUPED_WGRAD:
-            g_w2, g_b2 = _K.param_grads(L, g_f2, t)
+        # norm2 <- z2 = h + drop(f2):  g_z2 and g_f2 = dropmask(g_z2) in one pass
+        g_z2, g_f2 = _E(N, d, **f32), _E(N, d, **f32)
+        check(L.gps_bn_bwd_drop(ptr(z2), ptr(g_out), ref(bn2), N, d, 0, 0.0, 0, ptr(g_z2), ptr(g_n2w),
+                                ptr(g_n2b), p_f2, s[5], ptr(g_f2), ptr(ws), st), "gps_bn_bwd_drop")
+        # f2 = ff2(t);  t = drop(relu(f1));  f1 = ff1(h)
         g_t = g_f2.mm(layer.ff_linear2.weight)
         g_f1 = _K.act_drop_bwd(L, g_t, f1, True, p_f1, s[4], st)
-        if not _GROUPED_WGRAD:
-            g_w1, g_b1 = _K.param_grads(L, g_f1, h)
         g_h = g_z2.addmm_(g_f1, layer.ff_linear1.weight)                  # residual + FFN input
 
+        # h = BN_l(x1) + BN_a(za);  za = x + drop(ao):  g_x1, g_x1 + g_za, g_ao = dropmask(g_za)
+        g_x1, g_xres, g_ao = _E(N, d, **f32), _E(N, d, **f32), _E(N, d, **f32)
+        check(L.gps_bn_dual_bwd(ptr(x1), ref(bnl), ptr(za), ref(bna), ptr(g_h), N, d, ptr(g_x1),
+                                ptr(g_xres), p_l, s[3], ptr(g_ao), ptr(g_nlw), ptr(g_nlb), ptr(g_naw),
+                                ptr(g_nab), ptr(ws), st), "gps_bn_dual_bwd")
+        g_o = g_ao.mm(sa.out_proj.weight)
         # gradient of the merged projection: attention writes dq|dk|dv into columns 4d.., GatedGCN
         # writes g_Ax|g_Bx|g_Dx|g_Ex into columns 0..4d of ONE [N,7d] buffer -> one dgrad, one wgrad
         ldp = 7 * d
         fs = d * 4
-        g_pq = _E(N, ldp, **f32)
+        g_pq, delta = _E(N, ldp, **f32), _E(H, N, **f32)
         G, P = g_pq.data_ptr(), pq.data_ptr()
-        cur = torch.cuda.current_stream(dev)
-        br = _branch_stream(dev) if _BRANCH_ENABLED else None
-        if br is not None:
-            br.wait_stream(cur)                                  # g_h is complete
-        with (torch.cuda.stream(br) if br is not None else _ctx.nullcontext()):
-            # h = hl + BN_a(za);  za = x + drop(ao);  ao = out_proj(o)      (attention half)
-            sb = current_stream(dev)
-            g_za, g_naw, g_nab = _K.bn_bwd(L, za, g_h, ma, ra, layer.norm1_attn, False, 0.0, 0, sb)
-            g_ao = _K.act_drop_bwd(L, g_za, None, False, p_l, s[3], sb)
-            if not _GROUPED_WGRAD:
-                g_wo, g_bo = _K.param_grads(L, g_ao, o)
-            g_o = g_ao.mm(sa.out_proj.weight)
-            delta = _E(H, N, **f32)
-            check(L.gps_seg_attn_bwd(ptr(g_o), P + 4 * fs, ldp, ptr(o), ptr(lse), ptr(gi.ptr),
-                                     ptr(gi.tile_graph), ptr(gi.tile_row0), gi.max_tiles, N, H, dh,
-                                     scale, p_at, s[2], ptr(delta), G + 4 * fs, ldp, sb),
-                  "gps_seg_attn_bwd")
+        check(L.gps_seg_attn_bwd(ptr(g_o), P + 4 * fs, ldp, ptr(o), ptr(lse), ptr(gi.ptr),
+                                 ptr(gi.tile_graph), ptr(gi.tile_row0), gi.max_tiles, N, H, dh, scale,
+                                 p_at, s[2], ptr(delta), G + 4 * fs, ldp, st), "gps_seg_attn_bwd")
 
-        # hl = BN_l(x1);  x1 = x + drop(relu(BN_x(xt)));  e1 = e + drop(relu(BN_e(eh)))   (local half)
-        g_x1, g_nlw, g_nlb = _K.bn_bwd(L, x1, g_h, ml, rl, layer.norm1_local, False, 0.0, 0, st)
-        g_xt, g_bxw, g_bxb = _K.bn_bwd(L, xt, g_x1, mx, rx, lm.bn_node_x, True, p, s[0], st)
-        g_eh, g_bew, g_beb = _K.bn_bwd(L, eh, g_e1, me, re_, lm.bn_edge_e, True, p, s[1], st)
+        # x1 = x + drop(relu(BN_x(xt)));  e1 = e + drop(relu(BN_e(eh))):  both BN backwards as one list
+        g_xt, g_eh = _E(N, d, **f32), _E(E, d, **f32)
+        check(L.gps_bn_bwd_pair(ptr(xt), ptr(g_x1), ref(bnx), N, s[0], ptr(g_xt), ptr(g_bxw), ptr(g_bxb),
+                                ptr(eh), ptr(g_e1), ref(bne), E, s[1], ptr(g_eh), ptr(g_bew),
+                                ptr(g_beb), d, 1, p, ptr(ws), st), "gps_bn_bwd_pair")
         g_ce = _E(E, d, **f32)
         check(L.gps_gatedgcn_bwd(ptr(g_xt), ptr(g_eh), ptr(eh), P + fs, ldp, ptr(aggr),
                                  ptr(den), ptr(gi.rowptr_dst), ptr(gi.src_by_dst), ptr(gi.eid_by_dst),
                                  ptr(gi.rowptr_src), ptr(gi.dst_by_src), ptr(gi.eid_by_src), N, E, d,
                                  ptr(g_ce), G, G + fs, G + 2 * fs, G + 3 * fs, ldp, st),
               "gps_gatedgcn_bwd")
-        if br is not None:
-            cur.wait_stream(br)
-            for t_ in (g_za, g_naw, g_nab, g_ao) + (() if _GROUPED_WGRAD else (g_wo, g_bo)):
-                t_.record_stream(cur)
         wcat, _ = layer._xgroup._stacked()
+        pairs = [(g_pq, x), (g_ce, e), (g_ao, o), (g_f1, h), (g_f2, t)]
         if _GROUPED_WGRAD:
             ((g_wcat, g_bcat), (g_wc, g_bc), (g_wo, g_bo), (g_w1, g_b1), (g_w2, g_b2)) = \
-                _grouped_param_grads(L, [(g_pq, x), (g_ce, e), (g_ao, o), (g_f1, h), (g_f2, t)])
+                _grouped_param_grads(L, pairs)
         else:
-            g_wcat, g_bcat = _K.param_grads(L, g_pq, x)
-            g_wc, g_bc = _K.param_grads(L, g_ce, e)
-        g_x = g_za.addmm_(g_pq, wcat)                                     # residual(za) + A..E + in-proj
-        g_x.add_(g_x1)                                                     # residual of x1
-        g_e = torch.addmm(g_e1, g_ce, lm.C.weight)                         # residual of e1 + C input
-        g_wabde, g_babde = g_wcat, g_bcat
+            ((g_wcat, g_bcat), (g_wc, g_bc), (g_wo, g_bo), (g_w1, g_b1), (g_w2, g_b2)) = \
+                [_K.param_grads(L, g, a) for g, a in pairs]
+        g_x = g_xres.addmm_(g_pq, wcat)              # residuals of za and x1 + A..E + in-proj inputs
+        g_e = torch.addmm(g_e1, g_ce, lm.C.weight)   # residual of e1 + C input
         g_wi, g_bi = g_wcat[4 * d:], g_bcat[4 * d:]
 
-        abde = [g_wabde[i * d:(i + 1) * d] for i in range(4)] + [g_babde[i * d:(i + 1) * d] for i in range(4)]
-        # order must match GPSBlockRunner.params
+        abde = [g_wcat[i * d:(i + 1) * d] for i in range(4)] + [g_bcat[i * d:(i + 1) * d] for i in range(4)]
+        # order must match block_params()
         return (g_x, g_e, None, None, None,
                 *abde, g_wc, g_bc, g_bxw, g_bxb, g_bew, g_beb, g_nlw, g_nlb,
                 g_wi, g_bi, g_wo, g_bo, g_naw, g_nab, g_w1, g_b1, g_w2, g_b2, g_n2w, g_n2b)
@@ -332,7 +320,7 @@ def block_params(layer):
             layer.norm2.weight, layer.norm2.bias]
 
 
-def block_supported(layer, x) -> bool:
+def block_supported(layer, x, e=None) -> bool:
     """The single-node path covers the measured configuration: CustomGatedGCN + Transformer,
     BatchNorm, ReLU, training mode with gradients, fp32 on the GPU."""
     import torch.nn as nn
@@ -349,7 +337,12 @@ def block_supported(layer, x) -> bool:
     for bn in (lm.bn_node_x, lm.bn_edge_e, layer.norm1_local, layer.norm1_attn, layer.norm2):
         if not (bn.affine and bn.track_running_stats and bn.momentum is not None):
             return False
-    return x.shape[0] >= 2
+    d = x.shape[1]
+    if d % 4 != 0 or d > 1024 or x.shape[0] < 2:          # csrc/block_norm.hip row mapping
+        return False
+    if e is not None and (e.dim() != 2 or e.shape[0] < 2 or e.shape[1] != d or not e.is_contiguous()):
+        return False
+    return x.is_contiguous()
 
 
 def gps_block(layer, x, e, gi):

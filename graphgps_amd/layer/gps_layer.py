@@ -139,7 +139,7 @@ class GPSLayer(nn.Module):
         h_in1 = h  # for first residual connection
         gi = graph_index_of(batch)
 
-        if _BLOCK_ENABLED and block_supported(self, h):
+        if _BLOCK_ENABLED and block_supported(self, h, batch.edge_attr):
             # measured configuration (CustomGatedGCN+Transformer, BN, ReLU, training): the whole
             # block as ONE autograd node -- same kernels, ~4x less host time (layer/gps_block.py)
             h, e_new = gps_block(self, h, batch.edge_attr, gi)

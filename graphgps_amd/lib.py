@@ -52,6 +52,18 @@ _SIGNATURES = {
     "gps_adamw_step": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P]),
     "gps_wgrad_grouped_workspace_floats": (c_size_t, [c_int, _P]),
     "gps_wgrad_grouped": (c_int, [c_int, _P, _P, _P]),
+    "gps_block_norm_workspace_floats": (c_size_t, [c_int64, c_int64, c_int]),
+    "gps_bn_stats_pair": (c_int, [_P, c_int64, _P, _P, c_int64, _P, c_int, _P, _P]),
+    "gps_block_mid_fwd": (c_int, [_P, _P, _P, c_float, c_uint64, _P, _P, _P, _P, c_uint64, _P, _P, c_float,
+                                  c_uint64, _P, _P, _P, c_int64, c_int64, c_int, _P, _P]),
+    "gps_bn_dual_apply": (c_int, [_P, _P, _P, _P, c_int64, c_int, _P, _P]),
+    "gps_add_drop_stats": (c_int, [_P, _P, c_int64, c_int, c_float, c_uint64, _P, _P, _P, _P]),
+    "gps_bn_bwd_drop": (c_int, [_P, _P, _P, c_int64, c_int, c_int, c_float, c_uint64, _P, _P, _P, c_float,
+                                c_uint64, _P, _P, _P]),
+    "gps_bn_dual_bwd": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P, _P, c_float, c_uint64, _P, _P, _P,
+                                _P, _P, _P, _P]),
+    "gps_bn_bwd_pair": (c_int, [_P, _P, _P, c_int64, c_uint64, _P, _P, _P, _P, _P, _P, c_int64, c_uint64,
+                                _P, _P, _P, c_int, c_int, c_float, _P, _P]),
     "gps_segment_max_len": (c_int, [_P, c_int64, _P, _P]),
     "gps_favor_workspace_floats": (c_size_t, [c_int64, c_int]),
     "gps_favor_fwd": (c_int, [_P, c_int64, _P, c_int, _P, _P, _P, _P, c_int64, c_int64, c_int64, c_int,
@@ -66,6 +78,13 @@ _SIGNATURES = {
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+class BnDesc(ctypes.Structure):
+    """``gps_bn`` (include/gps_hip.h): one BatchNorm1d in training mode."""
+    _fields_ = [("gamma", c_void_p), ("beta", c_void_p), ("mean", c_void_p), ("rstd", c_void_p),
+                ("running_mean", c_void_p), ("running_var", c_void_p), ("eps", c_float),
+                ("momentum", c_float)]
 
 
 class WgradProblem(ctypes.Structure):

@@ -235,6 +235,59 @@ int gps_segment_pool_bwd(const float* g_out, const int32_t* ptr, const int32_t* 
                          int64_t N, int d, int mean, float* g_x, gps_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Task-list BatchNorm / residual / dropout stages of one CustomGatedGCN+Transformer GPS block
+ * (csrc/block_norm.hip).  Same arithmetic as the gps_bn_* / gps_act_drop_* entry points above
+ * (identical formulas, statistics and counter-hash dropout), issued as lists of independent row
+ * streams per launch and with neighbouring stages merged: 19 launches per layer instead of 37.
+ * Reference lines: graphgps/layer/gatedgcn_layer.py:72-83 (bn_node_x / bn_edge_e + ReLU + dropout +
+ * residual), graphgps/layer/gps_layer.py:191-194 (norm1_local), :212-217 (dropout_attn + residual +
+ * norm1_attn), :222 (branch sum), :225-229 (ff_dropout2 + residual + norm2).
+ * All row buffers [R, d] fp32, d % 4 == 0, d <= 1024, 16-byte aligned.
+ * ------------------------------------------------------------------------------------- */
+typedef struct gps_bn {       /* one torch.nn.BatchNorm1d in training mode */
+  const float* gamma;         /* weight [d] */
+  const float* beta;          /* bias [d] */
+  float* mean;                /* batch mean [d]: written by the *_stats stages, read by apply/backward */
+  float* rstd;                /* 1/sqrt(biased var + eps) [d] */
+  float* running_mean;        /* updated by the *_stats stages (both NULL: not tracked) */
+  float* running_var;
+  float eps, momentum;
+} gps_bn;
+size_t gps_block_norm_workspace_floats(int64_t N, int64_t E, int d);
+/* batch statistics of two row streams (x~ [RA,d] for bn_node_x, e^ [RB,d] for bn_edge_e) */
+int gps_bn_stats_pair(const float* zA, int64_t RA, const gps_bn* bnA, const float* zB, int64_t RB,
+                      const gps_bn* bnB, int d, float* ws, gps_stream_t stream);
+/* x1 = x + drop(relu(BN_x(xt)))  [+ statistics of x1 -> bn_local.mean/rstd]
+ * e1 = e + drop(relu(BN_e(eh)))
+ * za = x + drop_attn(ao)          [+ statistics of za -> bn_attn.mean/rstd]        one launch + finalize */
+int gps_block_mid_fwd(const float* xt, const float* x, const gps_bn* bn_x, float p, uint64_t seed_x,
+                      float* x1, const float* eh, const float* e, const gps_bn* bn_e, uint64_t seed_e,
+                      float* e1, const float* ao, float p_attn, uint64_t seed_a, float* za,
+                      const gps_bn* bn_local, const gps_bn* bn_attn, int64_t N, int64_t E, int d,
+                      float* ws, gps_stream_t stream);
+/* out = BN_1(z1) + BN_2(z2)   (gps_layer.py:194,217,222) */
+int gps_bn_dual_apply(const float* z1, const gps_bn* bn1, const float* z2, const gps_bn* bn2, int64_t R,
+                      int d, float* out, gps_stream_t stream);
+/* out = a + drop(b) and the batch statistics of out -> bn.mean/rstd (+ running stats) */
+int gps_add_drop_stats(const float* a, const float* b, int64_t R, int d, float p, uint64_t seed, float* out,
+                       const gps_bn* bn, float* ws, gps_stream_t stream);
+/* gps_bn_bwd + a second output g_drop = dropmask(seed2, p2)(g_z) / (1 - p2)  (g_drop may be NULL) */
+int gps_bn_bwd_drop(const float* z, const float* g_y, const gps_bn* bn, int64_t R, int d, int relu, float p,
+                    uint64_t seed, float* g_z, float* g_gamma, float* g_beta, float p2, uint64_t seed2,
+                    float* g_drop, float* ws, gps_stream_t stream);
+/* backward of out = BN_1(z1) + BN_2(z2) from g_y = dL/d out:
+ *   g_z1, g_sum = g_z1 + g_z2, g_drop2 = dropmask(seed2, p2)(g_z2) / (1 - p2)  (g_drop2 may be NULL) */
+int gps_bn_dual_bwd(const float* z1, const gps_bn* bn1, const float* z2, const gps_bn* bn2, const float* g_y,
+                    int64_t R, int d, float* g_z1, float* g_sum, float p2, uint64_t seed2, float* g_drop2,
+                    float* g_gamma1, float* g_beta1, float* g_gamma2, float* g_beta2, float* ws,
+                    gps_stream_t stream);
+/* gps_bn_bwd for two row streams (bn_node_x on [RA,d], bn_edge_e on [RB,d]) in one launch triple */
+int gps_bn_bwd_pair(const float* zA, const float* gA, const gps_bn* bnA, int64_t RA, uint64_t seedA,
+                    float* g_zA, float* g_gammaA, float* g_betaA, const float* zB, const float* gB,
+                    const gps_bn* bnB, int64_t RB, uint64_t seedB, float* g_zB, float* g_gammaB,
+                    float* g_betaB, int d, int relu, float p, float* ws, gps_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * Optimizer side of the step: gradient-norm clip + AdamW over a flat fp32 parameter arena.
  * Replaces torch.nn.utils.clip_grad_norm_(model.parameters(), cfg.optim.clip_grad_norm_value)
  * followed by optimizer.step() (graphgps/train/custom_train.py:33-37) for the optimizer
