@@ -207,41 +207,78 @@ __global__ __launch_bounds__(256) void k_attn_fwd(
   }
 }
 
-// delta[h][q] = sum_c dO[q][h*DH+c] * O[q][h*DH+c]
-__global__ void k_attn_delta(const float* __restrict__ d_out, const float* __restrict__ out,
-                             int64_t N, int H, int DH, float* __restrict__ delta) {
-  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  if (t >= N * H) return;
-  const int64_t q = t / H;
-  const int h = (int)(t - q * H);
-  const float* a = d_out + q * (int64_t)(H * DH) + h * DH;
-  const float* b = out + q * (int64_t)(H * DH) + h * DH;
-  float acc = 0.0f;
-  if ((DH & 3) == 0) {  // rows are 16-byte aligned when d % 4 == 0 (checked on the host side)
-    const float4* a4 = reinterpret_cast<const float4*>(a);
-    const float4* b4 = reinterpret_cast<const float4*>(b);
-    for (int c = 0; c < DH / 4; ++c) {
-      const float4 u = a4[c], v = b4[c];
-      acc += u.x * v.x + u.y * v.y + u.z * v.z + u.w * v.w;
-    }
-  } else {
-    for (int c = 0; c < DH; ++c) acc += a[c] * b[c];
+// =============================================================================================
+// backward, query-tile keyed: dQ (+ delta)
+// =============================================================================================
+// Same discipline as the forward block: one 64-key block with NT live tiles, branch-free, every K / V
+// operand (row slices for S^T and dP^T, column form of K for dQ^T) loaded before the first MFMA.
+// Key rows past the graph end are clamped to its last row (finite data); their P is forced to 0, so
+// dS = 0 and they contribute nothing.
+template <int DH, bool DROP, int NT>
+__device__ __forceinline__ void attn_dq_block(
+    const float* __restrict__ qkv, int64_t ld, int kb, int n0, int n1, int h, int d, int i, int grp,
+    const float (&qv)[Geo<DH>::KPL], const float (&dov)[Geo<DH>::KPL], float lse_q, float dl_q,
+    uint32_t rh, float p_drop, float inv_keep, f32x4 (&acc)[Geo<DH>::DT]) {
+  constexpr int KPL = Geo<DH>::KPL, DT = Geo<DH>::DT;
+  float kv[NT][KPL], vv[NT][KPL];
+  float kc[DT][NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int krow = min(kb + 16 * t + i, n1 - 1);
+    load_kslice<DH>(qkv, ld, krow, true, d + h * DH, grp, 1.0f, kv[t]);
+    load_kslice<DH>(qkv, ld, krow, true, 2 * d + h * DH, grp, 1.0f, vv[t]);
   }
-  delta[(int64_t)h * N + q] = acc;
+#pragma unroll
+  for (int dt = 0; dt < DT; ++dt)
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = min(kb + 16 * t + 4 * grp + r, n1 - 1);
+        const int col = dt * 16 + i;
+        kc[dt][t][r] = col < DH ? qkv[(int64_t)key * ld + d + h * DH + col] : 0.0f;
+      }
+  f32x4 s[NT], dp[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    dp[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int c = 0; c < KPL; ++c)          // 2*NT independent accumulator chains interleaved
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      s[t] = mfma16(kv[t][c], qv[c], s[t]);      // S^T[key][query]
+      dp[t] = mfma16(vv[t][c], dov[c], dp[t]);   // dP^T[key][query]
+    }
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int key = kb + 16 * t + 4 * grp + r;
+      const float p = key < n1 ? expf(s[t][r] - lse_q) : 0.0f;
+      float dpe = dp[t][r];
+      if (DROP) dpe = keep_elem(rh, (uint32_t)(key - n0), p_drop) ? dpe * inv_keep : 0.0f;
+      s[t][r] = p * (dpe - dl_q);                // dS^T, reused as the B operand below
+    }
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt)            // dQ^T[dh][query] += K^T[dh][key] dS^T[key][query]
+        acc[dt] = mfma16(kc[dt][t][r], s[t][r], acc[dt]);
 }
 
-// =============================================================================================
-// backward, query-tile keyed: dQ
-// =============================================================================================
 template <int DH, bool DROP>
 __global__ __launch_bounds__(256) void k_attn_bwd_dq(
     const float* __restrict__ d_out, const float* __restrict__ qkv, int64_t ld,
-    const float* __restrict__ lse, const float* __restrict__ delta,
+    const float* __restrict__ out, const float* __restrict__ lse, float* __restrict__ delta,
     const int32_t* __restrict__ ptr, const int32_t* __restrict__ tile_graph,
     const int32_t* __restrict__ tile_row0, int64_t n_work, int64_t N, int H, float scale,
     float p_drop, uint64_t seed, const uint64_t* __restrict__ salt, float* __restrict__ d_qkv, int64_t ldg) {
   seed = gps::salted_seed(seed, salt);
-  constexpr int KPL = Geo<DH>::KPL, DT = Geo<DH>::DT;
+  constexpr int KPL = Geo<DH>::KPL, DT = Geo<DH>::DT, KT = 4;
   const int lane = threadIdx.x & 63;
   const int64_t w = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
   if (w >= n_work) return;
@@ -256,11 +293,17 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(
   const int qrow = q0 + i;
   const bool q_ok = qrow < n1;
 
-  float qv[KPL], dov[KPL];
+  float qv[KPL], dov[KPL], ov[KPL];
   load_kslice<DH>(qkv, ld, qrow, q_ok, h * DH, grp, scale, qv);
   load_kslice<DH>(d_out, d, qrow, q_ok, h * DH, grp, 1.0f, dov);
+  load_kslice<DH>(out, d, qrow, q_ok, h * DH, grp, 1.0f, ov);
   const float lse_q = q_ok ? lse[(int64_t)h * N + qrow] : 0.0f;
-  const float dl_q = q_ok ? delta[(int64_t)h * N + qrow] : 0.0f;
+  // delta[h][q] = sum_c dO[q][h*DH+c] * O[q][h*DH+c]  (6 of the dh products per lane group)
+  float dl_part = 0.0f;
+#pragma unroll
+  for (int c = 0; c < KPL; ++c) dl_part += dov[c] * ov[c];
+  const float dl_q = group_sum(dl_part);
+  if (q_ok && grp == 0) delta[(int64_t)h * N + qrow] = dl_q;   // read by k_attn_bwd_dkv (same stream)
   const uint32_t rh = DROP ? row_hash((uint32_t)qrow * (uint32_t)H + (uint32_t)h, seed) : 0u;
   const float inv_keep = DROP ? 1.0f / (1.0f - p_drop) : 1.0f;
 
@@ -268,37 +311,14 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) acc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-#pragma unroll 2
-  for (int kb = n0; kb < n1; kb += 16) {
-    const int krow = kb + i;
-    float kv[KPL], vv[KPL];
-    load_kslice<DH>(qkv, ld, krow, krow < n1, d + h * DH, grp, 1.0f, kv);
-    load_kslice<DH>(qkv, ld, krow, krow < n1, 2 * d + h * DH, grp, 1.0f, vv);
-    f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < KPL; ++c) {
-      s = mfma16(kv[c], qv[c], s);     // S^T[key][query]
-      dp = mfma16(vv[c], dov[c], dp);  // dP^T[key][query]
+  for (int kb = n0; kb < n1; kb += 16 * KT) {
+    const int nt = min(KT, (n1 - kb + 15) >> 4);  // wave-uniform
+    switch (nt) {
+      case 1: attn_dq_block<DH, DROP, 1>(qkv, ld, kb, n0, n1, h, d, i, grp, qv, dov, lse_q, dl_q, rh, p_drop, inv_keep, acc); break;
+      case 2: attn_dq_block<DH, DROP, 2>(qkv, ld, kb, n0, n1, h, d, i, grp, qv, dov, lse_q, dl_q, rh, p_drop, inv_keep, acc); break;
+      case 3: attn_dq_block<DH, DROP, 3>(qkv, ld, kb, n0, n1, h, d, i, grp, qv, dov, lse_q, dl_q, rh, p_drop, inv_keep, acc); break;
+      default: attn_dq_block<DH, DROP, 4>(qkv, ld, kb, n0, n1, h, d, i, grp, qv, dov, lse_q, dl_q, rh, p_drop, inv_keep, acc); break;
     }
-    f32x4 ds;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int key = kb + 4 * grp + r;
-      const float p = key < n1 ? expf(s[r] - lse_q) : 0.0f;
-      float dpe = dp[r];
-      if (DROP) dpe = keep_elem(rh, (uint32_t)(key - n0), p_drop) ? dpe * inv_keep : 0.0f;
-      ds[r] = p * (dpe - dl_q);
-    }
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = kb + 4 * grp + r;
-        const int col = dt * 16 + i;
-        const bool ok = key < n1 && col < DH;
-        const float kk = ok ? qkv[(int64_t)key * ld + d + h * DH + col] : 0.0f;
-        acc[dt] = mfma16(kk, ds[r], acc[dt]);  // dQ^T[dh][query] += K^T[dh][key] dS^T[key][query]
-      }
   }
   if (q_ok) {
 #pragma unroll
@@ -315,6 +335,81 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(
 // =============================================================================================
 // backward, key-tile keyed: dK, dV
 // =============================================================================================
+// One 32-query block with NT (1..2) live tiles, all Q / dO operands (row slices for S and dP, column
+// forms for dK^T and dV^T) and the per-query lse / delta loaded before the first MFMA.
+template <int DH, bool DROP, int NT>
+__device__ __forceinline__ void attn_dkv_block(
+    const float* __restrict__ d_out, const float* __restrict__ qkv, int64_t ld,
+    const float* __restrict__ lse, const float* __restrict__ delta, int64_t N, int H, int qb, int n0,
+    int n1, int h, int d, int i, int grp, int krow, const float (&kv)[Geo<DH>::KPL],
+    const float (&vv)[Geo<DH>::KPL], float scale, uint64_t seed, float p_drop, float inv_keep,
+    f32x4 (&dk)[Geo<DH>::DT], f32x4 (&dv)[Geo<DH>::DT]) {
+  constexpr int KPL = Geo<DH>::KPL, DT = Geo<DH>::DT;
+  float qa[NT][KPL], da[NT][KPL];
+  float qc[DT][NT][4], dc[DT][NT][4];
+  float lq[NT][4], dq[NT][4];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    const int qrow = min(qb + 16 * t + i, n1 - 1);
+    load_kslice<DH>(qkv, ld, qrow, true, h * DH, grp, scale, qa[t]);
+    load_kslice<DH>(d_out, d, qrow, true, h * DH, grp, 1.0f, da[t]);
+  }
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qq = min(qb + 16 * t + 4 * grp + r, n1 - 1);
+      lq[t][r] = lse[(int64_t)h * N + qq];
+      dq[t][r] = delta[(int64_t)h * N + qq];
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const int col = dt * 16 + i;
+        const bool ok = col < DH;
+        dc[dt][t][r] = ok ? d_out[(int64_t)qq * d + h * DH + col] : 0.0f;
+        qc[dt][t][r] = ok ? qkv[(int64_t)qq * ld + h * DH + col] * scale : 0.0f;
+      }
+    }
+  f32x4 s[NT], dp[NT];
+#pragma unroll
+  for (int t = 0; t < NT; ++t) {
+    s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    dp[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
+#pragma unroll
+  for (int c = 0; c < KPL; ++c)
+#pragma unroll
+    for (int t = 0; t < NT; ++t) {
+      s[t] = mfma16(qa[t][c], kv[c], s[t]);      // S[query][key]   (C layout: query = 4*grp+r, key = i)
+      dp[t] = mfma16(da[t][c], vv[c], dp[t]);    // dP[query][key]
+    }
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qq = qb + 16 * t + 4 * grp + r;
+      const float pr = qq < n1 ? expf(s[t][r] - lq[t][r]) : 0.0f;
+      float dpe = dp[t][r];
+      float pd = pr;
+      if (DROP) {
+        const uint32_t rh = row_hash((uint32_t)qq * (uint32_t)H + (uint32_t)h, seed);
+        const bool keep = keep_elem(rh, (uint32_t)(krow - n0), p_drop);
+        pd = keep ? pr * inv_keep : 0.0f;
+        dpe = keep ? dpe * inv_keep : 0.0f;
+      }
+      s[t][r] = pd;                              // P_drop
+      dp[t][r] = pr * (dpe - dq[t][r]);          // dS
+    }
+#pragma unroll
+  for (int t = 0; t < NT; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        dv[dt] = mfma16(dc[dt][t][r], s[t][r], dv[dt]);    // dV^T[dh][key] += dO^T[dh][q] P_drop[q][key]
+        dk[dt] = mfma16(qc[dt][t][r], dp[t][r], dk[dt]);   // dK^T[dh][key] += (scale Q)^T[dh][q] dS[q][key]
+      }
+}
+
 template <int DH, bool DROP>
 __global__ __launch_bounds__(256) void k_attn_bwd_dkv(
     const float* __restrict__ d_out, const float* __restrict__ qkv, int64_t ld,
@@ -323,7 +418,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(
     const int32_t* __restrict__ tile_row0, int64_t n_work, int64_t N, int H, float scale,
     float p_drop, uint64_t seed, const uint64_t* __restrict__ salt, float* __restrict__ d_qkv, int64_t ldg) {
   seed = gps::salted_seed(seed, salt);
-  constexpr int KPL = Geo<DH>::KPL, DT = Geo<DH>::DT;
+  constexpr int KPL = Geo<DH>::KPL, DT = Geo<DH>::DT, QT = 2;
   const int lane = threadIdx.x & 63;
   const int64_t w = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
   if (w >= n_work) return;
@@ -350,49 +445,13 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(
     dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
 
-#pragma unroll 2
-  for (int qb = n0; qb < n1; qb += 16) {
-    const int qrow = qb + i;
-    float qa[KPL], da[KPL];
-    load_kslice<DH>(qkv, ld, qrow, qrow < n1, h * DH, grp, scale, qa);
-    load_kslice<DH>(d_out, d, qrow, qrow < n1, h * DH, grp, 1.0f, da);
-    f32x4 s = (f32x4){0.f, 0.f, 0.f, 0.f}, dp = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < KPL; ++c) {
-      s = mfma16(qa[c], kv[c], s);     // S[query][key]   (C layout: query = 4*grp+r, key = i)
-      dp = mfma16(da[c], vv[c], dp);   // dP[query][key]
-    }
-    f32x4 p, ds;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int qq = qb + 4 * grp + r;
-      const bool ok = qq < n1;
-      const float lse_q = ok ? lse[(int64_t)h * N + qq] : 0.0f;
-      const float dl_q = ok ? delta[(int64_t)h * N + qq] : 0.0f;
-      float pr = ok ? expf(s[r] - lse_q) : 0.0f;
-      float dpe = dp[r];
-      float pd = pr;
-      if (DROP) {
-        const uint32_t rh = row_hash((uint32_t)qq * (uint32_t)H + (uint32_t)h, seed);
-        const bool keep = keep_elem(rh, (uint32_t)(krow - n0), p_drop);
-        pd = keep ? pr * inv_keep : 0.0f;
-        dpe = keep ? dpe * inv_keep : 0.0f;
-      }
-      p[r] = pd;
-      ds[r] = pr * (dpe - dl_q);
-    }
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int qq = qb + 4 * grp + r;
-        const int col = dt * 16 + i;
-        const bool ok = qq < n1 && col < DH;
-        const float dof = ok ? d_out[(int64_t)qq * d + h * DH + col] : 0.0f;
-        const float qf = ok ? qkv[(int64_t)qq * ld + h * DH + col] * scale : 0.0f;
-        dv[dt] = mfma16(dof, p[r], dv[dt]);   // dV^T[dh][key] += dO^T[dh][q] P_drop[q][key]
-        dk[dt] = mfma16(qf, ds[r], dk[dt]);   // dK^T[dh][key] += (scale Q)^T[dh][q] dS[q][key]
-      }
+  for (int qb = n0; qb < n1; qb += 16 * QT) {
+    if (n1 - qb > 16)
+      attn_dkv_block<DH, DROP, 2>(d_out, qkv, ld, lse, delta, N, H, qb, n0, n1, h, d, i, grp, krow, kv, vv,
+                                  scale, seed, p_drop, inv_keep, dk, dv);
+    else
+      attn_dkv_block<DH, DROP, 1>(d_out, qkv, ld, lse, delta, N, H, qb, n0, n1, h, d, i, grp, krow, kv, vv,
+                                  scale, seed, p_drop, inv_keep, dk, dv);
   }
   if (k_ok) {
 #pragma unroll
@@ -480,19 +539,18 @@ int gps_seg_attn_bwd(const float* d_out, const float* qkv, int64_t ld_qkv, const
   const int64_t n_work = max_tiles * H;
   const unsigned grid = gps::grid_for(n_work, 4);
   hipStream_t s = gps::as_stream(stream);
-  k_attn_delta<<<gps::grid_for(N * H, 256), 256, 0, s>>>(d_out, out, N, H, dh, delta);
   switch (dh) {
 #define X(D)                                                                                       \
   case D:                                                                                          \
     if (p_drop > 0.0f) {                                                                           \
-      k_attn_bwd_dq<D, true><<<grid, 256, 0, s>>>(d_out, qkv, ld_qkv, lse, delta, ptr, tile_graph, \
+      k_attn_bwd_dq<D, true><<<grid, 256, 0, s>>>(d_out, qkv, ld_qkv, out, lse, delta, ptr, tile_graph, \
                                                   tile_row0, n_work, N, H, scale, p_drop, seed, gps::dropout_salt(),    \
                                                   d_qkv, ld_dqkv);                                 \
       k_attn_bwd_dkv<D, true><<<grid, 256, 0, s>>>(d_out, qkv, ld_qkv, lse, delta, ptr,            \
                                                    tile_graph, tile_row0, n_work, N, H, scale,     \
                                                    p_drop, seed, gps::dropout_salt(), d_qkv, ld_dqkv);                  \
     } else {                                                                                       \
-      k_attn_bwd_dq<D, false><<<grid, 256, 0, s>>>(d_out, qkv, ld_qkv, lse, delta, ptr,            \
+      k_attn_bwd_dq<D, false><<<grid, 256, 0, s>>>(d_out, qkv, ld_qkv, out, lse, delta, ptr,       \
                                                    tile_graph, tile_row0, n_work, N, H, scale,     \
                                                    p_drop, seed, gps::dropout_salt(), d_qkv, ld_dqkv);                  \
       k_attn_bwd_dkv<D, false><<<grid, 256, 0, s>>>(d_out, qkv, ld_qkv, lse, delta, ptr,           \
