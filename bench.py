@@ -180,6 +180,21 @@ def kernel_rooflines(dev, profile, nb, d=384, H=16):
     flb = 8 * s2 * d
     res["seg_attn_bwd"] = dict(bound="mfma", ms=t, flops=flb, achieved=flb / t / 1e9,
                                peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", launches=3)
+    # the five weight(+bias) gradients of one block as ONE grouped split-K launch (csrc/wgrad.hip)
+    shapes = [(N, d, 7 * d), (E, d, d), (N, d, d), (N, d, 2 * d), (N, 2 * d, d)]   # (rows, in, out)
+    pairs = [(f(R, n), f(R, k)) for R, k, n in shapes]
+    probs = (L_.WgradProblem * len(pairs))()
+    keep = []
+    for q, (g_, x_) in zip(probs, pairs):
+        gw, gb = torch.empty(g_.shape[1], x_.shape[1], device=dev), torch.empty(g_.shape[1], device=dev)
+        keep.append((gw, gb))
+        q.g, q.x, q.gw, q.gb = g_.data_ptr(), x_.data_ptr(), gw.data_ptr(), gb.data_ptr()
+        q.ldg, q.ldx, q.R, q.M, q.Nn = g_.stride(0), x_.stride(0), g_.shape[0], g_.shape[1], x_.shape[1]
+    wws = torch.empty(max(L.gps_wgrad_grouped_workspace_floats(len(pairs), probs), 4), device=dev)
+    t = time_kernel(lambda: check(L.gps_wgrad_grouped(len(pairs), probs, ptr(wws), st)))
+    flw = sum(2.0 * R * k * n for R, k, n in shapes)
+    res["wgrad_grouped"] = dict(bound="mfma", ms=t, flops=flw, achieved=flw / t / 1e9,
+                                peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", launches=2)
     for v in res.values():
         v["frac"] = v["achieved"] / v["peak"]
     return res, dict(N=N, E=E, d=d, H=H, sum_n2=s2)
@@ -336,7 +351,7 @@ def main():
             log(f"launch-mode trial: eager {trial['eager']:.2f} ms, graph {trial['graph']:.2f} ms "
                 f"-> {launch}")
         ts.use_replay = launch == "graph"
-        graph_mode = ts.mode if launch == "graph" else "eager (3 HIP streams: main, weight-gradient)"
+        graph_mode = ts.mode if launch == "graph" else "eager (2 HIP streams: main + weight-gradient)"
         allreduce_bytes = exchange.num_bytes if exchange is not None else 0
     log("model on device, starting warm-up")
     for i in range(args.warmup):

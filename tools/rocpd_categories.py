@@ -13,9 +13,9 @@ CATS = [
     ("segment attention (HIP)", r"k_attn_"),
     ("GatedGCN / GINE sparse (HIP)", r"k_gatedgcn|k_gine"),
     ("FAVOR+ (HIP)", r"k_favor"),
-    ("fused BN / act / dropout / colsum (HIP)", r"k_bn_|k_act_drop|k_colsum"),
+    ("BN / residual / dropout task lists (HIP)", r"k_bn_|k_act_drop|k_colsum|k_rows_fwd|k_stats_finalize|k_bwd_partial|k_bwd_finalize|k_bwd_apply"),
     ("graph index + pooling (HIP)", r"k_histogram|k_scan|k_fill|k_sort_and_resolve|k_tile_map|k_ptr_from|k_pool|k_node_graph|k_segment_max"),
-    ("optimizer + grad clip (ATen foreach)", r"multi_tensor|FusedOptimizer|lpnorm|LpNorm"),
+    ("clip + AdamW (HIP) + gradient pack", r"k_adamw|k_sqnorm|multi_tensor|FusedOptimizer|lpnorm|LpNorm"),
     ("ATen elementwise / reduce / copy", r"elementwise|reduce_kernel|CatArray|copyBuffer|fillBuffer|index|scatter|gather|embedding|rocprim|sort"),
 ]
 
