@@ -13,6 +13,7 @@ from .layer.gps_layer import GPSLayer  # noqa: F401
 from .layer.gatedgcn_layer import GatedGCNLayer, GatedGCNGraphGymLayer  # noqa: F401
 from .layer.gine_conv_layer import GINEConv, GINEConvLayer, GINEConvGraphGymLayer  # noqa: F401
 from .network.gps_model import GPSModel  # noqa: F401
+from .network.custom_gnn import CustomGNN  # noqa: F401
 from .loss import losses as _losses  # noqa: F401
 from .optim import FlatAdamW, ParamArena  # noqa: F401
 

@@ -291,7 +291,26 @@ def load_cfg(cfg: CfgNode, cfg_file: Optional[str] = None,
     if opts:
         cfg.merge_from_list(opts)
     resolve_posenc_times(cfg)
+    assert_cfg(cfg)
     return cfg
+
+
+def assert_cfg(cfg: CfgNode) -> None:
+    """GraphGym's ``assert_cfg`` (PyG 2.2 ``graphgym/config.py``, third-party), which its
+    ``load_cfg`` runs after merging: the rules that change what gets built."""
+    if cfg.dataset.task not in ('node', 'edge', 'graph', 'link_pred'):
+        raise ValueError(f"Task {cfg.dataset.task} not supported, must be one of node, edge, graph, "
+                         f"link_pred")
+    if 'classification' in cfg.dataset.task_type and cfg.model.loss_fun == 'mse':
+        cfg.model.loss_fun = 'cross_entropy'
+    elif cfg.dataset.task_type == 'regression' and cfg.model.loss_fun == 'cross_entropy':
+        cfg.model.loss_fun = 'mse'
+    if cfg.dataset.task == 'graph' and cfg.dataset.transductive:
+        cfg.dataset.transductive = False
+    if cfg.gnn.layers_post_mp < 1:
+        cfg.gnn.layers_post_mp = 1
+    if cfg.gnn.head == 'default':
+        cfg.gnn.head = cfg.dataset.task
 
 
 cfg = CfgNode()

@@ -11,6 +11,7 @@ from ..encoder import encoders as _encoders  # noqa: F401  (fills the encoder re
 from ..encoder.encoders import BatchNorm1dNode
 from ..graphgym import register
 from ..graphgym.config import cfg
+from ..graphgym.layers import GNNPreMP
 from ..graphgym.register import register_network
 from ..head import ogb_code_graph as _h1, san_graph as _h2  # noqa: F401
 from ..layer.gps_layer import GPSLayer
@@ -53,9 +54,9 @@ class GPSModel(torch.nn.Module):
         self.encoder = FeatureEncoder(dim_in)
         dim_in = self.encoder.dim_in
 
-        if cfg.gnn.layers_pre_mp > 0:
-            raise NotImplementedError(
-                "gnn.layers_pre_mp > 0 needs GraphGym's GNNPreMP; every configs/GPS/*.yaml sets 0")
+        if cfg.gnn.layers_pre_mp > 0:                    # reference :67-70
+            self.pre_mp = GNNPreMP(dim_in, cfg.gnn.dim_inner, cfg.gnn.layers_pre_mp, cfg)
+            dim_in = cfg.gnn.dim_inner
 
         if not cfg.gt.dim_hidden == cfg.gnn.dim_inner == dim_in:
             raise ValueError(

@@ -296,12 +296,52 @@ class OracleGPSLayer(nn.Module):
         return batch
 
 
+class _OracleGatedGCNBatchLayer(OracleGatedGCNLayer):
+    """``GatedGCNLayer.forward(batch)`` (graphgps/layer/gatedgcn_layer.py:45-88) as custom_gnn calls it."""
+
+    def forward(self, batch):
+        x, e = super().forward(batch.x, batch.edge_attr, batch.edge_index)
+        batch.x, batch.edge_attr = x, e
+        return batch
+
+
+class _OracleGINEConvLayer(nn.Module):
+    """graphgps/layer/gine_conv_layer.py:90-116 (GINEConvLayer: GINE -> relu -> dropout -> residual)."""
+
+    def __init__(self, dim_in, dim_out, dropout, residual):
+        super().__init__()
+        self.dropout, self.residual = dropout, residual
+        gin_nn = nn.Sequential(nn.Linear(dim_in, dim_out), nn.ReLU(), nn.Linear(dim_out, dim_out))
+        self.model = OracleGINEConv(gin_nn)
+
+    def forward(self, batch):
+        x_in = batch.x
+        x = self.model(batch.x, batch.edge_index, batch.edge_attr)
+        x = F.dropout(F.relu(x), p=self.dropout, training=self.training)
+        batch.x = x_in + x if self.residual else x
+        return batch
+
+
 def to_oracle_model(model: nn.Module) -> nn.Module:
-    """Swap every HIP-backed ``GPSLayer`` in a ``graphgps_amd`` ``GPSModel`` for an
-    ``OracleGPSLayer`` with identical ``state_dict`` keys (encoders / head are plain
-    PyTorch in both).  Used by the parity tests and bench.py's cpu_baseline leg."""
+    """Swap every HIP-backed layer of a ``graphgps_amd`` ``GPSModel`` (``layers``: ``GPSLayer``) or
+    ``CustomGNN`` (``gnn_layers``: ``GatedGCNLayer`` / ``GINEConvLayer``) for its oracle twin with
+    identical ``state_dict`` keys (encoders / heads are plain PyTorch in both).  Used by the parity
+    tests and bench.py's cpu_baseline leg."""
     import copy
     model = copy.deepcopy(model).cpu()
+    if hasattr(model, "gnn_layers"):
+        new_layers = []
+        for layer in model.gnn_layers:
+            if hasattr(layer, "bn_node_x"):
+                o = _OracleGatedGCNBatchLayer(layer.A.in_features, layer.A.out_features, layer.dropout,
+                                              layer.residual)
+            else:
+                o = _OracleGINEConvLayer(layer.dim_in, layer.dim_out, layer.dropout, layer.residual)
+            o.load_state_dict(layer.state_dict(), strict=True)
+            o.train(layer.training)
+            new_layers.append(o)
+        model.gnn_layers = nn.Sequential(*new_layers)
+        return model
     new_layers = []
     for layer in model.layers:
         o = OracleGPSLayer(**layer.ctor_kwargs)

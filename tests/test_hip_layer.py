@@ -228,3 +228,39 @@ def test_block_and_operator_paths_match_fixture(monkeypatch, block):
     for name in ("gatedgcn_transformer_d32h4", "gatedgcn_transformer_d48h2"):
         _check_against_fixture(name)
     assert bool(calls) == block
+
+
+@pytest.mark.parametrize("layer_type,residual", [("gatedgcnconv", True), ("gineconv", True),
+                                                 ("gatedgcnconv", False)])
+def test_custom_gnn_vs_oracle(layer_type, residual):
+    """custom_gnn (graphgps/network/custom_gnn.py): a 3-layer GatedGCN / GINE stack + GraphGym's default
+    graph head on the HIP kernels vs the oracle: prediction, loss and every parameter gradient."""
+    from graphgps_amd.synthetic import model_batch
+    from oracle.gps_oracle import to_oracle_model
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = _build_model("pcqm4m_gpsmedium_rwse.yaml", 9, 3,
+                         ["model.type", "custom_gnn", "gnn.layer_type", layer_type, "gnn.layers_mp", 3,
+                          "gnn.dim_inner", 64, "gt.dim_hidden", 64, "gnn.head", "graph",
+                          "gnn.layers_post_mp", 2, "gnn.residual", residual, "gnn.dropout", 0.0])
+    assert type(model).__name__ == "CustomGNN"
+    model.train()
+    oracle = to_oracle_model(model)
+    model.to(dev)
+    b = model_batch("pcqm4m", 48, seed=11)
+    po, _ = oracle(b.clone())
+    lo = (po ** 2).mean() + po.sum() * 0.01
+    lo.backward()
+    pg, _ = model(b.clone().to(dev))
+    lg = (pg ** 2).mean() + pg.sum() * 0.01
+    lg.backward()
+    assert_close(pg, po, 1e-4, "pred")
+    assert_close(lg, lo, 1e-5, "loss")
+    op = dict(oracle.named_parameters())
+    checked = 0
+    for k, p in model.named_parameters():
+        if op[k].grad is None or p.grad is None:
+            continue
+        assert_close(p.grad, op[k].grad, 1e-3, f"grad {k}", rel_to_max=True)
+        checked += 1
+    assert checked > 20
