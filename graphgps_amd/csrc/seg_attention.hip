@@ -22,6 +22,13 @@
 // tests/test_hip_ops.py.
 #include "gps_common.hpp"
 
+#ifndef GPS_ATTN_KT
+#define GPS_ATTN_KT 2   // 16-key tiles per block (forward, dQ): registers scale with it
+#endif
+#ifndef GPS_ATTN_QT
+#define GPS_ATTN_QT 1   // 16-query tiles per block (dK/dV)
+#endif
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -49,19 +56,41 @@ template <int DH>
 struct Geo {
   static constexpr int KPL = (DH + 3) / 4;    // contraction elements per lane group
   static constexpr int DT = (DH + 15) / 16;   // 16-wide output tiles along dh
+  static constexpr bool EXACT = (KPL * 4 == DH);
 };
 
-// Load the KPL contiguous floats this lane contributes to a dh-contraction for `row`.
-template <int DH>
-__device__ __forceinline__ void load_kslice(const float* __restrict__ base, int64_t ld, int row,
-                                            bool row_ok, int col0, int grp, float scale,
-                                            float (&dst)[Geo<DH>::KPL]) {
+// Addressing discipline (the kernels were VALU-bound on 64-bit index arithmetic: ~775 VALU
+// instructions per wave around 56 MFMAs): every tensor is reached through a WAVE-UNIFORM base
+// pointer (graph's first row, head's first column -> scalar registers) plus a 32-bit per-lane element
+// offset `local_row * ld + col` (one v_mad_u32_u24).  Rows are clamped to the last row of the BUFFER
+// (never read out of bounds) and rows past the end of the GRAPH are zeroed by a select, so no
+// multiplication by zero ever has to cancel foreign (possibly non-finite) data.
+__device__ __forceinline__ uint32_t row_off(uint32_t lrow, uint32_t rmax, uint32_t ld) {
+  return __umul24(min(lrow, rmax), ld);
+}
+
+// The KPL contiguous floats lane group `grp` contributes to a dh-contraction, from `base[off ...]`
+// (off already includes grp * KPL).  VEC: 8-byte loads (host guarantees alignment).
+template <int DH, bool VEC>
+__device__ __forceinline__ void load_slice(const float* __restrict__ base, uint32_t off, bool ok, int grp,
+                                           float scale, float (&dst)[Geo<DH>::KPL]) {
   constexpr int KPL = Geo<DH>::KPL;
-  const float* p = base + (int64_t)row * ld + col0 + grp * KPL;
+  if constexpr (VEC && Geo<DH>::EXACT && (KPL % 2 == 0)) {
+    const float2* p = reinterpret_cast<const float2*>(base + off);
 #pragma unroll
-  for (int s = 0; s < KPL; ++s) {
-    const bool ok = row_ok && (grp * KPL + s < DH);
-    dst[s] = ok ? p[s] * scale : 0.0f;
+    for (int s = 0; s < KPL / 2; ++s) {
+      const float2 v = p[s];
+      dst[2 * s] = ok ? v.x * scale : 0.0f;
+      dst[2 * s + 1] = ok ? v.y * scale : 0.0f;
+    }
+  } else {
+    const float* p = base + off;
+#pragma unroll
+    for (int s = 0; s < KPL; ++s) {
+      const bool in = Geo<DH>::EXACT || (grp * KPL + s < DH);
+      const float v = in ? p[s] : 0.0f;
+      dst[s] = (ok && in) ? v * scale : 0.0f;
+    }
   }
 }
 
@@ -76,37 +105,77 @@ __device__ __forceinline__ float group_sum(float v) {
   return v;
 }
 
+// 4 consecutive output floats of one lane (columns col..col+3 of row `off`)
+template <int DH, bool VEC>
+__device__ __forceinline__ void store4(float* __restrict__ base, uint32_t off, int col, f32x4 v) {
+  if constexpr (VEC && (DH % 4 == 0)) {
+    if (col < DH) *reinterpret_cast<float4*>(base + off) = make_float4(v[0], v[1], v[2], v[3]);
+  } else {
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+      if (col + r < DH) base[off + r] = v[r];
+  }
+}
+
+// What every (16-row tile, head) wave needs: graph extent, head, uniform base pointers.
+struct Wave {
+  int n0, n, h, l0;          // graph's first row, size, head, tile's first LOCAL row
+  uint32_t rmax;             // last local row that is still inside the buffer
+  bool live;
+};
+__device__ __forceinline__ Wave wave_setup(const int32_t* __restrict__ ptr,
+                                           const int32_t* __restrict__ tile_graph,
+                                           const int32_t* __restrict__ tile_row0, int64_t n_work,
+                                           int64_t N, int H) {
+  Wave w;
+  w.live = false;
+  const int64_t wi = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (wi >= n_work) return w;
+  const int64_t tile = wi / H;
+  w.h = (int)(wi - tile * H);
+  const int g = tile_graph[tile];
+  if (g < 0) return w;
+  w.n0 = ptr[g];
+  w.n = ptr[g + 1] - w.n0;
+  w.l0 = tile_row0[tile] - w.n0;
+  w.rmax = (uint32_t)(N - 1 - w.n0);
+  w.live = true;
+  return w;
+}
+
 // =============================================================================================
 // forward
 // =============================================================================================
 // One 64-key block with NT (1..4) live 16-key tiles.  Branch-free and fully unrolled on purpose:
 // every K and V operand load of the block is issued before the first MFMA, so a wave pays ONE
 // memory round trip per block instead of one per tile (the kernel is latency-bound at molecule
-// sizes: ~30 x 30 x 24 per (graph, head)).  Rows past the graph end are clamped to its last row
-// (finite data) and their scores masked to -inf, so they contribute exactly 0.
-template <int DH, bool DROP, int NT>
+// sizes: ~30 x 30 x 24 per (graph, head)).
+template <int DH, bool DROP, bool VEC, int NT>
 __device__ __forceinline__ void attn_fwd_block(
-    const float* __restrict__ qkv, int64_t ld, int kb, int n0, int n1, int h, int d, int i, int grp,
-    const float (&qv)[Geo<DH>::KPL], uint32_t rh, float p_drop, float inv_keep, float& m, float& lsum,
-    f32x4 (&oacc)[Geo<DH>::DT]) {
+    const float* __restrict__ Kb, const float* __restrict__ Vb, uint32_t ld, int kb, const Wave& w, int i,
+    int grp, const float (&qv)[Geo<DH>::KPL], uint32_t rh, float p_drop, float inv_keep, float& m,
+    float& lsum, f32x4 (&oacc)[Geo<DH>::DT]) {
   constexpr int KPL = Geo<DH>::KPL, DT = Geo<DH>::DT;
   float kv[NT][KPL];
   float vv[DT][NT][4];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    const int krow = min(kb + 16 * t + i, n1 - 1);
-    load_kslice<DH>(qkv, ld, krow, true, d + h * DH, grp, 1.0f, kv[t]);
+    const int kr = kb + 16 * t + i;
+    load_slice<DH, VEC>(Kb, row_off(kr, w.rmax, ld) + grp * KPL, kr < w.n, grp, 1.0f, kv[t]);
   }
 #pragma unroll
-  for (int dt = 0; dt < DT; ++dt)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int r = 0; r < 4; ++r) {
+      const int key = kb + 16 * t + 4 * grp + r;
+      const uint32_t off = row_off(key, w.rmax, ld) + i;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = min(kb + 16 * t + 4 * grp + r, n1 - 1);
-        const int col = dt * 16 + i;
-        vv[dt][t][r] = col < DH ? qkv[(int64_t)key * ld + 2 * d + h * DH + col] : 0.0f;
+      for (int dt = 0; dt < DT; ++dt) {
+        const bool in = dt * 16 + i < DH;
+        const float v = in ? Vb[off + dt * 16] : 0.0f;
+        vv[dt][t][r] = (in && key < w.n) ? v : 0.0f;
       }
+    }
   f32x4 s[NT];
   float mloc = -INFINITY;
 #pragma unroll
@@ -120,7 +189,7 @@ __device__ __forceinline__ void attn_fwd_block(
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int key = kb + 16 * t + 4 * grp + r;
-      s[t][r] = key < n1 ? s[t][r] : -INFINITY;
+      s[t][r] = key < w.n ? s[t][r] : -INFINITY;
       mloc = fmaxf(mloc, s[t][r]);
     }
   const float mnew = fmaxf(m, group_max(mloc));
@@ -134,7 +203,7 @@ __device__ __forceinline__ void attn_fwd_block(
       float p = expf(s[t][r] - mnew);  // masked keys: exp(-inf) = 0
       psum += p;
       if (DROP) {
-        const uint32_t key_local = (uint32_t)(kb + 16 * t + 4 * grp + r - n0);
+        const uint32_t key_local = (uint32_t)(kb + 16 * t + 4 * grp + r);
         p = keep_elem(rh, key_local, p_drop) ? p * inv_keep : 0.0f;
       }
       s[t][r] = p;
@@ -151,31 +220,29 @@ __device__ __forceinline__ void attn_fwd_block(
         oacc[dt] = mfma16(vv[dt][t][r], s[t][r], oacc[dt]);
 }
 
-template <int DH, bool DROP>
+template <int DH, bool DROP, bool VEC>
 __global__ __launch_bounds__(256) void k_attn_fwd(
-    const float* __restrict__ qkv, int64_t ld, const int32_t* __restrict__ ptr,
+    const float* __restrict__ qkv, int64_t ld64, const int32_t* __restrict__ ptr,
     const int32_t* __restrict__ tile_graph, const int32_t* __restrict__ tile_row0,
     int64_t n_work, int64_t N, int H, float scale, float p_drop, uint64_t seed, const uint64_t* __restrict__ salt,
     float* __restrict__ out, float* __restrict__ lse) {
+  const Wave w = wave_setup(ptr, tile_graph, tile_row0, n_work, N, H);
+  if (!w.live) return;
   seed = gps::salted_seed(seed, salt);
-  constexpr int KPL = Geo<DH>::KPL, DT = Geo<DH>::DT, KT = 4;
+  constexpr int KPL = Geo<DH>::KPL, DT = Geo<DH>::DT, KT = GPS_ATTN_KT;
   const int lane = threadIdx.x & 63;
-  const int64_t w = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (w >= n_work) return;
-  const int64_t tile = w / H;
-  const int h = (int)(w - tile * H);
-  const int g = tile_graph[tile];
-  if (g < 0) return;
-  const int q0 = tile_row0[tile];
-  const int n0 = ptr[g], n1 = ptr[g + 1];
   const int i = lane & 15, grp = lane >> 4;
   const int d = H * DH;
-  const int qrow = q0 + i;
-  const bool q_ok = qrow < n1;
+  const uint32_t ld = (uint32_t)ld64;
+  const float* __restrict__ Qb = qkv + (int64_t)w.n0 * ld64 + w.h * DH;   // wave-uniform bases
+  const float* __restrict__ Kb = Qb + d;
+  const float* __restrict__ Vb = Qb + 2 * d;
+  const int ql = w.l0 + i;                  // local query row
+  const bool q_ok = ql < w.n;
 
   float qv[KPL];
-  load_kslice<DH>(qkv, ld, qrow, q_ok, h * DH, grp, scale, qv);
-  const uint32_t rh = DROP ? row_hash((uint32_t)qrow * (uint32_t)H + (uint32_t)h, seed) : 0u;
+  load_slice<DH, VEC>(Qb, row_off(ql, w.rmax, ld) + grp * KPL, q_ok, grp, scale, qv);
+  const uint32_t rh = DROP ? row_hash((uint32_t)(w.n0 + ql) * (uint32_t)H + (uint32_t)w.h, seed) : 0u;
   const float inv_keep = DROP ? 1.0f / (1.0f - p_drop) : 1.0f;
 
   float m = -INFINITY, lsum = 0.0f;
@@ -183,27 +250,26 @@ __global__ __launch_bounds__(256) void k_attn_fwd(
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) oacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int kb = n0; kb < n1; kb += 16 * KT) {
-    const int nt = min(KT, (n1 - kb + 15) >> 4);  // wave-uniform
+  for (int kb = 0; kb < w.n; kb += 16 * KT) {
+    const int nt = min(KT, (w.n - kb + 15) >> 4);  // wave-uniform
     switch (nt) {
-      case 1: attn_fwd_block<DH, DROP, 1>(qkv, ld, kb, n0, n1, h, d, i, grp, qv, rh, p_drop, inv_keep, m, lsum, oacc); break;
-      case 2: attn_fwd_block<DH, DROP, 2>(qkv, ld, kb, n0, n1, h, d, i, grp, qv, rh, p_drop, inv_keep, m, lsum, oacc); break;
-      case 3: attn_fwd_block<DH, DROP, 3>(qkv, ld, kb, n0, n1, h, d, i, grp, qv, rh, p_drop, inv_keep, m, lsum, oacc); break;
-      default: attn_fwd_block<DH, DROP, 4>(qkv, ld, kb, n0, n1, h, d, i, grp, qv, rh, p_drop, inv_keep, m, lsum, oacc); break;
+      case 1: attn_fwd_block<DH, DROP, VEC, 1>(Kb, Vb, ld, kb, w, i, grp, qv, rh, p_drop, inv_keep, m, lsum, oacc); break;
+      case 2: attn_fwd_block<DH, DROP, VEC, (KT >= 2 ? 2 : KT)>(Kb, Vb, ld, kb, w, i, grp, qv, rh, p_drop, inv_keep, m, lsum, oacc); break;
+      case 3: attn_fwd_block<DH, DROP, VEC, (KT >= 3 ? 3 : KT)>(Kb, Vb, ld, kb, w, i, grp, qv, rh, p_drop, inv_keep, m, lsum, oacc); break;
+      default: attn_fwd_block<DH, DROP, VEC, KT>(Kb, Vb, ld, kb, w, i, grp, qv, rh, p_drop, inv_keep, m, lsum, oacc); break;
     }
   }
   const float ltot = group_sum(lsum);
   const float inv_l = 1.0f / ltot;
   if (q_ok) {
+    float* __restrict__ Ob = out + (int64_t)w.n0 * d + w.h * DH;
+    const uint32_t orow = (uint32_t)ql * (uint32_t)d;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
       const int col = dt * 16 + 4 * grp;
-      float* o = out + (int64_t)qrow * d + h * DH + col;
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (col + r < DH) o[r] = oacc[dt][r] * inv_l;
+      store4<DH, VEC>(Ob, orow + col, col, oacc[dt] * inv_l);
     }
-    if (grp == 0) lse[(int64_t)h * N + qrow] = m + logf(ltot);
+    if (grp == 0) lse[(int64_t)w.h * N + w.n0 + ql] = m + logf(ltot);
   }
 }
 
@@ -212,32 +278,34 @@ __global__ __launch_bounds__(256) void k_attn_fwd(
 // =============================================================================================
 // Same discipline as the forward block: one 64-key block with NT live tiles, branch-free, every K / V
 // operand (row slices for S^T and dP^T, column form of K for dQ^T) loaded before the first MFMA.
-// Key rows past the graph end are clamped to its last row (finite data); their P is forced to 0, so
-// dS = 0 and they contribute nothing.
-template <int DH, bool DROP, int NT>
+template <int DH, bool DROP, bool VEC, int NT>
 __device__ __forceinline__ void attn_dq_block(
-    const float* __restrict__ qkv, int64_t ld, int kb, int n0, int n1, int h, int d, int i, int grp,
-    const float (&qv)[Geo<DH>::KPL], const float (&dov)[Geo<DH>::KPL], float lse_q, float dl_q,
+    const float* __restrict__ Kb, const float* __restrict__ Vb, uint32_t ld, int kb, const Wave& w, int i,
+    int grp, const float (&qv)[Geo<DH>::KPL], const float (&dov)[Geo<DH>::KPL], float lse_q, float dl_q,
     uint32_t rh, float p_drop, float inv_keep, f32x4 (&acc)[Geo<DH>::DT]) {
   constexpr int KPL = Geo<DH>::KPL, DT = Geo<DH>::DT;
   float kv[NT][KPL], vv[NT][KPL];
   float kc[DT][NT][4];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    const int krow = min(kb + 16 * t + i, n1 - 1);
-    load_kslice<DH>(qkv, ld, krow, true, d + h * DH, grp, 1.0f, kv[t]);
-    load_kslice<DH>(qkv, ld, krow, true, 2 * d + h * DH, grp, 1.0f, vv[t]);
+    const int kr = kb + 16 * t + i;
+    const uint32_t off = row_off(kr, w.rmax, ld) + grp * KPL;
+    load_slice<DH, VEC>(Kb, off, kr < w.n, grp, 1.0f, kv[t]);
+    load_slice<DH, VEC>(Vb, off, kr < w.n, grp, 1.0f, vv[t]);
   }
 #pragma unroll
-  for (int dt = 0; dt < DT; ++dt)
+  for (int t = 0; t < NT; ++t)
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+    for (int r = 0; r < 4; ++r) {
+      const int key = kb + 16 * t + 4 * grp + r;
+      const uint32_t off = row_off(key, w.rmax, ld) + i;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = min(kb + 16 * t + 4 * grp + r, n1 - 1);
-        const int col = dt * 16 + i;
-        kc[dt][t][r] = col < DH ? qkv[(int64_t)key * ld + d + h * DH + col] : 0.0f;
+      for (int dt = 0; dt < DT; ++dt) {
+        const bool in = dt * 16 + i < DH;
+        const float v = in ? Kb[off + dt * 16] : 0.0f;
+        kc[dt][t][r] = (in && key < w.n) ? v : 0.0f;
       }
+    }
   f32x4 s[NT], dp[NT];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
@@ -256,10 +324,10 @@ __device__ __forceinline__ void attn_dq_block(
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int key = kb + 16 * t + 4 * grp + r;
-      const float p = key < n1 ? expf(s[t][r] - lse_q) : 0.0f;
+      const float p = expf(s[t][r] - lse_q);
       float dpe = dp[t][r];
-      if (DROP) dpe = keep_elem(rh, (uint32_t)(key - n0), p_drop) ? dpe * inv_keep : 0.0f;
-      s[t][r] = p * (dpe - dl_q);                // dS^T, reused as the B operand below
+      if (DROP) dpe = keep_elem(rh, (uint32_t)key, p_drop) ? dpe * inv_keep : 0.0f;
+      s[t][r] = key < w.n ? p * (dpe - dl_q) : 0.0f;   // dS^T, reused as the B operand below
     }
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -270,64 +338,65 @@ __device__ __forceinline__ void attn_dq_block(
         acc[dt] = mfma16(kc[dt][t][r], s[t][r], acc[dt]);
 }
 
-template <int DH, bool DROP>
+template <int DH, bool DROP, bool VEC>
 __global__ __launch_bounds__(256) void k_attn_bwd_dq(
-    const float* __restrict__ d_out, const float* __restrict__ qkv, int64_t ld,
+    const float* __restrict__ d_out, const float* __restrict__ qkv, int64_t ld64,
     const float* __restrict__ out, const float* __restrict__ lse, float* __restrict__ delta,
     const int32_t* __restrict__ ptr, const int32_t* __restrict__ tile_graph,
     const int32_t* __restrict__ tile_row0, int64_t n_work, int64_t N, int H, float scale,
-    float p_drop, uint64_t seed, const uint64_t* __restrict__ salt, float* __restrict__ d_qkv, int64_t ldg) {
+    float p_drop, uint64_t seed, const uint64_t* __restrict__ salt, float* __restrict__ d_qkv, int64_t ldg64) {
+  const Wave w = wave_setup(ptr, tile_graph, tile_row0, n_work, N, H);
+  if (!w.live) return;
   seed = gps::salted_seed(seed, salt);
-  constexpr int KPL = Geo<DH>::KPL, DT = Geo<DH>::DT, KT = 4;
+  constexpr int KPL = Geo<DH>::KPL, DT = Geo<DH>::DT, KT = GPS_ATTN_KT;
   const int lane = threadIdx.x & 63;
-  const int64_t w = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (w >= n_work) return;
-  const int64_t tile = w / H;
-  const int h = (int)(w - tile * H);
-  const int g = tile_graph[tile];
-  if (g < 0) return;
-  const int q0 = tile_row0[tile];
-  const int n0 = ptr[g], n1 = ptr[g + 1];
   const int i = lane & 15, grp = lane >> 4;
   const int d = H * DH;
-  const int qrow = q0 + i;
-  const bool q_ok = qrow < n1;
+  const uint32_t ld = (uint32_t)ld64;
+  const float* __restrict__ Qb = qkv + (int64_t)w.n0 * ld64 + w.h * DH;
+  const float* __restrict__ Kb = Qb + d;
+  const float* __restrict__ Vb = Qb + 2 * d;
+  const float* __restrict__ dOb = d_out + (int64_t)w.n0 * d + w.h * DH;
+  const float* __restrict__ Ob = out + (int64_t)w.n0 * d + w.h * DH;
+  const int ql = w.l0 + i;
+  const bool q_ok = ql < w.n;
 
   float qv[KPL], dov[KPL], ov[KPL];
-  load_kslice<DH>(qkv, ld, qrow, q_ok, h * DH, grp, scale, qv);
-  load_kslice<DH>(d_out, d, qrow, q_ok, h * DH, grp, 1.0f, dov);
-  load_kslice<DH>(out, d, qrow, q_ok, h * DH, grp, 1.0f, ov);
-  const float lse_q = q_ok ? lse[(int64_t)h * N + qrow] : 0.0f;
-  // delta[h][q] = sum_c dO[q][h*DH+c] * O[q][h*DH+c]  (6 of the dh products per lane group)
+  load_slice<DH, VEC>(Qb, row_off(ql, w.rmax, ld) + grp * KPL, q_ok, grp, scale, qv);
+  const uint32_t orow = row_off(ql, w.rmax, (uint32_t)d) + grp * KPL;
+  load_slice<DH, VEC>(dOb, orow, q_ok, grp, 1.0f, dov);
+  load_slice<DH, VEC>(Ob, orow, q_ok, grp, 1.0f, ov);
+  const int64_t sidx = (int64_t)w.h * N + w.n0 + min((uint32_t)ql, w.rmax);
+  const float lse_q = lse[sidx];
+  // delta[h][q] = sum_c dO[q][h*DH+c] * O[q][h*DH+c]  (KPL of the dh products per lane group)
   float dl_part = 0.0f;
 #pragma unroll
   for (int c = 0; c < KPL; ++c) dl_part += dov[c] * ov[c];
   const float dl_q = group_sum(dl_part);
-  if (q_ok && grp == 0) delta[(int64_t)h * N + qrow] = dl_q;   // read by k_attn_bwd_dkv (same stream)
-  const uint32_t rh = DROP ? row_hash((uint32_t)qrow * (uint32_t)H + (uint32_t)h, seed) : 0u;
+  if (q_ok && grp == 0) delta[sidx] = dl_q;   // read by k_attn_bwd_dkv (same stream)
+  const uint32_t rh = DROP ? row_hash((uint32_t)(w.n0 + ql) * (uint32_t)H + (uint32_t)w.h, seed) : 0u;
   const float inv_keep = DROP ? 1.0f / (1.0f - p_drop) : 1.0f;
 
   f32x4 acc[DT];
 #pragma unroll
   for (int dt = 0; dt < DT; ++dt) acc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  for (int kb = n0; kb < n1; kb += 16 * KT) {
-    const int nt = min(KT, (n1 - kb + 15) >> 4);  // wave-uniform
+  for (int kb = 0; kb < w.n; kb += 16 * KT) {
+    const int nt = min(KT, (w.n - kb + 15) >> 4);  // wave-uniform
     switch (nt) {
-      case 1: attn_dq_block<DH, DROP, 1>(qkv, ld, kb, n0, n1, h, d, i, grp, qv, dov, lse_q, dl_q, rh, p_drop, inv_keep, acc); break;
-      case 2: attn_dq_block<DH, DROP, 2>(qkv, ld, kb, n0, n1, h, d, i, grp, qv, dov, lse_q, dl_q, rh, p_drop, inv_keep, acc); break;
-      case 3: attn_dq_block<DH, DROP, 3>(qkv, ld, kb, n0, n1, h, d, i, grp, qv, dov, lse_q, dl_q, rh, p_drop, inv_keep, acc); break;
-      default: attn_dq_block<DH, DROP, 4>(qkv, ld, kb, n0, n1, h, d, i, grp, qv, dov, lse_q, dl_q, rh, p_drop, inv_keep, acc); break;
+      case 1: attn_dq_block<DH, DROP, VEC, 1>(Kb, Vb, ld, kb, w, i, grp, qv, dov, lse_q, dl_q, rh, p_drop, inv_keep, acc); break;
+      case 2: attn_dq_block<DH, DROP, VEC, (KT >= 2 ? 2 : KT)>(Kb, Vb, ld, kb, w, i, grp, qv, dov, lse_q, dl_q, rh, p_drop, inv_keep, acc); break;
+      case 3: attn_dq_block<DH, DROP, VEC, (KT >= 3 ? 3 : KT)>(Kb, Vb, ld, kb, w, i, grp, qv, dov, lse_q, dl_q, rh, p_drop, inv_keep, acc); break;
+      default: attn_dq_block<DH, DROP, VEC, KT>(Kb, Vb, ld, kb, w, i, grp, qv, dov, lse_q, dl_q, rh, p_drop, inv_keep, acc); break;
     }
   }
   if (q_ok) {
+    float* __restrict__ Gq = d_qkv + (int64_t)w.n0 * ldg64 + w.h * DH;
+    const uint32_t grow = (uint32_t)ql * (uint32_t)ldg64;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
       const int col = dt * 16 + 4 * grp;
-      float* o = d_qkv + (int64_t)qrow * ldg + h * DH + col;
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (col + r < DH) o[r] = acc[dt][r] * scale;
+      store4<DH, VEC>(Gq, grow + col, col, acc[dt] * scale);
     }
   }
 }
@@ -337,36 +406,39 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(
 // =============================================================================================
 // One 32-query block with NT (1..2) live tiles, all Q / dO operands (row slices for S and dP, column
 // forms for dK^T and dV^T) and the per-query lse / delta loaded before the first MFMA.
-template <int DH, bool DROP, int NT>
+template <int DH, bool DROP, bool VEC, int NT>
 __device__ __forceinline__ void attn_dkv_block(
-    const float* __restrict__ d_out, const float* __restrict__ qkv, int64_t ld,
-    const float* __restrict__ lse, const float* __restrict__ delta, int64_t N, int H, int qb, int n0,
-    int n1, int h, int d, int i, int grp, int krow, const float (&kv)[Geo<DH>::KPL],
-    const float (&vv)[Geo<DH>::KPL], float scale, uint64_t seed, float p_drop, float inv_keep,
-    f32x4 (&dk)[Geo<DH>::DT], f32x4 (&dv)[Geo<DH>::DT]) {
+    const float* __restrict__ Qb, const float* __restrict__ dOb, const float* __restrict__ lse_b,
+    const float* __restrict__ delta_b, uint32_t ld, uint32_t d, int H, int qb, const Wave& w, int i, int grp,
+    int kl, const float (&kv)[Geo<DH>::KPL], const float (&vv)[Geo<DH>::KPL], float scale, uint64_t seed,
+    float p_drop, float inv_keep, f32x4 (&dk)[Geo<DH>::DT], f32x4 (&dv)[Geo<DH>::DT]) {
   constexpr int KPL = Geo<DH>::KPL, DT = Geo<DH>::DT;
   float qa[NT][KPL], da[NT][KPL];
   float qc[DT][NT][4], dc[DT][NT][4];
   float lq[NT][4], dq[NT][4];
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
-    const int qrow = min(qb + 16 * t + i, n1 - 1);
-    load_kslice<DH>(qkv, ld, qrow, true, h * DH, grp, scale, qa[t]);
-    load_kslice<DH>(d_out, d, qrow, true, h * DH, grp, 1.0f, da[t]);
+    const int qr = qb + 16 * t + i;
+    load_slice<DH, VEC>(Qb, row_off(qr, w.rmax, ld) + grp * KPL, qr < w.n, grp, scale, qa[t]);
+    load_slice<DH, VEC>(dOb, row_off(qr, w.rmax, d) + grp * KPL, qr < w.n, grp, 1.0f, da[t]);
   }
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int qq = min(qb + 16 * t + 4 * grp + r, n1 - 1);
-      lq[t][r] = lse[(int64_t)h * N + qq];
-      dq[t][r] = delta[(int64_t)h * N + qq];
+      const int qq = qb + 16 * t + 4 * grp + r;
+      const bool q_in = qq < w.n;
+      const uint32_t qcl = min((uint32_t)qq, w.rmax);
+      lq[t][r] = lse_b[qcl];
+      dq[t][r] = delta_b[qcl];
+      const uint32_t offq = __umul24(qcl, ld) + i, offd = __umul24(qcl, d) + i;
 #pragma unroll
       for (int dt = 0; dt < DT; ++dt) {
-        const int col = dt * 16 + i;
-        const bool ok = col < DH;
-        dc[dt][t][r] = ok ? d_out[(int64_t)qq * d + h * DH + col] : 0.0f;
-        qc[dt][t][r] = ok ? qkv[(int64_t)qq * ld + h * DH + col] * scale : 0.0f;
+        const bool in = dt * 16 + i < DH;
+        const float vq = in ? Qb[offq + dt * 16] : 0.0f;
+        const float vd = in ? dOb[offd + dt * 16] : 0.0f;
+        qc[dt][t][r] = (in && q_in) ? vq * scale : 0.0f;
+        dc[dt][t][r] = (in && q_in) ? vd : 0.0f;
       }
     }
   f32x4 s[NT], dp[NT];
@@ -387,17 +459,18 @@ __device__ __forceinline__ void attn_dkv_block(
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int qq = qb + 16 * t + 4 * grp + r;
-      const float pr = qq < n1 ? expf(s[t][r] - lq[t][r]) : 0.0f;
+      const bool q_in = qq < w.n;
+      const float pr = q_in ? expf(s[t][r] - lq[t][r]) : 0.0f;
       float dpe = dp[t][r];
       float pd = pr;
       if (DROP) {
-        const uint32_t rh = row_hash((uint32_t)qq * (uint32_t)H + (uint32_t)h, seed);
-        const bool keep = keep_elem(rh, (uint32_t)(krow - n0), p_drop);
+        const uint32_t rh = row_hash((uint32_t)(w.n0 + qq) * (uint32_t)H + (uint32_t)w.h, seed);
+        const bool keep = keep_elem(rh, (uint32_t)kl, p_drop);
         pd = keep ? pr * inv_keep : 0.0f;
         dpe = keep ? dpe * inv_keep : 0.0f;
       }
-      s[t][r] = pd;                              // P_drop
-      dp[t][r] = pr * (dpe - dq[t][r]);          // dS
+      s[t][r] = pd;                                        // P_drop
+      dp[t][r] = q_in ? pr * (dpe - dq[t][r]) : 0.0f;      // dS
     }
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -410,33 +483,35 @@ __device__ __forceinline__ void attn_dkv_block(
       }
 }
 
-template <int DH, bool DROP>
+template <int DH, bool DROP, bool VEC>
 __global__ __launch_bounds__(256) void k_attn_bwd_dkv(
-    const float* __restrict__ d_out, const float* __restrict__ qkv, int64_t ld,
+    const float* __restrict__ d_out, const float* __restrict__ qkv, int64_t ld64,
     const float* __restrict__ lse, const float* __restrict__ delta,
     const int32_t* __restrict__ ptr, const int32_t* __restrict__ tile_graph,
     const int32_t* __restrict__ tile_row0, int64_t n_work, int64_t N, int H, float scale,
-    float p_drop, uint64_t seed, const uint64_t* __restrict__ salt, float* __restrict__ d_qkv, int64_t ldg) {
+    float p_drop, uint64_t seed, const uint64_t* __restrict__ salt, float* __restrict__ d_qkv, int64_t ldg64) {
+  const Wave w = wave_setup(ptr, tile_graph, tile_row0, n_work, N, H);
+  if (!w.live) return;
   seed = gps::salted_seed(seed, salt);
-  constexpr int KPL = Geo<DH>::KPL, DT = Geo<DH>::DT, QT = 2;
+  constexpr int KPL = Geo<DH>::KPL, DT = Geo<DH>::DT, QT = GPS_ATTN_QT;
   const int lane = threadIdx.x & 63;
-  const int64_t w = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (w >= n_work) return;
-  const int64_t tile = w / H;
-  const int h = (int)(w - tile * H);
-  const int g = tile_graph[tile];
-  if (g < 0) return;
-  const int k0 = tile_row0[tile];
-  const int n0 = ptr[g], n1 = ptr[g + 1];
   const int i = lane & 15, grp = lane >> 4;
   const int d = H * DH;
-  const int krow = k0 + i;
-  const bool k_ok = krow < n1;
+  const uint32_t ld = (uint32_t)ld64;
+  const float* __restrict__ Qb = qkv + (int64_t)w.n0 * ld64 + w.h * DH;
+  const float* __restrict__ Kb = Qb + d;
+  const float* __restrict__ Vb = Qb + 2 * d;
+  const float* __restrict__ dOb = d_out + (int64_t)w.n0 * d + w.h * DH;
+  const float* __restrict__ lse_b = lse + (int64_t)w.h * N + w.n0;
+  const float* __restrict__ delta_b = delta + (int64_t)w.h * N + w.n0;
+  const int kl = w.l0 + i;                  // local key row
+  const bool k_ok = kl < w.n;
   const float inv_keep = DROP ? 1.0f / (1.0f - p_drop) : 1.0f;
 
   float kv[KPL], vv[KPL];
-  load_kslice<DH>(qkv, ld, krow, k_ok, d + h * DH, grp, 1.0f, kv);
-  load_kslice<DH>(qkv, ld, krow, k_ok, 2 * d + h * DH, grp, 1.0f, vv);
+  const uint32_t koff = row_off(kl, w.rmax, ld) + grp * KPL;
+  load_slice<DH, VEC>(Kb, koff, k_ok, grp, 1.0f, kv);
+  load_slice<DH, VEC>(Vb, koff, k_ok, grp, 1.0f, vv);
 
   f32x4 dk[DT], dv[DT];
 #pragma unroll
@@ -445,26 +520,23 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(
     dv[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
 
-  for (int qb = n0; qb < n1; qb += 16 * QT) {
-    if (n1 - qb > 16)
-      attn_dkv_block<DH, DROP, 2>(d_out, qkv, ld, lse, delta, N, H, qb, n0, n1, h, d, i, grp, krow, kv, vv,
-                                  scale, seed, p_drop, inv_keep, dk, dv);
+  for (int qb = 0; qb < w.n; qb += 16 * QT) {
+    if (QT > 1 && w.n - qb > 16)
+      attn_dkv_block<DH, DROP, VEC, QT>(Qb, dOb, lse_b, delta_b, ld, (uint32_t)d, H, qb, w, i, grp, kl, kv, vv,
+                                        scale, seed, p_drop, inv_keep, dk, dv);
     else
-      attn_dkv_block<DH, DROP, 1>(d_out, qkv, ld, lse, delta, N, H, qb, n0, n1, h, d, i, grp, krow, kv, vv,
-                                  scale, seed, p_drop, inv_keep, dk, dv);
+      attn_dkv_block<DH, DROP, VEC, 1>(Qb, dOb, lse_b, delta_b, ld, (uint32_t)d, H, qb, w, i, grp, kl, kv, vv,
+                                       scale, seed, p_drop, inv_keep, dk, dv);
   }
   if (k_ok) {
+    float* __restrict__ Gk = d_qkv + (int64_t)w.n0 * ldg64 + d + w.h * DH;
+    float* __restrict__ Gv = Gk + d;
+    const uint32_t grow = (uint32_t)kl * (uint32_t)ldg64;
 #pragma unroll
     for (int dt = 0; dt < DT; ++dt) {
       const int col = dt * 16 + 4 * grp;
-      float* ok_ = d_qkv + (int64_t)krow * ldg + d + h * DH + col;
-      float* ov_ = d_qkv + (int64_t)krow * ldg + 2 * d + h * DH + col;
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-        if (col + r < DH) {
-          ok_[r] = dk[dt][r];
-          ov_[r] = dv[dt][r];
-        }
+      store4<DH, VEC>(Gk, grow + col, col, dk[dt]);
+      store4<DH, VEC>(Gv, grow + col, col, dv[dt]);
     }
   }
 }
@@ -472,6 +544,8 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(
 #define GPS_FOR_EACH_DH(X) X(4) X(6) X(8) X(12) X(13) X(16) X(18) X(24) X(32) X(48) X(64) X(76) X(96) X(128)
 
 }  // namespace
+
+static inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) % 16) == 0; }
 
 extern "C" {
 
@@ -500,22 +574,27 @@ int gps_seg_attn_fwd(const float* qkv, int64_t ld_qkv, const int32_t* ptr,
     gps::set_error("gps_seg_attn_fwd: head dim %d has no compiled kernel", dh);
     return GPS_EUNSUPPORTED;
   }
+  GPS_REQUIRE(N * ld_qkv < (int64_t(1) << 31), "gps_seg_attn_fwd: N * ld exceeds 32-bit element offsets");
   const int64_t n_work = max_tiles * H;
   const unsigned grid = gps::grid_for(n_work, 4);
   hipStream_t s = gps::as_stream(stream);
+  const bool vec = ld_qkv % 4 == 0 && (H * dh) % 4 == 0 && al16(qkv) && al16(out);
+#define LAUNCH_FWD(D, DROP, VEC)                                                                 \
+  k_attn_fwd<D, DROP, VEC><<<grid, 256, 0, s>>>(qkv, ld_qkv, ptr, tile_graph, tile_row0, n_work, N, H, \
+                                                scale, p_drop, seed, gps::dropout_salt(), out, lse)
   switch (dh) {
-#define X(D)                                                                                      \
-  case D:                                                                                         \
-    if (p_drop > 0.0f)                                                                            \
-      k_attn_fwd<D, true><<<grid, 256, 0, s>>>(qkv, ld_qkv, ptr, tile_graph, tile_row0, n_work, N, \
-                                               H, scale, p_drop, seed, gps::dropout_salt(), out, lse);                 \
-    else                                                                                          \
-      k_attn_fwd<D, false><<<grid, 256, 0, s>>>(qkv, ld_qkv, ptr, tile_graph, tile_row0, n_work,  \
-                                                N, H, scale, p_drop, seed, gps::dropout_salt(), out, lse);             \
+#define X(D)                                                             \
+  case D:                                                                \
+    if (p_drop > 0.0f) {                                                 \
+      if (vec) LAUNCH_FWD(D, true, true); else LAUNCH_FWD(D, true, false);   \
+    } else {                                                             \
+      if (vec) LAUNCH_FWD(D, false, true); else LAUNCH_FWD(D, false, false); \
+    }                                                                    \
     break;
     GPS_FOR_EACH_DH(X)
 #undef X
   }
+#undef LAUNCH_FWD
   return gps::launch_status("gps_seg_attn_fwd");
 }
 
@@ -536,31 +615,35 @@ int gps_seg_attn_bwd(const float* d_out, const float* qkv, int64_t ld_qkv, const
     gps::set_error("gps_seg_attn_bwd: head dim %d has no compiled kernel", dh);
     return GPS_EUNSUPPORTED;
   }
+  GPS_REQUIRE(N * ld_qkv < (int64_t(1) << 31) && N * ld_dqkv < (int64_t(1) << 31),
+              "gps_seg_attn_bwd: N * ld exceeds 32-bit element offsets");
   const int64_t n_work = max_tiles * H;
   const unsigned grid = gps::grid_for(n_work, 4);
   hipStream_t s = gps::as_stream(stream);
+  const bool vec = ld_qkv % 4 == 0 && ld_dqkv % 4 == 0 && (H * dh) % 4 == 0 && al16(qkv) && al16(out) &&
+                   al16(d_out) && al16(d_qkv);
+#define LAUNCH_BWD(D, DROP, VEC)                                                                    \
+  do {                                                                                              \
+    k_attn_bwd_dq<D, DROP, VEC><<<grid, 256, 0, s>>>(d_out, qkv, ld_qkv, out, lse, delta, ptr, tile_graph, \
+                                                     tile_row0, n_work, N, H, scale, p_drop, seed,  \
+                                                     gps::dropout_salt(), d_qkv, ld_dqkv);          \
+    k_attn_bwd_dkv<D, DROP, VEC><<<grid, 256, 0, s>>>(d_out, qkv, ld_qkv, lse, delta, ptr, tile_graph,     \
+                                                      tile_row0, n_work, N, H, scale, p_drop, seed, \
+                                                      gps::dropout_salt(), d_qkv, ld_dqkv);         \
+  } while (0)
   switch (dh) {
-#define X(D)                                                                                       \
-  case D:                                                                                          \
-    if (p_drop > 0.0f) {                                                                           \
-      k_attn_bwd_dq<D, true><<<grid, 256, 0, s>>>(d_out, qkv, ld_qkv, out, lse, delta, ptr, tile_graph, \
-                                                  tile_row0, n_work, N, H, scale, p_drop, seed, gps::dropout_salt(),    \
-                                                  d_qkv, ld_dqkv);                                 \
-      k_attn_bwd_dkv<D, true><<<grid, 256, 0, s>>>(d_out, qkv, ld_qkv, lse, delta, ptr,            \
-                                                   tile_graph, tile_row0, n_work, N, H, scale,     \
-                                                   p_drop, seed, gps::dropout_salt(), d_qkv, ld_dqkv);                  \
-    } else {                                                                                       \
-      k_attn_bwd_dq<D, false><<<grid, 256, 0, s>>>(d_out, qkv, ld_qkv, out, lse, delta, ptr,       \
-                                                   tile_graph, tile_row0, n_work, N, H, scale,     \
-                                                   p_drop, seed, gps::dropout_salt(), d_qkv, ld_dqkv);                  \
-      k_attn_bwd_dkv<D, false><<<grid, 256, 0, s>>>(d_out, qkv, ld_qkv, lse, delta, ptr,           \
-                                                    tile_graph, tile_row0, n_work, N, H, scale,    \
-                                                    p_drop, seed, gps::dropout_salt(), d_qkv, ld_dqkv);                 \
-    }                                                                                              \
+#define X(D)                                                             \
+  case D:                                                                \
+    if (p_drop > 0.0f) {                                                 \
+      if (vec) LAUNCH_BWD(D, true, true); else LAUNCH_BWD(D, true, false);   \
+    } else {                                                             \
+      if (vec) LAUNCH_BWD(D, false, true); else LAUNCH_BWD(D, false, false); \
+    }                                                                    \
     break;
     GPS_FOR_EACH_DH(X)
 #undef X
   }
+#undef LAUNCH_BWD
   return gps::launch_status("gps_seg_attn_bwd");
 }
 
