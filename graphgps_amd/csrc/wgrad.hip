@@ -30,6 +30,34 @@
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// Exact 3-way split of 8 fp32 values into bf16 pieces (hi + mid + lo == v bit-for-bit: each piece
+// takes the next 8 significant bits by truncation, the remainders are exact fp32 subtractions),
+// packed as the bf16x8 operand of v_mfma_f32_32x32x16_bf16.  The product a*b is then formed from 6 of
+// the 9 piece products -- hh, hm, mh, hl, lh, mm; the dropped ml, lm, ll are below 2^-21 of |a||b| --
+// with fp32 accumulation, on the bf16 pipe that runs 16x the fp32-input MFMA rate.
+union Pack {
+  uint32_t u[4];
+  bf16x8 v;
+};
+__device__ __forceinline__ void split3(const float (&v)[8], Pack& hi, Pack& mid, Pack& lo) {
+  uint32_t h[8], m[8], l[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    h[j] = __float_as_uint(v[j]) & 0xFFFF0000u;
+    const float r1 = v[j] - __uint_as_float(h[j]);
+    m[j] = __float_as_uint(r1) & 0xFFFF0000u;
+    const float r2 = r1 - __uint_as_float(m[j]);
+    l[j] = __float_as_uint(r2) & 0xFFFF0000u;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    hi.u[q] = (h[2 * q] >> 16) | h[2 * q + 1];
+    mid.u[q] = (m[2 * q] >> 16) | m[2 * q + 1];
+    lo.u[q] = (l[2 * q] >> 16) | l[2 * q + 1];
+  }
+}
 constexpr int BM = 128, BN = 128, BK = 32;
 constexpr int NLD = BK / 8;   // float4 loads per thread per operand per chunk (256 threads x 4 floats = 8 rows)
 constexpr int kMaxGroup = 8;
@@ -52,7 +80,9 @@ struct Group {
   int n;
 };
 
-// One (tile, slice) work item of problem P.
+// One (tile, slice) work item of problem P.  SPLIT: contraction on the bf16 pipe via the exact
+// 3-way split above (default); otherwise on the fp32-input MFMA.
+template <bool SPLIT>
 __device__ __forceinline__ void wgrad_tile(const Problem& P, int tile, int slice, float (*As)[BK][BM],
                                            float (*Bs)[BK][BN]) {
   const float* __restrict__ g = P.g;
@@ -115,27 +145,61 @@ __device__ __forceinline__ void wgrad_tile(const Problem& P, int tile, int slice
   for (int64_t r0 = r_begin; r0 < r_end; r0 += BK) {
     const bool more = r0 + BK < r_end;
     if (more) load_chunk(r0 + BK);     // global loads in flight during the MFMAs below
-    // operands of step ks+1 are fetched from LDS into their own registers BEFORE the MFMAs of
-    // step ks issue (sched_barrier: the scheduler sinks the prefetch next to its use otherwise)
-    const float* ap = &As[buf][kh][wm * 64 + li];
-    const float* bp = &Bs[buf][kh][wn * 64 + li];
-    float a0 = ap[0], a1 = ap[32], b0 = bp[0], b1 = bp[32];
+    if constexpr (SPLIT) {
+      // lane (li, kh) owns rows 16*ks + 8*kh + j (j = 0..7) of the chunk for its column: any
+      // assignment of rows to the instruction's 16 k-slots is valid as long as A and B use the same
+      // one (a contraction index is order-free)
 #pragma unroll
-    for (int ks = 0; ks < BK / 2; ++ks) {
-      float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
-      if (ks + 1 < BK / 2) {
-        na0 = ap[(2 * ks + 2) * BM];
-        na1 = ap[(2 * ks + 2) * BM + 32];
-        nb0 = bp[(2 * ks + 2) * BN];
-        nb1 = bp[(2 * ks + 2) * BN + 32];
+      for (int ks = 0; ks < BK / 16; ++ks) {
+        const float* ap = &As[buf][16 * ks + 8 * kh][wm * 64 + li];
+        const float* bp = &Bs[buf][16 * ks + 8 * kh][wn * 64 + li];
+        float a0[8], a1[8], b0[8], b1[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          a0[j] = ap[j * BM];
+          a1[j] = ap[j * BM + 32];
+          b0[j] = bp[j * BN];
+          b1[j] = bp[j * BN + 32];
+        }
+        Pack A[2][3], B[2][3];
+        split3(a0, A[0][0], A[0][1], A[0][2]);
+        split3(a1, A[1][0], A[1][1], A[1][2]);
+        split3(b0, B[0][0], B[0][1], B[0][2]);
+        split3(b1, B[1][0], B[1][1], B[1][2]);
+        // smallest terms first; the four accumulators rotate so no MFMA waits on its predecessor
+        constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};
+#pragma unroll
+        for (int term = 0; term < 6; ++term)
+#pragma unroll
+          for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A[i][TA[term]].v, B[j][TB[term]].v,
+                                                                  acc[i][j], 0, 0, 0);
       }
-      __builtin_amdgcn_sched_barrier(0);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-      a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+    } else {
+    // operands of step ks+1 are fetched from LDS into their own registers BEFORE the MFMAs of
+      // step ks issue (sched_barrier: the scheduler sinks the prefetch next to its use otherwise)
+      const float* ap = &As[buf][kh][wm * 64 + li];
+      const float* bp = &Bs[buf][kh][wn * 64 + li];
+      float a0 = ap[0], a1 = ap[32], b0 = bp[0], b1 = bp[32];
+  #pragma unroll
+      for (int ks = 0; ks < BK / 2; ++ks) {
+        float na0 = 0.f, na1 = 0.f, nb0 = 0.f, nb1 = 0.f;
+        if (ks + 1 < BK / 2) {
+          na0 = ap[(2 * ks + 2) * BM];
+          na1 = ap[(2 * ks + 2) * BM + 32];
+          nb0 = bp[(2 * ks + 2) * BN];
+          nb1 = bp[(2 * ks + 2) * BN + 32];
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        a0 = na0; a1 = na1; b0 = nb0; b1 = nb1;
+      }
     }
     if (more) store_chunk(buf ^ 1, r0 + BK);
     __syncthreads();
@@ -172,6 +236,7 @@ __device__ __forceinline__ void wgrad_tile(const Problem& P, int tile, int slice
 // plain map: consecutive blocks = the tiles of one row slice.  (An XCD-grouped map -- all tiles
 // of a slice on one XCD for L2 reuse -- was measured 25-50 % SLOWER here: with ~250 workgroups
 // the uneven tiles-per-XCD split costs a second dispatch round on some XCDs.)
+template <bool SPLIT>
 __global__ __launch_bounds__(256) void k_wgrad(const Group G) {
   __shared__ __attribute__((aligned(16))) float As[2][BK][BM];
   __shared__ __attribute__((aligned(16))) float Bs[2][BK][BN];
@@ -184,7 +249,7 @@ __global__ __launch_bounds__(256) void k_wgrad(const Group G) {
   const int tiles = P.tiles_m * P.tiles_n;
   const int slice = local / tiles;
   if (slice >= P.S) return;
-  wgrad_tile(P, local - slice * tiles, slice, As, Bs);
+  wgrad_tile<SPLIT>(P, local - slice * tiles, slice, As, Bs);
 }
 
 // out[i] = sum_s part[s][i] in slice order (one float per thread: enough threads to pull the
@@ -284,7 +349,12 @@ int launch_group(Group& G, float* ws, hipStream_t s, const char* who) {
     p.out_begin = outs;
     outs += ((int64_t)p.M * p.Nn + 255) / 256 * 256;   // whole reduce blocks per problem
   }
-  k_wgrad<<<(unsigned)blocks, 256, 0, s>>>(G);
+  // GPS_WGRAD_FP32_MFMA=1 keeps the contraction on the fp32-input MFMA (v_mfma_f32_32x32x2_f32)
+  static const bool fp32_pipe = [] { const char* e = getenv("GPS_WGRAD_FP32_MFMA"); return e && atoi(e) != 0; }();
+  if (fp32_pipe)
+    k_wgrad<false><<<(unsigned)blocks, 256, 0, s>>>(G);
+  else
+    k_wgrad<true><<<(unsigned)blocks, 256, 0, s>>>(G);
   k_wgrad_reduce<<<gps::grid_for(outs, 256), 256, 0, s>>>(G);
   return gps::launch_status(who);
 }

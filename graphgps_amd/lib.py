@@ -50,6 +50,8 @@ _SIGNATURES = {
     "gps_wgrad": (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int, c_int, _P, _P, _P, _P]),
     "gps_optim_chunk": (c_int, []),
     "gps_adamw_step": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P]),
+    "gps_gemm_nt": (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int, c_int, _P, _P, c_int64, _P, c_int64,
+                            _P]),
     "gps_wgrad_grouped_workspace_floats": (c_size_t, [c_int, _P]),
     "gps_wgrad_grouped": (c_int, [c_int, _P, _P, _P]),
     "gps_block_norm_workspace_floats": (c_size_t, [c_int64, c_int64, c_int]),

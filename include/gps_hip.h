@@ -207,6 +207,18 @@ int gps_colsum(const float* x, int64_t R, int d, float* out, float* ws, gps_stre
 size_t gps_wgrad_workspace_floats(int64_t R, int M, int Nn);
 int gps_wgrad(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t R, int M, int Nn,
               float* gw, float* gb, float* ws, gps_stream_t stream);
+/* Dense projection, fp32 in / fp32 out:  C[R,M] = A[R,K] * B[M,K]^T (+ bias[M]) (+ Cin[R,M]).
+ * With B = an nn.Linear weight [out, in] this is y = x W^T + b (graphgps/layer/gatedgcn_layer.py:57-61,
+ * graphgps/layer/gps_layer.py:143-144,234-241,253-257); with B = W^T it is the input gradient g W, and Cin
+ * folds the residual accumulation of the backward into the epilogue (C may alias Cin).
+ * The contraction runs on the bf16 MFMA pipe through an EXACT 3-way bf16 split of both operands (6 of the
+ * 9 piece products, fp32 accumulate; every partial product is exact in fp32): same rounding model as an
+ * fp32-input MFMA GEMM, error vs fp64 at or below rocBLAS' fp32 GEMM (tests/test_hip_ops.py).
+ * K, lda, ldb multiples of 4; A, B 16-byte aligned. */
+int gps_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, int64_t R, int M, int K,
+                const float* bias, const float* Cin, int64_t ldcin, float* C, int64_t ldc,
+                gps_stream_t stream);
+
 /* Grouped form: up to 8 independent weight(+bias)-gradient problems -- the five of one GPS block:
  * merged A|B|D|E|in_proj, C, out_proj, ff_linear1, ff_linear2 -- in ONE launch + ONE reduce launch,
  * the row ranges split so that every workgroup gets an equal share of the whole list.

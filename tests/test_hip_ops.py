@@ -408,3 +408,60 @@ def test_wgrad_split_k(R, M, Nn):
     gw2 = torch.empty_like(gw)
     check(L.gps_wgrad(ptr(gd), M, ptr(xd), Nn, R, M, Nn, ptr(gw2), None, ptr(ws), current_stream(dev)))
     assert torch.equal(gw, gw2)     # deterministic, and the bias output is optional
+
+
+def test_wgrad_grouped_and_bf16_split_exactness():
+    """(1) The grouped launch returns, per problem, what the single-problem launch returns to fp32
+    rounding.  (2) The contraction runs on the bf16 pipe through an exact 3-way split: its error against
+    fp64 must not exceed that of an fp32 GEMM (torch.mm through rocBLAS) on the same data -- including
+    data with a large common offset, where a lossy (2-piece) split would show."""
+    from graphgps_amd import lib as L_
+    from graphgps_amd.lib import check, current_stream, ptr
+    L = L_.load()
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(5)
+    shapes = [(3001, 384, 2688), (4002, 384, 384), (3001, 768, 384)]          # (rows, in, out)
+    pairs = [((torch.randn(R, n, generator=gen) * 3 + 100.0).to(dev), (torch.randn(R, k, generator=gen) + 7.0).to(dev))
+             for R, k, n in shapes]
+    probs = (L_.WgradProblem * len(pairs))()
+    outs = []
+    for q, (g, x) in zip(probs, pairs):
+        gw, gb = torch.empty(g.shape[1], x.shape[1], device=dev), torch.empty(g.shape[1], device=dev)
+        q.g, q.x, q.gw, q.gb = g.data_ptr(), x.data_ptr(), gw.data_ptr(), gb.data_ptr()
+        q.ldg, q.ldx, q.R, q.M, q.Nn = g.stride(0), x.stride(0), g.shape[0], g.shape[1], x.shape[1]
+        outs.append((gw, gb))
+    ws = torch.empty(max(L.gps_wgrad_grouped_workspace_floats(len(pairs), probs), 4), device=dev)
+    check(L.gps_wgrad_grouped(len(pairs), probs, ptr(ws), current_stream(dev)), "gps_wgrad_grouped")
+    for (g, x), (gw, gb) in zip(pairs, outs):
+        ref = g.double().t() @ x.double()
+        scale = ref.abs().max()
+        err = ((gw.double() - ref).abs().max() / scale).item()
+        err_lib = ((g.t().mm(x).double() - ref).abs().max() / scale).item()
+        assert err <= max(1.5 * err_lib, 2e-6), (err, err_lib)
+        assert_close(gb, g.double().sum(0), Tol.GRAD_REL, "gb", rel_to_max=True)
+
+
+@pytest.mark.parametrize("R,K,M", [(7569, 384, 2688), (7569, 2688, 384), (15348, 384, 384), (1000, 52, 100),
+                                   (37, 64, 20), (129, 4, 130)])
+def test_gemm_nt_bf16_split(R, K, M):
+    """C = A B^T + bias + Cin on the bf16 pipe through the exact 3-way split (csrc/gemm_split.hip): error
+    against fp64 no larger than the fp32 library GEMM's; partial tiles, K tails, in-place residual."""
+    from graphgps_amd import lib as L_
+    from graphgps_amd.lib import check, current_stream, ptr
+    L = L_.load()
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(R * 7 + K)
+    a = (torch.randn(R, K, generator=gen) + 2.0).to(dev)
+    b = (torch.randn(M, K, generator=gen) / K ** 0.5).to(dev)
+    bias, cin = torch.randn(M, generator=gen).to(dev), torch.randn(R, M, generator=gen).to(dev)
+    ref = a.double() @ b.double().t() + bias.double() + cin.double()
+    out = cin.clone()                                      # C aliases Cin (residual accumulate in place)
+    check(L.gps_gemm_nt(ptr(a), K, ptr(b), K, R, M, K, ptr(bias), ptr(out), M, ptr(out), M,
+                        current_stream(dev)), "gps_gemm_nt")
+    scale = ref.abs().max()
+    err = ((out.double() - ref).abs().max() / scale).item()
+    err_lib = (((torch.addmm(bias, a, b.t()) + cin).double() - ref).abs().max() / scale).item()
+    assert err <= max(1.5 * err_lib, 2e-6), (err, err_lib)
+    plain = torch.empty(R, M, device=dev)
+    check(L.gps_gemm_nt(ptr(a), K, ptr(b), K, R, M, K, None, None, 0, ptr(plain), M, current_stream(dev)))
+    assert_close(plain, a.double() @ b.double().t(), Tol.GRAD_REL, "A B^T", rel_to_max=True)
