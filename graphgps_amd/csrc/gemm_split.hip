@@ -19,9 +19,13 @@
 // A/B fragments want (lane = row, 8 consecutive k), so nothing is ever transposed: 16-byte global loads
 // (8 lanes x 16 B = one 128-byte line per row), split once per workgroup while staging, pieces stored in
 // LDS as [piece][row][32 k] bf16 with an 80-byte row pitch (ds_read_b128 of 16 consecutive rows hits 16
-// distinct 16-byte slots), fragments fetched with one ds_read_b128 each.  128 x 128 tile, 4 waves of
-// 64 x 64 (2 x 2 accumulators of 32 x 32), single LDS buffer + register prefetch of the next chunk so two
-// workgroups fit a CU and one's split/stage phase hides under the other's MFMAs.
+// distinct 16-byte slots), fragments fetched with one ds_read_b128 each.  128 x 128 tile; 8 waves:
+// 4 consumers of 64 x 64 (2 x 2 accumulators of 32 x 32) + 4 producers (loads, split, LDS stores) working
+// one chunk ahead in the other LDS buffer.
+// Status: parity-tested, NOT on the measured path -- at the block's shapes it matches, not beats, the
+// TunableOp-selected library kernels: the 3-piece fragments cost 6 B of LDS read per element per use against
+// 32-cycle MFMAs (64 B/clk/CU of the LDS' 128 before bank conflicts), i.e. the kernel is co-limited by LDS
+// bandwidth and the split's VALU work, not by the MFMA pipe.
 #include "gps_common.hpp"
 
 namespace {
@@ -68,9 +72,16 @@ struct GemmArgs {
   int M, K, tiles_m, tiles_n;
 };
 
-__global__ __launch_bounds__(256, 2) void k_gemm_nt(const GemmArgs G) {
-  // [operand][piece][row][PITCH] bf16
-  __shared__ __attribute__((aligned(16))) uint16_t lds[2][3][TM][PITCH];
+// Wave-specialised: waves 0-3 multiply (pure ds_read_b128 + MFMA stream), waves 4-7 produce (global loads,
+// exact bf16 split, LDS stores) into the other LDS buffer; each SIMD hosts one of each, so the split's VALU
+// work runs under the other wave's MFMAs instead of in a phase of its own.  One barrier per chunk.
+constexpr int kLdsBuf = 2 * 3 * TM * PITCH;   // uint16 elements per buffer (A + B, 3 pieces)
+
+__global__ __launch_bounds__(512) void k_gemm_nt(const GemmArgs G) {
+  extern __shared__ __attribute__((aligned(16))) uint16_t lds_raw[];   // [2 buffers][operand][piece][row][PITCH]
+  auto L = [&](int buf, int op, int pc, int row, int k) -> uint16_t* {
+    return lds_raw + (size_t)buf * kLdsBuf + ((size_t)(op * 3 + pc) * TM + row) * PITCH + k;
+  };
   // XCD-aware tile order: the 8 XCDs take workgroups round-robin, so give each XCD a contiguous run
   // of tiles (same A row-tile, consecutive B column tiles -> the A tile is re-read from that XCD's L2)
   const int ntiles = G.tiles_m * G.tiles_n;
@@ -80,26 +91,75 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const GemmArgs G) {
   const int tm = tile / G.tiles_n, tn = tile - tm * G.tiles_n;
   const int64_t r0 = (int64_t)tm * TM;
   const int m0 = tn * TN;
-  const int t = threadIdx.x;
+  const int K = G.K;
+  const int nchunks = (K + BK - 1) / BK;
+  const bool producer = threadIdx.x >= 256;
+  const int t = threadIdx.x & 255;
+
+  if (producer) {
+    // staging: thread -> (row = t/8 + 32*pass, k-quad = t%8)
+    const int srow = t >> 3, skq = (t & 7) * 4;
+    const float* ap[NPASS];
+    const float* bp[NPASS];
+    bool a_ok[NPASS], b_ok[NPASS];
+#pragma unroll
+    for (int p = 0; p < NPASS; ++p) {
+      const int64_t ra = r0 + srow + 32 * p;
+      const int rb = m0 + srow + 32 * p;
+      a_ok[p] = ra < G.R;
+      b_ok[p] = rb < G.M;
+      ap[p] = G.A + (a_ok[p] ? ra : G.R - 1) * G.lda;
+      bp[p] = G.B + (int64_t)(b_ok[p] ? rb : G.M - 1) * G.ldb;
+    }
+    float4 ra0[NPASS], rb0[NPASS], ra1[NPASS], rb1[NPASS];
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto load_chunk = [&](int c, float4 (&ra)[NPASS], float4 (&rb)[NPASS]) {
+      // raw loads only; a k-quad past K reads quad 0 and is zeroed at split time
+      const int kk = (c * BK + skq < K) ? c * BK + skq : 0;
+#pragma unroll
+      for (int p = 0; p < NPASS; ++p) {
+        ra[p] = *reinterpret_cast<const float4*>(ap[p] + kk);
+        rb[p] = *reinterpret_cast<const float4*>(bp[p] + kk);
+      }
+    };
+    auto store_chunk = [&](int c, int buf, const float4 (&ra)[NPASS], const float4 (&rb)[NPASS]) {
+      const bool k_ok = c * BK + skq < K;
+#pragma unroll
+      for (int p = 0; p < NPASS; ++p) {
+        uint2 h, m, l;
+        const int row = srow + 32 * p;
+        split4((a_ok[p] && k_ok) ? ra[p] : zero4, h, m, l);
+        *reinterpret_cast<uint2*>(L(buf, 0, 0, row, skq)) = h;
+        *reinterpret_cast<uint2*>(L(buf, 0, 1, row, skq)) = m;
+        *reinterpret_cast<uint2*>(L(buf, 0, 2, row, skq)) = l;
+        split4((b_ok[p] && k_ok) ? rb[p] : zero4, h, m, l);
+        *reinterpret_cast<uint2*>(L(buf, 1, 0, row, skq)) = h;
+        *reinterpret_cast<uint2*>(L(buf, 1, 1, row, skq)) = m;
+        *reinterpret_cast<uint2*>(L(buf, 1, 2, row, skq)) = l;
+      }
+    };
+    load_chunk(0, ra0, rb0);
+    if (nchunks > 1) load_chunk(1, ra1, rb1);
+    store_chunk(0, 0, ra0, rb0);
+    __syncthreads();                                   // buffer 0 ready
+    for (int c = 0; c < nchunks; c += 2) {
+      // consumers multiply chunk c (buffer 0): stage chunk c+1 into buffer 1, fetch chunk c+2
+      if (c + 2 < nchunks) load_chunk(c + 2, ra0, rb0);
+      if (c + 1 < nchunks) store_chunk(c + 1, 1, ra1, rb1);
+      __syncthreads();
+      if (c + 1 >= nchunks) break;
+      // consumers multiply chunk c+1 (buffer 1): stage chunk c+2 into buffer 0, fetch chunk c+3
+      if (c + 3 < nchunks) load_chunk(c + 3, ra1, rb1);
+      if (c + 2 < nchunks) store_chunk(c + 2, 0, ra0, rb0);
+      __syncthreads();
+    }
+    return;
+  }
+
+  // ---- consumers --------------------------------------------------------------------------------
   const int lane = t & 63, wave = t >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, kh = lane >> 5;
-  const int K = G.K;
-
-  // staging: thread -> (row = t/8 + 32*pass, k-quad = t%8)
-  const int srow = t >> 3, skq = (t & 7) * 4;
-  const float* ap[NPASS];
-  const float* bp[NPASS];
-  bool a_ok[NPASS], b_ok[NPASS];
-#pragma unroll
-  for (int p = 0; p < NPASS; ++p) {
-    const int64_t ra = r0 + srow + 32 * p;
-    const int rb = m0 + srow + 32 * p;
-    a_ok[p] = ra < G.R;
-    b_ok[p] = rb < G.M;
-    ap[p] = G.A + (a_ok[p] ? ra : G.R - 1) * G.lda;
-    bp[p] = G.B + (int64_t)(b_ok[p] ? rb : G.M - 1) * G.ldb;
-  }
   f32x16 acc[2][2];
 #pragma unroll
   for (int i = 0; i < 2; ++i)
@@ -107,44 +167,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const GemmArgs G) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.0f;
-
-  // Per chunk (one LDS buffer, so two workgroups fit a CU and one's split/stage phase overlaps the
-  // other's MFMAs): split + stage the chunk whose loads were issued a phase ago -> barrier -> issue the
-  // next chunk's loads -> MFMAs -> barrier.  (Measured alternatives that did NOT pay on MI355X: a
-  // two-deep register prefetch -- same time, the kernel is not latency-bound -- and interleaving the
-  // split between the MFMAs of the previous chunk -- needs > 256 registers per lane, spills.)
-  float4 ra[NPASS], rb[NPASS];
-  const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-  auto load_chunk = [&](int k0) {     // raw loads only; a k-quad past K reads quad 0 and is zeroed at store time
-    const int kk = (k0 + skq < K) ? k0 + skq : 0;
-#pragma unroll
-    for (int p = 0; p < NPASS; ++p) {
-      ra[p] = *reinterpret_cast<const float4*>(ap[p] + kk);
-      rb[p] = *reinterpret_cast<const float4*>(bp[p] + kk);
-    }
-  };
-  auto store_chunk = [&](int k0) {
-    const bool k_ok = k0 + skq < K;
-#pragma unroll
-    for (int p = 0; p < NPASS; ++p) {
-      uint2 h, m, l;
-      split4((a_ok[p] && k_ok) ? ra[p] : zero4, h, m, l);
-      const int row = srow + 32 * p;
-      *reinterpret_cast<uint2*>(&lds[0][0][row][skq]) = h;
-      *reinterpret_cast<uint2*>(&lds[0][1][row][skq]) = m;
-      *reinterpret_cast<uint2*>(&lds[0][2][row][skq]) = l;
-      split4((b_ok[p] && k_ok) ? rb[p] : zero4, h, m, l);
-      *reinterpret_cast<uint2*>(&lds[1][0][row][skq]) = h;
-      *reinterpret_cast<uint2*>(&lds[1][1][row][skq]) = m;
-      *reinterpret_cast<uint2*>(&lds[1][2][row][skq]) = l;
-    }
-  };
-
-  load_chunk(0);
-  for (int k0 = 0; k0 < K; k0 += BK) {
-    store_chunk(k0);
-    __syncthreads();
-    if (k0 + BK < K) load_chunk(k0 + BK);  // in flight during the MFMAs below
+  auto multiply = [&](int buf) {
 #pragma unroll
     for (int ks = 0; ks < BK / 16; ++ks) {
       Frag A[2][3], B[2][3];
@@ -152,8 +175,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const GemmArgs G) {
       for (int pc = 0; pc < 3; ++pc)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-          const uint4 a = *reinterpret_cast<const uint4*>(&lds[0][pc][wm * 64 + i * 32 + li][16 * ks + 8 * kh]);
-          const uint4 b = *reinterpret_cast<const uint4*>(&lds[1][pc][wn * 64 + i * 32 + li][16 * ks + 8 * kh]);
+          const uint4 a = *reinterpret_cast<const uint4*>(L(buf, 0, pc, wm * 64 + i * 32 + li, 16 * ks + 8 * kh));
+          const uint4 b = *reinterpret_cast<const uint4*>(L(buf, 1, pc, wn * 64 + i * 32 + li, 16 * ks + 8 * kh));
           A[i][pc].u[0] = a.x; A[i][pc].u[1] = a.y; A[i][pc].u[2] = a.z; A[i][pc].u[3] = a.w;
           B[i][pc].u[0] = b.x; B[i][pc].u[1] = b.y; B[i][pc].u[2] = b.z; B[i][pc].u[3] = b.w;
         }
@@ -171,7 +194,14 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt(const GemmArgs G) {
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i][j], 0, 0, 0);
           }
     }
-    __syncthreads();                       // all fragment reads done before the next store_chunk
+  };
+  __syncthreads();                                     // buffer 0 ready
+  for (int c = 0; c < nchunks; c += 2) {
+    multiply(0);
+    __syncthreads();
+    if (c + 1 >= nchunks) break;
+    multiply(1);
+    __syncthreads();
   }
 
   // epilogue: D[row = (q&3) + 8*(q>>2) + 4*(lane>>5)][col = lane&31]  (+ bias, + Cin)
@@ -216,7 +246,12 @@ int gps_gemm_nt(const float* A, int64_t lda, const float* B, int64_t ldb, int64_
   G.tiles_n = (M + TN - 1) / TN;
   const int ntiles = G.tiles_m * G.tiles_n;
   const int per_xcd = (ntiles + 7) / 8;
-  k_gemm_nt<<<(unsigned)(per_xcd * 8), 256, 0, gps::as_stream(stream)>>>(G);
+  constexpr size_t lds_bytes = 2 * (size_t)kLdsBuf * sizeof(uint16_t);     // 120 KB of the CU's 160 KB
+  static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_nt),
+                                                     hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     (int)lds_bytes);
+  GPS_REQUIRE(attr == hipSuccess, "gps_gemm_nt: cannot reserve %zu bytes of LDS", lds_bytes);
+  k_gemm_nt<<<(unsigned)(per_xcd * 8), 512, lds_bytes, gps::as_stream(stream)>>>(G);
   return gps::launch_status("gps_gemm_nt");
 }
 
