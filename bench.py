@@ -59,8 +59,12 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--graphs-per-gpu", type=int, default=256)
-    ap.add_argument("--profile", default="P30", help="synthetic size profile (P30 | P14)")
+    ap.add_argument("--graphs-per-gpu", type=int, default=0, help="0 = the config's train.batch_size")
+    ap.add_argument("--profile", default=None, help="synthetic size profile (pcqm4m: P30 | P14)")
+    ap.add_argument("--workload", choices=("pcqm4m", "zinc", "code2"), default="pcqm4m",
+                    help="pcqm4m = the BASELINE.json metric (default).  zinc (GINE+Transformer, 10L x 64d, "
+                         "32 graphs) and code2 (CustomGatedGCN+Performer, 4L x 256d, 32 graphs of 600-1000 "
+                         "nodes) are the other BASELINE configs: extra measurements, not the headline")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--launch", choices=("auto", "graph", "eager"), default="auto",
                     help="how the step is launched: replayed from hipGraph(s), eagerly, or (auto) "
@@ -259,18 +263,30 @@ def main():
 
     import graphgps_amd as g
     from graphgps_amd.dp import GradBucketReducer
-    from graphgps_amd.loss.losses import compute_loss
+    from graphgps_amd.loss.losses import compute_loss, subtoken_cross_entropy
     from graphgps_amd.synthetic import model_batch
 
     tunable = None
     if not args.no_gemm_tuning:                # rocBLAS/hipBLASLt solution selection per GEMM shape,
         tunable = g.enable_gemm_tuning()       # timed at first use during the untimed warm-up
     torch.manual_seed(0)                       # identical initial weights on every rank
-    model = g.create_model(os.path.join(g.CONFIG_DIR, "pcqm4m_gpsmedium_rwse.yaml"), None, 9, 1)
+    WORKLOADS = {   # yaml, dim_in, dim_out, default graphs/GPU (the config's train.batch_size), label
+        "pcqm4m": ("pcqm4m_gpsmedium_rwse.yaml", 9, 1, 256,
+                   "pcqm4m-GPSmedium+RWSE (CustomGatedGCN+Transformer, 10L x 384d, 16 heads, dropout 0.1/0.1)"),
+        "zinc": ("zinc_gps_rwse.yaml", 1, 1, 32, "zinc-GPS+RWSE (GINE+Transformer, 10L x 64d, 4 heads)"),
+        "code2": ("code2_gps.yaml", 2, 5002, 32,
+                  "ogbg-code2-GPS (CustomGatedGCN+Performer, 4L x 256d, 4 heads x 64, m=266)"),
+    }
+    yaml_name, dim_in, dim_out, default_nb, wl_label = WORKLOADS[args.workload]
+    model = g.create_model(os.path.join(g.CONFIG_DIR, yaml_name), None, dim_in, dim_out)
     cfg = g.cfg
     model.train()
-    nb = args.graphs_per_gpu
-    batch_cpu = model_batch("pcqm4m", nb, seed=1234 + rank, profile=args.profile)
+    if args.workload == "code2":
+        compute_loss = subtoken_cross_entropy       # custom_train.py:24-25
+    nb = args.graphs_per_gpu or default_nb
+    if args.workload != "pcqm4m":
+        args.no_kernel_roofline = True              # the kernel table is the PCQM4M layer shape
+    batch_cpu = model_batch(args.workload, nb, seed=1234 + rank, profile=args.profile)
     cpu_ref_model = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         import copy
@@ -389,13 +405,15 @@ def main():
     if rank == 0:
         N, E = batch_dev.x.shape[0], batch_dev.edge_index.shape[1]
         out = {
-            "metric": "graphs/sec, PCQM4M GPS-medium training step (fwd+bwd+optimizer)",
+            "metric": ("graphs/sec, PCQM4M GPS-medium training step (fwd+bwd+optimizer)"
+                       if args.workload == "pcqm4m" else
+                       f"graphs/sec, {args.workload} GPS training step (fwd+bwd+optimizer)"),
             "value": world * nb / (ms / 1e3), "unit": "graphs/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "config": {"workload": f"pcqm4m-GPSmedium+RWSE (CustomGatedGCN+Transformer, 10L x 384d, "
-                                   f"16 heads, dropout 0.1/0.1), synthetic profile {args.profile}, "
+            "config": {"workload": f"{wl_label}, synthetic profile "
+                                   f"{args.profile or {'pcqm4m': 'P30', 'zinc': 'ZINC', 'code2': 'CODE2_LONG'}[args.workload]}, "
                                    f"{nb} graphs/GPU ({N} nodes, {E} directed edges on rank 0)",
                        "global_batch": world * nb, "parallelism": f"dp{world}",
                        "timed_region": "graph-index build + forward + L1 loss + backward + "
@@ -410,7 +428,7 @@ def main():
                               if tunable is not None else "library default heuristics",
         }
         if not args.no_kernel_roofline:
-            kr, shape = kernel_rooflines(dev, args.profile, nb)
+            kr, shape = kernel_rooflines(dev, args.profile or "P30", nb)
             log("kernel rooflines done")
             k = kr["gatedgcn_fwd"]
             traffic = None
