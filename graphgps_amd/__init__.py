@@ -47,5 +47,7 @@ def enable_gemm_tuning(filename=None, max_ms_per_solution=30):
     t.enable(True)
     t.tuning_enable(True)
     t.set_max_tuning_duration(int(max_ms_per_solution))
-    t.set_filename(filename or _os.path.join(tempfile.gettempdir(), "graphgps_amd_tunableop.csv"))
+    # one results file per process: ranks of a data-parallel job tune (and write) independently
+    rank = _os.environ.get("LOCAL_RANK", _os.environ.get("RANK", "0"))
+    t.set_filename(filename or _os.path.join(tempfile.gettempdir(), f"graphgps_amd_tunableop_r{rank}.csv"))
     return t
