@@ -292,11 +292,15 @@ inline void plan_slices(Problem& p, int64_t chunks_per_block) {
   p.S = (int)((p.R + rps - 1) / rps);
 }
 
-// Smallest chunks-per-workgroup for which the whole list fits in ONE dispatch round: kTargetBlocks =
-// 2 workgroups per CU (64 KB LDS and 140 registers each -> two are co-resident, and one's MFMAs fill
-// the other's chunk-boundary bubble: measured 93 -> 107 TFLOP/s on the grouped block list vs one per
-// CU); one workgroup more would cost a second round.  GPS_WGRAD_TARGET_BLOCKS overrides (tuning).
-static const int kTargetBlocks = [] { const char* e = getenv("GPS_WGRAD_TARGET_BLOCKS"); return e ? atoi(e) : 512; }();
+// Smallest chunks-per-workgroup for which the whole list fits in ONE dispatch round of kTargetBlocks
+// workgroups (one more would cost a second round).  One workgroup per CU: standalone, two per CU are
+// faster (one's MFMAs fill the other's chunk-boundary bubble: 291 vs 335 us on the fp32-input path), but
+// this kernel runs on the weight-gradient stream NEXT TO the main stream's backward kernels, and two
+// workgroups per CU take every vector register of the chip (2 x 248 per lane), locking those kernels out
+// until it drains; with one per CU the HBM-bound norm / attention / GatedGCN kernels co-run with it.
+// Measured in the training step, same box: 13.60 ms (512 workgroups) vs 13.14-13.33 ms (256).
+// GPS_WGRAD_TARGET_BLOCKS overrides (tuning).
+static const int kTargetBlocks = [] { const char* e = getenv("GPS_WGRAD_TARGET_BLOCKS"); return e ? atoi(e) : 256; }();
 inline int64_t balanced_chunks(const int64_t* R, const int* M, const int* Nn, int n) {
   int64_t work = 0, tiles_total = 0;
   for (int i = 0; i < n; ++i) {
