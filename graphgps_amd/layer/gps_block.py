@@ -137,6 +137,52 @@ def _grouped_param_grads(L, pairs):
 
 _GROUPED_WGRAD = _os.environ.get("GPS_WGRAD_GROUPED", "1") != "0"
 
+# The attention half (attention core + out-projection GEMM) and the local half (C GEMM + GatedGCN) of a
+# block only meet at the norm stage, so the attention half can run on its own HIP stream: its latency-bound
+# kernels fill the gaps of the local half's HBM/MFMA-bound ones.  Under hipGraph replay this is a fork/join
+# in the graph (no host cost; measured 13.18 -> 13.00 ms/step); launched eagerly the extra stream switches
+# cost more host time than the overlap returns (13.3 -> 13.7..16.7 ms), so the fork is only taken while
+# the step is being CAPTURED.  GPS_BRANCH_STREAM=0 disables it, =2 forces it in eager mode too.
+_BRANCH = _os.environ.get("GPS_BRANCH_STREAM", "1")
+_branch_streams = {}
+
+
+def _branch_stream(dev):
+    st = _branch_streams.get(dev.index)
+    if st is None:
+        st = _branch_streams[dev.index] = torch.cuda.Stream(device=dev)
+    return st
+
+
+class _Fork:
+    """``with _Fork(dev) as f:`` runs the body on the branch stream after the current stream's work so
+    far; ``f.join(*tensors)`` makes the current stream wait for it (tensors allocated inside are handed
+    over to the current stream's allocator bookkeeping)."""
+
+    def __init__(self, dev, mode):
+        self.dev = dev
+        self.enabled = mode == "2" or (mode == "1" and torch.cuda.is_current_stream_capturing())
+
+    def __enter__(self):
+        if self.enabled:
+            self.cur = torch.cuda.current_stream(self.dev)
+            self.br = _branch_stream(self.dev)
+            self.br.wait_stream(self.cur)
+            self.ctx = torch.cuda.stream(self.br)
+            self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.enabled:
+            self.ctx.__exit__(*exc)
+        return False
+
+    def join(self, *tensors):
+        if self.enabled:
+            self.cur.wait_stream(self.br)
+            for t in tensors:
+                t.record_stream(self.cur)
+
 
 def _bn_desc(bn, mean, rstd):
     """``gps_bn`` descriptor of a BatchNorm1d + the [d] buffers holding its batch statistics."""
@@ -174,19 +220,23 @@ class _GPSBlock(torch.autograd.Function):
         pq = torch.addmm(bcat, x, wcat.t())                     # [N, 4d + 3d]
         ldp = 7 * d
         P, fs = pq.data_ptr(), d * 4
+        # -- global branch (forked): varlen attention over the PRE-layer x (gps_layer.py:199-201,234-241)
+        with _Fork(dev, _BRANCH) as fork:
+            sb = current_stream(dev)
+            o, lse = _E(N, d, **f32), _E(H, N, **f32)
+            scale = float(dh) ** -0.5
+            check(L.gps_seg_attn_fwd(P + 4 * fs, ldp, ptr(gi.ptr), ptr(gi.tile_graph), ptr(gi.tile_row0),
+                                     gi.max_tiles, N, H, dh, scale, p_at, s[2], ptr(o), ptr(lse), sb),
+                  "gps_seg_attn_fwd")
+            ao = torch.addmm(sa.out_proj.bias, o, sa.out_proj.weight.t())
+        # -- local branch: C projection + GatedGCN core ----------------------------------------
         ce = torch.addmm(lm.C.bias, e, lm.C.weight.t())
         xt, eh = _E(N, d, **f32), _E(E, d, **f32)
         aggr, den = _E(N, d, **f32), _E(N, d, **f32)
         check(L.gps_gatedgcn_fwd(P, P + fs, P + 2 * fs, P + 3 * fs, ldp, ptr(ce), ptr(gi.rowptr_dst),
                                  ptr(gi.src_by_dst), ptr(gi.eid_by_dst), N, E, d, ptr(xt), ptr(eh),
                                  ptr(aggr), ptr(den), st), "gps_gatedgcn_fwd")
-        # -- global branch: varlen attention over the PRE-layer x (gps_layer.py:199-201,234-241)
-        o, lse = _E(N, d, **f32), _E(H, N, **f32)
-        scale = float(dh) ** -0.5
-        check(L.gps_seg_attn_fwd(P + 4 * fs, ldp, ptr(gi.ptr), ptr(gi.tile_graph), ptr(gi.tile_row0),
-                                 gi.max_tiles, N, H, dh, scale, p_at, s[2], ptr(o), ptr(lse), st),
-              "gps_seg_attn_fwd")
-        ao = torch.addmm(sa.out_proj.bias, o, sa.out_proj.weight.t())
+        fork.join(o, lse, ao)
 
         # -- the five BatchNorms, residuals and dropouts as task lists (csrc/block_norm.hip) -------
         stats = _E(10, d, **f32)                                # (mean, rstd) x 5
@@ -265,16 +315,19 @@ class _GPSBlock(torch.autograd.Function):
         check(L.gps_bn_dual_bwd(ptr(x1), ref(bnl), ptr(za), ref(bna), ptr(g_h), N, d, ptr(g_x1),
                                 ptr(g_xres), p_l, s[3], ptr(g_ao), ptr(g_nlw), ptr(g_nlb), ptr(g_naw),
                                 ptr(g_nab), ptr(ws), st), "gps_bn_dual_bwd")
-        g_o = g_ao.mm(sa.out_proj.weight)
         # gradient of the merged projection: attention writes dq|dk|dv into columns 4d.., GatedGCN
         # writes g_Ax|g_Bx|g_Dx|g_Ex into columns 0..4d of ONE [N,7d] buffer -> one dgrad, one wgrad
         ldp = 7 * d
         fs = d * 4
-        g_pq, delta = _E(N, ldp, **f32), _E(H, N, **f32)
+        g_pq = _E(N, ldp, **f32)
         G, P = g_pq.data_ptr(), pq.data_ptr()
-        check(L.gps_seg_attn_bwd(ptr(g_o), P + 4 * fs, ldp, ptr(o), ptr(lse), ptr(gi.ptr),
-                                 ptr(gi.tile_graph), ptr(gi.tile_row0), gi.max_tiles, N, H, dh, scale,
-                                 p_at, s[2], ptr(delta), G + 4 * fs, ldp, st), "gps_seg_attn_bwd")
+        with _Fork(dev, _BRANCH) as fork:            # attention half of the backward
+            sb = current_stream(dev)
+            g_o = g_ao.mm(sa.out_proj.weight)
+            delta = _E(H, N, **f32)
+            check(L.gps_seg_attn_bwd(ptr(g_o), P + 4 * fs, ldp, ptr(o), ptr(lse), ptr(gi.ptr),
+                                     ptr(gi.tile_graph), ptr(gi.tile_row0), gi.max_tiles, N, H, dh, scale,
+                                     p_at, s[2], ptr(delta), G + 4 * fs, ldp, sb), "gps_seg_attn_bwd")
 
         # x1 = x + drop(relu(BN_x(xt)));  e1 = e + drop(relu(BN_e(eh))):  both BN backwards as one list
         g_xt, g_eh = _E(N, d, **f32), _E(E, d, **f32)
@@ -287,6 +340,7 @@ class _GPSBlock(torch.autograd.Function):
                                  ptr(gi.rowptr_src), ptr(gi.dst_by_src), ptr(gi.eid_by_src), N, E, d,
                                  ptr(g_ce), G, G + fs, G + 2 * fs, G + 3 * fs, ldp, st),
               "gps_gatedgcn_bwd")
+        fork.join()
         wcat, _ = layer._xgroup._stacked()
         pairs = [(g_pq, x), (g_ce, e), (g_ao, o), (g_f1, h), (g_f2, t)]
         if _GROUPED_WGRAD:
