@@ -264,3 +264,73 @@ def test_custom_gnn_vs_oracle(layer_type, residual):
         assert_close(p.grad, op[k].grad, 1e-3, f"grad {k}", rel_to_max=True)
         checked += 1
     assert checked > 20
+
+
+def _ragged_batch(sizes, d, seed, isolated=()):
+    """Graphs of the given sizes: random tree + a chord each way, both directions adjacent (OGB order);
+    graphs listed in ``isolated`` get no edges at all (isolated nodes: empty CSR segments)."""
+    from graphgps_amd.data import Batch
+    gen = torch.Generator().manual_seed(seed)
+    src, dst, ptr = [], [], [0]
+    for gi, n in enumerate(sizes):
+        base = ptr[-1]
+        if gi not in isolated:
+            for v in range(1, n):
+                u = int(torch.randint(max(0, v - 4), v, (1,), generator=gen))
+                src += [base + u, base + v]
+                dst += [base + v, base + u]
+            if n > 5:
+                a, b = 0, n - 1
+                src += [base + a, base + b]
+                dst += [base + b, base + a]
+        ptr.append(base + n)
+    N = ptr[-1]
+    ei = torch.tensor([src, dst], dtype=torch.int64)
+    batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
+    b = Batch(x=torch.randn(N, d, generator=gen), edge_index=ei,
+              edge_attr=torch.randn(ei.shape[1], d, generator=gen), batch=batch,
+              ptr=torch.tensor(ptr, dtype=torch.int64))
+    b.num_graphs = len(sizes)
+    return b
+
+
+@pytest.mark.parametrize("local,glob,d,H", [("CustomGatedGCN", "Transformer", 32, 4),    # block path
+                                            ("GINE", "Transformer", 48, 2),              # operator path
+                                            ("CustomGatedGCN", "Performer", 64, 1)])
+def test_gpslayer_ragged_and_boundary_graph_sizes(local, glob, d, H):
+    """Graph sizes straddling every tile boundary of the kernels (1, 2, 15..17, 31..33, 63..65, 129),
+    single-node graphs, a graph made of isolated nodes, the last graph ending exactly at N: outputs and
+    gradients of one training-mode layer vs the oracle."""
+    from graphgps_amd.layer.gps_layer import GPSLayer
+    sizes = [1, 17, 2, 16, 33, 1, 15, 64, 31, 65, 32, 63, 129, 5, 1]
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    layer = GPSLayer(d, local, glob, H, dropout=0.0, attn_dropout=0.0)
+    oracle = _oracle_layer_like(layer).train()
+    layer.to(dev).train()
+    b = _ragged_batch(sizes, d, seed=9, isolated=(13,))
+    gen = torch.Generator().manual_seed(6)
+    wx, we = torch.randn(b.x.shape, generator=gen), torch.randn(b.edge_attr.shape, generator=gen)
+    bc = b.clone()
+    bc.x.requires_grad_(True); bc.edge_attr.requires_grad_(True)
+    xo, eo = bc.x, bc.edge_attr
+    oo = oracle(bc)
+    loss_o = (oo.x * wx).sum() + ((oo.edge_attr * we).sum() if local == "CustomGatedGCN" else 0.0)
+    loss_o.backward()
+    bg = b.clone().to(dev)
+    bg.x.requires_grad_(True); bg.edge_attr.requires_grad_(True)
+    xg, eg = bg.x, bg.edge_attr
+    og = layer(bg)
+    loss_g = (og.x * wx.to(dev)).sum() + ((og.edge_attr * we.to(dev)).sum() if local == "CustomGatedGCN" else 0.0)
+    loss_g.backward()
+    assert_close(og.x, oo.x, Tol.ACT, "out.x")
+    assert_close(og.edge_attr, oo.edge_attr, Tol.ACT, "out.edge_attr")
+    assert_close(xg.grad, xo.grad, Tol.GRAD_REL, "grad x", rel_to_max=True)
+    assert_close(eg.grad, eo.grad, Tol.GRAD_REL, "grad edge_attr", rel_to_max=True)
+    op = dict(oracle.named_parameters())
+    gscale = max(float(q.grad.abs().max()) for q in op.values() if q.grad is not None)
+    for k, p in layer.named_parameters():
+        if op[k].grad is None:
+            continue
+        diff = (p.grad.detach().cpu().double() - op[k].grad.double()).abs().max().item()
+        assert diff <= 1e-4 * max(float(op[k].grad.abs().max()), 0.01 * gscale, 1.0), f"grad {k}: {diff:.3e}"
