@@ -52,29 +52,6 @@ __global__ __launch_bounds__(256) void k_pool_bwd(const float* __restrict__ g_ou
   v.store(g_x + n * (int64_t)d + c);
 }
 
-// out[s] = sum over k in [rowptr[s], rowptr[s+1]) of x[idx[k]]  (rows gathered through idx; segments may be
-// empty -> zero row).  The weight gradient of an embedding lookup once the lookups are grouped by token
-// (stable CSR from gps_graph_index_build): deterministic, no atomics, no sort of the gradient rows.
-template <int VEC>
-__global__ __launch_bounds__(256) void k_gather_segment_sum(const float* __restrict__ x,
-                                                            const int32_t* __restrict__ rowptr,
-                                                            const int32_t* __restrict__ idx, int64_t S,
-                                                            int d, float* __restrict__ out) {
-  const int lanes_per_row = d / VEC;
-  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  const int64_t s = t / lanes_per_row;
-  if (s >= S) return;
-  const int c = (int)(t - s * lanes_per_row) * VEC;
-  const int k0 = rowptr[s], k1 = rowptr[s + 1];
-  Vec<VEC> acc = Vec<VEC>::zero();
-  for (int k = k0; k < k1; ++k) {
-    const Vec<VEC> v = Vec<VEC>::load(x + (int64_t)idx[k] * d + c);
-#pragma unroll
-    for (int j = 0; j < VEC; ++j) acc[j] += v[j];
-  }
-  acc.store(out + s * (int64_t)d + c);
-}
-
 __global__ void k_node_graph(const int32_t* __restrict__ ptr, int64_t B, int32_t* __restrict__ node_graph) {
   const int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (g >= B) return;
@@ -89,21 +66,6 @@ int gps_node_graph_from_ptr(const int32_t* ptr, int64_t B, int32_t* node_graph, 
   GPS_REQUIRE(ptr && B >= 0 && (node_graph || B == 0), "gps_node_graph_from_ptr: bad arguments");
   if (B > 0) k_node_graph<<<gps::grid_for(B, 256), 256, 0, gps::as_stream(stream)>>>(ptr, B, node_graph);
   return gps::launch_status("gps_node_graph_from_ptr");
-}
-
-int gps_gather_segment_sum(const float* x, const int32_t* rowptr, const int32_t* idx, int64_t S, int d,
-                           float* out, gps_stream_t stream) {
-  GPS_REQUIRE(S >= 0 && d > 0, "gps_gather_segment_sum: bad sizes");
-  if (S == 0) return GPS_OK;
-  GPS_REQUIRE(x && rowptr && idx && out, "gps_gather_segment_sum: null buffer");
-  hipStream_t s = gps::as_stream(stream);
-  const bool a16 = ((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 16 == 0);
-  const bool a8 = ((uintptr_t)x % 8 == 0) && ((uintptr_t)out % 8 == 0);
-  GPS_DISPATCH_VEC(d, a16, a8, {
-    k_gather_segment_sum<VEC><<<gps::grid_for(S * (int64_t)(d / VEC), 256), 256, 0, s>>>(x, rowptr, idx, S, d,
-                                                                                      out);
-  });
-  return gps::launch_status("gps_gather_segment_sum");
 }
 
 int gps_segment_pool_fwd(const float* x, const int32_t* ptr, int64_t B, int d, int mean, float* out,

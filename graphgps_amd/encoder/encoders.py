@@ -19,7 +19,6 @@ import torch.nn as nn
 from ..graphgym.config import cfg
 from ..graphgym.register import (node_encoder_dict, register_edge_encoder,
                                  register_node_encoder)
-from ..ops import embedding
 from ..synthetic import ATOM_FEATURE_DIMS, BOND_FEATURE_DIMS
 
 
@@ -89,7 +88,7 @@ class TypeDictNodeEncoder(nn.Module):
         self.encoder = nn.Embedding(num_embeddings=num_types, embedding_dim=emb_dim)
 
     def forward(self, batch):
-        batch.x = embedding(batch.x[:, 0].contiguous(), self.encoder.weight)  # only the first column
+        batch.x = self.encoder(batch.x[:, 0])  # only the first column
         return batch
 
 
@@ -103,8 +102,7 @@ class TypeDictEdgeEncoder(nn.Module):
         self.encoder = nn.Embedding(num_embeddings=num_types, embedding_dim=emb_dim)
 
     def forward(self, batch):
-        ea = batch.edge_attr
-        batch.edge_attr = embedding(ea, self.encoder.weight) if ea.dim() == 1 else self.encoder(ea)
+        batch.edge_attr = self.encoder(batch.edge_attr)
         return batch
 
 
@@ -120,9 +118,8 @@ class ASTNodeEncoder(nn.Module):
     def forward(self, batch):
         x = batch.x
         depth = batch.node_depth.view(-1).clamp(max=self.max_depth)
-        batch.x = (embedding(x[:, 0].contiguous(), self.type_encoder.weight)
-                   + embedding(x[:, 1].contiguous(), self.attribute_encoder.weight)
-                   + embedding(depth.contiguous(), self.depth_encoder.weight))
+        batch.x = (self.type_encoder(x[:, 0]) + self.attribute_encoder(x[:, 1])
+                   + self.depth_encoder(depth))
         return batch
 
 
@@ -134,8 +131,8 @@ class ASTEdgeEncoder(nn.Module):
         self.embedding_direction = nn.Embedding(2, emb_dim)
 
     def forward(self, batch):
-        batch.edge_attr = (embedding(batch.edge_attr[:, 0].contiguous(), self.embedding_type.weight)
-                           + embedding(batch.edge_attr[:, 1].contiguous(), self.embedding_direction.weight))
+        batch.edge_attr = (self.embedding_type(batch.edge_attr[:, 0])
+                           + self.embedding_direction(batch.edge_attr[:, 1]))
         return batch
 
 

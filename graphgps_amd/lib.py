@@ -36,7 +36,6 @@ _SIGNATURES = {
     "gps_gine_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int64, c_int, c_float, _P,
                              _P, _P]),
     "gps_node_graph_from_ptr": (c_int, [_P, c_int64, _P, _P]),
-    "gps_gather_segment_sum": (c_int, [_P, _P, _P, c_int64, c_int, _P, _P]),
     "gps_segment_pool_fwd": (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P]),
     "gps_segment_pool_bwd": (c_int, [_P, _P, _P, c_int64, c_int, c_int, _P, _P]),
     "gps_bn_workspace_floats": (c_size_t, [c_int64, c_int]),

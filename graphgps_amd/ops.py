@@ -454,52 +454,3 @@ def favor_attention(qkv: torch.Tensor, proj: torch.Tensor, gi: GraphIndex,
     THE PADDED BATCH, including the padded-key contribution to the normaliser
     (graphgps/layer/performer_layer.py:485-487)."""
     return _FavorAttention.apply(qkv, proj, gi, num_heads)
-
-
-# -------------------------------------------------------------------------------------------
-# embedding lookup with a sort-free, deterministic weight gradient
-# -------------------------------------------------------------------------------------------
-class _Embedding(torch.autograd.Function):
-    """``weight[idx]`` (nn.Embedding without padding_idx / max_norm).  Backward groups the lookups by
-    token with the same stable counting sort that builds the graph index and sums each group's gradient
-    rows in one pass (ATen: radix sort + sum_and_scatter, ~0.4 ms per 25k x 256 lookup on MI355X)."""
-
-    @staticmethod
-    def forward(ctx, idx, weight):
-        ctx.save_for_backward(idx)
-        ctx.vocab = weight.shape[0]
-        return weight.index_select(0, idx)
-
-    @staticmethod
-    def backward(ctx, g):
-        (idx,) = ctx.saved_tensors
-        L = _lib.load()
-        dev = g.device
-        g = _f32c(g, "g")
-        n, d = g.shape
-        V = ctx.vocab
-        st = current_stream(dev)
-        i32 = dict(dtype=torch.int32, device=dev)
-        pairs = torch.stack([torch.arange(n, device=dev, dtype=torch.int64), idx.to(torch.int64)])
-        # the CSR has one row per node index 0..S-1 on BOTH sides of the pairs: S = max(V, n)
-        S = max(V, n)
-        rowptr_dst, rowptr_src = torch.empty(S + 1, **i32), torch.empty(S + 1, **i32)
-        src_by_dst, eid_by_dst = torch.empty(n, **i32), torch.empty(n, **i32)
-        dst_by_src, eid_by_src = torch.empty(n, **i32), torch.empty(n, **i32)
-        ws_bytes = L.gps_graph_index_workspace_bytes(S, n)
-        ws = torch.empty(max(ws_bytes, 4), dtype=torch.uint8, device=dev)
-        check(L.gps_graph_index_build(ptr(pairs), S, n, ptr(rowptr_dst), ptr(src_by_dst), ptr(eid_by_dst),
-                                      ptr(rowptr_src), ptr(dst_by_src), ptr(eid_by_src), ptr(ws),
-                                      ws_bytes, st), "gps_graph_index_build")
-        g_w = torch.empty(V, d, dtype=torch.float32, device=dev)
-        check(L.gps_gather_segment_sum(ptr(g), ptr(rowptr_dst), ptr(src_by_dst), V, d, ptr(g_w), st),
-              "gps_gather_segment_sum")
-        return None, g_w
-
-
-def embedding(idx: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
-    """``nn.Embedding`` lookup; on the GPU with gradients enabled the weight gradient is the HIP path."""
-    if weight.is_cuda and weight.dtype == torch.float32 and idx.dim() == 1 and idx.numel() > 0 \
-            and torch.is_grad_enabled() and weight.requires_grad:
-        return _Embedding.apply(idx, weight)
-    return torch.nn.functional.embedding(idx, weight)

@@ -241,12 +241,6 @@ int gps_wgrad_grouped(int n, const gps_wgrad_problem* probs, float* ws, gps_stre
  * `node_graph` int32 [N] (graph id per node) comes from gps_node_graph_from_ptr.
  * ------------------------------------------------------------------------------------- */
 int gps_node_graph_from_ptr(const int32_t* ptr, int64_t B, int32_t* node_graph, gps_stream_t stream);
-/* out[s] = sum_{k in [rowptr[s], rowptr[s+1])} x[idx[k]]  -- with (rowptr, idx) = the stable by-target CSR of
- * the pairs (lookup position, token id) from gps_graph_index_build this is the weight gradient of an
- * nn.Embedding lookup (ATen: sort + sum_and_scatter; graphgps/encoder/ast_encoder.py:23-33,
- * type_dict_encoder.py:36-40), deterministic and without atomics. */
-int gps_gather_segment_sum(const float* x, const int32_t* rowptr, const int32_t* idx, int64_t S, int d,
-                           float* out, gps_stream_t stream);
 int gps_segment_pool_fwd(const float* x, const int32_t* ptr, int64_t B, int d, int mean, float* out,
                          gps_stream_t stream);
 int gps_segment_pool_bwd(const float* g_out, const int32_t* ptr, const int32_t* node_graph,

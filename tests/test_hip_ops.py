@@ -465,27 +465,3 @@ def test_gemm_nt_bf16_split(R, K, M):
     plain = torch.empty(R, M, device=dev)
     check(L.gps_gemm_nt(ptr(a), K, ptr(b), K, R, M, K, None, None, 0, ptr(plain), M, current_stream(dev)))
     assert_close(plain, a.double() @ b.double().t(), Tol.GRAD_REL, "A B^T", rel_to_max=True)
-
-
-@pytest.mark.parametrize("n,V,d", [(25000, 10030, 256), (743, 28, 64), (5, 98, 52), (4000, 2, 256), (1, 7, 3)])
-def test_embedding_weight_gradient(n, V, d):
-    """ops.embedding: forward = nn.Embedding lookup (bitwise), weight gradient from the counting-sort CSR +
-    gather-segment-sum kernels vs F.embedding's in fp64; deterministic (bitwise run to run)."""
-    from graphgps_amd.ops import embedding
-    dev = torch.device("cuda:0")
-    gen = torch.Generator().manual_seed(n + V)
-    w = torch.randn(V, d, generator=gen)
-    idx = torch.randint(0, V, (n,), generator=gen)
-    idx[0] = V - 1                                          # the last token is hit, token 0 maybe not
-    g = torch.randn(n, d, generator=gen)
-    wr = w.double().requires_grad_(True)
-    torch.nn.functional.embedding(idx, wr).backward(g.double())
-    grads = []
-    for _ in range(2):
-        wd = w.to(dev).requires_grad_(True)
-        out = embedding(idx.to(dev), wd)
-        assert torch.equal(out.detach().cpu(), w[idx])
-        out.backward(g.to(dev))
-        grads.append(wd.grad.clone())
-    assert torch.equal(grads[0], grads[1])
-    assert_close(grads[0], wr.grad, Tol.GRAD_REL, "g_weight", rel_to_max=True)
