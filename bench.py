@@ -141,13 +141,13 @@ def kernel_rooflines(dev, profile, nb, d=384, H=16):
     def gg_fwd():
         check(L.gps_gatedgcn_fwd(P, P + fs, P + 2 * fs, P + 3 * fs, 4 * d, ptr(ce), ptr(gi.rowptr_dst),
                                  ptr(gi.src_by_dst), ptr(gi.eid_by_dst), N, E, d, ptr(xt), ptr(eh),
-                                 ptr(ag), ptr(dn), st))
+                                 ptr(ag), ptr(dn), None, st))
 
     def gg_bwd():
         check(L.gps_gatedgcn_bwd(ptr(gx), ptr(ge), ptr(eh), P + fs, 4 * d, ptr(ag), ptr(dn),
                                  ptr(gi.rowptr_dst), ptr(gi.src_by_dst), ptr(gi.eid_by_dst),
                                  ptr(gi.rowptr_src), ptr(gi.dst_by_src), ptr(gi.eid_by_src), N, E, d,
-                                 ptr(gce), G, G + fs, G + 2 * fs, G + 3 * fs, 4 * d, st))
+                                 ptr(gce), G, G + fs, G + 2 * fs, G + 3 * fs, 4 * d, None, st))
 
     dh = d // H
     qkv, out, lse = f(N, 3 * d), f(N, d), f(H, N)

@@ -18,13 +18,16 @@
 
 namespace {
 
-template <int VEC, bool SAVE>
+// GATE: the EquivStableLapPE variant (gatedgcn_layer.py:101-104): sigma_ij is multiplied by a per-edge
+// scalar r_ij in (0,1) (r_edge[edge id]) before it gates and normalises.
+template <int VEC, bool SAVE, bool GATE>
 __global__ __launch_bounds__(256) void k_gatedgcn_fwd(
     const float* __restrict__ Ax, const float* __restrict__ Bx, const float* __restrict__ Dx,
     const float* __restrict__ Ex, int64_t ld, const float* __restrict__ Ce,
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src,
     const int32_t* __restrict__ eid, int64_t N, int d, float* __restrict__ x_tilde,
-    float* __restrict__ e_hat, float* __restrict__ aggr_out, float* __restrict__ den_out) {
+    float* __restrict__ e_hat, float* __restrict__ aggr_out, float* __restrict__ den_out,
+    const float* __restrict__ r_edge) {
   const int lanes_per_row = d / VEC;
   const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   const int64_t node = t / lanes_per_row;
@@ -40,10 +43,12 @@ __global__ __launch_bounds__(256) void k_gatedgcn_fwd(
     const Vec<VEC> bx = Vec<VEC>::load(Bx + j * ld + c);
     const Vec<VEC> ce = Vec<VEC>::load(Ce + id * d + c);
     Vec<VEC> eh;
+    const float rr = GATE ? r_edge[id] : 1.0f;
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
       eh[v] = (dx[v] + ex[v]) + ce[v];  // e_ij = Dx_i + Ex_j + Ce            (:96)
-      const float s = sigmoidf_exact(eh[v]);  //                               (:97)
+      float s = sigmoidf_exact(eh[v]);  //                                     (:97)
+      if (GATE) s = s * rr;             // sigma_ij * r_ij                     (:101-104)
       num[v] += s * bx[v];                    // scatter(sigma*Bx_j)           (:117-119)
       den[v] += s;                            // scatter(sigma)                (:121-123)
     }
@@ -67,13 +72,14 @@ __global__ __launch_bounds__(256) void k_gatedgcn_fwd(
 //   a_i = g_x_i / D_i,  b_i = -g_x_i * aggr_i / D_i           (D_i = den_i + 1e-6)
 //   delta_ij = g_e_ij + (a_i * Bx_j + b_i) * sig_ij * (1 - sig_ij)
 //   g_Ce[eid] = delta_ij ;  g_Dx_i = sum_j delta_ij ;  g_Ax_i = g_x_i
-template <int VEC>
+template <int VEC, bool GATE>
 __global__ __launch_bounds__(256) void k_gatedgcn_bwd_dst(
     const float* __restrict__ g_x, const float* __restrict__ g_e, const float* __restrict__ e_hat,
     const float* __restrict__ Bx, int64_t ld, const float* __restrict__ aggr,
     const float* __restrict__ den, const int32_t* __restrict__ rowptr,
     const int32_t* __restrict__ src, const int32_t* __restrict__ eid, int64_t N, int d,
-    float* __restrict__ g_Ce, float* __restrict__ g_Ax, float* __restrict__ g_Dx, int64_t ldg) {
+    float* __restrict__ g_Ce, float* __restrict__ g_Ax, float* __restrict__ g_Dx, int64_t ldg,
+    const float* __restrict__ r_edge) {
   const int lanes_per_row = d / VEC;
   const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   const int64_t node = t / lanes_per_row;
@@ -97,10 +103,13 @@ __global__ __launch_bounds__(256) void k_gatedgcn_bwd_dst(
     const Vec<VEC> ge = Vec<VEC>::load(g_e + id * d + c);
     const Vec<VEC> bx = Vec<VEC>::load(Bx + j * ld + c);
     Vec<VEC> dl;
+    const float rr = GATE ? r_edge[id] : 1.0f;
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
       const float s = sigmoidf_exact(eh[v]);
-      dl[v] = ge[v] + (a[v] * bx[v] + b[v]) * (s * (1.0f - s));
+      float gs = a[v] * bx[v] + b[v];          // gradient wrt the (gated) sigma
+      if (GATE) gs = gs * rr;
+      dl[v] = ge[v] + gs * (s * (1.0f - s));
       gdx[v] += dl[v];
     }
     dl.store(g_Ce + id * d + c);
@@ -111,12 +120,12 @@ __global__ __launch_bounds__(256) void k_gatedgcn_bwd_dst(
 
 // Backward pass 2, keyed by SOURCE j (reads the delta written by pass 1):
 //   g_Ex_j = sum_{j->i} delta_ij ;   g_Bx_j = sum_{j->i} sig_ij * a_i
-template <int VEC>
+template <int VEC, bool GATE>
 __global__ __launch_bounds__(256) void k_gatedgcn_bwd_src(
     const float* __restrict__ g_x, const float* __restrict__ e_hat, const float* __restrict__ den,
     const float* __restrict__ delta, const int32_t* __restrict__ rowptr,
     const int32_t* __restrict__ dst, const int32_t* __restrict__ eid, int64_t N, int d,
-    float* __restrict__ g_Bx, float* __restrict__ g_Ex, int64_t ldg) {
+    float* __restrict__ g_Bx, float* __restrict__ g_Ex, int64_t ldg, const float* __restrict__ r_edge) {
   const int lanes_per_row = d / VEC;
   const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   const int64_t node = t / lanes_per_row;
@@ -131,9 +140,11 @@ __global__ __launch_bounds__(256) void k_gatedgcn_bwd_src(
     const Vec<VEC> eh = Vec<VEC>::load(e_hat + id * d + c);
     const Vec<VEC> gx = Vec<VEC>::load(g_x + i * d + c);
     const Vec<VEC> dn = Vec<VEC>::load(den + i * d + c);
+    const float rr = GATE ? r_edge[id] : 1.0f;
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
-      const float s = sigmoidf_exact(eh[v]);
+      float s = sigmoidf_exact(eh[v]);
+      if (GATE) s = s * rr;
       gex[v] += dl[v];
       gbx[v] += s * (gx[v] / (dn[v] + 1e-6f));
     }
@@ -146,13 +157,25 @@ inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintp
 
 }  // namespace
 
+#define GPS_GG_FWD(SAVE, GATE)                                                                      \
+  k_gatedgcn_fwd<VEC, SAVE, GATE><<<gps::grid_for(work, 256), 256, 0, s>>>(                         \
+      Ax, Bx, Dx, Ex, ld_node, Ce, rowptr_dst, src_by_dst, eid_by_dst, N, d, x_tilde, e_hat, aggr, den, r_edge)
+#define GPS_GG_BWD(GATE)                                                                           \
+  do {                                                                                             \
+    k_gatedgcn_bwd_dst<VEC, GATE><<<gps::grid_for(work, 256), 256, 0, s>>>(                        \
+        g_x, g_e, e_hat, Bx, ld_node, aggr, den, rowptr_dst, src_by_dst, eid_by_dst, N, d, g_Ce,   \
+        g_Ax, g_Dx, ld_gnode, r_edge);                                                             \
+    k_gatedgcn_bwd_src<VEC, GATE><<<gps::grid_for(work, 256), 256, 0, s>>>(                        \
+        g_x, e_hat, den, g_Ce, rowptr_src, dst_by_src, eid_by_src, N, d, g_Bx, g_Ex, ld_gnode, r_edge); \
+  } while (0)
+
 extern "C" {
 
 int gps_gatedgcn_fwd(const float* Ax, const float* Bx, const float* Dx, const float* Ex,
                      int64_t ld_node, const float* Ce, const int32_t* rowptr_dst,
                      const int32_t* src_by_dst, const int32_t* eid_by_dst, int64_t N, int64_t E,
                      int d, float* x_tilde, float* e_hat, float* aggr, float* den,
-                     gps_stream_t stream) {
+                     const float* r_edge, gps_stream_t stream) {
   GPS_REQUIRE(N >= 0 && E >= 0 && d > 0 && ld_node >= d, "gps_gatedgcn_fwd: bad sizes N=%lld E=%lld d=%d ld=%lld",
               (long long)N, (long long)E, d, (long long)ld_node);
   if (N == 0) return GPS_OK;
@@ -168,12 +191,8 @@ int gps_gatedgcn_fwd(const float* Ax, const float* Bx, const float* Dx, const fl
   hipStream_t s = gps::as_stream(stream);
   GPS_DISPATCH_VEC(d, ld_node % 4 == 0 && ok(16), ld_node % 2 == 0 && ok(8), {
     const int64_t work = N * (int64_t)(d / VEC);
-    if (save)
-      k_gatedgcn_fwd<VEC, true><<<gps::grid_for(work, 256), 256, 0, s>>>(
-          Ax, Bx, Dx, Ex, ld_node, Ce, rowptr_dst, src_by_dst, eid_by_dst, N, d, x_tilde, e_hat, aggr, den);
-    else
-      k_gatedgcn_fwd<VEC, false><<<gps::grid_for(work, 256), 256, 0, s>>>(
-          Ax, Bx, Dx, Ex, ld_node, Ce, rowptr_dst, src_by_dst, eid_by_dst, N, d, x_tilde, e_hat, aggr, den);
+    if (save) { if (r_edge) GPS_GG_FWD(true, true); else GPS_GG_FWD(true, false); }
+    else { if (r_edge) GPS_GG_FWD(false, true); else GPS_GG_FWD(false, false); }
   });
   return gps::launch_status("gps_gatedgcn_fwd");
 }
@@ -184,7 +203,7 @@ int gps_gatedgcn_bwd(const float* g_x, const float* g_e, const float* e_hat, con
                      const int32_t* eid_by_dst, const int32_t* rowptr_src,
                      const int32_t* dst_by_src, const int32_t* eid_by_src, int64_t N, int64_t E,
                      int d, float* g_Ce, float* g_Ax, float* g_Bx, float* g_Dx, float* g_Ex,
-                     int64_t ld_gnode, gps_stream_t stream) {
+                     int64_t ld_gnode, const float* r_edge, gps_stream_t stream) {
   GPS_REQUIRE(N >= 0 && E >= 0 && d > 0 && ld_node >= d && ld_gnode >= d, "gps_gatedgcn_bwd: bad sizes");
   if (N == 0) return GPS_OK;
   GPS_REQUIRE(g_x && Bx && aggr && den && rowptr_dst && rowptr_src && g_Ax && g_Bx && g_Dx && g_Ex,
@@ -200,11 +219,7 @@ int gps_gatedgcn_bwd(const float* g_x, const float* g_e, const float* e_hat, con
   GPS_DISPATCH_VEC(d, ld_node % 4 == 0 && ld_gnode % 4 == 0 && ok(16),
                    ld_node % 2 == 0 && ld_gnode % 2 == 0 && ok(8), {
     const int64_t work = N * (int64_t)(d / VEC);
-    k_gatedgcn_bwd_dst<VEC><<<gps::grid_for(work, 256), 256, 0, s>>>(
-        g_x, g_e, e_hat, Bx, ld_node, aggr, den, rowptr_dst, src_by_dst, eid_by_dst, N, d, g_Ce,
-        g_Ax, g_Dx, ld_gnode);
-    k_gatedgcn_bwd_src<VEC><<<gps::grid_for(work, 256), 256, 0, s>>>(
-        g_x, e_hat, den, g_Ce, rowptr_src, dst_by_src, eid_by_src, N, d, g_Bx, g_Ex, ld_gnode);
+    if (r_edge) GPS_GG_BWD(true); else GPS_GG_BWD(false);
   });
   return gps::launch_status("gps_gatedgcn_bwd");
 }

@@ -10,13 +10,16 @@
 
 namespace {
 
-template <int VEC>
+// GATE: GINEConvESLapPE (graphgps/layer/gine_conv_layer.py:70-84): relu(x_j + e_ji) * r_ij with a
+// per-edge scalar r_edge[edge id].
+template <int VEC, bool GATE>
 __global__ __launch_bounds__(256) void k_gine_fwd(const float* __restrict__ x,
                                                   const float* __restrict__ e,
                                                   const int32_t* __restrict__ rowptr,
                                                   const int32_t* __restrict__ src,
                                                   const int32_t* __restrict__ eid, int64_t N, int d,
-                                                  float one_plus_eps, float* __restrict__ out) {
+                                                  float one_plus_eps, float* __restrict__ out,
+                                                  const float* __restrict__ r_edge) {
   const int lanes_per_row = d / VEC;
   const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   const int64_t node = t / lanes_per_row;
@@ -27,8 +30,12 @@ __global__ __launch_bounds__(256) void k_gine_fwd(const float* __restrict__ x,
   for (int k = beg; k < end; ++k) {
     const Vec<VEC> xj = Vec<VEC>::load(x + (int64_t)src[k] * d + c);
     const Vec<VEC> ee = Vec<VEC>::load(e + (int64_t)eid[k] * d + c);
+    const float rr = GATE ? r_edge[eid[k]] : 1.0f;
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) acc[v] += fmaxf(xj[v] + ee[v], 0.0f);
+    for (int v = 0; v < VEC; ++v) {
+      const float m = fmaxf(xj[v] + ee[v], 0.0f);
+      acc[v] += GATE ? m * rr : m;
+    }
   }
   const Vec<VEC> xi = Vec<VEC>::load(x + node * (int64_t)d + c);
   Vec<VEC> o;
@@ -38,14 +45,15 @@ __global__ __launch_bounds__(256) void k_gine_fwd(const float* __restrict__ x,
 }
 
 // target-keyed: g_e[eid] = g_out[i] * [x_j + e > 0]
-template <int VEC>
+template <int VEC, bool GATE>
 __global__ __launch_bounds__(256) void k_gine_bwd_dst(const float* __restrict__ g_out,
                                                       const float* __restrict__ x,
                                                       const float* __restrict__ e,
                                                       const int32_t* __restrict__ rowptr,
                                                       const int32_t* __restrict__ src,
                                                       const int32_t* __restrict__ eid, int64_t N,
-                                                      int d, float* __restrict__ g_e) {
+                                                      int d, float* __restrict__ g_e,
+                                                      const float* __restrict__ r_edge) {
   const int lanes_per_row = d / VEC;
   const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   const int64_t node = t / lanes_per_row;
@@ -58,8 +66,9 @@ __global__ __launch_bounds__(256) void k_gine_bwd_dst(const float* __restrict__ 
     const Vec<VEC> xj = Vec<VEC>::load(x + (int64_t)src[k] * d + c);
     const Vec<VEC> ee = Vec<VEC>::load(e + id * d + c);
     Vec<VEC> ge;
+    const float rr = GATE ? r_edge[id] : 1.0f;
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) ge[v] = (xj[v] + ee[v]) > 0.0f ? go[v] : 0.0f;
+    for (int v = 0; v < VEC; ++v) ge[v] = (xj[v] + ee[v]) > 0.0f ? (GATE ? go[v] * rr : go[v]) : 0.0f;
     ge.store(g_e + id * d + c);
   }
 }
@@ -99,7 +108,7 @@ extern "C" {
 
 int gps_gine_fwd(const float* x, const float* e, const int32_t* rowptr_dst,
                  const int32_t* src_by_dst, const int32_t* eid_by_dst, int64_t N, int64_t E, int d,
-                 float eps, float* out, gps_stream_t stream) {
+                 float eps, float* out, const float* r_edge, gps_stream_t stream) {
   GPS_REQUIRE(N >= 0 && E >= 0 && d > 0, "gps_gine_fwd: bad sizes");
   if (N == 0) return GPS_OK;
   GPS_REQUIRE(x && rowptr_dst && out && (E == 0 || (e && src_by_dst && eid_by_dst)),
@@ -107,8 +116,11 @@ int gps_gine_fwd(const float* x, const float* e, const int32_t* rowptr_dst,
   auto ok = [&](size_t a) { return aligned_to(x, a) && aligned_to(e, a) && aligned_to(out, a); };
   hipStream_t s = gps::as_stream(stream);
   GPS_DISPATCH_VEC(d, ok(16), ok(8), {
-    k_gine_fwd<VEC><<<gps::grid_for(N * (int64_t)(d / VEC), 256), 256, 0, s>>>(
-        x, e, rowptr_dst, src_by_dst, eid_by_dst, N, d, 1.0f + eps, out);
+    const unsigned grid = gps::grid_for(N * (int64_t)(d / VEC), 256);
+    if (r_edge)
+      k_gine_fwd<VEC, true><<<grid, 256, 0, s>>>(x, e, rowptr_dst, src_by_dst, eid_by_dst, N, d, 1.0f + eps, out, r_edge);
+    else
+      k_gine_fwd<VEC, false><<<grid, 256, 0, s>>>(x, e, rowptr_dst, src_by_dst, eid_by_dst, N, d, 1.0f + eps, out, r_edge);
   });
   return gps::launch_status("gps_gine_fwd");
 }
@@ -116,7 +128,7 @@ int gps_gine_fwd(const float* x, const float* e, const int32_t* rowptr_dst,
 int gps_gine_bwd(const float* g_out, const float* x, const float* e, const int32_t* rowptr_dst,
                  const int32_t* src_by_dst, const int32_t* eid_by_dst, const int32_t* rowptr_src,
                  const int32_t* eid_by_src, int64_t N, int64_t E, int d, float eps, float* g_x,
-                 float* g_e, gps_stream_t stream) {
+                 float* g_e, const float* r_edge, gps_stream_t stream) {
   GPS_REQUIRE(N >= 0 && E >= 0 && d > 0, "gps_gine_bwd: bad sizes");
   if (N == 0) return GPS_OK;
   GPS_REQUIRE(g_out && x && rowptr_dst && rowptr_src && g_x &&
@@ -129,7 +141,10 @@ int gps_gine_bwd(const float* g_out, const float* x, const float* e, const int32
   hipStream_t s = gps::as_stream(stream);
   GPS_DISPATCH_VEC(d, ok(16), ok(8), {
     const unsigned grid = gps::grid_for(N * (int64_t)(d / VEC), 256);
-    k_gine_bwd_dst<VEC><<<grid, 256, 0, s>>>(g_out, x, e, rowptr_dst, src_by_dst, eid_by_dst, N, d, g_e);
+    if (r_edge)
+      k_gine_bwd_dst<VEC, true><<<grid, 256, 0, s>>>(g_out, x, e, rowptr_dst, src_by_dst, eid_by_dst, N, d, g_e, r_edge);
+    else
+      k_gine_bwd_dst<VEC, false><<<grid, 256, 0, s>>>(g_out, x, e, rowptr_dst, src_by_dst, eid_by_dst, N, d, g_e, r_edge);
     k_gine_bwd_src<VEC><<<grid, 256, 0, s>>>(g_out, g_e, rowptr_src, eid_by_src, N, d, 1.0f + eps, g_x);
   });
   return gps::launch_status("gps_gine_bwd");

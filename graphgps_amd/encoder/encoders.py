@@ -205,6 +205,31 @@ HKdiagSENodeEncoder = _kernel_encoder('HKdiagSE')
 ElstaticSENodeEncoder = _kernel_encoder('ElstaticSE')
 
 
+@register_node_encoder('EquivStableLapPE', overwrite=True)
+class EquivStableLapPENodeEncoder(nn.Module):
+    """graphgps/encoder/equivstable_laplace_pos_encoder.py:8-50: k-dim node LapPE -> d-dim, kept apart from
+    ``batch.x`` in ``batch.pe_EquivStableLapPE`` (used by the local GNN as an edge gate)."""
+
+    def __init__(self, dim_emb):
+        super().__init__()
+        pecfg = cfg.posenc_EquivStableLapPE
+        max_freqs = pecfg.eigen.max_freqs
+        self.raw_norm = nn.BatchNorm1d(max_freqs) if pecfg.raw_norm_type.lower() == 'batchnorm' else None
+        self.linear_encoder_eigenvec = nn.Linear(max_freqs, dim_emb)
+
+    def forward(self, batch):
+        if not (hasattr(batch, 'EigVals') and hasattr(batch, 'EigVecs')):
+            raise ValueError("Precomputed eigen values and vectors are "
+                             f"required for {self.__class__.__name__}; set "
+                             f"config 'posenc_EquivStableLapPE.enable' to True")
+        pos_enc = batch.EigVecs
+        pos_enc = torch.where(torch.isnan(pos_enc), torch.zeros_like(pos_enc), pos_enc)
+        if self.raw_norm:
+            pos_enc = self.raw_norm(pos_enc)
+        batch.pe_EquivStableLapPE = self.linear_encoder_eigenvec(pos_enc)
+        return batch
+
+
 def concat_node_encoders(enc1_cls, enc2_cls, enc2_name):
     """Dataset encoder to (dim_emb - dim_pe) then PE encoder appending dim_pe
     (composed_encoders.py:36-58, non-EquivStable branch)."""
@@ -212,9 +237,13 @@ def concat_node_encoders(enc1_cls, enc2_cls, enc2_name):
     class Concat2NodeEncoder(nn.Module):
         def __init__(self, dim_emb):
             super().__init__()
-            enc2_dim_pe = getattr(cfg, f"posenc_{enc2_name}").dim_pe
-            self.encoder1 = enc1_cls(dim_emb - enc2_dim_pe)
-            self.encoder2 = enc2_cls(dim_emb, expand_x=False)
+            if cfg.posenc_EquivStableLapPE.enable:   # node feats and PE are not concatenated (:45-47)
+                self.encoder1 = enc1_cls(dim_emb)
+                self.encoder2 = enc2_cls(dim_emb)
+            else:
+                enc2_dim_pe = getattr(cfg, f"posenc_{enc2_name}").dim_pe
+                self.encoder1 = enc1_cls(dim_emb - enc2_dim_pe)
+                self.encoder2 = enc2_cls(dim_emb, expand_x=False)
 
         def forward(self, batch):
             return self.encoder2(self.encoder1(batch))
@@ -226,7 +255,8 @@ def concat_node_encoders(enc1_cls, enc2_cls, enc2_name):
 for _ds_name, _ds_cls in (('Atom', AtomEncoder), ('ASTNode', ASTNodeEncoder),
                           ('TypeDictNode', TypeDictNodeEncoder)):
     for _pe_name, _pe_cls in (('RWSE', RWSENodeEncoder), ('HKdiagSE', HKdiagSENodeEncoder),
-                              ('ElstaticSE', ElstaticSENodeEncoder)):
+                              ('ElstaticSE', ElstaticSENodeEncoder),
+                              ('EquivStableLapPE', EquivStableLapPENodeEncoder)):
         register_node_encoder(f"{_ds_name}+{_pe_name}",
                               concat_node_encoders(_ds_cls, _pe_cls, _pe_name), overwrite=True)
 

@@ -24,10 +24,6 @@ class GatedGCNLayer(nn.Module):
     def __init__(self, in_dim, out_dim, dropout, residual, act='relu',
                  equivstable_pe=False, **kwargs):
         super().__init__()
-        if equivstable_pe:
-            raise NotImplementedError(
-                "GatedGCNLayer(equivstable_pe=True) (gatedgcn_layer.py:30-35,101-104) is outside "
-                "the HIP hot path built so far; no BASELINE.json config enables it")
         if in_dim != out_dim and residual:
             raise ValueError("residual GatedGCN needs in_dim == out_dim")
         self.activation = register.act_dict[act]
@@ -36,7 +32,11 @@ class GatedGCNLayer(nn.Module):
         self.C = nn.Linear(in_dim, out_dim, bias=True)
         self.D = nn.Linear(in_dim, out_dim, bias=True)
         self.E = nn.Linear(in_dim, out_dim, bias=True)
-        self.EquivStablePE = False
+        # Equivariant and Stable PE using LapPE (reference :28-35): r_ij = MLP(||PE_i - PE_j||^2)
+        self.EquivStablePE = equivstable_pe
+        if self.EquivStablePE:
+            self.mlp_r_ij = nn.Sequential(nn.Linear(1, out_dim), self.activation(),
+                                          nn.Linear(out_dim, 1), nn.Sigmoid())
         self.bn_node_x = nn.BatchNorm1d(out_dim)
         self.bn_edge_e = nn.BatchNorm1d(out_dim)
         self.act_fn_x = self.activation()
@@ -45,15 +45,26 @@ class GatedGCNLayer(nn.Module):
         self.residual = residual
         self._abde = None
 
-    def forward_tensors(self, x, e, gi):
+    def _r_ij(self, pe, gi):
+        """Per-edge scalar gate of the EquivStableLapPE variant (reference :101-104); a 1 -> d -> 1 MLP
+        on E scalars: plain torch ops, the gate itself is applied inside the HIP kernel."""
+        r = ((pe.index_select(0, gi.edge_dst) - pe.index_select(0, gi.edge_src)) ** 2).sum(dim=-1, keepdim=True)
+        return self.mlp_r_ij(r).view(-1)
+
+    def forward_tensors(self, x, e, gi, pe=None):
         x_in, e_in = x, e
+        r = None
+        if self.EquivStablePE:
+            if pe is None:
+                raise ValueError("GatedGCNLayer(equivstable_pe=True) needs batch.pe_EquivStableLapPE")
+            r = self._r_ij(pe, gi)
         # Ax|Bx|Dx|Ex in one GEMM over a zero-copy stacked view of the four weights; column
         # block order is what csrc/gatedgcn.hip expects
         if self._abde is None:
             self._abde = LinearGroup([self.A, self.B, self.D, self.E])
         proj = self._abde(x)
         ce = linear(e, self.C.weight, self.C.bias)
-        x, e = gatedgcn_aggregate(proj, ce, gi)
+        x, e = gatedgcn_aggregate(proj, ce, gi, r)
         if isinstance(self.act_fn_x, nn.ReLU) and isinstance(self.act_fn_e, nn.ReLU):
             # lines :72-83 as two fused passes per stream (csrc/bn_fused.hip)
             p = self.dropout if self.training else 0.0
@@ -72,7 +83,8 @@ class GatedGCNLayer(nn.Module):
         return x, e
 
     def forward(self, batch):
-        x, e = self.forward_tensors(batch.x, batch.edge_attr, graph_index_of(batch))
+        pe = batch.pe_EquivStableLapPE if self.EquivStablePE else None
+        x, e = self.forward_tensors(batch.x, batch.edge_attr, graph_index_of(batch), pe)
         batch.x = x
         batch.edge_attr = e
         return batch

@@ -40,6 +40,33 @@ class GINEConv(nn.Module):
         return f'{self.__class__.__name__}(nn={self.nn})'
 
 
+class GINEConvESLapPE(GINEConv):
+    """``GINEConvESLapPE`` (graphgps/layer/gine_conv_layer.py:11-87): GINE whose messages are scaled by
+    r_ij = MLP(||PE_i - PE_j||^2) (a per-edge scalar in (0,1)); parameter names ``nn.*``, ``eps``,
+    ``mlp_r_ij.{0,2}.*``."""
+
+    def __init__(self, nn_module: nn.Module, eps: float = 0., train_eps: bool = False, edge_dim=None,
+                 **kwargs):
+        super().__init__(nn_module, eps, train_eps, edge_dim, **kwargs)
+        out_dim = nn_module[0].out_features
+        self.mlp_r_ij = nn.Sequential(nn.Linear(1, out_dim), nn.ReLU(), nn.Linear(out_dim, 1),
+                                      nn.Sigmoid())
+
+    def forward_tensors(self, x, edge_attr, gi, pe_LapPE=None):
+        if pe_LapPE is None:
+            raise ValueError("GINEConvESLapPE needs pe_LapPE (batch.pe_EquivStableLapPE)")
+        r = ((pe_LapPE.index_select(0, gi.edge_dst) - pe_LapPE.index_select(0, gi.edge_src)) ** 2) \
+            .sum(dim=-1, keepdim=True)
+        r = self.mlp_r_ij(r).view(-1)
+        return self.nn(gine_aggregate(x, edge_attr, gi, self.initial_eps, r))
+
+    def forward(self, x, edge_index, edge_attr, pe_LapPE=None, gi=None):
+        if gi is None:
+            n = x.shape[0]
+            gi = build_graph_index(edge_index, n, 1, ptr_vec=torch.tensor([0, n], device=x.device))
+        return self.forward_tensors(x, edge_attr, gi, pe_LapPE)
+
+
 class GINEConvLayer(nn.Module):
     """graphgps/layer/gine_conv_layer.py:90-116."""
 

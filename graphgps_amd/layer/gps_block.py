@@ -235,7 +235,7 @@ class _GPSBlock(torch.autograd.Function):
         aggr, den = _E(N, d, **f32), _E(N, d, **f32)
         check(L.gps_gatedgcn_fwd(P, P + fs, P + 2 * fs, P + 3 * fs, ldp, ptr(ce), ptr(gi.rowptr_dst),
                                  ptr(gi.src_by_dst), ptr(gi.eid_by_dst), N, E, d, ptr(xt), ptr(eh),
-                                 ptr(aggr), ptr(den), st), "gps_gatedgcn_fwd")
+                                 ptr(aggr), ptr(den), None, st), "gps_gatedgcn_fwd")
         fork.join(o, lse, ao)
 
         # -- the five BatchNorms, residuals and dropouts as task lists (csrc/block_norm.hip) -------
@@ -338,7 +338,7 @@ class _GPSBlock(torch.autograd.Function):
         check(L.gps_gatedgcn_bwd(ptr(g_xt), ptr(g_eh), ptr(eh), P + fs, ldp, ptr(aggr),
                                  ptr(den), ptr(gi.rowptr_dst), ptr(gi.src_by_dst), ptr(gi.eid_by_dst),
                                  ptr(gi.rowptr_src), ptr(gi.dst_by_src), ptr(gi.eid_by_src), N, E, d,
-                                 ptr(g_ce), G, G + fs, G + 2 * fs, G + 3 * fs, ldp, st),
+                                 ptr(g_ce), G, G + fs, G + 2 * fs, G + 3 * fs, ldp, None, st),
               "gps_gatedgcn_bwd")
         fork.join()
         wcat, _ = layer._xgroup._stacked()
@@ -383,7 +383,7 @@ def block_supported(layer, x, e=None) -> bool:
         return False
     if layer.local_gnn_type != 'CustomGatedGCN' or layer.global_model_type != 'Transformer':
         return False
-    if not layer.batch_norm or not lm.residual:
+    if not layer.batch_norm or not lm.residual or getattr(lm, "EquivStablePE", False):
         return False
     if not (isinstance(lm.act_fn_x, nn.ReLU) and isinstance(lm.act_fn_e, nn.ReLU)
             and isinstance(layer.act_fn_ff, nn.ReLU)):

@@ -24,7 +24,7 @@ from ..graphgym import act as _act  # noqa: F401
 from ..fused import add_dropout, bn_act, linear, relu_dropout
 from ..ops import graph_index_of, segment_attention
 from .gatedgcn_layer import GatedGCNLayer
-from .gine_conv_layer import GINEConv
+from .gine_conv_layer import GINEConv, GINEConvESLapPE
 from .gps_block import block_supported, gps_block
 
 import os as _os
@@ -46,8 +46,9 @@ class GPSLayer(nn.Module):
         super().__init__()
         self.ctor_kwargs = dict(dim_h=dim_h, local_gnn_type=local_gnn_type,
                                 global_model_type=global_model_type, num_heads=num_heads,
-                                act=act, dropout=dropout, attn_dropout=attn_dropout,
-                                layer_norm=layer_norm, batch_norm=batch_norm)
+                                act=act, equivstable_pe=equivstable_pe, dropout=dropout,
+                                attn_dropout=attn_dropout, layer_norm=layer_norm,
+                                batch_norm=batch_norm)
         self.dim_h = dim_h
         self.num_heads = num_heads
         self.attn_dropout = attn_dropout
@@ -64,9 +65,6 @@ class GPSLayer(nn.Module):
         if log_attn_weights:
             raise NotImplementedError(
                 "log_attn_weights materialises [B,H,n,n]; the varlen kernel never forms it")
-        if equivstable_pe:
-            raise NotImplementedError("equivstable_pe (posenc_EquivStableLapPE) is outside the "
-                                      "HIP hot path; no BASELINE.json config enables it")
 
         # Local message-passing model (reference :43-98).
         self.local_gnn_with_edge_attr = True
@@ -75,7 +73,10 @@ class GPSLayer(nn.Module):
         elif local_gnn_type == 'GINE':
             gin_nn = nn.Sequential(nn.Linear(dim_h, dim_h), self.activation(),
                                    nn.Linear(dim_h, dim_h))
-            self.local_model = GINEConv(gin_nn)
+            if self.equivstable_pe:          # specialised GINE layer for EquivStableLapPE (:66-67)
+                self.local_model = GINEConvESLapPE(gin_nn)
+            else:
+                self.local_model = GINEConv(gin_nn)
         elif local_gnn_type == 'CustomGatedGCN':
             self.local_model = GatedGCNLayer(dim_h, dim_h, dropout=dropout, residual=True,
                                              act=act, equivstable_pe=equivstable_pe)
@@ -151,10 +152,15 @@ class GPSLayer(nn.Module):
         if self.local_model is not None:
             if self.local_gnn_type == 'CustomGatedGCN':
                 # GatedGCN does residual connection and dropout internally (reference :164-174)
-                h_local, e_new = self.local_model.forward_tensors(h, batch.edge_attr, gi)
+                es = batch.pe_EquivStableLapPE if self.equivstable_pe else None      # :165-166
+                h_local, e_new = self.local_model.forward_tensors(h, batch.edge_attr, gi, es)
                 batch.edge_attr = e_new
             else:
-                h_local = self.local_model.forward_tensors(h, batch.edge_attr, gi)
+                if self.equivstable_pe:                                              # :177-181
+                    h_local = self.local_model.forward_tensors(h, batch.edge_attr, gi,
+                                                               batch.pe_EquivStableLapPE)
+                else:
+                    h_local = self.local_model.forward_tensors(h, batch.edge_attr, gi)
                 # dropout_local + residual (reference :188-189)
                 h_local = add_dropout(h_in1, h_local, self.dropout_local.p, self.training)
             if self.batch_norm:

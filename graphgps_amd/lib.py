@@ -14,7 +14,7 @@ import torch  # noqa: F401  -- must be imported first: it maps the HIP runtime o
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libgps_hip.so")
-ABI_VERSION = 1
+ABI_VERSION = 2
 
 _lib: Optional[ctypes.CDLL] = None
 
@@ -29,12 +29,12 @@ _SIGNATURES = {
     "gps_segment_ptr_from_batch": (c_int, [_P, c_int64, c_int64, _P, _P]),
     "gps_attn_tile_map": (c_int, [_P, c_int64, c_int64, _P, _P, _P]),
     "gps_gatedgcn_fwd": (c_int, [_P, _P, _P, _P, c_int64, _P, _P, _P, _P, c_int64, c_int64, c_int,
-                                 _P, _P, _P, _P, _P]),
+                                 _P, _P, _P, _P, _P, _P]),
     "gps_gatedgcn_bwd": (c_int, [_P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, c_int64,
-                                 c_int64, c_int, _P, _P, _P, _P, _P, c_int64, _P]),
-    "gps_gine_fwd": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int64, c_int, c_float, _P, _P]),
+                                 c_int64, c_int, _P, _P, _P, _P, _P, c_int64, _P, _P]),
+    "gps_gine_fwd": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int64, c_int, c_float, _P, _P, _P]),
     "gps_gine_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int64, c_int, c_float, _P,
-                             _P, _P]),
+                             _P, _P, _P]),
     "gps_node_graph_from_ptr": (c_int, [_P, c_int64, _P, _P]),
     "gps_segment_pool_fwd": (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P]),
     "gps_segment_pool_bwd": (c_int, [_P, _P, _P, c_int64, c_int, c_int, _P, _P]),

@@ -56,6 +56,8 @@ class GraphIndex:
     tile_row0: torch.Tensor    # int32 [max_tiles]
     max_tiles: int
     key: tuple = ()
+    edge_src: Optional[torch.Tensor] = None   # int64 [E] = edge_index[0] (edge order)
+    edge_dst: Optional[torch.Tensor] = None   # int64 [E] = edge_index[1]
 
 
 def build_graph_index(edge_index: torch.Tensor, num_nodes: int, num_graphs: int,
@@ -107,7 +109,8 @@ def build_graph_index(edge_index: torch.Tensor, num_nodes: int, num_graphs: int,
     check(L.gps_attn_tile_map(ptr(p32), B, max_tiles, ptr(tile_graph), ptr(tile_row0), stream),
           "gps_attn_tile_map")
     return GraphIndex(N, E, B, rowptr_dst, src_by_dst, eid_by_dst, rowptr_src, dst_by_src,
-                      eid_by_src, p32, tile_graph, tile_row0, max_tiles)
+                      eid_by_src, p32, tile_graph, tile_row0, max_tiles,
+                      edge_src=edge_index[0], edge_dst=edge_index[1])
 
 
 def graph_index_of(batch) -> GraphIndex:
@@ -133,12 +136,13 @@ def graph_index_of(batch) -> GraphIndex:
 # GatedGCN sparse core
 # -------------------------------------------------------------------------------------------
 class _GatedGCNAggregate(torch.autograd.Function):
-    """(proj [N,4d] = Ax|Bx|Dx|Ex, Ce [E,d]) -> (x_tilde [N,d], e_hat [E,d]).
+    """(proj [N,4d] = Ax|Bx|Dx|Ex, Ce [E,d][, r [E]]) -> (x_tilde [N,d], e_hat [E,d]).
 
-    graphgps/layer/gatedgcn_layer.py:67-70,90-136."""
+    graphgps/layer/gatedgcn_layer.py:67-70,90-136.  ``r`` is the EquivStableLapPE gate r_ij (:101-104):
+    sigma_ij * r_ij replaces sigma_ij in both sums."""
 
     @staticmethod
-    def forward(ctx, proj: torch.Tensor, ce: torch.Tensor, gi: GraphIndex):
+    def forward(ctx, proj: torch.Tensor, ce: torch.Tensor, gi: GraphIndex, r=None):
         L = _lib.load()
         dev = _require_cuda(proj, ce)
         proj, ce = _f32c(proj, "proj"), _f32c(ce, "Ce")
@@ -147,7 +151,11 @@ class _GatedGCNAggregate(torch.autograd.Function):
         if proj.shape != (N, 4 * d) or ce.shape != (E, d):
             raise _lib.GpsHipError(f"gatedgcn: proj {tuple(proj.shape)} / Ce {tuple(ce.shape)} do "
                                    f"not match N={N} E={E}")
-        need_grad = ctx.needs_input_grad[0] or ctx.needs_input_grad[1]
+        if r is not None:
+            r = _f32c(r.reshape(-1), "r_ij")
+            if r.numel() != E:
+                raise _lib.GpsHipError(f"gatedgcn: r_ij has {r.numel()} entries for E={E} edges")
+        need_grad = any(ctx.needs_input_grad)
         x_tilde = torch.empty(N, d, dtype=torch.float32, device=dev)
         e_hat = torch.empty(E, d, dtype=torch.float32, device=dev)
         aggr = torch.empty(N, d, dtype=torch.float32, device=dev) if need_grad else None
@@ -155,17 +163,17 @@ class _GatedGCNAggregate(torch.autograd.Function):
         base, fs = proj.data_ptr(), d * 4  # fs = byte offset between the Ax|Bx|Dx|Ex column blocks
         check(L.gps_gatedgcn_fwd(base, base + fs, base + 2 * fs, base + 3 * fs, 4 * d, ptr(ce),
                                  ptr(gi.rowptr_dst), ptr(gi.src_by_dst), ptr(gi.eid_by_dst), N, E,
-                                 d, ptr(x_tilde), ptr(e_hat), ptr(aggr), ptr(den),
+                                 d, ptr(x_tilde), ptr(e_hat), ptr(aggr), ptr(den), ptr(r),
                                  current_stream(dev)), "gps_gatedgcn_fwd")
         if need_grad:
-            ctx.save_for_backward(proj, e_hat, aggr, den)
+            ctx.save_for_backward(proj, e_hat, aggr, den, r)
             ctx.gi = gi
         return x_tilde, e_hat
 
     @staticmethod
     def backward(ctx, g_x: torch.Tensor, g_e: torch.Tensor):
         L = _lib.load()
-        proj, e_hat, aggr, den = ctx.saved_tensors
+        proj, e_hat, aggr, den, r = ctx.saved_tensors
         gi: GraphIndex = ctx.gi
         dev = proj.device
         N, E = gi.N, gi.E
@@ -179,22 +187,32 @@ class _GatedGCNAggregate(torch.autograd.Function):
                                  ptr(aggr), ptr(den), ptr(gi.rowptr_dst), ptr(gi.src_by_dst),
                                  ptr(gi.eid_by_dst), ptr(gi.rowptr_src), ptr(gi.dst_by_src),
                                  ptr(gi.eid_by_src), N, E, d, ptr(g_ce), gb, gb + fs, gb + 2 * fs,
-                                 gb + 3 * fs, 4 * d, current_stream(dev)), "gps_gatedgcn_bwd")
-        return g_proj, g_ce, None
+                                 gb + 3 * fs, 4 * d, ptr(r), current_stream(dev)), "gps_gatedgcn_bwd")
+        g_r = None
+        if r is not None and ctx.needs_input_grad[3]:
+            # g_r[e] = sum_c g_sigma'[e,c] * sigma[e,c],  g_sigma' = a_i * Bx_j + b_i  (a, b as in the kernel).
+            # A per-edge channel reduction: plain gathers + a row sum (rare option, [E,d] temporaries)
+            src, dst = gi.edge_src, gi.edge_dst
+            a = g_x / (den + 1e-6)
+            bterm = -a * aggr
+            gs = a.index_select(0, dst) * proj[:, d:2 * d].index_select(0, src) + bterm.index_select(0, dst)
+            g_r = (gs * torch.sigmoid(e_hat)).sum(-1)
+        return g_proj, g_ce, None, g_r
 
 
-def gatedgcn_aggregate(proj: torch.Tensor, ce: torch.Tensor, gi: GraphIndex):
-    return _GatedGCNAggregate.apply(proj, ce, gi)
+def gatedgcn_aggregate(proj: torch.Tensor, ce: torch.Tensor, gi: GraphIndex, r=None):
+    return _GatedGCNAggregate.apply(proj, ce, gi, r)
 
 
 # -------------------------------------------------------------------------------------------
 # GINE sparse core
 # -------------------------------------------------------------------------------------------
 class _GINEAggregate(torch.autograd.Function):
-    """out_i = (1+eps) x_i + sum_{j->i} relu(x_j + e_ji)  (PyG GINEConv, pre-MLP)."""
+    """out_i = (1+eps) x_i + sum_{j->i} relu(x_j + e_ji) [* r_ji]  (PyG GINEConv, pre-MLP; with ``r``:
+    GINEConvESLapPE, graphgps/layer/gine_conv_layer.py:70-84)."""
 
     @staticmethod
-    def forward(ctx, x: torch.Tensor, e: torch.Tensor, gi: GraphIndex, eps: float):
+    def forward(ctx, x: torch.Tensor, e: torch.Tensor, gi: GraphIndex, eps: float, r=None):
         L = _lib.load()
         dev = _require_cuda(x, e)
         x, e = _f32c(x, "x"), _f32c(e, "edge_attr")
@@ -202,30 +220,38 @@ class _GINEAggregate(torch.autograd.Function):
         if x.shape[0] != N or e.shape != (E, d):
             raise ValueError("Node and edge feature dimensionalities do not match. Consider "
                              "setting the 'edge_dim' attribute of 'GINEConv'")
+        if r is not None:
+            r = _f32c(r.reshape(-1), "r_ij")
+            if r.numel() != E:
+                raise _lib.GpsHipError(f"gine: r_ij has {r.numel()} entries for E={E} edges")
         out = torch.empty_like(x)
         check(L.gps_gine_fwd(ptr(x), ptr(e), ptr(gi.rowptr_dst), ptr(gi.src_by_dst),
-                             ptr(gi.eid_by_dst), N, E, d, float(eps), ptr(out),
+                             ptr(gi.eid_by_dst), N, E, d, float(eps), ptr(out), ptr(r),
                              current_stream(dev)), "gps_gine_fwd")
-        ctx.save_for_backward(x, e)
+        ctx.save_for_backward(x, e, r)
         ctx.gi, ctx.eps = gi, float(eps)
         return out
 
     @staticmethod
     def backward(ctx, g_out: torch.Tensor):
         L = _lib.load()
-        x, e = ctx.saved_tensors
+        x, e, r = ctx.saved_tensors
         gi: GraphIndex = ctx.gi
         g_out = _f32c(g_out, "g_out")
         g_x, g_e = torch.empty_like(x), torch.empty_like(e)
         check(L.gps_gine_bwd(ptr(g_out), ptr(x), ptr(e), ptr(gi.rowptr_dst), ptr(gi.src_by_dst),
                              ptr(gi.eid_by_dst), ptr(gi.rowptr_src), ptr(gi.eid_by_src), gi.N,
-                             gi.E, x.shape[1], ctx.eps, ptr(g_x), ptr(g_e),
+                             gi.E, x.shape[1], ctx.eps, ptr(g_x), ptr(g_e), ptr(r),
                              current_stream(x.device)), "gps_gine_bwd")
-        return g_x, g_e, None, None
+        g_r = None
+        if r is not None and ctx.needs_input_grad[4]:
+            src, dst = gi.edge_src, gi.edge_dst
+            g_r = (g_out.index_select(0, dst) * (x.index_select(0, src) + e).relu()).sum(-1)
+        return g_x, g_e, None, None, g_r
 
 
-def gine_aggregate(x: torch.Tensor, e: torch.Tensor, gi: GraphIndex, eps: float = 0.0):
-    return _GINEAggregate.apply(x, e, gi, eps)
+def gine_aggregate(x: torch.Tensor, e: torch.Tensor, gi: GraphIndex, eps: float = 0.0, r=None):
+    return _GINEAggregate.apply(x, e, gi, eps, r)
 
 
 # -------------------------------------------------------------------------------------------

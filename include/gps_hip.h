@@ -79,12 +79,15 @@ int gps_attn_tile_map(const int32_t* ptr, int64_t B, int64_t max_tiles, int32_t*
  *   x_tilde[i] = Ax[i] + (sum_j sig*Bx[j]) / (sum_j sig + 1e-6)
  * Ax/Bx/Dx/Ex are [N, d] views with row stride ld_node (a fused [N,4d] projection passes
  * ld_node = 4d).  `aggr`/`den` ([N,d]) are saved for the backward (may be NULL in inference).
+ * `r_edge` (float[E] by edge id, or NULL): the EquivStableLapPE gate r_ij of
+ * graphgps/layer/gatedgcn_layer.py:101-104 -- sig is replaced by sig * r_edge[eid] in both sums
+ * (and in the backward; the gradient wrt r_edge itself is the caller's: graphgps_amd/ops.py).
  * ------------------------------------------------------------------------------------- */
 int gps_gatedgcn_fwd(const float* Ax, const float* Bx, const float* Dx, const float* Ex,
                      int64_t ld_node, const float* Ce, const int32_t* rowptr_dst,
                      const int32_t* src_by_dst, const int32_t* eid_by_dst, int64_t N, int64_t E,
                      int d, float* x_tilde, float* e_hat, float* aggr, float* den,
-                     gps_stream_t stream);
+                     const float* r_edge, gps_stream_t stream);
 
 /* Backward.  Inputs: g_x [N,d] (grad wrt x_tilde), g_e [E,d] (grad wrt e_hat), saved e_hat,
  * Bx (ld_node), aggr, den.  Outputs: g_Ce [E,d]; g_Ax/g_Bx/g_Dx/g_Ex [N,d] views with row stride
@@ -96,21 +99,23 @@ int gps_gatedgcn_bwd(const float* g_x, const float* g_e, const float* e_hat, con
                      const int32_t* eid_by_dst, const int32_t* rowptr_src,
                      const int32_t* dst_by_src, const int32_t* eid_by_src, int64_t N, int64_t E,
                      int d, float* g_Ce, float* g_Ax, float* g_Bx, float* g_Dx, float* g_Ex,
-                     int64_t ld_gnode, gps_stream_t stream);
+                     int64_t ld_gnode, const float* r_edge, gps_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * GINE sparse core.  Replaces PyG GINEConv's gather + relu + scatter-add + (1+eps)*x
  * (constructed graphgps/layer/gps_layer.py:62-69, called :183-185):
  *   out[i] = (1+eps) * x[i] + sum_{j->i} relu(x[j] + e[eid])
  * Backward: g_e[eid] = g_out[i] * [x[j]+e[eid] > 0];  g_x[j] = (1+eps)*g_out[j] + sum_{j->.} g_e.
+ * `r_edge` (float[E] by edge id, or NULL): GINEConvESLapPE's per-edge scale r_ij on the message
+ * (graphgps/layer/gine_conv_layer.py:70-84): relu(.) * r_edge[eid], g_e scaled likewise.
  * ------------------------------------------------------------------------------------- */
 int gps_gine_fwd(const float* x, const float* e, const int32_t* rowptr_dst,
                  const int32_t* src_by_dst, const int32_t* eid_by_dst, int64_t N, int64_t E, int d,
-                 float eps, float* out, gps_stream_t stream);
+                 float eps, float* out, const float* r_edge, gps_stream_t stream);
 int gps_gine_bwd(const float* g_out, const float* x, const float* e, const int32_t* rowptr_dst,
                  const int32_t* src_by_dst, const int32_t* eid_by_dst, const int32_t* rowptr_src,
                  const int32_t* eid_by_src, int64_t N, int64_t E, int d, float eps, float* g_x,
-                 float* g_e, gps_stream_t stream);
+                 float* g_e, const float* r_edge, gps_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Segment (per-graph, varlen) multi-head attention core on fp32 MFMA (v_mfma_f32_16x16x4_f32).

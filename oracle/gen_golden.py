@@ -35,6 +35,9 @@ _pkg = types.ModuleType("graphgps")
 _pkg.__path__ = [os.path.join(REF, "graphgps")]   # skip graphgps/__init__.py (imports ogb, wandb, ...)
 sys.modules["graphgps"] = _pkg
 set_cfg(cfg)
+# the reference's files register their GraphGym wrappers under the same names as this package's
+for _k in ("gatedgcnconv", "gineconv"):
+    graphgps_amd.graphgym.register.layer_dict.pop(_k, None)
 from graphgps.layer.gps_layer import GPSLayer as RefGPSLayer  # noqa: E402
 from torch_geometric.data import Batch as StubBatch  # noqa: E402
 
@@ -50,6 +53,15 @@ CASES = {
                                       global_model_type="Performer", num_heads=2), "P30", 4, 14),
     "gatedgcn_only_d16": (dict(dim_h=16, local_gnn_type="CustomGatedGCN",
                                global_model_type="None", num_heads=1), "P14", 5, 15),
+    # EquivStableLapPE variants (gatedgcn_layer.py:28-35,101-104; gine_conv_layer.py:11-87): the layer
+    # additionally reads batch.pe_EquivStableLapPE [N, d]
+    "gatedgcn_eslappe_transformer_d32h4": (dict(dim_h=32, local_gnn_type="CustomGatedGCN",
+                                                global_model_type="Transformer", num_heads=4,
+                                                equivstable_pe=True), "P14", 6, 16),
+    # (no GINE + equivstable_pe fixture: the reference's GINEConvESLapPE cannot be constructed -- its
+    #  __init__ calls reset_parameters(), which touches self.mlp_r_ij, before defining it:
+    #  gine_conv_layer.py:35 vs :43-54.  The HIP layer implements the intended arithmetic and is
+    #  checked against the oracle restatement only.)
 }
 
 
@@ -72,6 +84,10 @@ def run_case(name, kw, profile, num_graphs, seed):
     wx = torch.randn(N, d, generator=gen)
     we = torch.randn(E, d, generator=gen)
     batch = StubBatch(x=x, edge_index=edge_index, edge_attr=e, batch=bvec)
+    pe = None
+    if kw.get("equivstable_pe"):
+        pe = (torch.randn(N, d, generator=gen) * 0.5).requires_grad_(True)
+        batch.pe_EquivStableLapPE = pe
     out = layer(batch)
     loss = (out.x * wx).sum() + (out.edge_attr * we).sum()
     loss.backward()
@@ -85,9 +101,15 @@ def run_case(name, kw, profile, num_graphs, seed):
         param_grads={k: p.grad.clone() for k, p in layer.named_parameters() if p.grad is not None},
         state_dict_after=({k: v.clone() for k, v in layer.state_dict().items()}),
     )
+    if pe is not None:
+        fix["pe"] = pe.detach().clone()
+        fix["grad_pe"] = pe.grad.clone()
     layer.eval()
     with torch.no_grad():
-        ob = layer(StubBatch(x=x.detach(), edge_index=edge_index, edge_attr=e.detach(), batch=bvec))
+        eb = StubBatch(x=x.detach(), edge_index=edge_index, edge_attr=e.detach(), batch=bvec)
+        if pe is not None:
+            eb.pe_EquivStableLapPE = pe.detach()
+        ob = layer(eb)
     fix["eval_out_x"] = ob.x.clone()
     fix["eval_out_edge_attr"] = ob.edge_attr.clone()
     return fix

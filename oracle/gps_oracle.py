@@ -70,8 +70,12 @@ def to_dense_batch(x: torch.Tensor, batch: torch.Tensor,
 class OracleGatedGCNLayer(nn.Module):
     """graphgps/layer/gatedgcn_layer.py:11-136 (equivstable_pe=False branch)."""
 
-    def __init__(self, in_dim, out_dim, dropout, residual, act="relu"):
+    def __init__(self, in_dim, out_dim, dropout, residual, act="relu", equivstable_pe=False):
         super().__init__()
+        self.EquivStablePE = equivstable_pe                       # :28-35
+        if equivstable_pe:
+            self.mlp_r_ij = nn.Sequential(nn.Linear(1, out_dim), ACT[act](), nn.Linear(out_dim, 1),
+                                          nn.Sigmoid())
         # :21-25  pyg_nn.Linear(bias=True) == nn.Linear for shapes/keys
         self.A = nn.Linear(in_dim, out_dim, bias=True)
         self.B = nn.Linear(in_dim, out_dim, bias=True)
@@ -85,7 +89,7 @@ class OracleGatedGCNLayer(nn.Module):
         self.dropout = dropout
         self.residual = residual
 
-    def forward(self, x, e, edge_index):
+    def forward(self, x, e, edge_index, pe=None):
         x_in, e_in = x, e                                         # :54-55
         Ax, Bx, Ce, Dx, Ex = self.A(x), self.B(x), self.C(e), self.D(x), self.E(x)  # :57-61
         # propagate (:67-70): PyG flow source_to_target => _j = edge_index[0], _i = edge_index[1]
@@ -93,6 +97,9 @@ class OracleGatedGCNLayer(nn.Module):
         Dx_i, Ex_j, Bx_j = Dx.index_select(0, i), Ex.index_select(0, j), Bx.index_select(0, j)
         e_ij = Dx_i + Ex_j + Ce                                   # :96
         sigma_ij = torch.sigmoid(e_ij)                            # :97
+        if self.EquivStablePE:                                    # :101-104
+            r_ij = ((pe.index_select(0, i) - pe.index_select(0, j)) ** 2).sum(dim=-1, keepdim=True)
+            sigma_ij = sigma_ij * self.mlp_r_ij(r_ij)
         N = Bx.shape[0]                                           # :115
         num = scatter_sum(sigma_ij * Bx_j, i, N)                  # :117-119
         den = scatter_sum(sigma_ij, i, N)                         # :121-123
@@ -115,14 +122,22 @@ class OracleGINEConv(nn.Module):
     constructed at graphgps/layer/gps_layer.py:62-69; message form mirrored in-tree
     at graphgps/layer/gine_conv_layer.py:70-84 (minus the r_ij factor)."""
 
-    def __init__(self, nn_module: nn.Module, eps: float = 0.0):
+    def __init__(self, nn_module: nn.Module, eps: float = 0.0, equivstable_pe: bool = False):
         super().__init__()
         self.nn = nn_module
         self.register_buffer("eps", torch.tensor([eps]))
+        if equivstable_pe:   # GINEConvESLapPE, graphgps/layer/gine_conv_layer.py:43-48,80-84
+            out_dim = nn_module[0].out_features
+            self.mlp_r_ij = nn.Sequential(nn.Linear(1, out_dim), nn.ReLU(), nn.Linear(out_dim, 1),
+                                          nn.Sigmoid())
+        self.EquivStablePE = equivstable_pe
 
-    def forward(self, x, edge_index, edge_attr):
+    def forward(self, x, edge_index, edge_attr, pe=None):
         j, i = edge_index[0], edge_index[1]
         msg = (x.index_select(0, j) + edge_attr).relu()
+        if self.EquivStablePE:
+            r_ij = ((pe.index_select(0, i) - pe.index_select(0, j)) ** 2).sum(dim=-1, keepdim=True)
+            msg = msg * self.mlp_r_ij(r_ij)
         out = scatter_sum(msg, i, x.shape[0])
         out = out + (1 + self.eps) * x
         return self.nn(out)
@@ -222,8 +237,9 @@ class OracleGPSLayer(nn.Module):
                  pna_degrees=None, equivstable_pe=False, dropout=0.0, attn_dropout=0.0,
                  layer_norm=False, batch_norm=True, bigbird_cfg=None, log_attn_weights=False):
         super().__init__()
-        if equivstable_pe or layer_norm or log_attn_weights:
+        if layer_norm or log_attn_weights:
             raise NotImplementedError("oracle covers the BASELINE.json configurations only")
+        self.equivstable_pe = equivstable_pe
         self.dim_h, self.num_heads = dim_h, num_heads
         self.batch_norm = batch_norm
         self.local_gnn_type, self.global_model_type = local_gnn_type, global_model_type
@@ -231,10 +247,10 @@ class OracleGPSLayer(nn.Module):
             self.local_model = None
         elif local_gnn_type == "GINE":
             gin_nn = nn.Sequential(nn.Linear(dim_h, dim_h), ACT[act](), nn.Linear(dim_h, dim_h))
-            self.local_model = OracleGINEConv(gin_nn)                       # :62-69
+            self.local_model = OracleGINEConv(gin_nn, equivstable_pe=equivstable_pe)   # :62-69
         elif local_gnn_type == "CustomGatedGCN":
-            self.local_model = OracleGatedGCNLayer(dim_h, dim_h, dropout=dropout,
-                                                   residual=True, act=act)  # :91-96
+            self.local_model = OracleGatedGCNLayer(dim_h, dim_h, dropout=dropout, residual=True,
+                                                   act=act, equivstable_pe=equivstable_pe)  # :91-96
         else:
             raise ValueError(f"Unsupported local GNN model: {local_gnn_type}")
         if global_model_type == "None":
@@ -266,10 +282,12 @@ class OracleGPSLayer(nn.Module):
         outs = []
         if self.local_model is not None:
             if self.local_gnn_type == "CustomGatedGCN":
-                h_local, e = self.local_model(h, batch.edge_attr, batch.edge_index)  # :164-174
+                pe = batch.pe_EquivStableLapPE if self.equivstable_pe else None
+                h_local, e = self.local_model(h, batch.edge_attr, batch.edge_index, pe)  # :164-174
                 batch.edge_attr = e
             else:
-                h_local = self.local_model(h, batch.edge_index, batch.edge_attr)     # :183-185
+                pe = batch.pe_EquivStableLapPE if self.equivstable_pe else None
+                h_local = self.local_model(h, batch.edge_index, batch.edge_attr, pe)  # :177-185
                 h_local = self.dropout_local(h_local)
                 h_local = h_in1 + h_local                                            # :188-189
             if self.batch_norm:

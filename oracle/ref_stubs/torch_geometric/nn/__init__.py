@@ -18,3 +18,14 @@ class _Norm:
 
 
 norm = _Norm
+
+
+class inits:  # noqa: N801  (module-like namespace: torch_geometric.nn.inits)
+    @staticmethod
+    def reset(value):
+        """PyG ``inits.reset``: reset_parameters() on the module, else recursively on its children."""
+        if hasattr(value, 'reset_parameters'):
+            value.reset_parameters()
+        else:
+            for child in value.children() if hasattr(value, 'children') else []:
+                inits.reset(child)

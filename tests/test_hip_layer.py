@@ -20,8 +20,14 @@ def _run_layer(layer, fix, dev):
     e = fix["edge_attr"].to(dev).requires_grad_(True)
     b = Batch(x=x, edge_index=fix["edge_index"].to(dev), edge_attr=e, batch=fix["batch"].to(dev),
               ptr=fix["ptr"].to(dev))
+    pe = None
+    if "pe" in fix:                       # EquivStableLapPE fixtures
+        pe = fix["pe"].to(dev).requires_grad_(True)
+        b.pe_EquivStableLapPE = pe
     out = layer(b)
     ((out.x * fix["wx"].to(dev)).sum() + (out.edge_attr * fix["we"].to(dev)).sum()).backward()
+    if pe is not None:
+        assert_close(pe.grad, fix["grad_pe"], Tol.GRAD_REL, "grad pe", rel_to_max=True)
     return out, x, e
 
 
@@ -52,8 +58,11 @@ def _check_against_fixture(name):
             assert_close(after[k], v, Tol.ACT, f"state {k}")
     layer.eval()
     with torch.no_grad():
-        ob = layer(Batch(x=fix["x"].to(dev), edge_index=fix["edge_index"].to(dev),
-                         edge_attr=fix["edge_attr"].to(dev), batch=fix["batch"].to(dev)))
+        eb = Batch(x=fix["x"].to(dev), edge_index=fix["edge_index"].to(dev),
+                   edge_attr=fix["edge_attr"].to(dev), batch=fix["batch"].to(dev))
+        if "pe" in fix:
+            eb.pe_EquivStableLapPE = fix["pe"].to(dev)
+        ob = layer(eb)
     assert_close(ob.x, fix["eval_out_x"], Tol.ACT, "eval out.x")
     assert_close(ob.edge_attr, fix["eval_out_edge_attr"], Tol.ACT, "eval out.edge_attr")
 
@@ -294,10 +303,12 @@ def _ragged_batch(sizes, d, seed, isolated=()):
     return b
 
 
-@pytest.mark.parametrize("local,glob,d,H", [("CustomGatedGCN", "Transformer", 32, 4),    # block path
-                                            ("GINE", "Transformer", 48, 2),              # operator path
-                                            ("CustomGatedGCN", "Performer", 64, 1)])
-def test_gpslayer_ragged_and_boundary_graph_sizes(local, glob, d, H):
+@pytest.mark.parametrize("local,glob,d,H,es", [("CustomGatedGCN", "Transformer", 32, 4, False),   # block path
+                                               ("GINE", "Transformer", 48, 2, False),            # operator path
+                                               ("CustomGatedGCN", "Performer", 64, 1, False),
+                                               ("CustomGatedGCN", "Transformer", 32, 4, True),   # EquivStableLapPE gate
+                                               ("GINE", "Transformer", 48, 2, True)])
+def test_gpslayer_ragged_and_boundary_graph_sizes(local, glob, d, H, es):
     """Graph sizes straddling every tile boundary of the kernels (1, 2, 15..17, 31..33, 63..65, 129),
     single-node graphs, a graph made of isolated nodes, the last graph ending exactly at N: outputs and
     gradients of one training-mode layer vs the oracle."""
@@ -305,21 +316,27 @@ def test_gpslayer_ragged_and_boundary_graph_sizes(local, glob, d, H):
     sizes = [1, 17, 2, 16, 33, 1, 15, 64, 31, 65, 32, 63, 129, 5, 1]
     dev = torch.device("cuda:0")
     torch.manual_seed(3)
-    layer = GPSLayer(d, local, glob, H, dropout=0.0, attn_dropout=0.0)
+    layer = GPSLayer(d, local, glob, H, dropout=0.0, attn_dropout=0.0, equivstable_pe=es)
     oracle = _oracle_layer_like(layer).train()
     layer.to(dev).train()
     b = _ragged_batch(sizes, d, seed=9, isolated=(13,))
     gen = torch.Generator().manual_seed(6)
+    if es:
+        b.pe_EquivStableLapPE = torch.randn(b.x.shape[0], d, generator=gen) * 0.5
     wx, we = torch.randn(b.x.shape, generator=gen), torch.randn(b.edge_attr.shape, generator=gen)
     bc = b.clone()
     bc.x.requires_grad_(True); bc.edge_attr.requires_grad_(True)
     xo, eo = bc.x, bc.edge_attr
+    if es:
+        bc.pe_EquivStableLapPE = bc.pe_EquivStableLapPE.clone().requires_grad_(True)
     oo = oracle(bc)
     loss_o = (oo.x * wx).sum() + ((oo.edge_attr * we).sum() if local == "CustomGatedGCN" else 0.0)
     loss_o.backward()
     bg = b.clone().to(dev)
     bg.x.requires_grad_(True); bg.edge_attr.requires_grad_(True)
     xg, eg = bg.x, bg.edge_attr
+    if es:
+        bg.pe_EquivStableLapPE = bg.pe_EquivStableLapPE.clone().requires_grad_(True)
     og = layer(bg)
     loss_g = (og.x * wx.to(dev)).sum() + ((og.edge_attr * we.to(dev)).sum() if local == "CustomGatedGCN" else 0.0)
     loss_g.backward()
@@ -327,6 +344,9 @@ def test_gpslayer_ragged_and_boundary_graph_sizes(local, glob, d, H):
     assert_close(og.edge_attr, oo.edge_attr, Tol.ACT, "out.edge_attr")
     assert_close(xg.grad, xo.grad, Tol.GRAD_REL, "grad x", rel_to_max=True)
     assert_close(eg.grad, eo.grad, Tol.GRAD_REL, "grad edge_attr", rel_to_max=True)
+    if es:
+        assert_close(bg.pe_EquivStableLapPE.grad, bc.pe_EquivStableLapPE.grad, Tol.GRAD_REL, "grad pe",
+                     rel_to_max=True)
     op = dict(oracle.named_parameters())
     gscale = max(float(q.grad.abs().max()) for q in op.values() if q.grad is not None)
     for k, p in layer.named_parameters():

@@ -18,8 +18,14 @@ def test_oracle_matches_reference_fixture(name):
     x = fix["x"].clone().requires_grad_(True)
     e = fix["edge_attr"].clone().requires_grad_(True)
     b = Batch(x=x, edge_index=fix["edge_index"], edge_attr=e, batch=fix["batch"], ptr=fix["ptr"])
+    pe = None
+    if "pe" in fix:                       # EquivStableLapPE fixtures carry the PE input and its gradient
+        pe = fix["pe"].clone().requires_grad_(True)
+        b.pe_EquivStableLapPE = pe
     out = layer(b)
     ((out.x * fix["wx"]).sum() + (out.edge_attr * fix["we"]).sum()).backward()
+    if pe is not None:
+        assert_close(pe.grad, fix["grad_pe"], Tol.GRAD_REL, "grad pe", rel_to_max=True)
     assert_close(out.x, fix["out_x"], Tol.ACT, "out.x")
     assert_close(out.edge_attr, fix["out_edge_attr"], Tol.ACT, "out.edge_attr")
     assert_close(x.grad, fix["grad_x"], Tol.GRAD_REL, "grad x", rel_to_max=True)
@@ -36,8 +42,11 @@ def test_oracle_matches_reference_fixture(name):
             assert torch.equal(after[k], v), k
     layer.eval()
     with torch.no_grad():
-        ob = layer(Batch(x=fix["x"], edge_index=fix["edge_index"], edge_attr=fix["edge_attr"],
-                         batch=fix["batch"], ptr=fix["ptr"]))
+        eb = Batch(x=fix["x"], edge_index=fix["edge_index"], edge_attr=fix["edge_attr"],
+                   batch=fix["batch"], ptr=fix["ptr"])
+        if "pe" in fix:
+            eb.pe_EquivStableLapPE = fix["pe"]
+        ob = layer(eb)
     assert_close(ob.x, fix["eval_out_x"], Tol.ACT, "eval out.x")
     assert_close(ob.edge_attr, fix["eval_out_edge_attr"], Tol.ACT, "eval out.edge_attr")
 
