@@ -192,11 +192,13 @@ class _GatedGCNAggregate(torch.autograd.Function):
         if r is not None and ctx.needs_input_grad[3]:
             # g_r[e] = sum_c g_sigma'[e,c] * sigma[e,c],  g_sigma' = a_i * Bx_j + b_i  (a, b as in the kernel).
             # A per-edge channel reduction: plain gathers + a row sum (rare option, [E,d] temporaries)
+            # (fp64: a * Bx_j + b cancels, and this scalar feeds a 1 -> d -> 1 MLP's gradients)
             src, dst = gi.edge_src, gi.edge_dst
-            a = g_x / (den + 1e-6)
-            bterm = -a * aggr
-            gs = a.index_select(0, dst) * proj[:, d:2 * d].index_select(0, src) + bterm.index_select(0, dst)
-            g_r = (gs * torch.sigmoid(e_hat)).sum(-1)
+            a = g_x.double() / (den.double() + 1e-6)
+            bterm = -a * aggr.double()
+            gs = a.index_select(0, dst) * proj[:, d:2 * d].double().index_select(0, src) \
+                + bterm.index_select(0, dst)
+            g_r = (gs * torch.sigmoid(e_hat.double())).sum(-1).float()
         return g_proj, g_ce, None, g_r
 
 
@@ -246,7 +248,8 @@ class _GINEAggregate(torch.autograd.Function):
         g_r = None
         if r is not None and ctx.needs_input_grad[4]:
             src, dst = gi.edge_src, gi.edge_dst
-            g_r = (g_out.index_select(0, dst) * (x.index_select(0, src) + e).relu()).sum(-1)
+            g_r = (g_out.double().index_select(0, dst)
+                   * (x.index_select(0, src) + e).relu().double()).sum(-1).float()
         return g_x, g_e, None, None, g_r
 
 
