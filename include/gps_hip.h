@@ -305,6 +305,18 @@ int gps_bn_bwd_pair(const float* zA, const float* gA, const gps_bn* bnA, int64_t
                     float* g_betaB, int d, int relu, float p, float* ws, gps_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Random-walk structural encoding: out[v][k - kmin] = (P^k)[v][v] * k^(space_dim/2), P = D^-1 A per graph,
+ * for every graph of a batch in one launch (one workgroup per graph, P in LDS up to gps_rwse_lds_nodes()
+ * nodes, else in `scratch` at float offset scratch_off[g], 3 n^2 floats per such graph).
+ * Replaces graphgps/transform/posenc_stats.py:184-230 (get_rw_landing_probs; CPU, per graph).
+ * `rowptr_src`/`dst_by_src` = the by-source CSR of gps_graph_index_build, `ptr` the graph offsets.
+ * ------------------------------------------------------------------------------------- */
+int gps_rwse_lds_nodes(void);
+int gps_rwse(const int32_t* rowptr_src, const int32_t* dst_by_src, const int32_t* ptr, int64_t B, int64_t N,
+             int kmin, int kmax, float space_dim, float* scratch, const int64_t* scratch_off, float* out,
+             gps_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * Optimizer side of the step: gradient-norm clip + AdamW over a flat fp32 parameter arena.
  * Replaces torch.nn.utils.clip_grad_norm_(model.parameters(), cfg.optim.clip_grad_norm_value)
  * followed by optimizer.step() (graphgps/train/custom_train.py:33-37) for the optimizer

@@ -465,3 +465,60 @@ def test_gemm_nt_bf16_split(R, K, M):
     plain = torch.empty(R, M, device=dev)
     check(L.gps_gemm_nt(ptr(a), K, ptr(b), K, R, M, K, None, None, 0, ptr(plain), M, current_stream(dev)))
     assert_close(plain, a.double() @ b.double().t(), Tol.GRAD_REL, "A B^T", rel_to_max=True)
+
+
+def _rw_landing_probs_ref(ksteps, edge_index, num_nodes, space_dim=0):
+    """graphgps/transform/posenc_stats.py:184-230 restated with plain dense torch ops in fp64 (the
+    reference uses torch_scatter.scatter + PyG to_dense_adj, absent here: multi-edges ADD in the dense
+    adjacency, out-degree normalisation, 1/0 -> 0)."""
+    src, dst = edge_index[0], edge_index[1]
+    A = torch.zeros(num_nodes, num_nodes, dtype=torch.float64)
+    A.index_put_((src, dst), torch.ones(src.numel(), dtype=torch.float64), accumulate=True)
+    deg = torch.zeros(num_nodes, dtype=torch.float64).index_add_(0, src, torch.ones(src.numel(), dtype=torch.float64))
+    deg_inv = deg.pow(-1.0)
+    deg_inv[deg_inv == float("inf")] = 0
+    P = torch.diag(deg_inv) @ A
+    rws = []
+    Pk = torch.linalg.matrix_power(P, min(ksteps))
+    for k in range(min(ksteps), max(ksteps) + 1):
+        rws.append(torch.diagonal(Pk) * (k ** (space_dim / 2)))
+        Pk = Pk @ P
+    full = torch.stack(rws, 1)
+    return full[:, [k - min(ksteps) for k in ksteps]]
+
+
+@pytest.mark.parametrize("ksteps,space_dim", [(list(range(1, 17)), 0), (list(range(1, 21)), 0),
+                                              ([2, 3, 4], 2.0), ([1, 4, 9], 0)])
+def test_rwse_landing_probabilities(ksteps, space_dim):
+    """Batched RWSE kernel vs the per-graph restatement of get_rw_landing_probs: molecule-like graphs,
+    a single-node graph, isolated nodes, a multi-edge, a directed (asymmetric) edge, and one graph larger
+    than the LDS limit (global-scratch path)."""
+    from graphgps_amd.transform import rw_landing_probs
+    dev = torch.device("cuda:0")
+    b = _ragged_batch_ops([1, 17, 2, 33, 5, 64, 140, 9], seed=4)
+    ei, ptr = b["edge_index"], b["ptr"]
+    got = rw_landing_probs(ksteps, ei.to(dev), ptr.to(dev), space_dim=space_dim).cpu()
+    assert got.shape == (int(ptr[-1]), len(ksteps))
+    for g in range(len(ptr) - 1):
+        n0, n1 = int(ptr[g]), int(ptr[g + 1])
+        m = (ei[0] >= n0) & (ei[0] < n1)
+        ref = _rw_landing_probs_ref(ksteps, ei[:, m] - n0, n1 - n0, space_dim)
+        assert_close(got[n0:n1], ref, 1e-6, f"graph {g} (n={n1 - n0})")
+
+
+def _ragged_batch_ops(sizes, seed):
+    gen = torch.Generator().manual_seed(seed)
+    src, dst, ptr = [], [], [0]
+    for gi, n in enumerate(sizes):
+        base = ptr[-1]
+        for v in range(1, n):
+            if gi == 4 and v == n - 1:
+                continue                                   # leaves an isolated node in graph 4
+            u = int(torch.randint(max(0, v - 4), v, (1,), generator=gen))
+            src += [base + u, base + v]
+            dst += [base + v, base + u]
+        if n > 5:
+            src += [base, base + n - 1, base, base + 1]    # chord both ways + a multi-edge + one directed edge
+            dst += [base + n - 1, base, base + 1, base + 3]
+        ptr.append(base + n)
+    return dict(edge_index=torch.tensor([src, dst], dtype=torch.int64), ptr=torch.tensor(ptr, dtype=torch.int64))
