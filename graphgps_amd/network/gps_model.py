@@ -13,7 +13,7 @@ from ..graphgym import register
 from ..graphgym.config import cfg
 from ..graphgym.layers import GNNPreMP
 from ..graphgym.register import register_network
-from ..head import ogb_code_graph as _h1, san_graph as _h2  # noqa: F401
+from ..head import inductive_node as _h0, ogb_code_graph as _h1, san_graph as _h2  # noqa: F401
 from ..layer.gps_layer import GPSLayer
 
 
