@@ -11,6 +11,12 @@ gradient all-reduce (N > 1) -> grad-clip + AdamW step, i.e. the whole of the ref
 train_epoch body (graphgps/train/custom_train.py:22-39) minus logging.  Dropout is ON
 (0.1 / 0.1 as in configs/GPS/pcqm4m-GPSmedium+RWSE.yaml).  Weak scaling: per-GPU work is fixed.
 
+How the step is driven (graphgps_amd/train.py: TrainStep): flat-arena clip+AdamW; for N > 1 ONE RCCL
+all-reduce of the flat gradient arena between [index + fwd + bwd + pack] and [clip + AdamW]; the step is
+launched eagerly or replayed from hipGraph(s), whichever of the two measures faster on 6 untimed trial
+steps after the warm-up (--launch auto; every rank takes the same decision).  rocBLAS / hipBLASLt GEMM
+solutions are picked per shape by TunableOp during the warm-up and frozen before the timed region.
+
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline      the GatedGCN gather-gate-segment-reduce forward kernel (HBM-bound): algorithmic
                 bytes (8*E*d + 20*N*d + CSR index bytes) / mean launch

@@ -31,3 +31,27 @@ for k, ks in by.items():
           f"gaps<100us: {sum(small)/1e6/a.steps:.2f} ms/step over {len(small)/a.steps:.0f} gaps "
           f"(mean {sum(small)/max(len(small),1)/1e3:.2f} us); overlap(neg gaps) {sum(1 for g in gaps if g<=0)/a.steps:.0f}/step")
     print("   gap histogram (us: count/step):", {f"{b}": round(n / a.steps, 1) for b, n in sorted(hist.items())})
+
+# ---- GPU-wide idle time: union of all kernel intervals vs the span they cover -------------------
+iv = sorted((s, e) for s, e, _ in ((r[1], r[2], 0) for r in rows))
+# keep only the steady-state tail: last 60 % of dispatches (skips tuning / capture / warm-up)
+iv = iv[int(len(iv) * 0.4):]
+span = iv[-1][1] - iv[0][0]
+covered, cur_s, cur_e = 0, iv[0][0], iv[0][1]
+idle_hist = defaultdict(int)
+idle_ns = defaultdict(int)
+for s, e in iv[1:]:
+    if s > cur_e:
+        covered += cur_e - cur_s
+        g = s - cur_e
+        b = min(int(g // 2000) * 2, 40)
+        idle_hist[b] += 1
+        idle_ns[b] += g
+        cur_s, cur_e = s, e
+    else:
+        cur_e = max(cur_e, e)
+covered += cur_e - cur_s
+print(f"GPU-wide (steady-state tail): span {span/1e6:.2f} ms, some kernel running {covered/1e6:.2f} ms "
+      f"({100*covered/span:.1f} %), idle {100*(span-covered)/span:.1f} %")
+print("   idle-gap histogram (us bucket: count, total ms):",
+      {f"{b}-{b+2}": (n, round(idle_ns[b] / 1e6, 2)) for b, n in sorted(idle_hist.items())})
