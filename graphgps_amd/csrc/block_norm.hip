@@ -289,6 +289,8 @@ struct BwdTask {
   float* g_z;            // primary input gradient
   float* g_sum;          // dual: g_z + g_z2
   float* g_drop;         // dropmask(seed2, p2) of g_z (dual: of g_z2), or nullptr
+  float p1x;             // dual only: dropout (p1x, seed1x) applied to the STORED g_z (g_sum stays unmasked)
+  uint64_t seed1x;
   int64_t R;
   uint64_t seed, seed2;
   float p, p2;
@@ -428,7 +430,7 @@ __global__ __launch_bounds__(256) void k_bwd_finalize(const BwdGroup G) {
 
 template <bool RELU, bool DROP, bool DUAL>
 __device__ __forceinline__ void run_bwd_apply(const BwdTask& T, int d, int64_t row, int c, uint64_t seed,
-                                              uint64_t seed2) {
+                                              uint64_t seed2, uint64_t seed1x = 0) {
   const V4 v = V4::load(T.z + row * d + c);
   const V4 gy = V4::load(T.g_y + row * d + c);
   const Col c1 = load_col(T.bn, c);
@@ -439,7 +441,16 @@ __device__ __forceinline__ void run_bwd_apply(const BwdTask& T, int d, int64_t r
   out_grad<RELU, DROP>(v, gy, c1, DROP ? row_hash((uint32_t)row, seed) : 0u, c, T.p, inv_keep, g, zh);
 #pragma unroll
   for (int j = 0; j < 4; ++j) o[j] = c1.ga[j] * c1.rs[j] * (g[j] - s1[j] * inv_n - zh[j] * s2[j] * inv_n);
-  o.store(T.g_z + row * d + c);
+  if (DUAL && T.p1x > 0.0f) {
+    const uint32_t rh1 = row_hash((uint32_t)row, seed1x);
+    const float ik1 = 1.0f / (1.0f - T.p1x);
+    V4 om;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) om[j] = keep_elem(rh1, (uint32_t)(c + j), T.p1x) ? o[j] * ik1 : 0.0f;
+    om.store(T.g_z + row * d + c);
+  } else {
+    o.store(T.g_z + row * d + c);
+  }
   V4 last = o;
   if (DUAL) {
     const V4 v2 = V4::load(T.z2 + row * d + c);
@@ -481,7 +492,10 @@ __global__ __launch_bounds__(256) void k_bwd_apply(const BwdGroup G) {
   const int c = (int)(t - row * L) * 4;
   const uint64_t seed = gps::salted_seed(T.seed, G.salt), seed2 = gps::salted_seed(T.seed2, G.salt);
   const bool drop = T.p > 0.0f;
-  if (T.z2) { run_bwd_apply<false, false, true>(T, d, row, c, seed, seed2); return; }
+  if (T.z2) {
+    run_bwd_apply<false, false, true>(T, d, row, c, seed, seed2, gps::salted_seed(T.seed1x, G.salt));
+    return;
+  }
   if (T.relu) {
     if (drop) run_bwd_apply<true, true, false>(T, d, row, c, seed, seed2);
     else run_bwd_apply<true, false, false>(T, d, row, c, seed, seed2);
@@ -652,6 +666,22 @@ int gps_add_drop_stats(const float* a, const float* b, int64_t R, int d, float p
   return launch_fwd(P, gps::as_stream(stream), "gps_add_drop_stats");
 }
 
+int gps_add_drop_stats_pair(const float* a1, const float* b1, float p1, uint64_t seed1, float* out1,
+                            const gps_bn* bn1, const float* a2, const float* b2, float p2, uint64_t seed2,
+                            float* out2, const gps_bn* bn2, int64_t R, int d, float* ws, gps_stream_t stream) {
+  if (int rc = check_common("gps_add_drop_stats_pair", R, d)) return rc;
+  if (int rc = check_bn("gps_add_drop_stats_pair", bn1, true)) return rc;
+  if (int rc = check_bn("gps_add_drop_stats_pair", bn2, true)) return rc;
+  GPS_REQUIRE(a1 && b1 && out1 && a2 && b2 && out2 && ws && al16(a1) && al16(b1) && al16(out1) && al16(a2) &&
+                  al16(b2) && al16(out2) && al16(ws) && p1 >= 0.f && p1 < 1.f && p2 >= 0.f && p2 < 1.f,
+              "gps_add_drop_stats_pair: bad arguments");
+  FwdPlan P{};
+  P.g.d = d;
+  add_fwd(P, K_ADD_DROP, a1, b1, nullptr, nullptr, nullptr, 0, p1, seed1, out1, R, bn1, ws);
+  add_fwd(P, K_ADD_DROP, a2, b2, nullptr, nullptr, nullptr, 0, p2, seed2, out2, R, bn2, ws);
+  return launch_fwd(P, gps::as_stream(stream), "gps_add_drop_stats_pair");
+}
+
 int gps_bn_bwd_drop(const float* z, const float* g_y, const gps_bn* bn, int64_t R, int d, int relu, float p,
                     uint64_t seed, float* g_z, float* g_gamma, float* g_beta, float p2, uint64_t seed2,
                     float* g_drop, float* ws, gps_stream_t stream) {
@@ -670,7 +700,8 @@ int gps_bn_bwd_drop(const float* z, const float* g_y, const gps_bn* bn, int64_t 
 }
 
 int gps_bn_dual_bwd(const float* z1, const gps_bn* bn1, const float* z2, const gps_bn* bn2, const float* g_y,
-                    int64_t R, int d, float* g_z1, float* g_sum, float p2, uint64_t seed2, float* g_drop2,
+                    int64_t R, int d, float* g_z1, float p1, uint64_t seed1, float* g_sum, float p2,
+                    uint64_t seed2, float* g_drop2,
                     float* g_gamma1, float* g_beta1, float* g_gamma2, float* g_beta2, float* ws,
                     gps_stream_t stream) {
   if (int rc = check_common("gps_bn_dual_bwd", R, d)) return rc;
@@ -687,6 +718,8 @@ int gps_bn_dual_bwd(const float* z1, const gps_bn* bn1, const float* z2, const g
   int64_t threads = 0;
   add_bwd(G, blocks, fin, threads, z1, g_y, bn1, 0, 0.f, 0, z2, bn2, g_beta1, g_gamma1, g_beta2, g_gamma2,
           g_z1, g_sum, g_drop2, p2, seed2, R, ws);
+  G.t[0].p1x = p1;
+  G.t[0].seed1x = seed1;
   return launch_bwd(G, blocks, fin, threads, gps::as_stream(stream), "gps_bn_dual_bwd");
 }
 

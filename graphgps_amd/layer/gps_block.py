@@ -312,7 +312,7 @@ class _GPSBlock(torch.autograd.Function):
 
         # h = BN_l(x1) + BN_a(za);  za = x + drop(ao):  g_x1, g_x1 + g_za, g_ao = dropmask(g_za)
         g_x1, g_xres, g_ao = _E(N, d, **f32), _E(N, d, **f32), _E(N, d, **f32)
-        check(L.gps_bn_dual_bwd(ptr(x1), ref(bnl), ptr(za), ref(bna), ptr(g_h), N, d, ptr(g_x1),
+        check(L.gps_bn_dual_bwd(ptr(x1), ref(bnl), ptr(za), ref(bna), ptr(g_h), N, d, ptr(g_x1), 0.0, 0,
                                 ptr(g_xres), p_l, s[3], ptr(g_ao), ptr(g_nlw), ptr(g_nlb), ptr(g_naw),
                                 ptr(g_nab), ptr(ws), st), "gps_bn_dual_bwd")
         # gradient of the merged projection: attention writes dq|dk|dv into columns 4d.., GatedGCN
@@ -358,6 +358,177 @@ class _GPSBlock(torch.autograd.Function):
         return (g_x, g_e, None, None, None,
                 *abde, g_wc, g_bc, g_bxw, g_bxb, g_bew, g_beb, g_nlw, g_nlb,
                 g_wi, g_bi, g_wo, g_bo, g_naw, g_nab, g_w1, g_b1, g_w2, g_b2, g_n2w, g_n2b)
+
+
+class _GPSBlockGINE(torch.autograd.Function):
+    """The same single-node treatment for ``GINE+Transformer`` blocks (zinc-GPS+RWSE.yaml and most
+    configs/GPS/*.yaml): GINE core -> its 2-layer MLP, attention, both residual+dropout+norm stages as
+    one task list, dual apply, FFN + norm2.  GINE does not update ``edge_attr``
+    (graphgps/layer/gps_layer.py:176-189)."""
+
+    @staticmethod
+    def forward(ctx, x, e, layer, gi: GraphIndex, seed: int, *params):
+        L = _lib.load()
+        dev = x.device
+        st = current_stream(dev)
+        lm, sa = layer.local_model, layer.self_attn
+        lin1, lin2 = lm.nn[0], lm.nn[2]
+        N, d = x.shape
+        E = e.shape[0]
+        H = layer.num_heads
+        dh = d // H
+        p_loc, p_l = float(layer.dropout_local.p), float(layer.dropout_attn.p)
+        p_f1, p_f2 = float(layer.ff_dropout1.p), float(layer.ff_dropout2.p)
+        p_at = float(layer.attn_dropout)
+        s = [(seed + 0x9E3779B97F4A7C15 * (i + 1)) & 0xFFFFFFFFFFFFFFFF for i in range(7)]
+        f32 = dict(dtype=torch.float32, device=dev)
+        ref = _BY_REF
+
+        # -- attention half (forked while capturing) ------------------------------------------------
+        with _Fork(dev, _BRANCH) as fork:
+            sb = current_stream(dev)
+            qkv = torch.addmm(sa.in_proj_bias, x, sa.in_proj_weight.t())
+            o, lse = _E(N, d, **f32), _E(H, N, **f32)
+            scale = float(dh) ** -0.5
+            check(L.gps_seg_attn_fwd(ptr(qkv), 3 * d, ptr(gi.ptr), ptr(gi.tile_graph), ptr(gi.tile_row0),
+                                     gi.max_tiles, N, H, dh, scale, p_at, s[2], ptr(o), ptr(lse), sb),
+                  "gps_seg_attn_fwd")
+            ao = torch.addmm(sa.out_proj.bias, o, sa.out_proj.weight.t())
+        # -- local half: GINE core + MLP (gps_layer.py:62-69,183-185) -------------------------------
+        agg = _E(N, d, **f32)
+        check(L.gps_gine_fwd(ptr(x), ptr(e), ptr(gi.rowptr_dst), ptr(gi.src_by_dst), ptr(gi.eid_by_dst),
+                             N, E, d, float(lm.initial_eps), ptr(agg), None, st), "gps_gine_fwd")
+        g1 = torch.addmm(lin1.bias, agg, lin1.weight.t())
+        g1r = _K.act_drop_add(L, None, g1, True, 0.0, 0, st)
+        g2 = torch.addmm(lin2.bias, g1r, lin2.weight.t())
+        fork.join(qkv, o, lse, ao)
+
+        # -- zl = x + drop(g2), za = x + drop(ao) with their statistics; h = BN_l(zl) + BN_a(za) -----
+        stats = _E(6, d, **f32)
+        ws = _E(L.gps_block_norm_workspace_floats(N, max(E, 1), d), **f32)
+        bnl = _bn_desc(layer.norm1_local, stats[0], stats[1])
+        bna = _bn_desc(layer.norm1_attn, stats[2], stats[3])
+        bn2 = _bn_desc(layer.norm2, stats[4], stats[5])
+        zl, za = _E(N, d, **f32), _E(N, d, **f32)
+        check(L.gps_add_drop_stats_pair(ptr(x), ptr(g2), p_loc, s[0], ptr(zl), ref(bnl), ptr(x), ptr(ao),
+                                        p_l, s[3], ptr(za), ref(bna), N, d, ptr(ws), st),
+              "gps_add_drop_stats_pair")
+        h = _E(N, d, **f32)
+        check(L.gps_bn_dual_apply(ptr(zl), ref(bnl), ptr(za), ref(bna), N, d, ptr(h), st),
+              "gps_bn_dual_apply")
+        # -- FFN + norm2 --------------------------------------------------------------------------------
+        f1 = torch.addmm(layer.ff_linear1.bias, h, layer.ff_linear1.weight.t())
+        t = _K.act_drop_add(L, None, f1, True, p_f1, s[4], st)
+        f2 = torch.addmm(layer.ff_linear2.bias, t, layer.ff_linear2.weight.t())
+        z2 = _E(N, d, **f32)
+        check(L.gps_add_drop_stats(ptr(h), ptr(f2), N, d, p_f2, s[5], ptr(z2), ref(bn2), ptr(ws), st),
+              "gps_add_drop_stats")
+        out = _K.bn_apply(L, z2, stats[4], stats[5], layer.norm2, None, False, 0.0, 0, st)
+        torch._foreach_add_([layer.norm1_local.num_batches_tracked, layer.norm1_attn.num_batches_tracked,
+                             layer.norm2.num_batches_tracked], 1)
+        ctx.save_for_backward(x, e, agg, g1, g1r, qkv, o, lse, zl, za, h, f1, t, z2, stats)
+        ctx.layer, ctx.gi, ctx.seeds = layer, gi, s
+        ctx.cfg = (p_loc, p_l, p_f1, p_f2, p_at, H, dh, scale)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out):
+        L = _lib.load()
+        x, e, agg, g1, g1r, qkv, o, lse, zl, za, h, f1, t, z2, stats = ctx.saved_tensors
+        layer, gi, s = ctx.layer, ctx.gi, ctx.seeds
+        p_loc, p_l, p_f1, p_f2, p_at, H, dh, scale = ctx.cfg
+        lm, sa = layer.local_model, layer.self_attn
+        lin1, lin2 = lm.nn[0], lm.nn[2]
+        dev = x.device
+        st = current_stream(dev)
+        N, d = x.shape
+        E = e.shape[0]
+        f32 = dict(dtype=torch.float32, device=dev)
+        ref = _BY_REF
+        g_out = g_out.contiguous()
+        ws = _E(L.gps_block_norm_workspace_floats(N, max(E, 1), d), **f32)
+        bnl = _bn_desc(layer.norm1_local, stats[0], stats[1])
+        bna = _bn_desc(layer.norm1_attn, stats[2], stats[3])
+        bn2 = _bn_desc(layer.norm2, stats[4], stats[5])
+        gpar = _E(6, d, **f32)
+        g_nlw, g_nlb, g_naw, g_nab, g_n2w, g_n2b = gpar.unbind(0)
+
+        g_z2, g_f2 = _E(N, d, **f32), _E(N, d, **f32)
+        check(L.gps_bn_bwd_drop(ptr(z2), ptr(g_out), ref(bn2), N, d, 0, 0.0, 0, ptr(g_z2), ptr(g_n2w),
+                                ptr(g_n2b), p_f2, s[5], ptr(g_f2), ptr(ws), st), "gps_bn_bwd_drop")
+        g_t = g_f2.mm(layer.ff_linear2.weight)
+        g_f1 = _K.act_drop_bwd(L, g_t, f1, True, p_f1, s[4], st)
+        g_h = g_z2.addmm_(g_f1, layer.ff_linear1.weight)
+        # g_g2 = dropmask_local(g_zl), g_xres = g_zl + g_za, g_ao = dropmask_attn(g_za)
+        g_g2, g_xres, g_ao = _E(N, d, **f32), _E(N, d, **f32), _E(N, d, **f32)
+        check(L.gps_bn_dual_bwd(ptr(zl), ref(bnl), ptr(za), ref(bna), ptr(g_h), N, d, ptr(g_g2), p_loc,
+                                s[0], ptr(g_xres), p_l, s[3], ptr(g_ao), ptr(g_nlw), ptr(g_nlb),
+                                ptr(g_naw), ptr(g_nab), ptr(ws), st), "gps_bn_dual_bwd")
+        with _Fork(dev, _BRANCH) as fork:            # attention half
+            sb = current_stream(dev)
+            g_o = g_ao.mm(sa.out_proj.weight)
+            g_qkv, delta = _E(N, 3 * d, **f32), _E(H, N, **f32)
+            check(L.gps_seg_attn_bwd(ptr(g_o), ptr(qkv), 3 * d, ptr(o), ptr(lse), ptr(gi.ptr),
+                                     ptr(gi.tile_graph), ptr(gi.tile_row0), gi.max_tiles, N, H, dh, scale,
+                                     p_at, s[2], ptr(delta), ptr(g_qkv), 3 * d, sb), "gps_seg_attn_bwd")
+        # local half: MLP backward, GINE core backward
+        g_g1r = g_g2.mm(lin2.weight)
+        g_g1 = _K.act_drop_bwd(L, g_g1r, g1, True, 0.0, 0, st)
+        g_agg = g_g1.mm(lin1.weight)
+        g_xg, g_e = _E(N, d, **f32), _E(E, d, **f32)
+        check(L.gps_gine_bwd(ptr(g_agg), ptr(x), ptr(e), ptr(gi.rowptr_dst), ptr(gi.src_by_dst),
+                             ptr(gi.eid_by_dst), ptr(gi.rowptr_src), ptr(gi.eid_by_src), N, E, d,
+                             float(lm.initial_eps), ptr(g_xg), ptr(g_e), None, st), "gps_gine_bwd")
+        fork.join(g_qkv)
+        pairs = [(g_qkv, x), (g_ao, o), (g_g2, g1r), (g_g1, agg), (g_f1, h), (g_f2, t)]
+        if _GROUPED_WGRAD:
+            grads = _grouped_param_grads(L, pairs)
+        else:
+            grads = [_K.param_grads(L, g, a) for g, a in pairs]
+        (g_wi, g_bi), (g_wo, g_bo), (g_wl2, g_bl2), (g_wl1, g_bl1), (g_w1, g_b1), (g_w2, g_b2) = grads
+        g_x = g_xres.addmm_(g_qkv, sa.in_proj_weight)
+        g_x.add_(g_xg)
+        # order must match block_params_gine()
+        return (g_x, g_e, None, None, None,
+                g_wl1, g_bl1, g_wl2, g_bl2, g_nlw, g_nlb, g_wi, g_bi, g_wo, g_bo, g_naw, g_nab,
+                g_w1, g_b1, g_w2, g_b2, g_n2w, g_n2b)
+
+
+def block_params_gine(layer):
+    lm, sa = layer.local_model, layer.self_attn
+    return [lm.nn[0].weight, lm.nn[0].bias, lm.nn[2].weight, lm.nn[2].bias,
+            layer.norm1_local.weight, layer.norm1_local.bias,
+            sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight, sa.out_proj.bias,
+            layer.norm1_attn.weight, layer.norm1_attn.bias,
+            layer.ff_linear1.weight, layer.ff_linear1.bias,
+            layer.ff_linear2.weight, layer.ff_linear2.bias,
+            layer.norm2.weight, layer.norm2.bias]
+
+
+def gine_block_supported(layer, x, e=None) -> bool:
+    import torch.nn as nn
+    lm = layer.local_model
+    if not (layer.training and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32):
+        return False
+    if layer.local_gnn_type != 'GINE' or layer.global_model_type != 'Transformer' or layer.equivstable_pe:
+        return False
+    if not layer.batch_norm or not isinstance(layer.act_fn_ff, nn.ReLU):
+        return False
+    seq = getattr(lm, "nn", None)
+    if not (isinstance(seq, nn.Sequential) and len(seq) == 3 and isinstance(seq[0], nn.Linear)
+            and isinstance(seq[1], nn.ReLU) and isinstance(seq[2], nn.Linear)):
+        return False
+    for bn in (layer.norm1_local, layer.norm1_attn, layer.norm2):
+        if not (bn.affine and bn.track_running_stats and bn.momentum is not None):
+            return False
+    d = x.shape[1]
+    if d % 4 != 0 or d > 1024 or x.shape[0] < 2 or not x.is_contiguous():
+        return False
+    return e is None or (e.dim() == 2 and e.shape[1] == d and e.is_contiguous())
+
+
+def gps_block_gine(layer, x, e, gi):
+    return _GPSBlockGINE.apply(x, e, layer, gi, draw_dropout_seed(), *block_params_gine(layer))
 
 
 def block_params(layer):

@@ -25,7 +25,7 @@ from ..fused import add_dropout, bn_act, linear, relu_dropout
 from ..ops import graph_index_of, segment_attention
 from .gatedgcn_layer import GatedGCNLayer
 from .gine_conv_layer import GINEConv, GINEConvESLapPE
-from .gps_block import block_supported, gps_block
+from .gps_block import block_supported, gine_block_supported, gps_block, gps_block_gine
 
 import os as _os
 # single-node block path (layer/gps_block.py): merges the A|B|D|E and in-proj GEMMs; measured
@@ -146,6 +146,9 @@ class GPSLayer(nn.Module):
             h, e_new = gps_block(self, h, batch.edge_attr, gi)
             batch.x = h
             batch.edge_attr = e_new
+            return batch
+        if _BLOCK_ENABLED and gine_block_supported(self, h, batch.edge_attr):
+            batch.x = gps_block_gine(self, h, batch.edge_attr, gi)      # GINE leaves edge_attr as is
             return batch
 
         h_local = h_attn = None

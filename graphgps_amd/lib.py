@@ -62,8 +62,10 @@ _SIGNATURES = {
     "gps_add_drop_stats": (c_int, [_P, _P, c_int64, c_int, c_float, c_uint64, _P, _P, _P, _P]),
     "gps_bn_bwd_drop": (c_int, [_P, _P, _P, c_int64, c_int, c_int, c_float, c_uint64, _P, _P, _P, c_float,
                                 c_uint64, _P, _P, _P]),
-    "gps_bn_dual_bwd": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P, _P, c_float, c_uint64, _P, _P, _P,
-                                _P, _P, _P, _P]),
+    "gps_add_drop_stats_pair": (c_int, [_P, _P, c_float, c_uint64, _P, _P, _P, _P, c_float, c_uint64, _P, _P,
+                                        c_int64, c_int, _P, _P]),
+    "gps_bn_dual_bwd": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P, c_float, c_uint64, _P, c_float,
+                                c_uint64, _P, _P, _P, _P, _P, _P, _P]),
     "gps_bn_bwd_pair": (c_int, [_P, _P, _P, c_int64, c_uint64, _P, _P, _P, _P, _P, _P, c_int64, c_uint64,
                                 _P, _P, _P, c_int, c_int, c_float, _P, _P]),
     "gps_rwse_lds_nodes": (c_int, []),

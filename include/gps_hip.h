@@ -292,10 +292,16 @@ int gps_add_drop_stats(const float* a, const float* b, int64_t R, int d, float p
 int gps_bn_bwd_drop(const float* z, const float* g_y, const gps_bn* bn, int64_t R, int d, int relu, float p,
                     uint64_t seed, float* g_z, float* g_gamma, float* g_beta, float p2, uint64_t seed2,
                     float* g_drop, float* ws, gps_stream_t stream);
+/* two of the above in one launch pair (GINE block: zl = x + drop(gin_out), za = x + drop(attn_out)) */
+int gps_add_drop_stats_pair(const float* a1, const float* b1, float p1, uint64_t seed1, float* out1,
+                            const gps_bn* bn1, const float* a2, const float* b2, float p2, uint64_t seed2,
+                            float* out2, const gps_bn* bn2, int64_t R, int d, float* ws, gps_stream_t stream);
 /* backward of out = BN_1(z1) + BN_2(z2) from g_y = dL/d out:
- *   g_z1, g_sum = g_z1 + g_z2, g_drop2 = dropmask(seed2, p2)(g_z2) / (1 - p2)  (g_drop2 may be NULL) */
+ *   g_sum = g_z1 + g_z2;  g_z1 stored as dropmask(seed1, p1)(g_z1) / (1 - p1)  (p1 = 0: plain g_z1);
+ *   g_drop2 = dropmask(seed2, p2)(g_z2) / (1 - p2)  (g_drop2 may be NULL) */
 int gps_bn_dual_bwd(const float* z1, const gps_bn* bn1, const float* z2, const gps_bn* bn2, const float* g_y,
-                    int64_t R, int d, float* g_z1, float* g_sum, float p2, uint64_t seed2, float* g_drop2,
+                    int64_t R, int d, float* g_z1, float p1, uint64_t seed1, float* g_sum, float p2,
+                    uint64_t seed2, float* g_drop2,
                     float* g_gamma1, float* g_beta1, float* g_gamma2, float* g_beta2, float* ws,
                     gps_stream_t stream);
 /* gps_bn_bwd for two row streams (bn_node_x on [RA,d], bn_edge_e on [RB,d]) in one launch triple */

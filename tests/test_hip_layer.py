@@ -231,12 +231,13 @@ def test_block_and_operator_paths_match_fixture(monkeypatch, block):
     the operator-by-operator path (GPS_FUSED_BLOCK=0).  Both must meet the reference fixtures."""
     import graphgps_amd.layer.gps_layer as gl
     monkeypatch.setattr(gl, "_BLOCK_ENABLED", block)
-    calls = []
-    orig = gl.gps_block
+    calls, calls_gine = [], []
+    orig, orig_gine = gl.gps_block, gl.gps_block_gine
     monkeypatch.setattr(gl, "gps_block", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
-    for name in ("gatedgcn_transformer_d32h4", "gatedgcn_transformer_d48h2"):
+    monkeypatch.setattr(gl, "gps_block_gine", lambda *a, **k: (calls_gine.append(1), orig_gine(*a, **k))[1])
+    for name in ("gatedgcn_transformer_d32h4", "gatedgcn_transformer_d48h2", "gine_transformer_d32h2"):
         _check_against_fixture(name)
-    assert bool(calls) == block
+    assert bool(calls) == block and bool(calls_gine) == block
 
 
 @pytest.mark.parametrize("layer_type,residual", [("gatedgcnconv", True), ("gineconv", True),
