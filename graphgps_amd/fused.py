@@ -1,8 +1,12 @@
-"""Fused BatchNorm / ReLU / dropout / residual operators (csrc/bn_fused.hip).
+"""Operators of the modular (operator-by-operator) path around the sparse / attention kernels.
 
-``bn_act``       y = res + dropout(relu(BatchNorm1d(z)))   -- every stage optional
+``bn_act``       y = res + dropout(relu(BatchNorm1d(z)))   -- every stage optional   (csrc/bn_fused.hip)
 ``add_dropout``  out = a + dropout(b)
 ``relu_dropout`` out = dropout(relu(x))
+``linear``       y = x W^T + b with the weight + bias gradient from the split-K MFMA kernel (csrc/wgrad.hip)
+                 on a side HIP stream that joins at the end of backward
+``LinearGroup``  several nn.Linear that share an input evaluated as ONE GEMM over a zero-copy stack of
+                 their weights (the stack is a view of the parameters' own storage)
 
 They stand in for the module chains of the reference (``gatedgcn_layer.py:72-83``,
 ``gps_layer.py:191-194,212-217,225-229,253-257``) in TRAINING mode on the GPU; semantics are

@@ -1,19 +1,27 @@
-"""One autograd node for a whole ``CustomGatedGCN+Transformer`` GPS block (training mode).
+"""One autograd node per GPS block (training mode): ``CustomGatedGCN+Transformer`` (``_GPSBlock``) and
+``GINE+Transformer`` (``_GPSBlockGINE``).
 
-Same arithmetic, same kernels and same kernel order as the operator-by-operator path in
-``gps_layer.py`` / ``gatedgcn_layer.py`` (which stays the general path: evaluation, GINE,
-Performer, non-ReLU activations, ``batch_norm=False``).  What this buys is host time: the
-modular path spends ~18 us of Python/autograd bookkeeping per launch (~100 launches per layer),
-which is as long as the GPU work itself at PCQM4M sizes; here a layer's forward and backward are
-two straight-line Python functions that call the C ABI and rocBLAS directly, with hand-written
-backward formulas (the ones SURVEY.md section 8a lists and the per-operator tests pin).
+Same arithmetic as the operator-by-operator path in ``gps_layer.py`` / ``gatedgcn_layer.py`` /
+``gine_conv_layer.py`` (which stays the general path: evaluation, Performer, EquivStableLapPE, non-ReLU
+activations, ``batch_norm=False``).  A layer's forward and backward are two straight-line Python functions
+that call the C ABI and rocBLAS directly, with hand-written backward formulas (the ones SURVEY.md section 8a
+lists and the per-operator tests pin).  What that buys:
+  * host time: the modular path spends ~18 us of Python/autograd bookkeeping per launch;
+  * merged GEMMs: A|B|D|E and the attention in-projection as ONE ``[N,d] x [d,7d]`` GEMM (forward, dgrad
+    and weight gradient);
+  * the norm / residual / dropout stages as task lists (csrc/block_norm.hip): 19 launches per layer
+    instead of 37;
+  * all weight gradients of the block as ONE grouped split-K launch on the side stream (csrc/wgrad.hip);
+  * while the step is being captured into a hipGraph, the attention half forks onto its own stream.
 
 Reference lines: graphgps/layer/gps_layer.py:155-232, graphgps/layer/gatedgcn_layer.py:45-88.
 """
 from __future__ import annotations
 
+import ctypes as _ctypes
+import os as _os
+
 import torch
-import torch.nn.functional as F
 
 from .. import lib as _lib
 from ..fused import _SIDE_ENABLED, _queue_join, _side_stream
@@ -21,22 +29,11 @@ from ..lib import check, current_stream, ptr
 from ..ops import GraphIndex, draw_dropout_seed
 
 _E = torch.empty
-_BY_REF = __import__("ctypes").byref
-
-import os as _os
+_BY_REF = _ctypes.byref
 
 
 class _K:
     """Raw (non-autograd) launch helpers; every call enqueues on torch's current stream."""
-
-    @staticmethod
-    def bn_stats(L, z, bn, st):
-        R, d = z.shape
-        mean, rstd = _E(d, dtype=z.dtype, device=z.device), _E(d, dtype=z.dtype, device=z.device)
-        ws = _E(max(L.gps_bn_workspace_floats(R, d), 1), dtype=z.dtype, device=z.device)
-        check(L.gps_bn_stats(ptr(z), R, d, float(bn.eps), float(bn.momentum), ptr(mean), ptr(rstd),
-                             ptr(bn.running_mean), ptr(bn.running_var), ptr(ws), st), "gps_bn_stats")
-        return mean, rstd
 
     @staticmethod
     def bn_apply(L, z, mean, rstd, bn, res, relu, p, seed, st):
@@ -45,18 +42,6 @@ class _K:
         check(L.gps_bn_apply(ptr(z), ptr(mean), ptr(rstd), ptr(bn.weight), ptr(bn.bias), ptr(res), R, d,
                              int(relu), p, seed, ptr(y), st), "gps_bn_apply")
         return y
-
-    @staticmethod
-    def bn_bwd(L, z, g_y, mean, rstd, bn, relu, p, seed, st):
-        R, d = z.shape
-        g_z = torch.empty_like(z)
-        g_gamma = _E(d, dtype=z.dtype, device=z.device)
-        g_beta = _E(d, dtype=z.dtype, device=z.device)
-        ws = _E(max(L.gps_bn_workspace_floats(R, d), 1), dtype=z.dtype, device=z.device)
-        check(L.gps_bn_bwd(ptr(z), ptr(g_y), ptr(mean), ptr(rstd), ptr(bn.weight), ptr(bn.bias), R, d,
-                           int(relu), p, seed, ptr(g_z), ptr(g_gamma), ptr(g_beta), ptr(ws), st),
-              "gps_bn_bwd")
-        return g_z, g_gamma, g_beta
 
     @staticmethod
     def act_drop_add(L, a, b, relu, p, seed, st):
