@@ -150,3 +150,47 @@ def test_custom_gnn_configs_construct_with_published_param_counts():
     with pytest.raises(ValueError, match="Model gcnconv unavailable"):
         g.create_model(os.path.join(REF, "configs", "GatedGCN/peptides-func-GatedGCN.yaml"),
                        ["gnn.layer_type", "gcnconv"], 9, 10)
+
+
+def test_graphgym_layer_machinery_names_and_rules():
+    """GraphGym pieces the callers around the hot path construct (graphgym/layers.py, config.assert_cfg):
+    parameter names follow GraphGym (checkpoint interchange) and load_cfg applies GraphGym's post-merge
+    rules."""
+    import torch
+    import graphgps_amd as g
+    from graphgps_amd.graphgym.layers import MLP, GNNPreMP, new_layer_config
+    g.create_model(os.path.join(g.CONFIG_DIR, "zinc_gps_rwse.yaml"),
+                   ["gnn.layers_post_mp", 3, "gnn.batchnorm", True, "gnn.dropout", 0.1, "gnn.head", "default",
+                    "dataset.task", "graph"], 1, 1)
+    cfg = g.cfg
+    assert cfg.gnn.head == "graph"                       # 'default' -> dataset.task (assert_cfg)
+    mlp = MLP(new_layer_config(64, 5, 3, has_act=False, has_bias=True, cfg=cfg))
+    keys = list(mlp.state_dict())
+    assert "model.0.Layer_0.layer.model.weight" in keys and "model.0.Layer_1.post_layer.0.running_mean" in keys
+    assert "model.0.Layer_0.layer.model.bias" not in keys          # BN follows -> no bias (GeneralLayer)
+    assert keys[-2:] == ["model.1.model.weight", "model.1.model.bias"]
+    assert mlp(torch.randn(7, 64)).shape == (7, 5)
+    pre = GNNPreMP(9, 64, 2, cfg)
+    pre_w = [k for k in pre.state_dict() if k.endswith("layer.model.weight")]
+    assert pre_w == ["Layer_0.layer.model.weight", "Layer_1.layer.model.weight"]
+    # layers_post_mp < 1 is raised to 1; classification + mse becomes cross_entropy
+    g.create_model(os.path.join(g.CONFIG_DIR, "zinc_gps_rwse.yaml"),
+                   ["gnn.layers_post_mp", 0, "dataset.task_type", "classification", "model.loss_fun", "mse"], 1, 1)
+    assert g.cfg.gnn.layers_post_mp == 1 and g.cfg.model.loss_fun == "cross_entropy"
+    with pytest.raises(ValueError, match="not supported"):
+        g.create_model(os.path.join(g.CONFIG_DIR, "zinc_gps_rwse.yaml"), ["dataset.task", "galaxy"], 1, 1)
+
+
+def test_optimizer_registration_and_train_step_contract():
+    import torch
+    import graphgps_amd as g
+    from graphgps_amd.optim import FlatAdamW
+    from graphgps_amd.train import TrainStep
+    lin = torch.nn.Linear(4, 4)
+    opt = g.register.optimizer_dict["adamW"](lin.parameters(), 1e-3, 0.01)      # extra_optimizers.py:21-24
+    assert isinstance(opt, FlatAdamW) and opt.param_groups[0]["lr"] == 1e-3
+    assert opt.param_groups[0]["weight_decay"] == 0.01 and opt.arena.intact()
+    with pytest.raises(TypeError):
+        TrainStep(lin, torch.optim.AdamW(lin.parameters()))
+    sd = opt.state_dict()                                    # no steps yet: torch creates state lazily
+    assert sd["state"] == {} and sd["param_groups"][0]["params"] == [0, 1]
