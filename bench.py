@@ -353,6 +353,13 @@ def main():
                 log(f"hipGraph capture failed ({type(exc).__name__}: {exc}); running eagerly")
                 ts = TrainStep(model, opt, loss_fn=compute_loss, exchange=exchange, salt=salt)
                 launch = "eager"
+            if world > 1:                    # one rank falling back must take every rank with it
+                ok = torch.tensor([0.0 if launch == "eager" else 1.0], device=dev)
+                torch.distributed.all_reduce(ok, op=torch.distributed.ReduceOp.MIN)
+                if float(ok) == 0.0 and launch != "eager":
+                    log("another rank could not capture the step; running eagerly everywhere")
+                    launch = "eager"
+                    ts.use_replay = False
 
         def step():
             return ts(make_batch())
