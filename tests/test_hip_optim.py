@@ -200,3 +200,44 @@ def test_train_epoch_mirrors_reference_loop():
 
     a, b = run(True), run(False)
     assert torch.equal(a, b)
+
+
+def test_train_step_two_graphs_around_rccl_allreduce_world1():
+    """The N > 1 product path on one rank: [index + fwd + bwd + pack] and [clip + AdamW] captured as two
+    hipGraphs with an eager RCCL all-reduce of the flat gradient arena between them (world size 1, so the
+    averaged gradient is the gradient) must reproduce the eager single-GPU step."""
+    import socket
+    import torch.distributed as dist
+    from graphgps_amd.dp import FlatGradExchange
+    from graphgps_amd.loss.losses import compute_loss
+    from graphgps_amd.optim import FlatAdamW
+    from graphgps_amd.synthetic import model_batch
+    from graphgps_amd.train import TrainStep
+    dev = torch.device("cuda:0")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group(backend="nccl", rank=0, world_size=1, device_id=dev)
+    try:
+        b = model_batch("zinc", 16, seed=7).to(dev)
+        runs = []
+        for split in (False, True):
+            model = _zinc_model(dev)
+            opt = FlatAdamW(model.parameters(), lr=1e-3, weight_decay=0.0, max_grad_norm=1.0)
+            ex = FlatGradExchange(opt.arena, force_collective=True) if split else None
+            ts = TrainStep(model, opt, loss_fn=compute_loss, exchange=ex)
+            if split:
+                assert ex.active and ex.num_bytes == opt.arena.num_bytes
+                snap = {k: v.detach().clone() for k, v in model.state_dict().items()}
+                ts.capture(b.clone, warmup=2)
+                assert "RCCL all-reduce" in ts.mode
+                with torch.no_grad():
+                    for k, v in model.state_dict().items():
+                        v.copy_(snap[k])
+                    opt.exp_avg.zero_(), opt.exp_avg_sq.zero_(), opt.hyper[6].zero_(), opt.param_step.zero_()
+            runs.append([float(ts(b.clone())) for _ in range(4)])
+        for a, c in zip(*runs):
+            assert abs(a - c) <= 1e-6 * max(abs(a), 1.0), runs
+    finally:
+        dist.destroy_process_group()
