@@ -124,6 +124,9 @@ ATTN_CASES = [  # (H, dh, graph sizes)
     (4, 76, [40, 18]),
     (2, 32, [150, 70, 129]),      # > 64 keys: several online-softmax blocks
     (4, 96, [31, 66]),
+    (4, 64, [1000, 3, 601]),      # code2-size graphs (master_loader.py:366-368 clips at 1000 nodes)
+    (1, 128, [48, 2]),            # widest compiled head
+    (2, 4, [5, 16, 32, 64]),      # narrowest compiled head, sizes exactly on the tile boundaries
 ]
 
 
