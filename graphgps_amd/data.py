@@ -57,6 +57,16 @@ class Batch:
                 self.__dict__[k] = v.to(device, non_blocking=non_blocking)
         return self
 
+    def shallow_copy(self) -> "Batch":
+        """A new batch object over the SAME tensors (no device copies) without the cached graph index:
+        what a loader hands the step for the next batch of the same storage.  The GPS path never writes
+        into the tensors it is given (it re-assigns ``batch.x`` / ``batch.edge_attr``)."""
+        out = Batch()
+        for k, v in self.__dict__.items():
+            if k != "_gps_index":
+                out.__dict__[k] = v
+        return out
+
     def clone(self) -> "Batch":
         out = Batch()
         for k, v in self.__dict__.items():
