@@ -13,8 +13,8 @@ train_epoch body (graphgps/train/custom_train.py:22-39) minus logging.  Dropout 
 
 How the step is driven (graphgps_amd/train.py: TrainStep): flat-arena clip+AdamW; for N > 1 ONE RCCL
 all-reduce of the flat gradient arena between [index + fwd + bwd + pack] and [clip + AdamW]; the step is
-launched eagerly or replayed from hipGraph(s), whichever of the two measures faster on 6 untimed trial
-steps after the warm-up (--launch auto; every rank takes the same decision).  rocBLAS / hipBLASLt GEMM
+launched eagerly or replayed from hipGraph(s), whichever of the two measures faster on 8 untimed trial
+steps each (eager measured before anything is captured) (--launch auto; every rank takes the same decision).  rocBLAS / hipBLASLt GEMM
 solutions are picked per shape by TunableOp during the warm-up and frozen before the timed region.
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
@@ -347,6 +347,29 @@ def main():
         launch = "eager" if args.no_graph else args.launch
         salt = None if launch == "eager" else enable_dropout_salt(dev)
         ts = TrainStep(model, opt, loss_fn=compute_loss, exchange=exchange, salt=salt)
+
+        def step():
+            if ts.use_replay and ts.mode != "eager":
+                return ts.replay()           # the captured step owns its (static) batch
+            return ts.run_eager(make_batch())
+
+        def trial_ms(n_warm=3, n=8):
+            for _ in range(n_warm):
+                step()
+            barrier()
+            tt = time.perf_counter()
+            for _ in range(n):
+                step()
+            barrier()
+            t = (time.perf_counter() - tt) / n * 1e3
+            if world > 1:                    # every rank must take the same decision
+                tv = torch.tensor([t], device=dev, dtype=torch.float64)
+                torch.distributed.all_reduce(tv, op=torch.distributed.ReduceOp.MAX)
+                t = float(tv[0])
+            return t
+
+        if launch == "auto":                 # untimed trial, eager first: measured BEFORE anything is captured
+            trial["eager"] = trial_ms()      # (a live hipGraph slows eager launches down by ~5 % here)
         if launch != "eager":
             try:
                 ts.capture(make_batch)
@@ -361,30 +384,15 @@ def main():
                 if float(ok) == 0.0 and launch != "eager":
                     log("another rank could not capture the step; running eagerly everywhere")
                     launch = "eager"
-                    ts.use_replay = False
-
-        def step():
-            if ts.use_replay and ts.mode != "eager":
-                return ts.replay()           # the captured step owns its (static) batch
-            return ts.run_eager(make_batch())
-        if launch == "auto":                 # untimed trial: 6 steps each way, keep the faster
-            for mode in ("eager", "graph"):
-                ts.use_replay = mode == "graph"
-                for _ in range(2):
-                    step()
-                barrier()
-                tt = time.perf_counter()
-                for _ in range(6):
-                    step()
-                barrier()
-                trial[mode] = (time.perf_counter() - tt) / 6 * 1e3
-            if world > 1:                    # every rank must take the same decision
-                tv = torch.tensor([trial["eager"], trial["graph"]], device=dev, dtype=torch.float64)
-                torch.distributed.all_reduce(tv, op=torch.distributed.ReduceOp.MAX)
-                trial = {"eager": float(tv[0]), "graph": float(tv[1])}
+        if launch == "auto":
+            ts.use_replay = True
+            trial["graph"] = trial_ms()
             launch = min(trial, key=trial.get)
             log(f"launch-mode trial: eager {trial['eager']:.2f} ms, graph {trial['graph']:.2f} ms "
                 f"-> {launch}")
+        if launch == "eager" and ts.mode != "eager":
+            # drop the captured graphs (and their private memory pool) before running eagerly
+            ts = TrainStep(model, opt, loss_fn=compute_loss, exchange=exchange, salt=salt)
         ts.use_replay = launch == "graph"
         graph_mode = ts.mode if launch == "graph" else "eager (2 HIP streams: main + weight-gradient)"
         allreduce_bytes = exchange.num_bytes if exchange is not None else 0
