@@ -22,6 +22,7 @@ from typing import Callable, Optional
 import torch
 
 from .graphgym.config import cfg
+from .loader import DeviceLoader
 from .loss.losses import train_loss
 from .optim import FlatAdamW
 
@@ -135,9 +136,9 @@ def train_epoch(logger, loader, model, optimizer, scheduler, batch_accumulation,
     n_iters = len(loader)
     pending = []
     time_start = time.time()
-    for it, batch in enumerate(loader):
+    # next batch's H2D copies + graph index run on a copy stream behind the current step
+    for it, batch in enumerate(DeviceLoader(loader, device)):
         batch.split = 'train'
-        batch = batch.to(device) or batch
         loss, pred_score, true = step.forward_backward(batch, zero=False)
         if ((it + 1) % batch_accumulation == 0) or (it + 1 == n_iters):
             step.reduce()

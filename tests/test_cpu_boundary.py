@@ -194,3 +194,16 @@ def test_optimizer_registration_and_train_step_contract():
         TrainStep(lin, torch.optim.AdamW(lin.parameters()))
     sd = opt.state_dict()                                    # no steps yet: torch creates state lazily
     assert sd["state"] == {} and sd["param_groups"][0]["params"] == [0, 1]
+
+
+def test_device_loader_is_a_pass_through_on_cpu():
+    """On a CPU device DeviceLoader adds nothing (no CPU kernels exist on the product path): same batch
+    objects, same order, same length as the wrapped loader."""
+    from graphgps_amd.loader import DeviceLoader
+    from graphgps_amd.synthetic import model_batch
+    host = [model_batch("zinc", 3, seed=i) for i in range(4)]
+    dl = DeviceLoader(host, "cpu", depth=2)
+    assert len(dl) == 4
+    out = list(dl)
+    assert all(a is b for a, b in zip(out, host))
+    assert all("_gps_index" not in b.__dict__ for b in out)

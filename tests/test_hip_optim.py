@@ -241,3 +241,36 @@ def test_train_step_two_graphs_around_rccl_allreduce_world1():
             assert abs(a - c) <= 1e-6 * max(abs(a), 1.0), runs
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("depth", [1, 3])
+def test_device_loader_stages_batches_and_index_ahead_of_the_step(depth):
+    """graphgps_amd.loader.DeviceLoader (replaces the blocking ``batch.to(device)`` of custom_train.py:21-22):
+    batches arrive in order, bit-identical to a blocking copy, with the graph index already attached and
+    equal to one built directly; consuming them on the step's stream while the next is in flight is safe."""
+    from graphgps_amd.loader import DeviceLoader
+    from graphgps_amd.ops import build_graph_index
+    from graphgps_amd.synthetic import model_batch
+    dev = torch.device("cuda:0")
+    host = [model_batch("zinc", 4 + 3 * i, seed=7 + i) for i in range(6)]
+    keep = [b.clone() for b in host]
+    sums = []
+    for i, b in enumerate(DeviceLoader(host, dev, depth=depth)):
+        ref = keep[i]
+        for k in ref.keys():
+            v = getattr(ref, k)
+            if torch.is_tensor(v):
+                got = getattr(b, k)
+                assert got.device == dev and torch.equal(got.cpu(), v), k
+        gi = b.__dict__["_gps_index"]
+        want = build_graph_index(b.edge_index, b.num_nodes, b.num_graphs, ptr_vec=b.ptr)
+        for name in ("rowptr_dst", "src_by_dst", "eid_by_dst", "rowptr_src", "dst_by_src", "eid_by_src",
+                     "ptr"):
+            assert torch.equal(getattr(gi, name), getattr(want, name)), name
+        n_tiles = int(want.max_tiles)
+        assert gi.max_tiles == n_tiles
+        # some work on the consumer's stream that outlives the loop body
+        sums.append(b.x.float().sum() + b.edge_index.float().sum())
+    assert len(sums) == len(host)
+    for s, ref in zip(sums, keep):
+        assert float(s) == float(ref.x.float().sum() + ref.edge_index.float().sum())
