@@ -14,6 +14,9 @@ from .layer.gatedgcn_layer import GatedGCNLayer, GatedGCNGraphGymLayer  # noqa: 
 from .layer.gine_conv_layer import GINEConv, GINEConvLayer, GINEConvGraphGymLayer  # noqa: F401
 from .network.gps_model import GPSModel  # noqa: F401
 from .network.custom_gnn import CustomGNN  # noqa: F401
+from .encoder import graphormer_encoder as _graphormer_encoder  # noqa: F401
+from .layer.graphormer_layer import GraphormerLayer  # noqa: F401
+from .network.graphormer import GraphormerModel  # noqa: F401
 from .loss import losses as _losses  # noqa: F401
 from .optim import FlatAdamW, ParamArena  # noqa: F401
 

@@ -119,7 +119,7 @@ __device__ __forceinline__ void store4(float* __restrict__ base, uint32_t off, i
 
 // What every (16-row tile, head) wave needs: graph extent, head, uniform base pointers.
 struct Wave {
-  int n0, n, h, l0;          // graph's first row, size, head, tile's first LOCAL row
+  int n0, n, h, l0, g;       // graph's first row, size, head, tile's first LOCAL row, graph id
   uint32_t rmax;             // last local row that is still inside the buffer
   bool live;
 };
@@ -135,12 +135,34 @@ __device__ __forceinline__ Wave wave_setup(const int32_t* __restrict__ ptr,
   w.h = (int)(wi - tile * H);
   const int g = tile_graph[tile];
   if (g < 0) return w;
+  w.g = g;
   w.n0 = ptr[g];
   w.n = ptr[g + 1] - w.n0;
   w.l0 = tile_row0[tile] - w.n0;
   w.rmax = (uint32_t)(N - 1 - w.n0);
   w.live = true;
   return w;
+}
+
+// Additive attention bias (the reference's `attn_mask=batch.attn_bias`, gps_layer.py:201-203 and
+// graphormer_layer.py:43-44): a dense fp32 [B*H, nmax, nmax] tensor in the layout the reference's
+// BiasEncoder emits (graphormer_encoder.py:148-183), element [(g*H + h), query, key] added to the
+// scaled scores before the softmax.  The kernels read only the n x n corner of graph g and write the
+// same corner of its gradient (dS); the padded remainder is never touched (the host zero-fills it).
+struct Bias {
+  const float* __restrict__ b;   // wave-uniform: first element of this (graph, head) plane
+  float* __restrict__ g;         // same plane of the gradient (dQ kernel only), or nullptr
+  uint32_t nmax, nlast;          // plane pitch; last local row of the graph (clamp for padding lanes)
+};
+__device__ __forceinline__ Bias bias_setup(const float* bias, float* g_bias, int64_t nmax, const Wave& w,
+                                           int H) {
+  Bias b;
+  const int64_t plane = ((int64_t)w.g * H + w.h) * nmax * nmax;
+  b.b = bias ? bias + plane : nullptr;
+  b.g = g_bias ? g_bias + plane : nullptr;
+  b.nmax = (uint32_t)nmax;
+  b.nlast = (uint32_t)max(min(w.n, (int)nmax) - 1, 0);
+  return b;
 }
 
 // =============================================================================================
@@ -150,14 +172,22 @@ __device__ __forceinline__ Wave wave_setup(const int32_t* __restrict__ ptr,
 // every K and V operand load of the block is issued before the first MFMA, so a wave pays ONE
 // memory round trip per block instead of one per tile (the kernel is latency-bound at molecule
 // sizes: ~30 x 30 x 24 per (graph, head)).
-template <int DH, bool DROP, bool VEC, int NT>
+template <int DH, bool DROP, bool VEC, bool BIAS, int NT>
 __device__ __forceinline__ void attn_fwd_block(
     const float* __restrict__ Kb, const float* __restrict__ Vb, uint32_t ld, int kb, const Wave& w, int i,
-    int grp, const float (&qv)[Geo<DH>::KPL], uint32_t rh, float p_drop, float inv_keep, float& m,
-    float& lsum, f32x4 (&oacc)[Geo<DH>::DT]) {
+    int grp, const float (&qv)[Geo<DH>::KPL], uint32_t rh, float p_drop, float inv_keep, const Bias& bs,
+    uint32_t bq_off, float& m, float& lsum, f32x4 (&oacc)[Geo<DH>::DT]) {
   constexpr int KPL = Geo<DH>::KPL, DT = Geo<DH>::DT;
   float kv[NT][KPL];
   float vv[DT][NT][4];
+  float bv[NT][4];
+  if constexpr (BIAS) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        bv[t][r] = bs.b[bq_off + min((uint32_t)(kb + 16 * t + 4 * grp + r), bs.nlast)];
+  }
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int kr = kb + 16 * t + i;
@@ -189,6 +219,7 @@ __device__ __forceinline__ void attn_fwd_block(
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int key = kb + 16 * t + 4 * grp + r;
+      if constexpr (BIAS) s[t][r] += bv[t][r];
       s[t][r] = key < w.n ? s[t][r] : -INFINITY;
       mloc = fmaxf(mloc, s[t][r]);
     }
@@ -220,12 +251,12 @@ __device__ __forceinline__ void attn_fwd_block(
         oacc[dt] = mfma16(vv[dt][t][r], s[t][r], oacc[dt]);
 }
 
-template <int DH, bool DROP, bool VEC>
+template <int DH, bool DROP, bool VEC, bool BIAS>
 __global__ __launch_bounds__(256) void k_attn_fwd(
     const float* __restrict__ qkv, int64_t ld64, const int32_t* __restrict__ ptr,
     const int32_t* __restrict__ tile_graph, const int32_t* __restrict__ tile_row0,
     int64_t n_work, int64_t N, int H, float scale, float p_drop, uint64_t seed, const uint64_t* __restrict__ salt,
-    float* __restrict__ out, float* __restrict__ lse) {
+    const float* __restrict__ bias, int64_t nmax, float* __restrict__ out, float* __restrict__ lse) {
   const Wave w = wave_setup(ptr, tile_graph, tile_row0, n_work, N, H);
   if (!w.live) return;
   seed = gps::salted_seed(seed, salt);
@@ -244,6 +275,8 @@ __global__ __launch_bounds__(256) void k_attn_fwd(
   load_slice<DH, VEC>(Qb, row_off(ql, w.rmax, ld) + grp * KPL, q_ok, grp, scale, qv);
   const uint32_t rh = DROP ? row_hash((uint32_t)(w.n0 + ql) * (uint32_t)H + (uint32_t)w.h, seed) : 0u;
   const float inv_keep = DROP ? 1.0f / (1.0f - p_drop) : 1.0f;
+  const Bias bs = BIAS ? bias_setup(bias, nullptr, nmax, w, H) : Bias{nullptr, nullptr, 0u, 0u};
+  const uint32_t bq_off = BIAS ? min((uint32_t)ql, bs.nlast) * bs.nmax : 0u;
 
   float m = -INFINITY, lsum = 0.0f;
   f32x4 oacc[DT];
@@ -253,10 +286,10 @@ __global__ __launch_bounds__(256) void k_attn_fwd(
   for (int kb = 0; kb < w.n; kb += 16 * KT) {
     const int nt = min(KT, (w.n - kb + 15) >> 4);  // wave-uniform
     switch (nt) {
-      case 1: attn_fwd_block<DH, DROP, VEC, 1>(Kb, Vb, ld, kb, w, i, grp, qv, rh, p_drop, inv_keep, m, lsum, oacc); break;
-      case 2: attn_fwd_block<DH, DROP, VEC, (KT >= 2 ? 2 : KT)>(Kb, Vb, ld, kb, w, i, grp, qv, rh, p_drop, inv_keep, m, lsum, oacc); break;
-      case 3: attn_fwd_block<DH, DROP, VEC, (KT >= 3 ? 3 : KT)>(Kb, Vb, ld, kb, w, i, grp, qv, rh, p_drop, inv_keep, m, lsum, oacc); break;
-      default: attn_fwd_block<DH, DROP, VEC, KT>(Kb, Vb, ld, kb, w, i, grp, qv, rh, p_drop, inv_keep, m, lsum, oacc); break;
+      case 1: attn_fwd_block<DH, DROP, VEC, BIAS, 1>(Kb, Vb, ld, kb, w, i, grp, qv, rh, p_drop, inv_keep, bs, bq_off, m, lsum, oacc); break;
+      case 2: attn_fwd_block<DH, DROP, VEC, BIAS, (KT >= 2 ? 2 : KT)>(Kb, Vb, ld, kb, w, i, grp, qv, rh, p_drop, inv_keep, bs, bq_off, m, lsum, oacc); break;
+      case 3: attn_fwd_block<DH, DROP, VEC, BIAS, (KT >= 3 ? 3 : KT)>(Kb, Vb, ld, kb, w, i, grp, qv, rh, p_drop, inv_keep, bs, bq_off, m, lsum, oacc); break;
+      default: attn_fwd_block<DH, DROP, VEC, BIAS, KT>(Kb, Vb, ld, kb, w, i, grp, qv, rh, p_drop, inv_keep, bs, bq_off, m, lsum, oacc); break;
     }
   }
   const float ltot = group_sum(lsum);
@@ -278,14 +311,23 @@ __global__ __launch_bounds__(256) void k_attn_fwd(
 // =============================================================================================
 // Same discipline as the forward block: one 64-key block with NT live tiles, branch-free, every K / V
 // operand (row slices for S^T and dP^T, column form of K for dQ^T) loaded before the first MFMA.
-template <int DH, bool DROP, bool VEC, int NT>
+template <int DH, bool DROP, bool VEC, bool BIAS, int NT>
 __device__ __forceinline__ void attn_dq_block(
     const float* __restrict__ Kb, const float* __restrict__ Vb, uint32_t ld, int kb, const Wave& w, int i,
     int grp, const float (&qv)[Geo<DH>::KPL], const float (&dov)[Geo<DH>::KPL], float lse_q, float dl_q,
-    uint32_t rh, float p_drop, float inv_keep, f32x4 (&acc)[Geo<DH>::DT]) {
+    uint32_t rh, float p_drop, float inv_keep, const Bias& bs, uint32_t bq_off, bool q_ok,
+    f32x4 (&acc)[Geo<DH>::DT]) {
   constexpr int KPL = Geo<DH>::KPL, DT = Geo<DH>::DT;
   float kv[NT][KPL], vv[NT][KPL];
   float kc[DT][NT][4];
+  float bv[NT][4];
+  if constexpr (BIAS) {
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        bv[t][r] = bs.b[bq_off + min((uint32_t)(kb + 16 * t + 4 * grp + r), bs.nlast)];
+  }
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int kr = kb + 16 * t + i;
@@ -324,10 +366,14 @@ __device__ __forceinline__ void attn_dq_block(
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int key = kb + 16 * t + 4 * grp + r;
+      if constexpr (BIAS) s[t][r] += bv[t][r];
       const float p = expf(s[t][r] - lse_q);
       float dpe = dp[t][r];
       if (DROP) dpe = keep_elem(rh, (uint32_t)key, p_drop) ? dpe * inv_keep : 0.0f;
       s[t][r] = key < w.n ? p * (dpe - dl_q) : 0.0f;   // dS^T, reused as the B operand below
+      if constexpr (BIAS) {                            // d(bias)[query][key] = dS[query][key]
+        if (q_ok && key < w.n) bs.g[bq_off + (uint32_t)key] = s[t][r];
+      }
     }
 #pragma unroll
   for (int t = 0; t < NT; ++t)
@@ -338,13 +384,14 @@ __device__ __forceinline__ void attn_dq_block(
         acc[dt] = mfma16(kc[dt][t][r], s[t][r], acc[dt]);
 }
 
-template <int DH, bool DROP, bool VEC>
+template <int DH, bool DROP, bool VEC, bool BIAS>
 __global__ __launch_bounds__(256) void k_attn_bwd_dq(
     const float* __restrict__ d_out, const float* __restrict__ qkv, int64_t ld64,
     const float* __restrict__ out, const float* __restrict__ lse, float* __restrict__ delta,
     const int32_t* __restrict__ ptr, const int32_t* __restrict__ tile_graph,
     const int32_t* __restrict__ tile_row0, int64_t n_work, int64_t N, int H, float scale,
-    float p_drop, uint64_t seed, const uint64_t* __restrict__ salt, float* __restrict__ d_qkv, int64_t ldg64) {
+    float p_drop, uint64_t seed, const uint64_t* __restrict__ salt, const float* __restrict__ bias,
+    float* __restrict__ g_bias, int64_t nmax, float* __restrict__ d_qkv, int64_t ldg64) {
   const Wave w = wave_setup(ptr, tile_graph, tile_row0, n_work, N, H);
   if (!w.live) return;
   seed = gps::salted_seed(seed, salt);
@@ -376,6 +423,8 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(
   if (q_ok && grp == 0) delta[sidx] = dl_q;   // read by k_attn_bwd_dkv (same stream)
   const uint32_t rh = DROP ? row_hash((uint32_t)(w.n0 + ql) * (uint32_t)H + (uint32_t)w.h, seed) : 0u;
   const float inv_keep = DROP ? 1.0f / (1.0f - p_drop) : 1.0f;
+  const Bias bs = BIAS ? bias_setup(bias, g_bias, nmax, w, H) : Bias{nullptr, nullptr, 0u, 0u};
+  const uint32_t bq_off = BIAS ? min((uint32_t)ql, bs.nlast) * bs.nmax : 0u;
 
   f32x4 acc[DT];
 #pragma unroll
@@ -384,10 +433,10 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(
   for (int kb = 0; kb < w.n; kb += 16 * KT) {
     const int nt = min(KT, (w.n - kb + 15) >> 4);  // wave-uniform
     switch (nt) {
-      case 1: attn_dq_block<DH, DROP, VEC, 1>(Kb, Vb, ld, kb, w, i, grp, qv, dov, lse_q, dl_q, rh, p_drop, inv_keep, acc); break;
-      case 2: attn_dq_block<DH, DROP, VEC, (KT >= 2 ? 2 : KT)>(Kb, Vb, ld, kb, w, i, grp, qv, dov, lse_q, dl_q, rh, p_drop, inv_keep, acc); break;
-      case 3: attn_dq_block<DH, DROP, VEC, (KT >= 3 ? 3 : KT)>(Kb, Vb, ld, kb, w, i, grp, qv, dov, lse_q, dl_q, rh, p_drop, inv_keep, acc); break;
-      default: attn_dq_block<DH, DROP, VEC, KT>(Kb, Vb, ld, kb, w, i, grp, qv, dov, lse_q, dl_q, rh, p_drop, inv_keep, acc); break;
+      case 1: attn_dq_block<DH, DROP, VEC, BIAS, 1>(Kb, Vb, ld, kb, w, i, grp, qv, dov, lse_q, dl_q, rh, p_drop, inv_keep, bs, bq_off, q_ok, acc); break;
+      case 2: attn_dq_block<DH, DROP, VEC, BIAS, (KT >= 2 ? 2 : KT)>(Kb, Vb, ld, kb, w, i, grp, qv, dov, lse_q, dl_q, rh, p_drop, inv_keep, bs, bq_off, q_ok, acc); break;
+      case 3: attn_dq_block<DH, DROP, VEC, BIAS, (KT >= 3 ? 3 : KT)>(Kb, Vb, ld, kb, w, i, grp, qv, dov, lse_q, dl_q, rh, p_drop, inv_keep, bs, bq_off, q_ok, acc); break;
+      default: attn_dq_block<DH, DROP, VEC, BIAS, KT>(Kb, Vb, ld, kb, w, i, grp, qv, dov, lse_q, dl_q, rh, p_drop, inv_keep, bs, bq_off, q_ok, acc); break;
     }
   }
   if (q_ok) {
@@ -406,16 +455,25 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(
 // =============================================================================================
 // One 32-query block with NT (1..2) live tiles, all Q / dO operands (row slices for S and dP, column
 // forms for dK^T and dV^T) and the per-query lse / delta loaded before the first MFMA.
-template <int DH, bool DROP, bool VEC, int NT>
+template <int DH, bool DROP, bool VEC, bool BIAS, int NT>
 __device__ __forceinline__ void attn_dkv_block(
     const float* __restrict__ Qb, const float* __restrict__ dOb, const float* __restrict__ lse_b,
     const float* __restrict__ delta_b, uint32_t ld, uint32_t d, int H, int qb, const Wave& w, int i, int grp,
     int kl, const float (&kv)[Geo<DH>::KPL], const float (&vv)[Geo<DH>::KPL], float scale, uint64_t seed,
-    float p_drop, float inv_keep, f32x4 (&dk)[Geo<DH>::DT], f32x4 (&dv)[Geo<DH>::DT]) {
+    float p_drop, float inv_keep, const Bias& bs, f32x4 (&dk)[Geo<DH>::DT], f32x4 (&dv)[Geo<DH>::DT]) {
   constexpr int KPL = Geo<DH>::KPL, DT = Geo<DH>::DT;
   float qa[NT][KPL], da[NT][KPL];
   float qc[DT][NT][4], dc[DT][NT][4];
   float lq[NT][4], dq[NT][4];
+  float bv[NT][4];
+  if constexpr (BIAS) {
+    const uint32_t bk = min((uint32_t)kl, bs.nlast);
+#pragma unroll
+    for (int t = 0; t < NT; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+        bv[t][r] = bs.b[min((uint32_t)(qb + 16 * t + 4 * grp + r), bs.nlast) * bs.nmax + bk];
+  }
 #pragma unroll
   for (int t = 0; t < NT; ++t) {
     const int qr = qb + 16 * t + i;
@@ -460,6 +518,7 @@ __device__ __forceinline__ void attn_dkv_block(
     for (int r = 0; r < 4; ++r) {
       const int qq = qb + 16 * t + 4 * grp + r;
       const bool q_in = qq < w.n;
+      if constexpr (BIAS) s[t][r] += bv[t][r];
       const float pr = q_in ? expf(s[t][r] - lq[t][r]) : 0.0f;
       float dpe = dp[t][r];
       float pd = pr;
@@ -483,13 +542,14 @@ __device__ __forceinline__ void attn_dkv_block(
       }
 }
 
-template <int DH, bool DROP, bool VEC>
+template <int DH, bool DROP, bool VEC, bool BIAS>
 __global__ __launch_bounds__(256) void k_attn_bwd_dkv(
     const float* __restrict__ d_out, const float* __restrict__ qkv, int64_t ld64,
     const float* __restrict__ lse, const float* __restrict__ delta,
     const int32_t* __restrict__ ptr, const int32_t* __restrict__ tile_graph,
     const int32_t* __restrict__ tile_row0, int64_t n_work, int64_t N, int H, float scale,
-    float p_drop, uint64_t seed, const uint64_t* __restrict__ salt, float* __restrict__ d_qkv, int64_t ldg64) {
+    float p_drop, uint64_t seed, const uint64_t* __restrict__ salt, const float* __restrict__ bias,
+    int64_t nmax, float* __restrict__ d_qkv, int64_t ldg64) {
   const Wave w = wave_setup(ptr, tile_graph, tile_row0, n_work, N, H);
   if (!w.live) return;
   seed = gps::salted_seed(seed, salt);
@@ -507,6 +567,7 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(
   const int kl = w.l0 + i;                  // local key row
   const bool k_ok = kl < w.n;
   const float inv_keep = DROP ? 1.0f / (1.0f - p_drop) : 1.0f;
+  const Bias bs = BIAS ? bias_setup(bias, nullptr, nmax, w, H) : Bias{nullptr, nullptr, 0u, 0u};
 
   float kv[KPL], vv[KPL];
   const uint32_t koff = row_off(kl, w.rmax, ld) + grp * KPL;
@@ -522,11 +583,11 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(
 
   for (int qb = 0; qb < w.n; qb += 16 * QT) {
     if (QT > 1 && w.n - qb > 16)
-      attn_dkv_block<DH, DROP, VEC, QT>(Qb, dOb, lse_b, delta_b, ld, (uint32_t)d, H, qb, w, i, grp, kl, kv, vv,
-                                        scale, seed, p_drop, inv_keep, dk, dv);
+      attn_dkv_block<DH, DROP, VEC, BIAS, QT>(Qb, dOb, lse_b, delta_b, ld, (uint32_t)d, H, qb, w, i, grp, kl, kv,
+                                              vv, scale, seed, p_drop, inv_keep, bs, dk, dv);
     else
-      attn_dkv_block<DH, DROP, VEC, 1>(Qb, dOb, lse_b, delta_b, ld, (uint32_t)d, H, qb, w, i, grp, kl, kv, vv,
-                                       scale, seed, p_drop, inv_keep, dk, dv);
+      attn_dkv_block<DH, DROP, VEC, BIAS, 1>(Qb, dOb, lse_b, delta_b, ld, (uint32_t)d, H, qb, w, i, grp, kl, kv,
+                                             vv, scale, seed, p_drop, inv_keep, bs, dk, dv);
   }
   if (k_ok) {
     float* __restrict__ Gk = d_qkv + (int64_t)w.n0 * ldg64 + d + w.h * DH;
@@ -541,7 +602,8 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(
   }
 }
 
-#define GPS_FOR_EACH_DH(X) X(4) X(6) X(8) X(12) X(13) X(16) X(18) X(24) X(32) X(48) X(64) X(76) X(96) X(128)
+#define GPS_FOR_EACH_DH(X) \
+  X(4) X(6) X(8) X(10) X(12) X(13) X(16) X(18) X(20) X(24) X(32) X(48) X(64) X(76) X(96) X(128)
 
 }  // namespace
 
@@ -560,42 +622,113 @@ int gps_attn_supported_head_dim(int dh) {
   }
 }
 
-int gps_seg_attn_fwd(const float* qkv, int64_t ld_qkv, const int32_t* ptr,
-                     const int32_t* tile_graph, const int32_t* tile_row0, int64_t max_tiles,
-                     int64_t N, int H, int dh, float scale, float p_drop, uint64_t seed, float* out,
-                     float* lse, gps_stream_t stream) {
+// Shared launcher of the plain and the biased forward (bias == nullptr: plain).
+static int seg_attn_fwd_impl(const char* who, const float* qkv, int64_t ld_qkv, const float* bias,
+                             int64_t nmax, const int32_t* ptr, const int32_t* tile_graph,
+                             const int32_t* tile_row0, int64_t max_tiles, int64_t N, int H, int dh, float scale,
+                             float p_drop, uint64_t seed, float* out, float* lse, gps_stream_t stream) {
   GPS_REQUIRE(N >= 0 && H > 0 && dh > 0 && max_tiles >= 0 && ld_qkv >= 3LL * H * dh,
-              "gps_seg_attn_fwd: bad sizes N=%lld H=%d dh=%d ld=%lld", (long long)N, H, dh, (long long)ld_qkv);
-  GPS_REQUIRE(p_drop >= 0.0f && p_drop < 1.0f, "gps_seg_attn_fwd: p_drop=%f outside [0,1)", p_drop);
-  GPS_REQUIRE(N * (int64_t)H < INT32_MAX, "gps_seg_attn_fwd: N*H exceeds the 32-bit dropout row id");
+              "%s: bad sizes N=%lld H=%d dh=%d ld=%lld", who, (long long)N, H, dh, (long long)ld_qkv);
+  GPS_REQUIRE(p_drop >= 0.0f && p_drop < 1.0f, "%s: p_drop=%f outside [0,1)", who, p_drop);
+  GPS_REQUIRE(N * (int64_t)H < INT32_MAX, "%s: N*H exceeds the 32-bit dropout row id", who);
   if (N == 0 || max_tiles == 0) return GPS_OK;
-  GPS_REQUIRE(qkv && ptr && tile_graph && tile_row0 && out && lse, "gps_seg_attn_fwd: null buffer");
+  GPS_REQUIRE(qkv && ptr && tile_graph && tile_row0 && out && lse, "%s: null buffer", who);
   if (!gps_attn_supported_head_dim(dh)) {
-    gps::set_error("gps_seg_attn_fwd: head dim %d has no compiled kernel", dh);
+    gps::set_error("%s: head dim %d has no compiled kernel", who, dh);
     return GPS_EUNSUPPORTED;
   }
-  GPS_REQUIRE(N * ld_qkv < (int64_t(1) << 31), "gps_seg_attn_fwd: N * ld exceeds 32-bit element offsets");
+  GPS_REQUIRE(N * ld_qkv < (int64_t(1) << 31), "%s: N * ld exceeds 32-bit element offsets", who);
+  if (bias) GPS_REQUIRE(nmax > 0 && nmax * nmax < (int64_t(1) << 31), "%s: bad bias pitch nmax=%lld", who,
+                        (long long)nmax);
   const int64_t n_work = max_tiles * H;
   const unsigned grid = gps::grid_for(n_work, 4);
   hipStream_t s = gps::as_stream(stream);
   const bool vec = ld_qkv % 4 == 0 && (H * dh) % 4 == 0 && al16(qkv) && al16(out);
-#define LAUNCH_FWD(D, DROP, VEC)                                                                 \
-  k_attn_fwd<D, DROP, VEC><<<grid, 256, 0, s>>>(qkv, ld_qkv, ptr, tile_graph, tile_row0, n_work, N, H, \
-                                                scale, p_drop, seed, gps::dropout_salt(), out, lse)
+#define LAUNCH_FWD(D, DROP, VEC, BIAS)                                                                  \
+  k_attn_fwd<D, DROP, VEC, BIAS><<<grid, 256, 0, s>>>(qkv, ld_qkv, ptr, tile_graph, tile_row0, n_work, N, H, \
+                                                      scale, p_drop, seed, gps::dropout_salt(), bias, nmax,  \
+                                                      out, lse)
   switch (dh) {
-#define X(D)                                                             \
-  case D:                                                                \
-    if (p_drop > 0.0f) {                                                 \
-      if (vec) LAUNCH_FWD(D, true, true); else LAUNCH_FWD(D, true, false);   \
-    } else {                                                             \
-      if (vec) LAUNCH_FWD(D, false, true); else LAUNCH_FWD(D, false, false); \
-    }                                                                    \
+#define X(D)                                                                              \
+  case D:                                                                                 \
+    if (bias) {                                                                           \
+      if (p_drop > 0.0f) LAUNCH_FWD(D, true, false, true); else LAUNCH_FWD(D, false, false, true); \
+    } else if (p_drop > 0.0f) {                                                           \
+      if (vec) LAUNCH_FWD(D, true, true, false); else LAUNCH_FWD(D, true, false, false);   \
+    } else {                                                                              \
+      if (vec) LAUNCH_FWD(D, false, true, false); else LAUNCH_FWD(D, false, false, false); \
+    }                                                                                     \
     break;
     GPS_FOR_EACH_DH(X)
 #undef X
   }
 #undef LAUNCH_FWD
-  return gps::launch_status("gps_seg_attn_fwd");
+  return gps::launch_status(who);
+}
+
+static int seg_attn_bwd_impl(const char* who, const float* d_out, const float* qkv, int64_t ld_qkv,
+                             const float* bias, int64_t nmax, const float* out, const float* lse,
+                             const int32_t* ptr, const int32_t* tile_graph, const int32_t* tile_row0,
+                             int64_t max_tiles, int64_t N, int H, int dh, float scale, float p_drop,
+                             uint64_t seed, float* delta, float* d_qkv, int64_t ld_dqkv, float* d_bias,
+                             gps_stream_t stream) {
+  GPS_REQUIRE(N >= 0 && H > 0 && dh > 0 && max_tiles >= 0 && ld_qkv >= 3LL * H * dh &&
+                  ld_dqkv >= 3LL * H * dh,
+              "%s: bad sizes", who);
+  GPS_REQUIRE(p_drop >= 0.0f && p_drop < 1.0f, "%s: p_drop=%f outside [0,1)", who, p_drop);
+  GPS_REQUIRE(N * (int64_t)H < INT32_MAX, "%s: N*H exceeds the 32-bit dropout row id", who);
+  if (N == 0 || max_tiles == 0) return GPS_OK;
+  GPS_REQUIRE(d_out && qkv && out && lse && ptr && tile_graph && tile_row0 && delta && d_qkv,
+              "%s: null buffer", who);
+  if (!gps_attn_supported_head_dim(dh)) {
+    gps::set_error("%s: head dim %d has no compiled kernel", who, dh);
+    return GPS_EUNSUPPORTED;
+  }
+  GPS_REQUIRE(N * ld_qkv < (int64_t(1) << 31) && N * ld_dqkv < (int64_t(1) << 31),
+              "%s: N * ld exceeds 32-bit element offsets", who);
+  if (bias) GPS_REQUIRE(d_bias && nmax > 0 && nmax * nmax < (int64_t(1) << 31),
+                        "%s: bias needs its gradient buffer and a pitch < 46341 (nmax=%lld)", who,
+                        (long long)nmax);
+  const int64_t n_work = max_tiles * H;
+  const unsigned grid = gps::grid_for(n_work, 4);
+  hipStream_t s = gps::as_stream(stream);
+  const bool vec = ld_qkv % 4 == 0 && ld_dqkv % 4 == 0 && (H * dh) % 4 == 0 && al16(qkv) && al16(out) &&
+                   al16(d_out) && al16(d_qkv);
+#define LAUNCH_BWD(D, DROP, VEC, BIAS)                                                                     \
+  do {                                                                                                     \
+    k_attn_bwd_dq<D, DROP, VEC, BIAS><<<grid, 256, 0, s>>>(d_out, qkv, ld_qkv, out, lse, delta, ptr,       \
+                                                           tile_graph, tile_row0, n_work, N, H, scale,     \
+                                                           p_drop, seed, gps::dropout_salt(), bias, d_bias, \
+                                                           nmax, d_qkv, ld_dqkv);                          \
+    k_attn_bwd_dkv<D, DROP, VEC, BIAS><<<grid, 256, 0, s>>>(d_out, qkv, ld_qkv, lse, delta, ptr, tile_graph, \
+                                                            tile_row0, n_work, N, H, scale, p_drop, seed,  \
+                                                            gps::dropout_salt(), bias, nmax, d_qkv,        \
+                                                            ld_dqkv);                                      \
+  } while (0)
+  switch (dh) {
+#define X(D)                                                                              \
+  case D:                                                                                 \
+    if (bias) {                                                                           \
+      if (p_drop > 0.0f) LAUNCH_BWD(D, true, false, true); else LAUNCH_BWD(D, false, false, true); \
+    } else if (p_drop > 0.0f) {                                                           \
+      if (vec) LAUNCH_BWD(D, true, true, false); else LAUNCH_BWD(D, true, false, false);   \
+    } else {                                                                              \
+      if (vec) LAUNCH_BWD(D, false, true, false); else LAUNCH_BWD(D, false, false, false); \
+    }                                                                                     \
+    break;
+    GPS_FOR_EACH_DH(X)
+#undef X
+  }
+#undef LAUNCH_BWD
+  return gps::launch_status(who);
+}
+
+int gps_seg_attn_fwd(const float* qkv, int64_t ld_qkv, const int32_t* ptr,
+                     const int32_t* tile_graph, const int32_t* tile_row0, int64_t max_tiles,
+                     int64_t N, int H, int dh, float scale, float p_drop, uint64_t seed, float* out,
+                     float* lse, gps_stream_t stream) {
+  return seg_attn_fwd_impl("gps_seg_attn_fwd", qkv, ld_qkv, nullptr, 0, ptr, tile_graph, tile_row0, max_tiles,
+                           N, H, dh, scale, p_drop, seed, out, lse, stream);
 }
 
 int gps_seg_attn_bwd(const float* d_out, const float* qkv, int64_t ld_qkv, const float* out,
@@ -603,48 +736,29 @@ int gps_seg_attn_bwd(const float* d_out, const float* qkv, int64_t ld_qkv, const
                      const int32_t* tile_row0, int64_t max_tiles, int64_t N, int H, int dh,
                      float scale, float p_drop, uint64_t seed, float* delta, float* d_qkv,
                      int64_t ld_dqkv, gps_stream_t stream) {
-  GPS_REQUIRE(N >= 0 && H > 0 && dh > 0 && max_tiles >= 0 && ld_qkv >= 3LL * H * dh &&
-                  ld_dqkv >= 3LL * H * dh,
-              "gps_seg_attn_bwd: bad sizes");
-  GPS_REQUIRE(p_drop >= 0.0f && p_drop < 1.0f, "gps_seg_attn_bwd: p_drop=%f outside [0,1)", p_drop);
-  GPS_REQUIRE(N * (int64_t)H < INT32_MAX, "gps_seg_attn_bwd: N*H exceeds the 32-bit dropout row id");
-  if (N == 0 || max_tiles == 0) return GPS_OK;
-  GPS_REQUIRE(d_out && qkv && out && lse && ptr && tile_graph && tile_row0 && delta && d_qkv,
-              "gps_seg_attn_bwd: null buffer");
-  if (!gps_attn_supported_head_dim(dh)) {
-    gps::set_error("gps_seg_attn_bwd: head dim %d has no compiled kernel", dh);
-    return GPS_EUNSUPPORTED;
-  }
-  GPS_REQUIRE(N * ld_qkv < (int64_t(1) << 31) && N * ld_dqkv < (int64_t(1) << 31),
-              "gps_seg_attn_bwd: N * ld exceeds 32-bit element offsets");
-  const int64_t n_work = max_tiles * H;
-  const unsigned grid = gps::grid_for(n_work, 4);
-  hipStream_t s = gps::as_stream(stream);
-  const bool vec = ld_qkv % 4 == 0 && ld_dqkv % 4 == 0 && (H * dh) % 4 == 0 && al16(qkv) && al16(out) &&
-                   al16(d_out) && al16(d_qkv);
-#define LAUNCH_BWD(D, DROP, VEC)                                                                    \
-  do {                                                                                              \
-    k_attn_bwd_dq<D, DROP, VEC><<<grid, 256, 0, s>>>(d_out, qkv, ld_qkv, out, lse, delta, ptr, tile_graph, \
-                                                     tile_row0, n_work, N, H, scale, p_drop, seed,  \
-                                                     gps::dropout_salt(), d_qkv, ld_dqkv);          \
-    k_attn_bwd_dkv<D, DROP, VEC><<<grid, 256, 0, s>>>(d_out, qkv, ld_qkv, lse, delta, ptr, tile_graph,     \
-                                                      tile_row0, n_work, N, H, scale, p_drop, seed, \
-                                                      gps::dropout_salt(), d_qkv, ld_dqkv);         \
-  } while (0)
-  switch (dh) {
-#define X(D)                                                             \
-  case D:                                                                \
-    if (p_drop > 0.0f) {                                                 \
-      if (vec) LAUNCH_BWD(D, true, true); else LAUNCH_BWD(D, true, false);   \
-    } else {                                                             \
-      if (vec) LAUNCH_BWD(D, false, true); else LAUNCH_BWD(D, false, false); \
-    }                                                                    \
-    break;
-    GPS_FOR_EACH_DH(X)
-#undef X
-  }
-#undef LAUNCH_BWD
-  return gps::launch_status("gps_seg_attn_bwd");
+  return seg_attn_bwd_impl("gps_seg_attn_bwd", d_out, qkv, ld_qkv, nullptr, 0, out, lse, ptr, tile_graph,
+                           tile_row0, max_tiles, N, H, dh, scale, p_drop, seed, delta, d_qkv, ld_dqkv, nullptr,
+                           stream);
+}
+
+int gps_seg_attn_bias_fwd(const float* qkv, int64_t ld_qkv, const float* bias, int64_t nmax,
+                          const int32_t* ptr, const int32_t* tile_graph, const int32_t* tile_row0,
+                          int64_t max_tiles, int64_t N, int H, int dh, float scale, float p_drop,
+                          uint64_t seed, float* out, float* lse, gps_stream_t stream) {
+  GPS_REQUIRE(bias != nullptr || N == 0, "gps_seg_attn_bias_fwd: null bias");
+  return seg_attn_fwd_impl("gps_seg_attn_bias_fwd", qkv, ld_qkv, bias, nmax, ptr, tile_graph, tile_row0,
+                           max_tiles, N, H, dh, scale, p_drop, seed, out, lse, stream);
+}
+
+int gps_seg_attn_bias_bwd(const float* d_out, const float* qkv, int64_t ld_qkv, const float* bias,
+                          int64_t nmax, const float* out, const float* lse, const int32_t* ptr,
+                          const int32_t* tile_graph, const int32_t* tile_row0, int64_t max_tiles, int64_t N,
+                          int H, int dh, float scale, float p_drop, uint64_t seed, float* delta,
+                          float* d_qkv, int64_t ld_dqkv, float* d_bias, gps_stream_t stream) {
+  GPS_REQUIRE(bias != nullptr || N == 0, "gps_seg_attn_bias_bwd: null bias");
+  return seg_attn_bwd_impl("gps_seg_attn_bias_bwd", d_out, qkv, ld_qkv, bias, nmax, out, lse, ptr, tile_graph,
+                           tile_row0, max_tiles, N, H, dh, scale, p_drop, seed, delta, d_qkv, ld_dqkv, d_bias,
+                           stream);
 }
 
 }  // extern "C"

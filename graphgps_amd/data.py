@@ -86,8 +86,8 @@ class Batch:
     @staticmethod
     def from_graph_list(graphs: Iterable[Dict[str, torch.Tensor]]) -> "Batch":
         """Block-diagonal batching (PyG ``Batch.from_data_list`` semantics): node
-        tensors are concatenated, ``edge_index`` is offset by the running node
-        count, ``batch``/``ptr`` are emitted.  A key is a node tensor if its first
+        tensors are concatenated, ``edge_index`` (any ``*index*`` key) is offset by the running
+        node count, ``batch``/``ptr`` are emitted.  A key is a node tensor if its first
         dim equals the graph's ``x.shape[0]``, an edge tensor if it equals
         ``edge_index.shape[1]``, else per-graph."""
         graphs = list(graphs)
@@ -96,15 +96,15 @@ class Batch:
         for gi, g in enumerate(graphs):
             n = int(g["x"].shape[0])
             for k, v in g.items():
-                if k == "edge_index":
-                    v = v + off
+                if "index" in k:      # PyG: attributes named *index* hold node ids (edge_index, and
+                    v = v + off       # Graphormer's all-pairs graph_index) -> shifted, joined on dim -1
                 cat.setdefault(k, []).append(v)
             batch_vec.append(torch.full((n,), gi, dtype=torch.long))
             off += n
             ptr.append(off)
         out = Batch()
         for k, vs in cat.items():
-            out.__dict__[k] = torch.cat(vs, dim=1 if k == "edge_index" else 0)
+            out.__dict__[k] = torch.cat(vs, dim=-1 if "index" in k else 0)
         out.batch = torch.cat(batch_vec) if batch_vec else torch.zeros(0, dtype=torch.long)
         out.ptr = torch.tensor(ptr, dtype=torch.long)
         out.num_graphs = len(graphs)

@@ -91,7 +91,8 @@ class GPSLayer(nn.Module):
         # Global attention transformer-style model (reference :100-123).
         if global_model_type == 'None':
             self.self_attn = None
-        elif global_model_type == 'Transformer':
+        elif global_model_type in ('Transformer', 'BiasedTransformer'):
+            # BiasedTransformer = the same module, called with attn_mask=batch.attn_bias (:201-203)
             if dim_h % num_heads != 0:
                 raise AssertionError("embed_dim must be divisible by num_heads")
             # parameter container only (same names/init as the reference's module, :104-106);
@@ -107,10 +108,10 @@ class GPSLayer(nn.Module):
                     "built in this tree") from e
             self.self_attn = SelfAttention(dim=dim_h, heads=num_heads,
                                            dropout=self.attn_dropout, causal=False)
-        elif global_model_type in ('BiasedTransformer', 'BigBird'):
+        elif global_model_type == 'BigBird':
             raise NotImplementedError(
-                f"global_model_type={global_model_type!r} is outside the HIP hot path "
-                f"(SURVEY.md section 8f rank 3); supported: 'None', 'Transformer', 'Performer'")
+                "global_model_type='BigBird' (block-sparse attention) is outside the HIP hot path; "
+                "supported: 'None', 'Transformer', 'BiasedTransformer', 'Performer'")
         else:
             raise ValueError(f"Unsupported global x-former model: {global_model_type}")
         self.global_model_type = global_model_type
@@ -173,6 +174,9 @@ class GPSLayer(nn.Module):
             # the global branch attends over the PRE-layer h (reference :156,199)
             if self.global_model_type == 'Transformer':
                 h_attn = self._sa_block(h, gi)
+            elif self.global_model_type == 'BiasedTransformer':
+                # Graphormer-like conditioning, requires `batch.attn_bias` (reference :201-203)
+                h_attn = self._sa_block(h, gi, batch.attn_bias)
             elif self.global_model_type == 'Performer':
                 h_attn = self.self_attn.forward_segments(h, gi)
             else:
@@ -197,14 +201,15 @@ class GPSLayer(nn.Module):
         batch.x = h
         return batch
 
-    def _sa_block(self, x, gi):
+    def _sa_block(self, x, gi, attn_bias=None):
         """Self-attention block: packed in-proj GEMM -> varlen MFMA attention -> out-proj GEMM.
-        Same arithmetic as nn.MultiheadAttention(x, x, x, key_padding_mask=~mask)[mask]
-        (reference :199-201,234-241) without the dense padding."""
+        Same arithmetic as nn.MultiheadAttention(x, x, x, attn_mask=attn_bias,
+        key_padding_mask=~mask)[mask] (reference :199-203,234-241) without the dense padding; the
+        dense ``[B*H, nmax, nmax]`` bias is read in place, its n_g x n_g corners only."""
         sa = self.self_attn
         qkv = linear(x, sa.in_proj_weight, sa.in_proj_bias)
         p = self.attn_dropout if self.training else 0.0
-        o = segment_attention(qkv, gi, self.num_heads, p)
+        o = segment_attention(qkv, gi, self.num_heads, p, bias=attn_bias)
         return linear(o, sa.out_proj.weight, sa.out_proj.bias)
 
     def _ff_block(self, x):

@@ -284,9 +284,10 @@ def enable_dropout_salt(device) -> torch.Tensor:
 
 class _SegmentAttention(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, qkv: torch.Tensor, gi: GraphIndex, num_heads: int, p_drop: float, seed: int):
+    def forward(ctx, qkv: torch.Tensor, gi: GraphIndex, num_heads: int, p_drop: float, seed: int,
+                bias: Optional[torch.Tensor] = None):
         L = _lib.load()
-        dev = _require_cuda(qkv)
+        dev = _require_cuda(qkv, bias)
         qkv = _f32c(qkv, "qkv")
         N, H = gi.N, int(num_heads)
         d = qkv.shape[1] // 3
@@ -296,41 +297,84 @@ class _SegmentAttention(torch.autograd.Function):
         out = torch.empty(N, d, dtype=torch.float32, device=dev)
         lse = torch.empty(H, N, dtype=torch.float32, device=dev)
         scale = float(dh) ** -0.5
-        check(L.gps_seg_attn_fwd(ptr(qkv), 3 * d, ptr(gi.ptr), ptr(gi.tile_graph),
-                                 ptr(gi.tile_row0), gi.max_tiles, N, H, dh, scale, float(p_drop),
-                                 seed, ptr(out), ptr(lse), current_stream(dev)),
-              "gps_seg_attn_fwd")
-        ctx.save_for_backward(qkv, out, lse)
+        if bias is None:
+            check(L.gps_seg_attn_fwd(ptr(qkv), 3 * d, ptr(gi.ptr), ptr(gi.tile_graph),
+                                     ptr(gi.tile_row0), gi.max_tiles, N, H, dh, scale, float(p_drop),
+                                     seed, ptr(out), ptr(lse), current_stream(dev)),
+                  "gps_seg_attn_fwd")
+            ctx.save_for_backward(qkv, out, lse)
+        else:
+            bias = _f32c(bias, "attn_bias")
+            nmax = _check_attn_bias(bias, gi, H)
+            check(L.gps_seg_attn_bias_fwd(ptr(qkv), 3 * d, ptr(bias), nmax, ptr(gi.ptr),
+                                          ptr(gi.tile_graph), ptr(gi.tile_row0), gi.max_tiles, N, H, dh,
+                                          scale, float(p_drop), seed, ptr(out), ptr(lse),
+                                          current_stream(dev)), "gps_seg_attn_bias_fwd")
+            ctx.save_for_backward(qkv, out, lse, bias)
+        ctx.biased = bias is not None
         ctx.gi, ctx.H, ctx.dh, ctx.scale, ctx.p_drop, ctx.seed = gi, H, dh, scale, float(p_drop), seed
         return out
 
     @staticmethod
     def backward(ctx, d_out: torch.Tensor):
         L = _lib.load()
-        qkv, out, lse = ctx.saved_tensors
+        qkv, out, lse = ctx.saved_tensors[:3]
         gi: GraphIndex = ctx.gi
         dev = qkv.device
         d_out = _f32c(d_out, "d_out")
         N, H, dh = gi.N, ctx.H, ctx.dh
         d_qkv = torch.empty_like(qkv)
         delta = torch.empty(H, N, dtype=torch.float32, device=dev)
-        check(L.gps_seg_attn_bwd(ptr(d_out), ptr(qkv), qkv.shape[1], ptr(out), ptr(lse), ptr(gi.ptr),
-                                 ptr(gi.tile_graph), ptr(gi.tile_row0), gi.max_tiles, N, H, dh,
-                                 ctx.scale, ctx.p_drop, ctx.seed, ptr(delta), ptr(d_qkv),
-                                 d_qkv.shape[1], current_stream(dev)), "gps_seg_attn_bwd")
-        return d_qkv, None, None, None, None
+        if not ctx.biased:
+            check(L.gps_seg_attn_bwd(ptr(d_out), ptr(qkv), qkv.shape[1], ptr(out), ptr(lse), ptr(gi.ptr),
+                                     ptr(gi.tile_graph), ptr(gi.tile_row0), gi.max_tiles, N, H, dh,
+                                     ctx.scale, ctx.p_drop, ctx.seed, ptr(delta), ptr(d_qkv),
+                                     d_qkv.shape[1], current_stream(dev)), "gps_seg_attn_bwd")
+            return d_qkv, None, None, None, None, None
+        bias = ctx.saved_tensors[3]
+        d_bias = torch.zeros_like(bias)       # padded region: zero gradient, as under the reference's mask
+        check(L.gps_seg_attn_bias_bwd(ptr(d_out), ptr(qkv), qkv.shape[1], ptr(bias), bias.shape[1],
+                                      ptr(out), ptr(lse), ptr(gi.ptr), ptr(gi.tile_graph),
+                                      ptr(gi.tile_row0), gi.max_tiles, N, H, dh, ctx.scale, ctx.p_drop,
+                                      ctx.seed, ptr(delta), ptr(d_qkv), d_qkv.shape[1], ptr(d_bias),
+                                      current_stream(dev)), "gps_seg_attn_bias_bwd")
+        return d_qkv, None, None, None, None, d_bias
+
+
+def max_graph_size(gi: GraphIndex) -> int:
+    """Largest graph of the batch (what ``to_dense_batch`` pads to).  One device->host read per batch,
+    cached on the index; only the biased-attention path needs it on the host (to validate the dense
+    ``attn_bias`` it is handed), the plain path never asks."""
+    n = gi.__dict__.get("_nmax_host")
+    if n is None:
+        n = int((gi.ptr[1:] - gi.ptr[:-1]).max().item()) if gi.B > 0 else 0
+        gi.__dict__["_nmax_host"] = n
+    return n
+
+
+def _check_attn_bias(bias: torch.Tensor, gi: GraphIndex, H: int) -> int:
+    if bias.dim() != 3 or bias.shape[0] != gi.B * H or bias.shape[1] != bias.shape[2]:
+        raise _lib.GpsHipError(f"attn_bias must be [B*H, nmax, nmax] = [{gi.B * H}, n, n], got "
+                               f"{tuple(bias.shape)}")
+    nmax = int(bias.shape[1])
+    need = max_graph_size(gi)
+    if nmax < need:
+        raise _lib.GpsHipError(f"attn_bias is padded to {nmax} nodes but the largest graph has {need}")
+    return nmax
 
 
 def segment_attention(qkv: torch.Tensor, gi: GraphIndex, num_heads: int, p_drop: float = 0.0,
-                      seed: Optional[int] = None) -> torch.Tensor:
-    """softmax(q k^T / sqrt(dh)) (dropout) v per graph and head, straight off ``ptr``.
+                      seed: Optional[int] = None, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """softmax(q k^T / sqrt(dh) [+ bias]) (dropout) v per graph and head, straight off ``ptr``.
 
     ``qkv`` is the packed in-projection output [N, 3d] (``torch.nn.MultiheadAttention``'s
     ``in_proj_weight`` layout).  Replaces graphgps/layer/gps_layer.py:199-201 + the core of
-    ``nn.MultiheadAttention``."""
+    ``nn.MultiheadAttention``.  ``bias`` is the reference's dense ``batch.attn_bias``
+    ``[B*H, nmax, nmax]`` (gps_layer.py:201-203, graphormer_layer.py:43-44): its gradient comes back in
+    the same dense layout."""
     if p_drop > 0.0 and seed is None:
         seed = draw_dropout_seed()
-    return _SegmentAttention.apply(qkv, gi, num_heads, float(p_drop), int(seed or 0))
+    return _SegmentAttention.apply(qkv, gi, num_heads, float(p_drop), int(seed or 0), bias)
 
 
 def attn_dropout_keep_mask(seed: int, q_global: torch.Tensor, head: int, num_heads: int,

@@ -126,7 +126,8 @@ int gps_gine_bwd(const float* g_out, const float* x, const float* e, const int32
  *   out  [N, d]   heads merged;   lse [H, N] log-sum-exp per (head, query), saved for backward
  * Attention dropout (p_drop in [0,1)) uses a counter-based hash of (seed, query, head, key) so
  * that forward and backward regenerate the same mask; p_drop == 0 disables it.
- * Supported head dims: 4..128 (any), see gps_attn_supported_head_dim().
+ * Supported head dims: the compiled set {4, 6, 8, 10, 12, 13, 16, 18, 20, 24, 32, 48, 64, 76, 96, 128}
+ * (every dim_hidden / n_heads of configs/GPS and configs/Graphormer), see gps_attn_supported_head_dim().
  * ------------------------------------------------------------------------------------- */
 int gps_attn_supported_head_dim(int dh);
 int gps_seg_attn_fwd(const float* qkv, int64_t ld_qkv, const int32_t* ptr,
@@ -140,6 +141,24 @@ int gps_seg_attn_bwd(const float* d_out, const float* qkv, int64_t ld_qkv, const
                      const int32_t* tile_row0, int64_t max_tiles, int64_t N, int H, int dh,
                      float scale, float p_drop, uint64_t seed, float* delta, float* d_qkv,
                      int64_t ld_dqkv, gps_stream_t stream);
+/* The same core with an additive attention bias: the reference's `attn_mask=batch.attn_bias` operand of
+ * torch.nn.MultiheadAttention in the BiasedTransformer branch (graphgps/layer/gps_layer.py:201-203,
+ * 234-241) and in GraphormerLayer (graphgps/layer/graphormer_layer.py:43-44).
+ *   bias   fp32 [B*H, nmax, nmax], plane (g*H + h), element [query, key] -- the layout the reference's
+ *          BiasEncoder emits (graphgps/encoder/graphormer_encoder.py:148-183); nmax >= every graph size.
+ *          softmax(q k^T / sqrt(dh) + bias): only the n_g x n_g corner of each plane is read.
+ *   d_bias same shape, caller ZERO-FILLED: the backward writes dS into the n_g x n_g corners only
+ *          (the padded region has zero gradient in the reference as well: -inf-masked keys).
+ * nmax * nmax must stay below 2^31 (32-bit element offsets inside a plane). */
+int gps_seg_attn_bias_fwd(const float* qkv, int64_t ld_qkv, const float* bias, int64_t nmax,
+                          const int32_t* ptr, const int32_t* tile_graph, const int32_t* tile_row0,
+                          int64_t max_tiles, int64_t N, int H, int dh, float scale, float p_drop,
+                          uint64_t seed, float* out, float* lse, gps_stream_t stream);
+int gps_seg_attn_bias_bwd(const float* d_out, const float* qkv, int64_t ld_qkv, const float* bias,
+                          int64_t nmax, const float* out, const float* lse, const int32_t* ptr,
+                          const int32_t* tile_graph, const int32_t* tile_row0, int64_t max_tiles, int64_t N,
+                          int H, int dh, float scale, float p_drop, uint64_t seed, float* delta,
+                          float* d_qkv, int64_t ld_dqkv, float* d_bias, gps_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * FAVOR+ (Performer softmax-kernel linear attention) over `ptr` segments on fp32 MFMA.

@@ -7,7 +7,7 @@ it needs /root/reference, which does not exist on the GPU box.
     python oracle/gen_golden.py            # rewrites tests/golden/*.pt
 
 What executes: ``/root/reference/graphgps/layer/{gps_layer,gatedgcn_layer,gine_conv_layer,
-performer_layer}.py`` imported unmodified from where they lie, hosted on the stand-in modules
+performer_layer,graphormer_layer}.py`` and ``graphgps/encoder/graphormer_encoder.py`` imported unmodified from where they lie, hosted on the stand-in modules
 in ``oracle/ref_stubs`` for the third-party packages that are absent here.  So the in-tree
 arithmetic of the fixtures is the reference's; PyG / torch_scatter semantics are the stubs'
 restatement (see oracle/ref_stubs/README.md).
@@ -38,6 +38,7 @@ set_cfg(cfg)
 # the reference's files register their GraphGym wrappers under the same names as this package's
 for _k in ("gatedgcnconv", "gineconv"):
     graphgps_amd.graphgym.register.layer_dict.pop(_k, None)
+graphgps_amd.graphgym.register.node_encoder_dict.pop("GraphormerBias", None)
 from graphgps.layer.gps_layer import GPSLayer as RefGPSLayer  # noqa: E402
 from torch_geometric.data import Batch as StubBatch  # noqa: E402
 
@@ -58,6 +59,10 @@ CASES = {
     "gatedgcn_eslappe_transformer_d32h4": (dict(dim_h=32, local_gnn_type="CustomGatedGCN",
                                                 global_model_type="Transformer", num_heads=4,
                                                 equivstable_pe=True), "P14", 6, 16),
+    # BiasedTransformer (gps_layer.py:201-203): the layer additionally reads a dense batch.attn_bias
+    # [B*H, nmax, nmax] (random here; graphormer_encoder.py produces it in a model)
+    "gine_biasedtransformer_d32h4": (dict(dim_h=32, local_gnn_type="GINE",
+                                          global_model_type="BiasedTransformer", num_heads=4), "ZINC", 5, 22),
     # (no GINE + equivstable_pe fixture: the reference's GINEConvESLapPE cannot be constructed -- its
     #  __init__ calls reset_parameters(), which touches self.mlp_r_ij, before defining it:
     #  gine_conv_layer.py:35 vs :43-54.  The HIP layer implements the intended arithmetic and is
@@ -88,6 +93,11 @@ def run_case(name, kw, profile, num_graphs, seed):
     if kw.get("equivstable_pe"):
         pe = (torch.randn(N, d, generator=gen) * 0.5).requires_grad_(True)
         batch.pe_EquivStableLapPE = pe
+    bias = None
+    if kw["global_model_type"] == "BiasedTransformer":
+        nmax = int((ptr[1:] - ptr[:-1]).max())
+        bias = torch.randn(num_graphs * kw["num_heads"], nmax, nmax, generator=gen, requires_grad=True)
+        batch.attn_bias = bias
     out = layer(batch)
     loss = (out.x * wx).sum() + (out.edge_attr * we).sum()
     loss.backward()
@@ -104,20 +114,120 @@ def run_case(name, kw, profile, num_graphs, seed):
     if pe is not None:
         fix["pe"] = pe.detach().clone()
         fix["grad_pe"] = pe.grad.clone()
+    if bias is not None:
+        fix["attn_bias"] = bias.detach().clone()
+        fix["grad_attn_bias"] = bias.grad.clone()
     layer.eval()
     with torch.no_grad():
         eb = StubBatch(x=x.detach(), edge_index=edge_index, edge_attr=e.detach(), batch=bvec)
         if pe is not None:
             eb.pe_EquivStableLapPE = pe.detach()
+        if bias is not None:
+            eb.attn_bias = bias.detach()
         ob = layer(eb)
     fix["eval_out_x"] = ob.x.clone()
     fix["eval_out_edge_attr"] = ob.edge_attr.clone()
     return fix
 
 
+def _graphormer_graphs(seed, sizes, num_edge_types=4, num_node_types=28):
+    """Small directed test graphs: an undirected random tree + a few extra (some one-way) edges, one isolated
+    node in the last graph, duplicate edge columns in the first -- the cases the pre-processing must agree on
+    (multi-path ties, unreachable pairs, clipping at `distance`)."""
+    g = torch.Generator().manual_seed(seed)
+    graphs = []
+    for gi_, n in enumerate(sizes):
+        src, dst = [], []
+        last = n - 1 if gi_ == len(sizes) - 1 and n > 2 else n      # leave the last node isolated
+        for v in range(1, last):
+            u = int(torch.randint(0, v, (1,), generator=g))
+            src += [u, v]
+            dst += [v, u]
+        for _ in range(max(1, n // 3)):
+            u, v = (int(t) for t in torch.randint(0, last, (2,), generator=g))
+            if u != v:
+                src.append(u)
+                dst.append(v)
+        if gi_ == 0 and src:
+            src.append(src[0])
+            dst.append(dst[0])
+        ei = torch.tensor([src, dst], dtype=torch.long)
+        perm = torch.randperm(ei.shape[1], generator=g)
+        ei = ei[:, perm]
+        graphs.append(dict(x=torch.randint(0, num_node_types, (n, 1), generator=g), edge_index=ei,
+                           edge_attr=torch.randint(0, num_edge_types, (ei.shape[1],), generator=g)))
+    return graphs
+
+
+def run_graphormer(seed=21):
+    """The reference's Graphormer pieces, unmodified: graphormer_pre_processing (networkx shortest paths),
+    BiasEncoder + NodeEncoder (graphormer_encoder.py), GraphormerLayer (graphormer_layer.py) and the
+    BiasedTransformer branch of GPSLayer (gps_layer.py:201-203)."""
+    from graphgps.encoder.graphormer_encoder import (BiasEncoder, NodeEncoder,
+                                                     graphormer_pre_processing)
+    from graphgps.layer.graphormer_layer import GraphormerLayer as RefGraphormerLayer
+    from graphgps_amd.data import Batch as MyBatch
+    torch.manual_seed(seed)
+    H, D, dist = 4, 40, 5
+    cfg.posenc_GraphormerBias.num_in_degrees = 16
+    cfg.posenc_GraphormerBias.num_out_degrees = 16
+    cfg.posenc_GraphormerBias.node_degrees_only = False
+    out = {}
+    for token in (False, True):
+        graphs = _graphormer_graphs(seed, [7, 12, 5, 9])
+        pre = []
+        for gr in graphs:
+            d = StubBatch(**{k: v.clone() for k, v in gr.items()})
+            d.num_nodes = gr["x"].shape[0]
+            d = graphormer_pre_processing(d, dist)
+            pre.append({k: getattr(d, k) for k in ("x", "edge_index", "edge_attr", "in_degrees", "out_degrees",
+                                                   "spatial_types", "graph_index", "shortest_path_types")})
+        b = MyBatch.from_graph_list(pre)
+        data = StubBatch(**{k: getattr(b, k) for k in b.keys()})
+        bias_enc = BiasEncoder(H, dist, 4, use_graph_token=token)
+        node_enc = NodeEncoder(D, 16, 16, input_dropout=0.0, use_graph_token=token)
+        layer = RefGraphormerLayer(D, H, dropout=0.0, attention_dropout=0.0, mlp_dropout=0.0)
+        layer.train()
+        sd = {"bias": {k: v.clone() for k, v in bias_enc.state_dict().items()},
+              "node": {k: v.clone() for k, v in node_enc.state_dict().items()},
+              "layer": {k: v.clone() for k, v in layer.state_dict().items()}}
+        data.x = torch.randn(b.x.shape[0], D)
+        x0 = data.x.clone()
+        data = bias_enc(data)
+        # add_graph_token (graphormer_encoder.py:199-203) groups the token rows with their graphs through
+        # ``torch.sort(data.batch)`` and relies on equal keys keeping their order -- which torch.sort only
+        # guarantees with stable=True (on this CPU build the default already scrambles the rows of a
+        # 13-node graph, after which the reference's attn_bias no longer lines up with its own rows and the
+        # token is not the first row ``graph_token`` pooling reads).  The fixture records the intended
+        # behaviour: the reference's code, run with a stable sort.
+        _sort = torch.sort
+        torch.sort = lambda t, *a, **k: _sort(t, *a, **dict(k, stable=True))
+        try:
+            data = node_enc(data)
+        finally:
+            torch.sort = _sort
+        attn_bias, x_enc = data.attn_bias, data.x
+        attn_bias.retain_grad()
+        data = layer(data)
+        w = torch.randn(data.x.shape)
+        (data.x * w).sum().backward()
+        key = "token" if token else "plain"
+        out[key] = dict(
+            graphs=graphs, pre=pre, H=H, D=D, dist=dist, state=sd, x0=x0, w=w,
+            attn_bias=attn_bias.detach().clone(), x_enc=x_enc.detach().clone(), batch_after=data.batch.clone(),
+            out_x=data.x.detach().clone(), grad_attn_bias=attn_bias.grad.clone(),
+            grads={"bias": {k: p.grad.clone() for k, p in bias_enc.named_parameters() if p.grad is not None},
+                   "node": {k: p.grad.clone() for k, p in node_enc.named_parameters() if p.grad is not None},
+                   "layer": {k: p.grad.clone() for k, p in layer.named_parameters() if p.grad is not None}})
+    return out
+
+
 def main():
     outdir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(outdir, exist_ok=True)
+    fix = run_graphormer()
+    torch.save(fix, os.path.join(outdir, "graphormer_encoder_layer.pt"))
+    print("graphormer_encoder_layer:", {k: tuple(v["attn_bias"].shape) for k, v in fix.items()})
     for name, (kw, profile, nb, seed) in CASES.items():
         fix = run_case(name, kw, profile, nb, seed)
         path = os.path.join(outdir, f"{name}.pt")

@@ -231,7 +231,7 @@ class OraclePerformerSelfAttention(nn.Module):
 # ---------------------------------------------------------------------------
 class OracleGPSLayer(nn.Module):
     """graphgps/layer/gps_layer.py:15-257 for local in {None, CustomGatedGCN, GINE} and
-    global in {None, Transformer, Performer}, batch_norm or no norm."""
+    global in {None, Transformer, BiasedTransformer, Performer}, batch_norm or no norm."""
 
     def __init__(self, dim_h, local_gnn_type, global_model_type, num_heads, act="relu",
                  pna_degrees=None, equivstable_pe=False, dropout=0.0, attn_dropout=0.0,
@@ -255,7 +255,7 @@ class OracleGPSLayer(nn.Module):
             raise ValueError(f"Unsupported local GNN model: {local_gnn_type}")
         if global_model_type == "None":
             self.self_attn = None
-        elif global_model_type == "Transformer":
+        elif global_model_type in ("Transformer", "BiasedTransformer"):
             self.self_attn = nn.MultiheadAttention(dim_h, num_heads, dropout=attn_dropout,
                                                    batch_first=True)        # :104-106
         elif global_model_type == "Performer":
@@ -299,6 +299,9 @@ class OracleGPSLayer(nn.Module):
             if self.global_model_type == "Transformer":
                 h_attn = self.self_attn(h_dense, h_dense, h_dense, attn_mask=None,
                                         key_padding_mask=~mask, need_weights=False)[0][mask]  # :201,238-241
+            elif self.global_model_type == "BiasedTransformer":
+                h_attn = self.self_attn(h_dense, h_dense, h_dense, attn_mask=batch.attn_bias,
+                                        key_padding_mask=~mask, need_weights=False)[0][mask]  # :203
             else:
                 h_attn = self.self_attn(h_dense, mask=mask)[mask]                    # :206
             h_attn = self.dropout_attn(h_attn)
@@ -312,6 +315,30 @@ class OracleGPSLayer(nn.Module):
             h = self.norm2(h)
         batch.x = h
         return batch
+
+
+class OracleGraphormerLayer(nn.Module):
+    """graphgps/layer/graphormer_layer.py:5-49: pre-LN MHA with the additive ``attn_bias`` mask,
+    dropout + residual, then the pre-LN GELU MLP (hidden = embed dim) + residual."""
+
+    def __init__(self, embed_dim, num_heads, dropout, attention_dropout, mlp_dropout):
+        super().__init__()
+        self.attention = nn.MultiheadAttention(embed_dim, num_heads, attention_dropout,
+                                               batch_first=True)                     # :21-24
+        self.input_norm = nn.LayerNorm(embed_dim)
+        self.dropout = nn.Dropout(dropout)
+        self.mlp = nn.Sequential(nn.LayerNorm(embed_dim), nn.Linear(embed_dim, embed_dim), nn.GELU(),
+                                 nn.Dropout(mlp_dropout), nn.Linear(embed_dim, embed_dim),
+                                 nn.Dropout(dropout))                                # :30-37
+
+    def forward(self, data):
+        x = self.input_norm(data.x)                                                  # :40
+        x, real = to_dense_batch(x, data.batch, getattr(data, "num_graphs", None))   # :41
+        bias = getattr(data, "attn_bias", None)
+        x = self.attention(x, x, x, ~real, attn_mask=bias)[0][real]                  # :43-46
+        x = self.dropout(x) + data.x                                                 # :47
+        data.x = self.mlp(x) + x                                                     # :48
+        return data
 
 
 class _OracleGatedGCNBatchLayer(OracleGatedGCNLayer):
@@ -341,7 +368,8 @@ class _OracleGINEConvLayer(nn.Module):
 
 
 def to_oracle_model(model: nn.Module) -> nn.Module:
-    """Swap every HIP-backed layer of a ``graphgps_amd`` ``GPSModel`` (``layers``: ``GPSLayer``) or
+    """Swap every HIP-backed layer of a ``graphgps_amd`` ``GPSModel`` / ``GraphormerModel`` (``layers``:
+    ``GPSLayer`` / ``GraphormerLayer``) or
     ``CustomGNN`` (``gnn_layers``: ``GatedGCNLayer`` / ``GINEConvLayer``) for its oracle twin with
     identical ``state_dict`` keys (encoders / heads are plain PyTorch in both).  Used by the parity
     tests and bench.py's cpu_baseline leg."""
@@ -362,7 +390,10 @@ def to_oracle_model(model: nn.Module) -> nn.Module:
         return model
     new_layers = []
     for layer in model.layers:
-        o = OracleGPSLayer(**layer.ctor_kwargs)
+        if hasattr(layer, "input_norm"):          # graphgps_amd.layer.graphormer_layer.GraphormerLayer
+            o = OracleGraphormerLayer(**layer.ctor_kwargs)
+        else:
+            o = OracleGPSLayer(**layer.ctor_kwargs)
         missing = o.load_state_dict(layer.state_dict(), strict=True)
         o.train(layer.training)
         new_layers.append(o)

@@ -22,3 +22,38 @@ def to_dense_batch(x, batch=None, fill_value=0.0, max_num_nodes=None, batch_size
     mask = torch.zeros(batch_size * max_num_nodes, dtype=torch.bool, device=x.device)
     mask[idx] = 1
     return out, mask.view(batch_size, max_num_nodes)
+
+
+def to_dense_adj(edge_index, batch=None, edge_attr=None, max_num_nodes=None):
+    """PyG 2.2 published behaviour: [B, Nmax, Nmax, *attr dims] with entry (b, i - first(b), j - first(b))
+    = sum of edge_attr over the edges (i, j) of graph b (ones when edge_attr is None), zeros elsewhere."""
+    if batch is None:
+        batch = edge_index.new_zeros(int(edge_index.max()) + 1 if edge_index.numel() else 0)
+    batch_size = int(batch.max()) + 1 if batch.numel() else 1
+    num_nodes = torch.zeros(batch_size, dtype=torch.long, device=batch.device).index_add_(
+        0, batch, torch.ones_like(batch))
+    cum_nodes = torch.cat([batch.new_zeros(1), num_nodes.cumsum(dim=0)])
+    idx0 = batch[edge_index[0]]
+    idx1 = edge_index[0] - cum_nodes[batch][edge_index[0]]
+    idx2 = edge_index[1] - cum_nodes[batch][edge_index[1]]
+    if max_num_nodes is None:
+        max_num_nodes = int(num_nodes.max())
+    if edge_attr is None:
+        edge_attr = torch.ones(idx0.numel(), device=edge_index.device)
+    size = [batch_size, max_num_nodes, max_num_nodes] + list(edge_attr.size())[1:]
+    flat = idx0 * max_num_nodes * max_num_nodes + idx1 * max_num_nodes + idx2
+    adj = edge_attr.new_zeros([batch_size * max_num_nodes * max_num_nodes] + list(edge_attr.size())[1:])
+    adj = adj.index_add(0, flat, edge_attr)
+    return adj.view(size)
+
+
+def to_networkx(data, *args, **kwargs):
+    """PyG 2.2 published behaviour (defaults): a networkx.DiGraph with nodes 0..num_nodes-1 added in order
+    and one edge per column of ``edge_index``, added in column order."""
+    import networkx as nx
+    G = nx.DiGraph()
+    n = int(data.num_nodes) if getattr(data, "num_nodes", None) is not None else int(data.x.shape[0])
+    G.add_nodes_from(range(n))
+    for u, v in zip(data.edge_index[0].tolist(), data.edge_index[1].tolist()):
+        G.add_edge(u, v)
+    return G

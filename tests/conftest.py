@@ -24,8 +24,12 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+GRAPHORMER_GOLDEN = "graphormer_encoder_layer"      # encoder + GraphormerLayer fixture (own structure)
+
+
 def golden_names():
-    return sorted(f[:-3] for f in os.listdir(GOLDEN_DIR) if f.endswith(".pt"))
+    """The GPSLayer fixtures (one layer, one batch each)."""
+    return sorted(f[:-3] for f in os.listdir(GOLDEN_DIR) if f.endswith(".pt") and f[:-3] != GRAPHORMER_GOLDEN)
 
 
 def load_golden(name):

@@ -21,8 +21,9 @@ def gine_core_ref(x, e, edge_index, eps=0.0):
     return scatter_sum((x.index_select(0, j) + e).relu(), i, x.shape[0]) + (1 + eps) * x
 
 
-def segment_attention_ref(qkv, ptr, H, keep=None, p_drop=0.0):
-    """Dense per-graph softmax attention; ``keep`` optional list (per graph) of bool [H,n,n]."""
+def segment_attention_ref(qkv, ptr, H, keep=None, p_drop=0.0, bias=None):
+    """Dense per-graph softmax attention; ``keep`` optional list (per graph) of bool [H,n,n]; ``bias`` the
+    reference's dense additive mask [B*H, nmax, nmax] (plane g*H + h, its n x n corner is what counts)."""
     N, d3 = qkv.shape
     d = d3 // 3
     dh = d // H
@@ -37,6 +38,8 @@ def segment_attention_ref(qkv, ptr, H, keep=None, p_drop=0.0):
         k = qkv[a:b, d:2 * d].view(n, H, dh).transpose(0, 1)
         v = qkv[a:b, 2 * d:].view(n, H, dh).transpose(0, 1)
         s = (q * dh ** -0.5) @ k.transpose(1, 2)
+        if bias is not None:
+            s = s + bias[g * H:(g + 1) * H, :n, :n]
         p = torch.softmax(s, dim=-1)
         if keep is not None:
             p = p * keep[g].to(p.dtype) / (1.0 - p_drop)

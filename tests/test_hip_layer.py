@@ -24,10 +24,16 @@ def _run_layer(layer, fix, dev):
     if "pe" in fix:                       # EquivStableLapPE fixtures
         pe = fix["pe"].to(dev).requires_grad_(True)
         b.pe_EquivStableLapPE = pe
+    bias = None
+    if "attn_bias" in fix:                # BiasedTransformer fixtures: dense [B*H, nmax, nmax] operand
+        bias = fix["attn_bias"].to(dev).requires_grad_(True)
+        b.attn_bias = bias
     out = layer(b)
     ((out.x * fix["wx"].to(dev)).sum() + (out.edge_attr * fix["we"].to(dev)).sum()).backward()
     if pe is not None:
         assert_close(pe.grad, fix["grad_pe"], Tol.GRAD_REL, "grad pe", rel_to_max=True)
+    if bias is not None:
+        assert_close(bias.grad, fix["grad_attn_bias"], Tol.GRAD_REL, "grad attn_bias", rel_to_max=True)
     return out, x, e
 
 
@@ -62,6 +68,8 @@ def _check_against_fixture(name):
                    edge_attr=fix["edge_attr"].to(dev), batch=fix["batch"].to(dev))
         if "pe" in fix:
             eb.pe_EquivStableLapPE = fix["pe"].to(dev)
+        if "attn_bias" in fix:
+            eb.attn_bias = fix["attn_bias"].to(dev)
         ob = layer(eb)
     assert_close(ob.x, fix["eval_out_x"], Tol.ACT, "eval out.x")
     assert_close(ob.edge_attr, fix["eval_out_edge_attr"], Tol.ACT, "eval out.edge_attr")
@@ -355,3 +363,88 @@ def test_gpslayer_ragged_and_boundary_graph_sizes(local, glob, d, H, es):
             continue
         diff = (p.grad.detach().cpu().double() - op[k].grad.double()).abs().max().item()
         assert diff <= 1e-4 * max(float(op[k].grad.abs().max()), 0.01 * gscale, 1.0), f"grad {k}: {diff:.3e}"
+
+
+@pytest.mark.parametrize("variant", ["plain", "token"])
+def test_graphormer_layer_and_encoders_match_reference_fixture(variant):
+    """Reference graphormer_encoder.py + graphormer_layer.py fixture (oracle/gen_golden.py:run_graphormer) on
+    the GPU: BiasEncoder -> NodeEncoder (device torch ops) -> GraphormerLayer (varlen MFMA attention with the
+    dense bias operand, dh = 10): attn_bias, encoded x, layer output, d(attn_bias) from the kernel, and every
+    parameter gradient of the three modules (the embedding tables get theirs THROUGH the kernel's d_bias)."""
+    from conftest import GRAPHORMER_GOLDEN
+    from graphgps_amd.data import Batch
+    from graphgps_amd.encoder.graphormer_encoder import BiasEncoder, NodeEncoder
+    from graphgps_amd.layer.graphormer_layer import GraphormerLayer
+    dev = torch.device("cuda:0")
+    fix = load_golden(GRAPHORMER_GOLDEN)[variant]
+    token = variant == "token"
+    H, D = fix["H"], fix["D"]
+    data = Batch.from_graph_list(fix["pre"])
+    data.x = fix["x0"].clone()
+    data = data.to(dev)
+    bias_enc = BiasEncoder(H, fix["dist"], 4, use_graph_token=token)
+    node_enc = NodeEncoder(D, 16, 16, input_dropout=0.0, use_graph_token=token)
+    layer = GraphormerLayer(D, H, dropout=0.0, attention_dropout=0.0, mlp_dropout=0.0)
+    bias_enc.load_state_dict(fix["state"]["bias"], strict=True)
+    node_enc.load_state_dict(fix["state"]["node"], strict=True)
+    layer.load_state_dict(fix["state"]["layer"], strict=True)      # checkpoint interchange contract
+    for m in (bias_enc, node_enc, layer):
+        m.to(dev).train()
+    data = node_enc(bias_enc(data))
+    assert_close(data.attn_bias, fix["attn_bias"], Tol.ACT, "attn_bias")
+    assert_close(data.x, fix["x_enc"], Tol.ACT, "encoded x")
+    assert torch.equal(data.batch.cpu(), fix["batch_after"])
+    bias = data.attn_bias
+    bias.retain_grad()
+    data = layer(data)
+    (data.x * fix["w"].to(dev)).sum().backward()
+    assert_close(data.x, fix["out_x"], Tol.ACT, "layer out")
+    assert_close(bias.grad, fix["grad_attn_bias"], Tol.GRAD_REL, "grad attn_bias", rel_to_max=True)
+    for part, mod in (("bias", bias_enc), ("node", node_enc), ("layer", layer)):
+        got = dict(mod.named_parameters())
+        gs = max(float(v.abs().max()) for v in fix["grads"][part].values())
+        for k, g in fix["grads"][part].items():
+            a_, b_ = got[k].grad.detach().double().cpu(), g.double()
+            assert (a_ - b_).abs().max().item() <= Tol.GRAD_REL * max(float(b_.abs().max()), 0.01 * gs, 1.0), \
+                f"grad {part}.{k}: {(a_ - b_).abs().max().item():.3e}"
+
+
+@pytest.mark.parametrize("cfg_name,overrides", [
+    # configs/Graphormer/zinc-Graphormer.yaml: graph token, graph_token pooling, 8 heads x dh 10
+    ("zinc_graphormer.yaml", ["graphormer.num_layers", 3, "graphormer.attention_dropout", 0.0,
+                              "graphormer.mlp_dropout", 0.0, "graphormer.input_dropout", 0.0]),
+    # configs/GPS/zinc-GPSwGraphormer.yaml: GINE + BiasedTransformer GPS layers, bias from the same encoder
+    ("zinc_gps_graphormer_rwse.yaml", ["gt.layers", 3, "gt.attn_dropout", 0.0]),
+])
+def test_graphormer_models_vs_oracle(cfg_name, overrides):
+    """Whole models on the Graphormer attention bias: encoder (host shortest-path statistics -> device
+    BiasEncoder) -> layers on the HIP kernels -> head, against the oracle model: prediction, loss and every
+    parameter gradient (the bias embeddings receive theirs through the kernel's d_bias)."""
+    from graphgps_amd.encoder.graphormer_encoder import add_graphormer_stats
+    from graphgps_amd.synthetic import model_batch
+    from oracle.gps_oracle import to_oracle_model
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = _build_model(cfg_name, 1, 1, overrides)
+    model.train()
+    oracle = to_oracle_model(model)
+    model.to(dev)
+    b = add_graphormer_stats(model_batch("zinc", 24, seed=5))
+    po, _ = oracle(b.clone())
+    lo = (po ** 2).mean() + po.sum() * 0.01
+    lo.backward()
+    pg, _ = model(b.clone().to(dev))
+    lg = (pg ** 2).mean() + pg.sum() * 0.01
+    lg.backward()
+    assert_close(pg, po, 1e-4, "pred")
+    assert_close(lg, lo, 1e-5, "loss")
+    op = dict(oracle.named_parameters())
+    checked = 0
+    for k, p in model.named_parameters():
+        if op[k].grad is None or p.grad is None:
+            continue
+        assert_close(p.grad, op[k].grad, 1e-3, f"grad {k}", rel_to_max=True)
+        checked += 1
+    assert checked > 20
+    assert any("spatial_encoder" in k and p.grad is not None and float(p.grad.abs().max()) > 0
+               for k, p in model.named_parameters())

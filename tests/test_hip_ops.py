@@ -127,6 +127,8 @@ ATTN_CASES = [  # (H, dh, graph sizes)
     (4, 64, [1000, 3, 601]),      # code2-size graphs (master_loader.py:366-368 clips at 1000 nodes)
     (1, 128, [48, 2]),            # widest compiled head
     (2, 4, [5, 16, 32, 64]),      # narrowest compiled head, sizes exactly on the tile boundaries
+    (8, 10, [12, 33, 7]),         # zinc-Graphormer: embed 80 / 8 heads
+    (4, 20, [31, 5, 48]),
 ]
 
 
@@ -195,6 +197,66 @@ def test_segment_attention_dropout_shared_mask(H, dh, sizes):
     (out * w.cuda()).sum().backward()
     assert_close(out, ref, Tol.ACT, "attn out (dropout)")
     assert_close(qg.grad, qr.grad, Tol.GRAD_REL, "d_qkv (dropout)", rel_to_max=True)
+
+
+@pytest.mark.parametrize("H,dh,sizes,pad,p", [
+    (4, 16, [23, 9, 37, 16, 1, 17], 0, 0.0),     # zinc-GPSwGraphormer head shape; sizes on/around tile edges
+    (8, 10, [12, 33, 20, 5], 0, 0.0),            # zinc-Graphormer: embed 80 / 8 heads
+    (4, 20, [31, 64, 2], 3, 0.0),                # bias padded wider than the largest graph
+    (16, 24, [30, 45, 70], 0, 0.25),             # two key blocks + attention dropout (shared mask)
+    (2, 64, [150, 129], 1, 0.0),                 # several online-softmax blocks
+])
+def test_segment_attention_additive_bias(H, dh, sizes, pad, p):
+    """softmax(q k^T / sqrt(dh) + bias) with the reference's dense [B*H, nmax, nmax] bias operand
+    (gps_layer.py:201-203, graphormer_layer.py:43-44): output, d_qkv and d_bias against the dense per-graph
+    fp64 reference; the gradient of the padded region is exactly zero."""
+    from graphgps_amd.ops import attn_dropout_keep_mask, segment_attention
+    seed = 0x0BADC0DE12345678
+    qkv, w, ptr, ei, bvec = _attn_inputs(H, dh, sizes, seed=4)
+    nmax = max(sizes) + pad
+    gen = torch.Generator().manual_seed(9)
+    bias = torch.randn(len(sizes) * H, nmax, nmax, generator=gen) * 2.0
+    keep = None
+    if p > 0:
+        keep = []
+        for g in range(len(sizes)):
+            a, b = int(ptr[g]), int(ptr[g + 1])
+            keep.append(torch.stack([attn_dropout_keep_mask(seed, torch.arange(a, b), h, H,
+                                                            torch.arange(b - a), p) for h in range(H)]))
+    qr = qkv.clone().double().requires_grad_(True)
+    br = bias.clone().double().requires_grad_(True)
+    ref = segment_attention_ref(qr, ptr, H, keep=keep, p_drop=p, bias=br)
+    (ref * w.double()).sum().backward()
+    gi = _index(ei, bvec, ptr)
+    qg = qkv.cuda().requires_grad_(True)
+    bg = bias.cuda().requires_grad_(True)
+    out = segment_attention(qg, gi, H, p, seed=seed, bias=bg)
+    (out * w.cuda()).sum().backward()
+    assert_close(out, ref, Tol.ACT, "attn out (bias)")
+    assert_close(qg.grad, qr.grad, Tol.GRAD_REL, "d_qkv (bias)", rel_to_max=True)
+    assert_close(bg.grad, br.grad, Tol.GRAD_REL, "d_bias", rel_to_max=True)
+    outside = torch.ones_like(bias, dtype=torch.bool)
+    for g, n in enumerate(sizes):
+        outside[g * H:(g + 1) * H, :n, :n] = False
+    assert (bg.grad.cpu()[outside] == 0).all()
+    # same result as without a bias when the bias is zero
+    plain = segment_attention(qkv.cuda(), gi, H, 0.0)
+    zero = segment_attention(qkv.cuda(), gi, H, 0.0, bias=torch.zeros_like(bg))
+    assert_close(zero, plain, 1e-6, "zero bias == no bias")
+
+
+def test_segment_attention_bias_shape_errors():
+    from graphgps_amd.lib import GpsHipError
+    from graphgps_amd.ops import segment_attention
+    H, dh, sizes = 2, 16, [9, 20]
+    qkv, w, ptr, ei, bvec = _attn_inputs(H, dh, sizes)
+    gi = _index(ei, bvec, ptr)
+    with pytest.raises(GpsHipError):      # padded narrower than the largest graph
+        segment_attention(qkv.cuda(), gi, H, 0.0, bias=torch.zeros(len(sizes) * H, 19, 19).cuda())
+    with pytest.raises(GpsHipError):      # wrong number of planes
+        segment_attention(qkv.cuda(), gi, H, 0.0, bias=torch.zeros(H, 20, 20).cuda())
+    with pytest.raises(GpsHipError):      # CPU operand
+        segment_attention(qkv.cuda(), gi, H, 0.0, bias=torch.zeros(len(sizes) * H, 20, 20))
 
 
 def test_segment_attention_padding_invariance():

@@ -22,10 +22,16 @@ def test_oracle_matches_reference_fixture(name):
     if "pe" in fix:                       # EquivStableLapPE fixtures carry the PE input and its gradient
         pe = fix["pe"].clone().requires_grad_(True)
         b.pe_EquivStableLapPE = pe
+    bias = None
+    if "attn_bias" in fix:                # BiasedTransformer fixtures carry the dense bias and its gradient
+        bias = fix["attn_bias"].clone().requires_grad_(True)
+        b.attn_bias = bias
     out = layer(b)
     ((out.x * fix["wx"]).sum() + (out.edge_attr * fix["we"]).sum()).backward()
     if pe is not None:
         assert_close(pe.grad, fix["grad_pe"], Tol.GRAD_REL, "grad pe", rel_to_max=True)
+    if bias is not None:
+        assert_close(bias.grad, fix["grad_attn_bias"], Tol.GRAD_REL, "grad attn_bias", rel_to_max=True)
     assert_close(out.x, fix["out_x"], Tol.ACT, "out.x")
     assert_close(out.edge_attr, fix["out_edge_attr"], Tol.ACT, "out.edge_attr")
     assert_close(x.grad, fix["grad_x"], Tol.GRAD_REL, "grad x", rel_to_max=True)
@@ -46,6 +52,8 @@ def test_oracle_matches_reference_fixture(name):
                    batch=fix["batch"], ptr=fix["ptr"])
         if "pe" in fix:
             eb.pe_EquivStableLapPE = fix["pe"]
+        if "attn_bias" in fix:
+            eb.attn_bias = fix["attn_bias"]
         ob = layer(eb)
     assert_close(ob.x, fix["eval_out_x"], Tol.ACT, "eval out.x")
     assert_close(ob.edge_attr, fix["eval_out_edge_attr"], Tol.ACT, "eval out.edge_attr")
@@ -59,3 +67,55 @@ def test_state_dict_keys_match_reference():
         mine = {k: tuple(v.shape) for k, v in layer.state_dict().items()}
         ref = {k: tuple(v.shape) for k, v in fix["state_dict"].items()}
         assert mine == ref, name
+
+
+@pytest.mark.parametrize("variant", ["plain", "token"])
+def test_graphormer_oracle_and_encoders_match_reference_fixture(variant):
+    """The Graphormer fixture (reference graphormer_encoder.py + graphormer_layer.py run by
+    oracle/gen_golden.py) pins, on the CPU: (1) the host pre-processing bit-exactly (degrees, spatial types,
+    all-pairs index, edge types along the chosen shortest path: same path as networkx picks), (2) this
+    package's BiasEncoder / NodeEncoder (plain torch, ragged evaluation + one scatter) forward and
+    parameter gradients, (3) the oracle's GraphormerLayer, which is what the HIP layer is checked against."""
+    from conftest import GRAPHORMER_GOLDEN
+    from graphgps_amd.encoder.graphormer_encoder import (BiasEncoder, NodeEncoder,
+                                                         graphormer_pre_processing)
+    from graphgps_amd.graphgym.config import cfg, set_cfg
+    from oracle.gps_oracle import OracleGraphormerLayer
+    fix = load_golden(GRAPHORMER_GOLDEN)[variant]
+    token = variant == "token"
+    set_cfg(cfg)
+    cfg.posenc_GraphormerBias.num_in_degrees = 16
+    cfg.posenc_GraphormerBias.num_out_degrees = 16
+    cfg.posenc_GraphormerBias.node_degrees_only = False
+    pre = []
+    for gr, want in zip(fix["graphs"], fix["pre"]):
+        d = Batch(**{k: v.clone() for k, v in gr.items()})
+        d = graphormer_pre_processing(d, fix["dist"])
+        for k in ("in_degrees", "out_degrees", "spatial_types", "graph_index", "shortest_path_types"):
+            assert torch.equal(getattr(d, k), want[k]), k
+        pre.append({k: getattr(d, k) for k in want})
+    H, D = fix["H"], fix["D"]
+    data = Batch.from_graph_list(pre)
+    data.x = fix["x0"].clone()
+    bias_enc = BiasEncoder(H, fix["dist"], 4, use_graph_token=token)
+    node_enc = NodeEncoder(D, 16, 16, input_dropout=0.0, use_graph_token=token)
+    layer = OracleGraphormerLayer(D, H, dropout=0.0, attention_dropout=0.0, mlp_dropout=0.0).train()
+    bias_enc.load_state_dict(fix["state"]["bias"], strict=True)
+    node_enc.load_state_dict(fix["state"]["node"], strict=True)
+    layer.load_state_dict(fix["state"]["layer"], strict=True)
+    data = node_enc(bias_enc(data))
+    assert_close(data.attn_bias, fix["attn_bias"], Tol.ACT, "attn_bias")
+    assert_close(data.x, fix["x_enc"], Tol.ACT, "encoded x")
+    assert torch.equal(data.batch, fix["batch_after"])
+    assert torch.equal(data.ptr, torch.cat([torch.zeros(1, dtype=torch.long),
+                                            torch.bincount(fix["batch_after"]).cumsum(0)]))
+    bias = data.attn_bias
+    bias.retain_grad()
+    data = layer(data)
+    (data.x * fix["w"]).sum().backward()
+    assert_close(data.x, fix["out_x"], Tol.ACT, "layer out")
+    assert_close(bias.grad, fix["grad_attn_bias"], Tol.GRAD_REL, "grad attn_bias", rel_to_max=True)
+    for part, mod in (("bias", bias_enc), ("node", node_enc), ("layer", layer)):
+        got = dict(mod.named_parameters())
+        for k, g in fix["grads"][part].items():
+            assert_close(got[k].grad, g, Tol.GRAD_REL, f"grad {part}.{k}", rel_to_max=True)
