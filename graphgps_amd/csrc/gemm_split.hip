@@ -28,6 +28,12 @@
 // bandwidth and the split's VALU work, not by the MFMA pipe.
 #include "gps_common.hpp"
 
+#ifdef GPS_ABL_NO_BARRIER   // ablation: no workgroup barriers (results are garbage, timing only)
+#define GPS_BARRIER() do {} while (0)
+#else
+#define GPS_BARRIER() __syncthreads()
+#endif
+
 namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -35,31 +41,44 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int TM = 128, TN = 128, BK = 32;
 constexpr int PITCH = 40;            // bf16 elements per LDS row (32 + 8 pad = 80 bytes)
-constexpr int NPASS = TM / 32;       // staging passes: 256 threads = 32 rows x 8 k-quads per pass
+constexpr int NPASS = TM / 64;       // staging passes: 256 threads = 64 rows x 4 units of 8 k per pass
 
 struct Frag {
   uint32_t u[4];
 };
 
-// 4 fp32 -> three packed bf16x4 (8 bytes each).  Round-to-nearest pieces (v_cvt_pk_bf16_f32 packs two
-// at a time): hi = rne(v), r1 = v - hi (exact), mid = rne(r1), r2 = r1 - mid (exact, <= 8 significant
-// bits), lo = r2 exactly -- hi + mid + lo == v bit for bit.
-typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+// 8 consecutive fp32 -> three packed bf16x8 (16 bytes each) by TRUNCATION: hi = top 16 bits of v,
+// r1 = v - hi (exact), mid = top 16 bits of r1, r2 = r1 - mid (exact, <= 8 significant bits) = lo exactly
+// -- hi + mid + lo == v bit for bit.  Full-rate VALU only: v_and / v_pk_add_f32 / v_perm_b32 (the RNE
+// variant went through v_cvt_pk_bf16_f32 and a shift/mask pair to convert back; the truncated pieces are
+// one bit coarser, the dropped products ml, lm, ll stay below 2^-20 |a||b|).
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ uint32_t pack2(f32x2 v, f32x2& back) {
-  const bf16x2 b = __builtin_convertvector(v, bf16x2);
-  back = __builtin_convertvector(b, f32x2);
-  uint32_t u;
-  __builtin_memcpy(&u, &b, 4);
-  return u;
+__device__ __forceinline__ uint32_t top16(float lo_elem, float hi_elem) {     // {bf16(lo_elem), bf16(hi_elem)}
+  return __builtin_amdgcn_perm(__float_as_uint(hi_elem), __float_as_uint(lo_elem), 0x07060302u);
 }
-__device__ __forceinline__ void split4(const float4 v, uint2& hi, uint2& mid, uint2& lo) {
-  f32x2 a = {v.x, v.y}, c = {v.z, v.w}, ba, bc;
-  hi.x = pack2(a, ba); hi.y = pack2(c, bc);
-  a -= ba; c -= bc;
-  mid.x = pack2(a, ba); mid.y = pack2(c, bc);
-  a -= ba; c -= bc;
-  lo.x = pack2(a, ba); lo.y = pack2(c, bc);
+__device__ __forceinline__ void split2(float x0, float x1, uint32_t& hi, uint32_t& mid, uint32_t& lo) {
+#ifdef GPS_ABL_NO_SPLIT   // ablation (tools/micro/gemm_ablate.sh): no VALU split, pieces = raw bits
+  hi = __float_as_uint(x0); mid = __float_as_uint(x1); lo = hi;
+  return;
+#endif
+  constexpr uint32_t M = 0xffff0000u;
+  hi = top16(x0, x1);
+  const f32x2 r1 = f32x2{x0, x1} - f32x2{__uint_as_float(__float_as_uint(x0) & M),
+                                         __uint_as_float(__float_as_uint(x1) & M)};
+  mid = top16(r1[0], r1[1]);
+  const f32x2 r2 = r1 - f32x2{__uint_as_float(__float_as_uint(r1[0]) & M),
+                              __uint_as_float(__float_as_uint(r1[1]) & M)};
+  lo = top16(r2[0], r2[1]);
+}
+// component-wise (a conditional between two float4 lvalues is a pointer select: it pins both in scratch)
+__device__ __forceinline__ float4 keep_if(bool ok, const float4 v) {
+  return make_float4(ok ? v.x : 0.0f, ok ? v.y : 0.0f, ok ? v.z : 0.0f, ok ? v.w : 0.0f);
+}
+__device__ __forceinline__ void split8(const float4 v0, const float4 v1, uint4& hi, uint4& mid, uint4& lo) {
+  split2(v0.x, v0.y, hi.x, mid.x, lo.x);
+  split2(v0.z, v0.w, hi.y, mid.y, lo.y);
+  split2(v1.x, v1.y, hi.z, mid.z, lo.z);
+  split2(v1.z, v1.w, hi.w, mid.w, lo.w);
 }
 
 struct GemmArgs {
@@ -97,61 +116,91 @@ __global__ __launch_bounds__(512) void k_gemm_nt(const GemmArgs G) {
   const int t = threadIdx.x & 255;
 
   if (producer) {
-    // staging: thread -> (row = t/8 + 32*pass, k-quad = t%8)
-    const int srow = t >> 3, skq = (t & 7) * 4;
+    // staging: thread -> (row = t/4 + 64*pass, 8 consecutive k = two 16-byte loads, one ds_write_b128 per
+    // piece); 4 lanes cover one 128-byte line of a row
+    const int srow = t >> 2, sk8 = (t & 3) * 8;
     const float* ap[NPASS];
     const float* bp[NPASS];
     bool a_ok[NPASS], b_ok[NPASS];
 #pragma unroll
     for (int p = 0; p < NPASS; ++p) {
-      const int64_t ra = r0 + srow + 32 * p;
-      const int rb = m0 + srow + 32 * p;
+      const int64_t ra = r0 + srow + 64 * p;
+      const int rb = m0 + srow + 64 * p;
       a_ok[p] = ra < G.R;
       b_ok[p] = rb < G.M;
       ap[p] = G.A + (a_ok[p] ? ra : G.R - 1) * G.lda;
       bp[p] = G.B + (int64_t)(b_ok[p] ? rb : G.M - 1) * G.ldb;
     }
-    float4 ra0[NPASS], rb0[NPASS], ra1[NPASS], rb1[NPASS];
-    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto load_chunk = [&](int c, float4 (&ra)[NPASS], float4 (&rb)[NPASS]) {
+    // wave-uniform: interior tiles (every row valid, K a multiple of the chunk) skip the zero-fill selects
+    const bool edge = (r0 + TM > G.R) || (m0 + TN > G.M) || (K % BK != 0);
+    constexpr int NU = NPASS * 2;       // 16-byte loads per operand per chunk: [pass][half of the 8-k unit]
+    float4 sa0[NU], sb0[NU], sa1[NU], sb1[NU];
+    auto load_chunk = [&](int c, float4 (&sa)[NU], float4 (&sb)[NU]) {
       // raw loads only; a k-quad past K reads quad 0 and is zeroed at split time
-      const int kk = (c * BK + skq < K) ? c * BK + skq : 0;
+      const int kq0 = c * BK + sk8, kq1 = kq0 + 4;
+      const int kk0 = kq0 < K ? kq0 : 0, kk1 = kq1 < K ? kq1 : 0;
 #pragma unroll
       for (int p = 0; p < NPASS; ++p) {
-        ra[p] = *reinterpret_cast<const float4*>(ap[p] + kk);
-        rb[p] = *reinterpret_cast<const float4*>(bp[p] + kk);
+#ifdef GPS_ABL_NO_GLOBAL  // ablation: operands from registers, no global traffic
+        sa[2 * p] = make_float4(1.0f + kk0, 2.0f, 3.0f, 4.0f);
+        sa[2 * p + 1] = make_float4(1.0f + kk1, 2.0f, 3.0f, 4.0f);
+        sb[2 * p] = make_float4(0.5f, 0.25f + kk0, 0.125f, 1.0f);
+        sb[2 * p + 1] = make_float4(0.5f, 0.25f + kk1, 0.125f, 1.0f);
+#else
+        sa[2 * p] = *reinterpret_cast<const float4*>(ap[p] + kk0);
+        sa[2 * p + 1] = *reinterpret_cast<const float4*>(ap[p] + kk1);
+        sb[2 * p] = *reinterpret_cast<const float4*>(bp[p] + kk0);
+        sb[2 * p + 1] = *reinterpret_cast<const float4*>(bp[p] + kk1);
+#endif
       }
     };
-    auto store_chunk = [&](int c, int buf, const float4 (&ra)[NPASS], const float4 (&rb)[NPASS]) {
-      const bool k_ok = c * BK + skq < K;
+    auto store_chunk = [&](int c, int buf, const float4 (&sa)[NU], const float4 (&sb)[NU]) {
+      const bool k0 = c * BK + sk8 < K, k1 = c * BK + sk8 + 4 < K;
 #pragma unroll
       for (int p = 0; p < NPASS; ++p) {
-        uint2 h, m, l;
-        const int row = srow + 32 * p;
-        split4((a_ok[p] && k_ok) ? ra[p] : zero4, h, m, l);
-        *reinterpret_cast<uint2*>(L(buf, 0, 0, row, skq)) = h;
-        *reinterpret_cast<uint2*>(L(buf, 0, 1, row, skq)) = m;
-        *reinterpret_cast<uint2*>(L(buf, 0, 2, row, skq)) = l;
-        split4((b_ok[p] && k_ok) ? rb[p] : zero4, h, m, l);
-        *reinterpret_cast<uint2*>(L(buf, 1, 0, row, skq)) = h;
-        *reinterpret_cast<uint2*>(L(buf, 1, 1, row, skq)) = m;
-        *reinterpret_cast<uint2*>(L(buf, 1, 2, row, skq)) = l;
+        uint4 h, m, l;
+        const int row = srow + 64 * p;
+#ifdef GPS_ABL_NO_LDSWRITE  // ablation: staging registers consumed without touching LDS
+        if (sa[2 * p].x == 123.456f && sb[2 * p + 1].y == 654.321f) *reinterpret_cast<uint4*>(L(buf, 0, 0, row, sk8)) = h;
+        continue;
+#endif
+        float4 a0 = sa[2 * p], a1 = sa[2 * p + 1], b0 = sb[2 * p], b1 = sb[2 * p + 1];
+        if (edge) {
+          a0 = keep_if(a_ok[p] && k0, a0);
+          a1 = keep_if(a_ok[p] && k1, a1);
+          b0 = keep_if(b_ok[p] && k0, b0);
+          b1 = keep_if(b_ok[p] && k1, b1);
+        }
+        split8(a0, a1, h, m, l);
+        *reinterpret_cast<uint4*>(L(buf, 0, 0, row, sk8)) = h;
+        *reinterpret_cast<uint4*>(L(buf, 0, 1, row, sk8)) = m;
+        *reinterpret_cast<uint4*>(L(buf, 0, 2, row, sk8)) = l;
+        split8(b0, b1, h, m, l);
+        *reinterpret_cast<uint4*>(L(buf, 1, 0, row, sk8)) = h;
+        *reinterpret_cast<uint4*>(L(buf, 1, 1, row, sk8)) = m;
+        *reinterpret_cast<uint4*>(L(buf, 1, 2, row, sk8)) = l;
       }
     };
-    load_chunk(0, ra0, rb0);
-    if (nchunks > 1) load_chunk(1, ra1, rb1);
-    store_chunk(0, 0, ra0, rb0);
-    __syncthreads();                                   // buffer 0 ready
+    // The global loads are UNCONDITIONAL (past the last chunk they re-read it): the compiler's s_waitcnt
+    // bookkeeping merges control-flow paths conservatively, and a load that is issued on one path only
+    // collapses the vmcnt it allows at the next use to ~0, i.e. the chunk c+2 prefetch would be waited
+    // for before chunk c+1 is even staged.  With a path-independent count the wait is vmcnt(8): exactly
+    // the loads of the chunk being staged, the newer 8 stay in flight across the barrier.
+    const int last = nchunks - 1;
+    load_chunk(0, sa0, sb0);
+    load_chunk(min(1, last), sa1, sb1);
+    store_chunk(0, 0, sa0, sb0);
+    GPS_BARRIER();                                   // buffer 0 ready
     for (int c = 0; c < nchunks; c += 2) {
       // consumers multiply chunk c (buffer 0): stage chunk c+1 into buffer 1, fetch chunk c+2
-      if (c + 2 < nchunks) load_chunk(c + 2, ra0, rb0);
-      if (c + 1 < nchunks) store_chunk(c + 1, 1, ra1, rb1);
-      __syncthreads();
+      load_chunk(min(c + 2, last), sa0, sb0);
+      if (c + 1 < nchunks) store_chunk(c + 1, 1, sa1, sb1);
+      GPS_BARRIER();
       if (c + 1 >= nchunks) break;
       // consumers multiply chunk c+1 (buffer 1): stage chunk c+2 into buffer 0, fetch chunk c+3
-      if (c + 3 < nchunks) load_chunk(c + 3, ra1, rb1);
-      if (c + 2 < nchunks) store_chunk(c + 2, 0, ra0, rb0);
-      __syncthreads();
+      load_chunk(min(c + 3, last), sa1, sb1);
+      if (c + 2 < nchunks) store_chunk(c + 2, 0, sa0, sb0);
+      GPS_BARRIER();
     }
     return;
   }
@@ -167,41 +216,70 @@ __global__ __launch_bounds__(512) void k_gemm_nt(const GemmArgs G) {
     for (int j = 0; j < 2; ++j)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.0f;
-  auto multiply = [&](int buf) {
-#pragma unroll
-    for (int ks = 0; ks < BK / 16; ++ks) {
-      Frag A[2][3], B[2][3];
-#pragma unroll
-      for (int pc = 0; pc < 3; ++pc)
-#pragma unroll
-        for (int i = 0; i < 2; ++i) {
-          const uint4 a = *reinterpret_cast<const uint4*>(L(buf, 0, pc, wm * 64 + i * 32 + li, 16 * ks + 8 * kh));
-          const uint4 b = *reinterpret_cast<const uint4*>(L(buf, 1, pc, wn * 64 + i * 32 + li, 16 * ks + 8 * kh));
-          A[i][pc].u[0] = a.x; A[i][pc].u[1] = a.y; A[i][pc].u[2] = a.z; A[i][pc].u[3] = a.w;
-          B[i][pc].u[0] = b.x; B[i][pc].u[1] = b.y; B[i][pc].u[2] = b.z; B[i][pc].u[3] = b.w;
-        }
-      // smallest terms first; the four accumulators rotate so no MFMA waits on its predecessor
-      constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};
-#pragma unroll
-      for (int term = 0; term < 6; ++term)
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            bf16x8 av, bv;
-            __builtin_memcpy(&av, &A[i][TA[term]], 16);
-            __builtin_memcpy(&bv, &B[j][TB[term]], 16);
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i][j], 0, 0, 0);
-          }
-    }
+  // Fragment double buffering at the K16-step level: the ds_read_b128s of step s+1 are in flight while
+  // the 24 MFMAs of step s run, so the wave never sits on LDS latency with an idle matrix pipe.  One
+  // barrier per chunk, placed after the LAST read of the buffer (it releases that buffer to the producers
+  // and, by their arrival, publishes the other one).
+  struct Frags {
+    Frag A[2][3], B[2][3];
   };
-  __syncthreads();                                     // buffer 0 ready
-  for (int c = 0; c < nchunks; c += 2) {
-    multiply(0);
-    __syncthreads();
-    if (c + 1 >= nchunks) break;
-    multiply(1);
-    __syncthreads();
+  auto fetch = [&](int buf, int ks, Frags& F) {
+#ifdef GPS_ABL_NO_LDSREAD  // ablation: fragments from registers, no LDS reads
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          F.A[i][pc].u[q] = 0x3f803f80u + (uint32_t)(buf + pc + i + q + lane);
+          F.B[i][pc].u[q] = 0x3f803f80u + (uint32_t)(buf + pc + i + q);
+        }
+#else
+#pragma unroll
+    for (int pc = 0; pc < 3; ++pc)
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const uint4 a = *reinterpret_cast<const uint4*>(L(buf, 0, pc, wm * 64 + i * 32 + li, 16 * ks + 8 * kh));
+        const uint4 b = *reinterpret_cast<const uint4*>(L(buf, 1, pc, wn * 64 + i * 32 + li, 16 * ks + 8 * kh));
+        F.A[i][pc].u[0] = a.x; F.A[i][pc].u[1] = a.y; F.A[i][pc].u[2] = a.z; F.A[i][pc].u[3] = a.w;
+        F.B[i][pc].u[0] = b.x; F.B[i][pc].u[1] = b.y; F.B[i][pc].u[2] = b.z; F.B[i][pc].u[3] = b.w;
+      }
+#endif
+  };
+  auto mma = [&](const Frags& F) {
+    // smallest terms first; the four accumulators rotate so no MFMA waits on its predecessor
+    constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};
+#pragma unroll
+    for (int term = 0; term < 6; ++term)
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          bf16x8 av, bv;
+          __builtin_memcpy(&av, &F.A[i][TA[term]], 16);
+          __builtin_memcpy(&bv, &F.B[j][TB[term]], 16);
+#ifdef GPS_ABL_NO_MFMA     // ablation: fragments consumed by one VALU op instead of the MFMA
+          acc[i][j][term] += __uint_as_float(F.A[i][TA[term]].u[0] ^ F.B[j][TB[term]].u[1]);
+#else
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i][j], 0, 0, 0);
+#endif
+        }
+  };
+  static_assert(BK == 32, "two K16 steps per chunk");
+  Frags F0, F1;
+  GPS_BARRIER();                                     // buffer 0 ready
+  fetch(0, 0, F0);
+  for (int c = 0; c < nchunks; ++c) {
+    const int buf = c & 1;
+    fetch(buf, 1, F1);                               // in flight under the MFMAs of step 0
+    __builtin_amdgcn_sched_barrier(0);
+    mma(F0);
+    __builtin_amdgcn_sched_barrier(0);
+    GPS_BARRIER();                                   // buffer `buf` fully read; the other one is published
+    if (c + 1 < nchunks) fetch(buf ^ 1, 0, F0);      // in flight under the MFMAs of step 1
+    __builtin_amdgcn_sched_barrier(0);
+    mma(F1);
+    __builtin_amdgcn_sched_barrier(0);
   }
 
   // epilogue: D[row = (q&3) + 8*(q>>2) + 4*(lane>>5)][col = lane&31]  (+ bias, + Cin)

@@ -32,6 +32,39 @@ __global__ void k16(float* out, int iters, float a, float b) {
   if (s == 123.456f) out[0] = s;
 }
 
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// v_mfma_f32_32x32x16_bf16 (NACC independent accumulator chains) and v_mfma_f32_16x16x32_bf16
+template <int NACC>
+__global__ void kb32(float* out, int iters, float a, float b) {
+  f32x16 acc[NACC];
+  bf16x8 av, bv;
+  for (int q = 0; q < 8; ++q) { av[q] = (__bf16)a; bv[q] = (__bf16)b; }
+  for (int i = 0; i < NACC; ++i)
+    for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, acc[i], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int i = 0; i < NACC; ++i) s += acc[i][0];
+  if (s == 123.456f) out[0] = s;
+}
+template <int NACC>
+__global__ void kb16(float* out, int iters, float a, float b) {
+  f32x4 acc[NACC];
+  bf16x8 av, bv;
+  for (int q = 0; q < 8; ++q) { av[q] = (__bf16)a; bv[q] = (__bf16)b; }
+  for (int i = 0; i < NACC; ++i)
+    for (int q = 0; q < 4; ++q) acc[i][q] = 0.f;
+  for (int it = 0; it < iters; ++it) {
+#pragma unroll
+    for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(av, bv, acc[i], 0, 0, 0);
+  }
+  float s = 0.f;
+  for (int i = 0; i < NACC; ++i) s += acc[i][0];
+  if (s == 123.456f) out[0] = s;
+}
+
 template <typename F>
 double run(F launch, double flops) {
   hipEvent_t e0, e1;
@@ -53,6 +86,11 @@ int main() {
     double t32 = run([&] { k32<4><<<grid, block>>>(out, iters, 1.f, 2.f); }, waves * iters * 4 * 4096.0);
     double t16 = run([&] { k16<4><<<grid, block>>>(out, iters, 1.f, 2.f); }, waves * iters * 4 * 2048.0);
     double t16b = run([&] { k16<2><<<grid, block>>>(out, iters, 1.f, 2.f); }, waves * iters * 2 * 2048.0);
+    double b32 = run([&] { kb32<4><<<grid, block>>>(out, iters, 1.f, 2.f); }, waves * iters * 4 * 32768.0);
+    double b32c = run([&] { kb32<1><<<grid, block>>>(out, iters, 1.f, 2.f); }, waves * iters * 1 * 32768.0);
+    double b16 = run([&] { kb16<4><<<grid, block>>>(out, iters, 1.f, 2.f); }, waves * iters * 4 * 32768.0);
+    printf("waves/SIMD %d: bf16 32x32x16 (4 chains) %.0f TF  (1 chain) %.0f TF   bf16 16x16x32 (4 chains) %.0f TF\n",
+           wps, b32, b32c, b16);
     printf("waves/SIMD %d: 32x32x2 (4 chains) %.1f TF   16x16x4 (4 chains) %.1f TF   16x16x4 (2 chains) %.1f TF\n",
            wps, t32, t16, t16b);
   }
