@@ -433,20 +433,24 @@ def main():
     # secondary, never `value`: the same step fed from pinned HOST batches through the prefetching
     # DeviceLoader (H2D copies + graph index on a copy stream, one batch ahead) -- the PCIe-inclusive rate
     h2d_ms = None
-    if not args.no_h2d_leg and reducer is None:
-        from graphgps_amd.loader import DeviceLoader
-        pinned = batch_cpu.shallow_copy()
-        for k, v in list(pinned.__dict__.items()):
-            if torch.is_tensor(v):
-                pinned.__dict__[k] = v.pin_memory()
-        for n_h in (3, min(args.steps, 20)):       # 3 untimed, then the measured pass
-            torch.cuda.synchronize()
-            th = time.perf_counter()
-            for b in DeviceLoader((pinned.shallow_copy() for _ in range(n_h)), dev):
-                ts.run_eager(b)
-            torch.cuda.synchronize()
-            h2d_ms = (time.perf_counter() - th) / n_h * 1e3
-        log(f"host-batch leg (H2D + index on the copy stream, eager launch): {h2d_ms:.2f} ms/step")
+    if not args.no_h2d_leg and reducer is None and world == 1:     # a 1-GPU side measurement only
+        try:
+            from graphgps_amd.loader import DeviceLoader
+            pinned = batch_cpu.shallow_copy()
+            for k, v in list(pinned.__dict__.items()):
+                if torch.is_tensor(v):
+                    pinned.__dict__[k] = v.pin_memory()
+            for n_h in (3, min(args.steps, 20)):       # 3 untimed, then the measured pass
+                torch.cuda.synchronize()
+                th = time.perf_counter()
+                for b in DeviceLoader((pinned.shallow_copy() for _ in range(n_h)), dev):
+                    ts.run_eager(b)
+                torch.cuda.synchronize()
+                h2d_ms = (time.perf_counter() - th) / n_h * 1e3
+            log(f"host-batch leg (H2D + index on the copy stream, eager launch): {h2d_ms:.2f} ms/step")
+        except Exception as exc:       # never let the side measurement take the headline line with it
+            h2d_ms = None
+            log(f"host-batch leg skipped ({type(exc).__name__}: {exc})")
 
     if rank == 0:
         N, E = batch_dev.x.shape[0], batch_dev.edge_index.shape[1]
