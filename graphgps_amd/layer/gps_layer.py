@@ -24,6 +24,7 @@ from ..graphgym import act as _act  # noqa: F401
 from ..fused import add_dropout, bn_act, linear, relu_dropout
 from ..ops import graph_index_of, segment_attention
 from .gatedgcn_layer import GatedGCNLayer
+from .gcn_conv_layer import GCNConv
 from .gine_conv_layer import GINEConv, GINEConvESLapPE
 from .gps_block import block_supported, gine_block_supported, gps_block, gps_block_gine
 
@@ -32,7 +33,7 @@ import os as _os
 # 16.9 -> 15.8 ms/step on MI355X.  GPS_FUSED_BLOCK=0 keeps the operator-by-operator path.
 _BLOCK_ENABLED = _os.environ.get("GPS_FUSED_BLOCK", "1") != "0"
 
-_NEEDS_PYG = {"GCN", "GIN", "GENConv", "GAT", "PNA"}
+_NEEDS_PYG = {"GIN", "GENConv", "GAT", "PNA"}
 
 
 class GPSLayer(nn.Module):
@@ -70,6 +71,9 @@ class GPSLayer(nn.Module):
         self.local_gnn_with_edge_attr = True
         if local_gnn_type == 'None':
             self.local_model = None
+        elif local_gnn_type == 'GCN':            # MPNN without edge attributes (reference :50-52)
+            self.local_gnn_with_edge_attr = False
+            self.local_model = GCNConv(dim_h, dim_h)
         elif local_gnn_type == 'GINE':
             gin_nn = nn.Sequential(nn.Linear(dim_h, dim_h), self.activation(),
                                    nn.Linear(dim_h, dim_h))
@@ -83,7 +87,7 @@ class GPSLayer(nn.Module):
         elif local_gnn_type in _NEEDS_PYG:
             raise NotImplementedError(
                 f"local_gnn_type={local_gnn_type!r} is a PyG-native conv outside the HIP hot path "
-                f"(SURVEY.md section 8b item 4); supported: 'None', 'GINE', 'CustomGatedGCN'")
+                f"(SURVEY.md section 8b item 4); supported: 'None', 'GCN', 'GINE', 'CustomGatedGCN'")
         else:
             raise ValueError(f"Unsupported local GNN model: {local_gnn_type}")
         self.local_gnn_type = local_gnn_type
@@ -141,14 +145,15 @@ class GPSLayer(nn.Module):
         h_in1 = h  # for first residual connection
         gi = graph_index_of(batch)
 
-        if _BLOCK_ENABLED and block_supported(self, h, batch.edge_attr):
+        edge_attr = getattr(batch, 'edge_attr', None)      # absent for MPNNs without edge attributes
+        if _BLOCK_ENABLED and block_supported(self, h, edge_attr):
             # measured configuration (CustomGatedGCN+Transformer, BN, ReLU, training): the whole
             # block as ONE autograd node -- same kernels, ~4x less host time (layer/gps_block.py)
             h, e_new = gps_block(self, h, batch.edge_attr, gi)
             batch.x = h
             batch.edge_attr = e_new
             return batch
-        if _BLOCK_ENABLED and gine_block_supported(self, h, batch.edge_attr):
+        if _BLOCK_ENABLED and gine_block_supported(self, h, edge_attr):
             batch.x = gps_block_gine(self, h, batch.edge_attr, gi)      # GINE leaves edge_attr as is
             return batch
 
@@ -160,7 +165,9 @@ class GPSLayer(nn.Module):
                 h_local, e_new = self.local_model.forward_tensors(h, batch.edge_attr, gi, es)
                 batch.edge_attr = e_new
             else:
-                if self.equivstable_pe:                                              # :177-181
+                if not self.local_gnn_with_edge_attr:                                # :183
+                    h_local = self.local_model.forward_tensors(h, gi)
+                elif self.equivstable_pe:                                            # :177-181
                     h_local = self.local_model.forward_tensors(h, batch.edge_attr, gi,
                                                                batch.pe_EquivStableLapPE)
                 else:

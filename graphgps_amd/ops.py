@@ -258,6 +258,56 @@ def gine_aggregate(x: torch.Tensor, e: torch.Tensor, gi: GraphIndex, eps: float 
 
 
 # -------------------------------------------------------------------------------------------
+# GCN sparse core
+# -------------------------------------------------------------------------------------------
+def gcn_dinv(gi: GraphIndex) -> torch.Tensor:
+    """deg^-1/2 of gcn_norm (one unit self loop per node + every non-loop incoming edge), cached on the
+    index: 10 layers and their backward passes share it."""
+    dinv = gi.__dict__.get("_gcn_dinv")
+    if dinv is None:
+        dev = gi.rowptr_dst.device
+        dinv = torch.empty(gi.N, dtype=torch.float32, device=dev)
+        check(_lib.load().gps_gcn_dinv(ptr(gi.rowptr_dst), ptr(gi.src_by_dst), gi.N, gi.E, ptr(dinv),
+                                       current_stream(dev)), "gps_gcn_dinv")
+        gi.__dict__["_gcn_dinv"] = dinv
+    return dinv
+
+
+class _GCNAggregate(torch.autograd.Function):
+    """out = D^-1/2 (A + I) D^-1/2 x over the batch's edges (PyG GCNConv.propagate after gcn_norm); the
+    backward is the transposed product = the same kernel on the source-keyed half of the index."""
+
+    @staticmethod
+    def forward(ctx, x: torch.Tensor, gi: GraphIndex):
+        L = _lib.load()
+        dev = _require_cuda(x)
+        x = _f32c(x, "x")
+        if x.dim() != 2 or x.shape[0] != gi.N:
+            raise _lib.GpsHipError(f"gcn_aggregate: x {tuple(x.shape)} vs N={gi.N}")
+        dinv = gcn_dinv(gi)
+        out = torch.empty_like(x)
+        check(L.gps_gcn_spmm(ptr(x), x.shape[1], ptr(gi.rowptr_dst), ptr(gi.src_by_dst), ptr(dinv), gi.N,
+                             gi.E, x.shape[1], ptr(out), current_stream(dev)), "gps_gcn_spmm")
+        ctx.gi = gi
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out: torch.Tensor):
+        L = _lib.load()
+        gi: GraphIndex = ctx.gi
+        g_out = _f32c(g_out, "g_out")
+        g_x = torch.empty_like(g_out)
+        check(L.gps_gcn_spmm(ptr(g_out), g_out.shape[1], ptr(gi.rowptr_src), ptr(gi.dst_by_src),
+                             ptr(gcn_dinv(gi)), gi.N, gi.E, g_out.shape[1], ptr(g_x),
+                             current_stream(g_out.device)), "gps_gcn_spmm")
+        return g_x, None
+
+
+def gcn_aggregate(x: torch.Tensor, gi: GraphIndex) -> torch.Tensor:
+    return _GCNAggregate.apply(x, gi)
+
+
+# -------------------------------------------------------------------------------------------
 # segment attention
 # -------------------------------------------------------------------------------------------
 def draw_dropout_seed() -> int:

@@ -118,6 +118,19 @@ int gps_gine_bwd(const float* g_out, const float* x, const float* e, const int32
                  float* g_e, const float* r_edge, gps_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * GCN sparse core: out_i = dinv_i (dinv_i x_i + sum_{j->i, j != i} dinv_j x_j), dinv = deg^-1/2 with
+ * deg_i = 1 + #{edges j->i, j != i}.  Replaces PyG GCNConv's gcn_norm (add_remaining_self_loops + scatter-add
+ * degree) + propagate (gather, scale, scatter-add) -- the `GCN` local model of graphgps/layer/gps_layer.py:
+ * 53-55,176-183 (configs/GPS/{actor,webkb-*,wn-*}-GPS.yaml).  x may be strided (ld_x >= d).
+ * Forward: gps_gcn_dinv on the CSR-by-target, then gps_gcn_spmm(rowptr_dst, src_by_dst).  Backward (the
+ * operator's transpose): the same gps_gcn_spmm on the CSC half, (rowptr_src, dst_by_src), applied to g_out.
+ * ------------------------------------------------------------------------------------- */
+int gps_gcn_dinv(const int32_t* rowptr_dst, const int32_t* src_by_dst, int64_t N, int64_t E, float* dinv,
+                 gps_stream_t stream);
+int gps_gcn_spmm(const float* x, int64_t ld_x, const int32_t* rowptr, const int32_t* nbr, const float* dinv,
+                 int64_t N, int64_t E, int d, float* out, gps_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * Segment (per-graph, varlen) multi-head attention core on fp32 MFMA (v_mfma_f32_16x16x4_f32).
  * Replaces to_dense_batch + the softmax(QK^T/sqrt(dh) + key-padding mask) -> dropout -> .V core
  * of torch.nn.MultiheadAttention + the [mask] un-pad (graphgps/layer/gps_layer.py:199-201,

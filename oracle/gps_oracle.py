@@ -146,6 +146,30 @@ class OracleGINEConv(nn.Module):
 # ---------------------------------------------------------------------------
 # Performer (FAVOR+)
 # ---------------------------------------------------------------------------
+class OracleGCNConv(nn.Module):
+    """PyG 2.2 ``GCNConv(in, out)`` with its defaults (third-party; published algorithm): ``lin`` without bias,
+    ``gcn_norm`` = drop the input's self loops, add ONE unit self loop per node (add_remaining_self_loops),
+    deg = scatter-add of ones over TARGETS, weight(j->i) = deg_j^-1/2 deg_i^-1/2; sum-aggregate; + ``bias``.
+    Local model of ``gt.layer_type: GCN+...`` (graphgps/layer/gps_layer.py:53-55,183)."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.lin = nn.Linear(in_channels, out_channels, bias=False)
+        self.bias = nn.Parameter(torch.zeros(out_channels))
+
+    def forward(self, x, edge_index):
+        n = x.shape[0]
+        keep = edge_index[0] != edge_index[1]
+        loops = torch.arange(n, dtype=edge_index.dtype)
+        row = torch.cat([edge_index[0][keep], loops])          # sources
+        col = torch.cat([edge_index[1][keep], loops])          # targets
+        deg = torch.zeros(n, dtype=x.dtype).index_add_(0, col, torch.ones(col.numel(), dtype=x.dtype))
+        dinv = deg.pow(-0.5)
+        w = dinv[row] * dinv[col]
+        h = self.lin(x)
+        return scatter_sum(w[:, None] * h.index_select(0, row), col, n) + self.bias
+
+
 def orthogonal_matrix_chunk(cols: int) -> torch.Tensor:
     # graphgps/layer/performer_layer.py:163-170
     q, _ = torch.linalg.qr(torch.randn(cols, cols), mode="reduced")
@@ -230,7 +254,7 @@ class OraclePerformerSelfAttention(nn.Module):
 # GPS block
 # ---------------------------------------------------------------------------
 class OracleGPSLayer(nn.Module):
-    """graphgps/layer/gps_layer.py:15-257 for local in {None, CustomGatedGCN, GINE} and
+    """graphgps/layer/gps_layer.py:15-257 for local in {None, GCN, CustomGatedGCN, GINE} and
     global in {None, Transformer, BiasedTransformer, Performer}, batch_norm or no norm."""
 
     def __init__(self, dim_h, local_gnn_type, global_model_type, num_heads, act="relu",
@@ -245,6 +269,8 @@ class OracleGPSLayer(nn.Module):
         self.local_gnn_type, self.global_model_type = local_gnn_type, global_model_type
         if local_gnn_type == "None":
             self.local_model = None
+        elif local_gnn_type == "GCN":
+            self.local_model = OracleGCNConv(dim_h, dim_h)                              # :53-55
         elif local_gnn_type == "GINE":
             gin_nn = nn.Sequential(nn.Linear(dim_h, dim_h), ACT[act](), nn.Linear(dim_h, dim_h))
             self.local_model = OracleGINEConv(gin_nn, equivstable_pe=equivstable_pe)   # :62-69
@@ -287,7 +313,10 @@ class OracleGPSLayer(nn.Module):
                 batch.edge_attr = e
             else:
                 pe = batch.pe_EquivStableLapPE if self.equivstable_pe else None
-                h_local = self.local_model(h, batch.edge_index, batch.edge_attr, pe)  # :177-185
+                if self.local_gnn_type == "GCN":
+                    h_local = self.local_model(h, batch.edge_index)                  # :183
+                else:
+                    h_local = self.local_model(h, batch.edge_index, batch.edge_attr, pe)  # :177-185
                 h_local = self.dropout_local(h_local)
                 h_local = h_in1 + h_local                                            # :188-189
             if self.batch_norm:

@@ -448,3 +448,106 @@ def test_graphormer_models_vs_oracle(cfg_name, overrides):
     assert checked > 20
     assert any("spatial_encoder" in k and p.grad is not None and float(p.grad.abs().max()) > 0
                for k, p in model.named_parameters())
+
+
+def _random_digraph_batch(sizes, d, seed):
+    """Directed random graphs with a few duplicate edges and self loops (GCN's normalisation cases)."""
+    from graphgps_amd.data import Batch
+    gen = torch.Generator().manual_seed(seed)
+    parts, off = [], 0
+    for n in sizes:
+        ei = torch.randint(0, n, (2, 4 * n), generator=gen)
+        parts.append(torch.cat([ei, ei[:, :3]], dim=1) + off)
+        off += n
+    ei = torch.cat(parts, dim=1)
+    ptr = torch.tensor([0] + list(torch.tensor(sizes).cumsum(0)))
+    b = Batch(x=torch.randn(off, d, generator=gen), edge_index=ei,
+              batch=torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes)), ptr=ptr)
+    b.num_graphs = len(sizes)
+    return b, gen
+
+
+@pytest.mark.parametrize("glob,bn,act", [("Transformer", False, "gelu"), ("None", True, "relu")])
+def test_gpslayer_gcn_local_model_vs_oracle(glob, bn, act):
+    """GPSLayer with the GCN local model (gps_layer.py:53-55,183; configs/GPS/actor-GPS.yaml: GCN+Transformer,
+    GELU, no normalisation, no edge attributes) on the HIP sparse core vs the oracle's restatement of PyG
+    GCNConv: output, input gradient and every parameter gradient."""
+    from graphgps_amd.layer.gps_layer import GPSLayer
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    d, H = 64, 4
+    layer = GPSLayer(d, "GCN", glob, H, act=act, dropout=0.0, attn_dropout=0.0, batch_norm=bn)
+    with torch.no_grad():
+        layer.local_model.bias.uniform_(-0.2, 0.2)
+    assert {"local_model.lin.weight", "local_model.bias"} <= set(layer.state_dict())
+    oracle = _oracle_layer_like(layer).train()
+    layer.to(dev).train()
+    b, gen = _random_digraph_batch([150, 33, 1, 64], d, seed=9)
+    wx = torch.randn(b.x.shape, generator=gen)
+    bc = b.clone()
+    bc.x.requires_grad_(True)
+    xo = bc.x
+    oo = oracle(bc)
+    (oo.x * wx).sum().backward()
+    bg = b.clone().to(dev)
+    bg.x.requires_grad_(True)
+    xg = bg.x
+    og = layer(bg)
+    (og.x * wx.to(dev)).sum().backward()
+    assert_close(og.x, oo.x, Tol.ACT, "out.x")
+    assert_close(xg.grad, xo.grad, Tol.GRAD_REL, "grad x", rel_to_max=True)
+    op = dict(oracle.named_parameters())
+    gs = max(float(p.grad.abs().max()) for p in op.values() if p.grad is not None)
+    for k, p in layer.named_parameters():
+        if op[k].grad is None:
+            continue
+        a_, b_ = p.grad.detach().double().cpu(), op[k].grad.double()
+        if float(b_.abs().max()) < 1e-5 * gs:
+            # a bias that feeds a BatchNorm: mathematically zero gradient, rounding residue on both sides
+            assert float(a_.abs().max()) < 1e-5 * gs, k
+            continue
+        assert (a_ - b_).abs().max().item() <= Tol.GRAD_REL * max(float(b_.abs().max()), 0.01 * gs, 1.0), \
+            f"grad {k}: {(a_ - b_).abs().max().item():.3e}"
+
+
+def test_actor_gps_model_vs_oracle():
+    """configs/GPS/actor-GPS.yaml shape: LapPE DeepSet encoder -> 2 x GPSLayer(GCN+Transformer, GELU, no norm)
+    -> GraphGym node head with the split mask, one transductive graph (attention over all 1,200 nodes of it):
+    prediction and parameter gradients vs the oracle model.  Eval mode: the LapPE encoder's training-mode sign
+    flips draw from different generators on the two devices."""
+    from graphgps_amd.data import Batch
+    from oracle.gps_oracle import to_oracle_model
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = _build_model("actor_gps.yaml", 32, 5)
+    assert type(model.post_mp).__name__ == "GNNNodeHead"
+    model.eval()
+    oracle = to_oracle_model(model).eval()
+    model.to(dev)
+    gen = torch.Generator().manual_seed(1)
+    N = 1200
+    vecs = torch.randn(N, 4, generator=gen)
+    vecs[:7, 3] = float("nan")                       # graphs with fewer eigenvectors pad with NaN
+    vals = torch.randn(N, 4, 1, generator=gen)
+    vals[:7, 3] = float("nan")
+    b = Batch(x=torch.randn(N, 32, generator=gen), edge_index=torch.randint(0, N, (2, 6 * N), generator=gen),
+              batch=torch.zeros(N, dtype=torch.long), ptr=torch.tensor([0, N]), EigVals=vals, EigVecs=vecs,
+              y=torch.randint(0, 5, (N,), generator=gen), train_mask=torch.rand(N, generator=gen) < 0.6)
+    b.split, b.num_graphs = "train", 1
+    po, yo = oracle(b.clone())
+    lo = torch.nn.functional.cross_entropy(po, yo)
+    lo.backward()
+    pg, yg = model(b.clone().to(dev))
+    lg = torch.nn.functional.cross_entropy(pg, yg)
+    lg.backward()
+    assert torch.equal(yg.cpu(), yo)
+    assert_close(pg, po, 1e-4, "pred")
+    assert_close(lg, lo, 1e-5, "loss")
+    op = dict(oracle.named_parameters())
+    checked = 0
+    for k, p in model.named_parameters():
+        if op[k].grad is None or p.grad is None:
+            continue
+        assert_close(p.grad, op[k].grad, 1e-3, f"grad {k}", rel_to_max=True)
+        checked += 1
+    assert checked > 15
