@@ -58,6 +58,32 @@ __global__ __launch_bounds__(256) void k_gcn_spmm(const float* __restrict__ x, i
   o.store(out + node * (int64_t)d + c);
 }
 
+// Plain adjacency sum with a weighted self term: out_i = self_w * x_i + sum_{k in segment(i)} x_{nbr[k]}
+// (every stored edge counts, self loops and duplicates included) = PyG GINConv's (1 + eps) x_i + sum_j x_j
+// before its MLP -- the phi network of SignNet (graphgps/encoder/signnet_pos_encoder.py:70-110) runs it over
+// the [N, k * channels] eigenvector features.  Transpose = the same kernel on the CSC half.
+template <int VEC>
+__global__ __launch_bounds__(256) void k_adj_sum(const float* __restrict__ x, int64_t ldx,
+                                                 const int32_t* __restrict__ rowptr,
+                                                 const int32_t* __restrict__ nbr, float self_w, int64_t N, int d,
+                                                 float* __restrict__ out) {
+  const int lanes_per_row = d / VEC;
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t node = t / lanes_per_row;
+  if (node >= N) return;
+  const int c = (int)(t - node * lanes_per_row) * VEC;
+  const Vec<VEC> xi = Vec<VEC>::load(x + node * ldx + c);
+  Vec<VEC> acc;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) acc[v] = self_w * xi[v];
+  for (int k = rowptr[node]; k < rowptr[node + 1]; ++k) {
+    const Vec<VEC> xj = Vec<VEC>::load(x + (int64_t)nbr[k] * ldx + c);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) acc[v] += xj[v];
+  }
+  acc.store(out + node * (int64_t)d + c);
+}
+
 inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
 }  // namespace
@@ -85,6 +111,20 @@ int gps_gcn_spmm(const float* x, int64_t ld_x, const int32_t* rowptr, const int3
     k_gcn_spmm<VEC><<<grid, 256, 0, s>>>(x, ld_x, rowptr, nbr, dinv, N, d, out);
   });
   return gps::launch_status("gps_gcn_spmm");
+}
+
+int gps_adj_sum(const float* x, int64_t ld_x, const int32_t* rowptr, const int32_t* nbr, float self_w, int64_t N,
+                int64_t E, int d, float* out, gps_stream_t stream) {
+  GPS_REQUIRE(N >= 0 && E >= 0 && d > 0 && ld_x >= d, "gps_adj_sum: bad sizes");
+  if (N == 0) return GPS_OK;
+  GPS_REQUIRE(x && rowptr && out && (E == 0 || nbr), "gps_adj_sum: null buffer");
+  auto ok = [&](size_t a) { return aligned_to(x, a) && aligned_to(out, a) && (ld_x * sizeof(float)) % a == 0; };
+  hipStream_t s = gps::as_stream(stream);
+  GPS_DISPATCH_VEC(d, ok(16), ok(8), {
+    const unsigned grid = gps::grid_for(N * (int64_t)(d / VEC), 256);
+    k_adj_sum<VEC><<<grid, 256, 0, s>>>(x, ld_x, rowptr, nbr, self_w, N, d, out);
+  });
+  return gps::launch_status("gps_adj_sum");
 }
 
 }  // extern "C"

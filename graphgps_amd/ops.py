@@ -307,6 +307,37 @@ def gcn_aggregate(x: torch.Tensor, gi: GraphIndex) -> torch.Tensor:
     return _GCNAggregate.apply(x, gi)
 
 
+class _GINAggregate(torch.autograd.Function):
+    """out_i = (1 + eps) x_i + sum_{j->i} x_j over every stored edge (PyG GINConv before its MLP)."""
+
+    @staticmethod
+    def forward(ctx, x: torch.Tensor, gi: GraphIndex, eps: float):
+        dev = _require_cuda(x)
+        x = _f32c(x, "x")
+        if x.dim() != 2 or x.shape[0] != gi.N:
+            raise _lib.GpsHipError(f"gin_aggregate: x {tuple(x.shape)} vs N={gi.N}")
+        out = torch.empty_like(x)
+        check(_lib.load().gps_adj_sum(ptr(x), x.shape[1], ptr(gi.rowptr_dst), ptr(gi.src_by_dst),
+                                      1.0 + float(eps), gi.N, gi.E, x.shape[1], ptr(out),
+                                      current_stream(dev)), "gps_adj_sum")
+        ctx.gi, ctx.eps = gi, float(eps)
+        return out
+
+    @staticmethod
+    def backward(ctx, g_out: torch.Tensor):
+        gi: GraphIndex = ctx.gi
+        g_out = _f32c(g_out, "g_out")
+        g_x = torch.empty_like(g_out)
+        check(_lib.load().gps_adj_sum(ptr(g_out), g_out.shape[1], ptr(gi.rowptr_src), ptr(gi.dst_by_src),
+                                      1.0 + ctx.eps, gi.N, gi.E, g_out.shape[1], ptr(g_x),
+                                      current_stream(g_out.device)), "gps_adj_sum")
+        return g_x, None, None
+
+
+def gin_aggregate(x: torch.Tensor, gi: GraphIndex, eps: float = 0.0) -> torch.Tensor:
+    return _GINAggregate.apply(x, gi, eps)
+
+
 # -------------------------------------------------------------------------------------------
 # segment attention
 # -------------------------------------------------------------------------------------------

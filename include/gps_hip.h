@@ -129,6 +129,11 @@ int gps_gcn_dinv(const int32_t* rowptr_dst, const int32_t* src_by_dst, int64_t N
                  gps_stream_t stream);
 int gps_gcn_spmm(const float* x, int64_t ld_x, const int32_t* rowptr, const int32_t* nbr, const float* dinv,
                  int64_t N, int64_t E, int d, float* out, gps_stream_t stream);
+/* out_i = self_w * x_i + sum_{k in segment(i)} x_{nbr[k]} (all stored edges, loops and duplicates included):
+ * PyG GINConv's aggregation (1 + eps) x_i + sum_{j->i} x_j before its MLP, the phi network of SignNet
+ * (graphgps/encoder/signnet_pos_encoder.py:70-110).  CSR-by-target forward, CSC-by-source = transpose. */
+int gps_adj_sum(const float* x, int64_t ld_x, const int32_t* rowptr, const int32_t* nbr, float self_w, int64_t N,
+                int64_t E, int d, float* out, gps_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Segment (per-graph, varlen) multi-head attention core on fp32 MFMA (v_mfma_f32_16x16x4_f32).

@@ -38,7 +38,8 @@ set_cfg(cfg)
 # the reference's files register their GraphGym wrappers under the same names as this package's
 for _k in ("gatedgcnconv", "gineconv"):
     graphgps_amd.graphgym.register.layer_dict.pop(_k, None)
-graphgps_amd.graphgym.register.node_encoder_dict.pop("GraphormerBias", None)
+for _k in ("GraphormerBias", "SignNet"):
+    graphgps_amd.graphgym.register.node_encoder_dict.pop(_k, None)
 from graphgps.layer.gps_layer import GPSLayer as RefGPSLayer  # noqa: E402
 from torch_geometric.data import Batch as StubBatch  # noqa: E402
 
@@ -63,6 +64,10 @@ CASES = {
     # [B*H, nmax, nmax] (random here; graphormer_encoder.py produces it in a model)
     "gine_biasedtransformer_d32h4": (dict(dim_h=32, local_gnn_type="GINE",
                                           global_model_type="BiasedTransformer", num_heads=4), "ZINC", 5, 22),
+    # GCN local model (gps_layer.py:50-52,183: called without edge attributes; PyG GCNConv semantics are the
+    # stub's restatement, the wiring is the reference's)
+    "gcn_transformer_d32h4": (dict(dim_h=32, local_gnn_type="GCN", global_model_type="Transformer",
+                                   num_heads=4), "P14", 6, 23),
     # (no GINE + equivstable_pe fixture: the reference's GINEConvESLapPE cannot be constructed -- its
     #  __init__ calls reset_parameters(), which touches self.mlp_r_ij, before defining it:
     #  gine_conv_layer.py:35 vs :43-54.  The HIP layer implements the intended arithmetic and is
@@ -222,9 +227,53 @@ def run_graphormer(seed=21):
     return out
 
 
+def run_signnet(seed=31):
+    """The reference's SignNetNodeEncoder (signnet_pos_encoder.py), both rho models, on a small batch with
+    NaN-padded eigenvectors: state_dict, encoded x, parameter gradients."""
+    from graphgps.encoder.signnet_pos_encoder import SignNetNodeEncoder as RefSignNet
+    out = {}
+    for model, k in (("MLP", 5), ("DeepSet", 9)):
+        torch.manual_seed(seed)
+        cfg.share.dim_in = 7
+        cfg.posenc_SignNet.model = model
+        cfg.posenc_SignNet.dim_pe = 6
+        cfg.posenc_SignNet.layers = 3
+        cfg.posenc_SignNet.post_layers = 2
+        cfg.posenc_SignNet.phi_hidden_dim = 16
+        cfg.posenc_SignNet.phi_out_dim = 4
+        cfg.posenc_SignNet.eigen.max_freqs = k
+        cfg.posenc_SignNet.pass_as_var = False
+        # float64: the gradient of the first phi layer (in_channels = 1, followed by BatchNorm, summed over
+        # the +v / -v branches) is a heavily cancelling sum -- in float32 the reference's own value for it is
+        # only good to ~2e-3 relative, which is no yardstick for a 1e-5 comparison
+        enc = RefSignNet(20).double()
+        enc.train()
+        sizes, edge_index, bvec, ptr, gen, _ = make_structure("P14", 5, seed)
+        N = int(ptr[-1])
+        x = torch.randn(N, 7, generator=gen).double()
+        vecs = torch.randn(N, k, generator=gen).double()
+        if model == "DeepSet":                 # graphs with fewer than k nodes pad their eigenvectors with NaN
+            n_of = (ptr[1:] - ptr[:-1])[bvec]
+            vecs[torch.arange(k)[None, :] >= n_of[:, None]] = float("nan")
+        w = torch.randn(N, 20, generator=gen).double()
+        sd = {kk: v.clone() for kk, v in enc.state_dict().items()}
+        b = StubBatch(x=x.clone(), edge_index=edge_index, batch=bvec, eigvecs_sn=vecs.clone(),
+                      eigvals_sn=torch.zeros(N, k, 1, dtype=torch.float64))
+        o = enc(b)
+        (o.x * w).sum().backward()
+        out[model] = dict(k=k, state_dict=sd, x=x, edge_index=edge_index, batch=bvec, ptr=ptr, eigvecs=vecs, w=w,
+                          out_x=o.x.detach().clone(),
+                          grads={kk: p.grad.clone() for kk, p in enc.named_parameters() if p.grad is not None},
+                          state_dict_after={kk: v.clone() for kk, v in enc.state_dict().items()})
+    return out
+
+
 def main():
     outdir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(outdir, exist_ok=True)
+    fix = run_signnet()
+    torch.save(fix, os.path.join(outdir, "signnet_encoder.pt"))
+    print("signnet_encoder:", {k: tuple(v["out_x"].shape) for k, v in fix.items()})
     fix = run_graphormer()
     torch.save(fix, os.path.join(outdir, "graphormer_encoder_layer.pt"))
     print("graphormer_encoder_layer:", {k: tuple(v["attn_bias"].shape) for k, v in fix.items()})

@@ -112,5 +112,47 @@ def _unsupported(name):
     return _U
 
 
-GCNConv, GINConv, GENConv, GATConv, PNAConv = (_unsupported(n) for n in
-                                              ("GCNConv", "GINConv", "GENConv", "GATConv", "PNAConv"))
+class GINConv(torch.nn.Module):
+    """PyG 2.2 GINConv, published behaviour: out_i = nn((1 + eps) * x_i + sum_{j->i} x_j) with the node axis at
+    dim -2 (so [k, N, C] inputs aggregate over N); ``eps`` is a buffer unless train_eps."""
+
+    def __init__(self, nn, eps=0.0, train_eps=False, **kwargs):
+        super().__init__()
+        assert not train_eps
+        self.nn = nn
+        self.register_buffer("eps", torch.Tensor([eps]))
+
+    def forward(self, x, edge_index, size=None):
+        agg = torch.zeros_like(x).index_add_(-2, edge_index[1], x.index_select(-2, edge_index[0]))
+        return self.nn(agg + (1 + self.eps) * x)
+
+
+class GCNConv(torch.nn.Module):
+    """PyG 2.2 GCNConv with its defaults, published behaviour: ``lin`` (glorot weight, no bias), gcn_norm =
+    input self loops dropped and ONE unit self loop per node added (add_remaining_self_loops), degree =
+    scatter-add of ones over targets, weight(j->i) = deg_j^-1/2 deg_i^-1/2, sum aggregation, + ``bias``
+    (zeros at init)."""
+
+    def __init__(self, in_channels, out_channels, **kwargs):
+        super().__init__()
+        assert not kwargs
+        self.lin = torch.nn.Linear(in_channels, out_channels, bias=False)
+        a = (6.0 / (in_channels + out_channels)) ** 0.5
+        torch.nn.init.uniform_(self.lin.weight, -a, a)
+        self.bias = torch.nn.Parameter(torch.zeros(out_channels))
+
+    def forward(self, x, edge_index, edge_weight=None):
+        assert edge_weight is None
+        n = x.size(0)
+        keep = edge_index[0] != edge_index[1]
+        loops = torch.arange(n, dtype=edge_index.dtype, device=x.device)
+        row = torch.cat([edge_index[0][keep], loops])
+        col = torch.cat([edge_index[1][keep], loops])
+        deg = torch.zeros(n, dtype=x.dtype, device=x.device).index_add_(0, col, torch.ones_like(col, dtype=x.dtype))
+        dinv = deg.pow(-0.5)
+        h = self.lin(x)
+        msg = (dinv[row] * dinv[col]).unsqueeze(-1) * h.index_select(0, row)
+        return torch.zeros_like(h).index_add_(0, col, msg) + self.bias
+
+
+GENConv, GATConv, PNAConv = (_unsupported(n) for n in ("GENConv", "GATConv", "PNAConv"))

@@ -25,11 +25,13 @@ def pytest_collection_modifyitems(config, items):
 
 
 GRAPHORMER_GOLDEN = "graphormer_encoder_layer"      # encoder + GraphormerLayer fixture (own structure)
+SIGNNET_GOLDEN = "signnet_encoder"                   # SignNet encoder fixture (own structure)
 
 
 def golden_names():
     """The GPSLayer fixtures (one layer, one batch each)."""
-    return sorted(f[:-3] for f in os.listdir(GOLDEN_DIR) if f.endswith(".pt") and f[:-3] != GRAPHORMER_GOLDEN)
+    return sorted(f[:-3] for f in os.listdir(GOLDEN_DIR)
+                  if f.endswith(".pt") and f[:-3] not in (GRAPHORMER_GOLDEN, SIGNNET_GOLDEN))
 
 
 def load_golden(name):

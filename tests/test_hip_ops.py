@@ -635,3 +635,31 @@ def test_gcn_aggregate(d):
     assert_close(xg.grad, xr.grad, Tol.GRAD_REL, "gcn d_x", rel_to_max=True)
     out2 = gcn_aggregate(x.cuda(), gi)
     assert torch.equal(out2, out.detach())            # fixed reduction order: bitwise reproducible
+
+
+def test_gin_aggregate_matches_index_add():
+    """csrc/gcn.hip:k_adj_sum = PyG GINConv's (1 + eps) x_i + sum_{j->i} x_j over EVERY stored edge (self loops
+    and duplicates count), forward and transpose, on the wide [N, k * C] feature layout SignNet uses."""
+    from graphgps_amd.ops import gin_aggregate
+    gen = torch.Generator().manual_seed(5)
+    sizes = [30, 2, 51]
+    ptr = torch.tensor([0] + list(np.cumsum(sizes)))
+    N = int(ptr[-1])
+    parts = []
+    for g, n in enumerate(sizes):
+        ei = torch.randint(0, n, (2, 3 * n), generator=gen)
+        parts.append(torch.cat([ei, ei[:, :4]], dim=1) + int(ptr[g]))        # duplicates; random self loops
+    ei = torch.cat(parts, dim=1)
+    bvec = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
+    for d, eps in ((36, 0.0), (5, 0.25)):
+        x = torch.randn(N, d, generator=gen)
+        w = torch.randn(N, d, generator=gen)
+        xr = x.clone().double().requires_grad_(True)
+        ref = ((1 + eps) * xr).index_add(0, ei[1], xr.index_select(0, ei[0]))
+        (ref * w.double()).sum().backward()
+        gi = _index(ei, bvec, ptr)
+        xg = x.cuda().requires_grad_(True)
+        out = gin_aggregate(xg, gi, eps)
+        (out * w.cuda()).sum().backward()
+        assert_close(out, ref, Tol.ACT, "gin out")
+        assert_close(xg.grad, xr.grad, Tol.GRAD_REL, "gin d_x", rel_to_max=True)

@@ -119,3 +119,49 @@ def test_graphormer_oracle_and_encoders_match_reference_fixture(variant):
         got = dict(mod.named_parameters())
         for k, g in fix["grads"][part].items():
             assert_close(got[k].grad, g, Tol.GRAD_REL, f"grad {part}.{k}", rel_to_max=True)
+
+
+def _signnet_case(model, dev, grad_tol=Tol.GRAD_REL):
+    """This package's SignNet encoder against the reference-generated fixture (reference
+    signnet_pos_encoder.py hosted on the GINConv / scatter stubs): strict state_dict load = parameter-name
+    contract, encoded x, every parameter gradient, BatchNorm running statistics."""
+    from conftest import SIGNNET_GOLDEN
+    from graphgps_amd.encoder.signnet_encoder import SignNetNodeEncoder
+    from graphgps_amd.graphgym.config import cfg, set_cfg
+    fix = load_golden(SIGNNET_GOLDEN)[model]
+    set_cfg(cfg)
+    cfg.share.dim_in = 7
+    pe = cfg.posenc_SignNet
+    pe.model, pe.dim_pe, pe.layers, pe.post_layers = model, 6, 3, 2
+    pe.phi_hidden_dim, pe.phi_out_dim, pe.pass_as_var = 16, 4, False
+    pe.eigen.max_freqs = fix["k"]
+    enc = SignNetNodeEncoder(20)
+    enc.load_state_dict(fix["state_dict"], strict=True)      # fixture tensors are float64 (see gen_golden.py)
+    enc.float().to(dev).train()
+    b = Batch(x=fix["x"].float().to(dev), edge_index=fix["edge_index"].to(dev), batch=fix["batch"].to(dev),
+              ptr=fix["ptr"].to(dev), eigvecs_sn=fix["eigvecs"].float().to(dev),
+              eigvals_sn=torch.zeros(fix["x"].shape[0], fix["k"], 1, device=dev))
+    b.num_graphs = int(fix["ptr"].numel() - 1)
+    out = enc(b)
+    (out.x * fix["w"].float().to(dev)).sum().backward()
+    assert_close(out.x, fix["out_x"], Tol.ACT, "encoded x")
+    got = dict(enc.named_parameters())
+    gs = max(float(v.abs().max()) for v in fix["grads"].values())
+    for k, g in fix["grads"].items():
+        a_, b_ = got[k].grad.detach().double().cpu(), g.double()
+        if float(b_.abs().max()) < 1e-6 * gs:
+            # a bias that feeds a BatchNorm: mathematically zero (1e-14 in the float64 fixture), float32
+            # rounding residue here
+            assert float(a_.abs().max()) < 1e-5 * gs, k
+            continue
+        assert (a_ - b_).abs().max().item() <= grad_tol * max(float(b_.abs().max()), 0.01 * gs, 1.0), \
+            f"grad {k}: {(a_ - b_).abs().max().item():.3e}"
+    after = enc.state_dict()
+    for k, v in fix["state_dict_after"].items():
+        if v.dtype.is_floating_point:
+            assert_close(after[k], v, Tol.ACT, f"state {k}")
+
+
+@pytest.mark.parametrize("model", ["MLP", "DeepSet"])
+def test_signnet_encoder_matches_reference_fixture_cpu(model):
+    _signnet_case(model, torch.device("cpu"))
