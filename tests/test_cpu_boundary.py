@@ -207,3 +207,30 @@ def test_device_loader_is_a_pass_through_on_cpu():
     out = list(dl)
     assert all(a is b for a, b in zip(out, host))
     assert all("_gps_index" not in b.__dict__ for b in out)
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/configs"), reason="needs the reference's configs/ tree")
+def test_reference_configs_construct():
+    """Every YAML under the reference's configs/ goes through set_cfg + load_cfg + network_dict[...](dim_in,
+    dim_out) -- the create_model path of main.py:118-121,144 -- on this package's registrations.  The only
+    ones that do not construct: the SAN family (its edge-softmax layers are not built: DESIGN.md section 7) and
+    the two *-inference.yaml files, whose `posenc_RWSE.model: none` the reference's own RWSE encoder rejects with
+    the same ValueError (kernel_pos_encoder.py:75-77)."""
+    import glob
+    import graphgps_amd as g
+    root = "/root/reference/configs"
+    failed = {}
+    total = 0
+    for f in sorted(glob.glob(os.path.join(root, "**", "*.yaml"), recursive=True)):
+        name = os.path.relpath(f, root)
+        total += 1
+        try:
+            g.create_model(f, [], 9, 1 if "pcqm-contact" in name else 3)
+        except Exception as exc:       # noqa: BLE001  (the point is to collect every reason)
+            failed[name] = f"{type(exc).__name__}: {exc}"
+    assert total >= 80
+    unexpected = {k: v for k, v in failed.items()
+                  if not (k.startswith("SAN/") or (k.endswith("-inference.yaml") and "'none' encoder" in v))}
+    assert not unexpected, unexpected
+    assert all(k.startswith("SAN/") and "SANTransformer" in v for k, v in failed.items() if k.startswith("SAN/"))
+    assert len(failed) == 12, sorted(failed)
