@@ -52,6 +52,18 @@ __device__ __forceinline__ bool keep_elem(uint32_t rh, uint32_t key_local, float
   return (float)(r >> 8) * (1.0f / 16777216.0f) >= p_drop;
 }
 
+// exp for the softmax numerators: exp2(x * log2 e) on the transcendental unit (v_exp_f32).  Arguments are
+// <= 0 and rarely below -20, where the product's rounding costs <= 2e-6 relative -- inside the 1e-5 budget --
+// against ~8 extra VALU instructions per element for the correctly rounded expf (the kernels are
+// VALU-issue-bound).  GPS_ATTN_EXACT_EXP=1 at compile time restores expf.
+__device__ __forceinline__ float sm_exp(float x) {
+#ifdef GPS_ATTN_EXACT_EXP
+  return expf(x);
+#else
+  return __builtin_amdgcn_exp2f(x * 1.44269504088896341f);
+#endif
+}
+
 template <int DH>
 struct Geo {
   static constexpr int KPL = (DH + 3) / 4;    // contraction elements per lane group
@@ -224,14 +236,14 @@ __device__ __forceinline__ void attn_fwd_block(
       mloc = fmaxf(mloc, s[t][r]);
     }
   const float mnew = fmaxf(m, group_max(mloc));
-  const float alpha = expf(m - mnew);  // m = -inf on the first block -> 0
+  const float alpha = sm_exp(m - mnew);  // m = -inf on the first block -> 0
   m = mnew;
   float psum = 0.0f;
 #pragma unroll
   for (int t = 0; t < NT; ++t)
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      float p = expf(s[t][r] - mnew);  // masked keys: exp(-inf) = 0
+      float p = sm_exp(s[t][r] - mnew);  // masked keys: exp(-inf) = 0
       psum += p;
       if (DROP) {
         const uint32_t key_local = (uint32_t)(kb + 16 * t + 4 * grp + r);
@@ -367,7 +379,7 @@ __device__ __forceinline__ void attn_dq_block(
     for (int r = 0; r < 4; ++r) {
       const int key = kb + 16 * t + 4 * grp + r;
       if constexpr (BIAS) s[t][r] += bv[t][r];
-      const float p = expf(s[t][r] - lse_q);
+      const float p = sm_exp(s[t][r] - lse_q);
       float dpe = dp[t][r];
       if (DROP) dpe = keep_elem(rh, (uint32_t)key, p_drop) ? dpe * inv_keep : 0.0f;
       s[t][r] = key < w.n ? p * (dpe - dl_q) : 0.0f;   // dS^T, reused as the B operand below
@@ -519,7 +531,7 @@ __device__ __forceinline__ void attn_dkv_block(
       const int qq = qb + 16 * t + 4 * grp + r;
       const bool q_in = qq < w.n;
       if constexpr (BIAS) s[t][r] += bv[t][r];
-      const float pr = q_in ? expf(s[t][r] - lq[t][r]) : 0.0f;
+      const float pr = q_in ? sm_exp(s[t][r] - lq[t][r]) : 0.0f;
       float dpe = dp[t][r];
       float pd = pr;
       if (DROP) {

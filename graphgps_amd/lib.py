@@ -13,7 +13,8 @@ from typing import Optional
 import torch  # noqa: F401  -- must be imported first: it maps the HIP runtime our .so binds to
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libgps_hip.so")
+# GPS_HIP_LIB: an alternative build of the same ABI (A/B timing of kernel variants in one process launch each)
+LIB_PATH = os.environ.get("GPS_HIP_LIB") or os.path.join(_HERE, "csrc", "libgps_hip.so")
 ABI_VERSION = 2
 
 _lib: Optional[ctypes.CDLL] = None
