@@ -47,7 +47,7 @@ __global__ __launch_bounds__(256) void k_gatedgcn_fwd(
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
       eh[v] = (dx[v] + ex[v]) + ce[v];  // e_ij = Dx_i + Ex_j + Ce            (:96)
-      float s = sigmoidf_exact(eh[v]);  //                                     (:97)
+      float s = sigmoidf_fast(eh[v]);  //                                     (:97)
       if (GATE) s = s * rr;             // sigma_ij * r_ij                     (:101-104)
       num[v] += s * bx[v];                    // scatter(sigma*Bx_j)           (:117-119)
       den[v] += s;                            // scatter(sigma)                (:121-123)
@@ -106,7 +106,7 @@ __global__ __launch_bounds__(256) void k_gatedgcn_bwd_dst(
     const float rr = GATE ? r_edge[id] : 1.0f;
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
-      const float s = sigmoidf_exact(eh[v]);
+      const float s = sigmoidf_fast(eh[v]);
       float gs = a[v] * bx[v] + b[v];          // gradient wrt the (gated) sigma
       if (GATE) gs = gs * rr;
       dl[v] = ge[v] + gs * (s * (1.0f - s));
@@ -143,7 +143,7 @@ __global__ __launch_bounds__(256) void k_gatedgcn_bwd_src(
     const float rr = GATE ? r_edge[id] : 1.0f;
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
-      float s = sigmoidf_exact(eh[v]);
+      float s = sigmoidf_fast(eh[v]);
       if (GATE) s = s * rr;
       gex[v] += dl[v];
       gbx[v] += s * (gx[v] / (dn[v] + 1e-6f));

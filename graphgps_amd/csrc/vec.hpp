@@ -36,6 +36,16 @@ struct Vec<1> {
 };
 
 __device__ __forceinline__ float sigmoidf_exact(float x) { return 1.0f / (1.0f + expf(-x)); }
+// The gate of the GatedGCN kernels, once per edge element: v_exp_f32 + v_rcp_f32 (each 1 ulp) instead of the
+// correctly rounded expf and IEEE division (~20 VALU instructions) -- <= 3e-7 relative on sigma, which enters
+// x~ through a ratio of sums of ~3 terms.  GPS_EXACT_SIGMOID at compile time restores the exact form.
+__device__ __forceinline__ float sigmoidf_fast(float x) {
+#ifdef GPS_EXACT_SIGMOID
+  return sigmoidf_exact(x);
+#else
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * x));
+#endif
+}
 
 // Dispatch on the widest vector that divides d AND keeps every row pointer aligned.
 #define GPS_DISPATCH_VEC(d, ld_ok4, ld_ok2, ...)                              \
