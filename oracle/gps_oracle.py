@@ -13,14 +13,15 @@ piece citing the reference file:line it follows (paths relative to
 Pinning status (also in DESIGN.md):
 * The reference ships no golden vectors / KATs for this path.
 * In-tree arithmetic -- ``GatedGCNLayer`` (graphgps/layer/gatedgcn_layer.py),
-  ``GPSLayer`` wiring (graphgps/layer/gps_layer.py) and FAVOR+
-  (graphgps/layer/performer_layer.py) -- IS pinned: ``oracle/gen_golden.py`` imports
-  those reference files unmodified in this container (hosting them on the stub
-  modules in ``oracle/ref_stubs``) and writes ``tests/golden/*.pt``;
+  ``GPSLayer`` wiring incl. the BiasedTransformer branch (graphgps/layer/gps_layer.py), FAVOR+
+  (graphgps/layer/performer_layer.py), ``GraphormerLayer`` (graphgps/layer/graphormer_layer.py) and the
+  Graphormer / SignNet encoders (graphgps/encoder/{graphormer_encoder,signnet_pos_encoder}.py) -- IS pinned:
+  ``oracle/gen_golden.py`` imports those reference files unmodified in this container (hosting them on the
+  stub modules in ``oracle/ref_stubs``) and writes ``tests/golden/*.pt``;
   ``tests/test_oracle_golden.py`` checks this oracle against them.
 * Third-party semantics the reference relies on but does not vendor
-  (PyG 2.2 ``MessagePassing.propagate`` index convention, ``GINEConv``,
-  ``to_dense_batch``; ``torch_scatter.scatter``) are restated from their published
+  (PyG 2.2 ``MessagePassing.propagate`` index convention, ``GINEConv`` / ``GCNConv`` / ``GINConv``,
+  ``to_dense_batch`` / ``to_dense_adj``; ``torch_scatter.scatter``) are restated from their published
   behaviour both here and in the stubs -> that part is "parity unpinned".
 """
 from __future__ import annotations
