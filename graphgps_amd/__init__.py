@@ -17,7 +17,7 @@ from .network.custom_gnn import CustomGNN  # noqa: F401
 from .encoder import graphormer_encoder as _graphormer_encoder  # noqa: F401
 from .encoder import extra_encoders as _extra_encoders  # noqa: F401
 from .encoder import signnet_encoder as _signnet_encoder  # noqa: F401
-from .head import gnn_heads as _gnn_heads  # noqa: F401
+from .head import edge_head as _edge_head, heads as _heads  # noqa: F401
 from .layer.graphormer_layer import GraphormerLayer  # noqa: F401
 from .network.graphormer import GraphormerModel  # noqa: F401
 from .loss import losses as _losses  # noqa: F401

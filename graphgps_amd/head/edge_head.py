@@ -1,37 +1,14 @@
-"""GraphGym's default node head and the inductive edge head (plain torch, after the layers).
+"""The inductive edge / link-prediction head (plain torch, after the layers).
 
-  * ``head_dict['node']``: PyG 2.2 ``GNNNodeHead`` (third-party; what ``gnn.head: node`` and the default of
-    ``dataset.task: node`` resolve to, e.g. configs/GPS/actor-GPS.yaml, configs/Graphormer/actor-Graphormer.yaml):
-    ``layer_post_mp`` MLP over ``batch.x``, rows selected by ``batch.<split>_mask``.
   * ``head_dict['inductive_edge']``: /root/reference/graphgps/head/inductive_edge.py:9-155 (``layer_post_mp``;
     'dot' / 'cosine_similarity' / 'concat' decoding of ``batch.edge_index_labeled``; Hits@k / MRR in eval mode).
 """
 import torch
 import torch.nn as nn
 
-from ..graphgym import register
 from ..graphgym.config import cfg
 from ..graphgym.layers import MLP, new_layer_config
 from ..graphgym.register import register_head
-
-
-class GNNNodeHead(nn.Module):
-    def __init__(self, dim_in, dim_out):
-        super().__init__()
-        self.layer_post_mp = MLP(new_layer_config(dim_in, dim_out, cfg.gnn.layers_post_mp,
-                                                  has_act=False, has_bias=True, cfg=cfg))
-
-    def _apply_index(self, batch):
-        mask = getattr(batch, f'{batch.split}_mask')
-        return batch.x[mask], batch.y[mask]
-
-    def forward(self, batch):
-        batch = self.layer_post_mp(batch)
-        return self._apply_index(batch)
-
-
-if 'node' not in register.head_dict:         # real PyG registers its own
-    register_head('node', GNNNodeHead)
 
 
 def _hits_and_mrr(pos, neg):

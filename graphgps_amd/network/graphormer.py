@@ -1,50 +1,28 @@
 """``GraphormerModel`` behind ``register_network('Graphormer')``.
 
-Drop-in for ``/root/reference/graphgps/network/graphormer.py:10-52``: ``(dim_in, dim_out)`` resolved from the
-global ``cfg`` (``cfg.graphormer.*``, :35-43), children ``encoder`` / ``pre_mp`` / ``layers`` / ``post_mp``
-applied in order (:49-52)."""
-import torch
-
-from ..graphgym import register
+Drop-in for ``/root/reference/graphgps/network/graphormer.py:10-52``: ``(dim_in, dim_out)`` resolved from
+``cfg.graphormer.*``; children ``encoder`` / ``pre_mp`` / ``layers`` / ``post_mp`` (network/base.py)."""
 from ..graphgym.config import cfg
-from ..graphgym.layers import GNNPreMP
 from ..graphgym.register import register_network
-from ..head import graphormer_graph as _h  # noqa: F401
+from ..head import heads as _heads  # noqa: F401
 from ..layer.graphormer_layer import GraphormerLayer
-from .gps_model import FeatureEncoder
+from .base import GraphGymNetwork
 
 
 @register_network('Graphormer', overwrite=True)
-class GraphormerModel(torch.nn.Module):
+class GraphormerModel(GraphGymNetwork):
     def __init__(self, dim_in, dim_out):
         super().__init__()
-        self.encoder = FeatureEncoder(dim_in)
-        dim_in = self.encoder.dim_in
-
-        if cfg.gnn.layers_pre_mp > 0:
-            self.pre_mp = GNNPreMP(dim_in, cfg.gnn.dim_inner, cfg.gnn.layers_pre_mp, cfg)
-            dim_in = cfg.gnn.dim_inner
-
-        if not cfg.graphormer.embed_dim == cfg.gnn.dim_inner == dim_in:
+        width = self._front(dim_in)
+        gcfg = cfg.graphormer
+        if not gcfg.embed_dim == cfg.gnn.dim_inner == width:
             raise ValueError(
                 f"The inner and embed dims must match: "
-                f"embed_dim={cfg.graphormer.embed_dim} "
-                f"dim_inner={cfg.gnn.dim_inner} dim_in={dim_in}")
-
-        layers = []
-        for _ in range(cfg.graphormer.num_layers):
-            layers.append(GraphormerLayer(
-                embed_dim=cfg.graphormer.embed_dim,
-                num_heads=cfg.graphormer.num_heads,
-                dropout=cfg.graphormer.dropout,
-                attention_dropout=cfg.graphormer.attention_dropout,
-                mlp_dropout=cfg.graphormer.mlp_dropout))
-        self.layers = torch.nn.Sequential(*layers)
-
-        GNNHead = register.head_dict[cfg.gnn.head]
-        self.post_mp = GNNHead(dim_in=cfg.gnn.dim_inner, dim_out=dim_out)
-
-    def forward(self, batch):
-        for module in self.children():
-            batch = module(batch)
-        return batch
+                f"embed_dim={gcfg.embed_dim} "
+                f"dim_inner={cfg.gnn.dim_inner} dim_in={width}")
+        self._stack('layers',
+                    lambda: GraphormerLayer(embed_dim=gcfg.embed_dim, num_heads=gcfg.num_heads,
+                                            dropout=gcfg.dropout, attention_dropout=gcfg.attention_dropout,
+                                            mlp_dropout=gcfg.mlp_dropout),
+                    gcfg.num_layers)
+        self._head(dim_out)
