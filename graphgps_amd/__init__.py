@@ -20,6 +20,7 @@ from .encoder import signnet_encoder as _signnet_encoder  # noqa: F401
 from .head import edge_head as _edge_head, heads as _heads  # noqa: F401
 from .layer.graphormer_layer import GraphormerLayer  # noqa: F401
 from .network.graphormer import GraphormerModel  # noqa: F401
+from .network.san_transformer import SANTransformer  # noqa: F401
 from .loss import losses as _losses  # noqa: F401
 from .optim import FlatAdamW, ParamArena  # noqa: F401
 

@@ -268,9 +268,46 @@ def run_signnet(seed=31):
     return out
 
 
+def run_san(seed=41):
+    """The reference's SANLayer / SAN2Layer (san_layer.py, san2_layer.py; full_graph=True: real edges + the
+    complement pairs of graphgps/utils.py:negate_edge_index), one layer each on a small batch."""
+    from graphgps.layer.san_layer import SANLayer as RefSAN
+    from graphgps.layer.san2_layer import SAN2Layer as RefSAN2
+
+    class _B(StubBatch):
+        def size(self, dim=None):
+            return self.x.shape[0] if dim == 0 else (self.x.shape[0], self.x.shape[0])
+
+    out = {}
+    for name, cls in (("SANLayer", RefSAN), ("SAN2Layer", RefSAN2)):
+        torch.manual_seed(seed)
+        d, H = 32, 4
+        fake = torch.nn.Embedding(1, d)
+        layer = cls(gamma=0.1, in_dim=d, out_dim=d, num_heads=H, full_graph=True, fake_edge_emb=fake,
+                    dropout=0.0, layer_norm=False, batch_norm=True, residual=True)
+        layer.train()
+        sd = {k: v.clone() for k, v in layer.state_dict().items()}
+        sizes, edge_index, bvec, ptr, gen, _ = make_structure("P14", 5, seed)
+        N, E = int(ptr[-1]), edge_index.shape[1]
+        x = torch.randn(N, d, generator=gen, requires_grad=True)
+        e = torch.randn(E, d, generator=gen, requires_grad=True)
+        w = torch.randn(N, d, generator=gen)
+        b = _B(x=x, edge_index=edge_index, edge_attr=e, batch=bvec)
+        o = layer(b)
+        (o.x * w).sum().backward()
+        out[name] = dict(d=d, H=H, gamma=0.1, state_dict=sd, x=x.detach().clone(), edge_attr=e.detach().clone(),
+                         edge_index=edge_index, batch=bvec, ptr=ptr, w=w, out_x=o.x.detach().clone(),
+                         grad_x=x.grad.clone(), grad_edge_attr=e.grad.clone(),
+                         grads={k: p.grad.clone() for k, p in layer.named_parameters() if p.grad is not None})
+    return out
+
+
 def main():
     outdir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(outdir, exist_ok=True)
+    fix = run_san()
+    torch.save(fix, os.path.join(outdir, "san_layers.pt"))
+    print("san_layers:", {k: tuple(v["out_x"].shape) for k, v in fix.items()})
     fix = run_signnet()
     torch.save(fix, os.path.join(outdir, "signnet_encoder.pt"))
     print("signnet_encoder:", {k: tuple(v["out_x"].shape) for k, v in fix.items()})

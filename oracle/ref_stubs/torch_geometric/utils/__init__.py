@@ -57,3 +57,20 @@ def to_networkx(data, *args, **kwargs):
     for u, v in zip(data.edge_index[0].tolist(), data.edge_index[1].tolist()):
         G.add_edge(u, v)
     return G
+
+
+def remove_self_loops(edge_index, edge_attr=None):
+    """PyG published behaviour: drop the columns with source == target."""
+    keep = edge_index[0] != edge_index[1]
+    return edge_index[:, keep], (None if edge_attr is None else edge_attr[keep])
+
+
+def degree(index, num_nodes=None, dtype=None):
+    n = int(index.max()) + 1 if num_nodes is None else num_nodes
+    return torch.zeros(n, dtype=dtype or torch.float).index_add_(0, index, torch.ones(index.numel(), dtype=dtype or torch.float))
+
+
+def scatter(src, index, dim=0, dim_size=None, reduce="sum"):
+    """PyG 2.3 ``utils.scatter`` (dim 0): sum / add / mul."""
+    from torch_scatter import scatter as _scatter
+    return _scatter(src, index, dim=dim, dim_size=dim_size, reduce=reduce)

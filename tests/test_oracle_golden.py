@@ -165,3 +165,57 @@ def _signnet_case(model, dev, grad_tol=Tol.GRAD_REL):
 @pytest.mark.parametrize("model", ["MLP", "DeepSet"])
 def test_signnet_encoder_matches_reference_fixture_cpu(model):
     _signnet_case(model, torch.device("cpu"))
+
+
+@pytest.mark.parametrize("name", ["SANLayer", "SAN2Layer"])
+def test_san_layers_match_reference_fixture(name):
+    """The torch-level SAN layers (graphgps_amd/layer/san_layers.py; real edges + vectorised complement pairs)
+    against the reference's san_layer.py / san2_layer.py run by oracle/gen_golden.py: strict state_dict load,
+    output, input / edge-feature gradients and every parameter gradient."""
+    from conftest import SAN_GOLDEN
+    from graphgps_amd.layer import san_layers
+    fix = load_golden(SAN_GOLDEN)[name]
+    d, H = fix["d"], fix["H"]
+    layer = getattr(san_layers, name)(gamma=fix["gamma"], in_dim=d, out_dim=d, num_heads=H, full_graph=True,
+                                      fake_edge_emb=torch.nn.Embedding(1, d), dropout=0.0, layer_norm=False,
+                                      batch_norm=True, residual=True)
+    layer.load_state_dict(fix["state_dict"], strict=True)
+    layer.train()
+    x = fix["x"].clone().requires_grad_(True)
+    e = fix["edge_attr"].clone().requires_grad_(True)
+    b = Batch(x=x, edge_index=fix["edge_index"], edge_attr=e, batch=fix["batch"], ptr=fix["ptr"])
+    out = layer(b)
+    (out.x * fix["w"]).sum().backward()
+    assert_close(out.x, fix["out_x"], Tol.ACT, "out.x")
+    assert_close(x.grad, fix["grad_x"], Tol.GRAD_REL, "grad x", rel_to_max=True)
+    assert_close(e.grad, fix["grad_edge_attr"], Tol.GRAD_REL, "grad edge_attr", rel_to_max=True)
+    got = dict(layer.named_parameters())
+    assert set(fix["grads"]) <= set(got)
+    gs = max(float(v.abs().max()) for v in fix["grads"].values())
+    for k, g in fix["grads"].items():
+        a_, b_ = got[k].grad.detach().double(), g.double()
+        assert (a_ - b_).abs().max().item() <= Tol.GRAD_REL * max(float(b_.abs().max()), 0.01 * gs, 1.0), \
+            f"grad {k}: {(a_ - b_).abs().max().item():.3e}"
+
+
+def test_complement_edge_index_is_the_adjacency_complement():
+    """Every ordered same-graph pair that is neither an edge nor a self pair, nothing across graphs; duplicate
+    and self-loop columns in the input change nothing (graphgps/utils.py:12-66)."""
+    from graphgps_amd.layer.san_layers import complement_edge_index
+    gen = torch.Generator().manual_seed(0)
+    sizes = [5, 1, 7, 3]
+    ptr = [0]
+    for n in sizes:
+        ptr.append(ptr[-1] + n)
+    batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
+    cols = []
+    for g, n in enumerate(sizes):
+        if n > 1:
+            ei = torch.randint(0, n, (2, 2 * n), generator=gen) + ptr[g]
+            cols.append(torch.cat([ei, ei[:, :2]], dim=1))
+    ei = torch.cat(cols, dim=1)
+    got = {(int(a), int(b)) for a, b in complement_edge_index(ei, batch).t()}
+    edges = {(int(a), int(b)) for a, b in ei.t()}
+    want = {(i, j) for g in range(len(sizes)) for i in range(ptr[g], ptr[g + 1]) for j in range(ptr[g], ptr[g + 1])
+            if i != j and (i, j) not in edges}
+    assert got == want
