@@ -38,7 +38,7 @@ set_cfg(cfg)
 # the reference's files register their GraphGym wrappers under the same names as this package's
 for _k in ("gatedgcnconv", "gineconv"):
     graphgps_amd.graphgym.register.layer_dict.pop(_k, None)
-for _k in ("GraphormerBias", "SignNet"):
+for _k in ("GraphormerBias", "SignNet", "LapPE"):
     graphgps_amd.graphgym.register.node_encoder_dict.pop(_k, None)
 from graphgps.layer.gps_layer import GPSLayer as RefGPSLayer  # noqa: E402
 from torch_geometric.data import Batch as StubBatch  # noqa: E402
@@ -302,9 +302,48 @@ def run_san(seed=41):
     return out
 
 
+def run_lappe(seed=51):
+    """The reference's LapPENodeEncoder (laplace_pos_encoder.py), DeepSet and Transformer models, training mode
+    (the random sign flip draws ``torch.rand(k)`` right after ``torch.manual_seed(seed + 1)``), NaN-padded
+    frequencies, BatchNorm on the raw PE, a post-MLP."""
+    from graphgps.encoder.laplace_pos_encoder import LapPENodeEncoder as RefLapPE
+    out = {}
+    for model, layers, post, norm in (("DeepSet", 3, 2, "BatchNorm"), ("DeepSet", 1, 0, "none"),
+                                      ("Transformer", 2, 1, "none")):
+        torch.manual_seed(seed)
+        cfg.share.dim_in = 6
+        pe = cfg.posenc_LapPE
+        pe.model, pe.dim_pe, pe.layers, pe.post_layers, pe.n_heads = model, 8, layers, post, 2
+        pe.raw_norm_type, pe.pass_as_var = norm, False
+        pe.eigen.max_freqs = 5
+        enc = RefLapPE(24)
+        enc.train()
+        gen = torch.Generator().manual_seed(seed)
+        N, k = 40, 5
+        x = torch.randn(N, 6, generator=gen)
+        vecs = torch.randn(N, k, generator=gen)
+        vals = torch.randn(N, k, 1, generator=gen)
+        vecs[:6, 3:] = float("nan")
+        vals[:6, 3:] = float("nan")
+        w = torch.randn(N, 24, generator=gen)
+        sd = {kk: v.clone() for kk, v in enc.state_dict().items()}
+        b = StubBatch(x=x.clone(), EigVals=vals.clone(), EigVecs=vecs.clone())
+        torch.manual_seed(seed + 1)
+        o = enc(b)
+        (o.x * w).sum().backward()
+        out[f"{model}-{layers}-{post}-{norm}"] = dict(
+            model=model, layers=layers, post=post, norm=norm, state_dict=sd, x=x, EigVals=vals, EigVecs=vecs,
+            w=w, seed=seed + 1, out_x=o.x.detach().clone(),
+            grads={kk: p.grad.clone() for kk, p in enc.named_parameters() if p.grad is not None})
+    return out
+
+
 def main():
     outdir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(outdir, exist_ok=True)
+    fix = run_lappe()
+    torch.save(fix, os.path.join(outdir, "lappe_encoder.pt"))
+    print("lappe_encoder:", {k: tuple(v["out_x"].shape) for k, v in fix.items()})
     fix = run_san()
     torch.save(fix, os.path.join(outdir, "san_layers.pt"))
     print("san_layers:", {k: tuple(v["out_x"].shape) for k, v in fix.items()})

@@ -233,3 +233,40 @@ def test_reference_configs_construct():
                   if not (k.endswith("-inference.yaml") and "'none' encoder" in v)}
     assert not unexpected, unexpected
     assert len(failed) == 2, sorted(failed)
+
+
+def test_heads_row_selection_and_link_metrics():
+    """GraphGym node head returns the rows of the current split's mask; graph_token pooling picks each graph's
+    first row; the inductive edge head's eval statistics (Hits@k / MRR per graph, positives ranked against every
+    other target of the same source) on a hand-checkable case."""
+    import graphgps_amd as g
+    from graphgps_amd.graphgym import register
+    from graphgps_amd.graphgym.config import cfg, set_cfg
+    from graphgps_amd.head.edge_head import GNNInductiveEdgeHead
+    from graphgps_amd.head.heads import GNNNodeHead, graph_token_pooling
+    set_cfg(cfg)
+    cfg.gnn.layers_post_mp = 1
+    torch.manual_seed(0)
+    head = GNNNodeHead(4, 3)
+    b = g.Batch(x=torch.randn(6, 4), y=torch.arange(6), val_mask=torch.tensor([0, 1, 0, 0, 1, 1]).bool())
+    b.split = 'val'
+    pred, true = head(b)
+    assert pred.shape == (3, 3) and true.tolist() == [1, 4, 5]
+    assert register.head_dict['node'] is GNNNodeHead or register.head_dict['node'].__name__ == 'GNNNodeHead'
+
+    x = torch.arange(12.0).view(6, 2)
+    bvec = torch.tensor([0, 0, 0, 1, 1, 1])
+    assert torch.equal(graph_token_pooling(x, bvec), x[[0, 3]])
+
+    cfg.model.edge_decoding = 'dot'
+    eh = GNNInductiveEdgeHead(2, 1).eval()
+    with torch.no_grad():                                  # identity post-MP: scores are plain dot products
+        eh.layer_post_mp.model[0].model.weight.copy_(torch.eye(2))
+        eh.layer_post_mp.model[0].model.bias.zero_()
+    # one graph, 3 nodes on a line: x0.x1 = 2, x0.x2 = 3, x0.x0 = 1 -> positive (0 -> 1) ranks 2nd of {1, 2, 0}
+    eb = g.Batch(x=torch.tensor([[1.0, 0.0], [2.0, 0.0], [3.0, 0.0]]), batch=torch.zeros(3, dtype=torch.long),
+                 ptr=torch.tensor([0, 3]), edge_index_labeled=torch.tensor([[0, 1], [1, 2]]),
+                 edge_label=torch.tensor([1, 0]))
+    pred, label, stats = eh(eb)
+    assert pred.tolist() == [2.0, 6.0] and label.tolist() == [1, 0]
+    assert stats == {'hits@1': 0.0, 'hits@3': 1.0, 'hits@10': 1.0, 'mrr': 0.5}

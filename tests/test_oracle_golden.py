@@ -219,3 +219,34 @@ def test_complement_edge_index_is_the_adjacency_complement():
     want = {(i, j) for g in range(len(sizes)) for i in range(ptr[g], ptr[g + 1]) for j in range(ptr[g], ptr[g + 1])
             if i != j and (i, j) not in edges}
     assert got == want
+
+
+@pytest.mark.parametrize("case", ["DeepSet-3-2-BatchNorm", "DeepSet-1-0-none", "Transformer-2-1-none"])
+def test_lappe_encoder_matches_reference_fixture(case):
+    """This package's LapPE encoder against the reference's laplace_pos_encoder.py (training mode, the random
+    sign flip reproduced by seeding right before the call; NaN-padded frequencies; DeepSet / Transformer; raw
+    BatchNorm; post-MLP): strict state_dict load, encoded x, every parameter gradient."""
+    from conftest import LAPPE_GOLDEN
+    from graphgps_amd.encoder.extra_encoders import LapPENodeEncoder
+    from graphgps_amd.graphgym.config import cfg, set_cfg
+    fix = load_golden(LAPPE_GOLDEN)[case]
+    set_cfg(cfg)
+    cfg.share.dim_in = 6
+    pe = cfg.posenc_LapPE
+    pe.model, pe.dim_pe, pe.layers, pe.post_layers, pe.n_heads = fix["model"], 8, fix["layers"], fix["post"], 2
+    pe.raw_norm_type, pe.pass_as_var = fix["norm"], False
+    pe.eigen.max_freqs = 5
+    enc = LapPENodeEncoder(24)
+    enc.load_state_dict(fix["state_dict"], strict=True)
+    enc.train()
+    b = Batch(x=fix["x"].clone(), EigVals=fix["EigVals"].clone(), EigVecs=fix["EigVecs"].clone())
+    torch.manual_seed(fix["seed"])
+    out = enc(b)
+    (out.x * fix["w"]).sum().backward()
+    assert_close(out.x, fix["out_x"], Tol.ACT, "encoded x")
+    got = dict(enc.named_parameters())
+    gs = max(float(v.abs().max()) for v in fix["grads"].values())
+    for k, g in fix["grads"].items():
+        a_, b_ = got[k].grad.detach().double(), g.double()
+        assert (a_ - b_).abs().max().item() <= Tol.GRAD_REL * max(float(b_.abs().max()), 0.01 * gs, 1.0), \
+            f"grad {k}: {(a_ - b_).abs().max().item():.3e}"
