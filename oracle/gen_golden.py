@@ -338,9 +338,43 @@ def run_lappe(seed=51):
     return out
 
 
+def run_custom_gnn_layers(seed=61):
+    """The layer classes custom_gnn stacks (network/custom_gnn.py:44-50), from the reference's own files:
+    ``GatedGCNLayer.forward(batch)`` (gatedgcn_layer.py:45-88) and ``GINEConvLayer`` (gine_conv_layer.py:90-116),
+    with and without the residual."""
+    from graphgps.layer.gatedgcn_layer import GatedGCNLayer as RefGated
+    from graphgps.layer.gine_conv_layer import GINEConvLayer as RefGINE
+    out = {}
+    for kind, cls in (("gatedgcn", RefGated), ("gine", RefGINE)):
+        for residual in (True, False):
+            torch.manual_seed(seed)
+            d = 24
+            layer = cls(d, d, dropout=0.0, residual=residual)
+            layer.train()
+            sd = {k: v.clone() for k, v in layer.state_dict().items()}
+            sizes, edge_index, bvec, ptr, gen, _ = make_structure("ZINC", 4, seed)
+            N, E = int(ptr[-1]), edge_index.shape[1]
+            x = torch.randn(N, d, generator=gen, requires_grad=True)
+            e = torch.randn(E, d, generator=gen, requires_grad=True)
+            wx, we = torch.randn(N, d, generator=gen), torch.randn(E, d, generator=gen)
+            b = StubBatch(x=x, edge_index=edge_index, edge_attr=e, batch=bvec)
+            o = layer(b)
+            ((o.x * wx).sum() + (o.edge_attr * we).sum()).backward()
+            out[f"{kind}-{'res' if residual else 'nores'}"] = dict(
+                kind=kind, residual=residual, d=d, state_dict=sd, x=x.detach().clone(),
+                edge_attr=e.detach().clone(), edge_index=edge_index, batch=bvec, ptr=ptr, wx=wx, we=we,
+                out_x=o.x.detach().clone(), out_edge_attr=o.edge_attr.detach().clone(), grad_x=x.grad.clone(),
+                grad_edge_attr=e.grad.clone(),
+                grads={k: p.grad.clone() for k, p in layer.named_parameters() if p.grad is not None})
+    return out
+
+
 def main():
     outdir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(outdir, exist_ok=True)
+    fix = run_custom_gnn_layers()
+    torch.save(fix, os.path.join(outdir, "custom_gnn_layers.pt"))
+    print("custom_gnn_layers:", sorted(fix))
     fix = run_lappe()
     torch.save(fix, os.path.join(outdir, "lappe_encoder.pt"))
     print("lappe_encoder:", {k: tuple(v["out_x"].shape) for k, v in fix.items()})

@@ -28,12 +28,13 @@ GRAPHORMER_GOLDEN = "graphormer_encoder_layer"      # encoder + GraphormerLayer 
 SIGNNET_GOLDEN = "signnet_encoder"                   # SignNet encoder fixture (own structure)
 SAN_GOLDEN = "san_layers"                            # SANLayer / SAN2Layer fixture (own structure)
 LAPPE_GOLDEN = "lappe_encoder"                       # LapPE encoder fixture (own structure)
+CUSTOM_GNN_GOLDEN = "custom_gnn_layers"              # GatedGCNLayer(batch) / GINEConvLayer fixtures
 
 
 def golden_names():
     """The GPSLayer fixtures (one layer, one batch each)."""
     return sorted(f[:-3] for f in os.listdir(GOLDEN_DIR)
-                  if f.endswith(".pt") and f[:-3] not in (GRAPHORMER_GOLDEN, SIGNNET_GOLDEN, SAN_GOLDEN, LAPPE_GOLDEN))
+                  if f.endswith(".pt") and f[:-3] not in (GRAPHORMER_GOLDEN, SIGNNET_GOLDEN, SAN_GOLDEN, LAPPE_GOLDEN, CUSTOM_GNN_GOLDEN))
 
 
 def load_golden(name):

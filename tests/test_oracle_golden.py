@@ -250,3 +250,32 @@ def test_lappe_encoder_matches_reference_fixture(case):
         a_, b_ = got[k].grad.detach().double(), g.double()
         assert (a_ - b_).abs().max().item() <= Tol.GRAD_REL * max(float(b_.abs().max()), 0.01 * gs, 1.0), \
             f"grad {k}: {(a_ - b_).abs().max().item():.3e}"
+
+
+@pytest.mark.parametrize("case", ["gatedgcn-res", "gatedgcn-nores", "gine-res", "gine-nores"])
+def test_custom_gnn_layer_oracles_match_reference_fixture(case):
+    """The oracle twins that ``to_oracle_model`` puts into a ``custom_gnn`` stack -- ``GatedGCNLayer.forward(batch)``
+    and ``GINEConvLayer`` -- against the reference's own classes (gatedgcn_layer.py:45-88,
+    gine_conv_layer.py:90-116), with and without the residual.  The HIP layers are checked against these oracles
+    on the GPU (tests/test_hip_layer.py::test_custom_gnn_vs_oracle)."""
+    from conftest import CUSTOM_GNN_GOLDEN
+    from oracle.gps_oracle import _OracleGatedGCNBatchLayer, _OracleGINEConvLayer
+    fix = load_golden(CUSTOM_GNN_GOLDEN)[case]
+    d = fix["d"]
+    if fix["kind"] == "gatedgcn":
+        layer = _OracleGatedGCNBatchLayer(d, d, 0.0, fix["residual"])
+    else:
+        layer = _OracleGINEConvLayer(d, d, 0.0, fix["residual"])
+    layer.load_state_dict(fix["state_dict"], strict=True)
+    layer.train()
+    x = fix["x"].clone().requires_grad_(True)
+    e = fix["edge_attr"].clone().requires_grad_(True)
+    out = layer(Batch(x=x, edge_index=fix["edge_index"], edge_attr=e, batch=fix["batch"], ptr=fix["ptr"]))
+    ((out.x * fix["wx"]).sum() + (out.edge_attr * fix["we"]).sum()).backward()
+    assert_close(out.x, fix["out_x"], Tol.ACT, "out.x")
+    assert_close(out.edge_attr, fix["out_edge_attr"], Tol.ACT, "out.edge_attr")
+    assert_close(x.grad, fix["grad_x"], Tol.GRAD_REL, "grad x", rel_to_max=True)
+    assert_close(e.grad, fix["grad_edge_attr"], Tol.GRAD_REL, "grad edge_attr", rel_to_max=True)
+    got = dict(layer.named_parameters())
+    for k, g in fix["grads"].items():
+        assert_close(got[k].grad, g, Tol.GRAD_REL, f"grad {k}", rel_to_max=True)
