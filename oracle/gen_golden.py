@@ -369,6 +369,91 @@ def run_custom_gnn_layers(seed=61):
     return out
 
 
+def run_aux_modules(seed=71):
+    """Encoders and heads either side of the layers, from the reference's own files, forward only (they are
+    plain torch on both sides; the point is the parameter names -- strict state_dict load -- and the arithmetic):
+    TypeDictNode/Edge, ASTNode/ASTEdge, RWSE (linear and 3-layer MLP, BatchNorm on the raw statistics),
+    EquivStableLapPE, heads san_graph / ogb_code_graph / graphormer_graph (+ graph_token pooling) /
+    inductive_node."""
+    import importlib
+    reg = graphgps_amd.graphgym.register
+    for d_, keys in ((reg.node_encoder_dict, ("TypeDictNode", "ASTNode", "RWSE", "HKdiagSE", "ElstaticSE",
+                                              "EquivStableLapPE")),
+                     (reg.edge_encoder_dict, ("TypeDictEdge", "ASTEdge")),
+                     (reg.head_dict, ("san_graph", "ogb_code_graph", "graphormer_graph", "inductive_node")),
+                     (reg.pooling_dict, ("graph_token",))):
+        for k in keys:
+            d_.pop(k, None)
+    enc = {m: importlib.import_module(f"graphgps.encoder.{m}") for m in
+           ("type_dict_encoder", "ast_encoder", "kernel_pos_encoder", "equivstable_laplace_pos_encoder")}
+    head = {m: importlib.import_module(f"graphgps.head.{m}") for m in
+            ("san_graph", "ogb_code_graph", "graphormer_graph", "inductive_node")}
+    importlib.import_module("graphgps.pooling.graph_token")
+    gen = torch.Generator().manual_seed(seed)
+    sizes, edge_index, bvec, ptr, _, _ = make_structure("ZINC", 4, seed)
+    N, E = int(ptr[-1]), edge_index.shape[1]
+    out = {}
+
+    def record(name, module, inputs, outputs):
+        module.eval()
+        b = StubBatch(**{k: (v.clone() if torch.is_tensor(v) else v) for k, v in inputs.items()})
+        res = module(b)
+        vals = outputs(b, res)
+        out[name] = dict(state_dict={k: v.clone() for k, v in module.state_dict().items()}, inputs=inputs,
+                         outputs=[v.detach().clone() for v in vals])
+
+    cfg.dataset.node_encoder_num_types, cfg.dataset.edge_encoder_num_types = 28, 4
+    torch.manual_seed(seed)
+    record("TypeDictNode", enc["type_dict_encoder"].TypeDictNodeEncoder(12),
+           dict(x=torch.randint(0, 28, (N, 1), generator=gen)), lambda b, r: [b.x])
+    record("TypeDictEdge", enc["type_dict_encoder"].TypeDictEdgeEncoder(12),
+           dict(edge_attr=torch.randint(0, 4, (E,), generator=gen)), lambda b, r: [b.edge_attr])
+    record("ASTNode", enc["ast_encoder"].ASTNodeEncoder(12),
+           dict(x=torch.stack([torch.randint(0, 98, (N,), generator=gen),
+                               torch.randint(0, 10030, (N,), generator=gen)], 1),
+                node_depth=torch.randint(0, 30, (N, 1), generator=gen)), lambda b, r: [b.x])
+    record("ASTEdge", enc["ast_encoder"].ASTEdgeEncoder(12),
+           dict(edge_attr=torch.randint(0, 2, (E, 2), generator=gen)), lambda b, r: [b.edge_attr])
+    cfg.share.dim_in = 5
+    for model, layers in (("Linear", 1), ("mlp", 3)):
+        pe = cfg.posenc_RWSE
+        pe.model, pe.layers, pe.dim_pe, pe.raw_norm_type, pe.pass_as_var = model, layers, 8, "BatchNorm", True
+        pe.kernel.times = list(range(1, 13))
+        torch.manual_seed(seed)
+        record(f"RWSE-{model}", enc["kernel_pos_encoder"].RWSENodeEncoder(20),
+               dict(x=torch.randn(N, 5, generator=gen), pestat_RWSE=torch.rand(N, 12, generator=gen)),
+               lambda b, r: [b.x, b.pe_RWSE])
+    pe = cfg.posenc_EquivStableLapPE
+    pe.eigen.max_freqs, pe.raw_norm_type = 6, "BatchNorm"
+    vecs = torch.randn(N, 6, generator=gen)
+    vecs[:3, 4:] = float("nan")
+    torch.manual_seed(seed)
+    record("EquivStableLapPE", enc["equivstable_laplace_pos_encoder"].EquivStableLapPENodeEncoder(16),
+           dict(x=torch.randn(N, 16, generator=gen), EigVals=torch.zeros(N, 6, 1), EigVecs=vecs),
+           lambda b, r: [b.pe_EquivStableLapPE])
+    hx = torch.randn(N, 16, generator=gen)
+    cfg.gnn.act = "relu"
+    for pool in ("add", "mean"):
+        cfg.model.graph_pooling = pool
+        torch.manual_seed(seed)
+        record(f"san_graph-{pool}", head["san_graph"].SANGraphHead(16, 3),
+               dict(x=hx, batch=bvec, y=torch.zeros(4)), lambda b, r: [r[0]])
+    cfg.model.graph_pooling = "mean"
+    torch.manual_seed(seed)
+    record("ogb_code_graph", head["ogb_code_graph"].OGBCodeGraphHead(16, 5002),
+           dict(x=hx, batch=bvec, y=torch.zeros(4), y_arr=torch.zeros(4, 5)), lambda b, r: list(r[0]))
+    cfg.model.graph_pooling = "graph_token"
+    torch.manual_seed(seed)
+    record("graphormer_graph", head["graphormer_graph"].GraphormerHead(16, 2),
+           dict(x=hx, batch=bvec, y=torch.zeros(4)), lambda b, r: [r[0]])
+    cfg.gnn.layers_post_mp = 2
+    torch.manual_seed(seed)
+    record("inductive_node", head["inductive_node"].GNNInductiveNodeHead(16, 3),
+           dict(x=hx, batch=bvec, y=torch.zeros(N)), lambda b, r: [r[0]])
+    out["_meta"] = dict(N=N, E=E, num_graphs=4, ptr=ptr)
+    return out
+
+
 def main():
     outdir = os.path.join(ROOT, "tests", "golden")
     os.makedirs(outdir, exist_ok=True)
@@ -393,6 +478,9 @@ def main():
         torch.save(fix, path)
         print(f"{name}: N={fix['x'].shape[0]} E={fix['edge_index'].shape[1]} "
               f"|out_x|max={fix['out_x'].abs().max():.4f} -> {os.path.getsize(path)/1024:.0f} KiB")
+    fix = run_aux_modules()
+    torch.save(fix, os.path.join(outdir, "aux_modules.pt"))
+    print("aux_modules:", sorted(k for k in fix if not k.startswith("_")))
 
 
 if __name__ == "__main__":

@@ -21,3 +21,12 @@ class LayerConfig:
     final_act: bool = True
     act: str = "relu"
     keep_edge: float = 0.5
+
+
+def __getattr__(name):
+    # GraphGym's own ``MLP`` / ``new_layer_config`` (third-party to the reference): the in-repo restatement,
+    # resolved lazily so that importing this stub does not pull the package in before the registry is set up
+    if name in ("MLP", "new_layer_config"):
+        import graphgps_amd.graphgym.layers as _l
+        return getattr(_l, name)
+    raise AttributeError(name)

@@ -29,12 +29,13 @@ SIGNNET_GOLDEN = "signnet_encoder"                   # SignNet encoder fixture (
 SAN_GOLDEN = "san_layers"                            # SANLayer / SAN2Layer fixture (own structure)
 LAPPE_GOLDEN = "lappe_encoder"                       # LapPE encoder fixture (own structure)
 CUSTOM_GNN_GOLDEN = "custom_gnn_layers"              # GatedGCNLayer(batch) / GINEConvLayer fixtures
+AUX_GOLDEN = "aux_modules"                           # encoders / heads either side of the layers
 
 
 def golden_names():
     """The GPSLayer fixtures (one layer, one batch each)."""
     return sorted(f[:-3] for f in os.listdir(GOLDEN_DIR)
-                  if f.endswith(".pt") and f[:-3] not in (GRAPHORMER_GOLDEN, SIGNNET_GOLDEN, SAN_GOLDEN, LAPPE_GOLDEN, CUSTOM_GNN_GOLDEN))
+                  if f.endswith(".pt") and f[:-3] not in (GRAPHORMER_GOLDEN, SIGNNET_GOLDEN, SAN_GOLDEN, LAPPE_GOLDEN, CUSTOM_GNN_GOLDEN, AUX_GOLDEN))
 
 
 def load_golden(name):
