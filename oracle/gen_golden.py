@@ -450,6 +450,29 @@ def run_aux_modules(seed=71):
     torch.manual_seed(seed)
     record("inductive_node", head["inductive_node"].GNNInductiveNodeHead(16, 3),
            dict(x=hx, batch=bvec, y=torch.zeros(N)), lambda b, r: [r[0]])
+    # registered losses (graphgps/loss/*.py), forward values on fixed logits / targets
+    for k in ("l1_losses", "subtoken_cross_entropy", "weighted_cross_entropy", "multilabel_cross_entropy"):
+        reg.loss_dict.pop(k, None)
+    losses = {m: importlib.import_module(f"graphgps.loss.{m}") for m in
+              ("l1", "subtoken_prediction_loss", "weighted_cross_entropy", "multilabel_classification_loss")}
+    logits = torch.randn(50, 6, generator=gen)
+    target = torch.randint(0, 5, (50,), generator=gen)            # class 5 never occurs
+    blogits, btarget = torch.randn(50, generator=gen), torch.randint(0, 2, (50,), generator=gen)
+    mlogits = torch.randn(20, 7, generator=gen)
+    mtarget = torch.randint(0, 2, (20, 7), generator=gen).float()
+    mtarget[torch.rand(20, 7, generator=gen) < 0.2] = float("nan")
+    cfg.model.loss_fun = "weighted_cross_entropy"
+    wl, wp = losses["weighted_cross_entropy"].weighted_cross_entropy(logits, target)
+    bl, bp = losses["weighted_cross_entropy"].weighted_cross_entropy(blogits, btarget)
+    cfg.model.loss_fun, cfg.dataset.task_type = "cross_entropy", "classification_multilabel"
+    ml, mp = losses["multilabel_classification_loss"].multilabel_cross_entropy(mlogits, mtarget)
+    cfg.dataset.task_type = "regression"
+    cfg.model.loss_fun = "smoothl1"
+    sl, _ = losses["l1"].l1_losses(blogits, btarget.float())
+    out["_losses"] = dict(logits=logits, target=target, blogits=blogits, btarget=btarget, mlogits=mlogits,
+                          mtarget=mtarget, weighted_multiclass=(wl.clone(), wp.clone()),
+                          weighted_binary=(bl.clone(), bp.clone()), multilabel=(ml.clone(), mp.clone()),
+                          smoothl1=sl.clone())
     out["_meta"] = dict(N=N, E=E, num_graphs=4, ptr=ptr)
     return out
 

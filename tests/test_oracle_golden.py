@@ -345,3 +345,36 @@ def test_encoders_and_heads_match_reference_fixture(case):
     assert len(got) == len(fix["outputs"])
     for i, (a_, w_) in enumerate(zip(got, fix["outputs"])):
         assert_close(a_, w_, Tol.ACT, f"{case} output {i}")
+
+
+def test_losses_match_reference_fixture():
+    """graphgps_amd/loss/losses.py against the reference's registered losses (graphgps/loss/*.py) on fixed
+    logits: class-frequency weighted CE (multiclass with an absent class, binary), multilabel BCE with NaN
+    targets, smooth-L1; plus GraphGym's built-in multiclass / binary cross-entropy through compute_loss."""
+    from conftest import AUX_GOLDEN
+    from graphgps_amd.graphgym.config import cfg, set_cfg
+    from graphgps_amd.loss import losses as L
+    f = load_golden(AUX_GOLDEN)["_losses"]
+    set_cfg(cfg)
+    cfg.model.loss_fun = "weighted_cross_entropy"
+    for (logits, target, key) in ((f["logits"], f["target"], "weighted_multiclass"),
+                                  (f["blogits"], f["btarget"], "weighted_binary")):
+        loss, pred = L.compute_loss(logits, target)
+        assert_close(loss, f[key][0], 1e-6, key)
+        assert_close(pred, f[key][1], 1e-6, key + " pred")
+    cfg.model.loss_fun, cfg.dataset.task_type = "cross_entropy", "classification_multilabel"
+    loss, pred = L.compute_loss(f["mlogits"], f["mtarget"])
+    assert_close(loss, f["multilabel"][0], 1e-6, "multilabel")
+    assert torch.equal(pred, f["multilabel"][1])
+    cfg.dataset.task_type = "regression"
+    cfg.model.loss_fun = "smoothl1"
+    assert_close(L.compute_loss(f["blogits"], f["btarget"].float())[0], f["smoothl1"], 1e-6, "smoothl1")
+    # GraphGym built-ins (published behaviour): multiclass = mean NLL of log-softmax; binary = BCE with logits
+    cfg.model.loss_fun, cfg.dataset.task_type = "cross_entropy", "classification"
+    loss, pred = L.compute_loss(f["logits"], f["target"])
+    assert_close(loss, torch.nn.functional.cross_entropy(f["logits"], f["target"]), 1e-6, "multiclass CE")
+    assert_close(pred, torch.log_softmax(f["logits"], -1), 1e-6, "log-softmax")
+    loss, pred = L.compute_loss(f["blogits"].unsqueeze(-1), f["btarget"].unsqueeze(-1))
+    assert_close(loss, torch.nn.functional.binary_cross_entropy_with_logits(f["blogits"], f["btarget"].float()),
+                 1e-6, "binary CE")
+    assert_close(pred, torch.sigmoid(f["blogits"]), 1e-6, "sigmoid")
