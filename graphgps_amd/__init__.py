@@ -23,6 +23,7 @@ from .network.graphormer import GraphormerModel  # noqa: F401
 from .network.san_transformer import SANTransformer  # noqa: F401
 from .loss import losses as _losses  # noqa: F401
 from .optim import FlatAdamW, ParamArena  # noqa: F401
+from . import schedulers as _schedulers  # noqa: F401
 
 import os as _os
 

@@ -473,6 +473,33 @@ def run_aux_modules(seed=71):
                           mtarget=mtarget, weighted_multiclass=(wl.clone(), wp.clone()),
                           weighted_binary=(bl.clone(), bp.clone()), multilabel=(ml.clone(), mp.clone()),
                           smoothl1=sl.clone())
+    # LR schedules (graphgps/optimizer/extra_optimizers.py:92-225): the learning rate after each of 40 epochs
+    for k in ("adagrad", "adamW"):
+        reg.optimizer_dict.pop(k, None)
+    for k in ("plateau", "reduce_on_plateau", "linear_with_warmup", "cosine_with_warmup", "polynomial_with_warmup"):
+        reg.scheduler_dict.pop(k, None)
+    _gg = types.ModuleType("torch_geometric.graphgym.optim")
+
+    class SchedulerConfig:            # the dataclass base the reference extends (fields unused here)
+        pass
+    _gg.SchedulerConfig = SchedulerConfig
+    sys.modules["torch_geometric.graphgym.optim"] = _gg
+    xo = importlib.import_module("graphgps.optimizer.extra_optimizers")
+    sched = {}
+    for name, fn in (("linear_with_warmup", xo.linear_with_warmup_scheduler),
+                     ("cosine_with_warmup", xo.cosine_with_warmup_scheduler),
+                     ("polynomial_with_warmup", xo.polynomial_with_warmup_scheduler)):
+        for warm, total in ((5, 30), (0, 12)):
+            p0 = torch.nn.Parameter(torch.zeros(1))
+            opt = torch.optim.SGD([p0], lr=0.01)
+            sc = fn(opt, warm, total)
+            lrs = [sc.get_last_lr()[0]]
+            for _ in range(40):
+                opt.step()
+                sc.step()
+                lrs.append(sc.get_last_lr()[0])
+            sched[f"{name}-{warm}-{total}"] = lrs
+    out["_schedules"] = sched
     out["_meta"] = dict(N=N, E=E, num_graphs=4, ptr=ptr)
     return out
 

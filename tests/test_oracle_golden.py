@@ -378,3 +378,27 @@ def test_losses_match_reference_fixture():
     assert_close(loss, torch.nn.functional.binary_cross_entropy_with_logits(f["blogits"], f["btarget"].float()),
                  1e-6, "binary CE")
     assert_close(pred, torch.sigmoid(f["blogits"]), 1e-6, "sigmoid")
+
+
+def test_lr_schedulers_match_reference_fixture():
+    """graphgps_amd/schedulers.py against the reference's warm-up schedules (extra_optimizers.py:92-225): the
+    learning rate after each of 40 epochs, with and without warm-up, past the end of the schedule."""
+    from conftest import AUX_GOLDEN
+    import graphgps_amd  # noqa: F401
+    from graphgps_amd.graphgym import register
+    want = load_golden(AUX_GOLDEN)["_schedules"]
+    assert len(want) == 6
+    for key, lrs in want.items():
+        name, warm, total = key.rsplit("-", 2)
+        p0 = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.SGD([p0], lr=0.01)
+        sc = register.scheduler_dict[name](opt, int(warm), int(total))
+        got = [sc.get_last_lr()[0]]
+        for _ in range(40):
+            opt.step()
+            sc.step()
+            got.append(sc.get_last_lr()[0])
+        assert len(got) == len(lrs)
+        assert max(abs(a - b) for a, b in zip(got, lrs)) <= 1e-12, key
+    assert {'adagrad', 'adamW'} <= set(register.optimizer_dict)
+    assert {'plateau', 'reduce_on_plateau'} <= set(register.scheduler_dict)
