@@ -270,3 +270,45 @@ def test_heads_row_selection_and_link_metrics():
     pred, label, stats = eh(eb)
     assert pred.tolist() == [2.0, 6.0] and label.tolist() == [1, 0]
     assert stats == {'hits@1': 0.0, 'hits@3': 1.0, 'hits@10': 1.0, 'mrr': 0.5}
+
+
+@pytest.mark.skipif(not os.path.isdir("/root/reference/graphgps/config"), reason="needs the reference tree")
+def test_config_defaults_equal_the_reference_register_config_functions():
+    """Every key the reference's ``@register_config`` functions define (graphgps/config/*.py: gt, posenc_*,
+    graphormer, optim extensions, dataset / split / wandb / pretrained extensions and the defaults they
+    overwrite) has the same default in graphgym/config.py.  The reference's functions are executed unmodified
+    on an empty node, hosted on the yacs / GraphGym stand-ins of oracle/ref_stubs."""
+    import subprocess
+    import sys
+    code = r'''
+import sys, os, types, importlib
+ROOT, REF = sys.argv[1], "/root/reference"
+sys.path.insert(0, ROOT)
+import graphgps_amd.graphgym.register as reg
+from graphgps_amd.graphgym.config import CfgNode, cfg, set_cfg
+sys.path.insert(0, os.path.join(ROOT, "oracle", "ref_stubs"))
+pkg = types.ModuleType("graphgps"); pkg.__path__ = [os.path.join(REF, "graphgps")]; sys.modules["graphgps"] = pkg
+reg.config_dict.clear()
+for f in sorted(os.listdir(os.path.join(REF, "graphgps", "config"))):
+    if f.endswith(".py") and f != "__init__.py":
+        importlib.import_module("graphgps.config." + f[:-3])
+set_cfg(cfg)
+ref = CfgNode()
+for g in ("dataset", "train", "model", "gnn", "optim", "bn", "mem", "share", "wandb"):
+    ref[g] = CfgNode()
+for fn in reg.config_dict.values():
+    fn(ref)
+def flat(n, prefix=""):
+    out = {}
+    for k, v in n.items():
+        out.update(flat(v, prefix + k + ".") if isinstance(v, dict) else {prefix + k: v})
+    return out
+fr, fm = flat(ref), flat(cfg)
+diff = [(k, fr[k], fm.get(k, "<missing>")) for k in sorted(fr) if fm.get(k, "<missing>") != fr[k]]
+print(len(fr), len(diff), diff[:5])
+'''
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code, root], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    n_keys, n_diff = (int(t) for t in out.stdout.split()[:2])
+    assert n_keys >= 120 and n_diff == 0, out.stdout
