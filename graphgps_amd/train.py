@@ -156,3 +156,32 @@ def train_epoch(logger, loader, model, optimizer, scheduler, batch_accumulation,
             _pred = pred_score.detach().to('cpu')
         logger.update_stats(true=_true, pred=_pred, loss=loss.cpu().item(), lr=lr, time_used=dt,
                             params=cfg.params, dataset_name=cfg.dataset.name)
+
+
+@torch.no_grad()
+def eval_epoch(logger, loader, model, split='val'):
+    """Drop-in for ``custom_train.eval_epoch`` (custom_train.py:48-77), same arguments: eval-mode forward + loss
+    for every batch of ``loader``, the logger fed once per batch.  As in ``train_epoch`` the next batch's H2D
+    copies and graph index run on a copy stream behind the current forward, and the device->host reads the
+    logger needs happen after the loop (one sync per epoch instead of one per batch)."""
+    model.eval()
+    device = torch.device(cfg.accelerator)
+    pending = []
+    time_start = time.time()
+    for batch in DeviceLoader(loader, device):
+        batch.split = split
+        if cfg.gnn.head == 'inductive_edge':
+            pred, true, extra_stats = model(batch)
+        else:
+            pred, true = model(batch)
+            extra_stats = {}
+        loss, pred_score = train_loss(pred, true)
+        pending.append((true, pred_score, loss.detach(), time.time() - time_start, extra_stats))
+        time_start = time.time()
+    for true, pred_score, loss, dt, extra_stats in pending:
+        if cfg.dataset.name == 'ogbg-code2':
+            _true, _pred = true, pred_score
+        else:
+            _true, _pred = true.detach().to('cpu'), pred_score.detach().to('cpu')
+        logger.update_stats(true=_true, pred=_pred, loss=loss.cpu().item(), lr=0, time_used=dt,
+                            params=cfg.params, dataset_name=cfg.dataset.name, **extra_stats)

@@ -312,3 +312,39 @@ print(len(fr), len(diff), diff[:5])
     assert out.returncode == 0, out.stderr[-2000:]
     n_keys, n_diff = (int(t) for t in out.stdout.split()[:2])
     assert n_keys >= 120 and n_diff == 0, out.stdout
+
+
+def test_eval_epoch_mirrors_reference_loop_on_cpu():
+    """graphgps_amd.train.eval_epoch (custom_train.py:48-77) with a plain torch model on the CPU (the loop is
+    host code; DeviceLoader is a pass-through there): eval mode, no gradients, one logger row per batch with the
+    split set on the batch, lr = 0, float loss, CPU predictions."""
+    import graphgps_amd as g
+    from graphgps_amd.graphgym.config import cfg, set_cfg
+    from graphgps_amd.train import eval_epoch
+    set_cfg(cfg)
+    cfg.accelerator, cfg.model.loss_fun, cfg.params = "cpu", "l1", 0
+
+    class Model(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.lin = torch.nn.Linear(3, 1)
+            self.seen = []
+
+        def forward(self, batch):
+            assert not self.training and not torch.is_grad_enabled()
+            self.seen.append(batch.split)
+            return self.lin(batch.x), batch.y
+
+    class Logger:
+        rows = []
+
+        def update_stats(self, **kw):
+            self.rows.append(kw)
+
+    loader = [g.Batch(x=torch.randn(5, 3), y=torch.randn(5, 1)) for _ in range(3)]
+    model, log = Model(), Logger()
+    eval_epoch(log, loader, model, split='test')
+    assert model.seen == ['test'] * 3 and len(log.rows) == 3
+    for r in log.rows:
+        assert r["lr"] == 0 and isinstance(r["loss"], float) and r["pred"].device.type == "cpu"
+        assert r["pred"].shape == (5,) and r["true"].shape == (5, 1) or r["true"].shape == (5,)
