@@ -278,7 +278,11 @@ def main():
 
     tunable = None
     if not args.no_gemm_tuning:                # rocBLAS/hipBLASLt solution selection per GEMM shape,
-        tunable = g.enable_gemm_tuning()       # timed at first use during the untimed warm-up
+        try:                                   # timed at first use during the untimed warm-up
+            tunable = g.enable_gemm_tuning()
+        except Exception as exc:               # an optimisation, never a requirement
+            log(f"TunableOp unavailable ({type(exc).__name__}: {exc}); library default heuristics")
+            tunable = None
     torch.manual_seed(0)                       # identical initial weights on every rank
     WORKLOADS = {   # yaml, dim_in, dim_out, default graphs/GPU (the config's train.batch_size), label
         "pcqm4m": ("pcqm4m_gpsmedium_rwse.yaml", 9, 1, 256,
@@ -405,7 +409,10 @@ def main():
             torch.cuda.synchronize()
             log("first step done")
     if tunable is not None:
-        tunable.tuning_enable(False)           # frozen: nothing is tuned inside the timed region
+        try:
+            tunable.tuning_enable(False)       # frozen: nothing is tuned inside the timed region
+        except Exception as exc:
+            log(f"could not freeze TunableOp ({type(exc).__name__}: {exc})")
     barrier()
     log("warm-up done")
     t0 = time.perf_counter()
