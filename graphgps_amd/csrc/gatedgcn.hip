@@ -1,224 +1,339 @@
-// GatedGCN sparse core: gather -> gate -> segment-reduce -> node update, in one pass.
+// GatedGCN sparse core: gather -> gate -> segment-reduce -> node update, one launch forward, one launch backward.
 //
 // Reference semantics: graphgps/layer/gatedgcn_layer.py:67-70 (propagate), :90-107 (message),
 // :109-126 (aggregate), :128-136 (update).  Index convention (PyG flow source_to_target):
 // j = edge_index[0] (source), i = edge_index[1] (target); sums are keyed by the TARGET.
 //
-// Mapping to the machine (HBM-bound, no MFMA): lane = VEC consecutive channels of one node, a
-// node row of d floats is d/VEC consecutive lanes, so every access (node rows Ax/Bx/Dx/Ex, the
-// gathered source rows, the Ce/e_hat edge rows) is a whole-row coalesced burst.  The reduction
-// over a node's incoming edges runs sequentially inside the lane over the CSR segment: no
-// cross-lane traffic, no atomics, and the summation order (ascending original edge id) is the
-// order of the reference's CPU scatter_add -> results are reproducible run to run.
+// Mapping to the machine (HBM-bound, no MFMA):
+//   * lane = VEC consecutive channels of one node; a node row of d floats is d/VEC consecutive lanes, so every
+//     access (node rows Ax/Bx/Dx/Ex, gathered source rows, Ce / e_hat edge rows) is a whole-row coalesced burst;
+//   * a workgroup (768 threads) owns a CONTIGUOUS block of `nb` nodes and walks it `npi` = 768/(d/VEC) rows at a
+//     time.  The CSR (and, backward, CSC) slices of that block -- contiguous index ranges -- are staged once in
+//     LDS with coalesced loads, so the per-edge neighbour ids / edge ids never cost a dependent global round trip;
+//   * blockIdx -> node-block map is XCD-aware: the dispatcher deals workgroup b to XCD b % 8, so logical block
+//     (b % 8) * (grid / 8) + b / 8 gives every XCD one contiguous eighth of the node range.  Neighbours of a
+//     molecule / AST node are a few rows away, i.e. in the SAME XCD's 4 MiB L2: the per-edge re-gathers of
+//     Ex_j / Bx_j (round 1: 1.3x the algorithmic read bytes, each XCD fetching its own copy) become L2 hits;
+//   * the reduction over a node's incoming edges runs inside the lane over its CSR segment, two edges in flight:
+//     no cross-lane traffic, no atomics, summation in ascending original edge id = the order of the reference's
+//     CPU scatter_add -> bitwise reproducible.
 //
-// Algorithmic HBM bytes (fp32, per layer):  fwd 8*E*d + 20*N*d (+8*N*d saved
-// aggr/den in training), bwd 12*E*d + 28*N*d; index traffic 4(N+1)+8E per pass.
+// Backward = ONE launch, two phases around a workgroup barrier:
+//   A (target-keyed): num_i recomputed from the saved e_hat (nothing but `den` is saved by the forward),
+//     a_i = g_x_i / D_i, b_i = -a_i num_i / D_i, delta_ij = g_e_ij + (a_i Bx_j + b_i) sig(1-sig) -> g_Ce (edge
+//     order), g_Dx_i = sum_j delta_ij;
+//   B (source-keyed): g_Ex_j = sum_{j->i} delta_ij, g_Bx_j = sum_{j->i} sig_ij a_i.  For an edge whose target lies
+//     in this workgroup's node block (~85-90 % at molecule / AST locality) delta is re-read from the g_Ce row this
+//     workgroup wrote a moment ago (same CU, L2-resident); for the others it is recomputed from its inputs
+//     (aggr_i = x_tilde_i - Ax_i), so no workgroup ever waits for another.  e_hat / g_e / g_Ce therefore cross the
+//     HBM interface once each: 12*E*d + 28*N*d bytes, the algorithmic figure.
+//
+// Algorithmic HBM bytes (fp32, per layer):  fwd 8*E*d + 20*N*d (+4*N*d for the saved `den` when
+// training), bwd 12*E*d + 28*N*d; index traffic 4(N+1)+8E per CSR/CSC slice.
 #include "gps_common.hpp"
 #include "vec.hpp"
 
 namespace {
 
+constexpr int GG_T = 768;        // threads per workgroup (12 wavefronts; 2 workgroups per CU)
+constexpr int GG_MAXNB = 512;    // node rows per workgroup, upper bound (LDS rowptr slice)
+constexpr int GG_MAXE = 1536;    // staged CSR / CSC entries per workgroup; larger slices read the index from global
+
+struct NodeBlock {
+  int64_t n0, n1;
+  __device__ bool valid() const { return n0 < n1; }
+};
+
+// XCD-aware logical block (grid is a multiple of 8).
+__device__ __forceinline__ NodeBlock node_block(int64_t N, int nb) {
+  const int per = gridDim.x >> 3;
+  const int64_t L = (int64_t)(blockIdx.x & 7) * per + (blockIdx.x >> 3);
+  NodeBlock r;
+  r.n0 = L * nb;
+  r.n1 = r.n0 + nb < N ? r.n0 + nb : N;
+  return r;
+}
+
+// Stage rowptr[n0..n1] and, if it fits, idx_a/idx_b[e0..e1) into LDS.  Returns whether the index slice was staged.
+__device__ __forceinline__ bool stage_slice(const int32_t* __restrict__ rowptr, const int32_t* __restrict__ ia,
+                                            const int32_t* __restrict__ ib, const NodeBlock& nbk, int* s_rp,
+                                            int* s_a, int* s_b) {
+  const int cnt = (int)(nbk.n1 - nbk.n0);
+  for (int t = threadIdx.x; t <= cnt; t += GG_T) s_rp[t] = rowptr[nbk.n0 + t];
+  const int e0 = rowptr[nbk.n0], e1 = rowptr[nbk.n1];
+  const bool staged = (e1 - e0) <= GG_MAXE;
+  if (staged)
+    for (int t = threadIdx.x; t < e1 - e0; t += GG_T) {
+      s_a[t] = ia[e0 + t];
+      s_b[t] = ib[e0 + t];
+    }
+  return staged;
+}
+
 // GATE: the EquivStableLapPE variant (gatedgcn_layer.py:101-104): sigma_ij is multiplied by a per-edge
 // scalar r_ij in (0,1) (r_edge[edge id]) before it gates and normalises.
 template <int VEC, bool SAVE, bool GATE>
-__global__ __launch_bounds__(256) void k_gatedgcn_fwd(
+__global__ __launch_bounds__(GG_T) void k_gatedgcn_fwd(
     const float* __restrict__ Ax, const float* __restrict__ Bx, const float* __restrict__ Dx,
     const float* __restrict__ Ex, int64_t ld, const float* __restrict__ Ce,
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src,
     const int32_t* __restrict__ eid, int64_t N, int d, float* __restrict__ x_tilde,
-    float* __restrict__ e_hat, float* __restrict__ aggr_out, float* __restrict__ den_out,
-    const float* __restrict__ r_edge) {
-  const int lanes_per_row = d / VEC;
-  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  const int64_t node = t / lanes_per_row;
-  if (node >= N) return;
-  const int c = (int)(t - node * lanes_per_row) * VEC;
-  const int beg = rowptr[node], end = rowptr[node + 1];
-  const Vec<VEC> dx = Vec<VEC>::load(Dx + node * ld + c);
-  Vec<VEC> num = Vec<VEC>::zero(), den = Vec<VEC>::zero();
-  for (int k = beg; k < end; ++k) {
-    const int64_t j = src[k];
-    const int64_t id = eid[k];
-    const Vec<VEC> ex = Vec<VEC>::load(Ex + j * ld + c);
-    const Vec<VEC> bx = Vec<VEC>::load(Bx + j * ld + c);
-    const Vec<VEC> ce = Vec<VEC>::load(Ce + id * d + c);
-    Vec<VEC> eh;
-    const float rr = GATE ? r_edge[id] : 1.0f;
+    float* __restrict__ e_hat, float* __restrict__ den_out, const float* __restrict__ r_edge, int nb, int npi) {
+  __shared__ int s_rp[GG_MAXNB + 1];
+  __shared__ int s_src[GG_MAXE], s_eid[GG_MAXE];
+  const NodeBlock blk = node_block(N, nb);
+  if (!blk.valid()) return;
+  const bool staged = stage_slice(rowptr, src, eid, blk, s_rp, s_src, s_eid);
+  __syncthreads();
+  const int lpr = d / VEC;
+  const int row = threadIdx.x / lpr;
+  if (row >= npi) return;
+  const int c = (threadIdx.x - row * lpr) * VEC;
+  const int e0 = s_rp[0];
+  for (int64_t node = blk.n0 + row; node < blk.n1; node += npi) {
+    const int beg = s_rp[node - blk.n0], end = s_rp[node - blk.n0 + 1];
+    const Vec<VEC> dx = Vec<VEC>::load(Dx + node * ld + c);
+    const Vec<VEC> ax = Vec<VEC>::load(Ax + node * ld + c);
+    Vec<VEC> num = Vec<VEC>::zero(), den = Vec<VEC>::zero();
+    auto edge = [&](const Vec<VEC>& ex, const Vec<VEC>& bx, const Vec<VEC>& ce, float rr, int64_t id) {
+      Vec<VEC> eh;
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      eh[v] = (dx[v] + ex[v]) + ce[v];  // e_ij = Dx_i + Ex_j + Ce            (:96)
-      float s = sigmoidf_fast(eh[v]);  //                                     (:97)
-      if (GATE) s = s * rr;             // sigma_ij * r_ij                     (:101-104)
-      num[v] += s * bx[v];                    // scatter(sigma*Bx_j)           (:117-119)
-      den[v] += s;                            // scatter(sigma)                (:121-123)
+      for (int v = 0; v < VEC; ++v) {
+        eh[v] = (dx[v] + ex[v]) + ce[v];  // e_ij = Dx_i + Ex_j + Ce            (:96)
+        float s = sigmoidf_fast(eh[v]);  //                                     (:97)
+        if (GATE) s = s * rr;             // sigma_ij * r_ij                     (:101-104)
+        num[v] += s * bx[v];              // scatter(sigma*Bx_j)                 (:117-119)
+        den[v] += s;                      // scatter(sigma)                      (:121-123)
+      }
+      eh.store(e_hat + id * d + c);       // self.e = e_ij, returned in edge order (:106,134)
+    };
+    int k = beg;
+    for (; k + 1 < end; k += 2) {         // two edges in flight (loads of both issued before the first use)
+      const int64_t j0 = staged ? s_src[k - e0] : src[k], j1 = staged ? s_src[k + 1 - e0] : src[k + 1];
+      const int64_t i0 = staged ? s_eid[k - e0] : eid[k], i1 = staged ? s_eid[k + 1 - e0] : eid[k + 1];
+      const Vec<VEC> ex0 = Vec<VEC>::load(Ex + j0 * ld + c), ex1 = Vec<VEC>::load(Ex + j1 * ld + c);
+      const Vec<VEC> bx0 = Vec<VEC>::load(Bx + j0 * ld + c), bx1 = Vec<VEC>::load(Bx + j1 * ld + c);
+      const Vec<VEC> ce0 = Vec<VEC>::load(Ce + i0 * d + c), ce1 = Vec<VEC>::load(Ce + i1 * d + c);
+      const float r0 = GATE ? r_edge[i0] : 1.0f, r1 = GATE ? r_edge[i1] : 1.0f;
+      edge(ex0, bx0, ce0, r0, i0);
+      edge(ex1, bx1, ce1, r1, i1);
     }
-    eh.store(e_hat + id * d + c);  // self.e = e_ij, returned in edge order    (:106,134)
-  }
-  const Vec<VEC> ax = Vec<VEC>::load(Ax + node * ld + c);
-  Vec<VEC> xt, ag;
+    if (k < end) {
+      const int64_t j0 = staged ? s_src[k - e0] : src[k];
+      const int64_t i0 = staged ? s_eid[k - e0] : eid[k];
+      edge(Vec<VEC>::load(Ex + j0 * ld + c), Vec<VEC>::load(Bx + j0 * ld + c), Vec<VEC>::load(Ce + i0 * d + c),
+           GATE ? r_edge[i0] : 1.0f, i0);
+    }
+    Vec<VEC> xt;
 #pragma unroll
-  for (int v = 0; v < VEC; ++v) {
-    ag[v] = num[v] / (den[v] + 1e-6f);  //                                    (:125)
-    xt[v] = ax[v] + ag[v];              //                                    (:133)
-  }
-  xt.store(x_tilde + node * (int64_t)d + c);
-  if (SAVE) {
-    ag.store(aggr_out + node * (int64_t)d + c);
-    den.store(den_out + node * (int64_t)d + c);
+    for (int v = 0; v < VEC; ++v) xt[v] = ax[v] + num[v] / (den[v] + 1e-6f);  //          (:125,133)
+    xt.store(x_tilde + node * (int64_t)d + c);
+    if (SAVE) den.store(den_out + node * (int64_t)d + c);
   }
 }
 
-// Backward pass 1, keyed by TARGET i:
-//   a_i = g_x_i / D_i,  b_i = -g_x_i * aggr_i / D_i           (D_i = den_i + 1e-6)
+// Backward, one launch (see the header comment):
+//   a_i = g_x_i / D_i,  b_i = -a_i * num_i / D_i                 (D_i = den_i + 1e-6, num_i recomputed)
 //   delta_ij = g_e_ij + (a_i * Bx_j + b_i) * sig_ij * (1 - sig_ij)
 //   g_Ce[eid] = delta_ij ;  g_Dx_i = sum_j delta_ij ;  g_Ax_i = g_x_i
-template <int VEC, bool GATE>
-__global__ __launch_bounds__(256) void k_gatedgcn_bwd_dst(
-    const float* __restrict__ g_x, const float* __restrict__ g_e, const float* __restrict__ e_hat,
-    const float* __restrict__ Bx, int64_t ld, const float* __restrict__ aggr,
-    const float* __restrict__ den, const int32_t* __restrict__ rowptr,
-    const int32_t* __restrict__ src, const int32_t* __restrict__ eid, int64_t N, int d,
-    float* __restrict__ g_Ce, float* __restrict__ g_Ax, float* __restrict__ g_Dx, int64_t ldg,
-    const float* __restrict__ r_edge) {
-  const int lanes_per_row = d / VEC;
-  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  const int64_t node = t / lanes_per_row;
-  if (node >= N) return;
-  const int c = (int)(t - node * lanes_per_row) * VEC;
-  const int beg = rowptr[node], end = rowptr[node + 1];
-  const Vec<VEC> gx = Vec<VEC>::load(g_x + node * (int64_t)d + c);
-  const Vec<VEC> ag = Vec<VEC>::load(aggr + node * (int64_t)d + c);
-  const Vec<VEC> dn = Vec<VEC>::load(den + node * (int64_t)d + c);
-  Vec<VEC> a, b, gdx = Vec<VEC>::zero();
-#pragma unroll
-  for (int v = 0; v < VEC; ++v) {
-    const float inv = 1.0f / (dn[v] + 1e-6f);
-    a[v] = gx[v] * inv;
-    b[v] = -a[v] * ag[v];
-  }
-  for (int k = beg; k < end; ++k) {
-    const int64_t j = src[k];
-    const int64_t id = eid[k];
-    const Vec<VEC> eh = Vec<VEC>::load(e_hat + id * d + c);
-    const Vec<VEC> ge = Vec<VEC>::load(g_e + id * d + c);
-    const Vec<VEC> bx = Vec<VEC>::load(Bx + j * ld + c);
-    Vec<VEC> dl;
-    const float rr = GATE ? r_edge[id] : 1.0f;
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      const float s = sigmoidf_fast(eh[v]);
-      float gs = a[v] * bx[v] + b[v];          // gradient wrt the (gated) sigma
-      if (GATE) gs = gs * rr;
-      dl[v] = ge[v] + gs * (s * (1.0f - s));
-      gdx[v] += dl[v];
-    }
-    dl.store(g_Ce + id * d + c);
-  }
-  gx.store(g_Ax + node * ldg + c);
-  gdx.store(g_Dx + node * ldg + c);
-}
-
-// Backward pass 2, keyed by SOURCE j (reads the delta written by pass 1):
 //   g_Ex_j = sum_{j->i} delta_ij ;   g_Bx_j = sum_{j->i} sig_ij * a_i
 template <int VEC, bool GATE>
-__global__ __launch_bounds__(256) void k_gatedgcn_bwd_src(
-    const float* __restrict__ g_x, const float* __restrict__ e_hat, const float* __restrict__ den,
-    const float* __restrict__ delta, const int32_t* __restrict__ rowptr,
-    const int32_t* __restrict__ dst, const int32_t* __restrict__ eid, int64_t N, int d,
-    float* __restrict__ g_Bx, float* __restrict__ g_Ex, int64_t ldg, const float* __restrict__ r_edge) {
-  const int lanes_per_row = d / VEC;
-  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
-  const int64_t node = t / lanes_per_row;
-  if (node >= N) return;
-  const int c = (int)(t - node * lanes_per_row) * VEC;
-  const int beg = rowptr[node], end = rowptr[node + 1];
-  Vec<VEC> gbx = Vec<VEC>::zero(), gex = Vec<VEC>::zero();
-  for (int k = beg; k < end; ++k) {
-    const int64_t i = dst[k];
-    const int64_t id = eid[k];
-    const Vec<VEC> dl = Vec<VEC>::load(delta + id * d + c);
-    const Vec<VEC> eh = Vec<VEC>::load(e_hat + id * d + c);
-    const Vec<VEC> gx = Vec<VEC>::load(g_x + i * d + c);
-    const Vec<VEC> dn = Vec<VEC>::load(den + i * d + c);
-    const float rr = GATE ? r_edge[id] : 1.0f;
+__global__ __launch_bounds__(GG_T) void k_gatedgcn_bwd(
+    const float* __restrict__ g_x, int64_t ldgx, const float* __restrict__ g_e, const float* __restrict__ e_hat,
+    const float* __restrict__ Ax, const float* __restrict__ Bx, int64_t ld, const float* __restrict__ x_tilde,
+    const float* __restrict__ den, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src,
+    const int32_t* __restrict__ eid, const int32_t* __restrict__ rowptr_s, const int32_t* __restrict__ dst,
+    const int32_t* __restrict__ eid_s, int64_t N, int d, float* g_Ce, float* __restrict__ g_Ax,
+    float* __restrict__ g_Bx, float* __restrict__ g_Dx, float* __restrict__ g_Ex, int64_t ldg,
+    const float* __restrict__ r_edge, int nb, int npi) {
+  __shared__ int s_rp[GG_MAXNB + 1], s_rq[GG_MAXNB + 1];
+  __shared__ int s_src[GG_MAXE], s_eid[GG_MAXE], s_dst[GG_MAXE], s_eid2[GG_MAXE];
+  const NodeBlock blk = node_block(N, nb);
+  if (!blk.valid()) return;                 // whole workgroup leaves together
+  const bool st_d = stage_slice(rowptr, src, eid, blk, s_rp, s_src, s_eid);
+  const bool st_s = stage_slice(rowptr_s, dst, eid_s, blk, s_rq, s_dst, s_eid2);
+  __syncthreads();
+  const int lpr = d / VEC;
+  const int row = threadIdx.x / lpr;
+  const bool active = row < npi;
+  const int c = (threadIdx.x - row * lpr) * VEC;
+  // ---- phase A: keyed by target ------------------------------------------------------------------
+  if (active) {
+    const int e0 = s_rp[0];
+    for (int64_t node = blk.n0 + row; node < blk.n1; node += npi) {
+      const int beg = s_rp[node - blk.n0], end = s_rp[node - blk.n0 + 1];
+      const Vec<VEC> gx = Vec<VEC>::load(g_x + node * ldgx + c);
+      const Vec<VEC> dn = Vec<VEC>::load(den + node * (int64_t)d + c);
+      Vec<VEC> num = Vec<VEC>::zero();
+      for (int k = beg; k < end; ++k) {       // recompute num_i = sum_j sig_ij Bx_j (fwd order)
+        const int64_t j = st_d ? s_src[k - e0] : src[k];
+        const int64_t id = st_d ? s_eid[k - e0] : eid[k];
+        const Vec<VEC> eh = Vec<VEC>::load(e_hat + id * d + c);
+        const Vec<VEC> bx = Vec<VEC>::load(Bx + j * ld + c);
+        const float rr = GATE ? r_edge[id] : 1.0f;
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      float s = sigmoidf_fast(eh[v]);
-      if (GATE) s = s * rr;
-      gex[v] += dl[v];
-      gbx[v] += s * (gx[v] / (dn[v] + 1e-6f));
+        for (int v = 0; v < VEC; ++v) {
+          float s = sigmoidf_fast(eh[v]);
+          if (GATE) s = s * rr;
+          num[v] += s * bx[v];
+        }
+      }
+      Vec<VEC> a, b, gdx = Vec<VEC>::zero();
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const float inv = 1.0f / (dn[v] + 1e-6f);
+        a[v] = gx[v] * inv;
+        b[v] = -a[v] * (num[v] * inv);
+      }
+      for (int k = beg; k < end; ++k) {       // the rows below were just touched: L1 / L2 hits
+        const int64_t j = st_d ? s_src[k - e0] : src[k];
+        const int64_t id = st_d ? s_eid[k - e0] : eid[k];
+        const Vec<VEC> eh = Vec<VEC>::load(e_hat + id * d + c);
+        const Vec<VEC> ge = Vec<VEC>::load(g_e + id * d + c);
+        const Vec<VEC> bx = Vec<VEC>::load(Bx + j * ld + c);
+        const float rr = GATE ? r_edge[id] : 1.0f;
+        Vec<VEC> dl;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          const float s = sigmoidf_fast(eh[v]);
+          float gs = a[v] * bx[v] + b[v];        // gradient wrt the (gated) sigma
+          if (GATE) gs = gs * rr;
+          dl[v] = ge[v] + gs * (s * (1.0f - s));
+          gdx[v] += dl[v];
+        }
+        dl.store(g_Ce + id * d + c);
+      }
+      if (g_Ax) gx.store(g_Ax + node * ldg + c);
+      gdx.store(g_Dx + node * ldg + c);
     }
   }
-  gbx.store(g_Bx + node * ldg + c);
-  gex.store(g_Ex + node * ldg + c);
+  __threadfence_block();
+  __syncthreads();            // this workgroup's g_Ce rows are visible to all of its lanes (same CU)
+  // ---- phase B: keyed by source ------------------------------------------------------------------
+  if (!active) return;
+  const int q0 = s_rq[0];
+  for (int64_t node = blk.n0 + row; node < blk.n1; node += npi) {
+    const int beg = s_rq[node - blk.n0], end = s_rq[node - blk.n0 + 1];
+    const Vec<VEC> bxj = Vec<VEC>::load(Bx + node * ld + c);
+    Vec<VEC> gbx = Vec<VEC>::zero(), gex = Vec<VEC>::zero();
+    for (int k = beg; k < end; ++k) {
+      const int64_t i = st_s ? s_dst[k - q0] : dst[k];
+      const int64_t id = st_s ? s_eid2[k - q0] : eid_s[k];
+      const Vec<VEC> eh = Vec<VEC>::load(e_hat + id * d + c);
+      const Vec<VEC> gx = Vec<VEC>::load(g_x + i * ldgx + c);
+      const Vec<VEC> dn = Vec<VEC>::load(den + i * d + c);
+      const float rr = GATE ? r_edge[id] : 1.0f;
+      Vec<VEC> dl;
+      const bool internal = i >= blk.n0 && i < blk.n1;
+      if (internal) {
+        dl = Vec<VEC>::load(g_Ce + id * d + c);
+      } else {
+        const Vec<VEC> ge = Vec<VEC>::load(g_e + id * d + c);
+        const Vec<VEC> xt = Vec<VEC>::load(x_tilde + i * d + c);
+        const Vec<VEC> axi = Vec<VEC>::load(Ax + i * ld + c);
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          const float ai = gx[v] / (dn[v] + 1e-6f);
+          const float s = sigmoidf_fast(eh[v]);
+          float gs = ai * bxj[v] - ai * (xt[v] - axi[v]);   // a_i Bx_j + b_i,  b_i = -a_i aggr_i
+          if (GATE) gs = gs * rr;
+          dl[v] = ge[v] + gs * (s * (1.0f - s));
+        }
+      }
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        float s = sigmoidf_fast(eh[v]);
+        if (GATE) s = s * rr;
+        gex[v] += dl[v];
+        gbx[v] += s * (gx[v] / (dn[v] + 1e-6f));
+      }
+    }
+    gbx.store(g_Bx + node * ldg + c);
+    gex.store(g_Ex + node * ldg + c);
+  }
 }
 
 inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
+// Node rows per workgroup: aim at ~2 workgroups per CU (512 in flight = one full wave of the chip), never fewer
+// rows than one pass of the workgroup, never more than the LDS rowptr slice holds.
+struct Plan { int npi, nb; unsigned grid; };
+inline Plan plan_for(int64_t N, int lanes_per_row) {
+  Plan p;
+  p.npi = GG_T / lanes_per_row;
+  int64_t nb = (N + 511) / 512;
+  nb = ((nb + p.npi - 1) / p.npi) * p.npi;
+  const int cap = (GG_MAXNB / p.npi) * p.npi;
+  if (nb > cap) nb = cap;
+  if (nb < p.npi) nb = p.npi;
+  p.nb = (int)nb;
+  const int64_t blocks = (N + nb - 1) / nb;
+  p.grid = (unsigned)(((blocks + 7) / 8) * 8);
+  return p;
+}
+
 }  // namespace
 
-#define GPS_GG_FWD(SAVE, GATE)                                                                      \
-  k_gatedgcn_fwd<VEC, SAVE, GATE><<<gps::grid_for(work, 256), 256, 0, s>>>(                         \
-      Ax, Bx, Dx, Ex, ld_node, Ce, rowptr_dst, src_by_dst, eid_by_dst, N, d, x_tilde, e_hat, aggr, den, r_edge)
-#define GPS_GG_BWD(GATE)                                                                           \
-  do {                                                                                             \
-    k_gatedgcn_bwd_dst<VEC, GATE><<<gps::grid_for(work, 256), 256, 0, s>>>(                        \
-        g_x, g_e, e_hat, Bx, ld_node, aggr, den, rowptr_dst, src_by_dst, eid_by_dst, N, d, g_Ce,   \
-        g_Ax, g_Dx, ld_gnode, r_edge);                                                             \
-    k_gatedgcn_bwd_src<VEC, GATE><<<gps::grid_for(work, 256), 256, 0, s>>>(                        \
-        g_x, e_hat, den, g_Ce, rowptr_src, dst_by_src, eid_by_src, N, d, g_Bx, g_Ex, ld_gnode, r_edge); \
-  } while (0)
+#define GPS_GG_FWD(SAVE, GATE)                                                                       \
+  k_gatedgcn_fwd<VEC, SAVE, GATE><<<pl.grid, GG_T, 0, s>>>(Ax, Bx, Dx, Ex, ld_node, Ce, rowptr_dst,  \
+      src_by_dst, eid_by_dst, N, d, x_tilde, e_hat, den, r_edge, pl.nb, pl.npi)
+#define GPS_GG_BWD(GATE)                                                                             \
+  k_gatedgcn_bwd<VEC, GATE><<<pl.grid, GG_T, 0, s>>>(g_x, ld_gx, g_e, e_hat, Ax, Bx, ld_node, x_tilde, \
+      den, rowptr_dst, src_by_dst, eid_by_dst, rowptr_src, dst_by_src, eid_by_src, N, d, g_Ce,        \
+      g_Ax == g_x ? nullptr : g_Ax, g_Bx, g_Dx, g_Ex, ld_gnode, r_edge, pl.nb, pl.npi)
 
 extern "C" {
 
 int gps_gatedgcn_fwd(const float* Ax, const float* Bx, const float* Dx, const float* Ex,
                      int64_t ld_node, const float* Ce, const int32_t* rowptr_dst,
                      const int32_t* src_by_dst, const int32_t* eid_by_dst, int64_t N, int64_t E,
-                     int d, float* x_tilde, float* e_hat, float* aggr, float* den,
+                     int d, float* x_tilde, float* e_hat, float* den,
                      const float* r_edge, gps_stream_t stream) {
   GPS_REQUIRE(N >= 0 && E >= 0 && d > 0 && ld_node >= d, "gps_gatedgcn_fwd: bad sizes N=%lld E=%lld d=%d ld=%lld",
               (long long)N, (long long)E, d, (long long)ld_node);
   if (N == 0) return GPS_OK;
   GPS_REQUIRE(Ax && Bx && Dx && Ex && rowptr_dst && x_tilde, "gps_gatedgcn_fwd: null node buffer");
   GPS_REQUIRE(E == 0 || (Ce && src_by_dst && eid_by_dst && e_hat), "gps_gatedgcn_fwd: null edge buffer");
-  GPS_REQUIRE((aggr == nullptr) == (den == nullptr), "gps_gatedgcn_fwd: aggr/den must both be set or both NULL");
-  const bool save = aggr != nullptr;
+  const bool save = den != nullptr;
   auto ok = [&](size_t a) {
     return aligned_to(Ax, a) && aligned_to(Bx, a) && aligned_to(Dx, a) && aligned_to(Ex, a) &&
-           aligned_to(Ce, a) && aligned_to(x_tilde, a) && aligned_to(e_hat, a) &&
-           aligned_to(aggr, a) && aligned_to(den, a);
+           aligned_to(Ce, a) && aligned_to(x_tilde, a) && aligned_to(e_hat, a) && aligned_to(den, a);
   };
   hipStream_t s = gps::as_stream(stream);
   GPS_DISPATCH_VEC(d, ld_node % 4 == 0 && ok(16), ld_node % 2 == 0 && ok(8), {
-    const int64_t work = N * (int64_t)(d / VEC);
+    GPS_REQUIRE(d / VEC <= GG_T, "gps_gatedgcn_fwd: d=%d too wide for one workgroup pass (%d lanes)", d, d / VEC);
+    const Plan pl = plan_for(N, d / VEC);
     if (save) { if (r_edge) GPS_GG_FWD(true, true); else GPS_GG_FWD(true, false); }
     else { if (r_edge) GPS_GG_FWD(false, true); else GPS_GG_FWD(false, false); }
   });
   return gps::launch_status("gps_gatedgcn_fwd");
 }
 
-int gps_gatedgcn_bwd(const float* g_x, const float* g_e, const float* e_hat, const float* Bx,
-                     int64_t ld_node, const float* aggr, const float* den,
+int gps_gatedgcn_bwd(const float* g_x, int64_t ld_gx, const float* g_e, const float* e_hat, const float* Ax,
+                     const float* Bx, int64_t ld_node, const float* x_tilde, const float* den,
                      const int32_t* rowptr_dst, const int32_t* src_by_dst,
                      const int32_t* eid_by_dst, const int32_t* rowptr_src,
                      const int32_t* dst_by_src, const int32_t* eid_by_src, int64_t N, int64_t E,
                      int d, float* g_Ce, float* g_Ax, float* g_Bx, float* g_Dx, float* g_Ex,
                      int64_t ld_gnode, const float* r_edge, gps_stream_t stream) {
-  GPS_REQUIRE(N >= 0 && E >= 0 && d > 0 && ld_node >= d && ld_gnode >= d, "gps_gatedgcn_bwd: bad sizes");
+  GPS_REQUIRE(N >= 0 && E >= 0 && d > 0 && ld_node >= d && ld_gnode >= d && ld_gx >= d,
+              "gps_gatedgcn_bwd: bad sizes");
   if (N == 0) return GPS_OK;
-  GPS_REQUIRE(g_x && Bx && aggr && den && rowptr_dst && rowptr_src && g_Ax && g_Bx && g_Dx && g_Ex,
+  GPS_REQUIRE(g_x && Ax && Bx && x_tilde && den && rowptr_dst && rowptr_src && g_Ax && g_Bx && g_Dx && g_Ex,
               "gps_gatedgcn_bwd: null node buffer");
   GPS_REQUIRE(E == 0 || (g_e && e_hat && src_by_dst && eid_by_dst && dst_by_src && eid_by_src && g_Ce),
               "gps_gatedgcn_bwd: null edge buffer");
+  GPS_REQUIRE(g_Ax != g_x || ld_gx == ld_gnode, "gps_gatedgcn_bwd: g_Ax aliases g_x with a different stride");
   auto ok = [&](size_t a) {
-    return aligned_to(g_x, a) && aligned_to(g_e, a) && aligned_to(e_hat, a) && aligned_to(Bx, a) &&
-           aligned_to(aggr, a) && aligned_to(den, a) && aligned_to(g_Ce, a) && aligned_to(g_Ax, a) &&
-           aligned_to(g_Bx, a) && aligned_to(g_Dx, a) && aligned_to(g_Ex, a);
+    return aligned_to(g_x, a) && aligned_to(g_e, a) && aligned_to(e_hat, a) && aligned_to(Ax, a) &&
+           aligned_to(Bx, a) && aligned_to(x_tilde, a) && aligned_to(den, a) && aligned_to(g_Ce, a) &&
+           aligned_to(g_Ax, a) && aligned_to(g_Bx, a) && aligned_to(g_Dx, a) && aligned_to(g_Ex, a);
   };
   hipStream_t s = gps::as_stream(stream);
-  GPS_DISPATCH_VEC(d, ld_node % 4 == 0 && ld_gnode % 4 == 0 && ok(16),
-                   ld_node % 2 == 0 && ld_gnode % 2 == 0 && ok(8), {
-    const int64_t work = N * (int64_t)(d / VEC);
+  GPS_DISPATCH_VEC(d, ld_node % 4 == 0 && ld_gnode % 4 == 0 && ld_gx % 4 == 0 && ok(16),
+                   ld_node % 2 == 0 && ld_gnode % 2 == 0 && ld_gx % 2 == 0 && ok(8), {
+    GPS_REQUIRE(d / VEC <= GG_T, "gps_gatedgcn_bwd: d=%d too wide for one workgroup pass (%d lanes)", d, d / VEC);
+    const Plan pl = plan_for(N, d / VEC);
     if (r_edge) GPS_GG_BWD(true); else GPS_GG_BWD(false);
   });
   return gps::launch_status("gps_gatedgcn_bwd");

@@ -119,7 +119,14 @@ class GeneralMultiLayer(nn.Module):
 
 
 class MLP(nn.Module):
-    """(num_layers - 1) hidden GeneralLayer('linear') + a final plain Linear with bias."""
+    """(num_layers - 1) hidden GeneralLayer('linear') + a final plain Linear with bias.
+
+    As published in PyG 2.2 (``graphgym/models/layer.py``, ``MLP.__init__``) the hidden stack's sub-config is
+    ``LayerConfig(num_layers=num_layers - 1, dim_in=dim_in, dim_out=dim_inner, dim_inner=dim_inner,
+    final_act=True)`` and NOTHING else: the hidden layers therefore run on LayerConfig's own defaults -- no
+    BatchNorm (so ``Layer_<i>.layer.model.bias`` exists), dropout 0, ReLU, ``has_l2norm=True`` -- whatever
+    ``cfg.gnn.batchnorm / dropout / act / l2norm`` say.  (Not pinnable here: PyG is absent; restated from the
+    published source)"""
 
     def __init__(self, layer_config: LayerConfig, **kwargs):
         super().__init__()
@@ -128,11 +135,7 @@ class MLP(nn.Module):
         layers = []
         if layer_config.num_layers > 1:
             sub = LayerConfig(num_layers=layer_config.num_layers - 1, dim_in=layer_config.dim_in,
-                              dim_out=dim_inner, dim_inner=dim_inner, final_act=True,
-                              has_batchnorm=layer_config.has_batchnorm, bn_eps=layer_config.bn_eps,
-                              bn_mom=layer_config.bn_mom, mem_inplace=layer_config.mem_inplace,
-                              has_l2norm=layer_config.has_l2norm, dropout=layer_config.dropout,
-                              act=layer_config.act)
+                              dim_out=dim_inner, dim_inner=dim_inner, final_act=True)
             layers.append(GeneralMultiLayer('linear', sub))
             layer_config = replace(layer_config, dim_in=dim_inner)
         layers.append(Linear(layer_config))

@@ -23,6 +23,14 @@ class GINEConv(nn.Module):
         self.initial_eps = eps
         self.register_buffer('eps', torch.Tensor([eps]))
 
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kwargs):
+        # ``eps`` is a (non-trained) buffer: a checkpoint may carry a value other than the constructor's.  The
+        # kernels take eps as a host scalar (no device sync per call), so mirror a loaded buffer into the float.
+        v = state_dict.get(prefix + 'eps')
+        if v is not None:
+            self.initial_eps = float(v.reshape(-1)[0])
+        super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
+
     def forward_tensors(self, x, edge_attr, gi):
         # eps is a constant buffer (never trained): read the Python float, no device sync
         return self.nn(gine_aggregate(x, edge_attr, gi, self.initial_eps))

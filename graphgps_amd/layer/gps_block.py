@@ -60,8 +60,9 @@ class _K:
         return out
 
     @staticmethod
-    def param_grads(L, g, x):
-        """(g^T x, colsum(g)) on the side stream (see fused.py)."""
+    def param_grads(L, g, x, params=()):
+        """(g^T x, colsum(g)) on the side stream (see fused.py); on the main stream when a target
+        parameter already holds a ``.grad`` (gradient accumulation, see ``_accumulating``)."""
         dev = g.device
 
         def compute():
@@ -74,7 +75,7 @@ class _K:
                               ptr(ws), current_stream(dev)), "gps_wgrad")
             return g_w, g_b
 
-        if not _SIDE_ENABLED:
+        if not _SIDE_ENABLED or _accumulating(params):
             return compute()
         cur, side = torch.cuda.current_stream(dev), _side_stream(dev)
         side.wait_stream(cur)
@@ -86,9 +87,22 @@ class _K:
         return out
 
 
-def _grouped_param_grads(L, pairs):
+def _accumulating(params) -> bool:
+    """True when autograd will ACCUMULATE into an existing ``.grad`` of one of ``params`` right after this
+    backward node returns (``train_epoch`` with ``optim.batch_accumulation`` > 1, custom_train.py:29-38: from the
+    second micro-batch on).  ``AccumulateGrad`` runs ``p.grad.add_(g)`` on the MAIN stream as soon as the node
+    returns, i.e. before the end-of-backward join with the side stream, so in that regime the weight gradients
+    have to be produced on the main stream (same rule as ``fused._param_grads``)."""
+    for p in params:
+        if p is not None and p.grad is not None:
+            return True
+    return False
+
+
+def _grouped_param_grads(L, pairs, params=()):
     """[(g, x), ...] -> [(g^T x, colsum(g)), ...]: all weight/bias gradients of the block in ONE
-    split-K MFMA launch + one reduce launch (csrc/wgrad.hip grouped form) on the side stream."""
+    split-K MFMA launch + one reduce launch (csrc/wgrad.hip grouped form) on the side stream
+    (main stream when ``params`` already hold gradients: see ``_accumulating``)."""
     dev = pairs[0][0].device
     n = len(pairs)
 
@@ -107,7 +121,7 @@ def _grouped_param_grads(L, pairs):
         check(L.gps_wgrad_grouped(n, probs, ptr(ws), current_stream(dev)), "gps_wgrad_grouped")
         return outs
 
-    if not _SIDE_ENABLED:
+    if not _SIDE_ENABLED or _accumulating(params):
         return compute()
     cur, side = torch.cuda.current_stream(dev), _side_stream(dev)
     side.wait_stream(cur)
@@ -217,10 +231,10 @@ class _GPSBlock(torch.autograd.Function):
         # -- local branch: C projection + GatedGCN core ----------------------------------------
         ce = torch.addmm(lm.C.bias, e, lm.C.weight.t())
         xt, eh = _E(N, d, **f32), _E(E, d, **f32)
-        aggr, den = _E(N, d, **f32), _E(N, d, **f32)
+        den = _E(N, d, **f32)
         check(L.gps_gatedgcn_fwd(P, P + fs, P + 2 * fs, P + 3 * fs, ldp, ptr(ce), ptr(gi.rowptr_dst),
                                  ptr(gi.src_by_dst), ptr(gi.eid_by_dst), N, E, d, ptr(xt), ptr(eh),
-                                 ptr(aggr), ptr(den), None, st), "gps_gatedgcn_fwd")
+                                 ptr(den), None, st), "gps_gatedgcn_fwd")
         fork.join(o, lse, ao)
 
         # -- the five BatchNorms, residuals and dropouts as task lists (csrc/block_norm.hip) -------
@@ -257,7 +271,7 @@ class _GPSBlock(torch.autograd.Function):
                              layer.norm1_attn.num_batches_tracked,
                              layer.norm2.num_batches_tracked], 1)
 
-        ctx.save_for_backward(x, e, pq, eh, aggr, den, xt, x1, o, lse, za, h, f1, t, z2, stats)
+        ctx.save_for_backward(x, e, pq, eh, den, xt, x1, o, lse, za, h, f1, t, z2, stats)
         ctx.layer, ctx.gi, ctx.seeds = layer, gi, s
         ctx.cfg = (p, p_l, p_f1, p_f2, p_at, H, dh, scale)
         return out, e1
@@ -265,7 +279,7 @@ class _GPSBlock(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_out, g_e1):
         L = _lib.load()
-        x, e, pq, eh, aggr, den, xt, x1, o, lse, za, h, f1, t, z2, stats = ctx.saved_tensors
+        x, e, pq, eh, den, xt, x1, o, lse, za, h, f1, t, z2, stats = ctx.saved_tensors
         layer, gi, s = ctx.layer, ctx.gi, ctx.seeds
         p, p_l, p_f1, p_f2, p_at, H, dh, scale = ctx.cfg
         lm, sa = layer.local_model, layer.self_attn
@@ -320,7 +334,7 @@ class _GPSBlock(torch.autograd.Function):
                                 ptr(eh), ptr(g_e1), ref(bne), E, s[1], ptr(g_eh), ptr(g_bew),
                                 ptr(g_beb), d, 1, p, ptr(ws), st), "gps_bn_bwd_pair")
         g_ce = _E(E, d, **f32)
-        check(L.gps_gatedgcn_bwd(ptr(g_xt), ptr(g_eh), ptr(eh), P + fs, ldp, ptr(aggr),
+        check(L.gps_gatedgcn_bwd(ptr(g_xt), d, ptr(g_eh), ptr(eh), P, P + fs, ldp, ptr(xt),
                                  ptr(den), ptr(gi.rowptr_dst), ptr(gi.src_by_dst), ptr(gi.eid_by_dst),
                                  ptr(gi.rowptr_src), ptr(gi.dst_by_src), ptr(gi.eid_by_src), N, E, d,
                                  ptr(g_ce), G, G + fs, G + 2 * fs, G + 3 * fs, ldp, None, st),
@@ -328,12 +342,13 @@ class _GPSBlock(torch.autograd.Function):
         fork.join()
         wcat, _ = layer._xgroup._stacked()
         pairs = [(g_pq, x), (g_ce, e), (g_ao, o), (g_f1, h), (g_f2, t)]
+        leaves = block_params(layer)
         if _GROUPED_WGRAD:
             ((g_wcat, g_bcat), (g_wc, g_bc), (g_wo, g_bo), (g_w1, g_b1), (g_w2, g_b2)) = \
-                _grouped_param_grads(L, pairs)
+                _grouped_param_grads(L, pairs, leaves)
         else:
             ((g_wcat, g_bcat), (g_wc, g_bc), (g_wo, g_bo), (g_w1, g_b1), (g_w2, g_b2)) = \
-                [_K.param_grads(L, g, a) for g, a in pairs]
+                [_K.param_grads(L, g, a, leaves) for g, a in pairs]
         g_x = g_xres.addmm_(g_pq, wcat)              # residuals of za and x1 + A..E + in-proj inputs
         g_e = torch.addmm(g_e1, g_ce, lm.C.weight)   # residual of e1 + C input
         g_wi, g_bi = g_wcat[4 * d:], g_bcat[4 * d:]
@@ -466,10 +481,11 @@ class _GPSBlockGINE(torch.autograd.Function):
                              float(lm.initial_eps), ptr(g_xg), ptr(g_e), None, st), "gps_gine_bwd")
         fork.join(g_qkv)
         pairs = [(g_qkv, x), (g_ao, o), (g_g2, g1r), (g_g1, agg), (g_f1, h), (g_f2, t)]
+        leaves = block_params_gine(layer)
         if _GROUPED_WGRAD:
-            grads = _grouped_param_grads(L, pairs)
+            grads = _grouped_param_grads(L, pairs, leaves)
         else:
-            grads = [_K.param_grads(L, g, a) for g, a in pairs]
+            grads = [_K.param_grads(L, g, a, leaves) for g, a in pairs]
         (g_wi, g_bi), (g_wo, g_bo), (g_wl2, g_bl2), (g_wl1, g_bl1), (g_w1, g_b1), (g_w2, g_b2) = grads
         g_x = g_xres.addmm_(g_qkv, sa.in_proj_weight)
         g_x.add_(g_xg)

@@ -37,37 +37,63 @@ class DeviceLoader:
         return len(self.loader)
 
     # -- one batch: pinned staging + async copies + index, all on the copy stream ----------------
+    @staticmethod
+    def _keys(batch):
+        """Attribute names of the batch's tensors.  A ``torch_geometric`` ``Batch`` / ``Data`` keeps them in
+        ``batch._store`` (NOT in ``__dict__``) and lists them through ``keys`` (a property in PyG 2.2, a method
+        from 2.4 on); ``graphgps_amd.data.Batch`` has the same ``keys()``.  Anything else: public ``__dict__``."""
+        ks = getattr(batch, "keys", None)
+        if callable(ks):
+            ks = ks()
+        if ks is None:
+            ks = [k for k in vars(batch) if not k.startswith("_")]
+        return list(ks)
+
+    @staticmethod
+    def _host_copy(batch):
+        """A shallow copy of the host batch (same tensors, new container): staging re-points attributes at device
+        tensors and the model re-assigns ``batch.x`` / ``batch.edge_attr`` (gps_layer.py:174,231), which must not
+        leak into a list-style loader that is iterated again next epoch."""
+        if hasattr(batch, "shallow_copy"):
+            return batch.shallow_copy()
+        import copy
+        return copy.copy(batch)             # PyG Data implements __copy__ as a per-store shallow copy
+
     def _stage(self, batch, copy_stream):
         dev = self.device
+        batch = self._host_copy(batch)
+        vars(batch).pop("_gps_index", None)
         with torch.cuda.stream(copy_stream):
-            for k, v in list(batch.__dict__.items()):
-                if k == "_gps_index":
-                    del batch.__dict__[k]
-                elif torch.is_tensor(v) and v.device != dev:
+            for k in self._keys(batch):
+                v = getattr(batch, k, None)
+                if torch.is_tensor(v) and v.device != dev:
                     if v.device.type == "cpu" and not v.is_pinned():
                         v = v.pin_memory()
-                    batch.__dict__[k] = v.to(dev, non_blocking=True)
+                    setattr(batch, k, v.to(dev, non_blocking=True))
             if self.build_index and hasattr(batch, "edge_index"):
                 graph_index_of(batch)
             ready = torch.cuda.Event()
             ready.record(copy_stream)
         return batch, ready
 
-    @staticmethod
-    def _hand_over(batch, stream) -> None:
+    @classmethod
+    def _hand_over(cls, batch, stream) -> None:
         """The tensors were allocated on the copy stream: tell the caching allocator the consumer's
         stream uses them, so their blocks are not recycled while the step still reads them."""
-        for k, v in batch.__dict__.items():
+        for k in cls._keys(batch):
+            v = getattr(batch, k, None)
             if torch.is_tensor(v) and v.is_cuda:
                 v.record_stream(stream)
-            elif k == "_gps_index":
-                for t in v.__dict__.values():
-                    if torch.is_tensor(t) and t.is_cuda:
-                        t.record_stream(stream)
+        gi = vars(batch).get("_gps_index")
+        if gi is not None:
+            for t in vars(gi).values():
+                if torch.is_tensor(t) and t.is_cuda:
+                    t.record_stream(stream)
 
     def __iter__(self) -> Iterator:
         if self.device.type != "cuda":
             for batch in self.loader:
+                batch = self._host_copy(batch)
                 yield batch.to(self.device) or batch
             return
         copy_stream = torch.cuda.Stream(device=self.device)

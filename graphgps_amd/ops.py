@@ -158,22 +158,22 @@ class _GatedGCNAggregate(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad)
         x_tilde = torch.empty(N, d, dtype=torch.float32, device=dev)
         e_hat = torch.empty(E, d, dtype=torch.float32, device=dev)
-        aggr = torch.empty(N, d, dtype=torch.float32, device=dev) if need_grad else None
+        # the only extra tensor the backward needs: den_i = sum_j sigma_ij (num is recomputed from e_hat)
         den = torch.empty(N, d, dtype=torch.float32, device=dev) if need_grad else None
         base, fs = proj.data_ptr(), d * 4  # fs = byte offset between the Ax|Bx|Dx|Ex column blocks
         check(L.gps_gatedgcn_fwd(base, base + fs, base + 2 * fs, base + 3 * fs, 4 * d, ptr(ce),
                                  ptr(gi.rowptr_dst), ptr(gi.src_by_dst), ptr(gi.eid_by_dst), N, E,
-                                 d, ptr(x_tilde), ptr(e_hat), ptr(aggr), ptr(den), ptr(r),
+                                 d, ptr(x_tilde), ptr(e_hat), ptr(den), ptr(r),
                                  current_stream(dev)), "gps_gatedgcn_fwd")
         if need_grad:
-            ctx.save_for_backward(proj, e_hat, aggr, den, r)
+            ctx.save_for_backward(proj, e_hat, x_tilde, den, r)
             ctx.gi = gi
         return x_tilde, e_hat
 
     @staticmethod
     def backward(ctx, g_x: torch.Tensor, g_e: torch.Tensor):
         L = _lib.load()
-        proj, e_hat, aggr, den, r = ctx.saved_tensors
+        proj, e_hat, x_tilde, den, r = ctx.saved_tensors
         gi: GraphIndex = ctx.gi
         dev = proj.device
         N, E = gi.N, gi.E
@@ -183,8 +183,8 @@ class _GatedGCNAggregate(torch.autograd.Function):
         g_proj = torch.empty(N, 4 * d, dtype=torch.float32, device=dev)
         g_ce = torch.empty(E, d, dtype=torch.float32, device=dev)
         gb, fs = g_proj.data_ptr(), d * 4
-        check(L.gps_gatedgcn_bwd(ptr(g_x), ptr(g_e), ptr(e_hat), proj.data_ptr() + fs, 4 * d,
-                                 ptr(aggr), ptr(den), ptr(gi.rowptr_dst), ptr(gi.src_by_dst),
+        check(L.gps_gatedgcn_bwd(ptr(g_x), d, ptr(g_e), ptr(e_hat), proj.data_ptr(), proj.data_ptr() + fs, 4 * d,
+                                 ptr(x_tilde), ptr(den), ptr(gi.rowptr_dst), ptr(gi.src_by_dst),
                                  ptr(gi.eid_by_dst), ptr(gi.rowptr_src), ptr(gi.dst_by_src),
                                  ptr(gi.eid_by_src), N, E, d, ptr(g_ce), gb, gb + fs, gb + 2 * fs,
                                  gb + 3 * fs, 4 * d, ptr(r), current_stream(dev)), "gps_gatedgcn_bwd")
@@ -195,7 +195,7 @@ class _GatedGCNAggregate(torch.autograd.Function):
             # (fp64: a * Bx_j + b cancels, and this scalar feeds a 1 -> d -> 1 MLP's gradients)
             src, dst = gi.edge_src, gi.edge_dst
             a = g_x.double() / (den.double() + 1e-6)
-            bterm = -a * aggr.double()
+            bterm = -a * (x_tilde.double() - proj[:, :d].double())     # aggr_i = x_tilde_i - Ax_i
             gs = a.index_select(0, dst) * proj[:, d:2 * d].double().index_select(0, src) \
                 + bterm.index_select(0, dst)
             g_r = (gs * torch.sigmoid(e_hat.double())).sum(-1).float()

@@ -8,8 +8,8 @@ Mirror of ``graphgps/train/custom_train.py:16-47``::
 
 with three differences that are about the machine, not the arithmetic:
   * the reference's per-iteration ``loss.detach().cpu().item()`` (:42) -- a device sync that
-    drains the queue every step -- is gone: losses/predictions stay on the device and the logger
-    is fed once per epoch;
+    drains the queue every step -- is gone: losses/predictions wait on the device (detached) and the
+    logger is fed ``LOGGER_FLUSH_EVERY`` iterations at a time (one sync per flush, bounded memory);
   * clip + AdamW are the two-launch flat-arena step of ``optim.FlatAdamW``;
   * ``TrainStep`` splits the step at the only point another GPU is involved (the gradient
     all-reduce), so both halves can be replayed from hipGraphs when the batch shape is fixed.
@@ -27,6 +27,17 @@ from .loss.losses import train_loss
 from .optim import FlatAdamW
 
 
+def _has_dropout(model) -> bool:
+    for m in model.modules():
+        if isinstance(m, torch.nn.Dropout) and m.p > 0:
+            return True
+        for name in ("dropout", "attn_dropout"):
+            v = getattr(m, name, None)
+            if isinstance(v, float) and v > 0:
+                return True
+    return False
+
+
 class TrainStep:
     """forward + loss + backward + gradient pack | [all-reduce] | clip + AdamW.
 
@@ -34,10 +45,14 @@ class TrainStep:
     dropout salt (``ops.enable_dropout_salt``) a captured step must advance so every replay draws
     new dropout masks."""
 
-    def __init__(self, model: torch.nn.Module, optimizer: FlatAdamW,
+    def __init__(self, model: torch.nn.Module, optimizer,
                  loss_fn: Optional[Callable] = None, exchange=None, salt=None):
-        if not isinstance(optimizer, FlatAdamW):
-            raise TypeError("TrainStep drives optim.FlatAdamW (register_optimizer('adamW'))")
+        # optim.FlatAdamW (register_optimizer('adamW'), what every configs/GPS/*.yaml names) is the fused
+        # two-launch path; any other torch optimizer (GraphGym's 'adam' / 'sgd', the reference's 'adagrad')
+        # takes the reference's own clip_grad_norm_ + optimizer.step() (custom_train.py:33-37), eagerly.
+        self.flat = isinstance(optimizer, FlatAdamW)
+        if not self.flat and exchange is not None:
+            raise TypeError("the flat gradient exchange rides on optim.FlatAdamW's gradient arena")
         self.model, self.opt = model, optimizer
         self.loss_fn = loss_fn or train_loss
         self.exchange = exchange
@@ -57,7 +72,8 @@ class TrainStep:
         pred, true = self.model(batch)
         loss, pred_score = self.loss_fn(pred, true)
         loss.backward()
-        self.opt.pack_grads()
+        if self.flat:
+            self.opt.pack_grads()
         return loss, pred_score, true
 
     def reduce(self) -> None:
@@ -65,6 +81,8 @@ class TrainStep:
             self.exchange.all_reduce()
 
     def update(self) -> None:
+        if not self.flat and cfg.optim.clip_grad_norm:
+            torch.nn.utils.clip_grad_norm_(self.model.parameters(), cfg.optim.clip_grad_norm_value)
         self.opt.step()
 
     def __call__(self, batch):
@@ -84,6 +102,13 @@ class TrainStep:
         object over the same device tensors: a shape bucket of a loader, or the synthetic bench
         batch).  One graph when there is no exchange; two (either side of the all-reduce, which
         stays an eager RCCL call on the same stream) when there is."""
+        if not self.flat:
+            raise TypeError("hipGraph capture of the step needs optim.FlatAdamW (device-resident hyper-parameters)")
+        if self.salt is None and _has_dropout(self.model):
+            # a captured step replays the SAME counter-hash seeds: without the device-side salt every replay
+            # would draw the same dropout masks
+            from .ops import enable_dropout_salt
+            self.salt = enable_dropout_salt(self.opt.arena.device)
         dev = self.opt.arena.device
         side = torch.cuda.Stream(device=dev)
         side.wait_stream(torch.cuda.current_stream(dev))
@@ -121,21 +146,71 @@ class TrainStep:
         return self._static_loss
 
 
+LOGGER_FLUSH_EVERY = 16     # iterations between device->host reads for the logger (one sync per flush)
+
+
+def _detached(obj):
+    """Detach tensors (and lists / dicts of tensors) so a deferred logger record keeps no autograd graph alive."""
+    if torch.is_tensor(obj):
+        return obj.detach()
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_detached(o) for o in obj)
+    if isinstance(obj, dict):
+        return {k: _detached(v) for k, v in obj.items()}
+    return obj
+
+
+class _DeferredLogger:
+    """Feeds ``logger.update_stats`` (graphgps/logger.py:201-230) with exactly the arguments the reference loop
+    passes, but ``LOGGER_FLUSH_EVERY`` iterations at a time: the reference's per-iteration
+    ``loss.detach().cpu().item()`` (custom_train.py:42) drains the GPU queue every step; here the records wait
+    on the device, detached, and one flush costs one sync.  Memory stays bounded (code2 holds 5 x [B, 5002]
+    logits per iteration -- the reference logger argmax-decodes them per iteration for the same reason,
+    logger.py:208-217 -- so at most ``LOGGER_FLUSH_EVERY`` of them are alive).  ``time_used`` is the wall time
+    between two flushes (device-synchronised by the flush itself) divided over the iterations it covers."""
+
+    def __init__(self, logger):
+        self.logger, self.pending = logger, []
+        self.t_last = time.time()
+
+    def add(self, true, pred_score, loss, lr, **extra):
+        self.pending.append((_detached(true), _detached(pred_score), loss.detach(), lr, extra))
+        if len(self.pending) >= LOGGER_FLUSH_EVERY:
+            self.flush()
+
+    def flush(self):
+        if not self.pending:
+            return
+        rows = []
+        for true, pred_score, loss, lr, extra in self.pending:
+            if cfg.dataset.name == 'ogbg-code2':
+                _true, _pred = true, pred_score          # the logger decodes them itself (logger.py:203-217)
+            else:
+                _true, _pred = true.to('cpu'), pred_score.to('cpu')
+            rows.append((_true, _pred, loss.cpu().item(), lr, extra))     # .item(): the sync
+        now = time.time()
+        dt = (now - self.t_last) / len(rows)
+        self.t_last = now
+        self.pending = []
+        for _true, _pred, loss, lr, extra in rows:
+            self.logger.update_stats(true=_true, pred=_pred, loss=loss, lr=lr, time_used=dt,
+                                     params=cfg.params, dataset_name=cfg.dataset.name, **extra)
+
+
 def train_epoch(logger, loader, model, optimizer, scheduler, batch_accumulation, exchange=None):
     """Drop-in for ``custom_train.train_epoch`` (custom_train.py:16-47), same arguments (+ the
     optional data-parallel ``exchange``).  ``cfg.optim.clip_grad_norm`` is applied inside the
-    fused optimizer step."""
+    fused optimizer step (``FlatAdamW``) or by ``clip_grad_norm_`` (any other optimizer)."""
     model.train()
-    if cfg.optim.clip_grad_norm:
-        optimizer.param_groups[0]["max_grad_norm"] = cfg.optim.clip_grad_norm_value
-    else:
-        optimizer.param_groups[0]["max_grad_norm"] = None
+    flat = isinstance(optimizer, FlatAdamW)
+    if flat:
+        optimizer.param_groups[0]["max_grad_norm"] = (cfg.optim.clip_grad_norm_value
+                                                      if cfg.optim.clip_grad_norm else None)
     step = TrainStep(model, optimizer, exchange=exchange)
     optimizer.zero_grad()
     device = torch.device(cfg.accelerator)
     n_iters = len(loader)
-    pending = []
-    time_start = time.time()
+    log = _DeferredLogger(logger)
     # next batch's H2D copies + graph index run on a copy stream behind the current step
     for it, batch in enumerate(DeviceLoader(loader, device)):
         batch.split = 'train'
@@ -144,18 +219,8 @@ def train_epoch(logger, loader, model, optimizer, scheduler, batch_accumulation,
             step.reduce()
             step.update()
             optimizer.zero_grad()
-        pending.append((true, pred_score, loss.detach(), scheduler.get_last_lr()[0],
-                        time.time() - time_start))
-        time_start = time.time()
-    # one D2H at the end of the epoch instead of one sync per iteration
-    for true, pred_score, loss, lr, dt in pending:
-        if cfg.dataset.name == 'ogbg-code2':
-            _true, _pred = true, pred_score
-        else:
-            _true = true.detach().to('cpu')
-            _pred = pred_score.detach().to('cpu')
-        logger.update_stats(true=_true, pred=_pred, loss=loss.cpu().item(), lr=lr, time_used=dt,
-                            params=cfg.params, dataset_name=cfg.dataset.name)
+        log.add(true, pred_score, loss, scheduler.get_last_lr()[0])
+    log.flush()
 
 
 @torch.no_grad()
@@ -163,11 +228,10 @@ def eval_epoch(logger, loader, model, split='val'):
     """Drop-in for ``custom_train.eval_epoch`` (custom_train.py:48-77), same arguments: eval-mode forward + loss
     for every batch of ``loader``, the logger fed once per batch.  As in ``train_epoch`` the next batch's H2D
     copies and graph index run on a copy stream behind the current forward, and the device->host reads the
-    logger needs happen after the loop (one sync per epoch instead of one per batch)."""
+    logger needs happen ``LOGGER_FLUSH_EVERY`` batches at a time."""
     model.eval()
     device = torch.device(cfg.accelerator)
-    pending = []
-    time_start = time.time()
+    log = _DeferredLogger(logger)
     for batch in DeviceLoader(loader, device):
         batch.split = split
         if cfg.gnn.head == 'inductive_edge':
@@ -176,12 +240,5 @@ def eval_epoch(logger, loader, model, split='val'):
             pred, true = model(batch)
             extra_stats = {}
         loss, pred_score = train_loss(pred, true)
-        pending.append((true, pred_score, loss.detach(), time.time() - time_start, extra_stats))
-        time_start = time.time()
-    for true, pred_score, loss, dt, extra_stats in pending:
-        if cfg.dataset.name == 'ogbg-code2':
-            _true, _pred = true, pred_score
-        else:
-            _true, _pred = true.detach().to('cpu'), pred_score.detach().to('cpu')
-        logger.update_stats(true=_true, pred=_pred, loss=loss.cpu().item(), lr=0, time_used=dt,
-                            params=cfg.params, dataset_name=cfg.dataset.name, **extra_stats)
+        log.add(true, pred_score, loss, 0, **extra_stats)
+    log.flush()

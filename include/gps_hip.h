@@ -74,27 +74,33 @@ int gps_attn_tile_map(const int32_t* ptr, int64_t B, int64_t max_tiles, int32_t*
 /* ---------------------------------------------------------------------------------------
  * GatedGCN sparse core.  Replaces propagate()'s 3 index_select gathers, the sigmoid gate and
  * the 2 torch_scatter.scatter sums + the node update (graphgps/layer/gatedgcn_layer.py:67-70,
- * 90-136) with ONE gather-gate-segment-reduce kernel (forward) and TWO (backward).
+ * 90-136) with ONE gather-gate-segment-reduce launch forward and ONE launch backward.
  *   e_hat[eid] = Dx[i] + Ex[j] + Ce[eid]                      (edge order, pre-BN edge output)
  *   x_tilde[i] = Ax[i] + (sum_j sig*Bx[j]) / (sum_j sig + 1e-6)
- * Ax/Bx/Dx/Ex are [N, d] views with row stride ld_node (a fused [N,4d] projection passes
- * ld_node = 4d).  `aggr`/`den` ([N,d]) are saved for the backward (may be NULL in inference).
+ * Ax/Bx/Dx/Ex are [N, d] views with row stride ld_node (a fused [N,4d] / [N,7d] projection passes
+ * ld_node = 4d / 7d).  `den` ([N,d] = sum_j sig, the only tensor saved for the backward besides the
+ * outputs; NULL in inference).
  * `r_edge` (float[E] by edge id, or NULL): the EquivStableLapPE gate r_ij of
  * graphgps/layer/gatedgcn_layer.py:101-104 -- sig is replaced by sig * r_edge[eid] in both sums
  * (and in the backward; the gradient wrt r_edge itself is the caller's: graphgps_amd/ops.py).
+ * A workgroup owns a contiguous block of node rows (its CSR / CSC slices staged in LDS); d / vector
+ * width must be <= 768 lanes (d <= 3072 for 16-byte aligned rows).
  * ------------------------------------------------------------------------------------- */
 int gps_gatedgcn_fwd(const float* Ax, const float* Bx, const float* Dx, const float* Ex,
                      int64_t ld_node, const float* Ce, const int32_t* rowptr_dst,
                      const int32_t* src_by_dst, const int32_t* eid_by_dst, int64_t N, int64_t E,
-                     int d, float* x_tilde, float* e_hat, float* aggr, float* den,
+                     int d, float* x_tilde, float* e_hat, float* den,
                      const float* r_edge, gps_stream_t stream);
 
-/* Backward.  Inputs: g_x [N,d] (grad wrt x_tilde), g_e [E,d] (grad wrt e_hat), saved e_hat,
- * Bx (ld_node), aggr, den.  Outputs: g_Ce [E,d]; g_Ax/g_Bx/g_Dx/g_Ex [N,d] views with row stride
- * ld_gnode (all four written; g_Ax = g_x).  Two launches: a target-keyed pass (delta, g_Ce,
- * g_Dx) and a source-keyed pass (g_Ex, g_Bx).  Deterministic, no atomics. */
-int gps_gatedgcn_bwd(const float* g_x, const float* g_e, const float* e_hat, const float* Bx,
-                     int64_t ld_node, const float* aggr, const float* den,
+/* Backward.  Inputs: g_x [N,d] with row stride ld_gx (grad wrt x_tilde), g_e [E,d] (grad wrt e_hat), the
+ * forward's e_hat, x_tilde, den and its Ax / Bx inputs (ld_node).  Outputs: g_Ce [E,d]; g_Ax/g_Bx/g_Dx/g_Ex
+ * [N,d] views with row stride ld_gnode (g_Ax = g_x; pass g_Ax == g_x with ld_gx == ld_gnode when the incoming
+ * gradient already sits in its slot and the copy is skipped).  One launch: a target-keyed phase (num
+ * recomputed, delta -> g_Ce, g_Dx), a workgroup barrier, a source-keyed phase (g_Ex, g_Bx) that re-reads this
+ * workgroup's own g_Ce rows and recomputes delta for edges whose target another workgroup owns.
+ * Deterministic, no atomics; e_hat / g_e / g_Ce cross HBM once each. */
+int gps_gatedgcn_bwd(const float* g_x, int64_t ld_gx, const float* g_e, const float* e_hat, const float* Ax,
+                     const float* Bx, int64_t ld_node, const float* x_tilde, const float* den,
                      const int32_t* rowptr_dst, const int32_t* src_by_dst,
                      const int32_t* eid_by_dst, const int32_t* rowptr_src,
                      const int32_t* dst_by_src, const int32_t* eid_by_src, int64_t N, int64_t E,

@@ -86,7 +86,7 @@ def test_c_abi_exports_every_declared_symbol():
     assert L.gps_abi_version() == lib.ABI_VERSION
     # argument validation works without a GPU and reports through gps_last_error()
     rc = L.gps_gatedgcn_fwd(None, None, None, None, 8, None, None, None, None, 4, 0, 8,
-                            None, None, None, None, None, None)
+                            None, None, None, None, None)
     assert rc == -1 and b"null" in L.gps_last_error()
     assert L.gps_attn_supported_head_dim(24) == 1 and L.gps_attn_supported_head_dim(7) == 0
 
@@ -166,8 +166,12 @@ def test_graphgym_layer_machinery_names_and_rules():
     assert cfg.gnn.head == "graph"                       # 'default' -> dataset.task (assert_cfg)
     mlp = MLP(new_layer_config(64, 5, 3, has_act=False, has_bias=True, cfg=cfg))
     keys = list(mlp.state_dict())
-    assert "model.0.Layer_0.layer.model.weight" in keys and "model.0.Layer_1.post_layer.0.running_mean" in keys
-    assert "model.0.Layer_0.layer.model.bias" not in keys          # BN follows -> no bias (GeneralLayer)
+    # PyG 2.2 builds the hidden stack from LayerConfig DEFAULTS (only num_layers / dims / final_act are passed on):
+    # no BatchNorm in the hidden layers even with gnn.batchnorm=True, hence a bias; ReLU; l2norm
+    assert "model.0.Layer_0.layer.model.weight" in keys and "model.0.Layer_0.layer.model.bias" in keys
+    assert "model.0.Layer_1.layer.model.bias" in keys and not any("running_mean" in k for k in keys)
+    hidden = mlp.model[0].Layer_0
+    assert hidden.has_l2norm and len(hidden.post_layer) == 1 and isinstance(hidden.post_layer[0], torch.nn.ReLU)
     assert keys[-2:] == ["model.1.model.weight", "model.1.model.bias"]
     assert mlp(torch.randn(7, 64)).shape == (7, 5)
     pre = GNNPreMP(9, 64, 2, cfg)
@@ -190,23 +194,65 @@ def test_optimizer_registration_and_train_step_contract():
     opt = g.register.optimizer_dict["adamW"](lin.parameters(), 1e-3, 0.01)      # extra_optimizers.py:21-24
     assert isinstance(opt, FlatAdamW) and opt.param_groups[0]["lr"] == 1e-3
     assert opt.param_groups[0]["weight_decay"] == 0.01 and opt.arena.intact()
-    with pytest.raises(TypeError):
-        TrainStep(lin, torch.optim.AdamW(lin.parameters()))
+    # any other torch optimizer (GraphGym 'adam' / 'sgd', the reference's 'adagrad') is driven eagerly through the
+    # reference's clip_grad_norm_ + step(); what needs the flat arena says so
+    other = TrainStep(lin, torch.optim.Adagrad(lin.parameters()))
+    assert not other.flat
+    with pytest.raises(TypeError, match="FlatAdamW"):
+        other.capture(lambda: None)
+    with pytest.raises(TypeError, match="arena"):
+        TrainStep(lin, torch.optim.Adagrad(lin.parameters()), exchange=object())
     sd = opt.state_dict()                                    # no steps yet: torch creates state lazily
     assert sd["state"] == {} and sd["param_groups"][0]["params"] == [0, 1]
 
 
 def test_device_loader_is_a_pass_through_on_cpu():
-    """On a CPU device DeviceLoader adds nothing (no CPU kernels exist on the product path): same batch
-    objects, same order, same length as the wrapped loader."""
+    """On a CPU device DeviceLoader adds nothing (no CPU kernels exist on the product path): same tensors, same
+    order, same length as the wrapped loader -- handed out in fresh shallow containers, so whatever the model
+    re-assigns (``batch.x`` / ``batch.edge_attr``, gps_layer.py:174,231) never leaks into a list-style loader that
+    is iterated again next epoch.  A PyG-style batch that keeps its tensors behind ``keys`` / attribute access
+    (``batch._store``, not ``__dict__``) is walked through that interface."""
     from graphgps_amd.loader import DeviceLoader
     from graphgps_amd.synthetic import model_batch
     host = [model_batch("zinc", 3, seed=i) for i in range(4)]
     dl = DeviceLoader(host, "cpu", depth=2)
     assert len(dl) == 4
     out = list(dl)
-    assert all(a is b for a, b in zip(out, host))
+    assert all(a is not b and a.x is b.x and a.edge_index is b.edge_index for a, b in zip(out, host))
     assert all("_gps_index" not in b.__dict__ for b in out)
+    out[0].x = out[0].x.float() * 2              # what a model does
+    assert host[0].x.dtype == torch.int64        # ... stays out of the loader's batch
+
+    class StoreBatch:                            # tensors NOT in __dict__ (torch_geometric.data.Data layout)
+        def __init__(self, **kw):
+            object.__setattr__(self, "_store", dict(kw))
+
+        @property
+        def keys(self):                          # PyG 2.2: a property
+            return list(self._store)
+
+        def __getattr__(self, k):
+            try:
+                return object.__getattribute__(self, "_store")[k]
+            except KeyError:
+                raise AttributeError(k)
+
+        def __setattr__(self, k, v):
+            self._store[k] = v
+
+        def __copy__(self):
+            return StoreBatch(**self._store)
+
+        def to(self, device, non_blocking=False):
+            for k, v in list(self._store.items()):
+                if torch.is_tensor(v):
+                    self._store[k] = v.to(device)
+            return self
+
+    sb = StoreBatch(x=torch.ones(3, 2), edge_index=torch.zeros(2, 0, dtype=torch.long), note="s")
+    assert DeviceLoader._keys(sb) == ["x", "edge_index", "note"]
+    got = list(DeviceLoader([sb], "cpu"))[0]
+    assert got is not sb and got.x is sb.x
 
 
 @pytest.mark.skipif(not os.path.isdir("/root/reference/configs"), reason="needs the reference's configs/ tree")

@@ -62,7 +62,8 @@ def _worker(rank, world, port, q):
         for k in got:
             want = sum(pr[k] for pr in per_rank) / world
             worst = max(worst, (got[k] - want).abs().max().item() / max(want.abs().max().item(), 1e-30))
-        q.put((rank, worst, reducer.num_bytes))
+        n_params = sum(p.numel() for p in model.parameters() if p.requires_grad)
+        q.put((rank, worst, reducer.num_bytes, 4 * n_params))
     finally:
         dist.destroy_process_group()
 
@@ -79,9 +80,10 @@ def test_bucketed_allreduce_world2_gloo():
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    for rank, worst, nbytes in results:
+    for rank, worst, nbytes, want_bytes in results:
         assert worst < 1e-6, (rank, worst)
-        assert nbytes == 423_717 * 4 - (10 - 2) * 0 or nbytes > 0
+        # every trainable parameter is exchanged exactly once, as fp32: the per-step all-reduce volume
+        assert nbytes == want_bytes and nbytes > 4 * 80_000, (nbytes, want_bytes)
 
 
 def test_single_process_reducer_is_a_noop_wrapper():
@@ -154,6 +156,112 @@ def test_flat_arena_allreduce_world2_gloo():
     for rank, worst, nbytes in results:
         assert worst < 1e-6, (rank, worst)
         assert nbytes >= 4 * 80_000
+
+
+# ---------------------------------------------------------------------------------------------
+# the whole N > 1 step API: train.TrainStep + optim.FlatAdamW arena + dp.FlatGradExchange, world 2
+# ---------------------------------------------------------------------------------------------
+def _cpu_flat_adamw():
+    """FlatAdamW whose ``step()`` is a torch restatement of csrc/optim.hip over the SAME flat arena (test stand-in:
+    the product's step is a HIP kernel and refuses CPU parameters).  Everything else -- arena adoption, gradient
+    packing, ``zero_grad``, the buffer the exchange all-reduces -- is the product code."""
+    from graphgps_amd.optim import FlatAdamW
+
+    class CpuFlatAdamW(FlatAdamW):
+        @torch.no_grad()
+        def step(self, closure=None):
+            a, g = self.arena, self.param_groups[0]
+            if not self._packed:
+                self.pack_grads()
+            grad = a.flat_g
+            if g.get("max_grad_norm"):
+                norm = grad.double().norm().float()
+                grad = grad * torch.clamp(g["max_grad_norm"] / (norm + 1e-6), max=1.0)
+            self.hyper[6] += 1
+            t = float(self.hyper[6])
+            b1, b2 = g["betas"]
+            a.flat_p.mul_(1 - g["lr"] * g["weight_decay"])
+            self.exp_avg.mul_(b1).add_(grad, alpha=1 - b1)
+            self.exp_avg_sq.mul_(b2).addcmul_(grad, grad, value=1 - b2)
+            denom = (self.exp_avg_sq.sqrt() / (1 - b2 ** t) ** 0.5).add_(g["eps"])
+            a.flat_p.addcdiv_(self.exp_avg, denom, value=-g["lr"] / (1 - b1 ** t))
+            self._packed = False
+
+    return CpuFlatAdamW
+
+
+def _trainstep_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
+                      WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from graphgps_amd.dp import FlatGradExchange
+        from graphgps_amd.loss.losses import compute_loss
+        from graphgps_amd.synthetic import model_batch
+        from graphgps_amd.train import TrainStep
+        model = _make_oracle_model()                       # the oracle model stands in for the HIP model
+        opt = _cpu_flat_adamw()(model.parameters(), lr=1e-3, weight_decay=1e-5, max_grad_norm=1.0)
+        ex = FlatGradExchange(opt.arena)
+        assert ex.active and ex.num_bytes == opt.arena.num_bytes
+        ts = TrainStep(model, opt, loss_fn=compute_loss, exchange=ex)
+        losses = [float(ts(model_batch("zinc", 8, seed=1234 + 10 * step + rank))) for step in range(3)]
+        # single-process reference: torch.optim.AdamW + clip_grad_norm_ fed the rank-mean gradient
+        ref = _make_oracle_model()
+        o_ref = torch.optim.AdamW(ref.parameters(), lr=1e-3, weight_decay=1e-5)
+        for step in range(3):
+            grads = []
+            for r in range(world):
+                ref.zero_grad(set_to_none=True)
+                pred, true = ref(model_batch("zinc", 8, seed=1234 + 10 * step + r))
+                compute_loss(pred, true)[0].backward()
+                grads.append([p.grad.clone() for p in ref.parameters()])
+            for i, p in enumerate(ref.parameters()):
+                p.grad = sum(g[i] for g in grads) / world
+            torch.nn.utils.clip_grad_norm_(ref.parameters(), 1.0)
+            o_ref.step()
+        # Adam turns ANY non-zero gradient into a +-lr step, so parameters whose gradient is mathematically zero
+        # (biases feeding a BatchNorm: rounding residue on both sides) random-walk apart; the first moment is
+        # linear in the gradients and is compared for every parameter, the weights for those with a real signal
+        gmax = max(float(o_ref.state[p]["exp_avg"].abs().max()) for p in ref.parameters())
+        worst_m = worst = 0.0
+        n_cmp = 0
+        for off, p_got, p_ref in zip(opt.arena.offsets, opt.arena.params, ref.parameters()):
+            m_ref = o_ref.state[p_ref]["exp_avg"]
+            m_got = opt.exp_avg[off:off + p_got.numel()].view_as(p_got)
+            worst_m = max(worst_m, (m_got - m_ref).abs().max().item() / gmax)
+            if float(m_ref.abs().max()) > 1e-3 * gmax and float(m_ref.abs().min()) > 1e-6 * gmax:
+                worst = max(worst, (p_got - p_ref).abs().max().item())
+                n_cmp += 1
+        assert worst_m < 1e-6, worst_m
+        assert n_cmp >= 5, n_cmp
+        flat = opt.arena.flat_p.detach().clone()
+        both = [torch.zeros_like(flat) for _ in range(world)]
+        dist.all_gather(both, flat)
+        q.put((rank, worst, bool(torch.equal(both[0], both[1])), losses))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_trainstep_flat_exchange_world2_gloo():
+    """TrainStep([fwd + bwd + pack] | FlatGradExchange.all_reduce | [clip + AdamW]) on two gloo ranks, three steps
+    with different per-rank batches: both ranks end with bit-identical weights, equal (to fp32 rounding) to a
+    single-process AdamW run fed the mean of the per-rank gradients (SURVEY.md section 8e parity statement)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_trainstep_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, worst, same, losses in results:
+        assert same, "ranks diverged"
+        assert worst < 2e-6, (rank, worst)
+        assert all(l == l for l in losses)
 
 
 def test_param_arena_keeps_linear_group_stacks_and_follows_moves():

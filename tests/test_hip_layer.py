@@ -147,6 +147,84 @@ def test_gpslayer_vs_oracle_baseline_sizes(local, glob, d, H, profile, nb):
             print(f"grad {k}: {r[2]} kink rows, max rel {r[0]:.2e} outside them")
 
 
+def test_gpslayer_performer_code2_size_vs_oracle():
+    """BASELINE configs[4] layer shape (configs/GPS/ogbg-code2-GPS.yaml:31,40-47): GPSLayer(256,
+    'CustomGatedGCN', 'Performer', 4) -- Performer's dim_head stays 64 (performer_layer.py:427,441-442), m = 266
+    random features -- on a CODE2_LONG batch (32 ASTs of 600-1000 nodes, 4 concatenated edge groups) vs the CPU
+    oracle (the reference's padded to_dense_batch -> SelfAttention -> [mask] path, gps_layer.py:199,206):
+    outputs 1e-5, input gradients 1e-5 of max|g| outside ReLU-kink rows, parameter gradients 1e-4."""
+    from graphgps_amd.layer.gps_layer import GPSLayer
+    from graphgps_amd.synthetic import layer_batch
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    layer = GPSLayer(256, "CustomGatedGCN", "Performer", 4, dropout=0.0, attn_dropout=0.0)
+    oracle = _oracle_layer_like(layer).train()
+    layer.to(dev).train()
+    b = layer_batch("CODE2_LONG", 32, 256, seed=21)
+    sizes = (b.ptr[1:] - b.ptr[:-1])
+    assert int(sizes.max()) <= 1000 and int(sizes.min()) >= 600 and int(sizes.max()) - int(sizes.min()) > 200
+    gen = torch.Generator().manual_seed(8)
+    wx = torch.randn(b.x.shape, generator=gen)
+    we = torch.randn(b.edge_attr.shape, generator=gen)
+    bc = b.clone()
+    bc.x.requires_grad_(True); bc.edge_attr.requires_grad_(True)
+    xo, eo = bc.x, bc.edge_attr
+    oo = oracle(bc)
+    ((oo.x * wx).sum() + (oo.edge_attr * we).sum()).backward()
+    bg = b.clone().to(dev)
+    bg.x.requires_grad_(True); bg.edge_attr.requires_grad_(True)
+    xg, eg = bg.x, bg.edge_attr
+    og = layer(bg)
+    ((og.x * wx.to(dev)).sum() + (og.edge_attr * we.to(dev)).sum()).backward()
+    assert_close(og.x, oo.x, Tol.ACT, "out.x")
+    assert_close(og.edge_attr, oo.edge_attr, Tol.ACT, "out.edge_attr")
+    # FAVOR+ mixes all rows of a graph: a kink flip in one graph touches up to 1000 rows
+    rx = assert_close_kink_tolerant(xg.grad, xo.grad, Tol.GRAD_REL, "grad x", min_allowed_rows=2 * 1000)
+    re_ = assert_close_kink_tolerant(eg.grad, eo.grad, Tol.GRAD_REL, "grad e")
+    print(f"code2 layer: grad x max rel {rx[0]:.2e} outside {rx[2]} kink rows; grad e {re_[0]:.2e} / {re_[2]}")
+    op = dict(oracle.named_parameters())
+    gscale = max(float(q.grad.abs().max()) for q in op.values() if q.grad is not None)
+    for k, p in layer.named_parameters():
+        if op[k].grad is None:
+            continue
+        assert_close_kink_tolerant(p.grad, op[k].grad, 1e-4, f"grad {k}", min_scale=max(1.0, 0.01 * gscale))
+
+
+def test_code2_model_vs_oracle():
+    """The 4-layer ``ogbg-code2-GPS.yaml`` model (ASTNode/ASTEdge encoders, 4 x CustomGatedGCN+Performer at
+    d=256, ogb_code_graph head, sub-token cross entropy) on 32 code2-long graphs, dropout off: every one of the
+    5 prediction heads, the loss and all parameter gradients vs the oracle model."""
+    from graphgps_amd.loss.losses import compute_loss
+    from graphgps_amd.synthetic import model_batch
+    from oracle.gps_oracle import to_oracle_model
+    import graphgps_amd as g
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = _build_model("code2_gps.yaml", 2, 5002, ["gt.dropout", 0.0, "gt.attn_dropout", 0.0])
+    assert type(model.layers[0].self_attn).__name__ == "SelfAttention" and len(model.layers) == 4
+    model.train()
+    oracle = to_oracle_model(model)
+    model.to(dev)
+    b = model_batch("code2", 32, seed=4321)
+    assert int((b.ptr[1:] - b.ptr[:-1]).max()) > 900
+    po, to_ = oracle(b.clone())
+    lo, _ = compute_loss(po, to_)
+    lo.backward()
+    pg, tg = model(b.clone().to(dev))
+    lg, _ = compute_loss(pg, tg)
+    lg.backward()
+    for i, (a_, b_) in enumerate(zip(pg, po)):
+        assert_close(a_, b_, 1e-4, f"pred[{i}]")
+    assert_close(lg, lo, 1e-5, "loss")
+    op = dict(oracle.named_parameters())
+    worst = 0.0
+    for k, p in model.named_parameters():
+        if op[k].grad is None or p.grad is None:
+            continue
+        worst = max(worst, assert_close(p.grad, op[k].grad, 1e-3, f"grad {k}", rel_to_max=True))
+    print(f"code2 model: worst relative parameter-gradient error {worst:.2e}")
+
+
 def test_gpslayer_edge_permutation_and_determinism():
     """Shuffling edge order must not change node outputs (and permutes edge outputs); two
     identical runs are bitwise identical (no atomics anywhere on the path)."""

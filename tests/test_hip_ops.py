@@ -326,7 +326,13 @@ def _favor_ref(qkv, proj, ptr, H):
 
 
 @pytest.mark.parametrize("H,sizes", [(2, [40, 7, 64, 33]), (4, [25, 25, 25]), (1, [130]),
-                                     (2, [3, 300, 17, 1])])
+                                     (2, [3, 300, 17, 1]),
+                                     # BASELINE configs[4] sizes (ogbg-code2-GPS.yaml: 4 heads x dim_head 64, graphs
+                                     # clipped at 1000 nodes, master_loader.py:366-368): a 3-node graph next to a
+                                     # 1000-node one is 997 padded key rows short of Nmax, so the closed-form
+                                     # padded-key term (performer_layer.py:485-487: v masked, k not) dominates its D
+                                     (4, [1000, 3, 601]),
+                                     (4, [60, 999, 1, 16])])
 def test_favor_attention_fwd_bwd(H, sizes):
     from graphgps_amd.ops import favor_attention
     from oracle.gps_oracle import gaussian_orthogonal_random_matrix

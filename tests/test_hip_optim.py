@@ -202,6 +202,48 @@ def test_train_epoch_mirrors_reference_loop():
     assert torch.equal(a, b)
 
 
+@pytest.mark.parametrize("layer_type", ["CustomGatedGCN+Transformer", "GINE+Transformer"])
+def test_gradient_accumulation_matches_oracle_sum(layer_type):
+    """``optim.batch_accumulation`` > 1 (custom_train.py:29-38; the reference configs use 2 and 4): from the second
+    micro-batch on every parameter already holds a ``.grad`` and autograd accumulates into it as soon as a block's
+    backward node returns -- the block's weight gradients must then NOT still be in flight on the side stream
+    (gps_block._accumulating).  Three micro-batches at a width where the weight-gradient kernel runs long enough
+    to lose a race (d=256, 64 graphs), against the CPU oracle's sum of the three gradients."""
+    import graphgps_amd as g
+    from graphgps_amd.loss.losses import compute_loss
+    from graphgps_amd.optim import FlatAdamW
+    from graphgps_amd.synthetic import model_batch
+    from graphgps_amd.train import TrainStep
+    from oracle.gps_oracle import to_oracle_model
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = g.create_model(os.path.join(g.CONFIG_DIR, "zinc_gps_rwse.yaml"),
+                           ["gt.layers", 2, "gt.layer_type", layer_type, "gt.dim_hidden", 256,
+                            "gnn.dim_inner", 256, "gt.n_heads", 8, "gt.dropout", 0.0, "gt.attn_dropout", 0.0],
+                           1, 1).train()
+    oracle = to_oracle_model(model).train()
+    model.to(dev)
+    opt = FlatAdamW(model.parameters(), lr=1e-3, weight_decay=0.0)
+    ts = TrainStep(model, opt, loss_fn=compute_loss)
+    batches = [model_batch("zinc", 64, seed=300 + i) for i in range(3)]
+    opt.zero_grad()
+    for b in batches:
+        lo, _ = compute_loss(*oracle(b.clone()))
+        lo.backward()                                   # torch accumulates on the CPU side too
+        ts.forward_backward(b.clone().to(dev), zero=False)
+    torch.cuda.synchronize()
+    og = dict(oracle.named_parameters())
+    gscale = max(float(q.grad.abs().max()) for q in og.values() if q.grad is not None)
+    checked = 0
+    for k, p in model.named_parameters():
+        if og[k].grad is None or p.grad is None:
+            continue
+        diff = (p.grad.detach().cpu().double() - og[k].grad.double()).abs().max().item()
+        assert diff <= 1e-4 * max(float(og[k].grad.abs().max()), 0.01 * gscale, 1.0), f"grad {k}: {diff:.3e}"
+        checked += 1
+    assert checked > 30
+
+
 def test_train_step_two_graphs_around_rccl_allreduce_world1():
     """The N > 1 product path on one rank: [index + fwd + bwd + pack] and [clip + AdamW] captured as two
     hipGraphs with an eager RCCL all-reduce of the flat gradient arena between them (world size 1, so the
