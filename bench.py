@@ -17,13 +17,21 @@ launched eagerly or replayed from hipGraph(s), whichever of the two measures fas
 steps each (eager measured before anything is captured) (--launch auto; every rank takes the same decision).  rocBLAS / hipBLASLt GEMM
 solutions are picked per shape by TunableOp during the warm-up and frozen before the timed region.
 
+`python bench.py --gpus N` with N > 1 and no launcher environment re-executes itself under
+torch.distributed.run (one rank per GPU, rendezvous on 127.0.0.1).
+
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
   roofline      the GatedGCN gather-gate-segment-reduce forward kernel (HBM-bound): algorithmic
-                bytes (8*E*d + 20*N*d + CSR index bytes) / mean launch
-                duration measured with HIP events on the launching stream
-  kernels       the same measurement for every hand-written kernel (HBM GB/s or MFMA TFLOP/s)
-  cpu_baseline  the CPU oracle (pure-torch restatement of the reference path) timed on the
-                host cores of the same box, same batch, same step definition (rank 0, N = 1)
+                bytes (8*E*d + 20*N*d + CSR index bytes) / its mean launch
+                duration INSIDE the training step (roctracer kernel records of a few extra steps after the
+                timed region -- the same quantity `rocprofv3 --kernel-trace --stats` reports, committed
+                under profiles/); the isolated HIP-event durations (hot: one buffer set, resident in the
+                256 MiB Infinity Cache; rotating: > 512 MiB of buffer sets, so every launch comes from
+                HBM) are carried next to it
+  kernels       the same three durations for every hand-written kernel (HBM GB/s or MFMA TFLOP/s)
+  cpu_baseline  the CPU oracle (pure-torch restatement of the reference path) timed on the host cores of the
+                same box, same batch, same step definition (rank 0, N = 1): all usable cores (the headline
+                leg) and torch.set_num_threads(6) = the reference's default cfg.num_threads (main.py:125)
 """
 import argparse
 import json
@@ -86,7 +94,7 @@ def parse_args():
     ap.add_argument("--no-kernel-roofline", action="store_true")
     ap.add_argument("--no-h2d-leg", action="store_true",
                     help="skip the secondary PCIe-inclusive measurement (host batches through DeviceLoader)")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--cpu-threads", type=int, default=0,
                     help="torch threads for the CPU baseline (0 = min(usable cores, 32))")
     return ap.parse_args()
@@ -114,23 +122,61 @@ def make_step(model, opt, reducer, batch_dev, compute_loss, clip_value, salt=Non
     return step
 
 
-def time_kernel(fn, iters=50, warm=5):
-    """Mean duration (ms) of ``fn`` (enqueues on torch's current stream, the stream the C-ABI
-    launches on) measured with HIP events."""
-    for _ in range(warm):
-        fn()
+def time_kernel(fn, iters=48, warm=6, nsets=1):
+    """Mean duration (ms) of ``fn(i)`` (enqueues on torch's current stream, the stream the C-ABI
+    launches on) measured with HIP events.  ``i`` cycles over ``nsets`` operand sets: 1 = the same
+    buffers every launch (they stay in the 256 MiB Infinity Cache), > 1 = a rotation larger than
+    the cache, so every launch streams from HBM."""
+    for i in range(warm):
+        fn(i % nsets)
     torch.cuda.synchronize()
     t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     t0.record()
-    for _ in range(iters):
-        fn()
+    for i in range(iters):
+        fn(i % nsets)
     t1.record()
     torch.cuda.synchronize()
     return t0.elapsed_time(t1) / iters
 
 
-def kernel_rooflines(dev, profile, nb, d=384, H=16):
-    """Layer-shaped micro-measurements of each hand-written kernel at the benchmark's sizes."""
+ROTATE_BYTES = 640 << 20      # > 2x the Infinity Cache: a rotation this large cannot be served from it
+
+
+def in_step_kernel_ms(step, n_steps=3):
+    """{kernel name: (mean duration in ms, launches per step)} from the GPU activity records (roctracer via
+    torch.profiler) of ``n_steps`` training steps -- the durations rocprofv3 --kernel-trace reports, taken in the
+    step's real context (neighbouring kernels, the weight-gradient stream running beside it)."""
+    from torch.profiler import ProfilerActivity, profile
+    torch.cuda.synchronize()
+    with profile(activities=[ProfilerActivity.CUDA]) as prof:
+        for _ in range(n_steps):
+            step()
+        torch.cuda.synchronize()
+    out = {}
+    for ev in prof.key_averages():
+        tot = getattr(ev, "device_time_total", None)
+        if tot is None:
+            tot = getattr(ev, "cuda_time_total", 0.0)
+        if ev.count and tot:
+            out[ev.key] = (tot / ev.count / 1e3, ev.count / n_steps)
+    return out
+
+
+def _match(in_step, *needles):
+    """(sum of the MEAN launch durations of the distinct kernels whose name contains one of ``needles`` -- one
+    layer's worth when each of them runs once per layer --, launches per step seen).  Means, not totals: the
+    activity buffer may drop records of the tail of a step."""
+    ms = n = 0.0
+    for k, (t, c) in in_step.items():
+        if any(x in k for x in needles):
+            ms += t
+            n += c
+    return (ms, n) if n else (None, 0)
+
+
+def kernel_rooflines(dev, profile, nb, d=384, H=16, in_step=None, layers=10, only=None):
+    """Layer-shaped measurements of each hand-written kernel at the benchmark's sizes: isolated (hot and
+    rotating operand sets, HIP events) and -- when ``in_step`` holds the step's kernel records -- in-step."""
     from graphgps_amd import lib as L_
     from graphgps_amd.lib import check, current_stream, ptr
     from graphgps_amd.ops import build_graph_index
@@ -139,59 +185,94 @@ def kernel_rooflines(dev, profile, nb, d=384, H=16):
     b = layer_batch(profile, nb, d, seed=1234).to(dev)
     N, E = b.x.shape[0], b.edge_index.shape[1]
     gi = build_graph_index(b.edge_index, N, nb, ptr_vec=b.ptr)
+    nmax_host = int((b.ptr[1:] - b.ptr[:-1]).max())
     st = current_stream(dev)
     f = lambda *s: torch.randn(*s, device=dev)
-    proj, ce = f(N, 4 * d), f(E, d)
-    xt, eh, ag, dn = f(N, d), f(E, d), f(N, d), f(N, d)
-    gx, ge, gproj, gce = f(N, d), f(E, d), f(N, 4 * d), f(E, d)
-    P, G, fs = proj.data_ptr(), gproj.data_ptr(), d * 4
-
-    def gg_fwd():
-        check(L.gps_gatedgcn_fwd(P, P + fs, P + 2 * fs, P + 3 * fs, 4 * d, ptr(ce), ptr(gi.rowptr_dst),
-                                 ptr(gi.src_by_dst), ptr(gi.eid_by_dst), N, E, d, ptr(xt), ptr(eh),
-                                 ptr(ag), ptr(dn), None, st))
-
-    def gg_bwd():
-        check(L.gps_gatedgcn_bwd(ptr(gx), ptr(ge), ptr(eh), P + fs, 4 * d, ptr(ag), ptr(dn),
-                                 ptr(gi.rowptr_dst), ptr(gi.src_by_dst), ptr(gi.eid_by_dst),
-                                 ptr(gi.rowptr_src), ptr(gi.dst_by_src), ptr(gi.eid_by_src), N, E, d,
-                                 ptr(gce), G, G + fs, G + 2 * fs, G + 3 * fs, 4 * d, None, st))
-
+    fs = d * 4
     dh = d // H
-    qkv, out, lse = f(N, 3 * d), f(N, d), f(H, N)
-    dout, delta, dqkv = f(N, d), f(H, N), f(N, 3 * d)
     scale = dh ** -0.5
-
-    def at_fwd(p=0.1):
-        check(L.gps_seg_attn_fwd(ptr(qkv), 3 * d, ptr(gi.ptr), ptr(gi.tile_graph), ptr(gi.tile_row0),
-                                 gi.max_tiles, N, H, dh, scale, p, 1234, ptr(out), ptr(lse), st))
-
-    def at_bwd(p=0.1):
-        check(L.gps_seg_attn_bwd(ptr(dout), ptr(qkv), 3 * d, ptr(out), ptr(lse), ptr(gi.ptr),
-                                 ptr(gi.tile_graph), ptr(gi.tile_row0), gi.max_tiles, N, H, dh, scale,
-                                 p, 1234, ptr(delta), ptr(dqkv), 3 * d, st))
-
-    gg_fwd(); at_fwd()                     # produce valid saved tensors for the backward kernels
     sizes = (b.ptr[1:] - b.ptr[:-1]).double()
     s2 = float((sizes * sizes).sum())
     idx = 4 * (N + 1) + 8 * E
+
+    def gg_set():
+        return dict(proj=f(N, 4 * d), ce=f(E, d), xt=f(N, d), eh=f(E, d), dn=f(N, d).abs_() + 1.0,
+                    gx=f(N, d), ge=f(E, d), gproj=f(N, 4 * d), gce=f(E, d))
+    set_bytes = 4 * (2 * N * 4 * d + 4 * E * d + 3 * N * d)
+    n_rot = max(2, -(-ROTATE_BYTES // set_bytes))
+    gsets = [gg_set() for _ in range(n_rot)]
+
+    def gg_fwd(i=0):
+        q = gsets[i]
+        P = q["proj"].data_ptr()
+        check(L.gps_gatedgcn_fwd(P, P + fs, P + 2 * fs, P + 3 * fs, 4 * d, ptr(q["ce"]), ptr(gi.rowptr_dst),
+                                 ptr(gi.src_by_dst), ptr(gi.eid_by_dst), N, E, d, ptr(q["xt"]), ptr(q["eh"]),
+                                 ptr(q["dn"]), None, st))
+
+    def gg_bwd(i=0):
+        q = gsets[i]
+        P, G = q["proj"].data_ptr(), q["gproj"].data_ptr()
+        check(L.gps_gatedgcn_bwd(ptr(q["gx"]), d, ptr(q["ge"]), ptr(q["eh"]), P, P + fs, 4 * d, ptr(q["xt"]),
+                                 ptr(q["dn"]), ptr(gi.rowptr_dst), ptr(gi.src_by_dst), ptr(gi.eid_by_dst),
+                                 ptr(gi.rowptr_src), ptr(gi.dst_by_src), ptr(gi.eid_by_src), N, E, d,
+                                 ptr(q["gce"]), G, G + fs, G + 2 * fs, G + 3 * fs, 4 * d, None, st))
+
+    def at_set():
+        return dict(qkv=f(N, 3 * d), out=f(N, d), lse=f(H, N), dout=f(N, d), delta=f(H, N), dqkv=f(N, 3 * d))
+    a_bytes = 4 * (2 * N * 3 * d + 2 * N * d + 2 * H * N)
+    a_rot = max(2, -(-ROTATE_BYTES // a_bytes))
+    asets = [at_set() for _ in range(a_rot)]
+
+    def at_fwd(i=0, p=0.1):
+        q = asets[i]
+        check(L.gps_seg_attn_fwd(ptr(q["qkv"]), 3 * d, ptr(gi.ptr), ptr(gi.tile_graph), ptr(gi.tile_row0),
+                                 gi.max_tiles, N, H, dh, scale, p, 1234, ptr(q["out"]), ptr(q["lse"]), nmax_host, st))
+
+    def at_bwd(i=0, p=0.1):
+        q = asets[i]
+        check(L.gps_seg_attn_bwd(ptr(q["dout"]), ptr(q["qkv"]), 3 * d, ptr(q["out"]), ptr(q["lse"]), ptr(gi.ptr),
+                                 ptr(gi.tile_graph), ptr(gi.tile_row0), gi.max_tiles, N, H, dh, scale,
+                                 p, 1234, ptr(q["delta"]), ptr(q["dqkv"]), 3 * d, nmax_host, st))
+
+    for i in range(n_rot):                 # valid saved tensors (e_hat, den) for the backward kernels
+        gg_fwd(i)
+    for i in range(a_rot):
+        at_fwd(i)
     res = {}
-    t = time_kernel(gg_fwd)
-    bytes_f = 8 * E * d + 20 * N * d + idx
-    res["gatedgcn_fwd"] = dict(bound="hbm", ms=t, bytes=bytes_f, achieved=bytes_f / t / 1e6,
-                               peak=HBM_PEAK_GBS, unit="GB/s")
-    t = time_kernel(gg_bwd)
-    bytes_b = 12 * E * d + 28 * N * d + 2 * idx
-    res["gatedgcn_bwd"] = dict(bound="hbm", ms=t, bytes=bytes_b, achieved=bytes_b / t / 1e6,
-                               peak=HBM_PEAK_GBS, unit="GB/s", launches=2)
-    t = time_kernel(at_fwd)
-    fl = 4 * s2 * d
-    res["seg_attn_fwd"] = dict(bound="mfma", ms=t, flops=fl, achieved=fl / t / 1e9,
-                               peak=MFMA_F32_PEAK_TF, unit="TFLOP/s")
-    t = time_kernel(at_bwd)
-    flb = 8 * s2 * d
-    res["seg_attn_bwd"] = dict(bound="mfma", ms=t, flops=flb, achieved=flb / t / 1e9,
-                               peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", launches=3)
+
+    def entry(name, fn, nsets, bound, work, launches, needles, note=None):
+        if only is not None and name not in only:
+            return
+        hot = time_kernel(fn, nsets=1)
+        rot = time_kernel(fn, nsets=nsets)
+        ins, cnt = _match(in_step, *needles) if in_step else (None, 0)
+        peak, unit, div = (HBM_PEAK_GBS, "GB/s", 1e6) if bound == "hbm" else (MFMA_F32_PEAK_TF, "TFLOP/s", 1e9)
+        ms = ins if ins is not None else rot
+        e = dict(bound=bound, ms=ms, ms_source="in-step (roctracer)" if ins is not None else "isolated, rotating",
+                 in_step_ms=ins, isolated_hot_ms=hot, isolated_rotating_ms=rot,
+                 achieved=work / ms / div, peak=peak, unit=unit, launches=launches,
+                 in_step_launches_per_step=cnt or None)
+        e["bytes" if bound == "hbm" else "flops"] = work
+        e["frac"] = e["achieved"] / peak
+        e["frac_isolated_hot"] = work / hot / div / peak
+        e["frac_isolated_rotating"] = work / rot / div / peak
+        if note:
+            e["note"] = note
+        res[name] = e
+
+    entry("gatedgcn_fwd", gg_fwd, n_rot, "hbm", 8 * E * d + 20 * N * d + idx, 1, ("k_gatedgcn_fwd",))
+    entry("gatedgcn_bwd", gg_bwd, n_rot, "hbm", 12 * E * d + 28 * N * d + 2 * idx, 1, ("k_gatedgcn_bwd",))
+    # the attention core is HBM-bound at these graph sizes (7.8 flop/byte against a ridge of 19.6): the binding
+    # roofline is Q/K/V read + O write (fwd), + dO read + dQ/dK/dV write (bwd); the MFMA figure rides along
+    entry("seg_attn_fwd", at_fwd, a_rot, "hbm", 16 * N * d + 4 * H * N, 1, ("k_attn_fwd", "k_sattn_fwd"))
+    if "seg_attn_fwd" in res:
+        res["seg_attn_fwd"]["mfma_tflops"] = 4 * s2 * d / res["seg_attn_fwd"]["ms"] / 1e9
+        res["seg_attn_fwd"]["mfma_frac"] = res["seg_attn_fwd"]["mfma_tflops"] / MFMA_F32_PEAK_TF
+    entry("seg_attn_bwd", at_bwd, a_rot, "hbm", 32 * N * d + 12 * H * N, 2,
+          ("k_attn_bwd", "k_sattn_bwd"))
+    if "seg_attn_bwd" in res:
+        res["seg_attn_bwd"]["mfma_tflops"] = 8 * s2 * d / res["seg_attn_bwd"]["ms"] / 1e9
+        res["seg_attn_bwd"]["mfma_frac"] = res["seg_attn_bwd"]["mfma_tflops"] / MFMA_F32_PEAK_TF
     # the five weight(+bias) gradients of one block as ONE grouped split-K launch (csrc/wgrad.hip)
     shapes = [(N, d, 7 * d), (E, d, d), (N, d, d), (N, d, 2 * d), (N, 2 * d, d)]   # (rows, in, out)
     pairs = [(f(R, n), f(R, k)) for R, k, n in shapes]
@@ -203,28 +284,102 @@ def kernel_rooflines(dev, profile, nb, d=384, H=16):
         q.g, q.x, q.gw, q.gb = g_.data_ptr(), x_.data_ptr(), gw.data_ptr(), gb.data_ptr()
         q.ldg, q.ldx, q.R, q.M, q.Nn = g_.stride(0), x_.stride(0), g_.shape[0], g_.shape[1], x_.shape[1]
     wws = torch.empty(max(L.gps_wgrad_grouped_workspace_floats(len(pairs), probs), 4), device=dev)
-    t = time_kernel(lambda: check(L.gps_wgrad_grouped(len(pairs), probs, ptr(wws), st)))
-    flw = sum(2.0 * R * k * n for R, k, n in shapes)
-    res["wgrad_grouped"] = dict(bound="mfma", ms=t, flops=flw, achieved=flw / t / 1e9,
-                                peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", launches=2,
-                                note="fp32-equivalent flops against the fp32-input MFMA peak; the contraction "
-                                     "itself runs on the bf16 pipe (exact 3-way split, 6 products)")
-    for v in res.values():
-        v["frac"] = v["achieved"] / v["peak"]
-    return res, dict(N=N, E=E, d=d, H=H, sum_n2=s2)
+    entry("wgrad_grouped", lambda i=0: check(L.gps_wgrad_grouped(len(pairs), probs, ptr(wws), st)), 1, "mfma",
+          sum(2.0 * R * k * n for R, k, n in shapes), 2, ("k_wgrad",),
+          note="fp32-equivalent flops against the fp32-input MFMA peak; the contraction itself runs on the "
+               "bf16 pipe (exact 3-way split, 6 products); in-step it shares the chip with the main stream")
+    return res, dict(N=N, E=E, d=d, H=H, sum_n2=s2, rotation_sets=dict(gatedgcn=n_rot, attention=a_rot))
+
+
+def favor_rooflines(dev, nb, d=256, H=4, in_step=None):
+    """BASELINE configs[4] (ogbg-code2-GPS.yaml): the FAVOR+ kernels (csrc/favor.hip) at code2-long sizes --
+    4 heads x dim_head 64, m = 266 random features -- against the fp32 MFMA peak.  Flops per layer (the
+    reference's formulation): fwd 8*N*m*(64H) + 2*N*m*H, bwd 2x."""
+    from graphgps_amd import lib as L_
+    from graphgps_amd.lib import check, current_stream, ptr
+    from graphgps_amd.ops import _nmax_dev, build_graph_index
+    from graphgps_amd.synthetic import layer_batch
+    L = L_.load()
+    b = layer_batch("CODE2_LONG", nb, d, seed=1234).to(dev)
+    N, E = b.x.shape[0], b.edge_index.shape[1]
+    gi = build_graph_index(b.edge_index, N, nb, ptr_vec=b.ptr)
+    st = current_stream(dev)
+    dh, m = 64, 266
+    inner = H * dh
+    f32 = dict(dtype=torch.float32, device=dev)
+    torch.manual_seed(0)
+    from graphgps_amd.layer.performer_layer import gaussian_orthogonal_random_matrix
+    proj = gaussian_orthogonal_random_matrix(m, dh).to(dev)
+    qkv = torch.randn(N, 3 * inner, **f32) * 0.7
+    out = torch.empty(N, inner, **f32)
+    cbuf, ksum = torch.empty(nb * H, 272, dh, **f32), torch.empty(nb * H, 272, **f32)
+    kmax = torch.empty(nb * H, dtype=torch.int64, device=dev)
+    mq, D = torch.empty(H, N, **f32), torch.empty(H, N, **f32)
+    nmax = _nmax_dev(gi)
+    g_out = torch.randn(N, inner, **f32)
+    gD, g_ctx, g_ksum = torch.empty(H, N, **f32), torch.empty_like(cbuf), torch.empty_like(ksum)
+    gm_part = torch.empty(max(gi.max_tiles * H, 1), **f32)
+    d_qkv = torch.empty_like(qkv)
+
+    def fwd(i=0):
+        check(L.gps_favor_fwd(ptr(qkv), 3 * inner, ptr(proj), m, ptr(gi.ptr), ptr(nmax), ptr(gi.tile_graph),
+                              ptr(gi.tile_row0), gi.max_tiles, N, nb, H, dh, ptr(out), ptr(cbuf), ptr(ksum),
+                              ptr(kmax), ptr(mq), ptr(D), st))
+
+    def bwd(i=0):
+        check(L.gps_favor_bwd(ptr(g_out), ptr(qkv), 3 * inner, ptr(proj), m, ptr(out), ptr(gi.ptr), ptr(nmax),
+                              ptr(gi.tile_graph), ptr(gi.tile_row0), gi.max_tiles, N, nb, H, dh, ptr(cbuf),
+                              ptr(ksum), ptr(kmax), ptr(mq), ptr(D), ptr(gD), ptr(g_ctx), ptr(g_ksum),
+                              ptr(gm_part), ptr(d_qkv), 3 * inner, st))
+
+    fwd()
+    flf = 8.0 * N * m * inner + 2.0 * N * m * H
+    res = {}
+    for name, fn, fl, is_bwd in (("favor_fwd", fwd, flf, False), ("favor_bwd", bwd, 2 * flf, True)):
+        t = time_kernel(fn, iters=20, warm=3)
+        e = dict(bound="mfma", isolated_hot_ms=t, flops=fl, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s")
+        if in_step:
+            import re
+            names = [k for k in in_step if "favor" in k.lower() and ("bwd" in k.lower()) == is_bwd]
+            short = lambda k: (re.search(r"k_favor\w*", k) or re.search(r"\w+", k)).group(0)
+            e["in_step_kernels"] = {short(k): dict(ms=in_step[k][0], per_step=in_step[k][1]) for k in names}
+            tot = sum(in_step[k][0] for k in names)      # each kernel runs once per layer: sum of mean durations
+            if tot:
+                e["in_step_ms"] = tot
+        e["ms"] = e.get("in_step_ms", t)
+        t = e["ms"]
+        e["achieved"] = fl / t / 1e9
+        e["frac"] = e["achieved"] / MFMA_F32_PEAK_TF
+        res[name] = e
+    if in_step:     # in-step: all FAVOR kernels of a step / (layers x (fwd + bwd)) against 3x the forward flops
+        tot = sum(t for k, (t, c) in in_step.items() if "favor" in k.lower())
+        if tot:
+            res["favor_in_step"] = dict(bound="mfma", ms_per_layer_fwd_bwd=tot, flops=3 * flf,
+                                        achieved=3 * flf / tot / 1e9, peak=MFMA_F32_PEAK_TF,
+                                        unit="TFLOP/s", frac=3 * flf / tot / 1e9 / MFMA_F32_PEAK_TF)
+    return res, dict(N=N, E=E, d=d, H=H, dim_head=dh, nb_features=m)
+
+
+def cpu_model_name():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(model, batch_cpu, compute_loss, clip_value, steps, threads=0):
-    """CPU oracle (kind='port'): same batch, same step definition, on the host cores.  The op
-    granularity of the reference path ([7.7k,384] GEMMs, gathers, elementwise) stops scaling
-    well before 32 threads, so more threads than that only add barrier cost."""
+    """CPU oracle (kind='port'): same batch, same step definition, on the host cores -- two legs:
+    all usable cores (capped at 32: the op granularity of the reference path -- [7.7k,384] GEMMs, gathers,
+    elementwise -- stops scaling well before that) and torch.set_num_threads(6), the reference's default
+    ``cfg.num_threads`` (main.py:125).  The headline leg is the faster one."""
     from oracle.gps_oracle import to_oracle_model
-    cores = threads or min(usable_cores(), 32)
-    torch.set_num_threads(cores)
-    log(f"cpu baseline: {cores} torch threads of {usable_cores()} usable cores")
     oracle = to_oracle_model(model).train()
     opt = torch.optim.AdamW(oracle.parameters(), lr=2e-4, weight_decay=0.0)
     params = list(oracle.parameters())
+    nb = int(batch_cpu.num_graphs)
 
     def step():
         opt.zero_grad(set_to_none=True)
@@ -234,19 +389,46 @@ def cpu_baseline(model, batch_cpu, compute_loss, clip_value, steps, threads=0):
         torch.nn.utils.clip_grad_norm_(params, clip_value)
         opt.step()
 
-    tw = time.perf_counter()
-    step()                                   # warm-up (allocator, thread pool)
-    log(f"cpu baseline: warm-up step {time.perf_counter() - tw:.2f}s")
-    t0 = time.perf_counter()
-    done = 0
-    while done < steps and (done == 0 or time.perf_counter() - t0 < 30.0):
-        step()
-        done += 1
-    dt = (time.perf_counter() - t0) / done
-    nb = int(batch_cpu.num_graphs)
-    return dict(value=nb / dt, unit="graphs/s", cores=cores, kind="port", ms_per_step=dt * 1e3,
-                sample=f"{done} full training step(s) of the same {nb}-graph batch after 1 warm-up, "
-                       f"pure-torch CPU oracle of the reference path, torch threads={cores}")
+    def leg(cores, budget_s):
+        torch.set_num_threads(cores)
+        tw = time.perf_counter()
+        step()                                   # warm-up (allocator, thread pool)
+        log(f"cpu baseline [{cores} threads]: warm-up step {time.perf_counter() - tw:.2f}s")
+        t0 = time.perf_counter()
+        done = 0
+        while done < steps and (done == 0 or time.perf_counter() - t0 < budget_s):
+            step()
+            done += 1
+        dt = (time.perf_counter() - t0) / done
+        return dict(value=nb / dt, unit="graphs/s", cores=cores, ms_per_step=dt * 1e3, steps=done)
+
+    all_cores = threads or min(usable_cores(), 32)
+    legs = [leg(all_cores, 12.0)]
+    if all_cores != 6 and usable_cores() >= 6:
+        legs.append(leg(6, 12.0))
+    best = max(legs, key=lambda l: l["value"])
+    return dict(value=best["value"], unit="graphs/s", cores=best["cores"], kind="port",
+                ms_per_step=best["ms_per_step"], cpu_model=cpu_model_name(), usable_cores=usable_cores(),
+                legs=legs,
+                sample=f"{best['steps']} full training step(s) of the same {nb}-graph batch after 1 warm-up per leg, "
+                       f"pure-torch CPU oracle of the reference path; legs: "
+                       + ", ".join(f"{l['cores']} threads = {l['value']:.1f} graphs/s" for l in legs))
+
+
+def respawn_under_launcher(n):
+    """`python bench.py --gpus N` (N > 1) without a launcher environment: re-execute under torch.distributed.run,
+    one rank per GPU, rendezvous on 127.0.0.1 -- the command the driver itself uses."""
+    import socket
+    import subprocess
+    if torch.cuda.device_count() < n:
+        raise SystemExit(f"--gpus {n}: only {torch.cuda.device_count()} GPU(s) visible")
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    log("re-executing under the launcher: " + " ".join(cmd))
+    raise SystemExit(subprocess.call(cmd))
 
 
 def main():
@@ -259,11 +441,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the GPS hot path has no CPU fallback")
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        os.dup2(real_stdout, 1)                # the ranks inherit the real stdout for the JSON line
+        respawn_under_launcher(args.gpus)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -298,8 +482,8 @@ def main():
     if args.workload == "code2":
         compute_loss = subtoken_cross_entropy       # custom_train.py:24-25
     nb = args.graphs_per_gpu or default_nb
-    if args.workload != "pcqm4m":
-        args.no_kernel_roofline = True              # the kernel table is the PCQM4M layer shape
+    if args.workload == "zinc":
+        args.no_kernel_roofline = True              # launch-latency-bound sizes: numerics config, no roofline
     batch_cpu = model_batch(args.workload, nb, seed=1234 + rank, profile=args.profile)
     cpu_ref_model = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
@@ -469,6 +653,8 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
+            "dropout": "on (config values; masks from the kernels' counter hash -- parity of this configuration "
+                       "is statistical / shared-mask, tests/test_hip_ops.py)",
             "config": {"workload": f"{wl_label}, synthetic profile "
                                    f"{args.profile or {'pcqm4m': 'P30', 'zinc': 'ZINC', 'code2': 'CODE2_LONG'}[args.workload]}, "
                                    f"{nb} graphs/GPU ({N} nodes, {E} directed edges on rank 0)",
@@ -486,17 +672,36 @@ def main():
                               if tunable is not None else "library default heuristics",
         }
         if not args.no_kernel_roofline:
-            kr, shape = kernel_rooflines(dev, args.profile or "P30", nb)
+            in_step = None
+            try:
+                in_step = in_step_kernel_ms(step)
+                out["in_step_kernel_ms"] = {k: dict(ms=round(v[0], 5), per_step=v[1]) for k, v in
+                                            sorted(in_step.items(), key=lambda kv: -kv[1][0] * kv[1][1])[:24]}
+            except Exception as exc:
+                log(f"in-step kernel records unavailable ({type(exc).__name__}: {exc}); isolated timings only")
+            if args.workload == "pcqm4m":
+                kr, shape = kernel_rooflines(dev, args.profile or "P30", nb, in_step=in_step,
+                                              layers=int(cfg.gt.layers))
+                k = kr["gatedgcn_fwd"]
+                traffic, traffic_src = None, None
+                pmc = os.path.join(ROOT, "profiles", "pmc_gatedgcn_fwd.json")
+                if os.path.exists(pmc):           # HBM bytes per launch from a separate rocprofv3 --pmc pass
+                    rec = json.load(open(pmc))
+                    traffic, traffic_src = rec.get("hbm_bytes_per_launch"), rec.get("source")
+                out["roofline"] = {"kernel": "k_gatedgcn_fwd", "bound": "hbm", "achieved": k["achieved"],
+                                   "peak": k["peak"], "unit": "GB/s", "frac": k["frac"],
+                                   "launch_ms": k["ms"], "launch_ms_source": k["ms_source"],
+                                   "isolated_hot_ms": k["isolated_hot_ms"],
+                                   "isolated_rotating_ms": k["isolated_rotating_ms"],
+                                   "traffic": traffic, "traffic_source": traffic_src,
+                                   "algorithmic_bytes": k["bytes"]}
+            else:
+                kr, shape = favor_rooflines(dev, nb, in_step=in_step)
+                k = kr.get("favor_in_step") or kr["favor_fwd"]
+                out["roofline"] = {"kernel": "k_favor_* (FAVOR+ forward + backward of one layer)", "bound": "mfma",
+                                   "achieved": k["achieved"], "peak": k["peak"], "unit": "TFLOP/s",
+                                   "frac": k["frac"], "traffic": None}
             log("kernel rooflines done")
-            k = kr["gatedgcn_fwd"]
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "pmc_gatedgcn_fwd.json")
-            if os.path.exists(pmc):           # HBM bytes per launch from a rocprofv3 --pmc pass
-                traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-            out["roofline"] = {"kernel": "k_gatedgcn_fwd", "bound": "hbm", "achieved": k["achieved"],
-                               "peak": k["peak"], "unit": "GB/s", "frac": k["frac"],
-                               "traffic": traffic, "algorithmic_bytes": k["bytes"],
-                               "launch_ms": k["ms"]}
             out["kernels"] = kr
             out["kernel_shape"] = shape
         if cpu_ref_model is not None:

@@ -30,6 +30,8 @@
 //
 // Algorithmic HBM bytes (fp32, per layer):  fwd 8*E*d + 20*N*d (+4*N*d for the saved `den` when
 // training), bwd 12*E*d + 28*N*d; index traffic 4(N+1)+8E per CSR/CSC slice.
+#include <cstdlib>
+
 #include "gps_common.hpp"
 #include "vec.hpp"
 
@@ -59,19 +61,88 @@ __device__ __forceinline__ bool stage_slice(const int32_t* __restrict__ rowptr, 
                                             const int32_t* __restrict__ ib, const NodeBlock& nbk, int* s_rp,
                                             int* s_a, int* s_b) {
   const int cnt = (int)(nbk.n1 - nbk.n0);
-  for (int t = threadIdx.x; t <= cnt; t += GG_T) s_rp[t] = rowptr[nbk.n0 + t];
+  const int T = blockDim.x;
+  for (int t = threadIdx.x; t <= cnt; t += T) s_rp[t] = rowptr[nbk.n0 + t];
   const int e0 = rowptr[nbk.n0], e1 = rowptr[nbk.n1];
   const bool staged = (e1 - e0) <= GG_MAXE;
   if (staged)
-    for (int t = threadIdx.x; t < e1 - e0; t += GG_T) {
+    for (int t = threadIdx.x; t < e1 - e0; t += T) {
       s_a[t] = ia[e0 + t];
       s_b[t] = ib[e0 + t];
     }
   return staged;
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Edge chunks.  D (1..4) edges of one node: every operand row is requested before the first one is used, so a node
+// with <= 4 edges (molecules, ASTs) costs ONE memory round trip; longer segments are walked 4 edges at a time.
+// D is a template parameter (switch on the degree) so that each body is straight-line code: with run-time
+// predicates the compiler splits the loads over basic blocks and waits between them.
 // GATE: the EquivStableLapPE variant (gatedgcn_layer.py:101-104): sigma_ij is multiplied by a per-edge
 // scalar r_ij in (0,1) (r_edge[edge id]) before it gates and normalises.
+// ---------------------------------------------------------------------------------------------------------
+template <int VEC, bool GATE, int D>
+__device__ __forceinline__ void fwd_chunk(const float* __restrict__ Bx, const float* __restrict__ Ex, int64_t ld,
+                                          const float* __restrict__ Ce, const float* __restrict__ r_edge, int d,
+                                          int c, const int* nbr, const int* eids, const Vec<VEC>& dx,
+                                          Vec<VEC>& num, Vec<VEC>& den, float* __restrict__ e_hat) {
+  int64_t id[D];
+  Vec<VEC> ex[D], bx[D], ce[D];
+  float rr[D];
+#pragma unroll
+  for (int u = 0; u < D; ++u) {
+    const int64_t j = nbr[u];
+    id[u] = eids[u];
+    ex[u] = Vec<VEC>::load(Ex + j * ld + c);
+    bx[u] = Vec<VEC>::load(Bx + j * ld + c);
+    ce[u] = Vec<VEC>::load(Ce + id[u] * d + c);
+    rr[u] = GATE ? r_edge[id[u]] : 1.0f;
+  }
+#pragma unroll
+  for (int u = 0; u < D; ++u) {
+    Vec<VEC> eh;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      eh[v] = (dx[v] + ex[u][v]) + ce[u][v];  // e_ij = Dx_i + Ex_j + Ce            (:96)
+      float s = sigmoidf_fast(eh[v]);        //                                     (:97)
+      if (GATE) s = s * rr[u];                // sigma_ij * r_ij                     (:101-104)
+      num[v] += s * bx[u][v];                 // scatter(sigma*Bx_j)                 (:117-119)
+      den[v] += s;                            // scatter(sigma)                      (:121-123)
+    }
+    eh.store(e_hat + id[u] * d + c);          // self.e = e_ij, returned in edge order (:106,134)
+  }
+}
+
+template <int VEC, bool SAVE, bool GATE>
+__device__ __forceinline__ void fwd_rows(const float* __restrict__ Ax, const float* __restrict__ Bx,
+                                         const float* __restrict__ Dx, const float* __restrict__ Ex, int64_t ld,
+                                         const float* __restrict__ Ce, const int* rp, const int* nbr,
+                                         const int* eids, const NodeBlock& blk, int d, int row, int npi, int c,
+                                         float* __restrict__ x_tilde, float* __restrict__ e_hat,
+                                         float* __restrict__ den_out, const float* __restrict__ r_edge) {
+  for (int64_t node = blk.n0 + row; node < blk.n1; node += npi) {
+    const int beg = rp[node - blk.n0], end = rp[node - blk.n0 + 1];
+    const Vec<VEC> dx = Vec<VEC>::load(Dx + node * ld + c);
+    const Vec<VEC> ax = Vec<VEC>::load(Ax + node * ld + c);
+    Vec<VEC> num = Vec<VEC>::zero(), den = Vec<VEC>::zero();
+    int k = beg;
+    for (; k + 4 < end; k += 4)
+      fwd_chunk<VEC, GATE, 4>(Bx, Ex, ld, Ce, r_edge, d, c, nbr + k, eids + k, dx, num, den, e_hat);
+    switch (end - k) {
+      case 1: fwd_chunk<VEC, GATE, 1>(Bx, Ex, ld, Ce, r_edge, d, c, nbr + k, eids + k, dx, num, den, e_hat); break;
+      case 2: fwd_chunk<VEC, GATE, 2>(Bx, Ex, ld, Ce, r_edge, d, c, nbr + k, eids + k, dx, num, den, e_hat); break;
+      case 3: fwd_chunk<VEC, GATE, 3>(Bx, Ex, ld, Ce, r_edge, d, c, nbr + k, eids + k, dx, num, den, e_hat); break;
+      case 4: fwd_chunk<VEC, GATE, 4>(Bx, Ex, ld, Ce, r_edge, d, c, nbr + k, eids + k, dx, num, den, e_hat); break;
+      default: break;
+    }
+    Vec<VEC> xt;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) xt[v] = ax[v] + num[v] / (den[v] + 1e-6f);  //          (:125,133)
+    xt.store(x_tilde + node * (int64_t)d + c);
+    if (SAVE) den.store(den_out + node * (int64_t)d + c);
+  }
+}
+
 template <int VEC, bool SAVE, bool GATE>
 __global__ __launch_bounds__(GG_T) void k_gatedgcn_fwd(
     const float* __restrict__ Ax, const float* __restrict__ Bx, const float* __restrict__ Dx,
@@ -90,46 +161,12 @@ __global__ __launch_bounds__(GG_T) void k_gatedgcn_fwd(
   if (row >= npi) return;
   const int c = (threadIdx.x - row * lpr) * VEC;
   const int e0 = s_rp[0];
-  for (int64_t node = blk.n0 + row; node < blk.n1; node += npi) {
-    const int beg = s_rp[node - blk.n0], end = s_rp[node - blk.n0 + 1];
-    const Vec<VEC> dx = Vec<VEC>::load(Dx + node * ld + c);
-    const Vec<VEC> ax = Vec<VEC>::load(Ax + node * ld + c);
-    Vec<VEC> num = Vec<VEC>::zero(), den = Vec<VEC>::zero();
-    auto edge = [&](const Vec<VEC>& ex, const Vec<VEC>& bx, const Vec<VEC>& ce, float rr, int64_t id) {
-      Vec<VEC> eh;
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) {
-        eh[v] = (dx[v] + ex[v]) + ce[v];  // e_ij = Dx_i + Ex_j + Ce            (:96)
-        float s = sigmoidf_fast(eh[v]);  //                                     (:97)
-        if (GATE) s = s * rr;             // sigma_ij * r_ij                     (:101-104)
-        num[v] += s * bx[v];              // scatter(sigma*Bx_j)                 (:117-119)
-        den[v] += s;                      // scatter(sigma)                      (:121-123)
-      }
-      eh.store(e_hat + id * d + c);       // self.e = e_ij, returned in edge order (:106,134)
-    };
-    int k = beg;
-    for (; k + 1 < end; k += 2) {         // two edges in flight (loads of both issued before the first use)
-      const int64_t j0 = staged ? s_src[k - e0] : src[k], j1 = staged ? s_src[k + 1 - e0] : src[k + 1];
-      const int64_t i0 = staged ? s_eid[k - e0] : eid[k], i1 = staged ? s_eid[k + 1 - e0] : eid[k + 1];
-      const Vec<VEC> ex0 = Vec<VEC>::load(Ex + j0 * ld + c), ex1 = Vec<VEC>::load(Ex + j1 * ld + c);
-      const Vec<VEC> bx0 = Vec<VEC>::load(Bx + j0 * ld + c), bx1 = Vec<VEC>::load(Bx + j1 * ld + c);
-      const Vec<VEC> ce0 = Vec<VEC>::load(Ce + i0 * d + c), ce1 = Vec<VEC>::load(Ce + i1 * d + c);
-      const float r0 = GATE ? r_edge[i0] : 1.0f, r1 = GATE ? r_edge[i1] : 1.0f;
-      edge(ex0, bx0, ce0, r0, i0);
-      edge(ex1, bx1, ce1, r1, i1);
-    }
-    if (k < end) {
-      const int64_t j0 = staged ? s_src[k - e0] : src[k];
-      const int64_t i0 = staged ? s_eid[k - e0] : eid[k];
-      edge(Vec<VEC>::load(Ex + j0 * ld + c), Vec<VEC>::load(Bx + j0 * ld + c), Vec<VEC>::load(Ce + i0 * d + c),
-           GATE ? r_edge[i0] : 1.0f, i0);
-    }
-    Vec<VEC> xt;
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) xt[v] = ax[v] + num[v] / (den[v] + 1e-6f);  //          (:125,133)
-    xt.store(x_tilde + node * (int64_t)d + c);
-    if (SAVE) den.store(den_out + node * (int64_t)d + c);
-  }
+  if (staged)     // index slices in LDS (workgroup-uniform branch: two copies of the body, one address space each)
+    fwd_rows<VEC, SAVE, GATE>(Ax, Bx, Dx, Ex, ld, Ce, s_rp, s_src - e0, s_eid - e0, blk, d, row, npi, c, x_tilde,
+                              e_hat, den_out, r_edge);
+  else            // a hub-heavy block (> GG_MAXE entries): same code on the global index arrays
+    fwd_rows<VEC, SAVE, GATE>(Ax, Bx, Dx, Ex, ld, Ce, s_rp, src, eid, blk, d, row, npi, c, x_tilde, e_hat,
+                              den_out, r_edge);
 }
 
 // Backward, one launch (see the header comment):
@@ -137,6 +174,191 @@ __global__ __launch_bounds__(GG_T) void k_gatedgcn_fwd(
 //   delta_ij = g_e_ij + (a_i * Bx_j + b_i) * sig_ij * (1 - sig_ij)
 //   g_Ce[eid] = delta_ij ;  g_Dx_i = sum_j delta_ij ;  g_Ax_i = g_x_i
 //   g_Ex_j = sum_{j->i} delta_ij ;   g_Bx_j = sum_{j->i} sig_ij * a_i
+// Phase A, a node with D <= 4 incoming edges in ONE pass: with t_ij = g_e_ij + a_i Bx_j s'_ij and
+// s'_ij = r_ij sig (1 - sig) kept in registers, delta_ij = t_ij + b_i s'_ij once num_i (hence b_i) is known.
+template <int VEC, bool GATE, int D>
+__device__ __forceinline__ void bwd_a_chunk(const float* __restrict__ g_e, const float* __restrict__ e_hat,
+                                            const float* __restrict__ Bx, int64_t ld,
+                                            const float* __restrict__ r_edge, int d, int c, const int* nbr,
+                                            const int* eids, const Vec<VEC>& a, const Vec<VEC>& inv,
+                                            Vec<VEC>& gdx, float* g_Ce) {
+  int64_t id[D];
+  Vec<VEC> eh[D], ge[D], bx[D];
+  float rr[D];
+#pragma unroll
+  for (int u = 0; u < D; ++u) {
+    const int64_t j = nbr[u];
+    id[u] = eids[u];
+    eh[u] = Vec<VEC>::load(e_hat + id[u] * d + c);
+    ge[u] = Vec<VEC>::load(g_e + id[u] * d + c);
+    bx[u] = Vec<VEC>::load(Bx + j * ld + c);
+    rr[u] = GATE ? r_edge[id[u]] : 1.0f;
+  }
+  Vec<VEC> num = Vec<VEC>::zero();
+#pragma unroll
+  for (int u = 0; u < D; ++u)
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      const float s = sigmoidf_fast(eh[u][v]);
+      float sp = s * (1.0f - s);
+      if (GATE) sp = sp * rr[u];
+      num[v] += (GATE ? s * rr[u] : s) * bx[u][v];
+      ge[u][v] += (a[v] * bx[u][v]) * sp;     // t_ij
+      eh[u][v] = sp;                          // s'_ij
+    }
+#pragma unroll
+  for (int u = 0; u < D; ++u) {
+    Vec<VEC> dl;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      const float b = -a[v] * (num[v] * inv[v]);
+      dl[v] = ge[u][v] + b * eh[u][v];
+      gdx[v] += dl[v];
+    }
+    dl.store(g_Ce + id[u] * d + c);
+  }
+}
+
+template <int VEC, bool GATE>
+__device__ __forceinline__ void bwd_a_rows(const float* __restrict__ g_x, int64_t ldgx,
+                                           const float* __restrict__ g_e, const float* __restrict__ e_hat,
+                                           const float* __restrict__ Bx, int64_t ld, const float* __restrict__ den,
+                                           const int* rp, const int* nbr, const int* eids, const NodeBlock& blk,
+                                           int d, int row, int npi, int c, float* g_Ce, float* __restrict__ g_Ax,
+                                           float* __restrict__ g_Dx, int64_t ldg,
+                                           const float* __restrict__ r_edge) {
+  for (int64_t node = blk.n0 + row; node < blk.n1; node += npi) {
+    const int beg = rp[node - blk.n0], end = rp[node - blk.n0 + 1];
+    const Vec<VEC> gx = Vec<VEC>::load(g_x + node * ldgx + c);
+    const Vec<VEC> dn = Vec<VEC>::load(den + node * (int64_t)d + c);
+    Vec<VEC> a, inv, gdx = Vec<VEC>::zero();
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      inv[v] = 1.0f / (dn[v] + 1e-6f);
+      a[v] = gx[v] * inv[v];
+    }
+    switch (end - beg) {
+      case 0: break;
+      case 1: bwd_a_chunk<VEC, GATE, 1>(g_e, e_hat, Bx, ld, r_edge, d, c, nbr + beg, eids + beg, a, inv, gdx, g_Ce); break;
+      case 2: bwd_a_chunk<VEC, GATE, 2>(g_e, e_hat, Bx, ld, r_edge, d, c, nbr + beg, eids + beg, a, inv, gdx, g_Ce); break;
+      case 3: bwd_a_chunk<VEC, GATE, 3>(g_e, e_hat, Bx, ld, r_edge, d, c, nbr + beg, eids + beg, a, inv, gdx, g_Ce); break;
+      case 4: bwd_a_chunk<VEC, GATE, 4>(g_e, e_hat, Bx, ld, r_edge, d, c, nbr + beg, eids + beg, a, inv, gdx, g_Ce); break;
+      default: {                               // long segment: num_i first, then the deltas (rows re-read from L1 / L2)
+        Vec<VEC> num = Vec<VEC>::zero();
+        for (int k = beg; k < end; ++k) {
+          const int64_t j = nbr[k], id = eids[k];
+          const Vec<VEC> eh = Vec<VEC>::load(e_hat + id * d + c);
+          const Vec<VEC> bx = Vec<VEC>::load(Bx + j * ld + c);
+          const float rr = GATE ? r_edge[id] : 1.0f;
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            float s = sigmoidf_fast(eh[v]);
+            if (GATE) s = s * rr;
+            num[v] += s * bx[v];
+          }
+        }
+        for (int k = beg; k < end; ++k) {
+          const int64_t j = nbr[k], id = eids[k];
+          const Vec<VEC> eh = Vec<VEC>::load(e_hat + id * d + c);
+          const Vec<VEC> ge = Vec<VEC>::load(g_e + id * d + c);
+          const Vec<VEC> bx = Vec<VEC>::load(Bx + j * ld + c);
+          const float rr = GATE ? r_edge[id] : 1.0f;
+          Vec<VEC> dl;
+#pragma unroll
+          for (int v = 0; v < VEC; ++v) {
+            const float s = sigmoidf_fast(eh[v]);
+            float sp = s * (1.0f - s);
+            if (GATE) sp = sp * rr;
+            const float b = -a[v] * (num[v] * inv[v]);
+            dl[v] = (ge[v] + (a[v] * bx[v]) * sp) + b * sp;     // same association as the one-pass form
+            gdx[v] += dl[v];
+          }
+          dl.store(g_Ce + id * d + c);
+        }
+      }
+    }
+    if (g_Ax) gx.store(g_Ax + node * ldg + c);
+    gdx.store(g_Dx + node * ldg + c);
+  }
+}
+
+// Phase B, D outgoing edges of one source node.
+template <int VEC, bool GATE, int D>
+__device__ __forceinline__ void bwd_b_chunk(const float* __restrict__ g_x, int64_t ldgx,
+                                            const float* __restrict__ g_e, const float* __restrict__ e_hat,
+                                            const float* __restrict__ Ax, int64_t ld,
+                                            const float* __restrict__ x_tilde, const float* __restrict__ den,
+                                            const float* __restrict__ r_edge, const float* g_Ce, int d, int c,
+                                            const int* tgt, const int* eids, const NodeBlock& blk,
+                                            const Vec<VEC>& bxj, Vec<VEC>& gbx, Vec<VEC>& gex) {
+  int64_t ti[D];
+  bool in[D];
+  Vec<VEC> eh[D], gx[D], dn[D], p0[D];
+  float rr[D];
+#pragma unroll
+  for (int u = 0; u < D; ++u) {
+    ti[u] = tgt[u];
+    const int64_t id = eids[u];
+    in[u] = ti[u] >= blk.n0 && ti[u] < blk.n1;
+    eh[u] = Vec<VEC>::load(e_hat + id * d + c);
+    gx[u] = Vec<VEC>::load(g_x + ti[u] * ldgx + c);
+    dn[u] = Vec<VEC>::load(den + ti[u] * d + c);
+    p0[u] = Vec<VEC>::load((in[u] ? g_Ce : g_e) + id * d + c);   // this workgroup's delta row, or g_e to rebuild it
+    rr[u] = GATE ? r_edge[id] : 1.0f;
+  }
+#pragma unroll
+  for (int u = 0; u < D; ++u) {
+    Vec<VEC> xt = Vec<VEC>::zero(), axi = Vec<VEC>::zero();
+    if (!in[u]) {                                // ~10-15 % of the edges: one more round trip
+      xt = Vec<VEC>::load(x_tilde + ti[u] * d + c);
+      axi = Vec<VEC>::load(Ax + ti[u] * ld + c);
+    }
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      const float ai = gx[u][v] * (1.0f / (dn[u][v] + 1e-6f));
+      const float s = sigmoidf_fast(eh[u][v]);
+      float dl = p0[u][v];
+      if (!in[u]) {
+        float sp = s * (1.0f - s);
+        if (GATE) sp = sp * rr[u];
+        dl = (dl + (ai * bxj[v]) * sp) + (-ai * (xt[v] - axi[v])) * sp;   // b_i = -a_i aggr_i
+      }
+      gex[v] += dl;
+      gbx[v] += (GATE ? s * rr[u] : s) * ai;
+    }
+  }
+}
+
+template <int VEC, bool GATE>
+__device__ __forceinline__ void bwd_b_rows(const float* __restrict__ g_x, int64_t ldgx,
+                                           const float* __restrict__ g_e, const float* __restrict__ e_hat,
+                                           const float* __restrict__ Ax, const float* __restrict__ Bx, int64_t ld,
+                                           const float* __restrict__ x_tilde, const float* __restrict__ den,
+                                           const int* rq, const int* tgt, const int* eids, const NodeBlock& blk,
+                                           int d, int row, int npi, int c, const float* g_Ce,
+                                           float* __restrict__ g_Bx, float* __restrict__ g_Ex, int64_t ldg,
+                                           const float* __restrict__ r_edge) {
+#define GPS_BWD_B(DD) bwd_b_chunk<VEC, GATE, DD>(g_x, ldgx, g_e, e_hat, Ax, ld, x_tilde, den, r_edge, g_Ce, d, c, \
+                                                 tgt + k, eids + k, blk, bxj, gbx, gex)
+  for (int64_t node = blk.n0 + row; node < blk.n1; node += npi) {
+    const int beg = rq[node - blk.n0], end = rq[node - blk.n0 + 1];
+    const Vec<VEC> bxj = Vec<VEC>::load(Bx + node * ld + c);
+    Vec<VEC> gbx = Vec<VEC>::zero(), gex = Vec<VEC>::zero();
+    int k = beg;
+    for (; k + 4 < end; k += 4) GPS_BWD_B(4);
+    switch (end - k) {
+      case 1: GPS_BWD_B(1); break;
+      case 2: GPS_BWD_B(2); break;
+      case 3: GPS_BWD_B(3); break;
+      case 4: GPS_BWD_B(4); break;
+      default: break;
+    }
+    gbx.store(g_Bx + node * ldg + c);
+    gex.store(g_Ex + node * ldg + c);
+  }
+#undef GPS_BWD_B
+}
+
 template <int VEC, bool GATE>
 __global__ __launch_bounds__(GG_T) void k_gatedgcn_bwd(
     const float* __restrict__ g_x, int64_t ldgx, const float* __restrict__ g_e, const float* __restrict__ e_hat,
@@ -160,108 +382,44 @@ __global__ __launch_bounds__(GG_T) void k_gatedgcn_bwd(
   // ---- phase A: keyed by target ------------------------------------------------------------------
   if (active) {
     const int e0 = s_rp[0];
-    for (int64_t node = blk.n0 + row; node < blk.n1; node += npi) {
-      const int beg = s_rp[node - blk.n0], end = s_rp[node - blk.n0 + 1];
-      const Vec<VEC> gx = Vec<VEC>::load(g_x + node * ldgx + c);
-      const Vec<VEC> dn = Vec<VEC>::load(den + node * (int64_t)d + c);
-      Vec<VEC> num = Vec<VEC>::zero();
-      for (int k = beg; k < end; ++k) {       // recompute num_i = sum_j sig_ij Bx_j (fwd order)
-        const int64_t j = st_d ? s_src[k - e0] : src[k];
-        const int64_t id = st_d ? s_eid[k - e0] : eid[k];
-        const Vec<VEC> eh = Vec<VEC>::load(e_hat + id * d + c);
-        const Vec<VEC> bx = Vec<VEC>::load(Bx + j * ld + c);
-        const float rr = GATE ? r_edge[id] : 1.0f;
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-          float s = sigmoidf_fast(eh[v]);
-          if (GATE) s = s * rr;
-          num[v] += s * bx[v];
-        }
-      }
-      Vec<VEC> a, b, gdx = Vec<VEC>::zero();
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) {
-        const float inv = 1.0f / (dn[v] + 1e-6f);
-        a[v] = gx[v] * inv;
-        b[v] = -a[v] * (num[v] * inv);
-      }
-      for (int k = beg; k < end; ++k) {       // the rows below were just touched: L1 / L2 hits
-        const int64_t j = st_d ? s_src[k - e0] : src[k];
-        const int64_t id = st_d ? s_eid[k - e0] : eid[k];
-        const Vec<VEC> eh = Vec<VEC>::load(e_hat + id * d + c);
-        const Vec<VEC> ge = Vec<VEC>::load(g_e + id * d + c);
-        const Vec<VEC> bx = Vec<VEC>::load(Bx + j * ld + c);
-        const float rr = GATE ? r_edge[id] : 1.0f;
-        Vec<VEC> dl;
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-          const float s = sigmoidf_fast(eh[v]);
-          float gs = a[v] * bx[v] + b[v];        // gradient wrt the (gated) sigma
-          if (GATE) gs = gs * rr;
-          dl[v] = ge[v] + gs * (s * (1.0f - s));
-          gdx[v] += dl[v];
-        }
-        dl.store(g_Ce + id * d + c);
-      }
-      if (g_Ax) gx.store(g_Ax + node * ldg + c);
-      gdx.store(g_Dx + node * ldg + c);
-    }
+    if (st_d)
+      bwd_a_rows<VEC, GATE>(g_x, ldgx, g_e, e_hat, Bx, ld, den, s_rp, s_src - e0, s_eid - e0, blk, d, row, npi, c,
+                            g_Ce, g_Ax, g_Dx, ldg, r_edge);
+    else
+      bwd_a_rows<VEC, GATE>(g_x, ldgx, g_e, e_hat, Bx, ld, den, s_rp, src, eid, blk, d, row, npi, c, g_Ce, g_Ax,
+                            g_Dx, ldg, r_edge);
   }
   __threadfence_block();
   __syncthreads();            // this workgroup's g_Ce rows are visible to all of its lanes (same CU)
   // ---- phase B: keyed by source ------------------------------------------------------------------
   if (!active) return;
   const int q0 = s_rq[0];
-  for (int64_t node = blk.n0 + row; node < blk.n1; node += npi) {
-    const int beg = s_rq[node - blk.n0], end = s_rq[node - blk.n0 + 1];
-    const Vec<VEC> bxj = Vec<VEC>::load(Bx + node * ld + c);
-    Vec<VEC> gbx = Vec<VEC>::zero(), gex = Vec<VEC>::zero();
-    for (int k = beg; k < end; ++k) {
-      const int64_t i = st_s ? s_dst[k - q0] : dst[k];
-      const int64_t id = st_s ? s_eid2[k - q0] : eid_s[k];
-      const Vec<VEC> eh = Vec<VEC>::load(e_hat + id * d + c);
-      const Vec<VEC> gx = Vec<VEC>::load(g_x + i * ldgx + c);
-      const Vec<VEC> dn = Vec<VEC>::load(den + i * d + c);
-      const float rr = GATE ? r_edge[id] : 1.0f;
-      Vec<VEC> dl;
-      const bool internal = i >= blk.n0 && i < blk.n1;
-      if (internal) {
-        dl = Vec<VEC>::load(g_Ce + id * d + c);
-      } else {
-        const Vec<VEC> ge = Vec<VEC>::load(g_e + id * d + c);
-        const Vec<VEC> xt = Vec<VEC>::load(x_tilde + i * d + c);
-        const Vec<VEC> axi = Vec<VEC>::load(Ax + i * ld + c);
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-          const float ai = gx[v] / (dn[v] + 1e-6f);
-          const float s = sigmoidf_fast(eh[v]);
-          float gs = ai * bxj[v] - ai * (xt[v] - axi[v]);   // a_i Bx_j + b_i,  b_i = -a_i aggr_i
-          if (GATE) gs = gs * rr;
-          dl[v] = ge[v] + gs * (s * (1.0f - s));
-        }
-      }
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) {
-        float s = sigmoidf_fast(eh[v]);
-        if (GATE) s = s * rr;
-        gex[v] += dl[v];
-        gbx[v] += s * (gx[v] / (dn[v] + 1e-6f));
-      }
-    }
-    gbx.store(g_Bx + node * ldg + c);
-    gex.store(g_Ex + node * ldg + c);
-  }
+  if (st_s)
+    bwd_b_rows<VEC, GATE>(g_x, ldgx, g_e, e_hat, Ax, Bx, ld, x_tilde, den, s_rq, s_dst - q0, s_eid2 - q0, blk, d,
+                          row, npi, c, g_Ce, g_Bx, g_Ex, ldg, r_edge);
+  else
+    bwd_b_rows<VEC, GATE>(g_x, ldgx, g_e, e_hat, Ax, Bx, ld, x_tilde, den, s_rq, dst, eid_s, blk, d, row, npi, c,
+                          g_Ce, g_Bx, g_Ex, ldg, r_edge);
 }
 
 inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
-// Node rows per workgroup: aim at ~2 workgroups per CU (512 in flight = one full wave of the chip), never fewer
-// rows than one pass of the workgroup, never more than the LDS rowptr slice holds.
-struct Plan { int npi, nb; unsigned grid; };
+// Launch shape.  Threads per workgroup (GPS_GG_THREADS, default 768 = 12 wavefronts) and the number of workgroups
+// aimed at (GPS_GG_TARGET_WG, default 512) are read once; node rows per workgroup = N / target rounded up to whole
+// passes, never more than the LDS rowptr slice holds.
+struct Plan { int threads, npi, nb; unsigned grid; };
+inline int env_int(const char* name, int dflt) {
+  const char* v = getenv(name);
+  return v && *v ? atoi(v) : dflt;
+}
 inline Plan plan_for(int64_t N, int lanes_per_row) {
+  static const int cfg_threads = env_int("GPS_GG_THREADS", GG_T);
+  static const int cfg_target = env_int("GPS_GG_TARGET_WG", 512);
   Plan p;
-  p.npi = GG_T / lanes_per_row;
-  int64_t nb = (N + 511) / 512;
+  p.threads = cfg_threads < 64 ? 64 : (cfg_threads > GG_T ? GG_T : (cfg_threads / 64) * 64);
+  if (p.threads < lanes_per_row) p.threads = GG_T;
+  p.npi = p.threads / lanes_per_row;
+  int64_t nb = (N + cfg_target - 1) / cfg_target;
   nb = ((nb + p.npi - 1) / p.npi) * p.npi;
   const int cap = (GG_MAXNB / p.npi) * p.npi;
   if (nb > cap) nb = cap;
@@ -275,10 +433,10 @@ inline Plan plan_for(int64_t N, int lanes_per_row) {
 }  // namespace
 
 #define GPS_GG_FWD(SAVE, GATE)                                                                       \
-  k_gatedgcn_fwd<VEC, SAVE, GATE><<<pl.grid, GG_T, 0, s>>>(Ax, Bx, Dx, Ex, ld_node, Ce, rowptr_dst,  \
+  k_gatedgcn_fwd<VEC, SAVE, GATE><<<pl.grid, pl.threads, 0, s>>>(Ax, Bx, Dx, Ex, ld_node, Ce, rowptr_dst,  \
       src_by_dst, eid_by_dst, N, d, x_tilde, e_hat, den, r_edge, pl.nb, pl.npi)
 #define GPS_GG_BWD(GATE)                                                                             \
-  k_gatedgcn_bwd<VEC, GATE><<<pl.grid, GG_T, 0, s>>>(g_x, ld_gx, g_e, e_hat, Ax, Bx, ld_node, x_tilde, \
+  k_gatedgcn_bwd<VEC, GATE><<<pl.grid, pl.threads, 0, s>>>(g_x, ld_gx, g_e, e_hat, Ax, Bx, ld_node, x_tilde, \
       den, rowptr_dst, src_by_dst, eid_by_dst, rowptr_src, dst_by_src, eid_by_src, N, d, g_Ce,        \
       g_Ax == g_x ? nullptr : g_Ax, g_Bx, g_Dx, g_Ex, ld_gnode, r_edge, pl.nb, pl.npi)
 

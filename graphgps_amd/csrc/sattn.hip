@@ -1,0 +1,463 @@
+// Segment attention, block form: one wavefront per (graph, 64-query block, head), K-side operands resident in registers.
+//
+// Same arithmetic and lane algebra as seg_attention.hip (the reference's to_dense_batch -> nn.MultiheadAttention
+// core -> un-pad path, graphgps/layer/gps_layer.py:199-201,234-241); what changes is how much work one wavefront
+// owns.  At molecule sizes the core is latency- and VALU-issue-bound, not flop-bound (0.36 GFLOP against 46.5 MB per
+// layer; ~775 VALU instructions around 56 MFMAs per wave in the per-(16-row tile, head) kernels, every query tile of
+// a graph re-loading and re-addressing that graph's K / V).  Here a wavefront
+//   * loads the K-side operands of a 64-key block ONCE -- row slices for S^T = K Q^T, column form of V for
+//     O^T = V^T P^T -- with every load issued before the first use (one memory round trip), keeps them in registers
+//     and serves ALL (up to 4) query tiles of its 64-query block from them: K / V loads, their addressing and the
+//     masking selects are amortised over the query tiles, and a graph of <= 64 nodes reads each K / V element once
+//     per head instead of once per (head, query tile);
+//   * takes one dropout hash per two adjacent keys (attn_common.hpp);
+//   * needs no LDS and no barrier in the forward, so every (graph, head) of a 256-molecule batch is resident at once
+//     (4096 wavefronts, 16 per CU): nothing queues behind anything.  (A workgroup-per-graph variant that staged Q | K | V
+//     rows through LDS -- fully coalesced, each line read exactly once -- was built and measured first: 43 us against
+//     27 us for the round-1 kernel at P30.  76.8 KB of LDS per workgroup left 8 wavefronts per CU, the ~1900 tile
+//     slots that start no 64-row block still had to wait for an LDS allocation to find that out, and the problem is
+//     bound by latency and issue slots, not by the 1.5x re-read traffic the staging removed.)
+// Both kernels cover batches whose longest graph has <= 64 nodes (the caller passes that bound, known to the host
+// from `ptr` before the batch ever reaches the device); anything longer takes the per-tile kernels of
+// seg_attention.hip, which walk the keys in blocks with the online softmax.
+//
+// Backward (k_sattn_bwd, graphs of <= 64 nodes): ONE launch per layer instead of two.  S^T, P and dS are computed once
+// per (query tile, key tile) in the query-column orientation (what dQ^T = K^T dS^T needs), then P_drop and dS are
+// transposed through a 2.5 KB per-wave LDS scratch into the key-column orientation that dV^T = dO^T P and
+// dK^T = Q^T dS need -- the softmax / dropout VALU work is done once instead of twice.  delta = rowsum(dO o O) is
+// formed on the fly.
+#include <cstdlib>
+
+#include "attn_common.hpp"
+
+namespace {
+using namespace attn;
+
+constexpr int SA_ROWS = 64;
+
+template <int DH>
+struct SGeo {
+  static constexpr int KPL = DH / 4;          // contraction elements per lane group
+  static constexpr int DT = (DH + 15) / 16;   // 16-wide output tiles along dh
+  static_assert(DH % 8 == 0, "row-slice loads are 8-byte");
+};
+
+// KPL contiguous floats of row `row` (< nrows, else zeros) for this lane group: 8-byte loads off a wave-uniform base
+template <int KPL>
+__device__ __forceinline__ void row_slice(const float* __restrict__ base, uint32_t ld, int row, int nrows, int col,
+                                          float scale, float (&dst)[KPL]) {
+  const bool ok = row < nrows;
+  const float2* p = reinterpret_cast<const float2*>(base + __umul24((uint32_t)(ok ? row : 0), ld) + col);
+#pragma unroll
+  for (int c = 0; c < KPL / 2; ++c) {
+    const float2 v = ok ? p[c] : make_float2(0.f, 0.f);
+    dst[2 * c] = v.x * scale;
+    dst[2 * c + 1] = v.y * scale;
+  }
+}
+// element [row][col] (zero outside the graph / the head)
+__device__ __forceinline__ float col_elem(const float* __restrict__ base, uint32_t ld, int row, int nrows, int col,
+                                          bool col_ok) {
+  const bool ok = col_ok && row < nrows;
+  const float v = base[__umul24((uint32_t)(ok ? row : 0), ld) + (ok ? col : 0)];
+  return ok ? v : 0.0f;
+}
+
+struct Item {
+  int n0, n, q0, nq, h;
+  bool live;
+};
+// wavefront -> (tile slot, head); only the slot that starts a 64-row block of its graph is live
+__device__ __forceinline__ Item item_setup(const int32_t* __restrict__ ptr, const int32_t* __restrict__ tile_graph,
+                                           const int32_t* __restrict__ tile_row0, int64_t n_work, int H) {
+  Item it;
+  it.live = false;
+  const int64_t wi = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (wi >= n_work) return it;
+  const int64_t tile = wi / H;
+  it.h = (int)(wi - tile * H);
+  const int g = tile_graph[tile];
+  if (g < 0) return it;
+  it.n0 = ptr[g];
+  it.n = ptr[g + 1] - it.n0;
+  it.q0 = tile_row0[tile] - it.n0;
+  if (it.q0 & (SA_ROWS - 1)) return it;
+  it.nq = min(SA_ROWS, it.n - it.q0);
+  it.live = true;
+  return it;
+}
+
+// =============================================================================================================
+// forward
+// =============================================================================================================
+template <int DH, bool DROP>
+__global__ __launch_bounds__(256, 4) void k_sattn_fwd(
+    const float* __restrict__ qkv, int64_t ld64, const int32_t* __restrict__ ptr,
+    const int32_t* __restrict__ tile_graph, const int32_t* __restrict__ tile_row0, int64_t n_work, int64_t N, int H,
+    float scale, uint32_t thr16, float inv_keep, uint64_t seed, const uint64_t* __restrict__ salt,
+    float* __restrict__ out, float* __restrict__ lse) {
+  using G = SGeo<DH>;
+  constexpr int KPL = G::KPL, DT = G::DT;
+  const Item it = item_setup(ptr, tile_graph, tile_row0, n_work, H);
+  if (!it.live || it.q0 != 0) return;         // host guarantees n <= 64: one block per graph
+  seed = gps::salted_seed(seed, salt);
+  const int lane = threadIdx.x & 63, i = lane & 15, grp = lane >> 4;
+  const int h = it.h, d = H * DH;
+  const uint32_t ld = (uint32_t)ld64;
+  const float* __restrict__ Qb = qkv + (int64_t)it.n0 * ld64 + h * DH;   // wave-uniform bases
+  const float* __restrict__ Kb = Qb + d;
+  const float* __restrict__ Vb = Qb + 2 * d;
+  float* __restrict__ Ob = out + (int64_t)it.n0 * d + h * DH;
+  const int nt = (it.n + 15) >> 4;            // live 16-row tiles (queries and keys alike)
+
+  // K-side operands of the graph: every load issued before the first use, resident for all query tiles
+  float kv[4][KPL];
+  float vv[DT][4][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+    if (t < nt) {
+      row_slice<KPL>(Kb, ld, 16 * t + i, it.n, grp * KPL, 1.0f, kv[t]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+          vv[dt][t][r] = col_elem(Vb, ld, 16 * t + 4 * grp + r, it.n, dt * 16 + i, dt * 16 + i < DH);
+    }
+  float qv[KPL];
+  row_slice<KPL>(Qb, ld, i, it.n, grp * KPL, scale, qv);
+#pragma unroll 1
+  for (int qt = 0; qt < nt; ++qt) {
+    const int ql = 16 * qt + i;
+    f32x4 s[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int c = 0; c < KPL; ++c)            // key tiles interleaved: independent accumulator chains
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (t < nt) s[t] = mfma16(kv[t][c], qv[c], s[t]);            // S^T[key][query]
+    if (qt + 1 < nt) row_slice<KPL>(Qb, ld, ql + 16, it.n, grp * KPL, scale, qv);   // next tile's Q, in flight
+    float mloc = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (t < nt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = 16 * t + 4 * grp + r;
+          s[t][r] = key < it.n ? s[t][r] : -INFINITY;
+          mloc = fmaxf(mloc, s[t][r]);
+        }
+      }
+    const float m = group_max(mloc);
+    const uint32_t rh = DROP ? row_hash((uint32_t)(it.n0 + ql) * (uint32_t)H + (uint32_t)h, seed) : 0u;
+    float psum = 0.0f;
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (t < nt) {
+        uint32_t h0 = 0, h1 = 0;
+        if (DROP) {
+          const uint32_t kp = (uint32_t)(16 * t + 4 * grp) >> 1;
+          h0 = pair_hash(rh, kp);
+          h1 = pair_hash(rh, kp + 1);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float p = sm_exp(s[t][r] - m);       // masked keys: exp(-inf) = 0
+          psum += p;
+          if (DROP) {
+            const uint32_t hh = r < 2 ? h0 : h1;
+            const bool keep = (r & 1) ? keep_hi(hh, thr16) : keep_lo(hh, thr16);
+            p = keep ? p * inv_keep : 0.0f;
+          }
+          s[t][r] = p;
+        }
+      }
+    f32x4 oacc[DT];
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) oacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (t < nt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt)      // O^T[dh][query] += V^T[dh][key] P^T[key][query]
+            oacc[dt] = mfma16(vv[dt][t][r], s[t][r], oacc[dt]);
+      }
+    const float ltot = group_sum(psum);
+    const float inv_l = 1.0f / ltot;
+    if (ql < it.n) {
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const int col = dt * 16 + 4 * grp;
+        if (col < DH) {
+          const f32x4 o = oacc[dt] * inv_l;
+          *reinterpret_cast<float4*>(Ob + (int64_t)ql * d + col) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+      }
+      if (grp == 0) lse[(int64_t)h * N + it.n0 + ql] = m + logf(ltot);
+    }
+  }
+}
+
+// =============================================================================================================
+// backward, graphs of <= 64 nodes: dQ, dK, dV in one launch
+// =============================================================================================================
+template <int DH, bool DROP>
+__global__ __launch_bounds__(256, 2) void k_sattn_bwd(
+    const float* __restrict__ d_out, const float* __restrict__ qkv, int64_t ld64, const float* __restrict__ out,
+    const float* __restrict__ lse, const int32_t* __restrict__ ptr, const int32_t* __restrict__ tile_graph,
+    const int32_t* __restrict__ tile_row0, int64_t n_work, int64_t N, int H, float scale, uint32_t thr16,
+    float inv_keep, uint64_t seed, const uint64_t* __restrict__ salt, float* __restrict__ d_qkv, int64_t ldg) {
+  using G = SGeo<DH>;
+  constexpr int KPL = G::KPL, DT = G::DT;
+  constexpr int PT = 20;                      // transpose scratch pitch (floats): 16 + 4, rows stay 16-byte aligned
+  __shared__ __attribute__((aligned(16))) float sT[4][2][16 * PT];   // per-wave transpose scratch (P_drop, dS)
+  const Item it = item_setup(ptr, tile_graph, tile_row0, n_work, H);
+  if (!it.live || it.q0 != 0) return;         // host guarantees n <= 64: one block per graph
+  seed = gps::salted_seed(seed, salt);
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, grp = lane >> 4;
+  const int h = it.h, d = H * DH;
+  const uint32_t ld = (uint32_t)ld64, du = (uint32_t)d;
+  const float* __restrict__ Qb = qkv + (int64_t)it.n0 * ld64 + h * DH;
+  const float* __restrict__ Kb = Qb + d;
+  const float* __restrict__ Vb = Qb + 2 * d;
+  const float* __restrict__ dOb = d_out + (int64_t)it.n0 * d + h * DH;
+  const float* __restrict__ Ob = out + (int64_t)it.n0 * d + h * DH;
+  const float* __restrict__ lse_b = lse + (int64_t)h * N + it.n0;
+  const int nt = (it.n + 15) >> 4;            // live 16-row tiles (queries and keys alike)
+  float* __restrict__ tP = &sT[wave][0][0];
+  float* __restrict__ tS = &sT[wave][1][0];
+
+  // K-side operands, resident for all query tiles: row slices of K and V (S^T = K Q^T, dP^T = V dO^T) and the
+  // column form of K (dQ^T = K^T dS^T)
+  float kv[4][KPL], vk[4][KPL];
+  float kc[DT][4][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+    if (t < nt) {
+      row_slice<KPL>(Kb, ld, 16 * t + i, it.n, grp * KPL, 1.0f, kv[t]);
+      row_slice<KPL>(Vb, ld, 16 * t + i, it.n, grp * KPL, 1.0f, vk[t]);
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt)
+          kc[dt][t][r] = col_elem(Kb, ld, 16 * t + 4 * grp + r, it.n, dt * 16 + i, dt * 16 + i < DH);
+    }
+  f32x4 dk[4][DT], dv[4][DT];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int dt = 0; dt < DT; ++dt) {
+      dk[t][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      dv[t][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+
+#pragma unroll 1
+  for (int qt = 0; qt < nt; ++qt) {
+    const int ql = 16 * qt + i;               // this lane's query (column of the ^T tiles)
+    const bool q_ok = ql < it.n;
+    // everything this query tile needs from memory, requested up front
+    float qv[KPL], dov[KPL], ov[KPL];
+    row_slice<KPL>(Qb, ld, ql, it.n, grp * KPL, scale, qv);
+    row_slice<KPL>(dOb, du, ql, it.n, grp * KPL, 1.0f, dov);
+    row_slice<KPL>(Ob, du, ql, it.n, grp * KPL, 1.0f, ov);
+    float qc[DT][4], dc[DT][4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) {
+        const bool in = dt * 16 + i < DH;
+        qc[dt][r] = col_elem(Qb, ld, 16 * qt + 4 * grp + r, it.n, dt * 16 + i, in) * scale;
+        dc[dt][r] = col_elem(dOb, du, 16 * qt + 4 * grp + r, it.n, dt * 16 + i, in);
+      }
+    const float lse_q = lse_b[min(ql, it.n - 1)];
+    // delta_q = sum_c dO[q][c] O[q][c] over the head's dh columns
+    float dl_part = 0.0f;
+#pragma unroll
+    for (int c = 0; c < KPL; ++c) dl_part += dov[c] * ov[c];
+    const float dl_q = group_sum(dl_part);
+    const uint32_t rh = DROP ? row_hash((uint32_t)(it.n0 + ql) * (uint32_t)H + (uint32_t)h, seed) : 0u;
+
+    f32x4 s[4], dp[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      dp[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+#pragma unroll
+    for (int c = 0; c < KPL; ++c)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (t < nt) {
+          s[t] = mfma16(kv[t][c], qv[c], s[t]);       // S^T[key][query]
+          dp[t] = mfma16(vk[t][c], dov[c], dp[t]);    // dP^T[key][query]
+        }
+    // P, dropout, dS^T; s <- dS^T (B operand of dQ^T), dp <- P_drop^T
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (t < nt) {
+        uint32_t h0 = 0, h1 = 0;
+        if (DROP) {
+          const uint32_t kp = (uint32_t)(16 * t + 4 * grp) >> 1;
+          h0 = pair_hash(rh, kp);
+          h1 = pair_hash(rh, kp + 1);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = 16 * t + 4 * grp + r;
+          const bool live = key < it.n && q_ok;
+          const float p = live ? sm_exp(s[t][r] - lse_q) : 0.0f;
+          float dpe = dp[t][r], pd = p;
+          if (DROP) {
+            const uint32_t hh = r < 2 ? h0 : h1;
+            const bool keep = (r & 1) ? keep_hi(hh, thr16) : keep_lo(hh, thr16);
+            pd = keep ? p * inv_keep : 0.0f;
+            dpe = keep ? dpe * inv_keep : 0.0f;
+          }
+          s[t][r] = p * (dpe - dl_q);                  // dS^T[key][query]
+          dp[t][r] = pd;                               // P_drop^T[key][query]
+        }
+      }
+    // dQ^T[dh][query] = sum_key K^T[dh][key] dS^T[key][query]
+    {
+      f32x4 acc[DT];
+#pragma unroll
+      for (int dt = 0; dt < DT; ++dt) acc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (t < nt) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int dt = 0; dt < DT; ++dt) acc[dt] = mfma16(kc[dt][t][r], s[t][r], acc[dt]);
+        }
+      if (q_ok) {
+        float* __restrict__ Gq = d_qkv + (int64_t)(it.n0 + ql) * ldg + h * DH;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const int col = dt * 16 + 4 * grp;
+          if (col < DH) {
+            const f32x4 o = acc[dt] * scale;
+            *reinterpret_cast<float4*>(Gq + col) = make_float4(o[0], o[1], o[2], o[3]);
+          }
+        }
+      }
+    }
+    // per key tile: transpose (P_drop^T, dS^T)[key][query] -> [query][key] through the wave's scratch, then
+    // dV^T[dh][key] += dO^T[dh][q] P_drop[q][key],  dK^T[dh][key] += (scale Q)^T[dh][q] dS[q][key]
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+      if (t < nt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          tP[(4 * grp + r) * PT + i] = dp[t][r];      // row = key (local to the tile), column = query
+          tS[(4 * grp + r) * PT + i] = s[t][r];
+        }
+        // same wave wrote and reads: LDS operations of one wave complete in order (the fence only pins the
+        // compiler's ordering of the stores above against the loads below)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const float4 pT = *reinterpret_cast<const float4*>(tP + i * PT + 4 * grp);   // [key i][query 4grp..+3]
+        const float4 sT_ = *reinterpret_cast<const float4*>(tS + i * PT + 4 * grp);
+        const float pv[4] = {pT.x, pT.y, pT.z, pT.w}, sv[4] = {sT_.x, sT_.y, sT_.z, sT_.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            dv[t][dt] = mfma16(dc[dt][r], pv[r], dv[t][dt]);
+            dk[t][dt] = mfma16(qc[dt][r], sv[r], dk[t][dt]);
+          }
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");   // the next tile overwrites the scratch
+        __builtin_amdgcn_wave_barrier();
+      }
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+    if (t < nt) {
+      const int kl = 16 * t + i;
+      if (kl < it.n) {
+        float* __restrict__ Gk = d_qkv + (int64_t)(it.n0 + kl) * ldg + d + h * DH;
+        float* __restrict__ Gv = Gk + d;
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const int col = dt * 16 + 4 * grp;
+          if (col < DH) {
+            *reinterpret_cast<float4*>(Gk + col) = make_float4(dk[t][dt][0], dk[t][dt][1], dk[t][dt][2], dk[t][dt][3]);
+            *reinterpret_cast<float4*>(Gv + col) = make_float4(dv[t][dt][0], dv[t][dt][1], dv[t][dt][2], dv[t][dt][3]);
+          }
+        }
+      }
+    }
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) % 16) == 0; }
+
+}  // namespace
+
+namespace attn {
+
+static bool sattn_dh_ok(int dh) { return dh == 8 || dh == 16 || dh == 24 || dh == 32; }
+
+bool sattn_applicable(const void* qkv, int64_t ld_qkv, const void* out, int H, int dh) {
+  const char* sw = getenv("GPS_SATTN");
+  if (sw && sw[0] == '0') return false;
+  return sattn_dh_ok(dh) && ld_qkv % 4 == 0 && (H * dh) % 4 == 0 && al16(qkv) && al16(out);
+}
+
+// Launch the block-form forward.  Preconditions: sattn_applicable().
+void sattn_fwd_launch(const float* qkv, int64_t ld_qkv, const int32_t* ptr, const int32_t* tile_graph,
+                      const int32_t* tile_row0, int64_t max_tiles, int64_t N, int H, int dh, float scale,
+                      float p_drop, uint64_t seed, float* out, float* lse, hipStream_t s) {
+  const uint32_t thr16 = drop_thr16(p_drop);
+  const float inv_keep = p_drop > 0.0f ? drop_inv_keep(thr16) : 1.0f;
+  const int64_t n_work = max_tiles * H;
+  const unsigned grid = gps::grid_for(n_work, 4);
+#define SA_FWD(D)                                                                                               \
+  do {                                                                                                          \
+    if (p_drop > 0.0f)                                                                                          \
+      k_sattn_fwd<D, true><<<grid, 256, 0, s>>>(qkv, ld_qkv, ptr, tile_graph, tile_row0, n_work, N, H, scale,    \
+                                                thr16, inv_keep, seed, gps::dropout_salt(), out, lse);           \
+    else                                                                                                        \
+      k_sattn_fwd<D, false><<<grid, 256, 0, s>>>(qkv, ld_qkv, ptr, tile_graph, tile_row0, n_work, N, H, scale,   \
+                                                 thr16, inv_keep, seed, gps::dropout_salt(), out, lse);          \
+  } while (0)
+  switch (dh) {
+    case 8: SA_FWD(8); break;
+    case 16: SA_FWD(16); break;
+    case 24: SA_FWD(24); break;
+    case 32: SA_FWD(32); break;
+  }
+#undef SA_FWD
+}
+
+// Launch the fused backward (every graph has <= 64 nodes).  Preconditions: sattn_applicable(), aligned d_out / d_qkv.
+void sattn_bwd_launch(const float* d_out, const float* qkv, int64_t ld_qkv, const float* out, const float* lse,
+                      const int32_t* ptr, const int32_t* tile_graph, const int32_t* tile_row0, int64_t max_tiles,
+                      int64_t N, int H, int dh, float scale, float p_drop, uint64_t seed, float* d_qkv,
+                      int64_t ld_dqkv, hipStream_t s) {
+  const uint32_t thr16 = drop_thr16(p_drop);
+  const float inv_keep = p_drop > 0.0f ? drop_inv_keep(thr16) : 1.0f;
+  const int64_t n_work = max_tiles * H;
+  const unsigned grid = gps::grid_for(n_work, 4);
+#define SA_BWD(D)                                                                                               \
+  do {                                                                                                          \
+    if (p_drop > 0.0f)                                                                                          \
+      k_sattn_bwd<D, true><<<grid, 256, 0, s>>>(d_out, qkv, ld_qkv, out, lse, ptr, tile_graph, tile_row0,        \
+                                                n_work, N, H, scale, thr16, inv_keep, seed, gps::dropout_salt(), \
+                                                d_qkv, ld_dqkv);                                                 \
+    else                                                                                                        \
+      k_sattn_bwd<D, false><<<grid, 256, 0, s>>>(d_out, qkv, ld_qkv, out, lse, ptr, tile_graph, tile_row0,       \
+                                                 n_work, N, H, scale, thr16, inv_keep, seed,                     \
+                                                 gps::dropout_salt(), d_qkv, ld_dqkv);                           \
+  } while (0)
+  switch (dh) {
+    case 8: SA_BWD(8); break;
+    case 16: SA_BWD(16); break;
+    case 24: SA_BWD(24); break;
+    case 32: SA_BWD(32); break;
+  }
+#undef SA_BWD
+}
+
+}  // namespace attn

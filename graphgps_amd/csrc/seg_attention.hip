@@ -20,6 +20,7 @@
 // Lane algebra validated against a numpy model of the MFMA lane map before being written
 // (see DESIGN.md "segment attention"); numerics validated against the CPU oracle in
 // tests/test_hip_ops.py.
+#include "attn_common.hpp"
 #include "gps_common.hpp"
 
 #ifndef GPS_ATTN_KT
@@ -31,38 +32,7 @@
 
 namespace {
 
-typedef float f32x4 __attribute__((ext_vector_type(4)));
-
-__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
-  return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
-}
-
-// --- counter-based dropout mask -------------------------------------------------------------
-// keep(seed, row id = query*H + head, key index local to the graph).  Mirrored bit-for-bit by
-// graphgps_amd/ops.py:attn_dropout_keep_mask (used by the parity tests).
-__device__ __forceinline__ uint32_t mix32(uint32_t x) {
-  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
-  return x;
-}
-__device__ __forceinline__ uint32_t row_hash(uint32_t rowid, uint64_t seed) {
-  return mix32(rowid ^ (uint32_t)seed) + (uint32_t)(seed >> 32);
-}
-__device__ __forceinline__ bool keep_elem(uint32_t rh, uint32_t key_local, float p_drop) {
-  const uint32_t r = mix32(rh + key_local * 0x9E3779B9U);
-  return (float)(r >> 8) * (1.0f / 16777216.0f) >= p_drop;
-}
-
-// exp for the softmax numerators: exp2(x * log2 e) on the transcendental unit (v_exp_f32).  Arguments are
-// <= 0 and rarely below -20, where the product's rounding costs <= 2e-6 relative -- inside the 1e-5 budget --
-// against ~8 extra VALU instructions per element for the correctly rounded expf (the kernels are
-// VALU-issue-bound).  GPS_ATTN_EXACT_EXP=1 at compile time restores expf.
-__device__ __forceinline__ float sm_exp(float x) {
-#ifdef GPS_ATTN_EXACT_EXP
-  return expf(x);
-#else
-  return __builtin_amdgcn_exp2f(x * 1.44269504088896341f);
-#endif
-}
+using namespace attn;
 
 template <int DH>
 struct Geo {
@@ -104,17 +74,6 @@ __device__ __forceinline__ void load_slice(const float* __restrict__ base, uint3
       dst[s] = (ok && in) ? v * scale : 0.0f;
     }
   }
-}
-
-__device__ __forceinline__ float group_max(float v) {  // over the 4 lane groups (same l&15)
-  v = fmaxf(v, __shfl_xor(v, 16));
-  v = fmaxf(v, __shfl_xor(v, 32));
-  return v;
-}
-__device__ __forceinline__ float group_sum(float v) {
-  v += __shfl_xor(v, 16);
-  v += __shfl_xor(v, 32);
-  return v;
 }
 
 // 4 consecutive output floats of one lane (columns col..col+3 of row `off`)
@@ -187,7 +146,7 @@ __device__ __forceinline__ Bias bias_setup(const float* bias, float* g_bias, int
 template <int DH, bool DROP, bool VEC, bool BIAS, int NT>
 __device__ __forceinline__ void attn_fwd_block(
     const float* __restrict__ Kb, const float* __restrict__ Vb, uint32_t ld, int kb, const Wave& w, int i,
-    int grp, const float (&qv)[Geo<DH>::KPL], uint32_t rh, float p_drop, float inv_keep, const Bias& bs,
+    int grp, const float (&qv)[Geo<DH>::KPL], uint32_t rh, uint32_t thr16, float inv_keep, const Bias& bs,
     uint32_t bq_off, float& m, float& lsum, f32x4 (&oacc)[Geo<DH>::DT]) {
   constexpr int KPL = Geo<DH>::KPL, DT = Geo<DH>::DT;
   float kv[NT][KPL];
@@ -247,7 +206,7 @@ __device__ __forceinline__ void attn_fwd_block(
       psum += p;
       if (DROP) {
         const uint32_t key_local = (uint32_t)(kb + 16 * t + 4 * grp + r);
-        p = keep_elem(rh, key_local, p_drop) ? p * inv_keep : 0.0f;
+        p = keep_elem(rh, key_local, thr16) ? p * inv_keep : 0.0f;
       }
       s[t][r] = p;
     }
@@ -286,7 +245,8 @@ __global__ __launch_bounds__(256) void k_attn_fwd(
   float qv[KPL];
   load_slice<DH, VEC>(Qb, row_off(ql, w.rmax, ld) + grp * KPL, q_ok, grp, scale, qv);
   const uint32_t rh = DROP ? row_hash((uint32_t)(w.n0 + ql) * (uint32_t)H + (uint32_t)w.h, seed) : 0u;
-  const float inv_keep = DROP ? 1.0f / (1.0f - p_drop) : 1.0f;
+  const uint32_t thr16 = drop_thr16(p_drop);
+  const float inv_keep = DROP ? drop_inv_keep(thr16) : 1.0f;
   const Bias bs = BIAS ? bias_setup(bias, nullptr, nmax, w, H) : Bias{nullptr, nullptr, 0u, 0u};
   const uint32_t bq_off = BIAS ? min((uint32_t)ql, bs.nlast) * bs.nmax : 0u;
 
@@ -298,10 +258,10 @@ __global__ __launch_bounds__(256) void k_attn_fwd(
   for (int kb = 0; kb < w.n; kb += 16 * KT) {
     const int nt = min(KT, (w.n - kb + 15) >> 4);  // wave-uniform
     switch (nt) {
-      case 1: attn_fwd_block<DH, DROP, VEC, BIAS, 1>(Kb, Vb, ld, kb, w, i, grp, qv, rh, p_drop, inv_keep, bs, bq_off, m, lsum, oacc); break;
-      case 2: attn_fwd_block<DH, DROP, VEC, BIAS, (KT >= 2 ? 2 : KT)>(Kb, Vb, ld, kb, w, i, grp, qv, rh, p_drop, inv_keep, bs, bq_off, m, lsum, oacc); break;
-      case 3: attn_fwd_block<DH, DROP, VEC, BIAS, (KT >= 3 ? 3 : KT)>(Kb, Vb, ld, kb, w, i, grp, qv, rh, p_drop, inv_keep, bs, bq_off, m, lsum, oacc); break;
-      default: attn_fwd_block<DH, DROP, VEC, BIAS, KT>(Kb, Vb, ld, kb, w, i, grp, qv, rh, p_drop, inv_keep, bs, bq_off, m, lsum, oacc); break;
+      case 1: attn_fwd_block<DH, DROP, VEC, BIAS, 1>(Kb, Vb, ld, kb, w, i, grp, qv, rh, thr16, inv_keep, bs, bq_off, m, lsum, oacc); break;
+      case 2: attn_fwd_block<DH, DROP, VEC, BIAS, (KT >= 2 ? 2 : KT)>(Kb, Vb, ld, kb, w, i, grp, qv, rh, thr16, inv_keep, bs, bq_off, m, lsum, oacc); break;
+      case 3: attn_fwd_block<DH, DROP, VEC, BIAS, (KT >= 3 ? 3 : KT)>(Kb, Vb, ld, kb, w, i, grp, qv, rh, thr16, inv_keep, bs, bq_off, m, lsum, oacc); break;
+      default: attn_fwd_block<DH, DROP, VEC, BIAS, KT>(Kb, Vb, ld, kb, w, i, grp, qv, rh, thr16, inv_keep, bs, bq_off, m, lsum, oacc); break;
     }
   }
   const float ltot = group_sum(lsum);
@@ -327,7 +287,7 @@ template <int DH, bool DROP, bool VEC, bool BIAS, int NT>
 __device__ __forceinline__ void attn_dq_block(
     const float* __restrict__ Kb, const float* __restrict__ Vb, uint32_t ld, int kb, const Wave& w, int i,
     int grp, const float (&qv)[Geo<DH>::KPL], const float (&dov)[Geo<DH>::KPL], float lse_q, float dl_q,
-    uint32_t rh, float p_drop, float inv_keep, const Bias& bs, uint32_t bq_off, bool q_ok,
+    uint32_t rh, uint32_t thr16, float inv_keep, const Bias& bs, uint32_t bq_off, bool q_ok,
     f32x4 (&acc)[Geo<DH>::DT]) {
   constexpr int KPL = Geo<DH>::KPL, DT = Geo<DH>::DT;
   float kv[NT][KPL], vv[NT][KPL];
@@ -381,7 +341,7 @@ __device__ __forceinline__ void attn_dq_block(
       if constexpr (BIAS) s[t][r] += bv[t][r];
       const float p = sm_exp(s[t][r] - lse_q);
       float dpe = dp[t][r];
-      if (DROP) dpe = keep_elem(rh, (uint32_t)key, p_drop) ? dpe * inv_keep : 0.0f;
+      if (DROP) dpe = keep_elem(rh, (uint32_t)key, thr16) ? dpe * inv_keep : 0.0f;
       s[t][r] = key < w.n ? p * (dpe - dl_q) : 0.0f;   // dS^T, reused as the B operand below
       if constexpr (BIAS) {                            // d(bias)[query][key] = dS[query][key]
         if (q_ok && key < w.n) bs.g[bq_off + (uint32_t)key] = s[t][r];
@@ -434,7 +394,8 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(
   const float dl_q = group_sum(dl_part);
   if (q_ok && grp == 0) delta[sidx] = dl_q;   // read by k_attn_bwd_dkv (same stream)
   const uint32_t rh = DROP ? row_hash((uint32_t)(w.n0 + ql) * (uint32_t)H + (uint32_t)w.h, seed) : 0u;
-  const float inv_keep = DROP ? 1.0f / (1.0f - p_drop) : 1.0f;
+  const uint32_t thr16 = drop_thr16(p_drop);
+  const float inv_keep = DROP ? drop_inv_keep(thr16) : 1.0f;
   const Bias bs = BIAS ? bias_setup(bias, g_bias, nmax, w, H) : Bias{nullptr, nullptr, 0u, 0u};
   const uint32_t bq_off = BIAS ? min((uint32_t)ql, bs.nlast) * bs.nmax : 0u;
 
@@ -445,10 +406,10 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dq(
   for (int kb = 0; kb < w.n; kb += 16 * KT) {
     const int nt = min(KT, (w.n - kb + 15) >> 4);  // wave-uniform
     switch (nt) {
-      case 1: attn_dq_block<DH, DROP, VEC, BIAS, 1>(Kb, Vb, ld, kb, w, i, grp, qv, dov, lse_q, dl_q, rh, p_drop, inv_keep, bs, bq_off, q_ok, acc); break;
-      case 2: attn_dq_block<DH, DROP, VEC, BIAS, (KT >= 2 ? 2 : KT)>(Kb, Vb, ld, kb, w, i, grp, qv, dov, lse_q, dl_q, rh, p_drop, inv_keep, bs, bq_off, q_ok, acc); break;
-      case 3: attn_dq_block<DH, DROP, VEC, BIAS, (KT >= 3 ? 3 : KT)>(Kb, Vb, ld, kb, w, i, grp, qv, dov, lse_q, dl_q, rh, p_drop, inv_keep, bs, bq_off, q_ok, acc); break;
-      default: attn_dq_block<DH, DROP, VEC, BIAS, KT>(Kb, Vb, ld, kb, w, i, grp, qv, dov, lse_q, dl_q, rh, p_drop, inv_keep, bs, bq_off, q_ok, acc); break;
+      case 1: attn_dq_block<DH, DROP, VEC, BIAS, 1>(Kb, Vb, ld, kb, w, i, grp, qv, dov, lse_q, dl_q, rh, thr16, inv_keep, bs, bq_off, q_ok, acc); break;
+      case 2: attn_dq_block<DH, DROP, VEC, BIAS, (KT >= 2 ? 2 : KT)>(Kb, Vb, ld, kb, w, i, grp, qv, dov, lse_q, dl_q, rh, thr16, inv_keep, bs, bq_off, q_ok, acc); break;
+      case 3: attn_dq_block<DH, DROP, VEC, BIAS, (KT >= 3 ? 3 : KT)>(Kb, Vb, ld, kb, w, i, grp, qv, dov, lse_q, dl_q, rh, thr16, inv_keep, bs, bq_off, q_ok, acc); break;
+      default: attn_dq_block<DH, DROP, VEC, BIAS, KT>(Kb, Vb, ld, kb, w, i, grp, qv, dov, lse_q, dl_q, rh, thr16, inv_keep, bs, bq_off, q_ok, acc); break;
     }
   }
   if (q_ok) {
@@ -472,7 +433,7 @@ __device__ __forceinline__ void attn_dkv_block(
     const float* __restrict__ Qb, const float* __restrict__ dOb, const float* __restrict__ lse_b,
     const float* __restrict__ delta_b, uint32_t ld, uint32_t d, int H, int qb, const Wave& w, int i, int grp,
     int kl, const float (&kv)[Geo<DH>::KPL], const float (&vv)[Geo<DH>::KPL], float scale, uint64_t seed,
-    float p_drop, float inv_keep, const Bias& bs, f32x4 (&dk)[Geo<DH>::DT], f32x4 (&dv)[Geo<DH>::DT]) {
+    uint32_t thr16, float inv_keep, const Bias& bs, f32x4 (&dk)[Geo<DH>::DT], f32x4 (&dv)[Geo<DH>::DT]) {
   constexpr int KPL = Geo<DH>::KPL, DT = Geo<DH>::DT;
   float qa[NT][KPL], da[NT][KPL];
   float qc[DT][NT][4], dc[DT][NT][4];
@@ -536,7 +497,7 @@ __device__ __forceinline__ void attn_dkv_block(
       float pd = pr;
       if (DROP) {
         const uint32_t rh = row_hash((uint32_t)(w.n0 + qq) * (uint32_t)H + (uint32_t)w.h, seed);
-        const bool keep = keep_elem(rh, (uint32_t)kl, p_drop);
+        const bool keep = keep_elem(rh, (uint32_t)kl, thr16);
         pd = keep ? pr * inv_keep : 0.0f;
         dpe = keep ? dpe * inv_keep : 0.0f;
       }
@@ -578,7 +539,8 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(
   const float* __restrict__ delta_b = delta + (int64_t)w.h * N + w.n0;
   const int kl = w.l0 + i;                  // local key row
   const bool k_ok = kl < w.n;
-  const float inv_keep = DROP ? 1.0f / (1.0f - p_drop) : 1.0f;
+  const uint32_t thr16 = drop_thr16(p_drop);
+  const float inv_keep = DROP ? drop_inv_keep(thr16) : 1.0f;
   const Bias bs = BIAS ? bias_setup(bias, nullptr, nmax, w, H) : Bias{nullptr, nullptr, 0u, 0u};
 
   float kv[KPL], vv[KPL];
@@ -596,10 +558,10 @@ __global__ __launch_bounds__(256) void k_attn_bwd_dkv(
   for (int qb = 0; qb < w.n; qb += 16 * QT) {
     if (QT > 1 && w.n - qb > 16)
       attn_dkv_block<DH, DROP, VEC, BIAS, QT>(Qb, dOb, lse_b, delta_b, ld, (uint32_t)d, H, qb, w, i, grp, kl, kv,
-                                              vv, scale, seed, p_drop, inv_keep, bs, dk, dv);
+                                              vv, scale, seed, thr16, inv_keep, bs, dk, dv);
     else
       attn_dkv_block<DH, DROP, VEC, BIAS, 1>(Qb, dOb, lse_b, delta_b, ld, (uint32_t)d, H, qb, w, i, grp, kl, kv,
-                                             vv, scale, seed, p_drop, inv_keep, bs, dk, dv);
+                                             vv, scale, seed, thr16, inv_keep, bs, dk, dv);
   }
   if (k_ok) {
     float* __restrict__ Gk = d_qkv + (int64_t)w.n0 * ldg64 + d + w.h * DH;
@@ -638,7 +600,8 @@ int gps_attn_supported_head_dim(int dh) {
 static int seg_attn_fwd_impl(const char* who, const float* qkv, int64_t ld_qkv, const float* bias,
                              int64_t nmax, const int32_t* ptr, const int32_t* tile_graph,
                              const int32_t* tile_row0, int64_t max_tiles, int64_t N, int H, int dh, float scale,
-                             float p_drop, uint64_t seed, float* out, float* lse, gps_stream_t stream) {
+                             float p_drop, uint64_t seed, float* out, float* lse, int64_t max_graph_nodes,
+                             gps_stream_t stream) {
   GPS_REQUIRE(N >= 0 && H > 0 && dh > 0 && max_tiles >= 0 && ld_qkv >= 3LL * H * dh,
               "%s: bad sizes N=%lld H=%d dh=%d ld=%lld", who, (long long)N, H, dh, (long long)ld_qkv);
   GPS_REQUIRE(p_drop >= 0.0f && p_drop < 1.0f, "%s: p_drop=%f outside [0,1)", who, p_drop);
@@ -655,6 +618,12 @@ static int seg_attn_fwd_impl(const char* who, const float* qkv, int64_t ld_qkv, 
   const int64_t n_work = max_tiles * H;
   const unsigned grid = gps::grid_for(n_work, 4);
   hipStream_t s = gps::as_stream(stream);
+  if (!bias && max_graph_nodes > 0 && max_graph_nodes <= 64 &&
+      attn::sattn_applicable(qkv, ld_qkv, out, H, dh)) {            // block form (sattn.hip)
+    attn::sattn_fwd_launch(qkv, ld_qkv, ptr, tile_graph, tile_row0, max_tiles, N, H, dh, scale, p_drop, seed, out,
+                           lse, s);
+    return gps::launch_status(who);
+  }
   const bool vec = ld_qkv % 4 == 0 && (H * dh) % 4 == 0 && al16(qkv) && al16(out);
 #define LAUNCH_FWD(D, DROP, VEC, BIAS)                                                                  \
   k_attn_fwd<D, DROP, VEC, BIAS><<<grid, 256, 0, s>>>(qkv, ld_qkv, ptr, tile_graph, tile_row0, n_work, N, H, \
@@ -683,7 +652,7 @@ static int seg_attn_bwd_impl(const char* who, const float* d_out, const float* q
                              const int32_t* ptr, const int32_t* tile_graph, const int32_t* tile_row0,
                              int64_t max_tiles, int64_t N, int H, int dh, float scale, float p_drop,
                              uint64_t seed, float* delta, float* d_qkv, int64_t ld_dqkv, float* d_bias,
-                             gps_stream_t stream) {
+                             int64_t max_graph_nodes, gps_stream_t stream) {
   GPS_REQUIRE(N >= 0 && H > 0 && dh > 0 && max_tiles >= 0 && ld_qkv >= 3LL * H * dh &&
                   ld_dqkv >= 3LL * H * dh,
               "%s: bad sizes", who);
@@ -704,6 +673,12 @@ static int seg_attn_bwd_impl(const char* who, const float* d_out, const float* q
   const int64_t n_work = max_tiles * H;
   const unsigned grid = gps::grid_for(n_work, 4);
   hipStream_t s = gps::as_stream(stream);
+  if (!bias && max_graph_nodes > 0 && max_graph_nodes <= 64 && attn::sattn_applicable(qkv, ld_qkv, out, H, dh) &&
+      ld_dqkv % 4 == 0 && al16(d_out) && al16(d_qkv)) {          // one fused launch (sattn.hip)
+    attn::sattn_bwd_launch(d_out, qkv, ld_qkv, out, lse, ptr, tile_graph, tile_row0, max_tiles, N, H, dh, scale,
+                           p_drop, seed, d_qkv, ld_dqkv, s);
+    return gps::launch_status(who);
+  }
   const bool vec = ld_qkv % 4 == 0 && ld_dqkv % 4 == 0 && (H * dh) % 4 == 0 && al16(qkv) && al16(out) &&
                    al16(d_out) && al16(d_qkv);
 #define LAUNCH_BWD(D, DROP, VEC, BIAS)                                                                     \
@@ -738,19 +713,19 @@ static int seg_attn_bwd_impl(const char* who, const float* d_out, const float* q
 int gps_seg_attn_fwd(const float* qkv, int64_t ld_qkv, const int32_t* ptr,
                      const int32_t* tile_graph, const int32_t* tile_row0, int64_t max_tiles,
                      int64_t N, int H, int dh, float scale, float p_drop, uint64_t seed, float* out,
-                     float* lse, gps_stream_t stream) {
+                     float* lse, int64_t max_graph_nodes, gps_stream_t stream) {
   return seg_attn_fwd_impl("gps_seg_attn_fwd", qkv, ld_qkv, nullptr, 0, ptr, tile_graph, tile_row0, max_tiles,
-                           N, H, dh, scale, p_drop, seed, out, lse, stream);
+                           N, H, dh, scale, p_drop, seed, out, lse, max_graph_nodes, stream);
 }
 
 int gps_seg_attn_bwd(const float* d_out, const float* qkv, int64_t ld_qkv, const float* out,
                      const float* lse, const int32_t* ptr, const int32_t* tile_graph,
                      const int32_t* tile_row0, int64_t max_tiles, int64_t N, int H, int dh,
                      float scale, float p_drop, uint64_t seed, float* delta, float* d_qkv,
-                     int64_t ld_dqkv, gps_stream_t stream) {
+                     int64_t ld_dqkv, int64_t max_graph_nodes, gps_stream_t stream) {
   return seg_attn_bwd_impl("gps_seg_attn_bwd", d_out, qkv, ld_qkv, nullptr, 0, out, lse, ptr, tile_graph,
                            tile_row0, max_tiles, N, H, dh, scale, p_drop, seed, delta, d_qkv, ld_dqkv, nullptr,
-                           stream);
+                           max_graph_nodes, stream);
 }
 
 int gps_seg_attn_bias_fwd(const float* qkv, int64_t ld_qkv, const float* bias, int64_t nmax,
@@ -759,7 +734,7 @@ int gps_seg_attn_bias_fwd(const float* qkv, int64_t ld_qkv, const float* bias, i
                           uint64_t seed, float* out, float* lse, gps_stream_t stream) {
   GPS_REQUIRE(bias != nullptr || N == 0, "gps_seg_attn_bias_fwd: null bias");
   return seg_attn_fwd_impl("gps_seg_attn_bias_fwd", qkv, ld_qkv, bias, nmax, ptr, tile_graph, tile_row0,
-                           max_tiles, N, H, dh, scale, p_drop, seed, out, lse, stream);
+                           max_tiles, N, H, dh, scale, p_drop, seed, out, lse, 0, stream);
 }
 
 int gps_seg_attn_bias_bwd(const float* d_out, const float* qkv, int64_t ld_qkv, const float* bias,
@@ -769,7 +744,7 @@ int gps_seg_attn_bias_bwd(const float* d_out, const float* qkv, int64_t ld_qkv, 
                           float* d_qkv, int64_t ld_dqkv, float* d_bias, gps_stream_t stream) {
   GPS_REQUIRE(bias != nullptr || N == 0, "gps_seg_attn_bias_bwd: null bias");
   return seg_attn_bwd_impl("gps_seg_attn_bias_bwd", d_out, qkv, ld_qkv, bias, nmax, out, lse, ptr, tile_graph,
-                           tile_row0, max_tiles, N, H, dh, scale, p_drop, seed, delta, d_qkv, ld_dqkv, d_bias,
+                           tile_row0, max_tiles, N, H, dh, scale, p_drop, seed, delta, d_qkv, ld_dqkv, d_bias, 0,
                            stream);
 }
 

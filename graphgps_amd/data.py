@@ -50,6 +50,11 @@ class Batch:
         self.__dict__["_num_graphs"] = int(value)
 
     def to(self, device, non_blocking: bool = False) -> "Batch":
+        # while ``ptr`` is still on the host: note the longest graph (a free kernel-selection hint for the device
+        # side, ops._host_max_graph_nodes)
+        p = self.__dict__.get("ptr")
+        if torch.is_tensor(p) and not p.is_cuda and p.numel() > 1:
+            self.__dict__.setdefault("_gps_meta", {})["nmax"] = int((p[1:] - p[:-1]).max())
         for k, v in list(self.__dict__.items()):
             if k == "_gps_index":  # device-side CSR cache is tied to the old device
                 del self.__dict__[k]
@@ -61,6 +66,9 @@ class Batch:
         """A new batch object over the SAME tensors (no device copies) without the cached graph index:
         what a loader hands the step for the next batch of the same storage.  The GPS path never writes
         into the tensors it is given (it re-assigns ``batch.x`` / ``batch.edge_attr``)."""
+        # ``_gps_meta``: a small host-side record shared BY REFERENCE by every shallow copy of this batch (what
+        # the host knows about it without touching the device: e.g. the longest graph, ops._host_max_graph_nodes)
+        self.__dict__.setdefault("_gps_meta", {})
         out = Batch()
         for k, v in self.__dict__.items():
             if k != "_gps_index":
@@ -70,9 +78,10 @@ class Batch:
     def clone(self) -> "Batch":
         out = Batch()
         for k, v in self.__dict__.items():
-            if k == "_gps_index":
+            if k in ("_gps_index", "_gps_meta"):
                 continue
             out.__dict__[k] = v.clone() if torch.is_tensor(v) else v
+        out.__dict__["_gps_meta"] = dict(self.__dict__.get("_gps_meta") or {})
         return out
 
     def __repr__(self) -> str:

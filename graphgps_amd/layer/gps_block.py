@@ -225,8 +225,8 @@ class _GPSBlock(torch.autograd.Function):
             o, lse = _E(N, d, **f32), _E(H, N, **f32)
             scale = float(dh) ** -0.5
             check(L.gps_seg_attn_fwd(P + 4 * fs, ldp, ptr(gi.ptr), ptr(gi.tile_graph), ptr(gi.tile_row0),
-                                     gi.max_tiles, N, H, dh, scale, p_at, s[2], ptr(o), ptr(lse), sb),
-                  "gps_seg_attn_fwd")
+                                     gi.max_tiles, N, H, dh, scale, p_at, s[2], ptr(o), ptr(lse),
+                                     int(gi.nmax_host), sb), "gps_seg_attn_fwd")
             ao = torch.addmm(sa.out_proj.bias, o, sa.out_proj.weight.t())
         # -- local branch: C projection + GatedGCN core ----------------------------------------
         ce = torch.addmm(lm.C.bias, e, lm.C.weight.t())
@@ -326,7 +326,8 @@ class _GPSBlock(torch.autograd.Function):
             delta = _E(H, N, **f32)
             check(L.gps_seg_attn_bwd(ptr(g_o), P + 4 * fs, ldp, ptr(o), ptr(lse), ptr(gi.ptr),
                                      ptr(gi.tile_graph), ptr(gi.tile_row0), gi.max_tiles, N, H, dh, scale,
-                                     p_at, s[2], ptr(delta), G + 4 * fs, ldp, sb), "gps_seg_attn_bwd")
+                                     p_at, s[2], ptr(delta), G + 4 * fs, ldp, int(gi.nmax_host), sb),
+                  "gps_seg_attn_bwd")
 
         # x1 = x + drop(relu(BN_x(xt)));  e1 = e + drop(relu(BN_e(eh))):  both BN backwards as one list
         g_xt, g_eh = _E(N, d, **f32), _E(E, d, **f32)
@@ -391,8 +392,8 @@ class _GPSBlockGINE(torch.autograd.Function):
             o, lse = _E(N, d, **f32), _E(H, N, **f32)
             scale = float(dh) ** -0.5
             check(L.gps_seg_attn_fwd(ptr(qkv), 3 * d, ptr(gi.ptr), ptr(gi.tile_graph), ptr(gi.tile_row0),
-                                     gi.max_tiles, N, H, dh, scale, p_at, s[2], ptr(o), ptr(lse), sb),
-                  "gps_seg_attn_fwd")
+                                     gi.max_tiles, N, H, dh, scale, p_at, s[2], ptr(o), ptr(lse),
+                                     int(gi.nmax_host), sb), "gps_seg_attn_fwd")
             ao = torch.addmm(sa.out_proj.bias, o, sa.out_proj.weight.t())
         # -- local half: GINE core + MLP (gps_layer.py:62-69,183-185) -------------------------------
         agg = _E(N, d, **f32)
@@ -470,7 +471,8 @@ class _GPSBlockGINE(torch.autograd.Function):
             g_qkv, delta = _E(N, 3 * d, **f32), _E(H, N, **f32)
             check(L.gps_seg_attn_bwd(ptr(g_o), ptr(qkv), 3 * d, ptr(o), ptr(lse), ptr(gi.ptr),
                                      ptr(gi.tile_graph), ptr(gi.tile_row0), gi.max_tiles, N, H, dh, scale,
-                                     p_at, s[2], ptr(delta), ptr(g_qkv), 3 * d, sb), "gps_seg_attn_bwd")
+                                     p_at, s[2], ptr(delta), ptr(g_qkv), 3 * d, int(gi.nmax_host), sb),
+                  "gps_seg_attn_bwd")
         # local half: MLP backward, GINE core backward
         g_g1r = g_g2.mm(lin2.weight)
         g_g1 = _K.act_drop_bwd(L, g_g1r, g1, True, 0.0, 0, st)

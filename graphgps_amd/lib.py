@@ -79,9 +79,9 @@ _SIGNATURES = {
                               c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P]),
     "gps_attn_supported_head_dim": (c_int, [c_int]),
     "gps_seg_attn_fwd": (c_int, [_P, c_int64, _P, _P, _P, c_int64, c_int64, c_int, c_int, c_float,
-                                 c_float, c_uint64, _P, _P, _P]),
+                                 c_float, c_uint64, _P, _P, c_int64, _P]),
     "gps_seg_attn_bwd": (c_int, [_P, _P, c_int64, _P, _P, _P, _P, _P, c_int64, c_int64, c_int, c_int,
-                                 c_float, c_float, c_uint64, _P, _P, c_int64, _P]),
+                                 c_float, c_float, c_uint64, _P, _P, c_int64, c_int64, _P]),
     "gps_gcn_dinv": (c_int, [_P, _P, c_int64, c_int64, _P, _P]),
     "gps_gcn_spmm": (c_int, [_P, c_int64, _P, _P, _P, c_int64, c_int64, c_int, _P, _P]),
     "gps_adj_sum": (c_int, [_P, c_int64, _P, _P, c_float, c_int64, c_int64, c_int, _P, _P]),

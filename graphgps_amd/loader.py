@@ -63,6 +63,10 @@ class DeviceLoader:
         dev = self.device
         batch = self._host_copy(batch)
         vars(batch).pop("_gps_index", None)
+        # what the host can tell the kernels for free while ``ptr`` is still here: the longest graph of the batch
+        p = getattr(batch, "ptr", None)
+        if torch.is_tensor(p) and not p.is_cuda and p.numel() > 1:
+            vars(batch)["_gps_meta"] = {"nmax": int((p[1:] - p[:-1]).max())}
         with torch.cuda.stream(copy_stream):
             for k in self._keys(batch):
                 v = getattr(batch, k, None)

@@ -58,6 +58,7 @@ class GraphIndex:
     key: tuple = ()
     edge_src: Optional[torch.Tensor] = None   # int64 [E] = edge_index[0] (edge order)
     edge_dst: Optional[torch.Tensor] = None   # int64 [E] = edge_index[1]
+    nmax_host: int = 0         # longest graph of the batch as the HOST knows it (0 = unknown; a kernel-selection hint)
 
 
 def build_graph_index(edge_index: torch.Tensor, num_nodes: int, num_graphs: int,
@@ -113,6 +114,40 @@ def build_graph_index(edge_index: torch.Tensor, num_nodes: int, num_graphs: int,
                       edge_src=edge_index[0], edge_dst=edge_index[1])
 
 
+def _host_max_graph_nodes(batch) -> int:
+    """Longest graph of the batch WITHOUT stalling the step: from the shared per-batch record
+    (``batch._gps_meta['nmax']``: written by ``loader.DeviceLoader`` from the host-side ``ptr`` before the H2D copy,
+    or by an earlier call here), from a ``ptr`` / ``batch`` vector that still lives on the host, or -- once per
+    source batch, never inside a hipGraph capture -- by one device read.  0 = unknown (the kernels that want the
+    bound then take their general form).  It is a kernel-selection hint, never an array bound."""
+    d = getattr(batch, "__dict__", None)
+    if d is None:
+        return 0
+    meta = d.get("_gps_meta")
+    if meta is None and hasattr(batch, "shallow_copy"):        # graphgps_amd.data.Batch: give it its record
+        meta = d["_gps_meta"] = {}
+    if meta is not None and "nmax" in meta:
+        return int(meta["nmax"])
+    p, bv = getattr(batch, "ptr", None), getattr(batch, "batch", None)
+    val = None
+    if torch.is_tensor(p) and p.numel() > 1 and not p.is_cuda:
+        val = int((p[1:] - p[:-1]).max())
+    elif p is None and torch.is_tensor(bv) and bv.numel() and not bv.is_cuda:
+        val = int(torch.bincount(bv).max())
+    elif meta is not None and not (torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
+        # a device-resident batch that carries the shareable record (graphgps_amd.data.Batch: shallow copies of
+        # one batch share it): one synchronising read, paid once for all of its copies
+        if torch.is_tensor(p) and p.numel() > 1:
+            val = int((p[1:] - p[:-1]).max().item())
+        elif torch.is_tensor(bv) and bv.numel():
+            val = int(torch.bincount(bv).max().item())
+    if val is None:
+        return 0
+    if meta is not None:
+        meta["nmax"] = val
+    return val
+
+
 def graph_index_of(batch) -> GraphIndex:
     """Index cached on the batch object (one build per batch, not per layer)."""
     ei = batch.edge_index
@@ -125,6 +160,7 @@ def graph_index_of(batch) -> GraphIndex:
     gi = build_graph_index(ei, N, B, batch_vec=getattr(batch, "batch", None),
                            ptr_vec=getattr(batch, "ptr", None))
     gi.key = key
+    gi.nmax_host = _host_max_graph_nodes(batch)
     try:
         batch.__dict__["_gps_index"] = gi
     except Exception:
@@ -381,7 +417,7 @@ class _SegmentAttention(torch.autograd.Function):
         if bias is None:
             check(L.gps_seg_attn_fwd(ptr(qkv), 3 * d, ptr(gi.ptr), ptr(gi.tile_graph),
                                      ptr(gi.tile_row0), gi.max_tiles, N, H, dh, scale, float(p_drop),
-                                     seed, ptr(out), ptr(lse), current_stream(dev)),
+                                     seed, ptr(out), ptr(lse), int(gi.nmax_host), current_stream(dev)),
                   "gps_seg_attn_fwd")
             ctx.save_for_backward(qkv, out, lse)
         else:
@@ -410,7 +446,7 @@ class _SegmentAttention(torch.autograd.Function):
             check(L.gps_seg_attn_bwd(ptr(d_out), ptr(qkv), qkv.shape[1], ptr(out), ptr(lse), ptr(gi.ptr),
                                      ptr(gi.tile_graph), ptr(gi.tile_row0), gi.max_tiles, N, H, dh,
                                      ctx.scale, ctx.p_drop, ctx.seed, ptr(delta), ptr(d_qkv),
-                                     d_qkv.shape[1], current_stream(dev)), "gps_seg_attn_bwd")
+                                     d_qkv.shape[1], int(gi.nmax_host), current_stream(dev)), "gps_seg_attn_bwd")
             return d_qkv, None, None, None, None, None
         bias = ctx.saved_tensors[3]
         d_bias = torch.zeros_like(bias)       # padded region: zero gradient, as under the reference's mask
@@ -459,11 +495,14 @@ def segment_attention(qkv: torch.Tensor, gi: GraphIndex, num_heads: int, p_drop:
 
 
 def attn_dropout_keep_mask(seed: int, q_global: torch.Tensor, head: int, num_heads: int,
-                           key_local: torch.Tensor, p_drop: float) -> torch.Tensor:
-    """Bit-exact host model of the kernel's counter-based dropout mask
-    (csrc/seg_attention.hip: row_hash/keep_elem).  ``q_global`` [Q] and ``key_local`` [K] are
-    integer tensors; returns bool [Q, K].  Used by the parity tests to inject the SAME mask
-    into the oracle."""
+                           key_local: torch.Tensor, p_drop: float, paired: bool = False) -> torch.Tensor:
+    """Bit-exact host model of the kernels' counter-based dropout masks; ``q_global`` [Q] and ``key_local`` [K]
+    are integer tensors; returns bool [Q, K].  Used by the parity tests to inject the SAME mask into the oracle.
+
+    ``paired=False``: the row kernels (csrc/bn_fused.hip, block_norm.hip), one hash per element keyed (row,
+    column), 24 bits against p.  ``paired=True``: the attention kernels (csrc/attn_common.hpp: row_hash /
+    pair_hash / keep_elem), one hash per PAIR of adjacent keys, 16 bits each against round(p * 65536) -- the
+    drop probability is then ``attn_dropout_effective_p(p)`` and survivors are scaled by 1 / (1 - that)."""
     M = 0xFFFFFFFF
 
     def mix(x):
@@ -479,9 +518,18 @@ def attn_dropout_keep_mask(seed: int, q_global: torch.Tensor, head: int, num_hea
     k = key_local.to(torch.int64).cpu()
     rowid = (q * num_heads + head) & M
     rh = (mix(rowid ^ (seed & M)) + ((seed >> 32) & M)) & M
+    if paired:
+        h = mix((rh[:, None] + ((k[None, :] >> 1) * 0x9E3779B9)) & M)
+        bits = torch.where((k[None, :] & 1) == 1, h >> 16, h & 0xFFFF)
+        return bits >= int(p_drop * 65536.0 + 0.5)
     r = mix((rh[:, None] + (k[None, :] * 0x9E3779B9)) & M)
     u = (r >> 8).to(torch.float32) * (1.0 / 16777216.0)
     return u >= torch.tensor(p_drop, dtype=torch.float32)
+
+
+def attn_dropout_effective_p(p_drop: float) -> float:
+    """Drop probability the attention kernels realise for a nominal ``p_drop``: round(p * 2^16) / 2^16."""
+    return int(p_drop * 65536.0 + 0.5) / 65536.0
 
 
 # -------------------------------------------------------------------------------------------

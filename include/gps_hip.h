@@ -148,8 +148,15 @@ int gps_adj_sum(const float* x, int64_t ld_x, const int32_t* rowptr, const int32
  * 234-241).  No padding, no mask tensor: graphs are walked through `ptr`.
  *   qkv  [N, 3d] packed in-proj output (q | k | v, head h at columns h*dh..), row stride ld_qkv
  *   out  [N, d]   heads merged;   lse [H, N] log-sum-exp per (head, query), saved for backward
- * Attention dropout (p_drop in [0,1)) uses a counter-based hash of (seed, query, head, key) so
- * that forward and backward regenerate the same mask; p_drop == 0 disables it.
+ * Attention dropout (p_drop in [0,1)) uses a counter-based hash of (seed, query, head, key pair) so
+ * that forward and backward regenerate the same mask (one 32-bit hash decides two adjacent keys, 16 bits
+ * each: the realised drop probability is round(p * 2^16) / 2^16 and survivors are scaled by its exact
+ * complement); p_drop == 0 disables it.
+ * Two kernel families behind the same entry points.  `max_graph_nodes` is an upper bound on the longest
+ * graph of the batch known to the HOST (0 = unknown): when it is <= 64 and dh is one of {8, 16, 24, 32}
+ * the block form runs -- one wavefront per (graph, head) keeps that graph's K-side operands in registers and
+ * serves all of its query tiles; the backward is ONE launch (csrc/sattn.hip).  Everything else takes the
+ * one-wavefront-per-(16-row tile, head) form with the online softmax (csrc/seg_attention.hip).
  * Supported head dims: the compiled set {4, 6, 8, 10, 12, 13, 16, 18, 20, 24, 32, 48, 64, 76, 96, 128}
  * (every dim_hidden / n_heads of configs/GPS and configs/Graphormer), see gps_attn_supported_head_dim().
  * ------------------------------------------------------------------------------------- */
@@ -157,14 +164,16 @@ int gps_attn_supported_head_dim(int dh);
 int gps_seg_attn_fwd(const float* qkv, int64_t ld_qkv, const int32_t* ptr,
                      const int32_t* tile_graph, const int32_t* tile_row0, int64_t max_tiles,
                      int64_t N, int H, int dh, float scale, float p_drop, uint64_t seed, float* out,
-                     float* lse, gps_stream_t stream);
+                     float* lse, int64_t max_graph_nodes, gps_stream_t stream);
 /* d_qkv [N,3d] (row stride ld_dqkv) receives dq | dk | dv.  `delta` is an [H,N] scratch buffer
- * (rowsum(dO*O)).  Three launches: delta, dQ (query-tile keyed), dK+dV (key-tile keyed). */
+ * (rowsum(dO*O)).  Block form (max_graph_nodes in 1..64, see above): ONE launch -- S, P, dS computed once per
+ * tile pair, dQ / dK / dV from it, delta formed on the fly (the scratch buffer stays untouched); otherwise
+ * two launches: dQ + delta (query-tile keyed), dK + dV (key-tile keyed). */
 int gps_seg_attn_bwd(const float* d_out, const float* qkv, int64_t ld_qkv, const float* out,
                      const float* lse, const int32_t* ptr, const int32_t* tile_graph,
                      const int32_t* tile_row0, int64_t max_tiles, int64_t N, int H, int dh,
                      float scale, float p_drop, uint64_t seed, float* delta, float* d_qkv,
-                     int64_t ld_dqkv, gps_stream_t stream);
+                     int64_t ld_dqkv, int64_t max_graph_nodes, gps_stream_t stream);
 /* The same core with an additive attention bias: the reference's `attn_mask=batch.attn_bias` operand of
  * torch.nn.MultiheadAttention in the BiasedTransformer branch (graphgps/layer/gps_layer.py:201-203,
  * 234-241) and in GraphormerLayer (graphgps/layer/graphormer_layer.py:43-44).

@@ -6,7 +6,8 @@ import os
 import pytest
 import torch
 
-from conftest import Tol, assert_close, assert_close_kink_tolerant, golden_names, load_golden
+from conftest import (Tol, assert_close, assert_close_kink_tolerant, assert_fp32_grade, golden_names,
+                      load_golden)
 
 pytestmark = pytest.mark.gpu
 
@@ -86,6 +87,15 @@ def test_gpslayer_performer_matches_reference_fixture(name):
     _check_against_fixture(name)
 
 
+def _double_batch(b):
+    """The same batch with every floating tensor in fp64 (integer features / indices untouched)."""
+    out = b.clone()
+    for k, v in list(out.__dict__.items()):
+        if torch.is_tensor(v) and v.is_floating_point():
+            out.__dict__[k] = v.double()
+    return out
+
+
 def _oracle_layer_like(layer):
     from oracle.gps_oracle import OracleGPSLayer
     o = OracleGPSLayer(**layer.ctor_kwargs)
@@ -152,7 +162,8 @@ def test_gpslayer_performer_code2_size_vs_oracle():
     'CustomGatedGCN', 'Performer', 4) -- Performer's dim_head stays 64 (performer_layer.py:427,441-442), m = 266
     random features -- on a CODE2_LONG batch (32 ASTs of 600-1000 nodes, 4 concatenated edge groups) vs the CPU
     oracle (the reference's padded to_dense_batch -> SelfAttention -> [mask] path, gps_layer.py:199,206):
-    outputs 1e-5, input gradients 1e-5 of max|g| outside ReLU-kink rows, parameter gradients 1e-4."""
+    outputs 1e-5, input gradients 1e-5 of max|g| outside ReLU-kink rows; parameter gradients graded against the
+    fp64 evaluation of the same oracle (conftest.assert_fp32_grade)."""
     from graphgps_amd.layer.gps_layer import GPSLayer
     from graphgps_amd.synthetic import layer_batch
     dev = torch.device("cuda:0")
@@ -182,19 +193,40 @@ def test_gpslayer_performer_code2_size_vs_oracle():
     rx = assert_close_kink_tolerant(xg.grad, xo.grad, Tol.GRAD_REL, "grad x", min_allowed_rows=2 * 1000)
     re_ = assert_close_kink_tolerant(eg.grad, eo.grad, Tol.GRAD_REL, "grad e")
     print(f"code2 layer: grad x max rel {rx[0]:.2e} outside {rx[2]} kink rows; grad e {re_[0]:.2e} / {re_[2]}")
-    op = dict(oracle.named_parameters())
-    gscale = max(float(q.grad.abs().max()) for q in op.values() if q.grad is not None)
+    # parameter gradients are sums over 25.6k rows / 76k edges in which every kink row (a few dozen here: FAVOR+
+    # couples all rows of a graph) lands undamped: judged against the fp64 evaluation of the same oracle
+    import copy
+    o64 = copy.deepcopy(oracle).double()
+    o64.zero_grad(set_to_none=True)
+    b64 = b.clone()
+    b64.x = b64.x.double(); b64.edge_attr = b64.edge_attr.double()
+    r64 = o64(b64)
+    ((r64.x * wx.double()).sum() + (r64.edge_attr * we.double()).sum()).backward()
+    op, o6 = dict(oracle.named_parameters()), dict(o64.named_parameters())
+    gscale = max(float(q.grad.abs().max()) for q in o6.values() if q.grad is not None)
+    worst = (0.0, "")
     for k, p in layer.named_parameters():
         if op[k].grad is None:
             continue
-        assert_close_kink_tolerant(p.grad, op[k].grad, 1e-4, f"grad {k}", min_scale=max(1.0, 0.01 * gscale))
+        # floor 2e-4: a kink flip is a Poisson event (27 kink rows of 25.6k between HIP and the CPU oracle above);
+        # with a handful of them per side the two rms errors differ by small-count noise, not by arithmetic
+        rg, rc, mg, mc = assert_fp32_grade(p.grad, op[k].grad, o6[k].grad, f"grad {k}", floor=2e-4, factor=5.0,
+                                           min_scale=max(1.0, 0.01 * gscale))
+        worst = max(worst, (rg / max(rc, 1e-12), k))
+        print(f"  {k:32s} rms err vs fp64: hip {rg:.2e}  cpu-fp32 {rc:.2e}   max: hip {mg:.2e}  cpu-fp32 {mc:.2e}")
+    print(f"code2 layer: worst hip/cpu rms-error ratio {worst[0]:.2f} ({worst[1]})")
 
 
 def test_code2_model_vs_oracle():
     """The 4-layer ``ogbg-code2-GPS.yaml`` model (ASTNode/ASTEdge encoders, 4 x CustomGatedGCN+Performer at
     d=256, ogb_code_graph head, sub-token cross entropy) on 32 code2-long graphs, dropout off: every one of the
     5 prediction heads, the loss and all parameter gradients vs the oracle model."""
-    from graphgps_amd.loss.losses import compute_loss
+    import torch.nn.functional as F
+
+    def compute_loss(pred_list, true):
+        # graphgps/loss/subtoken_prediction_loss.py:6-20 without its .to(float32) cast, so that the fp64 leg stays
+        # fp64 end to end (for the two fp32 legs this IS the reference's loss)
+        return sum(F.cross_entropy(p_, true['y_arr'][:, i]) for i, p_ in enumerate(pred_list)) / len(pred_list), pred_list
     from graphgps_amd.synthetic import model_batch
     from oracle.gps_oracle import to_oracle_model
     import graphgps_amd as g
@@ -207,22 +239,35 @@ def test_code2_model_vs_oracle():
     model.to(dev)
     b = model_batch("code2", 32, seed=4321)
     assert int((b.ptr[1:] - b.ptr[:-1]).max()) > 900
+    import copy
+    o64 = copy.deepcopy(oracle).double()
     po, to_ = oracle(b.clone())
     lo, _ = compute_loss(po, to_)
     lo.backward()
+    p64, t64 = o64(_double_batch(b))
+    l64, _ = compute_loss(p64, t64)
+    l64.backward()
     pg, tg = model(b.clone().to(dev))
     lg, _ = compute_loss(pg, tg)
     lg.backward()
-    for i, (a_, b_) in enumerate(zip(pg, po)):
-        assert_close(a_, b_, 1e-4, f"pred[{i}]")
+    for i, (a_, b_, c_) in enumerate(zip(pg, po, p64)):
+        rg, rc, mg, mc = assert_fp32_grade(a_, b_, c_, f"pred[{i}]", floor=1e-5)
+        assert_close(a_, b_, max(1e-5, 4 * (mg + mc)), f"pred[{i}] (hip vs cpu oracle)")
     assert_close(lg, lo, 1e-5, "loss")
-    op = dict(oracle.named_parameters())
-    worst = 0.0
+    op, o6 = dict(oracle.named_parameters()), dict(o64.named_parameters())
+    gscale = max(float(q.grad.abs().max()) for q in o6.values() if q.grad is not None)
+    worst = (0.0, 0.0, "")
     for k, p in model.named_parameters():
         if op[k].grad is None or p.grad is None:
             continue
-        worst = max(worst, assert_close(p.grad, op[k].grad, 1e-3, f"grad {k}", rel_to_max=True))
-    print(f"code2 model: worst relative parameter-gradient error {worst:.2e}")
+        # floor 1e-4 rms: one ReLU-kink flip in a later layer perturbs, through FAVOR+'s all-rows coupling, the
+        # gradient of every row of that graph (1 of 32) and with it every earlier weight gradient by ~1e-5..1e-4
+        # of its scale; whether the fp32 CPU oracle or the HIP path catches such a flip is a coin toss (on MI355X:
+        # HIP 2.6e-5 rms on layers.0.ff_linear2.weight against a CPU oracle that happened to have none, 1.7e-8)
+        rg, rc, mg, mc = assert_fp32_grade(p.grad, op[k].grad, o6[k].grad, f"grad {k}", floor=1e-4, factor=5.0,
+                                           min_scale=max(1.0, 0.01 * gscale))
+        worst = max(worst, (rg, rc, k))
+    print(f"code2 model: largest rms error vs fp64: hip {worst[0]:.2e} (cpu-fp32 oracle {worst[1]:.2e}) on {worst[2]}")
 
 
 def test_gpslayer_edge_permutation_and_determinism():
@@ -256,9 +301,13 @@ def _build_model(cfg_name, dim_in, dim_out, overrides=()):
     ("zinc_gps_rwse.yaml", "zinc", 1, 32),
 ])
 def test_full_model_vs_oracle(cfg_name, kind, dim_in, nb):
-    """10-layer stack, dropout off (train mode, BN batch stats): prediction, loss and gradients
-    vs the CPU oracle model.  Per-layer error ~1e-6 compounds through 10 BN-normalised layers;
-    the stack-level bar is 1e-4 on predictions and 1e-3 of max|g| on gradients."""
+    """10-layer stack, dropout off (train mode, BN batch stats): prediction, loss and every parameter gradient
+    vs the CPU oracle model -- and vs the SAME oracle evaluated in fp64, which is what makes the tolerance a
+    statement: the fp32 CPU oracle is itself only an approximation of the function (per-layer rounding ~1e-6
+    compounds through 10 BN-normalised layers; a ReLU pre-activation within rounding of 0 flips sides), so
+    (i) the HIP prediction / gradients must be as close to fp64 as the CPU fp32 oracle is (rms, factor 3), and
+    (ii) the direct HIP-vs-CPU-oracle difference is bounded by the figures that (i) supports."""
+    import copy
     from graphgps_amd.loss.losses import compute_loss
     from graphgps_amd.synthetic import model_batch
     from oracle.gps_oracle import to_oracle_model
@@ -267,23 +316,38 @@ def test_full_model_vs_oracle(cfg_name, kind, dim_in, nb):
     model = _build_model(cfg_name, dim_in, 1, ["gt.dropout", 0.0, "gt.attn_dropout", 0.0])
     model.train()
     oracle = to_oracle_model(model)
+    o64 = copy.deepcopy(oracle).double()
     model.to(dev)
     b = model_batch(kind, nb, seed=1234)
     po, to_ = oracle(b.clone())
     lo, _ = compute_loss(po, to_)
     lo.backward()
+    p64, t64 = o64(_double_batch(b))
+    l64, _ = compute_loss(p64, t64)
+    l64.backward()
     pg, tg = model(b.clone().to(dev))
     lg, _ = compute_loss(pg, tg)
     lg.backward()
-    assert_close(pg, po, 1e-4, "pred")
+    rg, rc, mg, mc = assert_fp32_grade(pg, po, p64, "pred")
+    print(f"pred  vs fp64: hip rms {rg:.2e} max {mg:.2e} | cpu-fp32 rms {rc:.2e} max {mc:.2e}")
+    assert_close(pg, po, max(1e-5, 4 * (mg + mc)), "pred (hip vs cpu oracle)")
     assert_close(lg, lo, 1e-5, "loss")
-    op = dict(oracle.named_parameters())
-    worst = 0.0
+    op, o6 = dict(oracle.named_parameters()), dict(o64.named_parameters())
+    gscale = max(float(q.grad.abs().max()) for q in o6.values() if q.grad is not None)
+    worst_ratio, worst_hip, worst_cpu, worst_direct = (0.0, ""), 0.0, 0.0, 0.0
     for k, p in model.named_parameters():
         if op[k].grad is None or p.grad is None:
             continue
-        worst = max(worst, assert_close(p.grad, op[k].grad, 1e-3, f"grad {k}", rel_to_max=True))
-    print(f"worst relative parameter-gradient error over the stack: {worst:.2e}")
+        rg, rc, mg, mc = assert_fp32_grade(p.grad, op[k].grad, o6[k].grad, f"grad {k}",
+                                           min_scale=max(1.0, 0.01 * gscale))
+        worst_ratio = max(worst_ratio, (rg / max(rc, 1e-9), k))
+        worst_hip, worst_cpu = max(worst_hip, mg), max(worst_cpu, mc)
+        # the direct comparison, bounded by what the two fp64 distances allow (triangle inequality)
+        worst_direct = max(worst_direct, assert_close(p.grad, op[k].grad, max(1e-5, 1.5 * (mg + mc)), f"grad {k}",
+                                                      rel_to_max=True))
+    print(f"parameter gradients vs fp64 (max over parameters of max|err|/max|g|): hip {worst_hip:.2e}, "
+          f"cpu-fp32 oracle {worst_cpu:.2e}; worst hip/cpu rms ratio {worst_ratio[0]:.2f} ({worst_ratio[1]}); "
+          f"hip vs cpu oracle directly {worst_direct:.2e}")
 
 
 def test_full_model_train_step_with_dropout_runs():

@@ -17,11 +17,17 @@ def _structure(profile, nb, seed):
     return sizes, ei, bvec, ptr, gen
 
 
-def _index(ei, bvec, ptr, use_ptr=True):
+def _index(ei, bvec, ptr, use_ptr=True, host_hint=True):
+    """Graph index of a test batch.  ``host_hint``: record the longest graph as the host knows it (what a loader
+    batch carries), which lets batches of <= 64-node graphs take the block-form attention kernels (csrc/sattn.hip);
+    False = unknown, the per-tile kernels (csrc/seg_attention.hip) run whatever the sizes."""
     from graphgps_amd.ops import build_graph_index
     dev = torch.device("cuda:0")
-    return build_graph_index(ei.to(dev), int(ptr[-1]), len(ptr) - 1,
-                             batch_vec=bvec.to(dev), ptr_vec=ptr.to(dev) if use_ptr else None)
+    gi = build_graph_index(ei.to(dev), int(ptr[-1]), len(ptr) - 1,
+                           batch_vec=bvec.to(dev), ptr_vec=ptr.to(dev) if use_ptr else None)
+    if host_hint and len(ptr) > 1:
+        gi.nmax_host = int((ptr[1:] - ptr[:-1]).max())
+    return gi
 
 
 @pytest.mark.parametrize("profile,nb,seed", [("P30", 64, 1), ("P14", 256, 2), ("CODE2_REAL", 8, 3)])
@@ -129,6 +135,9 @@ ATTN_CASES = [  # (H, dh, graph sizes)
     (2, 4, [5, 16, 32, 64]),      # narrowest compiled head, sizes exactly on the tile boundaries
     (8, 10, [12, 33, 7]),         # zinc-Graphormer: embed 80 / 8 heads
     (4, 20, [31, 5, 48]),
+    (8, 8, [64, 1, 63, 17, 16]),  # block form (graphs <= 64, dh in {8,16,24,32}): every tile count, single rows
+    (4, 32, [33, 48, 2, 64]),
+    (16, 24, [64, 64, 5, 49, 32, 1, 15]),
 ]
 
 
@@ -143,15 +152,21 @@ def _attn_inputs(H, dh, sizes, seed=0):
     return qkv, w, ptr, ei, bvec
 
 
+@pytest.mark.parametrize("hint", [True, False])
 @pytest.mark.parametrize("H,dh,sizes", ATTN_CASES)
-def test_segment_attention_fwd_bwd(H, dh, sizes):
+def test_segment_attention_fwd_bwd(H, dh, sizes, hint):
+    """Both kernel families against the dense fp64 softmax attention: with the host-side size hint the batches of
+    <= 64-node graphs with dh in {8, 16, 24, 32} take the block form (one launch forward, one backward), without
+    it everything takes the per-tile kernels."""
     from graphgps_amd.ops import segment_attention
+    if not hint and (max(sizes) > 64 or dh not in (8, 16, 24, 32)):
+        pytest.skip("same kernels as with the hint")
     qkv, w, ptr, ei, bvec = _attn_inputs(H, dh, sizes)
     qr = qkv.clone().double().requires_grad_(True)
     ref = segment_attention_ref(qr, ptr, H)
     (ref * w.double()).sum().backward()
     dev = torch.device("cuda:0")
-    gi = _index(ei, bvec, ptr)
+    gi = _index(ei, bvec, ptr, host_hint=hint)
     qg = qkv.to(dev).requires_grad_(True)
     out = segment_attention(qg, gi, H, 0.0)
     (out * w.to(dev)).sum().backward()
@@ -175,21 +190,24 @@ def test_segment_attention_spiked_scores():
     assert_close(out, ref, Tol.ACT, "attn out (spiked)")
 
 
-@pytest.mark.parametrize("H,dh,sizes", [(4, 16, [23, 9, 37]), (16, 24, [30, 45, 70])])
+@pytest.mark.parametrize("H,dh,sizes", [(4, 16, [23, 9, 37]), (16, 24, [30, 45, 70]), (16, 24, [30, 64, 17, 5])])
 def test_segment_attention_dropout_shared_mask(H, dh, sizes):
     """Dropout parity by injecting the kernel's own counter-based mask into the reference."""
-    from graphgps_amd.ops import attn_dropout_keep_mask, segment_attention
+    from graphgps_amd.ops import attn_dropout_effective_p, attn_dropout_keep_mask, segment_attention
     p, seed = 0.3, 0x1234_5678_9ABC_DEF1
     qkv, w, ptr, ei, bvec = _attn_inputs(H, dh, sizes, seed=1)
     keep = []
     for g in range(len(sizes)):
         a, b = int(ptr[g]), int(ptr[g + 1])
         keep.append(torch.stack([attn_dropout_keep_mask(seed, torch.arange(a, b), h, H,
-                                                        torch.arange(b - a), p) for h in range(H)]))
+                                                        torch.arange(b - a), p, paired=True) for h in range(H)]))
     rate = torch.cat([k.flatten() for k in keep]).float().mean().item()
     assert abs(rate - (1 - p)) < 0.02, rate
+    # the two decisions taken from one hash are independent: P(both kept) = (1-p)^2 over adjacent key pairs
+    allk = torch.cat([k[:, :, :(k.shape[2] // 2) * 2].reshape(-1, 2) for k in keep]).float()
+    assert abs((allk[:, 0] * allk[:, 1]).mean().item() - (1 - p) ** 2) < 0.02
     qr = qkv.clone().double().requires_grad_(True)
-    ref = segment_attention_ref(qr, ptr, H, keep=keep, p_drop=p)
+    ref = segment_attention_ref(qr, ptr, H, keep=keep, p_drop=attn_dropout_effective_p(p))
     (ref * w.double()).sum().backward()
     gi = _index(ei, bvec, ptr)
     qg = qkv.cuda().requires_grad_(True)
@@ -210,7 +228,7 @@ def test_segment_attention_additive_bias(H, dh, sizes, pad, p):
     """softmax(q k^T / sqrt(dh) + bias) with the reference's dense [B*H, nmax, nmax] bias operand
     (gps_layer.py:201-203, graphormer_layer.py:43-44): output, d_qkv and d_bias against the dense per-graph
     fp64 reference; the gradient of the padded region is exactly zero."""
-    from graphgps_amd.ops import attn_dropout_keep_mask, segment_attention
+    from graphgps_amd.ops import attn_dropout_effective_p, attn_dropout_keep_mask, segment_attention
     seed = 0x0BADC0DE12345678
     qkv, w, ptr, ei, bvec = _attn_inputs(H, dh, sizes, seed=4)
     nmax = max(sizes) + pad
@@ -222,10 +240,10 @@ def test_segment_attention_additive_bias(H, dh, sizes, pad, p):
         for g in range(len(sizes)):
             a, b = int(ptr[g]), int(ptr[g + 1])
             keep.append(torch.stack([attn_dropout_keep_mask(seed, torch.arange(a, b), h, H,
-                                                            torch.arange(b - a), p) for h in range(H)]))
+                                                            torch.arange(b - a), p, paired=True) for h in range(H)]))
     qr = qkv.clone().double().requires_grad_(True)
     br = bias.clone().double().requires_grad_(True)
-    ref = segment_attention_ref(qr, ptr, H, keep=keep, p_drop=p, bias=br)
+    ref = segment_attention_ref(qr, ptr, H, keep=keep, p_drop=attn_dropout_effective_p(p), bias=br)
     (ref * w.double()).sum().backward()
     gi = _index(ei, bvec, ptr)
     qg = qkv.cuda().requires_grad_(True)
