@@ -124,17 +124,40 @@ def make_step(model, opt, reducer, batch_dev, compute_loss, clip_value, salt=Non
 
 def time_kernel(fn, iters=48, warm=6, nsets=1):
     """Mean duration (ms) of ``fn(i)`` (enqueues on torch's current stream, the stream the C-ABI
-    launches on) measured with HIP events.  ``i`` cycles over ``nsets`` operand sets: 1 = the same
-    buffers every launch (they stay in the 256 MiB Infinity Cache), > 1 = a rotation larger than
-    the cache, so every launch streams from HBM."""
+    launches on) measured with HIP events around ONE hipGraph replay of ``iters`` back-to-back launches: a
+    ctypes call + hipLaunchKernel costs the host 10-25 us, so an eagerly launched loop of kernels shorter than
+    that measures the host, not the kernel.  ``i`` cycles over ``nsets`` operand sets: 1 = the same buffers every
+    launch (they stay in the 256 MiB Infinity Cache), > 1 = a rotation larger than the cache, so every launch
+    streams from HBM.  Falls back to the eager loop when the launches cannot be captured."""
     for i in range(warm):
         fn(i % nsets)
     torch.cuda.synchronize()
     t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0.record()
-    for i in range(iters):
-        fn(i % nsets)
-    t1.record()
+    graph = None
+    try:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.stream(side):
+            with torch.cuda.graph(g, stream=side, capture_error_mode="thread_local"):
+                for i in range(iters):
+                    fn(i % nsets)
+        torch.cuda.current_stream().wait_stream(side)
+        graph = g
+    except Exception as exc:                      # noqa: BLE001 -- measurement fallback only
+        log(f"time_kernel: capture failed ({type(exc).__name__}: {exc}); eager loop (host-bound below ~25 us)")
+        torch.cuda.synchronize()
+    if graph is not None:
+        graph.replay()                            # one untimed replay (graph upload)
+        torch.cuda.synchronize()
+        t0.record()
+        graph.replay()
+        t1.record()
+    else:
+        t0.record()
+        for i in range(iters):
+            fn(i % nsets)
+        t1.record()
     torch.cuda.synchronize()
     return t0.elapsed_time(t1) / iters
 
@@ -207,7 +230,7 @@ def kernel_rooflines(dev, profile, nb, d=384, H=16, in_step=None, layers=10, onl
         P = q["proj"].data_ptr()
         check(L.gps_gatedgcn_fwd(P, P + fs, P + 2 * fs, P + 3 * fs, 4 * d, ptr(q["ce"]), ptr(gi.rowptr_dst),
                                  ptr(gi.src_by_dst), ptr(gi.eid_by_dst), N, E, d, ptr(q["xt"]), ptr(q["eh"]),
-                                 ptr(q["dn"]), None, st))
+                                 ptr(q["dn"]), None, current_stream(dev)))
 
     def gg_bwd(i=0):
         q = gsets[i]
@@ -215,7 +238,7 @@ def kernel_rooflines(dev, profile, nb, d=384, H=16, in_step=None, layers=10, onl
         check(L.gps_gatedgcn_bwd(ptr(q["gx"]), d, ptr(q["ge"]), ptr(q["eh"]), P, P + fs, 4 * d, ptr(q["xt"]),
                                  ptr(q["dn"]), ptr(gi.rowptr_dst), ptr(gi.src_by_dst), ptr(gi.eid_by_dst),
                                  ptr(gi.rowptr_src), ptr(gi.dst_by_src), ptr(gi.eid_by_src), N, E, d,
-                                 ptr(q["gce"]), G, G + fs, G + 2 * fs, G + 3 * fs, 4 * d, None, st))
+                                 ptr(q["gce"]), G, G + fs, G + 2 * fs, G + 3 * fs, 4 * d, None, current_stream(dev)))
 
     def at_set():
         return dict(qkv=f(N, 3 * d), out=f(N, d), lse=f(H, N), dout=f(N, d), delta=f(H, N), dqkv=f(N, 3 * d))
@@ -226,13 +249,13 @@ def kernel_rooflines(dev, profile, nb, d=384, H=16, in_step=None, layers=10, onl
     def at_fwd(i=0, p=0.1):
         q = asets[i]
         check(L.gps_seg_attn_fwd(ptr(q["qkv"]), 3 * d, ptr(gi.ptr), ptr(gi.tile_graph), ptr(gi.tile_row0),
-                                 gi.max_tiles, N, H, dh, scale, p, 1234, ptr(q["out"]), ptr(q["lse"]), nmax_host, st))
+                                 gi.max_tiles, N, H, dh, scale, p, 1234, ptr(q["out"]), ptr(q["lse"]), nb, nmax_host, current_stream(dev)))
 
     def at_bwd(i=0, p=0.1):
         q = asets[i]
         check(L.gps_seg_attn_bwd(ptr(q["dout"]), ptr(q["qkv"]), 3 * d, ptr(q["out"]), ptr(q["lse"]), ptr(gi.ptr),
                                  ptr(gi.tile_graph), ptr(gi.tile_row0), gi.max_tiles, N, H, dh, scale,
-                                 p, 1234, ptr(q["delta"]), ptr(q["dqkv"]), 3 * d, nmax_host, st))
+                                 p, 1234, ptr(q["delta"]), ptr(q["dqkv"]), 3 * d, nb, nmax_host, current_stream(dev)))
 
     for i in range(n_rot):                 # valid saved tensors (e_hat, den) for the backward kernels
         gg_fwd(i)
@@ -284,7 +307,7 @@ def kernel_rooflines(dev, profile, nb, d=384, H=16, in_step=None, layers=10, onl
         q.g, q.x, q.gw, q.gb = g_.data_ptr(), x_.data_ptr(), gw.data_ptr(), gb.data_ptr()
         q.ldg, q.ldx, q.R, q.M, q.Nn = g_.stride(0), x_.stride(0), g_.shape[0], g_.shape[1], x_.shape[1]
     wws = torch.empty(max(L.gps_wgrad_grouped_workspace_floats(len(pairs), probs), 4), device=dev)
-    entry("wgrad_grouped", lambda i=0: check(L.gps_wgrad_grouped(len(pairs), probs, ptr(wws), st)), 1, "mfma",
+    entry("wgrad_grouped", lambda i=0: check(L.gps_wgrad_grouped(len(pairs), probs, ptr(wws), current_stream(dev))), 1, "mfma",
           sum(2.0 * R * k * n for R, k, n in shapes), 2, ("k_wgrad",),
           note="fp32-equivalent flops against the fp32-input MFMA peak; the contraction itself runs on the "
                "bf16 pipe (exact 3-way split, 6 products); in-step it shares the chip with the main stream")
@@ -324,13 +347,13 @@ def favor_rooflines(dev, nb, d=256, H=4, in_step=None):
     def fwd(i=0):
         check(L.gps_favor_fwd(ptr(qkv), 3 * inner, ptr(proj), m, ptr(gi.ptr), ptr(nmax), ptr(gi.tile_graph),
                               ptr(gi.tile_row0), gi.max_tiles, N, nb, H, dh, ptr(out), ptr(cbuf), ptr(ksum),
-                              ptr(kmax), ptr(mq), ptr(D), st))
+                              ptr(kmax), ptr(mq), ptr(D), current_stream(dev)))
 
     def bwd(i=0):
         check(L.gps_favor_bwd(ptr(g_out), ptr(qkv), 3 * inner, ptr(proj), m, ptr(out), ptr(gi.ptr), ptr(nmax),
                               ptr(gi.tile_graph), ptr(gi.tile_row0), gi.max_tiles, N, nb, H, dh, ptr(cbuf),
                               ptr(ksum), ptr(kmax), ptr(mq), ptr(D), ptr(gD), ptr(g_ctx), ptr(g_ksum),
-                              ptr(gm_part), ptr(d_qkv), 3 * inner, st))
+                              ptr(gm_part), ptr(d_qkv), 3 * inner, current_stream(dev)))
 
     fwd()
     flf = 8.0 * N * m * inner + 2.0 * N * m * H

@@ -181,7 +181,8 @@ __device__ __forceinline__ void bwd_a_chunk(const float* __restrict__ g_e, const
                                             const float* __restrict__ Bx, int64_t ld,
                                             const float* __restrict__ r_edge, int d, int c, const int* nbr,
                                             const int* eids, const Vec<VEC>& a, const Vec<VEC>& inv,
-                                            Vec<VEC>& gdx, float* g_Ce) {
+                                            Vec<VEC>& gdx, float* g_Ce, float* __restrict__ sD,
+                                            float* __restrict__ sS, int slot0, int cap) {
   int64_t id[D];
   Vec<VEC> eh[D], ge[D], bx[D];
   float rr[D];
@@ -202,9 +203,11 @@ __device__ __forceinline__ void bwd_a_chunk(const float* __restrict__ g_e, const
       const float s = sigmoidf_fast(eh[u][v]);
       float sp = s * (1.0f - s);
       if (GATE) sp = sp * rr[u];
-      num[v] += (GATE ? s * rr[u] : s) * bx[u][v];
+      const float sg = GATE ? s * rr[u] : s;
+      num[v] += sg * bx[u][v];
       ge[u][v] += (a[v] * bx[u][v]) * sp;     // t_ij
       eh[u][v] = sp;                          // s'_ij
+      bx[u][v] = sg * a[v];                   // sig_ij a_i: what the source-keyed phase adds to g_Bx_j
     }
 #pragma unroll
   for (int u = 0; u < D; ++u) {
@@ -216,6 +219,10 @@ __device__ __forceinline__ void bwd_a_chunk(const float* __restrict__ g_e, const
       gdx[v] += dl[v];
     }
     dl.store(g_Ce + id[u] * d + c);
+    if (slot0 + u < cap) {                    // hand-over to phase B through LDS (no second trip to memory)
+      dl.store(sD + (slot0 + u) * d + c);
+      bx[u].store(sS + (slot0 + u) * d + c);
+    }
   }
 }
 
@@ -226,7 +233,8 @@ __device__ __forceinline__ void bwd_a_rows(const float* __restrict__ g_x, int64_
                                            const int* rp, const int* nbr, const int* eids, const NodeBlock& blk,
                                            int d, int row, int npi, int c, float* g_Ce, float* __restrict__ g_Ax,
                                            float* __restrict__ g_Dx, int64_t ldg,
-                                           const float* __restrict__ r_edge) {
+                                           const float* __restrict__ r_edge, float* __restrict__ sD,
+                                           float* __restrict__ sS, int e0, int cap) {
   for (int64_t node = blk.n0 + row; node < blk.n1; node += npi) {
     const int beg = rp[node - blk.n0], end = rp[node - blk.n0 + 1];
     const Vec<VEC> gx = Vec<VEC>::load(g_x + node * ldgx + c);
@@ -239,10 +247,10 @@ __device__ __forceinline__ void bwd_a_rows(const float* __restrict__ g_x, int64_
     }
     switch (end - beg) {
       case 0: break;
-      case 1: bwd_a_chunk<VEC, GATE, 1>(g_e, e_hat, Bx, ld, r_edge, d, c, nbr + beg, eids + beg, a, inv, gdx, g_Ce); break;
-      case 2: bwd_a_chunk<VEC, GATE, 2>(g_e, e_hat, Bx, ld, r_edge, d, c, nbr + beg, eids + beg, a, inv, gdx, g_Ce); break;
-      case 3: bwd_a_chunk<VEC, GATE, 3>(g_e, e_hat, Bx, ld, r_edge, d, c, nbr + beg, eids + beg, a, inv, gdx, g_Ce); break;
-      case 4: bwd_a_chunk<VEC, GATE, 4>(g_e, e_hat, Bx, ld, r_edge, d, c, nbr + beg, eids + beg, a, inv, gdx, g_Ce); break;
+      case 1: bwd_a_chunk<VEC, GATE, 1>(g_e, e_hat, Bx, ld, r_edge, d, c, nbr + beg, eids + beg, a, inv, gdx, g_Ce, sD, sS, beg - e0, cap); break;
+      case 2: bwd_a_chunk<VEC, GATE, 2>(g_e, e_hat, Bx, ld, r_edge, d, c, nbr + beg, eids + beg, a, inv, gdx, g_Ce, sD, sS, beg - e0, cap); break;
+      case 3: bwd_a_chunk<VEC, GATE, 3>(g_e, e_hat, Bx, ld, r_edge, d, c, nbr + beg, eids + beg, a, inv, gdx, g_Ce, sD, sS, beg - e0, cap); break;
+      case 4: bwd_a_chunk<VEC, GATE, 4>(g_e, e_hat, Bx, ld, r_edge, d, c, nbr + beg, eids + beg, a, inv, gdx, g_Ce, sD, sS, beg - e0, cap); break;
       default: {                               // long segment: num_i first, then the deltas (rows re-read from L1 / L2)
         Vec<VEC> num = Vec<VEC>::zero();
         for (int k = beg; k < end; ++k) {
@@ -274,6 +282,16 @@ __device__ __forceinline__ void bwd_a_rows(const float* __restrict__ g_x, int64_
             gdx[v] += dl[v];
           }
           dl.store(g_Ce + id * d + c);
+          if (k - e0 < cap) {
+            Vec<VEC> sa;
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+              const float s = sigmoidf_fast(eh[v]);
+              sa[v] = (GATE ? s * rr : s) * a[v];
+            }
+            dl.store(sD + (k - e0) * d + c);
+            sa.store(sS + (k - e0) * d + c);
+          }
         }
       }
     }
@@ -282,7 +300,9 @@ __device__ __forceinline__ void bwd_a_rows(const float* __restrict__ g_x, int64_
   }
 }
 
-// Phase B, D outgoing edges of one source node.
+// Phase B, D outgoing edges of one source node.  An edge whose target this workgroup owns finds its delta and
+// sig a_i in the LDS stash phase A filled (slot = the edge's position in the block's CSR slice, looked up through the
+// target's <= few-entry segment); only edges to other workgroups' nodes -- or beyond the stash -- go back to memory.
 template <int VEC, bool GATE, int D>
 __device__ __forceinline__ void bwd_b_chunk(const float* __restrict__ g_x, int64_t ldgx,
                                             const float* __restrict__ g_e, const float* __restrict__ e_hat,
@@ -290,41 +310,58 @@ __device__ __forceinline__ void bwd_b_chunk(const float* __restrict__ g_x, int64
                                             const float* __restrict__ x_tilde, const float* __restrict__ den,
                                             const float* __restrict__ r_edge, const float* g_Ce, int d, int c,
                                             const int* tgt, const int* eids, const NodeBlock& blk,
-                                            const Vec<VEC>& bxj, Vec<VEC>& gbx, Vec<VEC>& gex) {
-  int64_t ti[D];
-  bool in[D];
-  Vec<VEC> eh[D], gx[D], dn[D], p0[D];
-  float rr[D];
+                                            const float* __restrict__ Bx, int64_t node, Vec<VEC>& gbx,
+                                            Vec<VEC>& gex, const int* rp_d, const int* eids_d, int e0,
+                                            const float* __restrict__ sD, const float* __restrict__ sS, int cap) {
+  int64_t ti[D], id[D];
+  int slot[D];
 #pragma unroll
   for (int u = 0; u < D; ++u) {
     ti[u] = tgt[u];
-    const int64_t id = eids[u];
-    in[u] = ti[u] >= blk.n0 && ti[u] < blk.n1;
-    eh[u] = Vec<VEC>::load(e_hat + id * d + c);
-    gx[u] = Vec<VEC>::load(g_x + ti[u] * ldgx + c);
-    dn[u] = Vec<VEC>::load(den + ti[u] * d + c);
-    p0[u] = Vec<VEC>::load((in[u] ? g_Ce : g_e) + id * d + c);   // this workgroup's delta row, or g_e to rebuild it
-    rr[u] = GATE ? r_edge[id] : 1.0f;
+    id[u] = eids[u];
+    slot[u] = -1;
+    if (cap > 0 && ti[u] >= blk.n0 && ti[u] < blk.n1) {
+      const int b0 = rp_d[ti[u] - blk.n0], b1 = rp_d[ti[u] - blk.n0 + 1];
+      for (int kk = b0; kk < b1; ++kk)
+        if (eids_d[kk] == (int)id[u] && kk - e0 < cap) slot[u] = kk - e0;
+    }
   }
 #pragma unroll
   for (int u = 0; u < D; ++u) {
-    Vec<VEC> xt = Vec<VEC>::zero(), axi = Vec<VEC>::zero();
-    if (!in[u]) {                                // ~10-15 % of the edges: one more round trip
-      xt = Vec<VEC>::load(x_tilde + ti[u] * d + c);
-      axi = Vec<VEC>::load(Ax + ti[u] * ld + c);
-    }
+    if (slot[u] >= 0) {                      // common case: LDS only
+      const Vec<VEC> dl = Vec<VEC>::load(sD + slot[u] * d + c);
+      const Vec<VEC> sa = Vec<VEC>::load(sS + slot[u] * d + c);
 #pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      const float ai = gx[u][v] * (1.0f / (dn[u][v] + 1e-6f));
-      const float s = sigmoidf_fast(eh[u][v]);
-      float dl = p0[u][v];
-      if (!in[u]) {
-        float sp = s * (1.0f - s);
-        if (GATE) sp = sp * rr[u];
-        dl = (dl + (ai * bxj[v]) * sp) + (-ai * (xt[v] - axi[v])) * sp;   // b_i = -a_i aggr_i
+      for (int v = 0; v < VEC; ++v) {
+        gex[v] += dl[v];
+        gbx[v] += sa[v];
       }
-      gex[v] += dl;
-      gbx[v] += (GATE ? s * rr[u] : s) * ai;
+    } else {                                 // target owned by another workgroup (or stash overflow)
+      const bool in = ti[u] >= blk.n0 && ti[u] < blk.n1;
+      const Vec<VEC> eh = Vec<VEC>::load(e_hat + id[u] * d + c);
+      const Vec<VEC> gx = Vec<VEC>::load(g_x + ti[u] * ldgx + c);
+      const Vec<VEC> dn = Vec<VEC>::load(den + ti[u] * d + c);
+      const Vec<VEC> p0 = Vec<VEC>::load((in ? g_Ce : g_e) + id[u] * d + c);   // own delta row, or g_e to rebuild it
+      const float rr = GATE ? r_edge[id[u]] : 1.0f;
+      Vec<VEC> xt = Vec<VEC>::zero(), axi = Vec<VEC>::zero(), bxj = Vec<VEC>::zero();
+      if (!in) {
+        xt = Vec<VEC>::load(x_tilde + ti[u] * d + c);
+        axi = Vec<VEC>::load(Ax + ti[u] * ld + c);
+        bxj = Vec<VEC>::load(Bx + node * ld + c);
+      }
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const float ai = gx[v] * (1.0f / (dn[v] + 1e-6f));
+        const float s = sigmoidf_fast(eh[v]);
+        float dl = p0[v];
+        if (!in) {
+          float sp = s * (1.0f - s);
+          if (GATE) sp = sp * rr;
+          dl = (dl + (ai * bxj[v]) * sp) + (-ai * (xt[v] - axi[v])) * sp;   // b_i = -a_i aggr_i
+        }
+        gex[v] += dl;
+        gbx[v] += (GATE ? s * rr : s) * ai;
+      }
     }
   }
 }
@@ -337,12 +374,14 @@ __device__ __forceinline__ void bwd_b_rows(const float* __restrict__ g_x, int64_
                                            const int* rq, const int* tgt, const int* eids, const NodeBlock& blk,
                                            int d, int row, int npi, int c, const float* g_Ce,
                                            float* __restrict__ g_Bx, float* __restrict__ g_Ex, int64_t ldg,
-                                           const float* __restrict__ r_edge) {
+                                           const float* __restrict__ r_edge, const int* rp_d, const int* eids_d,
+                                           int e0, const float* __restrict__ sD, const float* __restrict__ sS,
+                                           int cap) {
 #define GPS_BWD_B(DD) bwd_b_chunk<VEC, GATE, DD>(g_x, ldgx, g_e, e_hat, Ax, ld, x_tilde, den, r_edge, g_Ce, d, c, \
-                                                 tgt + k, eids + k, blk, bxj, gbx, gex)
+                                                 tgt + k, eids + k, blk, Bx, node, gbx, gex, rp_d, eids_d, e0, sD, \
+                                                 sS, cap)
   for (int64_t node = blk.n0 + row; node < blk.n1; node += npi) {
     const int beg = rq[node - blk.n0], end = rq[node - blk.n0 + 1];
-    const Vec<VEC> bxj = Vec<VEC>::load(Bx + node * ld + c);
     Vec<VEC> gbx = Vec<VEC>::zero(), gex = Vec<VEC>::zero();
     int k = beg;
     for (; k + 4 < end; k += 4) GPS_BWD_B(4);
@@ -367,9 +406,10 @@ __global__ __launch_bounds__(GG_T) void k_gatedgcn_bwd(
     const int32_t* __restrict__ eid, const int32_t* __restrict__ rowptr_s, const int32_t* __restrict__ dst,
     const int32_t* __restrict__ eid_s, int64_t N, int d, float* g_Ce, float* __restrict__ g_Ax,
     float* __restrict__ g_Bx, float* __restrict__ g_Dx, float* __restrict__ g_Ex, int64_t ldg,
-    const float* __restrict__ r_edge, int nb, int npi) {
+    const float* __restrict__ r_edge, int nb, int npi, int cap_arg) {
   __shared__ int s_rp[GG_MAXNB + 1], s_rq[GG_MAXNB + 1];
   __shared__ int s_src[GG_MAXE], s_eid[GG_MAXE], s_dst[GG_MAXE], s_eid2[GG_MAXE];
+  extern __shared__ __attribute__((aligned(16))) float g_stash[];   // [2][cap][d]: delta | sig a_i per CSR slot
   const NodeBlock blk = node_block(N, nb);
   if (!blk.valid()) return;                 // whole workgroup leaves together
   const bool st_d = stage_slice(rowptr, src, eid, blk, s_rp, s_src, s_eid);
@@ -380,14 +420,17 @@ __global__ __launch_bounds__(GG_T) void k_gatedgcn_bwd(
   const bool active = row < npi;
   const int c = (threadIdx.x - row * lpr) * VEC;
   // ---- phase A: keyed by target ------------------------------------------------------------------
+  const int e0 = s_rp[0];
+  const int cap = st_d ? cap_arg : 0;       // the slot lookup of phase B walks the staged CSR slice
+  float* sD = g_stash;
+  float* sS = g_stash + (int64_t)cap_arg * d;
   if (active) {
-    const int e0 = s_rp[0];
     if (st_d)
       bwd_a_rows<VEC, GATE>(g_x, ldgx, g_e, e_hat, Bx, ld, den, s_rp, s_src - e0, s_eid - e0, blk, d, row, npi, c,
-                            g_Ce, g_Ax, g_Dx, ldg, r_edge);
+                            g_Ce, g_Ax, g_Dx, ldg, r_edge, sD, sS, e0, cap);
     else
       bwd_a_rows<VEC, GATE>(g_x, ldgx, g_e, e_hat, Bx, ld, den, s_rp, src, eid, blk, d, row, npi, c, g_Ce, g_Ax,
-                            g_Dx, ldg, r_edge);
+                            g_Dx, ldg, r_edge, sD, sS, e0, 0);
   }
   __threadfence_block();
   __syncthreads();            // this workgroup's g_Ce rows are visible to all of its lanes (same CU)
@@ -396,10 +439,10 @@ __global__ __launch_bounds__(GG_T) void k_gatedgcn_bwd(
   const int q0 = s_rq[0];
   if (st_s)
     bwd_b_rows<VEC, GATE>(g_x, ldgx, g_e, e_hat, Ax, Bx, ld, x_tilde, den, s_rq, s_dst - q0, s_eid2 - q0, blk, d,
-                          row, npi, c, g_Ce, g_Bx, g_Ex, ldg, r_edge);
+                          row, npi, c, g_Ce, g_Bx, g_Ex, ldg, r_edge, s_rp, s_eid - e0, e0, sD, sS, cap);
   else
     bwd_b_rows<VEC, GATE>(g_x, ldgx, g_e, e_hat, Ax, Bx, ld, x_tilde, den, s_rq, dst, eid_s, blk, d, row, npi, c,
-                          g_Ce, g_Bx, g_Ex, ldg, r_edge);
+                          g_Ce, g_Bx, g_Ex, ldg, r_edge, s_rp, s_eid - e0, e0, sD, sS, cap);
 }
 
 inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
@@ -436,9 +479,9 @@ inline Plan plan_for(int64_t N, int lanes_per_row) {
   k_gatedgcn_fwd<VEC, SAVE, GATE><<<pl.grid, pl.threads, 0, s>>>(Ax, Bx, Dx, Ex, ld_node, Ce, rowptr_dst,  \
       src_by_dst, eid_by_dst, N, d, x_tilde, e_hat, den, r_edge, pl.nb, pl.npi)
 #define GPS_GG_BWD(GATE)                                                                             \
-  k_gatedgcn_bwd<VEC, GATE><<<pl.grid, pl.threads, 0, s>>>(g_x, ld_gx, g_e, e_hat, Ax, Bx, ld_node, x_tilde, \
+  k_gatedgcn_bwd<VEC, GATE><<<pl.grid, pl.threads, stash_bytes, s>>>(g_x, ld_gx, g_e, e_hat, Ax, Bx, ld_node, x_tilde, \
       den, rowptr_dst, src_by_dst, eid_by_dst, rowptr_src, dst_by_src, eid_by_src, N, d, g_Ce,        \
-      g_Ax == g_x ? nullptr : g_Ax, g_Bx, g_Dx, g_Ex, ld_gnode, r_edge, pl.nb, pl.npi)
+      g_Ax == g_x ? nullptr : g_Ax, g_Bx, g_Dx, g_Ex, ld_gnode, r_edge, pl.nb, pl.npi, cap)
 
 extern "C" {
 
@@ -492,6 +535,11 @@ int gps_gatedgcn_bwd(const float* g_x, int64_t ld_gx, const float* g_e, const fl
                    ld_node % 2 == 0 && ld_gnode % 2 == 0 && ld_gx % 2 == 0 && ok(8), {
     GPS_REQUIRE(d / VEC <= GG_T, "gps_gatedgcn_bwd: d=%d too wide for one workgroup pass (%d lanes)", d, d / VEC);
     const Plan pl = plan_for(N, d / VEC);
+    // LDS stash of phase A's per-edge results for phase B: [2][cap][d] floats next to the 29 KB of index slices
+    static const int stash_kb = env_int("GPS_GG_STASH_KB", 112);
+    int cap = (int)(((int64_t)stash_kb * 1024) / (8LL * d));
+    if (cap > GG_MAXE) cap = GG_MAXE;
+    const size_t stash_bytes = (size_t)cap * d * 8;
     if (r_edge) GPS_GG_BWD(true); else GPS_GG_BWD(false);
   });
   return gps::launch_status("gps_gatedgcn_bwd");

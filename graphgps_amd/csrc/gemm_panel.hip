@@ -1,0 +1,358 @@
+// Row-panel GEMM for the dense side of the GPS block: C = A W^T (+ bias, + addend, ReLU/dropout epilogues), fp32 in,
+// fp32 out, fp32-exact products on the bf16 MFMA pipe.
+//
+// What it replaces: the rocBLAS / hipBLASLt fp32 GEMMs behind the nn.Linear modules of the block
+// (graphgps/layer/gatedgcn_layer.py:57-61 A..E, graphgps/layer/gps_layer.py:104-106 in/out-proj, :143-144,253-257
+// FFN) and their input-gradient GEMMs.  Shapes at PCQM4M: M = 7.6k nodes or 15.3k edges, N and K in {384, 768, 2688}.
+// Through the libraries these run at 50-119 TFLOP/s (35-76 % of the 157 TFLOP/s fp32-input MFMA peak): K is short
+// (12-24 k-steps), so a 128-row tile spends as long in its prologue / epilogue as in its loop, and 7569 / 128 = 60
+// row tiles x 3 column tiles leaves 30 % of the CUs idle.
+//
+// Arithmetic (same as csrc/wgrad.hip): every fp32 operand value is split EXACTLY into three bf16 pieces
+// (hi + mid + lo == v bit for bit) and a*b is formed from 6 of the 9 piece products (hh, hm, mh, hl, lh, mm; the
+// dropped ones are < 2^-21 |a||b|) with fp32 accumulation in v_mfma_f32_32x32x16_bf16.  Every partial product is
+// exact in fp32, so the rounding model is that of an fp32-input MFMA GEMM (measured 7e-7 vs fp64), while the bf16
+// pipe issues 16x the fp32-input rate: 6 MFMAs per fp32 one leave a 2.7x higher ceiling (417 TFLOP/s-equivalent).
+//
+// Data movement (the part round 1's gps_gemm_nt got wrong: it split A again in every one of up to 21 column tiles,
+// in producer wavefronts whose VALU work did not hide, and quantised to 128 x 128 tiles):
+//   * W is split ONCE per optimizer step by k_split_weights into a k-stage-major image Wp[piece][K/32][N][32] bf16
+//     (both W and W^T, for forward and input-gradient), so a column panel's k-stage is ONE contiguous 12 KB block
+//     per piece: global -> LDS is a straight 16-byte-per-lane copy, every L2 line used whole;
+//   * a workgroup owns a 64-row x 192-column panel for the whole K: 7569 rows -> 119 row tiles, N / 192 = 2, 4 or 14
+//     column panels -> 238 / 476 / 1666 workgroups = 0.93, 1.86, 6.5 rounds of 256 CUs (93 % of the chip busy where
+//     128 x 128 tiles give 70 %); blocks are numbered panel-major, so the ~256 resident workgroups stream the same
+//     one or two weight panels (0.4 MB each) out of L2 while A rows come from HBM once per panel;
+//   * A (fp32) is loaded one 64 x 32 stage ahead into registers, split by the loading lane (8 values per lane per
+//     stage: ~80 VALU instructions that interleave with the 36 MFMAs of the stage) and written to LDS as three bf16
+//     tiles; stages are single-buffered in LDS (61 KB) so that TWO workgroups share a CU and cover each other's
+//     staging / barrier phases;
+//   * 4 wavefronts as 2 x 2, each 32 x 96 of the panel = 3 accumulator blocks: per 16-wide k-step 3 + 9 16-byte LDS
+//     fragment reads (conflict-free at an 80-byte row pitch) feed 18 MFMAs (576 cycles) -- the loop is MFMA-bound.
+// Epilogues (all optional, applied to the accumulators before the one store of C):
+//   + bias[n]; + Cin[m][n] (residual / gradient accumulation, may alias C); ReLU + dropout(p, seed) keyed
+//   (row, column) exactly as csrc/bn_fused.hip's act_drop (gps_layer.py:256); multiplication by the ReLU/dropout mask
+//   of a saved activation `mask_src` (the FFN's backward, = gps_act_drop_bwd).
+#include <cstdint>
+
+#include "gps_common.hpp"
+
+namespace {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int TM = 64, TN = 192, BK = 32;
+constexpr int PITCH = 40;          // bf16 per LDS row: 32 + 8 (80 bytes: conflict-free 16-byte fragment reads)
+constexpr int NTHREADS = 256;
+
+__device__ __forceinline__ uint32_t mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+// (row, column) dropout mask of the row kernels (csrc/bn_fused.hip: row_hash / keep_elem)
+__device__ __forceinline__ uint32_t row_hash(uint32_t rowid, uint64_t seed) {
+  return mix32(rowid ^ (uint32_t)seed) + (uint32_t)(seed >> 32);
+}
+__device__ __forceinline__ bool keep_elem(uint32_t rh, uint32_t col, float p_drop) {
+  const uint32_t r = mix32(rh + col * 0x9E3779B9U);
+  return (float)(r >> 8) * (1.0f / 16777216.0f) >= p_drop;
+}
+
+// exact 3-way split of one fp32 into bf16 bit patterns (in the high halves)
+__device__ __forceinline__ void split1(float v, uint32_t& h, uint32_t& m, uint32_t& l) {
+  h = __float_as_uint(v) & 0xFFFF0000u;
+  const float r1 = v - __uint_as_float(h);
+  m = __float_as_uint(r1) & 0xFFFF0000u;
+  const float r2 = r1 - __uint_as_float(m);
+  l = __float_as_uint(r2) & 0xFFFF0000u;
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// weight images
+// ------------------------------------------------------------------------------------------------------------
+struct SplitDesc {
+  const float* W;       // [rows][cols] fp32, row stride ldw
+  int64_t ldw;
+  int rows, cols;
+  uint16_t* nt;         // image of B[n = row][k = col]  (forward: C = A W^T), or nullptr
+  uint16_t* tn;         // image of B[n = col][k = row]  (input gradient: C = G W), or nullptr
+  int block_begin;
+};
+constexpr int kMaxSplit = 8;
+struct SplitGroup {
+  SplitDesc d[kMaxSplit];
+  int n;
+};
+
+// image index of element (n, k) of a B matrix with N rows and K columns, piece p
+__device__ __forceinline__ int64_t img_index(int p, int n, int k, int N, int K) {
+  return (((int64_t)p * (K / BK) + (k / BK)) * N + n) * BK + (k % BK);
+}
+
+// One workgroup = a 32-row x 128-column tile of W (one k-stage of the transposed image, four of the direct one).
+// Rows are read coalesced and split once; the direct image takes 8-byte stores straight from registers, the
+// transposed image goes through an LDS transpose so that its 64-byte (n, 32 k) runs leave as 16-byte stores
+// (2-byte scattered stores made this kernel 31 us per layer; it runs once per layer and step).
+constexpr int ST_R = 32, ST_C = 128, ST_P = ST_R + 8;      // LDS tile [3][128 columns][32 rows + pad] bf16
+__global__ __launch_bounds__(256) void k_split_weights(const SplitGroup G) {
+  __shared__ __attribute__((aligned(16))) uint16_t T[3][ST_C * ST_P];
+  int di = 0;
+#pragma unroll
+  for (int i = 1; i < kMaxSplit; ++i)
+    if (i < G.n && (int)blockIdx.x >= G.d[i].block_begin) di = i;
+  const SplitDesc& D = G.d[di];
+  const int ctiles = (D.cols + ST_C - 1) / ST_C;
+  const int tile = blockIdx.x - D.block_begin;
+  const int r0 = (tile / ctiles) * ST_R, c0 = (tile % ctiles) * ST_C;
+  const int t = threadIdx.x;
+  // 32 rows x 32 float4 column groups = 1024 float4: 4 per thread
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = t + 256 * i;
+    const int r = idx >> 5, cq = (idx & 31) * 4;
+    const int row = r0 + r, col = c0 + cq;
+    const bool ok = row < D.rows && col < D.cols;
+    const f32x4 v = ok ? *reinterpret_cast<const f32x4*>(D.W + (int64_t)row * D.ldw + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    uint32_t h[4], m[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) split1(v[j], h[j], m[j], l[j]);
+    if (D.nt && ok) {       // B[n = row][k = col..col+3]: 4 consecutive k of one row -> one 8-byte store per piece
+      *reinterpret_cast<u32x2*>(D.nt + img_index(0, row, col, D.rows, D.cols)) = (u32x2){(h[0] >> 16) | h[1], (h[2] >> 16) | h[3]};
+      *reinterpret_cast<u32x2*>(D.nt + img_index(1, row, col, D.rows, D.cols)) = (u32x2){(m[0] >> 16) | m[1], (m[2] >> 16) | m[3]};
+      *reinterpret_cast<u32x2*>(D.nt + img_index(2, row, col, D.rows, D.cols)) = (u32x2){(l[0] >> 16) | l[1], (l[2] >> 16) | l[3]};
+    }
+    if (D.tn) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        T[0][(cq + j) * ST_P + r] = (uint16_t)(h[j] >> 16);
+        T[1][(cq + j) * ST_P + r] = (uint16_t)(m[j] >> 16);
+        T[2][(cq + j) * ST_P + r] = (uint16_t)(l[j] >> 16);
+      }
+    }
+  }
+  if (!D.tn) return;
+  __syncthreads();
+  // transposed image B[n = col][k = row]: this tile is stage r0 / 32, columns c0 .. c0 + 127, 64 bytes per (piece, n):
+  // 3 pieces x 128 n x 4 chunks of 16 bytes = 1536 chunks, 6 per thread
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    const int idx = t + 256 * i;
+    const int p = idx / (ST_C * 4), rem = idx - p * (ST_C * 4);
+    const int n = rem >> 2, ch = rem & 3;
+    if (c0 + n < D.cols && r0 + ch * 8 < D.rows) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(&T[p][n * ST_P + ch * 8]);
+      *reinterpret_cast<u32x4*>(D.tn + img_index(p, c0 + n, r0 + ch * 8, D.cols, D.rows)) = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// the GEMM
+// ------------------------------------------------------------------------------------------------------------
+struct PanelArgs {
+  const float* A;
+  int64_t lda, M;
+  int K, N;
+  const uint16_t* Bp;      // weight image [3][K/32][N][32]
+  const float* bias;       // [N] or nullptr
+  const float* Cin;        // [M][N] addend (row stride ldcin) or nullptr; may alias C
+  int64_t ldcin;
+  float* C;
+  int64_t ldc;
+  int epilogue;            // 0 none, 1 relu + dropout(p, seed), 2 multiply by the relu/dropout mask of mask_src
+  const float* mask_src;   // [M][N] (row stride ldmask): the saved activation whose mask is applied (epilogue 2)
+  int64_t ldmask;
+  float p_drop;
+  uint64_t seed;
+  const uint64_t* salt;
+  int row_tiles;
+};
+
+template <int EPI, bool HAS_CIN>
+__global__ __launch_bounds__(NTHREADS) void k_gemm_panel(const PanelArgs P) {
+  // single-buffered stages (61 KB): TWO workgroups share a CU, and while one of them splits / stages / waits at its
+  // barrier the other one's wavefronts keep the MFMA pipe busy (double-buffered at 123 KB = one workgroup per CU,
+  // one wavefront per SIMD, every non-MFMA cycle was an idle MFMA cycle: measured 0.6x the library GEMMs)
+  __shared__ __attribute__((aligned(16))) uint16_t As[3][TM * PITCH];
+  __shared__ __attribute__((aligned(16))) uint16_t Bs[3][TN * PITCH];
+  const int panel = blockIdx.x / P.row_tiles, rt = blockIdx.x - panel * P.row_tiles;   // panel-major numbering
+  const int64_t m0 = (int64_t)rt * TM;
+  const int n0 = panel * TN;
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, kh = lane >> 5;
+  const int KS = P.K / BK;
+
+  // staging roles.  A: 2 float4 per thread (rows ar, ar + 32; 4 k at akq); W: 9 16-byte chunks per thread
+  const int ar = t >> 3, akq = (t & 7) * 4;
+  const float* __restrict__ Ag = P.A;
+  const int64_t arow0 = min(m0 + ar, P.M - 1), arow1 = min(m0 + ar + 32, P.M - 1);
+  const bool aok0 = m0 + ar < P.M, aok1 = m0 + ar + 32 < P.M;
+  // A comes from HBM (~1-2 us under load) and a stage is only ~0.4 us of MFMA work: ADEPTH stages of A are kept in
+  // flight per workgroup (a one-stage prefetch left 8 KB per CU outstanding and the loop ran at the pace of one
+  // HBM round trip per stage: measured 0.55x the library GEMMs); W stages come from L2, one stage ahead
+  constexpr int ADEPTH = 4;
+  f32x4 ra[ADEPTH][2];     // native vector types: HIP's float4 / uint4 structs kept these arrays in scratch memory
+  u32x4 rb[9];
+  auto load_a = [&](int s, f32x4 (&dst)[2]) __attribute__((always_inline)) {
+    // A is read once per column panel and C written once: both marked non-temporal, so that the weight panel
+    // every workgroup of the XCD re-streams (0.4 MB) stays in the 4 MB L2 instead of being evicted by them
+    dst[0] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Ag + arow0 * P.lda + s * BK + akq));
+    dst[1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Ag + arow1 * P.lda + s * BK + akq));
+  };
+  auto load_b = [&](int s, u32x4 (&rbuf)[9]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+      // piece p, stage s, rows n0 .. n0 + 191: one contiguous block of 192 * 32 bf16 = 768 16-byte chunks
+      const u32x4* src = reinterpret_cast<const u32x4*>(P.Bp + (((int64_t)p * KS + s) * P.N + n0) * BK);
+#pragma unroll
+      for (int i = 0; i < 3; ++i) rbuf[p * 3 + i] = src[t + NTHREADS * i];
+    }
+  };
+  auto store_lds = [&](const f32x4 (&src)[2], const u32x4 (&rbuf)[9]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const f32x4 v = src[i];
+      const bool ok = i == 0 ? aok0 : aok1;
+      uint32_t h[4], m[4], l[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) split1(ok ? v[j] : 0.0f, h[j], m[j], l[j]);
+      const int off = (ar + 32 * i) * PITCH + akq;
+      *reinterpret_cast<u32x2*>(&As[0][off]) = (u32x2){(h[0] >> 16) | h[1], (h[2] >> 16) | h[3]};
+      *reinterpret_cast<u32x2*>(&As[1][off]) = (u32x2){(m[0] >> 16) | m[1], (m[2] >> 16) | m[3]};
+      *reinterpret_cast<u32x2*>(&As[2][off]) = (u32x2){(l[0] >> 16) | l[1], (l[2] >> 16) | l[3]};
+    }
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int c = t + NTHREADS * i;          // chunk: row c >> 2, 8 bf16 at (c & 3) * 8
+        *reinterpret_cast<u32x4*>(&Bs[p][(c >> 2) * PITCH + (c & 3) * 8]) = rbuf[p * 3 + i];
+      }
+  };
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[j][q] = 0.0f;
+
+#pragma unroll
+  for (int q = 0; q < ADEPTH; ++q) load_a(q, ra[q]);      // KS is a multiple of ADEPTH (host check)
+  load_b(0, rb);
+  for (int s0 = 0; s0 < KS; s0 += ADEPTH) {
+#pragma unroll
+    for (int q = 0; q < ADEPTH; ++q) {
+      const int s = s0 + q;
+      if (s) __syncthreads();                  // every wave is done with stage s-1's tiles
+      store_lds(ra[q], rb);                    // stage s
+      // unconditional (past the last stage the last one is re-read): a load under a condition makes the register
+      // arrays live across control flow and the compiler parks them in scratch memory (measured: 0.53x)
+      load_a(min(s + ADEPTH, KS - 1), ra[q]);
+      load_b(min(s + 1, KS - 1), rb);          // in flight during the MFMAs below
+      __syncthreads();
+#pragma unroll
+      for (int ks = 0; ks < BK / 16; ++ks) {
+        bf16x8 a[3], b[3][3];
+        const int aoff = (wm * 32 + li) * PITCH + ks * 16 + 8 * kh;
+#pragma unroll
+        for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const bf16x8*>(&As[p][aoff]);
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+          const int boff = (wn * 96 + j * 32 + li) * PITCH + ks * 16 + 8 * kh;
+#pragma unroll
+          for (int p = 0; p < 3; ++p) b[j][p] = *reinterpret_cast<const bf16x8*>(&Bs[p][boff]);
+        }
+        // smallest terms first; the three accumulators rotate so no MFMA waits on its predecessor
+        constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};
+#pragma unroll
+        for (int term = 0; term < 6; ++term)
+#pragma unroll
+          for (int j = 0; j < 3; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[term]], b[j][TB[term]], acc[j], 0, 0, 0);
+      }
+    }
+  }
+
+  // epilogue: D[row = (q&3) + 8*(q>>2) + 4*kh][col = li] of each 32 x 32 block; 32 lanes = 128 contiguous bytes per row
+  const uint64_t seed = gps::salted_seed(P.seed, P.salt);
+  const bool drop = EPI != 0 && P.p_drop > 0.0f;
+  const float inv_keep = drop ? 1.0f / (1.0f - P.p_drop) : 1.0f;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int col = n0 + wn * 96 + j * 32 + li;
+    const float bv = P.bias ? P.bias[col] : 0.0f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int64_t row = m0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh;
+      const int64_t rc = row < P.M ? row : P.M - 1;          // clamped: loads unconditional, the store predicated
+      float v = acc[j][q] + bv;
+      if (HAS_CIN) v += __builtin_nontemporal_load(P.Cin + rc * P.ldcin + col);
+      if (EPI == 1) v = fmaxf(v, 0.0f);
+      if (EPI == 2) v = P.mask_src[rc * P.ldmask + col] > 0.0f ? v : 0.0f;
+      if (EPI != 0) {
+        const bool keep = !drop || keep_elem(row_hash((uint32_t)rc, seed), (uint32_t)col, P.p_drop);
+        v = keep ? v * inv_keep : 0.0f;
+      }
+      if (row < P.M) __builtin_nontemporal_store(v, P.C + row * P.ldc + col);
+    }
+  }
+}
+
+inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) % 16) == 0; }
+
+}  // namespace
+
+extern "C" {
+
+size_t gps_gemm_image_elems(int64_t N, int64_t K) { return (size_t)(3 * N * K); }
+
+int gps_gemm_panel_supported(int64_t N, int64_t K) { return N > 0 && K > 0 && N % TN == 0 && K % (4 * BK) == 0; }
+
+int gps_gemm_split_weights(int n, const gps_gemm_split* descs, gps_stream_t stream) {
+  GPS_REQUIRE(n >= 1 && n <= kMaxSplit && descs, "gps_gemm_split_weights: 1..%d weights per launch", kMaxSplit);
+  SplitGroup G{};
+  G.n = n;
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    const gps_gemm_split& d = descs[i];
+    GPS_REQUIRE(d.W && d.rows > 0 && d.cols > 0 && d.ldw >= d.cols && d.cols % 4 == 0 && d.ldw % 4 == 0 && al16(d.W),
+                "gps_gemm_split_weights: weight %d: bad shape / alignment", i);
+    GPS_REQUIRE(!d.image_nt || (d.cols % BK == 0 && al16(d.image_nt)), "gps_gemm_split_weights: weight %d: cols %% 32", i);
+    GPS_REQUIRE(!d.image_tn || d.rows % BK == 0, "gps_gemm_split_weights: weight %d: rows %% 32", i);
+    G.d[i] = SplitDesc{d.W, d.ldw, d.rows, d.cols, d.image_nt, d.image_tn, blocks};
+    blocks += ((d.rows + ST_R - 1) / ST_R) * ((d.cols + ST_C - 1) / ST_C);
+  }
+  k_split_weights<<<(unsigned)blocks, 256, 0, gps::as_stream(stream)>>>(G);
+  return gps::launch_status("gps_gemm_split_weights");
+}
+
+int gps_gemm_panel(const float* A, int64_t lda, int64_t M, int K, const uint16_t* image, int N, const float* bias,
+                   const float* Cin, int64_t ldcin, float* C, int64_t ldc, int epilogue, const float* mask_src,
+                   int64_t ldmask, float p_drop, uint64_t seed, gps_stream_t stream) {
+  GPS_REQUIRE(M >= 0 && gps_gemm_panel_supported(N, K), "gps_gemm_panel: needs N %% 192 == 0 and K %% 128 == 0 (N=%d K=%d)",
+              N, K);
+  if (M == 0) return GPS_OK;
+  GPS_REQUIRE(A && image && C && lda >= K && ldc >= N && lda % 4 == 0 && al16(A) && al16(image),
+              "gps_gemm_panel: null / misaligned buffer");
+  GPS_REQUIRE(!Cin || ldcin >= N, "gps_gemm_panel: bad addend stride");
+  GPS_REQUIRE(epilogue >= 0 && epilogue <= 2 && (epilogue != 2 || (mask_src && ldmask >= N)), "gps_gemm_panel: epilogue");
+  GPS_REQUIRE(p_drop >= 0.0f && p_drop < 1.0f, "gps_gemm_panel: p_drop");
+  PanelArgs P{};
+  P.A = A; P.lda = lda; P.M = M; P.K = K; P.N = N; P.Bp = image; P.bias = bias; P.Cin = Cin; P.ldcin = ldcin;
+  P.C = C; P.ldc = ldc; P.epilogue = epilogue; P.mask_src = mask_src; P.ldmask = ldmask;
+  P.p_drop = epilogue ? p_drop : 0.0f; P.seed = seed; P.salt = gps::dropout_salt();
+  P.row_tiles = (int)((M + TM - 1) / TM);
+  const unsigned grid = (unsigned)(P.row_tiles * (N / TN));
+  hipStream_t s = gps::as_stream(stream);
+  if (epilogue == 0) { if (Cin) k_gemm_panel<0, true><<<grid, NTHREADS, 0, s>>>(P); else k_gemm_panel<0, false><<<grid, NTHREADS, 0, s>>>(P); }
+  else if (epilogue == 1) { if (Cin) k_gemm_panel<1, true><<<grid, NTHREADS, 0, s>>>(P); else k_gemm_panel<1, false><<<grid, NTHREADS, 0, s>>>(P); }
+  else { if (Cin) k_gemm_panel<2, true><<<grid, NTHREADS, 0, s>>>(P); else k_gemm_panel<2, false><<<grid, NTHREADS, 0, s>>>(P); }
+  return gps::launch_status("gps_gemm_panel");
+}
+
+}  // extern "C"

@@ -33,7 +33,7 @@
 namespace {
 using namespace attn;
 
-constexpr int SA_ROWS = 64;
+// (graphs of up to 64 nodes = 4 key tiles x 4 query tiles per wavefront)
 
 template <int DH>
 struct SGeo {
@@ -50,9 +50,9 @@ __device__ __forceinline__ void row_slice(const float* __restrict__ base, uint32
   const float2* p = reinterpret_cast<const float2*>(base + __umul24((uint32_t)(ok ? row : 0), ld) + col);
 #pragma unroll
   for (int c = 0; c < KPL / 2; ++c) {
-    const float2 v = ok ? p[c] : make_float2(0.f, 0.f);
-    dst[2 * c] = v.x * scale;
-    dst[2 * c + 1] = v.y * scale;
+    const float2 v = p[c];                 // unconditional (the address is clamped into the graph): a load under a
+    dst[2 * c] = ok ? v.x * scale : 0.0f;  // condition becomes a branch, and the loads stop being issued together
+    dst[2 * c + 1] = ok ? v.y * scale : 0.0f;
   }
 }
 // element [row][col] (zero outside the graph / the head)
@@ -64,43 +64,38 @@ __device__ __forceinline__ float col_elem(const float* __restrict__ base, uint32
 }
 
 struct Item {
-  int n0, n, q0, nq, h;
+  int n0, n, h;
   bool live;
 };
-// wavefront -> (tile slot, head); only the slot that starts a 64-row block of its graph is live
-__device__ __forceinline__ Item item_setup(const int32_t* __restrict__ ptr, const int32_t* __restrict__ tile_graph,
-                                           const int32_t* __restrict__ tile_row0, int64_t n_work, int H) {
+// wavefront -> (graph, head).  Indexed by GRAPH, not through the 16-row tile map: every wavefront launched is live
+// (with the tile map two thirds of the slots start no block, and although such a wave exits at once, the live ones
+// end up spread over three dispatch generations instead of one -- measured: 27 us against the ~8 us of one
+// generation).
+__device__ __forceinline__ Item item_setup(const int32_t* __restrict__ ptr, int64_t B, int H) {
   Item it;
   it.live = false;
   const int64_t wi = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (wi >= n_work) return it;
-  const int64_t tile = wi / H;
-  it.h = (int)(wi - tile * H);
-  const int g = tile_graph[tile];
-  if (g < 0) return it;
+  if (wi >= B * H) return it;
+  const int64_t g = wi / H;
+  it.h = (int)(wi - g * H);
   it.n0 = ptr[g];
   it.n = ptr[g + 1] - it.n0;
-  it.q0 = tile_row0[tile] - it.n0;
-  if (it.q0 & (SA_ROWS - 1)) return it;
-  it.nq = min(SA_ROWS, it.n - it.q0);
-  it.live = true;
+  it.live = it.n > 0;
   return it;
 }
 
 // =============================================================================================================
 // forward
 // =============================================================================================================
-template <int DH, bool DROP>
-__global__ __launch_bounds__(256, 4) void k_sattn_fwd(
-    const float* __restrict__ qkv, int64_t ld64, const int32_t* __restrict__ ptr,
-    const int32_t* __restrict__ tile_graph, const int32_t* __restrict__ tile_row0, int64_t n_work, int64_t N, int H,
-    float scale, uint32_t thr16, float inv_keep, uint64_t seed, const uint64_t* __restrict__ salt,
-    float* __restrict__ out, float* __restrict__ lse) {
+// NT = live 16-row tiles of the graph (queries and keys alike), a template parameter: with run-time tile predicates the
+// compiler splits the operand loads over basic blocks and waits after each (measured: 24 us; the wave spent its life
+// in ~35 serial memory round trips).  Straight-line per NT, every K-side load is in flight before the first use.
+template <int DH, bool DROP, int NT>
+__device__ __forceinline__ void sattn_fwd_body(const Item& it, const float* __restrict__ qkv, int64_t ld64, int64_t N,
+                                               int H, float scale, uint32_t thr16, float inv_keep, uint64_t seed,
+                                               float* __restrict__ out, float* __restrict__ lse) {
   using G = SGeo<DH>;
   constexpr int KPL = G::KPL, DT = G::DT;
-  const Item it = item_setup(ptr, tile_graph, tile_row0, n_work, H);
-  if (!it.live || it.q0 != 0) return;         // host guarantees n <= 64: one block per graph
-  seed = gps::salted_seed(seed, salt);
   const int lane = threadIdx.x & 63, i = lane & 15, grp = lane >> 4;
   const int h = it.h, d = H * DH;
   const uint32_t ld = (uint32_t)ld64;
@@ -108,14 +103,13 @@ __global__ __launch_bounds__(256, 4) void k_sattn_fwd(
   const float* __restrict__ Kb = Qb + d;
   const float* __restrict__ Vb = Qb + 2 * d;
   float* __restrict__ Ob = out + (int64_t)it.n0 * d + h * DH;
-  const int nt = (it.n + 15) >> 4;            // live 16-row tiles (queries and keys alike)
 
   // K-side operands of the graph: every load issued before the first use, resident for all query tiles
   float kv[4][KPL];
   float vv[DT][4][4];
 #pragma unroll
   for (int t = 0; t < 4; ++t)
-    if (t < nt) {
+    if (t < NT) {
       row_slice<KPL>(Kb, ld, 16 * t + i, it.n, grp * KPL, 1.0f, kv[t]);
 #pragma unroll
       for (int r = 0; r < 4; ++r)
@@ -126,7 +120,7 @@ __global__ __launch_bounds__(256, 4) void k_sattn_fwd(
   float qv[KPL];
   row_slice<KPL>(Qb, ld, i, it.n, grp * KPL, scale, qv);
 #pragma unroll 1
-  for (int qt = 0; qt < nt; ++qt) {
+  for (int qt = 0; qt < NT; ++qt) {
     const int ql = 16 * qt + i;
     f32x4 s[4];
 #pragma unroll
@@ -135,12 +129,12 @@ __global__ __launch_bounds__(256, 4) void k_sattn_fwd(
     for (int c = 0; c < KPL; ++c)            // key tiles interleaved: independent accumulator chains
 #pragma unroll
       for (int t = 0; t < 4; ++t)
-        if (t < nt) s[t] = mfma16(kv[t][c], qv[c], s[t]);            // S^T[key][query]
-    if (qt + 1 < nt) row_slice<KPL>(Qb, ld, ql + 16, it.n, grp * KPL, scale, qv);   // next tile's Q, in flight
+        if (t < NT) s[t] = mfma16(kv[t][c], qv[c], s[t]);            // S^T[key][query]
+    if (qt + 1 < NT) row_slice<KPL>(Qb, ld, ql + 16, it.n, grp * KPL, scale, qv);   // next tile's Q, in flight
     float mloc = -INFINITY;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
-      if (t < nt) {
+      if (t < NT) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int key = 16 * t + 4 * grp + r;
@@ -153,7 +147,7 @@ __global__ __launch_bounds__(256, 4) void k_sattn_fwd(
     float psum = 0.0f;
 #pragma unroll
     for (int t = 0; t < 4; ++t)
-      if (t < nt) {
+      if (t < NT) {
         uint32_t h0 = 0, h1 = 0;
         if (DROP) {
           const uint32_t kp = (uint32_t)(16 * t + 4 * grp) >> 1;
@@ -177,7 +171,7 @@ __global__ __launch_bounds__(256, 4) void k_sattn_fwd(
     for (int dt = 0; dt < DT; ++dt) oacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int t = 0; t < 4; ++t)
-      if (t < nt) {
+      if (t < NT) {
 #pragma unroll
         for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -200,23 +194,35 @@ __global__ __launch_bounds__(256, 4) void k_sattn_fwd(
   }
 }
 
+template <int DH, bool DROP>
+__global__ __launch_bounds__(256, 4) void k_sattn_fwd(
+    const float* __restrict__ qkv, int64_t ld64, const int32_t* __restrict__ ptr, int64_t B, int64_t N, int H,
+    float scale, uint32_t thr16, float inv_keep, uint64_t seed, const uint64_t* __restrict__ salt,
+    float* __restrict__ out, float* __restrict__ lse) {
+  const Item it = item_setup(ptr, B, H);      // host guarantees n <= 64: one block per graph
+  if (!it.live) return;
+  seed = gps::salted_seed(seed, salt);
+  switch ((it.n + 15) >> 4) {
+    case 1: sattn_fwd_body<DH, DROP, 1>(it, qkv, ld64, N, H, scale, thr16, inv_keep, seed, out, lse); break;
+    case 2: sattn_fwd_body<DH, DROP, 2>(it, qkv, ld64, N, H, scale, thr16, inv_keep, seed, out, lse); break;
+    case 3: sattn_fwd_body<DH, DROP, 3>(it, qkv, ld64, N, H, scale, thr16, inv_keep, seed, out, lse); break;
+    default: sattn_fwd_body<DH, DROP, 4>(it, qkv, ld64, N, H, scale, thr16, inv_keep, seed, out, lse); break;
+  }
+}
+
 // =============================================================================================================
 // backward, graphs of <= 64 nodes: dQ, dK, dV in one launch
 // =============================================================================================================
-template <int DH, bool DROP>
-__global__ __launch_bounds__(256, 2) void k_sattn_bwd(
-    const float* __restrict__ d_out, const float* __restrict__ qkv, int64_t ld64, const float* __restrict__ out,
-    const float* __restrict__ lse, const int32_t* __restrict__ ptr, const int32_t* __restrict__ tile_graph,
-    const int32_t* __restrict__ tile_row0, int64_t n_work, int64_t N, int H, float scale, uint32_t thr16,
-    float inv_keep, uint64_t seed, const uint64_t* __restrict__ salt, float* __restrict__ d_qkv, int64_t ldg) {
+template <int DH, bool DROP, int NT>
+__device__ __forceinline__ void sattn_bwd_body(const Item& it, float* __restrict__ tP, const float* __restrict__ d_out,
+                                               const float* __restrict__ qkv, int64_t ld64,
+                                               const float* __restrict__ out, const float* __restrict__ lse,
+                                               int64_t N, int H, float scale, uint32_t thr16, float inv_keep,
+                                               uint64_t seed, float* __restrict__ d_qkv, int64_t ldg) {
   using G = SGeo<DH>;
   constexpr int KPL = G::KPL, DT = G::DT;
   constexpr int PT = 20;                      // transpose scratch pitch (floats): 16 + 4, rows stay 16-byte aligned
-  __shared__ __attribute__((aligned(16))) float sT[4][2][16 * PT];   // per-wave transpose scratch (P_drop, dS)
-  const Item it = item_setup(ptr, tile_graph, tile_row0, n_work, H);
-  if (!it.live || it.q0 != 0) return;         // host guarantees n <= 64: one block per graph
-  seed = gps::salted_seed(seed, salt);
-  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, i = lane & 15, grp = lane >> 4;
+  const int lane = threadIdx.x & 63, i = lane & 15, grp = lane >> 4;
   const int h = it.h, d = H * DH;
   const uint32_t ld = (uint32_t)ld64, du = (uint32_t)d;
   const float* __restrict__ Qb = qkv + (int64_t)it.n0 * ld64 + h * DH;
@@ -225,9 +231,7 @@ __global__ __launch_bounds__(256, 2) void k_sattn_bwd(
   const float* __restrict__ dOb = d_out + (int64_t)it.n0 * d + h * DH;
   const float* __restrict__ Ob = out + (int64_t)it.n0 * d + h * DH;
   const float* __restrict__ lse_b = lse + (int64_t)h * N + it.n0;
-  const int nt = (it.n + 15) >> 4;            // live 16-row tiles (queries and keys alike)
-  float* __restrict__ tP = &sT[wave][0][0];
-  float* __restrict__ tS = &sT[wave][1][0];
+  float* __restrict__ tS = tP + 16 * PT;
 
   // K-side operands, resident for all query tiles: row slices of K and V (S^T = K Q^T, dP^T = V dO^T) and the
   // column form of K (dQ^T = K^T dS^T)
@@ -235,7 +239,7 @@ __global__ __launch_bounds__(256, 2) void k_sattn_bwd(
   float kc[DT][4][4];
 #pragma unroll
   for (int t = 0; t < 4; ++t)
-    if (t < nt) {
+    if (t < NT) {
       row_slice<KPL>(Kb, ld, 16 * t + i, it.n, grp * KPL, 1.0f, kv[t]);
       row_slice<KPL>(Vb, ld, 16 * t + i, it.n, grp * KPL, 1.0f, vk[t]);
 #pragma unroll
@@ -254,7 +258,7 @@ __global__ __launch_bounds__(256, 2) void k_sattn_bwd(
     }
 
 #pragma unroll 1
-  for (int qt = 0; qt < nt; ++qt) {
+  for (int qt = 0; qt < NT; ++qt) {
     const int ql = 16 * qt + i;               // this lane's query (column of the ^T tiles)
     const bool q_ok = ql < it.n;
     // everything this query tile needs from memory, requested up front
@@ -289,14 +293,14 @@ __global__ __launch_bounds__(256, 2) void k_sattn_bwd(
     for (int c = 0; c < KPL; ++c)
 #pragma unroll
       for (int t = 0; t < 4; ++t)
-        if (t < nt) {
+        if (t < NT) {
           s[t] = mfma16(kv[t][c], qv[c], s[t]);       // S^T[key][query]
           dp[t] = mfma16(vk[t][c], dov[c], dp[t]);    // dP^T[key][query]
         }
     // P, dropout, dS^T; s <- dS^T (B operand of dQ^T), dp <- P_drop^T
 #pragma unroll
     for (int t = 0; t < 4; ++t)
-      if (t < nt) {
+      if (t < NT) {
         uint32_t h0 = 0, h1 = 0;
         if (DROP) {
           const uint32_t kp = (uint32_t)(16 * t + 4 * grp) >> 1;
@@ -326,7 +330,7 @@ __global__ __launch_bounds__(256, 2) void k_sattn_bwd(
       for (int dt = 0; dt < DT; ++dt) acc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int t = 0; t < 4; ++t)
-        if (t < nt) {
+        if (t < NT) {
 #pragma unroll
           for (int r = 0; r < 4; ++r)
 #pragma unroll
@@ -348,7 +352,7 @@ __global__ __launch_bounds__(256, 2) void k_sattn_bwd(
     // dV^T[dh][key] += dO^T[dh][q] P_drop[q][key],  dK^T[dh][key] += (scale Q)^T[dh][q] dS[q][key]
 #pragma unroll
     for (int t = 0; t < 4; ++t)
-      if (t < nt) {
+      if (t < NT) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           tP[(4 * grp + r) * PT + i] = dp[t][r];      // row = key (local to the tile), column = query
@@ -374,7 +378,7 @@ __global__ __launch_bounds__(256, 2) void k_sattn_bwd(
   }
 #pragma unroll
   for (int t = 0; t < 4; ++t)
-    if (t < nt) {
+    if (t < NT) {
       const int kl = 16 * t + i;
       if (kl < it.n) {
         float* __restrict__ Gk = d_qkv + (int64_t)(it.n0 + kl) * ldg + d + h * DH;
@@ -389,6 +393,28 @@ __global__ __launch_bounds__(256, 2) void k_sattn_bwd(
         }
       }
     }
+}
+
+template <int DH, bool DROP>
+__global__ __launch_bounds__(256, 2) void k_sattn_bwd(
+    const float* __restrict__ d_out, const float* __restrict__ qkv, int64_t ld64, const float* __restrict__ out,
+    const float* __restrict__ lse, const int32_t* __restrict__ ptr, int64_t B, int64_t N, int H, float scale,
+    uint32_t thr16, float inv_keep, uint64_t seed, const uint64_t* __restrict__ salt, float* __restrict__ d_qkv,
+    int64_t ldg) {
+  __shared__ __attribute__((aligned(16))) float sT[4][2 * 16 * 20];   // per-wave transpose scratch (P_drop | dS)
+  const Item it = item_setup(ptr, B, H);      // host guarantees n <= 64: one block per graph
+  if (!it.live) return;
+  seed = gps::salted_seed(seed, salt);
+  float* tP = &sT[threadIdx.x >> 6][0];
+#define SA_BODY(NTV) sattn_bwd_body<DH, DROP, NTV>(it, tP, d_out, qkv, ld64, out, lse, N, H, scale, thr16, inv_keep, \
+                                                  seed, d_qkv, ldg)
+  switch ((it.n + 15) >> 4) {
+    case 1: SA_BODY(1); break;
+    case 2: SA_BODY(2); break;
+    case 3: SA_BODY(3); break;
+    default: SA_BODY(4); break;
+  }
+#undef SA_BODY
 }
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) % 16) == 0; }
@@ -406,21 +432,19 @@ bool sattn_applicable(const void* qkv, int64_t ld_qkv, const void* out, int H, i
 }
 
 // Launch the block-form forward.  Preconditions: sattn_applicable().
-void sattn_fwd_launch(const float* qkv, int64_t ld_qkv, const int32_t* ptr, const int32_t* tile_graph,
-                      const int32_t* tile_row0, int64_t max_tiles, int64_t N, int H, int dh, float scale,
-                      float p_drop, uint64_t seed, float* out, float* lse, hipStream_t s) {
+void sattn_fwd_launch(const float* qkv, int64_t ld_qkv, const int32_t* ptr, int64_t B, int64_t N, int H, int dh,
+                      float scale, float p_drop, uint64_t seed, float* out, float* lse, hipStream_t s) {
   const uint32_t thr16 = drop_thr16(p_drop);
   const float inv_keep = p_drop > 0.0f ? drop_inv_keep(thr16) : 1.0f;
-  const int64_t n_work = max_tiles * H;
-  const unsigned grid = gps::grid_for(n_work, 4);
+  const unsigned grid = gps::grid_for(B * H, 4);
 #define SA_FWD(D)                                                                                               \
   do {                                                                                                          \
     if (p_drop > 0.0f)                                                                                          \
-      k_sattn_fwd<D, true><<<grid, 256, 0, s>>>(qkv, ld_qkv, ptr, tile_graph, tile_row0, n_work, N, H, scale,    \
-                                                thr16, inv_keep, seed, gps::dropout_salt(), out, lse);           \
+      k_sattn_fwd<D, true><<<grid, 256, 0, s>>>(qkv, ld_qkv, ptr, B, N, H, scale, thr16, inv_keep, seed,         \
+                                                gps::dropout_salt(), out, lse);                                  \
     else                                                                                                        \
-      k_sattn_fwd<D, false><<<grid, 256, 0, s>>>(qkv, ld_qkv, ptr, tile_graph, tile_row0, n_work, N, H, scale,   \
-                                                 thr16, inv_keep, seed, gps::dropout_salt(), out, lse);          \
+      k_sattn_fwd<D, false><<<grid, 256, 0, s>>>(qkv, ld_qkv, ptr, B, N, H, scale, thr16, inv_keep, seed,        \
+                                                 gps::dropout_salt(), out, lse);                                 \
   } while (0)
   switch (dh) {
     case 8: SA_FWD(8); break;
@@ -433,23 +457,19 @@ void sattn_fwd_launch(const float* qkv, int64_t ld_qkv, const int32_t* ptr, cons
 
 // Launch the fused backward (every graph has <= 64 nodes).  Preconditions: sattn_applicable(), aligned d_out / d_qkv.
 void sattn_bwd_launch(const float* d_out, const float* qkv, int64_t ld_qkv, const float* out, const float* lse,
-                      const int32_t* ptr, const int32_t* tile_graph, const int32_t* tile_row0, int64_t max_tiles,
-                      int64_t N, int H, int dh, float scale, float p_drop, uint64_t seed, float* d_qkv,
-                      int64_t ld_dqkv, hipStream_t s) {
+                      const int32_t* ptr, int64_t B, int64_t N, int H, int dh, float scale, float p_drop,
+                      uint64_t seed, float* d_qkv, int64_t ld_dqkv, hipStream_t s) {
   const uint32_t thr16 = drop_thr16(p_drop);
   const float inv_keep = p_drop > 0.0f ? drop_inv_keep(thr16) : 1.0f;
-  const int64_t n_work = max_tiles * H;
-  const unsigned grid = gps::grid_for(n_work, 4);
+  const unsigned grid = gps::grid_for(B * H, 4);
 #define SA_BWD(D)                                                                                               \
   do {                                                                                                          \
     if (p_drop > 0.0f)                                                                                          \
-      k_sattn_bwd<D, true><<<grid, 256, 0, s>>>(d_out, qkv, ld_qkv, out, lse, ptr, tile_graph, tile_row0,        \
-                                                n_work, N, H, scale, thr16, inv_keep, seed, gps::dropout_salt(), \
-                                                d_qkv, ld_dqkv);                                                 \
+      k_sattn_bwd<D, true><<<grid, 256, 0, s>>>(d_out, qkv, ld_qkv, out, lse, ptr, B, N, H, scale, thr16,        \
+                                                inv_keep, seed, gps::dropout_salt(), d_qkv, ld_dqkv);            \
     else                                                                                                        \
-      k_sattn_bwd<D, false><<<grid, 256, 0, s>>>(d_out, qkv, ld_qkv, out, lse, ptr, tile_graph, tile_row0,       \
-                                                 n_work, N, H, scale, thr16, inv_keep, seed,                     \
-                                                 gps::dropout_salt(), d_qkv, ld_dqkv);                           \
+      k_sattn_bwd<D, false><<<grid, 256, 0, s>>>(d_out, qkv, ld_qkv, out, lse, ptr, B, N, H, scale, thr16,       \
+                                                 inv_keep, seed, gps::dropout_salt(), d_qkv, ld_dqkv);           \
   } while (0)
   switch (dh) {
     case 8: SA_BWD(8); break;

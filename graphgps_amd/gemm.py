@@ -1,0 +1,67 @@
+"""Row-panel GEMM (csrc/gemm_panel.hip) behind the nn.Linear modules of the GPS block.
+
+``C = A W^T (+ bias) (+ addend)`` with optional ReLU/dropout epilogues, fp32 in / fp32 out, products formed exactly on
+the bf16 MFMA pipe.  The weight operand is a pre-split IMAGE (three bf16 pieces, k-stage-major) made from the fp32
+weight by ``split_weights`` -- once per optimizer step for training (the weights change under the optimizer's HIP
+kernel, which torch's version counters do not see, so a training forward always re-splits: ~6 us per layer), cached
+across calls only in evaluation.  Replaces ``torch.addmm`` / ``mm`` (rocBLAS / hipBLASLt) for the projections of
+``/root/reference/graphgps/layer/gatedgcn_layer.py:57-61`` and ``graphgps/layer/gps_layer.py:104-106,143-144,253-257``
+where the shape qualifies (N % 192 == 0, K % 128 == 0: d = 384 does); everything else stays on the libraries.
+"""
+from __future__ import annotations
+
+import os
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import lib as _lib
+from .lib import check, current_stream, ptr
+
+ENABLED = os.environ.get("GPS_GEMM_PANEL", "1") != "0"
+
+
+def supported(N: int, K: int) -> bool:
+    return ENABLED and N > 0 and K > 0 and N % 192 == 0 and K % 128 == 0
+
+
+def split_weights(weights: Sequence[torch.Tensor], nt: bool = True, tn: bool = True
+                  ) -> List[Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]]:
+    """[(image of W, image of W^T), ...] for up to 8 fp32 weights ``[rows, cols]`` in ONE launch.
+    ``image of W`` serves ``x @ W.T`` (forward), ``image of W^T`` serves ``g @ W`` (input gradient)."""
+    L = _lib.load()
+    n = len(weights)
+    descs = (_lib.GemmSplit * n)()
+    out = []
+    dev = weights[0].device
+    for q, w in zip(descs, weights):
+        if w.dtype != torch.float32 or w.dim() != 2 or w.stride(1) != 1 or not w.is_cuda:
+            raise _lib.GpsHipError("split_weights: fp32 [rows, cols] CUDA weights with unit column stride")
+        rows, cols = w.shape
+        i_nt = torch.empty(3 * rows * cols, dtype=torch.int16, device=dev) if nt else None
+        i_tn = torch.empty(3 * rows * cols, dtype=torch.int16, device=dev) if tn else None
+        q.W, q.ldw, q.rows, q.cols = w.data_ptr(), w.stride(0), rows, cols
+        q.image_nt = i_nt.data_ptr() if nt else None
+        q.image_tn = i_tn.data_ptr() if tn else None
+        out.append((i_nt, i_tn))
+    check(L.gps_gemm_split_weights(n, descs, current_stream(dev)), "gps_gemm_split_weights")
+    return out
+
+
+def gemm_panel(a: torch.Tensor, image: torch.Tensor, N: int, bias: Optional[torch.Tensor] = None,
+               addend: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, epilogue: int = 0,
+               mask_src: Optional[torch.Tensor] = None, p_drop: float = 0.0, seed: int = 0) -> torch.Tensor:
+    """``out = a @ B^T (+ bias) (+ addend)`` where ``image`` is the split image of B ``[N, K]``.
+    ``a`` may be a column slice of a wider buffer (row stride >= K); ``out`` likewise (row stride >= N).
+    epilogue 1: ReLU then dropout(p_drop, seed); epilogue 2: multiply by the ReLU/dropout mask of ``mask_src``."""
+    L = _lib.load()
+    M, K = a.shape
+    if a.stride(1) != 1 or a.dtype != torch.float32:
+        raise _lib.GpsHipError("gemm_panel: fp32 A with unit column stride")
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    check(L.gps_gemm_panel(ptr(a), a.stride(0), M, K, ptr(image), N, ptr(bias), ptr(addend),
+                           addend.stride(0) if addend is not None else 0, ptr(out), out.stride(0), int(epilogue),
+                           ptr(mask_src), mask_src.stride(0) if mask_src is not None else 0, float(p_drop),
+                           int(seed), current_stream(a.device)), "gps_gemm_panel")
+    return out

@@ -23,6 +23,7 @@ import os as _os
 
 import torch
 
+from .. import gemm as _gemm
 from .. import lib as _lib
 from ..fused import _SIDE_ENABLED, _queue_join, _side_stream
 from ..lib import check, current_stream, ptr
@@ -216,7 +217,15 @@ class _GPSBlock(torch.autograd.Function):
         # -- one GEMM for everything that consumes the layer input x: Ax|Bx|Dx|Ex (gatedgcn_layer.py:
         # 57-61) and the attention in-projection q|k|v (gps_layer.py:238): [N,d] x [d,7d]
         wcat, bcat = layer._xgroup._stacked()
-        pq = torch.addmm(bcat, x, wcat.t())                     # [N, 4d + 3d]
+        # dense side: the row-panel GEMM (csrc/gemm_panel.hip; d % 192 == 0) or the library GEMMs
+        panel = _gemm.supported(d, d) and _gemm.supported(2 * d, d) and _gemm.supported(7 * d, d) and E >= 1
+        imgs = None
+        if panel:       # weight images of the block's five projections (W and W^T), ONE launch per layer and step
+            imgs = _gemm.split_weights([wcat, lm.C.weight, sa.out_proj.weight, layer.ff_linear1.weight,
+                                        layer.ff_linear2.weight])
+            pq = _gemm.gemm_panel(x, imgs[0][0], 7 * d, bias=bcat)
+        else:
+            pq = torch.addmm(bcat, x, wcat.t())                 # [N, 4d + 3d]
         ldp = 7 * d
         P, fs = pq.data_ptr(), d * 4
         # -- global branch (forked): varlen attention over the PRE-layer x (gps_layer.py:199-201,234-241)
@@ -226,10 +235,12 @@ class _GPSBlock(torch.autograd.Function):
             scale = float(dh) ** -0.5
             check(L.gps_seg_attn_fwd(P + 4 * fs, ldp, ptr(gi.ptr), ptr(gi.tile_graph), ptr(gi.tile_row0),
                                      gi.max_tiles, N, H, dh, scale, p_at, s[2], ptr(o), ptr(lse),
-                                     int(gi.nmax_host), sb), "gps_seg_attn_fwd")
-            ao = torch.addmm(sa.out_proj.bias, o, sa.out_proj.weight.t())
+                                     gi.B, int(gi.nmax_host), sb), "gps_seg_attn_fwd")
+            ao = (_gemm.gemm_panel(o, imgs[2][0], d, bias=sa.out_proj.bias) if panel
+                  else torch.addmm(sa.out_proj.bias, o, sa.out_proj.weight.t()))
         # -- local branch: C projection + GatedGCN core ----------------------------------------
-        ce = torch.addmm(lm.C.bias, e, lm.C.weight.t())
+        ce = (_gemm.gemm_panel(e, imgs[1][0], d, bias=lm.C.bias) if panel
+              else torch.addmm(lm.C.bias, e, lm.C.weight.t()))
         xt, eh = _E(N, d, **f32), _E(E, d, **f32)
         den = _E(N, d, **f32)
         check(L.gps_gatedgcn_fwd(P, P + fs, P + 2 * fs, P + 3 * fs, ldp, ptr(ce), ptr(gi.rowptr_dst),
@@ -259,9 +270,14 @@ class _GPSBlock(torch.autograd.Function):
               "gps_bn_dual_apply")
 
         # -- FFN + norm2 (gps_layer.py:225-229,253-257) ----------------------------------------
-        f1 = torch.addmm(layer.ff_linear1.bias, h, layer.ff_linear1.weight.t())
-        t = _K.act_drop_add(L, None, f1, True, p_f1, s[4], st)
-        f2 = torch.addmm(layer.ff_linear2.bias, t, layer.ff_linear2.weight.t())
+        if panel:       # t = drop(relu(ff1(h))) in the GEMM's epilogue: f1 is never materialised
+            f1 = None
+            t = _gemm.gemm_panel(h, imgs[3][0], 2 * d, bias=layer.ff_linear1.bias, epilogue=1, p_drop=p_f1, seed=s[4])
+            f2 = _gemm.gemm_panel(t, imgs[4][0], d, bias=layer.ff_linear2.bias)
+        else:
+            f1 = torch.addmm(layer.ff_linear1.bias, h, layer.ff_linear1.weight.t())
+            t = _K.act_drop_add(L, None, f1, True, p_f1, s[4], st)
+            f2 = torch.addmm(layer.ff_linear2.bias, t, layer.ff_linear2.weight.t())
         z2 = _E(N, d, **f32)                                    # h + drop(f2) and its statistics
         check(L.gps_add_drop_stats(ptr(h), ptr(f2), N, d, p_f2, s[5], ptr(z2), ref(bn2), ptr(ws), st),
               "gps_add_drop_stats")
@@ -271,8 +287,9 @@ class _GPSBlock(torch.autograd.Function):
                              layer.norm1_attn.num_batches_tracked,
                              layer.norm2.num_batches_tracked], 1)
 
-        ctx.save_for_backward(x, e, pq, eh, den, xt, x1, o, lse, za, h, f1, t, z2, stats)
+        ctx.save_for_backward(x, e, pq, eh, den, xt, x1, o, lse, za, h, f1 if f1 is not None else t, t, z2, stats)
         ctx.layer, ctx.gi, ctx.seeds = layer, gi, s
+        ctx.imgs = imgs     # W^T images for the input-gradient GEMMs (None: library GEMMs)
         ctx.cfg = (p, p_l, p_f1, p_f2, p_at, H, dh, scale)
         return out, e1
 
@@ -305,9 +322,16 @@ class _GPSBlock(torch.autograd.Function):
         check(L.gps_bn_bwd_drop(ptr(z2), ptr(g_out), ref(bn2), N, d, 0, 0.0, 0, ptr(g_z2), ptr(g_n2w),
                                 ptr(g_n2b), p_f2, s[5], ptr(g_f2), ptr(ws), st), "gps_bn_bwd_drop")
         # f2 = ff2(t);  t = drop(relu(f1));  f1 = ff1(h)
-        g_t = g_f2.mm(layer.ff_linear2.weight)
-        g_f1 = _K.act_drop_bwd(L, g_t, f1, True, p_f1, s[4], st)
-        g_h = g_z2.addmm_(g_f1, layer.ff_linear1.weight)                  # residual + FFN input
+        imgs = ctx.imgs
+        if imgs is not None:
+            # g_f1 = relu/dropout mask of t applied to g_f2 W2 (the mask of t is the mask of f1 wherever it matters:
+            # a kept element has t > 0 iff f1 > 0, a dropped one has gradient 0 either way), in the GEMM's epilogue
+            g_f1 = _gemm.gemm_panel(g_f2, imgs[4][1], 2 * d, epilogue=2, mask_src=t, p_drop=p_f1, seed=s[4])
+            g_h = _gemm.gemm_panel(g_f1, imgs[3][1], d, addend=g_z2, out=g_z2)     # residual + FFN input
+        else:
+            g_t = g_f2.mm(layer.ff_linear2.weight)
+            g_f1 = _K.act_drop_bwd(L, g_t, f1, True, p_f1, s[4], st)
+            g_h = g_z2.addmm_(g_f1, layer.ff_linear1.weight)              # residual + FFN input
 
         # h = BN_l(x1) + BN_a(za);  za = x + drop(ao):  g_x1, g_x1 + g_za, g_ao = dropmask(g_za)
         g_x1, g_xres, g_ao = _E(N, d, **f32), _E(N, d, **f32), _E(N, d, **f32)
@@ -322,11 +346,11 @@ class _GPSBlock(torch.autograd.Function):
         G, P = g_pq.data_ptr(), pq.data_ptr()
         with _Fork(dev, _BRANCH) as fork:            # attention half of the backward
             sb = current_stream(dev)
-            g_o = g_ao.mm(sa.out_proj.weight)
+            g_o = _gemm.gemm_panel(g_ao, imgs[2][1], d) if imgs is not None else g_ao.mm(sa.out_proj.weight)
             delta = _E(H, N, **f32)
             check(L.gps_seg_attn_bwd(ptr(g_o), P + 4 * fs, ldp, ptr(o), ptr(lse), ptr(gi.ptr),
                                      ptr(gi.tile_graph), ptr(gi.tile_row0), gi.max_tiles, N, H, dh, scale,
-                                     p_at, s[2], ptr(delta), G + 4 * fs, ldp, int(gi.nmax_host), sb),
+                                     p_at, s[2], ptr(delta), G + 4 * fs, ldp, gi.B, int(gi.nmax_host), sb),
                   "gps_seg_attn_bwd")
 
         # x1 = x + drop(relu(BN_x(xt)));  e1 = e + drop(relu(BN_e(eh))):  both BN backwards as one list
@@ -350,8 +374,12 @@ class _GPSBlock(torch.autograd.Function):
         else:
             ((g_wcat, g_bcat), (g_wc, g_bc), (g_wo, g_bo), (g_w1, g_b1), (g_w2, g_b2)) = \
                 [_K.param_grads(L, g, a, leaves) for g, a in pairs]
-        g_x = g_xres.addmm_(g_pq, wcat)              # residuals of za and x1 + A..E + in-proj inputs
-        g_e = torch.addmm(g_e1, g_ce, lm.C.weight)   # residual of e1 + C input
+        if imgs is not None:
+            g_x = _gemm.gemm_panel(g_pq, imgs[0][1], d, addend=g_xres, out=g_xres)
+            g_e = _gemm.gemm_panel(g_ce, imgs[1][1], d, addend=g_e1)
+        else:
+            g_x = g_xres.addmm_(g_pq, wcat)          # residuals of za and x1 + A..E + in-proj inputs
+            g_e = torch.addmm(g_e1, g_ce, lm.C.weight)   # residual of e1 + C input
         g_wi, g_bi = g_wcat[4 * d:], g_bcat[4 * d:]
 
         abde = [g_wcat[i * d:(i + 1) * d] for i in range(4)] + [g_bcat[i * d:(i + 1) * d] for i in range(4)]
@@ -393,7 +421,7 @@ class _GPSBlockGINE(torch.autograd.Function):
             scale = float(dh) ** -0.5
             check(L.gps_seg_attn_fwd(ptr(qkv), 3 * d, ptr(gi.ptr), ptr(gi.tile_graph), ptr(gi.tile_row0),
                                      gi.max_tiles, N, H, dh, scale, p_at, s[2], ptr(o), ptr(lse),
-                                     int(gi.nmax_host), sb), "gps_seg_attn_fwd")
+                                     gi.B, int(gi.nmax_host), sb), "gps_seg_attn_fwd")
             ao = torch.addmm(sa.out_proj.bias, o, sa.out_proj.weight.t())
         # -- local half: GINE core + MLP (gps_layer.py:62-69,183-185) -------------------------------
         agg = _E(N, d, **f32)
@@ -471,7 +499,7 @@ class _GPSBlockGINE(torch.autograd.Function):
             g_qkv, delta = _E(N, 3 * d, **f32), _E(H, N, **f32)
             check(L.gps_seg_attn_bwd(ptr(g_o), ptr(qkv), 3 * d, ptr(o), ptr(lse), ptr(gi.ptr),
                                      ptr(gi.tile_graph), ptr(gi.tile_row0), gi.max_tiles, N, H, dh, scale,
-                                     p_at, s[2], ptr(delta), ptr(g_qkv), 3 * d, int(gi.nmax_host), sb),
+                                     p_at, s[2], ptr(delta), ptr(g_qkv), 3 * d, gi.B, int(gi.nmax_host), sb),
                   "gps_seg_attn_bwd")
         # local half: MLP backward, GINE core backward
         g_g1r = g_g2.mm(lin2.weight)

@@ -79,9 +79,14 @@ _SIGNATURES = {
                               c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P]),
     "gps_attn_supported_head_dim": (c_int, [c_int]),
     "gps_seg_attn_fwd": (c_int, [_P, c_int64, _P, _P, _P, c_int64, c_int64, c_int, c_int, c_float,
-                                 c_float, c_uint64, _P, _P, c_int64, _P]),
+                                 c_float, c_uint64, _P, _P, c_int64, c_int64, _P]),
     "gps_seg_attn_bwd": (c_int, [_P, _P, c_int64, _P, _P, _P, _P, _P, c_int64, c_int64, c_int, c_int,
-                                 c_float, c_float, c_uint64, _P, _P, c_int64, c_int64, _P]),
+                                 c_float, c_float, c_uint64, _P, _P, c_int64, c_int64, c_int64, _P]),
+    "gps_gemm_image_elems": (c_size_t, [c_int64, c_int64]),
+    "gps_gemm_panel_supported": (c_int, [c_int64, c_int64]),
+    "gps_gemm_split_weights": (c_int, [c_int, _P, _P]),
+    "gps_gemm_panel": (c_int, [_P, c_int64, c_int64, c_int, _P, c_int, _P, _P, c_int64, _P, c_int64, c_int, _P,
+                               c_int64, c_float, c_uint64, _P]),
     "gps_gcn_dinv": (c_int, [_P, _P, c_int64, c_int64, _P, _P]),
     "gps_gcn_spmm": (c_int, [_P, c_int64, _P, _P, _P, c_int64, c_int64, c_int, _P, _P]),
     "gps_adj_sum": (c_int, [_P, c_int64, _P, _P, c_float, c_int64, c_int64, c_int, _P, _P]),
@@ -106,6 +111,12 @@ class WgradProblem(ctypes.Structure):
     _fields_ = [("g", c_void_p), ("x", c_void_p), ("gw", c_void_p), ("gb", c_void_p),
                 ("ldg", c_int64), ("ldx", c_int64), ("R", c_int64), ("M", ctypes.c_int32),
                 ("Nn", ctypes.c_int32)]
+
+
+class GemmSplit(ctypes.Structure):
+    """``gps_gemm_split`` (include/gps_hip.h)."""
+    _fields_ = [("W", c_void_p), ("ldw", c_int64), ("rows", ctypes.c_int32), ("cols", ctypes.c_int32),
+                ("image_nt", c_void_p), ("image_tn", c_void_p)]
 
 
 class GpsHipError(RuntimeError):

@@ -142,6 +142,35 @@ int gps_adj_sum(const float* x, int64_t ld_x, const int32_t* rowptr, const int32
                 int64_t E, int d, float* out, gps_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
+ * Row-panel GEMM for the nn.Linear modules of the block and their input gradients (csrc/gemm_panel.hip):
+ *     C[M, N] = A[M, K] * B[N, K]^T (+ bias[N]) (+ Cin[M, N])  with an optional ReLU / dropout epilogue.
+ * Replaces the rocBLAS / hipBLASLt fp32 GEMMs behind graphgps/layer/gatedgcn_layer.py:57-61 (A..E),
+ * graphgps/layer/gps_layer.py:104-106 (MultiheadAttention in/out projection) and :143-144,253-257 (FFN).
+ * fp32 in, fp32 out; products formed exactly on the bf16 MFMA pipe (3-way exact split, 6 of 9 piece products,
+ * fp32 accumulation: the rounding model of an fp32-input MFMA GEMM, ~7e-7 against fp64).
+ * B is passed as a pre-split IMAGE (uint16 bf16 patterns, layout [3 pieces][K/32][N][32]) produced from the fp32
+ * weight by gps_gemm_split_weights -- once per optimizer step, for the weight (`image_nt`: B[n][k] = W[n][k],
+ * forward) and/or its transpose (`image_tn`: B[n][k] = W[k][n], input gradient); gps_gemm_image_elems(N, K)
+ * uint16 elements each.  Shapes: N % 192 == 0 and K % 128 == 0 (gps_gemm_panel_supported); anything else stays
+ * on the library GEMMs.
+ * epilogue: 0 none | 1 relu then dropout(p_drop, seed) keyed (row, column) like gps_act_drop_add
+ *           | 2 multiply by the relu/dropout mask of `mask_src` (= gps_act_drop_bwd applied to the product).
+ * ------------------------------------------------------------------------------------- */
+typedef struct gps_gemm_split {
+  const float* W;      /* [rows][cols] fp32, row stride ldw (floats) */
+  int64_t ldw;
+  int rows, cols;
+  uint16_t* image_nt;  /* image of B = W   (N = rows, K = cols), or NULL */
+  uint16_t* image_tn;  /* image of B = W^T (N = cols, K = rows), or NULL */
+} gps_gemm_split;
+size_t gps_gemm_image_elems(int64_t N, int64_t K);
+int gps_gemm_panel_supported(int64_t N, int64_t K);
+int gps_gemm_split_weights(int n, const gps_gemm_split* descs, gps_stream_t stream);   /* n <= 8, one launch */
+int gps_gemm_panel(const float* A, int64_t lda, int64_t M, int K, const uint16_t* image, int N, const float* bias,
+                   const float* Cin, int64_t ldcin, float* C, int64_t ldc, int epilogue, const float* mask_src,
+                   int64_t ldmask, float p_drop, uint64_t seed, gps_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
  * Segment (per-graph, varlen) multi-head attention core on fp32 MFMA (v_mfma_f32_16x16x4_f32).
  * Replaces to_dense_batch + the softmax(QK^T/sqrt(dh) + key-padding mask) -> dropout -> .V core
  * of torch.nn.MultiheadAttention + the [mask] un-pad (graphgps/layer/gps_layer.py:199-201,
@@ -152,8 +181,9 @@ int gps_adj_sum(const float* x, int64_t ld_x, const int32_t* rowptr, const int32
  * that forward and backward regenerate the same mask (one 32-bit hash decides two adjacent keys, 16 bits
  * each: the realised drop probability is round(p * 2^16) / 2^16 and survivors are scaled by its exact
  * complement); p_drop == 0 disables it.
- * Two kernel families behind the same entry points.  `max_graph_nodes` is an upper bound on the longest
- * graph of the batch known to the HOST (0 = unknown): when it is <= 64 and dh is one of {8, 16, 24, 32}
+ * Two kernel families behind the same entry points.  `num_graphs` = B (entries of `ptr` minus one) and
+ * `max_graph_nodes` = an upper bound on the longest graph of the batch known to the HOST (0 = unknown): when it
+ * is <= 64 and dh is one of {8, 16, 24, 32}
  * the block form runs -- one wavefront per (graph, head) keeps that graph's K-side operands in registers and
  * serves all of its query tiles; the backward is ONE launch (csrc/sattn.hip).  Everything else takes the
  * one-wavefront-per-(16-row tile, head) form with the online softmax (csrc/seg_attention.hip).
@@ -164,7 +194,7 @@ int gps_attn_supported_head_dim(int dh);
 int gps_seg_attn_fwd(const float* qkv, int64_t ld_qkv, const int32_t* ptr,
                      const int32_t* tile_graph, const int32_t* tile_row0, int64_t max_tiles,
                      int64_t N, int H, int dh, float scale, float p_drop, uint64_t seed, float* out,
-                     float* lse, int64_t max_graph_nodes, gps_stream_t stream);
+                     float* lse, int64_t num_graphs, int64_t max_graph_nodes, gps_stream_t stream);
 /* d_qkv [N,3d] (row stride ld_dqkv) receives dq | dk | dv.  `delta` is an [H,N] scratch buffer
  * (rowsum(dO*O)).  Block form (max_graph_nodes in 1..64, see above): ONE launch -- S, P, dS computed once per
  * tile pair, dQ / dK / dV from it, delta formed on the fly (the scratch buffer stays untouched); otherwise
@@ -173,7 +203,7 @@ int gps_seg_attn_bwd(const float* d_out, const float* qkv, int64_t ld_qkv, const
                      const float* lse, const int32_t* ptr, const int32_t* tile_graph,
                      const int32_t* tile_row0, int64_t max_tiles, int64_t N, int H, int dh,
                      float scale, float p_drop, uint64_t seed, float* delta, float* d_qkv,
-                     int64_t ld_dqkv, int64_t max_graph_nodes, gps_stream_t stream);
+                     int64_t ld_dqkv, int64_t num_graphs, int64_t max_graph_nodes, gps_stream_t stream);
 /* The same core with an additive attention bias: the reference's `attn_mask=batch.attn_bias` operand of
  * torch.nn.MultiheadAttention in the BiasedTransformer branch (graphgps/layer/gps_layer.py:201-203,
  * 234-241) and in GraphormerLayer (graphgps/layer/graphormer_layer.py:43-44).

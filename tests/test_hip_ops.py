@@ -687,3 +687,72 @@ def test_gin_aggregate_matches_index_add():
         (out * w.cuda()).sum().backward()
         assert_close(out, ref, Tol.ACT, "gin out")
         assert_close(xg.grad, xr.grad, Tol.GRAD_REL, "gin d_x", rel_to_max=True)
+
+
+@pytest.mark.parametrize("M,K,N", [(7569, 384, 2688), (1000, 384, 384), (15348, 384, 384), (7569, 768, 384),
+                                   (333, 2688, 384), (64, 128, 192), (65, 256, 768)])
+def test_gemm_panel_fp32_exact_products(M, K, N):
+    """csrc/gemm_panel.hip at the block's projection shapes (N, K in {384, 768, 2688}; M = nodes / edges, ragged last
+    row tile): C = A W^T + bias against fp64, through the weight image (forward) and through the transposed image
+    (input gradient), with the addend and both epilogues; the error is that of an fp32 GEMM (a few 1e-7 of the
+    result scale), also with a +100 offset on the operands where a lossy split would show at 1e-3."""
+    from graphgps_amd.gemm import gemm_panel, split_weights
+    from graphgps_amd.ops import attn_dropout_keep_mask
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(M + K + N)
+    a = torch.randn(M, K, generator=gen)
+    w = torch.randn(N, K, generator=gen) / K ** 0.5
+    b = torch.randn(N, generator=gen)
+    add = torch.randn(M, N, generator=gen)
+    ag, wg, bg = a.to(dev), w.to(dev), b.to(dev)
+    (img_nt, img_tn), = split_weights([wg])
+    ref = a.double() @ w.double().t()
+    scale = float(ref.abs().max())
+    # yardstick: the library's own fp32 GEMM on the same operands (an fp32 dot product of K terms carries
+    # ~sqrt(K) * 6e-8 * sum|a||b|, more than 2e-6 of max|result| once K reaches the hundreds)
+    lib_err = float((torch.mm(ag, wg.t()).double().cpu() - ref).abs().max())
+    tol = max(4e-6 * scale, 1.5 * lib_err)     # K = 2688: one fp32 accumulation chain of 1008 MFMA steps
+    out = gemm_panel(ag, img_nt, N)
+    err = float((out.double().cpu() - ref).abs().max())
+    print(f"gemm_panel {M}x{K}x{N}: max err {err:.2e} (library fp32 GEMM {lib_err:.2e}, scale {scale:.2f})")
+    assert err <= tol, (err, lib_err)
+    out = gemm_panel(ag, img_nt, N, bias=bg, addend=add.to(dev))
+    assert_close(out, ref + b.double() + add.double(), tol, "A W^T + b + C")
+    # the transposed image: G [M, N] @ W [N, K]
+    g = torch.randn(M, N, generator=gen)
+    gref = g.double() @ w.double()
+    gout = gemm_panel(g.to(dev), img_tn, K) if K % 192 == 0 else None
+    if gout is not None:
+        gtol = max(2e-6 * float(gref.abs().max()),
+                   1.5 * float((torch.mm(g.to(dev), wg).double().cpu() - gref).abs().max()))
+        assert_close(gout, gref, gtol, "G W")
+    # in-place accumulation into a column slice of a wider buffer (the block's g_x += g_pq W pattern)
+    if K % 192 == 0:
+        wide = torch.zeros(M, K + 64, device=dev)
+        wide[:, :K] = 1.0
+        gemm_panel(g.to(dev), img_tn, K, addend=wide[:, :K], out=wide[:, :K])
+        assert_close(wide[:, :K], gref + 1.0, gtol, "accumulate in place")
+        assert float(wide[:, K:].abs().max()) == 0.0
+    # epilogue 1: relu + dropout keyed (row, col) like gps_act_drop_add; epilogue 2: the mask of a saved activation
+    p, seed = 0.25, 0x1234ABCD5678
+    keep = attn_dropout_keep_mask(seed, torch.arange(M), 0, 1, torch.arange(N), p).double()
+    t_ref = (ref + b.double()).clamp(min=0) * keep / (1 - p)
+    t = gemm_panel(ag, img_nt, N, bias=bg, epilogue=1, p_drop=p, seed=seed)
+    assert_close(t, t_ref, 2 * tol, "relu + dropout epilogue")
+    m_ref = ref * (t_ref > 0) * keep / (1 - p)
+    mo = gemm_panel(ag, img_nt, N, epilogue=2, mask_src=t, p_drop=p, seed=seed)
+    settled = ((ref + b.double()).abs() > 1e-4).double()      # the ReLU side of a pre-activation within rounding of 0
+    assert_close(mo.double().cpu() * settled, m_ref * settled, 2 * tol, "mask epilogue")   # is anybody's guess
+    # operands with a common offset (mean / std = 3).  The split itself is exact; what grows with the offset is the
+    # MFMA's own accumulation error: every product is TRUNCATED against the running accumulator (measured, for the
+    # fp32-input MFMA of the library GEMM as well: error ~ 0.28 ulp(acc) per product), and the 6-term form adds 6x
+    # as many products per k-step.  For the block's operands (BatchNorm / ReLU outputs, weights: |mean| <~ std) this
+    # sits at the library's own ~1e-6; at mean/std = 100 it reaches 2e-4 of the result (library: 3e-5).
+    a2, w2 = a + 3.0, w + 3.0 / K ** 0.5
+    (i2, _), = split_weights([w2.to(dev)], tn=False)
+    ref2 = a2.double() @ w2.double().t()
+    out2 = gemm_panel(a2.to(dev), i2, N)
+    lib2 = float((torch.mm(a2.to(dev), w2.to(dev).t()).double().cpu() - ref2).abs().max())
+    err2 = float((out2.double().cpu() - ref2).abs().max())
+    print(f"  offset operands: max err {err2:.2e} (library {lib2:.2e}, scale {float(ref2.abs().max()):.1f})")
+    assert err2 <= max(4e-6 * float(ref2.abs().max()), 8.0 * lib2), (err2, lib2)

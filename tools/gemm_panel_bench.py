@@ -1,0 +1,47 @@
+#!/usr/bin/env python
+"""gps_gemm_panel against torch.addmm (rocBLAS / hipBLASLt, TunableOp-selected) on the GPS block's projection shapes at
+P30 x 256 graphs, d = 384: HIP-event time of one hipGraph replay of 40 back-to-back launches over rotating operands."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+import graphgps_amd as g  # noqa: E402
+from graphgps_amd.gemm import gemm_panel, split_weights  # noqa: E402
+
+if __name__ == "__main__":
+    dev = torch.device("cuda:0")
+    try:
+        g.enable_gemm_tuning()
+    except Exception as exc:
+        print("TunableOp unavailable:", exc)
+    Nn, E, d = 7569, 15348, 384
+    shapes = [("pq  x[N,d] W[7d,d]", Nn, d, 7 * d), ("out o[N,d] W[d,d]", Nn, d, d), ("C   e[E,d] W[d,d]", E, d, d),
+              ("ff1 h[N,d] W[2d,d]", Nn, d, 2 * d), ("ff2 t[N,2d] W[d,2d]", Nn, 2 * d, d),
+              ("dgrad g_pq[N,7d] wcat", Nn, 7 * d, d), ("dgrad g_f1[N,2d] W1", Nn, 2 * d, d)]
+    print(f"{'shape':28s} {'GF':>6s} | torch us  TF/s | panel us  TF/s | speedup")
+    tot_t = tot_p = 0.0
+    for name, M, K, N in shapes:
+        nset = max(2, int(bench.ROTATE_BYTES // (4 * (M * K + M * N))) + 1)
+        A = [torch.randn(M, K, device=dev) for _ in range(nset)]
+        C = [torch.empty(M, N, device=dev) for _ in range(nset)]
+        w = torch.randn(N, K, device=dev) / K ** 0.5
+        b = torch.randn(N, device=dev)
+        (img, _), = split_weights([w], tn=False)
+        for i in range(3):
+            torch.addmm(b, A[0], w.t(), out=C[0])          # TunableOp picks its solution here
+        tt = bench.time_kernel(lambda i: torch.addmm(b, A[i], w.t(), out=C[i]), iters=40, nsets=nset)
+        tp = bench.time_kernel(lambda i: gemm_panel(A[i], img, N, bias=b, out=C[i]), iters=40, nsets=nset)
+        gf = 2.0 * M * K * N / 1e9
+        tot_t += tt
+        tot_p += tp
+        print(f"{name:28s} {gf:6.2f} | {tt*1e3:8.1f} {gf/tt/1e3:5.0f} | {tp*1e3:8.1f} {gf/tp/1e3:5.0f} | {tt/tp:5.2f}x",
+              flush=True)
+    print(f"sum: torch {tot_t*1e3:.1f} us, panel {tot_p*1e3:.1f} us")
+    w5 = [torch.randn(7 * d, d, device=dev), torch.randn(d, d, device=dev), torch.randn(d, d, device=dev),
+          torch.randn(2 * d, d, device=dev), torch.randn(d, 2 * d, device=dev)]
+    ts = bench.time_kernel(lambda i: split_weights(w5), iters=20)
+    print(f"split_weights (5 weights of one layer, both images): {ts*1e3:.1f} us")

@@ -45,6 +45,8 @@ def main():
     if os.environ.get("GG_COPY"):
         return copy_baseline()
     grid = [(768, 512), (768, 256), (768, 1024), (384, 512), (384, 1024), (384, 2048), (192, 2048), (192, 4096)]
+    if os.environ.get("GG_GRID"):
+        grid = [tuple(int(v) for v in item.split(":")) for item in os.environ["GG_GRID"].split(",")]
     print(f"{'threads':>8} {'target':>7} | fwd hot / rot us (frac rot) | bwd hot / rot us (frac rot)")
     for th, tg in grid:
         env = dict(os.environ, GG_ONE="1", GPS_GG_THREADS=str(th), GPS_GG_TARGET_WG=str(tg))
