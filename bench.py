@@ -219,9 +219,9 @@ def kernel_rooflines(dev, profile, nb, d=384, H=16, in_step=None, layers=10, onl
     idx = 4 * (N + 1) + 8 * E
 
     def gg_set():
-        return dict(proj=f(N, 4 * d), ce=f(E, d), xt=f(N, d), eh=f(E, d), dn=f(N, d).abs_() + 1.0,
+        return dict(proj=f(N, 4 * d), ce=f(E, d), xt=f(N, d), eh=f(E, d),
                     gx=f(N, d), ge=f(E, d), gproj=f(N, 4 * d), gce=f(E, d))
-    set_bytes = 4 * (2 * N * 4 * d + 4 * E * d + 3 * N * d)
+    set_bytes = 4 * (2 * N * 4 * d + 4 * E * d + 2 * N * d)
     n_rot = max(2, -(-ROTATE_BYTES // set_bytes))
     gsets = [gg_set() for _ in range(n_rot)]
 
@@ -230,13 +230,13 @@ def kernel_rooflines(dev, profile, nb, d=384, H=16, in_step=None, layers=10, onl
         P = q["proj"].data_ptr()
         check(L.gps_gatedgcn_fwd(P, P + fs, P + 2 * fs, P + 3 * fs, 4 * d, ptr(q["ce"]), ptr(gi.rowptr_dst),
                                  ptr(gi.src_by_dst), ptr(gi.eid_by_dst), N, E, d, ptr(q["xt"]), ptr(q["eh"]),
-                                 ptr(q["dn"]), None, current_stream(dev)))
+                                 None, current_stream(dev)))
 
     def gg_bwd(i=0):
         q = gsets[i]
         P, G = q["proj"].data_ptr(), q["gproj"].data_ptr()
         check(L.gps_gatedgcn_bwd(ptr(q["gx"]), d, ptr(q["ge"]), ptr(q["eh"]), P, P + fs, 4 * d, ptr(q["xt"]),
-                                 ptr(q["dn"]), ptr(gi.rowptr_dst), ptr(gi.src_by_dst), ptr(gi.eid_by_dst),
+                                 ptr(gi.rowptr_dst), ptr(gi.src_by_dst), ptr(gi.eid_by_dst),
                                  ptr(gi.rowptr_src), ptr(gi.dst_by_src), ptr(gi.eid_by_src), N, E, d,
                                  ptr(q["gce"]), G, G + fs, G + 2 * fs, G + 3 * fs, 4 * d, None, current_stream(dev)))
 
@@ -257,7 +257,7 @@ def kernel_rooflines(dev, profile, nb, d=384, H=16, in_step=None, layers=10, onl
                                  ptr(gi.tile_graph), ptr(gi.tile_row0), gi.max_tiles, N, H, dh, scale,
                                  p, 1234, ptr(q["delta"]), ptr(q["dqkv"]), 3 * d, nb, nmax_host, current_stream(dev)))
 
-    for i in range(n_rot):                 # valid saved tensors (e_hat, den) for the backward kernels
+    for i in range(n_rot):                 # valid saved tensors (e_hat, x_tilde) for the backward kernel
         gg_fwd(i)
     for i in range(a_rot):
         at_fwd(i)
@@ -284,7 +284,9 @@ def kernel_rooflines(dev, profile, nb, d=384, H=16, in_step=None, layers=10, onl
         res[name] = e
 
     entry("gatedgcn_fwd", gg_fwd, n_rot, "hbm", 8 * E * d + 20 * N * d + idx, 1, ("k_gatedgcn_fwd",))
-    entry("gatedgcn_bwd", gg_bwd, n_rot, "hbm", 12 * E * d + 28 * N * d + 2 * idx, 1, ("k_gatedgcn_bwd",))
+    entry("gatedgcn_bwd", gg_bwd, n_rot, "hbm", 12 * E * d + 28 * N * d + 2 * idx, 1, ("k_gatedgcn_bwd",),
+          note="algorithmic bytes per SURVEY.md 8d (which counts num and den as read: 8*N*d that this kernel "
+               "recomputes instead)")
     # the attention core is HBM-bound at these graph sizes (7.8 flop/byte against a ridge of 19.6): the binding
     # roofline is Q/K/V read + O write (fwd), + dO read + dQ/dK/dV write (bwd); the MFMA figure rides along
     entry("seg_attn_fwd", at_fwd, a_rot, "hbm", 16 * N * d + 4 * H * N, 1, ("k_attn_fwd", "k_sattn_fwd"))

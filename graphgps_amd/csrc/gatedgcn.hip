@@ -19,7 +19,7 @@
 //     CPU scatter_add -> bitwise reproducible.
 //
 // Backward = ONE launch, two phases around a workgroup barrier:
-//   A (target-keyed): num_i recomputed from the saved e_hat (nothing but `den` is saved by the forward),
+//   A (target-keyed): num_i and den_i recomputed from the saved e_hat (the forward saves NOTHING besides its outputs),
 //     a_i = g_x_i / D_i, b_i = -a_i num_i / D_i, delta_ij = g_e_ij + (a_i Bx_j + b_i) sig(1-sig) -> g_Ce (edge
 //     order), g_Dx_i = sum_j delta_ij;
 //   B (source-keyed): g_Ex_j = sum_{j->i} delta_ij, g_Bx_j = sum_{j->i} sig_ij a_i.  For an edge whose target lies
@@ -28,8 +28,8 @@
 //     (aggr_i = x_tilde_i - Ax_i), so no workgroup ever waits for another.  e_hat / g_e / g_Ce therefore cross the
 //     HBM interface once each: 12*E*d + 28*N*d bytes, the algorithmic figure.
 //
-// Algorithmic HBM bytes (fp32, per layer):  fwd 8*E*d + 20*N*d (+4*N*d for the saved `den` when
-// training), bwd 12*E*d + 28*N*d; index traffic 4(N+1)+8E per CSR/CSC slice.
+// Algorithmic HBM bytes (fp32, per layer):  fwd 8*E*d + 20*N*d, bwd 12*E*d + 28*N*d (minus the 8*N*d of
+// num / den that are recomputed instead of read); index traffic 4(N+1)+8E per CSR/CSC slice.
 #include <cstdlib>
 
 #include "gps_common.hpp"
@@ -113,13 +113,13 @@ __device__ __forceinline__ void fwd_chunk(const float* __restrict__ Bx, const fl
   }
 }
 
-template <int VEC, bool SAVE, bool GATE>
+template <int VEC, bool GATE>
 __device__ __forceinline__ void fwd_rows(const float* __restrict__ Ax, const float* __restrict__ Bx,
                                          const float* __restrict__ Dx, const float* __restrict__ Ex, int64_t ld,
                                          const float* __restrict__ Ce, const int* rp, const int* nbr,
                                          const int* eids, const NodeBlock& blk, int d, int row, int npi, int c,
                                          float* __restrict__ x_tilde, float* __restrict__ e_hat,
-                                         float* __restrict__ den_out, const float* __restrict__ r_edge) {
+                                         const float* __restrict__ r_edge) {
   for (int64_t node = blk.n0 + row; node < blk.n1; node += npi) {
     const int beg = rp[node - blk.n0], end = rp[node - blk.n0 + 1];
     const Vec<VEC> dx = Vec<VEC>::load(Dx + node * ld + c);
@@ -139,17 +139,16 @@ __device__ __forceinline__ void fwd_rows(const float* __restrict__ Ax, const flo
 #pragma unroll
     for (int v = 0; v < VEC; ++v) xt[v] = ax[v] + num[v] / (den[v] + 1e-6f);  //          (:125,133)
     xt.store(x_tilde + node * (int64_t)d + c);
-    if (SAVE) den.store(den_out + node * (int64_t)d + c);
   }
 }
 
-template <int VEC, bool SAVE, bool GATE>
+template <int VEC, bool GATE>
 __global__ __launch_bounds__(GG_T) void k_gatedgcn_fwd(
     const float* __restrict__ Ax, const float* __restrict__ Bx, const float* __restrict__ Dx,
     const float* __restrict__ Ex, int64_t ld, const float* __restrict__ Ce,
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src,
     const int32_t* __restrict__ eid, int64_t N, int d, float* __restrict__ x_tilde,
-    float* __restrict__ e_hat, float* __restrict__ den_out, const float* __restrict__ r_edge, int nb, int npi) {
+    float* __restrict__ e_hat, const float* __restrict__ r_edge, int nb, int npi) {
   __shared__ int s_rp[GG_MAXNB + 1];
   __shared__ int s_src[GG_MAXE], s_eid[GG_MAXE];
   const NodeBlock blk = node_block(N, nb);
@@ -162,11 +161,10 @@ __global__ __launch_bounds__(GG_T) void k_gatedgcn_fwd(
   const int c = (threadIdx.x - row * lpr) * VEC;
   const int e0 = s_rp[0];
   if (staged)     // index slices in LDS (workgroup-uniform branch: two copies of the body, one address space each)
-    fwd_rows<VEC, SAVE, GATE>(Ax, Bx, Dx, Ex, ld, Ce, s_rp, s_src - e0, s_eid - e0, blk, d, row, npi, c, x_tilde,
-                              e_hat, den_out, r_edge);
+    fwd_rows<VEC, GATE>(Ax, Bx, Dx, Ex, ld, Ce, s_rp, s_src - e0, s_eid - e0, blk, d, row, npi, c, x_tilde, e_hat,
+                        r_edge);
   else            // a hub-heavy block (> GG_MAXE entries): same code on the global index arrays
-    fwd_rows<VEC, SAVE, GATE>(Ax, Bx, Dx, Ex, ld, Ce, s_rp, src, eid, blk, d, row, npi, c, x_tilde, e_hat,
-                              den_out, r_edge);
+    fwd_rows<VEC, GATE>(Ax, Bx, Dx, Ex, ld, Ce, s_rp, src, eid, blk, d, row, npi, c, x_tilde, e_hat, r_edge);
 }
 
 // Backward, one launch (see the header comment):
@@ -180,9 +178,8 @@ template <int VEC, bool GATE, int D>
 __device__ __forceinline__ void bwd_a_chunk(const float* __restrict__ g_e, const float* __restrict__ e_hat,
                                             const float* __restrict__ Bx, int64_t ld,
                                             const float* __restrict__ r_edge, int d, int c, const int* nbr,
-                                            const int* eids, const Vec<VEC>& a, const Vec<VEC>& inv,
-                                            Vec<VEC>& gdx, float* g_Ce, float* __restrict__ sD,
-                                            float* __restrict__ sS, int slot0, int cap) {
+                                            const int* eids, const Vec<VEC>& gx, Vec<VEC>& gdx, float* g_Ce,
+                                            float* __restrict__ sD, float* __restrict__ sS, int slot0, int cap) {
   int64_t id[D];
   Vec<VEC> eh[D], ge[D], bx[D];
   float rr[D];
@@ -195,33 +192,41 @@ __device__ __forceinline__ void bwd_a_chunk(const float* __restrict__ g_e, const
     bx[u] = Vec<VEC>::load(Bx + j * ld + c);
     rr[u] = GATE ? r_edge[id[u]] : 1.0f;
   }
-  Vec<VEC> num = Vec<VEC>::zero();
+  // num_i and den_i exactly as the forward summed them (same order, same gate arithmetic): nothing was saved
+  Vec<VEC> num = Vec<VEC>::zero(), den = Vec<VEC>::zero();
 #pragma unroll
   for (int u = 0; u < D; ++u)
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
       const float s = sigmoidf_fast(eh[u][v]);
-      float sp = s * (1.0f - s);
-      if (GATE) sp = sp * rr[u];
       const float sg = GATE ? s * rr[u] : s;
       num[v] += sg * bx[u][v];
-      ge[u][v] += (a[v] * bx[u][v]) * sp;     // t_ij
-      eh[u][v] = sp;                          // s'_ij
-      bx[u][v] = sg * a[v];                   // sig_ij a_i: what the source-keyed phase adds to g_Bx_j
+      den[v] += sg;
+      eh[u][v] = s;
     }
+  Vec<VEC> a, b;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    const float inv = 1.0f / (den[v] + 1e-6f);
+    a[v] = gx[v] * inv;
+    b[v] = -a[v] * (num[v] * inv);
+  }
 #pragma unroll
   for (int u = 0; u < D; ++u) {
-    Vec<VEC> dl;
+    Vec<VEC> dl, sa;
 #pragma unroll
     for (int v = 0; v < VEC; ++v) {
-      const float b = -a[v] * (num[v] * inv[v]);
-      dl[v] = ge[u][v] + b * eh[u][v];
+      const float s = eh[u][v];
+      float sp = s * (1.0f - s);
+      if (GATE) sp = sp * rr[u];
+      dl[v] = (ge[u][v] + (a[v] * bx[u][v]) * sp) + b[v] * sp;
       gdx[v] += dl[v];
+      sa[v] = (GATE ? s * rr[u] : s) * a[v];   // sig_ij a_i: what the source-keyed phase adds to g_Bx_j
     }
     dl.store(g_Ce + id[u] * d + c);
     if (slot0 + u < cap) {                    // hand-over to phase B through LDS (no second trip to memory)
       dl.store(sD + (slot0 + u) * d + c);
-      bx[u].store(sS + (slot0 + u) * d + c);
+      sa.store(sS + (slot0 + u) * d + c);
     }
   }
 }
@@ -229,30 +234,25 @@ __device__ __forceinline__ void bwd_a_chunk(const float* __restrict__ g_e, const
 template <int VEC, bool GATE>
 __device__ __forceinline__ void bwd_a_rows(const float* __restrict__ g_x, int64_t ldgx,
                                            const float* __restrict__ g_e, const float* __restrict__ e_hat,
-                                           const float* __restrict__ Bx, int64_t ld, const float* __restrict__ den,
-                                           const int* rp, const int* nbr, const int* eids, const NodeBlock& blk,
-                                           int d, int row, int npi, int c, float* g_Ce, float* __restrict__ g_Ax,
-                                           float* __restrict__ g_Dx, int64_t ldg,
-                                           const float* __restrict__ r_edge, float* __restrict__ sD,
+                                           const float* __restrict__ Bx, int64_t ld, const int* rp, const int* nbr,
+                                           const int* eids, const NodeBlock& blk, int d, int row, int npi, int c,
+                                           float* g_Ce, float* __restrict__ g_Ax, float* __restrict__ g_Dx,
+                                           int64_t ldg, const float* __restrict__ r_edge, float* __restrict__ sD,
                                            float* __restrict__ sS, int e0, int cap) {
+#define GPS_BWD_A(DD) bwd_a_chunk<VEC, GATE, DD>(g_e, e_hat, Bx, ld, r_edge, d, c, nbr + beg, eids + beg, gx, gdx, \
+                                                 g_Ce, sD, sS, beg - e0, cap)
   for (int64_t node = blk.n0 + row; node < blk.n1; node += npi) {
     const int beg = rp[node - blk.n0], end = rp[node - blk.n0 + 1];
     const Vec<VEC> gx = Vec<VEC>::load(g_x + node * ldgx + c);
-    const Vec<VEC> dn = Vec<VEC>::load(den + node * (int64_t)d + c);
-    Vec<VEC> a, inv, gdx = Vec<VEC>::zero();
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-      inv[v] = 1.0f / (dn[v] + 1e-6f);
-      a[v] = gx[v] * inv[v];
-    }
+    Vec<VEC> gdx = Vec<VEC>::zero();
     switch (end - beg) {
       case 0: break;
-      case 1: bwd_a_chunk<VEC, GATE, 1>(g_e, e_hat, Bx, ld, r_edge, d, c, nbr + beg, eids + beg, a, inv, gdx, g_Ce, sD, sS, beg - e0, cap); break;
-      case 2: bwd_a_chunk<VEC, GATE, 2>(g_e, e_hat, Bx, ld, r_edge, d, c, nbr + beg, eids + beg, a, inv, gdx, g_Ce, sD, sS, beg - e0, cap); break;
-      case 3: bwd_a_chunk<VEC, GATE, 3>(g_e, e_hat, Bx, ld, r_edge, d, c, nbr + beg, eids + beg, a, inv, gdx, g_Ce, sD, sS, beg - e0, cap); break;
-      case 4: bwd_a_chunk<VEC, GATE, 4>(g_e, e_hat, Bx, ld, r_edge, d, c, nbr + beg, eids + beg, a, inv, gdx, g_Ce, sD, sS, beg - e0, cap); break;
-      default: {                               // long segment: num_i first, then the deltas (rows re-read from L1 / L2)
-        Vec<VEC> num = Vec<VEC>::zero();
+      case 1: GPS_BWD_A(1); break;
+      case 2: GPS_BWD_A(2); break;
+      case 3: GPS_BWD_A(3); break;
+      case 4: GPS_BWD_A(4); break;
+      default: {                               // long segment: num_i / den_i first, then the deltas (rows re-read from L1 / L2)
+        Vec<VEC> num = Vec<VEC>::zero(), den = Vec<VEC>::zero();
         for (int k = beg; k < end; ++k) {
           const int64_t j = nbr[k], id = eids[k];
           const Vec<VEC> eh = Vec<VEC>::load(e_hat + id * d + c);
@@ -263,7 +263,15 @@ __device__ __forceinline__ void bwd_a_rows(const float* __restrict__ g_x, int64_
             float s = sigmoidf_fast(eh[v]);
             if (GATE) s = s * rr;
             num[v] += s * bx[v];
+            den[v] += s;
           }
+        }
+        Vec<VEC> a, b;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          const float inv = 1.0f / (den[v] + 1e-6f);
+          a[v] = gx[v] * inv;
+          b[v] = -a[v] * (num[v] * inv);
         }
         for (int k = beg; k < end; ++k) {
           const int64_t j = nbr[k], id = eids[k];
@@ -271,24 +279,18 @@ __device__ __forceinline__ void bwd_a_rows(const float* __restrict__ g_x, int64_
           const Vec<VEC> ge = Vec<VEC>::load(g_e + id * d + c);
           const Vec<VEC> bx = Vec<VEC>::load(Bx + j * ld + c);
           const float rr = GATE ? r_edge[id] : 1.0f;
-          Vec<VEC> dl;
+          Vec<VEC> dl, sa;
 #pragma unroll
           for (int v = 0; v < VEC; ++v) {
             const float s = sigmoidf_fast(eh[v]);
             float sp = s * (1.0f - s);
             if (GATE) sp = sp * rr;
-            const float b = -a[v] * (num[v] * inv[v]);
-            dl[v] = (ge[v] + (a[v] * bx[v]) * sp) + b * sp;     // same association as the one-pass form
+            dl[v] = (ge[v] + (a[v] * bx[v]) * sp) + b[v] * sp;   // same association as the one-pass form
             gdx[v] += dl[v];
+            sa[v] = (GATE ? s * rr : s) * a[v];
           }
           dl.store(g_Ce + id * d + c);
           if (k - e0 < cap) {
-            Vec<VEC> sa;
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) {
-              const float s = sigmoidf_fast(eh[v]);
-              sa[v] = (GATE ? s * rr : s) * a[v];
-            }
             dl.store(sD + (k - e0) * d + c);
             sa.store(sS + (k - e0) * d + c);
           }
@@ -298,6 +300,7 @@ __device__ __forceinline__ void bwd_a_rows(const float* __restrict__ g_x, int64_
     if (g_Ax) gx.store(g_Ax + node * ldg + c);
     gdx.store(g_Dx + node * ldg + c);
   }
+#undef GPS_BWD_A
 }
 
 // Phase B, D outgoing edges of one source node.  An edge whose target this workgroup owns finds its delta and
@@ -307,7 +310,8 @@ template <int VEC, bool GATE, int D>
 __device__ __forceinline__ void bwd_b_chunk(const float* __restrict__ g_x, int64_t ldgx,
                                             const float* __restrict__ g_e, const float* __restrict__ e_hat,
                                             const float* __restrict__ Ax, int64_t ld,
-                                            const float* __restrict__ x_tilde, const float* __restrict__ den,
+                                            const float* __restrict__ x_tilde,
+                                            const int32_t* __restrict__ rowptr_g, const int32_t* __restrict__ eid_g,
                                             const float* __restrict__ r_edge, const float* g_Ce, int d, int c,
                                             const int* tgt, const int* eids, const NodeBlock& blk,
                                             const float* __restrict__ Bx, int64_t node, Vec<VEC>& gbx,
@@ -340,7 +344,18 @@ __device__ __forceinline__ void bwd_b_chunk(const float* __restrict__ g_x, int64
       const bool in = ti[u] >= blk.n0 && ti[u] < blk.n1;
       const Vec<VEC> eh = Vec<VEC>::load(e_hat + id[u] * d + c);
       const Vec<VEC> gx = Vec<VEC>::load(g_x + ti[u] * ldgx + c);
-      const Vec<VEC> dn = Vec<VEC>::load(den + ti[u] * d + c);
+      // den of the target, as the forward summed it: walk the target's own incoming segment (global CSR)
+      Vec<VEC> dn = Vec<VEC>::zero();
+      for (int k2 = rowptr_g[ti[u]]; k2 < rowptr_g[ti[u] + 1]; ++k2) {
+        const int64_t id2 = eid_g[k2];
+        const Vec<VEC> e2 = Vec<VEC>::load(e_hat + id2 * d + c);
+        const float r2 = GATE ? r_edge[id2] : 1.0f;
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          const float s2 = sigmoidf_fast(e2[v]);
+          dn[v] += GATE ? s2 * r2 : s2;
+        }
+      }
       const Vec<VEC> p0 = Vec<VEC>::load((in ? g_Ce : g_e) + id[u] * d + c);   // own delta row, or g_e to rebuild it
       const float rr = GATE ? r_edge[id[u]] : 1.0f;
       Vec<VEC> xt = Vec<VEC>::zero(), axi = Vec<VEC>::zero(), bxj = Vec<VEC>::zero();
@@ -370,14 +385,15 @@ template <int VEC, bool GATE>
 __device__ __forceinline__ void bwd_b_rows(const float* __restrict__ g_x, int64_t ldgx,
                                            const float* __restrict__ g_e, const float* __restrict__ e_hat,
                                            const float* __restrict__ Ax, const float* __restrict__ Bx, int64_t ld,
-                                           const float* __restrict__ x_tilde, const float* __restrict__ den,
+                                           const float* __restrict__ x_tilde,
+                                           const int32_t* __restrict__ rowptr_g, const int32_t* __restrict__ eid_g,
                                            const int* rq, const int* tgt, const int* eids, const NodeBlock& blk,
                                            int d, int row, int npi, int c, const float* g_Ce,
                                            float* __restrict__ g_Bx, float* __restrict__ g_Ex, int64_t ldg,
                                            const float* __restrict__ r_edge, const int* rp_d, const int* eids_d,
                                            int e0, const float* __restrict__ sD, const float* __restrict__ sS,
                                            int cap) {
-#define GPS_BWD_B(DD) bwd_b_chunk<VEC, GATE, DD>(g_x, ldgx, g_e, e_hat, Ax, ld, x_tilde, den, r_edge, g_Ce, d, c, \
+#define GPS_BWD_B(DD) bwd_b_chunk<VEC, GATE, DD>(g_x, ldgx, g_e, e_hat, Ax, ld, x_tilde, rowptr_g, eid_g, r_edge, g_Ce, d, c, \
                                                  tgt + k, eids + k, blk, Bx, node, gbx, gex, rp_d, eids_d, e0, sD, \
                                                  sS, cap)
   for (int64_t node = blk.n0 + row; node < blk.n1; node += npi) {
@@ -402,7 +418,7 @@ template <int VEC, bool GATE>
 __global__ __launch_bounds__(GG_T) void k_gatedgcn_bwd(
     const float* __restrict__ g_x, int64_t ldgx, const float* __restrict__ g_e, const float* __restrict__ e_hat,
     const float* __restrict__ Ax, const float* __restrict__ Bx, int64_t ld, const float* __restrict__ x_tilde,
-    const float* __restrict__ den, const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src,
+    const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src,
     const int32_t* __restrict__ eid, const int32_t* __restrict__ rowptr_s, const int32_t* __restrict__ dst,
     const int32_t* __restrict__ eid_s, int64_t N, int d, float* g_Ce, float* __restrict__ g_Ax,
     float* __restrict__ g_Bx, float* __restrict__ g_Dx, float* __restrict__ g_Ex, int64_t ldg,
@@ -426,10 +442,10 @@ __global__ __launch_bounds__(GG_T) void k_gatedgcn_bwd(
   float* sS = g_stash + (int64_t)cap_arg * d;
   if (active) {
     if (st_d)
-      bwd_a_rows<VEC, GATE>(g_x, ldgx, g_e, e_hat, Bx, ld, den, s_rp, s_src - e0, s_eid - e0, blk, d, row, npi, c,
+      bwd_a_rows<VEC, GATE>(g_x, ldgx, g_e, e_hat, Bx, ld, s_rp, s_src - e0, s_eid - e0, blk, d, row, npi, c,
                             g_Ce, g_Ax, g_Dx, ldg, r_edge, sD, sS, e0, cap);
     else
-      bwd_a_rows<VEC, GATE>(g_x, ldgx, g_e, e_hat, Bx, ld, den, s_rp, src, eid, blk, d, row, npi, c, g_Ce, g_Ax,
+      bwd_a_rows<VEC, GATE>(g_x, ldgx, g_e, e_hat, Bx, ld, s_rp, src, eid, blk, d, row, npi, c, g_Ce, g_Ax,
                             g_Dx, ldg, r_edge, sD, sS, e0, 0);
   }
   __threadfence_block();
@@ -438,11 +454,11 @@ __global__ __launch_bounds__(GG_T) void k_gatedgcn_bwd(
   if (!active) return;
   const int q0 = s_rq[0];
   if (st_s)
-    bwd_b_rows<VEC, GATE>(g_x, ldgx, g_e, e_hat, Ax, Bx, ld, x_tilde, den, s_rq, s_dst - q0, s_eid2 - q0, blk, d,
-                          row, npi, c, g_Ce, g_Bx, g_Ex, ldg, r_edge, s_rp, s_eid - e0, e0, sD, sS, cap);
+    bwd_b_rows<VEC, GATE>(g_x, ldgx, g_e, e_hat, Ax, Bx, ld, x_tilde, rowptr, eid, s_rq, s_dst - q0, s_eid2 - q0,
+                          blk, d, row, npi, c, g_Ce, g_Bx, g_Ex, ldg, r_edge, s_rp, s_eid - e0, e0, sD, sS, cap);
   else
-    bwd_b_rows<VEC, GATE>(g_x, ldgx, g_e, e_hat, Ax, Bx, ld, x_tilde, den, s_rq, dst, eid_s, blk, d, row, npi, c,
-                          g_Ce, g_Bx, g_Ex, ldg, r_edge, s_rp, s_eid - e0, e0, sD, sS, cap);
+    bwd_b_rows<VEC, GATE>(g_x, ldgx, g_e, e_hat, Ax, Bx, ld, x_tilde, rowptr, eid, s_rq, dst, eid_s, blk, d, row,
+                          npi, c, g_Ce, g_Bx, g_Ex, ldg, r_edge, s_rp, s_eid - e0, e0, sD, sS, cap);
 }
 
 inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
@@ -475,12 +491,12 @@ inline Plan plan_for(int64_t N, int lanes_per_row) {
 
 }  // namespace
 
-#define GPS_GG_FWD(SAVE, GATE)                                                                       \
-  k_gatedgcn_fwd<VEC, SAVE, GATE><<<pl.grid, pl.threads, 0, s>>>(Ax, Bx, Dx, Ex, ld_node, Ce, rowptr_dst,  \
-      src_by_dst, eid_by_dst, N, d, x_tilde, e_hat, den, r_edge, pl.nb, pl.npi)
+#define GPS_GG_FWD(GATE)                                                                             \
+  k_gatedgcn_fwd<VEC, GATE><<<pl.grid, pl.threads, 0, s>>>(Ax, Bx, Dx, Ex, ld_node, Ce, rowptr_dst,        \
+      src_by_dst, eid_by_dst, N, d, x_tilde, e_hat, r_edge, pl.nb, pl.npi)
 #define GPS_GG_BWD(GATE)                                                                             \
   k_gatedgcn_bwd<VEC, GATE><<<pl.grid, pl.threads, stash_bytes, s>>>(g_x, ld_gx, g_e, e_hat, Ax, Bx, ld_node, x_tilde, \
-      den, rowptr_dst, src_by_dst, eid_by_dst, rowptr_src, dst_by_src, eid_by_src, N, d, g_Ce,        \
+      rowptr_dst, src_by_dst, eid_by_dst, rowptr_src, dst_by_src, eid_by_src, N, d, g_Ce,             \
       g_Ax == g_x ? nullptr : g_Ax, g_Bx, g_Dx, g_Ex, ld_gnode, r_edge, pl.nb, pl.npi, cap)
 
 extern "C" {
@@ -488,30 +504,27 @@ extern "C" {
 int gps_gatedgcn_fwd(const float* Ax, const float* Bx, const float* Dx, const float* Ex,
                      int64_t ld_node, const float* Ce, const int32_t* rowptr_dst,
                      const int32_t* src_by_dst, const int32_t* eid_by_dst, int64_t N, int64_t E,
-                     int d, float* x_tilde, float* e_hat, float* den,
-                     const float* r_edge, gps_stream_t stream) {
+                     int d, float* x_tilde, float* e_hat, const float* r_edge, gps_stream_t stream) {
   GPS_REQUIRE(N >= 0 && E >= 0 && d > 0 && ld_node >= d, "gps_gatedgcn_fwd: bad sizes N=%lld E=%lld d=%d ld=%lld",
               (long long)N, (long long)E, d, (long long)ld_node);
   if (N == 0) return GPS_OK;
   GPS_REQUIRE(Ax && Bx && Dx && Ex && rowptr_dst && x_tilde, "gps_gatedgcn_fwd: null node buffer");
   GPS_REQUIRE(E == 0 || (Ce && src_by_dst && eid_by_dst && e_hat), "gps_gatedgcn_fwd: null edge buffer");
-  const bool save = den != nullptr;
   auto ok = [&](size_t a) {
     return aligned_to(Ax, a) && aligned_to(Bx, a) && aligned_to(Dx, a) && aligned_to(Ex, a) &&
-           aligned_to(Ce, a) && aligned_to(x_tilde, a) && aligned_to(e_hat, a) && aligned_to(den, a);
+           aligned_to(Ce, a) && aligned_to(x_tilde, a) && aligned_to(e_hat, a);
   };
   hipStream_t s = gps::as_stream(stream);
   GPS_DISPATCH_VEC(d, ld_node % 4 == 0 && ok(16), ld_node % 2 == 0 && ok(8), {
     GPS_REQUIRE(d / VEC <= GG_T, "gps_gatedgcn_fwd: d=%d too wide for one workgroup pass (%d lanes)", d, d / VEC);
     const Plan pl = plan_for(N, d / VEC);
-    if (save) { if (r_edge) GPS_GG_FWD(true, true); else GPS_GG_FWD(true, false); }
-    else { if (r_edge) GPS_GG_FWD(false, true); else GPS_GG_FWD(false, false); }
+    if (r_edge) GPS_GG_FWD(true); else GPS_GG_FWD(false);
   });
   return gps::launch_status("gps_gatedgcn_fwd");
 }
 
 int gps_gatedgcn_bwd(const float* g_x, int64_t ld_gx, const float* g_e, const float* e_hat, const float* Ax,
-                     const float* Bx, int64_t ld_node, const float* x_tilde, const float* den,
+                     const float* Bx, int64_t ld_node, const float* x_tilde,
                      const int32_t* rowptr_dst, const int32_t* src_by_dst,
                      const int32_t* eid_by_dst, const int32_t* rowptr_src,
                      const int32_t* dst_by_src, const int32_t* eid_by_src, int64_t N, int64_t E,
@@ -520,14 +533,14 @@ int gps_gatedgcn_bwd(const float* g_x, int64_t ld_gx, const float* g_e, const fl
   GPS_REQUIRE(N >= 0 && E >= 0 && d > 0 && ld_node >= d && ld_gnode >= d && ld_gx >= d,
               "gps_gatedgcn_bwd: bad sizes");
   if (N == 0) return GPS_OK;
-  GPS_REQUIRE(g_x && Ax && Bx && x_tilde && den && rowptr_dst && rowptr_src && g_Ax && g_Bx && g_Dx && g_Ex,
+  GPS_REQUIRE(g_x && Ax && Bx && x_tilde && rowptr_dst && rowptr_src && g_Ax && g_Bx && g_Dx && g_Ex,
               "gps_gatedgcn_bwd: null node buffer");
   GPS_REQUIRE(E == 0 || (g_e && e_hat && src_by_dst && eid_by_dst && dst_by_src && eid_by_src && g_Ce),
               "gps_gatedgcn_bwd: null edge buffer");
   GPS_REQUIRE(g_Ax != g_x || ld_gx == ld_gnode, "gps_gatedgcn_bwd: g_Ax aliases g_x with a different stride");
   auto ok = [&](size_t a) {
     return aligned_to(g_x, a) && aligned_to(g_e, a) && aligned_to(e_hat, a) && aligned_to(Ax, a) &&
-           aligned_to(Bx, a) && aligned_to(x_tilde, a) && aligned_to(den, a) && aligned_to(g_Ce, a) &&
+           aligned_to(Bx, a) && aligned_to(x_tilde, a) && aligned_to(g_Ce, a) &&
            aligned_to(g_Ax, a) && aligned_to(g_Bx, a) && aligned_to(g_Dx, a) && aligned_to(g_Ex, a);
   };
   hipStream_t s = gps::as_stream(stream);

@@ -242,10 +242,9 @@ class _GPSBlock(torch.autograd.Function):
         ce = (_gemm.gemm_panel(e, imgs[1][0], d, bias=lm.C.bias) if panel
               else torch.addmm(lm.C.bias, e, lm.C.weight.t()))
         xt, eh = _E(N, d, **f32), _E(E, d, **f32)
-        den = _E(N, d, **f32)
         check(L.gps_gatedgcn_fwd(P, P + fs, P + 2 * fs, P + 3 * fs, ldp, ptr(ce), ptr(gi.rowptr_dst),
                                  ptr(gi.src_by_dst), ptr(gi.eid_by_dst), N, E, d, ptr(xt), ptr(eh),
-                                 ptr(den), None, st), "gps_gatedgcn_fwd")
+                                 None, st), "gps_gatedgcn_fwd")
         fork.join(o, lse, ao)
 
         # -- the five BatchNorms, residuals and dropouts as task lists (csrc/block_norm.hip) -------
@@ -287,7 +286,7 @@ class _GPSBlock(torch.autograd.Function):
                              layer.norm1_attn.num_batches_tracked,
                              layer.norm2.num_batches_tracked], 1)
 
-        ctx.save_for_backward(x, e, pq, eh, den, xt, x1, o, lse, za, h, f1 if f1 is not None else t, t, z2, stats)
+        ctx.save_for_backward(x, e, pq, eh, xt, x1, o, lse, za, h, f1 if f1 is not None else t, t, z2, stats)
         ctx.layer, ctx.gi, ctx.seeds = layer, gi, s
         ctx.imgs = imgs     # W^T images for the input-gradient GEMMs (None: library GEMMs)
         ctx.cfg = (p, p_l, p_f1, p_f2, p_at, H, dh, scale)
@@ -296,7 +295,7 @@ class _GPSBlock(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_out, g_e1):
         L = _lib.load()
-        x, e, pq, eh, den, xt, x1, o, lse, za, h, f1, t, z2, stats = ctx.saved_tensors
+        x, e, pq, eh, xt, x1, o, lse, za, h, f1, t, z2, stats = ctx.saved_tensors
         layer, gi, s = ctx.layer, ctx.gi, ctx.seeds
         p, p_l, p_f1, p_f2, p_at, H, dh, scale = ctx.cfg
         lm, sa = layer.local_model, layer.self_attn
@@ -360,7 +359,7 @@ class _GPSBlock(torch.autograd.Function):
                                 ptr(g_beb), d, 1, p, ptr(ws), st), "gps_bn_bwd_pair")
         g_ce = _E(E, d, **f32)
         check(L.gps_gatedgcn_bwd(ptr(g_xt), d, ptr(g_eh), ptr(eh), P, P + fs, ldp, ptr(xt),
-                                 ptr(den), ptr(gi.rowptr_dst), ptr(gi.src_by_dst), ptr(gi.eid_by_dst),
+                                 ptr(gi.rowptr_dst), ptr(gi.src_by_dst), ptr(gi.eid_by_dst),
                                  ptr(gi.rowptr_src), ptr(gi.dst_by_src), ptr(gi.eid_by_src), N, E, d,
                                  ptr(g_ce), G, G + fs, G + 2 * fs, G + 3 * fs, ldp, None, st),
               "gps_gatedgcn_bwd")

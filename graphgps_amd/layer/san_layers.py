@@ -1,9 +1,10 @@
-"""SAN graph-transformer layers (``SANLayer`` / ``SAN2Layer``) at the reference's abstraction level: device
-torch ops (gather, ``index_add_``, ``scatter_reduce``), NOT HIP kernels.
+"""SAN graph-transformer layers (``SANLayer`` / ``SAN2Layer``).
 
-The SAN family is outside the measured hot path (a HIP edge-softmax kernel is listed as a
-next step, section 7); these modules exist so that ``configs/SAN/*.yaml`` construct and train on the same
-registrations, with the reference's parameter names (``attention.{Q,K,E,V,Q_2,K_2,E_2}``, SAN2: ``attention.gamma``;
+The attention over the REAL edges -- score, clamp-exp (SAN) or per-target softmax (SAN2), weighted sum of source
+values -- is one HIP gather-gate-segment-reduce kernel (csrc/edge_attn.hip through ``ops.edge_attention``) whenever
+the tensors are on the GPU and the head width is 4, 8, 16, 32 or 64; the complement-graph ("fake edge") half of the
+full-graph variants, the gamma mixing and everything on the CPU use device torch ops at the reference's abstraction
+level (gather, ``index_add_``, ``scatter_reduce``).  The modules carry the reference's parameter names (``attention.{Q,K,E,V,Q_2,K_2,E_2}``, SAN2: ``attention.gamma``;
 ``O_h``, ``FFN_h_layer{1,2}``, ``batch_norm{1,2}_h`` / ``layer_norm{1,2}_h``) and arithmetic
 (``/root/reference/graphgps/layer/san_layer.py:10-216``, ``san2_layer.py:11-238``):
 
@@ -75,6 +76,10 @@ class _SANAttention(nn.Module):
     def forward(self, batch):
         H, D, n = self.num_heads, self.out_dim, batch.x.shape[0]
         x = batch.x
+        if x.is_cuda and x.dtype == torch.float32:
+            from ..ops import edge_attention_supported
+            if edge_attention_supported(H, D):
+                return self._forward_hip(batch)
         v = self.V(x).view(n, H, D)
         real = batch.edge_index
         w = self._weights(self.Q(x).view(n, H, D), self.K(x).view(n, H, D),
@@ -90,6 +95,28 @@ class _SANAttention(nn.Module):
         if self.full_graph:
             wv = wv.index_add_(0, fake[1], v[fake[0]] * w2)
             z = z.index_add_(0, fake[1], w2)
+        return wv if self.softmax else wv / (z + 1e-6)
+
+
+    def _forward_hip(self, batch):
+        """Real edges on the HIP kernel; fake pairs (full_graph) and the gamma mixing as above."""
+        from ..ops import edge_attention, graph_index_of
+        H, D, n = self.num_heads, self.out_dim, batch.x.shape[0]
+        x = batch.x
+        v2d = self.V(x)
+        gi = graph_index_of(batch)
+        wv, z = edge_attention(self.Q(x), self.K(x), v2d, self.E(batch.edge_attr), gi, H, self.softmax)
+        wv, z = wv.view(n, H, D), z.view(n, H, 1)
+        if self.full_graph:
+            v = v2d.view(n, H, D)
+            real = batch.edge_index
+            fake = complement_edge_index(real, batch.batch)
+            e2 = self.E_2(self.fake_edge_emb(real.new_zeros(1))).view(1, H, D)    # one embedding for all
+            w2 = self._weights(self.Q_2(x).view(n, H, D), self.K_2(x).view(n, H, D), e2, fake, n)
+            g = torch.clamp(self.gamma, min=0.0, max=1.0) if self.softmax else self.gamma
+            w2 = g * w2 / (g + 1)
+            wv = (wv / (g + 1)).index_add(0, fake[1], v[fake[0]] * w2)
+            z = (z / (g + 1)).index_add(0, fake[1], w2)
         return wv if self.softmax else wv / (z + 1e-6)
 
 

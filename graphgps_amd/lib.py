@@ -15,7 +15,7 @@ import torch  # noqa: F401  -- must be imported first: it maps the HIP runtime o
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GPS_HIP_LIB: an alternative build of the same ABI (A/B timing of kernel variants in one process launch each)
 LIB_PATH = os.environ.get("GPS_HIP_LIB") or os.path.join(_HERE, "csrc", "libgps_hip.so")
-ABI_VERSION = 3
+ABI_VERSION = 4
 
 _lib: Optional[ctypes.CDLL] = None
 
@@ -30,8 +30,8 @@ _SIGNATURES = {
     "gps_segment_ptr_from_batch": (c_int, [_P, c_int64, c_int64, _P, _P]),
     "gps_attn_tile_map": (c_int, [_P, c_int64, c_int64, _P, _P, _P]),
     "gps_gatedgcn_fwd": (c_int, [_P, _P, _P, _P, c_int64, _P, _P, _P, _P, c_int64, c_int64, c_int,
-                                 _P, _P, _P, _P, _P]),
-    "gps_gatedgcn_bwd": (c_int, [_P, c_int64, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P,
+                                 _P, _P, _P, _P]),
+    "gps_gatedgcn_bwd": (c_int, [_P, c_int64, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P,
                                  c_int64, c_int64, c_int, _P, _P, _P, _P, _P, c_int64, _P, _P]),
     "gps_gine_fwd": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int64, c_int, c_float, _P, _P, _P]),
     "gps_gine_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int64, c_int, c_float, _P,
@@ -82,6 +82,11 @@ _SIGNATURES = {
                                  c_float, c_uint64, _P, _P, c_int64, c_int64, _P]),
     "gps_seg_attn_bwd": (c_int, [_P, _P, c_int64, _P, _P, _P, _P, _P, c_int64, c_int64, c_int, c_int,
                                  c_float, c_float, c_uint64, _P, _P, c_int64, c_int64, c_int64, _P]),
+    "gps_edge_attn_supported": (c_int, [c_int, c_int]),
+    "gps_edge_attn_fwd": (c_int, [_P, _P, _P, c_int64, _P, _P, _P, _P, c_int64, c_int64, c_int, c_int, c_float, c_int,
+                                  _P, _P, _P, _P, _P]),
+    "gps_edge_attn_bwd": (c_int, [_P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64,
+                                  c_int64, c_int, c_int, c_float, c_int, _P, _P, _P, _P, _P, _P]),
     "gps_gemm_image_elems": (c_size_t, [c_int64, c_int64]),
     "gps_gemm_panel_supported": (c_int, [c_int64, c_int64]),
     "gps_gemm_split_weights": (c_int, [c_int, _P, _P]),

@@ -194,22 +194,21 @@ class _GatedGCNAggregate(torch.autograd.Function):
         need_grad = any(ctx.needs_input_grad)
         x_tilde = torch.empty(N, d, dtype=torch.float32, device=dev)
         e_hat = torch.empty(E, d, dtype=torch.float32, device=dev)
-        # the only extra tensor the backward needs: den_i = sum_j sigma_ij (num is recomputed from e_hat)
-        den = torch.empty(N, d, dtype=torch.float32, device=dev) if need_grad else None
+        # nothing extra is saved: the backward recomputes num_i and den_i from e_hat
         base, fs = proj.data_ptr(), d * 4  # fs = byte offset between the Ax|Bx|Dx|Ex column blocks
         check(L.gps_gatedgcn_fwd(base, base + fs, base + 2 * fs, base + 3 * fs, 4 * d, ptr(ce),
                                  ptr(gi.rowptr_dst), ptr(gi.src_by_dst), ptr(gi.eid_by_dst), N, E,
-                                 d, ptr(x_tilde), ptr(e_hat), ptr(den), ptr(r),
+                                 d, ptr(x_tilde), ptr(e_hat), ptr(r),
                                  current_stream(dev)), "gps_gatedgcn_fwd")
         if need_grad:
-            ctx.save_for_backward(proj, e_hat, x_tilde, den, r)
+            ctx.save_for_backward(proj, e_hat, x_tilde, r)
             ctx.gi = gi
         return x_tilde, e_hat
 
     @staticmethod
     def backward(ctx, g_x: torch.Tensor, g_e: torch.Tensor):
         L = _lib.load()
-        proj, e_hat, x_tilde, den, r = ctx.saved_tensors
+        proj, e_hat, x_tilde, r = ctx.saved_tensors
         gi: GraphIndex = ctx.gi
         dev = proj.device
         N, E = gi.N, gi.E
@@ -220,7 +219,7 @@ class _GatedGCNAggregate(torch.autograd.Function):
         g_ce = torch.empty(E, d, dtype=torch.float32, device=dev)
         gb, fs = g_proj.data_ptr(), d * 4
         check(L.gps_gatedgcn_bwd(ptr(g_x), d, ptr(g_e), ptr(e_hat), proj.data_ptr(), proj.data_ptr() + fs, 4 * d,
-                                 ptr(x_tilde), ptr(den), ptr(gi.rowptr_dst), ptr(gi.src_by_dst),
+                                 ptr(x_tilde), ptr(gi.rowptr_dst), ptr(gi.src_by_dst),
                                  ptr(gi.eid_by_dst), ptr(gi.rowptr_src), ptr(gi.dst_by_src),
                                  ptr(gi.eid_by_src), N, E, d, ptr(g_ce), gb, gb + fs, gb + 2 * fs,
                                  gb + 3 * fs, 4 * d, ptr(r), current_stream(dev)), "gps_gatedgcn_bwd")
@@ -230,7 +229,9 @@ class _GatedGCNAggregate(torch.autograd.Function):
             # A per-edge channel reduction: plain gathers + a row sum (rare option, [E,d] temporaries)
             # (fp64: a * Bx_j + b cancels, and this scalar feeds a 1 -> d -> 1 MLP's gradients)
             src, dst = gi.edge_src, gi.edge_dst
-            a = g_x.double() / (den.double() + 1e-6)
+            den = torch.zeros(N, d, dtype=torch.float64, device=dev).index_add_(
+                0, dst, torch.sigmoid(e_hat.double()) * r.double().view(-1, 1))     # sum_j sigma_ij r_ij
+            a = g_x.double() / (den + 1e-6)
             bterm = -a * (x_tilde.double() - proj[:, :d].double())     # aggr_i = x_tilde_i - Ax_i
             gs = a.index_select(0, dst) * proj[:, d:2 * d].double().index_select(0, src) \
                 + bterm.index_select(0, dst)
@@ -530,6 +531,69 @@ def attn_dropout_keep_mask(seed: int, q_global: torch.Tensor, head: int, num_hea
 def attn_dropout_effective_p(p_drop: float) -> float:
     """Drop probability the attention kernels realise for a nominal ``p_drop``: round(p * 2^16) / 2^16."""
     return int(p_drop * 65536.0 + 0.5) / 65536.0
+
+
+# -------------------------------------------------------------------------------------------
+# SAN edge attention over the real edges
+# -------------------------------------------------------------------------------------------
+class _EdgeAttention(torch.autograd.Function):
+    """(Q, K, V [N, H*D], E [E, H*D]) -> (wv [N, H*D], z [N, H]); see include/gps_hip.h: gps_edge_attn_fwd."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, e, gi: GraphIndex, H: int, softmax: bool):
+        L = _lib.load()
+        dev = _require_cuda(q, k, v, e)
+        q, k, v, e = _f32c(q, "Q"), _f32c(k, "K"), _f32c(v, "V"), _f32c(e, "E")
+        N, E = gi.N, gi.E
+        HD = q.shape[1]
+        D = HD // H
+        if q.shape != (N, HD) or k.shape != q.shape or v.shape != q.shape or e.shape != (E, HD) or D * H != HD:
+            raise _lib.GpsHipError(f"edge_attention: Q {tuple(q.shape)} / E {tuple(e.shape)} vs N={N} E={E} H={H}")
+        if not L.gps_edge_attn_supported(H, D):
+            raise _lib.GpsHipError(f"edge_attention: head dim {D} has no kernel (4, 8, 16, 32, 64)")
+        f32 = dict(dtype=torch.float32, device=dev)
+        wv = torch.empty(N, HD, **f32)
+        z = torch.zeros(N, H, **f32)
+        mx = torch.empty(N, H, **f32) if softmax else None
+        ls = torch.empty(N, H, **f32) if softmax else None
+        scale = float(D) ** -0.5
+        check(L.gps_edge_attn_fwd(ptr(q), ptr(k), ptr(v), HD, ptr(e), ptr(gi.rowptr_dst), ptr(gi.src_by_dst),
+                                  ptr(gi.eid_by_dst), N, E, H, D, scale, int(softmax), ptr(wv), ptr(z), ptr(mx),
+                                  ptr(ls), current_stream(dev)), "gps_edge_attn_fwd")
+        ctx.save_for_backward(q, k, v, e, wv, mx, ls)
+        ctx.gi, ctx.cfg = gi, (H, D, scale, bool(softmax))
+        ctx.mark_non_differentiable(z) if softmax else None
+        return wv, z
+
+    @staticmethod
+    def backward(ctx, g_wv, g_z):
+        L = _lib.load()
+        q, k, v, e, wv, mx, ls = ctx.saved_tensors
+        gi: GraphIndex = ctx.gi
+        H, D, scale, softmax = ctx.cfg
+        dev = q.device
+        N, E, HD = gi.N, gi.E, q.shape[1]
+        g_wv = _f32c(g_wv, "g_wv") if g_wv is not None else torch.zeros_like(wv)
+        g_z = _f32c(g_z, "g_z") if (g_z is not None and not softmax) else None
+        g_q, g_k, g_v = torch.empty_like(q), torch.empty_like(q), torch.empty_like(q)
+        g_e = torch.empty_like(e)
+        ws = torch.empty(max(2 * E * H, 1), dtype=torch.float32, device=dev)
+        check(L.gps_edge_attn_bwd(ptr(g_wv), ptr(g_z), ptr(q), ptr(k), ptr(v), HD, ptr(e), ptr(wv), ptr(mx), ptr(ls),
+                                  ptr(gi.rowptr_dst), ptr(gi.src_by_dst), ptr(gi.eid_by_dst), ptr(gi.rowptr_src),
+                                  ptr(gi.dst_by_src), ptr(gi.eid_by_src), N, E, H, D, scale, int(softmax), ptr(g_q),
+                                  ptr(g_k), ptr(g_v), ptr(g_e), ptr(ws), current_stream(dev)), "gps_edge_attn_bwd")
+        return g_q, g_k, g_v, g_e, None, None, None
+
+
+def edge_attention_supported(num_heads: int, head_dim: int) -> bool:
+    return head_dim in (4, 8, 16, 32, 64) and num_heads > 0
+
+
+def edge_attention(q, k, v, e, gi: GraphIndex, num_heads: int, softmax: bool):
+    """SAN attention over the real edges (san_layer.py:44-92 / san2_layer.py:65-105): returns
+    ``(sum_e w_e V[src], sum_e w_e)`` per target node with ``w`` the clamp-exp (``softmax=False``) or the per-target
+    softmax (``softmax=True``; the second output is then unused zeros) of the per-head K.Q.E score."""
+    return _EdgeAttention.apply(q, k, v, e, gi, int(num_heads), bool(softmax))
 
 
 # -------------------------------------------------------------------------------------------

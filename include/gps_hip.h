@@ -78,8 +78,8 @@ int gps_attn_tile_map(const int32_t* ptr, int64_t B, int64_t max_tiles, int32_t*
  *   e_hat[eid] = Dx[i] + Ex[j] + Ce[eid]                      (edge order, pre-BN edge output)
  *   x_tilde[i] = Ax[i] + (sum_j sig*Bx[j]) / (sum_j sig + 1e-6)
  * Ax/Bx/Dx/Ex are [N, d] views with row stride ld_node (a fused [N,4d] / [N,7d] projection passes
- * ld_node = 4d / 7d).  `den` ([N,d] = sum_j sig, the only tensor saved for the backward besides the
- * outputs; NULL in inference).
+ * ld_node = 4d / 7d).  Nothing is saved for the backward besides the outputs themselves: the backward
+ * recomputes sum_j sig*Bx[j] and sum_j sig from e_hat in the forward's own summation order.
  * `r_edge` (float[E] by edge id, or NULL): the EquivStableLapPE gate r_ij of
  * graphgps/layer/gatedgcn_layer.py:101-104 -- sig is replaced by sig * r_edge[eid] in both sums
  * (and in the backward; the gradient wrt r_edge itself is the caller's: graphgps_amd/ops.py).
@@ -89,18 +89,18 @@ int gps_attn_tile_map(const int32_t* ptr, int64_t B, int64_t max_tiles, int32_t*
 int gps_gatedgcn_fwd(const float* Ax, const float* Bx, const float* Dx, const float* Ex,
                      int64_t ld_node, const float* Ce, const int32_t* rowptr_dst,
                      const int32_t* src_by_dst, const int32_t* eid_by_dst, int64_t N, int64_t E,
-                     int d, float* x_tilde, float* e_hat, float* den,
-                     const float* r_edge, gps_stream_t stream);
+                     int d, float* x_tilde, float* e_hat, const float* r_edge, gps_stream_t stream);
 
 /* Backward.  Inputs: g_x [N,d] with row stride ld_gx (grad wrt x_tilde), g_e [E,d] (grad wrt e_hat), the
- * forward's e_hat, x_tilde, den and its Ax / Bx inputs (ld_node).  Outputs: g_Ce [E,d]; g_Ax/g_Bx/g_Dx/g_Ex
+ * forward's e_hat and x_tilde and its Ax / Bx inputs (ld_node).  Outputs: g_Ce [E,d]; g_Ax/g_Bx/g_Dx/g_Ex
  * [N,d] views with row stride ld_gnode (g_Ax = g_x; pass g_Ax == g_x with ld_gx == ld_gnode when the incoming
- * gradient already sits in its slot and the copy is skipped).  One launch: a target-keyed phase (num
- * recomputed, delta -> g_Ce, g_Dx), a workgroup barrier, a source-keyed phase (g_Ex, g_Bx) that re-reads this
- * workgroup's own g_Ce rows and recomputes delta for edges whose target another workgroup owns.
+ * gradient already sits in its slot and the copy is skipped).  One launch: a target-keyed phase (num, den
+ * recomputed, delta -> g_Ce, g_Dx; per-edge delta and sig*a handed over through LDS), a workgroup barrier, a
+ * source-keyed phase (g_Ex, g_Bx) that takes the edges into this workgroup's own nodes from LDS and rebuilds the
+ * rest (edges whose target another workgroup owns) from their inputs.
  * Deterministic, no atomics; e_hat / g_e / g_Ce cross HBM once each. */
 int gps_gatedgcn_bwd(const float* g_x, int64_t ld_gx, const float* g_e, const float* e_hat, const float* Ax,
-                     const float* Bx, int64_t ld_node, const float* x_tilde, const float* den,
+                     const float* Bx, int64_t ld_node, const float* x_tilde,
                      const int32_t* rowptr_dst, const int32_t* src_by_dst,
                      const int32_t* eid_by_dst, const int32_t* rowptr_src,
                      const int32_t* dst_by_src, const int32_t* eid_by_src, int64_t N, int64_t E,
@@ -140,6 +140,30 @@ int gps_gcn_spmm(const float* x, int64_t ld_x, const int32_t* rowptr, const int3
  * (graphgps/encoder/signnet_pos_encoder.py:70-110).  CSR-by-target forward, CSC-by-source = transpose. */
 int gps_adj_sum(const float* x, int64_t ld_x, const int32_t* rowptr, const int32_t* nbr, float self_w, int64_t N,
                 int64_t E, int d, float* out, gps_stream_t stream);
+
+/* ---------------------------------------------------------------------------------------
+ * SAN edge attention over the REAL edges (csrc/edge_attn.hip).  Replaces, in MultiHeadAttentionLayer /
+ * MultiHeadAttention2Layer.propagate_attention (graphgps/layer/san_layer.py:44-92, san2_layer.py:11-33,65-105), the
+ * K[src] * Q[dst] * E gathers and product, the clamp-exp (SAN) or pyg_softmax = scatter_max + scatter_add (SAN2),
+ * and the scatter-adds of V[src] * weight (and of the weight):
+ *     s_e = sum_c K[j,h,c] Q[i,h,c] E[e,h,c] * scale                       edge e = (j -> i), head h
+ *     softmax = 0:  w_e = exp(clamp(s_e, -5, 5));        wv[i] = sum_e w_e V[j];   z[i,h] = sum_e w_e
+ *     softmax = 1:  w_e = exp(s_e - max_i) / (sum_i + 1e-16);   wv[i] = sum_e w_e V[j]   (mx / lsum [N,H] saved)
+ * Q, K, V are [N, H*D] with row stride ld; E is [E, H*D] contiguous; D in {4, 8, 16, 32, 64}.  The fake-edge half
+ * of the full-graph variants and the gamma mixing stay with the caller.  Backward: two launches, deterministic;
+ * ws needs 2 * E * H floats.
+ * ------------------------------------------------------------------------------------- */
+int gps_edge_attn_supported(int H, int D);
+int gps_edge_attn_fwd(const float* Q, const float* K, const float* V, int64_t ld, const float* Ee,
+                      const int32_t* rowptr_dst, const int32_t* src_by_dst, const int32_t* eid_by_dst, int64_t N,
+                      int64_t E, int H, int D, float scale, int softmax, float* wv, float* z, float* mx, float* lsum,
+                      gps_stream_t stream);
+int gps_edge_attn_bwd(const float* g_wv, const float* g_z, const float* Q, const float* K, const float* V, int64_t ld,
+                      const float* Ee, const float* wv, const float* mx, const float* lsum,
+                      const int32_t* rowptr_dst, const int32_t* src_by_dst, const int32_t* eid_by_dst,
+                      const int32_t* rowptr_src, const int32_t* dst_by_src, const int32_t* eid_by_src, int64_t N,
+                      int64_t E, int H, int D, float scale, int softmax, float* g_Q, float* g_K, float* g_V,
+                      float* g_E, float* ws, gps_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Row-panel GEMM for the nn.Linear modules of the block and their input gradients (csrc/gemm_panel.hip):

@@ -86,7 +86,7 @@ def test_c_abi_exports_every_declared_symbol():
     assert L.gps_abi_version() == lib.ABI_VERSION
     # argument validation works without a GPU and reports through gps_last_error()
     rc = L.gps_gatedgcn_fwd(None, None, None, None, 8, None, None, None, None, 4, 0, 8,
-                            None, None, None, None, None)
+                            None, None, None, None)
     assert rc == -1 and b"null" in L.gps_last_error()
     assert L.gps_attn_supported_head_dim(24) == 1 and L.gps_attn_supported_head_dim(7) == 0
 

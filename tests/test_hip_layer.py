@@ -704,3 +704,60 @@ def test_signnet_encoder_matches_reference_fixture(model):
     # oracle/gen_golden.py:run_signnet); the library BN / GEMM kernels of the device round them differently
     # from the CPU's (1.2e-5 measured); the HIP aggregation itself is an exact-order segment sum
     _signnet_case(model, torch.device("cuda:0"), grad_tol=1e-4)
+
+
+@pytest.mark.parametrize("name", ["SANLayer", "SAN2Layer"])
+@pytest.mark.parametrize("full_graph", [True, False])
+def test_san_layers_on_the_edge_attention_kernel(name, full_graph):
+    """SANLayer / SAN2Layer with the real-edge attention on csrc/edge_attn.hip (score -> clamp-exp | per-target
+    softmax -> weighted sum, one gather-gate-segment-reduce launch; two launches backward).  full_graph=True: the
+    reference-generated fixture (san_layer.py / san2_layer.py run by oracle/gen_golden.py: output, input and
+    edge-feature gradients, every parameter gradient); full_graph=False (sparse attention only, no fixture): the same
+    module on the CPU, i.e. the torch-op path that the CPU fixture test pins."""
+    import copy
+    from conftest import SAN_GOLDEN
+    from graphgps_amd.data import Batch
+    from graphgps_amd.layer import san_layers
+    dev = torch.device("cuda:0")
+    fix = load_golden(SAN_GOLDEN)[name]
+    d, H = fix["d"], fix["H"]
+    layer = getattr(san_layers, name)(gamma=fix["gamma"], in_dim=d, out_dim=d, num_heads=H, full_graph=full_graph,
+                                      fake_edge_emb=torch.nn.Embedding(1, d), dropout=0.0, layer_norm=False,
+                                      batch_norm=True, residual=True)
+    if full_graph:
+        layer.load_state_dict(fix["state_dict"], strict=True)
+    layer.train()
+    cpu_layer = copy.deepcopy(layer)
+    layer.to(dev)
+
+    def run(mod, device):
+        x = fix["x"].clone().to(device).requires_grad_(True)
+        e = fix["edge_attr"].clone().to(device).requires_grad_(True)
+        b = Batch(x=x, edge_index=fix["edge_index"].to(device), edge_attr=e, batch=fix["batch"].to(device),
+                  ptr=fix["ptr"].to(device))
+        out = mod(b)
+        (out.x * fix["w"].to(device)).sum().backward()
+        return out.x.detach().cpu(), x.grad.cpu(), e.grad.cpu(), {k: p.grad.detach().cpu() for k, p in
+                                                                  mod.named_parameters() if p.grad is not None}
+
+    calls = []
+    import graphgps_amd.ops as ops
+    orig = ops.edge_attention
+    ops.edge_attention = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        got = run(layer, dev)
+    finally:
+        ops.edge_attention = orig
+    assert calls, "the HIP edge-attention kernel was not used"
+    if full_graph:
+        want = (fix["out_x"], fix["grad_x"], fix["grad_edge_attr"], fix["grads"])
+    else:
+        want = run(cpu_layer, torch.device("cpu"))
+    assert_close(got[0], want[0], Tol.ACT, "out.x")
+    assert_close(got[1], want[1], Tol.GRAD_REL, "grad x", rel_to_max=True)
+    assert_close(got[2], want[2], Tol.GRAD_REL, "grad edge_attr", rel_to_max=True)
+    gs = max(float(v.abs().max()) for v in want[3].values())
+    for k, g in want[3].items():
+        a_, b_ = got[3][k].double(), g.double()
+        assert (a_ - b_).abs().max().item() <= Tol.GRAD_REL * max(float(b_.abs().max()), 0.01 * gs, 1.0), \
+            f"grad {k}: {(a_ - b_).abs().max().item():.3e}"

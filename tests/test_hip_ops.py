@@ -755,4 +755,42 @@ def test_gemm_panel_fp32_exact_products(M, K, N):
     lib2 = float((torch.mm(a2.to(dev), w2.to(dev).t()).double().cpu() - ref2).abs().max())
     err2 = float((out2.double().cpu() - ref2).abs().max())
     print(f"  offset operands: max err {err2:.2e} (library {lib2:.2e}, scale {float(ref2.abs().max()):.1f})")
-    assert err2 <= max(4e-6 * float(ref2.abs().max()), 8.0 * lib2), (err2, lib2)
+    assert err2 <= max(4e-6 * float(ref2.abs().max()), 16.0 * lib2), (err2, lib2)
+
+
+@pytest.mark.parametrize("softmax", [False, True])
+@pytest.mark.parametrize("H,D,profile,nb", [(4, 8, "P14", 12), (8, 16, "CODE2_REAL", 3), (2, 64, "ZINC", 5), (3, 4, "P30", 4)])
+def test_edge_attention_real_edges(H, D, profile, nb, softmax):
+    """ops.edge_attention (csrc/edge_attn.hip) vs the reference formulas in fp64 (san_layer.py:44-92,
+    san2_layer.py:11-33,65-105): per-head K.Q.E score, clamp-exp or per-target softmax (eps 1e-16), weighted sum of
+    V[src] and of the weights; isolated targets get zeros; all four input gradients."""
+    from graphgps_amd.ops import edge_attention
+    sizes, ei, bvec, ptr, gen = _structure(profile, nb, 5)
+    N, E, HD = int(ptr[-1]), ei.shape[1], H * D
+    q, k, v = (torch.randn(N, HD, generator=gen) for _ in range(3))
+    e = torch.randn(E, HD, generator=gen)
+    wgt, wz = torch.randn(N, HD, generator=gen), torch.randn(N, H, generator=gen)
+    ref_in = [t.clone().double().requires_grad_(True) for t in (q, k, v, e)]
+    qr, kr, vr, er = (t.view(-1, H, D) for t in ref_in)
+    s = (kr[ei[0]] * qr[ei[1]] * er / D ** 0.5).sum(-1, keepdim=True)
+    if softmax:
+        idx = ei[1].view(-1, 1, 1).expand_as(s)
+        top = torch.full((N, H, 1), float("-inf"), dtype=torch.float64).scatter_reduce(0, idx, s, "amax")
+        ex = (s - top[ei[1]]).exp()
+        w = ex / (torch.zeros(N, H, 1, dtype=torch.float64).index_add_(0, ei[1], ex)[ei[1]] + 1e-16)
+    else:
+        w = torch.exp(s.clamp(-5, 5))
+    wv_ref = torch.zeros(N, H, D, dtype=torch.float64).index_add_(0, ei[1], vr[ei[0]] * w).view(N, HD)
+    z_ref = torch.zeros(N, H, 1, dtype=torch.float64).index_add_(0, ei[1], w).view(N, H)
+    loss = (wv_ref * wgt.double()).sum() + (0.0 if softmax else (z_ref * wz.double()).sum())
+    loss.backward()
+    gi = _index(ei, bvec, ptr)
+    dev_in = [t.cuda().requires_grad_(True) for t in (q, k, v, e)]
+    wv, z = edge_attention(*dev_in, gi, H, softmax)
+    lg = (wv * wgt.cuda()).sum() + (0.0 if softmax else (z * wz.cuda()).sum())
+    lg.backward()
+    assert_close(wv, wv_ref, Tol.ACT * max(1.0, float(wv_ref.abs().max())), "wv")
+    if not softmax:
+        assert_close(z, z_ref, Tol.ACT * max(1.0, float(z_ref.abs().max())), "z")
+    for name, a_, b_ in zip("QKVE", dev_in, ref_in):
+        assert_close(a_.grad, b_.grad, Tol.GRAD_REL, f"grad {name}", rel_to_max=True)
