@@ -34,6 +34,7 @@
 //   (row, column) exactly as csrc/bn_fused.hip's act_drop (gps_layer.py:256); multiplication by the ReLU/dropout mask
 //   of a saved activation `mask_src` (the FFN's backward, = gps_act_drop_bwd).
 #include <cstdint>
+#include <cstdlib>
 
 #include "gps_common.hpp"
 
@@ -172,6 +173,35 @@ struct PanelArgs {
   int row_tiles;
 };
 
+// Epilogue shared by both kernels.  D[row = (q&3) + 8*(q>>2) + 4*kh][col = li] of each 32 x 32 block; 32 lanes = 128
+// contiguous bytes per row.
+template <int EPI, bool HAS_CIN>
+__device__ __forceinline__ void panel_epilogue(const PanelArgs& P, const f32x16 (&acc)[3], int64_t m0, int n0, int wm,
+                                               int wn, int li, int kh) {
+  const uint64_t seed = gps::salted_seed(P.seed, P.salt);
+  const bool drop = EPI != 0 && P.p_drop > 0.0f;
+  const float inv_keep = drop ? 1.0f / (1.0f - P.p_drop) : 1.0f;
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    const int col = n0 + wn * 96 + j * 32 + li;
+    const float bv = P.bias ? P.bias[col] : 0.0f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int64_t row = m0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh;
+      const int64_t rc = row < P.M ? row : P.M - 1;          // clamped: loads unconditional, the store predicated
+      float v = acc[j][q] + bv;
+      if (HAS_CIN) v += __builtin_nontemporal_load(P.Cin + rc * P.ldcin + col);
+      if (EPI == 1) v = fmaxf(v, 0.0f);
+      if (EPI == 2) v = P.mask_src[rc * P.ldmask + col] > 0.0f ? v : 0.0f;
+      if (EPI != 0) {
+        const bool keep = !drop || keep_elem(row_hash((uint32_t)rc, seed), (uint32_t)col, P.p_drop);
+        v = keep ? v * inv_keep : 0.0f;
+      }
+      if (row < P.M) __builtin_nontemporal_store(v, P.C + row * P.ldc + col);
+    }
+  }
+}
+
 template <int EPI, bool HAS_CIN>
 __global__ __launch_bounds__(NTHREADS) void k_gemm_panel(const PanelArgs P) {
   // single-buffered stages (61 KB): TWO workgroups share a CU, and while one of them splits / stages / waits at its
@@ -278,29 +308,205 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm_panel(const PanelArgs P) {
     }
   }
 
-  // epilogue: D[row = (q&3) + 8*(q>>2) + 4*kh][col = li] of each 32 x 32 block; 32 lanes = 128 contiguous bytes per row
-  const uint64_t seed = gps::salted_seed(P.seed, P.salt);
-  const bool drop = EPI != 0 && P.p_drop > 0.0f;
-  const float inv_keep = drop ? 1.0f / (1.0f - P.p_drop) : 1.0f;
+  panel_epilogue<EPI, HAS_CIN>(P, acc, m0, n0, wm, wn, li, kh);
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// Ring kernel: the same 64 x 192 panel and the same arithmetic, with the staging rebuilt around LDS-DMA.
+//
+// k_gemm_panel above stages through registers (global -> VGPR -> split -> ds_write) into ONE LDS stage behind two
+// barriers; rocprofv3 PMC at the block's shapes: MFMA pipe 31 % busy (17 % at N = 384), 48 % of wave time in issue
+// stalls, 32 % parked at waitcnt / barriers, 2.7 bank-conflict cycles per LDS instruction (the padded pitch is
+// conflict-free for the fragment reads but 2-way for the staging writes).  Here:
+//   * every global -> LDS byte moves by global_load_lds_dwordx4 (1 KB per wave-instruction, no VGPR, no ds_write) into
+//     a THREE-slot ring: stage s+2 is issued while stage s is multiplied, a counted vmcnt(11) leaves it in flight
+//     across the ONE barrier per stage (a plain __syncthreads would drain it);
+//   * A travels as raw fp32 (64 rows x 128 B per stage); a wave reads its 32 x 16 fragment as two ds_read_b128 per
+//     lane and splits it in registers right before the MFMAs (11 VALU per value pair, in the MFMAs' shadow): no
+//     split-then-write pass, no second barrier; the two column-waves of a row block split the same values twice,
+//     which costs VALU slots that were idle;
+//   * LDS images are lane-linear (the DMA writes base + 16 * lane), so the bank swizzle sits on the per-lane SOURCE
+//     address and, identically, on the fragment read: A chunk' = chunk ^ ((row >> 1) & 7) over the 8 chunks of a
+//     128-byte row, W chunk' = chunk ^ ((row >> 2) & 3) over the 4 chunks of a 64-byte row -- each ds_read_b128 lane
+//     group {0-3,12-15,20-27 | 4-11,16-19,28-31} then covers all sixteen 16-byte slots of the 256-byte bank row;
+//   * fragments are double-buffered in registers one 16-wide k-step ahead, the barrier sits BETWEEN the two k-steps of
+//     a stage, so every fragment read has 18 MFMAs (576 cycles) of cover and no MFMA waits on LDS latency.
+// One workgroup per CU (132 KB of LDS), one wavefront per SIMD.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int RG_A = TM * BK * 4;              // raw fp32 A stage: 8 KB
+constexpr int RG_BP = TN * BK * 2;             // one bf16 piece of the W stage: 12 KB
+constexpr int RG_SLOT = RG_A + 3 * RG_BP;      // 44 KB
+constexpr int RG_SLOTS = 3;
+constexpr int RG_LDS = RG_SLOTS * RG_SLOT;     // 132 KB
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* gbl_void_ptr;
+__device__ __forceinline__ void glds16(const unsigned char* g, unsigned char* l) {
+  __builtin_amdgcn_global_load_lds((gbl_void_ptr)g, (lds_void_ptr)l, 16, 0, 0);
+}
+
+struct RingFrag {
+  bf16x8 b[3][3];      // W fragments of one 16-wide k-step: [column block][piece]
+};
+struct RingA {
+  u32x4 p[3];          // the A fragment of one k-step as bf16 pairs: hi, mid, lo
+};
+
+template <int EPI, bool HAS_CIN>
+__global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring(const PanelArgs P) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];
+  const int panel = blockIdx.x / P.row_tiles, rt = blockIdx.x - panel * P.row_tiles;   // panel-major numbering
+  const int64_t m0 = (int64_t)rt * TM;
+  const int n0 = panel * TN;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, kh = lane >> 5;
+  const int KS = P.K / BK;
+
+  // ---- DMA sources -------------------------------------------------------------------------------------------
+  // A: wave w fills rows 16w .. 16w+15 of the stage, two instructions of 8 rows x 128 B; lane -> (row, LDS chunk
+  // position lane & 7), which fetches source chunk pos ^ ((row >> 1) & 7).  Rows past M re-read row M-1 (never stored).
+  const unsigned char* a_src[2];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const int col = n0 + wn * 96 + j * 32 + li;
-    const float bv = P.bias ? P.bias[col] : 0.0f;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int64_t row = m0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh;
-      const int64_t rc = row < P.M ? row : P.M - 1;          // clamped: loads unconditional, the store predicated
-      float v = acc[j][q] + bv;
-      if (HAS_CIN) v += __builtin_nontemporal_load(P.Cin + rc * P.ldcin + col);
-      if (EPI == 1) v = fmaxf(v, 0.0f);
-      if (EPI == 2) v = P.mask_src[rc * P.ldmask + col] > 0.0f ? v : 0.0f;
-      if (EPI != 0) {
-        const bool keep = !drop || keep_elem(row_hash((uint32_t)rc, seed), (uint32_t)col, P.p_drop);
-        v = keep ? v * inv_keep : 0.0f;
-      }
-      if (row < P.M) __builtin_nontemporal_store(v, P.C + row * P.ldc + col);
-    }
+  for (int i = 0; i < 2; ++i) {
+    const int row = 16 * wave + 8 * i + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    const int64_t grow = min(m0 + row, P.M - 1);
+    a_src[i] = reinterpret_cast<const unsigned char*>(P.A + grow * P.lda) + c * 16;
   }
+  // W: per piece 12 blocks of 16 rows x 64 B; wave w moves blocks 3w .. 3w+2 of every piece (9 instructions).
+  // lane -> (row lane >> 2 of the block, position lane & 3) fetching chunk pos ^ ((row >> 2) & 3)
+  const int64_t stage_stride = (int64_t)P.N * (BK * 2);             // bytes between k-stages of one piece
+  const int64_t piece_stride = stage_stride * KS;
+  const unsigned char* b_src = reinterpret_cast<const unsigned char*>(P.Bp) + ((int64_t)n0 + 48 * wave + (lane >> 2)) * (BK * 2) +
+                               (((lane & 3) ^ ((lane >> 4) & 3)) * 16);
+  // DMA transfer g (0 .. 10) of stage s into `slot`: 0, 1 = the A rows, 2 .. 10 = W piece (g-2)/3, block (g-2)%3
+  auto dma = [&](int g, int s, unsigned char* slot) __attribute__((always_inline)) {
+    if (g < 2) {
+      glds16(a_src[g] + (int64_t)s * (BK * 4), slot + wave * 2048 + g * 1024);
+    } else {
+      const int i = g - 2;
+      glds16(b_src + s * stage_stride + (i / 3) * piece_stride + (i % 3) * 1024,
+             slot + RG_A + (i / 3) * RG_BP + wave * 3072 + (i % 3) * 1024);
+    }
+  };
+
+  // ---- fragment addresses (byte offsets inside a slot) ---------------------------------------------------------
+  int a_off[2][2], b_off[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int c0 = ks * 4 + kh * 2, sw = (li >> 1) & 7;
+    a_off[ks][0] = (wm * 32 + li) * 128 + ((c0 ^ sw) * 16);
+    a_off[ks][1] = (wm * 32 + li) * 128 + (((c0 + 1) ^ sw) * 16);
+    b_off[ks] = RG_A + (wn * 96 + li) * 64 + (((ks * 2 + kh) ^ ((li >> 2) & 3)) * 16);
+  }
+
+  f32x16 acc[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) acc[j][q] = 0.0f;
+
+  // exact 3-way split of one pair of fp32 values into bf16 pairs, in three instalments (4 + 4 + 3 VALU) so that it can
+  // be dealt out over MFMA issue gaps; v_perm_b32 packs the two high halves
+  float sv0, sv1, sr0, sr1;     // state carried between the instalments of a pair
+  auto split_part = [&](int part, const f32x4 (&raw)[2], int d, RingA& out) __attribute__((always_inline)) {
+    if (part == 0) {
+      sv0 = raw[d >> 1][(d & 1) * 2];
+      sv1 = raw[d >> 1][(d & 1) * 2 + 1];
+      sr0 = sv0 - __uint_as_float(__float_as_uint(sv0) & 0xFFFF0000u);
+      sr1 = sv1 - __uint_as_float(__float_as_uint(sv1) & 0xFFFF0000u);
+    } else if (part == 1) {
+      out.p[0][d] = __builtin_amdgcn_perm(__float_as_uint(sv1), __float_as_uint(sv0), 0x07060302u);
+      out.p[1][d] = __builtin_amdgcn_perm(__float_as_uint(sr1), __float_as_uint(sr0), 0x07060302u);
+      sv0 = sr0 - __uint_as_float(__float_as_uint(sr0) & 0xFFFF0000u);
+      sv1 = sr1 - __uint_as_float(__float_as_uint(sr1) & 0xFFFF0000u);
+    } else {
+      out.p[2][d] = __builtin_amdgcn_perm(__float_as_uint(sv1), __float_as_uint(sv0), 0x07060302u);
+    }
+  };
+
+  constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};   // smallest terms first
+
+  // One region = the 18 MFMAs of k-step u (operands `ac`, `fc`, already in registers), with the staging of k-step u+1
+  // dealt into their issue gaps (at one wavefront per SIMD the matrix pipe takes an MFMA every 32 cycles, which hides
+  // ~5 other instructions; a burst of loads or VALU between two MFMAs is idle pipe time):
+  //   gaps 0 .. 3  the two raw-A reads and the nine W-fragment reads of step u+1 (all of them early: the compiler
+  //                waits lgkmcnt(0) at the first use of a raw value, so every read should have landed by gap 6)
+  //   gaps 0 .. 5  up to six DMA transfers (dma_first .. dma_first + dma_count - 1 of stage dma_stage)
+  //   gaps 6 .. 17 the split of the raw A values (4 pairs x 3 instalments), which have had 6 MFMAs to arrive
+  // sched_barrier(0) after every gap pins this order.
+  f32x4 raw[2];
+  auto region = [&](const RingA& ac, const RingFrag& fc, RingA& an, RingFrag& fn, const unsigned char* rd_slot, int rd_ks,
+                    int dma_stage, unsigned char* dma_slot, int dma_first, int dma_count) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < 18; ++i) {
+      acc[i % 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ac.p[TA[i / 3]]), fc.b[i % 3][TB[i / 3]],
+                                                          acc[i % 3], 0, 0, 0);
+      if (i == 0) {
+        raw[0] = *reinterpret_cast<const f32x4*>(rd_slot + a_off[rd_ks][0]);
+        raw[1] = *reinterpret_cast<const f32x4*>(rd_slot + a_off[rd_ks][1]);
+      }
+      if (i < 4) {
+        constexpr int first[5] = {0, 1, 4, 7, 9};        // W-fragment reads per gap: 1, 3, 3, 2
+#pragma unroll
+        for (int k = first[i]; k < first[i + 1]; ++k)
+          fn.b[k / 3][k % 3] = *reinterpret_cast<const bf16x8*>(rd_slot + b_off[rd_ks] + (k / 3) * (32 * 64) + (k % 3) * RG_BP);
+      }
+      if (i < dma_count) dma(dma_first + i, dma_stage, dma_slot);
+      if (i >= 6) split_part((i - 6) % 3, raw, (i - 6) / 3, an);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  unsigned char* const slot0 = ring;
+  unsigned char* const slot1 = ring + RG_SLOT;
+  unsigned char* const slot2 = ring + 2 * RG_SLOT;
+  // prologue: stages 0 and 1 whole, the first five transfers of stage 2 (KS >= 3: host check)
+#pragma unroll
+  for (int g = 0; g < 11; ++g) dma(g, 0, slot0);
+#pragma unroll
+  for (int g = 0; g < 11; ++g) dma(g, 1, slot1);
+#pragma unroll
+  for (int g = 0; g < 5; ++g) dma(g, 2, slot2);
+  __builtin_amdgcn_s_waitcnt(0x4F70);                     // vmcnt(16): this wave's share of stage 0 has landed
+  __builtin_amdgcn_s_barrier();                           // ... and every other wave's
+  RingFrag f0, f1;
+  RingA a0, a1;
+  raw[0] = *reinterpret_cast<const f32x4*>(slot0 + a_off[0][0]);
+  raw[1] = *reinterpret_cast<const f32x4*>(slot0 + a_off[0][1]);
+#pragma unroll
+  for (int j = 0; j < 3; ++j)
+#pragma unroll
+    for (int p = 0; p < 3; ++p)
+      f0.b[j][p] = *reinterpret_cast<const bf16x8*>(slot0 + b_off[0] + j * (32 * 64) + p * RG_BP);
+#pragma unroll
+  for (int d = 0; d < 4; ++d)
+#pragma unroll
+    for (int part = 0; part < 3; ++part) split_part(part, raw, d, a0);
+  __builtin_amdgcn_sched_barrier(0);
+
+  // Stage s (slot CUR) = regions 2s and 2s+1.  Region 2s multiplies k-step 2s while k-step 2s+1 is fetched from CUR and
+  // the last six transfers of stage s+2 are issued; then the stage barrier: the counted wait retires this wave's share
+  // of stage s+1 (the 11 transfers of stage s+2 stay in flight across it), lgkmcnt(0) retires its reads of CUR, so
+  // after the barrier CUR may be refilled.  Region 2s+1 multiplies k-step 2s+1, fetches k-step 2s+2 from NXT and
+  // issues the first five transfers of stage s+3 into CUR.  Past the last stage the DMA re-fetches stage KS-1 into the
+  // free slot, which keeps the counted wait uniform.
+#define GPS_RING_STAGE(S, CUR, NXT, NX2)                                                       \
+  region(a0, f0, a1, f1, CUR, 1, min((S) + 2, KS - 1), NX2, 5, 6);                             \
+  __builtin_amdgcn_s_waitcnt(0x007B); /* vmcnt(11) lgkmcnt(0); the builtin, so that the compiler's own counter bookkeeping sees it */ \
+  __builtin_amdgcn_s_barrier();                                                                \
+  __builtin_amdgcn_sched_barrier(0);                                                           \
+  region(a1, f1, a0, f0, NXT, 0, min((S) + 3, KS - 1), CUR, 0, 5);
+  for (int s0 = 0; s0 < KS; s0 += 3) {                    // KS is a multiple of 3 (host check): slots are static
+    GPS_RING_STAGE(s0, slot0, slot1, slot2)
+    GPS_RING_STAGE(s0 + 1, slot1, slot2, slot0)
+    GPS_RING_STAGE(s0 + 2, slot2, slot0, slot1)
+  }
+#undef GPS_RING_STAGE
+  __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0): no DMA may still be writing this workgroup's LDS when it retires
+  panel_epilogue<EPI, HAS_CIN>(P, acc, m0, n0, wm, wn, li, kh);
 }
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) % 16) == 0; }
@@ -349,9 +555,25 @@ int gps_gemm_panel(const float* A, int64_t lda, int64_t M, int K, const uint16_t
   P.row_tiles = (int)((M + TM - 1) / TM);
   const unsigned grid = (unsigned)(P.row_tiles * (N / TN));
   hipStream_t s = gps::as_stream(stream);
-  if (epilogue == 0) { if (Cin) k_gemm_panel<0, true><<<grid, NTHREADS, 0, s>>>(P); else k_gemm_panel<0, false><<<grid, NTHREADS, 0, s>>>(P); }
-  else if (epilogue == 1) { if (Cin) k_gemm_panel<1, true><<<grid, NTHREADS, 0, s>>>(P); else k_gemm_panel<1, false><<<grid, NTHREADS, 0, s>>>(P); }
-  else { if (Cin) k_gemm_panel<2, true><<<grid, NTHREADS, 0, s>>>(P); else k_gemm_panel<2, false><<<grid, NTHREADS, 0, s>>>(P); }
+  // ring kernel (LDS-DMA, three-slot ring) whenever the k-stages come in threes; GPS_GEMM_RING=0 keeps the
+  // register-staged kernel (A/B measurements)
+  static const bool use_ring = []() { const char* v = getenv("GPS_GEMM_RING"); return !(v && v[0] == '0'); }();
+  const bool ring = use_ring && (K / BK) % RG_SLOTS == 0 && K / BK >= RG_SLOTS;
+#define GPS_PANEL_LAUNCH(E, C)                                                                        \
+  do {                                                                                                \
+    if (ring) {                                                                                       \
+      static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring<E, C>),    \
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, RG_LDS);  \
+      GPS_REQUIRE(attr == hipSuccess, "gps_gemm_panel: cannot reserve %d bytes of LDS", RG_LDS);              \
+      k_gemm_ring<E, C><<<grid, NTHREADS, RG_LDS, s>>>(P);                                            \
+    } else {                                                                                          \
+      k_gemm_panel<E, C><<<grid, NTHREADS, 0, s>>>(P);                                                \
+    }                                                                                                 \
+  } while (0)
+  if (epilogue == 0) { if (Cin) GPS_PANEL_LAUNCH(0, true); else GPS_PANEL_LAUNCH(0, false); }
+  else if (epilogue == 1) { if (Cin) GPS_PANEL_LAUNCH(1, true); else GPS_PANEL_LAUNCH(1, false); }
+  else { if (Cin) GPS_PANEL_LAUNCH(2, true); else GPS_PANEL_LAUNCH(2, false); }
+#undef GPS_PANEL_LAUNCH
   return gps::launch_status("gps_gemm_panel");
 }
 

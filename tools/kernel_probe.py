@@ -18,3 +18,16 @@ if __name__ == "__main__":
     torch.cuda.set_device(0)
     res, shape = bench.kernel_rooflines(dev, sys.argv[1] if len(sys.argv) > 1 else "P30", 256)
     print(shape, {k: round(v["ms"] * 1e3, 2) for k, v in res.items()})
+    if os.environ.get("GPS_PROBE_GEMM", "1") != "0":
+        # the panel GEMM at two of the block's shapes: k_gemm_panel<0, false> = x[N,d] W[7d,d] (14 column panels),
+        # k_gemm_panel<0, true> = t[N,2d] W[d,2d] + residual (2 column panels)
+        from graphgps_amd.gemm import gemm_panel, split_weights
+        Nn, d = 7569, 384
+        for K, N, cin in ((d, 7 * d, False), (2 * d, d, True)):
+            a = torch.randn(Nn, K, device=dev)
+            w = torch.randn(N, K, device=dev) / K ** 0.5
+            (img, _), = split_weights([w], tn=False)
+            c = torch.zeros(Nn, N, device=dev)
+            for _ in range(20):
+                gemm_panel(a, img, N, bias=None, addend=c if cin else None, out=c)
+        torch.cuda.synchronize()
