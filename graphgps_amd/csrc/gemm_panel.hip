@@ -171,6 +171,7 @@ struct PanelArgs {
   uint64_t seed;
   const uint64_t* salt;
   int row_tiles;
+  unsigned long long* trace;   // debugging aid (gps_gemm_panel_trace): 4 shader-clock stamps per workgroup, or nullptr
 };
 
 // Epilogue shared by both kernels.  D[row = (q&3) + 8*(q>>2) + 4*kh][col = li] of each 32 x 32 block; 32 lanes = 128
@@ -333,11 +334,13 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm_panel(const PanelArgs P) {
 //     a stage, so every fragment read has 18 MFMAs (576 cycles) of cover and no MFMA waits on LDS latency.
 // One workgroup per CU (132 KB of LDS), one wavefront per SIMD.
 // ------------------------------------------------------------------------------------------------------------
-constexpr int RG_A = TM * BK * 4;              // raw fp32 A stage: 8 KB
 constexpr int RG_BP = TN * BK * 2;             // one bf16 piece of the W stage: 12 KB
-constexpr int RG_SLOT = RG_A + 3 * RG_BP;      // 44 KB
 constexpr int RG_SLOTS = 3;
-constexpr int RG_LDS = RG_SLOTS * RG_SLOT;     // 132 KB
+constexpr int rg_a_bytes(int mb) { return 64 * mb * BK * 4; }                  // raw fp32 A stage: 8 KB per 64 rows
+constexpr int rg_slot_bytes(int mb) { return rg_a_bytes(mb) + 3 * RG_BP; }     // 44 KB (64 rows) / 52 KB (128 rows)
+constexpr int rg_lds_bytes(int mb) { return RG_SLOTS * rg_slot_bytes(mb); }    // 132 KB / 156 KB
+// s_waitcnt immediate (gfx9 layout): vmcnt in bits 3:0 and 15:14, expcnt (left open) in 6:4, lgkmcnt in 11:8
+constexpr int waitcnt_imm(int vm, int lgkm) { return (vm & 15) | (7 << 4) | ((lgkm & 15) << 8) | ((vm >> 4) << 14); }
 
 typedef __attribute__((address_space(3))) void* lds_void_ptr;
 typedef const __attribute__((address_space(1))) void* gbl_void_ptr;
@@ -349,14 +352,74 @@ struct RingFrag {
   bf16x8 b[3][3];      // W fragments of one 16-wide k-step: [column block][piece]
 };
 struct RingA {
-  u32x4 p[3];          // the A fragment of one k-step as bf16 pairs: hi, mid, lo
+  u32x4 p[3];          // the A fragment of one row block and k-step as bf16 pairs: hi, mid, lo
 };
 
-template <int EPI, bool HAS_CIN>
+constexpr int kZeroBias = 8192;
+__device__ float g_zero_bias[kZeroBias];      // stands in for a null bias, so that the epilogue's bias load is unconditional
+
+// Epilogue of the ring kernel: MB row blocks of 32 per wave.  D[row = (q&3) + 8*(q>>2) + 4*kh][col = li] of each
+// 32 x 32 block; 32 lanes = 128 contiguous bytes per row.  FULL (every row of the panel exists: all but the last row
+// tile) is straight-line code: a store under a per-row branch made the compiler wait vmcnt(0) -- i.e. for every
+// earlier STORE to retire -- before each of the 48 / 96 stores of a lane (measured: 10k / 23k cycles per workgroup,
+// a third of its lifetime).
+template <int MB, int EPI, bool HAS_CIN, bool FULL>
+__device__ __forceinline__ void ring_store(const PanelArgs& P, const f32x16 (&acc)[MB][3], int64_t m0, int n0, int wm,
+                                           int wn, int li, int kh) {
+  const uint64_t seed = gps::salted_seed(P.seed, P.salt);
+  const bool drop = EPI != 0 && P.p_drop > 0.0f;
+  const float inv_keep = drop ? 1.0f / (1.0f - P.p_drop) : 1.0f;
+  float bv[3];
+#pragma unroll
+  for (int j = 0; j < 3; ++j) bv[j] = P.bias[n0 + wn * 96 + j * 32 + li];     // never null here: the host passes g_zero_bias
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int col = n0 + wn * 96 + j * 32 + li;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int64_t row = m0 + (wm * MB + mb) * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh;
+        const int64_t rc = FULL ? row : (row < P.M ? row : P.M - 1);   // clamped: loads unconditional, the store predicated
+        float v = acc[mb][j][q] + bv[j];
+        if (HAS_CIN) v += __builtin_nontemporal_load(P.Cin + rc * P.ldcin + col);
+        if (EPI == 1) v = fmaxf(v, 0.0f);
+        if (EPI == 2) v = P.mask_src[rc * P.ldmask + col] > 0.0f ? v : 0.0f;
+        if (EPI != 0) {
+          const bool keep = !drop || keep_elem(row_hash((uint32_t)rc, seed), (uint32_t)col, P.p_drop);
+          v = keep ? v * inv_keep : 0.0f;
+        }
+        if (FULL || row < P.M) __builtin_nontemporal_store(v, P.C + row * P.ldc + col);
+      }
+    }
+}
+template <int MB, int EPI, bool HAS_CIN>
+__device__ __forceinline__ void ring_epilogue(const PanelArgs& P, const f32x16 (&acc)[MB][3], int64_t m0, int n0, int wm,
+                                              int wn, int li, int kh) {
+  if (m0 + 64 * MB <= P.M) ring_store<MB, EPI, HAS_CIN, true>(P, acc, m0, n0, wm, wn, li, kh);      // workgroup-uniform
+  else ring_store<MB, EPI, HAS_CIN, false>(P, acc, m0, n0, wm, wn, li, kh);
+}
+
+// MB = row blocks of 32 per wave: the workgroup's panel is (64 * MB) rows x 192 columns, 2 x 2 waves of (32 * MB) x 96.
+// MB = 2 halves the W bytes (and the LDS fragment reads) per MFMA: measured with MB = 1 a long-K panel runs at ~2350
+// cycles per stage against 1152 of MFMA issue, i.e. at ~19 bytes / cycle / CU through the global -> LDS path, the same
+// per-CU rate the 256 x 256 bf16 reference kernels sustain -- the load path, not the matrix pipe, was the bound.
+template <int MB, int EPI, bool HAS_CIN>
 __global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring(const PanelArgs P) {
+  constexpr int TMV = 64 * MB;                  // panel rows
+  constexpr int A_BYTES = rg_a_bytes(MB), SLOT = rg_slot_bytes(MB);
+  constexpr int NA = 2 * MB;                    // A transfers per wave and stage (8 rows x 128 B each)
+  constexpr int ND = NA + 9;                    // DMA transfers per wave and stage
+  constexpr int ND_ODD = ND / 2, ND_EVEN = ND - ND_ODD;   // dealt over the two regions of a stage
+  constexpr int G = 18 * MB;                    // MFMAs (= issue gaps) per region
+  constexpr int SPLIT0 = G - 12 * MB - (MB > 1 ? 2 : 0);  // first gap of the A split (4 * MB pairs x 3 instalments)
   extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];
+  auto stamp = [&](int k) __attribute__((always_inline)) {
+    if (P.trace && threadIdx.x == 0) P.trace[4 * (size_t)blockIdx.x + k] = __builtin_amdgcn_s_memtime();
+  };
+  stamp(0);
   const int panel = blockIdx.x / P.row_tiles, rt = blockIdx.x - panel * P.row_tiles;   // panel-major numbering
-  const int64_t m0 = (int64_t)rt * TM;
+  const int64_t m0 = (int64_t)rt * TMV;
   const int n0 = panel * TN;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
@@ -365,12 +428,12 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring(const PanelArgs P) {
   const int KS = P.K / BK;
 
   // ---- DMA sources -------------------------------------------------------------------------------------------
-  // A: wave w fills rows 16w .. 16w+15 of the stage, two instructions of 8 rows x 128 B; lane -> (row, LDS chunk
-  // position lane & 7), which fetches source chunk pos ^ ((row >> 1) & 7).  Rows past M re-read row M-1 (never stored).
-  const unsigned char* a_src[2];
+  // A: wave w fills rows 16 MB w .. of the stage, NA instructions of 8 rows x 128 B; lane -> (row, LDS chunk position
+  // lane & 7), which fetches source chunk pos ^ ((row >> 1) & 7).  Rows past M re-read row M-1 (never stored).
+  const unsigned char* a_src[NA];
 #pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int row = 16 * wave + 8 * i + (lane >> 3);
+  for (int i = 0; i < NA; ++i) {
+    const int row = 8 * NA * wave + 8 * i + (lane >> 3);
     const int c = (lane & 7) ^ ((row >> 1) & 7);
     const int64_t grow = min(m0 + row, P.M - 1);
     a_src[i] = reinterpret_cast<const unsigned char*>(P.A + grow * P.lda) + c * 16;
@@ -381,32 +444,34 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring(const PanelArgs P) {
   const int64_t piece_stride = stage_stride * KS;
   const unsigned char* b_src = reinterpret_cast<const unsigned char*>(P.Bp) + ((int64_t)n0 + 48 * wave + (lane >> 2)) * (BK * 2) +
                                (((lane & 3) ^ ((lane >> 4) & 3)) * 16);
-  // DMA transfer g (0 .. 10) of stage s into `slot`: 0, 1 = the A rows, 2 .. 10 = W piece (g-2)/3, block (g-2)%3
+  // DMA transfer g (0 .. ND-1) of stage s into `slot`: the first NA = A rows, then W piece i / 3, block i % 3
   auto dma = [&](int g, int s, unsigned char* slot) __attribute__((always_inline)) {
-    if (g < 2) {
-      glds16(a_src[g] + (int64_t)s * (BK * 4), slot + wave * 2048 + g * 1024);
+    if (g < NA) {
+      glds16(a_src[g] + (int64_t)s * (BK * 4), slot + wave * (NA * 1024) + g * 1024);
     } else {
-      const int i = g - 2;
+      const int i = g - NA;
       glds16(b_src + s * stage_stride + (i / 3) * piece_stride + (i % 3) * 1024,
-             slot + RG_A + (i / 3) * RG_BP + wave * 3072 + (i % 3) * 1024);
+             slot + A_BYTES + (i / 3) * RG_BP + wave * 3072 + (i % 3) * 1024);
     }
   };
 
   // ---- fragment addresses (byte offsets inside a slot) ---------------------------------------------------------
-  int a_off[2][2], b_off[2];
+  int a_off[2][2], b_off[2];      // A: row block 0 (block mb is 32 rows = 4096 bytes further)
 #pragma unroll
   for (int ks = 0; ks < 2; ++ks) {
     const int c0 = ks * 4 + kh * 2, sw = (li >> 1) & 7;
-    a_off[ks][0] = (wm * 32 + li) * 128 + ((c0 ^ sw) * 16);
-    a_off[ks][1] = (wm * 32 + li) * 128 + (((c0 + 1) ^ sw) * 16);
-    b_off[ks] = RG_A + (wn * 96 + li) * 64 + (((ks * 2 + kh) ^ ((li >> 2) & 3)) * 16);
+    a_off[ks][0] = (wm * 32 * MB + li) * 128 + ((c0 ^ sw) * 16);
+    a_off[ks][1] = (wm * 32 * MB + li) * 128 + (((c0 + 1) ^ sw) * 16);
+    b_off[ks] = A_BYTES + (wn * 96 + li) * 64 + (((ks * 2 + kh) ^ ((li >> 2) & 3)) * 16);
   }
 
-  f32x16 acc[3];
+  f32x16 acc[MB][3];
 #pragma unroll
-  for (int j = 0; j < 3; ++j)
+  for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) acc[j][q] = 0.0f;
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[mb][j][q] = 0.0f;
 
   // exact 3-way split of one pair of fp32 values into bf16 pairs, in three instalments (4 + 4 + 3 VALU) so that it can
   // be dealt out over MFMA issue gaps; v_perm_b32 packs the two high halves
@@ -429,24 +494,29 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring(const PanelArgs P) {
 
   constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};   // smallest terms first
 
-  // One region = the 18 MFMAs of k-step u (operands `ac`, `fc`, already in registers), with the staging of k-step u+1
-  // dealt into their issue gaps (at one wavefront per SIMD the matrix pipe takes an MFMA every 32 cycles, which hides
-  // ~5 other instructions; a burst of loads or VALU between two MFMAs is idle pipe time):
-  //   gaps 0 .. 3  the two raw-A reads and the nine W-fragment reads of step u+1 (all of them early: the compiler
-  //                waits lgkmcnt(0) at the first use of a raw value, so every read should have landed by gap 6)
-  //   gaps 0 .. 5  up to six DMA transfers (dma_first .. dma_first + dma_count - 1 of stage dma_stage)
-  //   gaps 6 .. 17 the split of the raw A values (4 pairs x 3 instalments), which have had 6 MFMAs to arrive
-  // sched_barrier(0) after every gap pins this order.
-  f32x4 raw[2];
-  auto region = [&](const RingA& ac, const RingFrag& fc, RingA& an, RingFrag& fn, const unsigned char* rd_slot, int rd_ks,
-                    int dma_stage, unsigned char* dma_slot, int dma_first, int dma_count) __attribute__((always_inline)) {
+  // One region = the G = 18 MB MFMAs of k-step u (operands `ac`, `fc`, already in registers), with the staging of
+  // k-step u+1 dealt into their issue gaps (at one wavefront per SIMD the matrix pipe takes an MFMA every 32 cycles,
+  // which hides ~5 other instructions; a burst of loads or VALU between two MFMAs is idle pipe time):
+  //   gaps 0 .. 3        the raw-A reads and the nine W-fragment reads of step u+1 (all of them early: the compiler waits
+  //                      lgkmcnt(0) at the first use of a raw value, so every read should have landed by then)
+  //   gaps 0 .. 6        up to seven DMA transfers (dma_first .. dma_first + dma_count - 1 of stage dma_stage)
+  //   gaps SPLIT0 ..     the split of the raw A values (4 MB pairs x 3 instalments)
+  // sched_barrier(0) after every gap pins this order.  The 3 MB accumulators rotate, so no MFMA waits on its predecessor.
+  f32x4 raw[MB][2];
+  auto region = [&](const RingA (&ac)[MB], const RingFrag& fc, RingA (&an)[MB], RingFrag& fn, const unsigned char* rd_slot,
+                    int rd_ks, int dma_stage, unsigned char* dma_slot, int dma_first, int dma_count)
+                    __attribute__((always_inline)) {
 #pragma unroll
-    for (int i = 0; i < 18; ++i) {
-      acc[i % 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ac.p[TA[i / 3]]), fc.b[i % 3][TB[i / 3]],
-                                                          acc[i % 3], 0, 0, 0);
+    for (int i = 0; i < G; ++i) {
+      const int term = i / (3 * MB), mb = (i / 3) % MB, j = i % 3;
+      acc[mb][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ac[mb].p[TA[term]]), fc.b[j][TB[term]],
+                                                          acc[mb][j], 0, 0, 0);
       if (i == 0) {
-        raw[0] = *reinterpret_cast<const f32x4*>(rd_slot + a_off[rd_ks][0]);
-        raw[1] = *reinterpret_cast<const f32x4*>(rd_slot + a_off[rd_ks][1]);
+#pragma unroll
+        for (int b = 0; b < MB; ++b) {
+          raw[b][0] = *reinterpret_cast<const f32x4*>(rd_slot + a_off[rd_ks][0] + b * 4096);
+          raw[b][1] = *reinterpret_cast<const f32x4*>(rd_slot + a_off[rd_ks][1] + b * 4096);
+        }
       }
       if (i < 4) {
         constexpr int first[5] = {0, 1, 4, 7, 9};        // W-fragment reads per gap: 1, 3, 3, 2
@@ -455,65 +525,85 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring(const PanelArgs P) {
           fn.b[k / 3][k % 3] = *reinterpret_cast<const bf16x8*>(rd_slot + b_off[rd_ks] + (k / 3) * (32 * 64) + (k % 3) * RG_BP);
       }
       if (i < dma_count) dma(dma_first + i, dma_stage, dma_slot);
-      if (i >= 6) split_part((i - 6) % 3, raw, (i - 6) / 3, an);
+      if (i >= SPLIT0 && i < SPLIT0 + 12 * MB) {
+        const int q = i - SPLIT0;                        // pair q / 3 (row block (q / 3) / 4, dword (q / 3) % 4), instalment q % 3
+        split_part(q % 3, raw[(q / 3) / 4], (q / 3) % 4, an[(q / 3) / 4]);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
   };
 
   unsigned char* const slot0 = ring;
-  unsigned char* const slot1 = ring + RG_SLOT;
-  unsigned char* const slot2 = ring + 2 * RG_SLOT;
-  // prologue: stages 0 and 1 whole, the first five transfers of stage 2 (KS >= 3: host check)
+  unsigned char* const slot1 = ring + SLOT;
+  unsigned char* const slot2 = ring + 2 * SLOT;
+  // prologue: stages 0 and 1 whole, the first ND_ODD transfers of stage 2 (KS >= 3: host check)
 #pragma unroll
-  for (int g = 0; g < 11; ++g) dma(g, 0, slot0);
+  for (int g = 0; g < ND; ++g) dma(g, 0, slot0);
 #pragma unroll
-  for (int g = 0; g < 11; ++g) dma(g, 1, slot1);
+  for (int g = 0; g < ND; ++g) dma(g, 1, slot1);
 #pragma unroll
-  for (int g = 0; g < 5; ++g) dma(g, 2, slot2);
-  __builtin_amdgcn_s_waitcnt(0x4F70);                     // vmcnt(16): this wave's share of stage 0 has landed
-  __builtin_amdgcn_s_barrier();                           // ... and every other wave's
+  for (int g = 0; g < ND_ODD; ++g) dma(g, 2, slot2);
+  __builtin_amdgcn_s_waitcnt(waitcnt_imm(ND + ND_ODD, 15));   // this wave's share of stage 0 has landed
+  __builtin_amdgcn_s_barrier();                               // ... and every other wave's
+  stamp(1);
   RingFrag f0, f1;
-  RingA a0, a1;
-  raw[0] = *reinterpret_cast<const f32x4*>(slot0 + a_off[0][0]);
-  raw[1] = *reinterpret_cast<const f32x4*>(slot0 + a_off[0][1]);
+  RingA a0[MB], a1[MB];
+#pragma unroll
+  for (int b = 0; b < MB; ++b) {
+    raw[b][0] = *reinterpret_cast<const f32x4*>(slot0 + a_off[0][0] + b * 4096);
+    raw[b][1] = *reinterpret_cast<const f32x4*>(slot0 + a_off[0][1] + b * 4096);
+  }
 #pragma unroll
   for (int j = 0; j < 3; ++j)
 #pragma unroll
     for (int p = 0; p < 3; ++p)
       f0.b[j][p] = *reinterpret_cast<const bf16x8*>(slot0 + b_off[0] + j * (32 * 64) + p * RG_BP);
 #pragma unroll
-  for (int d = 0; d < 4; ++d)
+  for (int b = 0; b < MB; ++b)
 #pragma unroll
-    for (int part = 0; part < 3; ++part) split_part(part, raw, d, a0);
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int part = 0; part < 3; ++part) split_part(part, raw[b], d, a0[b]);
   __builtin_amdgcn_sched_barrier(0);
 
   // Stage s (slot CUR) = regions 2s and 2s+1.  Region 2s multiplies k-step 2s while k-step 2s+1 is fetched from CUR and
-  // the last six transfers of stage s+2 are issued; then the stage barrier: the counted wait retires this wave's share
-  // of stage s+1 (the 11 transfers of stage s+2 stay in flight across it), lgkmcnt(0) retires its reads of CUR, so
-  // after the barrier CUR may be refilled.  Region 2s+1 multiplies k-step 2s+1, fetches k-step 2s+2 from NXT and
-  // issues the first five transfers of stage s+3 into CUR.  Past the last stage the DMA re-fetches stage KS-1 into the
-  // free slot, which keeps the counted wait uniform.
+  // the last ND_EVEN transfers of stage s+2 are issued; then the stage barrier: the counted wait retires this wave's
+  // share of stage s+1 (the ND transfers of stage s+2 stay in flight across it), lgkmcnt(0) retires its reads of CUR,
+  // so after the barrier CUR may be refilled.  Region 2s+1 multiplies k-step 2s+1, fetches k-step 2s+2 from NXT and
+  // issues the first ND_ODD transfers of stage s+3 into CUR.  Past the last stage the DMA re-fetches stage KS-1 into the
+  // free slot, which keeps the counted wait uniform.  (The wait is the builtin, not inline asm, so that the compiler's
+  // own counter bookkeeping sees it.)
 #define GPS_RING_STAGE(S, CUR, NXT, NX2)                                                       \
-  region(a0, f0, a1, f1, CUR, 1, min((S) + 2, KS - 1), NX2, 5, 6);                             \
-  __builtin_amdgcn_s_waitcnt(0x007B); /* vmcnt(11) lgkmcnt(0); the builtin, so that the compiler's own counter bookkeeping sees it */ \
+  region(a0, f0, a1, f1, CUR, 1, min((S) + 2, KS - 1), NX2, ND_ODD, ND_EVEN);                  \
+  __builtin_amdgcn_s_waitcnt(waitcnt_imm(ND, 0));                                              \
   __builtin_amdgcn_s_barrier();                                                                \
   __builtin_amdgcn_sched_barrier(0);                                                           \
-  region(a1, f1, a0, f0, NXT, 0, min((S) + 3, KS - 1), CUR, 0, 5);
+  region(a1, f1, a0, f0, NXT, 0, min((S) + 3, KS - 1), CUR, 0, ND_ODD);
   for (int s0 = 0; s0 < KS; s0 += 3) {                    // KS is a multiple of 3 (host check): slots are static
     GPS_RING_STAGE(s0, slot0, slot1, slot2)
     GPS_RING_STAGE(s0 + 1, slot1, slot2, slot0)
     GPS_RING_STAGE(s0 + 2, slot2, slot0, slot1)
   }
 #undef GPS_RING_STAGE
-  __builtin_amdgcn_s_waitcnt(0x0F70);                     // vmcnt(0): no DMA may still be writing this workgroup's LDS when it retires
-  panel_epilogue<EPI, HAS_CIN>(P, acc, m0, n0, wm, wn, li, kh);
+  __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 15));         // no DMA may still be writing this workgroup's LDS when it retires
+  stamp(2);
+  ring_epilogue<MB, EPI, HAS_CIN>(P, acc, m0, n0, wm, wn, li, kh);
+  __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 15));
+  stamp(3);
 }
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) % 16) == 0; }
 
 }  // namespace
 
+unsigned long long* g_panel_trace = nullptr;
+
 extern "C" {
+
+// Debugging aid, not part of the drop-in surface: subsequent gps_gemm_panel launches of the ring kernel record
+// s_memtime at entry / first stage landed / loop done / stores done, 4 x uint64 per workgroup, into `buf` (device
+// memory, >= 4 * grid entries); nullptr switches it off.
+int gps_gemm_panel_trace(unsigned long long* buf) { g_panel_trace = buf; return GPS_OK; }
 
 size_t gps_gemm_image_elems(int64_t N, int64_t K) { return (size_t)(3 * N * K); }
 
@@ -553,26 +643,44 @@ int gps_gemm_panel(const float* A, int64_t lda, int64_t M, int K, const uint16_t
   P.C = C; P.ldc = ldc; P.epilogue = epilogue; P.mask_src = mask_src; P.ldmask = ldmask;
   P.p_drop = epilogue ? p_drop : 0.0f; P.seed = seed; P.salt = gps::dropout_salt();
   P.row_tiles = (int)((M + TM - 1) / TM);
-  const unsigned grid = (unsigned)(P.row_tiles * (N / TN));
+  P.trace = g_panel_trace;
+  unsigned grid = (unsigned)(P.row_tiles * (N / TN));
   hipStream_t s = gps::as_stream(stream);
   // ring kernel (LDS-DMA, three-slot ring) whenever the k-stages come in threes; GPS_GEMM_RING=0 keeps the
-  // register-staged kernel (A/B measurements)
-  static const bool use_ring = []() { const char* v = getenv("GPS_GEMM_RING"); return !(v && v[0] == '0'); }();
-  const bool ring = use_ring && (K / BK) % RG_SLOTS == 0 && K / BK >= RG_SLOTS;
+  // register-staged kernel (A/B measurements).  128-row panels when they still give every CU a workgroup
+  // (GPS_GEMM_RING_MB = 1 / 2 forces one).
+  static const int ring_cfg = []() { const char* v = getenv("GPS_GEMM_RING"); return v && *v ? atoi(v) : 1; }();
+  static const int mb_cfg = []() { const char* v = getenv("GPS_GEMM_RING_MB"); return v && *v ? atoi(v) : 0; }();
+  const bool ring = ring_cfg != 0 && (K / BK) % RG_SLOTS == 0 && K / BK >= RG_SLOTS;
+  const int64_t tiles128 = ((M + 127) / 128) * (N / TN);
+  const int mb = mb_cfg == 1 || mb_cfg == 2 ? mb_cfg : (tiles128 >= 200 ? 2 : 1);
+  if (ring) {
+    if (!P.bias) {
+      GPS_REQUIRE(N <= kZeroBias, "gps_gemm_panel: N=%d without a bias exceeds the built-in zero row (%d)", N, kZeroBias);
+      static float* zeros = []() { void* p = nullptr; return hipGetSymbolAddress(&p, HIP_SYMBOL(g_zero_bias)) == hipSuccess ? (float*)p : nullptr; }();
+      GPS_REQUIRE(zeros, "gps_gemm_panel: zero-bias symbol");
+      P.bias = zeros;
+    }
+    P.row_tiles = (int)((M + 64 * mb - 1) / (64 * mb));
+    grid = (unsigned)(P.row_tiles * (N / TN));
+  }
+#define GPS_RING_LAUNCH(MBV, E, C)                                                                    \
+  do {                                                                                                \
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring<MBV, E, C>), \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, rg_lds_bytes(MBV)); \
+    GPS_REQUIRE(attr == hipSuccess, "gps_gemm_panel: cannot reserve %d bytes of LDS", rg_lds_bytes(MBV));      \
+    k_gemm_ring<MBV, E, C><<<grid, NTHREADS, rg_lds_bytes(MBV), s>>>(P);                              \
+  } while (0)
 #define GPS_PANEL_LAUNCH(E, C)                                                                        \
   do {                                                                                                \
-    if (ring) {                                                                                       \
-      static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring<E, C>),    \
-                                                         hipFuncAttributeMaxDynamicSharedMemorySize, RG_LDS);  \
-      GPS_REQUIRE(attr == hipSuccess, "gps_gemm_panel: cannot reserve %d bytes of LDS", RG_LDS);              \
-      k_gemm_ring<E, C><<<grid, NTHREADS, RG_LDS, s>>>(P);                                            \
-    } else {                                                                                          \
-      k_gemm_panel<E, C><<<grid, NTHREADS, 0, s>>>(P);                                                \
-    }                                                                                                 \
+    if (ring && mb == 2) GPS_RING_LAUNCH(2, E, C);                                                    \
+    else if (ring) GPS_RING_LAUNCH(1, E, C);                                                          \
+    else k_gemm_panel<E, C><<<grid, NTHREADS, 0, s>>>(P);                                             \
   } while (0)
   if (epilogue == 0) { if (Cin) GPS_PANEL_LAUNCH(0, true); else GPS_PANEL_LAUNCH(0, false); }
   else if (epilogue == 1) { if (Cin) GPS_PANEL_LAUNCH(1, true); else GPS_PANEL_LAUNCH(1, false); }
   else { if (Cin) GPS_PANEL_LAUNCH(2, true); else GPS_PANEL_LAUNCH(2, false); }
+#undef GPS_RING_LAUNCH
 #undef GPS_PANEL_LAUNCH
   return gps::launch_status("gps_gemm_panel");
 }

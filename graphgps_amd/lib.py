@@ -90,6 +90,7 @@ _SIGNATURES = {
     "gps_gemm_image_elems": (c_size_t, [c_int64, c_int64]),
     "gps_gemm_panel_supported": (c_int, [c_int64, c_int64]),
     "gps_gemm_split_weights": (c_int, [c_int, _P, _P]),
+    "gps_gemm_panel_trace": (c_int, [_P]),
     "gps_gemm_panel": (c_int, [_P, c_int64, c_int64, c_int, _P, c_int, _P, _P, c_int64, _P, c_int64, c_int, _P,
                                c_int64, c_float, c_uint64, _P]),
     "gps_gcn_dinv": (c_int, [_P, _P, c_int64, c_int64, _P, _P]),

@@ -190,6 +190,10 @@ typedef struct gps_gemm_split {
 size_t gps_gemm_image_elems(int64_t N, int64_t K);
 int gps_gemm_panel_supported(int64_t N, int64_t K);
 int gps_gemm_split_weights(int n, const gps_gemm_split* descs, gps_stream_t stream);   /* n <= 8, one launch */
+/* Debugging aid (tools/gemm_trace.py): the ring kernel stamps s_memtime per workgroup into buf (4 x uint64 each);
+ * NULL switches it off. */
+int gps_gemm_panel_trace(unsigned long long* buf);
+
 int gps_gemm_panel(const float* A, int64_t lda, int64_t M, int K, const uint16_t* image, int N, const float* bias,
                    const float* Cin, int64_t ldcin, float* C, int64_t ldc, int epilogue, const float* mask_src,
                    int64_t ldmask, float p_drop, uint64_t seed, gps_stream_t stream);
