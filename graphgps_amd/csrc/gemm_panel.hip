@@ -372,8 +372,13 @@ __device__ __forceinline__ void ring_store(const PanelArgs& P, const f32x16 (&ac
   float bv[3];
 #pragma unroll
   for (int j = 0; j < 3; ++j) bv[j] = P.bias[n0 + wn * 96 + j * 32 + li];     // never null here: the host passes g_zero_bias
+  // One 32-row block at a time: EVERY addend / mask value of the block is requested before the first store.  The addend
+  // may alias C (in-place accumulation), so the compiler cannot move a load above an earlier store by itself, and one
+  // load -> add -> store round trip per element cost 34-40 us per launch at the block's shapes; a lane only ever
+  // re-reads elements it writes itself, so loading ahead is safe.
 #pragma unroll
-  for (int mb = 0; mb < MB; ++mb)
+  for (int mb = 0; mb < MB; ++mb) {
+    float cin[3][16], msk[3][16];
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
       const int col = n0 + wn * 96 + j * 32 + li;
@@ -381,10 +386,21 @@ __device__ __forceinline__ void ring_store(const PanelArgs& P, const f32x16 (&ac
       for (int q = 0; q < 16; ++q) {
         const int64_t row = m0 + (wm * MB + mb) * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh;
         const int64_t rc = FULL ? row : (row < P.M ? row : P.M - 1);   // clamped: loads unconditional, the store predicated
+        if (HAS_CIN) cin[j][q] = __builtin_nontemporal_load(P.Cin + rc * P.ldcin + col);
+        if (EPI == 2) msk[j][q] = __builtin_nontemporal_load(P.mask_src + rc * P.ldmask + col);
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      const int col = n0 + wn * 96 + j * 32 + li;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int64_t row = m0 + (wm * MB + mb) * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh;
+        const int64_t rc = FULL ? row : (row < P.M ? row : P.M - 1);
         float v = acc[mb][j][q] + bv[j];
-        if (HAS_CIN) v += __builtin_nontemporal_load(P.Cin + rc * P.ldcin + col);
+        if (HAS_CIN) v += cin[j][q];
         if (EPI == 1) v = fmaxf(v, 0.0f);
-        if (EPI == 2) v = P.mask_src[rc * P.ldmask + col] > 0.0f ? v : 0.0f;
+        if (EPI == 2) v = msk[j][q] > 0.0f ? v : 0.0f;
         if (EPI != 0) {
           const bool keep = !drop || keep_elem(row_hash((uint32_t)rc, seed), (uint32_t)col, P.p_drop);
           v = keep ? v * inv_keep : 0.0f;
@@ -392,6 +408,7 @@ __device__ __forceinline__ void ring_store(const PanelArgs& P, const f32x16 (&ac
         if (FULL || row < P.M) __builtin_nontemporal_store(v, P.C + row * P.ldc + col);
       }
     }
+  }
 }
 template <int MB, int EPI, bool HAS_CIN>
 __device__ __forceinline__ void ring_epilogue(const PanelArgs& P, const f32x16 (&acc)[MB][3], int64_t m0, int n0, int wm,

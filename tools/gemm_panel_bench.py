@@ -41,6 +41,22 @@ if __name__ == "__main__":
         print(f"{name:28s} {gf:6.2f} | {tt*1e3:8.1f} {gf/tt/1e3:5.0f} | {tp*1e3:8.1f} {gf/tp/1e3:5.0f} | {tt/tp:5.2f}x",
               flush=True)
     print(f"sum: torch {tot_t*1e3:.1f} us, panel {tot_p*1e3:.1f} us")
+    # the epilogue forms the block uses (panel only): in-place addend, ReLU + dropout, mask of a saved activation
+    for name, M, K, N, kw in (("dgrad C  + addend (in place)", E, d, d, dict(addend=True)),
+                              ("dgrad out + addend", Nn, d, d, dict(addend=True)),
+                              ("ff1 relu + dropout", Nn, d, 2 * d, dict(epilogue=1, p_drop=0.1, seed=7)),
+                              ("dgrad ff2 x mask", Nn, d, 2 * d, dict(epilogue=2, p_drop=0.1, seed=7, mask=True))):
+        nset = max(2, int(bench.ROTATE_BYTES // (4 * (M * K + 2 * M * N))) + 1)
+        A = [torch.randn(M, K, device=dev) for _ in range(nset)]
+        C = [torch.randn(M, N, device=dev) for _ in range(nset)]
+        S = [torch.randn(M, N, device=dev) for _ in range(nset)] if kw.get("mask") else None
+        w = torch.randn(N, K, device=dev) / K ** 0.5
+        (img, _), = split_weights([w], tn=False)
+        def run(i):
+            gemm_panel(A[i], img, N, addend=C[i] if kw.get("addend") else None, out=C[i], epilogue=kw.get("epilogue", 0),
+                       mask_src=S[i] if S else None, p_drop=kw.get("p_drop", 0.0), seed=kw.get("seed", 0))
+        tp = bench.time_kernel(run, iters=40, nsets=nset)
+        print(f"{name:28s} {2.0 * M * K * N / 1e9:6.2f} | panel {tp*1e3:8.1f} us", flush=True)
     w5 = [torch.randn(7 * d, d, device=dev), torch.randn(d, d, device=dev), torch.randn(d, d, device=dev),
           torch.randn(2 * d, d, device=dev), torch.randn(d, 2 * d, device=dev)]
     ts = bench.time_kernel(lambda i: split_weights(w5), iters=20)
