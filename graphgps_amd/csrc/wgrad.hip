@@ -252,6 +252,309 @@ __global__ __launch_bounds__(256) void k_wgrad(const Group G) {
   wgrad_tile<SPLIT>(P, local - slice * tiles, slice, As, Bs);
 }
 
+
+// ------------------------------------------------------------------------------------------------------------
+// Streaming kernel (M and Nn multiples of 128, the shapes of the GPS block): same (tile, row-slice) work items, same
+// arithmetic, rebuilt around what rocprofv3 showed for k_wgrad: MFMA pipe 28 % busy with 70k VALU instructions per
+// wave -- four waves of 64 x 64 each split two g and two x fragments per k-step (176 VALU) for 24 MFMAs, i.e. 7 VALU
+// per MFMA issue gap that hides ~5, and every value was split by two waves.
+//   * split-K INSIDE the workgroup: each of the 4 waves owns the whole 128 x 128 tile (16 accumulators, 256 AGPRs) and
+//     every fourth 16-row k-step of the slice.  A value is split exactly once per workgroup: 8 fragments (352 VALU) per
+//     96 MFMAs = 3.7 per gap.  The four partial tiles are summed through LDS in wave order at the end (deterministic);
+//   * a wave stages ONLY its own rows: 16 rows x 128 columns of g and of x per stage arrive by LDS-DMA
+//     (global_load_lds_dwordx4, 16 transfers per wave and stage) in a private two-slot ring, so the k-loop has no
+//     barrier at all -- the wave's own counted vmcnt orders its DMA against its own reads;
+//   * the stage is software-pipelined by hand over four groups of 24 MFMAs (4 accumulators rotating in each, so no MFMA
+//     waits on its predecessor): while a group multiplies, the fragments of the next group -- and in the second half of
+//     the stage those of the next stage -- are read (ds_read_b32 down a column: the contraction index is the slow one)
+//     and split in instalments of <= 4 VALU dealt into the MFMA issue gaps; sched_barrier(0) pins the interleave;
+//   * the g half of a slot is refilled as soon as its last fragment has been read (group 1), the x half in group 2:
+//     a transfer has more than a full stage (3072 cycles of MFMA issue) to land.
+// Rows of the last slice beyond a multiple of 64 go through one extra, unpipelined stage whose DMA sources are selected
+// per lane (g rows past the end read a zero row).
+// ------------------------------------------------------------------------------------------------------------
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+constexpr int WS_ROWS = 16;                     // rows per wave and stage: one 16-wide k-step
+constexpr int WS_STAGE = 4 * WS_ROWS;           // rows per workgroup stage
+constexpr int WS_PART = WS_ROWS * 128 * 4;      // 8 KB: 16 rows x 128 fp32 of one operand
+constexpr int WS_SLOT = 2 * WS_PART;            // g | x
+constexpr int WS_WAVE = 2 * WS_SLOT;            // two slots per wave
+constexpr int WS_LDS = 4 * WS_WAVE;             // 128 KB
+
+__device__ float g_zero_row[128];
+
+struct Pieces {
+  u32x4 p[3];      // one fragment as bf16 pairs: hi, mid, lo
+};
+
+typedef __attribute__((address_space(3))) void* lds_void_ptr;
+typedef const __attribute__((address_space(1))) void* gbl_void_ptr;
+__device__ __forceinline__ void glds16(const unsigned char* g, unsigned char* l) {
+  __builtin_amdgcn_global_load_lds((gbl_void_ptr)g, (lds_void_ptr)l, 16, 0, 0);
+}
+constexpr int waitcnt_imm(int vm, int lgkm) { return (vm & 15) | (7 << 4) | ((lgkm & 15) << 8) | ((vm >> 4) << 14); }
+
+__global__ __launch_bounds__(256, 1) void k_wgrad_stream(const Group G) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < kMaxGroup; ++i)
+    if (i < G.n && (int)blockIdx.x >= G.p[i].block_begin) pi = i;
+  const Problem& P = G.p[pi];
+  const int local = blockIdx.x - P.block_begin;
+  const int tiles = P.tiles_m * P.tiles_n;
+  const int slice = local / tiles;
+  if (slice >= P.S) return;
+  const int tile = local - slice * tiles;
+  const int tm = tile / P.tiles_n, tn = tile - tm * P.tiles_n;
+  const int m0 = tm * 128, n0 = tn * 128;
+  const int64_t r_begin = (int64_t)slice * P.rows_per_slice;
+  const int64_t r_end = min(P.R, r_begin + P.rows_per_slice);
+  const int NS = (int)((r_end - r_begin) / WS_STAGE);           // full stages
+  const int tail = (int)((r_end - r_begin) - (int64_t)NS * WS_STAGE);
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int li = lane & 31, kh = lane >> 5;
+  unsigned char* const my = lds + wave * WS_WAVE;
+
+  // DMA: transfer i (0..7) of an operand = rows 2i, 2i+1 of the wave's 16; lane -> row 2i + (lane >> 5), chunk lane & 31
+  const int64_t gstage = (int64_t)WS_STAGE * P.ldg * 4, xstage = (int64_t)WS_STAGE * P.ldx * 4;
+  const int64_t grow2 = 2 * P.ldg * 4, xrow2 = 2 * P.ldx * 4;
+  const unsigned char* gsrc = reinterpret_cast<const unsigned char*>(P.g + (r_begin + wave * WS_ROWS + kh) * P.ldg + m0) + li * 16;
+  const unsigned char* xsrc = reinterpret_cast<const unsigned char*>(P.x + (r_begin + wave * WS_ROWS + kh) * P.ldx + n0) + li * 16;
+  auto dma_g = [&](int i, int stage, unsigned char* slot) __attribute__((always_inline)) {
+    glds16(gsrc + stage * gstage + i * grow2, slot + i * 1024);
+  };
+  auto dma_x = [&](int i, int stage, unsigned char* slot) __attribute__((always_inline)) {
+    glds16(xsrc + stage * xstage + i * xrow2, slot + WS_PART + i * 1024);
+  };
+  // a fragment's raw values: lane (li, kh) takes rows 8 kh .. 8 kh + 7 of its column (block blk of 32 columns)
+  const int frag_off = (8 * kh) * 512 + li * 4;
+  auto read2 = [&](const unsigned char* part, int blk, int j, float (&v)[8]) __attribute__((always_inline)) {
+    v[j] = *reinterpret_cast<const float*>(part + frag_off + j * 512 + blk * 128);
+    v[j + 1] = *reinterpret_cast<const float*>(part + frag_off + (j + 1) * 512 + blk * 128);
+  };
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.0f;
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+
+  // exact 3-way split of values (2d, 2d+1) of a fragment in three instalments (4 + 4 + 3 VALU); `bs` (g fragments only)
+  // accumulates the bias gradient, scaled by `bw` (0 for the prefetch that runs past the last stage)
+  float sv0, sv1, sr0, sr1;
+  auto split_part = [&](int part, const float (&raw)[8], int d, Pieces& out, float* bs, float bw) __attribute__((always_inline)) {
+    if (part == 0) {
+      sv0 = raw[2 * d];
+      sv1 = raw[2 * d + 1];
+      if (bs) *bs = fmaf(sv0 + sv1, bw, *bs);
+      sr0 = sv0 - __uint_as_float(__float_as_uint(sv0) & 0xFFFF0000u);
+      sr1 = sv1 - __uint_as_float(__float_as_uint(sv1) & 0xFFFF0000u);
+    } else if (part == 1) {
+      out.p[0][d] = __builtin_amdgcn_perm(__float_as_uint(sv1), __float_as_uint(sv0), 0x07060302u);
+      out.p[1][d] = __builtin_amdgcn_perm(__float_as_uint(sr1), __float_as_uint(sr0), 0x07060302u);
+      sv0 = sr0 - __uint_as_float(__float_as_uint(sr0) & 0xFFFF0000u);
+      sv1 = sr1 - __uint_as_float(__float_as_uint(sr1) & 0xFFFF0000u);
+    } else {
+      out.p[2][d] = __builtin_amdgcn_perm(__float_as_uint(sv1), __float_as_uint(sv0), 0x07060302u);
+    }
+  };
+  auto split_all = [&](const float (&raw)[8], Pieces& out, float* bs, float bw) __attribute__((always_inline)) {
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int part = 0; part < 3; ++part) split_part(part, raw, d, out, bs, bw);
+  };
+  constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};   // smallest terms first
+  auto mfma = [&](const Pieces& a, const Pieces& b, int term, f32x16& c) __attribute__((always_inline)) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a.p[TA[term]]), __builtin_bit_cast(bf16x8, b.p[TB[term]]), c, 0, 0, 0);
+  };
+
+  Pieces A01[2][2], A23[2], B[4];
+  float rawA23[2][8], rawB23[2][8], rawA01[2][8], rawB01[2][8];
+  unsigned char* const slot0 = my;
+  unsigned char* const slot1 = my + WS_SLOT;
+
+  if (NS > 0) {
+    // prologue: stages 0 and 1 (stage 1 = stage 0 again when there is only one: harmless)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dma_g(i, 0, slot0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dma_x(i, 0, slot0);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dma_g(i, min(1, NS - 1), slot1);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dma_x(i, min(1, NS - 1), slot1);
+    __builtin_amdgcn_s_waitcnt(waitcnt_imm(16, 15));        // stage 0 has landed (this wave's own rows: no barrier)
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        read2(slot0, f, j, rawA01[f]);
+        read2(slot0 + WS_PART, f, j, rawB01[f]);
+        read2(slot0, 2 + f, j, rawA23[f]);
+      }
+#pragma unroll
+    for (int f = 0; f < 2; ++f) {
+      split_all(rawA01[f], A01[0][f], &bsum[f], 1.0f);
+      split_all(rawB01[f], B[f], nullptr, 0.0f);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+  // One group = 24 MFMAs on 4 accumulators (pairs (ia, jb) given per call), `fill(m)` = what goes into the gap after MFMA m
+#define WS_GROUP(AI0, AI1, AI2, AI3, J0, J1, J2, J3, I0, I1, I2, I3, FILL)                              \
+  _Pragma("unroll") for (int m = 0; m < 24; ++m) {                                                       \
+    const int term = m >> 2, pr = m & 3;                                                                \
+    if (pr == 0) mfma(AI0, B[J0], term, acc[I0][J0]);                                                   \
+    if (pr == 1) mfma(AI1, B[J1], term, acc[I1][J1]);                                                   \
+    if (pr == 2) mfma(AI2, B[J2], term, acc[I2][J2]);                                                   \
+    if (pr == 3) mfma(AI3, B[J3], term, acc[I3][J3]);                                                   \
+    FILL(m);                                                                                            \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+  }
+
+  // Stage s in slot CUR (parity C of the A0/A1 piece sets); NXT holds stage s+1.
+  //   group 1: pairs (0,0)(1,0)(0,1)(1,1) | read x blocks 2,3 of s; refill the g half of CUR with stage s+2; split A2, A3
+  //   group 2: pairs (2,0)(2,1)(3,0)(3,1) | split B2, B3; refill the x half of CUR; wait for stage s+1; read its A0, A1
+  //   group 3: pairs (0,2)(1,2)(0,3)(1,3) | read B0, B1 of s+1; split A0, A1 of s+1 (into the other piece set)
+  //   group 4: pairs (2,2)(3,2)(2,3)(3,3) | read A2, A3 of s+1; split B0, B1 of s+1 (B[0], B[1] are free after group 2)
+#define WS_STAGE_BODY(S, C, CUR, NXT)                                                                     \
+  {                                                                                                       \
+    const int st2 = min((S) + 2, NS - 1);                                                                 \
+    const float bw_next = (S) + 1 < NS ? 1.0f : 0.0f;                                                     \
+    auto fill1 = [&](int m) __attribute__((always_inline)) {                                              \
+      if (m < 8) read2(CUR + WS_PART, 2 + m / 4, 2 * (m % 4), rawB23[m / 4]);                              \
+      if (m >= 8 && m < 16) dma_g(m - 8, st2, CUR);                                                       \
+      split_part(m % 3, rawA23[m / 12], (m % 12) / 3, A23[m / 12], &bsum[2 + m / 12], 1.0f);               \
+    };                                                                                                    \
+    WS_GROUP(A01[C][0], A01[C][1], A01[C][0], A01[C][1], 0, 0, 1, 1, 0, 1, 0, 1, fill1)                   \
+    auto fill2 = [&](int m) __attribute__((always_inline)) {                                              \
+      split_part(m % 3, rawB23[m / 12], (m % 12) / 3, B[2 + m / 12], nullptr, 0.0f);                      \
+      if (m == 8) __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, 0));   /* lgkmcnt(0): every read of CUR's x half is done */ \
+      if (m >= 8 && m < 16) dma_x(m - 8, st2, CUR);                                                       \
+      if (m == 16) __builtin_amdgcn_s_waitcnt(waitcnt_imm(16, 15)); /* vmcnt(16): stage s+1 has landed */  \
+      if (m >= 16) read2(NXT, (m - 16) / 4, 2 * ((m - 16) % 4), rawA01[(m - 16) / 4]);                     \
+    };                                                                                                    \
+    WS_GROUP(A23[0], A23[0], A23[1], A23[1], 0, 1, 0, 1, 2, 2, 3, 3, fill2)                               \
+    auto fill3 = [&](int m) __attribute__((always_inline)) {                                              \
+      if (m < 8) read2(NXT + WS_PART, m / 4, 2 * (m % 4), rawB01[m / 4]);                                  \
+      split_part(m % 3, rawA01[m / 12], (m % 12) / 3, A01[(C) ^ 1][m / 12], &bsum[m / 12], bw_next);       \
+    };                                                                                                    \
+    WS_GROUP(A01[C][0], A01[C][1], A01[C][0], A01[C][1], 2, 2, 3, 3, 0, 1, 0, 1, fill3)                   \
+    auto fill4 = [&](int m) __attribute__((always_inline)) {                                              \
+      if (m < 8) read2(NXT, 2 + m / 4, 2 * (m % 4), rawA23[m / 4]);                                        \
+      split_part(m % 3, rawB01[m / 12], (m % 12) / 3, B[m / 12], nullptr, 0.0f);                          \
+    };                                                                                                    \
+    WS_GROUP(A23[0], A23[0], A23[1], A23[1], 2, 3, 2, 3, 2, 2, 3, 3, fill4)                               \
+  }
+
+  for (int s = 0; s < NS; s += 2) {
+    WS_STAGE_BODY(s, 0, slot0, slot1)
+    if (s + 1 < NS) {
+      WS_STAGE_BODY(s + 1, 1, slot1, slot0)
+    }
+  }
+#undef WS_STAGE_BODY
+
+  __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 0));            // every DMA of this wave has landed, every read returned
+  if (tail > 0) {
+    // the last slice's rows past a multiple of 64: one unpipelined stage with per-lane source selection
+    const int64_t rt = r_begin + (int64_t)NS * WS_STAGE + wave * WS_ROWS + kh;     // row of transfer 0
+    const unsigned char* zrow = reinterpret_cast<const unsigned char*>(g_zero_row) + li * 16;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int64_t r = rt + 2 * i;
+      const bool ok = r < r_end;
+      const unsigned char* gs = reinterpret_cast<const unsigned char*>(P.g + (ok ? r : 0) * P.ldg + m0) + li * 16;
+      const unsigned char* xs = reinterpret_cast<const unsigned char*>(P.x + (ok ? r : r_end - 1) * P.ldx + n0) + li * 16;
+      glds16(ok ? gs : zrow, slot0 + i * 1024);
+      glds16(xs, slot0 + WS_PART + i * 1024);
+    }
+    __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 15));
+    float ra[4][8], rb[4][8];
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int j = 0; j < 8; j += 2) {
+        read2(slot0, f, j, ra[f]);
+        read2(slot0 + WS_PART, f, j, rb[f]);
+      }
+    Pieces TAp[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+      split_all(ra[f], TAp[f], &bsum[f], 1.0f);
+      split_all(rb[f], B[f], nullptr, 0.0f);
+    }
+#pragma unroll
+    for (int term = 0; term < 6; ++term)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mfma(TAp[i], B[j], term, acc[i][j]);
+    __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 0));
+  }
+#undef WS_GROUP
+
+  // ---- the four waves' partial tiles summed through LDS, in wave order; two passes of 64 rows (8 blocks) each ------
+  // layout [wave][block 0..7][lane][16 floats]: a lane re-reads exactly the slots the same lane of the other waves wrote
+  float* const red = reinterpret_cast<float*>(lds);
+  float* po = P.part + (int64_t)slice * P.M * P.Nn;
+#pragma unroll
+  for (int pass = 0; pass < 2; ++pass) {
+    __syncthreads();                                        // LDS is free (k-loop reads done / previous pass read)
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const int i = 2 * pass + (b >> 2), j = b & 3;
+      float* dst = red + ((wave * 8 + b) * 64 + lane) * 16;
+#pragma unroll
+      for (int q = 0; q < 16; q += 4)
+        *reinterpret_cast<float4*>(dst + q) = make_float4(acc[i][j][q], acc[i][j][q + 1], acc[i][j][q + 2], acc[i][j][q + 3]);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int bb = 0; bb < 2; ++bb) {
+      const int b = 2 * wave + bb;                          // this wave sums blocks 2w, 2w+1 of the pass
+      const int i = 2 * pass + (b >> 2), j = b & 3;
+      float sum[16];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) sum[q] = 0.0f;
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        const float* src = red + ((w * 8 + b) * 64 + lane) * 16;
+#pragma unroll
+        for (int q = 0; q < 16; q += 4) {
+          const float4 v = *reinterpret_cast<const float4*>(src + q);
+          sum[q] += v.x; sum[q + 1] += v.y; sum[q + 2] += v.z; sum[q + 3] += v.w;
+        }
+      }
+      const int col = n0 + j * 32 + li;
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const int row = m0 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh;
+        po[(int64_t)row * P.Nn + col] = sum[q];
+      }
+    }
+  }
+  if (P.bias_part && tn == 0) {
+    __syncthreads();
+    float* sc = reinterpret_cast<float*>(lds);              // [wave][kh][128 columns]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sc[(wave * 2 + kh) * 128 + i * 32 + li] = bsum[i];
+    __syncthreads();
+    if (t < 128) {
+      float a = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) a += sc[q * 128 + t];
+      P.bias_part[(int64_t)slice * P.M + m0 + t] = a;
+    }
+  }
+}
+
 // out[i] = sum_s part[s][i] in slice order (one float per thread: enough threads to pull the
 // S x M x Nn partials at bandwidth); bias likewise, by the first threads of each problem
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const Group G) {
@@ -278,7 +581,7 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const Group G) {
 }
 
 // Slices for a problem so that one workgroup owns about `chunks_per_block` 32-row chunks.
-inline void plan_slices(Problem& p, int64_t chunks_per_block) {
+inline void plan_slices(Problem& p, int64_t chunks_per_block, int quantum = BK) {
   p.tiles_m = (p.M + BM - 1) / BM;
   p.tiles_n = (p.Nn + BN - 1) / BN;
   const int64_t chunks = (p.R + BK - 1) / BK;
@@ -287,7 +590,7 @@ inline void plan_slices(Problem& p, int64_t chunks_per_block) {
   if (S > max_s) S = max_s;
   if (S < 1) S = 1;
   int64_t rps = (p.R + S - 1) / S;
-  rps = (rps + BK - 1) / BK * BK;
+  rps = (rps + quantum - 1) / quantum * quantum;
   p.rows_per_slice = (int)rps;
   p.S = (int)((p.R + rps - 1) / rps);
 }
@@ -339,6 +642,23 @@ int check_problem(const char* who, const float* g, int64_t ldg, const float* x, 
   return GPS_OK;
 }
 
+// the streaming kernel takes whole 128 x 128 tiles and 16-byte-aligned rows (GPS_WGRAD_STREAM=0: never)
+inline bool stream_shapes(const int* M, const int* Nn, int n) {
+  static const bool on = [] { const char* e = getenv("GPS_WGRAD_STREAM"); return !(e && e[0] == '0'); }();
+  if (!on) return false;
+  for (int i = 0; i < n; ++i)
+    if (M[i] % 128 != 0 || Nn[i] % 128 != 0) return false;
+  return true;
+}
+inline bool stream_ok(const Group& G) {
+  int M[kMaxGroup], Nn[kMaxGroup];
+  for (int i = 0; i < G.n; ++i) { M[i] = G.p[i].M; Nn[i] = G.p[i].Nn; }
+  if (!stream_shapes(M, Nn, G.n)) return false;
+  for (int i = 0; i < G.n; ++i)
+    if (G.p[i].rows_per_slice % WS_STAGE != 0) return false;
+  return true;
+}
+
 int launch_group(Group& G, float* ws, hipStream_t s, const char* who) {
   int blocks = 0;
   int64_t outs = 0;
@@ -355,7 +675,12 @@ int launch_group(Group& G, float* ws, hipStream_t s, const char* who) {
   }
   // GPS_WGRAD_FP32_MFMA=1 keeps the contraction on the fp32-input MFMA (v_mfma_f32_32x32x2_f32)
   static const bool fp32_pipe = [] { const char* e = getenv("GPS_WGRAD_FP32_MFMA"); return e && atoi(e) != 0; }();
-  if (fp32_pipe)
+  if (stream_ok(G) && !fp32_pipe) {
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_stream),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS);
+    GPS_REQUIRE(attr == hipSuccess, "%s: cannot reserve %d bytes of LDS", who, WS_LDS);
+    k_wgrad_stream<<<(unsigned)blocks, 256, WS_LDS, s>>>(G);
+  } else if (fp32_pipe)
     k_wgrad<false><<<(unsigned)blocks, 256, 0, s>>>(G);
   else
     k_wgrad<true><<<(unsigned)blocks, 256, 0, s>>>(G);
@@ -371,7 +696,7 @@ size_t gps_wgrad_workspace_floats(int64_t R, int M, int Nn) {
   if (R <= 0 || M <= 0 || Nn <= 0) return 0;
   Problem p{};
   p.R = R; p.M = M; p.Nn = Nn;
-  plan_slices(p, balanced_chunks(&R, &M, &Nn, 1));
+  plan_slices(p, balanced_chunks(&R, &M, &Nn, 1), stream_shapes(&M, &Nn, 1) ? WS_STAGE : BK);
   return problem_ws_floats(p);
 }
 
@@ -383,7 +708,7 @@ int gps_wgrad(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t 
   G.n = 1;
   Problem& p = G.p[0];
   p.g = g; p.x = x; p.gw = gw; p.gb = gb; p.ldg = ldg; p.ldx = ldx; p.R = R; p.M = M; p.Nn = Nn;
-  plan_slices(p, balanced_chunks(&R, &M, &Nn, 1));
+  plan_slices(p, balanced_chunks(&R, &M, &Nn, 1), stream_shapes(&M, &Nn, 1) ? WS_STAGE : BK);
   return launch_group(G, ws, gps::as_stream(stream), "gps_wgrad");
 }
 
@@ -393,12 +718,13 @@ size_t gps_wgrad_grouped_workspace_floats(int n, const gps_wgrad_problem* probs)
   int M[kMaxGroup], Nn[kMaxGroup];
   for (int i = 0; i < n; ++i) { R[i] = probs[i].R; M[i] = probs[i].M; Nn[i] = probs[i].Nn; }
   const int64_t cpb = balanced_chunks(R, M, Nn, n);
+  const int quantum = stream_shapes(M, Nn, n) ? WS_STAGE : BK;
   size_t total = 0;
   for (int i = 0; i < n; ++i) {
     if (R[i] <= 0 || M[i] <= 0 || Nn[i] <= 0) return 0;
     Problem p{};
     p.R = R[i]; p.M = M[i]; p.Nn = Nn[i];
-    plan_slices(p, cpb);
+    plan_slices(p, cpb, quantum);
     total += problem_ws_floats(p);
   }
   return total;
@@ -419,12 +745,13 @@ int gps_wgrad_grouped(int n, const gps_wgrad_problem* probs, float* ws, gps_stre
     R[i] = q.R; M[i] = q.M; Nn[i] = q.Nn;
   }
   const int64_t cpb = balanced_chunks(R, M, Nn, n);
+  const int quantum = stream_shapes(M, Nn, n) ? WS_STAGE : BK;
   for (int i = 0; i < n; ++i) {
     const gps_wgrad_problem& q = probs[i];
     Problem& p = G.p[i];
     p.g = q.g; p.x = q.x; p.gw = q.gw; p.gb = q.gb; p.ldg = q.ldg; p.ldx = q.ldx;
     p.R = q.R; p.M = q.M; p.Nn = q.Nn;
-    plan_slices(p, cpb);
+    plan_slices(p, cpb, quantum);
   }
   return launch_group(G, ws, gps::as_stream(stream), "gps_wgrad_grouped");
 }
