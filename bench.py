@@ -47,6 +47,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 MFMA_F32_PEAK_TF = 157.3     # v_mfma_f32_16x16x4_f32 dense peak
+MFMA_BF16_PEAK_TF = 2500.0   # v_mfma_f32_32x32x16_bf16 dense peak (MI355X_MICROARCH.md: 2495 measured)
 
 
 _T0 = time.time()
@@ -269,7 +270,8 @@ def kernel_rooflines(dev, profile, nb, d=384, H=16, in_step=None, layers=10, onl
         hot = time_kernel(fn, nsets=1)
         rot = time_kernel(fn, nsets=nsets)
         ins, cnt = _match(in_step, *needles) if in_step else (None, 0)
-        peak, unit, div = (HBM_PEAK_GBS, "GB/s", 1e6) if bound == "hbm" else (MFMA_F32_PEAK_TF, "TFLOP/s", 1e9)
+        peak, unit, div = {"hbm": (HBM_PEAK_GBS, "GB/s", 1e6), "mfma": (MFMA_F32_PEAK_TF, "TFLOP/s", 1e9),
+                           "mfma_bf16": (MFMA_BF16_PEAK_TF, "TFLOP/s", 1e9)}[bound]
         ms = ins if ins is not None else rot
         e = dict(bound=bound, ms=ms, ms_source="in-step (roctracer)" if ins is not None else "isolated, rotating",
                  in_step_ms=ins, isolated_hot_ms=hot, isolated_rotating_ms=rot,
@@ -309,10 +311,28 @@ def kernel_rooflines(dev, profile, nb, d=384, H=16, in_step=None, layers=10, onl
         q.g, q.x, q.gw, q.gb = g_.data_ptr(), x_.data_ptr(), gw.data_ptr(), gb.data_ptr()
         q.ldg, q.ldx, q.R, q.M, q.Nn = g_.stride(0), x_.stride(0), g_.shape[0], g_.shape[1], x_.shape[1]
     wws = torch.empty(max(L.gps_wgrad_grouped_workspace_floats(len(pairs), probs), 4), device=dev)
-    entry("wgrad_grouped", lambda i=0: check(L.gps_wgrad_grouped(len(pairs), probs, ptr(wws), current_stream(dev))), 1, "mfma",
-          sum(2.0 * R * k * n for R, k, n in shapes), 2, ("k_wgrad",),
-          note="fp32-equivalent flops against the fp32-input MFMA peak; the contraction itself runs on the "
-               "bf16 pipe (exact 3-way split, 6 products); in-step it shares the chip with the main stream")
+    SPLIT_NOTE = ("flops = the bf16 MFMA flops issued: 6 piece products per fp32 product (exact 3-way split, "
+                  "hh hm mh hl lh mm), against the dense bf16 MFMA peak; fp32-equivalent rate = achieved / 6")
+    entry("wgrad_grouped", lambda i=0: check(L.gps_wgrad_grouped(len(pairs), probs, ptr(wws), current_stream(dev))), 1,
+          "mfma_bf16", 6 * sum(2.0 * R * k * n for R, k, n in shapes), 2, ("k_wgrad",), note=SPLIT_NOTE)
+    # the projection GEMMs of one block through the ring kernel (csrc/gemm_panel.hip): forward five, input-gradient five
+    from graphgps_amd import gemm as _gemm
+    if _gemm.supported(d, d):
+        ws_ = [f(n, k) for _, k, n in shapes]
+        imgs = _gemm.split_weights(ws_)
+        xs_ = [f(R, k) for R, k, _ in shapes]
+        gs_ = [f(R, n) for R, _, n in shapes]
+        ys_ = [torch.empty(R, n, device=dev) for R, _, n in shapes]
+        dx_ = [torch.empty(R, k, device=dev) for R, k, _ in shapes]
+        def fwd5(i=0):
+            for x_, (nt, _), y_, (_, _, n) in zip(xs_, imgs, ys_, shapes):
+                _gemm.gemm_panel(x_, nt, n, out=y_)
+        def dgrad5(i=0):
+            for g_, (_, tn), o_, (_, k, _) in zip(gs_, imgs, dx_, shapes):
+                _gemm.gemm_panel(g_, tn, k, out=o_)
+        fl = 6 * sum(2.0 * R * k * n for R, k, n in shapes)
+        entry("gemm_fwd_block", fwd5, 1, "mfma_bf16", fl, 5, (), note=SPLIT_NOTE + "; isolated only (one kernel name serves every shape)")
+        entry("gemm_dgrad_block", dgrad5, 1, "mfma_bf16", fl, 5, (), note=SPLIT_NOTE + "; isolated only")
     return res, dict(N=N, E=E, d=d, H=H, sum_n2=s2, rotation_sets=dict(gatedgcn=n_rot, attention=a_rot))
 
 
@@ -609,7 +629,10 @@ def main():
             # drop the captured graphs (and their private memory pool) before running eagerly
             ts = TrainStep(model, opt, loss_fn=compute_loss, exchange=exchange, salt=salt)
         ts.use_replay = launch == "graph"
-        graph_mode = ts.mode if launch == "graph" else "eager (2 HIP streams: main + weight-gradient)"
+        from graphgps_amd import fused as _fused
+        two = _fused._BLOCK_SIDE_ENABLED if args.workload == "pcqm4m" else _fused._SIDE_ENABLED
+        graph_mode = ts.mode if launch == "graph" else (
+            "eager (2 HIP streams: main + weight-gradient)" if two else "eager (one HIP stream)")
         allreduce_bytes = exchange.num_bytes if exchange is not None else 0
     log("model on device, starting warm-up")
     for i in range(args.warmup):

@@ -132,18 +132,30 @@ def add_dropout(a: torch.Tensor, b: torch.Tensor, p_drop: float, training: bool,
 # weight / bias gradients on a second HIP stream
 # -------------------------------------------------------------------------------------------
 # The weight-gradient GEMMs (long K = N or E rows, small [out, in] result) are off the critical
-# path of the backward chain: nothing needs them before the optimizer.  With GPS_WGRAD_SIDE_STREAM=1 they
-# are issued on a side stream so they overlap the small latency-bound kernels of the chain (BN passes,
-# attention, sparse kernels); the main stream re-joins the side stream (a) at the end of every backward
-# pass (autograd engine callback) and (b) wherever dp.py packs gradients.
-# Default since round 2: OFF.  It paid while the projection GEMMs left half of every CU's LDS free
-# (12.2 vs 12.6 ms per step); the ring GEMM (csrc/gemm_panel.hip) owns a CU's whole LDS, so a co-scheduled
-# weight-gradient workgroup and a ring workgroup exclude each other from the CU, and one stream replayed
-# as a hipGraph is faster: 11.39 ms (graph, one stream) vs 11.60 ms (eager, two streams), MI355X, PCQM4M
-# GPS-medium step (tools/gpu_r2q.sh).
+# path of the backward chain: nothing needs them before the optimizer.  They are issued on a side
+# stream so they overlap the small latency-bound kernels of the chain (BN passes, attention,
+# sparse kernels) instead of serialising with them.  The main stream re-joins the side stream
+# (a) at the end of every backward pass (autograd engine callback) and (b) wherever dp.py packs
+# gradients.  GPS_WGRAD_SIDE_STREAM=0 disables it for the per-module path below.
+#
+# Two switches since round 2:
+#   * this file (nn.Linear-shaped modules outside the fused block: encoders, heads, the Performer / GINE / SAN
+#     layers): side stream ON by default, as validated in round 1.  Do not turn it off under hipGraph capture on
+#     the code2 configuration: with the transposed library GEMM of the 25010-wide head (g^T x, K = 32 rows) on
+#     the CAPTURE stream the replay dies with "Write access to a read-only page" (MI355X, ROCm 7.0.2 / torch
+#     2.10; eager is fine, zinc is fine, the same step with that GEMM on this persistent side stream is fine
+#     -- tools/gpu_r2w.sh).  The GEMM's workspace is the only allocation whose lifetime differs; not chased
+#     further, the default avoids it.
+#   * layer/gps_block.py (the fused CustomGatedGCN+Transformer block): GPS_BLOCK_WGRAD_SIDE_STREAM, default OFF.
+#     It paid while the projection GEMMs left half of every CU's LDS free (12.2 vs 12.6 ms per step); the ring
+#     GEMM (csrc/gemm_panel.hip) owns a CU's whole LDS, so a co-scheduled weight-gradient workgroup and a ring
+#     workgroup exclude each other from the CU, and one stream replayed as a hipGraph is faster: 11.39 ms
+#     (graph, one stream) vs 11.60 ms (eager, two streams), PCQM4M GPS-medium step before the streaming
+#     weight-gradient kernel (tools/gpu_r2q.sh).
 import os as _os
 
-_SIDE_ENABLED = _os.environ.get("GPS_WGRAD_SIDE_STREAM", "0") != "0"
+_SIDE_ENABLED = _os.environ.get("GPS_WGRAD_SIDE_STREAM", "1") != "0"
+_BLOCK_SIDE_ENABLED = _os.environ.get("GPS_BLOCK_WGRAD_SIDE_STREAM", "0") != "0"
 _side_streams = {}
 _join_pending = set()
 

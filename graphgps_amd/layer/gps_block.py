@@ -25,7 +25,7 @@ import torch
 
 from .. import gemm as _gemm
 from .. import lib as _lib
-from ..fused import _SIDE_ENABLED, _queue_join, _side_stream
+from ..fused import _BLOCK_SIDE_ENABLED as _SIDE_ENABLED, _queue_join, _side_stream
 from ..lib import check, current_stream, ptr
 from ..ops import GraphIndex, draw_dropout_seed
 
