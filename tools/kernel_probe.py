@@ -16,11 +16,12 @@ import bench  # noqa: E402
 if __name__ == "__main__":
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)
-    res, shape = bench.kernel_rooflines(dev, sys.argv[1] if len(sys.argv) > 1 else "P30", 256)
+    res, shape = bench.kernel_rooflines(dev, sys.argv[1] if len(sys.argv) > 1 else "P30", 256,
+                                        only=("gatedgcn_fwd", "gatedgcn_bwd", "seg_attn_fwd", "seg_attn_bwd", "wgrad_grouped"))
     print(shape, {k: round(v["ms"] * 1e3, 2) for k, v in res.items()})
     if os.environ.get("GPS_PROBE_GEMM", "1") != "0":
-        # the panel GEMM at two of the block's shapes: k_gemm_panel<0, false> = x[N,d] W[7d,d] (14 column panels),
-        # k_gemm_panel<0, true> = t[N,2d] W[d,2d] + residual (2 column panels)
+        # the ring GEMM at two of the block's shapes: k_gemm_ring<2, 0, false> = x[N,d] W[7d,d] (14 column panels of
+        # 128 rows), k_gemm_ring<1, 0, true> = t[N,2d] W[d,2d] + residual (2 column panels of 64 rows)
         from graphgps_amd.gemm import gemm_panel, split_weights
         Nn, d = 7569, 384
         for K, N, cin in ((d, 7 * d, False), (2 * d, d, True)):
