@@ -237,12 +237,22 @@ __global__ __launch_bounds__(256) void k_stats_finalize(const FinGroup G) {
   const int b0 = chunk * per;
   float mb[FPER], qb[FPER], nbv[FPER];
   float a = 0.f;
+  // every partial is requested before the first one is used: the loads are unconditional from a clamped address and
+  // the out-of-range ones are zeroed by a select afterwards (a load under a condition becomes its own exec-masked
+  // block and the 64 loads of a thread stop being one burst: this launch is pure latency, 10 -> ~4 us)
+  const int cc = min(c, d - 1);
+#pragma unroll
+  for (int j = 0; j < FPER; ++j) {
+    const int bb = min(b0 + j, T.nblk - 1);
+    mb[j] = T.ws[(int64_t)bb * 2 * d + cc];
+    qb[j] = T.ws[(int64_t)bb * 2 * d + d + cc];
+  }
 #pragma unroll
   for (int j = 0; j < FPER; ++j) {
     const int b = b0 + j;
     const bool ok = c < d && j < per && b < T.nblk;
-    mb[j] = ok ? T.ws[(int64_t)b * 2 * d + c] : 0.f;
-    qb[j] = ok ? T.ws[(int64_t)b * 2 * d + d + c] : 0.f;
+    mb[j] = ok ? mb[j] : 0.f;
+    qb[j] = ok ? qb[j] : 0.f;
     nbv[j] = ok ? fminf((float)T.rpb, T.count - (float)b * (float)T.rpb) : 0.f;
   }
 #pragma unroll
@@ -410,12 +420,24 @@ __global__ __launch_bounds__(256) void k_bwd_finalize(const BwdGroup G) {
   const int b0 = chunk * per, b1 = min(T.nblk, b0 + per);
   const bool dual = T.z2 != nullptr;
   float a = 0.f, b = 0.f, e = 0.f;
-  if (c < d) {
-#pragma unroll 8
-    for (int k = b0; k < b1; ++k) {
-      a += T.ws[(int64_t)k * 3 * d + c];
-      b += T.ws[(int64_t)k * 3 * d + d + c];
-      if (dual) e += T.ws[(int64_t)k * 3 * d + 2 * d + c];
+  {
+    // one burst of loads (clamped addresses, masked afterwards), summed in ascending block order
+    float va[FPER], vb[FPER], vc[FPER];
+    const int cc = min(c, d - 1);
+    const int64_t third = dual ? 2 * d : d;        // non-dual: re-read the second column block (unused)
+#pragma unroll
+    for (int j = 0; j < FPER; ++j) {
+      const int kk = min(b0 + j, T.nblk - 1);
+      va[j] = T.ws[(int64_t)kk * 3 * d + cc];
+      vb[j] = T.ws[(int64_t)kk * 3 * d + d + cc];
+      vc[j] = T.ws[(int64_t)kk * 3 * d + third + cc];
+    }
+#pragma unroll
+    for (int j = 0; j < FPER; ++j) {
+      const bool ok = c < d && b0 + j < b1;
+      a += ok ? va[j] : 0.f;
+      b += ok ? vb[j] : 0.f;
+      e += (ok && dual) ? vc[j] : 0.f;
     }
   }
   sh[chunk][col][0] = a; sh[chunk][col][1] = b; sh[chunk][col][2] = e;
