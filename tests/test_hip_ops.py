@@ -794,3 +794,56 @@ def test_edge_attention_real_edges(H, D, profile, nb, softmax):
         assert_close(z, z_ref, Tol.ACT * max(1.0, float(z_ref.abs().max())), "z")
     for name, a_, b_ in zip("QKVE", dev_in, ref_in):
         assert_close(a_.grad, b_.grad, Tol.GRAD_REL, f"grad {name}", rel_to_max=True)
+
+
+@pytest.mark.gpu
+def test_dma_kernels_race_screen():
+    """The ring GEMM and the streaming weight-gradient kernel order their LDS-DMA against their LDS reads with counted
+    vmcnt waits and (GEMM) one barrier per stage; a read placed one wait too early returns stale LDS only when the DMA
+    happens to land late -- rare wrong tiles that come and go with timing.  Screen: the same launch 30 times, with
+    unrelated memory traffic in between to move the timing, must reproduce the first result bit for bit (both kernels
+    are deterministic by construction), and that result must be the right one."""
+    from graphgps_amd import lib as L_
+    from graphgps_amd.gemm import gemm_panel, split_weights
+    from graphgps_amd.lib import check, current_stream, ptr
+    L = L_.load()
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(99)
+    noise = torch.empty(64 << 20, device=dev)
+    for M, K, N in ((7569, 384, 2688), (7569, 2688, 384), (15348, 384, 384)):
+        a = torch.randn(M, K, generator=gen).to(dev)
+        w = (torch.randn(N, K, generator=gen) / K ** 0.5).to(dev)
+        (img, _), = split_weights([w], tn=False)
+        first = gemm_panel(a, img, N).clone()
+        ref = a.double() @ w.double().t()
+        assert float((first.double() - ref).abs().max()) <= 4e-6 * float(ref.abs().max()) + 1e-5
+        for it in range(30):
+            if it % 3 == 0:
+                noise.normal_()                     # evict caches, shift arrival times
+            out = gemm_panel(a, img, N)
+            assert torch.equal(out, first), f"ring GEMM {M}x{K}x{N}: run {it} differs from run 0"
+    R = 7569
+    shapes = [(R, 384, 2688), (15348, 384, 384), (R, 384, 384), (R, 384, 768), (R, 768, 384)]   # (rows, in, out)
+    pairs = [(torch.randn(r, n, generator=gen).to(dev), torch.randn(r, k, generator=gen).to(dev)) for r, k, n in shapes]
+    probs = (L_.WgradProblem * len(pairs))()
+    outs = []
+    for q, (g, x) in zip(probs, pairs):
+        gw, gb = torch.empty(g.shape[1], x.shape[1], device=dev), torch.empty(g.shape[1], device=dev)
+        q.g, q.x, q.gw, q.gb = g.data_ptr(), x.data_ptr(), gw.data_ptr(), gb.data_ptr()
+        q.ldg, q.ldx, q.R, q.M, q.Nn = g.stride(0), x.stride(0), g.shape[0], g.shape[1], x.shape[1]
+        outs.append((gw, gb))
+    ws = torch.empty(max(L.gps_wgrad_grouped_workspace_floats(len(pairs), probs), 4), device=dev)
+    firsts = None
+    for it in range(30):
+        if it % 3 == 0:
+            noise.normal_()
+        check(L.gps_wgrad_grouped(len(pairs), probs, ptr(ws), current_stream(dev)), "gps_wgrad_grouped")
+        cur = [(gw.clone(), gb.clone()) for gw, gb in outs]
+        if firsts is None:
+            firsts = cur
+            for (g, x), (gw, gb) in zip(pairs, cur):
+                assert_close(gw, g.double().t() @ x.double(), Tol.GRAD_REL, "gW", rel_to_max=True)
+                assert_close(gb, g.double().sum(0), Tol.GRAD_REL, "gb", rel_to_max=True)
+        else:
+            for i, ((gw, gb), (fw, fb)) in enumerate(zip(cur, firsts)):
+                assert torch.equal(gw, fw) and torch.equal(gb, fb), f"streaming wgrad problem {i}: run {it} differs"
