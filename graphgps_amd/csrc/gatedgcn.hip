@@ -463,7 +463,7 @@ __global__ __launch_bounds__(GG_T) void k_gatedgcn_bwd(
 
 inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
-// Launch shape.  Threads per workgroup (GPS_GG_THREADS, default 768 = 12 wavefronts) and the number of workgroups
+// Launch shape.  Threads per workgroup (GPS_GG_FWD_THREADS / GPS_GG_THREADS) and the number of workgroups
 // aimed at (GPS_GG_TARGET_WG, default 512) are read once; node rows per workgroup = N / target rounded up to whole
 // passes, never more than the LDS rowptr slice holds.
 struct Plan { int threads, npi, nb; unsigned grid; };
@@ -471,9 +471,13 @@ inline int env_int(const char* name, int dflt) {
   const char* v = getenv(name);
   return v && *v ? atoi(v) : dflt;
 }
-inline Plan plan_for(int64_t N, int lanes_per_row) {
-  static const int cfg_threads = env_int("GPS_GG_THREADS", GG_T);
+inline Plan plan_for(int64_t N, int lanes_per_row, bool forward) {
+  // forward: 512 threads (two 8-wave workgroups per CU cover each other's index staging; measured at P30 x 256, d = 384,
+  // rotating operands: 24.6 us against 26.3 us with 768); backward: 768 (one workgroup per CU either way: 140 KB of LDS)
+  static const int fwd_threads = env_int("GPS_GG_FWD_THREADS", 512);
+  static const int bwd_threads = env_int("GPS_GG_THREADS", GG_T);
   static const int cfg_target = env_int("GPS_GG_TARGET_WG", 512);
+  const int cfg_threads = forward ? fwd_threads : bwd_threads;
   Plan p;
   p.threads = cfg_threads < 64 ? 64 : (cfg_threads > GG_T ? GG_T : (cfg_threads / 64) * 64);
   if (p.threads < lanes_per_row) p.threads = GG_T;
@@ -517,7 +521,7 @@ int gps_gatedgcn_fwd(const float* Ax, const float* Bx, const float* Dx, const fl
   hipStream_t s = gps::as_stream(stream);
   GPS_DISPATCH_VEC(d, ld_node % 4 == 0 && ok(16), ld_node % 2 == 0 && ok(8), {
     GPS_REQUIRE(d / VEC <= GG_T, "gps_gatedgcn_fwd: d=%d too wide for one workgroup pass (%d lanes)", d, d / VEC);
-    const Plan pl = plan_for(N, d / VEC);
+    const Plan pl = plan_for(N, d / VEC, true);
     if (r_edge) GPS_GG_FWD(true); else GPS_GG_FWD(false);
   });
   return gps::launch_status("gps_gatedgcn_fwd");
@@ -547,7 +551,7 @@ int gps_gatedgcn_bwd(const float* g_x, int64_t ld_gx, const float* g_e, const fl
   GPS_DISPATCH_VEC(d, ld_node % 4 == 0 && ld_gnode % 4 == 0 && ld_gx % 4 == 0 && ok(16),
                    ld_node % 2 == 0 && ld_gnode % 2 == 0 && ld_gx % 2 == 0 && ok(8), {
     GPS_REQUIRE(d / VEC <= GG_T, "gps_gatedgcn_bwd: d=%d too wide for one workgroup pass (%d lanes)", d, d / VEC);
-    const Plan pl = plan_for(N, d / VEC);
+    const Plan pl = plan_for(N, d / VEC, false);
     // LDS stash of phase A's per-edge results for phase B: [2][cap][d] floats next to the 29 KB of index slices
     static const int stash_kb = env_int("GPS_GG_STASH_KB", 112);
     int cap = (int)(((int64_t)stash_kb * 1024) / (8LL * d));

@@ -49,7 +49,7 @@ def main():
         grid = [tuple(int(v) for v in item.split(":")) for item in os.environ["GG_GRID"].split(",")]
     print(f"{'threads':>8} {'target':>7} | fwd hot / rot us (frac rot) | bwd hot / rot us (frac rot)")
     for th, tg in grid:
-        env = dict(os.environ, GG_ONE="1", GPS_GG_THREADS=str(th), GPS_GG_TARGET_WG=str(tg))
+        env = dict(os.environ, GG_ONE="1", GPS_GG_THREADS=str(th), GPS_GG_FWD_THREADS=str(th), GPS_GG_TARGET_WG=str(tg))
         r = subprocess.run([sys.executable, os.path.abspath(__file__)], env=env, capture_output=True, text=True)
         line = [l for l in r.stdout.splitlines() if l.startswith("RESULT ")]
         if not line:
