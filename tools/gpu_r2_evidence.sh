@@ -14,13 +14,15 @@ export TMPDIR=/tmp
 cd /tmp
 for w in pcqm4m code2; do
   rm -rf /tmp/prof_$w
-  timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/prof_$w -o bench -- python $R/bench.py --workload $w --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-roofline --no-h2d-leg --no-gemm-tuning > $R/$O/prof_$w.json 2> $R/$O/prof_$w.log
+  timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_$w -o bench -- python $R/bench.py --workload $w --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-roofline --no-h2d-leg --no-gemm-tuning > $R/$O/prof_$w.json 2> $R/$O/prof_$w.log
   DB=$(find /tmp/prof_$w -name "*.db" | head -1)
   if [ -n "$DB" ]; then python $R/tools/rocpd_stats.py $DB --top 70 > $R/$O/kernel_trace_stats_$w.txt 2>&1; fi
   rm -rf /tmp/prof_$w
 done
 cd $R
-bash tools/pmc_collect.sh $O/pmc > $O/pmc_collect.log 2>&1
+timeout 300 python tools/gemm_panel_bench.py > $O/gemm_ring.txt 2>&1
+timeout 200 python tools/gemm_trace.py > $O/gemm_timeline.txt 2>&1
+timeout 900 bash tools/pmc_collect.sh $O/pmc > $O/pmc_collect.log 2>&1
 python - <<'PY'
 import json
 for n in ('bench_default','bench_code2','prof_pcqm4m','prof_code2'):
