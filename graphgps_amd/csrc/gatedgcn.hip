@@ -472,11 +472,11 @@ inline int env_int(const char* name, int dflt) {
   return v && *v ? atoi(v) : dflt;
 }
 inline Plan plan_for(int64_t N, int lanes_per_row, bool forward) {
-  // GPS_GG_FWD_THREADS: isolated, the forward is faster with 512-thread workgroups (two 8-wave workgroups per CU cover
-  // each other's index staging: 24.6 us against 26.3 us, rotating operands), but inside the captured step, where the
-  // attention half runs beside it on the branch stream, it is slower (33.9 against 26.0 us per launch under the
-  // tracer) -- 768 stays the default
-  static const int fwd_threads = env_int("GPS_GG_FWD_THREADS", GG_T);
+  // forward: 512 threads (two 8-wave workgroups per CU cover each other's index staging).  Measured at P30 x 256,
+  // d = 384: isolated, rotating operands 24.6 us against 26.3 us with 768; overlapped with the attention kernel on the
+  // branch stream (GPS_GEMM_MERGE=1 schedule) 34 us against 45 us.  backward: 768 (one workgroup per CU either way:
+  // 140 KB of LDS)
+  static const int fwd_threads = env_int("GPS_GG_FWD_THREADS", 512);
   static const int bwd_threads = env_int("GPS_GG_THREADS", GG_T);
   static const int cfg_target = env_int("GPS_GG_TARGET_WG", 512);
   const int cfg_threads = forward ? fwd_threads : bwd_threads;

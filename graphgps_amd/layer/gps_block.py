@@ -136,7 +136,12 @@ def _grouped_param_grads(L, pairs, params=()):
 
 
 _GROUPED_WGRAD = _os.environ.get("GPS_WGRAD_GROUPED", "1") != "0"
-_MERGE_PROJ = _os.environ.get("GPS_GEMM_MERGE", "1") != "0"
+# GPS_GEMM_MERGE=1: x -> A|B|D|E|QKV and e -> Ce as ONE launch on the ring kernel's persistent grid.  Same-box A/B,
+# three runs each: 10.30 vs 10.36 ms per step (-0.6 %).  Off by default: without the separate edge-projection launch
+# the GatedGCN forward starts together with the forked attention kernel and the two overlap for their whole length, so
+# neither kernel's in-step duration (what bench.py's roofline line reports) is its own any more (k_gatedgcn_fwd: 26 us
+# alone, 34-45 us overlapped).
+_MERGE_PROJ = _os.environ.get("GPS_GEMM_MERGE", "0") != "0"
 
 # The attention half (attention core + out-projection GEMM) and the local half (C GEMM + GatedGCN) of a
 # block only meet at the norm stage, so the attention half can run on its own HIP stream: its latency-bound
