@@ -472,11 +472,13 @@ inline int env_int(const char* name, int dflt) {
   return v && *v ? atoi(v) : dflt;
 }
 inline Plan plan_for(int64_t N, int lanes_per_row, bool forward) {
-  // forward: 512 threads (two 8-wave workgroups per CU cover each other's index staging).  Measured at P30 x 256,
-  // d = 384: isolated, rotating operands 24.6 us against 26.3 us with 768; overlapped with the attention kernel on the
-  // branch stream (GPS_GEMM_MERGE=1 schedule) 34 us against 45 us.  backward: 768 (one workgroup per CU either way:
-  // 140 KB of LDS)
-  static const int fwd_threads = env_int("GPS_GG_FWD_THREADS", 512);
+  // GPS_GG_FWD_THREADS.  Measured at P30 x 256, d = 384 (us per launch):
+  //                                         768 threads   512 threads
+  //   isolated, rotating operands              26.3          24.6     (two 8-wave workgroups per CU cover each other)
+  //   in the captured step, default schedule   26.0          31.7-34.9   (the forked attention kernel runs beside it)
+  //   in the step, GPS_GEMM_MERGE=1            40-45         34
+  // The step is what counts: 768.  backward: 768 (one workgroup per CU either way: 140 KB of LDS)
+  static const int fwd_threads = env_int("GPS_GG_FWD_THREADS", GG_T);
   static const int bwd_threads = env_int("GPS_GG_THREADS", GG_T);
   static const int cfg_target = env_int("GPS_GG_TARGET_WG", 512);
   const int cfg_threads = forward ? fwd_threads : bwd_threads;

@@ -1,15 +1,19 @@
 #!/bin/bash
 set -u
-O=gpurun_out/r2z; mkdir -p $O
-for rep in 1 2; do
-for cfg in "1 768" "0 768" "0 512" "1 512"; do
-set -- $cfg
-GPS_BRANCH_STREAM=$1 GPS_GG_FWD_THREADS=$2 timeout 600 python bench.py --steps 40 --warmup 5 --no-cpu-baseline --no-h2d-leg --launch graph > $O/b.json 2> $O/b.err
-python - $1 $2 <<'PY'
-import json,sys
-d=json.load(open('gpurun_out/r2z/b.json'))
-k=d['kernels']
-print('branch',sys.argv[1],'fwdthreads',sys.argv[2], round(d['ms_per_step'],3), 'gg_fwd in-step us', round(k['gatedgcn_fwd']['in_step_ms']*1e3,1), 'gg_bwd', round(k['gatedgcn_bwd']['in_step_ms']*1e3,1), 'attn fwd', round(k['seg_attn_fwd']['in_step_ms']*1e3,1), 'bwd', round(k['seg_attn_bwd']['in_step_ms']*1e3,1))
+O=gpurun_out/r2v; mkdir -p $O
+timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; echo "bench rc=$?"
+export TMPDIR=/tmp
+cd /tmp; rm -rf /tmp/prof_p
+timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_p -o bench -- python $GRAFT_REPO_ROOT/bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-roofline --no-h2d-leg --no-gemm-tuning > $GRAFT_REPO_ROOT/$O/prof_pcqm4m.json 2> $GRAFT_REPO_ROOT/$O/prof_pcqm4m.log
+DB=$(find /tmp/prof_p -name "*.db" | head -1)
+cd $GRAFT_REPO_ROOT
+if [ -n "$DB" ]; then python tools/rocpd_stats.py $DB --top 70 > $O/kernel_trace_stats_pcqm4m.txt 2>&1; fi
+python - <<'PY'
+import json
+d=json.load(open('gpurun_out/r2v/bench_default.json'))
+print(round(d['ms_per_step'],3), round(d['value']), d['launch_mode'][:14], d['launch_trial_ms'])
+print(json.dumps(d['roofline']))
+for kn,v in d['kernels'].items():
+    print(kn, {a:(round(b,4) if isinstance(b,float) else b) for a,b in v.items() if a in ('in_step_ms','isolated_hot_ms','isolated_rotating_ms','frac')})
 PY
-done
-done
+grep -n "gatedgcn" $O/kernel_trace_stats_pcqm4m.txt | cut -c1-110
