@@ -171,22 +171,11 @@ struct PanelArgs {
   uint64_t seed;
   const uint64_t* salt;
   int row_tiles;
-  int64_t row_base;        // index of row 0 for the (row, column) dropout hash (a launch over a row slice of a larger problem)
   unsigned long long* trace;   // debugging aid (gps_gemm_panel_trace): 4 shader-clock stamps per workgroup, or nullptr
 };
 
 // Epilogue shared by both kernels.  D[row = (q&3) + 8*(q>>2) + 4*kh][col = li] of each 32 x 32 block; 32 lanes = 128
 // contiguous bytes per row.
-// Up to four problems of one (panel height, epilogue, addend) form in ONE launch of the ring kernel: the tiles of all
-// of them are dealt to a persistent grid (one workgroup per CU), so that a problem's last, partly filled dispatch round
-// is filled by the next problem's tiles and no workgroup is re-dispatched (LDS re-allocation, prologue ramp) per tile.
-constexpr int kMaxPanelGroup = 4;
-struct PanelGroup {
-  PanelArgs p[kMaxPanelGroup];
-  int tile_begin[kMaxPanelGroup + 1];     // first global tile of each problem; [n] = total
-  int n;
-};
-
 template <int EPI, bool HAS_CIN>
 __device__ __forceinline__ void panel_epilogue(const PanelArgs& P, const f32x16 (&acc)[3], int64_t m0, int n0, int wm,
                                                int wn, int li, int kh) {
@@ -206,7 +195,7 @@ __device__ __forceinline__ void panel_epilogue(const PanelArgs& P, const f32x16 
       if (EPI == 1) v = fmaxf(v, 0.0f);
       if (EPI == 2) v = P.mask_src[rc * P.ldmask + col] > 0.0f ? v : 0.0f;
       if (EPI != 0) {
-        const bool keep = !drop || keep_elem(row_hash((uint32_t)(rc + P.row_base), seed), (uint32_t)col, P.p_drop);
+        const bool keep = !drop || keep_elem(row_hash((uint32_t)rc, seed), (uint32_t)col, P.p_drop);
         v = keep ? v * inv_keep : 0.0f;
       }
       if (row < P.M) __builtin_nontemporal_store(v, P.C + row * P.ldc + col);
@@ -413,7 +402,7 @@ __device__ __forceinline__ void ring_store(const PanelArgs& P, const f32x16 (&ac
         if (EPI == 1) v = fmaxf(v, 0.0f);
         if (EPI == 2) v = msk[j][q] > 0.0f ? v : 0.0f;
         if (EPI != 0) {
-          const bool keep = !drop || keep_elem(row_hash((uint32_t)(rc + P.row_base), seed), (uint32_t)col, P.p_drop);
+          const bool keep = !drop || keep_elem(row_hash((uint32_t)rc, seed), (uint32_t)col, P.p_drop);
           v = keep ? v * inv_keep : 0.0f;
         }
         if (FULL || row < P.M) __builtin_nontemporal_store(v, P.C + row * P.ldc + col);
@@ -433,15 +422,7 @@ __device__ __forceinline__ void ring_epilogue(const PanelArgs& P, const f32x16 (
 // cycles per stage against 1152 of MFMA issue, i.e. at ~19 bytes / cycle / CU through the global -> LDS path, the same
 // per-CU rate the 256 x 256 bf16 reference kernels sustain -- the load path, not the matrix pipe, was the bound.
 template <int MB, int EPI, bool HAS_CIN>
-__global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring(const PanelGroup GRP) {
-  for (int tile = blockIdx.x; tile < GRP.tile_begin[GRP.n]; tile += gridDim.x) {     // persistent: tiles dealt round-robin
-  int pi = 0;
-#pragma unroll
-  for (int i = 1; i < kMaxPanelGroup; ++i)
-    if (i < GRP.n && tile >= GRP.tile_begin[i]) pi = i;
-  const PanelArgs& P = GRP.p[pi];
-  const int ltile = tile - GRP.tile_begin[pi];
-  if (tile != (int)blockIdx.x) __syncthreads();   // the previous tile's last LDS reads are done before this one's DMA lands
+__global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring(const PanelArgs P) {
   constexpr int TMV = 64 * MB;                  // panel rows
   constexpr int A_BYTES = rg_a_bytes(MB), SLOT = rg_slot_bytes(MB);
   constexpr int NA = 2 * MB;                    // A transfers per wave and stage (8 rows x 128 B each)
@@ -451,10 +432,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring(const PanelGroup GRP)
   constexpr int SPLIT0 = G - 12 * MB - (MB > 1 ? 2 : 0);  // first gap of the A split (4 * MB pairs x 3 instalments)
   extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];
   auto stamp = [&](int k) __attribute__((always_inline)) {
-    if (P.trace && threadIdx.x == 0) P.trace[4 * (size_t)tile + k] = __builtin_amdgcn_s_memtime();
+    if (P.trace && threadIdx.x == 0) P.trace[4 * (size_t)blockIdx.x + k] = __builtin_amdgcn_s_memtime();
   };
   stamp(0);
-  const int panel = ltile / P.row_tiles, rt = ltile - panel * P.row_tiles;   // panel-major numbering
+  const int panel = blockIdx.x / P.row_tiles, rt = blockIdx.x - panel * P.row_tiles;   // panel-major numbering
   const int64_t m0 = (int64_t)rt * TMV;
   const int n0 = panel * TN;
   const int t = threadIdx.x, lane = t & 63;
@@ -626,7 +607,6 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring(const PanelGroup GRP)
   ring_epilogue<MB, EPI, HAS_CIN>(P, acc, m0, n0, wm, wn, li, kh);
   __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 15));
   stamp(3);
-  }   // tile loop
 }
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) % 16) == 0; }
@@ -664,104 +644,62 @@ int gps_gemm_split_weights(int n, const gps_gemm_split* descs, gps_stream_t stre
   return gps::launch_status("gps_gemm_split_weights");
 }
 
-namespace {
-int fill_panel_args(PanelArgs& P, const gps_gemm_panel_desc& d, const char* who) {
-  GPS_REQUIRE(d.M >= 0 && gps_gemm_panel_supported(d.N, d.K), "%s: needs N %% 192 == 0 and K %% 128 == 0 (N=%d K=%d)", who, d.N, d.K);
-  GPS_REQUIRE(d.A && d.image && d.C && d.lda >= d.K && d.ldc >= d.N && d.lda % 4 == 0 && al16(d.A) && al16(d.image),
-              "%s: null / misaligned buffer", who);
-  GPS_REQUIRE(!d.Cin || d.ldcin >= d.N, "%s: bad addend stride", who);
-  GPS_REQUIRE(d.epilogue >= 0 && d.epilogue <= 2 && (d.epilogue != 2 || (d.mask_src && d.ldmask >= d.N)), "%s: epilogue", who);
-  GPS_REQUIRE(d.p_drop >= 0.0f && d.p_drop < 1.0f, "%s: p_drop", who);
-  P = PanelArgs{};
-  P.A = d.A; P.lda = d.lda; P.M = d.M; P.K = d.K; P.N = d.N; P.Bp = d.image; P.bias = d.bias; P.Cin = d.Cin; P.ldcin = d.ldcin;
-  P.C = d.C; P.ldc = d.ldc; P.epilogue = d.epilogue; P.mask_src = d.mask_src; P.ldmask = d.ldmask;
-  P.p_drop = d.epilogue ? d.p_drop : 0.0f; P.seed = d.seed; P.salt = gps::dropout_salt();
-  P.row_tiles = (int)((d.M + TM - 1) / TM);
-  P.row_base = d.row_base;
+int gps_gemm_panel(const float* A, int64_t lda, int64_t M, int K, const uint16_t* image, int N, const float* bias,
+                   const float* Cin, int64_t ldcin, float* C, int64_t ldc, int epilogue, const float* mask_src,
+                   int64_t ldmask, float p_drop, uint64_t seed, gps_stream_t stream) {
+  GPS_REQUIRE(M >= 0 && gps_gemm_panel_supported(N, K), "gps_gemm_panel: needs N %% 192 == 0 and K %% 128 == 0 (N=%d K=%d)",
+              N, K);
+  if (M == 0) return GPS_OK;
+  GPS_REQUIRE(A && image && C && lda >= K && ldc >= N && lda % 4 == 0 && al16(A) && al16(image),
+              "gps_gemm_panel: null / misaligned buffer");
+  GPS_REQUIRE(!Cin || ldcin >= N, "gps_gemm_panel: bad addend stride");
+  GPS_REQUIRE(epilogue >= 0 && epilogue <= 2 && (epilogue != 2 || (mask_src && ldmask >= N)), "gps_gemm_panel: epilogue");
+  GPS_REQUIRE(p_drop >= 0.0f && p_drop < 1.0f, "gps_gemm_panel: p_drop");
+  PanelArgs P{};
+  P.A = A; P.lda = lda; P.M = M; P.K = K; P.N = N; P.Bp = image; P.bias = bias; P.Cin = Cin; P.ldcin = ldcin;
+  P.C = C; P.ldc = ldc; P.epilogue = epilogue; P.mask_src = mask_src; P.ldmask = ldmask;
+  P.p_drop = epilogue ? p_drop : 0.0f; P.seed = seed; P.salt = gps::dropout_salt();
+  P.row_tiles = (int)((M + TM - 1) / TM);
   P.trace = g_panel_trace;
-  return GPS_OK;
-}
-}  // namespace
-
-int gps_gemm_panel_multi(int n, const gps_gemm_panel_desc* descs, gps_stream_t stream) {
-  GPS_REQUIRE(n >= 1 && n <= kMaxPanelGroup && descs, "gps_gemm_panel_multi: 1..%d problems per launch", kMaxPanelGroup);
+  unsigned grid = (unsigned)(P.row_tiles * (N / TN));
   hipStream_t s = gps::as_stream(stream);
   // ring kernel (LDS-DMA, three-slot ring) whenever the k-stages come in threes; GPS_GEMM_RING=0 keeps the
   // register-staged kernel (A/B measurements).  128-row panels when they still give every CU a workgroup
   // (GPS_GEMM_RING_MB = 1 / 2 forces one).
   static const int ring_cfg = []() { const char* v = getenv("GPS_GEMM_RING"); return v && *v ? atoi(v) : 1; }();
   static const int mb_cfg = []() { const char* v = getenv("GPS_GEMM_RING_MB"); return v && *v ? atoi(v) : 0; }();
-  static const int n_cu = []() { int v = 0; return hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, 0) == hipSuccess && v > 0 ? v : 256; }();
-  PanelGroup G{};
-  bool ring = ring_cfg != 0;
-  int64_t tiles128 = 0;
-  int live = 0;
-  for (int i = 0; i < n; ++i) {
-    if (descs[i].M == 0) continue;
-    PanelArgs& P = G.p[live];
-    if (int rc = fill_panel_args(P, descs[i], "gps_gemm_panel")) return rc;
-    GPS_REQUIRE(P.epilogue == G.p[0].epilogue && (P.Cin != nullptr) == (G.p[0].Cin != nullptr),
-                "gps_gemm_panel_multi: the problems of one launch share the epilogue form and the presence of an addend");
-    ring = ring && (P.K / BK) % RG_SLOTS == 0 && P.K / BK >= RG_SLOTS;
-    tiles128 += ((P.M + 127) / 128) * (P.N / TN);
-    ++live;
-  }
-  if (live == 0) return GPS_OK;
-  G.n = live;
-  const int epilogue = G.p[0].epilogue;
-  const bool has_cin = G.p[0].Cin != nullptr;
-  if (!ring) {        // register-staged kernel: one launch per problem
-    for (int i = 0; i < live; ++i) {
-      const PanelArgs& P = G.p[i];
-      const unsigned grid = (unsigned)(P.row_tiles * (P.N / TN));
-      if (epilogue == 0) { if (has_cin) k_gemm_panel<0, true><<<grid, NTHREADS, 0, s>>>(P); else k_gemm_panel<0, false><<<grid, NTHREADS, 0, s>>>(P); }
-      else if (epilogue == 1) { if (has_cin) k_gemm_panel<1, true><<<grid, NTHREADS, 0, s>>>(P); else k_gemm_panel<1, false><<<grid, NTHREADS, 0, s>>>(P); }
-      else { if (has_cin) k_gemm_panel<2, true><<<grid, NTHREADS, 0, s>>>(P); else k_gemm_panel<2, false><<<grid, NTHREADS, 0, s>>>(P); }
-    }
-    return gps::launch_status("gps_gemm_panel");
-  }
+  const bool ring = ring_cfg != 0 && (K / BK) % RG_SLOTS == 0 && K / BK >= RG_SLOTS;
+  const int64_t tiles128 = ((M + 127) / 128) * (N / TN);
   const int mb = mb_cfg == 1 || mb_cfg == 2 ? mb_cfg : (tiles128 >= 200 ? 2 : 1);
-  int total = 0;
-  for (int i = 0; i < live; ++i) {
-    PanelArgs& P = G.p[i];
+  if (ring) {
     if (!P.bias) {
-      GPS_REQUIRE(P.N <= kZeroBias, "gps_gemm_panel: N=%d without a bias exceeds the built-in zero row (%d)", P.N, kZeroBias);
+      GPS_REQUIRE(N <= kZeroBias, "gps_gemm_panel: N=%d without a bias exceeds the built-in zero row (%d)", N, kZeroBias);
       static float* zeros = []() { void* p = nullptr; return hipGetSymbolAddress(&p, HIP_SYMBOL(g_zero_bias)) == hipSuccess ? (float*)p : nullptr; }();
       GPS_REQUIRE(zeros, "gps_gemm_panel: zero-bias symbol");
       P.bias = zeros;
     }
-    P.row_tiles = (int)((P.M + 64 * mb - 1) / (64 * mb));
-    G.tile_begin[i] = total;
-    total += P.row_tiles * (P.N / TN);
+    P.row_tiles = (int)((M + 64 * mb - 1) / (64 * mb));
+    grid = (unsigned)(P.row_tiles * (N / TN));
   }
-  for (int i = live; i <= kMaxPanelGroup; ++i) G.tile_begin[i] = total;
-  const unsigned grid = (unsigned)(total < n_cu ? total : n_cu);     // persistent: one workgroup per CU
 #define GPS_RING_LAUNCH(MBV, E, C)                                                                    \
   do {                                                                                                \
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring<MBV, E, C>), \
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, rg_lds_bytes(MBV)); \
     GPS_REQUIRE(attr == hipSuccess, "gps_gemm_panel: cannot reserve %d bytes of LDS", rg_lds_bytes(MBV));      \
-    k_gemm_ring<MBV, E, C><<<grid, NTHREADS, rg_lds_bytes(MBV), s>>>(G);                              \
+    k_gemm_ring<MBV, E, C><<<grid, NTHREADS, rg_lds_bytes(MBV), s>>>(P);                              \
   } while (0)
 #define GPS_PANEL_LAUNCH(E, C)                                                                        \
   do {                                                                                                \
-    if (mb == 2) GPS_RING_LAUNCH(2, E, C); else GPS_RING_LAUNCH(1, E, C);                             \
+    if (ring && mb == 2) GPS_RING_LAUNCH(2, E, C);                                                    \
+    else if (ring) GPS_RING_LAUNCH(1, E, C);                                                          \
+    else k_gemm_panel<E, C><<<grid, NTHREADS, 0, s>>>(P);                                             \
   } while (0)
-  if (epilogue == 0) { if (has_cin) GPS_PANEL_LAUNCH(0, true); else GPS_PANEL_LAUNCH(0, false); }
-  else if (epilogue == 1) { if (has_cin) GPS_PANEL_LAUNCH(1, true); else GPS_PANEL_LAUNCH(1, false); }
-  else { if (has_cin) GPS_PANEL_LAUNCH(2, true); else GPS_PANEL_LAUNCH(2, false); }
+  if (epilogue == 0) { if (Cin) GPS_PANEL_LAUNCH(0, true); else GPS_PANEL_LAUNCH(0, false); }
+  else if (epilogue == 1) { if (Cin) GPS_PANEL_LAUNCH(1, true); else GPS_PANEL_LAUNCH(1, false); }
+  else { if (Cin) GPS_PANEL_LAUNCH(2, true); else GPS_PANEL_LAUNCH(2, false); }
 #undef GPS_RING_LAUNCH
 #undef GPS_PANEL_LAUNCH
   return gps::launch_status("gps_gemm_panel");
-}
-
-int gps_gemm_panel(const float* A, int64_t lda, int64_t M, int K, const uint16_t* image, int N, const float* bias,
-                   const float* Cin, int64_t ldcin, float* C, int64_t ldc, int epilogue, const float* mask_src,
-                   int64_t ldmask, float p_drop, uint64_t seed, gps_stream_t stream) {
-  gps_gemm_panel_desc d{};
-  d.A = A; d.lda = lda; d.M = M; d.K = K; d.image = image; d.N = N; d.bias = bias; d.Cin = Cin; d.ldcin = ldcin;
-  d.C = C; d.ldc = ldc; d.epilogue = epilogue; d.mask_src = mask_src; d.ldmask = ldmask; d.p_drop = p_drop; d.seed = seed;
-  return gps_gemm_panel_multi(1, &d, stream);
 }
 
 }  // extern "C"

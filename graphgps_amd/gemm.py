@@ -65,36 +65,3 @@ def gemm_panel(a: torch.Tensor, image: torch.Tensor, N: int, bias: Optional[torc
                            ptr(mask_src), mask_src.stride(0) if mask_src is not None else 0, float(p_drop),
                            int(seed), current_stream(a.device)), "gps_gemm_panel")
     return out
-
-
-def gemm_panel_multi(problems: Sequence[dict]) -> List[torch.Tensor]:
-    """Several :func:`gemm_panel` problems (keyword dicts: ``a, image, N`` and optionally ``bias, addend, out,
-    epilogue, mask_src, p_drop, seed``) as ONE launch on a persistent grid -- all with the same epilogue form and all
-    with or all without an addend.  Returns the outputs in order."""
-    L = _lib.load()
-    n = len(problems)
-    descs = (_lib.GemmPanelDesc * n)()
-    outs, keep = [], []
-    for q, pr in zip(descs, problems):
-        a, image, N = pr["a"], pr["image"], int(pr["N"])
-        M, K = a.shape
-        if a.stride(1) != 1 or a.dtype != torch.float32:
-            raise _lib.GpsHipError("gemm_panel_multi: fp32 A with unit column stride")
-        out = pr.get("out")
-        if out is None:
-            out = torch.empty(M, N, dtype=torch.float32, device=a.device)
-        bias, addend, mask_src = pr.get("bias"), pr.get("addend"), pr.get("mask_src")
-        q.A, q.lda, q.M, q.K = a.data_ptr(), a.stride(0), M, K
-        q.image, q.N = image.data_ptr(), N
-        q.bias = bias.data_ptr() if bias is not None else None
-        q.Cin = addend.data_ptr() if addend is not None else None
-        q.ldcin = addend.stride(0) if addend is not None else 0
-        q.C, q.ldc = out.data_ptr(), out.stride(0)
-        q.epilogue = int(pr.get("epilogue", 0))
-        q.mask_src = mask_src.data_ptr() if mask_src is not None else None
-        q.ldmask = mask_src.stride(0) if mask_src is not None else 0
-        q.p_drop, q.seed = float(pr.get("p_drop", 0.0)), int(pr.get("seed", 0)) & 0xFFFFFFFFFFFFFFFF
-        outs.append(out)
-        keep.append((a, image, bias, addend, mask_src))
-    check(L.gps_gemm_panel_multi(n, descs, current_stream(problems[0]["a"].device)), "gps_gemm_panel_multi")
-    return outs

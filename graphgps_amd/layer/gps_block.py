@@ -136,12 +136,6 @@ def _grouped_param_grads(L, pairs, params=()):
 
 
 _GROUPED_WGRAD = _os.environ.get("GPS_WGRAD_GROUPED", "1") != "0"
-# GPS_GEMM_MERGE=1: x -> A|B|D|E|QKV and e -> Ce as ONE launch on the ring kernel's persistent grid.  Same-box A/B,
-# three runs each: 10.30 vs 10.36 ms per step (-0.6 %).  Off by default: without the separate edge-projection launch
-# the GatedGCN forward starts together with the forked attention kernel and the two overlap for their whole length, so
-# neither kernel's in-step duration (what bench.py's roofline line reports) is its own any more (k_gatedgcn_fwd: 26 us
-# alone, 34-45 us overlapped).
-_MERGE_PROJ = _os.environ.get("GPS_GEMM_MERGE", "0") != "0"
 
 # The attention half (attention core + out-projection GEMM) and the local half (C GEMM + GatedGCN) of a
 # block only meet at the norm stage, so the attention half can run on its own HIP stream: its latency-bound
@@ -229,14 +223,7 @@ class _GPSBlock(torch.autograd.Function):
         if panel:       # weight images of the block's five projections (W and W^T), ONE launch per layer and step
             imgs = _gemm.split_weights([wcat, lm.C.weight, sa.out_proj.weight, layer.ff_linear1.weight,
                                         layer.ff_linear2.weight])
-            # x -> A|B|D|E|QKV and e -> Ce are independent: one launch on the persistent grid (the edge projection's
-            # panels fill the merged projection's last dispatch round)
-            if _MERGE_PROJ:
-                pq, ce = _gemm.gemm_panel_multi([dict(a=x, image=imgs[0][0], N=7 * d, bias=bcat),
-                                                 dict(a=e, image=imgs[1][0], N=d, bias=lm.C.bias)])
-            else:
-                pq = _gemm.gemm_panel(x, imgs[0][0], 7 * d, bias=bcat)
-                ce = _gemm.gemm_panel(e, imgs[1][0], d, bias=lm.C.bias)
+            pq = _gemm.gemm_panel(x, imgs[0][0], 7 * d, bias=bcat)
         else:
             pq = torch.addmm(bcat, x, wcat.t())                 # [N, 4d + 3d]
         ldp = 7 * d
@@ -252,8 +239,8 @@ class _GPSBlock(torch.autograd.Function):
             ao = (_gemm.gemm_panel(o, imgs[2][0], d, bias=sa.out_proj.bias) if panel
                   else torch.addmm(sa.out_proj.bias, o, sa.out_proj.weight.t()))
         # -- local branch: C projection + GatedGCN core ----------------------------------------
-        if not panel:
-            ce = torch.addmm(lm.C.bias, e, lm.C.weight.t())
+        ce = (_gemm.gemm_panel(e, imgs[1][0], d, bias=lm.C.bias) if panel
+              else torch.addmm(lm.C.bias, e, lm.C.weight.t()))
         xt, eh = _E(N, d, **f32), _E(E, d, **f32)
         check(L.gps_gatedgcn_fwd(P, P + fs, P + 2 * fs, P + 3 * fs, ldp, ptr(ce), ptr(gi.rowptr_dst),
                                  ptr(gi.src_by_dst), ptr(gi.eid_by_dst), N, E, d, ptr(xt), ptr(eh),

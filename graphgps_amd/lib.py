@@ -91,7 +91,6 @@ _SIGNATURES = {
     "gps_gemm_panel_supported": (c_int, [c_int64, c_int64]),
     "gps_gemm_split_weights": (c_int, [c_int, _P, _P]),
     "gps_gemm_panel_trace": (c_int, [_P]),
-    "gps_gemm_panel_multi": (c_int, [c_int, _P, _P]),
     "gps_gemm_panel": (c_int, [_P, c_int64, c_int64, c_int, _P, c_int, _P, _P, c_int64, _P, c_int64, c_int, _P,
                                c_int64, c_float, c_uint64, _P]),
     "gps_gcn_dinv": (c_int, [_P, _P, c_int64, c_int64, _P, _P]),
@@ -124,15 +123,6 @@ class GemmSplit(ctypes.Structure):
     """``gps_gemm_split`` (include/gps_hip.h)."""
     _fields_ = [("W", c_void_p), ("ldw", c_int64), ("rows", ctypes.c_int32), ("cols", ctypes.c_int32),
                 ("image_nt", c_void_p), ("image_tn", c_void_p)]
-
-
-class GemmPanelDesc(ctypes.Structure):
-    """``gps_gemm_panel_desc`` (include/gps_hip.h)."""
-    _fields_ = [("A", c_void_p), ("lda", c_int64), ("M", c_int64), ("K", ctypes.c_int32),
-                ("image", c_void_p), ("N", ctypes.c_int32), ("bias", c_void_p),
-                ("Cin", c_void_p), ("ldcin", c_int64), ("C", c_void_p), ("ldc", c_int64),
-                ("epilogue", ctypes.c_int32), ("mask_src", c_void_p), ("ldmask", c_int64),
-                ("p_drop", ctypes.c_float), ("seed", ctypes.c_uint64), ("row_base", c_int64)]
 
 
 class GpsHipError(RuntimeError):

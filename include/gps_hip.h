@@ -190,22 +190,6 @@ typedef struct gps_gemm_split {
 size_t gps_gemm_image_elems(int64_t N, int64_t K);
 int gps_gemm_panel_supported(int64_t N, int64_t K);
 int gps_gemm_split_weights(int n, const gps_gemm_split* descs, gps_stream_t stream);   /* n <= 8, one launch */
-/* Several gps_gemm_panel problems (same epilogue form, all with or all without an addend) as ONE launch on a
- * persistent grid: the tiles of all of them are dealt to one workgroup per CU, so a problem's partly filled last
- * dispatch round is filled by the next problem's tiles (forward of the block: x -> A|B|D|E|QKV together with e -> Ce).
- * Field meanings as the arguments of gps_gemm_panel. */
-typedef struct gps_gemm_panel_desc {
-  const float* A; int64_t lda; int64_t M; int K;
-  const uint16_t* image; int N;
-  const float* bias;
-  const float* Cin; int64_t ldcin;
-  float* C; int64_t ldc;
-  int epilogue; const float* mask_src; int64_t ldmask; float p_drop; uint64_t seed;
-  int64_t row_base;   /* index of A's row 0 in the (row, column) dropout hash: 0, or the slice offset when the rows of one
-                         logical problem are given as several problems */
-} gps_gemm_panel_desc;
-int gps_gemm_panel_multi(int n, const gps_gemm_panel_desc* descs, gps_stream_t stream);
-
 /* Debugging aid (tools/gemm_trace.py): the ring kernel stamps s_memtime per workgroup into buf (4 x uint64 each);
  * NULL switches it off. */
 int gps_gemm_panel_trace(unsigned long long* buf);
