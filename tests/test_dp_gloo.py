@@ -297,8 +297,17 @@ def test_param_arena_keeps_linear_group_stacks_and_follows_moves():
     # a parameter leaves (what .to() / a re-stack does): detected, re-adopted, values kept
     extra.weight.data = extra.weight.data.clone()
     assert not arena.intact()
+    n_before = arena.flat_p.numel()
     arena.adopt()
     assert arena.intact() and torch.equal(lins[1].weight, want_w[8:16] * 2)
+    # re-adoption re-packs: the parameters that stayed do not drag the old arena's span (and the hole the leaver left)
+    # along -- the flat buffer a data-parallel step all-reduces stays the size of the parameters
+    assert arena.flat_p.numel() <= n_before
+    w2, b2 = grp._stacked()                       # the group adopted earlier is still one contiguous block
+    for l, rows in zip(lins, range(0, 24, 8)):
+        assert l.weight.data_ptr() == w2.data_ptr() + rows * 8 * 4
+    lo2, hi2 = arena.flat_p.data_ptr(), arena.flat_p.data_ptr() + arena.flat_p.numel() * 4
+    assert lo2 <= w2.data_ptr() < hi2
     # gradients: packed into the flat buffer, None -> inactive and zero
     for p in params:
         p.grad = torch.full_like(p, 3.0)
