@@ -144,14 +144,14 @@ def add_dropout(a: torch.Tensor, b: torch.Tensor, p_drop: float, training: bool,
 #     the code2 configuration: with the transposed library GEMM of the 25010-wide head (g^T x, K = 32 rows) on
 #     the CAPTURE stream the replay dies with "Write access to a read-only page" (MI355X, ROCm 7.0.2 / torch
 #     2.10; eager is fine, zinc is fine, the same step with that GEMM on this persistent side stream is fine
-#     -- tools/gpu_r2w.sh).  The GEMM's workspace is the only allocation whose lifetime differs; not chased
+#     -- tools/runs/gpu_r2w.sh).  The GEMM's workspace is the only allocation whose lifetime differs; not chased
 #     further, the default avoids it.
 #   * layer/gps_block.py (the fused CustomGatedGCN+Transformer block): GPS_BLOCK_WGRAD_SIDE_STREAM, default OFF.
 #     It paid while the projection GEMMs left half of every CU's LDS free (12.2 vs 12.6 ms per step); the ring
 #     GEMM (csrc/gemm_panel.hip) owns a CU's whole LDS, so a co-scheduled weight-gradient workgroup and a ring
 #     workgroup exclude each other from the CU, and one stream replayed as a hipGraph is faster: 11.39 ms
 #     (graph, one stream) vs 11.60 ms (eager, two streams), PCQM4M GPS-medium step before the streaming
-#     weight-gradient kernel (tools/gpu_r2q.sh).
+#     weight-gradient kernel (tools/runs/gpu_r2q.sh).
 import os as _os
 
 _SIDE_ENABLED = _os.environ.get("GPS_WGRAD_SIDE_STREAM", "1") != "0"
