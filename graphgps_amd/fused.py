@@ -140,12 +140,10 @@ def add_dropout(a: torch.Tensor, b: torch.Tensor, p_drop: float, training: bool,
 #
 # Two switches since round 2:
 #   * this file (nn.Linear-shaped modules outside the fused block: encoders, heads, the Performer / GINE / SAN
-#     layers): side stream ON by default, as validated in round 1.  Do not turn it off under hipGraph capture on
-#     the code2 configuration: with the transposed library GEMM of the 25010-wide head (g^T x, K = 32 rows) on
-#     the CAPTURE stream the replay dies with "Write access to a read-only page" (MI355X, ROCm 7.0.2 / torch
-#     2.10; eager is fine, zinc is fine, the same step with that GEMM on this persistent side stream is fine
-#     -- tools/runs/gpu_r2w.sh).  The GEMM's workspace is the only allocation whose lifetime differs; not chased
-#     further, the default avoids it.
+#     layers): side stream ON by default, as validated in round 1.  (Turned off, the captured code2 step used to die at
+#     replay with "Write access to a read-only page": a one-stream capture is a purely linear hipGraph, which this
+#     runtime mishandles -- train.py:TrainStep.capture now adds a trivial forked node to every capture; DESIGN.md
+#     section 7, tools/runs/gpu_r2w.sh.)
 #   * layer/gps_block.py (the fused CustomGatedGCN+Transformer block): GPS_BLOCK_WGRAD_SIDE_STREAM, default OFF.
 #     It paid while the projection GEMMs left half of every CU's LDS free (12.2 vs 12.6 ms per step); the ring
 #     GEMM (csrc/gemm_panel.hip) owns a CU's whole LDS, so a co-scheduled weight-gradient workgroup and a ring

@@ -143,7 +143,8 @@ _GROUPED_WGRAD = _os.environ.get("GPS_WGRAD_GROUPED", "1") != "0"
 # in the graph (no host cost; measured 13.18 -> 13.00 ms/step); launched eagerly the extra stream switches
 # cost more host time than the overlap returns (13.3 -> 13.7..16.7 ms), so the fork is only taken while
 # the step is being CAPTURED.  GPS_BRANCH_STREAM=0 disables it, =2 forces it in eager mode too.
-# (Known issue, DESIGN.md section 7: with =0 the captured PCQM4M step is a one-stream capture and its replay faults.)
+# (With =0 the captured PCQM4M step is a one-stream capture; train.py:TrainStep.capture adds a trivial forked node so
+# that the resulting purely linear hipGraph does not trip the runtime -- DESIGN.md section 7.)
 _BRANCH = _os.environ.get("GPS_BRANCH_STREAM", "1")
 _branch_streams = {}
 

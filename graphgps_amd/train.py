@@ -19,6 +19,8 @@ from __future__ import annotations
 import time
 from typing import Callable, Optional
 
+import os as _os
+
 import torch
 
 from .graphgym.config import cfg
@@ -123,10 +125,24 @@ class TrainStep:
         self.opt.sync_hyper()
         split = self.exchange is not None and self.exchange.active
         g_fb = torch.cuda.CUDAGraph()
+        # A capture that stays on ONE stream -- a linear chain of ~600 kernel nodes -- dies at replay with "Write access to
+        # a read-only page" on this stack (ROCm 7.0.2 runtime under torch 2.10; PCQM4M step without the forked attention
+        # branch, code2 step without the weight-gradient stream), while the same kernels captured with any second branch
+        # joined in replay fine.  One trivial forked node (a 4-byte add on a second stream, joined at the end) is enough
+        # to avoid it and costs nothing, so every capture gets one.  GPS_CAPTURE_TICK=0 removes it (to reproduce).
+        tick = torch.zeros(1, device=dev) if _os.environ.get("GPS_CAPTURE_TICK", "1") != "0" else None
         with torch.cuda.graph(g_fb, capture_error_mode="thread_local"):
+            if tick is not None:
+                cur = torch.cuda.current_stream(dev)
+                tside = torch.cuda.Stream(device=dev)
+                tside.wait_stream(cur)
+                with torch.cuda.stream(tside):
+                    tick.add_(1.0)
             loss, _, _ = self.forward_backward(make_batch())
             if not split:
                 self.update()
+            if tick is not None:
+                torch.cuda.current_stream(dev).wait_stream(tside)
         g_up = None
         if split:
             g_up = torch.cuda.CUDAGraph()
