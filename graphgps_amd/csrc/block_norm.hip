@@ -1,44 +1,44 @@
-// Task-list BatchNorm / residual / dropout kernels for one CustomGatedGCN+Transformer GPS block.
+// Task-list BatchNorm / residual / dropout kernels of the fused GPS blocks (graphgps_amd/layer/gps_block.py).
 //
-// bn_fused.hip gives every BatchNorm1d of the reference block its own three launches (partial
-// statistics, finalize, apply) plus one launch per residual+dropout (gatedgcn_layer.py:72-83,
-// gps_layer.py:191-194,212-217,225-229): 18 forward + 19 backward launches per layer of 5-10 us
-// each -- latency-bound kernels that the PCQM4M-size step cannot hide.  Here the same arithmetic
-// (same formulas, same counter-hash dropout, same two-pass statistics) is issued as LISTS of up to
-// four independent row-stream tasks per launch, and neighbouring stages are merged:
+// Reference stages: graphgps/layer/gatedgcn_layer.py:72-83 (bn_node_x / bn_edge_e, ReLU, dropout, residual),
+// graphgps/layer/gps_layer.py:191-194,212-229 (norm1_local, norm1_attn, the h_local + h_attn sum, norm2) and their
+// autograd backward.  bn_fused.hip gives every BatchNorm1d its own three launches (partial statistics, finalize, apply)
+// plus one launch per residual + dropout: 37 launches per layer.  Round 1 issued the same arithmetic as LISTS of up to
+// four independent row-stream tasks per launch (19 launches per layer, 17 in round 2).  Round 3:
+//   * no finalize launches: every kernel that produces column partials (batch statistics forward, sum g / sum g*zhat
+//     backward) completes them in-launch through csrc/col_tree.hpp (write-through records, arrival tickets, the last
+//     arriver of a group / of the tree combines in index order: deterministic, nobody waits);
+//   * the backward applies are row-block kernels like the partials (column constants loaded once per thread, two rows in
+//     flight) and can CHAIN: while a task writes the gradient it produces, it accumulates the column partials of the next
+//     BatchNorm backward that consumes that gradient (norm1_local's g_x1 -> bn_node_x's sum g, sum g*zhat), which removes
+//     that BatchNorm's own partial pass;
+//   * the C ABI is a generic task list (gps_norm_fwd / gps_norm_bwd_partial / gps_norm_bwd_apply), composed by the host.
+// Launches per CustomGatedGCN+Transformer layer: forward mid + dual apply + norm2 apply (statistics of x~ / e^ come from
+// the GatedGCN kernel, those of z2 and za from the ring GEMM epilogues), backward 5  =>  8 (round 2: 17).
 //
-//   forward   stats{x~, e^}                                           partial + finalize
-//             {x1 = x + drop(relu(BN_x(x~))) [+ stats of x1],
-//              e1 = e + drop(relu(BN_e(e^))),
-//              za = x + drop(attn_out)       [+ stats of za]}         one launch
-//             finalize{x1, za}
-//             h = BN_l(x1) + BN_a(za)                                 one launch (dual apply)
-//             z2 = h + drop(ffn_out) [+ stats] ; finalize ; BN_2      three launches
-//   backward  BN_2: partial, finalize, apply -> (g_z2, g_f2 = dropmask(g_z2))
-//             {BN_l, BN_a} share dL/dh: partial (reads dL/dh once), finalize,
-//                 apply -> (g_x1, g_x1 + g_za, g_ao = dropmask(g_za))
-//             {BN_x, BN_e}: partial, finalize, apply as two-task lists
-//
-// 10 + 9 launches instead of 18 + 19, ~25 % less HBM traffic on these stages.
-// Row kernels keep the lane-owns-4-channels mapping (d % 4 == 0, d <= 1024).
+// Row kernels keep the lane-owns-4-channels mapping (d % 4 == 0, d <= 1024): a workgroup is RS rows x d/4 lanes
+// (RS = 512 / (d/4): 384 threads at d = 384), rows of a block are walked RS at a time, two passes in flight.
 #include <algorithm>
 
+#include "col_tree.hpp"
 #include "gps_common.hpp"
 #include "vec.hpp"
 
 namespace {
 
-constexpr int TARGET_BLOCKS = 512;       // stage-1 partial blocks per task (~2 per CU)
-constexpr int FCOLS = 16, FCHUNKS = 16;  // stage-2 block = 16 columns x 16 partial-list chunks
-constexpr int FPER = (TARGET_BLOCKS + FCHUNKS - 1) / FCHUNKS;
+namespace tr = gps::tree;
+
+constexpr int TARGET_BLOCKS = 512;       // row blocks per task (~2 per CU); <= tr::kMaxParts
+constexpr int kMaxThreads = 512;
 constexpr int kMaxTasks = 4;
+constexpr int MAXI = tr::kMaxFan;
 typedef Vec<4> V4;
 
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
   x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
   return x;
 }
-// identical to bn_fused.hip / seg_attention.hip: (row id, element index) -> keep decision
+// identical to bn_fused.hip / gemm_panel.hip: (row id, element index) -> keep decision
 __device__ __forceinline__ uint32_t row_hash(uint32_t rowid, uint64_t seed) {
   return mix32(rowid ^ (uint32_t)seed) + (uint32_t)(seed >> 32);
 }
@@ -60,6 +60,25 @@ __device__ __forceinline__ Col load_col(const Bn& b, int c) {
   return o;
 }
 
+// reduce `NVEC` per-thread column vectors over the RS row lanes of the block (fixed order); result valid for rsub == 0
+template <int NVEC>
+__device__ __forceinline__ void reduce_rows(V4 (&s)[NVEC], float* lds, int d, int RS, int rsub, int c) {
+  if (rsub > 0) {
+#pragma unroll
+    for (int v = 0; v < NVEC; ++v)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) lds[(rsub * NVEC + v) * d + c + j] = s[v][j];
+  }
+  __syncthreads();
+  if (rsub == 0) {
+    for (int q = 1; q < RS; ++q)
+#pragma unroll
+      for (int v = 0; v < NVEC; ++v)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[v][j] += lds[(q * NVEC + v) * d + c + j];
+  }
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward: produce rows (optionally store them, optionally accumulate their column statistics)
 // ------------------------------------------------------------------------------------------------
@@ -68,12 +87,12 @@ enum { K_LOAD = 0, K_ADD_DROP = 1, K_BN_ACT = 2, K_BN_DUAL = 3 };
 struct FwdTask {
   const float *a, *b, *res;
   Bn bn1, bn2;
-  float* out;     // produced rows (nullptr: K_LOAD)
-  float* ws;      // [nblk][2][d] (mean_b, M2_b) of the produced rows, or nullptr
+  float* out;     // produced rows (nullptr: statistics only)
   int64_t R;
   uint64_t seed;
   float p;
-  int kind, relu, rpb, nblk, block_begin;
+  int kind, relu, rpb, nblk, block_begin, has_stats;
+  tr::Tree tree;  // statistics of the produced rows
 };
 struct FwdGroup {
   FwdTask t[kMaxTasks];
@@ -81,106 +100,107 @@ struct FwdGroup {
   int n, d;
 };
 
+struct RowIn {
+  V4 a, b, r;
+};
+template <int KIND>
+__device__ __forceinline__ RowIn load_in(const FwdTask& T, int64_t row, int c, int d) {
+  RowIn in;
+  in.a = V4::load(T.a + row * d + c);
+  in.b = (KIND == K_ADD_DROP || KIND == K_BN_DUAL) ? V4::load(T.b + row * d + c) : V4::zero();
+  in.r = (KIND == K_BN_ACT && T.res) ? V4::load(T.res + row * d + c) : V4::zero();
+  return in;
+}
 template <int KIND, bool RELU, bool DROP>
-__device__ __forceinline__ V4 eval_row(const FwdTask& T, int64_t r, int c, int d, const Col& c1,
-                                       const Col& c2, uint64_t seed, float inv_keep) {
+__device__ __forceinline__ V4 eval_row(const FwdTask& T, const RowIn& in, int64_t r, int c, const Col& c1, const Col& c2,
+                                       uint64_t seed, float inv_keep) {
   V4 o;
   if (KIND == K_LOAD) {
-    o = V4::load(T.a + r * d + c);
+    o = in.a;
   } else if (KIND == K_ADD_DROP) {             // a + drop(b)
-    const V4 a = V4::load(T.a + r * d + c), b = V4::load(T.b + r * d + c);
     const uint32_t rh = DROP ? row_hash((uint32_t)r, seed) : 0u;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      float u = b[j];
+      float u = in.b[j];
       if (DROP) u = keep_elem(rh, (uint32_t)(c + j), T.p) ? u * inv_keep : 0.0f;
-      o[j] = a[j] + u;
+      o[j] = in.a[j] + u;
     }
   } else if (KIND == K_BN_ACT) {               // res + drop(relu(BN(a)))
-    const V4 v = V4::load(T.a + r * d + c);
     const uint32_t rh = DROP ? row_hash((uint32_t)r, seed) : 0u;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      float u = (v[j] - c1.mu[j]) * c1.rs[j] * c1.ga[j] + c1.be[j];
+      float u = (in.a[j] - c1.mu[j]) * c1.rs[j] * c1.ga[j] + c1.be[j];
       if (RELU) u = fmaxf(u, 0.0f);
       if (DROP) u = keep_elem(rh, (uint32_t)(c + j), T.p) ? u * inv_keep : 0.0f;
-      o[j] = u;
-    }
-    if (T.res) {
-      const V4 rr = V4::load(T.res + r * d + c);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) o[j] = rr[j] + o[j];
+      o[j] = T.res ? in.r[j] + u : u;
     }
   } else {                                     // BN1(a) + BN2(b)
-    const V4 v1 = V4::load(T.a + r * d + c), v2 = V4::load(T.b + r * d + c);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float u1 = (v1[j] - c1.mu[j]) * c1.rs[j] * c1.ga[j] + c1.be[j];
-      const float u2 = (v2[j] - c2.mu[j]) * c2.rs[j] * c2.ga[j] + c2.be[j];
+      const float u1 = (in.a[j] - c1.mu[j]) * c1.rs[j] * c1.ga[j] + c1.be[j];
+      const float u2 = (in.b[j] - c2.mu[j]) * c2.rs[j] * c2.ga[j] + c2.be[j];
       o[j] = u1 + u2;
     }
   }
   return o;
 }
 
+// Returns whether this block wrote a level-0 statistics record (then the kernel calls tr::arrive, ONE copy per kernel).
 template <int KIND, bool RELU, bool DROP>
-__device__ __forceinline__ void run_fwd(const FwdTask& T, int d, int local_block, uint64_t seed, float* lds) {
+__device__ __forceinline__ bool run_fwd(const FwdTask& T, int d, int lb, uint64_t seed, float* lds) {
   const int L = d >> 2;
-  const int RS = 256 / L;
+  const int RS = blockDim.x / L;
   const int rsub = threadIdx.x / L;
   const int c = (threadIdx.x - rsub * L) * 4;
-  const int64_t row0 = (int64_t)local_block * T.rpb;
+  const int64_t row0 = (int64_t)lb * T.rpb;
   const int64_t row1 = min(T.R, row0 + T.rpb);
-  const bool active = rsub < RS;
-  const bool stats = T.ws != nullptr;
+  const bool stats = T.has_stats != 0;
   const float inv_keep = DROP ? 1.0f / (1.0f - T.p) : 1.0f;
-  V4 k = V4::zero(), s1 = V4::zero(), s2 = V4::zero();
-  if (active) {
-    Col c1, c2;
-    if (KIND == K_BN_ACT || KIND == K_BN_DUAL) c1 = load_col(T.bn1, c);
-    if (KIND == K_BN_DUAL) c2 = load_col(T.bn2, c);
-    // shift = the block's own first produced row (see bn_fused.hip: block-local shifted sums)
-    if (stats) k = eval_row<KIND, RELU, DROP>(T, row0, c, d, c1, c2, seed, inv_keep);
-    for (int64_t r = row0 + rsub; r < row1; r += RS) {
-      const V4 v = eval_row<KIND, RELU, DROP>(T, r, c, d, c1, c2, seed, inv_keep);
-      if (T.out) v.store(T.out + r * d + c);
-      if (stats) {
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float t = v[j] - k[j];
-          s1[j] += t;
-          s2[j] += t * t;
-        }
-      }
-    }
-    if (stats && rsub > 0) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        lds[(rsub * 2 + 0) * d + c + j] = s1[j];
-        lds[(rsub * 2 + 1) * d + c + j] = s2[j];
-      }
-    }
-  }
-  if (!stats) return;            // block-uniform
-  __syncthreads();
-  if (active && rsub == 0) {
+  Col c1, c2;
+  if (KIND == K_BN_ACT || KIND == K_BN_DUAL) c1 = load_col(T.bn1, c);
+  if (KIND == K_BN_DUAL) c2 = load_col(T.bn2, c);
+  V4 k = V4::zero();
+  V4 s[2] = {V4::zero(), V4::zero()};
+  // shift = the block's own first produced row (block-local shifted sums, see bn_fused.hip)
+  if (stats) k = eval_row<KIND, RELU, DROP>(T, load_in<KIND>(T, row0, c, d), row0, c, c1, c2, seed, inv_keep);
+  auto account = [&](const V4& v) __attribute__((always_inline)) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      float a = s1[j], b = s2[j];
-      for (int q = 1; q < RS; ++q) {   // fixed order
-        a += lds[(q * 2 + 0) * d + c + j];
-        b += lds[(q * 2 + 1) * d + c + j];
-      }
-      const float n = (float)(row1 - row0);
-      float* o = T.ws + (int64_t)local_block * 2 * d;
-      o[c + j] = k[j] + a / n;
-      o[d + c + j] = fmaxf(b - a * a / n, 0.0f);
+      const float t = v[j] - k[j];
+      s[0][j] += t;
+      s[1][j] += t * t;
     }
+  };
+  int64_t r = row0 + rsub;
+  for (; r + RS < row1; r += 2 * RS) {          // two rows in flight, straight-line
+    const RowIn i0 = load_in<KIND>(T, r, c, d), i1 = load_in<KIND>(T, r + RS, c, d);
+    const V4 v0 = eval_row<KIND, RELU, DROP>(T, i0, r, c, c1, c2, seed, inv_keep);
+    const V4 v1 = eval_row<KIND, RELU, DROP>(T, i1, r + RS, c, c1, c2, seed, inv_keep);
+    if (T.out) { v0.store(T.out + r * d + c); v1.store(T.out + (r + RS) * d + c); }
+    if (stats) { account(v0); account(v1); }
   }
+  if (r < row1) {
+    const V4 v0 = eval_row<KIND, RELU, DROP>(T, load_in<KIND>(T, r, c, d), r, c, c1, c2, seed, inv_keep);
+    if (T.out) v0.store(T.out + r * d + c);
+    if (stats) account(v0);
+  }
+  if (!stats) return false;      // block-uniform
+  reduce_rows<2>(s, lds, d, RS, rsub, c);
+  if (rsub == 0) {
+    const float n = (float)(row1 - row0);
+    float* rec = T.tree.part + (int64_t)lb * 2 * d;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      tr::st_sc1(rec + c + j, k[j] + s[0][j] / n);
+      tr::st_sc1(rec + d + c + j, fmaxf(s[1][j] - s[0][j] * s[0][j] / n, 0.0f));
+    }
+    if (c == 0) tr::st_sc1(T.tree.pcnt + lb, n);
+  }
+  return true;
 }
 
-__global__ __launch_bounds__(256) void k_rows_fwd(const FwdGroup G) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];   // [RS][2][d]
+__global__ __launch_bounds__(kMaxThreads) void k_rows_fwd(const FwdGroup G) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
   int ti = 0;
 #pragma unroll
   for (int i = 1; i < kMaxTasks; ++i)
@@ -190,100 +210,25 @@ __global__ __launch_bounds__(256) void k_rows_fwd(const FwdGroup G) {
   if (lb >= T.nblk) return;
   const uint64_t seed = gps::salted_seed(T.seed, G.salt);
   const bool drop = T.p > 0.0f;
+  bool rec;
   switch (T.kind) {
-    case K_LOAD: run_fwd<K_LOAD, false, false>(T, G.d, lb, seed, lds); break;
+    case K_LOAD: rec = run_fwd<K_LOAD, false, false>(T, G.d, lb, seed, lds); break;
     case K_ADD_DROP:
-      if (drop) run_fwd<K_ADD_DROP, false, true>(T, G.d, lb, seed, lds);
-      else run_fwd<K_ADD_DROP, false, false>(T, G.d, lb, seed, lds);
+      if (drop) rec = run_fwd<K_ADD_DROP, false, true>(T, G.d, lb, seed, lds);
+      else rec = run_fwd<K_ADD_DROP, false, false>(T, G.d, lb, seed, lds);
       break;
     case K_BN_ACT:
       if (T.relu) {
-        if (drop) run_fwd<K_BN_ACT, true, true>(T, G.d, lb, seed, lds);
-        else run_fwd<K_BN_ACT, true, false>(T, G.d, lb, seed, lds);
+        if (drop) rec = run_fwd<K_BN_ACT, true, true>(T, G.d, lb, seed, lds);
+        else rec = run_fwd<K_BN_ACT, true, false>(T, G.d, lb, seed, lds);
       } else {
-        if (drop) run_fwd<K_BN_ACT, false, true>(T, G.d, lb, seed, lds);
-        else run_fwd<K_BN_ACT, false, false>(T, G.d, lb, seed, lds);
+        if (drop) rec = run_fwd<K_BN_ACT, false, true>(T, G.d, lb, seed, lds);
+        else rec = run_fwd<K_BN_ACT, false, false>(T, G.d, lb, seed, lds);
       }
       break;
-    default: run_fwd<K_BN_DUAL, false, false>(T, G.d, lb, seed, lds); break;
+    default: rec = run_fwd<K_BN_DUAL, false, false>(T, G.d, lb, seed, lds); break;
   }
-}
-
-// Stage 2 of the statistics, for a list of tasks: identical arithmetic to bn_fused.hip:k_bn_finalize
-// (pass 1 global mean, pass 2 sum of M2_b + n_b (mean_b - mean)^2; fixed tree).
-struct FinTask {
-  const float* ws;
-  float *mean, *rstd, *running_mean, *running_var;
-  float count, eps, momentum;
-  int nblk, rpb, block_begin;
-};
-struct FinGroup {
-  FinTask t[kMaxTasks];
-  int n, d;
-};
-
-__global__ __launch_bounds__(256) void k_stats_finalize(const FinGroup G) {
-  __shared__ float sh[FCHUNKS][FCOLS];
-  __shared__ float sh_mean[FCOLS];
-  int ti = 0;
-#pragma unroll
-  for (int i = 1; i < kMaxTasks; ++i)
-    if (i < G.n && (int)blockIdx.x >= G.t[i].block_begin) ti = i;
-  const FinTask& T = G.t[ti];
-  const int d = G.d;
-  const int col = threadIdx.x % FCOLS, chunk = threadIdx.x / FCOLS;
-  const int c = (blockIdx.x - T.block_begin) * FCOLS + col;
-  const int per = (T.nblk + FCHUNKS - 1) / FCHUNKS;   // <= FPER
-  const int b0 = chunk * per;
-  float mb[FPER], qb[FPER], nbv[FPER];
-  float a = 0.f;
-  // every partial is requested before the first one is used: the loads are unconditional from a clamped address and
-  // the out-of-range ones are zeroed by a select afterwards (a load under a condition becomes its own exec-masked
-  // block and the 64 loads of a thread stop being one burst: this launch is pure latency, 10 -> ~4 us)
-  const int cc = min(c, d - 1);
-#pragma unroll
-  for (int j = 0; j < FPER; ++j) {
-    const int bb = min(b0 + j, T.nblk - 1);
-    mb[j] = T.ws[(int64_t)bb * 2 * d + cc];
-    qb[j] = T.ws[(int64_t)bb * 2 * d + d + cc];
-  }
-#pragma unroll
-  for (int j = 0; j < FPER; ++j) {
-    const int b = b0 + j;
-    const bool ok = c < d && j < per && b < T.nblk;
-    mb[j] = ok ? mb[j] : 0.f;
-    qb[j] = ok ? qb[j] : 0.f;
-    nbv[j] = ok ? fminf((float)T.rpb, T.count - (float)b * (float)T.rpb) : 0.f;
-  }
-#pragma unroll
-  for (int j = 0; j < FPER; ++j) a += nbv[j] * mb[j];
-  sh[chunk][col] = a;
-  __syncthreads();
-  if (chunk == 0) {
-    for (int q = 1; q < FCHUNKS; ++q) a += sh[q][col];
-    sh_mean[col] = a / T.count;
-  }
-  __syncthreads();
-  const float mean = sh_mean[col];
-  float m2 = 0.f;
-#pragma unroll
-  for (int j = 0; j < FPER; ++j) {
-    const float dl = mb[j] - mean;
-    m2 += qb[j] + nbv[j] * dl * dl;
-  }
-  __syncthreads();
-  sh[chunk][col] = m2;
-  __syncthreads();
-  if (chunk == 0 && c < d) {
-    for (int q = 1; q < FCHUNKS; ++q) m2 += sh[q][col];
-    T.mean[c] = mean;
-    T.rstd[c] = 1.0f / sqrtf(m2 / T.count + T.eps);
-    if (T.running_mean) {
-      T.running_mean[c] = (1.0f - T.momentum) * T.running_mean[c] + T.momentum * mean;
-      T.running_var[c] =
-          (1.0f - T.momentum) * T.running_var[c] + T.momentum * (m2 / fmaxf(T.count - 1.0f, 1.0f));
-    }
-  }
+  if (rec) tr::arrive<2, tr::STATS, MAXI>(T.tree, lb, G.d, lds);     // block-uniform
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -294,8 +239,7 @@ struct BwdTask {
   Bn bn;                 // primary BN; relu / (p, seed) are the masks applied to ITS output
   const float* z2;       // dual: a second BN (no masks) fed by the same g_y, or nullptr
   Bn bn2;
-  float* ws;             // [nblk][3][d]: sum g, sum g*zhat, sum g*zhat2
-  float *g_beta, *g_gamma, *g_beta2, *g_gamma2;
+  float *g_beta, *g_gamma, *g_beta2, *g_gamma2;   // column sums: written by the partial kernel, read by the apply kernel
   float* g_z;            // primary input gradient
   float* g_sum;          // dual: g_z + g_z2
   float* g_drop;         // dropmask(seed2, p2) of g_z (dual: of g_z2), or nullptr
@@ -304,8 +248,15 @@ struct BwdTask {
   int64_t R;
   uint64_t seed, seed2;
   float p, p2;
-  int relu, rpb, nblk, block_begin, fin_begin;
-  int64_t thread_begin;  // apply kernel: first flat thread of this task
+  int relu, rpb, nblk, block_begin;
+  // chain (apply kernel): the produced primary gradient (before the p1x mask) is the output gradient of another
+  // BatchNorm(cz) -> ReLU -> dropout(cp, cseed); its column sums are accumulated here
+  const float* cz;
+  Bn cbn;
+  uint64_t cseed;
+  float cp;
+  int crelu, has_chain;
+  tr::Tree tree;         // partial kernel: sums of this task; apply kernel: sums of the chain
 };
 struct BwdGroup {
   BwdTask t[kMaxTasks];
@@ -330,63 +281,56 @@ __device__ __forceinline__ void out_grad(const V4& v, const V4& gy, const Col& c
 template <bool RELU, bool DROP, bool DUAL>
 __device__ __forceinline__ void run_bwd_partial(const BwdTask& T, int d, int lb, uint64_t seed, float* lds) {
   const int L = d >> 2;
-  const int RS = 256 / L;
+  const int RS = blockDim.x / L;
   const int rsub = threadIdx.x / L;
   const int c = (threadIdx.x - rsub * L) * 4;
   const int64_t row0 = (int64_t)lb * T.rpb;
   const int64_t row1 = min(T.R, row0 + T.rpb);
-  const bool active = rsub < RS;
-  V4 sg = V4::zero(), sgz = V4::zero(), sgz2 = V4::zero();
-  if (active) {
-    const Col c1 = load_col(T.bn, c);
-    Col c2;
-    if (DUAL) c2 = load_col(T.bn2, c);
-    const float inv_keep = DROP ? 1.0f / (1.0f - T.p) : 1.0f;
-    for (int64_t r = row0 + rsub; r < row1; r += RS) {
-      const V4 v = V4::load(T.z + r * d + c);
-      const V4 gy = V4::load(T.g_y + r * d + c);
-      V4 g, zh;
-      out_grad<RELU, DROP>(v, gy, c1, DROP ? row_hash((uint32_t)r, seed) : 0u, c, T.p, inv_keep, g, zh);
+  constexpr int NV = DUAL ? 3 : 2;
+  V4 s[NV];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        sg[j] += g[j];
-        sgz[j] += g[j] * zh[j];
-      }
-      if (DUAL) {
-        const V4 v2 = V4::load(T.z2 + r * d + c);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) sgz2[j] += g[j] * ((v2[j] - c2.mu[j]) * c2.rs[j]);
-      }
-    }
-    if (rsub > 0) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        lds[(rsub * 3 + 0) * d + c + j] = sg[j];
-        lds[(rsub * 3 + 1) * d + c + j] = sgz[j];
-        if (DUAL) lds[(rsub * 3 + 2) * d + c + j] = sgz2[j];
-      }
-    }
-  }
-  __syncthreads();
-  if (active && rsub == 0) {
+  for (int v = 0; v < NV; ++v) s[v] = V4::zero();
+  const Col c1 = load_col(T.bn, c);
+  Col c2;
+  if (DUAL) c2 = load_col(T.bn2, c);
+  const float inv_keep = DROP ? 1.0f / (1.0f - T.p) : 1.0f;
+  auto account = [&](int64_t r, const V4& v, const V4& gy, const V4& v2) __attribute__((always_inline)) {
+    V4 g, zh;
+    out_grad<RELU, DROP>(v, gy, c1, DROP ? row_hash((uint32_t)r, seed) : 0u, c, T.p, inv_keep, g, zh);
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      float a = sg[j], b = sgz[j], e = sgz2[j];
-      for (int q = 1; q < RS; ++q) {
-        a += lds[(q * 3 + 0) * d + c + j];
-        b += lds[(q * 3 + 1) * d + c + j];
-        if (DUAL) e += lds[(q * 3 + 2) * d + c + j];
-      }
-      float* o = T.ws + (int64_t)lb * 3 * d;
-      o[c + j] = a;
-      o[d + c + j] = b;
-      if (DUAL) o[2 * d + c + j] = e;
+      s[0][j] += g[j];
+      s[1][j] += g[j] * zh[j];
+      if (DUAL) s[NV - 1][j] += g[j] * ((v2[j] - c2.mu[j]) * c2.rs[j]);
     }
+  };
+  int64_t r = row0 + rsub;
+  for (; r + RS < row1; r += 2 * RS) {
+    const int64_t rb = r + RS;
+    const V4 va = V4::load(T.z + r * d + c), ga = V4::load(T.g_y + r * d + c);
+    const V4 vb = V4::load(T.z + rb * d + c), gb = V4::load(T.g_y + rb * d + c);
+    const V4 wa = DUAL ? V4::load(T.z2 + r * d + c) : V4::zero();
+    const V4 wb = DUAL ? V4::load(T.z2 + rb * d + c) : V4::zero();
+    account(r, va, ga, wa);
+    account(rb, vb, gb, wb);
+  }
+  if (r < row1) {
+    const V4 va = V4::load(T.z + r * d + c), ga = V4::load(T.g_y + r * d + c);
+    const V4 wa = DUAL ? V4::load(T.z2 + r * d + c) : V4::zero();
+    account(r, va, ga, wa);
+  }
+  reduce_rows<NV>(s, lds, d, RS, rsub, c);
+  if (rsub == 0) {
+    float* rec = T.tree.part + (int64_t)lb * NV * d;
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) tr::st_sc1(rec + v * d + c + j, s[v][j]);
   }
 }
 
-__global__ __launch_bounds__(256) void k_bwd_partial(const BwdGroup G) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];   // [RS][3][d]
+__global__ __launch_bounds__(kMaxThreads) void k_bwd_partial(const BwdGroup G) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
   int ti = 0;
 #pragma unroll
   for (int i = 1; i < kMaxTasks; ++i)
@@ -396,7 +340,11 @@ __global__ __launch_bounds__(256) void k_bwd_partial(const BwdGroup G) {
   if (lb >= T.nblk) return;
   const uint64_t seed = gps::salted_seed(T.seed, G.salt);
   const bool drop = T.p > 0.0f;
-  if (T.z2) { run_bwd_partial<false, false, true>(T, G.d, lb, seed, lds); return; }
+  if (T.z2) {
+    run_bwd_partial<false, false, true>(T, G.d, lb, seed, lds);
+    tr::arrive<3, tr::SUMS, MAXI>(T.tree, lb, G.d, lds);
+    return;
+  }
   if (T.relu) {
     if (drop) run_bwd_partial<true, true, false>(T, G.d, lb, seed, lds);
     else run_bwd_partial<true, false, false>(T, G.d, lb, seed, lds);
@@ -404,85 +352,40 @@ __global__ __launch_bounds__(256) void k_bwd_partial(const BwdGroup G) {
     if (drop) run_bwd_partial<false, true, false>(T, G.d, lb, seed, lds);
     else run_bwd_partial<false, false, false>(T, G.d, lb, seed, lds);
   }
+  tr::arrive<2, tr::SUMS, MAXI>(T.tree, lb, G.d, lds);
 }
 
-__global__ __launch_bounds__(256) void k_bwd_finalize(const BwdGroup G) {
-  __shared__ float sh[FCHUNKS][FCOLS][3];
-  int ti = 0;
-#pragma unroll
-  for (int i = 1; i < kMaxTasks; ++i)
-    if (i < G.n && (int)blockIdx.x >= G.t[i].fin_begin) ti = i;
-  const BwdTask& T = G.t[ti];
-  const int d = G.d;
-  const int col = threadIdx.x % FCOLS, chunk = threadIdx.x / FCOLS;
-  const int c = (blockIdx.x - T.fin_begin) * FCOLS + col;
-  const int per = (T.nblk + FCHUNKS - 1) / FCHUNKS;
-  const int b0 = chunk * per, b1 = min(T.nblk, b0 + per);
-  const bool dual = T.z2 != nullptr;
-  float a = 0.f, b = 0.f, e = 0.f;
-  {
-    // one burst of loads (clamped addresses, masked afterwards), summed in ascending block order
-    float va[FPER], vb[FPER], vc[FPER];
-    const int cc = min(c, d - 1);
-    const int64_t third = dual ? 2 * d : d;        // non-dual: re-read the second column block (unused)
-#pragma unroll
-    for (int j = 0; j < FPER; ++j) {
-      const int kk = min(b0 + j, T.nblk - 1);
-      va[j] = T.ws[(int64_t)kk * 3 * d + cc];
-      vb[j] = T.ws[(int64_t)kk * 3 * d + d + cc];
-      vc[j] = T.ws[(int64_t)kk * 3 * d + third + cc];
-    }
-#pragma unroll
-    for (int j = 0; j < FPER; ++j) {
-      const bool ok = c < d && b0 + j < b1;
-      a += ok ? va[j] : 0.f;
-      b += ok ? vb[j] : 0.f;
-      e += (ok && dual) ? vc[j] : 0.f;
-    }
-  }
-  sh[chunk][col][0] = a; sh[chunk][col][1] = b; sh[chunk][col][2] = e;
-  __syncthreads();
-  if (chunk == 0 && c < d) {
-    for (int q = 1; q < FCHUNKS; ++q) { a += sh[q][col][0]; b += sh[q][col][1]; e += sh[q][col][2]; }
-    T.g_beta[c] = a;
-    T.g_gamma[c] = b;
-    if (dual) { T.g_beta2[c] = a; T.g_gamma2[c] = e; }
-  }
-}
+struct ApplyCtx {
+  Col c1, c2, cc;
+  V4 s1, s2, s3;
+  float inv_keep, inv_n, ik1, ik2, cik;
+  uint64_t seed, seed2, seed1x, cseed;
+};
 
+// one row of an apply task: stores the gradients, returns the primary one (input of the chain)
 template <bool RELU, bool DROP, bool DUAL>
-__device__ __forceinline__ void run_bwd_apply(const BwdTask& T, int d, int64_t row, int c, uint64_t seed,
-                                              uint64_t seed2, uint64_t seed1x = 0) {
-  const V4 v = V4::load(T.z + row * d + c);
-  const V4 gy = V4::load(T.g_y + row * d + c);
-  const Col c1 = load_col(T.bn, c);
-  const V4 s1 = V4::load(T.g_beta + c), s2 = V4::load(T.g_gamma + c);
-  const float inv_keep = DROP ? 1.0f / (1.0f - T.p) : 1.0f;
-  const float inv_n = 1.0f / (float)T.R;
+__device__ __forceinline__ V4 apply_row(const BwdTask& T, const ApplyCtx& A, int d, int64_t row, int c, const V4& v,
+                                        const V4& gy, const V4& v2) {
   V4 g, zh, o;
-  out_grad<RELU, DROP>(v, gy, c1, DROP ? row_hash((uint32_t)row, seed) : 0u, c, T.p, inv_keep, g, zh);
+  out_grad<RELU, DROP>(v, gy, A.c1, DROP ? row_hash((uint32_t)row, A.seed) : 0u, c, T.p, A.inv_keep, g, zh);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) o[j] = c1.ga[j] * c1.rs[j] * (g[j] - s1[j] * inv_n - zh[j] * s2[j] * inv_n);
+  for (int j = 0; j < 4; ++j) o[j] = A.c1.ga[j] * A.c1.rs[j] * (g[j] - A.s1[j] * A.inv_n - zh[j] * A.s2[j] * A.inv_n);
   if (DUAL && T.p1x > 0.0f) {
-    const uint32_t rh1 = row_hash((uint32_t)row, seed1x);
-    const float ik1 = 1.0f / (1.0f - T.p1x);
+    const uint32_t rh1 = row_hash((uint32_t)row, A.seed1x);
     V4 om;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) om[j] = keep_elem(rh1, (uint32_t)(c + j), T.p1x) ? o[j] * ik1 : 0.0f;
+    for (int j = 0; j < 4; ++j) om[j] = keep_elem(rh1, (uint32_t)(c + j), T.p1x) ? o[j] * A.ik1 : 0.0f;
     om.store(T.g_z + row * d + c);
   } else {
     o.store(T.g_z + row * d + c);
   }
   V4 last = o;
   if (DUAL) {
-    const V4 v2 = V4::load(T.z2 + row * d + c);
-    const Col c2 = load_col(T.bn2, c);
-    const V4 s3 = V4::load(T.g_gamma2 + c);
     V4 o2, sum;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float zh2 = (v2[j] - c2.mu[j]) * c2.rs[j];
-      o2[j] = c2.ga[j] * c2.rs[j] * (g[j] - s1[j] * inv_n - zh2 * s3[j] * inv_n);
+      const float zh2 = (v2[j] - A.c2.mu[j]) * A.c2.rs[j];
+      o2[j] = A.c2.ga[j] * A.c2.rs[j] * (g[j] - A.s1[j] * A.inv_n - zh2 * A.s3[j] * A.inv_n);
       sum[j] = o[j] + o2[j];
     }
     if (T.g_sum) sum.store(T.g_sum + row * d + c);
@@ -491,39 +394,113 @@ __device__ __forceinline__ void run_bwd_apply(const BwdTask& T, int d, int64_t r
   if (T.g_drop) {
     V4 q = last;
     if (T.p2 > 0.0f) {
-      const uint32_t rh2 = row_hash((uint32_t)row, seed2);
-      const float ik2 = 1.0f / (1.0f - T.p2);
+      const uint32_t rh2 = row_hash((uint32_t)row, A.seed2);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) q[j] = keep_elem(rh2, (uint32_t)(c + j), T.p2) ? last[j] * ik2 : 0.0f;
+      for (int j = 0; j < 4; ++j) q[j] = keep_elem(rh2, (uint32_t)(c + j), T.p2) ? last[j] * A.ik2 : 0.0f;
     }
     q.store(T.g_drop + row * d + c);
   }
+  return o;
 }
 
-__global__ __launch_bounds__(256) void k_bwd_apply(const BwdGroup G) {
-  const int64_t gt = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+template <bool RELU, bool DROP, bool DUAL, bool CHAIN>
+__device__ __forceinline__ void run_bwd_apply(const BwdTask& T, int d, int lb, const uint64_t* salt, float* lds) {
+  const int L = d >> 2;
+  const int RS = blockDim.x / L;
+  const int rsub = threadIdx.x / L;
+  const int c = (threadIdx.x - rsub * L) * 4;
+  const int64_t row0 = (int64_t)lb * T.rpb;
+  const int64_t row1 = min(T.R, row0 + T.rpb);
+  ApplyCtx A;
+  A.c1 = load_col(T.bn, c);
+  if (DUAL) A.c2 = load_col(T.bn2, c);
+  if (CHAIN) A.cc = load_col(T.cbn, c);
+  A.s1 = V4::load(T.g_beta + c);
+  A.s2 = V4::load(T.g_gamma + c);
+  A.s3 = DUAL ? V4::load(T.g_gamma2 + c) : V4::zero();
+  A.inv_keep = DROP ? 1.0f / (1.0f - T.p) : 1.0f;
+  A.inv_n = 1.0f / (float)T.R;
+  A.ik1 = T.p1x > 0.0f ? 1.0f / (1.0f - T.p1x) : 1.0f;
+  A.ik2 = T.p2 > 0.0f ? 1.0f / (1.0f - T.p2) : 1.0f;
+  A.cik = CHAIN && T.cp > 0.0f ? 1.0f / (1.0f - T.cp) : 1.0f;
+  A.seed = gps::salted_seed(T.seed, salt);
+  A.seed2 = gps::salted_seed(T.seed2, salt);
+  A.seed1x = gps::salted_seed(T.seed1x, salt);
+  A.cseed = gps::salted_seed(T.cseed, salt);
+  V4 s[2] = {V4::zero(), V4::zero()};
+  const bool cdrop = CHAIN && T.cp > 0.0f, crelu = CHAIN && T.crelu != 0;
+  auto chain = [&](int64_t row, const V4& o, const V4& cz) __attribute__((always_inline)) {
+    const uint32_t rh = cdrop ? row_hash((uint32_t)row, A.cseed) : 0u;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float zh = (cz[j] - A.cc.mu[j]) * A.cc.rs[j];
+      float gg = o[j];
+      if (cdrop) gg = keep_elem(rh, (uint32_t)(c + j), T.cp) ? gg * A.cik : 0.0f;
+      if (crelu) gg = (zh * A.cc.ga[j] + A.cc.be[j]) > 0.0f ? gg : 0.0f;
+      s[0][j] += gg;
+      s[1][j] += gg * zh;
+    }
+  };
+  int64_t r = row0 + rsub;
+  for (; r + RS < row1; r += 2 * RS) {
+    const int64_t rb = r + RS;
+    const V4 va = V4::load(T.z + r * d + c), ga = V4::load(T.g_y + r * d + c);
+    const V4 vb = V4::load(T.z + rb * d + c), gb = V4::load(T.g_y + rb * d + c);
+    const V4 wa = DUAL ? V4::load(T.z2 + r * d + c) : V4::zero();
+    const V4 wb = DUAL ? V4::load(T.z2 + rb * d + c) : V4::zero();
+    const V4 ca = CHAIN ? V4::load(T.cz + r * d + c) : V4::zero();
+    const V4 cb = CHAIN ? V4::load(T.cz + rb * d + c) : V4::zero();
+    const V4 oa = apply_row<RELU, DROP, DUAL>(T, A, d, r, c, va, ga, wa);
+    const V4 ob = apply_row<RELU, DROP, DUAL>(T, A, d, rb, c, vb, gb, wb);
+    if (CHAIN) { chain(r, oa, ca); chain(rb, ob, cb); }
+  }
+  if (r < row1) {
+    const V4 va = V4::load(T.z + r * d + c), ga = V4::load(T.g_y + r * d + c);
+    const V4 wa = DUAL ? V4::load(T.z2 + r * d + c) : V4::zero();
+    const V4 ca = CHAIN ? V4::load(T.cz + r * d + c) : V4::zero();
+    const V4 oa = apply_row<RELU, DROP, DUAL>(T, A, d, r, c, va, ga, wa);
+    if (CHAIN) chain(r, oa, ca);
+  }
+  if (!CHAIN) return;
+  reduce_rows<2>(s, lds, d, RS, rsub, c);
+  if (rsub == 0) {
+    float* rec = T.tree.part + (int64_t)lb * 2 * d;
+#pragma unroll
+    for (int v = 0; v < 2; ++v)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) tr::st_sc1(rec + v * d + c + j, s[v][j]);
+  }
+}
+
+__global__ __launch_bounds__(kMaxThreads) void k_bwd_apply(const BwdGroup G) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];
   int ti = 0;
 #pragma unroll
   for (int i = 1; i < kMaxTasks; ++i)
-    if (i < G.n && gt >= G.t[i].thread_begin) ti = i;
+    if (i < G.n && (int)blockIdx.x >= G.t[i].block_begin) ti = i;
   const BwdTask& T = G.t[ti];
-  const int d = G.d, L = d >> 2;
-  const int64_t t = gt - T.thread_begin;
-  const int64_t row = t / L;
-  if (row >= T.R) return;
-  const int c = (int)(t - row * L) * 4;
-  const uint64_t seed = gps::salted_seed(T.seed, G.salt), seed2 = gps::salted_seed(T.seed2, G.salt);
+  const int lb = blockIdx.x - T.block_begin;
+  if (lb >= T.nblk) return;
   const bool drop = T.p > 0.0f;
-  if (T.z2) {
-    run_bwd_apply<false, false, true>(T, d, row, c, seed, seed2, gps::salted_seed(T.seed1x, G.salt));
+  if (T.has_chain) {       // block-uniform; the chain's column sums complete in this launch
+    if (T.z2) run_bwd_apply<false, false, true, true>(T, G.d, lb, G.salt, lds);
+    else if (T.relu) {
+      if (drop) run_bwd_apply<true, true, false, true>(T, G.d, lb, G.salt, lds);
+      else run_bwd_apply<true, false, false, true>(T, G.d, lb, G.salt, lds);
+    } else {
+      if (drop) run_bwd_apply<false, true, false, true>(T, G.d, lb, G.salt, lds);
+      else run_bwd_apply<false, false, false, true>(T, G.d, lb, G.salt, lds);
+    }
+    tr::arrive<2, tr::SUMS, MAXI>(T.tree, lb, G.d, lds);
     return;
   }
+  if (T.z2) { run_bwd_apply<false, false, true, false>(T, G.d, lb, G.salt, lds); return; }
   if (T.relu) {
-    if (drop) run_bwd_apply<true, true, false>(T, d, row, c, seed, seed2);
-    else run_bwd_apply<true, false, false>(T, d, row, c, seed, seed2);
+    if (drop) run_bwd_apply<true, true, false, false>(T, G.d, lb, G.salt, lds);
+    else run_bwd_apply<true, false, false, false>(T, G.d, lb, G.salt, lds);
   } else {
-    if (drop) run_bwd_apply<false, true, false>(T, d, row, c, seed, seed2);
-    else run_bwd_apply<false, false, false>(T, d, row, c, seed, seed2);
+    if (drop) run_bwd_apply<false, true, false, false>(T, G.d, lb, G.salt, lds);
+    else run_bwd_apply<false, false, false, false>(T, G.d, lb, G.salt, lds);
   }
 }
 
@@ -534,239 +511,170 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) % 16) =
 inline int rows_per_block(int64_t R) { return (int)std::max<int64_t>(8, (R + TARGET_BLOCKS - 1) / TARGET_BLOCKS); }
 inline int nblocks_for(int64_t R) { const int rpb = rows_per_block(R); return (int)((R + rpb - 1) / rpb); }
 inline Bn bn_of(const gps_bn* b) { return Bn{b->mean, b->rstd, b->gamma, b->beta}; }
+inline int threads_for(int d) { const int L = d / 4; return std::max(1, kMaxThreads / L) * L; }
+inline size_t lds_bytes_for(int d, int nvec) {
+  const int threads = threads_for(d), RS = threads / (d / 4);
+  const size_t rows = (size_t)RS * nvec * d, scr = (size_t)tr::scratch_floats(3, threads);
+  return sizeof(float) * std::max(rows, scr) + 16;
+}
 
 int check_common(const char* who, int64_t R, int d) {
   GPS_REQUIRE(d > 0 && d % 4 == 0 && d <= 1024, "%s: d=%d must be a multiple of 4, <= 1024", who, d);
   GPS_REQUIRE(R >= 2 && R < INT32_MAX, "%s: need 2 <= rows < 2^31 (got %lld)", who, (long long)R);
   return GPS_OK;
 }
-int check_bn(const char* who, const gps_bn* b, bool need_stats_out) {
+int check_bn(const char* who, const gps_bn* b) {
   GPS_REQUIRE(b && b->gamma && b->beta && b->mean && b->rstd, "%s: incomplete gps_bn", who);
   GPS_REQUIRE(al16(b->gamma) && al16(b->beta) && al16(b->mean) && al16(b->rstd), "%s: gps_bn buffers must be 16-byte aligned", who);
   GPS_REQUIRE((b->running_mean == nullptr) == (b->running_var == nullptr), "%s: running stats", who);
-  (void)need_stats_out;
   return GPS_OK;
 }
 
-struct FwdPlan {
-  FwdGroup g;
-  FinGroup f;
-  int blocks, fin_blocks;
-};
-
-void add_fwd(FwdPlan& P, int kind, const float* a, const float* b, const float* res, const gps_bn* bn1,
-             const gps_bn* bn2, int relu, float p, uint64_t seed, float* out, int64_t R,
-             const gps_bn* stats_for, float*& ws) {
-  FwdTask& T = P.g.t[P.g.n++];
-  T = FwdTask{};
-  T.a = a; T.b = b; T.res = res;
-  if (bn1) T.bn1 = bn_of(bn1);
-  if (bn2) T.bn2 = bn_of(bn2);
-  T.out = out; T.R = R; T.seed = seed; T.p = p; T.kind = kind; T.relu = relu;
-  T.rpb = rows_per_block(R); T.nblk = nblocks_for(R);
-  T.block_begin = P.blocks;
-  P.blocks += T.nblk;
-  if (stats_for) {
-    T.ws = ws;
-    FinTask& F = P.f.t[P.f.n++];
-    F = FinTask{};
-    F.ws = ws; F.mean = stats_for->mean; F.rstd = stats_for->rstd;
-    F.running_mean = stats_for->running_mean; F.running_var = stats_for->running_var;
-    F.count = (float)R; F.eps = stats_for->eps; F.momentum = stats_for->momentum;
-    F.nblk = T.nblk; F.rpb = T.rpb; F.block_begin = P.fin_blocks;
-    P.fin_blocks += (P.g.d + FCOLS - 1) / FCOLS;
-    ws += (size_t)T.nblk * 2 * P.g.d;
-  }
-}
-
-int launch_fwd(FwdPlan& P, hipStream_t s, const char* who) {
-  const int d = P.g.d;
-  P.f.d = d;
-  P.g.salt = gps::dropout_salt();
-  const int RS = 256 / (d / 4);
-  if (P.blocks > 0) k_rows_fwd<<<(unsigned)P.blocks, 256, sizeof(float) * 2 * RS * d, s>>>(P.g);
-  if (P.f.n > 0) k_stats_finalize<<<(unsigned)P.fin_blocks, 256, 0, s>>>(P.f);
-  return gps::launch_status(who);
-}
-
-void add_bwd(BwdGroup& G, int& blocks, int& fin_blocks, int64_t& threads, const float* z, const float* g_y,
-             const gps_bn* bn, int relu, float p, uint64_t seed, const float* z2, const gps_bn* bn2,
-             float* g_beta, float* g_gamma, float* g_beta2, float* g_gamma2, float* g_z, float* g_sum,
-             float* g_drop, float p2, uint64_t seed2, int64_t R, float*& ws) {
-  BwdTask& T = G.t[G.n++];
-  T = BwdTask{};
-  T.z = z; T.g_y = g_y; T.bn = bn_of(bn); T.z2 = z2;
-  if (bn2) T.bn2 = bn_of(bn2);
-  T.ws = ws; T.g_beta = g_beta; T.g_gamma = g_gamma; T.g_beta2 = g_beta2; T.g_gamma2 = g_gamma2;
-  T.g_z = g_z; T.g_sum = g_sum; T.g_drop = g_drop;
-  T.R = R; T.seed = seed; T.seed2 = seed2; T.p = p; T.p2 = p2; T.relu = relu;
-  T.rpb = rows_per_block(R); T.nblk = nblocks_for(R);
-  T.block_begin = blocks; blocks += T.nblk;
-  T.fin_begin = fin_blocks; fin_blocks += (G.d + FCOLS - 1) / FCOLS;
-  T.thread_begin = threads;
-  threads += (R * (int64_t)(G.d / 4) + 255) / 256 * 256;
-  ws += (size_t)T.nblk * 3 * G.d;
-}
-
-int launch_bwd(BwdGroup& G, int blocks, int fin_blocks, int64_t threads, hipStream_t s, const char* who) {
-  G.salt = gps::dropout_salt();
-  const int d = G.d;
-  const int RS = 256 / (d / 4);
-  k_bwd_partial<<<(unsigned)blocks, 256, sizeof(float) * 3 * RS * d, s>>>(G);
-  k_bwd_finalize<<<(unsigned)fin_blocks, 256, 0, s>>>(G);
-  k_bwd_apply<<<gps::grid_for(threads, 256), 256, 0, s>>>(G);
-  return gps::launch_status(who);
+// carve one tree out of the caller's workspace / counters
+int take_tree(const char* who, tr::Tree& T, int P, int NV, int mode, int d, float*& ws, float* ws_end, uint32_t* sync,
+              int& n_trees) {
+  GPS_REQUIRE(P >= 1 && P <= tr::kMaxParts, "%s: %d column partials exceed the tree (%d)", who, P, tr::kMaxParts);
+  GPS_REQUIRE(ws && sync, "%s: statistics need a workspace and a counter buffer", who);
+  GPS_REQUIRE(n_trees < 2 * kMaxTasks, "%s: too many trees in one launch", who);
+  GPS_REQUIRE(ws + tr::floats_for(P, NV, d) <= ws_end, "%s: workspace too small (see gps_norm_tree_floats)", who);
+  T = tr::carve(ws, sync + (size_t)n_trees * tr::kSyncWords, P, NV, mode, d);
+  ++n_trees;
+  return GPS_OK;
 }
 
 }  // namespace
 
 extern "C" {
 
-size_t gps_block_norm_workspace_floats(int64_t N, int64_t E, int d) {
-  if (N < 1 || E < 0 || d < 1) return 0;
-  // the largest list: three tasks with up to 3 partial columns each
-  return ((size_t)nblocks_for(N) * 2 + (size_t)nblocks_for(std::max<int64_t>(E, 1))) * 3 * (size_t)d + 16;
+size_t gps_norm_tree_floats(int64_t R, int d) {
+  if (R < 1 || d < 1) return 0;
+  return tr::floats_for(nblocks_for(std::max<int64_t>(R, 2)), 3, d) + 16;
 }
 
-int gps_bn_stats_pair(const float* zA, int64_t RA, const gps_bn* bnA, const float* zB, int64_t RB,
-                      const gps_bn* bnB, int d, float* ws, gps_stream_t stream) {
-  if (int rc = check_common("gps_bn_stats_pair", RA, d)) return rc;
-  if (int rc = check_common("gps_bn_stats_pair", RB, d)) return rc;
-  if (int rc = check_bn("gps_bn_stats_pair", bnA, true)) return rc;
-  if (int rc = check_bn("gps_bn_stats_pair", bnB, true)) return rc;
-  GPS_REQUIRE(zA && zB && ws && al16(zA) && al16(zB) && al16(ws), "gps_bn_stats_pair: null/misaligned buffer");
-  FwdPlan P{};
-  P.g.d = d;
-  add_fwd(P, K_LOAD, zA, nullptr, nullptr, nullptr, nullptr, 0, 0.f, 0, nullptr, RA, bnA, ws);
-  add_fwd(P, K_LOAD, zB, nullptr, nullptr, nullptr, nullptr, 0, 0.f, 0, nullptr, RB, bnB, ws);
-  return launch_fwd(P, gps::as_stream(stream), "gps_bn_stats_pair");
+int gps_norm_sync_words(void) { return 2 * kMaxTasks * tr::kSyncWords; }
+
+int gps_norm_fwd(int n, const gps_norm_fwd_task* tasks, int d, float* ws, size_t ws_floats, uint32_t* sync,
+                 gps_stream_t stream) {
+  static const char* who = "gps_norm_fwd";
+  GPS_REQUIRE(n >= 1 && n <= kMaxTasks && tasks, "%s: 1..%d tasks per launch", who, kMaxTasks);
+  GPS_REQUIRE(al16(ws), "%s: misaligned workspace", who);
+  FwdGroup G{};
+  G.n = n; G.d = d;
+  G.salt = gps::dropout_salt();
+  float* wp = ws;
+  float* wend = ws + ws_floats;
+  int blocks = 0, n_trees = 0;
+  for (int i = 0; i < n; ++i) {
+    const gps_norm_fwd_task& S = tasks[i];
+    if (int rc = check_common(who, S.R, d)) return rc;
+    GPS_REQUIRE(S.kind >= K_LOAD && S.kind <= K_BN_DUAL, "%s: task %d: unknown kind %d", who, i, S.kind);
+    GPS_REQUIRE(S.a && al16(S.a) && al16(S.b) && al16(S.res) && al16(S.out), "%s: task %d: null / misaligned rows", who, i);
+    GPS_REQUIRE((S.kind != K_ADD_DROP && S.kind != K_BN_DUAL) || S.b, "%s: task %d: second operand missing", who, i);
+    GPS_REQUIRE(S.p >= 0.f && S.p < 1.f, "%s: task %d: dropout p", who, i);
+    GPS_REQUIRE(S.out || S.stats, "%s: task %d produces nothing", who, i);
+    FwdTask& T = G.t[i];
+    T.a = S.a; T.b = S.b; T.res = S.kind == K_BN_ACT ? S.res : nullptr;
+    if (S.kind == K_BN_ACT || S.kind == K_BN_DUAL) {
+      if (int rc = check_bn(who, S.bn1)) return rc;
+      T.bn1 = bn_of(S.bn1);
+    }
+    if (S.kind == K_BN_DUAL) {
+      if (int rc = check_bn(who, S.bn2)) return rc;
+      T.bn2 = bn_of(S.bn2);
+    }
+    T.out = S.out; T.R = S.R; T.seed = S.seed;
+    T.p = (S.kind == K_ADD_DROP || S.kind == K_BN_ACT) ? S.p : 0.f;
+    T.kind = S.kind; T.relu = S.relu;
+    T.rpb = rows_per_block(S.R); T.nblk = nblocks_for(S.R);
+    T.block_begin = blocks;
+    blocks += T.nblk;
+    if (S.stats) {
+      if (int rc = check_bn(who, S.stats)) return rc;
+      if (int rc = take_tree(who, T.tree, T.nblk, 2, tr::STATS, d, wp, wend, sync, n_trees)) return rc;
+      T.has_stats = 1;
+      T.tree.o0 = S.stats->mean; T.tree.o1 = S.stats->rstd;
+      T.tree.o2 = S.stats->running_mean; T.tree.o3 = S.stats->running_var;
+      T.tree.eps = S.stats->eps; T.tree.momentum = S.stats->momentum;
+    }
+  }
+  k_rows_fwd<<<(unsigned)blocks, threads_for(d), lds_bytes_for(d, 2), gps::as_stream(stream)>>>(G);
+  return gps::launch_status(who);
 }
 
-int gps_block_mid_fwd(const float* xt, const float* x, const gps_bn* bn_x, float p, uint64_t seed_x,
-                      float* x1, const float* eh, const float* e, const gps_bn* bn_e, uint64_t seed_e,
-                      float* e1, const float* ao, float p_attn, uint64_t seed_a, float* za,
-                      const gps_bn* bn_local, const gps_bn* bn_attn, int64_t N, int64_t E, int d,
-                      float* ws, gps_stream_t stream) {
-  if (int rc = check_common("gps_block_mid_fwd", N, d)) return rc;
-  if (int rc = check_common("gps_block_mid_fwd", E, d)) return rc;
-  for (const gps_bn* b : {bn_x, bn_e, bn_local, bn_attn})
-    if (int rc = check_bn("gps_block_mid_fwd", b, true)) return rc;
-  GPS_REQUIRE(xt && x && x1 && eh && e && e1 && ao && za && ws, "gps_block_mid_fwd: null buffer");
-  GPS_REQUIRE(al16(xt) && al16(x) && al16(x1) && al16(eh) && al16(e) && al16(e1) && al16(ao) && al16(za) && al16(ws),
-              "gps_block_mid_fwd: buffers must be 16-byte aligned");
-  GPS_REQUIRE(p >= 0.f && p < 1.f && p_attn >= 0.f && p_attn < 1.f, "gps_block_mid_fwd: dropout p");
-  FwdPlan P{};
-  P.g.d = d;
-  add_fwd(P, K_BN_ACT, xt, nullptr, x, bn_x, nullptr, 1, p, seed_x, x1, N, bn_local, ws);
-  add_fwd(P, K_BN_ACT, eh, nullptr, e, bn_e, nullptr, 1, p, seed_e, e1, E, nullptr, ws);
-  add_fwd(P, K_ADD_DROP, x, ao, nullptr, nullptr, nullptr, 0, p_attn, seed_a, za, N, bn_attn, ws);
-  return launch_fwd(P, gps::as_stream(stream), "gps_block_mid_fwd");
+static int fill_bwd(const char* who, int n, const gps_norm_bwd_task* tasks, int d, BwdGroup& G, int& blocks) {
+  GPS_REQUIRE(n >= 1 && n <= kMaxTasks && tasks, "%s: 1..%d tasks per launch", who, kMaxTasks);
+  G.n = n; G.d = d;
+  G.salt = gps::dropout_salt();
+  blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    const gps_norm_bwd_task& S = tasks[i];
+    if (int rc = check_common(who, S.R, d)) return rc;
+    if (int rc = check_bn(who, S.bn)) return rc;
+    GPS_REQUIRE(S.z && S.g_y && S.g_gamma && S.g_beta && al16(S.z) && al16(S.g_y) && al16(S.g_gamma) && al16(S.g_beta),
+                "%s: task %d: null / misaligned buffer", who, i);
+    GPS_REQUIRE(S.p >= 0.f && S.p < 1.f && S.p2 >= 0.f && S.p2 < 1.f && S.p1x >= 0.f && S.p1x < 1.f && S.cp >= 0.f && S.cp < 1.f,
+                "%s: task %d: dropout p", who, i);
+    BwdTask& T = G.t[i];
+    T.z = S.z; T.g_y = S.g_y; T.bn = bn_of(S.bn); T.z2 = S.z2;
+    if (S.z2) {
+      if (int rc = check_bn(who, S.bn2)) return rc;
+      GPS_REQUIRE(al16(S.z2) && S.g_gamma2 && S.g_beta2 && al16(S.g_gamma2) && al16(S.g_beta2), "%s: task %d: dual buffers", who, i);
+      GPS_REQUIRE(!S.relu && S.p == 0.f, "%s: task %d: a dual task carries no masks on its BatchNorm outputs", who, i);
+      T.bn2 = bn_of(S.bn2);
+    }
+    T.g_beta = S.g_beta; T.g_gamma = S.g_gamma; T.g_beta2 = S.g_beta2; T.g_gamma2 = S.g_gamma2;
+    T.g_z = S.g_z; T.g_sum = S.g_sum; T.g_drop = S.g_drop;
+    T.p1x = S.z2 ? S.p1x : 0.f; T.seed1x = S.seed1x;
+    T.R = S.R; T.seed = S.seed; T.seed2 = S.seed2; T.p = S.p; T.p2 = S.p2; T.relu = S.relu;
+    T.rpb = rows_per_block(S.R); T.nblk = nblocks_for(S.R);
+    T.block_begin = blocks;
+    blocks += T.nblk;
+  }
+  return GPS_OK;
 }
 
-int gps_bn_dual_apply(const float* z1, const gps_bn* bn1, const float* z2, const gps_bn* bn2, int64_t R,
-                      int d, float* out, gps_stream_t stream) {
-  if (int rc = check_common("gps_bn_dual_apply", R, d)) return rc;
-  if (int rc = check_bn("gps_bn_dual_apply", bn1, false)) return rc;
-  if (int rc = check_bn("gps_bn_dual_apply", bn2, false)) return rc;
-  GPS_REQUIRE(z1 && z2 && out && al16(z1) && al16(z2) && al16(out), "gps_bn_dual_apply: null/misaligned buffer");
-  FwdPlan P{};
-  P.g.d = d;
-  float* none = nullptr;
-  add_fwd(P, K_BN_DUAL, z1, z2, nullptr, bn1, bn2, 0, 0.f, 0, out, R, nullptr, none);
-  return launch_fwd(P, gps::as_stream(stream), "gps_bn_dual_apply");
-}
-
-int gps_add_drop_stats(const float* a, const float* b, int64_t R, int d, float p, uint64_t seed, float* out,
-                       const gps_bn* bn, float* ws, gps_stream_t stream) {
-  if (int rc = check_common("gps_add_drop_stats", R, d)) return rc;
-  if (int rc = check_bn("gps_add_drop_stats", bn, true)) return rc;
-  GPS_REQUIRE(a && b && out && ws && al16(a) && al16(b) && al16(out) && al16(ws) && p >= 0.f && p < 1.f,
-              "gps_add_drop_stats: bad arguments");
-  FwdPlan P{};
-  P.g.d = d;
-  add_fwd(P, K_ADD_DROP, a, b, nullptr, nullptr, nullptr, 0, p, seed, out, R, bn, ws);
-  return launch_fwd(P, gps::as_stream(stream), "gps_add_drop_stats");
-}
-
-int gps_add_drop_stats_pair(const float* a1, const float* b1, float p1, uint64_t seed1, float* out1,
-                            const gps_bn* bn1, const float* a2, const float* b2, float p2, uint64_t seed2,
-                            float* out2, const gps_bn* bn2, int64_t R, int d, float* ws, gps_stream_t stream) {
-  if (int rc = check_common("gps_add_drop_stats_pair", R, d)) return rc;
-  if (int rc = check_bn("gps_add_drop_stats_pair", bn1, true)) return rc;
-  if (int rc = check_bn("gps_add_drop_stats_pair", bn2, true)) return rc;
-  GPS_REQUIRE(a1 && b1 && out1 && a2 && b2 && out2 && ws && al16(a1) && al16(b1) && al16(out1) && al16(a2) &&
-                  al16(b2) && al16(out2) && al16(ws) && p1 >= 0.f && p1 < 1.f && p2 >= 0.f && p2 < 1.f,
-              "gps_add_drop_stats_pair: bad arguments");
-  FwdPlan P{};
-  P.g.d = d;
-  add_fwd(P, K_ADD_DROP, a1, b1, nullptr, nullptr, nullptr, 0, p1, seed1, out1, R, bn1, ws);
-  add_fwd(P, K_ADD_DROP, a2, b2, nullptr, nullptr, nullptr, 0, p2, seed2, out2, R, bn2, ws);
-  return launch_fwd(P, gps::as_stream(stream), "gps_add_drop_stats_pair");
-}
-
-int gps_bn_bwd_drop(const float* z, const float* g_y, const gps_bn* bn, int64_t R, int d, int relu, float p,
-                    uint64_t seed, float* g_z, float* g_gamma, float* g_beta, float p2, uint64_t seed2,
-                    float* g_drop, float* ws, gps_stream_t stream) {
-  if (int rc = check_common("gps_bn_bwd_drop", R, d)) return rc;
-  if (int rc = check_bn("gps_bn_bwd_drop", bn, false)) return rc;
-  GPS_REQUIRE(z && g_y && g_z && g_gamma && g_beta && ws && al16(z) && al16(g_y) && al16(g_z) &&
-                  al16(g_gamma) && al16(g_beta) && al16(g_drop) && al16(ws),
-              "gps_bn_bwd_drop: null/misaligned buffer");
+int gps_norm_bwd_partial(int n, const gps_norm_bwd_task* tasks, int d, float* ws, size_t ws_floats, uint32_t* sync,
+                         gps_stream_t stream) {
+  static const char* who = "gps_norm_bwd_partial";
   BwdGroup G{};
-  G.d = d;
-  int blocks = 0, fin = 0;
-  int64_t threads = 0;
-  add_bwd(G, blocks, fin, threads, z, g_y, bn, relu, p, seed, nullptr, nullptr, g_beta, g_gamma, nullptr,
-          nullptr, g_z, nullptr, g_drop, p2, seed2, R, ws);
-  return launch_bwd(G, blocks, fin, threads, gps::as_stream(stream), "gps_bn_bwd_drop");
+  int blocks = 0, n_trees = 0;
+  if (int rc = fill_bwd(who, n, tasks, d, G, blocks)) return rc;
+  GPS_REQUIRE(al16(ws), "%s: misaligned workspace", who);
+  float* wp = ws;
+  float* wend = ws + ws_floats;
+  for (int i = 0; i < n; ++i) {
+    BwdTask& T = G.t[i];
+    const bool dual = T.z2 != nullptr;
+    if (int rc = take_tree(who, T.tree, T.nblk, dual ? 3 : 2, tr::SUMS, d, wp, wend, sync, n_trees)) return rc;
+    T.tree.o0 = T.g_beta; T.tree.o1 = T.g_gamma; T.tree.o2 = T.g_beta2; T.tree.o3 = T.g_gamma2;
+  }
+  k_bwd_partial<<<(unsigned)blocks, threads_for(d), lds_bytes_for(d, 3), gps::as_stream(stream)>>>(G);
+  return gps::launch_status(who);
 }
 
-int gps_bn_dual_bwd(const float* z1, const gps_bn* bn1, const float* z2, const gps_bn* bn2, const float* g_y,
-                    int64_t R, int d, float* g_z1, float p1, uint64_t seed1, float* g_sum, float p2,
-                    uint64_t seed2, float* g_drop2,
-                    float* g_gamma1, float* g_beta1, float* g_gamma2, float* g_beta2, float* ws,
-                    gps_stream_t stream) {
-  if (int rc = check_common("gps_bn_dual_bwd", R, d)) return rc;
-  if (int rc = check_bn("gps_bn_dual_bwd", bn1, false)) return rc;
-  if (int rc = check_bn("gps_bn_dual_bwd", bn2, false)) return rc;
-  GPS_REQUIRE(z1 && z2 && g_y && g_z1 && g_sum && g_gamma1 && g_beta1 && g_gamma2 && g_beta2 && ws,
-              "gps_bn_dual_bwd: null buffer");
-  GPS_REQUIRE(al16(z1) && al16(z2) && al16(g_y) && al16(g_z1) && al16(g_sum) && al16(g_drop2) &&
-                  al16(g_gamma1) && al16(g_beta1) && al16(g_gamma2) && al16(g_beta2) && al16(ws),
-              "gps_bn_dual_bwd: buffers must be 16-byte aligned");
+int gps_norm_bwd_apply(int n, const gps_norm_bwd_task* tasks, int d, float* ws, size_t ws_floats, uint32_t* sync,
+                       gps_stream_t stream) {
+  static const char* who = "gps_norm_bwd_apply";
   BwdGroup G{};
-  G.d = d;
-  int blocks = 0, fin = 0;
-  int64_t threads = 0;
-  add_bwd(G, blocks, fin, threads, z1, g_y, bn1, 0, 0.f, 0, z2, bn2, g_beta1, g_gamma1, g_beta2, g_gamma2,
-          g_z1, g_sum, g_drop2, p2, seed2, R, ws);
-  G.t[0].p1x = p1;
-  G.t[0].seed1x = seed1;
-  return launch_bwd(G, blocks, fin, threads, gps::as_stream(stream), "gps_bn_dual_bwd");
-}
-
-int gps_bn_bwd_pair(const float* zA, const float* gA, const gps_bn* bnA, int64_t RA, uint64_t seedA,
-                    float* g_zA, float* g_gammaA, float* g_betaA, const float* zB, const float* gB,
-                    const gps_bn* bnB, int64_t RB, uint64_t seedB, float* g_zB, float* g_gammaB,
-                    float* g_betaB, int d, int relu, float p, float* ws, gps_stream_t stream) {
-  if (int rc = check_common("gps_bn_bwd_pair", RA, d)) return rc;
-  if (int rc = check_common("gps_bn_bwd_pair", RB, d)) return rc;
-  if (int rc = check_bn("gps_bn_bwd_pair", bnA, false)) return rc;
-  if (int rc = check_bn("gps_bn_bwd_pair", bnB, false)) return rc;
-  GPS_REQUIRE(zA && gA && g_zA && g_gammaA && g_betaA && zB && gB && g_zB && g_gammaB && g_betaB && ws,
-              "gps_bn_bwd_pair: null buffer");
-  GPS_REQUIRE(al16(zA) && al16(gA) && al16(g_zA) && al16(g_gammaA) && al16(g_betaA) && al16(zB) && al16(gB) &&
-                  al16(g_zB) && al16(g_gammaB) && al16(g_betaB) && al16(ws),
-              "gps_bn_bwd_pair: buffers must be 16-byte aligned");
-  BwdGroup G{};
-  G.d = d;
-  int blocks = 0, fin = 0;
-  int64_t threads = 0;
-  add_bwd(G, blocks, fin, threads, zA, gA, bnA, relu, p, seedA, nullptr, nullptr, g_betaA, g_gammaA, nullptr,
-          nullptr, g_zA, nullptr, nullptr, 0.f, 0, RA, ws);
-  add_bwd(G, blocks, fin, threads, zB, gB, bnB, relu, p, seedB, nullptr, nullptr, g_betaB, g_gammaB, nullptr,
-          nullptr, g_zB, nullptr, nullptr, 0.f, 0, RB, ws);
-  return launch_bwd(G, blocks, fin, threads, gps::as_stream(stream), "gps_bn_bwd_pair");
+  int blocks = 0, n_trees = 0;
+  if (int rc = fill_bwd(who, n, tasks, d, G, blocks)) return rc;
+  float* wp = ws;
+  float* wend = ws + ws_floats;
+  for (int i = 0; i < n; ++i) {
+    const gps_norm_bwd_task& S = tasks[i];
+    BwdTask& T = G.t[i];
+    GPS_REQUIRE(S.g_z && al16(S.g_z) && al16(S.g_sum) && al16(S.g_drop), "%s: task %d: null / misaligned output", who, i);
+    if (S.cz) {
+      if (int rc = check_bn(who, S.cbn)) return rc;
+      GPS_REQUIRE(al16(ws) && al16(S.cz) && S.cg_gamma && S.cg_beta && al16(S.cg_gamma) && al16(S.cg_beta),
+                  "%s: task %d: chain buffers", who, i);
+      T.cz = S.cz; T.cbn = bn_of(S.cbn); T.cseed = S.cseed; T.cp = S.cp; T.crelu = S.crelu; T.has_chain = 1;
+      if (int rc = take_tree(who, T.tree, T.nblk, 2, tr::SUMS, d, wp, wend, sync, n_trees)) return rc;
+      T.tree.o0 = S.cg_beta; T.tree.o1 = S.cg_gamma;
+    }
+  }
+  k_bwd_apply<<<(unsigned)blocks, threads_for(d), lds_bytes_for(d, 2), gps::as_stream(stream)>>>(G);
+  return gps::launch_status(who);
 }
 
 }  // extern "C"

@@ -30,12 +30,16 @@
 //
 // Algorithmic HBM bytes (fp32, per layer):  fwd 8*E*d + 20*N*d, bwd 12*E*d + 28*N*d (minus the 8*N*d of
 // num / den that are recomputed instead of read); index traffic 4(N+1)+8E per CSR/CSC slice.
+#include <algorithm>
 #include <cstdlib>
 
+#include "col_tree.hpp"
 #include "gps_common.hpp"
 #include "vec.hpp"
 
 namespace {
+
+namespace tr = gps::tree;
 
 constexpr int GG_T = 768;        // threads per workgroup (12 wavefronts; 2 workgroups per CU)
 constexpr int GG_MAXNB = 512;    // node rows per workgroup, upper bound (LDS rowptr slice)
@@ -73,6 +77,39 @@ __device__ __forceinline__ bool stage_slice(const int32_t* __restrict__ rowptr, 
   return staged;
 }
 
+// Per-thread shifted sums of the rows this lane produces (its VEC channels): the batch statistics of x~ (bn_node_x) and
+// e^ (bn_edge_e) -- graphgps/layer/gatedgcn_layer.py:72-73 -- fall out of the forward instead of a second pass over both
+// tensors.  Shift = the lane's own first value, so the sums stay accurate whatever the column mean is.
+template <int VEC>
+struct StatAcc {
+  Vec<VEC> kx, sx1, sx2, ke, se1, se2;
+  float nx, ne;
+  __device__ void init() {
+    kx = sx1 = sx2 = ke = se1 = se2 = Vec<VEC>::zero();
+    nx = ne = 0.f;
+  }
+  __device__ __forceinline__ void add_x(const Vec<VEC>& v) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      kx[i] = nx == 0.f ? v[i] : kx[i];
+      const float t = v[i] - kx[i];
+      sx1[i] += t;
+      sx2[i] += t * t;
+    }
+    nx += 1.f;
+  }
+  __device__ __forceinline__ void add_e(const Vec<VEC>& v) {
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      ke[i] = ne == 0.f ? v[i] : ke[i];
+      const float t = v[i] - ke[i];
+      se1[i] += t;
+      se2[i] += t * t;
+    }
+    ne += 1.f;
+  }
+};
+
 // ---------------------------------------------------------------------------------------------------------
 // Edge chunks.  D (1..4) edges of one node: every operand row is requested before the first one is used, so a node
 // with <= 4 edges (molecules, ASTs) costs ONE memory round trip; longer segments are walked 4 edges at a time.
@@ -81,11 +118,11 @@ __device__ __forceinline__ bool stage_slice(const int32_t* __restrict__ rowptr, 
 // GATE: the EquivStableLapPE variant (gatedgcn_layer.py:101-104): sigma_ij is multiplied by a per-edge
 // scalar r_ij in (0,1) (r_edge[edge id]) before it gates and normalises.
 // ---------------------------------------------------------------------------------------------------------
-template <int VEC, bool GATE, int D>
+template <int VEC, bool GATE, bool STATS, int D>
 __device__ __forceinline__ void fwd_chunk(const float* __restrict__ Bx, const float* __restrict__ Ex, int64_t ld,
                                           const float* __restrict__ Ce, const float* __restrict__ r_edge, int d,
                                           int c, const int* nbr, const int* eids, const Vec<VEC>& dx,
-                                          Vec<VEC>& num, Vec<VEC>& den, float* __restrict__ e_hat) {
+                                          Vec<VEC>& num, Vec<VEC>& den, float* __restrict__ e_hat, StatAcc<VEC>& sa) {
   int64_t id[D];
   Vec<VEC> ex[D], bx[D], ce[D];
   float rr[D];
@@ -110,16 +147,17 @@ __device__ __forceinline__ void fwd_chunk(const float* __restrict__ Bx, const fl
       den[v] += s;                            // scatter(sigma)                      (:121-123)
     }
     eh.store(e_hat + id[u] * d + c);          // self.e = e_ij, returned in edge order (:106,134)
+    if (STATS) sa.add_e(eh);
   }
 }
 
-template <int VEC, bool GATE>
+template <int VEC, bool GATE, bool STATS>
 __device__ __forceinline__ void fwd_rows(const float* __restrict__ Ax, const float* __restrict__ Bx,
                                          const float* __restrict__ Dx, const float* __restrict__ Ex, int64_t ld,
                                          const float* __restrict__ Ce, const int* rp, const int* nbr,
                                          const int* eids, const NodeBlock& blk, int d, int row, int npi, int c,
                                          float* __restrict__ x_tilde, float* __restrict__ e_hat,
-                                         const float* __restrict__ r_edge) {
+                                         const float* __restrict__ r_edge, StatAcc<VEC>& sa) {
   for (int64_t node = blk.n0 + row; node < blk.n1; node += npi) {
     const int beg = rp[node - blk.n0], end = rp[node - blk.n0 + 1];
     const Vec<VEC> dx = Vec<VEC>::load(Dx + node * ld + c);
@@ -127,44 +165,104 @@ __device__ __forceinline__ void fwd_rows(const float* __restrict__ Ax, const flo
     Vec<VEC> num = Vec<VEC>::zero(), den = Vec<VEC>::zero();
     int k = beg;
     for (; k + 4 < end; k += 4)
-      fwd_chunk<VEC, GATE, 4>(Bx, Ex, ld, Ce, r_edge, d, c, nbr + k, eids + k, dx, num, den, e_hat);
+      fwd_chunk<VEC, GATE, STATS, 4>(Bx, Ex, ld, Ce, r_edge, d, c, nbr + k, eids + k, dx, num, den, e_hat, sa);
     switch (end - k) {
-      case 1: fwd_chunk<VEC, GATE, 1>(Bx, Ex, ld, Ce, r_edge, d, c, nbr + k, eids + k, dx, num, den, e_hat); break;
-      case 2: fwd_chunk<VEC, GATE, 2>(Bx, Ex, ld, Ce, r_edge, d, c, nbr + k, eids + k, dx, num, den, e_hat); break;
-      case 3: fwd_chunk<VEC, GATE, 3>(Bx, Ex, ld, Ce, r_edge, d, c, nbr + k, eids + k, dx, num, den, e_hat); break;
-      case 4: fwd_chunk<VEC, GATE, 4>(Bx, Ex, ld, Ce, r_edge, d, c, nbr + k, eids + k, dx, num, den, e_hat); break;
+      case 1: fwd_chunk<VEC, GATE, STATS, 1>(Bx, Ex, ld, Ce, r_edge, d, c, nbr + k, eids + k, dx, num, den, e_hat, sa); break;
+      case 2: fwd_chunk<VEC, GATE, STATS, 2>(Bx, Ex, ld, Ce, r_edge, d, c, nbr + k, eids + k, dx, num, den, e_hat, sa); break;
+      case 3: fwd_chunk<VEC, GATE, STATS, 3>(Bx, Ex, ld, Ce, r_edge, d, c, nbr + k, eids + k, dx, num, den, e_hat, sa); break;
+      case 4: fwd_chunk<VEC, GATE, STATS, 4>(Bx, Ex, ld, Ce, r_edge, d, c, nbr + k, eids + k, dx, num, den, e_hat, sa); break;
       default: break;
     }
     Vec<VEC> xt;
 #pragma unroll
     for (int v = 0; v < VEC; ++v) xt[v] = ax[v] + num[v] / (den[v] + 1e-6f);  //          (:125,133)
     xt.store(x_tilde + node * (int64_t)d + c);
+    if (STATS) sa.add_x(xt);
   }
 }
 
-template <int VEC, bool GATE>
+// Block-level finish of the statistics (STATS kernels): the npi row lanes of every column meet through LDS (merged in
+// row order by Chan's formula), lane row 0 writes the workgroup's record -- (mean, M2) of x~ and of e^ with the two row
+// counts -- write-through, and the tree (records = node blocks) completes in this launch (csrc/col_tree.hpp).
+template <int VEC>
+__device__ __forceinline__ void fwd_stats_finish(const StatAcc<VEC>& sa, const tr::Tree& T, int64_t L, bool active, int row,
+                                                 int npi, int c, int d, float* lds) {
+  float* cntx = lds;                     // [npi] nodes per row lane
+  float* cnte = lds + npi;               // [npi] edges per row lane
+  float* buf = lds + 2 * ((npi + 3) & ~3);   // [npi][2][d]
+  Vec<VEC> m[2], q[2];
+  float n[2] = {sa.nx, sa.ne};
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    m[0][v] = sa.nx > 0.f ? sa.kx[v] + sa.sx1[v] / sa.nx : 0.f;
+    q[0][v] = sa.nx > 0.f ? fmaxf(sa.sx2[v] - sa.sx1[v] * sa.sx1[v] / sa.nx, 0.f) : 0.f;
+    m[1][v] = sa.ne > 0.f ? sa.ke[v] + sa.se1[v] / sa.ne : 0.f;
+    q[1][v] = sa.ne > 0.f ? fmaxf(sa.se2[v] - sa.se1[v] * sa.se1[v] / sa.ne, 0.f) : 0.f;
+  }
+  if (active && c == 0) { cntx[row] = sa.nx; cnte[row] = sa.ne; }
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {          // x~ first, then e^, through the same LDS region
+    if (s) __syncthreads();
+    if (active && row > 0) {
+      m[s].store(buf + (row * 2 + 0) * d + c);
+      q[s].store(buf + (row * 2 + 1) * d + c);
+    }
+    __syncthreads();
+    if (active && row == 0) {
+      const float* cn = s ? cnte : cntx;
+      for (int r2 = 1; r2 < npi; ++r2) {
+        const Vec<VEC> m2 = Vec<VEC>::load(buf + (r2 * 2 + 0) * d + c), q2 = Vec<VEC>::load(buf + (r2 * 2 + 1) * d + c);
+        const float n2 = cn[r2];
+        float nn = n[s];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+          nn = n[s];
+          tr::chan_merge(nn, m[s][v], q[s][v], n2, m2[v], q2[v]);
+        }
+        n[s] = nn;
+      }
+      float* rec = T.part + (L * 4 + 2 * s) * d;
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        tr::st_sc1(rec + c + v, m[s][v]);
+        tr::st_sc1(rec + d + c + v, q[s][v]);
+      }
+      if (c == 0) tr::st_sc1(T.pcnt + L * 2 + s, n[s]);
+    }
+  }
+  tr::arrive<4, tr::STATS, tr::kMaxFan / 2>(T, (int)L, d, lds);
+}
+
+template <int VEC, bool GATE, bool STATS>
 __global__ __launch_bounds__(GG_T) void k_gatedgcn_fwd(
     const float* __restrict__ Ax, const float* __restrict__ Bx, const float* __restrict__ Dx,
     const float* __restrict__ Ex, int64_t ld, const float* __restrict__ Ce,
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src,
     const int32_t* __restrict__ eid, int64_t N, int d, float* __restrict__ x_tilde,
-    float* __restrict__ e_hat, const float* __restrict__ r_edge, int nb, int npi) {
+    float* __restrict__ e_hat, const float* __restrict__ r_edge, int nb, int npi, const tr::Tree stats) {
   __shared__ int s_rp[GG_MAXNB + 1];
   __shared__ int s_src[GG_MAXE], s_eid[GG_MAXE];
+  extern __shared__ __attribute__((aligned(16))) float g_fwd_lds[];   // STATS: row-lane exchange + tree scratch
   const NodeBlock blk = node_block(N, nb);
-  if (!blk.valid()) return;
+  if (!blk.valid()) return;            // (the tree counts the valid node blocks only)
   const bool staged = stage_slice(rowptr, src, eid, blk, s_rp, s_src, s_eid);
   __syncthreads();
   const int lpr = d / VEC;
   const int row = threadIdx.x / lpr;
-  if (row >= npi) return;
+  const bool active = row < npi;
+  if (!STATS && !active) return;
   const int c = (threadIdx.x - row * lpr) * VEC;
   const int e0 = s_rp[0];
-  if (staged)     // index slices in LDS (workgroup-uniform branch: two copies of the body, one address space each)
-    fwd_rows<VEC, GATE>(Ax, Bx, Dx, Ex, ld, Ce, s_rp, s_src - e0, s_eid - e0, blk, d, row, npi, c, x_tilde, e_hat,
-                        r_edge);
-  else            // a hub-heavy block (> GG_MAXE entries): same code on the global index arrays
-    fwd_rows<VEC, GATE>(Ax, Bx, Dx, Ex, ld, Ce, s_rp, src, eid, blk, d, row, npi, c, x_tilde, e_hat, r_edge);
+  StatAcc<VEC> sa;
+  if (STATS) sa.init();
+  if (active) {
+    if (staged)     // index slices in LDS (workgroup-uniform branch: two copies of the body, one address space each)
+      fwd_rows<VEC, GATE, STATS>(Ax, Bx, Dx, Ex, ld, Ce, s_rp, s_src - e0, s_eid - e0, blk, d, row, npi, c, x_tilde, e_hat,
+                                 r_edge, sa);
+    else            // a hub-heavy block (> GG_MAXE entries): same code on the global index arrays
+      fwd_rows<VEC, GATE, STATS>(Ax, Bx, Dx, Ex, ld, Ce, s_rp, src, eid, blk, d, row, npi, c, x_tilde, e_hat, r_edge, sa);
+  }
+  if (STATS) fwd_stats_finish<VEC>(sa, stats, blk.n0 / nb, active, row, npi, c, d, g_fwd_lds);
 }
 
 // Backward, one launch (see the header comment):
@@ -499,9 +597,9 @@ inline Plan plan_for(int64_t N, int lanes_per_row, bool forward) {
 
 }  // namespace
 
-#define GPS_GG_FWD(GATE)                                                                             \
-  k_gatedgcn_fwd<VEC, GATE><<<pl.grid, pl.threads, 0, s>>>(Ax, Bx, Dx, Ex, ld_node, Ce, rowptr_dst,        \
-      src_by_dst, eid_by_dst, N, d, x_tilde, e_hat, r_edge, pl.nb, pl.npi)
+#define GPS_GG_FWD(GATE, STATS, LDS)                                                                  \
+  k_gatedgcn_fwd<VEC, GATE, STATS><<<pl.grid, pl.threads, LDS, s>>>(Ax, Bx, Dx, Ex, ld_node, Ce, rowptr_dst, \
+      src_by_dst, eid_by_dst, N, d, x_tilde, e_hat, r_edge, pl.nb, pl.npi, tree)
 #define GPS_GG_BWD(GATE)                                                                             \
   k_gatedgcn_bwd<VEC, GATE><<<pl.grid, pl.threads, stash_bytes, s>>>(g_x, ld_gx, g_e, e_hat, Ax, Bx, ld_node, x_tilde, \
       rowptr_dst, src_by_dst, eid_by_dst, rowptr_src, dst_by_src, eid_by_src, N, d, g_Ce,             \
@@ -509,10 +607,46 @@ inline Plan plan_for(int64_t N, int lanes_per_row, bool forward) {
 
 extern "C" {
 
+size_t gps_gatedgcn_stats_floats(int64_t N, int d) {
+  if (N < 1 || d < 4 || d % 4) return 0;
+  const Plan pl = plan_for(N, d / 4, true);
+  return tr::floats_for((int)((N + pl.nb - 1) / pl.nb), 4, d) + 16;
+}
+int gps_gatedgcn_stats_sync_words(void) { return tr::kSyncWords; }
+
+static int gatedgcn_fwd_impl(const float* Ax, const float* Bx, const float* Dx, const float* Ex,
+                             int64_t ld_node, const float* Ce, const int32_t* rowptr_dst,
+                             const int32_t* src_by_dst, const int32_t* eid_by_dst, int64_t N, int64_t E,
+                             int d, float* x_tilde, float* e_hat, const float* r_edge, const gps_bn* bn_x,
+                             const gps_bn* bn_e, float* ws, size_t ws_floats, uint32_t* sync, gps_stream_t stream);
+
 int gps_gatedgcn_fwd(const float* Ax, const float* Bx, const float* Dx, const float* Ex,
                      int64_t ld_node, const float* Ce, const int32_t* rowptr_dst,
                      const int32_t* src_by_dst, const int32_t* eid_by_dst, int64_t N, int64_t E,
                      int d, float* x_tilde, float* e_hat, const float* r_edge, gps_stream_t stream) {
+  return gatedgcn_fwd_impl(Ax, Bx, Dx, Ex, ld_node, Ce, rowptr_dst, src_by_dst, eid_by_dst, N, E, d, x_tilde, e_hat, r_edge,
+                           nullptr, nullptr, nullptr, 0, nullptr, stream);
+}
+
+int gps_gatedgcn_fwd_stats(const float* Ax, const float* Bx, const float* Dx, const float* Ex,
+                           int64_t ld_node, const float* Ce, const int32_t* rowptr_dst,
+                           const int32_t* src_by_dst, const int32_t* eid_by_dst, int64_t N, int64_t E,
+                           int d, float* x_tilde, float* e_hat, const float* r_edge, const gps_bn* bn_x,
+                           const gps_bn* bn_e, float* ws, size_t ws_floats, uint32_t* sync, gps_stream_t stream) {
+  GPS_REQUIRE(bn_x && bn_e && bn_x->mean && bn_x->rstd && bn_e->mean && bn_e->rstd && ws && sync,
+              "gps_gatedgcn_fwd_stats: null statistics buffer");
+  GPS_REQUIRE(N >= 2 && E >= 2 && d % 4 == 0, "gps_gatedgcn_fwd_stats: needs N, E >= 2 and d %% 4 == 0");
+  GPS_REQUIRE((bn_x->running_mean == nullptr) == (bn_x->running_var == nullptr) &&
+              (bn_e->running_mean == nullptr) == (bn_e->running_var == nullptr), "gps_gatedgcn_fwd_stats: running stats");
+  return gatedgcn_fwd_impl(Ax, Bx, Dx, Ex, ld_node, Ce, rowptr_dst, src_by_dst, eid_by_dst, N, E, d, x_tilde, e_hat, r_edge,
+                           bn_x, bn_e, ws, ws_floats, sync, stream);
+}
+
+static int gatedgcn_fwd_impl(const float* Ax, const float* Bx, const float* Dx, const float* Ex,
+                             int64_t ld_node, const float* Ce, const int32_t* rowptr_dst,
+                             const int32_t* src_by_dst, const int32_t* eid_by_dst, int64_t N, int64_t E,
+                             int d, float* x_tilde, float* e_hat, const float* r_edge, const gps_bn* bn_x,
+                             const gps_bn* bn_e, float* ws, size_t ws_floats, uint32_t* sync, gps_stream_t stream) {
   GPS_REQUIRE(N >= 0 && E >= 0 && d > 0 && ld_node >= d, "gps_gatedgcn_fwd: bad sizes N=%lld E=%lld d=%d ld=%lld",
               (long long)N, (long long)E, d, (long long)ld_node);
   if (N == 0) return GPS_OK;
@@ -526,7 +660,25 @@ int gps_gatedgcn_fwd(const float* Ax, const float* Bx, const float* Dx, const fl
   GPS_DISPATCH_VEC(d, ld_node % 4 == 0 && ok(16), ld_node % 2 == 0 && ok(8), {
     GPS_REQUIRE(d / VEC <= GG_T, "gps_gatedgcn_fwd: d=%d too wide for one workgroup pass (%d lanes)", d, d / VEC);
     const Plan pl = plan_for(N, d / VEC, true);
-    if (r_edge) GPS_GG_FWD(true); else GPS_GG_FWD(false);
+    tr::Tree tree{};
+    if (bn_x) {
+      GPS_REQUIRE(VEC == 4, "gps_gatedgcn_fwd_stats: rows must be 16-byte aligned (d %% 4 == 0, ld %% 4 == 0)");
+      const int P = (int)((N + pl.nb - 1) / pl.nb);
+      GPS_REQUIRE(P <= tr::kMaxParts, "gps_gatedgcn_fwd_stats: %d node blocks exceed the tree (%d)", P, tr::kMaxParts);
+      GPS_REQUIRE(aligned_to(ws, 16) && ws_floats >= tr::floats_for(P, 4, d), "gps_gatedgcn_fwd_stats: workspace (gps_gatedgcn_stats_floats)");
+      float* wp = ws;
+      tree = tr::carve(wp, sync, P, 4, tr::STATS, d);
+      tree.o0 = bn_x->mean; tree.o1 = bn_x->rstd; tree.o2 = bn_x->running_mean; tree.o3 = bn_x->running_var;
+      tree.eps = bn_x->eps; tree.momentum = bn_x->momentum;
+      tree.p0 = bn_e->mean; tree.p1 = bn_e->rstd; tree.p2 = bn_e->running_mean; tree.p3 = bn_e->running_var;
+      tree.eps2 = bn_e->eps; tree.momentum2 = bn_e->momentum;
+      // dynamic LDS: [2 npi] counts + [npi][2][d] row-lane exchange, or the tree's scratch
+      const size_t ex = 2 * (size_t)((pl.npi + 3) & ~3) + (size_t)pl.npi * 2 * d;
+      const size_t lds = sizeof(float) * std::max(ex, (size_t)tr::scratch_floats(4, pl.threads)) + 16;
+      if (r_edge) GPS_GG_FWD(true, true, lds); else GPS_GG_FWD(false, true, lds);
+    } else {
+      if (r_edge) GPS_GG_FWD(true, false, 0); else GPS_GG_FWD(false, false, 0);
+    }
   });
   return gps::launch_status("gps_gatedgcn_fwd");
 }

@@ -36,9 +36,12 @@
 #include <cstdint>
 #include <cstdlib>
 
+#include "col_tree.hpp"
 #include "gps_common.hpp"
 
 namespace {
+
+namespace tr = gps::tree;
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -172,6 +175,14 @@ struct PanelArgs {
   const uint64_t* salt;
   int row_tiles;
   unsigned long long* trace;   // debugging aid (gps_gemm_panel_trace): 4 shader-clock stamps per workgroup, or nullptr
+  // epilogue 3 (ring kernel only): C = Cin + dropout(A W^T + bias) and the column statistics of C (a training-mode
+  // BatchNorm1d over the M rows), completed in-launch by one csrc/col_tree.hpp tree per 192-column panel whose level-0
+  // records are the row tiles.  Tree of panel q: workspace st_ws + q * st_stride, counters st_tick + q * kSyncWords.
+  float* st_ws;
+  size_t st_stride;
+  unsigned* st_tick;
+  float *st_mean, *st_rstd, *st_rmean, *st_rvar;
+  float st_eps, st_mom;
 };
 
 // Epilogue shared by both kernels.  D[row = (q&3) + 8*(q>>2) + 4*kh][col = li] of each 32 x 32 block; 32 lanes = 128
@@ -363,9 +374,11 @@ __device__ float g_zero_bias[kZeroBias];      // stands in for a null bias, so t
 // tile) is straight-line code: a store under a per-row branch made the compiler wait vmcnt(0) -- i.e. for every
 // earlier STORE to retire -- before each of the 48 / 96 stores of a lane (measured: 10k / 23k cycles per workgroup,
 // a third of its lifetime).
+// EPI == 3 additionally accumulates, per lane and column block j, the shifted sums of the values it stores
+// (sk = the wave's first row, s1 = sum (v - sk), s2 = sum (v - sk)^2 over the rows this lane owns).
 template <int MB, int EPI, bool HAS_CIN, bool FULL>
 __device__ __forceinline__ void ring_store(const PanelArgs& P, const f32x16 (&acc)[MB][3], int64_t m0, int n0, int wm,
-                                           int wn, int li, int kh) {
+                                           int wn, int li, int kh, float (&sk)[3], float (&s1)[3], float (&s2)[3]) {
   const uint64_t seed = gps::salted_seed(P.seed, P.salt);
   const bool drop = EPI != 0 && P.p_drop > 0.0f;
   const float inv_keep = drop ? 1.0f / (1.0f - P.p_drop) : 1.0f;
@@ -398,12 +411,19 @@ __device__ __forceinline__ void ring_store(const PanelArgs& P, const f32x16 (&ac
         const int64_t row = m0 + (wm * MB + mb) * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh;
         const int64_t rc = FULL ? row : (row < P.M ? row : P.M - 1);
         float v = acc[mb][j][q] + bv[j];
-        if (HAS_CIN) v += cin[j][q];
+        if (HAS_CIN && EPI != 3) v += cin[j][q];
         if (EPI == 1) v = fmaxf(v, 0.0f);
         if (EPI == 2) v = msk[j][q] > 0.0f ? v : 0.0f;
         if (EPI != 0) {
           const bool keep = !drop || keep_elem(row_hash((uint32_t)rc, seed), (uint32_t)col, P.p_drop);
           v = keep ? v * inv_keep : 0.0f;
+        }
+        if (EPI == 3) {                 // the residual is NOT dropped: C = Cin + dropout(product)
+          if (HAS_CIN) v += cin[j][q];
+          if (mb == 0 && q == 0) sk[j] = __shfl(v, li);      // row 0 of the wave's row range sits in lane li (kh = 0)
+          const float t = (FULL || row < P.M) ? v - sk[j] : 0.0f;
+          s1[j] += t;
+          s2[j] += t * t;
         }
         if (FULL || row < P.M) __builtin_nontemporal_store(v, P.C + row * P.ldc + col);
       }
@@ -412,9 +432,59 @@ __device__ __forceinline__ void ring_store(const PanelArgs& P, const f32x16 (&ac
 }
 template <int MB, int EPI, bool HAS_CIN>
 __device__ __forceinline__ void ring_epilogue(const PanelArgs& P, const f32x16 (&acc)[MB][3], int64_t m0, int n0, int wm,
-                                              int wn, int li, int kh) {
-  if (m0 + 64 * MB <= P.M) ring_store<MB, EPI, HAS_CIN, true>(P, acc, m0, n0, wm, wn, li, kh);      // workgroup-uniform
-  else ring_store<MB, EPI, HAS_CIN, false>(P, acc, m0, n0, wm, wn, li, kh);
+                                              int wn, int li, int kh, float (&sk)[3], float (&s1)[3], float (&s2)[3]) {
+  if (m0 + 64 * MB <= P.M) ring_store<MB, EPI, HAS_CIN, true>(P, acc, m0, n0, wm, wn, li, kh, sk, s1, s2);   // workgroup-uniform
+  else ring_store<MB, EPI, HAS_CIN, false>(P, acc, m0, n0, wm, wn, li, kh, sk, s1, s2);
+}
+
+// Column statistics of the panel (EPI == 3): the two row-waves of each column half meet through LDS (the ring is free
+// by now), one thread per column merges them (Chan) and writes the workgroup's level-0 record write-through; the tree of
+// this column panel (records = row tiles) then completes in-launch (csrc/col_tree.hpp).
+template <int MB>
+__device__ __forceinline__ void ring_stats(const PanelArgs& P, int rt, int panel, int64_t m0, int wm, int wn, int li, int kh,
+                                           const float (&sk)[3], float (&s1)[3], float (&s2)[3], float* lds) {
+  constexpr int ROWS = 32 * MB;                       // rows per wave
+  __syncthreads();      // every wave is past its final vmcnt(0): no LDS-DMA of the main loop can still land in the ring
+  const int64_t left = P.M - (m0 + (int64_t)wm * ROWS);
+  const float nw = left <= 0 ? 0.0f : (left < ROWS ? (float)left : (float)ROWS);
+  float* rec = lds + 16;                              // [2 row-waves][2][192]
+#pragma unroll
+  for (int j = 0; j < 3; ++j) {
+    s1[j] += __shfl_xor(s1[j], 32);
+    s2[j] += __shfl_xor(s2[j], 32);
+    if (kh == 0) {
+      const int col = wn * 96 + j * 32 + li;
+      rec[(wm * 2 + 0) * TN + col] = nw > 0.0f ? sk[j] + s1[j] / nw : 0.0f;
+      rec[(wm * 2 + 1) * TN + col] = nw > 0.0f ? fmaxf(s2[j] - s1[j] * s1[j] / nw, 0.0f) : 0.0f;
+    }
+  }
+  __syncthreads();
+  tr::Tree T{};
+  T.P = P.row_tiles; T.NV = 2; T.mode = tr::STATS;
+  T.fan = tr::fan_for(T.P);
+  T.NG = (T.P + T.fan - 1) / T.fan;
+  float* w = P.st_ws + (size_t)panel * P.st_stride;
+  T.part = w; w += tr::pad4((size_t)T.P * 2 * TN);
+  T.pcnt = w; w += tr::pad4((size_t)2 * T.P);
+  T.grp = w; w += tr::pad4((size_t)T.NG * 2 * TN);
+  T.gcnt = w;
+  T.tick = P.st_tick + (size_t)panel * tr::kSyncWords;
+  const int n0 = panel * TN;
+  T.o0 = P.st_mean + n0; T.o1 = P.st_rstd + n0;
+  T.o2 = P.st_rmean ? P.st_rmean + n0 : nullptr; T.o3 = P.st_rvar ? P.st_rvar + n0 : nullptr;
+  T.eps = P.st_eps; T.momentum = P.st_mom;
+  const int t = threadIdx.x;
+  const int64_t l0 = P.M - m0;                        // rows of this tile that exist
+  const float n0w = l0 < ROWS ? (float)l0 : (float)ROWS;
+  const float n1w = l0 <= ROWS ? 0.0f : (l0 < 2 * ROWS ? (float)(l0 - ROWS) : (float)ROWS);
+  if (t < TN) {
+    const float ma = rec[0 * TN + t], qa = rec[1 * TN + t], mb_ = rec[2 * TN + t], qb = rec[3 * TN + t];
+    const float nn = n0w + n1w, dl = mb_ - ma, wgt = n1w / nn;
+    tr::st_sc1(T.part + ((int64_t)rt * 2 + 0) * TN + t, ma + dl * wgt);
+    tr::st_sc1(T.part + ((int64_t)rt * 2 + 1) * TN + t, qa + qb + dl * dl * n0w * wgt);
+    if (t == 0) tr::st_sc1(T.pcnt + rt, nn);
+  }
+  tr::arrive<2, tr::STATS, tr::kMaxFan>(T, rt, TN, lds);
 }
 
 // MB = row blocks of 32 per wave: the workgroup's panel is (64 * MB) rows x 192 columns, 2 x 2 waves of (32 * MB) x 96.
@@ -604,7 +674,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring(const PanelArgs P) {
 #undef GPS_RING_STAGE
   __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 15));         // no DMA may still be writing this workgroup's LDS when it retires
   stamp(2);
-  ring_epilogue<MB, EPI, HAS_CIN>(P, acc, m0, n0, wm, wn, li, kh);
+  float sk[3] = {0.f, 0.f, 0.f}, s1[3] = {0.f, 0.f, 0.f}, s2[3] = {0.f, 0.f, 0.f};
+  ring_epilogue<MB, EPI, HAS_CIN>(P, acc, m0, n0, wm, wn, li, kh, sk, s1, s2);
+  if (EPI == 3) ring_stats<MB>(P, rt, panel, m0, wm, wn, li, kh, sk, s1, s2, reinterpret_cast<float*>(ring));
   __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 15));
   stamp(3);
 }
@@ -614,6 +686,21 @@ inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) % 16) =
 }  // namespace
 
 unsigned long long* g_panel_trace = nullptr;
+
+static int panel_launch(const float* A, int64_t lda, int64_t M, int K, const uint16_t* image, int N, const float* bias,
+                        const float* Cin, int64_t ldcin, float* C, int64_t ldc, int epilogue, const float* mask_src,
+                        int64_t ldmask, float p_drop, uint64_t seed, const gps_bn* stats, float* ws, size_t ws_floats,
+                        uint32_t* sync, gps_stream_t stream);
+
+static int ring_mb(int64_t M, int N) {
+  static const int mb_cfg = []() { const char* v = getenv("GPS_GEMM_RING_MB"); return v && *v ? atoi(v) : 0; }();
+  const int64_t tiles128 = ((M + 127) / 128) * (N / TN);
+  return mb_cfg == 1 || mb_cfg == 2 ? mb_cfg : (tiles128 >= 200 ? 2 : 1);
+}
+static bool ring_enabled() {
+  static const int ring_cfg = []() { const char* v = getenv("GPS_GEMM_RING"); return v && *v ? atoi(v) : 1; }();
+  return ring_cfg != 0;
+}
 
 extern "C" {
 
@@ -644,16 +731,51 @@ int gps_gemm_split_weights(int n, const gps_gemm_split* descs, gps_stream_t stre
   return gps::launch_status("gps_gemm_split_weights");
 }
 
+size_t gps_gemm_stats_floats(int64_t M, int N) {
+  if (M < 1 || N < TN) return 0;
+  const int rt = (int)((M + 64 * ring_mb(M, N) - 1) / (64 * ring_mb(M, N)));
+  return (size_t)(N / TN) * (tr::floats_for(rt, 2, TN) + 16);
+}
+int gps_gemm_stats_sync_words(int N) { return (N / TN) * tr::kSyncWords; }
+int gps_gemm_stats_supported(int64_t M, int N, int K) {
+  if (!gps_gemm_panel_supported(N, K) || !ring_enabled() || (K / BK) % RG_SLOTS != 0 || M < 2) return 0;
+  const int mb = ring_mb(M, N);
+  return (M + 64 * mb - 1) / (64 * mb) <= tr::kMaxParts;
+}
+
 int gps_gemm_panel(const float* A, int64_t lda, int64_t M, int K, const uint16_t* image, int N, const float* bias,
                    const float* Cin, int64_t ldcin, float* C, int64_t ldc, int epilogue, const float* mask_src,
                    int64_t ldmask, float p_drop, uint64_t seed, gps_stream_t stream) {
+  GPS_REQUIRE(epilogue >= 0 && epilogue <= 2, "gps_gemm_panel: epilogue");
+  return panel_launch(A, lda, M, K, image, N, bias, Cin, ldcin, C, ldc, epilogue, mask_src, ldmask, p_drop, seed, nullptr,
+                      nullptr, 0, nullptr, stream);
+}
+
+int gps_gemm_panel_stats(const float* A, int64_t lda, int64_t M, int K, const uint16_t* image, int N, const float* bias,
+                         const float* Cin, int64_t ldcin, float* C, int64_t ldc, float p_drop, uint64_t seed,
+                         const gps_bn* stats, float* ws, size_t ws_floats, uint32_t* sync, gps_stream_t stream) {
+  GPS_REQUIRE(gps_gemm_stats_supported(M, N, K), "gps_gemm_panel_stats: shape M=%lld N=%d K=%d not served by the ring kernel",
+              (long long)M, N, K);
+  GPS_REQUIRE(Cin && stats && stats->mean && stats->rstd && ws && sync && al16(ws), "gps_gemm_panel_stats: null / misaligned buffer");
+  GPS_REQUIRE((stats->running_mean == nullptr) == (stats->running_var == nullptr), "gps_gemm_panel_stats: running stats");
+  GPS_REQUIRE(ws_floats >= gps_gemm_stats_floats(M, N), "gps_gemm_panel_stats: workspace too small (gps_gemm_stats_floats)");
+  return panel_launch(A, lda, M, K, image, N, bias, Cin, ldcin, C, ldc, 3, nullptr, 0, p_drop, seed, stats, ws, ws_floats, sync,
+                      stream);
+}
+
+}  // extern "C"
+
+static int panel_launch(const float* A, int64_t lda, int64_t M, int K, const uint16_t* image, int N, const float* bias,
+                        const float* Cin, int64_t ldcin, float* C, int64_t ldc, int epilogue, const float* mask_src,
+                        int64_t ldmask, float p_drop, uint64_t seed, const gps_bn* stats, float* ws, size_t ws_floats,
+                        uint32_t* sync, gps_stream_t stream) {
   GPS_REQUIRE(M >= 0 && gps_gemm_panel_supported(N, K), "gps_gemm_panel: needs N %% 192 == 0 and K %% 128 == 0 (N=%d K=%d)",
               N, K);
   if (M == 0) return GPS_OK;
   GPS_REQUIRE(A && image && C && lda >= K && ldc >= N && lda % 4 == 0 && al16(A) && al16(image),
               "gps_gemm_panel: null / misaligned buffer");
   GPS_REQUIRE(!Cin || ldcin >= N, "gps_gemm_panel: bad addend stride");
-  GPS_REQUIRE(epilogue >= 0 && epilogue <= 2 && (epilogue != 2 || (mask_src && ldmask >= N)), "gps_gemm_panel: epilogue");
+  GPS_REQUIRE(epilogue >= 0 && epilogue <= 3 && (epilogue != 2 || (mask_src && ldmask >= N)), "gps_gemm_panel: epilogue");
   GPS_REQUIRE(p_drop >= 0.0f && p_drop < 1.0f, "gps_gemm_panel: p_drop");
   PanelArgs P{};
   P.A = A; P.lda = lda; P.M = M; P.K = K; P.N = N; P.Bp = image; P.bias = bias; P.Cin = Cin; P.ldcin = ldcin;
@@ -666,11 +788,9 @@ int gps_gemm_panel(const float* A, int64_t lda, int64_t M, int K, const uint16_t
   // ring kernel (LDS-DMA, three-slot ring) whenever the k-stages come in threes; GPS_GEMM_RING=0 keeps the
   // register-staged kernel (A/B measurements).  128-row panels when they still give every CU a workgroup
   // (GPS_GEMM_RING_MB = 1 / 2 forces one).
-  static const int ring_cfg = []() { const char* v = getenv("GPS_GEMM_RING"); return v && *v ? atoi(v) : 1; }();
-  static const int mb_cfg = []() { const char* v = getenv("GPS_GEMM_RING_MB"); return v && *v ? atoi(v) : 0; }();
-  const bool ring = ring_cfg != 0 && (K / BK) % RG_SLOTS == 0 && K / BK >= RG_SLOTS;
-  const int64_t tiles128 = ((M + 127) / 128) * (N / TN);
-  const int mb = mb_cfg == 1 || mb_cfg == 2 ? mb_cfg : (tiles128 >= 200 ? 2 : 1);
+  const bool ring = ring_enabled() && (K / BK) % RG_SLOTS == 0 && K / BK >= RG_SLOTS;
+  const int mb = ring_mb(M, N);
+  GPS_REQUIRE(epilogue != 3 || ring, "gps_gemm_panel: the statistics epilogue needs the ring kernel");
   if (ring) {
     if (!P.bias) {
       GPS_REQUIRE(N <= kZeroBias, "gps_gemm_panel: N=%d without a bias exceeds the built-in zero row (%d)", N, kZeroBias);
@@ -680,6 +800,14 @@ int gps_gemm_panel(const float* A, int64_t lda, int64_t M, int K, const uint16_t
     }
     P.row_tiles = (int)((M + 64 * mb - 1) / (64 * mb));
     grid = (unsigned)(P.row_tiles * (N / TN));
+    if (epilogue == 3) {
+      P.st_ws = ws;
+      P.st_stride = tr::floats_for(P.row_tiles, 2, TN) + 16;
+      P.st_tick = sync;
+      P.st_mean = stats->mean; P.st_rstd = stats->rstd; P.st_rmean = stats->running_mean; P.st_rvar = stats->running_var;
+      P.st_eps = stats->eps; P.st_mom = stats->momentum;
+      (void)ws_floats;
+    }
   }
 #define GPS_RING_LAUNCH(MBV, E, C)                                                                    \
   do {                                                                                                \
@@ -696,10 +824,9 @@ int gps_gemm_panel(const float* A, int64_t lda, int64_t M, int K, const uint16_t
   } while (0)
   if (epilogue == 0) { if (Cin) GPS_PANEL_LAUNCH(0, true); else GPS_PANEL_LAUNCH(0, false); }
   else if (epilogue == 1) { if (Cin) GPS_PANEL_LAUNCH(1, true); else GPS_PANEL_LAUNCH(1, false); }
-  else { if (Cin) GPS_PANEL_LAUNCH(2, true); else GPS_PANEL_LAUNCH(2, false); }
+  else if (epilogue == 2) { if (Cin) GPS_PANEL_LAUNCH(2, true); else GPS_PANEL_LAUNCH(2, false); }
+  else { if (mb == 2) GPS_RING_LAUNCH(2, 3, true); else GPS_RING_LAUNCH(1, 3, true); }
 #undef GPS_RING_LAUNCH
 #undef GPS_PANEL_LAUNCH
   return gps::launch_status("gps_gemm_panel");
 }
-
-}  // extern "C"

@@ -25,6 +25,38 @@ def supported(N: int, K: int) -> bool:
     return ENABLED and N > 0 and K > 0 and N % 192 == 0 and K % 128 == 0
 
 
+_stats_ok = {}
+
+
+def stats_supported(M: int, N: int, K: int) -> bool:
+    """Whether ``gemm_panel_stats`` serves ``[M, K] x [K, N]`` (the ring kernel with <= 576 row tiles)."""
+    key = (M, N, K)
+    v = _stats_ok.get(key)
+    if v is None:
+        v = _stats_ok[key] = bool(supported(N, K) and _lib.load().gps_gemm_stats_supported(M, N, K))
+    return v
+
+
+def gemm_panel_stats(a: torch.Tensor, image: torch.Tensor, N: int, bias: Optional[torch.Tensor], addend: torch.Tensor,
+                     p_drop: float, seed: int, bn_desc, sync_ptr: int) -> torch.Tensor:
+    """``out = addend + dropout(a @ B^T + bias; p_drop, seed)`` and the batch statistics of ``out`` over its rows
+    (-> ``bn_desc.mean / rstd`` + running statistics), complete when the launch retires: the residual + dropout +
+    statistics pass of ``norm1_attn`` / ``norm2`` (graphgps/layer/gps_layer.py:212-217,225-229) in the GEMM's epilogue.
+    ``sync_ptr``: arrival counters (``norm.SyncArena.site``), zero at entry and exit."""
+    import ctypes
+    L = _lib.load()
+    M, K = a.shape
+    if a.stride(1) != 1 or a.dtype != torch.float32:
+        raise _lib.GpsHipError("gemm_panel_stats: fp32 A with unit column stride")
+    out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    wsf = L.gps_gemm_stats_floats(M, N)
+    ws = torch.empty(wsf, dtype=torch.float32, device=a.device)
+    check(L.gps_gemm_panel_stats(ptr(a), a.stride(0), M, K, ptr(image), N, ptr(bias), ptr(addend), addend.stride(0),
+                                 ptr(out), out.stride(0), float(p_drop), int(seed), ctypes.byref(bn_desc), ptr(ws), wsf,
+                                 sync_ptr, current_stream(a.device)), "gps_gemm_panel_stats")
+    return out
+
+
 def split_weights(weights: Sequence[torch.Tensor], nt: bool = True, tn: bool = True
                   ) -> List[Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]]:
     """[(image of W, image of W^T), ...] for up to 8 fp32 weights ``[rows, cols]`` in ONE launch.

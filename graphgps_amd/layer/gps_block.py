@@ -9,8 +9,10 @@ lists and the per-operator tests pin).  What that buys:
   * host time: the modular path spends ~18 us of Python/autograd bookkeeping per launch;
   * merged GEMMs: A|B|D|E and the attention in-projection as ONE ``[N,d] x [d,7d]`` GEMM (forward, dgrad
     and weight gradient);
-  * the norm / residual / dropout stages as task lists (csrc/block_norm.hip): 19 launches per layer
-    instead of 37;
+  * the norm / residual / dropout stages as task lists (csrc/block_norm.hip) whose column reductions finish
+    inside the producing launch (csrc/col_tree.hpp); the batch statistics of x~ / e^ come out of the GatedGCN
+    forward, those of za / z2 out of the ring GEMM epilogues: 8 norm launches per layer (round 2: 17, the
+    operator path: 37);
   * all weight gradients of the block as ONE grouped split-K launch on the side stream (csrc/wgrad.hip);
   * while the step is being captured into a hipGraph, the attention half forks onto its own stream.
 
@@ -25,12 +27,20 @@ import torch
 
 from .. import gemm as _gemm
 from .. import lib as _lib
+from .. import norm as _norm
 from ..fused import _BLOCK_SIDE_ENABLED as _SIDE_ENABLED, _queue_join, _side_stream
 from ..lib import check, current_stream, ptr
 from ..ops import GraphIndex, draw_dropout_seed
 
 _E = torch.empty
 _BY_REF = _ctypes.byref
+
+# A/B switches (default: everything fused).  GPS_GG_STATS=0: statistics of x~ / e^ by a row pass instead of the GatedGCN
+# forward; GPS_GEMM_STATS=0: za / z2 and their statistics by row tasks instead of the ring GEMM epilogue.
+_GG_STATS = _os.environ.get("GPS_GG_STATS", "1") != "0"
+_GEMM_STATS = _os.environ.get("GPS_GEMM_STATS", "1") != "0"
+# launch sites of one layer that own arrival counters (norm.SyncArena.site): sites that may be in flight together differ
+_S_GG, _S_AO, _S_XE, _S_MID, _S_Z2, _S_B1, _S_B3, _S_B4 = range(8)
 
 
 class _K:
@@ -186,10 +196,7 @@ class _Fork:
                 t.record_stream(self.cur)
 
 
-def _bn_desc(bn, mean, rstd):
-    """``gps_bn`` descriptor of a BatchNorm1d + the [d] buffers holding its batch statistics."""
-    return _lib.BnDesc(ptr(bn.weight), ptr(bn.bias), ptr(mean), ptr(rstd), ptr(bn.running_mean),
-                       ptr(bn.running_var), float(bn.eps), float(bn.momentum))
+_bn_desc = _norm.bn_desc
 
 
 class _GPSBlock(torch.autograd.Function):
@@ -230,6 +237,16 @@ class _GPSBlock(torch.autograd.Function):
             pq = torch.addmm(bcat, x, wcat.t())                 # [N, 4d + 3d]
         ldp = 7 * d
         P, fs = pq.data_ptr(), d * 4
+        # -- the five BatchNorms: descriptors over one [10, d] statistics buffer ----------------------------
+        stats = _E(10, d, **f32)                                # (mean, rstd) x 5
+        bnx = _bn_desc(lm.bn_node_x, stats[0], stats[1])
+        bne = _bn_desc(lm.bn_edge_e, stats[2], stats[3])
+        bnl = _bn_desc(layer.norm1_local, stats[4], stats[5])
+        bna = _bn_desc(layer.norm1_attn, stats[6], stats[7])
+        bn2 = _bn_desc(layer.norm2, stats[8], stats[9])
+        ref = _BY_REF
+        sync = _norm.sync_arena(layer, dev)
+        gemm_stats = panel and _GEMM_STATS and _gemm.stats_supported(N, d, d) and _gemm.stats_supported(N, d, 2 * d)
         # -- global branch (forked): varlen attention over the PRE-layer x (gps_layer.py:199-201,234-241)
         with _Fork(dev, _BRANCH) as fork:
             sb = current_stream(dev)
@@ -238,51 +255,61 @@ class _GPSBlock(torch.autograd.Function):
             check(L.gps_seg_attn_fwd(P + 4 * fs, ldp, ptr(gi.ptr), ptr(gi.tile_graph), ptr(gi.tile_row0),
                                      gi.max_tiles, N, H, dh, scale, p_at, s[2], ptr(o), ptr(lse),
                                      gi.B, int(gi.nmax_host), sb), "gps_seg_attn_fwd")
-            ao = (_gemm.gemm_panel(o, imgs[2][0], d, bias=sa.out_proj.bias) if panel
-                  else torch.addmm(sa.out_proj.bias, o, sa.out_proj.weight.t()))
+            if gemm_stats:      # za = x + drop(out_proj(o)) and the statistics of za (norm1_attn) in the GEMM's epilogue
+                ao = None
+                za = _gemm.gemm_panel_stats(o, imgs[2][0], d, sa.out_proj.bias, x, p_l, s[3], bna, sync.site(_S_AO))
+            else:
+                za = None
+                ao = (_gemm.gemm_panel(o, imgs[2][0], d, bias=sa.out_proj.bias) if panel
+                      else torch.addmm(sa.out_proj.bias, o, sa.out_proj.weight.t()))
         # -- local branch: C projection + GatedGCN core ----------------------------------------
         ce = (_gemm.gemm_panel(e, imgs[1][0], d, bias=lm.C.bias) if panel
               else torch.addmm(lm.C.bias, e, lm.C.weight.t()))
         xt, eh = _E(N, d, **f32), _E(E, d, **f32)
-        check(L.gps_gatedgcn_fwd(P, P + fs, P + 2 * fs, P + 3 * fs, ldp, ptr(ce), ptr(gi.rowptr_dst),
-                                 ptr(gi.src_by_dst), ptr(gi.eid_by_dst), N, E, d, ptr(xt), ptr(eh),
-                                 None, st), "gps_gatedgcn_fwd")
-        fork.join(o, lse, ao)
+        if _GG_STATS:           # statistics of x~ (bn_node_x) and e^ (bn_edge_e) fall out of the same launch
+            wsf = L.gps_gatedgcn_stats_floats(N, d)
+            gws = _E(wsf, **f32)
+            check(L.gps_gatedgcn_fwd_stats(P, P + fs, P + 2 * fs, P + 3 * fs, ldp, ptr(ce), ptr(gi.rowptr_dst),
+                                           ptr(gi.src_by_dst), ptr(gi.eid_by_dst), N, E, d, ptr(xt), ptr(eh),
+                                           None, ref(bnx), ref(bne), ptr(gws), wsf, sync.site(_S_GG), st),
+                  "gps_gatedgcn_fwd_stats")
+        else:
+            check(L.gps_gatedgcn_fwd(P, P + fs, P + 2 * fs, P + 3 * fs, ldp, ptr(ce), ptr(gi.rowptr_dst),
+                                     ptr(gi.src_by_dst), ptr(gi.eid_by_dst), N, E, d, ptr(xt), ptr(eh),
+                                     None, st), "gps_gatedgcn_fwd")
+            _norm.fwd([_norm.fwd_task(_norm.LOAD, xt, N, stats=bnx), _norm.fwd_task(_norm.LOAD, eh, E, stats=bne)],
+                      d, dev, sync.site(_S_XE))
+        fork.join(o, lse, *([za] if ao is None else [ao]))
 
-        # -- the five BatchNorms, residuals and dropouts as task lists (csrc/block_norm.hip) -------
-        stats = _E(10, d, **f32)                                # (mean, rstd) x 5
-        ws = _E(L.gps_block_norm_workspace_floats(N, E, d), **f32)
-        bnx = _bn_desc(lm.bn_node_x, stats[0], stats[1])
-        bne = _bn_desc(lm.bn_edge_e, stats[2], stats[3])
-        bnl = _bn_desc(layer.norm1_local, stats[4], stats[5])
-        bna = _bn_desc(layer.norm1_attn, stats[6], stats[7])
-        bn2 = _bn_desc(layer.norm2, stats[8], stats[9])
-        ref = _BY_REF
-        check(L.gps_bn_stats_pair(ptr(xt), N, ref(bnx), ptr(eh), E, ref(bne), d, ptr(ws), st),
-              "gps_bn_stats_pair")
-        x1, e1, za = _E(N, d, **f32), _E(E, d, **f32), _E(N, d, **f32)
-        # x1 = x + drop(relu(BN_x(xt))), e1 = e + drop(relu(BN_e(eh))), za = x + drop(ao)
-        # (+ statistics of x1 and za for norm1_local / norm1_attn)
-        check(L.gps_block_mid_fwd(ptr(xt), ptr(x), ref(bnx), p, s[0], ptr(x1), ptr(eh), ptr(e), ref(bne),
-                                  s[1], ptr(e1), ptr(ao), p_l, s[3], ptr(za), ref(bnl), ref(bna), N, E,
-                                  d, ptr(ws), st), "gps_block_mid_fwd")
+        # -- x1 = x + drop(relu(BN_x(xt))) [+ statistics -> norm1_local], e1 = e + drop(relu(BN_e(eh))),
+        #    za = x + drop(ao) [+ statistics -> norm1_attn] unless the out-projection already produced it
+        x1, e1 = _E(N, d, **f32), _E(E, d, **f32)
+        mid = [_norm.fwd_task(_norm.BN_ACT, xt, N, res=x, bn1=bnx, relu=True, p=p, seed=s[0], out=x1, stats=bnl),
+               _norm.fwd_task(_norm.BN_ACT, eh, E, res=e, bn1=bne, relu=True, p=p, seed=s[1], out=e1)]
+        if za is None:
+            za = _E(N, d, **f32)
+            mid.append(_norm.fwd_task(_norm.ADD_DROP, x, N, b=ao, p=p_l, seed=s[3], out=za, stats=bna))
+        _norm.fwd(mid, d, dev, sync.site(_S_MID))
         h = _E(N, d, **f32)                                     # BN_l(x1) + BN_a(za)  (gps_layer.py:222)
-        check(L.gps_bn_dual_apply(ptr(x1), ref(bnl), ptr(za), ref(bna), N, d, ptr(h), st),
-              "gps_bn_dual_apply")
+        _norm.fwd([_norm.fwd_task(_norm.BN_DUAL, x1, N, b=za, bn1=bnl, bn2=bna, out=h)], d, dev, None)
 
         # -- FFN + norm2 (gps_layer.py:225-229,253-257) ----------------------------------------
         if panel:       # t = drop(relu(ff1(h))) in the GEMM's epilogue: f1 is never materialised
             f1 = None
             t = _gemm.gemm_panel(h, imgs[3][0], 2 * d, bias=layer.ff_linear1.bias, epilogue=1, p_drop=p_f1, seed=s[4])
-            f2 = _gemm.gemm_panel(t, imgs[4][0], d, bias=layer.ff_linear2.bias)
         else:
             f1 = torch.addmm(layer.ff_linear1.bias, h, layer.ff_linear1.weight.t())
             t = _K.act_drop_add(L, None, f1, True, p_f1, s[4], st)
-            f2 = torch.addmm(layer.ff_linear2.bias, t, layer.ff_linear2.weight.t())
-        z2 = _E(N, d, **f32)                                    # h + drop(f2) and its statistics
-        check(L.gps_add_drop_stats(ptr(h), ptr(f2), N, d, p_f2, s[5], ptr(z2), ref(bn2), ptr(ws), st),
-              "gps_add_drop_stats")
-        out = _K.bn_apply(L, z2, stats[8], stats[9], layer.norm2, None, False, 0.0, 0, st)
+        if gemm_stats:  # z2 = h + drop(ff2(t)) and the statistics of z2 (norm2) in the GEMM's epilogue
+            z2 = _gemm.gemm_panel_stats(t, imgs[4][0], d, layer.ff_linear2.bias, h, p_f2, s[5], bn2, sync.site(_S_Z2))
+        else:
+            f2 = (_gemm.gemm_panel(t, imgs[4][0], d, bias=layer.ff_linear2.bias) if panel
+                  else torch.addmm(layer.ff_linear2.bias, t, layer.ff_linear2.weight.t()))
+            z2 = _E(N, d, **f32)                                # h + drop(f2) and its statistics
+            _norm.fwd([_norm.fwd_task(_norm.ADD_DROP, h, N, b=f2, p=p_f2, seed=s[5], out=z2, stats=bn2)], d, dev,
+                      sync.site(_S_Z2))
+        out = _E(N, d, **f32)
+        _norm.fwd([_norm.fwd_task(_norm.BN_ACT, z2, N, bn1=bn2, out=out)], d, dev, None)
         torch._foreach_add_([lm.bn_node_x.num_batches_tracked, lm.bn_edge_e.num_batches_tracked,
                              layer.norm1_local.num_batches_tracked,
                              layer.norm1_attn.num_batches_tracked,
@@ -308,20 +335,22 @@ class _GPSBlock(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         g_out = g_out.contiguous()
         g_e1 = g_e1.contiguous() if g_e1 is not None else torch.zeros(E, d, **f32)
-        ws = _E(L.gps_block_norm_workspace_floats(N, E, d), **f32)
         bnx = _bn_desc(lm.bn_node_x, stats[0], stats[1])
         bne = _bn_desc(lm.bn_edge_e, stats[2], stats[3])
         bnl = _bn_desc(layer.norm1_local, stats[4], stats[5])
         bna = _bn_desc(layer.norm1_attn, stats[6], stats[7])
         bn2 = _bn_desc(layer.norm2, stats[8], stats[9])
-        ref = _BY_REF
+        sync = _norm.sync_arena(layer, dev)
         gpar = _E(10, d, **f32)              # (g_gamma, g_beta) of the five norms
         g_bxw, g_bxb, g_bew, g_beb, g_nlw, g_nlb, g_naw, g_nab, g_n2w, g_n2b = gpar.unbind(0)
 
-        # norm2 <- z2 = h + drop(f2):  g_z2 and g_f2 = dropmask(g_z2) in one pass
-        g_z2, g_f2 = _E(N, d, **f32), _E(N, d, **f32)
-        check(L.gps_bn_bwd_drop(ptr(z2), ptr(g_out), ref(bn2), N, d, 0, 0.0, 0, ptr(g_z2), ptr(g_n2w),
-                                ptr(g_n2b), p_f2, s[5], ptr(g_f2), ptr(ws), st), "gps_bn_bwd_drop")
+        # norm2 <- z2 = h + drop(f2):  g_z2 and g_f2 = dropmask(g_z2);  bn_edge_e <- e^ (its output gradient g_e1 is an
+        # input of this node, so its column sums and its apply ride along): ONE partial launch, ONE apply launch
+        g_z2, g_f2, g_eh = _E(N, d, **f32), _E(N, d, **f32), _E(E, d, **f32)
+        b1 = [_norm.bwd_task(z2, g_out, bn2, N, g_n2w, g_n2b, g_z=g_z2, g_drop=g_f2, p2=p_f2, seed2=s[5]),
+              _norm.bwd_task(eh, g_e1, bne, E, g_bew, g_beb, relu=True, p=p, seed=s[1], g_z=g_eh)]
+        _norm.bwd_partial(b1, d, dev, sync.site(_S_B1))
+        _norm.bwd_apply(b1, d, dev, None)
         # f2 = ff2(t);  t = drop(relu(f1));  f1 = ff1(h)
         imgs = ctx.imgs
         if imgs is not None:
@@ -334,11 +363,15 @@ class _GPSBlock(torch.autograd.Function):
             g_f1 = _K.act_drop_bwd(L, g_t, f1, True, p_f1, s[4], st)
             g_h = g_z2.addmm_(g_f1, layer.ff_linear1.weight)              # residual + FFN input
 
-        # h = BN_l(x1) + BN_a(za);  za = x + drop(ao):  g_x1, g_x1 + g_za, g_ao = dropmask(g_za)
+        # h = BN_l(x1) + BN_a(za);  za = x + drop(ao):  g_x1, g_x1 + g_za, g_ao = dropmask(g_za).  The apply CHAINS into
+        # bn_node_x (x1 = x + drop(relu(BN_x(xt))): g_x1 is that BatchNorm's output gradient): its column sums come out of
+        # the same pass, so bn_node_x needs no partial launch of its own
         g_x1, g_xres, g_ao = _E(N, d, **f32), _E(N, d, **f32), _E(N, d, **f32)
-        check(L.gps_bn_dual_bwd(ptr(x1), ref(bnl), ptr(za), ref(bna), ptr(g_h), N, d, ptr(g_x1), 0.0, 0,
-                                ptr(g_xres), p_l, s[3], ptr(g_ao), ptr(g_nlw), ptr(g_nlb), ptr(g_naw),
-                                ptr(g_nab), ptr(ws), st), "gps_bn_dual_bwd")
+        b3 = [_norm.bwd_task(x1, g_h, bnl, N, g_nlw, g_nlb, z2=za, bn2=bna, g_gamma2=g_naw, g_beta2=g_nab,
+                             g_z=g_x1, g_sum=g_xres, g_drop=g_ao, p2=p_l, seed2=s[3],
+                             cz=xt, cbn=bnx, crelu=True, cp=p, cseed=s[0], cg_gamma=g_bxw, cg_beta=g_bxb)]
+        _norm.bwd_partial(b3, d, dev, sync.site(_S_B3))
+        _norm.bwd_apply(b3, d, dev, sync.site(_S_B4))
         # gradient of the merged projection: attention writes dq|dk|dv into columns 4d.., GatedGCN
         # writes g_Ax|g_Bx|g_Dx|g_Ex into columns 0..4d of ONE [N,7d] buffer -> one dgrad, one wgrad
         ldp = 7 * d
@@ -354,11 +387,9 @@ class _GPSBlock(torch.autograd.Function):
                                      p_at, s[2], ptr(delta), G + 4 * fs, ldp, gi.B, int(gi.nmax_host), sb),
                   "gps_seg_attn_bwd")
 
-        # x1 = x + drop(relu(BN_x(xt)));  e1 = e + drop(relu(BN_e(eh))):  both BN backwards as one list
-        g_xt, g_eh = _E(N, d, **f32), _E(E, d, **f32)
-        check(L.gps_bn_bwd_pair(ptr(xt), ptr(g_x1), ref(bnx), N, s[0], ptr(g_xt), ptr(g_bxw), ptr(g_bxb),
-                                ptr(eh), ptr(g_e1), ref(bne), E, s[1], ptr(g_eh), ptr(g_bew),
-                                ptr(g_beb), d, 1, p, ptr(ws), st), "gps_bn_bwd_pair")
+        # x1 = x + drop(relu(BN_x(xt))):  bn_node_x's apply (its sums came from the chain above)
+        g_xt = _E(N, d, **f32)
+        _norm.bwd_apply([_norm.bwd_task(xt, g_x1, bnx, N, g_bxw, g_bxb, relu=True, p=p, seed=s[0], g_z=g_xt)], d, dev, None)
         g_ce = _E(E, d, **f32)
         check(L.gps_gatedgcn_bwd(ptr(g_xt), d, ptr(g_eh), ptr(eh), P, P + fs, ldp, ptr(xt),
                                  ptr(gi.rowptr_dst), ptr(gi.src_by_dst), ptr(gi.eid_by_dst),
@@ -435,25 +466,25 @@ class _GPSBlockGINE(torch.autograd.Function):
 
         # -- zl = x + drop(g2), za = x + drop(ao) with their statistics; h = BN_l(zl) + BN_a(za) -----
         stats = _E(6, d, **f32)
-        ws = _E(L.gps_block_norm_workspace_floats(N, max(E, 1), d), **f32)
         bnl = _bn_desc(layer.norm1_local, stats[0], stats[1])
         bna = _bn_desc(layer.norm1_attn, stats[2], stats[3])
         bn2 = _bn_desc(layer.norm2, stats[4], stats[5])
+        sync = _norm.sync_arena(layer, dev)
         zl, za = _E(N, d, **f32), _E(N, d, **f32)
-        check(L.gps_add_drop_stats_pair(ptr(x), ptr(g2), p_loc, s[0], ptr(zl), ref(bnl), ptr(x), ptr(ao),
-                                        p_l, s[3], ptr(za), ref(bna), N, d, ptr(ws), st),
-              "gps_add_drop_stats_pair")
+        _norm.fwd([_norm.fwd_task(_norm.ADD_DROP, x, N, b=g2, p=p_loc, seed=s[0], out=zl, stats=bnl),
+                   _norm.fwd_task(_norm.ADD_DROP, x, N, b=ao, p=p_l, seed=s[3], out=za, stats=bna)],
+                  d, dev, sync.site(_S_MID))
         h = _E(N, d, **f32)
-        check(L.gps_bn_dual_apply(ptr(zl), ref(bnl), ptr(za), ref(bna), N, d, ptr(h), st),
-              "gps_bn_dual_apply")
+        _norm.fwd([_norm.fwd_task(_norm.BN_DUAL, zl, N, b=za, bn1=bnl, bn2=bna, out=h)], d, dev, None)
         # -- FFN + norm2 --------------------------------------------------------------------------------
         f1 = torch.addmm(layer.ff_linear1.bias, h, layer.ff_linear1.weight.t())
         t = _K.act_drop_add(L, None, f1, True, p_f1, s[4], st)
         f2 = torch.addmm(layer.ff_linear2.bias, t, layer.ff_linear2.weight.t())
         z2 = _E(N, d, **f32)
-        check(L.gps_add_drop_stats(ptr(h), ptr(f2), N, d, p_f2, s[5], ptr(z2), ref(bn2), ptr(ws), st),
-              "gps_add_drop_stats")
-        out = _K.bn_apply(L, z2, stats[4], stats[5], layer.norm2, None, False, 0.0, 0, st)
+        _norm.fwd([_norm.fwd_task(_norm.ADD_DROP, h, N, b=f2, p=p_f2, seed=s[5], out=z2, stats=bn2)], d, dev,
+                  sync.site(_S_Z2))
+        out = _E(N, d, **f32)
+        _norm.fwd([_norm.fwd_task(_norm.BN_ACT, z2, N, bn1=bn2, out=out)], d, dev, None)
         torch._foreach_add_([layer.norm1_local.num_batches_tracked, layer.norm1_attn.num_batches_tracked,
                              layer.norm2.num_batches_tracked], 1)
         ctx.save_for_backward(x, e, agg, g1, g1r, qkv, o, lse, zl, za, h, f1, t, z2, stats)
@@ -476,24 +507,26 @@ class _GPSBlockGINE(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         ref = _BY_REF
         g_out = g_out.contiguous()
-        ws = _E(L.gps_block_norm_workspace_floats(N, max(E, 1), d), **f32)
         bnl = _bn_desc(layer.norm1_local, stats[0], stats[1])
         bna = _bn_desc(layer.norm1_attn, stats[2], stats[3])
         bn2 = _bn_desc(layer.norm2, stats[4], stats[5])
+        sync = _norm.sync_arena(layer, dev)
         gpar = _E(6, d, **f32)
         g_nlw, g_nlb, g_naw, g_nab, g_n2w, g_n2b = gpar.unbind(0)
 
         g_z2, g_f2 = _E(N, d, **f32), _E(N, d, **f32)
-        check(L.gps_bn_bwd_drop(ptr(z2), ptr(g_out), ref(bn2), N, d, 0, 0.0, 0, ptr(g_z2), ptr(g_n2w),
-                                ptr(g_n2b), p_f2, s[5], ptr(g_f2), ptr(ws), st), "gps_bn_bwd_drop")
+        b1 = [_norm.bwd_task(z2, g_out, bn2, N, g_n2w, g_n2b, g_z=g_z2, g_drop=g_f2, p2=p_f2, seed2=s[5])]
+        _norm.bwd_partial(b1, d, dev, sync.site(_S_B1))
+        _norm.bwd_apply(b1, d, dev, None)
         g_t = g_f2.mm(layer.ff_linear2.weight)
         g_f1 = _K.act_drop_bwd(L, g_t, f1, True, p_f1, s[4], st)
         g_h = g_z2.addmm_(g_f1, layer.ff_linear1.weight)
         # g_g2 = dropmask_local(g_zl), g_xres = g_zl + g_za, g_ao = dropmask_attn(g_za)
         g_g2, g_xres, g_ao = _E(N, d, **f32), _E(N, d, **f32), _E(N, d, **f32)
-        check(L.gps_bn_dual_bwd(ptr(zl), ref(bnl), ptr(za), ref(bna), ptr(g_h), N, d, ptr(g_g2), p_loc,
-                                s[0], ptr(g_xres), p_l, s[3], ptr(g_ao), ptr(g_nlw), ptr(g_nlb),
-                                ptr(g_naw), ptr(g_nab), ptr(ws), st), "gps_bn_dual_bwd")
+        b3 = [_norm.bwd_task(zl, g_h, bnl, N, g_nlw, g_nlb, z2=za, bn2=bna, g_gamma2=g_naw, g_beta2=g_nab,
+                             g_z=g_g2, p1x=p_loc, seed1x=s[0], g_sum=g_xres, g_drop=g_ao, p2=p_l, seed2=s[3])]
+        _norm.bwd_partial(b3, d, dev, sync.site(_S_B3))
+        _norm.bwd_apply(b3, d, dev, None)
         with _Fork(dev, _BRANCH) as fork:            # attention half
             sb = current_stream(dev)
             g_o = g_ao.mm(sa.out_proj.weight)

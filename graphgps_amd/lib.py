@@ -15,7 +15,7 @@ import torch  # noqa: F401  -- must be imported first: it maps the HIP runtime o
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GPS_HIP_LIB: an alternative build of the same ABI (A/B timing of kernel variants in one process launch each)
 LIB_PATH = os.environ.get("GPS_HIP_LIB") or os.path.join(_HERE, "csrc", "libgps_hip.so")
-ABI_VERSION = 4
+ABI_VERSION = 5
 
 _lib: Optional[ctypes.CDLL] = None
 
@@ -31,6 +31,10 @@ _SIGNATURES = {
     "gps_attn_tile_map": (c_int, [_P, c_int64, c_int64, _P, _P, _P]),
     "gps_gatedgcn_fwd": (c_int, [_P, _P, _P, _P, c_int64, _P, _P, _P, _P, c_int64, c_int64, c_int,
                                  _P, _P, _P, _P]),
+    "gps_gatedgcn_stats_floats": (c_size_t, [c_int64, c_int]),
+    "gps_gatedgcn_stats_sync_words": (c_int, []),
+    "gps_gatedgcn_fwd_stats": (c_int, [_P, _P, _P, _P, c_int64, _P, _P, _P, _P, c_int64, c_int64, c_int,
+                                       _P, _P, _P, _P, _P, _P, c_size_t, _P, _P]),
     "gps_gatedgcn_bwd": (c_int, [_P, c_int64, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P,
                                  c_int64, c_int64, c_int, _P, _P, _P, _P, _P, c_int64, _P, _P]),
     "gps_gine_fwd": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int64, c_int, c_float, _P, _P, _P]),
@@ -55,20 +59,11 @@ _SIGNATURES = {
                             _P]),
     "gps_wgrad_grouped_workspace_floats": (c_size_t, [c_int, _P]),
     "gps_wgrad_grouped": (c_int, [c_int, _P, _P, _P]),
-    "gps_block_norm_workspace_floats": (c_size_t, [c_int64, c_int64, c_int]),
-    "gps_bn_stats_pair": (c_int, [_P, c_int64, _P, _P, c_int64, _P, c_int, _P, _P]),
-    "gps_block_mid_fwd": (c_int, [_P, _P, _P, c_float, c_uint64, _P, _P, _P, _P, c_uint64, _P, _P, c_float,
-                                  c_uint64, _P, _P, _P, c_int64, c_int64, c_int, _P, _P]),
-    "gps_bn_dual_apply": (c_int, [_P, _P, _P, _P, c_int64, c_int, _P, _P]),
-    "gps_add_drop_stats": (c_int, [_P, _P, c_int64, c_int, c_float, c_uint64, _P, _P, _P, _P]),
-    "gps_bn_bwd_drop": (c_int, [_P, _P, _P, c_int64, c_int, c_int, c_float, c_uint64, _P, _P, _P, c_float,
-                                c_uint64, _P, _P, _P]),
-    "gps_add_drop_stats_pair": (c_int, [_P, _P, c_float, c_uint64, _P, _P, _P, _P, c_float, c_uint64, _P, _P,
-                                        c_int64, c_int, _P, _P]),
-    "gps_bn_dual_bwd": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int, _P, c_float, c_uint64, _P, c_float,
-                                c_uint64, _P, _P, _P, _P, _P, _P, _P]),
-    "gps_bn_bwd_pair": (c_int, [_P, _P, _P, c_int64, c_uint64, _P, _P, _P, _P, _P, _P, c_int64, c_uint64,
-                                _P, _P, _P, c_int, c_int, c_float, _P, _P]),
+    "gps_norm_tree_floats": (c_size_t, [c_int64, c_int]),
+    "gps_norm_sync_words": (c_int, []),
+    "gps_norm_fwd": (c_int, [c_int, _P, c_int, _P, c_size_t, _P, _P]),
+    "gps_norm_bwd_partial": (c_int, [c_int, _P, c_int, _P, c_size_t, _P, _P]),
+    "gps_norm_bwd_apply": (c_int, [c_int, _P, c_int, _P, c_size_t, _P, _P]),
     "gps_rwse_lds_nodes": (c_int, []),
     "gps_rwse": (c_int, [_P, _P, _P, c_int64, c_int64, c_int, c_int, c_float, _P, _P, _P, _P]),
     "gps_segment_max_len": (c_int, [_P, c_int64, _P, _P]),
@@ -93,6 +88,11 @@ _SIGNATURES = {
     "gps_gemm_panel_trace": (c_int, [_P]),
     "gps_gemm_panel": (c_int, [_P, c_int64, c_int64, c_int, _P, c_int, _P, _P, c_int64, _P, c_int64, c_int, _P,
                                c_int64, c_float, c_uint64, _P]),
+    "gps_gemm_stats_floats": (c_size_t, [c_int64, c_int]),
+    "gps_gemm_stats_sync_words": (c_int, [c_int]),
+    "gps_gemm_stats_supported": (c_int, [c_int64, c_int, c_int]),
+    "gps_gemm_panel_stats": (c_int, [_P, c_int64, c_int64, c_int, _P, c_int, _P, _P, c_int64, _P, c_int64, c_float,
+                                     c_uint64, _P, _P, c_size_t, _P, _P]),
     "gps_gcn_dinv": (c_int, [_P, _P, c_int64, c_int64, _P, _P]),
     "gps_gcn_spmm": (c_int, [_P, c_int64, _P, _P, _P, c_int64, c_int64, c_int, _P, _P]),
     "gps_adj_sum": (c_int, [_P, c_int64, _P, _P, c_float, c_int64, c_int64, c_int, _P, _P]),

@@ -61,6 +61,7 @@ class TrainStep:
         self.salt = salt
         self._g_fb = self._g_up = None
         self._static_loss = None
+        self._tick = None
         self.use_replay = True           # once captured: replay (True) or keep launching eagerly
         self.mode = "eager"
 
@@ -130,6 +131,8 @@ class TrainStep:
         # branch, code2 step without the weight-gradient stream), while the same kernels captured with any second branch
         # joined in replay fine.  One trivial forked node (a 4-byte add on a second stream, joined at the end) is enough
         # to avoid it and costs nothing, so every capture gets one.  GPS_CAPTURE_TICK=0 removes it (to reproduce).
+        # The tick tensor is written by EVERY replay, so it must live exactly as long as the graphs do (a local would
+        # hand its block back to the caching allocator and each replay would then add 1.0f into whoever got it next).
         tick = torch.zeros(1, device=dev) if _os.environ.get("GPS_CAPTURE_TICK", "1") != "0" else None
         with torch.cuda.graph(g_fb, capture_error_mode="thread_local"):
             if tick is not None:
@@ -150,6 +153,7 @@ class TrainStep:
                 self.update()
         torch.cuda.synchronize(dev)
         self._g_fb, self._g_up, self._static_loss = g_fb, g_up, loss
+        self._tick = tick
         self.mode = ("hipGraph replay: [fwd+bwd+pack] -> RCCL all-reduce -> [clip+AdamW]" if split
                      else "hipGraph replay of the whole step")
 

@@ -33,6 +33,19 @@ extern "C" {
 
 typedef void* gps_stream_t; /* hipStream_t */
 
+/* One torch.nn.BatchNorm1d in training mode: its affine parameters and the [d] buffers that hold its batch statistics.
+ * Consumed by the task-list norm kernels (gps_norm_*) and by the producers that emit batch statistics in their own
+ * launch (gps_gatedgcn_fwd_stats, gps_gemm_panel_stats). */
+typedef struct gps_bn {       /* one torch.nn.BatchNorm1d in training mode */
+  const float* gamma;         /* weight [d] */
+  const float* beta;          /* bias [d] */
+  float* mean;                /* batch mean [d]: written by the statistics stages, read by apply/backward */
+  float* rstd;                /* 1/sqrt(biased var + eps) [d] */
+  float* running_mean;        /* updated by the statistics stages (both NULL: not tracked) */
+  float* running_var;
+  float eps, momentum;
+} gps_bn;
+
 int gps_abi_version(void);
 const char* gps_last_error(void);
 
@@ -90,6 +103,18 @@ int gps_gatedgcn_fwd(const float* Ax, const float* Bx, const float* Dx, const fl
                      int64_t ld_node, const float* Ce, const int32_t* rowptr_dst,
                      const int32_t* src_by_dst, const int32_t* eid_by_dst, int64_t N, int64_t E,
                      int d, float* x_tilde, float* e_hat, const float* r_edge, gps_stream_t stream);
+/* The same launch, additionally producing the batch statistics of x_tilde (-> bn_x: bn_node_x) and of e_hat
+ * (-> bn_e: bn_edge_e), graphgps/layer/gatedgcn_layer.py:72-73: every lane accumulates shifted sums of the rows it
+ * writes, a workgroup's row lanes meet through LDS, and the node blocks' records -- (mean, M2) of both tensors with
+ * their two row counts -- are combined in-launch (csrc/col_tree.hpp).  d % 4 == 0, N, E >= 2.
+ *   ws: gps_gatedgcn_stats_floats(N, d) floats; sync: gps_gatedgcn_stats_sync_words() uint32, zero at entry / exit. */
+size_t gps_gatedgcn_stats_floats(int64_t N, int d);
+int gps_gatedgcn_stats_sync_words(void);
+int gps_gatedgcn_fwd_stats(const float* Ax, const float* Bx, const float* Dx, const float* Ex,
+                           int64_t ld_node, const float* Ce, const int32_t* rowptr_dst,
+                           const int32_t* src_by_dst, const int32_t* eid_by_dst, int64_t N, int64_t E,
+                           int d, float* x_tilde, float* e_hat, const float* r_edge, const gps_bn* bn_x,
+                           const gps_bn* bn_e, float* ws, size_t ws_floats, uint32_t* sync, gps_stream_t stream);
 
 /* Backward.  Inputs: g_x [N,d] with row stride ld_gx (grad wrt x_tilde), g_e [E,d] (grad wrt e_hat), the
  * forward's e_hat and x_tilde and its Ax / Bx inputs (ld_node).  Outputs: g_Ce [E,d]; g_Ax/g_Bx/g_Dx/g_Ex
@@ -197,6 +222,19 @@ int gps_gemm_panel_trace(unsigned long long* buf);
 int gps_gemm_panel(const float* A, int64_t lda, int64_t M, int K, const uint16_t* image, int N, const float* bias,
                    const float* Cin, int64_t ldcin, float* C, int64_t ldc, int epilogue, const float* mask_src,
                    int64_t ldmask, float p_drop, uint64_t seed, gps_stream_t stream);
+/* Residual + dropout + BatchNorm statistics in the GEMM's epilogue (ring kernel):
+ *   C = Cin + dropout(A W^T + bias; p_drop, seed)      and the batch statistics of C over its M rows
+ *   -> stats->mean / rstd (+ running statistics), complete when the launch retires (csrc/col_tree.hpp: one tree per
+ *   192-column panel, level-0 records = the row tiles).  Replaces `h + dropout(ff_linear2(t))` / `x + dropout(attn)`
+ *   followed by the statistics pass of norm2 / norm1_attn (graphgps/layer/gps_layer.py:212-217,225-229).
+ *   ws: gps_gemm_stats_floats(M, N) floats; sync: gps_gemm_stats_sync_words(N) uint32, zero at entry, zero at exit.
+ *   Shapes: gps_gemm_stats_supported(M, N, K). */
+size_t gps_gemm_stats_floats(int64_t M, int N);
+int gps_gemm_stats_sync_words(int N);
+int gps_gemm_stats_supported(int64_t M, int N, int K);
+int gps_gemm_panel_stats(const float* A, int64_t lda, int64_t M, int K, const uint16_t* image, int N, const float* bias,
+                         const float* Cin, int64_t ldcin, float* C, int64_t ldc, float p_drop, uint64_t seed,
+                         const gps_bn* stats, float* ws, size_t ws_floats, uint32_t* sync, gps_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Segment (per-graph, varlen) multi-head attention core on fp32 MFMA (v_mfma_f32_16x16x4_f32).
@@ -362,63 +400,74 @@ int gps_segment_pool_bwd(const float* g_out, const int32_t* ptr, const int32_t* 
                          int64_t N, int d, int mean, float* g_x, gps_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
- * Task-list BatchNorm / residual / dropout stages of one CustomGatedGCN+Transformer GPS block
- * (csrc/block_norm.hip).  Same arithmetic as the gps_bn_* / gps_act_drop_* entry points above
- * (identical formulas, statistics and counter-hash dropout), issued as lists of independent row
- * streams per launch and with neighbouring stages merged: 19 launches per layer instead of 37.
+ * Task-list BatchNorm / residual / dropout stages of the fused GPS blocks (csrc/block_norm.hip).
+ * Same arithmetic as the gps_bn_* / gps_act_drop_* entry points above (identical formulas, statistics and
+ * counter-hash dropout), issued as LISTS of up to 4 independent row streams per launch; the column reductions
+ * every BatchNorm needs (batch statistics forward; sum g, sum g*zhat backward) complete INSIDE the producing
+ * launch (csrc/col_tree.hpp: write-through partial records, arrival tickets, the last-arriving workgroup combines
+ * in index order -- deterministic, no finalize launch, nobody waits).
  * Reference lines: graphgps/layer/gatedgcn_layer.py:72-83 (bn_node_x / bn_edge_e + ReLU + dropout +
  * residual), graphgps/layer/gps_layer.py:191-194 (norm1_local), :212-217 (dropout_attn + residual +
- * norm1_attn), :222 (branch sum), :225-229 (ff_dropout2 + residual + norm2).
- * All row buffers [R, d] fp32, d % 4 == 0, d <= 1024, 16-byte aligned.
+ * norm1_attn), :222 (branch sum), :225-229 (ff_dropout2 + residual + norm2), and their autograd backward.
+ * All row buffers [R, d] fp32, d % 4 == 0, d <= 1024, 16-byte aligned, R >= 2.
+ *   ws / ws_floats  scratch for the partial records: the sum of gps_norm_tree_floats(R, d) over the tasks that
+ *                   reduce (forward: tasks with `stats`; partial: every task; apply: tasks with a chain)
+ *   sync            gps_norm_sync_words() uint32 arrival counters, ZERO at entry and zero again at exit (so a
+ *                   buffer zeroed once serves every later call and every hipGraph replay).  Launches that may run
+ *                   concurrently (forked streams) must be given different counters.
  * ------------------------------------------------------------------------------------- */
-typedef struct gps_bn {       /* one torch.nn.BatchNorm1d in training mode */
-  const float* gamma;         /* weight [d] */
-  const float* beta;          /* bias [d] */
-  float* mean;                /* batch mean [d]: written by the *_stats stages, read by apply/backward */
-  float* rstd;                /* 1/sqrt(biased var + eps) [d] */
-  float* running_mean;        /* updated by the *_stats stages (both NULL: not tracked) */
-  float* running_var;
-  float eps, momentum;
-} gps_bn;
-size_t gps_block_norm_workspace_floats(int64_t N, int64_t E, int d);
-/* batch statistics of two row streams (x~ [RA,d] for bn_node_x, e^ [RB,d] for bn_edge_e) */
-int gps_bn_stats_pair(const float* zA, int64_t RA, const gps_bn* bnA, const float* zB, int64_t RB,
-                      const gps_bn* bnB, int d, float* ws, gps_stream_t stream);
-/* x1 = x + drop(relu(BN_x(xt)))  [+ statistics of x1 -> bn_local.mean/rstd]
- * e1 = e + drop(relu(BN_e(eh)))
- * za = x + drop_attn(ao)          [+ statistics of za -> bn_attn.mean/rstd]        one launch + finalize */
-int gps_block_mid_fwd(const float* xt, const float* x, const gps_bn* bn_x, float p, uint64_t seed_x,
-                      float* x1, const float* eh, const float* e, const gps_bn* bn_e, uint64_t seed_e,
-                      float* e1, const float* ao, float p_attn, uint64_t seed_a, float* za,
-                      const gps_bn* bn_local, const gps_bn* bn_attn, int64_t N, int64_t E, int d,
-                      float* ws, gps_stream_t stream);
-/* out = BN_1(z1) + BN_2(z2)   (gps_layer.py:194,217,222) */
-int gps_bn_dual_apply(const float* z1, const gps_bn* bn1, const float* z2, const gps_bn* bn2, int64_t R,
-                      int d, float* out, gps_stream_t stream);
-/* out = a + drop(b) and the batch statistics of out -> bn.mean/rstd (+ running stats) */
-int gps_add_drop_stats(const float* a, const float* b, int64_t R, int d, float p, uint64_t seed, float* out,
-                       const gps_bn* bn, float* ws, gps_stream_t stream);
-/* gps_bn_bwd + a second output g_drop = dropmask(seed2, p2)(g_z) / (1 - p2)  (g_drop may be NULL) */
-int gps_bn_bwd_drop(const float* z, const float* g_y, const gps_bn* bn, int64_t R, int d, int relu, float p,
-                    uint64_t seed, float* g_z, float* g_gamma, float* g_beta, float p2, uint64_t seed2,
-                    float* g_drop, float* ws, gps_stream_t stream);
-/* two of the above in one launch pair (GINE block: zl = x + drop(gin_out), za = x + drop(attn_out)) */
-int gps_add_drop_stats_pair(const float* a1, const float* b1, float p1, uint64_t seed1, float* out1,
-                            const gps_bn* bn1, const float* a2, const float* b2, float p2, uint64_t seed2,
-                            float* out2, const gps_bn* bn2, int64_t R, int d, float* ws, gps_stream_t stream);
-/* backward of out = BN_1(z1) + BN_2(z2) from g_y = dL/d out:
- *   g_sum = g_z1 + g_z2;  g_z1 stored as dropmask(seed1, p1)(g_z1) / (1 - p1)  (p1 = 0: plain g_z1);
- *   g_drop2 = dropmask(seed2, p2)(g_z2) / (1 - p2)  (g_drop2 may be NULL) */
-int gps_bn_dual_bwd(const float* z1, const gps_bn* bn1, const float* z2, const gps_bn* bn2, const float* g_y,
-                    int64_t R, int d, float* g_z1, float p1, uint64_t seed1, float* g_sum, float p2,
-                    uint64_t seed2, float* g_drop2,
-                    float* g_gamma1, float* g_beta1, float* g_gamma2, float* g_beta2, float* ws,
-                    gps_stream_t stream);
-/* gps_bn_bwd for two row streams (bn_node_x on [RA,d], bn_edge_e on [RB,d]) in one launch triple */
-int gps_bn_bwd_pair(const float* zA, const float* gA, const gps_bn* bnA, int64_t RA, uint64_t seedA,
-                    float* g_zA, float* g_gammaA, float* g_betaA, const float* zB, const float* gB,
-                    const gps_bn* bnB, int64_t RB, uint64_t seedB, float* g_zB, float* g_gammaB,
-                    float* g_betaB, int d, int relu, float p, float* ws, gps_stream_t stream);
+enum { GPS_NORM_LOAD = 0,     /* rows = a                                  (statistics of an existing tensor) */
+       GPS_NORM_ADD_DROP = 1, /* rows = a + dropout(b; p, seed)                                               */
+       GPS_NORM_BN_ACT = 2,   /* rows = [res +] dropout(relu?(BN1(a)); p, seed)                                */
+       GPS_NORM_BN_DUAL = 3   /* rows = BN1(a) + BN2(b)                    (gps_layer.py:194,217,222)          */ };
+typedef struct gps_norm_fwd_task {
+  int32_t kind, relu;
+  const float *a, *b, *res;
+  const gps_bn *bn1, *bn2;    /* statistics already final (a previous launch) */
+  float p;
+  uint64_t seed;
+  float* out;                 /* produced rows, or NULL (statistics only) */
+  int64_t R;
+  const gps_bn* stats;        /* batch statistics of the produced rows -> stats->mean / rstd (+ running stats), or NULL */
+} gps_norm_fwd_task;
+/* One BatchNorm backward, y = dropout(relu?(BN(z)); p, seed) with g_y = dL/dy (masks recomputed from z and the hash):
+ *   partial: g_beta = sum g, g_gamma = sum g * zhat          (g = g_y under the masks)
+ *   apply:   g_z = gamma * rstd * (g - g_beta / R - zhat * g_gamma / R), reading g_beta / g_gamma
+ * dual (z2 != NULL): out = BN(z) + BN2(z2) (no masks); g_gamma2 / g_beta2 likewise; the apply writes g_z (stored as
+ *   dropmask(seed1x, p1x)(g_z) / (1 - p1x) when p1x > 0), g_sum = g_z + g_z2 and
+ *   g_drop = dropmask(seed2, p2)(g_z2) / (1 - p2); non-dual: g_drop = dropmask(seed2, p2)(g_z) / (1 - p2).
+ * chain (apply only, cz != NULL): the produced g_z (before the p1x mask) is the output gradient of ANOTHER
+ *   BatchNorm backward, y' = dropout(relu?(BN_c(cz)); cp, cseed): its sums go to cg_beta / cg_gamma in the same pass. */
+typedef struct gps_norm_bwd_task {
+  const float *z, *g_y;
+  const gps_bn* bn;
+  int32_t relu;
+  float p;
+  uint64_t seed;
+  const float* z2;
+  const gps_bn* bn2;
+  float *g_gamma, *g_beta, *g_gamma2, *g_beta2;
+  float *g_z, *g_sum, *g_drop;
+  float p2;
+  uint64_t seed2;
+  float p1x;
+  uint64_t seed1x;
+  int64_t R;
+  const float* cz;
+  const gps_bn* cbn;
+  int32_t crelu;
+  float cp;
+  uint64_t cseed;
+  float *cg_gamma, *cg_beta;
+} gps_norm_bwd_task;
+size_t gps_norm_tree_floats(int64_t R, int d);
+int gps_norm_sync_words(void);
+int gps_norm_fwd(int n, const gps_norm_fwd_task* tasks, int d, float* ws, size_t ws_floats, uint32_t* sync,
+                 gps_stream_t stream);
+int gps_norm_bwd_partial(int n, const gps_norm_bwd_task* tasks, int d, float* ws, size_t ws_floats, uint32_t* sync,
+                         gps_stream_t stream);
+int gps_norm_bwd_apply(int n, const gps_norm_bwd_task* tasks, int d, float* ws, size_t ws_floats, uint32_t* sync,
+                       gps_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Random-walk structural encoding: out[v][k - kmin] = (P^k)[v][v] * k^(space_dim/2), P = D^-1 A per graph,

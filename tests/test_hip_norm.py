@@ -1,0 +1,329 @@
+"""GPU parity tests of the task-list norm kernels (csrc/block_norm.hip) and of the in-launch column reductions
+(csrc/col_tree.hpp) behind them, the GatedGCN forward's own batch statistics and the ring GEMM's residual + dropout +
+statistics epilogue -- all through the C ABI, against fp64 restatements of the reference stages
+(graphgps/layer/gatedgcn_layer.py:72-83, graphgps/layer/gps_layer.py:191-194,212-229).  Dropout masks are injected from
+the host model of the kernels' counter hash (ops.attn_dropout_keep_mask), so every comparison is element by element."""
+import ctypes
+
+import pytest
+import torch
+
+from conftest import Tol, assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _mask(seed, R, d, p):
+    from graphgps_amd.ops import attn_dropout_keep_mask
+    if p == 0:
+        return torch.ones(R, d, dtype=torch.float64)
+    return attn_dropout_keep_mask(seed, torch.arange(R), 0, 1, torch.arange(d), p).double() / (1 - p)
+
+
+def _bn(d, gen, dev=DEV):
+    bn = torch.nn.BatchNorm1d(d)
+    with torch.no_grad():
+        bn.weight.uniform_(0.5, 1.5, generator=gen)
+        bn.bias.uniform_(-0.5, 0.5, generator=gen)
+        bn.running_mean.uniform_(-1, 1, generator=gen)
+        bn.running_var.uniform_(0.5, 2, generator=gen)
+    return bn.to(dev).train()
+
+
+class _Owner:
+    pass
+
+
+def _desc(bn, d):
+    from graphgps_amd import norm
+    st = torch.empty(2, d, device=DEV)
+    return norm.bn_desc(bn, st[0], st[1]), st
+
+
+def _ref_stats(v, bn_before, eps=1e-5, mom=0.1):
+    v = v.double()
+    mean, var = v.mean(0), v.var(0, unbiased=False)
+    n = v.shape[0]
+    rm = (1 - mom) * bn_before[0].double() + mom * mean
+    rv = (1 - mom) * bn_before[1].double() + mom * var * n / max(n - 1, 1)
+    return mean, 1.0 / torch.sqrt(var + eps), rm, rv
+
+
+@pytest.mark.parametrize("R,d", [(2, 64), (9, 52), (1000, 256), (7569, 384), (15348, 384), (200000, 64), (5000, 1024),
+                                 (4097, 8)])
+def test_norm_statistics_tree(R, d):
+    """Batch statistics of a [R, d] tensor completed inside ONE launch (level-0 records -> groups -> root): mean, rstd
+    and both running statistics against fp64; large-mean columns keep their variance; bitwise reproducible; the
+    arrival counters are zero again afterwards."""
+    from graphgps_amd import norm
+    gen = torch.Generator().manual_seed(R * 7 + d)
+    z = torch.randn(R, d, generator=gen) * 1.3 + 0.4
+    z[:, 0] = z[:, 0] * 0.01 + 100.0                      # |mean| >> std
+    bn = _bn(d, gen)
+    before = (bn.running_mean.clone().cpu(), bn.running_var.clone().cpu())
+    desc, st = _desc(bn, d)
+    own = _Owner()
+    sync = norm.sync_arena(own, torch.device(DEV))
+    zg = z.to(DEV)
+    norm.fwd([norm.fwd_task(norm.LOAD, zg, R, stats=desc)], d, zg.device, sync.site(0))
+    mean, rstd, rm, rv = _ref_stats(z, before)
+    assert_close(st[0], mean, 2e-6 * max(1.0, float(mean.abs().max())), "mean")
+    rel = ((st[1].double().cpu() - rstd) / rstd).abs()
+    assert float(rel[1:].max() if d > 1 else 0) < 3e-6, float(rel[1:].max())
+    if R >= 1000:
+        assert float(rel[0]) < 2e-3, float(rel[0])       # the quantum of fp32 inputs at 100 against a std of 0.013
+    assert_close(bn.running_mean, rm, 2e-6 * max(1.0, float(rm.abs().max())), "running_mean")
+    assert float(((bn.running_var.double().cpu() - rv) / rv).abs()[1:].max()) < 5e-6
+    assert int(sync.buf.abs().sum()) == 0, "arrival counters must be left at zero"
+    first = st.clone()
+    for _ in range(3):
+        norm.fwd([norm.fwd_task(norm.LOAD, zg, R, stats=desc)], d, zg.device, sync.site(0))
+        assert torch.equal(st, first)
+
+
+def test_norm_fwd_kinds_with_shared_masks():
+    """The four row-stream kinds of one list launch (a residual + dropout(relu(BN)) stream with statistics, the same on
+    an edge-sized stream, an add + dropout stream with statistics) and the dual apply that consumes them."""
+    from graphgps_amd import norm
+    gen = torch.Generator().manual_seed(11)
+    N, E, d, p, pl = 1237, 2511, 384, 0.1, 0.25
+    xt, x, ao = (torch.randn(N, d, generator=gen) for _ in range(3))
+    eh, e = (torch.randn(E, d, generator=gen) * 1.5 + 0.3 for _ in range(2))
+    bns = [_bn(d, gen) for _ in range(4)]                 # bn_x, bn_e, bn_l, bn_a
+    own = _Owner()
+    sync = norm.sync_arena(own, torch.device(DEV))
+    (dx, sx), (de, se), (dl, sl), (da, sa_) = (_desc(b, d) for b in bns)
+    g = lambda t: t.to(DEV)
+    xtg, xg, aog, ehg, eg = g(xt), g(x), g(ao), g(eh), g(e)
+    norm.fwd([norm.fwd_task(norm.LOAD, xtg, N, stats=dx), norm.fwd_task(norm.LOAD, ehg, E, stats=de)], d, xg.device,
+             sync.site(0))
+    x1, e1, za, h = (torch.empty_like(t) for t in (xg, eg, xg, xg))
+    s0, s1, s3 = 0x1111222233334444, 0x5555666677778888, 0x9999AAAABBBBCCCC
+    norm.fwd([norm.fwd_task(norm.BN_ACT, xtg, N, res=xg, bn1=dx, relu=True, p=p, seed=s0, out=x1, stats=dl),
+              norm.fwd_task(norm.BN_ACT, ehg, E, res=eg, bn1=de, relu=True, p=p, seed=s1, out=e1),
+              norm.fwd_task(norm.ADD_DROP, xg, N, b=aog, p=pl, seed=s3, out=za, stats=da)], d, xg.device, sync.site(1))
+    norm.fwd([norm.fwd_task(norm.BN_DUAL, x1, N, b=za, bn1=dl, bn2=da, out=h)], d, xg.device, None)
+
+    def bn64(v, bn):
+        v = v.double()
+        return ((v - v.mean(0)) / torch.sqrt(v.var(0, unbiased=False) + 1e-5) * bn.weight.double().cpu()
+                + bn.bias.double().cpu())
+    x1r = x.double() + bn64(xt, bns[0]).relu() * _mask(s0, N, d, p)
+    e1r = e.double() + bn64(eh, bns[1]).relu() * _mask(s1, E, d, p)
+    zar = x.double() + ao.double() * _mask(s3, N, d, pl)
+    hr = bn64(x1r, bns[2]) + bn64(zar, bns[3])
+    assert_close(x1, x1r, Tol.ACT, "x1")
+    assert_close(e1, e1r, Tol.ACT, "e1")
+    assert_close(za, zar, Tol.ACT, "za")
+    assert_close(h, hr, 2 * Tol.ACT, "h = BN_l(x1) + BN_a(za)")
+    assert int(sync.buf.abs().sum()) == 0
+
+
+@pytest.mark.parametrize("N,E,d", [(1237, 2511, 384), (743, 1590, 64), (300, 20000, 256)])
+def test_norm_backward_lists_and_chain(N, E, d):
+    """The block's backward norm stages exactly as gps_block.py issues them -- {norm2, bn_edge_e} partial + apply,
+    the dual {norm1_local, norm1_attn} partial + apply CHAINED into bn_node_x's column sums, bn_node_x's apply --
+    against autograd in fp64 on the same function with the same dropout masks and the ReLU decisions the GPU took
+    (read off its forward: of ~1e6 pre-activations one sits within fp32 rounding of the kink)."""
+    from graphgps_amd import norm
+    gen = torch.Generator().manual_seed(N + d)
+    p, pl, pf2 = 0.1, 0.15, 0.2
+    s0, s1, s3, s5 = 101, 0xABCDEF0123, 303, 0x77777777FFFF
+    xt, x, za, z2, g_out, w_h = (torch.randn(N, d, generator=gen) for _ in range(6))   # w_h: the network above h
+    eh, e, g_e1 = (torch.randn(E, d, generator=gen) for _ in range(3))
+    bnx, bne, bnl, bna, bn2 = (_bn(d, gen) for _ in range(5))
+    own = _Owner()
+    dev = torch.device(DEV)
+    sync = norm.sync_arena(own, dev)
+    g = lambda t: t.to(DEV).contiguous()
+
+    # ---- HIP: the forward pieces the backward needs, then the backward lists -------------------------------------
+    xtg, xg, zag, z2g, ehg, eg = g(xt), g(x), g(za), g(z2), g(eh), g(e)
+    descs = [_desc(b, d) for b in (bnx, bne, bnl, bna, bn2)]       # (descriptor, its [2, d] statistics buffer): keep both alive
+    dx, de, dl, da, d2 = (q[0] for q in descs)
+    x1g, brx, bre = torch.empty_like(xg), torch.empty_like(xg), torch.empty_like(eg)
+    norm.fwd([norm.fwd_task(norm.LOAD, xtg, N, stats=dx), norm.fwd_task(norm.LOAD, ehg, E, stats=de),
+              norm.fwd_task(norm.LOAD, zag, N, stats=da), norm.fwd_task(norm.LOAD, z2g, N, stats=d2)], d, dev, sync.site(0))
+    norm.fwd([norm.fwd_task(norm.BN_ACT, xtg, N, res=xg, bn1=dx, relu=True, p=p, seed=s0, out=x1g, stats=dl),
+              norm.fwd_task(norm.BN_ACT, xtg, N, bn1=dx, relu=True, p=p, seed=s0, out=brx),      # the branches alone:
+              norm.fwd_task(norm.BN_ACT, ehg, E, bn1=de, relu=True, p=p, seed=s1, out=bre)],     # their zeros = decisions
+             d, dev, sync.site(1))
+    gp = torch.empty(10, d, device=DEV)
+    g_bxw, g_bxb, g_bew, g_beb, g_nlw, g_nlb, g_naw, g_nab, g_n2w, g_n2b = gp.unbind(0)
+    g_z2, g_f2, g_eh = torch.empty_like(xg), torch.empty_like(xg), torch.empty_like(eg)
+    g_outg, g_e1g, w_hg = g(g_out), g(g_e1), g(w_h)       # tasks hold raw pointers: the tensors must outlive the launches
+    b1 = [norm.bwd_task(z2g, g_outg, d2, N, g_n2w, g_n2b, g_z=g_z2, g_drop=g_f2, p2=pf2, seed2=s5),
+          norm.bwd_task(ehg, g_e1g, de, E, g_bew, g_beb, relu=True, p=p, seed=s1, g_z=g_eh)]
+    norm.bwd_partial(b1, d, dev, sync.site(2))
+    norm.bwd_apply(b1, d, dev, None)
+    g_x1, g_xres, g_ao, g_xt = (torch.empty_like(xg) for _ in range(4))
+    b3 = [norm.bwd_task(x1g, w_hg, dl, N, g_nlw, g_nlb, z2=zag, bn2=da, g_gamma2=g_naw, g_beta2=g_nab, g_z=g_x1,
+                        g_sum=g_xres, g_drop=g_ao, p2=pl, seed2=s3, cz=xtg, cbn=dx, crelu=True, cp=p, cseed=s0,
+                        cg_gamma=g_bxw, cg_beta=g_bxb)]
+    norm.bwd_partial(b3, d, dev, sync.site(3))
+    norm.bwd_apply(b3, d, dev, sync.site(4))
+    norm.bwd_apply([norm.bwd_task(xtg, g_x1, dx, N, g_bxw, g_bxb, relu=True, p=p, seed=s0, g_z=g_xt)], d, dev, None)
+    torch.cuda.synchronize()
+    assert int(sync.buf.abs().sum()) == 0
+
+    # ---- fp64 reference (autograd), BatchNorm parameters as leaves too ----------------------------------------------
+    leaf = lambda t: t.detach().double().cpu().clone().requires_grad_(True)
+    par = {name: (leaf(b.weight), leaf(b.bias)) for name, b in (("x", bnx), ("e", bne), ("l", bnl), ("a", bna), ("2", bn2))}
+
+    def BN(v, name):
+        wgt, bias = par[name]
+        return (v - v.mean(0)) / torch.sqrt(v.var(0, unbiased=False) + 1e-5) * wgt + bias
+    xt_r, za_r, z2_r, eh_r = leaf(xt), leaf(za), leaf(z2), leaf(eh)
+    m0, m1, m3, m5 = _mask(s0, N, d, p), _mask(s1, E, d, p), _mask(s3, N, d, pl), _mask(s5, N, d, pf2)
+    gx = ((brx.cpu() != 0) | (m0 == 0)).double()
+    ge = ((bre.cpu() != 0) | (m1 == 0)).double()
+    x1_r = x.double() + BN(xt_r, "x") * gx * m0
+    x1_r.retain_grad()
+    e1_r = e.double() + BN(eh_r, "e") * ge * m1
+    h_r = BN(x1_r, "l") + BN(za_r, "a")
+    loss = (h_r * w_h.double()).sum() + (BN(z2_r, "2") * g_out.double()).sum() + (e1_r * g_e1.double()).sum()
+    loss.backward()
+    assert_close(x1g, x1_r, Tol.ACT, "x1 (forward)")
+
+    tol = 2e-5          # gradients through up to two BatchNorm backwards; relative to the largest element
+    assert_close(g_z2, z2_r.grad, tol, "g_z2", rel_to_max=True)
+    assert_close(g_f2, z2_r.grad * m5, tol, "g_f2 = dropmask(g_z2)", rel_to_max=True)
+    assert_close(g_eh, eh_r.grad, tol, "g_eh", rel_to_max=True)
+    assert_close(g_x1, x1_r.grad, tol, "g_x1", rel_to_max=True)
+    assert_close(g_xt, xt_r.grad, tol, "g_xt (sums from the chain)", rel_to_max=True)
+    assert_close(g_ao, za_r.grad * m3, tol, "g_ao = dropmask(g_za)", rel_to_max=True)
+    assert_close(g_xres, x1_r.grad + za_r.grad, tol, "g_xres = g_x1 + g_za", rel_to_max=True)
+    for name, gw, gb in (("x", g_bxw, g_bxb), ("e", g_bew, g_beb), ("l", g_nlw, g_nlb), ("a", g_naw, g_nab),
+                         ("2", g_n2w, g_n2b)):
+        assert_close(gw, par[name][0].grad, 1e-4, f"g_gamma {name}", rel_to_max=True)
+        assert_close(gb, par[name][1].grad, 1e-4, f"g_beta {name}", rel_to_max=True)
+
+
+def test_tree_race_screen():
+    """The in-launch reductions hand data between workgroups (write-through records, arrival tickets, sc1 loads): a
+    protocol error shows as a STALE record -- rarely, and only under the right timing.  Screen: alternate two different
+    inputs through the same workspace sites 40 times each with unrelated memory traffic and a concurrent stream of
+    launches in between; every result must equal, bit for bit, the first result of its input (the trees are deterministic
+    by construction), the first results must be right, and the counters must end at zero."""
+    from graphgps_amd import norm
+    dev = torch.device(DEV)
+    gen = torch.Generator().manual_seed(5)
+    N, E, d = 7569, 15348, 384
+    own = _Owner()
+    sync = norm.sync_arena(own, dev)
+    bn_a, bn_b = _bn(d, gen), _bn(d, gen)
+    (da, sa_), (db, sb) = _desc(bn_a, d), _desc(bn_b, d)
+    inputs = []
+    for k in range(2):
+        zn = (torch.randn(N, d, generator=gen) * (1 + k) + k).to(dev)
+        ze = (torch.randn(E, d, generator=gen) * (2 - k) - k).to(dev)
+        gy = torch.randn(N, d, generator=gen).to(dev)
+        inputs.append((zn, ze, gy))
+    noise = torch.empty(48 << 20, device=dev)
+    side = torch.cuda.Stream(device=dev)
+    gpar = torch.empty(4, d, device=dev)
+    gz = torch.empty(N, d, device=dev)
+    firsts = {}
+    for it in range(80):
+        k = it & 1
+        zn, ze, gy = inputs[k]
+        if it % 3 == 0:
+            noise.normal_()
+        with torch.cuda.stream(side):            # unrelated concurrent load: uneven arrival order
+            noise[: 8 << 20].mul_(1.0001)
+        norm.fwd([norm.fwd_task(norm.LOAD, zn, N, stats=da), norm.fwd_task(norm.LOAD, ze, E, stats=db)], d, dev, sync.site(0))
+        tasks = [norm.bwd_task(zn, gy, da, N, gpar[0], gpar[1], relu=True, p=0.1, seed=7, g_z=gz)]
+        norm.bwd_partial(tasks, d, dev, sync.site(1))
+        norm.bwd_apply(tasks, d, dev, None)
+        cur = (sa_.clone(), sb.clone(), gpar[:2].clone(), gz.clone())
+        if k not in firsts:
+            firsts[k] = cur
+            mean, rstd, _, _ = _ref_stats(zn.cpu(), (torch.zeros(d), torch.ones(d)))
+            assert_close(cur[0][0], mean, 3e-6 * max(1.0, float(mean.abs().max())), "mean")
+            assert float(((cur[0][1].double().cpu() - rstd) / rstd).abs().max()) < 3e-6
+        else:
+            for a, b, what in zip(cur, firsts[k], ("node stats", "edge stats", "column sums", "g_z")):
+                assert torch.equal(a, b), f"iteration {it}: {what} differ from the first run of input {k}"
+    torch.cuda.synchronize()
+    assert int(sync.buf.abs().sum()) == 0
+
+
+@pytest.mark.parametrize("profile,nb,d", [("P30", 256, 384), ("P14", 64, 64), ("CODE2_REAL", 6, 256)])
+def test_gatedgcn_forward_emits_batch_statistics(profile, nb, d):
+    """gps_gatedgcn_fwd_stats = gps_gatedgcn_fwd (bitwise the same x~ / e^) + the batch statistics of both outputs
+    (bn_node_x, bn_edge_e: gatedgcn_layer.py:72-73) completed in the same launch."""
+    from graphgps_amd import lib as L_, norm
+    from graphgps_amd.lib import check, current_stream, ptr
+    from test_hip_ops import _index, _structure
+    L = L_.load()
+    sizes, ei, bvec, pt, gen = _structure(profile, nb, 3)
+    N, E = int(pt[-1]), ei.shape[1]
+    gi = _index(ei, bvec, pt)
+    proj = torch.randn(N, 4 * d, generator=gen).to(DEV)
+    ce = (torch.randn(E, d, generator=gen) * 1.2 + 0.2).to(DEV)
+    st = current_stream(proj.device)
+    P, fs = proj.data_ptr(), 4 * d
+    xt0, eh0 = torch.empty(N, d, device=DEV), torch.empty(E, d, device=DEV)
+    check(L.gps_gatedgcn_fwd(P, P + fs, P + 2 * fs, P + 3 * fs, 4 * d, ptr(ce), ptr(gi.rowptr_dst), ptr(gi.src_by_dst),
+                             ptr(gi.eid_by_dst), N, E, d, ptr(xt0), ptr(eh0), None, st), "fwd")
+    bnx, bne = _bn(d, gen), _bn(d, gen)
+    before = [(b.running_mean.clone().cpu(), b.running_var.clone().cpu()) for b in (bnx, bne)]
+    (dx, sx), (de, se) = _desc(bnx, d), _desc(bne, d)
+    own = _Owner()
+    sync = norm.sync_arena(own, proj.device)
+    wsf = L.gps_gatedgcn_stats_floats(N, d)
+    ws = torch.empty(wsf, device=DEV)
+    xt, eh = torch.empty(N, d, device=DEV), torch.empty(E, d, device=DEV)
+    first = None
+    for it in range(4):
+        check(L.gps_gatedgcn_fwd_stats(P, P + fs, P + 2 * fs, P + 3 * fs, 4 * d, ptr(ce), ptr(gi.rowptr_dst),
+                                       ptr(gi.src_by_dst), ptr(gi.eid_by_dst), N, E, d, ptr(xt), ptr(eh), None,
+                                       ctypes.byref(dx), ctypes.byref(de), ptr(ws), wsf, sync.site(0), st), "fwd_stats")
+        if first is None:
+            first = (sx.clone(), se.clone())
+            assert torch.equal(xt, xt0) and torch.equal(eh, eh0)
+            for got, v, bn, bef in ((sx, xt0, bnx, before[0]), (se, eh0, bne, before[1])):
+                mean, rstd, rm, rv = _ref_stats(v.cpu(), bef)
+                assert_close(got[0], mean, 3e-6 * max(1.0, float(mean.abs().max())), "mean")
+                assert float(((got[1].double().cpu() - rstd) / rstd).abs().max()) < 3e-6
+                assert_close(bn.running_mean, rm, 3e-6 * max(1.0, float(rm.abs().max())), "running_mean")
+                assert float(((bn.running_var.double().cpu() - rv) / rv).abs().max()) < 5e-6
+        else:
+            assert torch.equal(sx, first[0]) and torch.equal(se, first[1])
+    assert int(sync.buf.abs().sum()) == 0
+
+
+@pytest.mark.parametrize("M,K,N", [(7569, 768, 384), (7569, 384, 384), (15348, 384, 384), (130, 384, 192), (64, 384, 384)])
+def test_gemm_epilogue_residual_dropout_statistics(M, K, N):
+    """gps_gemm_panel_stats: C = Cin + dropout(A W^T + b) with the host model of the mask, and the batch statistics of C
+    (norm2 / norm1_attn: gps_layer.py:212-217,225-229) against fp64; repeated launches reproduce bit for bit."""
+    from graphgps_amd import gemm, norm
+    if not gemm.stats_supported(M, N, K):
+        pytest.skip("shape not served by the ring kernel")
+    gen = torch.Generator().manual_seed(M + K)
+    a = torch.randn(M, K, generator=gen)
+    w = torch.randn(N, K, generator=gen) / K ** 0.5
+    b = torch.randn(N, generator=gen)
+    res = torch.randn(M, N, generator=gen) * 1.5 + 0.5
+    p, seed = 0.1, 0xFEEDFACE12345
+    (img, _), = gemm.split_weights([w.to(DEV)], tn=False)
+    bn = _bn(N, gen)
+    before = (bn.running_mean.clone().cpu(), bn.running_var.clone().cpu())
+    desc, st = _desc(bn, N)
+    own = _Owner()
+    sync = norm.sync_arena(own, torch.device(DEV))
+    ag, bg, rg = a.to(DEV), b.to(DEV), res.to(DEV)
+    out = gemm.gemm_panel_stats(ag, img, N, bg, rg, p, seed, desc, sync.site(0))
+    ref = res.double() + (a.double() @ w.double().t() + b.double()) * _mask(seed, M, N, p)
+    scale = float(ref.abs().max())
+    assert_close(out, ref, 4e-6 * scale, "Cin + dropout(A W^T + b)")
+    mean, rstd, rm, rv = _ref_stats(out.cpu(), before)
+    assert_close(st[0], mean, 3e-6 * max(1.0, float(mean.abs().max())), "mean")
+    assert float(((st[1].double().cpu() - rstd) / rstd).abs().max()) < 3e-6
+    assert_close(bn.running_mean, rm, 3e-6 * max(1.0, float(rm.abs().max())), "running_mean")
+    first = (out.clone(), st.clone())
+    for _ in range(5):
+        out2 = gemm.gemm_panel_stats(ag, img, N, bg, rg, p, seed, desc, sync.site(0))
+        assert torch.equal(out2, first[0]) and torch.equal(st, first[1])
+    assert int(sync.buf.abs().sum()) == 0
