@@ -19,6 +19,7 @@
 // Row kernels keep the lane-owns-4-channels mapping (d % 4 == 0, d <= 1024): a workgroup is RS rows x d/4 lanes
 // (RS = 512 / (d/4): 384 threads at d = 384), rows of a block are walked RS at a time, two passes in flight.
 #include <algorithm>
+#include <cstdlib>
 
 #include "col_tree.hpp"
 #include "gps_common.hpp"
@@ -28,10 +29,14 @@ namespace {
 
 namespace tr = gps::tree;
 
-constexpr int TARGET_BLOCKS = 512;       // row blocks per task (~2 per CU); <= tr::kMaxParts
+// Row blocks per task: one per CU.  The blocks of a task are also the level-0 records of its reduction tree, and 256 records
+// = 16 groups of 16, so BOTH levels of the tree are ONE burst of <= 16 x 3 loads per thread (MAXI).  The burst lives in
+// registers, and the kernel's register allocation is its maximum over all paths: 24-record bursts (512 blocks) cost the
+// streaming loop half of its occupancy (133-154 VGPRs -> 3 waves per SIMD; measured 37 us for a 106 MB list).
+constexpr int TARGET_BLOCKS = 256;
 constexpr int kMaxThreads = 512;
 constexpr int kMaxTasks = 4;
-constexpr int MAXI = tr::kMaxFan;
+constexpr int MAXI = 16;
 typedef Vec<4> V4;
 
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
@@ -171,18 +176,25 @@ __device__ __forceinline__ bool run_fwd(const FwdTask& T, int d, int lb, uint64_
       s[1][j] += t * t;
     }
   };
+  // two rows per pass, the NEXT pass's rows requested before this pass's results are stored (clamped addresses: the
+  // loads are unconditional), so a pass costs issue time, not a memory round trip
   int64_t r = row0 + rsub;
-  for (; r + RS < row1; r += 2 * RS) {          // two rows in flight, straight-line
-    const RowIn i0 = load_in<KIND>(T, r, c, d), i1 = load_in<KIND>(T, r + RS, c, d);
-    const V4 v0 = eval_row<KIND, RELU, DROP>(T, i0, r, c, c1, c2, seed, inv_keep);
-    const V4 v1 = eval_row<KIND, RELU, DROP>(T, i1, r + RS, c, c1, c2, seed, inv_keep);
-    if (T.out) { v0.store(T.out + r * d + c); v1.store(T.out + (r + RS) * d + c); }
-    if (stats) { account(v0); account(v1); }
-  }
+  const int64_t rl = row1 - 1;
   if (r < row1) {
-    const V4 v0 = eval_row<KIND, RELU, DROP>(T, load_in<KIND>(T, r, c, d), r, c, c1, c2, seed, inv_keep);
-    if (T.out) v0.store(T.out + r * d + c);
-    if (stats) account(v0);
+    RowIn i0 = load_in<KIND>(T, r, c, d), i1 = load_in<KIND>(T, min(r + RS, rl), c, d);
+    for (; r + RS < row1; r += 2 * RS) {
+      const RowIn n0 = load_in<KIND>(T, min(r + 2 * RS, rl), c, d), n1 = load_in<KIND>(T, min(r + 3 * RS, rl), c, d);
+      const V4 v0 = eval_row<KIND, RELU, DROP>(T, i0, r, c, c1, c2, seed, inv_keep);
+      const V4 v1 = eval_row<KIND, RELU, DROP>(T, i1, r + RS, c, c1, c2, seed, inv_keep);
+      if (T.out) { v0.store(T.out + r * d + c); v1.store(T.out + (r + RS) * d + c); }
+      if (stats) { account(v0); account(v1); }
+      i0 = n0; i1 = n1;
+    }
+    if (r < row1) {
+      const V4 v0 = eval_row<KIND, RELU, DROP>(T, i0, r, c, c1, c2, seed, inv_keep);
+      if (T.out) v0.store(T.out + r * d + c);
+      if (stats) account(v0);
+    }
   }
   if (!stats) return false;      // block-uniform
   reduce_rows<2>(s, lds, d, RS, rsub, c);
@@ -304,20 +316,25 @@ __device__ __forceinline__ void run_bwd_partial(const BwdTask& T, int d, int lb,
       if (DUAL) s[NV - 1][j] += g[j] * ((v2[j] - c2.mu[j]) * c2.rs[j]);
     }
   };
+  struct In { V4 v, g, w; };
+  auto ld = [&](int64_t q) __attribute__((always_inline)) {
+    In x;
+    x.v = V4::load(T.z + q * d + c);
+    x.g = V4::load(T.g_y + q * d + c);
+    x.w = DUAL ? V4::load(T.z2 + q * d + c) : V4::zero();
+    return x;
+  };
   int64_t r = row0 + rsub;
-  for (; r + RS < row1; r += 2 * RS) {
-    const int64_t rb = r + RS;
-    const V4 va = V4::load(T.z + r * d + c), ga = V4::load(T.g_y + r * d + c);
-    const V4 vb = V4::load(T.z + rb * d + c), gb = V4::load(T.g_y + rb * d + c);
-    const V4 wa = DUAL ? V4::load(T.z2 + r * d + c) : V4::zero();
-    const V4 wb = DUAL ? V4::load(T.z2 + rb * d + c) : V4::zero();
-    account(r, va, ga, wa);
-    account(rb, vb, gb, wb);
-  }
-  if (r < row1) {
-    const V4 va = V4::load(T.z + r * d + c), ga = V4::load(T.g_y + r * d + c);
-    const V4 wa = DUAL ? V4::load(T.z2 + r * d + c) : V4::zero();
-    account(r, va, ga, wa);
+  const int64_t rl = row1 - 1;
+  if (r < row1) {           // two rows per pass, the next pass prefetched (see run_fwd)
+    In a = ld(r), b = ld(min(r + RS, rl));
+    for (; r + RS < row1; r += 2 * RS) {
+      const In na = ld(min(r + 2 * RS, rl)), nb = ld(min(r + 3 * RS, rl));
+      account(r, a.v, a.g, a.w);
+      account(r + RS, b.v, b.g, b.w);
+      a = na; b = nb;
+    }
+    if (r < row1) account(r, a.v, a.g, a.w);
   }
   reduce_rows<NV>(s, lds, d, RS, rsub, c);
   if (rsub == 0) {
@@ -441,25 +458,25 @@ __device__ __forceinline__ void run_bwd_apply(const BwdTask& T, int d, int lb, c
       s[1][j] += gg * zh;
     }
   };
+  struct In { V4 v, g, w, cz; };
+  auto ld = [&](int64_t q) __attribute__((always_inline)) {
+    In x;
+    x.v = V4::load(T.z + q * d + c);
+    x.g = V4::load(T.g_y + q * d + c);
+    x.w = DUAL ? V4::load(T.z2 + q * d + c) : V4::zero();
+    x.cz = CHAIN ? V4::load(T.cz + q * d + c) : V4::zero();
+    return x;
+  };
   int64_t r = row0 + rsub;
-  for (; r + RS < row1; r += 2 * RS) {
-    const int64_t rb = r + RS;
-    const V4 va = V4::load(T.z + r * d + c), ga = V4::load(T.g_y + r * d + c);
-    const V4 vb = V4::load(T.z + rb * d + c), gb = V4::load(T.g_y + rb * d + c);
-    const V4 wa = DUAL ? V4::load(T.z2 + r * d + c) : V4::zero();
-    const V4 wb = DUAL ? V4::load(T.z2 + rb * d + c) : V4::zero();
-    const V4 ca = CHAIN ? V4::load(T.cz + r * d + c) : V4::zero();
-    const V4 cb = CHAIN ? V4::load(T.cz + rb * d + c) : V4::zero();
-    const V4 oa = apply_row<RELU, DROP, DUAL>(T, A, d, r, c, va, ga, wa);
-    const V4 ob = apply_row<RELU, DROP, DUAL>(T, A, d, rb, c, vb, gb, wb);
-    if (CHAIN) { chain(r, oa, ca); chain(rb, ob, cb); }
-  }
-  if (r < row1) {
-    const V4 va = V4::load(T.z + r * d + c), ga = V4::load(T.g_y + r * d + c);
-    const V4 wa = DUAL ? V4::load(T.z2 + r * d + c) : V4::zero();
-    const V4 ca = CHAIN ? V4::load(T.cz + r * d + c) : V4::zero();
-    const V4 oa = apply_row<RELU, DROP, DUAL>(T, A, d, r, c, va, ga, wa);
-    if (CHAIN) chain(r, oa, ca);
+  const int64_t rl = row1 - 1;
+  if (r < row1) {           // one row per pass with the next one prefetched: this kernel's column constants (up to three
+    In a = ld(r);           // BatchNorms + their sums) leave no room for more rows in flight at a useful occupancy
+    for (; r < row1; r += RS) {
+      const In na = ld(min(r + RS, rl));
+      const V4 oa = apply_row<RELU, DROP, DUAL>(T, A, d, r, c, a.v, a.g, a.w);
+      if (CHAIN) chain(r, oa, a.cz);
+      a = na;
+    }
   }
   if (!CHAIN) return;
   reduce_rows<2>(s, lds, d, RS, rsub, c);
@@ -508,7 +525,15 @@ __global__ __launch_bounds__(kMaxThreads) void k_bwd_apply(const BwdGroup G) {
 // host side
 // ------------------------------------------------------------------------------------------------
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) % 16) == 0; }
-inline int rows_per_block(int64_t R) { return (int)std::max<int64_t>(8, (R + TARGET_BLOCKS - 1) / TARGET_BLOCKS); }
+inline int target_blocks() {       // GPS_NORM_BLOCKS: row blocks per task (A/B runs); <= tr::kMaxParts
+  static const int v = []() {
+    const char* e = getenv("GPS_NORM_BLOCKS");
+    const int x = e && *e ? atoi(e) : TARGET_BLOCKS;
+    return x < 8 ? 8 : (x > tr::kMaxParts ? tr::kMaxParts : x);
+  }();
+  return v;
+}
+inline int rows_per_block(int64_t R) { return (int)std::max<int64_t>(8, (R + target_blocks() - 1) / target_blocks()); }
 inline int nblocks_for(int64_t R) { const int rpb = rows_per_block(R); return (int)((R + rpb - 1) / rpb); }
 inline Bn bn_of(const gps_bn* b) { return Bn{b->mean, b->rstd, b->gamma, b->beta}; }
 inline int threads_for(int d) { const int L = d / 4; return std::max(1, kMaxThreads / L) * L; }

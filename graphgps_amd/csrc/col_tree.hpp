@@ -28,9 +28,9 @@
 namespace gps {
 namespace tree {
 
-constexpr int kMaxFan = 24;                     // fan-in of either level
+constexpr int kSyncWords = 32;                  // uint32 counters per tree: [0] root, [1 + g] group g
+constexpr int kMaxFan = kSyncWords - 1;         // fan-in of either level (the group count is bounded by the counters)
 constexpr int kMaxParts = kMaxFan * kMaxFan;    // level-0 records per tree
-constexpr int kSyncWords = 32;                  // uint32 counters per tree: [0] root, [1 + g] group g (<= 24 groups)
 enum { STATS = 0, SUMS = 1 };
 
 struct Tree {

@@ -230,7 +230,7 @@ __device__ __forceinline__ void fwd_stats_finish(const StatAcc<VEC>& sa, const t
       if (c == 0) tr::st_sc1(T.pcnt + L * 2 + s, n[s]);
     }
   }
-  tr::arrive<4, tr::STATS, tr::kMaxFan / 2>(T, (int)L, d, lds);
+  tr::arrive<4, tr::STATS, 12>(T, (int)L, d, lds);
 }
 
 template <int VEC, bool GATE, bool STATS>

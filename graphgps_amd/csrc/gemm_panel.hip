@@ -484,7 +484,7 @@ __device__ __forceinline__ void ring_stats(const PanelArgs& P, int rt, int panel
     tr::st_sc1(T.part + ((int64_t)rt * 2 + 1) * TN + t, qa + qb + dl * dl * n0w * wgt);
     if (t == 0) tr::st_sc1(T.pcnt + rt, nn);
   }
-  tr::arrive<2, tr::STATS, tr::kMaxFan>(T, rt, TN, lds);
+  tr::arrive<2, tr::STATS, 16>(T, rt, TN, lds);
 }
 
 // MB = row blocks of 32 per wave: the workgroup's panel is (64 * MB) rows x 192 columns, 2 x 2 waves of (32 * MB) x 96.

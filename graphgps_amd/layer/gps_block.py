@@ -229,11 +229,16 @@ class _GPSBlock(torch.autograd.Function):
         # dense side: the row-panel GEMM (csrc/gemm_panel.hip; d % 192 == 0) or the library GEMMs
         panel = _gemm.supported(d, d) and _gemm.supported(2 * d, d) and _gemm.supported(7 * d, d) and E >= 1
         imgs = None
+        # The C projection of the edges goes FIRST: it depends on nothing but e, and with it out of the way the two halves
+        # of the block that fork after the merged projection are balanced -- [attention core -> out-projection] beside
+        # [GatedGCN core] -- instead of [attention, out-projection] beside [C projection -> GatedGCN core].
         if panel:       # weight images of the block's five projections (W and W^T), ONE launch per layer and step
             imgs = _gemm.split_weights([wcat, lm.C.weight, sa.out_proj.weight, layer.ff_linear1.weight,
                                         layer.ff_linear2.weight])
+            ce = _gemm.gemm_panel(e, imgs[1][0], d, bias=lm.C.bias)
             pq = _gemm.gemm_panel(x, imgs[0][0], 7 * d, bias=bcat)
         else:
+            ce = torch.addmm(lm.C.bias, e, lm.C.weight.t())
             pq = torch.addmm(bcat, x, wcat.t())                 # [N, 4d + 3d]
         ldp = 7 * d
         P, fs = pq.data_ptr(), d * 4
@@ -262,9 +267,7 @@ class _GPSBlock(torch.autograd.Function):
                 za = None
                 ao = (_gemm.gemm_panel(o, imgs[2][0], d, bias=sa.out_proj.bias) if panel
                       else torch.addmm(sa.out_proj.bias, o, sa.out_proj.weight.t()))
-        # -- local branch: C projection + GatedGCN core ----------------------------------------
-        ce = (_gemm.gemm_panel(e, imgs[1][0], d, bias=lm.C.bias) if panel
-              else torch.addmm(lm.C.bias, e, lm.C.weight.t()))
+        # -- local branch: GatedGCN core ---------------------------------------------------------
         xt, eh = _E(N, d, **f32), _E(E, d, **f32)
         if _GG_STATS:           # statistics of x~ (bn_node_x) and e^ (bn_edge_e) fall out of the same launch
             wsf = L.gps_gatedgcn_stats_floats(N, d)
@@ -279,17 +282,20 @@ class _GPSBlock(torch.autograd.Function):
                                      None, st), "gps_gatedgcn_fwd")
             _norm.fwd([_norm.fwd_task(_norm.LOAD, xt, N, stats=bnx), _norm.fwd_task(_norm.LOAD, eh, E, stats=bne)],
                       d, dev, sync.site(_S_XE))
-        fork.join(o, lse, *([za] if ao is None else [ao]))
-
         # -- x1 = x + drop(relu(BN_x(xt))) [+ statistics -> norm1_local], e1 = e + drop(relu(BN_e(eh))),
-        #    za = x + drop(ao) [+ statistics -> norm1_attn] unless the out-projection already produced it
+        #    za = x + drop(ao) [+ statistics -> norm1_attn] unless the out-projection already produced it -- in which case
+        #    this launch needs nothing from the attention half and the join moves behind it (a cross-stream dependency
+        #    costs ~10 us of queue latency in a replayed graph even when it is long satisfied; here it hides under this launch)
         x1, e1 = _E(N, d, **f32), _E(E, d, **f32)
         mid = [_norm.fwd_task(_norm.BN_ACT, xt, N, res=x, bn1=bnx, relu=True, p=p, seed=s[0], out=x1, stats=bnl),
                _norm.fwd_task(_norm.BN_ACT, eh, E, res=e, bn1=bne, relu=True, p=p, seed=s[1], out=e1)]
         if za is None:
+            fork.join(o, lse, ao)
             za = _E(N, d, **f32)
             mid.append(_norm.fwd_task(_norm.ADD_DROP, x, N, b=ao, p=p_l, seed=s[3], out=za, stats=bna))
         _norm.fwd(mid, d, dev, sync.site(_S_MID))
+        if ao is None:
+            fork.join(o, lse, za)
         h = _E(N, d, **f32)                                     # BN_l(x1) + BN_a(za)  (gps_layer.py:222)
         _norm.fwd([_norm.fwd_task(_norm.BN_DUAL, x1, N, b=za, bn1=bnl, bn2=bna, out=h)], d, dev, None)
 

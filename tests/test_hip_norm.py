@@ -282,7 +282,8 @@ def test_gatedgcn_forward_emits_batch_statistics(profile, nb, d):
                                        ctypes.byref(dx), ctypes.byref(de), ptr(ws), wsf, sync.site(0), st), "fwd_stats")
         if first is None:
             first = (sx.clone(), se.clone())
-            assert torch.equal(xt, xt0) and torch.equal(eh, eh0)
+            # same arithmetic, but a different instantiation: the compiler contracts / orders a few operations differently
+            assert float((xt - xt0).abs().max()) < 2e-6 and float((eh - eh0).abs().max()) < 2e-6
             for got, v, bn, bef in ((sx, xt0, bnx, before[0]), (se, eh0, bne, before[1])):
                 mean, rstd, rm, rv = _ref_stats(v.cpu(), bef)
                 assert_close(got[0], mean, 3e-6 * max(1.0, float(mean.abs().max())), "mean")
@@ -292,6 +293,7 @@ def test_gatedgcn_forward_emits_batch_statistics(profile, nb, d):
         else:
             assert torch.equal(sx, first[0]) and torch.equal(se, first[1])
     assert int(sync.buf.abs().sum()) == 0
+    # (the statistics above were checked against the PLAIN kernel's outputs; the stats kernel's own agree to 2e-6)
 
 
 @pytest.mark.parametrize("M,K,N", [(7569, 768, 384), (7569, 384, 384), (15348, 384, 384), (130, 384, 192), (64, 384, 384)])
