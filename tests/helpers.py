@@ -47,3 +47,76 @@ def segment_attention_ref(qkv, ptr, H, keep=None, p_drop=0.0, bias=None):
     if not outs:
         return qkv.new_zeros(N, d)
     return torch.cat([o for o, _, _ in outs], 0)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# Dropout-ON parity: the oracle with every dropout replaced by an INJECTED mask (the host model of the kernels'
+# counter hash), so a training-mode layer with the measured configuration's dropout rates can be compared element by
+# element.  graphgps/layer/gps_layer.py:139-140,152-153,253-257, gatedgcn_layer.py:78-79.
+# ---------------------------------------------------------------------------------------------------------------
+class MaskedSegmentMHA(torch.nn.Module):
+    """Stands in for the oracle's ``nn.MultiheadAttention`` (same parameters) with the attention-probability dropout
+    replaced by given keep masks: ``keep[g]`` bool [H, n_g, n_g], survivors scaled by 1 / (1 - p_eff)."""
+
+    def __init__(self, mha, ptr, keep, p_eff):
+        super().__init__()
+        self.in_proj_weight, self.in_proj_bias, self.out_proj = mha.in_proj_weight, mha.in_proj_bias, mha.out_proj
+        self.H, self.ptr, self.keep, self.p_eff = mha.num_heads, ptr, keep, p_eff
+
+    def forward(self, q, k, v, attn_mask=None, key_padding_mask=None, need_weights=False):
+        mask = ~key_padding_mask                                   # [B, Nmax]
+        x = q[mask]                                                # ragged [N, d]
+        qkv = torch.nn.functional.linear(x, self.in_proj_weight, self.in_proj_bias)
+        o = segment_attention_ref(qkv, self.ptr, self.H, keep=self.keep, p_drop=self.p_eff)
+        out = torch.zeros_like(q)
+        out[mask] = self.out_proj(o)
+        return out, None
+
+
+class inject_dropout_masks:
+    """``with inject_dropout_masks([m0, m1, ...]):`` every ``F.dropout`` call inside (``nn.Dropout`` modules included)
+    multiplies its input by the next mask of the list (already scaled by 1 / (1 - p)) instead of drawing one."""
+
+    def __init__(self, masks):
+        self.masks = list(masks)
+
+    def __enter__(self):
+        import torch.nn.functional as F
+        self._orig = F.dropout
+        queue = self.masks
+
+        def fake(x, p=0.5, training=True, inplace=False):
+            m = queue.pop(0)
+            assert m.shape == x.shape, (tuple(m.shape), tuple(x.shape))
+            return x * m.to(x.dtype)
+        F.dropout = fake
+        return self
+
+    def __exit__(self, *exc):
+        import torch.nn.functional as F
+        F.dropout = self._orig
+        assert exc[0] is not None or not self.masks, f"{len(self.masks)} injected masks were not consumed"
+        return False
+
+
+def block_seeds(seed):
+    """The seven per-stage seeds a fused block derives from its one drawn seed (layer/gps_block.py)."""
+    return [(seed + 0x9E3779B97F4A7C15 * (i + 1)) & 0xFFFFFFFFFFFFFFFF for i in range(7)]
+
+
+def row_mask(seed, R, d, p):
+    """Keep mask of the row kernels / GEMM epilogues, keyed (row, column), as a multiplier (0 or 1 / (1 - p))."""
+    from graphgps_amd.ops import attn_dropout_keep_mask
+    if p == 0:
+        return torch.ones(R, d, dtype=torch.float64)
+    return attn_dropout_keep_mask(seed, torch.arange(R), 0, 1, torch.arange(d), p).double() / (1 - p)
+
+
+def attention_keep(seed, ptr, H, p):
+    from graphgps_amd.ops import attn_dropout_keep_mask
+    keep = []
+    for g in range(len(ptr) - 1):
+        a, b = int(ptr[g]), int(ptr[g + 1])
+        keep.append(torch.stack([attn_dropout_keep_mask(seed, torch.arange(a, b), h, H, torch.arange(b - a), p,
+                                                        paired=True) for h in range(H)]))
+    return keep

@@ -157,6 +157,104 @@ def test_gpslayer_vs_oracle_baseline_sizes(local, glob, d, H, profile, nb):
             print(f"grad {k}: {r[2]} kink rows, max rel {r[0]:.2e} outside them")
 
 
+def _masked_oracle_run(oracle, b, seeds_per_layer, H, p, p_attn, wx, we, dtype, local):
+    """Forward + backward of a stack of oracle layers with every dropout replaced by the mask the fused block draws
+    from its seed (tests/helpers.py): returns (x_out, e_out, grad x, grad e, {param: grad} per layer)."""
+    import copy
+    from graphgps_amd.ops import attn_dropout_effective_p
+    from helpers import MaskedSegmentMHA, attention_keep, block_seeds, inject_dropout_masks, row_mask
+    layers = [copy.deepcopy(o).to(dtype).train() for o in oracle]
+    bc = b.clone()
+    bc.x = bc.x.to(dtype).requires_grad_(True)
+    bc.edge_attr = bc.edge_attr.to(dtype).requires_grad_(True)
+    x0, e0 = bc.x, bc.edge_attr
+    N, d = bc.x.shape
+    E = bc.edge_attr.shape[0]
+    masks = []
+    for lay, seed in zip(layers, seeds_per_layer):
+        s = block_seeds(seed)
+        keep = attention_keep(s[2], b.ptr, H, p_attn) if p_attn > 0 else None
+        lay.self_attn = MaskedSegmentMHA(lay.self_attn, b.ptr, keep, attn_dropout_effective_p(p_attn))
+        if local == "CustomGatedGCN":       # call order: gatedgcn x, e | dropout_attn | ff_dropout1 | ff_dropout2
+            masks += [row_mask(s[0], N, d, p), row_mask(s[1], E, d, p)]
+        else:                               # GINE: dropout_local | dropout_attn | ff_dropout1 | ff_dropout2
+            masks += [row_mask(s[0], N, d, p)]
+        masks += [row_mask(s[3], N, d, p), row_mask(s[4], N, 2 * d, p), row_mask(s[5], N, d, p)]
+    with inject_dropout_masks(masks):
+        for lay in layers:
+            bc = lay(bc)
+    loss = (bc.x * wx.to(dtype)).sum()
+    if local == "CustomGatedGCN":
+        loss = loss + (bc.edge_attr * we.to(dtype)).sum()
+    loss.backward()
+    grads = [{k: q.grad for k, q in lay.named_parameters() if q.grad is not None} for lay in layers]
+    return bc.x, bc.edge_attr, x0.grad, e0.grad, grads
+
+
+@pytest.mark.parametrize("local,d,H,profile,nb,p,p_attn,n_layers", [
+    ("CustomGatedGCN", 384, 16, "P30", 256, 0.1, 0.1, 1),     # the MEASURED configuration (pcqm4m-GPSmedium: dropout 0.1 / 0.1)
+    ("CustomGatedGCN", 384, 16, "P14", 64, 0.1, 0.1, 2),      # two stacked layers, each with its own seed
+    ("GINE", 64, 4, "ZINC", 32, 0.0, 0.5, 1),                 # zinc-GPS+RWSE.yaml: dropout 0.0, attn_dropout 0.5
+    ("GINE", 64, 4, "ZINC", 32, 0.2, 0.5, 2),
+])
+def test_fused_block_with_dropout_on_vs_masked_oracle(local, d, H, profile, nb, p, p_attn, n_layers, monkeypatch):
+    """Parity of the configuration bench.py measures, dropout ON: the fused block's seven seeds give seven masks (row /
+    (row, column) hash of the norm kernels and GEMM epilogues, the paired-key hash of the attention kernels); the same
+    masks, from the host model of the hash, are injected into the oracle (graphgps/layer/gps_layer.py:139-140,152-153,
+    253-257, gatedgcn_layer.py:78-79).  Outputs to 1e-5; gradients to 1e-5 of their largest element outside ReLU-kink
+    rows; three-way against the fp64 evaluation for the parameter gradients."""
+    from graphgps_amd.layer import gps_block
+    from graphgps_amd.layer.gps_layer import GPSLayer
+    from graphgps_amd.synthetic import layer_batch
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    layers = [GPSLayer(d, local, "Transformer", H, dropout=p, attn_dropout=p_attn) for _ in range(n_layers)]
+    oracle = [_oracle_layer_like(l) for l in layers]
+    for l in layers:
+        l.to(dev).train()
+    b = layer_batch(profile, nb, d, seed=91)
+    gen = torch.Generator().manual_seed(6)
+    wx = torch.randn(b.x.shape, generator=gen)
+    we = torch.randn(b.edge_attr.shape, generator=gen)
+    seeds = [0x0123456789ABCDEF + 977 * i for i in range(n_layers)]
+    it = iter(seeds)
+    monkeypatch.setattr(gps_block, "draw_dropout_seed", lambda: next(it))
+    bg = b.clone().to(dev)
+    bg.x.requires_grad_(True); bg.edge_attr.requires_grad_(True)
+    xg, eg = bg.x, bg.edge_attr
+    og = bg
+    for l in layers:
+        assert (gps_block.block_supported(l, og.x, og.edge_attr) if local == "CustomGatedGCN"
+                else gps_block.gine_block_supported(l, og.x, og.edge_attr)), "the fused block path must be the one under test"
+        og = l(og)
+    loss = (og.x * wx.to(dev)).sum()
+    if local == "CustomGatedGCN":
+        loss = loss + (og.edge_attr * we.to(dev)).sum()
+    loss.backward()
+    r32 = _masked_oracle_run(oracle, b, seeds, H, p, p_attn, wx, we, torch.float32, local)
+    r64 = _masked_oracle_run(oracle, b, seeds, H, p, p_attn, wx, we, torch.float64, local)
+    assert_close(og.x, r64[0], Tol.ACT * n_layers, "out.x (dropout on)")
+    if local == "CustomGatedGCN":
+        assert_close(og.edge_attr, r64[1], Tol.ACT * n_layers, "out.edge_attr (dropout on)")
+    gmax = int((b.ptr[1:] - b.ptr[:-1]).max())
+    rx = assert_close_kink_tolerant(xg.grad, r64[2], Tol.GRAD_REL * n_layers, "grad x (dropout on)",
+                                    min_allowed_rows=4 * gmax * n_layers)
+    print(f"dropout on, {local} x{n_layers}: grad x max rel {rx[0]:.2e} outside {rx[2]} kink rows")
+    if local == "CustomGatedGCN":
+        re_ = assert_close_kink_tolerant(eg.grad, r64[3], Tol.GRAD_REL * n_layers, "grad e (dropout on)")
+        print(f"   grad e max rel {re_[0]:.2e} outside {re_[2]} kink rows")
+    worst = (0.0, 0.0, "")
+    for li, l in enumerate(layers):
+        for k, q in l.named_parameters():
+            if k not in r64[4][li]:
+                continue
+            rg, rc, _, _ = assert_fp32_grade(q.grad, r32[4][li][k], r64[4][li][k], f"layer {li} grad {k} (dropout on)",
+                                             floor=2e-6, factor=4.0, min_scale=1.0)
+            if rg > worst[0]:
+                worst = (rg, rc, f"{li}.{k}")
+    print(f"   parameter gradients: largest rms error vs fp64 {worst[0]:.2e} (cpu-fp32 masked oracle {worst[1]:.2e}) on {worst[2]}")
+
+
 def test_gpslayer_performer_code2_size_vs_oracle():
     """BASELINE configs[4] layer shape (configs/GPS/ogbg-code2-GPS.yaml:31,40-47): GPSLayer(256,
     'CustomGatedGCN', 'Performer', 4) -- Performer's dim_head stays 64 (performer_layer.py:427,441-442), m = 266
@@ -220,16 +318,20 @@ def test_gpslayer_performer_code2_size_vs_oracle():
 def test_code2_model_vs_oracle():
     """The 4-layer ``ogbg-code2-GPS.yaml`` model (ASTNode/ASTEdge encoders, 4 x CustomGatedGCN+Performer at
     d=256, ogb_code_graph head, sub-token cross entropy) on 32 code2-long graphs, dropout off: every one of the
-    5 prediction heads, the loss and all parameter gradients vs the oracle model."""
-    import torch.nn.functional as F
+    5 prediction heads, the loss and all parameter gradients vs the oracle model -- three-way (HIP, the CPU fp32
+    oracle, its fp64 evaluation).
 
-    def compute_loss(pred_list, true):
-        # graphgps/loss/subtoken_prediction_loss.py:6-20 without its .to(float32) cast, so that the fp64 leg stays
-        # fp64 end to end (for the two fp32 legs this IS the reference's loss)
-        return sum(F.cross_entropy(p_, true['y_arr'][:, i]) for i, p_ in enumerate(pred_list)) / len(pred_list), pred_list
+    Pass 1 compares the whole batch.  Its parameter gradients carry a floor of 1e-4 rms, and round 2 only ASSERTED
+    why: a ReLU pre-activation within fp32 rounding of 0 lands on different sides in two fp32 evaluation orders, the
+    forward moves by 1e-7, but the gate of that element flips, and FAVOR+ couples all ~800 rows of its graph, so that
+    graph's whole gradient contribution moves.  Pass 2 DEMONSTRATES it: the error of the gradient w.r.t. the first
+    layer's input is attributed graph by graph (a flip is confined to its own graph: the only cross-graph coupling is
+    BatchNorm's batch statistics, O(1/rows)); graphs whose error stands out are the flipped ones; with exactly those
+    graphs' loss terms weighted 0 -- same inputs, same forward, same flips -- every parameter gradient must agree with
+    the fp64 evaluation to 5x what the reference's own fp32 arithmetic achieves, floor 2e-6."""
+    import torch.nn.functional as F
     from graphgps_amd.synthetic import model_batch
     from oracle.gps_oracle import to_oracle_model
-    import graphgps_amd as g
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     model = _build_model("code2_gps.yaml", 2, 5002, ["gt.dropout", 0.0, "gt.attn_dropout", 0.0])
@@ -238,36 +340,76 @@ def test_code2_model_vs_oracle():
     oracle = to_oracle_model(model)
     model.to(dev)
     b = model_batch("code2", 32, seed=4321)
+    B = len(b.ptr) - 1
     assert int((b.ptr[1:] - b.ptr[:-1]).max()) > 900
     import copy
     o64 = copy.deepcopy(oracle).double()
-    po, to_ = oracle(b.clone())
-    lo, _ = compute_loss(po, to_)
-    lo.backward()
-    p64, t64 = o64(_double_batch(b))
-    l64, _ = compute_loss(p64, t64)
-    l64.backward()
-    pg, tg = model(b.clone().to(dev))
-    lg, _ = compute_loss(pg, tg)
-    lg.backward()
-    for i, (a_, b_, c_) in enumerate(zip(pg, po, p64)):
+
+    def run(m, batch, w):
+        """(preds, loss, d loss / d (input of layer 0) [N, d], {parameter: grad}); the loss is the reference's
+        graphgps/loss/subtoken_prediction_loss.py:6-20 (mean over graphs of the mean over the 5 heads) without its
+        .to(float32) cast, with per-graph weights ``w`` (all ones = the reference's loss)."""
+        m.zero_grad(set_to_none=True)     # (training mode: the running statistics the passes move play no role)
+        hold = {}
+
+        def grab(mod, args):
+            args[0].x.retain_grad()
+            hold["x"] = args[0].x
+        h = m.layers[0].register_forward_pre_hook(grab)
+        pred, true = m(batch)
+        h.remove()
+        w = w.to(pred[0].device, pred[0].dtype)
+        loss = sum((F.cross_entropy(p_, true['y_arr'][:, i], reduction='none') * w).sum() / w.sum()
+                   for i, p_ in enumerate(pred)) / len(pred)
+        loss.backward()
+        return pred, loss, hold["x"].grad, {k: q.grad for k, q in m.named_parameters() if q.grad is not None}
+
+    ones = torch.ones(B)
+    legs = {"hip": (model, b.clone().to(dev)), "cpu": (oracle, b.clone()), "f64": (o64, _double_batch(b))}
+    r = {k: run(m, bb, ones) for k, (m, bb) in legs.items()}
+    for i, (a_, b_, c_) in enumerate(zip(r["hip"][0], r["cpu"][0], r["f64"][0])):
         rg, rc, mg, mc = assert_fp32_grade(a_, b_, c_, f"pred[{i}]", floor=1e-5)
         assert_close(a_, b_, max(1e-5, 4 * (mg + mc)), f"pred[{i}] (hip vs cpu oracle)")
-    assert_close(lg, lo, 1e-5, "loss")
-    op, o6 = dict(oracle.named_parameters()), dict(o64.named_parameters())
-    gscale = max(float(q.grad.abs().max()) for q in o6.values() if q.grad is not None)
-    worst = (0.0, 0.0, "")
-    for k, p in model.named_parameters():
-        if op[k].grad is None or p.grad is None:
-            continue
-        # floor 1e-4 rms: one ReLU-kink flip in a later layer perturbs, through FAVOR+'s all-rows coupling, the
-        # gradient of every row of that graph (1 of 32) and with it every earlier weight gradient by ~1e-5..1e-4
-        # of its scale; whether the fp32 CPU oracle or the HIP path catches such a flip is a coin toss (on MI355X:
-        # HIP 2.6e-5 rms on layers.0.ff_linear2.weight against a CPU oracle that happened to have none, 1.7e-8)
-        rg, rc, mg, mc = assert_fp32_grade(p.grad, op[k].grad, o6[k].grad, f"grad {k}", floor=1e-4, factor=5.0,
-                                           min_scale=max(1.0, 0.01 * gscale))
-        worst = max(worst, (rg, rc, k))
-    print(f"code2 model: largest rms error vs fp64: hip {worst[0]:.2e} (cpu-fp32 oracle {worst[1]:.2e}) on {worst[2]}")
+    assert_close(r["hip"][1], r["cpu"][1], 1e-5, "loss")
+
+    def grade(res, floor, factor, tag):
+        gscale = max(float(q.abs().max()) for q in res["f64"][3].values())
+        worst = (0.0, 0.0, "")
+        for k, g64 in res["f64"][3].items():
+            if k not in res["hip"][3] or k not in res["cpu"][3]:
+                continue
+            rg, rc, _, _ = assert_fp32_grade(res["hip"][3][k], res["cpu"][3][k], g64, f"grad {k} ({tag})", floor=floor,
+                                             factor=factor, min_scale=max(1.0, 0.01 * gscale))
+            worst = max(worst, (rg, rc, k))
+        print(f"code2 model, {tag}: largest rms error vs fp64: hip {worst[0]:.2e} (cpu-fp32 oracle {worst[1]:.2e}) on {worst[2]}")
+        return worst
+    grade(r, 1e-4, 5.0, "all 32 graphs")
+
+    # ---- attribution: whose gradient moved?  error of d loss / d x0 per graph, relative to the largest fp64 element ----
+    g64 = r["f64"][2]
+    scale = float(g64.abs().max())
+    ptr = b.ptr.tolist()
+
+    def per_graph(err):
+        e = err.detach().double().cpu().abs().max(dim=1).values / scale
+        return torch.stack([e[ptr[g]:ptr[g + 1]].max() for g in range(B)])
+    eh, ec = per_graph(r["hip"][2].cpu() - g64), per_graph(r["cpu"][2] - g64)
+    med = float(torch.cat([eh, ec]).median())
+    thr = max(20 * med, 2e-6)
+    flipped_h = [g for g in range(B) if float(eh[g]) > thr]
+    flipped_c = [g for g in range(B) if float(ec[g]) > thr]
+    print(f"   per-graph error of d loss / d x0 vs fp64: median {med:.1e}; above {thr:.1e}: hip graphs {flipped_h} "
+          f"(max {float(eh.max()):.1e}), cpu-fp32 graphs {flipped_c} (max {float(ec.max()):.1e})")
+    drop = sorted(set(flipped_h) | set(flipped_c))
+    assert len(drop) <= B // 4, f"errors in {len(drop)} of {B} graphs are not isolated kink events"
+    # ---- the same batch, the same forward, the flipped graphs' loss terms switched off ---------------------------------
+    w = ones.clone()
+    w[drop] = 0.0
+    r2 = {k: run(m, bb, w) for k, (m, bb) in legs.items()}
+    worst = grade(r2, 2e-6, 5.0, f"without graphs {drop}")
+    eh2 = per_graph(r2["hip"][2].cpu() - r2["f64"][2])
+    keep = [g for g in range(B) if g not in drop]
+    assert float(eh2[keep].max()) <= max(thr, 1e-5), "a kept graph still carries an outlier gradient error"
 
 
 def test_gpslayer_edge_permutation_and_determinism():
