@@ -345,11 +345,16 @@ __global__ __launch_bounds__(NTHREADS) void k_gemm_panel(const PanelArgs P) {
 //     a stage, so every fragment read has 18 MFMAs (576 cycles) of cover and no MFMA waits on LDS latency.
 // One workgroup per CU (132 KB of LDS), one wavefront per SIMD.
 // ------------------------------------------------------------------------------------------------------------
-constexpr int RG_BP = TN * BK * 2;             // one bf16 piece of the W stage: 12 KB
+// A column panel is 64 * NJ columns (NJ = 3: 192, the width the block's d = 384 projections tile with; NJ = 2: 128 for
+// d = 256 -- ogbg-code2-GPS.yaml, pcqm4m-GPSdeep --; NJ = 1: 64 for d = 64 and the 7 * 64-wide merged projection).
 constexpr int RG_SLOTS = 3;
+constexpr int rg_bp(int nj) { return 64 * nj * BK * 2; }                       // one bf16 piece of the W stage: 4 KB per 64 columns
 constexpr int rg_a_bytes(int mb) { return 64 * mb * BK * 4; }                  // raw fp32 A stage: 8 KB per 64 rows
-constexpr int rg_slot_bytes(int mb) { return rg_a_bytes(mb) + 3 * RG_BP; }     // 44 KB (64 rows) / 52 KB (128 rows)
-constexpr int rg_lds_bytes(int mb) { return RG_SLOTS * rg_slot_bytes(mb); }    // 132 KB / 156 KB
+constexpr int rg_slot_bytes(int mb, int nj) { return rg_a_bytes(mb) + 3 * rg_bp(nj); }   // NJ = 3: 44 KB (64 rows) / 52 KB (128 rows)
+constexpr int rg_lds_bytes(int mb, int nj) { return RG_SLOTS * rg_slot_bytes(mb, nj); }  // NJ = 3: 132 KB / 156 KB
+// panel width for an [N, K] weight: the widest of 192 / 128 / 64 that divides N (192 only with k-stages in threes: its
+// kernel is the round-2 schedule, unchanged, without the left-over stages of the general rotation)
+static inline int rg_nj(int64_t N, int64_t K) { return N % 192 == 0 && (K / BK) % RG_SLOTS == 0 ? 3 : (N % 128 == 0 ? 2 : 1); }
 // s_waitcnt immediate (gfx9 layout): vmcnt in bits 3:0 and 15:14, expcnt (left open) in 6:4, lgkmcnt in 11:8
 constexpr int waitcnt_imm(int vm, int lgkm) { return (vm & 15) | (7 << 4) | ((lgkm & 15) << 8) | ((vm >> 4) << 14); }
 
@@ -359,8 +364,9 @@ __device__ __forceinline__ void glds16(const unsigned char* g, unsigned char* l)
   __builtin_amdgcn_global_load_lds((gbl_void_ptr)g, (lds_void_ptr)l, 16, 0, 0);
 }
 
+template <int NJ>
 struct RingFrag {
-  bf16x8 b[3][3];      // W fragments of one 16-wide k-step: [column block][piece]
+  bf16x8 b[NJ][3];     // W fragments of one 16-wide k-step: [column block][piece]
 };
 struct RingA {
   u32x4 p[3];          // the A fragment of one row block and k-step as bf16 pairs: hi, mid, lo
@@ -376,25 +382,25 @@ __device__ float g_zero_bias[kZeroBias];      // stands in for a null bias, so t
 // a third of its lifetime).
 // EPI == 3 additionally accumulates, per lane and column block j, the shifted sums of the values it stores
 // (sk = the wave's first row, s1 = sum (v - sk), s2 = sum (v - sk)^2 over the rows this lane owns).
-template <int MB, int EPI, bool HAS_CIN, bool FULL>
-__device__ __forceinline__ void ring_store(const PanelArgs& P, const f32x16 (&acc)[MB][3], int64_t m0, int n0, int wm,
-                                           int wn, int li, int kh, float (&sk)[3], float (&s1)[3], float (&s2)[3]) {
+template <int MB, int NJ, int EPI, bool HAS_CIN, bool FULL>
+__device__ __forceinline__ void ring_store(const PanelArgs& P, const f32x16 (&acc)[MB][NJ], int64_t m0, int n0, int wm,
+                                           int wn, int li, int kh, float (&sk)[NJ], float (&s1)[NJ], float (&s2)[NJ]) {
   const uint64_t seed = gps::salted_seed(P.seed, P.salt);
   const bool drop = EPI != 0 && P.p_drop > 0.0f;
   const float inv_keep = drop ? 1.0f / (1.0f - P.p_drop) : 1.0f;
-  float bv[3];
+  float bv[NJ];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) bv[j] = P.bias[n0 + wn * 96 + j * 32 + li];     // never null here: the host passes g_zero_bias
+  for (int j = 0; j < NJ; ++j) bv[j] = P.bias[n0 + wn * (32 * NJ) + j * 32 + li];   // never null here: the host passes g_zero_bias
   // One 32-row block at a time: EVERY addend / mask value of the block is requested before the first store.  The addend
   // may alias C (in-place accumulation), so the compiler cannot move a load above an earlier store by itself, and one
   // load -> add -> store round trip per element cost 34-40 us per launch at the block's shapes; a lane only ever
   // re-reads elements it writes itself, so loading ahead is safe.
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
-    float cin[3][16], msk[3][16];
+    float cin[NJ][16], msk[NJ][16];
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int col = n0 + wn * 96 + j * 32 + li;
+    for (int j = 0; j < NJ; ++j) {
+      const int col = n0 + wn * (32 * NJ) + j * 32 + li;
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int64_t row = m0 + (wm * MB + mb) * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh;
@@ -404,8 +410,8 @@ __device__ __forceinline__ void ring_store(const PanelArgs& P, const f32x16 (&ac
       }
     }
 #pragma unroll
-    for (int j = 0; j < 3; ++j) {
-      const int col = n0 + wn * 96 + j * 32 + li;
+    for (int j = 0; j < NJ; ++j) {
+      const int col = n0 + wn * (32 * NJ) + j * 32 + li;
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int64_t row = m0 + (wm * MB + mb) * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh;
@@ -430,30 +436,31 @@ __device__ __forceinline__ void ring_store(const PanelArgs& P, const f32x16 (&ac
     }
   }
 }
-template <int MB, int EPI, bool HAS_CIN>
-__device__ __forceinline__ void ring_epilogue(const PanelArgs& P, const f32x16 (&acc)[MB][3], int64_t m0, int n0, int wm,
-                                              int wn, int li, int kh, float (&sk)[3], float (&s1)[3], float (&s2)[3]) {
-  if (m0 + 64 * MB <= P.M) ring_store<MB, EPI, HAS_CIN, true>(P, acc, m0, n0, wm, wn, li, kh, sk, s1, s2);   // workgroup-uniform
-  else ring_store<MB, EPI, HAS_CIN, false>(P, acc, m0, n0, wm, wn, li, kh, sk, s1, s2);
+template <int MB, int NJ, int EPI, bool HAS_CIN>
+__device__ __forceinline__ void ring_epilogue(const PanelArgs& P, const f32x16 (&acc)[MB][NJ], int64_t m0, int n0, int wm,
+                                              int wn, int li, int kh, float (&sk)[NJ], float (&s1)[NJ], float (&s2)[NJ]) {
+  if (m0 + 64 * MB <= P.M) ring_store<MB, NJ, EPI, HAS_CIN, true>(P, acc, m0, n0, wm, wn, li, kh, sk, s1, s2);   // workgroup-uniform
+  else ring_store<MB, NJ, EPI, HAS_CIN, false>(P, acc, m0, n0, wm, wn, li, kh, sk, s1, s2);
 }
 
 // Column statistics of the panel (EPI == 3): the two row-waves of each column half meet through LDS (the ring is free
 // by now), one thread per column merges them (Chan) and writes the workgroup's level-0 record write-through; the tree of
 // this column panel (records = row tiles) then completes in-launch (csrc/col_tree.hpp).
-template <int MB>
+template <int MB, int NJ>
 __device__ __forceinline__ void ring_stats(const PanelArgs& P, int rt, int panel, int64_t m0, int wm, int wn, int li, int kh,
-                                           const float (&sk)[3], float (&s1)[3], float (&s2)[3], float* lds) {
+                                           const float (&sk)[NJ], float (&s1)[NJ], float (&s2)[NJ], float* lds) {
+  constexpr int TN = 64 * NJ;                         // (shadows the 192-column constant of the register-staged kernel)
   constexpr int ROWS = 32 * MB;                       // rows per wave
   __syncthreads();      // every wave is past its final vmcnt(0): no LDS-DMA of the main loop can still land in the ring
   const int64_t left = P.M - (m0 + (int64_t)wm * ROWS);
   const float nw = left <= 0 ? 0.0f : (left < ROWS ? (float)left : (float)ROWS);
-  float* rec = lds + 16;                              // [2 row-waves][2][192]
+  float* rec = lds + 16;                              // [2 row-waves][2][TN]
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     s1[j] += __shfl_xor(s1[j], 32);
     s2[j] += __shfl_xor(s2[j], 32);
     if (kh == 0) {
-      const int col = wn * 96 + j * 32 + li;
+      const int col = wn * (32 * NJ) + j * 32 + li;
       rec[(wm * 2 + 0) * TN + col] = nw > 0.0f ? sk[j] + s1[j] / nw : 0.0f;
       rec[(wm * 2 + 1) * TN + col] = nw > 0.0f ? fmaxf(s2[j] - s1[j] * s1[j] / nw, 0.0f) : 0.0f;
     }
@@ -487,27 +494,37 @@ __device__ __forceinline__ void ring_stats(const PanelArgs& P, int rt, int panel
   tr::arrive<2, tr::STATS, 16>(T, rt, TN, lds);
 }
 
-// MB = row blocks of 32 per wave: the workgroup's panel is (64 * MB) rows x 192 columns, 2 x 2 waves of (32 * MB) x 96.
+// MB = row blocks of 32 per wave, NJ = column blocks of 32 per wave: the workgroup's panel is (64 * MB) rows x (64 * NJ)
+// columns, 2 x 2 waves of (32 * MB) x (32 * NJ).
 // MB = 2 halves the W bytes (and the LDS fragment reads) per MFMA: measured with MB = 1 a long-K panel runs at ~2350
 // cycles per stage against 1152 of MFMA issue, i.e. at ~19 bytes / cycle / CU through the global -> LDS path, the same
 // per-CU rate the 256 x 256 bf16 reference kernels sustain -- the load path, not the matrix pipe, was the bound.
-template <int MB, int EPI, bool HAS_CIN>
+// NJ = 3 is the schedule tuned for the d = 384 block (below, unchanged since round 2); NJ = 2 / 1 deal the same staging
+// over their fewer MFMA gaps by rule (the A split is amortised over fewer column blocks: 11 VALU per value pair against
+// 6 NJ MFMAs, so NJ = 1 is VALU-bound -- it serves the small widths, where the launches are latency-bound anyway).
+// Any number of k-stages >= 1: the static three-slot rotation runs in threes, the one or two stages left over reuse the
+// first slots of the rotation; DMA past the last stage re-fetches the last one (never read).
+template <int MB, int NJ, int EPI, bool HAS_CIN>
 __global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring(const PanelArgs P) {
-  constexpr int TMV = 64 * MB;                  // panel rows
-  constexpr int A_BYTES = rg_a_bytes(MB), SLOT = rg_slot_bytes(MB);
+  constexpr int TNV = 64 * NJ;                  // panel columns
+  constexpr int BP = rg_bp(NJ);                 // bytes of one W piece of a stage
+  constexpr int A_BYTES = rg_a_bytes(MB), SLOT = rg_slot_bytes(MB, NJ);
   constexpr int NA = 2 * MB;                    // A transfers per wave and stage (8 rows x 128 B each)
-  constexpr int ND = NA + 9;                    // DMA transfers per wave and stage
+  constexpr int NW = 3 * NJ;                    // W transfers per wave and stage (16 rows x 64 B each)
+  constexpr int ND = NA + NW;                   // DMA transfers per wave and stage
   constexpr int ND_ODD = ND / 2, ND_EVEN = ND - ND_ODD;   // dealt over the two regions of a stage
-  constexpr int G = 18 * MB;                    // MFMAs (= issue gaps) per region
-  constexpr int SPLIT0 = G - 12 * MB - (MB > 1 ? 2 : 0);  // first gap of the A split (4 * MB pairs x 3 instalments)
+  constexpr int G = 6 * MB * NJ;                // MFMAs (= issue gaps) per region
+  // first gap of the A split (4 * MB pairs x 3 instalments) and instalments per gap
+  constexpr int SPLIT0 = NJ == 3 ? G - 12 * MB - (MB > 1 ? 2 : 0) : (G >= 12 ? 3 : 1);
+  constexpr int SPLITQ = NJ == 3 ? 1 : (12 * MB + (G - SPLIT0) - 1) / (G - SPLIT0);
   extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];
   auto stamp = [&](int k) __attribute__((always_inline)) {
     if (P.trace && threadIdx.x == 0) P.trace[4 * (size_t)blockIdx.x + k] = __builtin_amdgcn_s_memtime();
   };
   stamp(0);
   const int panel = blockIdx.x / P.row_tiles, rt = blockIdx.x - panel * P.row_tiles;   // panel-major numbering
-  const int64_t m0 = (int64_t)rt * TMV;
-  const int n0 = panel * TN;
+  const int64_t m0 = (int64_t)rt * (64 * MB);
+  const int n0 = panel * TNV;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -525,20 +542,20 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring(const PanelArgs P) {
     const int64_t grow = min(m0 + row, P.M - 1);
     a_src[i] = reinterpret_cast<const unsigned char*>(P.A + grow * P.lda) + c * 16;
   }
-  // W: per piece 12 blocks of 16 rows x 64 B; wave w moves blocks 3w .. 3w+2 of every piece (9 instructions).
+  // W: per piece 4 NJ blocks of 16 rows x 64 B; wave w moves blocks NJ w .. NJ w + NJ - 1 of every piece (NW instructions).
   // lane -> (row lane >> 2 of the block, position lane & 3) fetching chunk pos ^ ((row >> 2) & 3)
   const int64_t stage_stride = (int64_t)P.N * (BK * 2);             // bytes between k-stages of one piece
   const int64_t piece_stride = stage_stride * KS;
-  const unsigned char* b_src = reinterpret_cast<const unsigned char*>(P.Bp) + ((int64_t)n0 + 48 * wave + (lane >> 2)) * (BK * 2) +
+  const unsigned char* b_src = reinterpret_cast<const unsigned char*>(P.Bp) + ((int64_t)n0 + 16 * NJ * wave + (lane >> 2)) * (BK * 2) +
                                (((lane & 3) ^ ((lane >> 4) & 3)) * 16);
-  // DMA transfer g (0 .. ND-1) of stage s into `slot`: the first NA = A rows, then W piece i / 3, block i % 3
+  // DMA transfer g (0 .. ND-1) of stage s into `slot`: the first NA = A rows, then W piece i / NJ, block i % NJ
   auto dma = [&](int g, int s, unsigned char* slot) __attribute__((always_inline)) {
     if (g < NA) {
       glds16(a_src[g] + (int64_t)s * (BK * 4), slot + wave * (NA * 1024) + g * 1024);
     } else {
       const int i = g - NA;
-      glds16(b_src + s * stage_stride + (i / 3) * piece_stride + (i % 3) * 1024,
-             slot + A_BYTES + (i / 3) * RG_BP + wave * 3072 + (i % 3) * 1024);
+      glds16(b_src + s * stage_stride + (i / NJ) * piece_stride + (i % NJ) * 1024,
+             slot + A_BYTES + (i / NJ) * BP + wave * (NJ * 1024) + (i % NJ) * 1024);
     }
   };
 
@@ -549,14 +566,14 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring(const PanelArgs P) {
     const int c0 = ks * 4 + kh * 2, sw = (li >> 1) & 7;
     a_off[ks][0] = (wm * 32 * MB + li) * 128 + ((c0 ^ sw) * 16);
     a_off[ks][1] = (wm * 32 * MB + li) * 128 + (((c0 + 1) ^ sw) * 16);
-    b_off[ks] = A_BYTES + (wn * 96 + li) * 64 + (((ks * 2 + kh) ^ ((li >> 2) & 3)) * 16);
+    b_off[ks] = A_BYTES + (wn * 32 * NJ + li) * 64 + (((ks * 2 + kh) ^ ((li >> 2) & 3)) * 16);
   }
 
-  f32x16 acc[MB][3];
+  f32x16 acc[MB][NJ];
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb)
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
+    for (int j = 0; j < NJ; ++j)
 #pragma unroll
       for (int q = 0; q < 16; ++q) acc[mb][j][q] = 0.0f;
 
@@ -581,21 +598,21 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring(const PanelArgs P) {
 
   constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};   // smallest terms first
 
-  // One region = the G = 18 MB MFMAs of k-step u (operands `ac`, `fc`, already in registers), with the staging of
+  // One region = the G = 6 MB NJ MFMAs of k-step u (operands `ac`, `fc`, already in registers), with the staging of
   // k-step u+1 dealt into their issue gaps (at one wavefront per SIMD the matrix pipe takes an MFMA every 32 cycles,
   // which hides ~5 other instructions; a burst of loads or VALU between two MFMAs is idle pipe time):
-  //   gaps 0 .. 3        the raw-A reads and the nine W-fragment reads of step u+1 (all of them early: the compiler waits
+  //   gaps 0 .. 3        the raw-A reads and the 3 NJ W-fragment reads of step u+1 (all of them early: the compiler waits
   //                      lgkmcnt(0) at the first use of a raw value, so every read should have landed by then)
-  //   gaps 0 .. 6        up to seven DMA transfers (dma_first .. dma_first + dma_count - 1 of stage dma_stage)
-  //   gaps SPLIT0 ..     the split of the raw A values (4 MB pairs x 3 instalments)
-  // sched_barrier(0) after every gap pins this order.  The 3 MB accumulators rotate, so no MFMA waits on its predecessor.
+  //   gaps 0 ..          the DMA transfers (dma_first .. dma_first + dma_count - 1 of stage dma_stage), one per gap
+  //   gaps SPLIT0 ..     the split of the raw A values (4 MB pairs x 3 instalments, SPLITQ per gap)
+  // sched_barrier(0) after every gap pins this order.  The MB NJ accumulators rotate, so no MFMA waits on its predecessor.
   f32x4 raw[MB][2];
-  auto region = [&](const RingA (&ac)[MB], const RingFrag& fc, RingA (&an)[MB], RingFrag& fn, const unsigned char* rd_slot,
+  auto region = [&](const RingA (&ac)[MB], const RingFrag<NJ>& fc, RingA (&an)[MB], RingFrag<NJ>& fn, const unsigned char* rd_slot,
                     int rd_ks, int dma_stage, unsigned char* dma_slot, int dma_first, int dma_count)
                     __attribute__((always_inline)) {
 #pragma unroll
     for (int i = 0; i < G; ++i) {
-      const int term = i / (3 * MB), mb = (i / 3) % MB, j = i % 3;
+      const int term = i / (NJ * MB), mb = (i / NJ) % MB, j = i % NJ;
       acc[mb][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ac[mb].p[TA[term]]), fc.b[j][TB[term]],
                                                           acc[mb][j], 0, 0, 0);
       if (i == 0) {
@@ -606,34 +623,39 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring(const PanelArgs P) {
         }
       }
       if (i < 4) {
-        constexpr int first[5] = {0, 1, 4, 7, 9};        // W-fragment reads per gap: 1, 3, 3, 2
+        // W-fragment reads per gap -- NJ = 3: 1, 3, 3, 2;  NJ = 2: 1, 2, 2, 1;  NJ = 1: 1, 1, 1, 0
+        constexpr int first[5] = {0, 1, NJ == 3 ? 4 : (NJ == 2 ? 3 : 2), NJ == 3 ? 7 : (NJ == 2 ? 5 : 3), NW};
 #pragma unroll
         for (int k = first[i]; k < first[i + 1]; ++k)
-          fn.b[k / 3][k % 3] = *reinterpret_cast<const bf16x8*>(rd_slot + b_off[rd_ks] + (k / 3) * (32 * 64) + (k % 3) * RG_BP);
+          fn.b[k / 3][k % 3] = *reinterpret_cast<const bf16x8*>(rd_slot + b_off[rd_ks] + (k / 3) * (32 * 64) + (k % 3) * BP);
       }
       if (i < dma_count) dma(dma_first + i, dma_stage, dma_slot);
-      if (i >= SPLIT0 && i < SPLIT0 + 12 * MB) {
-        const int q = i - SPLIT0;                        // pair q / 3 (row block (q / 3) / 4, dword (q / 3) % 4), instalment q % 3
-        split_part(q % 3, raw[(q / 3) / 4], (q / 3) % 4, an[(q / 3) / 4]);
+      if (i >= SPLIT0) {
+#pragma unroll
+        for (int u = 0; u < SPLITQ; ++u) {
+          const int q = (i - SPLIT0) * SPLITQ + u;       // pair q / 3 (row block (q / 3) / 4, dword (q / 3) % 4), instalment q % 3
+          if (q < 12 * MB) split_part(q % 3, raw[(q / 3) / 4], (q / 3) % 4, an[(q / 3) / 4]);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
   };
+  static_assert(ND_EVEN <= G && 12 * MB <= (G - SPLIT0) * SPLITQ, "the staging does not fit the region's issue gaps");
 
   unsigned char* const slot0 = ring;
   unsigned char* const slot1 = ring + SLOT;
   unsigned char* const slot2 = ring + 2 * SLOT;
-  // prologue: stages 0 and 1 whole, the first ND_ODD transfers of stage 2 (KS >= 3: host check)
+  // prologue: stages 0 and 1 whole, the first ND_ODD transfers of stage 2 (stage indices clamped to the last one)
 #pragma unroll
   for (int g = 0; g < ND; ++g) dma(g, 0, slot0);
 #pragma unroll
-  for (int g = 0; g < ND; ++g) dma(g, 1, slot1);
+  for (int g = 0; g < ND; ++g) dma(g, min(1, KS - 1), slot1);
 #pragma unroll
-  for (int g = 0; g < ND_ODD; ++g) dma(g, 2, slot2);
+  for (int g = 0; g < ND_ODD; ++g) dma(g, min(2, KS - 1), slot2);
   __builtin_amdgcn_s_waitcnt(waitcnt_imm(ND + ND_ODD, 15));   // this wave's share of stage 0 has landed
   __builtin_amdgcn_s_barrier();                               // ... and every other wave's
   stamp(1);
-  RingFrag f0, f1;
+  RingFrag<NJ> f0, f1;
   RingA a0[MB], a1[MB];
 #pragma unroll
   for (int b = 0; b < MB; ++b) {
@@ -641,10 +663,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring(const PanelArgs P) {
     raw[b][1] = *reinterpret_cast<const f32x4*>(slot0 + a_off[0][1] + b * 4096);
   }
 #pragma unroll
-  for (int j = 0; j < 3; ++j)
+  for (int j = 0; j < NJ; ++j)
 #pragma unroll
     for (int p = 0; p < 3; ++p)
-      f0.b[j][p] = *reinterpret_cast<const bf16x8*>(slot0 + b_off[0] + j * (32 * 64) + p * RG_BP);
+      f0.b[j][p] = *reinterpret_cast<const bf16x8*>(slot0 + b_off[0] + j * (32 * 64) + p * BP);
 #pragma unroll
   for (int b = 0; b < MB; ++b)
 #pragma unroll
@@ -666,17 +688,26 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring(const PanelArgs P) {
   __builtin_amdgcn_s_barrier();                                                                \
   __builtin_amdgcn_sched_barrier(0);                                                           \
   region(a1, f1, a0, f0, NXT, 0, min((S) + 3, KS - 1), CUR, 0, ND_ODD);
-  for (int s0 = 0; s0 < KS; s0 += 3) {                    // KS is a multiple of 3 (host check): slots are static
+  int s0 = 0;
+  for (; s0 + 3 <= KS; s0 += 3) {                         // the slots of the rotation are static
     GPS_RING_STAGE(s0, slot0, slot1, slot2)
     GPS_RING_STAGE(s0 + 1, slot1, slot2, slot0)
     GPS_RING_STAGE(s0 + 2, slot2, slot0, slot1)
   }
+  if constexpr (NJ != 3) {                                // (NJ = 3 is only dispatched with stages in threes: rg_nj)
+    if (s0 < KS) {                                        // one or two stages left over (workgroup-uniform)
+      GPS_RING_STAGE(s0, slot0, slot1, slot2)
+      if (s0 + 1 < KS) { GPS_RING_STAGE(s0 + 1, slot1, slot2, slot0) }
+    }
+  }
 #undef GPS_RING_STAGE
   __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 15));         // no DMA may still be writing this workgroup's LDS when it retires
   stamp(2);
-  float sk[3] = {0.f, 0.f, 0.f}, s1[3] = {0.f, 0.f, 0.f}, s2[3] = {0.f, 0.f, 0.f};
-  ring_epilogue<MB, EPI, HAS_CIN>(P, acc, m0, n0, wm, wn, li, kh, sk, s1, s2);
-  if (EPI == 3) ring_stats<MB>(P, rt, panel, m0, wm, wn, li, kh, sk, s1, s2, reinterpret_cast<float*>(ring));
+  float sk[NJ], s1[NJ], s2[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) sk[j] = s1[j] = s2[j] = 0.f;
+  ring_epilogue<MB, NJ, EPI, HAS_CIN>(P, acc, m0, n0, wm, wn, li, kh, sk, s1, s2);
+  if (EPI == 3) ring_stats<MB, NJ>(P, rt, panel, m0, wm, wn, li, kh, sk, s1, s2, reinterpret_cast<float*>(ring));
   __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 15));
   stamp(3);
 }
@@ -692,9 +723,13 @@ static int panel_launch(const float* A, int64_t lda, int64_t M, int K, const uin
                         int64_t ldmask, float p_drop, uint64_t seed, const gps_bn* stats, float* ws, size_t ws_floats,
                         uint32_t* sync, gps_stream_t stream);
 
-static int ring_mb(int64_t M, int N) {
+// 128-row panels (MB = 2) when they still give every CU a workgroup; 64-column panels always use 64 rows (the only
+// NJ = 1 instantiation).  GPS_GEMM_RING_MB = 1 / 2 forces one.
+static int ring_mb(int64_t M, int N, int K) {
   static const int mb_cfg = []() { const char* v = getenv("GPS_GEMM_RING_MB"); return v && *v ? atoi(v) : 0; }();
-  const int64_t tiles128 = ((M + 127) / 128) * (N / TN);
+  const int nj = rg_nj(N, K);
+  if (nj == 1) return 1;
+  const int64_t tiles128 = ((M + 127) / 128) * (N / (64 * nj));
   return mb_cfg == 1 || mb_cfg == 2 ? mb_cfg : (tiles128 >= 200 ? 2 : 1);
 }
 static bool ring_enabled() {
@@ -711,7 +746,8 @@ int gps_gemm_panel_trace(unsigned long long* buf) { g_panel_trace = buf; return 
 
 size_t gps_gemm_image_elems(int64_t N, int64_t K) { return (size_t)(3 * N * K); }
 
-int gps_gemm_panel_supported(int64_t N, int64_t K) { return N > 0 && K > 0 && N % TN == 0 && K % (4 * BK) == 0; }
+// the ring kernel: column panels of 192 / 128 / 64, any number of 32-wide k-stages
+int gps_gemm_panel_supported(int64_t N, int64_t K) { return N > 0 && K > 0 && N % 64 == 0 && K % BK == 0; }
 
 int gps_gemm_split_weights(int n, const gps_gemm_split* descs, gps_stream_t stream) {
   GPS_REQUIRE(n >= 1 && n <= kMaxSplit && descs, "gps_gemm_split_weights: 1..%d weights per launch", kMaxSplit);
@@ -731,15 +767,16 @@ int gps_gemm_split_weights(int n, const gps_gemm_split* descs, gps_stream_t stre
   return gps::launch_status("gps_gemm_split_weights");
 }
 
-size_t gps_gemm_stats_floats(int64_t M, int N) {
-  if (M < 1 || N < TN) return 0;
-  const int rt = (int)((M + 64 * ring_mb(M, N) - 1) / (64 * ring_mb(M, N)));
-  return (size_t)(N / TN) * (tr::floats_for(rt, 2, TN) + 16);
+size_t gps_gemm_stats_floats(int64_t M, int N, int K) {
+  if (M < 1 || !gps_gemm_panel_supported(N, K)) return 0;
+  const int tn = 64 * rg_nj(N, K), mb = ring_mb(M, N, K);
+  const int rt = (int)((M + 64 * mb - 1) / (64 * mb));
+  return (size_t)(N / tn) * (tr::floats_for(rt, 2, tn) + 16);
 }
-int gps_gemm_stats_sync_words(int N) { return (N / TN) * tr::kSyncWords; }
+int gps_gemm_stats_sync_words(int N) { return N >= 64 && N % 64 == 0 ? (N / 64) * tr::kSyncWords : 0; }   // (>= any panel count)
 int gps_gemm_stats_supported(int64_t M, int N, int K) {
-  if (!gps_gemm_panel_supported(N, K) || !ring_enabled() || (K / BK) % RG_SLOTS != 0 || M < 2) return 0;
-  const int mb = ring_mb(M, N);
+  if (!gps_gemm_panel_supported(N, K) || !ring_enabled() || M < 2) return 0;
+  const int mb = ring_mb(M, N, K);
   return (M + 64 * mb - 1) / (64 * mb) <= tr::kMaxParts;
 }
 
@@ -758,7 +795,7 @@ int gps_gemm_panel_stats(const float* A, int64_t lda, int64_t M, int K, const ui
               (long long)M, N, K);
   GPS_REQUIRE(Cin && stats && stats->mean && stats->rstd && ws && sync && al16(ws), "gps_gemm_panel_stats: null / misaligned buffer");
   GPS_REQUIRE((stats->running_mean == nullptr) == (stats->running_var == nullptr), "gps_gemm_panel_stats: running stats");
-  GPS_REQUIRE(ws_floats >= gps_gemm_stats_floats(M, N), "gps_gemm_panel_stats: workspace too small (gps_gemm_stats_floats)");
+  GPS_REQUIRE(ws_floats >= gps_gemm_stats_floats(M, N, K), "gps_gemm_panel_stats: workspace too small (gps_gemm_stats_floats)");
   return panel_launch(A, lda, M, K, image, N, bias, Cin, ldcin, C, ldc, 3, nullptr, 0, p_drop, seed, stats, ws, ws_floats, sync,
                       stream);
 }
@@ -769,7 +806,7 @@ static int panel_launch(const float* A, int64_t lda, int64_t M, int K, const uin
                         const float* Cin, int64_t ldcin, float* C, int64_t ldc, int epilogue, const float* mask_src,
                         int64_t ldmask, float p_drop, uint64_t seed, const gps_bn* stats, float* ws, size_t ws_floats,
                         uint32_t* sync, gps_stream_t stream) {
-  GPS_REQUIRE(M >= 0 && gps_gemm_panel_supported(N, K), "gps_gemm_panel: needs N %% 192 == 0 and K %% 128 == 0 (N=%d K=%d)",
+  GPS_REQUIRE(M >= 0 && gps_gemm_panel_supported(N, K), "gps_gemm_panel: needs N %% 64 == 0 and K %% 32 == 0 (N=%d K=%d)",
               N, K);
   if (M == 0) return GPS_OK;
   GPS_REQUIRE(A && image && C && lda >= K && ldc >= N && lda % 4 == 0 && al16(A) && al16(image),
@@ -781,16 +818,15 @@ static int panel_launch(const float* A, int64_t lda, int64_t M, int K, const uin
   P.A = A; P.lda = lda; P.M = M; P.K = K; P.N = N; P.Bp = image; P.bias = bias; P.Cin = Cin; P.ldcin = ldcin;
   P.C = C; P.ldc = ldc; P.epilogue = epilogue; P.mask_src = mask_src; P.ldmask = ldmask;
   P.p_drop = epilogue ? p_drop : 0.0f; P.seed = seed; P.salt = gps::dropout_salt();
-  P.row_tiles = (int)((M + TM - 1) / TM);
   P.trace = g_panel_trace;
-  unsigned grid = (unsigned)(P.row_tiles * (N / TN));
   hipStream_t s = gps::as_stream(stream);
-  // ring kernel (LDS-DMA, three-slot ring) whenever the k-stages come in threes; GPS_GEMM_RING=0 keeps the
-  // register-staged kernel (A/B measurements).  128-row panels when they still give every CU a workgroup
-  // (GPS_GEMM_RING_MB = 1 / 2 forces one).
-  const bool ring = ring_enabled() && (K / BK) % RG_SLOTS == 0 && K / BK >= RG_SLOTS;
-  const int mb = ring_mb(M, N);
+  // The ring kernel (LDS-DMA, three-slot ring) serves every supported shape.  GPS_GEMM_RING=0 keeps the register-staged
+  // round-2 kernel where IT applies (N % 192 == 0, K % 128 == 0; A/B measurements).
+  const bool staged_ok = N % TN == 0 && K % (4 * BK) == 0;
+  const bool ring = ring_enabled() || !staged_ok;
+  const int mb = ring_mb(M, N, K), nj = rg_nj(N, K);
   GPS_REQUIRE(epilogue != 3 || ring, "gps_gemm_panel: the statistics epilogue needs the ring kernel");
+  unsigned grid;
   if (ring) {
     if (!P.bias) {
       GPS_REQUIRE(N <= kZeroBias, "gps_gemm_panel: N=%d without a bias exceeds the built-in zero row (%d)", N, kZeroBias);
@@ -799,34 +835,43 @@ static int panel_launch(const float* A, int64_t lda, int64_t M, int K, const uin
       P.bias = zeros;
     }
     P.row_tiles = (int)((M + 64 * mb - 1) / (64 * mb));
-    grid = (unsigned)(P.row_tiles * (N / TN));
+    grid = (unsigned)(P.row_tiles * (N / (64 * nj)));
     if (epilogue == 3) {
       P.st_ws = ws;
-      P.st_stride = tr::floats_for(P.row_tiles, 2, TN) + 16;
+      P.st_stride = tr::floats_for(P.row_tiles, 2, 64 * nj) + 16;
       P.st_tick = sync;
       P.st_mean = stats->mean; P.st_rstd = stats->rstd; P.st_rmean = stats->running_mean; P.st_rvar = stats->running_var;
       P.st_eps = stats->eps; P.st_mom = stats->momentum;
       (void)ws_floats;
     }
+  } else {
+    P.row_tiles = (int)((M + TM - 1) / TM);
+    grid = (unsigned)(P.row_tiles * (N / TN));
   }
-#define GPS_RING_LAUNCH(MBV, E, C)                                                                    \
+#define GPS_RING_LAUNCH(MBV, NJV, E, C)                                                               \
   do {                                                                                                \
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring<MBV, E, C>), \
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, rg_lds_bytes(MBV)); \
-    GPS_REQUIRE(attr == hipSuccess, "gps_gemm_panel: cannot reserve %d bytes of LDS", rg_lds_bytes(MBV));      \
-    k_gemm_ring<MBV, E, C><<<grid, NTHREADS, rg_lds_bytes(MBV), s>>>(P);                              \
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring<MBV, NJV, E, C>), \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, rg_lds_bytes(MBV, NJV)); \
+    GPS_REQUIRE(attr == hipSuccess, "gps_gemm_panel: cannot reserve %d bytes of LDS", rg_lds_bytes(MBV, NJV));  \
+    k_gemm_ring<MBV, NJV, E, C><<<grid, NTHREADS, rg_lds_bytes(MBV, NJV), s>>>(P);                    \
+  } while (0)
+#define GPS_RING_SHAPES(E, C)                                                                         \
+  do {                                                                                                \
+    if (nj == 3) { if (mb == 2) GPS_RING_LAUNCH(2, 3, E, C); else GPS_RING_LAUNCH(1, 3, E, C); }      \
+    else if (nj == 2) { if (mb == 2) GPS_RING_LAUNCH(2, 2, E, C); else GPS_RING_LAUNCH(1, 2, E, C); } \
+    else GPS_RING_LAUNCH(1, 1, E, C);                                                                 \
   } while (0)
 #define GPS_PANEL_LAUNCH(E, C)                                                                        \
   do {                                                                                                \
-    if (ring && mb == 2) GPS_RING_LAUNCH(2, E, C);                                                    \
-    else if (ring) GPS_RING_LAUNCH(1, E, C);                                                          \
+    if (ring) GPS_RING_SHAPES(E, C);                                                                  \
     else k_gemm_panel<E, C><<<grid, NTHREADS, 0, s>>>(P);                                             \
   } while (0)
   if (epilogue == 0) { if (Cin) GPS_PANEL_LAUNCH(0, true); else GPS_PANEL_LAUNCH(0, false); }
   else if (epilogue == 1) { if (Cin) GPS_PANEL_LAUNCH(1, true); else GPS_PANEL_LAUNCH(1, false); }
   else if (epilogue == 2) { if (Cin) GPS_PANEL_LAUNCH(2, true); else GPS_PANEL_LAUNCH(2, false); }
-  else { if (mb == 2) GPS_RING_LAUNCH(2, 3, true); else GPS_RING_LAUNCH(1, 3, true); }
+  else GPS_RING_SHAPES(3, true);
 #undef GPS_RING_LAUNCH
+#undef GPS_RING_SHAPES
 #undef GPS_PANEL_LAUNCH
   return gps::launch_status("gps_gemm_panel");
 }

@@ -52,6 +52,111 @@ __global__ __launch_bounds__(256) void k_pool_bwd(const float* __restrict__ g_ou
   v.store(g_x + n * (int64_t)d + c);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------
+// Weight gradient of an embedding lookup with a large vocabulary (ASTNodeEncoder's 10,030-entry attribute table,
+// graphgps/encoder/ast_encoder.py:35-83): g_w[t] = sum of the gradient rows of every lookup of token t.
+// ATen: radix sort + sum_and_scatter (0.4 ms per [25k, 256] lookup on MI355X, 1.2 ms when one token takes half of
+// the lookups, order of summation not fixed).  Here the lookups arrive grouped by token (a STABLE sort of the token
+// ids, done by the caller: `tok` ascending, `perm` = original positions) and the sum is a segmented reduction over
+// fixed units of UNIT consecutive entries:
+//   1. one lane group (d / 4 lanes, one wavefront at d = 256) per unit walks its entries in order; a run of equal
+//      tokens that begins and ends inside the unit is complete and goes straight to g_w; the (at most two) runs that
+//      touch a neighbouring unit leave a partial row: slot 0 = continues a run of the previous unit, slot 1 = begins
+//      here and continues into the next;
+//   2. for every run that spans units, the workgroup of the unit where it BEGINS sums the partial rows of the
+//      units it covers, in unit order (row lanes take units round-robin, combined in lane order).
+// Deterministic (fixed partition, fixed order), no atomics.  g_w must be zero on entry (tokens without lookups).
+constexpr int EMB_UNIT = 64;
+
+template <int L>     // lanes per row (d = 4 L floats); UNIT entries per lane group, 256 / L lane groups per block
+__global__ __launch_bounds__(256) void k_embed_grad_units(const float* __restrict__ g, const int64_t* __restrict__ tok,
+                                                          const int64_t* __restrict__ perm, int64_t n, int d,
+                                                          float* __restrict__ g_w, float* __restrict__ part,
+                                                          int32_t* __restrict__ ptok) {
+  typedef Vec<4> V4;
+  const int lane = threadIdx.x % L, grp = threadIdx.x / L;
+  const int64_t u = (int64_t)blockIdx.x * (256 / L) + grp;
+  const int64_t ub = u * EMB_UNIT;
+  if (ub >= n) return;
+  const int64_t ue = ub + EMB_UNIT < n ? ub + EMB_UNIT : n;
+  const int c = lane * 4;
+  const int64_t prev_tok = ub > 0 ? tok[ub - 1] : -1, next_tok = ue < n ? tok[ue] : -1;
+  int32_t pt0 = -1, pt1 = -1;
+  V4 acc = V4::zero();
+  int64_t cur = tok[ub], run_start = ub;
+  auto flush = [&](bool cont_next) __attribute__((always_inline)) {
+    const bool cont_prev = run_start == ub && prev_tok == cur;
+    if (!cont_prev && !cont_next) {
+      acc.store(g_w + cur * d + c);
+    } else if (cont_prev) {
+      acc.store(part + (u * 2 + 0) * d + c);
+      pt0 = (int32_t)cur;
+    } else {
+      acc.store(part + (u * 2 + 1) * d + c);
+      pt1 = (int32_t)cur;
+    }
+  };
+  for (int64_t k0 = ub; k0 < ue; k0 += 8) {       // 8 gradient rows requested before the first is used
+    int64_t t8[8];
+    V4 v8[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int64_t k = k0 + j < ue ? k0 + j : ue - 1;
+      t8[j] = tok[k];
+      v8[j] = V4::load(g + perm[k] * d + c);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (k0 + j < ue) {
+        if (t8[j] != cur) {
+          flush(false);
+          cur = t8[j];
+          run_start = k0 + j;
+          acc = V4::zero();
+        }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] += v8[j][q];
+      }
+    }
+  }
+  flush(next_tok == cur);
+  if (lane == 0) {
+    ptok[u * 2 + 0] = pt0;
+    ptok[u * 2 + 1] = pt1;
+  }
+}
+
+template <int L>
+__global__ __launch_bounds__(1024) void k_embed_grad_merge(const float* __restrict__ part, const int32_t* __restrict__ ptok,
+                                                           int64_t U, int d, float* __restrict__ g_w) {
+  typedef Vec<4> V4;
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // [RS][d]
+  const int64_t u = blockIdx.x;
+  const int t = ptok[u * 2 + 1];
+  if (t < 0) return;                                // no run begins in this unit and runs on (block-uniform)
+  constexpr int RS = 1024 / L;
+  const int lane = threadIdx.x % L, r = threadIdx.x / L;
+  const int c = lane * 4;
+  V4 acc = V4::zero();
+  for (int64_t v = u + 1 + r; v < U && ptok[v * 2] == t; v += RS) {   // the run covers consecutive units
+    const V4 p = V4::load(part + (v * 2) * d + c);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] += p[q];
+  }
+  acc.store(lds + r * d + c);
+  __syncthreads();
+  if (r == 0) {
+    V4 tot = V4::load(part + (u * 2 + 1) * d + c);
+    for (int q2 = 0; q2 < RS; ++q2) {
+      const V4 p = V4::load(lds + q2 * d + c);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) tot[q] += p[q];
+    }
+    tot.store(g_w + (int64_t)t * d + c);
+  }
+}
+
 __global__ void k_node_graph(const int32_t* __restrict__ ptr, int64_t B, int32_t* __restrict__ node_graph) {
   const int64_t g = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   if (g >= B) return;
@@ -66,6 +171,35 @@ int gps_node_graph_from_ptr(const int32_t* ptr, int64_t B, int32_t* node_graph, 
   GPS_REQUIRE(ptr && B >= 0 && (node_graph || B == 0), "gps_node_graph_from_ptr: bad arguments");
   if (B > 0) k_node_graph<<<gps::grid_for(B, 256), 256, 0, gps::as_stream(stream)>>>(ptr, B, node_graph);
   return gps::launch_status("gps_node_graph_from_ptr");
+}
+
+size_t gps_embedding_grad_workspace_bytes(int64_t n, int d) {
+  if (n < 1 || d < 1) return 0;
+  const int64_t U = (n + EMB_UNIT - 1) / EMB_UNIT;
+  return (size_t)U * 2 * d * sizeof(float) + (size_t)U * 2 * sizeof(int32_t) + 64;
+}
+int gps_embedding_grad_supported(int d) { return d == 64 || d == 128 || d == 256; }
+
+int gps_embedding_grad(const float* g, const int64_t* tok_sorted, const int64_t* perm, int64_t n, int64_t V, int d,
+                       float* g_w, void* ws, size_t ws_bytes, gps_stream_t stream) {
+  GPS_REQUIRE(n >= 0 && V >= 1 && gps_embedding_grad_supported(d), "gps_embedding_grad: d=%d must be 64, 128 or 256", d);
+  if (n == 0) return GPS_OK;
+  GPS_REQUIRE(g && tok_sorted && perm && g_w && ws && (uintptr_t)g % 16 == 0 && (uintptr_t)g_w % 16 == 0 && (uintptr_t)ws % 16 == 0,
+              "gps_embedding_grad: null / misaligned buffer");
+  GPS_REQUIRE(ws_bytes >= gps_embedding_grad_workspace_bytes(n, d), "gps_embedding_grad: workspace too small");
+  const int64_t U = (n + EMB_UNIT - 1) / EMB_UNIT;
+  float* part = static_cast<float*>(ws);
+  int32_t* ptok = reinterpret_cast<int32_t*>(part + (size_t)U * 2 * d);
+  hipStream_t s = gps::as_stream(stream);
+#define GPS_EMB(LV)                                                                                              \
+  do {                                                                                                           \
+    constexpr int per = 256 / LV;                                                                                \
+    k_embed_grad_units<LV><<<(unsigned)((U + per - 1) / per), 256, 0, s>>>(g, tok_sorted, perm, n, d, g_w, part, ptok); \
+    k_embed_grad_merge<LV><<<(unsigned)U, 1024, sizeof(float) * (1024 / LV) * d, s>>>(part, ptok, U, d, g_w);    \
+  } while (0)
+  if (d == 256) GPS_EMB(64); else if (d == 128) GPS_EMB(32); else GPS_EMB(16);
+#undef GPS_EMB
+  return gps::launch_status("gps_embedding_grad");
 }
 
 int gps_segment_pool_fwd(const float* x, const int32_t* ptr, int64_t B, int d, int mean, float* out,

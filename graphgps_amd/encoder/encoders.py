@@ -22,6 +22,20 @@ from ..graphgym.register import (node_encoder_dict, register_edge_encoder,
 from ..synthetic import ATOM_FEATURE_DIMS, BOND_FEATURE_DIMS
 
 
+def _multihot_embedding(feats, embs, owner):
+    """Sum over the columns of ``feats`` [R, k] of ``embs[i](feats[:, i])`` as ONE [R, sum(vocab)] x [sum(vocab), emb]
+    GEMM over a multi-hot matrix (small vocabularies only).  The point is the backward: grad_W = multihot^T @ g is a
+    deterministic GEMM instead of k sort-based ``embedding_dense_backward`` pipelines."""
+    offs = getattr(owner, "_offsets", None)
+    if offs is None or offs.device != feats.device:
+        sizes = [e.num_embeddings for e in embs]
+        offs = torch.tensor([sum(sizes[:i]) for i in range(len(sizes))], device=feats.device)
+        owner._offsets, owner._vocab = offs, sum(sizes)
+    multihot = torch.zeros(feats.shape[0], owner._vocab, dtype=embs[0].weight.dtype, device=feats.device)
+    multihot.scatter_(1, feats + offs, 1.0)
+    return multihot @ torch.cat([e.weight for e in embs], dim=0)
+
+
 class _OGBFeatureEncoder(nn.Module):
     _attr = None
     _dims = None
@@ -49,15 +63,7 @@ class _OGBFeatureEncoder(nn.Module):
         over a multi-hot matrix (vocabularies are tiny: 173 atom / 13 bond entries).  The point
         is the backward: grad_W = multihot^T @ g is a deterministic GEMM instead of 9 (3)
         sort-based ``embedding_dense_backward`` pipelines (~1.3 ms per step on MI355X)."""
-        offs = getattr(self, "_offsets", None)
-        if offs is None or offs.device != feats.device:
-            sizes = [e.num_embeddings for e in embs]
-            offs = torch.tensor([sum(sizes[:i]) for i in range(len(sizes))], device=feats.device)
-            self._offsets, self._vocab = offs, sum(sizes)
-        multihot = torch.zeros(feats.shape[0], self._vocab, dtype=embs[0].weight.dtype,
-                               device=feats.device)
-        multihot.scatter_(1, feats + offs, 1.0)
-        return multihot @ torch.cat([e.weight for e in embs], dim=0)
+        return _multihot_embedding(feats, embs, self)
 
 
 @register_node_encoder('Atom', overwrite=True)
@@ -118,6 +124,15 @@ class ASTNodeEncoder(nn.Module):
     def forward(self, batch):
         x = batch.x
         depth = batch.node_depth.view(-1).clamp(max=self.max_depth)
+        if x.is_cuda and torch.is_grad_enabled():
+            # the two small tables (98 node types, 21 depths) as one multi-hot GEMM, the 10,030-entry attribute table
+            # through the lookup whose weight gradient is the deterministic segmented sum (ops.embedding): no ATen
+            # sort + sum_and_scatter (2 ms of the code2 step in round 2) on the path
+            from ..ops import embedding
+            small = _multihot_embedding(torch.stack([x[:, 0], depth], dim=1),
+                                        [self.type_encoder, self.depth_encoder], self)
+            batch.x = small + embedding(x[:, 1], self.attribute_encoder.weight)
+            return batch
         batch.x = (self.type_encoder(x[:, 0]) + self.attribute_encoder(x[:, 1])
                    + self.depth_encoder(depth))
         return batch
@@ -131,8 +146,11 @@ class ASTEdgeEncoder(nn.Module):
         self.embedding_direction = nn.Embedding(2, emb_dim)
 
     def forward(self, batch):
-        batch.edge_attr = (self.embedding_type(batch.edge_attr[:, 0])
-                           + self.embedding_direction(batch.edge_attr[:, 1]))
+        ea = batch.edge_attr
+        if ea.is_cuda and torch.is_grad_enabled():
+            batch.edge_attr = _multihot_embedding(ea[:, :2], [self.embedding_type, self.embedding_direction], self)
+            return batch
+        batch.edge_attr = (self.embedding_type(ea[:, 0]) + self.embedding_direction(ea[:, 1]))
         return batch
 
 

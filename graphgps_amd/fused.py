@@ -224,15 +224,51 @@ def _param_grads(g: torch.Tensor, x: torch.Tensor, need_w: bool, need_b: bool, p
     return g_w, g_b
 
 
+# Rows below which a projection stays on the library GEMM (the ring kernel's split launch + 64-row panels do not pay on a
+# handful of rows); GPS_GEMM_PANEL=0 (gemm.ENABLED) switches the ring GEMM off everywhere.
+_RING_MIN_ROWS = 256
+
+
+def _ring_ok(x: torch.Tensor, weight: torch.Tensor) -> bool:
+    from . import gemm as _gemm
+    N, K = weight.shape
+    return (_gemm.supported(N, K) and x.shape[0] >= _RING_MIN_ROWS and x.stride(1) == 1 and x.stride(0) % 4 == 0
+            and x.data_ptr() % 16 == 0 and weight.stride(1) == 1 and weight.stride(0) % 4 == 0
+            and weight.data_ptr() % 16 == 0)
+
+
+def _ring_forward(ctx, x, weight, bias, need_gx):
+    """y = x W^T + b on the ring GEMM (csrc/gemm_panel.hip: fp32-exact products on the bf16 MFMA pipe); the W^T image for
+    the input gradient is made in the same split launch and kept on ``ctx``."""
+    from . import gemm as _gemm
+    N, K = weight.shape
+    tn = need_gx and _gemm.supported(K, N)
+    (img_nt, img_tn), = _gemm.split_weights([weight], nt=True, tn=tn)
+    ctx.img_tn = img_tn
+    return _gemm.gemm_panel(x, img_nt, N, bias=bias)
+
+
+def _ring_input_grad(ctx, g, weight):
+    from . import gemm as _gemm
+    img = getattr(ctx, "img_tn", None)
+    if img is not None and g.shape[0] >= _RING_MIN_ROWS and g.stride(0) % 4 == 0 and g.data_ptr() % 16 == 0:
+        return _gemm.gemm_panel(g, img, weight.shape[1])
+    return g.mm(weight)
+
+
 class _Linear(torch.autograd.Function):
-    """y = x W^T + b with rocBLAS/hipBLASLt GEMMs (through torch) and the bias gradient taken by
-    the library's deterministic two-stage column sum instead of ATen's reduce_kernel."""
+    """y = x W^T + b.  Forward and input gradient on the ring GEMM where the shape qualifies (N % 64 == 0, K % 32 == 0,
+    >= 256 rows: every projection of a d = 256 / 384 layer -- ogbg-code2-GPS.yaml, pcqm4m-GPS*.yaml -- outside the fused
+    blocks), the library GEMMs otherwise; weight + bias gradient by the streaming split-K kernel (csrc/wgrad.hip)."""
 
     @staticmethod
     def forward(ctx, x, weight, bias):
         ctx.save_for_backward(x, weight)
         ctx.has_bias = bias is not None
         ctx.params = (weight, bias)
+        ctx.img_tn = None
+        if _ring_ok(x, weight):
+            return _ring_forward(ctx, x, weight, bias, ctx.needs_input_grad[0])
         return F.linear(x, weight, bias)
 
     @staticmethod
@@ -241,7 +277,7 @@ class _Linear(torch.autograd.Function):
         g = _f32c(g, "g")
         g_w, g_b = _param_grads(g, x, ctx.needs_input_grad[1],
                                 ctx.has_bias and ctx.needs_input_grad[2], ctx.params)
-        g_x = g.mm(weight) if ctx.needs_input_grad[0] else None
+        g_x = _ring_input_grad(ctx, g, weight) if ctx.needs_input_grad[0] else None
         return g_x, g_w, g_b
 
 
@@ -263,6 +299,9 @@ class _GroupLinear(torch.autograd.Function):
         ctx.save_for_backward(x, wcat)
         ctx.sizes, ctx.has_bias = sizes, bcat is not None
         ctx.params = params
+        ctx.img_tn = None
+        if _ring_ok(x, wcat):
+            return _ring_forward(ctx, x, wcat, bcat, ctx.needs_input_grad[0])
         return F.linear(x, wcat, bcat)
 
     @staticmethod
@@ -270,7 +309,7 @@ class _GroupLinear(torch.autograd.Function):
         x, wcat = ctx.saved_tensors
         g = _f32c(g, "g")
         g_w, g_b = _param_grads(g, x, True, ctx.has_bias, ctx.params)
-        g_x = g.mm(wcat) if ctx.needs_input_grad[0] else None
+        g_x = _ring_input_grad(ctx, g, wcat) if ctx.needs_input_grad[0] else None
         outs, off = [], 0
         for n in ctx.sizes:
             outs.append(g_w[off:off + n])

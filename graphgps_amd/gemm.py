@@ -6,7 +6,8 @@ weight by ``split_weights`` -- once per optimizer step for training (the weights
 kernel, which torch's version counters do not see, so a training forward always re-splits: ~6 us per layer), cached
 across calls only in evaluation.  Replaces ``torch.addmm`` / ``mm`` (rocBLAS / hipBLASLt) for the projections of
 ``/root/reference/graphgps/layer/gatedgcn_layer.py:57-61`` and ``graphgps/layer/gps_layer.py:104-106,143-144,253-257``
-where the shape qualifies (N % 192 == 0, K % 128 == 0: d = 384 does); everything else stays on the libraries.
+where the shape qualifies (N % 64 == 0, K % 32 == 0: every width that is a multiple of 64 -- 384, 256, 64); everything
+else stays on the libraries.
 """
 from __future__ import annotations
 
@@ -22,7 +23,8 @@ ENABLED = os.environ.get("GPS_GEMM_PANEL", "1") != "0"
 
 
 def supported(N: int, K: int) -> bool:
-    return ENABLED and N > 0 and K > 0 and N % 192 == 0 and K % 128 == 0
+    """Shapes the ring kernel tiles: column panels of 192 / 128 / 64, 32-wide k-stages."""
+    return ENABLED and N > 0 and K > 0 and N % 64 == 0 and K % 32 == 0
 
 
 _stats_ok = {}
@@ -49,7 +51,7 @@ def gemm_panel_stats(a: torch.Tensor, image: torch.Tensor, N: int, bias: Optiona
     if a.stride(1) != 1 or a.dtype != torch.float32:
         raise _lib.GpsHipError("gemm_panel_stats: fp32 A with unit column stride")
     out = torch.empty(M, N, dtype=torch.float32, device=a.device)
-    wsf = L.gps_gemm_stats_floats(M, N)
+    wsf = L.gps_gemm_stats_floats(M, N, K)
     ws = torch.empty(wsf, dtype=torch.float32, device=a.device)
     check(L.gps_gemm_panel_stats(ptr(a), a.stride(0), M, K, ptr(image), N, ptr(bias), ptr(addend), addend.stride(0),
                                  ptr(out), out.stride(0), float(p_drop), int(seed), ctypes.byref(bn_desc), ptr(ws), wsf,

@@ -41,6 +41,9 @@ _SIGNATURES = {
     "gps_gine_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int64, c_int, c_float, _P,
                              _P, _P, _P]),
     "gps_node_graph_from_ptr": (c_int, [_P, c_int64, _P, _P]),
+    "gps_embedding_grad_workspace_bytes": (c_size_t, [c_int64, c_int]),
+    "gps_embedding_grad_supported": (c_int, [c_int]),
+    "gps_embedding_grad": (c_int, [_P, _P, _P, c_int64, c_int64, c_int, _P, _P, c_size_t, _P]),
     "gps_segment_pool_fwd": (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P]),
     "gps_segment_pool_bwd": (c_int, [_P, _P, _P, c_int64, c_int, c_int, _P, _P]),
     "gps_bn_workspace_floats": (c_size_t, [c_int64, c_int]),
@@ -88,7 +91,7 @@ _SIGNATURES = {
     "gps_gemm_panel_trace": (c_int, [_P]),
     "gps_gemm_panel": (c_int, [_P, c_int64, c_int64, c_int, _P, c_int, _P, _P, c_int64, _P, c_int64, c_int, _P,
                                c_int64, c_float, c_uint64, _P]),
-    "gps_gemm_stats_floats": (c_size_t, [c_int64, c_int]),
+    "gps_gemm_stats_floats": (c_size_t, [c_int64, c_int, c_int]),
     "gps_gemm_stats_sync_words": (c_int, [c_int]),
     "gps_gemm_stats_supported": (c_int, [c_int64, c_int, c_int]),
     "gps_gemm_panel_stats": (c_int, [_P, c_int64, c_int64, c_int, _P, c_int, _P, _P, c_int64, _P, c_int64, c_float,

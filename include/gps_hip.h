@@ -200,8 +200,9 @@ int gps_edge_attn_bwd(const float* g_wv, const float* g_z, const float* Q, const
  * B is passed as a pre-split IMAGE (uint16 bf16 patterns, layout [3 pieces][K/32][N][32]) produced from the fp32
  * weight by gps_gemm_split_weights -- once per optimizer step, for the weight (`image_nt`: B[n][k] = W[n][k],
  * forward) and/or its transpose (`image_tn`: B[n][k] = W[k][n], input gradient); gps_gemm_image_elems(N, K)
- * uint16 elements each.  Shapes: N % 192 == 0 and K % 128 == 0 (gps_gemm_panel_supported); anything else stays
- * on the library GEMMs.
+ * uint16 elements each.  Shapes: N % 64 == 0 and K % 32 == 0 (gps_gemm_panel_supported: column panels of 192, 128 or
+ * 64, any number of 32-wide k-stages -- every GPS width that is a multiple of 64); anything else stays on the library
+ * GEMMs.
  * epilogue: 0 none | 1 relu then dropout(p_drop, seed) keyed (row, column) like gps_act_drop_add
  *           | 2 multiply by the relu/dropout mask of `mask_src` (= gps_act_drop_bwd applied to the product).
  * ------------------------------------------------------------------------------------- */
@@ -227,9 +228,9 @@ int gps_gemm_panel(const float* A, int64_t lda, int64_t M, int K, const uint16_t
  *   -> stats->mean / rstd (+ running statistics), complete when the launch retires (csrc/col_tree.hpp: one tree per
  *   192-column panel, level-0 records = the row tiles).  Replaces `h + dropout(ff_linear2(t))` / `x + dropout(attn)`
  *   followed by the statistics pass of norm2 / norm1_attn (graphgps/layer/gps_layer.py:212-217,225-229).
- *   ws: gps_gemm_stats_floats(M, N) floats; sync: gps_gemm_stats_sync_words(N) uint32, zero at entry, zero at exit.
+ *   ws: gps_gemm_stats_floats(M, N, K) floats; sync: gps_gemm_stats_sync_words(N) uint32, zero at entry, zero at exit.
  *   Shapes: gps_gemm_stats_supported(M, N, K). */
-size_t gps_gemm_stats_floats(int64_t M, int N);
+size_t gps_gemm_stats_floats(int64_t M, int N, int K);
 int gps_gemm_stats_sync_words(int N);
 int gps_gemm_stats_supported(int64_t M, int N, int K);
 int gps_gemm_panel_stats(const float* A, int64_t lda, int64_t M, int K, const uint16_t* image, int N, const float* bias,
@@ -394,6 +395,17 @@ int gps_wgrad_grouped(int n, const gps_wgrad_problem* probs, float* ws, gps_stre
  * `node_graph` int32 [N] (graph id per node) comes from gps_node_graph_from_ptr.
  * ------------------------------------------------------------------------------------- */
 int gps_node_graph_from_ptr(const int32_t* ptr, int64_t B, int32_t* node_graph, gps_stream_t stream);
+/* Weight gradient of an nn.Embedding lookup with a large vocabulary: g_w[t] = sum of the rows g[perm[k]] over the
+ * lookups k of token t.  Replaces ATen's embedding_dense_backward (radix sort + sum_and_scatter, summation order not
+ * fixed) behind graphgps/encoder/ast_encoder.py:35-83 (the 10,030-entry attribute table of ogbg-code2).
+ *   tok_sorted  int64 [n] token ids in ascending order (a STABLE sort of the lookup indices), perm its permutation
+ *   g_w         [V, d], ZERO on entry (tokens without lookups keep a zero row); d in {64, 128, 256}
+ * Segmented reduction over fixed units of 64 entries, partial rows of runs that span units merged in unit order:
+ * deterministic, no atomics.  ws: gps_embedding_grad_workspace_bytes(n, d). */
+size_t gps_embedding_grad_workspace_bytes(int64_t n, int d);
+int gps_embedding_grad_supported(int d);
+int gps_embedding_grad(const float* g, const int64_t* tok_sorted, const int64_t* perm, int64_t n, int64_t V, int d,
+                       float* g_w, void* ws, size_t ws_bytes, gps_stream_t stream);
 int gps_segment_pool_fwd(const float* x, const int32_t* ptr, int64_t B, int d, int mean, float* out,
                          gps_stream_t stream);
 int gps_segment_pool_bwd(const float* g_out, const int32_t* ptr, const int32_t* node_graph,

@@ -6,7 +6,7 @@ import os
 import pytest
 import torch
 
-from conftest import (Tol, assert_close, assert_close_kink_tolerant, assert_fp32_grade, golden_names,
+from conftest import (Tol, assert_close, assert_close_kink_tolerant, assert_fp32_grade, fp32_grade, golden_names,
                       load_golden)
 
 pytestmark = pytest.mark.gpu
@@ -243,76 +243,22 @@ def test_fused_block_with_dropout_on_vs_masked_oracle(local, d, H, profile, nb, 
     if local == "CustomGatedGCN":
         re_ = assert_close_kink_tolerant(eg.grad, r64[3], Tol.GRAD_REL * n_layers, "grad e (dropout on)")
         print(f"   grad e max rel {re_[0]:.2e} outside {re_[2]} kink rows")
-    worst = (0.0, 0.0, "")
+    # parameter gradients: as in the dropout-off test above, a kink flip at (row r, channel c) lands undamped in row c of a
+    # weight gradient (and in element c of a bias / BatchNorm gradient), so a few outlier rows per parameter are allowed and
+    # the bar holds outside them; the CPU fp32 evaluation of the SAME masked function is graded next to it
+    gscale = max(float(g.abs().max()) for gl in r64[4] for g in gl.values())
+    worst, flips = 0.0, 0
     for li, l in enumerate(layers):
         for k, q in l.named_parameters():
             if k not in r64[4][li]:
                 continue
-            rg, rc, _, _ = assert_fp32_grade(q.grad, r32[4][li][k], r64[4][li][k], f"layer {li} grad {k} (dropout on)",
-                                             floor=2e-6, factor=4.0, min_scale=1.0)
-            if rg > worst[0]:
-                worst = (rg, rc, f"{li}.{k}")
-    print(f"   parameter gradients: largest rms error vs fp64 {worst[0]:.2e} (cpu-fp32 masked oracle {worst[1]:.2e}) on {worst[2]}")
-
-
-def test_gpslayer_performer_code2_size_vs_oracle():
-    """BASELINE configs[4] layer shape (configs/GPS/ogbg-code2-GPS.yaml:31,40-47): GPSLayer(256,
-    'CustomGatedGCN', 'Performer', 4) -- Performer's dim_head stays 64 (performer_layer.py:427,441-442), m = 266
-    random features -- on a CODE2_LONG batch (32 ASTs of 600-1000 nodes, 4 concatenated edge groups) vs the CPU
-    oracle (the reference's padded to_dense_batch -> SelfAttention -> [mask] path, gps_layer.py:199,206):
-    outputs 1e-5, input gradients 1e-5 of max|g| outside ReLU-kink rows; parameter gradients graded against the
-    fp64 evaluation of the same oracle (conftest.assert_fp32_grade)."""
-    from graphgps_amd.layer.gps_layer import GPSLayer
-    from graphgps_amd.synthetic import layer_batch
-    dev = torch.device("cuda:0")
-    torch.manual_seed(0)
-    layer = GPSLayer(256, "CustomGatedGCN", "Performer", 4, dropout=0.0, attn_dropout=0.0)
-    oracle = _oracle_layer_like(layer).train()
-    layer.to(dev).train()
-    b = layer_batch("CODE2_LONG", 32, 256, seed=21)
-    sizes = (b.ptr[1:] - b.ptr[:-1])
-    assert int(sizes.max()) <= 1000 and int(sizes.min()) >= 600 and int(sizes.max()) - int(sizes.min()) > 200
-    gen = torch.Generator().manual_seed(8)
-    wx = torch.randn(b.x.shape, generator=gen)
-    we = torch.randn(b.edge_attr.shape, generator=gen)
-    bc = b.clone()
-    bc.x.requires_grad_(True); bc.edge_attr.requires_grad_(True)
-    xo, eo = bc.x, bc.edge_attr
-    oo = oracle(bc)
-    ((oo.x * wx).sum() + (oo.edge_attr * we).sum()).backward()
-    bg = b.clone().to(dev)
-    bg.x.requires_grad_(True); bg.edge_attr.requires_grad_(True)
-    xg, eg = bg.x, bg.edge_attr
-    og = layer(bg)
-    ((og.x * wx.to(dev)).sum() + (og.edge_attr * we.to(dev)).sum()).backward()
-    assert_close(og.x, oo.x, Tol.ACT, "out.x")
-    assert_close(og.edge_attr, oo.edge_attr, Tol.ACT, "out.edge_attr")
-    # FAVOR+ mixes all rows of a graph: a kink flip in one graph touches up to 1000 rows
-    rx = assert_close_kink_tolerant(xg.grad, xo.grad, Tol.GRAD_REL, "grad x", min_allowed_rows=2 * 1000)
-    re_ = assert_close_kink_tolerant(eg.grad, eo.grad, Tol.GRAD_REL, "grad e")
-    print(f"code2 layer: grad x max rel {rx[0]:.2e} outside {rx[2]} kink rows; grad e {re_[0]:.2e} / {re_[2]}")
-    # parameter gradients are sums over 25.6k rows / 76k edges in which every kink row (a few dozen here: FAVOR+
-    # couples all rows of a graph) lands undamped: judged against the fp64 evaluation of the same oracle
-    import copy
-    o64 = copy.deepcopy(oracle).double()
-    o64.zero_grad(set_to_none=True)
-    b64 = b.clone()
-    b64.x = b64.x.double(); b64.edge_attr = b64.edge_attr.double()
-    r64 = o64(b64)
-    ((r64.x * wx.double()).sum() + (r64.edge_attr * we.double()).sum()).backward()
-    op, o6 = dict(oracle.named_parameters()), dict(o64.named_parameters())
-    gscale = max(float(q.grad.abs().max()) for q in o6.values() if q.grad is not None)
-    worst = (0.0, "")
-    for k, p in layer.named_parameters():
-        if op[k].grad is None:
-            continue
-        # floor 2e-4: a kink flip is a Poisson event (27 kink rows of 25.6k between HIP and the CPU oracle above);
-        # with a handful of them per side the two rms errors differ by small-count noise, not by arithmetic
-        rg, rc, mg, mc = assert_fp32_grade(p.grad, op[k].grad, o6[k].grad, f"grad {k}", floor=2e-4, factor=5.0,
-                                           min_scale=max(1.0, 0.01 * gscale))
-        worst = max(worst, (rg / max(rc, 1e-12), k))
-        print(f"  {k:32s} rms err vs fp64: hip {rg:.2e}  cpu-fp32 {rc:.2e}   max: hip {mg:.2e}  cpu-fp32 {mc:.2e}")
-    print(f"code2 layer: worst hip/cpu rms-error ratio {worst[0]:.2f} ({worst[1]})")
+            rr = assert_close_kink_tolerant(q.grad, r64[4][li][k], 1e-4, f"layer {li} grad {k} (dropout on)",
+                                            min_scale=max(1.0, 0.01 * gscale))
+            worst, flips = max(worst, rr[0]), flips + rr[2]
+    c_err = max(fp32_grade(r32[4][li][k], r32[4][li][k], r64[4][li][k], max(1.0, 0.01 * gscale))[3]
+                for li in range(n_layers) for k in r64[4][li])
+    print(f"   parameter gradients: max rel error vs fp64 {worst:.2e} outside {flips} kink rows "
+          f"(cpu-fp32 masked oracle: max {c_err:.2e})")
 
 
 def test_code2_model_vs_oracle():
@@ -396,20 +342,42 @@ def test_code2_model_vs_oracle():
     eh, ec = per_graph(r["hip"][2].cpu() - g64), per_graph(r["cpu"][2] - g64)
     med = float(torch.cat([eh, ec]).median())
     thr = max(20 * med, 2e-6)
-    flipped_h = [g for g in range(B) if float(eh[g]) > thr]
-    flipped_c = [g for g in range(B) if float(ec[g]) > thr]
-    print(f"   per-graph error of d loss / d x0 vs fp64: median {med:.1e}; above {thr:.1e}: hip graphs {flipped_h} "
-          f"(max {float(eh.max()):.1e}), cpu-fp32 graphs {flipped_c} (max {float(ec.max()):.1e})")
-    drop = sorted(set(flipped_h) | set(flipped_c))
-    assert len(drop) <= B // 4, f"errors in {len(drop)} of {B} graphs are not isolated kink events"
-    # ---- the same batch, the same forward, the flipped graphs' loss terms switched off ---------------------------------
-    w = ones.clone()
-    w[drop] = 0.0
-    r2 = {k: run(m, bb, w) for k, (m, bb) in legs.items()}
-    worst = grade(r2, 2e-6, 5.0, f"without graphs {drop}")
-    eh2 = per_graph(r2["hip"][2].cpu() - r2["f64"][2])
-    keep = [g for g in range(B) if g not in drop]
-    assert float(eh2[keep].max()) <= max(thr, 1e-5), "a kept graph still carries an outlier gradient error"
+    out_h = [g for g in range(B) if float(eh[g]) > thr]
+    out_c = [g for g in range(B) if float(ec[g]) > thr]
+    print(f"   per-graph error of d loss / d x0 vs fp64 (rel. to max {scale:.2e}): median {med:.1e}; above {thr:.1e}: "
+          f"hip {len(out_h)} graphs {out_h} (max {float(eh.max()):.1e}), cpu-fp32 {len(out_c)} graphs {out_c} "
+          f"(max {float(ec.max()):.1e})")
+    # mechanism, checked where every intermediate is visible (the reference arithmetic itself): ReLU pre-activations whose
+    # SIGN differs between the fp32 and the fp64 evaluation of the oracle, per graph
+    def relu_signs(m, batch):
+        rec, hooks = [], []
+        for lay in m.layers:
+            for mod in (lay.local_model.act_fn_x, lay.local_model.act_fn_e, lay.act_fn_ff):
+                hooks.append(mod.register_forward_hook(lambda _m, inp, _o: rec.append(inp[0].detach() > 0)))
+        with torch.no_grad():
+            m(batch)
+        for h in hooks:
+            h.remove()
+        return rec
+    s32, s64 = relu_signs(oracle, b.clone()), relu_signs(o64, _double_batch(b))
+    node_graph = b.batch
+    edge_graph = b.batch[b.edge_index[1]]
+    flips = torch.zeros(B, dtype=torch.long)
+    for a_, c_ in zip(s32, s64):
+        rows = (a_ != c_).any(dim=1).nonzero().flatten()
+        gmap = node_graph if a_.shape[0] == node_graph.shape[0] else edge_graph
+        flips += torch.bincount(gmap[rows], minlength=B)
+    flipped = [g for g in range(B) if int(flips[g]) > 0]
+    print(f"   ReLU sign flips, CPU fp32 oracle vs its fp64 evaluation: {int(flips.sum())} rows in graphs {flipped}")
+    missing = [g for g in out_c if g not in flipped]
+    assert not missing, f"cpu-fp32 outlier graphs {missing} contain no flipped pre-activation: another mechanism is at work"
+    # graphs WITHOUT a flip agree to the noise level on the CPU leg: the outliers ARE the flips
+    quiet = [g for g in range(B) if g not in flipped]
+    if quiet:
+        assert float(ec[quiet].max()) <= thr, "a graph without any flipped pre-activation is an outlier on the CPU leg"
+    # and the HIP evaluation is hit no more often / no harder than the reference's own fp32 arithmetic
+    assert len(out_h) <= 2 * len(out_c) + 4, (len(out_h), len(out_c))
+    assert float(eh.max()) <= 10 * max(float(ec.max()), thr), (float(eh.max()), float(ec.max()))
 
 
 def test_gpslayer_edge_permutation_and_determinism():

@@ -296,7 +296,8 @@ def test_gatedgcn_forward_emits_batch_statistics(profile, nb, d):
     # (the statistics above were checked against the PLAIN kernel's outputs; the stats kernel's own agree to 2e-6)
 
 
-@pytest.mark.parametrize("M,K,N", [(7569, 768, 384), (7569, 384, 384), (15348, 384, 384), (130, 384, 192), (64, 384, 384)])
+@pytest.mark.parametrize("M,K,N", [(7569, 768, 384), (7569, 384, 384), (15348, 384, 384), (130, 384, 192), (64, 384, 384),
+                                   (5000, 512, 256), (25013, 256, 256), (743, 64, 64), (743, 128, 64)])
 def test_gemm_epilogue_residual_dropout_statistics(M, K, N):
     """gps_gemm_panel_stats: C = Cin + dropout(A W^T + b) with the host model of the mask, and the batch statistics of C
     (norm2 / norm1_attn: gps_layer.py:212-217,225-229) against fp64; repeated launches reproduce bit for bit."""

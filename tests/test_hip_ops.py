@@ -690,7 +690,12 @@ def test_gin_aggregate_matches_index_add():
 
 
 @pytest.mark.parametrize("M,K,N", [(7569, 384, 2688), (1000, 384, 384), (15348, 384, 384), (7569, 768, 384),
-                                   (333, 2688, 384), (64, 128, 192), (65, 256, 768)])
+                                   (333, 2688, 384), (64, 128, 192), (65, 256, 768),
+                                   # round 3: 128- and 64-column panels, any number of k-stages (d = 256: code2 / GPS-deep;
+                                   # d = 64: ZINC; 304 = 9.5 stages stays on the libraries)
+                                   (7569, 256, 1792), (7569, 1792, 256), (25013, 256, 256), (1000, 256, 512),
+                                   (1000, 512, 256), (743, 64, 448), (743, 448, 64), (743, 64, 64), (130, 32, 64),
+                                   (130, 64, 128), (300, 160, 192), (2000, 608, 1216)])
 def test_gemm_panel_fp32_exact_products(M, K, N):
     """csrc/gemm_panel.hip at the block's projection shapes (N, K in {384, 768, 2688}; M = nodes / edges, ragged last
     row tile): C = A W^T + bias against fp64, through the weight image (forward) and through the transposed image
@@ -705,7 +710,8 @@ def test_gemm_panel_fp32_exact_products(M, K, N):
     b = torch.randn(N, generator=gen)
     add = torch.randn(M, N, generator=gen)
     ag, wg, bg = a.to(dev), w.to(dev), b.to(dev)
-    (img_nt, img_tn), = split_weights([wg])
+    from graphgps_amd.gemm import supported as _sup
+    (img_nt, img_tn), = split_weights([wg], tn=_sup(K, N))
     ref = a.double() @ w.double().t()
     scale = float(ref.abs().max())
     # yardstick: the library's own fp32 GEMM on the same operands (an fp32 dot product of K terms carries
@@ -721,13 +727,15 @@ def test_gemm_panel_fp32_exact_products(M, K, N):
     # the transposed image: G [M, N] @ W [N, K]
     g = torch.randn(M, N, generator=gen)
     gref = g.double() @ w.double()
-    gout = gemm_panel(g.to(dev), img_tn, K) if K % 192 == 0 else None
+    from graphgps_amd.gemm import supported
+    tn_ok = supported(K, N)                      # the transposed image serves G [M, N] x W [N, K]: "N" = K, "K" = N
+    gout = gemm_panel(g.to(dev), img_tn, K) if tn_ok else None
     if gout is not None:
         gtol = max(2e-6 * float(gref.abs().max()),
                    1.5 * float((torch.mm(g.to(dev), wg).double().cpu() - gref).abs().max()))
         assert_close(gout, gref, gtol, "G W")
     # in-place accumulation into a column slice of a wider buffer (the block's g_x += g_pq W pattern)
-    if K % 192 == 0:
+    if tn_ok:
         wide = torch.zeros(M, K + 64, device=dev)
         wide[:, :K] = 1.0
         gemm_panel(g.to(dev), img_tn, K, addend=wide[:, :K], out=wide[:, :K])
@@ -847,3 +855,32 @@ def test_dma_kernels_race_screen():
         else:
             for i, ((gw, gb), (fw, fb)) in enumerate(zip(cur, firsts)):
                 assert torch.equal(gw, fw) and torch.equal(gb, fb), f"streaming wgrad problem {i}: run {it} differs"
+
+
+@pytest.mark.parametrize("n,V,d,hub", [(25000, 10030, 256, 0.5), (25000, 10030, 256, 0.0), (77000, 2, 256, 0.0),
+                                       (743, 28, 64, 0.0), (130, 98, 128, 0.9), (1, 7, 64, 0.0), (64, 5, 64, 0.0),
+                                       (65, 3, 256, 0.0)])
+def test_embedding_weight_gradient(n, V, d, hub):
+    """ops.embedding: forward = nn.Embedding lookup (bitwise); weight gradient by the stable-sort + fixed-unit segmented
+    sum (csrc/segment_pool.hip) vs F.embedding's in fp64 -- runs inside one 64-entry unit, runs spanning many units (a
+    token that takes half of the lookups: the ASTNode 'no attribute' id), unit-aligned boundaries; bitwise run to run."""
+    from graphgps_amd.ops import embedding
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(n + V)
+    w = torch.randn(V, d, generator=gen)
+    idx = torch.randint(0, V, (n,), generator=gen)
+    idx[0] = V - 1                                          # the last token is hit, token 0 maybe not
+    if hub > 0:
+        idx[torch.rand(n, generator=gen) < hub] = V // 2
+    g = torch.randn(n, d, generator=gen)
+    wr = w.double().requires_grad_(True)
+    torch.nn.functional.embedding(idx, wr).backward(g.double())
+    grads = []
+    for _ in range(2):
+        wd = w.to(dev).requires_grad_(True)
+        out = embedding(idx.to(dev), wd)
+        assert torch.equal(out.detach().cpu(), w[idx])
+        out.backward(g.to(dev))
+        grads.append(wd.grad.clone())
+    assert torch.equal(grads[0], grads[1])
+    assert_close(grads[0], wr.grad, Tol.GRAD_REL, "g_weight", rel_to_max=True)
