@@ -555,6 +555,7 @@ def main():
     make_batch = batch_dev.shallow_copy
     reducer = exchange = None
     trial = {}
+    h2d_ms = None
     if args.exchange == "bucketed" and use_exchange:
         # hook-driven per-layer buckets overlapped with backward (dp.GradBucketReducer), eager
         reducer = GradBucketReducer(model, force_collective=True)
@@ -605,6 +606,27 @@ def main():
 
         if launch == "auto":                 # untimed trial, eager first: measured BEFORE anything is captured
             trial["eager"] = trial_ms()      # (a live hipGraph slows eager launches down by ~5 % here)
+        # secondary, never `value`: the same step fed from pinned HOST batches through the prefetching DeviceLoader (H2D
+        # copies + graph index staged by a worker thread on a copy stream) -- the PCIe-inclusive rate, i.e. what
+        # train_epoch sees.  Eager launches, so it is measured here, before a captured graph is alive.
+        if not args.no_h2d_leg and world == 1:
+            try:
+                from graphgps_amd.loader import DeviceLoader
+                pinned = batch_cpu.shallow_copy()
+                for k, v in list(pinned.__dict__.items()):
+                    if torch.is_tensor(v):
+                        pinned.__dict__[k] = v.pin_memory()
+                for n_h in (4, min(max(args.steps, 8), 24)):       # a few untimed, then the measured pass
+                    torch.cuda.synchronize()
+                    th = time.perf_counter()
+                    for b in DeviceLoader((pinned.shallow_copy() for _ in range(n_h)), dev):
+                        ts.run_eager(b)
+                    torch.cuda.synchronize()
+                    h2d_ms = (time.perf_counter() - th) / n_h * 1e3
+                log(f"host-batch leg (H2D + index staged on a worker thread / copy stream, eager launch): {h2d_ms:.2f} ms/step")
+            except Exception as exc:       # never let the side measurement take the headline line with it
+                h2d_ms = None
+                log(f"host-batch leg skipped ({type(exc).__name__}: {exc})")
         if launch != "eager":
             try:
                 ts.capture(make_batch)
@@ -669,27 +691,7 @@ def main():
     torch.cuda.synchronize()
     host_enqueue_ms = min(host_ms)
     log(f"timed region done: {ms:.2f} ms/step")
-    # secondary, never `value`: the same step fed from pinned HOST batches through the prefetching
-    # DeviceLoader (H2D copies + graph index on a copy stream, one batch ahead) -- the PCIe-inclusive rate
-    h2d_ms = None
-    if not args.no_h2d_leg and reducer is None and world == 1:     # a 1-GPU side measurement only
-        try:
-            from graphgps_amd.loader import DeviceLoader
-            pinned = batch_cpu.shallow_copy()
-            for k, v in list(pinned.__dict__.items()):
-                if torch.is_tensor(v):
-                    pinned.__dict__[k] = v.pin_memory()
-            for n_h in (3, min(args.steps, 20)):       # 3 untimed, then the measured pass
-                torch.cuda.synchronize()
-                th = time.perf_counter()
-                for b in DeviceLoader((pinned.shallow_copy() for _ in range(n_h)), dev):
-                    ts.run_eager(b)
-                torch.cuda.synchronize()
-                h2d_ms = (time.perf_counter() - th) / n_h * 1e3
-            log(f"host-batch leg (H2D + index on the copy stream, eager launch): {h2d_ms:.2f} ms/step")
-        except Exception as exc:       # never let the side measurement take the headline line with it
-            h2d_ms = None
-            log(f"host-batch leg skipped ({type(exc).__name__}: {exc})")
+    # (the host-batch leg -- pcie_inclusive_ms_per_step -- was measured before the capture, see host_batch_leg above)
 
     if rank == 0:
         N, E = batch_dev.x.shape[0], batch_dev.edge_index.shape[1]

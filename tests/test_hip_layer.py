@@ -319,15 +319,19 @@ def test_code2_model_vs_oracle():
     assert_close(r["hip"][1], r["cpu"][1], 1e-5, "loss")
 
     def grade(res, floor, factor, tag):
+        # every parameter's error relative to ITS OWN largest gradient element, but never below 1 % of the largest
+        # gradient element of the whole model (round 2 divided by max(1, ...): with gradients of O(1e-2) that hid two
+        # orders of magnitude)
         gscale = max(float(q.abs().max()) for q in res["f64"][3].values())
         worst = (0.0, 0.0, "")
         for k, g64 in res["f64"][3].items():
             if k not in res["hip"][3] or k not in res["cpu"][3]:
                 continue
             rg, rc, _, _ = assert_fp32_grade(res["hip"][3][k], res["cpu"][3][k], g64, f"grad {k} ({tag})", floor=floor,
-                                             factor=factor, min_scale=max(1.0, 0.01 * gscale))
+                                             factor=factor, min_scale=0.01 * gscale)
             worst = max(worst, (rg, rc, k))
-        print(f"code2 model, {tag}: largest rms error vs fp64: hip {worst[0]:.2e} (cpu-fp32 oracle {worst[1]:.2e}) on {worst[2]}")
+        print(f"code2 model, {tag}: largest rms error vs fp64 relative to the parameter's own scale (model max {gscale:.2e}): "
+              f"hip {worst[0]:.2e} (cpu-fp32 oracle {worst[1]:.2e}) on {worst[2]}")
         return worst
     grade(r, 1e-4, 5.0, "all 32 graphs")
 

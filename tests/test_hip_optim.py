@@ -285,8 +285,8 @@ def test_train_step_two_graphs_around_rccl_allreduce_world1():
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("depth", [1, 3])
-def test_device_loader_stages_batches_and_index_ahead_of_the_step(depth):
+@pytest.mark.parametrize("depth,background", [(1, True), (3, True), (1, False), (3, False)])
+def test_device_loader_stages_batches_and_index_ahead_of_the_step(depth, background):
     """graphgps_amd.loader.DeviceLoader (replaces the blocking ``batch.to(device)`` of custom_train.py:21-22):
     batches arrive in order, bit-identical to a blocking copy, with the graph index already attached and
     equal to one built directly; consuming them on the step's stream while the next is in flight is safe."""
@@ -297,7 +297,7 @@ def test_device_loader_stages_batches_and_index_ahead_of_the_step(depth):
     host = [model_batch("zinc", 4 + 3 * i, seed=7 + i) for i in range(6)]
     keep = [b.clone() for b in host]
     sums = []
-    for i, b in enumerate(DeviceLoader(host, dev, depth=depth)):
+    for i, b in enumerate(DeviceLoader(host, dev, depth=depth, background=background)):
         ref = keep[i]
         for k in ref.keys():
             v = getattr(ref, k)
@@ -316,3 +316,10 @@ def test_device_loader_stages_batches_and_index_ahead_of_the_step(depth):
     assert len(sums) == len(host)
     for s, ref in zip(sums, keep):
         assert float(s) == float(ref.x.float().sum() + ref.edge_index.float().sum())
+    # a consumer that stops early must not leave the staging thread blocked on its queue
+    import threading
+    for i, b in enumerate(DeviceLoader(host, dev, depth=depth, background=background)):
+        if i == 1:
+            break
+    torch.cuda.synchronize()
+    assert not [t for t in threading.enumerate() if t.name == "gps-device-loader" and t.is_alive()]

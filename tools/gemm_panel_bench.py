@@ -18,7 +18,8 @@ if __name__ == "__main__":
         g.enable_gemm_tuning()
     except Exception as exc:
         print("TunableOp unavailable:", exc)
-    Nn, E, d = 7569, 15348, 384
+    # GEMM_BENCH="d,N,E" (default: the pcqm4m block; "256,25600,76800" = the code2-long layer)
+    d, Nn, E = (int(v) for v in os.environ.get("GEMM_BENCH", "384,7569,15348").split(","))
     shapes = [("pq  x[N,d] W[7d,d]", Nn, d, 7 * d), ("out o[N,d] W[d,d]", Nn, d, d), ("C   e[E,d] W[d,d]", E, d, d),
               ("ff1 h[N,d] W[2d,d]", Nn, d, 2 * d), ("ff2 t[N,2d] W[d,2d]", Nn, 2 * d, d),
               ("dgrad g_pq[N,7d] wcat", Nn, 7 * d, d), ("dgrad g_f1[N,2d] W1", Nn, 2 * d, d)]
