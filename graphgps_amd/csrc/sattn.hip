@@ -201,6 +201,9 @@ __global__ __launch_bounds__(256, 4) void k_sattn_fwd(
     float* __restrict__ out, float* __restrict__ lse) {
   const Item it = item_setup(ptr, B, H);      // host guarantees n <= 64: one block per graph
   if (!it.live) return;
+  // the block form is selected by a HOST hint (the batch's longest graph); a stale or wrong hint must not produce a silently
+  // truncated result (only the first 64 rows of the graph would be touched): abort the launch loudly instead
+  if (it.n > 64) __builtin_trap();
   seed = gps::salted_seed(seed, salt);
   switch ((it.n + 15) >> 4) {
     case 1: sattn_fwd_body<DH, DROP, 1>(it, qkv, ld64, N, H, scale, thr16, inv_keep, seed, out, lse); break;
@@ -404,6 +407,9 @@ __global__ __launch_bounds__(256, 2) void k_sattn_bwd(
   __shared__ __attribute__((aligned(16))) float sT[4][2 * 16 * 20];   // per-wave transpose scratch (P_drop | dS)
   const Item it = item_setup(ptr, B, H);      // host guarantees n <= 64: one block per graph
   if (!it.live) return;
+  // the block form is selected by a HOST hint (the batch's longest graph); a stale or wrong hint must not produce a silently
+  // truncated result (only the first 64 rows of the graph would be touched): abort the launch loudly instead
+  if (it.n > 64) __builtin_trap();
   seed = gps::salted_seed(seed, salt);
   float* tP = &sT[threadIdx.x >> 6][0];
 #define SA_BODY(NTV) sattn_bwd_body<DH, DROP, NTV>(it, tP, d_out, qkv, ld64, out, lse, N, H, scale, thr16, inv_keep, \

@@ -165,6 +165,116 @@ class TrainStep:
             self._g_up.replay()
         return self._static_loss
 
+    # -- hipGraph replay for loader batches: one captured step per batch SHAPE -------------------------------
+    def step_cached(self, batch, max_graphs: int = 8):
+        """One optimisation step on a DEVICE batch from a loader (``custom_train.py:21-39``), replayed from a hipGraph
+        whenever a step of this batch's shape has been captured: returns ``(loss, pred_score, true)`` (fresh tensors).
+
+        A captured step is tied to the SHAPES of its inputs, not their contents: the graph index, the encoders and every
+        kernel are part of the capture and read the batch tensors where they sat at capture time.  So each distinct shape
+        -- (nodes, edges, graphs, the shapes of every other tensor of the batch, and whether the longest graph allows the
+        block-form attention kernels) -- gets its own static input buffers + captured step, kept in an LRU of
+        ``max_graphs`` entries over ONE shared memory pool; a batch whose shape has an entry is copied into the static
+        buffers (one multi-tensor copy) and replayed, the first batch of a new shape runs eagerly and the second one
+        captures.  Loaders that emit a few fixed shapes (bucketed / padded datasets, the synthetic benches) replay every
+        step; a loader whose shapes never repeat simply stays on the eager path.  Needs ``optim.FlatAdamW``."""
+        if not self.flat or (self.exchange is not None and self.exchange.active):
+            return self._eager_triplet(batch)
+        key = self._shape_key(batch)
+        cache = self.__dict__.setdefault("_shape_cache", {})
+        ent = cache.get(key)
+        if ent is None:
+            seen = self.__dict__.setdefault("_shape_seen", set())
+            if key not in seen:              # first sight of this shape: run it eagerly, capture if it comes back
+                seen.add(key)
+                return self._eager_triplet(batch)
+            ent = self._capture_shape(batch)
+            if ent is None:                  # capture is an optimisation, never a requirement
+                return self._eager_triplet(batch)
+            cache[key] = ent
+            while len(cache) > max_graphs:   # LRU: dicts keep insertion order
+                cache.pop(next(iter(cache)))
+        else:
+            cache[key] = cache.pop(key)      # most recently used last
+            torch._foreach_copy_(ent["dst"], [getattr(batch, k) for k in ent["keys"]])
+        self.opt.sync_hyper()
+        ent["graph"].replay()
+        loss, pred, true = ent["out"]
+        return loss.clone(), _cloned(pred), _cloned(true)
+
+    def _eager_triplet(self, batch):
+        loss, pred_score, true = self.forward_backward(batch)
+        self.reduce()
+        self.update()
+        return loss, pred_score, true
+
+    @staticmethod
+    def _tensor_keys(batch):
+        return sorted(k for k in DeviceLoader._keys(batch) if torch.is_tensor(getattr(batch, k, None)))
+
+    def _shape_key(self, batch):
+        meta = vars(batch).get("_gps_meta") or {}
+        nmax = int(meta.get("nmax", 0))
+        return (tuple((k, tuple(getattr(batch, k).shape), str(getattr(batch, k).dtype)) for k in self._tensor_keys(batch)),
+                0 < nmax <= 64)
+
+    def _capture_shape(self, batch):
+        """Static copies of the batch's tensors + the step captured over them (NOT executed: the caller replays)."""
+        import copy
+        dev = self.opt.arena.device
+        if self.salt is None and _has_dropout(self.model):
+            from .ops import enable_dropout_salt
+            self.salt = enable_dropout_salt(dev)
+        keys = self._tensor_keys(batch)
+        static = DeviceLoader._host_copy(batch)
+        vars(static).pop("_gps_index", None)
+        dst = []
+        for k in keys:
+            t = getattr(batch, k).clone()
+            setattr(static, k, t)
+            dst.append(t)
+        if "_gps_meta" in vars(batch):
+            vars(static)["_gps_meta"] = dict(vars(batch)["_gps_meta"])
+        pool = self.__dict__.get("_shape_pool")
+        if pool is None:
+            pool = self.__dict__["_shape_pool"] = torch.cuda.graph_pool_handle()
+
+        def fresh():                         # a new container over the static tensors per trace (the model re-assigns
+            b = DeviceLoader._host_copy(static)   # batch.x / batch.edge_attr), without a cached graph index
+            vars(b).pop("_gps_index", None)
+            return b
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        tick = torch.zeros(1, device=dev) if _os.environ.get("GPS_CAPTURE_TICK", "1") != "0" else None
+        try:
+            self.opt.zero_grad()
+            self.opt.sync_hyper()
+            with torch.cuda.graph(graph, pool=pool, capture_error_mode="thread_local"):
+                if tick is not None:         # see capture(): a purely linear graph of the step faults at replay
+                    cur = torch.cuda.current_stream(dev)
+                    tside = torch.cuda.Stream(device=dev)
+                    tside.wait_stream(cur)
+                    with torch.cuda.stream(tside):
+                        tick.add_(1.0)
+                out = self.forward_backward(fresh())
+                self.update()
+                if tick is not None:
+                    torch.cuda.current_stream(dev).wait_stream(tside)
+        except Exception:
+            return None
+        torch.cuda.synchronize(dev)
+        return {"graph": graph, "keys": keys, "dst": dst, "out": out, "tick": tick, "static": static}
+
+
+def _cloned(obj):
+    if torch.is_tensor(obj):
+        return obj.detach().clone()
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_cloned(o) for o in obj)
+    if isinstance(obj, dict):
+        return {k: _cloned(v) for k, v in obj.items()}
+    return obj
+
 
 LOGGER_FLUSH_EVERY = 16     # iterations between device->host reads for the logger (one sync per flush)
 
@@ -232,13 +342,19 @@ def train_epoch(logger, loader, model, optimizer, scheduler, batch_accumulation,
     n_iters = len(loader)
     log = _DeferredLogger(logger)
     # next batch's H2D copies + graph index run on a copy stream behind the current step
+    # without gradient accumulation a step is one self-contained unit: replay it from a hipGraph whenever a step of
+    # the batch's shape has been captured (TrainStep.step_cached; GPS_TRAIN_REPLAY=0 keeps every step eager)
+    cached = flat and batch_accumulation == 1 and device.type == "cuda" and _os.environ.get("GPS_TRAIN_REPLAY", "1") != "0"
     for it, batch in enumerate(DeviceLoader(loader, device)):
         batch.split = 'train'
-        loss, pred_score, true = step.forward_backward(batch, zero=False)
-        if ((it + 1) % batch_accumulation == 0) or (it + 1 == n_iters):
-            step.reduce()
-            step.update()
-            optimizer.zero_grad()
+        if cached:
+            loss, pred_score, true = step.step_cached(batch)
+        else:
+            loss, pred_score, true = step.forward_backward(batch, zero=False)
+            if ((it + 1) % batch_accumulation == 0) or (it + 1 == n_iters):
+                step.reduce()
+                step.update()
+                optimizer.zero_grad()
         log.add(true, pred_score, loss, scheduler.get_last_lr()[0])
     log.flush()
 

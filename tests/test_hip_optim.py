@@ -151,6 +151,58 @@ def test_train_step_hipgraph_replay_equals_eager():
         assert abs(a - c) <= 1e-6 * max(abs(a), 1.0), runs
 
 
+def test_step_cached_replays_across_batch_shapes_like_eager():
+    """TrainStep.step_cached (what train_epoch runs): loader batches of THREE different shapes in rotation, every step
+    after a shape's second appearance replayed from that shape's captured hipGraph (static input buffers refreshed by one
+    multi-tensor copy) -- losses, predictions and the final weights equal an all-eager run of the same sequence; a batch
+    of a fourth shape in between falls back to eager; the LRU keeps at most ``max_graphs`` captures."""
+    from graphgps_amd.loader import DeviceLoader
+    from graphgps_amd.loss.losses import compute_loss
+    from graphgps_amd.optim import FlatAdamW
+    from graphgps_amd.synthetic import model_batch
+    from graphgps_amd.train import TrainStep
+    dev = torch.device("cuda:0")
+    # 3 shapes x 4 rounds with DIFFERENT contents each time (same graph sizes per shape: seed -> structure is fixed per
+    # (num_graphs, seed), so vary the features instead), one odd shape in the middle
+    base = [model_batch("zinc", n, seed=50 + n) for n in (8, 13, 21)]
+    seq = []
+    gen = torch.Generator().manual_seed(3)
+    for rnd in range(4):
+        for b in base:
+            c = b.clone()
+            c.y = torch.randn(c.y.shape, generator=gen)
+            c.pestat_RWSE = torch.rand(c.pestat_RWSE.shape, generator=gen)
+            perm = torch.randperm(c.x.shape[0], generator=gen)
+            c.x = c.x[perm % c.x.shape[0]].contiguous()          # other node types, same shape
+            seq.append(c)
+        if rnd == 1:
+            seq.append(model_batch("zinc", 5, seed=99))
+    results = {}
+    for mode in ("eager", "cached"):
+        model = _zinc_model(dev)
+        opt = FlatAdamW(model.parameters(), lr=1e-3, weight_decay=0.0, max_grad_norm=1.0)
+        ts = TrainStep(model, opt, loss_fn=compute_loss)
+        losses, preds = [], []
+        for b in DeviceLoader([q.clone() for q in seq], dev):
+            if mode == "cached":
+                loss, pred, true = ts.step_cached(b, max_graphs=2)
+            else:
+                loss, pred, true = ts._eager_triplet(b)
+            losses.append(float(loss))
+            preds.append(pred.detach().float().cpu().clone())
+        if mode == "cached":
+            cache = ts.__dict__["_shape_cache"]
+            assert 1 <= len(cache) <= 2, len(cache)              # 3 shapes seen twice or more, LRU of 2
+        results[mode] = (losses, preds, torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu())
+    le, lc = results["eager"][0], results["cached"][0]
+    assert le[0] > le[-3] or le[1] > le[-2]                      # it trains
+    for i, (a, c) in enumerate(zip(le, lc)):
+        assert abs(a - c) <= 2e-6 * max(abs(a), 1.0), (i, a, c)
+    for a, c in zip(results["eager"][1], results["cached"][1]):
+        assert_close(c, a, 1e-5, "predictions, replayed vs eager")
+    assert_close(results["cached"][2], results["eager"][2], 1e-6, "weights after the sequence")
+
+
 def test_train_epoch_mirrors_reference_loop():
     """graphgps_amd.train.train_epoch (custom_train.py:16-47): batch accumulation, clip inside the fused
     optimizer step, scheduler lr passed through, logger fed once per iteration (after the epoch, no
