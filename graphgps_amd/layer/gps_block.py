@@ -192,8 +192,15 @@ class _Fork:
     def join(self, *tensors):
         if self.enabled:
             self.cur.wait_stream(self.br)
-            for t in tensors:
-                t.record_stream(self.cur)
+            # Eagerly the caching allocator has to be told that the joined stream reads these blocks.  While CAPTURING they
+            # come from the graph's private pool, where a block only ever returns to the free list of the stream that
+            # allocated it -- the branch stream, whose next use is ordered behind the next fork -- so the hand-over is
+            # implied; and record_stream inside a capture makes the allocator record pooled events at capture_end, which on
+            # this runtime (ROCm 7.0.2 under torch 2.10) segfaults in hipStreamEndCapture whenever such an event was ever
+            # recorded on another stream before (tools/capture_probe.py: any eager step on loader-staged tensors).
+            if _os.environ.get("GPS_FORK_RECORD_STREAM", "0") == "1" or not torch.cuda.is_current_stream_capturing():
+                for t in tensors:
+                    t.record_stream(self.cur)
 
 
 _bn_desc = _norm.bn_desc

@@ -19,7 +19,14 @@ from typing import Iterable, Iterator
 
 import torch
 
+import os
+
 from .ops import graph_index_of
+
+# Held while a batch is staged (worker thread) and while a step is captured into a hipGraph (train.TrainStep): stream
+# capture on one thread and allocations / copies / launches on another must not interleave on this runtime.
+STAGE_LOCK = threading.RLock()
+_BACKGROUND_DEFAULT = os.environ.get("GPS_LOADER_BACKGROUND", "1") != "0"
 
 
 class DeviceLoader:
@@ -32,12 +39,12 @@ class DeviceLoader:
     the launching thread is a millisecond of idle GPU).  On a CPU ``device`` this is a pass-through: the product path
     has no CPU kernels, and the reference's loop is what the oracle runs."""
 
-    def __init__(self, loader: Iterable, device, depth: int = 2, build_index: bool = True, background: bool = True):
+    def __init__(self, loader: Iterable, device, depth: int = 2, build_index: bool = True, background: bool = None):
         self.loader = loader
         self.device = torch.device(device)
         self.depth = max(int(depth), 1)
         self.build_index = build_index
-        self.background = background
+        self.background = _BACKGROUND_DEFAULT if background is None else bool(background)
 
     def __len__(self) -> int:
         return len(self.loader)
@@ -90,6 +97,8 @@ class DeviceLoader:
     def _hand_over(cls, batch, stream) -> None:
         """The tensors were allocated on the copy stream: tell the caching allocator the consumer's
         stream uses them, so their blocks are not recycled while the step still reads them."""
+        if os.environ.get("GPS_LOADER_RECORD_STREAM", "1") == "0":
+            return
         for k in cls._keys(batch):
             v = getattr(batch, k, None)
             if torch.is_tensor(v) and v.is_cuda:
@@ -149,7 +158,9 @@ class DeviceLoader:
             try:
                 torch.cuda.set_device(self.device)
                 for host in self.loader:
-                    if not put(self._stage(host, copy_stream)):
+                    with STAGE_LOCK:
+                        item = self._stage(host, copy_stream)
+                    if not put(item):
                         return
                 put(END)
             except BaseException as exc:       # surfaced on the consumer's thread

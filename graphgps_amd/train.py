@@ -24,7 +24,7 @@ import os as _os
 import torch
 
 from .graphgym.config import cfg
-from .loader import DeviceLoader
+from .loader import STAGE_LOCK, DeviceLoader
 from .loss.losses import train_loss
 from .optim import FlatAdamW
 
@@ -77,7 +77,18 @@ class TrainStep:
         loss.backward()
         if self.flat:
             self.opt.pack_grads()
-        return loss, pred_score, true
+        # Nothing that leaves this function may keep the step's autograd graph alive.  The model re-assigns ``batch.x`` /
+        # ``batch.edge_attr`` to graph-attached tensors (gps_layer.py:174,231), so a batch object the caller still holds --
+        # a loop variable is enough -- pins every node of the graph, the parameters' AccumulateGrad nodes included, and
+        # those remember the stream they were created on: the DEFAULT stream for an eager step.  A later capture of the
+        # step then finds them, autograd routes the gradient accumulation through the default stream, the null stream
+        # joins the capture and hipStreamEndCapture segfaults (rocgdb: hip::Stream::EndCapture, recursing into the parallel
+        # capture stream; tools/capture_probe.py reproduces it with one line: keep the last eager batch alive).
+        for k in DeviceLoader._keys(batch):
+            v = getattr(batch, k, None)
+            if torch.is_tensor(v) and v.grad_fn is not None:
+                setattr(batch, k, v.detach())
+        return loss.detach(), _detached(pred_score), _detached(true)
 
     def reduce(self) -> None:
         if self.exchange is not None:
@@ -122,6 +133,8 @@ class TrainStep:
                 self.update()
         torch.cuda.current_stream(dev).wait_stream(side)
         torch.cuda.synchronize(dev)
+        if _os.environ.get("GPS_CAPTURE_EMPTY_CACHE", "0") == "1":
+            torch.cuda.empty_cache()
         self.opt.zero_grad()
         self.opt.sync_hyper()
         split = self.exchange is not None and self.exchange.active
@@ -134,7 +147,7 @@ class TrainStep:
         # The tick tensor is written by EVERY replay, so it must live exactly as long as the graphs do (a local would
         # hand its block back to the caching allocator and each replay would then add 1.0f into whoever got it next).
         tick = torch.zeros(1, device=dev) if _os.environ.get("GPS_CAPTURE_TICK", "1") != "0" else None
-        with torch.cuda.graph(g_fb, capture_error_mode="thread_local"):
+        with STAGE_LOCK, torch.cuda.graph(g_fb, capture_error_mode=_os.environ.get("GPS_CAPTURE_MODE", "thread_local")):
             if tick is not None:
                 cur = torch.cuda.current_stream(dev)
                 tside = torch.cuda.Stream(device=dev)
@@ -243,23 +256,24 @@ class TrainStep:
             b = DeviceLoader._host_copy(static)   # batch.x / batch.edge_attr), without a cached graph index
             vars(b).pop("_gps_index", None)
             return b
-        torch.cuda.synchronize(dev)
         graph = torch.cuda.CUDAGraph()
         tick = torch.zeros(1, device=dev) if _os.environ.get("GPS_CAPTURE_TICK", "1") != "0" else None
         try:
-            self.opt.zero_grad()
-            self.opt.sync_hyper()
-            with torch.cuda.graph(graph, pool=pool, capture_error_mode="thread_local"):
-                if tick is not None:         # see capture(): a purely linear graph of the step faults at replay
-                    cur = torch.cuda.current_stream(dev)
-                    tside = torch.cuda.Stream(device=dev)
-                    tside.wait_stream(cur)
-                    with torch.cuda.stream(tside):
-                        tick.add_(1.0)
-                out = self.forward_backward(fresh())
-                self.update()
-                if tick is not None:
-                    torch.cuda.current_stream(dev).wait_stream(tside)
+            with STAGE_LOCK:                 # no staging thread allocates / copies / launches while this thread captures
+                torch.cuda.synchronize(dev)
+                self.opt.zero_grad()
+                self.opt.sync_hyper()
+                with torch.cuda.graph(graph, pool=pool, capture_error_mode="thread_local"):
+                    if tick is not None:     # see capture(): a purely linear graph of the step faults at replay
+                        cur = torch.cuda.current_stream(dev)
+                        tside = torch.cuda.Stream(device=dev)
+                        tside.wait_stream(cur)
+                        with torch.cuda.stream(tside):
+                            tick.add_(1.0)
+                    out = self.forward_backward(fresh())
+                    self.update()
+                    if tick is not None:
+                        torch.cuda.current_stream(dev).wait_stream(tside)
         except Exception:
             return None
         torch.cuda.synchronize(dev)
