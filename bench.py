@@ -631,6 +631,20 @@ def main():
             try:
                 ts.capture(make_batch)
                 log("step captured: " + ts.mode)
+                if os.environ.get("GPS_BENCH_SNAPSHOT"):     # who owns which page (the linear-capture fault)
+                    torch.cuda.synchronize()
+                    segs = [{"address": q["address"], "size": q["total_size"], "type": q.get("segment_type"),
+                             "pool": str(q.get("segment_pool_id")),
+                             "blocks": [{"address": b_.get("address"), "size": b_["size"], "state": b_["state"]}
+                                        for b_ in q.get("blocks", [])][:2000]}
+                            for q in torch.cuda.memory_snapshot()]
+                    maps = []
+                    with open("/proc/self/maps") as f:
+                        for line in f:
+                            p_ = line.split()
+                            lo, hi = (int(x, 16) for x in p_[0].split("-"))
+                            maps.append({"lo": lo, "hi": hi, "perm": p_[1], "name": p_[-1] if len(p_) > 5 else ""})
+                    json.dump({"segments": segs, "maps": maps}, open(os.environ["GPS_BENCH_SNAPSHOT"], "w"))
             except Exception as exc:         # capture is an optimisation, never a requirement
                 log(f"hipGraph capture failed ({type(exc).__name__}: {exc}); running eagerly")
                 ts = TrainStep(model, opt, loss_fn=compute_loss, exchange=exchange, salt=salt)

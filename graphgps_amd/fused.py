@@ -183,12 +183,15 @@ def _queue_join(dev: torch.device) -> None:
         join_side_stream(dev)
 
 
-def _param_grads(g: torch.Tensor, x: torch.Tensor, need_w: bool, need_b: bool, params=()):
+def _param_grads(g: torch.Tensor, x: torch.Tensor, need_w: bool, need_b: bool, params=(), targets=None):
     """(g^T x, column sums of g): rocBLAS GEMM + the library's two-stage colsum.  ``params`` are
     the leaf parameters the results go to: if any already holds a ``.grad`` autograd will
     accumulate into it on the main stream right after this function returns, so the side stream
-    is only used when they are all empty (the zero_grad(set_to_none=True) regime)."""
+    is only used when they are all empty (the zero_grad(set_to_none=True) regime).  ``targets`` = (weight, bias) the
+    results belong to (possibly zero-copy stacks): in that regime, and when they live in an optimizer arena, the kernel
+    writes straight into their gradient slots (optim.grad_slot) and the per-step gradient packing has nothing to copy."""
     dev = g.device
+    accumulating = any(p is not None and p.grad is not None for p in params)
 
     def compute():
         L = _lib.load()
@@ -197,8 +200,15 @@ def _param_grads(g: torch.Tensor, x: torch.Tensor, need_w: bool, need_b: bool, p
         st = current_stream(dev)
         if need_w and d % 4 == 0 and k % 4 == 0 and g.stride(0) % 4 == 0 and x.stride(0) % 4 == 0:
             # split-K MFMA kernel: weight AND bias gradient in one pass (csrc/wgrad.hip)
-            g_w = torch.empty(d, k, dtype=torch.float32, device=dev)
-            g_b = torch.empty(d, dtype=torch.float32, device=dev) if need_b else None
+            g_w = g_b = None
+            if targets is not None and not accumulating:
+                from .optim import grad_slot
+                g_w = grad_slot(targets[0]) if targets[0] is not None else None
+                g_b = grad_slot(targets[1]) if need_b and targets[1] is not None else None
+            if g_w is None or g_w.shape != (d, k):
+                g_w = torch.empty(d, k, dtype=torch.float32, device=dev)
+            if need_b and (g_b is None or g_b.shape != (d,)):
+                g_b = torch.empty(d, dtype=torch.float32, device=dev)
             ws = torch.empty(max(L.gps_wgrad_workspace_floats(R, d, k), 4), dtype=torch.float32,
                              device=dev)
             check(L.gps_wgrad(ptr(g), g.stride(0), ptr(x), x.stride(0), R, d, k, ptr(g_w), ptr(g_b),
@@ -212,7 +222,7 @@ def _param_grads(g: torch.Tensor, x: torch.Tensor, need_w: bool, need_b: bool, p
             check(L.gps_colsum(ptr(g), R, d, ptr(g_b), ptr(ws), st), "gps_colsum")
         return g_w, g_b
 
-    if not _SIDE_ENABLED or any(p is not None and p.grad is not None for p in params):
+    if not _SIDE_ENABLED or accumulating:
         return compute()
     cur, side = torch.cuda.current_stream(dev), _side_stream(dev)
     side.wait_stream(cur)                 # g and x are complete
@@ -276,7 +286,7 @@ class _Linear(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         g = _f32c(g, "g")
         g_w, g_b = _param_grads(g, x, ctx.needs_input_grad[1],
-                                ctx.has_bias and ctx.needs_input_grad[2], ctx.params)
+                                ctx.has_bias and ctx.needs_input_grad[2], ctx.params, targets=ctx.params)
         g_x = _ring_input_grad(ctx, g, weight) if ctx.needs_input_grad[0] else None
         return g_x, g_w, g_b
 
@@ -299,6 +309,7 @@ class _GroupLinear(torch.autograd.Function):
         ctx.save_for_backward(x, wcat)
         ctx.sizes, ctx.has_bias = sizes, bcat is not None
         ctx.params = params
+        ctx.bcat = bcat
         ctx.img_tn = None
         if _ring_ok(x, wcat):
             return _ring_forward(ctx, x, wcat, bcat, ctx.needs_input_grad[0])
@@ -308,7 +319,7 @@ class _GroupLinear(torch.autograd.Function):
     def backward(ctx, g):
         x, wcat = ctx.saved_tensors
         g = _f32c(g, "g")
-        g_w, g_b = _param_grads(g, x, True, ctx.has_bias, ctx.params)
+        g_w, g_b = _param_grads(g, x, True, ctx.has_bias, ctx.params, targets=(wcat, ctx.bcat))
         g_x = _ring_input_grad(ctx, g, wcat) if ctx.needs_input_grad[0] else None
         outs, off = [], 0
         for n in ctx.sizes:

@@ -35,9 +35,11 @@ from ..ops import GraphIndex, draw_dropout_seed
 _E = torch.empty
 _BY_REF = _ctypes.byref
 
-# A/B switches (default: everything fused).  GPS_GG_STATS=0: statistics of x~ / e^ by a row pass instead of the GatedGCN
-# forward; GPS_GEMM_STATS=0: za / z2 and their statistics by row tasks instead of the ring GEMM epilogue.
-_GG_STATS = _os.environ.get("GPS_GG_STATS", "1") != "0"
+# A/B switches.  GPS_GG_STATS=1: the batch statistics of x~ / e^ out of the GatedGCN forward itself (one launch fewer, 35 MB
+# less traffic -- and the kernel's in-launch reduction tail: 26 -> 47 us per launch, the step unchanged at 9.95 vs 9.91 ms;
+# default 0, a statistics-only row pass, which keeps the HBM-bound kernel at its roofline); GPS_GEMM_STATS=0: za / z2 and
+# their statistics by row tasks instead of the ring GEMM epilogue (default 1: -0.3 ms per step).
+_GG_STATS = _os.environ.get("GPS_GG_STATS", "0") != "0"
 _GEMM_STATS = _os.environ.get("GPS_GEMM_STATS", "1") != "0"
 # launch sites of one layer that own arrival counters (norm.SyncArena.site): sites that may be in flight together differ
 _S_GG, _S_AO, _S_XE, _S_MID, _S_Z2, _S_B1, _S_B3, _S_B4 = range(8)
@@ -110,21 +112,32 @@ def _accumulating(params) -> bool:
     return False
 
 
-def _grouped_param_grads(L, pairs, params=()):
+def _grouped_param_grads(L, pairs, params=(), targets=None):
     """[(g, x), ...] -> [(g^T x, colsum(g)), ...]: all weight/bias gradients of the block in ONE
     split-K MFMA launch + one reduce launch (csrc/wgrad.hip grouped form) on the side stream
-    (main stream when ``params`` already hold gradients: see ``_accumulating``)."""
+    (main stream when ``params`` already hold gradients: see ``_accumulating``).
+    ``targets`` = [(weight, bias), ...] the (stacked) parameters the results belong to: when they live in an optimizer
+    arena and nothing is being accumulated the kernel writes straight into their gradient slots (optim.grad_slot)."""
     dev = pairs[0][0].device
     n = len(pairs)
+    direct = targets is not None and not _accumulating(params)
 
     def compute():
+        from ..optim import grad_slot
         probs = (_lib.WgradProblem * n)()
         outs = []
-        for q, (g, x) in zip(probs, pairs):
+        for i, (q, (g, x)) in enumerate(zip(probs, pairs)):
             R, M = g.shape
             Nn = x.shape[1]
-            g_w = _E(M, Nn, dtype=g.dtype, device=dev)
-            g_b = _E(M, dtype=g.dtype, device=dev)
+            g_w = g_b = None
+            if direct:
+                tw, tb = targets[i]
+                g_w = grad_slot(tw) if tw is not None else None
+                g_b = grad_slot(tb) if tb is not None else None
+            if g_w is None or g_w.shape != (M, Nn):
+                g_w = _E(M, Nn, dtype=g.dtype, device=dev)
+            if g_b is None or g_b.shape != (M,):
+                g_b = _E(M, dtype=g.dtype, device=dev)
             q.g, q.x, q.gw, q.gb = g.data_ptr(), x.data_ptr(), g_w.data_ptr(), g_b.data_ptr()
             q.ldg, q.ldx, q.R, q.M, q.Nn = g.stride(0), x.stride(0), R, M, Nn
             outs.append((g_w, g_b))
@@ -147,15 +160,15 @@ def _grouped_param_grads(L, pairs, params=()):
 
 _GROUPED_WGRAD = _os.environ.get("GPS_WGRAD_GROUPED", "1") != "0"
 
-# The attention half (attention core + out-projection GEMM) and the local half (C GEMM + GatedGCN) of a
-# block only meet at the norm stage, so the attention half can run on its own HIP stream: its latency-bound
-# kernels fill the gaps of the local half's HBM/MFMA-bound ones.  Under hipGraph replay this is a fork/join
-# in the graph (no host cost; measured 13.18 -> 13.00 ms/step); launched eagerly the extra stream switches
-# cost more host time than the overlap returns (13.3 -> 13.7..16.7 ms), so the fork is only taken while
-# the step is being CAPTURED.  GPS_BRANCH_STREAM=0 disables it, =2 forces it in eager mode too.
-# (With =0 the captured PCQM4M step is a one-stream capture; train.py:TrainStep.capture adds a trivial forked node so
-# that the resulting purely linear hipGraph does not trip the runtime -- DESIGN.md section 7.)
-_BRANCH = _os.environ.get("GPS_BRANCH_STREAM", "1")
+# The attention half (attention core + out-projection GEMM) and the local half (GatedGCN core) of a block only meet at
+# the norm stage, so the attention half CAN run on its own HIP stream (a fork / join inside a captured graph).  Round 1-2
+# took that fork while capturing.  Round 3 measured it again on the fused step (tools/runs/gpu_r3q.sh, same box, ms per
+# step): forked 9.92, serial 9.95 -- nothing, because what overlaps does not run concurrently: a ring-GEMM workgroup owns
+# its CU's whole LDS, so the GatedGCN workgroups (40-140 KB of LDS) only get the CUs the GEMM has not taken and both
+# kernels stretch (GatedGCN forward 26 -> 71 us, backward 52 -> 89 us, block attention backward 54 -> 70 us) while every
+# fork and join costs ~10 us of queue latency in the replayed graph.  Default since round 3: ONE stream (= 0); the
+# per-kernel durations inside the step are then the kernels' own.  GPS_BRANCH_STREAM=1 forks while capturing, =2 always.
+_BRANCH = _os.environ.get("GPS_BRANCH_STREAM", "0")
 _branch_streams = {}
 
 
@@ -354,8 +367,14 @@ class _GPSBlock(torch.autograd.Function):
         bna = _bn_desc(layer.norm1_attn, stats[6], stats[7])
         bn2 = _bn_desc(layer.norm2, stats[8], stats[9])
         sync = _norm.sync_arena(layer, dev)
-        gpar = _E(10, d, **f32)              # (g_gamma, g_beta) of the five norms
+        gpar = _E(10, d, **f32)              # (g_gamma, g_beta) of the five norms ...
         g_bxw, g_bxb, g_bew, g_beb, g_nlw, g_nlb, g_naw, g_nab, g_n2w, g_n2b = gpar.unbind(0)
+        if not _accumulating(block_params(layer)):      # ... or their slots in the optimizer's gradient arena
+            from ..optim import grad_slot
+            bns = (lm.bn_node_x, lm.bn_edge_e, layer.norm1_local, layer.norm1_attn, layer.norm2)
+            slots = [grad_slot(q) for bn in bns for q in (bn.weight, bn.bias)]
+            if all(q is not None for q in slots):
+                g_bxw, g_bxb, g_bew, g_beb, g_nlw, g_nlb, g_naw, g_nab, g_n2w, g_n2b = slots
 
         # norm2 <- z2 = h + drop(f2):  g_z2 and g_f2 = dropmask(g_z2);  bn_edge_e <- e^ (its output gradient g_e1 is an
         # input of this node, so its column sums and its apply ride along): ONE partial launch, ONE apply launch
@@ -410,12 +429,14 @@ class _GPSBlock(torch.autograd.Function):
                                  ptr(g_ce), G, G + fs, G + 2 * fs, G + 3 * fs, ldp, None, st),
               "gps_gatedgcn_bwd")
         fork.join()
-        wcat, _ = layer._xgroup._stacked()
+        wcat, bcat = layer._xgroup._stacked()
         pairs = [(g_pq, x), (g_ce, e), (g_ao, o), (g_f1, h), (g_f2, t)]
         leaves = block_params(layer)
         if _GROUPED_WGRAD:
+            targets = [(wcat, bcat), (lm.C.weight, lm.C.bias), (sa.out_proj.weight, sa.out_proj.bias),
+                       (layer.ff_linear1.weight, layer.ff_linear1.bias), (layer.ff_linear2.weight, layer.ff_linear2.bias)]
             ((g_wcat, g_bcat), (g_wc, g_bc), (g_wo, g_bo), (g_w1, g_b1), (g_w2, g_b2)) = \
-                _grouped_param_grads(L, pairs, leaves)
+                _grouped_param_grads(L, pairs, leaves, targets)
         else:
             ((g_wcat, g_bcat), (g_wc, g_bc), (g_wo, g_bo), (g_w1, g_b1), (g_w2, g_b2)) = \
                 [_K.param_grads(L, g, a, leaves) for g, a in pairs]

@@ -20,6 +20,8 @@ from __future__ import annotations
 
 from typing import Iterable, List, Optional
 
+import weakref
+
 import torch
 import torch.nn as nn
 
@@ -27,6 +29,24 @@ from . import lib as _lib
 from .lib import check, current_stream, ptr
 
 _ALIGN = 64          # floats (256 B): start of every storage block in the arena
+
+
+_ARENAS = {}      # data_ptr of an arena's parameter storage -> weakref(arena): lets the backward kernels find a gradient slot
+
+
+def grad_slot(t: torch.Tensor):
+    """The view of the gradient arena that mirrors ``t`` -- a parameter, or a zero-copy stack of adjacent parameters
+    (fused.LinearGroup) -- when ``t`` lives in a ParamArena; else None.  A weight-gradient kernel that writes there has
+    produced ``p.grad`` in place: autograd adopts the returned view and ``pack_grads`` finds nothing left to copy (the
+    per-step multi-tensor copy of all 77.7 MB of gradients was 0.16 ms of the PCQM4M step)."""
+    ref = _ARENAS.get(t.untyped_storage().data_ptr())
+    arena = ref() if ref is not None else None
+    if arena is None or not t.is_contiguous() or arena.flat_p.untyped_storage().data_ptr() != t.untyped_storage().data_ptr():
+        return None
+    off = t.storage_offset()
+    if off < 0 or off + t.numel() > arena.flat_g.numel():
+        return None
+    return arena.flat_g[off:off + t.numel()].view(t.shape)
 
 
 class ParamArena:
@@ -112,6 +132,7 @@ class ParamArena:
                 p.data = flat_p[offsets[i]:offsets[i] + p.numel()].view(p.shape)
         self.flat_p = flat_p
         self.flat_g = torch.zeros_like(flat_p)
+        _ARENAS[flat_p.untyped_storage().data_ptr()] = weakref.ref(self)
         self.offsets = offsets
         self.grad_views = [self.flat_g[o:o + p.numel()].view(p.shape)
                            for o, p in zip(offsets, self.params)]
