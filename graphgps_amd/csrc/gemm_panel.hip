@@ -85,6 +85,7 @@ struct SplitDesc {
   uint16_t* nt;         // image of B[n = row][k = col]  (forward: C = A W^T), or nullptr
   uint16_t* tn;         // image of B[n = col][k = row]  (input gradient: C = G W), or nullptr
   int block_begin;
+  int nt_n, nt_k, tn_n, tn_k;   // padded image geometry (rows of the image, contraction length): see rg_npad / rg_kpad
 };
 constexpr int kMaxSplit = 8;
 struct SplitGroup {
@@ -124,10 +125,12 @@ __global__ __launch_bounds__(256) void k_split_weights(const SplitGroup G) {
     uint32_t h[4], m[4], l[4];
 #pragma unroll
     for (int j = 0; j < 4; ++j) split1(v[j], h[j], m[j], l[j]);
-    if (D.nt && ok) {       // B[n = row][k = col..col+3]: 4 consecutive k of one row -> one 8-byte store per piece
-      *reinterpret_cast<u32x2*>(D.nt + img_index(0, row, col, D.rows, D.cols)) = (u32x2){(h[0] >> 16) | h[1], (h[2] >> 16) | h[3]};
-      *reinterpret_cast<u32x2*>(D.nt + img_index(1, row, col, D.rows, D.cols)) = (u32x2){(m[0] >> 16) | m[1], (m[2] >> 16) | m[3]};
-      *reinterpret_cast<u32x2*>(D.nt + img_index(2, row, col, D.rows, D.cols)) = (u32x2){(l[0] >> 16) | l[1], (l[2] >> 16) | l[3]};
+    // B[n = row][k = col..col+3]: 4 consecutive k of one row -> one 8-byte store per piece; columns between cols and the
+    // padded contraction length get the zeros of the half-empty last stage
+    if (D.nt && row < D.rows && col < D.nt_k) {
+      *reinterpret_cast<u32x2*>(D.nt + img_index(0, row, col, D.nt_n, D.nt_k)) = (u32x2){(h[0] >> 16) | h[1], (h[2] >> 16) | h[3]};
+      *reinterpret_cast<u32x2*>(D.nt + img_index(1, row, col, D.nt_n, D.nt_k)) = (u32x2){(m[0] >> 16) | m[1], (m[2] >> 16) | m[3]};
+      *reinterpret_cast<u32x2*>(D.nt + img_index(2, row, col, D.nt_n, D.nt_k)) = (u32x2){(l[0] >> 16) | l[1], (l[2] >> 16) | l[3]};
     }
     if (D.tn) {
 #pragma unroll
@@ -147,9 +150,9 @@ __global__ __launch_bounds__(256) void k_split_weights(const SplitGroup G) {
     const int idx = t + 256 * i;
     const int p = idx / (ST_C * 4), rem = idx - p * (ST_C * 4);
     const int n = rem >> 2, ch = rem & 3;
-    if (c0 + n < D.cols && r0 + ch * 8 < D.rows) {
+    if (c0 + n < D.cols && r0 + ch * 8 < D.tn_k) {       // (rows past D.rows were loaded as zeros: the k padding)
       const u32x4 v = *reinterpret_cast<const u32x4*>(&T[p][n * ST_P + ch * 8]);
-      *reinterpret_cast<u32x4*>(D.tn + img_index(p, c0 + n, r0 + ch * 8, D.cols, D.rows)) = v;
+      *reinterpret_cast<u32x4*>(D.tn + img_index(p, c0 + n, r0 + ch * 8, D.tn_n, D.tn_k)) = v;
     }
   }
 }
@@ -161,7 +164,8 @@ struct PanelArgs {
   const float* A;
   int64_t lda, M;
   int K, N;
-  const uint16_t* Bp;      // weight image [3][K/32][N][32]
+  int Nimg;                // rows of the weight image (N rounded up to whole column panels: rg_npad)
+  const uint16_t* Bp;      // weight image [3][ceil(K/32)][Nimg][32]
   const float* bias;       // [N] or nullptr
   const float* Cin;        // [M][N] addend (row stride ldcin) or nullptr; may alias C
   int64_t ldcin;
@@ -352,9 +356,34 @@ constexpr int rg_bp(int nj) { return 64 * nj * BK * 2; }                       /
 constexpr int rg_a_bytes(int mb) { return 64 * mb * BK * 4; }                  // raw fp32 A stage: 8 KB per 64 rows
 constexpr int rg_slot_bytes(int mb, int nj) { return rg_a_bytes(mb) + 3 * rg_bp(nj); }   // NJ = 3: 44 KB (64 rows) / 52 KB (128 rows)
 constexpr int rg_lds_bytes(int mb, int nj) { return RG_SLOTS * rg_slot_bytes(mb, nj); }  // NJ = 3: 132 KB / 156 KB
-// panel width for an [N, K] weight: the widest of 192 / 128 / 64 that divides N (192 only with k-stages in threes: its
-// kernel is the round-2 schedule, unchanged, without the left-over stages of the general rotation)
-static inline int rg_nj(int64_t N, int64_t K) { return N % 192 == 0 && (K / BK) % RG_SLOTS == 0 ? 3 : (N % 128 == 0 ? 2 : 1); }
+// Geometry of a [N, K] weight (N = output columns, K = contraction), both multiples of 16:
+//   * k-stages of 32: KS = ceil(K / 32); when K % 32 == 16 the last stage is half empty -- the image holds zeros there
+//     and the A operand re-reads valid columns (EDGE kernels), so the padding contributes exact zeros;
+//   * column panels of 64 * nj: the widest of 192 / 128 / 64 that divides N (192 only with k-stages in threes: its kernel
+//     is the round-2 schedule, unchanged, without the left-over stages of the general rotation); when none divides N
+//     (304 = 4.75 x 64, 48, 96: GPS-small and the narrow configs) the panel count is rounded up and the last panel's
+//     surplus columns are computed and never stored (EDGE kernels), choosing nj by padded width / panel efficiency.
+static inline int rg_ks(int64_t K) { return (int)((K + BK - 1) / BK); }
+static inline int rg_nj(int64_t N, int64_t K) {
+  const bool threes = rg_ks(K) % RG_SLOTS == 0;
+  if (N % 192 == 0 && threes) return 3;
+  if (K % BK == 0) {                       // whole stages: whole panels wherever a width divides N (the measured rule)
+    if (N % 128 == 0) return 2;
+    if (N % 64 == 0) return 1;
+  }
+  int best = 1;                            // EDGE kernels either way: the cheapest padded width
+  double best_cost = 1e30;
+  for (int nj = 1; nj <= 3; ++nj) {
+    if (nj == 3 && !threes) continue;
+    const double eff = nj == 3 ? 1.0 : (nj == 2 ? 0.9 : 0.7);
+    const double cost = (double)((N + 64 * nj - 1) / (64 * nj) * (64 * nj)) / eff;
+    if (cost < best_cost) { best_cost = cost; best = nj; }
+  }
+  return best;
+}
+static inline int64_t rg_npad(int64_t N, int64_t K) { const int tn = 64 * rg_nj(N, K); return (N + tn - 1) / tn * tn; }
+static inline int64_t rg_kpad(int64_t K) { return (int64_t)rg_ks(K) * BK; }
+static inline bool rg_edge(int64_t N, int64_t K) { return rg_npad(N, K) != N || rg_kpad(K) != K; }
 // s_waitcnt immediate (gfx9 layout): vmcnt in bits 3:0 and 15:14, expcnt (left open) in 6:4, lgkmcnt in 11:8
 constexpr int waitcnt_imm(int vm, int lgkm) { return (vm & 15) | (7 << 4) | ((lgkm & 15) << 8) | ((vm >> 4) << 14); }
 
@@ -382,7 +411,9 @@ __device__ float g_zero_bias[kZeroBias];      // stands in for a null bias, so t
 // a third of its lifetime).
 // EPI == 3 additionally accumulates, per lane and column block j, the shifted sums of the values it stores
 // (sk = the wave's first row, s1 = sum (v - sk), s2 = sum (v - sk)^2 over the rows this lane owns).
-template <int MB, int NJ, int EPI, bool HAS_CIN, bool FULL>
+// EDGE: a last column panel that reaches past N (its surplus columns are computed from whatever the image holds there
+// and never stored): column indices of the loads are clamped, the stores predicated.
+template <int MB, int NJ, int EPI, bool HAS_CIN, bool FULL, bool EDGE>
 __device__ __forceinline__ void ring_store(const PanelArgs& P, const f32x16 (&acc)[MB][NJ], int64_t m0, int n0, int wm,
                                            int wn, int li, int kh, float (&sk)[NJ], float (&s1)[NJ], float (&s2)[NJ]) {
   const uint64_t seed = gps::salted_seed(P.seed, P.salt);
@@ -390,7 +421,10 @@ __device__ __forceinline__ void ring_store(const PanelArgs& P, const f32x16 (&ac
   const float inv_keep = drop ? 1.0f / (1.0f - P.p_drop) : 1.0f;
   float bv[NJ];
 #pragma unroll
-  for (int j = 0; j < NJ; ++j) bv[j] = P.bias[n0 + wn * (32 * NJ) + j * 32 + li];   // never null here: the host passes g_zero_bias
+  for (int j = 0; j < NJ; ++j) {         // never null here: the host passes g_zero_bias
+    const int col = n0 + wn * (32 * NJ) + j * 32 + li;
+    bv[j] = P.bias[EDGE ? min(col, P.N - 1) : col];
+  }
   // One 32-row block at a time: EVERY addend / mask value of the block is requested before the first store.  The addend
   // may alias C (in-place accumulation), so the compiler cannot move a load above an earlier store by itself, and one
   // load -> add -> store round trip per element cost 34-40 us per launch at the block's shapes; a lane only ever
@@ -400,7 +434,8 @@ __device__ __forceinline__ void ring_store(const PanelArgs& P, const f32x16 (&ac
     float cin[NJ][16], msk[NJ][16];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
-      const int col = n0 + wn * (32 * NJ) + j * 32 + li;
+      const int col0 = n0 + wn * (32 * NJ) + j * 32 + li;
+      const int col = EDGE ? min(col0, P.N - 1) : col0;
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int64_t row = m0 + (wm * MB + mb) * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh;
@@ -431,16 +466,18 @@ __device__ __forceinline__ void ring_store(const PanelArgs& P, const f32x16 (&ac
           s1[j] += t;
           s2[j] += t * t;
         }
-        if (FULL || row < P.M) __builtin_nontemporal_store(v, P.C + row * P.ldc + col);
+        if ((FULL || row < P.M) && (!EDGE || col < P.N)) __builtin_nontemporal_store(v, P.C + row * P.ldc + col);
       }
     }
   }
 }
-template <int MB, int NJ, int EPI, bool HAS_CIN>
+template <int MB, int NJ, int EPI, bool HAS_CIN, bool EDGE>
 __device__ __forceinline__ void ring_epilogue(const PanelArgs& P, const f32x16 (&acc)[MB][NJ], int64_t m0, int n0, int wm,
                                               int wn, int li, int kh, float (&sk)[NJ], float (&s1)[NJ], float (&s2)[NJ]) {
-  if (m0 + 64 * MB <= P.M) ring_store<MB, NJ, EPI, HAS_CIN, true>(P, acc, m0, n0, wm, wn, li, kh, sk, s1, s2);   // workgroup-uniform
-  else ring_store<MB, NJ, EPI, HAS_CIN, false>(P, acc, m0, n0, wm, wn, li, kh, sk, s1, s2);
+  // (all workgroup-uniform) only the last column panel of an EDGE shape can be partial; the others take the straight-line stores
+  if (EDGE && n0 + 64 * NJ > P.N) ring_store<MB, NJ, EPI, HAS_CIN, false, true>(P, acc, m0, n0, wm, wn, li, kh, sk, s1, s2);
+  else if (m0 + 64 * MB <= P.M) ring_store<MB, NJ, EPI, HAS_CIN, true, false>(P, acc, m0, n0, wm, wn, li, kh, sk, s1, s2);   // workgroup-uniform
+  else ring_store<MB, NJ, EPI, HAS_CIN, false, false>(P, acc, m0, n0, wm, wn, li, kh, sk, s1, s2);
 }
 
 // Column statistics of the panel (EPI == 3): the two row-waves of each column half meet through LDS (the ring is free
@@ -504,7 +541,9 @@ __device__ __forceinline__ void ring_stats(const PanelArgs& P, int rt, int panel
 // 6 NJ MFMAs, so NJ = 1 is VALU-bound -- it serves the small widths, where the launches are latency-bound anyway).
 // Any number of k-stages >= 1: the static three-slot rotation runs in threes, the one or two stages left over reuse the
 // first slots of the rotation; DMA past the last stage re-fetches the last one (never read).
-template <int MB, int NJ, int EPI, bool HAS_CIN>
+// EDGE: N need not be a whole number of panels (ring_store) and K may end half a stage early -- the last
+// stage's A transfers then re-read the row's valid half (finite values, multiplied by the zeros the image holds there).
+template <int MB, int NJ, int EPI, bool HAS_CIN, bool EDGE = false>
 __global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring(const PanelArgs P) {
   constexpr int TNV = 64 * NJ;                  // panel columns
   constexpr int BP = rg_bp(NJ);                 // bytes of one W piece of a stage
@@ -529,29 +568,33 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring(const PanelArgs P) {
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave >> 1, wn = wave & 1;
   const int li = lane & 31, kh = lane >> 5;
-  const int KS = P.K / BK;
+  const int KS = (P.K + BK - 1) / BK;
 
   // ---- DMA sources -------------------------------------------------------------------------------------------
   // A: wave w fills rows 16 MB w .. of the stage, NA instructions of 8 rows x 128 B; lane -> (row, LDS chunk position
   // lane & 7), which fetches source chunk pos ^ ((row >> 1) & 7).  Rows past M re-read row M-1 (never stored).
   const unsigned char* a_src[NA];
+  int a_tail[NA];           // EDGE: byte offset to subtract in the last stage so that a chunk past K re-reads a valid one
+  const bool ktail = EDGE && (P.K % BK) != 0;
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     const int row = 8 * NA * wave + 8 * i + (lane >> 3);
     const int c = (lane & 7) ^ ((row >> 1) & 7);
     const int64_t grow = min(m0 + row, P.M - 1);
     a_src[i] = reinterpret_cast<const unsigned char*>(P.A + grow * P.lda) + c * 16;
+    a_tail[i] = (ktail && c >= 4) ? 64 : 0;
   }
   // W: per piece 4 NJ blocks of 16 rows x 64 B; wave w moves blocks NJ w .. NJ w + NJ - 1 of every piece (NW instructions).
   // lane -> (row lane >> 2 of the block, position lane & 3) fetching chunk pos ^ ((row >> 2) & 3)
-  const int64_t stage_stride = (int64_t)P.N * (BK * 2);             // bytes between k-stages of one piece
+  const int64_t stage_stride = (int64_t)P.Nimg * (BK * 2);          // bytes between k-stages of one piece
   const int64_t piece_stride = stage_stride * KS;
   const unsigned char* b_src = reinterpret_cast<const unsigned char*>(P.Bp) + ((int64_t)n0 + 16 * NJ * wave + (lane >> 2)) * (BK * 2) +
                                (((lane & 3) ^ ((lane >> 4) & 3)) * 16);
   // DMA transfer g (0 .. ND-1) of stage s into `slot`: the first NA = A rows, then W piece i / NJ, block i % NJ
   auto dma = [&](int g, int s, unsigned char* slot) __attribute__((always_inline)) {
     if (g < NA) {
-      glds16(a_src[g] + (int64_t)s * (BK * 4), slot + wave * (NA * 1024) + g * 1024);
+      if (EDGE) glds16(a_src[g] + (int64_t)s * (BK * 4) - (s == KS - 1 ? a_tail[g] : 0), slot + wave * (NA * 1024) + g * 1024);
+      else glds16(a_src[g] + (int64_t)s * (BK * 4), slot + wave * (NA * 1024) + g * 1024);
     } else {
       const int i = g - NA;
       glds16(b_src + s * stage_stride + (i / NJ) * piece_stride + (i % NJ) * 1024,
@@ -706,7 +749,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring(const PanelArgs P) {
   float sk[NJ], s1[NJ], s2[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) sk[j] = s1[j] = s2[j] = 0.f;
-  ring_epilogue<MB, NJ, EPI, HAS_CIN>(P, acc, m0, n0, wm, wn, li, kh, sk, s1, s2);
+  ring_epilogue<MB, NJ, EPI, HAS_CIN, EDGE>(P, acc, m0, n0, wm, wn, li, kh, sk, s1, s2);
   if (EPI == 3) ring_stats<MB, NJ>(P, rt, panel, m0, wm, wn, li, kh, sk, s1, s2, reinterpret_cast<float*>(ring));
   __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 15));
   stamp(3);
@@ -729,7 +772,7 @@ static int ring_mb(int64_t M, int N, int K) {
   static const int mb_cfg = []() { const char* v = getenv("GPS_GEMM_RING_MB"); return v && *v ? atoi(v) : 0; }();
   const int nj = rg_nj(N, K);
   if (nj == 1) return 1;
-  const int64_t tiles128 = ((M + 127) / 128) * (N / (64 * nj));
+  const int64_t tiles128 = ((M + 127) / 128) * (rg_npad(N, K) / (64 * nj));
   return mb_cfg == 1 || mb_cfg == 2 ? mb_cfg : (tiles128 >= 200 ? 2 : 1);
 }
 static bool ring_enabled() {
@@ -744,10 +787,12 @@ extern "C" {
 // memory, >= 4 * grid entries); nullptr switches it off.
 int gps_gemm_panel_trace(unsigned long long* buf) { g_panel_trace = buf; return GPS_OK; }
 
-size_t gps_gemm_image_elems(int64_t N, int64_t K) { return (size_t)(3 * N * K); }
+// bf16 elements of the image of an [N, K] weight: N padded to whole column panels, K to whole stages (rg_npad / rg_kpad)
+size_t gps_gemm_image_elems(int64_t N, int64_t K) { return N > 0 && K > 0 ? (size_t)(3 * rg_npad(N, K) * rg_kpad(K)) : 0; }
 
-// the ring kernel: column panels of 192 / 128 / 64, any number of 32-wide k-stages
-int gps_gemm_panel_supported(int64_t N, int64_t K) { return N > 0 && K > 0 && N % 64 == 0 && K % BK == 0; }
+// the ring kernel: column panels of 192 / 128 / 64 (the last one partial when none divides N), any number of 32-wide
+// k-stages (the last one half empty when K % 32 == 16)
+int gps_gemm_panel_supported(int64_t N, int64_t K) { return N > 0 && K > 0 && N % 16 == 0 && K % 16 == 0; }
 
 int gps_gemm_split_weights(int n, const gps_gemm_split* descs, gps_stream_t stream) {
   GPS_REQUIRE(n >= 1 && n <= kMaxSplit && descs, "gps_gemm_split_weights: 1..%d weights per launch", kMaxSplit);
@@ -758,9 +803,12 @@ int gps_gemm_split_weights(int n, const gps_gemm_split* descs, gps_stream_t stre
     const gps_gemm_split& d = descs[i];
     GPS_REQUIRE(d.W && d.rows > 0 && d.cols > 0 && d.ldw >= d.cols && d.cols % 4 == 0 && d.ldw % 4 == 0 && al16(d.W),
                 "gps_gemm_split_weights: weight %d: bad shape / alignment", i);
-    GPS_REQUIRE(!d.image_nt || (d.cols % BK == 0 && al16(d.image_nt)), "gps_gemm_split_weights: weight %d: cols %% 32", i);
-    GPS_REQUIRE(!d.image_tn || d.rows % BK == 0, "gps_gemm_split_weights: weight %d: rows %% 32", i);
-    G.d[i] = SplitDesc{d.W, d.ldw, d.rows, d.cols, d.image_nt, d.image_tn, blocks};
+    GPS_REQUIRE(!d.image_nt || (gps_gemm_panel_supported(d.rows, d.cols) && al16(d.image_nt)),
+                "gps_gemm_split_weights: weight %d: rows, cols %% 16", i);
+    GPS_REQUIRE(!d.image_tn || (gps_gemm_panel_supported(d.cols, d.rows) && al16(d.image_tn)),
+                "gps_gemm_split_weights: weight %d: rows, cols %% 16", i);
+    G.d[i] = SplitDesc{d.W, d.ldw, d.rows, d.cols, d.image_nt, d.image_tn, blocks,
+                       (int)rg_npad(d.rows, d.cols), (int)rg_kpad(d.cols), (int)rg_npad(d.cols, d.rows), (int)rg_kpad(d.rows)};
     blocks += ((d.rows + ST_R - 1) / ST_R) * ((d.cols + ST_C - 1) / ST_C);
   }
   k_split_weights<<<(unsigned)blocks, 256, 0, gps::as_stream(stream)>>>(G);
@@ -768,14 +816,14 @@ int gps_gemm_split_weights(int n, const gps_gemm_split* descs, gps_stream_t stre
 }
 
 size_t gps_gemm_stats_floats(int64_t M, int N, int K) {
-  if (M < 1 || !gps_gemm_panel_supported(N, K)) return 0;
+  if (M < 1 || !gps_gemm_panel_supported(N, K) || rg_edge(N, K)) return 0;
   const int tn = 64 * rg_nj(N, K), mb = ring_mb(M, N, K);
   const int rt = (int)((M + 64 * mb - 1) / (64 * mb));
   return (size_t)(N / tn) * (tr::floats_for(rt, 2, tn) + 16);
 }
 int gps_gemm_stats_sync_words(int N) { return N >= 64 && N % 64 == 0 ? (N / 64) * tr::kSyncWords : 0; }   // (>= any panel count)
 int gps_gemm_stats_supported(int64_t M, int N, int K) {
-  if (!gps_gemm_panel_supported(N, K) || !ring_enabled() || M < 2) return 0;
+  if (!gps_gemm_panel_supported(N, K) || rg_edge(N, K) || !ring_enabled() || M < 2) return 0;   // (whole panels only)
   const int mb = ring_mb(M, N, K);
   return (M + 64 * mb - 1) / (64 * mb) <= tr::kMaxParts;
 }
@@ -806,7 +854,7 @@ static int panel_launch(const float* A, int64_t lda, int64_t M, int K, const uin
                         const float* Cin, int64_t ldcin, float* C, int64_t ldc, int epilogue, const float* mask_src,
                         int64_t ldmask, float p_drop, uint64_t seed, const gps_bn* stats, float* ws, size_t ws_floats,
                         uint32_t* sync, gps_stream_t stream) {
-  GPS_REQUIRE(M >= 0 && gps_gemm_panel_supported(N, K), "gps_gemm_panel: needs N %% 64 == 0 and K %% 32 == 0 (N=%d K=%d)",
+  GPS_REQUIRE(M >= 0 && gps_gemm_panel_supported(N, K), "gps_gemm_panel: needs N %% 16 == 0 and K %% 16 == 0 (N=%d K=%d)",
               N, K);
   if (M == 0) return GPS_OK;
   GPS_REQUIRE(A && image && C && lda >= K && ldc >= N && lda % 4 == 0 && al16(A) && al16(image),
@@ -815,7 +863,7 @@ static int panel_launch(const float* A, int64_t lda, int64_t M, int K, const uin
   GPS_REQUIRE(epilogue >= 0 && epilogue <= 3 && (epilogue != 2 || (mask_src && ldmask >= N)), "gps_gemm_panel: epilogue");
   GPS_REQUIRE(p_drop >= 0.0f && p_drop < 1.0f, "gps_gemm_panel: p_drop");
   PanelArgs P{};
-  P.A = A; P.lda = lda; P.M = M; P.K = K; P.N = N; P.Bp = image; P.bias = bias; P.Cin = Cin; P.ldcin = ldcin;
+  P.A = A; P.lda = lda; P.M = M; P.K = K; P.N = N; P.Nimg = (int)rg_npad(N, K); P.Bp = image; P.bias = bias; P.Cin = Cin; P.ldcin = ldcin;
   P.C = C; P.ldc = ldc; P.epilogue = epilogue; P.mask_src = mask_src; P.ldmask = ldmask;
   P.p_drop = epilogue ? p_drop : 0.0f; P.seed = seed; P.salt = gps::dropout_salt();
   P.trace = g_panel_trace;
@@ -825,6 +873,8 @@ static int panel_launch(const float* A, int64_t lda, int64_t M, int K, const uin
   const bool staged_ok = N % TN == 0 && K % (4 * BK) == 0;
   const bool ring = ring_enabled() || !staged_ok;
   const int mb = ring_mb(M, N, K), nj = rg_nj(N, K);
+  const bool edge = rg_edge(N, K);
+  GPS_REQUIRE(epilogue != 3 || !edge, "gps_gemm_panel: the statistics epilogue needs whole column panels and k-stages");
   GPS_REQUIRE(epilogue != 3 || ring, "gps_gemm_panel: the statistics epilogue needs the ring kernel");
   unsigned grid;
   if (ring) {
@@ -835,7 +885,7 @@ static int panel_launch(const float* A, int64_t lda, int64_t M, int K, const uin
       P.bias = zeros;
     }
     P.row_tiles = (int)((M + 64 * mb - 1) / (64 * mb));
-    grid = (unsigned)(P.row_tiles * (N / (64 * nj)));
+    grid = (unsigned)(P.row_tiles * (P.Nimg / (64 * nj)));
     if (epilogue == 3) {
       P.st_ws = ws;
       P.st_stride = tr::floats_for(P.row_tiles, 2, 64 * nj) + 16;
@@ -855,9 +905,21 @@ static int panel_launch(const float* A, int64_t lda, int64_t M, int K, const uin
     GPS_REQUIRE(attr == hipSuccess, "gps_gemm_panel: cannot reserve %d bytes of LDS", rg_lds_bytes(MBV, NJV));  \
     k_gemm_ring<MBV, NJV, E, C><<<grid, NTHREADS, rg_lds_bytes(MBV, NJV), s>>>(P);                    \
   } while (0)
+#define GPS_RING_EDGE(MBV, NJV, E, C)                                                                 \
+  do {                                                                                                \
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring<MBV, NJV, E, C, true>), \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, rg_lds_bytes(MBV, NJV)); \
+    GPS_REQUIRE(attr == hipSuccess, "gps_gemm_panel: cannot reserve %d bytes of LDS", rg_lds_bytes(MBV, NJV));  \
+    k_gemm_ring<MBV, NJV, E, C, true><<<grid, NTHREADS, rg_lds_bytes(MBV, NJV), s>>>(P);              \
+  } while (0)
 #define GPS_RING_SHAPES(E, C)                                                                         \
   do {                                                                                                \
-    if (nj == 3) { if (mb == 2) GPS_RING_LAUNCH(2, 3, E, C); else GPS_RING_LAUNCH(1, 3, E, C); }      \
+    if (edge) {                                                                                       \
+      if (nj == 3) { if (mb == 2) GPS_RING_EDGE(2, 3, E, C); else GPS_RING_EDGE(1, 3, E, C); }        \
+      else if (nj == 2) { if (mb == 2) GPS_RING_EDGE(2, 2, E, C); else GPS_RING_EDGE(1, 2, E, C); }   \
+      else GPS_RING_EDGE(1, 1, E, C);                                                                 \
+    }                                                                                                 \
+    else if (nj == 3) { if (mb == 2) GPS_RING_LAUNCH(2, 3, E, C); else GPS_RING_LAUNCH(1, 3, E, C); }      \
     else if (nj == 2) { if (mb == 2) GPS_RING_LAUNCH(2, 2, E, C); else GPS_RING_LAUNCH(1, 2, E, C); } \
     else GPS_RING_LAUNCH(1, 1, E, C);                                                                 \
   } while (0)
@@ -869,7 +931,12 @@ static int panel_launch(const float* A, int64_t lda, int64_t M, int K, const uin
   if (epilogue == 0) { if (Cin) GPS_PANEL_LAUNCH(0, true); else GPS_PANEL_LAUNCH(0, false); }
   else if (epilogue == 1) { if (Cin) GPS_PANEL_LAUNCH(1, true); else GPS_PANEL_LAUNCH(1, false); }
   else if (epilogue == 2) { if (Cin) GPS_PANEL_LAUNCH(2, true); else GPS_PANEL_LAUNCH(2, false); }
-  else GPS_RING_SHAPES(3, true);
+  else {      // (never an edge shape: required above)
+    if (nj == 3) { if (mb == 2) GPS_RING_LAUNCH(2, 3, 3, true); else GPS_RING_LAUNCH(1, 3, 3, true); }
+    else if (nj == 2) { if (mb == 2) GPS_RING_LAUNCH(2, 2, 3, true); else GPS_RING_LAUNCH(1, 2, 3, true); }
+    else GPS_RING_LAUNCH(1, 1, 3, true);
+  }
+#undef GPS_RING_EDGE
 #undef GPS_RING_LAUNCH
 #undef GPS_RING_SHAPES
 #undef GPS_PANEL_LAUNCH

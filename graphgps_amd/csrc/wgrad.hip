@@ -78,6 +78,7 @@ struct Problem {
 struct Group {
   Problem p[kMaxGroup];
   int n;
+  int xcd_map;   // k_wgrad_stream: work items dealt to workgroups XCD by XCD (below)
 };
 
 // One (tile, slice) work item of problem P.  SPLIT: contraction on the bf16 pipe via the exact
@@ -296,12 +297,25 @@ constexpr int waitcnt_imm(int vm, int lgkm) { return (vm & 15) | (7 << 4) | ((lg
 
 __global__ __launch_bounds__(256, 1) void k_wgrad_stream(const Group G) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+  // Work item of this workgroup.  Items are numbered (problem, row slice, g-column tile, x-column tile), x fastest: items
+  // that are neighbours in that order read the same 128-column slab of g (and one of the few slabs of x) over the same
+  // rows.  Workgroup b runs on XCD b % 8 (round-robin dispatch), each XCD with its own L2: dealt out in launch order,
+  // the three tiles of one g slab land on three different XCDs and every slab crosses the fabric once per tile (PMC,
+  // round 2: 844 MB per launch against 233 MB of operands, 5.4 TB/s at the fabric -- as close to that ceiling as to the
+  // issue bound).  Instead XCD c takes the CONTIGUOUS c-th eighth of the item list: the sharers of a slab run at the
+  // same time on the same L2.  A bijection on [0, gridDim): one workgroup per CU and the same count per XCD as
+  // before (the grouping tried in round 1 changed the count per XCD and paid a second dispatch round for it).
+  int bid = blockIdx.x;
+  if (G.xcd_map) {
+    const int n = gridDim.x, q = n >> 3, r = n & 7, c = bid & 7;
+    bid = c * q + min(c, r) + (bid >> 3);
+  }
   int pi = 0;
 #pragma unroll
   for (int i = 1; i < kMaxGroup; ++i)
-    if (i < G.n && (int)blockIdx.x >= G.p[i].block_begin) pi = i;
+    if (i < G.n && bid >= G.p[i].block_begin) pi = i;
   const Problem& P = G.p[pi];
-  const int local = blockIdx.x - P.block_begin;
+  const int local = bid - P.block_begin;
   const int tiles = P.tiles_m * P.tiles_n;
   const int slice = local / tiles;
   if (slice >= P.S) return;
@@ -679,6 +693,8 @@ int launch_group(Group& G, float* ws, hipStream_t s, const char* who) {
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_stream),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS);
     GPS_REQUIRE(attr == hipSuccess, "%s: cannot reserve %d bytes of LDS", who, WS_LDS);
+    static const int xcd_map = [] { const char* e = getenv("GPS_WGRAD_XCD_MAP"); return e && *e ? atoi(e) : 1; }();
+    G.xcd_map = xcd_map;
     k_wgrad_stream<<<(unsigned)blocks, 256, WS_LDS, s>>>(G);
   } else if (fp32_pipe)
     k_wgrad<false><<<(unsigned)blocks, 256, 0, s>>>(G);

@@ -2,12 +2,13 @@
 
 ``C = A W^T (+ bias) (+ addend)`` with optional ReLU/dropout epilogues, fp32 in / fp32 out, products formed exactly on
 the bf16 MFMA pipe.  The weight operand is a pre-split IMAGE (three bf16 pieces, k-stage-major) made from the fp32
-weight by ``split_weights`` -- once per optimizer step for training (the weights change under the optimizer's HIP
-kernel, which torch's version counters do not see, so a training forward always re-splits: ~6 us per layer), cached
-across calls only in evaluation.  Replaces ``torch.addmm`` / ``mm`` (rocBLAS / hipBLASLt) for the projections of
+weight by ``split_weights`` -- once per layer and forward (the weights change under the optimizer's HIP kernel, which
+torch's version counters do not see, so nothing is cached across calls: ~10 us per layer for the five weights of a
+block, both images; callers that never run an input gradient pass ``tn=False``).  Replaces ``torch.addmm`` / ``mm`` (rocBLAS / hipBLASLt) for the projections of
 ``/root/reference/graphgps/layer/gatedgcn_layer.py:57-61`` and ``graphgps/layer/gps_layer.py:104-106,143-144,253-257``
-where the shape qualifies (N % 64 == 0, K % 32 == 0: every width that is a multiple of 64 -- 384, 256, 64); everything
-else stays on the libraries.
+where the shape qualifies (N % 16 == 0, K % 16 == 0: every ``dim_hidden`` the reference's configs use -- 384, 304,
+256, 96, 64, 48, ...; widths that are not whole 64-column panels / 32-wide k-stages run the kernel's EDGE variants over a
+padded image); everything else stays on the libraries.
 """
 from __future__ import annotations
 
@@ -23,15 +24,16 @@ ENABLED = os.environ.get("GPS_GEMM_PANEL", "1") != "0"
 
 
 def supported(N: int, K: int) -> bool:
-    """Shapes the ring kernel tiles: column panels of 192 / 128 / 64, 32-wide k-stages."""
-    return ENABLED and N > 0 and K > 0 and N % 64 == 0 and K % 32 == 0
+    """Shapes the ring kernel tiles: column panels of 192 / 128 / 64 (the last one may be partial), 32-wide k-stages
+    (the last one may be half empty)."""
+    return ENABLED and N > 0 and K > 0 and N % 16 == 0 and K % 16 == 0
 
 
 _stats_ok = {}
 
 
 def stats_supported(M: int, N: int, K: int) -> bool:
-    """Whether ``gemm_panel_stats`` serves ``[M, K] x [K, N]`` (the ring kernel with <= 576 row tiles)."""
+    """Whether ``gemm_panel_stats`` serves ``[M, K] x [K, N]`` (whole column panels and k-stages, <= 961 row tiles)."""
     key = (M, N, K)
     v = _stats_ok.get(key)
     if v is None:
@@ -72,8 +74,10 @@ def split_weights(weights: Sequence[torch.Tensor], nt: bool = True, tn: bool = T
         if w.dtype != torch.float32 or w.dim() != 2 or w.stride(1) != 1 or not w.is_cuda:
             raise _lib.GpsHipError("split_weights: fp32 [rows, cols] CUDA weights with unit column stride")
         rows, cols = w.shape
-        i_nt = torch.empty(3 * rows * cols, dtype=torch.int16, device=dev) if nt else None
-        i_tn = torch.empty(3 * rows * cols, dtype=torch.int16, device=dev) if tn else None
+        # padded to whole column panels / k-stages by the library's own geometry; the split kernel writes the zeros of
+        # the k padding, the surplus rows of the last panel feed columns that are never stored
+        i_nt = torch.empty(L.gps_gemm_image_elems(rows, cols), dtype=torch.int16, device=dev) if nt else None
+        i_tn = torch.empty(L.gps_gemm_image_elems(cols, rows), dtype=torch.int16, device=dev) if tn else None
         q.W, q.ldw, q.rows, q.cols = w.data_ptr(), w.stride(0), rows, cols
         q.image_nt = i_nt.data_ptr() if nt else None
         q.image_tn = i_tn.data_ptr() if tn else None

@@ -77,9 +77,13 @@ class DeviceLoader:
         batch = self._host_copy(batch)
         vars(batch).pop("_gps_index", None)
         # what the host can tell the kernels for free while ``ptr`` is still here: the longest graph of the batch
-        p = getattr(batch, "ptr", None)
+        # (from ``ptr``, or from a host-side ``batch`` vector when the collater emitted no ``ptr``: without the record
+        # ops._host_max_graph_nodes would pay a synchronising device read on the copy stream)
+        p, bv = getattr(batch, "ptr", None), getattr(batch, "batch", None)
         if torch.is_tensor(p) and not p.is_cuda and p.numel() > 1:
             vars(batch)["_gps_meta"] = {"nmax": int((p[1:] - p[:-1]).max())}
+        elif p is None and torch.is_tensor(bv) and not bv.is_cuda and bv.numel():
+            vars(batch)["_gps_meta"] = {"nmax": int(torch.bincount(bv).max())}
         with torch.cuda.stream(copy_stream):
             for k in self._keys(batch):
                 v = getattr(batch, k, None)

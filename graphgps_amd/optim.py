@@ -87,14 +87,16 @@ class ParamArena:
                 blocks.setdefault(key, []).append(i)
         # ... they are re-packed as runs of parameters that are adjacent there (a stack that was adopted earlier stays
         # one block, so its stacked view stays a view)
+        # Parameters that alias or overlap one range (tied weights held as separate Parameter objects) stay in one run
+        # as well: copied separately they would silently come untied.
         in_prev.sort(key=lambda i: self.params[i].data.storage_offset())
-        run = []
+        run, run_end = [], 0
         for i in in_prev:
-            if run:
-                j = run[-1]
-                if self.params[j].data.storage_offset() + self.params[j].numel() != self.params[i].data.storage_offset():
-                    blocks[("run", run[0])] = run
-                    run = []
+            off = self.params[i].data.storage_offset()
+            if run and off > run_end:           # a hole in front of this one: the run ends
+                blocks[("run", run[0])] = run
+                run = []
+            run_end = max(run_end, off + self.params[i].numel()) if run else off + self.params[i].numel()
             run.append(i)
         if run:
             blocks[("run", run[0])] = run

@@ -197,12 +197,15 @@ int gps_edge_attn_bwd(const float* g_wv, const float* g_z, const float* Q, const
  * graphgps/layer/gps_layer.py:104-106 (MultiheadAttention in/out projection) and :143-144,253-257 (FFN).
  * fp32 in, fp32 out; products formed exactly on the bf16 MFMA pipe (3-way exact split, 6 of 9 piece products,
  * fp32 accumulation: the rounding model of an fp32-input MFMA GEMM, ~7e-7 against fp64).
- * B is passed as a pre-split IMAGE (uint16 bf16 patterns, layout [3 pieces][K/32][N][32]) produced from the fp32
+ * B is passed as a pre-split IMAGE (uint16 bf16 patterns, layout [3 pieces][ceil(K/32)][N'][32], N' = N rounded up to
+ * whole column panels; the split kernel writes zeros into the k padding) produced from the fp32
  * weight by gps_gemm_split_weights -- once per optimizer step, for the weight (`image_nt`: B[n][k] = W[n][k],
  * forward) and/or its transpose (`image_tn`: B[n][k] = W[k][n], input gradient); gps_gemm_image_elems(N, K)
- * uint16 elements each.  Shapes: N % 64 == 0 and K % 32 == 0 (gps_gemm_panel_supported: column panels of 192, 128 or
- * 64, any number of 32-wide k-stages -- every GPS width that is a multiple of 64); anything else stays on the library
- * GEMMs.
+ * uint16 elements each (padding included).  Shapes: N % 16 == 0 and K % 16 == 0 (gps_gemm_panel_supported: column
+ * panels of 192, 128 or 64, any number of 32-wide k-stages; when no panel width divides N or K % 32 == 16 -- d = 304,
+ * 96, 48 -- the EDGE variants compute the surplus columns without storing them and multiply the half-empty last stage
+ * by the image's zeros); anything else stays on the library GEMMs.  gps_gemm_panel_stats additionally needs whole
+ * panels and stages (gps_gemm_stats_supported).
  * epilogue: 0 none | 1 relu then dropout(p_drop, seed) keyed (row, column) like gps_act_drop_add
  *           | 2 multiply by the relu/dropout mask of `mask_src` (= gps_act_drop_bwd applied to the product).
  * ------------------------------------------------------------------------------------- */

@@ -107,6 +107,9 @@ def _oracle_layer_like(layer):
     ("CustomGatedGCN", "Transformer", 384, 16, "P30", 256),   # BASELINE configs[2] layer shape
     ("CustomGatedGCN", "Transformer", 384, 16, "P14", 256),
     ("GINE", "Transformer", 64, 4, "ZINC", 32),               # BASELINE configs[1] layer shape
+    ("CustomGatedGCN", "Transformer", 304, 4, "P30", 256),    # pcqm4m-GPS.yaml (GPS-small): 4.75 column panels, 9.5 k-stages
+    ("CustomGatedGCN", "Transformer", 304, 4, "P14", 128),
+    ("CustomGatedGCN", "Transformer", 96, 4, "P30", 64),      # peptides-*-GPS.yaml width: 1.5 panels
 ])
 def test_gpslayer_vs_oracle_baseline_sizes(local, glob, d, H, profile, nb):
     from graphgps_amd.layer.gps_layer import GPSLayer

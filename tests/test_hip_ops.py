@@ -692,10 +692,15 @@ def test_gin_aggregate_matches_index_add():
 @pytest.mark.parametrize("M,K,N", [(7569, 384, 2688), (1000, 384, 384), (15348, 384, 384), (7569, 768, 384),
                                    (333, 2688, 384), (64, 128, 192), (65, 256, 768),
                                    # round 3: 128- and 64-column panels, any number of k-stages (d = 256: code2 / GPS-deep;
-                                   # d = 64: ZINC; 304 = 9.5 stages stays on the libraries)
+                                   # d = 64: ZINC)
                                    (7569, 256, 1792), (7569, 1792, 256), (25013, 256, 256), (1000, 256, 512),
                                    (1000, 512, 256), (743, 64, 448), (743, 448, 64), (743, 64, 64), (130, 32, 64),
-                                   (130, 64, 128), (300, 160, 192), (2000, 608, 1216)])
+                                   (130, 64, 128), (300, 160, 192), (2000, 608, 1216),
+                                   # EDGE variants: a partial last column panel and / or a half-empty last k-stage
+                                   # (d = 304: GPS-small PCQM4Mv2 / peptides; 96, 48, 16: narrow configs)
+                                   (7569, 304, 2128), (7569, 2128, 304), (2000, 304, 304), (2000, 304, 608),
+                                   (2000, 608, 304), (1000, 304, 1216), (743, 96, 672), (743, 96, 96), (743, 48, 48),
+                                   (300, 48, 336), (130, 16, 16), (500, 384, 80), (500, 80, 384)])
 def test_gemm_panel_fp32_exact_products(M, K, N):
     """csrc/gemm_panel.hip at the block's projection shapes (N, K in {384, 768, 2688}; M = nodes / edges, ragged last
     row tile): C = A W^T + bias against fp64, through the weight image (forward) and through the transposed image
