@@ -146,6 +146,10 @@ class TrainStep:
         # to avoid it and costs nothing, so every capture gets one.  GPS_CAPTURE_TICK=0 removes it (to reproduce).
         # The tick tensor is written by EVERY replay, so it must live exactly as long as the graphs do (a local would
         # hand its block back to the caching allocator and each replay would then add 1.0f into whoever got it next).
+        # (Measured and dropped, round 3: two / three instances of the captured step replayed alternately, to hide the
+        # ~1 ms host side of hipGraphLaunch behind the previous replay -- 10.54 vs 10.55 ms, and the ~0.3 ms of idle gaps
+        # at the head of every replayed step, two of them 85-100 us in front of the edge encoder's scatter_ / cat nodes,
+        # stay where they are: they are not the host's enqueue pace.  tools/runs/gpu_r4b.sh.)
         tick = torch.zeros(1, device=dev) if _os.environ.get("GPS_CAPTURE_TICK", "1") != "0" else None
         with STAGE_LOCK, torch.cuda.graph(g_fb, capture_error_mode=_os.environ.get("GPS_CAPTURE_MODE", "thread_local")):
             if tick is not None:

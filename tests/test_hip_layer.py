@@ -119,45 +119,84 @@ def test_gpslayer_vs_oracle_baseline_sizes(local, glob, d, H, profile, nb):
     layer = GPSLayer(d, local, glob, H, dropout=0.0, attn_dropout=0.0)
     oracle = _oracle_layer_like(layer).train()
     layer.to(dev).train()
+    state0 = {k: v.clone() for k, v in layer.state_dict().items()}          # (BN running statistics move per forward)
     b = layer_batch(profile, nb, d, seed=77)
     gen = torch.Generator().manual_seed(5)
     wx = torch.randn(b.x.shape, generator=gen)
     we = torch.randn(b.edge_attr.shape, generator=gen)
-    bc = b.clone()
-    bc.x.requires_grad_(True); bc.edge_attr.requires_grad_(True)
-    xo, eo = bc.x, bc.edge_attr
-    oo = oracle(bc)
-    ((oo.x * wx).sum() + (oo.edge_attr * we).sum()).backward()
-    bg = b.clone().to(dev)
-    bg.x.requires_grad_(True); bg.edge_attr.requires_grad_(True)
-    xg, eg = bg.x, bg.edge_attr
-    og = layer(bg)
-    ((og.x * wx.to(dev)).sum() + (og.edge_attr * we.to(dev)).sum()).backward()
+
+    def run(wx, we):
+        """One forward + backward of the loss sum(wx * x') + sum(we * e') on both sides."""
+        for m in (oracle, layer):
+            m.zero_grad(set_to_none=True)
+        layer.load_state_dict(state0)
+        oracle.load_state_dict({k: v.cpu() for k, v in state0.items()})
+        bc = b.clone()
+        bc.x.requires_grad_(True); bc.edge_attr.requires_grad_(True)
+        xo, eo = bc.x, bc.edge_attr             # (the layer re-binds batch.x / batch.edge_attr to its outputs)
+        oo = oracle(bc)
+        ((oo.x * wx).sum() + (oo.edge_attr * we).sum()).backward()
+        bg = b.clone().to(dev)
+        bg.x.requires_grad_(True); bg.edge_attr.requires_grad_(True)
+        xg, eg = bg.x, bg.edge_attr
+        og = layer(bg)
+        ((og.x * wx.to(dev)).sum() + (og.edge_attr * we.to(dev)).sum()).backward()
+        return oo, og, xo.grad, eo.grad, xg.grad, eg.grad
+
+    def check_params(strict):
+        """Parameter gradients: sums over ~8k rows / ~16k edges of fp32 products, the reduction order differs between
+        the HIP kernels and the CPU BLAS (bar 1e-4 of max|g|), and a ReLU-kink flip at (row r, channel c) lands
+        undamped in row c of a weight gradient, so a few outlier rows per parameter are allowed
+        (assert_close_kink_tolerant).  Biases that feed a BatchNorm have a mathematically zero gradient: what both
+        sides hold is the rounding residue of a 7.5k-term cancelling sum, so the scale floor is 1 % of the layer's
+        largest parameter gradient rather than the parameter's own (noise) magnitude.  Returns the failures."""
+        op = dict(oracle.named_parameters())
+        gscale = max(float(q.grad.abs().max()) for q in op.values() if q.grad is not None)
+        bad = []
+        for k, p in layer.named_parameters():
+            if op[k].grad is None:
+                continue
+            try:
+                r = assert_close_kink_tolerant(p.grad, op[k].grad, 1e-4, f"grad {k}", min_scale=max(1.0, 0.01 * gscale))
+                if r[2]:
+                    print(f"grad {k}: {r[2]} kink rows, max rel {r[0]:.2e} outside them")
+            except AssertionError as exc:
+                if strict:
+                    raise
+                bad.append(str(exc))
+        return bad
+
+    oo, og, gxo, geo, gxg, geg = run(wx, we)
     assert_close(og.x, oo.x, Tol.ACT, "out.x")
     assert_close(og.edge_attr, oo.edge_attr, Tol.ACT, "out.edge_attr")
     # a kink flip inside the attention / FFN path of one graph perturbs every node row of that
     # graph (attention mixes them): allow a few graphs' worth of rows
     gmax = int((b.ptr[1:] - b.ptr[:-1]).max())
-    rx = assert_close_kink_tolerant(xg.grad, xo.grad, Tol.GRAD_REL, "grad x", min_allowed_rows=4 * gmax)
-    re_ = assert_close_kink_tolerant(eg.grad, eo.grad, Tol.GRAD_REL, "grad e")
+    rx = assert_close_kink_tolerant(gxg, gxo, Tol.GRAD_REL, "grad x", min_allowed_rows=4 * gmax)
+    re_ = assert_close_kink_tolerant(geg, geo, Tol.GRAD_REL, "grad e")
     print(f"grad x: max rel {rx[0]:.2e} outside {rx[2]} kink rows; "
           f"grad e: max rel {re_[0]:.2e} outside {re_[2]} kink rows")
-    op = dict(oracle.named_parameters())
-    gscale = max(float(q.grad.abs().max()) for q in op.values() if q.grad is not None)
-    for k, p in layer.named_parameters():
-        if op[k].grad is None:
-            continue
-        # parameter gradients are sums over ~8k rows / ~16k edges of fp32 products: reduction
-        # order differs between rocBLAS and the CPU BLAS (bar 1e-4 of max|g|), and a ReLU-kink
-        # flip at (row r, channel c) lands undamped in row c of a weight gradient, so a few
-        # outlier rows per parameter are allowed (see assert_close_kink_tolerant)
-        # biases that feed a BatchNorm have a mathematically zero gradient: what both sides hold
-        # is the rounding residue of a 7.5k-term cancelling sum, so the scale floor is 1 % of the
-        # layer's largest parameter gradient rather than the parameter's own (noise) magnitude
-        r = assert_close_kink_tolerant(p.grad, op[k].grad, 1e-4, f"grad {k}",
-                                       min_scale=max(1.0, 0.01 * gscale))
-        if r[2]:
-            print(f"grad {k}: {r[2]} kink rows, max rel {r[0]:.2e} outside them")
+    bad = check_params(strict=False)
+    if not bad:
+        return
+    # Some parameter gradient is off by more than a few rows' worth.  The one legitimate cause is a kink flip UPSTREAM of
+    # the attention: every node of that graph then carries a kink-sized gradient error (the rows counted above), and in
+    # a small batch (P14 x 128: 1.8k rows) one graph's rows weigh enough to move every row of a weight gradient past
+    # 1e-4.  Attribution instead of a wider tolerance: give the graphs that own the kink rows zero weight in the loss
+    # (on both sides; the flips themselves stay where they are) -- every parameter gradient must then meet the bar.
+    scale_x, scale_e = max(float(gxo.abs().max()), 1.0), max(float(geo.abs().max()), 1.0)
+    kx = ((gxg.cpu() - gxo).abs().amax(dim=1) / scale_x > Tol.GRAD_REL).nonzero().flatten()
+    ke = ((geg.cpu() - geo).abs().amax(dim=1) / scale_e > Tol.GRAD_REL).nonzero().flatten()
+    graphs = set(b.batch[kx].tolist()) | set(b.batch[b.edge_index[1][ke]].tolist())
+    assert graphs, "parameter gradients differ although no input-gradient row does:\n" + "\n".join(bad)
+    assert len(graphs) <= 4, f"{len(graphs)} graphs with kink-sized gradient rows"
+    print(f"{len(bad)} parameter gradients past 1e-4 with kink rows in graphs {sorted(graphs)}; second pass without them")
+    keep_n = torch.ones(b.x.shape[0], 1)
+    for g_ in graphs:
+        keep_n[b.batch == g_] = 0.0
+    keep_e = keep_n[b.edge_index[1]]
+    run(wx * keep_n, we * keep_e)
+    check_params(strict=True)
 
 
 def _masked_oracle_run(oracle, b, seeds_per_layer, H, p, p_attn, wx, we, dtype, local):

@@ -32,7 +32,13 @@ def main():
     c = sqlite3.connect(a.db)
     cols = [r[1] for r in c.execute("pragma table_info(kernels)")]
     key = "stream_id" if "stream_id" in cols else "queue_id"
-    rows = c.execute(f"select {key}, start, end, name from kernels order by start").fetchall()
+    rows = c.execute(f"select {key}, start, end, name from kernels").fetchall()
+    try:        # copies / fills that are not kernels (rocprofv3 --memory-copy-trace): they explain idle gaps
+        rows += [(r[0], r[1], r[2], f"memcpy:{r[3]}:{r[4]}B") for r in
+                 c.execute(f"select {key}, start, end, name, size from memory_copies")]
+    except sqlite3.Error:
+        pass
+    rows.sort(key=lambda r: r[1])
     marks = [i for i, r in enumerate(rows) if "k_adamw" in r[3]]
     if len(marks) < 3:
         raise SystemExit("fewer than 3 optimizer launches in the trace")
