@@ -87,7 +87,7 @@ struct SplitDesc {
   int block_begin;
   int nt_n, nt_k, tn_n, tn_k;   // padded image geometry (rows of the image, contraction length): see rg_npad / rg_kpad
 };
-constexpr int kMaxSplit = 8;
+constexpr int kMaxSplit = 56;      // 56 x 64-byte descriptors: the launch's kernel arguments stay under 4 KB
 struct SplitGroup {
   SplitDesc d[kMaxSplit];
   int n;
@@ -105,10 +105,11 @@ __device__ __forceinline__ int64_t img_index(int p, int n, int k, int N, int K) 
 constexpr int ST_R = 32, ST_C = 128, ST_P = ST_R + 8;      // LDS tile [3][128 columns][32 rows + pad] bf16
 __global__ __launch_bounds__(256) void k_split_weights(const SplitGroup G) {
   __shared__ __attribute__((aligned(16))) uint16_t T[3][ST_C * ST_P];
-  int di = 0;
-#pragma unroll
-  for (int i = 1; i < kMaxSplit; ++i)
-    if (i < G.n && (int)blockIdx.x >= G.d[i].block_begin) di = i;
+  int di = 0, hi = G.n - 1;            // descriptor of this workgroup: the last one that begins at or before it
+  while (di < hi) {
+    const int mid = (di + hi + 1) >> 1;
+    if ((int)blockIdx.x >= G.d[mid].block_begin) di = mid; else hi = mid - 1;
+  }
   const SplitDesc& D = G.d[di];
   const int ctiles = (D.cols + ST_C - 1) / ST_C;
   const int tile = blockIdx.x - D.block_begin;

@@ -21,6 +21,7 @@ from . import lib as _lib
 from .lib import check, current_stream, ptr
 
 ENABLED = os.environ.get("GPS_GEMM_PANEL", "1") != "0"
+MAX_SPLIT = 56      # csrc/gemm_panel.hip kMaxSplit
 
 
 def supported(N: int, K: int) -> bool:
@@ -63,8 +64,14 @@ def gemm_panel_stats(a: torch.Tensor, image: torch.Tensor, N: int, bias: Optiona
 
 def split_weights(weights: Sequence[torch.Tensor], nt: bool = True, tn: bool = True
                   ) -> List[Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]]:
-    """[(image of W, image of W^T), ...] for up to 8 fp32 weights ``[rows, cols]`` in ONE launch.
+    """[(image of W, image of W^T), ...] for fp32 weights ``[rows, cols]``, up to 56 per launch (the five projections
+    of every block of a 10-layer stack: ONE launch per step, layer/gps_block.py stack_begin).
     ``image of W`` serves ``x @ W.T`` (forward), ``image of W^T`` serves ``g @ W`` (input gradient)."""
+    if len(weights) > MAX_SPLIT:
+        out = []
+        for i in range(0, len(weights), MAX_SPLIT):
+            out += split_weights(weights[i:i + MAX_SPLIT], nt, tn)
+        return out
     L = _lib.load()
     n = len(weights)
     descs = (_lib.GemmSplit * n)()

@@ -41,6 +41,71 @@ _BY_REF = _ctypes.byref
 # their statistics by row tasks instead of the ring GEMM epilogue (default 1: -0.3 ms per step).
 _GG_STATS = _os.environ.get("GPS_GG_STATS", "0") != "0"
 _GEMM_STATS = _os.environ.get("GPS_GEMM_STATS", "1") != "0"
+_STACK_PREP = _os.environ.get("GPS_STACK_PREP", "1") != "0"
+
+# Work that is per layer only by accident, hoisted to the layer STACK when a network drives the blocks (network/base.py
+# brackets its layer stack with stack_begin / stack_end; a block called on its own behaves as before):
+#   * the weight images of every block's five projections come out of ONE split launch at the head of the stack instead
+#     of one 12 us launch per layer (the weights only change in the optimizer step);
+#   * the BatchNorm ``num_batches_tracked`` counters of all blocks take ONE multi-tensor add at the end of the stack
+#     instead of one 5 us launch per layer.
+_STACK = {"active": False, "nbt": []}
+
+
+def _count_batches(counters):
+    if _STACK["active"]:
+        _STACK["nbt"].extend(counters)
+    else:
+        torch._foreach_add_(counters, 1)
+
+
+def _ensure_xgroup(layer):
+    from ..fused import LinearGroup
+    lm, sa = layer.local_model, layer.self_attn
+    if getattr(layer, "_xgroup", None) is None:
+        # zero-copy stack of every weight that multiplies the layer input: A, B, D, E, in_proj
+        layer._xgroup = LinearGroup(weights=[lm.A.weight, lm.B.weight, lm.D.weight, lm.E.weight,
+                                             sa.in_proj_weight],
+                                    biases=[lm.A.bias, lm.B.bias, lm.D.bias, lm.E.bias,
+                                            sa.in_proj_bias])
+    return layer._xgroup._stacked()
+
+
+def stack_begin(layers, batch) -> bool:
+    """Called by the network in front of its layer stack (training, gradients on, CUDA).  Returns whether stack_end is
+    due."""
+    x = getattr(batch, "x", None)
+    if not (_STACK_PREP and torch.is_tensor(x) and x.is_cuda and torch.is_grad_enabled()) or _STACK["active"]:
+        return False
+    _STACK["active"], _STACK["nbt"] = True, []
+    weights, owners = [], []
+    for layer in layers:
+        if not (getattr(layer, "training", False) and getattr(layer, "local_gnn_type", None) == 'CustomGatedGCN'
+                and getattr(layer, "global_model_type", None) == 'Transformer' and block_supported(layer, x)):
+            continue
+        d = layer.dim_h
+        if not (_gemm.supported(d, d) and _gemm.supported(2 * d, d) and _gemm.supported(7 * d, d)):
+            continue
+        wcat, _ = _ensure_xgroup(layer)
+        lm, sa = layer.local_model, layer.self_attn
+        weights += [wcat, lm.C.weight, sa.out_proj.weight, layer.ff_linear1.weight, layer.ff_linear2.weight]
+        owners.append(layer)
+    if owners:
+        imgs = _gemm.split_weights(weights)
+        for i, layer in enumerate(owners):
+            layer.__dict__["_presplit"] = imgs[5 * i:5 * i + 5]
+    _STACK["owners"] = owners
+    return True
+
+
+def stack_end() -> None:
+    nbt, _STACK["nbt"] = _STACK["nbt"], []
+    _STACK["active"] = False
+    for layer in _STACK.pop("owners", []):
+        layer.__dict__.pop("_presplit", None)      # (a layer that did not take the block path this time)
+    if nbt:
+        torch._foreach_add_(nbt, 1)
+
 # launch sites of one layer that own arrival counters (norm.SyncArena.site): sites that may be in flight together differ
 _S_GG, _S_AO, _S_XE, _S_MID, _S_Z2, _S_B1, _S_B3, _S_B4 = range(8)
 
@@ -252,9 +317,11 @@ class _GPSBlock(torch.autograd.Function):
         # The C projection of the edges goes FIRST: it depends on nothing but e, and with it out of the way the two halves
         # of the block that fork after the merged projection are balanced -- [attention core -> out-projection] beside
         # [GatedGCN core] -- instead of [attention, out-projection] beside [C projection -> GatedGCN core].
-        if panel:       # weight images of the block's five projections (W and W^T), ONE launch per layer and step
-            imgs = _gemm.split_weights([wcat, lm.C.weight, sa.out_proj.weight, layer.ff_linear1.weight,
-                                        layer.ff_linear2.weight])
+        if panel:       # weight images of the block's five projections (W and W^T): made for the whole stack at once
+            imgs = layer.__dict__.pop("_presplit", None)        # (stack_begin), else ONE launch per layer and step
+            if imgs is None:
+                imgs = _gemm.split_weights([wcat, lm.C.weight, sa.out_proj.weight, layer.ff_linear1.weight,
+                                            layer.ff_linear2.weight])
             ce = _gemm.gemm_panel(e, imgs[1][0], d, bias=lm.C.bias)
             pq = _gemm.gemm_panel(x, imgs[0][0], 7 * d, bias=bcat)
         else:
@@ -336,10 +403,9 @@ class _GPSBlock(torch.autograd.Function):
                       sync.site(_S_Z2))
         out = _E(N, d, **f32)
         _norm.fwd([_norm.fwd_task(_norm.BN_ACT, z2, N, bn1=bn2, out=out)], d, dev, None)
-        torch._foreach_add_([lm.bn_node_x.num_batches_tracked, lm.bn_edge_e.num_batches_tracked,
-                             layer.norm1_local.num_batches_tracked,
-                             layer.norm1_attn.num_batches_tracked,
-                             layer.norm2.num_batches_tracked], 1)
+        _count_batches([lm.bn_node_x.num_batches_tracked, lm.bn_edge_e.num_batches_tracked,
+                        layer.norm1_local.num_batches_tracked, layer.norm1_attn.num_batches_tracked,
+                        layer.norm2.num_batches_tracked])
 
         ctx.save_for_backward(x, e, pq, eh, xt, x1, o, lse, za, h, f1 if f1 is not None else t, t, z2, stats)
         ctx.layer, ctx.gi, ctx.seeds = layer, gi, s
@@ -519,8 +585,8 @@ class _GPSBlockGINE(torch.autograd.Function):
                   sync.site(_S_Z2))
         out = _E(N, d, **f32)
         _norm.fwd([_norm.fwd_task(_norm.BN_ACT, z2, N, bn1=bn2, out=out)], d, dev, None)
-        torch._foreach_add_([layer.norm1_local.num_batches_tracked, layer.norm1_attn.num_batches_tracked,
-                             layer.norm2.num_batches_tracked], 1)
+        _count_batches([layer.norm1_local.num_batches_tracked, layer.norm1_attn.num_batches_tracked,
+                        layer.norm2.num_batches_tracked])
         ctx.save_for_backward(x, e, agg, g1, g1r, qkv, o, lse, zl, za, h, f1, t, z2, stats)
         ctx.layer, ctx.gi, ctx.seeds = layer, gi, s
         ctx.cfg = (p_loc, p_l, p_f1, p_f2, p_at, H, dh, scale)
@@ -670,13 +736,5 @@ def block_supported(layer, x, e=None) -> bool:
 
 
 def gps_block(layer, x, e, gi):
-    from ..fused import LinearGroup
-    lm, sa = layer.local_model, layer.self_attn
-    if getattr(layer, "_xgroup", None) is None:
-        # zero-copy stack of every weight that multiplies the layer input: A, B, D, E, in_proj
-        layer._xgroup = LinearGroup(weights=[lm.A.weight, lm.B.weight, lm.D.weight, lm.E.weight,
-                                             sa.in_proj_weight],
-                                    biases=[lm.A.bias, lm.B.bias, lm.D.bias, lm.E.bias,
-                                            sa.in_proj_bias])
-    layer._xgroup._stacked()
+    _ensure_xgroup(layer)
     return _GPSBlock.apply(x, e, layer, gi, draw_dropout_seed(), *block_params(layer))

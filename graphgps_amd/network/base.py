@@ -61,5 +61,20 @@ class GraphGymNetwork(torch.nn.Module):
 
     def forward(self, batch):
         for module in self.children():
-            batch = module(batch)
+            if isinstance(module, torch.nn.Sequential) and len(module) and hasattr(module[0], "local_gnn_type"):
+                batch = self._run_stack(module, batch)
+            else:
+                batch = module(batch)
         return batch
+
+    @staticmethod
+    def _run_stack(layers, batch):
+        """The GPS layer stack, bracketed so that the fused blocks share their per-step set-up (one weight-image
+        launch, one BatchNorm counter launch for all layers: layer/gps_block.py stack_begin / stack_end)."""
+        from ..layer import gps_block as _blk
+        if not _blk.stack_begin(layers, batch):
+            return layers(batch)
+        try:
+            return layers(batch)
+        finally:
+            _blk.stack_end()

@@ -218,7 +218,7 @@ typedef struct gps_gemm_split {
 } gps_gemm_split;
 size_t gps_gemm_image_elems(int64_t N, int64_t K);
 int gps_gemm_panel_supported(int64_t N, int64_t K);
-int gps_gemm_split_weights(int n, const gps_gemm_split* descs, gps_stream_t stream);   /* n <= 8, one launch */
+int gps_gemm_split_weights(int n, const gps_gemm_split* descs, gps_stream_t stream);   /* n <= 56, one launch */
 /* Debugging aid (tools/gemm_trace.py): the ring kernel stamps s_memtime per workgroup into buf (4 x uint64 each);
  * NULL switches it off. */
 int gps_gemm_panel_trace(unsigned long long* buf);

@@ -523,11 +523,17 @@ def test_full_model_train_step_with_dropout_runs():
         losses.append(loss.item())
     assert all(torch.isfinite(p.grad).all() for p in model.parameters() if p.grad is not None)
     assert losses[0] != losses[1]
+    # the blocks' BatchNorm counters are bumped once per forward by ONE launch for the whole stack (gps_block.stack_end),
+    # and no layer keeps a stale set of pre-split weight images
+    counters = {k: int(v) for k, v in model.state_dict().items() if k.endswith("num_batches_tracked")}
+    assert counters and set(counters.values()) == {2}, counters
+    assert not any("_presplit" in vars(m) for m in model.modules())
     model.eval()
     with torch.no_grad():
         p1, _ = model(b.clone())
         p2, _ = model(b.clone())
     assert torch.equal(p1, p2)
+    assert {int(v) for k, v in model.state_dict().items() if k.endswith("num_batches_tracked")} == {2}
 
 
 @pytest.mark.parametrize("block", [True, False])
