@@ -41,6 +41,7 @@ _BY_REF = _ctypes.byref
 # their statistics by row tasks instead of the ring GEMM epilogue (default 1: -0.3 ms per step).
 _GG_STATS = _os.environ.get("GPS_GG_STATS", "0") != "0"
 _GEMM_STATS = _os.environ.get("GPS_GEMM_STATS", "1") != "0"
+_GG_FIRST = _os.environ.get("GPS_GG_FIRST", "1") != "0"
 _STACK_PREP = _os.environ.get("GPS_STACK_PREP", "1") != "0"
 
 # Work that is per layer only by accident, hoisted to the layer STACK when a network drives the blocks (network/base.py
@@ -339,6 +340,30 @@ class _GPSBlock(torch.autograd.Function):
         ref = _BY_REF
         sync = _norm.sync_arena(layer, dev)
         gemm_stats = panel and _GEMM_STATS and _gemm.stats_supported(N, d, d) and _gemm.stats_supported(N, d, 2 * d)
+        # -- local branch: GatedGCN core ---------------------------------------------------------
+        def local_half():
+            xt, eh = _E(N, d, **f32), _E(E, d, **f32)
+            if _GG_STATS:           # statistics of x~ (bn_node_x) and e^ (bn_edge_e) fall out of the same launch
+                wsf = L.gps_gatedgcn_stats_floats(N, d)
+                gws = _E(wsf, **f32)
+                check(L.gps_gatedgcn_fwd_stats(P, P + fs, P + 2 * fs, P + 3 * fs, ldp, ptr(ce), ptr(gi.rowptr_dst),
+                                               ptr(gi.src_by_dst), ptr(gi.eid_by_dst), N, E, d, ptr(xt), ptr(eh),
+                                               None, ref(bnx), ref(bne), ptr(gws), wsf, sync.site(_S_GG), st),
+                      "gps_gatedgcn_fwd_stats")
+            else:
+                check(L.gps_gatedgcn_fwd(P, P + fs, P + 2 * fs, P + 3 * fs, ldp, ptr(ce), ptr(gi.rowptr_dst),
+                                         ptr(gi.src_by_dst), ptr(gi.eid_by_dst), N, E, d, ptr(xt), ptr(eh),
+                                         None, st), "gps_gatedgcn_fwd")
+                _norm.fwd([_norm.fwd_task(_norm.LOAD, xt, N, stats=bnx), _norm.fwd_task(_norm.LOAD, eh, E, stats=bne)],
+                          d, dev, sync.site(_S_XE))
+            return xt, eh
+
+        # Single-stream order (GPS_GG_FIRST, default 1): the GatedGCN core directly behind the merged projection that
+        # wrote its four operands (and one launch behind the C projection), while they are still in the L2s / Infinity
+        # Cache; the attention half, whose operands are 3/7 of the same buffer, follows.
+        gg_first = _GG_FIRST and _BRANCH == "0"
+        if gg_first:
+            xt, eh = local_half()
         # -- global branch (forked): varlen attention over the PRE-layer x (gps_layer.py:199-201,234-241)
         with _Fork(dev, _BRANCH) as fork:
             sb = current_stream(dev)
@@ -354,21 +379,8 @@ class _GPSBlock(torch.autograd.Function):
                 za = None
                 ao = (_gemm.gemm_panel(o, imgs[2][0], d, bias=sa.out_proj.bias) if panel
                       else torch.addmm(sa.out_proj.bias, o, sa.out_proj.weight.t()))
-        # -- local branch: GatedGCN core ---------------------------------------------------------
-        xt, eh = _E(N, d, **f32), _E(E, d, **f32)
-        if _GG_STATS:           # statistics of x~ (bn_node_x) and e^ (bn_edge_e) fall out of the same launch
-            wsf = L.gps_gatedgcn_stats_floats(N, d)
-            gws = _E(wsf, **f32)
-            check(L.gps_gatedgcn_fwd_stats(P, P + fs, P + 2 * fs, P + 3 * fs, ldp, ptr(ce), ptr(gi.rowptr_dst),
-                                           ptr(gi.src_by_dst), ptr(gi.eid_by_dst), N, E, d, ptr(xt), ptr(eh),
-                                           None, ref(bnx), ref(bne), ptr(gws), wsf, sync.site(_S_GG), st),
-                  "gps_gatedgcn_fwd_stats")
-        else:
-            check(L.gps_gatedgcn_fwd(P, P + fs, P + 2 * fs, P + 3 * fs, ldp, ptr(ce), ptr(gi.rowptr_dst),
-                                     ptr(gi.src_by_dst), ptr(gi.eid_by_dst), N, E, d, ptr(xt), ptr(eh),
-                                     None, st), "gps_gatedgcn_fwd")
-            _norm.fwd([_norm.fwd_task(_norm.LOAD, xt, N, stats=bnx), _norm.fwd_task(_norm.LOAD, eh, E, stats=bne)],
-                      d, dev, sync.site(_S_XE))
+        if not gg_first:
+            xt, eh = local_half()
         # -- x1 = x + drop(relu(BN_x(xt))) [+ statistics -> norm1_local], e1 = e + drop(relu(BN_e(eh))),
         #    za = x + drop(ao) [+ statistics -> norm1_attn] unless the out-projection already produced it -- in which case
         #    this launch needs nothing from the attention half and the join moves behind it (a cross-stream dependency

@@ -84,10 +84,12 @@ class TrainStep:
         # step then finds them, autograd routes the gradient accumulation through the default stream, the null stream
         # joins the capture and hipStreamEndCapture segfaults (rocgdb: hip::Stream::EndCapture, recursing into the parallel
         # capture stream; tools/capture_probe.py reproduces it with one line: keep the last eager batch alive).
+        # (tensor attributes, and containers of tensors: the ogb_code_graph head leaves ``batch.pred_list``, a list of five
+        # graph-attached predictions -- the code2 bench segfaulted in its capture after the host-batch leg over exactly that)
         for k in DeviceLoader._keys(batch):
             v = getattr(batch, k, None)
-            if torch.is_tensor(v) and v.grad_fn is not None:
-                setattr(batch, k, v.detach())
+            if _graph_attached(v):
+                setattr(batch, k, _detached(v))
         return loss.detach(), _detached(pred_score), _detached(true)
 
     def reduce(self) -> None:
@@ -295,6 +297,16 @@ def _cloned(obj):
 
 
 LOGGER_FLUSH_EVERY = 16     # iterations between device->host reads for the logger (one sync per flush)
+
+
+def _graph_attached(obj) -> bool:
+    if torch.is_tensor(obj):
+        return obj.grad_fn is not None
+    if isinstance(obj, (list, tuple)):
+        return any(_graph_attached(o) for o in obj)
+    if isinstance(obj, dict):
+        return any(_graph_attached(o) for o in obj.values())
+    return False
 
 
 def _detached(obj):

@@ -151,6 +151,35 @@ def test_train_step_hipgraph_replay_equals_eager():
         assert abs(a - c) <= 1e-6 * max(abs(a), 1.0), runs
 
 
+@pytest.mark.gpu
+def test_eager_step_leaves_no_graph_attached_batch_attribute_code2():
+    """A batch object that outlives its eager step must not pin the step's autograd graph: the next capture would find
+    the graph's AccumulateGrad nodes on the default stream and hipStreamEndCapture segfaults (train.py:forward_backward).
+    The ogb_code_graph head leaves a LIST of graph-attached predictions on the batch (``batch.pred_list``): containers
+    are scrubbed like tensors.  Then the capture itself, with the eager batch still held."""
+    import os
+    import graphgps_amd as g
+    from graphgps_amd.loss.losses import compute_loss
+    from graphgps_amd.optim import FlatAdamW
+    from graphgps_amd.synthetic import model_batch
+    from graphgps_amd.train import TrainStep, _graph_attached
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = g.create_model(os.path.join(g.CONFIG_DIR, "code2_gps.yaml"),
+                           ["gt.layers", 2, "gt.dropout", 0.0, "gt.attn_dropout", 0.0], 2, 5002).to(dev).train()
+    opt = FlatAdamW(model.parameters(), lr=1e-4, weight_decay=0.0, max_grad_norm=1.0)
+    ts = TrainStep(model, opt, loss_fn=compute_loss)
+    b = model_batch("code2", 4, seed=3).to(dev)
+    held = b.clone()
+    ts.run_eager(held)                                   # on the default stream, batch kept alive
+    assert hasattr(held, "pred_list")
+    bad = [k for k in held.keys() if _graph_attached(getattr(held, k, None))]
+    assert not bad, bad
+    ts.capture(b.clone, warmup=1)
+    l1 = float(ts(b.clone()))
+    assert l1 == l1
+
+
 def test_step_cached_replays_across_batch_shapes_like_eager():
     """TrainStep.step_cached (what train_epoch runs): loader batches of THREE different shapes in rotation, every step
     after a shape's second appearance replayed from that shape's captured hipGraph (static input buffers refreshed by one
