@@ -13,6 +13,8 @@ Mirrors, with identical parameter names:
     (graphgps/network/gps_model.py:27-46) -- note the reference applies it to ``batch.x`` for the
     edge case as well; kept.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -22,18 +24,50 @@ from ..graphgym.register import (node_encoder_dict, register_edge_encoder,
 from ..synthetic import ATOM_FEATURE_DIMS, BOND_FEATURE_DIMS
 
 
+class _MultihotMM(torch.autograd.Function):
+    """``multihot @ table`` whose weight gradient ``multihot^T @ g`` -- a [V, R] x [R, emb] product with R = every node /
+    edge of the batch and a handful of output rows -- runs on the split-K weight-gradient kernel (csrc/wgrad.hip:
+    deterministic, fp32-exact products) instead of a library GEMM that leaves most of the chip idle on this shape."""
+
+    @staticmethod
+    def forward(ctx, multihot, table):
+        ctx.save_for_backward(multihot)
+        return multihot @ table
+
+    @staticmethod
+    def backward(ctx, g):
+        from ..fused import _param_grads
+        (multihot,) = ctx.saved_tensors
+        g_w, _ = _param_grads(multihot, g.contiguous(), True, False)
+        return None, g_w
+
+
+_MULTIHOT_WGRAD = os.environ.get("GPS_MULTIHOT_WGRAD", "1") != "0"
+
+
 def _multihot_embedding(feats, embs, owner):
     """Sum over the columns of ``feats`` [R, k] of ``embs[i](feats[:, i])`` as ONE [R, sum(vocab)] x [sum(vocab), emb]
     GEMM over a multi-hot matrix (small vocabularies only).  The point is the backward: grad_W = multihot^T @ g is a
-    deterministic GEMM instead of k sort-based ``embedding_dense_backward`` pipelines."""
+    deterministic GEMM instead of k sort-based ``embedding_dense_backward`` pipelines.  The vocabulary axis is padded to
+    a multiple of 4 (zero columns / zero table rows) so that the weight-gradient kernel takes it."""
     offs = getattr(owner, "_offsets", None)
     if offs is None or offs.device != feats.device:
         sizes = [e.num_embeddings for e in embs]
         offs = torch.tensor([sum(sizes[:i]) for i in range(len(sizes))], device=feats.device)
         owner._offsets, owner._vocab = offs, sum(sizes)
-    multihot = torch.zeros(feats.shape[0], owner._vocab, dtype=embs[0].weight.dtype, device=feats.device)
+    vocab = owner._vocab
+    vpad = -(-vocab // 4) * 4
+    w = embs[0].weight
+    multihot = torch.zeros(feats.shape[0], vpad, dtype=w.dtype, device=feats.device)
     multihot.scatter_(1, feats + offs, 1.0)
-    return multihot @ torch.cat([e.weight for e in embs], dim=0)
+    tables = [e.weight for e in embs]
+    if vpad != vocab:
+        tables.append(w.new_zeros(vpad - vocab, w.shape[1]))
+    table = torch.cat(tables, dim=0)
+    if (_MULTIHOT_WGRAD and feats.is_cuda and torch.is_grad_enabled() and w.dtype == torch.float32
+            and w.shape[1] % 4 == 0 and feats.shape[0] >= 256):
+        return _MultihotMM.apply(multihot, table)
+    return multihot @ table
 
 
 class _OGBFeatureEncoder(nn.Module):

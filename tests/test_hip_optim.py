@@ -159,7 +159,7 @@ def test_eager_step_leaves_no_graph_attached_batch_attribute_code2():
     are scrubbed like tensors.  Then the capture itself, with the eager batch still held."""
     import os
     import graphgps_amd as g
-    from graphgps_amd.loss.losses import compute_loss
+    from graphgps_amd.loss.losses import subtoken_cross_entropy      # custom_train.py:24-25: code2 bypasses compute_loss
     from graphgps_amd.optim import FlatAdamW
     from graphgps_amd.synthetic import model_batch
     from graphgps_amd.train import TrainStep, _graph_attached
@@ -168,7 +168,7 @@ def test_eager_step_leaves_no_graph_attached_batch_attribute_code2():
     model = g.create_model(os.path.join(g.CONFIG_DIR, "code2_gps.yaml"),
                            ["gt.layers", 2, "gt.dropout", 0.0, "gt.attn_dropout", 0.0], 2, 5002).to(dev).train()
     opt = FlatAdamW(model.parameters(), lr=1e-4, weight_decay=0.0, max_grad_norm=1.0)
-    ts = TrainStep(model, opt, loss_fn=compute_loss)
+    ts = TrainStep(model, opt, loss_fn=subtoken_cross_entropy)
     b = model_batch("code2", 4, seed=3).to(dev)
     held = b.clone()
     ts.run_eager(held)                                   # on the default stream, batch kept alive
