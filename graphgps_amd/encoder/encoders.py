@@ -42,7 +42,9 @@ class _MultihotMM(torch.autograd.Function):
         return None, g_w
 
 
-_MULTIHOT_WGRAD = os.environ.get("GPS_MULTIHOT_WGRAD", "1") != "0"
+# off by default: measured neutral in the pcqm4m step (10.03 vs 10.05 ms, same box, replayed) -- the two library GEMMs it
+# replaces are ~35 us each after TunableOp, the split-K launch + its reduce + the stream hand-over cost about the same
+_MULTIHOT_WGRAD = os.environ.get("GPS_MULTIHOT_WGRAD", "0") != "0"
 
 
 def _multihot_embedding(feats, embs, owner):
