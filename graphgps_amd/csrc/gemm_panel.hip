@@ -357,8 +357,8 @@ constexpr int rg_bp(int nj) { return 64 * nj * BK * 2; }                       /
 constexpr int rg_a_bytes(int mb) { return 64 * mb * BK * 4; }                  // raw fp32 A stage: 8 KB per 64 rows
 constexpr int rg_slot_bytes(int mb, int nj) { return rg_a_bytes(mb) + 3 * rg_bp(nj); }   // NJ = 3: 44 KB (64 rows) / 52 KB (128 rows)
 constexpr int rg_lds_bytes(int mb, int nj) { return RG_SLOTS * rg_slot_bytes(mb, nj); }  // NJ = 3: 132 KB / 156 KB
-// Geometry of a [N, K] weight (N = output columns, K = contraction), both multiples of 16:
-//   * k-stages of 32: KS = ceil(K / 32); when K % 32 == 16 the last stage is half empty -- the image holds zeros there
+// Geometry of a [N, K] weight (N = output columns, K = contraction), both multiples of 4:
+//   * k-stages of 32: KS = ceil(K / 32); when K % 32 != 0 the last stage is partly empty -- the image holds zeros there
 //     and the A operand re-reads valid columns (EDGE kernels), so the padding contributes exact zeros;
 //   * column panels of 64 * nj: the widest of 192 / 128 / 64 that divides N (192 only with k-stages in threes: its kernel
 //     is the round-2 schedule, unchanged, without the left-over stages of the general rotation); when none divides N
@@ -542,8 +542,8 @@ __device__ __forceinline__ void ring_stats(const PanelArgs& P, int rt, int panel
 // 6 NJ MFMAs, so NJ = 1 is VALU-bound -- it serves the small widths, where the launches are latency-bound anyway).
 // Any number of k-stages >= 1: the static three-slot rotation runs in threes, the one or two stages left over reuse the
 // first slots of the rotation; DMA past the last stage re-fetches the last one (never read).
-// EDGE: N need not be a whole number of panels (ring_store) and K may end half a stage early -- the last
-// stage's A transfers then re-read the row's valid half (finite values, multiplied by the zeros the image holds there).
+// EDGE: N need not be a whole number of panels (ring_store) and K may end inside a stage -- the last stage's A transfers
+// past K then re-read the stage's first chunk (finite values, multiplied by the zeros the image holds there).
 template <int MB, int NJ, int EPI, bool HAS_CIN, bool EDGE = false>
 __global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring(const PanelArgs P) {
   constexpr int TNV = 64 * NJ;                  // panel columns
@@ -576,14 +576,14 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring(const PanelArgs P) {
   // lane & 7), which fetches source chunk pos ^ ((row >> 1) & 7).  Rows past M re-read row M-1 (never stored).
   const unsigned char* a_src[NA];
   int a_tail[NA];           // EDGE: byte offset to subtract in the last stage so that a chunk past K re-reads a valid one
-  const bool ktail = EDGE && (P.K % BK) != 0;
+  const int nvc = EDGE ? (P.K - (KS - 1) * BK) / 4 : 8;     // valid 16-byte chunks of the last stage (K % 4 == 0)
 #pragma unroll
   for (int i = 0; i < NA; ++i) {
     const int row = 8 * NA * wave + 8 * i + (lane >> 3);
     const int c = (lane & 7) ^ ((row >> 1) & 7);
     const int64_t grow = min(m0 + row, P.M - 1);
     a_src[i] = reinterpret_cast<const unsigned char*>(P.A + grow * P.lda) + c * 16;
-    a_tail[i] = (ktail && c >= 4) ? 64 : 0;
+    a_tail[i] = (EDGE && c >= nvc) ? c * 16 : 0;             // -> chunk 0 of that stage (always valid)
   }
   // W: per piece 4 NJ blocks of 16 rows x 64 B; wave w moves blocks NJ w .. NJ w + NJ - 1 of every piece (NW instructions).
   // lane -> (row lane >> 2 of the block, position lane & 3) fetching chunk pos ^ ((row >> 2) & 3)
@@ -792,8 +792,8 @@ int gps_gemm_panel_trace(unsigned long long* buf) { g_panel_trace = buf; return 
 size_t gps_gemm_image_elems(int64_t N, int64_t K) { return N > 0 && K > 0 ? (size_t)(3 * rg_npad(N, K) * rg_kpad(K)) : 0; }
 
 // the ring kernel: column panels of 192 / 128 / 64 (the last one partial when none divides N), any number of 32-wide
-// k-stages (the last one half empty when K % 32 == 16)
-int gps_gemm_panel_supported(int64_t N, int64_t K) { return N > 0 && K > 0 && N % 16 == 0 && K % 16 == 0; }
+// k-stages (the last one partly empty when K % 32 != 0); N and K multiples of 4 (16-byte rows / chunks)
+int gps_gemm_panel_supported(int64_t N, int64_t K) { return N > 0 && K > 0 && N % 4 == 0 && K % 4 == 0; }
 
 int gps_gemm_split_weights(int n, const gps_gemm_split* descs, gps_stream_t stream) {
   GPS_REQUIRE(n >= 1 && n <= kMaxSplit && descs, "gps_gemm_split_weights: 1..%d weights per launch", kMaxSplit);
@@ -805,9 +805,9 @@ int gps_gemm_split_weights(int n, const gps_gemm_split* descs, gps_stream_t stre
     GPS_REQUIRE(d.W && d.rows > 0 && d.cols > 0 && d.ldw >= d.cols && d.cols % 4 == 0 && d.ldw % 4 == 0 && al16(d.W),
                 "gps_gemm_split_weights: weight %d: bad shape / alignment", i);
     GPS_REQUIRE(!d.image_nt || (gps_gemm_panel_supported(d.rows, d.cols) && al16(d.image_nt)),
-                "gps_gemm_split_weights: weight %d: rows, cols %% 16", i);
+                "gps_gemm_split_weights: weight %d: rows, cols %% 4", i);
     GPS_REQUIRE(!d.image_tn || (gps_gemm_panel_supported(d.cols, d.rows) && al16(d.image_tn)),
-                "gps_gemm_split_weights: weight %d: rows, cols %% 16", i);
+                "gps_gemm_split_weights: weight %d: rows, cols %% 4", i);
     G.d[i] = SplitDesc{d.W, d.ldw, d.rows, d.cols, d.image_nt, d.image_tn, blocks,
                        (int)rg_npad(d.rows, d.cols), (int)rg_kpad(d.cols), (int)rg_npad(d.cols, d.rows), (int)rg_kpad(d.rows)};
     blocks += ((d.rows + ST_R - 1) / ST_R) * ((d.cols + ST_C - 1) / ST_C);
@@ -855,7 +855,7 @@ static int panel_launch(const float* A, int64_t lda, int64_t M, int K, const uin
                         const float* Cin, int64_t ldcin, float* C, int64_t ldc, int epilogue, const float* mask_src,
                         int64_t ldmask, float p_drop, uint64_t seed, const gps_bn* stats, float* ws, size_t ws_floats,
                         uint32_t* sync, gps_stream_t stream) {
-  GPS_REQUIRE(M >= 0 && gps_gemm_panel_supported(N, K), "gps_gemm_panel: needs N %% 16 == 0 and K %% 16 == 0 (N=%d K=%d)",
+  GPS_REQUIRE(M >= 0 && gps_gemm_panel_supported(N, K), "gps_gemm_panel: needs N %% 4 == 0 and K %% 4 == 0 (N=%d K=%d)",
               N, K);
   if (M == 0) return GPS_OK;
   GPS_REQUIRE(A && image && C && lda >= K && ldc >= N && lda % 4 == 0 && al16(A) && al16(image),

@@ -6,8 +6,8 @@ weight by ``split_weights`` -- once per layer and forward (the weights change un
 torch's version counters do not see, so nothing is cached across calls: ~10 us per layer for the five weights of a
 block, both images; callers that never run an input gradient pass ``tn=False``).  Replaces ``torch.addmm`` / ``mm`` (rocBLAS / hipBLASLt) for the projections of
 ``/root/reference/graphgps/layer/gatedgcn_layer.py:57-61`` and ``graphgps/layer/gps_layer.py:104-106,143-144,253-257``
-where the shape qualifies (N % 16 == 0, K % 16 == 0: every ``dim_hidden`` the reference's configs use -- 384, 304,
-256, 96, 64, 48, ...; widths that are not whole 64-column panels / 32-wide k-stages run the kernel's EDGE variants over a
+where the shape qualifies (N % 4 == 0, K % 4 == 0: every ``dim_hidden`` the reference's configs use -- 384, 304, 256,
+96, 72, 64, 52, 48; widths that are not whole 64-column panels / 32-wide k-stages run the kernel's EDGE variants over a
 padded image); everything else stays on the libraries.
 """
 from __future__ import annotations
@@ -26,8 +26,8 @@ MAX_SPLIT = 56      # csrc/gemm_panel.hip kMaxSplit
 
 def supported(N: int, K: int) -> bool:
     """Shapes the ring kernel tiles: column panels of 192 / 128 / 64 (the last one may be partial), 32-wide k-stages
-    (the last one may be half empty)."""
-    return ENABLED and N > 0 and K > 0 and N % 16 == 0 and K % 16 == 0
+    (the last one may be partly empty)."""
+    return ENABLED and N > 0 and K > 0 and N % 4 == 0 and K % 4 == 0
 
 
 _stats_ok = {}

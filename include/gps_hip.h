@@ -201,10 +201,10 @@ int gps_edge_attn_bwd(const float* g_wv, const float* g_z, const float* Q, const
  * whole column panels; the split kernel writes zeros into the k padding) produced from the fp32
  * weight by gps_gemm_split_weights -- once per optimizer step, for the weight (`image_nt`: B[n][k] = W[n][k],
  * forward) and/or its transpose (`image_tn`: B[n][k] = W[k][n], input gradient); gps_gemm_image_elems(N, K)
- * uint16 elements each (padding included).  Shapes: N % 16 == 0 and K % 16 == 0 (gps_gemm_panel_supported: column
- * panels of 192, 128 or 64, any number of 32-wide k-stages; when no panel width divides N or K % 32 == 16 -- d = 304,
- * 96, 48 -- the EDGE variants compute the surplus columns without storing them and multiply the half-empty last stage
- * by the image's zeros); anything else stays on the library GEMMs.  gps_gemm_panel_stats additionally needs whole
+ * uint16 elements each (padding included).  Shapes: N % 4 == 0 and K % 4 == 0 (gps_gemm_panel_supported: column
+ * panels of 192, 128 or 64, any number of 32-wide k-stages; when no panel width divides N or K % 32 != 0 -- d = 304,
+ * 96, 72, 52, 48 -- the EDGE variants compute the surplus columns without storing them and multiply the partly empty
+ * last stage by the image's zeros); anything else stays on the library GEMMs.  gps_gemm_panel_stats additionally needs whole
  * panels and stages (gps_gemm_stats_supported).
  * epilogue: 0 none | 1 relu then dropout(p_drop, seed) keyed (row, column) like gps_act_drop_add
  *           | 2 multiply by the relu/dropout mask of `mask_src` (= gps_act_drop_bwd applied to the product).

@@ -91,6 +91,25 @@ def test_c_abi_exports_every_declared_symbol():
     assert L.gps_attn_supported_head_dim(24) == 1 and L.gps_attn_supported_head_dim(7) == 0
 
 
+def test_ring_gemm_geometry_covers_every_reference_width():
+    """Host-side geometry of csrc/gemm_panel.hip (no GPU involved): the ring GEMM takes every ``dim_hidden`` of the
+    reference's configs/GPS/*.yaml (48, 52, 64, 72, 96, 256, 304, 384) in all five projection shapes of a block, the
+    image is padded to whole column panels / k-stages, and the statistics epilogue is offered for whole panels only."""
+    from graphgps_amd import lib
+    L = lib.load()
+    for d in (48, 52, 64, 72, 96, 256, 304, 384):
+        for N, K in ((7 * d, d), (d, d), (2 * d, d), (d, 2 * d), (d, 7 * d)):
+            assert L.gps_gemm_panel_supported(N, K) == 1, (N, K)
+            elems = L.gps_gemm_image_elems(N, K)
+            assert elems >= 3 * N * K and elems % (3 * 64 * 32) == 0, (N, K, elems)
+            assert elems <= 3 * (N + 191) * (K + 31), (N, K, elems)          # never more than one panel / stage of padding
+    assert L.gps_gemm_image_elems(384, 384) == 3 * 384 * 384                  # whole panels: no padding
+    assert L.gps_gemm_image_elems(304, 304) == 3 * 384 * 320                  # 3 panels of 128 (cheaper than 5 of 64), 9.5 -> 10 stages
+    assert L.gps_gemm_panel_supported(50, 64) == 0 and L.gps_gemm_panel_supported(64, 0) == 0
+    assert L.gps_gemm_stats_supported(7569, 384, 384) == 1 and L.gps_gemm_stats_supported(7569, 304, 304) == 0
+    assert L.gps_gemm_stats_floats(7569, 304, 304) == 0
+
+
 def test_product_path_has_no_cpu_fallback():
     import graphgps_amd as g
     from graphgps_amd.lib import GpsHipError

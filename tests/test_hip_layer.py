@@ -110,6 +110,7 @@ def _oracle_layer_like(layer):
     ("CustomGatedGCN", "Transformer", 304, 4, "P30", 256),    # pcqm4m-GPS.yaml (GPS-small): 4.75 column panels, 9.5 k-stages
     ("CustomGatedGCN", "Transformer", 304, 4, "P14", 128),
     ("CustomGatedGCN", "Transformer", 96, 4, "P30", 64),      # peptides-*-GPS.yaml width: 1.5 panels
+    ("CustomGatedGCN", "Transformer", 52, 4, "P30", 64),      # a width that is a multiple of 4 only (dh = 13)
 ])
 def test_gpslayer_vs_oracle_baseline_sizes(local, glob, d, H, profile, nb):
     from graphgps_amd.layer.gps_layer import GPSLayer

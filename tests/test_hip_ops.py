@@ -700,7 +700,9 @@ def test_gin_aggregate_matches_index_add():
                                    # (d = 304: GPS-small PCQM4Mv2 / peptides; 96, 48, 16: narrow configs)
                                    (7569, 304, 2128), (7569, 2128, 304), (2000, 304, 304), (2000, 304, 608),
                                    (2000, 608, 304), (1000, 304, 1216), (743, 96, 672), (743, 96, 96), (743, 48, 48),
-                                   (300, 48, 336), (130, 16, 16), (500, 384, 80), (500, 80, 384)])
+                                   (300, 48, 336), (130, 16, 16), (500, 384, 80), (500, 80, 384),
+                                   # N, K multiples of 4 only (d = 52: ZINC GPS-small variants, 72: peptides SAN/GPS)
+                                   (500, 52, 364), (500, 364, 52), (743, 72, 72), (300, 52, 52), (500, 20, 36)])
 def test_gemm_panel_fp32_exact_products(M, K, N):
     """csrc/gemm_panel.hip at the block's projection shapes (N, K in {384, 768, 2688}; M = nodes / edges, ragged last
     row tile): C = A W^T + bias against fp64, through the weight image (forward) and through the transposed image
