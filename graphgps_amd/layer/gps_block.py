@@ -60,6 +60,60 @@ def _count_batches(counters):
         torch._foreach_add_(counters, 1)
 
 
+class _Refs:
+    """The submodules and parameters of one CustomGatedGCN + Transformer layer, looked up once: ``nn.Module.__getattr__``
+    costs ~0.3 us per access and the block touched ~140 of them per layer and step (1.4k per step, 0.7 ms of host time
+    forward + backward).  Parameters and modules are cached by identity (``p.data`` may be re-pointed by an arena, the
+    Parameter object stays); ``valid`` notices a replaced submodule."""
+    __slots__ = ("lm", "sa", "A", "B", "D", "E", "C", "out_proj", "ff1", "ff2", "bnx", "bne", "bnl", "bna", "bn2",
+                 "drop_attn", "ff_drop1", "ff_drop2", "params", "_ids")
+
+    def __init__(self, layer):
+        m = layer._modules
+        self.lm, self.sa = m["local_model"], m["self_attn"]
+        lmm = self.lm._modules
+        self.A, self.B, self.D, self.E, self.C = lmm["A"], lmm["B"], lmm["D"], lmm["E"], lmm["C"]
+        self.out_proj = self.sa._modules["out_proj"]
+        self.ff1, self.ff2 = m["ff_linear1"], m["ff_linear2"]
+        self.bnx, self.bne = lmm["bn_node_x"], lmm["bn_edge_e"]
+        self.bnl, self.bna, self.bn2 = m["norm1_local"], m["norm1_attn"], m["norm2"]
+        self.drop_attn, self.ff_drop1, self.ff_drop2 = m["dropout_attn"], m["ff_dropout1"], m["ff_dropout2"]
+        W, Bv = (lambda mod: mod._parameters["weight"]), (lambda mod: mod._parameters["bias"])
+        self.params = [W(self.A), W(self.B), W(self.D), W(self.E), Bv(self.A), Bv(self.B), Bv(self.D), Bv(self.E),
+                       W(self.C), Bv(self.C), W(self.bnx), Bv(self.bnx), W(self.bne), Bv(self.bne),
+                       W(self.bnl), Bv(self.bnl), self.sa._parameters["in_proj_weight"],
+                       self.sa._parameters["in_proj_bias"], W(self.out_proj), Bv(self.out_proj),
+                       W(self.bna), Bv(self.bna), W(self.ff1), Bv(self.ff1), W(self.ff2), Bv(self.ff2),
+                       W(self.bn2), Bv(self.bn2)]
+        self._ids = self._snapshot(layer)
+
+    @staticmethod
+    def _snapshot(layer):
+        m = layer._modules
+        lm, sa = m["local_model"], m["self_attn"]
+        mods = (lm, sa, m["ff_linear1"], m["ff_linear2"], m["norm1_local"], m["norm1_attn"], m["norm2"],
+                lm._modules["C"], lm._modules["bn_node_x"], lm._modules["bn_edge_e"], sa._modules["out_proj"])
+        return tuple(id(x) for x in mods) + tuple(id(x._parameters.get("weight")) for x in mods[2:])
+
+    def valid(self, layer) -> bool:
+        return self._ids == self._snapshot(layer)
+
+
+def _refs(layer) -> _Refs:
+    r = layer.__dict__.get("_blk_refs")
+    if r is None or not r.valid(layer):
+        r = layer.__dict__["_blk_refs"] = _Refs(layer)
+    return r
+
+
+def _W(mod):
+    return mod._parameters["weight"]
+
+
+def _B(mod):
+    return mod._parameters["bias"]
+
+
 def _ensure_xgroup(layer):
     from ..fused import LinearGroup
     lm, sa = layer.local_model, layer.self_attn
@@ -88,8 +142,8 @@ def stack_begin(layers, batch) -> bool:
         if not (_gemm.supported(d, d) and _gemm.supported(2 * d, d) and _gemm.supported(7 * d, d)):
             continue
         wcat, _ = _ensure_xgroup(layer)
-        lm, sa = layer.local_model, layer.self_attn
-        weights += [wcat, lm.C.weight, sa.out_proj.weight, layer.ff_linear1.weight, layer.ff_linear2.weight]
+        R = _refs(layer)
+        weights += [wcat, _W(R.C), _W(R.out_proj), _W(R.ff1), _W(R.ff2)]
         owners.append(layer)
     if owners:
         imgs = _gemm.split_weights(weights)
@@ -297,14 +351,15 @@ class _GPSBlock(torch.autograd.Function):
         L = _lib.load()
         dev = x.device
         st = current_stream(dev)
-        lm, sa = layer.local_model, layer.self_attn
+        R = _refs(layer)
+        lm, sa = R.lm, R.sa
         N, d = x.shape
         E = e.shape[0]
         H = layer.num_heads
         dh = d // H
         p = float(lm.dropout)
-        p_l = float(layer.dropout_attn.p)
-        p_f1, p_f2 = float(layer.ff_dropout1.p), float(layer.ff_dropout2.p)
+        p_l = float(R.drop_attn.p)
+        p_f1, p_f2 = float(R.ff_drop1.p), float(R.ff_drop2.p)
         p_at = float(layer.attn_dropout)
         s = [(seed + 0x9E3779B97F4A7C15 * (i + 1)) & 0xFFFFFFFFFFFFFFFF for i in range(7)]
         f32 = dict(dtype=torch.float32, device=dev)
@@ -321,22 +376,22 @@ class _GPSBlock(torch.autograd.Function):
         if panel:       # weight images of the block's five projections (W and W^T): made for the whole stack at once
             imgs = layer.__dict__.pop("_presplit", None)        # (stack_begin), else ONE launch per layer and step
             if imgs is None:
-                imgs = _gemm.split_weights([wcat, lm.C.weight, sa.out_proj.weight, layer.ff_linear1.weight,
-                                            layer.ff_linear2.weight])
-            ce = _gemm.gemm_panel(e, imgs[1][0], d, bias=lm.C.bias)
+                imgs = _gemm.split_weights([wcat, _W(R.C), _W(R.out_proj), _W(R.ff1),
+                                            _W(R.ff2)])
+            ce = _gemm.gemm_panel(e, imgs[1][0], d, bias=_B(R.C))
             pq = _gemm.gemm_panel(x, imgs[0][0], 7 * d, bias=bcat)
         else:
-            ce = torch.addmm(lm.C.bias, e, lm.C.weight.t())
+            ce = torch.addmm(_B(R.C), e, _W(R.C).t())
             pq = torch.addmm(bcat, x, wcat.t())                 # [N, 4d + 3d]
         ldp = 7 * d
         P, fs = pq.data_ptr(), d * 4
         # -- the five BatchNorms: descriptors over one [10, d] statistics buffer ----------------------------
         stats = _E(10, d, **f32)                                # (mean, rstd) x 5
-        bnx = _bn_desc(lm.bn_node_x, stats[0], stats[1])
-        bne = _bn_desc(lm.bn_edge_e, stats[2], stats[3])
-        bnl = _bn_desc(layer.norm1_local, stats[4], stats[5])
-        bna = _bn_desc(layer.norm1_attn, stats[6], stats[7])
-        bn2 = _bn_desc(layer.norm2, stats[8], stats[9])
+        bnx = _bn_desc(R.bnx, stats[0], stats[1])
+        bne = _bn_desc(R.bne, stats[2], stats[3])
+        bnl = _bn_desc(R.bnl, stats[4], stats[5])
+        bna = _bn_desc(R.bna, stats[6], stats[7])
+        bn2 = _bn_desc(R.bn2, stats[8], stats[9])
         ref = _BY_REF
         sync = _norm.sync_arena(layer, dev)
         gemm_stats = panel and _GEMM_STATS and _gemm.stats_supported(N, d, d) and _gemm.stats_supported(N, d, 2 * d)
@@ -374,11 +429,11 @@ class _GPSBlock(torch.autograd.Function):
                                      gi.B, int(gi.nmax_host), sb), "gps_seg_attn_fwd")
             if gemm_stats:      # za = x + drop(out_proj(o)) and the statistics of za (norm1_attn) in the GEMM's epilogue
                 ao = None
-                za = _gemm.gemm_panel_stats(o, imgs[2][0], d, sa.out_proj.bias, x, p_l, s[3], bna, sync.site(_S_AO))
+                za = _gemm.gemm_panel_stats(o, imgs[2][0], d, _B(R.out_proj), x, p_l, s[3], bna, sync.site(_S_AO))
             else:
                 za = None
-                ao = (_gemm.gemm_panel(o, imgs[2][0], d, bias=sa.out_proj.bias) if panel
-                      else torch.addmm(sa.out_proj.bias, o, sa.out_proj.weight.t()))
+                ao = (_gemm.gemm_panel(o, imgs[2][0], d, bias=_B(R.out_proj)) if panel
+                      else torch.addmm(_B(R.out_proj), o, _W(R.out_proj).t()))
         if not gg_first:
             xt, eh = local_half()
         # -- x1 = x + drop(relu(BN_x(xt))) [+ statistics -> norm1_local], e1 = e + drop(relu(BN_e(eh))),
@@ -401,23 +456,23 @@ class _GPSBlock(torch.autograd.Function):
         # -- FFN + norm2 (gps_layer.py:225-229,253-257) ----------------------------------------
         if panel:       # t = drop(relu(ff1(h))) in the GEMM's epilogue: f1 is never materialised
             f1 = None
-            t = _gemm.gemm_panel(h, imgs[3][0], 2 * d, bias=layer.ff_linear1.bias, epilogue=1, p_drop=p_f1, seed=s[4])
+            t = _gemm.gemm_panel(h, imgs[3][0], 2 * d, bias=_B(R.ff1), epilogue=1, p_drop=p_f1, seed=s[4])
         else:
-            f1 = torch.addmm(layer.ff_linear1.bias, h, layer.ff_linear1.weight.t())
+            f1 = torch.addmm(_B(R.ff1), h, _W(R.ff1).t())
             t = _K.act_drop_add(L, None, f1, True, p_f1, s[4], st)
         if gemm_stats:  # z2 = h + drop(ff2(t)) and the statistics of z2 (norm2) in the GEMM's epilogue
-            z2 = _gemm.gemm_panel_stats(t, imgs[4][0], d, layer.ff_linear2.bias, h, p_f2, s[5], bn2, sync.site(_S_Z2))
+            z2 = _gemm.gemm_panel_stats(t, imgs[4][0], d, _B(R.ff2), h, p_f2, s[5], bn2, sync.site(_S_Z2))
         else:
-            f2 = (_gemm.gemm_panel(t, imgs[4][0], d, bias=layer.ff_linear2.bias) if panel
-                  else torch.addmm(layer.ff_linear2.bias, t, layer.ff_linear2.weight.t()))
+            f2 = (_gemm.gemm_panel(t, imgs[4][0], d, bias=_B(R.ff2)) if panel
+                  else torch.addmm(_B(R.ff2), t, _W(R.ff2).t()))
             z2 = _E(N, d, **f32)                                # h + drop(f2) and its statistics
             _norm.fwd([_norm.fwd_task(_norm.ADD_DROP, h, N, b=f2, p=p_f2, seed=s[5], out=z2, stats=bn2)], d, dev,
                       sync.site(_S_Z2))
         out = _E(N, d, **f32)
         _norm.fwd([_norm.fwd_task(_norm.BN_ACT, z2, N, bn1=bn2, out=out)], d, dev, None)
-        _count_batches([lm.bn_node_x.num_batches_tracked, lm.bn_edge_e.num_batches_tracked,
-                        layer.norm1_local.num_batches_tracked, layer.norm1_attn.num_batches_tracked,
-                        layer.norm2.num_batches_tracked])
+        _count_batches([R.bnx._buffers["num_batches_tracked"], R.bne._buffers["num_batches_tracked"],
+                        R.bnl._buffers["num_batches_tracked"], R.bna._buffers["num_batches_tracked"],
+                        R.bn2._buffers["num_batches_tracked"]])
 
         ctx.save_for_backward(x, e, pq, eh, xt, x1, o, lse, za, h, f1 if f1 is not None else t, t, z2, stats)
         ctx.layer, ctx.gi, ctx.seeds = layer, gi, s
@@ -431,7 +486,8 @@ class _GPSBlock(torch.autograd.Function):
         x, e, pq, eh, xt, x1, o, lse, za, h, f1, t, z2, stats = ctx.saved_tensors
         layer, gi, s = ctx.layer, ctx.gi, ctx.seeds
         p, p_l, p_f1, p_f2, p_at, H, dh, scale = ctx.cfg
-        lm, sa = layer.local_model, layer.self_attn
+        R = _refs(layer)
+        lm, sa = R.lm, R.sa
         dev = x.device
         st = current_stream(dev)
         N, d = x.shape
@@ -439,17 +495,17 @@ class _GPSBlock(torch.autograd.Function):
         f32 = dict(dtype=torch.float32, device=dev)
         g_out = g_out.contiguous()
         g_e1 = g_e1.contiguous() if g_e1 is not None else torch.zeros(E, d, **f32)
-        bnx = _bn_desc(lm.bn_node_x, stats[0], stats[1])
-        bne = _bn_desc(lm.bn_edge_e, stats[2], stats[3])
-        bnl = _bn_desc(layer.norm1_local, stats[4], stats[5])
-        bna = _bn_desc(layer.norm1_attn, stats[6], stats[7])
-        bn2 = _bn_desc(layer.norm2, stats[8], stats[9])
+        bnx = _bn_desc(R.bnx, stats[0], stats[1])
+        bne = _bn_desc(R.bne, stats[2], stats[3])
+        bnl = _bn_desc(R.bnl, stats[4], stats[5])
+        bna = _bn_desc(R.bna, stats[6], stats[7])
+        bn2 = _bn_desc(R.bn2, stats[8], stats[9])
         sync = _norm.sync_arena(layer, dev)
         gpar = _E(10, d, **f32)              # (g_gamma, g_beta) of the five norms ...
         g_bxw, g_bxb, g_bew, g_beb, g_nlw, g_nlb, g_naw, g_nab, g_n2w, g_n2b = gpar.unbind(0)
         if not _accumulating(block_params(layer)):      # ... or their slots in the optimizer's gradient arena
             from ..optim import grad_slot
-            bns = (lm.bn_node_x, lm.bn_edge_e, layer.norm1_local, layer.norm1_attn, layer.norm2)
+            bns = (R.bnx, R.bne, R.bnl, R.bna, R.bn2)
             slots = [grad_slot(q) for bn in bns for q in (bn.weight, bn.bias)]
             if all(q is not None for q in slots):
                 g_bxw, g_bxb, g_bew, g_beb, g_nlw, g_nlb, g_naw, g_nab, g_n2w, g_n2b = slots
@@ -469,9 +525,9 @@ class _GPSBlock(torch.autograd.Function):
             g_f1 = _gemm.gemm_panel(g_f2, imgs[4][1], 2 * d, epilogue=2, mask_src=t, p_drop=p_f1, seed=s[4])
             g_h = _gemm.gemm_panel(g_f1, imgs[3][1], d, addend=g_z2, out=g_z2)     # residual + FFN input
         else:
-            g_t = g_f2.mm(layer.ff_linear2.weight)
+            g_t = g_f2.mm(_W(R.ff2))
             g_f1 = _K.act_drop_bwd(L, g_t, f1, True, p_f1, s[4], st)
-            g_h = g_z2.addmm_(g_f1, layer.ff_linear1.weight)              # residual + FFN input
+            g_h = g_z2.addmm_(g_f1, _W(R.ff1))              # residual + FFN input
 
         # h = BN_l(x1) + BN_a(za);  za = x + drop(ao):  g_x1, g_x1 + g_za, g_ao = dropmask(g_za).  The apply CHAINS into
         # bn_node_x (x1 = x + drop(relu(BN_x(xt))): g_x1 is that BatchNorm's output gradient): its column sums come out of
@@ -490,7 +546,7 @@ class _GPSBlock(torch.autograd.Function):
         G, P = g_pq.data_ptr(), pq.data_ptr()
         with _Fork(dev, _BRANCH) as fork:            # attention half of the backward
             sb = current_stream(dev)
-            g_o = _gemm.gemm_panel(g_ao, imgs[2][1], d) if imgs is not None else g_ao.mm(sa.out_proj.weight)
+            g_o = _gemm.gemm_panel(g_ao, imgs[2][1], d) if imgs is not None else g_ao.mm(_W(R.out_proj))
             delta = _E(H, N, **f32)
             check(L.gps_seg_attn_bwd(ptr(g_o), P + 4 * fs, ldp, ptr(o), ptr(lse), ptr(gi.ptr),
                                      ptr(gi.tile_graph), ptr(gi.tile_row0), gi.max_tiles, N, H, dh, scale,
@@ -511,8 +567,8 @@ class _GPSBlock(torch.autograd.Function):
         pairs = [(g_pq, x), (g_ce, e), (g_ao, o), (g_f1, h), (g_f2, t)]
         leaves = block_params(layer)
         if _GROUPED_WGRAD:
-            targets = [(wcat, bcat), (lm.C.weight, lm.C.bias), (sa.out_proj.weight, sa.out_proj.bias),
-                       (layer.ff_linear1.weight, layer.ff_linear1.bias), (layer.ff_linear2.weight, layer.ff_linear2.bias)]
+            targets = [(wcat, bcat), (_W(R.C), _B(R.C)), (_W(R.out_proj), _B(R.out_proj)),
+                       (_W(R.ff1), _B(R.ff1)), (_W(R.ff2), _B(R.ff2))]
             ((g_wcat, g_bcat), (g_wc, g_bc), (g_wo, g_bo), (g_w1, g_b1), (g_w2, g_b2)) = \
                 _grouped_param_grads(L, pairs, leaves, targets)
         else:
@@ -523,7 +579,7 @@ class _GPSBlock(torch.autograd.Function):
             g_e = _gemm.gemm_panel(g_ce, imgs[1][1], d, addend=g_e1)
         else:
             g_x = g_xres.addmm_(g_pq, wcat)          # residuals of za and x1 + A..E + in-proj inputs
-            g_e = torch.addmm(g_e1, g_ce, lm.C.weight)   # residual of e1 + C input
+            g_e = torch.addmm(g_e1, g_ce, _W(R.C))   # residual of e1 + C input
         g_wi, g_bi = g_wcat[4 * d:], g_bcat[4 * d:]
 
         abde = [g_wcat[i * d:(i + 1) * d] for i in range(4)] + [g_bcat[i * d:(i + 1) * d] for i in range(4)]
@@ -722,23 +778,29 @@ def block_params(layer):
             layer.norm2.weight, layer.norm2.bias]
 
 
+def _block_static_ok(layer) -> bool:
+    """The part of block_supported that only depends on how the layer was built (cached on the layer)."""
+    import torch.nn as nn
+    ok = layer.__dict__.get("_blk_static")
+    if ok is None:
+        lm = layer.local_model
+        ok = (layer.local_gnn_type == 'CustomGatedGCN' and layer.global_model_type == 'Transformer'
+              and bool(layer.batch_norm) and bool(lm.residual) and not getattr(lm, "EquivStablePE", False)
+              and isinstance(lm.act_fn_x, nn.ReLU) and isinstance(lm.act_fn_e, nn.ReLU)
+              and isinstance(layer.act_fn_ff, nn.ReLU)
+              and all(bn.affine and bn.track_running_stats and bn.momentum is not None
+                      for bn in (lm.bn_node_x, lm.bn_edge_e, layer.norm1_local, layer.norm1_attn, layer.norm2)))
+        layer.__dict__["_blk_static"] = ok
+    return ok
+
+
 def block_supported(layer, x, e=None) -> bool:
     """The single-node path covers the measured configuration: CustomGatedGCN + Transformer,
     BatchNorm, ReLU, training mode with gradients, fp32 on the GPU."""
-    import torch.nn as nn
-    lm = layer.local_model
     if not (layer.training and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32):
         return False
-    if layer.local_gnn_type != 'CustomGatedGCN' or layer.global_model_type != 'Transformer':
+    if not _block_static_ok(layer):
         return False
-    if not layer.batch_norm or not lm.residual or getattr(lm, "EquivStablePE", False):
-        return False
-    if not (isinstance(lm.act_fn_x, nn.ReLU) and isinstance(lm.act_fn_e, nn.ReLU)
-            and isinstance(layer.act_fn_ff, nn.ReLU)):
-        return False
-    for bn in (lm.bn_node_x, lm.bn_edge_e, layer.norm1_local, layer.norm1_attn, layer.norm2):
-        if not (bn.affine and bn.track_running_stats and bn.momentum is not None):
-            return False
     d = x.shape[1]
     if d % 4 != 0 or d > 1024 or x.shape[0] < 2:          # csrc/block_norm.hip row mapping
         return False
@@ -749,4 +811,4 @@ def block_supported(layer, x, e=None) -> bool:
 
 def gps_block(layer, x, e, gi):
     _ensure_xgroup(layer)
-    return _GPSBlock.apply(x, e, layer, gi, draw_dropout_seed(), *block_params(layer))
+    return _GPSBlock.apply(x, e, layer, gi, draw_dropout_seed(), *_refs(layer).params)

@@ -186,4 +186,14 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 
 def current_stream(device: torch.device) -> Optional[int]:
-    return torch.cuda.current_stream(device).cuda_stream
+    """Raw ``hipStream_t`` of torch's current stream on ``device`` (0 = the default stream).  Asked for ~230 times per
+    training step: the raw query is ~0.3 us, ``torch.cuda.current_stream(device).cuda_stream`` builds a Stream object
+    each time (~5 us, 1 ms of host time per step)."""
+    idx = device.index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    return _raw_stream(idx)
+
+
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None) or (
+    lambda idx: torch.cuda.current_stream(idx).cuda_stream)

@@ -48,8 +48,10 @@ def _bn(desc):
 
 def bn_desc(bn, mean, rstd) -> BnDesc:
     """``gps_bn`` descriptor of a BatchNorm1d + the [d] buffers holding its batch statistics."""
-    return BnDesc(bn.weight.data_ptr(), bn.bias.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
-                  bn.running_mean.data_ptr(), bn.running_var.data_ptr(), float(bn.eps), float(bn.momentum))
+    # (straight from the module's dictionaries: nn.Module.__getattr__ is the slow path, and this runs 100 times per step)
+    pr, bf = bn._parameters, bn._buffers
+    return BnDesc(pr["weight"].data_ptr(), pr["bias"].data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                  bf["running_mean"].data_ptr(), bf["running_var"].data_ptr(), float(bn.eps), float(bn.momentum))
 
 
 def fwd_task(kind, a, R, *, b=None, res=None, bn1=None, bn2=None, relu=False, p=0.0, seed=0, out=None, stats=None):
