@@ -13,8 +13,9 @@
 //     BatchNorm backward that consumes that gradient (norm1_local's g_x1 -> bn_node_x's sum g, sum g*zhat), which removes
 //     that BatchNorm's own partial pass;
 //   * the C ABI is a generic task list (gps_norm_fwd / gps_norm_bwd_partial / gps_norm_bwd_apply), composed by the host.
-// Launches per CustomGatedGCN+Transformer layer: forward mid + dual apply + norm2 apply (statistics of x~ / e^ come from
-// the GatedGCN kernel, those of z2 and za from the ring GEMM epilogues), backward 5  =>  8 (round 2: 17).
+// Launches per CustomGatedGCN+Transformer layer: forward statistics of x~ / e^ (a LOAD list; or out of the GatedGCN
+// kernel, gps_gatedgcn_fwd_stats) + mid + dual apply + norm2 apply (the statistics of z2 and za come from the ring GEMM
+// epilogues), backward 5  =>  9, or 8 with the GatedGCN variant (round 2: 17).
 //
 // Row kernels keep the lane-owns-4-channels mapping (d % 4 == 0, d <= 1024): a workgroup is RS rows x d/4 lanes
 // (RS = 512 / (d/4): 384 threads at d = 384), rows of a block are walked RS at a time, two passes in flight.

@@ -10,11 +10,15 @@ lists and the per-operator tests pin).  What that buys:
   * merged GEMMs: A|B|D|E and the attention in-projection as ONE ``[N,d] x [d,7d]`` GEMM (forward, dgrad
     and weight gradient);
   * the norm / residual / dropout stages as task lists (csrc/block_norm.hip) whose column reductions finish
-    inside the producing launch (csrc/col_tree.hpp); the batch statistics of x~ / e^ come out of the GatedGCN
-    forward, those of za / z2 out of the ring GEMM epilogues: 8 norm launches per layer (round 2: 17, the
-    operator path: 37);
-  * all weight gradients of the block as ONE grouped split-K launch on the side stream (csrc/wgrad.hip);
-  * while the step is being captured into a hipGraph, the attention half forks onto its own stream.
+    inside the producing launch (csrc/col_tree.hpp); the batch statistics of za / z2 come out of the ring GEMM
+    epilogues, those of x~ / e^ from one statistics-only launch (or, GPS_GG_STATS=1, out of the GatedGCN forward):
+    9 norm launches per layer (8 with GPS_GG_STATS=1; round 2: 17, the operator path: 37);
+  * all weight gradients of the block as ONE grouped split-K launch (csrc/wgrad.hip) that writes straight into the
+    optimizer's gradient arena;
+  * one stream (round 3 default; GPS_BRANCH_STREAM=1|2 forks the attention half while capturing / always: the ring
+    GEMM owns a CU's whole LDS, so the forked half cannot co-run with it and each fork / join costs ~10 us);
+  * per-step set-up shared by the whole layer stack (stack_begin / stack_end): one weight-image launch, one
+    BatchNorm-counter launch, and the block's submodule / parameter references cached per layer (_Refs).
 
 Reference lines: graphgps/layer/gps_layer.py:155-232, graphgps/layer/gatedgcn_layer.py:45-88.
 """
