@@ -413,3 +413,34 @@ def test_eval_epoch_mirrors_reference_loop_on_cpu():
     for r in log.rows:
         assert r["lr"] == 0 and isinstance(r["loss"], float) and r["pred"].device.type == "cpu"
         assert r["pred"].shape == (5,) and r["true"].shape == (5, 1) or r["true"].shape == (5,)
+
+
+def test_block_reference_cache_and_train_helpers_on_cpu():
+    """Host logic added in round 3 that needs no GPU: the per-layer cache of submodule / parameter references of the
+    fused block (same objects, same order as ``block_params``; a replaced submodule invalidates it), the stack bracket
+    declining CPU batches and the scrub helpers of ``TrainStep.forward_backward``."""
+    import torch.nn as nn
+    from graphgps_amd.layer import gps_block as blk
+    from graphgps_amd.layer.gps_layer import GPSLayer
+    from graphgps_amd.synthetic import model_batch
+    from graphgps_amd.train import _detached, _graph_attached
+    layer = GPSLayer(16, "CustomGatedGCN", "Transformer", 4, dropout=0.1, attn_dropout=0.1)
+    r = blk._refs(layer)
+    assert blk._refs(layer) is r
+    want = blk.block_params(layer)
+    assert len(r.params) == len(want) and all(p is q for p, q in zip(r.params, want))
+    assert r.bnx is layer.local_model.bn_node_x and r.ff2 is layer.ff_linear2 and r.out_proj is layer.self_attn.out_proj
+    layer.ff_linear2 = nn.Linear(32, 16)                  # a replaced submodule: the cache must notice
+    r2 = blk._refs(layer)
+    assert r2 is not r and r2.ff2 is layer.ff_linear2 and r2.params[24] is layer.ff_linear2.weight
+    assert blk._block_static_ok(layer) is True
+    assert blk._block_static_ok(GPSLayer(16, "GINE", "Transformer", 4)) is False
+    b = model_batch("pcqm4m", 4, seed=1)
+    assert blk.stack_begin([layer], b) is False and blk._STACK["active"] is False       # CPU batch: nothing bracketed
+    # scrub helpers
+    w = torch.ones(3, requires_grad=True)
+    y = w * 2
+    assert _graph_attached(y) and _graph_attached([1, (y,)]) and _graph_attached({"a": y})
+    assert not _graph_attached(w) and not _graph_attached([w.detach(), "x", None])
+    d = _detached({"a": [y, 3], "b": (y,)})
+    assert not _graph_attached(d) and d["a"][1] == 3 and torch.equal(d["b"][0], y.detach())

@@ -316,3 +316,28 @@ def test_param_arena_keeps_linear_group_stacks_and_follows_moves():
     assert arena.active.tolist() == [1] * 8 + [0] * 0 or arena.active.tolist()[-1] == 0
     assert float(arena.grad_views[-1].abs().sum()) == 0.0
     assert float(arena.grad_views[0].mean()) == 3.0 and lins[0].weight.grad.data_ptr() == arena.grad_views[0].data_ptr()
+
+
+def test_param_arena_readoption_keeps_aliased_parameters_tied():
+    """Two Parameter objects over ONE range of storage (tied weights) must still alias each other after the arena is
+    rebuilt, also when they already lived in the previous arena: re-adoption re-packs that arena's parameters as runs,
+    and a run must not end between two parameters that overlap (adjacency-only runs copied them apart)."""
+    from graphgps_amd.optim import ParamArena
+    torch.manual_seed(0)
+    a, b, c = torch.nn.Linear(6, 4), torch.nn.Linear(4, 4), torch.nn.Linear(4, 2)
+    tied = torch.nn.Parameter(a.weight.data)              # same storage, same offset, a second Parameter object
+    params = list(a.parameters()) + [tied] + list(b.parameters()) + list(c.parameters())
+    arena = ParamArena(params)
+    assert tied.data_ptr() == a.weight.data_ptr()
+    c.weight.data = c.weight.data.clone()                 # one parameter leaves: the next adopt() rebuilds the arena
+    assert not arena.intact()
+    want = a.weight.detach().clone()
+    arena.adopt()
+    assert arena.intact()
+    assert tied.data_ptr() == a.weight.data_ptr(), "tied parameters were copied apart"
+    assert torch.equal(a.weight, want) and torch.equal(tied, want)
+    with torch.no_grad():
+        a.weight.add_(1.0)
+    assert torch.equal(tied, want + 1.0)
+    lo, hi = arena.flat_p.data_ptr(), arena.flat_p.data_ptr() + arena.flat_p.numel() * 4
+    assert all(lo <= p.data_ptr() < hi for p in params)
