@@ -137,6 +137,15 @@ def stack_begin(layers, batch) -> bool:
     if not (_STACK_PREP and torch.is_tensor(x) and x.is_cuda and torch.is_grad_enabled()) or _STACK["active"]:
         return False
     _STACK["active"], _STACK["nbt"] = True, []
+    try:
+        _STACK["owners"] = _presplit_stack(layers, x)
+    except BaseException:
+        _STACK["active"] = False            # never leave the bracket half open: blocks would defer their counters forever
+        raise
+    return True
+
+
+def _presplit_stack(layers, x):
     weights, owners = [], []
     for layer in layers:
         if not (getattr(layer, "training", False) and getattr(layer, "local_gnn_type", None) == 'CustomGatedGCN'
@@ -153,8 +162,7 @@ def stack_begin(layers, batch) -> bool:
         imgs = _gemm.split_weights(weights)
         for i, layer in enumerate(owners):
             layer.__dict__["_presplit"] = imgs[5 * i:5 * i + 5]
-    _STACK["owners"] = owners
-    return True
+    return owners
 
 
 def stack_end() -> None:

@@ -205,6 +205,8 @@ class TrainStep:
         if ent is None:
             seen = self.__dict__.setdefault("_shape_seen", set())
             if key not in seen:              # first sight of this shape: run it eagerly, capture if it comes back
+                if len(seen) >= 4096:        # a loader whose shapes never repeat: do not remember them all
+                    seen.clear()
                 seen.add(key)
                 return self._eager_triplet(batch)
             ent = self._capture_shape(batch)
@@ -212,6 +214,9 @@ class TrainStep:
                 return self._eager_triplet(batch)
             cache[key] = ent
             while len(cache) > max_graphs:   # LRU: dicts keep insertion order
+                # the host runs several replays ahead of the GPU: the evicted graph may still be queued, and its
+                # executable graph + static inputs must outlive that (a rare event -- more live shapes than max_graphs)
+                torch.cuda.current_stream(self.opt.arena.device).synchronize()
                 cache.pop(next(iter(cache)))
         else:
             cache[key] = cache.pop(key)      # most recently used last
