@@ -415,6 +415,25 @@ def test_eval_epoch_mirrors_reference_loop_on_cpu():
         assert r["pred"].shape == (5,) and r["true"].shape == (5, 1) or r["true"].shape == (5,)
 
 
+def test_in_launch_reduction_workspaces_and_counters_are_sized_by_the_library():
+    """The entry points that finish a column reduction in-launch (csrc/col_tree.hpp) size their own scratch: workspace
+    floats grow with the row count and saturate once every row block is in use (norm lists: 256 blocks per task), are
+    16-byte multiples, and the arrival-counter words per call site are constants the host arena is built from."""
+    from graphgps_amd import lib, norm
+    L = lib.load()
+    assert L.gps_norm_sync_words() == 256 and norm.N_SITES * 256 * 4 <= 1 << 16
+    assert L.gps_gatedgcn_stats_sync_words() == 32
+    assert L.gps_gemm_stats_sync_words(384) == 6 * 32 and L.gps_gemm_stats_sync_words(100) == 0
+    for d in (64, 384):
+        sizes = [L.gps_norm_tree_floats(R, d) for R in (2, 100, 7569, 15348, 10 ** 6)]
+        assert all(v > 0 and v % 4 == 0 for v in sizes) and sizes == sorted(sizes)
+        assert sizes[-1] == sizes[-2]                      # 256 row blocks either way
+        assert sizes[-1] >= 256 * 2 * d                    # at least one (mean, M2) record per row block
+    assert L.gps_gatedgcn_stats_floats(7569, 384) >= 4 * 384 * 473     # 4 values x d per node block (16 rows each)
+    assert L.gps_gemm_stats_floats(7569, 384, 384) > 0 and L.gps_gemm_stats_floats(7569, 384, 2688) > 0
+    assert L.gps_norm_tree_floats(7569, 6) == 0 or L.gps_norm_tree_floats(7569, 6) % 4 == 0
+
+
 def test_block_reference_cache_and_train_helpers_on_cpu():
     """Host logic added in round 3 that needs no GPU: the per-layer cache of submodule / parameter references of the
     fused block (same objects, same order as ``block_params``; a replaced submodule invalidates it), the stack bracket
