@@ -48,6 +48,9 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int TM = 64, TN = 192, BK = 32;
 constexpr int PITCH = 40;          // bf16 per LDS row: 32 + 8 (80 bytes: conflict-free 16-byte fragment reads)
@@ -188,6 +191,9 @@ struct PanelArgs {
   unsigned* st_tick;
   float *st_mean, *st_rstd, *st_rmean, *st_rvar;
   float st_eps, st_mom;
+  // fp16 form (k_gemm_ring16): max|A| and max|B| as fp32 bit patterns (device words written by gps_absmax / a producer)
+  const uint32_t* a_amax;
+  const uint32_t* w_amax;
 };
 
 // Epilogue shared by both kernels.  D[row = (q&3) + 8*(q>>2) + 4*kh][col = li] of each 32 x 32 block; 32 lanes = 128
@@ -756,6 +762,378 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring(const PanelArgs P) {
   stamp(3);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// fp16 form of the ring kernel (round 4): the same panels, LDS images and epilogues, with every fp32 operand value
+// carried as TWO fp16 pieces of its power-of-two-scaled value and a*b formed from THREE piece products
+// (lo*hi, hi*lo, hi*hi; the dropped lo*lo is < 2^-22 |a||b|) on v_mfma_f32_32x32x16_f16 -- half the matrix-pipe work
+// of the 3 x bf16 / 6-product form above, and 6 VALU per value pair for the split instead of 11.
+//   * pieces: t = v * 2^e (exact), hi = RN_fp16(t), lo = RN_fp16(t - hi) (the remainder is exact in fp32; both
+//     conversions round to nearest, v_cvt_pk_f16_f32): |t - hi - lo| <= 2^-22 |t|, i.e. 22 significant bits per operand,
+//     against 24 for fp32 -- below the accumulation error of any fp32 GEMM of K >= 16 (tools/gemm16_emulate.py: max
+//     and rms error against fp64 equal to or below the 6-product form at every shape of the block, offsets and
+//     gradient-sized operands included; the MFMA rounds three partial sums per k-step into the accumulator, not six);
+//   * range: fp16 keeps 11 bits only between 2^-14 and 2^16, so each operand TENSOR is scaled by the power of two
+//     that puts its largest magnitude in [2^14, 2^15): e = 141 - biased_exponent(max|v|).  The maxima are device words
+//     (fp32 bit patterns: max over |v| is an unsigned integer max, order-free, deterministic) written by gps_absmax or
+//     by the operand's producer; the weight image carries its own.  Elements more than 2^17 below their tensor's
+//     maximum lose relative precision (lo goes subnormal; the absolute error stays below 2^-39 of the maximum);
+//     the accumulators are un-scaled by 2^-(eA + eB) (exact) in the epilogue;
+//   * the ring is deeper: a slot is A (raw fp32) + 2 W pieces = 32-40 KB, so FOUR or FIVE slots fit the CU's 160 KB
+//     where the 3-piece form had three.  With the MFMA time per stage halved, the bytes in flight -- not the matrix
+//     pipe -- decide whether the loop stalls: 2.5-3.5 stages are now outstanding across every barrier.
+// ------------------------------------------------------------------------------------------------------------
+constexpr unsigned kAmaxFloor = 16;      // biased exponent floor: tensors below 2^-111 are treated as that size
+__device__ __forceinline__ unsigned amax_be(const uint32_t* slot) {
+  const unsigned be = (__builtin_nontemporal_load(slot) >> 23) & 255u;
+  return be < kAmaxFloor ? kAmaxFloor : be;
+}
+__device__ __forceinline__ float amax_scale(unsigned be) { return __uint_as_float((268u - be) << 23); }     // 2^(141 - be)
+__device__ __forceinline__ float amax_unscale(unsigned be) { return __uint_as_float((be - 14u) << 23); }    // 2^(be - 141)
+
+// (v0, v1) -> packed fp16 pairs hi, lo of the scaled values
+__device__ __forceinline__ void split16(float v0, float v1, float s, uint32_t& hi, uint32_t& lo) {
+  const f32x2 t = (f32x2){v0, v1} * s;
+  const f16x2 h = __builtin_convertvector(t, f16x2);
+  const f32x2 r = t - __builtin_convertvector(h, f32x2);      // exact
+  const f16x2 l = __builtin_convertvector(r, f16x2);
+  hi = __builtin_bit_cast(uint32_t, h);
+  lo = __builtin_bit_cast(uint32_t, l);
+}
+
+// ---- max |v| of up to 56 row-major fp32 matrices in one launch ------------------------------------------------------
+struct AbsDesc {
+  const float* A;
+  int64_t ld, rows;
+  int cols;
+  int nr;              // rows per workgroup
+  uint32_t* slot;
+  int block_begin;
+};
+constexpr int kMaxAbs = 56;
+struct AbsGroup {
+  AbsDesc d[kMaxAbs];
+  int n;
+};
+__global__ __launch_bounds__(256) void k_absmax(const AbsGroup G) {
+  int di = 0, hi = G.n - 1;
+  while (di < hi) {
+    const int mid = (di + hi + 1) >> 1;
+    if ((int)blockIdx.x >= G.d[mid].block_begin) di = mid; else hi = mid - 1;
+  }
+  const AbsDesc& D = G.d[di];
+  const int cq = D.cols >> 2;
+  const int64_t r0 = (int64_t)(blockIdx.x - D.block_begin) * D.nr;
+  const int64_t nrows = min((int64_t)D.nr, D.rows - r0);
+  const int n4 = (int)(nrows * cq);
+  const float* base = D.A + r0 * D.ld;
+  uint32_t m = 0;
+#pragma unroll 4
+  for (int idx = threadIdx.x; idx < n4; idx += 256) {
+    const int r = idx / cq, c = idx - r * cq;
+    const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(base + (int64_t)r * D.ld + 4 * c));
+    m = max(max(m, v[0] & 0x7FFFFFFFu), max(v[1] & 0x7FFFFFFFu, max(v[2] & 0x7FFFFFFFu, v[3] & 0x7FFFFFFFu)));
+  }
+#pragma unroll
+  for (int o = 32; o; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(D.slot, m);
+}
+
+// ---- weight images, fp16 form: [2 pieces][K/32][N'][32], same geometry as the 3-piece image ------------------------------
+struct SplitDesc16 {
+  SplitDesc d;
+  const uint32_t* amax;
+};
+constexpr int kMaxSplit16 = 48;      // 48 x 72-byte descriptors
+struct SplitGroup16 {
+  SplitDesc16 d[kMaxSplit16];
+  int n;
+};
+__global__ __launch_bounds__(256) void k_split_weights16(const SplitGroup16 G) {
+  __shared__ __attribute__((aligned(16))) uint16_t T[2][ST_C * ST_P];
+  int di = 0, hi = G.n - 1;
+  while (di < hi) {
+    const int mid = (di + hi + 1) >> 1;
+    if ((int)blockIdx.x >= G.d[mid].d.block_begin) di = mid; else hi = mid - 1;
+  }
+  const SplitDesc& D = G.d[di].d;
+  const float sc = amax_scale(amax_be(G.d[di].amax));
+  const int ctiles = (D.cols + ST_C - 1) / ST_C;
+  const int tile = blockIdx.x - D.block_begin;
+  const int r0 = (tile / ctiles) * ST_R, c0 = (tile % ctiles) * ST_C;
+  const int t = threadIdx.x;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = t + 256 * i;
+    const int r = idx >> 5, cq = (idx & 31) * 4;
+    const int row = r0 + r, col = c0 + cq;
+    const bool ok = row < D.rows && col < D.cols;
+    const f32x4 v = ok ? *reinterpret_cast<const f32x4*>(D.W + (int64_t)row * D.ldw + col) : (f32x4){0.f, 0.f, 0.f, 0.f};
+    uint32_t h[2], l[2];
+    split16(v[0], v[1], sc, h[0], l[0]);
+    split16(v[2], v[3], sc, h[1], l[1]);
+    if (D.nt && row < D.rows && col < D.nt_k) {
+      *reinterpret_cast<u32x2*>(D.nt + img_index(0, row, col, D.nt_n, D.nt_k)) = (u32x2){h[0], h[1]};
+      *reinterpret_cast<u32x2*>(D.nt + img_index(1, row, col, D.nt_n, D.nt_k)) = (u32x2){l[0], l[1]};
+    }
+    if (D.tn) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        T[0][(cq + j) * ST_P + r] = (uint16_t)(h[j >> 1] >> (16 * (j & 1)));
+        T[1][(cq + j) * ST_P + r] = (uint16_t)(l[j >> 1] >> (16 * (j & 1)));
+      }
+    }
+  }
+  if (!D.tn) return;
+  __syncthreads();
+  // 2 pieces x 128 n x 4 chunks of 16 bytes = 1024 chunks, 4 per thread
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int idx = t + 256 * i;
+    const int p = idx / (ST_C * 4), rem = idx - p * (ST_C * 4);
+    const int n = rem >> 2, ch = rem & 3;
+    if (c0 + n < D.cols && r0 + ch * 8 < D.tn_k) {
+      const u32x4 v = *reinterpret_cast<const u32x4*>(&T[p][n * ST_P + ch * 8]);
+      *reinterpret_cast<u32x4*>(D.tn + img_index(p, c0 + n, r0 + ch * 8, D.tn_n, D.tn_k)) = v;
+    }
+  }
+}
+
+constexpr int r16_slot_bytes(int mb, int nj) { return rg_a_bytes(mb) + 2 * rg_bp(nj); }        // 16-40 KB
+constexpr int r16_slots(int mb, int nj) { return 163840 / r16_slot_bytes(mb, nj) > 5 ? 5 : 163840 / r16_slot_bytes(mb, nj); }
+constexpr int r16_lds_bytes(int mb, int nj) { return r16_slots(mb, nj) * r16_slot_bytes(mb, nj); }
+// first W-fragment read of gap i when nw reads are dealt over `gaps` gaps: one beside the raw-A reads of gap 0, the rest evenly
+constexpr int r16_rd_first(int i, int nw, int gaps) {
+  return i <= 0 ? 0 : (i >= gaps ? nw : 1 + ((i - 1) * (nw - 1) + (gaps - 1) - 1) / (gaps - 1));
+}
+
+template <int NJ>
+struct Ring16Frag {
+  u32x4 b[NJ][2];      // W fragments of one 16-wide k-step: [column block][hi, lo] as fp16 pairs
+};
+struct Ring16A {
+  u32x4 p[2];          // the A fragment of one row block and k-step: hi, lo
+};
+template <int I>
+struct IntC { static constexpr int value = I; };
+
+template <int MB, int NJ, int EPI, bool HAS_CIN, bool EDGE = false>
+__global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring16(const PanelArgs P) {
+  constexpr int TNV = 64 * NJ;
+  constexpr int BP = rg_bp(NJ);
+  constexpr int A_BYTES = rg_a_bytes(MB), SLOT = r16_slot_bytes(MB, NJ);
+  constexpr int S = r16_slots(MB, NJ);          // ring depth
+  constexpr int NA = 2 * MB;                    // A transfers per wave and stage
+  constexpr int NW = 2 * NJ;                    // W transfers per wave and stage
+  constexpr int ND = NA + NW;
+  constexpr int ND_ODD = ND / 2, ND_EVEN = ND - ND_ODD;
+  constexpr int G = 3 * MB * NJ;                // MFMAs (= issue gaps) per region
+  constexpr int RD_GAPS = G < 4 ? G : 4;        // gaps that carry the W-fragment reads of the next k-step
+  // the split of the next k-step's raw A values: 4 MB pairs x 3 instalments of 2-3 VALU, SPLITQ instalments per gap in the
+  // LAST gaps of the region (the compiler waits lgkmcnt(0) at the first use of a raw value: by then every LDS read of gaps
+  // 0 .. 3 should have landed, or the wait is a stall of one LDS round trip per region); regions of fewer than 9 MFMAs
+  // (the narrow panels: latency-bound shapes) deal it evenly from gap 1
+  constexpr int SPLITQ = G >= 9 ? (12 * MB + (G - 4) - 1) / (G - 4) : (12 * MB + (G - 1) - 1) / (G - 1);
+  constexpr int SPLIT0 = G >= 9 ? G - (12 * MB + SPLITQ - 1) / SPLITQ : 1;
+  static_assert(ND_EVEN <= G && 12 * MB <= (G - SPLIT0) * SPLITQ, "the staging does not fit the region's issue gaps");
+  static_assert((S - 2) * ND + ND_ODD <= 63 && S >= 3, "vmcnt range");
+  extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];
+  auto stamp = [&](int k) __attribute__((always_inline)) {
+    if (P.trace && threadIdx.x == 0) P.trace[4 * (size_t)blockIdx.x + k] = __builtin_amdgcn_s_memtime();
+  };
+  stamp(0);
+  const int panel = blockIdx.x / P.row_tiles, rt = blockIdx.x - panel * P.row_tiles;   // panel-major numbering
+  const int64_t m0 = (int64_t)rt * (64 * MB);
+  const int n0 = panel * TNV;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, kh = lane >> 5;
+  const int KS = (P.K + BK - 1) / BK;
+  const unsigned bea = amax_be(P.a_amax), bew = amax_be(P.w_amax);
+  const float sa = amax_scale(bea);
+
+  // ---- DMA sources (as k_gemm_ring, two W pieces) ------------------------------------------------------------------
+  const unsigned char* a_src[NA];
+  int a_tail[NA];
+  const int nvc = EDGE ? (P.K - (KS - 1) * BK) / 4 : 8;
+#pragma unroll
+  for (int i = 0; i < NA; ++i) {
+    const int row = 8 * NA * wave + 8 * i + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
+    const int64_t grow = min(m0 + row, P.M - 1);
+    a_src[i] = reinterpret_cast<const unsigned char*>(P.A + grow * P.lda) + c * 16;
+    a_tail[i] = (EDGE && c >= nvc) ? c * 16 : 0;
+  }
+  const int64_t stage_stride = (int64_t)P.Nimg * (BK * 2);
+  const int64_t piece_stride = stage_stride * KS;
+  const unsigned char* b_src = reinterpret_cast<const unsigned char*>(P.Bp) + ((int64_t)n0 + 16 * NJ * wave + (lane >> 2)) * (BK * 2) +
+                               (((lane & 3) ^ ((lane >> 4) & 3)) * 16);
+  auto dma = [&](int g, int s, unsigned char* slot) __attribute__((always_inline)) {
+    if (g < NA) {
+      if (EDGE) glds16(a_src[g] + (int64_t)s * (BK * 4) - (s == KS - 1 ? a_tail[g] : 0), slot + wave * (NA * 1024) + g * 1024);
+      else glds16(a_src[g] + (int64_t)s * (BK * 4), slot + wave * (NA * 1024) + g * 1024);
+    } else {
+      const int i = g - NA;
+      glds16(b_src + s * stage_stride + (i / NJ) * piece_stride + (i % NJ) * 1024,
+             slot + A_BYTES + (i / NJ) * BP + wave * (NJ * 1024) + (i % NJ) * 1024);
+    }
+  };
+
+  // ---- fragment addresses (byte offsets inside a slot) ---------------------------------------------------------
+  int a_off[2][2], b_off[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int c0 = ks * 4 + kh * 2, sw = (li >> 1) & 7;
+    a_off[ks][0] = (wm * 32 * MB + li) * 128 + ((c0 ^ sw) * 16);
+    a_off[ks][1] = (wm * 32 * MB + li) * 128 + (((c0 + 1) ^ sw) * 16);
+    b_off[ks] = A_BYTES + (wn * 32 * NJ + li) * 64 + (((ks * 2 + kh) ^ ((li >> 2) & 3)) * 16);
+  }
+
+  f32x16 acc[MB][NJ];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[mb][j][q] = 0.0f;
+
+  // split of one pair of raw values in three instalments of 2 VALU: scale + pack hi | hi back to fp32 | remainder + pack lo
+  // (the packed hi travels between the instalments in its own register: read back out of the partly written fragment
+  // `out.p[0][d]` it was folded to the FIRST pair's value by the compiler -- caught in the ISA, tools/kernel_regs.py era)
+  f32x2 st_hb;
+  uint32_t st_hi;
+  auto split_part = [&](int part, const f32x4 (&raw)[2], int d, Ring16A& out) __attribute__((always_inline)) {
+    const f32x2 v = (f32x2){raw[d >> 1][(d & 1) * 2], raw[d >> 1][(d & 1) * 2 + 1]};
+    if (part == 0) {
+      st_hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v * sa, f16x2));
+      out.p[0][d] = st_hi;
+    } else if (part == 1) {
+      st_hb = __builtin_convertvector(__builtin_bit_cast(f16x2, st_hi), f32x2);
+    } else {
+      out.p[1][d] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v * sa - st_hb, f16x2));
+    }
+  };
+
+  constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};     // lo*hi, hi*lo, hi*hi: smallest terms first
+
+  f32x4 raw[MB][2];
+  auto region = [&](const Ring16A (&ac)[MB], const Ring16Frag<NJ>& fc, Ring16A (&an)[MB], Ring16Frag<NJ>& fn, const unsigned char* rd_slot,
+                    int rd_ks, int dma_stage, unsigned char* dma_slot, int dma_first, int dma_count)
+                    __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+      const int term = i / (NJ * MB), mb = (i / NJ) % MB, j = i % NJ;
+      acc[mb][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ac[mb].p[TA[term]]),
+                                                         __builtin_bit_cast(f16x8, fc.b[j][TB[term]]), acc[mb][j], 0, 0, 0);
+      if (i == 0) {
+#pragma unroll
+        for (int b = 0; b < MB; ++b) {
+          raw[b][0] = *reinterpret_cast<const f32x4*>(rd_slot + a_off[rd_ks][0] + b * 4096);
+          raw[b][1] = *reinterpret_cast<const f32x4*>(rd_slot + a_off[rd_ks][1] + b * 4096);
+        }
+      }
+      if (i < RD_GAPS) {
+#pragma unroll
+        for (int k = r16_rd_first(i, NW, RD_GAPS); k < r16_rd_first(i + 1, NW, RD_GAPS); ++k)
+          fn.b[k / 2][k % 2] = *reinterpret_cast<const u32x4*>(rd_slot + b_off[rd_ks] + (k / 2) * (32 * 64) + (k % 2) * BP);
+      }
+      if (i < dma_count) dma(dma_first + i, dma_stage, dma_slot);
+      if (i >= SPLIT0) {
+#pragma unroll
+        for (int u = 0; u < SPLITQ; ++u) {
+          const int q = (i - SPLIT0) * SPLITQ + u;
+          if (q < 12 * MB) split_part(q % 3, raw[(q / 3) / 4], (q / 3) % 4, an[(q / 3) / 4]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  // prologue: stages 0 .. S-2 whole, the first ND_ODD transfers of stage S-1 (stage indices clamped to the last one)
+#pragma unroll
+  for (int st = 0; st < S - 1; ++st)
+#pragma unroll
+    for (int g = 0; g < ND; ++g) dma(g, min(st, KS - 1), ring + st * SLOT);
+#pragma unroll
+  for (int g = 0; g < ND_ODD; ++g) dma(g, min(S - 1, KS - 1), ring + (S - 1) * SLOT);
+  __builtin_amdgcn_s_waitcnt(waitcnt_imm((S - 2) * ND + ND_ODD, 15));   // this wave's share of stage 0 has landed
+  __builtin_amdgcn_s_barrier();                                         // ... and every other wave's
+  stamp(1);
+  Ring16Frag<NJ> f0, f1;
+  Ring16A a0[MB], a1[MB];
+#pragma unroll
+  for (int b = 0; b < MB; ++b) {
+    raw[b][0] = *reinterpret_cast<const f32x4*>(ring + a_off[0][0] + b * 4096);
+    raw[b][1] = *reinterpret_cast<const f32x4*>(ring + a_off[0][1] + b * 4096);
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+      f0.b[j][p] = *reinterpret_cast<const u32x4*>(ring + b_off[0] + j * (32 * 64) + p * BP);
+#pragma unroll
+  for (int b = 0; b < MB; ++b)
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int part = 0; part < 3; ++part) split_part(part, raw[b], d, a0[b]);
+  __builtin_amdgcn_sched_barrier(0);
+
+  // Stage s sits in slot s % S.  Region 2s multiplies k-step 2s while k-step 2s+1 is fetched from the same slot and the
+  // last ND_EVEN transfers of stage s+S-1 are issued; then the stage barrier: the counted wait retires this wave's share
+  // of stage s+1 (stages s+2 .. s+S-1 stay in flight across it), lgkmcnt(0) retires its reads of slot s % S, which may
+  // be refilled after the barrier.  Region 2s+1 multiplies k-step 2s+1, fetches k-step 2s+2 from the next slot and
+  // issues the first ND_ODD transfers of stage s+S into the slot just freed.
+  auto stage = [&](auto ic, int s) __attribute__((always_inline)) {
+    constexpr int I = decltype(ic)::value;
+    unsigned char* const cur = ring + I * SLOT;
+    unsigned char* const nxt = ring + ((I + 1) % S) * SLOT;
+    unsigned char* const lst = ring + ((I + S - 1) % S) * SLOT;
+    region(a0, f0, a1, f1, cur, 1, min(s + S - 1, KS - 1), lst, ND_ODD, ND_EVEN);
+    __builtin_amdgcn_s_waitcnt(waitcnt_imm((S - 2) * ND, 0));
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    region(a1, f1, a0, f0, nxt, 0, min(s + S, KS - 1), cur, 0, ND_ODD);
+  };
+  int s0 = 0;
+  for (; s0 + S <= KS; s0 += S) {
+    stage(IntC<0>{}, s0);
+    stage(IntC<1>{}, s0 + 1);
+    stage(IntC<2>{}, s0 + 2);
+    if constexpr (S > 3) stage(IntC<3 % S>{}, s0 + 3);
+    if constexpr (S > 4) stage(IntC<4 % S>{}, s0 + 4);
+  }
+  if (s0 < KS) {                                            // up to S-1 stages left over (workgroup-uniform)
+    stage(IntC<0>{}, s0);
+    if (s0 + 1 < KS) {
+      stage(IntC<1>{}, s0 + 1);
+      if (s0 + 2 < KS) {
+        stage(IntC<2>{}, s0 + 2);
+        if constexpr (S > 4) {
+          if (s0 + 3 < KS) stage(IntC<3 % S>{}, s0 + 3);
+        }
+      }
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 15));         // no DMA may still be writing this workgroup's LDS when it retires
+  stamp(2);
+  // un-scale: exact powers of two, two factors so that neither can leave the fp32 exponent range on its own
+  const float ua = amax_unscale(bea), uw = amax_unscale(bew);
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[mb][j][q] = (acc[mb][j][q] * ua) * uw;
+  float sk[NJ], s1[NJ], s2[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) sk[j] = s1[j] = s2[j] = 0.f;
+  ring_epilogue<MB, NJ, EPI, HAS_CIN, EDGE>(P, acc, m0, n0, wm, wn, li, kh, sk, s1, s2);
+  if (EPI == 3) ring_stats<MB, NJ>(P, rt, panel, m0, wm, wn, li, kh, sk, s1, s2, reinterpret_cast<float*>(ring));
+  __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 15));
+  stamp(3);
+}
+
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) % 16) == 0; }
 
 }  // namespace
@@ -765,7 +1143,7 @@ unsigned long long* g_panel_trace = nullptr;
 static int panel_launch(const float* A, int64_t lda, int64_t M, int K, const uint16_t* image, int N, const float* bias,
                         const float* Cin, int64_t ldcin, float* C, int64_t ldc, int epilogue, const float* mask_src,
                         int64_t ldmask, float p_drop, uint64_t seed, const gps_bn* stats, float* ws, size_t ws_floats,
-                        uint32_t* sync, gps_stream_t stream);
+                        uint32_t* sync, gps_stream_t stream, const uint32_t* a_amax = nullptr, const uint32_t* w_amax = nullptr);
 
 // 128-row panels (MB = 2) when they still give every CU a workgroup; 64-column panels always use 64 rows (the only
 // NJ = 1 instantiation).  GPS_GEMM_RING_MB = 1 / 2 forces one.
@@ -849,12 +1227,80 @@ int gps_gemm_panel_stats(const float* A, int64_t lda, int64_t M, int K, const ui
                       stream);
 }
 
+// ---- fp16 form (k_gemm_ring16): the operand maxima travel as device words ------------------------------------------------
+size_t gps_gemm16_image_elems(int64_t N, int64_t K) { return N > 0 && K > 0 ? (size_t)(2 * rg_npad(N, K) * rg_kpad(K)) : 0; }
+
+int gps_absmax(int n, const gps_absmax_desc* descs, gps_stream_t stream) {
+  GPS_REQUIRE(n >= 1 && n <= kMaxAbs && descs, "gps_absmax: 1..%d matrices per launch", kMaxAbs);
+  AbsGroup G{};
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    const gps_absmax_desc& d = descs[i];
+    GPS_REQUIRE(d.A && d.slot && d.rows >= 0 && d.cols > 0 && d.cols % 4 == 0 && d.ld >= d.cols && d.ld % 4 == 0 && al16(d.A),
+                "gps_absmax: matrix %d: bad shape / alignment", i);
+    if (d.rows == 0) continue;
+    const int cq = d.cols / 4;
+    const int nr = cq >= 2048 ? 1 : 2048 / cq;                 // ~32 KB per workgroup
+    G.d[G.n] = AbsDesc{d.A, d.ld, d.rows, d.cols, nr, d.slot, blocks};
+    blocks += (int)((d.rows + nr - 1) / nr);
+    ++G.n;
+  }
+  if (G.n == 0) return GPS_OK;
+  k_absmax<<<(unsigned)blocks, 256, 0, gps::as_stream(stream)>>>(G);
+  return gps::launch_status("gps_absmax");
+}
+
+int gps_gemm16_split_weights(int n, const gps_gemm_split16* descs, gps_stream_t stream) {
+  GPS_REQUIRE(n >= 1 && n <= kMaxSplit16 && descs, "gps_gemm16_split_weights: 1..%d weights per launch", kMaxSplit16);
+  SplitGroup16 G{};
+  G.n = n;
+  int blocks = 0;
+  for (int i = 0; i < n; ++i) {
+    const gps_gemm_split16& d = descs[i];
+    GPS_REQUIRE(d.W && d.amax && d.rows > 0 && d.cols > 0 && d.ldw >= d.cols && d.cols % 4 == 0 && d.ldw % 4 == 0 && al16(d.W),
+                "gps_gemm16_split_weights: weight %d: bad shape / alignment", i);
+    GPS_REQUIRE(!d.image_nt || (gps_gemm_panel_supported(d.rows, d.cols) && al16(d.image_nt)),
+                "gps_gemm16_split_weights: weight %d: rows, cols %% 4", i);
+    GPS_REQUIRE(!d.image_tn || (gps_gemm_panel_supported(d.cols, d.rows) && al16(d.image_tn)),
+                "gps_gemm16_split_weights: weight %d: rows, cols %% 4", i);
+    G.d[i].d = SplitDesc{d.W, d.ldw, d.rows, d.cols, d.image_nt, d.image_tn, blocks,
+                         (int)rg_npad(d.rows, d.cols), (int)rg_kpad(d.cols), (int)rg_npad(d.cols, d.rows), (int)rg_kpad(d.rows)};
+    G.d[i].amax = d.amax;
+    blocks += ((d.rows + ST_R - 1) / ST_R) * ((d.cols + ST_C - 1) / ST_C);
+  }
+  k_split_weights16<<<(unsigned)blocks, 256, 0, gps::as_stream(stream)>>>(G);
+  return gps::launch_status("gps_gemm16_split_weights");
+}
+
+int gps_gemm16_panel(const float* A, int64_t lda, int64_t M, int K, const uint32_t* a_amax, const uint16_t* image,
+                     const uint32_t* w_amax, int N, const float* bias, const float* Cin, int64_t ldcin, float* C, int64_t ldc,
+                     int epilogue, const float* mask_src, int64_t ldmask, float p_drop, uint64_t seed, gps_stream_t stream) {
+  GPS_REQUIRE(epilogue >= 0 && epilogue <= 2, "gps_gemm16_panel: epilogue");
+  GPS_REQUIRE(a_amax && w_amax, "gps_gemm16_panel: operand maxima");
+  return panel_launch(A, lda, M, K, image, N, bias, Cin, ldcin, C, ldc, epilogue, mask_src, ldmask, p_drop, seed, nullptr,
+                      nullptr, 0, nullptr, stream, a_amax, w_amax);
+}
+
+int gps_gemm16_panel_stats(const float* A, int64_t lda, int64_t M, int K, const uint32_t* a_amax, const uint16_t* image,
+                           const uint32_t* w_amax, int N, const float* bias, const float* Cin, int64_t ldcin, float* C,
+                           int64_t ldc, float p_drop, uint64_t seed, const gps_bn* stats, float* ws, size_t ws_floats,
+                           uint32_t* sync, gps_stream_t stream) {
+  GPS_REQUIRE(gps_gemm_stats_supported(M, N, K), "gps_gemm16_panel_stats: shape M=%lld N=%d K=%d not served by the ring kernel",
+              (long long)M, N, K);
+  GPS_REQUIRE(a_amax && w_amax, "gps_gemm16_panel_stats: operand maxima");
+  GPS_REQUIRE(Cin && stats && stats->mean && stats->rstd && ws && sync && al16(ws), "gps_gemm16_panel_stats: null / misaligned buffer");
+  GPS_REQUIRE((stats->running_mean == nullptr) == (stats->running_var == nullptr), "gps_gemm16_panel_stats: running stats");
+  GPS_REQUIRE(ws_floats >= gps_gemm_stats_floats(M, N, K), "gps_gemm16_panel_stats: workspace too small (gps_gemm_stats_floats)");
+  return panel_launch(A, lda, M, K, image, N, bias, Cin, ldcin, C, ldc, 3, nullptr, 0, p_drop, seed, stats, ws, ws_floats, sync,
+                      stream, a_amax, w_amax);
+}
+
 }  // extern "C"
 
 static int panel_launch(const float* A, int64_t lda, int64_t M, int K, const uint16_t* image, int N, const float* bias,
                         const float* Cin, int64_t ldcin, float* C, int64_t ldc, int epilogue, const float* mask_src,
                         int64_t ldmask, float p_drop, uint64_t seed, const gps_bn* stats, float* ws, size_t ws_floats,
-                        uint32_t* sync, gps_stream_t stream) {
+                        uint32_t* sync, gps_stream_t stream, const uint32_t* a_amax, const uint32_t* w_amax) {
   GPS_REQUIRE(M >= 0 && gps_gemm_panel_supported(N, K), "gps_gemm_panel: needs N %% 4 == 0 and K %% 4 == 0 (N=%d K=%d)",
               N, K);
   if (M == 0) return GPS_OK;
@@ -868,11 +1314,14 @@ static int panel_launch(const float* A, int64_t lda, int64_t M, int K, const uin
   P.C = C; P.ldc = ldc; P.epilogue = epilogue; P.mask_src = mask_src; P.ldmask = ldmask;
   P.p_drop = epilogue ? p_drop : 0.0f; P.seed = seed; P.salt = gps::dropout_salt();
   P.trace = g_panel_trace;
+  P.a_amax = a_amax; P.w_amax = w_amax;
+  const bool f16 = a_amax != nullptr;
+  GPS_REQUIRE((a_amax == nullptr) == (w_amax == nullptr), "gps_gemm16_panel: both operand maxima or neither");
   hipStream_t s = gps::as_stream(stream);
   // The ring kernel (LDS-DMA, three-slot ring) serves every supported shape.  GPS_GEMM_RING=0 keeps the register-staged
   // round-2 kernel where IT applies (N % 192 == 0, K % 128 == 0; A/B measurements).
   const bool staged_ok = N % TN == 0 && K % (4 * BK) == 0;
-  const bool ring = ring_enabled() || !staged_ok;
+  const bool ring = ring_enabled() || !staged_ok || f16;
   const int mb = ring_mb(M, N, K), nj = rg_nj(N, K);
   const bool edge = rg_edge(N, K);
   GPS_REQUIRE(epilogue != 3 || !edge, "gps_gemm_panel: the statistics epilogue needs whole column panels and k-stages");
@@ -899,19 +1348,22 @@ static int panel_launch(const float* A, int64_t lda, int64_t M, int K, const uin
     P.row_tiles = (int)((M + TM - 1) / TM);
     grid = (unsigned)(P.row_tiles * (N / TN));
   }
+#define GPS_RING_ANY(KERNEL, LDS)                                                                     \
+  do {                                                                                                \
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL),        \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
+    GPS_REQUIRE(attr == hipSuccess, "gps_gemm_panel: cannot reserve %d bytes of LDS", LDS);           \
+    KERNEL<<<grid, NTHREADS, LDS, s>>>(P);                                                            \
+  } while (0)
 #define GPS_RING_LAUNCH(MBV, NJV, E, C)                                                               \
   do {                                                                                                \
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring<MBV, NJV, E, C>), \
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, rg_lds_bytes(MBV, NJV)); \
-    GPS_REQUIRE(attr == hipSuccess, "gps_gemm_panel: cannot reserve %d bytes of LDS", rg_lds_bytes(MBV, NJV));  \
-    k_gemm_ring<MBV, NJV, E, C><<<grid, NTHREADS, rg_lds_bytes(MBV, NJV), s>>>(P);                    \
+    if (f16) GPS_RING_ANY((k_gemm_ring16<MBV, NJV, E, C>), r16_lds_bytes(MBV, NJV));                  \
+    else GPS_RING_ANY((k_gemm_ring<MBV, NJV, E, C>), rg_lds_bytes(MBV, NJV));                         \
   } while (0)
 #define GPS_RING_EDGE(MBV, NJV, E, C)                                                                 \
   do {                                                                                                \
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring<MBV, NJV, E, C, true>), \
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, rg_lds_bytes(MBV, NJV)); \
-    GPS_REQUIRE(attr == hipSuccess, "gps_gemm_panel: cannot reserve %d bytes of LDS", rg_lds_bytes(MBV, NJV));  \
-    k_gemm_ring<MBV, NJV, E, C, true><<<grid, NTHREADS, rg_lds_bytes(MBV, NJV), s>>>(P);              \
+    if (f16) GPS_RING_ANY((k_gemm_ring16<MBV, NJV, E, C, true>), r16_lds_bytes(MBV, NJV));            \
+    else GPS_RING_ANY((k_gemm_ring<MBV, NJV, E, C, true>), rg_lds_bytes(MBV, NJV));                   \
   } while (0)
 #define GPS_RING_SHAPES(E, C)                                                                         \
   do {                                                                                                \
@@ -939,6 +1391,7 @@ static int panel_launch(const float* A, int64_t lda, int64_t M, int K, const uin
   }
 #undef GPS_RING_EDGE
 #undef GPS_RING_LAUNCH
+#undef GPS_RING_ANY
 #undef GPS_RING_SHAPES
 #undef GPS_PANEL_LAUNCH
   return gps::launch_status("gps_gemm_panel");

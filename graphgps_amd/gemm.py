@@ -1,7 +1,8 @@
 """Row-panel GEMM (csrc/gemm_panel.hip) behind the nn.Linear modules of the GPS block.
 
-``C = A W^T (+ bias) (+ addend)`` with optional ReLU/dropout epilogues, fp32 in / fp32 out, products formed exactly on
-the bf16 MFMA pipe.  The weight operand is a pre-split IMAGE (three bf16 pieces, k-stage-major) made from the fp32
+``C = A W^T (+ bias) (+ addend)`` with optional ReLU/dropout epilogues, fp32 in / fp32 out, products formed from fp16
+pieces (round 4: two per value, 3 products) or bf16 pieces (round 2: three per value, 6 products, exact) on the MFMA pipe.
+The weight operand is a pre-split IMAGE (pieces k-stage-major) made from the fp32
 weight by ``split_weights`` -- once per layer and forward (the weights change under the optimizer's HIP kernel, which
 torch's version counters do not see, so nothing is cached across calls: ~10 us per layer for the five weights of a
 block, both images; callers that never run an input gradient pass ``tn=False``).  Replaces ``torch.addmm`` / ``mm`` (rocBLAS / hipBLASLt) for the projections of
@@ -22,6 +23,46 @@ from .lib import check, current_stream, ptr
 
 ENABLED = os.environ.get("GPS_GEMM_PANEL", "1") != "0"
 MAX_SPLIT = 56      # csrc/gemm_panel.hip kMaxSplit
+# Arithmetic form of the ring GEMM (round 4).  F16 (default): two fp16 pieces per operand value under a per-tensor
+# power-of-two scale, 3 piece products on v_mfma_f32_32x32x16_f16 -- half the matrix-pipe work of the round-2 form (three
+# bf16 pieces, 6 products), error against fp64 at or below it.  The scale comes from max|operand|, a device word
+# (``absmax``): the weights' words are made with the images, an activation's word is computed once and shared by every
+# GEMM that consumes the tensor.  GPS_GEMM_F16=0 keeps the 6-product form everywhere (A/B runs).
+F16 = os.environ.get("GPS_GEMM_F16", "1") != "0"
+MAX_SPLIT16 = 48    # csrc/gemm_panel.hip kMaxSplit16
+MAX_ABS = 56        # csrc/gemm_panel.hip kMaxAbs
+
+
+class WImage:
+    """A weight image and, for the fp16 form, the device word holding max|W| it was scaled by (``amax``: int32 [1])."""
+    __slots__ = ("t", "amax")
+
+    def __init__(self, t: torch.Tensor, amax: Optional[torch.Tensor] = None):
+        self.t, self.amax = t, amax
+
+    def data_ptr(self) -> int:
+        return self.t.data_ptr()
+
+
+def absmax(tensors: Sequence[torch.Tensor], out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """int32 ``[len(tensors)]``: word i = fp32 bit pattern of ``max|tensors[i]|`` (csrc/gemm_panel.hip ``gps_absmax``, one
+    launch for up to 56 row-major fp32 matrices with ``cols % 4 == 0``).  ``out``: words to raise instead (they must hold
+    zeros or an earlier maximum of the same tensors)."""
+    L = _lib.load()
+    n = len(tensors)
+    dev = tensors[0].device
+    if out is None:
+        out = torch.zeros(n, dtype=torch.int32, device=dev)
+    base = out.data_ptr()
+    for i0 in range(0, n, MAX_ABS):
+        chunk = tensors[i0:i0 + MAX_ABS]
+        descs = (_lib.AbsmaxDesc * len(chunk))()
+        for j, (q, t) in enumerate(zip(descs, chunk)):
+            if t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1 or not t.is_cuda:
+                raise _lib.GpsHipError("absmax: fp32 [rows, cols] CUDA matrices with unit column stride")
+            q.A, q.ld, q.rows, q.cols, q.slot = t.data_ptr(), t.stride(0), t.shape[0], t.shape[1], base + 4 * (i0 + j)
+        check(L.gps_absmax(len(chunk), descs, current_stream(dev)), "gps_absmax")
+    return out
 
 
 def supported(N: int, K: int) -> bool:
@@ -42,8 +83,15 @@ def stats_supported(M: int, N: int, K: int) -> bool:
     return v
 
 
-def gemm_panel_stats(a: torch.Tensor, image: torch.Tensor, N: int, bias: Optional[torch.Tensor], addend: torch.Tensor,
-                     p_drop: float, seed: int, bn_desc, sync_ptr: int) -> torch.Tensor:
+def _a_word(a: torch.Tensor, a_amax: Optional[torch.Tensor]) -> int:
+    """Address of max|a|'s word: the caller's, or one made here (a pre-pass over ``a``)."""
+    if a_amax is None:
+        a_amax = absmax([a])
+    return a_amax.data_ptr()
+
+
+def gemm_panel_stats(a: torch.Tensor, image, N: int, bias: Optional[torch.Tensor], addend: torch.Tensor,
+                     p_drop: float, seed: int, bn_desc, sync_ptr: int, a_amax: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``out = addend + dropout(a @ B^T + bias; p_drop, seed)`` and the batch statistics of ``out`` over its rows
     (-> ``bn_desc.mean / rstd`` + running statistics), complete when the launch retires: the residual + dropout +
     statistics pass of ``norm1_attn`` / ``norm2`` (graphgps/layer/gps_layer.py:212-217,225-229) in the GEMM's epilogue.
@@ -56,21 +104,55 @@ def gemm_panel_stats(a: torch.Tensor, image: torch.Tensor, N: int, bias: Optiona
     out = torch.empty(M, N, dtype=torch.float32, device=a.device)
     wsf = L.gps_gemm_stats_floats(M, N, K)
     ws = torch.empty(wsf, dtype=torch.float32, device=a.device)
+    if getattr(image, "amax", None) is not None:
+        check(L.gps_gemm16_panel_stats(ptr(a), a.stride(0), M, K, _a_word(a, a_amax), ptr(image), ptr(image.amax), N,
+                                       ptr(bias), ptr(addend), addend.stride(0), ptr(out), out.stride(0), float(p_drop),
+                                       int(seed), ctypes.byref(bn_desc), ptr(ws), wsf, sync_ptr,
+                                       current_stream(a.device)), "gps_gemm16_panel_stats")
+        return out
     check(L.gps_gemm_panel_stats(ptr(a), a.stride(0), M, K, ptr(image), N, ptr(bias), ptr(addend), addend.stride(0),
                                  ptr(out), out.stride(0), float(p_drop), int(seed), ctypes.byref(bn_desc), ptr(ws), wsf,
                                  sync_ptr, current_stream(a.device)), "gps_gemm_panel_stats")
     return out
 
 
-def split_weights(weights: Sequence[torch.Tensor], nt: bool = True, tn: bool = True
-                  ) -> List[Tuple[Optional[torch.Tensor], Optional[torch.Tensor]]]:
+def _split_weights16(weights, nt, tn):
+    """fp16 images: one ``gps_absmax`` launch over all weights, then one split launch per 48 of them."""
+    L = _lib.load()
+    dev = weights[0].device
+    for w in weights:
+        if w.dtype != torch.float32 or w.dim() != 2 or w.stride(1) != 1 or not w.is_cuda:
+            raise _lib.GpsHipError("split_weights: fp32 [rows, cols] CUDA weights with unit column stride")
+    words = absmax(list(weights))
+    out = []
+    for i0 in range(0, len(weights), MAX_SPLIT16):
+        chunk = weights[i0:i0 + MAX_SPLIT16]
+        descs = (_lib.GemmSplit16 * len(chunk))()
+        for j, (q, w) in enumerate(zip(descs, chunk)):
+            rows, cols = w.shape
+            i_nt = torch.empty(L.gps_gemm16_image_elems(rows, cols), dtype=torch.int16, device=dev) if nt else None
+            i_tn = torch.empty(L.gps_gemm16_image_elems(cols, rows), dtype=torch.int16, device=dev) if tn else None
+            word = words[i0 + j:i0 + j + 1]
+            q.W, q.ldw, q.rows, q.cols = w.data_ptr(), w.stride(0), rows, cols
+            q.image_nt = i_nt.data_ptr() if nt else None
+            q.image_tn = i_tn.data_ptr() if tn else None
+            q.amax = word.data_ptr()
+            out.append((WImage(i_nt, word) if nt else None, WImage(i_tn, word) if tn else None))
+        check(L.gps_gemm16_split_weights(len(chunk), descs, current_stream(dev)), "gps_gemm16_split_weights")
+    return out
+
+
+def split_weights(weights: Sequence[torch.Tensor], nt: bool = True, tn: bool = True, f16: Optional[bool] = None
+                  ) -> List[Tuple[Optional["WImage"], Optional["WImage"]]]:
     """[(image of W, image of W^T), ...] for fp32 weights ``[rows, cols]``, up to 56 per launch (the five projections
     of every block of a 10-layer stack: ONE launch per step, layer/gps_block.py stack_begin).
     ``image of W`` serves ``x @ W.T`` (forward), ``image of W^T`` serves ``g @ W`` (input gradient)."""
+    if F16 if f16 is None else f16:
+        return _split_weights16(list(weights), nt, tn)
     if len(weights) > MAX_SPLIT:
         out = []
         for i in range(0, len(weights), MAX_SPLIT):
-            out += split_weights(weights[i:i + MAX_SPLIT], nt, tn)
+            out += split_weights(weights[i:i + MAX_SPLIT], nt, tn, False)
         return out
     L = _lib.load()
     n = len(weights)
@@ -88,14 +170,15 @@ def split_weights(weights: Sequence[torch.Tensor], nt: bool = True, tn: bool = T
         q.W, q.ldw, q.rows, q.cols = w.data_ptr(), w.stride(0), rows, cols
         q.image_nt = i_nt.data_ptr() if nt else None
         q.image_tn = i_tn.data_ptr() if tn else None
-        out.append((i_nt, i_tn))
+        out.append((WImage(i_nt) if nt else None, WImage(i_tn) if tn else None))
     check(L.gps_gemm_split_weights(n, descs, current_stream(dev)), "gps_gemm_split_weights")
     return out
 
 
-def gemm_panel(a: torch.Tensor, image: torch.Tensor, N: int, bias: Optional[torch.Tensor] = None,
+def gemm_panel(a: torch.Tensor, image, N: int, bias: Optional[torch.Tensor] = None,
                addend: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, epilogue: int = 0,
-               mask_src: Optional[torch.Tensor] = None, p_drop: float = 0.0, seed: int = 0) -> torch.Tensor:
+               mask_src: Optional[torch.Tensor] = None, p_drop: float = 0.0, seed: int = 0,
+               a_amax: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``out = a @ B^T (+ bias) (+ addend)`` where ``image`` is the split image of B ``[N, K]``.
     ``a`` may be a column slice of a wider buffer (row stride >= K); ``out`` likewise (row stride >= N).
     epilogue 1: ReLU then dropout(p_drop, seed); epilogue 2: multiply by the ReLU/dropout mask of ``mask_src``."""
@@ -105,6 +188,14 @@ def gemm_panel(a: torch.Tensor, image: torch.Tensor, N: int, bias: Optional[torc
         raise _lib.GpsHipError("gemm_panel: fp32 A with unit column stride")
     if out is None:
         out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    if M == 0:
+        return out
+    if getattr(image, "amax", None) is not None:       # fp16 form: ``a_amax`` = the word of max|a| (made here when absent)
+        check(L.gps_gemm16_panel(ptr(a), a.stride(0), M, K, _a_word(a, a_amax), ptr(image), ptr(image.amax), N, ptr(bias),
+                                 ptr(addend), addend.stride(0) if addend is not None else 0, ptr(out), out.stride(0),
+                                 int(epilogue), ptr(mask_src), mask_src.stride(0) if mask_src is not None else 0,
+                                 float(p_drop), int(seed), current_stream(a.device)), "gps_gemm16_panel")
+        return out
     check(L.gps_gemm_panel(ptr(a), a.stride(0), M, K, ptr(image), N, ptr(bias), ptr(addend),
                            addend.stride(0) if addend is not None else 0, ptr(out), out.stride(0), int(epilogue),
                            ptr(mask_src), mask_src.stride(0) if mask_src is not None else 0, float(p_drop),

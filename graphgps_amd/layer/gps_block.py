@@ -390,9 +390,17 @@ class _GPSBlock(torch.autograd.Function):
             if imgs is None:
                 imgs = _gemm.split_weights([wcat, _W(R.C), _W(R.out_proj), _W(R.ff1),
                                             _W(R.ff2)])
-            ce = _gemm.gemm_panel(e, imgs[1][0], d, bias=_B(R.C))
-            pq = _gemm.gemm_panel(x, imgs[0][0], 7 * d, bias=bcat)
+            # fp16 form of the ring GEMM (gemm.F16): the word of max|A| of every GEMM operand of this layer, made once per
+            # tensor (one batched launch where two operands are ready together) and shared by the GEMMs that read it
+            am = None
+            if imgs[0][0].amax is not None:
+                am = torch.zeros(5, dtype=torch.int32, device=dev)        # x, e, o, h, t
+                _gemm.absmax([x, e], out=am[0:2])
+            aw = (lambda i: None) if am is None else (lambda i: am[i:i + 1])
+            ce = _gemm.gemm_panel(e, imgs[1][0], d, bias=_B(R.C), a_amax=aw(1))
+            pq = _gemm.gemm_panel(x, imgs[0][0], 7 * d, bias=bcat, a_amax=aw(0))
         else:
+            am, aw = None, (lambda i: None)
             ce = torch.addmm(_B(R.C), e, _W(R.C).t())
             pq = torch.addmm(bcat, x, wcat.t())                 # [N, 4d + 3d]
         ldp = 7 * d
@@ -439,12 +447,15 @@ class _GPSBlock(torch.autograd.Function):
             check(L.gps_seg_attn_fwd(P + 4 * fs, ldp, ptr(gi.ptr), ptr(gi.tile_graph), ptr(gi.tile_row0),
                                      gi.max_tiles, N, H, dh, scale, p_at, s[2], ptr(o), ptr(lse),
                                      gi.B, int(gi.nmax_host), sb), "gps_seg_attn_fwd")
+            if am is not None:
+                _gemm.absmax([o], out=am[2:3])
             if gemm_stats:      # za = x + drop(out_proj(o)) and the statistics of za (norm1_attn) in the GEMM's epilogue
                 ao = None
-                za = _gemm.gemm_panel_stats(o, imgs[2][0], d, _B(R.out_proj), x, p_l, s[3], bna, sync.site(_S_AO))
+                za = _gemm.gemm_panel_stats(o, imgs[2][0], d, _B(R.out_proj), x, p_l, s[3], bna, sync.site(_S_AO),
+                                            a_amax=aw(2))
             else:
                 za = None
-                ao = (_gemm.gemm_panel(o, imgs[2][0], d, bias=_B(R.out_proj)) if panel
+                ao = (_gemm.gemm_panel(o, imgs[2][0], d, bias=_B(R.out_proj), a_amax=aw(2)) if panel
                       else torch.addmm(_B(R.out_proj), o, _W(R.out_proj).t()))
         if not gg_first:
             xt, eh = local_half()
@@ -468,14 +479,18 @@ class _GPSBlock(torch.autograd.Function):
         # -- FFN + norm2 (gps_layer.py:225-229,253-257) ----------------------------------------
         if panel:       # t = drop(relu(ff1(h))) in the GEMM's epilogue: f1 is never materialised
             f1 = None
-            t = _gemm.gemm_panel(h, imgs[3][0], 2 * d, bias=_B(R.ff1), epilogue=1, p_drop=p_f1, seed=s[4])
+            if am is not None:
+                _gemm.absmax([h], out=am[3:4])
+            t = _gemm.gemm_panel(h, imgs[3][0], 2 * d, bias=_B(R.ff1), epilogue=1, p_drop=p_f1, seed=s[4], a_amax=aw(3))
+            if am is not None:
+                _gemm.absmax([t], out=am[4:5])
         else:
             f1 = torch.addmm(_B(R.ff1), h, _W(R.ff1).t())
             t = _K.act_drop_add(L, None, f1, True, p_f1, s[4], st)
         if gemm_stats:  # z2 = h + drop(ff2(t)) and the statistics of z2 (norm2) in the GEMM's epilogue
-            z2 = _gemm.gemm_panel_stats(t, imgs[4][0], d, _B(R.ff2), h, p_f2, s[5], bn2, sync.site(_S_Z2))
+            z2 = _gemm.gemm_panel_stats(t, imgs[4][0], d, _B(R.ff2), h, p_f2, s[5], bn2, sync.site(_S_Z2), a_amax=aw(4))
         else:
-            f2 = (_gemm.gemm_panel(t, imgs[4][0], d, bias=_B(R.ff2)) if panel
+            f2 = (_gemm.gemm_panel(t, imgs[4][0], d, bias=_B(R.ff2), a_amax=aw(4)) if panel
                   else torch.addmm(_B(R.ff2), t, _W(R.ff2).t()))
             z2 = _E(N, d, **f32)                                # h + drop(f2) and its statistics
             _norm.fwd([_norm.fwd_task(_norm.ADD_DROP, h, N, b=f2, p=p_f2, seed=s[5], out=z2, stats=bn2)], d, dev,
@@ -531,11 +546,19 @@ class _GPSBlock(torch.autograd.Function):
         _norm.bwd_apply(b1, d, dev, None)
         # f2 = ff2(t);  t = drop(relu(f1));  f1 = ff1(h)
         imgs = ctx.imgs
+        bm = None
+        if imgs is not None and imgs[0][1].amax is not None:        # fp16 form: the words of the gradient operands
+            bm = torch.zeros(5, dtype=torch.int32, device=dev)      # g_f2, g_f1, g_ao, g_pq, g_ce
+        bw = (lambda i: None) if bm is None else (lambda i: bm[i:i + 1])
         if imgs is not None:
             # g_f1 = relu/dropout mask of t applied to g_f2 W2 (the mask of t is the mask of f1 wherever it matters:
             # a kept element has t > 0 iff f1 > 0, a dropped one has gradient 0 either way), in the GEMM's epilogue
-            g_f1 = _gemm.gemm_panel(g_f2, imgs[4][1], 2 * d, epilogue=2, mask_src=t, p_drop=p_f1, seed=s[4])
-            g_h = _gemm.gemm_panel(g_f1, imgs[3][1], d, addend=g_z2, out=g_z2)     # residual + FFN input
+            if bm is not None:
+                _gemm.absmax([g_f2], out=bm[0:1])
+            g_f1 = _gemm.gemm_panel(g_f2, imgs[4][1], 2 * d, epilogue=2, mask_src=t, p_drop=p_f1, seed=s[4], a_amax=bw(0))
+            if bm is not None:
+                _gemm.absmax([g_f1], out=bm[1:2])
+            g_h = _gemm.gemm_panel(g_f1, imgs[3][1], d, addend=g_z2, out=g_z2, a_amax=bw(1))     # residual + FFN input
         else:
             g_t = g_f2.mm(_W(R.ff2))
             g_f1 = _K.act_drop_bwd(L, g_t, f1, True, p_f1, s[4], st)
@@ -558,7 +581,9 @@ class _GPSBlock(torch.autograd.Function):
         G, P = g_pq.data_ptr(), pq.data_ptr()
         with _Fork(dev, _BRANCH) as fork:            # attention half of the backward
             sb = current_stream(dev)
-            g_o = _gemm.gemm_panel(g_ao, imgs[2][1], d) if imgs is not None else g_ao.mm(_W(R.out_proj))
+            if bm is not None:
+                _gemm.absmax([g_ao], out=bm[2:3])
+            g_o = _gemm.gemm_panel(g_ao, imgs[2][1], d, a_amax=bw(2)) if imgs is not None else g_ao.mm(_W(R.out_proj))
             delta = _E(H, N, **f32)
             check(L.gps_seg_attn_bwd(ptr(g_o), P + 4 * fs, ldp, ptr(o), ptr(lse), ptr(gi.ptr),
                                      ptr(gi.tile_graph), ptr(gi.tile_row0), gi.max_tiles, N, H, dh, scale,
@@ -587,8 +612,10 @@ class _GPSBlock(torch.autograd.Function):
             ((g_wcat, g_bcat), (g_wc, g_bc), (g_wo, g_bo), (g_w1, g_b1), (g_w2, g_b2)) = \
                 [_K.param_grads(L, g, a, leaves) for g, a in pairs]
         if imgs is not None:
-            g_x = _gemm.gemm_panel(g_pq, imgs[0][1], d, addend=g_xres, out=g_xres)
-            g_e = _gemm.gemm_panel(g_ce, imgs[1][1], d, addend=g_e1)
+            if bm is not None:
+                _gemm.absmax([g_pq, g_ce], out=bm[3:5])
+            g_x = _gemm.gemm_panel(g_pq, imgs[0][1], d, addend=g_xres, out=g_xres, a_amax=bw(3))
+            g_e = _gemm.gemm_panel(g_ce, imgs[1][1], d, addend=g_e1, a_amax=bw(4))
         else:
             g_x = g_xres.addmm_(g_pq, wcat)          # residuals of za and x1 + A..E + in-proj inputs
             g_e = torch.addmm(g_e1, g_ce, _W(R.C))   # residual of e1 + C input

@@ -15,7 +15,7 @@ import torch  # noqa: F401  -- must be imported first: it maps the HIP runtime o
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GPS_HIP_LIB: an alternative build of the same ABI (A/B timing of kernel variants in one process launch each)
 LIB_PATH = os.environ.get("GPS_HIP_LIB") or os.path.join(_HERE, "csrc", "libgps_hip.so")
-ABI_VERSION = 5
+ABI_VERSION = 6
 
 _lib: Optional[ctypes.CDLL] = None
 
@@ -96,6 +96,13 @@ _SIGNATURES = {
     "gps_gemm_stats_supported": (c_int, [c_int64, c_int, c_int]),
     "gps_gemm_panel_stats": (c_int, [_P, c_int64, c_int64, c_int, _P, c_int, _P, _P, c_int64, _P, c_int64, c_float,
                                      c_uint64, _P, _P, c_size_t, _P, _P]),
+    "gps_absmax": (c_int, [c_int, _P, _P]),
+    "gps_gemm16_image_elems": (c_size_t, [c_int64, c_int64]),
+    "gps_gemm16_split_weights": (c_int, [c_int, _P, _P]),
+    "gps_gemm16_panel": (c_int, [_P, c_int64, c_int64, c_int, _P, _P, _P, c_int, _P, _P, c_int64, _P, c_int64, c_int, _P,
+                                 c_int64, c_float, c_uint64, _P]),
+    "gps_gemm16_panel_stats": (c_int, [_P, c_int64, c_int64, c_int, _P, _P, _P, c_int, _P, _P, c_int64, _P, c_int64,
+                                       c_float, c_uint64, _P, _P, c_size_t, _P, _P]),
     "gps_gcn_dinv": (c_int, [_P, _P, c_int64, c_int64, _P, _P]),
     "gps_gcn_spmm": (c_int, [_P, c_int64, _P, _P, _P, c_int64, c_int64, c_int, _P, _P]),
     "gps_adj_sum": (c_int, [_P, c_int64, _P, _P, c_float, c_int64, c_int64, c_int, _P, _P]),
@@ -126,6 +133,17 @@ class GemmSplit(ctypes.Structure):
     """``gps_gemm_split`` (include/gps_hip.h)."""
     _fields_ = [("W", c_void_p), ("ldw", c_int64), ("rows", ctypes.c_int32), ("cols", ctypes.c_int32),
                 ("image_nt", c_void_p), ("image_tn", c_void_p)]
+
+
+class AbsmaxDesc(ctypes.Structure):
+    """``gps_absmax_desc`` (include/gps_hip.h)."""
+    _fields_ = [("A", c_void_p), ("ld", c_int64), ("rows", c_int64), ("cols", ctypes.c_int32), ("slot", c_void_p)]
+
+
+class GemmSplit16(ctypes.Structure):
+    """``gps_gemm_split16`` (include/gps_hip.h)."""
+    _fields_ = [("W", c_void_p), ("ldw", c_int64), ("rows", ctypes.c_int32), ("cols", ctypes.c_int32),
+                ("image_nt", c_void_p), ("image_tn", c_void_p), ("amax", c_void_p)]
 
 
 class GpsHipError(RuntimeError):

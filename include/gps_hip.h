@@ -240,6 +240,43 @@ int gps_gemm_panel_stats(const float* A, int64_t lda, int64_t M, int K, const ui
                          const float* Cin, int64_t ldcin, float* C, int64_t ldc, float p_drop, uint64_t seed,
                          const gps_bn* stats, float* ws, size_t ws_floats, uint32_t* sync, gps_stream_t stream);
 
+/* fp16 form of the same GEMM (round 4; csrc/gemm_panel.hip k_gemm_ring16): identical shapes, images' geometry and
+ * epilogues, replaces the same library GEMMs (graphgps/layer/gatedgcn_layer.py:57-61, gps_layer.py:104-106,143-144,
+ * 253-257).  Every operand value is carried as TWO fp16 pieces of its power-of-two-scaled value (round to nearest:
+ * 22 significant bits) and a*b is formed from 3 piece products on v_mfma_f32_32x32x16_f16 with fp32 accumulation --
+ * half the matrix-pipe work of the 6-product form; measured / emulated error against fp64 at or below the 6-product
+ * form's (fewer roundings into the accumulator), both below an fp32 library GEMM.  The scale of an operand TENSOR is
+ * derived from max|v|, which travels as a device word holding the fp32 bit pattern (an unsigned max, order-free):
+ *   gps_absmax          max over up to 56 row-major matrices per launch: slot = max(slot, max|A|) (atomic; the caller
+ *                       zeroes the words once; several matrices may share a word)
+ *   gps_gemm16_split_weights   image [2 pieces][ceil(K/32)][N'][32] fp16 of each weight under the scale of its `amax` word
+ *   gps_gemm16_panel(_stats)   as gps_gemm_panel(_stats) with `a_amax` (>= max|A|) and `w_amax` (the word the image was
+ *                       made with).  A word LARGER than the true maximum only costs precision (one bit per factor 2). */
+typedef struct gps_absmax_desc {
+  const float* A;      /* [rows][cols] fp32, row stride ld (floats); cols % 4 == 0, 16-byte aligned rows */
+  int64_t ld, rows;
+  int cols;
+  uint32_t* slot;
+} gps_absmax_desc;
+int gps_absmax(int n, const gps_absmax_desc* descs, gps_stream_t stream);
+typedef struct gps_gemm_split16 {
+  const float* W;
+  int64_t ldw;
+  int rows, cols;
+  uint16_t* image_nt;
+  uint16_t* image_tn;
+  const uint32_t* amax;   /* max|W| word (gps_absmax), read by the kernel */
+} gps_gemm_split16;
+size_t gps_gemm16_image_elems(int64_t N, int64_t K);
+int gps_gemm16_split_weights(int n, const gps_gemm_split16* descs, gps_stream_t stream);   /* n <= 48, one launch */
+int gps_gemm16_panel(const float* A, int64_t lda, int64_t M, int K, const uint32_t* a_amax, const uint16_t* image,
+                     const uint32_t* w_amax, int N, const float* bias, const float* Cin, int64_t ldcin, float* C, int64_t ldc,
+                     int epilogue, const float* mask_src, int64_t ldmask, float p_drop, uint64_t seed, gps_stream_t stream);
+int gps_gemm16_panel_stats(const float* A, int64_t lda, int64_t M, int K, const uint32_t* a_amax, const uint16_t* image,
+                           const uint32_t* w_amax, int N, const float* bias, const float* Cin, int64_t ldcin, float* C,
+                           int64_t ldc, float p_drop, uint64_t seed, const gps_bn* stats, float* ws, size_t ws_floats,
+                           uint32_t* sync, gps_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * Segment (per-graph, varlen) multi-head attention core on fp32 MFMA (v_mfma_f32_16x16x4_f32).
  * Replaces to_dense_batch + the softmax(QK^T/sqrt(dh) + key-padding mask) -> dropout -> .V core

@@ -298,7 +298,8 @@ def test_gatedgcn_forward_emits_batch_statistics(profile, nb, d):
 
 @pytest.mark.parametrize("M,K,N", [(7569, 768, 384), (7569, 384, 384), (15348, 384, 384), (130, 384, 192), (64, 384, 384),
                                    (5000, 512, 256), (25013, 256, 256), (743, 64, 64), (743, 128, 64)])
-def test_gemm_epilogue_residual_dropout_statistics(M, K, N):
+@pytest.mark.parametrize("f16", [True, False], ids=["f16x3", "bf16x6"])
+def test_gemm_epilogue_residual_dropout_statistics(M, K, N, f16):
     """gps_gemm_panel_stats: C = Cin + dropout(A W^T + b) with the host model of the mask, and the batch statistics of C
     (norm2 / norm1_attn: gps_layer.py:212-217,225-229) against fp64; repeated launches reproduce bit for bit."""
     from graphgps_amd import gemm, norm
@@ -310,7 +311,7 @@ def test_gemm_epilogue_residual_dropout_statistics(M, K, N):
     b = torch.randn(N, generator=gen)
     res = torch.randn(M, N, generator=gen) * 1.5 + 0.5
     p, seed = 0.1, 0xFEEDFACE12345
-    (img, _), = gemm.split_weights([w.to(DEV)], tn=False)
+    (img, _), = gemm.split_weights([w.to(DEV)], tn=False, f16=f16)
     bn = _bn(N, gen)
     before = (bn.running_mean.clone().cpu(), bn.running_var.clone().cpu())
     desc, st = _desc(bn, N)

@@ -703,11 +703,17 @@ def test_gin_aggregate_matches_index_add():
                                    (300, 48, 336), (130, 16, 16), (500, 384, 80), (500, 80, 384),
                                    # N, K multiples of 4 only (d = 52: ZINC GPS-small variants, 72: peptides SAN/GPS)
                                    (500, 52, 364), (500, 364, 52), (743, 72, 72), (300, 52, 52), (500, 20, 36)])
-def test_gemm_panel_fp32_exact_products(M, K, N):
+@pytest.mark.parametrize("f16", [True, False], ids=["f16x3", "bf16x6"])
+def test_gemm_panel_fp32_exact_products(M, K, N, f16):
     """csrc/gemm_panel.hip at the block's projection shapes (N, K in {384, 768, 2688}; M = nodes / edges, ragged last
     row tile): C = A W^T + bias against fp64, through the weight image (forward) and through the transposed image
     (input gradient), with the addend and both epilogues; the error is that of an fp32 GEMM (a few 1e-7 of the
-    result scale), also with a +100 offset on the operands where a lossy split would show at 1e-3."""
+    result scale), also with a +100 offset on the operands where a lossy split would show at 1e-3.  Both arithmetic
+    forms (round 4: two fp16 pieces / 3 products, the default; round 2: three bf16 pieces / 6 products) meet the SAME
+    bounds."""
+    import functools
+    from graphgps_amd import gemm as _g
+    _sw = functools.partial(_g.split_weights, f16=f16)
     from graphgps_amd.gemm import gemm_panel, split_weights
     from graphgps_amd.ops import attn_dropout_keep_mask
     dev = torch.device("cuda:0")
@@ -718,7 +724,7 @@ def test_gemm_panel_fp32_exact_products(M, K, N):
     add = torch.randn(M, N, generator=gen)
     ag, wg, bg = a.to(dev), w.to(dev), b.to(dev)
     from graphgps_amd.gemm import supported as _sup
-    (img_nt, img_tn), = split_weights([wg], tn=_sup(K, N))
+    (img_nt, img_tn), = _sw([wg], tn=_sup(K, N))
     ref = a.double() @ w.double().t()
     scale = float(ref.abs().max())
     # yardstick: the library's own fp32 GEMM on the same operands (an fp32 dot product of K terms carries
@@ -764,7 +770,7 @@ def test_gemm_panel_fp32_exact_products(M, K, N):
     # as many products per k-step.  For the block's operands (BatchNorm / ReLU outputs, weights: |mean| <~ std) this
     # sits at the library's own ~1e-6; at mean/std = 100 it reaches 2e-4 of the result (library: 3e-5).
     a2, w2 = a + 3.0, w + 3.0 / K ** 0.5
-    (i2, _), = split_weights([w2.to(dev)], tn=False)
+    (i2, _), = _sw([w2.to(dev)], tn=False)
     ref2 = a2.double() @ w2.double().t()
     out2 = gemm_panel(a2.to(dev), i2, N)
     lib2 = float((torch.mm(a2.to(dev), w2.to(dev).t()).double().cpu() - ref2).abs().max())
@@ -812,6 +818,43 @@ def test_edge_attention_real_edges(H, D, profile, nb, softmax):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("mag", [1e-30, 3e-9, 1.0, 7e5, 2e30])
+def test_gemm16_operand_scales(mag):
+    """fp16 form of the ring GEMM: the per-tensor power-of-two scale keeps the result at fp32 grade whatever the
+    magnitude of the operands (gradient-sized 3e-9, near-denormal 1e-30, huge 2e30), for rows far below the tensor's
+    maximum (absolute error stays relative to the maximum), all-zero operands, and a word LARGER than the true maximum;
+    ``absmax`` itself is bit-exact against torch."""
+    from graphgps_amd import gemm as _g
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(31)
+    M, K, N = 1000, 384, 384
+    a = torch.randn(M, K, generator=gen) * mag
+    a[::7] *= 1e-4                                  # rows far below the maximum
+    a[5] = 0.0
+    w = torch.randn(N, K, generator=gen) / K ** 0.5 * (1.0 / mag if 1e-20 < mag < 1e20 else 1.0)
+    ag, wg = a.to(dev), w.to(dev)
+    words = _g.absmax([ag, wg, ag[:, :128]])
+    want = torch.stack([ag.abs().max(), wg.abs().max(), ag[:, :128].abs().max()]).view(torch.int32)
+    assert torch.equal(words.cpu(), want.cpu())
+    (img, _), = _g.split_weights([wg], tn=False, f16=True)
+    ref = a.double() @ w.double().t()
+    scale = float(ref.abs().max())
+    out = _g.gemm_panel(ag, img, N)
+    err = float((out.double().cpu() - ref).abs().max())
+    lib_err = float((torch.mm(ag, wg.t()).double().cpu() - ref).abs().max())
+    print(f"gemm16 |a| ~ {mag:g}: max err {err:.2e} (library {lib_err:.2e}, scale {scale:.3g})")
+    assert err <= max(4e-6 * scale, 1.5 * lib_err)
+    assert float(out[5].abs().max()) == 0.0
+    # a word twice / 64 times the true maximum: one / six bits of precision less, never a wrong result
+    for k, bound in ((1, 8e-6), (6, 2e-4)):
+        big = (ag.abs().max() * 2.0 ** k).reshape(1).view(torch.int32)
+        out2 = _g.gemm_panel(ag, img, N, a_amax=big)
+        assert float((out2.double().cpu() - ref).abs().max()) <= bound * scale
+    z = torch.zeros(M, K, device=dev)
+    assert float(_g.gemm_panel(z, img, N).abs().max()) == 0.0
+
+
+@pytest.mark.gpu
 def test_dma_kernels_race_screen():
     """The ring GEMM and the streaming weight-gradient kernel order their LDS-DMA against their LDS reads with counted
     vmcnt waits and (GEMM) one barrier per stage; a read placed one wait too early returns stale LDS only when the DMA
@@ -825,10 +868,11 @@ def test_dma_kernels_race_screen():
     dev = torch.device("cuda:0")
     gen = torch.Generator().manual_seed(99)
     noise = torch.empty(64 << 20, device=dev)
-    for M, K, N in ((7569, 384, 2688), (7569, 2688, 384), (15348, 384, 384)):
+    for M, K, N, f16 in ((7569, 384, 2688, True), (7569, 2688, 384, True), (15348, 384, 384, True), (7569, 768, 384, True),
+                         (7569, 256, 1792, True), (7569, 384, 2688, False), (7569, 2688, 384, False), (15348, 384, 384, False)):
         a = torch.randn(M, K, generator=gen).to(dev)
         w = (torch.randn(N, K, generator=gen) / K ** 0.5).to(dev)
-        (img, _), = split_weights([w], tn=False)
+        (img, _), = split_weights([w], tn=False, f16=f16)
         first = gemm_panel(a, img, N).clone()
         ref = a.double() @ w.double().t()
         assert float((first.double() - ref).abs().max()) <= 4e-6 * float(ref.abs().max()) + 1e-5
