@@ -85,6 +85,28 @@ __device__ __forceinline__ void reduce_rows(V4 (&s)[NVEC], float* lds, int d, in
   }
 }
 
+// max |.| over a block's stored values -> ONE atomic on the tensor's word (fp32 bit patterns: an unsigned max, order-free).
+// The words feed the fp16 form of the ring GEMM (csrc/gemm_panel.hip) that consumes the stored tensor.  Through LDS, not
+// wave shuffles: the last wave of a block may be partly inactive (480 threads at d = 384).
+__device__ __forceinline__ float vmax4(float mx, const V4& v) {
+  return fmaxf(fmaxf(fmaxf(fmaxf(mx, fabsf(v[0])), fabsf(v[1])), fabsf(v[2])), fabsf(v[3]));     // (a chain: no temporaries)
+}
+__device__ __forceinline__ void block_amax(float mx, uint32_t* slot, float* lds) {
+  uint32_t* w = reinterpret_cast<uint32_t*>(lds);
+  const int t = threadIdx.x, n = blockDim.x;
+  __syncthreads();                               // whoever used the scratch before is done
+  w[t] = __float_as_uint(mx);
+  __syncthreads();
+  if (t < 64) {                                  // wave 0 is always whole (threads_for >= 256)
+    uint32_t m = w[t];
+    for (int q = t + 64; q < n; q += 64) m = max(m, w[q]);
+#pragma unroll
+    for (int o = 32; o; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+    if (t == 0 && m) atomicMax(slot, m);
+  }
+  __syncthreads();                               // the scratch may be reused
+}
+
 // ------------------------------------------------------------------------------------------------
 // forward: produce rows (optionally store them, optionally accumulate their column statistics)
 // ------------------------------------------------------------------------------------------------
@@ -94,6 +116,7 @@ struct FwdTask {
   const float *a, *b, *res;
   Bn bn1, bn2;
   float* out;     // produced rows (nullptr: statistics only)
+  uint32_t* amax; // max|out| word, or nullptr
   int64_t R;
   uint64_t seed;
   float p;
@@ -181,6 +204,7 @@ __device__ __forceinline__ bool run_fwd(const FwdTask& T, int d, int lb, uint64_
   // loads are unconditional), so a pass costs issue time, not a memory round trip
   int64_t r = row0 + rsub;
   const int64_t rl = row1 - 1;
+  float mx = 0.0f;
   if (r < row1) {
     RowIn i0 = load_in<KIND>(T, r, c, d), i1 = load_in<KIND>(T, min(r + RS, rl), c, d);
     for (; r + RS < row1; r += 2 * RS) {
@@ -189,14 +213,17 @@ __device__ __forceinline__ bool run_fwd(const FwdTask& T, int d, int lb, uint64_
       const V4 v1 = eval_row<KIND, RELU, DROP>(T, i1, r + RS, c, c1, c2, seed, inv_keep);
       if (T.out) { v0.store(T.out + r * d + c); v1.store(T.out + (r + RS) * d + c); }
       if (stats) { account(v0); account(v1); }
+      mx = vmax4(vmax4(mx, v0), v1);
       i0 = n0; i1 = n1;
     }
     if (r < row1) {
       const V4 v0 = eval_row<KIND, RELU, DROP>(T, i0, r, c, c1, c2, seed, inv_keep);
       if (T.out) v0.store(T.out + r * d + c);
       if (stats) account(v0);
+      mx = vmax4(mx, v0);
     }
   }
+  if (T.amax) block_amax(mx, T.amax, lds);      // block-uniform
   if (!stats) return false;      // block-uniform
   reduce_rows<2>(s, lds, d, RS, rsub, c);
   if (rsub == 0) {
@@ -256,6 +283,7 @@ struct BwdTask {
   float* g_z;            // primary input gradient
   float* g_sum;          // dual: g_z + g_z2
   float* g_drop;         // dropmask(seed2, p2) of g_z (dual: of g_z2), or nullptr
+  uint32_t* amax_drop;   // apply kernel: max|g_drop| word, or nullptr
   float p1x;             // dual only: dropout (p1x, seed1x) applied to the STORED g_z (g_sum stays unmasked)
   uint64_t seed1x;
   int64_t R;
@@ -383,7 +411,7 @@ struct ApplyCtx {
 // one row of an apply task: stores the gradients, returns the primary one (input of the chain)
 template <bool RELU, bool DROP, bool DUAL>
 __device__ __forceinline__ V4 apply_row(const BwdTask& T, const ApplyCtx& A, int d, int64_t row, int c, const V4& v,
-                                        const V4& gy, const V4& v2) {
+                                        const V4& gy, const V4& v2, float& dmx) {
   V4 g, zh, o;
   out_grad<RELU, DROP>(v, gy, A.c1, DROP ? row_hash((uint32_t)row, A.seed) : 0u, c, T.p, A.inv_keep, g, zh);
 #pragma unroll
@@ -417,6 +445,7 @@ __device__ __forceinline__ V4 apply_row(const BwdTask& T, const ApplyCtx& A, int
       for (int j = 0; j < 4; ++j) q[j] = keep_elem(rh2, (uint32_t)(c + j), T.p2) ? last[j] * A.ik2 : 0.0f;
     }
     q.store(T.g_drop + row * d + c);
+    dmx = vmax4(dmx, q);
   }
   return o;
 }
@@ -470,15 +499,17 @@ __device__ __forceinline__ void run_bwd_apply(const BwdTask& T, int d, int lb, c
   };
   int64_t r = row0 + rsub;
   const int64_t rl = row1 - 1;
+  float dmx = 0.0f;
   if (r < row1) {           // one row per pass with the next one prefetched: this kernel's column constants (up to three
     In a = ld(r);           // BatchNorms + their sums) leave no room for more rows in flight at a useful occupancy
     for (; r < row1; r += RS) {
       const In na = ld(min(r + RS, rl));
-      const V4 oa = apply_row<RELU, DROP, DUAL>(T, A, d, r, c, a.v, a.g, a.w);
+      const V4 oa = apply_row<RELU, DROP, DUAL>(T, A, d, r, c, a.v, a.g, a.w, dmx);
       if (CHAIN) chain(r, oa, a.cz);
       a = na;
     }
   }
+  if (T.amax_drop) block_amax(dmx, T.amax_drop, lds);      // block-uniform
   if (!CHAIN) return;
   reduce_rows<2>(s, lds, d, RS, rsub, c);
   if (rsub == 0) {
@@ -490,7 +521,9 @@ __device__ __forceinline__ void run_bwd_apply(const BwdTask& T, int d, int lb, c
   }
 }
 
-__global__ __launch_bounds__(kMaxThreads) void k_bwd_apply(const BwdGroup G) {
+// (two 480-thread blocks per CU = 4 waves per SIMD = 128 VGPRs: two-task lists have 512 blocks, and at 130 registers the
+// second block of a CU waited for the first -- the bound keeps the allocator at the 128 the kernel had before the max|.| word)
+__global__ __launch_bounds__(kMaxThreads, 4) void k_bwd_apply(const BwdGroup G) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   int ti = 0;
 #pragma unroll
@@ -609,6 +642,7 @@ int gps_norm_fwd(int n, const gps_norm_fwd_task* tasks, int d, float* ws, size_t
       T.bn2 = bn_of(S.bn2);
     }
     T.out = S.out; T.R = S.R; T.seed = S.seed;
+    T.amax = S.out ? S.amax : nullptr;
     T.p = (S.kind == K_ADD_DROP || S.kind == K_BN_ACT) ? S.p : 0.f;
     T.kind = S.kind; T.relu = S.relu;
     T.rpb = rows_per_block(S.R); T.nblk = nblocks_for(S.R);
@@ -690,6 +724,7 @@ int gps_norm_bwd_apply(int n, const gps_norm_bwd_task* tasks, int d, float* ws, 
     const gps_norm_bwd_task& S = tasks[i];
     BwdTask& T = G.t[i];
     GPS_REQUIRE(S.g_z && al16(S.g_z) && al16(S.g_sum) && al16(S.g_drop), "%s: task %d: null / misaligned output", who, i);
+    T.amax_drop = S.g_drop ? S.amax_drop : nullptr;
     if (S.cz) {
       if (int rc = check_bn(who, S.cbn)) return rc;
       GPS_REQUIRE(al16(ws) && al16(S.cz) && S.cg_gamma && S.cg_beta && al16(S.cg_gamma) && al16(S.cg_beta),

@@ -33,6 +33,7 @@
 //   + bias[n]; + Cin[m][n] (residual / gradient accumulation, may alias C); ReLU + dropout(p, seed) keyed
 //   (row, column) exactly as csrc/bn_fused.hip's act_drop (gps_layer.py:256); multiplication by the ReLU/dropout mask
 //   of a saved activation `mask_src` (the FFN's backward, = gps_act_drop_bwd).
+#include <algorithm>
 #include <cstdint>
 #include <cstdlib>
 
@@ -194,6 +195,7 @@ struct PanelArgs {
   // fp16 form (k_gemm_ring16): max|A| and max|B| as fp32 bit patterns (device words written by gps_absmax / a producer)
   const uint32_t* a_amax;
   const uint32_t* w_amax;
+  uint32_t* c_amax;        // optional: raised to max|C| over the stored elements (the word of the NEXT GEMM that reads C)
 };
 
 // Epilogue shared by both kernels.  D[row = (q&3) + 8*(q>>2) + 4*kh][col = li] of each 32 x 32 block; 32 lanes = 128
@@ -422,7 +424,8 @@ __device__ float g_zero_bias[kZeroBias];      // stands in for a null bias, so t
 // and never stored): column indices of the loads are clamped, the stores predicated.
 template <int MB, int NJ, int EPI, bool HAS_CIN, bool FULL, bool EDGE>
 __device__ __forceinline__ void ring_store(const PanelArgs& P, const f32x16 (&acc)[MB][NJ], int64_t m0, int n0, int wm,
-                                           int wn, int li, int kh, float (&sk)[NJ], float (&s1)[NJ], float (&s2)[NJ]) {
+                                           int wn, int li, int kh, float (&sk)[NJ], float (&s1)[NJ], float (&s2)[NJ],
+                                           float& amx) {
   const uint64_t seed = gps::salted_seed(P.seed, P.salt);
   const bool drop = EPI != 0 && P.p_drop > 0.0f;
   const float inv_keep = drop ? 1.0f / (1.0f - P.p_drop) : 1.0f;
@@ -473,18 +476,21 @@ __device__ __forceinline__ void ring_store(const PanelArgs& P, const f32x16 (&ac
           s1[j] += t;
           s2[j] += t * t;
         }
-        if ((FULL || row < P.M) && (!EDGE || col < P.N)) __builtin_nontemporal_store(v, P.C + row * P.ldc + col);
+        const bool live = (FULL || row < P.M) && (!EDGE || col < P.N);
+        amx = live ? fmaxf(amx, fabsf(v)) : amx;        // (one v_max with |.|: dead code wherever the caller drops amx)
+        if (live) __builtin_nontemporal_store(v, P.C + row * P.ldc + col);
       }
     }
   }
 }
 template <int MB, int NJ, int EPI, bool HAS_CIN, bool EDGE>
 __device__ __forceinline__ void ring_epilogue(const PanelArgs& P, const f32x16 (&acc)[MB][NJ], int64_t m0, int n0, int wm,
-                                              int wn, int li, int kh, float (&sk)[NJ], float (&s1)[NJ], float (&s2)[NJ]) {
+                                              int wn, int li, int kh, float (&sk)[NJ], float (&s1)[NJ], float (&s2)[NJ],
+                                              float& amx) {
   // (all workgroup-uniform) only the last column panel of an EDGE shape can be partial; the others take the straight-line stores
-  if (EDGE && n0 + 64 * NJ > P.N) ring_store<MB, NJ, EPI, HAS_CIN, false, true>(P, acc, m0, n0, wm, wn, li, kh, sk, s1, s2);
-  else if (m0 + 64 * MB <= P.M) ring_store<MB, NJ, EPI, HAS_CIN, true, false>(P, acc, m0, n0, wm, wn, li, kh, sk, s1, s2);   // workgroup-uniform
-  else ring_store<MB, NJ, EPI, HAS_CIN, false, false>(P, acc, m0, n0, wm, wn, li, kh, sk, s1, s2);
+  if (EDGE && n0 + 64 * NJ > P.N) ring_store<MB, NJ, EPI, HAS_CIN, false, true>(P, acc, m0, n0, wm, wn, li, kh, sk, s1, s2, amx);
+  else if (m0 + 64 * MB <= P.M) ring_store<MB, NJ, EPI, HAS_CIN, true, false>(P, acc, m0, n0, wm, wn, li, kh, sk, s1, s2, amx);   // workgroup-uniform
+  else ring_store<MB, NJ, EPI, HAS_CIN, false, false>(P, acc, m0, n0, wm, wn, li, kh, sk, s1, s2, amx);
 }
 
 // Column statistics of the panel (EPI == 3): the two row-waves of each column half meet through LDS (the ring is free
@@ -756,7 +762,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring(const PanelArgs P) {
   float sk[NJ], s1[NJ], s2[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) sk[j] = s1[j] = s2[j] = 0.f;
-  ring_epilogue<MB, NJ, EPI, HAS_CIN, EDGE>(P, acc, m0, n0, wm, wn, li, kh, sk, s1, s2);
+  float amx_unused = 0.f;
+  ring_epilogue<MB, NJ, EPI, HAS_CIN, EDGE>(P, acc, m0, n0, wm, wn, li, kh, sk, s1, s2, amx_unused);
   if (EPI == 3) ring_stats<MB, NJ>(P, rt, panel, m0, wm, wn, li, kh, sk, s1, s2, reinterpret_cast<float*>(ring));
   __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 15));
   stamp(3);
@@ -827,7 +834,7 @@ __global__ __launch_bounds__(256) void k_absmax(const AbsGroup G) {
   const int n4 = (int)(nrows * cq);
   const float* base = D.A + r0 * D.ld;
   uint32_t m = 0;
-#pragma unroll 4
+#pragma unroll 8
   for (int idx = threadIdx.x; idx < n4; idx += 256) {
     const int r = idx / cq, c = idx - r * cq;
     const u32x4 v = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(base + (int64_t)r * D.ld + 4 * c));
@@ -835,7 +842,15 @@ __global__ __launch_bounds__(256) void k_absmax(const AbsGroup G) {
   }
 #pragma unroll
   for (int o = 32; o; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
-  if ((threadIdx.x & 63) == 0 && m) atomicMax(D.slot, m);
+  // ONE atomic per workgroup: atomics on one word serialise at the L2 (~6 ns each -- with one per wavefront a 12 MB
+  // matrix took 20 us, 0.6 TB/s, whatever its size)
+  __shared__ uint32_t wmax[4];
+  if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+    if (m) atomicMax(D.slot, m);
+  }
 }
 
 // ---- weight images, fp16 form: [2 pieces][K/32][N'][32], same geometry as the 3-piece image ------------------------------
@@ -1128,8 +1143,22 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring16(const PanelArgs P) 
   float sk[NJ], s1[NJ], s2[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) sk[j] = s1[j] = s2[j] = 0.f;
-  ring_epilogue<MB, NJ, EPI, HAS_CIN, EDGE>(P, acc, m0, n0, wm, wn, li, kh, sk, s1, s2);
+  float amx = 0.f;
+  ring_epilogue<MB, NJ, EPI, HAS_CIN, EDGE>(P, acc, m0, n0, wm, wn, li, kh, sk, s1, s2, amx);
   if (EPI == 3) ring_stats<MB, NJ>(P, rt, panel, m0, wm, wn, li, kh, sk, s1, s2, reinterpret_cast<float*>(ring));
+  if (P.c_amax) {                                        // workgroup-uniform: max|C| of this tile -> one atomic
+    uint32_t m = __float_as_uint(amx);
+#pragma unroll
+    for (int o = 32; o; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+    uint32_t* wmax = reinterpret_cast<uint32_t*>(ring);
+    __syncthreads();                                     // the ring (and the statistics scratch) is free
+    if (lane == 0) wmax[wave] = m;
+    __syncthreads();
+    if (t == 0) {
+      m = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
+      if (m) atomicMax(P.c_amax, m);
+    }
+  }
   __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 15));
   stamp(3);
 }
@@ -1143,7 +1172,8 @@ unsigned long long* g_panel_trace = nullptr;
 static int panel_launch(const float* A, int64_t lda, int64_t M, int K, const uint16_t* image, int N, const float* bias,
                         const float* Cin, int64_t ldcin, float* C, int64_t ldc, int epilogue, const float* mask_src,
                         int64_t ldmask, float p_drop, uint64_t seed, const gps_bn* stats, float* ws, size_t ws_floats,
-                        uint32_t* sync, gps_stream_t stream, const uint32_t* a_amax = nullptr, const uint32_t* w_amax = nullptr);
+                        uint32_t* sync, gps_stream_t stream, const uint32_t* a_amax = nullptr, const uint32_t* w_amax = nullptr,
+                        uint32_t* c_amax = nullptr);
 
 // 128-row panels (MB = 2) when they still give every CU a workgroup; 64-column panels always use 64 rows (the only
 // NJ = 1 instantiation).  GPS_GEMM_RING_MB = 1 / 2 forces one.
@@ -1240,8 +1270,9 @@ int gps_absmax(int n, const gps_absmax_desc* descs, gps_stream_t stream) {
                 "gps_absmax: matrix %d: bad shape / alignment", i);
     if (d.rows == 0) continue;
     const int cq = d.cols / 4;
-    const int nr = cq >= 2048 ? 1 : 2048 / cq;                 // ~32 KB per workgroup
-    G.d[G.n] = AbsDesc{d.A, d.ld, d.rows, d.cols, nr, d.slot, blocks};
+    int64_t nr = cq >= 1024 ? 1 : 1024 / cq;                   // >= 16 KB per workgroup ...
+    nr = std::max<int64_t>(nr, (d.rows + 255) / 256);          // ... and at most 256 workgroups (= atomics) per matrix
+    G.d[G.n] = AbsDesc{d.A, d.ld, d.rows, d.cols, (int)nr, d.slot, blocks};
     blocks += (int)((d.rows + nr - 1) / nr);
     ++G.n;
   }
@@ -1274,11 +1305,12 @@ int gps_gemm16_split_weights(int n, const gps_gemm_split16* descs, gps_stream_t 
 
 int gps_gemm16_panel(const float* A, int64_t lda, int64_t M, int K, const uint32_t* a_amax, const uint16_t* image,
                      const uint32_t* w_amax, int N, const float* bias, const float* Cin, int64_t ldcin, float* C, int64_t ldc,
-                     int epilogue, const float* mask_src, int64_t ldmask, float p_drop, uint64_t seed, gps_stream_t stream) {
+                     int epilogue, const float* mask_src, int64_t ldmask, float p_drop, uint64_t seed, uint32_t* c_amax,
+                     gps_stream_t stream) {
   GPS_REQUIRE(epilogue >= 0 && epilogue <= 2, "gps_gemm16_panel: epilogue");
   GPS_REQUIRE(a_amax && w_amax, "gps_gemm16_panel: operand maxima");
   return panel_launch(A, lda, M, K, image, N, bias, Cin, ldcin, C, ldc, epilogue, mask_src, ldmask, p_drop, seed, nullptr,
-                      nullptr, 0, nullptr, stream, a_amax, w_amax);
+                      nullptr, 0, nullptr, stream, a_amax, w_amax, c_amax);
 }
 
 int gps_gemm16_panel_stats(const float* A, int64_t lda, int64_t M, int K, const uint32_t* a_amax, const uint16_t* image,
@@ -1300,7 +1332,7 @@ int gps_gemm16_panel_stats(const float* A, int64_t lda, int64_t M, int K, const 
 static int panel_launch(const float* A, int64_t lda, int64_t M, int K, const uint16_t* image, int N, const float* bias,
                         const float* Cin, int64_t ldcin, float* C, int64_t ldc, int epilogue, const float* mask_src,
                         int64_t ldmask, float p_drop, uint64_t seed, const gps_bn* stats, float* ws, size_t ws_floats,
-                        uint32_t* sync, gps_stream_t stream, const uint32_t* a_amax, const uint32_t* w_amax) {
+                        uint32_t* sync, gps_stream_t stream, const uint32_t* a_amax, const uint32_t* w_amax, uint32_t* c_amax) {
   GPS_REQUIRE(M >= 0 && gps_gemm_panel_supported(N, K), "gps_gemm_panel: needs N %% 4 == 0 and K %% 4 == 0 (N=%d K=%d)",
               N, K);
   if (M == 0) return GPS_OK;
@@ -1314,7 +1346,7 @@ static int panel_launch(const float* A, int64_t lda, int64_t M, int K, const uin
   P.C = C; P.ldc = ldc; P.epilogue = epilogue; P.mask_src = mask_src; P.ldmask = ldmask;
   P.p_drop = epilogue ? p_drop : 0.0f; P.seed = seed; P.salt = gps::dropout_salt();
   P.trace = g_panel_trace;
-  P.a_amax = a_amax; P.w_amax = w_amax;
+  P.a_amax = a_amax; P.w_amax = w_amax; P.c_amax = c_amax;
   const bool f16 = a_amax != nullptr;
   GPS_REQUIRE((a_amax == nullptr) == (w_amax == nullptr), "gps_gemm16_panel: both operand maxima or neither");
   hipStream_t s = gps::as_stream(stream);

@@ -31,6 +31,9 @@ namespace {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 // Exact 3-way split of 8 fp32 values into bf16 pieces (hi + mid + lo == v bit-for-bit: each piece
 // takes the next 8 significant bits by truncation, the remainders are exact fp32 subtractions),
@@ -73,6 +76,8 @@ struct Problem {
   int M, Nn, tiles_m, tiles_n, S, rows_per_slice;
   int block_begin;    // first workgroup of this problem (grouped launch)
   int64_t out_begin;  // first reduce-thread index of this problem (grouped reduce)
+  const uint32_t* g_amax;   // fp16 form (k_wgrad_stream<true>): max|g| / max|x| words (csrc/gemm_panel.hip gps_absmax), or null
+  const uint32_t* x_amax;
 };
 
 struct Group {
@@ -295,6 +300,15 @@ __device__ __forceinline__ void glds16(const unsigned char* g, unsigned char* l)
 }
 constexpr int waitcnt_imm(int vm, int lgkm) { return (vm & 15) | (7 << 4) | ((lgkm & 15) << 8) | ((vm >> 4) << 14); }
 
+// F16 (round 4): the arithmetic of csrc/gemm_panel.hip's k_gemm_ring16 -- each operand value as two fp16 pieces of its
+// scaled value (scale = the power of two that puts the operand TENSOR's max|.| word in [2^14, 2^15)), three piece products
+// per value product on v_mfma_f32_32x32x16_f16: 48 MFMAs per stage instead of 96 and 8 VALU per value pair instead of 11.
+// The groups keep their shape (4 accumulators rotating, the same fills in the same order), two fill slots per issue gap.
+__device__ __forceinline__ unsigned amax_be(const uint32_t* slot) {
+  const unsigned be = (__builtin_nontemporal_load(slot) >> 23) & 255u;
+  return be < 16u ? 16u : be;
+}
+template <bool F16>
 __global__ __launch_bounds__(256, 1) void k_wgrad_stream(const Group G) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
   // Work item of this workgroup.  Items are numbered (problem, row slice, g-column tile, x-column tile), x fastest: items
@@ -361,8 +375,24 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_stream(const Group G) {
   // exact 3-way split of values (2d, 2d+1) of a fragment in three instalments (4 + 4 + 3 VALU); `bs` (g fragments only)
   // accumulates the bias gradient, scaled by `bw` (0 for the prefetch that runs past the last stage)
   float sv0, sv1, sr0, sr1;
+  f32x2 st_hb;
+  uint32_t st_hi;
+  const unsigned beg = F16 ? amax_be(P.g_amax) : 127u, bex = F16 ? amax_be(P.x_amax) : 127u;
+  const float scg = __uint_as_float((268u - beg) << 23), scx = __uint_as_float((268u - bex) << 23);     // 2^(141 - be)
   auto split_part = [&](int part, const float (&raw)[8], int d, Pieces& out, float* bs, float bw) __attribute__((always_inline)) {
-    if (part == 0) {
+    if constexpr (F16) {
+      const f32x2 v = (f32x2){raw[2 * d], raw[2 * d + 1]};
+      const float sc = bs ? scg : scx;                       // (g fragments carry the bias-gradient accumulator)
+      if (part == 0) {
+        if (bs) *bs = fmaf(v[0] + v[1], bw, *bs);
+        st_hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v * sc, f16x2));
+        out.p[0][d] = st_hi;
+      } else if (part == 1) {
+        st_hb = __builtin_convertvector(__builtin_bit_cast(f16x2, st_hi), f32x2);
+      } else {
+        out.p[1][d] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v * sc - st_hb, f16x2));
+      }
+    } else if (part == 0) {
       sv0 = raw[2 * d];
       sv1 = raw[2 * d + 1];
       if (bs) *bs = fmaf(sv0 + sv1, bw, *bs);
@@ -383,9 +413,14 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_stream(const Group G) {
 #pragma unroll
       for (int part = 0; part < 3; ++part) split_part(part, raw, d, out, bs, bw);
   };
+  constexpr int NT = F16 ? 3 : 6;                                          // piece products per value product
   constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};   // smallest terms first
+  constexpr int TA16[3] = {1, 0, 0}, TB16[3] = {0, 1, 0};                 // lo*hi, hi*lo, hi*hi
   auto mfma = [&](const Pieces& a, const Pieces& b, int term, f32x16& c) __attribute__((always_inline)) {
-    c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a.p[TA[term]]), __builtin_bit_cast(bf16x8, b.p[TB[term]]), c, 0, 0, 0);
+    if constexpr (F16)
+      c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a.p[TA16[term]]), __builtin_bit_cast(f16x8, b.p[TB16[term]]), c, 0, 0, 0);
+    else
+      c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a.p[TA[term]]), __builtin_bit_cast(bf16x8, b.p[TB[term]]), c, 0, 0, 0);
   };
 
   Pieces A01[2][2], A23[2], B[4];
@@ -422,13 +457,13 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_stream(const Group G) {
 
   // One group = 24 MFMAs on 4 accumulators (pairs (ia, jb) given per call), `fill(m)` = what goes into the gap after MFMA m
 #define WS_GROUP(AI0, AI1, AI2, AI3, J0, J1, J2, J3, I0, I1, I2, I3, FILL)                              \
-  _Pragma("unroll") for (int m = 0; m < 24; ++m) {                                                       \
+  _Pragma("unroll") for (int m = 0; m < 4 * NT; ++m) {                                                   \
     const int term = m >> 2, pr = m & 3;                                                                \
     if (pr == 0) mfma(AI0, B[J0], term, acc[I0][J0]);                                                   \
     if (pr == 1) mfma(AI1, B[J1], term, acc[I1][J1]);                                                   \
     if (pr == 2) mfma(AI2, B[J2], term, acc[I2][J2]);                                                   \
     if (pr == 3) mfma(AI3, B[J3], term, acc[I3][J3]);                                                   \
-    FILL(m);                                                                                            \
+    if constexpr (F16) { FILL(2 * m); FILL(2 * m + 1); } else { FILL(m); }   /* 24 fill slots per group either way */ \
     __builtin_amdgcn_sched_barrier(0);                                                                  \
   }
 
@@ -505,7 +540,7 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_stream(const Group G) {
       split_all(rb[f], B[f], nullptr, 0.0f);
     }
 #pragma unroll
-    for (int term = 0; term < 6; ++term)
+    for (int term = 0; term < NT; ++term)
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -547,10 +582,12 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_stream(const Group G) {
         }
       }
       const int col = n0 + j * 32 + li;
+      // fp16 form: back from the scaled operands, two exact power-of-two factors (neither can leave the exponent range alone)
+      const float ug = __uint_as_float((beg - 14u) << 23), ux = __uint_as_float((bex - 14u) << 23);
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int row = m0 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh;
-        po[(int64_t)row * P.Nn + col] = sum[q];
+        po[(int64_t)row * P.Nn + col] = F16 ? (sum[q] * ug) * ux : sum[q];
       }
     }
   }
@@ -690,12 +727,17 @@ int launch_group(Group& G, float* ws, hipStream_t s, const char* who) {
   // GPS_WGRAD_FP32_MFMA=1 keeps the contraction on the fp32-input MFMA (v_mfma_f32_32x32x2_f32)
   static const bool fp32_pipe = [] { const char* e = getenv("GPS_WGRAD_FP32_MFMA"); return e && atoi(e) != 0; }();
   if (stream_ok(G) && !fp32_pipe) {
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_stream),
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_stream<false>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS);
-    GPS_REQUIRE(attr == hipSuccess, "%s: cannot reserve %d bytes of LDS", who, WS_LDS);
+    static const hipError_t attr16 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_stream<true>),
+                                                         hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS);
+    GPS_REQUIRE(attr == hipSuccess && attr16 == hipSuccess, "%s: cannot reserve %d bytes of LDS", who, WS_LDS);
     static const int xcd_map = [] { const char* e = getenv("GPS_WGRAD_XCD_MAP"); return e && *e ? atoi(e) : 1; }();
     G.xcd_map = xcd_map;
-    k_wgrad_stream<<<(unsigned)blocks, 256, WS_LDS, s>>>(G);
+    bool f16 = true;                 // every problem of the launch carries its operands' max|.| words
+    for (int i = 0; i < G.n; ++i) f16 = f16 && G.p[i].g_amax && G.p[i].x_amax;
+    if (f16) k_wgrad_stream<true><<<(unsigned)blocks, 256, WS_LDS, s>>>(G);
+    else k_wgrad_stream<false><<<(unsigned)blocks, 256, WS_LDS, s>>>(G);
   } else if (fp32_pipe)
     k_wgrad<false><<<(unsigned)blocks, 256, 0, s>>>(G);
   else
@@ -726,6 +768,20 @@ int gps_wgrad(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t 
   p.g = g; p.x = x; p.gw = gw; p.gb = gb; p.ldg = ldg; p.ldx = ldx; p.R = R; p.M = M; p.Nn = Nn;
   plan_slices(p, balanced_chunks(&R, &M, &Nn, 1), stream_shapes(&M, &Nn, 1) ? WS_STAGE : BK);
   return launch_group(G, ws, gps::as_stream(stream), "gps_wgrad");
+}
+
+int gps_wgrad16(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t R, int M, int Nn, const uint32_t* g_amax,
+                const uint32_t* x_amax, float* gw, float* gb, float* ws, gps_stream_t stream) {
+  if (int rc = check_problem("gps_wgrad16", g, ldg, x, ldx, R, M, Nn, gw)) return rc;
+  GPS_REQUIRE(ws && reinterpret_cast<uintptr_t>(ws) % 16 == 0, "gps_wgrad16: workspace null/misaligned");
+  GPS_REQUIRE(g_amax && x_amax, "gps_wgrad16: operand maxima");
+  Group G{};
+  G.n = 1;
+  Problem& p = G.p[0];
+  p.g = g; p.x = x; p.gw = gw; p.gb = gb; p.ldg = ldg; p.ldx = ldx; p.R = R; p.M = M; p.Nn = Nn;
+  p.g_amax = g_amax; p.x_amax = x_amax;
+  plan_slices(p, balanced_chunks(&R, &M, &Nn, 1), stream_shapes(&M, &Nn, 1) ? WS_STAGE : BK);
+  return launch_group(G, ws, gps::as_stream(stream), "gps_wgrad16");
 }
 
 size_t gps_wgrad_grouped_workspace_floats(int n, const gps_wgrad_problem* probs) {
@@ -767,6 +823,7 @@ int gps_wgrad_grouped(int n, const gps_wgrad_problem* probs, float* ws, gps_stre
     Problem& p = G.p[i];
     p.g = q.g; p.x = q.x; p.gw = q.gw; p.gb = q.gb; p.ldg = q.ldg; p.ldx = q.ldx;
     p.R = q.R; p.M = q.M; p.Nn = q.Nn;
+    p.g_amax = q.g_amax; p.x_amax = q.x_amax;
     plan_slices(p, cpb, quantum);
   }
   return launch_group(G, ws, gps::as_stream(stream), "gps_wgrad_grouped");

@@ -153,6 +153,7 @@ def add_dropout(a: torch.Tensor, b: torch.Tensor, p_drop: float, training: bool,
 import os as _os
 
 _SIDE_ENABLED = _os.environ.get("GPS_WGRAD_SIDE_STREAM", "1") != "0"
+_WGRAD_F16 = _os.environ.get("GPS_WGRAD_F16", "1") != "0"
 _BLOCK_SIDE_ENABLED = _os.environ.get("GPS_BLOCK_WGRAD_SIDE_STREAM", "0") != "0"
 _side_streams = {}
 _join_pending = set()
@@ -211,6 +212,13 @@ def _param_grads(g: torch.Tensor, x: torch.Tensor, need_w: bool, need_b: bool, p
                 g_b = torch.empty(d, dtype=torch.float32, device=dev)
             ws = torch.empty(max(L.gps_wgrad_workspace_floats(R, d, k), 4), dtype=torch.float32,
                              device=dev)
+            from . import gemm as _gemm
+            if _gemm.F16 and _WGRAD_F16 and d % 128 == 0 and k % 128 == 0 and R >= _RING_MIN_ROWS:
+                # fp16 form of the streaming kernel (csrc/wgrad.hip): the operands' max|.| words from one pre-pass
+                words = _gemm.absmax([g, x])
+                check(L.gps_wgrad16(ptr(g), g.stride(0), ptr(x), x.stride(0), R, d, k, ptr(words[0:1]), ptr(words[1:2]),
+                                    ptr(g_w), ptr(g_b), ptr(ws), st), "gps_wgrad16")
+                return g_w, g_b
             check(L.gps_wgrad(ptr(g), g.stride(0), ptr(x), x.stride(0), R, d, k, ptr(g_w), ptr(g_b),
                               ptr(ws), st), "gps_wgrad")
             return g_w, g_b

@@ -178,10 +178,12 @@ def split_weights(weights: Sequence[torch.Tensor], nt: bool = True, tn: bool = T
 def gemm_panel(a: torch.Tensor, image, N: int, bias: Optional[torch.Tensor] = None,
                addend: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None, epilogue: int = 0,
                mask_src: Optional[torch.Tensor] = None, p_drop: float = 0.0, seed: int = 0,
-               a_amax: Optional[torch.Tensor] = None) -> torch.Tensor:
+               a_amax: Optional[torch.Tensor] = None, c_amax: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``out = a @ B^T (+ bias) (+ addend)`` where ``image`` is the split image of B ``[N, K]``.
     ``a`` may be a column slice of a wider buffer (row stride >= K); ``out`` likewise (row stride >= N).
-    epilogue 1: ReLU then dropout(p_drop, seed); epilogue 2: multiply by the ReLU/dropout mask of ``mask_src``."""
+    epilogue 1: ReLU then dropout(p_drop, seed); epilogue 2: multiply by the ReLU/dropout mask of ``mask_src``.
+    fp16-form images: ``a_amax`` = the word of max|a| (made by a pre-pass here when absent); ``c_amax`` (int32 [1], zero or an
+    earlier maximum) is raised to max|out| by the kernel's epilogue -- the word of the next GEMM that reads ``out``."""
     L = _lib.load()
     M, K = a.shape
     if a.stride(1) != 1 or a.dtype != torch.float32:
@@ -194,8 +196,10 @@ def gemm_panel(a: torch.Tensor, image, N: int, bias: Optional[torch.Tensor] = No
         check(L.gps_gemm16_panel(ptr(a), a.stride(0), M, K, _a_word(a, a_amax), ptr(image), ptr(image.amax), N, ptr(bias),
                                  ptr(addend), addend.stride(0) if addend is not None else 0, ptr(out), out.stride(0),
                                  int(epilogue), ptr(mask_src), mask_src.stride(0) if mask_src is not None else 0,
-                                 float(p_drop), int(seed), current_stream(a.device)), "gps_gemm16_panel")
+                                 float(p_drop), int(seed), ptr(c_amax), current_stream(a.device)), "gps_gemm16_panel")
         return out
+    if c_amax is not None:
+        raise _lib.GpsHipError("gemm_panel: c_amax needs an fp16-form image")
     check(L.gps_gemm_panel(ptr(a), a.stride(0), M, K, ptr(image), N, ptr(bias), ptr(addend),
                            addend.stride(0) if addend is not None else 0, ptr(out), out.stride(0), int(epilogue),
                            ptr(mask_src), mask_src.stride(0) if mask_src is not None else 0, float(p_drop),

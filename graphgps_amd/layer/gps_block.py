@@ -137,6 +137,7 @@ def stack_begin(layers, batch) -> bool:
     if not (_STACK_PREP and torch.is_tensor(x) and x.is_cuda and torch.is_grad_enabled()) or _STACK["active"]:
         return False
     _STACK["active"], _STACK["nbt"] = True, []
+    _STACK.pop("words", None)
     try:
         _STACK["owners"] = _presplit_stack(layers, x)
     except BaseException:
@@ -168,6 +169,7 @@ def _presplit_stack(layers, x):
 def stack_end() -> None:
     nbt, _STACK["nbt"] = _STACK["nbt"], []
     _STACK["active"] = False
+    _STACK.pop("words", None)
     for layer in _STACK.pop("owners", []):
         layer.__dict__.pop("_presplit", None)      # (a layer that did not take the block path this time)
     if nbt:
@@ -244,12 +246,13 @@ def _accumulating(params) -> bool:
     return False
 
 
-def _grouped_param_grads(L, pairs, params=(), targets=None):
+def _grouped_param_grads(L, pairs, params=(), targets=None, words=None):
     """[(g, x), ...] -> [(g^T x, colsum(g)), ...]: all weight/bias gradients of the block in ONE
     split-K MFMA launch + one reduce launch (csrc/wgrad.hip grouped form) on the side stream
     (main stream when ``params`` already hold gradients: see ``_accumulating``).
     ``targets`` = [(weight, bias), ...] the (stacked) parameters the results belong to: when they live in an optimizer
-    arena and nothing is being accumulated the kernel writes straight into their gradient slots (optim.grad_slot)."""
+    arena and nothing is being accumulated the kernel writes straight into their gradient slots (optim.grad_slot).
+    ``words`` = [(max|g| word, max|x| word), ...] (int32 [1] tensors, gemm.absmax): the fp16 form of the contraction."""
     dev = pairs[0][0].device
     n = len(pairs)
     direct = targets is not None and not _accumulating(params)
@@ -272,6 +275,8 @@ def _grouped_param_grads(L, pairs, params=(), targets=None):
                 g_b = _E(M, dtype=g.dtype, device=dev)
             q.g, q.x, q.gw, q.gb = g.data_ptr(), x.data_ptr(), g_w.data_ptr(), g_b.data_ptr()
             q.ldg, q.ldx, q.R, q.M, q.Nn = g.stride(0), x.stride(0), R, M, Nn
+            if words is not None:
+                q.g_amax, q.x_amax = words[i][0].data_ptr(), words[i][1].data_ptr()
             outs.append((g_w, g_b))
         ws = _E(max(L.gps_wgrad_grouped_workspace_floats(n, probs), 4), dtype=torch.float32, device=dev)
         check(L.gps_wgrad_grouped(n, probs, ptr(ws), current_stream(dev)), "gps_wgrad_grouped")
@@ -291,6 +296,8 @@ def _grouped_param_grads(L, pairs, params=(), targets=None):
 
 
 _GROUPED_WGRAD = _os.environ.get("GPS_WGRAD_GROUPED", "1") != "0"
+# GPS_WGRAD_F16=0: the weight gradients stay on the 3 x bf16 / 6-product form while the ring GEMMs take the fp16 form (A/B)
+_WGRAD_F16 = _os.environ.get("GPS_WGRAD_F16", "1") != "0"
 
 # The attention half (attention core + out-projection GEMM) and the local half (GatedGCN core) of a block only meet at
 # the norm stage, so the attention half CAN run on its own HIP stream (a fork / join inside a captured graph).  Round 1-2
@@ -394,9 +401,17 @@ class _GPSBlock(torch.autograd.Function):
             # tensor (one batched launch where two operands are ready together) and shared by the GEMMs that read it
             am = None
             if imgs[0][0].amax is not None:
-                am = torch.zeros(5, dtype=torch.int32, device=dev)        # x, e, o, h, t
-                _gemm.absmax([x, e], out=am[0:2])
-            aw = (lambda i: None) if am is None else (lambda i: am[i:i + 1])
+                # words 0..4 = x, e, o, h, t; 5, 6 = this layer's outputs (the next layer's x and e).  x / e arrive with
+                # their words when the previous block of the stack produced them (its norm tasks tracked the maxima),
+                # otherwise one pre-pass makes them; o: a pre-pass; h, t and the outputs: by their producers
+                amb = torch.zeros(7, dtype=torch.int32, device=dev)
+                am = [amb[i:i + 1] for i in range(7)]
+                handed = _STACK.pop("words", None) if _STACK["active"] else None
+                if handed is not None and handed[0] == x.data_ptr() and handed[1] == e.data_ptr():
+                    am[0], am[1] = handed[2], handed[3]
+                else:
+                    _gemm.absmax([x, e], out=amb[0:2])
+            aw = (lambda i: None) if am is None else (lambda i: am[i])
             ce = _gemm.gemm_panel(e, imgs[1][0], d, bias=_B(R.C), a_amax=aw(1))
             pq = _gemm.gemm_panel(x, imgs[0][0], 7 * d, bias=bcat, a_amax=aw(0))
         else:
@@ -448,7 +463,7 @@ class _GPSBlock(torch.autograd.Function):
                                      gi.max_tiles, N, H, dh, scale, p_at, s[2], ptr(o), ptr(lse),
                                      gi.B, int(gi.nmax_host), sb), "gps_seg_attn_fwd")
             if am is not None:
-                _gemm.absmax([o], out=am[2:3])
+                _gemm.absmax([o], out=am[2])
             if gemm_stats:      # za = x + drop(out_proj(o)) and the statistics of za (norm1_attn) in the GEMM's epilogue
                 ao = None
                 za = _gemm.gemm_panel_stats(o, imgs[2][0], d, _B(R.out_proj), x, p_l, s[3], bna, sync.site(_S_AO),
@@ -465,7 +480,7 @@ class _GPSBlock(torch.autograd.Function):
         #    costs ~10 us of queue latency in a replayed graph even when it is long satisfied; here it hides under this launch)
         x1, e1 = _E(N, d, **f32), _E(E, d, **f32)
         mid = [_norm.fwd_task(_norm.BN_ACT, xt, N, res=x, bn1=bnx, relu=True, p=p, seed=s[0], out=x1, stats=bnl),
-               _norm.fwd_task(_norm.BN_ACT, eh, E, res=e, bn1=bne, relu=True, p=p, seed=s[1], out=e1)]
+               _norm.fwd_task(_norm.BN_ACT, eh, E, res=e, bn1=bne, relu=True, p=p, seed=s[1], out=e1, amax=aw(6))]
         if za is None:
             fork.join(o, lse, ao)
             za = _E(N, d, **f32)
@@ -474,16 +489,13 @@ class _GPSBlock(torch.autograd.Function):
         if ao is None:
             fork.join(o, lse, za)
         h = _E(N, d, **f32)                                     # BN_l(x1) + BN_a(za)  (gps_layer.py:222)
-        _norm.fwd([_norm.fwd_task(_norm.BN_DUAL, x1, N, b=za, bn1=bnl, bn2=bna, out=h)], d, dev, None)
+        _norm.fwd([_norm.fwd_task(_norm.BN_DUAL, x1, N, b=za, bn1=bnl, bn2=bna, out=h, amax=aw(3))], d, dev, None)
 
         # -- FFN + norm2 (gps_layer.py:225-229,253-257) ----------------------------------------
         if panel:       # t = drop(relu(ff1(h))) in the GEMM's epilogue: f1 is never materialised
             f1 = None
-            if am is not None:
-                _gemm.absmax([h], out=am[3:4])
-            t = _gemm.gemm_panel(h, imgs[3][0], 2 * d, bias=_B(R.ff1), epilogue=1, p_drop=p_f1, seed=s[4], a_amax=aw(3))
-            if am is not None:
-                _gemm.absmax([t], out=am[4:5])
+            t = _gemm.gemm_panel(h, imgs[3][0], 2 * d, bias=_B(R.ff1), epilogue=1, p_drop=p_f1, seed=s[4], a_amax=aw(3),
+                                 c_amax=aw(4))
         else:
             f1 = torch.addmm(_B(R.ff1), h, _W(R.ff1).t())
             t = _K.act_drop_add(L, None, f1, True, p_f1, s[4], st)
@@ -496,7 +508,9 @@ class _GPSBlock(torch.autograd.Function):
             _norm.fwd([_norm.fwd_task(_norm.ADD_DROP, h, N, b=f2, p=p_f2, seed=s[5], out=z2, stats=bn2)], d, dev,
                       sync.site(_S_Z2))
         out = _E(N, d, **f32)
-        _norm.fwd([_norm.fwd_task(_norm.BN_ACT, z2, N, bn1=bn2, out=out)], d, dev, None)
+        _norm.fwd([_norm.fwd_task(_norm.BN_ACT, z2, N, bn1=bn2, out=out, amax=aw(5))], d, dev, None)
+        if am is not None and _STACK["active"]:        # hand the outputs' words to the next block of the stack
+            _STACK["words"] = (out.data_ptr(), e1.data_ptr(), am[5], am[6])
         _count_batches([R.bnx._buffers["num_batches_tracked"], R.bne._buffers["num_batches_tracked"],
                         R.bnl._buffers["num_batches_tracked"], R.bna._buffers["num_batches_tracked"],
                         R.bn2._buffers["num_batches_tracked"]])
@@ -504,6 +518,7 @@ class _GPSBlock(torch.autograd.Function):
         ctx.save_for_backward(x, e, pq, eh, xt, x1, o, lse, za, h, f1 if f1 is not None else t, t, z2, stats)
         ctx.layer, ctx.gi, ctx.seeds = layer, gi, s
         ctx.imgs = imgs     # W^T images for the input-gradient GEMMs (None: library GEMMs)
+        ctx.am = am         # fp16 form: the max|.| words of x, e, o, h, t (the weight gradients' second operands)
         ctx.cfg = (p, p_l, p_f1, p_f2, p_at, H, dh, scale)
         return out, e1
 
@@ -539,25 +554,23 @@ class _GPSBlock(torch.autograd.Function):
 
         # norm2 <- z2 = h + drop(f2):  g_z2 and g_f2 = dropmask(g_z2);  bn_edge_e <- e^ (its output gradient g_e1 is an
         # input of this node, so its column sums and its apply ride along): ONE partial launch, ONE apply launch
+        imgs = ctx.imgs
+        bm = None
+        if imgs is not None and imgs[0][1].amax is not None:        # fp16 form: the words of the gradient operands
+            bm = torch.zeros(5, dtype=torch.int32, device=dev)      # g_f2, g_f1, g_ao (by their producers), g_pq, g_ce
         g_z2, g_f2, g_eh = _E(N, d, **f32), _E(N, d, **f32), _E(E, d, **f32)
-        b1 = [_norm.bwd_task(z2, g_out, bn2, N, g_n2w, g_n2b, g_z=g_z2, g_drop=g_f2, p2=p_f2, seed2=s[5]),
+        b1 = [_norm.bwd_task(z2, g_out, bn2, N, g_n2w, g_n2b, g_z=g_z2, g_drop=g_f2, p2=p_f2, seed2=s[5],
+                             amax_drop=None if bm is None else bm[0:1]),
               _norm.bwd_task(eh, g_e1, bne, E, g_bew, g_beb, relu=True, p=p, seed=s[1], g_z=g_eh)]
         _norm.bwd_partial(b1, d, dev, sync.site(_S_B1))
         _norm.bwd_apply(b1, d, dev, None)
         # f2 = ff2(t);  t = drop(relu(f1));  f1 = ff1(h)
-        imgs = ctx.imgs
-        bm = None
-        if imgs is not None and imgs[0][1].amax is not None:        # fp16 form: the words of the gradient operands
-            bm = torch.zeros(5, dtype=torch.int32, device=dev)      # g_f2, g_f1, g_ao, g_pq, g_ce
         bw = (lambda i: None) if bm is None else (lambda i: bm[i:i + 1])
         if imgs is not None:
             # g_f1 = relu/dropout mask of t applied to g_f2 W2 (the mask of t is the mask of f1 wherever it matters:
             # a kept element has t > 0 iff f1 > 0, a dropped one has gradient 0 either way), in the GEMM's epilogue
-            if bm is not None:
-                _gemm.absmax([g_f2], out=bm[0:1])
-            g_f1 = _gemm.gemm_panel(g_f2, imgs[4][1], 2 * d, epilogue=2, mask_src=t, p_drop=p_f1, seed=s[4], a_amax=bw(0))
-            if bm is not None:
-                _gemm.absmax([g_f1], out=bm[1:2])
+            g_f1 = _gemm.gemm_panel(g_f2, imgs[4][1], 2 * d, epilogue=2, mask_src=t, p_drop=p_f1, seed=s[4], a_amax=bw(0),
+                                    c_amax=bw(1))
             g_h = _gemm.gemm_panel(g_f1, imgs[3][1], d, addend=g_z2, out=g_z2, a_amax=bw(1))     # residual + FFN input
         else:
             g_t = g_f2.mm(_W(R.ff2))
@@ -570,7 +583,8 @@ class _GPSBlock(torch.autograd.Function):
         g_x1, g_xres, g_ao = _E(N, d, **f32), _E(N, d, **f32), _E(N, d, **f32)
         b3 = [_norm.bwd_task(x1, g_h, bnl, N, g_nlw, g_nlb, z2=za, bn2=bna, g_gamma2=g_naw, g_beta2=g_nab,
                              g_z=g_x1, g_sum=g_xres, g_drop=g_ao, p2=p_l, seed2=s[3],
-                             cz=xt, cbn=bnx, crelu=True, cp=p, cseed=s[0], cg_gamma=g_bxw, cg_beta=g_bxb)]
+                             cz=xt, cbn=bnx, crelu=True, cp=p, cseed=s[0], cg_gamma=g_bxw, cg_beta=g_bxb,
+                             amax_drop=bw(2))]
         _norm.bwd_partial(b3, d, dev, sync.site(_S_B3))
         _norm.bwd_apply(b3, d, dev, sync.site(_S_B4))
         # gradient of the merged projection: attention writes dq|dk|dv into columns 4d.., GatedGCN
@@ -581,8 +595,6 @@ class _GPSBlock(torch.autograd.Function):
         G, P = g_pq.data_ptr(), pq.data_ptr()
         with _Fork(dev, _BRANCH) as fork:            # attention half of the backward
             sb = current_stream(dev)
-            if bm is not None:
-                _gemm.absmax([g_ao], out=bm[2:3])
             g_o = _gemm.gemm_panel(g_ao, imgs[2][1], d, a_amax=bw(2)) if imgs is not None else g_ao.mm(_W(R.out_proj))
             delta = _E(H, N, **f32)
             check(L.gps_seg_attn_bwd(ptr(g_o), P + 4 * fs, ldp, ptr(o), ptr(lse), ptr(gi.ptr),
@@ -603,17 +615,21 @@ class _GPSBlock(torch.autograd.Function):
         wcat, bcat = layer._xgroup._stacked()
         pairs = [(g_pq, x), (g_ce, e), (g_ao, o), (g_f1, h), (g_f2, t)]
         leaves = block_params(layer)
+        words = None
+        if bm is not None:
+            _gemm.absmax([g_pq, g_ce], out=bm[3:5])
+            am = ctx.am
+            if am is not None and _WGRAD_F16:
+                words = [(bm[3:4], am[0]), (bm[4:5], am[1]), (bm[2:3], am[2]), (bm[1:2], am[3]), (bm[0:1], am[4])]
         if _GROUPED_WGRAD:
             targets = [(wcat, bcat), (_W(R.C), _B(R.C)), (_W(R.out_proj), _B(R.out_proj)),
                        (_W(R.ff1), _B(R.ff1)), (_W(R.ff2), _B(R.ff2))]
             ((g_wcat, g_bcat), (g_wc, g_bc), (g_wo, g_bo), (g_w1, g_b1), (g_w2, g_b2)) = \
-                _grouped_param_grads(L, pairs, leaves, targets)
+                _grouped_param_grads(L, pairs, leaves, targets, words)
         else:
             ((g_wcat, g_bcat), (g_wc, g_bc), (g_wo, g_bo), (g_w1, g_b1), (g_w2, g_b2)) = \
                 [_K.param_grads(L, g, a, leaves) for g, a in pairs]
         if imgs is not None:
-            if bm is not None:
-                _gemm.absmax([g_pq, g_ce], out=bm[3:5])
             g_x = _gemm.gemm_panel(g_pq, imgs[0][1], d, addend=g_xres, out=g_xres, a_amax=bw(3))
             g_e = _gemm.gemm_panel(g_ce, imgs[1][1], d, addend=g_e1, a_amax=bw(4))
         else:

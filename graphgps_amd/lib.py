@@ -56,6 +56,7 @@ _SIGNATURES = {
     "gps_colsum": (c_int, [_P, c_int64, c_int, _P, _P, _P]),
     "gps_wgrad_workspace_floats": (c_size_t, [c_int64, c_int, c_int]),
     "gps_wgrad": (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int, c_int, _P, _P, _P, _P]),
+    "gps_wgrad16": (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int, c_int, _P, _P, _P, _P, _P, _P]),
     "gps_optim_chunk": (c_int, []),
     "gps_adamw_step": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P]),
     "gps_gemm_nt": (c_int, [_P, c_int64, _P, c_int64, c_int64, c_int, c_int, _P, _P, c_int64, _P, c_int64,
@@ -100,7 +101,7 @@ _SIGNATURES = {
     "gps_gemm16_image_elems": (c_size_t, [c_int64, c_int64]),
     "gps_gemm16_split_weights": (c_int, [c_int, _P, _P]),
     "gps_gemm16_panel": (c_int, [_P, c_int64, c_int64, c_int, _P, _P, _P, c_int, _P, _P, c_int64, _P, c_int64, c_int, _P,
-                                 c_int64, c_float, c_uint64, _P]),
+                                 c_int64, c_float, c_uint64, _P, _P]),
     "gps_gemm16_panel_stats": (c_int, [_P, c_int64, c_int64, c_int, _P, _P, _P, c_int, _P, _P, c_int64, _P, c_int64,
                                        c_float, c_uint64, _P, _P, c_size_t, _P, _P]),
     "gps_gcn_dinv": (c_int, [_P, _P, c_int64, c_int64, _P, _P]),
@@ -126,7 +127,7 @@ class WgradProblem(ctypes.Structure):
     """``gps_wgrad_problem`` (include/gps_hip.h)."""
     _fields_ = [("g", c_void_p), ("x", c_void_p), ("gw", c_void_p), ("gb", c_void_p),
                 ("ldg", c_int64), ("ldx", c_int64), ("R", c_int64), ("M", ctypes.c_int32),
-                ("Nn", ctypes.c_int32)]
+                ("Nn", ctypes.c_int32), ("g_amax", c_void_p), ("x_amax", c_void_p)]
 
 
 class GemmSplit(ctypes.Structure):

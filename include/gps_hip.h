@@ -271,7 +271,8 @@ size_t gps_gemm16_image_elems(int64_t N, int64_t K);
 int gps_gemm16_split_weights(int n, const gps_gemm_split16* descs, gps_stream_t stream);   /* n <= 48, one launch */
 int gps_gemm16_panel(const float* A, int64_t lda, int64_t M, int K, const uint32_t* a_amax, const uint16_t* image,
                      const uint32_t* w_amax, int N, const float* bias, const float* Cin, int64_t ldcin, float* C, int64_t ldc,
-                     int epilogue, const float* mask_src, int64_t ldmask, float p_drop, uint64_t seed, gps_stream_t stream);
+                     int epilogue, const float* mask_src, int64_t ldmask, float p_drop, uint64_t seed, uint32_t* c_amax,
+                     gps_stream_t stream);      /* c_amax (or NULL): raised to max|C| -- the word of the GEMM that reads C next */
 int gps_gemm16_panel_stats(const float* A, int64_t lda, int64_t M, int K, const uint32_t* a_amax, const uint16_t* image,
                            const uint32_t* w_amax, int N, const float* bias, const float* Cin, int64_t ldcin, float* C,
                            int64_t ldc, float p_drop, uint64_t seed, const gps_bn* stats, float* ws, size_t ws_floats,
@@ -424,9 +425,17 @@ typedef struct gps_wgrad_problem {
   float* gb;        /* [M] out, or NULL */
   int64_t ldg, ldx, R;
   int32_t M, Nn;
+  /* ABI v6: max|g| / max|x| words (gps_absmax) -- when EVERY problem of a launch carries both (and the shapes take the
+   * streaming kernel: M, Nn multiples of 128), the contraction runs in the fp16 form of gps_gemm16_panel (two fp16 pieces
+   * per value, 3 piece products); NULL keeps the 3 x bf16 / 6-product form. */
+  const uint32_t* g_amax;
+  const uint32_t* x_amax;
 } gps_wgrad_problem;
 size_t gps_wgrad_grouped_workspace_floats(int n, const gps_wgrad_problem* probs);
 int gps_wgrad_grouped(int n, const gps_wgrad_problem* probs, float* ws, gps_stream_t stream);
+/* gps_wgrad with the operands' max|.| words: the fp16 form where the streaming kernel applies (else as gps_wgrad) */
+int gps_wgrad16(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t R, int M, int Nn, const uint32_t* g_amax,
+                const uint32_t* x_amax, float* gw, float* gb, float* ws, gps_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Graph pooling over `ptr` segments (sum: mean = 0, mean: mean = 1) and its backward.
@@ -481,6 +490,7 @@ typedef struct gps_norm_fwd_task {
   float* out;                 /* produced rows, or NULL (statistics only) */
   int64_t R;
   const gps_bn* stats;        /* batch statistics of the produced rows -> stats->mean / rstd (+ running stats), or NULL */
+  uint32_t* amax;             /* ABI v6: raised to max|out| (fp32 bit pattern; the word gps_gemm16_panel takes), or NULL */
 } gps_norm_fwd_task;
 /* One BatchNorm backward, y = dropout(relu?(BN(z)); p, seed) with g_y = dL/dy (masks recomputed from z and the hash):
  *   partial: g_beta = sum g, g_gamma = sum g * zhat          (g = g_y under the masks)
@@ -511,6 +521,7 @@ typedef struct gps_norm_bwd_task {
   float cp;
   uint64_t cseed;
   float *cg_gamma, *cg_beta;
+  uint32_t* amax_drop;        /* ABI v6 (apply only): raised to max|g_drop|, or NULL */
 } gps_norm_bwd_task;
 size_t gps_norm_tree_floats(int64_t R, int d);
 int gps_norm_sync_words(void);

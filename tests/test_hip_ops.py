@@ -497,14 +497,27 @@ def test_wgrad_split_k(R, M, Nn):
     gw2 = torch.empty_like(gw)
     check(L.gps_wgrad(ptr(gd), M, ptr(xd), Nn, R, M, Nn, ptr(gw2), None, ptr(ws), current_stream(dev)))
     assert torch.equal(gw, gw2)     # deterministic, and the bias output is optional
+    # fp16 form (round 4): the same bound, with the operands' max|.| words; gradient-sized g (1e-7) as well
+    from graphgps_amd.gemm import absmax
+    for gs in (1.0, 1e-7):
+        g3 = gd * gs
+        words = absmax([g3, xd])
+        gw3, gb3 = torch.empty_like(gw), torch.empty_like(gb)
+        check(L.gps_wgrad16(ptr(g3), M, ptr(xd), Nn, R, M, Nn, ptr(words[0:1]), ptr(words[1:2]), ptr(gw3), ptr(gb3), ptr(ws),
+                            current_stream(dev)))
+        assert_close(gw3 / gs, g.double().t() @ x.double(), Tol.GRAD_REL, "gW (fp16 form)", rel_to_max=True)
+        assert_close(gb3 / gs, g.double().sum(0), Tol.GRAD_REL, "gb (fp16 form)", rel_to_max=True)
 
 
-def test_wgrad_grouped_and_bf16_split_exactness():
+@pytest.mark.parametrize("f16", [True, False], ids=["f16x3", "bf16x6"])
+def test_wgrad_grouped_and_bf16_split_exactness(f16):
     """(1) The grouped launch returns, per problem, what the single-problem launch returns to fp32
-    rounding.  (2) The contraction runs on the bf16 pipe through an exact 3-way split: its error against
+    rounding.  (2) The contraction runs on the bf16 pipe through an exact 3-way split (or, round 4, on the fp16 pipe through
+    two fp16 pieces under a power-of-two scale): its error against
     fp64 must not exceed that of an fp32 GEMM (torch.mm through rocBLAS) on the same data -- including
-    data with a large common offset, where a lossy (2-piece) split would show."""
+    data with a large common offset, where a lossy split would show."""
     from graphgps_amd import lib as L_
+    from graphgps_amd.gemm import absmax
     from graphgps_amd.lib import check, current_stream, ptr
     L = L_.load()
     dev = torch.device("cuda:0")
@@ -513,11 +526,15 @@ def test_wgrad_grouped_and_bf16_split_exactness():
     pairs = [((torch.randn(R, n, generator=gen) * 3 + 100.0).to(dev), (torch.randn(R, k, generator=gen) + 7.0).to(dev))
              for R, k, n in shapes]
     probs = (L_.WgradProblem * len(pairs))()
-    outs = []
+    outs, keep = [], []
     for q, (g, x) in zip(probs, pairs):
         gw, gb = torch.empty(g.shape[1], x.shape[1], device=dev), torch.empty(g.shape[1], device=dev)
         q.g, q.x, q.gw, q.gb = g.data_ptr(), x.data_ptr(), gw.data_ptr(), gb.data_ptr()
         q.ldg, q.ldx, q.R, q.M, q.Nn = g.stride(0), x.stride(0), g.shape[0], g.shape[1], x.shape[1]
+        if f16:
+            w = absmax([g, x])
+            keep.append(w)
+            q.g_amax, q.x_amax = w[0:1].data_ptr(), w[1:2].data_ptr()
         outs.append((gw, gb))
     ws = torch.empty(max(L.gps_wgrad_grouped_workspace_floats(len(pairs), probs), 4), device=dev)
     check(L.gps_wgrad_grouped(len(pairs), probs, ptr(ws), current_stream(dev)), "gps_wgrad_grouped")
@@ -892,20 +909,26 @@ def test_dma_kernels_race_screen():
         q.ldg, q.ldx, q.R, q.M, q.Nn = g.stride(0), x.stride(0), g.shape[0], g.shape[1], x.shape[1]
         outs.append((gw, gb))
     ws = torch.empty(max(L.gps_wgrad_grouped_workspace_floats(len(pairs), probs), 4), device=dev)
-    firsts = None
-    for it in range(30):
-        if it % 3 == 0:
-            noise.normal_()
-        check(L.gps_wgrad_grouped(len(pairs), probs, ptr(ws), current_stream(dev)), "gps_wgrad_grouped")
-        cur = [(gw.clone(), gb.clone()) for gw, gb in outs]
-        if firsts is None:
-            firsts = cur
-            for (g, x), (gw, gb) in zip(pairs, cur):
-                assert_close(gw, g.double().t() @ x.double(), Tol.GRAD_REL, "gW", rel_to_max=True)
-                assert_close(gb, g.double().sum(0), Tol.GRAD_REL, "gb", rel_to_max=True)
-        else:
-            for i, ((gw, gb), (fw, fb)) in enumerate(zip(cur, firsts)):
-                assert torch.equal(gw, fw) and torch.equal(gb, fb), f"streaming wgrad problem {i}: run {it} differs"
+    from graphgps_amd.gemm import absmax
+    words = absmax([t for pr in pairs for t in pr])
+    for f16 in (False, True):
+        for i, q in enumerate(probs):
+            q.g_amax = words[2 * i:2 * i + 1].data_ptr() if f16 else None
+            q.x_amax = words[2 * i + 1:2 * i + 2].data_ptr() if f16 else None
+        firsts = None
+        for it in range(30):
+            if it % 3 == 0:
+                noise.normal_()
+            check(L.gps_wgrad_grouped(len(pairs), probs, ptr(ws), current_stream(dev)), "gps_wgrad_grouped")
+            cur = [(gw.clone(), gb.clone()) for gw, gb in outs]
+            if firsts is None:
+                firsts = cur
+                for (g, x), (gw, gb) in zip(pairs, cur):
+                    assert_close(gw, g.double().t() @ x.double(), Tol.GRAD_REL, "gW", rel_to_max=True)
+                    assert_close(gb, g.double().sum(0), Tol.GRAD_REL, "gb", rel_to_max=True)
+            else:
+                for i, ((gw, gb), (fw, fb)) in enumerate(zip(cur, firsts)):
+                    assert torch.equal(gw, fw) and torch.equal(gb, fb), f"streaming wgrad (f16={f16}) problem {i}: run {it} differs"
 
 
 @pytest.mark.parametrize("n,V,d,hub", [(25000, 10030, 256, 0.5), (25000, 10030, 256, 0.0), (77000, 2, 256, 0.0),
