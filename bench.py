@@ -549,6 +549,13 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
+    if world > 1:
+        # replicas: rank 0's parameters and buffers everywhere (dp.broadcast_state: BatchNorm running statistics, the
+        # Performer's random projection buffers) -- identical seeds above already make them equal; this makes it a property
+        # of the run instead of a property of the seeding
+        from graphgps_amd.dp import broadcast_state
+        bcast_bytes = broadcast_state(model)
+        log(f"rank {rank}: replica state broadcast from rank 0 ({bcast_bytes / 1e6:.1f} MB)")
     torch.manual_seed(1000 + rank)             # dropout streams differ per rank
     # fresh batch object over the resident tensors -> the graph index is rebuilt every step, nothing is
     # copied (inputs already in HBM is the measurement contract)

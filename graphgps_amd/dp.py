@@ -26,6 +26,49 @@ import torch.distributed as dist
 import torch.nn as nn
 
 
+def broadcast_state(model: nn.Module, src: int = 0, process_group=None, bucket_bytes: int = 64 << 20) -> int:
+    """Replica initialisation ("running BN stats / Performer projection buffers: broadcast from
+    rank 0 at init"): every parameter AND every buffer of ``model`` is overwritten with rank ``src``'s values --
+    BatchNorm ``running_mean / running_var / num_batches_tracked`` and, above all, the Performer's
+    ``fast_attention.projection_matrix``, a RANDOM buffer drawn at construction
+    (graphgps/layer/performer_layer.py:272-273): ranks seeded differently would otherwise train silently different
+    models whose gradients are then averaged.  Tensors travel in flat per-dtype buckets of <= ``bucket_bytes`` (one
+    broadcast each: a handful of collectives for 19.4 M parameters instead of ~700); in-place copies, so views held by
+    an optimizer arena or a LinearGroup stack stay valid.  Returns the number of bytes broadcast (0 when no process
+    group is initialised or the world has one rank).  Call once after construction / checkpoint loading, before the
+    first step (``train.train_epoch`` and ``bench.py`` do)."""
+    if not dist.is_initialized() or dist.get_world_size(process_group) < 2:
+        return 0
+    tensors, seen = [], set()
+    for t in list(model.parameters()) + list(model.buffers()):
+        key = (t.data_ptr(), t.numel(), t.dtype)
+        if t.numel() == 0 or key in seen:           # tied / aliased storage travels once
+            continue
+        seen.add(key)
+        tensors.append(t.data)
+    total = 0
+    by_dtype: Dict[torch.dtype, List[torch.Tensor]] = {}
+    for t in tensors:
+        by_dtype.setdefault(t.dtype, []).append(t)
+    with torch.no_grad():
+        for dtype, ts in by_dtype.items():
+            i = 0
+            while i < len(ts):
+                chunk, nbytes = [], 0
+                while i < len(ts) and (not chunk or nbytes + ts[i].numel() * ts[i].element_size() <= bucket_bytes):
+                    chunk.append(ts[i])
+                    nbytes += ts[i].numel() * ts[i].element_size()
+                    i += 1
+                flat = torch.cat([t.reshape(-1) for t in chunk])
+                dist.broadcast(flat, src=src, group=process_group)
+                off = 0
+                for t in chunk:
+                    t.copy_(flat[off:off + t.numel()].view_as(t))
+                    off += t.numel()
+                total += nbytes
+    return total
+
+
 class _Bucket:
     __slots__ = ("name", "params", "flat", "views", "pending", "work")
 

@@ -34,7 +34,7 @@ from .. import lib as _lib
 from .. import norm as _norm
 from ..fused import _BLOCK_SIDE_ENABLED as _SIDE_ENABLED, _queue_join, _side_stream
 from ..lib import check, current_stream, ptr
-from ..ops import GraphIndex, draw_dropout_seed
+from ..ops import GraphIndex, _nmax_dev, draw_dropout_seed
 
 _E = torch.empty
 _BY_REF = _ctypes.byref
@@ -70,23 +70,27 @@ class _Refs:
     forward + backward).  Parameters and modules are cached by identity (``p.data`` may be re-pointed by an arena, the
     Parameter object stays); ``valid`` notices a replaced submodule."""
     __slots__ = ("lm", "sa", "A", "B", "D", "E", "C", "out_proj", "ff1", "ff2", "bnx", "bne", "bnl", "bna", "bn2",
-                 "drop_attn", "ff_drop1", "ff_drop2", "params", "_ids")
+                 "drop_attn", "ff_drop1", "ff_drop2", "params", "_ids", "perf")
 
     def __init__(self, layer):
         m = layer._modules
         self.lm, self.sa = m["local_model"], m["self_attn"]
         lmm = self.lm._modules
         self.A, self.B, self.D, self.E, self.C = lmm["A"], lmm["B"], lmm["D"], lmm["E"], lmm["C"]
-        self.out_proj = self.sa._modules["out_proj"]
+        self.perf = layer.global_model_type == 'Performer'
+        # (Performer: the output projection is ``to_out``, performer_layer.py:461-464)
+        self.out_proj = self.sa._modules["to_out" if self.perf else "out_proj"]
         self.ff1, self.ff2 = m["ff_linear1"], m["ff_linear2"]
         self.bnx, self.bne = lmm["bn_node_x"], lmm["bn_edge_e"]
         self.bnl, self.bna, self.bn2 = m["norm1_local"], m["norm1_attn"], m["norm2"]
         self.drop_attn, self.ff_drop1, self.ff_drop2 = m["dropout_attn"], m["ff_dropout1"], m["ff_dropout2"]
         W, Bv = (lambda mod: mod._parameters["weight"]), (lambda mod: mod._parameters["bias"])
+        sam = self.sa._modules
+        inproj = ([W(sam["to_q"]), W(sam["to_k"]), W(sam["to_v"])] if self.perf
+                  else [self.sa._parameters["in_proj_weight"], self.sa._parameters["in_proj_bias"]])
         self.params = [W(self.A), W(self.B), W(self.D), W(self.E), Bv(self.A), Bv(self.B), Bv(self.D), Bv(self.E),
                        W(self.C), Bv(self.C), W(self.bnx), Bv(self.bnx), W(self.bne), Bv(self.bne),
-                       W(self.bnl), Bv(self.bnl), self.sa._parameters["in_proj_weight"],
-                       self.sa._parameters["in_proj_bias"], W(self.out_proj), Bv(self.out_proj),
+                       W(self.bnl), Bv(self.bnl), *inproj, W(self.out_proj), Bv(self.out_proj),
                        W(self.bna), Bv(self.bna), W(self.ff1), Bv(self.ff1), W(self.ff2), Bv(self.ff2),
                        W(self.bn2), Bv(self.bn2)]
         self._ids = self._snapshot(layer)
@@ -96,7 +100,8 @@ class _Refs:
         m = layer._modules
         lm, sa = m["local_model"], m["self_attn"]
         mods = (lm, sa, m["ff_linear1"], m["ff_linear2"], m["norm1_local"], m["norm1_attn"], m["norm2"],
-                lm._modules["C"], lm._modules["bn_node_x"], lm._modules["bn_edge_e"], sa._modules["out_proj"])
+                lm._modules["C"], lm._modules["bn_node_x"], lm._modules["bn_edge_e"],
+                sa._modules.get("out_proj") or sa._modules["to_out"])
         return tuple(id(x) for x in mods) + tuple(id(x._parameters.get("weight")) for x in mods[2:])
 
     def valid(self, layer) -> bool:
@@ -122,12 +127,31 @@ def _ensure_xgroup(layer):
     from ..fused import LinearGroup
     lm, sa = layer.local_model, layer.self_attn
     if getattr(layer, "_xgroup", None) is None:
-        # zero-copy stack of every weight that multiplies the layer input: A, B, D, E, in_proj
-        layer._xgroup = LinearGroup(weights=[lm.A.weight, lm.B.weight, lm.D.weight, lm.E.weight,
-                                             sa.in_proj_weight],
-                                    biases=[lm.A.bias, lm.B.bias, lm.D.bias, lm.E.bias,
-                                            sa.in_proj_bias])
+        # zero-copy stack of every weight that multiplies the layer input: A, B, D, E, in_proj (Performer: to_q, to_k, to_v,
+        # which carry no bias -- the merged GEMM's bias row is padded with zeros, _merged_bias)
+        if layer.global_model_type == 'Performer':
+            layer._xgroup = LinearGroup(weights=[lm.A.weight, lm.B.weight, lm.D.weight, lm.E.weight,
+                                                 sa.to_q.weight, sa.to_k.weight, sa.to_v.weight],
+                                        biases=[lm.A.bias, lm.B.bias, lm.D.bias, lm.E.bias])
+        else:
+            layer._xgroup = LinearGroup(weights=[lm.A.weight, lm.B.weight, lm.D.weight, lm.E.weight,
+                                                 sa.in_proj_weight],
+                                        biases=[lm.A.bias, lm.B.bias, lm.D.bias, lm.E.bias,
+                                                sa.in_proj_bias])
     return layer._xgroup._stacked()
+
+
+def _merged_bias(layer, wcat, bcat):
+    """Bias row of the merged projection.  Transformer: the stacked biases themselves.  Performer: A..E's biases followed
+    by zeros for q | k | v (performer_layer.py:436: qkv_bias=False), a per-layer buffer whose head is refreshed from the
+    parameters once per step (the optimizer moves them)."""
+    if bcat.shape[0] == wcat.shape[0]:
+        return bcat
+    buf = layer.__dict__.get("_pbias")
+    if buf is None or buf.shape[0] != wcat.shape[0] or buf.device != wcat.device:
+        buf = layer.__dict__["_pbias"] = torch.zeros(wcat.shape[0], dtype=torch.float32, device=wcat.device)
+    buf[:bcat.shape[0]].copy_(bcat)
+    return buf
 
 
 def stack_begin(layers, batch) -> bool:
@@ -150,10 +174,10 @@ def _presplit_stack(layers, x):
     weights, owners = [], []
     for layer in layers:
         if not (getattr(layer, "training", False) and getattr(layer, "local_gnn_type", None) == 'CustomGatedGCN'
-                and getattr(layer, "global_model_type", None) == 'Transformer' and block_supported(layer, x)):
+                and getattr(layer, "global_model_type", None) in ('Transformer', 'Performer') and block_supported(layer, x)):
             continue
         d = layer.dim_h
-        if not (_gemm.supported(d, d) and _gemm.supported(2 * d, d) and _gemm.supported(7 * d, d)):
+        if not _panel_ok(layer, d):
             continue
         wcat, _ = _ensure_xgroup(layer)
         R = _refs(layer)
@@ -164,6 +188,18 @@ def _presplit_stack(layers, x):
         for i, layer in enumerate(owners):
             layer.__dict__["_presplit"] = imgs[5 * i:5 * i + 5]
     return owners
+
+
+def _inner(layer, d) -> int:
+    """Width of q, k and v each: d for nn.MultiheadAttention, 64 * heads for the Performer (dim_head defaults to 64
+    whatever dim_h / heads is, performer_layer.py:427,441-442)."""
+    return layer.self_attn.to_q.weight.shape[0] if layer.global_model_type == 'Performer' else d
+
+
+def _panel_ok(layer, d) -> bool:
+    inner = _inner(layer, d)
+    return (_gemm.supported(d, d) and _gemm.supported(2 * d, d) and _gemm.supported(4 * d + 3 * inner, d)
+            and _gemm.supported(d, inner) and _gemm.supported(inner, d) and _gemm.supported(d, 4 * d + 3 * inner))
 
 
 def stack_end() -> None:
@@ -375,19 +411,29 @@ class _GPSBlock(torch.autograd.Function):
         N, d = x.shape
         E = e.shape[0]
         H = layer.num_heads
-        dh = d // H
+        perf = R.perf
+        inner = _inner(layer, d)            # width of q, k, v each (Performer: 64 * heads)
+        dh = inner // H
         p = float(lm.dropout)
         p_l = float(R.drop_attn.p)
         p_f1, p_f2 = float(R.ff_drop1.p), float(R.ff_drop2.p)
         p_at = float(layer.attn_dropout)
+        if perf:
+            # Performer: dropout(attn_dropout) on the OUTPUT of to_out (performer_layer.py:500-503), then GPSLayer's
+            # dropout_attn (gps_layer.py:212): two independent Bernoulli masks with their 1/(1-p) scalings ARE one mask
+            # with keep probability (1 - p_at)(1 - p_l) and its scaling -- the same distribution, one hash per element
+            p_l = 1.0 - (1.0 - float(sa.dropout.p)) * (1.0 - p_l)
+            p_at = 0.0
         s = [(seed + 0x9E3779B97F4A7C15 * (i + 1)) & 0xFFFFFFFFFFFFFFFF for i in range(7)]
         f32 = dict(dtype=torch.float32, device=dev)
 
         # -- one GEMM for everything that consumes the layer input x: Ax|Bx|Dx|Ex (gatedgcn_layer.py:
         # 57-61) and the attention in-projection q|k|v (gps_layer.py:238): [N,d] x [d,7d]
         wcat, bcat = layer._xgroup._stacked()
-        # dense side: the row-panel GEMM (csrc/gemm_panel.hip; d % 192 == 0) or the library GEMMs
-        panel = _gemm.supported(d, d) and _gemm.supported(2 * d, d) and _gemm.supported(7 * d, d) and E >= 1
+        bias_m = _merged_bias(layer, wcat, bcat)
+        ldp = 4 * d + 3 * inner
+        # dense side: the row-panel GEMM (csrc/gemm_panel.hip) or the library GEMMs
+        panel = _panel_ok(layer, d) and E >= 1
         imgs = None
         # The C projection of the edges goes FIRST: it depends on nothing but e, and with it out of the way the two halves
         # of the block that fork after the merged projection are balanced -- [attention core -> out-projection] beside
@@ -413,12 +459,11 @@ class _GPSBlock(torch.autograd.Function):
                     _gemm.absmax([x, e], out=amb[0:2])
             aw = (lambda i: None) if am is None else (lambda i: am[i])
             ce = _gemm.gemm_panel(e, imgs[1][0], d, bias=_B(R.C), a_amax=aw(1))
-            pq = _gemm.gemm_panel(x, imgs[0][0], 7 * d, bias=bcat, a_amax=aw(0))
+            pq = _gemm.gemm_panel(x, imgs[0][0], ldp, bias=bias_m, a_amax=aw(0))
         else:
             am, aw = None, (lambda i: None)
             ce = torch.addmm(_B(R.C), e, _W(R.C).t())
-            pq = torch.addmm(bcat, x, wcat.t())                 # [N, 4d + 3d]
-        ldp = 7 * d
+            pq = torch.addmm(bias_m, x, wcat.t())               # [N, 4d + 3 inner]
         P, fs = pq.data_ptr(), d * 4
         # -- the five BatchNorms: descriptors over one [10, d] statistics buffer ----------------------------
         stats = _E(10, d, **f32)                                # (mean, rstd) x 5
@@ -429,7 +474,7 @@ class _GPSBlock(torch.autograd.Function):
         bn2 = _bn_desc(R.bn2, stats[8], stats[9])
         ref = _BY_REF
         sync = _norm.sync_arena(layer, dev)
-        gemm_stats = panel and _GEMM_STATS and _gemm.stats_supported(N, d, d) and _gemm.stats_supported(N, d, 2 * d)
+        gemm_stats = panel and _GEMM_STATS and _gemm.stats_supported(N, d, inner) and _gemm.stats_supported(N, d, 2 * d)
         # -- local branch: GatedGCN core ---------------------------------------------------------
         def local_half():
             xt, eh = _E(N, d, **f32), _E(E, d, **f32)
@@ -457,11 +502,21 @@ class _GPSBlock(torch.autograd.Function):
         # -- global branch (forked): varlen attention over the PRE-layer x (gps_layer.py:199-201,234-241)
         with _Fork(dev, _BRANCH) as fork:
             sb = current_stream(dev)
-            o, lse = _E(N, d, **f32), _E(H, N, **f32)
+            o, lse = _E(N, inner, **f32), _E(H, N, **f32)       # (Performer: `lse` holds the query row maxima mq)
             scale = float(dh) ** -0.5
-            check(L.gps_seg_attn_fwd(P + 4 * fs, ldp, ptr(gi.ptr), ptr(gi.tile_graph), ptr(gi.tile_row0),
-                                     gi.max_tiles, N, H, dh, scale, p_at, s[2], ptr(o), ptr(lse),
-                                     gi.B, int(gi.nmax_host), sb), "gps_seg_attn_fwd")
+            fav = None
+            if perf:    # FAVOR+ over the ptr segments (csrc/favor.hip; performer_layer.py:119-144,200-205)
+                proj = sa.fast_attention.projection_matrix
+                BH = gi.B * H
+                fav = (proj, _E(BH, 272, dh, **f32), _E(BH, 272, **f32), _E(BH, dtype=torch.int64, device=dev),
+                       _E(H, N, **f32))                         # projection, ctx, ksum, kmax, D
+                check(L.gps_favor_fwd(P + 4 * fs, ldp, ptr(proj), proj.shape[0], ptr(gi.ptr), ptr(_nmax_dev(gi)),
+                                      ptr(gi.tile_graph), ptr(gi.tile_row0), gi.max_tiles, N, gi.B, H, dh, ptr(o),
+                                      ptr(fav[1]), ptr(fav[2]), ptr(fav[3]), ptr(lse), ptr(fav[4]), sb), "gps_favor_fwd")
+            else:
+                check(L.gps_seg_attn_fwd(P + 4 * fs, ldp, ptr(gi.ptr), ptr(gi.tile_graph), ptr(gi.tile_row0),
+                                         gi.max_tiles, N, H, dh, scale, p_at, s[2], ptr(o), ptr(lse),
+                                         gi.B, int(gi.nmax_host), sb), "gps_seg_attn_fwd")
             if am is not None:
                 _gemm.absmax([o], out=am[2])
             if gemm_stats:      # za = x + drop(out_proj(o)) and the statistics of za (norm1_attn) in the GEMM's epilogue
@@ -515,7 +570,8 @@ class _GPSBlock(torch.autograd.Function):
                         R.bnl._buffers["num_batches_tracked"], R.bna._buffers["num_batches_tracked"],
                         R.bn2._buffers["num_batches_tracked"]])
 
-        ctx.save_for_backward(x, e, pq, eh, xt, x1, o, lse, za, h, f1 if f1 is not None else t, t, z2, stats)
+        ctx.save_for_backward(x, e, pq, eh, xt, x1, o, lse, za, h, f1 if f1 is not None else t, t, z2, stats,
+                              *(fav if fav is not None else ()))
         ctx.layer, ctx.gi, ctx.seeds = layer, gi, s
         ctx.imgs = imgs     # W^T images for the input-gradient GEMMs (None: library GEMMs)
         ctx.am = am         # fp16 form: the max|.| words of x, e, o, h, t (the weight gradients' second operands)
@@ -525,7 +581,7 @@ class _GPSBlock(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g_out, g_e1):
         L = _lib.load()
-        x, e, pq, eh, xt, x1, o, lse, za, h, f1, t, z2, stats = ctx.saved_tensors
+        x, e, pq, eh, xt, x1, o, lse, za, h, f1, t, z2, stats, *fav = ctx.saved_tensors
         layer, gi, s = ctx.layer, ctx.gi, ctx.seeds
         p, p_l, p_f1, p_f2, p_at, H, dh, scale = ctx.cfg
         R = _refs(layer)
@@ -534,6 +590,8 @@ class _GPSBlock(torch.autograd.Function):
         st = current_stream(dev)
         N, d = x.shape
         E = e.shape[0]
+        perf = R.perf
+        inner = o.shape[1]
         f32 = dict(dtype=torch.float32, device=dev)
         g_out = g_out.contiguous()
         g_e1 = g_e1.contiguous() if g_e1 is not None else torch.zeros(E, d, **f32)
@@ -545,7 +603,7 @@ class _GPSBlock(torch.autograd.Function):
         sync = _norm.sync_arena(layer, dev)
         gpar = _E(10, d, **f32)              # (g_gamma, g_beta) of the five norms ...
         g_bxw, g_bxb, g_bew, g_beb, g_nlw, g_nlb, g_naw, g_nab, g_n2w, g_n2b = gpar.unbind(0)
-        if not _accumulating(block_params(layer)):      # ... or their slots in the optimizer's gradient arena
+        if not _accumulating(R.params):      # ... or their slots in the optimizer's gradient arena
             from ..optim import grad_slot
             bns = (R.bnx, R.bne, R.bnl, R.bna, R.bn2)
             slots = [grad_slot(q) for bn in bns for q in (bn.weight, bn.bias)]
@@ -589,18 +647,28 @@ class _GPSBlock(torch.autograd.Function):
         _norm.bwd_apply(b3, d, dev, sync.site(_S_B4))
         # gradient of the merged projection: attention writes dq|dk|dv into columns 4d.., GatedGCN
         # writes g_Ax|g_Bx|g_Dx|g_Ex into columns 0..4d of ONE [N,7d] buffer -> one dgrad, one wgrad
-        ldp = 7 * d
+        ldp = 4 * d + 3 * inner
         fs = d * 4
         g_pq = _E(N, ldp, **f32)
         G, P = g_pq.data_ptr(), pq.data_ptr()
         with _Fork(dev, _BRANCH) as fork:            # attention half of the backward
             sb = current_stream(dev)
-            g_o = _gemm.gemm_panel(g_ao, imgs[2][1], d, a_amax=bw(2)) if imgs is not None else g_ao.mm(_W(R.out_proj))
-            delta = _E(H, N, **f32)
-            check(L.gps_seg_attn_bwd(ptr(g_o), P + 4 * fs, ldp, ptr(o), ptr(lse), ptr(gi.ptr),
-                                     ptr(gi.tile_graph), ptr(gi.tile_row0), gi.max_tiles, N, H, dh, scale,
-                                     p_at, s[2], ptr(delta), G + 4 * fs, ldp, gi.B, int(gi.nmax_host), sb),
-                  "gps_seg_attn_bwd")
+            g_o = (_gemm.gemm_panel(g_ao, imgs[2][1], inner, a_amax=bw(2)) if imgs is not None
+                   else g_ao.mm(_W(R.out_proj)))
+            if perf:
+                proj, cbuf, ksum, kmax, Dn = fav
+                gD, g_ctx, g_ksum = _E(H, N, **f32), torch.empty_like(cbuf), torch.empty_like(ksum)
+                gm_part = _E(max(gi.max_tiles * H, 1), **f32)
+                check(L.gps_favor_bwd(ptr(g_o), P + 4 * fs, ldp, ptr(proj), proj.shape[0], ptr(o), ptr(gi.ptr),
+                                      ptr(_nmax_dev(gi)), ptr(gi.tile_graph), ptr(gi.tile_row0), gi.max_tiles, N, gi.B,
+                                      H, dh, ptr(cbuf), ptr(ksum), ptr(kmax), ptr(lse), ptr(Dn), ptr(gD), ptr(g_ctx),
+                                      ptr(g_ksum), ptr(gm_part), G + 4 * fs, ldp, sb), "gps_favor_bwd")
+            else:
+                delta = _E(H, N, **f32)
+                check(L.gps_seg_attn_bwd(ptr(g_o), P + 4 * fs, ldp, ptr(o), ptr(lse), ptr(gi.ptr),
+                                         ptr(gi.tile_graph), ptr(gi.tile_row0), gi.max_tiles, N, H, dh, scale,
+                                         p_at, s[2], ptr(delta), G + 4 * fs, ldp, gi.B, int(gi.nmax_host), sb),
+                      "gps_seg_attn_bwd")
 
         # x1 = x + drop(relu(BN_x(xt))):  bn_node_x's apply (its sums came from the chain above)
         g_xt = _E(N, d, **f32)
@@ -614,7 +682,7 @@ class _GPSBlock(torch.autograd.Function):
         fork.join()
         wcat, bcat = layer._xgroup._stacked()
         pairs = [(g_pq, x), (g_ce, e), (g_ao, o), (g_f1, h), (g_f2, t)]
-        leaves = block_params(layer)
+        leaves = R.params
         words = None
         if bm is not None:
             _gemm.absmax([g_pq, g_ce], out=bm[3:5])
@@ -635,13 +703,16 @@ class _GPSBlock(torch.autograd.Function):
         else:
             g_x = g_xres.addmm_(g_pq, wcat)          # residuals of za and x1 + A..E + in-proj inputs
             g_e = torch.addmm(g_e1, g_ce, _W(R.C))   # residual of e1 + C input
-        g_wi, g_bi = g_wcat[4 * d:], g_bcat[4 * d:]
+        if perf:        # to_q | to_k | to_v rows of the stacked gradient (no bias: the zero columns' sums are dropped)
+            inproj = [g_wcat[4 * d + i * inner:4 * d + (i + 1) * inner] for i in range(3)]
+        else:
+            inproj = [g_wcat[4 * d:], g_bcat[4 * d:]]
 
         abde = [g_wcat[i * d:(i + 1) * d] for i in range(4)] + [g_bcat[i * d:(i + 1) * d] for i in range(4)]
-        # order must match block_params()
+        # order must match _Refs.params
         return (g_x, g_e, None, None, None,
                 *abde, g_wc, g_bc, g_bxw, g_bxb, g_bew, g_beb, g_nlw, g_nlb,
-                g_wi, g_bi, g_wo, g_bo, g_naw, g_nab, g_w1, g_b1, g_w2, g_b2, g_n2w, g_n2b)
+                *inproj, g_wo, g_bo, g_naw, g_nab, g_w1, g_b1, g_w2, g_b2, g_n2w, g_n2b)
 
 
 class _GPSBlockGINE(torch.autograd.Function):
@@ -820,17 +891,9 @@ def gps_block_gine(layer, x, e, gi):
 
 
 def block_params(layer):
-    lm, sa = layer.local_model, layer.self_attn
-    return [lm.A.weight, lm.B.weight, lm.D.weight, lm.E.weight,
-            lm.A.bias, lm.B.bias, lm.D.bias, lm.E.bias,
-            lm.C.weight, lm.C.bias,
-            lm.bn_node_x.weight, lm.bn_node_x.bias, lm.bn_edge_e.weight, lm.bn_edge_e.bias,
-            layer.norm1_local.weight, layer.norm1_local.bias,
-            sa.in_proj_weight, sa.in_proj_bias, sa.out_proj.weight, sa.out_proj.bias,
-            layer.norm1_attn.weight, layer.norm1_attn.bias,
-            layer.ff_linear1.weight, layer.ff_linear1.bias,
-            layer.ff_linear2.weight, layer.ff_linear2.bias,
-            layer.norm2.weight, layer.norm2.bias]
+    """Leaf parameters of a CustomGatedGCN + Transformer / Performer block in the order ``_GPSBlock.backward`` returns
+    their gradients (``_Refs.params``)."""
+    return list(_refs(layer).params)
 
 
 def _block_static_ok(layer) -> bool:
@@ -839,7 +902,14 @@ def _block_static_ok(layer) -> bool:
     ok = layer.__dict__.get("_blk_static")
     if ok is None:
         lm = layer.local_model
-        ok = (layer.local_gnn_type == 'CustomGatedGCN' and layer.global_model_type == 'Transformer'
+        glob = layer.global_model_type
+        sa = layer.self_attn
+        glob_ok = glob == 'Transformer' or (
+            glob == 'Performer' and all(hasattr(sa, k) for k in ("to_q", "to_k", "to_v", "to_out", "fast_attention"))
+            and sa.to_q.bias is None and sa.to_out.bias is not None
+            and sa.to_q.weight.shape[0] == 64 * layer.num_heads                     # csrc/favor.hip: dim_head 64, m <= 272
+            and sa.fast_attention.projection_matrix.shape[0] <= 272 and sa.fast_attention.projection_matrix.shape[1] == 64)
+        ok = (layer.local_gnn_type == 'CustomGatedGCN' and glob_ok
               and bool(layer.batch_norm) and bool(lm.residual) and not getattr(lm, "EquivStablePE", False)
               and isinstance(lm.act_fn_x, nn.ReLU) and isinstance(lm.act_fn_e, nn.ReLU)
               and isinstance(layer.act_fn_ff, nn.ReLU)

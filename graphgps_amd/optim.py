@@ -18,6 +18,8 @@ There is no CPU path: ``step()`` on CPU parameters raises.
 """
 from __future__ import annotations
 
+import bisect
+
 from typing import Iterable, List, Optional
 
 import weakref
@@ -46,6 +48,17 @@ def grad_slot(t: torch.Tensor):
     off = t.storage_offset()
     if off < 0 or off + t.numel() > arena.flat_g.numel():
         return None
+    # ONE direct writer per range and step: a weight applied twice in one backward (a Linear called twice,
+    # tied weights held as separate Parameters) reaches here once per use, each time with ``p.grad is None`` --
+    # AccumulateGrad only runs after ALL contributions arrived -- and two kernels writing the same slot would leave
+    # 2 * g_last where g_1 + g_2 belongs.  The first use of a range claims it (until FlatAdamW.zero_grad); later uses get
+    # None, i.e. a fresh tensor that autograd sums with the first.
+    claimed = arena.__dict__.setdefault("_claimed", [])
+    lo, hi = off, off + t.numel()
+    i = bisect.bisect_left(claimed, (lo, lo))
+    if (i < len(claimed) and claimed[i][0] < hi) or (i > 0 and claimed[i - 1][1] > lo):
+        return None
+    claimed.insert(i, (lo, hi))
     return arena.flat_g[off:off + t.numel()].view(t.shape)
 
 
@@ -296,6 +309,7 @@ class FlatAdamW(torch.optim.Optimizer):
         # gradients are re-packed every step, so dropping the references is all there is to do
         for p in self.arena.params:
             p.grad = None
+        self.arena.__dict__["_claimed"] = []       # direct-write claims of the step that ended (grad_slot)
         self._packed = False
 
     # ------------------------------------------------------------------ checkpointing

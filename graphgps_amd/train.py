@@ -196,12 +196,17 @@ class TrainStep:
         ``max_graphs`` entries over ONE shared memory pool; a batch whose shape has an entry is copied into the static
         buffers (one multi-tensor copy) and replayed, the first batch of a new shape runs eagerly and the second one
         captures.  Loaders that emit a few fixed shapes (bucketed / padded datasets, the synthetic benches) replay every
-        step; a loader whose shapes never repeat simply stays on the eager path.  Needs ``optim.FlatAdamW``."""
-        if not self.flat or (self.exchange is not None and self.exchange.active):
+        step; a loader whose shapes never repeat simply stays on the eager path.  Needs ``optim.FlatAdamW``.
+        With an active data-parallel exchange the step is captured as TWO graphs either side of the all-reduce (as
+        ``capture`` does).  A shape whose capture fails is remembered and runs eagerly from then on; after three failed
+        captures replay is switched off for this ``TrainStep`` (one log line each)."""
+        if not self.flat or not self.__dict__.get("_replay_ok", True):
             return self._eager_triplet(batch)
         key = self._shape_key(batch)
         cache = self.__dict__.setdefault("_shape_cache", {})
         ent = cache.get(key)
+        if ent is False:                     # this shape's capture failed before: never retried (ADVICE r3)
+            return self._eager_triplet(batch)
         if ent is None:
             seen = self.__dict__.setdefault("_shape_seen", set())
             if key not in seen:              # first sight of this shape: run it eagerly, capture if it comes back
@@ -210,7 +215,11 @@ class TrainStep:
                 seen.add(key)
                 return self._eager_triplet(batch)
             ent = self._capture_shape(batch)
-            if ent is None:                  # capture is an optimisation, never a requirement
+            if ent is None:                  # capture is an optimisation, never a requirement -- but a failure is remembered:
+                cache[key] = False           # a step that cannot be captured (a host read in a head, a boolean-mask loss)
+                fails = self.__dict__["_capture_failures"] = self.__dict__.get("_capture_failures", 0) + 1
+                if fails >= 3:               # would otherwise pay an aborted capture on every repeat of every shape
+                    self.__dict__["_replay_ok"] = False
                 return self._eager_triplet(batch)
             cache[key] = ent
             while len(cache) > max_graphs:   # LRU: dicts keep insertion order
@@ -223,6 +232,9 @@ class TrainStep:
             torch._foreach_copy_(ent["dst"], [getattr(batch, k) for k in ent["keys"]])
         self.opt.sync_hyper()
         ent["graph"].replay()
+        if ent["graph_up"] is not None:      # data-parallel: [fwd + bwd + pack] -> RCCL all-reduce -> [clip + AdamW]
+            self.exchange.all_reduce()
+            ent["graph_up"].replay()
         loss, pred, true = ent["out"]
         return loss.clone(), _cloned(pred), _cloned(true)
 
@@ -268,6 +280,8 @@ class TrainStep:
             vars(b).pop("_gps_index", None)
             return b
         graph = torch.cuda.CUDAGraph()
+        split = self.exchange is not None and self.exchange.active
+        graph_up = torch.cuda.CUDAGraph() if split else None
         tick = torch.zeros(1, device=dev) if _os.environ.get("GPS_CAPTURE_TICK", "1") != "0" else None
         try:
             with STAGE_LOCK:                 # no staging thread allocates / copies / launches while this thread captures
@@ -282,13 +296,22 @@ class TrainStep:
                         with torch.cuda.stream(tside):
                             tick.add_(1.0)
                     out = self.forward_backward(fresh())
-                    self.update()
+                    if not split:
+                        self.update()
                     if tick is not None:
                         torch.cuda.current_stream(dev).wait_stream(tside)
-        except Exception:
+                if split:                    # the all-reduce stays an eager RCCL call between the two graphs
+                    with torch.cuda.graph(graph_up, pool=pool, capture_error_mode="thread_local"):
+                        self.update()
+        except RuntimeError as exc:          # (torch / HIP report capture violations as RuntimeError; anything else is a bug)
+            import warnings
+            warnings.warn(f"TrainStep.step_cached: capture of a step failed, this batch shape stays eager: "
+                          f"{type(exc).__name__}: {str(exc).splitlines()[0] if str(exc) else ''}")
+            torch.cuda.synchronize(dev)      # leave no half-issued work of the aborted capture behind
+            self.opt.zero_grad()
             return None
         torch.cuda.synchronize(dev)
-        return {"graph": graph, "keys": keys, "dst": dst, "out": out, "tick": tick, "static": static}
+        return {"graph": graph, "graph_up": graph_up, "keys": keys, "dst": dst, "out": out, "tick": tick, "static": static}
 
 
 def _cloned(obj):
@@ -372,6 +395,12 @@ def train_epoch(logger, loader, model, optimizer, scheduler, batch_accumulation,
         optimizer.param_groups[0]["max_grad_norm"] = (cfg.optim.clip_grad_norm_value
                                                       if cfg.optim.clip_grad_norm else None)
     step = TrainStep(model, optimizer, exchange=exchange)
+    if exchange is not None and not getattr(model, "_gps_replicas_synced", False):
+        # replicas start from rank 0's parameters AND buffers (BatchNorm running statistics, the Performer's random
+        # projection matrix): once per model, whatever seeds the ranks were constructed under (dp.broadcast_state)
+        from .dp import broadcast_state
+        broadcast_state(model, process_group=getattr(exchange, "group", None))
+        model._gps_replicas_synced = True
     optimizer.zero_grad()
     device = torch.device(cfg.accelerator)
     n_iters = len(loader)

@@ -463,3 +463,54 @@ def test_block_reference_cache_and_train_helpers_on_cpu():
     assert not _graph_attached(w) and not _graph_attached([w.detach(), "x", None])
     d = _detached({"a": [y, 3], "b": (y,)})
     assert not _graph_attached(d) and d["a"][1] == 3 and torch.equal(d["b"][0], y.detach())
+
+
+def test_grad_slot_admits_one_direct_writer_per_range_and_step():
+    """the weight-gradient kernels write straight into the optimizer's gradient arena when ``p.grad is None``
+    (optim.grad_slot).  A weight used TWICE in one backward reaches that check twice with ``p.grad`` still None
+    (AccumulateGrad runs after all contributions arrived); two direct writers into one slot left 2 * g_last instead of
+    g_1 + g_2.  The first use of a range claims it for the step; later uses -- the same parameter, a stack that contains
+    it, a member of a claimed stack -- get None (a fresh tensor, summed by autograd).  Simulated on a CPU arena with an
+    autograd Function that writes its weight gradient the way fused._Linear does."""
+    import torch
+    import torch.nn as nn
+    from graphgps_amd.optim import ParamArena, grad_slot
+
+    class DirectLinear(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w):
+            ctx.save_for_backward(x, w)
+            return x @ w.t()
+
+        @staticmethod
+        def backward(ctx, g):
+            x, w = ctx.saved_tensors
+            gw = grad_slot(w) if w.grad is None else None
+            if gw is None:
+                gw = torch.empty_like(w)
+            torch.mm(g.t(), x, out=gw)                # the kernel's plain store (no accumulation)
+            return g @ w, gw
+
+    torch.manual_seed(0)
+    lin = nn.Linear(6, 6, bias=False)
+    arena = ParamArena(lin.parameters())
+    x = torch.randn(5, 6)
+    y = DirectLinear.apply(DirectLinear.apply(x, lin.weight), lin.weight)     # the same weight twice
+    y.square().sum().backward()
+    ref = nn.Linear(6, 6, bias=False)
+    ref.load_state_dict(lin.state_dict())
+    ref(ref(x)).square().sum().backward()
+    assert torch.allclose(lin.weight.grad, ref.weight.grad, rtol=1e-5, atol=1e-6)
+    # claims: one per range until the optimizer's zero_grad; stacks and their members exclude each other
+    arena.__dict__["_claimed"] = []
+    a, b = nn.Parameter(torch.zeros(3, 4)), nn.Parameter(torch.zeros(2, 4))
+    ar2 = ParamArena([a, b])
+    stack = a.data.new_empty(0).set_(a.data.untyped_storage(), a.data.storage_offset(), (5, 4)) \
+        if b.data_ptr() == a.data_ptr() + a.numel() * 4 else None
+    assert grad_slot(a) is not None and grad_slot(a) is None
+    if stack is not None:
+        assert grad_slot(stack) is None           # overlaps the claimed member
+    assert grad_slot(b) is not None
+    ar2.__dict__["_claimed"] = []                  # (what FlatAdamW.zero_grad does)
+    if stack is not None:
+        assert grad_slot(stack) is not None and grad_slot(a) is None and grad_slot(b) is None

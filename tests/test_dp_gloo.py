@@ -341,3 +341,55 @@ def test_param_arena_readoption_keeps_aliased_parameters_tied():
     assert torch.equal(tied, want + 1.0)
     lo, hi = arena.flat_p.data_ptr(), arena.flat_p.data_ptr() + arena.flat_p.numel() * 4
     assert all(lo <= p.data_ptr() < hi for p in params)
+
+
+def _bcast_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import hashlib
+        import graphgps_amd as g
+        from graphgps_amd.dp import broadcast_state
+        # ranks seeded DIFFERENTLY: different initial weights and -- the silent one -- different random Performer
+        # projection matrices (performer_layer.py:272-273); a code2-shaped model (CustomGatedGCN+Performer layers)
+        torch.manual_seed(100 + rank)
+        m = g.create_model(os.path.join(g.CONFIG_DIR, "code2_gps.yaml"), ["gt.layers", 2], 1, 1)
+        for bn in [mod for mod in m.modules() if isinstance(mod, torch.nn.BatchNorm1d)]:
+            bn.running_mean.add_(float(rank + 1))            # buffers that moved during some rank-local warm-up
+            bn.num_batches_tracked.add_(rank + 3)
+
+        def digest():
+            h = hashlib.sha256()
+            for k, t in sorted(list(m.named_parameters()) + list(m.named_buffers()), key=lambda kv: kv[0]):
+                h.update(k.encode()); h.update(t.detach().cpu().contiguous().numpy().tobytes())
+            return h.hexdigest()
+        before = digest()
+        proj = [k for k, _ in m.named_buffers() if k.endswith("projection_matrix")]
+        assert proj, "the model under test must hold a random Performer projection buffer"
+        nbytes = broadcast_state(m)
+        q.put((rank, before, digest(), nbytes, len(proj)))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_broadcast_state_makes_differently_seeded_replicas_identical_world2_gloo():
+    """dp.broadcast_state: ranks constructed under different seeds (different weights, different random Performer
+    projection buffers, different BatchNorm running statistics) hold bit-identical parameters AND buffers afterwards
+    (SURVEY.md section 8e)."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_bcast_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=240) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    (_, b0, a0, n0, k0), (_, b1, a1, n1, k1) = results
+    assert b0 != b1, "the two ranks were supposed to start from different states"
+    assert a0 == a1, "replicas differ after broadcast_state"
+    assert a0 == b0, "rank 0's state is the one that must survive"
+    assert n0 == n1 and n0 > 0 and k0 == 2

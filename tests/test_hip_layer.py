@@ -200,7 +200,7 @@ def test_gpslayer_vs_oracle_baseline_sizes(local, glob, d, H, profile, nb):
     check_params(strict=True)
 
 
-def _masked_oracle_run(oracle, b, seeds_per_layer, H, p, p_attn, wx, we, dtype, local):
+def _masked_oracle_run(oracle, b, seeds_per_layer, H, p, p_attn, wx, we, dtype, local, glob="Transformer"):
     """Forward + backward of a stack of oracle layers with every dropout replaced by the mask the fused block draws
     from its seed (tests/helpers.py): returns (x_out, e_out, grad x, grad e, {param: grad} per layer)."""
     import copy
@@ -216,13 +216,28 @@ def _masked_oracle_run(oracle, b, seeds_per_layer, H, p, p_attn, wx, we, dtype, 
     masks = []
     for lay, seed in zip(layers, seeds_per_layer):
         s = block_seeds(seed)
-        keep = attention_keep(s[2], b.ptr, H, p_attn) if p_attn > 0 else None
-        lay.self_attn = MaskedSegmentMHA(lay.self_attn, b.ptr, keep, attn_dropout_effective_p(p_attn))
+        if glob == "Transformer":
+            keep = attention_keep(s[2], b.ptr, H, p_attn) if p_attn > 0 else None
+            lay.self_attn = MaskedSegmentMHA(lay.self_attn, b.ptr, keep, attn_dropout_effective_p(p_attn))
         if local == "CustomGatedGCN":       # call order: gatedgcn x, e | dropout_attn | ff_dropout1 | ff_dropout2
             masks += [row_mask(s[0], N, d, p), row_mask(s[1], E, d, p)]
         else:                               # GINE: dropout_local | dropout_attn | ff_dropout1 | ff_dropout2
             masks += [row_mask(s[0], N, d, p)]
-        masks += [row_mask(s[3], N, d, p), row_mask(s[4], N, 2 * d, p), row_mask(s[5], N, d, p)]
+        if glob == "Performer":
+            # The Performer drops its OUTPUT (performer_layer.py:500-503), GPSLayer's dropout_attn drops it again
+            # (gps_layer.py:212): two independent keep decisions with their scalings are ONE Bernoulli mask with keep
+            # probability (1 - p_attn)(1 - p) -- the form the fused block draws (one hash per element).  Injected into
+            # the reference's two calls as (that mask, all ones).
+            p_eff = 1.0 - (1.0 - p_attn) * (1.0 - p)
+            sizes = (b.ptr[1:] - b.ptr[:-1]).tolist()
+            dense = torch.ones(len(sizes), max(sizes), d, dtype=torch.float64)     # the reference drops the PADDED batch
+            rm = row_mask(s[3], N, d, p_eff)
+            for g_, n_ in enumerate(sizes):
+                dense[g_, :n_] = rm[int(b.ptr[g_]):int(b.ptr[g_]) + n_]
+            masks += [dense, torch.ones(N, d, dtype=torch.float64)]
+        else:
+            masks += [row_mask(s[3], N, d, p)]
+        masks += [row_mask(s[4], N, 2 * d, p), row_mask(s[5], N, d, p)]
     with inject_dropout_masks(masks):
         for lay in layers:
             bc = lay(bc)
@@ -302,6 +317,68 @@ def test_fused_block_with_dropout_on_vs_masked_oracle(local, d, H, profile, nb, 
                 for li in range(n_layers) for k in r64[4][li])
     print(f"   parameter gradients: max rel error vs fp64 {worst:.2e} outside {flips} kink rows "
           f"(cpu-fp32 masked oracle: max {c_err:.2e})")
+
+
+@pytest.mark.parametrize("d,H,profile,nb,p,p_attn,n_layers", [
+    (256, 4, "CODE2_REAL", 32, 0.2, 0.5, 1),      # ogbg-code2-GPS.yaml: d = 256, 4 x 64-wide heads, dropout 0.2 / 0.5
+    (256, 4, "CODE2_REAL", 16, 0.2, 0.5, 2),
+    (64, 2, "P30", 64, 0.1, 0.0, 1),              # a narrow layer: inner = 128 != d
+])
+def test_performer_block_with_dropout_on_vs_masked_oracle(d, H, profile, nb, p, p_attn, n_layers, monkeypatch):
+    """The CustomGatedGCN+Performer layer as ONE autograd node (round 4: layer/gps_block.py; BASELINE configs[4]) with the
+    config's dropout rates ON, against the oracle with the block's masks injected -- graphgps/layer/gps_layer.py:111-114,
+    206,212-229, performer_layer.py:119-144,200-205,500-503.  Same bars as the Transformer block's test; FAVOR+ couples
+    all rows of a graph, so a ReLU-kink flip moves a whole graph's gradient rows: those rows are counted, not widened."""
+    from graphgps_amd.layer import gps_block
+    from graphgps_amd.layer.gps_layer import GPSLayer
+    from graphgps_amd.synthetic import layer_batch
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    layers = [GPSLayer(d, "CustomGatedGCN", "Performer", H, dropout=p, attn_dropout=p_attn) for _ in range(n_layers)]
+    oracle = [_oracle_layer_like(l) for l in layers]
+    for l in layers:
+        l.to(dev).train()
+    b = layer_batch(profile, nb, d, seed=93)
+    gen = torch.Generator().manual_seed(8)
+    wx = torch.randn(b.x.shape, generator=gen)
+    we = torch.randn(b.edge_attr.shape, generator=gen)
+    seeds = [0x0FEDCBA987654321 + 131 * i for i in range(n_layers)]
+    it = iter(seeds)
+    monkeypatch.setattr(gps_block, "draw_dropout_seed", lambda: next(it))
+    bg = b.clone().to(dev)
+    bg.x.requires_grad_(True); bg.edge_attr.requires_grad_(True)
+    xg, eg = bg.x, bg.edge_attr
+    og = bg
+    for l in layers:
+        assert gps_block.block_supported(l, og.x, og.edge_attr), "the fused block path must be the one under test"
+        og = l(og)
+    ((og.x * wx.to(dev)).sum() + (og.edge_attr * we.to(dev)).sum()).backward()
+    r32 = _masked_oracle_run(oracle, b, seeds, H, p, p_attn, wx, we, torch.float32, "CustomGatedGCN", "Performer")
+    r64 = _masked_oracle_run(oracle, b, seeds, H, p, p_attn, wx, we, torch.float64, "CustomGatedGCN", "Performer")
+    # the CPU fp32 evaluation of the same masked function is the yardstick: FAVOR+'s exp / normaliser chain at 100-1000
+    # keys is worth a few 1e-6 in fp32 on either side
+    o32 = float((r32[0].double() - r64[0]).abs().max())
+    tol = max(Tol.ACT * n_layers, 3.0 * o32)
+    assert_close(og.x, r64[0], tol, "out.x (Performer block, dropout on)")
+    assert_close(og.edge_attr, r64[1], Tol.ACT * n_layers, "out.edge_attr")
+    gmax = int((b.ptr[1:] - b.ptr[:-1]).max())
+    g32 = float((r32[2].double() - r64[2]).abs().max() / max(1.0, float(r64[2].abs().max())))
+    rx = assert_close_kink_tolerant(xg.grad, r64[2], max(Tol.GRAD_REL * n_layers, 3.0 * g32), "grad x",
+                                    min_allowed_rows=4 * gmax * n_layers)
+    re_ = assert_close_kink_tolerant(eg.grad, r64[3], Tol.GRAD_REL * n_layers, "grad e")
+    print(f"Performer block x{n_layers}, dropout on: out.x err {float((og.x.double().cpu() - r64[0]).abs().max()):.2e} "
+          f"(cpu fp32 {o32:.2e}); grad x {rx[0]:.2e} outside {rx[2]} rows (cpu fp32 {g32:.2e}); grad e {re_[0]:.2e}")
+    gscale = max(float(g.abs().max()) for gl in r64[4] for g in gl.values())
+    worst = 0.0
+    for li, l in enumerate(layers):
+        for k, q in l.named_parameters():
+            if k not in r64[4][li]:
+                continue
+            c32 = float((r32[4][li][k].double() - r64[4][li][k]).abs().max()) / max(1.0, 0.01 * gscale)
+            rr = assert_close_kink_tolerant(q.grad, r64[4][li][k], max(1e-4, 3.0 * c32), f"layer {li} grad {k}",
+                                            min_scale=max(1.0, 0.01 * gscale))
+            worst = max(worst, rr[0])
+    print(f"   parameter gradients: max rel error vs fp64 {worst:.2e}")
 
 
 def test_code2_model_vs_oracle():
