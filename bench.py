@@ -239,7 +239,8 @@ def kernel_rooflines(dev, profile, nb, d=384, H=16, in_step=None, layers=10, onl
         check(L.gps_gatedgcn_bwd(ptr(q["gx"]), d, ptr(q["ge"]), ptr(q["eh"]), P, P + fs, 4 * d, ptr(q["xt"]),
                                  ptr(gi.rowptr_dst), ptr(gi.src_by_dst), ptr(gi.eid_by_dst),
                                  ptr(gi.rowptr_src), ptr(gi.dst_by_src), ptr(gi.eid_by_src), N, E, d,
-                                 ptr(q["gce"]), G, G + fs, G + 2 * fs, G + 3 * fs, 4 * d, None, current_stream(dev)))
+                                 ptr(q["gce"]), G, G + fs, G + 2 * fs, G + 3 * fs, 4 * d, None, None, None,
+                                 current_stream(dev)))
 
     def at_set():
         return dict(qkv=f(N, 3 * d), out=f(N, d), lse=f(H, N), dout=f(N, d), delta=f(H, N), dqkv=f(N, 3 * d))
@@ -724,8 +725,10 @@ def main():
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": ms,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
             "data": "synthetic",
-            "dropout": "on (config values; masks from the kernels' counter hash -- parity of this configuration "
-                       "is statistical / shared-mask, tests/test_hip_ops.py)",
+            "dropout": "on (config values; masks from the kernels' counter hash -- parity of this configuration is "
+                       "element-wise: the oracle with the blocks' masks injected, 1 / 2 layers and the 10-layer model, "
+                       "tests/test_hip_layer.py::test_fused_block_with_dropout_on_vs_masked_oracle, "
+                       "::test_full_model_with_dropout_on_vs_masked_oracle)",
             "config": {"workload": f"{wl_label}, synthetic profile "
                                    f"{args.profile or {'pcqm4m': 'P30', 'zinc': 'ZINC', 'code2': 'CODE2_LONG'}[args.workload]}, "
                                    f"{nb} graphs/GPU ({N} nodes, {E} directed edges on rank 0)",
@@ -758,7 +761,9 @@ def main():
                 pmc = os.path.join(ROOT, "profiles", "pmc_gatedgcn_fwd.json")
                 if os.path.exists(pmc):           # HBM bytes per launch from a separate rocprofv3 --pmc pass
                     rec = json.load(open(pmc))
-                    traffic, traffic_src = rec.get("hbm_bytes_per_launch"), rec.get("source")
+                    # (static: measured by a separate counter pass -- counters and timing never share a run -- and read
+                    # from the committed file, not collected by this run)
+                    traffic, traffic_src = rec.get("hbm_bytes_per_launch"), "static: " + str(rec.get("source"))
                 out["roofline"] = {"kernel": "k_gatedgcn_fwd", "bound": "hbm", "achieved": k["achieved"],
                                    "peak": k["peak"], "unit": "GB/s", "frac": k["frac"],
                                    "launch_ms": k["ms"], "launch_ms_source": k["ms_source"],

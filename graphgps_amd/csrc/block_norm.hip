@@ -102,7 +102,7 @@ __device__ __forceinline__ void block_amax(float mx, uint32_t* slot, float* lds)
     for (int q = t + 64; q < n; q += 64) m = max(m, w[q]);
 #pragma unroll
     for (int o = 32; o; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
-    if (t == 0 && m) atomicMax(slot, m);
+    if (t == 0) gps::amax_raise(slot, m);
   }
   __syncthreads();                               // the scratch may be reused
 }
@@ -611,6 +611,31 @@ size_t gps_norm_tree_floats(int64_t R, int d) {
 }
 
 int gps_norm_sync_words(void) { return 2 * kMaxTasks * tr::kSyncWords; }
+
+// Arrival counters of the in-launch reductions (csrc/col_tree.hpp): zero at entry of every launch, zero at exit.
+// gps_sync_reset re-zeroes a buffer (a caller that survived a failed launch); gps_sync_nonzero counts the non-zero words
+// into *count (device uint32, raised atomically) -- a debugging aid behind GPS_CHECK_TICKS=1 (layer/gps_block.py).
+int gps_sync_reset(uint32_t* sync, size_t words, gps_stream_t stream) {
+  GPS_REQUIRE(sync || words == 0, "gps_sync_reset: null buffer");
+  if (words == 0) return GPS_OK;
+  const hipError_t e = hipMemsetAsync(sync, 0, words * sizeof(uint32_t), gps::as_stream(stream));
+  GPS_REQUIRE(e == hipSuccess, "gps_sync_reset: %s", hipGetErrorString(e));
+  return GPS_OK;
+}
+}  // extern "C"
+namespace {
+__global__ void k_sync_nonzero(const uint32_t* sync, size_t words, uint32_t* count) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i < words && __hip_atomic_load(sync + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) atomicAdd(count, 1u);
+}
+}  // namespace
+extern "C" {
+int gps_sync_nonzero(const uint32_t* sync, size_t words, uint32_t* count, gps_stream_t stream) {
+  GPS_REQUIRE((sync && count) || words == 0, "gps_sync_nonzero: null buffer");
+  if (words == 0) return GPS_OK;
+  k_sync_nonzero<<<gps::grid_for((int64_t)words, 256), 256, 0, gps::as_stream(stream)>>>(sync, words, count);
+  return gps::launch_status("gps_sync_nonzero");
+}
 
 int gps_norm_fwd(int n, const gps_norm_fwd_task* tasks, int d, float* ws, size_t ws_floats, uint32_t* sync,
                  gps_stream_t stream) {

@@ -17,10 +17,28 @@
 //     ready without a memset node; two launches that may run CONCURRENTLY (forked streams) must use different counters.
 // Determinism: records are combined in index order, never in arrival order, so the result is bitwise reproducible.
 //
+// Memory model: the records travel as RELAXED agent-scope atomics (write-through `sc1` stores, L1-bypassing
+// `sc1` loads) ordered against the ticket by `s_waitcnt vmcnt(0)` + the workgroup barrier, NOT by release / acquire on the
+// ticket.  That is deliberate and specific to gfx942 / gfx950 (this header refuses other targets below): an agent-scope
+// release there is a `buffer_wbl2` -- a write-back of the XCD's whole L2, i.e. of the very tensor the producing kernel has
+// just stored (tens of MB) -- once per workgroup, which would cost more than the launch this protocol removes; the
+// write-through stores make the records visible at the memory side without it, and every reader bypasses its own caches.
+//
+// Counters must be ZERO at entry.  A launch that died mid-tree (a fault elsewhere in the process, a killed graph replay)
+// leaves them non-zero; the next launch on those counters would then elect the wrong "last" workgroup and publish
+// statistics of incomplete records.  That cannot happen silently: whatever the stale value, at least one workgroup of the
+// next launch draws a ticket >= the group size, and a ticket that large TRAPS (the launch -- and with it the HIP context --
+// fails loudly; tests/test_hip_norm.py poisons a counter in a child process to show it).  gps_sync_reset (include/
+// gps_hip.h) re-zeroes a counter buffer for a caller that survived the original failure and wants to go on.
+//
 // Record kinds: STATS = (mean_b, M2_b; n_b) combined exactly as csrc/bn_fused.hip's finalize (weighted mean, then
 // sum of M2_b + n_b (mean_b - mean)^2: Welford/Chan-grade accuracy); SUMS = plain column sums.
 #pragma once
 #include <hip/hip_runtime.h>
+
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "col_tree.hpp: the write-through / relaxed-atomic protocol is validated for gfx942 / gfx950 only (see the header comment)"
+#endif
 
 #include <cstddef>
 #include <cstdint>
@@ -227,6 +245,7 @@ __device__ __forceinline__ void arrive(const Tree& T, int b, int d, float* lds) 
   const int cnt = T.P - i0 < T.fan ? T.P - i0 : T.fan;
   if (threadIdx.x == 0) {
     const unsigned t = __hip_atomic_fetch_add(T.tick + 1 + g, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t >= (unsigned)cnt) __builtin_trap();           // the counter was not zero at entry: fail loudly (header comment)
     *flag = t == (unsigned)(cnt - 1);
   }
   __syncthreads();
@@ -247,6 +266,7 @@ __device__ __forceinline__ void arrive(const Tree& T, int b, int d, float* lds) 
   __syncthreads();
   if (threadIdx.x == 0) {
     const unsigned t = __hip_atomic_fetch_add(T.tick, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (t >= (unsigned)T.NG) __builtin_trap();
     *flag = t == (unsigned)(T.NG - 1);
   }
   __syncthreads();

@@ -277,7 +277,8 @@ __device__ __forceinline__ void bwd_a_chunk(const float* __restrict__ g_e, const
                                             const float* __restrict__ Bx, int64_t ld,
                                             const float* __restrict__ r_edge, int d, int c, const int* nbr,
                                             const int* eids, const Vec<VEC>& gx, Vec<VEC>& gdx, float* g_Ce,
-                                            float* __restrict__ sD, float* __restrict__ sS, int slot0, int cap) {
+                                            float* __restrict__ sD, float* __restrict__ sS, int slot0, int cap,
+                                            float& mce) {
   int64_t id[D];
   Vec<VEC> eh[D], ge[D], bx[D];
   float rr[D];
@@ -320,6 +321,7 @@ __device__ __forceinline__ void bwd_a_chunk(const float* __restrict__ g_e, const
       dl[v] = (ge[u][v] + (a[v] * bx[u][v]) * sp) + b[v] * sp;
       gdx[v] += dl[v];
       sa[v] = (GATE ? s * rr[u] : s) * a[v];   // sig_ij a_i: what the source-keyed phase adds to g_Bx_j
+      mce = fmaxf(mce, fabsf(dl[v]));          // max|g_Ce|: the record of the GEMMs that consume g_Ce (gps_hip.h)
     }
     dl.store(g_Ce + id[u] * d + c);
     if (slot0 + u < cap) {                    // hand-over to phase B through LDS (no second trip to memory)
@@ -336,9 +338,9 @@ __device__ __forceinline__ void bwd_a_rows(const float* __restrict__ g_x, int64_
                                            const int* eids, const NodeBlock& blk, int d, int row, int npi, int c,
                                            float* g_Ce, float* __restrict__ g_Ax, float* __restrict__ g_Dx,
                                            int64_t ldg, const float* __restrict__ r_edge, float* __restrict__ sD,
-                                           float* __restrict__ sS, int e0, int cap) {
+                                           float* __restrict__ sS, int e0, int cap, float& mce, float& mnode) {
 #define GPS_BWD_A(DD) bwd_a_chunk<VEC, GATE, DD>(g_e, e_hat, Bx, ld, r_edge, d, c, nbr + beg, eids + beg, gx, gdx, \
-                                                 g_Ce, sD, sS, beg - e0, cap)
+                                                 g_Ce, sD, sS, beg - e0, cap, mce)
   for (int64_t node = blk.n0 + row; node < blk.n1; node += npi) {
     const int beg = rp[node - blk.n0], end = rp[node - blk.n0 + 1];
     const Vec<VEC> gx = Vec<VEC>::load(g_x + node * ldgx + c);
@@ -386,6 +388,7 @@ __device__ __forceinline__ void bwd_a_rows(const float* __restrict__ g_x, int64_
             dl[v] = (ge[v] + (a[v] * bx[v]) * sp) + b[v] * sp;   // same association as the one-pass form
             gdx[v] += dl[v];
             sa[v] = (GATE ? s * rr : s) * a[v];
+            mce = fmaxf(mce, fabsf(dl[v]));
           }
           dl.store(g_Ce + id * d + c);
           if (k - e0 < cap) {
@@ -397,6 +400,8 @@ __device__ __forceinline__ void bwd_a_rows(const float* __restrict__ g_x, int64_
     }
     if (g_Ax) gx.store(g_Ax + node * ldg + c);
     gdx.store(g_Dx + node * ldg + c);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) mnode = fmaxf(mnode, fmaxf(fabsf(gx[v]), fabsf(gdx[v])));
   }
 #undef GPS_BWD_A
 }
@@ -490,7 +495,7 @@ __device__ __forceinline__ void bwd_b_rows(const float* __restrict__ g_x, int64_
                                            float* __restrict__ g_Bx, float* __restrict__ g_Ex, int64_t ldg,
                                            const float* __restrict__ r_edge, const int* rp_d, const int* eids_d,
                                            int e0, const float* __restrict__ sD, const float* __restrict__ sS,
-                                           int cap) {
+                                           int cap, float& mnode) {
 #define GPS_BWD_B(DD) bwd_b_chunk<VEC, GATE, DD>(g_x, ldgx, g_e, e_hat, Ax, ld, x_tilde, rowptr_g, eid_g, r_edge, g_Ce, d, c, \
                                                  tgt + k, eids + k, blk, Bx, node, gbx, gex, rp_d, eids_d, e0, sD, \
                                                  sS, cap)
@@ -508,6 +513,8 @@ __device__ __forceinline__ void bwd_b_rows(const float* __restrict__ g_x, int64_
     }
     gbx.store(g_Bx + node * ldg + c);
     gex.store(g_Ex + node * ldg + c);
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) mnode = fmaxf(mnode, fmaxf(fabsf(gbx[v]), fabsf(gex[v])));
   }
 #undef GPS_BWD_B
 }
@@ -520,8 +527,9 @@ __global__ __launch_bounds__(GG_T) void k_gatedgcn_bwd(
     const int32_t* __restrict__ eid, const int32_t* __restrict__ rowptr_s, const int32_t* __restrict__ dst,
     const int32_t* __restrict__ eid_s, int64_t N, int d, float* g_Ce, float* __restrict__ g_Ax,
     float* __restrict__ g_Bx, float* __restrict__ g_Dx, float* __restrict__ g_Ex, int64_t ldg,
-    const float* __restrict__ r_edge, int nb, int npi, int cap_arg) {
+    const float* __restrict__ r_edge, int nb, int npi, int cap_arg, uint32_t* amax_node, uint32_t* amax_ce) {
   __shared__ int s_rp[GG_MAXNB + 1], s_rq[GG_MAXNB + 1];
+  __shared__ uint32_t s_amax[2][GG_T / 64];
   __shared__ int s_src[GG_MAXE], s_eid[GG_MAXE], s_dst[GG_MAXE], s_eid2[GG_MAXE];
   extern __shared__ __attribute__((aligned(16))) float g_stash[];   // [2][cap][d]: delta | sig a_i per CSR slot
   const NodeBlock blk = node_block(N, nb);
@@ -538,25 +546,44 @@ __global__ __launch_bounds__(GG_T) void k_gatedgcn_bwd(
   const int cap = st_d ? cap_arg : 0;       // the slot lookup of phase B walks the staged CSR slice
   float* sD = g_stash;
   float* sS = g_stash + (int64_t)cap_arg * d;
+  float mce = 0.0f, mnode = 0.0f;        // max|g_Ce|, max over the four node gradients: the records of their GEMMs
   if (active) {
     if (st_d)
       bwd_a_rows<VEC, GATE>(g_x, ldgx, g_e, e_hat, Bx, ld, s_rp, s_src - e0, s_eid - e0, blk, d, row, npi, c,
-                            g_Ce, g_Ax, g_Dx, ldg, r_edge, sD, sS, e0, cap);
+                            g_Ce, g_Ax, g_Dx, ldg, r_edge, sD, sS, e0, cap, mce, mnode);
     else
       bwd_a_rows<VEC, GATE>(g_x, ldgx, g_e, e_hat, Bx, ld, s_rp, src, eid, blk, d, row, npi, c, g_Ce, g_Ax,
-                            g_Dx, ldg, r_edge, sD, sS, e0, 0);
+                            g_Dx, ldg, r_edge, sD, sS, e0, 0, mce, mnode);
   }
   __threadfence_block();
   __syncthreads();            // this workgroup's g_Ce rows are visible to all of its lanes (same CU)
   // ---- phase B: keyed by source ------------------------------------------------------------------
-  if (!active) return;
-  const int q0 = s_rq[0];
-  if (st_s)
-    bwd_b_rows<VEC, GATE>(g_x, ldgx, g_e, e_hat, Ax, Bx, ld, x_tilde, rowptr, eid, s_rq, s_dst - q0, s_eid2 - q0,
-                          blk, d, row, npi, c, g_Ce, g_Bx, g_Ex, ldg, r_edge, s_rp, s_eid - e0, e0, sD, sS, cap);
-  else
-    bwd_b_rows<VEC, GATE>(g_x, ldgx, g_e, e_hat, Ax, Bx, ld, x_tilde, rowptr, eid, s_rq, dst, eid_s, blk, d, row,
-                          npi, c, g_Ce, g_Bx, g_Ex, ldg, r_edge, s_rp, s_eid - e0, e0, sD, sS, cap);
+  if (!active && !amax_node) return;
+  if (active) {
+    const int q0 = s_rq[0];
+    if (st_s)
+      bwd_b_rows<VEC, GATE>(g_x, ldgx, g_e, e_hat, Ax, Bx, ld, x_tilde, rowptr, eid, s_rq, s_dst - q0, s_eid2 - q0,
+                            blk, d, row, npi, c, g_Ce, g_Bx, g_Ex, ldg, r_edge, s_rp, s_eid - e0, e0, sD, sS, cap, mnode);
+    else
+      bwd_b_rows<VEC, GATE>(g_x, ldgx, g_e, e_hat, Ax, Bx, ld, x_tilde, rowptr, eid, s_rq, dst, eid_s, blk, d, row,
+                            npi, c, g_Ce, g_Bx, g_Ex, ldg, r_edge, s_rp, s_eid - e0, e0, sD, sS, cap, mnode);
+  }
+  if (!amax_node) return;                  // (kernel-uniform)
+  // one atomic per record and workgroup: through LDS (a wave of the block may hold inactive rows' lanes only)
+  const int wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+  uint32_t m0 = __float_as_uint(mnode), m1 = __float_as_uint(mce);
+#pragma unroll
+  for (int o = 32; o; o >>= 1) {
+    m0 = max(m0, (uint32_t)__shfl_xor((int)m0, o));
+    m1 = max(m1, (uint32_t)__shfl_xor((int)m1, o));
+  }
+  if ((threadIdx.x & 63) == 0) { s_amax[0][wave] = m0; s_amax[1][wave] = m1; }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    uint32_t m = 0;
+    for (int w = 0; w < nw; ++w) m = max(m, s_amax[threadIdx.x][w]);
+    gps::amax_raise(threadIdx.x == 0 ? amax_node : amax_ce, m);
+  }
 }
 
 inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
@@ -603,7 +630,7 @@ inline Plan plan_for(int64_t N, int lanes_per_row, bool forward) {
 #define GPS_GG_BWD(GATE)                                                                             \
   k_gatedgcn_bwd<VEC, GATE><<<pl.grid, pl.threads, stash_bytes, s>>>(g_x, ld_gx, g_e, e_hat, Ax, Bx, ld_node, x_tilde, \
       rowptr_dst, src_by_dst, eid_by_dst, rowptr_src, dst_by_src, eid_by_src, N, d, g_Ce,             \
-      g_Ax == g_x ? nullptr : g_Ax, g_Bx, g_Dx, g_Ex, ld_gnode, r_edge, pl.nb, pl.npi, cap)
+      g_Ax == g_x ? nullptr : g_Ax, g_Bx, g_Dx, g_Ex, ld_gnode, r_edge, pl.nb, pl.npi, cap, amax_node, amax_ce)
 
 extern "C" {
 
@@ -689,9 +716,10 @@ int gps_gatedgcn_bwd(const float* g_x, int64_t ld_gx, const float* g_e, const fl
                      const int32_t* eid_by_dst, const int32_t* rowptr_src,
                      const int32_t* dst_by_src, const int32_t* eid_by_src, int64_t N, int64_t E,
                      int d, float* g_Ce, float* g_Ax, float* g_Bx, float* g_Dx, float* g_Ex,
-                     int64_t ld_gnode, const float* r_edge, gps_stream_t stream) {
+                     int64_t ld_gnode, const float* r_edge, uint32_t* amax_node, uint32_t* amax_ce, gps_stream_t stream) {
   GPS_REQUIRE(N >= 0 && E >= 0 && d > 0 && ld_node >= d && ld_gnode >= d && ld_gx >= d,
               "gps_gatedgcn_bwd: bad sizes");
+  GPS_REQUIRE((amax_node == nullptr) == (amax_ce == nullptr), "gps_gatedgcn_bwd: both max|.| records or neither");
   if (N == 0) return GPS_OK;
   GPS_REQUIRE(g_x && Ax && Bx && x_tilde && rowptr_dst && rowptr_src && g_Ax && g_Bx && g_Dx && g_Ex,
               "gps_gatedgcn_bwd: null node buffer");

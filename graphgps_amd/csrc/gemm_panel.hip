@@ -464,8 +464,10 @@ __device__ __forceinline__ void ring_store(const PanelArgs& P, const f32x16 (&ac
         float v = acc[mb][j][q] + bv[j];
         if (HAS_CIN && EPI != 3) v += cin[j][q];
         if (EPI == 1) v = fmaxf(v, 0.0f);
-        if (EPI == 2) v = msk[j][q] > 0.0f ? v : 0.0f;
-        if (EPI != 0) {
+        // EPI 2: the saved activation IS the mask -- t = dropout(relu(f1)) is positive exactly where the element was kept
+        // and f1 > 0, so no hash is re-evaluated here (12 VALU per element, round 3), only the 1 / (1 - p) scaling
+        if (EPI == 2) v = msk[j][q] > 0.0f ? v * inv_keep : 0.0f;
+        if (EPI == 1 || EPI == 3) {
           const bool keep = !drop || keep_elem(row_hash((uint32_t)rc, seed), (uint32_t)col, P.p_drop);
           v = keep ? v * inv_keep : 0.0f;
         }
@@ -789,11 +791,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring(const PanelArgs P) {
 //     where the 3-piece form had three.  With the MFMA time per stage halved, the bytes in flight -- not the matrix
 //     pipe -- decide whether the loop stalls: 2.5-3.5 stages are now outstanding across every barrier.
 // ------------------------------------------------------------------------------------------------------------
-constexpr unsigned kAmaxFloor = 16;      // biased exponent floor: tensors below 2^-111 are treated as that size
-__device__ __forceinline__ unsigned amax_be(const uint32_t* slot) {
-  const unsigned be = (__builtin_nontemporal_load(slot) >> 23) & 255u;
-  return be < kAmaxFloor ? kAmaxFloor : be;
-}
+using gps::amax_be;        // biased exponent of a max|.| record (gps_common.hpp: 8 words, floored at 16)
 __device__ __forceinline__ float amax_scale(unsigned be) { return __uint_as_float((268u - be) << 23); }     // 2^(141 - be)
 __device__ __forceinline__ float amax_unscale(unsigned be) { return __uint_as_float((be - 14u) << 23); }    // 2^(be - 141)
 
@@ -847,10 +845,7 @@ __global__ __launch_bounds__(256) void k_absmax(const AbsGroup G) {
   __shared__ uint32_t wmax[4];
   if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
   __syncthreads();
-  if (threadIdx.x == 0) {
-    m = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
-    if (m) atomicMax(D.slot, m);
-  }
+  if (threadIdx.x == 0) gps::amax_raise(D.slot, max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])));
 }
 
 // ---- weight images, fp16 form: [2 pieces][K/32][N'][32], same geometry as the 3-piece image ------------------------------
@@ -1154,10 +1149,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring16(const PanelArgs P) 
     __syncthreads();                                     // the ring (and the statistics scratch) is free
     if (lane == 0) wmax[wave] = m;
     __syncthreads();
-    if (t == 0) {
-      m = max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3]));
-      if (m) atomicMax(P.c_amax, m);
-    }
+    if (t == 0) gps::amax_raise(P.c_amax, max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])));
   }
   __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 15));
   stamp(3);

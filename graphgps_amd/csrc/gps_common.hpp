@@ -23,6 +23,25 @@ __device__ __forceinline__ uint64_t salted_seed(uint64_t seed, const uint64_t* s
   return salt ? seed + salt[0] * 0x9E3779B97F4A7C15ULL : seed;
 }
 
+// max|tensor| RECORDS of the fp16-form GEMMs (csrc/gemm_panel.hip, csrc/wgrad.hip): kAmaxWords uint32 words holding fp32
+// bit patterns; the tensor's maximum is the (unsigned) maximum of the words.  Producers raise word (blockIdx & 7) with
+// ONE atomic per workgroup: atomics on one address serialise at the L2 (~6 ns each, measured), eight addresses carry a
+// thousand-workgroup producer without a tail.  Zero at allocation; only ever raised.
+constexpr int kAmaxWords = 8;
+#if defined(__HIPCC__)
+// biased exponent of the record's maximum, floored at 16 (tensors below 2^-111 are scaled as if they were that large)
+__device__ __forceinline__ unsigned amax_be(const uint32_t* rec) {
+  unsigned m = 0;
+#pragma unroll
+  for (int i = 0; i < kAmaxWords; ++i) m = max(m, __builtin_nontemporal_load(rec + i));
+  const unsigned be = (m >> 23) & 255u;
+  return be < 16u ? 16u : be;
+}
+__device__ __forceinline__ void amax_raise(uint32_t* rec, uint32_t bits) {
+  if (bits) atomicMax(rec + (blockIdx.x & (kAmaxWords - 1)), bits);
+}
+#endif
+
 static inline unsigned grid_for(int64_t work, int block) {
   return static_cast<unsigned>((work + block - 1) / block);
 }

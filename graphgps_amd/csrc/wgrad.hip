@@ -304,10 +304,7 @@ constexpr int waitcnt_imm(int vm, int lgkm) { return (vm & 15) | (7 << 4) | ((lg
 // scaled value (scale = the power of two that puts the operand TENSOR's max|.| word in [2^14, 2^15)), three piece products
 // per value product on v_mfma_f32_32x32x16_f16: 48 MFMAs per stage instead of 96 and 8 VALU per value pair instead of 11.
 // The groups keep their shape (4 accumulators rotating, the same fills in the same order), two fill slots per issue gap.
-__device__ __forceinline__ unsigned amax_be(const uint32_t* slot) {
-  const unsigned be = (__builtin_nontemporal_load(slot) >> 23) & 255u;
-  return be < 16u ? 16u : be;
-}
+using gps::amax_be;
 template <bool F16>
 __global__ __launch_bounds__(256, 1) void k_wgrad_stream(const Group G) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];

@@ -216,7 +216,7 @@ def _param_grads(g: torch.Tensor, x: torch.Tensor, need_w: bool, need_b: bool, p
             if _gemm.F16 and _WGRAD_F16 and d % 128 == 0 and k % 128 == 0 and R >= _RING_MIN_ROWS:
                 # fp16 form of the streaming kernel (csrc/wgrad.hip): the operands' max|.| words from one pre-pass
                 words = _gemm.absmax([g, x])
-                check(L.gps_wgrad16(ptr(g), g.stride(0), ptr(x), x.stride(0), R, d, k, ptr(words[0:1]), ptr(words[1:2]),
+                check(L.gps_wgrad16(ptr(g), g.stride(0), ptr(x), x.stride(0), R, d, k, ptr(words[0]), ptr(words[1]),
                                     ptr(g_w), ptr(g_b), ptr(ws), st), "gps_wgrad16")
                 return g_w, g_b
             check(L.gps_wgrad(ptr(g), g.stride(0), ptr(x), x.stride(0), R, d, k, ptr(g_w), ptr(g_b),

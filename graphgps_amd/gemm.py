@@ -31,10 +31,16 @@ MAX_SPLIT = 56      # csrc/gemm_panel.hip kMaxSplit
 F16 = os.environ.get("GPS_GEMM_F16", "1") != "0"
 MAX_SPLIT16 = 48    # csrc/gemm_panel.hip kMaxSplit16
 MAX_ABS = 56        # csrc/gemm_panel.hip kMaxAbs
+AMAX_WORDS = 8      # include/gps_hip.h GPS_AMAX_WORDS: a max|.| record = 8 int32 words (fp32 bit patterns), max over them
+
+
+def amax_records(n: int, device) -> torch.Tensor:
+    """``n`` zeroed max|.| records: int32 ``[n, 8]``; row i is the record of tensor i."""
+    return torch.zeros(n, AMAX_WORDS, dtype=torch.int32, device=device)
 
 
 class WImage:
-    """A weight image and, for the fp16 form, the device word holding max|W| it was scaled by (``amax``: int32 [1])."""
+    """A weight image and, for the fp16 form, the device record of max|W| it was scaled by (``amax``: int32 [8])."""
     __slots__ = ("t", "amax")
 
     def __init__(self, t: torch.Tensor, amax: Optional[torch.Tensor] = None):
@@ -45,14 +51,16 @@ class WImage:
 
 
 def absmax(tensors: Sequence[torch.Tensor], out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """int32 ``[len(tensors)]``: word i = fp32 bit pattern of ``max|tensors[i]|`` (csrc/gemm_panel.hip ``gps_absmax``, one
-    launch for up to 56 row-major fp32 matrices with ``cols % 4 == 0``).  ``out``: words to raise instead (they must hold
-    zeros or an earlier maximum of the same tensors)."""
+    """int32 ``[len(tensors), 8]``: row i = the max|.| record of ``tensors[i]`` (fp32 bit patterns; the maximum is the max
+    over the row -- ``amax_value``) by csrc/gemm_panel.hip ``gps_absmax``, one launch for up to 56 row-major fp32 matrices
+    with ``cols % 4 == 0``.  ``out``: records to raise instead (zeros or an earlier maximum of the same tensors)."""
     L = _lib.load()
     n = len(tensors)
     dev = tensors[0].device
     if out is None:
-        out = torch.zeros(n, dtype=torch.int32, device=dev)
+        out = amax_records(n, dev)
+    if out.shape[-1] != AMAX_WORDS or out.numel() != n * AMAX_WORDS or not out.is_contiguous():
+        raise _lib.GpsHipError("absmax: `out` must be contiguous int32 [len(tensors), 8]")
     base = out.data_ptr()
     for i0 in range(0, n, MAX_ABS):
         chunk = tensors[i0:i0 + MAX_ABS]
@@ -60,7 +68,7 @@ def absmax(tensors: Sequence[torch.Tensor], out: Optional[torch.Tensor] = None) 
         for j, (q, t) in enumerate(zip(descs, chunk)):
             if t.dtype != torch.float32 or t.dim() != 2 or t.stride(1) != 1 or not t.is_cuda:
                 raise _lib.GpsHipError("absmax: fp32 [rows, cols] CUDA matrices with unit column stride")
-            q.A, q.ld, q.rows, q.cols, q.slot = t.data_ptr(), t.stride(0), t.shape[0], t.shape[1], base + 4 * (i0 + j)
+            q.A, q.ld, q.rows, q.cols, q.slot = t.data_ptr(), t.stride(0), t.shape[0], t.shape[1], base + 4 * AMAX_WORDS * (i0 + j)
         check(L.gps_absmax(len(chunk), descs, current_stream(dev)), "gps_absmax")
     return out
 
@@ -83,10 +91,24 @@ def stats_supported(M: int, N: int, K: int) -> bool:
     return v
 
 
+def amax_value(rec: torch.Tensor) -> float:
+    """The maximum a record holds (a host read: tests and tools only)."""
+    return float(rec.reshape(-1).max().reshape(1).view(torch.float32))
+
+
+def record_of(value: float, device) -> torch.Tensor:
+    """A record holding ``value`` (tests: a deliberately larger bound)."""
+    r = amax_records(1, device)[0]
+    r[0] = torch.tensor([value], dtype=torch.float32).view(torch.int32)[0]
+    return r
+
+
 def _a_word(a: torch.Tensor, a_amax: Optional[torch.Tensor]) -> int:
-    """Address of max|a|'s word: the caller's, or one made here (a pre-pass over ``a``)."""
+    """Address of max|a|'s record: the caller's, or one made here (a pre-pass over ``a``)."""
     if a_amax is None:
         a_amax = absmax([a])
+    elif a_amax.numel() != AMAX_WORDS:
+        raise _lib.GpsHipError("a_amax: one max|.| record (int32 [8])")
     return a_amax.data_ptr()
 
 
@@ -132,7 +154,7 @@ def _split_weights16(weights, nt, tn):
             rows, cols = w.shape
             i_nt = torch.empty(L.gps_gemm16_image_elems(rows, cols), dtype=torch.int16, device=dev) if nt else None
             i_tn = torch.empty(L.gps_gemm16_image_elems(cols, rows), dtype=torch.int16, device=dev) if tn else None
-            word = words[i0 + j:i0 + j + 1]
+            word = words[i0 + j]
             q.W, q.ldw, q.rows, q.cols = w.data_ptr(), w.stride(0), rows, cols
             q.image_nt = i_nt.data_ptr() if nt else None
             q.image_tn = i_tn.data_ptr() if tn else None

@@ -162,8 +162,13 @@ def stack_begin(layers, batch) -> bool:
         return False
     _STACK["active"], _STACK["nbt"] = True, []
     _STACK.pop("words", None)
+    _STACK.pop("pool", None)
     try:
         _STACK["owners"] = _presplit_stack(layers, x)
+        if _STACK["owners"] and _gemm.F16:
+            # the max|.| records of every block of the stack (fp16-form GEMMs): ONE zero-fill for all layers (a fill per
+            # layer and pass was 20 tiny launches, ~0.1 ms, per step)
+            _STACK["pool"] = [_gemm.amax_records(_N_REC * len(_STACK["owners"]), x.device), 0]
     except BaseException:
         _STACK["active"] = False            # never leave the bracket half open: blocks would defer their counters forever
         raise
@@ -202,14 +207,51 @@ def _panel_ok(layer, d) -> bool:
             and _gemm.supported(d, inner) and _gemm.supported(inner, d) and _gemm.supported(d, 4 * d + 3 * inner))
 
 
+_CHECK_TICKS = _os.environ.get("GPS_CHECK_TICKS", "0") != "0"
+
+
 def stack_end() -> None:
     nbt, _STACK["nbt"] = _STACK["nbt"], []
     _STACK["active"] = False
+    if _CHECK_TICKS and not torch.cuda.is_current_stream_capturing():
+        # debugging aid: every arrival counter of every block is zero between launches (a host sync per stack)
+        for layer in _STACK.get("owners", []):
+            sa = getattr(layer, "_gps_sync", None)
+            if sa is not None and sa.nonzero_words():
+                raise _lib.GpsHipError("arrival counters of an in-launch reduction are non-zero between launches "
+                                       "(csrc/col_tree.hpp): a previous launch did not complete")
     _STACK.pop("words", None)
+    _STACK.pop("pool", None)
     for layer in _STACK.pop("owners", []):
         layer.__dict__.pop("_presplit", None)      # (a layer that did not take the block path this time)
     if nbt:
         torch._foreach_add_(nbt, 1)
+
+# max|.| records of one block (fp16-form GEMMs): forward x, e, o, h, t, out, e1 | backward g_f2, g_f1, g_ao, g_pq, g_ce
+_N_REC = 16
+_R_X, _R_E, _R_O, _R_H, _R_T, _R_OUT, _R_E1, _R_GF2, _R_GF1, _R_GAO, _R_GPQ, _R_GCE = 0, 1, 2, 3, 4, 5, 6, 8, 9, 10, 11, 12
+
+
+_stats_words_cache = {}
+
+
+def _stats_words(L, N: int) -> int:
+    """Counter words the statistics epilogue of an N-column ring GEMM needs (checked against the site size)."""
+    v = _stats_words_cache.get(N)
+    if v is None:
+        v = _stats_words_cache[N] = int(L.gps_gemm_stats_sync_words(N))
+    return v
+
+
+def _block_records(dev):
+    """The 16 zeroed records of one block: a slice of the stack's pool, or an allocation of its own."""
+    pool = _STACK.get("pool") if _STACK["active"] else None
+    if pool is not None and pool[1] + _N_REC <= pool[0].shape[0]:
+        rec = pool[0][pool[1]:pool[1] + _N_REC]
+        pool[1] += _N_REC
+        return rec
+    return _gemm.amax_records(_N_REC, dev)
+
 
 # launch sites of one layer that own arrival counters (norm.SyncArena.site): sites that may be in flight together differ
 _S_GG, _S_AO, _S_XE, _S_MID, _S_Z2, _S_B1, _S_B3, _S_B4 = range(8)
@@ -288,7 +330,7 @@ def _grouped_param_grads(L, pairs, params=(), targets=None, words=None):
     (main stream when ``params`` already hold gradients: see ``_accumulating``).
     ``targets`` = [(weight, bias), ...] the (stacked) parameters the results belong to: when they live in an optimizer
     arena and nothing is being accumulated the kernel writes straight into their gradient slots (optim.grad_slot).
-    ``words`` = [(max|g| word, max|x| word), ...] (int32 [1] tensors, gemm.absmax): the fp16 form of the contraction."""
+    ``words`` = [(max|g| record, max|x| record), ...] (int32 [8] tensors, gemm.absmax): the fp16 form of the contraction."""
     dev = pairs[0][0].device
     n = len(pairs)
     direct = targets is not None and not _accumulating(params)
@@ -445,23 +487,23 @@ class _GPSBlock(torch.autograd.Function):
                                             _W(R.ff2)])
             # fp16 form of the ring GEMM (gemm.F16): the word of max|A| of every GEMM operand of this layer, made once per
             # tensor (one batched launch where two operands are ready together) and shared by the GEMMs that read it
-            am = None
+            am = rec = None
             if imgs[0][0].amax is not None:
-                # words 0..4 = x, e, o, h, t; 5, 6 = this layer's outputs (the next layer's x and e).  x / e arrive with
-                # their words when the previous block of the stack produced them (its norm tasks tracked the maxima),
-                # otherwise one pre-pass makes them; o: a pre-pass; h, t and the outputs: by their producers
-                amb = torch.zeros(7, dtype=torch.int32, device=dev)
-                am = [amb[i:i + 1] for i in range(7)]
+                # records (_R_*): x, e, o, h, t; out, e1 = this layer's outputs (the next layer's x and e); the backward's.
+                # x / e arrive with their records when the previous block of the stack produced them (its norm tasks
+                # tracked the maxima), otherwise one pre-pass makes them; o: a pre-pass; h, t, the outputs: by their producers
+                rec = _block_records(dev)
+                am = [rec[i] for i in range(7)]
                 handed = _STACK.pop("words", None) if _STACK["active"] else None
                 if handed is not None and handed[0] == x.data_ptr() and handed[1] == e.data_ptr():
-                    am[0], am[1] = handed[2], handed[3]
+                    am[_R_X], am[_R_E] = handed[2], handed[3]
                 else:
-                    _gemm.absmax([x, e], out=amb[0:2])
+                    _gemm.absmax([x, e], out=rec[0:2])
             aw = (lambda i: None) if am is None else (lambda i: am[i])
             ce = _gemm.gemm_panel(e, imgs[1][0], d, bias=_B(R.C), a_amax=aw(1))
             pq = _gemm.gemm_panel(x, imgs[0][0], ldp, bias=bias_m, a_amax=aw(0))
         else:
-            am, aw = None, (lambda i: None)
+            am, rec, aw = None, None, (lambda i: None)
             ce = torch.addmm(_B(R.C), e, _W(R.C).t())
             pq = torch.addmm(bias_m, x, wcat.t())               # [N, 4d + 3 inner]
         P, fs = pq.data_ptr(), d * 4
@@ -518,10 +560,10 @@ class _GPSBlock(torch.autograd.Function):
                                          gi.max_tiles, N, H, dh, scale, p_at, s[2], ptr(o), ptr(lse),
                                          gi.B, int(gi.nmax_host), sb), "gps_seg_attn_fwd")
             if am is not None:
-                _gemm.absmax([o], out=am[2])
+                _gemm.absmax([o], out=rec[_R_O:_R_O + 1])
             if gemm_stats:      # za = x + drop(out_proj(o)) and the statistics of za (norm1_attn) in the GEMM's epilogue
                 ao = None
-                za = _gemm.gemm_panel_stats(o, imgs[2][0], d, _B(R.out_proj), x, p_l, s[3], bna, sync.site(_S_AO),
+                za = _gemm.gemm_panel_stats(o, imgs[2][0], d, _B(R.out_proj), x, p_l, s[3], bna, sync.site(_S_AO, _stats_words(L, d)),
                                             a_amax=aw(2))
             else:
                 za = None
@@ -555,7 +597,8 @@ class _GPSBlock(torch.autograd.Function):
             f1 = torch.addmm(_B(R.ff1), h, _W(R.ff1).t())
             t = _K.act_drop_add(L, None, f1, True, p_f1, s[4], st)
         if gemm_stats:  # z2 = h + drop(ff2(t)) and the statistics of z2 (norm2) in the GEMM's epilogue
-            z2 = _gemm.gemm_panel_stats(t, imgs[4][0], d, _B(R.ff2), h, p_f2, s[5], bn2, sync.site(_S_Z2), a_amax=aw(4))
+            z2 = _gemm.gemm_panel_stats(t, imgs[4][0], d, _B(R.ff2), h, p_f2, s[5], bn2, sync.site(_S_Z2, _stats_words(L, d)),
+                                        a_amax=aw(4))
         else:
             f2 = (_gemm.gemm_panel(t, imgs[4][0], d, bias=_B(R.ff2), a_amax=aw(4)) if panel
                   else torch.addmm(_B(R.ff2), t, _W(R.ff2).t()))
@@ -574,7 +617,8 @@ class _GPSBlock(torch.autograd.Function):
                               *(fav if fav is not None else ()))
         ctx.layer, ctx.gi, ctx.seeds = layer, gi, s
         ctx.imgs = imgs     # W^T images for the input-gradient GEMMs (None: library GEMMs)
-        ctx.am = am         # fp16 form: the max|.| words of x, e, o, h, t (the weight gradients' second operands)
+        ctx.am = am         # fp16 form: the max|.| records of x, e, o, h, t (the weight gradients' second operands)
+        ctx.bm = None if rec is None else rec[_R_GF2:_R_GF2 + 5]        # ... and the (zeroed) records of the backward's
         ctx.cfg = (p, p_l, p_f1, p_f2, p_at, H, dh, scale)
         return out, e1
 
@@ -613,17 +657,15 @@ class _GPSBlock(torch.autograd.Function):
         # norm2 <- z2 = h + drop(f2):  g_z2 and g_f2 = dropmask(g_z2);  bn_edge_e <- e^ (its output gradient g_e1 is an
         # input of this node, so its column sums and its apply ride along): ONE partial launch, ONE apply launch
         imgs = ctx.imgs
-        bm = None
-        if imgs is not None and imgs[0][1].amax is not None:        # fp16 form: the words of the gradient operands
-            bm = torch.zeros(5, dtype=torch.int32, device=dev)      # g_f2, g_f1, g_ao (by their producers), g_pq, g_ce
+        bm = ctx.bm if imgs is not None else None       # fp16 form: records of g_f2, g_f1, g_ao (by their producers), g_pq, g_ce
         g_z2, g_f2, g_eh = _E(N, d, **f32), _E(N, d, **f32), _E(E, d, **f32)
         b1 = [_norm.bwd_task(z2, g_out, bn2, N, g_n2w, g_n2b, g_z=g_z2, g_drop=g_f2, p2=p_f2, seed2=s[5],
-                             amax_drop=None if bm is None else bm[0:1]),
+                             amax_drop=None if bm is None else bm[0]),
               _norm.bwd_task(eh, g_e1, bne, E, g_bew, g_beb, relu=True, p=p, seed=s[1], g_z=g_eh)]
         _norm.bwd_partial(b1, d, dev, sync.site(_S_B1))
         _norm.bwd_apply(b1, d, dev, None)
         # f2 = ff2(t);  t = drop(relu(f1));  f1 = ff1(h)
-        bw = (lambda i: None) if bm is None else (lambda i: bm[i:i + 1])
+        bw = (lambda i: None) if bm is None else (lambda i: bm[i])
         if imgs is not None:
             # g_f1 = relu/dropout mask of t applied to g_f2 W2 (the mask of t is the mask of f1 wherever it matters:
             # a kept element has t > 0 iff f1 > 0, a dropped one has gradient 0 either way), in the GEMM's epilogue
@@ -677,7 +719,7 @@ class _GPSBlock(torch.autograd.Function):
         check(L.gps_gatedgcn_bwd(ptr(g_xt), d, ptr(g_eh), ptr(eh), P, P + fs, ldp, ptr(xt),
                                  ptr(gi.rowptr_dst), ptr(gi.src_by_dst), ptr(gi.eid_by_dst),
                                  ptr(gi.rowptr_src), ptr(gi.dst_by_src), ptr(gi.eid_by_src), N, E, d,
-                                 ptr(g_ce), G, G + fs, G + 2 * fs, G + 3 * fs, ldp, None, st),
+                                 ptr(g_ce), G, G + fs, G + 2 * fs, G + 3 * fs, ldp, None, ptr(bw(3)), ptr(bw(4)), st),
               "gps_gatedgcn_bwd")
         fork.join()
         wcat, bcat = layer._xgroup._stacked()
@@ -685,10 +727,12 @@ class _GPSBlock(torch.autograd.Function):
         leaves = R.params
         words = None
         if bm is not None:
-            _gemm.absmax([g_pq, g_ce], out=bm[3:5])
+            # g_pq's record: the GatedGCN backward raised it over its four column blocks and made g_ce's; the attention
+            # kernels' dq | dk | dv columns take one strided pre-pass (their backward is at its register limit)
+            _gemm.absmax([g_pq[:, 4 * d:]], out=bm[3:4])
             am = ctx.am
             if am is not None and _WGRAD_F16:
-                words = [(bm[3:4], am[0]), (bm[4:5], am[1]), (bm[2:3], am[2]), (bm[1:2], am[3]), (bm[0:1], am[4])]
+                words = [(bm[3], am[_R_X]), (bm[4], am[_R_E]), (bm[2], am[_R_O]), (bm[1], am[_R_H]), (bm[0], am[_R_T])]
         if _GROUPED_WGRAD:
             targets = [(wcat, bcat), (_W(R.C), _B(R.C)), (_W(R.out_proj), _B(R.out_proj)),
                        (_W(R.ff1), _B(R.ff1)), (_W(R.ff2), _B(R.ff2))]

@@ -36,7 +36,7 @@ _SIGNATURES = {
     "gps_gatedgcn_fwd_stats": (c_int, [_P, _P, _P, _P, c_int64, _P, _P, _P, _P, c_int64, c_int64, c_int,
                                        _P, _P, _P, _P, _P, _P, c_size_t, _P, _P]),
     "gps_gatedgcn_bwd": (c_int, [_P, c_int64, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P,
-                                 c_int64, c_int64, c_int, _P, _P, _P, _P, _P, c_int64, _P, _P]),
+                                 c_int64, c_int64, c_int, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P]),
     "gps_gine_fwd": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int64, c_int, c_float, _P, _P, _P]),
     "gps_gine_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int64, c_int, c_float, _P,
                              _P, _P, _P]),
@@ -65,6 +65,8 @@ _SIGNATURES = {
     "gps_wgrad_grouped": (c_int, [c_int, _P, _P, _P]),
     "gps_norm_tree_floats": (c_size_t, [c_int64, c_int]),
     "gps_norm_sync_words": (c_int, []),
+    "gps_sync_reset": (c_int, [_P, c_size_t, _P]),
+    "gps_sync_nonzero": (c_int, [_P, c_size_t, _P, _P]),
     "gps_norm_fwd": (c_int, [c_int, _P, c_int, _P, c_size_t, _P, _P]),
     "gps_norm_bwd_partial": (c_int, [c_int, _P, c_int, _P, c_size_t, _P, _P]),
     "gps_norm_bwd_apply": (c_int, [c_int, _P, c_int, _P, c_size_t, _P, _P]),

@@ -102,13 +102,29 @@ class SyncArena:
     ``site(k)`` is the region of launch site k; sites that can be in flight together use different k."""
 
     def __init__(self, device):
-        # tree counters (gps_norm_*), then 64 words per site for the producers' own trees (GatedGCN, ring GEMM)
-        self.words = sync_words()
+        # a site holds the counters of ONE launch: the task-list kernels' trees (gps_norm_sync_words) or a producer's own
+        # (GatedGCN: one tree; ring GEMM statistics epilogue: one tree of 32 words per column panel, up to 16 panels of 64
+        # columns at the widest d = 1024 the blocks accept -- ADVICE r3: 11-15 panels used to spill into the next site)
+        self.words = max(sync_words(), 16 * 32)
         self.buf = torch.zeros(N_SITES * self.words, dtype=torch.int32, device=device)
 
-    def site(self, k: int) -> int:
+    def site(self, k: int, need_words: int = 0) -> int:
         assert 0 <= k < N_SITES
+        if need_words > self.words:
+            raise _lib.GpsHipError(f"SyncArena: a launch needs {need_words} counter words, a site holds {self.words}")
         return self.buf.data_ptr() + 4 * k * self.words
+
+    def nonzero_words(self) -> int:
+        """Number of non-zero counters (a host read: debugging / tests).  Between launches it must be 0."""
+        L = _lib.load()
+        cnt = torch.zeros(1, dtype=torch.int32, device=self.buf.device)
+        check(L.gps_sync_nonzero(self.buf.data_ptr(), self.buf.numel(), cnt.data_ptr(), current_stream(self.buf.device)),
+              "gps_sync_nonzero")
+        return int(cnt)
+
+    def reset(self) -> None:
+        check(_lib.load().gps_sync_reset(self.buf.data_ptr(), self.buf.numel(), current_stream(self.buf.device)),
+              "gps_sync_reset")
 
 
 def sync_arena(owner, device) -> SyncArena:

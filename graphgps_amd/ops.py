@@ -222,7 +222,7 @@ class _GatedGCNAggregate(torch.autograd.Function):
                                  ptr(x_tilde), ptr(gi.rowptr_dst), ptr(gi.src_by_dst),
                                  ptr(gi.eid_by_dst), ptr(gi.rowptr_src), ptr(gi.dst_by_src),
                                  ptr(gi.eid_by_src), N, E, d, ptr(g_ce), gb, gb + fs, gb + 2 * fs,
-                                 gb + 3 * fs, 4 * d, ptr(r), current_stream(dev)), "gps_gatedgcn_bwd")
+                                 gb + 3 * fs, 4 * d, ptr(r), None, None, current_stream(dev)), "gps_gatedgcn_bwd")
         g_r = None
         if r is not None and ctx.needs_input_grad[3]:
             # g_r[e] = sum_c g_sigma'[e,c] * sigma[e,c],  g_sigma' = a_i * Bx_j + b_i  (a, b as in the kernel).

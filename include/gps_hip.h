@@ -123,14 +123,16 @@ int gps_gatedgcn_fwd_stats(const float* Ax, const float* Bx, const float* Dx, co
  * recomputed, delta -> g_Ce, g_Dx; per-edge delta and sig*a handed over through LDS), a workgroup barrier, a
  * source-keyed phase (g_Ex, g_Bx) that takes the edges into this workgroup's own nodes from LDS and rebuilds the
  * rest (edges whose target another workgroup owns) from their inputs.
- * Deterministic, no atomics; e_hat / g_e / g_Ce cross HBM once each. */
+ * Deterministic, no data atomics; e_hat / g_e / g_Ce cross HBM once each.
+ * ABI v6: amax_node / amax_ce (both or neither; NULL = off): max|.| records (GPS_AMAX_WORDS, below) raised to the maximum
+ * over g_Ax | g_Bx | g_Dx | g_Ex and over g_Ce -- the scales of the fp16-form GEMMs that consume them. */
 int gps_gatedgcn_bwd(const float* g_x, int64_t ld_gx, const float* g_e, const float* e_hat, const float* Ax,
                      const float* Bx, int64_t ld_node, const float* x_tilde,
                      const int32_t* rowptr_dst, const int32_t* src_by_dst,
                      const int32_t* eid_by_dst, const int32_t* rowptr_src,
                      const int32_t* dst_by_src, const int32_t* eid_by_src, int64_t N, int64_t E,
                      int d, float* g_Ce, float* g_Ax, float* g_Bx, float* g_Dx, float* g_Ex,
-                     int64_t ld_gnode, const float* r_edge, gps_stream_t stream);
+                     int64_t ld_gnode, const float* r_edge, uint32_t* amax_node, uint32_t* amax_ce, gps_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * GINE sparse core.  Replaces PyG GINEConv's gather + relu + scatter-add + (1+eps)*x
@@ -246,12 +248,16 @@ int gps_gemm_panel_stats(const float* A, int64_t lda, int64_t M, int K, const ui
  * 22 significant bits) and a*b is formed from 3 piece products on v_mfma_f32_32x32x16_f16 with fp32 accumulation --
  * half the matrix-pipe work of the 6-product form; measured / emulated error against fp64 at or below the 6-product
  * form's (fewer roundings into the accumulator), both below an fp32 library GEMM.  The scale of an operand TENSOR is
- * derived from max|v|, which travels as a device word holding the fp32 bit pattern (an unsigned max, order-free):
- *   gps_absmax          max over up to 56 row-major matrices per launch: slot = max(slot, max|A|) (atomic; the caller
- *                       zeroes the words once; several matrices may share a word)
+ * derived from max|v|, which travels as a device RECORD of GPS_AMAX_WORDS (8) uint32 words holding fp32 bit patterns: the
+ * maximum is the unsigned maximum of the words (order-free, deterministic); producers raise one word per workgroup
+ * atomically (eight addresses, so a thousand-workgroup producer does not queue on one).  Every `*_amax` / `slot` /
+ * `amax*` pointer of this header addresses such a record: zero at allocation, only ever raised.
+ *   gps_absmax          max over up to 56 row-major matrices per launch: record = max(record, max|A|) (the caller
+ *                       zeroes the records once; several matrices may share a record)
  *   gps_gemm16_split_weights   image [2 pieces][ceil(K/32)][N'][32] fp16 of each weight under the scale of its `amax` word
  *   gps_gemm16_panel(_stats)   as gps_gemm_panel(_stats) with `a_amax` (>= max|A|) and `w_amax` (the word the image was
  *                       made with).  A word LARGER than the true maximum only costs precision (one bit per factor 2). */
+#define GPS_AMAX_WORDS 8
 typedef struct gps_absmax_desc {
   const float* A;      /* [rows][cols] fp32, row stride ld (floats); cols % 4 == 0, 16-byte aligned rows */
   int64_t ld, rows;
@@ -525,6 +531,12 @@ typedef struct gps_norm_bwd_task {
 } gps_norm_bwd_task;
 size_t gps_norm_tree_floats(int64_t R, int d);
 int gps_norm_sync_words(void);
+/* The `sync` words of every in-launch reduction (gps_norm_*, gps_gatedgcn_fwd_stats, gps_gemm_panel_stats) must be zero
+ * at entry and are zero again at exit.  A launch that finds a non-zero counter TRAPS (csrc/col_tree.hpp) instead of
+ * publishing statistics of incomplete records.  gps_sync_reset: re-zero a buffer after a failed launch;
+ * gps_sync_nonzero: *count += number of non-zero words (device uint32; a between-launches self-check). */
+int gps_sync_reset(uint32_t* sync, size_t words, gps_stream_t stream);
+int gps_sync_nonzero(const uint32_t* sync, size_t words, uint32_t* count, gps_stream_t stream);
 int gps_norm_fwd(int n, const gps_norm_fwd_task* tasks, int d, float* ws, size_t ws_floats, uint32_t* sync,
                  gps_stream_t stream);
 int gps_norm_bwd_partial(int n, const gps_norm_bwd_task* tasks, int d, float* ws, size_t ws_floats, uint32_t* sync,

@@ -118,7 +118,9 @@ def test_gpslayer_vs_oracle_baseline_sizes(local, glob, d, H, profile, nb):
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     layer = GPSLayer(d, local, glob, H, dropout=0.0, attn_dropout=0.0)
+    import copy
     oracle = _oracle_layer_like(layer).train()
+    o64 = copy.deepcopy(oracle).double().train()          # the same oracle in fp64: the yardstick of the gradient bars
     layer.to(dev).train()
     state0 = {k: v.clone() for k, v in layer.state_dict().items()}          # (BN running statistics move per forward)
     b = layer_batch(profile, nb, d, seed=77)
@@ -127,11 +129,16 @@ def test_gpslayer_vs_oracle_baseline_sizes(local, glob, d, H, profile, nb):
     we = torch.randn(b.edge_attr.shape, generator=gen)
 
     def run(wx, we):
-        """One forward + backward of the loss sum(wx * x') + sum(we * e') on both sides."""
-        for m in (oracle, layer):
+        """One forward + backward of the loss sum(wx * x') + sum(we * e') on all three sides."""
+        for m in (oracle, o64, layer):
             m.zero_grad(set_to_none=True)
         layer.load_state_dict(state0)
         oracle.load_state_dict({k: v.cpu() for k, v in state0.items()})
+        o64.load_state_dict({k: (v.cpu().double() if v.is_floating_point() else v.cpu()) for k, v in state0.items()})
+        b6 = _double_batch(b)
+        b6.x.requires_grad_(True); b6.edge_attr.requires_grad_(True)
+        o6 = o64(b6)
+        ((o6.x * wx.double()).sum() + (o6.edge_attr * we.double()).sum()).backward()
         bc = b.clone()
         bc.x.requires_grad_(True); bc.edge_attr.requires_grad_(True)
         xo, eo = bc.x, bc.edge_attr             # (the layer re-binds batch.x / batch.edge_attr to its outputs)
@@ -151,14 +158,19 @@ def test_gpslayer_vs_oracle_baseline_sizes(local, glob, d, H, profile, nb):
         (assert_close_kink_tolerant).  Biases that feed a BatchNorm have a mathematically zero gradient: what both
         sides hold is the rounding residue of a 7.5k-term cancelling sum, so the scale floor is 1 % of the layer's
         largest parameter gradient rather than the parameter's own (noise) magnitude.  Returns the failures."""
-        op = dict(oracle.named_parameters())
-        gscale = max(float(q.grad.abs().max()) for q in op.values() if q.grad is not None)
+        op, o6p = dict(oracle.named_parameters()), dict(o64.named_parameters())
+        gscale = max(float(q.grad.abs().max()) for q in o6p.values() if q.grad is not None)
         bad = []
         for k, p in layer.named_parameters():
             if op[k].grad is None:
                 continue
             try:
-                r = assert_close_kink_tolerant(p.grad, op[k].grad, 1e-4, f"grad {k}", min_scale=max(1.0, 0.01 * gscale))
+                # the bar is what the reference's own fp32 arithmetic achieves against fp64 on this parameter (x 3,
+                # floor 1e-5 = north_star), not a constant: VERDICT r3 -- a fixed 1e-4 would pass a 3x regression
+                ms = max(1.0, 0.01 * gscale)
+                c32 = _kink_free_err(op[k].grad, o6p[k].grad, ms)
+                r = assert_close_kink_tolerant(p.grad, o6p[k].grad, max(1e-5, 3.0 * c32), f"grad {k} (cpu fp32 {c32:.1e})",
+                                               min_scale=ms)
                 if r[2]:
                     print(f"grad {k}: {r[2]} kink rows, max rel {r[0]:.2e} outside them")
             except AssertionError as exc:
@@ -200,6 +212,18 @@ def test_gpslayer_vs_oracle_baseline_sizes(local, glob, d, H, profile, nb):
     check_params(strict=True)
 
 
+def _kink_free_err(a32, ref64, min_scale, frac=1e-3):
+    """max|a32 - ref64| / max(max|ref64|, min_scale) over all rows but the worst ``frac`` of them (the rows a ReLU-kink flip
+    of the CPU fp32 evaluation lands in: the same allowance ``assert_close_kink_tolerant`` gives the HIP side)."""
+    e = (a32.detach().double().cpu() - ref64.detach().double().cpu()).abs()
+    scale = max(float(ref64.abs().max()), min_scale)
+    rows = e.reshape(e.shape[0], -1).amax(dim=1) if e.dim() > 1 else e
+    k = max(int(rows.numel() * frac), 2 if rows.numel() > 8 else 0)
+    if k and rows.numel() > k:
+        rows = rows.sort().values[:rows.numel() - k]
+    return float(rows.max()) / scale if rows.numel() else 0.0
+
+
 def _masked_oracle_run(oracle, b, seeds_per_layer, H, p, p_attn, wx, we, dtype, local, glob="Transformer"):
     """Forward + backward of a stack of oracle layers with every dropout replaced by the mask the fused block draws
     from its seed (tests/helpers.py): returns (x_out, e_out, grad x, grad e, {param: grad} per layer)."""
@@ -213,6 +237,23 @@ def _masked_oracle_run(oracle, b, seeds_per_layer, H, p, p_attn, wx, we, dtype, 
     x0, e0 = bc.x, bc.edge_attr
     N, d = bc.x.shape
     E = bc.edge_attr.shape[0]
+    masks = _block_masks(layers, b, seeds_per_layer, N, E, d, H, p, p_attn, local, glob)
+    with inject_dropout_masks(masks):
+        for lay in layers:
+            bc = lay(bc)
+    loss = (bc.x * wx.to(dtype)).sum()
+    if local == "CustomGatedGCN":
+        loss = loss + (bc.edge_attr * we.to(dtype)).sum()
+    loss.backward()
+    grads = [{k: q.grad for k, q in lay.named_parameters() if q.grad is not None} for lay in layers]
+    return bc.x, bc.edge_attr, x0.grad, e0.grad, grads
+
+
+def _block_masks(layers, b, seeds_per_layer, N, E, d, H, p, p_attn, local, glob="Transformer"):
+    """The dropout masks a stack of fused blocks draws from its per-layer seeds, in the order the oracle layers call
+    ``F.dropout``; swaps each oracle layer's attention module for the masked one (Transformer)."""
+    from graphgps_amd.ops import attn_dropout_effective_p
+    from helpers import MaskedSegmentMHA, attention_keep, block_seeds, row_mask
     masks = []
     for lay, seed in zip(layers, seeds_per_layer):
         s = block_seeds(seed)
@@ -238,15 +279,7 @@ def _masked_oracle_run(oracle, b, seeds_per_layer, H, p, p_attn, wx, we, dtype, 
         else:
             masks += [row_mask(s[3], N, d, p)]
         masks += [row_mask(s[4], N, 2 * d, p), row_mask(s[5], N, d, p)]
-    with inject_dropout_masks(masks):
-        for lay in layers:
-            bc = lay(bc)
-    loss = (bc.x * wx.to(dtype)).sum()
-    if local == "CustomGatedGCN":
-        loss = loss + (bc.edge_attr * we.to(dtype)).sum()
-    loss.backward()
-    grads = [{k: q.grad for k, q in lay.named_parameters() if q.grad is not None} for lay in layers]
-    return bc.x, bc.edge_attr, x0.grad, e0.grad, grads
+    return masks
 
 
 @pytest.mark.parametrize("local,d,H,profile,nb,p,p_attn,n_layers", [
@@ -310,10 +343,15 @@ def test_fused_block_with_dropout_on_vs_masked_oracle(local, d, H, profile, nb, 
         for k, q in l.named_parameters():
             if k not in r64[4][li]:
                 continue
-            rr = assert_close_kink_tolerant(q.grad, r64[4][li][k], 1e-4, f"layer {li} grad {k} (dropout on)",
-                                            min_scale=max(1.0, 0.01 * gscale))
+            # the bar is the reference's own fp32 arithmetic, not a constant: outside the kink rows the HIP
+            # gradient may be no further from fp64 than 3 x what the CPU fp32 evaluation of the same masked function is
+            # (floor: north_star's 1e-5).  A fixed 1e-4 would also have passed a 3x regression.
+            ms = max(1.0, 0.01 * gscale)
+            c32 = _kink_free_err(r32[4][li][k], r64[4][li][k], ms)
+            rr = assert_close_kink_tolerant(q.grad, r64[4][li][k], max(1e-5, 3.0 * c32),
+                                            f"layer {li} grad {k} (dropout on; cpu fp32 {c32:.1e})", min_scale=ms)
             worst, flips = max(worst, rr[0]), flips + rr[2]
-    c_err = max(fp32_grade(r32[4][li][k], r32[4][li][k], r64[4][li][k], max(1.0, 0.01 * gscale))[3]
+    c_err = max(_kink_free_err(r32[4][li][k], r64[4][li][k], max(1.0, 0.01 * gscale))
                 for li in range(n_layers) for k in r64[4][li])
     print(f"   parameter gradients: max rel error vs fp64 {worst:.2e} outside {flips} kink rows "
           f"(cpu-fp32 masked oracle: max {c_err:.2e})")
@@ -582,6 +620,65 @@ def test_full_model_vs_oracle(cfg_name, kind, dim_in, nb):
     print(f"parameter gradients vs fp64 (max over parameters of max|err|/max|g|): hip {worst_hip:.2e}, "
           f"cpu-fp32 oracle {worst_cpu:.2e}; worst hip/cpu rms ratio {worst_ratio[0]:.2f} ({worst_ratio[1]}); "
           f"hip vs cpu oracle directly {worst_direct:.2e}")
+
+
+def test_full_model_with_dropout_on_vs_masked_oracle(monkeypatch):
+    """The MEASURED configuration at model depth: the 10-layer pcqm4m-GPSmedium+RWSE ``GPSModel``
+    -- encoders, 10 fused blocks with dropout 0.1 / attention dropout 0.1, ``san_graph`` head, L1 -- on 256 P30 graphs
+    against the oracle model with every block's seven masks injected (per-layer seeds; graphgps/layer/gps_layer.py:139-140,
+    152-153, network/gps_model.py:12-51), evaluated in fp32 and in fp64.  Prediction, loss and every parameter gradient
+    three-way: the HIP error against fp64 may not exceed 3 x the CPU fp32 oracle's own (rms; floor 1e-6)."""
+    import copy
+    from graphgps_amd.layer import gps_block
+    from graphgps_amd.loss.losses import compute_loss
+    from graphgps_amd.synthetic import model_batch
+    from helpers import inject_dropout_masks
+    from oracle.gps_oracle import to_oracle_model
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = _build_model("pcqm4m_gpsmedium_rwse.yaml", 9, 1)          # the config's own dropout: 0.1 / 0.1
+    model.train()
+    n_layers = len(model.layers)
+    H, d = model.layers[0].num_heads, model.layers[0].dim_h
+    p, p_attn = float(model.layers[0].dropout_attn.p), float(model.layers[0].attn_dropout)
+    assert n_layers == 10 and p == 0.1 and p_attn == 0.1
+    b = model_batch("pcqm4m", 256, seed=1234)
+    N, E = b.x.shape[0], b.edge_index.shape[1]
+    seeds = [0x1BADB002 + 7919 * i for i in range(n_layers)]
+    it = iter(seeds)
+    monkeypatch.setattr(gps_block, "draw_dropout_seed", lambda: next(it))
+
+    def oracle_run(dtype):
+        o = to_oracle_model(model)
+        if dtype == torch.float64:
+            o = o.double()
+        o.train()
+        masks = _block_masks(list(o.layers), b, seeds, N, E, d, H, p, p_attn, "CustomGatedGCN")
+        with inject_dropout_masks(masks):
+            pred, true = o(_double_batch(b) if dtype == torch.float64 else b.clone())
+        loss, _ = compute_loss(pred, true)
+        loss.backward()
+        return pred, loss, {k: q.grad for k, q in o.named_parameters() if q.grad is not None}
+    p32, l32, g32 = oracle_run(torch.float32)
+    p64, l64, g64 = oracle_run(torch.float64)
+    model.to(dev)
+    pg, tg = model(b.clone().to(dev))
+    lg, _ = compute_loss(pg, tg)
+    lg.backward()
+    rg, rc, mg, mc = assert_fp32_grade(pg, p32, p64, "pred (10 layers, dropout on)")
+    print(f"pred vs fp64: hip rms {rg:.2e} max {mg:.2e} | cpu-fp32 masked oracle rms {rc:.2e} max {mc:.2e}")
+    assert abs(float(lg) - float(l64)) <= max(1e-5, 3 * abs(float(l32) - float(l64))) * max(1.0, abs(float(l64)))
+    gscale = max(float(g.abs().max()) for g in g64.values())
+    worst = (0.0, "")
+    n = 0
+    for k, q in model.named_parameters():
+        if k not in g64 or q.grad is None:
+            continue
+        rg, rc, mg, mc = assert_fp32_grade(q.grad, g32[k], g64[k], f"grad {k}", min_scale=max(1.0, 0.01 * gscale))
+        worst = max(worst, (rg / max(rc, 1e-9), k))
+        n += 1
+    assert n > 250
+    print(f"{n} parameter gradients three-way; worst hip/cpu rms ratio {worst[0]:.2f} ({worst[1]})")
 
 
 def test_full_model_train_step_with_dropout_runs():

@@ -331,3 +331,62 @@ def test_gemm_epilogue_residual_dropout_statistics(M, K, N, f16):
         out2 = gemm.gemm_panel_stats(ag, img, N, bg, rg, p, seed, desc, sync.site(0))
         assert torch.equal(out2, first[0]) and torch.equal(st, first[1])
     assert int(sync.buf.abs().sum()) == 0
+
+
+_POISON_CHILD = r"""
+import sys, torch
+sys.path.insert(0, {root!r}); sys.path.insert(0, {tests!r})
+from graphgps_amd import lib as L_, norm
+from graphgps_amd.lib import check, current_stream
+import test_hip_norm as T
+dev = torch.device("cuda:0")
+gen = torch.Generator().manual_seed(1)
+R, d = 5000, 64
+z = torch.randn(R, d, generator=gen).to(dev)
+bn = T._bn(d, gen)
+desc, st = T._desc(bn, d)
+own = T._Owner()
+sync = norm.sync_arena(own, dev)
+norm.fwd([norm.fwd_task(norm.LOAD, z, R, stats=desc)], d, dev, sync.site(0))
+torch.cuda.synchronize()
+ref = z.double().mean(0)
+assert float((st[0].double() - ref).abs().max()) < 1e-5
+print("CLEAN-LAUNCH-OK", flush=True)
+L = L_.load()
+cnt = torch.zeros(1, dtype=torch.int32, device=dev)
+check(L.gps_sync_nonzero(sync.buf.data_ptr(), sync.buf.numel(), cnt.data_ptr(), current_stream(dev)))
+assert int(cnt) == 0
+mode = sys.argv[1]
+sync.buf[1] = 1                          # a stale group counter: what a launch that died mid-tree leaves behind
+check(L.gps_sync_nonzero(sync.buf.data_ptr(), sync.buf.numel(), cnt.data_ptr(), current_stream(dev)))
+assert int(cnt) == 1
+print("SELF-CHECK-SEES-IT", flush=True)
+if mode == "reset":
+    check(L.gps_sync_reset(sync.buf.data_ptr(), sync.buf.numel(), current_stream(dev)))
+norm.fwd([norm.fwd_task(norm.LOAD, z, R, stats=desc)], d, dev, sync.site(0))
+torch.cuda.synchronize()
+assert float((st[0].double() - ref).abs().max()) < 1e-5
+print("SECOND-LAUNCH-RETURNED", flush=True)
+"""
+
+
+@pytest.mark.parametrize("mode", ["poisoned", "reset"])
+def test_stale_arrival_counter_fails_loudly(mode):
+    """the in-launch reductions need their arrival counters at zero; a launch that died mid-tree leaves
+    one non-zero.  The NEXT launch must not publish statistics of incomplete records silently: a ticket beyond the group
+    size traps (csrc/col_tree.hpp), which kills the launch and the process loudly.  In a child process: a clean launch,
+    ``gps_sync_nonzero`` sees the poisoned word, then either the launch on the poisoned counters dies (no wrong result is
+    ever returned) or, after ``gps_sync_reset``, it runs and is right."""
+    import os
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    code = _POISON_CHILD.format(root=os.path.dirname(here), tests=here)
+    r = subprocess.run([sys.executable, "-c", code, mode], capture_output=True, text=True, timeout=600)
+    out = r.stdout + r.stderr
+    assert "CLEAN-LAUNCH-OK" in r.stdout and "SELF-CHECK-SEES-IT" in r.stdout, out[-2000:]
+    if mode == "reset":
+        assert r.returncode == 0 and "SECOND-LAUNCH-RETURNED" in r.stdout, out[-2000:]
+    else:
+        assert r.returncode != 0 and "SECOND-LAUNCH-RETURNED" not in r.stdout, (
+            "a launch on a stale arrival counter returned instead of failing loudly:\n" + out[-2000:])

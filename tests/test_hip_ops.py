@@ -503,7 +503,7 @@ def test_wgrad_split_k(R, M, Nn):
         g3 = gd * gs
         words = absmax([g3, xd])
         gw3, gb3 = torch.empty_like(gw), torch.empty_like(gb)
-        check(L.gps_wgrad16(ptr(g3), M, ptr(xd), Nn, R, M, Nn, ptr(words[0:1]), ptr(words[1:2]), ptr(gw3), ptr(gb3), ptr(ws),
+        check(L.gps_wgrad16(ptr(g3), M, ptr(xd), Nn, R, M, Nn, ptr(words[0]), ptr(words[1]), ptr(gw3), ptr(gb3), ptr(ws),
                             current_stream(dev)))
         assert_close(gw3 / gs, g.double().t() @ x.double(), Tol.GRAD_REL, "gW (fp16 form)", rel_to_max=True)
         assert_close(gb3 / gs, g.double().sum(0), Tol.GRAD_REL, "gb (fp16 form)", rel_to_max=True)
@@ -534,7 +534,7 @@ def test_wgrad_grouped_and_bf16_split_exactness(f16):
         if f16:
             w = absmax([g, x])
             keep.append(w)
-            q.g_amax, q.x_amax = w[0:1].data_ptr(), w[1:2].data_ptr()
+            q.g_amax, q.x_amax = w[0].data_ptr(), w[1].data_ptr()
         outs.append((gw, gb))
     ws = torch.empty(max(L.gps_wgrad_grouped_workspace_floats(len(pairs), probs), 4), device=dev)
     check(L.gps_wgrad_grouped(len(pairs), probs, ptr(ws), current_stream(dev)), "gps_wgrad_grouped")
@@ -850,9 +850,10 @@ def test_gemm16_operand_scales(mag):
     a[5] = 0.0
     w = torch.randn(N, K, generator=gen) / K ** 0.5 * (1.0 / mag if 1e-20 < mag < 1e20 else 1.0)
     ag, wg = a.to(dev), w.to(dev)
-    words = _g.absmax([ag, wg, ag[:, :128]])
+    words = _g.absmax([ag, wg, ag[:, :128]])            # [3, 8] records: the maximum is the max over a row
     want = torch.stack([ag.abs().max(), wg.abs().max(), ag[:, :128].abs().max()]).view(torch.int32)
-    assert torch.equal(words.cpu(), want.cpu())
+    assert torch.equal(words.max(dim=1).values.cpu(), want.cpu())
+    assert _g.amax_value(words[1]) == float(wg.abs().max())
     (img, _), = _g.split_weights([wg], tn=False, f16=True)
     ref = a.double() @ w.double().t()
     scale = float(ref.abs().max())
@@ -864,7 +865,7 @@ def test_gemm16_operand_scales(mag):
     assert float(out[5].abs().max()) == 0.0
     # a word twice / 64 times the true maximum: one / six bits of precision less, never a wrong result
     for k, bound in ((1, 8e-6), (6, 2e-4)):
-        big = (ag.abs().max() * 2.0 ** k).reshape(1).view(torch.int32)
+        big = _g.record_of(float(ag.abs().max()) * 2.0 ** k, dev)
         out2 = _g.gemm_panel(ag, img, N, a_amax=big)
         assert float((out2.double().cpu() - ref).abs().max()) <= bound * scale
     z = torch.zeros(M, K, device=dev)
@@ -913,8 +914,8 @@ def test_dma_kernels_race_screen():
     words = absmax([t for pr in pairs for t in pr])
     for f16 in (False, True):
         for i, q in enumerate(probs):
-            q.g_amax = words[2 * i:2 * i + 1].data_ptr() if f16 else None
-            q.x_amax = words[2 * i + 1:2 * i + 2].data_ptr() if f16 else None
+            q.g_amax = words[2 * i].data_ptr() if f16 else None
+            q.x_amax = words[2 * i + 1].data_ptr() if f16 else None
         firsts = None
         for it in range(30):
             if it % 3 == 0:

@@ -286,12 +286,9 @@ def _aux_cases():
             "san_graph-add", "san_graph-mean", "ogb_code_graph", "graphormer_graph", "inductive_node"]
 
 
-@pytest.mark.parametrize("case", _aux_cases())
-def test_encoders_and_heads_match_reference_fixture(case):
-    """The encoders / heads either side of the layers against the reference's own classes (oracle/gen_golden.py:
-    run_aux_modules): strict state_dict load = the parameter-name contract, eval-mode forward = the arithmetic
-    (embedding sums, depth clipping, RWSE linear / MLP with raw BatchNorm, NaN-padded eigenvectors, add / mean /
-    graph_token pooling, halving MLP, 5 x vocabulary classifiers, post-MP MLP)."""
+def aux_case_outputs(case, device="cpu"):
+    """One encoder / head of ``aux_modules.pt`` on ``device``: (outputs, the reference's outputs).  On a CUDA device the
+    modules take their GPU forms (multi-hot GEMM embeddings, ``ops.embedding``, the ptr-segmented pooling kernels)."""
     from conftest import AUX_GOLDEN
     import graphgps_amd  # noqa: F401  (registrations)
     from graphgps_amd.encoder import encoders as E
@@ -335,16 +332,39 @@ def test_encoders_and_heads_match_reference_fixture(case):
         cfg.gnn.layers_post_mp = 2
         mod, outputs = H.GNNInductiveNodeHead(16, 3), lambda b, r: [r[0]]
     mod.load_state_dict(fix["state_dict"], strict=True)
-    mod.eval()
-    b = Batch(**{k: (v.clone() if torch.is_tensor(v) else v) for k, v in fix["inputs"].items()})
+    mod.eval().to(device)
+    b = Batch(**{k: (v.clone().to(device) if torch.is_tensor(v) else v) for k, v in fix["inputs"].items()})
     if "batch" in fix["inputs"]:
         b.num_graphs = meta["num_graphs"]
     with torch.no_grad():
         res = mod(b)
-    got = outputs(b, res)
-    assert len(got) == len(fix["outputs"])
-    for i, (a_, w_) in enumerate(zip(got, fix["outputs"])):
+    return outputs(b, res), fix["outputs"]
+
+
+@pytest.mark.parametrize("case", _aux_cases())
+def test_encoders_and_heads_match_reference_fixture(case):
+    """The encoders / heads either side of the layers against the reference's own classes (oracle/gen_golden.py:
+    run_aux_modules): strict state_dict load = the parameter-name contract, eval-mode forward = the arithmetic
+    (embedding sums, depth clipping, RWSE linear / MLP with raw BatchNorm, NaN-padded eigenvectors, add / mean /
+    graph_token pooling, halving MLP, 5 x vocabulary classifiers, post-MP MLP)."""
+    got, want = aux_case_outputs(case)
+    assert len(got) == len(want)
+    for i, (a_, w_) in enumerate(zip(got, want)):
         assert_close(a_, w_, Tol.ACT, f"{case} output {i}")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", _aux_cases())
+def test_encoders_and_heads_gpu_forms_match_reference_fixture(case):
+    """The same reference fixtures through the modules' GPU forms: on the device the TypeDict / AST / Atom
+    encoders are multi-hot GEMMs or ``ops.embedding`` lookups and the heads pool with the ptr-segmented kernels
+    (csrc/segment_pool.hip) -- different code from the CPU branches the test above pins
+    (graphgps/encoder/ast_encoder.py:35-83, type_dict_encoder.py, head/san_graph.py:19-42, head/ogb_code_graph.py)."""
+    got, want = aux_case_outputs(case, "cuda:0")
+    assert len(got) == len(want)
+    for i, (a_, w_) in enumerate(zip(got, want)):
+        assert a_.is_cuda
+        assert_close(a_, w_, Tol.ACT, f"{case} output {i} (GPU form)")
 
 
 def test_losses_match_reference_fixture():

@@ -34,7 +34,7 @@ if __name__ == "__main__":
             q.g, q.x, q.gw, q.gb = g.data_ptr(), x.data_ptr(), gw.data_ptr(), gb.data_ptr()
             q.ldg, q.ldx, q.R, q.M, q.Nn = g.stride(0), x.stride(0), g.shape[0], g.shape[1], x.shape[1]
             if f16:
-                q.g_amax, q.x_amax = words[2 * j:2 * j + 1].data_ptr(), words[2 * j + 1:2 * j + 2].data_ptr()
+                q.g_amax, q.x_amax = words[2 * j].data_ptr(), words[2 * j + 1].data_ptr()
         return probs
 
     ws = torch.empty(max(L.gps_wgrad_grouped_workspace_floats(5, problems(0, False)), 4), device=dev)
