@@ -366,17 +366,19 @@ def favor_rooflines(dev, nb, d=256, H=4, in_step=None):
     gD, g_ctx, g_ksum = torch.empty(H, N, **f32), torch.empty_like(cbuf), torch.empty_like(ksum)
     gm_part = torch.empty(max(gi.max_tiles * H, 1), **f32)
     d_qkv = torch.empty_like(qkv)
+    wsf = int(L.gps_favor_workspace_floats(N, nb, H))       # partial context records of the row slices
+    fws = torch.empty(max(wsf, 1), **f32)
 
     def fwd(i=0):
         check(L.gps_favor_fwd(ptr(qkv), 3 * inner, ptr(proj), m, ptr(gi.ptr), ptr(nmax), ptr(gi.tile_graph),
                               ptr(gi.tile_row0), gi.max_tiles, N, nb, H, dh, ptr(out), ptr(cbuf), ptr(ksum),
-                              ptr(kmax), ptr(mq), ptr(D), current_stream(dev)))
+                              ptr(kmax), ptr(mq), ptr(D), ptr(fws) if wsf else None, wsf, current_stream(dev)))
 
     def bwd(i=0):
         check(L.gps_favor_bwd(ptr(g_out), ptr(qkv), 3 * inner, ptr(proj), m, ptr(out), ptr(gi.ptr), ptr(nmax),
                               ptr(gi.tile_graph), ptr(gi.tile_row0), gi.max_tiles, N, nb, H, dh, ptr(cbuf),
                               ptr(ksum), ptr(kmax), ptr(mq), ptr(D), ptr(gD), ptr(g_ctx), ptr(g_ksum),
-                              ptr(gm_part), ptr(d_qkv), 3 * inner, current_stream(dev)))
+                              ptr(gm_part), ptr(d_qkv), 3 * inner, ptr(fws) if wsf else None, wsf, current_stream(dev)))
 
     fwd()
     flf = 8.0 * N * m * inner + 2.0 * N * m * H

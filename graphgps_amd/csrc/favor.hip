@@ -23,6 +23,8 @@
 // every cross-row reduction keyed so that it is summed in a fixed order: deterministic.
 #include "gps_common.hpp"
 
+#include <cstdlib>
+
 namespace {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -161,21 +163,33 @@ __global__ __launch_bounds__(256) void k_favor_kmax(
 // ---------------------------------------------------------------------------------------------
 // F2: per (graph, head, feature tile): ctx[m][64] = phi_k^T v and ksum[m] over all keys.
 // ---------------------------------------------------------------------------------------------
+// Round 4: the rows of a graph are dealt to S wavefronts (slices of whole 16-row blocks).  One wavefront per (graph, head,
+// feature tile) walked all ~800 rows of a code2 graph alone -- 2,176 wavefronts on 1,024 SIMDs, every iteration a chain of
+// dependent loads: the kernel ran at 1/7 of its MFMA time.  With S slices there are enough wavefronts in flight to cover
+// the loads; the partial sums go to a workspace and k_favor_sum_parts adds them in slice order (deterministic).
 __global__ __launch_bounds__(256) void k_favor_ctx(
     const float* __restrict__ qkv, int64_t ld, const float* __restrict__ P, int m, float c,
     float ratio, const int32_t* __restrict__ ptr, const int32_t* __restrict__ nmax_dev, int64_t B,
     int H, const unsigned long long* __restrict__ kmax, float* __restrict__ ctx,
-    float* __restrict__ ksum) {
+    float* __restrict__ ksum, int S) {
   const int lane = threadIdx.x & 63;
-  const int64_t w = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (w >= B * H * MT) return;
+  int64_t w = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (w >= B * H * MT * S) return;
+  const int sl = (int)(w % S);
+  w /= S;
   const int mt = (int)(w % MT);
   const int gh = (int)(w / MT);
   const int g = gh / H, h = gh - g * H;
-  const int n0 = ptr[g], n1 = ptr[g + 1];
+  const int n0 = ptr[g], n1_all = ptr[g + 1];
+  const int per = ((n1_all - n0 + 15) / 16 + S - 1) / S * 16;       // rows per slice (whole blocks)
+  const int k0 = min(n1_all, n0 + sl * per), n1 = min(n1_all, k0 + per);
+  if (S > 1) {                                                      // this slice's partial records
+    ctx += (int64_t)sl * B * H * 272 * DH;
+    ksum += (int64_t)sl * B * H * 272;
+  }
   const int i = lane & 15, grp = lane >> 4;
   const int inner = H * DH;
-  const int pad = nmax_dev[0] - (n1 - n0);
+  const int pad = nmax_dev[0] - (n1_all - n0);
   const float M = key_max_M(kmax, gh, pad);
   const int f = mt * 16 + i;  // this lane's feature column
   float pv[KPL];
@@ -184,7 +198,7 @@ __global__ __launch_bounds__(256) void k_favor_ctx(
 #pragma unroll
   for (int et = 0; et < 4; ++et) acc[et] = zero4();
   float ks = 0.0f;
-  for (int kb = n0; kb < n1; kb += 16) {
+  for (int kb = k0; kb < n1; kb += 16) {
     const int krow = kb + i;
     float kv[KPL];
     load_row16(qkv + (int64_t)krow * ld + inner + h * DH + 16 * grp, krow < n1, c, kv);
@@ -215,7 +229,35 @@ __global__ __launch_bounds__(256) void k_favor_ctx(
     for (int et = 0; et < 4; ++et)
       *reinterpret_cast<float4*>(cp + et * 16 + 4 * grp) =
           make_float4(acc[et][0], acc[et][1], acc[et][2], acc[et][3]);
-    if (grp == 0) ksum[(int64_t)gh * 272 + f] = ks + (float)pad * (ratio * (expf(-M) + FEPS));
+    // (the padded rows' closed-form term: here when the graph is one slice, else by k_favor_sum_parts)
+    if (grp == 0) ksum[(int64_t)gh * 272 + f] = S > 1 ? ks : ks + (float)pad * (ratio * (expf(-M) + FEPS));
+  }
+}
+
+// out[j] = sum_s part[s][j] over the S row slices, in slice order; ksum additionally takes the padded rows' term
+// pad * r (exp(-M) + 1e-4) (forward only: kmax != nullptr).
+__global__ __launch_bounds__(256) void k_favor_sum_parts(const float* __restrict__ cpart, const float* __restrict__ kpart,
+                                                         int S, int64_t BH, int m, float ratio,
+                                                         const int32_t* __restrict__ ptr,
+                                                         const int32_t* __restrict__ nmax_dev, int H,
+                                                         const unsigned long long* __restrict__ kmax,
+                                                         float* __restrict__ cout, float* __restrict__ kout) {
+  const int64_t nc = BH * 272 * (DH / 4), nk = BH * 272;
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  if (t < nc) {
+    f32x4 a = zero4();
+    for (int sl = 0; sl < S; ++sl) a += *reinterpret_cast<const f32x4*>(cpart + (sl * nc + t) * 4);
+    *reinterpret_cast<f32x4*>(cout + t * 4) = a;
+  } else if (t < nc + nk) {
+    const int64_t j = t - nc;
+    float a = 0.0f;
+    for (int sl = 0; sl < S; ++sl) a += kpart[sl * nk + j];
+    if (kmax) {
+      const int gh = (int)(j / 272), g = gh / H;
+      const int pad = nmax_dev[0] - (ptr[g + 1] - ptr[g]);
+      a += (float)pad * (ratio * (expf(-key_max_M(kmax, gh, pad)) + FEPS));
+    }
+    kout[j] = a;
   }
 }
 
@@ -413,14 +455,22 @@ __global__ __launch_bounds__(256) void k_favor_bwd_ctx(
     const float* __restrict__ g_out, const float* __restrict__ qkv, int64_t ld,
     const float* __restrict__ P, int m, float c, float ratio, const int32_t* __restrict__ ptr,
     int64_t B, int64_t N, int H, const float* __restrict__ mq_in, const float* __restrict__ D_in,
-    const float* __restrict__ gD_in, float* __restrict__ g_ctx, float* __restrict__ g_ksum) {
+    const float* __restrict__ gD_in, float* __restrict__ g_ctx, float* __restrict__ g_ksum, int S) {
   const int lane = threadIdx.x & 63;
-  const int64_t w = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
-  if (w >= B * H * MT) return;
+  int64_t w = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  if (w >= B * H * MT * S) return;
+  const int sl = (int)(w % S);                 // row slice (see k_favor_ctx)
+  w /= S;
   const int mt = (int)(w % MT);
   const int gh = (int)(w / MT);
   const int g = gh / H, h = gh - g * H;
-  const int n0 = ptr[g], n1 = ptr[g + 1];
+  const int n_beg = ptr[g], n_end = ptr[g + 1];
+  const int per = ((n_end - n_beg + 15) / 16 + S - 1) / S * 16;
+  const int n0 = min(n_end, n_beg + sl * per), n1 = min(n_end, n0 + per);
+  if (S > 1) {
+    g_ctx += (int64_t)sl * B * H * 272 * DH;
+    g_ksum += (int64_t)sl * B * H * 272;
+  }
   const int i = lane & 15, grp = lane >> 4;
   const int inner = H * DH;
   const int f = mt * 16 + i;
@@ -610,12 +660,31 @@ int gps_segment_max_len(const int32_t* ptr, int64_t B, int32_t* nmax, gps_stream
   return gps::launch_status("gps_segment_max_len");
 }
 
-size_t gps_favor_workspace_floats(int64_t B, int H) { return (size_t)B * H * 272 * (DH + 1); }
+}  // extern "C"
+// Row slices per (graph, head, feature tile) of the two context kernels: enough wavefronts to put ~8 on every SIMD, at
+// least 4 row blocks per slice on average, at most 8.
+static int favor_slices(int64_t N, int64_t B, int H) {
+  static const int forced = [] { const char* e = getenv("GPS_FAVOR_SLICES"); return e && *e ? atoi(e) : 0; }();
+  if (forced >= 1) return forced > 8 ? 8 : forced;
+  if (B <= 0 || H <= 0) return 1;
+  const int64_t waves = B * H * MT;
+  int64_t S = (8192 + waves - 1) / waves;
+  const int64_t blocks = N / B / 16;
+  if (S > blocks / 4) S = blocks / 4;
+  return (int)(S < 1 ? 1 : (S > 8 ? 8 : S));
+}
+extern "C" {
+
+// floats of workspace gps_favor_fwd / gps_favor_bwd take (partial context records of the row slices; 0: no slicing)
+size_t gps_favor_workspace_floats(int64_t N, int64_t B, int H) {
+  const int S = favor_slices(N, B, H);
+  return S > 1 ? (size_t)S * B * H * 272 * (DH + 1) : 0;
+}
 
 int gps_favor_fwd(const float* qkv, int64_t ld_qkv, const float* proj, int m, const int32_t* ptr,
                   const int32_t* nmax, const int32_t* tile_graph, const int32_t* tile_row0,
                   int64_t max_tiles, int64_t N, int64_t B, int H, int dh, float* out, float* ctx,
-                  float* ksum, uint64_t* kmax, float* mq, float* D, gps_stream_t stream) {
+                  float* ksum, uint64_t* kmax, float* mq, float* D, float* ws, size_t ws_floats, gps_stream_t stream) {
   GPS_REQUIRE(N >= 0 && B >= 0 && H > 0 && max_tiles >= 0, "gps_favor_fwd: bad sizes");
   if (dh != DH || m <= 0 || m > 16 * MT) {
     gps::set_error("gps_favor_fwd: only dim_head=64 with nb_features<=272 is compiled (got dh=%d m=%d)", dh, m);
@@ -632,8 +701,19 @@ int gps_favor_fwd(const float* qkv, int64_t ld_qkv, const float* proj, int m, co
   const int64_t n_work = max_tiles * H;
   k_favor_kmax<<<gps::grid_for(n_work, 4), 256, 0, s>>>(qkv, ld_qkv, proj, m, c, ptr, tile_graph, tile_row0,
                                                         n_work, H, (unsigned long long*)kmax);
-  k_favor_ctx<<<gps::grid_for(B * H * MT, 4), 256, 0, s>>>(qkv, ld_qkv, proj, m, c, ratio, ptr, nmax, B, H,
-                                                           (const unsigned long long*)kmax, ctx, ksum);
+  int S = favor_slices(N, B, H);
+  if (!ws || ws_floats < (size_t)S * B * H * 272 * (DH + 1)) S = 1;       // no workspace: one wavefront per record
+  if (S > 1) {
+    float* cpart = ws;
+    float* kpart = ws + (size_t)S * B * H * 272 * DH;
+    k_favor_ctx<<<gps::grid_for(B * H * MT * S, 4), 256, 0, s>>>(qkv, ld_qkv, proj, m, c, ratio, ptr, nmax, B, H,
+                                                                 (const unsigned long long*)kmax, cpart, kpart, S);
+    k_favor_sum_parts<<<gps::grid_for(B * H * 272 * (DH / 4 + 1), 256), 256, 0, s>>>(
+        cpart, kpart, S, B * H, m, ratio, ptr, nmax, H, (const unsigned long long*)kmax, ctx, ksum);
+  } else {
+    k_favor_ctx<<<gps::grid_for(B * H * MT, 4), 256, 0, s>>>(qkv, ld_qkv, proj, m, c, ratio, ptr, nmax, B, H,
+                                                             (const unsigned long long*)kmax, ctx, ksum, 1);
+  }
   k_favor_out<<<gps::grid_for(n_work, 4), 256, 0, s>>>(qkv, ld_qkv, proj, m, c, ratio, ptr, tile_graph,
                                                        tile_row0, n_work, N, H, ctx, ksum, out, mq, D);
   return gps::launch_status("gps_favor_fwd");
@@ -644,7 +724,7 @@ int gps_favor_bwd(const float* g_out, const float* qkv, int64_t ld_qkv, const fl
                   const int32_t* tile_row0, int64_t max_tiles, int64_t N, int64_t B, int H, int dh,
                   const float* ctx, const float* ksum, const uint64_t* kmax, const float* mq,
                   const float* D, float* gD, float* g_ctx, float* g_ksum, float* gM_part,
-                  float* d_qkv, int64_t ld_dqkv, gps_stream_t stream) {
+                  float* d_qkv, int64_t ld_dqkv, float* ws, size_t ws_floats, gps_stream_t stream) {
   GPS_REQUIRE(N >= 0 && B >= 0 && H > 0 && max_tiles >= 0, "gps_favor_bwd: bad sizes");
   if (dh != DH || m <= 0 || m > 16 * MT) {
     gps::set_error("gps_favor_bwd: only dim_head=64 with nb_features<=272 is compiled (got dh=%d m=%d)", dh, m);
@@ -663,8 +743,19 @@ int gps_favor_bwd(const float* g_out, const float* qkv, int64_t ld_qkv, const fl
   k_favor_bwd_q<<<gps::grid_for(n_work, 4), 256, 0, s>>>(g_out, qkv, ld_qkv, proj, m, c, ratio, ptr, tile_graph,
                                                          tile_row0, n_work, N, H, ctx, ksum, mq, D, gD, d_qkv,
                                                          ld_dqkv);
-  k_favor_bwd_ctx<<<gps::grid_for(B * H * MT, 4), 256, 0, s>>>(g_out, qkv, ld_qkv, proj, m, c, ratio, ptr, B, N,
-                                                               H, mq, D, gD, g_ctx, g_ksum);
+  int S = favor_slices(N, B, H);
+  if (!ws || ws_floats < (size_t)S * B * H * 272 * (DH + 1)) S = 1;
+  if (S > 1) {
+    float* cpart = ws;
+    float* kpart = ws + (size_t)S * B * H * 272 * DH;
+    k_favor_bwd_ctx<<<gps::grid_for(B * H * MT * S, 4), 256, 0, s>>>(g_out, qkv, ld_qkv, proj, m, c, ratio, ptr, B, N,
+                                                                     H, mq, D, gD, cpart, kpart, S);
+    k_favor_sum_parts<<<gps::grid_for(B * H * 272 * (DH / 4 + 1), 256), 256, 0, s>>>(
+        cpart, kpart, S, B * H, m, ratio, ptr, nmax, H, nullptr, g_ctx, g_ksum);
+  } else {
+    k_favor_bwd_ctx<<<gps::grid_for(B * H * MT, 4), 256, 0, s>>>(g_out, qkv, ld_qkv, proj, m, c, ratio, ptr, B, N,
+                                                                 H, mq, D, gD, g_ctx, g_ksum, 1);
+  }
   k_favor_bwd_k<<<gps::grid_for(n_work, 4), 256, 0, s>>>(qkv, ld_qkv, proj, m, c, ratio, ptr, tile_graph,
                                                          tile_row0, n_work, nmax, H,
                                                          (const unsigned long long*)kmax, g_ctx, g_ksum, d_qkv,

@@ -216,8 +216,10 @@ __global__ __launch_bounds__(256, 4) void k_sattn_fwd(
 // =============================================================================================================
 // backward, graphs of <= 64 nodes: dQ, dK, dV in one launch
 // =============================================================================================================
+constexpr int KTP = 68;      // K^T scratch pitch (floats): 64 keys + 4, rows stay 16-byte aligned
 template <int DH, bool DROP, int NT>
-__device__ __forceinline__ void sattn_bwd_body(const Item& it, float* __restrict__ tP, const float* __restrict__ d_out,
+__device__ __forceinline__ void sattn_bwd_body(const Item& it, float* __restrict__ tP, float* __restrict__ kT,
+                                               const float* __restrict__ d_out,
                                                const float* __restrict__ qkv, int64_t ld64,
                                                const float* __restrict__ out, const float* __restrict__ lse,
                                                int64_t N, int H, float scale, uint32_t thr16, float inv_keep,
@@ -236,21 +238,22 @@ __device__ __forceinline__ void sattn_bwd_body(const Item& it, float* __restrict
   const float* __restrict__ lse_b = lse + (int64_t)h * N + it.n0;
   float* __restrict__ tS = tP + 16 * PT;
 
-  // K-side operands, resident for all query tiles: row slices of K and V (S^T = K Q^T, dP^T = V dO^T) and the
-  // column form of K (dQ^T = K^T dS^T)
+  // K-side operands, resident for all query tiles: row slices of K and V (S^T = K Q^T, dP^T = V dO^T).  The column
+  // form of K (dQ^T = K^T dS^T) lives in the wave's LDS scratch as K^T[dh][key] (round 4): as 32 more resident registers
+  // it put the dh = 24 instantiation at 256 VGPRs with 13 spilled (56 bytes of scratch per lane); each query tile now
+  // fetches its K^T fragments with DT x NT 16-byte LDS reads, written once from the row slices already in registers.
   float kv[4][KPL], vk[4][KPL];
-  float kc[DT][4][4];
 #pragma unroll
   for (int t = 0; t < 4; ++t)
     if (t < NT) {
       row_slice<KPL>(Kb, ld, 16 * t + i, it.n, grp * KPL, 1.0f, kv[t]);
       row_slice<KPL>(Vb, ld, 16 * t + i, it.n, grp * KPL, 1.0f, vk[t]);
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-          kc[dt][t][r] = col_elem(Kb, ld, 16 * t + 4 * grp + r, it.n, dt * 16 + i, dt * 16 + i < DH);
+      for (int c = 0; c < KPL; ++c)           // lane (i, grp) holds K[key 16t + i][dh grp * KPL + c]
+        if (grp * KPL + c < DT * 16) kT[(grp * KPL + c) * KTP + 16 * t + i] = kv[t][c];
     }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");     // same wave writes and reads: LDS is in order per wave
+  __builtin_amdgcn_wave_barrier();
   f32x4 dk[4][DT], dv[4][DT];
 #pragma unroll
   for (int t = 0; t < 4; ++t)
@@ -335,9 +338,12 @@ __device__ __forceinline__ void sattn_bwd_body(const Item& it, float* __restrict
       for (int t = 0; t < 4; ++t)
         if (t < NT) {
 #pragma unroll
-          for (int r = 0; r < 4; ++r)
+          for (int dt = 0; dt < DT; ++dt) {   // K^T[dh 16dt + i][keys 16t + 4grp .. + 3]
+            const bool in = dt * 16 + i < DH;
+            const f32x4 k4 = *reinterpret_cast<const f32x4*>(kT + (dt * 16 + i) * KTP + 16 * t + 4 * grp);
 #pragma unroll
-            for (int dt = 0; dt < DT; ++dt) acc[dt] = mfma16(kc[dt][t][r], s[t][r], acc[dt]);
+            for (int r = 0; r < 4; ++r) acc[dt] = mfma16(in ? k4[r] : 0.0f, s[t][r], acc[dt]);
+          }
         }
       if (q_ok) {
         float* __restrict__ Gq = d_qkv + (int64_t)(it.n0 + ql) * ldg + h * DH;
@@ -405,6 +411,7 @@ __global__ __launch_bounds__(256, 2) void k_sattn_bwd(
     uint32_t thr16, float inv_keep, uint64_t seed, const uint64_t* __restrict__ salt, float* __restrict__ d_qkv,
     int64_t ldg) {
   __shared__ __attribute__((aligned(16))) float sT[4][2 * 16 * 20];   // per-wave transpose scratch (P_drop | dS)
+  __shared__ __attribute__((aligned(16))) float sK[4][SGeo<DH>::DT * 16 * KTP];   // per-wave K^T[dh][key]
   const Item it = item_setup(ptr, B, H);      // host guarantees n <= 64: one block per graph
   if (!it.live) return;
   // the block form is selected by a HOST hint (the batch's longest graph); a stale or wrong hint must not produce a silently
@@ -412,7 +419,8 @@ __global__ __launch_bounds__(256, 2) void k_sattn_bwd(
   if (it.n > 64) __builtin_trap();
   seed = gps::salted_seed(seed, salt);
   float* tP = &sT[threadIdx.x >> 6][0];
-#define SA_BODY(NTV) sattn_bwd_body<DH, DROP, NTV>(it, tP, d_out, qkv, ld64, out, lse, N, H, scale, thr16, inv_keep, \
+  float* kT = &sK[threadIdx.x >> 6][0];
+#define SA_BODY(NTV) sattn_bwd_body<DH, DROP, NTV>(it, tP, kT, d_out, qkv, ld64, out, lse, N, H, scale, thr16, inv_keep, \
                                                   seed, d_qkv, ldg)
   switch ((it.n + 15) >> 4) {
     case 1: SA_BODY(1); break;

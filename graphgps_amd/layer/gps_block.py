@@ -34,7 +34,7 @@ from .. import lib as _lib
 from .. import norm as _norm
 from ..fused import _BLOCK_SIDE_ENABLED as _SIDE_ENABLED, _queue_join, _side_stream
 from ..lib import check, current_stream, ptr
-from ..ops import GraphIndex, _nmax_dev, draw_dropout_seed
+from ..ops import GraphIndex, _nmax_dev, draw_dropout_seed, favor_workspace_floats
 
 _E = torch.empty
 _BY_REF = _ctypes.byref
@@ -552,9 +552,12 @@ class _GPSBlock(torch.autograd.Function):
                 BH = gi.B * H
                 fav = (proj, _E(BH, 272, dh, **f32), _E(BH, 272, **f32), _E(BH, dtype=torch.int64, device=dev),
                        _E(H, N, **f32))                         # projection, ctx, ksum, kmax, D
+                wsf = favor_workspace_floats(N, gi.B, H)
+                fws = _E(wsf, **f32) if wsf else None
                 check(L.gps_favor_fwd(P + 4 * fs, ldp, ptr(proj), proj.shape[0], ptr(gi.ptr), ptr(_nmax_dev(gi)),
                                       ptr(gi.tile_graph), ptr(gi.tile_row0), gi.max_tiles, N, gi.B, H, dh, ptr(o),
-                                      ptr(fav[1]), ptr(fav[2]), ptr(fav[3]), ptr(lse), ptr(fav[4]), sb), "gps_favor_fwd")
+                                      ptr(fav[1]), ptr(fav[2]), ptr(fav[3]), ptr(lse), ptr(fav[4]), ptr(fws), wsf, sb),
+                      "gps_favor_fwd")
             else:
                 check(L.gps_seg_attn_fwd(P + 4 * fs, ldp, ptr(gi.ptr), ptr(gi.tile_graph), ptr(gi.tile_row0),
                                          gi.max_tiles, N, H, dh, scale, p_at, s[2], ptr(o), ptr(lse),
@@ -701,10 +704,12 @@ class _GPSBlock(torch.autograd.Function):
                 proj, cbuf, ksum, kmax, Dn = fav
                 gD, g_ctx, g_ksum = _E(H, N, **f32), torch.empty_like(cbuf), torch.empty_like(ksum)
                 gm_part = _E(max(gi.max_tiles * H, 1), **f32)
+                wsf = favor_workspace_floats(N, gi.B, H)
+                fws = _E(wsf, **f32) if wsf else None
                 check(L.gps_favor_bwd(ptr(g_o), P + 4 * fs, ldp, ptr(proj), proj.shape[0], ptr(o), ptr(gi.ptr),
                                       ptr(_nmax_dev(gi)), ptr(gi.tile_graph), ptr(gi.tile_row0), gi.max_tiles, N, gi.B,
                                       H, dh, ptr(cbuf), ptr(ksum), ptr(kmax), ptr(lse), ptr(Dn), ptr(gD), ptr(g_ctx),
-                                      ptr(g_ksum), ptr(gm_part), G + 4 * fs, ldp, sb), "gps_favor_bwd")
+                                      ptr(g_ksum), ptr(gm_part), G + 4 * fs, ldp, ptr(fws), wsf, sb), "gps_favor_bwd")
             else:
                 delta = _E(H, N, **f32)
                 check(L.gps_seg_attn_bwd(ptr(g_o), P + 4 * fs, ldp, ptr(o), ptr(lse), ptr(gi.ptr),

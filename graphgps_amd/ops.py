@@ -660,6 +660,11 @@ def _nmax_dev(gi: GraphIndex) -> torch.Tensor:
     return nm
 
 
+def favor_workspace_floats(N: int, B: int, H: int) -> int:
+    """Floats of scratch the FAVOR+ context kernels take for the partial records of their row slices (0: no slicing)."""
+    return int(_lib.load().gps_favor_workspace_floats(N, B, H))
+
+
 class _FavorAttention(torch.autograd.Function):
     @staticmethod
     def forward(ctx, qkv: torch.Tensor, proj: torch.Tensor, gi: GraphIndex, num_heads: int):
@@ -681,9 +686,11 @@ class _FavorAttention(torch.autograd.Function):
         mq = torch.empty(H, N, **f32)
         D = torch.empty(H, N, **f32)
         nmax = _nmax_dev(gi)
+        wsf = favor_workspace_floats(N, B, H)
+        ws = torch.empty(wsf, **f32) if wsf else None
         check(L.gps_favor_fwd(ptr(qkv), qkv.shape[1], ptr(proj), m, ptr(gi.ptr), ptr(nmax),
                               ptr(gi.tile_graph), ptr(gi.tile_row0), gi.max_tiles, N, B, H, dh,
-                              ptr(out), ptr(cbuf), ptr(ksum), ptr(kmax), ptr(mq), ptr(D),
+                              ptr(out), ptr(cbuf), ptr(ksum), ptr(kmax), ptr(mq), ptr(D), ptr(ws), wsf,
                               current_stream(dev)), "gps_favor_fwd")
         ctx.save_for_backward(qkv, proj, out, cbuf, ksum, kmax, mq, D)
         ctx.gi, ctx.H, ctx.dh = gi, H, dh
@@ -703,11 +710,13 @@ class _FavorAttention(torch.autograd.Function):
         g_ksum = torch.empty_like(ksum)
         gm_part = torch.empty(max(gi.max_tiles * H, 1), **f32)
         d_qkv = torch.empty_like(qkv)
+        wsf = favor_workspace_floats(N, B, H)
+        ws = torch.empty(wsf, **f32) if wsf else None
         check(L.gps_favor_bwd(ptr(g_out), ptr(qkv), qkv.shape[1], ptr(proj), proj.shape[0], ptr(out),
                               ptr(gi.ptr), ptr(_nmax_dev(gi)), ptr(gi.tile_graph), ptr(gi.tile_row0),
                               gi.max_tiles, N, B, H, dh, ptr(cbuf), ptr(ksum), ptr(kmax), ptr(mq),
                               ptr(D), ptr(gD), ptr(g_ctx), ptr(g_ksum), ptr(gm_part), ptr(d_qkv),
-                              d_qkv.shape[1], current_stream(dev)), "gps_favor_bwd")
+                              d_qkv.shape[1], ptr(ws), wsf, current_stream(dev)), "gps_favor_bwd")
         return d_qkv, None, None, None
 
 

@@ -352,17 +352,20 @@ int gps_seg_attn_bias_bwd(const float* d_out, const float* qkv, int64_t ld_qkv, 
  * gM_part [max_tiles*H]; d_qkv [N, 3*64H] receives dq | dk | dv.
  * ------------------------------------------------------------------------------------- */
 int gps_segment_max_len(const int32_t* ptr, int64_t B, int32_t* nmax, gps_stream_t stream);
-size_t gps_favor_workspace_floats(int64_t B, int H);
+/* ABI v6: `ws` (gps_favor_workspace_floats(N, B, H) floats, or NULL): partial context records -- the rows of a graph are
+ * dealt to several wavefronts per (graph, head, feature tile) and summed in slice order (deterministic); without it one
+ * wavefront walks all rows of its graph (the round-1 form). */
+size_t gps_favor_workspace_floats(int64_t N, int64_t B, int H);
 int gps_favor_fwd(const float* qkv, int64_t ld_qkv, const float* proj, int m, const int32_t* ptr,
                   const int32_t* nmax, const int32_t* tile_graph, const int32_t* tile_row0,
                   int64_t max_tiles, int64_t N, int64_t B, int H, int dh, float* out, float* ctx,
-                  float* ksum, uint64_t* kmax, float* mq, float* D, gps_stream_t stream);
+                  float* ksum, uint64_t* kmax, float* mq, float* D, float* ws, size_t ws_floats, gps_stream_t stream);
 int gps_favor_bwd(const float* g_out, const float* qkv, int64_t ld_qkv, const float* proj, int m,
                   const float* out, const int32_t* ptr, const int32_t* nmax, const int32_t* tile_graph,
                   const int32_t* tile_row0, int64_t max_tiles, int64_t N, int64_t B, int H, int dh,
                   const float* ctx, const float* ksum, const uint64_t* kmax, const float* mq,
                   const float* D, float* gD, float* g_ctx, float* g_ksum, float* gM_part,
-                  float* d_qkv, int64_t ld_dqkv, gps_stream_t stream);
+                  float* d_qkv, int64_t ld_dqkv, float* ws, size_t ws_floats, gps_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Fused BatchNorm1d epilogues for [R, d] activation streams (training mode, batch statistics).
