@@ -42,6 +42,16 @@ struct SGeo {
   static_assert(DH % 8 == 0, "row-slice loads are 8-byte");
 };
 
+// One atomic per wavefront on the tensor's max|.| record (gps_common.hpp: eight words, so the ~4,000 wavefronts of a
+// launch queue ~500 deep per address, spread over the launch).  Every lane of the wave is live here.
+__device__ __forceinline__ void wave_amax(float amx, uint32_t* __restrict__ rec) {
+  if (!rec) return;                           // (kernel-uniform)
+  uint32_t m = __float_as_uint(amx);
+#pragma unroll
+  for (int o = 32; o; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+  if ((threadIdx.x & 63) == 0) gps::amax_raise(rec, m);
+}
+
 // KPL contiguous floats of row `row` (< nrows, else zeros) for this lane group: 8-byte loads off a wave-uniform base
 template <int KPL>
 __device__ __forceinline__ void row_slice(const float* __restrict__ base, uint32_t ld, int row, int nrows, int col,
@@ -93,7 +103,7 @@ __device__ __forceinline__ Item item_setup(const int32_t* __restrict__ ptr, int6
 template <int DH, bool DROP, int NT>
 __device__ __forceinline__ void sattn_fwd_body(const Item& it, const float* __restrict__ qkv, int64_t ld64, int64_t N,
                                                int H, float scale, uint32_t thr16, float inv_keep, uint64_t seed,
-                                               float* __restrict__ out, float* __restrict__ lse) {
+                                               float* __restrict__ out, float* __restrict__ lse, float& amx) {
   using G = SGeo<DH>;
   constexpr int KPL = G::KPL, DT = G::DT;
   const int lane = threadIdx.x & 63, i = lane & 15, grp = lane >> 4;
@@ -187,6 +197,7 @@ __device__ __forceinline__ void sattn_fwd_body(const Item& it, const float* __re
         if (col < DH) {
           const f32x4 o = oacc[dt] * inv_l;
           *reinterpret_cast<float4*>(Ob + (int64_t)ql * d + col) = make_float4(o[0], o[1], o[2], o[3]);
+          amx = fmaxf(fmaxf(fmaxf(fmaxf(amx, fabsf(o[0])), fabsf(o[1])), fabsf(o[2])), fabsf(o[3]));
         }
       }
       if (grp == 0) lse[(int64_t)h * N + it.n0 + ql] = m + logf(ltot);
@@ -194,23 +205,26 @@ __device__ __forceinline__ void sattn_fwd_body(const Item& it, const float* __re
   }
 }
 
+// (dh = 32 needs 136 registers with the dropout hash and the max|out| word: three wavefronts per SIMD there, no spills)
 template <int DH, bool DROP>
-__global__ __launch_bounds__(256, 4) void k_sattn_fwd(
+__global__ __launch_bounds__(256, DH >= 32 ? 3 : 4) void k_sattn_fwd(
     const float* __restrict__ qkv, int64_t ld64, const int32_t* __restrict__ ptr, int64_t B, int64_t N, int H,
     float scale, uint32_t thr16, float inv_keep, uint64_t seed, const uint64_t* __restrict__ salt,
-    float* __restrict__ out, float* __restrict__ lse) {
+    float* __restrict__ out, float* __restrict__ lse, uint32_t* __restrict__ amax) {
   const Item it = item_setup(ptr, B, H);      // host guarantees n <= 64: one block per graph
   if (!it.live) return;
   // the block form is selected by a HOST hint (the batch's longest graph); a stale or wrong hint must not produce a silently
   // truncated result (only the first 64 rows of the graph would be touched): abort the launch loudly instead
   if (it.n > 64) __builtin_trap();
   seed = gps::salted_seed(seed, salt);
+  float amx = 0.0f;                           // max|out| of this (graph, head): the record of the out-projection GEMM
   switch ((it.n + 15) >> 4) {
-    case 1: sattn_fwd_body<DH, DROP, 1>(it, qkv, ld64, N, H, scale, thr16, inv_keep, seed, out, lse); break;
-    case 2: sattn_fwd_body<DH, DROP, 2>(it, qkv, ld64, N, H, scale, thr16, inv_keep, seed, out, lse); break;
-    case 3: sattn_fwd_body<DH, DROP, 3>(it, qkv, ld64, N, H, scale, thr16, inv_keep, seed, out, lse); break;
-    default: sattn_fwd_body<DH, DROP, 4>(it, qkv, ld64, N, H, scale, thr16, inv_keep, seed, out, lse); break;
+    case 1: sattn_fwd_body<DH, DROP, 1>(it, qkv, ld64, N, H, scale, thr16, inv_keep, seed, out, lse, amx); break;
+    case 2: sattn_fwd_body<DH, DROP, 2>(it, qkv, ld64, N, H, scale, thr16, inv_keep, seed, out, lse, amx); break;
+    case 3: sattn_fwd_body<DH, DROP, 3>(it, qkv, ld64, N, H, scale, thr16, inv_keep, seed, out, lse, amx); break;
+    default: sattn_fwd_body<DH, DROP, 4>(it, qkv, ld64, N, H, scale, thr16, inv_keep, seed, out, lse, amx); break;
   }
+  wave_amax(amx, amax);
 }
 
 // =============================================================================================================
@@ -223,7 +237,7 @@ __device__ __forceinline__ void sattn_bwd_body(const Item& it, float* __restrict
                                                const float* __restrict__ qkv, int64_t ld64,
                                                const float* __restrict__ out, const float* __restrict__ lse,
                                                int64_t N, int H, float scale, uint32_t thr16, float inv_keep,
-                                               uint64_t seed, float* __restrict__ d_qkv, int64_t ldg) {
+                                               uint64_t seed, float* __restrict__ d_qkv, int64_t ldg, float& amx) {
   using G = SGeo<DH>;
   constexpr int KPL = G::KPL, DT = G::DT;
   constexpr int PT = 20;                      // transpose scratch pitch (floats): 16 + 4, rows stay 16-byte aligned
@@ -353,6 +367,7 @@ __device__ __forceinline__ void sattn_bwd_body(const Item& it, float* __restrict
           if (col < DH) {
             const f32x4 o = acc[dt] * scale;
             *reinterpret_cast<float4*>(Gq + col) = make_float4(o[0], o[1], o[2], o[3]);
+            amx = fmaxf(fmaxf(fmaxf(fmaxf(amx, fabsf(o[0])), fabsf(o[1])), fabsf(o[2])), fabsf(o[3]));
           }
         }
       }
@@ -398,6 +413,8 @@ __device__ __forceinline__ void sattn_bwd_body(const Item& it, float* __restrict
           if (col < DH) {
             *reinterpret_cast<float4*>(Gk + col) = make_float4(dk[t][dt][0], dk[t][dt][1], dk[t][dt][2], dk[t][dt][3]);
             *reinterpret_cast<float4*>(Gv + col) = make_float4(dv[t][dt][0], dv[t][dt][1], dv[t][dt][2], dv[t][dt][3]);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) amx = fmaxf(fmaxf(amx, fabsf(dk[t][dt][r])), fabsf(dv[t][dt][r]));
           }
         }
       }
@@ -409,7 +426,7 @@ __global__ __launch_bounds__(256, 2) void k_sattn_bwd(
     const float* __restrict__ d_out, const float* __restrict__ qkv, int64_t ld64, const float* __restrict__ out,
     const float* __restrict__ lse, const int32_t* __restrict__ ptr, int64_t B, int64_t N, int H, float scale,
     uint32_t thr16, float inv_keep, uint64_t seed, const uint64_t* __restrict__ salt, float* __restrict__ d_qkv,
-    int64_t ldg) {
+    int64_t ldg, uint32_t* __restrict__ amax) {
   __shared__ __attribute__((aligned(16))) float sT[4][2 * 16 * 20];   // per-wave transpose scratch (P_drop | dS)
   __shared__ __attribute__((aligned(16))) float sK[4][SGeo<DH>::DT * 16 * KTP];   // per-wave K^T[dh][key]
   const Item it = item_setup(ptr, B, H);      // host guarantees n <= 64: one block per graph
@@ -420,8 +437,9 @@ __global__ __launch_bounds__(256, 2) void k_sattn_bwd(
   seed = gps::salted_seed(seed, salt);
   float* tP = &sT[threadIdx.x >> 6][0];
   float* kT = &sK[threadIdx.x >> 6][0];
+  float amx = 0.0f;                           // max over this item's dq | dk | dv: the record of the GEMMs that read d_qkv
 #define SA_BODY(NTV) sattn_bwd_body<DH, DROP, NTV>(it, tP, kT, d_out, qkv, ld64, out, lse, N, H, scale, thr16, inv_keep, \
-                                                  seed, d_qkv, ldg)
+                                                  seed, d_qkv, ldg, amx)
   switch ((it.n + 15) >> 4) {
     case 1: SA_BODY(1); break;
     case 2: SA_BODY(2); break;
@@ -429,6 +447,7 @@ __global__ __launch_bounds__(256, 2) void k_sattn_bwd(
     default: SA_BODY(4); break;
   }
 #undef SA_BODY
+  wave_amax(amx, amax);
 }
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) % 16) == 0; }
@@ -447,7 +466,7 @@ bool sattn_applicable(const void* qkv, int64_t ld_qkv, const void* out, int H, i
 
 // Launch the block-form forward.  Preconditions: sattn_applicable().
 void sattn_fwd_launch(const float* qkv, int64_t ld_qkv, const int32_t* ptr, int64_t B, int64_t N, int H, int dh,
-                      float scale, float p_drop, uint64_t seed, float* out, float* lse, hipStream_t s) {
+                      float scale, float p_drop, uint64_t seed, float* out, float* lse, uint32_t* amax, hipStream_t s) {
   const uint32_t thr16 = drop_thr16(p_drop);
   const float inv_keep = p_drop > 0.0f ? drop_inv_keep(thr16) : 1.0f;
   const unsigned grid = gps::grid_for(B * H, 4);
@@ -455,10 +474,10 @@ void sattn_fwd_launch(const float* qkv, int64_t ld_qkv, const int32_t* ptr, int6
   do {                                                                                                          \
     if (p_drop > 0.0f)                                                                                          \
       k_sattn_fwd<D, true><<<grid, 256, 0, s>>>(qkv, ld_qkv, ptr, B, N, H, scale, thr16, inv_keep, seed,         \
-                                                gps::dropout_salt(), out, lse);                                  \
+                                                gps::dropout_salt(), out, lse, amax);                            \
     else                                                                                                        \
       k_sattn_fwd<D, false><<<grid, 256, 0, s>>>(qkv, ld_qkv, ptr, B, N, H, scale, thr16, inv_keep, seed,        \
-                                                 gps::dropout_salt(), out, lse);                                 \
+                                                 gps::dropout_salt(), out, lse, amax);                           \
   } while (0)
   switch (dh) {
     case 8: SA_FWD(8); break;
@@ -472,7 +491,7 @@ void sattn_fwd_launch(const float* qkv, int64_t ld_qkv, const int32_t* ptr, int6
 // Launch the fused backward (every graph has <= 64 nodes).  Preconditions: sattn_applicable(), aligned d_out / d_qkv.
 void sattn_bwd_launch(const float* d_out, const float* qkv, int64_t ld_qkv, const float* out, const float* lse,
                       const int32_t* ptr, int64_t B, int64_t N, int H, int dh, float scale, float p_drop,
-                      uint64_t seed, float* d_qkv, int64_t ld_dqkv, hipStream_t s) {
+                      uint64_t seed, float* d_qkv, int64_t ld_dqkv, uint32_t* amax, hipStream_t s) {
   const uint32_t thr16 = drop_thr16(p_drop);
   const float inv_keep = p_drop > 0.0f ? drop_inv_keep(thr16) : 1.0f;
   const unsigned grid = gps::grid_for(B * H, 4);
@@ -480,10 +499,10 @@ void sattn_bwd_launch(const float* d_out, const float* qkv, int64_t ld_qkv, cons
   do {                                                                                                          \
     if (p_drop > 0.0f)                                                                                          \
       k_sattn_bwd<D, true><<<grid, 256, 0, s>>>(d_out, qkv, ld_qkv, out, lse, ptr, B, N, H, scale, thr16,        \
-                                                inv_keep, seed, gps::dropout_salt(), d_qkv, ld_dqkv);            \
+                                                inv_keep, seed, gps::dropout_salt(), d_qkv, ld_dqkv, amax);      \
     else                                                                                                        \
       k_sattn_bwd<D, false><<<grid, 256, 0, s>>>(d_out, qkv, ld_qkv, out, lse, ptr, B, N, H, scale, thr16,       \
-                                                 inv_keep, seed, gps::dropout_salt(), d_qkv, ld_dqkv);           \
+                                                 inv_keep, seed, gps::dropout_salt(), d_qkv, ld_dqkv, amax);     \
   } while (0)
   switch (dh) {
     case 8: SA_BWD(8); break;

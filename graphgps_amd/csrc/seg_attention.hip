@@ -601,7 +601,7 @@ static int seg_attn_fwd_impl(const char* who, const float* qkv, int64_t ld_qkv, 
                              int64_t nmax, const int32_t* ptr, const int32_t* tile_graph,
                              const int32_t* tile_row0, int64_t max_tiles, int64_t N, int H, int dh, float scale,
                              float p_drop, uint64_t seed, float* out, float* lse, int64_t num_graphs,
-                             int64_t max_graph_nodes, gps_stream_t stream) {
+                             int64_t max_graph_nodes, uint32_t* amax, gps_stream_t stream) {
   GPS_REQUIRE(N >= 0 && H > 0 && dh > 0 && max_tiles >= 0 && ld_qkv >= 3LL * H * dh,
               "%s: bad sizes N=%lld H=%d dh=%d ld=%lld", who, (long long)N, H, dh, (long long)ld_qkv);
   GPS_REQUIRE(p_drop >= 0.0f && p_drop < 1.0f, "%s: p_drop=%f outside [0,1)", who, p_drop);
@@ -620,7 +620,7 @@ static int seg_attn_fwd_impl(const char* who, const float* qkv, int64_t ld_qkv, 
   hipStream_t s = gps::as_stream(stream);
   if (!bias && num_graphs > 0 && max_graph_nodes > 0 && max_graph_nodes <= 64 &&
       attn::sattn_applicable(qkv, ld_qkv, out, H, dh)) {            // block form (sattn.hip)
-    attn::sattn_fwd_launch(qkv, ld_qkv, ptr, num_graphs, N, H, dh, scale, p_drop, seed, out, lse, s);
+    attn::sattn_fwd_launch(qkv, ld_qkv, ptr, num_graphs, N, H, dh, scale, p_drop, seed, out, lse, amax, s);
     return gps::launch_status(who);
   }
   const bool vec = ld_qkv % 4 == 0 && (H * dh) % 4 == 0 && al16(qkv) && al16(out);
@@ -643,7 +643,12 @@ static int seg_attn_fwd_impl(const char* who, const float* qkv, int64_t ld_qkv, 
 #undef X
   }
 #undef LAUNCH_FWD
-  return gps::launch_status(who);
+  if (int rc = gps::launch_status(who)) return rc;
+  if (amax) {        // the tile kernels do not track the maximum: one pre-pass over the output (gps_absmax)
+    const gps_absmax_desc dsc{out, (int64_t)H * dh, N, H * dh, amax};
+    return gps_absmax(1, &dsc, stream);
+  }
+  return GPS_OK;
 }
 
 static int seg_attn_bwd_impl(const char* who, const float* d_out, const float* qkv, int64_t ld_qkv,
@@ -651,7 +656,7 @@ static int seg_attn_bwd_impl(const char* who, const float* d_out, const float* q
                              const int32_t* ptr, const int32_t* tile_graph, const int32_t* tile_row0,
                              int64_t max_tiles, int64_t N, int H, int dh, float scale, float p_drop,
                              uint64_t seed, float* delta, float* d_qkv, int64_t ld_dqkv, float* d_bias,
-                             int64_t num_graphs, int64_t max_graph_nodes, gps_stream_t stream) {
+                             int64_t num_graphs, int64_t max_graph_nodes, uint32_t* amax, gps_stream_t stream) {
   GPS_REQUIRE(N >= 0 && H > 0 && dh > 0 && max_tiles >= 0 && ld_qkv >= 3LL * H * dh &&
                   ld_dqkv >= 3LL * H * dh,
               "%s: bad sizes", who);
@@ -675,7 +680,7 @@ static int seg_attn_bwd_impl(const char* who, const float* d_out, const float* q
   if (!bias && num_graphs > 0 && max_graph_nodes > 0 && max_graph_nodes <= 64 &&
       attn::sattn_applicable(qkv, ld_qkv, out, H, dh) && ld_dqkv % 4 == 0 && al16(d_out) && al16(d_qkv)) {
     attn::sattn_bwd_launch(d_out, qkv, ld_qkv, out, lse, ptr, num_graphs, N, H, dh, scale, p_drop, seed, d_qkv,
-                           ld_dqkv, s);                          // one fused launch (sattn.hip)
+                           ld_dqkv, amax, s);                    // one fused launch (sattn.hip)
     return gps::launch_status(who);
   }
   const bool vec = ld_qkv % 4 == 0 && ld_dqkv % 4 == 0 && (H * dh) % 4 == 0 && al16(qkv) && al16(out) &&
@@ -706,25 +711,32 @@ static int seg_attn_bwd_impl(const char* who, const float* d_out, const float* q
 #undef X
   }
 #undef LAUNCH_BWD
-  return gps::launch_status(who);
+  if (int rc = gps::launch_status(who)) return rc;
+  if (amax && (3LL * H * dh) % 4 == 0 && ld_dqkv % 4 == 0 && al16(d_qkv)) {
+    const gps_absmax_desc dsc{d_qkv, ld_dqkv, N, 3 * H * dh, amax};
+    return gps_absmax(1, &dsc, stream);
+  }
+  GPS_REQUIRE(!amax, "%s: the max|d_qkv| record needs 16-byte-aligned rows", who);
+  return GPS_OK;
 }
 
 int gps_seg_attn_fwd(const float* qkv, int64_t ld_qkv, const int32_t* ptr,
                      const int32_t* tile_graph, const int32_t* tile_row0, int64_t max_tiles,
                      int64_t N, int H, int dh, float scale, float p_drop, uint64_t seed, float* out,
-                     float* lse, int64_t num_graphs, int64_t max_graph_nodes, gps_stream_t stream) {
+                     float* lse, int64_t num_graphs, int64_t max_graph_nodes, uint32_t* amax, gps_stream_t stream) {
+  GPS_REQUIRE(!amax || ((H * dh) % 4 == 0 && al16(out)), "gps_seg_attn_fwd: the max|out| record needs 16-byte-aligned rows");
   return seg_attn_fwd_impl("gps_seg_attn_fwd", qkv, ld_qkv, nullptr, 0, ptr, tile_graph, tile_row0, max_tiles,
-                           N, H, dh, scale, p_drop, seed, out, lse, num_graphs, max_graph_nodes, stream);
+                           N, H, dh, scale, p_drop, seed, out, lse, num_graphs, max_graph_nodes, amax, stream);
 }
 
 int gps_seg_attn_bwd(const float* d_out, const float* qkv, int64_t ld_qkv, const float* out,
                      const float* lse, const int32_t* ptr, const int32_t* tile_graph,
                      const int32_t* tile_row0, int64_t max_tiles, int64_t N, int H, int dh,
                      float scale, float p_drop, uint64_t seed, float* delta, float* d_qkv,
-                     int64_t ld_dqkv, int64_t num_graphs, int64_t max_graph_nodes, gps_stream_t stream) {
+                     int64_t ld_dqkv, int64_t num_graphs, int64_t max_graph_nodes, uint32_t* amax, gps_stream_t stream) {
   return seg_attn_bwd_impl("gps_seg_attn_bwd", d_out, qkv, ld_qkv, nullptr, 0, out, lse, ptr, tile_graph,
                            tile_row0, max_tiles, N, H, dh, scale, p_drop, seed, delta, d_qkv, ld_dqkv, nullptr,
-                           num_graphs, max_graph_nodes, stream);
+                           num_graphs, max_graph_nodes, amax, stream);
 }
 
 int gps_seg_attn_bias_fwd(const float* qkv, int64_t ld_qkv, const float* bias, int64_t nmax,
@@ -733,7 +745,7 @@ int gps_seg_attn_bias_fwd(const float* qkv, int64_t ld_qkv, const float* bias, i
                           uint64_t seed, float* out, float* lse, gps_stream_t stream) {
   GPS_REQUIRE(bias != nullptr || N == 0, "gps_seg_attn_bias_fwd: null bias");
   return seg_attn_fwd_impl("gps_seg_attn_bias_fwd", qkv, ld_qkv, bias, nmax, ptr, tile_graph, tile_row0,
-                           max_tiles, N, H, dh, scale, p_drop, seed, out, lse, 0, 0, stream);
+                           max_tiles, N, H, dh, scale, p_drop, seed, out, lse, 0, 0, nullptr, stream);
 }
 
 int gps_seg_attn_bias_bwd(const float* d_out, const float* qkv, int64_t ld_qkv, const float* bias,
@@ -744,7 +756,7 @@ int gps_seg_attn_bias_bwd(const float* d_out, const float* qkv, int64_t ld_qkv, 
   GPS_REQUIRE(bias != nullptr || N == 0, "gps_seg_attn_bias_bwd: null bias");
   return seg_attn_bwd_impl("gps_seg_attn_bias_bwd", d_out, qkv, ld_qkv, bias, nmax, out, lse, ptr, tile_graph,
                            tile_row0, max_tiles, N, H, dh, scale, p_drop, seed, delta, d_qkv, ld_dqkv, d_bias, 0, 0,
-                           stream);
+                           nullptr, stream);
 }
 
 }  // extern "C"

@@ -561,8 +561,8 @@ class _GPSBlock(torch.autograd.Function):
             else:
                 check(L.gps_seg_attn_fwd(P + 4 * fs, ldp, ptr(gi.ptr), ptr(gi.tile_graph), ptr(gi.tile_row0),
                                          gi.max_tiles, N, H, dh, scale, p_at, s[2], ptr(o), ptr(lse),
-                                         gi.B, int(gi.nmax_host), sb), "gps_seg_attn_fwd")
-            if am is not None:
+                                         gi.B, int(gi.nmax_host), ptr(aw(_R_O)), sb), "gps_seg_attn_fwd")
+            if am is not None and perf:         # (the attention kernel raised o's record itself; FAVOR+ does not)
                 _gemm.absmax([o], out=rec[_R_O:_R_O + 1])
             if gemm_stats:      # za = x + drop(out_proj(o)) and the statistics of za (norm1_attn) in the GEMM's epilogue
                 ao = None
@@ -714,7 +714,7 @@ class _GPSBlock(torch.autograd.Function):
                 delta = _E(H, N, **f32)
                 check(L.gps_seg_attn_bwd(ptr(g_o), P + 4 * fs, ldp, ptr(o), ptr(lse), ptr(gi.ptr),
                                          ptr(gi.tile_graph), ptr(gi.tile_row0), gi.max_tiles, N, H, dh, scale,
-                                         p_at, s[2], ptr(delta), G + 4 * fs, ldp, gi.B, int(gi.nmax_host), sb),
+                                         p_at, s[2], ptr(delta), G + 4 * fs, ldp, gi.B, int(gi.nmax_host), ptr(bw(3)), sb),
                       "gps_seg_attn_bwd")
 
         # x1 = x + drop(relu(BN_x(xt))):  bn_node_x's apply (its sums came from the chain above)
@@ -732,9 +732,10 @@ class _GPSBlock(torch.autograd.Function):
         leaves = R.params
         words = None
         if bm is not None:
-            # g_pq's record: the GatedGCN backward raised it over its four column blocks and made g_ce's; the attention
-            # kernels' dq | dk | dv columns take one strided pre-pass (their backward is at its register limit)
-            _gemm.absmax([g_pq[:, 4 * d:]], out=bm[3:4])
+            # g_pq's record: the GatedGCN backward raised it over its four column blocks (and made g_ce's), the attention
+            # backward over dq | dk | dv; FAVOR+ does not track: its columns take one strided pre-pass
+            if perf:
+                _gemm.absmax([g_pq[:, 4 * d:]], out=bm[3:4])
             am = ctx.am
             if am is not None and _WGRAD_F16:
                 words = [(bm[3], am[_R_X]), (bm[4], am[_R_E]), (bm[2], am[_R_O]), (bm[1], am[_R_H]), (bm[0], am[_R_T])]
@@ -796,7 +797,7 @@ class _GPSBlockGINE(torch.autograd.Function):
             scale = float(dh) ** -0.5
             check(L.gps_seg_attn_fwd(ptr(qkv), 3 * d, ptr(gi.ptr), ptr(gi.tile_graph), ptr(gi.tile_row0),
                                      gi.max_tiles, N, H, dh, scale, p_at, s[2], ptr(o), ptr(lse),
-                                     gi.B, int(gi.nmax_host), sb), "gps_seg_attn_fwd")
+                                     gi.B, int(gi.nmax_host), None, sb), "gps_seg_attn_fwd")
             ao = torch.addmm(sa.out_proj.bias, o, sa.out_proj.weight.t())
         # -- local half: GINE core + MLP (gps_layer.py:62-69,183-185) -------------------------------
         agg = _E(N, d, **f32)
@@ -876,7 +877,7 @@ class _GPSBlockGINE(torch.autograd.Function):
             g_qkv, delta = _E(N, 3 * d, **f32), _E(H, N, **f32)
             check(L.gps_seg_attn_bwd(ptr(g_o), ptr(qkv), 3 * d, ptr(o), ptr(lse), ptr(gi.ptr),
                                      ptr(gi.tile_graph), ptr(gi.tile_row0), gi.max_tiles, N, H, dh, scale,
-                                     p_at, s[2], ptr(delta), ptr(g_qkv), 3 * d, gi.B, int(gi.nmax_host), sb),
+                                     p_at, s[2], ptr(delta), ptr(g_qkv), 3 * d, gi.B, int(gi.nmax_host), None, sb),
                   "gps_seg_attn_bwd")
         # local half: MLP backward, GINE core backward
         g_g1r = g_g2.mm(lin2.weight)

@@ -80,9 +80,9 @@ _SIGNATURES = {
                               c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, c_size_t, _P]),
     "gps_attn_supported_head_dim": (c_int, [c_int]),
     "gps_seg_attn_fwd": (c_int, [_P, c_int64, _P, _P, _P, c_int64, c_int64, c_int, c_int, c_float,
-                                 c_float, c_uint64, _P, _P, c_int64, c_int64, _P]),
+                                 c_float, c_uint64, _P, _P, c_int64, c_int64, _P, _P]),
     "gps_seg_attn_bwd": (c_int, [_P, _P, c_int64, _P, _P, _P, _P, _P, c_int64, c_int64, c_int, c_int,
-                                 c_float, c_float, c_uint64, _P, _P, c_int64, c_int64, c_int64, _P]),
+                                 c_float, c_float, c_uint64, _P, _P, c_int64, c_int64, c_int64, _P, _P]),
     "gps_edge_attn_supported": (c_int, [c_int, c_int]),
     "gps_edge_attn_fwd": (c_int, [_P, _P, _P, c_int64, _P, _P, _P, _P, c_int64, c_int64, c_int, c_int, c_float, c_int,
                                   _P, _P, _P, _P, _P]),

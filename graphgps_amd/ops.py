@@ -418,7 +418,7 @@ class _SegmentAttention(torch.autograd.Function):
         if bias is None:
             check(L.gps_seg_attn_fwd(ptr(qkv), 3 * d, ptr(gi.ptr), ptr(gi.tile_graph),
                                      ptr(gi.tile_row0), gi.max_tiles, N, H, dh, scale, float(p_drop),
-                                     seed, ptr(out), ptr(lse), gi.B, int(gi.nmax_host), current_stream(dev)),
+                                     seed, ptr(out), ptr(lse), gi.B, int(gi.nmax_host), None, current_stream(dev)),
                   "gps_seg_attn_fwd")
             ctx.save_for_backward(qkv, out, lse)
         else:
@@ -447,7 +447,7 @@ class _SegmentAttention(torch.autograd.Function):
             check(L.gps_seg_attn_bwd(ptr(d_out), ptr(qkv), qkv.shape[1], ptr(out), ptr(lse), ptr(gi.ptr),
                                      ptr(gi.tile_graph), ptr(gi.tile_row0), gi.max_tiles, N, H, dh,
                                      ctx.scale, ctx.p_drop, ctx.seed, ptr(delta), ptr(d_qkv),
-                                     d_qkv.shape[1], gi.B, int(gi.nmax_host), current_stream(dev)), "gps_seg_attn_bwd")
+                                     d_qkv.shape[1], gi.B, int(gi.nmax_host), None, current_stream(dev)), "gps_seg_attn_bwd")
             return d_qkv, None, None, None, None, None
         bias = ctx.saved_tensors[3]
         d_bias = torch.zeros_like(bias)       # padded region: zero gradient, as under the reference's mask
