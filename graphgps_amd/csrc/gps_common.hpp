@@ -24,22 +24,28 @@ __device__ __forceinline__ uint64_t salted_seed(uint64_t seed, const uint64_t* s
 }
 
 // max|tensor| RECORDS of the fp16-form GEMMs (csrc/gemm_panel.hip, csrc/wgrad.hip): kAmaxWords uint32 words holding fp32
-// bit patterns; the tensor's maximum is the (unsigned) maximum of the words.  Producers raise word (blockIdx & 7) with
-// ONE atomic per workgroup: atomics on one address serialise at the L2 (~6 ns each, measured), eight addresses carry a
-// thousand-workgroup producer without a tail.  Zero at allocation; only ever raised.
+// bit patterns, kAmaxStride words (256 bytes) apart; the tensor's maximum is the (unsigned) maximum of the words.
+// Producers raise word (blockIdx & 7) with one atomic per workgroup (or wavefront).  Why eight LINES: atomics on one
+// cache line serialise at the L2 at ~6 ns each (measured twice: one atomic per wavefront on ONE word made a 12 MB max
+// pass take 20 us whatever its size; the attention forward's 4,096 per-wavefront atomics on eight words of ONE line took
+// it from 24 to 60 us).  Zero at allocation; only ever raised.
 constexpr int kAmaxWords = 8;
+constexpr int kAmaxStride = 64;                            // words between the words of a record
+constexpr int kAmaxRecordWords = kAmaxWords * kAmaxStride;  // footprint of a record: 2 KB
 #if defined(__HIPCC__)
 // biased exponent of the record's maximum, floored at 16 (tensors below 2^-111 are scaled as if they were that large)
 __device__ __forceinline__ unsigned amax_be(const uint32_t* rec) {
   unsigned m = 0;
 #pragma unroll
-  for (int i = 0; i < kAmaxWords; ++i) m = max(m, __builtin_nontemporal_load(rec + i));
+  for (int i = 0; i < kAmaxWords; ++i) m = max(m, __builtin_nontemporal_load(rec + i * kAmaxStride));
   const unsigned be = (m >> 23) & 255u;
   return be < 16u ? 16u : be;
 }
-__device__ __forceinline__ void amax_raise(uint32_t* rec, uint32_t bits) {
-  if (bits) atomicMax(rec + (blockIdx.x & (kAmaxWords - 1)), bits);
+// `spread`: which of the eight words this caller raises (workgroups: blockIdx; wavefronts: their global index)
+__device__ __forceinline__ void amax_raise(uint32_t* rec, uint32_t bits, unsigned spread) {
+  if (bits) atomicMax(rec + (spread & (kAmaxWords - 1)) * kAmaxStride, bits);
 }
+__device__ __forceinline__ void amax_raise(uint32_t* rec, uint32_t bits) { amax_raise(rec, bits, blockIdx.x); }
 #endif
 
 static inline unsigned grid_for(int64_t work, int block) {

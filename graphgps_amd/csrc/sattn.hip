@@ -42,14 +42,14 @@ struct SGeo {
   static_assert(DH % 8 == 0, "row-slice loads are 8-byte");
 };
 
-// One atomic per wavefront on the tensor's max|.| record (gps_common.hpp: eight words, so the ~4,000 wavefronts of a
-// launch queue ~500 deep per address, spread over the launch).  Every lane of the wave is live here.
+// One atomic per wavefront on the tensor's max|.| record (gps_common.hpp: eight words on eight different lines, so the
+// ~4,000 wavefronts of a launch queue ~500 deep per line, spread over the launch).  Every lane of the wave is live here.
 __device__ __forceinline__ void wave_amax(float amx, uint32_t* __restrict__ rec) {
   if (!rec) return;                           // (kernel-uniform)
   uint32_t m = __float_as_uint(amx);
 #pragma unroll
   for (int o = 32; o; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
-  if ((threadIdx.x & 63) == 0) gps::amax_raise(rec, m);
+  if ((threadIdx.x & 63) == 0) gps::amax_raise(rec, m, blockIdx.x * 4u + (threadIdx.x >> 6));
 }
 
 // KPL contiguous floats of row `row` (< nrows, else zeros) for this lane group: 8-byte loads off a wave-uniform base

@@ -31,16 +31,18 @@ MAX_SPLIT = 56      # csrc/gemm_panel.hip kMaxSplit
 F16 = os.environ.get("GPS_GEMM_F16", "1") != "0"
 MAX_SPLIT16 = 48    # csrc/gemm_panel.hip kMaxSplit16
 MAX_ABS = 56        # csrc/gemm_panel.hip kMaxAbs
-AMAX_WORDS = 8      # include/gps_hip.h GPS_AMAX_WORDS: a max|.| record = 8 int32 words (fp32 bit patterns), max over them
+# include/gps_hip.h GPS_AMAX_RECORD_WORDS: a max|.| record occupies 512 int32 words -- 8 live words (fp32 bit patterns)
+# 64 words apart, the rest zero; the maximum is the max over the row
+AMAX_WORDS = 512
 
 
 def amax_records(n: int, device) -> torch.Tensor:
-    """``n`` zeroed max|.| records: int32 ``[n, 8]``; row i is the record of tensor i."""
+    """``n`` zeroed max|.| records: int32 ``[n, 512]``; row i is the record of tensor i."""
     return torch.zeros(n, AMAX_WORDS, dtype=torch.int32, device=device)
 
 
 class WImage:
-    """A weight image and, for the fp16 form, the device record of max|W| it was scaled by (``amax``: int32 [8])."""
+    """A weight image and, for the fp16 form, the device record of max|W| it was scaled by (``amax``: int32 [512])."""
     __slots__ = ("t", "amax")
 
     def __init__(self, t: torch.Tensor, amax: Optional[torch.Tensor] = None):
@@ -51,7 +53,7 @@ class WImage:
 
 
 def absmax(tensors: Sequence[torch.Tensor], out: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """int32 ``[len(tensors), 8]``: row i = the max|.| record of ``tensors[i]`` (fp32 bit patterns; the maximum is the max
+    """int32 ``[len(tensors), 512]``: row i = the max|.| record of ``tensors[i]`` (fp32 bit patterns; the maximum is the max
     over the row -- ``amax_value``) by csrc/gemm_panel.hip ``gps_absmax``, one launch for up to 56 row-major fp32 matrices
     with ``cols % 4 == 0``.  ``out``: records to raise instead (zeros or an earlier maximum of the same tensors)."""
     L = _lib.load()
@@ -60,7 +62,7 @@ def absmax(tensors: Sequence[torch.Tensor], out: Optional[torch.Tensor] = None) 
     if out is None:
         out = amax_records(n, dev)
     if out.shape[-1] != AMAX_WORDS or out.numel() != n * AMAX_WORDS or not out.is_contiguous():
-        raise _lib.GpsHipError("absmax: `out` must be contiguous int32 [len(tensors), 8]")
+        raise _lib.GpsHipError("absmax: `out` must be contiguous int32 [len(tensors), 512]")
     base = out.data_ptr()
     for i0 in range(0, n, MAX_ABS):
         chunk = tensors[i0:i0 + MAX_ABS]
@@ -108,7 +110,7 @@ def _a_word(a: torch.Tensor, a_amax: Optional[torch.Tensor]) -> int:
     if a_amax is None:
         a_amax = absmax([a])
     elif a_amax.numel() != AMAX_WORDS:
-        raise _lib.GpsHipError("a_amax: one max|.| record (int32 [8])")
+        raise _lib.GpsHipError("a_amax: one max|.| record (int32 [512])")
     return a_amax.data_ptr()
 
 

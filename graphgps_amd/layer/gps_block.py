@@ -330,7 +330,7 @@ def _grouped_param_grads(L, pairs, params=(), targets=None, words=None):
     (main stream when ``params`` already hold gradients: see ``_accumulating``).
     ``targets`` = [(weight, bias), ...] the (stacked) parameters the results belong to: when they live in an optimizer
     arena and nothing is being accumulated the kernel writes straight into their gradient slots (optim.grad_slot).
-    ``words`` = [(max|g| record, max|x| record), ...] (int32 [8] tensors, gemm.absmax): the fp16 form of the contraction."""
+    ``words`` = [(max|g| record, max|x| record), ...] (int32 [512] tensors, gemm.absmax): the fp16 form of the contraction."""
     dev = pairs[0][0].device
     n = len(pairs)
     direct = targets is not None and not _accumulating(params)

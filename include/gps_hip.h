@@ -248,16 +248,19 @@ int gps_gemm_panel_stats(const float* A, int64_t lda, int64_t M, int K, const ui
  * 22 significant bits) and a*b is formed from 3 piece products on v_mfma_f32_32x32x16_f16 with fp32 accumulation --
  * half the matrix-pipe work of the 6-product form; measured / emulated error against fp64 at or below the 6-product
  * form's (fewer roundings into the accumulator), both below an fp32 library GEMM.  The scale of an operand TENSOR is
- * derived from max|v|, which travels as a device RECORD of GPS_AMAX_WORDS (8) uint32 words holding fp32 bit patterns: the
- * maximum is the unsigned maximum of the words (order-free, deterministic); producers raise one word per workgroup
- * atomically (eight addresses, so a thousand-workgroup producer does not queue on one).  Every `*_amax` / `slot` /
- * `amax*` pointer of this header addresses such a record: zero at allocation, only ever raised.
+ * derived from max|v|, which travels as a device RECORD: GPS_AMAX_WORDS (8) uint32 words holding fp32 bit patterns,
+ * GPS_AMAX_STRIDE (64) words apart -- a footprint of GPS_AMAX_RECORD_WORDS (512) words, the rest unused.  The maximum is
+ * the unsigned maximum of the eight words (order-free, deterministic); producers raise one of them per workgroup or
+ * wavefront atomically (eight different cache lines: atomics on one line serialise at ~6 ns each).  Every `*_amax` /
+ * `slot` / `amax*` pointer of this header addresses such a record: zero at allocation, only ever raised.
  *   gps_absmax          max over up to 56 row-major matrices per launch: record = max(record, max|A|) (the caller
  *                       zeroes the records once; several matrices may share a record)
  *   gps_gemm16_split_weights   image [2 pieces][ceil(K/32)][N'][32] fp16 of each weight under the scale of its `amax` word
  *   gps_gemm16_panel(_stats)   as gps_gemm_panel(_stats) with `a_amax` (>= max|A|) and `w_amax` (the word the image was
  *                       made with).  A word LARGER than the true maximum only costs precision (one bit per factor 2). */
 #define GPS_AMAX_WORDS 8
+#define GPS_AMAX_STRIDE 64
+#define GPS_AMAX_RECORD_WORDS (GPS_AMAX_WORDS * GPS_AMAX_STRIDE)
 typedef struct gps_absmax_desc {
   const float* A;      /* [rows][cols] fp32, row stride ld (floats); cols % 4 == 0, 16-byte aligned rows */
   int64_t ld, rows;

@@ -850,7 +850,7 @@ def test_gemm16_operand_scales(mag):
     a[5] = 0.0
     w = torch.randn(N, K, generator=gen) / K ** 0.5 * (1.0 / mag if 1e-20 < mag < 1e20 else 1.0)
     ag, wg = a.to(dev), w.to(dev)
-    words = _g.absmax([ag, wg, ag[:, :128]])            # [3, 8] records: the maximum is the max over a row
+    words = _g.absmax([ag, wg, ag[:, :128]])            # [3, 512] records: the maximum is the max over a row
     want = torch.stack([ag.abs().max(), wg.abs().max(), ag[:, :128].abs().max()]).view(torch.int32)
     assert torch.equal(words.max(dim=1).values.cpu(), want.cpu())
     assert _g.amax_value(words[1]) == float(wg.abs().max())

@@ -41,7 +41,7 @@ if __name__ == "__main__":
         tp = bench.time_kernel(lambda i: gemm_panel(A[i], img, N, bias=b, out=C[i]), iters=40, nsets=nset)
         th = bench.time_kernel(lambda i: gemm_panel(A[i], img16, N, bias=b, out=C[i], a_amax=words[i]), iters=40,
                                nsets=nset)
-        wz = torch.zeros(nset, 8, dtype=torch.int32, device=dev)     # (words only ever rise: re-raising them costs the same pass)
+        wz = torch.zeros(nset, 512, dtype=torch.int32, device=dev)     # (words only ever rise: re-raising them costs the same pass)
         ta = bench.time_kernel(lambda i: absmax([A[i]], out=wz[i:i + 1]), iters=40, nsets=nset)
         gf = 2.0 * M * K * N / 1e9
         tot_t += tt
