@@ -312,12 +312,22 @@ def kernel_rooflines(dev, profile, nb, d=384, H=16, in_step=None, layers=10, onl
         q.g, q.x, q.gw, q.gb = g_.data_ptr(), x_.data_ptr(), gw.data_ptr(), gb.data_ptr()
         q.ldg, q.ldx, q.R, q.M, q.Nn = g_.stride(0), x_.stride(0), g_.shape[0], g_.shape[1], x_.shape[1]
     wws = torch.empty(max(L.gps_wgrad_grouped_workspace_floats(len(pairs), probs), 4), device=dev)
-    SPLIT_NOTE = ("flops = the bf16 MFMA flops issued: 6 piece products per fp32 product (exact 3-way split, "
-                  "hh hm mh hl lh mm), against the dense bf16 MFMA peak; fp32-equivalent rate = achieved / 6")
-    entry("wgrad_grouped", lambda i=0: check(L.gps_wgrad_grouped(len(pairs), probs, ptr(wws), current_stream(dev))), 1,
-          "mfma_bf16", 6 * sum(2.0 * R * k * n for R, k, n in shapes), 2, ("k_wgrad",), note=SPLIT_NOTE)
-    # the projection GEMMs of one block through the ring kernel (csrc/gemm_panel.hip): forward five, input-gradient five
     from graphgps_amd import gemm as _gemm
+    f16 = bool(_gemm.F16)
+    NPROD = 3 if f16 else 6         # piece products per fp32 product: 2 x fp16 / 3 products (round 4) or 3 x bf16 / 6
+    if f16:                         # the operands' max|.| records, made once (in the step their producers make them)
+        wrec = _gemm.absmax([t_ for pr in pairs for t_ in pr])
+        keep.append(wrec)
+        for j, q in enumerate(probs):
+            q.g_amax, q.x_amax = wrec[2 * j].data_ptr(), wrec[2 * j + 1].data_ptr()
+    SPLIT_NOTE = (("flops = the fp16 MFMA flops issued: 3 piece products per fp32 product (two fp16 pieces per value "
+                   "under a per-tensor power-of-two scale: lo*hi, hi*lo, hi*hi), against the dense fp16 / bf16 MFMA peak; "
+                   "fp32-equivalent rate = achieved / 3") if f16 else
+                  ("flops = the bf16 MFMA flops issued: 6 piece products per fp32 product (exact 3-way split, "
+                   "hh hm mh hl lh mm), against the dense bf16 MFMA peak; fp32-equivalent rate = achieved / 6"))
+    entry("wgrad_grouped", lambda i=0: check(L.gps_wgrad_grouped(len(pairs), probs, ptr(wws), current_stream(dev))), 1,
+          "mfma_bf16", NPROD * sum(2.0 * R * k * n for R, k, n in shapes), 2, ("k_wgrad",), note=SPLIT_NOTE)
+    # the projection GEMMs of one block through the ring kernel (csrc/gemm_panel.hip): forward five, input-gradient five
     if _gemm.supported(d, d):
         ws_ = [f(n, k) for _, k, n in shapes]
         imgs = _gemm.split_weights(ws_)
@@ -325,13 +335,15 @@ def kernel_rooflines(dev, profile, nb, d=384, H=16, in_step=None, layers=10, onl
         gs_ = [f(R, n) for R, _, n in shapes]
         ys_ = [torch.empty(R, n, device=dev) for R, _, n in shapes]
         dx_ = [torch.empty(R, k, device=dev) for R, k, _ in shapes]
+        xrec = _gemm.absmax(xs_) if f16 else [None] * len(xs_)
+        grec = _gemm.absmax(gs_) if f16 else [None] * len(gs_)
         def fwd5(i=0):
-            for x_, (nt, _), y_, (_, _, n) in zip(xs_, imgs, ys_, shapes):
-                _gemm.gemm_panel(x_, nt, n, out=y_)
+            for x_, (nt, _), y_, (_, _, n), r_ in zip(xs_, imgs, ys_, shapes, xrec):
+                _gemm.gemm_panel(x_, nt, n, out=y_, a_amax=r_)
         def dgrad5(i=0):
-            for g_, (_, tn), o_, (_, k, _) in zip(gs_, imgs, dx_, shapes):
-                _gemm.gemm_panel(g_, tn, k, out=o_)
-        fl = 6 * sum(2.0 * R * k * n for R, k, n in shapes)
+            for g_, (_, tn), o_, (_, k, _), r_ in zip(gs_, imgs, dx_, shapes, grec):
+                _gemm.gemm_panel(g_, tn, k, out=o_, a_amax=r_)
+        fl = NPROD * sum(2.0 * R * k * n for R, k, n in shapes)
         entry("gemm_fwd_block", fwd5, 1, "mfma_bf16", fl, 5, (), note=SPLIT_NOTE + "; isolated only (one kernel name serves every shape)")
         entry("gemm_dgrad_block", dgrad5, 1, "mfma_bf16", fl, 5, (), note=SPLIT_NOTE + "; isolated only")
     return res, dict(N=N, E=E, d=d, H=H, sum_n2=s2, rotation_sets=dict(gatedgcn=n_rot, attention=a_rot))

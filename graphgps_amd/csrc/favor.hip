@@ -54,22 +54,22 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
-// 16 contiguous floats of `row` starting at column 16*grp (zero if !ok), scaled.
+// 16 contiguous floats of a row starting at column 16*grp (zero if !ok), scaled.  `p` must be a VALID address whatever
+// `ok` is (callers clamp the row index): the loads are unconditional and the zeros come from the scale -- a load under a
+// condition compiles to a branch around it, which serialises the issue of the row's four loads and of whatever follows
+// (round 4, GPS_FAVOR A/B in DESIGN 4.5).
 __device__ __forceinline__ void load_row16(const float* __restrict__ p, bool ok, float scale,
                                            float (&dst)[KPL]) {
-  if (ok) {
-    const float4* q = reinterpret_cast<const float4*>(p);
+  const float4* q = reinterpret_cast<const float4*>(p);
+  const float sc = ok ? scale : 0.0f;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const float4 v = q[s];
-      dst[4 * s + 0] = v.x * scale; dst[4 * s + 1] = v.y * scale;
-      dst[4 * s + 2] = v.z * scale; dst[4 * s + 3] = v.w * scale;
-    }
-  } else {
-#pragma unroll
-    for (int s = 0; s < KPL; ++s) dst[s] = 0.0f;
+  for (int s = 0; s < 4; ++s) {
+    const float4 v = q[s];
+    dst[4 * s + 0] = v.x * sc; dst[4 * s + 1] = v.y * sc;
+    dst[4 * s + 2] = v.z * sc; dst[4 * s + 3] = v.w * sc;
   }
 }
+__device__ __forceinline__ int clampi(int v, int hi) { return v < hi ? v : hi; }
 __device__ __forceinline__ f32x4 mm_rows(const float (&a)[KPL], const float (&b)[KPL], f32x4 c) {
 #pragma unroll
   for (int s = 0; s < KPL; ++s) c = mfma16(a[s], b[s], c);
@@ -134,13 +134,13 @@ __global__ __launch_bounds__(256) void k_favor_kmax(
   const int inner = H * DH;
   const int krow = s.row0 + s.i;
   float kv[KPL];
-  load_row16(qkv + (int64_t)krow * ld + inner + s.h * DH + 16 * s.grp, krow < s.n1, c, kv);
+  load_row16(qkv + (int64_t)clampi(krow, s.n1 - 1) * ld + inner + s.h * DH + 16 * s.grp, krow < s.n1, c, kv);
   float best = -INFINITY;
   uint32_t best_idx = 0;
   for (int mt = 0; mt < MT; ++mt) {
     const int prow = mt * 16 + s.i;
     float pv[KPL];
-    load_row16(P + (int64_t)prow * DH + 16 * s.grp, prow < m, 1.0f, pv);
+    load_row16(P + (int64_t)clampi(prow, m - 1) * DH + 16 * s.grp, prow < m, 1.0f, pv);
     const f32x4 dd = mm_rows(pv, kv, zero4());  // [feature 4g+r][key l&15]
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -193,7 +193,7 @@ __global__ __launch_bounds__(256) void k_favor_ctx(
   const float M = key_max_M(kmax, gh, pad);
   const int f = mt * 16 + i;  // this lane's feature column
   float pv[KPL];
-  load_row16(P + (int64_t)f * DH + 16 * grp, f < m, 1.0f, pv);
+  load_row16(P + (int64_t)clampi(f, m - 1) * DH + 16 * grp, f < m, 1.0f, pv);
   f32x4 acc[4];
 #pragma unroll
   for (int et = 0; et < 4; ++et) acc[et] = zero4();
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(256) void k_favor_ctx(
   for (int kb = k0; kb < n1; kb += 16) {
     const int krow = kb + i;
     float kv[KPL];
-    load_row16(qkv + (int64_t)krow * ld + inner + h * DH + 16 * grp, krow < n1, c, kv);
+    load_row16(qkv + (int64_t)clampi(krow, n1 - 1) * ld + inner + h * DH + 16 * grp, krow < n1, c, kv);
     const float nrm = group_sum(sumsq16(kv));       // |c k|^2 of row (l&15)
     f32x4 dd = mm_rows(kv, pv, zero4());            // [key 4g+r][feature l&15]
     f32x4 phi;
@@ -218,7 +218,8 @@ __global__ __launch_bounds__(256) void k_favor_ctx(
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int key = kb + 4 * grp + r;
-        const float vv = key < n1 ? qkv[(int64_t)key * ld + 2 * inner + h * DH + et * 16 + i] : 0.0f;
+        // (clamped address; rows past the slice carry phi = 0, so their V value needs no select)
+        const float vv = qkv[(int64_t)clampi(key, n1 - 1) * ld + 2 * inner + h * DH + et * 16 + i];
         acc[et] = mfma16(vv, phi[r], acc[et]);      // ctx^T[e 4g+r'][feature l&15]
       }
   }
@@ -270,7 +271,7 @@ __device__ __forceinline__ void query_features(const float (&qv)[KPL], const flo
   for (int mt = 0; mt < MT; ++mt) {
     const int prow = mt * 16 + i;
     float pv[KPL];
-    load_row16(P + (int64_t)prow * DH + 16 * grp, prow < m, 1.0f, pv);
+    load_row16(P + (int64_t)clampi(prow, m - 1) * DH + 16 * grp, prow < m, 1.0f, pv);
     const f32x4 t = mm_rows(pv, qv, zero4());
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -297,7 +298,7 @@ __global__ __launch_bounds__(256) void k_favor_out(
   const int qrow = s.row0 + s.i;
   const bool q_ok = qrow < s.n1;
   float qv[KPL];
-  load_row16(qkv + (int64_t)qrow * ld + s.h * DH + 16 * s.grp, q_ok, c, qv);
+  load_row16(qkv + (int64_t)clampi(qrow, s.n1 - 1) * ld + s.h * DH + 16 * s.grp, q_ok, c, qv);
   const float half_nrm = 0.5f * group_sum(sumsq16(qv));
   float dd[MT][4];
   float mq;
@@ -315,14 +316,14 @@ __global__ __launch_bounds__(256) void k_favor_out(
       const int f = mt * 16 + 4 * s.grp + r;
       const float phi = f < m ? ratio * (expf(dd[mt][r] - half_nrm - mq) + FEPS) : 0.0f;
       dd[mt][r] = phi;
-      dpart += f < m ? phi * kbase[f] : 0.0f;
+      dpart += phi * kbase[clampi(f, m - 1)];          // (phi = 0 past m)
     }
 #pragma unroll
     for (int et = 0; et < 4; ++et)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int f = mt * 16 + 4 * s.grp + r;
-        const float cv = f < m ? cbase[(int64_t)f * DH + et * 16 + s.i] : 0.0f;
+        const float cv = cbase[(int64_t)clampi(f, m - 1) * DH + et * 16 + s.i];      // (dd = phi = 0 past m)
         acc[et] = mfma16(cv, dd[mt][r], acc[et]);   // num^T[e 4g+r'][query l&15]
       }
   }
@@ -382,12 +383,14 @@ __global__ __launch_bounds__(256) void k_favor_bwd_q(
   const int qrow = s.row0 + s.i;
   const bool q_ok = qrow < s.n1;
   float qv[KPL], gn[KPL];
-  load_row16(qkv + (int64_t)qrow * ld + s.h * DH + 16 * s.grp, q_ok, c, qv);
+  const int qrc = clampi(qrow, s.n1 - 1);             // (valid addresses; the row's results are dropped when !q_ok)
+  load_row16(qkv + (int64_t)qrc * ld + s.h * DH + 16 * s.grp, q_ok, c, qv);
   const float half_nrm = 0.5f * group_sum(sumsq16(qv));
-  float mq = q_ok ? mq_in[(int64_t)s.h * N + qrow] : 0.0f;
-  const float Dq = q_ok ? D_in[(int64_t)s.h * N + qrow] : 1.0f;
-  const float gDq = q_ok ? gD_in[(int64_t)s.h * N + qrow] : 0.0f;
-  load_row16(g_out + (int64_t)qrow * inner + s.h * DH + 16 * s.grp, q_ok, 1.0f / Dq, gn);  // g_num
+  const float mq_l = mq_in[(int64_t)s.h * N + qrc], D_l = D_in[(int64_t)s.h * N + qrc], gD_l = gD_in[(int64_t)s.h * N + qrc];
+  float mq = q_ok ? mq_l : 0.0f;
+  const float Dq = q_ok ? D_l : 1.0f;
+  const float gDq = q_ok ? gD_l : 0.0f;
+  load_row16(g_out + (int64_t)qrc * inner + s.h * DH + 16 * s.grp, q_ok, 1.0f / Dq, gn);  // g_num
   float dd[MT][4];
   query_features(qv, P, m, s.i, s.grp, dd, mq, true);
   const float* cbase = ctx + (int64_t)gh * 272 * DH;
@@ -398,16 +401,13 @@ __global__ __launch_bounds__(256) void k_favor_bwd_q(
   for (int mt = 0; mt < MT; ++mt) {
     const int crow = mt * 16 + s.i;
     float cv[KPL];
-    load_row16(cbase + (int64_t)crow * DH + 16 * s.grp, crow < m, 1.0f, cv);
+    load_row16(cbase + (int64_t)clampi(crow, m - 1) * DH + 16 * s.grp, crow < m, 1.0f, cv);
     const f32x4 gphi = mm_rows(cv, gn, zero4());   // [feature 4g+r][query]: sum_e ctx[f][e] g_num[q][e]
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int f = mt * 16 + 4 * s.grp + r;
-      float ga = 0.0f;
-      if (f < m) {
-        const float ex = ratio * expf(dd[mt][r] - half_nrm - mq);   // = phi - r*eps
-        ga = (gphi[r] + kbase[f] * gDq) * ex;
-      }
+      const float ex = ratio * expf(dd[mt][r] - half_nrm - mq);     // = phi - r*eps
+      const float ga = f < m ? (gphi[r] + kbase[clampi(f, m - 1)] * gDq) * ex : 0.0f;
       gA[mt][r] = ga;
       s1 += ga;
     }
@@ -429,7 +429,7 @@ __global__ __launch_bounds__(256) void k_favor_bwd_q(
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int f = mt * 16 + 4 * s.grp + r;
-        const float pv = f < m ? P[(int64_t)f * DH + dt * 16 + s.i] : 0.0f;
+        const float pv = P[(int64_t)clampi(f, m - 1) * DH + dt * 16 + s.i];      // (gA = 0 past m)
         acc[dt] = mfma16(pv, gA[mt][r], acc[dt]);   // g_q^T[dh 4g+r'][query]
       }
   }
@@ -475,7 +475,7 @@ __global__ __launch_bounds__(256) void k_favor_bwd_ctx(
   const int inner = H * DH;
   const int f = mt * 16 + i;
   float pv[KPL];
-  load_row16(P + (int64_t)f * DH + 16 * grp, f < m, 1.0f, pv);
+  load_row16(P + (int64_t)clampi(f, m - 1) * DH + 16 * grp, f < m, 1.0f, pv);
   f32x4 acc[4];
 #pragma unroll
   for (int et = 0; et < 4; ++et) acc[et] = zero4();
@@ -483,7 +483,7 @@ __global__ __launch_bounds__(256) void k_favor_bwd_ctx(
   for (int qb = n0; qb < n1; qb += 16) {
     const int qrow = qb + i;
     float qv[KPL];
-    load_row16(qkv + (int64_t)qrow * ld + h * DH + 16 * grp, qrow < n1, c, qv);
+    load_row16(qkv + (int64_t)clampi(qrow, n1 - 1) * ld + h * DH + 16 * grp, qrow < n1, c, qv);
     const float nrm = group_sum(sumsq16(qv));
     const f32x4 dd = mm_rows(qv, pv, zero4());     // [query 4g+r][feature l&15]
     f32x4 phi;
@@ -493,17 +493,18 @@ __global__ __launch_bounds__(256) void k_favor_bwd_ctx(
       const int qq = qb + 4 * grp + r;
       const bool ok = qq < n1 && f < m;
       const float dg = 0.5f * __shfl(nrm, 4 * grp + r);
-      const float mqv = qq < n1 ? mq_in[(int64_t)h * N + qq] : 0.0f;
+      const int64_t qi = (int64_t)h * N + clampi(qq, n1 - 1);      // valid address; masked by `ok` / `qq < n1` below
+      const float mqv = mq_in[qi], Dv = D_in[qi], gDv = gD_in[qi];
       phi[r] = ok ? ratio * (expf(dd[r] - dg - mqv) + FEPS) : 0.0f;
-      invD[r] = qq < n1 ? 1.0f / D_in[(int64_t)h * N + qq] : 0.0f;
-      gks += qq < n1 ? gD_in[(int64_t)h * N + qq] * phi[r] : 0.0f;
+      invD[r] = qq < n1 ? 1.0f / Dv : 0.0f;
+      gks += gDv * phi[r];                                         // (phi = 0 past the slice)
     }
 #pragma unroll
     for (int et = 0; et < 4; ++et)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int qq = qb + 4 * grp + r;
-        const float gv = qq < n1 ? g_out[(int64_t)qq * inner + h * DH + et * 16 + i] * invD[r] : 0.0f;
+        const float gv = g_out[(int64_t)clampi(qq, n1 - 1) * inner + h * DH + et * 16 + i] * invD[r];   // (invD = 0 past the slice)
         acc[et] = mfma16(gv, phi[r], acc[et]);     // g_ctx^T[e 4g+r'][feature l&15]
       }
   }
@@ -541,8 +542,9 @@ __global__ __launch_bounds__(256) void k_favor_bwd_k(
   const int pad = nmax_dev[0] - (s.n1 - s.n0);
   const float M = key_max_M(kmax, gh, pad);
   float kv[KPL], vv[KPL];
-  load_row16(qkv + (int64_t)krow * ld + inner + s.h * DH + 16 * s.grp, k_ok, c, kv);
-  load_row16(qkv + (int64_t)krow * ld + 2 * inner + s.h * DH + 16 * s.grp, k_ok, 1.0f, vv);
+  const int krc = clampi(krow, s.n1 - 1);
+  load_row16(qkv + (int64_t)krc * ld + inner + s.h * DH + 16 * s.grp, k_ok, c, kv);
+  load_row16(qkv + (int64_t)krc * ld + 2 * inner + s.h * DH + 16 * s.grp, k_ok, 1.0f, vv);
   const float half_nrm = 0.5f * group_sum(sumsq16(kv));
   const float* gcb = g_ctx + (int64_t)gh * 272 * DH;
   const float* gkb = g_ksum + (int64_t)gh * 272;
@@ -553,8 +555,8 @@ __global__ __launch_bounds__(256) void k_favor_bwd_k(
   for (int mt = 0; mt < MT; ++mt) {
     const int prow = mt * 16 + s.i;
     float pv[KPL], gc[KPL];
-    load_row16(P + (int64_t)prow * DH + 16 * s.grp, prow < m, 1.0f, pv);
-    load_row16(gcb + (int64_t)prow * DH + 16 * s.grp, prow < m, 1.0f, gc);
+    load_row16(P + (int64_t)clampi(prow, m - 1) * DH + 16 * s.grp, prow < m, 1.0f, pv);
+    load_row16(gcb + (int64_t)clampi(prow, m - 1) * DH + 16 * s.grp, prow < m, 1.0f, gc);
     const f32x4 dd = mm_rows(pv, kv, zero4());     // [feature 4g+r][key l&15]
     const f32x4 gphi = mm_rows(gc, vv, zero4());   // sum_e g_ctx[f][e] v[key][e]
     f32x4 phi, gB;
@@ -564,7 +566,7 @@ __global__ __launch_bounds__(256) void k_favor_bwd_k(
       const bool ok = f < m && k_ok;
       const float ex = ok ? ratio * expf(dd[r] - half_nrm - M) : 0.0f;
       phi[r] = ok ? ex + ratio * FEPS : 0.0f;
-      gB[r] = ok ? (gphi[r] + gkb[f]) * ex : 0.0f;
+      gB[r] = (gphi[r] + gkb[clampi(f, m - 1)]) * ex;        // (ex = 0 when !ok)
       sk += gB[r];
     }
 #pragma unroll
@@ -572,8 +574,9 @@ __global__ __launch_bounds__(256) void k_favor_bwd_k(
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int f = mt * 16 + 4 * s.grp + r;
-        const float pe = f < m ? P[(int64_t)f * DH + t * 16 + s.i] : 0.0f;
-        const float ge = f < m ? gcb[(int64_t)f * DH + t * 16 + s.i] : 0.0f;
+        const int fc = clampi(f, m - 1);               // (gB = phi = 0 past m)
+        const float pe = P[(int64_t)fc * DH + t * 16 + s.i];
+        const float ge = gcb[(int64_t)fc * DH + t * 16 + s.i];
         accK[t] = mfma16(pe, gB[r], accK[t]);      // g_k^T[dh][key] += P^T[dh][f] g_B[f][key]
         accV[t] = mfma16(ge, phi[r], accV[t]);     // g_v^T[e][key]  += g_ctx^T[e][f] phi_k^T[f][key]
       }

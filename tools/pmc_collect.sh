@@ -12,7 +12,7 @@ for grp in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE S
   rm -rf /tmp/pmc_$i
   timeout 600 rocprofv3 --kernel-trace --pmc $grp -d /tmp/pmc_$i -o probe -- python $ROOT/tools/kernel_probe.py > $ROOT/$OUT/pmc_$i.log 2>&1
   DB=$(find /tmp/pmc_$i -name "*.db" | head -1)
-  if [ -n "$DB" ]; then python $ROOT/tools/rocpd_pmc.py $DB --match "k_gatedgcn|k_sattn|k_attn|k_wgrad|k_gemm_panel|k_gemm_ring" > $ROOT/$OUT/pmc_$i.txt 2>&1; fi
+  if [ -n "$DB" ]; then python $ROOT/tools/rocpd_pmc.py $DB --match "k_gatedgcn|k_sattn|k_attn|k_wgrad|k_gemm_panel|k_gemm_ring|k_absmax" > $ROOT/$OUT/pmc_$i.txt 2>&1; fi
   rm -rf /tmp/pmc_$i
 done
 cd $ROOT

@@ -19,7 +19,7 @@ def main():
             if not m:
                 continue
             ctr, n, avg, name = m.group(1), int(m.group(2)), float(m.group(3)), m.group(4)
-            k = re.search(r"k_gemm_(?:panel|ring)<[^>]*>|k_\w+", name)
+            k = re.search(r"k_gemm_(?:panel|ring|ring16)<[^>]*>|k_wgrad_stream<[^>]*>|k_\w+", name)
             if not k:
                 continue
             ker.setdefault(k.group(0), {})[ctr] = avg
