@@ -158,16 +158,23 @@ class DeviceLoader:
                     continue
             return False
 
+        # The iterator is created HERE, on the consumer's thread: a DataLoader draws its base seed from the
+        # global CPU generator in __iter__, and drawn on the worker it would race whatever the training thread draws
+        # from the same generator (shuffle order no longer a function of the seed alone).
+        source = iter(self.loader)
+        failure = []
+
         def worker():
             try:
                 torch.cuda.set_device(self.device)
-                for host in self.loader:
+                for host in source:
                     with STAGE_LOCK:
                         item = self._stage(host, copy_stream)
                     if not put(item):
                         return
                 put(END)
-            except BaseException as exc:       # surfaced on the consumer's thread
+            except BaseException as exc:       # surfaced on the consumer's thread -- also when the consumer is leaving
+                failure.append(exc)            # (`put` gives up once `stop` is set: the exception would be dropped)
                 put(exc)
 
         th = threading.Thread(target=worker, name="gps-device-loader", daemon=True)
@@ -185,5 +192,24 @@ class DeviceLoader:
                 self._hand_over(batch, stream)
                 yield batch
         finally:
+            # Early exit (a `break` in the consumer, an exception): stop the worker, drain what it staged so that a
+            # blocked `put` returns, and close the source iterator (a DataLoader's workers shut down with it).  The
+            # worker is a daemon thread: if it is stuck inside the source's `next` for longer than the join below, it is
+            # left behind and ends with the process.
             stop.set()
+            while True:
+                try:
+                    q.get_nowait()
+                except queue.Empty:
+                    break
             th.join(timeout=5.0)
+            close = getattr(source, "close", None) or getattr(source, "_shutdown_workers", None)
+            if close is not None and not th.is_alive():
+                try:
+                    close()
+                except Exception:
+                    pass
+            if failure and not isinstance(failure[0], (GeneratorExit, StopIteration)):
+                import sys
+                if sys.exc_info()[0] is None:      # nothing else is propagating: do not swallow the worker's error
+                    raise failure[0]
