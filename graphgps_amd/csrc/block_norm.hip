@@ -117,6 +117,7 @@ struct FwdTask {
   Bn bn1, bn2;
   float* out;     // produced rows (nullptr: statistics only)
   uint32_t* amax; // max|out| word, or nullptr
+  const int32_t* rdev;   // padded batches: the number of REAL rows (device word; rows R_real .. R-1 are padding), or nullptr
   int64_t R;
   uint64_t seed;
   float p;
@@ -183,6 +184,9 @@ __device__ __forceinline__ bool run_fwd(const FwdTask& T, int d, int lb, uint64_
   const int c = (threadIdx.x - rsub * L) * 4;
   const int64_t row0 = (int64_t)lb * T.rpb;
   const int64_t row1 = min(T.R, row0 + T.rpb);
+  // Padded batches (round 4: a loader pads N / E up to a bucket so that a captured step can be replayed): rows at or past
+  // *rdev are computed and stored like any other row but never enter the statistics.
+  const int64_t rreal = T.rdev ? min((int64_t)*T.rdev, T.R) : T.R;
   const bool stats = T.has_stats != 0;
   const float inv_keep = DROP ? 1.0f / (1.0f - T.p) : 1.0f;
   Col c1, c2;
@@ -212,14 +216,17 @@ __device__ __forceinline__ bool run_fwd(const FwdTask& T, int d, int lb, uint64_
       const V4 v0 = eval_row<KIND, RELU, DROP>(T, i0, r, c, c1, c2, seed, inv_keep);
       const V4 v1 = eval_row<KIND, RELU, DROP>(T, i1, r + RS, c, c1, c2, seed, inv_keep);
       if (T.out) { v0.store(T.out + r * d + c); v1.store(T.out + (r + RS) * d + c); }
-      if (stats) { account(v0); account(v1); }
+      if (stats) {
+        if (r < rreal) account(v0);
+        if (r + RS < rreal) account(v1);
+      }
       mx = vmax4(vmax4(mx, v0), v1);
       i0 = n0; i1 = n1;
     }
     if (r < row1) {
       const V4 v0 = eval_row<KIND, RELU, DROP>(T, i0, r, c, c1, c2, seed, inv_keep);
       if (T.out) v0.store(T.out + r * d + c);
-      if (stats) account(v0);
+      if (stats && r < rreal) account(v0);
       mx = vmax4(mx, v0);
     }
   }
@@ -227,12 +234,14 @@ __device__ __forceinline__ bool run_fwd(const FwdTask& T, int d, int lb, uint64_
   if (!stats) return false;      // block-uniform
   reduce_rows<2>(s, lds, d, RS, rsub, c);
   if (rsub == 0) {
-    const float n = (float)(row1 - row0);
+    const int64_t nreal = min(row1, rreal) - row0;
+    const float n = nreal > 0 ? (float)nreal : 0.0f;        // a block of padding only: an empty record (count 0)
+    const float inv = n > 0.0f ? 1.0f / n : 0.0f;
     float* rec = T.tree.part + (int64_t)lb * 2 * d;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      tr::st_sc1(rec + c + j, k[j] + s[0][j] / n);
-      tr::st_sc1(rec + d + c + j, fmaxf(s[1][j] - s[0][j] * s[0][j] / n, 0.0f));
+      tr::st_sc1(rec + c + j, n > 0.0f ? k[j] + s[0][j] * inv : 0.0f);
+      tr::st_sc1(rec + d + c + j, fmaxf(s[1][j] - s[0][j] * s[0][j] * inv, 0.0f));
     }
     if (c == 0) tr::st_sc1(T.tree.pcnt + lb, n);
   }
@@ -284,6 +293,7 @@ struct BwdTask {
   float* g_sum;          // dual: g_z + g_z2
   float* g_drop;         // dropmask(seed2, p2) of g_z (dual: of g_z2), or nullptr
   uint32_t* amax_drop;   // apply kernel: max|g_drop| word, or nullptr
+  const int32_t* rdev;   // padded batches: number of REAL rows (device word), or nullptr
   float p1x;             // dual only: dropout (p1x, seed1x) applied to the STORED g_z (g_sum stays unmasked)
   uint64_t seed1x;
   int64_t R;
@@ -411,11 +421,12 @@ struct ApplyCtx {
 // one row of an apply task: stores the gradients, returns the primary one (input of the chain)
 template <bool RELU, bool DROP, bool DUAL>
 __device__ __forceinline__ V4 apply_row(const BwdTask& T, const ApplyCtx& A, int d, int64_t row, int c, const V4& v,
-                                        const V4& gy, const V4& v2, float& dmx) {
+                                        const V4& gy, const V4& v2, float& dmx, float gate) {
   V4 g, zh, o;
   out_grad<RELU, DROP>(v, gy, A.c1, DROP ? row_hash((uint32_t)row, A.seed) : 0u, c, T.p, A.inv_keep, g, zh);
 #pragma unroll
-  for (int j = 0; j < 4; ++j) o[j] = A.c1.ga[j] * A.c1.rs[j] * (g[j] - A.s1[j] * A.inv_n - zh[j] * A.s2[j] * A.inv_n);
+  for (int j = 0; j < 4; ++j)      // gate = 0 on the padding rows of a padded batch (1 everywhere else)
+    o[j] = gate * (A.c1.ga[j] * A.c1.rs[j] * (g[j] - A.s1[j] * A.inv_n - zh[j] * A.s2[j] * A.inv_n));
   if (DUAL && T.p1x > 0.0f) {
     const uint32_t rh1 = row_hash((uint32_t)row, A.seed1x);
     V4 om;
@@ -431,7 +442,7 @@ __device__ __forceinline__ V4 apply_row(const BwdTask& T, const ApplyCtx& A, int
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const float zh2 = (v2[j] - A.c2.mu[j]) * A.c2.rs[j];
-      o2[j] = A.c2.ga[j] * A.c2.rs[j] * (g[j] - A.s1[j] * A.inv_n - zh2 * A.s3[j] * A.inv_n);
+      o2[j] = gate * (A.c2.ga[j] * A.c2.rs[j] * (g[j] - A.s1[j] * A.inv_n - zh2 * A.s3[j] * A.inv_n));
       sum[j] = o[j] + o2[j];
     }
     if (T.g_sum) sum.store(T.g_sum + row * d + c);
@@ -466,7 +477,12 @@ __device__ __forceinline__ void run_bwd_apply(const BwdTask& T, int d, int lb, c
   A.s2 = V4::load(T.g_gamma + c);
   A.s3 = DUAL ? V4::load(T.g_gamma2 + c) : V4::zero();
   A.inv_keep = DROP ? 1.0f / (1.0f - T.p) : 1.0f;
-  A.inv_n = 1.0f / (float)T.R;
+  // Padded batches: the statistics were taken over the real rows, so 1/R is 1/R_real, and the padding rows' gradients are
+  // forced to zero HERE -- a zero output gradient does not give a zero input gradient through BatchNorm
+  // (- mean(g) - zhat mean(g zhat)), and every contraction over rows downstream (weight gradients, column sums) relies on
+  // padding rows being exactly zero.
+  const int64_t rreal = T.rdev ? min((int64_t)*T.rdev, T.R) : T.R;
+  A.inv_n = 1.0f / (float)rreal;
   A.ik1 = T.p1x > 0.0f ? 1.0f / (1.0f - T.p1x) : 1.0f;
   A.ik2 = T.p2 > 0.0f ? 1.0f / (1.0f - T.p2) : 1.0f;
   A.cik = CHAIN && T.cp > 0.0f ? 1.0f / (1.0f - T.cp) : 1.0f;
@@ -504,7 +520,7 @@ __device__ __forceinline__ void run_bwd_apply(const BwdTask& T, int d, int lb, c
     In a = ld(r);           // BatchNorms + their sums) leave no room for more rows in flight at a useful occupancy
     for (; r < row1; r += RS) {
       const In na = ld(min(r + RS, rl));
-      const V4 oa = apply_row<RELU, DROP, DUAL>(T, A, d, r, c, a.v, a.g, a.w, dmx);
+      const V4 oa = apply_row<RELU, DROP, DUAL>(T, A, d, r, c, a.v, a.g, a.w, dmx, r < rreal ? 1.0f : 0.0f);
       if (CHAIN) chain(r, oa, a.cz);
       a = na;
     }
@@ -668,6 +684,7 @@ int gps_norm_fwd(int n, const gps_norm_fwd_task* tasks, int d, float* ws, size_t
     }
     T.out = S.out; T.R = S.R; T.seed = S.seed;
     T.amax = S.out ? S.amax : nullptr;
+    T.rdev = S.rdev;
     T.p = (S.kind == K_ADD_DROP || S.kind == K_BN_ACT) ? S.p : 0.f;
     T.kind = S.kind; T.relu = S.relu;
     T.rpb = rows_per_block(S.R); T.nblk = nblocks_for(S.R);
@@ -711,6 +728,7 @@ static int fill_bwd(const char* who, int n, const gps_norm_bwd_task* tasks, int 
     T.g_z = S.g_z; T.g_sum = S.g_sum; T.g_drop = S.g_drop;
     T.p1x = S.z2 ? S.p1x : 0.f; T.seed1x = S.seed1x;
     T.R = S.R; T.seed = S.seed; T.seed2 = S.seed2; T.p = S.p; T.p2 = S.p2; T.relu = S.relu;
+    T.rdev = S.rdev;
     T.rpb = rows_per_block(S.R); T.nblk = nblocks_for(S.R);
     T.block_begin = blocks;
     blocks += T.nblk;

@@ -196,6 +196,8 @@ struct PanelArgs {
   const uint32_t* a_amax;
   const uint32_t* w_amax;
   uint32_t* c_amax;        // optional: raised to max|C| over the stored elements (the word of the NEXT GEMM that reads C)
+  const int32_t* m_dev;    // epilogue 3, padded batches: the number of REAL rows (device word; rows past it are stored but kept
+                           // out of the column statistics), or nullptr
 };
 
 // Epilogue shared by both kernels.  D[row = (q&3) + 8*(q>>2) + 4*kh][col = li] of each 32 x 32 block; 32 lanes = 128
@@ -429,6 +431,7 @@ __device__ __forceinline__ void ring_store(const PanelArgs& P, const f32x16 (&ac
   const uint64_t seed = gps::salted_seed(P.seed, P.salt);
   const bool drop = EPI != 0 && P.p_drop > 0.0f;
   const float inv_keep = drop ? 1.0f / (1.0f - P.p_drop) : 1.0f;
+  const int64_t mreal = (EPI == 3 && P.m_dev) ? min((int64_t)*P.m_dev, P.M) : P.M;
   float bv[NJ];
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {         // never null here: the host passes g_zero_bias
@@ -474,7 +477,7 @@ __device__ __forceinline__ void ring_store(const PanelArgs& P, const f32x16 (&ac
         if (EPI == 3) {                 // the residual is NOT dropped: C = Cin + dropout(product)
           if (HAS_CIN) v += cin[j][q];
           if (mb == 0 && q == 0) sk[j] = __shfl(v, li);      // row 0 of the wave's row range sits in lane li (kh = 0)
-          const float t = (FULL || row < P.M) ? v - sk[j] : 0.0f;
+          const float t = row < mreal ? v - sk[j] : 0.0f;     // (mreal <= M: also the ragged last tile's guard)
           s1[j] += t;
           s2[j] += t * t;
         }
@@ -504,7 +507,8 @@ __device__ __forceinline__ void ring_stats(const PanelArgs& P, int rt, int panel
   constexpr int TN = 64 * NJ;                         // (shadows the 192-column constant of the register-staged kernel)
   constexpr int ROWS = 32 * MB;                       // rows per wave
   __syncthreads();      // every wave is past its final vmcnt(0): no LDS-DMA of the main loop can still land in the ring
-  const int64_t left = P.M - (m0 + (int64_t)wm * ROWS);
+  const int64_t mreal = P.m_dev ? min((int64_t)*P.m_dev, P.M) : P.M;       // padded batches: real rows only
+  const int64_t left = mreal - (m0 + (int64_t)wm * ROWS);
   const float nw = left <= 0 ? 0.0f : (left < ROWS ? (float)left : (float)ROWS);
   float* rec = lds + 16;                              // [2 row-waves][2][TN]
 #pragma unroll
@@ -533,12 +537,12 @@ __device__ __forceinline__ void ring_stats(const PanelArgs& P, int rt, int panel
   T.o2 = P.st_rmean ? P.st_rmean + n0 : nullptr; T.o3 = P.st_rvar ? P.st_rvar + n0 : nullptr;
   T.eps = P.st_eps; T.momentum = P.st_mom;
   const int t = threadIdx.x;
-  const int64_t l0 = P.M - m0;                        // rows of this tile that exist
-  const float n0w = l0 < ROWS ? (float)l0 : (float)ROWS;
+  const int64_t l0 = mreal - m0;                      // (real) rows of this tile that exist; <= 0: a tile of padding only
+  const float n0w = l0 <= 0 ? 0.0f : (l0 < ROWS ? (float)l0 : (float)ROWS);
   const float n1w = l0 <= ROWS ? 0.0f : (l0 < 2 * ROWS ? (float)(l0 - ROWS) : (float)ROWS);
   if (t < TN) {
     const float ma = rec[0 * TN + t], qa = rec[1 * TN + t], mb_ = rec[2 * TN + t], qb = rec[3 * TN + t];
-    const float nn = n0w + n1w, dl = mb_ - ma, wgt = n1w / nn;
+    const float nn = n0w + n1w, dl = mb_ - ma, wgt = nn > 0.0f ? n1w / nn : 0.0f;
     tr::st_sc1(T.part + ((int64_t)rt * 2 + 0) * TN + t, ma + dl * wgt);
     tr::st_sc1(T.part + ((int64_t)rt * 2 + 1) * TN + t, qa + qb + dl * dl * n0w * wgt);
     if (t == 0) tr::st_sc1(T.pcnt + rt, nn);
@@ -1165,7 +1169,7 @@ static int panel_launch(const float* A, int64_t lda, int64_t M, int K, const uin
                         const float* Cin, int64_t ldcin, float* C, int64_t ldc, int epilogue, const float* mask_src,
                         int64_t ldmask, float p_drop, uint64_t seed, const gps_bn* stats, float* ws, size_t ws_floats,
                         uint32_t* sync, gps_stream_t stream, const uint32_t* a_amax = nullptr, const uint32_t* w_amax = nullptr,
-                        uint32_t* c_amax = nullptr);
+                        uint32_t* c_amax = nullptr, const int32_t* m_dev = nullptr);
 
 // 128-row panels (MB = 2) when they still give every CU a workgroup; 64-column panels always use 64 rows (the only
 // NJ = 1 instantiation).  GPS_GEMM_RING_MB = 1 / 2 forces one.
@@ -1308,7 +1312,7 @@ int gps_gemm16_panel(const float* A, int64_t lda, int64_t M, int K, const uint32
 int gps_gemm16_panel_stats(const float* A, int64_t lda, int64_t M, int K, const uint32_t* a_amax, const uint16_t* image,
                            const uint32_t* w_amax, int N, const float* bias, const float* Cin, int64_t ldcin, float* C,
                            int64_t ldc, float p_drop, uint64_t seed, const gps_bn* stats, float* ws, size_t ws_floats,
-                           uint32_t* sync, gps_stream_t stream) {
+                           uint32_t* sync, const int32_t* m_dev, gps_stream_t stream) {
   GPS_REQUIRE(gps_gemm_stats_supported(M, N, K), "gps_gemm16_panel_stats: shape M=%lld N=%d K=%d not served by the ring kernel",
               (long long)M, N, K);
   GPS_REQUIRE(a_amax && w_amax, "gps_gemm16_panel_stats: operand maxima");
@@ -1316,7 +1320,7 @@ int gps_gemm16_panel_stats(const float* A, int64_t lda, int64_t M, int K, const 
   GPS_REQUIRE((stats->running_mean == nullptr) == (stats->running_var == nullptr), "gps_gemm16_panel_stats: running stats");
   GPS_REQUIRE(ws_floats >= gps_gemm_stats_floats(M, N, K), "gps_gemm16_panel_stats: workspace too small (gps_gemm_stats_floats)");
   return panel_launch(A, lda, M, K, image, N, bias, Cin, ldcin, C, ldc, 3, nullptr, 0, p_drop, seed, stats, ws, ws_floats, sync,
-                      stream, a_amax, w_amax);
+                      stream, a_amax, w_amax, nullptr, m_dev);
 }
 
 }  // extern "C"
@@ -1324,7 +1328,8 @@ int gps_gemm16_panel_stats(const float* A, int64_t lda, int64_t M, int K, const 
 static int panel_launch(const float* A, int64_t lda, int64_t M, int K, const uint16_t* image, int N, const float* bias,
                         const float* Cin, int64_t ldcin, float* C, int64_t ldc, int epilogue, const float* mask_src,
                         int64_t ldmask, float p_drop, uint64_t seed, const gps_bn* stats, float* ws, size_t ws_floats,
-                        uint32_t* sync, gps_stream_t stream, const uint32_t* a_amax, const uint32_t* w_amax, uint32_t* c_amax) {
+                        uint32_t* sync, gps_stream_t stream, const uint32_t* a_amax, const uint32_t* w_amax, uint32_t* c_amax,
+                        const int32_t* m_dev) {
   GPS_REQUIRE(M >= 0 && gps_gemm_panel_supported(N, K), "gps_gemm_panel: needs N %% 4 == 0 and K %% 4 == 0 (N=%d K=%d)",
               N, K);
   if (M == 0) return GPS_OK;
@@ -1338,7 +1343,7 @@ static int panel_launch(const float* A, int64_t lda, int64_t M, int K, const uin
   P.C = C; P.ldc = ldc; P.epilogue = epilogue; P.mask_src = mask_src; P.ldmask = ldmask;
   P.p_drop = epilogue ? p_drop : 0.0f; P.seed = seed; P.salt = gps::dropout_salt();
   P.trace = g_panel_trace;
-  P.a_amax = a_amax; P.w_amax = w_amax; P.c_amax = c_amax;
+  P.a_amax = a_amax; P.w_amax = w_amax; P.c_amax = c_amax; P.m_dev = epilogue == 3 ? m_dev : nullptr;
   const bool f16 = a_amax != nullptr;
   GPS_REQUIRE((a_amax == nullptr) == (w_amax == nullptr), "gps_gemm16_panel: both operand maxima or neither");
   hipStream_t s = gps::as_stream(stream);

@@ -115,7 +115,8 @@ def _a_word(a: torch.Tensor, a_amax: Optional[torch.Tensor]) -> int:
 
 
 def gemm_panel_stats(a: torch.Tensor, image, N: int, bias: Optional[torch.Tensor], addend: torch.Tensor,
-                     p_drop: float, seed: int, bn_desc, sync_ptr: int, a_amax: Optional[torch.Tensor] = None) -> torch.Tensor:
+                     p_drop: float, seed: int, bn_desc, sync_ptr: int, a_amax: Optional[torch.Tensor] = None,
+                     m_dev: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``out = addend + dropout(a @ B^T + bias; p_drop, seed)`` and the batch statistics of ``out`` over its rows
     (-> ``bn_desc.mean / rstd`` + running statistics), complete when the launch retires: the residual + dropout +
     statistics pass of ``norm1_attn`` / ``norm2`` (graphgps/layer/gps_layer.py:212-217,225-229) in the GEMM's epilogue.
@@ -131,9 +132,11 @@ def gemm_panel_stats(a: torch.Tensor, image, N: int, bias: Optional[torch.Tensor
     if getattr(image, "amax", None) is not None:
         check(L.gps_gemm16_panel_stats(ptr(a), a.stride(0), M, K, _a_word(a, a_amax), ptr(image), ptr(image.amax), N,
                                        ptr(bias), ptr(addend), addend.stride(0), ptr(out), out.stride(0), float(p_drop),
-                                       int(seed), ctypes.byref(bn_desc), ptr(ws), wsf, sync_ptr,
+                                       int(seed), ctypes.byref(bn_desc), ptr(ws), wsf, sync_ptr, ptr(m_dev),
                                        current_stream(a.device)), "gps_gemm16_panel_stats")
         return out
+    if m_dev is not None:
+        raise _lib.GpsHipError("gemm_panel_stats: padded batches (m_dev) need the fp16-form image")
     check(L.gps_gemm_panel_stats(ptr(a), a.stride(0), M, K, ptr(image), N, ptr(bias), ptr(addend), addend.stride(0),
                                  ptr(out), out.stride(0), float(p_drop), int(seed), ctypes.byref(bn_desc), ptr(ws), wsf,
                                  sync_ptr, current_stream(a.device)), "gps_gemm_panel_stats")

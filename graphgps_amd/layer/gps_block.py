@@ -516,6 +516,9 @@ class _GPSBlock(torch.autograd.Function):
         bn2 = _bn_desc(R.bn2, stats[8], stats[9])
         ref = _BY_REF
         sync = _norm.sync_arena(layer, dev)
+        rn, re_ = gi.n_real, gi.e_real       # padded batches: device words with the real row counts (else None)
+        if rn is not None and (_GG_STATS or not panel or imgs[0][0].amax is None):
+            raise _lib.GpsHipError("padded batches need the default block path (fp16-form ring GEMMs, GPS_GG_STATS=0)")
         gemm_stats = panel and _GEMM_STATS and _gemm.stats_supported(N, d, inner) and _gemm.stats_supported(N, d, 2 * d)
         # -- local branch: GatedGCN core ---------------------------------------------------------
         def local_half():
@@ -531,8 +534,8 @@ class _GPSBlock(torch.autograd.Function):
                 check(L.gps_gatedgcn_fwd(P, P + fs, P + 2 * fs, P + 3 * fs, ldp, ptr(ce), ptr(gi.rowptr_dst),
                                          ptr(gi.src_by_dst), ptr(gi.eid_by_dst), N, E, d, ptr(xt), ptr(eh),
                                          None, st), "gps_gatedgcn_fwd")
-                _norm.fwd([_norm.fwd_task(_norm.LOAD, xt, N, stats=bnx), _norm.fwd_task(_norm.LOAD, eh, E, stats=bne)],
-                          d, dev, sync.site(_S_XE))
+                _norm.fwd([_norm.fwd_task(_norm.LOAD, xt, N, stats=bnx, rdev=rn),
+                           _norm.fwd_task(_norm.LOAD, eh, E, stats=bne, rdev=re_)], d, dev, sync.site(_S_XE))
             return xt, eh
 
         # GPS_GG_FIRST=1 (single stream only): the GatedGCN core directly behind the merged projection that wrote its four
@@ -567,7 +570,7 @@ class _GPSBlock(torch.autograd.Function):
             if gemm_stats:      # za = x + drop(out_proj(o)) and the statistics of za (norm1_attn) in the GEMM's epilogue
                 ao = None
                 za = _gemm.gemm_panel_stats(o, imgs[2][0], d, _B(R.out_proj), x, p_l, s[3], bna, sync.site(_S_AO, _stats_words(L, d)),
-                                            a_amax=aw(2))
+                                            a_amax=aw(2), m_dev=rn)
             else:
                 za = None
                 ao = (_gemm.gemm_panel(o, imgs[2][0], d, bias=_B(R.out_proj), a_amax=aw(2)) if panel
@@ -579,12 +582,12 @@ class _GPSBlock(torch.autograd.Function):
         #    this launch needs nothing from the attention half and the join moves behind it (a cross-stream dependency
         #    costs ~10 us of queue latency in a replayed graph even when it is long satisfied; here it hides under this launch)
         x1, e1 = _E(N, d, **f32), _E(E, d, **f32)
-        mid = [_norm.fwd_task(_norm.BN_ACT, xt, N, res=x, bn1=bnx, relu=True, p=p, seed=s[0], out=x1, stats=bnl),
+        mid = [_norm.fwd_task(_norm.BN_ACT, xt, N, res=x, bn1=bnx, relu=True, p=p, seed=s[0], out=x1, stats=bnl, rdev=rn),
                _norm.fwd_task(_norm.BN_ACT, eh, E, res=e, bn1=bne, relu=True, p=p, seed=s[1], out=e1, amax=aw(6))]
         if za is None:
             fork.join(o, lse, ao)
             za = _E(N, d, **f32)
-            mid.append(_norm.fwd_task(_norm.ADD_DROP, x, N, b=ao, p=p_l, seed=s[3], out=za, stats=bna))
+            mid.append(_norm.fwd_task(_norm.ADD_DROP, x, N, b=ao, p=p_l, seed=s[3], out=za, stats=bna, rdev=rn))
         _norm.fwd(mid, d, dev, sync.site(_S_MID))
         if ao is None:
             fork.join(o, lse, za)
@@ -601,12 +604,12 @@ class _GPSBlock(torch.autograd.Function):
             t = _K.act_drop_add(L, None, f1, True, p_f1, s[4], st)
         if gemm_stats:  # z2 = h + drop(ff2(t)) and the statistics of z2 (norm2) in the GEMM's epilogue
             z2 = _gemm.gemm_panel_stats(t, imgs[4][0], d, _B(R.ff2), h, p_f2, s[5], bn2, sync.site(_S_Z2, _stats_words(L, d)),
-                                        a_amax=aw(4))
+                                        a_amax=aw(4), m_dev=rn)
         else:
             f2 = (_gemm.gemm_panel(t, imgs[4][0], d, bias=_B(R.ff2), a_amax=aw(4)) if panel
                   else torch.addmm(_B(R.ff2), t, _W(R.ff2).t()))
             z2 = _E(N, d, **f32)                                # h + drop(f2) and its statistics
-            _norm.fwd([_norm.fwd_task(_norm.ADD_DROP, h, N, b=f2, p=p_f2, seed=s[5], out=z2, stats=bn2)], d, dev,
+            _norm.fwd([_norm.fwd_task(_norm.ADD_DROP, h, N, b=f2, p=p_f2, seed=s[5], out=z2, stats=bn2, rdev=rn)], d, dev,
                       sync.site(_S_Z2))
         out = _E(N, d, **f32)
         _norm.fwd([_norm.fwd_task(_norm.BN_ACT, z2, N, bn1=bn2, out=out, amax=aw(5))], d, dev, None)
@@ -648,6 +651,7 @@ class _GPSBlock(torch.autograd.Function):
         bna = _bn_desc(R.bna, stats[6], stats[7])
         bn2 = _bn_desc(R.bn2, stats[8], stats[9])
         sync = _norm.sync_arena(layer, dev)
+        rn, re_ = gi.n_real, gi.e_real       # padded batches: 1/R_real and a zero gate on the padding rows in every apply
         gpar = _E(10, d, **f32)              # (g_gamma, g_beta) of the five norms ...
         g_bxw, g_bxb, g_bew, g_beb, g_nlw, g_nlb, g_naw, g_nab, g_n2w, g_n2b = gpar.unbind(0)
         if not _accumulating(R.params):      # ... or their slots in the optimizer's gradient arena
@@ -663,8 +667,8 @@ class _GPSBlock(torch.autograd.Function):
         bm = ctx.bm if imgs is not None else None       # fp16 form: records of g_f2, g_f1, g_ao (by their producers), g_pq, g_ce
         g_z2, g_f2, g_eh = _E(N, d, **f32), _E(N, d, **f32), _E(E, d, **f32)
         b1 = [_norm.bwd_task(z2, g_out, bn2, N, g_n2w, g_n2b, g_z=g_z2, g_drop=g_f2, p2=p_f2, seed2=s[5],
-                             amax_drop=None if bm is None else bm[0]),
-              _norm.bwd_task(eh, g_e1, bne, E, g_bew, g_beb, relu=True, p=p, seed=s[1], g_z=g_eh)]
+                             amax_drop=None if bm is None else bm[0], rdev=rn),
+              _norm.bwd_task(eh, g_e1, bne, E, g_bew, g_beb, relu=True, p=p, seed=s[1], g_z=g_eh, rdev=re_)]
         _norm.bwd_partial(b1, d, dev, sync.site(_S_B1))
         _norm.bwd_apply(b1, d, dev, None)
         # f2 = ff2(t);  t = drop(relu(f1));  f1 = ff1(h)
@@ -687,7 +691,7 @@ class _GPSBlock(torch.autograd.Function):
         b3 = [_norm.bwd_task(x1, g_h, bnl, N, g_nlw, g_nlb, z2=za, bn2=bna, g_gamma2=g_naw, g_beta2=g_nab,
                              g_z=g_x1, g_sum=g_xres, g_drop=g_ao, p2=p_l, seed2=s[3],
                              cz=xt, cbn=bnx, crelu=True, cp=p, cseed=s[0], cg_gamma=g_bxw, cg_beta=g_bxb,
-                             amax_drop=bw(2))]
+                             amax_drop=bw(2), rdev=rn)]
         _norm.bwd_partial(b3, d, dev, sync.site(_S_B3))
         _norm.bwd_apply(b3, d, dev, sync.site(_S_B4))
         # gradient of the merged projection: attention writes dq|dk|dv into columns 4d.., GatedGCN
@@ -719,7 +723,8 @@ class _GPSBlock(torch.autograd.Function):
 
         # x1 = x + drop(relu(BN_x(xt))):  bn_node_x's apply (its sums came from the chain above)
         g_xt = _E(N, d, **f32)
-        _norm.bwd_apply([_norm.bwd_task(xt, g_x1, bnx, N, g_bxw, g_bxb, relu=True, p=p, seed=s[0], g_z=g_xt)], d, dev, None)
+        _norm.bwd_apply([_norm.bwd_task(xt, g_x1, bnx, N, g_bxw, g_bxb, relu=True, p=p, seed=s[0], g_z=g_xt, rdev=rn)], d,
+                        dev, None)
         g_ce = _E(E, d, **f32)
         check(L.gps_gatedgcn_bwd(ptr(g_xt), d, ptr(g_eh), ptr(eh), P, P + fs, ldp, ptr(xt),
                                  ptr(gi.rowptr_dst), ptr(gi.src_by_dst), ptr(gi.eid_by_dst),

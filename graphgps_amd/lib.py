@@ -105,7 +105,7 @@ _SIGNATURES = {
     "gps_gemm16_panel": (c_int, [_P, c_int64, c_int64, c_int, _P, _P, _P, c_int, _P, _P, c_int64, _P, c_int64, c_int, _P,
                                  c_int64, c_float, c_uint64, _P, _P]),
     "gps_gemm16_panel_stats": (c_int, [_P, c_int64, c_int64, c_int, _P, _P, _P, c_int, _P, _P, c_int64, _P, c_int64,
-                                       c_float, c_uint64, _P, _P, c_size_t, _P, _P]),
+                                       c_float, c_uint64, _P, _P, c_size_t, _P, _P, _P]),
     "gps_gcn_dinv": (c_int, [_P, _P, c_int64, c_int64, _P, _P]),
     "gps_gcn_spmm": (c_int, [_P, c_int64, _P, _P, _P, c_int64, c_int64, c_int, _P, _P]),
     "gps_adj_sum": (c_int, [_P, c_int64, _P, _P, c_float, c_int64, c_int64, c_int, _P, _P]),

@@ -24,7 +24,7 @@ class FwdTask(ctypes.Structure):
     """``gps_norm_fwd_task`` (include/gps_hip.h)."""
     _fields_ = [("kind", c_int32), ("relu", c_int32), ("a", c_void_p), ("b", c_void_p), ("res", c_void_p),
                 ("bn1", c_void_p), ("bn2", c_void_p), ("p", c_float), ("seed", c_uint64), ("out", c_void_p),
-                ("R", c_int64), ("stats", c_void_p), ("amax", c_void_p)]
+                ("R", c_int64), ("stats", c_void_p), ("amax", c_void_p), ("rdev", c_void_p)]
 
 
 class BwdTask(ctypes.Structure):
@@ -35,7 +35,7 @@ class BwdTask(ctypes.Structure):
                 ("g_z", c_void_p), ("g_sum", c_void_p), ("g_drop", c_void_p),
                 ("p2", c_float), ("seed2", c_uint64), ("p1x", c_float), ("seed1x", c_uint64), ("R", c_int64),
                 ("cz", c_void_p), ("cbn", c_void_p), ("crelu", c_int32), ("cp", c_float), ("cseed", c_uint64),
-                ("cg_gamma", c_void_p), ("cg_beta", c_void_p), ("amax_drop", c_void_p)]
+                ("cg_gamma", c_void_p), ("cg_beta", c_void_p), ("amax_drop", c_void_p), ("rdev", c_void_p)]
 
 
 def _p(t):
@@ -55,21 +55,22 @@ def bn_desc(bn, mean, rstd) -> BnDesc:
 
 
 def fwd_task(kind, a, R, *, b=None, res=None, bn1=None, bn2=None, relu=False, p=0.0, seed=0, out=None, stats=None,
-             amax=None):
-    """Keeps the ``BnDesc`` objects it points to alive through ``._keep``.  ``amax`` (int32 [1]): raised to max|out|."""
+             amax=None, rdev=None):
+    """Keeps the ``BnDesc`` objects it points to alive through ``._keep``.  ``amax`` (a max|.| record): raised to max|out|;
+    ``rdev`` (int32 [1] on the device): the number of real rows of a padded batch."""
     t = FwdTask(kind, int(relu), _p(a), _p(b), _p(res), _bn(bn1), _bn(bn2), float(p), int(seed), _p(out), int(R),
-                _bn(stats), _p(amax))
+                _bn(stats), _p(amax), _p(rdev))
     t._keep = (bn1, bn2, stats)
     return t
 
 
 def bwd_task(z, g_y, bn, R, g_gamma, g_beta, *, relu=False, p=0.0, seed=0, z2=None, bn2=None, g_gamma2=None,
              g_beta2=None, g_z=None, g_sum=None, g_drop=None, p2=0.0, seed2=0, p1x=0.0, seed1x=0,
-             cz=None, cbn=None, crelu=False, cp=0.0, cseed=0, cg_gamma=None, cg_beta=None, amax_drop=None):
+             cz=None, cbn=None, crelu=False, cp=0.0, cseed=0, cg_gamma=None, cg_beta=None, amax_drop=None, rdev=None):
     t = BwdTask(_p(z), _p(g_y), _bn(bn), int(relu), float(p), int(seed), _p(z2), _bn(bn2),
                 _p(g_gamma), _p(g_beta), _p(g_gamma2), _p(g_beta2), _p(g_z), _p(g_sum), _p(g_drop),
                 float(p2), int(seed2), float(p1x), int(seed1x), int(R),
-                _p(cz), _bn(cbn), int(crelu), float(cp), int(cseed), _p(cg_gamma), _p(cg_beta), _p(amax_drop))
+                _p(cz), _bn(cbn), int(crelu), float(cp), int(cseed), _p(cg_gamma), _p(cg_beta), _p(amax_drop), _p(rdev))
     t._keep = (bn, bn2, cbn)
     return t
 

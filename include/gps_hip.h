@@ -285,7 +285,9 @@ int gps_gemm16_panel(const float* A, int64_t lda, int64_t M, int K, const uint32
 int gps_gemm16_panel_stats(const float* A, int64_t lda, int64_t M, int K, const uint32_t* a_amax, const uint16_t* image,
                            const uint32_t* w_amax, int N, const float* bias, const float* Cin, int64_t ldcin, float* C,
                            int64_t ldc, float p_drop, uint64_t seed, const gps_bn* stats, float* ws, size_t ws_floats,
-                           uint32_t* sync, gps_stream_t stream);
+                           uint32_t* sync, const int32_t* m_dev, gps_stream_t stream);
+/* m_dev (or NULL): padded batches -- device word with the number of REAL rows; rows past it are computed and stored but
+ * stay out of the column statistics (see gps_norm_fwd_task.rdev). */
 
 /* ---------------------------------------------------------------------------------------
  * Segment (per-graph, varlen) multi-head attention core on fp32 MFMA (v_mfma_f32_16x16x4_f32).
@@ -505,6 +507,8 @@ typedef struct gps_norm_fwd_task {
   int64_t R;
   const gps_bn* stats;        /* batch statistics of the produced rows -> stats->mean / rstd (+ running stats), or NULL */
   uint32_t* amax;             /* ABI v6: raised to max|out| (fp32 bit pattern; the word gps_gemm16_panel takes), or NULL */
+  const int32_t* rdev;        /* ABI v6, padded batches: device word holding the number of REAL rows r (rows r .. R-1 are
+                                 padding: produced like any row, excluded from the statistics), or NULL = all R rows */
 } gps_norm_fwd_task;
 /* One BatchNorm backward, y = dropout(relu?(BN(z)); p, seed) with g_y = dL/dy (masks recomputed from z and the hash):
  *   partial: g_beta = sum g, g_gamma = sum g * zhat          (g = g_y under the masks)
@@ -536,6 +540,8 @@ typedef struct gps_norm_bwd_task {
   uint64_t cseed;
   float *cg_gamma, *cg_beta;
   uint32_t* amax_drop;        /* ABI v6 (apply only): raised to max|g_drop|, or NULL */
+  const int32_t* rdev;        /* ABI v6, padded batches (apply only): number of REAL rows r = rdev[0]: 1/R becomes 1/r and the
+                                 padding rows' gradients are forced to zero; or NULL */
 } gps_norm_bwd_task;
 size_t gps_norm_tree_floats(int64_t R, int d);
 int gps_norm_sync_words(void);
