@@ -95,6 +95,10 @@ def parse_args():
     ap.add_argument("--no-kernel-roofline", action="store_true")
     ap.add_argument("--no-h2d-leg", action="store_true",
                     help="skip the secondary PCIe-inclusive measurement (host batches through DeviceLoader)")
+    ap.add_argument("--bucketed-leg", action="store_true",
+                    help="pcqm4m, 1 GPU: a third, secondary measurement after the timed region -- DIFFERENT host batches "
+                         "(a shuffled loader's never-repeating shapes) through DeviceLoader(pad=BucketPadding) and "
+                         "TrainStep.step_cached, i.e. what train_epoch does with GPS_LOADER_BUCKETS=1")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--cpu-threads", type=int, default=0,
                     help="torch threads for the CPU baseline (0 = min(usable cores, 32))")
@@ -475,6 +479,58 @@ def cpu_baseline(model, batch_cpu, compute_loss, clip_value, steps, threads=0):
                        + ", ".join(f"{l['cores']} threads = {l['value']:.1f} graphs/s" for l in legs))
 
 
+def bucketed_loader_leg(model, opt, loss_fn, nb, profile, dev, n_batches=24):
+    """Secondary, never `value`: the loader-fed step on batches that DIFFER in shape like a shuffled loader's
+    (custom_train.py:16-47 feeds every batch of the epoch through the same step): `n_batches` synthetic batches of
+    different structure, pinned on the host, through DeviceLoader(pad=BucketPadding()) -- padded up to shape buckets,
+    H2D copies + graph index staged ahead on a copy stream -- and TrainStep.step_cached, which replays a captured step
+    per bucket.  Pass 1 (untimed) meets the buckets (first sight eager, second sight captured), pass 2 (timed) runs the
+    same batches in another order.  Runs after the timed region: it cannot move `value`."""
+    try:
+        from graphgps_amd.loader import BucketPadding, DeviceLoader
+        from graphgps_amd.synthetic import model_batch
+        from graphgps_amd.train import TrainStep, padding_supported
+        if not padding_supported(model):
+            return {"skipped": "model not served by the padded path"}
+        host = []
+        for i in range(n_batches):
+            b = model_batch("pcqm4m", nb, seed=5000 + i, profile=profile)
+            for k, v in list(b.__dict__.items()):
+                if torch.is_tensor(v):
+                    b.__dict__[k] = v.pin_memory()
+            host.append(b)
+        raw_shapes = len({(b.x.shape[0], b.edge_index.shape[1]) for b in host})
+        pad = BucketPadding()
+        tsb = TrainStep(model, opt, loss_fn=loss_fn)
+        order2 = [host[(7 * i + 3) % n_batches] for i in range(n_batches)]
+        replays = rows = real = 0
+        for timed, seq in ((False, host + host), (True, order2)):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for b in DeviceLoader((q.shallow_copy() for q in seq), dev, pad=pad):
+                if timed:
+                    key = tsb._shape_key(b)
+                    replays += int(bool(tsb.__dict__.get("_shape_cache", {}).get(key)))
+                    rows += b.x.shape[0] + b.edge_index.shape[1]
+                    real += int(b.__dict__["_gps_meta"]["n_real"]) + int(b.__dict__["_gps_meta"]["e_real"])
+                tsb.step_cached(b, max_graphs=12)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / len(seq) * 1e3
+        cache = tsb.__dict__.get("_shape_cache", {})
+        out = {"ms_per_step": dt, "batches": n_batches, "distinct_raw_shapes": raw_shapes,
+               "shape_buckets": len(cache), "failed_captures": sum(1 for v in cache.values() if v is False),
+               "replayed_steps": replays, "padding_fraction": rows / max(real, 1) - 1.0,
+               "node_step": pad.node_step, "edge_step": pad.edge_step}
+        log(f"bucketed loader leg: {dt:.2f} ms/step over {n_batches} batches of {raw_shapes} raw shapes in "
+            f"{len(cache)} buckets, {replays} replayed, padding {out['padding_fraction'] * 100:.1f} %")
+        torch.cuda.synchronize()
+        del tsb
+        return out
+    except Exception as exc:        # a side measurement never takes the headline line with it
+        log(f"bucketed loader leg skipped ({type(exc).__name__}: {exc})")
+        return {"skipped": f"{type(exc).__name__}: {exc}"}
+
+
 def respawn_under_launcher(n):
     """`python bench.py --gpus N` (N > 1) without a launcher environment: re-execute under torch.distributed.run,
     one rank per GPU, rendezvous on 127.0.0.1 -- the command the driver itself uses."""
@@ -728,6 +784,9 @@ def main():
     host_enqueue_ms = min(host_ms)
     log(f"timed region done: {ms:.2f} ms/step")
     # (the host-batch leg -- pcie_inclusive_ms_per_step -- was measured before the capture, see host_batch_leg above)
+    bucketed = None
+    if args.bucketed_leg and args.workload == "pcqm4m" and world == 1 and reducer is None:
+        bucketed = bucketed_loader_leg(model, opt, compute_loss, nb, args.profile, dev)
 
     if rank == 0:
         N, E = batch_dev.x.shape[0], batch_dev.edge_index.shape[1]
@@ -752,6 +811,7 @@ def main():
             "final_loss": final_loss,
             "host_enqueue_ms_per_step": host_enqueue_ms,
             "pcie_inclusive_ms_per_step": h2d_ms,
+            "pcie_inclusive_bucketed": bucketed,
             "launch_mode": graph_mode,
             "launch_trial_ms": trial or None,
             "grad_allreduce_bytes": allreduce_bytes,

@@ -72,6 +72,40 @@ def _multihot_embedding(feats, embs, owner):
     return multihot @ table
 
 
+def masked_batch_norm(bn: nn.BatchNorm1d, x: torch.Tensor, n_real: torch.Tensor) -> torch.Tensor:
+    """``bn(x)`` of a PADDED batch in training mode: batch statistics over the first ``n_real[0]`` rows only (a device
+    int32 word -- ``batch.gps_counts[0:1]`` of loader.BucketPadding -- so the arithmetic has static shapes and can sit in a
+    captured step), every row normalised with them, running statistics updated as ``nn.BatchNorm1d`` does (unbiased
+    variance, ``momentum`` or the cumulative average).  On an un-padded batch (n_real = rows) it equals ``bn(x)``."""
+    R = x.shape[0]
+    w = (torch.arange(R, device=x.device) < n_real).to(x.dtype).unsqueeze(1)         # [R, 1]: 1 on real rows
+    n = n_real.to(x.dtype)
+    mean = (x * w).sum(0) / n
+    xc = (x - mean) * w
+    var = (xc * xc).sum(0) / n
+    y = (x - mean) * torch.rsqrt(var + bn.eps)
+    if bn.affine:
+        y = y * bn.weight + bn.bias
+    if bn.track_running_stats and bn.running_mean is not None:
+        with torch.no_grad():
+            bn.num_batches_tracked.add_(1)
+            if bn.momentum is None:
+                m = 1.0 / bn.num_batches_tracked.to(x.dtype)
+            else:
+                m = bn.momentum
+            bn.running_mean.mul_(1.0 - m).add_(mean.detach() * m)
+            bn.running_var.mul_(1.0 - m).add_(var.detach() * (n / (n - 1.0).clamp(min=1.0)) * m)
+    return y
+
+
+def _batch_norm(bn: nn.BatchNorm1d, x: torch.Tensor, batch) -> torch.Tensor:
+    """``bn(x)`` over the node rows of ``batch``; on a padded batch in training mode the statistics skip the padding."""
+    counts = getattr(batch, "gps_counts", None)
+    if torch.is_tensor(counts) and bn.training:
+        return masked_batch_norm(bn, x, counts[0:1])
+    return bn(x)
+
+
 class _OGBFeatureEncoder(nn.Module):
     _attr = None
     _dims = None
@@ -239,7 +273,7 @@ class KernelPENodeEncoder(nn.Module):
                              f"'posenc.kernel.times' values")
         pos_enc = getattr(batch, pestat_var)
         if self.raw_norm:
-            pos_enc = self.raw_norm(pos_enc)
+            pos_enc = _batch_norm(self.raw_norm, pos_enc, batch)
         pos_enc = self.pe_encoder(pos_enc)
         h = self.linear_x(batch.x) if self.expand_x else batch.x
         batch.x = torch.cat((h, pos_enc), 1)
@@ -279,7 +313,7 @@ class EquivStableLapPENodeEncoder(nn.Module):
         pos_enc = batch.EigVecs
         pos_enc = torch.where(torch.isnan(pos_enc), torch.zeros_like(pos_enc), pos_enc)
         if self.raw_norm:
-            pos_enc = self.raw_norm(pos_enc)
+            pos_enc = _batch_norm(self.raw_norm, pos_enc, batch)
         batch.pe_EquivStableLapPE = self.linear_encoder_eigenvec(pos_enc)
         return batch
 
@@ -323,5 +357,5 @@ class BatchNorm1dNode(nn.Module):
         self.bn = nn.BatchNorm1d(dim_in, eps=eps, momentum=momentum)
 
     def forward(self, batch):
-        batch.x = self.bn(batch.x)
+        batch.x = _batch_norm(self.bn, batch.x, batch)
         return batch

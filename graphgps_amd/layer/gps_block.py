@@ -517,8 +517,9 @@ class _GPSBlock(torch.autograd.Function):
         ref = _BY_REF
         sync = _norm.sync_arena(layer, dev)
         rn, re_ = gi.n_real, gi.e_real       # padded batches: device words with the real row counts (else None)
-        if rn is not None and (_GG_STATS or not panel or imgs[0][0].amax is None):
-            raise _lib.GpsHipError("padded batches need the default block path (fp16-form ring GEMMs, GPS_GG_STATS=0)")
+        if rn is not None and (_GG_STATS or perf or not panel or imgs[0][0].amax is None):
+            raise _lib.GpsHipError("padded batches need the default Transformer block path (fp16-form ring GEMMs, "
+                                   "GPS_GG_STATS=0); the Performer block has not been taken through padding")
         gemm_stats = panel and _GEMM_STATS and _gemm.stats_supported(N, d, inner) and _gemm.stats_supported(N, d, 2 * d)
         # -- local branch: GatedGCN core ---------------------------------------------------------
         def local_half():

@@ -29,6 +29,124 @@ STAGE_LOCK = threading.RLock()
 _BACKGROUND_DEFAULT = os.environ.get("GPS_LOADER_BACKGROUND", "1") != "0"
 
 
+_NODE_KEYS = ("x", "batch", "node_depth", "node_is_attributed", "EigVecs", "EigVals")
+_EDGE_KEYS = ("edge_attr",)
+_GRAPH_KEYS = ("y", "y_arr")
+
+
+def _bucket_step(n: int, frac: float) -> int:
+    """Power of two nearest (in the log) to ``frac * n``, at least 64: the granularity of a padded axis."""
+    import math
+    return max(64, 1 << max(0, round(math.log2(max(frac * n, 1.0)))))
+
+
+class BucketPadding:
+    """Pads a HOST batch up to a shape bucket so that a captured step can be replayed on it (``TrainStep.step_cached``
+    keys on shapes; a shuffled loader never emits the same (nodes, edges) twice: graphgps/train/custom_train.py:16-47
+    runs every batch through the same Python, a hipGraph needs the same shapes).
+
+    What is appended, always at the END of every axis so that real rows keep their indices (the dropout masks are
+    counter hashes of the row index):
+      * ``dead_graphs`` extra graphs, each with >= 1 padding node (features 0), that take the nodes up to the next
+        multiple of ``node_step``;
+      * padding edges up to the next multiple of ``edge_step``: self-loops on the padding nodes, round-robin -- they
+        connect padding to padding only;
+      * zero rows for every per-graph tensor (``y``).
+    The batch additionally carries ``gps_counts`` = int32 [real nodes, real edges, real graphs] -- a TENSOR, staged
+    to the device and copied into a captured step's static inputs like any other: the BatchNorm statistics, their
+    gradients' ``1 / R`` and the zero gate on padding rows read the real counts from it (ops.GraphIndex.n_real /
+    e_real, csrc/block_norm.hip ``rdev``, csrc/gemm_panel.hip ``m_dev``) -- and ``_gps_meta['b_real']``, the host-side
+    number of real graphs: ``TrainStep`` takes the loss over ``pred[:b_real]`` only.  Padding never reaches a real row:
+    message passing and attention stay inside a graph, statistics skip padding rows, and every backward tensor is exactly
+    zero on them (the loss ignores the dead graphs; the BatchNorm backward gates them), so the row contractions of the
+    weight gradients see zeros.
+
+    ``node_step`` / ``edge_step``: 0 = chosen from the first batch (the power of two nearest to 3 % of its size).
+    ``tie_edges``: the edge bucket is at least what the node bucket implies through the first batch's edges-per-node
+    ratio -- nodes and edges of a batch of molecules move together, and two independent axes would multiply the number
+    of live shapes (P30 x 256 graphs, 50 shuffled batches: 5 shapes untied, 3 tied, at 2.5 % average padding)."""
+
+    def __init__(self, node_step: int = 0, edge_step: int = 0, dead_graphs: int = 8, frac: float = 0.03,
+                 tie_edges: bool = True):
+        self.node_step, self.edge_step = int(node_step), int(edge_step)
+        self.dead_graphs = max(int(dead_graphs), 1)
+        self.frac = float(frac)
+        self.tie_edges = bool(tie_edges)
+        self.edges_per_node = None          # of the first batch (tie_edges)
+
+    @staticmethod
+    def _kind(key, t, N, E, B):
+        if key in _NODE_KEYS or key.startswith("pestat_") or key.startswith("pe_"):
+            return "node"
+        if key in _EDGE_KEYS:
+            return "edge"
+        if key in _GRAPH_KEYS:
+            return "graph"
+        hits = [k for k, n in (("node", N), ("edge", E), ("graph", B)) if t.dim() >= 1 and t.shape[0] == n]
+        if len(hits) == 1:
+            return hits[0]
+        raise ValueError(f"BucketPadding: cannot tell which axis tensor {key!r} {tuple(t.shape)} lives on "
+                         f"(nodes {N}, edges {E}, graphs {B})")
+
+    def __call__(self, batch):
+        """A new host batch (new container, new tensors where rows were appended)."""
+        ei = batch.edge_index
+        if ei.is_cuda:
+            raise ValueError("BucketPadding pads HOST batches (before the H2D copy)")
+        N, E = int(batch.x.shape[0]), int(ei.shape[1])
+        ptr = getattr(batch, "ptr", None)
+        bv = getattr(batch, "batch", None)
+        B = int(batch.num_graphs)
+        if self.node_step <= 0:
+            self.node_step = _bucket_step(N, self.frac)
+        if self.edge_step <= 0:
+            self.edge_step = _bucket_step(max(E, 1), self.frac)
+        G = self.dead_graphs
+        n_pad = -(-(N + G) // self.node_step) * self.node_step
+        e_pad = -(-E // self.edge_step) * self.edge_step
+        if self.tie_edges:
+            if self.edges_per_node is None:
+                self.edges_per_node = E / max(N, 1)
+            e_pad = max(e_pad, -(-int(self.edges_per_node * n_pad) // self.edge_step) * self.edge_step)
+        pn, pe = n_pad - N, e_pad - E                       # pn >= G: every dead graph owns a node
+        sizes = torch.full((G,), pn // G, dtype=torch.long)
+        sizes[: pn % G] += 1
+        out = DeviceLoader._host_copy(batch)
+        vars(out).pop("_gps_index", None)
+        for k in DeviceLoader._keys(batch):
+            v = getattr(batch, k, None)
+            if not torch.is_tensor(v):
+                continue
+            if k == "edge_index":
+                loops = N + torch.arange(pe, dtype=ei.dtype) % pn
+                new = torch.cat([v, torch.stack([loops, loops])], dim=1)
+            elif k == "ptr":
+                new = torch.cat([v, v[-1] + torch.cumsum(sizes, 0).to(v.dtype)])
+            elif k == "batch":
+                new = torch.cat([v, B + torch.repeat_interleave(torch.arange(G, dtype=v.dtype), sizes)])
+            elif k == "gps_counts":
+                raise ValueError("BucketPadding: this batch is padded already")
+            else:
+                rows = {"node": pn, "edge": pe, "graph": G}[self._kind(k, v, N, E, B)]
+                new = torch.cat([v, v.new_zeros((rows,) + tuple(v.shape[1:]))], dim=0)
+            setattr(out, k, new)
+        out.gps_counts = torch.tensor([N, E, B], dtype=torch.int32)
+        try:
+            out.num_graphs = B + G
+        except Exception:                   # a PyG Batch: num_graphs is a read-only property over _num_graphs
+            vars(out)["_num_graphs"] = B + G
+        if torch.is_tensor(ptr) and ptr.numel() > 1:
+            real_max = int((ptr[1:] - ptr[:-1]).max())
+        elif torch.is_tensor(bv) and bv.numel():
+            real_max = int(torch.bincount(bv).max())
+        else:
+            real_max = 0
+        meta = dict(vars(batch).get("_gps_meta") or {})
+        meta.update(nmax=max(real_max, int(sizes.max())), b_real=B, n_real=N, e_real=E, padded=True)
+        vars(out)["_gps_meta"] = meta
+        return out
+
+
 class DeviceLoader:
     """Iterate ``loader`` (host batches) and yield device batches with the graph index attached.
 
@@ -39,8 +157,10 @@ class DeviceLoader:
     the launching thread is a millisecond of idle GPU).  On a CPU ``device`` this is a pass-through: the product path
     has no CPU kernels, and the reference's loop is what the oracle runs."""
 
-    def __init__(self, loader: Iterable, device, depth: int = 2, build_index: bool = True, background: bool = None):
+    def __init__(self, loader: Iterable, device, depth: int = 2, build_index: bool = True, background: bool = None,
+                 pad: "BucketPadding" = None):
         self.loader = loader
+        self.pad = pad                      # shape buckets (BucketPadding): applied to the host batch before it is pinned
         self.device = torch.device(device)
         self.depth = max(int(depth), 1)
         self.build_index = build_index
@@ -74,13 +194,16 @@ class DeviceLoader:
 
     def _stage(self, batch, copy_stream):
         dev = self.device
-        batch = self._host_copy(batch)
+        batch = self.pad(batch) if self.pad is not None else self._host_copy(batch)
         vars(batch).pop("_gps_index", None)
         # what the host can tell the kernels for free while ``ptr`` is still here: the longest graph of the batch
         # (from ``ptr``, or from a host-side ``batch`` vector when the collater emitted no ``ptr``: without the record
         # ops._host_max_graph_nodes would pay a synchronising device read on the copy stream)
         p, bv = getattr(batch, "ptr", None), getattr(batch, "batch", None)
-        if torch.is_tensor(p) and not p.is_cuda and p.numel() > 1:
+        meta = vars(batch).get("_gps_meta") if self.pad is not None else None     # (a padded batch brings its record)
+        if meta is not None and "nmax" in meta:
+            pass
+        elif torch.is_tensor(p) and not p.is_cuda and p.numel() > 1:
             vars(batch)["_gps_meta"] = {"nmax": int((p[1:] - p[:-1]).max())}
         elif p is None and torch.is_tensor(bv) and not bv.is_cuda and bv.numel():
             vars(batch)["_gps_meta"] = {"nmax": int(torch.bincount(bv).max())}

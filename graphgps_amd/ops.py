@@ -59,7 +59,7 @@ class GraphIndex:
     edge_src: Optional[torch.Tensor] = None   # int64 [E] = edge_index[0] (edge order)
     edge_dst: Optional[torch.Tensor] = None   # int64 [E] = edge_index[1]
     nmax_host: int = 0         # longest graph of the batch as the HOST knows it (0 = unknown; a kernel-selection hint)
-    # padded batches (loader.BucketPadding, round 4): int32 [1] device words with the number of REAL nodes / edges -- rows
+    # padded batches (loader.BucketPadding, round 4; batch.gps_counts): int32 [1] device words with the number of REAL nodes / edges -- rows
     # past them are padding, kept out of every BatchNorm statistic and forced to zero gradient; None = no padding
     n_real: Optional[torch.Tensor] = None
     e_real: Optional[torch.Tensor] = None
@@ -165,8 +165,11 @@ def graph_index_of(batch) -> GraphIndex:
                            ptr_vec=getattr(batch, "ptr", None))
     gi.key = key
     gi.nmax_host = _host_max_graph_nodes(batch)
-    counts = batch.__dict__.get("_gps_counts") if hasattr(batch, "__dict__") else None
-    if counts is not None:               # int32 [>= 2] on the device: real nodes, real edges (a padded batch)
+    counts = getattr(batch, "gps_counts", None)
+    if torch.is_tensor(counts):          # int32 [real nodes, real edges, real graphs] on the device: a padded batch
+        if counts.dtype != torch.int32 or counts.numel() < 2 or counts.device != ei.device:
+            raise _lib.GpsHipError(f"batch.gps_counts must be int32 [>= 2] on {ei.device}, got {counts.dtype} "
+                                   f"{tuple(counts.shape)} on {counts.device}")
         gi.n_real, gi.e_real = counts[0:1], counts[1:2]
     try:
         batch.__dict__["_gps_index"] = gi

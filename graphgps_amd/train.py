@@ -73,6 +73,9 @@ class TrainStep:
         if zero:
             self.opt.zero_grad()
         pred, true = self.model(batch)
+        b_real = _real_graphs_of(batch)
+        if b_real is not None:               # a padded batch (loader.BucketPadding): the dead graphs' rows never reach the
+            pred, true = _head_rows(pred, b_real), _head_rows(true, b_real)     # loss, the logger or the caller
         loss, pred_score = self.loss_fn(pred, true)
         loss.backward()
         if self.flat:
@@ -252,7 +255,7 @@ class TrainStep:
         meta = vars(batch).get("_gps_meta") or {}
         nmax = int(meta.get("nmax", 0))
         return (tuple((k, tuple(getattr(batch, k).shape), str(getattr(batch, k).dtype)) for k in self._tensor_keys(batch)),
-                0 < nmax <= 64)
+                0 < nmax <= 64, meta.get("b_real"))    # (b_real: the loss's static slice over the real graphs)
 
     def _capture_shape(self, batch):
         """Static copies of the batch's tensors + the step captured over them (NOT executed: the caller replays)."""
@@ -314,6 +317,54 @@ class TrainStep:
         return {"graph": graph, "graph_up": graph_up, "keys": keys, "dst": dst, "out": out, "tick": tick, "static": static}
 
 
+def _real_graphs_of(batch):
+    """Number of real graphs of a padded batch (host int, ``loader.BucketPadding``), or None."""
+    meta = getattr(batch, "__dict__", {}).get("_gps_meta")
+    return None if not meta else meta.get("b_real")
+
+
+def _head_rows(obj, n: int):
+    """First ``n`` rows of a graph-level prediction / target (tensor, or list / dict of tensors: the code2 head)."""
+    if torch.is_tensor(obj):
+        return obj[:n] if obj.dim() >= 1 else obj
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_head_rows(o, n) for o in obj)
+    if isinstance(obj, dict):
+        return {k: _head_rows(v, n) for k, v in obj.items()}
+    return obj
+
+
+def padding_supported(model) -> bool:
+    """True when ``loader.BucketPadding`` is invisible to ``model``: every GPS layer runs as the fused
+    CustomGatedGCN+Transformer block (whose BatchNorms read the real row counts from the device), every other
+    BatchNorm of the model is one the encoders compute over the real rows (encoder/encoders.py ``_batch_norm``), and
+    the head is graph-level over 'add' / 'mean' pooling (the dead graphs' rows are dropped before the loss)."""
+    from .encoder.encoders import (BatchNorm1dNode, EquivStableLapPENodeEncoder, KernelPENodeEncoder)
+    from .head.heads import _GraphLevelHead
+    from .layer import gps_block as _blk
+    from .layer.gps_layer import GPSLayer
+    from . import gemm as _gemm
+    known, layers = set(), 0
+    for m in model.modules():
+        if isinstance(m, GPSLayer):
+            if not (_blk._block_static_ok(m) and m.global_model_type == 'Transformer' and _blk._panel_ok(m, m.dim_h)):
+                return False
+            lm = m.local_model
+            known |= {id(q) for q in (lm.bn_node_x, lm.bn_edge_e, m.norm1_local, m.norm1_attn, m.norm2)}
+            layers += 1
+        elif isinstance(m, (KernelPENodeEncoder, EquivStableLapPENodeEncoder)) and m.raw_norm is not None:
+            known.add(id(m.raw_norm))
+        elif isinstance(m, BatchNorm1dNode):
+            known.add(id(m.bn))
+    if layers == 0 or _blk._GG_STATS or not getattr(_gemm, "F16", False):
+        return False
+    for m in model.modules():
+        if isinstance(m, torch.nn.modules.batchnorm._NormBase) and id(m) not in known:
+            return False
+    head = getattr(model, "post_mp", None)
+    return isinstance(head, _GraphLevelHead) and cfg.model.graph_pooling in ("add", "mean")
+
+
 def _cloned(obj):
     if torch.is_tensor(obj):
         return obj.detach().clone()
@@ -324,6 +375,7 @@ def _cloned(obj):
     return obj
 
 
+_BUCKETS_DEFAULT = "0"      # GPS_LOADER_BUCKETS: train_epoch pads loader batches up to shape buckets (BucketPadding)
 LOGGER_FLUSH_EVERY = 16     # iterations between device->host reads for the logger (one sync per flush)
 
 
@@ -409,7 +461,14 @@ def train_epoch(logger, loader, model, optimizer, scheduler, batch_accumulation,
     # without gradient accumulation a step is one self-contained unit: replay it from a hipGraph whenever a step of
     # the batch's shape has been captured (TrainStep.step_cached; GPS_TRAIN_REPLAY=0 keeps every step eager)
     cached = flat and batch_accumulation == 1 and device.type == "cuda" and _os.environ.get("GPS_TRAIN_REPLAY", "1") != "0"
-    for it, batch in enumerate(DeviceLoader(loader, device)):
+    # shape buckets: a shuffled loader never repeats a (nodes, edges) pair, so without them `cached` never replays
+    pad = None
+    if cached and _os.environ.get("GPS_LOADER_BUCKETS", _BUCKETS_DEFAULT) != "0" and padding_supported(model):
+        pad = model.__dict__.get("_gps_bucket_padding")     # one instance per model: the bucket steps are fixed by the
+        if pad is None:                                      # first batch it sees
+            from .loader import BucketPadding
+            pad = model.__dict__["_gps_bucket_padding"] = BucketPadding()
+    for it, batch in enumerate(DeviceLoader(loader, device, pad=pad)):
         batch.split = 'train'
         if cached:
             loss, pred_score, true = step.step_cached(batch)

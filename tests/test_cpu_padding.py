@@ -1,0 +1,179 @@
+"""Host side of the padded-batch path (no GPU): ``loader.BucketPadding`` (what it appends and where), the encoders'
+BatchNorm over the real rows of a padded batch against ``nn.BatchNorm1d`` on the un-padded rows, and the loss slice
+``TrainStep`` takes.  Reference loop: graphgps/train/custom_train.py:16-47 (every batch through the same step); reference
+BatchNorms either side of the layers: graphgps/encoder/kernel_pos_encoder.py:44-47,92-94, graphgps/network/gps_model.py:27-46."""
+import collections
+import os
+
+import pytest
+import torch
+
+from graphgps_amd.loader import BucketPadding
+from graphgps_amd.synthetic import make_structure, model_batch
+
+
+def _sizes(batch):
+    return int(batch.x.shape[0]), int(batch.edge_index.shape[1]), int(batch.num_graphs)
+
+
+@pytest.mark.parametrize("kind,nb", [("pcqm4m", 64), ("zinc", 32), ("code2", 3)])
+def test_bucket_padding_appends_dead_graphs_and_self_loops_only(kind, nb):
+    b = model_batch(kind, nb, seed=5)
+    N, E, B = _sizes(b)
+    pad = BucketPadding(node_step=64, edge_step=128, dead_graphs=4, tie_edges=False)
+    pb = pad(b)
+    Np, Ep, Bp = _sizes(pb)
+    assert Np % 64 == 0 and Ep % 128 == 0 and Bp == B + 4
+    assert N + 4 <= Np < N + 4 + 64 and E <= Ep < E + 128
+    # real rows first and untouched, on every axis
+    for k in b.keys():
+        v, w = getattr(b, k), getattr(pb, k)
+        if not torch.is_tensor(v):
+            continue
+        if k == "edge_index":
+            assert torch.equal(w[:, :E], v)
+        elif k == "ptr":
+            assert torch.equal(w[:B + 1], v)
+        else:
+            assert torch.equal(w[:v.shape[0]], v), k
+            assert k == "batch" or not w[v.shape[0]:].any(), k  # zeros behind them (ptr / batch / edge_index aside)
+        assert getattr(b, k).shape == v.shape                    # the source batch is left alone
+    assert pb.x.shape[0] == pb.batch.shape[0] == int(pb.ptr[-1])
+    assert pb.edge_attr.shape[0] == Ep and pb.y.shape[0] == Bp
+    # dead graphs: every one owns a node, their sizes differ by at most one, batch / ptr agree
+    dead = pb.ptr[B + 1:] - pb.ptr[B:-1]
+    assert dead.min() >= 1 and dead.max() - dead.min() <= 1 and int(dead.sum()) == Np - N
+    assert torch.equal(pb.batch, torch.repeat_interleave(torch.arange(Bp), pb.ptr[1:] - pb.ptr[:-1]))
+    # padding edges: self-loops on padding nodes only, spread round-robin
+    ps, pd = pb.edge_index[0, E:], pb.edge_index[1, E:]
+    assert torch.equal(ps, pd) and (ps >= N).all() and (ps < Np).all()
+    if Ep > E:
+        deg = torch.bincount(ps - N, minlength=Np - N)
+        assert deg.max() - deg.min() <= 1
+    assert pb.gps_counts.dtype == torch.int32 and pb.gps_counts.tolist() == [N, E, B]
+    meta = vars(pb)["_gps_meta"]
+    assert meta["b_real"] == B and meta["padded"] and meta["nmax"] == max(int((b.ptr[1:] - b.ptr[:-1]).max()), int(dead.max()))
+    assert "b_real" not in (vars(b).get("_gps_meta") or {})     # the record of the source batch is not written to
+    with pytest.raises(ValueError, match="padded already"):
+        pad(pb)
+
+
+def test_bucket_padding_ambiguous_axis_is_an_error_and_known_names_are_not():
+    b = model_batch("pcqm4m", 8, seed=1)
+    N, E, B = _sizes(b)
+    b.mystery = torch.zeros(N, 3)
+    pad = BucketPadding(node_step=64, edge_step=64)
+    assert pad(b).mystery.shape[0] % 64 == 0                    # first dim matches the node axis only
+    # make nodes == edges: an unknown tensor is ambiguous now, the named ones still resolve
+    sizes, ei, bv, ptr, gen, _ = make_structure("P14", 4, 3)
+    n = int(ptr[-1])
+    from graphgps_amd.data import Batch
+    c = Batch(x=torch.zeros(n, 2, dtype=torch.long), edge_index=ei[:, :n].contiguous(), edge_attr=torch.zeros(n, dtype=torch.long),
+              batch=bv, ptr=ptr, y=torch.zeros(4))
+    c.num_graphs = 4
+    pc = pad(c)
+    assert pc.x.shape[0] % 64 == 0 and pc.edge_attr.shape[0] % 64 == 0
+    c.mystery = torch.zeros(n)
+    with pytest.raises(ValueError, match="cannot tell which axis"):
+        pad(c)
+
+
+def test_bucket_padding_ties_the_edge_bucket_to_the_node_bucket():
+    """P30 x 256 graphs, 50 shuffled batches: the auto-chosen 3 % steps are 256 nodes / 512 edges; with the edge bucket
+    tied to the node bucket the stream falls into <= 4 shapes (so a second-sight capture policy replays >= 90 % of it),
+    the average padding stays under 3.5 %."""
+    pad = BucketPadding()
+    shapes, waste = [], 0.0
+    from graphgps_amd.data import Batch
+    for s in range(50):
+        sizes, ei, bv, ptr, gen, _ = make_structure("P30", 256, 2000 + s)
+        n = int(ptr[-1])
+        b = Batch(x=torch.zeros(n, 1, dtype=torch.long), edge_index=ei, batch=bv, ptr=ptr)
+        b.num_graphs = 256
+        pb = pad(b)
+        shapes.append((pb.x.shape[0], pb.edge_index.shape[1]))
+        waste += (pb.x.shape[0] - n) / n + (pb.edge_index.shape[1] - ei.shape[1]) / ei.shape[1]
+    assert (pad.node_step, pad.edge_step) == (256, 512)
+    distinct = collections.Counter(shapes)
+    assert len(distinct) <= 4, distinct
+    assert 1.0 - len(distinct) / 50 >= 0.9
+    assert waste / 100 < 0.035, waste / 100
+
+
+@pytest.mark.parametrize("momentum", [0.1, None])
+def test_masked_batch_norm_equals_batchnorm1d_on_the_real_rows(momentum):
+    """encoder/encoders.py masked_batch_norm (the RWSE raw-norm / BatchNorm1dNode of a padded batch) against
+    nn.BatchNorm1d over the un-padded rows: outputs of the real rows, running statistics, gradients of the input's real
+    rows and of (weight, bias) when the padding rows receive no gradient (what the step guarantees)."""
+    from graphgps_amd.encoder.encoders import masked_batch_norm
+    torch.manual_seed(0)
+    R, P, C = 301, 19, 16
+    x = torch.rand(R, C) * 3 - 0.5
+    ref = torch.nn.BatchNorm1d(C, momentum=momentum)
+    got = torch.nn.BatchNorm1d(C, momentum=momentum)
+    with torch.no_grad():
+        ref.weight.uniform_(0.5, 1.5); ref.bias.uniform_(-1, 1)
+        got.load_state_dict(ref.state_dict())
+    gy = torch.randn(R, C)
+    for step in range(3):
+        xr = (x + step).clone().requires_grad_(True)
+        xp = torch.cat([x + step, torch.full((P, C), 7.0)]).requires_grad_(True)       # padding far from the data
+        yr = ref(xr)
+        yp = masked_batch_norm(got, xp, torch.tensor([R], dtype=torch.int32))
+        assert torch.isfinite(yp).all()
+        torch.testing.assert_close(yp[:R], yr, rtol=1e-5, atol=1e-5)
+        (yr * gy).sum().backward()
+        (yp[:R] * gy).sum().backward()
+        torch.testing.assert_close(xp.grad[:R], xr.grad, rtol=1e-4, atol=1e-5)
+        assert not xp.grad[R:].any()
+        torch.testing.assert_close(got.weight.grad, ref.weight.grad, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(got.bias.grad, ref.bias.grad, rtol=1e-4, atol=1e-4)
+        torch.testing.assert_close(got.running_mean, ref.running_mean, rtol=1e-5, atol=1e-6)
+        torch.testing.assert_close(got.running_var, ref.running_var, rtol=1e-5, atol=1e-6)
+        assert int(got.num_batches_tracked) == int(ref.num_batches_tracked) == step + 1
+        ref.zero_grad(); got.zero_grad()
+    # eval mode: the running statistics, padding or not
+    got.eval(); ref.eval()
+    from graphgps_amd.encoder.encoders import _batch_norm
+
+    class B:
+        gps_counts = torch.tensor([R, 0, 0], dtype=torch.int32)
+    torch.testing.assert_close(_batch_norm(got, xp.detach(), B)[:R], ref(x + 2))
+
+
+def test_rwse_encoder_ignores_padding_rows_in_training_mode():
+    """The measured configuration's node encoder (Atom+RWSE: graphgps/encoder/composed_encoders.py:36-58 with the raw
+    BatchNorm of kernel_pos_encoder.py:92-94) on a padded CPU batch: real rows and running statistics as on the
+    un-padded batch."""
+    import graphgps_amd as g
+    torch.manual_seed(0)
+    model = g.create_model(os.path.join(g.CONFIG_DIR, "pcqm4m_gpsmedium_rwse.yaml"), ["gt.layers", 1], 9, 1)
+    enc = model.encoder.node_encoder
+    enc.train()
+    import copy
+    enc2 = copy.deepcopy(enc)
+    b = model_batch("pcqm4m", 16, seed=3)
+    N = b.x.shape[0]
+    pb = BucketPadding(node_step=64, edge_step=64)(b)
+    out = enc(b.clone()).x
+    outp = enc2(pb).x
+    assert outp.shape[0] == pb.batch.shape[0] and torch.isfinite(outp).all()
+    torch.testing.assert_close(outp[:N], out, rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(enc2.encoder2.raw_norm.running_var, enc.encoder2.raw_norm.running_var, rtol=1e-5, atol=1e-6)
+
+
+def test_head_rows_and_padding_support_predicate():
+    import graphgps_amd as g
+    from graphgps_amd.train import _head_rows, _real_graphs_of, padding_supported
+    t = torch.arange(10.0)
+    assert torch.equal(_head_rows(t, 4), t[:4])
+    assert [x.shape[0] for x in _head_rows([t.view(10, 1), t], 3)] == [3, 3]
+    assert _head_rows({"y_arr": t.view(5, 2)}, 2)["y_arr"].shape == (2, 2)
+    b = model_batch("pcqm4m", 8, seed=1)
+    assert _real_graphs_of(b) is None
+    assert _real_graphs_of(BucketPadding(node_step=64, edge_step=64)(b)) == 8
+    cfgs = {"pcqm4m_gpsmedium_rwse.yaml": (9, 1, True), "zinc_gps_rwse.yaml": (1, 1, False),      # GINE local model
+            "code2_gps.yaml": (2, 5002, False)}                                                   # Performer
+    for name, (din, dout, want) in cfgs.items():
+        model = g.create_model(os.path.join(g.CONFIG_DIR, name), ["gt.layers", 1], din, dout)
+        assert padding_supported(model) is want, name

@@ -1,0 +1,202 @@
+"""GPU tests of padded batches (loader.BucketPadding -> TrainStep.step_cached): padding must be invisible to the real
+graphs -- predictions, loss, parameter gradients and BatchNorm running statistics of a padded step equal those of the
+un-padded step -- and a shuffled stream of PCQM-shaped batches must replay captured steps.
+
+Checker: the product's own un-padded eager step (itself pinned to the oracle by tests/test_hip_layer.py and
+tests/test_hip_optim.py).  Reference loop: graphgps/train/custom_train.py:16-47."""
+import os
+
+import pytest
+import torch
+
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _pcqm_model(dev, layers, dropout):
+    import graphgps_amd as g
+    m = g.create_model(os.path.join(g.CONFIG_DIR, "pcqm4m_gpsmedium_rwse.yaml"),
+                       ["gt.layers", layers, "gt.dropout", dropout, "gt.attn_dropout", dropout], 9, 1)
+    return m.to(dev).train()
+
+
+def _grads(model):
+    return {k: p.grad.detach().clone() for k, p in model.named_parameters() if p.grad is not None}
+
+
+def _buffers(model):
+    return {k: b.detach().clone() for k, b in model.named_buffers() if "running_" in k}
+
+
+@pytest.mark.parametrize("dropout", [0.0, 0.1])
+def test_padding_is_invisible_to_the_real_graphs(dropout):
+    """ONE step on a batch and on its padded form (same weights, same dropout seeds: the masks are counter hashes of the
+    row index and real rows keep their indices): predictions of the real graphs, the loss, every parameter gradient and
+    every BatchNorm running statistic agree to fp32 rounding.  A padding row that reached a statistic would move them by
+    ~1e-2 (3-8 % extra rows of a different distribution), the bars below are 100 x tighter."""
+    from graphgps_amd.loader import BucketPadding
+    from graphgps_amd.loss.losses import compute_loss
+    from graphgps_amd.synthetic import model_batch
+    dev = torch.device(DEV)
+    torch.manual_seed(0)
+    model = _pcqm_model(dev, 3, dropout)
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    b = model_batch("pcqm4m", 64, seed=21)
+    N, E, B = b.x.shape[0], b.edge_index.shape[1], 64
+    pb = BucketPadding(node_step=128, edge_step=256)(b)
+    assert pb.x.shape[0] > N and pb.edge_index.shape[1] > E
+
+    def run(batch, b_real):
+        model.load_state_dict(state)
+        model.zero_grad(set_to_none=True)
+        torch.manual_seed(1234)                      # the layers draw their dropout seeds from the CPU generator
+        pred, true = model(batch.to(dev))
+        if b_real is not None:
+            pred, true = pred[:b_real], true[:b_real]
+        loss, _ = compute_loss(pred, true)
+        loss.backward()
+        torch.cuda.synchronize()
+        return pred.detach().clone(), float(loss), _grads(model), _buffers(model)
+
+    p0, l0, g0, s0 = run(b.clone(), None)
+    p1, l1, g1, s1 = run(pb, B)
+    assert torch.isfinite(p1).all()
+    assert_close(p1, p0, 2e-5, "predictions of the real graphs, padded vs un-padded")
+    assert abs(l1 - l0) <= 2e-5 * max(abs(l0), 1.0), (l0, l1)
+    assert g0.keys() == g1.keys()
+    worst = 0.0
+    for k in g0:
+        assert torch.isfinite(g1[k]).all(), k
+        worst = max(worst, assert_close(g1[k], g0[k], 2e-4, f"grad {k}", rel_to_max=True))
+    for k in s0:
+        assert_close(s1[k], s0[k], 2e-5, f"buffer {k}", rel_to_max=True)
+    print(f"padded vs un-padded (dropout {dropout}): max|dpred| {float((p1 - p0).abs().max()):.2e}, worst relative "
+          f"parameter-gradient difference {worst:.2e}")
+
+
+def test_padded_batch_on_an_unsupported_layer_fails_loudly():
+    """Padding is only invisible where the BatchNorms read the real row counts: the GINE block and the Performer block
+    refuse a padded batch instead of silently normalising over the padding."""
+    import graphgps_amd as g
+    from graphgps_amd.lib import GpsHipError
+    from graphgps_amd.loader import BucketPadding
+    from graphgps_amd.synthetic import model_batch
+    dev = torch.device(DEV)
+    zinc = g.create_model(os.path.join(g.CONFIG_DIR, "zinc_gps_rwse.yaml"), ["gt.layers", 1], 1, 1).to(dev).train()
+    pb = BucketPadding(node_step=64, edge_step=64)(model_batch("zinc", 8, seed=2))
+    with pytest.raises(GpsHipError, match="padded batches"):
+        zinc(pb.to(dev))
+    code2 = g.create_model(os.path.join(g.CONFIG_DIR, "code2_gps.yaml"), ["gt.layers", 1], 2, 5002).to(dev).train()
+    pc = BucketPadding(node_step=64, edge_step=64)(model_batch("code2", 2, seed=2))
+    with pytest.raises(GpsHipError, match="padded batches"):
+        code2(pc.to(dev))
+    torch.cuda.synchronize()
+
+
+def test_bucketed_loader_replays_shuffled_batches_like_eager():
+    """50 shuffled PCQM-shaped batches (64 graphs each, every one a different (nodes, edges) pair) through
+    DeviceLoader(pad=BucketPadding) + TrainStep.step_cached: the stream falls into a handful of shape buckets, every step
+    after a bucket's first (eager) sight is a hipGraph replay -- >= 90 % of the 50 -- and replaying changes nothing: losses,
+    predictions and final weights equal the same padded batches stepped eagerly (same arithmetic, 1e-6), and the padded
+    stream tracks the un-padded one (different rounding, so only as far as 50 AdamW steps keep rounding differences small)."""
+    from graphgps_amd.loader import BucketPadding, DeviceLoader
+    from graphgps_amd.loss.losses import compute_loss
+    from graphgps_amd.optim import FlatAdamW
+    from graphgps_amd.synthetic import model_batch
+    from graphgps_amd.train import TrainStep
+    dev = torch.device(DEV)
+    seq = [model_batch("pcqm4m", 64, seed=300 + i) for i in range(50)]
+    assert len({(b.x.shape[0], b.edge_index.shape[1]) for b in seq}) >= 45       # the raw stream never repeats a shape
+    results, replays = {}, 0
+    for mode in ("eager", "eager-padded", "cached-padded"):
+        torch.manual_seed(0)
+        model = _pcqm_model(dev, 2, 0.0)
+        opt = FlatAdamW(model.parameters(), lr=2e-4, weight_decay=0.0, max_grad_norm=1.0)
+        ts = TrainStep(model, opt, loss_fn=compute_loss)
+        pad = None if mode == "eager" else BucketPadding(node_step=128, edge_step=256)
+        losses, preds = [], []
+        for b in DeviceLoader([q.clone() for q in seq], dev, pad=pad):
+            if mode == "cached-padded":
+                cache = ts.__dict__.get("_shape_cache", {})
+                key = ts._shape_key(b)
+                will_replay = key in cache or key in ts.__dict__.get("_shape_seen", set())
+                loss, pred, true = ts.step_cached(b, max_graphs=8)
+                assert ts.__dict__["_shape_cache"].get(key, None) is not False, "capture of a padded step failed"
+                replays += int(will_replay)
+            else:
+                loss, pred, true = ts._eager_triplet(b)
+            assert pred.shape[0] == 64 and true.shape[0] == 64               # the dead graphs never leave the step
+            losses.append(float(loss))
+            preds.append(pred.detach().float().cpu().clone())
+        torch.cuda.synchronize()
+        results[mode] = (losses, preds, torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu())
+        if mode == "cached-padded":
+            shapes = len(ts.__dict__["_shape_cache"])
+    print(f"bucketed stream: {replays} of 50 steps replayed, {shapes} captured shapes")
+    assert replays >= 45, (replays, shapes)
+    le, lp, lc = (results[m][0] for m in ("eager", "eager-padded", "cached-padded"))
+    assert all(x == x for x in lc)
+    for i, (a, c) in enumerate(zip(lp, lc)):                                 # replay == eager on the same padded batches
+        assert abs(a - c) <= 2e-6 * max(abs(a), 1.0), (i, a, c)
+    for a, c in zip(results["eager-padded"][1], results["cached-padded"][1]):
+        assert_close(c, a, 1e-5, "predictions, replayed vs eager (padded)")
+    assert_close(results["cached-padded"][2], results["eager-padded"][2], 1e-6, "weights after the sequence")
+    for i, (a, c) in enumerate(zip(le, lc)):                                 # padded == un-padded up to rounding growth
+        assert abs(a - c) <= (2e-5 if i == 0 else 5e-3) * max(abs(a), 1.0), (i, a, c)
+    assert_close(results["cached-padded"][1][0], results["eager"][1][0], 2e-5, "first-step predictions, padded vs un-padded")
+
+
+def test_train_epoch_pads_to_buckets_and_feeds_the_logger_real_graphs(monkeypatch):
+    """train_epoch with GPS_LOADER_BUCKETS=1: a shuffled stream is padded, steps are replayed, and the logger still sees
+    the reference's records -- one per iteration, ``true`` / ``pred`` of the 64 real graphs only."""
+    import graphgps_amd as g
+    from graphgps_amd.optim import FlatAdamW
+    from graphgps_amd.synthetic import model_batch
+    from graphgps_amd import train as T
+    dev = torch.device(DEV)
+    monkeypatch.setenv("GPS_LOADER_BUCKETS", "1")
+
+    class Logger:
+        def __init__(self):
+            self.rows = []
+
+        def update_stats(self, **kw):
+            self.rows.append(kw)
+
+    class Sched:
+        def get_last_lr(self):
+            return [1e-3]
+
+    torch.manual_seed(0)
+    model = _pcqm_model(dev, 2, 0.1)
+    assert T.padding_supported(model)
+    opt = FlatAdamW(model.parameters(), lr=1e-3, weight_decay=0.0)
+    seq = [model_batch("pcqm4m", 64, seed=700 + i) for i in range(24)]
+    from graphgps_amd.graphgym.config import cfg
+    old = cfg.accelerator
+    cfg.accelerator = DEV
+    cfg.optim.clip_grad_norm = True
+    cfg.optim.clip_grad_norm_value = 1.0
+    if not hasattr(cfg, "params"):
+        cfg.params = 0
+    seen = []
+    orig = T.TrainStep.step_cached
+
+    def spy(self, batch, *a, **kw):
+        seen.append((tuple(batch.x.shape), tuple(batch.edge_index.shape), hasattr(batch, "gps_counts")))
+        return orig(self, batch, *a, **kw)
+    monkeypatch.setattr(T.TrainStep, "step_cached", spy)
+    try:
+        log = Logger()
+        T.train_epoch(log, seq, model, opt, Sched(), 1)
+    finally:
+        cfg.accelerator = old
+    torch.cuda.synchronize()
+    assert len(log.rows) == 24
+    assert all(r["true"].shape[0] == 64 and r["pred"].shape[0] == 64 for r in log.rows)
+    assert all(r["loss"] == r["loss"] for r in log.rows)
+    assert all(s[2] for s in seen) and len({s[:2] for s in seen}) <= 6, seen
+    assert all(s[0][0] % 64 == 0 for s in seen)
