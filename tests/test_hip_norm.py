@@ -122,6 +122,21 @@ def test_norm_fwd_kinds_with_shared_masks():
 
 @pytest.mark.parametrize("N,E,d", [(1237, 2511, 384), (743, 1590, 64), (300, 20000, 256)])
 def test_norm_backward_lists_and_chain(N, E, d):
+    _norm_backward_case(N, E, d)
+
+
+@pytest.mark.parametrize("N,E,d,pn,pe", [(1237, 2511, 384, 43, 177), (743, 1590, 64, 25, 10), (300, 20000, 256, 84, 480),
+                                         (1000, 2000, 384, 1, 0)])
+def test_norm_lists_on_padded_batches_see_the_real_rows_only(N, E, d, pn, pe):
+    """The same stages on PADDED streams (loader.BucketPadding: ``pn`` / ``pe`` rows of junk appended, the real row
+    counts in device words -- gps_norm_fwd_task.rdev / gps_norm_bwd_task.rdev): statistics, running statistics and every
+    gradient equal the fp64 reference over the REAL rows alone (divisors 1 / R_real), and the gradients the apply kernels
+    write on padding rows are exactly zero whatever the BatchNorm backward's mean terms are -- what keeps padding out of
+    the weight-gradient contractions downstream.  Sizes with whole row blocks of padding (300 + 84) and with one row."""
+    _norm_backward_case(N, E, d, pn, pe)
+
+
+def _norm_backward_case(N, E, d, pn=0, pe=0):
     """The block's backward norm stages exactly as gps_block.py issues them -- {norm2, bn_edge_e} partial + apply,
     the dual {norm1_local, norm1_attn} partial + apply CHAINED into bn_node_x's column sums, bn_node_x's apply --
     against autograd in fp64 on the same function with the same dropout masks and the ReLU decisions the GPU took
@@ -132,6 +147,17 @@ def test_norm_backward_lists_and_chain(N, E, d):
     s0, s1, s3, s5 = 101, 0xABCDEF0123, 303, 0x77777777FFFF
     xt, x, za, z2, g_out, w_h = (torch.randn(N, d, generator=gen) for _ in range(6))   # w_h: the network above h
     eh, e, g_e1 = (torch.randn(E, d, generator=gen) for _ in range(3))
+    padded = pn > 0 or pe > 0
+    NR, ER = N, E                                  # real rows; from here on N / E are the row counts the kernels are given
+    if padded:
+        junk = lambda t, k: torch.cat([t, torch.randn(k, d, generator=gen) * 3.0 + 2.0])     # far from the data
+        zero = lambda t, k: torch.cat([t, torch.zeros(k, d)])                                  # no gradient arrives there
+        xt, x, za, z2 = (junk(t, pn) for t in (xt, x, za, z2))
+        eh, e = junk(eh, pe), junk(e, pe)
+        g_out, w_h, g_e1 = zero(g_out, pn), zero(w_h, pn), zero(g_e1, pe)
+        N, E = N + pn, E + pe
+    rn = torch.tensor([NR], dtype=torch.int32, device=DEV) if padded else None
+    re_ = torch.tensor([ER], dtype=torch.int32, device=DEV) if padded else None
     bnx, bne, bnl, bna, bn2 = (_bn(d, gen) for _ in range(5))
     own = _Owner()
     dev = torch.device(DEV)
@@ -143,9 +169,11 @@ def test_norm_backward_lists_and_chain(N, E, d):
     descs = [_desc(b, d) for b in (bnx, bne, bnl, bna, bn2)]       # (descriptor, its [2, d] statistics buffer): keep both alive
     dx, de, dl, da, d2 = (q[0] for q in descs)
     x1g, brx, bre = torch.empty_like(xg), torch.empty_like(xg), torch.empty_like(eg)
-    norm.fwd([norm.fwd_task(norm.LOAD, xtg, N, stats=dx), norm.fwd_task(norm.LOAD, ehg, E, stats=de),
-              norm.fwd_task(norm.LOAD, zag, N, stats=da), norm.fwd_task(norm.LOAD, z2g, N, stats=d2)], d, dev, sync.site(0))
-    norm.fwd([norm.fwd_task(norm.BN_ACT, xtg, N, res=xg, bn1=dx, relu=True, p=p, seed=s0, out=x1g, stats=dl),
+    before = {k: (b.running_mean.clone().cpu(), b.running_var.clone().cpu()) for k, b in (("x", bnx), ("e", bne), ("l", bnl))}
+    norm.fwd([norm.fwd_task(norm.LOAD, xtg, N, stats=dx, rdev=rn), norm.fwd_task(norm.LOAD, ehg, E, stats=de, rdev=re_),
+              norm.fwd_task(norm.LOAD, zag, N, stats=da, rdev=rn), norm.fwd_task(norm.LOAD, z2g, N, stats=d2, rdev=rn)],
+             d, dev, sync.site(0))
+    norm.fwd([norm.fwd_task(norm.BN_ACT, xtg, N, res=xg, bn1=dx, relu=True, p=p, seed=s0, out=x1g, stats=dl, rdev=rn),
               norm.fwd_task(norm.BN_ACT, xtg, N, bn1=dx, relu=True, p=p, seed=s0, out=brx),      # the branches alone:
               norm.fwd_task(norm.BN_ACT, ehg, E, bn1=de, relu=True, p=p, seed=s1, out=bre)],     # their zeros = decisions
              d, dev, sync.site(1))
@@ -153,19 +181,35 @@ def test_norm_backward_lists_and_chain(N, E, d):
     g_bxw, g_bxb, g_bew, g_beb, g_nlw, g_nlb, g_naw, g_nab, g_n2w, g_n2b = gp.unbind(0)
     g_z2, g_f2, g_eh = torch.empty_like(xg), torch.empty_like(xg), torch.empty_like(eg)
     g_outg, g_e1g, w_hg = g(g_out), g(g_e1), g(w_h)       # tasks hold raw pointers: the tensors must outlive the launches
-    b1 = [norm.bwd_task(z2g, g_outg, d2, N, g_n2w, g_n2b, g_z=g_z2, g_drop=g_f2, p2=pf2, seed2=s5),
-          norm.bwd_task(ehg, g_e1g, de, E, g_bew, g_beb, relu=True, p=p, seed=s1, g_z=g_eh)]
+    b1 = [norm.bwd_task(z2g, g_outg, d2, N, g_n2w, g_n2b, g_z=g_z2, g_drop=g_f2, p2=pf2, seed2=s5, rdev=rn),
+          norm.bwd_task(ehg, g_e1g, de, E, g_bew, g_beb, relu=True, p=p, seed=s1, g_z=g_eh, rdev=re_)]
     norm.bwd_partial(b1, d, dev, sync.site(2))
     norm.bwd_apply(b1, d, dev, None)
     g_x1, g_xres, g_ao, g_xt = (torch.empty_like(xg) for _ in range(4))
     b3 = [norm.bwd_task(x1g, w_hg, dl, N, g_nlw, g_nlb, z2=zag, bn2=da, g_gamma2=g_naw, g_beta2=g_nab, g_z=g_x1,
                         g_sum=g_xres, g_drop=g_ao, p2=pl, seed2=s3, cz=xtg, cbn=dx, crelu=True, cp=p, cseed=s0,
-                        cg_gamma=g_bxw, cg_beta=g_bxb)]
+                        cg_gamma=g_bxw, cg_beta=g_bxb, rdev=rn)]
     norm.bwd_partial(b3, d, dev, sync.site(3))
     norm.bwd_apply(b3, d, dev, sync.site(4))
-    norm.bwd_apply([norm.bwd_task(xtg, g_x1, dx, N, g_bxw, g_bxb, relu=True, p=p, seed=s0, g_z=g_xt)], d, dev, None)
+    norm.bwd_apply([norm.bwd_task(xtg, g_x1, dx, N, g_bxw, g_bxb, relu=True, p=p, seed=s0, g_z=g_xt, rdev=rn)], d, dev, None)
     torch.cuda.synchronize()
     assert int(sync.buf.abs().sum()) == 0
+    if padded:
+        # padding rows: exactly zero in everything the apply kernels wrote; then drop them -- the reference below is
+        # the un-padded computation
+        for name, t, k in (("g_z2", g_z2, NR), ("g_f2", g_f2, NR), ("g_eh", g_eh, ER), ("g_x1", g_x1, NR),
+                           ("g_xres", g_xres, NR), ("g_ao", g_ao, NR), ("g_xt", g_xt, NR)):
+            assert not t[k:].any(), f"{name}: non-zero gradient on a padding row"
+        assert torch.isfinite(x1g).all()
+        g_z2, g_f2, g_x1, g_xres, g_ao, g_xt, x1g, brx = (t[:NR] for t in (g_z2, g_f2, g_x1, g_xres, g_ao, g_xt, x1g, brx))
+        g_eh, bre = g_eh[:ER], bre[:ER]
+        xt, x, za, z2, g_out, w_h = (t[:NR] for t in (xt, x, za, z2, g_out, w_h))
+        eh, e, g_e1 = (t[:ER] for t in (eh, e, g_e1))
+        N, E = NR, ER
+        for k, b, v in (("x", bnx, xt), ("e", bne, eh)):          # running statistics: over the real rows
+            _, _, rm, rv = _ref_stats(v, before[k])
+            assert_close(b.running_mean, rm, 2e-6 * max(1.0, float(rm.abs().max())), f"running_mean {k}")
+            assert float(((b.running_var.double().cpu() - rv) / rv).abs().max()) < 5e-6, k
 
     # ---- fp64 reference (autograd), BatchNorm parameters as leaves too ----------------------------------------------
     leaf = lambda t: t.detach().double().cpu().clone().requires_grad_(True)
@@ -330,6 +374,45 @@ def test_gemm_epilogue_residual_dropout_statistics(M, K, N, f16):
     for _ in range(5):
         out2 = gemm.gemm_panel_stats(ag, img, N, bg, rg, p, seed, desc, sync.site(0))
         assert torch.equal(out2, first[0]) and torch.equal(st, first[1])
+    assert int(sync.buf.abs().sum()) == 0
+
+
+@pytest.mark.parametrize("M,K,N,real", [(7680, 768, 384, 7569), (7680, 384, 384, 7569), (2048, 768, 384, 1900), (192, 384, 384, 130),
+                                        (7680, 384, 384, 7680), (1024, 256, 256, 3)])
+def test_gemm_statistics_epilogue_skips_padding_rows(M, K, N, real):
+    """gps_gemm16_panel_stats with ``m_dev`` (padded batches): every row of C is produced as before, the batch
+    statistics cover rows [0, m_dev[0]) only -- tiles that straddle the boundary, tiles of padding only (count-0
+    records in the tree), no padding at all (m_dev = M), and a near-empty batch."""
+    from graphgps_amd import gemm, norm
+    if not gemm.stats_supported(M, N, K):
+        pytest.skip("shape not served by the ring kernel")
+    gen = torch.Generator().manual_seed(M + K + real)
+    a = torch.randn(M, K, generator=gen)
+    a[real:] = a[real:] * 4.0 + 3.0                       # padding far from the data
+    w = torch.randn(N, K, generator=gen) / K ** 0.5
+    b = torch.randn(N, generator=gen)
+    res = torch.randn(M, N, generator=gen) * 1.5 + 0.5
+    p, seed = 0.1, 0xFEEDFACE12345
+    (img, _), = gemm.split_weights([w.to(DEV)], tn=False, f16=True)
+    bn = _bn(N, gen)
+    before = (bn.running_mean.clone().cpu(), bn.running_var.clone().cpu())
+    desc, st = _desc(bn, N)
+    own = _Owner()
+    sync = norm.sync_arena(own, torch.device(DEV))
+    ag, bg, rg = a.to(DEV), b.to(DEV), res.to(DEV)
+    m_dev = torch.tensor([real], dtype=torch.int32, device=DEV)
+    out = gemm.gemm_panel_stats(ag, img, N, bg, rg, p, seed, desc, sync.site(0), m_dev=m_dev)
+    ref = res.double() + (a.double() @ w.double().t() + b.double()) * _mask(seed, M, N, p)
+    assert_close(out, ref, 4e-6 * float(ref.abs().max()), "Cin + dropout(A W^T + b), padding rows included")
+    mean, rstd, rm, rv = _ref_stats(out[:real].cpu(), before)
+    assert_close(st[0], mean, 3e-6 * max(1.0, float(mean.abs().max())), "mean over the real rows")
+    assert float(((st[1].double().cpu() - rstd) / rstd).abs().max()) < 3e-6
+    assert_close(bn.running_mean, rm, 3e-6 * max(1.0, float(rm.abs().max())), "running_mean")
+    if real > 1:
+        assert float(((bn.running_var.double().cpu() - rv) / rv).abs().max()) < 1e-5
+    first = (out.clone(), st.clone())
+    out2 = gemm.gemm_panel_stats(ag, img, N, bg, rg, p, seed, desc, sync.site(0), m_dev=m_dev)
+    assert torch.equal(out2, first[0]) and torch.equal(st, first[1])
     assert int(sync.buf.abs().sum()) == 0
 
 
