@@ -993,3 +993,91 @@ def block_supported(layer, x, e=None) -> bool:
 def gps_block(layer, x, e, gi):
     _ensure_xgroup(layer)
     return _GPSBlock.apply(x, e, layer, gi, draw_dropout_seed(), *_refs(layer).params)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Inference form (graphgps/train/custom_train.py:50-77 eval_epoch, the `PCQM4Mv2-inference` mode: model.eval() under
+# no_grad): the same kernels minus everything training needs -- BatchNorms read their running statistics, no dropout, no
+# statistics tasks or in-launch trees, nothing saved, no input-gradient images.  13 launches per layer (+ the weight
+# images and the two operand maxima).
+# ---------------------------------------------------------------------------------------------------------------------
+def block_eval_supported(layer, x, e=None) -> bool:
+    """CustomGatedGCN + Transformer, BatchNorm with running statistics, ReLU, ``layer.eval()`` with gradients off, fp32 on
+    the GPU, widths the ring GEMM tiles."""
+    if layer.training or torch.is_grad_enabled() or not (x.is_cuda and x.dtype == torch.float32):
+        return False
+    if not _block_static_ok(layer) or layer.global_model_type != 'Transformer':
+        return False
+    d = x.shape[1]
+    if d % 4 != 0 or d > 1024 or x.shape[0] < 2 or not x.is_contiguous():
+        return False
+    if e is None or e.dim() != 2 or e.shape[0] < 2 or e.shape[1] != d or not e.is_contiguous() or e.dtype != torch.float32:
+        return False
+    return _panel_ok(layer, d)
+
+
+def _eval_stats(R: _Refs, d: int, dev) -> torch.Tensor:
+    """[10, d]: (running_mean, 1 / sqrt(running_var + eps)) of the block's five BatchNorms -- what F.batch_norm uses in
+    eval mode (gatedgcn_layer.py:72-73, gps_layer.py:191-194,212-229 under model.eval())."""
+    bns = (R.bnx, R.bne, R.bnl, R.bna, R.bn2)
+    out = _E(10, d, dtype=torch.float32, device=dev)
+    means, rstds = out[0::2], out[1::2]
+    means.copy_(torch.stack([bn._buffers["running_mean"] for bn in bns]))
+    var = torch.stack([bn._buffers["running_var"] for bn in bns])
+    eps = {float(bn.eps) for bn in bns}
+    if len(eps) == 1:
+        rstds.copy_(torch.rsqrt(var + eps.pop()))
+    else:
+        for i, bn in enumerate(bns):
+            rstds[i].copy_(torch.rsqrt(var[i] + float(bn.eps)))
+    return out
+
+
+@torch.no_grad()
+def gps_block_eval(layer, x, e, gi):
+    """``(x, e) -> (h, e_new)`` of one layer in eval mode: merged A|B|D|E|q|k|v projection and C projection on the ring
+    GEMM, GatedGCN core, attention core (no dropout), out-projection with the residual in its epilogue, the two
+    residual + ReLU(BatchNorm) streams, the dual BatchNorm sum, FFN (ReLU in the first GEMM's epilogue, residual in the
+    second's) and norm2 -- gps_layer.py:155-232 with every BatchNorm on its running statistics."""
+    L = _lib.load()
+    dev = x.device
+    st = current_stream(dev)
+    wcat, bcat = _ensure_xgroup(layer)
+    R = _refs(layer)
+    N, d = x.shape
+    E = e.shape[0]
+    H = layer.num_heads
+    dh = d // H
+    ldp = 7 * d
+    fs = d * 4
+    f32 = dict(dtype=torch.float32, device=dev)
+    imgs = _gemm.split_weights([wcat, _W(R.C), _W(R.out_proj), _W(R.ff1), _W(R.ff2)], tn=False)
+    am = None
+    if imgs[0][0].amax is not None:             # fp16-form GEMMs: the records of max|operand|, made by the producers
+        rec = _gemm.amax_records(_N_REC, dev)
+        am = [rec[i] for i in range(7)]
+        _gemm.absmax([x, e], out=rec[0:2])
+    aw = (lambda i: None) if am is None else (lambda i: am[i])
+    ce = _gemm.gemm_panel(e, imgs[1][0], d, bias=_B(R.C), a_amax=aw(_R_E))
+    pq = _gemm.gemm_panel(x, imgs[0][0], ldp, bias=_merged_bias(layer, wcat, bcat), a_amax=aw(_R_X))
+    P = pq.data_ptr()
+    stats = _eval_stats(R, d, dev)
+    bnx, bne, bnl, bna, bn2 = (_bn_desc(bn, stats[2 * i], stats[2 * i + 1])
+                               for i, bn in enumerate((R.bnx, R.bne, R.bnl, R.bna, R.bn2)))
+    xt, eh = _E(N, d, **f32), _E(E, d, **f32)
+    check(L.gps_gatedgcn_fwd(P, P + fs, P + 2 * fs, P + 3 * fs, ldp, ptr(ce), ptr(gi.rowptr_dst), ptr(gi.src_by_dst),
+                             ptr(gi.eid_by_dst), N, E, d, ptr(xt), ptr(eh), None, st), "gps_gatedgcn_fwd")
+    o, lse = _E(N, d, **f32), _E(H, N, **f32)
+    check(L.gps_seg_attn_fwd(P + 4 * fs, ldp, ptr(gi.ptr), ptr(gi.tile_graph), ptr(gi.tile_row0), gi.max_tiles, N, H, dh,
+                             float(dh) ** -0.5, 0.0, 0, ptr(o), ptr(lse), gi.B, int(gi.nmax_host), ptr(aw(_R_O)), st),
+          "gps_seg_attn_fwd")
+    za = _gemm.gemm_panel(o, imgs[2][0], d, bias=_B(R.out_proj), addend=x, a_amax=aw(_R_O))     # x + out_proj(o)
+    x1, e1, h, out = _E(N, d, **f32), _E(E, d, **f32), _E(N, d, **f32), _E(N, d, **f32)
+    _norm.fwd([_norm.fwd_task(_norm.BN_ACT, xt, N, res=x, bn1=bnx, relu=True, out=x1),
+               _norm.fwd_task(_norm.BN_ACT, eh, E, res=e, bn1=bne, relu=True, out=e1, amax=aw(6))], d, dev, None)
+    _norm.fwd([_norm.fwd_task(_norm.BN_DUAL, x1, N, b=za, bn1=bnl, bn2=bna, out=h, amax=aw(_R_H))], d, dev, None)
+    t = _gemm.gemm_panel(h, imgs[3][0], 2 * d, bias=_B(R.ff1), epilogue=1, p_drop=0.0, seed=0, a_amax=aw(_R_H),
+                         c_amax=aw(_R_T))
+    z2 = _gemm.gemm_panel(t, imgs[4][0], d, bias=_B(R.ff2), addend=h, a_amax=aw(_R_T))
+    _norm.fwd([_norm.fwd_task(_norm.BN_ACT, z2, N, bn1=bn2, out=out, amax=aw(_R_OUT))], d, dev, None)
+    return out, e1

@@ -26,12 +26,16 @@ from ..ops import graph_index_of, segment_attention
 from .gatedgcn_layer import GatedGCNLayer
 from .gcn_conv_layer import GCNConv
 from .gine_conv_layer import GINEConv, GINEConvESLapPE
-from .gps_block import block_supported, gine_block_supported, gps_block, gps_block_gine
+from .gps_block import (block_eval_supported, block_supported, gine_block_supported, gps_block, gps_block_eval,
+                        gps_block_gine)
 
 import os as _os
 # single-node block path (layer/gps_block.py): merges the A|B|D|E and in-proj GEMMs; measured
 # 16.9 -> 15.8 ms/step on MI355X.  GPS_FUSED_BLOCK=0 keeps the operator-by-operator path.
 _BLOCK_ENABLED = _os.environ.get("GPS_FUSED_BLOCK", "1") != "0"
+# inference form of the block (model.eval() under no_grad: eval_epoch, custom_train.py:50-77); GPS_EVAL_BLOCK=0 keeps
+# the operator-by-operator path there
+_EVAL_BLOCK = _os.environ.get("GPS_EVAL_BLOCK", "1") != "0"
 
 _NEEDS_PYG = {"GIN", "GENConv", "GAT", "PNA"}
 
@@ -153,7 +157,13 @@ class GPSLayer(nn.Module):
             batch.x = h
             batch.edge_attr = e_new
             return batch
-        if gi.n_real is not None:
+        if _BLOCK_ENABLED and _EVAL_BLOCK and block_eval_supported(self, h, edge_attr):
+            # model.eval() under no_grad (eval_epoch, inference): the same kernels on the running statistics
+            h, e_new = gps_block_eval(self, h, batch.edge_attr, gi)
+            batch.x = h
+            batch.edge_attr = e_new
+            return batch
+        if gi.n_real is not None and self.training:
             # a padded batch (loader.BucketPadding) that did not take the block above: every other path computes its
             # BatchNorm statistics over ALL rows it is given -- padding would silently change the batch
             from ..lib import GpsHipError

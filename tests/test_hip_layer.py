@@ -732,6 +732,62 @@ def test_block_and_operator_paths_match_fixture(monkeypatch, block):
     assert bool(calls) == block and bool(calls_gine) == block
 
 
+@pytest.mark.parametrize("nb,profile", [(64, "P30"), (48, "P14")])
+def test_eval_mode_block_matches_operator_path_and_oracle(monkeypatch, nb, profile):
+    """model.eval() under no_grad -- eval_epoch / inference (graphgps/train/custom_train.py:50-77): the inference form of
+    the block (layer/gps_block.py gps_block_eval: BatchNorms on their running statistics, no dropout, no statistics
+    tasks) against the operator-by-operator path and against the CPU oracle in eval mode, on a 3-layer GPS-medium model
+    whose running statistics are NOT the initial (0, 1): layer outputs (node and edge streams) and predictions."""
+    import graphgps_amd.layer.gps_layer as gl
+    from graphgps_amd.synthetic import model_batch
+    from oracle.gps_oracle import to_oracle_model
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    model = _build_model("pcqm4m_gpsmedium_rwse.yaml", 9, 1, ["gt.layers", 3])
+    gen = torch.Generator().manual_seed(7)
+    with torch.no_grad():
+        for m in model.modules():
+            if isinstance(m, torch.nn.BatchNorm1d):
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=gen) * 0.3)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=gen) * 1.5 + 0.5)
+                m.weight.copy_(torch.rand(m.weight.shape, generator=gen) + 0.5)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=gen) * 0.2)
+    model.eval()
+    oracle = to_oracle_model(model).eval()
+    model.to(dev)
+    b = model_batch("pcqm4m", nb, seed=77, profile=profile)
+    calls = []
+    orig = gl.gps_block_eval
+    monkeypatch.setattr(gl, "gps_block_eval", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+
+    def run(m, batch):
+        with torch.no_grad():
+            batch = m.encoder(batch)
+            batch = m._run_stack(m.layers, batch) if hasattr(m, "_run_stack") and batch.x.is_cuda else m.layers(batch)
+            x, e = batch.x.clone(), batch.edge_attr.clone()
+            pred, _ = m.post_mp(batch)
+        return x, e, pred
+    xo, eo, po = run(oracle, b.clone())
+    monkeypatch.setattr(gl, "_EVAL_BLOCK", False)
+    x0, e0, p0 = run(model, b.clone().to(dev))
+    assert not calls
+    monkeypatch.setattr(gl, "_EVAL_BLOCK", True)
+    x1, e1, p1 = run(model, b.clone().to(dev))
+    assert len(calls) == 3, calls
+    torch.cuda.synchronize()
+    tol = 2e-5          # three BatchNorm-normalised layers of unit-scale activations (Tol.ACT per layer and stream)
+    for what, got, ref in (("x (block vs oracle)", x1, xo), ("e (block vs oracle)", e1, eo), ("pred (block vs oracle)", p1, po),
+                           ("x (operator path vs oracle)", x0, xo), ("pred (operator path vs oracle)", p0, po),
+                           ("x (block vs operator path)", x1, x0), ("e (block vs operator path)", e1, e0),
+                           ("pred (block vs operator path)", p1, p0)):
+        assert torch.isfinite(got).all(), what
+        assert_close(got, ref, tol * max(1.0, float(ref.abs().max())), what)
+    # the training-mode path is untouched by an eval pass in between: one training step still runs
+    model.train()
+    pt, _ = model(b.clone().to(dev))
+    assert torch.isfinite(pt).all()
+
+
 @pytest.mark.parametrize("layer_type,residual", [("gatedgcnconv", True), ("gineconv", True),
                                                  ("gatedgcnconv", False)])
 def test_custom_gnn_vs_oracle(layer_type, residual):
