@@ -482,49 +482,61 @@ def cpu_baseline(model, batch_cpu, compute_loss, clip_value, steps, threads=0):
 def bucketed_loader_leg(model, opt, loss_fn, nb, profile, dev, n_batches=24):
     """Secondary, never `value`: the loader-fed step on batches that DIFFER in shape like a shuffled loader's
     (custom_train.py:16-47 feeds every batch of the epoch through the same step): `n_batches` synthetic batches of
-    different structure, pinned on the host, through DeviceLoader(pad=BucketPadding()) -- padded up to shape buckets,
-    H2D copies + graph index staged ahead on a copy stream -- and TrainStep.step_cached, which replays a captured step
-    per bucket.  Pass 1 (untimed) meets the buckets (first sight eager, second sight captured), pass 2 (timed) runs the
-    same batches in another order.  Runs after the timed region: it cannot move `value`."""
+    different structure through DeviceLoader + BucketPadding -- padded up to shape buckets, H2D copies + graph index
+    staged ahead on a copy stream -- and TrainStep.step_cached, which replays a captured step per bucket.  Two forms:
+    the padding on DeviceLoader's staging thread (host batches arrive un-padded and un-pinned, as from a plain
+    DataLoader), and batches that arrive padded and pinned (BucketPadding.collate in the DataLoader's worker processes +
+    pin_memory=True).  Untimed passes meet the buckets (first sight eager, second sight captured), the timed pass runs
+    the same batches in another order.  For scale, the eager step on the same un-padded stream (every batch a new shape:
+    the caching allocator cannot recycle) is timed too.  Runs after the timed region: it cannot move `value`."""
     try:
         from graphgps_amd.loader import BucketPadding, DeviceLoader
         from graphgps_amd.synthetic import model_batch
         from graphgps_amd.train import TrainStep, padding_supported
         if not padding_supported(model):
             return {"skipped": "model not served by the padded path"}
-        host = []
-        for i in range(n_batches):
-            b = model_batch("pcqm4m", nb, seed=5000 + i, profile=profile)
-            for k, v in list(b.__dict__.items()):
-                if torch.is_tensor(v):
-                    b.__dict__[k] = v.pin_memory()
-            host.append(b)
+        host = [model_batch("pcqm4m", nb, seed=5000 + i, profile=profile) for i in range(n_batches)]
         raw_shapes = len({(b.x.shape[0], b.edge_index.shape[1]) for b in host})
-        pad = BucketPadding()
-        tsb = TrainStep(model, opt, loss_fn=loss_fn)
-        order2 = [host[(7 * i + 3) % n_batches] for i in range(n_batches)]
-        replays = rows = real = 0
-        for timed, seq in ((False, host + host), (True, order2)):
+        order2 = lambda seq: [seq[(7 * i + 3) % n_batches] for i in range(n_batches)]
+
+        def run(ts, seq, pad, cached):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             for b in DeviceLoader((q.shallow_copy() for q in seq), dev, pad=pad):
-                if timed:
-                    key = tsb._shape_key(b)
-                    replays += int(bool(tsb.__dict__.get("_shape_cache", {}).get(key)))
-                    rows += b.x.shape[0] + b.edge_index.shape[1]
-                    real += int(b.__dict__["_gps_meta"]["n_real"]) + int(b.__dict__["_gps_meta"]["e_real"])
-                tsb.step_cached(b, max_graphs=12)
+                ts.step_cached(b, max_graphs=12) if cached else ts._eager_triplet(b)
             torch.cuda.synchronize()
-            dt = (time.perf_counter() - t0) / len(seq) * 1e3
+            return (time.perf_counter() - t0) / len(seq) * 1e3
+        out = {"batches": n_batches, "distinct_raw_shapes": raw_shapes}
+        # (0) eager on the un-padded stream
+        tse = TrainStep(model, opt, loss_fn=loss_fn)
+        run(tse, host, None, False)
+        out["eager_unpadded_ms_per_step"] = run(tse, order2(host), None, False)
+        # (a) padding on the staging thread
+        pad = BucketPadding()
+        tsb = TrainStep(model, opt, loss_fn=loss_fn)
+        run(tsb, host + host, pad, True)
+        out["staging_thread_padding_ms_per_step"] = run(tsb, order2(host), pad, True)
+        # (b) batches arrive padded and pinned
+        pre = [pad(b) for b in host]
+        real = sum(int(b.__dict__["_gps_meta"]["n_real"]) + int(b.__dict__["_gps_meta"]["e_real"]) for b in pre)
+        rows = sum(b.x.shape[0] + b.edge_index.shape[1] for b in pre)
+        for b in pre:
+            for k, v in list(b.__dict__.items()):
+                if torch.is_tensor(v):
+                    b.__dict__[k] = v.pin_memory()
+        run(tsb, pre, None, True)
         cache = tsb.__dict__.get("_shape_cache", {})
-        out = {"ms_per_step": dt, "batches": n_batches, "distinct_raw_shapes": raw_shapes,
-               "shape_buckets": len(cache), "failed_captures": sum(1 for v in cache.values() if v is False),
-               "replayed_steps": replays, "padding_fraction": rows / max(real, 1) - 1.0,
-               "node_step": pad.node_step, "edge_step": pad.edge_step}
-        log(f"bucketed loader leg: {dt:.2f} ms/step over {n_batches} batches of {raw_shapes} raw shapes in "
-            f"{len(cache)} buckets, {replays} replayed, padding {out['padding_fraction'] * 100:.1f} %")
+        before = {k for k, v in cache.items() if v}
+        out["ms_per_step"] = run(tsb, order2(pre), None, True)
+        out.update(shape_buckets=len(cache), failed_captures=sum(1 for v in cache.values() if v is False),
+                   replayed_steps=sum(1 for b in pre if tsb._shape_key(b) in before),
+                   padding_fraction=rows / max(real, 1) - 1.0, node_step=pad.node_step, edge_step=pad.edge_step)
+        log(f"bucketed loader leg: {out['ms_per_step']:.2f} ms/step with batches that arrive padded + pinned, "
+            f"{out['staging_thread_padding_ms_per_step']:.2f} with the padding on the staging thread, "
+            f"{out['eager_unpadded_ms_per_step']:.2f} eager on the un-padded stream ({raw_shapes} raw shapes in "
+            f"{len(cache)} buckets, padding {out['padding_fraction'] * 100:.1f} %)")
         torch.cuda.synchronize()
-        del tsb
+        del tsb, tse
         return out
     except Exception as exc:        # a side measurement never takes the headline line with it
         log(f"bucketed loader leg skipped ({type(exc).__name__}: {exc})")

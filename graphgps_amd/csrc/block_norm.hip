@@ -236,12 +236,11 @@ __device__ __forceinline__ bool run_fwd(const FwdTask& T, int d, int lb, uint64_
   if (rsub == 0) {
     const int64_t nreal = min(row1, rreal) - row0;
     const float n = nreal > 0 ? (float)nreal : 0.0f;        // a block of padding only: an empty record (count 0)
-    const float inv = n > 0.0f ? 1.0f / n : 0.0f;
     float* rec = T.tree.part + (int64_t)lb * 2 * d;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      tr::st_sc1(rec + c + j, n > 0.0f ? k[j] + s[0][j] * inv : 0.0f);
-      tr::st_sc1(rec + d + c + j, fmaxf(s[1][j] - s[0][j] * s[0][j] * inv, 0.0f));
+    for (int j = 0; j < 4; ++j) {       // (divisions, not a reciprocal: the un-padded records keep the bits they always had)
+      tr::st_sc1(rec + c + j, n > 0.0f ? k[j] + s[0][j] / n : 0.0f);
+      tr::st_sc1(rec + d + c + j, n > 0.0f ? fmaxf(s[1][j] - s[0][j] * s[0][j] / n, 0.0f) : 0.0f);
     }
     if (c == 0) tr::st_sc1(T.tree.pcnt + lb, n);
   }

@@ -11,6 +11,35 @@ if ROOT not in sys.path:
 GOLDEN_DIR = os.path.join(ROOT, "tests", "golden")
 
 
+def _usable_cores() -> int:
+    """Host cores this process may actually use: affinity mask AND cgroup CPU quota.  torch sizes its intra-op pool by the
+    visible cores; on a GPU box that shows every core of the host but grants a 16-core quota, the CPU oracle legs of the
+    parity tests ran oversubscribed (the round-4 suite took > 9 minutes of mostly throttled CPU time)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+torch.set_num_threads(max(1, min(torch.get_num_threads(), _usable_cores())))
+
+
+@pytest.fixture(autouse=True)
+def _zero_dropout_salt():
+    """The host model of the kernels' dropout hash (ops.attn_dropout_keep_mask, helpers.row_mask) assumes the
+    device-resident salt is 0; a test that captured a step (TrainStep.capture / step_cached install the salt and advance it
+    per step) would otherwise change the masks of every masked-oracle test that runs after it in the same process."""
+    yield
+    if torch.cuda.is_available():
+        from graphgps_amd import ops
+        if ops._dropout_salt is not None:
+            ops._dropout_salt.zero_()
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 

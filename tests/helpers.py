@@ -23,30 +23,39 @@ def gine_core_ref(x, e, edge_index, eps=0.0):
 
 def segment_attention_ref(qkv, ptr, H, keep=None, p_drop=0.0, bias=None):
     """Dense per-graph softmax attention; ``keep`` optional list (per graph) of bool [H,n,n]; ``bias`` the
-    reference's dense additive mask [B*H, nmax, nmax] (plane g*H + h, its n x n corner is what counts)."""
+    reference's dense additive mask [B*H, nmax, nmax] (plane g*H + h, its n x n corner is what counts).
+    Graphs of the same size are evaluated together (one batched product per distinct size instead of one per graph:
+    a 10-layer model over 256 graphs is 2,560 per-graph evaluations and ~10 autograd nodes each otherwise -- two minutes
+    of the GPU suite were this loop's backward); every graph's rows are still a function of that graph alone."""
     N, d3 = qkv.shape
     d = d3 // 3
     dh = d // H
-    out = torch.zeros(N, d, dtype=qkv.dtype)
-    outs = []
-    for g in range(len(ptr) - 1):
-        a, b = int(ptr[g]), int(ptr[g + 1])
-        n = b - a
-        if n == 0:
-            continue
-        q = qkv[a:b, :d].view(n, H, dh).transpose(0, 1)
-        k = qkv[a:b, d:2 * d].view(n, H, dh).transpose(0, 1)
-        v = qkv[a:b, 2 * d:].view(n, H, dh).transpose(0, 1)
-        s = (q * dh ** -0.5) @ k.transpose(1, 2)
-        if bias is not None:
-            s = s + bias[g * H:(g + 1) * H, :n, :n]
-        p = torch.softmax(s, dim=-1)
-        if keep is not None:
-            p = p * keep[g].to(p.dtype) / (1.0 - p_drop)
-        outs.append(((p @ v).transpose(0, 1).reshape(n, d), a, b))
-    if not outs:
+    sizes = (ptr[1:] - ptr[:-1]).tolist()
+    starts = ptr[:-1].tolist()
+    by_size = {}
+    for g, n in enumerate(sizes):
+        if n > 0:
+            by_size.setdefault(int(n), []).append(g)
+    if not by_size:
         return qkv.new_zeros(N, d)
-    return torch.cat([o for o, _, _ in outs], 0)
+    pieces, rows_all = [], []
+    for n, gs in by_size.items():
+        rows = (torch.tensor([int(starts[g]) for g in gs]).unsqueeze(1) + torch.arange(n).unsqueeze(0)).reshape(-1)   # [G*n]
+        blk = qkv.index_select(0, rows).view(len(gs), n, 3, H, dh)
+        q, k, v = (blk[:, :, i].transpose(1, 2) for i in range(3))          # [G, H, n, dh]
+        s_ = (q * dh ** -0.5) @ k.transpose(2, 3)
+        if bias is not None:
+            s_ = s_ + torch.stack([bias[g * H:(g + 1) * H, :n, :n] for g in gs])
+        p = torch.softmax(s_, dim=-1)
+        if keep is not None:
+            p = p * torch.stack([keep[g] for g in gs]).to(p.dtype) / (1.0 - p_drop)
+        pieces.append((p @ v).transpose(1, 2).reshape(len(gs) * n, d))
+        rows_all.append(rows)
+    rows_all = torch.cat(rows_all)
+    out = torch.cat(pieces, 0)
+    inv = torch.empty_like(rows_all)
+    inv[rows_all] = torch.arange(rows_all.numel())
+    return out.index_select(0, inv)             # back to batch order (empty graphs own no rows: these are all N)
 
 
 # ---------------------------------------------------------------------------------------------------------------

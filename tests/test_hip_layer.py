@@ -253,16 +253,24 @@ def _masked_oracle_run(oracle, b, seeds_per_layer, H, p, p_attn, wx, we, dtype, 
     return bc.x, bc.edge_attr, x0.grad, e0.grad, grads
 
 
-def _block_masks(layers, b, seeds_per_layer, N, E, d, H, p, p_attn, local, glob="Transformer"):
+def _block_masks(layers, b, seeds_per_layer, N, E, d, H, p, p_attn, local, glob="Transformer", cache=None):
     """The dropout masks a stack of fused blocks draws from its per-layer seeds, in the order the oracle layers call
-    ``F.dropout``; swaps each oracle layer's attention module for the masked one (Transformer)."""
+    ``F.dropout``; swaps each oracle layer's attention module for the masked one (Transformer).  ``cache`` (a dict): the
+    masks are a function of the seeds alone, so a second oracle (the fp64 evaluation of the same step) reuses the first
+    one's instead of re-running the host model of the hash (~2 s per layer at 256 graphs)."""
     from graphgps_amd.ops import attn_dropout_effective_p
     from helpers import MaskedSegmentMHA, attention_keep, block_seeds, row_mask
-    masks = []
+    if cache is not None and "masks" in cache:
+        if glob == "Transformer":
+            for lay, keep in zip(layers, cache["keeps"]):
+                lay.self_attn = MaskedSegmentMHA(lay.self_attn, b.ptr, keep, attn_dropout_effective_p(p_attn))
+        return list(cache["masks"])
+    masks, keeps = [], []
     for lay, seed in zip(layers, seeds_per_layer):
         s = block_seeds(seed)
         if glob == "Transformer":
             keep = attention_keep(s[2], b.ptr, H, p_attn) if p_attn > 0 else None
+            keeps.append(keep)
             lay.self_attn = MaskedSegmentMHA(lay.self_attn, b.ptr, keep, attn_dropout_effective_p(p_attn))
         if local == "CustomGatedGCN":       # call order: gatedgcn x, e | dropout_attn | ff_dropout1 | ff_dropout2
             masks += [row_mask(s[0], N, d, p), row_mask(s[1], E, d, p)]
@@ -283,6 +291,8 @@ def _block_masks(layers, b, seeds_per_layer, N, E, d, H, p, p_attn, local, glob=
         else:
             masks += [row_mask(s[3], N, d, p)]
         masks += [row_mask(s[4], N, 2 * d, p), row_mask(s[5], N, d, p)]
+    if cache is not None:
+        cache["masks"], cache["keeps"] = list(masks), keeps
     return masks
 
 
@@ -653,12 +663,14 @@ def test_full_model_with_dropout_on_vs_masked_oracle(monkeypatch):
     it = iter(seeds)
     monkeypatch.setattr(gps_block, "draw_dropout_seed", lambda: next(it))
 
+    mask_cache = {}
+
     def oracle_run(dtype):
         o = to_oracle_model(model)
         if dtype == torch.float64:
             o = o.double()
         o.train()
-        masks = _block_masks(list(o.layers), b, seeds, N, E, d, H, p, p_attn, "CustomGatedGCN")
+        masks = _block_masks(list(o.layers), b, seeds, N, E, d, H, p, p_attn, "CustomGatedGCN", cache=mask_cache)
         with inject_dropout_masks(masks):
             pred, true = o(_double_batch(b) if dtype == torch.float64 else b.clone())
         loss, _ = compute_loss(pred, true)
