@@ -95,10 +95,11 @@ def parse_args():
     ap.add_argument("--no-kernel-roofline", action="store_true")
     ap.add_argument("--no-h2d-leg", action="store_true",
                     help="skip the secondary PCIe-inclusive measurement (host batches through DeviceLoader)")
-    ap.add_argument("--bucketed-leg", action="store_true",
-                    help="pcqm4m, 1 GPU: a third, secondary measurement after the timed region -- DIFFERENT host batches "
-                         "(a shuffled loader's never-repeating shapes) through DeviceLoader(pad=BucketPadding) and "
-                         "TrainStep.step_cached, i.e. what train_epoch does with GPS_LOADER_BUCKETS=1")
+    ap.add_argument("--no-bucketed-leg", action="store_true",
+                    help="skip the third, secondary measurement (pcqm4m, 1 GPU, after the timed region): DIFFERENT host "
+                         "batches (a shuffled loader's never-repeating shapes) through DeviceLoader + BucketPadding and "
+                         "TrainStep.step_cached -- what train_epoch does -- beside the eager step on the same stream")
+    ap.add_argument("--bucketed-leg", action="store_true", help="(default since round 4; kept for old command lines)")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--cpu-threads", type=int, default=0,
                     help="torch threads for the CPU baseline (0 = min(usable cores, 32))")
@@ -797,7 +798,7 @@ def main():
     log(f"timed region done: {ms:.2f} ms/step")
     # (the host-batch leg -- pcie_inclusive_ms_per_step -- was measured before the capture, see host_batch_leg above)
     bucketed = None
-    if args.bucketed_leg and args.workload == "pcqm4m" and world == 1 and reducer is None:
+    if not args.no_bucketed_leg and args.workload == "pcqm4m" and world == 1 and reducer is None:
         bucketed = bucketed_loader_leg(model, opt, compute_loss, nb, args.profile, dev)
 
     if rank == 0:
