@@ -14,13 +14,13 @@ timeout 900 python bench.py > $O/bench_default.json 2> $O/bench_default.err; ech
 timeout 900 python bench.py --workload code2 --no-cpu-baseline > $O/bench_code2.json 2> $O/bench_code2.err; echo "bench code2 rc=$?" >> $O/rc.txt
 timeout 600 python bench.py --workload zinc --no-cpu-baseline > $O/bench_zinc.json 2> $O/bench_zinc.err; echo "bench zinc rc=$?" >> $O/rc.txt
 # same-box A/B of the arithmetic forms (the 6-product bf16 form of rounds 2-3 against the default)
-GPS_GEMM_F16=0 GPS_WGRAD_F16=0 timeout 400 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-roofline --no-h2d-leg > $O/bench_bf16x6.json 2> $O/bench_bf16x6.err; echo "bench bf16x6 rc=$?" >> $O/rc.txt
-GPS_MULTIHOT_WGRAD=1 timeout 400 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-roofline --no-h2d-leg > $O/bench_multihot.json 2> $O/bench_multihot.err; echo "bench multihot rc=$?" >> $O/rc.txt
+GPS_GEMM_F16=0 GPS_WGRAD_F16=0 timeout 400 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-roofline --no-h2d-leg --no-bucketed-leg > $O/bench_bf16x6.json 2> $O/bench_bf16x6.err; echo "bench bf16x6 rc=$?" >> $O/rc.txt
+GPS_MULTIHOT_WGRAD=1 timeout 400 python bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-roofline --no-h2d-leg --no-bucketed-leg > $O/bench_multihot.json 2> $O/bench_multihot.err; echo "bench multihot rc=$?" >> $O/rc.txt
 export TMPDIR=/tmp
 cd /tmp
 for w in pcqm4m code2; do
   rm -rf /tmp/prof_$w
-  timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_$w -o bench -- python $R/bench.py --workload $w --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-roofline --no-h2d-leg --no-gemm-tuning > $R/$O/prof_$w.json 2> $R/$O/prof_$w.log
+  timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof_$w -o bench -- python $R/bench.py --workload $w --steps 20 --warmup 5 --no-cpu-baseline --no-kernel-roofline --no-h2d-leg --no-bucketed-leg --no-gemm-tuning > $R/$O/prof_$w.json 2> $R/$O/prof_$w.log
   DB=$(find /tmp/prof_$w -name "*.db" | head -1)
   if [ -n "$DB" ]; then
     python $R/tools/rocpd_stats.py $DB --top 70 > $R/$O/kernel_trace_stats_$w.txt 2>&1
