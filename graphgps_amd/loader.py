@@ -40,6 +40,16 @@ def _bucket_step(n: int, frac: float) -> int:
     return max(64, 1 << max(0, round(math.log2(max(frac * n, 1.0)))))
 
 
+class _PaddedCollate:
+    """``collate_fn`` then ``pad``: a picklable callable (DataLoader workers under the spawn start method)."""
+
+    def __init__(self, pad, collate_fn):
+        self.pad, self.collate_fn = pad, collate_fn
+
+    def __call__(self, items):
+        return self.pad(self.collate_fn(items))
+
+
 class BucketPadding:
     """Pads a HOST batch up to a shape bucket so that a captured step can be replayed on it (``TrainStep.step_cached``
     keys on shapes; a shuffled loader never emits the same (nodes, edges) twice: graphgps/train/custom_train.py:16-47
@@ -96,9 +106,7 @@ class BucketPadding:
         interpreter lock with the thread that launches the steps, and 33 ms for the eager step on the un-padded stream).
         Fix ``node_step`` / ``edge_step`` in the constructor then: every worker process holds its own copy of this object,
         and steps chosen from 'the first batch' would be chosen per worker."""
-        def padded(items):
-            return self(collate_fn(items))
-        return padded
+        return _PaddedCollate(self, collate_fn)
 
     def __call__(self, batch):
         """A new host batch (new container, new tensors where rows were appended)."""

@@ -177,3 +177,56 @@ def test_head_rows_and_padding_support_predicate():
     for name, (din, dout, want) in cfgs.items():
         model = g.create_model(os.path.join(g.CONFIG_DIR, name), ["gt.layers", 1], din, dout)
         assert padding_supported(model) is want, name
+
+
+def _collate_graphs(items):
+    from graphgps_amd.data import Batch
+    return Batch.from_graph_list(items)
+
+
+class _Molecules(torch.utils.data.Dataset):
+    """Synthetic PCQM-like graphs as dicts (what Batch.from_graph_list collates)."""
+
+    def __init__(self, n):
+        from graphgps_amd.synthetic import ATOM_FEATURE_DIMS, BOND_FEATURE_DIMS, graph_sizes, molecule_edges
+        gen = torch.Generator().manual_seed(11)
+        self.items = []
+        for k in graph_sizes("P14", n, gen):
+            ei = molecule_edges(k, gen)
+            self.items.append(dict(
+                x=torch.stack([torch.randint(0, d, (k,), generator=gen) for d in ATOM_FEATURE_DIMS], 1),
+                edge_index=ei,
+                edge_attr=torch.stack([torch.randint(0, d, (ei.shape[1],), generator=gen) for d in BOND_FEATURE_DIMS], 1),
+                pestat_RWSE=torch.rand(k, 16, generator=gen), y=torch.randn(1, generator=gen)))
+
+    def __len__(self):
+        return len(self.items)
+
+    def __getitem__(self, i):
+        return self.items[i]
+
+
+def test_padding_in_the_dataloader_workers_collate():
+    """BucketPadding.collate: the padding as part of a torch DataLoader's collate function, in its worker PROCESSES
+    (shuffled, two workers): every emitted batch is padded (gps_counts, dead graphs), the shuffled epoch falls into a
+    few shape buckets although (almost) no two raw batches share a shape; padding twice is refused."""
+    import pickle
+    from torch.utils.data import DataLoader
+    ds = _Molecules(64 * 12)
+    pad = BucketPadding(node_step=64, edge_step=128)               # fixed steps: every worker holds its own copy
+    pickle.loads(pickle.dumps(pad.collate(_collate_graphs)))        # (spawn-safe)
+    torch.manual_seed(0)
+    dl = DataLoader(ds, batch_size=64, shuffle=True, num_workers=2, collate_fn=pad.collate(_collate_graphs))
+    shapes, raw = [], set()
+    for b in dl:
+        n, e, g = b.gps_counts.tolist()
+        assert g == 64 and b.num_graphs == 64 + pad.dead_graphs and b.y.shape[0] == b.num_graphs
+        assert b.x.shape[0] % 64 == 0 and b.edge_index.shape[1] % 128 == 0
+        assert vars(b)["_gps_meta"]["padded"] and vars(b)["_gps_meta"]["b_real"] == 64
+        assert int(b.ptr[64]) == n and int(b.ptr[-1]) == b.x.shape[0]
+        raw.add((n, e))
+        shapes.append((b.x.shape[0], b.edge_index.shape[1]))
+    assert len(shapes) == 12 and len(raw) >= 11
+    assert len(set(shapes)) <= 4, set(shapes)
+    with pytest.raises(ValueError, match="padded already"):
+        pad(b)
