@@ -489,7 +489,7 @@ def bucketed_loader_leg(model, opt, loss_fn, nb, profile, dev, n_batches=24):
     DataLoader), and batches that arrive padded and pinned (BucketPadding.collate in the DataLoader's worker processes +
     pin_memory=True).  Untimed passes meet the buckets (first sight eager, second sight captured), the timed pass runs
     the same batches in another order.  For scale, the eager step on the same un-padded stream (every batch a new shape:
-    the caching allocator cannot recycle) is timed too.  Runs after the timed region: it cannot move `value`."""
+    every first sight of a row count costs host time in the libraries) is timed too.  Runs after the timed region: it cannot move `value`."""
     try:
         from graphgps_amd.loader import BucketPadding, DeviceLoader
         from graphgps_amd.synthetic import model_batch

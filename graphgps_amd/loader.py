@@ -95,6 +95,8 @@ class BucketPadding:
         hits = [k for k, n in (("node", N), ("edge", E), ("graph", B)) if t.dim() >= 1 and t.shape[0] == n]
         if len(hits) == 1:
             return hits[0]
+        if not hits:            # lives on none of the three axes (a per-batch scalar, a lookup table): left as it is
+            return None
         raise ValueError(f"BucketPadding: cannot tell which axis tensor {key!r} {tuple(t.shape)} lives on "
                          f"(nodes {N}, edges {E}, graphs {B})")
 
@@ -147,7 +149,10 @@ class BucketPadding:
             elif k == "gps_counts":
                 raise ValueError("BucketPadding: this batch is padded already")
             else:
-                rows = {"node": pn, "edge": pe, "graph": G}[self._kind(k, v, N, E, B)]
+                kind = self._kind(k, v, N, E, B)
+                if kind is None:
+                    continue
+                rows = {"node": pn, "edge": pe, "graph": G}[kind]
                 new = torch.cat([v, v.new_zeros((rows,) + tuple(v.shape[1:]))], dim=0)
             setattr(out, k, new)
         out.gps_counts = torch.tensor([N, E, B], dtype=torch.int32)

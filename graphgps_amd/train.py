@@ -377,7 +377,7 @@ def _cloned(obj):
 
 # GPS_LOADER_BUCKETS (default on): train_epoch pads loader batches up to shape buckets (loader.BucketPadding) when the model
 # is served by the padded path (padding_supported) -- measured on 256-graph batches of never-repeating shapes: 33.8 ms per
-# eager step un-padded (the caching allocator cannot recycle), 16.0 ms padded on the staging thread and replayed, 9.8 ms when
+# eager step un-padded (host-bound: e.g. 3.8 ms inside rocBLAS at every first sight of a K = rows GEMM), 16.0 ms padded on the staging thread and replayed, 9.8 ms when
 # the batches arrive padded and pinned (BucketPadding.collate in the DataLoader's workers)
 _BUCKETS_DEFAULT = "1"
 LOGGER_FLUSH_EVERY = 16     # iterations between device->host reads for the logger (one sync per flush)

@@ -62,8 +62,12 @@ def test_bucket_padding_ambiguous_axis_is_an_error_and_known_names_are_not():
     b = model_batch("pcqm4m", 8, seed=1)
     N, E, B = _sizes(b)
     b.mystery = torch.zeros(N, 3)
+    b.table = torch.arange(5.0)                                  # on none of the axes: passes through
+    b.scalar = torch.tensor(3.0)
     pad = BucketPadding(node_step=64, edge_step=64)
-    assert pad(b).mystery.shape[0] % 64 == 0                    # first dim matches the node axis only
+    pb = pad(b)
+    assert pb.mystery.shape[0] % 64 == 0                         # first dim matches the node axis only
+    assert pb.table is b.table and pb.scalar is b.scalar
     # make nodes == edges: an unknown tensor is ambiguous now, the named ones still resolve
     sizes, ei, bv, ptr, gen, _ = make_structure("P14", 4, 3)
     n = int(ptr[-1])
