@@ -8,7 +8,12 @@ graph index (CSR by target, CSC by source, ``ptr``, attention tile map: ``ops.bu
 built on that same stream right behind the copies.  The step's stream only waits on one event.
 
 At PCQM4M sizes a batch is ~1.7 MB of int64 features/indices + fp32 RWSE (≈35 µs of PCIe) and the index
-build is ≈30 µs, against a 12 ms step, so with one batch of look-ahead neither shows up in the step time.
+build is ≈30 µs, against a 9 ms step, so with one batch of look-ahead neither shows up in the step time.
+
+``BucketPadding`` (round 4) is the other half of feeding the step from a real loader: a shuffled loader never emits the
+same (nodes, edges) twice, a captured step replays on ONE shape, so host batches are padded up to a few shape buckets --
+in the staging thread here, or in the DataLoader's worker processes (``BucketPadding.collate``) -- with the real row
+counts travelling to the device as a tensor of the batch (``gps_counts``).
 """
 from __future__ import annotations
 
