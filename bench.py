@@ -503,8 +503,7 @@ def bucketed_loader_leg(model, opt, loss_fn, nb, profile, dev, n_batches=24):
         def run(ts, seq, pad, cached):
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            # (replayed steps build the graph index inside the captured graph: none is staged for them)
-            for b in DeviceLoader((q.shallow_copy() for q in seq), dev, pad=pad, build_index=not cached):
+            for b in DeviceLoader((q.shallow_copy() for q in seq), dev, pad=pad):
                 ts.step_cached(b, max_graphs=12) if cached else ts._eager_triplet(b)
             torch.cuda.synchronize()
             return (time.perf_counter() - t0) / len(seq) * 1e3

@@ -472,9 +472,7 @@ def train_epoch(logger, loader, model, optimizer, scheduler, batch_accumulation,
         if pad is None:                                      # first batch it sees
             from .loader import BucketPadding
             pad = model.__dict__["_gps_bucket_padding"] = BucketPadding()
-    # (bucketed batches are replayed, and a captured step builds its graph index from its own static inputs: staging one
-    # per batch on the copy stream would be work nobody reads; the eager first sight of a bucket builds its own)
-    for it, batch in enumerate(DeviceLoader(loader, device, pad=pad, build_index=pad is None)):
+    for it, batch in enumerate(DeviceLoader(loader, device, pad=pad)):
         batch.split = 'train'
         if cached:
             loss, pred_score, true = step.step_cached(batch)
