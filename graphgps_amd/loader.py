@@ -34,6 +34,27 @@ STAGE_LOCK = threading.RLock()
 _BACKGROUND_DEFAULT = os.environ.get("GPS_LOADER_BACKGROUND", "1") != "0"
 
 
+_SWITCH = {"users": 0, "saved": None, "lock": threading.Lock()}
+
+
+def _short_switch_interval(enter: bool, interval: float = 2e-4) -> None:
+    """The interpreter's thread switch interval, lowered while at least one background loader is alive and put back when
+    the last one ends (counted: a train and an eval loader may overlap, and each restoring "its" old value would leave the
+    process on the short interval for good)."""
+    import sys
+    with _SWITCH["lock"]:
+        if enter:
+            if _SWITCH["users"] == 0:
+                _SWITCH["saved"] = sys.getswitchinterval()
+                sys.setswitchinterval(min(_SWITCH["saved"], interval))
+            _SWITCH["users"] += 1
+        elif _SWITCH["users"] > 0:
+            _SWITCH["users"] -= 1
+            if _SWITCH["users"] == 0 and _SWITCH["saved"] is not None:
+                sys.setswitchinterval(_SWITCH["saved"])
+                _SWITCH["saved"] = None
+
+
 _NODE_KEYS = ("x", "batch", "node_depth", "node_is_attributed", "EigVecs", "EigVals")
 _EDGE_KEYS = ("edge_attr",)
 _GRAPH_KEYS = ("y", "y_arr")
@@ -336,9 +357,7 @@ class DeviceLoader:
         # launching thread can sit for milliseconds behind the staging thread every time it comes back from a call
         # that released the lock (a graph replay, a synchronising copy): measured 10.8 ms per replay call against 7.0
         # without a busy staging thread.  A short interval while the loader is alive keeps the hand-over prompt.
-        import sys as _sys
-        old_interval = _sys.getswitchinterval()
-        _sys.setswitchinterval(min(old_interval, 2e-4))
+        _short_switch_interval(True)
         th = threading.Thread(target=worker, name="gps-device-loader", daemon=True)
         th.start()
         try:
@@ -359,7 +378,7 @@ class DeviceLoader:
             # worker is a daemon thread: if it is stuck inside the source's `next` for longer than the join below, it is
             # left behind and ends with the process.
             stop.set()
-            _sys.setswitchinterval(old_interval)
+            _short_switch_interval(False)
             while True:
                 try:
                     q.get_nowait()

@@ -234,3 +234,29 @@ def test_padding_in_the_dataloader_workers_collate():
     assert len(set(shapes)) <= 4, set(shapes)
     with pytest.raises(ValueError, match="padded already"):
         pad(b)
+
+
+def test_switch_interval_is_counted_and_restored():
+    """loader._short_switch_interval: lowered by the first background loader, restored by the LAST one to end -- whatever
+    the order in which overlapping loaders finish."""
+    import sys
+    from graphgps_amd import loader as L
+    before = sys.getswitchinterval()
+    try:
+        sys.setswitchinterval(0.005)
+        L._short_switch_interval(True)
+        assert sys.getswitchinterval() == pytest.approx(2e-4, rel=0.05)
+        L._short_switch_interval(True)                 # a second loader while the first is alive
+        L._short_switch_interval(False)                # the first one ends: still short
+        assert sys.getswitchinterval() == pytest.approx(2e-4, rel=0.05)
+        L._short_switch_interval(False)                # the last one ends: restored
+        assert sys.getswitchinterval() == pytest.approx(0.005, rel=0.05)
+        L._short_switch_interval(False)                # an unmatched exit changes nothing
+        assert sys.getswitchinterval() == pytest.approx(0.005, rel=0.05) and L._SWITCH["users"] == 0
+        sys.setswitchinterval(1e-4)                    # a process that already runs shorter keeps its value
+        L._short_switch_interval(True)
+        assert sys.getswitchinterval() == pytest.approx(1e-4, rel=0.05)
+        L._short_switch_interval(False)
+        assert sys.getswitchinterval() == pytest.approx(1e-4, rel=0.05)
+    finally:
+        sys.setswitchinterval(before)
