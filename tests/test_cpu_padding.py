@@ -260,3 +260,65 @@ def test_switch_interval_is_counted_and_restored():
         assert sys.getswitchinterval() == pytest.approx(1e-4, rel=0.05)
     finally:
         sys.setswitchinterval(before)
+
+
+def test_background_loader_control_flow_without_a_gpu(monkeypatch):
+    """DeviceLoader._iter_background with the device side stubbed out (streams, events, staging): order of the batches,
+    a consumer that leaves early (worker stopped, source iterator closed), a worker exception surfaced on the consumer's
+    thread -- and the switch interval back at its value after each of them."""
+    import sys
+    import threading
+    from graphgps_amd import loader as L
+
+    class Ev:
+        pass
+
+    class Stream:
+        def wait_event(self, ev):
+            assert isinstance(ev, Ev)
+
+    monkeypatch.setattr(torch.cuda, "Stream", lambda device=None: Stream())
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda device=None: Stream())
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: None)
+    monkeypatch.setattr(L.DeviceLoader, "_hand_over", classmethod(lambda cls, b, s: None))
+    staged = []
+
+    def stage(self, host, copy_stream):
+        if host == "boom":
+            raise RuntimeError("staging failed")
+        staged.append((host, threading.current_thread().name))
+        return ("dev-" + host, Ev())
+    monkeypatch.setattr(L.DeviceLoader, "_stage", stage)
+    before = sys.getswitchinterval()
+
+    class Source:
+        def __init__(self, items):
+            self.items, self.closed = list(items), False
+
+        def __iter__(self):
+            return self
+
+        def __next__(self):
+            if not self.items:
+                raise StopIteration
+            return self.items.pop(0)
+
+        def close(self):
+            self.closed = True
+
+    dl = L.DeviceLoader(Source(["a", "b", "c", "d"]), "cuda:0", depth=2, background=True)
+    assert list(dl) == ["dev-a", "dev-b", "dev-c", "dev-d"]
+    assert {t for _, t in staged} == {"gps-device-loader"}              # staged on the worker thread
+    assert sys.getswitchinterval() == pytest.approx(before, rel=0.05) and L._SWITCH["users"] == 0
+    src = Source([str(i) for i in range(50)])
+    for i, b in enumerate(L.DeviceLoader(src, "cuda:0", depth=2, background=True)):
+        assert L._SWITCH["users"] == 1 and sys.getswitchinterval() <= 2.1e-4
+        if i == 2:
+            break                                                        # early exit: GeneratorExit inside the loader
+    import gc
+    gc.collect()
+    assert L._SWITCH["users"] == 0 and sys.getswitchinterval() == pytest.approx(before, rel=0.05)
+    assert src.closed and len(src.items) > 40                            # stopped early, source closed
+    with pytest.raises(RuntimeError, match="staging failed"):
+        list(L.DeviceLoader(Source(["a", "boom", "c"]), "cuda:0", depth=2, background=True))
+    assert L._SWITCH["users"] == 0 and sys.getswitchinterval() == pytest.approx(before, rel=0.05)
