@@ -39,19 +39,34 @@ def broadcast_state(model: nn.Module, src: int = 0, process_group=None, bucket_b
     first step (``train.train_epoch`` and ``bench.py`` do)."""
     if not dist.is_initialized() or dist.get_world_size(process_group) < 2:
         return 0
+    return _broadcast_tensors(list(model.parameters()) + list(model.buffers()), src, process_group, bucket_bytes)
+
+
+def broadcast_buffers(model: nn.Module, src: int = 0, process_group=None, bucket_bytes: int = 64 << 20) -> int:
+    """Buffers only (BatchNorm running statistics, ``num_batches_tracked``, the Performer projections), from rank ``src``.
+    torch's DDP re-broadcasts buffers on EVERY forward (``broadcast_buffers=True``); here the training step keeps them per
+    rank (the step is a replayed hipGraph: no collective inside it) and they are brought back in line where a reader
+    outside the step looks at them -- before an evaluation pass and before a checkpoint is written
+    (``train.eval_epoch`` calls this).  Returns the bytes broadcast (0 without a process group)."""
+    if not dist.is_initialized() or dist.get_world_size(process_group) < 2:
+        return 0
+    return _broadcast_tensors(list(model.buffers()), src, process_group, bucket_bytes)
+
+
+def _broadcast_tensors(all_tensors, src, process_group, bucket_bytes) -> int:
     tensors, seen = [], set()
-    for t in list(model.parameters()) + list(model.buffers()):
+    for t in all_tensors:
         key = (t.data_ptr(), t.numel(), t.dtype)
         if t.numel() == 0 or key in seen:           # tied / aliased storage travels once
             continue
         seen.add(key)
         tensors.append(t.data)
     total = 0
-    by_dtype: Dict[torch.dtype, List[torch.Tensor]] = {}
-    for t in tensors:
-        by_dtype.setdefault(t.dtype, []).append(t)
+    by_dtype: Dict[tuple, List[torch.Tensor]] = {}      # one flat bucket per (dtype, device): a CPU buffer next to
+    for t in tensors:                                    # device parameters must not meet them in one torch.cat
+        by_dtype.setdefault((t.dtype, t.device), []).append(t)
     with torch.no_grad():
-        for dtype, ts in by_dtype.items():
+        for _, ts in by_dtype.items():
             i = 0
             while i < len(ts):
                 chunk, nbytes = [], 0

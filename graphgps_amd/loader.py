@@ -66,6 +66,35 @@ def _bucket_step(n: int, frac: float) -> int:
     return max(64, 1 << max(0, round(math.log2(max(frac * n, 1.0)))))
 
 
+def _set_num_graphs(batch, n: int) -> None:
+    """``batch.num_graphs = n`` that is checked.  A ``torch_geometric`` ``Batch`` exposes ``num_graphs`` as a property
+    WITHOUT a setter over ``_num_graphs``; its ``__setattr__`` then files the assignment as a new key of ``_store`` and
+    raises nothing, and ``batch.num_graphs`` keeps answering the old count while ``ptr`` / ``batch`` / ``y`` describe
+    the padded one.  So: assign, read back, and if the answer is not ``n`` set the backing field and remove
+    the stray store key."""
+    try:
+        batch.num_graphs = n
+    except Exception:                       # a read-only property that does raise
+        pass
+    try:
+        ok = int(batch.num_graphs) == n
+    except Exception:
+        ok = False
+    if ok:
+        return
+    vars(batch)["_num_graphs"] = n
+    store = vars(batch).get("_store")
+    for holder in (store, getattr(store, "_mapping", None)):
+        try:
+            if holder is not None and "num_graphs" in holder:
+                del holder["num_graphs"]
+        except Exception:
+            pass
+    if int(batch.num_graphs) != n:
+        raise ValueError(f"BucketPadding: could not set num_graphs = {n} on a {type(batch).__name__} "
+                         f"(it answers {batch.num_graphs})")
+
+
 class _PaddedCollate:
     """``collate_fn`` then ``pad``: a picklable callable (DataLoader workers under the spawn start method)."""
 
@@ -116,9 +145,16 @@ class BucketPadding:
             return "node"
         if key in _EDGE_KEYS:
             return "edge"
-        if key in _GRAPH_KEYS:
-            return "graph"
         hits = [k for k, n in (("node", N), ("edge", E), ("graph", B)) if t.dim() >= 1 and t.shape[0] == n]
+        if key in _GRAPH_KEYS:
+            # a target lives on the axis its leading dimension says (graph-level: B rows; node- / edge-level tasks: N / E
+            # rows); the name only settles a tie (B == N happens with one-node graphs) and never overrides the shape
+            if "graph" in hits:
+                return "graph"
+            if len(hits) == 1:
+                return hits[0]
+            raise ValueError(f"BucketPadding: target {key!r} {tuple(t.shape)} matches none of the batch's axes "
+                             f"unambiguously (nodes {N}, edges {E}, graphs {B})")
         if len(hits) == 1:
             return hits[0]
         if not hits:            # lives on none of the three axes (a per-batch scalar, a lookup table): left as it is
@@ -182,10 +218,7 @@ class BucketPadding:
                 new = torch.cat([v, v.new_zeros((rows,) + tuple(v.shape[1:]))], dim=0)
             setattr(out, k, new)
         out.gps_counts = torch.tensor([N, E, B], dtype=torch.int32)
-        try:
-            out.num_graphs = B + G
-        except Exception:                   # a PyG Batch: num_graphs is a read-only property over _num_graphs
-            vars(out)["_num_graphs"] = B + G
+        _set_num_graphs(out, B + G)
         if torch.is_tensor(ptr) and ptr.numel() > 1:
             real_max = int((ptr[1:] - ptr[:-1]).max())
         elif torch.is_tensor(bv) and bv.numel():

@@ -207,9 +207,10 @@ class TrainStep:
             return self._eager_triplet(batch)
         key = self._shape_key(batch)
         cache = self.__dict__.setdefault("_shape_cache", {})
-        ent = cache.get(key)
-        if ent is False:                     # this shape's capture failed before: never retried
-            return self._eager_triplet(batch)
+        failed = self.__dict__.setdefault("_shape_failed", set())
+        if key in failed:                    # this shape's capture failed before: never retried; kept apart
+            return self._eager_triplet(batch)    # from the LRU of live graphs, so a marker can neither evict a working
+        ent = cache.get(key)                     # graph nor be evicted and retried
         if ent is None:
             seen = self.__dict__.setdefault("_shape_seen", set())
             if key not in seen:              # first sight of this shape: run it eagerly, capture if it comes back
@@ -219,7 +220,7 @@ class TrainStep:
                 return self._eager_triplet(batch)
             ent = self._capture_shape(batch)
             if ent is None:                  # capture is an optimisation, never a requirement -- but a failure is remembered:
-                cache[key] = False           # a step that cannot be captured (a host read in a head, a boolean-mask loss)
+                failed.add(key)              # a step that cannot be captured (a host read in a head, a boolean-mask loss)
                 fails = self.__dict__["_capture_failures"] = self.__dict__.get("_capture_failures", 0) + 1
                 if fails >= 3:               # would otherwise pay an aborted capture on every repeat of every shape
                     self.__dict__["_replay_ok"] = False
@@ -343,7 +344,10 @@ def padding_supported(model) -> bool:
     from .head.heads import _GraphLevelHead
     from .layer import gps_block as _blk
     from .layer.gps_layer import GPSLayer
+    from .layer import gps_layer as _gl
     from . import gemm as _gemm
+    if not _gl._BLOCK_ENABLED:           # GPS_FUSED_BLOCK=0 (the A/B switch): the operator path refuses padded batches
+        return False
     known, layers = set(), 0
     for m in model.modules():
         if isinstance(m, GPSLayer):
@@ -494,6 +498,9 @@ def eval_epoch(logger, loader, model, split='val'):
     logger needs happen ``LOGGER_FLUSH_EVERY`` batches at a time."""
     model.eval()
     device = torch.device(cfg.accelerator)
+    if torch.distributed.is_available() and torch.distributed.is_initialized():
+        from .dp import broadcast_buffers    # running statistics drift per rank during training (DDP re-broadcasts them
+        broadcast_buffers(model)             # every forward; here once per evaluation pass): every rank evaluates rank 0's
     log = _DeferredLogger(logger)
     for batch in DeviceLoader(loader, device):
         batch.split = split

@@ -322,3 +322,74 @@ def test_background_loader_control_flow_without_a_gpu(monkeypatch):
     with pytest.raises(RuntimeError, match="staging failed"):
         list(L.DeviceLoader(Source(["a", "boom", "c"]), "cuda:0", depth=2, background=True))
     assert L._SWITCH["users"] == 0 and sys.getswitchinterval() == pytest.approx(before, rel=0.05)
+
+
+class _PyGLikeBatch:
+    """What a torch_geometric ``Batch`` does with ``num_graphs``: a property WITHOUT a setter over
+    ``_num_graphs``, and a ``__setattr__`` that files an assignment to it as a key of ``_store`` without raising."""
+
+    def __init__(self, **kw):
+        object.__setattr__(self, "_store", {})
+        object.__setattr__(self, "_num_graphs", None)
+        for k, v in kw.items():
+            setattr(self, k, v)
+
+    @property
+    def num_graphs(self):
+        return self._num_graphs
+
+    def __setattr__(self, k, v):
+        if k.startswith("_"):
+            object.__setattr__(self, k, v)
+        else:
+            self._store[k] = v              # 'num_graphs' lands here too: no setter, no exception
+
+    def __getattr__(self, k):
+        store = object.__getattribute__(self, "_store")
+        if k in store:
+            return store[k]
+        raise AttributeError(k)
+
+    def keys(self):
+        return [k for k in self._store if k != "num_graphs"]
+
+    def __copy__(self):
+        out = _PyGLikeBatch.__new__(_PyGLikeBatch)
+        object.__setattr__(out, "_store", dict(self._store))
+        object.__setattr__(out, "_num_graphs", self._num_graphs)
+        for k, v in vars(self).items():
+            if k not in ("_store", "_num_graphs"):
+                object.__setattr__(out, k, v)
+        return out
+
+
+def test_bucket_padding_sets_num_graphs_on_a_batch_whose_property_has_no_setter():
+    """on a PyG ``Batch`` the plain assignment ``out.num_graphs = B + G`` is swallowed by ``_store`` and
+    ``batch.num_graphs`` keeps answering B while ptr / batch / y describe B + G graphs; graph_index_of and the pooling
+    head read ``num_graphs``."""
+    b = model_batch("pcqm4m", 8, seed=2)
+    N, E, B = _sizes(b)
+    pg = _PyGLikeBatch(**{k: getattr(b, k) for k in b.keys() if torch.is_tensor(getattr(b, k))})
+    pg._num_graphs = B
+    assert pg.num_graphs == B
+    pg.num_graphs = 99                      # the trap itself: no exception, no effect
+    assert pg.num_graphs == B
+    del pg._store["num_graphs"]
+    pad = BucketPadding(node_step=64, edge_step=64, dead_graphs=4)
+    out = pad(pg)
+    assert out.num_graphs == B + 4 == out.ptr.numel() - 1 == out.y.shape[0]
+    assert "num_graphs" not in out._store   # no stray key left behind
+    assert pg.num_graphs == B               # the source batch is left alone
+    assert out.gps_counts.tolist() == [N, E, B]
+
+
+def test_bucket_padding_puts_a_node_level_target_on_the_node_axis():
+    """``y`` of a node-level task has N rows; it is padded with the node padding, not with G graph rows."""
+    b = model_batch("pcqm4m", 8, seed=3)
+    N, E, B = _sizes(b)
+    b.y = torch.arange(N, dtype=torch.float32)
+    pb = BucketPadding(node_step=64, edge_step=64, dead_graphs=4)(b)
+    assert pb.y.shape[0] == pb.x.shape[0] and torch.equal(pb.y[:N], b.y) and not pb.y[N:].any()
+    b.y = torch.zeros(B + 1)                # on none of the axes: a target must not pass through silently mis-sized
+    with pytest.raises(ValueError, match="matches none of the batch's axes"):
+        BucketPadding(node_step=64, edge_step=64)(b)

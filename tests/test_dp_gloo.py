@@ -368,7 +368,25 @@ def _bcast_worker(rank, world, port, q):
         proj = [k for k, _ in m.named_buffers() if k.endswith("projection_matrix")]
         assert proj, "the model under test must hold a random Performer projection buffer"
         nbytes = broadcast_state(m)
-        q.put((rank, before, digest(), nbytes, len(proj)))
+        after = digest()
+        # buffers drift per rank while training (running statistics); dp.broadcast_buffers (eval_epoch, before a
+        # checkpoint) brings the BUFFERS back to rank 0's and leaves the parameters alone
+        from graphgps_amd.dp import broadcast_buffers
+
+        def part(named):
+            h = hashlib.sha256()
+            for k, t in sorted(named, key=lambda kv: kv[0]):
+                h.update(k.encode()); h.update(t.detach().cpu().contiguous().numpy().tobytes())
+            return h.hexdigest()
+        with torch.no_grad():
+            for bn in [mod for mod in m.modules() if isinstance(mod, torch.nn.BatchNorm1d)]:
+                bn.running_var.mul_(1.0 + 0.5 * rank)
+            first = next(m.parameters())
+            first.add_(float(rank))          # a parameter that differs: must NOT be touched by broadcast_buffers
+        m.register_buffer("cpu_side_table", torch.full((3,), float(rank)))      # a second (dtype, device) bucket
+        m.cpu_side_table = m.cpu_side_table.double()
+        nb2 = broadcast_buffers(m)
+        q.put((rank, before, after, nbytes, len(proj), part(m.named_buffers()), part(m.named_parameters()), nb2))
     finally:
         dist.destroy_process_group()
 
@@ -388,8 +406,11 @@ def test_broadcast_state_makes_differently_seeded_replicas_identical_world2_gloo
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    (_, b0, a0, n0, k0), (_, b1, a1, n1, k1) = results
+    (_, b0, a0, n0, k0, buf0, par0, nb0), (_, b1, a1, n1, k1, buf1, par1, nb1) = results
     assert b0 != b1, "the two ranks were supposed to start from different states"
     assert a0 == a1, "replicas differ after broadcast_state"
     assert a0 == b0, "rank 0's state is the one that must survive"
     assert n0 == n1 and n0 > 0 and k0 == 2
+    assert buf0 == buf1, "buffers differ after broadcast_buffers"
+    assert par0 != par1, "broadcast_buffers must leave the parameters alone"
+    assert 0 < nb0 == nb1 < n0

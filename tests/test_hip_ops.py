@@ -721,7 +721,7 @@ def test_gin_aggregate_matches_index_add():
                                    # N, K multiples of 4 only (d = 52: ZINC GPS-small variants, 72: peptides SAN/GPS)
                                    (500, 52, 364), (500, 364, 52), (743, 72, 72), (300, 52, 52), (500, 20, 36)])
 @pytest.mark.parametrize("f16", [True, False], ids=["f16x3", "bf16x6"])
-def test_gemm_panel_fp32_exact_products(M, K, N, f16):
+def test_gemm_panel_split_products(M, K, N, f16):
     """csrc/gemm_panel.hip at the block's projection shapes (N, K in {384, 768, 2688}; M = nodes / edges, ragged last
     row tile): C = A W^T + bias against fp64, through the weight image (forward) and through the transposed image
     (input gradient), with the addend and both epilogues; the error is that of an fp32 GEMM (a few 1e-7 of the
