@@ -32,6 +32,100 @@ __global__ __launch_bounds__(256) void k_pool_fwd(const float* __restrict__ x,
   acc.store(out + g * (int64_t)d + c);
 }
 
+// Round 5 -- the forward over ROW SLICES.  k_pool_fwd above gives one lane group to a whole graph: 32 code2 graphs of
+// ~800 rows are 8 workgroups on 256 CUs walking 800 dependent-free but serial rows each (273 us for 26 MB = 1.2 % of the HBM
+// rate).  Here a graph's rows are cut into slices of POOL_SL rows and every slice gets a workgroup: slot
+// floor(ptr[g] / SL) + g is the first slice of graph g (the tile-map numbering of csrc/graph_index.hip: provably
+// non-overlapping, needs no host knowledge of the graph sizes; floor(N / SL) + B slots in all), a workgroup finds its
+// (graph, slice) by a binary search over ptr, R = 256 / (d / VEC) row-lanes walk the slice's rows round-robin and are
+// summed in row-lane order through LDS.  A graph of one slice is written straight to `out`; the partial rows of longer
+// graphs go to the workspace and k_pool_merge adds them in slice order.  Fixed partition, fixed order: deterministic.
+constexpr int POOL_SL = 32;
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_pool_slices(const float* __restrict__ x, const int32_t* __restrict__ ptr,
+                                                     int64_t B, int d, int mean, float* __restrict__ out,
+                                                     float* __restrict__ part) {
+  extern __shared__ __attribute__((aligned(16))) float lds[];   // [R][d]
+  const int b = blockIdx.x;
+  // largest g with floor(ptr[g] / SL) + g <= b   (slot numbers increase strictly with g)
+  int lo = 0, hi = (int)B - 1;
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if (ptr[mid] / POOL_SL + mid <= b) lo = mid; else hi = mid - 1;
+  }
+  const int g = lo;
+  const int n0 = ptr[g], n1 = ptr[g + 1];
+  const int k = b - (n0 / POOL_SL + g);
+  const int r0 = n0 + k * POOL_SL;
+  if (r0 >= n1) return;                                  // a slot past the graph's last slice (workgroup-uniform)
+  const int r1 = min(r0 + POOL_SL, n1);
+  const int L = d / VEC;                                 // lanes per row
+  const int Lc = L < 256 ? L : 256;
+  const int R = 256 / Lc;                                // rows walked side by side
+  const int lane = threadIdx.x % Lc, r = threadIdx.x / Lc;
+  const bool single = n1 - n0 <= POOL_SL;
+  for (int cl = lane; cl < L; cl += Lc) {                // (one trip unless d / VEC > 256)
+    const int c = cl * VEC;
+    Vec<VEC> acc = Vec<VEC>::zero();
+    if (r < R) {
+#pragma unroll 4
+      for (int n = r0 + r; n < r1; n += R) {
+        const Vec<VEC> v = Vec<VEC>::load(x + (int64_t)n * d + c);
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) acc[q] += v[q];
+      }
+      if (r > 0) acc.store(lds + (r - 1) * d + c);
+    }
+    __syncthreads();
+    if (r == 0) {
+      for (int q2 = 1; q2 < R; ++q2) {
+        const Vec<VEC> p = Vec<VEC>::load(lds + (q2 - 1) * d + c);
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) acc[q] += p[q];
+      }
+      if (single) {
+        if (mean) {
+          const float cnt = (float)(n1 - n0);
+#pragma unroll
+          for (int q = 0; q < VEC; ++q) acc[q] = acc[q] / cnt;
+        }
+        acc.store(out + (int64_t)g * d + c);
+      } else {
+        acc.store(part + (int64_t)b * d + c);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+template <int VEC>
+__global__ __launch_bounds__(256) void k_pool_merge(const float* __restrict__ part, const int32_t* __restrict__ ptr,
+                                                    int64_t B, int d, int mean, float* __restrict__ out) {
+  const int lanes_per_row = d / VEC;
+  const int64_t t = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
+  const int64_t g = t / lanes_per_row;
+  if (g >= B) return;
+  const int c = (int)(t - g * lanes_per_row) * VEC;
+  const int n0 = ptr[g], n1 = ptr[g + 1];
+  const int n = n1 - n0;
+  if (n > 0 && n <= POOL_SL) return;                     // written by k_pool_slices
+  Vec<VEC> acc = Vec<VEC>::zero();                        // (an empty graph pools to zero)
+  const int64_t slot0 = n0 / POOL_SL + g;
+  const int ns = (n + POOL_SL - 1) / POOL_SL;
+  for (int k = 0; k < ns; ++k) {
+    const Vec<VEC> v = Vec<VEC>::load(part + (slot0 + k) * d + c);
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) acc[q] += v[q];
+  }
+  if (mean) {
+    const float cnt = (float)max(n, 1);                   // PyG clamps the count to >= 1
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) acc[q] = acc[q] / cnt;
+  }
+  acc.store(out + g * (int64_t)d + c);
+}
+
 template <int VEC>
 __global__ __launch_bounds__(256) void k_pool_bwd(const float* __restrict__ g_out,
                                                   const int32_t* __restrict__ ptr,
@@ -214,6 +308,33 @@ int gps_segment_pool_fwd(const float* x, const int32_t* ptr, int64_t B, int d, i
     k_pool_fwd<VEC><<<gps::grid_for(B * (int64_t)(d / VEC), 256), 256, 0, s>>>(x, ptr, B, d, mean, out);
   });
   return gps::launch_status("gps_segment_pool_fwd");
+}
+
+size_t gps_segment_pool_workspace_bytes(int64_t N, int64_t B, int d) {
+  if (N < 0 || B < 1 || d < 1) return 0;
+  return (size_t)(N / POOL_SL + B) * d * sizeof(float) + 64;
+}
+
+int gps_segment_pool_fwd_sliced(const float* x, const int32_t* ptr, int64_t N, int64_t B, int d, int mean, float* out,
+                                void* ws, size_t ws_bytes, gps_stream_t stream) {
+  GPS_REQUIRE(B >= 0 && N >= 0 && d > 0, "gps_segment_pool_fwd_sliced: bad sizes");
+  if (B == 0) return GPS_OK;
+  GPS_REQUIRE(ptr && out && ws && (x || N == 0), "gps_segment_pool_fwd_sliced: null buffer");
+  GPS_REQUIRE(ws_bytes >= gps_segment_pool_workspace_bytes(N, B, d) && (uintptr_t)ws % 16 == 0,
+              "gps_segment_pool_fwd_sliced: workspace too small / misaligned");
+  GPS_REQUIRE(N / POOL_SL + B < (1ll << 31), "gps_segment_pool_fwd_sliced: too many slices");
+  hipStream_t s = gps::as_stream(stream);
+  float* part = static_cast<float*>(ws);
+  const unsigned slots = (unsigned)(N / POOL_SL + B);
+  const bool a16 = ((uintptr_t)x % 16 == 0) && ((uintptr_t)out % 16 == 0);
+  const bool a8 = ((uintptr_t)x % 8 == 0) && ((uintptr_t)out % 8 == 0);
+  GPS_DISPATCH_VEC(d, a16, a8, {
+    const int L = d / VEC, Lc = L < 256 ? L : 256;
+    const size_t lds = sizeof(float) * (size_t)(256 / Lc) * d;
+    k_pool_slices<VEC><<<slots, 256, lds, s>>>(x, ptr, B, d, mean, out, part);
+    k_pool_merge<VEC><<<gps::grid_for(B * (int64_t)(d / VEC), 256), 256, 0, s>>>(part, ptr, B, d, mean, out);
+  });
+  return gps::launch_status("gps_segment_pool_fwd_sliced");
 }
 
 int gps_segment_pool_bwd(const float* g_out, const int32_t* ptr, const int32_t* node_graph,

@@ -15,7 +15,7 @@ import torch  # noqa: F401  -- must be imported first: it maps the HIP runtime o
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GPS_HIP_LIB: an alternative build of the same ABI (A/B timing of kernel variants in one process launch each)
 LIB_PATH = os.environ.get("GPS_HIP_LIB") or os.path.join(_HERE, "csrc", "libgps_hip.so")
-ABI_VERSION = 6
+ABI_VERSION = 7
 
 _lib: Optional[ctypes.CDLL] = None
 
@@ -46,6 +46,8 @@ _SIGNATURES = {
     "gps_embedding_grad": (c_int, [_P, _P, _P, c_int64, c_int64, c_int, _P, _P, c_size_t, _P]),
     "gps_segment_pool_fwd": (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P]),
     "gps_segment_pool_bwd": (c_int, [_P, _P, _P, c_int64, c_int, c_int, _P, _P]),
+    "gps_segment_pool_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
+    "gps_segment_pool_fwd_sliced": (c_int, [_P, _P, c_int64, c_int64, c_int, c_int, _P, _P, c_size_t, _P]),
     "gps_bn_workspace_floats": (c_size_t, [c_int64, c_int]),
     "gps_bn_stats": (c_int, [_P, c_int64, c_int, c_float, c_float, _P, _P, _P, _P, _P, _P]),
     "gps_bn_apply": (c_int, [_P, _P, _P, _P, _P, _P, c_int64, c_int, c_int, c_float, c_uint64, _P, _P]),

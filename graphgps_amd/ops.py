@@ -9,6 +9,8 @@ from __future__ import annotations
 from dataclasses import dataclass
 from typing import Optional, Tuple
 
+import os
+
 import torch
 
 from . import lib as _lib
@@ -621,6 +623,9 @@ def _node_graph(gi: GraphIndex) -> torch.Tensor:
     return ng
 
 
+_POOL_SLICED = os.environ.get("GPS_POOL_SLICED", "1") != "0"
+
+
 class _SegmentPool(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x: torch.Tensor, gi: GraphIndex, mean: bool):
@@ -629,8 +634,14 @@ class _SegmentPool(torch.autograd.Function):
         x = _f32c(x, "x")
         d = x.shape[1]
         out = torch.empty(gi.B, d, dtype=torch.float32, device=dev)
-        check(L.gps_segment_pool_fwd(ptr(x), ptr(gi.ptr), gi.B, d, int(mean), ptr(out),
-                                     current_stream(dev)), "gps_segment_pool_fwd")
+        if _POOL_SLICED:                     # round 5: one workgroup per (graph, 32-row slice) + a merge in slice order
+            nb = L.gps_segment_pool_workspace_bytes(gi.N, gi.B, d)
+            ws = torch.empty((nb + 3) // 4, dtype=torch.float32, device=dev)
+            check(L.gps_segment_pool_fwd_sliced(ptr(x), ptr(gi.ptr), gi.N, gi.B, d, int(mean), ptr(out), ptr(ws), nb,
+                                                current_stream(dev)), "gps_segment_pool_fwd_sliced")
+        else:                                # GPS_POOL_SLICED=0: one lane group per graph (rounds 1-4)
+            check(L.gps_segment_pool_fwd(ptr(x), ptr(gi.ptr), gi.B, d, int(mean), ptr(out),
+                                         current_stream(dev)), "gps_segment_pool_fwd")
         ctx.gi, ctx.mean, ctx.d = gi, bool(mean), d
         return out
 

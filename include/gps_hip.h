@@ -473,6 +473,15 @@ int gps_embedding_grad(const float* g, const int64_t* tok_sorted, const int64_t*
                        float* g_w, void* ws, size_t ws_bytes, gps_stream_t stream);
 int gps_segment_pool_fwd(const float* x, const int32_t* ptr, int64_t B, int d, int mean, float* out,
                          gps_stream_t stream);
+/* The same pooling with the rows of a graph cut into slices of 32 (round 5): one workgroup per (graph, slice) -- slot
+ * floor(ptr[g] / 32) + g is graph g's first slice, floor(N / 32) + B slots in all, found on the device from `ptr` alone --
+ * partial rows of multi-slice graphs summed in slice order by a second launch.  Same result contract as
+ * gps_segment_pool_fwd (global_add_pool / global_mean_pool: graphgps/head/san_graph.py:35, ogb_code_graph.py:37; an empty
+ * graph pools to 0), deterministic; what it changes is who does the work: 32 graphs of ~800 rows were 8 workgroups.
+ * ws: gps_segment_pool_workspace_bytes(N, B, d) bytes, 16-byte aligned, contents irrelevant on entry. */
+size_t gps_segment_pool_workspace_bytes(int64_t N, int64_t B, int d);
+int gps_segment_pool_fwd_sliced(const float* x, const int32_t* ptr, int64_t N, int64_t B, int d, int mean, float* out,
+                                void* ws, size_t ws_bytes, gps_stream_t stream);
 int gps_segment_pool_bwd(const float* g_out, const int32_t* ptr, const int32_t* node_graph,
                          int64_t N, int d, int mean, float* g_x, gps_stream_t stream);
 

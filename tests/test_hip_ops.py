@@ -319,6 +319,47 @@ def test_segment_pool(mode):
     assert_close(xg.grad, xr.grad, Tol.GRAD_REL, "pool grad", rel_to_max=True)
 
 
+@pytest.mark.parametrize("d", [256, 384, 52, 6, 1028])
+@pytest.mark.parametrize("mode", ["mean", "add"])
+def test_segment_pool_over_row_slices(mode, d):
+    """Round 5, csrc/segment_pool.hip k_pool_slices / k_pool_merge (one workgroup per 32-row slice of a graph, partial rows
+    merged in slice order) against fp64 index_add: graphs of 1, 31, 32, 33, 64, 65 and 1,000 rows, EMPTY graphs (first,
+    middle, last: pooled to 0, mean count clamped to 1 as PyG does), widths with 4- / 2-float lanes, more lanes per row than
+    a workgroup has threads; bitwise reproducible; same results as the one-lane-group-per-graph kernel to rounding."""
+    from graphgps_amd import ops as _ops
+    from graphgps_amd.ops import segment_pool
+    sizes = torch.tensor([0, 1, 31, 32, 0, 33, 64, 65, 1000, 7, 0])
+    B = len(sizes)
+    ptr = torch.cat([torch.zeros(1, dtype=torch.long), torch.cumsum(sizes, 0)])
+    N = int(ptr[-1])
+    bvec = torch.repeat_interleave(torch.arange(B), sizes)
+    gen = torch.Generator().manual_seed(d)
+    ei = torch.stack([torch.arange(N), torch.arange(N)])                   # self loops: the index only needs ptr here
+    x, w = torch.randn(N, d, generator=gen), torch.randn(B, d, generator=gen)
+    xr = x.double().requires_grad_(True)
+    ref = torch.zeros(B, d, dtype=torch.float64).index_add_(0, bvec, xr)
+    if mode == "mean":
+        ref = ref / sizes.clamp(min=1)[:, None]
+    (ref * w.double()).sum().backward()
+    gi = _index(ei, bvec, ptr)
+    xg = x.cuda().requires_grad_(True)
+    out = segment_pool(xg, gi, mode)
+    (out * w.cuda()).sum().backward()
+    scale = 1.0 if mode == "mean" else 30.0                                # |sum of 1,000 N(0,1)| ~ 30
+    assert_close(out, ref, Tol.ACT * scale, "pool over slices")
+    assert_close(xg.grad, xr.grad, Tol.GRAD_REL, "pool grad", rel_to_max=True)
+    assert float(out[0].abs().max()) == 0.0 and float(out[4].abs().max()) == 0.0 and float(out[-1].abs().max()) == 0.0
+    again = segment_pool(x.cuda(), gi, mode)
+    assert torch.equal(again, out.detach()), "the sliced pooling is not bitwise reproducible"
+    old = _ops._POOL_SLICED
+    try:
+        _ops._POOL_SLICED = False
+        one = segment_pool(x.cuda(), gi, mode)
+    finally:
+        _ops._POOL_SLICED = old
+    assert_close(one, ref, Tol.ACT * scale, "pool, one lane group per graph")
+
+
 def test_cpu_tensor_is_rejected():
     from graphgps_amd.lib import GpsHipError
     from graphgps_amd.ops import build_graph_index

@@ -53,6 +53,39 @@ def _step(model, state, batch, b_real, dev):
     return pred.detach().clone(), float(loss), _grads(model), _buffers(model), x0.grad.clone(), e0.grad.clone()
 
 
+def _reverse_graphs(b):
+    """The same host batch with its graphs in reverse order (nodes, edges, per-graph rows moved along)."""
+    ptr = b.ptr
+    B = ptr.numel() - 1
+    order = torch.arange(B - 1, -1, -1)
+    sizes = (ptr[1:] - ptr[:-1])[order]
+    new_ptr = torch.cat([ptr.new_zeros(1), torch.cumsum(sizes, 0)])
+    node_src = torch.cat([torch.arange(int(ptr[g]), int(ptr[g + 1])) for g in order.tolist()])     # new row -> old row
+    new_of_old = torch.empty_like(node_src)
+    new_of_old[node_src] = torch.arange(node_src.numel())
+    eg = b.batch[b.edge_index[0]]                           # graph of every edge
+    edge_src = torch.cat([(eg == g).nonzero().flatten() for g in order.tolist()])                    # keeps the order inside a graph
+    out = b.clone()
+    N, E = b.x.shape[0], b.edge_index.shape[1]
+    for k in b.keys():
+        v = getattr(b, k)
+        if not torch.is_tensor(v):
+            continue
+        if k == "edge_index":
+            setattr(out, k, new_of_old[v[:, edge_src]])
+        elif k == "ptr":
+            setattr(out, k, new_ptr)
+        elif k == "batch":
+            setattr(out, k, torch.repeat_interleave(torch.arange(B), sizes))
+        elif k in ("y",) and v.shape[0] == B:
+            setattr(out, k, v[order])
+        elif v.dim() >= 1 and v.shape[0] == N and k != "edge_attr":
+            setattr(out, k, v[node_src])
+        elif v.dim() >= 1 and v.shape[0] == E:
+            setattr(out, k, v[edge_src])
+    return out
+
+
 @pytest.mark.parametrize("dropout", [0.0, 0.1])
 def test_padding_is_invisible_to_the_real_graphs(dropout):
     """ONE step of a 3-layer model (same weights, same dropout seeds: the masks are counter hashes of the row index and
@@ -97,6 +130,15 @@ def test_padding_is_invisible_to_the_real_graphs(dropout):
     assert (junk.batch[junk.edge_index[0]] == junk.batch[junk.edge_index[1]]).all()
 
     p0, l0, g0, s0, _, _ = _step(model, state, b.clone(), None, dev)
+    # yardstick (parity item 4): the SAME un-padded batch with its graphs in reverse order -- the same function
+    # of the same graphs, summed in another order; what it moves in a parameter gradient is rounding (and, rarely, a ReLU
+    # decision), i.e. the un-padded step's own noise.  Only with dropout off: the masks are hashes of the row index.
+    yard = None
+    if dropout == 0.0:
+        _, lr_, gr_, _, _, _ = _step(model, state, _reverse_graphs(b), None, dev)
+        assert abs(lr_ - l0) <= 2e-5 * max(abs(l0), 1.0), (l0, lr_)
+        gs0 = max(float(v.norm()) for v in g0.values())
+        yard = max(float((gr_[k] - g0[k]).norm()) / max(float(g0[k].norm()), 1e-3 * gs0) for k in g0)
     p1, l1, g1, s1, gx1, ge1 = _step(model, state, pb, B, dev)
     p2, l2, g2, s2, gx2, ge2 = _step(model, state, junk, B, dev)
     assert torch.isfinite(p1).all() and torch.isfinite(p2).all()
@@ -127,7 +169,13 @@ def test_padding_is_invisible_to_the_real_graphs(dropout):
         # tensors whose gradient is rounding noise (biases in front of a BatchNorm) are graded against the model's scale
         rel = float((g1[k] - g0[k]).norm()) / max(float(g0[k].norm()), 1e-3 * gscale)
         worst = max(worst, rel)
-        assert rel <= 2e-2, f"grad {k}: |d|_2 / |g|_2 = {rel:.2e}"
+        # round 5: 5e-3 (was 2e-2; measured 5e-6 .. 4e-4, the upper end when one ReLU decision moved)
+        assert rel <= 5e-3, f"grad {k}: |d|_2 / |g|_2 = {rel:.2e}"
+    if yard is not None:
+        # padded vs un-padded must be no further apart than 5 x what re-ordering the un-padded batch's graphs does
+        # (floor 1e-3: one flipped ReLU decision on either side is a chance event of that size)
+        print(f"  un-padded, graphs reversed: worst 2-norm relative parameter-gradient difference {yard:.2e}")
+        assert worst <= max(5.0 * yard, 1e-3), (worst, yard)
     print(f"padded vs un-padded (dropout {dropout}): max|dpred| {float((p1 - p0).abs().max()):.2e}, worst 2-norm relative "
           f"parameter-gradient difference {worst:.2e}; junk vs zero padding max|dpred| {float((p2 - p1).abs().max()):.2e}, "
           f"worst gradient difference {worst_junk:.2e}")
