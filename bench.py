@@ -105,6 +105,9 @@ def parse_args():
     ap.add_argument("--no-secondary", action="store_true",
                     help="skip the `secondary` block (pcqm4m, 1 GPU, after the timed region): the zinc and code2 workloads "
                          "-- BASELINE.json configs[1] and configs[4] -- a few steps each, in child processes")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="no GPU: gloo ranks that sleep instead of stepping -- exercises the launcher / barrier / "
+                         "max-over-ranks / JSON-line path of --gpus N on a CPU box (CPU test suite)")
     ap.add_argument("--cpu-steps", type=int, default=3)
     ap.add_argument("--cpu-threads", type=int, default=0,
                     help="torch threads for the CPU baseline (0 = min(usable cores, 32))")
@@ -621,12 +624,72 @@ def bucketed_loader_leg(model, opt, loss_fn, nb, profile, dev, n_batches=24):
         return {"skipped": f"{type(exc).__name__}: {exc}"}
 
 
-def respawn_under_launcher(n):
+def timed_region(step, steps, barrier, world, dev):
+    """EXACTLY ``steps`` steps between two barriers (torch.distributed.barrier + device synchronize), the MAX of the
+    elapsed wall time over the ranks: (seconds, last step's return value).  Shared by the real run and --dry-run."""
+    loss = None
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        loss = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, loss
+
+
+def dry_run(args, real_stdout):
+    """--dry-run: the launcher / rank / barrier / max-over-ranks / one-JSON-line path of ``--gpus N`` WITHOUT a GPU -- gloo
+    on CPU, the step replaced by a rank-dependent sleep (rank r sleeps 2 (r + 1) ms, so the max over ranks is checkable).
+    Exists so that the first real 8-GPU run is not the first run of this path (tests/test_cpu_boundary.py drives it with
+    2 ranks under torch.distributed.run and through the self-respawn).  Nothing of the product is measured."""
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        os.dup2(real_stdout, 1)
+        respawn_under_launcher(args.gpus, check_devices=False)
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    dev = torch.device("cpu")
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.distributed.init_process_group(backend="gloo")
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    def step():
+        time.sleep(2e-3 * (rank + 1))
+        return torch.zeros(())
+    for _ in range(args.warmup):
+        step()
+    elapsed, _ = timed_region(step, args.steps, barrier, world, dev)
+    ms = elapsed / args.steps * 1e3
+    nb = args.graphs_per_gpu or 256
+    if rank == 0:
+        out = {"metric": "dry-run of the launcher path (no GPU work, nothing of the product measured)",
+               "value": world * nb / (ms / 1e3), "unit": "graphs/s", "n_gpus": world, "steps": args.steps,
+               "warmup": args.warmup, "ms_per_step": ms, "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "none", "data": "none (dry run: sleeps)",
+               "config": {"workload": "dry-run", "global_batch": world * nb, "parallelism": f"dp{world}"}}
+        sys.stdout.flush()
+        os.dup2(real_stdout, 1)
+        print(json.dumps(out), flush=True)
+        os.dup2(2, 1)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+def respawn_under_launcher(n, check_devices=True):
     """`python bench.py --gpus N` (N > 1) without a launcher environment: re-execute under torch.distributed.run,
     one rank per GPU, rendezvous on 127.0.0.1 -- the command the driver itself uses."""
     import socket
     import subprocess
-    if torch.cuda.device_count() < n:
+    if check_devices and torch.cuda.device_count() < n:
         raise SystemExit(f"--gpus {n}: only {torch.cuda.device_count()} GPU(s) visible")
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
@@ -644,6 +707,8 @@ def main():
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
+    if args.dry_run:
+        return dry_run(args, real_stdout)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -867,17 +932,8 @@ def main():
             tunable.tuning_enable(False)       # frozen: nothing is tuned inside the timed region
         except Exception as exc:
             log(f"could not freeze TunableOp ({type(exc).__name__}: {exc})")
-    barrier()
     log("warm-up done")
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = step()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed, loss = timed_region(step, args.steps, barrier, world, dev)
     ms = elapsed / args.steps * 1e3
     final_loss = float(loss.item())
     # host-side cost of enqueueing one step (GPU queue drained first): if this is close to

@@ -514,3 +514,40 @@ def test_grad_slot_admits_one_direct_writer_per_range_and_step():
     ar2.__dict__["_claimed"] = []                  # (what FlatAdamW.zero_grad does)
     if stack is not None:
         assert grad_slot(stack) is not None and grad_slot(a) is None and grad_slot(b) is None
+
+
+@pytest.mark.timeout(240)
+@pytest.mark.parametrize("how", ["self-respawn", "driver-command"])
+def test_bench_multi_gpu_launcher_path_dry_run(how):
+    """`bench.py --gpus 2` without a GPU: the launcher / RANK / barrier / max-over-ranks / ONE JSON line
+    path on gloo ranks that sleep 2 (rank + 1) ms instead of stepping -- through bench.py's own re-execution and through
+    the command the driver uses (`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N --steps K --warmup W`).  The timed region is the code the real run uses
+    (bench.timed_region)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    tail = [os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "6", "--warmup", "1", "--dry-run"]
+    if how == "self-respawn":
+        cmd = [sys.executable] + tail
+    else:
+        with socket.socket() as sk:
+            sk.bind(("127.0.0.1", 0))
+            port = sk.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+               "--master-addr", "127.0.0.1", "--master-port", str(port)] + tail
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=200, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, r.stdout                           # the contract: rank 0 prints ONE JSON line, nobody else anything
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["n_gpus"] == 2 and d["steps"] == 6 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["ms_per_step"] >= 4.0                             # the MAX over ranks: rank 1 sleeps 4 ms per step
+    assert abs(d["value"] - 2 * 256 / (d["ms_per_step"] / 1e3)) <= 1e-6 * d["value"]      # whole-job aggregate
+    assert d["config"]["global_batch"] == 512 and d["config"]["parallelism"] == "dp2"
