@@ -1018,6 +1018,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring16(const PanelArgs P) 
   uint32_t st_hi;
   auto split_part = [&](int part, const f32x4 (&raw)[2], int d, Ring16A& out) __attribute__((always_inline)) {
     const f32x2 v = (f32x2){raw[d >> 1][(d & 1) * 2], raw[d >> 1][(d & 1) * 2 + 1]};
+#ifdef GPS_ABL_R16_NO_SPLIT     // ablation (tools/micro/ring_ablate.sh; results are garbage, timing only): raw bits as pieces
+    if (part == 0) { out.p[0][d] = __float_as_uint(v[0]); out.p[1][d] = __float_as_uint(v[1]); }
+    return;
+#endif
     if (part == 0) {
       st_hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v * sa, f16x2));
       out.p[0][d] = st_hi;
@@ -1037,8 +1041,13 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring16(const PanelArgs P) 
 #pragma unroll
     for (int i = 0; i < G; ++i) {
       const int term = i / (NJ * MB), mb = (i / NJ) % MB, j = i % NJ;
+#ifdef GPS_ABL_R16_NO_MFMA      // ablation: one VALU op in the MFMA's place
+      acc[mb][j][0] += __uint_as_float(ac[mb].p[TA[term]][0]) * __uint_as_float(fc.b[j][TB[term]][0]);
+#else
       acc[mb][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ac[mb].p[TA[term]]),
                                                          __builtin_bit_cast(f16x8, fc.b[j][TB[term]]), acc[mb][j], 0, 0, 0);
+#endif
+#ifndef GPS_ABL_R16_NO_RD       // ablation: no fragment reads in the loop (registers keep the prologue's fragments)
       if (i == 0) {
 #pragma unroll
         for (int b = 0; b < MB; ++b) {
@@ -1051,7 +1060,12 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring16(const PanelArgs P) 
         for (int k = r16_rd_first(i, NW, RD_GAPS); k < r16_rd_first(i + 1, NW, RD_GAPS); ++k)
           fn.b[k / 2][k % 2] = *reinterpret_cast<const u32x4*>(rd_slot + b_off[rd_ks] + (k / 2) * (32 * 64) + (k % 2) * BP);
       }
+#else
+      if (i == 0) fn = fc;
+#endif
+#ifndef GPS_ABL_R16_NO_DMA      // ablation: no global -> LDS transfers in the loop (the prologue's stay)
       if (i < dma_count) dma(dma_first + i, dma_stage, dma_slot);
+#endif
       if (i >= SPLIT0) {
 #pragma unroll
         for (int u = 0; u < SPLITQ; ++u) {
@@ -1105,7 +1119,9 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring16(const PanelArgs P) 
     unsigned char* const lst = ring + ((I + S - 1) % S) * SLOT;
     region(a0, f0, a1, f1, cur, 1, min(s + S - 1, KS - 1), lst, ND_ODD, ND_EVEN);
     __builtin_amdgcn_s_waitcnt(waitcnt_imm((S - 2) * ND, 0));
+#ifndef GPS_ABL_R16_NO_BAR      // ablation: no stage barrier
     __builtin_amdgcn_s_barrier();
+#endif
     __builtin_amdgcn_sched_barrier(0);
     region(a1, f1, a0, f0, nxt, 0, min(s + S, KS - 1), cur, 0, ND_ODD);
   };
@@ -1143,7 +1159,20 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring16(const PanelArgs P) 
 #pragma unroll
   for (int j = 0; j < NJ; ++j) sk[j] = s1[j] = s2[j] = 0.f;
   float amx = 0.f;
+#ifdef GPS_ABL_R16_NO_STORE     // ablation: no epilogue (one conditional store keeps the accumulators alive)
+  {
+    float sum = 0.f;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+      for (int j = 0; j < NJ; ++j)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) sum += acc[mb][j][q];
+    if (sum == 1.2345678e-30f) P.C[0] = sum;
+  }
+#else
   ring_epilogue<MB, NJ, EPI, HAS_CIN, EDGE>(P, acc, m0, n0, wm, wn, li, kh, sk, s1, s2, amx);
+#endif
   if (EPI == 3) ring_stats<MB, NJ>(P, rt, panel, m0, wm, wn, li, kh, sk, s1, s2, reinterpret_cast<float*>(ring));
   if (P.c_amax) {                                        // workgroup-uniform: max|C| of this tile -> one atomic
     uint32_t m = __float_as_uint(amx);

@@ -386,6 +386,14 @@ _WGRAD_F16 = _os.environ.get("GPS_WGRAD_F16", "1") != "0"
 # fork and join costs ~10 us of queue latency in the replayed graph.  Default since round 3: ONE stream (= 0); the
 # per-kernel durations inside the step are then the kernels' own.  GPS_BRANCH_STREAM=1 forks while capturing, =2 always.
 _BRANCH = _os.environ.get("GPS_BRANCH_STREAM", "0")
+# Round 5: a NARROWER fork (GPS_CORE_FORK=1, Transformer block, one-stream mode only): just the attention CORE kernel runs on
+# the branch stream, beside the GatedGCN core on the main stream -- the two kernels of a block that are not GEMMs, need
+# little or no LDS between them and bound on different things (the attention core: VALU issue and its own load -> compute
+# -> store lockstep; the GatedGCN core: HBM).  Every GEMM stays on the main stream, so no ring-GEMM workgroup ever
+# competes with a forked kernel for a CU's LDS (what made the round-3 fork of the whole attention half useless).
+# The backward pair only co-resides when the GatedGCN backward's LDS stash leaves room for an attention workgroup
+# (GPS_GG_STASH_KB <= ~80 next to the 45 KB of k_sattn_bwd).
+_CORE_FORK = _os.environ.get("GPS_CORE_FORK", "0") != "0"
 _branch_streams = {}
 
 
@@ -542,11 +550,12 @@ class _GPSBlock(torch.autograd.Function):
         # GPS_GG_FIRST=1 (single stream only): the GatedGCN core directly behind the merged projection that wrote its four
         # operands, the attention half after it.  Measured, same box: 9.948 vs 9.958 ms per step, the GatedGCN forward at
         # 26.3 vs 25.9 us -- the operands are Infinity-Cache resident either way; the default keeps the documented order.
-        gg_first = _GG_FIRST and _BRANCH == "0"
+        core_fork = _CORE_FORK and _BRANCH == "0" and not perf
+        gg_first = _GG_FIRST and _BRANCH == "0" and not core_fork
         if gg_first:
             xt, eh = local_half()
         # -- global branch (forked): varlen attention over the PRE-layer x (gps_layer.py:199-201,234-241)
-        with _Fork(dev, _BRANCH) as fork:
+        with _Fork(dev, "2" if core_fork else _BRANCH) as fork:
             sb = current_stream(dev)
             o, lse = _E(N, inner, **f32), _E(H, N, **f32)       # (Performer: `lse` holds the query row maxima mq)
             scale = float(dh) ** -0.5
@@ -568,15 +577,21 @@ class _GPSBlock(torch.autograd.Function):
                                          gi.B, int(gi.nmax_host), ptr(aw(_R_O)), sb), "gps_seg_attn_fwd")
             if am is not None and perf:         # (the attention kernel raised o's record itself; FAVOR+ does not)
                 _gemm.absmax([o], out=rec[_R_O:_R_O + 1])
-            if gemm_stats:      # za = x + drop(out_proj(o)) and the statistics of za (norm1_attn) in the GEMM's epilogue
-                ao = None
-                za = _gemm.gemm_panel_stats(o, imgs[2][0], d, _B(R.out_proj), x, p_l, s[3], bna, sync.site(_S_AO, _stats_words(L, d)),
-                                            a_amax=aw(2), m_dev=rn)
-            else:
-                za = None
-                ao = (_gemm.gemm_panel(o, imgs[2][0], d, bias=_B(R.out_proj), a_amax=aw(2)) if panel
-                      else torch.addmm(_B(R.out_proj), o, _W(R.out_proj).t()))
-        if not gg_first:
+
+            def out_projection():
+                if gemm_stats:  # za = x + drop(out_proj(o)) and the statistics of za (norm1_attn) in the GEMM's epilogue
+                    return _gemm.gemm_panel_stats(o, imgs[2][0], d, _B(R.out_proj), x, p_l, s[3], bna,
+                                                  sync.site(_S_AO, _stats_words(L, d)), a_amax=aw(2), m_dev=rn), None
+                return None, (_gemm.gemm_panel(o, imgs[2][0], d, bias=_B(R.out_proj), a_amax=aw(2)) if panel
+                              else torch.addmm(_B(R.out_proj), o, _W(R.out_proj).t()))
+            if not core_fork:
+                za, ao = out_projection()
+        if core_fork:           # the GatedGCN core beside the attention core; the out-projection GEMM behind the join
+            xt, eh = local_half()
+            fork.join(o, lse)
+            fork.enabled = False
+            za, ao = out_projection()
+        elif not gg_first:
             xt, eh = local_half()
         # -- x1 = x + drop(relu(BN_x(xt))) [+ statistics -> norm1_local], e1 = e + drop(relu(BN_e(eh))),
         #    za = x + drop(ao) [+ statistics -> norm1_attn] unless the out-projection already produced it -- in which case
@@ -701,10 +716,15 @@ class _GPSBlock(torch.autograd.Function):
         fs = d * 4
         g_pq = _E(N, ldp, **f32)
         G, P = g_pq.data_ptr(), pq.data_ptr()
-        with _Fork(dev, _BRANCH) as fork:            # attention half of the backward
-            sb = current_stream(dev)
+        core_fork = _CORE_FORK and _BRANCH == "0" and not perf
+        if core_fork:                                # (the out-projection's input gradient stays on the main stream)
             g_o = (_gemm.gemm_panel(g_ao, imgs[2][1], inner, a_amax=bw(2)) if imgs is not None
                    else g_ao.mm(_W(R.out_proj)))
+        with _Fork(dev, "2" if core_fork else _BRANCH) as fork:            # attention half of the backward
+            sb = current_stream(dev)
+            if not core_fork:
+                g_o = (_gemm.gemm_panel(g_ao, imgs[2][1], inner, a_amax=bw(2)) if imgs is not None
+                       else g_ao.mm(_W(R.out_proj)))
             if perf:
                 proj, cbuf, ksum, kmax, Dn = fav
                 gD, g_ctx, g_ksum = _E(H, N, **f32), torch.empty_like(cbuf), torch.empty_like(ksum)

