@@ -184,12 +184,14 @@ __device__ __forceinline__ void combine_column(const float* src, const float* n_
 
 // One level: every column of the d-wide records [i0, i0 + cnt) of `src` -> handler(c, acc, n) called by one thread
 // per column.  Threads beyond d columns split the record list (nsub slices) and meet through LDS, merged in slice order.
-template <int NV, int MODE, int MAXI, typename F>
+// NTH: the threads that take part (0 = the whole workgroup; a kernel whose trailing wavefronts have already exited -- the
+// loader wavefronts of k_gemm_ring16L -- names the count of the leading threads that are still there).
+template <int NV, int MODE, int MAXI, int NTH = 0, typename F>
 __device__ __forceinline__ void level(const float* src, const float* n_src, int i0, int cnt, int d, float* scr,
                                       F&& handler) {
   constexpr int NS = Counts<NV, MODE>::value;
   constexpr int RW = NV + NS;                            // floats per exchanged record
-  const int T = blockDim.x, tid = threadIdx.x;
+  const int T = NTH > 0 ? NTH : (int)blockDim.x, tid = threadIdx.x;
   const int nsub = T >= 2 * d ? T / d : 1;
   const int cpp = nsub > 1 ? d : (T < d ? T : d);      // columns per pass
   const int sub = tid / cpp, cl = tid - sub * cpp;
@@ -233,7 +235,7 @@ __device__ __forceinline__ void level(const float* src, const float* n_src, int 
 
 // Called by EVERY thread of workgroup-record b after the record's stores (st_sc1) were issued.  `lds`: scratch_floats(NV,
 // blockDim.x) floats, 16-byte aligned, free to overwrite.  Returns only after this workgroup's share of the tree is done.
-template <int NV, int MODE, int MAXI>
+template <int NV, int MODE, int MAXI, int NTH = 0>
 __device__ __forceinline__ void arrive(const Tree& T, int b, int d, float* lds) {
   constexpr int NS = Counts<NV, MODE>::value;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // every storing wave drains its write-through stores
@@ -253,7 +255,7 @@ __device__ __forceinline__ void arrive(const Tree& T, int b, int d, float* lds) 
   __syncthreads();                                      // the flag word is rewritten below
   float* gdst = T.grp + (int64_t)g * NV * d;
   float* gn = T.gcnt + (int64_t)g * NS;
-  level<NV, MODE, MAXI>(T.part, T.pcnt, i0, cnt, d, scr, [&](int c, const float (&acc)[NV], const float (&n)[NV / 2 + 1]) {
+  level<NV, MODE, MAXI, NTH>(T.part, T.pcnt, i0, cnt, d, scr, [&](int c, const float (&acc)[NV], const float (&n)[NV / 2 + 1]) {
 #pragma unroll
     for (int v = 0; v < NV; ++v) st_sc1(gdst + (int64_t)v * d + c, acc[v]);
     if (c == 0) {
@@ -273,7 +275,7 @@ __device__ __forceinline__ void arrive(const Tree& T, int b, int d, float* lds) 
   if (!*flag) return;
   __syncthreads();
   const Tree R = T;       // by value: the lambda below runs after T's storage may have been re-read a few times
-  level<NV, MODE, MAXI>(T.grp, T.gcnt, 0, T.NG, d, scr, [&](int c, const float (&acc)[NV], const float (&n)[NV / 2 + 1]) {
+  level<NV, MODE, MAXI, NTH>(T.grp, T.gcnt, 0, T.NG, d, scr, [&](int c, const float (&acc)[NV], const float (&n)[NV / 2 + 1]) {
     if constexpr (MODE == STATS) {
       stats_out(R.o0, R.o1, R.o2, R.o3, R.eps, R.momentum, c, acc[0], acc[1], n[0]);
       if constexpr (NV >= 4) stats_out(R.p0, R.p1, R.p2, R.p3, R.eps2, R.momentum2, c, acc[2], acc[3], n[1]);

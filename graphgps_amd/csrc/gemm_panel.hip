@@ -501,7 +501,7 @@ __device__ __forceinline__ void ring_epilogue(const PanelArgs& P, const f32x16 (
 // Column statistics of the panel (EPI == 3): the two row-waves of each column half meet through LDS (the ring is free
 // by now), one thread per column merges them (Chan) and writes the workgroup's level-0 record write-through; the tree of
 // this column panel (records = row tiles) then completes in-launch (csrc/col_tree.hpp).
-template <int MB, int NJ>
+template <int MB, int NJ, int NTH = 0>
 __device__ __forceinline__ void ring_stats(const PanelArgs& P, int rt, int panel, int64_t m0, int wm, int wn, int li, int kh,
                                            const float (&sk)[NJ], float (&s1)[NJ], float (&s2)[NJ], float* lds) {
   constexpr int TN = 64 * NJ;                         // (shadows the 192-column constant of the register-staged kernel)
@@ -547,7 +547,7 @@ __device__ __forceinline__ void ring_stats(const PanelArgs& P, int rt, int panel
     tr::st_sc1(T.part + ((int64_t)rt * 2 + 1) * TN + t, qa + qb + dl * dl * n0w * wgt);
     if (t == 0) tr::st_sc1(T.pcnt + rt, nn);
   }
-  tr::arrive<2, tr::STATS, 16>(T, rt, TN, lds);
+  tr::arrive<2, tr::STATS, 16, NTH>(T, rt, TN, lds);
 }
 
 // MB = row blocks of 32 per wave, NJ = column blocks of 32 per wave: the workgroup's panel is (64 * MB) rows x (64 * NJ)
@@ -1188,6 +1188,259 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring16(const PanelArgs P) 
   stamp(3);
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Round 5 -- the same kernel with LOADER WAVEFRONTS (k_gemm_ring16L): 4 consumer wavefronts (the 2 x 2 register tiles
+// of k_gemm_ring16, unchanged arithmetic, fragments, swizzles and epilogues) + 2 wavefronts that do nothing but move
+// global -> LDS.  Why: the PMC passes of the round (profiles/r05_pmc_gemm16.json) show the merged projection's wavefronts
+// issuing 49 % of their cycles and stalled on issue for another 33 %, matrix pipe 42 % busy over a wavefront's lifetime;
+// the ablation builds (profiles/r05_gemm_ring16_ablation.txt) say where: the SAME loop without its LDS-DMA instructions
+// runs the seven projection shapes of a block in 209 us instead of 257 (the K = 2688 input gradient: 49 instead of 70) --
+// an in-order wavefront that issues a global_load_lds between two MFMAs pays 60-180 cycles of issue for it
+// (MI355X_MICROARCH.md, "LDS-DMA piece issue cost"), ten times per 1152-cycle stage, and the matrix pipe drains behind
+// it.  Moved to their own wavefronts those instructions cost the consumers nothing: VMEM issue and MFMA issue of
+// DIFFERENT wavefronts of a SIMD proceed side by side.
+// Protocol (one s_barrier per stage, as before; every barrier counts all six wavefronts):
+//   loaders   fill all S slots; wait until stage 0 has landed (their own vmcnt); barrier B0
+//             stage s:  vmcnt((S-2) PER): stage s+1 has landed | barrier B(s+1): every consumer is done with slot s % S |
+//                       issue stage s+S into that slot (past the last stage: re-fetch the last one, never read -- the
+//                       count of transfers in flight must stay (S-1) PER for the counted wait to mean what it says)
+//   consumers barrier B0; stage s:  region 2s (multiplies k-step 2s, fetches the fragments of k-step 2s+1 from slot s % S) |
+//                       lgkmcnt(0) | barrier B(s+1) | region 2s+1 (multiplies 2s+1, fetches 2s+2 from slot (s+1) % S)
+//   end       loaders drain (vmcnt(0): no transfer may still be landing when the LDS is handed back or re-used as
+//             scratch), meet the consumers at one more barrier when the epilogue uses LDS (statistics, max|C|), and exit;
+//             a terminated wavefront no longer counts in later barriers.
+// Each loader serves the transfers of two consumers' shares (PER = 2 ND <= 20 per stage, so (S-1) PER <= 63 fits vmcnt
+// except for the 5-slot rings, where the 64th transfer simply waits for the first to land).
+// GPS_GEMM_LOADERS=0 keeps k_gemm_ring16 (A/B); EDGE shapes stay on it.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int R16L_NLOAD = 2;
+constexpr int NTHREADS_L = NTHREADS + 64 * R16L_NLOAD;
+
+template <int MB, int NJ, int EPI, bool HAS_CIN>
+__global__ __launch_bounds__(NTHREADS_L, 2) void k_gemm_ring16L(const PanelArgs P) {
+  constexpr int TNV = 64 * NJ;
+  constexpr int BP = rg_bp(NJ);
+  constexpr int A_BYTES = rg_a_bytes(MB), SLOT = r16_slot_bytes(MB, NJ);
+  constexpr int S = r16_slots(MB, NJ);          // ring depth
+  constexpr int NA = 2 * MB;                    // A transfers per consumer share and stage
+  constexpr int NW = 2 * NJ;                    // W transfers per consumer share and stage
+  constexpr int ND = NA + NW;
+  constexpr int PER = 2 * ND;                   // transfers per loader and stage
+  constexpr int G = 3 * MB * NJ;                // MFMAs (= issue gaps) per region
+  constexpr int RD_GAPS = G < 4 ? G : 4;
+  constexpr int SPLITQ = G >= 9 ? (12 * MB + (G - 4) - 1) / (G - 4) : (12 * MB + (G - 1) - 1) / (G - 1);
+  constexpr int SPLIT0 = G >= 9 ? G - (12 * MB + SPLITQ - 1) / SPLITQ : 1;
+  static_assert(12 * MB <= (G - SPLIT0) * SPLITQ, "the staging does not fit the region's issue gaps");
+  static_assert((S - 2) * PER <= 63 && S >= 3, "vmcnt range");
+  extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];
+  auto stamp = [&](int k) __attribute__((always_inline)) {
+    if (P.trace && threadIdx.x == 0) P.trace[4 * (size_t)blockIdx.x + k] = __builtin_amdgcn_s_memtime();
+  };
+  stamp(0);
+  const int panel = blockIdx.x / P.row_tiles, rt = blockIdx.x - panel * P.row_tiles;   // panel-major numbering
+  const int64_t m0 = (int64_t)rt * (64 * MB);
+  const int n0 = panel * TNV;
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int KS = (P.K + BK - 1) / BK;
+  const bool lds_after = EPI == 3 || P.c_amax != nullptr;       // (kernel-uniform) the epilogue re-uses the ring as scratch
+
+  if (wave >= 4) {
+    // ================================ loader ================================
+    const int lw = wave - 4;
+    const unsigned char* a_src[2][NA];
+    const unsigned char* b_src[2];
+#pragma unroll
+    for (int vv = 0; vv < 2; ++vv) {
+      const int v = 2 * lw + vv;                // the consumer whose share this is
+#pragma unroll
+      for (int i = 0; i < NA; ++i) {
+        const int row = 8 * NA * v + 8 * i + (lane >> 3);
+        const int c = (lane & 7) ^ ((row >> 1) & 7);
+        const int64_t grow = min(m0 + row, P.M - 1);
+        a_src[vv][i] = reinterpret_cast<const unsigned char*>(P.A + grow * P.lda) + c * 16;
+      }
+      b_src[vv] = reinterpret_cast<const unsigned char*>(P.Bp) + ((int64_t)n0 + 16 * NJ * v + (lane >> 2)) * (BK * 2) +
+                  (((lane & 3) ^ ((lane >> 4) & 3)) * 16);
+    }
+    const int64_t stage_stride = (int64_t)P.Nimg * (BK * 2);
+    const int64_t piece_stride = stage_stride * KS;
+    auto fill = [&](int s, unsigned char* slot) __attribute__((always_inline)) {
+#pragma unroll
+      for (int vv = 0; vv < 2; ++vv) {
+        const int v = 2 * lw + vv;
+#pragma unroll
+        for (int g = 0; g < NA; ++g)
+          glds16(a_src[vv][g] + (int64_t)s * (BK * 4), slot + v * (NA * 1024) + g * 1024);
+#pragma unroll
+        for (int i = 0; i < NW; ++i)
+          glds16(b_src[vv] + s * stage_stride + (i / NJ) * piece_stride + (i % NJ) * 1024,
+                 slot + A_BYTES + (i / NJ) * BP + v * (NJ * 1024) + (i % NJ) * 1024);
+      }
+    };
+#pragma unroll
+    for (int st = 0; st < S; ++st) fill(min(st, KS - 1), ring + st * SLOT);
+    __builtin_amdgcn_s_waitcnt(waitcnt_imm((S - 1) * PER > 63 ? 63 : (S - 1) * PER, 15));     // stage 0 has landed
+    __builtin_amdgcn_s_barrier();                                                              // B0
+    int slot_i = 0;
+    for (int s = 0; s < KS; ++s) {
+      __builtin_amdgcn_s_waitcnt(waitcnt_imm((S - 2) * PER, 15));        // stage s+1 has landed (s+2 .. s+S-1 in flight)
+      __builtin_amdgcn_s_barrier();                                      // B(s+1): slot s % S is free
+      fill(min(s + S, KS - 1), ring + slot_i * SLOT);
+      slot_i = slot_i + 1 == S ? 0 : slot_i + 1;
+    }
+    __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 15));                      // nothing of this wavefront still lands in LDS
+    if (lds_after) __builtin_amdgcn_s_barrier();                         // ... before the consumers re-use the ring
+    return;
+  }
+
+  // ================================ consumers ================================
+  const int wm = wave >> 1, wn = wave & 1;
+  const int li = lane & 31, kh = lane >> 5;
+  const unsigned bea = amax_be(P.a_amax), bew = amax_be(P.w_amax);
+  const float sa = amax_scale(bea);
+  int a_off[2][2], b_off[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    const int c0 = ks * 4 + kh * 2, sw = (li >> 1) & 7;
+    a_off[ks][0] = (wm * 32 * MB + li) * 128 + ((c0 ^ sw) * 16);
+    a_off[ks][1] = (wm * 32 * MB + li) * 128 + (((c0 + 1) ^ sw) * 16);
+    b_off[ks] = A_BYTES + (wn * 32 * NJ + li) * 64 + (((ks * 2 + kh) ^ ((li >> 2) & 3)) * 16);
+  }
+  f32x16 acc[MB][NJ];
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[mb][j][q] = 0.0f;
+
+  f32x2 st_hb;
+  uint32_t st_hi;
+  auto split_part = [&](int part, const f32x4 (&raw)[2], int d, Ring16A& out) __attribute__((always_inline)) {
+    const f32x2 v = (f32x2){raw[d >> 1][(d & 1) * 2], raw[d >> 1][(d & 1) * 2 + 1]};
+    if (part == 0) {
+      st_hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v * sa, f16x2));
+      out.p[0][d] = st_hi;
+    } else if (part == 1) {
+      st_hb = __builtin_convertvector(__builtin_bit_cast(f16x2, st_hi), f32x2);
+    } else {
+      out.p[1][d] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v * sa - st_hb, f16x2));
+    }
+  };
+  constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};     // lo*hi, hi*lo, hi*hi: smallest terms first
+  f32x4 raw[MB][2];
+  auto region = [&](const Ring16A (&ac)[MB], const Ring16Frag<NJ>& fc, Ring16A (&an)[MB], Ring16Frag<NJ>& fn,
+                    const unsigned char* rd_slot, int rd_ks) __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < G; ++i) {
+      const int term = i / (NJ * MB), mb = (i / NJ) % MB, j = i % NJ;
+      acc[mb][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ac[mb].p[TA[term]]),
+                                                         __builtin_bit_cast(f16x8, fc.b[j][TB[term]]), acc[mb][j], 0, 0, 0);
+      if (i == 0) {
+#pragma unroll
+        for (int b = 0; b < MB; ++b) {
+          raw[b][0] = *reinterpret_cast<const f32x4*>(rd_slot + a_off[rd_ks][0] + b * 4096);
+          raw[b][1] = *reinterpret_cast<const f32x4*>(rd_slot + a_off[rd_ks][1] + b * 4096);
+        }
+      }
+      if (i < RD_GAPS) {
+#pragma unroll
+        for (int k = r16_rd_first(i, NW, RD_GAPS); k < r16_rd_first(i + 1, NW, RD_GAPS); ++k)
+          fn.b[k / 2][k % 2] = *reinterpret_cast<const u32x4*>(rd_slot + b_off[rd_ks] + (k / 2) * (32 * 64) + (k % 2) * BP);
+      }
+      if (i >= SPLIT0) {
+#pragma unroll
+        for (int u = 0; u < SPLITQ; ++u) {
+          const int q = (i - SPLIT0) * SPLITQ + u;
+          if (q < 12 * MB) split_part(q % 3, raw[(q / 3) / 4], (q / 3) % 4, an[(q / 3) / 4]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
+  __builtin_amdgcn_s_barrier();                                         // B0: stage 0 is in slot 0
+  stamp(1);
+  Ring16Frag<NJ> f0, f1;
+  Ring16A a0[MB], a1[MB];
+#pragma unroll
+  for (int b = 0; b < MB; ++b) {
+    raw[b][0] = *reinterpret_cast<const f32x4*>(ring + a_off[0][0] + b * 4096);
+    raw[b][1] = *reinterpret_cast<const f32x4*>(ring + a_off[0][1] + b * 4096);
+  }
+#pragma unroll
+  for (int j = 0; j < NJ; ++j)
+#pragma unroll
+    for (int p = 0; p < 2; ++p)
+      f0.b[j][p] = *reinterpret_cast<const u32x4*>(ring + b_off[0] + j * (32 * 64) + p * BP);
+#pragma unroll
+  for (int b = 0; b < MB; ++b)
+#pragma unroll
+    for (int d = 0; d < 4; ++d)
+#pragma unroll
+      for (int part = 0; part < 3; ++part) split_part(part, raw[b], d, a0[b]);
+  __builtin_amdgcn_sched_barrier(0);
+
+  auto stage = [&](auto ic) __attribute__((always_inline)) {
+    constexpr int I = decltype(ic)::value;
+    unsigned char* const cur = ring + I * SLOT;
+    unsigned char* const nxt = ring + ((I + 1) % S) * SLOT;
+    region(a0, f0, a1, f1, cur, 1);
+    __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, 0));       // this wavefront's reads of slot I have returned
+    __builtin_amdgcn_s_barrier();                         // B(s+1): stage s+1 has landed; slot I may be refilled
+    __builtin_amdgcn_sched_barrier(0);
+    region(a1, f1, a0, f0, nxt, 0);
+  };
+  int s0 = 0;
+  for (; s0 + S <= KS; s0 += S) {
+    stage(IntC<0>{});
+    stage(IntC<1>{});
+    stage(IntC<2>{});
+    if constexpr (S > 3) stage(IntC<3 % S>{});
+    if constexpr (S > 4) stage(IntC<4 % S>{});
+  }
+  if (s0 < KS) {                                            // up to S-1 stages left over (workgroup-uniform)
+    stage(IntC<0>{});
+    if (s0 + 1 < KS) {
+      stage(IntC<1>{});
+      if (s0 + 2 < KS) {
+        stage(IntC<2>{});
+        if constexpr (S > 4) {
+          if (s0 + 3 < KS) stage(IntC<3 % S>{});
+        }
+      }
+    }
+  }
+  __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, 0));
+  if (lds_after) __builtin_amdgcn_s_barrier();            // the loaders have drained: the ring is scratch from here on
+  stamp(2);
+  const float ua = amax_unscale(bea), uw = amax_unscale(bew);
+#pragma unroll
+  for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+    for (int j = 0; j < NJ; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[mb][j][q] = (acc[mb][j][q] * ua) * uw;
+  float sk[NJ], s1[NJ], s2[NJ];
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) sk[j] = s1[j] = s2[j] = 0.f;
+  float amx = 0.f;
+  ring_epilogue<MB, NJ, EPI, HAS_CIN, false>(P, acc, m0, n0, wm, wn, li, kh, sk, s1, s2, amx);
+  if (EPI == 3) ring_stats<MB, NJ, NTHREADS>(P, rt, panel, m0, wm, wn, li, kh, sk, s1, s2, reinterpret_cast<float*>(ring));
+  if (P.c_amax) {                                        // workgroup-uniform: max|C| of this tile -> one atomic
+    uint32_t m = __float_as_uint(amx);
+#pragma unroll
+    for (int o = 32; o; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
+    uint32_t* wmax = reinterpret_cast<uint32_t*>(ring);
+    __syncthreads();                                     // (the four consumers: the loaders have exited)
+    if (lane == 0) wmax[wave] = m;
+    __syncthreads();
+    if (t == 0) gps::amax_raise(P.c_amax, max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])));
+  }
+  stamp(3);
+}
+
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) % 16) == 0; }
 
 }  // namespace
@@ -1382,6 +1635,9 @@ static int panel_launch(const float* A, int64_t lda, int64_t M, int K, const uin
   const bool ring = ring_enabled() || !staged_ok || f16;
   const int mb = ring_mb(M, N, K), nj = rg_nj(N, K);
   const bool edge = rg_edge(N, K);
+  // round 5: loader wavefronts for the fp16 form (k_gemm_ring16L; whole panels and k-stages only).  GPS_GEMM_LOADERS=0: off
+  static const bool loaders_on = []() { const char* v = getenv("GPS_GEMM_LOADERS"); return !(v && v[0] == '0'); }();
+  const bool loaders = loaders_on && f16 && !edge;
   GPS_REQUIRE(epilogue != 3 || !edge, "gps_gemm_panel: the statistics epilogue needs whole column panels and k-stages");
   GPS_REQUIRE(epilogue != 3 || ring, "gps_gemm_panel: the statistics epilogue needs the ring kernel");
   unsigned grid;
@@ -1406,16 +1662,18 @@ static int panel_launch(const float* A, int64_t lda, int64_t M, int K, const uin
     P.row_tiles = (int)((M + TM - 1) / TM);
     grid = (unsigned)(P.row_tiles * (N / TN));
   }
-#define GPS_RING_ANY(KERNEL, LDS)                                                                     \
+#define GPS_RING_ANY_T(KERNEL, LDS, THREADS)                                                          \
   do {                                                                                                \
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL),        \
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS); \
     GPS_REQUIRE(attr == hipSuccess, "gps_gemm_panel: cannot reserve %d bytes of LDS", LDS);           \
-    KERNEL<<<grid, NTHREADS, LDS, s>>>(P);                                                            \
+    KERNEL<<<grid, THREADS, LDS, s>>>(P);                                                             \
   } while (0)
+#define GPS_RING_ANY(KERNEL, LDS) GPS_RING_ANY_T(KERNEL, LDS, NTHREADS)
 #define GPS_RING_LAUNCH(MBV, NJV, E, C)                                                               \
   do {                                                                                                \
-    if (f16) GPS_RING_ANY((k_gemm_ring16<MBV, NJV, E, C>), r16_lds_bytes(MBV, NJV));                  \
+    if (f16 && loaders) GPS_RING_ANY_T((k_gemm_ring16L<MBV, NJV, E, C>), r16_lds_bytes(MBV, NJV), NTHREADS_L); \
+    else if (f16) GPS_RING_ANY((k_gemm_ring16<MBV, NJV, E, C>), r16_lds_bytes(MBV, NJV));             \
     else GPS_RING_ANY((k_gemm_ring<MBV, NJV, E, C>), rg_lds_bytes(MBV, NJV));                         \
   } while (0)
 #define GPS_RING_EDGE(MBV, NJV, E, C)                                                                 \
@@ -1450,6 +1708,7 @@ static int panel_launch(const float* A, int64_t lda, int64_t M, int K, const uin
 #undef GPS_RING_EDGE
 #undef GPS_RING_LAUNCH
 #undef GPS_RING_ANY
+#undef GPS_RING_ANY_T
 #undef GPS_RING_SHAPES
 #undef GPS_PANEL_LAUNCH
   return gps::launch_status("gps_gemm_panel");

@@ -113,7 +113,8 @@ __global__ __launch_bounds__(256) void k_pool_merge(const float* __restrict__ pa
   Vec<VEC> acc = Vec<VEC>::zero();                        // (an empty graph pools to zero)
   const int64_t slot0 = n0 / POOL_SL + g;
   const int ns = (n + POOL_SL - 1) / POOL_SL;
-  for (int k = 0; k < ns; ++k) {
+#pragma unroll 8
+  for (int k = 0; k < ns; ++k) {            // (independent loads, one add chain: the unroll keeps 8 rows in flight)
     const Vec<VEC> v = Vec<VEC>::load(part + (slot0 + k) * d + c);
 #pragma unroll
     for (int q = 0; q < VEC; ++q) acc[q] += v[q];
