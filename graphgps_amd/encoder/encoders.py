@@ -42,6 +42,67 @@ class _MultihotMM(torch.autograd.Function):
         return None, g_w
 
 
+class _EmbedSum(torch.autograd.Function):
+    """``sum_i tables[i][feats[:, i]]`` in ONE launch (csrc/embed.hip ``gps_embed_sum``: the tables read in place, columns
+    added in index order -- the reference's own summation order, ogb's ``x_embedding += emb[i](x[:, i])``).  Backward: ONE
+    launch writes the multi-hot matrix of the features (``gps_multihot_fill``) and the stacked table gradient is the GEMM
+    ``multihot^T @ g`` -- deterministic, what the multi-hot form of rounds 1-4 was built for -- handed back as row slices.
+    Replaces zeros + index add + ``scatter_`` + pad + ``cat`` + GEMM (6 launches, and ~0.35 ms of idle time per replayed
+    pcqm4m step in front of the ATen index kernels of the edge encoder: DESIGN section 5)."""
+
+    @staticmethod
+    def forward(ctx, feats, *tables):
+        import ctypes
+        from .. import lib as _lib
+        L = _lib.load()
+        R, k = feats.shape
+        emb = tables[0].shape[1]
+        out = torch.empty(R, emb, dtype=torch.float32, device=feats.device)
+        ptrs = (ctypes.c_void_p * k)(*[t.data_ptr() for t in tables])
+        vocab = (ctypes.c_int * k)(*[t.shape[0] for t in tables])
+        _lib.check(L.gps_embed_sum(_lib.ptr(feats), feats.stride(0), R, k, ptrs, vocab, emb, _lib.ptr(out),
+                                   _lib.current_stream(feats.device)), "gps_embed_sum")
+        ctx.save_for_backward(feats)
+        ctx.vocab = [t.shape[0] for t in tables]
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        import ctypes
+        from .. import lib as _lib
+        L = _lib.load()
+        (feats,) = ctx.saved_tensors
+        R, k = feats.shape
+        vocab = (ctypes.c_int * k)(*ctx.vocab)
+        vpad = L.gps_multihot_columns(k, vocab)
+        multihot = torch.empty(R, vpad, dtype=torch.float32, device=g.device)
+        _lib.check(L.gps_multihot_fill(_lib.ptr(feats), feats.stride(0), R, k, vocab, _lib.ptr(multihot),
+                                       _lib.current_stream(g.device)), "gps_multihot_fill")
+        g = g.contiguous()
+        if _MULTIHOT_WGRAD and R >= 256:
+            from ..fused import _param_grads
+            g_w, _ = _param_grads(multihot, g, True, False)
+        else:
+            g_w = multihot.t() @ g
+        outs, off = [], 0
+        for v in ctx.vocab:
+            outs.append(g_w[off:off + v])
+            off += v
+        return (None, *outs)
+
+
+_EMBED_SUM = os.environ.get("GPS_EMBED_SUM", "1") != "0"      # 0: the multi-hot GEMM forward of rounds 1-4 (A/B)
+
+
+def _embed_sum_ok(feats, embs) -> bool:
+    w = embs[0].weight
+    return (_EMBED_SUM and feats.is_cuda and feats.dtype == torch.int64 and feats.dim() == 2 and feats.stride(1) == 1
+            and 1 <= len(embs) <= 16 and feats.shape[1] == len(embs) and feats.shape[0] > 0
+            and all(e.weight.dtype == torch.float32 and e.weight.is_contiguous() and e.weight.data_ptr() % 16 == 0
+                    and e.weight.shape[1] == w.shape[1] and e.padding_idx is None and e.max_norm is None for e in embs)
+            and w.shape[1] % 4 == 0)
+
+
 # off by default: measured neutral in the pcqm4m step (10.03 vs 10.05 ms, same box, replayed) -- the two library GEMMs it
 # replaces are ~35 us each after TunableOp, the split-K launch + its reduce + the stream hand-over cost about the same
 _MULTIHOT_WGRAD = os.environ.get("GPS_MULTIHOT_WGRAD", "0") != "0"
@@ -52,6 +113,8 @@ def _multihot_embedding(feats, embs, owner):
     GEMM over a multi-hot matrix (small vocabularies only).  The point is the backward: grad_W = multihot^T @ g is a
     deterministic GEMM instead of k sort-based ``embedding_dense_backward`` pipelines.  The vocabulary axis is padded to
     a multiple of 4 (zero columns / zero table rows) so that the weight-gradient kernel takes it."""
+    if _embed_sum_ok(feats, embs):           # round 5: one gather-sum launch (csrc/embed.hip); the multi-hot matrix only
+        return _EmbedSum.apply(feats, *[e.weight for e in embs])      # exists in the backward, for the table-gradient GEMM
     offs = getattr(owner, "_offsets", None)
     if offs is None or offs.device != feats.device:
         sizes = [e.num_embeddings for e in embs]

@@ -46,6 +46,9 @@ _SIGNATURES = {
     "gps_embedding_grad": (c_int, [_P, _P, _P, c_int64, c_int64, c_int, _P, _P, c_size_t, _P]),
     "gps_segment_pool_fwd": (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P]),
     "gps_segment_pool_bwd": (c_int, [_P, _P, _P, c_int64, c_int, c_int, _P, _P]),
+    "gps_embed_sum": (c_int, [_P, c_int64, c_int64, c_int, _P, _P, c_int, _P, _P]),
+    "gps_multihot_columns": (c_int, [c_int, _P]),
+    "gps_multihot_fill": (c_int, [_P, c_int64, c_int64, c_int, _P, _P, _P]),
     "gps_segment_pool_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
     "gps_segment_pool_fwd_sliced": (c_int, [_P, _P, c_int64, c_int64, c_int, c_int, _P, _P, c_size_t, _P]),
     "gps_bn_workspace_floats": (c_size_t, [c_int64, c_int]),

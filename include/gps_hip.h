@@ -471,6 +471,20 @@ size_t gps_embedding_grad_workspace_bytes(int64_t n, int d);
 int gps_embedding_grad_supported(int d);
 int gps_embedding_grad(const float* g, const int64_t* tok_sorted, const int64_t* perm, int64_t n, int64_t V, int d,
                        float* g_w, void* ws, size_t ws_bytes, gps_stream_t stream);
+/* Sum-of-embeddings encoders over small vocabularies (csrc/embed.hip, round 5): out[r, :] = sum_i table_i[feats[r, i], :]
+ * -- OGB's AtomEncoder / BondEncoder as the reference registers them (graphgps/encoder/ via ogb.graphproppred.mol_encoder:
+ * `x_embedding += emb[i](x[:, i])`), the AST type / depth tables (graphgps/encoder/ast_encoder.py:35-83) and the TypeDict
+ * encoders (graphgps/encoder/type_dict_encoder.py) -- in ONE launch, columns added in index order (the reference's own
+ * summation order).  feats: int64 [R, k] with row stride ld, 1 <= k <= 16; tables: HOST array of k device pointers to
+ * contiguous [vocab[i], emb] fp32 tables (16-byte aligned, emb % 4 == 0); indices outside a table are clamped, never faulted
+ * on (nn.Embedding raises on them on the host side of the reference).
+ * gps_multihot_fill writes the [R, vpad] multi-hot matrix of the same features (1.0 at column offset_i + feats[r, i],
+ * vpad = gps_multihot_columns(k, vocab) = sum of the vocabularies rounded up to a multiple of 4) whose transpose times the
+ * output gradient is the stacked table gradient: the deterministic form of k embedding_dense_backward passes. */
+int gps_embed_sum(const int64_t* feats, int64_t ld, int64_t R, int k, const float* const* tables, const int* vocab, int emb,
+                  float* out, gps_stream_t stream);
+int gps_multihot_columns(int k, const int* vocab);
+int gps_multihot_fill(const int64_t* feats, int64_t ld, int64_t R, int k, const int* vocab, float* out, gps_stream_t stream);
 int gps_segment_pool_fwd(const float* x, const int32_t* ptr, int64_t B, int d, int mean, float* out,
                          gps_stream_t stream);
 /* The same pooling with the rows of a graph cut into slices of 32 (round 5): one workgroup per (graph, slice) -- slot
