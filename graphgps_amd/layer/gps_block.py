@@ -393,7 +393,7 @@ _BRANCH = _os.environ.get("GPS_BRANCH_STREAM", "0")
 # competes with a forked kernel for a CU's LDS (what made the round-3 fork of the whole attention half useless).
 # The backward pair only co-resides when the GatedGCN backward's LDS stash leaves room for an attention workgroup
 # (GPS_GG_STASH_KB <= ~80 next to the 45 KB of k_sattn_bwd).
-_CORE_FORK = _os.environ.get("GPS_CORE_FORK", "0") != "0"
+_CORE_FORK = _os.environ.get("GPS_CORE_FORK", "1") != "0"
 _branch_streams = {}
 
 
