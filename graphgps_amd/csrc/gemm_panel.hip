@@ -1211,8 +1211,15 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring16(const PanelArgs P) 
 //             a terminated wavefront no longer counts in later barriers.
 // Each loader serves the transfers of two consumers' shares (PER = 2 ND <= 20 per stage, so (S-1) PER <= 63 fits vmcnt
 // except for the 5-slot rings, where the 64th transfer simply waits for the first to land).
-// GPS_GEMM_LOADERS=0 keeps k_gemm_ring16 (A/B); EDGE shapes stay on it.
+// EDGE shapes stay on k_gemm_ring16.
 // ------------------------------------------------------------------------------------------------------------
+// MEASURED (profiles/r05_gemm_ring16_loader_wavefronts.txt, tools/runs/gpu_r6c.sh): parity green on all 142 GEMM / statistics
+// tests, and NO faster -- the seven projection shapes 256.4 us against 250.3 for k_gemm_ring16, the step 8.89-8.93 against
+// 8.94 ms.  So the issue slots of the transfers were not what the ablation's 47 us were: without its transfers the loop
+// has no DATA to wait for; the loop is bound by the arrival of 40 KB per stage and CU through the L2 -> LDS path (~20 bytes
+// per cycle and CU at these sizes), whoever issues them.  Kept as a record of the experiment, compiled only with
+// -DGPS_RING16_LOADERS (then GPS_GEMM_LOADERS=1 selects it at run time).
+#ifdef GPS_RING16_LOADERS
 constexpr int R16L_NLOAD = 2;
 constexpr int NTHREADS_L = NTHREADS + 64 * R16L_NLOAD;
 
@@ -1441,6 +1448,8 @@ __global__ __launch_bounds__(NTHREADS_L, 2) void k_gemm_ring16L(const PanelArgs 
   stamp(3);
 }
 
+#endif  // GPS_RING16_LOADERS
+
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) % 16) == 0; }
 
 }  // namespace
@@ -1635,8 +1644,12 @@ static int panel_launch(const float* A, int64_t lda, int64_t M, int K, const uin
   const bool ring = ring_enabled() || !staged_ok || f16;
   const int mb = ring_mb(M, N, K), nj = rg_nj(N, K);
   const bool edge = rg_edge(N, K);
-  // round 5: loader wavefronts for the fp16 form (k_gemm_ring16L; whole panels and k-stages only).  GPS_GEMM_LOADERS=0: off
-  static const bool loaders_on = []() { const char* v = getenv("GPS_GEMM_LOADERS"); return !(v && v[0] == '0'); }();
+  // round 5 experiment: loader wavefronts for the fp16 form (k_gemm_ring16L; whole panels and k-stages only)
+#ifdef GPS_RING16_LOADERS
+  static const bool loaders_on = []() { const char* v = getenv("GPS_GEMM_LOADERS"); return v && v[0] == '1'; }();
+#else
+  constexpr bool loaders_on = false;
+#endif
   const bool loaders = loaders_on && f16 && !edge;
   GPS_REQUIRE(epilogue != 3 || !edge, "gps_gemm_panel: the statistics epilogue needs whole column panels and k-stages");
   GPS_REQUIRE(epilogue != 3 || ring, "gps_gemm_panel: the statistics epilogue needs the ring kernel");
@@ -1670,9 +1683,14 @@ static int panel_launch(const float* A, int64_t lda, int64_t M, int K, const uin
     KERNEL<<<grid, THREADS, LDS, s>>>(P);                                                             \
   } while (0)
 #define GPS_RING_ANY(KERNEL, LDS) GPS_RING_ANY_T(KERNEL, LDS, NTHREADS)
+#ifdef GPS_RING16_LOADERS
+#define GPS_RING16L(KERNEL, LDS) GPS_RING_ANY_T(KERNEL, LDS, NTHREADS_L)
+#else
+#define GPS_RING16L(KERNEL, LDS) GPS_REQUIRE(false, "gps_gemm_panel: built without -DGPS_RING16_LOADERS")
+#endif
 #define GPS_RING_LAUNCH(MBV, NJV, E, C)                                                               \
   do {                                                                                                \
-    if (f16 && loaders) GPS_RING_ANY_T((k_gemm_ring16L<MBV, NJV, E, C>), r16_lds_bytes(MBV, NJV), NTHREADS_L); \
+    if (f16 && loaders) GPS_RING16L((k_gemm_ring16L<MBV, NJV, E, C>), r16_lds_bytes(MBV, NJV));        \
     else if (f16) GPS_RING_ANY((k_gemm_ring16<MBV, NJV, E, C>), r16_lds_bytes(MBV, NJV));             \
     else GPS_RING_ANY((k_gemm_ring<MBV, NJV, E, C>), rg_lds_bytes(MBV, NJV));                         \
   } while (0)
@@ -1709,6 +1727,7 @@ static int panel_launch(const float* A, int64_t lda, int64_t M, int K, const uin
 #undef GPS_RING_LAUNCH
 #undef GPS_RING_ANY
 #undef GPS_RING_ANY_T
+#undef GPS_RING16L
 #undef GPS_RING_SHAPES
 #undef GPS_PANEL_LAUNCH
   return gps::launch_status("gps_gemm_panel");
