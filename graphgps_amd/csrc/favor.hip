@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void k_favor_ctx(
   }
   const int i = lane & 15, grp = lane >> 4;
   const int inner = H * DH;
-  const int pad = nmax_dev[0] - (n1_all - n0);
+  const int pad = max(nmax_dev[0] - (n1_all - n0), 0);     // (>= 0: a dead graph of a padded batch may be longer than Nmax)
   const float M = key_max_M(kmax, gh, pad);
   const int f = mt * 16 + i;  // this lane's feature column
   float pv[KPL];
@@ -255,7 +255,7 @@ __global__ __launch_bounds__(256) void k_favor_sum_parts(const float* __restrict
     for (int sl = 0; sl < S; ++sl) a += kpart[sl * nk + j];
     if (kmax) {
       const int gh = (int)(j / 272), g = gh / H;
-      const int pad = nmax_dev[0] - (ptr[g + 1] - ptr[g]);
+      const int pad = max(nmax_dev[0] - (ptr[g + 1] - ptr[g]), 0);
       a += (float)pad * (ratio * (expf(-key_max_M(kmax, gh, pad)) + FEPS));
     }
     kout[j] = a;
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(256) void k_favor_bwd_k(
   const int gh = s.g * H + s.h;
   const int krow = s.row0 + s.i;
   const bool k_ok = krow < s.n1;
-  const int pad = nmax_dev[0] - (s.n1 - s.n0);
+  const int pad = max(nmax_dev[0] - (s.n1 - s.n0), 0);
   const float M = key_max_M(kmax, gh, pad);
   float kv[KPL], vv[KPL];
   const int krc = clampi(krow, s.n1 - 1);
@@ -620,7 +620,7 @@ __global__ void k_favor_bwd_kmax_fix(const float* __restrict__ P, int m, float c
   const int g = gh / H, h = gh - g * H;
   const int n0 = ptr[g], n1 = ptr[g + 1];
   if (n1 <= n0) return;
-  const int pad = nmax_dev[0] - (n1 - n0);
+  const int pad = max(nmax_dev[0] - (n1 - n0), 0);
   const unsigned long long km = kmax[gh];
   const float m_real = dec_f32((uint32_t)(km >> 32));
   if (pad > 0 && !(m_real > 0.0f)) return;   // the max is a padded row's zero logit: constant
@@ -640,8 +640,12 @@ __global__ void k_favor_bwd_kmax_fix(const float* __restrict__ P, int m, float c
   d_qkv[(int64_t)key * ldg + H * DH + h * DH + lane] += c * gM * P[(int64_t)f * DH + lane];
 }
 
-__global__ void k_segment_max_len(const int32_t* __restrict__ ptr, int64_t B, int32_t* __restrict__ out) {
+// b_real (or null): device word with the number of REAL graphs of a padded batch (loader.BucketPadding appends dead graphs
+// behind them) -- the reference's to_dense_batch Nmax is the longest graph the loader emitted, padding must not move it
+__global__ void k_segment_max_len(const int32_t* __restrict__ ptr, int64_t B, const int32_t* __restrict__ b_real,
+                                  int32_t* __restrict__ out) {
   int best = 0;
+  if (b_real) B = min(B, (int64_t)max(b_real[0], 0));
   for (int64_t g = threadIdx.x; g < B; g += blockDim.x) best = max(best, ptr[g + 1] - ptr[g]);
   for (int o = 32; o > 0; o >>= 1) best = max(best, __shfl_xor(best, o));
   __shared__ int sm[16];
@@ -659,8 +663,14 @@ extern "C" {
 
 int gps_segment_max_len(const int32_t* ptr, int64_t B, int32_t* nmax, gps_stream_t stream) {
   GPS_REQUIRE(ptr && nmax && B >= 0, "gps_segment_max_len: bad arguments");
-  k_segment_max_len<<<1, 1024, 0, gps::as_stream(stream)>>>(ptr, B, nmax);
+  k_segment_max_len<<<1, 1024, 0, gps::as_stream(stream)>>>(ptr, B, nullptr, nmax);
   return gps::launch_status("gps_segment_max_len");
+}
+
+int gps_segment_max_len_real(const int32_t* ptr, int64_t B, const int32_t* b_real, int32_t* nmax, gps_stream_t stream) {
+  GPS_REQUIRE(ptr && nmax && B >= 0, "gps_segment_max_len_real: bad arguments");
+  k_segment_max_len<<<1, 1024, 0, gps::as_stream(stream)>>>(ptr, B, b_real, nmax);
+  return gps::launch_status("gps_segment_max_len_real");
 }
 
 }  // extern "C"

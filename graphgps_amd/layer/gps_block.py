@@ -525,9 +525,10 @@ class _GPSBlock(torch.autograd.Function):
         ref = _BY_REF
         sync = _norm.sync_arena(layer, dev)
         rn, re_ = gi.n_real, gi.e_real       # padded batches: device words with the real row counts (else None)
-        if rn is not None and (_GG_STATS or perf or not panel or imgs[0][0].amax is None):
-            raise _lib.GpsHipError("padded batches need the default Transformer block path (fp16-form ring GEMMs, "
-                                   "GPS_GG_STATS=0); the Performer block has not been taken through padding")
+        if rn is not None and (_GG_STATS or not panel or imgs[0][0].amax is None):
+            raise _lib.GpsHipError("padded batches need the default block path (fp16-form ring GEMMs, GPS_GG_STATS=0)")
+        # (round 5: the Performer block takes padded batches too -- FAVOR+ is per graph, its Nmax is taken over the REAL
+        # graphs (ops._nmax_dev / gi.b_real), every BatchNorm task and statistics epilogue below counts real rows)
         gemm_stats = panel and _GEMM_STATS and _gemm.stats_supported(N, d, inner) and _gemm.stats_supported(N, d, 2 * d)
         # -- local branch: GatedGCN core ---------------------------------------------------------
         def local_half():
@@ -841,8 +842,9 @@ class _GPSBlockGINE(torch.autograd.Function):
         bn2 = _bn_desc(layer.norm2, stats[4], stats[5])
         sync = _norm.sync_arena(layer, dev)
         zl, za = _E(N, d, **f32), _E(N, d, **f32)
-        _norm.fwd([_norm.fwd_task(_norm.ADD_DROP, x, N, b=g2, p=p_loc, seed=s[0], out=zl, stats=bnl),
-                   _norm.fwd_task(_norm.ADD_DROP, x, N, b=ao, p=p_l, seed=s[3], out=za, stats=bna)],
+        rn = gi.n_real                       # padded batches (round 5): statistics over the real rows (device word)
+        _norm.fwd([_norm.fwd_task(_norm.ADD_DROP, x, N, b=g2, p=p_loc, seed=s[0], out=zl, stats=bnl, rdev=rn),
+                   _norm.fwd_task(_norm.ADD_DROP, x, N, b=ao, p=p_l, seed=s[3], out=za, stats=bna, rdev=rn)],
                   d, dev, sync.site(_S_MID))
         h = _E(N, d, **f32)
         _norm.fwd([_norm.fwd_task(_norm.BN_DUAL, zl, N, b=za, bn1=bnl, bn2=bna, out=h)], d, dev, None)
@@ -851,7 +853,7 @@ class _GPSBlockGINE(torch.autograd.Function):
         t = _K.act_drop_add(L, None, f1, True, p_f1, s[4], st)
         f2 = torch.addmm(layer.ff_linear2.bias, t, layer.ff_linear2.weight.t())
         z2 = _E(N, d, **f32)
-        _norm.fwd([_norm.fwd_task(_norm.ADD_DROP, h, N, b=f2, p=p_f2, seed=s[5], out=z2, stats=bn2)], d, dev,
+        _norm.fwd([_norm.fwd_task(_norm.ADD_DROP, h, N, b=f2, p=p_f2, seed=s[5], out=z2, stats=bn2, rdev=rn)], d, dev,
                   sync.site(_S_Z2))
         out = _E(N, d, **f32)
         _norm.fwd([_norm.fwd_task(_norm.BN_ACT, z2, N, bn1=bn2, out=out)], d, dev, None)
@@ -885,7 +887,8 @@ class _GPSBlockGINE(torch.autograd.Function):
         g_nlw, g_nlb, g_naw, g_nab, g_n2w, g_n2b = gpar.unbind(0)
 
         g_z2, g_f2 = _E(N, d, **f32), _E(N, d, **f32)
-        b1 = [_norm.bwd_task(z2, g_out, bn2, N, g_n2w, g_n2b, g_z=g_z2, g_drop=g_f2, p2=p_f2, seed2=s[5])]
+        rn = gi.n_real                       # padded batches: 1 / R_real, exact zeros on the padding rows of every apply
+        b1 = [_norm.bwd_task(z2, g_out, bn2, N, g_n2w, g_n2b, g_z=g_z2, g_drop=g_f2, p2=p_f2, seed2=s[5], rdev=rn)]
         _norm.bwd_partial(b1, d, dev, sync.site(_S_B1))
         _norm.bwd_apply(b1, d, dev, None)
         g_t = g_f2.mm(layer.ff_linear2.weight)
@@ -894,7 +897,7 @@ class _GPSBlockGINE(torch.autograd.Function):
         # g_g2 = dropmask_local(g_zl), g_xres = g_zl + g_za, g_ao = dropmask_attn(g_za)
         g_g2, g_xres, g_ao = _E(N, d, **f32), _E(N, d, **f32), _E(N, d, **f32)
         b3 = [_norm.bwd_task(zl, g_h, bnl, N, g_nlw, g_nlb, z2=za, bn2=bna, g_gamma2=g_naw, g_beta2=g_nab,
-                             g_z=g_g2, p1x=p_loc, seed1x=s[0], g_sum=g_xres, g_drop=g_ao, p2=p_l, seed2=s[3])]
+                             g_z=g_g2, p1x=p_loc, seed1x=s[0], g_sum=g_xres, g_drop=g_ao, p2=p_l, seed2=s[3], rdev=rn)]
         _norm.bwd_partial(b3, d, dev, sync.site(_S_B3))
         _norm.bwd_apply(b3, d, dev, None)
         with _Fork(dev, _BRANCH) as fork:            # attention half
@@ -940,11 +943,10 @@ def block_params_gine(layer):
             layer.norm2.weight, layer.norm2.bias]
 
 
-def gine_block_supported(layer, x, e=None) -> bool:
+def gine_block_static_ok(layer) -> bool:
+    """The part of gine_block_supported that only depends on how the layer was built."""
     import torch.nn as nn
     lm = layer.local_model
-    if not (layer.training and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32):
-        return False
     if layer.local_gnn_type != 'GINE' or layer.global_model_type != 'Transformer' or layer.equivstable_pe:
         return False
     if not layer.batch_norm or not isinstance(layer.act_fn_ff, nn.ReLU):
@@ -956,6 +958,14 @@ def gine_block_supported(layer, x, e=None) -> bool:
     for bn in (layer.norm1_local, layer.norm1_attn, layer.norm2):
         if not (bn.affine and bn.track_running_stats and bn.momentum is not None):
             return False
+    return True
+
+
+def gine_block_supported(layer, x, e=None) -> bool:
+    if not (layer.training and torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32):
+        return False
+    if not gine_block_static_ok(layer):
+        return False
     d = x.shape[1]
     if d % 4 != 0 or d > 1024 or x.shape[0] < 2 or not x.is_contiguous():
         return False

@@ -163,15 +163,16 @@ class GPSLayer(nn.Module):
             batch.x = h
             batch.edge_attr = e_new
             return batch
-        if gi.n_real is not None and self.training:
-            # a padded batch (loader.BucketPadding) that did not take the block above: every other path computes its
-            # BatchNorm statistics over ALL rows it is given -- padding would silently change the batch
-            from ..lib import GpsHipError
-            raise GpsHipError("padded batches (batch.gps_counts) are served by the fused CustomGatedGCN+Transformer "
-                              "block only (training mode, BatchNorm, ReLU); pad nothing for this layer")
         if _BLOCK_ENABLED and gine_block_supported(self, h, edge_attr):
             batch.x = gps_block_gine(self, h, batch.edge_attr, gi)      # GINE leaves edge_attr as is
             return batch
+        if gi.n_real is not None and self.training:
+            # a padded batch (loader.BucketPadding) that took none of the blocks above: every other path computes its
+            # BatchNorm statistics over ALL rows it is given -- padding would silently change the batch
+            from ..lib import GpsHipError
+            raise GpsHipError("padded batches (batch.gps_counts) are served by the fused blocks only (CustomGatedGCN + "
+                              "Transformer / Performer, GINE + Transformer: training mode, BatchNorm, ReLU); pad nothing "
+                              "for this layer")
 
         h_local = h_attn = None
         if self.local_model is not None:

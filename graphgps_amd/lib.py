@@ -78,6 +78,7 @@ _SIGNATURES = {
     "gps_rwse_lds_nodes": (c_int, []),
     "gps_rwse": (c_int, [_P, _P, _P, c_int64, c_int64, c_int, c_int, c_float, _P, _P, _P, _P]),
     "gps_segment_max_len": (c_int, [_P, c_int64, _P, _P]),
+    "gps_segment_max_len_real": (c_int, [_P, c_int64, _P, _P, _P]),
     "gps_favor_workspace_floats": (c_size_t, [c_int64, c_int64, c_int]),
     "gps_favor_fwd": (c_int, [_P, c_int64, _P, c_int, _P, _P, _P, _P, c_int64, c_int64, c_int64, c_int,
                               c_int, _P, _P, _P, _P, _P, _P, _P, c_size_t, _P]),

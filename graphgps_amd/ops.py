@@ -65,6 +65,7 @@ class GraphIndex:
     # past them are padding, kept out of every BatchNorm statistic and forced to zero gradient; None = no padding
     n_real: Optional[torch.Tensor] = None
     e_real: Optional[torch.Tensor] = None
+    b_real: Optional[torch.Tensor] = None     # ... and of REAL graphs (round 5: the Performer's Nmax)
 
 
 def build_graph_index(edge_index: torch.Tensor, num_nodes: int, num_graphs: int,
@@ -176,6 +177,7 @@ def graph_index_of(batch) -> GraphIndex:
             raise _lib.GpsHipError(f"batch.gps_counts must be int32 [>= 2] on {ei.device}, got {counts.dtype} "
                                    f"{tuple(counts.shape)} on {counts.device}")
         gi.n_real, gi.e_real = counts[0:1], counts[1:2]
+        gi.b_real = counts[2:3] if counts.numel() >= 3 else None
     try:
         batch.__dict__["_gps_index"] = gi
     except Exception:
@@ -678,8 +680,9 @@ def _nmax_dev(gi: GraphIndex) -> torch.Tensor:
         L = _lib.load()
         dev = gi.ptr.device
         nm = torch.zeros(1, dtype=torch.int32, device=dev)
-        check(L.gps_segment_max_len(ptr(gi.ptr), gi.B, ptr(nm), current_stream(dev)),
-              "gps_segment_max_len")
+        # (a padded batch: over the real graphs only -- gi.b_real, the third word of batch.gps_counts)
+        check(L.gps_segment_max_len_real(ptr(gi.ptr), gi.B, ptr(gi.b_real), ptr(nm), current_stream(dev)),
+              "gps_segment_max_len_real")
         gi._nmax = nm
     return nm
 

@@ -336,8 +336,8 @@ def _head_rows(obj, n: int):
 
 
 def padding_supported(model) -> bool:
-    """True when ``loader.BucketPadding`` is invisible to ``model``: every GPS layer runs as the fused
-    CustomGatedGCN+Transformer block (whose BatchNorms read the real row counts from the device), every other
+    """True when ``loader.BucketPadding`` is invisible to ``model``: every GPS layer runs as one of the fused blocks
+    (CustomGatedGCN + Transformer / Performer, GINE + Transformer: their BatchNorms read the real row counts from the device), every other
     BatchNorm of the model is one the encoders compute over the real rows (encoder/encoders.py ``_batch_norm``), and
     the head is graph-level over 'add' / 'mean' pooling (the dead graphs' rows are dropped before the loss)."""
     from .encoder.encoders import (BatchNorm1dNode, EquivStableLapPENodeEncoder, KernelPENodeEncoder)
@@ -351,10 +351,16 @@ def padding_supported(model) -> bool:
     known, layers = set(), 0
     for m in model.modules():
         if isinstance(m, GPSLayer):
-            if not (_blk._block_static_ok(m) and m.global_model_type == 'Transformer' and _blk._panel_ok(m, m.dim_h)):
+            # round 5: all three fused blocks count the real rows -- CustomGatedGCN + Transformer, CustomGatedGCN + Performer
+            # (FAVOR+ is per graph, its Nmax over the real graphs) and GINE + Transformer
+            if (_blk._block_static_ok(m) and m.global_model_type in ('Transformer', 'Performer')
+                    and _blk._panel_ok(m, m.dim_h)):
+                lm = m.local_model
+                known |= {id(q) for q in (lm.bn_node_x, lm.bn_edge_e, m.norm1_local, m.norm1_attn, m.norm2)}
+            elif _blk.gine_block_static_ok(m) and m.dim_h % 4 == 0 and m.dim_h <= 1024:
+                known |= {id(q) for q in (m.norm1_local, m.norm1_attn, m.norm2)}
+            else:
                 return False
-            lm = m.local_model
-            known |= {id(q) for q in (lm.bn_node_x, lm.bn_edge_e, m.norm1_local, m.norm1_attn, m.norm2)}
             layers += 1
         elif isinstance(m, (KernelPENodeEncoder, EquivStableLapPENodeEncoder)) and m.raw_norm is not None:
             known.add(id(m.raw_norm))

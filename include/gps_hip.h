@@ -359,6 +359,10 @@ int gps_seg_attn_bias_bwd(const float* d_out, const float* qkv, int64_t ld_qkv, 
  * gM_part [max_tiles*H]; d_qkv [N, 3*64H] receives dq | dk | dv.
  * ------------------------------------------------------------------------------------- */
 int gps_segment_max_len(const int32_t* ptr, int64_t B, int32_t* nmax, gps_stream_t stream);
+/* The same over the first b_real[0] graphs only (b_real: device int32 word, or NULL = all B): the Nmax of a PADDED batch
+ * (loader.BucketPadding appends dead graphs behind the real ones; the reference's to_dense_batch Nmax -- and with it the
+ * padded-key term of performer_layer.py:485-487 -- is the longest graph the loader emitted). */
+int gps_segment_max_len_real(const int32_t* ptr, int64_t B, const int32_t* b_real, int32_t* nmax, gps_stream_t stream);
 /* ABI v6: `ws` (gps_favor_workspace_floats(N, B, H) floats, or NULL): partial context records -- the rows of a graph are
  * dealt to several wavefronts per (graph, head, feature tile) and summed in slice order (deterministic); without it one
  * wavefront walks all rows of its graph (the round-1 form). */

@@ -184,21 +184,19 @@ def test_padding_is_invisible_to_the_real_graphs(dropout):
 
 
 def test_padded_batch_on_an_unsupported_layer_fails_loudly():
-    """Padding is only invisible where the BatchNorms read the real row counts: the GINE block and the Performer block
-    refuse a padded batch instead of silently normalising over the padding."""
+    """Padding is only invisible where the BatchNorms read the real row counts -- the three fused blocks (round 5: GINE +
+    Transformer and CustomGatedGCN + Performer as well).  A layer that takes the operator path (here: no global model)
+    refuses a padded batch instead of silently normalising over the padding."""
     import graphgps_amd as g
     from graphgps_amd.lib import GpsHipError
     from graphgps_amd.loader import BucketPadding
     from graphgps_amd.synthetic import model_batch
     dev = torch.device(DEV)
-    zinc = g.create_model(os.path.join(g.CONFIG_DIR, "zinc_gps_rwse.yaml"), ["gt.layers", 1], 1, 1).to(dev).train()
+    zinc = g.create_model(os.path.join(g.CONFIG_DIR, "zinc_gps_rwse.yaml"),
+                          ["gt.layers", 1, "gt.layer_type", "GINE+None"], 1, 1).to(dev).train()
     pb = BucketPadding(node_step=64, edge_step=64)(model_batch("zinc", 8, seed=2))
     with pytest.raises(GpsHipError, match="padded batches"):
         zinc(pb.to(dev))
-    code2 = g.create_model(os.path.join(g.CONFIG_DIR, "code2_gps.yaml"), ["gt.layers", 1], 2, 5002).to(dev).train()
-    pc = BucketPadding(node_step=64, edge_step=64)(model_batch("code2", 2, seed=2))
-    with pytest.raises(GpsHipError, match="padded batches"):
-        code2(pc.to(dev))
     torch.cuda.synchronize()
 
 
@@ -309,3 +307,143 @@ def test_train_epoch_pads_to_buckets_and_feeds_the_logger_real_graphs(monkeypatc
     assert all(r["loss"] == r["loss"] for r in log.rows)
     assert all(s[2] for s in seen) and len({s[:2] for s in seen}) <= 6, seen
     assert all(s[0][0] % 64 == 0 for s in seen)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# round 5: the GINE + Transformer and CustomGatedGCN + Performer blocks on padded batches (VERDICT r4 missing 2 / item 7:
+# the 8 Performer configs -- configs/GPS/ogbg-code2-GPS.yaml:40 -- and the GINE configs -- zinc-GPS+RWSE.yaml:39 -- ran
+# eagerly on never-repeating shapes)
+# ---------------------------------------------------------------------------------------------------------------------
+_KINDS = {"zinc": ("zinc_gps_rwse.yaml", 1, 1), "code2": ("code2_gps.yaml", 2, 5002)}
+
+
+def _kind_model(kind, dev, layers, dropout):
+    import graphgps_amd as g
+    yaml, din, dout = _KINDS[kind]
+    m = g.create_model(os.path.join(g.CONFIG_DIR, yaml),
+                       ["gt.layers", layers, "gt.dropout", dropout, "gt.attn_dropout", dropout], din, dout)
+    return m.to(dev).train()
+
+
+def _kind_loss(kind):
+    from graphgps_amd.loss.losses import compute_loss, subtoken_cross_entropy
+    return subtoken_cross_entropy if kind == "code2" else compute_loss
+
+
+def _junk_padding(pb, b, gen):
+    """Random content in the padding rows of every node / edge tensor of the padded batch ``pb`` (same shapes)."""
+    N, E = b.x.shape[0], b.edge_index.shape[1]
+    out = pb.clone()
+    for k in pb.keys():
+        v = getattr(pb, k)
+        if not torch.is_tensor(v) or k in ("edge_index", "ptr", "batch", "gps_counts", "y", "y_arr"):
+            continue
+        real = N if v.shape[0] == pb.x.shape[0] else (E if v.shape[0] == pb.edge_index.shape[1] else None)
+        if real is None or v.shape[0] == real:
+            continue
+        w = v.clone()
+        if v.dtype.is_floating_point:
+            w[real:] = torch.rand(w[real:].shape, generator=gen)
+        else:                                             # per column: a value the real rows use as well
+            cols = w.reshape(w.shape[0], -1)
+            for c in range(cols.shape[1]):
+                hi = int(cols[:real, c].max()) + 1
+                cols[real:, c] = torch.randint(0, hi, (cols.shape[0] - real,), generator=gen)
+        setattr(out, k, w)
+    return out
+
+
+@pytest.mark.parametrize("kind,nb,steps", [("zinc", 32, (64, 64)), ("code2", 4, (256, 512))])
+def test_padding_is_invisible_to_the_gine_and_performer_blocks(kind, nb, steps):
+    """ONE step of a 2-layer model (zinc-GPS+RWSE: GINE + Transformer blocks; ogbg-code2-GPS: CustomGatedGCN + Performer
+    blocks, Nmax of FAVOR+'s padded-key term over the REAL graphs) on a batch, its padded form and its padded form with junk
+    in the padding rows: loss, running statistics and parameter gradients of the padded steps equal the un-padded step's
+    (forward quantities to fp32 rounding, gradients in the 2-norm: the runs round differently), and junk in the padding
+    changes nothing about them."""
+    from graphgps_amd.loader import BucketPadding
+    from graphgps_amd.optim import FlatAdamW
+    from graphgps_amd.synthetic import model_batch
+    from graphgps_amd.train import TrainStep, padding_supported
+    dev = torch.device(DEV)
+    torch.manual_seed(0)
+    model = _kind_model(kind, dev, 2, 0.0)
+    assert padding_supported(model)
+    opt = FlatAdamW(model.parameters(), lr=0.0, weight_decay=0.0, max_grad_norm=None)
+    ts = TrainStep(model, opt, loss_fn=_kind_loss(kind))
+    state = {k: v.detach().clone() for k, v in model.state_dict().items()}
+    names = {id(p): k for k, p in model.named_parameters()}
+    b = model_batch(kind, nb, seed=11)
+    pad = BucketPadding(node_step=steps[0], edge_step=steps[1], dead_graphs=4)
+    pb = pad(b)
+    assert pb.x.shape[0] > b.x.shape[0] + 4 and pb.edge_index.shape[1] >= b.edge_index.shape[1]
+    jb = _junk_padding(pb, b, torch.Generator().manual_seed(3))
+    vars(jb)["_gps_meta"] = dict(vars(pb)["_gps_meta"])
+
+    def run(batch):
+        model.load_state_dict(state)
+        torch.manual_seed(77)
+        loss, _, _ = ts._eager_triplet(batch.to(dev))
+        torch.cuda.synchronize()
+        grads = {names[id(p)]: v.detach().clone() for p, v in zip(opt.arena.params, opt.arena.grad_views)}
+        return float(loss), grads, _buffers(model)
+
+    l0, g0, s0 = run(b.clone())
+    l1, g1, s1 = run(pb)
+    l2, g2, s2 = run(jb)
+    assert l0 == l0 and l1 == l1 and l2 == l2
+    assert abs(l1 - l0) <= 2e-5 * max(abs(l0), 1.0), (l0, l1)
+    assert abs(l2 - l1) <= 1e-5 * max(abs(l1), 1.0), (l1, l2)
+    for k in s0:
+        assert_close(s1[k], s0[k], 2e-5, f"buffer {k}, padded vs un-padded", rel_to_max=True)
+        assert_close(s2[k], s1[k], 1e-5, f"buffer {k}, junk vs zero padding", rel_to_max=True)
+    gscale = max(float(v.norm()) for v in g0.values())
+    worst = worst_junk = 0.0
+    for k in g0:
+        assert torch.isfinite(g1[k]).all() and torch.isfinite(g2[k]).all(), k
+        den = max(float(g0[k].norm()), 1e-3 * gscale)
+        worst = max(worst, float((g1[k] - g0[k]).norm()) / den)
+        worst_junk = max(worst_junk, float((g2[k] - g1[k]).norm()) / den)
+    print(f"{kind}: padded vs un-padded loss {l1:.6f} / {l0:.6f}, worst 2-norm relative parameter-gradient difference "
+          f"{worst:.2e}; junk vs zero padding {worst_junk:.2e}")
+    assert worst <= 5e-3 and worst_junk <= 5e-3, (worst, worst_junk)
+
+
+@pytest.mark.parametrize("kind,nb,steps", [("zinc", 32, (64, 128)), ("code2", 4, (1024, 1024))])
+def test_bucketed_loader_replays_zinc_and_code2_streams(kind, nb, steps):
+    """24 shuffled batches of the other two BASELINE workloads through DeviceLoader(pad=BucketPadding) + TrainStep.step_cached:
+    a handful of shape buckets, most steps replayed, and replaying changes nothing (losses and final weights equal the same
+    padded batches stepped eagerly)."""
+    from graphgps_amd.loader import BucketPadding, DeviceLoader
+    from graphgps_amd.optim import FlatAdamW
+    from graphgps_amd.synthetic import model_batch
+    from graphgps_amd.train import TrainStep
+    dev = torch.device(DEV)
+    seq = [model_batch(kind, nb, seed=900 + i) for i in range(24)]
+    assert len({(b.x.shape[0], b.edge_index.shape[1]) for b in seq}) >= 20
+    results, replays, shapes = {}, 0, 0
+    for mode in ("eager-padded", "cached-padded"):
+        torch.manual_seed(0)
+        model = _kind_model(kind, dev, 2, 0.0)
+        opt = FlatAdamW(model.parameters(), lr=1e-4, weight_decay=0.0, max_grad_norm=1.0)
+        ts = TrainStep(model, opt, loss_fn=_kind_loss(kind))
+        pad = BucketPadding(node_step=steps[0], edge_step=steps[1], dead_graphs=4)
+        losses = []
+        for b in DeviceLoader([q.clone() for q in seq], dev, pad=pad):
+            if mode == "cached-padded":
+                key = ts._shape_key(b)
+                will_replay = key in ts.__dict__.get("_shape_cache", {}) or key in ts.__dict__.get("_shape_seen", set())
+                loss, pred, true = ts.step_cached(b, max_graphs=8)
+                assert key not in ts.__dict__.get("_shape_failed", set()), "capture of a padded step failed"
+                replays += int(will_replay)
+            else:
+                loss, pred, true = ts._eager_triplet(b)
+            losses.append(float(loss))
+        torch.cuda.synchronize()
+        results[mode] = (losses, torch.cat([p.detach().reshape(-1) for p in model.parameters()]).cpu())
+        if mode == "cached-padded":
+            shapes = len(ts.__dict__["_shape_cache"])
+    print(f"{kind}: {replays} of 24 steps replayed, {shapes} captured shapes")
+    assert replays >= 14, (replays, shapes)
+    for i, (a, c) in enumerate(zip(results["eager-padded"][0], results["cached-padded"][0])):
+        assert a == a and abs(a - c) <= 2e-6 * max(abs(a), 1.0), (i, a, c)
+    assert_close(results["cached-padded"][1], results["eager-padded"][1], 1e-6, "weights after the sequence")
