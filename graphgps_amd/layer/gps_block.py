@@ -393,7 +393,13 @@ _BRANCH = _os.environ.get("GPS_BRANCH_STREAM", "0")
 # competes with a forked kernel for a CU's LDS (what made the round-3 fork of the whole attention half useless).
 # The backward pair only co-resides when the GatedGCN backward's LDS stash leaves room for an attention workgroup
 # (GPS_GG_STASH_KB <= ~80 next to the 45 KB of k_sattn_bwd).
-_CORE_FORK = _os.environ.get("GPS_CORE_FORK", "1") != "0"
+# Default "bwd": the backward pair only (k_sattn_bwd beside k_gatedgcn_bwd: ~120 us serial -> ~85 us) -- the forward pair
+# gains nothing measurable (the two ~25 us kernels overlap for ~18 us and the fork / join costs ~16 us of queue latency:
+# profiles/r05_kernel_trace_stats_pcqm4m_corefork.txt) and forking it would only blur the in-step duration of the GatedGCN
+# forward, the kernel bench.py's `roofline` block is quoted on.  "1" = both passes, "0" = never.
+_CORE_FORK_MODE = _os.environ.get("GPS_CORE_FORK", "bwd")
+_CORE_FORK = _CORE_FORK_MODE != "0"
+_CORE_FORK_FWD = _CORE_FORK_MODE == "1"
 _branch_streams = {}
 
 
@@ -551,7 +557,7 @@ class _GPSBlock(torch.autograd.Function):
         # GPS_GG_FIRST=1 (single stream only): the GatedGCN core directly behind the merged projection that wrote its four
         # operands, the attention half after it.  Measured, same box: 9.948 vs 9.958 ms per step, the GatedGCN forward at
         # 26.3 vs 25.9 us -- the operands are Infinity-Cache resident either way; the default keeps the documented order.
-        core_fork = _CORE_FORK and _BRANCH == "0" and not perf
+        core_fork = _CORE_FORK_FWD and _BRANCH == "0" and not perf
         gg_first = _GG_FIRST and _BRANCH == "0" and not core_fork
         if gg_first:
             xt, eh = local_half()

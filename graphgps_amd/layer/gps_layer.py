@@ -126,9 +126,10 @@ class GPSLayer(nn.Module):
 
         if self.layer_norm and self.batch_norm:
             raise ValueError("Cannot apply two types of normalization together")
-        if self.layer_norm:
-            raise NotImplementedError("gt.layer_norm=True (PyG graph LayerNorm) is not built; "
-                                      "every configs/GPS/*.yaml uses batch_norm")
+        if self.layer_norm:                  # reference :129-131: pygnn.norm.LayerNorm(dim_h), PyG's graph-mode LayerNorm
+            from .graph_layernorm import GraphLayerNorm
+            self.norm1_local = GraphLayerNorm(dim_h)
+            self.norm1_attn = GraphLayerNorm(dim_h)
         if self.batch_norm:
             self.norm1_local = nn.BatchNorm1d(dim_h)
             self.norm1_attn = nn.BatchNorm1d(dim_h)
@@ -139,6 +140,9 @@ class GPSLayer(nn.Module):
         self.ff_linear1 = nn.Linear(dim_h, dim_h * 2)
         self.ff_linear2 = nn.Linear(dim_h * 2, dim_h)
         self.act_fn_ff = self.activation()
+        if self.layer_norm:                  # reference :148
+            from .graph_layernorm import GraphLayerNorm
+            self.norm2 = GraphLayerNorm(dim_h)
         if self.batch_norm:
             self.norm2 = nn.BatchNorm1d(dim_h)
         self.ff_dropout1 = nn.Dropout(dropout)
@@ -191,6 +195,8 @@ class GPSLayer(nn.Module):
                     h_local = self.local_model.forward_tensors(h, batch.edge_attr, gi)
                 # dropout_local + residual (reference :188-189)
                 h_local = add_dropout(h_in1, h_local, self.dropout_local.p, self.training)
+            if self.layer_norm:
+                h_local = self.norm1_local(h_local, gi)                      # :191-192
             if self.batch_norm:
                 h_local = bn_act(h_local, self.norm1_local)                  # :193-194
 
@@ -206,6 +212,8 @@ class GPSLayer(nn.Module):
             else:
                 raise RuntimeError(f"Unexpected {self.global_model_type}")
             h_attn = add_dropout(h_in1, h_attn, self.dropout_attn.p, self.training)  # :212-213
+            if self.layer_norm:
+                h_attn = self.norm1_attn(h_attn, gi)                         # :209-210
             if self.batch_norm:
                 # norm1_attn, with the branch sum h_local + h_attn (:222) folded into the
                 # BN epilogue as its residual operand
@@ -219,6 +227,8 @@ class GPSLayer(nn.Module):
         # Feed Forward block + norm2 (reference :225-229).
         ff = self._ff_block(h)
         h = add_dropout(h, ff, self.ff_dropout2.p, self.training)
+        if self.layer_norm:
+            h = self.norm2(h, gi)                                            # :226-227
         if self.batch_norm:
             h = bn_act(h, self.norm2)
 

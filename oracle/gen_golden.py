@@ -68,6 +68,13 @@ CASES = {
     # stub's restatement, the wiring is the reference's)
     "gcn_transformer_d32h4": (dict(dim_h=32, local_gnn_type="GCN", global_model_type="Transformer",
                                    num_heads=4), "P14", 6, 23),
+    # gt.layer_norm=True (gps_layer.py:129-134,148,191-192,209-210,226-227): PyG's graph-mode LayerNorm in place of the three
+    # BatchNorms (no configs/**/*.yaml sets it; the branch exists in the reference, so it exists here)
+    "gine_transformer_layernorm_d32h4": (dict(dim_h=32, local_gnn_type="GINE", global_model_type="Transformer",
+                                              num_heads=4, layer_norm=True, batch_norm=False), "P14", 6, 31),
+    "gatedgcn_transformer_layernorm_d32h4": (dict(dim_h=32, local_gnn_type="CustomGatedGCN",
+                                                  global_model_type="Transformer", num_heads=4, layer_norm=True,
+                                                  batch_norm=False), "ZINC", 5, 32),
     # (no GINE + equivstable_pe fixture: the reference's GINEConvESLapPE cannot be constructed -- its
     #  __init__ calls reset_parameters(), which touches self.mlp_r_ij, before defining it:
     #  gine_conv_layer.py:35 vs :43-54.  The HIP layer implements the intended arithmetic and is
@@ -77,13 +84,14 @@ CASES = {
 
 def run_case(name, kw, profile, num_graphs, seed):
     torch.manual_seed(seed)
-    layer = RefGPSLayer(**kw, act="relu", dropout=0.0, attn_dropout=0.0,
-                        layer_norm=False, batch_norm=True)
+    kw = dict(kw)
+    norms = dict(layer_norm=kw.pop("layer_norm", False), batch_norm=kw.pop("batch_norm", True))
+    layer = RefGPSLayer(**kw, act="relu", dropout=0.0, attn_dropout=0.0, **norms)
     layer.train()
     # non-trivial BN affine parameters so that their gradients are exercised
     with torch.no_grad():
         for mod in layer.modules():
-            if isinstance(mod, torch.nn.BatchNorm1d):
+            if isinstance(mod, torch.nn.BatchNorm1d) or type(mod).__name__ == "LayerNorm":
                 mod.weight.uniform_(0.5, 1.5)
                 mod.bias.uniform_(-0.3, 0.3)
     sd0 = {k: v.clone() for k, v in layer.state_dict().items()}
@@ -107,8 +115,7 @@ def run_case(name, kw, profile, num_graphs, seed):
     loss = (out.x * wx).sum() + (out.edge_attr * we).sum()
     loss.backward()
     fix = dict(
-        name=name, ctor=dict(kw, act="relu", dropout=0.0, attn_dropout=0.0,
-                             layer_norm=False, batch_norm=True),
+        name=name, ctor=dict(kw, act="relu", dropout=0.0, attn_dropout=0.0, **norms),
         state_dict=sd0, x=x.detach().clone(), edge_attr=e.detach().clone(),
         edge_index=edge_index, batch=bvec, ptr=ptr, wx=wx, we=we,
         out_x=out.x.detach().clone(), out_edge_attr=out.edge_attr.detach().clone(),

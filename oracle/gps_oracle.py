@@ -254,6 +254,27 @@ class OraclePerformerSelfAttention(nn.Module):
 # ---------------------------------------------------------------------------
 # GPS block
 # ---------------------------------------------------------------------------
+class OracleGraphLayerNorm(nn.Module):
+    """``pygnn.norm.LayerNorm(dim_h)`` as graphgps/layer/gps_layer.py:129-134,148 builds it and :191-192,209-210,226-227 call
+    it (``norm(h, batch.batch)``): PyG's graph-mode LayerNorm -- mean and (biased) variance of every graph over all of its
+    nodes AND channels, then the per-channel affine.  Third-party semantics (torch_geometric is absent): restated from the
+    published implementation, eps = 1e-5, weight = 1 / bias = 0 at construction."""
+
+    def __init__(self, dim, eps=1e-5):
+        super().__init__()
+        self.eps = eps
+        self.weight = nn.Parameter(torch.ones(dim))
+        self.bias = nn.Parameter(torch.zeros(dim))
+
+    def forward(self, x, batch):
+        B = int(batch.max()) + 1
+        cnt = torch.bincount(batch, minlength=B).to(x.dtype).clamp(min=1) * x.shape[-1]
+        mean = torch.zeros(B, dtype=x.dtype).index_add_(0, batch, x.sum(-1)) / cnt
+        xc = x - mean[batch].unsqueeze(-1)
+        var = torch.zeros(B, dtype=x.dtype).index_add_(0, batch, (xc * xc).sum(-1)) / cnt
+        return xc / (var + self.eps).sqrt()[batch].unsqueeze(-1) * self.weight + self.bias
+
+
 class OracleGPSLayer(nn.Module):
     """graphgps/layer/gps_layer.py:15-257 for local in {None, GCN, CustomGatedGCN, GINE} and
     global in {None, Transformer, BiasedTransformer, Performer}, batch_norm or no norm."""
@@ -262,8 +283,11 @@ class OracleGPSLayer(nn.Module):
                  pna_degrees=None, equivstable_pe=False, dropout=0.0, attn_dropout=0.0,
                  layer_norm=False, batch_norm=True, bigbird_cfg=None, log_attn_weights=False):
         super().__init__()
-        if layer_norm or log_attn_weights:
+        if log_attn_weights:
             raise NotImplementedError("oracle covers the BASELINE.json configurations only")
+        if layer_norm and batch_norm:
+            raise ValueError("Cannot apply two types of normalization together")           # :126-127
+        self.layer_norm = layer_norm
         self.equivstable_pe = equivstable_pe
         self.dim_h, self.num_heads = dim_h, num_heads
         self.batch_norm = batch_norm
@@ -290,6 +314,9 @@ class OracleGPSLayer(nn.Module):
                                                           dropout=attn_dropout)  # :111-114
         else:
             raise ValueError(f"Unsupported global x-former model: {global_model_type}")
+        if layer_norm:                                                                     # :129-131,148
+            self.norm1_local = OracleGraphLayerNorm(dim_h)
+            self.norm1_attn = OracleGraphLayerNorm(dim_h)
         if batch_norm:
             self.norm1_local = nn.BatchNorm1d(dim_h)
             self.norm1_attn = nn.BatchNorm1d(dim_h)
@@ -298,6 +325,8 @@ class OracleGPSLayer(nn.Module):
         self.ff_linear1 = nn.Linear(dim_h, dim_h * 2)
         self.ff_linear2 = nn.Linear(dim_h * 2, dim_h)
         self.act_fn_ff = ACT[act]()
+        if layer_norm:
+            self.norm2 = OracleGraphLayerNorm(dim_h)
         if batch_norm:
             self.norm2 = nn.BatchNorm1d(dim_h)
         self.ff_dropout1 = nn.Dropout(dropout)
@@ -320,6 +349,8 @@ class OracleGPSLayer(nn.Module):
                     h_local = self.local_model(h, batch.edge_index, batch.edge_attr, pe)  # :177-185
                 h_local = self.dropout_local(h_local)
                 h_local = h_in1 + h_local                                            # :188-189
+            if self.layer_norm:
+                h_local = self.norm1_local(h_local, batch.batch)                     # :191-192
             if self.batch_norm:
                 h_local = self.norm1_local(h_local)                                  # :193-194
             outs.append(h_local)
@@ -336,11 +367,15 @@ class OracleGPSLayer(nn.Module):
                 h_attn = self.self_attn(h_dense, mask=mask)[mask]                    # :206
             h_attn = self.dropout_attn(h_attn)
             h_attn = h_in1 + h_attn
+            if self.layer_norm:
+                h_attn = self.norm1_attn(h_attn, batch.batch)                        # :209-210
             if self.batch_norm:
                 h_attn = self.norm1_attn(h_attn)
             outs.append(h_attn)
         h = sum(outs)                                                                # :222
         h = h + self.ff_dropout2(self.ff_linear2(self.ff_dropout1(self.act_fn_ff(self.ff_linear1(h)))))
+        if self.layer_norm:
+            h = self.norm2(h, batch.batch)                                           # :226-227
         if self.batch_norm:
             h = self.norm2(h)
         batch.x = h
