@@ -447,3 +447,58 @@ def test_bucketed_loader_replays_zinc_and_code2_streams(kind, nb, steps):
     for i, (a, c) in enumerate(zip(results["eager-padded"][0], results["cached-padded"][0])):
         assert a == a and abs(a - c) <= 2e-6 * max(abs(a), 1.0), (i, a, c)
     assert_close(results["cached-padded"][1], results["eager-padded"][1], 1e-6, "weights after the sequence")
+
+
+@pytest.mark.parametrize("kind,nb", [("pcqm4m", 64), ("zinc", 32)])
+def test_eval_epoch_replays_padded_batches_like_eager(kind, nb, monkeypatch):
+    """eval_epoch (custom_train.py:50-77) with shape buckets + per-shape hipGraph replay (round 5, EvalStep) against the
+    plain eager evaluation of the un-padded batches: one logger record per batch with the real graphs only, losses and
+    predictions equal to fp32 rounding, most batches replayed.  Running statistics are made non-trivial first (eval-mode
+    BatchNorm reads them)."""
+    import graphgps_amd as g
+    from graphgps_amd.graphgym.config import cfg
+    from graphgps_amd.synthetic import model_batch
+    from graphgps_amd import train as T
+    dev = torch.device(DEV)
+
+    class Logger:
+        def __init__(self):
+            self.rows = []
+
+        def update_stats(self, **kw):
+            self.rows.append(kw)
+
+    torch.manual_seed(0)
+    model = _pcqm_model(dev, 3, 0.1) if kind == "pcqm4m" else _kind_model(kind, dev, 3, 0.1)
+    with torch.no_grad():
+        gen = torch.Generator().manual_seed(5)
+        for m in model.modules():
+            if isinstance(m, torch.nn.modules.batchnorm._NormBase) and m.running_mean is not None:
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=gen) * 0.2)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=gen) + 0.5)
+    seq = [model_batch(kind, nb, seed=1300 + i) for i in range(16)]
+    old = cfg.accelerator
+    cfg.accelerator = DEV
+    if not hasattr(cfg, "params"):
+        cfg.params = 0
+    try:
+        monkeypatch.setenv("GPS_TRAIN_REPLAY", "0")
+        monkeypatch.setenv("GPS_LOADER_BUCKETS", "0")
+        ref = Logger()
+        T.eval_epoch(ref, [b.clone() for b in seq], model, split='val')
+        monkeypatch.setenv("GPS_TRAIN_REPLAY", "1")
+        monkeypatch.setenv("GPS_LOADER_BUCKETS", "1")
+        got = Logger()
+        T.eval_epoch(got, [b.clone() for b in seq], model, split='val')
+    finally:
+        cfg.accelerator = old
+    torch.cuda.synchronize()
+    es = model.__dict__["_gps_eval_step"]
+    print(f"{kind}: {es.replays} of 16 evaluation batches replayed, {len(es.cache)} captured shapes")
+    assert not model.training and len(ref.rows) == len(got.rows) == 16
+    assert es.replays >= 8 and not es.failed
+    for i, (a, b) in enumerate(zip(ref.rows, got.rows)):
+        assert b["true"].shape[0] == nb and b["pred"].shape[0] == nb          # the dead graphs never reach the logger
+        assert abs(float(a["loss"]) - float(b["loss"])) <= 1e-5 * max(abs(float(a["loss"])), 1.0), (i, a["loss"], b["loss"])
+        assert_close(b["pred"], a["pred"], 2e-5, f"predictions of evaluation batch {i}", rel_to_max=True)
+        assert torch.equal(torch.as_tensor(a["true"]).cpu(), torch.as_tensor(b["true"]).cpu())
