@@ -952,6 +952,16 @@ def main():
     if not args.no_bucketed_leg and args.workload == "pcqm4m" and world == 1 and reducer is None:
         bucketed = bucketed_loader_leg(model, opt, compute_loss, nb, args.profile, dev)
 
+    # the in-step kernel records: a few more steps under the tracer.  On EVERY rank -- with N > 1 a step contains the
+    # gradient all-reduce, and a collective that only rank 0 enters never returns (found by reading the N > 1 path in round 5:
+    # no 8-GPU run has exercised it yet); rank 0 alone uses the records
+    in_step = None
+    if not args.no_kernel_roofline:
+        try:
+            in_step = in_step_kernel_ms(step)
+        except Exception as exc:
+            log(f"in-step kernel records unavailable ({type(exc).__name__}: {exc}); isolated timings only")
+        barrier()
     secondary = None
     if rank == 0 and world == 1 and args.workload == "pcqm4m" and not args.no_secondary:
         secondary = secondary_workloads()
@@ -993,13 +1003,9 @@ def main():
                               if tunable is not None else "library default heuristics",
         }
         if not args.no_kernel_roofline:
-            in_step = None
-            try:
-                in_step = in_step_kernel_ms(step)
+            if in_step is not None:
                 out["in_step_kernel_ms"] = {k: dict(ms=round(v[0], 5), per_step=v[1]) for k, v in
                                             sorted(in_step.items(), key=lambda kv: -kv[1][0] * kv[1][1])[:24]}
-            except Exception as exc:
-                log(f"in-step kernel records unavailable ({type(exc).__name__}: {exc}); isolated timings only")
             if args.workload == "pcqm4m":
                 kr, shape = kernel_rooflines(dev, args.profile or "P30", nb, in_step=in_step,
                                               layers=int(cfg.gt.layers))
