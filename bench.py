@@ -719,12 +719,21 @@ def main():
         respawn_under_launcher(args.gpus)
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    # GPS_BENCH_SHARE_GPU=1 + GPS_BENCH_BACKEND=gloo (testing only, never a measurement): every rank on device 0 with the
+    # collectives on gloo -- RCCL refuses two ranks on one device -- so that the N > 1 control flow of this file (matched
+    # collectives, the two-graph step around the all-reduce, one JSON line) can be run on a 1-GPU box
+    share_gpu = os.environ.get("GPS_BENCH_SHARE_GPU") == "1"
+    backend = os.environ.get("GPS_BENCH_BACKEND", "nccl")
+    dev_index = 0 if share_gpu else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     import graphgps_amd as g
     from graphgps_amd.dp import GradBucketReducer
@@ -996,6 +1005,9 @@ def main():
                             f"capture alive, {TRIAL_ROUNDS} x {TRIAL_STEPS} steps each, interleaved; "
                             "host_enqueue_ms_per_step is the chosen form's"),
             "gemm_arith": GEMM_ARITH,
+            "collective_backend": (None if world == 1 and not use_exchange else
+                                   ("RCCL (backend nccl)" if backend == "nccl" else f"{backend} -- TEST RUN, not a measurement"
+                                    + (", all ranks on one GPU" if share_gpu else ""))),
             "secondary": secondary,
             "grad_allreduce_bytes": allreduce_bytes,
             "optimizer": type(opt).__name__,
