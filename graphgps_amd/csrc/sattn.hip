@@ -73,6 +73,27 @@ __device__ __forceinline__ float col_elem(const float* __restrict__ base, uint32
   return ok ? v : 0.0f;
 }
 
+// elements [row][col], [row][col + 1] in ONE 8-byte load (col even; zeros outside the graph / the head)
+__device__ __forceinline__ float2 col_pair(const float* __restrict__ base, uint32_t ld, int row, int nrows, int col,
+                                           bool col_ok) {
+  const bool ok = col_ok && row < nrows;
+  const float2 v = *reinterpret_cast<const float2*>(base + __umul24((uint32_t)(ok ? row : 0), ld) + (ok ? col : 0));
+  return ok ? v : make_float2(0.0f, 0.0f);
+}
+// Round 5 -- column slots of the dh-side MFMA tiles when a head spans TWO 16-column tiles (dh = 24, 32).  Which head column a
+// slot of an output tile stands for is free (the contraction runs over keys / queries, never over dh), so tile 0 takes the EVEN
+// columns and tile 1 the ODD ones: slot i of tile dt is column 2 i + dt.  A lane's column-form operand elements of the two
+// tiles are then ADJACENT in memory -- one 8-byte load instead of two 4-byte loads (V in the forward: 16 -> 8 load
+// instructions per key tile; Q and dO in the backward: 16 -> 8 per query tile) -- and the four slots a lane holds of each
+// tile interleave into 8 consecutive columns, still two 16-byte stores.  Same sums in the same order: bit-identical
+// results.  (Measured first, `k_sattn_fwd2`: prefetching a second item's operands per wavefront made the forward SLOWER,
+// 29.0 vs 25.0 us -- its loads were sized for the batch's longest graph, 47 instead of ~28 load instructions per item -- so
+// the kernel is bound by the NUMBER of vector-memory instructions, not by a load / compute lockstep: DESIGN section 4.4.)
+template <int DT>
+struct Slots {
+  static constexpr bool PAIRED = DT == 2;
+};
+
 struct Item {
   int n0, n, h;
   bool live;
@@ -122,10 +143,17 @@ __device__ __forceinline__ void sattn_fwd_body(const Item& it, const float* __re
     if (t < NT) {
       row_slice<KPL>(Kb, ld, 16 * t + i, it.n, grp * KPL, 1.0f, kv[t]);
 #pragma unroll
-      for (int r = 0; r < 4; ++r)
+      for (int r = 0; r < 4; ++r) {
+        if constexpr (Slots<DT>::PAIRED) {      // slot i of tile dt = column 2 i + dt: one 8-byte load feeds both tiles
+          const float2 v2 = col_pair(Vb, ld, 16 * t + 4 * grp + r, it.n, 2 * i, 2 * i < DH);
+          vv[0][t][r] = v2.x;
+          vv[1][t][r] = v2.y;
+        } else {
 #pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-          vv[dt][t][r] = col_elem(Vb, ld, 16 * t + 4 * grp + r, it.n, dt * 16 + i, dt * 16 + i < DH);
+          for (int dt = 0; dt < DT; ++dt)
+            vv[dt][t][r] = col_elem(Vb, ld, 16 * t + 4 * grp + r, it.n, dt * 16 + i, dt * 16 + i < DH);
+        }
+      }
     }
   float qv[KPL];
   row_slice<KPL>(Qb, ld, i, it.n, grp * KPL, scale, qv);
@@ -191,13 +219,25 @@ __device__ __forceinline__ void sattn_fwd_body(const Item& it, const float* __re
     const float ltot = group_sum(psum);
     const float inv_l = 1.0f / ltot;
     if (ql < it.n) {
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {
-        const int col = dt * 16 + 4 * grp;
+      if constexpr (Slots<DT>::PAIRED) {        // slots 4 grp .. + 3 of the two tiles = columns 8 grp .. 8 grp + 7
+        const int col = 8 * grp;
         if (col < DH) {
-          const f32x4 o = oacc[dt] * inv_l;
-          *reinterpret_cast<float4*>(Ob + (int64_t)ql * d + col) = make_float4(o[0], o[1], o[2], o[3]);
-          amx = fmaxf(fmaxf(fmaxf(fmaxf(amx, fabsf(o[0])), fabsf(o[1])), fabsf(o[2])), fabsf(o[3]));
+          const f32x4 o0 = oacc[0] * inv_l, o1 = oacc[1] * inv_l;
+          float* dst = Ob + (int64_t)ql * d + col;
+          *reinterpret_cast<float4*>(dst) = make_float4(o0[0], o1[0], o0[1], o1[1]);
+          *reinterpret_cast<float4*>(dst + 4) = make_float4(o0[2], o1[2], o0[3], o1[3]);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) amx = fmaxf(fmaxf(amx, fabsf(o0[r])), fabsf(o1[r]));
+        }
+      } else {
+#pragma unroll
+        for (int dt = 0; dt < DT; ++dt) {
+          const int col = dt * 16 + 4 * grp;
+          if (col < DH) {
+            const f32x4 o = oacc[dt] * inv_l;
+            *reinterpret_cast<float4*>(Ob + (int64_t)ql * d + col) = make_float4(o[0], o[1], o[2], o[3]);
+            amx = fmaxf(fmaxf(fmaxf(fmaxf(amx, fabsf(o[0])), fabsf(o[1])), fabsf(o[2])), fabsf(o[3]));
+          }
         }
       }
       if (grp == 0) lse[(int64_t)h * N + it.n0 + ql] = m + logf(ltot);
@@ -227,182 +267,6 @@ __global__ __launch_bounds__(256, DH >= 32 ? 3 : 4) void k_sattn_fwd(
   wave_amax(amx, amax);
 }
 
-// -------------------------------------------------------------------------------------------------------------
-// Round 5 experiment (GPS_SATTN_FWD2=1): TWO (graph, head) items per wavefront, the second item's operands requested before
-// the first item is computed.  Why: 4,096 single-item wavefronts are exactly one generation (4 per SIMD), so the launch runs
-// in lockstep -- everybody loads (~7 us of HBM time for 35 MB), then everybody computes (~8 us of issue), then everybody
-// stores -- and the dispatch of 4,096 short wavefronts is 2-3 us by itself.  With two items per wavefront (2,048 wavefronts,
-// 2 per SIMD) the second half of the loads is in flight under the first half of the compute.  The loads of an item are
-// sized by NTM = the tile count of the batch's LONGEST graph (a kernel-uniform template parameter from the host's hint):
-// unconditional and straight-line, tiles past the item's own graph read a clamped address and are zeroed by row_slice's
-// select, so the compiler's waitcnt bookkeeping stays exact (operand loads under a per-item switch would merge to
-// vmcnt(0) at the join).  The compute is the single-item body's, dispatched on the item's own tile count.
-// -------------------------------------------------------------------------------------------------------------
-template <int DH, int NTM>
-__device__ __forceinline__ void sattn_fwd_load(const Item& it, const float* __restrict__ qkv, int64_t ld64, int H,
-                                               float scale, float (&kv)[4][SGeo<DH>::KPL],
-                                               float (&vv)[SGeo<DH>::DT][4][4], float (&qv)[SGeo<DH>::KPL]) {
-  using G = SGeo<DH>;
-  constexpr int KPL = G::KPL, DT = G::DT;
-  const int lane = threadIdx.x & 63, i = lane & 15, grp = lane >> 4;
-  const int d = H * DH;
-  const uint32_t ld = (uint32_t)ld64;
-  const float* __restrict__ Qb = qkv + (int64_t)it.n0 * ld64 + it.h * DH;
-  const float* __restrict__ Kb = Qb + d;
-  const float* __restrict__ Vb = Qb + 2 * d;
-#pragma unroll
-  for (int t = 0; t < 4; ++t)
-    if (t < NTM) {
-      row_slice<KPL>(Kb, ld, 16 * t + i, it.n, grp * KPL, 1.0f, kv[t]);
-#pragma unroll
-      for (int r = 0; r < 4; ++r)
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt)
-          vv[dt][t][r] = col_elem(Vb, ld, 16 * t + 4 * grp + r, it.n, dt * 16 + i, dt * 16 + i < DH);
-    }
-  row_slice<KPL>(Qb, ld, i, it.n, grp * KPL, scale, qv);
-}
-
-template <int DH, bool DROP, int NT>
-__device__ __forceinline__ void sattn_fwd_compute(const Item& it, const float (&kv)[4][SGeo<DH>::KPL],
-                                                  const float (&vv)[SGeo<DH>::DT][4][4], float (&qv)[SGeo<DH>::KPL],
-                                                  const float* __restrict__ qkv, int64_t ld64, int64_t N, int H,
-                                                  float scale, uint32_t thr16, float inv_keep, uint64_t seed,
-                                                  float* __restrict__ out, float* __restrict__ lse, float& amx) {
-  using G = SGeo<DH>;
-  constexpr int KPL = G::KPL, DT = G::DT;
-  const int lane = threadIdx.x & 63, i = lane & 15, grp = lane >> 4;
-  const int h = it.h, d = H * DH;
-  const uint32_t ld = (uint32_t)ld64;
-  const float* __restrict__ Qb = qkv + (int64_t)it.n0 * ld64 + h * DH;
-  float* __restrict__ Ob = out + (int64_t)it.n0 * d + h * DH;
-#pragma unroll 1
-  for (int qt = 0; qt < NT; ++qt) {
-    const int ql = 16 * qt + i;
-    f32x4 s[4];
-#pragma unroll
-    for (int t = 0; t < 4; ++t) s[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int c = 0; c < KPL; ++c)
-#pragma unroll
-      for (int t = 0; t < 4; ++t)
-        if (t < NT) s[t] = mfma16(kv[t][c], qv[c], s[t]);            // S^T[key][query]
-    if (qt + 1 < NT) row_slice<KPL>(Qb, ld, ql + 16, it.n, grp * KPL, scale, qv);   // next tile's Q, in flight
-    float mloc = -INFINITY;
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-      if (t < NT) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int key = 16 * t + 4 * grp + r;
-          s[t][r] = key < it.n ? s[t][r] : -INFINITY;
-          mloc = fmaxf(mloc, s[t][r]);
-        }
-      }
-    const float m = group_max(mloc);
-    const uint32_t rh = DROP ? row_hash((uint32_t)(it.n0 + ql) * (uint32_t)H + (uint32_t)h, seed) : 0u;
-    float psum = 0.0f;
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-      if (t < NT) {
-        uint32_t h0 = 0, h1 = 0;
-        if (DROP) {
-          const uint32_t kp = (uint32_t)(16 * t + 4 * grp) >> 1;
-          h0 = pair_hash(rh, kp);
-          h1 = pair_hash(rh, kp + 1);
-        }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float p = sm_exp(s[t][r] - m);
-          psum += p;
-          if (DROP) {
-            const uint32_t hh = r < 2 ? h0 : h1;
-            const bool keep = (r & 1) ? keep_hi(hh, thr16) : keep_lo(hh, thr16);
-            p = keep ? p * inv_keep : 0.0f;
-          }
-          s[t][r] = p;
-        }
-      }
-    f32x4 oacc[DT];
-#pragma unroll
-    for (int dt = 0; dt < DT; ++dt) oacc[dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-      if (t < NT) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r)
-#pragma unroll
-          for (int dt = 0; dt < DT; ++dt)
-            oacc[dt] = mfma16(vv[dt][t][r], s[t][r], oacc[dt]);
-      }
-    const float ltot = group_sum(psum);
-    const float inv_l = 1.0f / ltot;
-    if (ql < it.n) {
-#pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {
-        const int col = dt * 16 + 4 * grp;
-        if (col < DH) {
-          const f32x4 o = oacc[dt] * inv_l;
-          *reinterpret_cast<float4*>(Ob + (int64_t)ql * d + col) = make_float4(o[0], o[1], o[2], o[3]);
-          amx = fmaxf(fmaxf(fmaxf(fmaxf(amx, fabsf(o[0])), fabsf(o[1])), fabsf(o[2])), fabsf(o[3]));
-        }
-      }
-      if (grp == 0) lse[(int64_t)h * N + it.n0 + ql] = m + logf(ltot);
-    }
-  }
-}
-
-__device__ __forceinline__ Item item_at(const int32_t* __restrict__ ptr, int64_t B, int H, int64_t wi) {
-  Item it;
-  it.live = false;
-  it.n0 = 0; it.n = 0; it.h = 0;            // a dead slot loads (clamped) from the first rows of the tensor and computes nothing
-  if (wi >= B * H) return it;
-  const int64_t g = wi / H;
-  it.h = (int)(wi - g * H);
-  it.n0 = ptr[g];
-  it.n = ptr[g + 1] - it.n0;
-  it.live = it.n > 0;
-  if (!it.live) { it.n0 = 0; it.n = 0; it.h = 0; }
-  return it;
-}
-
-template <int DH, bool DROP, int NTM>
-__global__ __launch_bounds__(256, 2) void k_sattn_fwd2(
-    const float* __restrict__ qkv, int64_t ld64, const int32_t* __restrict__ ptr, int64_t B, int64_t N, int H,
-    float scale, uint32_t thr16, float inv_keep, uint64_t seed, const uint64_t* __restrict__ salt,
-    float* __restrict__ out, float* __restrict__ lse, uint32_t* __restrict__ amax) {
-  using G = SGeo<DH>;
-  const int64_t W = (int64_t)gridDim.x * 4;
-  const int64_t wi = blockIdx.x * (int64_t)4 + (threadIdx.x >> 6);
-  const Item a = item_at(ptr, B, H, wi), b = item_at(ptr, B, H, wi + W);
-  if (a.n > 16 * NTM || b.n > 16 * NTM) __builtin_trap();      // a stale host hint must not truncate a graph silently
-  seed = gps::salted_seed(seed, salt);
-  float kva[4][G::KPL], vva[G::DT][4][4], qa[G::KPL];
-  float kvb[4][G::KPL], vvb[G::DT][4][4], qb[G::KPL];
-  sattn_fwd_load<DH, NTM>(a, qkv, ld64, H, scale, kva, vva, qa);
-  sattn_fwd_load<DH, NTM>(b, qkv, ld64, H, scale, kvb, vvb, qb);
-  float amx = 0.0f;
-#define SA_C(IT, KV, VV, Q, NTV) sattn_fwd_compute<DH, DROP, NTV>(IT, KV, VV, Q, qkv, ld64, N, H, scale, thr16, inv_keep, seed, out, lse, amx)
-  if (a.live) {
-    switch ((a.n + 15) >> 4) {
-      case 1: SA_C(a, kva, vva, qa, 1); break;
-      case 2: if (NTM >= 2) SA_C(a, kva, vva, qa, 2); break;
-      case 3: if (NTM >= 3) SA_C(a, kva, vva, qa, 3); break;
-      default: if (NTM >= 4) SA_C(a, kva, vva, qa, 4); break;
-    }
-  }
-  if (b.live) {
-    switch ((b.n + 15) >> 4) {
-      case 1: SA_C(b, kvb, vvb, qb, 1); break;
-      case 2: if (NTM >= 2) SA_C(b, kvb, vvb, qb, 2); break;
-      case 3: if (NTM >= 3) SA_C(b, kvb, vvb, qb, 3); break;
-      default: if (NTM >= 4) SA_C(b, kvb, vvb, qb, 4); break;
-    }
-  }
-#undef SA_C
-  wave_amax(amx, amax);
-}
-
 // =============================================================================================================
 // backward, graphs of <= 64 nodes: dQ, dK, dV in one launch
 // =============================================================================================================
@@ -416,6 +280,9 @@ __device__ __forceinline__ void sattn_bwd_body(const Item& it, float* __restrict
                                                uint64_t seed, float* __restrict__ d_qkv, int64_t ldg, float& amx) {
   using G = SGeo<DH>;
   constexpr int KPL = G::KPL, DT = G::DT;
+  // paired column slots (Slots) in the backward for dh = 24 only: at dh = 32 the 8-byte operand pairs cost the no-dropout
+  // instantiation its last free registers (256 + 4 spilled); the forward pairs at both widths
+  constexpr bool PAIRED_B = Slots<DT>::PAIRED && DH != 32;
   constexpr int PT = 20;                      // transpose scratch pitch (floats): 16 + 4, rows stay 16-byte aligned
   const int lane = threadIdx.x & 63, i = lane & 15, grp = lane >> 4;
   const int h = it.h, d = H * DH;
@@ -464,13 +331,21 @@ __device__ __forceinline__ void sattn_bwd_body(const Item& it, float* __restrict
     row_slice<KPL>(Ob, du, ql, it.n, grp * KPL, 1.0f, ov);
     float qc[DT][4], dc[DT][4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r)
+    for (int r = 0; r < 4; ++r) {
+      if constexpr (PAIRED_B) {        // (slot i of tile dt = column 2 i + dt, see Slots)
+        const float2 q2 = col_pair(Qb, ld, 16 * qt + 4 * grp + r, it.n, 2 * i, 2 * i < DH);
+        const float2 d2 = col_pair(dOb, du, 16 * qt + 4 * grp + r, it.n, 2 * i, 2 * i < DH);
+        qc[0][r] = q2.x * scale; qc[1][r] = q2.y * scale;
+        dc[0][r] = d2.x; dc[1][r] = d2.y;
+      } else {
 #pragma unroll
-      for (int dt = 0; dt < DT; ++dt) {
-        const bool in = dt * 16 + i < DH;
-        qc[dt][r] = col_elem(Qb, ld, 16 * qt + 4 * grp + r, it.n, dt * 16 + i, in) * scale;
-        dc[dt][r] = col_elem(dOb, du, 16 * qt + 4 * grp + r, it.n, dt * 16 + i, in);
+        for (int dt = 0; dt < DT; ++dt) {
+          const bool in = dt * 16 + i < DH;
+          qc[dt][r] = col_elem(Qb, ld, 16 * qt + 4 * grp + r, it.n, dt * 16 + i, in) * scale;
+          dc[dt][r] = col_elem(dOb, du, 16 * qt + 4 * grp + r, it.n, dt * 16 + i, in);
+        }
       }
+    }
     const float lse_q = lse_b[min(ql, it.n - 1)];
     // delta_q = sum_c dO[q][c] O[q][c] over the head's dh columns
     float dl_part = 0.0f;
@@ -583,14 +458,28 @@ __device__ __forceinline__ void sattn_bwd_body(const Item& it, float* __restrict
       if (kl < it.n) {
         float* __restrict__ Gk = d_qkv + (int64_t)(it.n0 + kl) * ldg + d + h * DH;
         float* __restrict__ Gv = Gk + d;
-#pragma unroll
-        for (int dt = 0; dt < DT; ++dt) {
-          const int col = dt * 16 + 4 * grp;
+        if constexpr (PAIRED_B) {      // the dK^T / dV^T tiles carry the slot order of their Q^T / dO^T operands
+          const int col = 8 * grp;
           if (col < DH) {
-            *reinterpret_cast<float4*>(Gk + col) = make_float4(dk[t][dt][0], dk[t][dt][1], dk[t][dt][2], dk[t][dt][3]);
-            *reinterpret_cast<float4*>(Gv + col) = make_float4(dv[t][dt][0], dv[t][dt][1], dv[t][dt][2], dv[t][dt][3]);
+            *reinterpret_cast<float4*>(Gk + col) = make_float4(dk[t][0][0], dk[t][1][0], dk[t][0][1], dk[t][1][1]);
+            *reinterpret_cast<float4*>(Gk + col + 4) = make_float4(dk[t][0][2], dk[t][1][2], dk[t][0][3], dk[t][1][3]);
+            *reinterpret_cast<float4*>(Gv + col) = make_float4(dv[t][0][0], dv[t][1][0], dv[t][0][1], dv[t][1][1]);
+            *reinterpret_cast<float4*>(Gv + col + 4) = make_float4(dv[t][0][2], dv[t][1][2], dv[t][0][3], dv[t][1][3]);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) amx = fmaxf(fmaxf(amx, fabsf(dk[t][dt][r])), fabsf(dv[t][dt][r]));
+            for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+              for (int r = 0; r < 4; ++r) amx = fmaxf(fmaxf(amx, fabsf(dk[t][dt][r])), fabsf(dv[t][dt][r]));
+          }
+        } else {
+#pragma unroll
+          for (int dt = 0; dt < DT; ++dt) {
+            const int col = dt * 16 + 4 * grp;
+            if (col < DH) {
+              *reinterpret_cast<float4*>(Gk + col) = make_float4(dk[t][dt][0], dk[t][dt][1], dk[t][dt][2], dk[t][dt][3]);
+              *reinterpret_cast<float4*>(Gv + col) = make_float4(dv[t][dt][0], dv[t][dt][1], dv[t][dt][2], dv[t][dt][3]);
+#pragma unroll
+              for (int r = 0; r < 4; ++r) amx = fmaxf(fmaxf(amx, fabsf(dk[t][dt][r])), fabsf(dv[t][dt][r]));
+            }
           }
         }
       }
@@ -642,28 +531,9 @@ bool sattn_applicable(const void* qkv, int64_t ld_qkv, const void* out, int H, i
 
 // Launch the block-form forward.  Preconditions: sattn_applicable().
 void sattn_fwd_launch(const float* qkv, int64_t ld_qkv, const int32_t* ptr, int64_t B, int64_t N, int H, int dh,
-                      float scale, float p_drop, uint64_t seed, float* out, float* lse, uint32_t* amax, hipStream_t s,
-                      int64_t nmax) {
+                      float scale, float p_drop, uint64_t seed, float* out, float* lse, uint32_t* amax, hipStream_t s) {
   const uint32_t thr16 = drop_thr16(p_drop);
   const float inv_keep = p_drop > 0.0f ? drop_inv_keep(thr16) : 1.0f;
-  // round-5 experiment: two items per wavefront (dh = 24 only, batches of >= 2,048 items, longest graph 17 .. 64 nodes)
-  static const bool fwd2 = [] { const char* e = getenv("GPS_SATTN_FWD2"); return e && e[0] == '1'; }();
-  if (fwd2 && dh == 24 && B * H >= 2048 && nmax > 16 && nmax <= 64) {
-    const unsigned g2 = gps::grid_for((B * H + 1) / 2, 4);
-    const int ntm = (int)((nmax + 15) / 16);
-#define SA_F2(NTMV)                                                                                              \
-    do {                                                                                                         \
-      if (p_drop > 0.0f)                                                                                         \
-        k_sattn_fwd2<24, true, NTMV><<<g2, 256, 0, s>>>(qkv, ld_qkv, ptr, B, N, H, scale, thr16, inv_keep, seed, \
-                                                        gps::dropout_salt(), out, lse, amax);                    \
-      else                                                                                                       \
-        k_sattn_fwd2<24, false, NTMV><<<g2, 256, 0, s>>>(qkv, ld_qkv, ptr, B, N, H, scale, thr16, inv_keep, seed, \
-                                                         gps::dropout_salt(), out, lse, amax);                   \
-    } while (0)
-    if (ntm == 2) SA_F2(2); else if (ntm == 3) SA_F2(3); else SA_F2(4);
-#undef SA_F2
-    return;
-  }
   const unsigned grid = gps::grid_for(B * H, 4);
 #define SA_FWD(D)                                                                                               \
   do {                                                                                                          \

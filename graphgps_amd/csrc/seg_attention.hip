@@ -620,7 +620,7 @@ static int seg_attn_fwd_impl(const char* who, const float* qkv, int64_t ld_qkv, 
   hipStream_t s = gps::as_stream(stream);
   if (!bias && num_graphs > 0 && max_graph_nodes > 0 && max_graph_nodes <= 64 &&
       attn::sattn_applicable(qkv, ld_qkv, out, H, dh)) {            // block form (sattn.hip)
-    attn::sattn_fwd_launch(qkv, ld_qkv, ptr, num_graphs, N, H, dh, scale, p_drop, seed, out, lse, amax, s, max_graph_nodes);
+    attn::sattn_fwd_launch(qkv, ld_qkv, ptr, num_graphs, N, H, dh, scale, p_drop, seed, out, lse, amax, s);
     return gps::launch_status(who);
   }
   const bool vec = ld_qkv % 4 == 0 && (H * dh) % 4 == 0 && al16(qkv) && al16(out);
