@@ -83,8 +83,8 @@ __device__ __forceinline__ float2 col_pair(const float* __restrict__ base, uint3
 // Round 5 -- column slots of the dh-side MFMA tiles when a head spans TWO 16-column tiles (dh = 24, 32).  Which head column a
 // slot of an output tile stands for is free (the contraction runs over keys / queries, never over dh), so tile 0 takes the EVEN
 // columns and tile 1 the ODD ones: slot i of tile dt is column 2 i + dt.  A lane's column-form operand elements of the two
-// tiles are then ADJACENT in memory -- one 8-byte load instead of two 4-byte loads (V in the forward: 16 -> 8 load
-// instructions per key tile; Q and dO in the backward: 16 -> 8 per query tile) -- and the four slots a lane holds of each
+// tiles are then ADJACENT in memory -- one 8-byte load instead of two 4-byte loads (Q and dO in the backward: 16 -> 8 load
+// instructions per query tile; the forward's V loads likewise, measured slower there and left off) -- and the four slots a lane holds of each
 // tile interleave into 8 consecutive columns, still two 16-byte stores.  Same sums in the same order: bit-identical
 // results.  (Measured first, `k_sattn_fwd2`: prefetching a second item's operands per wavefront made the forward SLOWER,
 // 29.0 vs 25.0 us -- its loads were sized for the batch's longest graph, 47 instead of ~28 load instructions per item -- so
@@ -127,6 +127,10 @@ __device__ __forceinline__ void sattn_fwd_body(const Item& it, const float* __re
                                                float* __restrict__ out, float* __restrict__ lse, float& amx) {
   using G = SGeo<DH>;
   constexpr int KPL = G::KPL, DT = G::DT;
+  // paired column slots (Slots) are OFF in the forward: measured same box (tools/runs/gpu_r6k.sh), V as 8 eight-byte loads per
+  // key tile instead of 16 four-byte ones made this kernel 1 us SLOWER (21.5 vs 20.4 us hot, 23.5 vs 22.5 rotating), while the
+  // backward gained 5 us from the same change (44.2 vs 46.8 hot, 47.9 vs 53.0 rotating): the backward keeps it, this does not
+  constexpr bool PAIRED_F = false && Slots<DT>::PAIRED;
   const int lane = threadIdx.x & 63, i = lane & 15, grp = lane >> 4;
   const int h = it.h, d = H * DH;
   const uint32_t ld = (uint32_t)ld64;
@@ -144,7 +148,7 @@ __device__ __forceinline__ void sattn_fwd_body(const Item& it, const float* __re
       row_slice<KPL>(Kb, ld, 16 * t + i, it.n, grp * KPL, 1.0f, kv[t]);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        if constexpr (Slots<DT>::PAIRED) {      // slot i of tile dt = column 2 i + dt: one 8-byte load feeds both tiles
+        if constexpr (PAIRED_F) {      // slot i of tile dt = column 2 i + dt: one 8-byte load feeds both tiles
           const float2 v2 = col_pair(Vb, ld, 16 * t + 4 * grp + r, it.n, 2 * i, 2 * i < DH);
           vv[0][t][r] = v2.x;
           vv[1][t][r] = v2.y;
@@ -219,7 +223,7 @@ __device__ __forceinline__ void sattn_fwd_body(const Item& it, const float* __re
     const float ltot = group_sum(psum);
     const float inv_l = 1.0f / ltot;
     if (ql < it.n) {
-      if constexpr (Slots<DT>::PAIRED) {        // slots 4 grp .. + 3 of the two tiles = columns 8 grp .. 8 grp + 7
+      if constexpr (PAIRED_F) {        // slots 4 grp .. + 3 of the two tiles = columns 8 grp .. 8 grp + 7
         const int col = 8 * grp;
         if (col < DH) {
           const f32x4 o0 = oacc[0] * inv_l, o1 = oacc[1] * inv_l;
