@@ -33,22 +33,6 @@ constexpr int MT = 17;    // feature tiles of 16 -> m <= 272
 constexpr int KPL = 16;   // contiguous floats per lane when contracting over a 64-wide dim
 constexpr float FEPS = 1e-4f;
 
-// Round 5 -- column SLOTS of the dh-side MFMA tiles.  A head's 64 columns are four 16-column tiles (et / dt / t = 0 .. 3); which
-// column a slot of such a tile stands for is free (the contractions run over keys, queries or features, never over dh), so
-// slot i of tile e is column 4 i + e: a lane's column-form operand elements of the four tiles are then ADJACENT in memory --
-// ONE 16-byte load where rounds 2-4 issued four 4-byte loads (the block-form attention kernels showed these kernels' kind of
-// loop to be bound by the NUMBER of vector-memory instructions: DESIGN section 4.4) -- and the four slots 4 grp .. 4 grp + 3 a lane
-// holds of each tile interleave into the 16 consecutive columns 16 grp .. 16 grp + 15: four 16-byte stores, as before.
-// Same sums in the same order: bit-identical results, same memory layouts.
-__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
-__device__ __forceinline__ float f4(const float4& v, int e) { return e == 0 ? v.x : (e == 1 ? v.y : (e == 2 ? v.z : v.w)); }
-// store the lane's 4 x 4 block (tile e, slot 4 grp + k) at columns 16 grp + 4 k + e of a 64-wide row `row`
-__device__ __forceinline__ void st_slots(float* __restrict__ row, int grp, const f32x4 (&acc)[4]) {
-#pragma unroll
-  for (int k = 0; k < 4; ++k)
-    *reinterpret_cast<float4*>(row + 16 * grp + 4 * k) = make_float4(acc[0][k], acc[1][k], acc[2][k], acc[3][k]);
-}
-
 __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) {
   return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
 }
@@ -230,18 +214,22 @@ __global__ __launch_bounds__(256) void k_favor_ctx(
       ks += phi[r];
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int key = kb + 4 * grp + r;
-      // (clamped address; rows past the slice carry phi = 0, so their V value needs no select)
-      const float4 v4 = ld4(qkv + (int64_t)clampi(key, n1 - 1) * ld + 2 * inner + h * DH + 4 * i);   // slots i of the 4 tiles
+    for (int et = 0; et < 4; ++et)
 #pragma unroll
-      for (int et = 0; et < 4; ++et) acc[et] = mfma16(f4(v4, et), phi[r], acc[et]);      // ctx^T[e slot 4g+r'][feature l&15]
-    }
+      for (int r = 0; r < 4; ++r) {
+        const int key = kb + 4 * grp + r;
+        // (clamped address; rows past the slice carry phi = 0, so their V value needs no select)
+        const float vv = qkv[(int64_t)clampi(key, n1 - 1) * ld + 2 * inner + h * DH + et * 16 + i];
+        acc[et] = mfma16(vv, phi[r], acc[et]);      // ctx^T[e 4g+r'][feature l&15]
+      }
   }
   ks = group_sum(ks);
   if (f < m) {
     float* cp = ctx + ((int64_t)gh * 272 + f) * DH;
-    st_slots(cp, grp, acc);
+#pragma unroll
+    for (int et = 0; et < 4; ++et)
+      *reinterpret_cast<float4*>(cp + et * 16 + 4 * grp) =
+          make_float4(acc[et][0], acc[et][1], acc[et][2], acc[et][3]);
     // (the padded rows' closed-form term: here when the graph is one slice, else by k_favor_sum_parts)
     if (grp == 0) ksum[(int64_t)gh * 272 + f] = S > 1 ? ks : ks + (float)pad * (ratio * (expf(-M) + FEPS));
   }
@@ -331,20 +319,22 @@ __global__ __launch_bounds__(256) void k_favor_out(
       dpart += phi * kbase[clampi(f, m - 1)];          // (phi = 0 past m)
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int f = mt * 16 + 4 * s.grp + r;
-      const float4 c4 = ld4(cbase + (int64_t)clampi(f, m - 1) * DH + 4 * s.i);      // (dd = phi = 0 past m)
+    for (int et = 0; et < 4; ++et)
 #pragma unroll
-      for (int et = 0; et < 4; ++et) acc[et] = mfma16(f4(c4, et), dd[mt][r], acc[et]);   // num^T[e slot 4g+r'][query l&15]
-    }
+      for (int r = 0; r < 4; ++r) {
+        const int f = mt * 16 + 4 * s.grp + r;
+        const float cv = cbase[(int64_t)clampi(f, m - 1) * DH + et * 16 + s.i];      // (dd = phi = 0 past m)
+        acc[et] = mfma16(cv, dd[mt][r], acc[et]);   // num^T[e 4g+r'][query l&15]
+      }
   }
   const float D = group_sum(dpart);
   if (q_ok) {
     const float inv = 1.0f / D;
     float* o = out + (int64_t)qrow * inner + s.h * DH;
 #pragma unroll
-    for (int et = 0; et < 4; ++et) acc[et] = acc[et] * inv;
-    st_slots(o, s.grp, acc);
+    for (int et = 0; et < 4; ++et)
+      *reinterpret_cast<float4*>(o + et * 16 + 4 * s.grp) =
+          make_float4(acc[et][0] * inv, acc[et][1] * inv, acc[et][2] * inv, acc[et][3] * inv);
     if (s.grp == 0) {
       mq_out[(int64_t)s.h * N + qrow] = mq;
       D_out[(int64_t)s.h * N + qrow] = D;
@@ -435,24 +425,25 @@ __global__ __launch_bounds__(256) void k_favor_bwd_q(
       if (f < m && dd[mt][r] == mq) gA[mt][r] -= s1;
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int f = mt * 16 + 4 * s.grp + r;
-      const float4 p4 = ld4(P + (int64_t)clampi(f, m - 1) * DH + 4 * s.i);      // (gA = 0 past m)
+    for (int dt = 0; dt < 4; ++dt)
 #pragma unroll
-      for (int dt = 0; dt < 4; ++dt) acc[dt] = mfma16(f4(p4, dt), gA[mt][r], acc[dt]);   // g_q^T[dh slot 4g+r'][query]
-    }
+      for (int r = 0; r < 4; ++r) {
+        const int f = mt * 16 + 4 * s.grp + r;
+        const float pv = P[(int64_t)clampi(f, m - 1) * DH + dt * 16 + s.i];      // (gA = 0 past m)
+        acc[dt] = mfma16(pv, gA[mt][r], acc[dt]);   // g_q^T[dh 4g+r'][query]
+      }
   }
   if (q_ok) {
     const float* qsrc = qkv + (int64_t)qrow * ld + s.h * DH;
     float* o = d_qkv + (int64_t)qrow * ldg + s.h * DH;
     const float k2 = -s1 * c * c;                     // d(diag)/dq = c^2 q, g_diag = -s1
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {                     // columns 16 grp + 4 k + dt <- (tile dt, slot 4 grp + k)
-      const int col = 16 * s.grp + 4 * k;
+    for (int dt = 0; dt < 4; ++dt) {
+      const int col = dt * 16 + 4 * s.grp;
       const float4 qq = *reinterpret_cast<const float4*>(qsrc + col);
       *reinterpret_cast<float4*>(o + col) =
-          make_float4(c * acc[0][k] + k2 * qq.x, c * acc[1][k] + k2 * qq.y,
-                      c * acc[2][k] + k2 * qq.z, c * acc[3][k] + k2 * qq.w);
+          make_float4(c * acc[dt][0] + k2 * qq.x, c * acc[dt][1] + k2 * qq.y,
+                      c * acc[dt][2] + k2 * qq.z, c * acc[dt][3] + k2 * qq.w);
     }
   }
 }
@@ -509,18 +500,21 @@ __global__ __launch_bounds__(256) void k_favor_bwd_ctx(
       gks += gDv * phi[r];                                         // (phi = 0 past the slice)
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int qq = qb + 4 * grp + r;
-      const float4 g4 = ld4(g_out + (int64_t)clampi(qq, n1 - 1) * inner + h * DH + 4 * i);
+    for (int et = 0; et < 4; ++et)
 #pragma unroll
-      for (int et = 0; et < 4; ++et)                 // (invD = 0 past the slice)
-        acc[et] = mfma16(f4(g4, et) * invD[r], phi[r], acc[et]);     // g_ctx^T[e slot 4g+r'][feature l&15]
-    }
+      for (int r = 0; r < 4; ++r) {
+        const int qq = qb + 4 * grp + r;
+        const float gv = g_out[(int64_t)clampi(qq, n1 - 1) * inner + h * DH + et * 16 + i] * invD[r];   // (invD = 0 past the slice)
+        acc[et] = mfma16(gv, phi[r], acc[et]);     // g_ctx^T[e 4g+r'][feature l&15]
+      }
   }
   gks = group_sum(gks);
   if (f < m) {
     float* cp = g_ctx + ((int64_t)gh * 272 + f) * DH;
-    st_slots(cp, grp, acc);
+#pragma unroll
+    for (int et = 0; et < 4; ++et)
+      *reinterpret_cast<float4*>(cp + et * 16 + 4 * grp) =
+          make_float4(acc[et][0], acc[et][1], acc[et][2], acc[et][3]);
     if (grp == 0) g_ksum[(int64_t)gh * 272 + f] = gks;
   }
 }
@@ -576,17 +570,16 @@ __global__ __launch_bounds__(256) void k_favor_bwd_k(
       sk += gB[r];
     }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int f = mt * 16 + 4 * s.grp + r;
-      const int fc = clampi(f, m - 1);               // (gB = phi = 0 past m)
-      const float4 p4 = ld4(P + (int64_t)fc * DH + 4 * s.i);
-      const float4 g4 = ld4(gcb + (int64_t)fc * DH + 4 * s.i);
+    for (int t = 0; t < 4; ++t)
 #pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        accK[t] = mfma16(f4(p4, t), gB[r], accK[t]);      // g_k^T[dh slot][key] += P^T[dh][f] g_B[f][key]
-        accV[t] = mfma16(f4(g4, t), phi[r], accV[t]);     // g_v^T[e slot][key]  += g_ctx^T[e][f] phi_k^T[f][key]
+      for (int r = 0; r < 4; ++r) {
+        const int f = mt * 16 + 4 * s.grp + r;
+        const int fc = clampi(f, m - 1);               // (gB = phi = 0 past m)
+        const float pe = P[(int64_t)fc * DH + t * 16 + s.i];
+        const float ge = gcb[(int64_t)fc * DH + t * 16 + s.i];
+        accK[t] = mfma16(pe, gB[r], accK[t]);      // g_k^T[dh][key] += P^T[dh][f] g_B[f][key]
+        accV[t] = mfma16(ge, phi[r], accV[t]);     // g_v^T[e][key]  += g_ctx^T[e][f] phi_k^T[f][key]
       }
-    }
   }
   sk = group_sum(sk);                                // sum_f g_B for key (l&15)
   if (k_ok) {
@@ -595,14 +588,15 @@ __global__ __launch_bounds__(256) void k_favor_bwd_k(
     float* ov_ = d_qkv + (int64_t)krow * ldg + 2 * inner + s.h * DH;
     const float k2 = -sk * c * c;
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {                     // columns 16 grp + 4 k + t <- (tile t, slot 4 grp + k)
-      const int col = 16 * s.grp + 4 * k;
+    for (int t = 0; t < 4; ++t) {
+      const int col = t * 16 + 4 * s.grp;
       const float4 kk = *reinterpret_cast<const float4*>(ksrc + col);
       *reinterpret_cast<float4*>(ok_ + col) =
-          make_float4(c * accK[0][k] + k2 * kk.x, c * accK[1][k] + k2 * kk.y,
-                      c * accK[2][k] + k2 * kk.z, c * accK[3][k] + k2 * kk.w);
+          make_float4(c * accK[t][0] + k2 * kk.x, c * accK[t][1] + k2 * kk.y,
+                      c * accK[t][2] + k2 * kk.z, c * accK[t][3] + k2 * kk.w);
+      *reinterpret_cast<float4*>(ov_ + col) =
+          make_float4(accV[t][0], accV[t][1], accV[t][2], accV[t][3]);
     }
-    st_slots(ov_, s.grp, accV);
   }
   // this tile's contribution to -g_M: sum over its valid keys of sk (each key counted once: group 0)
   const float part = wave_sum((s.grp == 0 && k_ok) ? sk : 0.0f);
