@@ -724,7 +724,19 @@ class _GPSBlock(torch.autograd.Function):
         g_pq = _E(N, ldp, **f32)
         G, P = g_pq.data_ptr(), pq.data_ptr()
         core_fork = _CORE_FORK and _BRANCH == "0" and not perf
-        if core_fork:                                # (the out-projection's input gradient stays on the main stream)
+
+        def bnx_apply():
+            # x1 = x + drop(relu(BN_x(xt))):  bn_node_x's apply (its sums came from the chain above)
+            g = _E(N, d, **f32)
+            _norm.bwd_apply([_norm.bwd_task(xt, g_x1, bnx, N, g_bxw, g_bxb, relu=True, p=p, seed=s[0], g_z=g, rdev=rn)], d,
+                            dev, None)
+            return g
+        g_xt = None
+        if core_fork:
+            # everything the forked pair needs is made BEFORE the fork, alone on the chip: the 11 us bn_node_x apply ran 33 us
+            # beside the attention backward and held the GatedGCN backward back behind it (profiles/r05_timeline_pcqm4m.txt);
+            # the out-projection's input gradient stays on the main stream like every GEMM
+            g_xt = bnx_apply()
             g_o = (_gemm.gemm_panel(g_ao, imgs[2][1], inner, a_amax=bw(2)) if imgs is not None
                    else g_ao.mm(_W(R.out_proj)))
         with _Fork(dev, "2" if core_fork else _BRANCH) as fork:            # attention half of the backward
@@ -749,10 +761,8 @@ class _GPSBlock(torch.autograd.Function):
                                          p_at, s[2], ptr(delta), G + 4 * fs, ldp, gi.B, int(gi.nmax_host), ptr(bw(3)), sb),
                       "gps_seg_attn_bwd")
 
-        # x1 = x + drop(relu(BN_x(xt))):  bn_node_x's apply (its sums came from the chain above)
-        g_xt = _E(N, d, **f32)
-        _norm.bwd_apply([_norm.bwd_task(xt, g_x1, bnx, N, g_bxw, g_bxb, relu=True, p=p, seed=s[0], g_z=g_xt, rdev=rn)], d,
-                        dev, None)
+        if g_xt is None:
+            g_xt = bnx_apply()
         g_ce = _E(E, d, **f32)
         check(L.gps_gatedgcn_bwd(ptr(g_xt), d, ptr(g_eh), ptr(eh), P, P + fs, ldp, ptr(xt),
                                  ptr(gi.rowptr_dst), ptr(gi.src_by_dst), ptr(gi.eid_by_dst),
