@@ -207,6 +207,12 @@ class TrainStep:
             return self._eager_triplet(batch)
         key = self._shape_key(batch)
         cache = self.__dict__.setdefault("_shape_cache", {})
+        if cache and not self.opt.arena.intact():
+            # a captured step reads the parameters WHERE THEY SAT at capture time: if they have moved since (``model.to()``,
+            # ``load_state_dict(assign=True)``, a late LinearGroup re-stack) every captured graph is stale -- drop them all
+            # (the eager step below re-adopts the arena; the shapes are captured again at their next sight)
+            torch.cuda.current_stream(self.opt.arena.device).synchronize()
+            cache.clear()
         failed = self.__dict__.setdefault("_shape_failed", set())
         if key in failed:                    # this shape's capture failed before: never retried; kept apart
             return self._eager_triplet(batch)    # from the LRU of live graphs, so a marker can neither evict a working
@@ -533,9 +539,20 @@ class EvalStep:
         return (tuple((k, tuple(getattr(batch, k).shape), str(getattr(batch, k).dtype)) for k in keys),
                 0 < nmax <= 64, meta.get("b_real"), getattr(batch, "split", None))
 
+    def _addresses(self):
+        return tuple(t.data_ptr() for t in self.model.parameters()) + tuple(t.data_ptr() for t in self.model.buffers())
+
     @torch.no_grad()
     def step_cached(self, batch, max_graphs: int = 8):
         key = self._key(batch)
+        if self.cache:
+            # captured forwards read parameters and buffers where they sat at capture time (an optimizer arena adopted
+            # later, ``model.to()``, ``load_state_dict(assign=True)`` move them): stale graphs are dropped, never replayed
+            now = self._addresses()
+            if now != self.__dict__.get("_addr"):
+                torch.cuda.current_stream(batch.x.device).synchronize()
+                self.cache.clear()
+                self._addr = now
         if key in self.failed:
             return self.run_eager(batch)
         ent = self.cache.get(key)
@@ -549,6 +566,8 @@ class EvalStep:
             if ent is None:
                 self.failed.add(key)
                 return self.run_eager(batch)
+            if not self.cache:
+                self._addr = self._addresses()
             self.cache[key] = ent
             while len(self.cache) > max_graphs:
                 torch.cuda.current_stream(batch.x.device).synchronize()

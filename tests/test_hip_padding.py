@@ -502,3 +502,33 @@ def test_eval_epoch_replays_padded_batches_like_eager(kind, nb, monkeypatch):
         assert abs(float(a["loss"]) - float(b["loss"])) <= 1e-5 * max(abs(float(a["loss"])), 1.0), (i, a["loss"], b["loss"])
         assert_close(b["pred"], a["pred"], 2e-5, f"predictions of evaluation batch {i}", rel_to_max=True)
         assert torch.equal(torch.as_tensor(a["true"]).cpu(), torch.as_tensor(b["true"]).cpu())
+
+
+def test_eval_step_drops_stale_graphs_when_parameters_move():
+    """A captured evaluation forward reads the parameters where they sat at capture time.  Creating the optimizer afterwards
+    (FlatAdamW adopts every parameter into its arena: new addresses) must not leave a stale graph behind: the next
+    ``step_cached`` drops the cache and answers with the CURRENT weights."""
+    from graphgps_amd.optim import FlatAdamW
+    from graphgps_amd.synthetic import model_batch
+    from graphgps_amd.train import EvalStep
+    dev = torch.device(DEV)
+    torch.manual_seed(0)
+    model = _pcqm_model(dev, 2, 0.0).eval()
+    es = EvalStep(model)
+    b = model_batch("pcqm4m", 32, seed=41).to(dev)
+    for _ in range(3):
+        loss0, pred0, _ = es.step_cached(b.clone())
+    assert es.replays == 2 and len(es.cache) == 1
+    opt = FlatAdamW(model.parameters(), lr=1e-3, weight_decay=0.0)          # moves the parameters
+    with torch.no_grad():
+        for p in model.parameters():
+            p.mul_(1.05)                                                     # ... and the new storage now differs from the old
+    loss1, pred1, _ = es.step_cached(b.clone())
+    want_loss, want_pred, _ = es.run_eager(b.clone())
+    torch.cuda.synchronize()
+    assert_close(pred1, want_pred, 1e-6, "prediction after the parameters moved")
+    assert float((pred1 - pred0).abs().max()) > 1e-4, "the perturbed weights did not change the prediction"
+    for _ in range(2):
+        loss2, pred2, _ = es.step_cached(b.clone())                          # captured again on the new addresses
+    assert_close(pred2, want_pred, 1e-6, "replayed prediction on the new addresses")
+    assert opt.arena.intact()
