@@ -23,6 +23,7 @@
 // Grouped, every workgroup gets an equal share (~R*tiles/256 chunk-tiles) of the whole list, so slices
 // are long (S = 2..4) and the partial traffic drops 4x.
 #include "gps_common.hpp"
+#include "col_tree.hpp"
 
 #include <algorithm>
 #include <cstdlib>
@@ -78,12 +79,15 @@ struct Problem {
   int64_t out_begin;  // first reduce-thread index of this problem (grouped reduce)
   const uint32_t* g_amax;   // fp16 form (k_wgrad_stream<true>): max|g| / max|x| words (csrc/gemm_panel.hip gps_absmax), or null
   const uint32_t* x_amax;
+  int tick_begin;     // k_wgrad_stream with Group::tick: first arrival counter of this problem (one per tile)
 };
 
 struct Group {
   Problem p[kMaxGroup];
   int n;
   int xcd_map;   // k_wgrad_stream: work items dealt to workgroups XCD by XCD (below)
+  unsigned* tick;  // k_wgrad_stream: per-tile arrival counters, zero at entry and at exit -- the LAST slice of a tile to
+                   // arrive sums the tile's partials itself and no k_wgrad_reduce follows (null: the two-launch form)
 };
 
 // One (tile, slice) work item of problem P.  SPLIT: contraction on the bf16 pipe via the exact
@@ -584,7 +588,9 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_stream(const Group G) {
 #pragma unroll
       for (int q = 0; q < 16; ++q) {
         const int row = m0 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh;
-        po[(int64_t)row * P.Nn + col] = F16 ? (sum[q] * ug) * ux : sum[q];
+        const float v = F16 ? (sum[q] * ug) * ux : sum[q];
+        if (G.tick) gps::tree::st_sc1(po + (int64_t)row * P.Nn + col, v);    // read by another workgroup of this launch
+        else po[(int64_t)row * P.Nn + col] = v;
       }
     }
   }
@@ -598,13 +604,53 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_stream(const Group G) {
       float a = 0.f;
 #pragma unroll
       for (int q = 0; q < 8; ++q) a += sc[q * 128 + t];
-      P.bias_part[(int64_t)slice * P.M + m0 + t] = a;
+      if (G.tick) gps::tree::st_sc1(P.bias_part + (int64_t)slice * P.M + m0 + t, a);
+      else P.bias_part[(int64_t)slice * P.M + m0 + t] = a;
     }
   }
+  if (!G.tick) return;
+  // ---- in-launch reduce (round 5): csrc/col_tree.hpp's arrival protocol, one counter per tile -----------------------
+  // The partial tile went out with write-through stores; every storing wave drains them, the workgroup takes a ticket,
+  // and the one that draws the last ticket of its tile re-reads all S partials (L2-bypassing loads: the other slices ran
+  // on other XCDs) in slice order -- the additions of k_wgrad_reduce in the same order, bit-identical -- and leaves the
+  // counter at zero for the next launch (eager or replayed).  The other workgroups are done.
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  int* flag = reinterpret_cast<int*>(lds);
+  unsigned* const tk = G.tick + P.tick_begin + tile;
+  if (t == 0) {
+    const unsigned a = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (a >= (unsigned)P.S) __builtin_trap();             // the counter was not zero at entry: fail loudly
+    *flag = a == (unsigned)(P.S - 1);
+  }
+  __syncthreads();
+  if (!*flag) return;                                     // workgroup-uniform
+  const int64_t total = (int64_t)P.M * P.Nn;
+  const int S = P.S;
+#pragma unroll 4
+  for (int k = 0; k < 64; ++k) {
+    const int e = t + 256 * k;
+    const int64_t idx = (int64_t)(m0 + (e >> 7)) * P.Nn + n0 + (e & 127);
+    float a = 0.f;
+#pragma unroll 4
+    for (int sl = 0; sl < S; ++sl) a += gps::tree::ld_sc1(P.part + (int64_t)sl * total + idx);
+    P.gw[idx] = a;
+  }
+  if (P.gb && tn == 0 && t < 128) {
+    float a = 0.f;
+#pragma unroll 4
+    for (int sl = 0; sl < S; ++sl) a += gps::tree::ld_sc1(P.bias_part + (int64_t)sl * P.M + m0 + t);
+    P.gb[m0 + t] = a;
+  }
+  if (t == 0) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// out[i] = sum_s part[s][i] in slice order (one float per thread: enough threads to pull the
-// S x M x Nn partials at bandwidth); bias likewise, by the first threads of each problem
+// out[i] = sum_s part[s][i] in slice order; bias likewise, by the first threads of each problem.  VEC = 4 (round 5): a
+// thread owns four neighbouring outputs and pulls each slice with one 16-byte load, all S of them independent -- the
+// one-float form moved the 16 MB of partials of a GPS block at 1.3 TB/s (12.7 us per launch, rocprofv3 round 5), a
+// quarter of the threads each with four times the bytes in flight is what the memory system wants.  Same additions in
+// the same order per output: bit-identical.
+template <int VEC>
 __global__ __launch_bounds__(256) void k_wgrad_reduce(const Group G) {
   const int64_t gi = blockIdx.x * (int64_t)blockDim.x + threadIdx.x;
   int pi = 0;
@@ -614,11 +660,23 @@ __global__ __launch_bounds__(256) void k_wgrad_reduce(const Group G) {
   const Problem& P = G.p[pi];
   const int64_t i = gi - P.out_begin;
   const int64_t total = (int64_t)P.M * P.Nn;
-  if (i < total) {
-    float a = 0.f;
+  if constexpr (VEC == 4) {
+    if (i * 4 < total) {
+      float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+      for (int s = 0; s < P.S; ++s) {
+        const float4 v = *reinterpret_cast<const float4*>(P.part + (int64_t)s * total + i * 4);
+        a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+      }
+      *reinterpret_cast<float4*>(P.gw + i * 4) = a;
+    }
+  } else {
+    if (i < total) {
+      float a = 0.f;
 #pragma unroll 4
-    for (int s = 0; s < P.S; ++s) a += P.part[(int64_t)s * total + i];
-    P.gw[i] = a;
+      for (int s = 0; s < P.S; ++s) a += P.part[(int64_t)s * total + i];
+      P.gw[i] = a;
+    }
   }
   if (P.gb && i < P.M) {
     float a = 0.f;
@@ -707,8 +765,8 @@ inline bool stream_ok(const Group& G) {
   return true;
 }
 
-int launch_group(Group& G, float* ws, hipStream_t s, const char* who) {
-  int blocks = 0;
+int launch_group(Group& G, float* ws, hipStream_t s, const char* who, unsigned* tick = nullptr, int tick_words = 0) {
+  int blocks = 0, tiles = 0;
   int64_t outs = 0;
   for (int i = 0; i < G.n; ++i) {
     Problem& p = G.p[i];
@@ -718,8 +776,22 @@ int launch_group(Group& G, float* ws, hipStream_t s, const char* who) {
     ws += problem_ws_floats(p);
     p.block_begin = blocks;
     blocks += p.S * p.tiles_m * p.tiles_n;
+    p.tick_begin = tiles;
+    tiles += p.tiles_m * p.tiles_n;
+  }
+  // the reduce takes four outputs per thread when every problem allows 16-byte accesses (always, for the GPS blocks)
+  static const bool vec_off = [] { const char* e = getenv("GPS_WGRAD_REDUCE_VEC"); return e && atoi(e) == 0; }();
+  bool vec = !vec_off;
+  for (int i = 0; i < G.n; ++i) {
+    const Problem& p = G.p[i];
+    vec = vec && ((int64_t)p.M * p.Nn) % 4 == 0 && p.Nn >= 4 && reinterpret_cast<uintptr_t>(p.part) % 16 == 0 &&
+          reinterpret_cast<uintptr_t>(p.gw) % 16 == 0;
+  }
+  for (int i = 0; i < G.n; ++i) {
+    Problem& p = G.p[i];
     p.out_begin = outs;
-    outs += ((int64_t)p.M * p.Nn + 255) / 256 * 256;   // whole reduce blocks per problem
+    const int64_t threads = vec ? (int64_t)p.M * p.Nn / 4 : (int64_t)p.M * p.Nn;
+    outs += (threads + 255) / 256 * 256;               // whole reduce blocks per problem
   }
   // GPS_WGRAD_FP32_MFMA=1 keeps the contraction on the fp32-input MFMA (v_mfma_f32_32x32x2_f32)
   static const bool fp32_pipe = [] { const char* e = getenv("GPS_WGRAD_FP32_MFMA"); return e && atoi(e) != 0; }();
@@ -731,15 +803,18 @@ int launch_group(Group& G, float* ws, hipStream_t s, const char* who) {
     GPS_REQUIRE(attr == hipSuccess && attr16 == hipSuccess, "%s: cannot reserve %d bytes of LDS", who, WS_LDS);
     static const int xcd_map = [] { const char* e = getenv("GPS_WGRAD_XCD_MAP"); return e && *e ? atoi(e) : 1; }();
     G.xcd_map = xcd_map;
+    G.tick = tick && tiles <= tick_words ? tick : nullptr;   // more tiles than counters: the two-launch form
     bool f16 = true;                 // every problem of the launch carries its operands' max|.| words
     for (int i = 0; i < G.n; ++i) f16 = f16 && G.p[i].g_amax && G.p[i].x_amax;
     if (f16) k_wgrad_stream<true><<<(unsigned)blocks, 256, WS_LDS, s>>>(G);
     else k_wgrad_stream<false><<<(unsigned)blocks, 256, WS_LDS, s>>>(G);
+    if (G.tick) return gps::launch_status(who);
   } else if (fp32_pipe)
     k_wgrad<false><<<(unsigned)blocks, 256, 0, s>>>(G);
   else
     k_wgrad<true><<<(unsigned)blocks, 256, 0, s>>>(G);
-  k_wgrad_reduce<<<gps::grid_for(outs, 256), 256, 0, s>>>(G);
+  if (vec) k_wgrad_reduce<4><<<gps::grid_for(outs, 256), 256, 0, s>>>(G);
+  else k_wgrad_reduce<1><<<gps::grid_for(outs, 256), 256, 0, s>>>(G);
   return gps::launch_status(who);
 }
 
@@ -800,6 +875,11 @@ size_t gps_wgrad_grouped_workspace_floats(int n, const gps_wgrad_problem* probs)
 }
 
 int gps_wgrad_grouped(int n, const gps_wgrad_problem* probs, float* ws, gps_stream_t stream) {
+  return gps_wgrad_grouped_sync(n, probs, ws, nullptr, 0, stream);
+}
+
+int gps_wgrad_grouped_sync(int n, const gps_wgrad_problem* probs, float* ws, uint32_t* sync, int sync_words,
+                           gps_stream_t stream) {
   GPS_REQUIRE(n >= 1 && n <= kMaxGroup && probs, "gps_wgrad_grouped: n=%d (1..%d)", n, kMaxGroup);
   GPS_REQUIRE(ws && reinterpret_cast<uintptr_t>(ws) % 16 == 0,
               "gps_wgrad_grouped: workspace null/misaligned");
@@ -823,7 +903,8 @@ int gps_wgrad_grouped(int n, const gps_wgrad_problem* probs, float* ws, gps_stre
     p.g_amax = q.g_amax; p.x_amax = q.x_amax;
     plan_slices(p, cpb, quantum);
   }
-  return launch_group(G, ws, gps::as_stream(stream), "gps_wgrad_grouped");
+  GPS_REQUIRE(sync_words >= 0 && (sync || sync_words == 0), "gps_wgrad_grouped_sync: %d counter words at a null pointer", sync_words);
+  return launch_group(G, ws, gps::as_stream(stream), "gps_wgrad_grouped", sync, sync_words);
 }
 
 }  // extern "C"

@@ -255,6 +255,12 @@ def _block_records(dev):
 
 # launch sites of one layer that own arrival counters (norm.SyncArena.site): sites that may be in flight together differ
 _S_GG, _S_AO, _S_XE, _S_MID, _S_Z2, _S_B1, _S_B3, _S_B4 = range(8)
+_S_WG = 8       # the grouped weight-gradient launch: one counter per output tile, sites 8.. (SyncArena.tail)
+# GPS_WGRAD_FOLD=1: the cross-slice sum of the weight gradients inside the launch, by the last slice to arrive at a tile
+# (csrc/wgrad.hip, gps_wgrad_grouped_sync) instead of the reduce launch.  Bit-identical, and measured SLOWER (round 5,
+# profiles/r05_ab_wgrad_fold.txt: 9.05 vs 8.80 ms per step): one workgroup pulling the S x 64 KB of its tile is bound by
+# its own load latency, the reduce launch spreads the same bytes over the whole chip.  Off by default.
+_WGRAD_FOLD = _os.environ.get("GPS_WGRAD_FOLD", "0") == "1"
 
 
 class _K:
@@ -324,13 +330,14 @@ def _accumulating(params) -> bool:
     return False
 
 
-def _grouped_param_grads(L, pairs, params=(), targets=None, words=None):
+def _grouped_param_grads(L, pairs, params=(), targets=None, words=None, sync=None):
     """[(g, x), ...] -> [(g^T x, colsum(g)), ...]: all weight/bias gradients of the block in ONE
     split-K MFMA launch + one reduce launch (csrc/wgrad.hip grouped form) on the side stream
     (main stream when ``params`` already hold gradients: see ``_accumulating``).
     ``targets`` = [(weight, bias), ...] the (stacked) parameters the results belong to: when they live in an optimizer
     arena and nothing is being accumulated the kernel writes straight into their gradient slots (optim.grad_slot).
-    ``words`` = [(max|g| record, max|x| record), ...] (int32 [512] tensors, gemm.absmax): the fp16 form of the contraction."""
+    ``words`` = [(max|g| record, max|x| record), ...] (int32 [512] tensors, gemm.absmax): the fp16 form of the contraction.
+    ``sync`` = the owner's norm.SyncArena: the reduce folded into the launch (arrival counters from site _S_WG on)."""
     dev = pairs[0][0].device
     n = len(pairs)
     direct = targets is not None and not _accumulating(params)
@@ -357,7 +364,11 @@ def _grouped_param_grads(L, pairs, params=(), targets=None, words=None):
                 q.g_amax, q.x_amax = words[i][0].data_ptr(), words[i][1].data_ptr()
             outs.append((g_w, g_b))
         ws = _E(max(L.gps_wgrad_grouped_workspace_floats(n, probs), 4), dtype=torch.float32, device=dev)
-        check(L.gps_wgrad_grouped(n, probs, ptr(ws), current_stream(dev)), "gps_wgrad_grouped")
+        if sync is not None and _WGRAD_FOLD:
+            tick, tick_words = sync.tail(_S_WG)
+            check(L.gps_wgrad_grouped_sync(n, probs, ptr(ws), tick, tick_words, current_stream(dev)), "gps_wgrad_grouped_sync")
+        else:
+            check(L.gps_wgrad_grouped(n, probs, ptr(ws), current_stream(dev)), "gps_wgrad_grouped")
         return outs
 
     if not _SIDE_ENABLED or _accumulating(params):
@@ -786,7 +797,7 @@ class _GPSBlock(torch.autograd.Function):
             targets = [(wcat, bcat), (_W(R.C), _B(R.C)), (_W(R.out_proj), _B(R.out_proj)),
                        (_W(R.ff1), _B(R.ff1)), (_W(R.ff2), _B(R.ff2))]
             ((g_wcat, g_bcat), (g_wc, g_bc), (g_wo, g_bo), (g_w1, g_b1), (g_w2, g_b2)) = \
-                _grouped_param_grads(L, pairs, leaves, targets, words)
+                _grouped_param_grads(L, pairs, leaves, targets, words, sync)
         else:
             ((g_wcat, g_bcat), (g_wc, g_bc), (g_wo, g_bo), (g_w1, g_b1), (g_w2, g_b2)) = \
                 [_K.param_grads(L, g, a, leaves) for g, a in pairs]
@@ -936,7 +947,7 @@ class _GPSBlockGINE(torch.autograd.Function):
         pairs = [(g_qkv, x), (g_ao, o), (g_g2, g1r), (g_g1, agg), (g_f1, h), (g_f2, t)]
         leaves = block_params_gine(layer)
         if _GROUPED_WGRAD:
-            grads = _grouped_param_grads(L, pairs, leaves)
+            grads = _grouped_param_grads(L, pairs, leaves, sync=sync)
         else:
             grads = [_K.param_grads(L, g, a, leaves) for g, a in pairs]
         (g_wi, g_bi), (g_wo, g_bo), (g_wl2, g_bl2), (g_wl1, g_bl1), (g_w1, g_b1), (g_w2, g_b2) = grads

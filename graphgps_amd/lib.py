@@ -15,7 +15,7 @@ import torch  # noqa: F401  -- must be imported first: it maps the HIP runtime o
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GPS_HIP_LIB: an alternative build of the same ABI (A/B timing of kernel variants in one process launch each)
 LIB_PATH = os.environ.get("GPS_HIP_LIB") or os.path.join(_HERE, "csrc", "libgps_hip.so")
-ABI_VERSION = 7
+ABI_VERSION = 8
 
 _lib: Optional[ctypes.CDLL] = None
 
@@ -68,6 +68,7 @@ _SIGNATURES = {
                             _P]),
     "gps_wgrad_grouped_workspace_floats": (c_size_t, [c_int, _P]),
     "gps_wgrad_grouped": (c_int, [c_int, _P, _P, _P]),
+    "gps_wgrad_grouped_sync": (c_int, [c_int, _P, _P, _P, c_int, _P]),
     "gps_norm_tree_floats": (c_size_t, [c_int64, c_int]),
     "gps_norm_sync_words": (c_int, []),
     "gps_sync_reset": (c_int, [_P, c_size_t, _P]),

@@ -115,6 +115,12 @@ class SyncArena:
             raise _lib.GpsHipError(f"SyncArena: a launch needs {need_words} counter words, a site holds {self.words}")
         return self.buf.data_ptr() + 4 * k * self.words
 
+    def tail(self, k: int):
+        """(address, words) of everything from site k to the end of the arena: for the one launch whose counter need
+        grows with the problem (csrc/wgrad.hip: one counter per output tile); no site above k may be in use."""
+        assert 0 <= k < N_SITES
+        return self.buf.data_ptr() + 4 * k * self.words, (N_SITES - k) * self.words
+
     def nonzero_words(self) -> int:
         """Number of non-zero counters (a host read: debugging / tests).  Between launches it must be 0."""
         L = _lib.load()

@@ -453,6 +453,15 @@ typedef struct gps_wgrad_problem {
 } gps_wgrad_problem;
 size_t gps_wgrad_grouped_workspace_floats(int n, const gps_wgrad_problem* probs);
 int gps_wgrad_grouped(int n, const gps_wgrad_problem* probs, float* ws, gps_stream_t stream);
+/* ABI v8: the same launch with the cross-slice sum folded in.  `sync`: >= one zeroed uint32 counter per 128 x 128 output
+ * tile of the whole list (sum over problems of ceil(M/128) * ceil(Nn/128)), owned by the caller, left at zero by every
+ * launch (the contract of gps_norm_*'s sync words: zero once, never touched by the host again; eager calls and hipGraph
+ * replays share them; launches that can be in flight together need different words).  The slice that arrives LAST at
+ * a tile sums the tile's partials in slice order -- the additions of the reduce launch, bit-identical -- so the list
+ * costs one launch.  Where the streaming kernel does not apply (shapes, GPS_WGRAD_STREAM=0) or sync_words is too
+ * small, this IS gps_wgrad_grouped. */
+int gps_wgrad_grouped_sync(int n, const gps_wgrad_problem* probs, float* ws, uint32_t* sync, int sync_words,
+                           gps_stream_t stream);
 /* gps_wgrad with the operands' max|.| words: the fp16 form where the streaming kernel applies (else as gps_wgrad) */
 int gps_wgrad16(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t R, int M, int Nn, const uint32_t* g_amax,
                 const uint32_t* x_amax, float* gw, float* gb, float* ws, gps_stream_t stream);

@@ -1005,6 +1005,22 @@ def test_dma_kernels_race_screen():
             else:
                 for i, ((gw, gb), (fw, fb)) in enumerate(zip(cur, firsts)):
                     assert torch.equal(gw, fw) and torch.equal(gb, fb), f"streaming wgrad (f16={f16}) problem {i}: run {it} differs"
+        # round 5: the cross-slice sum folded into the launch (gps_wgrad_grouped_sync) -- the last slice to arrive at a
+        # tile adds the tile's partials in slice order: bit-identical to the two-launch form however the arrivals fall, the
+        # counters back at zero after every launch; too few counters = the two-launch form
+        tiles = sum(-(-g.shape[1] // 128) * -(-x.shape[1] // 128) for g, x in pairs)
+        tick = torch.zeros(tiles + 3, dtype=torch.int32, device=dev)
+        for it in range(40):
+            if it % 3 == 0:
+                noise.normal_()
+            for gw, gb in outs:
+                gw.fill_(float("nan")); gb.fill_(float("nan"))
+            words_given = tiles - 1 if it == 39 else tick.numel()
+            check(L.gps_wgrad_grouped_sync(len(pairs), probs, ptr(ws), tick.data_ptr(), words_given, current_stream(dev)),
+                  "gps_wgrad_grouped_sync")
+            for i, ((gw, gb), (fw, fb)) in enumerate(zip(outs, firsts)):
+                assert torch.equal(gw, fw) and torch.equal(gb, fb), f"folded wgrad (f16={f16}) problem {i}: run {it} differs"
+            assert int(tick.abs().sum()) == 0, "arrival counters not left at zero"
 
 
 @pytest.mark.parametrize("n,V,d,hub", [(25000, 10030, 256, 0.5), (25000, 10030, 256, 0.0), (77000, 2, 256, 0.0),
