@@ -17,6 +17,7 @@ counts travelling to the device as a tensor of the batch (``gps_counts``).
 """
 from __future__ import annotations
 
+import ctypes
 import queue
 import threading
 from collections import deque
@@ -53,6 +54,64 @@ def _short_switch_interval(enter: bool, interval: float = 2e-4) -> None:
             if _SWITCH["users"] == 0 and _SWITCH["saved"] is not None:
                 sys.setswitchinterval(_SWITCH["saved"])
                 _SWITCH["saved"] = None
+
+
+def _openmp_runtimes():
+    """The OpenMP runtime libraries loaded into this process (torch's intra-op pool lives in one of them), as ctypes
+    handles -- found in /proc/self/maps, loaded once."""
+    libs = _openmp_runtimes.__dict__.get("libs")
+    if libs is None:
+        import re
+        paths = set()
+        try:
+            with open("/proc/self/maps") as fh:
+                for line in fh:
+                    m = re.search(r"(/\S*lib(?:g|i)?omp[^/\s]*\.so[^/\s]*)", line)
+                    if m:
+                        paths.add(m.group(1))
+        except OSError:
+            pass
+        libs = []
+        for path in sorted(paths):
+            try:
+                lib = ctypes.CDLL(path)
+                lib.omp_get_max_threads.restype = ctypes.c_int
+                lib.omp_set_num_threads.argtypes = [ctypes.c_int]
+                libs.append(lib)
+            except (OSError, AttributeError):
+                pass
+        _openmp_runtimes.libs = libs
+    return libs
+
+
+class _SerialHostOps:
+    """While active, torch's CPU operators run single-threaded ON THE CALLING THREAD ONLY (OpenMP's thread count is a
+    per-thread setting; ``torch.set_num_threads`` would change the whole process).  The staging side of the loader is a
+    few dozen host operators on ~1 MB tensors (``cat``, ``new_zeros``, copies); each one above 32k elements fans out
+    over the intra-op pool, whose workers then spin on every core for a while.  Alone that is harmless (0.4 ms per
+    batch); beside the thread that launches the steps it is not: measured (round 5, tools/loader_stage_trace.py, 24
+    pcqm4m batches through DeviceLoader + step_cached) the padding took 10-11 ms per batch and the loader-fed step
+    17.1 ms, against 0.3 ms and 9.6 ms with these operators kept on one thread.  An optimisation: silently a no-op when
+    no OpenMP runtime is found."""
+
+    def __enter__(self):
+        torch.get_num_threads()             # ATen's per-thread lazy initialisation runs first (it sets the count itself)
+        self.prev = []
+        for lib in _openmp_runtimes():
+            try:
+                self.prev.append((lib, int(lib.omp_get_max_threads())))
+                lib.omp_set_num_threads(1)
+            except Exception:
+                pass
+        return self
+
+    def __exit__(self, *exc):
+        for lib, n in self.prev:
+            try:
+                lib.omp_set_num_threads(max(n, 1))
+            except Exception:
+                pass
+        return False
 
 
 _NODE_KEYS = ("x", "batch", "node_depth", "node_is_attributed", "EigVecs", "EigVals")
@@ -231,6 +290,51 @@ class BucketPadding:
         return out
 
 
+_PINNED_RING = os.environ.get("GPS_LOADER_PINNED_RING", "1") != "0"      # 0: ``tensor.pin_memory()`` per tensor (A/B)
+
+
+class _PinnedRing:
+    """Pinned staging buffers that are REUSED: ``slots`` slots, one per batch in flight, each with one pinned byte buffer
+    per tensor name (grown to the next power of two when a batch needs more), and the event behind the slot's last H2D
+    copies.  ``tensor.pin_memory()`` on the staging thread allocates pinned memory for every tensor of every batch; on
+    this runtime that allocation waits for the device (measured, round 5, tools/loader_stage_probe.py: the 24-batch
+    pcqm4m stream at 16.7 ms per step with the pinning on the staging thread against 9.7 with batches that arrive
+    pinned, although the pinning itself is 0.13 ms per batch when nothing else runs) -- the staged copy then no longer
+    overlaps the step it was meant to hide behind.  With the ring the steady state allocates nothing: a host memcpy into
+    the slot's buffer, the non-blocking copy out of it, and the slot is not written again before its event has completed."""
+
+    def __init__(self, slots: int):
+        self.slots = [{"bufs": {}, "ready": None} for _ in range(max(int(slots), 2))]
+        self.i = 0
+
+    def next_slot(self):
+        slot = self.slots[self.i % len(self.slots)]
+        self.i += 1
+        if slot["ready"] is not None:
+            slot["ready"].synchronize()     # the copies that read this slot's buffers are done (normally long ago)
+            slot["ready"] = None
+        return slot
+
+    @staticmethod
+    def stage(slot, key, v):
+        """``v`` (a host tensor) copied into the slot's pinned buffer for ``key``: a pinned tensor of v's shape / dtype."""
+        nbytes = v.numel() * v.element_size()
+        buf = slot["bufs"].get(key)
+        if buf is None or buf.numel() < nbytes:
+            cap = max(4096, 1 << max(nbytes - 1, 1).bit_length())
+            buf = slot["bufs"][key] = torch.empty(cap, dtype=torch.uint8, pin_memory=True)
+        out = buf[:nbytes].view(v.dtype).view(v.shape)
+        if nbytes and v.is_contiguous():
+            # one plain memcpy on THIS thread (ctypes drops the interpreter lock around it).  ``out.copy_(v)`` splits a
+            # copy of more than 32k elements over the intra-op thread pool, whose workers then spin on every core for a
+            # while: with the step being launched from the other thread that cost 7 ms per step (round 5,
+            # tools/loader_stage_trace.py: this copy 7.7 ms per batch under load, 0.1 ms alone)
+            ctypes.memmove(out.data_ptr(), v.data_ptr(), nbytes)
+        else:
+            out.copy_(v)
+        return out
+
+
 class DeviceLoader:
     """Iterate ``loader`` (host batches) and yield device batches with the graph index attached.
 
@@ -249,6 +353,7 @@ class DeviceLoader:
         self.depth = max(int(depth), 1)
         self.build_index = build_index
         self.background = _BACKGROUND_DEFAULT if background is None else bool(background)
+        self._rings = []                    # idle _PinnedRing objects (one is taken per iteration, handed back at its end)
 
     def __len__(self) -> int:
         return len(self.loader)
@@ -276,8 +381,9 @@ class DeviceLoader:
         import copy
         return copy.copy(batch)             # PyG Data implements __copy__ as a per-store shallow copy
 
-    def _stage(self, batch, copy_stream):
+    def _stage(self, batch, copy_stream, ring=None):
         dev = self.device
+        slot = ring.next_slot() if ring is not None else None
         already = bool((vars(batch).get("_gps_meta") or {}).get("padded"))     # padded by the DataLoader's collate
         batch = self.pad(batch) if self.pad is not None and not already else self._host_copy(batch)
         vars(batch).pop("_gps_index", None)
@@ -297,12 +403,14 @@ class DeviceLoader:
                 v = getattr(batch, k, None)
                 if torch.is_tensor(v) and v.device != dev:
                     if v.device.type == "cpu" and not v.is_pinned():
-                        v = v.pin_memory()
+                        v = _PinnedRing.stage(slot, k, v) if slot is not None else v.pin_memory()
                     setattr(batch, k, v.to(dev, non_blocking=True))
             if self.build_index and hasattr(batch, "edge_index"):
                 graph_index_of(batch)
             ready = torch.cuda.Event()
             ready.record(copy_stream)
+            if slot is not None:
+                slot["ready"] = ready
         return batch, ready
 
     @classmethod
@@ -328,9 +436,19 @@ class DeviceLoader:
                 yield batch.to(self.device) or batch
             return
         copy_stream = torch.cuda.Stream(device=self.device)
-        if self.background:
-            yield from self._iter_background(copy_stream)
-            return
+        ring = None
+        if _PINNED_RING:                    # depth staged + one being consumed + one being written
+            ring = self._rings.pop() if self._rings else _PinnedRing(self.depth + 2)
+        try:
+            if self.background:
+                yield from self._iter_background(copy_stream, ring)
+            else:
+                yield from self._iter_inline(copy_stream, ring)
+        finally:
+            if ring is not None and not getattr(ring, "abandoned", False):
+                self._rings.append(ring)
+
+    def _iter_inline(self, copy_stream, ring=None) -> Iterator:
         pending = deque()
         source = iter(self.loader)
 
@@ -340,7 +458,8 @@ class DeviceLoader:
                     host = next(source)
                 except StopIteration:
                     return
-                pending.append(self._stage(host, copy_stream))
+                with _SerialHostOps():
+                    pending.append(self._stage(host, copy_stream, ring))
 
         fill()
         while pending:
@@ -351,7 +470,7 @@ class DeviceLoader:
             self._hand_over(batch, stream)
             yield batch
 
-    def _iter_background(self, copy_stream) -> Iterator:
+    def _iter_background(self, copy_stream, ring=None) -> Iterator:
         """Staging on a worker thread, ``depth`` staged batches queued ahead of the consumer."""
         q: "queue.Queue" = queue.Queue(maxsize=self.depth)
         stop = threading.Event()
@@ -375,9 +494,10 @@ class DeviceLoader:
         def worker():
             try:
                 torch.cuda.set_device(self.device)
-                for host in source:
+                _SerialHostOps().__enter__()       # this thread's host operators stay on this thread (never undone: the
+                for host in source:                # setting is per thread and the thread ends with the iteration)
                     with STAGE_LOCK:
-                        item = self._stage(host, copy_stream)
+                        item = self._stage(host, copy_stream, ring)
                     if not put(item):
                         return
                 put(END)
@@ -418,6 +538,8 @@ class DeviceLoader:
                 except queue.Empty:
                     break
             th.join(timeout=5.0)
+            if th.is_alive() and ring is not None:
+                ring.abandoned = True          # a worker left behind may still write into it: never handed to another iteration
             close = getattr(source, "close", None) or getattr(source, "_shutdown_workers", None)
             if close is not None and not th.is_alive():
                 try:

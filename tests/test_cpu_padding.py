@@ -286,7 +286,7 @@ def test_background_loader_control_flow_without_a_gpu(monkeypatch):
     monkeypatch.setattr(L.DeviceLoader, "_hand_over", classmethod(lambda cls, b, s: None))
     staged = []
 
-    def stage(self, host, copy_stream):
+    def stage(self, host, copy_stream, ring=None):
         if host == "boom":
             raise RuntimeError("staging failed")
         staged.append((host, threading.current_thread().name))
@@ -325,6 +325,76 @@ def test_background_loader_control_flow_without_a_gpu(monkeypatch):
     with pytest.raises(RuntimeError, match="staging failed"):
         list(L.DeviceLoader(Source(["a", "boom", "c"]), "cuda:0", depth=2, background=True))
     assert L._SWITCH["users"] == 0 and sys.getswitchinterval() == pytest.approx(before, rel=0.05)
+
+
+def test_pinned_ring_reuses_buffers_and_keeps_contents(monkeypatch):
+    """loader._PinnedRing (round 5): the staging buffers are per (slot, tensor name), grown to a power of two, reused
+    for every later batch that fits, and a slot is not written before the event of its previous use was waited on.
+    Pinned allocation needs a device; here ``torch.empty`` is asked for pageable memory instead -- the logic under
+    test (views, growth, reuse, the wait) does not depend on where the bytes live."""
+    from graphgps_amd import loader as L
+    real_empty = torch.empty
+    allocs = []
+
+    def empty(*a, pin_memory=False, **kw):
+        allocs.append(a[0])
+        return real_empty(*a, **kw)
+    monkeypatch.setattr(torch, "empty", empty)
+    waited = []
+
+    class Ev:
+        def __init__(self, tag):
+            self.tag = tag
+
+        def synchronize(self):
+            waited.append(self.tag)
+
+    ring = L._PinnedRing(3)
+    gen = torch.Generator().manual_seed(3)
+    for i in range(9):
+        slot = ring.next_slot()
+        n = [700, 40, 1500, 0, 900, 1500, 2, 5000, 100][i]
+        src = {"x": torch.randint(0, 100, (n, 9), generator=gen),
+               "pe": torch.randn(n, 16, generator=gen)[:, ::2],                 # non-contiguous source
+               "ptr": torch.arange(n + 1, dtype=torch.int32)}
+        for k, v in src.items():
+            out = L._PinnedRing.stage(slot, k, v)
+            assert out.shape == v.shape and out.dtype == v.dtype and out.is_contiguous() and torch.equal(out, v)
+            assert out.untyped_storage().data_ptr() == slot["bufs"][k].untyped_storage().data_ptr()
+        slot["ready"] = Ev(i)
+    assert waited == [0, 1, 2, 3, 4, 5]                  # slot i % 3 waits for the batch that used it three batches ago
+    assert all(c & (c - 1) == 0 and c >= 4096 for c in allocs)
+    # 3 names x 3 slots first allocations + growth when a slot meets a bigger batch; never one allocation per tensor per batch
+    assert 9 <= len(allocs) <= 9 + 8
+
+
+def test_staging_thread_keeps_host_operators_on_one_thread():
+    """loader._SerialHostOps: the intra-op thread count drops to 1 on the thread that enters it and nowhere else, and
+    comes back on exit (the staging thread beside the launching thread: DESIGN section 6, round 5)."""
+    import threading
+    from graphgps_amd import loader as L
+    if not L._openmp_runtimes():
+        pytest.skip("no OpenMP runtime loaded")
+    before = torch.get_num_threads()
+    if before < 2:
+        pytest.skip("single-threaded torch build / machine")
+    seen = {}
+
+    def worker():
+        seen["worker_before"] = torch.get_num_threads()
+        L._SerialHostOps().__enter__()
+        seen["worker_inside"] = torch.get_num_threads()
+        x = torch.arange(1 << 18)
+        seen["sum"] = int(torch.cat([x, x.new_zeros(1 << 17)]).sum())       # operators above the parallel grain still work
+    th = threading.Thread(target=worker)
+    th.start()
+    th.join()
+    assert seen["worker_before"] == before and seen["worker_inside"] == 1
+    assert seen["sum"] == (1 << 18) * ((1 << 18) - 1) // 2
+    assert torch.get_num_threads() == before                                 # the main thread never noticed
+    with L._SerialHostOps():
+        assert torch.get_num_threads() == 1
+    assert torch.get_num_threads() == before
 
 
 class _PyGLikeBatch:

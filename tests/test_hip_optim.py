@@ -439,10 +439,20 @@ def test_device_loader_stages_batches_and_index_ahead_of_the_step(depth, backgro
     from graphgps_amd.ops import build_graph_index
     from graphgps_amd.synthetic import model_batch
     dev = torch.device("cuda:0")
-    host = [model_batch("zinc", 4 + 3 * i, seed=7 + i) for i in range(6)]
+    # sizes go up AND down: the pinned staging ring (loader._PinnedRing, round 5) re-uses a slot's buffers for every
+    # later batch that fits and grows them otherwise; the second pass runs on the ring the first pass handed back
+    host = [model_batch("zinc", n, seed=7 + i) for i, n in enumerate([4, 19, 7, 30, 5, 12, 30, 9, 2, 25, 6, 17])]
     keep = [b.clone() for b in host]
+    dl = DeviceLoader(host, dev, depth=depth, background=background)
+    for i, b in enumerate(dl):
+        torch.cuda._sleep(2_000_000)            # a slow consumer: the staging side runs ahead as far as the ring lets it
+        for k in keep[i].keys():
+            v = getattr(keep[i], k)
+            if torch.is_tensor(v):
+                assert torch.equal(getattr(b, k).cpu(), v), (i, k)
+    assert len(dl._rings) == 1
     sums = []
-    for i, b in enumerate(DeviceLoader(host, dev, depth=depth, background=background)):
+    for i, b in enumerate(dl):
         ref = keep[i]
         for k in ref.keys():
             v = getattr(ref, k)
