@@ -225,8 +225,10 @@ class BucketPadding:
         """``collate_fn`` followed by the padding: hand it to the ``DataLoader`` (``collate_fn=pad.collate(collater)``) so
         that the padding runs in the loader's WORKER PROCESSES and ``pin_memory=True`` pins the padded batch -- the staging
         thread of ``DeviceLoader`` is then left with the H2D copies and the index build (measured, 256-graph batches of
-        never-repeating shapes: 9.8 ms per step, against 16.0 ms with the padding on the staging thread, which shares the
-        interpreter lock with the thread that launches the steps, and 33.8 ms for the eager step on the un-padded stream).
+        never-repeating shapes, round 4: 9.8 ms per step, against 16.0 ms with the padding on the staging thread and 33.8
+        ms for the eager step on the un-padded stream.  Round 5 found what the staging-thread form was paying --
+        ``_SerialHostOps`` -- and it now runs at the same 9.3 ms; the worker-process form still takes the padding's
+        0.3 ms per batch off this process entirely).
         Fix ``node_step`` / ``edge_step`` in the constructor then: every worker process holds its own copy of this object,
         and steps chosen from 'the first batch' would be chosen per worker."""
         return _PaddedCollate(self, collate_fn)
@@ -296,12 +298,12 @@ _PINNED_RING = os.environ.get("GPS_LOADER_PINNED_RING", "1") != "0"      # 0: ``
 class _PinnedRing:
     """Pinned staging buffers that are REUSED: ``slots`` slots, one per batch in flight, each with one pinned byte buffer
     per tensor name (grown to the next power of two when a batch needs more), and the event behind the slot's last H2D
-    copies.  ``tensor.pin_memory()`` on the staging thread allocates pinned memory for every tensor of every batch; on
-    this runtime that allocation waits for the device (measured, round 5, tools/loader_stage_probe.py: the 24-batch
-    pcqm4m stream at 16.7 ms per step with the pinning on the staging thread against 9.7 with batches that arrive
-    pinned, although the pinning itself is 0.13 ms per batch when nothing else runs) -- the staged copy then no longer
-    overlaps the step it was meant to hide behind.  With the ring the steady state allocates nothing: a host memcpy into
-    the slot's buffer, the non-blocking copy out of it, and the slot is not written again before its event has completed."""
+    copies.  ``tensor.pin_memory()`` per tensor per batch is an allocation from the pinned-memory cache plus a copy that
+    fans out over the intra-op thread pool (see ``stage``): measured (round 5, tools/loader_stage_probe.py /
+    loader_stage_trace.py, profiles/r05_loader_staging_thread.txt) the 24-batch pcqm4m stream ran at 16.7 ms per step with
+    the pinning on the staging thread against 9.7 with batches that arrive pinned, although the pinning is 0.13 ms per
+    batch when nothing else runs.  With the ring the steady state allocates nothing: one plain memcpy into the slot's
+    buffer, the non-blocking copy out of it, and the slot is not written again before its event has completed (9.3 ms)."""
 
     def __init__(self, slots: int):
         self.slots = [{"bufs": {}, "ready": None} for _ in range(max(int(slots), 2))]
@@ -510,6 +512,8 @@ class DeviceLoader:
         # launching thread can sit for milliseconds behind the staging thread every time it comes back from a call
         # that released the lock (a graph replay, a synchronising copy): measured 10.8 ms per replay call against 7.0
         # without a busy staging thread.  A short interval while the loader is alive keeps the hand-over prompt.
+        # (Round 5: most of that measured gap was the intra-op pool's spinning workers, not the lock -- _SerialHostOps.
+        # The short interval stays: it costs nothing and the lock hand-over is still on the launching thread's path.)
         _short_switch_interval(True)
         th = threading.Thread(target=worker, name="gps-device-loader", daemon=True)
         th.start()
