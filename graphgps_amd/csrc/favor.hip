@@ -21,6 +21,8 @@
 // Forward: k-max (atomicMax, order-free) -> ctx/ksum per (graph, head, feature tile) -> output per
 // (16-query tile, head).  Backward: 4 passes (query side, context side, key side, key-max fix-up),
 // every cross-row reduction keyed so that it is summed in a fixed order: deterministic.
+// Round 5: key max, query side and key side also exist with the projection staged in LDS (LP = true, below) -- one workgroup
+// per CU walking the work items; bit-identical to the one-wavefront-per-tile form, chosen by the launch size.
 #include "gps_common.hpp"
 
 #include <cstdlib>
@@ -69,6 +71,15 @@ __device__ __forceinline__ void load_row16(const float* __restrict__ p, bool ok,
     dst[4 * s + 2] = v.z * sc; dst[4 * s + 3] = v.w * sc;
   }
 }
+// 16 contiguous floats of a row of the staged projection (csrc: stage_projection)
+__device__ __forceinline__ void lds_row16(const float* p, float (&dst)[KPL]) {
+  const float4* q = reinterpret_cast<const float4*>(p);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const float4 v = q[s];
+    dst[4 * s + 0] = v.x; dst[4 * s + 1] = v.y; dst[4 * s + 2] = v.z; dst[4 * s + 3] = v.w;
+  }
+}
 __device__ __forceinline__ int clampi(int v, int hi) { return v < hi ? v : hi; }
 __device__ __forceinline__ f32x4 mm_rows(const float (&a)[KPL], const float (&b)[KPL], f32x4 c) {
 #pragma unroll
@@ -91,16 +102,40 @@ __device__ __forceinline__ float dec_f32(uint32_t e) {
   return __uint_as_float((e & 0x80000000u) ? (e & 0x7FFFFFFFu) : ~e);
 }
 
+// ---- round 5: the projection staged in LDS (LP = true) ------------------------------------------------------------------
+// The four per-tile kernels (key max, output, query side and key side of the backward) contract every 16-row tile with the
+// whole projection P [m, 64] -- 70 KB that every wavefront pulled through L2 once or twice per tile (6,400 tiles at code2
+// sizes: 0.9-1.3 GB per launch), in a chain load -> 16-step contraction -> exp -> contraction per feature tile.  With LP the
+// launch is ONE workgroup per CU (12-16 wavefronts) that copies P into LDS once -- rows past m zero, row pitch 68 floats:
+// conflict-free both for the 16-floats-of-a-row reads (lane i: row i, pitch 272 B = 17 x 16 B) and for the one-float-per-
+// lane column reads (rows 4 grp + r: 68 x 4 = 16 banks apart) -- and then walks the work items, wavefront w taking items
+// w, w + W, w + 2 W, ...  Same loads of everything else, same arithmetic in the same order: bit-identical results.
+constexpr int PP = 68;                          // LDS row pitch of the staged projection (floats)
+constexpr int P_LDS_BYTES = 16 * MT * PP * 4;   // 73,984
+// threads of the one-workgroup-per-CU launches: what each kernel's registers allow per SIMD (key max 4 wavefronts; query
+// side 1 at 373 registers -- pinned to 2 per SIMD it spills and runs the same, 253 vs 259 us; key side 3 at 137).  The
+// OUTPUT kernel is not launched in this form: its item loop needs 333 registers, one wavefront per SIMD instead of two,
+// and it ran at 232 us against 149 (profiles/r05_favor_lds_projection.txt) -- the template parameter stays for the record.
+constexpr int FM_THREADS = 1024, FO_THREADS = 256, FQ_THREADS = 256, FK_THREADS = 768;
+__device__ __forceinline__ void stage_projection(float* __restrict__ lp, const float* __restrict__ P, int m) {
+  for (int idx = threadIdx.x; idx < 16 * MT * (DH / 4); idx += blockDim.x) {
+    const int row = idx / (DH / 4), c4 = idx % (DH / 4);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < m) v = reinterpret_cast<const float4*>(P + (int64_t)row * DH)[c4];
+    *reinterpret_cast<float4*>(lp + row * PP + 4 * c4) = v;
+  }
+  __syncthreads();
+}
+
 struct Seg {
   int g, h, row0, n0, n1, i, grp;
   bool valid;
 };
 __device__ __forceinline__ Seg tile_work(const int32_t* ptr, const int32_t* tile_graph,
-                                         const int32_t* tile_row0, int64_t n_work, int H) {
+                                         const int32_t* tile_row0, int64_t n_work, int H, int64_t w) {
   Seg s;
   s.valid = false;
   const int lane = threadIdx.x & 63;
-  const int64_t w = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
   s.i = lane & 15;
   s.grp = lane >> 4;
   if (w >= n_work) return s;
@@ -124,13 +159,26 @@ __device__ __forceinline__ float key_max_M(const unsigned long long* kmax, int g
 // ---------------------------------------------------------------------------------------------
 // F1: per (key tile, head): max over (key, feature) of dd_k, with its position, via atomicMax.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_favor_kmax(
+template <bool LP>
+__global__ __launch_bounds__(LP ? FM_THREADS : 256) void k_favor_kmax(
     const float* __restrict__ qkv, int64_t ld, const float* __restrict__ P, int m, float c,
     const int32_t* __restrict__ ptr, const int32_t* __restrict__ tile_graph,
     const int32_t* __restrict__ tile_row0, int64_t n_work, int H,
     unsigned long long* __restrict__ kmax) {
-  const Seg s = tile_work(ptr, tile_graph, tile_row0, n_work, H);
-  if (!s.valid) return;
+  extern __shared__ __attribute__((aligned(16))) float lds_proj[];
+  const float* Pp = P;
+  if constexpr (LP) {
+    stage_projection(lds_proj, P, m);
+    Pp = lds_proj;
+  }
+  constexpr int pp = LP ? PP : DH;
+  const int wpb = blockDim.x >> 6;
+  for (int64_t w = blockIdx.x * (int64_t)wpb + (threadIdx.x >> 6); w < n_work; w = LP ? w + (int64_t)gridDim.x * wpb : n_work) {
+  // (LP: the staged projection is the same for every work item -- without this the compiler hoists its reads out of the
+  // loop, i.e. tries to keep all of P in registers.  !LP: the launch has one wavefront per item, the loop runs once.)
+  if constexpr (LP) asm volatile("" ::: "memory");
+  const Seg s = tile_work(ptr, tile_graph, tile_row0, n_work, H, w);
+  if (!s.valid) continue;
   const int inner = H * DH;
   const int krow = s.row0 + s.i;
   float kv[KPL];
@@ -140,7 +188,7 @@ __global__ __launch_bounds__(256) void k_favor_kmax(
   for (int mt = 0; mt < MT; ++mt) {
     const int prow = mt * 16 + s.i;
     float pv[KPL];
-    load_row16(P + (int64_t)clampi(prow, m - 1) * DH + 16 * s.grp, prow < m, 1.0f, pv);
+    load_row16(Pp + clampi(prow, m - 1) * pp + 16 * s.grp, prow < m, 1.0f, pv);
     const f32x4 dd = mm_rows(pv, kv, zero4());  // [feature 4g+r][key l&15]
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -158,6 +206,7 @@ __global__ __launch_bounds__(256) void k_favor_kmax(
     key = other > key ? other : key;
   }
   if ((threadIdx.x & 63) == 0) atomicMax(&kmax[s.g * H + s.h], key);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -263,20 +312,40 @@ __global__ __launch_bounds__(256) void k_favor_sum_parts(const float* __restrict
 }
 
 // dd_q^T tiles [feature 4g+r + 16mt][query l&15] and phi_q for one 16-query tile
+template <int PITCH>
 __device__ __forceinline__ void query_features(const float (&qv)[KPL], const float* __restrict__ P,
                                                int m, int i, int grp, float (&dd)[MT][4], float& mq,
                                                bool have_mq) {
   float mx = -INFINITY;
+  if constexpr (PITCH == PP) {
+    // staged projection: rows past m are zero (no clamp, no select); the reads of tile mt + 1 are issued in front of the
+    // contraction of tile mt and nothing moves across the fence -- left alone the scheduler hoists all 68 reads to the top
+    // (272 registers of projection rows)
+    float pv[2][KPL];
+    lds_row16(P + i * PP + 16 * grp, pv[0]);
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) {
-    const int prow = mt * 16 + i;
-    float pv[KPL];
-    load_row16(P + (int64_t)clampi(prow, m - 1) * DH + 16 * grp, prow < m, 1.0f, pv);
-    const f32x4 t = mm_rows(pv, qv, zero4());
+    for (int mt = 0; mt < MT; ++mt) {
+      if (mt + 1 < MT) lds_row16(P + ((mt + 1) * 16 + i) * PP + 16 * grp, pv[(mt + 1) & 1]);
+      const f32x4 t = mm_rows(pv[mt & 1], qv, zero4());
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      dd[mt][r] = t[r];
-      if (mt * 16 + 4 * grp + r < m) mx = fmaxf(mx, t[r]);
+      for (int r = 0; r < 4; ++r) {
+        dd[mt][r] = t[r];
+        if (mt * 16 + 4 * grp + r < m) mx = fmaxf(mx, t[r]);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  } else {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      const int prow = mt * 16 + i;
+      float pv[KPL];
+      load_row16(P + clampi(prow, m - 1) * PITCH + 16 * grp, prow < m, 1.0f, pv);
+      const f32x4 t = mm_rows(pv, qv, zero4());
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        dd[mt][r] = t[r];
+        if (mt * 16 + 4 * grp + r < m) mx = fmaxf(mx, t[r]);
+      }
     }
   }
   if (!have_mq) mq = group_max(mx);
@@ -285,14 +354,27 @@ __device__ __forceinline__ void query_features(const float (&qv)[KPL], const flo
 // ---------------------------------------------------------------------------------------------
 // F3: per (query tile, head): out = (phi_q ctx) / (phi_q . ksum); saves mq (row max) and D.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_favor_out(
+template <bool LP>
+__global__ __launch_bounds__(LP ? FO_THREADS : 256) void k_favor_out(
     const float* __restrict__ qkv, int64_t ld, const float* __restrict__ P, int m, float c,
     float ratio, const int32_t* __restrict__ ptr, const int32_t* __restrict__ tile_graph,
     const int32_t* __restrict__ tile_row0, int64_t n_work, int64_t N, int H,
     const float* __restrict__ ctx, const float* __restrict__ ksum, float* __restrict__ out,
     float* __restrict__ mq_out, float* __restrict__ D_out) {
-  const Seg s = tile_work(ptr, tile_graph, tile_row0, n_work, H);
-  if (!s.valid) return;
+  extern __shared__ __attribute__((aligned(16))) float lds_proj[];
+  const float* Pp = P;
+  if constexpr (LP) {
+    stage_projection(lds_proj, P, m);
+    Pp = lds_proj;
+  }
+  constexpr int pp = LP ? PP : DH;
+  const int wpb = blockDim.x >> 6;
+  for (int64_t w = blockIdx.x * (int64_t)wpb + (threadIdx.x >> 6); w < n_work; w = LP ? w + (int64_t)gridDim.x * wpb : n_work) {
+  // (LP: the staged projection is the same for every work item -- without this the compiler hoists its reads out of the
+  // loop, i.e. tries to keep all of P in registers.  !LP: the launch has one wavefront per item, the loop runs once.)
+  if constexpr (LP) asm volatile("" ::: "memory");
+  const Seg s = tile_work(ptr, tile_graph, tile_row0, n_work, H, w);
+  if (!s.valid) continue;
   const int inner = H * DH;
   const int gh = s.g * H + s.h;
   const int qrow = s.row0 + s.i;
@@ -302,7 +384,7 @@ __global__ __launch_bounds__(256) void k_favor_out(
   const float half_nrm = 0.5f * group_sum(sumsq16(qv));
   float dd[MT][4];
   float mq;
-  query_features(qv, P, m, s.i, s.grp, dd, mq, false);
+  query_features<pp>(qv, Pp, m, s.i, s.grp, dd, mq, false);
   float dpart = 0.0f;
   f32x4 acc[4];
 #pragma unroll
@@ -340,6 +422,7 @@ __global__ __launch_bounds__(256) void k_favor_out(
       D_out[(int64_t)s.h * N + qrow] = D;
     }
   }
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -369,15 +452,28 @@ __global__ void k_favor_bwd_gd(const float* __restrict__ g_out, const float* __r
 // ---------------------------------------------------------------------------------------------
 // B1: per (query tile, head): g_q
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_favor_bwd_q(
+template <bool LP>
+__global__ __launch_bounds__(LP ? FQ_THREADS : 256) void k_favor_bwd_q(
     const float* __restrict__ g_out, const float* __restrict__ qkv, int64_t ld,
     const float* __restrict__ P, int m, float c, float ratio, const int32_t* __restrict__ ptr,
     const int32_t* __restrict__ tile_graph, const int32_t* __restrict__ tile_row0, int64_t n_work,
     int64_t N, int H, const float* __restrict__ ctx, const float* __restrict__ ksum,
     const float* __restrict__ mq_in, const float* __restrict__ D_in, const float* __restrict__ gD_in,
     float* __restrict__ d_qkv, int64_t ldg) {
-  const Seg s = tile_work(ptr, tile_graph, tile_row0, n_work, H);
-  if (!s.valid) return;
+  extern __shared__ __attribute__((aligned(16))) float lds_proj[];
+  const float* Pp = P;
+  if constexpr (LP) {
+    stage_projection(lds_proj, P, m);
+    Pp = lds_proj;
+  }
+  constexpr int pp = LP ? PP : DH;
+  const int wpb = blockDim.x >> 6;
+  for (int64_t w = blockIdx.x * (int64_t)wpb + (threadIdx.x >> 6); w < n_work; w = LP ? w + (int64_t)gridDim.x * wpb : n_work) {
+  // (LP: the staged projection is the same for every work item -- without this the compiler hoists its reads out of the
+  // loop, i.e. tries to keep all of P in registers.  !LP: the launch has one wavefront per item, the loop runs once.)
+  if constexpr (LP) asm volatile("" ::: "memory");
+  const Seg s = tile_work(ptr, tile_graph, tile_row0, n_work, H, w);
+  if (!s.valid) continue;
   const int inner = H * DH;
   const int gh = s.g * H + s.h;
   const int qrow = s.row0 + s.i;
@@ -392,7 +488,7 @@ __global__ __launch_bounds__(256) void k_favor_bwd_q(
   const float gDq = q_ok ? gD_l : 0.0f;
   load_row16(g_out + (int64_t)qrc * inner + s.h * DH + 16 * s.grp, q_ok, 1.0f / Dq, gn);  // g_num
   float dd[MT][4];
-  query_features(qv, P, m, s.i, s.grp, dd, mq, true);
+  query_features<pp>(qv, Pp, m, s.i, s.grp, dd, mq, true);
   const float* cbase = ctx + (int64_t)gh * 272 * DH;
   const float* kbase = ksum + (int64_t)gh * 272;
   float s1 = 0.0f;
@@ -429,7 +525,7 @@ __global__ __launch_bounds__(256) void k_favor_bwd_q(
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int f = mt * 16 + 4 * s.grp + r;
-        const float pv = P[(int64_t)clampi(f, m - 1) * DH + dt * 16 + s.i];      // (gA = 0 past m)
+        const float pv = Pp[clampi(f, m - 1) * pp + dt * 16 + s.i];      // (gA = 0 past m)
         acc[dt] = mfma16(pv, gA[mt][r], acc[dt]);   // g_q^T[dh 4g+r'][query]
       }
   }
@@ -442,9 +538,10 @@ __global__ __launch_bounds__(256) void k_favor_bwd_q(
       const int col = dt * 16 + 4 * s.grp;
       const float4 qq = *reinterpret_cast<const float4*>(qsrc + col);
       *reinterpret_cast<float4*>(o + col) =
-          make_float4(c * acc[dt][0] + k2 * qq.x, c * acc[dt][1] + k2 * qq.y,
-                      c * acc[dt][2] + k2 * qq.z, c * acc[dt][3] + k2 * qq.w);
+          make_float4(fmaf(k2, qq.x, c * acc[dt][0]), fmaf(k2, qq.y, c * acc[dt][1]),      // (explicit: left to the
+                      fmaf(k2, qq.z, c * acc[dt][2]), fmaf(k2, qq.w, c * acc[dt][3]));     // compiler, LP / !LP contracted differently)
     }
+  }
   }
 }
 
@@ -522,18 +619,30 @@ __global__ __launch_bounds__(256) void k_favor_bwd_ctx(
 // ---------------------------------------------------------------------------------------------
 // B3: per (key tile, head): g_k (without the key-max term), g_v, and this tile's share of g_M
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_favor_bwd_k(
+template <bool LP>
+__global__ __launch_bounds__(LP ? FK_THREADS : 256) void k_favor_bwd_k(
     const float* __restrict__ qkv, int64_t ld, const float* __restrict__ P, int m, float c,
     float ratio, const int32_t* __restrict__ ptr, const int32_t* __restrict__ tile_graph,
     const int32_t* __restrict__ tile_row0, int64_t n_work, const int32_t* __restrict__ nmax_dev,
     int H, const unsigned long long* __restrict__ kmax, const float* __restrict__ g_ctx,
     const float* __restrict__ g_ksum, float* __restrict__ d_qkv, int64_t ldg,
     float* __restrict__ gM_part) {
-  const Seg s = tile_work(ptr, tile_graph, tile_row0, n_work, H);
-  const int64_t w = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
+  extern __shared__ __attribute__((aligned(16))) float lds_proj[];
+  const float* Pp = P;
+  if constexpr (LP) {
+    stage_projection(lds_proj, P, m);
+    Pp = lds_proj;
+  }
+  constexpr int pp = LP ? PP : DH;
+  const int wpb = blockDim.x >> 6;
+  for (int64_t w = blockIdx.x * (int64_t)wpb + (threadIdx.x >> 6); w < n_work; w = LP ? w + (int64_t)gridDim.x * wpb : n_work) {
+  // (LP: the staged projection is the same for every work item -- without this the compiler hoists its reads out of the
+  // loop, i.e. tries to keep all of P in registers.  !LP: the launch has one wavefront per item, the loop runs once.)
+  if constexpr (LP) asm volatile("" ::: "memory");
+  const Seg s = tile_work(ptr, tile_graph, tile_row0, n_work, H, w);
   if (!s.valid) {
-    if (w < n_work && (threadIdx.x & 63) == 0) gM_part[w] = 0.0f;
-    return;
+    if ((threadIdx.x & 63) == 0) gM_part[w] = 0.0f;
+    continue;
   }
   const int inner = H * DH;
   const int gh = s.g * H + s.h;
@@ -555,7 +664,7 @@ __global__ __launch_bounds__(256) void k_favor_bwd_k(
   for (int mt = 0; mt < MT; ++mt) {
     const int prow = mt * 16 + s.i;
     float pv[KPL], gc[KPL];
-    load_row16(P + (int64_t)clampi(prow, m - 1) * DH + 16 * s.grp, prow < m, 1.0f, pv);
+    load_row16(Pp + clampi(prow, m - 1) * pp + 16 * s.grp, prow < m, 1.0f, pv);
     load_row16(gcb + (int64_t)clampi(prow, m - 1) * DH + 16 * s.grp, prow < m, 1.0f, gc);
     const f32x4 dd = mm_rows(pv, kv, zero4());     // [feature 4g+r][key l&15]
     const f32x4 gphi = mm_rows(gc, vv, zero4());   // sum_e g_ctx[f][e] v[key][e]
@@ -575,7 +684,7 @@ __global__ __launch_bounds__(256) void k_favor_bwd_k(
       for (int r = 0; r < 4; ++r) {
         const int f = mt * 16 + 4 * s.grp + r;
         const int fc = clampi(f, m - 1);               // (gB = phi = 0 past m)
-        const float pe = P[(int64_t)fc * DH + t * 16 + s.i];
+        const float pe = Pp[fc * pp + t * 16 + s.i];
         const float ge = gcb[(int64_t)fc * DH + t * 16 + s.i];
         accK[t] = mfma16(pe, gB[r], accK[t]);      // g_k^T[dh][key] += P^T[dh][f] g_B[f][key]
         accV[t] = mfma16(ge, phi[r], accV[t]);     // g_v^T[e][key]  += g_ctx^T[e][f] phi_k^T[f][key]
@@ -592,8 +701,8 @@ __global__ __launch_bounds__(256) void k_favor_bwd_k(
       const int col = t * 16 + 4 * s.grp;
       const float4 kk = *reinterpret_cast<const float4*>(ksrc + col);
       *reinterpret_cast<float4*>(ok_ + col) =
-          make_float4(c * accK[t][0] + k2 * kk.x, c * accK[t][1] + k2 * kk.y,
-                      c * accK[t][2] + k2 * kk.z, c * accK[t][3] + k2 * kk.w);
+          make_float4(fmaf(k2, kk.x, c * accK[t][0]), fmaf(k2, kk.y, c * accK[t][1]),
+                      fmaf(k2, kk.z, c * accK[t][2]), fmaf(k2, kk.w, c * accK[t][3]));
       *reinterpret_cast<float4*>(ov_ + col) =
           make_float4(accV[t][0], accV[t][1], accV[t][2], accV[t][3]);
     }
@@ -601,6 +710,7 @@ __global__ __launch_bounds__(256) void k_favor_bwd_k(
   // this tile's contribution to -g_M: sum over its valid keys of sk (each key counted once: group 0)
   const float part = wave_sum((s.grp == 0 && k_ok) ? sk : 0.0f);
   if ((threadIdx.x & 63) == 0) gM_part[w] = part;
+  }
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -686,6 +796,31 @@ static int favor_slices(int64_t N, int64_t B, int H) {
   if (S > blocks / 4) S = blocks / 4;
   return (int)(S < 1 ? 1 : (S > 8 ? 8 : S));
 }
+// The LDS-staged form of the per-tile kernels: one workgroup per CU.  GPS_FAVOR_LDS=0 never, =1 always (tests), default: when
+// there are at least two work items per wavefront slot of the chip to spread the 74 KB copy over.
+static bool favor_lds(int64_t n_work) {
+  const char* e = getenv("GPS_FAVOR_LDS");
+  if (e && *e) return atoi(e) != 0;
+  return n_work >= 2048;
+}
+static int cu_count() {
+  static const int n = [] {
+    int dev = 0, cus = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+      cus = 256;
+    return cus > 0 ? cus : 256;
+  }();
+  return n;
+}
+template <typename K>
+static bool favor_lds_ready(K kernel) {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             P_LDS_BYTES) == hipSuccess;
+}
+static unsigned favor_lds_grid(int64_t n_work, int threads) {
+  const int64_t wpb = threads / 64, blocks = (n_work + wpb - 1) / wpb;
+  return (unsigned)(blocks < cu_count() ? blocks : cu_count());
+}
 extern "C" {
 
 // floats of workspace gps_favor_fwd / gps_favor_bwd take (partial context records of the row slices; 0: no slicing)
@@ -712,8 +847,14 @@ int gps_favor_fwd(const float* qkv, int64_t ld_qkv, const float* proj, int m, co
   if (hipMemsetAsync(kmax, 0, sizeof(uint64_t) * B * H, s) != hipSuccess)
     return gps::launch_status("gps_favor_fwd/memset");
   const int64_t n_work = max_tiles * H;
-  k_favor_kmax<<<gps::grid_for(n_work, 4), 256, 0, s>>>(qkv, ld_qkv, proj, m, c, ptr, tile_graph, tile_row0,
-                                                        n_work, H, (unsigned long long*)kmax);
+  static const bool lds_ok = favor_lds_ready(&k_favor_kmax<true>);
+  const bool lp = lds_ok && favor_lds(n_work);
+  if (lp)
+    k_favor_kmax<true><<<favor_lds_grid(n_work, FM_THREADS), FM_THREADS, P_LDS_BYTES, s>>>(qkv, ld_qkv, proj, m, c, ptr, tile_graph,
+                                                                              tile_row0, n_work, H, (unsigned long long*)kmax);
+  else
+    k_favor_kmax<false><<<gps::grid_for(n_work, 4), 256, 0, s>>>(qkv, ld_qkv, proj, m, c, ptr, tile_graph, tile_row0,
+                                                                 n_work, H, (unsigned long long*)kmax);
   int S = favor_slices(N, B, H);
   if (!ws || ws_floats < (size_t)S * B * H * 272 * (DH + 1)) S = 1;       // no workspace: one wavefront per record
   if (S > 1) {
@@ -727,8 +868,10 @@ int gps_favor_fwd(const float* qkv, int64_t ld_qkv, const float* proj, int m, co
     k_favor_ctx<<<gps::grid_for(B * H * MT, 4), 256, 0, s>>>(qkv, ld_qkv, proj, m, c, ratio, ptr, nmax, B, H,
                                                              (const unsigned long long*)kmax, ctx, ksum, 1);
   }
-  k_favor_out<<<gps::grid_for(n_work, 4), 256, 0, s>>>(qkv, ld_qkv, proj, m, c, ratio, ptr, tile_graph,
-                                                       tile_row0, n_work, N, H, ctx, ksum, out, mq, D);
+  // (the output kernel stays one wavefront per tile: with the loop over items it needs 333 registers -- one wavefront per
+  // SIMD instead of two -- and ran at 232 us against 149, profiles/r05_favor_lds_projection.txt)
+  k_favor_out<false><<<gps::grid_for(n_work, 4), 256, 0, s>>>(qkv, ld_qkv, proj, m, c, ratio, ptr, tile_graph,
+                                                              tile_row0, n_work, N, H, ctx, ksum, out, mq, D);
   return gps::launch_status("gps_favor_fwd");
 }
 
@@ -753,9 +896,16 @@ int gps_favor_bwd(const float* g_out, const float* qkv, int64_t ld_qkv, const fl
   const float c = powf((float)DH, -0.25f), ratio = 1.0f / sqrtf((float)m);
   const int64_t n_work = max_tiles * H;
   k_favor_bwd_gd<<<gps::grid_for(N * H * 16, 256), 256, 0, s>>>(g_out, out, D, N, H, gD);
-  k_favor_bwd_q<<<gps::grid_for(n_work, 4), 256, 0, s>>>(g_out, qkv, ld_qkv, proj, m, c, ratio, ptr, tile_graph,
-                                                         tile_row0, n_work, N, H, ctx, ksum, mq, D, gD, d_qkv,
-                                                         ld_dqkv);
+  static const bool lds_ok = favor_lds_ready(&k_favor_bwd_q<true>) && favor_lds_ready(&k_favor_bwd_k<true>);
+  const bool lp = lds_ok && favor_lds(n_work);
+  if (lp)
+    k_favor_bwd_q<true><<<favor_lds_grid(n_work, FQ_THREADS), FQ_THREADS, P_LDS_BYTES, s>>>(g_out, qkv, ld_qkv, proj, m, c, ratio, ptr,
+                                                                                          tile_graph, tile_row0, n_work, N, H, ctx,
+                                                                                          ksum, mq, D, gD, d_qkv, ld_dqkv);
+  else
+    k_favor_bwd_q<false><<<gps::grid_for(n_work, 4), 256, 0, s>>>(g_out, qkv, ld_qkv, proj, m, c, ratio, ptr, tile_graph,
+                                                                  tile_row0, n_work, N, H, ctx, ksum, mq, D, gD, d_qkv,
+                                                                  ld_dqkv);
   int S = favor_slices(N, B, H);
   if (!ws || ws_floats < (size_t)S * B * H * 272 * (DH + 1)) S = 1;
   if (S > 1) {
@@ -769,10 +919,16 @@ int gps_favor_bwd(const float* g_out, const float* qkv, int64_t ld_qkv, const fl
     k_favor_bwd_ctx<<<gps::grid_for(B * H * MT, 4), 256, 0, s>>>(g_out, qkv, ld_qkv, proj, m, c, ratio, ptr, B, N,
                                                                  H, mq, D, gD, g_ctx, g_ksum, 1);
   }
-  k_favor_bwd_k<<<gps::grid_for(n_work, 4), 256, 0, s>>>(qkv, ld_qkv, proj, m, c, ratio, ptr, tile_graph,
-                                                         tile_row0, n_work, nmax, H,
-                                                         (const unsigned long long*)kmax, g_ctx, g_ksum, d_qkv,
-                                                         ld_dqkv, gM_part);
+  if (lp)
+    k_favor_bwd_k<true><<<favor_lds_grid(n_work, FK_THREADS), FK_THREADS, P_LDS_BYTES, s>>>(qkv, ld_qkv, proj, m, c, ratio, ptr, tile_graph,
+                                                                               tile_row0, n_work, nmax, H,
+                                                                               (const unsigned long long*)kmax, g_ctx, g_ksum,
+                                                                               d_qkv, ld_dqkv, gM_part);
+  else
+    k_favor_bwd_k<false><<<gps::grid_for(n_work, 4), 256, 0, s>>>(qkv, ld_qkv, proj, m, c, ratio, ptr, tile_graph,
+                                                                  tile_row0, n_work, nmax, H,
+                                                                  (const unsigned long long*)kmax, g_ctx, g_ksum, d_qkv,
+                                                                  ld_dqkv, gM_part);
   k_favor_bwd_kmax_fix<<<(unsigned)(B * H), 64, 0, s>>>(proj, m, c, ratio, ptr, nmax, B, H,
                                                         (const unsigned long long*)kmax, g_ksum, gM_part,
                                                         d_qkv, ld_dqkv);

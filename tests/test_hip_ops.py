@@ -453,6 +453,36 @@ def test_favor_attention_fwd_bwd(H, sizes):
     assert torch.equal(out2, out.detach())
 
 
+@pytest.mark.parametrize("H,sizes,m", [(4, [1000, 3, 601, 17, 333], 266), (2, [60, 999, 1, 16], 100)])
+def test_favor_projection_in_lds_is_bit_identical(monkeypatch, H, sizes, m):
+    """csrc/favor.hip round 5: key max, query side and key side of FAVOR+ with the projection staged in LDS and one
+    workgroup per CU walking the work items (GPS_FAVOR_LDS=1; the default from 2,048 work items on) against one wavefront
+    per (16-row tile, head) reading the projection through L2 (=0): the same arithmetic in the same order -- outputs and
+    every gradient element bit-identical, graphs shorter than a tile, feature counts that leave the last tiles empty."""
+    from graphgps_amd.ops import favor_attention
+    from oracle.gps_oracle import gaussian_orthogonal_random_matrix
+    gen = torch.Generator().manual_seed(23)
+    torch.manual_seed(23)
+    dh = 64
+    proj = gaussian_orthogonal_random_matrix(m, dh).cuda()
+    N, inner = sum(sizes), H * dh
+    ptr = torch.tensor([0] + list(np.cumsum(sizes)))
+    qkv = (torch.randn(N, 3 * inner, generator=gen) * 0.7).cuda()
+    w = torch.randn(N, inner, generator=gen).cuda()
+    bvec = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
+    gi = _index(torch.zeros(2, 0, dtype=torch.long), bvec, ptr)
+    res = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("GPS_FAVOR_LDS", mode)
+        q = qkv.clone().requires_grad_(True)
+        out = favor_attention(q, proj, gi, H)
+        (out * w).sum().backward()
+        res[mode] = (out.detach(), q.grad)
+    assert torch.equal(res["0"][0], res["1"][0])
+    assert torch.equal(res["0"][1], res["1"][1])
+    assert bool(torch.isfinite(res["1"][1]).all()) and float(res["1"][1].abs().max()) > 0
+
+
 def _drop_mask(seed, R, d, p):
     from graphgps_amd.ops import attn_dropout_keep_mask
     # the BN/elementwise kernels key the same hash by (row, column)
