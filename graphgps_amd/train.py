@@ -392,9 +392,10 @@ def _cloned(obj):
 
 
 # GPS_LOADER_BUCKETS (default on): train_epoch pads loader batches up to shape buckets (loader.BucketPadding) when the model
-# is served by the padded path (padding_supported) -- measured on 256-graph batches of never-repeating shapes: 33.8 ms per
-# eager step un-padded (host-bound: e.g. 3.8 ms inside rocBLAS at every first sight of a K = rows GEMM), 16.0 ms padded on the staging thread and replayed, 9.8 ms when
-# the batches arrive padded and pinned (BucketPadding.collate in the DataLoader's workers)
+# is served by the padded path (padding_supported) -- measured on 256-graph batches of never-repeating shapes (round 5,
+# profiles/r05_bench_default.json): 10.6 ms per eager step un-padded (plus 3.8 ms inside rocBLAS at every TRUE first sight of
+# a K = rows GEMM, which that leg does not contain), 9.6 ms padded and replayed -- on the staging thread or in the
+# DataLoader's workers (BucketPadding.collate) alike
 _BUCKETS_DEFAULT = "1"
 LOGGER_FLUSH_EVERY = 16     # iterations between device->host reads for the logger (one sync per flush)
 
