@@ -312,7 +312,7 @@ __global__ __launch_bounds__(256) void k_favor_sum_parts(const float* __restrict
 }
 
 // dd_q^T tiles [feature 4g+r + 16mt][query l&15] and phi_q for one 16-query tile
-template <int PITCH>
+template <int PITCH, bool FENCE = true>
 __device__ __forceinline__ void query_features(const float (&qv)[KPL], const float* __restrict__ P,
                                                int m, int i, int grp, float (&dd)[MT][4], float& mq,
                                                bool have_mq) {
@@ -332,7 +332,7 @@ __device__ __forceinline__ void query_features(const float (&qv)[KPL], const flo
         dd[mt][r] = t[r];
         if (mt * 16 + 4 * grp + r < m) mx = fmaxf(mx, t[r]);
       }
-      __builtin_amdgcn_sched_barrier(0);
+      if constexpr (FENCE) __builtin_amdgcn_sched_barrier(0);
     }
   } else {
 #pragma unroll
@@ -354,29 +354,12 @@ __device__ __forceinline__ void query_features(const float (&qv)[KPL], const flo
 // ---------------------------------------------------------------------------------------------
 // F3: per (query tile, head): out = (phi_q ctx) / (phi_q . ksum); saves mq (row max) and D.
 // ---------------------------------------------------------------------------------------------
-template <bool LP>
-__global__ __launch_bounds__(LP ? FO_THREADS : 256) void k_favor_out(
-    const float* __restrict__ qkv, int64_t ld, const float* __restrict__ P, int m, float c,
-    float ratio, const int32_t* __restrict__ ptr, const int32_t* __restrict__ tile_graph,
-    const int32_t* __restrict__ tile_row0, int64_t n_work, int64_t N, int H,
-    const float* __restrict__ ctx, const float* __restrict__ ksum, float* __restrict__ out,
-    float* __restrict__ mq_out, float* __restrict__ D_out) {
-  extern __shared__ __attribute__((aligned(16))) float lds_proj[];
-  const float* Pp = P;
-  if constexpr (LP) {
-    stage_projection(lds_proj, P, m);
-    Pp = lds_proj;
-  }
-  constexpr int pp = LP ? PP : DH;
-  const int wpb = blockDim.x >> 6;
-  for (int64_t w = blockIdx.x * (int64_t)wpb + (threadIdx.x >> 6); w < n_work; w = LP ? w + (int64_t)gridDim.x * wpb : n_work) {
-  // (LP: the staged projection is the same for every work item -- without this the compiler hoists its reads out of the
-  // loop, i.e. tries to keep all of P in registers.  !LP: the launch has one wavefront per item, the loop runs once.)
-  if constexpr (LP) asm volatile("" ::: "memory");
-  const Seg s = tile_work(ptr, tile_graph, tile_row0, n_work, H, w);
-  if (!s.valid) continue;
+// One work item of the output kernel (see favor_bwd_q_item for the pitch parameters).
+template <int PPITCH, int CPITCH, int KSTRIDE>
+__device__ __forceinline__ void favor_out_item(const Seg& s, const float* __restrict__ qkv, int64_t ld, const float* Pp, int m,
+                                               float c, float ratio, int64_t N, int H, const float* cbase, const float* kbase,
+                                               float* __restrict__ out, float* __restrict__ mq_out, float* __restrict__ D_out) {
   const int inner = H * DH;
-  const int gh = s.g * H + s.h;
   const int qrow = s.row0 + s.i;
   const bool q_ok = qrow < s.n1;
   float qv[KPL];
@@ -384,13 +367,11 @@ __global__ __launch_bounds__(LP ? FO_THREADS : 256) void k_favor_out(
   const float half_nrm = 0.5f * group_sum(sumsq16(qv));
   float dd[MT][4];
   float mq;
-  query_features<pp>(qv, Pp, m, s.i, s.grp, dd, mq, false);
+  query_features<PPITCH>(qv, Pp, m, s.i, s.grp, dd, mq, false);
   float dpart = 0.0f;
   f32x4 acc[4];
 #pragma unroll
   for (int et = 0; et < 4; ++et) acc[et] = zero4();
-  const float* cbase = ctx + (int64_t)gh * 272 * DH;
-  const float* kbase = ksum + (int64_t)gh * 272;
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
 #pragma unroll
@@ -398,14 +379,14 @@ __global__ __launch_bounds__(LP ? FO_THREADS : 256) void k_favor_out(
       const int f = mt * 16 + 4 * s.grp + r;
       const float phi = f < m ? ratio * (expf(dd[mt][r] - half_nrm - mq) + FEPS) : 0.0f;
       dd[mt][r] = phi;
-      dpart += phi * kbase[clampi(f, m - 1)];          // (phi = 0 past m)
+      dpart += phi * kbase[clampi(f, m - 1) * KSTRIDE];          // (phi = 0 past m)
     }
 #pragma unroll
     for (int et = 0; et < 4; ++et)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int f = mt * 16 + 4 * s.grp + r;
-        const float cv = cbase[(int64_t)clampi(f, m - 1) * DH + et * 16 + s.i];      // (dd = phi = 0 past m)
+        const float cv = cbase[clampi(f, m - 1) * CPITCH + et * 16 + s.i];      // (dd = phi = 0 past m)
         acc[et] = mfma16(cv, dd[mt][r], acc[et]);   // num^T[e 4g+r'][query l&15]
       }
   }
@@ -422,6 +403,30 @@ __global__ __launch_bounds__(LP ? FO_THREADS : 256) void k_favor_out(
       D_out[(int64_t)s.h * N + qrow] = D;
     }
   }
+}
+
+template <bool LP>
+__global__ __launch_bounds__(LP ? FO_THREADS : 256) void k_favor_out(
+    const float* __restrict__ qkv, int64_t ld, const float* __restrict__ P, int m, float c,
+    float ratio, const int32_t* __restrict__ ptr, const int32_t* __restrict__ tile_graph,
+    const int32_t* __restrict__ tile_row0, int64_t n_work, int64_t N, int H,
+    const float* __restrict__ ctx, const float* __restrict__ ksum, float* __restrict__ out,
+    float* __restrict__ mq_out, float* __restrict__ D_out) {
+  extern __shared__ __attribute__((aligned(16))) float lds_proj[];
+  const float* Pp = P;
+  if constexpr (LP) {
+    stage_projection(lds_proj, P, m);
+    Pp = lds_proj;
+  }
+  constexpr int pp = LP ? PP : DH;
+  const int wpb = blockDim.x >> 6;
+  for (int64_t w = blockIdx.x * (int64_t)wpb + (threadIdx.x >> 6); w < n_work; w = LP ? w + (int64_t)gridDim.x * wpb : n_work) {
+    if constexpr (LP) asm volatile("" ::: "memory");        // (see k_favor_bwd_q)
+    const Seg s = tile_work(ptr, tile_graph, tile_row0, n_work, H, w);
+    if (!s.valid) continue;
+    const int gh = s.g * H + s.h;
+    favor_out_item<pp, DH, 1>(s, qkv, ld, Pp, m, c, ratio, N, H, ctx + (int64_t)gh * 272 * DH, ksum + (int64_t)gh * 272, out,
+                              mq_out, D_out);
   }
 }
 
@@ -452,30 +457,14 @@ __global__ void k_favor_bwd_gd(const float* __restrict__ g_out, const float* __r
 // ---------------------------------------------------------------------------------------------
 // B1: per (query tile, head): g_q
 // ---------------------------------------------------------------------------------------------
-template <bool LP>
-__global__ __launch_bounds__(LP ? FQ_THREADS : 256) void k_favor_bwd_q(
-    const float* __restrict__ g_out, const float* __restrict__ qkv, int64_t ld,
-    const float* __restrict__ P, int m, float c, float ratio, const int32_t* __restrict__ ptr,
-    const int32_t* __restrict__ tile_graph, const int32_t* __restrict__ tile_row0, int64_t n_work,
-    int64_t N, int H, const float* __restrict__ ctx, const float* __restrict__ ksum,
-    const float* __restrict__ mq_in, const float* __restrict__ D_in, const float* __restrict__ gD_in,
-    float* __restrict__ d_qkv, int64_t ldg) {
-  extern __shared__ __attribute__((aligned(16))) float lds_proj[];
-  const float* Pp = P;
-  if constexpr (LP) {
-    stage_projection(lds_proj, P, m);
-    Pp = lds_proj;
-  }
-  constexpr int pp = LP ? PP : DH;
-  const int wpb = blockDim.x >> 6;
-  for (int64_t w = blockIdx.x * (int64_t)wpb + (threadIdx.x >> 6); w < n_work; w = LP ? w + (int64_t)gridDim.x * wpb : n_work) {
-  // (LP: the staged projection is the same for every work item -- without this the compiler hoists its reads out of the
-  // loop, i.e. tries to keep all of P in registers.  !LP: the launch has one wavefront per item, the loop runs once.)
-  if constexpr (LP) asm volatile("" ::: "memory");
-  const Seg s = tile_work(ptr, tile_graph, tile_row0, n_work, H, w);
-  if (!s.valid) continue;
+// One work item.  Pp: the projection with row pitch PPITCH (global: DH, staged: PP); cbase: the context record of the item's
+// (graph, head) with row pitch CPITCH; ksum[f] = kbase[f * KSTRIDE].
+template <int PPITCH, int CPITCH, int KSTRIDE, bool FENCE = true>
+__device__ __forceinline__ void favor_bwd_q_item(
+    const Seg& s, const float* __restrict__ g_out, const float* __restrict__ qkv, int64_t ld, const float* Pp, int m,
+    float c, float ratio, int64_t N, int H, const float* cbase, const float* kbase, const float* __restrict__ mq_in,
+    const float* __restrict__ D_in, const float* __restrict__ gD_in, float* __restrict__ d_qkv, int64_t ldg) {
   const int inner = H * DH;
-  const int gh = s.g * H + s.h;
   const int qrow = s.row0 + s.i;
   const bool q_ok = qrow < s.n1;
   float qv[KPL], gn[KPL];
@@ -488,25 +477,24 @@ __global__ __launch_bounds__(LP ? FQ_THREADS : 256) void k_favor_bwd_q(
   const float gDq = q_ok ? gD_l : 0.0f;
   load_row16(g_out + (int64_t)qrc * inner + s.h * DH + 16 * s.grp, q_ok, 1.0f / Dq, gn);  // g_num
   float dd[MT][4];
-  query_features<pp>(qv, Pp, m, s.i, s.grp, dd, mq, true);
-  const float* cbase = ctx + (int64_t)gh * 272 * DH;
-  const float* kbase = ksum + (int64_t)gh * 272;
+  query_features<PPITCH, FENCE>(qv, Pp, m, s.i, s.grp, dd, mq, true);
   float s1 = 0.0f;
   float gA[MT][4];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt) {
     const int crow = mt * 16 + s.i;
     float cv[KPL];
-    load_row16(cbase + (int64_t)clampi(crow, m - 1) * DH + 16 * s.grp, crow < m, 1.0f, cv);
+    load_row16(cbase + clampi(crow, m - 1) * CPITCH + 16 * s.grp, crow < m, 1.0f, cv);
     const f32x4 gphi = mm_rows(cv, gn, zero4());   // [feature 4g+r][query]: sum_e ctx[f][e] g_num[q][e]
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int f = mt * 16 + 4 * s.grp + r;
       const float ex = ratio * expf(dd[mt][r] - half_nrm - mq);     // = phi - r*eps
-      const float ga = f < m ? (gphi[r] + kbase[clampi(f, m - 1)] * gDq) * ex : 0.0f;
+      const float ga = f < m ? (gphi[r] + kbase[clampi(f, m - 1) * KSTRIDE] * gDq) * ex : 0.0f;
       gA[mt][r] = ga;
       s1 += ga;
     }
+    if constexpr (CPITCH == PP && FENCE) __builtin_amdgcn_sched_barrier(0);      // (staged record: as in query_features)
   }
   s1 = group_sum(s1);                                 // sum_m g_A of this query
   f32x4 acc[4];
@@ -525,7 +513,7 @@ __global__ __launch_bounds__(LP ? FQ_THREADS : 256) void k_favor_bwd_q(
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int f = mt * 16 + 4 * s.grp + r;
-        const float pv = Pp[clampi(f, m - 1) * pp + dt * 16 + s.i];      // (gA = 0 past m)
+        const float pv = Pp[clampi(f, m - 1) * PPITCH + dt * 16 + s.i];      // (gA = 0 past m)
         acc[dt] = mfma16(pv, gA[mt][r], acc[dt]);   // g_q^T[dh 4g+r'][query]
       }
   }
@@ -542,7 +530,181 @@ __global__ __launch_bounds__(LP ? FQ_THREADS : 256) void k_favor_bwd_q(
                       fmaf(k2, qq.z, c * acc[dt][2]), fmaf(k2, qq.w, c * acc[dt][3]));     // compiler, LP / !LP contracted differently)
     }
   }
+}
+
+template <bool LP>
+__global__ __launch_bounds__(LP ? FQ_THREADS : 256) void k_favor_bwd_q(
+    const float* __restrict__ g_out, const float* __restrict__ qkv, int64_t ld,
+    const float* __restrict__ P, int m, float c, float ratio, const int32_t* __restrict__ ptr,
+    const int32_t* __restrict__ tile_graph, const int32_t* __restrict__ tile_row0, int64_t n_work,
+    int64_t N, int H, const float* __restrict__ ctx, const float* __restrict__ ksum,
+    const float* __restrict__ mq_in, const float* __restrict__ D_in, const float* __restrict__ gD_in,
+    float* __restrict__ d_qkv, int64_t ldg) {
+  extern __shared__ __attribute__((aligned(16))) float lds_proj[];
+  const float* Pp = P;
+  if constexpr (LP) {
+    stage_projection(lds_proj, P, m);
+    Pp = lds_proj;
   }
+  constexpr int pp = LP ? PP : DH;
+  const int wpb = blockDim.x >> 6;
+  for (int64_t w = blockIdx.x * (int64_t)wpb + (threadIdx.x >> 6); w < n_work; w = LP ? w + (int64_t)gridDim.x * wpb : n_work) {
+    // (LP: the staged projection is the same for every work item -- without this the compiler hoists its reads out of the
+    // loop, i.e. tries to keep all of P in registers.  !LP: the launch has one wavefront per item, the loop runs once.)
+    if constexpr (LP) asm volatile("" ::: "memory");
+    const Seg s = tile_work(ptr, tile_graph, tile_row0, n_work, H, w);
+    if (!s.valid) continue;
+    const int gh = s.g * H + s.h;
+    favor_bwd_q_item<pp, DH, 1>(s, g_out, qkv, ld, Pp, m, c, ratio, N, H, ctx + (int64_t)gh * 272 * DH,
+                                ksum + (int64_t)gh * 272, mq_in, D_in, gD_in, d_qkv, ldg);
+  }
+}
+
+// ---- the context record staged as well (LC) -----------------------------------------------------------------------------
+// What the LP form still waits for is the context record of the item's (graph, head): 70 KB read row by row from global
+// memory in a chain load -> 16-step contraction per feature tile, at ONE wavefront per SIMD (the kernel holds ~370
+// registers) -- ~17 exposed memory round trips per work item, 98k cycles per item against 26k of matrix pipe.  Here a
+// workgroup (4 wavefronts, one per CU) takes CHUNKS = (graph, head, four consecutive 16-row tiles of that graph): it copies
+// the record [m, 64] and ksum [m] of (graph, head) into LDS next to the projection (pitch 68: the record's row in columns
+// 0..63, ksum in column 64) with all 256 threads, then every wavefront runs its tile against LDS only.  Chunks are numbered
+// (graph, quad, head), head fastest, and dealt to the workgroups in contiguous ranges; the graph of a chunk comes from a
+// prefix of quads per graph that every workgroup builds in LDS (B <= kLcMaxGraphs).  Same arithmetic per item, same order.
+constexpr int kLcMaxGraphs = 1024;
+constexpr int LC_LDS_BYTES = 2 * P_LDS_BYTES + (kLcMaxGraphs + 1) * 4;
+__device__ __forceinline__ void stage_record(float* __restrict__ lc, const float* __restrict__ rec, const float* __restrict__ vec,
+                                             int m) {
+  for (int idx = threadIdx.x; idx < 16 * MT * (DH / 4); idx += blockDim.x) {
+    const int row = idx / (DH / 4), c4 = idx % (DH / 4);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (row < m) v = reinterpret_cast<const float4*>(rec + (int64_t)row * DH)[c4];
+    *reinterpret_cast<float4*>(lc + row * PP + 4 * c4) = v;
+  }
+  for (int row = threadIdx.x; row < 16 * MT; row += blockDim.x) lc[row * PP + DH] = row < m ? vec[row] : 0.0f;
+}
+struct Chunk {
+  int g, h, q4;
+};
+// chunk ch of the launch -> (graph, head, quad of the graph); pre[g] = quads of the graphs before g (LDS)
+__device__ __forceinline__ Chunk chunk_of(const int* pre, int B, int H, int ch) {
+  const int cq = ch / H;
+  int lo = 0, hi = B;
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (pre[mid] <= cq) lo = mid; else hi = mid;
+  }
+  return Chunk{lo, ch - cq * H, cq - pre[lo]};          // (the LAST graph whose prefix is <= cq: empty graphs are skipped)
+}
+__device__ __forceinline__ int quad_prefix(int* pre, const int32_t* __restrict__ ptr, int B, int nw) {
+  if (threadIdx.x == 0) {
+    int a = 0;
+    for (int g = 0; g < B; ++g) {
+      pre[g] = a;
+      a += (((ptr[g + 1] - ptr[g]) + 15) / 16 + nw - 1) / nw;
+    }
+    pre[B] = a;
+  }
+  __syncthreads();
+  return pre[B];
+}
+
+// the same copy through registers (256 threads): issued for chunk c + 1 in front of chunk c's arithmetic, written behind it
+struct RecordRegs {
+  float4 v[16 * MT * (DH / 4) / 256];     // 17
+  float k0, k1;
+};
+__device__ __forceinline__ void load_record(RecordRegs& r, const float* __restrict__ rec, const float* __restrict__ vec, int m) {
+#pragma unroll
+  for (int j = 0; j < 16 * MT * (DH / 4) / 256; ++j) {
+    const int idx = threadIdx.x + 256 * j, row = idx / (DH / 4), c4 = idx % (DH / 4);
+    const float4 v = reinterpret_cast<const float4*>(rec + (int64_t)clampi(row, m - 1) * DH)[c4];      // (unconditional load)
+    r.v[j] = row < m ? v : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const int t = threadIdx.x;
+  const float a = vec[clampi(t, m - 1)], b = vec[clampi(256 + t, m - 1)];
+  r.k0 = t < m ? a : 0.0f;
+  r.k1 = 256 + t < m ? b : 0.0f;
+}
+__device__ __forceinline__ void write_record(float* __restrict__ lc, const RecordRegs& r) {
+#pragma unroll
+  for (int j = 0; j < 16 * MT * (DH / 4) / 256; ++j) {
+    const int idx = threadIdx.x + 256 * j, row = idx / (DH / 4), c4 = idx % (DH / 4);
+    *reinterpret_cast<float4*>(lc + row * PP + 4 * c4) = r.v[j];
+  }
+  const int t = threadIdx.x;
+  lc[t * PP + DH] = r.k0;
+  if (256 + t < 16 * MT) lc[(256 + t) * PP + DH] = r.k1;
+}
+
+// The chunk loop shared by the three kernels: `item(s, lp, lc)` runs one wavefront's tile against the staged projection
+// `lp` and the staged record `lc` (record rows in columns 0..63, the vector in column 64) of (s.g, s.h).
+template <bool PRE, int NW, typename F>
+__device__ __forceinline__ void lc_drive(float* lds, const float* __restrict__ P, int m, const int32_t* __restrict__ ptr, int B,
+                                         int H, const float* __restrict__ rec, const float* __restrict__ vec, F&& item) {
+  float* const lp = lds;
+  float* const lc = lds + 16 * MT * PP;
+  int* const pre = reinterpret_cast<int*>(lc + 16 * MT * PP);
+  stage_projection(lp, P, m);
+  const int n_chunks = quad_prefix(pre, ptr, B, NW) * H;
+  const int per = (n_chunks + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int c0 = (int)blockIdx.x * per, c1 = min(n_chunks, c0 + per);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  static_assert(!PRE || NW == 4, "the register copy is laid out for 256 threads");
+  RecordRegs nx;
+  if constexpr (PRE) {
+    if (c0 < c1) {
+      const Chunk k = chunk_of(pre, B, H, c0);
+      const int gh = k.g * H + k.h;
+      load_record(nx, rec + (int64_t)gh * 272 * DH, vec + (int64_t)gh * 272, m);
+    }
+  }
+  for (int ch = c0; ch < c1; ++ch) {
+    const Chunk k = chunk_of(pre, B, H, ch);
+    const int gh = k.g * H + k.h;
+    __syncthreads();                                  // the previous chunk's readers are done with the record
+    if constexpr (PRE) {
+      write_record(lc, nx);
+    } else {
+      stage_record(lc, rec + (int64_t)gh * 272 * DH, vec + (int64_t)gh * 272, m);
+    }
+    __syncthreads();
+    if constexpr (PRE) {
+      if (ch + 1 < c1) {                              // the next record's loads fly during this chunk's arithmetic
+        const Chunk kn = chunk_of(pre, B, H, ch + 1);
+        const int ghn = kn.g * H + kn.h;
+        load_record(nx, rec + (int64_t)ghn * 272 * DH, vec + (int64_t)ghn * 272, m);
+      }
+    }
+    Seg s;
+    s.g = k.g; s.h = k.h; s.n0 = ptr[k.g]; s.n1 = ptr[k.g + 1];
+    s.row0 = s.n0 + 16 * (NW * k.q4 + wave);
+    s.i = lane & 15; s.grp = lane >> 4;
+    s.valid = s.row0 < s.n1;
+    if (s.valid) item(s, lp, lc);
+  }
+}
+
+template <bool PRE, int NW>
+__global__ __launch_bounds__(64 * NW) void k_favor_bwd_q_lc(
+    const float* __restrict__ g_out, const float* __restrict__ qkv, int64_t ld,
+    const float* __restrict__ P, int m, float c, float ratio, const int32_t* __restrict__ ptr, int B,
+    int64_t N, int H, const float* __restrict__ ctx, const float* __restrict__ ksum,
+    const float* __restrict__ mq_in, const float* __restrict__ D_in, const float* __restrict__ gD_in,
+    float* __restrict__ d_qkv, int64_t ldg) {
+  extern __shared__ __attribute__((aligned(16))) float lds_proj[];
+  lc_drive<PRE, NW>(lds_proj, P, m, ptr, B, H, ctx, ksum, [&](const Seg& s, const float* lp, const float* lc) {
+    favor_bwd_q_item<PP, PP, PP, true>(s, g_out, qkv, ld, lp, m, c, ratio, N, H, lc, lc + DH, mq_in, D_in, gD_in, d_qkv, ldg);
+  });
+}
+
+template <bool PRE, int NW>
+__global__ __launch_bounds__(64 * NW) void k_favor_out_lc(
+    const float* __restrict__ qkv, int64_t ld, const float* __restrict__ P, int m, float c, float ratio,
+    const int32_t* __restrict__ ptr, int B, int64_t N, int H, const float* __restrict__ ctx,
+    const float* __restrict__ ksum, float* __restrict__ out, float* __restrict__ mq_out, float* __restrict__ D_out) {
+  extern __shared__ __attribute__((aligned(16))) float lds_proj[];
+  lc_drive<PRE, NW>(lds_proj, P, m, ptr, B, H, ctx, ksum, [&](const Seg& s, const float* lp, const float* lc) {
+    favor_out_item<PP, PP, PP>(s, qkv, ld, lp, m, c, ratio, N, H, lc, lc + DH, out, mq_out, D_out);
+  });
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -619,31 +781,13 @@ __global__ __launch_bounds__(256) void k_favor_bwd_ctx(
 // ---------------------------------------------------------------------------------------------
 // B3: per (key tile, head): g_k (without the key-max term), g_v, and this tile's share of g_M
 // ---------------------------------------------------------------------------------------------
-template <bool LP>
-__global__ __launch_bounds__(LP ? FK_THREADS : 256) void k_favor_bwd_k(
-    const float* __restrict__ qkv, int64_t ld, const float* __restrict__ P, int m, float c,
-    float ratio, const int32_t* __restrict__ ptr, const int32_t* __restrict__ tile_graph,
-    const int32_t* __restrict__ tile_row0, int64_t n_work, const int32_t* __restrict__ nmax_dev,
-    int H, const unsigned long long* __restrict__ kmax, const float* __restrict__ g_ctx,
-    const float* __restrict__ g_ksum, float* __restrict__ d_qkv, int64_t ldg,
-    float* __restrict__ gM_part) {
-  extern __shared__ __attribute__((aligned(16))) float lds_proj[];
-  const float* Pp = P;
-  if constexpr (LP) {
-    stage_projection(lds_proj, P, m);
-    Pp = lds_proj;
-  }
-  constexpr int pp = LP ? PP : DH;
-  const int wpb = blockDim.x >> 6;
-  for (int64_t w = blockIdx.x * (int64_t)wpb + (threadIdx.x >> 6); w < n_work; w = LP ? w + (int64_t)gridDim.x * wpb : n_work) {
-  // (LP: the staged projection is the same for every work item -- without this the compiler hoists its reads out of the
-  // loop, i.e. tries to keep all of P in registers.  !LP: the launch has one wavefront per item, the loop runs once.)
-  if constexpr (LP) asm volatile("" ::: "memory");
-  const Seg s = tile_work(ptr, tile_graph, tile_row0, n_work, H, w);
-  if (!s.valid) {
-    if ((threadIdx.x & 63) == 0) gM_part[w] = 0.0f;
-    continue;
-  }
+// One work item of the key-side kernel: gcb / gkb = the g_ctx / g_ksum record of the item's (graph, head); returns the
+// item's contribution to -g_M (valid on every lane).
+template <int PPITCH, int CPITCH, int KSTRIDE>
+__device__ __forceinline__ float favor_bwd_k_item(const Seg& s, const float* __restrict__ qkv, int64_t ld, const float* Pp, int m,
+                                                  float c, float ratio, const int32_t* __restrict__ nmax_dev, int H,
+                                                  const unsigned long long* __restrict__ kmax, const float* gcb,
+                                                  const float* gkb, float* __restrict__ d_qkv, int64_t ldg) {
   const int inner = H * DH;
   const int gh = s.g * H + s.h;
   const int krow = s.row0 + s.i;
@@ -655,8 +799,6 @@ __global__ __launch_bounds__(LP ? FK_THREADS : 256) void k_favor_bwd_k(
   load_row16(qkv + (int64_t)krc * ld + inner + s.h * DH + 16 * s.grp, k_ok, c, kv);
   load_row16(qkv + (int64_t)krc * ld + 2 * inner + s.h * DH + 16 * s.grp, k_ok, 1.0f, vv);
   const float half_nrm = 0.5f * group_sum(sumsq16(kv));
-  const float* gcb = g_ctx + (int64_t)gh * 272 * DH;
-  const float* gkb = g_ksum + (int64_t)gh * 272;
   float sk = 0.0f;
   f32x4 accK[4], accV[4];
 #pragma unroll
@@ -664,8 +806,8 @@ __global__ __launch_bounds__(LP ? FK_THREADS : 256) void k_favor_bwd_k(
   for (int mt = 0; mt < MT; ++mt) {
     const int prow = mt * 16 + s.i;
     float pv[KPL], gc[KPL];
-    load_row16(Pp + clampi(prow, m - 1) * pp + 16 * s.grp, prow < m, 1.0f, pv);
-    load_row16(gcb + (int64_t)clampi(prow, m - 1) * DH + 16 * s.grp, prow < m, 1.0f, gc);
+    load_row16(Pp + clampi(prow, m - 1) * PPITCH + 16 * s.grp, prow < m, 1.0f, pv);
+    load_row16(gcb + clampi(prow, m - 1) * CPITCH + 16 * s.grp, prow < m, 1.0f, gc);
     const f32x4 dd = mm_rows(pv, kv, zero4());     // [feature 4g+r][key l&15]
     const f32x4 gphi = mm_rows(gc, vv, zero4());   // sum_e g_ctx[f][e] v[key][e]
     f32x4 phi, gB;
@@ -675,7 +817,7 @@ __global__ __launch_bounds__(LP ? FK_THREADS : 256) void k_favor_bwd_k(
       const bool ok = f < m && k_ok;
       const float ex = ok ? ratio * expf(dd[r] - half_nrm - M) : 0.0f;
       phi[r] = ok ? ex + ratio * FEPS : 0.0f;
-      gB[r] = (gphi[r] + gkb[clampi(f, m - 1)]) * ex;        // (ex = 0 when !ok)
+      gB[r] = (gphi[r] + gkb[clampi(f, m - 1) * KSTRIDE]) * ex;        // (ex = 0 when !ok)
       sk += gB[r];
     }
 #pragma unroll
@@ -684,8 +826,8 @@ __global__ __launch_bounds__(LP ? FK_THREADS : 256) void k_favor_bwd_k(
       for (int r = 0; r < 4; ++r) {
         const int f = mt * 16 + 4 * s.grp + r;
         const int fc = clampi(f, m - 1);               // (gB = phi = 0 past m)
-        const float pe = Pp[fc * pp + t * 16 + s.i];
-        const float ge = gcb[(int64_t)fc * DH + t * 16 + s.i];
+        const float pe = Pp[fc * PPITCH + t * 16 + s.i];
+        const float ge = gcb[fc * CPITCH + t * 16 + s.i];
         accK[t] = mfma16(pe, gB[r], accK[t]);      // g_k^T[dh][key] += P^T[dh][f] g_B[f][key]
         accV[t] = mfma16(ge, phi[r], accV[t]);     // g_v^T[e][key]  += g_ctx^T[e][f] phi_k^T[f][key]
       }
@@ -708,9 +850,53 @@ __global__ __launch_bounds__(LP ? FK_THREADS : 256) void k_favor_bwd_k(
     }
   }
   // this tile's contribution to -g_M: sum over its valid keys of sk (each key counted once: group 0)
-  const float part = wave_sum((s.grp == 0 && k_ok) ? sk : 0.0f);
-  if ((threadIdx.x & 63) == 0) gM_part[w] = part;
+  return wave_sum((s.grp == 0 && k_ok) ? sk : 0.0f);
+}
+
+template <bool LP>
+__global__ __launch_bounds__(LP ? FK_THREADS : 256) void k_favor_bwd_k(
+    const float* __restrict__ qkv, int64_t ld, const float* __restrict__ P, int m, float c,
+    float ratio, const int32_t* __restrict__ ptr, const int32_t* __restrict__ tile_graph,
+    const int32_t* __restrict__ tile_row0, int64_t n_work, const int32_t* __restrict__ nmax_dev,
+    int H, const unsigned long long* __restrict__ kmax, const float* __restrict__ g_ctx,
+    const float* __restrict__ g_ksum, float* __restrict__ d_qkv, int64_t ldg,
+    float* __restrict__ gM_part) {
+  extern __shared__ __attribute__((aligned(16))) float lds_proj[];
+  const float* Pp = P;
+  if constexpr (LP) {
+    stage_projection(lds_proj, P, m);
+    Pp = lds_proj;
   }
+  constexpr int pp = LP ? PP : DH;
+  const int wpb = blockDim.x >> 6;
+  for (int64_t w = blockIdx.x * (int64_t)wpb + (threadIdx.x >> 6); w < n_work; w = LP ? w + (int64_t)gridDim.x * wpb : n_work) {
+    if constexpr (LP) asm volatile("" ::: "memory");        // (see k_favor_bwd_q)
+    const Seg s = tile_work(ptr, tile_graph, tile_row0, n_work, H, w);
+    if (!s.valid) {
+      if ((threadIdx.x & 63) == 0) gM_part[w] = 0.0f;
+      continue;
+    }
+    const int gh = s.g * H + s.h;
+    const float part = favor_bwd_k_item<pp, DH, 1>(s, qkv, ld, Pp, m, c, ratio, nmax_dev, H, kmax, g_ctx + (int64_t)gh * 272 * DH,
+                                                   g_ksum + (int64_t)gh * 272, d_qkv, ldg);
+    if ((threadIdx.x & 63) == 0) gM_part[w] = part;
+  }
+}
+
+// (gM_part: the slot of tile t of graph g is (ptr[g] >> 4) + g + t -- the tile map of ops.build_graph_index, which
+// k_favor_bwd_kmax_fix walks; slots of tiles that do not exist are never read)
+template <bool PRE, int NW>
+__global__ __launch_bounds__(64 * NW) void k_favor_bwd_k_lc(
+    const float* __restrict__ qkv, int64_t ld, const float* __restrict__ P, int m, float c, float ratio,
+    const int32_t* __restrict__ ptr, int B, const int32_t* __restrict__ nmax_dev, int H,
+    const unsigned long long* __restrict__ kmax, const float* __restrict__ g_ctx, const float* __restrict__ g_ksum,
+    float* __restrict__ d_qkv, int64_t ldg, float* __restrict__ gM_part) {
+  extern __shared__ __attribute__((aligned(16))) float lds_proj[];
+  lc_drive<PRE, NW>(lds_proj, P, m, ptr, B, H, g_ctx, g_ksum, [&](const Seg& s, const float* lp, const float* lc) {
+    const float part = favor_bwd_k_item<PP, PP, PP>(s, qkv, ld, lp, m, c, ratio, nmax_dev, H, kmax, lc, lc + DH, d_qkv, ldg);
+    const int64_t tile = (s.n0 >> 4) + s.g + ((s.row0 - s.n0) >> 4);
+    if ((threadIdx.x & 63) == 0) gM_part[tile * H + s.h] = part;
+  });
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -803,6 +989,37 @@ static bool favor_lds(int64_t n_work) {
   if (e && *e) return atoi(e) != 0;
   return n_work >= 2048;
 }
+// The chunked form with the context record staged too (k_favor_*_lc): long graphs only -- a chunk is four 16-row tiles of
+// ONE graph and costs a 70 KB copy.  GPS_FAVOR_LC=0 never, =1 whenever the shapes allow it.
+static bool favor_lc(int64_t max_tiles, int64_t B, const char* one = nullptr) {
+  if (B < 1 || B > kLcMaxGraphs) return false;
+  const char* e = getenv("GPS_FAVOR_LC");
+  if (e && *e && atoi(e) == 0) return false;
+  if (one) {                                   // per-kernel switch (A/B): GPS_FAVOR_LC_OUT / _Q / _K = 0
+    const char* o = getenv(one);
+    if (o && *o && atoi(o) == 0) return false;
+  }
+  if (e && *e) return true;
+  return max_tiles >= 16 * B && max_tiles >= 512;
+}
+// wavefronts per workgroup of a chunked kernel: 4 (the form that prefetches the next record through registers) or 8 (two
+// per SIMD, no prefetch).  Measured (profiles/r05_favor_lds_projection.txt, code2-long layer): query side 208 vs 217 us, key
+// side 253 vs 228, output 141 vs 128 -- hence the defaults below; GPS_FAVOR_LC_{Q,K,OUT}_WAVES / GPS_FAVOR_LC_WAVES override.
+static int favor_lc_waves(const char* one, int dflt) {
+  const char* e = getenv(one);
+  if (!(e && *e)) e = getenv("GPS_FAVOR_LC_WAVES");
+  if (!(e && *e)) return dflt;
+  return atoi(e) == 8 ? 8 : 4;
+}
+static bool favor_lc_prefetch() {
+  const char* pe = getenv("GPS_FAVOR_LC_PREFETCH");
+  return !(pe && atoi(pe) == 0);
+}
+template <typename K>
+static bool favor_lc_ready(K kernel) {
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                             LC_LDS_BYTES) == hipSuccess;
+}
 static int cu_count() {
   static const int n = [] {
     int dev = 0, cus = 0;
@@ -816,6 +1033,11 @@ template <typename K>
 static bool favor_lds_ready(K kernel) {
   return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                              P_LDS_BYTES) == hipSuccess;
+}
+static int cu_count();
+static unsigned favor_lc_grid(int64_t max_tiles, int64_t B, int H, int nw) {
+  const int64_t chunks = (max_tiles / nw + B) * H;                      // upper bound (the exact count is on the device)
+  return (unsigned)(chunks < cu_count() ? chunks : cu_count());
 }
 static unsigned favor_lds_grid(int64_t n_work, int threads) {
   const int64_t wpb = threads / 64, blocks = (n_work + wpb - 1) / wpb;
@@ -868,10 +1090,24 @@ int gps_favor_fwd(const float* qkv, int64_t ld_qkv, const float* proj, int m, co
     k_favor_ctx<<<gps::grid_for(B * H * MT, 4), 256, 0, s>>>(qkv, ld_qkv, proj, m, c, ratio, ptr, nmax, B, H,
                                                              (const unsigned long long*)kmax, ctx, ksum, 1);
   }
-  // (the output kernel stays one wavefront per tile: with the loop over items it needs 333 registers -- one wavefront per
-  // SIMD instead of two -- and ran at 232 us against 149, profiles/r05_favor_lds_projection.txt)
-  k_favor_out<false><<<gps::grid_for(n_work, 4), 256, 0, s>>>(qkv, ld_qkv, proj, m, c, ratio, ptr, tile_graph,
-                                                              tile_row0, n_work, N, H, ctx, ksum, out, mq, D);
+  // (LP form of the output kernel: not used -- with the loop over items it needs 333 registers, one wavefront per SIMD
+  // instead of two, and ran at 232 us against 149, profiles/r05_favor_lds_projection.txt; the chunked form with the context
+  // record staged as well is)
+  static const bool lc_ok = favor_lc_ready(&k_favor_out_lc<true, 4>) && favor_lc_ready(&k_favor_out_lc<false, 4>) &&
+                            favor_lc_ready(&k_favor_out_lc<false, 8>);
+  if (lc_ok && favor_lc(max_tiles, B, "GPS_FAVOR_LC_OUT")) {
+    if (favor_lc_waves("GPS_FAVOR_LC_OUT_WAVES", 8) == 8)
+      k_favor_out_lc<false, 8><<<favor_lc_grid(max_tiles, B, H, 8), 512, LC_LDS_BYTES, s>>>(qkv, ld_qkv, proj, m, c, ratio, ptr, (int)B, N,
+                                                                                           H, ctx, ksum, out, mq, D);
+    else if (favor_lc_prefetch())
+      k_favor_out_lc<true, 4><<<favor_lc_grid(max_tiles, B, H, 4), 256, LC_LDS_BYTES, s>>>(qkv, ld_qkv, proj, m, c, ratio, ptr, (int)B, N,
+                                                                                          H, ctx, ksum, out, mq, D);
+    else
+      k_favor_out_lc<false, 4><<<favor_lc_grid(max_tiles, B, H, 4), 256, LC_LDS_BYTES, s>>>(qkv, ld_qkv, proj, m, c, ratio, ptr, (int)B, N,
+                                                                                           H, ctx, ksum, out, mq, D);
+  } else
+    k_favor_out<false><<<gps::grid_for(n_work, 4), 256, 0, s>>>(qkv, ld_qkv, proj, m, c, ratio, ptr, tile_graph,
+                                                                tile_row0, n_work, N, H, ctx, ksum, out, mq, D);
   return gps::launch_status("gps_favor_fwd");
 }
 
@@ -898,7 +1134,22 @@ int gps_favor_bwd(const float* g_out, const float* qkv, int64_t ld_qkv, const fl
   k_favor_bwd_gd<<<gps::grid_for(N * H * 16, 256), 256, 0, s>>>(g_out, out, D, N, H, gD);
   static const bool lds_ok = favor_lds_ready(&k_favor_bwd_q<true>) && favor_lds_ready(&k_favor_bwd_k<true>);
   const bool lp = lds_ok && favor_lds(n_work);
-  if (lp)
+  static const bool lc_ok = favor_lc_ready(&k_favor_bwd_q_lc<true, 4>) && favor_lc_ready(&k_favor_bwd_q_lc<false, 4>) &&
+                            favor_lc_ready(&k_favor_bwd_q_lc<false, 8>) && favor_lc_ready(&k_favor_bwd_k_lc<true, 4>) &&
+                            favor_lc_ready(&k_favor_bwd_k_lc<false, 4>) && favor_lc_ready(&k_favor_bwd_k_lc<false, 8>);
+  if (lc_ok && favor_lc(max_tiles, B, "GPS_FAVOR_LC_Q")) {
+    const unsigned grid = favor_lc_grid(max_tiles, B, H, 4);
+    if (favor_lc_waves("GPS_FAVOR_LC_Q_WAVES", 4) == 8)
+      k_favor_bwd_q_lc<false, 8><<<favor_lc_grid(max_tiles, B, H, 8), 512, LC_LDS_BYTES, s>>>(g_out, qkv, ld_qkv, proj, m, c, ratio, ptr,
+                                                                                             (int)B, N, H, ctx, ksum, mq, D, gD, d_qkv,
+                                                                                             ld_dqkv);
+    else if (favor_lc_prefetch())
+      k_favor_bwd_q_lc<true, 4><<<grid, 256, LC_LDS_BYTES, s>>>(g_out, qkv, ld_qkv, proj, m, c, ratio, ptr, (int)B, N, H, ctx,
+                                                                ksum, mq, D, gD, d_qkv, ld_dqkv);
+    else
+      k_favor_bwd_q_lc<false, 4><<<grid, 256, LC_LDS_BYTES, s>>>(g_out, qkv, ld_qkv, proj, m, c, ratio, ptr, (int)B, N, H, ctx,
+                                                                 ksum, mq, D, gD, d_qkv, ld_dqkv);
+  } else if (lp)
     k_favor_bwd_q<true><<<favor_lds_grid(n_work, FQ_THREADS), FQ_THREADS, P_LDS_BYTES, s>>>(g_out, qkv, ld_qkv, proj, m, c, ratio, ptr,
                                                                                           tile_graph, tile_row0, n_work, N, H, ctx,
                                                                                           ksum, mq, D, gD, d_qkv, ld_dqkv);
@@ -919,7 +1170,21 @@ int gps_favor_bwd(const float* g_out, const float* qkv, int64_t ld_qkv, const fl
     k_favor_bwd_ctx<<<gps::grid_for(B * H * MT, 4), 256, 0, s>>>(g_out, qkv, ld_qkv, proj, m, c, ratio, ptr, B, N,
                                                                  H, mq, D, gD, g_ctx, g_ksum, 1);
   }
-  if (lp)
+  if (lc_ok && favor_lc(max_tiles, B, "GPS_FAVOR_LC_K")) {
+    const unsigned grid = favor_lc_grid(max_tiles, B, H, 4);
+    if (favor_lc_waves("GPS_FAVOR_LC_K_WAVES", 8) == 8)
+      k_favor_bwd_k_lc<false, 8><<<favor_lc_grid(max_tiles, B, H, 8), 512, LC_LDS_BYTES, s>>>(qkv, ld_qkv, proj, m, c, ratio, ptr, (int)B,
+                                                                                             nmax, H, (const unsigned long long*)kmax,
+                                                                                             g_ctx, g_ksum, d_qkv, ld_dqkv, gM_part);
+    else if (favor_lc_prefetch())
+      k_favor_bwd_k_lc<true, 4><<<grid, 256, LC_LDS_BYTES, s>>>(qkv, ld_qkv, proj, m, c, ratio, ptr, (int)B, nmax, H,
+                                                                (const unsigned long long*)kmax, g_ctx, g_ksum, d_qkv, ld_dqkv,
+                                                                gM_part);
+    else
+      k_favor_bwd_k_lc<false, 4><<<grid, 256, LC_LDS_BYTES, s>>>(qkv, ld_qkv, proj, m, c, ratio, ptr, (int)B, nmax, H,
+                                                                 (const unsigned long long*)kmax, g_ctx, g_ksum, d_qkv, ld_dqkv,
+                                                                 gM_part);
+  } else if (lp)
     k_favor_bwd_k<true><<<favor_lds_grid(n_work, FK_THREADS), FK_THREADS, P_LDS_BYTES, s>>>(qkv, ld_qkv, proj, m, c, ratio, ptr, tile_graph,
                                                                                tile_row0, n_work, nmax, H,
                                                                                (const unsigned long long*)kmax, g_ctx, g_ksum,

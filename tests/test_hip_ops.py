@@ -455,10 +455,12 @@ def test_favor_attention_fwd_bwd(H, sizes):
 
 @pytest.mark.parametrize("H,sizes,m", [(4, [1000, 3, 601, 17, 333], 266), (2, [60, 999, 1, 16], 100)])
 def test_favor_projection_in_lds_is_bit_identical(monkeypatch, H, sizes, m):
-    """csrc/favor.hip round 5: key max, query side and key side of FAVOR+ with the projection staged in LDS and one
-    workgroup per CU walking the work items (GPS_FAVOR_LDS=1; the default from 2,048 work items on) against one wavefront
-    per (16-row tile, head) reading the projection through L2 (=0): the same arithmetic in the same order -- outputs and
-    every gradient element bit-identical, graphs shorter than a tile, feature counts that leave the last tiles empty."""
+    """csrc/favor.hip round 5: the per-tile kernels of FAVOR+ with the projection staged in LDS and one workgroup per CU
+    walking the work items (LP: GPS_FAVOR_LDS=1, the default from 2,048 work items on), and with the context record of a
+    (graph, head) staged next to it, a workgroup per chunk of 4 / 8 tiles of one graph (LC: GPS_FAVOR_LC=1, the default for
+    long graphs), against one wavefront per (16-row tile, head) reading everything through L2: the same arithmetic in the
+    same order -- outputs and every gradient element bit-identical; graphs shorter than a tile, shorter than a chunk,
+    feature counts that leave the last tiles empty."""
     from graphgps_amd.ops import favor_attention
     from oracle.gps_oracle import gaussian_orthogonal_random_matrix
     gen = torch.Generator().manual_seed(23)
@@ -472,15 +474,26 @@ def test_favor_projection_in_lds_is_bit_identical(monkeypatch, H, sizes, m):
     bvec = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
     gi = _index(torch.zeros(2, 0, dtype=torch.long), bvec, ptr)
     res = {}
-    for mode in ("0", "1"):
-        monkeypatch.setenv("GPS_FAVOR_LDS", mode)
+    # plain / projection staged (LP) / projection + the (graph, head) record staged, chunks of 4 or 8 tiles (LC): default
+    # wavefront counts, all kernels at 4 (the register-prefetch form), all at 8, 4 without the prefetch
+    for mode, env in {"plain": dict(GPS_FAVOR_LDS="0", GPS_FAVOR_LC="0"), "lp": dict(GPS_FAVOR_LDS="1", GPS_FAVOR_LC="0"),
+                      "lc": dict(GPS_FAVOR_LDS="1", GPS_FAVOR_LC="1"),
+                      "lc4": dict(GPS_FAVOR_LDS="1", GPS_FAVOR_LC="1", GPS_FAVOR_LC_WAVES="4"),
+                      "lc8": dict(GPS_FAVOR_LDS="1", GPS_FAVOR_LC="1", GPS_FAVOR_LC_WAVES="8"),
+                      "lc4_nopre": dict(GPS_FAVOR_LDS="1", GPS_FAVOR_LC="1", GPS_FAVOR_LC_WAVES="4",
+                                        GPS_FAVOR_LC_PREFETCH="0")}.items():
+        for k in ("GPS_FAVOR_LDS", "GPS_FAVOR_LC", "GPS_FAVOR_LC_WAVES", "GPS_FAVOR_LC_PREFETCH"):
+            monkeypatch.delenv(k, raising=False)
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
         q = qkv.clone().requires_grad_(True)
         out = favor_attention(q, proj, gi, H)
         (out * w).sum().backward()
         res[mode] = (out.detach(), q.grad)
-    assert torch.equal(res["0"][0], res["1"][0])
-    assert torch.equal(res["0"][1], res["1"][1])
-    assert bool(torch.isfinite(res["1"][1]).all()) and float(res["1"][1].abs().max()) > 0
+    for mode in res:
+        assert torch.equal(res["plain"][0], res[mode][0]), mode
+        assert torch.equal(res["plain"][1], res[mode][1]), mode
+    assert bool(torch.isfinite(res["lc"][1]).all()) and float(res["lc"][1].abs().max()) > 0
 
 
 def _drop_mask(seed, R, d, p):

@@ -16,7 +16,7 @@ if __name__ == "__main__":
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
     bad = 0
-    for profile, nb, m in (("CODE2_LONG", 32, 266), ("CODE2_LONG", 3, 266), ("ZINC", 40, 100)):
+    for profile, nb, m in (("CODE2_LONG", 32, 266), ("CODE2_LONG", 3, 266), ("CODE2_REAL", 37, 266), ("ZINC", 40, 100)):
         sizes, ei, bvec, ptr, gen, _ = make_structure(profile, nb, 1234)
         N, H, dh = int(ptr[-1]), 4, 64
         gi = build_graph_index(ei.to(dev), N, len(ptr) - 1, batch_vec=bvec.to(dev), ptr_vec=ptr.to(dev))
@@ -24,21 +24,21 @@ if __name__ == "__main__":
         qkv0 = (torch.randn(N, 3 * H * dh, generator=gen) * 0.7).to(dev)
         w = torch.randn(N, H * dh, generator=gen).to(dev)
         res = {}
-        for mode in ("0", "1", "0again", "01"):
-            os.environ["GPS_FAVOR_LDS"] = mode[0]
+        for mode, (lds, lc) in {"plain": ("0", "0"), "lds": ("1", "0"), "lc": ("1", "1")}.items():
+            os.environ["GPS_FAVOR_LDS"], os.environ["GPS_FAVOR_LC"] = lds, lc
             qkv = qkv0.clone().requires_grad_(True)
             out = favor_attention(qkv, proj, gi, H)
-            os.environ["GPS_FAVOR_LDS"] = mode[-1] if mode != "0again" else "0"
             (out * w).sum().backward()
             torch.cuda.synchronize()
             res[mode] = (out.detach().clone(), qkv.grad.clone())
         inner = H * dh
-        for mode in ("1", "0again", "01"):
-            d = (res[mode][1] - res["0"][1]).abs()
+        for mode in ("lds", "lc"):
+            d = (res[mode][1] - res["plain"][1]).abs()
             parts = [float(d[:, i * inner:(i + 1) * inner].max()) for i in range(3)]
             rows = int((d.max(dim=1).values > 0).sum())
-            print(f"   mode {mode:7s} vs 0: max |d_q| {parts[0]:.3e} |d_k| {parts[1]:.3e} |d_v| {parts[2]:.3e}, rows that differ {rows} of {N}; "
-                  f"max |grad| {float(res['0'][1].abs().max()):.3e}")
+            print(f"   {mode:5s} vs plain: max |d_q| {parts[0]:.3e} |d_k| {parts[1]:.3e} |d_v| {parts[2]:.3e}, rows that differ {rows} of {N}, "
+                  f"out identical {torch.equal(res[mode][0], res['plain'][0])}")
+        res["0"], res["1"] = res["plain"], res["lc"]
         same_o, same_g = torch.equal(res["0"][0], res["1"][0]), torch.equal(res["0"][1], res["1"][1])
         print(f"{profile} x {nb} (N={N}, m={m}): out identical {same_o}, d_qkv identical {same_g}; "
               f"max|out| {float(res['1'][0].abs().max()):.3f}, finite {bool(torch.isfinite(res['1'][1]).all())}")

@@ -1,0 +1,15 @@
+#!/bin/bash
+# Round 5: FAVOR+ query side, context record in LDS: 4 vs 8 wavefronts per workgroup (one workgroup per CU)
+set -u
+O=gpurun_out/r7c; mkdir -p $O
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+GPS_FAVOR_LC_WAVES=8 timeout 300 python tools/favor_lds_check.py > $O/check_w8.txt 2> $O/check.err; echo "check(8 waves) rc=$?"; grep -v "vs plain" $O/check_w8.txt
+export TMPDIR=/tmp; cd /tmp
+for mode in 4 8; do
+  rm -rf /tmp/fv_$mode
+  GPS_FAVOR_LDS=1 GPS_FAVOR_LC=1 GPS_FAVOR_LC_WAVES=$mode FAVOR_ITERS=12 timeout 300 rocprofv3 --kernel-trace --stats -d /tmp/fv_$mode -o fv -- python $R/tools/favor_probe.py > $R/$O/probe_$mode.log 2>&1
+  DB=$(find /tmp/fv_$mode -name "*.db" | head -1)
+  [ -n "$DB" ] && python $R/tools/rocpd_stats.py $DB --top 20 2>&1 | grep -i "favor_bwd_q\|total" | cut -c1-120 > $R/$O/favor_stats_$mode.txt
+  echo "== waves $mode"; cat $R/$O/favor_stats_$mode.txt
+done
