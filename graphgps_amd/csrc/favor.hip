@@ -594,14 +594,27 @@ __device__ __forceinline__ Chunk chunk_of(const int* pre, int B, int H, int ch) 
   }
   return Chunk{lo, ch - cq * H, cq - pre[lo]};          // (the LAST graph whose prefix is <= cq: empty graphs are skipped)
 }
+// pre[g] = chunks of the graphs before g, pre[B] = all of them: counts by all threads, the prefix by the first wavefront
+// (each lane its own run of graphs, the runs joined by a wave scan) -- B up to kLcMaxGraphs costs a few hundred cycles
 __device__ __forceinline__ int quad_prefix(int* pre, const int32_t* __restrict__ ptr, int B, int nw) {
-  if (threadIdx.x == 0) {
-    int a = 0;
-    for (int g = 0; g < B; ++g) {
-      pre[g] = a;
-      a += (((ptr[g + 1] - ptr[g]) + 15) / 16 + nw - 1) / nw;
+  for (int g = threadIdx.x; g < B; g += blockDim.x) pre[g + 1] = (((ptr[g + 1] - ptr[g]) + 15) / 16 + nw - 1) / nw;
+  if (threadIdx.x == 0) pre[0] = 0;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int lane = threadIdx.x, per = (B + 63) / 64;
+    const int lo = min(lane * per, B), hi = min(lo + per, B);
+    int sum = 0;
+    for (int g = lo; g < hi; ++g) sum += pre[g + 1];
+    int incl = sum;
+    for (int o = 1; o < 64; o <<= 1) {
+      const int v = __shfl_up(incl, o);
+      if (lane >= o) incl += v;
     }
-    pre[B] = a;
+    int run = incl - sum;
+    for (int g = lo; g < hi; ++g) {
+      run += pre[g + 1];
+      pre[g + 1] = run;
+    }
   }
   __syncthreads();
   return pre[B];

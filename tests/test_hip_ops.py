@@ -453,7 +453,9 @@ def test_favor_attention_fwd_bwd(H, sizes):
     assert torch.equal(out2, out.detach())
 
 
-@pytest.mark.parametrize("H,sizes,m", [(4, [1000, 3, 601, 17, 333], 266), (2, [60, 999, 1, 16], 100)])
+@pytest.mark.parametrize("H,sizes,m", [(4, [1000, 3, 601, 17, 333], 266), (2, [60, 999, 1, 16], 100),
+                                       (2, [1 + (37 * i * i + 11 * i) % 90 for i in range(300)], 100)],
+                         ids=["long", "ragged", "300-graphs"])
 def test_favor_projection_in_lds_is_bit_identical(monkeypatch, H, sizes, m):
     """csrc/favor.hip round 5: the per-tile kernels of FAVOR+ with the projection staged in LDS and one workgroup per CU
     walking the work items (LP: GPS_FAVOR_LDS=1, the default from 2,048 work items on), and with the context record of a
