@@ -365,7 +365,12 @@ int gps_segment_max_len(const int32_t* ptr, int64_t B, int32_t* nmax, gps_stream
 int gps_segment_max_len_real(const int32_t* ptr, int64_t B, const int32_t* b_real, int32_t* nmax, gps_stream_t stream);
 /* ABI v6: `ws` (gps_favor_workspace_floats(N, B, H) floats, or NULL): partial context records -- the rows of a graph are
  * dealt to several wavefronts per (graph, head, feature tile) and summed in slice order (deterministic); without it one
- * wavefront walks all rows of its graph (the round-1 form). */
+ * wavefront walks all rows of its graph (the round-1 form).
+ * Round 5 (no ABI change): the per-tile kernels behind both calls run in one of three forms chosen from the launch shape
+ * -- one wavefront per (16-row tile, head); one workgroup per CU with the projection staged in LDS; workgroups over chunks
+ * of 4 / 8 tiles of one graph with the (graph, head) context record staged as well (long graphs, B <= 1024).  All three do
+ * the same arithmetic in the same order: results are bit-identical whichever is taken.  gM_part is indexed by the tile
+ * map of gps_graph_index_build (slot of tile t of graph g: (ptr[g] >> 4) + g + t). */
 size_t gps_favor_workspace_floats(int64_t N, int64_t B, int H);
 int gps_favor_fwd(const float* qkv, int64_t ld_qkv, const float* proj, int m, const int32_t* ptr,
                   const int32_t* nmax, const int32_t* tile_graph, const int32_t* tile_row0,
