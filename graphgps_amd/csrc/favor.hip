@@ -107,8 +107,12 @@ __device__ __forceinline__ float dec_f32(uint32_t e) {
 // whole projection P [m, 64] -- 70 KB that every wavefront pulled through L2 once or twice per tile (6,400 tiles at code2
 // sizes: 0.9-1.3 GB per launch), in a chain load -> 16-step contraction -> exp -> contraction per feature tile.  With LP the
 // launch is ONE workgroup per CU (12-16 wavefronts) that copies P into LDS once -- rows past m zero, row pitch 68 floats:
-// conflict-free both for the 16-floats-of-a-row reads (lane i: row i, pitch 272 B = 17 x 16 B) and for the one-float-per-
-// lane column reads (rows 4 grp + r: 68 x 4 = 16 banks apart) -- and then walks the work items, wavefront w taking items
+// conflict-free for the one-float-per-lane column reads (rows 4 grp + r: 68 x 4 = 16 banks apart); the 16-floats-of-a-row
+// reads are NOT quite (measured, profiles/r05_pmc_favor.txt: SQ_LDS_BANK_CONFLICT ~1.5 cycles per LDS instruction in the
+// query-side kernel = 3 % of its wave cycles, 0.7 % spent waiting on LDS): a ds_read_b128 is served in four NON-contiguous
+// 16-lane groups ({0-3, 12-15, 20-27}, ...) that mix two column blocks, which at this pitch puts half of a group's lanes two
+// to a slot.  The planes layout of the staged context kernels below ([column block][row][20 floats]) avoids that; P was
+// left as it is for the 1-2 % it would buy -- and then walks the work items, wavefront w taking items
 // w, w + W, w + 2 W, ...  Same loads of everything else, same arithmetic in the same order: bit-identical results.
 constexpr int PP = 68;                          // LDS row pitch of the staged projection (floats)
 constexpr int P_LDS_BYTES = 16 * MT * PP * 4;   // 73,984
@@ -280,7 +284,152 @@ __global__ __launch_bounds__(256) void k_favor_ctx(
       *reinterpret_cast<float4*>(cp + et * 16 + 4 * grp) =
           make_float4(acc[et][0], acc[et][1], acc[et][2], acc[et][3]);
     // (the padded rows' closed-form term: here when the graph is one slice, else by k_favor_sum_parts)
-    if (grp == 0) ksum[(int64_t)gh * 272 + f] = S > 1 ? ks : ks + (float)pad * (ratio * (expf(-M) + FEPS));
+    if (grp == 0) ksum[(int64_t)gh * 272 + f] = S > 1 ? ks : fmaf((float)pad, ratio * (expf(-M) + FEPS), ks);
+  }
+}
+
+// ---- round 5: the two context kernels with their rows staged in LDS (k_favor_ctx_st / k_favor_bwd_ctx_st) ---------------
+// One wavefront per (graph, head, feature tile, slice) meant that the 17 feature-tile wavefronts of a (graph, head, slice)
+// -- spread over 17 workgroups -- each pulled the same key and value rows: 420 MB fetched per launch for 52 MB of rows
+// (rocprofv3 FETCH_SIZE, profiles/r05_pmc_favor.txt), ~3.3 TB/s at the fabric.  Here ONE workgroup of W wavefronts (12; 9 compiled for the A/B) owns a
+// (graph, head, slice): every step its threads copy the next 16-row block of the operands into LDS (double-buffered, one
+// barrier per step) and wavefront j runs feature tiles j and j + W against the staged block.  Layouts: the operand that
+// is read 16-floats-of-a-row per lane (keys / queries) as four planes [column block][row][20 floats] -- the four 16-lane
+// groups of a ds_read_b128 then each see 16 different rows at 5 slots apart: conflict-free --, the operand that is read
+// one float per lane (values / g_out) as [row][68 floats].  Rows past the slice are copies of its last row, as the
+// clamped loads of the per-wavefront kernels read them.  Per record the same arithmetic in the same row order: the
+// partial records -- and everything downstream -- are bit-identical.
+constexpr int CS_RP = 20;                       // row pitch inside a plane (floats)
+constexpr int CS_PLANE = 16 * CS_RP;            // 320 floats per column block
+constexpr int CS_A = 4 * CS_PLANE;              // 1280: the row16 operand of one block
+constexpr int CS_B = 16 * PP;                   // 1088: the one-float-per-lane operand
+constexpr int CS_X = 64;                        // per-row scalars (backward: mq, 1 / D, gD; 16 each)
+constexpr int CS_BUF = CS_A + CS_B + CS_X;      // floats per stage buffer
+constexpr int CS_LDS_BYTES = 2 * CS_BUF * 4;
+
+__device__ __forceinline__ void cs_row16(const float* a_plane, int i, int grp, float sc, float (&dst)[KPL]) {
+  const float4* q = reinterpret_cast<const float4*>(a_plane + grp * CS_PLANE + i * CS_RP);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) {
+    const float4 v = q[s];
+    dst[4 * s + 0] = v.x * sc; dst[4 * s + 1] = v.y * sc;
+    dst[4 * s + 2] = v.z * sc; dst[4 * s + 3] = v.w * sc;
+  }
+}
+// thread t of the first 512 copies one float4: t < 256 -> operand A (row (t >> 4) & 15, 16-byte column t & 15),
+// else operand B
+// (threads past 511 load a valid address too and drop it: an unconditional load)
+__device__ __forceinline__ float4 cs_load(const float* __restrict__ a_src, int64_t a_ld, const float* __restrict__ b_src,
+                                          int64_t b_ld, int row0, int n1) {
+  const int t = threadIdx.x;
+  const int row = clampi(row0 + ((t >> 4) & 15), n1 - 1), c4 = t & 15;
+  const float* src = (t & 256) == 0 ? a_src + (int64_t)row * a_ld : b_src + (int64_t)row * b_ld;
+  return reinterpret_cast<const float4*>(src)[c4];
+}
+__device__ __forceinline__ void cs_store(float* buf, float4 v) {
+  const int t = threadIdx.x;
+  if (t < 512) {
+    const int row = (t >> 4) & 15, c4 = t & 15;
+    float* dst = t < 256 ? buf + (c4 >> 2) * CS_PLANE + row * CS_RP + 4 * (c4 & 3) : buf + CS_A + row * PP + 4 * c4;
+    *reinterpret_cast<float4*>(dst) = v;
+  }
+}
+
+template <int CS_WAVES>
+__global__ __launch_bounds__(64 * CS_WAVES) void k_favor_ctx_st(
+    const float* __restrict__ qkv, int64_t ld, const float* __restrict__ P, int m, float c,
+    float ratio, const int32_t* __restrict__ ptr, const int32_t* __restrict__ nmax_dev, int64_t B,
+    int H, const unsigned long long* __restrict__ kmax, float* __restrict__ ctx,
+    float* __restrict__ ksum, int S) {
+  extern __shared__ __attribute__((aligned(16))) float lds_proj[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int u = blockIdx.x;                                   // (graph-head, slice), slice fastest
+  const int sl = u % S, gh = u / S;
+  const int g = gh / H, h = gh - g * H;
+  const int n0 = ptr[g], n1_all = ptr[g + 1];
+  const int per = ((n1_all - n0 + 15) / 16 + S - 1) / S * 16;       // rows per slice (whole blocks), as k_favor_ctx
+  const int k0 = min(n1_all, n0 + sl * per), n1 = min(n1_all, k0 + per);
+  if (S > 1) {
+    ctx += (int64_t)sl * B * H * 272 * DH;
+    ksum += (int64_t)sl * B * H * 272;
+  }
+  const int i = lane & 15, grp = lane >> 4;
+  const int inner = H * DH;
+  const int pad = max(nmax_dev[0] - (n1_all - n0), 0);
+  const float M = key_max_M(kmax, gh, pad);
+  const int nt = wave + CS_WAVES < MT ? 2 : 1;                // feature tiles of this wavefront: wave, wave + W
+  float pv[2][KPL];
+  f32x4 acc[2][4];
+  float ks[2] = {0.0f, 0.0f};
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int f = (wave + t * CS_WAVES) * 16 + i;
+    load_row16(P + (int64_t)clampi(f, m - 1) * DH + 16 * grp, f < m && t < nt, 1.0f, pv[t]);
+#pragma unroll
+    for (int et = 0; et < 4; ++et) acc[t][et] = zero4();
+  }
+  const float* ksrc = qkv + inner + h * DH;
+  const float* vsrc = qkv + 2 * inner + h * DH;
+  // three row blocks in flight through registers (a block's loads are issued two and a half steps before it is written to
+  // LDS).  Measured the same as one block in flight (119 us): a step's ~4.7 us are its arithmetic -- per SIMD 4-5 feature
+  // tiles x (a 16-long dependent 16x16x4 chain + 16 more + ~200 vector instructions), serialised by the barrier per step
+  float4 nx0 = make_float4(0.f, 0.f, 0.f, 0.f), nx1 = nx0, nx2 = nx0;
+  if (k0 < n1) {
+    nx0 = cs_load(ksrc, ld, vsrc, ld, k0, n1);
+    cs_store(lds_proj, nx0);
+  }
+  if (k0 + 16 < n1) nx0 = cs_load(ksrc, ld, vsrc, ld, k0 + 16, n1);
+  if (k0 + 32 < n1) nx1 = cs_load(ksrc, ld, vsrc, ld, k0 + 32, n1);
+  __syncthreads();
+  int step = 0;
+  for (int kb = k0; kb < n1; kb += 16, ++step) {
+    const float* buf = lds_proj + (step & 1) * CS_BUF;
+    if (kb + 48 < n1) nx2 = cs_load(ksrc, ld, vsrc, ld, kb + 48, n1);
+    float kv[KPL];
+    cs_row16(buf, i, grp, kb + i < n1 ? c : 0.0f, kv);
+    const float nrm = group_sum(sumsq16(kv));       // |c k|^2 of row (l&15)
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      if (t < nt) {
+        const int f = (wave + t * CS_WAVES) * 16 + i;
+        f32x4 dd = mm_rows(kv, pv[t], zero4());     // [key 4g+r][feature l&15]
+        f32x4 phi;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int key = kb + 4 * grp + r;
+          const float dg = 0.5f * __shfl(nrm, 4 * grp + r);
+          const bool ok = key < n1 && f < m;
+          phi[r] = ok ? ratio * (expf(dd[r] - dg - M) + FEPS) : 0.0f;
+          ks[t] += phi[r];
+        }
+#pragma unroll
+        for (int et = 0; et < 4; ++et)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float vv = buf[CS_A + (4 * grp + r) * PP + et * 16 + i];
+            acc[t][et] = mfma16(vv, phi[r], acc[t][et]);      // ctx^T[e 4g+r'][feature l&15]
+          }
+      }
+    }
+    if (kb + 16 < n1) cs_store(lds_proj + ((step + 1) & 1) * CS_BUF, nx0);
+    __syncthreads();
+    nx0 = nx1;
+    nx1 = nx2;
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    if (t < nt) {
+      const int f = (wave + t * CS_WAVES) * 16 + i;
+      const float kt = group_sum(ks[t]);
+      if (f < m) {
+        float* cp = ctx + ((int64_t)gh * 272 + f) * DH;
+#pragma unroll
+        for (int et = 0; et < 4; ++et)
+          *reinterpret_cast<float4*>(cp + et * 16 + 4 * grp) =
+              make_float4(acc[t][et][0], acc[t][et][1], acc[t][et][2], acc[t][et][3]);
+        if (grp == 0) ksum[(int64_t)gh * 272 + f] = S > 1 ? kt : fmaf((float)pad, ratio * (expf(-M) + FEPS), kt);
+      }
+    }
   }
 }
 
@@ -769,7 +918,7 @@ __global__ __launch_bounds__(256) void k_favor_bwd_ctx(
       const float mqv = mq_in[qi], Dv = D_in[qi], gDv = gD_in[qi];
       phi[r] = ok ? ratio * (expf(dd[r] - dg - mqv) + FEPS) : 0.0f;
       invD[r] = qq < n1 ? 1.0f / Dv : 0.0f;
-      gks += gDv * phi[r];                                         // (phi = 0 past the slice)
+      gks = fmaf(gDv, phi[r], gks);                                // (phi = 0 past the slice; explicit: both forms of the kernel round alike)
     }
 #pragma unroll
     for (int et = 0; et < 4; ++et)
@@ -788,6 +937,130 @@ __global__ __launch_bounds__(256) void k_favor_bwd_ctx(
       *reinterpret_cast<float4*>(cp + et * 16 + 4 * grp) =
           make_float4(acc[et][0], acc[et][1], acc[et][2], acc[et][3]);
     if (grp == 0) g_ksum[(int64_t)gh * 272 + f] = gks;
+  }
+}
+
+// the backward context kernel in the staged form (see k_favor_ctx_st): operand A = the query rows, operand B = the g_out
+// rows, and three scalars per row (mq, D, gD)
+template <int CS_WAVES>
+__global__ __launch_bounds__(64 * CS_WAVES) void k_favor_bwd_ctx_st(
+    const float* __restrict__ g_out, const float* __restrict__ qkv, int64_t ld,
+    const float* __restrict__ P, int m, float c, float ratio, const int32_t* __restrict__ ptr,
+    int64_t B, int64_t N, int H, const float* __restrict__ mq_in, const float* __restrict__ D_in,
+    const float* __restrict__ gD_in, float* __restrict__ g_ctx, float* __restrict__ g_ksum, int S) {
+  extern __shared__ __attribute__((aligned(16))) float lds_proj[];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int u = blockIdx.x;
+  const int sl = u % S, gh = u / S;
+  const int g = gh / H, h = gh - g * H;
+  const int n_beg = ptr[g], n_end = ptr[g + 1];
+  const int per = ((n_end - n_beg + 15) / 16 + S - 1) / S * 16;
+  const int n0 = min(n_end, n_beg + sl * per), n1 = min(n_end, n0 + per);
+  if (S > 1) {
+    g_ctx += (int64_t)sl * B * H * 272 * DH;
+    g_ksum += (int64_t)sl * B * H * 272;
+  }
+  const int i = lane & 15, grp = lane >> 4;
+  const int inner = H * DH;
+  const int nt = wave + CS_WAVES < MT ? 2 : 1;
+  float pv[2][KPL];
+  f32x4 acc[2][4];
+  float gks[2] = {0.0f, 0.0f};
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int f = (wave + t * CS_WAVES) * 16 + i;
+    load_row16(P + (int64_t)clampi(f, m - 1) * DH + 16 * grp, f < m && t < nt, 1.0f, pv[t]);
+#pragma unroll
+    for (int et = 0; et < 4; ++et) acc[t][et] = zero4();
+  }
+  const float* qsrc = qkv + h * DH;
+  const float* gsrc = g_out + h * DH;
+  // threads 512..559 carry the per-row scalars of the block: mq | D | gD, 16 rows each
+  const int xt = (int)threadIdx.x - 512;
+  const bool has_x = xt >= 0 && xt < 48;
+  const float* const xsrc = (xt < 16 ? mq_in : xt < 32 ? D_in : gD_in) + (int64_t)h * N;
+  float4 nx0 = make_float4(0.f, 0.f, 0.f, 0.f), nx1 = nx0, nx2 = nx0;      // three row blocks in flight (see k_favor_ctx_st)
+  float xs0 = 0.0f, xs1 = 0.0f, xs2 = 0.0f;
+  if (n0 < n1) {
+    nx0 = cs_load(qsrc, ld, gsrc, inner, n0, n1);
+    xs0 = xsrc[clampi(n0 + (xt & 15), n1 - 1)];
+    cs_store(lds_proj, nx0);
+    if (has_x) lds_proj[CS_A + CS_B + xt] = xs0;
+  }
+  if (n0 + 16 < n1) {
+    nx0 = cs_load(qsrc, ld, gsrc, inner, n0 + 16, n1);
+    xs0 = xsrc[clampi(n0 + 16 + (xt & 15), n1 - 1)];
+  }
+  if (n0 + 32 < n1) {
+    nx1 = cs_load(qsrc, ld, gsrc, inner, n0 + 32, n1);
+    xs1 = xsrc[clampi(n0 + 32 + (xt & 15), n1 - 1)];
+  }
+  __syncthreads();
+  int step = 0;
+  for (int qb = n0; qb < n1; qb += 16, ++step) {
+    const float* buf = lds_proj + (step & 1) * CS_BUF;
+    if (qb + 48 < n1) {
+      nx2 = cs_load(qsrc, ld, gsrc, inner, qb + 48, n1);
+      xs2 = xsrc[clampi(qb + 48 + (xt & 15), n1 - 1)];
+    }
+    float qv[KPL];
+    cs_row16(buf, i, grp, qb + i < n1 ? c : 0.0f, qv);
+    const float nrm = group_sum(sumsq16(qv));
+    float dg[4], mqv[4], invD[4], gDv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int qq = qb + 4 * grp + r;
+      dg[r] = 0.5f * __shfl(nrm, 4 * grp + r);
+      const float* x = buf + CS_A + CS_B + 4 * grp + r;
+      mqv[r] = x[0];
+      invD[r] = qq < n1 ? 1.0f / x[16] : 0.0f;
+      gDv[r] = x[32];
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      if (t < nt) {
+        const int f = (wave + t * CS_WAVES) * 16 + i;
+        const f32x4 dd = mm_rows(qv, pv[t], zero4());     // [query 4g+r][feature l&15]
+        f32x4 phi;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int qq = qb + 4 * grp + r;
+          const bool ok = qq < n1 && f < m;
+          phi[r] = ok ? ratio * (expf(dd[r] - dg[r] - mqv[r]) + FEPS) : 0.0f;
+          gks[t] = fmaf(gDv[r], phi[r], gks[t]);                     // (phi = 0 past the slice)
+        }
+#pragma unroll
+        for (int et = 0; et < 4; ++et)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float gv = buf[CS_A + (4 * grp + r) * PP + et * 16 + i] * invD[r];   // (invD = 0 past the slice)
+            acc[t][et] = mfma16(gv, phi[r], acc[t][et]);     // g_ctx^T[e 4g+r'][feature l&15]
+          }
+      }
+    }
+    if (qb + 16 < n1) {
+      float* nb = lds_proj + ((step + 1) & 1) * CS_BUF;
+      cs_store(nb, nx0);
+      if (has_x) nb[CS_A + CS_B + xt] = xs0;
+    }
+    __syncthreads();
+    nx0 = nx1; xs0 = xs1;
+    nx1 = nx2; xs1 = xs2;
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    if (t < nt) {
+      const int f = (wave + t * CS_WAVES) * 16 + i;
+      const float gk = group_sum(gks[t]);
+      if (f < m) {
+        float* cp = g_ctx + ((int64_t)gh * 272 + f) * DH;
+#pragma unroll
+        for (int et = 0; et < 4; ++et)
+          *reinterpret_cast<float4*>(cp + et * 16 + 4 * grp) =
+              make_float4(acc[t][et][0], acc[t][et][1], acc[t][et][2], acc[t][et][3]);
+        if (grp == 0) g_ksum[(int64_t)gh * 272 + f] = gk;
+      }
+    }
   }
 }
 
@@ -1018,6 +1291,30 @@ static bool favor_lc(int64_t max_tiles, int64_t B, const char* one = nullptr) {
 // wavefronts per workgroup of a chunked kernel: 4 (the form that prefetches the next record through registers) or 8 (two
 // per SIMD, no prefetch).  Measured (profiles/r05_favor_lds_projection.txt, code2-long layer): query side 208 vs 217 us, key
 // side 253 vs 228, output 141 vs 128 -- hence the defaults below; GPS_FAVOR_LC_{Q,K,OUT}_WAVES / GPS_FAVOR_LC_WAVES override.
+// the context kernels with their rows staged in LDS (k_favor_*ctx_st): GPS_FAVOR_CTX_LDS=0 never, =1 always; default: graphs
+// of at least 64 rows on average (a workgroup per (graph, head, slice) needs a few row blocks to amortise its start)
+static bool favor_ctx_staged(int64_t N, int64_t B) {
+  const char* e = getenv("GPS_FAVOR_CTX_LDS");
+  if (e && *e) return atoi(e) != 0;
+  return B > 0 && N / B >= 64;
+}
+// wavefronts per workgroup of the staged context kernels: the 17 feature tiles are dealt w, w + W; 12 puts 5 / 4 / 4 / 4
+// tiles on the four SIMDs, 9 (GPS_FAVOR_CTX_WAVES=9) 6 / 4 / 4 / 3 -- measured the same (119 / 132 us); 16 needs a
+// 128-register cap, spills and loses (137 / 170)
+static int favor_ctx_waves() {
+  const char* e = getenv("GPS_FAVOR_CTX_WAVES");
+  return e && atoi(e) == 9 ? 9 : 12;
+}
+template <typename... A>
+static void launch_ctx_st(int waves, unsigned grid, hipStream_t s, A... a) {
+  if (waves == 9) k_favor_ctx_st<9><<<grid, 576, CS_LDS_BYTES, s>>>(a...);
+  else k_favor_ctx_st<12><<<grid, 768, CS_LDS_BYTES, s>>>(a...);
+}
+template <typename... A>
+static void launch_bwd_ctx_st(int waves, unsigned grid, hipStream_t s, A... a) {
+  if (waves == 9) k_favor_bwd_ctx_st<9><<<grid, 576, CS_LDS_BYTES, s>>>(a...);
+  else k_favor_bwd_ctx_st<12><<<grid, 768, CS_LDS_BYTES, s>>>(a...);
+}
 static int favor_lc_waves(const char* one, int dflt) {
   const char* e = getenv(one);
   if (!(e && *e)) e = getenv("GPS_FAVOR_LC_WAVES");
@@ -1092,13 +1389,21 @@ int gps_favor_fwd(const float* qkv, int64_t ld_qkv, const float* proj, int m, co
                                                                  n_work, H, (unsigned long long*)kmax);
   int S = favor_slices(N, B, H);
   if (!ws || ws_floats < (size_t)S * B * H * 272 * (DH + 1)) S = 1;       // no workspace: one wavefront per record
+  const bool staged = favor_ctx_staged(N, B);
   if (S > 1) {
     float* cpart = ws;
     float* kpart = ws + (size_t)S * B * H * 272 * DH;
-    k_favor_ctx<<<gps::grid_for(B * H * MT * S, 4), 256, 0, s>>>(qkv, ld_qkv, proj, m, c, ratio, ptr, nmax, B, H,
-                                                                 (const unsigned long long*)kmax, cpart, kpart, S);
+    if (staged)
+      launch_ctx_st(favor_ctx_waves(), (unsigned)(B * H * S), s, qkv, ld_qkv, proj, m, c, ratio, ptr, nmax, B, H,
+                    (const unsigned long long*)kmax, cpart, kpart, S);
+    else
+      k_favor_ctx<<<gps::grid_for(B * H * MT * S, 4), 256, 0, s>>>(qkv, ld_qkv, proj, m, c, ratio, ptr, nmax, B, H,
+                                                                   (const unsigned long long*)kmax, cpart, kpart, S);
     k_favor_sum_parts<<<gps::grid_for(B * H * 272 * (DH / 4 + 1), 256), 256, 0, s>>>(
         cpart, kpart, S, B * H, m, ratio, ptr, nmax, H, (const unsigned long long*)kmax, ctx, ksum);
+  } else if (staged) {
+    launch_ctx_st(favor_ctx_waves(), (unsigned)(B * H), s, qkv, ld_qkv, proj, m, c, ratio, ptr, nmax, B, H,
+                  (const unsigned long long*)kmax, ctx, ksum, 1);
   } else {
     k_favor_ctx<<<gps::grid_for(B * H * MT, 4), 256, 0, s>>>(qkv, ld_qkv, proj, m, c, ratio, ptr, nmax, B, H,
                                                              (const unsigned long long*)kmax, ctx, ksum, 1);
@@ -1172,13 +1477,21 @@ int gps_favor_bwd(const float* g_out, const float* qkv, int64_t ld_qkv, const fl
                                                                   ld_dqkv);
   int S = favor_slices(N, B, H);
   if (!ws || ws_floats < (size_t)S * B * H * 272 * (DH + 1)) S = 1;
+  const bool staged = favor_ctx_staged(N, B);
   if (S > 1) {
     float* cpart = ws;
     float* kpart = ws + (size_t)S * B * H * 272 * DH;
-    k_favor_bwd_ctx<<<gps::grid_for(B * H * MT * S, 4), 256, 0, s>>>(g_out, qkv, ld_qkv, proj, m, c, ratio, ptr, B, N,
-                                                                     H, mq, D, gD, cpart, kpart, S);
+    if (staged)
+      launch_bwd_ctx_st(favor_ctx_waves(), (unsigned)(B * H * S), s, g_out, qkv, ld_qkv, proj, m, c, ratio, ptr, B, N, H, mq, D, gD,
+                        cpart, kpart, S);
+    else
+      k_favor_bwd_ctx<<<gps::grid_for(B * H * MT * S, 4), 256, 0, s>>>(g_out, qkv, ld_qkv, proj, m, c, ratio, ptr, B, N,
+                                                                       H, mq, D, gD, cpart, kpart, S);
     k_favor_sum_parts<<<gps::grid_for(B * H * 272 * (DH / 4 + 1), 256), 256, 0, s>>>(
         cpart, kpart, S, B * H, m, ratio, ptr, nmax, H, nullptr, g_ctx, g_ksum);
+  } else if (staged) {
+    launch_bwd_ctx_st(favor_ctx_waves(), (unsigned)(B * H), s, g_out, qkv, ld_qkv, proj, m, c, ratio, ptr, B, N, H, mq, D, gD,
+                      g_ctx, g_ksum, 1);
   } else {
     k_favor_bwd_ctx<<<gps::grid_for(B * H * MT, 4), 256, 0, s>>>(g_out, qkv, ld_qkv, proj, m, c, ratio, ptr, B, N,
                                                                  H, mq, D, gD, g_ctx, g_ksum, 1);

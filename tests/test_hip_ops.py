@@ -478,13 +478,17 @@ def test_favor_projection_in_lds_is_bit_identical(monkeypatch, H, sizes, m):
     res = {}
     # plain / projection staged (LP) / projection + the (graph, head) record staged, chunks of 4 or 8 tiles (LC): default
     # wavefront counts, all kernels at 4 (the register-prefetch form), all at 8, 4 without the prefetch
-    for mode, env in {"plain": dict(GPS_FAVOR_LDS="0", GPS_FAVOR_LC="0"), "lp": dict(GPS_FAVOR_LDS="1", GPS_FAVOR_LC="0"),
-                      "lc": dict(GPS_FAVOR_LDS="1", GPS_FAVOR_LC="1"),
+    # (GPS_FAVOR_CTX_LDS: the two context kernels one wavefront per (graph, head, feature tile, slice) / a workgroup per
+    # (graph, head, slice) with the rows staged in LDS)
+    for mode, env in {"plain": dict(GPS_FAVOR_LDS="0", GPS_FAVOR_LC="0", GPS_FAVOR_CTX_LDS="0"),
+                      "ctx_staged": dict(GPS_FAVOR_LDS="0", GPS_FAVOR_LC="0", GPS_FAVOR_CTX_LDS="1"),
+                      "lp": dict(GPS_FAVOR_LDS="1", GPS_FAVOR_LC="0", GPS_FAVOR_CTX_LDS="0"),
+                      "lc": dict(GPS_FAVOR_LDS="1", GPS_FAVOR_LC="1", GPS_FAVOR_CTX_LDS="1"),
                       "lc4": dict(GPS_FAVOR_LDS="1", GPS_FAVOR_LC="1", GPS_FAVOR_LC_WAVES="4"),
-                      "lc8": dict(GPS_FAVOR_LDS="1", GPS_FAVOR_LC="1", GPS_FAVOR_LC_WAVES="8"),
+                      "lc8": dict(GPS_FAVOR_LDS="1", GPS_FAVOR_LC="1", GPS_FAVOR_LC_WAVES="8", GPS_FAVOR_CTX_LDS="0"),
                       "lc4_nopre": dict(GPS_FAVOR_LDS="1", GPS_FAVOR_LC="1", GPS_FAVOR_LC_WAVES="4",
                                         GPS_FAVOR_LC_PREFETCH="0")}.items():
-        for k in ("GPS_FAVOR_LDS", "GPS_FAVOR_LC", "GPS_FAVOR_LC_WAVES", "GPS_FAVOR_LC_PREFETCH"):
+        for k in ("GPS_FAVOR_LDS", "GPS_FAVOR_LC", "GPS_FAVOR_LC_WAVES", "GPS_FAVOR_LC_PREFETCH", "GPS_FAVOR_CTX_LDS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)

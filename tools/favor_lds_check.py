@@ -26,6 +26,7 @@ if __name__ == "__main__":
         res = {}
         for mode, (lds, lc) in {"plain": ("0", "0"), "lds": ("1", "0"), "lc": ("1", "1")}.items():
             os.environ["GPS_FAVOR_LDS"], os.environ["GPS_FAVOR_LC"] = lds, lc
+            os.environ["GPS_FAVOR_CTX_LDS"] = "0" if mode == "plain" else "1"      # context kernels: per-wavefront / staged
             qkv = qkv0.clone().requires_grad_(True)
             out = favor_attention(qkv, proj, gi, H)
             (out * w).sum().backward()
