@@ -303,7 +303,7 @@ constexpr int CS_RP = 20;                       // row pitch inside a plane (flo
 constexpr int CS_PLANE = 16 * CS_RP;            // 320 floats per column block
 constexpr int CS_A = 4 * CS_PLANE;              // 1280: the row16 operand of one block
 constexpr int CS_B = 16 * PP;                   // 1088: the one-float-per-lane operand
-constexpr int CS_X = 64;                        // per-row scalars (backward: mq, 1 / D, gD; 16 each)
+constexpr int CS_X = 64;                        // per-row scalars (backward: mq, D, gD; 16 each)
 constexpr int CS_BUF = CS_A + CS_B + CS_X;      // floats per stage buffer
 constexpr int CS_LDS_BYTES = 2 * CS_BUF * 4;
 
