@@ -1291,12 +1291,15 @@ static bool favor_lc(int64_t max_tiles, int64_t B, const char* one = nullptr) {
 // wavefronts per workgroup of a chunked kernel: 4 (the form that prefetches the next record through registers) or 8 (two
 // per SIMD, no prefetch).  Measured (profiles/r05_favor_lds_projection.txt, code2-long layer): query side 208 vs 217 us, key
 // side 253 vs 228, output 141 vs 128 -- hence the defaults below; GPS_FAVOR_LC_{Q,K,OUT}_WAVES / GPS_FAVOR_LC_WAVES override.
-// the context kernels with their rows staged in LDS (k_favor_*ctx_st): GPS_FAVOR_CTX_LDS=0 never, =1 always; default: graphs
-// of at least 64 rows on average (a workgroup per (graph, head, slice) needs a few row blocks to amortise its start)
+// the context kernels with their rows staged in LDS (k_favor_*ctx_st): GPS_FAVOR_CTX_LDS=0 never, =1 always; default: LONG
+// graphs only (>= 384 rows on average).  Measured (profiles/r05_favor_ctx_staged.txt): 600-1000-row graphs 129 -> 119 and
+// 158 -> 132 us, but at the code2 dataset's own sizes (~125 rows per graph) the staged form LOSES -- 44 -> 55 / 53 -> 61 us
+// at 32 graphs, 163 -> 204 / 199 -> 228 at 128: a workgroup per (graph, head, slice) has 17 times fewer units to spread
+// over the chip than a wavefront per feature tile, and 8 row blocks do not amortise its start.
 static bool favor_ctx_staged(int64_t N, int64_t B) {
   const char* e = getenv("GPS_FAVOR_CTX_LDS");
   if (e && *e) return atoi(e) != 0;
-  return B > 0 && N / B >= 64;
+  return B > 0 && N / B >= 384;
 }
 // wavefronts per workgroup of the staged context kernels: the 17 feature tiles are dealt w, w + W; 12 puts 5 / 4 / 4 / 4
 // tiles on the four SIMDs, 9 (GPS_FAVOR_CTX_WAVES=9) 6 / 4 / 4 / 3 -- measured the same (119 / 132 us); 16 needs a

@@ -18,7 +18,9 @@ if __name__ == "__main__":
     from oracle.gps_oracle import gaussian_orthogonal_random_matrix      # (test infrastructure: the fixed projection)
     dev = torch.device("cuda:0")
     torch.manual_seed(0)
-    sizes, ei, bvec, ptr, gen, _ = make_structure("CODE2_LONG", 32, 1234)
+    # FAVOR_PROFILE / FAVOR_GRAPHS: another batch shape (CODE2_REAL = the dataset's own sizes, ~125 nodes per graph)
+    sizes, ei, bvec, ptr, gen, _ = make_structure(os.environ.get("FAVOR_PROFILE", "CODE2_LONG"),
+                                                  int(os.environ.get("FAVOR_GRAPHS", "32")), 1234)
     N, H, dh, m = int(ptr[-1]), 4, 64, 266
     gi = build_graph_index(ei.to(dev), N, len(ptr) - 1, batch_vec=bvec.to(dev), ptr_vec=ptr.to(dev))
     proj = gaussian_orthogonal_random_matrix(m, dh).to(dev)
