@@ -101,3 +101,63 @@ def test_streaming_wgrad_stage_layout():
                     assert lds[row, col] == row * 128 + col
                     banks.add(((row * 512 + col * 4) // 4) % 64)
                 assert len(banks) == 32
+
+
+def _b128_conflict_cycles(byte_addr_of_lane):
+    """Extra LDS cycles of one ds_read_b128 (what SQ_LDS_BANK_CONFLICT counts): per lane group, the busiest 16-byte slot's
+    number of distinct addresses minus one."""
+    extra = 0
+    for grp in B128_GROUPS:
+        per_slot = {}
+        for l in grp:
+            per_slot.setdefault((byte_addr_of_lane[l] // 16) % 16, set()).add(byte_addr_of_lane[l])
+        extra += max(len(v) for v in per_slot.values()) - 1
+    return extra
+
+
+def _b32_conflict_cycles(byte_addr_of_lane):
+    """ds_read_b32: two 32-lane groups, bank = (a / 4) mod 32."""
+    extra = 0
+    for half in (range(0, 32), range(32, 64)):
+        per_bank = {}
+        for l in half:
+            per_bank.setdefault((byte_addr_of_lane[l] // 4) % 32, set()).add(byte_addr_of_lane[l])
+        extra += max(len(v) for v in per_bank.values()) - 1
+    return extra
+
+
+def test_favor_staging_layouts():
+    """csrc/favor.hip, round 5.  Lane l = (i = l & 15, grp = l >> 4).  (1) The staged projection / context record: rows of 64
+    floats at a pitch of 68.  The one-float-per-lane column reads (row 4 grp + r, column 16 t + i) are conflict-free; the
+    16-floats-of-a-row reads (row i, columns 16 grp .. 16 grp + 15, four ds_read_b128) are NOT: the non-contiguous lane
+    groups mix two column blocks and put half their lanes two to a slot -- one extra cycle per group, which is what the
+    counters show (profiles/r05_pmc_favor.txt: ~1.5 conflict cycles per LDS instruction in the query-side kernel).  (2) The
+    staged context kernels' row operand in four planes [column block][row][20 floats]: conflict-free; their one-float-per-
+    lane operand [row][68]: conflict-free."""
+    PP, RP, PLANE = 68, 20, 16 * 20
+    for mt in range(17):
+        for s in range(4):                       # the four 16-byte reads of a lane's 16 floats
+            addr = {l: 4 * ((mt * 16 + (l & 15)) * PP + 16 * (l >> 4) + 4 * s) for l in range(64)}
+            assert _b128_conflict_cycles(addr) == 4, mt          # 2-way in each of the four groups
+    for mt in range(17):
+        for r in range(4):
+            for t in range(4):
+                addr = {l: 4 * ((mt * 16 + 4 * (l >> 4) + r) * PP + 16 * t + (l & 15)) for l in range(64)}
+                assert _b32_conflict_cycles(addr) == 0
+    for s in range(4):
+        addr = {l: 4 * ((l >> 4) * PLANE + (l & 15) * RP + 4 * s) for l in range(64)}
+        assert _b128_conflict_cycles(addr) == 0
+    base_b = 4 * PLANE                           # floats in front of the second operand of a stage buffer
+    for r in range(4):
+        for et in range(4):
+            addr = {l: 4 * (base_b + (4 * (l >> 4) + r) * PP + 16 * et + (l & 15)) for l in range(64)}
+            assert _b32_conflict_cycles(addr) == 0
+    # what the staging threads write: thread t < 256 -> plane (t & 15) >> 2, row t >> 4, 16-byte column (t & 15) & 3 -- every
+    # (plane, row, column) exactly once, 16-byte aligned
+    seen = set()
+    for t in range(256):
+        row, c4 = (t >> 4) & 15, t & 15
+        off = (c4 >> 2) * PLANE + row * RP + 4 * (c4 & 3)
+        assert off % 4 == 0 and off not in seen and off + 4 <= 4 * PLANE
+        seen.add(off)
+    assert len(seen) == 256
