@@ -25,13 +25,17 @@ after the timed region; `gemm_arith` states the arithmetic of the dense products
 torch.distributed.run (one rank per GPU, rendezvous on 127.0.0.1).
 
 Rank 0 prints ONE JSON line.  Besides the contract fields it carries
-  roofline      the GatedGCN gather-gate-segment-reduce forward kernel (HBM-bound): algorithmic
-                bytes (8*E*d + 20*N*d + CSR index bytes) / its mean launch
-                duration INSIDE the training step (roctracer kernel records of a few extra steps after the
-                timed region -- the same quantity `rocprofv3 --kernel-trace --stats` reports, committed
-                under profiles/); the isolated HIP-event durations (hot: one buffer set, resident in the
-                256 MiB Infinity Cache; rotating: > 512 MiB of buffer sets, so every launch comes from
-                HBM) are carried next to it
+  roofline      the hand-written kernel with the LARGEST share of the step's GPU time (mean launch duration x
+                launches per step over the roctracer kernel records of a few extra steps after the timed region --
+                the quantity `rocprofv3 --kernel-trace --stats` reports, committed under profiles/): its algorithmic
+                flops (or bytes) per launch / its mean in-step launch duration, against the
+                dense fp16 MFMA peak (or 8 TB/s); `traffic` = HBM bytes per launch from the committed PMC passes
+                (profiles/pmc_static.json); `in_step_share` ranks the step's eight largest kernels.  The isolated
+                HIP-event durations (hot: one buffer set, resident in the 256 MiB Infinity Cache; rotating:
+                > 512 MiB of buffer sets, so every launch comes from HBM) are carried next to it
+  roofline_step the algorithmic floor of the WHOLE step (dense products at the fp16 MFMA peak + the bytes that must
+                cross HBM once at 6.3 TB/s) and floor / measured step
+  dispatches_per_step   GPU activity records (kernels + copies) per step, from the same records
   kernels       the same three durations for every hand-written kernel (HBM GB/s or MFMA TFLOP/s)
   cpu_baseline  the CPU oracle (pure-torch restatement of the reference path) timed on the host cores of the
                 same box, same batch, same step definition (rank 0, N = 1): all usable cores (the headline
@@ -52,6 +56,63 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.3 TB/s achievable)
 MFMA_F32_PEAK_TF = 157.3     # v_mfma_f32_16x16x4_f32 dense peak
 MFMA_BF16_PEAK_TF = 2500.0   # v_mfma_f32_32x32x16_bf16 dense peak (MI355X_MICROARCH.md: 2495 measured)
+
+
+HBM_ACHIEVABLE_GBS = 6300.0  # MI355X_MICROARCH.md: 6.29 TB/s measured float4 copy -- the byte rate the STEP floor is priced at
+
+# in-step kernel name -> entry of `kernels` that carries its work (flops / bytes per launch)
+_DOMINANT_TABLE = (("k_wgrad_stream", "wgrad_grouped"), ("k_gatedgcn_fwd", "gatedgcn_fwd"), ("k_gatedgcn_bwd", "gatedgcn_bwd"),
+                   ("k_sattn_fwd", "seg_attn_fwd"), ("k_attn_fwd", "seg_attn_fwd"), ("k_sattn_bwd", "seg_attn_bwd"),
+                   ("k_attn_bwd", "seg_attn_bwd"))
+
+
+def dominant_roofline(in_step, kr, pmc_static):
+    """`roofline` of the JSON line = the hand-written kernel with the LARGEST share of the step's GPU time (mean launch
+    duration x launches per step over the roctracer records), not the best one.  Kernels whose name serves several
+    shapes (k_gemm_ring16 instantiations, the norm task lists) have no per-launch work figure: they are ranked in
+    `in_step_share` beside it and the ring family carries its own entry (kernels.gemm_ring_in_step)."""
+    share = sorted(((t * c, k) for k, (t, c) in in_step.items()), reverse=True)
+    total = sum(x for x, _ in share) or 1.0
+    ranked = [dict(kernel=k[:96], ms_per_step=round(x, 4), share=round(x / total, 4)) for x, k in share[:8]]
+    for x, name in share:
+        ent = next((e for needle, e in _DOMINANT_TABLE if needle in name and e in kr), None)
+        if ent is None:
+            continue
+        k = kr[ent]
+        rec = pmc_static.get(ent, {})
+        r = {"kernel": name.split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "").strip(),
+             "kernels_entry": ent, "step_share": round(x / total, 4),
+             "bound": "hbm" if k["bound"] == "hbm" else "mfma", "achieved": k["achieved"], "peak": k["peak"],
+             "unit": k["unit"], "frac": k["frac"], "launch_ms": k["ms"], "launch_ms_source": k["ms_source"],
+             "isolated_hot_ms": k["isolated_hot_ms"], "isolated_rotating_ms": k["isolated_rotating_ms"],
+             "traffic": rec.get("hbm_bytes_per_launch"),
+             "traffic_source": ("static: " + str(rec.get("source"))) if rec else None,
+             "in_step_share": ranked}
+        r["algorithmic_bytes" if k["bound"] == "hbm" else "algorithmic_flops"] = k.get("bytes", k.get("flops"))
+        if k["bound"] != "hbm":
+            r["peak_note"] = "dense fp16 / bf16 MFMA peak; flops = the piece products issued (kernels.%s.note)" % ent
+        return r
+    return None
+
+
+def step_roofline(N, E, d, H, layers, n_params, ms, nprod):
+    """Algorithmic floor of the whole step (SURVEY.md section 8d figures): every dense product of the GPS blocks
+    (forward + input gradient + weight gradient = 3 x the forward flops, x `nprod` piece products) at the dense fp16 MFMA
+    peak, plus the bytes that must cross HBM once -- GatedGCN gather / scatter forward + backward, the attention core's
+    q|k|v / o / gradients, clip + AdamW's 28 B per parameter -- at the achievable copy rate.  Norm stages, encoders, head and
+    launch gaps have no term: the floor is what the arithmetic needs, `frac` is floor / measured step."""
+    shapes = [(N, d, 7 * d), (E, d, d), (N, d, d), (N, d, 2 * d), (N, 2 * d, d)]
+    gemm_flops = 3 * layers * sum(2.0 * R * k * n for R, k, n in shapes)
+    idx = 4 * (N + 1) + 8 * E
+    sparse = layers * ((8 * E * d + 20 * N * d + idx) + (12 * E * d + 28 * N * d + 2 * idx))
+    attn = layers * ((16 * N * d + 4 * H * N) + (32 * N * d + 12 * H * N))
+    adamw = 28 * n_params
+    mfma_ms = gemm_flops * nprod / (MFMA_BF16_PEAK_TF * 1e9)
+    hbm_ms = (sparse + attn + adamw) / (HBM_ACHIEVABLE_GBS * 1e6)
+    floor = mfma_ms + hbm_ms
+    return {"floor_ms": floor, "frac": floor / ms, "mfma_ms": mfma_ms, "hbm_ms": hbm_ms,
+            "gemm_flops_fp32_equiv": gemm_flops, "piece_products": nprod, "mfma_peak_tflops": MFMA_BF16_PEAK_TF,
+            "sparse_bytes": sparse, "attention_bytes": attn, "adamw_bytes": adamw, "hbm_rate_gbs": HBM_ACHIEVABLE_GBS}
 
 
 _T0 = time.time()
@@ -431,6 +492,19 @@ def kernel_rooflines(dev, profile, nb, d=384, H=16, in_step=None, layers=10, onl
         fl = NPROD * sum(2.0 * R * k * n for R, k, n in shapes)
         entry("gemm_fwd_block", fwd5, 1, "mfma_bf16", fl, 5, (), note=SPLIT_NOTE + "; isolated only (one kernel name serves every shape)")
         entry("gemm_dgrad_block", dgrad5, 1, "mfma_bf16", fl, 5, (), note=SPLIT_NOTE + "; isolated only")
+        if in_step and (only is None or "gemm_ring_in_step" in only):
+            # the ring GEMM FAMILY inside the step: every k_gemm_ring16 instantiation's (mean duration x launches per step)
+            # against the forward + input-gradient flops of all layers (one kernel name serves several shapes, so the
+            # family is the finest grain the in-step records resolve)
+            tot = sum(t * c for k_, (t, c) in in_step.items() if "k_gemm_ring" in k_)
+            cnt = sum(c for k_, (t, c) in in_step.items() if "k_gemm_ring" in k_)
+            if tot > 0:
+                work = 2 * fl * layers
+                res["gemm_ring_in_step"] = dict(
+                    bound="mfma_bf16", ms=tot, ms_source="in-step (roctracer), all instantiations, per STEP",
+                    in_step_ms=tot, achieved=work / tot / 1e9, peak=MFMA_BF16_PEAK_TF, unit="TFLOP/s", launches=cnt,
+                    in_step_launches_per_step=cnt, flops=work, frac=work / tot / 1e9 / MFMA_BF16_PEAK_TF,
+                    note=SPLIT_NOTE + "; flops and ms are per step (all layers, forward + input gradient)")
     return res, dict(N=N, E=E, d=d, H=H, sum_n2=s2, rotation_sets=dict(gatedgcn=n_rot, attention=a_rot))
 
 
@@ -1016,26 +1090,24 @@ def main():
         }
         if not args.no_kernel_roofline:
             if in_step is not None:
+                out["dispatches_per_step"] = round(sum(c for _, c in in_step.values()), 1)
                 out["in_step_kernel_ms"] = {k: dict(ms=round(v[0], 5), per_step=v[1]) for k, v in
                                             sorted(in_step.items(), key=lambda kv: -kv[1][0] * kv[1][1])[:24]}
             if args.workload == "pcqm4m":
-                kr, shape = kernel_rooflines(dev, args.profile or "P30", nb, in_step=in_step,
-                                              layers=int(cfg.gt.layers))
-                k = kr["gatedgcn_fwd"]
-                traffic, traffic_src = None, None
-                pmc = os.path.join(ROOT, "profiles", "pmc_gatedgcn_fwd.json")
-                if os.path.exists(pmc):           # HBM bytes per launch from a separate rocprofv3 --pmc pass
-                    rec = json.load(open(pmc))
-                    # (static: measured by a separate counter pass -- counters and timing never share a run -- and read
-                    # from the committed file, not collected by this run)
-                    traffic, traffic_src = rec.get("hbm_bytes_per_launch"), "static: " + str(rec.get("source"))
-                out["roofline"] = {"kernel": "k_gatedgcn_fwd", "bound": "hbm", "achieved": k["achieved"],
-                                   "peak": k["peak"], "unit": "GB/s", "frac": k["frac"],
-                                   "launch_ms": k["ms"], "launch_ms_source": k["ms_source"],
-                                   "isolated_hot_ms": k["isolated_hot_ms"],
-                                   "isolated_rotating_ms": k["isolated_rotating_ms"],
-                                   "traffic": traffic, "traffic_source": traffic_src,
-                                   "algorithmic_bytes": k["bytes"]}
+                layers_n = int(cfg.gt.layers)
+                kr, shape = kernel_rooflines(dev, args.profile or "P30", nb, in_step=in_step, layers=layers_n)
+                pmc_static = {}
+                pmc = os.path.join(ROOT, "profiles", "pmc_static.json")
+                if os.path.exists(pmc):           # HBM bytes per launch from separate rocprofv3 --pmc passes (counters and
+                    pmc_static = json.load(open(pmc))     # timing never share a run): read from the committed file
+                dom = dominant_roofline(in_step, kr, pmc_static) if in_step else None
+                if dom is None:                   # no in-step records: the largest kernel of the last committed profile
+                    dom = dominant_roofline({"k_wgrad_stream": (kr["wgrad_grouped"]["ms"], layers_n)}, kr, pmc_static)
+                out["roofline"] = dom
+                from graphgps_amd import gemm as _gemm
+                out["roofline_step"] = step_roofline(shape["N"], shape["E"], shape["d"], shape["H"], layers_n,
+                                                     sum(p.numel() for p in model.parameters()), ms,
+                                                     3 if _gemm.F16 else 6)
             else:
                 kr, shape = favor_rooflines(dev, nb, in_step=in_step)
                 k = kr.get("favor_in_step") or kr["favor_fwd"]

@@ -42,6 +42,28 @@ class _MultihotMM(torch.autograd.Function):
         return None, g_w
 
 
+# The gather-sum kernel CLAMPS out-of-range feature values (memory safety); ``nn.Embedding`` -- what the reference runs --
+# raises on them.  So that a corrupt or unsupported feature value (a new atom type ...) cannot train silently against the
+# wrong table row, the FIRST batch every table set sees is range-checked (one device read, never inside a capture);
+# GPS_EMBED_CHECK=all checks every eager batch, =0 none.
+_EMBED_CHECK = os.environ.get("GPS_EMBED_CHECK", "first")
+_range_checked = set()
+
+
+def _check_feature_range(feats, tables) -> None:
+    if _EMBED_CHECK == "0" or torch.cuda.is_current_stream_capturing():
+        return
+    key = (tables[0].data_ptr(), len(tables))
+    if _EMBED_CHECK != "all" and key in _range_checked:
+        return
+    vocab = torch.tensor([t.shape[0] for t in tables], device=feats.device)
+    bad = ((feats.amin(0) < 0) | (feats.amax(0) >= vocab)).nonzero().flatten().tolist()
+    if bad:
+        raise IndexError(f"embedding index out of range in feature column(s) {bad}: values must lie in [0, vocabulary) = "
+                         f"{[int(t.shape[0]) for t in tables]} (nn.Embedding raises here too)")
+    _range_checked.add(key)
+
+
 class _EmbedSum(torch.autograd.Function):
     """``sum_i tables[i][feats[:, i]]`` in ONE launch (csrc/embed.hip ``gps_embed_sum``: the tables read in place, columns
     added in index order -- the reference's own summation order, ogb's ``x_embedding += emb[i](x[:, i])``).  Backward: ONE
@@ -55,6 +77,7 @@ class _EmbedSum(torch.autograd.Function):
         import ctypes
         from .. import lib as _lib
         L = _lib.load()
+        _check_feature_range(feats, tables)
         R, k = feats.shape
         emb = tables[0].shape[1]
         out = torch.empty(R, emb, dtype=torch.float32, device=feats.device)

@@ -387,7 +387,18 @@ class DeviceLoader:
         dev = self.device
         slot = ring.next_slot() if ring is not None else None
         already = bool((vars(batch).get("_gps_meta") or {}).get("padded"))     # padded by the DataLoader's collate
-        batch = self.pad(batch) if self.pad is not None and not already else self._host_copy(batch)
+        if self.pad is not None and not already:
+            try:
+                batch = self.pad(batch)
+            except ValueError as exc:
+                # a tensor whose axis BucketPadding cannot tell (E == N, a pair-indexed operand ...): this loader's batches
+                # go un-padded from here on -- slower (fewer replays), never wrong and never an aborted epoch
+                import warnings
+                warnings.warn(f"DeviceLoader: shape buckets switched off for this loader: {exc}")
+                self.pad = None
+                batch = self._host_copy(batch)
+        else:
+            batch = self._host_copy(batch)
         vars(batch).pop("_gps_index", None)
         # what the host can tell the kernels for free while ``ptr`` is still here: the longest graph of the batch
         # (from ``ptr``, or from a host-side ``batch`` vector when the collater emitted no ``ptr``: without the record

@@ -246,7 +246,7 @@ class TrainStep:
             self.exchange.all_reduce()
             ent["graph_up"].replay()
         loss, pred, true = ent["out"]
-        return loss.clone(), _cloned(pred), _cloned(true)
+        return loss.clone(), _rebuilt(pred, ent["sources"], batch, ("pred",)), _rebuilt(true, ent["sources"], batch, ("true",))
 
     def _eager_triplet(self, batch):
         loss, pred_score, true = self.forward_backward(batch)
@@ -266,62 +266,145 @@ class TrainStep:
 
     def _capture_shape(self, batch):
         """Static copies of the batch's tensors + the step captured over them (NOT executed: the caller replays)."""
-        import copy
         dev = self.opt.arena.device
         if self.salt is None and _has_dropout(self.model):
             from .ops import enable_dropout_salt
             self.salt = enable_dropout_salt(dev)
-        keys = self._tensor_keys(batch)
-        static = DeviceLoader._host_copy(batch)
-        vars(static).pop("_gps_index", None)
-        dst = []
-        for k in keys:
-            t = getattr(batch, k).clone()
-            setattr(static, k, t)
-            dst.append(t)
-        if "_gps_meta" in vars(batch):
-            vars(static)["_gps_meta"] = dict(vars(batch)["_gps_meta"])
         pool = self.__dict__.get("_shape_pool")
         if pool is None:
             pool = self.__dict__["_shape_pool"] = torch.cuda.graph_pool_handle()
-
-        def fresh():                         # a new container over the static tensors per trace (the model re-assigns
-            b = DeviceLoader._host_copy(static)   # batch.x / batch.edge_attr), without a cached graph index
-            vars(b).pop("_gps_index", None)
-            return b
-        graph = torch.cuda.CUDAGraph()
         split = self.exchange is not None and self.exchange.active
-        graph_up = torch.cuda.CUDAGraph() if split else None
-        tick = torch.zeros(1, device=dev) if _os.environ.get("GPS_CAPTURE_TICK", "1") != "0" else None
-        try:
-            with STAGE_LOCK:                 # no staging thread allocates / copies / launches while this thread captures
-                torch.cuda.synchronize(dev)
-                self.opt.zero_grad()
-                self.opt.sync_hyper()
-                with torch.cuda.graph(graph, pool=pool, capture_error_mode="thread_local"):
-                    if tick is not None:     # see capture(): a purely linear graph of the step faults at replay
-                        cur = torch.cuda.current_stream(dev)
-                        tside = torch.cuda.Stream(device=dev)
-                        tside.wait_stream(cur)
-                        with torch.cuda.stream(tside):
-                            tick.add_(1.0)
-                    out = self.forward_backward(fresh())
-                    if not split:
-                        self.update()
-                    if tick is not None:
-                        torch.cuda.current_stream(dev).wait_stream(tside)
-                if split:                    # the all-reduce stays an eager RCCL call between the two graphs
-                    with torch.cuda.graph(graph_up, pool=pool, capture_error_mode="thread_local"):
-                        self.update()
-        except RuntimeError as exc:          # (torch / HIP report capture violations as RuntimeError; anything else is a bug)
-            import warnings
-            warnings.warn(f"TrainStep.step_cached: capture of a step failed, this batch shape stays eager: "
-                          f"{type(exc).__name__}: {str(exc).splitlines()[0] if str(exc) else ''}")
-            torch.cuda.synchronize(dev)      # leave no half-issued work of the aborted capture behind
+
+        def before():
             self.opt.zero_grad()
-            return None
-        torch.cuda.synchronize(dev)
-        return {"graph": graph, "graph_up": graph_up, "keys": keys, "dst": dst, "out": out, "tick": tick, "static": static}
+            self.opt.sync_hyper()
+
+        def body(b):
+            out = self.forward_backward(b)
+            if not split:
+                self.update()
+            return out
+        # (data-parallel: the all-reduce stays an eager RCCL call between the two graphs)
+        ent = _capture_static("TrainStep.step_cached", batch, dev, pool, body, before=before,
+                              tail=self.update if split else None)
+        if ent is None:
+            self.opt.zero_grad()
+        return ent
+
+
+class _NotCapturable(RuntimeError):
+    """A step whose outputs carry host-side values that no attribute of the batch accounts for: replaying it would
+    return the CAPTURE-time values for every later batch, so it stays eager."""
+
+
+def _batch_sources(out, batch, root):
+    """{path: batch attribute} for every non-tensor node of ``out`` that is (or equals) a non-tensor attribute of
+    ``batch`` -- e.g. the code2 head's ``true['y'] = batch.y``, a list of token-string lists that the reference logger
+    decodes into its F1 (graphgps/logger.py:218).  A replayed step refreshes TENSORS only (they live in the static
+    buffers the graph reads); these nodes are re-taken from the batch being replayed (``_rebuilt``).  Any other
+    non-tensor leaf except ``None`` cannot be refreshed: ``_NotCapturable``."""
+    host = [(k, getattr(batch, k, None)) for k in DeviceLoader._keys(batch)]
+    host = [(k, v) for k, v in host if v is not None and not torch.is_tensor(v)]
+    found = {}
+
+    def source_of(node):
+        for k, v in host:
+            if v is node:
+                return k
+        for k, v in host:        # (``_head_rows`` rebuilds list containers of a padded batch: equal, not identical)
+            if type(v) is type(node) and not isinstance(node, (int, float, bool, str)) and v == node:
+                return k
+        return None
+
+    def walk(node, path):
+        if torch.is_tensor(node) or node is None:
+            return
+        k = source_of(node)
+        if k is not None:
+            found[path] = k
+        elif isinstance(node, (list, tuple)):
+            for i, o in enumerate(node):
+                walk(o, path + (i,))
+        elif isinstance(node, dict):
+            for i, o in node.items():
+                walk(o, path + (i,))
+        else:
+            raise _NotCapturable(f"output leaf {'/'.join(map(str, path))} = {type(node).__name__} comes from no "
+                                 f"attribute of the batch")
+    for name, obj in root:
+        walk(obj, (name,))
+    return found
+
+
+def _rebuilt(obj, sources, batch, path):
+    """``_cloned`` with the nodes listed in ``sources`` re-taken from ``batch``."""
+    k = sources.get(path) if sources else None
+    if k is not None:
+        return getattr(batch, k)
+    if torch.is_tensor(obj):
+        return obj.detach().clone()
+    if isinstance(obj, (list, tuple)):
+        return type(obj)(_rebuilt(o, sources, batch, path + (i,)) for i, o in enumerate(obj))
+    if isinstance(obj, dict):
+        return {i: _rebuilt(o, sources, batch, path + (i,)) for i, o in obj.items()}
+    return obj
+
+
+def _capture_static(who, batch, dev, pool, body, before=None, tail=None):
+    """The capture both ``TrainStep.step_cached`` and ``EvalStep.step_cached`` replay from: static copies of ``batch``'s
+    tensors, ``body(fresh batch over them)`` -> ``(loss, pred, true)`` captured as one hipGraph (``tail()`` as a second one
+    when given: the optimizer half behind a data-parallel all-reduce), NOT executed.  Returns the cache entry, or None
+    when the step cannot be captured (one warning; the caller keeps the shape eager).
+
+    Every capture carries one forked tick node: a purely linear captured chain of the step faults at replay on this
+    stack (``TrainStep.capture``; profiles/r03_linear_capture_fault.md).  The tick tensor lives in the entry -- every
+    replay writes it."""
+    import warnings
+    keys = TrainStep._tensor_keys(batch)
+    static = DeviceLoader._host_copy(batch)
+    vars(static).pop("_gps_index", None)
+    dst = []
+    for k in keys:
+        t = getattr(batch, k).clone()
+        setattr(static, k, t)
+        dst.append(t)
+    if "_gps_meta" in vars(batch):
+        vars(static)["_gps_meta"] = dict(vars(batch)["_gps_meta"])
+
+    def fresh():                         # a new container over the static tensors per trace (the model re-assigns
+        b = DeviceLoader._host_copy(static)   # batch.x / batch.edge_attr), without a cached graph index
+        vars(b).pop("_gps_index", None)
+        return b
+    graph = torch.cuda.CUDAGraph()
+    graph_up = torch.cuda.CUDAGraph() if tail is not None else None
+    tick = torch.zeros(1, device=dev) if _os.environ.get("GPS_CAPTURE_TICK", "1") != "0" else None
+    try:
+        with STAGE_LOCK:                 # no staging thread allocates / copies / launches while this thread captures
+            torch.cuda.synchronize(dev)
+            if before is not None:
+                before()
+            with torch.cuda.graph(graph, pool=pool, capture_error_mode="thread_local"):
+                if tick is not None:
+                    cur = torch.cuda.current_stream(dev)
+                    tside = torch.cuda.Stream(device=dev)
+                    tside.wait_stream(cur)
+                    with torch.cuda.stream(tside):
+                        tick.add_(1.0)
+                out = body(fresh())
+                if tick is not None:
+                    torch.cuda.current_stream(dev).wait_stream(tside)
+            if tail is not None:
+                with torch.cuda.graph(graph_up, pool=pool, capture_error_mode="thread_local"):
+                    tail()
+        sources = _batch_sources(out, static, (("pred", out[1]), ("true", out[2])))
+    except RuntimeError as exc:          # (torch / HIP report capture violations as RuntimeError; anything else is a bug)
+        warnings.warn(f"{who}: capture of a step failed, this batch shape stays eager: "
+                      f"{type(exc).__name__}: {str(exc).splitlines()[0] if str(exc) else ''}")
+        torch.cuda.synchronize(dev)      # leave no half-issued work of the aborted capture behind
+        return None
+    torch.cuda.synchronize(dev)
+    return {"graph": graph, "graph_up": graph_up, "keys": keys, "dst": dst, "out": out, "tick": tick, "static": static,
+            "sources": sources}
 
 
 def _real_graphs_of(batch):
@@ -379,16 +462,6 @@ def padding_supported(model) -> bool:
             return False
     head = getattr(model, "post_mp", None)
     return isinstance(head, _GraphLevelHead) and cfg.model.graph_pooling in ("add", "mean")
-
-
-def _cloned(obj):
-    if torch.is_tensor(obj):
-        return obj.detach().clone()
-    if isinstance(obj, (list, tuple)):
-        return type(obj)(_cloned(o) for o in obj)
-    if isinstance(obj, dict):
-        return {k: _cloned(v) for k, v in obj.items()}
-    return obj
 
 
 # GPS_LOADER_BUCKETS (default on): train_epoch pads loader batches up to shape buckets (loader.BucketPadding) when the model
@@ -504,11 +577,42 @@ def train_epoch(logger, loader, model, optimizer, scheduler, batch_accumulation,
 
 
 def eval_padding_supported(model) -> bool:
-    """Padded batches in EVALUATION mode: every BatchNorm normalises with its running statistics, so padding rows reach no
-    statistic whatever the layer type; what remains is that the dead graphs' predictions can be dropped -- a graph-level
-    head -- and that the Performer's Nmax is taken over the real graphs (ops._nmax_dev does)."""
+    """Padded batches in EVALUATION mode.  Every BatchNorm normalises with its running statistics there, so padding rows
+    reach no statistic whatever the layer type; what has to hold is that ``loader.BucketPadding`` knows every tensor the
+    model reads off the batch and that the dead graphs' predictions can be dropped.  A WHITELIST: a
+    ``GPSModel`` whose layers pair a local model served on padded batches (CustomGatedGCN / GINE / GCN / None) with
+    Transformer / Performer / None -- no pair-indexed operand (``attn_bias`` of BiasedTransformer / Graphormer, SAN's
+    ``edge_index`` extensions), no EquivStableLapPE gate --, encoders out of the node- / edge-row families
+    ``BucketPadding`` pads by name, and a graph-level head.  Everything else evaluates un-padded (still replayed per
+    shape when shapes repeat)."""
+    from .encoder import encoders as _enc
+    from .encoder import extra_encoders as _xenc
     from .head.heads import _GraphLevelHead
-    return isinstance(getattr(model, "post_mp", None), _GraphLevelHead)
+    from .layer.gps_layer import GPSLayer
+    from .network.gps_model import GPSModel
+    if not isinstance(model, GPSModel) or not isinstance(getattr(model, "post_mp", None), _GraphLevelHead):
+        return False
+    layers = [m for m in model.modules() if isinstance(m, GPSLayer)]
+    if not layers:
+        return False
+    for m in layers:
+        if m.local_gnn_type not in ('CustomGatedGCN', 'GINE', 'GCN', 'None', None):
+            return False
+        if m.global_model_type not in ('Transformer', 'Performer', 'None', None) or getattr(m, "equivstable_pe", False):
+            return False
+    ok_enc = (_enc._OGBFeatureEncoder, _enc.TypeDictNodeEncoder, _enc.TypeDictEdgeEncoder, _enc.ASTNodeEncoder,
+              _enc.ASTEdgeEncoder, _enc.KernelPENodeEncoder, _enc.BatchNorm1dNode, _xenc.LinearEdgeEncoder,
+              _xenc.DummyEdgeEncoder)
+    enc = getattr(model, "encoder", None)
+
+    def parts(m):           # encoder/encoders.py concat_node_encoders: dataset encoder + positional encoder (may nest)
+        if hasattr(m, "encoder1") and hasattr(m, "encoder2"):
+            return parts(m.encoder1) + parts(m.encoder2)
+        return [m]
+    for m in (enc.children() if enc is not None else ()):
+        if not all(isinstance(q, ok_enc) for q in parts(m)):
+            return False
+    return True
 
 
 class EvalStep:
@@ -522,6 +626,8 @@ class EvalStep:
         self.loss_fn = loss_fn or train_loss
         self.cache, self.seen, self.failed = {}, set(), set()
         self.replays = 0
+        self.capture_failures = 0        # three failed captures switch replay off for good (as TrainStep does): a model
+        self.replay_ok = True            # whose eval forward reads the host would pay an aborted capture per shape
         self._pool = None
 
     @torch.no_grad()
@@ -545,6 +651,10 @@ class EvalStep:
 
     @torch.no_grad()
     def step_cached(self, batch, max_graphs: int = 8):
+        """``max_graphs`` live captures PER SPLIT (the key carries the split and the number of real graphs: val and test
+        sharing one LRU of 8 evicted each other's shapes on every pass)."""
+        if not self.replay_ok:
+            return self.run_eager(batch)
         key = self._key(batch)
         if self.cache:
             # captured forwards read parameters and buffers where they sat at capture time (an optimizer arena adopted
@@ -566,63 +676,29 @@ class EvalStep:
             ent = self._capture(batch)
             if ent is None:
                 self.failed.add(key)
+                self.capture_failures += 1
+                if self.capture_failures >= 3:
+                    self.replay_ok = False
                 return self.run_eager(batch)
             if not self.cache:
                 self._addr = self._addresses()
             self.cache[key] = ent
-            while len(self.cache) > max_graphs:
+            same = [k for k in self.cache if k[3] == key[3]]
+            while len(same) > max_graphs:
                 torch.cuda.current_stream(batch.x.device).synchronize()
-                self.cache.pop(next(iter(self.cache)))
+                self.cache.pop(same.pop(0))
         else:
             self.cache[key] = self.cache.pop(key)
             torch._foreach_copy_(ent["dst"], [getattr(batch, k) for k in ent["keys"]])
         ent["graph"].replay()
         self.replays += 1
         loss, pred, true = ent["out"]
-        return loss.clone(), _cloned(pred), _cloned(true)
+        return loss.clone(), _rebuilt(pred, ent["sources"], batch, ("pred",)), _rebuilt(true, ent["sources"], batch, ("true",))
 
     def _capture(self, batch):
-        dev = batch.x.device
-        keys = TrainStep._tensor_keys(batch)
-        static = DeviceLoader._host_copy(batch)
-        vars(static).pop("_gps_index", None)
-        dst = []
-        for k in keys:
-            t = getattr(batch, k).clone()
-            setattr(static, k, t)
-            dst.append(t)
-        if "_gps_meta" in vars(batch):
-            vars(static)["_gps_meta"] = dict(vars(batch)["_gps_meta"])
         if self._pool is None:
             self._pool = torch.cuda.graph_pool_handle()
-
-        def fresh():
-            b = DeviceLoader._host_copy(static)
-            vars(b).pop("_gps_index", None)
-            return b
-        graph = torch.cuda.CUDAGraph()
-        tick = torch.zeros(1, device=dev) if _os.environ.get("GPS_CAPTURE_TICK", "1") != "0" else None
-        try:
-            with STAGE_LOCK:
-                torch.cuda.synchronize(dev)
-                with torch.cuda.graph(graph, pool=self._pool, capture_error_mode="thread_local"):
-                    if tick is not None:     # (TrainStep.capture: a purely linear captured chain faults at replay on this stack)
-                        cur = torch.cuda.current_stream(dev)
-                        tside = torch.cuda.Stream(device=dev)
-                        tside.wait_stream(cur)
-                        with torch.cuda.stream(tside):
-                            tick.add_(1.0)
-                    out = self.run_eager(fresh())
-                    if tick is not None:
-                        torch.cuda.current_stream(dev).wait_stream(tside)
-        except RuntimeError as exc:
-            import warnings
-            warnings.warn(f"EvalStep.step_cached: capture failed, this batch shape stays eager: "
-                          f"{type(exc).__name__}: {str(exc).splitlines()[0] if str(exc) else ''}")
-            torch.cuda.synchronize(dev)
-            return None
-        torch.cuda.synchronize(dev)
-        return {"graph": graph, "keys": keys, "dst": dst, "out": out, "tick": tick, "static": static}
+        return _capture_static("EvalStep.step_cached", batch, batch.x.device, self._pool, self.run_eager)
 
 
 @torch.no_grad()

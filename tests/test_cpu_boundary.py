@@ -551,3 +551,39 @@ def test_bench_multi_gpu_launcher_path_dry_run(how):
     assert d["ms_per_step"] >= 4.0                             # the MAX over ranks: rank 1 sleeps 4 ms per step
     assert abs(d["value"] - 2 * 256 / (d["ms_per_step"] / 1e3)) <= 1e-6 * d["value"]      # whole-job aggregate
     assert d["config"]["global_batch"] == 512 and d["config"]["parallelism"] == "dp2"
+
+
+def test_eval_padding_is_whitelisted():
+    """Evaluation batches are padded only for models whose every batch tensor ``BucketPadding`` knows: the
+    GPS model with the row-family encoders -- not Graphormer / BiasedTransformer, whose pair-indexed operands were never
+    taken through the padding."""
+    import graphgps_amd as g
+    from graphgps_amd.train import eval_padding_supported
+    mk = lambda y, din, dout: g.create_model(os.path.join(g.CONFIG_DIR, y), ["gt.layers", 1], din, dout)
+    assert eval_padding_supported(mk("pcqm4m_gpsmedium_rwse.yaml", 9, 1))
+    assert eval_padding_supported(mk("zinc_gps_rwse.yaml", 1, 1))
+    assert eval_padding_supported(mk("code2_gps.yaml", 2, 5002))
+    assert not eval_padding_supported(mk("zinc_graphormer.yaml", 28, 1))
+    assert not eval_padding_supported(mk("zinc_gps_graphormer_rwse.yaml", 28, 1))
+
+
+def test_replayed_outputs_retake_host_leaves_from_the_current_batch():
+    """train._batch_sources / _rebuilt: non-tensor nodes of a captured step's outputs that are attributes of
+    the batch (code2: ``true['y']``, a list of token-string lists) are re-taken from the batch being replayed; a host
+    leaf no attribute accounts for makes the step un-capturable instead of silently stale."""
+    from graphgps_amd.data import Batch
+    from graphgps_amd.train import _NotCapturable, _batch_sources, _head_rows, _rebuilt
+    b0 = Batch(x=torch.zeros(4, 2), y_arr=torch.arange(10).view(2, 5), y=[["a", "b"], ["c"]])
+    b0.split = "val"
+    pred, true = [torch.ones(2, 3)], {"y_arr": b0.y_arr, "y": b0.y}
+    src = _batch_sources((None, pred, true), b0, (("pred", pred), ("true", true)))
+    assert src == {("true", "y"): "y"}
+    # a padded batch: _head_rows rebuilds the list container (equal, not identical)
+    true_p = _head_rows(true, 2)
+    assert true_p["y"] is not b0.y
+    assert _batch_sources(None, b0, (("true", true_p),)) == {("true", "y"): "y"}
+    b1 = Batch(x=torch.zeros(4, 2), y_arr=torch.arange(10).view(2, 5) + 1, y=[["d"], ["e", "f"]])
+    got = _rebuilt(true, src, b1, ("true",))
+    assert got["y"] is b1.y and torch.equal(got["y_arr"], b0.y_arr) and got["y_arr"] is not b0.y_arr
+    with pytest.raises(_NotCapturable):
+        _batch_sources(None, b0, (("true", {"n": 3}),))

@@ -394,6 +394,23 @@ def test_embed_sum_and_multihot_gradient(kind, emb, R):
     assert all(torch.equal(a, e.weight.grad) for a, e in zip(g1, embs))
 
 
+def test_embed_sum_rejects_out_of_range_features_like_nn_embedding():
+    """The gather-sum kernel clamps out-of-range indices (memory safety); the first batch a table set sees is range-checked
+    on the host so that corrupt features fail as ``nn.Embedding`` does instead of training against the wrong row."""
+    from graphgps_amd.encoder.encoders import _EmbedSum
+    dev = torch.device("cuda:0")
+    embs = torch.nn.ModuleList([torch.nn.Embedding(v, 16) for v in (5, 3)]).to(dev)
+    bad = torch.tensor([[0, 1], [4, 3]], device=dev)            # column 1 holds a 3: vocabulary is 3
+    with pytest.raises(IndexError, match="column"):
+        _EmbedSum.apply(bad, *[e.weight for e in embs])
+    neg = torch.tensor([[0, 1], [-1, 2]], device=dev)
+    with pytest.raises(IndexError):
+        _EmbedSum.apply(neg, *[e.weight for e in embs])
+    good = torch.tensor([[0, 1], [4, 2]], device=dev)
+    out = _EmbedSum.apply(good, *[e.weight for e in embs])
+    assert torch.equal(out, embs[0].weight[good[:, 0]] + embs[1].weight[good[:, 1]])
+
+
 def test_cpu_tensor_is_rejected():
     from graphgps_amd.lib import GpsHipError
     from graphgps_amd.ops import build_graph_index

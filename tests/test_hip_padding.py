@@ -532,3 +532,51 @@ def test_eval_step_drops_stale_graphs_when_parameters_move():
         loss2, pred2, _ = es.step_cached(b.clone())                          # captured again on the new addresses
     assert_close(pred2, want_pred, 1e-6, "replayed prediction on the new addresses")
     assert opt.arena.intact()
+
+
+@pytest.mark.parametrize("padded", [False, True])
+def test_replayed_steps_return_the_current_batch_host_targets(padded):
+    """ogbg-code2: the head returns ``true = {'y_arr': tensor, 'y': batch.y}`` where ``batch.y`` is a Python list of
+    token-string lists that the reference logger decodes into its F1 (graphgps/logger.py:218).  A replayed step
+    refreshes tensors only, so the list must be re-taken from the batch being replayed (every replayed batch
+    reported the CAPTURED batch's strings).  Two batches of one shape with different strings, evaluation and training."""
+    from graphgps_amd.loader import BucketPadding
+    from graphgps_amd.optim import FlatAdamW
+    from graphgps_amd.synthetic import model_batch
+    from graphgps_amd.train import EvalStep, TrainStep
+    dev = torch.device(DEV)
+    torch.manual_seed(0)
+    model = _kind_model("code2", dev, 1, 0.1)
+    nb = 8
+    base = model_batch("code2", nb, seed=77)
+    pad = BucketPadding() if padded else None
+
+    def variant(tag):
+        b = base.clone()
+        b.y_arr = (base.y_arr + tag) % 5002
+        b.y = [[f"tok{tag}_{g}_{j}" for j in range(3)] for g in range(nb)]
+        if pad is not None:
+            b = pad(b)
+        return b.to(dev)
+
+    es = EvalStep(model.eval(), loss_fn=_kind_loss("code2"))
+    for i in range(5):
+        b = variant(i)
+        want_y, want_arr = b.y, b.y_arr[:nb].clone()
+        _, _, true = es.step_cached(b)
+        assert true['y'] == want_y and true['y'] is not None, (i, true['y'][:1], want_y[:1])
+        assert torch.equal(true['y_arr'], want_arr), i
+    assert es.replays == 3 and not es.failed
+
+    model.train()
+    opt = FlatAdamW(model.parameters(), lr=1e-4, weight_decay=0.0)
+    ts = TrainStep(model, opt, loss_fn=_kind_loss("code2"))
+    for i in range(5):
+        b = variant(10 + i)
+        want_y, want_arr = b.y, b.y_arr[:nb].clone()
+        _, _, true = ts.step_cached(b)
+        assert true['y'] == want_y, (i, true['y'][:1], want_y[:1])
+        assert torch.equal(true['y_arr'], want_arr), i
+    torch.cuda.synchronize()
+    assert len(ts.__dict__["_shape_cache"]) == 1 and not ts.__dict__.get("_shape_failed")
+
