@@ -66,21 +66,34 @@ _DOMINANT_TABLE = (("k_wgrad_stream", "wgrad_grouped"), ("k_gatedgcn_fwd", "gate
                    ("k_attn_bwd", "seg_attn_bwd"))
 
 
-def dominant_roofline(in_step, kr, pmc_static):
+def _per_step(c, layers):
+    """Launches per step of a kernel from its record count.  The activity buffer drops records of long graph replays (a
+    once-per-layer kernel shows 6.2 launches per step for 10), so the counts of per-layer kernels are rounded up to whole
+    layers; kernels seen less than once per two layers are taken as recorded."""
+    return -(-c // layers) * layers if c > layers / 2 else c
+
+
+def dominant_roofline(in_step, kr, pmc_static, layers=10):
     """`roofline` of the JSON line = the hand-written kernel with the LARGEST share of the step's GPU time (mean launch
     duration x launches per step over the roctracer records), not the best one.  Kernels whose name serves several
     shapes (k_gemm_ring16 instantiations, the norm task lists) have no per-launch work figure: they are ranked in
     `in_step_share` beside it and the ring family carries its own entry (kernels.gemm_ring_in_step)."""
-    share = sorted(((t * c, k) for k, (t, c) in in_step.items()), reverse=True)
+    import re
+    per_step = lambda c: _per_step(c, layers)
+    share = sorted(((t * per_step(c), k) for k, (t, c) in in_step.items()), reverse=True)
     total = sum(x for x, _ in share) or 1.0
-    ranked = [dict(kernel=k[:96], ms_per_step=round(x, 4), share=round(x / total, 4)) for x, k in share[:8]]
+
+    def short(name):
+        m = re.search(r"(k_\w+(?:<[^>]*>)?|Cijk_\w{0,24}|\w+)\s*(?:\(|$)", name.replace("(anonymous namespace)::", ""))
+        return (m.group(1) if m else name)[:64]
+    ranked = [dict(kernel=short(k), ms_per_step=round(x, 4), share=round(x / total, 4)) for x, k in share[:8]]
     for x, name in share:
         ent = next((e for needle, e in _DOMINANT_TABLE if needle in name and e in kr), None)
         if ent is None:
             continue
         k = kr[ent]
         rec = pmc_static.get(ent, {})
-        r = {"kernel": name.split("(")[0].replace("void ", "").replace("(anonymous namespace)::", "").strip(),
+        r = {"kernel": short(name),
              "kernels_entry": ent, "step_share": round(x / total, 4),
              "bound": "hbm" if k["bound"] == "hbm" else "mfma", "achieved": k["achieved"], "peak": k["peak"],
              "unit": k["unit"], "frac": k["frac"], "launch_ms": k["ms"], "launch_ms_source": k["ms_source"],
@@ -496,8 +509,8 @@ def kernel_rooflines(dev, profile, nb, d=384, H=16, in_step=None, layers=10, onl
             # the ring GEMM FAMILY inside the step: every k_gemm_ring16 instantiation's (mean duration x launches per step)
             # against the forward + input-gradient flops of all layers (one kernel name serves several shapes, so the
             # family is the finest grain the in-step records resolve)
-            tot = sum(t * c for k_, (t, c) in in_step.items() if "k_gemm_ring" in k_)
-            cnt = sum(c for k_, (t, c) in in_step.items() if "k_gemm_ring" in k_)
+            tot = sum(t * _per_step(c, layers) for k_, (t, c) in in_step.items() if "k_gemm_ring" in k_)
+            cnt = sum(_per_step(c, layers) for k_, (t, c) in in_step.items() if "k_gemm_ring" in k_)
             if tot > 0:
                 work = 2 * fl * layers
                 res["gemm_ring_in_step"] = dict(
@@ -1090,7 +1103,7 @@ def main():
         }
         if not args.no_kernel_roofline:
             if in_step is not None:
-                out["dispatches_per_step"] = round(sum(c for _, c in in_step.values()), 1)
+                out["dispatches_per_step"] = round(sum(_per_step(c, int(cfg.gt.layers)) for _, c in in_step.values()), 1)
                 out["in_step_kernel_ms"] = {k: dict(ms=round(v[0], 5), per_step=v[1]) for k, v in
                                             sorted(in_step.items(), key=lambda kv: -kv[1][0] * kv[1][1])[:24]}
             if args.workload == "pcqm4m":
@@ -1100,9 +1113,9 @@ def main():
                 pmc = os.path.join(ROOT, "profiles", "pmc_static.json")
                 if os.path.exists(pmc):           # HBM bytes per launch from separate rocprofv3 --pmc passes (counters and
                     pmc_static = json.load(open(pmc))     # timing never share a run): read from the committed file
-                dom = dominant_roofline(in_step, kr, pmc_static) if in_step else None
+                dom = dominant_roofline(in_step, kr, pmc_static, layers_n) if in_step else None
                 if dom is None:                   # no in-step records: the largest kernel of the last committed profile
-                    dom = dominant_roofline({"k_wgrad_stream": (kr["wgrad_grouped"]["ms"], layers_n)}, kr, pmc_static)
+                    dom = dominant_roofline({"k_wgrad_stream": (kr["wgrad_grouped"]["ms"], layers_n)}, kr, pmc_static, layers_n)
                 out["roofline"] = dom
                 from graphgps_amd import gemm as _gemm
                 out["roofline_step"] = step_roofline(shape["N"], shape["E"], shape["d"], shape["H"], layers_n,

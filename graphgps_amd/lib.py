@@ -47,6 +47,9 @@ _SIGNATURES = {
     "gps_segment_pool_fwd": (c_int, [_P, _P, c_int64, c_int, c_int, _P, _P]),
     "gps_segment_pool_bwd": (c_int, [_P, _P, _P, c_int64, c_int, c_int, _P, _P]),
     "gps_embed_sum": (c_int, [_P, c_int64, c_int64, c_int, _P, _P, c_int, _P, _P]),
+    "gps_small_linear_fwd": (c_int, [_P, c_int64, _P, c_int64, _P, c_int, c_int, c_int, c_int, _P, c_int64, _P]),
+    "gps_small_linear_bwd": (c_int, [_P, c_int64, _P, c_int64, _P, c_int64, _P, c_int64, c_int, c_int, c_int, _P, c_int64,
+                                     _P, c_int64, _P, _P]),
     "gps_multihot_columns": (c_int, [c_int, _P]),
     "gps_multihot_fill": (c_int, [_P, c_int64, c_int64, c_int, _P, _P, _P]),
     "gps_segment_pool_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),

@@ -503,6 +503,19 @@ int gps_embed_sum(const int64_t* feats, int64_t ld, int64_t R, int k, const floa
                   float* out, gps_stream_t stream);
 int gps_multihot_columns(int k, const int* vocab);
 int gps_multihot_fill(const int64_t* feats, int64_t ld, int64_t R, int k, const int* vocab, float* out, gps_stream_t stream);
+/* Small dense products of the graph-level heads (csrc/small_gemm.hip, round 6): the Linear (+ ReLU) stages of
+ * graphgps/head/san_graph.py:19-42 on the pooled [B, dim_in] embedding and what autograd derives for them -- a few hundred
+ * rows, widths 1 .. 384 -- as exact fp32 products on v_mfma_f32_16x16x4_f32, one 16 x 16 output tile per workgroup.
+ *   gps_small_linear_fwd   y[M, N] = act(x[M, K] w[N, K]^T + bias)   (bias may be NULL; relu != 0: ReLU)
+ *   gps_small_linear_bwd   g' = g (.) [y > 0] when y != NULL (the layer applied ReLU), else g;
+ *                          g_x[M, K] = g' w  (NULL: skipped);  g_w[N, K] = g'^T x and g_b[N] = column sums of g'
+ *                          (g_w NULL: both skipped; g_b may be NULL)
+ * Row strides in elements; results are deterministic (contraction slices added in a fixed order, no atomics). */
+int gps_small_linear_fwd(const float* x, int64_t ldx, const float* w, int64_t ldw, const float* bias, int M, int N, int K,
+                         int relu, float* y, int64_t ldy, gps_stream_t stream);
+int gps_small_linear_bwd(const float* g, int64_t ldg, const float* y, int64_t ldy, const float* x, int64_t ldx,
+                         const float* w, int64_t ldw, int M, int N, int K, float* g_x, int64_t ldgx, float* g_w,
+                         int64_t ldgw, float* g_b, gps_stream_t stream);
 int gps_segment_pool_fwd(const float* x, const int32_t* ptr, int64_t B, int d, int mean, float* out,
                          gps_stream_t stream);
 /* The same pooling with the rows of a graph cut into slices of 32 (round 5): one workgroup per (graph, slice) -- slot

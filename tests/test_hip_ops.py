@@ -67,6 +67,59 @@ def test_graph_index_hub_and_isolated_nodes():
     assert torch.equal(gi.ptr.cpu(), ptr.to(torch.int32))
 
 
+def _hub_batch(deg, extra_graphs=3, seed=0):
+    """A star of ``deg`` leaves around node 0 (both directions, shuffled) followed by a few P30-like graphs: the degree
+    MalNet's function-call graphs reach (configs/GPS/malnettiny-GPS.yaml; hubs of thousands of callers)."""
+    gen = torch.Generator().manual_seed(seed)
+    n = deg + 1
+    hub = torch.stack([torch.arange(1, n), torch.zeros(n - 1, dtype=torch.long)])
+    parts, sizes, off = [hub, hub.flip(0)], [n], n
+    for g in range(extra_graphs):
+        k = 20 + 7 * g
+        a = torch.arange(k - 1)
+        chain = torch.stack([a, a + 1]) + off
+        parts += [chain, chain.flip(0)]
+        sizes.append(k)
+        off += k
+    ei = torch.cat(parts, 1)
+    ei = ei[:, torch.randperm(ei.shape[1], generator=gen)]
+    ptr = torch.tensor([0] + list(np.cumsum(sizes)))
+    bvec = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
+    return ei, bvec, ptr, gen
+
+
+def test_graph_index_and_gatedgcn_with_a_degree_5000_hub():
+    """Graph index bit-exact against numpy's stable argsort and the GatedGCN core against the CPU restatement when one node
+    has 5,000 in- and out-edges (the index sorts each CSR segment; the kernels walk a segment per node)."""
+    from graphgps_amd.ops import gatedgcn_aggregate
+    ei, bvec, ptr, gen = _hub_batch(5000)
+    N, E = int(ptr[-1]), ei.shape[1]
+    gi = _index(ei, bvec, ptr, use_ptr=False)
+    src, dst = ei[0].numpy(), ei[1].numpy()
+    for key, other, rowptr, oth_sorted, eid in ((dst, src, gi.rowptr_dst, gi.src_by_dst, gi.eid_by_dst),
+                                                (src, dst, gi.rowptr_src, gi.dst_by_src, gi.eid_by_src)):
+        perm = np.argsort(key, kind="stable")
+        rp = np.concatenate([[0], np.cumsum(np.bincount(key, minlength=N))])
+        assert np.array_equal(rowptr.cpu().numpy(), rp.astype(np.int32))
+        assert np.array_equal(eid.cpu().numpy(), perm.astype(np.int32))
+        assert np.array_equal(oth_sorted.cpu().numpy(), other[perm].astype(np.int32))
+    d = 128
+    proj = torch.randn(N, 4 * d, generator=gen)
+    ce = torch.randn(E, d, generator=gen)
+    wx, we = torch.randn(N, d, generator=gen), torch.randn(E, d, generator=gen)
+    pr, cr = proj.clone().double().requires_grad_(True), ce.clone().double().requires_grad_(True)
+    xr, er = gatedgcn_core_ref(pr, cr, ei)
+    ((xr * wx.double()).sum() + (er * we.double()).sum()).backward()
+    dev = torch.device("cuda:0")
+    pg, cg = proj.to(dev).requires_grad_(True), ce.to(dev).requires_grad_(True)
+    xg, eg = gatedgcn_aggregate(pg, cg, gi)
+    ((xg * wx.to(dev)).sum() + (eg * we.to(dev)).sum()).backward()
+    assert_close(xg, xr, Tol.ACT, "x_tilde (hub)")
+    assert_close(eg, er, Tol.ACT, "e_hat (hub)")
+    assert_close(pg.grad, pr.grad, Tol.GRAD_REL, "g_proj (hub)", rel_to_max=True)
+    assert_close(cg.grad, cr.grad, Tol.GRAD_REL, "g_Ce (hub)", rel_to_max=True)
+
+
 @pytest.mark.parametrize("d", [16, 52, 384])
 def test_gatedgcn_core(d):
     from graphgps_amd.ops import gatedgcn_aggregate
@@ -131,6 +184,7 @@ ATTN_CASES = [  # (H, dh, graph sizes)
     (2, 32, [150, 70, 129]),      # > 64 keys: several online-softmax blocks
     (4, 96, [31, 66]),
     (4, 64, [1000, 3, 601]),      # code2-size graphs (master_loader.py:366-368 clips at 1000 nodes)
+    (2, 64, [4500, 3]),           # MalNet-sized (configs/GPS/malnettiny-GPS.yaml: up to ~5,000 nodes): 282 row tiles per head
     (1, 128, [48, 2]),            # widest compiled head
     (2, 4, [5, 16, 32, 64]),      # narrowest compiled head, sizes exactly on the tile boundaries
     (8, 10, [12, 33, 7]),         # zinc-Graphormer: embed 80 / 8 heads
@@ -442,7 +496,10 @@ def _favor_ref(qkv, proj, ptr, H):
                                      # 1000-node one is 997 padded key rows short of Nmax, so the closed-form
                                      # padded-key term (performer_layer.py:485-487: v masked, k not) dominates its D
                                      (4, [1000, 3, 601]),
-                                     (4, [60, 999, 1, 16])])
+                                     (4, [60, 999, 1, 16]),
+                                     # MalNet-sized graphs (configs/GPS/malnettiny-GPS.yaml:40 runs CustomGatedGCN+Performer
+                                     # on graphs of up to ~5,000 nodes, mean ~1,400): 313 row tiles per (graph, head)
+                                     (4, [5000, 1400, 37])])
 def test_favor_attention_fwd_bwd(H, sizes):
     from graphgps_amd.ops import favor_attention
     from oracle.gps_oracle import gaussian_orthogonal_random_matrix
@@ -471,8 +528,9 @@ def test_favor_attention_fwd_bwd(H, sizes):
 
 
 @pytest.mark.parametrize("H,sizes,m", [(4, [1000, 3, 601, 17, 333], 266), (2, [60, 999, 1, 16], 100),
-                                       (2, [1 + (37 * i * i + 11 * i) % 90 for i in range(300)], 100)],
-                         ids=["long", "ragged", "300-graphs"])
+                                       (2, [1 + (37 * i * i + 11 * i) % 90 for i in range(300)], 100),
+                                       (4, [5000, 1400, 37], 266)],
+                         ids=["long", "ragged", "300-graphs", "malnet"])
 def test_favor_projection_in_lds_is_bit_identical(monkeypatch, H, sizes, m):
     """csrc/favor.hip round 5: the per-tile kernels of FAVOR+ with the projection staged in LDS and one workgroup per CU
     walking the work items (LP: GPS_FAVOR_LDS=1, the default from 2,048 work items on), and with the context record of a

@@ -566,7 +566,7 @@ def test_replayed_steps_return_the_current_batch_host_targets(padded):
         _, _, true = es.step_cached(b)
         assert true['y'] == want_y and true['y'] is not None, (i, true['y'][:1], want_y[:1])
         assert torch.equal(true['y_arr'], want_arr), i
-    assert es.replays == 3 and not es.failed
+    assert es.replays == 4 and not es.failed         # first sight eager; the capture and every later batch replay
 
     model.train()
     opt = FlatAdamW(model.parameters(), lr=1e-4, weight_decay=0.0)
