@@ -122,7 +122,8 @@ template <int VEC, bool GATE, bool STATS, int D>
 __device__ __forceinline__ void fwd_chunk(const float* __restrict__ Bx, const float* __restrict__ Ex, int64_t ld,
                                           const float* __restrict__ Ce, const float* __restrict__ r_edge, int d,
                                           int c, const int* nbr, const int* eids, const Vec<VEC>& dx,
-                                          Vec<VEC>& num, Vec<VEC>& den, float* __restrict__ e_hat, StatAcc<VEC>& sa) {
+                                          Vec<VEC>& num, Vec<VEC>& den, float* __restrict__ e_hat, StatAcc<VEC>& sa,
+                                          bool counted) {
   int64_t id[D];
   Vec<VEC> ex[D], bx[D], ce[D];
   float rr[D];
@@ -147,7 +148,7 @@ __device__ __forceinline__ void fwd_chunk(const float* __restrict__ Bx, const fl
       den[v] += s;                            // scatter(sigma)                      (:121-123)
     }
     eh.store(e_hat + id[u] * d + c);          // self.e = e_ij, returned in edge order (:106,134)
-    if (STATS) sa.add_e(eh);
+    if (STATS && counted) sa.add_e(eh);
   }
 }
 
@@ -157,35 +158,45 @@ __device__ __forceinline__ void fwd_rows(const float* __restrict__ Ax, const flo
                                          const float* __restrict__ Ce, const int* rp, const int* nbr,
                                          const int* eids, const NodeBlock& blk, int d, int row, int npi, int c,
                                          float* __restrict__ x_tilde, float* __restrict__ e_hat,
-                                         const float* __restrict__ r_edge, StatAcc<VEC>& sa) {
+                                         const float* __restrict__ r_edge, StatAcc<VEC>& sa, int64_t nreal) {
   for (int64_t node = blk.n0 + row; node < blk.n1; node += npi) {
     const int beg = rp[node - blk.n0], end = rp[node - blk.n0 + 1];
+    // padded batches (loader.BucketPadding): padding nodes sit at the end and their edges join padding to padding only, so
+    // "target node is real" gates the node's row AND its incoming edges out of the statistics
+    const bool counted = node < nreal;
     const Vec<VEC> dx = Vec<VEC>::load(Dx + node * ld + c);
     const Vec<VEC> ax = Vec<VEC>::load(Ax + node * ld + c);
     Vec<VEC> num = Vec<VEC>::zero(), den = Vec<VEC>::zero();
     int k = beg;
     for (; k + 4 < end; k += 4)
-      fwd_chunk<VEC, GATE, STATS, 4>(Bx, Ex, ld, Ce, r_edge, d, c, nbr + k, eids + k, dx, num, den, e_hat, sa);
+      fwd_chunk<VEC, GATE, STATS, 4>(Bx, Ex, ld, Ce, r_edge, d, c, nbr + k, eids + k, dx, num, den, e_hat, sa, counted);
     switch (end - k) {
-      case 1: fwd_chunk<VEC, GATE, STATS, 1>(Bx, Ex, ld, Ce, r_edge, d, c, nbr + k, eids + k, dx, num, den, e_hat, sa); break;
-      case 2: fwd_chunk<VEC, GATE, STATS, 2>(Bx, Ex, ld, Ce, r_edge, d, c, nbr + k, eids + k, dx, num, den, e_hat, sa); break;
-      case 3: fwd_chunk<VEC, GATE, STATS, 3>(Bx, Ex, ld, Ce, r_edge, d, c, nbr + k, eids + k, dx, num, den, e_hat, sa); break;
-      case 4: fwd_chunk<VEC, GATE, STATS, 4>(Bx, Ex, ld, Ce, r_edge, d, c, nbr + k, eids + k, dx, num, den, e_hat, sa); break;
+      case 1: fwd_chunk<VEC, GATE, STATS, 1>(Bx, Ex, ld, Ce, r_edge, d, c, nbr + k, eids + k, dx, num, den, e_hat, sa, counted); break;
+      case 2: fwd_chunk<VEC, GATE, STATS, 2>(Bx, Ex, ld, Ce, r_edge, d, c, nbr + k, eids + k, dx, num, den, e_hat, sa, counted); break;
+      case 3: fwd_chunk<VEC, GATE, STATS, 3>(Bx, Ex, ld, Ce, r_edge, d, c, nbr + k, eids + k, dx, num, den, e_hat, sa, counted); break;
+      case 4: fwd_chunk<VEC, GATE, STATS, 4>(Bx, Ex, ld, Ce, r_edge, d, c, nbr + k, eids + k, dx, num, den, e_hat, sa, counted); break;
       default: break;
     }
     Vec<VEC> xt;
 #pragma unroll
     for (int v = 0; v < VEC; ++v) xt[v] = ax[v] + num[v] / (den[v] + 1e-6f);  //          (:125,133)
     xt.store(x_tilde + node * (int64_t)d + c);
-    if (STATS) sa.add_x(xt);
+    if (STATS && counted) sa.add_x(xt);
   }
 }
 
 // Block-level finish of the statistics (STATS kernels): the npi row lanes of every column meet through LDS (merged in
-// row order by Chan's formula), lane row 0 writes the workgroup's record -- (mean, M2) of x~ and of e^ with the two row
-// counts -- write-through, and the tree (records = node blocks) completes in this launch (csrc/col_tree.hpp).
+// row order by Chan's formula) and lane row 0 writes the workgroup's RECORD -- (mean, M2) of x~ and of e^ with the two row
+// counts -- with plain stores: the records are combined by the launch behind this one (k_gg_stats_finalize).  Round 3 - 5
+// completed them in THIS launch through the two-level arrival tree (csrc/col_tree.hpp): its tail -- write-through stores,
+// tickets, two dependent combine levels by single workgroups -- cost the HBM-bound kernel 21 us (26 -> 47), as much as the
+// separate statistics pass over x~ and e^ it was meant to replace; a kernel boundary + a 96-workgroup combine costs ~6.
+struct StatRecords {
+  float* part;     // [P][4][d]: mean_x, M2_x, mean_e, M2_e of node block P
+  float* cnt;      // [P][2]: real nodes, real edges of the block
+};
 template <int VEC>
-__device__ __forceinline__ void fwd_stats_finish(const StatAcc<VEC>& sa, const tr::Tree& T, int64_t L, bool active, int row,
+__device__ __forceinline__ void fwd_stats_finish(const StatAcc<VEC>& sa, const StatRecords& T, int64_t L, bool active, int row,
                                                  int npi, int c, int d, float* lds) {
   float* cntx = lds;                     // [npi] nodes per row lane
   float* cnte = lds + npi;               // [npi] edges per row lane
@@ -222,15 +233,51 @@ __device__ __forceinline__ void fwd_stats_finish(const StatAcc<VEC>& sa, const t
         n[s] = nn;
       }
       float* rec = T.part + (L * 4 + 2 * s) * d;
-#pragma unroll
-      for (int v = 0; v < VEC; ++v) {
-        tr::st_sc1(rec + c + v, m[s][v]);
-        tr::st_sc1(rec + d + c + v, q[s][v]);
-      }
-      if (c == 0) tr::st_sc1(T.pcnt + L * 2 + s, n[s]);
+      m[s].store(rec + c);
+      q[s].store(rec + d + c);
+      if (c == 0) T.cnt[L * 2 + s] = n[s];
     }
   }
-  tr::arrive<4, tr::STATS, 12>(T, (int)L, d, lds);
+}
+
+// The records of P node blocks -> the (mean, rstd) vectors of bn_node_x and bn_edge_e (+ their running statistics).
+// A workgroup owns FC columns of ONE of the two statistics; its 256 threads are FC columns x FS record slices: a thread
+// merges records sl, sl + FS, ... (every load issued before the first use: one memory round trip for up to 16 x FS
+// records, more records repeat), the slices meet through LDS and are merged in slice order.  Combination by Chan's
+// formula in a fixed order: deterministic, the accuracy of csrc/col_tree.hpp's STATS records.
+constexpr int FC = 8, FS = 32;
+struct StatOut {
+  float *mean, *rstd, *rmean, *rvar;
+  float eps, mom;
+};
+__global__ __launch_bounds__(FC * FS) void k_gg_stats_finalize(const StatRecords T, int P, int d, const StatOut ox,
+                                                               const StatOut oe) {
+  __shared__ float sm[FS][3][FC];
+  const int per = d / FC;                         // workgroups per statistic (d % FC == 0: d % 8 == 0)
+  const int s = blockIdx.x / per;                 // 0: x~, 1: e^
+  const int cl = threadIdx.x % FC, sl = threadIdx.x / FC;
+  const int c = (blockIdx.x - s * per) * FC + cl;
+  float n = 0.f, m = 0.f, q = 0.f;
+  for (int base = sl; base < P; base += 16 * FS) {
+    float mv[16], qv[16], nv[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const int L = min(base + u * FS, P - 1);
+      mv[u] = T.part[((int64_t)L * 4 + 2 * s) * d + c];
+      qv[u] = T.part[((int64_t)L * 4 + 2 * s + 1) * d + c];
+      nv[u] = T.cnt[L * 2 + s];
+    }
+#pragma unroll
+    for (int u = 0; u < 16; ++u)
+      if (base + u * FS < P) tr::chan_merge(n, m, q, nv[u], mv[u], qv[u]);
+  }
+  sm[sl][0][cl] = n; sm[sl][1][cl] = m; sm[sl][2][cl] = q;
+  __syncthreads();
+  if (sl == 0) {
+    for (int r = 1; r < FS; ++r) tr::chan_merge(n, m, q, sm[r][0][cl], sm[r][1][cl], sm[r][2][cl]);
+    const StatOut& o = s ? oe : ox;
+    tr::stats_out(o.mean, o.rstd, o.rmean, o.rvar, o.eps, o.mom, c, m, q, n);
+  }
 }
 
 template <int VEC, bool GATE, bool STATS>
@@ -239,12 +286,14 @@ __global__ __launch_bounds__(GG_T) void k_gatedgcn_fwd(
     const float* __restrict__ Ex, int64_t ld, const float* __restrict__ Ce,
     const int32_t* __restrict__ rowptr, const int32_t* __restrict__ src,
     const int32_t* __restrict__ eid, int64_t N, int d, float* __restrict__ x_tilde,
-    float* __restrict__ e_hat, const float* __restrict__ r_edge, int nb, int npi, const tr::Tree stats) {
+    float* __restrict__ e_hat, const float* __restrict__ r_edge, int nb, int npi, const StatRecords stats,
+    const int32_t* __restrict__ n_real) {
   __shared__ int s_rp[GG_MAXNB + 1];
   __shared__ int s_src[GG_MAXE], s_eid[GG_MAXE];
   extern __shared__ __attribute__((aligned(16))) float g_fwd_lds[];   // STATS: row-lane exchange + tree scratch
   const NodeBlock blk = node_block(N, nb);
-  if (!blk.valid()) return;            // (the tree counts the valid node blocks only)
+  if (!blk.valid()) return;            // (records exist for the valid node blocks only)
+  const int64_t nreal = STATS && n_real ? (int64_t)*n_real : N;
   const bool staged = stage_slice(rowptr, src, eid, blk, s_rp, s_src, s_eid);
   __syncthreads();
   const int lpr = d / VEC;
@@ -258,9 +307,9 @@ __global__ __launch_bounds__(GG_T) void k_gatedgcn_fwd(
   if (active) {
     if (staged)     // index slices in LDS (workgroup-uniform branch: two copies of the body, one address space each)
       fwd_rows<VEC, GATE, STATS>(Ax, Bx, Dx, Ex, ld, Ce, s_rp, s_src - e0, s_eid - e0, blk, d, row, npi, c, x_tilde, e_hat,
-                                 r_edge, sa);
+                                 r_edge, sa, nreal);
     else            // a hub-heavy block (> GG_MAXE entries): same code on the global index arrays
-      fwd_rows<VEC, GATE, STATS>(Ax, Bx, Dx, Ex, ld, Ce, s_rp, src, eid, blk, d, row, npi, c, x_tilde, e_hat, r_edge, sa);
+      fwd_rows<VEC, GATE, STATS>(Ax, Bx, Dx, Ex, ld, Ce, s_rp, src, eid, blk, d, row, npi, c, x_tilde, e_hat, r_edge, sa, nreal);
   }
   if (STATS) fwd_stats_finish<VEC>(sa, stats, blk.n0 / nb, active, row, npi, c, d, g_fwd_lds);
 }
@@ -626,7 +675,7 @@ inline Plan plan_for(int64_t N, int lanes_per_row, bool forward) {
 
 #define GPS_GG_FWD(GATE, STATS, LDS)                                                                  \
   k_gatedgcn_fwd<VEC, GATE, STATS><<<pl.grid, pl.threads, LDS, s>>>(Ax, Bx, Dx, Ex, ld_node, Ce, rowptr_dst, \
-      src_by_dst, eid_by_dst, N, d, x_tilde, e_hat, r_edge, pl.nb, pl.npi, tree)
+      src_by_dst, eid_by_dst, N, d, x_tilde, e_hat, r_edge, pl.nb, pl.npi, recs, n_real)
 #define GPS_GG_BWD(GATE)                                                                             \
   k_gatedgcn_bwd<VEC, GATE><<<pl.grid, pl.threads, stash_bytes, s>>>(g_x, ld_gx, g_e, e_hat, Ax, Bx, ld_node, x_tilde, \
       rowptr_dst, src_by_dst, eid_by_dst, rowptr_src, dst_by_src, eid_by_src, N, d, g_Ce,             \
@@ -637,15 +686,15 @@ extern "C" {
 size_t gps_gatedgcn_stats_floats(int64_t N, int d) {
   if (N < 1 || d < 4 || d % 4) return 0;
   const Plan pl = plan_for(N, d / 4, true);
-  return tr::floats_for((int)((N + pl.nb - 1) / pl.nb), 4, d) + 16;
+  const size_t P = (size_t)((N + pl.nb - 1) / pl.nb);
+  return P * 4 * d + 2 * P + 16;
 }
-int gps_gatedgcn_stats_sync_words(void) { return tr::kSyncWords; }
 
 static int gatedgcn_fwd_impl(const float* Ax, const float* Bx, const float* Dx, const float* Ex,
                              int64_t ld_node, const float* Ce, const int32_t* rowptr_dst,
                              const int32_t* src_by_dst, const int32_t* eid_by_dst, int64_t N, int64_t E,
                              int d, float* x_tilde, float* e_hat, const float* r_edge, const gps_bn* bn_x,
-                             const gps_bn* bn_e, float* ws, size_t ws_floats, uint32_t* sync, gps_stream_t stream);
+                             const gps_bn* bn_e, float* ws, size_t ws_floats, const int32_t* n_real, gps_stream_t stream);
 
 int gps_gatedgcn_fwd(const float* Ax, const float* Bx, const float* Dx, const float* Ex,
                      int64_t ld_node, const float* Ce, const int32_t* rowptr_dst,
@@ -659,21 +708,21 @@ int gps_gatedgcn_fwd_stats(const float* Ax, const float* Bx, const float* Dx, co
                            int64_t ld_node, const float* Ce, const int32_t* rowptr_dst,
                            const int32_t* src_by_dst, const int32_t* eid_by_dst, int64_t N, int64_t E,
                            int d, float* x_tilde, float* e_hat, const float* r_edge, const gps_bn* bn_x,
-                           const gps_bn* bn_e, float* ws, size_t ws_floats, uint32_t* sync, gps_stream_t stream) {
-  GPS_REQUIRE(bn_x && bn_e && bn_x->mean && bn_x->rstd && bn_e->mean && bn_e->rstd && ws && sync,
+                           const gps_bn* bn_e, float* ws, size_t ws_floats, const int32_t* n_real, gps_stream_t stream) {
+  GPS_REQUIRE(bn_x && bn_e && bn_x->mean && bn_x->rstd && bn_e->mean && bn_e->rstd && ws,
               "gps_gatedgcn_fwd_stats: null statistics buffer");
-  GPS_REQUIRE(N >= 2 && E >= 2 && d % 4 == 0, "gps_gatedgcn_fwd_stats: needs N, E >= 2 and d %% 4 == 0");
+  GPS_REQUIRE(N >= 2 && E >= 2 && d % 8 == 0, "gps_gatedgcn_fwd_stats: needs N, E >= 2 and d %% 8 == 0");
   GPS_REQUIRE((bn_x->running_mean == nullptr) == (bn_x->running_var == nullptr) &&
               (bn_e->running_mean == nullptr) == (bn_e->running_var == nullptr), "gps_gatedgcn_fwd_stats: running stats");
   return gatedgcn_fwd_impl(Ax, Bx, Dx, Ex, ld_node, Ce, rowptr_dst, src_by_dst, eid_by_dst, N, E, d, x_tilde, e_hat, r_edge,
-                           bn_x, bn_e, ws, ws_floats, sync, stream);
+                           bn_x, bn_e, ws, ws_floats, n_real, stream);
 }
 
 static int gatedgcn_fwd_impl(const float* Ax, const float* Bx, const float* Dx, const float* Ex,
                              int64_t ld_node, const float* Ce, const int32_t* rowptr_dst,
                              const int32_t* src_by_dst, const int32_t* eid_by_dst, int64_t N, int64_t E,
                              int d, float* x_tilde, float* e_hat, const float* r_edge, const gps_bn* bn_x,
-                             const gps_bn* bn_e, float* ws, size_t ws_floats, uint32_t* sync, gps_stream_t stream) {
+                             const gps_bn* bn_e, float* ws, size_t ws_floats, const int32_t* n_real, gps_stream_t stream) {
   GPS_REQUIRE(N >= 0 && E >= 0 && d > 0 && ld_node >= d, "gps_gatedgcn_fwd: bad sizes N=%lld E=%lld d=%d ld=%lld",
               (long long)N, (long long)E, d, (long long)ld_node);
   if (N == 0) return GPS_OK;
@@ -687,22 +736,21 @@ static int gatedgcn_fwd_impl(const float* Ax, const float* Bx, const float* Dx, 
   GPS_DISPATCH_VEC(d, ld_node % 4 == 0 && ok(16), ld_node % 2 == 0 && ok(8), {
     GPS_REQUIRE(d / VEC <= GG_T, "gps_gatedgcn_fwd: d=%d too wide for one workgroup pass (%d lanes)", d, d / VEC);
     const Plan pl = plan_for(N, d / VEC, true);
-    tr::Tree tree{};
+    StatRecords recs{};
     if (bn_x) {
       GPS_REQUIRE(VEC == 4, "gps_gatedgcn_fwd_stats: rows must be 16-byte aligned (d %% 4 == 0, ld %% 4 == 0)");
       const int P = (int)((N + pl.nb - 1) / pl.nb);
-      GPS_REQUIRE(P <= tr::kMaxParts, "gps_gatedgcn_fwd_stats: %d node blocks exceed the tree (%d)", P, tr::kMaxParts);
-      GPS_REQUIRE(aligned_to(ws, 16) && ws_floats >= tr::floats_for(P, 4, d), "gps_gatedgcn_fwd_stats: workspace (gps_gatedgcn_stats_floats)");
-      float* wp = ws;
-      tree = tr::carve(wp, sync, P, 4, tr::STATS, d);
-      tree.o0 = bn_x->mean; tree.o1 = bn_x->rstd; tree.o2 = bn_x->running_mean; tree.o3 = bn_x->running_var;
-      tree.eps = bn_x->eps; tree.momentum = bn_x->momentum;
-      tree.p0 = bn_e->mean; tree.p1 = bn_e->rstd; tree.p2 = bn_e->running_mean; tree.p3 = bn_e->running_var;
-      tree.eps2 = bn_e->eps; tree.momentum2 = bn_e->momentum;
-      // dynamic LDS: [2 npi] counts + [npi][2][d] row-lane exchange, or the tree's scratch
-      const size_t ex = 2 * (size_t)((pl.npi + 3) & ~3) + (size_t)pl.npi * 2 * d;
-      const size_t lds = sizeof(float) * std::max(ex, (size_t)tr::scratch_floats(4, pl.threads)) + 16;
+      GPS_REQUIRE(aligned_to(ws, 16) && ws_floats >= (size_t)P * 4 * d + 2 * (size_t)P,
+                  "gps_gatedgcn_fwd_stats: workspace (gps_gatedgcn_stats_floats)");
+      recs.part = ws;
+      recs.cnt = ws + (size_t)P * 4 * d;
+      // dynamic LDS: [2 npi] counts + [npi][2][d] row-lane exchange
+      const size_t lds = sizeof(float) * (2 * (size_t)((pl.npi + 3) & ~3) + (size_t)pl.npi * 2 * d) + 16;
       if (r_edge) GPS_GG_FWD(true, true, lds); else GPS_GG_FWD(false, true, lds);
+      if (int rc = gps::launch_status("gps_gatedgcn_fwd_stats")) return rc;
+      const StatOut ox{bn_x->mean, bn_x->rstd, bn_x->running_mean, bn_x->running_var, bn_x->eps, bn_x->momentum};
+      const StatOut oe{bn_e->mean, bn_e->rstd, bn_e->running_mean, bn_e->running_var, bn_e->eps, bn_e->momentum};
+      k_gg_stats_finalize<<<2 * (d / FC), FC * FS, 0, s>>>(recs, P, d, ox, oe);
     } else {
       if (r_edge) GPS_GG_FWD(true, false, 0); else GPS_GG_FWD(false, false, 0);
     }

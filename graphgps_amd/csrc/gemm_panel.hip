@@ -53,8 +53,7 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-constexpr int TM = 64, TN = 192, BK = 32;
-constexpr int PITCH = 40;          // bf16 per LDS row: 32 + 8 (80 bytes: conflict-free 16-byte fragment reads)
+constexpr int BK = 32;               // contraction elements per k-stage
 constexpr int NTHREADS = 256;
 
 __device__ __forceinline__ uint32_t mix32(uint32_t x) {
@@ -200,149 +199,12 @@ struct PanelArgs {
                            // out of the column statistics), or nullptr
 };
 
-// Epilogue shared by both kernels.  D[row = (q&3) + 8*(q>>2) + 4*kh][col = li] of each 32 x 32 block; 32 lanes = 128
-// contiguous bytes per row.
-template <int EPI, bool HAS_CIN>
-__device__ __forceinline__ void panel_epilogue(const PanelArgs& P, const f32x16 (&acc)[3], int64_t m0, int n0, int wm,
-                                               int wn, int li, int kh) {
-  const uint64_t seed = gps::salted_seed(P.seed, P.salt);
-  const bool drop = EPI != 0 && P.p_drop > 0.0f;
-  const float inv_keep = drop ? 1.0f / (1.0f - P.p_drop) : 1.0f;
-#pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const int col = n0 + wn * 96 + j * 32 + li;
-    const float bv = P.bias ? P.bias[col] : 0.0f;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int64_t row = m0 + wm * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh;
-      const int64_t rc = row < P.M ? row : P.M - 1;          // clamped: loads unconditional, the store predicated
-      float v = acc[j][q] + bv;
-      if (HAS_CIN) v += __builtin_nontemporal_load(P.Cin + rc * P.ldcin + col);
-      if (EPI == 1) v = fmaxf(v, 0.0f);
-      if (EPI == 2) v = P.mask_src[rc * P.ldmask + col] > 0.0f ? v : 0.0f;
-      if (EPI != 0) {
-        const bool keep = !drop || keep_elem(row_hash((uint32_t)rc, seed), (uint32_t)col, P.p_drop);
-        v = keep ? v * inv_keep : 0.0f;
-      }
-      if (row < P.M) __builtin_nontemporal_store(v, P.C + row * P.ldc + col);
-    }
-  }
-}
-
-template <int EPI, bool HAS_CIN>
-__global__ __launch_bounds__(NTHREADS) void k_gemm_panel(const PanelArgs P) {
-  // single-buffered stages (61 KB): TWO workgroups share a CU, and while one of them splits / stages / waits at its
-  // barrier the other one's wavefronts keep the MFMA pipe busy (double-buffered at 123 KB = one workgroup per CU,
-  // one wavefront per SIMD, every non-MFMA cycle was an idle MFMA cycle: measured 0.6x the library GEMMs)
-  __shared__ __attribute__((aligned(16))) uint16_t As[3][TM * PITCH];
-  __shared__ __attribute__((aligned(16))) uint16_t Bs[3][TN * PITCH];
-  const int panel = blockIdx.x / P.row_tiles, rt = blockIdx.x - panel * P.row_tiles;   // panel-major numbering
-  const int64_t m0 = (int64_t)rt * TM;
-  const int n0 = panel * TN;
-  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int li = lane & 31, kh = lane >> 5;
-  const int KS = P.K / BK;
-
-  // staging roles.  A: 2 float4 per thread (rows ar, ar + 32; 4 k at akq); W: 9 16-byte chunks per thread
-  const int ar = t >> 3, akq = (t & 7) * 4;
-  const float* __restrict__ Ag = P.A;
-  const int64_t arow0 = min(m0 + ar, P.M - 1), arow1 = min(m0 + ar + 32, P.M - 1);
-  const bool aok0 = m0 + ar < P.M, aok1 = m0 + ar + 32 < P.M;
-  // A comes from HBM (~1-2 us under load) and a stage is only ~0.4 us of MFMA work: ADEPTH stages of A are kept in
-  // flight per workgroup (a one-stage prefetch left 8 KB per CU outstanding and the loop ran at the pace of one
-  // HBM round trip per stage: measured 0.55x the library GEMMs); W stages come from L2, one stage ahead
-  constexpr int ADEPTH = 4;
-  f32x4 ra[ADEPTH][2];     // native vector types: HIP's float4 / uint4 structs kept these arrays in scratch memory
-  u32x4 rb[9];
-  auto load_a = [&](int s, f32x4 (&dst)[2]) __attribute__((always_inline)) {
-    // A is read once per column panel and C written once: both marked non-temporal, so that the weight panel
-    // every workgroup of the XCD re-streams (0.4 MB) stays in the 4 MB L2 instead of being evicted by them
-    dst[0] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Ag + arow0 * P.lda + s * BK + akq));
-    dst[1] = __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(Ag + arow1 * P.lda + s * BK + akq));
-  };
-  auto load_b = [&](int s, u32x4 (&rbuf)[9]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int p = 0; p < 3; ++p) {
-      // piece p, stage s, rows n0 .. n0 + 191: one contiguous block of 192 * 32 bf16 = 768 16-byte chunks
-      const u32x4* src = reinterpret_cast<const u32x4*>(P.Bp + (((int64_t)p * KS + s) * P.N + n0) * BK);
-#pragma unroll
-      for (int i = 0; i < 3; ++i) rbuf[p * 3 + i] = src[t + NTHREADS * i];
-    }
-  };
-  auto store_lds = [&](const f32x4 (&src)[2], const u32x4 (&rbuf)[9]) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const f32x4 v = src[i];
-      const bool ok = i == 0 ? aok0 : aok1;
-      uint32_t h[4], m[4], l[4];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) split1(ok ? v[j] : 0.0f, h[j], m[j], l[j]);
-      const int off = (ar + 32 * i) * PITCH + akq;
-      *reinterpret_cast<u32x2*>(&As[0][off]) = (u32x2){(h[0] >> 16) | h[1], (h[2] >> 16) | h[3]};
-      *reinterpret_cast<u32x2*>(&As[1][off]) = (u32x2){(m[0] >> 16) | m[1], (m[2] >> 16) | m[3]};
-      *reinterpret_cast<u32x2*>(&As[2][off]) = (u32x2){(l[0] >> 16) | l[1], (l[2] >> 16) | l[3]};
-    }
-#pragma unroll
-    for (int p = 0; p < 3; ++p)
-#pragma unroll
-      for (int i = 0; i < 3; ++i) {
-        const int c = t + NTHREADS * i;          // chunk: row c >> 2, 8 bf16 at (c & 3) * 8
-        *reinterpret_cast<u32x4*>(&Bs[p][(c >> 2) * PITCH + (c & 3) * 8]) = rbuf[p * 3 + i];
-      }
-  };
-
-  f32x16 acc[3];
-#pragma unroll
-  for (int j = 0; j < 3; ++j)
-#pragma unroll
-    for (int q = 0; q < 16; ++q) acc[j][q] = 0.0f;
-
-#pragma unroll
-  for (int q = 0; q < ADEPTH; ++q) load_a(q, ra[q]);      // KS is a multiple of ADEPTH (host check)
-  load_b(0, rb);
-  for (int s0 = 0; s0 < KS; s0 += ADEPTH) {
-#pragma unroll
-    for (int q = 0; q < ADEPTH; ++q) {
-      const int s = s0 + q;
-      if (s) __syncthreads();                  // every wave is done with stage s-1's tiles
-      store_lds(ra[q], rb);                    // stage s
-      // unconditional (past the last stage the last one is re-read): a load under a condition makes the register
-      // arrays live across control flow and the compiler parks them in scratch memory (measured: 0.53x)
-      load_a(min(s + ADEPTH, KS - 1), ra[q]);
-      load_b(min(s + 1, KS - 1), rb);          // in flight during the MFMAs below
-      __syncthreads();
-#pragma unroll
-      for (int ks = 0; ks < BK / 16; ++ks) {
-        bf16x8 a[3], b[3][3];
-        const int aoff = (wm * 32 + li) * PITCH + ks * 16 + 8 * kh;
-#pragma unroll
-        for (int p = 0; p < 3; ++p) a[p] = *reinterpret_cast<const bf16x8*>(&As[p][aoff]);
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          const int boff = (wn * 96 + j * 32 + li) * PITCH + ks * 16 + 8 * kh;
-#pragma unroll
-          for (int p = 0; p < 3; ++p) b[j][p] = *reinterpret_cast<const bf16x8*>(&Bs[p][boff]);
-        }
-        // smallest terms first; the three accumulators rotate so no MFMA waits on its predecessor
-        constexpr int TA[6] = {1, 2, 0, 1, 0, 0}, TB[6] = {1, 0, 2, 0, 1, 0};
-#pragma unroll
-        for (int term = 0; term < 6; ++term)
-#pragma unroll
-          for (int j = 0; j < 3; ++j)
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[TA[term]], b[j][TB[term]], acc[j], 0, 0, 0);
-      }
-    }
-  }
-
-  panel_epilogue<EPI, HAS_CIN>(P, acc, m0, n0, wm, wn, li, kh);
-}
-
 // ------------------------------------------------------------------------------------------------------------
 // Ring kernel: the same 64 x 192 panel and the same arithmetic, with the staging rebuilt around LDS-DMA.
 //
-// k_gemm_panel above stages through registers (global -> VGPR -> split -> ds_write) into ONE LDS stage behind two
-// barriers; rocprofv3 PMC at the block's shapes: MFMA pipe 31 % busy (17 % at N = 384), 48 % of wave time in issue
+// Round 2's first kernel (k_gemm_panel, removed in round 6: the ring serves every supported shape since round 3) staged
+// through registers (global -> VGPR -> split -> ds_write) into ONE LDS stage behind two barriers; rocprofv3 PMC at the
+// block's shapes: MFMA pipe 31 % busy (17 % at N = 384), 48 % of wave time in issue
 // stalls, 32 % parked at waitcnt / barriers, 2.7 bank-conflict cycles per LDS instruction (the padded pitch is
 // conflict-free for the fragment reads but 2-way for the staging writes).  Here:
 //   * every global -> LDS byte moves by global_load_lds_dwordx4 (1 KB per wave-instruction, no VGPR, no ds_write) into
@@ -1018,10 +880,6 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring16(const PanelArgs P) 
   uint32_t st_hi;
   auto split_part = [&](int part, const f32x4 (&raw)[2], int d, Ring16A& out) __attribute__((always_inline)) {
     const f32x2 v = (f32x2){raw[d >> 1][(d & 1) * 2], raw[d >> 1][(d & 1) * 2 + 1]};
-#ifdef GPS_ABL_R16_NO_SPLIT     // ablation (tools/micro/ring_ablate.sh; results are garbage, timing only): raw bits as pieces
-    if (part == 0) { out.p[0][d] = __float_as_uint(v[0]); out.p[1][d] = __float_as_uint(v[1]); }
-    return;
-#endif
     if (part == 0) {
       st_hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v * sa, f16x2));
       out.p[0][d] = st_hi;
@@ -1041,13 +899,8 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring16(const PanelArgs P) 
 #pragma unroll
     for (int i = 0; i < G; ++i) {
       const int term = i / (NJ * MB), mb = (i / NJ) % MB, j = i % NJ;
-#ifdef GPS_ABL_R16_NO_MFMA      // ablation: one VALU op in the MFMA's place
-      acc[mb][j][0] += __uint_as_float(ac[mb].p[TA[term]][0]) * __uint_as_float(fc.b[j][TB[term]][0]);
-#else
       acc[mb][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ac[mb].p[TA[term]]),
                                                          __builtin_bit_cast(f16x8, fc.b[j][TB[term]]), acc[mb][j], 0, 0, 0);
-#endif
-#ifndef GPS_ABL_R16_NO_RD       // ablation: no fragment reads in the loop (registers keep the prologue's fragments)
       if (i == 0) {
 #pragma unroll
         for (int b = 0; b < MB; ++b) {
@@ -1060,12 +913,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring16(const PanelArgs P) 
         for (int k = r16_rd_first(i, NW, RD_GAPS); k < r16_rd_first(i + 1, NW, RD_GAPS); ++k)
           fn.b[k / 2][k % 2] = *reinterpret_cast<const u32x4*>(rd_slot + b_off[rd_ks] + (k / 2) * (32 * 64) + (k % 2) * BP);
       }
-#else
-      if (i == 0) fn = fc;
-#endif
-#ifndef GPS_ABL_R16_NO_DMA      // ablation: no global -> LDS transfers in the loop (the prologue's stay)
       if (i < dma_count) dma(dma_first + i, dma_stage, dma_slot);
-#endif
       if (i >= SPLIT0) {
 #pragma unroll
         for (int u = 0; u < SPLITQ; ++u) {
@@ -1119,9 +967,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring16(const PanelArgs P) 
     unsigned char* const lst = ring + ((I + S - 1) % S) * SLOT;
     region(a0, f0, a1, f1, cur, 1, min(s + S - 1, KS - 1), lst, ND_ODD, ND_EVEN);
     __builtin_amdgcn_s_waitcnt(waitcnt_imm((S - 2) * ND, 0));
-#ifndef GPS_ABL_R16_NO_BAR      // ablation: no stage barrier
     __builtin_amdgcn_s_barrier();
-#endif
     __builtin_amdgcn_sched_barrier(0);
     region(a1, f1, a0, f0, nxt, 0, min(s + S, KS - 1), cur, 0, ND_ODD);
   };
@@ -1159,20 +1005,7 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring16(const PanelArgs P) 
 #pragma unroll
   for (int j = 0; j < NJ; ++j) sk[j] = s1[j] = s2[j] = 0.f;
   float amx = 0.f;
-#ifdef GPS_ABL_R16_NO_STORE     // ablation: no epilogue (one conditional store keeps the accumulators alive)
-  {
-    float sum = 0.f;
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-      for (int j = 0; j < NJ; ++j)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) sum += acc[mb][j][q];
-    if (sum == 1.2345678e-30f) P.C[0] = sum;
-  }
-#else
   ring_epilogue<MB, NJ, EPI, HAS_CIN, EDGE>(P, acc, m0, n0, wm, wn, li, kh, sk, s1, s2, amx);
-#endif
   if (EPI == 3) ring_stats<MB, NJ>(P, rt, panel, m0, wm, wn, li, kh, sk, s1, s2, reinterpret_cast<float*>(ring));
   if (P.c_amax) {                                        // workgroup-uniform: max|C| of this tile -> one atomic
     uint32_t m = __float_as_uint(amx);
@@ -1188,267 +1021,6 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring16(const PanelArgs P) 
   stamp(3);
 }
 
-// ------------------------------------------------------------------------------------------------------------
-// Round 5 -- the same kernel with LOADER WAVEFRONTS (k_gemm_ring16L): 4 consumer wavefronts (the 2 x 2 register tiles
-// of k_gemm_ring16, unchanged arithmetic, fragments, swizzles and epilogues) + 2 wavefronts that do nothing but move
-// global -> LDS.  Why: the PMC passes of the round (profiles/r05_pmc_gemm16.json) show the merged projection's wavefronts
-// issuing 49 % of their cycles and stalled on issue for another 33 %, matrix pipe 42 % busy over a wavefront's lifetime;
-// the ablation builds (profiles/r05_gemm_ring16_ablation.txt) say where: the SAME loop without its LDS-DMA instructions
-// runs the seven projection shapes of a block in 209 us instead of 257 (the K = 2688 input gradient: 49 instead of 70) --
-// an in-order wavefront that issues a global_load_lds between two MFMAs pays 60-180 cycles of issue for it
-// (MI355X_MICROARCH.md, "LDS-DMA piece issue cost"), ten times per 1152-cycle stage, and the matrix pipe drains behind
-// it.  Moved to their own wavefronts those instructions cost the consumers nothing: VMEM issue and MFMA issue of
-// DIFFERENT wavefronts of a SIMD proceed side by side.
-// Protocol (one s_barrier per stage, as before; every barrier counts all six wavefronts):
-//   loaders   fill all S slots; wait until stage 0 has landed (their own vmcnt); barrier B0
-//             stage s:  vmcnt((S-2) PER): stage s+1 has landed | barrier B(s+1): every consumer is done with slot s % S |
-//                       issue stage s+S into that slot (past the last stage: re-fetch the last one, never read -- the
-//                       count of transfers in flight must stay (S-1) PER for the counted wait to mean what it says)
-//   consumers barrier B0; stage s:  region 2s (multiplies k-step 2s, fetches the fragments of k-step 2s+1 from slot s % S) |
-//                       lgkmcnt(0) | barrier B(s+1) | region 2s+1 (multiplies 2s+1, fetches 2s+2 from slot (s+1) % S)
-//   end       loaders drain (vmcnt(0): no transfer may still be landing when the LDS is handed back or re-used as
-//             scratch), meet the consumers at one more barrier when the epilogue uses LDS (statistics, max|C|), and exit;
-//             a terminated wavefront no longer counts in later barriers.
-// Each loader serves the transfers of two consumers' shares (PER = 2 ND <= 20 per stage, so (S-1) PER <= 63 fits vmcnt
-// except for the 5-slot rings, where the 64th transfer simply waits for the first to land).
-// EDGE shapes stay on k_gemm_ring16.
-// ------------------------------------------------------------------------------------------------------------
-// MEASURED (profiles/r05_gemm_ring16_loader_wavefronts.txt, tools/runs/gpu_r6c.sh): parity green on all 142 GEMM / statistics
-// tests, and NO faster -- the seven projection shapes 256.4 us against 250.3 for k_gemm_ring16, the step 8.89-8.93 against
-// 8.94 ms.  So the issue slots of the transfers were not what the ablation's 47 us were: without its transfers the loop
-// has no DATA to wait for; the loop is bound by the arrival of 40 KB per stage and CU through the L2 -> LDS path (~20 bytes
-// per cycle and CU at these sizes), whoever issues them.  Kept as a record of the experiment, compiled only with
-// -DGPS_RING16_LOADERS (then GPS_GEMM_LOADERS=1 selects it at run time).
-#ifdef GPS_RING16_LOADERS
-constexpr int R16L_NLOAD = 2;
-constexpr int NTHREADS_L = NTHREADS + 64 * R16L_NLOAD;
-
-template <int MB, int NJ, int EPI, bool HAS_CIN>
-__global__ __launch_bounds__(NTHREADS_L, 2) void k_gemm_ring16L(const PanelArgs P) {
-  constexpr int TNV = 64 * NJ;
-  constexpr int BP = rg_bp(NJ);
-  constexpr int A_BYTES = rg_a_bytes(MB), SLOT = r16_slot_bytes(MB, NJ);
-  constexpr int S = r16_slots(MB, NJ);          // ring depth
-  constexpr int NA = 2 * MB;                    // A transfers per consumer share and stage
-  constexpr int NW = 2 * NJ;                    // W transfers per consumer share and stage
-  constexpr int ND = NA + NW;
-  constexpr int PER = 2 * ND;                   // transfers per loader and stage
-  constexpr int G = 3 * MB * NJ;                // MFMAs (= issue gaps) per region
-  constexpr int RD_GAPS = G < 4 ? G : 4;
-  constexpr int SPLITQ = G >= 9 ? (12 * MB + (G - 4) - 1) / (G - 4) : (12 * MB + (G - 1) - 1) / (G - 1);
-  constexpr int SPLIT0 = G >= 9 ? G - (12 * MB + SPLITQ - 1) / SPLITQ : 1;
-  static_assert(12 * MB <= (G - SPLIT0) * SPLITQ, "the staging does not fit the region's issue gaps");
-  static_assert((S - 2) * PER <= 63 && S >= 3, "vmcnt range");
-  extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];
-  auto stamp = [&](int k) __attribute__((always_inline)) {
-    if (P.trace && threadIdx.x == 0) P.trace[4 * (size_t)blockIdx.x + k] = __builtin_amdgcn_s_memtime();
-  };
-  stamp(0);
-  const int panel = blockIdx.x / P.row_tiles, rt = blockIdx.x - panel * P.row_tiles;   // panel-major numbering
-  const int64_t m0 = (int64_t)rt * (64 * MB);
-  const int n0 = panel * TNV;
-  const int t = threadIdx.x, lane = t & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
-  const int KS = (P.K + BK - 1) / BK;
-  const bool lds_after = EPI == 3 || P.c_amax != nullptr;       // (kernel-uniform) the epilogue re-uses the ring as scratch
-
-  if (wave >= 4) {
-    // ================================ loader ================================
-    const int lw = wave - 4;
-    const unsigned char* a_src[2][NA];
-    const unsigned char* b_src[2];
-#pragma unroll
-    for (int vv = 0; vv < 2; ++vv) {
-      const int v = 2 * lw + vv;                // the consumer whose share this is
-#pragma unroll
-      for (int i = 0; i < NA; ++i) {
-        const int row = 8 * NA * v + 8 * i + (lane >> 3);
-        const int c = (lane & 7) ^ ((row >> 1) & 7);
-        const int64_t grow = min(m0 + row, P.M - 1);
-        a_src[vv][i] = reinterpret_cast<const unsigned char*>(P.A + grow * P.lda) + c * 16;
-      }
-      b_src[vv] = reinterpret_cast<const unsigned char*>(P.Bp) + ((int64_t)n0 + 16 * NJ * v + (lane >> 2)) * (BK * 2) +
-                  (((lane & 3) ^ ((lane >> 4) & 3)) * 16);
-    }
-    const int64_t stage_stride = (int64_t)P.Nimg * (BK * 2);
-    const int64_t piece_stride = stage_stride * KS;
-    auto fill = [&](int s, unsigned char* slot) __attribute__((always_inline)) {
-#pragma unroll
-      for (int vv = 0; vv < 2; ++vv) {
-        const int v = 2 * lw + vv;
-#pragma unroll
-        for (int g = 0; g < NA; ++g)
-          glds16(a_src[vv][g] + (int64_t)s * (BK * 4), slot + v * (NA * 1024) + g * 1024);
-#pragma unroll
-        for (int i = 0; i < NW; ++i)
-          glds16(b_src[vv] + s * stage_stride + (i / NJ) * piece_stride + (i % NJ) * 1024,
-                 slot + A_BYTES + (i / NJ) * BP + v * (NJ * 1024) + (i % NJ) * 1024);
-      }
-    };
-#pragma unroll
-    for (int st = 0; st < S; ++st) fill(min(st, KS - 1), ring + st * SLOT);
-    __builtin_amdgcn_s_waitcnt(waitcnt_imm((S - 1) * PER > 63 ? 63 : (S - 1) * PER, 15));     // stage 0 has landed
-    __builtin_amdgcn_s_barrier();                                                              // B0
-    int slot_i = 0;
-    for (int s = 0; s < KS; ++s) {
-      __builtin_amdgcn_s_waitcnt(waitcnt_imm((S - 2) * PER, 15));        // stage s+1 has landed (s+2 .. s+S-1 in flight)
-      __builtin_amdgcn_s_barrier();                                      // B(s+1): slot s % S is free
-      fill(min(s + S, KS - 1), ring + slot_i * SLOT);
-      slot_i = slot_i + 1 == S ? 0 : slot_i + 1;
-    }
-    __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 15));                      // nothing of this wavefront still lands in LDS
-    if (lds_after) __builtin_amdgcn_s_barrier();                         // ... before the consumers re-use the ring
-    return;
-  }
-
-  // ================================ consumers ================================
-  const int wm = wave >> 1, wn = wave & 1;
-  const int li = lane & 31, kh = lane >> 5;
-  const unsigned bea = amax_be(P.a_amax), bew = amax_be(P.w_amax);
-  const float sa = amax_scale(bea);
-  int a_off[2][2], b_off[2];
-#pragma unroll
-  for (int ks = 0; ks < 2; ++ks) {
-    const int c0 = ks * 4 + kh * 2, sw = (li >> 1) & 7;
-    a_off[ks][0] = (wm * 32 * MB + li) * 128 + ((c0 ^ sw) * 16);
-    a_off[ks][1] = (wm * 32 * MB + li) * 128 + (((c0 + 1) ^ sw) * 16);
-    b_off[ks] = A_BYTES + (wn * 32 * NJ + li) * 64 + (((ks * 2 + kh) ^ ((li >> 2) & 3)) * 16);
-  }
-  f32x16 acc[MB][NJ];
-#pragma unroll
-  for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[mb][j][q] = 0.0f;
-
-  f32x2 st_hb;
-  uint32_t st_hi;
-  auto split_part = [&](int part, const f32x4 (&raw)[2], int d, Ring16A& out) __attribute__((always_inline)) {
-    const f32x2 v = (f32x2){raw[d >> 1][(d & 1) * 2], raw[d >> 1][(d & 1) * 2 + 1]};
-    if (part == 0) {
-      st_hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v * sa, f16x2));
-      out.p[0][d] = st_hi;
-    } else if (part == 1) {
-      st_hb = __builtin_convertvector(__builtin_bit_cast(f16x2, st_hi), f32x2);
-    } else {
-      out.p[1][d] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v * sa - st_hb, f16x2));
-    }
-  };
-  constexpr int TA[3] = {1, 0, 0}, TB[3] = {0, 1, 0};     // lo*hi, hi*lo, hi*hi: smallest terms first
-  f32x4 raw[MB][2];
-  auto region = [&](const Ring16A (&ac)[MB], const Ring16Frag<NJ>& fc, Ring16A (&an)[MB], Ring16Frag<NJ>& fn,
-                    const unsigned char* rd_slot, int rd_ks) __attribute__((always_inline)) {
-#pragma unroll
-    for (int i = 0; i < G; ++i) {
-      const int term = i / (NJ * MB), mb = (i / NJ) % MB, j = i % NJ;
-      acc[mb][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, ac[mb].p[TA[term]]),
-                                                         __builtin_bit_cast(f16x8, fc.b[j][TB[term]]), acc[mb][j], 0, 0, 0);
-      if (i == 0) {
-#pragma unroll
-        for (int b = 0; b < MB; ++b) {
-          raw[b][0] = *reinterpret_cast<const f32x4*>(rd_slot + a_off[rd_ks][0] + b * 4096);
-          raw[b][1] = *reinterpret_cast<const f32x4*>(rd_slot + a_off[rd_ks][1] + b * 4096);
-        }
-      }
-      if (i < RD_GAPS) {
-#pragma unroll
-        for (int k = r16_rd_first(i, NW, RD_GAPS); k < r16_rd_first(i + 1, NW, RD_GAPS); ++k)
-          fn.b[k / 2][k % 2] = *reinterpret_cast<const u32x4*>(rd_slot + b_off[rd_ks] + (k / 2) * (32 * 64) + (k % 2) * BP);
-      }
-      if (i >= SPLIT0) {
-#pragma unroll
-        for (int u = 0; u < SPLITQ; ++u) {
-          const int q = (i - SPLIT0) * SPLITQ + u;
-          if (q < 12 * MB) split_part(q % 3, raw[(q / 3) / 4], (q / 3) % 4, an[(q / 3) / 4]);
-        }
-      }
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-
-  __builtin_amdgcn_s_barrier();                                         // B0: stage 0 is in slot 0
-  stamp(1);
-  Ring16Frag<NJ> f0, f1;
-  Ring16A a0[MB], a1[MB];
-#pragma unroll
-  for (int b = 0; b < MB; ++b) {
-    raw[b][0] = *reinterpret_cast<const f32x4*>(ring + a_off[0][0] + b * 4096);
-    raw[b][1] = *reinterpret_cast<const f32x4*>(ring + a_off[0][1] + b * 4096);
-  }
-#pragma unroll
-  for (int j = 0; j < NJ; ++j)
-#pragma unroll
-    for (int p = 0; p < 2; ++p)
-      f0.b[j][p] = *reinterpret_cast<const u32x4*>(ring + b_off[0] + j * (32 * 64) + p * BP);
-#pragma unroll
-  for (int b = 0; b < MB; ++b)
-#pragma unroll
-    for (int d = 0; d < 4; ++d)
-#pragma unroll
-      for (int part = 0; part < 3; ++part) split_part(part, raw[b], d, a0[b]);
-  __builtin_amdgcn_sched_barrier(0);
-
-  auto stage = [&](auto ic) __attribute__((always_inline)) {
-    constexpr int I = decltype(ic)::value;
-    unsigned char* const cur = ring + I * SLOT;
-    unsigned char* const nxt = ring + ((I + 1) % S) * SLOT;
-    region(a0, f0, a1, f1, cur, 1);
-    __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, 0));       // this wavefront's reads of slot I have returned
-    __builtin_amdgcn_s_barrier();                         // B(s+1): stage s+1 has landed; slot I may be refilled
-    __builtin_amdgcn_sched_barrier(0);
-    region(a1, f1, a0, f0, nxt, 0);
-  };
-  int s0 = 0;
-  for (; s0 + S <= KS; s0 += S) {
-    stage(IntC<0>{});
-    stage(IntC<1>{});
-    stage(IntC<2>{});
-    if constexpr (S > 3) stage(IntC<3 % S>{});
-    if constexpr (S > 4) stage(IntC<4 % S>{});
-  }
-  if (s0 < KS) {                                            // up to S-1 stages left over (workgroup-uniform)
-    stage(IntC<0>{});
-    if (s0 + 1 < KS) {
-      stage(IntC<1>{});
-      if (s0 + 2 < KS) {
-        stage(IntC<2>{});
-        if constexpr (S > 4) {
-          if (s0 + 3 < KS) stage(IntC<3 % S>{});
-        }
-      }
-    }
-  }
-  __builtin_amdgcn_s_waitcnt(waitcnt_imm(63, 0));
-  if (lds_after) __builtin_amdgcn_s_barrier();            // the loaders have drained: the ring is scratch from here on
-  stamp(2);
-  const float ua = amax_unscale(bea), uw = amax_unscale(bew);
-#pragma unroll
-  for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-    for (int j = 0; j < NJ; ++j)
-#pragma unroll
-      for (int q = 0; q < 16; ++q) acc[mb][j][q] = (acc[mb][j][q] * ua) * uw;
-  float sk[NJ], s1[NJ], s2[NJ];
-#pragma unroll
-  for (int j = 0; j < NJ; ++j) sk[j] = s1[j] = s2[j] = 0.f;
-  float amx = 0.f;
-  ring_epilogue<MB, NJ, EPI, HAS_CIN, false>(P, acc, m0, n0, wm, wn, li, kh, sk, s1, s2, amx);
-  if (EPI == 3) ring_stats<MB, NJ, NTHREADS>(P, rt, panel, m0, wm, wn, li, kh, sk, s1, s2, reinterpret_cast<float*>(ring));
-  if (P.c_amax) {                                        // workgroup-uniform: max|C| of this tile -> one atomic
-    uint32_t m = __float_as_uint(amx);
-#pragma unroll
-    for (int o = 32; o; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
-    uint32_t* wmax = reinterpret_cast<uint32_t*>(ring);
-    __syncthreads();                                     // (the four consumers: the loaders have exited)
-    if (lane == 0) wmax[wave] = m;
-    __syncthreads();
-    if (t == 0) gps::amax_raise(P.c_amax, max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])));
-  }
-  stamp(3);
-}
-
-#endif  // GPS_RING16_LOADERS
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) % 16) == 0; }
 
@@ -1463,17 +1035,12 @@ static int panel_launch(const float* A, int64_t lda, int64_t M, int K, const uin
                         uint32_t* c_amax = nullptr, const int32_t* m_dev = nullptr);
 
 // 128-row panels (MB = 2) when they still give every CU a workgroup; 64-column panels always use 64 rows (the only
-// NJ = 1 instantiation).  GPS_GEMM_RING_MB = 1 / 2 forces one.
+// NJ = 1 instantiation).
 static int ring_mb(int64_t M, int N, int K) {
-  static const int mb_cfg = []() { const char* v = getenv("GPS_GEMM_RING_MB"); return v && *v ? atoi(v) : 0; }();
   const int nj = rg_nj(N, K);
   if (nj == 1) return 1;
   const int64_t tiles128 = ((M + 127) / 128) * (rg_npad(N, K) / (64 * nj));
-  return mb_cfg == 1 || mb_cfg == 2 ? mb_cfg : (tiles128 >= 200 ? 2 : 1);
-}
-static bool ring_enabled() {
-  static const int ring_cfg = []() { const char* v = getenv("GPS_GEMM_RING"); return v && *v ? atoi(v) : 1; }();
-  return ring_cfg != 0;
+  return tiles128 >= 200 ? 2 : 1;
 }
 
 extern "C" {
@@ -1519,7 +1086,7 @@ size_t gps_gemm_stats_floats(int64_t M, int N, int K) {
 }
 int gps_gemm_stats_sync_words(int N) { return N >= 64 && N % 64 == 0 ? (N / 64) * tr::kSyncWords : 0; }   // (>= any panel count)
 int gps_gemm_stats_supported(int64_t M, int N, int K) {
-  if (!gps_gemm_panel_supported(N, K) || rg_edge(N, K) || !ring_enabled() || M < 2) return 0;   // (whole panels only)
+  if (!gps_gemm_panel_supported(N, K) || rg_edge(N, K) || M < 2) return 0;   // (whole panels only)
   const int mb = ring_mb(M, N, K);
   return (M + 64 * mb - 1) / (64 * mb) <= tr::kMaxParts;
 }
@@ -1638,23 +1205,13 @@ static int panel_launch(const float* A, int64_t lda, int64_t M, int K, const uin
   const bool f16 = a_amax != nullptr;
   GPS_REQUIRE((a_amax == nullptr) == (w_amax == nullptr), "gps_gemm16_panel: both operand maxima or neither");
   hipStream_t s = gps::as_stream(stream);
-  // The ring kernel (LDS-DMA, three-slot ring) serves every supported shape.  GPS_GEMM_RING=0 keeps the register-staged
-  // round-2 kernel where IT applies (N % 192 == 0, K % 128 == 0; A/B measurements).
-  const bool staged_ok = N % TN == 0 && K % (4 * BK) == 0;
-  const bool ring = ring_enabled() || !staged_ok || f16;
+  // The ring kernels (LDS-DMA; k_gemm_ring: three bf16 pieces, six products -- exact; k_gemm_ring16: two fp16 pieces, three
+  // products under per-tensor scales) serve every supported shape.
   const int mb = ring_mb(M, N, K), nj = rg_nj(N, K);
   const bool edge = rg_edge(N, K);
-  // round 5 experiment: loader wavefronts for the fp16 form (k_gemm_ring16L; whole panels and k-stages only)
-#ifdef GPS_RING16_LOADERS
-  static const bool loaders_on = []() { const char* v = getenv("GPS_GEMM_LOADERS"); return v && v[0] == '1'; }();
-#else
-  constexpr bool loaders_on = false;
-#endif
-  const bool loaders = loaders_on && f16 && !edge;
   GPS_REQUIRE(epilogue != 3 || !edge, "gps_gemm_panel: the statistics epilogue needs whole column panels and k-stages");
-  GPS_REQUIRE(epilogue != 3 || ring, "gps_gemm_panel: the statistics epilogue needs the ring kernel");
   unsigned grid;
-  if (ring) {
+  {
     if (!P.bias) {
       GPS_REQUIRE(N <= kZeroBias, "gps_gemm_panel: N=%d without a bias exceeds the built-in zero row (%d)", N, kZeroBias);
       static float* zeros = []() { void* p = nullptr; return hipGetSymbolAddress(&p, HIP_SYMBOL(g_zero_bias)) == hipSuccess ? (float*)p : nullptr; }();
@@ -1671,9 +1228,6 @@ static int panel_launch(const float* A, int64_t lda, int64_t M, int K, const uin
       P.st_eps = stats->eps; P.st_mom = stats->momentum;
       (void)ws_floats;
     }
-  } else {
-    P.row_tiles = (int)((M + TM - 1) / TM);
-    grid = (unsigned)(P.row_tiles * (N / TN));
   }
 #define GPS_RING_ANY_T(KERNEL, LDS, THREADS)                                                          \
   do {                                                                                                \
@@ -1683,15 +1237,9 @@ static int panel_launch(const float* A, int64_t lda, int64_t M, int K, const uin
     KERNEL<<<grid, THREADS, LDS, s>>>(P);                                                             \
   } while (0)
 #define GPS_RING_ANY(KERNEL, LDS) GPS_RING_ANY_T(KERNEL, LDS, NTHREADS)
-#ifdef GPS_RING16_LOADERS
-#define GPS_RING16L(KERNEL, LDS) GPS_RING_ANY_T(KERNEL, LDS, NTHREADS_L)
-#else
-#define GPS_RING16L(KERNEL, LDS) GPS_REQUIRE(false, "gps_gemm_panel: built without -DGPS_RING16_LOADERS")
-#endif
 #define GPS_RING_LAUNCH(MBV, NJV, E, C)                                                               \
   do {                                                                                                \
-    if (f16 && loaders) GPS_RING16L((k_gemm_ring16L<MBV, NJV, E, C>), r16_lds_bytes(MBV, NJV));        \
-    else if (f16) GPS_RING_ANY((k_gemm_ring16<MBV, NJV, E, C>), r16_lds_bytes(MBV, NJV));             \
+    if (f16) GPS_RING_ANY((k_gemm_ring16<MBV, NJV, E, C>), r16_lds_bytes(MBV, NJV));             \
     else GPS_RING_ANY((k_gemm_ring<MBV, NJV, E, C>), rg_lds_bytes(MBV, NJV));                         \
   } while (0)
 #define GPS_RING_EDGE(MBV, NJV, E, C)                                                                 \
@@ -1710,11 +1258,7 @@ static int panel_launch(const float* A, int64_t lda, int64_t M, int K, const uin
     else if (nj == 2) { if (mb == 2) GPS_RING_LAUNCH(2, 2, E, C); else GPS_RING_LAUNCH(1, 2, E, C); } \
     else GPS_RING_LAUNCH(1, 1, E, C);                                                                 \
   } while (0)
-#define GPS_PANEL_LAUNCH(E, C)                                                                        \
-  do {                                                                                                \
-    if (ring) GPS_RING_SHAPES(E, C);                                                                  \
-    else k_gemm_panel<E, C><<<grid, NTHREADS, 0, s>>>(P);                                             \
-  } while (0)
+#define GPS_PANEL_LAUNCH(E, C) GPS_RING_SHAPES(E, C)
   if (epilogue == 0) { if (Cin) GPS_PANEL_LAUNCH(0, true); else GPS_PANEL_LAUNCH(0, false); }
   else if (epilogue == 1) { if (Cin) GPS_PANEL_LAUNCH(1, true); else GPS_PANEL_LAUNCH(1, false); }
   else if (epilogue == 2) { if (Cin) GPS_PANEL_LAUNCH(2, true); else GPS_PANEL_LAUNCH(2, false); }
@@ -1727,7 +1271,6 @@ static int panel_launch(const float* A, int64_t lda, int64_t M, int K, const uin
 #undef GPS_RING_LAUNCH
 #undef GPS_RING_ANY
 #undef GPS_RING_ANY_T
-#undef GPS_RING16L
 #undef GPS_RING_SHAPES
 #undef GPS_PANEL_LAUNCH
   return gps::launch_status("gps_gemm_panel");

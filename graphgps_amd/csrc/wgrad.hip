@@ -79,15 +79,12 @@ struct Problem {
   int64_t out_begin;  // first reduce-thread index of this problem (grouped reduce)
   const uint32_t* g_amax;   // fp16 form (k_wgrad_stream<true>): max|g| / max|x| words (csrc/gemm_panel.hip gps_absmax), or null
   const uint32_t* x_amax;
-  int tick_begin;     // k_wgrad_stream with Group::tick: first arrival counter of this problem (one per tile)
 };
 
 struct Group {
   Problem p[kMaxGroup];
   int n;
   int xcd_map;   // k_wgrad_stream: work items dealt to workgroups XCD by XCD (below)
-  unsigned* tick;  // k_wgrad_stream: per-tile arrival counters, zero at entry and at exit -- the LAST slice of a tile to
-                   // arrive sums the tile's partials itself and no k_wgrad_reduce follows (null: the two-launch form)
 };
 
 // One (tile, slice) work item of problem P.  SPLIT: contraction on the bf16 pipe via the exact
@@ -589,8 +586,7 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_stream(const Group G) {
       for (int q = 0; q < 16; ++q) {
         const int row = m0 + i * 32 + (q & 3) + 8 * (q >> 2) + 4 * kh;
         const float v = F16 ? (sum[q] * ug) * ux : sum[q];
-        if (G.tick) gps::tree::st_sc1(po + (int64_t)row * P.Nn + col, v);    // read by another workgroup of this launch
-        else po[(int64_t)row * P.Nn + col] = v;
+        po[(int64_t)row * P.Nn + col] = v;
       }
     }
   }
@@ -604,45 +600,9 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_stream(const Group G) {
       float a = 0.f;
 #pragma unroll
       for (int q = 0; q < 8; ++q) a += sc[q * 128 + t];
-      if (G.tick) gps::tree::st_sc1(P.bias_part + (int64_t)slice * P.M + m0 + t, a);
-      else P.bias_part[(int64_t)slice * P.M + m0 + t] = a;
+      P.bias_part[(int64_t)slice * P.M + m0 + t] = a;
     }
   }
-  if (!G.tick) return;
-  // ---- in-launch reduce (round 5): csrc/col_tree.hpp's arrival protocol, one counter per tile -----------------------
-  // The partial tile went out with write-through stores; every storing wave drains them, the workgroup takes a ticket,
-  // and the one that draws the last ticket of its tile re-reads all S partials (L2-bypassing loads: the other slices ran
-  // on other XCDs) in slice order -- the additions of k_wgrad_reduce in the same order, bit-identical -- and leaves the
-  // counter at zero for the next launch (eager or replayed).  The other workgroups are done.
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  int* flag = reinterpret_cast<int*>(lds);
-  unsigned* const tk = G.tick + P.tick_begin + tile;
-  if (t == 0) {
-    const unsigned a = __hip_atomic_fetch_add(tk, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (a >= (unsigned)P.S) __builtin_trap();             // the counter was not zero at entry: fail loudly
-    *flag = a == (unsigned)(P.S - 1);
-  }
-  __syncthreads();
-  if (!*flag) return;                                     // workgroup-uniform
-  const int64_t total = (int64_t)P.M * P.Nn;
-  const int S = P.S;
-#pragma unroll 4
-  for (int k = 0; k < 64; ++k) {
-    const int e = t + 256 * k;
-    const int64_t idx = (int64_t)(m0 + (e >> 7)) * P.Nn + n0 + (e & 127);
-    float a = 0.f;
-#pragma unroll 4
-    for (int sl = 0; sl < S; ++sl) a += gps::tree::ld_sc1(P.part + (int64_t)sl * total + idx);
-    P.gw[idx] = a;
-  }
-  if (P.gb && tn == 0 && t < 128) {
-    float a = 0.f;
-#pragma unroll 4
-    for (int sl = 0; sl < S; ++sl) a += gps::tree::ld_sc1(P.bias_part + (int64_t)sl * P.M + m0 + t);
-    P.gb[m0 + t] = a;
-  }
-  if (t == 0) __hip_atomic_store(tk, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 // out[i] = sum_s part[s][i] in slice order; bias likewise, by the first threads of each problem.  VEC = 4 (round 5): a
@@ -708,8 +668,7 @@ inline void plan_slices(Problem& p, int64_t chunks_per_block, int quantum = BK) 
 // workgroups per CU take every vector register of the chip (2 x 248 per lane), locking those kernels out
 // until it drains; with one per CU the HBM-bound norm / attention / GatedGCN kernels co-run with it.
 // Measured in the training step, same box: 13.60 ms (512 workgroups) vs 13.14-13.33 ms (256).
-// GPS_WGRAD_TARGET_BLOCKS overrides (tuning).
-static const int kTargetBlocks = [] { const char* e = getenv("GPS_WGRAD_TARGET_BLOCKS"); return e ? atoi(e) : 256; }();
+constexpr int kTargetBlocks = 256;
 inline int64_t balanced_chunks(const int64_t* R, const int* M, const int* Nn, int n) {
   int64_t work = 0, tiles_total = 0;
   for (int i = 0; i < n; ++i) {
@@ -748,10 +707,8 @@ int check_problem(const char* who, const float* g, int64_t ldg, const float* x, 
   return GPS_OK;
 }
 
-// the streaming kernel takes whole 128 x 128 tiles and 16-byte-aligned rows (GPS_WGRAD_STREAM=0: never)
+// the streaming kernel takes whole 128 x 128 tiles and 16-byte-aligned rows
 inline bool stream_shapes(const int* M, const int* Nn, int n) {
-  static const bool on = [] { const char* e = getenv("GPS_WGRAD_STREAM"); return !(e && e[0] == '0'); }();
-  if (!on) return false;
   for (int i = 0; i < n; ++i)
     if (M[i] % 128 != 0 || Nn[i] % 128 != 0) return false;
   return true;
@@ -765,8 +722,8 @@ inline bool stream_ok(const Group& G) {
   return true;
 }
 
-int launch_group(Group& G, float* ws, hipStream_t s, const char* who, unsigned* tick = nullptr, int tick_words = 0) {
-  int blocks = 0, tiles = 0;
+int launch_group(Group& G, float* ws, hipStream_t s, const char* who) {
+  int blocks = 0;
   int64_t outs = 0;
   for (int i = 0; i < G.n; ++i) {
     Problem& p = G.p[i];
@@ -776,12 +733,9 @@ int launch_group(Group& G, float* ws, hipStream_t s, const char* who, unsigned* 
     ws += problem_ws_floats(p);
     p.block_begin = blocks;
     blocks += p.S * p.tiles_m * p.tiles_n;
-    p.tick_begin = tiles;
-    tiles += p.tiles_m * p.tiles_n;
   }
   // the reduce takes four outputs per thread when every problem allows 16-byte accesses (always, for the GPS blocks)
-  static const bool vec_off = [] { const char* e = getenv("GPS_WGRAD_REDUCE_VEC"); return e && atoi(e) == 0; }();
-  bool vec = !vec_off;
+  bool vec = true;
   for (int i = 0; i < G.n; ++i) {
     const Problem& p = G.p[i];
     vec = vec && ((int64_t)p.M * p.Nn) % 4 == 0 && p.Nn >= 4 && reinterpret_cast<uintptr_t>(p.part) % 16 == 0 &&
@@ -793,25 +747,18 @@ int launch_group(Group& G, float* ws, hipStream_t s, const char* who, unsigned* 
     const int64_t threads = vec ? (int64_t)p.M * p.Nn / 4 : (int64_t)p.M * p.Nn;
     outs += (threads + 255) / 256 * 256;               // whole reduce blocks per problem
   }
-  // GPS_WGRAD_FP32_MFMA=1 keeps the contraction on the fp32-input MFMA (v_mfma_f32_32x32x2_f32)
-  static const bool fp32_pipe = [] { const char* e = getenv("GPS_WGRAD_FP32_MFMA"); return e && atoi(e) != 0; }();
-  if (stream_ok(G) && !fp32_pipe) {
+  if (stream_ok(G)) {
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_stream<false>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS);
     static const hipError_t attr16 = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_stream<true>),
                                                          hipFuncAttributeMaxDynamicSharedMemorySize, WS_LDS);
     GPS_REQUIRE(attr == hipSuccess && attr16 == hipSuccess, "%s: cannot reserve %d bytes of LDS", who, WS_LDS);
-    static const int xcd_map = [] { const char* e = getenv("GPS_WGRAD_XCD_MAP"); return e && *e ? atoi(e) : 1; }();
-    G.xcd_map = xcd_map;
-    G.tick = tick && tiles <= tick_words ? tick : nullptr;   // more tiles than counters: the two-launch form
+    G.xcd_map = 1;          // (0: launch order -- the round-3 A/B, profiles/r03_pmc_wgrad_xcdmap0.txt)
     bool f16 = true;                 // every problem of the launch carries its operands' max|.| words
     for (int i = 0; i < G.n; ++i) f16 = f16 && G.p[i].g_amax && G.p[i].x_amax;
     if (f16) k_wgrad_stream<true><<<(unsigned)blocks, 256, WS_LDS, s>>>(G);
     else k_wgrad_stream<false><<<(unsigned)blocks, 256, WS_LDS, s>>>(G);
-    if (G.tick) return gps::launch_status(who);
-  } else if (fp32_pipe)
-    k_wgrad<false><<<(unsigned)blocks, 256, 0, s>>>(G);
-  else
+  } else
     k_wgrad<true><<<(unsigned)blocks, 256, 0, s>>>(G);
   if (vec) k_wgrad_reduce<4><<<gps::grid_for(outs, 256), 256, 0, s>>>(G);
   else k_wgrad_reduce<1><<<gps::grid_for(outs, 256), 256, 0, s>>>(G);
@@ -875,11 +822,6 @@ size_t gps_wgrad_grouped_workspace_floats(int n, const gps_wgrad_problem* probs)
 }
 
 int gps_wgrad_grouped(int n, const gps_wgrad_problem* probs, float* ws, gps_stream_t stream) {
-  return gps_wgrad_grouped_sync(n, probs, ws, nullptr, 0, stream);
-}
-
-int gps_wgrad_grouped_sync(int n, const gps_wgrad_problem* probs, float* ws, uint32_t* sync, int sync_words,
-                           gps_stream_t stream) {
   GPS_REQUIRE(n >= 1 && n <= kMaxGroup && probs, "gps_wgrad_grouped: n=%d (1..%d)", n, kMaxGroup);
   GPS_REQUIRE(ws && reinterpret_cast<uintptr_t>(ws) % 16 == 0,
               "gps_wgrad_grouped: workspace null/misaligned");
@@ -903,8 +845,7 @@ int gps_wgrad_grouped_sync(int n, const gps_wgrad_problem* probs, float* ws, uin
     p.g_amax = q.g_amax; p.x_amax = q.x_amax;
     plan_slices(p, cpb, quantum);
   }
-  GPS_REQUIRE(sync_words >= 0 && (sync || sync_words == 0), "gps_wgrad_grouped_sync: %d counter words at a null pointer", sync_words);
-  return launch_group(G, ws, gps::as_stream(stream), "gps_wgrad_grouped", sync, sync_words);
+  return launch_group(G, ws, gps::as_stream(stream), "gps_wgrad_grouped");
 }
 
 }  // extern "C"

@@ -17,6 +17,7 @@ import os
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from ..graphgym.config import cfg
 from ..graphgym.register import (node_encoder_dict, register_edge_encoder,
@@ -126,9 +127,11 @@ def _embed_sum_ok(feats, embs) -> bool:
             and w.shape[1] % 4 == 0)
 
 
-# off by default: measured neutral in the pcqm4m step (10.03 vs 10.05 ms, same box, replayed) -- the two library GEMMs it
-# replaces are ~35 us each after TunableOp, the split-K launch + its reduce + the stream hand-over cost about the same
-_MULTIHOT_WGRAD = os.environ.get("GPS_MULTIHOT_WGRAD", "0") != "0"
+# The table gradients of the sum-of-embeddings encoders (multihot^T g) and the PE encoder's Linear: [V, emb] / [dim_pe, steps]
+# results contracted over every node / edge of the batch.  On the split-K weight-gradient kernel (csrc/wgrad.hip) by default
+# since round 6: the library picked 71 / 57 / 43 us kernels for them (profiles/r05_kernel_trace_stats_pcqm4m.txt:
+# MT32x16x256, MT32x32x256, MT16x32x512).  GPS_MULTIHOT_WGRAD=0: the library GEMMs (A/B).
+_MULTIHOT_WGRAD = os.environ.get("GPS_MULTIHOT_WGRAD", "1") != "0"
 
 
 def _multihot_embedding(feats, embs, owner):
@@ -310,6 +313,29 @@ class ASTEdgeEncoder(nn.Module):
         return batch
 
 
+class _LinearSplitKGrad(torch.autograd.Function):
+    """``F.linear`` whose weight + bias gradient -- a [dim_pe, steps] result contracted over every node of the batch -- runs on
+    the split-K kernel (csrc/wgrad.hip: exact fp32 products, bias gradient in the same pass) instead of a library GEMM
+    (43 us: MT16x32x512 on a K = 7,569 contraction) + a column-sum reduction (28 us).  Forward and input gradient stay the
+    library's plain fp32 products: at K = 16 .. 20 there is no accumulation to hide the fp16-form ring GEMM's 2^-22
+    operand rounding behind (zinc model test: 2e-6 on the raw-norm gradient against 6e-9 for the CPU oracle)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.params = (weight, bias)
+        return F.linear(x, weight, bias)
+
+    @staticmethod
+    def backward(ctx, g):
+        from ..fused import _param_grads
+        x, weight = ctx.saved_tensors
+        g = g.contiguous()
+        g_w, g_b = _param_grads(g, x.contiguous(), ctx.needs_input_grad[1], ctx.needs_input_grad[2], ctx.params,
+                                targets=ctx.params)
+        return (g.mm(weight) if ctx.needs_input_grad[0] else None), g_w, g_b
+
+
 class KernelPENodeEncoder(nn.Module):
     """Kernel-statistics PE encoder (RWSE etc.): raw-norm -> Linear/MLP -> concat to x."""
     kernel_type = None
@@ -360,7 +386,11 @@ class KernelPENodeEncoder(nn.Module):
         pos_enc = getattr(batch, pestat_var)
         if self.raw_norm:
             pos_enc = _batch_norm(self.raw_norm, pos_enc, batch)
-        pos_enc = self.pe_encoder(pos_enc)
+        if (_MULTIHOT_WGRAD and isinstance(self.pe_encoder, nn.Linear) and pos_enc.is_cuda and torch.is_grad_enabled()
+                and pos_enc.shape[0] >= 256 and self.pe_encoder.bias is not None):
+            pos_enc = _LinearSplitKGrad.apply(pos_enc, self.pe_encoder.weight, self.pe_encoder.bias)
+        else:
+            pos_enc = self.pe_encoder(pos_enc)
         h = self.linear_x(batch.x) if self.expand_x else batch.x
         batch.x = torch.cat((h, pos_enc), 1)
         if self.pass_as_var:

@@ -307,6 +307,74 @@ def linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor]) 
     return _Linear.apply(x, weight, bias)
 
 
+# Rows up to which a Linear (+ ReLU) runs on csrc/small_gemm.hip: the graph-level heads' stages on one row per graph.
+_SMALL_MAX_ROWS = 2048
+_SMALL_LINEAR = _os.environ.get("GPS_SMALL_LINEAR", "1") != "0"      # 0: the library GEMMs (A/B)
+
+
+class _SmallLinear(torch.autograd.Function):
+    """``act(x W^T + b)`` for a few hundred rows (csrc/small_gemm.hip: exact fp32 MFMA products, one launch forward, two
+    backward -- the ReLU mask of the layer's own output is applied while its output gradient is loaded).  Reference:
+    graphgps/head/san_graph.py:36-41.  The library GEMMs pick macro tiles for large problems on these shapes
+    ([256 x 384] x [384 x 192] as ONE workgroup, 74 us)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, relu):
+        L = _lib.load()
+        M, K = x.shape
+        N = weight.shape[0]
+        y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        check(L.gps_small_linear_fwd(ptr(x), x.stride(0), ptr(weight), weight.stride(0), ptr(bias), M, N, K, int(relu),
+                                     ptr(y), N, current_stream(x.device)), "gps_small_linear_fwd")
+        ctx.save_for_backward(x, weight, y if relu else None)
+        ctx.relu, ctx.has_bias, ctx.params = bool(relu), bias is not None, (weight, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        L = _lib.load()
+        x, weight, y = ctx.saved_tensors
+        g = _f32c(g, "g")
+        M, K = x.shape
+        N = weight.shape[0]
+        dev = g.device
+        need_x, need_w = ctx.needs_input_grad[0], ctx.needs_input_grad[1]
+        need_b = ctx.has_bias and ctx.needs_input_grad[2]
+        g_x = torch.empty(M, K, dtype=torch.float32, device=dev) if need_x else None
+        g_w = g_b = None
+        if need_w:
+            if not any(p is not None and p.grad is not None for p in ctx.params):
+                from .optim import grad_slot          # straight into the optimizer's gradient arena when there is one
+                g_w = grad_slot(weight)
+                g_b = grad_slot(ctx.params[1]) if need_b else None
+            if g_w is None:
+                g_w = torch.empty(N, K, dtype=torch.float32, device=dev)
+            if need_b and g_b is None:
+                g_b = torch.empty(N, dtype=torch.float32, device=dev)
+        check(L.gps_small_linear_bwd(ptr(g), g.stride(0), ptr(y), N if y is not None else 0, ptr(x), x.stride(0),
+                                     ptr(weight), weight.stride(0), M, N, K, ptr(g_x), K, ptr(g_w), K, ptr(g_b),
+                                     current_stream(dev)), "gps_small_linear_bwd")
+        return g_x, g_w, g_b, None
+
+
+def small_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], relu: bool = False) -> torch.Tensor:
+    """``relu(F.linear(x, weight, bias))`` / ``F.linear`` for inputs of a few hundred rows (one per graph)."""
+    if (_SMALL_LINEAR and x.is_cuda and x.dim() == 2 and x.dtype == torch.float32 and weight.dtype == torch.float32
+            and 1 <= x.shape[0] <= _SMALL_MAX_ROWS and x.stride(1) == 1 and weight.stride(1) == 1
+            and (bias is None or (bias.dtype == torch.float32 and bias.is_contiguous()))):
+        if torch.is_grad_enabled() and (x.requires_grad or weight.requires_grad):
+            return _SmallLinear.apply(x, weight, bias, relu)
+        L = _lib.load()
+        M, K = x.shape
+        N = weight.shape[0]
+        y = torch.empty(M, N, dtype=torch.float32, device=x.device)
+        check(L.gps_small_linear_fwd(ptr(x), x.stride(0), ptr(weight), weight.stride(0), ptr(bias), M, N, K, int(relu),
+                                     ptr(y), N, current_stream(x.device)), "gps_small_linear_fwd")
+        return y
+    y = F.linear(x, weight, bias)
+    return torch.relu(y) if relu else y
+
+
 class _GroupLinear(torch.autograd.Function):
     """y = x [W_1; ...; W_k]^T + [b_1; ...; b_k] where the stacked weight is a zero-copy view of
     the k parameters' shared storage; the backward hands each parameter its row-slice of the

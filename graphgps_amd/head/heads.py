@@ -82,6 +82,13 @@ class SANGraphHead(_GraphLevelHead):
         self.activation = register.act_dict[cfg.gnn.act]()
 
     def predict(self, emb):
+        if emb.is_cuda and isinstance(self.activation, nn.ReLU):
+            # one row per graph: the small-product kernel (csrc/small_gemm.hip), ReLU in its epilogue
+            from ..fused import small_linear
+            for fc in self.FC_layers[:-1]:
+                emb = small_linear(emb, fc.weight, fc.bias, relu=True)
+            fc = self.FC_layers[-1]
+            return small_linear(emb, fc.weight, fc.bias)
         for fc in self.FC_layers[:-1]:
             emb = self.activation(fc(emb))
         return self.FC_layers[-1](emb)

@@ -39,11 +39,12 @@ from ..ops import GraphIndex, _nmax_dev, draw_dropout_seed, favor_workspace_floa
 _E = torch.empty
 _BY_REF = _ctypes.byref
 
-# A/B switches.  GPS_GG_STATS=1: the batch statistics of x~ / e^ out of the GatedGCN forward itself (one launch fewer, 35 MB
-# less traffic -- and the kernel's in-launch reduction tail: 26 -> 47 us per launch, the step unchanged at 9.95 vs 9.91 ms;
-# default 0, a statistics-only row pass, which keeps the HBM-bound kernel at its roofline); GPS_GEMM_STATS=0: za / z2 and
-# their statistics by row tasks instead of the ring GEMM epilogue (default 1: -0.3 ms per step).
-_GG_STATS = _os.environ.get("GPS_GG_STATS", "0") != "0"
+# A/B switches.  GPS_GG_STATS (default 1 since round 6): the batch statistics of x~ / e^ out of the GatedGCN forward itself
+# -- per-node-block records + a 96-workgroup combine launch inside the same C call -- instead of a statistics-only row pass
+# over both tensors (=0: 20 us and 35 MB per layer).  Rounds 3 - 5 had this off: the records were then combined IN the
+# GatedGCN launch through the arrival tree, whose tail cost the kernel as much as the pass (26 -> 47 us).
+# GPS_GEMM_STATS=0: za / z2 and their statistics by row tasks instead of the ring GEMM epilogue (default 1: -0.3 ms per step).
+_GG_STATS = _os.environ.get("GPS_GG_STATS", "1") != "0"
 _GEMM_STATS = _os.environ.get("GPS_GEMM_STATS", "1") != "0"
 _GG_FIRST = _os.environ.get("GPS_GG_FIRST", "0") != "0"
 _STACK_PREP = _os.environ.get("GPS_STACK_PREP", "1") != "0"
@@ -255,12 +256,6 @@ def _block_records(dev):
 
 # launch sites of one layer that own arrival counters (norm.SyncArena.site): sites that may be in flight together differ
 _S_GG, _S_AO, _S_XE, _S_MID, _S_Z2, _S_B1, _S_B3, _S_B4 = range(8)
-_S_WG = 8       # the grouped weight-gradient launch: one counter per output tile, sites 8.. (SyncArena.tail)
-# GPS_WGRAD_FOLD=1: the cross-slice sum of the weight gradients inside the launch, by the last slice to arrive at a tile
-# (csrc/wgrad.hip, gps_wgrad_grouped_sync) instead of the reduce launch.  Bit-identical, and measured SLOWER (round 5,
-# profiles/r05_ab_wgrad_fold.txt: 9.05 vs 8.80 ms per step): one workgroup pulling the S x 64 KB of its tile is bound by
-# its own load latency, the reduce launch spreads the same bytes over the whole chip.  Off by default.
-_WGRAD_FOLD = _os.environ.get("GPS_WGRAD_FOLD", "0") == "1"
 
 
 class _K:
@@ -330,14 +325,13 @@ def _accumulating(params) -> bool:
     return False
 
 
-def _grouped_param_grads(L, pairs, params=(), targets=None, words=None, sync=None):
+def _grouped_param_grads(L, pairs, params=(), targets=None, words=None):
     """[(g, x), ...] -> [(g^T x, colsum(g)), ...]: all weight/bias gradients of the block in ONE
     split-K MFMA launch + one reduce launch (csrc/wgrad.hip grouped form) on the side stream
     (main stream when ``params`` already hold gradients: see ``_accumulating``).
     ``targets`` = [(weight, bias), ...] the (stacked) parameters the results belong to: when they live in an optimizer
     arena and nothing is being accumulated the kernel writes straight into their gradient slots (optim.grad_slot).
-    ``words`` = [(max|g| record, max|x| record), ...] (int32 [512] tensors, gemm.absmax): the fp16 form of the contraction.
-    ``sync`` = the owner's norm.SyncArena: the reduce folded into the launch (arrival counters from site _S_WG on)."""
+    ``words`` = [(max|g| record, max|x| record), ...] (int32 [512] tensors, gemm.absmax): the fp16 form of the contraction."""
     dev = pairs[0][0].device
     n = len(pairs)
     direct = targets is not None and not _accumulating(params)
@@ -364,11 +358,7 @@ def _grouped_param_grads(L, pairs, params=(), targets=None, words=None, sync=Non
                 q.g_amax, q.x_amax = words[i][0].data_ptr(), words[i][1].data_ptr()
             outs.append((g_w, g_b))
         ws = _E(max(L.gps_wgrad_grouped_workspace_floats(n, probs), 4), dtype=torch.float32, device=dev)
-        if sync is not None and _WGRAD_FOLD:
-            tick, tick_words = sync.tail(_S_WG)
-            check(L.gps_wgrad_grouped_sync(n, probs, ptr(ws), tick, tick_words, current_stream(dev)), "gps_wgrad_grouped_sync")
-        else:
-            check(L.gps_wgrad_grouped(n, probs, ptr(ws), current_stream(dev)), "gps_wgrad_grouped")
+        check(L.gps_wgrad_grouped(n, probs, ptr(ws), current_stream(dev)), "gps_wgrad_grouped")
         return outs
 
     if not _SIDE_ENABLED or _accumulating(params):
@@ -542,20 +532,22 @@ class _GPSBlock(torch.autograd.Function):
         ref = _BY_REF
         sync = _norm.sync_arena(layer, dev)
         rn, re_ = gi.n_real, gi.e_real       # padded batches: device words with the real row counts (else None)
-        if rn is not None and (_GG_STATS or not panel or imgs[0][0].amax is None):
-            raise _lib.GpsHipError("padded batches need the default block path (fp16-form ring GEMMs, GPS_GG_STATS=0)")
+        if rn is not None and (not panel or imgs[0][0].amax is None):
+            raise _lib.GpsHipError("padded batches need the default block path (fp16-form ring GEMMs)")
         # (round 5: the Performer block takes padded batches too -- FAVOR+ is per graph, its Nmax is taken over the REAL
         # graphs (ops._nmax_dev / gi.b_real), every BatchNorm task and statistics epilogue below counts real rows)
         gemm_stats = panel and _GEMM_STATS and _gemm.stats_supported(N, d, inner) and _gemm.stats_supported(N, d, 2 * d)
         # -- local branch: GatedGCN core ---------------------------------------------------------
         def local_half():
             xt, eh = _E(N, d, **f32), _E(E, d, **f32)
-            if _GG_STATS:           # statistics of x~ (bn_node_x) and e^ (bn_edge_e) fall out of the same launch
+            if _GG_STATS and d % 8 == 0 and N >= 2 and E >= 2:
+                # the statistics of x~ (bn_node_x) and e^ (bn_edge_e) fall out of the same call: records per node block
+                # from the forward, combined by a second small launch (csrc/gatedgcn.hip k_gg_stats_finalize)
                 wsf = L.gps_gatedgcn_stats_floats(N, d)
                 gws = _E(wsf, **f32)
                 check(L.gps_gatedgcn_fwd_stats(P, P + fs, P + 2 * fs, P + 3 * fs, ldp, ptr(ce), ptr(gi.rowptr_dst),
                                                ptr(gi.src_by_dst), ptr(gi.eid_by_dst), N, E, d, ptr(xt), ptr(eh),
-                                               None, ref(bnx), ref(bne), ptr(gws), wsf, sync.site(_S_GG), st),
+                                               None, ref(bnx), ref(bne), ptr(gws), wsf, ptr(rn), st),
                       "gps_gatedgcn_fwd_stats")
             else:
                 check(L.gps_gatedgcn_fwd(P, P + fs, P + 2 * fs, P + 3 * fs, ldp, ptr(ce), ptr(gi.rowptr_dst),
@@ -797,7 +789,7 @@ class _GPSBlock(torch.autograd.Function):
             targets = [(wcat, bcat), (_W(R.C), _B(R.C)), (_W(R.out_proj), _B(R.out_proj)),
                        (_W(R.ff1), _B(R.ff1)), (_W(R.ff2), _B(R.ff2))]
             ((g_wcat, g_bcat), (g_wc, g_bc), (g_wo, g_bo), (g_w1, g_b1), (g_w2, g_b2)) = \
-                _grouped_param_grads(L, pairs, leaves, targets, words, sync)
+                _grouped_param_grads(L, pairs, leaves, targets, words)
         else:
             ((g_wcat, g_bcat), (g_wc, g_bc), (g_wo, g_bo), (g_w1, g_b1), (g_w2, g_b2)) = \
                 [_K.param_grads(L, g, a, leaves) for g, a in pairs]

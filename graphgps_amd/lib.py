@@ -32,7 +32,6 @@ _SIGNATURES = {
     "gps_gatedgcn_fwd": (c_int, [_P, _P, _P, _P, c_int64, _P, _P, _P, _P, c_int64, c_int64, c_int,
                                  _P, _P, _P, _P]),
     "gps_gatedgcn_stats_floats": (c_size_t, [c_int64, c_int]),
-    "gps_gatedgcn_stats_sync_words": (c_int, []),
     "gps_gatedgcn_fwd_stats": (c_int, [_P, _P, _P, _P, c_int64, _P, _P, _P, _P, c_int64, c_int64, c_int,
                                        _P, _P, _P, _P, _P, _P, c_size_t, _P, _P]),
     "gps_gatedgcn_bwd": (c_int, [_P, c_int64, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P,
@@ -71,7 +70,6 @@ _SIGNATURES = {
                             _P]),
     "gps_wgrad_grouped_workspace_floats": (c_size_t, [c_int, _P]),
     "gps_wgrad_grouped": (c_int, [c_int, _P, _P, _P]),
-    "gps_wgrad_grouped_sync": (c_int, [c_int, _P, _P, _P, c_int, _P]),
     "gps_norm_tree_floats": (c_size_t, [c_int64, c_int]),
     "gps_norm_sync_words": (c_int, []),
     "gps_sync_reset": (c_int, [_P, c_size_t, _P]),

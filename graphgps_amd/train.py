@@ -455,7 +455,7 @@ def padding_supported(model) -> bool:
             known.add(id(m.raw_norm))
         elif isinstance(m, BatchNorm1dNode):
             known.add(id(m.bn))
-    if layers == 0 or _blk._GG_STATS or not getattr(_gemm, "F16", False):
+    if layers == 0 or not getattr(_gemm, "F16", False):
         return False
     for m in model.modules():
         if isinstance(m, torch.nn.modules.batchnorm._NormBase) and id(m) not in known:

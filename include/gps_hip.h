@@ -105,16 +105,19 @@ int gps_gatedgcn_fwd(const float* Ax, const float* Bx, const float* Dx, const fl
                      int d, float* x_tilde, float* e_hat, const float* r_edge, gps_stream_t stream);
 /* The same launch, additionally producing the batch statistics of x_tilde (-> bn_x: bn_node_x) and of e_hat
  * (-> bn_e: bn_edge_e), graphgps/layer/gatedgcn_layer.py:72-73: every lane accumulates shifted sums of the rows it
- * writes, a workgroup's row lanes meet through LDS, and the node blocks' records -- (mean, M2) of both tensors with
- * their two row counts -- are combined in-launch (csrc/col_tree.hpp).  d % 4 == 0, N, E >= 2.
- *   ws: gps_gatedgcn_stats_floats(N, d) floats; sync: gps_gatedgcn_stats_sync_words() uint32, zero at entry / exit. */
+ * writes, a workgroup's row lanes meet through LDS, the node blocks' records -- (mean, M2) of both tensors with their two
+ * row counts -- go to `ws`, and a SECOND launch (96 workgroups at d = 384) combines them in a fixed order into mean / rstd
+ * / the running statistics (round 6; rounds 3 - 5 combined them in-launch through csrc/col_tree.hpp, whose tail cost this
+ * HBM-bound kernel as much as the separate statistics pass it replaced).  d % 8 == 0, N, E >= 2.
+ *   ws: gps_gatedgcn_stats_floats(N, d) floats.
+ *   n_real: padded batches (loader.BucketPadding) -- device word with the number of REAL nodes: padding nodes (the last
+ *   rows) and their incoming edges (padding joins padding only) are computed but never counted; NULL: every row counts. */
 size_t gps_gatedgcn_stats_floats(int64_t N, int d);
-int gps_gatedgcn_stats_sync_words(void);
 int gps_gatedgcn_fwd_stats(const float* Ax, const float* Bx, const float* Dx, const float* Ex,
                            int64_t ld_node, const float* Ce, const int32_t* rowptr_dst,
                            const int32_t* src_by_dst, const int32_t* eid_by_dst, int64_t N, int64_t E,
                            int d, float* x_tilde, float* e_hat, const float* r_edge, const gps_bn* bn_x,
-                           const gps_bn* bn_e, float* ws, size_t ws_floats, uint32_t* sync, gps_stream_t stream);
+                           const gps_bn* bn_e, float* ws, size_t ws_floats, const int32_t* n_real, gps_stream_t stream);
 
 /* Backward.  Inputs: g_x [N,d] with row stride ld_gx (grad wrt x_tilde), g_e [E,d] (grad wrt e_hat), the
  * forward's e_hat and x_tilde and its Ax / Bx inputs (ld_node).  Outputs: g_Ce [E,d]; g_Ax/g_Bx/g_Dx/g_Ex
@@ -458,15 +461,6 @@ typedef struct gps_wgrad_problem {
 } gps_wgrad_problem;
 size_t gps_wgrad_grouped_workspace_floats(int n, const gps_wgrad_problem* probs);
 int gps_wgrad_grouped(int n, const gps_wgrad_problem* probs, float* ws, gps_stream_t stream);
-/* ABI v8: the same launch with the cross-slice sum folded in.  `sync`: >= one zeroed uint32 counter per 128 x 128 output
- * tile of the whole list (sum over problems of ceil(M/128) * ceil(Nn/128)), owned by the caller, left at zero by every
- * launch (the contract of gps_norm_*'s sync words: zero once, never touched by the host again; eager calls and hipGraph
- * replays share them; launches that can be in flight together need different words).  The slice that arrives LAST at
- * a tile sums the tile's partials in slice order -- the additions of the reduce launch, bit-identical -- so the list
- * costs one launch.  Where the streaming kernel does not apply (shapes, GPS_WGRAD_STREAM=0) or sync_words is too
- * small, this IS gps_wgrad_grouped. */
-int gps_wgrad_grouped_sync(int n, const gps_wgrad_problem* probs, float* ws, uint32_t* sync, int sync_words,
-                           gps_stream_t stream);
 /* gps_wgrad with the operands' max|.| words: the fp16 form where the streaming kernel applies (else as gps_wgrad) */
 int gps_wgrad16(const float* g, int64_t ldg, const float* x, int64_t ldx, int64_t R, int M, int Nn, const uint32_t* g_amax,
                 const uint32_t* x_amax, float* gw, float* gb, float* ws, gps_stream_t stream);
@@ -599,7 +593,7 @@ typedef struct gps_norm_bwd_task {
 } gps_norm_bwd_task;
 size_t gps_norm_tree_floats(int64_t R, int d);
 int gps_norm_sync_words(void);
-/* The `sync` words of every in-launch reduction (gps_norm_*, gps_gatedgcn_fwd_stats, gps_gemm_panel_stats) must be zero
+/* The `sync` words of every in-launch reduction (gps_norm_*, gps_gemm_panel_stats) must be zero
  * at entry and are zero again at exit.  A launch that finds a non-zero counter TRAPS (csrc/col_tree.hpp) instead of
  * publishing statistics of incomplete records.  gps_sync_reset: re-zero a buffer after a failed launch;
  * gps_sync_nonzero: *count += number of non-zero words (device uint32; a between-launches self-check). */

@@ -422,7 +422,6 @@ def test_in_launch_reduction_workspaces_and_counters_are_sized_by_the_library():
     from graphgps_amd import lib, norm
     L = lib.load()
     assert L.gps_norm_sync_words() == 256 and norm.N_SITES * 256 * 4 <= 1 << 16
-    assert L.gps_gatedgcn_stats_sync_words() == 32
     assert L.gps_gemm_stats_sync_words(384) == 6 * 32 and L.gps_gemm_stats_sync_words(100) == 0
     for d in (64, 384):
         sizes = [L.gps_norm_tree_floats(R, d) for R in (2, 100, 7569, 15348, 10 ** 6)]

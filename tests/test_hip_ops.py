@@ -465,6 +465,39 @@ def test_embed_sum_rejects_out_of_range_features_like_nn_embedding():
     assert torch.equal(out, embs[0].weight[good[:, 0]] + embs[1].weight[good[:, 1]])
 
 
+@pytest.mark.parametrize("M,K,N,relu", [(256, 384, 192, True), (256, 192, 96, True), (256, 96, 1, False), (37, 52, 5, True),
+                                        (1, 7, 3, False), (2048, 64, 16, True), (33, 130, 10, False)])
+def test_small_linear_fwd_bwd(M, K, N, relu):
+    """csrc/small_gemm.hip (round 6): the Linear (+ ReLU) stages of the graph-level heads (graphgps/head/san_graph.py:36-41,
+    one row per graph) and their three gradients against an fp64 evaluation; exact fp32 MFMA products, so the bar is
+    fp32 accumulation rounding; x taken as a strided slice; deterministic."""
+    from graphgps_amd.fused import _SmallLinear, small_linear
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(M * 7 + K + N)
+    wide = torch.randn(M, K + 3, generator=gen)
+    w = torch.randn(N, K, generator=gen) / K ** 0.5
+    b = torch.randn(N, generator=gen)
+    gy = torch.randn(M, N, generator=gen)
+    xr, wr, br = wide[:, :K].double().requires_grad_(True), w.double().requires_grad_(True), b.double().requires_grad_(True)
+    yr = torch.nn.functional.linear(xr, wr, br)
+    yr = yr.relu() if relu else yr
+    (yr * gy.double()).sum().backward()
+    xg = wide.to(dev)[:, :K].requires_grad_(True)          # row stride K + 3
+    wg, bg = w.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    yg = small_linear(xg, wg, bg, relu=relu)
+    assert yg.grad_fn is not None and type(yg.grad_fn).__name__.startswith("_SmallLinear")
+    (yg * gy.to(dev)).sum().backward()
+    assert_close(yg, yr, 2e-6 * max(1.0, float(yr.abs().max())), "small linear out")
+    assert_close(xg.grad, xr.grad, 2e-6, "small linear g_x", rel_to_max=True)
+    assert_close(wg.grad, wr.grad, 2e-6, "small linear g_w", rel_to_max=True)
+    assert_close(bg.grad, br.grad, 2e-6, "small linear g_b", rel_to_max=True)
+    y2 = small_linear(xg.detach(), wg.detach(), bg.detach(), relu=relu)          # the no-grad form, same launch
+    assert torch.equal(y2, yg.detach())
+    y3 = small_linear(xg.detach(), wg.detach(), None, relu=relu)
+    ref3 = torch.nn.functional.linear(xr.detach(), wr.detach())
+    assert_close(y3, ref3.relu() if relu else ref3, 2e-6 * max(1.0, float(ref3.abs().max())), "small linear, no bias")
+
+
 def test_cpu_tensor_is_rejected():
     from graphgps_amd.lib import GpsHipError
     from graphgps_amd.ops import build_graph_index
@@ -1129,22 +1162,6 @@ def test_dma_kernels_race_screen():
             else:
                 for i, ((gw, gb), (fw, fb)) in enumerate(zip(cur, firsts)):
                     assert torch.equal(gw, fw) and torch.equal(gb, fb), f"streaming wgrad (f16={f16}) problem {i}: run {it} differs"
-        # round 5: the cross-slice sum folded into the launch (gps_wgrad_grouped_sync) -- the last slice to arrive at a
-        # tile adds the tile's partials in slice order: bit-identical to the two-launch form however the arrivals fall, the
-        # counters back at zero after every launch; too few counters = the two-launch form
-        tiles = sum(-(-g.shape[1] // 128) * -(-x.shape[1] // 128) for g, x in pairs)
-        tick = torch.zeros(tiles + 3, dtype=torch.int32, device=dev)
-        for it in range(40):
-            if it % 3 == 0:
-                noise.normal_()
-            for gw, gb in outs:
-                gw.fill_(float("nan")); gb.fill_(float("nan"))
-            words_given = tiles - 1 if it == 39 else tick.numel()
-            check(L.gps_wgrad_grouped_sync(len(pairs), probs, ptr(ws), tick.data_ptr(), words_given, current_stream(dev)),
-                  "gps_wgrad_grouped_sync")
-            for i, ((gw, gb), (fw, fb)) in enumerate(zip(outs, firsts)):
-                assert torch.equal(gw, fw) and torch.equal(gb, fb), f"folded wgrad (f16={f16}) problem {i}: run {it} differs"
-            assert int(tick.abs().sum()) == 0, "arrival counters not left at zero"
 
 
 @pytest.mark.parametrize("n,V,d,hub", [(25000, 10030, 256, 0.5), (25000, 10030, 256, 0.0), (77000, 2, 256, 0.0),
