@@ -792,8 +792,8 @@ struct Ring16A {
 template <int I>
 struct IntC { static constexpr int value = I; };
 
-template <int MB, int NJ, int EPI, bool HAS_CIN, bool EDGE = false>
-__global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring16(const PanelArgs P) {
+template <int MB, int NJ, int EPI, bool HAS_CIN, bool EDGE>
+__device__ __forceinline__ void ring16_body(const PanelArgs& P, const int bid) {
   constexpr int TNV = 64 * NJ;
   constexpr int BP = rg_bp(NJ);
   constexpr int A_BYTES = rg_a_bytes(MB), SLOT = r16_slot_bytes(MB, NJ);
@@ -814,10 +814,10 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring16(const PanelArgs P) 
   static_assert((S - 2) * ND + ND_ODD <= 63 && S >= 3, "vmcnt range");
   extern __shared__ __attribute__((aligned(1024))) unsigned char ring[];
   auto stamp = [&](int k) __attribute__((always_inline)) {
-    if (P.trace && threadIdx.x == 0) P.trace[4 * (size_t)blockIdx.x + k] = __builtin_amdgcn_s_memtime();
+    if (P.trace && threadIdx.x == 0) P.trace[4 * (size_t)bid + k] = __builtin_amdgcn_s_memtime();
   };
   stamp(0);
-  const int panel = blockIdx.x / P.row_tiles, rt = blockIdx.x - panel * P.row_tiles;   // panel-major numbering
+  const int panel = bid / P.row_tiles, rt = bid - panel * P.row_tiles;   // panel-major numbering
   const int64_t m0 = (int64_t)rt * (64 * MB);
   const int n0 = panel * TNV;
   const int t = threadIdx.x, lane = t & 63;
@@ -1021,6 +1021,21 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring16(const PanelArgs P) 
   stamp(3);
 }
 
+template <int MB, int NJ, int EPI, bool HAS_CIN, bool EDGE = false>
+__global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring16(const PanelArgs P) {
+  ring16_body<MB, NJ, EPI, HAS_CIN, EDGE>(P, (int)blockIdx.x);
+}
+
+// Two independent GEMMs in ONE dispatch (gps_gemm16_panel_pair): workgroups 0 .. split-1 are the tiles of the first problem,
+// the rest those of the second.  A dependent dispatch of a replayed graph costs ~4 us before its first workgroup runs, and a
+// GEMM of one dispatch round leaves every CU idle through its prologue and its epilogue; paired, the second problem's tiles
+// start as the first's retire.  The first problem should be the one with the longer tiles (they are dispatched first).
+template <int MB0, int MB1, int NJ, bool HAS_CIN>
+__global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring16_pair(const PanelArgs P0, const PanelArgs P1, const int split) {
+  if ((int)blockIdx.x < split) ring16_body<MB0, NJ, 0, HAS_CIN, false>(P0, (int)blockIdx.x);
+  else ring16_body<MB1, NJ, 0, HAS_CIN, false>(P1, (int)blockIdx.x - split);
+}
+
 
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) % 16) == 0; }
 
@@ -1033,6 +1048,18 @@ static int panel_launch(const float* A, int64_t lda, int64_t M, int K, const uin
                         int64_t ldmask, float p_drop, uint64_t seed, const gps_bn* stats, float* ws, size_t ws_floats,
                         uint32_t* sync, gps_stream_t stream, const uint32_t* a_amax = nullptr, const uint32_t* w_amax = nullptr,
                         uint32_t* c_amax = nullptr, const int32_t* m_dev = nullptr);
+
+// a checked, filled launch of the ring kernel: what panel_launch dispatches (and gps_gemm16_panel_pair dispatches two of)
+struct PanelPlan {
+  PanelArgs P;
+  int mb, nj;
+  bool edge, f16;
+  unsigned grid;
+};
+static int panel_prepare(PanelPlan& Q, const float* A, int64_t lda, int64_t M, int K, const uint16_t* image, int N,
+                         const float* bias, const float* Cin, int64_t ldcin, float* C, int64_t ldc, int epilogue,
+                         const float* mask_src, int64_t ldmask, float p_drop, uint64_t seed, const gps_bn* stats, float* ws,
+                         uint32_t* sync, const uint32_t* a_amax, const uint32_t* w_amax, uint32_t* c_amax, const int32_t* m_dev);
 
 // 128-row panels (MB = 2) when they still give every CU a workgroup; 64-column panels always use 64 rows (the only
 // NJ = 1 instantiation).
@@ -1183,20 +1210,19 @@ int gps_gemm16_panel_stats(const float* A, int64_t lda, int64_t M, int K, const 
 
 }  // extern "C"
 
-static int panel_launch(const float* A, int64_t lda, int64_t M, int K, const uint16_t* image, int N, const float* bias,
-                        const float* Cin, int64_t ldcin, float* C, int64_t ldc, int epilogue, const float* mask_src,
-                        int64_t ldmask, float p_drop, uint64_t seed, const gps_bn* stats, float* ws, size_t ws_floats,
-                        uint32_t* sync, gps_stream_t stream, const uint32_t* a_amax, const uint32_t* w_amax, uint32_t* c_amax,
-                        const int32_t* m_dev) {
-  GPS_REQUIRE(M >= 0 && gps_gemm_panel_supported(N, K), "gps_gemm_panel: needs N %% 4 == 0 and K %% 4 == 0 (N=%d K=%d)",
+static int panel_prepare(PanelPlan& Q, const float* A, int64_t lda, int64_t M, int K, const uint16_t* image, int N,
+                         const float* bias, const float* Cin, int64_t ldcin, float* C, int64_t ldc, int epilogue,
+                         const float* mask_src, int64_t ldmask, float p_drop, uint64_t seed, const gps_bn* stats, float* ws,
+                         uint32_t* sync, const uint32_t* a_amax, const uint32_t* w_amax, uint32_t* c_amax, const int32_t* m_dev) {
+  GPS_REQUIRE(M >= 1 && gps_gemm_panel_supported(N, K), "gps_gemm_panel: needs N %% 4 == 0 and K %% 4 == 0 (N=%d K=%d)",
               N, K);
-  if (M == 0) return GPS_OK;
   GPS_REQUIRE(A && image && C && lda >= K && ldc >= N && lda % 4 == 0 && al16(A) && al16(image),
               "gps_gemm_panel: null / misaligned buffer");
   GPS_REQUIRE(!Cin || ldcin >= N, "gps_gemm_panel: bad addend stride");
   GPS_REQUIRE(epilogue >= 0 && epilogue <= 3 && (epilogue != 2 || (mask_src && ldmask >= N)), "gps_gemm_panel: epilogue");
   GPS_REQUIRE(p_drop >= 0.0f && p_drop < 1.0f, "gps_gemm_panel: p_drop");
-  PanelArgs P{};
+  PanelArgs& P = Q.P;
+  P = PanelArgs{};
   P.A = A; P.lda = lda; P.M = M; P.K = K; P.N = N; P.Nimg = (int)rg_npad(N, K); P.Bp = image; P.bias = bias; P.Cin = Cin; P.ldcin = ldcin;
   P.C = C; P.ldc = ldc; P.epilogue = epilogue; P.mask_src = mask_src; P.ldmask = ldmask;
   P.p_drop = epilogue ? p_drop : 0.0f; P.seed = seed; P.salt = gps::dropout_salt();
@@ -1204,7 +1230,6 @@ static int panel_launch(const float* A, int64_t lda, int64_t M, int K, const uin
   P.a_amax = a_amax; P.w_amax = w_amax; P.c_amax = c_amax; P.m_dev = epilogue == 3 ? m_dev : nullptr;
   const bool f16 = a_amax != nullptr;
   GPS_REQUIRE((a_amax == nullptr) == (w_amax == nullptr), "gps_gemm16_panel: both operand maxima or neither");
-  hipStream_t s = gps::as_stream(stream);
   // The ring kernels (LDS-DMA; k_gemm_ring: three bf16 pieces, six products -- exact; k_gemm_ring16: two fp16 pieces, three
   // products under per-tensor scales) serve every supported shape.
   const int mb = ring_mb(M, N, K), nj = rg_nj(N, K);
@@ -1226,9 +1251,28 @@ static int panel_launch(const float* A, int64_t lda, int64_t M, int K, const uin
       P.st_tick = sync;
       P.st_mean = stats->mean; P.st_rstd = stats->rstd; P.st_rmean = stats->running_mean; P.st_rvar = stats->running_var;
       P.st_eps = stats->eps; P.st_mom = stats->momentum;
-      (void)ws_floats;
     }
   }
+  Q.mb = mb; Q.nj = nj; Q.edge = edge; Q.f16 = f16; Q.grid = grid;
+  return GPS_OK;
+}
+
+static int panel_launch(const float* A, int64_t lda, int64_t M, int K, const uint16_t* image, int N, const float* bias,
+                        const float* Cin, int64_t ldcin, float* C, int64_t ldc, int epilogue, const float* mask_src,
+                        int64_t ldmask, float p_drop, uint64_t seed, const gps_bn* stats, float* ws, size_t ws_floats,
+                        uint32_t* sync, gps_stream_t stream, const uint32_t* a_amax, const uint32_t* w_amax, uint32_t* c_amax,
+                        const int32_t* m_dev) {
+  GPS_REQUIRE(M >= 0, "gps_gemm_panel: M");
+  if (M == 0) return GPS_OK;
+  (void)ws_floats;
+  PanelPlan Q;
+  if (int rc = panel_prepare(Q, A, lda, M, K, image, N, bias, Cin, ldcin, C, ldc, epilogue, mask_src, ldmask, p_drop, seed, stats,
+                             ws, sync, a_amax, w_amax, c_amax, m_dev)) return rc;
+  const PanelArgs& P = Q.P;
+  const int mb = Q.mb, nj = Q.nj;
+  const bool edge = Q.edge, f16 = Q.f16;
+  const unsigned grid = Q.grid;
+  hipStream_t s = gps::as_stream(stream);
 #define GPS_RING_ANY_T(KERNEL, LDS, THREADS)                                                          \
   do {                                                                                                \
     static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&KERNEL),        \
@@ -1274,4 +1318,53 @@ static int panel_launch(const float* A, int64_t lda, int64_t M, int K, const uin
 #undef GPS_RING_SHAPES
 #undef GPS_PANEL_LAUNCH
   return gps::launch_status("gps_gemm_panel");
+}
+
+extern "C" int gps_gemm16_panel_pair(const gps_gemm16_problem* first, const gps_gemm16_problem* second, gps_stream_t stream) {
+  GPS_REQUIRE(first && second, "gps_gemm16_panel_pair: null problem");
+  const gps_gemm16_problem* pr[2] = {first, second};
+  PanelPlan Q[2];
+  bool live[2];
+  for (int i = 0; i < 2; ++i) {
+    const gps_gemm16_problem& p = *pr[i];
+    GPS_REQUIRE(p.M >= 0 && p.a_amax && p.w_amax, "gps_gemm16_panel_pair: problem %d: rows / operand maxima", i);
+    live[i] = p.M > 0;
+    if (!live[i]) continue;
+    if (int rc = panel_prepare(Q[i], p.A, p.lda, p.M, p.K, p.image, p.N, p.bias, p.Cin, p.ldcin, p.C, p.ldc, 0, nullptr, 0, 0.0f, 0,
+                               nullptr, nullptr, nullptr, p.a_amax, p.w_amax, p.c_amax, nullptr)) return rc;
+  }
+  // one dispatch when both problems take the same non-edge fp16-form instantiation family (column panel width, addend or not)
+  const bool paired = live[0] && live[1] && !Q[0].edge && !Q[1].edge && Q[0].nj == Q[1].nj && Q[0].nj >= 2 &&
+                      (Q[0].P.Cin != nullptr) == (Q[1].P.Cin != nullptr);
+  if (!paired) {
+    for (int i = 0; i < 2; ++i) {
+      const gps_gemm16_problem& p = *pr[i];
+      if (!live[i]) continue;
+      if (int rc = panel_launch(p.A, p.lda, p.M, p.K, p.image, p.N, p.bias, p.Cin, p.ldcin, p.C, p.ldc, 0, nullptr, 0, 0.0f, 0,
+                                nullptr, nullptr, 0, nullptr, stream, p.a_amax, p.w_amax, p.c_amax)) return rc;
+    }
+    return GPS_OK;
+  }
+  hipStream_t s = gps::as_stream(stream);
+  const unsigned grid = Q[0].grid + Q[1].grid;
+  const int split = (int)Q[0].grid;
+#define GPS_PAIR(MB0, MB1, NJV, C)                                                                                  \
+  do {                                                                                                              \
+    constexpr int LDS = r16_lds_bytes(MB0, NJV) > r16_lds_bytes(MB1, NJV) ? r16_lds_bytes(MB0, NJV) : r16_lds_bytes(MB1, NJV); \
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring16_pair<MB0, MB1, NJV, C>), \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS);            \
+    GPS_REQUIRE(attr == hipSuccess, "gps_gemm16_panel_pair: cannot reserve %d bytes of LDS", LDS);                  \
+    k_gemm_ring16_pair<MB0, MB1, NJV, C><<<grid, NTHREADS, LDS, s>>>(Q[0].P, Q[1].P, split);                        \
+  } while (0)
+#define GPS_PAIR_MB(NJV, C)                                                                                         \
+  do {                                                                                                              \
+    if (Q[0].mb == 2) { if (Q[1].mb == 2) GPS_PAIR(2, 2, NJV, C); else GPS_PAIR(2, 1, NJV, C); }                    \
+    else { if (Q[1].mb == 2) GPS_PAIR(1, 2, NJV, C); else GPS_PAIR(1, 1, NJV, C); }                                 \
+  } while (0)
+  const bool cin = Q[0].P.Cin != nullptr;
+  if (Q[0].nj == 3) { if (cin) GPS_PAIR_MB(3, true); else GPS_PAIR_MB(3, false); }
+  else { if (cin) GPS_PAIR_MB(2, true); else GPS_PAIR_MB(2, false); }
+#undef GPS_PAIR_MB
+#undef GPS_PAIR
+  return gps::launch_status("gps_gemm16_panel_pair");
 }

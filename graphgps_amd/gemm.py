@@ -232,3 +232,38 @@ def gemm_panel(a: torch.Tensor, image, N: int, bias: Optional[torch.Tensor] = No
                            ptr(mask_src), mask_src.stride(0) if mask_src is not None else 0, float(p_drop),
                            int(seed), current_stream(a.device)), "gps_gemm_panel")
     return out
+
+
+def gemm_panel_pair(first, second):
+    """Two independent ``gemm_panel`` products (epilogue 0) in ONE dispatch (``gps_gemm16_panel_pair``): each of ``first`` /
+    ``second`` is ``dict(a=, image=, N=, bias=None, addend=None, out=None, a_amax=None, c_amax=None)``.  Workgroups of
+    ``first`` are dispatched first: pass the product with the longer contraction there.  Needs fp16-form images; returns the
+    two outputs."""
+    import ctypes
+    L = _lib.load()
+    probs, outs = [], []
+    for q in (first, second):
+        a, image, N = q["a"], q["image"], q["N"]
+        if getattr(image, "amax", None) is None:
+            raise _lib.GpsHipError("gemm_panel_pair: fp16-form images only")
+        M, K = a.shape
+        if a.stride(1) != 1 or a.dtype != torch.float32:
+            raise _lib.GpsHipError("gemm_panel_pair: fp32 A with unit column stride")
+        out = q.get("out")
+        if out is None:
+            out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+        addend, bias = q.get("addend"), q.get("bias")
+        P = _lib.Gemm16Problem()
+        P.A, P.lda, P.M, P.K, P.N = a.data_ptr(), a.stride(0), M, K, N
+        P.a_amax = _a_word(a, q.get("a_amax"))
+        P.image, P.w_amax = image.data_ptr(), image.amax.data_ptr()
+        P.bias = bias.data_ptr() if bias is not None else None
+        P.Cin, P.ldcin = (addend.data_ptr(), addend.stride(0)) if addend is not None else (None, 0)
+        P.C, P.ldc = out.data_ptr(), out.stride(0)
+        c_amax = q.get("c_amax")
+        P.c_amax = c_amax.data_ptr() if c_amax is not None else None
+        probs.append(P)
+        outs.append(out)
+    check(L.gps_gemm16_panel_pair(ctypes.byref(probs[0]), ctypes.byref(probs[1]), current_stream(outs[0].device)),
+          "gps_gemm16_panel_pair")
+    return outs[0], outs[1]

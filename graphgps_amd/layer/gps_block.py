@@ -47,6 +47,9 @@ _BY_REF = _ctypes.byref
 _GG_STATS = _os.environ.get("GPS_GG_STATS", "1") != "0"
 _GEMM_STATS = _os.environ.get("GPS_GEMM_STATS", "1") != "0"
 _GG_FIRST = _os.environ.get("GPS_GG_FIRST", "0") != "0"
+# GPS_GEMM_PAIR=0: the edge projection C(e) and the merged node projection (forward), and their two input-gradient GEMMs
+# (backward), as two dispatches each instead of one (csrc/gemm_panel.hip k_gemm_ring16_pair) -- A/B
+_GEMM_PAIR = _os.environ.get("GPS_GEMM_PAIR", "1") != "0"
 _STACK_PREP = _os.environ.get("GPS_STACK_PREP", "1") != "0"
 
 # Work that is per layer only by accident, hoisted to the layer STACK when a network drives the blocks (network/base.py
@@ -515,8 +518,12 @@ class _GPSBlock(torch.autograd.Function):
                 else:
                     _gemm.absmax([x, e], out=rec[0:2])
             aw = (lambda i: None) if am is None else (lambda i: am[i])
-            ce = _gemm.gemm_panel(e, imgs[1][0], d, bias=_B(R.C), a_amax=aw(1))
-            pq = _gemm.gemm_panel(x, imgs[0][0], ldp, bias=bias_m, a_amax=aw(0))
+            if am is not None and _GEMM_PAIR:      # one dispatch for the two projections that depend on nothing but x / e
+                pq, ce = _gemm.gemm_panel_pair(dict(a=x, image=imgs[0][0], N=ldp, bias=bias_m, a_amax=am[0]),
+                                               dict(a=e, image=imgs[1][0], N=d, bias=_B(R.C), a_amax=am[1]))
+            else:
+                ce = _gemm.gemm_panel(e, imgs[1][0], d, bias=_B(R.C), a_amax=aw(1))
+                pq = _gemm.gemm_panel(x, imgs[0][0], ldp, bias=bias_m, a_amax=aw(0))
         else:
             am, rec, aw = None, None, (lambda i: None)
             ce = torch.addmm(_B(R.C), e, _W(R.C).t())
@@ -793,7 +800,11 @@ class _GPSBlock(torch.autograd.Function):
         else:
             ((g_wcat, g_bcat), (g_wc, g_bc), (g_wo, g_bo), (g_w1, g_b1), (g_w2, g_b2)) = \
                 [_K.param_grads(L, g, a, leaves) for g, a in pairs]
-        if imgs is not None:
+        if imgs is not None and bm is not None and _GEMM_PAIR:
+            # the two input gradients of the block in one dispatch, the K = 4d + 3 inner one first
+            g_x, g_e = _gemm.gemm_panel_pair(dict(a=g_pq, image=imgs[0][1], N=d, addend=g_xres, out=g_xres, a_amax=bm[3]),
+                                             dict(a=g_ce, image=imgs[1][1], N=d, addend=g_e1, a_amax=bm[4]))
+        elif imgs is not None:
             g_x = _gemm.gemm_panel(g_pq, imgs[0][1], d, addend=g_xres, out=g_xres, a_amax=bw(3))
             g_e = _gemm.gemm_panel(g_ce, imgs[1][1], d, addend=g_e1, a_amax=bw(4))
         else:
@@ -939,7 +950,7 @@ class _GPSBlockGINE(torch.autograd.Function):
         pairs = [(g_qkv, x), (g_ao, o), (g_g2, g1r), (g_g1, agg), (g_f1, h), (g_f2, t)]
         leaves = block_params_gine(layer)
         if _GROUPED_WGRAD:
-            grads = _grouped_param_grads(L, pairs, leaves, sync=sync)
+            grads = _grouped_param_grads(L, pairs, leaves)
         else:
             grads = [_K.param_grads(L, g, a, leaves) for g, a in pairs]
         (g_wi, g_bi), (g_wo, g_bo), (g_wl2, g_bl2), (g_wl1, g_bl1), (g_w1, g_b1), (g_w2, g_b2) = grads

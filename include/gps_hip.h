@@ -291,6 +291,26 @@ int gps_gemm16_panel_stats(const float* A, int64_t lda, int64_t M, int K, const 
                            uint32_t* sync, const int32_t* m_dev, gps_stream_t stream);
 /* m_dev (or NULL): padded batches -- device word with the number of REAL rows; rows past it are computed and stored but
  * stay out of the column statistics (see gps_norm_fwd_task.rdev). */
+/* Two INDEPENDENT products C = A W^T + bias (+ Cin) in one dispatch (epilogue 0 each): the edge projection C(e) beside the
+ * merged node projection of a GPS block (graphgps/layer/gatedgcn_layer.py:57-61 + gps_layer.py:238), and the two input
+ * gradients g_pq Wcat / g_ce W_C of its backward.  Workgroups of `first` are dispatched first: pass the problem with the
+ * longer contraction there.  Same arithmetic per problem as gps_gemm16_panel; problems whose shapes take different kernel
+ * families (edge shapes, different column panel widths, one with an addend and one without) run as two launches. */
+typedef struct gps_gemm16_problem {
+  const float* A;
+  int64_t lda, M;
+  int32_t K, N;
+  const uint32_t* a_amax;
+  const uint16_t* image;
+  const uint32_t* w_amax;
+  const float* bias;      /* [N] or NULL */
+  const float* Cin;       /* addend [M][N] (row stride ldcin) or NULL; may alias C */
+  int64_t ldcin;
+  float* C;
+  int64_t ldc;
+  uint32_t* c_amax;       /* or NULL */
+} gps_gemm16_problem;
+int gps_gemm16_panel_pair(const gps_gemm16_problem* first, const gps_gemm16_problem* second, gps_stream_t stream);
 
 /* ---------------------------------------------------------------------------------------
  * Segment (per-graph, varlen) multi-head attention core on fp32 MFMA (v_mfma_f32_16x16x4_f32).

@@ -938,6 +938,47 @@ def test_gin_aggregate_matches_index_add():
         assert_close(xg.grad, xr.grad, Tol.GRAD_REL, "gin d_x", rel_to_max=True)
 
 
+@pytest.mark.parametrize("p0,p1,cin", [
+    ((7569, 384, 2688), (15348, 384, 384), False),      # the block's forward pair: merged node projection | C(e)
+    ((7569, 2688, 384), (15348, 384, 384), True),       # its backward pair: g_pq Wcat (64-row tiles) | g_ce W_C (128-row tiles)
+    ((300, 384, 384), (5000, 384, 768), True), ((25013, 256, 256), (7000, 256, 1792), False),     # 128-column panels
+    ((1000, 384, 384), (1000, 256, 256), False),        # different panel widths: two launches behind the same call
+    ((743, 304, 304), (900, 384, 384), False),          # an edge shape: two launches
+    ((64, 384, 384), (0, 384, 384), False)])            # an empty problem
+def test_gemm_panel_pair_is_bit_identical(p0, p1, cin):
+    """gps_gemm16_panel_pair (two independent products in ONE dispatch, csrc/gemm_panel.hip k_gemm_ring16_pair) against the
+    two gps_gemm16_panel launches it replaces: the same tiles run the same code, so the results are bit-identical --
+    including the max|C| records and in-place accumulation into the addend."""
+    from graphgps_amd.gemm import absmax, amax_records, gemm_panel, gemm_panel_pair, split_weights
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(sum(p0) + sum(p1))
+    probs = []
+    for (M, K, N) in (p0, p1):
+        a = torch.randn(M, K, generator=gen).to(dev)
+        w = (torch.randn(N, K, generator=gen) / K ** 0.5).to(dev)
+        b = torch.randn(N, generator=gen).to(dev)
+        add = torch.randn(M, N, generator=gen).to(dev) if cin else None
+        (img, _), = split_weights([w], tn=False, f16=True)
+        rec = amax_records(1, dev)
+        if M:
+            absmax([a], out=rec)
+        probs.append((a, img, N, b, add, rec[0]))
+    singles, recs1 = [], amax_records(2, dev)
+    for i, (a, img, N, b, add, rec) in enumerate(probs):
+        singles.append(gemm_panel(a, img, N, bias=b, addend=add.clone() if cin else None, a_amax=rec, c_amax=recs1[i]))
+    recs2 = amax_records(2, dev)
+    outs = [q[4].clone() if cin else None for q in probs]
+    pair = gemm_panel_pair(*[dict(a=a, image=img, N=N, bias=b, addend=outs[i], out=outs[i], a_amax=rec, c_amax=recs2[i])
+                             for i, (a, img, N, b, add, rec) in enumerate(probs)])
+    torch.cuda.synchronize()
+    for i in range(2):
+        assert pair[i].shape == singles[i].shape
+        assert torch.equal(pair[i], singles[i]), f"problem {i}: {float((pair[i] - singles[i]).abs().max()):.3e}"
+        if cin:
+            assert pair[i].data_ptr() == outs[i].data_ptr()
+    assert torch.equal(recs1.view(2, -1).max(dim=1).values, recs2.view(2, -1).max(dim=1).values)
+
+
 @pytest.mark.parametrize("M,K,N", [(7569, 384, 2688), (1000, 384, 384), (15348, 384, 384), (7569, 768, 384),
                                    (333, 2688, 384), (64, 128, 192), (65, 256, 768),
                                    # round 3: 128- and 64-column panels, any number of k-stages (d = 256: code2 / GPS-deep;
