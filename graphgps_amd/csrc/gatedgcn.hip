@@ -314,6 +314,105 @@ __global__ __launch_bounds__(GG_T) void k_gatedgcn_fwd(
   if (STATS) fwd_stats_finish<VEC>(sa, stats, blk.n0 / nb, active, row, npi, c, d, g_fwd_lds);
 }
 
+// ---- BatchNorm backward folded into the loads of the output gradients (round 6) -----------------------------------------
+// The two gradients this kernel consumes are outputs of BatchNorm backward applies whose ONLY reader it is:
+//   g_x~ = dBN_x(g_x1; x~)   (gatedgcn_layer.py:72,75-78: x = x_in + dropout(relu(bn_node_x(x~))))
+//   g_e^ = dBN_e(g_e1; e^)   (gatedgcn_layer.py:73,76-79)
+// and it already reads x~ and e^.  With FOLD the kernel takes g_x1 / g_e1 and evaluates, per element it loads,
+//   g = relu'/dropout mask(row, col) * g_y ;  zhat = (z - mean) rstd ;  out = gate * gamma rstd (g - S1/n - zhat S2/n)
+// -- the arithmetic of csrc/block_norm.hip k_bwd_apply, same association -- from six column vectors held in registers
+// (S1 = sum g, S2 = sum g zhat: gps_norm_bwd_partial / the chain of an apply).  That removes the bn_node_x apply launch
+// (35 MB) and the bn_edge_e half of another (71 MB) per layer and pass.
+struct BnFold {
+  const float *mean, *rstd, *gamma, *beta, *sum_g, *sum_gz;
+  const int32_t* rdev;     // padded batches: number of real rows (device word), or nullptr
+  int64_t R;
+  uint64_t seed;
+  float p;
+  int relu;
+};
+__device__ __forceinline__ uint32_t gg_mix32(uint32_t x) {
+  x ^= x >> 16; x *= 0x7feb352dU; x ^= x >> 15; x *= 0x846ca68bU; x ^= x >> 16;
+  return x;
+}
+// Column vectors of one fold: mean, rstd, gamma, beta, S1, S2 over this lane's VEC channels
+template <int VEC>
+struct FoldVecs {
+  Vec<VEC> mu, rs, ga, be, s1, s2;
+  __device__ __forceinline__ void load(const BnFold& F, int c) {
+    mu = Vec<VEC>::load(F.mean + c); rs = Vec<VEC>::load(F.rstd + c);
+    ga = Vec<VEC>::load(F.gamma + c); be = Vec<VEC>::load(F.beta + c);
+    s1 = Vec<VEC>::load(F.sum_g + c); s2 = Vec<VEC>::load(F.sum_gz + c);
+  }
+  __device__ __forceinline__ void load_lds(const float* sF, int d, int c) {     // [6][d] staged by the workgroup
+    mu = Vec<VEC>::load(sF + c); rs = Vec<VEC>::load(sF + d + c);
+    ga = Vec<VEC>::load(sF + 2 * d + c); be = Vec<VEC>::load(sF + 3 * d + c);
+    s1 = Vec<VEC>::load(sF + 4 * d + c); s2 = Vec<VEC>::load(sF + 5 * d + c);
+  }
+};
+// ... and its launch-uniform scalars (the ReLU between the BatchNorm and the dropout is GatedGCN's own: always on)
+struct FoldScal {
+  float inv_n, inv_keep, p;
+  uint32_t seed_lo, seed_hi;
+  int rreal;
+  __device__ __forceinline__ void init(const BnFold& F, const uint64_t* salt) {
+    rreal = (int)(F.rdev ? min((int64_t)*F.rdev, F.R) : F.R);
+    inv_n = 1.0f / (float)rreal;
+    p = F.p;
+    inv_keep = F.p > 0.0f ? 1.0f / (1.0f - F.p) : 1.0f;
+    const uint64_t seed = gps::salted_seed(F.seed, salt);
+    seed_lo = (uint32_t)seed;
+    seed_hi = (uint32_t)(seed >> 32);
+  }
+};
+// identical to block_norm.hip row_hash / keep_elem / out_grad / apply_row
+template <int VEC>
+__device__ __forceinline__ Vec<VEC> fold_apply(const FoldScal& S, const FoldVecs<VEC>& K, const Vec<VEC>& gy, const Vec<VEC>& z,
+                                               int64_t row, int c) {
+  const bool drop = S.p > 0.0f;
+  const uint32_t rh = drop ? gg_mix32((uint32_t)row ^ S.seed_lo) + S.seed_hi : 0u;
+  const float gate = row < (int64_t)S.rreal ? 1.0f : 0.0f;
+  Vec<VEC> o;
+#pragma unroll
+  for (int v = 0; v < VEC; ++v) {
+    const float zh = (z[v] - K.mu[v]) * K.rs[v];
+    float gg = gy[v];
+    if (drop) {
+      const uint32_t r = gg_mix32(rh + (uint32_t)(c + v) * 0x9E3779B9U);
+      gg = (float)(r >> 8) * (1.0f / 16777216.0f) >= S.p ? gg * S.inv_keep : 0.0f;
+    }
+    gg = (zh * K.ga[v] + K.be[v]) > 0.0f ? gg : 0.0f;
+    o[v] = gate * (K.ga[v] * K.rs[v] * (gg - K.s1[v] * S.inv_n - zh * K.s2[v] * S.inv_n));
+  }
+  return o;
+}
+// The pair of folds of one launch.  The edge fold runs in the inner loops: its vectors live in registers.  The node fold
+// runs once per node (and per out-of-block target): its vectors are staged in LDS ([6][d] behind the stash) -- both sets in
+// registers spilled at 768 threads per workgroup (168 VGPRs).  An empty stand-in keeps the un-folded instantiation as it was.
+template <int VEC, int FOLD>
+struct Folds {
+  FoldScal es;
+  const float* sF;
+  int d;
+  __device__ __forceinline__ Vec<VEC> edge(const Vec<VEC>& gy, const Vec<VEC>& eh, int64_t id, int c) const {
+    FoldVecs<VEC> ev;
+    ev.load_lds(sF + 6 * d, d, c);
+    return fold_apply<VEC>(es, ev, gy, eh, id, c);
+  }
+  __device__ __forceinline__ Vec<VEC> node(const Vec<VEC>& gy, const Vec<VEC>& xt, int64_t n, int c) const {
+    FoldVecs<VEC> xv;
+    xv.load_lds(sF, d, c);
+    // the node fold's scalars come back from LDS too (once per node): 25 scalar registers spilled with them resident
+    const float* q = sF + 12 * d;
+    FoldScal xs;
+    xs.inv_n = q[0]; xs.inv_keep = q[1]; xs.p = q[2];
+    xs.seed_lo = __float_as_uint(q[3]); xs.seed_hi = __float_as_uint(q[4]); xs.rreal = __float_as_int(q[5]);
+    return fold_apply<VEC>(xs, xv, gy, xt, n, c);
+  }
+};
+template <int VEC>
+struct Folds<VEC, 0> {};
+
 // Backward, one launch (see the header comment):
 //   a_i = g_x_i / D_i,  b_i = -a_i * num_i / D_i                 (D_i = den_i + 1e-6, num_i recomputed)
 //   delta_ij = g_e_ij + (a_i * Bx_j + b_i) * sig_ij * (1 - sig_ij)
@@ -321,24 +420,28 @@ __global__ __launch_bounds__(GG_T) void k_gatedgcn_fwd(
 //   g_Ex_j = sum_{j->i} delta_ij ;   g_Bx_j = sum_{j->i} sig_ij * a_i
 // Phase A, a node with D <= 4 incoming edges in ONE pass: with t_ij = g_e_ij + a_i Bx_j s'_ij and
 // s'_ij = r_ij sig (1 - sig) kept in registers, delta_ij = t_ij + b_i s'_ij once num_i (hence b_i) is known.
-template <int VEC, bool GATE, int D>
+template <int VEC, bool GATE, int FOLD, int D>
 __device__ __forceinline__ void bwd_a_chunk(const float* __restrict__ g_e, const float* __restrict__ e_hat,
                                             const float* __restrict__ Bx, int64_t ld,
                                             const float* __restrict__ r_edge, int d, int c, const int* nbr,
                                             const int* eids, const Vec<VEC>& gx, Vec<VEC>& gdx, float* g_Ce,
                                             float* __restrict__ sD, float* __restrict__ sS, int slot0, int cap,
-                                            float& mce) {
-  int64_t id[D];
+                                            float& mce, const Folds<VEC, FOLD>& FK) {
+  int id[D];                  // (32-bit: widened at each use -- with the folds every register of this chunk counts)
   Vec<VEC> eh[D], ge[D], bx[D];
   float rr[D];
 #pragma unroll
   for (int u = 0; u < D; ++u) {
     const int64_t j = nbr[u];
     id[u] = eids[u];
-    eh[u] = Vec<VEC>::load(e_hat + id[u] * d + c);
-    ge[u] = Vec<VEC>::load(g_e + id[u] * d + c);
+    eh[u] = Vec<VEC>::load(e_hat + (int64_t)id[u] * d + c);
+    ge[u] = Vec<VEC>::load(g_e + (int64_t)id[u] * d + c);
     bx[u] = Vec<VEC>::load(Bx + j * ld + c);
     rr[u] = GATE ? r_edge[id[u]] : 1.0f;
+  }
+  if constexpr ((FOLD & 2) != 0) {
+#pragma unroll
+    for (int u = 0; u < D; ++u) ge[u] = FK.edge(ge[u], eh[u], id[u], c);
   }
   // num_i and den_i exactly as the forward summed them (same order, same gate arithmetic): nothing was saved
   Vec<VEC> num = Vec<VEC>::zero(), den = Vec<VEC>::zero();
@@ -372,7 +475,7 @@ __device__ __forceinline__ void bwd_a_chunk(const float* __restrict__ g_e, const
       sa[v] = (GATE ? s * rr[u] : s) * a[v];   // sig_ij a_i: what the source-keyed phase adds to g_Bx_j
       mce = fmaxf(mce, fabsf(dl[v]));          // max|g_Ce|: the record of the GEMMs that consume g_Ce (gps_hip.h)
     }
-    dl.store(g_Ce + id[u] * d + c);
+    dl.store(g_Ce + (int64_t)id[u] * d + c);
     if (slot0 + u < cap) {                    // hand-over to phase B through LDS (no second trip to memory)
       dl.store(sD + (slot0 + u) * d + c);
       sa.store(sS + (slot0 + u) * d + c);
@@ -380,26 +483,30 @@ __device__ __forceinline__ void bwd_a_chunk(const float* __restrict__ g_e, const
   }
 }
 
-template <int VEC, bool GATE>
+template <int VEC, bool GATE, int FOLD>
 __device__ __forceinline__ void bwd_a_rows(const float* __restrict__ g_x, int64_t ldgx,
                                            const float* __restrict__ g_e, const float* __restrict__ e_hat,
                                            const float* __restrict__ Bx, int64_t ld, const int* rp, const int* nbr,
                                            const int* eids, const NodeBlock& blk, int d, int row, int npi, int c,
                                            float* g_Ce, float* __restrict__ g_Ax, float* __restrict__ g_Dx,
                                            int64_t ldg, const float* __restrict__ r_edge, float* __restrict__ sD,
-                                           float* __restrict__ sS, int e0, int cap, float& mce, float& mnode) {
-#define GPS_BWD_A(DD) bwd_a_chunk<VEC, GATE, DD>(g_e, e_hat, Bx, ld, r_edge, d, c, nbr + beg, eids + beg, gx, gdx, \
-                                                 g_Ce, sD, sS, beg - e0, cap, mce)
+                                           float* __restrict__ sS, int e0, int cap, float& mce, float& mnode,
+                                           const float* __restrict__ x_tilde, const Folds<VEC, FOLD>& FK) {
+#define GPS_BWD_A(DD) bwd_a_chunk<VEC, GATE, FOLD, DD>(g_e, e_hat, Bx, ld, r_edge, d, c, nbr + beg, eids + beg, gx, gdx, \
+                                                       g_Ce, sD, sS, beg - e0, cap, mce, FK)
   for (int64_t node = blk.n0 + row; node < blk.n1; node += npi) {
     const int beg = rp[node - blk.n0], end = rp[node - blk.n0 + 1];
-    const Vec<VEC> gx = Vec<VEC>::load(g_x + node * ldgx + c);
+    Vec<VEC> gx = Vec<VEC>::load(g_x + node * ldgx + c);
+    if constexpr ((FOLD & 1) != 0) gx = FK.node(gx, Vec<VEC>::load(x_tilde + node * d + c), node, c);
     Vec<VEC> gdx = Vec<VEC>::zero();
-    switch (end - beg) {
+    // (with both folds the one-pass form holds three edges: four -- 48 registers of rows on top of the folds' -- spill at the
+    // 168 registers per lane of a 768-thread workgroup; a fourth incoming edge takes the two-pass form below)
+    switch ((FOLD == 3 && end - beg == 4) ? 5 : end - beg) {
       case 0: break;
       case 1: GPS_BWD_A(1); break;
       case 2: GPS_BWD_A(2); break;
       case 3: GPS_BWD_A(3); break;
-      case 4: GPS_BWD_A(4); break;
+      case 4: if constexpr (FOLD != 3) GPS_BWD_A(4); break;
       default: {                               // long segment: num_i / den_i first, then the deltas (rows re-read from L1 / L2)
         Vec<VEC> num = Vec<VEC>::zero(), den = Vec<VEC>::zero();
         for (int k = beg; k < end; ++k) {
@@ -425,7 +532,8 @@ __device__ __forceinline__ void bwd_a_rows(const float* __restrict__ g_x, int64_
         for (int k = beg; k < end; ++k) {
           const int64_t j = nbr[k], id = eids[k];
           const Vec<VEC> eh = Vec<VEC>::load(e_hat + id * d + c);
-          const Vec<VEC> ge = Vec<VEC>::load(g_e + id * d + c);
+          Vec<VEC> ge = Vec<VEC>::load(g_e + id * d + c);
+          if constexpr ((FOLD & 2) != 0) ge = FK.edge(ge, eh, id, c);
           const Vec<VEC> bx = Vec<VEC>::load(Bx + j * ld + c);
           const float rr = GATE ? r_edge[id] : 1.0f;
           Vec<VEC> dl, sa;
@@ -458,7 +566,7 @@ __device__ __forceinline__ void bwd_a_rows(const float* __restrict__ g_x, int64_
 // Phase B, D outgoing edges of one source node.  An edge whose target this workgroup owns finds its delta and
 // sig a_i in the LDS stash phase A filled (slot = the edge's position in the block's CSR slice, looked up through the
 // target's <= few-entry segment); only edges to other workgroups' nodes -- or beyond the stash -- go back to memory.
-template <int VEC, bool GATE, int D>
+template <int VEC, bool GATE, int FOLD, int D>
 __device__ __forceinline__ void bwd_b_chunk(const float* __restrict__ g_x, int64_t ldgx,
                                             const float* __restrict__ g_e, const float* __restrict__ e_hat,
                                             const float* __restrict__ Ax, int64_t ld,
@@ -468,7 +576,8 @@ __device__ __forceinline__ void bwd_b_chunk(const float* __restrict__ g_x, int64
                                             const int* tgt, const int* eids, const NodeBlock& blk,
                                             const float* __restrict__ Bx, int64_t node, Vec<VEC>& gbx,
                                             Vec<VEC>& gex, const int* rp_d, const int* eids_d, int e0,
-                                            const float* __restrict__ sD, const float* __restrict__ sS, int cap) {
+                                            const float* __restrict__ sD, const float* __restrict__ sS, int cap,
+                                            const Folds<VEC, FOLD>& FK) {
   int64_t ti[D], id[D];
   int slot[D];
 #pragma unroll
@@ -495,7 +604,8 @@ __device__ __forceinline__ void bwd_b_chunk(const float* __restrict__ g_x, int64
     } else {                                 // target owned by another workgroup (or stash overflow)
       const bool in = ti[u] >= blk.n0 && ti[u] < blk.n1;
       const Vec<VEC> eh = Vec<VEC>::load(e_hat + id[u] * d + c);
-      const Vec<VEC> gx = Vec<VEC>::load(g_x + ti[u] * ldgx + c);
+      Vec<VEC> gx = Vec<VEC>::load(g_x + ti[u] * ldgx + c);
+      if constexpr ((FOLD & 1) != 0) gx = FK.node(gx, Vec<VEC>::load(x_tilde + ti[u] * d + c), ti[u], c);
       // den of the target, as the forward summed it: walk the target's own incoming segment (global CSR)
       Vec<VEC> dn = Vec<VEC>::zero();
       for (int k2 = rowptr_g[ti[u]]; k2 < rowptr_g[ti[u] + 1]; ++k2) {
@@ -508,7 +618,8 @@ __device__ __forceinline__ void bwd_b_chunk(const float* __restrict__ g_x, int64
           dn[v] += GATE ? s2 * r2 : s2;
         }
       }
-      const Vec<VEC> p0 = Vec<VEC>::load((in ? g_Ce : g_e) + id[u] * d + c);   // own delta row, or g_e to rebuild it
+      Vec<VEC> p0 = Vec<VEC>::load((in ? g_Ce : g_e) + id[u] * d + c);   // own delta row, or g_e to rebuild it
+      if constexpr ((FOLD & 2) != 0) { if (!in) p0 = FK.edge(p0, eh, id[u], c); }
       const float rr = GATE ? r_edge[id[u]] : 1.0f;
       Vec<VEC> xt = Vec<VEC>::zero(), axi = Vec<VEC>::zero(), bxj = Vec<VEC>::zero();
       if (!in) {
@@ -533,7 +644,7 @@ __device__ __forceinline__ void bwd_b_chunk(const float* __restrict__ g_x, int64
   }
 }
 
-template <int VEC, bool GATE>
+template <int VEC, bool GATE, int FOLD>
 __device__ __forceinline__ void bwd_b_rows(const float* __restrict__ g_x, int64_t ldgx,
                                            const float* __restrict__ g_e, const float* __restrict__ e_hat,
                                            const float* __restrict__ Ax, const float* __restrict__ Bx, int64_t ld,
@@ -544,10 +655,10 @@ __device__ __forceinline__ void bwd_b_rows(const float* __restrict__ g_x, int64_
                                            float* __restrict__ g_Bx, float* __restrict__ g_Ex, int64_t ldg,
                                            const float* __restrict__ r_edge, const int* rp_d, const int* eids_d,
                                            int e0, const float* __restrict__ sD, const float* __restrict__ sS,
-                                           int cap, float& mnode) {
-#define GPS_BWD_B(DD) bwd_b_chunk<VEC, GATE, DD>(g_x, ldgx, g_e, e_hat, Ax, ld, x_tilde, rowptr_g, eid_g, r_edge, g_Ce, d, c, \
-                                                 tgt + k, eids + k, blk, Bx, node, gbx, gex, rp_d, eids_d, e0, sD, \
-                                                 sS, cap)
+                                           int cap, float& mnode, const Folds<VEC, FOLD>& FK) {
+#define GPS_BWD_B(DD) bwd_b_chunk<VEC, GATE, FOLD, DD>(g_x, ldgx, g_e, e_hat, Ax, ld, x_tilde, rowptr_g, eid_g, r_edge, g_Ce, d, \
+                                                       c, tgt + k, eids + k, blk, Bx, node, gbx, gex, rp_d, eids_d, e0, sD, \
+                                                       sS, cap, FK)
   for (int64_t node = blk.n0 + row; node < blk.n1; node += npi) {
     const int beg = rq[node - blk.n0], end = rq[node - blk.n0 + 1];
     Vec<VEC> gbx = Vec<VEC>::zero(), gex = Vec<VEC>::zero();
@@ -568,7 +679,7 @@ __device__ __forceinline__ void bwd_b_rows(const float* __restrict__ g_x, int64_
 #undef GPS_BWD_B
 }
 
-template <int VEC, bool GATE>
+template <int VEC, bool GATE, int FOLD>
 __global__ __launch_bounds__(GG_T) void k_gatedgcn_bwd(
     const float* __restrict__ g_x, int64_t ldgx, const float* __restrict__ g_e, const float* __restrict__ e_hat,
     const float* __restrict__ Ax, const float* __restrict__ Bx, int64_t ld, const float* __restrict__ x_tilde,
@@ -576,7 +687,8 @@ __global__ __launch_bounds__(GG_T) void k_gatedgcn_bwd(
     const int32_t* __restrict__ eid, const int32_t* __restrict__ rowptr_s, const int32_t* __restrict__ dst,
     const int32_t* __restrict__ eid_s, int64_t N, int d, float* g_Ce, float* __restrict__ g_Ax,
     float* __restrict__ g_Bx, float* __restrict__ g_Dx, float* __restrict__ g_Ex, int64_t ldg,
-    const float* __restrict__ r_edge, int nb, int npi, int cap_arg, uint32_t* amax_node, uint32_t* amax_ce) {
+    const float* __restrict__ r_edge, int nb, int npi, int cap_arg, uint32_t* amax_node, uint32_t* amax_ce,
+    const BnFold fold_x, const BnFold fold_e, const uint64_t* salt) {
   __shared__ int s_rp[GG_MAXNB + 1], s_rq[GG_MAXNB + 1];
   __shared__ uint32_t s_amax[2][GG_T / 64];
   __shared__ int s_src[GG_MAXE], s_eid[GG_MAXE], s_dst[GG_MAXE], s_eid2[GG_MAXE];
@@ -585,6 +697,30 @@ __global__ __launch_bounds__(GG_T) void k_gatedgcn_bwd(
   if (!blk.valid()) return;                 // whole workgroup leaves together
   const bool st_d = stage_slice(rowptr, src, eid, blk, s_rp, s_src, s_eid);
   const bool st_s = stage_slice(rowptr_s, dst, eid_s, blk, s_rq, s_dst, s_eid2);
+  float* sD = g_stash;
+  float* sS = g_stash + (int64_t)cap_arg * d;
+  float* sF = g_stash + 2 * (int64_t)cap_arg * d;       // FOLD: [12][d] column vectors of the node fold | the edge fold
+  if constexpr (FOLD != 0) {
+    if constexpr ((FOLD & 1) != 0) {
+      if (threadIdx.x == 0) {
+        FoldScal xs;
+        xs.init(fold_x, salt);
+        float* q = sF + 12 * d;
+        q[0] = xs.inv_n; q[1] = xs.inv_keep; q[2] = xs.p;
+        q[3] = __uint_as_float(xs.seed_lo); q[4] = __uint_as_float(xs.seed_hi); q[5] = __int_as_float(xs.rreal);
+      }
+    }
+    for (int t = threadIdx.x; t < d; t += blockDim.x) {
+      if constexpr ((FOLD & 1) != 0) {
+        sF[t] = fold_x.mean[t]; sF[d + t] = fold_x.rstd[t]; sF[2 * d + t] = fold_x.gamma[t];
+        sF[3 * d + t] = fold_x.beta[t]; sF[4 * d + t] = fold_x.sum_g[t]; sF[5 * d + t] = fold_x.sum_gz[t];
+      }
+      if constexpr ((FOLD & 2) != 0) {
+        sF[6 * d + t] = fold_e.mean[t]; sF[7 * d + t] = fold_e.rstd[t]; sF[8 * d + t] = fold_e.gamma[t];
+        sF[9 * d + t] = fold_e.beta[t]; sF[10 * d + t] = fold_e.sum_g[t]; sF[11 * d + t] = fold_e.sum_gz[t];
+      }
+    }
+  }
   __syncthreads();
   const int lpr = d / VEC;
   const int row = threadIdx.x / lpr;
@@ -593,16 +729,20 @@ __global__ __launch_bounds__(GG_T) void k_gatedgcn_bwd(
   // ---- phase A: keyed by target ------------------------------------------------------------------
   const int e0 = s_rp[0];
   const int cap = st_d ? cap_arg : 0;       // the slot lookup of phase B walks the staged CSR slice
-  float* sD = g_stash;
-  float* sS = g_stash + (int64_t)cap_arg * d;
   float mce = 0.0f, mnode = 0.0f;        // max|g_Ce|, max over the four node gradients: the records of their GEMMs
+  Folds<VEC, FOLD> FK;
+  if constexpr (FOLD != 0) {
+    if constexpr ((FOLD & 2) != 0) FK.es.init(fold_e, salt);
+    FK.sF = sF;
+    FK.d = d;
+  }
   if (active) {
     if (st_d)
-      bwd_a_rows<VEC, GATE>(g_x, ldgx, g_e, e_hat, Bx, ld, s_rp, s_src - e0, s_eid - e0, blk, d, row, npi, c,
-                            g_Ce, g_Ax, g_Dx, ldg, r_edge, sD, sS, e0, cap, mce, mnode);
+      bwd_a_rows<VEC, GATE, FOLD>(g_x, ldgx, g_e, e_hat, Bx, ld, s_rp, s_src - e0, s_eid - e0, blk, d, row, npi, c,
+                                  g_Ce, g_Ax, g_Dx, ldg, r_edge, sD, sS, e0, cap, mce, mnode, x_tilde, FK);
     else
-      bwd_a_rows<VEC, GATE>(g_x, ldgx, g_e, e_hat, Bx, ld, s_rp, src, eid, blk, d, row, npi, c, g_Ce, g_Ax,
-                            g_Dx, ldg, r_edge, sD, sS, e0, 0, mce, mnode);
+      bwd_a_rows<VEC, GATE, FOLD>(g_x, ldgx, g_e, e_hat, Bx, ld, s_rp, src, eid, blk, d, row, npi, c, g_Ce, g_Ax,
+                                  g_Dx, ldg, r_edge, sD, sS, e0, 0, mce, mnode, x_tilde, FK);
   }
   __threadfence_block();
   __syncthreads();            // this workgroup's g_Ce rows are visible to all of its lanes (same CU)
@@ -611,11 +751,12 @@ __global__ __launch_bounds__(GG_T) void k_gatedgcn_bwd(
   if (active) {
     const int q0 = s_rq[0];
     if (st_s)
-      bwd_b_rows<VEC, GATE>(g_x, ldgx, g_e, e_hat, Ax, Bx, ld, x_tilde, rowptr, eid, s_rq, s_dst - q0, s_eid2 - q0,
-                            blk, d, row, npi, c, g_Ce, g_Bx, g_Ex, ldg, r_edge, s_rp, s_eid - e0, e0, sD, sS, cap, mnode);
+      bwd_b_rows<VEC, GATE, FOLD>(g_x, ldgx, g_e, e_hat, Ax, Bx, ld, x_tilde, rowptr, eid, s_rq, s_dst - q0, s_eid2 - q0,
+                                  blk, d, row, npi, c, g_Ce, g_Bx, g_Ex, ldg, r_edge, s_rp, s_eid - e0, e0, sD, sS, cap, mnode,
+                                  FK);
     else
-      bwd_b_rows<VEC, GATE>(g_x, ldgx, g_e, e_hat, Ax, Bx, ld, x_tilde, rowptr, eid, s_rq, dst, eid_s, blk, d, row,
-                            npi, c, g_Ce, g_Bx, g_Ex, ldg, r_edge, s_rp, s_eid - e0, e0, sD, sS, cap, mnode);
+      bwd_b_rows<VEC, GATE, FOLD>(g_x, ldgx, g_e, e_hat, Ax, Bx, ld, x_tilde, rowptr, eid, s_rq, dst, eid_s, blk, d, row,
+                                  npi, c, g_Ce, g_Bx, g_Ex, ldg, r_edge, s_rp, s_eid - e0, e0, sD, sS, cap, mnode, FK);
   }
   if (!amax_node) return;                  // (kernel-uniform)
   // one atomic per record and workgroup: through LDS (a wave of the block may hold inactive rows' lanes only)
@@ -676,10 +817,11 @@ inline Plan plan_for(int64_t N, int lanes_per_row, bool forward) {
 #define GPS_GG_FWD(GATE, STATS, LDS)                                                                  \
   k_gatedgcn_fwd<VEC, GATE, STATS><<<pl.grid, pl.threads, LDS, s>>>(Ax, Bx, Dx, Ex, ld_node, Ce, rowptr_dst, \
       src_by_dst, eid_by_dst, N, d, x_tilde, e_hat, r_edge, pl.nb, pl.npi, recs, n_real)
-#define GPS_GG_BWD(GATE)                                                                             \
-  k_gatedgcn_bwd<VEC, GATE><<<pl.grid, pl.threads, stash_bytes, s>>>(g_x, ld_gx, g_e, e_hat, Ax, Bx, ld_node, x_tilde, \
+#define GPS_GG_BWD(GATE, FOLD)                                                                       \
+  k_gatedgcn_bwd<VEC, GATE, FOLD><<<pl.grid, pl.threads, stash_bytes, s>>>(g_x, ld_gx, g_e, e_hat, Ax, Bx, ld_node, x_tilde, \
       rowptr_dst, src_by_dst, eid_by_dst, rowptr_src, dst_by_src, eid_by_src, N, d, g_Ce,             \
-      g_Ax == g_x ? nullptr : g_Ax, g_Bx, g_Dx, g_Ex, ld_gnode, r_edge, pl.nb, pl.npi, cap, amax_node, amax_ce)
+      g_Ax == g_x ? nullptr : g_Ax, g_Bx, g_Dx, g_Ex, ld_gnode, r_edge, pl.nb, pl.npi, cap, amax_node, amax_ce, fx, fe, \
+      gps::dropout_salt())
 
 extern "C" {
 
@@ -758,6 +900,27 @@ static int gatedgcn_fwd_impl(const float* Ax, const float* Bx, const float* Dx, 
   return gps::launch_status("gps_gatedgcn_fwd");
 }
 
+static int fold_of(const char* who, const gps_bn_bwd_fold* f, int64_t rows, BnFold& out) {
+  GPS_REQUIRE(f->bn && f->bn->mean && f->bn->rstd && f->bn->gamma && f->bn->beta && f->sum_g && f->sum_gz,
+              "gps_gatedgcn_bwd_bn: %s: incomplete fold (BatchNorm vectors and both column sums)", who);
+  GPS_REQUIRE(aligned_to(f->bn->mean, 16) && aligned_to(f->bn->rstd, 16) && aligned_to(f->bn->gamma, 16) &&
+              aligned_to(f->bn->beta, 16) && aligned_to(f->sum_g, 16) && aligned_to(f->sum_gz, 16),
+              "gps_gatedgcn_bwd_bn: %s: column vectors must be 16-byte aligned", who);
+  GPS_REQUIRE(f->p >= 0.0f && f->p < 1.0f, "gps_gatedgcn_bwd_bn: %s: dropout p", who);
+  GPS_REQUIRE(f->relu == 1 && rows < INT32_MAX, "gps_gatedgcn_bwd_bn: %s: the fold is BatchNorm -> ReLU -> dropout (relu = 1)", who);
+  out = BnFold{f->bn->mean, f->bn->rstd, f->bn->gamma, f->bn->beta, f->sum_g, f->sum_gz, f->rdev, rows, f->seed, f->p, f->relu};
+  return GPS_OK;
+}
+
+static int gatedgcn_bwd_impl(const float* g_x, int64_t ld_gx, const float* g_e, const float* e_hat, const float* Ax,
+                             const float* Bx, int64_t ld_node, const float* x_tilde,
+                             const int32_t* rowptr_dst, const int32_t* src_by_dst,
+                             const int32_t* eid_by_dst, const int32_t* rowptr_src,
+                             const int32_t* dst_by_src, const int32_t* eid_by_src, int64_t N, int64_t E,
+                             int d, float* g_Ce, float* g_Ax, float* g_Bx, float* g_Dx, float* g_Ex,
+                             int64_t ld_gnode, const float* r_edge, uint32_t* amax_node, uint32_t* amax_ce,
+                             const gps_bn_bwd_fold* fold_x, const gps_bn_bwd_fold* fold_e, gps_stream_t stream);
+
 int gps_gatedgcn_bwd(const float* g_x, int64_t ld_gx, const float* g_e, const float* e_hat, const float* Ax,
                      const float* Bx, int64_t ld_node, const float* x_tilde,
                      const int32_t* rowptr_dst, const int32_t* src_by_dst,
@@ -765,8 +928,40 @@ int gps_gatedgcn_bwd(const float* g_x, int64_t ld_gx, const float* g_e, const fl
                      const int32_t* dst_by_src, const int32_t* eid_by_src, int64_t N, int64_t E,
                      int d, float* g_Ce, float* g_Ax, float* g_Bx, float* g_Dx, float* g_Ex,
                      int64_t ld_gnode, const float* r_edge, uint32_t* amax_node, uint32_t* amax_ce, gps_stream_t stream) {
+  return gatedgcn_bwd_impl(g_x, ld_gx, g_e, e_hat, Ax, Bx, ld_node, x_tilde, rowptr_dst, src_by_dst, eid_by_dst, rowptr_src,
+                           dst_by_src, eid_by_src, N, E, d, g_Ce, g_Ax, g_Bx, g_Dx, g_Ex, ld_gnode, r_edge, amax_node, amax_ce,
+                           nullptr, nullptr, stream);
+}
+
+int gps_gatedgcn_bwd_bn(const float* g_x1, int64_t ld_gx, const float* g_e1, const float* e_hat, const float* Ax,
+                        const float* Bx, int64_t ld_node, const float* x_tilde,
+                        const int32_t* rowptr_dst, const int32_t* src_by_dst,
+                        const int32_t* eid_by_dst, const int32_t* rowptr_src,
+                        const int32_t* dst_by_src, const int32_t* eid_by_src, int64_t N, int64_t E,
+                        int d, float* g_Ce, float* g_Ax, float* g_Bx, float* g_Dx, float* g_Ex,
+                        int64_t ld_gnode, const float* r_edge, uint32_t* amax_node, uint32_t* amax_ce,
+                        const gps_bn_bwd_fold* fold_x, const gps_bn_bwd_fold* fold_e, gps_stream_t stream) {
+  GPS_REQUIRE(!fold_x || g_Ax != g_x1, "gps_gatedgcn_bwd_bn: g_Ax receives the folded gradient and cannot alias g_x1");
+  return gatedgcn_bwd_impl(g_x1, ld_gx, g_e1, e_hat, Ax, Bx, ld_node, x_tilde, rowptr_dst, src_by_dst, eid_by_dst, rowptr_src,
+                           dst_by_src, eid_by_src, N, E, d, g_Ce, g_Ax, g_Bx, g_Dx, g_Ex, ld_gnode, r_edge, amax_node, amax_ce,
+                           fold_x, fold_e, stream);
+}
+
+static int gatedgcn_bwd_impl(const float* g_x, int64_t ld_gx, const float* g_e, const float* e_hat, const float* Ax,
+                             const float* Bx, int64_t ld_node, const float* x_tilde,
+                             const int32_t* rowptr_dst, const int32_t* src_by_dst,
+                             const int32_t* eid_by_dst, const int32_t* rowptr_src,
+                             const int32_t* dst_by_src, const int32_t* eid_by_src, int64_t N, int64_t E,
+                             int d, float* g_Ce, float* g_Ax, float* g_Bx, float* g_Dx, float* g_Ex,
+                             int64_t ld_gnode, const float* r_edge, uint32_t* amax_node, uint32_t* amax_ce,
+                             const gps_bn_bwd_fold* fold_x, const gps_bn_bwd_fold* fold_e, gps_stream_t stream) {
   GPS_REQUIRE(N >= 0 && E >= 0 && d > 0 && ld_node >= d && ld_gnode >= d && ld_gx >= d,
               "gps_gatedgcn_bwd: bad sizes");
+  BnFold fx{}, fe{};
+  const bool fold = fold_x != nullptr || fold_e != nullptr;
+  GPS_REQUIRE(!fold || !r_edge, "gps_gatedgcn_bwd_bn: the folded form is not built with the per-edge gate r_edge");
+  if (fold_x) { if (int rc = fold_of("nodes", fold_x, N, fx)) return rc; }
+  if (fold_e) { if (int rc = fold_of("edges", fold_e, E, fe)) return rc; }
   GPS_REQUIRE((amax_node == nullptr) == (amax_ce == nullptr), "gps_gatedgcn_bwd: both max|.| records or neither");
   if (N == 0) return GPS_OK;
   GPS_REQUIRE(g_x && Ax && Bx && x_tilde && rowptr_dst && rowptr_src && g_Ax && g_Bx && g_Dx && g_Ex,
@@ -786,10 +981,17 @@ int gps_gatedgcn_bwd(const float* g_x, int64_t ld_gx, const float* g_e, const fl
     const Plan pl = plan_for(N, d / VEC, false);
     // LDS stash of phase A's per-edge results for phase B: [2][cap][d] floats next to the 29 KB of index slices
     static const int stash_kb = env_int("GPS_GG_STASH_KB", 112);
-    int cap = (int)(((int64_t)stash_kb * 1024) / (8LL * d));
+    const size_t fold_bytes = fold ? ((size_t)12 * d + 8) * sizeof(float) : 0;     // the folds' column vectors behind the stash
+    int64_t stash_budget = (int64_t)stash_kb * 1024;
+    if (fold && stash_budget + (int64_t)fold_bytes > 131072) stash_budget = 131072 - (int64_t)fold_bytes;   // 29 KB static + 128 KB
+    GPS_REQUIRE(stash_budget >= 0, "gps_gatedgcn_bwd_bn: d=%d too wide for the folded form", d);
+    int cap = (int)(stash_budget / (8LL * d));
     if (cap > GG_MAXE) cap = GG_MAXE;
-    const size_t stash_bytes = (size_t)cap * d * 8;
-    if (r_edge) GPS_GG_BWD(true); else GPS_GG_BWD(false);
+    const size_t stash_bytes = (size_t)cap * d * 8 + fold_bytes;
+    if (fold_x && fold_e) GPS_GG_BWD(false, 3);
+    else if (fold_e) GPS_GG_BWD(false, 2);
+    else if (fold_x) GPS_GG_BWD(false, 1);
+    else { if (r_edge) GPS_GG_BWD(true, 0); else GPS_GG_BWD(false, 0); }
   });
   return gps::launch_status("gps_gatedgcn_bwd");
 }

@@ -50,6 +50,9 @@ _GG_FIRST = _os.environ.get("GPS_GG_FIRST", "0") != "0"
 # GPS_GEMM_PAIR=0: the edge projection C(e) and the merged node projection (forward), and their two input-gradient GEMMs
 # (backward), as two dispatches each instead of one (csrc/gemm_panel.hip k_gemm_ring16_pair) -- A/B
 _GEMM_PAIR = _os.environ.get("GPS_GEMM_PAIR", "1") != "0"
+# GPS_GG_BN_FOLD=0: bn_node_x / bn_edge_e backward applies as task-list launches in front of the GatedGCN backward (A/B)
+# (a mask: 1 = the node fold, 2 = the edge fold, 3 = both)
+_GG_BN_FOLD = int(_os.environ.get("GPS_GG_BN_FOLD", "3"))
 _STACK_PREP = _os.environ.get("GPS_STACK_PREP", "1") != "0"
 
 # Work that is per layer only by accident, hoisted to the layer STACK when a network drives the blocks (network/base.py
@@ -703,7 +706,11 @@ class _GPSBlock(torch.autograd.Function):
                              amax_drop=None if bm is None else bm[0], rdev=rn),
               _norm.bwd_task(eh, g_e1, bne, E, g_bew, g_beb, relu=True, p=p, seed=s[1], g_z=g_eh, rdev=re_)]
         _norm.bwd_partial(b1, d, dev, sync.site(_S_B1))
-        _norm.bwd_apply(b1, d, dev, None)
+        # GPS_GG_BN_FOLD (default): bn_edge_e's apply (g_e^ from g_e1) and bn_node_x's (g_x~ from g_x1) are evaluated by the
+        # GatedGCN backward while it loads those gradients -- it is their only reader and reads e^ / x~ anyway
+        # (gps_gatedgcn_bwd_bn): no g_e^ / g_x~ tensors, the edge task leaves this apply launch, bn_node_x's goes away
+        fold = int(_GG_BN_FOLD) if E >= 1 else 0
+        _norm.bwd_apply(b1[:1] if fold & 2 else b1, d, dev, None)
         # f2 = ff2(t);  t = drop(relu(f1));  f1 = ff1(h)
         bw = (lambda i: None) if bm is None else (lambda i: bm[i])
         if imgs is not None:
@@ -746,7 +753,8 @@ class _GPSBlock(torch.autograd.Function):
             # everything the forked pair needs is made BEFORE the fork, alone on the chip: the 11 us bn_node_x apply ran 33 us
             # beside the attention backward and held the GatedGCN backward back behind it (profiles/r05_timeline_pcqm4m.txt);
             # the out-projection's input gradient stays on the main stream like every GEMM
-            g_xt = bnx_apply()
+            if not fold & 1:
+                g_xt = bnx_apply()
             g_o = (_gemm.gemm_panel(g_ao, imgs[2][1], inner, a_amax=bw(2)) if imgs is not None
                    else g_ao.mm(_W(R.out_proj)))
         with _Fork(dev, "2" if core_fork else _BRANCH) as fork:            # attention half of the backward
@@ -771,14 +779,28 @@ class _GPSBlock(torch.autograd.Function):
                                          p_at, s[2], ptr(delta), G + 4 * fs, ldp, gi.B, int(gi.nmax_host), ptr(bw(3)), sb),
                       "gps_seg_attn_bwd")
 
-        if g_xt is None:
-            g_xt = bnx_apply()
         g_ce = _E(E, d, **f32)
-        check(L.gps_gatedgcn_bwd(ptr(g_xt), d, ptr(g_eh), ptr(eh), P, P + fs, ldp, ptr(xt),
-                                 ptr(gi.rowptr_dst), ptr(gi.src_by_dst), ptr(gi.eid_by_dst),
-                                 ptr(gi.rowptr_src), ptr(gi.dst_by_src), ptr(gi.eid_by_src), N, E, d,
-                                 ptr(g_ce), G, G + fs, G + 2 * fs, G + 3 * fs, ldp, None, ptr(bw(3)), ptr(bw(4)), st),
-              "gps_gatedgcn_bwd")
+        if fold:
+            fx = fe = None
+            if fold & 1:
+                fx = _BY_REF(_lib.BnBwdFold(_ctypes.addressof(bnx), g_bxb.data_ptr(), g_bxw.data_ptr(), p, s[0], 1, ptr(rn)))
+            elif g_xt is None:
+                g_xt = bnx_apply()
+            if fold & 2:
+                fe = _BY_REF(_lib.BnBwdFold(_ctypes.addressof(bne), g_beb.data_ptr(), g_bew.data_ptr(), p, s[1], 1, ptr(re_)))
+            check(L.gps_gatedgcn_bwd_bn(ptr(g_x1 if fold & 1 else g_xt), d, ptr(g_e1 if fold & 2 else g_eh), ptr(eh), P, P + fs,
+                                        ldp, ptr(xt), ptr(gi.rowptr_dst), ptr(gi.src_by_dst), ptr(gi.eid_by_dst),
+                                        ptr(gi.rowptr_src), ptr(gi.dst_by_src), ptr(gi.eid_by_src), N, E, d,
+                                        ptr(g_ce), G, G + fs, G + 2 * fs, G + 3 * fs, ldp, None, ptr(bw(3)), ptr(bw(4)),
+                                        fx, fe, st), "gps_gatedgcn_bwd_bn")
+        else:
+            if g_xt is None:
+                g_xt = bnx_apply()
+            check(L.gps_gatedgcn_bwd(ptr(g_xt), d, ptr(g_eh), ptr(eh), P, P + fs, ldp, ptr(xt),
+                                     ptr(gi.rowptr_dst), ptr(gi.src_by_dst), ptr(gi.eid_by_dst),
+                                     ptr(gi.rowptr_src), ptr(gi.dst_by_src), ptr(gi.eid_by_src), N, E, d,
+                                     ptr(g_ce), G, G + fs, G + 2 * fs, G + 3 * fs, ldp, None, ptr(bw(3)), ptr(bw(4)), st),
+                  "gps_gatedgcn_bwd")
         fork.join()
         wcat, bcat = layer._xgroup._stacked()
         pairs = [(g_pq, x), (g_ce, e), (g_ao, o), (g_f1, h), (g_f2, t)]

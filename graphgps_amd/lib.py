@@ -36,6 +36,8 @@ _SIGNATURES = {
                                        _P, _P, _P, _P, _P, _P, c_size_t, _P, _P]),
     "gps_gatedgcn_bwd": (c_int, [_P, c_int64, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P,
                                  c_int64, c_int64, c_int, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P]),
+    "gps_gatedgcn_bwd_bn": (c_int, [_P, c_int64, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, _P, _P,
+                                 c_int64, c_int64, c_int, _P, _P, _P, _P, _P, c_int64, _P, _P, _P, _P, _P, _P]),
     "gps_gine_fwd": (c_int, [_P, _P, _P, _P, _P, c_int64, c_int64, c_int, c_float, _P, _P, _P]),
     "gps_gine_bwd": (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, c_int64, c_int64, c_int, c_float, _P,
                              _P, _P, _P]),
@@ -139,6 +141,12 @@ class WgradProblem(ctypes.Structure):
     _fields_ = [("g", c_void_p), ("x", c_void_p), ("gw", c_void_p), ("gb", c_void_p),
                 ("ldg", c_int64), ("ldx", c_int64), ("R", c_int64), ("M", ctypes.c_int32),
                 ("Nn", ctypes.c_int32), ("g_amax", c_void_p), ("x_amax", c_void_p)]
+
+
+class BnBwdFold(ctypes.Structure):
+    """``gps_bn_bwd_fold`` (include/gps_hip.h)."""
+    _fields_ = [("bn", c_void_p), ("sum_g", c_void_p), ("sum_gz", c_void_p), ("p", c_float), ("seed", c_uint64),
+                ("relu", ctypes.c_int32), ("rdev", c_void_p)]
 
 
 class Gemm16Problem(ctypes.Structure):

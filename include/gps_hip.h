@@ -137,6 +137,35 @@ int gps_gatedgcn_bwd(const float* g_x, int64_t ld_gx, const float* g_e, const fl
                      int d, float* g_Ce, float* g_Ax, float* g_Bx, float* g_Dx, float* g_Ex,
                      int64_t ld_gnode, const float* r_edge, uint32_t* amax_node, uint32_t* amax_ce, gps_stream_t stream);
 
+/* ABI v9: the same backward with the two BatchNorm backward applies in front of it folded into its loads.  In
+ * GatedGCNLayer (gatedgcn_layer.py:72-83) x~ and e^ each feed ONE BatchNorm1d -> ReLU -> dropout -> residual:
+ *   x_out = x_in + dropout(relu(bn_node_x(x~))),   e_out = e_in + dropout(relu(bn_edge_e(e^)))
+ * so the gradients this kernel consumes, g_x~ and g_e^, are the outputs of two BatchNorm backward applies that nothing
+ * else reads, over tensors (x~, e^) the kernel reads anyway.  gps_gatedgcn_bwd_bn takes g_x1 / g_e1 -- the gradients of
+ * the two residual sums -- and evaluates, per loaded element,
+ *   g = relu' / dropout mask (row, col; p, seed) * g_y;  zhat = (z - mean) rstd;  gate * gamma rstd (g - S1/n - zhat S2/n)
+ * exactly as gps_norm_bwd_apply does (same association; gate = 0 on padding rows past *rdev, n = the real rows), from six
+ * column vectors per fold: the BatchNorm's mean / rstd / gamma / beta and its column sums S1 = sum g, S2 = sum g zhat
+ * (gps_norm_bwd_partial, or the chain of a gps_norm_bwd_apply task).  Everything else as gps_gatedgcn_bwd; g_Ax receives
+ * the folded g_x~ and may not alias g_x1. */
+typedef struct gps_bn_bwd_fold {
+  const gps_bn* bn;        /* mean, rstd (batch statistics of the forward), gamma, beta */
+  const float* sum_g;      /* [d] S1 */
+  const float* sum_gz;     /* [d] S2 */
+  float p;                 /* dropout on the BatchNorm -> ReLU output (0 = none) */
+  uint64_t seed;
+  int32_t relu;
+  const int32_t* rdev;     /* padded batches: device word with the number of real rows, or NULL */
+} gps_bn_bwd_fold;
+int gps_gatedgcn_bwd_bn(const float* g_x1, int64_t ld_gx, const float* g_e1, const float* e_hat, const float* Ax,
+                        const float* Bx, int64_t ld_node, const float* x_tilde,
+                        const int32_t* rowptr_dst, const int32_t* src_by_dst,
+                        const int32_t* eid_by_dst, const int32_t* rowptr_src,
+                        const int32_t* dst_by_src, const int32_t* eid_by_src, int64_t N, int64_t E,
+                        int d, float* g_Ce, float* g_Ax, float* g_Bx, float* g_Dx, float* g_Ex,
+                        int64_t ld_gnode, const float* r_edge, uint32_t* amax_node, uint32_t* amax_ce,
+                        const gps_bn_bwd_fold* fold_x, const gps_bn_bwd_fold* fold_e, gps_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * GINE sparse core.  Replaces PyG GINEConv's gather + relu + scatter-add + (1+eps)*x
  * (constructed graphgps/layer/gps_layer.py:62-69, called :183-185):

@@ -372,6 +372,51 @@ def test_fused_block_with_dropout_on_vs_masked_oracle(local, d, H, profile, nb, 
           f"(cpu-fp32 masked oracle: max {c_err:.2e})")
 
 
+@pytest.mark.parametrize("d,H,profile,nb,p", [(384, 16, "P30", 256, 0.1), (384, 16, "P14", 64, 0.0), (64, 4, "ZINC", 32, 0.25),
+                                              (256, 4, "CODE2_REAL", 8, 0.2)])
+def test_gatedgcn_backward_bn_fold_matches_the_apply_launches(d, H, profile, nb, p, monkeypatch):
+    """gps_gatedgcn_bwd_bn (round 6: the bn_node_x / bn_edge_e backward applies evaluated inside the GatedGCN backward's
+    loads, csrc/gatedgcn.hip FOLD) against the launches it replaces (gps_norm_bwd_apply tasks + gps_gatedgcn_bwd): the same
+    layer, the same dropout seeds, every gradient to 2e-6 of its largest element (the arithmetic per element is the same
+    expression; only fp32 contraction may differ between the two kernels).  Reference: gatedgcn_layer.py:72-83."""
+    from graphgps_amd.layer import gps_block
+    from graphgps_amd.layer.gps_layer import GPSLayer
+    from graphgps_amd.synthetic import layer_batch
+    dev = torch.device("cuda:0")
+    torch.manual_seed(3)
+    layer = GPSLayer(d, "CustomGatedGCN", "Transformer", H, dropout=p, attn_dropout=0.0).to(dev).train()
+    b = layer_batch(profile, nb, d, seed=17)
+    gen = torch.Generator().manual_seed(8)
+    wx = torch.randn(b.x.shape, generator=gen).to(dev)
+    we = torch.randn(b.edge_attr.shape, generator=gen).to(dev)
+    res = {}
+    for fold in (3, 2, 1, 0):
+        monkeypatch.setattr(gps_block, "_GG_BN_FOLD", fold)
+        monkeypatch.setattr(gps_block, "draw_dropout_seed", lambda: 0x0F1E2D3C4B5A6978)
+        layer.zero_grad(set_to_none=True)
+        bg = b.clone().to(dev)
+        bg.x.requires_grad_(True); bg.edge_attr.requires_grad_(True)
+        xg, eg = bg.x, bg.edge_attr
+        assert gps_block.block_supported(layer, bg.x, bg.edge_attr)
+        og = layer(bg)
+        ((og.x * wx).sum() + (og.edge_attr * we).sum()).backward()
+        res[fold] = dict(x=xg.grad.clone(), e=eg.grad.clone(), **{k: q.grad.clone() for k, q in layer.named_parameters()
+                                                                  if q.grad is not None})
+    worst = 0.0
+    # (the bias gradients of A / B / D / E are column sums of a BatchNorm backward output -- zero in exact arithmetic, pure
+    # rounding in fp32: every tensor is graded on a scale no smaller than 1e-3 of the largest gradient of the layer)
+    floor = 1e-3 * max(float(g.abs().max()) for g in res[0].values())
+    for k, ref in res[0].items():
+        scale = max(float(ref.abs().max()), floor)
+        if k.endswith(".bias") and k[:-4] + "weight" in res[0]:     # ... and a bias on the scale of its weight's gradient
+            scale = max(scale, float(res[0][k[:-4] + "weight"].abs().max()))
+        for fold in (3, 2, 1):
+            err = float((res[fold][k] - ref).abs().max()) / scale
+            worst = max(worst, err)
+            assert err <= 2e-6, f"{k}: folded ({fold}) vs launched BatchNorm backward differ by {err:.2e} of max|grad|"
+    print(f"BN-backward fold in gps_gatedgcn_bwd_bn, {profile} d={d} p={p}: worst relative difference {worst:.2e}")
+
+
 @pytest.mark.parametrize("d,H,profile,nb,p,p_attn,n_layers", [
     (256, 4, "CODE2_REAL", 32, 0.2, 0.5, 1),      # ogbg-code2-GPS.yaml: d = 256, 4 x 64-wide heads, dropout 0.2 / 0.5
     (256, 4, "CODE2_REAL", 16, 0.2, 0.5, 2),
