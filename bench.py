@@ -315,7 +315,7 @@ def eager_after_capture_probe(ts, make_batch, dev, n=20):
         ts.replay()
     torch.cuda.synchronize(dev)
     out["capture_alive_after_replays"] = leg("again, right after 3 replays")
-    ts._g_fb = ts._g_up = ts._static_loss = ts._tick = None
+    ts._g_fb = ts._g_fb2 = ts._g_up = ts._static_loss = ts._tick = None
     ts.mode = "eager"
     gc.collect()
     torch.cuda.synchronize(dev)
@@ -911,7 +911,12 @@ def main():
             exchange = FlatGradExchange(opt.arena, force_collective=True)
         launch = "eager" if args.no_graph else args.launch
         salt = None if launch == "eager" else enable_dropout_salt(dev)
-        ts = TrainStep(model, opt, loss_fn=compute_loss, exchange=exchange, salt=salt)
+        # N > 1: the backward is cut in the middle of the layer stack, the gradients of the upper half travel while the
+        # lower half is differentiated (train.TrainStep backward_split)
+        layers = getattr(model, "layers", None)
+        cut_at = layers[len(layers) // 2 - 1] if (exchange is not None and layers is not None and len(layers) >= 2
+                                                   and os.environ.get("GPS_DP_SPLIT", "1") != "0") else None
+        ts = TrainStep(model, opt, loss_fn=compute_loss, exchange=exchange, salt=salt, backward_split=cut_at)
 
         def step():
             if ts.use_replay and ts.mode != "eager":
@@ -976,7 +981,7 @@ def main():
                     json.dump({"segments": segs, "maps": maps}, open(os.environ["GPS_BENCH_SNAPSHOT"], "w"))
             except Exception as exc:         # capture is an optimisation, never a requirement
                 log(f"hipGraph capture failed ({type(exc).__name__}: {exc}); running eagerly")
-                ts = TrainStep(model, opt, loss_fn=compute_loss, exchange=exchange, salt=salt)
+                ts = TrainStep(model, opt, loss_fn=compute_loss, exchange=exchange, salt=salt, backward_split=cut_at)
                 launch = "eager"
             if world > 1:                    # one rank falling back must take every rank with it
                 ok = torch.tensor([0.0 if launch == "eager" else 1.0], device=dev)

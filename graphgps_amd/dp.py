@@ -183,15 +183,18 @@ class GradBucketReducer:
 
 
 class FlatGradExchange:
-    """The data-parallel exchange on a flat gradient arena (optim.ParamArena): ONE averaging
-    all-reduce of the whole gradient (77.7 MB for GPS-medium) per step.
+    """The data-parallel exchange on a flat gradient arena (optim.ParamArena): averaging all-reduces of ``arena.flat_g``,
+    issued OUTSIDE autograd so that the compute either side of them replays from hipGraphs (the
+    reference has no distributed code -- graphgps/train/custom_train.py:16-47 is the single-process step this wraps).
 
-    Why one unbucketed collective: on 8 MI355X a 78 MB all-reduce over xGMI costs ~0.5 ms against
-    a ~16 ms step, so overlapping it with backward buys < 3 %, while keeping every collective
-    OUT of autograd hooks lets the compute on either side of it (forward + backward + pack |
-    clip + AdamW) be replayed from two hipGraphs -- host work per step is then two graph launches
-    and one RCCL call, which matters more than the overlap when 8 ranks share the host's cores.
-    ``GradBucketReducer`` (above) remains the hook-driven, overlapped variant for eager steps."""
+    Two forms, both driven by ``train.TrainStep``:
+      * ``all_reduce()``: ONE collective over the whole arena (77.7 MB for GPS-medium) between [fwd + bwd + pack] and
+        [clip + AdamW];
+      * ``start(lo, hi)`` / ``finish(handles)``: the arena in RANGES, each started as soon as its half of the backward has
+        produced it (``TrainStep(backward_split=...)``: the upper layers' range is in flight -- on the process group's own
+        stream for RCCL -- while the lower layers are still being differentiated; only the last range is exposed).
+    Arithmetic of the exposed time at N = 8 for the 8.3 ms PCQM4M step: DESIGN.md section 6.
+    ``GradBucketReducer`` (above) remains the hook-driven variant for eager steps of arbitrary models."""
 
     def __init__(self, arena, process_group=None, force_collective: bool = False):
         self.arena = arena
@@ -209,10 +212,25 @@ class FlatGradExchange:
         """Average ``arena.flat_g`` over the ranks, in place, on the current stream."""
         if not self.active:
             return
-        flat = self.arena.flat_g
-        if self.native_avg:
-            dist.all_reduce(flat, op=dist.ReduceOp.AVG, group=self.group)
-        else:
-            dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
-            if self.world > 1:
+        self.finish([self.start(0, None)])
+
+    def start(self, lo: int = 0, hi: Optional[int] = None):
+        """Begin averaging ``arena.flat_g[lo:hi]`` (element offsets) over the ranks; returns a handle for ``finish``.
+        The collective is ordered behind the work already enqueued on the current stream and does not block it."""
+        if not self.active:
+            return None
+        flat = self.arena.flat_g[lo:hi]
+        if flat.numel() == 0:
+            return None
+        op = dist.ReduceOp.AVG if self.native_avg else dist.ReduceOp.SUM
+        return (dist.all_reduce(flat, op=op, group=self.group, async_op=True), flat)
+
+    def finish(self, handles) -> None:
+        """The current stream waits for the started ranges (and scales them where the backend has no averaging op)."""
+        for h in handles:
+            if h is None:
+                continue
+            work, flat = h
+            work.wait()
+            if not self.native_avg and self.world > 1:
                 flat.mul_(1.0 / self.world)

@@ -212,6 +212,28 @@ class ParamArena:
                 p.grad = v
 
 
+    def pack_range(self, i0: int, i1: Optional[int] = None) -> None:
+        """``pack_grads`` for the parameters ``i0 .. i1-1`` only, leaving the active flags alone: what a backward split in
+        two (train.TrainStep ``backward_split``) runs after its first half, so that the gradients of the upper half of the
+        network sit in ``flat_g`` -- ready for their all-reduce -- while the lower half is still being differentiated.
+        The full ``pack_grads`` at the end of the backward finds these parameters already adopted."""
+        from .fused import join_side_stream
+        if self.device.type == "cuda":
+            join_side_stream(self.device)
+        i1 = len(self.params) if i1 is None else i1
+        dst, src = [], []
+        for p, v in zip(self.params[i0:i1], self.grad_views[i0:i1]):
+            g = p.grad
+            if g is not None and g.data_ptr() != v.data_ptr():
+                dst.append(v)
+                src.append(g)
+        if dst:
+            torch._foreach_copy_(dst, src)
+        for p, v in zip(self.params[i0:i1], self.grad_views[i0:i1]):
+            if p.grad is not None:
+                p.grad = v
+
+
 class FlatAdamW(torch.optim.Optimizer):
     """AdamW (+ optional ``clip_grad_norm_``) over a :class:`ParamArena`, two HIP launches."""
 
@@ -281,6 +303,15 @@ class FlatAdamW(torch.optim.Optimizer):
             self._readopt()
         self.arena.pack_grads()
         self._packed = True
+
+    def pack_range(self, i0: int, i1: Optional[int] = None) -> bool:
+        """``arena.pack_range`` (the gradients of parameters ``i0 .. i1-1`` into ``flat_g``, mid-backward) when the arena
+        is intact; False -- nothing packed, the caller must not let that range travel early -- when parameters have moved
+        (the full ``pack_grads`` at the end of the backward re-adopts them)."""
+        if not self.arena.intact():
+            return False
+        self.arena.pack_range(i0, i1)
+        return True
 
     @torch.no_grad()
     def step(self, closure=None):

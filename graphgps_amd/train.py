@@ -40,6 +40,72 @@ def _has_dropout(model) -> bool:
     return False
 
 
+class _BackwardCut:
+    """Splits the step's backward in two at the OUTPUT of one module of the layer stack (the exchange
+    of the upper layers' gradients overlaps the backward of the lower layers).  A forward hook swaps the graph-attached
+    ``x`` / ``edge_attr`` the module returns for detached leaves (no copy); ``loss.backward()`` then stops at those
+    leaves -- every parameter used after the cut has its gradient, nothing before it has been touched -- and
+    ``resume()`` feeds the leaves' gradients back into the tensors they replaced."""
+
+    def __init__(self, module: torch.nn.Module):
+        self.on = False
+        self.pairs = []
+        self.handle = module.register_forward_hook(self._hook)
+
+    def _hook(self, module, args, out):
+        if not self.on or not torch.is_grad_enabled():
+            return None
+        self.pairs = []
+        for k in ("x", "edge_attr"):
+            v = getattr(out, k, None)
+            if torch.is_tensor(v) and v.grad_fn is not None:
+                leaf = v.detach().requires_grad_()
+                setattr(out, k, leaf)
+                self.pairs.append((v, leaf))
+        return out
+
+    def resume(self) -> None:
+        live = [(v, leaf.grad) for v, leaf in self.pairs if leaf.grad is not None]
+        self.pairs = []
+        if live:
+            torch.autograd.backward([v for v, _ in live], [g for _, g in live])
+
+
+class _Capture:
+    """One hipGraph capture with the forked tick node every capture of a step carries (see ``TrainStep.capture``: a
+    linear chain of several hundred kernel nodes on ONE stream faults at replay on this stack; one trivial forked node
+    avoids it).  ``begin`` / ``end`` instead of a ``with`` block: a split backward ends one capture and begins the next
+    in the middle of ``forward_backward``."""
+
+    def __init__(self, graph, dev, pool=None, mode="thread_local"):
+        self.graph, self.dev = graph, dev
+        kw = dict(capture_error_mode=mode)
+        if pool is not None:
+            kw["pool"] = pool
+        self.cm = torch.cuda.graph(graph, **kw)
+        self.tick = torch.zeros(1, device=dev) if _os.environ.get("GPS_CAPTURE_TICK", "1") != "0" else None
+        self.open = False
+
+    def begin(self):
+        self.cm.__enter__()
+        self.open = True
+        if self.tick is not None:
+            cur = torch.cuda.current_stream(self.dev)
+            self.tside = torch.cuda.Stream(device=self.dev)
+            self.tside.wait_stream(cur)
+            with torch.cuda.stream(self.tside):
+                self.tick.add_(1.0)
+        return self
+
+    def end(self, exc=(None, None, None)):
+        if not self.open:
+            return
+        self.open = False
+        if self.tick is not None and exc[0] is None:
+            torch.cuda.current_stream(self.dev).wait_stream(self.tside)
+        self.cm.__exit__(*exc)
+
+
 class TrainStep:
     """forward + loss + backward + gradient pack | [all-reduce] | clip + AdamW.
 
@@ -48,7 +114,7 @@ class TrainStep:
     new dropout masks."""
 
     def __init__(self, model: torch.nn.Module, optimizer,
-                 loss_fn: Optional[Callable] = None, exchange=None, salt=None):
+                 loss_fn: Optional[Callable] = None, exchange=None, salt=None, backward_split=None):
         # optim.FlatAdamW (register_optimizer('adamW'), what every configs/GPS/*.yaml names) is the fused
         # two-launch path; any other torch optimizer (GraphGym's 'adam' / 'sgd', the reference's 'adagrad')
         # takes the reference's own clip_grad_norm_ + optimizer.step() (custom_train.py:33-37), eagerly.
@@ -59,25 +125,61 @@ class TrainStep:
         self.loss_fn = loss_fn or train_loss
         self.exchange = exchange
         self.salt = salt
-        self._g_fb = self._g_up = None
+        self._g_fb = self._g_fb2 = self._g_up = None
         self._static_loss = None
         self._tick = None
+        # ``backward_split``: a module of the layer stack (e.g. ``model.layers[4]`` of ten).  With an active exchange the
+        # backward then runs in two halves around its output and the gradient arena travels in two ranges: the range of
+        # everything AFTER the cut (a suffix of the arena: parameters are adopted in registration = execution order) is
+        # all-reduced while the half BEFORE the cut is still being differentiated.  Replayed: three graphs,
+        # [fwd + upper bwd] | [lower bwd + pack] | [clip + AdamW], the two collectives started between them.
+        self._cut = None
+        self._cut_index = self._cut_off = 0
+        if backward_split is not None and self.flat and exchange is not None and exchange.active:
+            self._cut = _BackwardCut(backward_split)
+            ids = {id(q): i for i, q in enumerate(optimizer.arena.params)}
+            last = max((ids[id(q)] for q in backward_split.parameters() if id(q) in ids), default=-1)
+            if last < 0 or last + 1 >= len(optimizer.arena.params):
+                self._cut = None                 # nothing on one side of the cut: one range, one collective
+            else:
+                self._cut_index = last + 1
         self.use_replay = True           # once captured: replay (True) or keep launching eagerly
         self.mode = "eager"
 
     # -- the three pieces ------------------------------------------------------------------
-    def forward_backward(self, batch, zero: bool = True):
-        """Returns (loss, pred_score, true); gradients are packed in the arena afterwards."""
+    def forward_backward(self, batch, zero: bool = True, between: Optional[Callable[[], None]] = None):
+        """Returns (loss, pred_score, true); gradients are packed in the arena afterwards.
+        ``between`` (split backward only): called between the two halves of the backward, when the gradients of
+        everything after the cut sit in their arena range (``_cut_range()[0]``)."""
         if self.salt is not None:
             self.salt.add_(1)
         if zero:
             self.opt.zero_grad()
-        pred, true = self.model(batch)
+        cut = self._cut
+        if cut is not None:
+            cut.on = True
+        try:
+            pred, true = self.model(batch)
+        finally:
+            if cut is not None:
+                cut.on = False
         b_real = _real_graphs_of(batch)
         if b_real is not None:               # a padded batch (loader.BucketPadding): the dead graphs' rows never reach the
             pred, true = _head_rows(pred, b_real), _head_rows(true, b_real)     # loss, the logger or the caller
         loss, pred_score = self.loss_fn(pred, true)
         loss.backward()
+        if cut is not None and cut.pairs:
+            params = self.opt.arena.params
+            if any(q.grad is not None for q in params[:self._cut_index]):
+                # a parameter registered before the cut is also used after it (tied weights, a head reading an encoder
+                # table): its gradient is not complete yet and neither range may travel early -- one collective from now on
+                self._cut.handle.remove()
+                self._cut = None
+                cut.resume()
+            else:
+                if self.opt.pack_range(self._cut_index) and between is not None:
+                    between()
+                cut.resume()
         if self.flat:
             self.opt.pack_grads()
         # Nothing that leaves this function may keep the step's autograd graph alive.  The model re-assigns ``batch.x`` /
@@ -99,6 +201,12 @@ class TrainStep:
         if self.exchange is not None:
             self.exchange.all_reduce()
 
+    def _cut_range(self):
+        """Element ranges of the gradient arena (after the cut, before the cut)."""
+        a = self.opt.arena
+        off = int(a.offsets[self._cut_index])
+        return (off, None), (0, off)
+
     def update(self) -> None:
         if not self.flat and cfg.optim.clip_grad_norm:
             torch.nn.utils.clip_grad_norm_(self.model.parameters(), cfg.optim.clip_grad_norm_value)
@@ -110,10 +218,7 @@ class TrainStep:
         return self.run_eager(batch)
 
     def run_eager(self, batch):
-        loss, _, _ = self.forward_backward(batch)
-        self.reduce()
-        self.update()
-        return loss
+        return self._eager_triplet(batch)[0]
 
     # -- hipGraph replay for a fixed-shape batch ---------------------------------------------
     def capture(self, make_batch: Callable[[], object], warmup: int = 3) -> None:
@@ -143,46 +248,59 @@ class TrainStep:
         self.opt.zero_grad()
         self.opt.sync_hyper()
         split = self.exchange is not None and self.exchange.active
-        g_fb = torch.cuda.CUDAGraph()
         # A capture that stays on ONE stream -- a linear chain of ~600 kernel nodes -- dies at replay with "Write access to
         # a read-only page" on this stack (ROCm 7.0.2 runtime under torch 2.10; PCQM4M step without the forked attention
         # branch, code2 step without the weight-gradient stream), while the same kernels captured with any second branch
         # joined in replay fine.  One trivial forked node (a 4-byte add on a second stream, joined at the end) is enough
-        # to avoid it and costs nothing, so every capture gets one.  GPS_CAPTURE_TICK=0 removes it (to reproduce).
-        # The tick tensor is written by EVERY replay, so it must live exactly as long as the graphs do (a local would
-        # hand its block back to the caching allocator and each replay would then add 1.0f into whoever got it next).
+        # to avoid it and costs nothing, so every capture gets one (``_Capture``).  GPS_CAPTURE_TICK=0 removes it.
+        # The tick tensor is written by EVERY replay, so it lives exactly as long as the graphs do.
         # (Measured and dropped, round 3: two / three instances of the captured step replayed alternately, to hide the
-        # ~1 ms host side of hipGraphLaunch behind the previous replay -- 10.54 vs 10.55 ms, and the ~0.3 ms of idle gaps
-        # at the head of every replayed step, two of them 85-100 us in front of the edge encoder's scatter_ / cat nodes,
-        # stay where they are: they are not the host's enqueue pace.  tools/runs/gpu_r4b.sh.)
-        tick = torch.zeros(1, device=dev) if _os.environ.get("GPS_CAPTURE_TICK", "1") != "0" else None
-        with STAGE_LOCK, torch.cuda.graph(g_fb, capture_error_mode=_os.environ.get("GPS_CAPTURE_MODE", "thread_local")):
-            if tick is not None:
-                cur = torch.cuda.current_stream(dev)
-                tside = torch.cuda.Stream(device=dev)
-                tside.wait_stream(cur)
-                with torch.cuda.stream(tside):
-                    tick.add_(1.0)
-            loss, _, _ = self.forward_backward(make_batch())
-            if not split:
-                self.update()
-            if tick is not None:
-                torch.cuda.current_stream(dev).wait_stream(tside)
+        # ~1 ms host side of hipGraphLaunch behind the previous replay -- 10.54 vs 10.55 ms.  tools/runs/gpu_r4b.sh.)
+        mode = _os.environ.get("GPS_CAPTURE_MODE", "thread_local")
+        g_fb, g_fb2 = torch.cuda.CUDAGraph(), None
+        caps = [_Capture(g_fb, dev, mode=mode)]
+
+        def switch():                        # between the halves of a split backward: the first graph ends, the second
+            nonlocal g_fb2                   # begins in the same memory pool (it reads what the first one saved)
+            caps[-1].end()
+            g_fb2 = torch.cuda.CUDAGraph()
+            caps.append(_Capture(g_fb2, dev, pool=g_fb.pool(), mode=mode).begin())
+
+        with STAGE_LOCK:
+            caps[0].begin()
+            try:
+                loss, _, _ = self.forward_backward(make_batch(), between=switch if self._cut is not None else None)
+                if not split:
+                    self.update()
+            except BaseException:
+                import sys
+                caps[-1].end(sys.exc_info())
+                raise
+            caps[-1].end()
         g_up = None
         if split:
             g_up = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g_up, capture_error_mode="thread_local"):
                 self.update()
         torch.cuda.synchronize(dev)
-        self._g_fb, self._g_up, self._static_loss = g_fb, g_up, loss
-        self._tick = tick
-        self.mode = ("hipGraph replay: [fwd+bwd+pack] -> RCCL all-reduce -> [clip+AdamW]" if split
+        self._g_fb, self._g_fb2, self._g_up, self._static_loss = g_fb, g_fb2, g_up, loss
+        self._tick = [c.tick for c in caps]
+        self.mode = ("hipGraph replay: [fwd + upper bwd] -> all-reduce(upper) || [lower bwd + pack] -> all-reduce(lower) -> "
+                     "[clip+AdamW]" if g_fb2 is not None else
+                     "hipGraph replay: [fwd+bwd+pack] -> RCCL all-reduce -> [clip+AdamW]" if split
                      else "hipGraph replay of the whole step")
 
     def replay(self):
         self.opt.sync_hyper()                # LR schedulers write param_groups[0]['lr']
         self._g_fb.replay()
-        if self._g_up is not None:
+        if self._g_fb2 is not None:          # the upper range is in flight while the lower half of the backward replays
+            upper, lower = self._cut_range()
+            h = [self.exchange.start(*upper)]
+            self._g_fb2.replay()
+            h.append(self.exchange.start(*lower))
+            self.exchange.finish(h)
+            self._g_up.replay()
+        elif self._g_up is not None:
             self.exchange.all_reduce()
             self._g_up.replay()
         return self._static_loss
@@ -249,6 +367,17 @@ class TrainStep:
         return loss.clone(), _rebuilt(pred, ent["sources"], batch, ("pred",)), _rebuilt(true, ent["sources"], batch, ("true",))
 
     def _eager_triplet(self, batch):
+        if self._cut is not None:            # the upper range travels while the lower half of the backward runs
+            handles = []
+            upper, lower = self._cut_range()
+            out = self.forward_backward(batch, between=lambda: handles.append(self.exchange.start(*upper)))
+            if handles:
+                handles.append(self.exchange.start(*lower))
+                self.exchange.finish(handles)
+            else:                            # (the cut was dropped in this very step: see forward_backward)
+                self.reduce()
+            self.update()
+            return out
         loss, pred_score, true = self.forward_backward(batch)
         self.reduce()
         self.update()

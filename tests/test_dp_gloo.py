@@ -190,7 +190,7 @@ def _cpu_flat_adamw():
     return CpuFlatAdamW
 
 
-def _trainstep_worker(rank, world, port, q):
+def _trainstep_worker(rank, world, port, q, split=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank),
                       WORLD_SIZE=str(world))
     torch.set_num_threads(2)
@@ -204,7 +204,19 @@ def _trainstep_worker(rank, world, port, q):
         opt = _cpu_flat_adamw()(model.parameters(), lr=1e-3, weight_decay=1e-5, max_grad_norm=1.0)
         ex = FlatGradExchange(opt.arena)
         assert ex.active and ex.num_bytes == opt.arena.num_bytes
-        ts = TrainStep(model, opt, loss_fn=compute_loss, exchange=ex)
+        ts = TrainStep(model, opt, loss_fn=compute_loss, exchange=ex, backward_split=model.layers[0] if split else None)
+        if split:
+            # the cut sits behind layers.0: its range is a proper suffix of the arena, and the two collectives really are
+            # started at different points of the backward (the upper one while layers.0 / the encoders have no gradient yet)
+            started = []
+            real_start = ex.start
+
+            def spy(lo=0, hi=None):
+                lower_done = all(p.grad is not None for p in model.layers[0].parameters())
+                started.append((lo, hi, lower_done))
+                return real_start(lo, hi)
+            ex.start = spy
+            assert ts._cut is not None and 0 < ts._cut_index < len(opt.arena.params)
         losses = [float(ts(model_batch("zinc", 8, seed=1234 + 10 * step + rank))) for step in range(3)]
         # single-process reference: torch.optim.AdamW + clip_grad_norm_ fed the rank-mean gradient
         ref = _make_oracle_model()
@@ -238,9 +250,36 @@ def _trainstep_worker(rank, world, port, q):
         flat = opt.arena.flat_p.detach().clone()
         both = [torch.zeros_like(flat) for _ in range(world)]
         dist.all_gather(both, flat)
+        if split:
+            off = int(opt.arena.offsets[ts._cut_index])
+            assert ts._cut is not None, "the cut must survive: no parameter of this model is used on both sides of it"
+            assert len(started) == 6 and started[0::2] == [(off, None, False)] * 3 and started[1::2] == [(0, off, True)] * 3, started
         q.put((rank, worst, bool(torch.equal(both[0], both[1])), losses))
     finally:
         dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_trainstep_split_backward_overlapped_exchange_world2_gloo():
+    """The exchange SURVEY.md section 8e specifies, in the form the replayed step uses it: the backward cut behind
+    ``layers.0`` (TrainStep ``backward_split``), the gradient arena all-reduced as two ranges -- the upper layers' range
+    started between the two halves of the backward, before ``layers.0`` and the encoders have any gradient -- and the
+    same end state as the single-collective step: ranks bit-identical, weights equal to a single-process AdamW run on the
+    rank-mean gradient."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_trainstep_worker, args=(r, world, port, q, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, worst, same, losses in results:
+        assert same, "ranks diverged"
+        assert worst < 2e-6, (rank, worst)
+        assert all(l == l for l in losses)
 
 
 @pytest.mark.timeout(300)

@@ -409,23 +409,27 @@ def test_train_step_two_graphs_around_rccl_allreduce_world1():
     try:
         b = model_batch("zinc", 16, seed=7).to(dev)
         runs = []
-        for split in (False, True):
+        # split 2 (round 6): the backward cut in the middle of the layer stack, THREE graphs -- [fwd + upper bwd] |
+        # [lower bwd + pack] | [clip + AdamW] -- with the all-reduce of the upper layers' arena range started between the
+        # first two (train.TrainStep backward_split; dp.FlatGradExchange.start / finish)
+        for split in (0, 1, 2):
             model = _zinc_model(dev)
             opt = FlatAdamW(model.parameters(), lr=1e-3, weight_decay=0.0, max_grad_norm=1.0)
             ex = FlatGradExchange(opt.arena, force_collective=True) if split else None
-            ts = TrainStep(model, opt, loss_fn=compute_loss, exchange=ex)
+            cut = model.layers[len(model.layers) // 2 - 1] if split == 2 else None
+            ts = TrainStep(model, opt, loss_fn=compute_loss, exchange=ex, backward_split=cut)
             if split:
                 assert ex.active and ex.num_bytes == opt.arena.num_bytes
                 snap = {k: v.detach().clone() for k, v in model.state_dict().items()}
                 ts.capture(b.clone, warmup=2)
-                assert "RCCL all-reduce" in ts.mode
+                assert ("all-reduce(upper)" in ts.mode and ts._g_fb2 is not None) if split == 2 else "RCCL all-reduce" in ts.mode
                 with torch.no_grad():
                     for k, v in model.state_dict().items():
                         v.copy_(snap[k])
                     opt.exp_avg.zero_(), opt.exp_avg_sq.zero_(), opt.hyper[6].zero_(), opt.param_step.zero_()
             runs.append([float(ts(b.clone())) for _ in range(4)])
-        for a, c in zip(*runs):
-            assert abs(a - c) <= 1e-6 * max(abs(a), 1.0), runs
+        for a, c, e in zip(*runs):
+            assert abs(a - c) <= 1e-6 * max(abs(a), 1.0) and abs(a - e) <= 1e-6 * max(abs(a), 1.0), runs
     finally:
         dist.destroy_process_group()
 
