@@ -539,7 +539,7 @@ __device__ __forceinline__ void run_bwd_apply(const BwdTask& T, int d, int lb, c
 
 // (two 480-thread blocks per CU = 4 waves per SIMD = 128 VGPRs: two-task lists have 512 blocks, and at 130 registers the
 // second block of a CU waited for the first -- the bound keeps the allocator at the 128 the kernel had before the max|.| word)
-__global__ __launch_bounds__(kMaxThreads, 4) void k_bwd_apply(const BwdGroup G) {
+__global__ __launch_bounds__(kMaxThreads, 3) void k_bwd_apply(const BwdGroup G) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   int ti = 0;
 #pragma unroll

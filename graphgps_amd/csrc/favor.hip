@@ -1277,20 +1277,16 @@ static bool favor_lds(int64_t n_work) {
 }
 // The chunked form with the context record staged too (k_favor_*_lc): long graphs only -- a chunk is four 16-row tiles of
 // ONE graph and costs a 70 KB copy.  GPS_FAVOR_LC=0 never, =1 whenever the shapes allow it.
-static bool favor_lc(int64_t max_tiles, int64_t B, const char* one = nullptr) {
+static bool favor_lc(int64_t max_tiles, int64_t B) {
   if (B < 1 || B > kLcMaxGraphs) return false;
   const char* e = getenv("GPS_FAVOR_LC");
-  if (e && *e && atoi(e) == 0) return false;
-  if (one) {                                   // per-kernel switch (A/B): GPS_FAVOR_LC_OUT / _Q / _K = 0
-    const char* o = getenv(one);
-    if (o && *o && atoi(o) == 0) return false;
-  }
-  if (e && *e) return true;
+  if (e && *e) return atoi(e) != 0;
   return max_tiles >= 16 * B && max_tiles >= 512;
 }
-// wavefronts per workgroup of a chunked kernel: 4 (the form that prefetches the next record through registers) or 8 (two
-// per SIMD, no prefetch).  Measured (profiles/r05_favor_lds_projection.txt, code2-long layer): query side 208 vs 217 us, key
-// side 253 vs 228, output 141 vs 128 -- hence the defaults below; GPS_FAVOR_LC_{Q,K,OUT}_WAVES / GPS_FAVOR_LC_WAVES override.
+// Wavefronts per workgroup of the chunked kernels, as measured on the code2-long layer (profiles/r05_favor_lds_projection.txt:
+// 4 wavefronts with the next record prefetched through registers | 8 wavefronts, two per SIMD, no prefetch): query side
+// 208 | 217 us -> 4; key side 253 | 228 -> 8; output 141 | 128 -> 8.  Round 6 removed the forms that lost (among them the
+// 8-wavefront query kernel, which spilled 62 registers); only the instantiations below are built.
 // the context kernels with their rows staged in LDS (k_favor_*ctx_st): GPS_FAVOR_CTX_LDS=0 never, =1 always; default: LONG
 // graphs only (>= 384 rows on average).  Measured (profiles/r05_favor_ctx_staged.txt): 600-1000-row graphs 129 -> 119 and
 // 158 -> 132 us, but at the code2 dataset's own sizes (~125 rows per graph) the staged form LOSES -- 44 -> 55 / 53 -> 61 us
@@ -1301,32 +1297,15 @@ static bool favor_ctx_staged(int64_t N, int64_t B) {
   if (e && *e) return atoi(e) != 0;
   return B > 0 && N / B >= 384;
 }
-// wavefronts per workgroup of the staged context kernels: the 17 feature tiles are dealt w, w + W; 12 puts 5 / 4 / 4 / 4
-// tiles on the four SIMDs, 9 (GPS_FAVOR_CTX_WAVES=9) 6 / 4 / 4 / 3 -- measured the same (119 / 132 us); 16 needs a
-// 128-register cap, spills and loses (137 / 170)
-static int favor_ctx_waves() {
-  const char* e = getenv("GPS_FAVOR_CTX_WAVES");
-  return e && atoi(e) == 9 ? 9 : 12;
+// (staged context kernels: 12 wavefronts per workgroup -- the 17 feature tiles dealt 5 / 4 / 4 / 4 over the SIMDs; 9 measured
+// the same, 16 needs a 128-register cap, spills and loses: profiles/r05_favor_ctx_staged.txt)
+template <typename... A>
+static void launch_ctx_st(unsigned grid, hipStream_t s, A... a) {
+  k_favor_ctx_st<12><<<grid, 768, CS_LDS_BYTES, s>>>(a...);
 }
 template <typename... A>
-static void launch_ctx_st(int waves, unsigned grid, hipStream_t s, A... a) {
-  if (waves == 9) k_favor_ctx_st<9><<<grid, 576, CS_LDS_BYTES, s>>>(a...);
-  else k_favor_ctx_st<12><<<grid, 768, CS_LDS_BYTES, s>>>(a...);
-}
-template <typename... A>
-static void launch_bwd_ctx_st(int waves, unsigned grid, hipStream_t s, A... a) {
-  if (waves == 9) k_favor_bwd_ctx_st<9><<<grid, 576, CS_LDS_BYTES, s>>>(a...);
-  else k_favor_bwd_ctx_st<12><<<grid, 768, CS_LDS_BYTES, s>>>(a...);
-}
-static int favor_lc_waves(const char* one, int dflt) {
-  const char* e = getenv(one);
-  if (!(e && *e)) e = getenv("GPS_FAVOR_LC_WAVES");
-  if (!(e && *e)) return dflt;
-  return atoi(e) == 8 ? 8 : 4;
-}
-static bool favor_lc_prefetch() {
-  const char* pe = getenv("GPS_FAVOR_LC_PREFETCH");
-  return !(pe && atoi(pe) == 0);
+static void launch_bwd_ctx_st(unsigned grid, hipStream_t s, A... a) {
+  k_favor_bwd_ctx_st<12><<<grid, 768, CS_LDS_BYTES, s>>>(a...);
 }
 template <typename K>
 static bool favor_lc_ready(K kernel) {
@@ -1397,7 +1376,7 @@ int gps_favor_fwd(const float* qkv, int64_t ld_qkv, const float* proj, int m, co
     float* cpart = ws;
     float* kpart = ws + (size_t)S * B * H * 272 * DH;
     if (staged)
-      launch_ctx_st(favor_ctx_waves(), (unsigned)(B * H * S), s, qkv, ld_qkv, proj, m, c, ratio, ptr, nmax, B, H,
+      launch_ctx_st((unsigned)(B * H * S), s, qkv, ld_qkv, proj, m, c, ratio, ptr, nmax, B, H,
                     (const unsigned long long*)kmax, cpart, kpart, S);
     else
       k_favor_ctx<<<gps::grid_for(B * H * MT * S, 4), 256, 0, s>>>(qkv, ld_qkv, proj, m, c, ratio, ptr, nmax, B, H,
@@ -1405,7 +1384,7 @@ int gps_favor_fwd(const float* qkv, int64_t ld_qkv, const float* proj, int m, co
     k_favor_sum_parts<<<gps::grid_for(B * H * 272 * (DH / 4 + 1), 256), 256, 0, s>>>(
         cpart, kpart, S, B * H, m, ratio, ptr, nmax, H, (const unsigned long long*)kmax, ctx, ksum);
   } else if (staged) {
-    launch_ctx_st(favor_ctx_waves(), (unsigned)(B * H), s, qkv, ld_qkv, proj, m, c, ratio, ptr, nmax, B, H,
+    launch_ctx_st((unsigned)(B * H), s, qkv, ld_qkv, proj, m, c, ratio, ptr, nmax, B, H,
                   (const unsigned long long*)kmax, ctx, ksum, 1);
   } else {
     k_favor_ctx<<<gps::grid_for(B * H * MT, 4), 256, 0, s>>>(qkv, ld_qkv, proj, m, c, ratio, ptr, nmax, B, H,
@@ -1414,18 +1393,10 @@ int gps_favor_fwd(const float* qkv, int64_t ld_qkv, const float* proj, int m, co
   // (LP form of the output kernel: not used -- with the loop over items it needs 333 registers, one wavefront per SIMD
   // instead of two, and ran at 232 us against 149, profiles/r05_favor_lds_projection.txt; the chunked form with the context
   // record staged as well is)
-  static const bool lc_ok = favor_lc_ready(&k_favor_out_lc<true, 4>) && favor_lc_ready(&k_favor_out_lc<false, 4>) &&
-                            favor_lc_ready(&k_favor_out_lc<false, 8>);
-  if (lc_ok && favor_lc(max_tiles, B, "GPS_FAVOR_LC_OUT")) {
-    if (favor_lc_waves("GPS_FAVOR_LC_OUT_WAVES", 8) == 8)
-      k_favor_out_lc<false, 8><<<favor_lc_grid(max_tiles, B, H, 8), 512, LC_LDS_BYTES, s>>>(qkv, ld_qkv, proj, m, c, ratio, ptr, (int)B, N,
-                                                                                           H, ctx, ksum, out, mq, D);
-    else if (favor_lc_prefetch())
-      k_favor_out_lc<true, 4><<<favor_lc_grid(max_tiles, B, H, 4), 256, LC_LDS_BYTES, s>>>(qkv, ld_qkv, proj, m, c, ratio, ptr, (int)B, N,
-                                                                                          H, ctx, ksum, out, mq, D);
-    else
-      k_favor_out_lc<false, 4><<<favor_lc_grid(max_tiles, B, H, 4), 256, LC_LDS_BYTES, s>>>(qkv, ld_qkv, proj, m, c, ratio, ptr, (int)B, N,
-                                                                                           H, ctx, ksum, out, mq, D);
+  static const bool lc_ok = favor_lc_ready(&k_favor_out_lc<false, 8>);
+  if (lc_ok && favor_lc(max_tiles, B)) {
+    k_favor_out_lc<false, 8><<<favor_lc_grid(max_tiles, B, H, 8), 512, LC_LDS_BYTES, s>>>(qkv, ld_qkv, proj, m, c, ratio, ptr, (int)B, N,
+                                                                                         H, ctx, ksum, out, mq, D);
   } else
     k_favor_out<false><<<gps::grid_for(n_work, 4), 256, 0, s>>>(qkv, ld_qkv, proj, m, c, ratio, ptr, tile_graph,
                                                                 tile_row0, n_work, N, H, ctx, ksum, out, mq, D);
@@ -1455,21 +1426,11 @@ int gps_favor_bwd(const float* g_out, const float* qkv, int64_t ld_qkv, const fl
   k_favor_bwd_gd<<<gps::grid_for(N * H * 16, 256), 256, 0, s>>>(g_out, out, D, N, H, gD);
   static const bool lds_ok = favor_lds_ready(&k_favor_bwd_q<true>) && favor_lds_ready(&k_favor_bwd_k<true>);
   const bool lp = lds_ok && favor_lds(n_work);
-  static const bool lc_ok = favor_lc_ready(&k_favor_bwd_q_lc<true, 4>) && favor_lc_ready(&k_favor_bwd_q_lc<false, 4>) &&
-                            favor_lc_ready(&k_favor_bwd_q_lc<false, 8>) && favor_lc_ready(&k_favor_bwd_k_lc<true, 4>) &&
-                            favor_lc_ready(&k_favor_bwd_k_lc<false, 4>) && favor_lc_ready(&k_favor_bwd_k_lc<false, 8>);
-  if (lc_ok && favor_lc(max_tiles, B, "GPS_FAVOR_LC_Q")) {
-    const unsigned grid = favor_lc_grid(max_tiles, B, H, 4);
-    if (favor_lc_waves("GPS_FAVOR_LC_Q_WAVES", 4) == 8)
-      k_favor_bwd_q_lc<false, 8><<<favor_lc_grid(max_tiles, B, H, 8), 512, LC_LDS_BYTES, s>>>(g_out, qkv, ld_qkv, proj, m, c, ratio, ptr,
-                                                                                             (int)B, N, H, ctx, ksum, mq, D, gD, d_qkv,
-                                                                                             ld_dqkv);
-    else if (favor_lc_prefetch())
-      k_favor_bwd_q_lc<true, 4><<<grid, 256, LC_LDS_BYTES, s>>>(g_out, qkv, ld_qkv, proj, m, c, ratio, ptr, (int)B, N, H, ctx,
-                                                                ksum, mq, D, gD, d_qkv, ld_dqkv);
-    else
-      k_favor_bwd_q_lc<false, 4><<<grid, 256, LC_LDS_BYTES, s>>>(g_out, qkv, ld_qkv, proj, m, c, ratio, ptr, (int)B, N, H, ctx,
-                                                                 ksum, mq, D, gD, d_qkv, ld_dqkv);
+  static const bool lc_ok = favor_lc_ready(&k_favor_bwd_q_lc<true, 4>) && favor_lc_ready(&k_favor_bwd_k_lc<false, 8>);
+  if (lc_ok && favor_lc(max_tiles, B)) {
+    k_favor_bwd_q_lc<true, 4><<<favor_lc_grid(max_tiles, B, H, 4), 256, LC_LDS_BYTES, s>>>(g_out, qkv, ld_qkv, proj, m, c, ratio, ptr,
+                                                                                          (int)B, N, H, ctx, ksum, mq, D, gD, d_qkv,
+                                                                                          ld_dqkv);
   } else if (lp)
     k_favor_bwd_q<true><<<favor_lds_grid(n_work, FQ_THREADS), FQ_THREADS, P_LDS_BYTES, s>>>(g_out, qkv, ld_qkv, proj, m, c, ratio, ptr,
                                                                                           tile_graph, tile_row0, n_work, N, H, ctx,
@@ -1485,7 +1446,7 @@ int gps_favor_bwd(const float* g_out, const float* qkv, int64_t ld_qkv, const fl
     float* cpart = ws;
     float* kpart = ws + (size_t)S * B * H * 272 * DH;
     if (staged)
-      launch_bwd_ctx_st(favor_ctx_waves(), (unsigned)(B * H * S), s, g_out, qkv, ld_qkv, proj, m, c, ratio, ptr, B, N, H, mq, D, gD,
+      launch_bwd_ctx_st((unsigned)(B * H * S), s, g_out, qkv, ld_qkv, proj, m, c, ratio, ptr, B, N, H, mq, D, gD,
                         cpart, kpart, S);
     else
       k_favor_bwd_ctx<<<gps::grid_for(B * H * MT * S, 4), 256, 0, s>>>(g_out, qkv, ld_qkv, proj, m, c, ratio, ptr, B, N,
@@ -1493,26 +1454,16 @@ int gps_favor_bwd(const float* g_out, const float* qkv, int64_t ld_qkv, const fl
     k_favor_sum_parts<<<gps::grid_for(B * H * 272 * (DH / 4 + 1), 256), 256, 0, s>>>(
         cpart, kpart, S, B * H, m, ratio, ptr, nmax, H, nullptr, g_ctx, g_ksum);
   } else if (staged) {
-    launch_bwd_ctx_st(favor_ctx_waves(), (unsigned)(B * H), s, g_out, qkv, ld_qkv, proj, m, c, ratio, ptr, B, N, H, mq, D, gD,
+    launch_bwd_ctx_st((unsigned)(B * H), s, g_out, qkv, ld_qkv, proj, m, c, ratio, ptr, B, N, H, mq, D, gD,
                       g_ctx, g_ksum, 1);
   } else {
     k_favor_bwd_ctx<<<gps::grid_for(B * H * MT, 4), 256, 0, s>>>(g_out, qkv, ld_qkv, proj, m, c, ratio, ptr, B, N,
                                                                  H, mq, D, gD, g_ctx, g_ksum, 1);
   }
-  if (lc_ok && favor_lc(max_tiles, B, "GPS_FAVOR_LC_K")) {
-    const unsigned grid = favor_lc_grid(max_tiles, B, H, 4);
-    if (favor_lc_waves("GPS_FAVOR_LC_K_WAVES", 8) == 8)
-      k_favor_bwd_k_lc<false, 8><<<favor_lc_grid(max_tiles, B, H, 8), 512, LC_LDS_BYTES, s>>>(qkv, ld_qkv, proj, m, c, ratio, ptr, (int)B,
-                                                                                             nmax, H, (const unsigned long long*)kmax,
-                                                                                             g_ctx, g_ksum, d_qkv, ld_dqkv, gM_part);
-    else if (favor_lc_prefetch())
-      k_favor_bwd_k_lc<true, 4><<<grid, 256, LC_LDS_BYTES, s>>>(qkv, ld_qkv, proj, m, c, ratio, ptr, (int)B, nmax, H,
-                                                                (const unsigned long long*)kmax, g_ctx, g_ksum, d_qkv, ld_dqkv,
-                                                                gM_part);
-    else
-      k_favor_bwd_k_lc<false, 4><<<grid, 256, LC_LDS_BYTES, s>>>(qkv, ld_qkv, proj, m, c, ratio, ptr, (int)B, nmax, H,
-                                                                 (const unsigned long long*)kmax, g_ctx, g_ksum, d_qkv, ld_dqkv,
-                                                                 gM_part);
+  if (lc_ok && favor_lc(max_tiles, B)) {
+    k_favor_bwd_k_lc<false, 8><<<favor_lc_grid(max_tiles, B, H, 8), 512, LC_LDS_BYTES, s>>>(qkv, ld_qkv, proj, m, c, ratio, ptr, (int)B,
+                                                                                           nmax, H, (const unsigned long long*)kmax,
+                                                                                           g_ctx, g_ksum, d_qkv, ld_dqkv, gM_part);
   } else if (lp)
     k_favor_bwd_k<true><<<favor_lds_grid(n_work, FK_THREADS), FK_THREADS, P_LDS_BYTES, s>>>(qkv, ld_qkv, proj, m, c, ratio, ptr, tile_graph,
                                                                                tile_row0, n_work, nmax, H,

@@ -28,6 +28,13 @@
 // bandwidth and the split's VALU work, not by the MFMA pipe.
 #include "gps_common.hpp"
 
+// The GPS_ABL_* switches below time parts of this kernel with the rest removed (tools/micro/gemm_ablate.sh): their results
+// are garbage by design, so a build that defines one must say so -- they can never slip into the library by a stray -D.
+#if (defined(GPS_ABL_NO_BARRIER) || defined(GPS_ABL_NO_SPLIT) || defined(GPS_ABL_NO_GLOBAL) || defined(GPS_ABL_NO_LDSWRITE) || \
+     defined(GPS_ABL_NO_LDSREAD) || defined(GPS_ABL_NO_MFMA)) && !defined(GPS_ABLATION_BUILD)
+#error "GPS_ABL_* ablation switches produce wrong results: define GPS_ABLATION_BUILD as well (timing builds only)"
+#endif
+
 #ifdef GPS_ABL_NO_BARRIER   // ablation: no workgroup barriers (results are garbage, timing only)
 #define GPS_BARRIER() do {} while (0)
 #else

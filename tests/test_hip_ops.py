@@ -592,11 +592,8 @@ def test_favor_projection_in_lds_is_bit_identical(monkeypatch, H, sizes, m):
                       "ctx_staged": dict(GPS_FAVOR_LDS="0", GPS_FAVOR_LC="0", GPS_FAVOR_CTX_LDS="1"),
                       "lp": dict(GPS_FAVOR_LDS="1", GPS_FAVOR_LC="0", GPS_FAVOR_CTX_LDS="0"),
                       "lc": dict(GPS_FAVOR_LDS="1", GPS_FAVOR_LC="1", GPS_FAVOR_CTX_LDS="1"),
-                      "lc4": dict(GPS_FAVOR_LDS="1", GPS_FAVOR_LC="1", GPS_FAVOR_LC_WAVES="4"),
-                      "lc8": dict(GPS_FAVOR_LDS="1", GPS_FAVOR_LC="1", GPS_FAVOR_LC_WAVES="8", GPS_FAVOR_CTX_LDS="0"),
-                      "lc4_nopre": dict(GPS_FAVOR_LDS="1", GPS_FAVOR_LC="1", GPS_FAVOR_LC_WAVES="4",
-                                        GPS_FAVOR_LC_PREFETCH="0")}.items():
-        for k in ("GPS_FAVOR_LDS", "GPS_FAVOR_LC", "GPS_FAVOR_LC_WAVES", "GPS_FAVOR_LC_PREFETCH", "GPS_FAVOR_CTX_LDS"):
+                      "lc_plain_ctx": dict(GPS_FAVOR_LDS="1", GPS_FAVOR_LC="1", GPS_FAVOR_CTX_LDS="0")}.items():
+        for k in ("GPS_FAVOR_LDS", "GPS_FAVOR_LC", "GPS_FAVOR_CTX_LDS"):
             monkeypatch.delenv(k, raising=False)
         for k, v in env.items():
             monkeypatch.setenv(k, v)

@@ -12,7 +12,7 @@ if [ "$1" = "run" ]; then
 fi
 for v in $VARIANTS; do
   n=${v%%:*}; f=$(echo "${v#*:}" | tr ',' ' ')
-  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -I../../include -I$SRC $f \
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -DGPS_ABLATION_BUILD -I../../include -I$SRC $f \
       gemm_ablate.hip $SRC/gemm_split.hip $SRC/gps_common.hip -o abl_$n &
 done
 wait
