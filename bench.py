@@ -401,6 +401,24 @@ def kernel_rooflines(dev, profile, nb, d=384, H=16, in_step=None, layers=10, onl
                                  ptr(q["gce"]), G, G + fs, G + 2 * fs, G + 3 * fs, 4 * d, None, None, None,
                                  current_stream(dev)))
 
+    # the form the fused block launches since round 6: bn_node_x / bn_edge_e backward applies evaluated in the loads
+    # (gps_gatedgcn_bwd_bn): the same tensors cross HBM (g_x1 / g_e1 instead of g_x~ / g_e^) + x~ read once more
+    import ctypes as _ct
+    cols = [torch.rand(d, device=dev) + 0.5 for _ in range(8)] + [torch.randn(d, device=dev) for _ in range(4)]
+    bnd = [L_.BnDesc(cols[4 * i].data_ptr(), cols[4 * i + 1].data_ptr(), cols[4 * i + 2].data_ptr(), cols[4 * i + 3].data_ptr(),
+                     0, 0, 1e-5, 0.1) for i in range(2)]     # (weight, bias, mean, rstd, running stats unused)
+    folds = [L_.BnBwdFold(_ct.addressof(bnd[i]), cols[8 + 2 * i].data_ptr(), cols[9 + 2 * i].data_ptr(), 0.1, 77 + i, 1, None)
+             for i in range(2)]
+
+    def gg_bwd_bn(i=0):
+        q = gsets[i]
+        P, G = q["proj"].data_ptr(), q["gproj"].data_ptr()
+        check(L.gps_gatedgcn_bwd_bn(ptr(q["gx"]), d, ptr(q["ge"]), ptr(q["eh"]), P, P + fs, 4 * d, ptr(q["xt"]),
+                                    ptr(gi.rowptr_dst), ptr(gi.src_by_dst), ptr(gi.eid_by_dst),
+                                    ptr(gi.rowptr_src), ptr(gi.dst_by_src), ptr(gi.eid_by_src), N, E, d,
+                                    ptr(q["gce"]), G, G + fs, G + 2 * fs, G + 3 * fs, 4 * d, None, None, None,
+                                    _ct.byref(folds[0]), _ct.byref(folds[1]), current_stream(dev)))
+
     def at_set():
         return dict(qkv=f(N, 3 * d), out=f(N, d), lse=f(H, N), dout=f(N, d), delta=f(H, N), dqkv=f(N, 3 * d))
     a_bytes = 4 * (2 * N * 3 * d + 2 * N * d + 2 * H * N)
@@ -446,9 +464,11 @@ def kernel_rooflines(dev, profile, nb, d=384, H=16, in_step=None, layers=10, onl
         res[name] = e
 
     entry("gatedgcn_fwd", gg_fwd, n_rot, "hbm", 8 * E * d + 20 * N * d + idx, 1, ("k_gatedgcn_fwd",))
-    entry("gatedgcn_bwd", gg_bwd, n_rot, "hbm", 12 * E * d + 28 * N * d + 2 * idx, 1, ("k_gatedgcn_bwd",),
-          note="algorithmic bytes per SURVEY.md 8d (which counts num and den as read: 8*N*d that this kernel "
-               "recomputes instead)")
+    entry("gatedgcn_bwd", gg_bwd_bn, n_rot, "hbm", 12 * E * d + 32 * N * d + 2 * idx, 1, ("k_gatedgcn_bwd",),
+          note="the folded form the step runs (gps_gatedgcn_bwd_bn): algorithmic bytes per SURVEY.md 8d (which counts num "
+               "and den as read: 8*N*d that this kernel recomputes instead) + 4*N*d for x~ on the node fold")
+    entry("gatedgcn_bwd_unfolded", gg_bwd, n_rot, "hbm", 12 * E * d + 28 * N * d + 2 * idx, 1, ("k_gatedgcn_bwd<4, false, 0>",),
+          note="gps_gatedgcn_bwd behind two BatchNorm backward apply launches (rounds 1 - 5; GPS_GG_BN_FOLD=0)")
     # the attention core is HBM-bound at these graph sizes (7.8 flop/byte against a ridge of 19.6): the binding
     # roofline is Q/K/V read + O write (fwd), + dO read + dQ/dK/dV write (bwd); the MFMA figure rides along
     entry("seg_attn_fwd", at_fwd, a_rot, "hbm", 16 * N * d + 4 * H * N, 1, ("k_attn_fwd", "k_sattn_fwd"))

@@ -35,7 +35,6 @@ namespace tr = gps::tree;
 // registers, and the kernel's register allocation is its maximum over all paths: 24-record bursts (512 blocks) cost the
 // streaming loop half of its occupancy (133-154 VGPRs -> 3 waves per SIMD; measured 37 us for a 106 MB list).
 constexpr int TARGET_BLOCKS = 256;
-constexpr int FREE_BLOCKS = 256;
 constexpr int kMaxThreads = 512;
 constexpr int kMaxTasks = 4;
 constexpr int MAXI = 16;
@@ -583,20 +582,10 @@ inline int target_blocks() {       // GPS_NORM_BLOCKS: row blocks per task (A/B 
   }();
   return v;
 }
-// Tasks that own no reduction tree (plain applies) are not bound by the tree's record count: GPS_NORM_FREE_BLOCKS row blocks
-inline int free_blocks() {
-  static const int v = []() {
-    const char* e = getenv("GPS_NORM_FREE_BLOCKS");
-    const int x = e && *e ? atoi(e) : FREE_BLOCKS;
-    return x < 8 ? 8 : (x > 8192 ? 8192 : x);
-  }();
-  return v;
-}
-inline int rows_per_block(int64_t R, bool tree = true) {
-  const int tb = tree ? target_blocks() : free_blocks();
-  return (int)std::max<int64_t>(8, (R + tb - 1) / tb);
-}
-inline int nblocks_for(int64_t R, bool tree = true) { const int rpb = rows_per_block(R, tree); return (int)((R + rpb - 1) / rpb); }
+// (round 6: more row blocks for the tasks that own no reduction tree -- 512 .. 2,048 instead of 256 -- measured slower on
+// every launch of the block, tools/norm_probe.py: the launches are bound by their fixed costs, not by blocks in flight)
+inline int rows_per_block(int64_t R) { return (int)std::max<int64_t>(8, (R + target_blocks() - 1) / target_blocks()); }
+inline int nblocks_for(int64_t R) { const int rpb = rows_per_block(R); return (int)((R + rpb - 1) / rpb); }
 inline Bn bn_of(const gps_bn* b) { return Bn{b->mean, b->rstd, b->gamma, b->beta}; }
 inline int threads_for(int d) { const int L = d / 4; return std::max(1, kMaxThreads / L) * L; }
 inline size_t lds_bytes_for(int d, int nvec) {
@@ -699,7 +688,7 @@ int gps_norm_fwd(int n, const gps_norm_fwd_task* tasks, int d, float* ws, size_t
     T.rdev = S.rdev;
     T.p = (S.kind == K_ADD_DROP || S.kind == K_BN_ACT) ? S.p : 0.f;
     T.kind = S.kind; T.relu = S.relu;
-    T.rpb = rows_per_block(S.R, S.stats != nullptr); T.nblk = nblocks_for(S.R, S.stats != nullptr);
+    T.rpb = rows_per_block(S.R); T.nblk = nblocks_for(S.R);
     T.block_begin = blocks;
     blocks += T.nblk;
     if (S.stats) {
@@ -715,7 +704,7 @@ int gps_norm_fwd(int n, const gps_norm_fwd_task* tasks, int d, float* ws, size_t
   return gps::launch_status(who);
 }
 
-static int fill_bwd(const char* who, int n, const gps_norm_bwd_task* tasks, int d, BwdGroup& G, int& blocks, bool apply) {
+static int fill_bwd(const char* who, int n, const gps_norm_bwd_task* tasks, int d, BwdGroup& G, int& blocks) {
   GPS_REQUIRE(n >= 1 && n <= kMaxTasks && tasks, "%s: 1..%d tasks per launch", who, kMaxTasks);
   G.n = n; G.d = d;
   G.salt = gps::dropout_salt();
@@ -741,8 +730,7 @@ static int fill_bwd(const char* who, int n, const gps_norm_bwd_task* tasks, int 
     T.p1x = S.z2 ? S.p1x : 0.f; T.seed1x = S.seed1x;
     T.R = S.R; T.seed = S.seed; T.seed2 = S.seed2; T.p = S.p; T.p2 = S.p2; T.relu = S.relu;
     T.rdev = S.rdev;
-    const bool tree = !apply || S.cz != nullptr;
-    T.rpb = rows_per_block(S.R, tree); T.nblk = nblocks_for(S.R, tree);
+    T.rpb = rows_per_block(S.R); T.nblk = nblocks_for(S.R);
     T.block_begin = blocks;
     blocks += T.nblk;
   }
@@ -754,7 +742,7 @@ int gps_norm_bwd_partial(int n, const gps_norm_bwd_task* tasks, int d, float* ws
   static const char* who = "gps_norm_bwd_partial";
   BwdGroup G{};
   int blocks = 0, n_trees = 0;
-  if (int rc = fill_bwd(who, n, tasks, d, G, blocks, false)) return rc;
+  if (int rc = fill_bwd(who, n, tasks, d, G, blocks)) return rc;
   GPS_REQUIRE(al16(ws), "%s: misaligned workspace", who);
   float* wp = ws;
   float* wend = ws + ws_floats;
@@ -773,7 +761,7 @@ int gps_norm_bwd_apply(int n, const gps_norm_bwd_task* tasks, int d, float* ws, 
   static const char* who = "gps_norm_bwd_apply";
   BwdGroup G{};
   int blocks = 0, n_trees = 0;
-  if (int rc = fill_bwd(who, n, tasks, d, G, blocks, true)) return rc;
+  if (int rc = fill_bwd(who, n, tasks, d, G, blocks)) return rc;
   float* wp = ws;
   float* wend = ws + ws_floats;
   for (int i = 0; i < n; ++i) {

@@ -46,7 +46,6 @@ _BY_REF = _ctypes.byref
 # GPS_GEMM_STATS=0: za / z2 and their statistics by row tasks instead of the ring GEMM epilogue (default 1: -0.3 ms per step).
 _GG_STATS = _os.environ.get("GPS_GG_STATS", "1") != "0"
 _GEMM_STATS = _os.environ.get("GPS_GEMM_STATS", "1") != "0"
-_GG_FIRST = _os.environ.get("GPS_GG_FIRST", "0") != "0"
 # GPS_GEMM_PAIR=0: the edge projection C(e) and the merged node projection (forward), and their two input-gradient GEMMs
 # (backward), as two dispatches each instead of one (csrc/gemm_panel.hip k_gemm_ring16_pair) -- A/B
 _GEMM_PAIR = _os.environ.get("GPS_GEMM_PAIR", "1") != "0"
@@ -567,13 +566,7 @@ class _GPSBlock(torch.autograd.Function):
                            _norm.fwd_task(_norm.LOAD, eh, E, stats=bne, rdev=re_)], d, dev, sync.site(_S_XE))
             return xt, eh
 
-        # GPS_GG_FIRST=1 (single stream only): the GatedGCN core directly behind the merged projection that wrote its four
-        # operands, the attention half after it.  Measured, same box: 9.948 vs 9.958 ms per step, the GatedGCN forward at
-        # 26.3 vs 25.9 us -- the operands are Infinity-Cache resident either way; the default keeps the documented order.
         core_fork = _CORE_FORK_FWD and _BRANCH == "0" and not perf
-        gg_first = _GG_FIRST and _BRANCH == "0" and not core_fork
-        if gg_first:
-            xt, eh = local_half()
         # -- global branch (forked): varlen attention over the PRE-layer x (gps_layer.py:199-201,234-241)
         with _Fork(dev, "2" if core_fork else _BRANCH) as fork:
             sb = current_stream(dev)
@@ -611,7 +604,7 @@ class _GPSBlock(torch.autograd.Function):
             fork.join(o, lse)
             fork.enabled = False
             za, ao = out_projection()
-        elif not gg_first:
+        else:
             xt, eh = local_half()
         # -- x1 = x + drop(relu(BN_x(xt))) [+ statistics -> norm1_local], e1 = e + drop(relu(BN_e(eh))),
         #    za = x + drop(ao) [+ statistics -> norm1_attn] unless the out-projection already produced it -- in which case

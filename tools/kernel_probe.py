@@ -17,7 +17,7 @@ if __name__ == "__main__":
     dev = torch.device("cuda:0")
     torch.cuda.set_device(0)
     res, shape = bench.kernel_rooflines(dev, sys.argv[1] if len(sys.argv) > 1 else "P30", 256,
-                                        only=("gatedgcn_fwd", "gatedgcn_bwd", "seg_attn_fwd", "seg_attn_bwd", "wgrad_grouped"))
+                                        only=("gatedgcn_fwd", "gatedgcn_bwd", "gatedgcn_bwd_unfolded", "seg_attn_fwd", "seg_attn_bwd", "wgrad_grouped"))
     print(shape, {k: round(v["ms"] * 1e3, 2) for k, v in res.items()})
     if os.environ.get("GPS_PROBE_GEMM", "1") != "0":
         # the ring GEMM at two of the block's shapes: k_gemm_ring<2, 0, false> = x[N,d] W[7d,d] (14 column panels of

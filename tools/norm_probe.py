@@ -4,7 +4,7 @@
 (ten layers' worth of distinct tensors, so nothing is re-read out of the Infinity Cache that the real step would not find
 there either).  Prints us per launch and the algorithmic GB/s.
 
-    python tools/norm_probe.py [N E d]          GPS_NORM_BLOCKS / GPS_NORM_FREE_BLOCKS select the row blocks per task
+    python tools/norm_probe.py [N E d]          GPS_NORM_BLOCKS selects the row blocks per task
 """
 import os
 import sys
@@ -118,7 +118,7 @@ def main():
         total_b += nbytes
         print(f"{name:34s} {us:7.2f} us  {nbytes / 1e6:7.1f} MB  {nbytes / us / 1e3:6.0f} GB/s")
     print(f"{'sum':34s} {total_us:7.2f} us  {total_b / 1e6:7.1f} MB  {total_b / total_us / 1e3:6.0f} GB/s   "
-          f"(GPS_NORM_BLOCKS={os.environ.get('GPS_NORM_BLOCKS', '-')}, GPS_NORM_FREE_BLOCKS={os.environ.get('GPS_NORM_FREE_BLOCKS', '-')})")
+          f"(GPS_NORM_BLOCKS={os.environ.get('GPS_NORM_BLOCKS', '-')})")
 
 
 if __name__ == "__main__":
