@@ -306,6 +306,9 @@ constexpr int waitcnt_imm(int vm, int lgkm) { return (vm & 15) | (7 << 4) | ((lg
 // per value product on v_mfma_f32_32x32x16_f16: 48 MFMAs per stage instead of 96 and 8 VALU per value pair instead of 11.
 // The groups keep their shape (4 accumulators rotating, the same fills in the same order), two fill slots per issue gap.
 using gps::amax_be;
+__device__ __forceinline__ uint32_t cvt_pk_f16_rne(float a, float b) {       // v_cvt_pk_f16_f32 (gfx950): round to nearest even
+  return __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){a, b}, f16x2));
+}
 template <bool F16>
 __global__ __launch_bounds__(256, 1) void k_wgrad_stream(const Group G) {
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
@@ -372,23 +375,28 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_stream(const Group G) {
 
   // exact 3-way split of values (2d, 2d+1) of a fragment in three instalments (4 + 4 + 3 VALU); `bs` (g fragments only)
   // accumulates the bias gradient, scaled by `bw` (0 for the prefetch that runs past the last stage)
-  float sv0, sv1, sr0, sr1;
+  float sv0, sv1, sr0, sr1, st_s0, st_s1;
   f32x2 st_hb;
   uint32_t st_hi;
   const unsigned beg = F16 ? amax_be(P.g_amax) : 127u, bex = F16 ? amax_be(P.x_amax) : 127u;
   const float scg = __uint_as_float((268u - beg) << 23), scx = __uint_as_float((268u - bex) << 23);     // 2^(141 - be)
   auto split_part = [&](int part, const float (&raw)[8], int d, Pieces& out, float* bs, float bw) __attribute__((always_inline)) {
     if constexpr (F16) {
-      const f32x2 v = (f32x2){raw[2 * d], raw[2 * d + 1]};
+      // scalar form on purpose: the two values of a pair come out of two LDS words 512 bytes apart and the compiler's
+      // load merger does not always deliver them as one aligned register pair -- written on float2 it emitted v_mov gathers
+      // in front of v_pk_mul / v_pk_fma for half of the pairs (9.9 VALU per pair in the ISA); scalars take any registers
+      const float v0 = raw[2 * d], v1 = raw[2 * d + 1];
       const float sc = bs ? scg : scx;                       // (g fragments carry the bias-gradient accumulator)
       if (part == 0) {
-        if (bs) *bs = fmaf(v[0] + v[1], bw, *bs);
-        st_hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v * sc, f16x2));
+        if (bs) *bs = fmaf(v0 + v1, bw, *bs);
+        st_s0 = v0 * sc;                                     // exact: sc is a power of two
+        st_s1 = v1 * sc;
+        st_hi = cvt_pk_f16_rne(st_s0, st_s1);
         out.p[0][d] = st_hi;
       } else if (part == 1) {
         st_hb = __builtin_convertvector(__builtin_bit_cast(f16x2, st_hi), f32x2);
       } else {
-        out.p[1][d] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v * sc - st_hb, f16x2));
+        out.p[1][d] = cvt_pk_f16_rne(st_s0 - st_hb[0], st_s1 - st_hb[1]);
       }
     } else if (part == 0) {
       sv0 = raw[2 * d];
