@@ -88,6 +88,82 @@ def _hub_batch(deg, extra_graphs=3, seed=0):
     return ei, bvec, ptr, gen
 
 
+@pytest.mark.parametrize("case,d,p", [("p30", 384, 0.1), ("p30", 64, 0.0), ("hub", 128, 0.25), ("p30_padded", 256, 0.2)])
+def test_gatedgcn_bwd_bn_through_the_c_abi(case, d, p):
+    """gps_gatedgcn_bwd_bn (include/gps_hip.h, ABI v9) against the three launches it stands for -- gps_norm_bwd_apply of
+    bn_node_x and bn_edge_e, then gps_gatedgcn_bwd -- on the same operands and seeds: molecule-sized graphs (in-degrees 1 .. 6:
+    the one-pass chunks and, at degree >= 4 with both folds, the two-pass form), a hub of degree 300 (the long-segment path,
+    index slices past the LDS staging limit, out-of-block targets), and a padded batch whose last rows are junk beyond the
+    device-side real-row words (their folded gradients must come out exactly as the apply kernel's zeros make them).
+    Reference: gatedgcn_layer.py:72-83 and its autograd backward."""
+    import ctypes
+    from graphgps_amd import lib as _lib, norm as _norm
+    from graphgps_amd.lib import check, current_stream, ptr as P_
+    from graphgps_amd.synthetic import layer_batch
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(5 + d)
+    if case == "hub":
+        ei, bvec, ptr, _ = _hub_batch(300, extra_graphs=6, seed=3)
+    else:
+        b = layer_batch("P30", 48, d, seed=21)
+        ei, bvec, ptr = b.edge_index, b.batch, b.ptr
+    N, E = int(ptr[-1]), ei.shape[1]
+    gi = _index(ei, bvec, ptr, use_ptr=False)
+    n_real, e_real = (N - 37, E - 90) if case == "p30_padded" else (N, E)
+    rn = torch.tensor([n_real], dtype=torch.int32, device=dev) if case == "p30_padded" else None
+    re_ = torch.tensor([e_real], dtype=torch.int32, device=dev) if case == "p30_padded" else None
+    f = lambda *sh: torch.randn(*sh, generator=gen).to(dev)
+    proj, xt, eh = f(N, 4 * d), f(N, d), f(E, d)
+    g_x1, g_e1 = f(N, d), f(E, d)
+    L = _lib.load()
+    st = current_stream(dev)
+    bns = []
+    for _ in range(2):
+        m = torch.nn.BatchNorm1d(d).to(dev)
+        with torch.no_grad():
+            m.weight.uniform_(0.5, 1.5)
+            m.bias.uniform_(-0.5, 0.5)
+        bns.append(m)
+    stats = torch.empty(4, d, device=dev)
+    stats[0], stats[2] = xt[:n_real].mean(0), eh[:e_real].mean(0)
+    stats[1] = (xt[:n_real].var(0, unbiased=False) + 1e-5).rsqrt()
+    stats[3] = (eh[:e_real].var(0, unbiased=False) + 1e-5).rsqrt()
+    bnx, bne = _norm.bn_desc(bns[0], stats[0], stats[1]), _norm.bn_desc(bns[1], stats[2], stats[3])
+    sums = torch.zeros(4, d, device=dev)            # (g_gamma_x, g_beta_x, g_gamma_e, g_beta_e)
+    sx, se = 0x1111222233334444, 0x5555666677778888
+
+    class Owner:
+        pass
+    sync = _norm.sync_arena(Owner(), dev)
+    g_xt, g_eh = torch.empty(N, d, device=dev), torch.empty(E, d, device=dev)
+    tasks = [_norm.bwd_task(xt, g_x1, bnx, N, sums[0], sums[1], relu=True, p=p, seed=sx, g_z=g_xt, rdev=rn),
+             _norm.bwd_task(eh, g_e1, bne, E, sums[2], sums[3], relu=True, p=p, seed=se, g_z=g_eh, rdev=re_)]
+    _norm.bwd_partial(tasks, d, dev, sync.site(0))
+    _norm.bwd_apply(tasks, d, dev, None)
+    fs = 4 * d
+    outs = []
+    for folded in (False, True):
+        g_proj, g_ce = torch.zeros(N, 4 * d, device=dev), torch.zeros(E, d, device=dev)
+        Pp, G = proj.data_ptr(), g_proj.data_ptr()
+        common = (Pp, Pp + fs, 4 * d, P_(xt), P_(gi.rowptr_dst), P_(gi.src_by_dst), P_(gi.eid_by_dst), P_(gi.rowptr_src),
+                  P_(gi.dst_by_src), P_(gi.eid_by_src), N, E, d, P_(g_ce), G, G + fs, G + 2 * fs, G + 3 * fs, 4 * d, None, None, None)
+        if folded:
+            fx = _lib.BnBwdFold(ctypes.addressof(bnx), sums[1].data_ptr(), sums[0].data_ptr(), p, sx, 1, P_(rn))
+            fe = _lib.BnBwdFold(ctypes.addressof(bne), sums[3].data_ptr(), sums[2].data_ptr(), p, se, 1, P_(re_))
+            check(L.gps_gatedgcn_bwd_bn(P_(g_x1), d, P_(g_e1), P_(eh), *common, ctypes.byref(fx), ctypes.byref(fe), st),
+                  "gps_gatedgcn_bwd_bn")
+        else:
+            check(L.gps_gatedgcn_bwd(P_(g_xt), d, P_(g_eh), P_(eh), *common, st), "gps_gatedgcn_bwd")
+        outs.append((g_proj, g_ce))
+    torch.cuda.synchronize()
+    for name, a, c in (("g_Ax|g_Bx|g_Dx|g_Ex", outs[1][0], outs[0][0]), ("g_Ce", outs[1][1], outs[0][1])):
+        scale = float(c.abs().max())
+        err = float((a - c).abs().max()) / scale
+        assert err <= 2e-6, f"{case}: {name} folded vs launched differ by {err:.2e} of max|.|"
+    if case == "p30_padded":        # the padding rows' folded g_x~ (stored as g_Ax) are exactly zero, as the apply kernel makes them
+        assert float(outs[1][0][n_real:, :d].abs().max()) == 0.0
+
+
 def test_graph_index_and_gatedgcn_with_a_degree_5000_hub():
     """Graph index bit-exact against numpy's stable argsort and the GatedGCN core against the CPU restatement when one node
     has 5,000 in- and out-edges (the index sorts each CSR segment; the kernels walk a segment per node)."""
