@@ -574,14 +574,9 @@ __global__ __launch_bounds__(kMaxThreads, 3) void k_bwd_apply(const BwdGroup G) 
 // host side
 // ------------------------------------------------------------------------------------------------
 inline bool al16(const void* p) { return (reinterpret_cast<uintptr_t>(p) % 16) == 0; }
-inline int target_blocks() {       // GPS_NORM_BLOCKS: row blocks per task (A/B runs); <= tr::kMaxParts
-  static const int v = []() {
-    const char* e = getenv("GPS_NORM_BLOCKS");
-    const int x = e && *e ? atoi(e) : TARGET_BLOCKS;
-    return x < 8 ? 8 : (x > tr::kMaxParts ? tr::kMaxParts : x);
-  }();
-  return v;
-}
+// (row blocks per task were an A/B handle, GPS_NORM_BLOCKS, through round 6: 256 -- one per CU -- won every sweep,
+// profiles/r06_norm_probe_blocks.txt; the switch is gone)
+inline int target_blocks() { return TARGET_BLOCKS; }
 // (round 6: more row blocks for the tasks that own no reduction tree -- 512 .. 2,048 instead of 256 -- measured slower on
 // every launch of the block, tools/norm_probe.py: the launches are bound by their fixed costs, not by blocks in flight)
 inline int rows_per_block(int64_t R) { return (int)std::max<int64_t>(8, (R + target_blocks() - 1) / target_blocks()); }

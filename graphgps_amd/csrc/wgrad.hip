@@ -35,6 +35,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Exact 3-way split of 8 fp32 values into bf16 pieces (hi + mid + lo == v bit-for-bit: each piece
 // takes the next 8 significant bits by truncation, the remainders are exact fp32 subtractions),
@@ -613,6 +614,273 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_stream(const Group G) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------
+// Register path (round 6, fp16 form only).  The ablation of k_wgrad_stream (profiles/r06_wgrad_ablation.txt) priced its
+// load path: of 115 us, the 16 global -> LDS transfers per wavefront and stage cost 43 and the 64 ds_read_b32 that turn LDS
+// rows into MFMA fragments 34 -- the matrix loop itself 62.  A wavefront only ever reads back the rows it staged itself,
+// so LDS was a transposition buffer, not a shared one.  Here the rows never touch LDS:
+//   * lane (l, kh) loads, per stage, rows 8 kh .. 8 kh + 7 of its wavefront's 16 as eight 16-byte loads per operand at
+//     columns 4 l .. 4 l + 3: two fully coalesced 512-byte rows per wave-instruction, 16 instructions per stage like the
+//     16 transfers before -- but plain loads, whose issue costs a few cycles, into registers the split reads directly;
+//   * the four values of a load ARE four fragments: fragment c of an operand is the column set {4 l + c}.  The contraction
+//     does not care which lane carries which column as long as the output is stored accordingly: accumulator (a, b),
+//     element (ri, li), is g column 4 ri + a times x column 4 li + b -- so a lane's four b-accumulators are four
+//     NEIGHBOURING outputs and the partial tile leaves as 16-byte stores, whole 512-byte rows per wave-instruction;
+//   * two register sets alternate by stage parity: stage s+2 is requested (group 3 of stage s) into the set stage s has
+//     just finished with, one full stage before its first fragment is split; the compiler's own vmcnt accounting orders
+//     the uses (plain loads: no counted waits to maintain by hand);
+//   * the MFMA groups, the split's instalments in their issue gaps, the rotation of the piece sets and the cross-wavefront
+//     sum are k_wgrad_stream's, so every output element is the same sum of the same products in the same order.
+// Registers: 256 accumulators + 128 staging + 80 pieces: the file is full; one wavefront per SIMD.
+// ------------------------------------------------------------------------------------------------------------
+constexpr int WD_LDS = 4 * 4 * 64 * 16 * 4;       // 64 KB: [wave][b fragment][lane][16 floats] of one a-pass of the epilogue
+
+__global__ __launch_bounds__(256, 1) void k_wgrad_direct(const Group G) {
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+  int bid = blockIdx.x;
+  if (G.xcd_map) {
+    const int n = gridDim.x, q = n >> 3, r = n & 7, c = bid & 7;
+    bid = c * q + min(c, r) + (bid >> 3);
+  }
+  int pi = 0;
+#pragma unroll
+  for (int i = 1; i < kMaxGroup; ++i)
+    if (i < G.n && bid >= G.p[i].block_begin) pi = i;
+  const Problem& P = G.p[pi];
+  const int local = bid - P.block_begin;
+  const int tiles = P.tiles_m * P.tiles_n;
+  const int slice = local / tiles;
+  if (slice >= P.S) return;
+  const int tile = local - slice * tiles;
+  const int tm = tile / P.tiles_n, tn = tile - tm * P.tiles_n;
+  const int m0 = tm * 128, n0 = tn * 128;
+  const int64_t r_begin = (int64_t)slice * P.rows_per_slice;
+  const int64_t r_end = min(P.R, r_begin + P.rows_per_slice);
+  const int NS = (int)((r_end - r_begin) / WS_STAGE);           // full stages
+  const int tail = (int)((r_end - r_begin) - (int64_t)NS * WS_STAGE);
+  const int t = threadIdx.x, lane = t & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
+  const int li = lane & 31, kh = lane >> 5;
+
+  // row j (0..7) of stage st, this lane: r_begin + 64 st + 16 wave + 8 kh + j, columns 4 li .. 4 li + 3 of the tile's slab
+  const float* const gp = P.g + (r_begin + wave * WS_ROWS + 8 * kh) * P.ldg + m0 + 4 * li;
+  const float* const xp = P.x + (r_begin + wave * WS_ROWS + 8 * kh) * P.ldx + n0 + 4 * li;
+  const int64_t gstage = (int64_t)WS_STAGE * P.ldg, xstage = (int64_t)WS_STAGE * P.ldx;
+  f32x4 Rg[2][8], Rx[2][8];
+#define WD_LOAD(PAR, ST, I)                                                                                        \
+  do {                                                                                                             \
+    if ((I) < 8) Rg[PAR][(I) & 7] = *reinterpret_cast<const f32x4*>(gp + (ST) * gstage + ((I) & 7) * P.ldg);       \
+    else Rx[PAR][(I) & 7] = *reinterpret_cast<const f32x4*>(xp + (ST) * xstage + ((I) & 7) * P.ldx);               \
+  } while (0)
+
+  f32x16 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][j][q] = 0.0f;
+  float bsum[4] = {0.f, 0.f, 0.f, 0.f};
+
+  float st_s0, st_s1;
+  f32x2 st_hb;
+  uint32_t st_hi;
+  const unsigned beg = amax_be(P.g_amax), bex = amax_be(P.x_amax);
+  const float scg = __uint_as_float((268u - beg) << 23), scx = __uint_as_float((268u - bex) << 23);     // 2^(141 - be)
+  // the split of one pair of values in three instalments (k_wgrad_stream's fp16 form; scalar on purpose: 6 VALU per pair).
+  // (Measured and dropped: the pair as four v_fma_mix{lo,hi}_f16 through inline asm -- 4 VALU per pair, bit-identical, but the
+  // hazard s_nops the compiler puts around asm it cannot see into made the kernel 8 % SLOWER.)
+  auto split_part = [&](int part, float v0, float v1, int d, Pieces& out, float* bs, float bw) __attribute__((always_inline)) {
+    const float sc = bs ? scg : scx;
+    if (part == 0) {
+      if (bs) *bs = fmaf(v0 + v1, bw, *bs);
+      st_s0 = v0 * sc;
+      st_s1 = v1 * sc;
+      st_hi = cvt_pk_f16_rne(st_s0, st_s1);
+      out.p[0][d] = st_hi;
+    } else if (part == 1) {
+      st_hb = __builtin_convertvector(__builtin_bit_cast(f16x2, st_hi), f32x2);
+    } else {
+      out.p[1][d] = cvt_pk_f16_rne(st_s0 - st_hb[0], st_s1 - st_hb[1]);
+    }
+  };
+  constexpr int NT = 3;
+  constexpr int TA16[3] = {1, 0, 0}, TB16[3] = {0, 1, 0};                 // lo*hi, hi*lo, hi*hi
+  auto mfma = [&](const Pieces& a, const Pieces& b, int term, f32x16& c) __attribute__((always_inline)) {
+    c = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a.p[TA16[term]]), __builtin_bit_cast(f16x8, b.p[TB16[term]]), c, 0, 0, 0);
+  };
+
+  Pieces A01[2][2], A23[2], B[4];
+
+  if (NS > 0) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) WD_LOAD(0, 0, i);
+#pragma unroll
+    for (int i = 0; i < 16; ++i) WD_LOAD(1, min(1, NS - 1), i);
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int part = 0; part < 3; ++part) {
+          split_part(part, Rg[0][2 * d][f], Rg[0][2 * d + 1][f], d, A01[0][f], &bsum[f], 1.0f);
+        }
+#pragma unroll
+    for (int f = 0; f < 2; ++f)
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int part = 0; part < 3; ++part) split_part(part, Rx[0][2 * d][f], Rx[0][2 * d + 1][f], d, B[f], nullptr, 0.0f);
+    __builtin_amdgcn_sched_barrier(0);
+  }
+
+#define WD_GROUP(AI0, AI1, AI2, AI3, J0, J1, J2, J3, I0, I1, I2, I3, FILL)                              \
+  _Pragma("unroll") for (int m = 0; m < 4 * NT; ++m) {                                                   \
+    const int term = m >> 2, pr = m & 3;                                                                \
+    if (pr == 0) mfma(AI0, B[J0], term, acc[I0][J0]);                                                   \
+    if (pr == 1) mfma(AI1, B[J1], term, acc[I1][J1]);                                                   \
+    if (pr == 2) mfma(AI2, B[J2], term, acc[I2][J2]);                                                   \
+    if (pr == 3) mfma(AI3, B[J3], term, acc[I3][J3]);                                                   \
+    FILL(2 * m); FILL(2 * m + 1);                                                                       \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+  }
+
+  // Stage s, its rows in register set C (the next stage's in set C ^ 1):
+  //   group 1: pairs (0,0)(1,0)(0,1)(1,1) | split A2, A3 of s
+  //   group 2: pairs (2,0)(2,1)(3,0)(3,1) | split B2, B3 of s                      -> set C is free
+  //   group 3: pairs (0,2)(1,2)(0,3)(1,3) | request stage s+2 into set C; split A0, A1 of s+1 (into the other piece set)
+  //   group 4: pairs (2,2)(3,2)(2,3)(3,3) | split B0, B1 of s+1 (B[0], B[1] are free after group 2)
+#define WD_STAGE_BODY(S, C)                                                                               \
+  {                                                                                                       \
+    const int st2 = min((S) + 2, NS - 1);                                                                 \
+    const float bw_next = (S) + 1 < NS ? 1.0f : 0.0f;                                                     \
+    auto fill1 = [&](int m) __attribute__((always_inline)) {                                              \
+      const int f = 2 + m / 12, d = (m % 12) / 3;                                                         \
+      split_part(m % 3, Rg[C][2 * d][f], Rg[C][2 * d + 1][f], d, A23[m / 12], &bsum[f], 1.0f);             \
+    };                                                                                                    \
+    WD_GROUP(A01[C][0], A01[C][1], A01[C][0], A01[C][1], 0, 0, 1, 1, 0, 1, 0, 1, fill1)                   \
+    auto fill2 = [&](int m) __attribute__((always_inline)) {                                              \
+      const int f = 2 + m / 12, d = (m % 12) / 3;                                                         \
+      split_part(m % 3, Rx[C][2 * d][f], Rx[C][2 * d + 1][f], d, B[f], nullptr, 0.0f);                    \
+    };                                                                                                    \
+    WD_GROUP(A23[0], A23[0], A23[1], A23[1], 0, 1, 0, 1, 2, 2, 3, 3, fill2)                               \
+    auto fill3 = [&](int m) __attribute__((always_inline)) {                                              \
+      const int f = m / 12, d = (m % 12) / 3;                                                             \
+      if (m < 16) WD_LOAD(C, st2, m);                                                                     \
+      split_part(m % 3, Rg[(C) ^ 1][2 * d][f], Rg[(C) ^ 1][2 * d + 1][f], d, A01[(C) ^ 1][f], &bsum[f], bw_next); \
+    };                                                                                                    \
+    WD_GROUP(A01[C][0], A01[C][1], A01[C][0], A01[C][1], 2, 2, 3, 3, 0, 1, 0, 1, fill3)                   \
+    auto fill4 = [&](int m) __attribute__((always_inline)) {                                              \
+      const int f = m / 12, d = (m % 12) / 3;                                                             \
+      split_part(m % 3, Rx[(C) ^ 1][2 * d][f], Rx[(C) ^ 1][2 * d + 1][f], d, B[f], nullptr, 0.0f);         \
+    };                                                                                                    \
+    WD_GROUP(A23[0], A23[0], A23[1], A23[1], 2, 3, 2, 3, 2, 2, 3, 3, fill4)                               \
+  }
+
+  for (int s = 0; s < NS; s += 2) {
+    WD_STAGE_BODY(s, 0)
+    if (s + 1 < NS) {
+      WD_STAGE_BODY(s + 1, 1)
+    }
+  }
+#undef WD_STAGE_BODY
+
+  if (tail > 0) {
+    // the last slice's rows past a multiple of 64: one unpipelined stage, rows past the end contribute zeros (g) / any
+    // finite row (x: the last valid one)
+    const int64_t rt = r_begin + (int64_t)NS * WS_STAGE + wave * WS_ROWS + 8 * kh;
+    Pieces TAp[4];
+    float ra[4][8], rb[4][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int64_t r = rt + j;
+      const bool ok = r < r_end;
+      const f32x4 gv = *reinterpret_cast<const f32x4*>(P.g + (ok ? r : r_end - 1) * P.ldg + m0 + 4 * li);
+      const f32x4 xv = *reinterpret_cast<const f32x4*>(P.x + (ok ? r : r_end - 1) * P.ldx + n0 + 4 * li);
+#pragma unroll
+      for (int f = 0; f < 4; ++f) {
+        ra[f][j] = ok ? gv[f] : 0.0f;
+        rb[f][j] = xv[f];
+      }
+    }
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int part = 0; part < 3; ++part) {
+          split_part(part, ra[f][2 * d], ra[f][2 * d + 1], d, TAp[f], &bsum[f], 1.0f);
+        }
+#pragma unroll
+    for (int f = 0; f < 4; ++f)
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int part = 0; part < 3; ++part) split_part(part, rb[f][2 * d], rb[f][2 * d + 1], d, B[f], nullptr, 0.0f);
+#pragma unroll
+    for (int term = 0; term < NT; ++term)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) mfma(TAp[i], B[j], term, acc[i][j]);
+  }
+#undef WD_GROUP
+#undef WD_LOAD
+
+  // ---- the four waves' partial tiles summed through LDS in wave order, one g fragment (a) per pass: [wave][b][lane][16].
+  // Wave w finishes elements q = 4 w .. 4 w + 3 of all four b: its lane's four b-values of an element are the x columns
+  // 4 li .. 4 li + 3 of g column 4 ri + a -- one 16-byte store, 512 contiguous bytes per output row and wave-instruction.
+  float* const red = reinterpret_cast<float*>(lds);
+  float* po = P.part + (int64_t)slice * P.M * P.Nn;
+  const float ug = __uint_as_float((beg - 14u) << 23), ux = __uint_as_float((bex - 14u) << 23);
+#pragma unroll
+  for (int a = 0; a < 4; ++a) {
+    __syncthreads();                                        // LDS is free (previous pass read)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      float* dst = red + ((wave * 4 + b) * 64 + lane) * 16;
+#pragma unroll
+      for (int q = 0; q < 16; q += 4)
+        *reinterpret_cast<float4*>(dst + q) = make_float4(acc[a][b][q], acc[a][b][q + 1], acc[a][b][q + 2], acc[a][b][q + 3]);
+    }
+    __syncthreads();
+    float sum[4][4];
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) sum[b][e] = 0.0f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) {
+        const float4 v = *reinterpret_cast<const float4*>(red + ((w * 4 + b) * 64 + lane) * 16 + 4 * wave);
+        sum[b][0] += v.x; sum[b][1] += v.y; sum[b][2] += v.z; sum[b][3] += v.w;
+      }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int q = 4 * wave + e;
+      const int ri = (q & 3) + 8 * (q >> 2) + 4 * kh;
+      const int row = m0 + 4 * ri + a;
+      float4 o;
+      o.x = (sum[0][e] * ug) * ux; o.y = (sum[1][e] * ug) * ux; o.z = (sum[2][e] * ug) * ux; o.w = (sum[3][e] * ug) * ux;
+      *reinterpret_cast<float4*>(po + (int64_t)row * P.Nn + n0 + 4 * li) = o;
+    }
+  }
+  if (P.bias_part && tn == 0) {
+    __syncthreads();
+    float* sc = reinterpret_cast<float*>(lds);              // [wave][kh][128 columns]
+#pragma unroll
+    for (int i = 0; i < 4; ++i) sc[(wave * 2 + kh) * 128 + 4 * li + i] = bsum[i];
+    __syncthreads();
+    if (t < 128) {
+      float a = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) a += sc[q * 128 + t];
+      P.bias_part[(int64_t)slice * P.M + m0 + t] = a;
+    }
+  }
+}
+
 // out[i] = sum_s part[s][i] in slice order; bias likewise, by the first threads of each problem.  VEC = 4 (round 5): a
 // thread owns four neighbouring outputs and pulls each slice with one 16-byte load, all S of them independent -- the
 // one-float form moved the 16 MB of partials of a GPS block at 1.3 TB/s (12.7 us per launch, rocprofv3 round 5), a
@@ -764,7 +1032,13 @@ int launch_group(Group& G, float* ws, hipStream_t s, const char* who) {
     G.xcd_map = 1;          // (0: launch order -- the round-3 A/B, profiles/r03_pmc_wgrad_xcdmap0.txt)
     bool f16 = true;                 // every problem of the launch carries its operands' max|.| words
     for (int i = 0; i < G.n; ++i) f16 = f16 && G.p[i].g_amax && G.p[i].x_amax;
-    if (f16) k_wgrad_stream<true><<<(unsigned)blocks, 256, WS_LDS, s>>>(G);
+    static const bool direct = [] { const char* e = getenv("GPS_WGRAD_DIRECT"); return !(e && *e && atoi(e) == 0); }();
+    if (f16 && direct) {
+      static const hipError_t attrd = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_wgrad_direct),
+                                                          hipFuncAttributeMaxDynamicSharedMemorySize, WD_LDS);
+      GPS_REQUIRE(attrd == hipSuccess, "%s: cannot reserve %d bytes of LDS", who, WD_LDS);
+      k_wgrad_direct<<<(unsigned)blocks, 256, WD_LDS, s>>>(G);
+    } else if (f16) k_wgrad_stream<true><<<(unsigned)blocks, 256, WS_LDS, s>>>(G);
     else k_wgrad_stream<false><<<(unsigned)blocks, 256, WS_LDS, s>>>(G);
   } else
     k_wgrad<true><<<(unsigned)blocks, 256, 0, s>>>(G);

@@ -1,6 +1,8 @@
 """GPU parity tests of the individual HIP operators, through the C ABI (ctypes), against CPU
 restatements.  Tolerances: bit-exact for indices; 1e-5 absolute on O(1) activations and 1e-5
 relative-to-max on gradients (BASELINE.json north_star: 'within 1e-5 fp32')."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -1009,6 +1011,52 @@ def test_gin_aggregate_matches_index_add():
         (out * w.cuda()).sum().backward()
         assert_close(out, ref, Tol.ACT, "gin out")
         assert_close(xg.grad, xr.grad, Tol.GRAD_REL, "gin d_x", rel_to_max=True)
+
+
+_WGRAD_ID_SCRIPT = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[2])
+from graphgps_amd import lib as L_, gemm as G
+from graphgps_amd.lib import check, current_stream
+dev = torch.device('cuda:0'); L = L_.load()
+gen = torch.Generator().manual_seed(1)
+out = []
+for (R, M, Nn) in ((7569, 2688, 384), (15348, 384, 384), (7569, 384, 768), (1000, 128, 128), (333, 256, 128), (64, 128, 128), (70, 128, 256)):
+    g = torch.randn(R, M, generator=gen).to(dev); x = torch.randn(R, Nn, generator=gen).to(dev)
+    w = G.absmax([g, x])
+    gw = torch.empty(M, Nn, device=dev); gb = torch.empty(M, device=dev)
+    ws = torch.empty(max(L.gps_wgrad_workspace_floats(R, M, Nn), 4), device=dev)
+    check(L.gps_wgrad16(g.data_ptr(), g.stride(0), x.data_ptr(), x.stride(0), R, M, Nn, w[0].data_ptr(), w[1].data_ptr(),
+                        gw.data_ptr(), gb.data_ptr(), ws.data_ptr(), current_stream(dev)), 'gps_wgrad16')
+    torch.cuda.synchronize()
+    ref = g.double().t() @ x.double()
+    assert float((gw.double() - ref).abs().max() / ref.abs().max()) < 2e-6
+    assert float((gb.double() - g.double().sum(0)).abs().max() / g.double().sum(0).abs().max()) < 2e-6
+    out.append((gw.cpu(), gb.cpu()))
+torch.save(out, sys.argv[1])
+"""
+
+
+def test_wgrad_register_path_is_bit_identical_to_the_lds_path(tmp_path):
+    """csrc/wgrad.hip round 6: k_wgrad_direct (operands through registers, fragments = the four values of a 16-byte load,
+    outputs stored as the permutation that implies) against k_wgrad_stream (LDS-DMA ring + ds_read fragments,
+    GPS_WGRAD_DIRECT=0): every output element is the same sum of the same products in the same order -- weight and bias
+    gradients bit-identical at the block's shapes, short slices and ragged row counts (the tail stage); both within 2e-6 of
+    fp64.  The switch is read once per process, so each form runs in a child."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "wg.py"
+    script.write_text(_WGRAD_ID_SCRIPT)
+    outs = []
+    for v in ("1", "0"):
+        f = tmp_path / f"wg{v}.pt"
+        env = dict(os.environ, GPS_WGRAD_DIRECT=v)
+        r = subprocess.run([sys.executable, str(script), str(f), root], env=env, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(torch.load(f))
+    for (gw1, gb1), (gw0, gb0) in zip(*outs):
+        assert torch.equal(gw1, gw0) and torch.equal(gb1, gb0)
 
 
 @pytest.mark.parametrize("p0,p1,cin", [
