@@ -879,14 +879,14 @@ __device__ __forceinline__ void ring16_body(const PanelArgs& P, const int bid) {
   f32x2 st_hb;
   uint32_t st_hi;
   auto split_part = [&](int part, const f32x4 (&raw)[2], int d, Ring16A& out) __attribute__((always_inline)) {
-    const f32x2 v = (f32x2){raw[d >> 1][(d & 1) * 2], raw[d >> 1][(d & 1) * 2 + 1]};
+    const float v0 = raw[d >> 1][(d & 1) * 2], v1 = raw[d >> 1][(d & 1) * 2 + 1];
     if (part == 0) {
-      st_hi = __builtin_bit_cast(uint32_t, __builtin_convertvector(v * sa, f16x2));
+      st_hi = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){v0 * sa, v1 * sa}, f16x2));
       out.p[0][d] = st_hi;
     } else if (part == 1) {
       st_hb = __builtin_convertvector(__builtin_bit_cast(f16x2, st_hi), f32x2);
     } else {
-      out.p[1][d] = __builtin_bit_cast(uint32_t, __builtin_convertvector(v * sa - st_hb, f16x2));
+      out.p[1][d] = __builtin_bit_cast(uint32_t, __builtin_convertvector((f32x2){fmaf(v0, sa, -st_hb[0]), fmaf(v1, sa, -st_hb[1])}, f16x2));
     }
   };
 
