@@ -61,7 +61,7 @@ MFMA_BF16_PEAK_TF = 2500.0   # v_mfma_f32_32x32x16_bf16 dense peak (MI355X_MICRO
 HBM_ACHIEVABLE_GBS = 6300.0  # MI355X_MICROARCH.md: 6.29 TB/s measured float4 copy -- the byte rate the STEP floor is priced at
 
 # in-step kernel name -> entry of `kernels` that carries its work (flops / bytes per launch)
-_DOMINANT_TABLE = (("k_wgrad_stream", "wgrad_grouped"), ("k_gatedgcn_fwd", "gatedgcn_fwd"), ("k_gatedgcn_bwd", "gatedgcn_bwd"),
+_DOMINANT_TABLE = (("k_wgrad_direct", "wgrad_grouped"), ("k_wgrad_stream", "wgrad_grouped"), ("k_gatedgcn_fwd", "gatedgcn_fwd"), ("k_gatedgcn_bwd", "gatedgcn_bwd"),
                    ("k_sattn_fwd", "seg_attn_fwd"), ("k_attn_fwd", "seg_attn_fwd"), ("k_sattn_bwd", "seg_attn_bwd"),
                    ("k_attn_bwd", "seg_attn_bwd"))
 
@@ -1140,7 +1140,7 @@ def main():
                     pmc_static = json.load(open(pmc))     # timing never share a run): read from the committed file
                 dom = dominant_roofline(in_step, kr, pmc_static, layers_n) if in_step else None
                 if dom is None:                   # no in-step records: the largest kernel of the last committed profile
-                    dom = dominant_roofline({"k_wgrad_stream": (kr["wgrad_grouped"]["ms"], layers_n)}, kr, pmc_static, layers_n)
+                    dom = dominant_roofline({"k_wgrad_direct": (kr["wgrad_grouped"]["ms"], layers_n)}, kr, pmc_static, layers_n)
                 out["roofline"] = dom
                 from graphgps_amd import gemm as _gemm
                 out["roofline_step"] = step_roofline(shape["N"], shape["E"], shape["d"], shape["H"], layers_n,
