@@ -49,18 +49,27 @@ __global__ __launch_bounds__(kThreads) void k_rwse(const int32_t* __restrict__ r
   // registers + barrier when in LDS
   auto multiply = [&]() {
     if (in_lds) {
-      // each thread owns whole output elements; accumulate all of them first, then write
-      float acc[(kLdsNodes * kLdsNodes + kThreads - 1) / kThreads];
-      int cnt = 0;
-      for (int i = t; i < n * n; i += kThreads, ++cnt) {
-        const int r = i / n, c = i - r * n;
+      // each thread owns whole output elements; accumulate all of them first, then write.  The element loop is unrolled
+      // over its compile-time maximum so that `acc` is 64 registers, not a private array in scratch memory (it was:
+      // the only kernel of the library with a scratch segment).
+      constexpr int kAcc = (kLdsNodes * kLdsNodes + kThreads - 1) / kThreads;
+      float acc[kAcc];
+#pragma unroll
+      for (int cnt = 0; cnt < kAcc; ++cnt) {
+        const int i = t + cnt * kThreads;
         float s = 0.0f;
-        for (int k = 0; k < n; ++k) s += A[r * n + k] * P[k * n + c];
+        if (i < n * n) {
+          const int r = i / n, c = i - r * n;
+          for (int k = 0; k < n; ++k) s += A[r * n + k] * P[k * n + c];
+        }
         acc[cnt] = s;
       }
       __syncthreads();
-      cnt = 0;
-      for (int i = t; i < n * n; i += kThreads, ++cnt) A[i] = acc[cnt];
+#pragma unroll
+      for (int cnt = 0; cnt < kAcc; ++cnt) {
+        const int i = t + cnt * kThreads;
+        if (i < n * n) A[i] = acc[cnt];
+      }
       __syncthreads();
     } else {
       for (int i = t; i < n * n; i += kThreads) {
