@@ -747,8 +747,8 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_direct(const Group G) {
 
   // Stage s, its rows in register set C (the next stage's in set C ^ 1):
   //   group 1: pairs (0,0)(1,0)(0,1)(1,1) | split A2, A3 of s
-  //   group 2: pairs (2,0)(2,1)(3,0)(3,1) | split B2, B3 of s                      -> set C is free
-  //   group 3: pairs (0,2)(1,2)(0,3)(1,3) | request stage s+2 into set C; split A0, A1 of s+1 (into the other piece set)
+  //   group 2: pairs (2,0)(2,1)(3,0)(3,1) | split B2, B3 of s; request the g rows of stage s+2 into set C (free since group 1)
+  //   group 3: pairs (0,2)(1,2)(0,3)(1,3) | request its x rows (free since group 2); split A0, A1 of s+1 (into the other piece set)
   //   group 4: pairs (2,2)(3,2)(2,3)(3,3) | split B0, B1 of s+1 (B[0], B[1] are free after group 2)
 #define WD_STAGE_BODY(S, C)                                                                               \
   {                                                                                                       \
@@ -761,12 +761,13 @@ __global__ __launch_bounds__(256, 1) void k_wgrad_direct(const Group G) {
     WD_GROUP(A01[C][0], A01[C][1], A01[C][0], A01[C][1], 0, 0, 1, 1, 0, 1, 0, 1, fill1)                   \
     auto fill2 = [&](int m) __attribute__((always_inline)) {                                              \
       const int f = 2 + m / 12, d = (m % 12) / 3;                                                         \
+      if (m < 8) WD_LOAD(C, st2, m);             /* the g rows of set C are free since group 1 */           \
       split_part(m % 3, Rx[C][2 * d][f], Rx[C][2 * d + 1][f], d, B[f], nullptr, 0.0f);                    \
     };                                                                                                    \
     WD_GROUP(A23[0], A23[0], A23[1], A23[1], 0, 1, 0, 1, 2, 2, 3, 3, fill2)                               \
     auto fill3 = [&](int m) __attribute__((always_inline)) {                                              \
       const int f = m / 12, d = (m % 12) / 3;                                                             \
-      if (m < 16) WD_LOAD(C, st2, m);                                                                     \
+      if (m < 8) WD_LOAD(C, st2, 8 + m);         /* ... its x rows since group 2 */                          \
       split_part(m % 3, Rg[(C) ^ 1][2 * d][f], Rg[(C) ^ 1][2 * d + 1][f], d, A01[(C) ^ 1][f], &bsum[f], bw_next); \
     };                                                                                                    \
     WD_GROUP(A01[C][0], A01[C][1], A01[C][0], A01[C][1], 2, 2, 3, 3, 0, 1, 0, 1, fill3)                   \
