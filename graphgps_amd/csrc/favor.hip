@@ -1358,8 +1358,7 @@ int gps_favor_fwd(const float* qkv, int64_t ld_qkv, const float* proj, int m, co
               "gps_favor_fwd: null buffer");
   hipStream_t s = gps::as_stream(stream);
   const float c = powf((float)DH, -0.25f), ratio = 1.0f / sqrtf((float)m);
-  if (hipMemsetAsync(kmax, 0, sizeof(uint64_t) * B * H, s) != hipSuccess)
-    return gps::launch_status("gps_favor_fwd/memset");
+  gps::fill_words(kmax, 0u, (size_t)(2 * B * H), s);      // (a fill kernel, not a memset node: gps_common.hpp fill_words)
   const int64_t n_work = max_tiles * H;
   static const bool lds_ok = favor_lds_ready(&k_favor_kmax<true>);
   const bool lp = lds_ok && favor_lds(n_work);

@@ -48,6 +48,12 @@ __device__ __forceinline__ void amax_raise(uint32_t* rec, uint32_t bits, unsigne
 __device__ __forceinline__ void amax_raise(uint32_t* rec, uint32_t bits) { amax_raise(rec, bits, blockIdx.x); }
 #endif
 
+// Fill `words` 32-bit words with `value` by a KERNEL launch instead of hipMemsetAsync: a captured step then holds kernel
+// nodes only.  (Round 6 measured it: under rocprofv3 the memset nodes at the head of the replayed step sat behind 75 - 105 us
+// idle gaps, ~260 us per step, and the fill kernels do not -- but the untraced step is the same 8.18 ms either way: the gaps
+// are the tracer's, not the step's.  Kept because one node type is simpler to reason about.)
+void fill_words(void* dst, uint32_t value, size_t words, hipStream_t stream);
+
 static inline unsigned grid_for(int64_t work, int block) {
   return static_cast<unsigned>((work + block - 1) / block);
 }

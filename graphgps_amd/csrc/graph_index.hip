@@ -162,15 +162,13 @@ int gps_graph_index_build(const int64_t* edge_index, int64_t N, int64_t E, int32
   // each in a replayed step (~5 us apiece).  A caller that lays them out back to back -- rowptr_dst | rowptr_src | ws,
   // what ops.build_graph_index does since round 5 -- gets ONE fill.
   const bool packed = rowptr_src == rowptr_dst + (N + 1) && ws == static_cast<void*>(rowptr_src + (N + 1));
+  // (fill KERNELS, not hipMemsetAsync: a memset node stalls a replayed graph for ~80 - 100 us, gps_common.hpp fill_words)
   if (packed && N > 0 && E > 0) {
-    if (hipMemsetAsync(rowptr_dst, 0, sizeof(int32_t) * (2 * (N + 1) + 2 * N), s) != hipSuccess)
-      return gps::launch_status("gps_graph_index_build/memset");
+    gps::fill_words(rowptr_dst, 0u, (size_t)(2 * (N + 1) + 2 * N), s);
   } else {
-    if (hipMemsetAsync(rowptr_dst, 0, sizeof(int32_t) * (N + 1), s) != hipSuccess ||
-        hipMemsetAsync(rowptr_src, 0, sizeof(int32_t) * (N + 1), s) != hipSuccess)
-      return gps::launch_status("gps_graph_index_build/memset");
-    if (N > 0 && E > 0 && hipMemsetAsync(ws, 0, sizeof(int32_t) * 2 * N, s) != hipSuccess)
-      return gps::launch_status("gps_graph_index_build/memset-ws");
+    gps::fill_words(rowptr_dst, 0u, (size_t)(N + 1), s);
+    gps::fill_words(rowptr_src, 0u, (size_t)(N + 1), s);
+    if (N > 0 && E > 0) gps::fill_words(ws, 0u, (size_t)(2 * N), s);
   }
   if (N == 0 || E == 0) return gps::launch_status("gps_graph_index_build");
   int32_t* cur_dst = static_cast<int32_t*>(ws);
@@ -197,13 +195,12 @@ int gps_attn_tile_map(const int32_t* ptr, int64_t B, int64_t max_tiles, int32_t*
   GPS_REQUIRE(ptr && tile_graph && tile_row0 && B >= 0 && max_tiles >= 0,
               "gps_attn_tile_map: bad arguments");
   hipStream_t s = gps::as_stream(stream);
-  if (max_tiles > 0 && tile_row0 == tile_graph + max_tiles) {      // back to back: one fill node instead of two
-    if (hipMemsetAsync(tile_graph, 0xFF, sizeof(int32_t) * 2 * max_tiles, s) != hipSuccess)
-      return gps::launch_status("gps_attn_tile_map/memset");
-  } else if (max_tiles > 0 &&
-             (hipMemsetAsync(tile_graph, 0xFF, sizeof(int32_t) * max_tiles, s) != hipSuccess ||
-              hipMemsetAsync(tile_row0, 0xFF, sizeof(int32_t) * max_tiles, s) != hipSuccess))
-    return gps::launch_status("gps_attn_tile_map/memset");
+  if (max_tiles > 0 && tile_row0 == tile_graph + max_tiles) {      // back to back: one fill launch instead of two
+    gps::fill_words(tile_graph, 0xFFFFFFFFu, (size_t)(2 * max_tiles), s);
+  } else if (max_tiles > 0) {
+    gps::fill_words(tile_graph, 0xFFFFFFFFu, (size_t)max_tiles, s);
+    gps::fill_words(tile_row0, 0xFFFFFFFFu, (size_t)max_tiles, s);
+  }
   if (B > 0) k_tile_map<<<gps::grid_for(B, 256), 256, 0, s>>>(ptr, B, max_tiles, tile_graph, tile_row0);
   return gps::launch_status("gps_attn_tile_map");
 }
