@@ -197,6 +197,13 @@ struct PanelArgs {
   uint32_t* c_amax;        // optional: raised to max|C| over the stored elements (the word of the NEXT GEMM that reads C)
   const int32_t* m_dev;    // epilogue 3, padded batches: the number of REAL rows (device word; rows past it are stored but kept
                            // out of the column statistics), or nullptr
+  // epilogue 4 (k_gemm_ring16 only): C is the OUTPUT GRADIENT g of two BatchNorm1d's over the tensors cs_z / cs_z2 (same
+  // shape as C: norm1_local + norm1_attn of a GPS block), and their backward column sums S1 = sum_rows g,
+  // S2 = sum_rows g zhat (zhat = (z - mean) rstd) leave with it, completed in-launch by one SUMS tree per column panel
+  // (st_ws / st_stride / st_tick as epilogue 3) into st_mean (S1), st_rstd (S2), st_rmean (S1 again), st_rvar (S2 of cs_z2).
+  const float *cs_z, *cs_z2;
+  int64_t cs_ldz, cs_ldz2;
+  const float *cs_mu, *cs_rs, *cs_mu2, *cs_rs2;
 };
 
 // ------------------------------------------------------------------------------------------------------------
@@ -295,10 +302,12 @@ __device__ __forceinline__ void ring_store(const PanelArgs& P, const f32x16 (&ac
   const float inv_keep = drop ? 1.0f / (1.0f - P.p_drop) : 1.0f;
   const int64_t mreal = (EPI == 3 && P.m_dev) ? min((int64_t)*P.m_dev, P.M) : P.M;
   float bv[NJ];
+  float cmu[NJ], crs[NJ], cmu2[NJ], crs2[NJ];        // epilogue 4: the BatchNorms' column constants
 #pragma unroll
   for (int j = 0; j < NJ; ++j) {         // never null here: the host passes g_zero_bias
     const int col = n0 + wn * (32 * NJ) + j * 32 + li;
     bv[j] = P.bias[EDGE ? min(col, P.N - 1) : col];
+    if (EPI == 4) { cmu[j] = P.cs_mu[col]; crs[j] = P.cs_rs[col]; cmu2[j] = P.cs_mu2[col]; crs2[j] = P.cs_rs2[col]; }
   }
   // One 32-row block at a time: EVERY addend / mask value of the block is requested before the first store.  The addend
   // may alias C (in-place accumulation), so the compiler cannot move a load above an earlier store by itself, and one
@@ -306,7 +315,7 @@ __device__ __forceinline__ void ring_store(const PanelArgs& P, const f32x16 (&ac
   // re-reads elements it writes itself, so loading ahead is safe.
 #pragma unroll
   for (int mb = 0; mb < MB; ++mb) {
-    float cin[NJ][16], msk[NJ][16];
+    float cin[NJ][16], msk[NJ][16], zz[NJ][16], zz2[NJ][16];
 #pragma unroll
     for (int j = 0; j < NJ; ++j) {
       const int col0 = n0 + wn * (32 * NJ) + j * 32 + li;
@@ -317,6 +326,10 @@ __device__ __forceinline__ void ring_store(const PanelArgs& P, const f32x16 (&ac
         const int64_t rc = FULL ? row : (row < P.M ? row : P.M - 1);   // clamped: loads unconditional, the store predicated
         if (HAS_CIN) cin[j][q] = __builtin_nontemporal_load(P.Cin + rc * P.ldcin + col);
         if (EPI == 2) msk[j][q] = __builtin_nontemporal_load(P.mask_src + rc * P.ldmask + col);
+        if (EPI == 4) {                 // (both are read again by the apply behind this launch: cached loads)
+          zz[j][q] = P.cs_z[rc * P.cs_ldz + col];
+          zz2[j][q] = P.cs_z2[rc * P.cs_ldz2 + col];
+        }
       }
     }
 #pragma unroll
@@ -342,6 +355,12 @@ __device__ __forceinline__ void ring_store(const PanelArgs& P, const f32x16 (&ac
           const float t = row < mreal ? v - sk[j] : 0.0f;     // (mreal <= M: also the ragged last tile's guard)
           s1[j] += t;
           s2[j] += t * t;
+        }
+        if (EPI == 4) {                 // BatchNorm-backward column sums of the gradient this tile stores (sk = S1, s1 / s2 = S2)
+          const float g = (FULL || row < P.M) ? v : 0.0f;
+          sk[j] += g;
+          s1[j] += g * ((zz[j][q] - cmu[j]) * crs[j]);
+          s2[j] += g * ((zz2[j][q] - cmu2[j]) * crs2[j]);
         }
         const bool live = (FULL || row < P.M) && (!EDGE || col < P.N);
         amx = live ? fmaxf(amx, fabsf(v)) : amx;        // (one v_max with |.|: dead code wherever the caller drops amx)
@@ -410,6 +429,50 @@ __device__ __forceinline__ void ring_stats(const PanelArgs& P, int rt, int panel
     if (t == 0) tr::st_sc1(T.pcnt + rt, nn);
   }
   tr::arrive<2, tr::STATS, 16, NTH>(T, rt, TN, lds);
+}
+
+// Column SUMS of the panel (EPI == 4): NV plain sums per column (S1, S2, S2 of the second BatchNorm); the two halves of
+// a wave (kh) meet by a shuffle, the two row-waves through LDS, the tile's record goes out write-through and the panel's
+// SUMS tree (records = row tiles) completes in-launch.  Rows past M contributed zeros (ring_store).
+template <int MB, int NJ, int NV>
+__device__ __forceinline__ void ring_sums(const PanelArgs& P, int rt, int panel, int wm, int wn, int li, int kh,
+                                          float (&s0)[NJ], float (&s1)[NJ], float (&s2)[NJ], float* lds) {
+  constexpr int TN = 64 * NJ;
+  __syncthreads();      // every wave is past its final vmcnt(0): no LDS-DMA of the main loop can still land in the ring
+  float* rec = lds + 16;                              // [2 row-waves][NV][TN]
+#pragma unroll
+  for (int j = 0; j < NJ; ++j) {
+    s0[j] += __shfl_xor(s0[j], 32);
+    s1[j] += __shfl_xor(s1[j], 32);
+    if (NV > 2) s2[j] += __shfl_xor(s2[j], 32);
+    if (kh == 0) {
+      const int col = wn * (32 * NJ) + j * 32 + li;
+      rec[(wm * NV + 0) * TN + col] = s0[j];
+      rec[(wm * NV + 1) * TN + col] = s1[j];
+      if (NV > 2) rec[(wm * NV + 2) * TN + col] = s2[j];
+    }
+  }
+  __syncthreads();
+  tr::Tree T{};
+  T.P = P.row_tiles; T.NV = NV; T.mode = tr::SUMS;
+  T.fan = tr::fan_for(T.P);
+  T.NG = (T.P + T.fan - 1) / T.fan;
+  float* w = P.st_ws + (size_t)panel * P.st_stride;
+  T.part = w; w += tr::pad4((size_t)T.P * NV * TN);
+  T.pcnt = w; w += tr::pad4((size_t)2 * T.P);
+  T.grp = w; w += tr::pad4((size_t)T.NG * NV * TN);
+  T.gcnt = w;
+  T.tick = P.st_tick + (size_t)panel * tr::kSyncWords;
+  const int n0 = panel * TN;
+  T.o0 = P.st_mean + n0; T.o1 = P.st_rstd + n0;
+  T.o2 = NV > 2 ? P.st_rmean + n0 : nullptr; T.o3 = NV > 2 ? P.st_rvar + n0 : nullptr;
+  const int t = threadIdx.x;
+  if (t < TN) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v)
+      tr::st_sc1(T.part + ((int64_t)rt * NV + v) * TN + t, rec[(0 * NV + v) * TN + t] + rec[(1 * NV + v) * TN + t]);
+  }
+  tr::arrive<NV, tr::SUMS, 16>(T, rt, TN, lds);
 }
 
 // MB = row blocks of 32 per wave, NJ = column blocks of 32 per wave: the workgroup's panel is (64 * MB) rows x (64 * NJ)
@@ -1007,6 +1070,7 @@ __device__ __forceinline__ void ring16_body(const PanelArgs& P, const int bid) {
   float amx = 0.f;
   ring_epilogue<MB, NJ, EPI, HAS_CIN, EDGE>(P, acc, m0, n0, wm, wn, li, kh, sk, s1, s2, amx);
   if (EPI == 3) ring_stats<MB, NJ>(P, rt, panel, m0, wm, wn, li, kh, sk, s1, s2, reinterpret_cast<float*>(ring));
+  if (EPI == 4) ring_sums<MB, NJ, 3>(P, rt, panel, wm, wn, li, kh, sk, s1, s2, reinterpret_cast<float*>(ring));
   if (P.c_amax) {                                        // workgroup-uniform: max|C| of this tile -> one atomic
     uint32_t m = __float_as_uint(amx);
 #pragma unroll
@@ -1059,7 +1123,8 @@ struct PanelPlan {
 static int panel_prepare(PanelPlan& Q, const float* A, int64_t lda, int64_t M, int K, const uint16_t* image, int N,
                          const float* bias, const float* Cin, int64_t ldcin, float* C, int64_t ldc, int epilogue,
                          const float* mask_src, int64_t ldmask, float p_drop, uint64_t seed, const gps_bn* stats, float* ws,
-                         uint32_t* sync, const uint32_t* a_amax, const uint32_t* w_amax, uint32_t* c_amax, const int32_t* m_dev);
+                         uint32_t* sync, const uint32_t* a_amax, const uint32_t* w_amax, uint32_t* c_amax, const int32_t* m_dev,
+                         const gps_gemm_colsums* cs = nullptr);
 
 // 128-row panels (MB = 2) when they still give every CU a workgroup; 64-column panels always use 64 rows (the only
 // NJ = 1 instantiation).
@@ -1213,19 +1278,21 @@ int gps_gemm16_panel_stats(const float* A, int64_t lda, int64_t M, int K, const 
 static int panel_prepare(PanelPlan& Q, const float* A, int64_t lda, int64_t M, int K, const uint16_t* image, int N,
                          const float* bias, const float* Cin, int64_t ldcin, float* C, int64_t ldc, int epilogue,
                          const float* mask_src, int64_t ldmask, float p_drop, uint64_t seed, const gps_bn* stats, float* ws,
-                         uint32_t* sync, const uint32_t* a_amax, const uint32_t* w_amax, uint32_t* c_amax, const int32_t* m_dev) {
+                         uint32_t* sync, const uint32_t* a_amax, const uint32_t* w_amax, uint32_t* c_amax, const int32_t* m_dev,
+                         const gps_gemm_colsums* cs) {
   GPS_REQUIRE(M >= 1 && gps_gemm_panel_supported(N, K), "gps_gemm_panel: needs N %% 4 == 0 and K %% 4 == 0 (N=%d K=%d)",
               N, K);
   GPS_REQUIRE(A && image && C && lda >= K && ldc >= N && lda % 4 == 0 && al16(A) && al16(image),
               "gps_gemm_panel: null / misaligned buffer");
   GPS_REQUIRE(!Cin || ldcin >= N, "gps_gemm_panel: bad addend stride");
-  GPS_REQUIRE(epilogue >= 0 && epilogue <= 3 && (epilogue != 2 || (mask_src && ldmask >= N)), "gps_gemm_panel: epilogue");
+  GPS_REQUIRE(epilogue >= 0 && epilogue <= 4 && (epilogue != 2 || (mask_src && ldmask >= N)), "gps_gemm_panel: epilogue");
+  GPS_REQUIRE((epilogue == 4) == (cs != nullptr), "gps_gemm_panel: epilogue 4 carries a gps_gemm_colsums");
   GPS_REQUIRE(p_drop >= 0.0f && p_drop < 1.0f, "gps_gemm_panel: p_drop");
   PanelArgs& P = Q.P;
   P = PanelArgs{};
   P.A = A; P.lda = lda; P.M = M; P.K = K; P.N = N; P.Nimg = (int)rg_npad(N, K); P.Bp = image; P.bias = bias; P.Cin = Cin; P.ldcin = ldcin;
   P.C = C; P.ldc = ldc; P.epilogue = epilogue; P.mask_src = mask_src; P.ldmask = ldmask;
-  P.p_drop = epilogue ? p_drop : 0.0f; P.seed = seed; P.salt = gps::dropout_salt();
+  P.p_drop = (epilogue >= 1 && epilogue <= 3) ? p_drop : 0.0f; P.seed = seed; P.salt = gps::dropout_salt();
   P.trace = g_panel_trace;
   P.a_amax = a_amax; P.w_amax = w_amax; P.c_amax = c_amax; P.m_dev = epilogue == 3 ? m_dev : nullptr;
   const bool f16 = a_amax != nullptr;
@@ -1234,7 +1301,7 @@ static int panel_prepare(PanelPlan& Q, const float* A, int64_t lda, int64_t M, i
   // products under per-tensor scales) serve every supported shape.
   const int mb = ring_mb(M, N, K), nj = rg_nj(N, K);
   const bool edge = rg_edge(N, K);
-  GPS_REQUIRE(epilogue != 3 || !edge, "gps_gemm_panel: the statistics epilogue needs whole column panels and k-stages");
+  GPS_REQUIRE(epilogue < 3 || !edge, "gps_gemm_panel: the statistics epilogues need whole column panels and k-stages");
   unsigned grid;
   {
     if (!P.bias) {
@@ -1251,6 +1318,14 @@ static int panel_prepare(PanelPlan& Q, const float* A, int64_t lda, int64_t M, i
       P.st_tick = sync;
       P.st_mean = stats->mean; P.st_rstd = stats->rstd; P.st_rmean = stats->running_mean; P.st_rvar = stats->running_var;
       P.st_eps = stats->eps; P.st_mom = stats->momentum;
+    }
+    if (cs) {      // epilogue 4: BatchNorm-backward column sums of C (checked by gps_gemm16_panel_sums)
+      P.st_ws = cs->ws;
+      P.st_stride = tr::floats_for(P.row_tiles, 3, 64 * nj) + 16;
+      P.st_tick = cs->sync;
+      P.st_mean = cs->sum_g; P.st_rstd = cs->sum_gz; P.st_rmean = cs->sum_g2; P.st_rvar = cs->sum_gz2;
+      P.cs_z = cs->z; P.cs_ldz = cs->ldz; P.cs_mu = cs->bn->mean; P.cs_rs = cs->bn->rstd;
+      P.cs_z2 = cs->z2; P.cs_ldz2 = cs->ldz2; P.cs_mu2 = cs->bn2->mean; P.cs_rs2 = cs->bn2->rstd;
     }
   }
   Q.mb = mb; Q.nj = nj; Q.edge = edge; Q.f16 = f16; Q.grid = grid;
@@ -1367,4 +1442,44 @@ extern "C" int gps_gemm16_panel_pair(const gps_gemm16_problem* first, const gps_
 #undef GPS_PAIR_MB
 #undef GPS_PAIR
   return gps::launch_status("gps_gemm16_panel_pair");
+}
+
+// ---- BatchNorm-backward column sums out of an input-gradient GEMM's epilogue (ABI v10) ----------------------------------------
+static int colsums_tiles(int64_t M, int N, int K) { const int mb = ring_mb(M, N, K); return (int)((M + 64 * mb - 1) / (64 * mb)); }
+extern "C" int gps_gemm_colsums_supported(int64_t M, int N, int K) {
+  if (!gps_gemm_panel_supported(N, K) || rg_edge(N, K) || M < 2 || rg_nj(N, K) < 2) return 0;    // whole panels of 128 / 192 columns
+  return colsums_tiles(M, N, K) <= tr::kMaxParts;
+}
+extern "C" size_t gps_gemm_colsums_floats(int64_t M, int N, int K) {
+  if (!gps_gemm_colsums_supported(M, N, K)) return 0;
+  const int tn = 64 * rg_nj(N, K);
+  return (size_t)(N / tn) * (tr::floats_for(colsums_tiles(M, N, K), 3, tn) + 16);
+}
+extern "C" int gps_gemm16_panel_sums(const gps_gemm16_problem* prob, const gps_gemm_colsums* sums, gps_stream_t stream) {
+  const char* who = "gps_gemm16_panel_sums";
+  GPS_REQUIRE(prob && sums && prob->a_amax && prob->w_amax && prob->M >= 0, "%s: null problem / sums / operand maxima", who);
+  GPS_REQUIRE(prob->Cin, "%s: the input gradient accumulates onto an addend (Cin)", who);
+  const gps_gemm16_problem& p = *prob;
+  const gps_gemm_colsums* cs = sums;
+  GPS_REQUIRE(gps_gemm_colsums_supported(p.M, p.N, p.K), "%s: shape M=%lld N=%d K=%d not served (whole 128 / 192-column panels, M >= 2)",
+              who, (long long)p.M, p.N, p.K);
+  GPS_REQUIRE(cs->z && cs->ldz >= p.N && cs->bn && cs->bn->mean && cs->bn->rstd && cs->sum_g && cs->sum_gz &&
+              cs->z2 && cs->ldz2 >= p.N && cs->bn2 && cs->bn2->mean && cs->bn2->rstd && cs->sum_g2 && cs->sum_gz2 &&
+              cs->ws && cs->sync && al16(cs->ws), "%s: incomplete gps_gemm_colsums", who);
+  GPS_REQUIRE(cs->ws_floats >= gps_gemm_colsums_floats(p.M, p.N, p.K), "%s: workspace too small (gps_gemm_colsums_floats)", who);
+  PanelPlan Q;
+  if (int rc = panel_prepare(Q, p.A, p.lda, p.M, p.K, p.image, p.N, p.bias, p.Cin, p.ldcin, p.C, p.ldc, 4, nullptr, 0, 0.0f, 0,
+                             nullptr, nullptr, nullptr, p.a_amax, p.w_amax, p.c_amax, nullptr, sums)) return rc;
+  hipStream_t s = gps::as_stream(stream);
+#define GPS_SUMS_ONE(MBV, NJV)                                                                                        \
+  do {                                                                                                                \
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring16<MBV, NJV, 4, true>), \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, r16_lds_bytes(MBV, NJV)); \
+    GPS_REQUIRE(attr == hipSuccess, "%s: cannot reserve LDS", who);                                                   \
+    k_gemm_ring16<MBV, NJV, 4, true><<<Q.grid, NTHREADS, r16_lds_bytes(MBV, NJV), s>>>(Q.P);                          \
+  } while (0)
+  if (Q.nj == 3) { if (Q.mb == 2) GPS_SUMS_ONE(2, 3); else GPS_SUMS_ONE(1, 3); }
+  else { if (Q.mb == 2) GPS_SUMS_ONE(2, 2); else GPS_SUMS_ONE(1, 2); }
+#undef GPS_SUMS_ONE
+  return gps::launch_status(who);
 }

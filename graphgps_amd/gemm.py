@@ -267,3 +267,60 @@ def gemm_panel_pair(first, second):
     check(L.gps_gemm16_panel_pair(ctypes.byref(probs[0]), ctypes.byref(probs[1]), current_stream(outs[0].device)),
           "gps_gemm16_panel_pair")
     return outs[0], outs[1]
+
+
+_colsums_ok = {}
+
+
+def colsums_supported(M: int, N: int, K: int) -> bool:
+    """Whether ``gemm_panel_sums`` serves ``[M, K] x [K, N]`` (whole 128 / 192-column panels)."""
+    key = (M, N, K)
+    v = _colsums_ok.get(key)
+    if v is None:
+        v = _colsums_ok[key] = bool(supported(N, K) and _lib.load().gps_gemm_colsums_supported(M, N, K))
+    return v
+
+
+def _problem(q):
+    a, image, N = q["a"], q["image"], q["N"]
+    if getattr(image, "amax", None) is None:
+        raise _lib.GpsHipError("gemm_panel_sums: fp16-form images only")
+    M, K = a.shape
+    if a.stride(1) != 1 or a.dtype != torch.float32:
+        raise _lib.GpsHipError("gemm_panel_sums: fp32 A with unit column stride")
+    out = q.get("out")
+    if out is None:
+        out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    addend, bias = q.get("addend"), q.get("bias")
+    P = _lib.Gemm16Problem()
+    P.A, P.lda, P.M, P.K, P.N = a.data_ptr(), a.stride(0), M, K, N
+    P.a_amax = _a_word(a, q.get("a_amax"))
+    P.image, P.w_amax = image.data_ptr(), image.amax.data_ptr()
+    P.bias = bias.data_ptr() if bias is not None else None
+    P.Cin, P.ldcin = (addend.data_ptr(), addend.stride(0)) if addend is not None else (None, 0)
+    P.C, P.ldc = out.data_ptr(), out.stride(0)
+    c_amax = q.get("c_amax")
+    P.c_amax = c_amax.data_ptr() if c_amax is not None else None
+    return P, out, (M, N, K)
+
+
+def gemm_panel_sums(prob, sums, sync_ptr: int) -> torch.Tensor:
+    """``out = addend + a @ B^T`` (``prob``: a ``gemm_panel_pair`` dict with an addend) where ``out`` is the output gradient of
+    two BatchNorms -- ``sums = dict(z=, bn=, sum_g=, sum_gz=, z2=, bn2=, sum_g2=, sum_gz2=)``, ``bn`` / ``bn2``:
+    ``norm.bn_desc`` structures, the sums: fp32 [N] tensors -- whose backward column sums S1 = sum g, S2 = sum g zhat leave
+    with the launch (``gps_gemm16_panel_sums``) instead of a ``norm.bwd_partial`` pass over ``out`` and both BatchNorm inputs.
+    ``sync_ptr``: arrival counters (``norm.SyncArena.site``), ``gps_gemm_stats_sync_words(N)`` words, zero at entry and exit."""
+    import ctypes
+    L = _lib.load()
+    P, out, (M, N, K) = _problem(prob)
+    S = _lib.GemmColsums()
+    z, z2 = sums["z"], sums["z2"]
+    S.z, S.ldz, S.bn = z.data_ptr(), z.stride(0), ctypes.addressof(sums["bn"])
+    S.sum_g, S.sum_gz = sums["sum_g"].data_ptr(), sums["sum_gz"].data_ptr()
+    S.z2, S.ldz2, S.bn2 = z2.data_ptr(), z2.stride(0), ctypes.addressof(sums["bn2"])
+    S.sum_g2, S.sum_gz2 = sums["sum_g2"].data_ptr(), sums["sum_gz2"].data_ptr()
+    wsf = L.gps_gemm_colsums_floats(M, N, K)
+    ws = torch.empty(max(wsf, 4), dtype=torch.float32, device=z.device)
+    S.ws, S.ws_floats, S.sync = ws.data_ptr(), wsf, sync_ptr
+    check(L.gps_gemm16_panel_sums(ctypes.byref(P), ctypes.byref(S), current_stream(out.device)), "gps_gemm16_panel_sums")
+    return out

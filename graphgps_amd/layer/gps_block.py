@@ -53,6 +53,9 @@ _GEMM_PAIR = _os.environ.get("GPS_GEMM_PAIR", "1") != "0"
 # (a mask: 1 = the node fold, 2 = the edge fold, 3 = both)
 _GG_BN_FOLD = int(_os.environ.get("GPS_GG_BN_FOLD", "3"))
 _STACK_PREP = _os.environ.get("GPS_STACK_PREP", "1") != "0"
+# GPS_GEMM_BWDSUMS=0: the column sums of norm1_local + norm1_attn's backward by a gps_norm_bwd_partial launch instead of the
+# epilogue of the GEMM that produces their output gradient, g_h = g_z2 + g_f1 W1 (csrc/gemm_panel.hip epilogue 4) -- A/B
+_GEMM_BWDSUMS = _os.environ.get("GPS_GEMM_BWDSUMS", "1") != "0"
 
 # Work that is per layer only by accident, hoisted to the layer STACK when a network drives the blocks (network/base.py
 # brackets its layer stack with stack_begin / stack_end; a block called on its own behaves as before):
@@ -711,8 +714,17 @@ class _GPSBlock(torch.autograd.Function):
             # a kept element has t > 0 iff f1 > 0, a dropped one has gradient 0 either way), in the GEMM's epilogue
             g_f1 = _gemm.gemm_panel(g_f2, imgs[4][1], 2 * d, epilogue=2, mask_src=t, p_drop=p_f1, seed=s[4], a_amax=bw(0),
                                     c_amax=bw(1))
-            g_h = _gemm.gemm_panel(g_f1, imgs[3][1], d, addend=g_z2, out=g_z2, a_amax=bw(1))     # residual + FFN input
+            # residual + FFN input; g_h is the output gradient of norm1_local(x1) + norm1_attn(za): their column sums leave
+            # with it (csrc/gemm_panel.hip epilogue 4) instead of the partial launch below
+            dual_sums = _GEMM_BWDSUMS and bm is not None and _gemm.colsums_supported(N, d, 2 * d)
+            if dual_sums:
+                g_h = _gemm.gemm_panel_sums(dict(a=g_f1, image=imgs[3][1], N=d, addend=g_z2, out=g_z2, a_amax=bw(1)),
+                                            dict(z=x1, bn=bnl, sum_g=g_nlb, sum_gz=g_nlw, z2=za, bn2=bna, sum_g2=g_nab,
+                                                 sum_gz2=g_naw), sync.site(_S_B3, _stats_words(L, d)))
+            else:
+                g_h = _gemm.gemm_panel(g_f1, imgs[3][1], d, addend=g_z2, out=g_z2, a_amax=bw(1))
         else:
+            dual_sums = False
             g_t = g_f2.mm(_W(R.ff2))
             g_f1 = _K.act_drop_bwd(L, g_t, f1, True, p_f1, s[4], st)
             g_h = g_z2.addmm_(g_f1, _W(R.ff1))              # residual + FFN input
@@ -725,7 +737,8 @@ class _GPSBlock(torch.autograd.Function):
                              g_z=g_x1, g_sum=g_xres, g_drop=g_ao, p2=p_l, seed2=s[3],
                              cz=xt, cbn=bnx, crelu=True, cp=p, cseed=s[0], cg_gamma=g_bxw, cg_beta=g_bxb,
                              amax_drop=bw(2), rdev=rn)]
-        _norm.bwd_partial(b3, d, dev, sync.site(_S_B3))
+        if not dual_sums:
+            _norm.bwd_partial(b3, d, dev, sync.site(_S_B3))
         _norm.bwd_apply(b3, d, dev, sync.site(_S_B4))
         # gradient of the merged projection: attention writes dq|dk|dv into columns 4d.., GatedGCN
         # writes g_Ax|g_Bx|g_Dx|g_Ex into columns 0..4d of ONE [N,7d] buffer -> one dgrad, one wgrad

@@ -15,7 +15,7 @@ import torch  # noqa: F401  -- must be imported first: it maps the HIP runtime o
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GPS_HIP_LIB: an alternative build of the same ABI (A/B timing of kernel variants in one process launch each)
 LIB_PATH = os.environ.get("GPS_HIP_LIB") or os.path.join(_HERE, "csrc", "libgps_hip.so")
-ABI_VERSION = 9
+ABI_VERSION = 10
 
 _lib: Optional[ctypes.CDLL] = None
 
@@ -117,6 +117,9 @@ _SIGNATURES = {
     "gps_gemm16_panel_stats": (c_int, [_P, c_int64, c_int64, c_int, _P, _P, _P, c_int, _P, _P, c_int64, _P, c_int64,
                                        c_float, c_uint64, _P, _P, c_size_t, _P, _P, _P]),
     "gps_gemm16_panel_pair": (c_int, [_P, _P, _P]),
+    "gps_gemm_colsums_supported": (c_int, [c_int64, c_int, c_int]),
+    "gps_gemm_colsums_floats": (c_size_t, [c_int64, c_int, c_int]),
+    "gps_gemm16_panel_sums": (c_int, [_P, _P, _P]),
     "gps_gcn_dinv": (c_int, [_P, _P, c_int64, c_int64, _P, _P]),
     "gps_gcn_spmm": (c_int, [_P, c_int64, _P, _P, _P, c_int64, c_int64, c_int, _P, _P]),
     "gps_adj_sum": (c_int, [_P, c_int64, _P, _P, c_float, c_int64, c_int64, c_int, _P, _P]),
@@ -154,6 +157,13 @@ class Gemm16Problem(ctypes.Structure):
     _fields_ = [("A", c_void_p), ("lda", c_int64), ("M", c_int64), ("K", ctypes.c_int32), ("N", ctypes.c_int32),
                 ("a_amax", c_void_p), ("image", c_void_p), ("w_amax", c_void_p), ("bias", c_void_p), ("Cin", c_void_p),
                 ("ldcin", c_int64), ("C", c_void_p), ("ldc", c_int64), ("c_amax", c_void_p)]
+
+
+class GemmColsums(ctypes.Structure):
+    """``gps_gemm_colsums`` (include/gps_hip.h)."""
+    _fields_ = [("z", c_void_p), ("ldz", c_int64), ("bn", c_void_p), ("sum_g", c_void_p), ("sum_gz", c_void_p),
+                ("z2", c_void_p), ("ldz2", c_int64), ("bn2", c_void_p), ("sum_g2", c_void_p), ("sum_gz2", c_void_p),
+                ("ws", c_void_p), ("ws_floats", c_size_t), ("sync", c_void_p)]
 
 
 class GemmSplit(ctypes.Structure):

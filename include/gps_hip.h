@@ -341,6 +341,36 @@ typedef struct gps_gemm16_problem {
 } gps_gemm16_problem;
 int gps_gemm16_panel_pair(const gps_gemm16_problem* first, const gps_gemm16_problem* second, gps_stream_t stream);
 
+/* ABI v10: an input-gradient GEMM whose output IS the output gradient of two training-mode BatchNorm1d's leaves with their
+ * backward column sums -- autograd's sum(g) and sum(g * zhat) over the batch (= g_beta and g_gamma), which
+ * gps_norm_bwd_partial otherwise takes in a pass of its own over g and both inputs.  In a GPS block
+ * (graphgps/layer/gps_layer.py:219-222,225-229) g_h = g_z2 + g_f1 W1 -- the residual of z2 = h + ff(h) plus the FFN's input
+ * gradient -- is the output gradient of h = norm1_local(x1) + norm1_attn(za).  The sums are complete when the launch retires
+ * (one in-launch SUMS tree per column panel, csrc/col_tree.hpp: `sync` = gps_gemm_stats_sync_words(N) counters, zero at
+ * entry and exit); rows are summed in tile order: deterministic, not bit-identical to the row pass.  Padding rows of a
+ * padded batch must be zero in C (they are: every gradient of the block is).  (The same epilogue on the PAIRED input
+ * gradients of a block, for norm2 / bn_edge_e of the block below, was built and measured in round 6: +26 us on the pair
+ * for the 23 us launch it removed -- not kept.) */
+typedef struct gps_gemm_colsums {
+  const float* z;          /* [M][N] input of the first BatchNorm (row stride ldz) */
+  int64_t ldz;
+  const gps_bn* bn;        /* mean, rstd */
+  float* sum_g;            /* [N] out: S1 = sum_rows C */
+  float* sum_gz;           /* [N] out: S2 = sum_rows C * zhat */
+  const float* z2;         /* [M][N] input of the second BatchNorm */
+  int64_t ldz2;
+  const gps_bn* bn2;
+  float* sum_g2;           /* [N] out: S1 again (the second BatchNorm's g_beta) */
+  float* sum_gz2;          /* [N] out: S2 of the second BatchNorm */
+  float* ws;               /* gps_gemm_colsums_floats(M, N, K) floats, 16-byte aligned */
+  size_t ws_floats;
+  uint32_t* sync;
+} gps_gemm_colsums;
+int gps_gemm_colsums_supported(int64_t M, int N, int K);     /* whole 128- / 192-column panels, whole k-stages, M >= 2 */
+size_t gps_gemm_colsums_floats(int64_t M, int N, int K);
+/* C = Cin + A W^T (+ bias) and the sums (prob->Cin required; may alias C) */
+int gps_gemm16_panel_sums(const gps_gemm16_problem* prob, const gps_gemm_colsums* sums, gps_stream_t stream);
+
 /* ---------------------------------------------------------------------------------------
  * Segment (per-graph, varlen) multi-head attention core on fp32 MFMA (v_mfma_f32_16x16x4_f32).
  * Replaces to_dense_batch + the softmax(QK^T/sqrt(dh) + key-padding mask) -> dropout -> .V core

@@ -488,3 +488,67 @@ def test_stale_arrival_counter_fails_loudly(mode):
     else:
         assert r.returncode != 0 and "SECOND-LAUNCH-RETURNED" not in r.stdout, (
             "a launch on a stale arrival counter returned instead of failing loudly:\n" + out[-2000:])
+
+
+def _colsum_refs(g, z, st):
+    """fp64 S1 = sum g, S2 = sum g zhat (block_norm.hip run_bwd_partial)."""
+    zh = (z.double() - st[0].double().cpu()) * st[1].double().cpu()
+    return g.double().sum(0), (g.double() * zh).sum(0)
+
+
+@pytest.mark.parametrize("M,K,N", [(7569, 768, 384), (7569, 384, 384), (130, 384, 192), (64, 384, 384), (5000, 512, 256),
+                                   (25013, 256, 256), (2, 384, 384)])
+def test_gemm_epilogue_dual_batchnorm_backward_sums(M, K, N):
+    """gps_gemm16_panel_sums, two-BatchNorm form: g_h = g_z2 + g_f1 W1 (in place) leaves with sum g, sum g zhat(x1),
+    sum g zhat(za) -- the column sums of norm1_local / norm1_attn's backward (gps_layer.py:219-222) -- against fp64 and
+    against gps_norm_bwd_partial over the stored output; bit-reproducible; counters zero afterwards."""
+    from graphgps_amd import gemm, norm
+    if not gemm.colsums_supported(M, N, K):
+        pytest.skip("shape not served")
+    gen = torch.Generator().manual_seed(M * 3 + K)
+    a = torch.randn(M, K, generator=gen)
+    w = torch.randn(N, K, generator=gen) / K ** 0.5
+    res = torch.randn(M, N, generator=gen)
+    z1 = torch.randn(M, N, generator=gen) * 1.3 + 0.7
+    z2 = torch.randn(M, N, generator=gen) * 0.6 - 2.0
+    (img, _), = gemm.split_weights([w.to(DEV)], tn=False, f16=True)
+    bn1, bn2 = _bn(N, gen), _bn(N, gen)
+    d1, st1 = _desc(bn1, N)
+    d2, st2 = _desc(bn2, N)
+    for st, z in ((st1, z1), (st2, z2)):
+        st[0].copy_(z.mean(0)); st[1].copy_(1.0 / torch.sqrt(z.var(0, unbiased=False) + 1e-5))
+    own = _Owner()
+    sync = norm.sync_arena(own, torch.device(DEV))
+    ag, z1g, z2g = a.to(DEV), z1.to(DEV), z2.to(DEV)
+    sums = torch.full((4, N), float("nan"), device=DEV)
+
+    def run():
+        c = res.to(DEV)
+        out = gemm.gemm_panel_sums(dict(a=ag, image=img, N=N, addend=c, out=c),
+                                   dict(z=z1g, bn=d1, sum_g=sums[0], sum_gz=sums[1], z2=z2g, bn2=d2, sum_g2=sums[2],
+                                        sum_gz2=sums[3]), sync.site(0))
+        assert out.data_ptr() == c.data_ptr()
+        return out
+    out = run()
+    ref = res.double() + a.double() @ w.double().t()
+    assert_close(out, ref, 4e-6 * float(ref.abs().max()), "Cin + A W^T")
+    g = out.cpu()
+    s1, s2a = _colsum_refs(g, z1, st1)
+    _, s2b = _colsum_refs(g, z2, st2)
+    scale = float(max(s1.abs().max(), s2a.abs().max(), s2b.abs().max(), 1.0))
+    tol = 2e-6 * scale * max(1.0, (M / 1000.0) ** 0.5)
+    assert_close(sums[0], s1, tol, "sum g")
+    assert_close(sums[1], s2a, tol, "sum g zhat(z1)")
+    assert torch.equal(sums[2], sums[0])
+    assert_close(sums[3], s2b, tol, "sum g zhat(z2)")
+    # the row pass it replaces, over the same stored gradient
+    if M >= 2:
+        ps = torch.empty(4, N, device=DEV)
+        t = norm.bwd_task(z1g, out, d1, M, ps[1], ps[0], z2=z2g, bn2=d2, g_gamma2=ps[3], g_beta2=ps[2])
+        norm.bwd_partial([t], N, torch.device(DEV), sync.site(1))
+        assert_close(sums, ps.double().cpu(), tol, "vs gps_norm_bwd_partial")
+    first = (out.clone(), sums.clone())
+    for _ in range(3):
+        out2 = run()
+        assert torch.equal(out2, first[0]) and torch.equal(sums, first[1])
+    assert int(sync.buf.abs().sum()) == 0
