@@ -674,7 +674,7 @@ def bucketed_loader_leg(model, opt, loss_fn, nb, profile, dev, n_batches=24):
     staged ahead on a copy stream -- and TrainStep.step_cached, which replays a captured step per bucket.  Two forms:
     the padding on DeviceLoader's staging thread (host batches arrive un-padded and un-pinned, as from a plain
     DataLoader), and batches that arrive padded and pinned (BucketPadding.collate in the DataLoader's worker processes +
-    pin_memory=True).  Untimed passes meet the buckets (first sight eager, second sight captured), the timed pass runs
+    pin_memory=True).  Untimed passes meet the buckets (each captured at its first sight, after one eager step), the timed pass runs
     the same batches in another order.  For scale, the eager step on the same un-padded stream (every batch a new shape:
     every first sight of a row count costs host time in the libraries) is timed too.  Runs after the timed region: it cannot move `value`."""
     try:

@@ -315,8 +315,9 @@ class TrainStep:
         -- (nodes, edges, graphs, the shapes of every other tensor of the batch, and whether the longest graph allows the
         block-form attention kernels) -- gets its own static input buffers + captured step, kept in an LRU of
         ``max_graphs`` entries over ONE shared memory pool; a batch whose shape has an entry is copied into the static
-        buffers (one multi-tensor copy) and replayed, the first batch of a new shape runs eagerly and the second one
-        captures.  Loaders that emit a few fixed shapes (bucketed / padded datasets, the synthetic benches) replay every
+        buffers (one multi-tensor copy) and replayed; the first batch of a new shape runs eagerly and the second one
+        captures, except that a batch padded up to a shape bucket (``loader.BucketPadding``) is captured at its bucket's
+        first sight (after the very first, eager, step).  Loaders that emit a few fixed shapes (bucketed / padded datasets, the synthetic benches) replay every
         step; a loader whose shapes never repeat simply stays on the eager path.  Needs ``optim.FlatAdamW``.
         With an active data-parallel exchange the step is captured as TWO graphs either side of the all-reduce (as
         ``capture`` does).  A shape whose capture fails is remembered and runs eagerly from then on; after three failed
@@ -337,11 +338,16 @@ class TrainStep:
         ent = cache.get(key)                     # graph nor be evicted and retried
         if ent is None:
             seen = self.__dict__.setdefault("_shape_seen", set())
-            if key not in seen:              # first sight of this shape: run it eagerly, capture if it comes back
+            if key not in seen:              # first sight of this shape: run it eagerly, capture if it comes back ...
                 if len(seen) >= 4096:        # a loader whose shapes never repeat: do not remember them all
                     seen.clear()
                 seen.add(key)
-                return self._eager_triplet(batch)
+                # ... unless the batch was padded up to a shape BUCKET (loader.BucketPadding): a bucket does come back, so it
+                # is captured at its first sight -- a capture does not execute the step, the replay below is this batch's
+                # step -- once one eager step has run (arena adoption, the libraries' lazy set-up)
+                if not (_is_padded(batch) and self.__dict__.get("_eager_steps", 0) >= 1):
+                    self.__dict__["_eager_steps"] = self.__dict__.get("_eager_steps", 0) + 1
+                    return self._eager_triplet(batch)
             ent = self._capture_shape(batch)
             if ent is None:                  # capture is an optimisation, never a requirement -- but a failure is remembered:
                 failed.add(key)              # a step that cannot be captured (a host read in a head, a boolean-mask loss)
@@ -705,6 +711,12 @@ def train_epoch(logger, loader, model, optimizer, scheduler, batch_accumulation,
     log.flush()
 
 
+def _is_padded(batch) -> bool:
+    """Whether ``batch`` was padded up to a shape bucket (``loader.BucketPadding`` marks its batches)."""
+    meta = getattr(batch, "__dict__", {}).get("_gps_meta")
+    return bool(meta and meta.get("padded"))
+
+
 def eval_padding_supported(model) -> bool:
     """Padded batches in EVALUATION mode.  Every BatchNorm normalises with its running statistics there, so padding rows
     reach no statistic whatever the layer type; what has to hold is that ``loader.BucketPadding`` knows every tensor the
@@ -747,7 +759,8 @@ def eval_padding_supported(model) -> bool:
 class EvalStep:
     """``model.eval()`` forward + loss under ``no_grad`` (custom_train.py:50-77), replayed from a hipGraph per batch SHAPE
     exactly as ``TrainStep.step_cached`` does for training steps: static copies of the batch's tensors, first sight of a
-    shape eager, second sight captured, afterwards one multi-tensor copy + one graph launch per batch.  Round 5 (VERDICT r4,
+    shape eager, second sight captured (bucket-padded shapes: captured at first sight), afterwards one multi-tensor copy +
+    one graph launch per batch.  Round 5 (VERDICT r4,
     missing 2: "replayed eval_epoch")."""
 
     def __init__(self, model, loss_fn: Optional[Callable] = None):
@@ -801,7 +814,10 @@ class EvalStep:
                 if len(self.seen) >= 4096:
                     self.seen.clear()
                 self.seen.add(key)
-                return self.run_eager(batch)
+                # (a bucket-padded shape comes back: captured at its first sight once one eager forward has run)
+                if not (_is_padded(batch) and self.__dict__.get("_eager_steps", 0) >= 1):
+                    self.__dict__["_eager_steps"] = self.__dict__.get("_eager_steps", 0) + 1
+                    return self.run_eager(batch)
             ent = self._capture(batch)
             if ent is None:
                 self.failed.add(key)

@@ -202,8 +202,8 @@ def test_padded_batch_on_an_unsupported_layer_fails_loudly():
 
 def test_bucketed_loader_replays_shuffled_batches_like_eager():
     """50 shuffled PCQM-shaped batches (64 graphs each, every one a different (nodes, edges) pair) through
-    DeviceLoader(pad=BucketPadding) + TrainStep.step_cached: the stream falls into a handful of shape buckets, every step
-    after a bucket's first (eager) sight is a hipGraph replay -- >= 90 % of the 50 -- and replaying changes nothing: losses,
+    DeviceLoader(pad=BucketPadding) + TrainStep.step_cached: the stream falls into a handful of shape buckets, each captured
+    at its first sight, so every step but the very first is a hipGraph replay -- and replaying changes nothing: losses,
     predictions and final weights equal the same padded batches stepped eagerly (same arithmetic, 1e-6), and the padded
     stream tracks the un-padded one (different rounding, so only as far as 50 AdamW steps keep rounding differences small)."""
     from graphgps_amd.loader import BucketPadding, DeviceLoader
@@ -224,12 +224,11 @@ def test_bucketed_loader_replays_shuffled_batches_like_eager():
         losses, preds = [], []
         for b in DeviceLoader([q.clone() for q in seq], dev, pad=pad):
             if mode == "cached-padded":
-                cache = ts.__dict__.get("_shape_cache", {})
                 key = ts._shape_key(b)
-                will_replay = key in cache or key in ts.__dict__.get("_shape_seen", set())
+                eager_before = ts.__dict__.get("_eager_steps", 0)
                 loss, pred, true = ts.step_cached(b, max_graphs=8)
-                assert ts.__dict__["_shape_cache"].get(key, None) is not False, "capture of a padded step failed"
-                replays += int(will_replay)
+                assert key not in ts.__dict__.get("_shape_failed", set()), "capture of a padded step failed"
+                replays += int(ts.__dict__.get("_eager_steps", 0) == eager_before)
             else:
                 loss, pred, true = ts._eager_triplet(b)
             assert pred.shape[0] == 64 and true.shape[0] == 64               # the dead graphs never leave the step
@@ -240,7 +239,7 @@ def test_bucketed_loader_replays_shuffled_batches_like_eager():
         if mode == "cached-padded":
             shapes = len(ts.__dict__["_shape_cache"])
     print(f"bucketed stream: {replays} of 50 steps replayed, {shapes} captured shapes")
-    assert replays >= 45, (replays, shapes)
+    assert replays == 49, (replays, shapes)      # every bucket is captured at its first sight; only the very first step is eager
     le, lp, lc = (results[m][0] for m in ("eager", "eager-padded", "cached-padded"))
     assert all(x == x for x in lc)
     for i, (a, c) in enumerate(zip(lp, lc)):                                 # replay == eager on the same padded batches
@@ -431,10 +430,10 @@ def test_bucketed_loader_replays_zinc_and_code2_streams(kind, nb, steps):
         for b in DeviceLoader([q.clone() for q in seq], dev, pad=pad):
             if mode == "cached-padded":
                 key = ts._shape_key(b)
-                will_replay = key in ts.__dict__.get("_shape_cache", {}) or key in ts.__dict__.get("_shape_seen", set())
+                eager_before = ts.__dict__.get("_eager_steps", 0)
                 loss, pred, true = ts.step_cached(b, max_graphs=8)
                 assert key not in ts.__dict__.get("_shape_failed", set()), "capture of a padded step failed"
-                replays += int(will_replay)
+                replays += int(ts.__dict__.get("_eager_steps", 0) == eager_before)
             else:
                 loss, pred, true = ts._eager_triplet(b)
             losses.append(float(loss))
@@ -443,7 +442,7 @@ def test_bucketed_loader_replays_zinc_and_code2_streams(kind, nb, steps):
         if mode == "cached-padded":
             shapes = len(ts.__dict__["_shape_cache"])
     print(f"{kind}: {replays} of 24 steps replayed, {shapes} captured shapes")
-    assert replays >= 14, (replays, shapes)
+    assert replays == 23, (replays, shapes)      # buckets are captured at their first sight: one eager step in all
     for i, (a, c) in enumerate(zip(results["eager-padded"][0], results["cached-padded"][0])):
         assert a == a and abs(a - c) <= 2e-6 * max(abs(a), 1.0), (i, a, c)
     assert_close(results["cached-padded"][1], results["eager-padded"][1], 1e-6, "weights after the sequence")
