@@ -1094,10 +1094,16 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring16(const PanelArgs P) 
 // the rest those of the second.  A dependent dispatch of a replayed graph costs ~4 us before its first workgroup runs, and a
 // GEMM of one dispatch round leaves every CU idle through its prologue and its epilogue; paired, the second problem's tiles
 // start as the first's retire.  The first problem should be the one with the longer tiles (they are dispatched first).
-template <int MB0, int MB1, int NJ, bool HAS_CIN>
-__global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring16_pair(const PanelArgs P0, const PanelArgs P1, const int split) {
+// TAIL: the last rows of the second problem as a third one with 64-row tiles (gps_gemm16_panel_pair's tail balancing): tiles
+// are dispatched in blockIdx order onto CUs as they free up, so when the tile count leaves a last dispatch round mostly empty
+// (P30 x 256: 840 + 240 tiles of 128 x 192 on 256 CUs = 4.2 rounds, the fifth 22 % full), re-cutting that round's tiles in
+// halves ends the launch half a tile-time earlier.
+template <int MB0, int MB1, int NJ, bool HAS_CIN, bool TAIL = false>
+__global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring16_pair(const PanelArgs P0, const PanelArgs P1, const int split,
+                                                                 const PanelArgs P2, const int split2) {
   if ((int)blockIdx.x < split) ring16_body<MB0, NJ, 0, HAS_CIN, false>(P0, (int)blockIdx.x);
-  else ring16_body<MB1, NJ, 0, HAS_CIN, false>(P1, (int)blockIdx.x - split);
+  else if (!TAIL || (int)blockIdx.x < split2) ring16_body<MB1, NJ, 0, HAS_CIN, false>(P1, (int)blockIdx.x - split);
+  else ring16_body<1, NJ, 0, HAS_CIN, false>(P2, (int)blockIdx.x - split2);
 }
 
 
@@ -1421,20 +1427,53 @@ extern "C" int gps_gemm16_panel_pair(const gps_gemm16_problem* first, const gps_
     return GPS_OK;
   }
   hipStream_t s = gps::as_stream(stream);
-  const unsigned grid = Q[0].grid + Q[1].grid;
-  const int split = (int)Q[0].grid;
-#define GPS_PAIR(MB0, MB1, NJV, C)                                                                                  \
+  // Tail balancing (k_gemm_ring16_pair TAIL): when both problems run 128-row tiles and the tile count leaves a last dispatch
+  // round at most half full, the rows behind that round's tiles -- the last row tiles of the second problem -- are cut as
+  // 64-row tiles instead, so the launch ends half a tile-time earlier.  Same products, same per-element arithmetic: results
+  // are bit-identical to the un-balanced dispatch (a tile's rows do not interact).
+  static const int cus = []() {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+    return n;
+  }();
+  static const bool tail_on = []() { const char* v = getenv("GPS_GEMM_TAIL"); return !(v && v[0] == '0'); }();
+  PanelArgs P2 = Q[1].P;
+  unsigned grid2 = 0;
+  if (tail_on && cus > 0 && Q[0].mb == 2 && Q[1].mb == 2) {
+    const int panels1 = Q[1].P.Nimg / (64 * Q[1].nj);
+    const int rem = (int)((Q[0].grid + Q[1].grid) % (unsigned)cus);
+    const int r = (rem + panels1 - 1) / panels1;                     // 128-row tiles of problem 1 behind the last round
+    if (rem > 0 && 2 * rem <= cus && r >= 1 && r < Q[1].P.row_tiles) {
+      const int keep = Q[1].P.row_tiles - r;
+      const int64_t row0 = (int64_t)keep * 128, rows2 = Q[1].P.M - row0;
+      P2.A = Q[1].P.A + row0 * Q[1].P.lda;
+      P2.C = Q[1].P.C + row0 * Q[1].P.ldc;
+      if (Q[1].P.Cin) P2.Cin = Q[1].P.Cin + row0 * Q[1].P.ldcin;
+      P2.M = rows2;
+      P2.row_tiles = (int)((rows2 + 63) / 64);
+      grid2 = (unsigned)(P2.row_tiles * panels1);
+      Q[1].P.M = row0;
+      Q[1].P.row_tiles = keep;
+      Q[1].grid = (unsigned)(keep * panels1);
+    }
+  }
+  const unsigned grid = Q[0].grid + Q[1].grid + grid2;
+  const int split = (int)Q[0].grid, split2 = (int)(Q[0].grid + Q[1].grid);
+#define GPS_PAIR(MB0, MB1, NJV, C, T)                                                                               \
   do {                                                                                                              \
     constexpr int LDS = r16_lds_bytes(MB0, NJV) > r16_lds_bytes(MB1, NJV) ? r16_lds_bytes(MB0, NJV) : r16_lds_bytes(MB1, NJV); \
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring16_pair<MB0, MB1, NJV, C>), \
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring16_pair<MB0, MB1, NJV, C, T>), \
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);            \
     GPS_REQUIRE(attr == hipSuccess, "gps_gemm16_panel_pair: cannot reserve %d bytes of LDS", LDS);                  \
-    k_gemm_ring16_pair<MB0, MB1, NJV, C><<<grid, NTHREADS, LDS, s>>>(Q[0].P, Q[1].P, split);                        \
+    k_gemm_ring16_pair<MB0, MB1, NJV, C, T><<<grid, NTHREADS, LDS, s>>>(Q[0].P, Q[1].P, split, P2, split2);         \
   } while (0)
 #define GPS_PAIR_MB(NJV, C)                                                                                         \
   do {                                                                                                              \
-    if (Q[0].mb == 2) { if (Q[1].mb == 2) GPS_PAIR(2, 2, NJV, C); else GPS_PAIR(2, 1, NJV, C); }                    \
-    else { if (Q[1].mb == 2) GPS_PAIR(1, 2, NJV, C); else GPS_PAIR(1, 1, NJV, C); }                                 \
+    if (Q[0].mb == 2) {                                                                                             \
+      if (Q[1].mb == 2) { if (grid2) GPS_PAIR(2, 2, NJV, C, true); else GPS_PAIR(2, 2, NJV, C, false); }            \
+      else GPS_PAIR(2, 1, NJV, C, false);                                                                           \
+    }                                                                                                               \
+    else { if (Q[1].mb == 2) GPS_PAIR(1, 2, NJV, C, false); else GPS_PAIR(1, 1, NJV, C, false); }                   \
   } while (0)
   const bool cin = Q[0].P.Cin != nullptr;
   if (Q[0].nj == 3) { if (cin) GPS_PAIR_MB(3, true); else GPS_PAIR_MB(3, false); }

@@ -1060,7 +1060,10 @@ def test_wgrad_register_path_is_bit_identical_to_the_lds_path(tmp_path):
 
 
 @pytest.mark.parametrize("p0,p1,cin", [
-    ((7569, 384, 2688), (15348, 384, 384), False),      # the block's forward pair: merged node projection | C(e)
+    ((7569, 384, 2688), (15348, 384, 384), False),      # the block's forward pair: merged node projection | C(e); 1,080 tiles
+                                                        # on 256 CUs: the last 56 re-cut as 64-row tiles (tail balancing)
+    ((7569, 384, 2688), (15301, 384, 384), True),       # the same with addends and a ragged last 64-row tile
+    ((5000, 384, 768), (9000, 384, 384), True),         # 160 + 142 tiles: a tail of 46 behind one full round
     ((7569, 2688, 384), (15348, 384, 384), True),       # its backward pair: g_pq Wcat (64-row tiles) | g_ce W_C (128-row tiles)
     ((300, 384, 384), (5000, 384, 768), True), ((25013, 256, 256), (7000, 256, 1792), False),     # 128-column panels
     ((1000, 384, 384), (1000, 256, 256), False),        # different panel widths: two launches behind the same call
