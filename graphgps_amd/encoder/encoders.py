@@ -253,7 +253,13 @@ class TypeDictNodeEncoder(nn.Module):
         self.encoder = nn.Embedding(num_embeddings=num_types, embedding_dim=emb_dim)
 
     def forward(self, batch):
-        batch.x = self.encoder(batch.x[:, 0])  # only the first column
+        x = batch.x
+        if x.is_cuda and torch.is_grad_enabled() and x.dtype == torch.int64 and x.dim() == 2:
+            # the gather launch of the sum-of-embeddings encoders with ONE table: its table gradient is the deterministic
+            # multi-hot contraction instead of ATen's sort-based embedding backward (60 us per call on a 710-node ZINC batch)
+            batch.x = _multihot_embedding(x[:, 0:1], [self.encoder], self)
+            return batch
+        batch.x = self.encoder(x[:, 0])  # only the first column
         return batch
 
 
@@ -267,7 +273,11 @@ class TypeDictEdgeEncoder(nn.Module):
         self.encoder = nn.Embedding(num_embeddings=num_types, embedding_dim=emb_dim)
 
     def forward(self, batch):
-        batch.edge_attr = self.encoder(batch.edge_attr)
+        ea = batch.edge_attr
+        if ea.is_cuda and torch.is_grad_enabled() and ea.dtype == torch.int64 and ea.dim() == 1:
+            batch.edge_attr = _multihot_embedding(ea.unsqueeze(1), [self.encoder], self)        # (as TypeDictNodeEncoder)
+            return batch
+        batch.edge_attr = self.encoder(ea)
         return batch
 
 
