@@ -483,6 +483,77 @@ __device__ __forceinline__ void bwd_a_chunk(const float* __restrict__ g_e, const
   }
 }
 
+// Long segments (more incoming edges than the one-pass form holds): the two passes in CHUNKS -- every operand row of a chunk
+// is requested before the first one is used, so a node of degree 4 .. 8 costs 3 .. 5 memory round trips instead of one per
+// edge and pass (8 .. 16: with the folds a degree-4 node -- 6 % of a molecule batch's nodes, a third of an AST batch's --
+// already takes this path, and a workgroup's barrier waits for its slowest row).  Same values added in the same (ascending
+// edge) order as the edge-by-edge loops they replace (the compiler's FMA contraction may differ: results agree to rounding).
+template <int VEC, bool GATE, int D>
+__device__ __forceinline__ void bwd_a_numden(const float* __restrict__ e_hat, const float* __restrict__ Bx, int64_t ld,
+                                             const float* __restrict__ r_edge, int d, int c, const int* nbr, const int* eids,
+                                             Vec<VEC>& num, Vec<VEC>& den) {
+  Vec<VEC> eh[D], bx[D];
+  float rr[D];
+#pragma unroll
+  for (int u = 0; u < D; ++u) {
+    const int64_t j = nbr[u], id = eids[u];
+    eh[u] = Vec<VEC>::load(e_hat + id * d + c);
+    bx[u] = Vec<VEC>::load(Bx + j * ld + c);
+    rr[u] = GATE ? r_edge[id] : 1.0f;
+  }
+#pragma unroll
+  for (int u = 0; u < D; ++u)
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      float s = sigmoidf_fast(eh[u][v]);
+      if (GATE) s = s * rr[u];
+      num[v] += s * bx[u][v];
+      den[v] += s;
+    }
+}
+template <int VEC, bool GATE, int FOLD, int D>
+__device__ __forceinline__ void bwd_a_delta(const float* __restrict__ g_e, const float* __restrict__ e_hat,
+                                            const float* __restrict__ Bx, int64_t ld, const float* __restrict__ r_edge, int d,
+                                            int c, const int* nbr, const int* eids, const Vec<VEC>& a, const Vec<VEC>& b,
+                                            Vec<VEC>& gdx, float* g_Ce, float* __restrict__ sD, float* __restrict__ sS,
+                                            int slot0, int cap, float& mce, const Folds<VEC, FOLD>& FK) {
+  int id[D];
+  Vec<VEC> eh[D], ge[D], bx[D];
+  float rr[D];
+#pragma unroll
+  for (int u = 0; u < D; ++u) {
+    const int64_t j = nbr[u];
+    id[u] = eids[u];
+    eh[u] = Vec<VEC>::load(e_hat + (int64_t)id[u] * d + c);
+    ge[u] = Vec<VEC>::load(g_e + (int64_t)id[u] * d + c);
+    bx[u] = Vec<VEC>::load(Bx + j * ld + c);
+    rr[u] = GATE ? r_edge[id[u]] : 1.0f;
+  }
+  if constexpr ((FOLD & 2) != 0) {
+#pragma unroll
+    for (int u = 0; u < D; ++u) ge[u] = FK.edge(ge[u], eh[u], id[u], c);
+  }
+#pragma unroll
+  for (int u = 0; u < D; ++u) {
+    Vec<VEC> dl, sa;
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      const float s = sigmoidf_fast(eh[u][v]);
+      float sp = s * (1.0f - s);
+      if (GATE) sp = sp * rr[u];
+      dl[v] = (ge[u][v] + (a[v] * bx[u][v]) * sp) + b[v] * sp;   // same association as the one-pass form
+      gdx[v] += dl[v];
+      sa[v] = (GATE ? s * rr[u] : s) * a[v];
+      mce = fmaxf(mce, fabsf(dl[v]));
+    }
+    dl.store(g_Ce + (int64_t)id[u] * d + c);
+    if (slot0 + u < cap) {
+      dl.store(sD + (slot0 + u) * d + c);
+      sa.store(sS + (slot0 + u) * d + c);
+    }
+  }
+}
+
 template <int VEC, bool GATE, int FOLD>
 __device__ __forceinline__ void bwd_a_rows(const float* __restrict__ g_x, int64_t ldgx,
                                            const float* __restrict__ g_e, const float* __restrict__ e_hat,
@@ -509,19 +580,16 @@ __device__ __forceinline__ void bwd_a_rows(const float* __restrict__ g_x, int64_
       case 4: if constexpr (FOLD != 3) GPS_BWD_A(4); break;
       default: {                               // long segment: num_i / den_i first, then the deltas (rows re-read from L1 / L2)
         Vec<VEC> num = Vec<VEC>::zero(), den = Vec<VEC>::zero();
-        for (int k = beg; k < end; ++k) {
-          const int64_t j = nbr[k], id = eids[k];
-          const Vec<VEC> eh = Vec<VEC>::load(e_hat + id * d + c);
-          const Vec<VEC> bx = Vec<VEC>::load(Bx + j * ld + c);
-          const float rr = GATE ? r_edge[id] : 1.0f;
-#pragma unroll
-          for (int v = 0; v < VEC; ++v) {
-            float s = sigmoidf_fast(eh[v]);
-            if (GATE) s = s * rr;
-            num[v] += s * bx[v];
-            den[v] += s;
-          }
+        int k = beg;
+#define GPS_ND(DD) bwd_a_numden<VEC, GATE, DD>(e_hat, Bx, ld, r_edge, d, c, nbr + k, eids + k, num, den)
+        for (; k + 4 <= end; k += 4) GPS_ND(4);
+        switch (end - k) {
+          case 1: GPS_ND(1); break;
+          case 2: GPS_ND(2); break;
+          case 3: GPS_ND(3); break;
+          default: break;
         }
+#undef GPS_ND
         Vec<VEC> a, b;
 #pragma unroll
         for (int v = 0; v < VEC; ++v) {
@@ -529,30 +597,12 @@ __device__ __forceinline__ void bwd_a_rows(const float* __restrict__ g_x, int64_
           a[v] = gx[v] * inv;
           b[v] = -a[v] * (num[v] * inv);
         }
-        for (int k = beg; k < end; ++k) {
-          const int64_t j = nbr[k], id = eids[k];
-          const Vec<VEC> eh = Vec<VEC>::load(e_hat + id * d + c);
-          Vec<VEC> ge = Vec<VEC>::load(g_e + id * d + c);
-          if constexpr ((FOLD & 2) != 0) ge = FK.edge(ge, eh, id, c);
-          const Vec<VEC> bx = Vec<VEC>::load(Bx + j * ld + c);
-          const float rr = GATE ? r_edge[id] : 1.0f;
-          Vec<VEC> dl, sa;
-#pragma unroll
-          for (int v = 0; v < VEC; ++v) {
-            const float s = sigmoidf_fast(eh[v]);
-            float sp = s * (1.0f - s);
-            if (GATE) sp = sp * rr;
-            dl[v] = (ge[v] + (a[v] * bx[v]) * sp) + b[v] * sp;   // same association as the one-pass form
-            gdx[v] += dl[v];
-            sa[v] = (GATE ? s * rr : s) * a[v];
-            mce = fmaxf(mce, fabsf(dl[v]));
-          }
-          dl.store(g_Ce + id * d + c);
-          if (k - e0 < cap) {
-            dl.store(sD + (k - e0) * d + c);
-            sa.store(sS + (k - e0) * d + c);
-          }
-        }
+        k = beg;
+#define GPS_DL(DD) bwd_a_delta<VEC, GATE, FOLD, DD>(g_e, e_hat, Bx, ld, r_edge, d, c, nbr + k, eids + k, a, b, gdx, g_Ce, sD, sS, \
+                                                     k - e0, cap, mce, FK)
+        for (; k + 2 <= end; k += 2) GPS_DL(2);
+        if (k < end) GPS_DL(1);
+#undef GPS_DL
       }
     }
     if (g_Ax) gx.store(g_Ax + node * ldg + c);
@@ -561,6 +611,29 @@ __device__ __forceinline__ void bwd_a_rows(const float* __restrict__ g_x, int64_
     for (int v = 0; v < VEC; ++v) mnode = fmaxf(mnode, fmaxf(fabsf(gx[v]), fabsf(gdx[v])));
   }
 #undef GPS_BWD_A
+}
+
+// D entries of a target's incoming segment: sum of the gates sig (e^) in entry order, every row requested before the first use
+template <int VEC, bool GATE, int D>
+__device__ __forceinline__ void bwd_b_den(const float* __restrict__ e_hat, const int32_t* __restrict__ eids,
+                                          const float* __restrict__ r_edge, int d, int c, Vec<VEC>& dn) {
+  int64_t id2[D];
+#pragma unroll
+  for (int q = 0; q < D; ++q) id2[q] = eids[q];
+  Vec<VEC> e2[D];
+  float r2[D];
+#pragma unroll
+  for (int q = 0; q < D; ++q) {
+    e2[q] = Vec<VEC>::load(e_hat + id2[q] * d + c);
+    r2[q] = GATE ? r_edge[id2[q]] : 1.0f;
+  }
+#pragma unroll
+  for (int q = 0; q < D; ++q)
+#pragma unroll
+    for (int v = 0; v < VEC; ++v) {
+      const float s2 = sigmoidf_fast(e2[q][v]);
+      dn[v] += GATE ? s2 * r2[q] : s2;
+    }
 }
 
 // Phase B, D outgoing edges of one source node.  An edge whose target this workgroup owns finds its delta and
@@ -602,22 +675,19 @@ __device__ __forceinline__ void bwd_b_chunk(const float* __restrict__ g_x, int64
         gbx[v] += sa[v];
       }
     } else {                                 // target owned by another workgroup (or stash overflow)
+      // The target's segment (its den, as the forward summed it) is walked two entries at a time, both rows requested before
+      // the first is used: a dependent memory round trip per PAIR of entries instead of two per entry.  ~10 - 15 % of a molecule
+      // batch's edges come through here, and the rows of a workgroup wait for the slowest one at the end of the phase.
       const bool in = ti[u] >= blk.n0 && ti[u] < blk.n1;
+      const int s0 = rowptr_g[ti[u]], s1 = rowptr_g[ti[u] + 1];
       const Vec<VEC> eh = Vec<VEC>::load(e_hat + id[u] * d + c);
       Vec<VEC> gx = Vec<VEC>::load(g_x + ti[u] * ldgx + c);
       if constexpr ((FOLD & 1) != 0) gx = FK.node(gx, Vec<VEC>::load(x_tilde + ti[u] * d + c), ti[u], c);
       // den of the target, as the forward summed it: walk the target's own incoming segment (global CSR)
       Vec<VEC> dn = Vec<VEC>::zero();
-      for (int k2 = rowptr_g[ti[u]]; k2 < rowptr_g[ti[u] + 1]; ++k2) {
-        const int64_t id2 = eid_g[k2];
-        const Vec<VEC> e2 = Vec<VEC>::load(e_hat + id2 * d + c);
-        const float r2 = GATE ? r_edge[id2] : 1.0f;
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-          const float s2 = sigmoidf_fast(e2[v]);
-          dn[v] += GATE ? s2 * r2 : s2;
-        }
-      }
+      int k2 = s0;
+      for (; k2 + 2 <= s1; k2 += 2) bwd_b_den<VEC, GATE, 2>(e_hat, eid_g + k2, r_edge, d, c, dn);
+      if (k2 < s1) bwd_b_den<VEC, GATE, 1>(e_hat, eid_g + k2, r_edge, d, c, dn);
       Vec<VEC> p0 = Vec<VEC>::load((in ? g_Ce : g_e) + id[u] * d + c);   // own delta row, or g_e to rebuild it
       if constexpr ((FOLD & 2) != 0) { if (!in) p0 = FK.edge(p0, eh, id[u], c); }
       const float rr = GATE ? r_edge[id[u]] : 1.0f;
