@@ -425,16 +425,19 @@ def kernel_rooflines(dev, profile, nb, d=384, H=16, in_step=None, layers=10, onl
     a_rot = max(2, -(-ROTATE_BYTES // a_bytes))
     asets = [at_set() for _ in range(a_rot)]
 
+    gi.nmax_host = nmax_host
+    order = gi.attn_order(H)            # the balanced dispatch order the step's attention launches use (ops.GraphIndex)
+
     def at_fwd(i=0, p=0.1):
         q = asets[i]
         check(L.gps_seg_attn_fwd(ptr(q["qkv"]), 3 * d, ptr(gi.ptr), ptr(gi.tile_graph), ptr(gi.tile_row0),
-                                 gi.max_tiles, N, H, dh, scale, p, 1234, ptr(q["out"]), ptr(q["lse"]), nb, nmax_host, None, current_stream(dev)))
+                                 gi.max_tiles, N, H, dh, scale, p, 1234, ptr(q["out"]), ptr(q["lse"]), nb, nmax_host, None, ptr(order), current_stream(dev)))
 
     def at_bwd(i=0, p=0.1):
         q = asets[i]
         check(L.gps_seg_attn_bwd(ptr(q["dout"]), ptr(q["qkv"]), 3 * d, ptr(q["out"]), ptr(q["lse"]), ptr(gi.ptr),
                                  ptr(gi.tile_graph), ptr(gi.tile_row0), gi.max_tiles, N, H, dh, scale,
-                                 p, 1234, ptr(q["delta"]), ptr(q["dqkv"]), 3 * d, nb, nmax_host, None, current_stream(dev)))
+                                 p, 1234, ptr(q["delta"]), ptr(q["dqkv"]), 3 * d, nb, nmax_host, None, ptr(order), current_stream(dev)))
 
     for i in range(n_rot):                 # valid saved tensors (e_hat, x_tilde) for the backward kernel
         gg_fwd(i)

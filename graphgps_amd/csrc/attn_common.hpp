@@ -66,9 +66,10 @@ __device__ __forceinline__ float group_sum(float v) {
 // instantiation; the backward additionally needs every graph to fit one 64-row block.
 bool sattn_applicable(const void* qkv, int64_t ld_qkv, const void* out, int H, int dh);
 void sattn_fwd_launch(const float* qkv, int64_t ld_qkv, const int32_t* ptr, int64_t B, int64_t N, int H, int dh,
-                      float scale, float p_drop, uint64_t seed, float* out, float* lse, uint32_t* amax, hipStream_t s);
+                      float scale, float p_drop, uint64_t seed, float* out, float* lse, uint32_t* amax, const int32_t* order,
+                      hipStream_t s);
 void sattn_bwd_launch(const float* d_out, const float* qkv, int64_t ld_qkv, const float* out, const float* lse,
                       const int32_t* ptr, int64_t B, int64_t N, int H, int dh, float scale, float p_drop,
-                      uint64_t seed, float* d_qkv, int64_t ld_dqkv, uint32_t* amax, hipStream_t s);
+                      uint64_t seed, float* d_qkv, int64_t ld_dqkv, uint32_t* amax, const int32_t* order, hipStream_t s);
 
 }  // namespace attn

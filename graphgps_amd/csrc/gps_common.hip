@@ -44,7 +44,7 @@ int launch_status(const char* what) {
 }  // namespace gps
 
 extern "C" {
-int gps_abi_version(void) { return 10; }
+int gps_abi_version(void) { return 11; }
 const char* gps_last_error(void) { return gps::g_err; }
 int gps_set_dropout_salt(const uint64_t* device_salt) {
   gps::g_dropout_salt = device_salt;

@@ -4,6 +4,8 @@
 // atomic cursor (arbitrary), then each segment is sorted by original edge id, which is exactly
 // the stable counting-sort order (== numpy argsort(kind='stable')) and the order in which the
 // reference's CPU scatter accumulates (graphgps/layer/gatedgcn_layer.py:117-123).
+#include <algorithm>
+
 #include "gps_common.hpp"
 
 namespace {
@@ -136,6 +138,28 @@ __global__ void k_tile_map(const int32_t* __restrict__ ptr, int64_t B, int64_t m
   }
 }
 
+// Dispatch order of the block-form attention kernels (csrc/sattn.hip: one wavefront per (graph, head), every wavefront of the
+// launch resident at once, so a SIMD's time is the SUM of the work of the wavefronts it happens to hold and the launch ends
+// with the most loaded SIMD).  Slot t of `order` names the graph whose H wavefronts are dispatched t-th.  Graphs are ranked by
+// size (descending, ties by id) and dealt to the slots in a snake over rows of `cols` -- the slots t, t + cols, t + 2 cols, ...
+// share CUs -- so every CU gets a mix of long and short graphs: at P30 x 256 the most loaded SIMD holds 23 - 25 units of
+// tile-pair work instead of 36 - 43 (the mean is 23).  O(B^2) comparisons; beyond 4,096 graphs the identity.
+__global__ __launch_bounds__(256) void k_graph_order(const int32_t* __restrict__ ptr, int B, int cols, int32_t* __restrict__ order) {
+  const int g = blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= B) return;
+  if (B > 4096) { order[g] = g; return; }
+  const int n = ptr[g + 1] - ptr[g];
+  int rank = 0;
+  for (int j = 0; j < B; ++j) {
+    const int m = ptr[j + 1] - ptr[j];
+    rank += (m > n) || (m == n && j < g);
+  }
+  const int row = rank / cols, pos = rank - row * cols;
+  const int width = min(cols, B - row * cols);                  // (the last row may be partial)
+  const int col = (row & 1) ? width - 1 - pos : pos;
+  order[row * cols + col] = g;
+}
+
 }  // namespace
 
 extern "C" {
@@ -188,6 +212,20 @@ int gps_segment_ptr_from_batch(const int64_t* batch, int64_t N, int64_t B, int32
               "gps_segment_ptr_from_batch: bad arguments");
   k_ptr_from_batch<<<gps::grid_for(N + 1, 256), 256, 0, gps::as_stream(stream)>>>(batch, N, B, ptr);
   return gps::launch_status("gps_segment_ptr_from_batch");
+}
+
+int gps_attn_graph_order(const int32_t* ptr, int64_t B, int H, int32_t* order, gps_stream_t stream) {
+  GPS_REQUIRE(ptr && order && B >= 1 && H >= 1, "gps_attn_graph_order: bad arguments");
+  static const int cus = []() {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+    return n > 0 ? n : 256;
+  }();
+  // graphs per "row" of the chip: workgroup b of a fully resident grid runs on CU b % cus (tools/micro/hwid_probe.hip), a
+  // graph's H wavefronts are H / 4 consecutive 4-wavefront workgroups
+  const int cols = (int)std::max<int64_t>(1, (int64_t)cus * 4 / H);
+  k_graph_order<<<gps::grid_for(B, 256), 256, 0, gps::as_stream(stream)>>>(ptr, (int)std::min<int64_t>(B, INT32_MAX), cols, order);
+  return gps::launch_status("gps_attn_graph_order");
 }
 
 int gps_attn_tile_map(const int32_t* ptr, int64_t B, int64_t max_tiles, int32_t* tile_graph,

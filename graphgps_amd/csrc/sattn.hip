@@ -102,13 +102,15 @@ struct Item {
 // (with the tile map two thirds of the slots start no block, and although such a wave exits at once, the live ones
 // end up spread over three dispatch generations instead of one -- measured: 27 us against the ~8 us of one
 // generation).
-__device__ __forceinline__ Item item_setup(const int32_t* __restrict__ ptr, int64_t B, int H) {
+// `order` (or nullptr): slot -> graph, the balanced dispatch order of gps_attn_graph_order (csrc/graph_index.hip)
+__device__ __forceinline__ Item item_setup(const int32_t* __restrict__ ptr, int64_t B, int H, const int32_t* __restrict__ order) {
   Item it;
   it.live = false;
   const int64_t wi = blockIdx.x * (int64_t)(blockDim.x >> 6) + (threadIdx.x >> 6);
   if (wi >= B * H) return it;
-  const int64_t g = wi / H;
-  it.h = (int)(wi - g * H);
+  const int64_t slot = wi / H;
+  it.h = (int)(wi - slot * H);
+  const int64_t g = order ? order[slot] : slot;
   it.n0 = ptr[g];
   it.n = ptr[g + 1] - it.n0;
   it.live = it.n > 0;
@@ -254,8 +256,8 @@ template <int DH, bool DROP>
 __global__ __launch_bounds__(256, DH >= 32 ? 3 : 4) void k_sattn_fwd(
     const float* __restrict__ qkv, int64_t ld64, const int32_t* __restrict__ ptr, int64_t B, int64_t N, int H,
     float scale, uint32_t thr16, float inv_keep, uint64_t seed, const uint64_t* __restrict__ salt,
-    float* __restrict__ out, float* __restrict__ lse, uint32_t* __restrict__ amax) {
-  const Item it = item_setup(ptr, B, H);      // host guarantees n <= 64: one block per graph
+    float* __restrict__ out, float* __restrict__ lse, uint32_t* __restrict__ amax, const int32_t* __restrict__ order) {
+  const Item it = item_setup(ptr, B, H, order);      // host guarantees n <= 64: one block per graph
   if (!it.live) return;
   // the block form is selected by a HOST hint (the batch's longest graph); a stale or wrong hint must not produce a silently
   // truncated result (only the first 64 rows of the graph would be touched): abort the launch loudly instead
@@ -495,10 +497,10 @@ __global__ __launch_bounds__(256, 2) void k_sattn_bwd(
     const float* __restrict__ d_out, const float* __restrict__ qkv, int64_t ld64, const float* __restrict__ out,
     const float* __restrict__ lse, const int32_t* __restrict__ ptr, int64_t B, int64_t N, int H, float scale,
     uint32_t thr16, float inv_keep, uint64_t seed, const uint64_t* __restrict__ salt, float* __restrict__ d_qkv,
-    int64_t ldg, uint32_t* __restrict__ amax) {
+    int64_t ldg, uint32_t* __restrict__ amax, const int32_t* __restrict__ order) {
   __shared__ __attribute__((aligned(16))) float sT[4][2 * 16 * 20];   // per-wave transpose scratch (P_drop | dS)
   __shared__ __attribute__((aligned(16))) float sK[4][SGeo<DH>::DT * 16 * KTP];   // per-wave K^T[dh][key]
-  const Item it = item_setup(ptr, B, H);      // host guarantees n <= 64: one block per graph
+  const Item it = item_setup(ptr, B, H, order);      // host guarantees n <= 64: one block per graph
   if (!it.live) return;
   // the block form is selected by a HOST hint (the batch's longest graph); a stale or wrong hint must not produce a silently
   // truncated result (only the first 64 rows of the graph would be touched): abort the launch loudly instead
@@ -535,7 +537,8 @@ bool sattn_applicable(const void* qkv, int64_t ld_qkv, const void* out, int H, i
 
 // Launch the block-form forward.  Preconditions: sattn_applicable().
 void sattn_fwd_launch(const float* qkv, int64_t ld_qkv, const int32_t* ptr, int64_t B, int64_t N, int H, int dh,
-                      float scale, float p_drop, uint64_t seed, float* out, float* lse, uint32_t* amax, hipStream_t s) {
+                      float scale, float p_drop, uint64_t seed, float* out, float* lse, uint32_t* amax, const int32_t* order,
+                      hipStream_t s) {
   const uint32_t thr16 = drop_thr16(p_drop);
   const float inv_keep = p_drop > 0.0f ? drop_inv_keep(thr16) : 1.0f;
   const unsigned grid = gps::grid_for(B * H, 4);
@@ -543,10 +546,10 @@ void sattn_fwd_launch(const float* qkv, int64_t ld_qkv, const int32_t* ptr, int6
   do {                                                                                                          \
     if (p_drop > 0.0f)                                                                                          \
       k_sattn_fwd<D, true><<<grid, 256, 0, s>>>(qkv, ld_qkv, ptr, B, N, H, scale, thr16, inv_keep, seed,         \
-                                                gps::dropout_salt(), out, lse, amax);                            \
+                                                gps::dropout_salt(), out, lse, amax, order);                        \
     else                                                                                                        \
       k_sattn_fwd<D, false><<<grid, 256, 0, s>>>(qkv, ld_qkv, ptr, B, N, H, scale, thr16, inv_keep, seed,        \
-                                                 gps::dropout_salt(), out, lse, amax);                           \
+                                                 gps::dropout_salt(), out, lse, amax, order);                       \
   } while (0)
   switch (dh) {
     case 8: SA_FWD(8); break;
@@ -560,7 +563,7 @@ void sattn_fwd_launch(const float* qkv, int64_t ld_qkv, const int32_t* ptr, int6
 // Launch the fused backward (every graph has <= 64 nodes).  Preconditions: sattn_applicable(), aligned d_out / d_qkv.
 void sattn_bwd_launch(const float* d_out, const float* qkv, int64_t ld_qkv, const float* out, const float* lse,
                       const int32_t* ptr, int64_t B, int64_t N, int H, int dh, float scale, float p_drop,
-                      uint64_t seed, float* d_qkv, int64_t ld_dqkv, uint32_t* amax, hipStream_t s) {
+                      uint64_t seed, float* d_qkv, int64_t ld_dqkv, uint32_t* amax, const int32_t* order, hipStream_t s) {
   const uint32_t thr16 = drop_thr16(p_drop);
   const float inv_keep = p_drop > 0.0f ? drop_inv_keep(thr16) : 1.0f;
   const unsigned grid = gps::grid_for(B * H, 4);
@@ -568,10 +571,10 @@ void sattn_bwd_launch(const float* d_out, const float* qkv, int64_t ld_qkv, cons
   do {                                                                                                          \
     if (p_drop > 0.0f)                                                                                          \
       k_sattn_bwd<D, true><<<grid, 256, 0, s>>>(d_out, qkv, ld_qkv, out, lse, ptr, B, N, H, scale, thr16,        \
-                                                inv_keep, seed, gps::dropout_salt(), d_qkv, ld_dqkv, amax);      \
+                                                inv_keep, seed, gps::dropout_salt(), d_qkv, ld_dqkv, amax, order);      \
     else                                                                                                        \
       k_sattn_bwd<D, false><<<grid, 256, 0, s>>>(d_out, qkv, ld_qkv, out, lse, ptr, B, N, H, scale, thr16,       \
-                                                 inv_keep, seed, gps::dropout_salt(), d_qkv, ld_dqkv, amax);     \
+                                                 inv_keep, seed, gps::dropout_salt(), d_qkv, ld_dqkv, amax, order);     \
   } while (0)
   switch (dh) {
     case 8: SA_BWD(8); break;

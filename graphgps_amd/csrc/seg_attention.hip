@@ -601,7 +601,7 @@ static int seg_attn_fwd_impl(const char* who, const float* qkv, int64_t ld_qkv, 
                              int64_t nmax, const int32_t* ptr, const int32_t* tile_graph,
                              const int32_t* tile_row0, int64_t max_tiles, int64_t N, int H, int dh, float scale,
                              float p_drop, uint64_t seed, float* out, float* lse, int64_t num_graphs,
-                             int64_t max_graph_nodes, uint32_t* amax, gps_stream_t stream) {
+                             int64_t max_graph_nodes, uint32_t* amax, const int32_t* order, gps_stream_t stream) {
   GPS_REQUIRE(N >= 0 && H > 0 && dh > 0 && max_tiles >= 0 && ld_qkv >= 3LL * H * dh,
               "%s: bad sizes N=%lld H=%d dh=%d ld=%lld", who, (long long)N, H, dh, (long long)ld_qkv);
   GPS_REQUIRE(p_drop >= 0.0f && p_drop < 1.0f, "%s: p_drop=%f outside [0,1)", who, p_drop);
@@ -620,7 +620,7 @@ static int seg_attn_fwd_impl(const char* who, const float* qkv, int64_t ld_qkv, 
   hipStream_t s = gps::as_stream(stream);
   if (!bias && num_graphs > 0 && max_graph_nodes > 0 && max_graph_nodes <= 64 &&
       attn::sattn_applicable(qkv, ld_qkv, out, H, dh)) {            // block form (sattn.hip)
-    attn::sattn_fwd_launch(qkv, ld_qkv, ptr, num_graphs, N, H, dh, scale, p_drop, seed, out, lse, amax, s);
+    attn::sattn_fwd_launch(qkv, ld_qkv, ptr, num_graphs, N, H, dh, scale, p_drop, seed, out, lse, amax, order, s);
     return gps::launch_status(who);
   }
   const bool vec = ld_qkv % 4 == 0 && (H * dh) % 4 == 0 && al16(qkv) && al16(out);
@@ -656,7 +656,8 @@ static int seg_attn_bwd_impl(const char* who, const float* d_out, const float* q
                              const int32_t* ptr, const int32_t* tile_graph, const int32_t* tile_row0,
                              int64_t max_tiles, int64_t N, int H, int dh, float scale, float p_drop,
                              uint64_t seed, float* delta, float* d_qkv, int64_t ld_dqkv, float* d_bias,
-                             int64_t num_graphs, int64_t max_graph_nodes, uint32_t* amax, gps_stream_t stream) {
+                             int64_t num_graphs, int64_t max_graph_nodes, uint32_t* amax, const int32_t* order,
+                             gps_stream_t stream) {
   GPS_REQUIRE(N >= 0 && H > 0 && dh > 0 && max_tiles >= 0 && ld_qkv >= 3LL * H * dh &&
                   ld_dqkv >= 3LL * H * dh,
               "%s: bad sizes", who);
@@ -680,7 +681,7 @@ static int seg_attn_bwd_impl(const char* who, const float* d_out, const float* q
   if (!bias && num_graphs > 0 && max_graph_nodes > 0 && max_graph_nodes <= 64 &&
       attn::sattn_applicable(qkv, ld_qkv, out, H, dh) && ld_dqkv % 4 == 0 && al16(d_out) && al16(d_qkv)) {
     attn::sattn_bwd_launch(d_out, qkv, ld_qkv, out, lse, ptr, num_graphs, N, H, dh, scale, p_drop, seed, d_qkv,
-                           ld_dqkv, amax, s);                    // one fused launch (sattn.hip)
+                           ld_dqkv, amax, order, s);             // one fused launch (sattn.hip)
     return gps::launch_status(who);
   }
   const bool vec = ld_qkv % 4 == 0 && ld_dqkv % 4 == 0 && (H * dh) % 4 == 0 && al16(qkv) && al16(out) &&
@@ -723,20 +724,22 @@ static int seg_attn_bwd_impl(const char* who, const float* d_out, const float* q
 int gps_seg_attn_fwd(const float* qkv, int64_t ld_qkv, const int32_t* ptr,
                      const int32_t* tile_graph, const int32_t* tile_row0, int64_t max_tiles,
                      int64_t N, int H, int dh, float scale, float p_drop, uint64_t seed, float* out,
-                     float* lse, int64_t num_graphs, int64_t max_graph_nodes, uint32_t* amax, gps_stream_t stream) {
+                     float* lse, int64_t num_graphs, int64_t max_graph_nodes, uint32_t* amax, const int32_t* graph_order,
+                     gps_stream_t stream) {
   GPS_REQUIRE(!amax || ((H * dh) % 4 == 0 && al16(out)), "gps_seg_attn_fwd: the max|out| record needs 16-byte-aligned rows");
   return seg_attn_fwd_impl("gps_seg_attn_fwd", qkv, ld_qkv, nullptr, 0, ptr, tile_graph, tile_row0, max_tiles,
-                           N, H, dh, scale, p_drop, seed, out, lse, num_graphs, max_graph_nodes, amax, stream);
+                           N, H, dh, scale, p_drop, seed, out, lse, num_graphs, max_graph_nodes, amax, graph_order, stream);
 }
 
 int gps_seg_attn_bwd(const float* d_out, const float* qkv, int64_t ld_qkv, const float* out,
                      const float* lse, const int32_t* ptr, const int32_t* tile_graph,
                      const int32_t* tile_row0, int64_t max_tiles, int64_t N, int H, int dh,
                      float scale, float p_drop, uint64_t seed, float* delta, float* d_qkv,
-                     int64_t ld_dqkv, int64_t num_graphs, int64_t max_graph_nodes, uint32_t* amax, gps_stream_t stream) {
+                     int64_t ld_dqkv, int64_t num_graphs, int64_t max_graph_nodes, uint32_t* amax,
+                     const int32_t* graph_order, gps_stream_t stream) {
   return seg_attn_bwd_impl("gps_seg_attn_bwd", d_out, qkv, ld_qkv, nullptr, 0, out, lse, ptr, tile_graph,
                            tile_row0, max_tiles, N, H, dh, scale, p_drop, seed, delta, d_qkv, ld_dqkv, nullptr,
-                           num_graphs, max_graph_nodes, amax, stream);
+                           num_graphs, max_graph_nodes, amax, graph_order, stream);
 }
 
 int gps_seg_attn_bias_fwd(const float* qkv, int64_t ld_qkv, const float* bias, int64_t nmax,
@@ -745,7 +748,7 @@ int gps_seg_attn_bias_fwd(const float* qkv, int64_t ld_qkv, const float* bias, i
                           uint64_t seed, float* out, float* lse, gps_stream_t stream) {
   GPS_REQUIRE(bias != nullptr || N == 0, "gps_seg_attn_bias_fwd: null bias");
   return seg_attn_fwd_impl("gps_seg_attn_bias_fwd", qkv, ld_qkv, bias, nmax, ptr, tile_graph, tile_row0,
-                           max_tiles, N, H, dh, scale, p_drop, seed, out, lse, 0, 0, nullptr, stream);
+                           max_tiles, N, H, dh, scale, p_drop, seed, out, lse, 0, 0, nullptr, nullptr, stream);
 }
 
 int gps_seg_attn_bias_bwd(const float* d_out, const float* qkv, int64_t ld_qkv, const float* bias,
@@ -756,7 +759,7 @@ int gps_seg_attn_bias_bwd(const float* d_out, const float* qkv, int64_t ld_qkv, 
   GPS_REQUIRE(bias != nullptr || N == 0, "gps_seg_attn_bias_bwd: null bias");
   return seg_attn_bwd_impl("gps_seg_attn_bias_bwd", d_out, qkv, ld_qkv, bias, nmax, out, lse, ptr, tile_graph,
                            tile_row0, max_tiles, N, H, dh, scale, p_drop, seed, delta, d_qkv, ld_dqkv, d_bias, 0, 0,
-                           nullptr, stream);
+                           nullptr, nullptr, stream);
 }
 
 }  // extern "C"

@@ -590,7 +590,7 @@ class _GPSBlock(torch.autograd.Function):
             else:
                 check(L.gps_seg_attn_fwd(P + 4 * fs, ldp, ptr(gi.ptr), ptr(gi.tile_graph), ptr(gi.tile_row0),
                                          gi.max_tiles, N, H, dh, scale, p_at, s[2], ptr(o), ptr(lse),
-                                         gi.B, int(gi.nmax_host), ptr(aw(_R_O)), sb), "gps_seg_attn_fwd")
+                                         gi.B, int(gi.nmax_host), ptr(aw(_R_O)), ptr(gi.attn_order(H)), sb), "gps_seg_attn_fwd")
             if am is not None and perf:         # (the attention kernel raised o's record itself; FAVOR+ does not)
                 _gemm.absmax([o], out=rec[_R_O:_R_O + 1])
 
@@ -782,8 +782,8 @@ class _GPSBlock(torch.autograd.Function):
                 delta = _E(H, N, **f32)
                 check(L.gps_seg_attn_bwd(ptr(g_o), P + 4 * fs, ldp, ptr(o), ptr(lse), ptr(gi.ptr),
                                          ptr(gi.tile_graph), ptr(gi.tile_row0), gi.max_tiles, N, H, dh, scale,
-                                         p_at, s[2], ptr(delta), G + 4 * fs, ldp, gi.B, int(gi.nmax_host), ptr(bw(3)), sb),
-                      "gps_seg_attn_bwd")
+                                         p_at, s[2], ptr(delta), G + 4 * fs, ldp, gi.B, int(gi.nmax_host), ptr(bw(3)),
+                                         ptr(gi.attn_order(H)), sb), "gps_seg_attn_bwd")
 
         g_ce = _E(E, d, **f32)
         if fold:
@@ -882,7 +882,7 @@ class _GPSBlockGINE(torch.autograd.Function):
             scale = float(dh) ** -0.5
             check(L.gps_seg_attn_fwd(ptr(qkv), 3 * d, ptr(gi.ptr), ptr(gi.tile_graph), ptr(gi.tile_row0),
                                      gi.max_tiles, N, H, dh, scale, p_at, s[2], ptr(o), ptr(lse),
-                                     gi.B, int(gi.nmax_host), None, sb), "gps_seg_attn_fwd")
+                                     gi.B, int(gi.nmax_host), None, ptr(gi.attn_order(H)), sb), "gps_seg_attn_fwd")
             ao = torch.addmm(sa.out_proj.bias, o, sa.out_proj.weight.t())
         # -- local half: GINE core + MLP (gps_layer.py:62-69,183-185) -------------------------------
         agg = _E(N, d, **f32)
@@ -964,8 +964,8 @@ class _GPSBlockGINE(torch.autograd.Function):
             g_qkv, delta = _E(N, 3 * d, **f32), _E(H, N, **f32)
             check(L.gps_seg_attn_bwd(ptr(g_o), ptr(qkv), 3 * d, ptr(o), ptr(lse), ptr(gi.ptr),
                                      ptr(gi.tile_graph), ptr(gi.tile_row0), gi.max_tiles, N, H, dh, scale,
-                                     p_at, s[2], ptr(delta), ptr(g_qkv), 3 * d, gi.B, int(gi.nmax_host), None, sb),
-                  "gps_seg_attn_bwd")
+                                     p_at, s[2], ptr(delta), ptr(g_qkv), 3 * d, gi.B, int(gi.nmax_host), None,
+                                     ptr(gi.attn_order(H)), sb), "gps_seg_attn_bwd")
         # local half: MLP backward, GINE core backward
         g_g1r = g_g2.mm(lin2.weight)
         g_g1 = _K.act_drop_bwd(L, g_g1r, g1, True, 0.0, 0, st)
@@ -1157,8 +1157,8 @@ def gps_block_eval(layer, x, e, gi):
                              ptr(gi.eid_by_dst), N, E, d, ptr(xt), ptr(eh), None, st), "gps_gatedgcn_fwd")
     o, lse = _E(N, d, **f32), _E(H, N, **f32)
     check(L.gps_seg_attn_fwd(P + 4 * fs, ldp, ptr(gi.ptr), ptr(gi.tile_graph), ptr(gi.tile_row0), gi.max_tiles, N, H, dh,
-                             float(dh) ** -0.5, 0.0, 0, ptr(o), ptr(lse), gi.B, int(gi.nmax_host), ptr(aw(_R_O)), st),
-          "gps_seg_attn_fwd")
+                             float(dh) ** -0.5, 0.0, 0, ptr(o), ptr(lse), gi.B, int(gi.nmax_host), ptr(aw(_R_O)),
+                             ptr(gi.attn_order(H)), st), "gps_seg_attn_fwd")
     za = _gemm.gemm_panel(o, imgs[2][0], d, bias=_B(R.out_proj), addend=x, a_amax=aw(_R_O))     # x + out_proj(o)
     x1, e1, h, out = _E(N, d, **f32), _E(E, d, **f32), _E(N, d, **f32), _E(N, d, **f32)
     _norm.fwd([_norm.fwd_task(_norm.BN_ACT, xt, N, res=x, bn1=bnx, relu=True, out=x1),

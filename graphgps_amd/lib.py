@@ -15,7 +15,7 @@ import torch  # noqa: F401  -- must be imported first: it maps the HIP runtime o
 _HERE = os.path.dirname(os.path.abspath(__file__))
 # GPS_HIP_LIB: an alternative build of the same ABI (A/B timing of kernel variants in one process launch each)
 LIB_PATH = os.environ.get("GPS_HIP_LIB") or os.path.join(_HERE, "csrc", "libgps_hip.so")
-ABI_VERSION = 10
+ABI_VERSION = 11
 
 _lib: Optional[ctypes.CDLL] = None
 
@@ -90,9 +90,10 @@ _SIGNATURES = {
                               c_int, c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, c_int64, _P, c_size_t, _P]),
     "gps_attn_supported_head_dim": (c_int, [c_int]),
     "gps_seg_attn_fwd": (c_int, [_P, c_int64, _P, _P, _P, c_int64, c_int64, c_int, c_int, c_float,
-                                 c_float, c_uint64, _P, _P, c_int64, c_int64, _P, _P]),
+                                 c_float, c_uint64, _P, _P, c_int64, c_int64, _P, _P, _P]),
     "gps_seg_attn_bwd": (c_int, [_P, _P, c_int64, _P, _P, _P, _P, _P, c_int64, c_int64, c_int, c_int,
-                                 c_float, c_float, c_uint64, _P, _P, c_int64, c_int64, c_int64, _P, _P]),
+                                 c_float, c_float, c_uint64, _P, _P, c_int64, c_int64, c_int64, _P, _P, _P]),
+    "gps_attn_graph_order": (c_int, [_P, c_int64, c_int, _P, _P]),
     "gps_edge_attn_supported": (c_int, [c_int, c_int]),
     "gps_edge_attn_fwd": (c_int, [_P, _P, _P, c_int64, _P, _P, _P, _P, c_int64, c_int64, c_int, c_int, c_float, c_int,
                                   _P, _P, _P, _P, _P]),

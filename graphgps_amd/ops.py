@@ -41,6 +41,9 @@ def _f32c(t: torch.Tensor, name: str) -> torch.Tensor:
 # -------------------------------------------------------------------------------------------
 # per-batch graph index
 # -------------------------------------------------------------------------------------------
+_ATTN_ORDER = os.environ.get("GPS_ATTN_ORDER", "1") != "0"
+
+
 @dataclass
 class GraphIndex:
     """Device-side index of one batch; built once, shared by all layers (fwd and bwd)."""
@@ -66,6 +69,26 @@ class GraphIndex:
     n_real: Optional[torch.Tensor] = None
     e_real: Optional[torch.Tensor] = None
     b_real: Optional[torch.Tensor] = None     # ... and of REAL graphs (round 5: the Performer's Nmax)
+    orders: Optional[dict] = None             # head count -> int32 [B]: attn_order()
+
+    def attn_order(self, num_heads: int) -> Optional[torch.Tensor]:
+        """Balanced dispatch order of the graphs for the block-form attention kernels (``gps_attn_graph_order``: long and
+        short graphs dealt to the CUs in a snake; scheduling only, results do not depend on it), made on first use per head
+        count on the current stream -- inside the captured step when the index is.  None where it cannot matter (one
+        graph, graphs beyond the block form) or with GPS_ATTN_ORDER=0 (A/B)."""
+        if not _ATTN_ORDER or self.B < 2 or not 0 < int(self.nmax_host) <= 64:
+            return None
+        if self.orders is None:
+            self.orders = {}
+        if num_heads in self.orders:
+            return self.orders[num_heads]
+        t = None
+        if t is None:
+            t = torch.empty(self.B, dtype=torch.int32, device=self.ptr.device)
+            check(_lib.load().gps_attn_graph_order(ptr(self.ptr), self.B, int(num_heads), ptr(t),
+                                                   current_stream(self.ptr.device)), "gps_attn_graph_order")
+            self.orders[num_heads] = t
+        return t
 
 
 def build_graph_index(edge_index: torch.Tensor, num_nodes: int, num_graphs: int,
@@ -435,8 +458,8 @@ class _SegmentAttention(torch.autograd.Function):
         if bias is None:
             check(L.gps_seg_attn_fwd(ptr(qkv), 3 * d, ptr(gi.ptr), ptr(gi.tile_graph),
                                      ptr(gi.tile_row0), gi.max_tiles, N, H, dh, scale, float(p_drop),
-                                     seed, ptr(out), ptr(lse), gi.B, int(gi.nmax_host), None, current_stream(dev)),
-                  "gps_seg_attn_fwd")
+                                     seed, ptr(out), ptr(lse), gi.B, int(gi.nmax_host), None, ptr(gi.attn_order(H)),
+                                     current_stream(dev)), "gps_seg_attn_fwd")
             ctx.save_for_backward(qkv, out, lse)
         else:
             bias = _f32c(bias, "attn_bias")
@@ -464,7 +487,8 @@ class _SegmentAttention(torch.autograd.Function):
             check(L.gps_seg_attn_bwd(ptr(d_out), ptr(qkv), qkv.shape[1], ptr(out), ptr(lse), ptr(gi.ptr),
                                      ptr(gi.tile_graph), ptr(gi.tile_row0), gi.max_tiles, N, H, dh,
                                      ctx.scale, ctx.p_drop, ctx.seed, ptr(delta), ptr(d_qkv),
-                                     d_qkv.shape[1], gi.B, int(gi.nmax_host), None, current_stream(dev)), "gps_seg_attn_bwd")
+                                     d_qkv.shape[1], gi.B, int(gi.nmax_host), None, ptr(gi.attn_order(H)),
+                                     current_stream(dev)), "gps_seg_attn_bwd")
             return d_qkv, None, None, None, None, None
         bias = ctx.saved_tensors[3]
         d_bias = torch.zeros_like(bias)       # padded region: zero gradient, as under the reference's mask

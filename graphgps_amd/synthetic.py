@@ -47,6 +47,8 @@ def graph_sizes(profile: str, num_graphs: int, gen: torch.Generator) -> List[int
         mu = math.log(125.0) - 0.5 * sd * sd
         v = torch.exp(torch.randn(num_graphs, generator=gen) * sd + mu)
         return v.round().clamp(11, 1000).long().tolist()
+    if p.startswith("U") and p[1:].isdigit():        # probes: every graph of the same size (tools/kernel_probe.py U30)
+        return [int(p[1:])] * num_graphs
     raise ValueError(f"unknown synthetic profile {profile!r}")
 
 

@@ -395,7 +395,14 @@ int gps_attn_supported_head_dim(int dh);
 int gps_seg_attn_fwd(const float* qkv, int64_t ld_qkv, const int32_t* ptr,
                      const int32_t* tile_graph, const int32_t* tile_row0, int64_t max_tiles,
                      int64_t N, int H, int dh, float scale, float p_drop, uint64_t seed, float* out,
-                     float* lse, int64_t num_graphs, int64_t max_graph_nodes, uint32_t* amax, gps_stream_t stream);
+                     float* lse, int64_t num_graphs, int64_t max_graph_nodes, uint32_t* amax, const int32_t* graph_order,
+                     gps_stream_t stream);
+/* ABI v11: `graph_order` (or NULL) of gps_seg_attn_fwd / _bwd: int32 [num_graphs] made by gps_attn_graph_order -- the order
+ * in which the block form dispatches the graphs (slot t -> graph id).  Every wavefront of a block-form launch is resident at
+ * once, so a SIMD's time is the sum of the work of the wavefronts it holds; dealing long and short graphs to the CUs in a
+ * snake levels that sum (P30 x 256: forward 22.5 -> 18 us, backward 47.8 -> 38 us).  Scheduling only: results are
+ * bit-identical with or without it; the tile-map kernels ignore it. */
+int gps_attn_graph_order(const int32_t* ptr, int64_t B, int H, int32_t* order, gps_stream_t stream);
 /* ABI v6: `amax` (or NULL) of gps_seg_attn_fwd / _bwd: a max|.| record (GPS_AMAX_WORDS) raised to max|out| / max|d_qkv| --
  * by the block-form kernels themselves (one atomic per wavefront), by a gps_absmax pass behind the tile kernels. */
 /* d_qkv [N,3d] (row stride ld_dqkv) receives dq | dk | dv.  `delta` is an [H,N] scratch buffer
@@ -406,7 +413,8 @@ int gps_seg_attn_bwd(const float* d_out, const float* qkv, int64_t ld_qkv, const
                      const float* lse, const int32_t* ptr, const int32_t* tile_graph,
                      const int32_t* tile_row0, int64_t max_tiles, int64_t N, int H, int dh,
                      float scale, float p_drop, uint64_t seed, float* delta, float* d_qkv,
-                     int64_t ld_dqkv, int64_t num_graphs, int64_t max_graph_nodes, uint32_t* amax, gps_stream_t stream);
+                     int64_t ld_dqkv, int64_t num_graphs, int64_t max_graph_nodes, uint32_t* amax,
+                     const int32_t* graph_order, gps_stream_t stream);
 /* The same core with an additive attention bias: the reference's `attn_mask=batch.attn_bias` operand of
  * torch.nn.MultiheadAttention in the BiasedTransformer branch (graphgps/layer/gps_layer.py:201-203,
  * 234-241) and in GraphormerLayer (graphgps/layer/graphormer_layer.py:43-44).
