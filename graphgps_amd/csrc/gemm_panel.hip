@@ -1081,8 +1081,13 @@ __device__ __forceinline__ void ring16_body(const PanelArgs& P, const int bid) {
     __syncthreads();
     if (t == 0) gps::amax_raise(P.c_amax, max(max(wmax[0], wmax[1]), max(wmax[2], wmax[3])));
   }
-  __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 15));
-  stamp(3);
+  // A workgroup retires with its C stores still in flight (the memory system completes them; the end of the kernel orders
+  // them before the next launch): draining them here kept the CU from taking its next tile for a store round trip per
+  // dispatch round -- only the trace wants the stores-done stamp.
+  if (P.trace) {
+    __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 15));
+    stamp(3);
+  }
 }
 
 template <int MB, int NJ, int EPI, bool HAS_CIN, bool EDGE = false>
