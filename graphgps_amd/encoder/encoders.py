@@ -253,13 +253,10 @@ class TypeDictNodeEncoder(nn.Module):
         self.encoder = nn.Embedding(num_embeddings=num_types, embedding_dim=emb_dim)
 
     def forward(self, batch):
-        x = batch.x
-        if x.is_cuda and torch.is_grad_enabled() and x.dtype == torch.int64 and x.dim() == 2:
-            # the gather launch of the sum-of-embeddings encoders with ONE table: its table gradient is the deterministic
-            # multi-hot contraction instead of ATen's sort-based embedding backward (60 us per call on a 710-node ZINC batch)
-            batch.x = _multihot_embedding(x[:, 0:1], [self.encoder], self)
-            return batch
-        batch.x = self.encoder(x[:, 0])  # only the first column
+        # (nn.Embedding on purpose: the gather-sum / multi-hot path of the sum-of-embeddings encoders was tried here in round 6
+        # -- zinc step 2.55 -> 2.52 ms -- and withdrawn: its table gradient is a library GEMM for batches under 256 rows, and
+        # captured steps that held one died in hipGraph replay on about half of the boxes, profiles/r06_ab_step.txt)
+        batch.x = self.encoder(batch.x[:, 0])  # only the first column
         return batch
 
 
@@ -273,11 +270,7 @@ class TypeDictEdgeEncoder(nn.Module):
         self.encoder = nn.Embedding(num_embeddings=num_types, embedding_dim=emb_dim)
 
     def forward(self, batch):
-        ea = batch.edge_attr
-        if ea.is_cuda and torch.is_grad_enabled() and ea.dtype == torch.int64 and ea.dim() == 1:
-            batch.edge_attr = _multihot_embedding(ea.unsqueeze(1), [self.encoder], self)        # (as TypeDictNodeEncoder)
-            return batch
-        batch.edge_attr = self.encoder(ea)
+        batch.edge_attr = self.encoder(batch.edge_attr)
         return batch
 
 
