@@ -855,8 +855,16 @@ struct Ring16A {
 template <int I>
 struct IntC { static constexpr int value = I; };
 
-template <int MB, int NJ, int EPI, bool HAS_CIN, bool EDGE>
-__device__ __forceinline__ void ring16_body(const PanelArgs& P, const int bid) {
+// PERSIST (k_gemm_ring16_pair's first problem when it spans several dispatch rounds): the workgroup walks tiles bid,
+// bid + stride, ... < ntiles.  The k-loop issues its DMA S - 1 stages ahead and, past a tile's last stage, used to re-fetch
+// that stage to keep the counted waits uniform; here those transfers fetch the NEXT tile's first stages, the last region
+// reads and splits its first k-step, and after the epilogue (C stores; one vmcnt(0): loads and stores share the counter) the
+// loop simply goes on -- the ~3.6 us from a workgroup's entry to its first landed stage are paid once per workgroup instead
+// of once per tile (tools/gemm_trace.py: 20 % of a 128 x 192 tile's life).  Needs KS % S == 0 (the next tile's stage 0 must
+// land in slot 0), no edge shape, an epilogue that leaves the ring alone (EPI <= 2, no max|C| record).
+template <int MB, int NJ, int EPI, bool HAS_CIN, bool EDGE, bool PERSIST = false>
+__device__ __forceinline__ void ring16_body(const PanelArgs& P, const int bid, const int stride = 0, const int ntiles = 0) {
+  static_assert(!PERSIST || (!EDGE && EPI <= 2), "persistent tiles: whole panels, ring-free epilogue");
   constexpr int TNV = 64 * NJ;
   constexpr int BP = rg_bp(NJ);
   constexpr int A_BYTES = rg_a_bytes(MB), SLOT = r16_slot_bytes(MB, NJ);
@@ -880,9 +888,10 @@ __device__ __forceinline__ void ring16_body(const PanelArgs& P, const int bid) {
     if (P.trace && threadIdx.x == 0) P.trace[4 * (size_t)bid + k] = __builtin_amdgcn_s_memtime();
   };
   stamp(0);
-  const int panel = bid / P.row_tiles, rt = bid - panel * P.row_tiles;   // panel-major numbering
-  const int64_t m0 = (int64_t)rt * (64 * MB);
-  const int n0 = panel * TNV;
+  int tile = bid;
+  int panel = tile / P.row_tiles, rt = tile - panel * P.row_tiles;   // panel-major numbering
+  int64_t m0 = (int64_t)rt * (64 * MB);
+  int n0 = panel * TNV;
   const int t = threadIdx.x, lane = t & 63;
   const int wave = __builtin_amdgcn_readfirstlane(t >> 6);
   const int wm = wave >> 1, wn = wave & 1;
@@ -893,27 +902,36 @@ __device__ __forceinline__ void ring16_body(const PanelArgs& P, const int bid) {
 
   // ---- DMA sources (as k_gemm_ring, two W pieces) ------------------------------------------------------------------
   const unsigned char* a_src[NA];
+  const unsigned char* a_srcN[NA];          // PERSIST: the next tile's sources, pre-biased by -KS stages
   int a_tail[NA];
   const int nvc = EDGE ? (P.K - (KS - 1) * BK) / 4 : 8;
-#pragma unroll
-  for (int i = 0; i < NA; ++i) {
-    const int row = 8 * NA * wave + 8 * i + (lane >> 3);
-    const int c = (lane & 7) ^ ((row >> 1) & 7);
-    const int64_t grow = min(m0 + row, P.M - 1);
-    a_src[i] = reinterpret_cast<const unsigned char*>(P.A + grow * P.lda) + c * 16;
-    a_tail[i] = (EDGE && c >= nvc) ? c * 16 : 0;
-  }
   const int64_t stage_stride = (int64_t)P.Nimg * (BK * 2);
   const int64_t piece_stride = stage_stride * KS;
-  const unsigned char* b_src = reinterpret_cast<const unsigned char*>(P.Bp) + ((int64_t)n0 + 16 * NJ * wave + (lane >> 2)) * (BK * 2) +
-                               (((lane & 3) ^ ((lane >> 4) & 3)) * 16);
+  const unsigned char* b_src;
+  const unsigned char* b_srcN = nullptr;
+  auto sources = [&](int64_t tm0, int tn0, const unsigned char* (&as)[NA], const unsigned char*& bs, int64_t bias_stages)
+                     __attribute__((always_inline)) {
+#pragma unroll
+    for (int i = 0; i < NA; ++i) {
+      const int row = 8 * NA * wave + 8 * i + (lane >> 3);
+      const int c = (lane & 7) ^ ((row >> 1) & 7);
+      const int64_t grow = min(tm0 + row, P.M - 1);
+      as[i] = reinterpret_cast<const unsigned char*>(P.A + grow * P.lda) + c * 16 - bias_stages * (BK * 4);
+      if (bias_stages == 0) a_tail[i] = (EDGE && c >= nvc) ? c * 16 : 0;
+    }
+    bs = reinterpret_cast<const unsigned char*>(P.Bp) + ((int64_t)tn0 + 16 * NJ * wave + (lane >> 2)) * (BK * 2) +
+         (((lane & 3) ^ ((lane >> 4) & 3)) * 16) - bias_stages * stage_stride;
+  };
+  sources(m0, n0, a_src, b_src, 0);
+  bool has_next = false;                    // (workgroup-uniform)
   auto dma = [&](int g, int s, unsigned char* slot) __attribute__((always_inline)) {
+    const bool nx = PERSIST && s >= KS;     // past this tile's last stage: the next tile's first stages (has_next holds)
     if (g < NA) {
       if (EDGE) glds16(a_src[g] + (int64_t)s * (BK * 4) - (s == KS - 1 ? a_tail[g] : 0), slot + wave * (NA * 1024) + g * 1024);
-      else glds16(a_src[g] + (int64_t)s * (BK * 4), slot + wave * (NA * 1024) + g * 1024);
+      else glds16((nx ? a_srcN[g] : a_src[g]) + (int64_t)s * (BK * 4), slot + wave * (NA * 1024) + g * 1024);
     } else {
       const int i = g - NA;
-      glds16(b_src + s * stage_stride + (i / NJ) * piece_stride + (i % NJ) * 1024,
+      glds16((nx ? b_srcN : b_src) + s * stage_stride + (i / NJ) * piece_stride + (i % NJ) * 1024,
              slot + A_BYTES + (i / NJ) * BP + wave * (NJ * 1024) + (i % NJ) * 1024);
     }
   };
@@ -1028,12 +1046,20 @@ __device__ __forceinline__ void ring16_body(const PanelArgs& P, const int bid) {
     unsigned char* const cur = ring + I * SLOT;
     unsigned char* const nxt = ring + ((I + 1) % S) * SLOT;
     unsigned char* const lst = ring + ((I + S - 1) % S) * SLOT;
-    region(a0, f0, a1, f1, cur, 1, min(s + S - 1, KS - 1), lst, ND_ODD, ND_EVEN);
+    region(a0, f0, a1, f1, cur, 1, (PERSIST && has_next) ? s + S - 1 : min(s + S - 1, KS - 1), lst, ND_ODD, ND_EVEN);
     __builtin_amdgcn_s_waitcnt(waitcnt_imm((S - 2) * ND, 0));
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_sched_barrier(0);
-    region(a1, f1, a0, f0, nxt, 0, min(s + S, KS - 1), cur, 0, ND_ODD);
+    region(a1, f1, a0, f0, nxt, 0, (PERSIST && has_next) ? s + S : min(s + S, KS - 1), cur, 0, ND_ODD);
   };
+  if (PERSIST) {
+    has_next = tile + stride < ntiles;
+    if (has_next) {
+      const int t2 = tile + stride, p2 = t2 / P.row_tiles;
+      sources((int64_t)(t2 - p2 * P.row_tiles) * (64 * MB), p2 * TNV, a_srcN, b_srcN, KS);
+    }
+  }
+ next_tile:
   int s0 = 0;
   for (; s0 + S <= KS; s0 += S) {
     stage(IntC<0>{}, s0);
@@ -1054,7 +1080,8 @@ __device__ __forceinline__ void ring16_body(const PanelArgs& P, const int bid) {
       }
     }
   }
-  __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 15));         // no DMA may still be writing this workgroup's LDS when it retires
+  if (!(PERSIST && has_next))
+    __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 15));       // no DMA may still be writing this workgroup's LDS when it retires
   stamp(2);
   // un-scale: exact powers of two, two factors so that neither can leave the fp32 exponent range on its own
   const float ua = amax_unscale(bea), uw = amax_unscale(bew);
@@ -1069,6 +1096,29 @@ __device__ __forceinline__ void ring16_body(const PanelArgs& P, const int bid) {
   for (int j = 0; j < NJ; ++j) sk[j] = s1[j] = s2[j] = 0.f;
   float amx = 0.f;
   ring_epilogue<MB, NJ, EPI, HAS_CIN, EDGE>(P, acc, m0, n0, wm, wn, li, kh, sk, s1, s2, amx);
+  if constexpr (PERSIST) {
+    if (has_next) {       // the seam: the next tile's first stages are in the ring (or on their way), its first k-step in a0 / f0
+      __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 15));     // stores and DMA share vmcnt: the loop's counted waits must see DMA only
+#pragma unroll
+      for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int j = 0; j < NJ; ++j)
+#pragma unroll
+          for (int q = 0; q < 16; ++q) acc[mb][j][q] = 0.0f;
+      tile += stride;
+      panel = tile / P.row_tiles; rt = tile - panel * P.row_tiles;
+      m0 = (int64_t)rt * (64 * MB); n0 = panel * TNV;
+#pragma unroll
+      for (int i = 0; i < NA; ++i) a_src[i] = a_srcN[i] + (int64_t)KS * (BK * 4);
+      b_src = b_srcN + (int64_t)KS * stage_stride;
+      has_next = tile + stride < ntiles;
+      if (has_next) {
+        const int t2 = tile + stride, p2 = t2 / P.row_tiles;
+        sources((int64_t)(t2 - p2 * P.row_tiles) * (64 * MB), p2 * TNV, a_srcN, b_srcN, KS);
+      }
+      goto next_tile;
+    }
+  }
   if (EPI == 3) ring_stats<MB, NJ>(P, rt, panel, m0, wm, wn, li, kh, sk, s1, s2, reinterpret_cast<float*>(ring));
   if (EPI == 4) ring_sums<MB, NJ, 3>(P, rt, panel, wm, wn, li, kh, sk, s1, s2, reinterpret_cast<float*>(ring));
   if (P.c_amax) {                                        // workgroup-uniform: max|C| of this tile -> one atomic
@@ -1103,10 +1153,15 @@ __global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring16(const PanelArgs P) 
 // are dispatched in blockIdx order onto CUs as they free up, so when the tile count leaves a last dispatch round mostly empty
 // (P30 x 256: 840 + 240 tiles of 128 x 192 on 256 CUs = 4.2 rounds, the fifth 22 % full), re-cutting that round's tiles in
 // halves ends the launch half a tile-time earlier.
-template <int MB0, int MB1, int NJ, bool HAS_CIN, bool TAIL = false>
+// PERSIST0: the first problem's tiles are walked by `split` persistent workgroups (ring16_body PERSIST) instead of one
+// workgroup each: `tiles0` of them, workgroup b takes b, b + split, ...
+template <int MB0, int MB1, int NJ, bool HAS_CIN, bool TAIL = false, bool PERSIST0 = false>
 __global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring16_pair(const PanelArgs P0, const PanelArgs P1, const int split,
-                                                                 const PanelArgs P2, const int split2) {
-  if ((int)blockIdx.x < split) ring16_body<MB0, NJ, 0, HAS_CIN, false>(P0, (int)blockIdx.x);
+                                                                 const PanelArgs P2, const int split2, const int tiles0) {
+  if ((int)blockIdx.x < split) {
+    if constexpr (PERSIST0) ring16_body<MB0, NJ, 0, HAS_CIN, false, true>(P0, (int)blockIdx.x, split, tiles0);
+    else ring16_body<MB0, NJ, 0, HAS_CIN, false>(P0, (int)blockIdx.x);
+  }
   else if (!TAIL || (int)blockIdx.x < split2) ring16_body<MB1, NJ, 0, HAS_CIN, false>(P1, (int)blockIdx.x - split);
   else ring16_body<1, NJ, 0, HAS_CIN, false>(P2, (int)blockIdx.x - split2);
 }
@@ -1441,7 +1496,9 @@ extern "C" int gps_gemm16_panel_pair(const gps_gemm16_problem* first, const gps_
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
     return n;
   }();
-  static const bool tail_on = []() { const char* v = getenv("GPS_GEMM_TAIL"); return !(v && v[0] == '0'); }();
+  // GPS_GEMM_SCHED (a mask, default 3): 1 = tail balancing, 2 = persistent tiles of the first problem (A/B handles)
+  static const int sched = []() { const char* v = getenv("GPS_GEMM_SCHED"); return v && *v ? atoi(v) : 3; }();
+  const bool tail_on = (sched & 1) != 0;
   PanelArgs P2 = Q[1].P;
   unsigned grid2 = 0;
   if (tail_on && cus > 0 && Q[0].mb == 2 && Q[1].mb == 2) {
@@ -1462,23 +1519,34 @@ extern "C" int gps_gemm16_panel_pair(const gps_gemm16_problem* first, const gps_
       Q[1].grid = (unsigned)(keep * panels1);
     }
   }
-  const unsigned grid = Q[0].grid + Q[1].grid + grid2;
-  const int split = (int)Q[0].grid, split2 = (int)(Q[0].grid + Q[1].grid);
-#define GPS_PAIR(MB0, MB1, NJV, C, T)                                                                               \
+  // Persistent first problem (ring16_body PERSIST): when it spans two dispatch rounds or more, `cus` workgroups walk its tiles
+  // and prefetch across them.  128-row tiles only (the instantiations built), whole 4-slot rotations, no max|C| record.
+  const bool persist_on = (sched & 2) != 0;
+  const int tiles0 = (int)Q[0].grid;
+  const int ks0 = (Q[0].P.K + BK - 1) / BK;
+  const bool persist = persist_on && cus > 0 && Q[0].mb == 2 && Q[1].mb == 2 && tiles0 >= 2 * cus && !Q[0].P.c_amax &&
+                       ks0 % r16_slots(2, Q[0].nj) == 0 && !Q[0].P.trace;
+  const unsigned wg0 = persist ? (unsigned)cus : Q[0].grid;
+  const unsigned grid = wg0 + Q[1].grid + grid2;
+  const int split = (int)wg0, split2 = (int)(wg0 + Q[1].grid);
+#define GPS_PAIR(MB0, MB1, NJV, C, T, PS)                                                                           \
   do {                                                                                                              \
     constexpr int LDS = r16_lds_bytes(MB0, NJV) > r16_lds_bytes(MB1, NJV) ? r16_lds_bytes(MB0, NJV) : r16_lds_bytes(MB1, NJV); \
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring16_pair<MB0, MB1, NJV, C, T>), \
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring16_pair<MB0, MB1, NJV, C, T, PS>), \
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS);            \
     GPS_REQUIRE(attr == hipSuccess, "gps_gemm16_panel_pair: cannot reserve %d bytes of LDS", LDS);                  \
-    k_gemm_ring16_pair<MB0, MB1, NJV, C, T><<<grid, NTHREADS, LDS, s>>>(Q[0].P, Q[1].P, split, P2, split2);         \
+    k_gemm_ring16_pair<MB0, MB1, NJV, C, T, PS><<<grid, NTHREADS, LDS, s>>>(Q[0].P, Q[1].P, split, P2, split2, tiles0); \
   } while (0)
 #define GPS_PAIR_MB(NJV, C)                                                                                         \
   do {                                                                                                              \
     if (Q[0].mb == 2) {                                                                                             \
-      if (Q[1].mb == 2) { if (grid2) GPS_PAIR(2, 2, NJV, C, true); else GPS_PAIR(2, 2, NJV, C, false); }            \
-      else GPS_PAIR(2, 1, NJV, C, false);                                                                           \
+      if (Q[1].mb == 2) {                                                                                           \
+        if (persist) { if (grid2) GPS_PAIR(2, 2, NJV, C, true, true); else GPS_PAIR(2, 2, NJV, C, false, true); }   \
+        else { if (grid2) GPS_PAIR(2, 2, NJV, C, true, false); else GPS_PAIR(2, 2, NJV, C, false, false); }         \
+      }                                                                                                             \
+      else GPS_PAIR(2, 1, NJV, C, false, false);                                                                    \
     }                                                                                                               \
-    else { if (Q[1].mb == 2) GPS_PAIR(1, 2, NJV, C, false); else GPS_PAIR(1, 1, NJV, C, false); }                   \
+    else { if (Q[1].mb == 2) GPS_PAIR(1, 2, NJV, C, false, false); else GPS_PAIR(1, 1, NJV, C, false, false); }     \
   } while (0)
   const bool cin = Q[0].P.Cin != nullptr;
   if (Q[0].nj == 3) { if (cin) GPS_PAIR_MB(3, true); else GPS_PAIR_MB(3, false); }
