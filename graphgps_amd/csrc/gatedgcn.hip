@@ -426,7 +426,7 @@ __device__ __forceinline__ void bwd_a_chunk(const float* __restrict__ g_e, const
                                             const float* __restrict__ r_edge, int d, int c, const int* nbr,
                                             const int* eids, const Vec<VEC>& gx, Vec<VEC>& gdx, float* g_Ce,
                                             float* __restrict__ sD, float* __restrict__ sS, int slot0, int cap,
-                                            float& mce, const Folds<VEC, FOLD>& FK) {
+                                            float& mce, const Folds<VEC, FOLD>& FK, float* __restrict__ a_row) {
   int id[D];                  // (32-bit: widened at each use -- with the folds every register of this chunk counts)
   Vec<VEC> eh[D], ge[D], bx[D];
   float rr[D];
@@ -462,6 +462,7 @@ __device__ __forceinline__ void bwd_a_chunk(const float* __restrict__ g_e, const
     a[v] = gx[v] * inv;
     b[v] = -a[v] * (num[v] * inv);
   }
+  if (a_row) a.store(a_row);         // (ASTASH: a_i for phase B)
 #pragma unroll
   for (int u = 0; u < D; ++u) {
     Vec<VEC> dl, sa;
@@ -554,7 +555,7 @@ __device__ __forceinline__ void bwd_a_delta(const float* __restrict__ g_e, const
   }
 }
 
-template <int VEC, bool GATE, int FOLD>
+template <int VEC, bool GATE, int FOLD, bool ASTASH>
 __device__ __forceinline__ void bwd_a_rows(const float* __restrict__ g_x, int64_t ldgx,
                                            const float* __restrict__ g_e, const float* __restrict__ e_hat,
                                            const float* __restrict__ Bx, int64_t ld, const int* rp, const int* nbr,
@@ -564,12 +565,14 @@ __device__ __forceinline__ void bwd_a_rows(const float* __restrict__ g_x, int64_
                                            float* __restrict__ sS, int e0, int cap, float& mce, float& mnode,
                                            const float* __restrict__ x_tilde, const Folds<VEC, FOLD>& FK) {
 #define GPS_BWD_A(DD) bwd_a_chunk<VEC, GATE, FOLD, DD>(g_e, e_hat, Bx, ld, r_edge, d, c, nbr + beg, eids + beg, gx, gdx, \
-                                                       g_Ce, sD, sS, beg - e0, cap, mce, FK)
+                                                       g_Ce, sD, sS, beg - e0, ASTASH ? 0 : cap, mce, FK, a_row)
   for (int64_t node = blk.n0 + row; node < blk.n1; node += npi) {
     const int beg = rp[node - blk.n0], end = rp[node - blk.n0 + 1];
     Vec<VEC> gx = Vec<VEC>::load(g_x + node * ldgx + c);
     if constexpr ((FOLD & 1) != 0) gx = FK.node(gx, Vec<VEC>::load(x_tilde + node * d + c), node, c);
     Vec<VEC> gdx = Vec<VEC>::zero();
+    // ASTASH: a_i = g_x_i / D_i goes to phase B through LDS (cap = rows of that stash, sD = its base)
+    float* a_row = ASTASH && node - blk.n0 < cap ? sD + (node - blk.n0) * d + c : nullptr;
     // (with both folds the one-pass form holds three edges: four -- 48 registers of rows on top of the folds' -- spill at the
     // 168 registers per lane of a 768-thread workgroup; a fourth incoming edge takes the two-pass form below)
     switch ((FOLD == 3 && end - beg == 4) ? 5 : end - beg) {
@@ -597,9 +600,10 @@ __device__ __forceinline__ void bwd_a_rows(const float* __restrict__ g_x, int64_
           a[v] = gx[v] * inv;
           b[v] = -a[v] * (num[v] * inv);
         }
+        if (a_row) a.store(a_row);
         k = beg;
 #define GPS_DL(DD) bwd_a_delta<VEC, GATE, FOLD, DD>(g_e, e_hat, Bx, ld, r_edge, d, c, nbr + k, eids + k, a, b, gdx, g_Ce, sD, sS, \
-                                                     k - e0, cap, mce, FK)
+                                                     k - e0, ASTASH ? 0 : cap, mce, FK)
         for (; k + 2 <= end; k += 2) GPS_DL(2);
         if (k < end) GPS_DL(1);
 #undef GPS_DL
@@ -714,7 +718,55 @@ __device__ __forceinline__ void bwd_b_chunk(const float* __restrict__ g_x, int64
   }
 }
 
-template <int VEC, bool GATE, int FOLD>
+// Phase B with the a_i stash (ASTASH; blocks whose CSR slice is longer than the delta | sig a stash holds -- AST batches at
+// d = 256: ~120 entries per block against 56 slots): an in-block target's a_i row waits in LDS (nb rows instead of two rows
+// per EDGE), its delta is the g_Ce row this workgroup stored in phase A and sig comes again from the e^ row phase A read --
+// two L2 / L1 hits requested together for all D edges, where the slot-less path below walks the target's segment for its
+// den (>= 3 dependent round trips).  Same values, same order: sig a_i is rounded as a product before it is added, as the
+// stash held it.  Out-of-block targets take the recomputing path of bwd_b_chunk one edge at a time.
+template <int VEC, bool GATE, int FOLD, int D>
+__device__ __forceinline__ void bwd_b_chunk_a(const float* __restrict__ g_x, int64_t ldgx,
+                                              const float* __restrict__ g_e, const float* __restrict__ e_hat,
+                                              const float* __restrict__ Ax, int64_t ld,
+                                              const float* __restrict__ x_tilde,
+                                              const int32_t* __restrict__ rowptr_g, const int32_t* __restrict__ eid_g,
+                                              const float* __restrict__ r_edge, const float* g_Ce, int d, int c,
+                                              const int* tgt, const int* eids, const NodeBlock& blk,
+                                              const float* __restrict__ Bx, int64_t node, Vec<VEC>& gbx,
+                                              Vec<VEC>& gex, const int* rp_d, const int* eids_d, int e0,
+                                              const float* __restrict__ sA, int arows, const Folds<VEC, FOLD>& FK) {
+  int64_t ti[D], id[D];
+  bool hit[D];
+  Vec<VEC> dl[D], eh[D];
+  float rr[D];
+#pragma unroll
+  for (int u = 0; u < D; ++u) {
+    ti[u] = tgt[u];
+    id[u] = eids[u];
+    hit[u] = ti[u] >= blk.n0 && ti[u] < blk.n1 && ti[u] - blk.n0 < arows;
+    // (another workgroup's g_Ce row is never touched: a miss reads its e^ row twice, straight-line code either way)
+    dl[u] = Vec<VEC>::load((hit[u] ? g_Ce : e_hat) + id[u] * d + c);
+    eh[u] = Vec<VEC>::load(e_hat + id[u] * d + c);
+    rr[u] = GATE ? r_edge[id[u]] : 1.0f;
+  }
+#pragma unroll
+  for (int u = 0; u < D; ++u) {
+    if (hit[u]) {
+      const Vec<VEC> ai = Vec<VEC>::load(sA + (ti[u] - blk.n0) * d + c);
+#pragma unroll
+      for (int v = 0; v < VEC; ++v) {
+        const float s = sigmoidf_fast(eh[u][v]);
+        gex[v] += dl[u][v];
+        gbx[v] += __fmul_rn(GATE ? s * rr[u] : s, ai[v]);
+      }
+    } else {
+      bwd_b_chunk<VEC, GATE, FOLD, 1>(g_x, ldgx, g_e, e_hat, Ax, ld, x_tilde, rowptr_g, eid_g, r_edge, g_Ce, d, c, tgt + u,
+                                      eids + u, blk, Bx, node, gbx, gex, rp_d, eids_d, e0, nullptr, nullptr, 0, FK);
+    }
+  }
+}
+
+template <int VEC, bool GATE, int FOLD, bool ASTASH>
 __device__ __forceinline__ void bwd_b_rows(const float* __restrict__ g_x, int64_t ldgx,
                                            const float* __restrict__ g_e, const float* __restrict__ e_hat,
                                            const float* __restrict__ Ax, const float* __restrict__ Bx, int64_t ld,
@@ -729,27 +781,36 @@ __device__ __forceinline__ void bwd_b_rows(const float* __restrict__ g_x, int64_
 #define GPS_BWD_B(DD) bwd_b_chunk<VEC, GATE, FOLD, DD>(g_x, ldgx, g_e, e_hat, Ax, ld, x_tilde, rowptr_g, eid_g, r_edge, g_Ce, d, \
                                                        c, tgt + k, eids + k, blk, Bx, node, gbx, gex, rp_d, eids_d, e0, sD, \
                                                        sS, cap, FK)
+#define GPS_BWD_BA(DD) bwd_b_chunk_a<VEC, GATE, FOLD, DD>(g_x, ldgx, g_e, e_hat, Ax, ld, x_tilde, rowptr_g, eid_g, r_edge, g_Ce, \
+                                                          d, c, tgt + k, eids + k, blk, Bx, node, gbx, gex, rp_d, eids_d, e0, sD, \
+                                                          cap, FK)
   for (int64_t node = blk.n0 + row; node < blk.n1; node += npi) {
     const int beg = rq[node - blk.n0], end = rq[node - blk.n0 + 1];
     Vec<VEC> gbx = Vec<VEC>::zero(), gex = Vec<VEC>::zero();
     int k = beg;
-    for (; k + 4 < end; k += 4) GPS_BWD_B(4);
-    switch (end - k) {
-      case 1: GPS_BWD_B(1); break;
-      case 2: GPS_BWD_B(2); break;
-      case 3: GPS_BWD_B(3); break;
-      case 4: GPS_BWD_B(4); break;
-      default: break;
+    if constexpr (ASTASH) {      // two edges at a time: four with the recomputing path inlined behind each spill with both folds
+      for (; k + 2 <= end; k += 2) GPS_BWD_BA(2);
+      if (k < end) GPS_BWD_BA(1);
+    } else {
+      for (; k + 4 < end; k += 4) GPS_BWD_B(4);
+      switch (end - k) {
+        case 1: GPS_BWD_B(1); break;
+        case 2: GPS_BWD_B(2); break;
+        case 3: GPS_BWD_B(3); break;
+        case 4: GPS_BWD_B(4); break;
+        default: break;
+      }
     }
     gbx.store(g_Bx + node * ldg + c);
     gex.store(g_Ex + node * ldg + c);
 #pragma unroll
     for (int v = 0; v < VEC; ++v) mnode = fmaxf(mnode, fmaxf(fabsf(gbx[v]), fabsf(gex[v])));
   }
+#undef GPS_BWD_BA
 #undef GPS_BWD_B
 }
 
-template <int VEC, bool GATE, int FOLD>
+template <int VEC, bool GATE, int FOLD, bool ASTASH>
 __global__ __launch_bounds__(GG_T) void k_gatedgcn_bwd(
     const float* __restrict__ g_x, int64_t ldgx, const float* __restrict__ g_e, const float* __restrict__ e_hat,
     const float* __restrict__ Ax, const float* __restrict__ Bx, int64_t ld, const float* __restrict__ x_tilde,
@@ -762,14 +823,14 @@ __global__ __launch_bounds__(GG_T) void k_gatedgcn_bwd(
   __shared__ int s_rp[GG_MAXNB + 1], s_rq[GG_MAXNB + 1];
   __shared__ uint32_t s_amax[2][GG_T / 64];
   __shared__ int s_src[GG_MAXE], s_eid[GG_MAXE], s_dst[GG_MAXE], s_eid2[GG_MAXE];
-  extern __shared__ __attribute__((aligned(16))) float g_stash[];   // [2][cap][d]: delta | sig a_i per CSR slot
+  extern __shared__ __attribute__((aligned(16))) float g_stash[];   // [2][cap][d]: delta | sig a_i per CSR slot; ASTASH: [cap][d] a_i per node row
   const NodeBlock blk = node_block(N, nb);
   if (!blk.valid()) return;                 // whole workgroup leaves together
   const bool st_d = stage_slice(rowptr, src, eid, blk, s_rp, s_src, s_eid);
   const bool st_s = stage_slice(rowptr_s, dst, eid_s, blk, s_rq, s_dst, s_eid2);
   float* sD = g_stash;
   float* sS = g_stash + (int64_t)cap_arg * d;
-  float* sF = g_stash + 2 * (int64_t)cap_arg * d;       // FOLD: [12][d] column vectors of the node fold | the edge fold
+  float* sF = g_stash + (ASTASH ? 1 : 2) * (int64_t)cap_arg * d;   // FOLD: [12][d] column vectors of the node fold | the edge fold
   if constexpr (FOLD != 0) {
     if constexpr ((FOLD & 1) != 0) {
       if (threadIdx.x == 0) {
@@ -798,7 +859,7 @@ __global__ __launch_bounds__(GG_T) void k_gatedgcn_bwd(
   const int c = (threadIdx.x - row * lpr) * VEC;
   // ---- phase A: keyed by target ------------------------------------------------------------------
   const int e0 = s_rp[0];
-  const int cap = st_d ? cap_arg : 0;       // the slot lookup of phase B walks the staged CSR slice
+  const int cap = (ASTASH || st_d) ? cap_arg : 0;   // the slot lookup of phase B walks the staged CSR slice (ASTASH: a_i rows)
   float mce = 0.0f, mnode = 0.0f;        // max|g_Ce|, max over the four node gradients: the records of their GEMMs
   Folds<VEC, FOLD> FK;
   if constexpr (FOLD != 0) {
@@ -808,11 +869,11 @@ __global__ __launch_bounds__(GG_T) void k_gatedgcn_bwd(
   }
   if (active) {
     if (st_d)
-      bwd_a_rows<VEC, GATE, FOLD>(g_x, ldgx, g_e, e_hat, Bx, ld, s_rp, s_src - e0, s_eid - e0, blk, d, row, npi, c,
-                                  g_Ce, g_Ax, g_Dx, ldg, r_edge, sD, sS, e0, cap, mce, mnode, x_tilde, FK);
+      bwd_a_rows<VEC, GATE, FOLD, ASTASH>(g_x, ldgx, g_e, e_hat, Bx, ld, s_rp, s_src - e0, s_eid - e0, blk, d, row, npi, c,
+                                          g_Ce, g_Ax, g_Dx, ldg, r_edge, sD, sS, e0, cap, mce, mnode, x_tilde, FK);
     else
-      bwd_a_rows<VEC, GATE, FOLD>(g_x, ldgx, g_e, e_hat, Bx, ld, s_rp, src, eid, blk, d, row, npi, c, g_Ce, g_Ax,
-                                  g_Dx, ldg, r_edge, sD, sS, e0, 0, mce, mnode, x_tilde, FK);
+      bwd_a_rows<VEC, GATE, FOLD, ASTASH>(g_x, ldgx, g_e, e_hat, Bx, ld, s_rp, src, eid, blk, d, row, npi, c, g_Ce, g_Ax,
+                                          g_Dx, ldg, r_edge, sD, sS, e0, ASTASH ? cap : 0, mce, mnode, x_tilde, FK);
   }
   __threadfence_block();
   __syncthreads();            // this workgroup's g_Ce rows are visible to all of its lanes (same CU)
@@ -821,12 +882,13 @@ __global__ __launch_bounds__(GG_T) void k_gatedgcn_bwd(
   if (active) {
     const int q0 = s_rq[0];
     if (st_s)
-      bwd_b_rows<VEC, GATE, FOLD>(g_x, ldgx, g_e, e_hat, Ax, Bx, ld, x_tilde, rowptr, eid, s_rq, s_dst - q0, s_eid2 - q0,
-                                  blk, d, row, npi, c, g_Ce, g_Bx, g_Ex, ldg, r_edge, s_rp, s_eid - e0, e0, sD, sS, cap, mnode,
-                                  FK);
+      bwd_b_rows<VEC, GATE, FOLD, ASTASH>(g_x, ldgx, g_e, e_hat, Ax, Bx, ld, x_tilde, rowptr, eid, s_rq, s_dst - q0,
+                                          s_eid2 - q0, blk, d, row, npi, c, g_Ce, g_Bx, g_Ex, ldg, r_edge, s_rp, s_eid - e0, e0,
+                                          sD, sS, cap, mnode, FK);
     else
-      bwd_b_rows<VEC, GATE, FOLD>(g_x, ldgx, g_e, e_hat, Ax, Bx, ld, x_tilde, rowptr, eid, s_rq, dst, eid_s, blk, d, row,
-                                  npi, c, g_Ce, g_Bx, g_Ex, ldg, r_edge, s_rp, s_eid - e0, e0, sD, sS, cap, mnode, FK);
+      bwd_b_rows<VEC, GATE, FOLD, ASTASH>(g_x, ldgx, g_e, e_hat, Ax, Bx, ld, x_tilde, rowptr, eid, s_rq, dst, eid_s, blk, d,
+                                          row, npi, c, g_Ce, g_Bx, g_Ex, ldg, r_edge, s_rp, s_eid - e0, e0, sD, sS, cap, mnode,
+                                          FK);
   }
   if (!amax_node) return;                  // (kernel-uniform)
   // one atomic per record and workgroup: through LDS (a wave of the block may hold inactive rows' lanes only)
@@ -887,8 +949,8 @@ inline Plan plan_for(int64_t N, int lanes_per_row, bool forward) {
 #define GPS_GG_FWD(GATE, STATS, LDS)                                                                  \
   k_gatedgcn_fwd<VEC, GATE, STATS><<<pl.grid, pl.threads, LDS, s>>>(Ax, Bx, Dx, Ex, ld_node, Ce, rowptr_dst, \
       src_by_dst, eid_by_dst, N, d, x_tilde, e_hat, r_edge, pl.nb, pl.npi, recs, n_real)
-#define GPS_GG_BWD(GATE, FOLD)                                                                       \
-  k_gatedgcn_bwd<VEC, GATE, FOLD><<<pl.grid, pl.threads, stash_bytes, s>>>(g_x, ld_gx, g_e, e_hat, Ax, Bx, ld_node, x_tilde, \
+#define GPS_GG_BWD(GATE, FOLD, ASTASH)                                                               \
+  k_gatedgcn_bwd<VEC, GATE, FOLD, (ASTASH) && VEC == 4><<<pl.grid, pl.threads, stash_bytes, s>>>(g_x, ld_gx, g_e, e_hat, Ax, Bx, ld_node, x_tilde, \
       rowptr_dst, src_by_dst, eid_by_dst, rowptr_src, dst_by_src, eid_by_src, N, d, g_Ce,             \
       g_Ax == g_x ? nullptr : g_Ax, g_Bx, g_Dx, g_Ex, ld_gnode, r_edge, pl.nb, pl.npi, cap, amax_node, amax_ce, fx, fe, \
       gps::dropout_salt())
@@ -1057,11 +1119,25 @@ static int gatedgcn_bwd_impl(const float* g_x, int64_t ld_gx, const float* g_e, 
     GPS_REQUIRE(stash_budget >= 0, "gps_gatedgcn_bwd_bn: d=%d too wide for the folded form", d);
     int cap = (int)(stash_budget / (8LL * d));
     if (cap > GG_MAXE) cap = GG_MAXE;
-    const size_t stash_bytes = (size_t)cap * d * 8 + fold_bytes;
-    if (fold_x && fold_e) GPS_GG_BWD(false, 3);
-    else if (fold_e) GPS_GG_BWD(false, 2);
-    else if (fold_x) GPS_GG_BWD(false, 1);
-    else { if (r_edge) GPS_GG_BWD(true, 0); else GPS_GG_BWD(false, 0); }
+    // A block's CSR slice is ~nb E / N entries.  Where the per-edge stash cannot hold it (AST batches at d = 256: ~120 entries
+    // against 56 slots) the per-NODE stash takes over: a_i rows in LDS, delta and sig from the rows phase A touched
+    // (k_gatedgcn_bwd<.., ASTASH>: every in-block edge on a two-load path instead of the segment walk).  16-byte rows only.
+    static const int astash_cfg = env_int("GPS_GG_ASTASH", 1);
+    const bool astash = astash_cfg && VEC == 4 && (double)pl.nb * (double)E > (double)cap * (double)N &&
+                        (int64_t)pl.nb * d * 4 <= stash_budget;
+    if (astash) cap = pl.nb;
+    const size_t stash_bytes = (size_t)cap * d * (astash ? 4 : 8) + fold_bytes;
+    if (astash) {               // (VEC == 4 only: the macro maps the other widths onto the per-edge form)
+      if (fold_x && fold_e) GPS_GG_BWD(false, 3, true);
+      else if (fold_e) GPS_GG_BWD(false, 2, true);
+      else if (fold_x) GPS_GG_BWD(false, 1, true);
+      else { if (r_edge) GPS_GG_BWD(true, 0, true); else GPS_GG_BWD(false, 0, true); }
+    } else {
+      if (fold_x && fold_e) GPS_GG_BWD(false, 3, false);
+      else if (fold_e) GPS_GG_BWD(false, 2, false);
+      else if (fold_x) GPS_GG_BWD(false, 1, false);
+      else { if (r_edge) GPS_GG_BWD(true, 0, false); else GPS_GG_BWD(false, 0, false); }
+    }
   });
   return gps::launch_status("gps_gatedgcn_bwd");
 }

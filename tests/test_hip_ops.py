@@ -90,13 +90,16 @@ def _hub_batch(deg, extra_graphs=3, seed=0):
     return ei, bvec, ptr, gen
 
 
-@pytest.mark.parametrize("case,d,p", [("p30", 384, 0.1), ("p30", 64, 0.0), ("hub", 128, 0.25), ("p30_padded", 256, 0.2)])
+@pytest.mark.parametrize("case,d,p", [("p30", 384, 0.1), ("p30", 64, 0.0), ("hub", 128, 0.25), ("p30_padded", 256, 0.2),
+                                      ("ast", 256, 0.2)])
 def test_gatedgcn_bwd_bn_through_the_c_abi(case, d, p):
     """gps_gatedgcn_bwd_bn (include/gps_hip.h, ABI v9) against the three launches it stands for -- gps_norm_bwd_apply of
     bn_node_x and bn_edge_e, then gps_gatedgcn_bwd -- on the same operands and seeds: molecule-sized graphs (in-degrees 1 .. 6:
     the one-pass chunks and, at degree >= 4 with both folds, the two-pass form), a hub of degree 300 (the long-segment path,
     index slices past the LDS staging limit, out-of-block targets), and a padded batch whose last rows are junk beyond the
-    device-side real-row words (their folded gradients must come out exactly as the apply kernel's zeros make them).
+    device-side real-row words (their folded gradients must come out exactly as the apply kernel's zeros make them), and an
+    AST batch (24 graphs of 600 - 1000 nodes at d = 256: a node block's CSR slice outgrows the per-edge LDS stash, the
+    per-node a_i stash form of the backward runs -- csrc/gatedgcn.hip ASTASH).
     Reference: gatedgcn_layer.py:72-83 and its autograd backward."""
     import ctypes
     from graphgps_amd import lib as _lib, norm as _norm
@@ -106,6 +109,8 @@ def test_gatedgcn_bwd_bn_through_the_c_abi(case, d, p):
     gen = torch.Generator().manual_seed(5 + d)
     if case == "hub":
         ei, bvec, ptr, _ = _hub_batch(300, extra_graphs=6, seed=3)
+    elif case == "ast":
+        _, ei, bvec, ptr, _ = _structure("CODE2_LONG", 24, 4)
     else:
         b = layer_batch("P30", 48, d, seed=21)
         ei, bvec, ptr = b.edge_index, b.batch, b.ptr
@@ -198,10 +203,14 @@ def test_graph_index_and_gatedgcn_with_a_degree_5000_hub():
     assert_close(cg.grad, cr.grad, Tol.GRAD_REL, "g_Ce (hub)", rel_to_max=True)
 
 
-@pytest.mark.parametrize("d", [16, 52, 384])
-def test_gatedgcn_core(d):
+@pytest.mark.parametrize("d,profile,nb", [(16, "P30", 48), (52, "P30", 48), (384, "P30", 48), (256, "CODE2_LONG", 24),
+                                          (384, "CODE2_LONG", 16)],
+                         ids=["16", "52", "384", "ast-256", "ast-384"])
+def test_gatedgcn_core(d, profile, nb):
+    """(the two AST cases: node blocks whose CSR slices outgrow the per-edge LDS stash of the backward -- the per-node a_i
+    stash form, csrc/gatedgcn.hip ASTASH)"""
     from graphgps_amd.ops import gatedgcn_aggregate
-    sizes, ei, bvec, ptr, gen = _structure("P30", 48, 5)
+    sizes, ei, bvec, ptr, gen = _structure(profile, nb, 5)
     N, E = int(ptr[-1]), ei.shape[1]
     proj = torch.randn(N, 4 * d, generator=gen)
     ce = torch.randn(E, d, generator=gen)
