@@ -840,6 +840,10 @@ __global__ __launch_bounds__(256) void k_split_weights16(const SplitGroup16 G) {
 constexpr int r16_slot_bytes(int mb, int nj) { return rg_a_bytes(mb) + 2 * rg_bp(nj); }        // 16-40 KB
 constexpr int r16_slots(int mb, int nj) { return 163840 / r16_slot_bytes(mb, nj) > 5 ? 5 : 163840 / r16_slot_bytes(mb, nj); }
 constexpr int r16_lds_bytes(int mb, int nj) { return r16_slots(mb, nj) * r16_slot_bytes(mb, nj); }
+// ring depth of the PERSISTENT tiles: a tile's k-stages must be whole rotations, and depth is not what bounds the loop
+// (profiles/r06_gemm_tiles_occupancy.txt: 3 slots run as fast as 5), so the 128-column panels (5 slots fit) rotate over 4 --
+// K = 256 (8 stages: the AST batches' d) persists like K = 384 (12 stages) does on the 192-column panels
+constexpr int r16_persist_slots(int mb, int nj) { return r16_slots(mb, nj) > 4 ? 4 : r16_slots(mb, nj); }
 // first W-fragment read of gap i when nw reads are dealt over `gaps` gaps: one beside the raw-A reads of gap 0, the rest evenly
 constexpr int r16_rd_first(int i, int nw, int gaps) {
   return i <= 0 ? 0 : (i >= gaps ? nw : 1 + ((i - 1) * (nw - 1) + (gaps - 1) - 1) / (gaps - 1));
@@ -868,7 +872,7 @@ __device__ __forceinline__ void ring16_body(const PanelArgs& P, const int bid, c
   constexpr int TNV = 64 * NJ;
   constexpr int BP = rg_bp(NJ);
   constexpr int A_BYTES = rg_a_bytes(MB), SLOT = r16_slot_bytes(MB, NJ);
-  constexpr int S = r16_slots(MB, NJ);          // ring depth
+  constexpr int S = PERSIST ? r16_persist_slots(MB, NJ) : r16_slots(MB, NJ);          // ring depth
   constexpr int NA = 2 * MB;                    // A transfers per wave and stage
   constexpr int NW = 2 * NJ;                    // W transfers per wave and stage
   constexpr int ND = NA + NW;
@@ -1520,12 +1524,12 @@ extern "C" int gps_gemm16_panel_pair(const gps_gemm16_problem* first, const gps_
     }
   }
   // Persistent first problem (ring16_body PERSIST): when it spans two dispatch rounds or more, `cus` workgroups walk its tiles
-  // and prefetch across them.  128-row tiles only (the instantiations built), whole 4-slot rotations, no max|C| record.
+  // and prefetch across them.  128-row tiles only (the instantiations built), whole rotations of the (4-slot) ring, no max|C| record.
   const bool persist_on = (sched & 2) != 0;
   const int tiles0 = (int)Q[0].grid;
   const int ks0 = (Q[0].P.K + BK - 1) / BK;
   const bool persist = persist_on && cus > 0 && Q[0].mb == 2 && Q[1].mb == 2 && tiles0 >= 2 * cus && !Q[0].P.c_amax &&
-                       ks0 % r16_slots(2, Q[0].nj) == 0 && !Q[0].P.trace;
+                       ks0 % r16_persist_slots(2, Q[0].nj) == 0 && !Q[0].P.trace;
   const unsigned wg0 = persist ? (unsigned)cus : Q[0].grid;
   const unsigned grid = wg0 + Q[1].grid + grid2;
   const int split = (int)wg0, split2 = (int)(wg0 + Q[1].grid);

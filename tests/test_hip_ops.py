@@ -1145,6 +1145,38 @@ def test_gemm_panel_pair_is_bit_identical(p0, p1, cin):
     assert torch.equal(recs1.view(2, -1).max(dim=1).values, recs2.view(2, -1).max(dim=1).values)
 
 
+@pytest.mark.parametrize("p0,p1,cin", [
+    ((7569, 384, 2688), (15348, 384, 384), False),      # the molecule block's forward pair: 840 tiles of 12 k-stages on a 4-slot ring
+    ((25365, 256, 1792), (75856, 256, 256), False),     # the AST block's: 2,786 tiles of 8 k-stages, 128-column panels (4 of 5 slots)
+    ((25365, 256, 1792), (9000, 256, 256), True),       # with addends; a short second problem behind the persistent one
+    ((40000, 512, 1024), (3000, 512, 256), False)])     # 16 k-stages
+def test_gemm_panel_pair_persistent_tiles_bit_identical(p0, p1, cin):
+    """The pair dispatch WITHOUT max|C| records -- the form the blocks' forward pair runs: the first problem's tiles are walked by
+    one persistent workgroup per CU when they span two dispatch rounds or more (csrc/gemm_panel.hip ring16_body PERSIST: the
+    k-loop's past-the-end DMA fetches the next tile's first stages) -- against the two single launches: same tiles, same
+    arithmetic, bit-identical."""
+    from graphgps_amd.gemm import absmax, amax_records, gemm_panel, gemm_panel_pair, split_weights
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(sum(p0) + sum(p1) + 1)
+    probs = []
+    for (M, K, N) in (p0, p1):
+        a = torch.randn(M, K, generator=gen).to(dev)
+        w = (torch.randn(N, K, generator=gen) / K ** 0.5).to(dev)
+        b = torch.randn(N, generator=gen).to(dev)
+        add = torch.randn(M, N, generator=gen).to(dev) if cin else None
+        (img, _), = split_weights([w], tn=False, f16=True)
+        rec = amax_records(1, dev)
+        absmax([a], out=rec)
+        probs.append((a, img, N, b, add, rec[0]))
+    singles = [gemm_panel(a, img, N, bias=b, addend=add.clone() if cin else None, a_amax=rec) for a, img, N, b, add, rec in probs]
+    outs = [q[4].clone() if cin else None for q in probs]
+    pair = gemm_panel_pair(*[dict(a=a, image=img, N=N, bias=b, addend=outs[i], out=outs[i], a_amax=rec)
+                             for i, (a, img, N, b, add, rec) in enumerate(probs)])
+    torch.cuda.synchronize()
+    for i in range(2):
+        assert torch.equal(pair[i], singles[i]), f"problem {i}: {float((pair[i] - singles[i]).abs().max()):.3e}"
+
+
 @pytest.mark.parametrize("M,K,N", [(7569, 384, 2688), (1000, 384, 384), (15348, 384, 384), (7569, 768, 384),
                                    (333, 2688, 384), (64, 128, 192), (65, 256, 768),
                                    # round 3: 128- and 64-column panels, any number of k-stages (d = 256: code2 / GPS-deep;
