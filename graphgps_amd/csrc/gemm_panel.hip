@@ -865,7 +865,8 @@ struct IntC { static constexpr int value = I; };
 // reads and splits its first k-step, and after the epilogue (C stores; one vmcnt(0): loads and stores share the counter) the
 // loop simply goes on -- the ~3.6 us from a workgroup's entry to its first landed stage are paid once per workgroup instead
 // of once per tile (tools/gemm_trace.py: 20 % of a 128 x 192 tile's life).  Needs KS % S == 0 (the next tile's stage 0 must
-// land in slot 0), no edge shape, an epilogue that leaves the ring alone (EPI <= 2, no max|C| record).
+// land in slot 0), no edge shape, an epilogue that leaves the ring alone (EPI <= 2; the max|C| record uses the ring as
+// scratch once, behind the workgroup's LAST tile, from the running maximum over its tiles).
 template <int MB, int NJ, int EPI, bool HAS_CIN, bool EDGE, bool PERSIST = false>
 __device__ __forceinline__ void ring16_body(const PanelArgs& P, const int bid, const int stride = 0, const int ntiles = 0) {
   static_assert(!PERSIST || (!EDGE && EPI <= 2), "persistent tiles: whole panels, ring-free epilogue");
@@ -1063,6 +1064,7 @@ __device__ __forceinline__ void ring16_body(const PanelArgs& P, const int bid, c
       sources((int64_t)(t2 - p2 * P.row_tiles) * (64 * MB), p2 * TNV, a_srcN, b_srcN, KS);
     }
   }
+  float amx_run = 0.f;                      // max|C| over every tile this workgroup computes (one atomic at its end)
  next_tile:
   int s0 = 0;
   for (; s0 + S <= KS; s0 += S) {
@@ -1100,6 +1102,7 @@ __device__ __forceinline__ void ring16_body(const PanelArgs& P, const int bid, c
   for (int j = 0; j < NJ; ++j) sk[j] = s1[j] = s2[j] = 0.f;
   float amx = 0.f;
   ring_epilogue<MB, NJ, EPI, HAS_CIN, EDGE>(P, acc, m0, n0, wm, wn, li, kh, sk, s1, s2, amx);
+  amx_run = fmaxf(amx_run, amx);
   if constexpr (PERSIST) {
     if (has_next) {       // the seam: the next tile's first stages are in the ring (or on their way), its first k-step in a0 / f0
       __builtin_amdgcn_s_waitcnt(waitcnt_imm(0, 15));     // stores and DMA share vmcnt: the loop's counted waits must see DMA only
@@ -1125,8 +1128,8 @@ __device__ __forceinline__ void ring16_body(const PanelArgs& P, const int bid, c
   }
   if (EPI == 3) ring_stats<MB, NJ>(P, rt, panel, m0, wm, wn, li, kh, sk, s1, s2, reinterpret_cast<float*>(ring));
   if (EPI == 4) ring_sums<MB, NJ, 3>(P, rt, panel, wm, wn, li, kh, sk, s1, s2, reinterpret_cast<float*>(ring));
-  if (P.c_amax) {                                        // workgroup-uniform: max|C| of this tile -> one atomic
-    uint32_t m = __float_as_uint(amx);
+  if (P.c_amax) {                                        // workgroup-uniform: max|C| of this workgroup's tiles -> one atomic
+    uint32_t m = __float_as_uint(amx_run);
 #pragma unroll
     for (int o = 32; o; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o));
     uint32_t* wmax = reinterpret_cast<uint32_t*>(ring);
@@ -1147,6 +1150,13 @@ __device__ __forceinline__ void ring16_body(const PanelArgs& P, const int bid, c
 template <int MB, int NJ, int EPI, bool HAS_CIN, bool EDGE = false>
 __global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring16(const PanelArgs P) {
   ring16_body<MB, NJ, EPI, HAS_CIN, EDGE>(P, (int)blockIdx.x);
+}
+
+// One problem of two dispatch rounds or more (AST-sized batches: 792 tiles of 8 k-stages in FF1 and its input gradient) as
+// gridDim.x persistent workgroups: ring16_body PERSIST, workgroup b takes tiles b, b + gridDim.x, ...
+template <int MB, int NJ, int EPI, bool HAS_CIN>
+__global__ __launch_bounds__(NTHREADS, 1) void k_gemm_ring16_persist(const PanelArgs P, const int tiles) {
+  ring16_body<MB, NJ, EPI, HAS_CIN, false, true>(P, (int)blockIdx.x, (int)gridDim.x, tiles);
 }
 
 // Two independent GEMMs in ONE dispatch (gps_gemm16_panel_pair): workgroups 0 .. split-1 are the tiles of the first problem,
@@ -1402,6 +1412,21 @@ static int panel_prepare(PanelPlan& Q, const float* A, int64_t lda, int64_t M, i
   return GPS_OK;
 }
 
+// CUs of the device and GPS_GEMM_SCHED (a mask, default 3: 1 = tail balancing of the pair dispatch, 2 = persistent tiles; A/B
+// handles), each read once
+static int ring_cus() {
+  static const int cus = []() {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
+    return n;
+  }();
+  return cus;
+}
+static int ring_sched() {
+  static const int sched = []() { const char* v = getenv("GPS_GEMM_SCHED"); return v && *v ? atoi(v) : 3; }();
+  return sched;
+}
+
 static int panel_launch(const float* A, int64_t lda, int64_t M, int K, const uint16_t* image, int N, const float* bias,
                         const float* Cin, int64_t ldcin, float* C, int64_t ldc, int epilogue, const float* mask_src,
                         int64_t ldmask, float p_drop, uint64_t seed, const gps_bn* stats, float* ws, size_t ws_floats,
@@ -1448,6 +1473,30 @@ static int panel_launch(const float* A, int64_t lda, int64_t M, int K, const uin
     else GPS_RING_LAUNCH(1, 1, E, C);                                                                 \
   } while (0)
 #define GPS_PANEL_LAUNCH(E, C) GPS_RING_SHAPES(E, C)
+  // Persistent tiles (k_gemm_ring16_persist): 128-row tiles of whole panels over two dispatch rounds or more, k-stages in whole
+  // rotations of the 4-slot ring, epilogues 0 - 2.  Same tiles, same arithmetic: bit-identical to the one-workgroup-per-tile launch.
+  const int cus = ring_cus();
+  if (f16 && !edge && mb == 2 && nj >= 2 && epilogue <= 2 && (ring_sched() & 2) != 0 && cus > 0 && grid >= 2u * (unsigned)cus &&
+      ((K + BK - 1) / BK) % r16_persist_slots(2, nj) == 0 && !P.trace) {
+#define GPS_RING_PERSIST(NJV, E, C)                                                                                  \
+  do {                                                                                                                \
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_ring16_persist<2, NJV, E, C>), \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, r16_lds_bytes(2, NJV)); \
+    GPS_REQUIRE(attr == hipSuccess, "gps_gemm_panel: cannot reserve LDS");                                            \
+    k_gemm_ring16_persist<2, NJV, E, C><<<(unsigned)cus, NTHREADS, r16_lds_bytes(2, NJV), s>>>(P, (int)grid);         \
+  } while (0)
+#define GPS_RING_PERSIST_E(E)                                                                                         \
+  do {                                                                                                                \
+    if (nj == 3) { if (Cin) GPS_RING_PERSIST(3, E, true); else GPS_RING_PERSIST(3, E, false); }                       \
+    else { if (Cin) GPS_RING_PERSIST(2, E, true); else GPS_RING_PERSIST(2, E, false); }                               \
+  } while (0)
+    if (epilogue == 0) GPS_RING_PERSIST_E(0);
+    else if (epilogue == 1) GPS_RING_PERSIST_E(1);
+    else GPS_RING_PERSIST_E(2);
+#undef GPS_RING_PERSIST_E
+#undef GPS_RING_PERSIST
+    return gps::launch_status("gps_gemm_panel");
+  }
   if (epilogue == 0) { if (Cin) GPS_PANEL_LAUNCH(0, true); else GPS_PANEL_LAUNCH(0, false); }
   else if (epilogue == 1) { if (Cin) GPS_PANEL_LAUNCH(1, true); else GPS_PANEL_LAUNCH(1, false); }
   else if (epilogue == 2) { if (Cin) GPS_PANEL_LAUNCH(2, true); else GPS_PANEL_LAUNCH(2, false); }
@@ -1495,13 +1544,7 @@ extern "C" int gps_gemm16_panel_pair(const gps_gemm16_problem* first, const gps_
   // round at most half full, the rows behind that round's tiles -- the last row tiles of the second problem -- are cut as
   // 64-row tiles instead, so the launch ends half a tile-time earlier.  Same products, same per-element arithmetic: results
   // are bit-identical to the un-balanced dispatch (a tile's rows do not interact).
-  static const int cus = []() {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) n = 0;
-    return n;
-  }();
-  // GPS_GEMM_SCHED (a mask, default 3): 1 = tail balancing, 2 = persistent tiles of the first problem (A/B handles)
-  static const int sched = []() { const char* v = getenv("GPS_GEMM_SCHED"); return v && *v ? atoi(v) : 3; }();
+  const int cus = ring_cus(), sched = ring_sched();
   const bool tail_on = (sched & 1) != 0;
   PanelArgs P2 = Q[1].P;
   unsigned grid2 = 0;
@@ -1524,11 +1567,11 @@ extern "C" int gps_gemm16_panel_pair(const gps_gemm16_problem* first, const gps_
     }
   }
   // Persistent first problem (ring16_body PERSIST): when it spans two dispatch rounds or more, `cus` workgroups walk its tiles
-  // and prefetch across them.  128-row tiles only (the instantiations built), whole rotations of the (4-slot) ring, no max|C| record.
+  // and prefetch across them.  128-row tiles only (the instantiations built), whole rotations of the (4-slot) ring.
   const bool persist_on = (sched & 2) != 0;
   const int tiles0 = (int)Q[0].grid;
   const int ks0 = (Q[0].P.K + BK - 1) / BK;
-  const bool persist = persist_on && cus > 0 && Q[0].mb == 2 && Q[1].mb == 2 && tiles0 >= 2 * cus && !Q[0].P.c_amax &&
+  const bool persist = persist_on && cus > 0 && Q[0].mb == 2 && Q[1].mb == 2 && tiles0 >= 2 * cus &&
                        ks0 % r16_persist_slots(2, Q[0].nj) == 0 && !Q[0].P.trace;
   const unsigned wg0 = persist ? (unsigned)cus : Q[0].grid;
   const unsigned grid = wg0 + Q[1].grid + grid2;

@@ -1145,6 +1145,71 @@ def test_gemm_panel_pair_is_bit_identical(p0, p1, cin):
     assert torch.equal(recs1.view(2, -1).max(dim=1).values, recs2.view(2, -1).max(dim=1).values)
 
 
+_PERSIST_ID_SCRIPT = r"""
+import sys, torch
+sys.path.insert(0, sys.argv[2])
+from graphgps_amd.gemm import absmax, amax_records, gemm_panel, gemm_panel_pair, split_weights
+dev = torch.device('cuda:0')
+gen = torch.Generator().manual_seed(7)
+out = []
+# (M, K, N, epilogue, addend): FF1 and its input gradient at the AST block's size, the molecule block's merged projection,
+# a 16-stage contraction with an addend -- every one two dispatch rounds or more of 128-row tiles
+for (M, K, N, epi, cin) in ((25365, 256, 512, 1, False), (25365, 512, 256, 0, True), (25365, 256, 512, 2, False),
+                            (7569, 384, 2688, 0, False), (40000, 512, 768, 2, True), (33000, 384, 768, 1, False)):
+    a = torch.randn(M, K, generator=gen).to(dev)
+    w = (torch.randn(N, K, generator=gen) / K ** 0.5).to(dev)
+    b = torch.randn(N, generator=gen).to(dev)
+    add = torch.randn(M, N, generator=gen).to(dev) if cin else None
+    mask = torch.randn(M, N, generator=gen).to(dev) if epi == 2 else None
+    (img, _), = split_weights([w], tn=False, f16=True)
+    rec, crec = amax_records(1, dev), amax_records(1, dev)
+    absmax([a], out=rec)
+    c = gemm_panel(a, img, N, bias=b, addend=add, epilogue=epi, mask_src=mask, p_drop=0.1 if epi else 0.0, seed=99,
+                   a_amax=rec[0], c_amax=crec[0])
+    torch.cuda.synchronize()
+    if epi == 0:
+        ref = a.double() @ w.double().t() + b.double() + (add.double() if cin else 0)
+        assert float((c.double() - ref).abs().max() / ref.abs().max()) < 2e-6
+    out.append((c.cpu(), crec.cpu()))
+# the pair dispatch WITH max|C| records (the first problem persistent)
+probs = []
+for (M, K, N) in ((25365, 256, 1792), (75856, 256, 256)):
+    a = torch.randn(M, K, generator=gen).to(dev)
+    w = (torch.randn(N, K, generator=gen) / K ** 0.5).to(dev)
+    (img, _), = split_weights([w], tn=False, f16=True)
+    rec = amax_records(1, dev)
+    absmax([a], out=rec)
+    probs.append(dict(a=a, image=img, N=N, a_amax=rec[0], c_amax=amax_records(1, dev)[0]))
+pair = gemm_panel_pair(*probs)
+torch.cuda.synchronize()
+out += [(pair[i].cpu(), probs[i]['c_amax'].cpu()) for i in range(2)]
+torch.save(out, sys.argv[1])
+"""
+
+
+def test_gemm_persistent_tiles_are_bit_identical_to_one_workgroup_per_tile(tmp_path):
+    """csrc/gemm_panel.hip ring16_body PERSIST -- one workgroup per CU walking the tiles of a launch of two dispatch rounds or
+    more, the k-loop's past-the-end DMA fetching the next tile's first stages -- against the one-workgroup-per-tile launches
+    (GPS_GEMM_SCHED=1): epilogues 0 / 1 (ReLU + dropout) / 2 (mask of a saved activation), addends in place, max|C| records
+    (one atomic per workgroup from the running maximum over its tiles), and the pair dispatch with records.  Same tiles, same
+    arithmetic: outputs AND records bit-identical.  The switch is read once per process: each form runs in a child."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "pt.py"
+    script.write_text(_PERSIST_ID_SCRIPT)
+    outs = []
+    for v in ("3", "1"):
+        f = tmp_path / f"pt{v}.pt"
+        r = subprocess.run([sys.executable, str(script), str(f), root], env=dict(os.environ, GPS_GEMM_SCHED=v),
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append(torch.load(f))
+    for i, ((c1, r1), (c0, r0)) in enumerate(zip(*outs)):
+        assert torch.equal(c1, c0), f"case {i}: outputs differ by {float((c1 - c0).abs().max()):.3e}"
+        assert torch.equal(r1.max(), r0.max()), f"case {i}: max|C| records differ"
+
+
 @pytest.mark.parametrize("p0,p1,cin", [
     ((7569, 384, 2688), (15348, 384, 384), False),      # the molecule block's forward pair: 840 tiles of 12 k-stages on a 4-slot ring
     ((25365, 256, 1792), (75856, 256, 256), False),     # the AST block's: 2,786 tiles of 8 k-stages, 128-column panels (4 of 5 slots)
