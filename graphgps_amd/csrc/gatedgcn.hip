@@ -911,7 +911,10 @@ __global__ __launch_bounds__(GG_T) void k_gatedgcn_bwd(
 inline bool aligned_to(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) % a) == 0; }
 
 // Launch shape.  Threads per workgroup (GPS_GG_FWD_THREADS / GPS_GG_THREADS) and the number of workgroups
-// aimed at (GPS_GG_TARGET_WG, default 512) are read once; node rows per workgroup = N / target rounded up to whole
+// aimed at (GPS_GG_TARGET_WG; default = the device's CU count: both kernels hold one workgroup per CU, so that is ONE
+// dispatch round of the largest node blocks that still fill the chip -- round 6, with the per-node a_i stash behind it:
+// P30 x 256 at 32-node blocks 59 -> 53 us backward, 25 -> 23.5 forward, -0.14 ms per step against two rounds of 16-node
+// blocks; profiles/r06_gatedgcn_astash.txt) are read once; node rows per workgroup = N / target rounded up to whole
 // passes, never more than the LDS rowptr slice holds.
 struct Plan { int threads, npi, nb; unsigned grid; };
 inline int env_int(const char* name, int dflt) {
@@ -927,7 +930,12 @@ inline Plan plan_for(int64_t N, int lanes_per_row, bool forward) {
   // The step is what counts: 768.  backward: 768 (one workgroup per CU either way: 140 KB of LDS)
   static const int fwd_threads = env_int("GPS_GG_FWD_THREADS", GG_T);
   static const int bwd_threads = env_int("GPS_GG_THREADS", GG_T);
-  static const int cfg_target = env_int("GPS_GG_TARGET_WG", 512);
+  static const int cfg_target = []() {
+    int t = env_int("GPS_GG_TARGET_WG", 0), dev = 0;
+    if (t <= 0 && (hipGetDevice(&dev) != hipSuccess ||
+                   hipDeviceGetAttribute(&t, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || t <= 0)) t = 256;
+    return t;
+  }();
   const int cfg_threads = forward ? fwd_threads : bwd_threads;
   Plan p;
   p.threads = cfg_threads < 64 ? 64 : (cfg_threads > GG_T ? GG_T : (cfg_threads / 64) * 64);
@@ -1122,8 +1130,8 @@ static int gatedgcn_bwd_impl(const float* g_x, int64_t ld_gx, const float* g_e, 
     // A block's CSR slice is ~nb E / N entries.  Where the per-edge stash cannot hold it (AST batches at d = 256: ~120 entries
     // against 56 slots) the per-NODE stash takes over: a_i rows in LDS, delta and sig from the rows phase A touched
     // (k_gatedgcn_bwd<.., ASTASH>: every in-block edge on a two-load path instead of the segment walk).  16-byte rows only.
-    static const int astash_cfg = env_int("GPS_GG_ASTASH", 1);
-    const bool astash = astash_cfg && VEC == 4 && (double)pl.nb * (double)E > (double)cap * (double)N &&
+    static const int astash_cfg = env_int("GPS_GG_ASTASH", 1);       // 0 never | 1 where the per-edge stash overflows | 2 wherever it fits
+    const bool astash = astash_cfg && VEC == 4 && (astash_cfg == 2 || (double)pl.nb * (double)E > (double)cap * (double)N) &&
                         (int64_t)pl.nb * d * 4 <= stash_budget;
     if (astash) cap = pl.nb;
     const size_t stash_bytes = (size_t)cap * d * (astash ? 4 : 8) + fold_bytes;
