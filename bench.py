@@ -470,7 +470,7 @@ def kernel_rooflines(dev, profile, nb, d=384, H=16, in_step=None, layers=10, onl
     entry("gatedgcn_bwd", gg_bwd_bn, n_rot, "hbm", 12 * E * d + 32 * N * d + 2 * idx, 1, ("k_gatedgcn_bwd",),
           note="the folded form the step runs (gps_gatedgcn_bwd_bn): algorithmic bytes per SURVEY.md 8d (which counts num "
                "and den as read: 8*N*d that this kernel recomputes instead) + 4*N*d for x~ on the node fold")
-    entry("gatedgcn_bwd_unfolded", gg_bwd, n_rot, "hbm", 12 * E * d + 28 * N * d + 2 * idx, 1, ("k_gatedgcn_bwd<4, false, 0>",),
+    entry("gatedgcn_bwd_unfolded", gg_bwd, n_rot, "hbm", 12 * E * d + 28 * N * d + 2 * idx, 1, ("k_gatedgcn_bwd<4, false, 0>", "k_gatedgcn_bwd<4, false, 4>"),
           note="gps_gatedgcn_bwd behind two BatchNorm backward apply launches (rounds 1 - 5; GPS_GG_BN_FOLD=0)")
     # the attention core is HBM-bound at these graph sizes (7.8 flop/byte against a ridge of 19.6): the binding
     # roofline is Q/K/V read + O write (fwd), + dO read + dQ/dK/dV write (bwd); the MFMA figure rides along

@@ -810,7 +810,9 @@ __device__ __forceinline__ void bwd_b_rows(const float* __restrict__ g_x, int64_
 #undef GPS_BWD_B
 }
 
-template <int VEC, bool GATE, int FOLD, bool ASTASH>
+// FORM = FOLD | 4 * ASTASH (one template argument: the name the traces and bench.py's kernel tables match stays
+// k_gatedgcn_bwd<VEC, GATE, n>)
+template <int VEC, bool GATE, int FORM>
 __global__ __launch_bounds__(GG_T) void k_gatedgcn_bwd(
     const float* __restrict__ g_x, int64_t ldgx, const float* __restrict__ g_e, const float* __restrict__ e_hat,
     const float* __restrict__ Ax, const float* __restrict__ Bx, int64_t ld, const float* __restrict__ x_tilde,
@@ -820,6 +822,8 @@ __global__ __launch_bounds__(GG_T) void k_gatedgcn_bwd(
     float* __restrict__ g_Bx, float* __restrict__ g_Dx, float* __restrict__ g_Ex, int64_t ldg,
     const float* __restrict__ r_edge, int nb, int npi, int cap_arg, uint32_t* amax_node, uint32_t* amax_ce,
     const BnFold fold_x, const BnFold fold_e, const uint64_t* salt) {
+  constexpr int FOLD = FORM & 3;
+  constexpr bool ASTASH = (FORM & 4) != 0;
   __shared__ int s_rp[GG_MAXNB + 1], s_rq[GG_MAXNB + 1];
   __shared__ uint32_t s_amax[2][GG_T / 64];
   __shared__ int s_src[GG_MAXE], s_eid[GG_MAXE], s_dst[GG_MAXE], s_eid2[GG_MAXE];
@@ -958,7 +962,7 @@ inline Plan plan_for(int64_t N, int lanes_per_row, bool forward) {
   k_gatedgcn_fwd<VEC, GATE, STATS><<<pl.grid, pl.threads, LDS, s>>>(Ax, Bx, Dx, Ex, ld_node, Ce, rowptr_dst, \
       src_by_dst, eid_by_dst, N, d, x_tilde, e_hat, r_edge, pl.nb, pl.npi, recs, n_real)
 #define GPS_GG_BWD(GATE, FOLD, ASTASH)                                                               \
-  k_gatedgcn_bwd<VEC, GATE, FOLD, (ASTASH) && VEC == 4><<<pl.grid, pl.threads, stash_bytes, s>>>(g_x, ld_gx, g_e, e_hat, Ax, Bx, ld_node, x_tilde, \
+  k_gatedgcn_bwd<VEC, GATE, (FOLD) | ((ASTASH) && VEC == 4 ? 4 : 0)><<<pl.grid, pl.threads, stash_bytes, s>>>(g_x, ld_gx, g_e, e_hat, Ax, Bx, ld_node, x_tilde, \
       rowptr_dst, src_by_dst, eid_by_dst, rowptr_src, dst_by_src, eid_by_src, N, d, g_Ce,             \
       g_Ax == g_x ? nullptr : g_Ax, g_Bx, g_Dx, g_Ex, ld_gnode, r_edge, pl.nb, pl.npi, cap, amax_node, amax_ce, fx, fe, \
       gps::dropout_salt())
