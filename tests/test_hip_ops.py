@@ -232,6 +232,38 @@ def test_gatedgcn_core(d, profile, nb):
     assert torch.equal(xg2, xg.detach()) and torch.equal(eg2, eg.detach())
 
 
+def test_gatedgcn_core_with_edge_gate_at_the_benchmark_batch():
+    """The EquivStableLapPE form (sigma_ij * r_ij gates and normalises, gatedgcn_layer.py:101-104) at P30 x 256, d = 384:
+    32-node blocks of ~65 CSR entries, i.e. the backward's per-node a_i stash with the gate (k_gatedgcn_bwd<4, true, 4>),
+    against the fp64 restatement; r_ij receives no gradient here (the layer differentiates it through PyTorch)."""
+    from graphgps_amd.ops import gatedgcn_aggregate
+    d = 384
+    sizes, ei, bvec, ptr, gen = _structure("P30", 256, 9)
+    N, E = int(ptr[-1]), ei.shape[1]
+    proj = torch.randn(N, 4 * d, generator=gen)
+    ce = torch.randn(E, d, generator=gen)
+    r = torch.rand(E, generator=gen) * 0.9 + 0.05
+    wx, we = torch.randn(N, d, generator=gen), torch.randn(E, d, generator=gen)
+    pr, cr = proj.double().requires_grad_(True), ce.double().requires_grad_(True)
+    Ax, Bx, Dx, Ex = pr[:, :d], pr[:, d:2 * d], pr[:, 2 * d:3 * d], pr[:, 3 * d:]
+    j, i = ei[0], ei[1]
+    e_ij = Dx.index_select(0, i) + Ex.index_select(0, j) + cr
+    s = torch.sigmoid(e_ij) * r.double()[:, None]
+    num = torch.zeros(N, d, dtype=torch.float64).index_add_(0, i, s * Bx.index_select(0, j))
+    den = torch.zeros(N, d, dtype=torch.float64).index_add_(0, i, s)
+    xr = Ax + num / (den + 1e-6)
+    ((xr * wx.double()).sum() + (e_ij * we.double()).sum()).backward()
+    dev = torch.device("cuda:0")
+    gi = _index(ei, bvec, ptr)
+    pg, cg = proj.to(dev).requires_grad_(True), ce.to(dev).requires_grad_(True)
+    xg, eg = gatedgcn_aggregate(pg, cg, gi, r.to(dev))
+    ((xg * wx.to(dev)).sum() + (eg * we.to(dev)).sum()).backward()
+    assert_close(xg, xr, Tol.ACT, "x_tilde (gated)")
+    assert_close(eg, e_ij, Tol.ACT, "e_hat (gated)")
+    assert_close(pg.grad, pr.grad, Tol.GRAD_REL, "g_proj (gated)", rel_to_max=True)
+    assert_close(cg.grad, cr.grad, Tol.GRAD_REL, "g_Ce (gated)", rel_to_max=True)
+
+
 def test_gatedgcn_no_edges_and_odd_dim():
     from graphgps_amd.ops import build_graph_index, gatedgcn_aggregate
     dev = torch.device("cuda:0")
