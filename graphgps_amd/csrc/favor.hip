@@ -1256,15 +1256,31 @@ int gps_segment_max_len_real(const int32_t* ptr, int64_t B, const int32_t* b_rea
 }
 
 }  // extern "C"
+static bool favor_ctx_staged(int64_t N, int64_t B);
 // Row slices per (graph, head, feature tile) of the two context kernels: enough wavefronts to put ~8 on every SIMD, at
-// least 4 row blocks per slice on average, at most 8.
+// least 4 row blocks per slice on average, at most 8.  The STAGED context kernels launch one 12-wavefront workgroup per
+// (graph, head, slice) and a CU holds one of them (registers), so there the slices are what fills ONE dispatch round:
+// CUs / (graphs x heads), rounded down -- 32 AST graphs x 4 heads: 2 slices = 256 workgroups, where the wavefront rule's
+// 4 made two rounds and 3 make one and a half (code2 step, same box: 9.54 | 9.73 | 9.59 ms for 2 | 3 | 4;
+// profiles/r06_favor_slices.txt).
 static int favor_slices(int64_t N, int64_t B, int H) {
   static const int forced = [] { const char* e = getenv("GPS_FAVOR_SLICES"); return e && *e ? atoi(e) : 0; }();
   if (forced >= 1) return forced > 8 ? 8 : forced;
   if (B <= 0 || H <= 0) return 1;
-  const int64_t waves = B * H * MT;
-  int64_t S = (8192 + waves - 1) / waves;
   const int64_t blocks = N / B / 16;
+  int64_t S;
+  if (favor_ctx_staged(N, B)) {
+    static const int cus = [] {
+      int dev = 0, n = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess ||
+          n <= 0) n = 256;
+      return n;
+    }();
+    S = cus / (B * H);
+  } else {
+    const int64_t waves = B * H * MT;
+    S = (8192 + waves - 1) / waves;
+  }
   if (S > blocks / 4) S = blocks / 4;
   return (int)(S < 1 ? 1 : (S > 8 ? 8 : S));
 }
