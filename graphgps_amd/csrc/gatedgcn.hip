@@ -1125,7 +1125,7 @@ static int gatedgcn_bwd_impl(const float* g_x, int64_t ld_gx, const float* g_e, 
   GPS_DISPATCH_VEC(d, ld_node % 4 == 0 && ld_gnode % 4 == 0 && ld_gx % 4 == 0 && ok(16),
                    ld_node % 2 == 0 && ld_gnode % 2 == 0 && ld_gx % 2 == 0 && ok(8), {
     GPS_REQUIRE(d / VEC <= GG_T, "gps_gatedgcn_bwd: d=%d too wide for one workgroup pass (%d lanes)", d, d / VEC);
-    const Plan pl = plan_for(N, d / VEC, false);
+    Plan pl = plan_for(N, d / VEC, false);
     // LDS stash of phase A's per-edge results for phase B: [2][cap][d] floats next to the 29 KB of index slices
     static const int stash_kb = env_int("GPS_GG_STASH_KB", 112);
     const size_t fold_bytes = fold ? ((size_t)12 * d + 8) * sizeof(float) : 0;     // the folds' column vectors behind the stash
@@ -1138,8 +1138,15 @@ static int gatedgcn_bwd_impl(const float* g_x, int64_t ld_gx, const float* g_e, 
     // against 56 slots) the per-NODE stash takes over: a_i rows in LDS, delta and sig from the rows phase A touched
     // (k_gatedgcn_bwd<.., ASTASH>: every in-block edge on a two-load path instead of the segment walk).  16-byte rows only.
     static const int astash_cfg = env_int("GPS_GG_ASTASH", 1);       // 0 never | 1 where the per-edge stash overflows | 2 wherever it fits
-    const bool astash = astash_cfg && VEC == 4 && (astash_cfg == 2 || (double)pl.nb * (double)E > (double)cap * (double)N) &&
-                        (int64_t)pl.nb * d * 4 <= stash_budget;
+    const bool want_astash = astash_cfg && VEC == 4 && (astash_cfg == 2 || (double)pl.nb * (double)E > (double)cap * (double)N);
+    // a batch so large that one dispatch round's node blocks outgrow the a_i stash (50k nodes at d = 384: 196 rows against 73):
+    // smaller blocks over more rounds keep every in-block edge off the recomputing path
+    const int64_t rows_fit = (stash_budget / (4LL * d) / pl.npi) * pl.npi;
+    if (want_astash && pl.nb > rows_fit && rows_fit >= pl.npi) {
+      pl.nb = (int)rows_fit;
+      pl.grid = (unsigned)((((N + pl.nb - 1) / pl.nb + 7) / 8) * 8);
+    }
+    const bool astash = want_astash && (int64_t)pl.nb * d * 4 <= stash_budget;
     if (astash) cap = pl.nb;
     const size_t stash_bytes = (size_t)cap * d * (astash ? 4 : 8) + fold_bytes;
     if (astash) {               // (VEC == 4 only: the macro maps the other widths onto the per-edge form)

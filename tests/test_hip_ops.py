@@ -204,11 +204,12 @@ def test_graph_index_and_gatedgcn_with_a_degree_5000_hub():
 
 
 @pytest.mark.parametrize("d,profile,nb", [(16, "P30", 48), (52, "P30", 48), (384, "P30", 48), (256, "CODE2_LONG", 24),
-                                          (384, "CODE2_LONG", 16)],
-                         ids=["16", "52", "384", "ast-256", "ast-384"])
+                                          (384, "CODE2_LONG", 16), (384, "P30", 1500)],
+                         ids=["16", "52", "384", "ast-256", "ast-384", "1500-molecules"])
 def test_gatedgcn_core(d, profile, nb):
     """(the two AST cases: node blocks whose CSR slices outgrow the per-edge LDS stash of the backward -- the per-node a_i
-    stash form, csrc/gatedgcn.hip ASTASH)"""
+    stash form, csrc/gatedgcn.hip ASTASH; 1,500 molecules: ~45k nodes, where one dispatch round's 176-node blocks outgrow
+    the a_i stash too and the backward launches smaller blocks over several rounds)"""
     from graphgps_amd.ops import gatedgcn_aggregate
     sizes, ei, bvec, ptr, gen = _structure(profile, nb, 5)
     N, E = int(ptr[-1]), ei.shape[1]
